@@ -1,0 +1,162 @@
+/*
+ * vgk.h — C ABI of the MI355X-native per-read graph-alignment engine.
+ *
+ * This is the drop-in boundary for vg's alignment hot path.  Every entry point
+ * replaces a group of third-party C calls that vg's `Aligner` family makes
+ * today (citations are into the reference tree, vgteam/vg):
+ *
+ *   vgk_gssw_*      replaces  gssw_graph_create / gssw_node_create /
+ *                             gssw_nodes_add_edge / gssw_graph_fill_pinned /
+ *                             gssw_graph_trace_back /
+ *                             gssw_graph_trace_back_pinned_multi
+ *                             (src/aligner.cpp:30-85, 396-435, 537-557, 575-611)
+ *   vgk_xdrop_*     replaces  dz_init / dz_pack_query_* / dz_extend / dz_trace
+ *                             as driven by DozeuInterface::align_pinned
+ *                             (src/dozeu_interface.cpp:210-307, 687-766)
+ *   vgk_banded_*    replaces  BandedGlobalAligner<IntType>::align
+ *                             (src/banded_global_aligner.cpp:250-742, 2295-2423)
+ *   vgk_gapless_*   replaces  GaplessExtender match_initial/forward/backward +
+ *                             set_score (src/gbwt_extender.cpp:201-296)
+ *
+ * Everything is plain pointers and sizes.  All "graphs" handed over are DAGs
+ * whose nodes are ALREADY in the topological order the reference would use
+ * (src/aligner.cpp:32 `lazier_topological_order`), forward strand only, with
+ * predecessor lists in CSR form — exactly the information
+ * `create_gssw_graph` (src/aligner.cpp:30-85) extracts from a HandleGraph.
+ *
+ * Batch model: vg calls one (read, subgraph) problem at a time from OpenMP
+ * threads; a GPU needs thousands per launch.  The ABI is therefore
+ * batch-first: pack N problems (host → HBM), run (kernels only), fetch
+ * (HBM → host).  A batch of 1 gives the reference's synchronous semantics.
+ *
+ * Error model: return codes (0 = OK, <0 = VGK_E*), never exit()/abort();
+ * per-problem failures are reported in vgk_result.status.
+ */
+#ifndef VGK_H
+#define VGK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGK_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+    VGK_OK           = 0,
+    VGK_EINVAL       = -1,  /* malformed input (e.g. non-topological edge)      */
+    VGK_ENODEV       = -2,  /* no usable HIP device / HIP runtime error         */
+    VGK_ENOMEM       = -3,  /* host or device allocation failed                 */
+    VGK_ETOOLONG     = -4,  /* read longer than the engine supports             */
+    VGK_EOVERFLOW    = -5,  /* score left the int16 range gssw/dozeu support    */
+    VGK_EOPS         = -6,  /* CIGAR did not fit the per-problem op budget      */
+    VGK_ETOOBIG      = -7,  /* banded matrices exceed max_cells
+                               (BandMatricesTooBigException,
+                                src/banded_global_aligner.hpp:40-43)            */
+    VGK_ENOBAND      = -8,  /* no alignment inside the band
+                               (NoAlignmentInBandException, :31-38)             */
+    VGK_EUNSUPPORTED = -9   /* scoring parameters outside the kernels' range    */
+};
+
+/* ---- scoring (mirrors MatrixAlignmentScorer, src/alignment_scorer.cpp:284-314) */
+typedef struct vgk_scoring {
+    int8_t  matrix[25];      /* 5x5 row-major, index 5*nt[ref]+nt[read]; row/col 4 = N = 0 */
+    uint8_t gap_open;        /* gap of length n costs gap_open + (n-1)*gap_extend          */
+    uint8_t gap_extend;
+    int8_t  full_length_bonus;
+    uint8_t reserved;
+} vgk_scoring;
+
+/* ---- a DAG in topological order (what create_gssw_graph builds) ---------- */
+typedef struct vgk_graph {
+    uint32_t        n_nodes;
+    const uint32_t* node_len;   /* [n_nodes]   bases per node                          */
+    const char*     seq;        /* concatenated node sequences, ASCII, order = nodes   */
+    const uint32_t* pred_off;   /* [n_nodes+1] CSR offsets into pred_idx               */
+    const uint32_t* pred_idx;   /* predecessor node indices, each < the node's index   */
+} vgk_graph;
+
+/* ---- CIGAR element: one run on one node ---------------------------------- */
+enum { VGK_OP_M = 0,   /* match-or-mismatch run (gssw 'M'/'X'/'N'; the caller
+                          re-splits by character compare, src/aligner.cpp:171-205) */
+       VGK_OP_I = 1,   /* insertion (read bases, no graph bases)                   */
+       VGK_OP_D = 2,   /* deletion  (graph bases, no read bases)                   */
+       VGK_OP_S = 3 }; /* soft clip (only first / last element)                    */
+
+typedef struct vgk_op {
+    uint32_t node;      /* index into the problem's node order                      */
+    uint16_t len;
+    uint8_t  op;        /* VGK_OP_*                                                 */
+    uint8_t  pad;
+} vgk_op;
+
+/* ---- result header (16 B payload + bookkeeping) --------------------------- */
+typedef struct vgk_result {
+    int32_t  score;         /* gm->score / alignment->score1                        */
+    int32_t  status;        /* VGK_OK or VGK_E* for this problem                    */
+    int32_t  end_node;      /* node index of the last aligned graph base            */
+    int32_t  end_offset;    /* offset of that base in end_node (gssw ref_end1)      */
+    int32_t  end_read;      /* last aligned read base (gssw read_end1)              */
+    int32_t  first_offset;  /* offset in the first node where the alignment starts
+                               (gssw_graph_mapping.position)                       */
+    uint32_t n_ops;         /* number of vgk_op written for this problem            */
+    uint32_t ops_begin;     /* index of the first one in the batch's op array       */
+} vgk_result;
+
+/* ---- graph Smith-Waterman (gssw semantics) -------------------------------- */
+enum { VGK_GSSW_LOCAL       = 0,  /* Aligner::align: bonus at both ends (src/aligner.cpp:399-402) */
+       VGK_GSSW_PINNED      = 1,  /* Aligner::align_pinned (right-pinned; the caller reverses
+                                     graph+read for pin_left, src/aligner.cpp:365-383)            */
+       VGK_GSSW_TRACEBACK   = 16  /* OR-ed in: produce CIGAR; otherwise score + end only
+                                     (src/aligner.cpp:550-557)                                    */ };
+
+typedef struct vgk_gssw_problem {
+    const char*    read;         /* ASCII read                                         */
+    uint32_t       read_len;
+    uint32_t       flags;        /* VGK_GSSW_*                                         */
+    vgk_graph      graph;
+    const uint8_t* pinning;      /* PINNED only: [n_nodes] 1 = pinning node
+                                    (identify_pinning_points, src/aligner.cpp:87-118)  */
+} vgk_gssw_problem;
+
+typedef struct vgk_ctx   vgk_ctx;     /* one per (device, scoring) — like one Aligner      */
+typedef struct vgk_batch vgk_batch;   /* packed problems resident in HBM                   */
+
+int         vgk_abi_version(void);
+const char* vgk_strerror(int code);
+
+/* Create/destroy an engine bound to HIP device `device`.  Mirrors constructing
+ * an Aligner (src/aligner.hpp:164-168); thread-safe for concurrent batches. */
+int  vgk_create(int device, const vgk_scoring* scoring, vgk_ctx** out);
+void vgk_destroy(vgk_ctx* ctx);
+int  vgk_device_info(vgk_ctx* ctx, char* name_out, size_t name_cap,
+                     int* compute_units, size_t* hbm_bytes);
+
+/* gssw path.  pack = validate + encode + H2D; run = kernels only (asynchronous
+ * on the batch's HIP stream, bracketed by HIP events); fetch = wait + D2H. */
+int  vgk_gssw_pack (vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
+                    uint32_t ops_per_problem /* 0 = engine default */,
+                    vgk_batch** out);
+int  vgk_gssw_run  (vgk_batch* batch);
+int  vgk_gssw_fetch(vgk_batch* batch, vgk_result* results /* [n] */,
+                    vgk_op* ops, size_t ops_cap, size_t* ops_written);
+/* one-call convenience = pack + run + fetch + free */
+int  vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
+                    vgk_result* results, vgk_op* ops, size_t ops_cap,
+                    size_t* ops_written);
+
+/* batch introspection (used by bench.py for the roofline line) */
+void     vgk_batch_free(vgk_batch* batch);
+int      vgk_batch_sync(vgk_batch* batch);
+double   vgk_batch_kernel_ms(vgk_batch* batch, int which /* 0 = fill, 1 = traceback, -1 = all */);
+uint64_t vgk_batch_cells(vgk_batch* batch);          /* DP cells computed per run            */
+uint64_t vgk_batch_alg_bytes(vgk_batch* batch);      /* algorithmic bytes per run */
+uint64_t vgk_batch_device_bytes(vgk_batch* batch);   /* HBM footprint of the batch            */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGK_H */

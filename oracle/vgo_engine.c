@@ -1,0 +1,123 @@
+/*
+ * vgo_engine.c — the CPU ORACLE behind the same C ABI as the product
+ * (include/vgk.h), so that tests can (a) diff the HIP engine against it call
+ * for call and (b) exercise the host shim (vg_amd/host) without a GPU.
+ *
+ * TEST INFRASTRUCTURE ONLY.  liboracle is never loaded by the product path:
+ * vg_amd/host/engine.cpp binds libvgamd.so by default and fails loudly if the
+ * HIP library or a GPU is missing; only tests/ and bench.py's cpu_baseline leg
+ * name this library explicitly.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/vgk.h"
+
+int vgo_gssw_align(const vgk_scoring* sc, const vgk_gssw_problem* p,
+                   vgk_result* res, vgk_op* ops, uint32_t ops_cap);
+
+struct vgk_ctx { vgk_scoring sc; };
+struct vgk_batch {
+    vgk_ctx* ctx; const vgk_gssw_problem* probs; uint32_t n; uint32_t ops_per;
+    vgk_result* res; vgk_op* ops; int ran; uint64_t cells;
+};
+
+int vgk_abi_version(void) { return VGK_ABI_VERSION; }
+
+const char* vgk_strerror(int code) {
+    switch (code) {
+        case VGK_OK: return "ok";
+        case VGK_EINVAL: return "invalid argument";
+        case VGK_ENODEV: return "no device";
+        case VGK_ENOMEM: return "out of memory";
+        case VGK_ETOOLONG: return "read too long";
+        case VGK_EOVERFLOW: return "score overflow";
+        case VGK_EOPS: return "cigar buffer too small";
+        case VGK_ETOOBIG: return "band matrices too big";
+        case VGK_ENOBAND: return "no alignment in band";
+        case VGK_EUNSUPPORTED: return "unsupported scoring";
+        default: return "unknown";
+    }
+}
+
+int vgk_create(int device, const vgk_scoring* scoring, vgk_ctx** out) {
+    (void)device;
+    if (!scoring || !out) return VGK_EINVAL;
+    vgk_ctx* c = (vgk_ctx*)calloc(1, sizeof *c);
+    if (!c) return VGK_ENOMEM;
+    c->sc = *scoring; *out = c; return VGK_OK;
+}
+void vgk_destroy(vgk_ctx* ctx) { free(ctx); }
+
+int vgk_device_info(vgk_ctx* ctx, char* name_out, size_t name_cap, int* cus, size_t* hbm) {
+    (void)ctx;
+    if (name_out && name_cap) { strncpy(name_out, "cpu-oracle", name_cap - 1); name_out[name_cap - 1] = 0; }
+    if (cus) *cus = 0;
+    if (hbm) *hbm = 0;
+    return VGK_OK;
+}
+
+static uint32_t default_ops(const vgk_gssw_problem* p) {
+    uint64_t R = 0; for (uint32_t i = 0; i < p->graph.n_nodes; ++i) R += p->graph.node_len[i];
+    return (uint32_t)(p->read_len + R + p->graph.n_nodes + 4);
+}
+
+int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
+                  uint32_t ops_per_problem, vgk_batch** out) {
+    if (!ctx || (!problems && n) || !out) return VGK_EINVAL;
+    vgk_batch* b = (vgk_batch*)calloc(1, sizeof *b);
+    if (!b) return VGK_ENOMEM;
+    b->ctx = ctx; b->probs = problems; b->n = n;
+    uint32_t per = ops_per_problem;
+    if (!per) for (uint32_t i = 0; i < n; ++i) { uint32_t d = default_ops(&problems[i]); if (d > per) per = d; }
+    b->ops_per = per ? per : 1;
+    b->res = (vgk_result*)calloc(n ? n : 1, sizeof(vgk_result));
+    b->ops = (vgk_op*)calloc((size_t)(n ? n : 1) * b->ops_per, sizeof(vgk_op));
+    if (!b->res || !b->ops) { free(b->res); free(b->ops); free(b); return VGK_ENOMEM; }
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t R = 0; for (uint32_t k = 0; k < problems[i].graph.n_nodes; ++k) R += problems[i].graph.node_len[k];
+        b->cells += R * problems[i].read_len;
+    }
+    *out = b; return VGK_OK;
+}
+
+int vgk_gssw_run(vgk_batch* b) {
+    if (!b) return VGK_EINVAL;
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t i = 0; i < (int64_t)b->n; ++i)
+        vgo_gssw_align(&b->ctx->sc, &b->probs[i], &b->res[i], b->ops + (size_t)i * b->ops_per, b->ops_per);
+    b->ran = 1; return VGK_OK;
+}
+
+int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+    if (!b || !results) return VGK_EINVAL;
+    if (!b->ran) { int rc = vgk_gssw_run(b); if (rc) return rc; }
+    size_t w = 0;
+    for (uint32_t i = 0; i < b->n; ++i) {
+        results[i] = b->res[i];
+        results[i].ops_begin = (uint32_t)w;
+        if (w + b->res[i].n_ops > ops_cap) { results[i].status = VGK_EOPS; results[i].n_ops = 0; continue; }
+        if (ops) memcpy(ops + w, b->ops + (size_t)i * b->ops_per, sizeof(vgk_op) * b->res[i].n_ops);
+        w += b->res[i].n_ops;
+    }
+    if (ops_written) *ops_written = w;
+    return VGK_OK;
+}
+
+int vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
+                   vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+    vgk_batch* b = NULL;
+    int rc = vgk_gssw_pack(ctx, problems, n, 0, &b);
+    if (rc) return rc;
+    rc = vgk_gssw_run(b);
+    if (!rc) rc = vgk_gssw_fetch(b, results, ops, ops_cap, ops_written);
+    vgk_batch_free(b);
+    return rc;
+}
+
+void vgk_batch_free(vgk_batch* b) { if (b) { free(b->res); free(b->ops); free(b); } }
+int  vgk_batch_sync(vgk_batch* b) { (void)b; return VGK_OK; }
+double vgk_batch_kernel_ms(vgk_batch* b, int which) { (void)b; (void)which; return 0.0; }
+uint64_t vgk_batch_cells(vgk_batch* b) { return b ? b->cells : 0; }
+uint64_t vgk_batch_alg_bytes(vgk_batch* b) { (void)b; return 0; }
+uint64_t vgk_batch_device_bytes(vgk_batch* b) { (void)b; return 0; }

@@ -1,0 +1,49 @@
+"""Pin the gssw oracle (oracle/vgo_gssw.c) + host logic (vg_amd/host) against the
+reference's own known-answer unit tests, transcribed into tests/golden/ by
+tests/golden/extract_reference_tests.py from src/unittest/aligner.cpp and
+src/unittest/pinned_alignment.cpp.  CPU only: the host shim is bound to the
+oracle library explicitly here (the product binds the HIP library)."""
+import pytest
+
+from util import HostAligner, ORACLE_LIB, check_expectations, load_golden
+
+
+def _cases(fname, calls):
+    return [c for c in load_golden(fname) if c["call"] in calls and not c["qual_adj"]]
+
+
+def _run(case, engine_lib):
+    al = HostAligner(engine_lib, tuple(case["scores"]))
+    if case["call"] == "align":
+        tb = case["args"][1] if len(case["args"]) > 1 else True
+        return al.run(case["nodes"], case["edges"], case["read"], "align" if tb is True else "align_score")
+    if case["call"] == "align_pinned":
+        return al.run(case["nodes"], case["edges"], case["read"], "align_pinned", pin_left=bool(case["args"][1]))
+    raise AssertionError(case["call"])
+
+
+def run_group(cases, engine_lib):
+    """Cases from one source location may refer to each other's scores (aln1/aln2)."""
+    by_source = {}
+    for c in cases:
+        by_source.setdefault(c["source"], []).append(c)
+    n = 0
+    for src, group in by_source.items():
+        alns = {c["aln"]: _run(c, engine_lib) for c in group}
+        scores = {k: v["score"] for k, v in alns.items()}
+        for c in group:
+            check_expectations(c, alns[c["aln"]], scores)
+            n += len(c["expect"])
+    return n
+
+
+def test_oracle_matches_reference_aligner_unit_tests():
+    cases = [c for c in _cases("ref_aligner.json", {"align"}) if len(c["args"]) == 2 and c["args"][1] is True]
+    assert len(cases) >= 20
+    assert run_group(cases, ORACLE_LIB) >= 40
+
+
+def test_oracle_matches_reference_pinned_alignment_unit_tests():
+    cases = _cases("ref_pinned_alignment.json", {"align_pinned"})
+    assert len(cases) >= 28
+    assert run_group(cases, ORACLE_LIB) >= 400

@@ -1,0 +1,313 @@
+#include "aligner.hpp"
+#include <algorithm>
+#include <sstream>
+#include <stdexcept>
+
+namespace vgamd {
+
+std::string nonATGCNtoN(const std::string& s) {
+    std::string n = s;
+    for (auto& b : n) if (b != 'A' && b != 'T' && b != 'G' && b != 'C' && b != 'N') b = 'N';
+    return n;
+}
+
+MatrixAlignmentScorer::MatrixAlignmentScorer(const int8_t* m4, int8_t go, int8_t ge, int8_t bonus)
+    : match(m4[0]), mismatch((int8_t)-m4[1]), gap_open(go), gap_extension(ge), full_length_bonus(bonus) {
+    for (size_t i = 0, j = 0; i < 25; ++i) {
+        if (i % 5 == 4 || i / 5 == 4) score_matrix[i] = 0;
+        else score_matrix[i] = m4[j++];
+    }
+}
+
+size_t MatrixAlignmentScorer::longest_detectable_gap(size_t read_length, size_t read_pos) const {
+    int64_t overhang_length = (int64_t)std::min(read_pos, read_length - read_pos);
+    int64_t numer = (int64_t)match * overhang_length + full_length_bonus;
+    int64_t gap_length = (numer - gap_open) / gap_extension + 1;
+    return gap_length >= 0 && overhang_length > 0 ? (size_t)gap_length : 0;
+}
+
+vgk_scoring MatrixAlignmentScorer::as_vgk() const {
+    vgk_scoring s{};
+    for (int i = 0; i < 25; ++i) s.matrix[i] = score_matrix[i];
+    s.gap_open = (uint8_t)gap_open; s.gap_extend = (uint8_t)gap_extension; s.full_length_bonus = full_length_bonus;
+    return s;
+}
+
+GSSWAligner::GSSWAligner(std::unique_ptr<MatrixAlignmentScorer> owned_scorer, std::shared_ptr<EngineApi> eng, int device)
+    : scorer(std::move(owned_scorer)), engine(eng ? eng : load_engine()) {
+    vgk_scoring s = scorer->as_vgk();
+    int rc = engine->create(device, &s, &ctx);
+    if (rc != VGK_OK) throw std::runtime_error(std::string("vgamd: cannot create engine context: ") + engine->strerror(rc));
+}
+
+GSSWAligner::~GSSWAligner() { if (ctx) engine->destroy(ctx); }
+
+vgk_graph GSSWAligner::PackedGraph::view() const {
+    vgk_graph v{};
+    v.n_nodes = (uint32_t)order.size();
+    v.node_len = node_len.data(); v.seq = seq.data(); v.pred_off = pred_off.data(); v.pred_idx = pred_idx.data();
+    return v;
+}
+
+GSSWAligner::PackedGraph GSSWAligner::create_packed_graph(const HandleGraph& g) const {
+    return create_packed_graph(g, handlealgs::lazier_topological_order(&g));
+}
+
+GSSWAligner::PackedGraph GSSWAligner::create_packed_graph(const HandleGraph& g, const std::vector<handle_t>& order) const {
+    PackedGraph pg;
+    pg.order = order;
+    std::unordered_map<handle_t, uint32_t, handle_hash> index;
+    for (uint32_t i = 0; i < order.size(); ++i) index[order[i]] = i;
+    pg.pred_off.push_back(0);
+    for (uint32_t i = 0; i < order.size(); ++i) {
+        std::string s = nonATGCNtoN(g.get_sequence(order[i]));
+        pg.node_len.push_back((uint32_t)s.size());
+        pg.seq += s;
+        bool bad = false;
+        g.follow_edges_v(order[i], true, [&](const handle_t& prev) {
+            auto it = index.find(prev);
+            if (it == index.end()) return;            // edge leaves the ordered subgraph (src/aligner.cpp:596-599)
+            if (it->second >= i) { bad = true; return; }
+            pg.pred_idx.push_back(it->second);
+        });
+        if (bad) throw std::runtime_error("vgamd: graph handed to the aligner is not a DAG in the given order "
+                                          "(reference dies here too: src/aligner.cpp:61-78)");
+        pg.pred_off.push_back((uint32_t)pg.pred_idx.size());
+    }
+    return pg;
+}
+
+std::unordered_set<nid_t> GSSWAligner::identify_pinning_points(const HandleGraph& graph) const {
+    std::unordered_set<nid_t> return_val;
+    for (const handle_t& handle : handlealgs::tail_nodes(&graph)) {
+        std::vector<handle_t> stack(1, handle);
+        while (!stack.empty()) {
+            handle_t here = stack.back(); stack.pop_back();
+            if (graph.get_length(here) > 0) return_val.insert(graph.get_id(here));
+            else graph.follow_edges_v(here, true, [&](const handle_t& prev) {
+                if (!return_val.count(graph.get_id(prev))) stack.push_back(prev);
+            });
+        }
+    }
+    return return_val;
+}
+
+void GSSWAligner::ops_to_alignment(const PackedGraph& pg, const HandleGraph& seq_source, const vgk_result& res,
+                                   const vgk_op* ops, Alignment& alignment) const {
+    alignment.clear_path();
+    alignment.score = res.score;
+    alignment.query_position = 0;
+    const std::string& to_seq = alignment.sequence;
+    int to_pos = 0;
+    int from_pos = res.first_offset;
+    uint32_t i = 0; bool first_node = true;
+    while (i < res.n_ops) {
+        uint32_t node = ops[i].node;
+        uint32_t j = i; while (j < res.n_ops && ops[j].node == node) ++j;
+        const handle_t h = pg.order[node];
+        const std::string node_seq = nonATGCNtoN(seq_source.get_sequence(h));
+        alignment.path.mapping.emplace_back();
+        Mapping& mapping = alignment.path.mapping.back();
+        if (!first_node) from_pos = 0;
+        first_node = false;
+        mapping.position.node_id = seq_source.get_id(h);
+        mapping.position.offset = from_pos;
+        mapping.rank = (int64_t)alignment.path.mapping.size();
+        for (uint32_t k = i; k < j; ++k) {
+            int32_t length = ops[k].len;
+            switch (ops[k].op) {
+                case VGK_OP_M: {
+                    int hpos = from_pos, last_start = from_pos, q = to_pos;
+                    for (; hpos < from_pos + length; ++hpos, ++q) {
+                        if (node_seq[hpos] != to_seq[q]) {
+                            if (hpos - last_start > 0) { Edit e; e.from_length = e.to_length = hpos - last_start; mapping.edit.push_back(e); }
+                            Edit e; e.from_length = e.to_length = 1; e.sequence = to_seq.substr(q, 1); mapping.edit.push_back(e);
+                            last_start = hpos + 1;
+                        }
+                    }
+                    if (hpos - last_start > 0) { Edit e; e.from_length = e.to_length = hpos - last_start; mapping.edit.push_back(e); }
+                    to_pos += length; from_pos += length;
+                } break;
+                case VGK_OP_D: { Edit e; e.from_length = length; e.to_length = 0; mapping.edit.push_back(e); from_pos += length; } break;
+                case VGK_OP_I:
+                case VGK_OP_S: { Edit e; e.from_length = 0; e.to_length = length; e.sequence = to_seq.substr(to_pos, length);
+                                 mapping.edit.push_back(e); to_pos += length; } break;
+                default: throw std::runtime_error("vgamd: unsupported cigar op from engine");
+            }
+        }
+        i = j;
+    }
+    alignment.identity = identity(alignment.path);
+}
+
+Aligner::Aligner(const int8_t* score_matrix, int8_t gap_open, int8_t gap_extension, int8_t full_length_bonus,
+                 double /*gc_content*/, std::shared_ptr<EngineApi> eng, int device)
+    : GSSWAligner(std::make_unique<MatrixAlignmentScorer>(score_matrix, gap_open, gap_extension, full_length_bonus), eng, device) {}
+
+// unreverse_graph_mapping (src/aligner.cpp:255-300) on the flat op list
+static void unreverse_ops(std::vector<vgk_op>& ops, vgk_result& res, const std::vector<uint32_t>& node_len) {
+    std::reverse(ops.begin(), ops.end());      // reverses node order and the elements inside each node at once
+    if (ops.empty()) { res.first_offset = 0; return; }
+    uint32_t first = ops[0].node, aligned = 0, n_nodes = 1;
+    for (size_t i = 0; i < ops.size(); ++i) {
+        if (i && ops[i].node != ops[i - 1].node) ++n_nodes;
+        if (ops[i].node == first && n_nodes == 1 && (ops[i].op == VGK_OP_M || ops[i].op == VGK_OP_D)) aligned += ops[i].len;
+    }
+    res.first_offset = (int32_t)node_len[first] - (int32_t)aligned - (n_nodes == 1 ? res.first_offset : 0);
+}
+
+void Aligner::align_internal(Alignment& alignment, std::vector<Alignment>* multi_alignments, const HandleGraph& g,
+                             bool pinned, bool pin_left, int32_t max_alt_alns, bool traceback_aln) const {
+    // input contract (the reference prints and exit(1)s: src/aligner.cpp:348-363; we throw)
+    if (pin_left && !pinned) throw std::invalid_argument("error:[Aligner] cannot choose pinned end in non-pinned alignment");
+    if (multi_alignments && !pinned) throw std::invalid_argument("error:[Aligner] multiple traceback is not implemented in local alignment, only pinned and global");
+    if (!multi_alignments && max_alt_alns != 1) throw std::invalid_argument("error:[Aligner] cannot specify maximum number of alignments in single alignment");
+    if (max_alt_alns <= 0) throw std::invalid_argument("error:[Aligner] cannot do less than 1 alignment");
+
+    ReverseGraph reversed_graph(&g, false);
+    std::string reversed_sequence;
+    const HandleGraph* oriented_graph = &g;
+    const std::string* align_sequence = &alignment.sequence;
+    if (pin_left) {
+        oriented_graph = &reversed_graph;
+        reversed_sequence.assign(alignment.sequence.rbegin(), alignment.sequence.rend());
+        align_sequence = &reversed_sequence;
+    }
+    std::unordered_set<nid_t> pinning_ids;
+    std::unique_ptr<NullMaskingGraph> null_masked_graph;
+    const HandleGraph* align_graph = oriented_graph;
+    if (pinned) {
+        pinning_ids = identify_pinning_points(*oriented_graph);
+        null_masked_graph = std::make_unique<NullMaskingGraph>(oriented_graph);
+        align_graph = null_masked_graph.get();
+    }
+
+    PackedGraph pg = create_packed_graph(*align_graph);
+    vgk_result res{};
+    std::vector<vgk_op> ops;
+    bool did_dp = false;
+    if (!pg.order.empty() && !align_sequence->empty()) {
+        std::vector<uint8_t> pin_mask;
+        vgk_gssw_problem prob{};
+        prob.read = align_sequence->data(); prob.read_len = (uint32_t)align_sequence->size();
+        prob.flags = (pinned ? VGK_GSSW_PINNED : VGK_GSSW_LOCAL) | (traceback_aln ? VGK_GSSW_TRACEBACK : 0);
+        prob.graph = pg.view();
+        if (pinned) {
+            pin_mask.resize(pg.order.size());
+            for (size_t i = 0; i < pg.order.size(); ++i) pin_mask[i] = pinning_ids.count(align_graph->get_id(pg.order[i])) ? 1 : 0;
+            prob.pinning = pin_mask.data();
+        }
+        ops.resize(prob.read_len + pg.seq.size() + pg.order.size() + 4);
+        size_t written = 0;
+        int rc = engine->gssw_align(ctx, &prob, 1, &res, ops.data(), ops.size(), &written);
+        if (rc != VGK_OK) throw std::runtime_error(std::string("vgamd: gssw engine failed: ") + engine->strerror(rc));
+        if (res.status != VGK_OK) throw std::runtime_error(std::string("vgamd: gssw problem failed: ") + engine->strerror(res.status));
+        ops.resize(res.n_ops);
+        did_dp = true;
+    }
+
+    if (traceback_aln) {
+        if (pinned) {
+            if (did_dp && res.score > 0) {
+                if (pin_left) unreverse_ops(ops, res, pg.node_len);
+                // after un-reversal the cigar refers to the forward sequences of g
+                ops_to_alignment(pg, g, res, ops.data(), alignment);
+                if (multi_alignments) multi_alignments->emplace_back(alignment);   // alternates: see DESIGN.md (k-best not yet on device)
+            } else if (g.get_node_count() > 0) {
+                // no positive-score traceback: synthesise soft clips at the id-sorted tail nodes.
+                // The reference writes every alternate into `alignment` (src/aligner.cpp:505-520); reproduced as is.
+                auto pinning_points = handlealgs::tail_nodes(oriented_graph);
+                std::sort(pinning_points.begin(), pinning_points.end(), [&](const handle_t& a, const handle_t& b) {
+                    return oriented_graph->get_id(a) < oriented_graph->get_id(b); });
+                for (size_t i = 0; i < (size_t)max_alt_alns && i < pinning_points.size(); i++) {
+                    if (multi_alignments) multi_alignments->emplace_back();
+                    handle_t& pinning_point = pinning_points[i];
+                    alignment.path.mapping.emplace_back();
+                    Mapping& mapping = alignment.path.mapping.back();
+                    mapping.rank = 1;
+                    mapping.position.node_id = oriented_graph->get_id(pinning_point);
+                    mapping.position.offset = pin_left ? 0 : (int64_t)oriented_graph->get_length(pinning_point);
+                    Edit e; e.to_length = (int32_t)alignment.sequence.length(); e.sequence = alignment.sequence;
+                    mapping.edit.push_back(e);
+                    if (i == 0 && multi_alignments) multi_alignments->back() = alignment;
+                }
+            }
+        } else {
+            ops_to_alignment(pg, g, res, ops.data(), alignment);
+        }
+    } else {
+        alignment.score = res.score;
+        alignment.path.mapping.emplace_back();
+        Position& p = alignment.path.mapping.back().position;
+        if (res.end_node >= 0) { p.node_id = align_graph->get_id(pg.order[res.end_node]); p.offset = res.end_offset; }
+    }
+}
+
+void Aligner::align(Alignment& alignment, const HandleGraph& g, bool traceback_aln) const {
+    align_internal(alignment, nullptr, g, false, false, 1, traceback_aln);
+}
+
+void Aligner::align(Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& topological_order) const {
+    PackedGraph pg = create_packed_graph(g, topological_order);
+    vgk_gssw_problem prob{};
+    prob.read = alignment.sequence.data(); prob.read_len = (uint32_t)alignment.sequence.size();
+    prob.flags = VGK_GSSW_LOCAL | VGK_GSSW_TRACEBACK;
+    prob.graph = pg.view();
+    vgk_result res{};
+    std::vector<vgk_op> ops(prob.read_len + pg.seq.size() + pg.order.size() + 4);
+    size_t written = 0;
+    int rc = engine->gssw_align(ctx, &prob, 1, &res, ops.data(), ops.size(), &written);
+    if (rc != VGK_OK || res.status != VGK_OK)
+        throw std::runtime_error(std::string("vgamd: gssw engine failed: ") + engine->strerror(rc ? rc : res.status));
+    ops_to_alignment(pg, g, res, ops.data(), alignment);
+    // node ids were order indices inside the engine; ops_to_alignment already wrote
+    // g.get_id(handle); add the strand (src/aligner.cpp:615-621)
+    size_t gi = 0; uint32_t i = 0;
+    while (i < res.n_ops) {
+        uint32_t node = ops[i].node; while (i < res.n_ops && ops[i].node == node) ++i;
+        alignment.path.mapping[gi++].position.is_reverse = g.get_is_reverse(topological_order[node]);
+    }
+}
+
+void Aligner::align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left, bool xdrop,
+                           uint16_t /*xdrop_max_gap_length*/) const {
+    if (xdrop) throw std::runtime_error("vgamd: X-drop pinned alignment is not wired into this build of the host shim");
+    align_internal(alignment, nullptr, g, true, pin_left, 1, true);
+}
+
+void Aligner::align_pinned_multi(Alignment& alignment, std::vector<Alignment>& alt_alignments, const HandleGraph& g,
+                                 bool pin_left, int32_t max_alt_alns) const {
+    if (!alt_alignments.empty())
+        throw std::invalid_argument("error:[Aligner::align_pinned_multi] output vector must be empty for pinned multi-aligning");
+    align_internal(alignment, &alt_alignments, g, true, pin_left, max_alt_alns, true);
+}
+
+static void json_escape(std::ostringstream& o, const std::string& s) {
+    o << '"';
+    for (char c : s) { if (c == '"' || c == '\\') o << '\\'; o << c; }
+    o << '"';
+}
+
+std::string alignment_to_json(const Alignment& a) {
+    std::ostringstream o;
+    o << "{\"score\":" << a.score << ",\"identity\":" << a.identity << ",\"query_position\":" << a.query_position << ",\"sequence\":";
+    json_escape(o, a.sequence);
+    o << ",\"path\":{\"mapping\":[";
+    for (size_t i = 0; i < a.path.mapping.size(); ++i) {
+        const Mapping& m = a.path.mapping[i];
+        if (i) o << ',';
+        o << "{\"position\":{\"node_id\":" << m.position.node_id << ",\"offset\":" << m.position.offset
+          << ",\"is_reverse\":" << (m.position.is_reverse ? "true" : "false") << "},\"rank\":" << m.rank << ",\"edit\":[";
+        for (size_t j = 0; j < m.edit.size(); ++j) {
+            if (j) o << ',';
+            o << "{\"from_length\":" << m.edit[j].from_length << ",\"to_length\":" << m.edit[j].to_length << ",\"sequence\":";
+            json_escape(o, m.edit[j].sequence);
+            o << '}';
+        }
+        o << "]}";
+    }
+    o << "]}}";
+    return o.str();
+}
+
+}  // namespace vgamd

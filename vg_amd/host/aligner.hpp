@@ -1,0 +1,112 @@
+// aligner.hpp — host-side mirror of vg's aligner interface
+// (reference: src/aligner.hpp:32-213, src/alignment_scorer.hpp:18-29) whose
+// method bodies hand the DP to the MI355X engine through the C ABI in
+// include/vgk.h instead of calling gssw / dozeu / BandedGlobalAligner on the CPU.
+// Names, argument meaning and error behaviour follow the reference so that the
+// parity tests read like src/unittest/{aligner,pinned_alignment}.cpp.
+#pragma once
+#include <limits>
+#include <memory>
+#include <unordered_set>
+#include <vector>
+#include "alignment.hpp"
+#include "engine.hpp"
+#include "handle_graph.hpp"
+
+namespace vgamd {
+
+// default scoring parameters (reference: src/alignment_scorer.hpp:18-29)
+static constexpr int8_t default_match = 1;
+static constexpr int8_t default_mismatch = 4;
+static constexpr int8_t default_score_matrix[16] = {
+     default_match,    -default_mismatch, -default_mismatch, -default_mismatch,
+    -default_mismatch,  default_match,    -default_mismatch, -default_mismatch,
+    -default_mismatch, -default_mismatch,  default_match,    -default_mismatch,
+    -default_mismatch, -default_mismatch, -default_mismatch,  default_match };
+static constexpr int8_t default_gap_open = 6;
+static constexpr int8_t default_gap_extension = 1;
+static constexpr int8_t default_full_length_bonus = 5;
+static constexpr uint16_t default_xdrop_max_gap_length = 40;
+
+// MatrixAlignmentScorer (reference: src/alignment_scorer.cpp:284-314): 4x4 -> 5x5
+// with an all-zero N row/column; plus the closed-form helpers callers read.
+struct MatrixAlignmentScorer {
+    int8_t score_matrix[25];
+    int8_t match, mismatch, gap_open, gap_extension, full_length_bonus;
+    MatrixAlignmentScorer(const int8_t* score_matrix_4x4, int8_t go, int8_t ge, int8_t bonus);
+    // reference: src/alignment_scorer.cpp:264-271
+    size_t longest_detectable_gap(size_t read_length, size_t read_pos) const;
+    vgk_scoring as_vgk() const;
+};
+
+class BaseAligner {
+public:
+    virtual ~BaseAligner() = default;
+    virtual void align(Alignment& alignment, const HandleGraph& g, bool traceback_aln) const = 0;
+};
+
+class GSSWAligner : public BaseAligner {
+protected:
+    GSSWAligner(std::unique_ptr<MatrixAlignmentScorer> owned_scorer, std::shared_ptr<EngineApi> engine, int device);
+    ~GSSWAligner() override;
+
+    // what create_gssw_graph hands to gssw (src/aligner.cpp:30-85): nodes in
+    // lazier_topological_order, sequences cleaned by nonATGCNtoN, forward edges as CSR
+    struct PackedGraph {
+        std::vector<handle_t> order;
+        std::vector<uint32_t> node_len, pred_off, pred_idx;
+        std::string seq;
+        vgk_graph view() const;
+    };
+    PackedGraph create_packed_graph(const HandleGraph& g) const;
+    PackedGraph create_packed_graph(const HandleGraph& g, const std::vector<handle_t>& topological_order) const;
+    std::unordered_set<nid_t> identify_pinning_points(const HandleGraph& graph) const;   // src/aligner.cpp:87-118
+
+    // gssw_mapping_to_alignment (src/aligner.cpp:120-241) over the engine's op list
+    void ops_to_alignment(const PackedGraph& pg, const HandleGraph& seq_source, const vgk_result& res,
+                          const vgk_op* ops, Alignment& alignment) const;
+
+public:
+    GSSWAligner(const GSSWAligner&) = delete;
+    GSSWAligner& operator=(const GSSWAligner&) = delete;
+
+    virtual void align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left, bool xdrop = false,
+                              uint16_t xdrop_max_gap_length = default_xdrop_max_gap_length) const = 0;
+    virtual void align_pinned_multi(Alignment& alignment, std::vector<Alignment>& alt_alignments, const HandleGraph& g,
+                                    bool pin_left, int32_t max_alt_alns) const = 0;
+
+    std::unique_ptr<MatrixAlignmentScorer> scorer;
+
+protected:
+    std::shared_ptr<EngineApi> engine;
+    vgk_ctx* ctx = nullptr;
+};
+
+class Aligner : public GSSWAligner {
+public:
+    Aligner(const int8_t* score_matrix = default_score_matrix,
+            int8_t gap_open = default_gap_open,
+            int8_t gap_extension = default_gap_extension,
+            int8_t full_length_bonus = default_full_length_bonus,
+            double gc_content = 0.5,
+            std::shared_ptr<EngineApi> engine = nullptr,   // nullptr = the HIP product library
+            int device = 0);
+
+    // local alignment, bonus at both ends (src/aligner.cpp:566-569)
+    void align(Alignment& alignment, const HandleGraph& g, bool traceback_aln) const override;
+    // local alignment over a caller-supplied order that may mix strands (src/aligner.cpp:571-626)
+    void align(Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& topological_order) const;
+    void align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left, bool xdrop = false,
+                      uint16_t xdrop_max_gap_length = default_xdrop_max_gap_length) const override;
+    void align_pinned_multi(Alignment& alignment, std::vector<Alignment>& alt_alignments, const HandleGraph& g,
+                            bool pin_left, int32_t max_alt_alns) const override;
+
+private:
+    void align_internal(Alignment& alignment, std::vector<Alignment>* multi_alignments, const HandleGraph& g,
+                        bool pinned, bool pin_left, int32_t max_alt_alns, bool traceback_aln) const;
+};
+
+// nonATGCNtoN (reference: src/utility.cpp:323-332)
+std::string nonATGCNtoN(const std::string& s);
+
+}  // namespace vgamd

@@ -1,0 +1,47 @@
+#include "engine.hpp"
+#include <dlfcn.h>
+#include <cstdlib>
+#include <stdexcept>
+
+namespace vgamd {
+
+EngineApi::~EngineApi() { /* keep the library mapped: contexts may outlive us */ }
+
+static std::string default_engine_path() {
+    if (const char* e = std::getenv("VGAMD_ENGINE_LIB")) return e;
+    Dl_info info;
+    if (dladdr((void*)&default_engine_path, &info) && info.dli_fname) {
+        std::string self = info.dli_fname;
+        size_t slash = self.rfind('/');
+        std::string dir = slash == std::string::npos ? "." : self.substr(0, slash);
+        return dir + "/libvgamd.so";
+    }
+    return "libvgamd.so";
+}
+
+template <class F> static void bind(void* dl, const char* name, F& fn) {
+    fn = reinterpret_cast<F>(dlsym(dl, name));
+    if (!fn) throw std::runtime_error(std::string("vgamd engine: missing symbol ") + name);
+}
+
+std::shared_ptr<EngineApi> load_engine(const std::string& path) {
+    std::string p = path.empty() ? default_engine_path() : path;
+    void* dl = dlopen(p.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!dl) throw std::runtime_error("vgamd engine: cannot load " + p + ": " + dlerror() +
+                                      " (the HIP engine is required; there is no CPU fallback)");
+    auto api = std::make_shared<EngineApi>();
+    api->dl = dl;
+    bind(dl, "vgk_abi_version", api->abi_version);
+    bind(dl, "vgk_strerror", api->strerror);
+    bind(dl, "vgk_create", api->create);
+    bind(dl, "vgk_destroy", api->destroy);
+    bind(dl, "vgk_gssw_align", api->gssw_align);
+    bind(dl, "vgk_gssw_pack", api->gssw_pack);
+    bind(dl, "vgk_gssw_run", api->gssw_run);
+    bind(dl, "vgk_gssw_fetch", api->gssw_fetch);
+    bind(dl, "vgk_batch_free", api->batch_free);
+    if (api->abi_version() != VGK_ABI_VERSION) throw std::runtime_error("vgamd engine: ABI version mismatch in " + p);
+    return api;
+}
+
+}  // namespace vgamd

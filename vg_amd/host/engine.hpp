@@ -1,0 +1,33 @@
+// engine.hpp — binds the C ABI of include/vgk.h at run time.
+//
+// The product binds vg_amd/libvgamd.so (HIP kernels).  There is NO CPU fallback:
+// if the HIP library cannot be loaded or no gfx950 device answers, construction
+// throws and the caller fails loudly.  Tests may name another library exporting
+// the same ABI (oracle/libvgoracle.so) explicitly — that is the only way the
+// oracle is ever reached, and nothing in this directory names it.
+#pragma once
+#include <memory>
+#include <string>
+#include "../../include/vgk.h"
+
+namespace vgamd {
+
+struct EngineApi {
+    void* dl = nullptr;
+    decltype(&vgk_abi_version) abi_version = nullptr;
+    decltype(&vgk_strerror) strerror = nullptr;
+    decltype(&vgk_create) create = nullptr;
+    decltype(&vgk_destroy) destroy = nullptr;
+    decltype(&vgk_gssw_align) gssw_align = nullptr;
+    decltype(&vgk_gssw_pack) gssw_pack = nullptr;
+    decltype(&vgk_gssw_run) gssw_run = nullptr;
+    decltype(&vgk_gssw_fetch) gssw_fetch = nullptr;
+    decltype(&vgk_batch_free) batch_free = nullptr;
+    ~EngineApi();
+};
+
+// Load the ABI from `path`; empty path = the product library next to this shim
+// (libvgamd.so in the directory of libvgamd_host.so), or $VGAMD_ENGINE_LIB.
+std::shared_ptr<EngineApi> load_engine(const std::string& path = "");
+
+}  // namespace vgamd

@@ -1,0 +1,67 @@
+// host_capi.cpp — a small C surface over the C++ host shim so that other
+// languages (the pytest suite via ctypes, or a future binding) can drive the
+// mirrored Aligner interface exactly like src/unittest/*.cpp drives vg's.
+#include <cstring>
+#include <memory>
+#include <string>
+#include "aligner.hpp"
+
+using namespace vgamd;
+
+extern "C" {
+
+struct vgh_graph { HashGraph g; };
+struct vgh_aligner { std::unique_ptr<Aligner> a; };
+
+static thread_local std::string g_last_error;
+const char* vgh_last_error(void) { return g_last_error.c_str(); }
+
+vgh_graph* vgh_graph_create(void) { return new vgh_graph(); }
+void vgh_graph_destroy(vgh_graph* g) { delete g; }
+int vgh_graph_add_node(vgh_graph* g, int64_t id, const char* seq) {
+    try { g->g.create_handle(seq, id); return 0; } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+int vgh_graph_add_edge(vgh_graph* g, int64_t from, int64_t to) {
+    try { g->g.create_edge(g->g.get_handle(from), g->g.get_handle(to)); return 0; }
+    catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// engine_lib: NULL/"" = the HIP product library (fails loudly without it);
+// tests may pass the oracle's path to exercise the host logic on a CPU box.
+vgh_aligner* vgh_aligner_create(const char* engine_lib, int device, int match, int mismatch,
+                                int gap_open, int gap_extend, int full_length_bonus) {
+    try {
+        int8_t m[16];
+        for (int i = 0; i < 16; ++i) m[i] = (i % 5 == 0) ? (int8_t)match : (int8_t)-mismatch;   // src/aligner.cpp:1395-1413
+        auto eng = load_engine(engine_lib ? engine_lib : "");
+        auto* h = new vgh_aligner();
+        h->a = std::make_unique<Aligner>(m, (int8_t)gap_open, (int8_t)gap_extend, (int8_t)full_length_bonus, 0.5, eng, device);
+        return h;
+    } catch (std::exception& e) { g_last_error = e.what(); return nullptr; }
+}
+void vgh_aligner_destroy(vgh_aligner* a) { delete a; }
+
+static int emit(const Alignment& aln, char* out, size_t cap) {
+    std::string js = alignment_to_json(aln);
+    if (js.size() + 1 > cap) { g_last_error = "json buffer too small"; return -2; }
+    std::memcpy(out, js.c_str(), js.size() + 1);
+    return 0;
+}
+
+// call: 0 = align(traceback), 1 = align(score only), 2 = align_pinned, 3 = align_pinned_multi (primary only reported)
+int vgh_align(vgh_aligner* a, vgh_graph* g, const char* read, int call, int pin_left, int max_alt_alns,
+              char* json_out, size_t json_cap) {
+    try {
+        Alignment aln; aln.sequence = read;
+        switch (call) {
+            case 0: a->a->align(aln, g->g, true); break;
+            case 1: a->a->align(aln, g->g, false); break;
+            case 2: a->a->align_pinned(aln, g->g, pin_left != 0); break;
+            case 3: { std::vector<Alignment> alts; a->a->align_pinned_multi(aln, alts, g->g, pin_left != 0, max_alt_alns); } break;
+            default: g_last_error = "unknown call"; return -1;
+        }
+        return emit(aln, json_out, json_cap);
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+}  // extern "C"
