@@ -12,7 +12,7 @@ HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Wall -Wno-unu
 CXXFLAGS ?= -O2 -std=c++17 -fPIC -Iinclude -Wall
 CFLAGS   ?= -O3 -march=x86-64-v2 -std=c11 -fPIC -fopenmp -Iinclude -Wall
 
-LIB_SRCS    := $(wildcard vg_amd/csrc/*.hip)
+LIB_SRCS    := $(wildcard vg_amd/csrc/*.hip) $(wildcard vg_amd/csrc/*.cpp)
 LIB_HDRS    := $(wildcard vg_amd/csrc/*.h vg_amd/csrc/*.hpp include/*.h)
 HOST_SRCS   := $(wildcard vg_amd/host/*.cpp)
 HOST_HDRS   := $(wildcard vg_amd/host/*.hpp include/*.h)
@@ -23,8 +23,11 @@ lib: vg_amd/libvgamd.so
 host: vg_amd/libvgamd_host.so
 oracle: oracle/libvgoracle.so
 
+# the C-ABI/packing layer is plain C++; only backend_hip.hip carries device code
 vg_amd/libvgamd.so: $(LIB_SRCS) $(LIB_HDRS)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(LIB_SRCS)
+	$(CXX) $(CXXFLAGS) -O3 -c vg_amd/csrc/vgk_api.cpp -o vg_amd/csrc/vgk_api.o
+	$(HIPCC) $(HIPFLAGS) -c vg_amd/csrc/backend_hip.hip -o vg_amd/csrc/backend_hip.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ vg_amd/csrc/vgk_api.o vg_amd/csrc/backend_hip.o
 
 vg_amd/libvgamd_host.so: $(HOST_SRCS) $(HOST_HDRS)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRCS) -ldl
@@ -36,3 +39,9 @@ clean:
 	rm -f vg_amd/libvgamd.so vg_amd/libvgamd_host.so oracle/libvgoracle.so
 
 .PHONY: all lib host oracle clean
+
+# test-only: CPU lock-step emulation of the HIP lane code behind the same C ABI
+emu: tests/emu/libvgamd_emu.so
+tests/emu/libvgamd_emu.so: vg_amd/csrc/vgk_api.cpp tests/emu/backend_emu.cpp $(LIB_HDRS)
+	$(CXX) -O2 -g -std=c++17 -fPIC -Iinclude -Wall -shared -o $@ vg_amd/csrc/vgk_api.cpp tests/emu/backend_emu.cpp
+.PHONY: emu

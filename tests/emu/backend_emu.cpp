@@ -1,0 +1,54 @@
+// backend_emu.cpp — TEST-ONLY backend: runs the very same lane code
+// (vg_amd/csrc/gssw_device.hpp) and the same packing layer (vgk_api.cpp) on the
+// CPU by stepping all 64 lanes of every wavefront in lock-step, with the DPP
+// wave_shr:1 exchange replaced by reading the previous step's values of lane-1.
+// It lets the kernel logic be debugged in a container without a GPU.  It is
+// never built into, nor loaded by, the product library.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../vg_amd/csrc/backend.hpp"
+
+namespace vgk {
+
+class EmuBackend final : public Backend {
+public:
+    const char* name() const override { return "cpu-lockstep-emulator"; }
+    int compute_units() const override { return 0; }
+    size_t memory_bytes() const override { return 0; }
+    void* alloc(size_t bytes) override { return std::calloc(bytes ? bytes : 16, 1); }
+    void release(void* p) override { std::free(p); }
+    int upload(void* d, const void* s, size_t n) override { std::memcpy(d, s, n); return VGK_OK; }
+    int download(void* d, const void* s, size_t n) override { std::memcpy(d, s, n); return VGK_OK; }
+    int zero(void* d, size_t n) override { std::memset(d, 0, n); return VGK_OK; }
+    int sync() override { return VGK_OK; }
+    int run_gssw(const GsswParams& P, bool walk) override {
+        std::vector<Lane> lanes(64);
+        std::vector<uint32_t> oh(64), of(64), oi(64);
+        for (uint32_t w = 0; w < P.n_waves; ++w) {
+            const WaveDesc wd = P.waves[w];
+            for (uint32_t l = 0; l < 64; ++l) lane_init(lanes[l], P, wd, l);
+            for (uint32_t t = 0; t < wd.n_steps; ++t) {
+                for (uint32_t l = 0; l < 64; ++l) { oh[l] = lanes[l].out_h; of[l] = lanes[l].out_f; oi[l] = lanes[l].info; }
+                for (uint32_t l = 0; l < 64; ++l) {
+                    if ((t & 3u) == 0) lane_prefetch(lanes[l], P, t);
+                    const uint32_t rh = l ? oh[l - 1] : 0, rf = l ? of[l - 1] : 0, ri = l ? oi[l - 1] : 0;
+                    uint32_t* tb = P.want_tb ? P.tb + (wd.tb_off + (uint64_t)t * 64 + l) * 4 : nullptr;
+                    lane_step(lanes[l], P, t, rh, rf, ri, tb);
+                }
+            }
+            for (uint32_t l = 0; l < 64; ++l) for (int half = 0; half < 2; ++half) {
+                uint32_t prob; unsigned long long key;
+                if (lane_best(lanes[l], half, prob, key) && key > P.best[prob]) P.best[prob] = key;
+            }
+        }
+        if (walk) for (uint32_t i = 0; i < P.n_problems; ++i) walk_one(P, i);
+        return VGK_OK;
+    }
+    double last_ms(int) const override { return 0.0; }
+};
+
+Backend* make_backend(int, std::string&) { return new EmuBackend(); }
+
+}  // namespace vgk

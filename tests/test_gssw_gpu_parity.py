@@ -1,0 +1,60 @@
+"""GPU parity: the HIP engine (vg_amd/libvgamd.so) against the CPU oracle through
+the same C ABI, bit-exact in score, end cell and CIGAR.  Also the reference's own
+unit-test vectors driven through the C++ host shim bound to the HIP engine."""
+import numpy as np
+import pytest
+
+from gen import problem_set, random_problem
+from test_golden_gssw_oracle import _cases, run_group
+from test_gssw_emu_parity import compare
+from util import ENGINE_LIB, ORACLE_LIB
+from vg_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_engine_reports_a_gfx950_device():
+    name, cus, mem = capi.Engine(lib=ENGINE_LIB).device_info()
+    assert cus > 0 and mem > 0, (name, cus, mem)
+
+
+def test_hip_matches_oracle_random_small():
+    rng = np.random.default_rng(1234)
+    problems = [random_problem(rng) for _ in range(3000)]
+    res = compare(ENGINE_LIB, ORACLE_LIB, problems)
+    assert (res["score"] > 0).sum() > 2000
+
+
+def test_hip_matches_oracle_with_n_score_only_and_scoring():
+    rng = np.random.default_rng(99)
+    problems = [random_problem(rng, with_n=0.3) for _ in range(500)]
+    problems += [random_problem(rng, traceback=False) for _ in range(300)]
+    compare(ENGINE_LIB, ORACLE_LIB, problems)
+    problems = [random_problem(rng, max_nodes=20, max_node_len=40, max_read=400) for _ in range(200)]
+    compare(ENGINE_LIB, ORACLE_LIB, problems, capi.Scoring.simple(2, 3, 5, 2, 7))
+    problems = [random_problem(rng, max_nodes=6, max_node_len=8, max_read=40) for _ in range(500)]
+    compare(ENGINE_LIB, ORACLE_LIB, problems, capi.Scoring.simple(1, 4, 6, 1, 0))
+
+
+def test_hip_matches_oracle_read_length_edges():
+    rng = np.random.default_rng(5)
+    for L in (1, 2, 15, 16, 17, 31, 32, 33, 150, 255, 256, 257, 1000, 1024):
+        problems = []
+        for _ in range(6):
+            p = random_problem(rng, max_nodes=12, max_node_len=64, max_read=L)
+            problems.append(p)
+        compare(ENGINE_LIB, ORACLE_LIB, problems)
+
+
+def test_hip_rejects_what_it_cannot_do():
+    eng = capi.Engine(lib=ENGINE_LIB)
+    p = {"read": "A" * 1025, "nodes": ["ACGT"], "preds": [[]], "flags": capi.VGK_GSSW_TRACEBACK, "pinning": None}
+    with pytest.raises(capi.VgkError):
+        eng.align(problem_set([p]))
+
+
+def test_reference_unit_test_vectors_through_host_shim_on_hip():
+    cases = [c for c in _cases("ref_aligner.json", {"align"}) if len(c["args"]) == 2 and c["args"][1] is True]
+    assert run_group(cases, ENGINE_LIB) >= 40
+    cases = _cases("ref_pinned_alignment.json", {"align_pinned"})
+    assert run_group(cases, ENGINE_LIB) >= 400

@@ -1,0 +1,236 @@
+"""ctypes binding of the C ABI in include/vgk.h.
+
+Plumbing only: problems are described with numpy arrays (so a million of them
+can be assembled without a Python loop) and handed to the shared library as the
+plain-pointer structs the header declares.  The default library is the HIP
+product (vg_amd/libvgamd.so); loading fails loudly if it has not been built.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libvgamd.so")
+
+VGK_OK = 0
+VGK_GSSW_LOCAL = 0
+VGK_GSSW_PINNED = 1
+VGK_GSSW_TRACEBACK = 16
+OP_M, OP_I, OP_D, OP_S = 0, 1, 2, 3
+OP_CHARS = "MIDS"
+
+# struct layouts (must match include/vgk.h)
+GRAPH_DT = np.dtype([("n_nodes", "<u4"), ("_pad", "<u4"), ("node_len", "<u8"), ("seq", "<u8"),
+                     ("pred_off", "<u8"), ("pred_idx", "<u8")])
+PROBLEM_DT = np.dtype([("read", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), ("graph", GRAPH_DT), ("pinning", "<u8")])
+RESULT_DT = np.dtype([("score", "<i4"), ("status", "<i4"), ("end_node", "<i4"), ("end_offset", "<i4"),
+                      ("end_read", "<i4"), ("first_offset", "<i4"), ("n_ops", "<u4"), ("ops_begin", "<u4")])
+OP_DT = np.dtype([("node", "<u4"), ("len", "<u2"), ("op", "u1"), ("pad", "u1")])
+assert GRAPH_DT.itemsize == 40 and PROBLEM_DT.itemsize == 64 and RESULT_DT.itemsize == 32 and OP_DT.itemsize == 8
+
+
+class Scoring(ctypes.Structure):
+    _fields_ = [("matrix", ctypes.c_int8 * 25), ("gap_open", ctypes.c_uint8), ("gap_extend", ctypes.c_uint8),
+                ("full_length_bonus", ctypes.c_int8), ("reserved", ctypes.c_uint8)]
+
+    @classmethod
+    def simple(cls, match=1, mismatch=4, gap_open=6, gap_extend=1, bonus=5):
+        """match/mismatch matrix with the all-zero N row/column (src/alignment_scorer.cpp:297-304)."""
+        s = cls()
+        for i in range(25):
+            r, c = divmod(i, 5)
+            s.matrix[i] = 0 if (r == 4 or c == 4) else (match if r == c else -mismatch)
+        s.gap_open, s.gap_extend, s.full_length_bonus = gap_open, gap_extend, bonus
+        return s
+
+
+class VgkError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    path = path or os.environ.get("VGAMD_ENGINE_LIB") or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise VgkError("engine library %s is missing: run `make lib` (python -c 'import __graft_entry__ as g; g.build()'); "
+                       "there is no CPU fallback" % path)
+    lib = ctypes.CDLL(path)
+    vp, u32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t
+    lib.vgk_abi_version.restype = ctypes.c_int
+    lib.vgk_strerror.restype = ctypes.c_char_p
+    lib.vgk_strerror.argtypes = [ctypes.c_int]
+    lib.vgk_create.argtypes = [ctypes.c_int, ctypes.POINTER(Scoring), ctypes.POINTER(vp)]
+    lib.vgk_destroy.argtypes = [vp]
+    lib.vgk_device_info.argtypes = [vp, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(sz)]
+    lib.vgk_gssw_pack.argtypes = [vp, vp, u32, u32, ctypes.POINTER(vp)]
+    lib.vgk_gssw_run.argtypes = [vp]
+    lib.vgk_gssw_fetch.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz)]
+    lib.vgk_gssw_align.argtypes = [vp, vp, u32, vp, vp, sz, ctypes.POINTER(sz)]
+    lib.vgk_batch_free.argtypes = [vp]
+    lib.vgk_batch_sync.argtypes = [vp]
+    lib.vgk_batch_kernel_ms.restype = ctypes.c_double
+    lib.vgk_batch_kernel_ms.argtypes = [vp, ctypes.c_int]
+    for f in ("vgk_batch_cells", "vgk_batch_alg_bytes", "vgk_batch_device_bytes"):
+        getattr(lib, f).restype = ctypes.c_uint64
+        getattr(lib, f).argtypes = [vp]
+    return lib
+
+
+class ProblemSet:
+    """A batch of gssw problems laid out in shared numpy arenas.
+
+    reads     : uint8 array of all read bases (ASCII), read i = reads[read_off[i]:read_off[i+1]]
+    node_len  : uint32, all graphs' node lengths concatenated; graph i owns node_off[i]:node_off[i+1]
+    seq       : uint8 ASCII graph bases, graph i's nodes concatenated starting at seq_off[i]
+    pred_off  : uint32 per graph CSR offsets (n_nodes+1 entries each, LOCAL to the graph), laid out at node_off[i]+i
+    pred_idx  : uint32 predecessor indices, graph i's edges start at edge_off[i]
+    """
+
+    def __init__(self, reads, read_off, node_len, node_off, seq, seq_off, pred_off, pred_idx, edge_off, flags, pinning=None):
+        self.reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        self.read_off = np.asarray(read_off, dtype=np.int64)
+        self.node_len = np.ascontiguousarray(node_len, dtype=np.uint32)
+        self.node_off = np.asarray(node_off, dtype=np.int64)
+        self.seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        self.seq_off = np.asarray(seq_off, dtype=np.int64)
+        self.pred_off = np.ascontiguousarray(pred_off, dtype=np.uint32)
+        self.pred_idx = np.ascontiguousarray(pred_idx if len(pred_idx) else np.zeros(1, np.uint32), dtype=np.uint32)
+        self.edge_off = np.asarray(edge_off, dtype=np.int64)
+        self.flags = np.asarray(flags, dtype=np.uint32)
+        self.pinning = None if pinning is None else np.ascontiguousarray(pinning, dtype=np.uint8)
+        self.n = len(self.read_off) - 1
+        n = self.n
+        arr = np.zeros(n, dtype=PROBLEM_DT)
+        arr["read"] = self.reads.ctypes.data + self.read_off[:-1]
+        arr["read_len"] = np.diff(self.read_off)
+        arr["flags"] = self.flags
+        g = arr["graph"]
+        g["n_nodes"] = np.diff(self.node_off)
+        g["node_len"] = self.node_len.ctypes.data + 4 * self.node_off[:-1]
+        g["seq"] = self.seq.ctypes.data + self.seq_off[:-1]
+        g["pred_off"] = self.pred_off.ctypes.data + 4 * (self.node_off[:-1] + np.arange(n))
+        g["pred_idx"] = self.pred_idx.ctypes.data + 4 * self.edge_off[:-1]
+        arr["graph"] = g
+        if self.pinning is not None:
+            arr["pinning"] = self.pinning.ctypes.data + self.node_off[:-1]
+        self.array = arr
+
+    @property
+    def ptr(self):
+        return self.array.ctypes.data
+
+    @classmethod
+    def from_lists(cls, problems):
+        """problems: list of dicts {read: str, nodes: [str], preds: [[int]], flags: int, pinning: [0/1]|None}."""
+        reads, read_off, node_len, node_off, seq, seq_off, pred_off, pred_idx, edge_off, flags, pinning = \
+            [], [0], [], [0], [], [0], [], [], [0], [], []
+        any_pin = any(p.get("pinning") is not None for p in problems)
+        for p in problems:
+            reads.append(np.frombuffer(p["read"].encode(), dtype=np.uint8)); read_off.append(read_off[-1] + len(p["read"]))
+            nl = [len(s) for s in p["nodes"]]
+            node_len.extend(nl); node_off.append(node_off[-1] + len(nl))
+            s = "".join(p["nodes"]); seq.append(np.frombuffer(s.encode(), dtype=np.uint8)); seq_off.append(seq_off[-1] + len(s))
+            off = [0]
+            for pr in p["preds"]:
+                pred_idx.extend(pr); off.append(off[-1] + len(pr))
+            pred_off.extend(off); edge_off.append(edge_off[-1] + off[-1])
+            flags.append(p["flags"])
+            pinning.extend(p["pinning"] if p.get("pinning") is not None else [0] * len(nl))
+        cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.uint8)
+        return cls(cat(reads), read_off, node_len, node_off, cat(seq), seq_off, pred_off, pred_idx, edge_off, flags,
+                   pinning if any_pin else None)
+
+
+class Engine:
+    """One engine context = one (device, scoring) pair, like one vg Aligner."""
+
+    def __init__(self, scoring=None, device=0, lib=None):
+        self.lib = load_library(lib) if (lib is None or isinstance(lib, str)) else lib
+        self.scoring = scoring or Scoring.simple()
+        h = ctypes.c_void_p()
+        rc = self.lib.vgk_create(device, ctypes.byref(self.scoring), ctypes.byref(h))
+        if rc != VGK_OK:
+            raise VgkError("vgk_create: %s" % self.lib.vgk_strerror(rc).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vgk_destroy(self.h); self.h = None
+
+    __del__ = close
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(256); cus = ctypes.c_int(); mem = ctypes.c_size_t()
+        self.lib.vgk_device_info(self.h, name, 256, ctypes.byref(cus), ctypes.byref(mem))
+        return name.value.decode(), cus.value, mem.value
+
+    def _check(self, rc, what):
+        if rc != VGK_OK:
+            raise VgkError("%s: %s" % (what, self.lib.vgk_strerror(rc).decode()))
+
+    def pack(self, ps, ops_per_problem=0):
+        b = ctypes.c_void_p()
+        self._check(self.lib.vgk_gssw_pack(self.h, ps.ptr, ps.n, ops_per_problem, ctypes.byref(b)), "vgk_gssw_pack")
+        return Batch(self, b, ps, ops_per_problem)
+
+    def align(self, ps, ops_per_problem=0):
+        with self.pack(ps, ops_per_problem) as b:
+            b.run()
+            return b.fetch()
+
+
+class Batch:
+    def __init__(self, eng, h, ps, ops_per_problem):
+        self.eng, self.h, self.ps, self.ops_per = eng, h, ps, ops_per_problem
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.free()
+
+    def free(self):
+        if self.h:
+            self.eng.lib.vgk_batch_free(self.h); self.h = None
+
+    def run(self):
+        self.eng._check(self.eng.lib.vgk_gssw_run(self.h), "vgk_gssw_run")
+
+    def sync(self):
+        self.eng._check(self.eng.lib.vgk_batch_sync(self.h), "vgk_batch_sync")
+
+    def kernel_ms(self, which=-1):
+        return self.eng.lib.vgk_batch_kernel_ms(self.h, which)
+
+    def cells(self):
+        return self.eng.lib.vgk_batch_cells(self.h)
+
+    def alg_bytes(self):
+        return self.eng.lib.vgk_batch_alg_bytes(self.h)
+
+    def device_bytes(self):
+        return self.eng.lib.vgk_batch_device_bytes(self.h)
+
+    def fetch(self):
+        n = self.ps.n
+        res = np.zeros(n, dtype=RESULT_DT)
+        if self.ops_per:
+            cap = n * self.ops_per
+        else:
+            cap = int(np.diff(self.ps.read_off).sum() + np.diff(self.ps.seq_off).sum() + 2 * n)
+        ops = np.zeros(max(cap, 1), dtype=OP_DT)
+        written = ctypes.c_size_t()
+        self.eng._check(self.eng.lib.vgk_gssw_fetch(self.h, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written)),
+                        "vgk_gssw_fetch")
+        return res, ops[:written.value]
+
+
+def cigar_string(res_row, ops):
+    """'offset@node:3M1D,node:...' for debugging / comparison."""
+    o = ops[res_row["ops_begin"]:res_row["ops_begin"] + res_row["n_ops"]]
+    parts, cur = [], None
+    for e in o:
+        if cur != e["node"]:
+            parts.append("%d:" % e["node"]); cur = e["node"]
+        parts[-1] += "%d%s" % (e["len"], OP_CHARS[e["op"]])
+    return "%d@%s" % (res_row["first_offset"], ",".join(parts))

@@ -1,0 +1,33 @@
+// backend.hpp — the few device services the C-ABI layer needs.  The product
+// implementation is backend_hip.hip (HIP runtime + the gfx950 kernels).  A
+// second implementation exists only under tests/emu (CPU lock-step emulation of
+// the same lane code) so the packing / kernel logic can be debugged without a GPU.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include "gssw_device.hpp"
+
+namespace vgk {
+
+class Backend {
+public:
+    virtual ~Backend() = default;
+    virtual const char* name() const = 0;
+    virtual int compute_units() const = 0;
+    virtual size_t memory_bytes() const = 0;
+    virtual void* alloc(size_t bytes) = 0;                 // device memory (nullptr on failure)
+    virtual void  release(void* p) = 0;
+    virtual int   upload(void* dst, const void* src, size_t bytes) = 0;     // async on the stream
+    virtual int   download(void* dst, const void* src, size_t bytes) = 0;   // synchronous
+    virtual int   zero(void* dst, size_t bytes) = 0;                        // async on the stream
+    virtual int   sync() = 0;
+    // gssw kernels; timings (ms, HIP events on the launch stream) of the last run
+    virtual int   run_gssw(const GsswParams& p, bool walk) = 0;
+    virtual double last_ms(int which) const = 0;           // 0 = fill, 1 = traceback
+};
+
+// returns nullptr and sets err when the device cannot be used
+Backend* make_backend(int device, std::string& err);
+
+}  // namespace vgk

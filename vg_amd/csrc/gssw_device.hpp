@@ -1,0 +1,443 @@
+// gssw_device.hpp — the graph Smith-Waterman engine (gssw semantics) for gfx950.
+//
+// Replaces gssw_graph_fill_pinned + gssw_graph_trace_back* as called from
+// Aligner::align_internal (reference: src/aligner.cpp:396-402, 423-435, 537-557).
+//
+// MI355X mapping (see DESIGN.md §3 for the full rationale):
+//   * two reads share every 32-bit register (lo/hi unsigned 16-bit halves), so
+//     each packed VALU instruction (v_pk_*_u16) advances two DP cells;
+//   * a read pair is spread over G = ceil(L/16) adjacent lanes, lane g owning
+//     16 consecutive read rows; floor(64/G) pairs share one wavefront;
+//   * lanes run a skewed wavefront: at step t lane g computes graph column
+//     t-g, taking the vertical-gap value F and the diagonal H of the row above
+//     from lane g-1 with one DPP wave_shr:1 each — no LDS, no barriers;
+//   * the unsigned, bias-shifted arithmetic and saturating subtracts reproduce
+//     gssw's (SSW's) zero-floored E/F/H exactly;
+//   * per cell a 4-bit traceback code is produced; 16 rows x 2 reads = 16 B per
+//     lane per step, stored step-major so every wave store is one contiguous
+//     1 KiB burst;
+//   * node boundaries that are not simple chain links go through a small
+//     HBM scratch of per-node last columns (H and next-column E), which the
+//     traceback also uses to choose predecessors.
+//
+// Everything in this header is plain C++ over pk16.hpp so that the identical
+// lane code can be single-stepped by the CPU emulator in tests/emu.
+#pragma once
+#include <stdint.h>
+#include "../../include/vgk.h"
+#include "pk16.hpp"
+
+namespace vgk {
+
+constexpr int K = 16;   // read rows per lane
+
+// per-column info byte
+enum : uint32_t {
+    CI_BASE_MASK  = 7,     // 0..3 = ACGT, 4 = N
+    CI_NODE_START = 8,     // first column of a node
+    CI_STORE_END  = 16,    // last column of a node whose last column must be saved to scratch
+    CI_SEED_SLOW  = 32,    // first column of a node whose predecessors are not exactly {previous node}
+    CI_INVALID    = 128    // no column (before the start / past the end of this read's graph)
+};
+constexpr uint32_t CI_INVALID2 = CI_INVALID | (CI_INVALID << 16);
+
+struct ProbDesc {          // one per read
+    uint32_t col_off;      // byte offset of this read's column-info stream (4-aligned)
+    uint32_t R;            // graph columns
+    uint32_t L;            // read length
+    uint32_t read_off;     // byte offset of the read's base codes
+    uint32_t node_off;     // first NodeRec
+    uint32_t n_nodes;
+    uint32_t scratch_off;  // u32 index of this read's boundary scratch (16-aligned)
+    uint32_t n_slots;
+    uint32_t flags;        // VGK_GSSW_*
+    uint32_t ops_off;      // first vgk_op of this read's output window
+    uint32_t ops_cap;
+    uint32_t pad;
+};
+
+struct NodeRec {
+    uint32_t col_start;    // first column
+    uint32_t col_end;      // one past the last column
+    uint32_t pred_begin;   // index into preds[]
+    uint32_t n_pred;
+    int32_t  slot;         // scratch slot or -1
+    uint32_t pinning;      // 1 = pinning node (PINNED mode)
+};
+
+struct WaveDesc {
+    uint64_t tb_off;       // first 16-byte traceback record of this wave
+    uint32_t n_steps;
+    uint32_t first_pair;
+};
+
+struct GsswParams {
+    const ProbDesc* probs;
+    const uint8_t*  colinfo;
+    const uint8_t*  reads;
+    const NodeRec*  nodes;
+    const uint32_t* preds;
+    uint32_t*       scratch;    // per (slot,row): lo16 = H of the node's last column, hi16 = E for the column after it
+    uint32_t*       tb;         // 4 dwords per (step, lane)
+    const WaveDesc* waves;
+    unsigned long long* best;   // LOCAL mode: per read, max over cells of key64(score, col, row)
+    vgk_result*     results;
+    vgk_op*         ops;
+    uint32_t n_problems, n_pairs, n_waves;
+    uint32_t G;                 // lanes per read pair
+    uint32_t groups_per_wave;   // 64 / G
+    uint32_t Lpad;              // G*K rows per scratch slot
+    uint32_t prof4[5];          // per read base q: byte r = matrix[5r+q] + bias, r = 0..3
+    uint32_t bias;
+    uint32_t go, ge;
+    int32_t  bonus;             // full-length bonus
+    int32_t  want_tb;           // any problem wants traceback -> store codes
+    int8_t   matrix[25];
+};
+
+VGK_HD uint32_t rep2(uint32_t x) { return (x & 0xffffu) * 0x00010001u; }
+
+VGK_HD uint32_t row_bonus(const GsswParams& P, uint32_t row, uint32_t L, uint32_t flags) {
+    // start bonus on read base 0; end bonus on base L-1 unless pinned (src/aligner.cpp:401-402)
+    uint32_t b = 0;
+    if (row == 0) b += (uint32_t)P.bonus;
+    if (row + 1 == L && (flags & 15u) != VGK_GSSW_PINNED) b += (uint32_t)P.bonus;
+    return b;
+}
+
+VGK_HD unsigned long long key64(uint32_t score, uint32_t col, uint32_t row) {
+    return ((unsigned long long)score << 40) | ((unsigned long long)(0xFFFFFu - col) << 20) | (unsigned long long)(0xFFFFFu - row);
+}
+
+// ---------------------------------------------------------------------------
+// per-lane state of the fill
+// ---------------------------------------------------------------------------
+struct Lane {
+    uint32_t H[K];      // H of the last processed column          {B:A}
+    uint32_t E[K];      // E for the next column                   {B:A}
+    uint32_t PA[K];     // query profile of read A: 4 biased bytes (ref A,C,G,T) per row
+    uint32_t PB[K];
+    uint32_t out_h, out_f, info;    // handed to lane+1 at the next step
+    uint32_t prev_rh;               // H of the row above this lane's block, previous column
+    uint32_t best_lo, best_hi, step_lo, step_hi;
+    uint32_t nodeA, nodeB;
+    uint32_t g;                     // lane index inside the group
+    uint32_t probA, probB;          // read indices or 0xffffffff
+    uint32_t LA, LB, flagsA, flagsB;
+    uint32_t RA, RB, colA, colB;    // graph columns and column-info stream offsets
+    uint32_t ciA, ciB, ciA_n, ciB_n;  // leader only: info bytes of columns [4k,4k+4) and the prefetched next word
+    uint32_t one;                   // 0x00010001 kept opaque to the optimiser (see lane_rows)
+};
+
+VGK_HD void lane_init(Lane& s, const GsswParams& P, const WaveDesc& wd, uint32_t lane_id) {
+    const uint32_t q = lane_id / P.G;
+    s.g = lane_id - q * P.G;
+    const uint32_t pair = wd.first_pair + q;
+    const bool live = (q < P.groups_per_wave) && (pair < P.n_pairs);
+    s.probA = live ? 2 * pair : 0xffffffffu;
+    s.probB = (live && 2 * pair + 1 < P.n_problems) ? 2 * pair + 1 : 0xffffffffu;
+    s.LA = s.LB = 0; s.flagsA = s.flagsB = 0; s.RA = s.RB = 0; s.colA = s.colB = 0;
+    s.ciA = s.ciB = s.ciA_n = s.ciB_n = 0;
+    uint32_t roA = 0, roB = 0;
+    if (s.probA != 0xffffffffu) { const ProbDesc& d = P.probs[s.probA]; s.LA = d.L; s.flagsA = d.flags; roA = d.read_off; s.RA = d.R; s.colA = d.col_off; }
+    if (s.probB != 0xffffffffu) { const ProbDesc& d = P.probs[s.probB]; s.LB = d.L; s.flagsB = d.flags; roB = d.read_off; s.RB = d.R; s.colB = d.col_off; }
+    if (s.g == 0) {   // streams are padded with 8 readable bytes, so these loads never run off the arena
+        if (s.probA != 0xffffffffu) s.ciA_n = *(const uint32_t*)(P.colinfo + s.colA);
+        if (s.probB != 0xffffffffu) s.ciB_n = *(const uint32_t*)(P.colinfo + s.colB);
+    }
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        const uint32_t row = s.g * K + m;
+        uint32_t pa = 0, pb = 0;
+        if (row < s.LA) pa = P.prof4[P.reads[roA + row]] + 0x01010101u * row_bonus(P, row, s.LA, s.flagsA);
+        if (row < s.LB) pb = P.prof4[P.reads[roB + row]] + 0x01010101u * row_bonus(P, row, s.LB, s.flagsB);
+        s.PA[m] = pa; s.PB[m] = pb; s.H[m] = 0; s.E[m] = 0;
+    }
+    s.out_h = 0; s.out_f = 0; s.info = CI_INVALID2; s.prev_rh = 0;
+    s.best_lo = s.best_hi = 0; s.step_lo = s.step_hi = 0;
+    s.nodeA = s.nodeB = 0xffffffffu;
+    s.one = 0x00010001u;
+}
+
+// Group leaders (g == 0) pull the column-info stream 4 columns at a time, one
+// word ahead, so the HBM/L2 latency of the load hides behind four steps of DP.
+// Call at every step with (t & 3) == 0, before lane_step.
+VGK_HD void lane_prefetch(Lane& s, const GsswParams& P, uint32_t t) {
+    if (s.g != 0) return;
+    s.ciA = s.ciA_n; s.ciB = s.ciB_n;
+    if (t + 4 < s.RA) s.ciA_n = *(const uint32_t*)(P.colinfo + s.colA + t + 4);
+    if (t + 4 < s.RB) s.ciB_n = *(const uint32_t*)(P.colinfo + s.colB + t + 4);
+}
+
+// fresh column info for the group leader at step t: {infoB<<16 | infoA}
+VGK_HD uint32_t fetch_info(const Lane& s, const GsswParams& P, uint32_t t) {
+    (void)P;
+    const uint32_t sh = 8 * (t & 3u);
+    const uint32_t ia = t < s.RA ? (s.ciA >> sh) & 0xffu : (uint32_t)CI_INVALID;
+    const uint32_t ib = t < s.RB ? (s.ciB >> sh) & 0xffu : (uint32_t)CI_INVALID;
+    return ia | (ib << 16);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ uint32_t scratch_load(const uint32_t* p) {
+    // written earlier in this kernel, possibly by the neighbouring lane: bypass the CU's L1
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#else
+static inline uint32_t scratch_load(const uint32_t* p) { return *p; }
+#endif
+
+// SEED_SLOW: seed column = element-wise max over the predecessors' saved last
+// columns (gssw_create_seed_*); HALF = 0 for read A (low halves), 1 for read B.
+template <int HALF>
+VGK_HD void seed_from_scratch(Lane& s, const GsswParams& P, uint32_t prob, uint32_t node, uint32_t& diag0) {
+    const ProbDesc& d = P.probs[prob];
+    const NodeRec& nr = P.nodes[d.node_off + node];
+    uint32_t sh[K], se[K], sd = 0;
+#pragma unroll
+    for (int m = 0; m < K; ++m) { sh[m] = 0; se[m] = 0; }
+    for (uint32_t k = 0; k < nr.n_pred; ++k) {
+        const NodeRec& pr = P.nodes[d.node_off + P.preds[nr.pred_begin + k]];
+        const uint32_t* base = P.scratch + d.scratch_off + (uint32_t)pr.slot * P.Lpad + s.g * K;
+#pragma unroll
+        for (int m = 0; m < K; ++m) {
+            uint32_t v = scratch_load(base + m);
+            uint32_t h = v & 0xffffu, e = v >> 16;
+            sh[m] = h > sh[m] ? h : sh[m];
+            se[m] = e > se[m] ? e : se[m];
+        }
+        if (s.g > 0) { uint32_t h = scratch_load(base - 1) & 0xffffu; sd = h > sd ? h : sd; }
+    }
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        if (HALF == 0) { s.H[m] = set_lo(s.H[m], sh[m]); s.E[m] = set_lo(s.E[m], se[m]); }
+        else           { s.H[m] = set_hi(s.H[m], sh[m]); s.E[m] = set_hi(s.E[m], se[m]); }
+    }
+    diag0 = (HALF == 0) ? set_lo(diag0, sd) : set_hi(diag0, sd);
+}
+
+template <int HALF>
+VGK_HD void store_to_scratch(const Lane& s, const GsswParams& P, uint32_t prob, uint32_t node) {
+    const ProbDesc& d = P.probs[prob];
+    const NodeRec& nr = P.nodes[d.node_off + node];
+    uint32_t* base = P.scratch + d.scratch_off + (uint32_t)nr.slot * P.Lpad + s.g * K;
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        uint32_t h = HALF == 0 ? (s.H[m] & 0xffffu) : (s.H[m] >> 16);
+        uint32_t e = HALF == 0 ? (s.E[m] & 0xffffu) : (s.E[m] >> 16);
+        base[m] = h | (e << 16);
+    }
+}
+
+// The 16 rows of one lane for one column.  REFN = some half sees an N in the graph
+// (rare): the profile permute cannot express score 0, patch it per row.
+// Returns the four traceback dwords in acc[0..3] and the column key maximum.
+template <bool REFN>
+VGK_HD void lane_rows(Lane& s, const GsswParams& P, uint32_t sel, uint32_t diag0, uint32_t rf,
+                      bool nA, bool nB, uint32_t acc[4], uint32_t& colkey) {
+    const uint32_t bias2 = rep2(P.bias), go2 = rep2(P.go), ge2 = rep2(P.ge);
+    const uint32_t one = s.one, sixteen = 0x00100010u;
+    uint32_t f = rf, d = diag0, ck = 0;
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        uint32_t sb = byte_perm(s.PB[m], s.PA[m], sel);
+        if (REFN) {
+            const uint32_t row = s.g * K + m;
+            if (nA) sb = set_lo(sb, row < s.LA ? P.bias + row_bonus(P, row, s.LA, s.flagsA) : 0u);
+            if (nB) sb = set_hi(sb, row < s.LB ? P.bias + row_bonus(P, row, s.LB, s.flagsB) : 0u);
+        }
+        const uint32_t old = s.H[m];
+        const uint32_t t4 = pk_subs(pk_add(d, sb), bias2);     // max(0, diag + s)
+        const uint32_t e = s.E[m];
+        const uint32_t h = pk_max(pk_max(t4, e), f);
+        const uint32_t gg = pk_subs(h, go2);                   // max(0, H - go)
+        const uint32_t e2 = pk_subs(e, ge2), f2 = pk_subs(f, ge2);
+        const uint32_t en = pk_max(gg, e2), fn = pk_max(gg, f2);
+        // traceback code: bit0 = H not from diagonal, bit1 = H not from E (then F),
+        // bit2 = next-column E is an extension, bit3 = next-row F is an extension.
+        // min(x, 1) with an opaque `one` keeps this as 2 packed ops per flag.
+        const uint32_t nd = pk_min(pk_sub(h, t4), one);
+        const uint32_t ne = pk_min(pk_sub(h, e), one);
+        const uint32_t eb = pk_min(pk_subs(e2, gg), one);
+        const uint32_t fb = pk_min(pk_subs(f2, gg), one);
+        const uint32_t code = nd | (ne << 1) | (eb << 2) | (fb << 3);
+        acc[m >> 2] = (m & 3) == 0 ? code : pk_mad(acc[m >> 2], sixteen, code);
+        const uint32_t key = pk_mad(h, sixteen, rep2(15 - m));
+        ck = m == 0 ? key : pk_max(ck, key);
+        s.H[m] = h; s.E[m] = en; f = fn; d = old;
+    }
+    s.out_h = s.H[K - 1]; s.out_f = f;
+    colkey = ck;
+}
+
+// One step of one lane.  rh/rf/rinfo are lane-1's out_h/out_f/info from the
+// previous step (ignored by group leaders, which start a fresh column).
+// tbrec = this (step, lane)'s 4-dword traceback record, or nullptr.
+VGK_HD void lane_step(Lane& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tbrec) {
+    if (s.g == 0) { rh = 0; rf = 0; rinfo = fetch_info(s, P, t); }
+    s.info = rinfo;
+    const uint32_t ia = rinfo & 0xffu, ib = (rinfo >> 16) & 0xffu;
+    const bool vA = !(ia & CI_INVALID), vB = !(ib & CI_INVALID);
+    if (vA || vB) {
+        uint32_t diag0 = s.prev_rh;
+        if (vA && (ia & CI_NODE_START)) s.nodeA += 1;
+        if (vB && (ib & CI_NODE_START)) s.nodeB += 1;
+        if (vA && (ia & CI_SEED_SLOW)) seed_from_scratch<0>(s, P, s.probA, s.nodeA, diag0);
+        if (vB && (ib & CI_SEED_SLOW)) seed_from_scratch<1>(s, P, s.probB, s.nodeB, diag0);
+        // selector: byte0 <- PA[baseA], byte2 <- PB[baseB] (bytes 4..7 of the permute), bytes 1,3 <- 0
+        const uint32_t sel = (rinfo & 0x00030003u) | 0x0c040c00u;
+        const bool nA = vA && (ia & CI_BASE_MASK) == 4, nB = vB && (ib & CI_BASE_MASK) == 4;
+        uint32_t acc[4], colkey;
+        if (nA || nB) lane_rows<true>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
+        else          lane_rows<false>(s, P, sel, diag0, rf, false, false, acc, colkey);
+        if (tbrec) { tbrec[0] = acc[0]; tbrec[1] = acc[1]; tbrec[2] = acc[2]; tbrec[3] = acc[3]; }
+        // local end cell: first column with the best score, smallest row (SSW end_ref/end_read rule)
+        const uint32_t klo = colkey & 0xffffu, khi = colkey >> 16;
+        if (vA && (klo >> 4) > (s.best_lo >> 4)) { s.best_lo = klo; s.step_lo = t; }
+        if (vB && (khi >> 4) > (s.best_hi >> 4)) { s.best_hi = khi; s.step_hi = t; }
+        if (vA && (ia & CI_STORE_END)) store_to_scratch<0>(s, P, s.probA, s.nodeA);
+        if (vB && (ib & CI_STORE_END)) store_to_scratch<1>(s, P, s.probB, s.nodeB);
+    } else {
+        s.out_h = 0; s.out_f = 0;
+    }
+    s.prev_rh = rh;
+}
+
+// after the last step: publish this lane's best cell (LOCAL mode)
+VGK_HD bool lane_best(const Lane& s, int half, uint32_t& prob, unsigned long long& key) {
+    const uint32_t b = half ? s.best_hi : s.best_lo, st = half ? s.step_hi : s.step_lo;
+    prob = half ? s.probB : s.probA;
+    if (prob == 0xffffffffu || (b >> 4) == 0) return false;
+    const uint32_t L = half ? s.LB : s.LA, flags = half ? s.flagsB : s.flagsA;
+    if ((flags & 15u) != VGK_GSSW_LOCAL) return false;
+    const uint32_t row = s.g * K + (15 - (b & 15u));
+    if (row >= L) return false;   // cannot win, but never report a padding row
+    key = key64(b >> 4, st - s.g, row);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// traceback walker: one thread per read
+// ---------------------------------------------------------------------------
+struct Walker {
+    const GsswParams& P; const ProbDesc& d; uint32_t half, lane0; uint64_t tb_off;
+    VGK_HD uint32_t code(uint32_t r, uint32_t c) const {
+        const uint32_t g = r / K, t = c + g, j = (r & 15u) >> 2, i = r & 3u;
+        const uint32_t w = P.tb[(tb_off + (uint64_t)t * 64 + lane0 + g) * 4 + j];
+        return (w >> (16 * half + 4 * (3 - i))) & 15u;
+    }
+    VGK_HD int32_t score(uint32_t r, uint32_t c) const {
+        const uint32_t base = P.colinfo[d.col_off + c] & CI_BASE_MASK, q = P.reads[d.read_off + r];
+        return (int32_t)P.matrix[5 * base + q] + (int32_t)row_bonus(P, r, d.L, d.flags);
+    }
+    VGK_HD uint32_t saved(const NodeRec& n, uint32_t r) const { return P.scratch[d.scratch_off + (uint32_t)n.slot * P.Lpad + r]; }
+};
+
+VGK_HD void walk_one(const GsswParams& P, uint32_t i) {
+    const ProbDesc& d = P.probs[i];
+    vgk_result res;
+    res.score = 0; res.status = VGK_OK; res.end_node = -1; res.end_offset = -1; res.end_read = -1;
+    res.first_offset = 0; res.n_ops = 0; res.ops_begin = d.ops_off;
+    const uint32_t pair = i >> 1;
+    const uint32_t wave = pair / P.groups_per_wave, slot = pair - wave * P.groups_per_wave;
+    Walker w{P, d, i & 1u, slot * P.G, P.waves[wave].tb_off};
+    const NodeRec* nodes = P.nodes + d.node_off;
+    const bool pinned = (d.flags & 15u) == VGK_GSSW_PINNED;
+    const int32_t go = (int32_t)P.go, ge = (int32_t)P.ge;
+
+    int32_t cur = 0; uint32_t c = 0, node = 0; int32_t r = 0;
+    bool have = false;
+    if (pinned) {
+        r = (int32_t)d.L - 1;
+        for (uint32_t n = 0; n < d.n_nodes; ++n) {
+            if (!nodes[n].pinning) continue;
+            const int32_t v = (int32_t)(w.saved(nodes[n], (uint32_t)r) & 0xffffu);
+            if (!have || v > cur) { cur = v; node = n; have = true; }
+        }
+        if (have) c = nodes[node].col_end - 1;
+    } else {
+        const unsigned long long k = P.best[i];
+        cur = (int32_t)(k >> 40);
+        if (cur > 0) {
+            have = true;
+            c = 0xFFFFFu - (uint32_t)((k >> 20) & 0xFFFFFu);
+            r = (int32_t)(0xFFFFFu - (uint32_t)(k & 0xFFFFFu));
+            uint32_t lo = 0, hi = d.n_nodes;   // node containing column c
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (nodes[mid].col_start <= c) lo = mid; else hi = mid; }
+            node = lo;
+        }
+    }
+    if (pinned && !have) { res.status = VGK_EINVAL; P.results[i] = res; return; }
+    if (cur >= 4095) { res.status = VGK_EOVERFLOW; P.results[i] = res; return; }
+    if (!have || cur <= 0) { P.results[i] = res; return; }     // score 0: the caller synthesises soft clips
+    res.score = cur; res.end_node = (int32_t)node; res.end_offset = (int32_t)(c - nodes[node].col_start); res.end_read = r;
+    if (!(d.flags & VGK_GSSW_TRACEBACK)) { P.results[i] = res; return; }
+
+    // ops are produced back to front into the tail of this read's window
+    vgk_op* ops = P.ops + d.ops_off;
+    uint32_t pos = d.ops_cap;   // first used slot
+    int32_t status = VGK_OK;
+#define VGK_PUSH(NODE, OP, LEN) do { \
+        if (pos < d.ops_cap && ops[pos].node == (uint32_t)(NODE) && ops[pos].op == (uint8_t)(OP)) ops[pos].len = (uint16_t)(ops[pos].len + (LEN)); \
+        else if (pos == 0) { status = VGK_EOPS; } \
+        else { --pos; ops[pos].node = (uint32_t)(NODE); ops[pos].op = (uint8_t)(OP); ops[pos].len = (uint16_t)(LEN); ops[pos].pad = 0; } } while (0)
+
+    if (r < (int32_t)d.L - 1) VGK_PUSH(node, VGK_OP_S, d.L - 1 - (uint32_t)r);
+    enum { ST_H, ST_E, ST_F } st = ST_H;
+    uint32_t first_c = c;
+    // every iteration consumes a read base, a graph base or changes state once: bounded by 2(L+R)+2
+    for (uint32_t guard = 0; guard < 2 * (d.L + d.R) + 4 && status == VGK_OK; ++guard) {
+        const bool first = (c == nodes[node].col_start);
+        if (st == ST_H) {
+            if (cur == 0) break;
+            const uint32_t fl = w.code((uint32_t)r, c);
+            if (!(fl & 1u)) {
+                VGK_PUSH(node, VGK_OP_M, 1); first_c = c;
+                cur -= w.score((uint32_t)r, c); r -= 1;
+                if (r < 0 || cur == 0) break;
+                if (!first) c -= 1;
+                else {
+                    const NodeRec& nr = nodes[node];
+                    int32_t found = -1;
+                    if (nr.n_pred == 1) found = (int32_t)P.preds[nr.pred_begin];
+                    else for (uint32_t k = 0; k < nr.n_pred; ++k) {
+                        const uint32_t p = P.preds[nr.pred_begin + k];
+                        if ((int32_t)(w.saved(nodes[p], (uint32_t)r) & 0xffffu) == cur) { found = (int32_t)p; break; } }
+                    if (found < 0) { status = VGK_EINVAL; break; }
+                    node = (uint32_t)found; c = nodes[node].col_end - 1;
+                }
+            } else if (!(fl & 2u)) st = ST_E;
+            else st = ST_F;
+        } else if (st == ST_E) {
+            VGK_PUSH(node, VGK_OP_D, 1); first_c = c;
+            uint32_t pnode = node, pc = c - 1;
+            if (first) {
+                const NodeRec& nr = nodes[node];
+                int32_t found = -1;
+                if (nr.n_pred == 1) found = (int32_t)P.preds[nr.pred_begin];
+                else for (uint32_t k = 0; k < nr.n_pred; ++k) {
+                    const uint32_t p = P.preds[nr.pred_begin + k];
+                    if ((int32_t)(w.saved(nodes[p], (uint32_t)r) >> 16) == cur) { found = (int32_t)p; break; } }
+                if (found < 0) { status = VGK_EINVAL; break; }
+                pnode = (uint32_t)found; pc = nodes[pnode].col_end - 1;
+            }
+            if (!(w.code((uint32_t)r, pc) & 4u)) { st = ST_H; cur += go; } else cur += ge;
+            c = pc; node = pnode;
+        } else {
+            VGK_PUSH(node, VGK_OP_I, 1);
+            if (r == 0) { status = VGK_EINVAL; break; }
+            if (!(w.code((uint32_t)r - 1, c) & 8u)) { st = ST_H; cur += go; } else cur += ge;
+            r -= 1;
+        }
+    }
+    if (status == VGK_OK && r >= 0) VGK_PUSH(node, VGK_OP_S, (uint32_t)r + 1);
+#undef VGK_PUSH
+    res.status = status;
+    if (status == VGK_OK) {
+        res.n_ops = d.ops_cap - pos; res.ops_begin = d.ops_off + pos;
+        res.first_offset = (int32_t)(first_c - nodes[node].col_start);
+    }
+    P.results[i] = res;
+}
+
+}  // namespace vgk

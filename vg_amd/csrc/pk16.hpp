@@ -1,0 +1,61 @@
+// pk16.hpp — two unsigned 16-bit DP cells per 32-bit register.
+//
+// On gfx950 these map 1:1 onto CDNA4 packed VALU instructions (v_pk_add_u16,
+// v_pk_sub_u16 [clamp], v_pk_max_u16, v_pk_min_u16, v_pk_mad_u16, v_perm_b32).
+// The scalar bodies under !__HIP_DEVICE_COMPILE__ exist so the very same lane
+// code can be stepped on a CPU by the lock-step emulator in tests/emu (a test
+// of the kernel logic; never part of the product path).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define VGK_HD __host__ __device__ __forceinline__
+#else
+#define VGK_HD inline
+#endif
+
+namespace vgk {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ v2u16 as_v(uint32_t x) { return __builtin_bit_cast(v2u16, x); }
+static __device__ __forceinline__ uint32_t as_u(v2u16 x) { return __builtin_bit_cast(uint32_t, x); }
+static __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return as_u(as_v(a) + as_v(b)); }
+static __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u(as_v(a) - as_v(b)); }
+static __device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_sub_sat(as_v(a), as_v(b))); }
+static __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_max(as_v(a), as_v(b))); }
+static __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_min(as_v(a), as_v(b))); }
+static __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return as_u(as_v(a) * as_v(b) + as_v(c)); }
+// byte permute: selector byte k picks byte (sel&7) of {hi:lo} = {a:b}; 0x0c -> 0x00
+static __device__ __forceinline__ uint32_t byte_perm(uint32_t a, uint32_t b, uint32_t sel) { return __builtin_amdgcn_perm(a, b, sel); }
+#else
+static inline uint32_t pk_lo(uint32_t x) { return x & 0xffffu; }
+static inline uint32_t pk_hi(uint32_t x) { return x >> 16; }
+static inline uint32_t pk_mk(uint32_t lo, uint32_t hi) { return (lo & 0xffffu) | (hi << 16); }
+static inline uint32_t pk_add(uint32_t a, uint32_t b) { return pk_mk(pk_lo(a) + pk_lo(b), pk_hi(a) + pk_hi(b)); }
+static inline uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_mk(pk_lo(a) - pk_lo(b), pk_hi(a) - pk_hi(b)); }
+static inline uint32_t sat_sub16(uint32_t a, uint32_t b) { return a > b ? a - b : 0; }
+static inline uint32_t pk_subs(uint32_t a, uint32_t b) { return pk_mk(sat_sub16(pk_lo(a), pk_lo(b)), sat_sub16(pk_hi(a), pk_hi(b))); }
+static inline uint32_t pk_max(uint32_t a, uint32_t b) { return pk_mk(pk_lo(a) > pk_lo(b) ? pk_lo(a) : pk_lo(b), pk_hi(a) > pk_hi(b) ? pk_hi(a) : pk_hi(b)); }
+static inline uint32_t pk_min(uint32_t a, uint32_t b) { return pk_mk(pk_lo(a) < pk_lo(b) ? pk_lo(a) : pk_lo(b), pk_hi(a) < pk_hi(b) ? pk_hi(a) : pk_hi(b)); }
+static inline uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return pk_mk(pk_lo(a) * pk_lo(b) + pk_lo(c), pk_hi(a) * pk_hi(b) + pk_hi(c)); }
+static inline uint32_t byte_perm(uint32_t a, uint32_t b, uint32_t sel) {
+    uint64_t src = ((uint64_t)a << 32) | b;
+    uint32_t out = 0;
+    for (int k = 0; k < 4; ++k) {
+        uint32_t s = (sel >> (8 * k)) & 0xff, byte;
+        if (s <= 7) byte = (uint32_t)(src >> (8 * s)) & 0xff;
+        else if (s == 0x0c) byte = 0x00;
+        else if (s >= 0x0d) byte = 0xff;
+        else byte = 0;   // 8..11 (sign replicate) never used here
+        out |= byte << (8 * k);
+    }
+    return out;
+}
+#endif
+
+// replace the low / high 16-bit half
+VGK_HD uint32_t set_lo(uint32_t x, uint32_t v) { return (x & 0xffff0000u) | (v & 0xffffu); }
+VGK_HD uint32_t set_hi(uint32_t x, uint32_t v) { return (x & 0x0000ffffu) | (v << 16); }
+
+}  // namespace vgk

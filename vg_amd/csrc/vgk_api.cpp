@@ -1,0 +1,327 @@
+// vgk_api.cpp — the C ABI of include/vgk.h: validation, host-side packing of
+// (read, DAG) problems into flat HBM arenas, kernel orchestration, result fetch.
+//
+// Packing mirrors what GSSWAligner::create_gssw_graph does per call on the CPU
+// (reference: src/aligner.cpp:30-85) — one malloc'd gssw_node per graph node and an
+// unordered_map — but emits flat arrays: a per-column info byte stream (base code +
+// node-boundary flags), a node table, a predecessor CSR and a per-read descriptor.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+#include "backend.hpp"
+
+using namespace vgk;
+
+struct vgk_ctx {
+    vgk_scoring sc;
+    std::unique_ptr<Backend> be;
+    std::mutex mu;                 // one stream per context: batches on one context serialise
+    uint32_t bias = 1; int32_t max_score = 0;
+    uint32_t prof4[5];
+};
+
+struct vgk_batch {
+    vgk_ctx* ctx = nullptr;
+    uint32_t n = 0;
+    bool want_tb = false, ran = false;
+    GsswParams P{};
+    std::vector<void*> dev;        // every device allocation of this batch
+    uint64_t cells = 0, in_bytes = 0, dev_bytes = 0, alg_bytes = 0;
+    uint64_t ops_total = 0;
+    std::vector<ProbDesc> probs;   // kept for fetch()
+};
+
+static inline int nt_read(char ch) {   // gssw_create_nt_table: case-insensitive ACGT, else N
+    switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1;
+                  case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+static inline int nt_ref(char ch) {    // after nonATGCNtoN (src/aligner.cpp:39): upper-case ACGT only
+    switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
+}
+
+template <class T>
+static int to_device(vgk_batch* b, const std::vector<T>& v, const T*& out, size_t extra = 0) {
+    const size_t bytes = (v.size() + extra) * sizeof(T);
+    void* p = b->ctx->be->alloc(bytes);
+    if (!p) return VGK_ENOMEM;
+    b->dev.push_back(p); b->dev_bytes += bytes;
+    if (!v.empty()) { int rc = b->ctx->be->upload(p, v.data(), v.size() * sizeof(T)); if (rc) return rc; }
+    out = (const T*)p;
+    return VGK_OK;
+}
+
+template <class T>
+static int dev_alloc(vgk_batch* b, size_t count, T*& out) {
+    void* p = b->ctx->be->alloc(count * sizeof(T));
+    if (!p) return VGK_ENOMEM;
+    b->dev.push_back(p); b->dev_bytes += count * sizeof(T);
+    out = (T*)p;
+    return VGK_OK;
+}
+
+extern "C" {
+
+int vgk_abi_version(void) { return VGK_ABI_VERSION; }
+
+const char* vgk_strerror(int code) {
+    switch (code) {
+        case VGK_OK: return "ok";
+        case VGK_EINVAL: return "invalid argument";
+        case VGK_ENODEV: return "no usable HIP device";
+        case VGK_ENOMEM: return "out of memory";
+        case VGK_ETOOLONG: return "read too long for the engine (max 1024 bases)";
+        case VGK_EOVERFLOW: return "score overflow";
+        case VGK_EOPS: return "cigar buffer too small";
+        case VGK_ETOOBIG: return "band matrices too big";
+        case VGK_ENOBAND: return "no alignment in band";
+        case VGK_EUNSUPPORTED: return "scoring parameters outside the kernels' range";
+        default: return "unknown error";
+    }
+}
+
+int vgk_create(int device, const vgk_scoring* scoring, vgk_ctx** out) {
+    if (!scoring || !out) return VGK_EINVAL;
+    *out = nullptr;
+    int mn = 0, mx = 0;
+    for (int i = 0; i < 25; ++i) { mn = std::min<int>(mn, scoring->matrix[i]); mx = std::max<int>(mx, scoring->matrix[i]); }
+    const int bias = std::max(1, -mn);
+    // profile bytes hold score + bias + (up to two) bonuses; see gssw_device.hpp
+    if (scoring->full_length_bonus < 0 || mx + bias + 2 * scoring->full_length_bonus > 255) return VGK_EUNSUPPORTED;
+    std::string err;
+    Backend* be = make_backend(device, err);
+    if (!be) return VGK_ENODEV;
+    vgk_ctx* c = new (std::nothrow) vgk_ctx();
+    if (!c) { delete be; return VGK_ENOMEM; }
+    c->sc = *scoring; c->be.reset(be); c->bias = (uint32_t)bias; c->max_score = mx;
+    for (int q = 0; q < 5; ++q) {
+        uint32_t w = 0;
+        for (int r = 0; r < 4; ++r) w |= (uint32_t)(scoring->matrix[5 * r + q] + bias) << (8 * r);
+        c->prof4[q] = w;
+    }
+    *out = c;
+    return VGK_OK;
+}
+
+void vgk_destroy(vgk_ctx* ctx) { delete ctx; }
+
+int vgk_device_info(vgk_ctx* ctx, char* name_out, size_t name_cap, int* cus, size_t* hbm) {
+    if (!ctx) return VGK_EINVAL;
+    if (name_out && name_cap) { std::strncpy(name_out, ctx->be->name(), name_cap - 1); name_out[name_cap - 1] = 0; }
+    if (cus) *cus = ctx->be->compute_units();
+    if (hbm) *hbm = ctx->be->memory_bytes();
+    return VGK_OK;
+}
+
+void vgk_batch_free(vgk_batch* b) {
+    if (!b) return;
+    {
+        std::lock_guard<std::mutex> lk(b->ctx->mu);
+        b->ctx->be->sync();
+        for (void* p : b->dev) b->ctx->be->release(p);
+    }
+    delete b;
+}
+
+int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out) {
+    if (!ctx || !out || (!problems && n)) return VGK_EINVAL;
+    *out = nullptr;
+    std::unique_ptr<vgk_batch> hb(new (std::nothrow) vgk_batch());
+    if (!hb) return VGK_ENOMEM;
+    vgk_batch* b = hb.get();
+    b->ctx = ctx; b->n = n;
+
+    uint32_t maxL = 1;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (problems[i].read_len == 0 || !problems[i].read || problems[i].graph.n_nodes == 0) return VGK_EINVAL;
+        maxL = std::max(maxL, problems[i].read_len);
+    }
+    const uint32_t G = (maxL + K - 1) / K;
+    if (G > 64) return VGK_ETOOLONG;
+    // best-cell keys pack score*16 + row: keep every reachable score below 4095
+    if ((int64_t)maxL * std::max(ctx->max_score, 0) + 2 * (int64_t)ctx->sc.full_length_bonus > 4094) return VGK_EUNSUPPORTED;
+    const uint32_t gpw = 64 / G, Lpad = G * K;
+    const uint32_t n_pairs = (n + 1) / 2, n_waves = (n_pairs + gpw - 1) / gpw;
+
+    std::vector<ProbDesc>& probs = b->probs;
+    probs.resize(n);
+    std::vector<uint8_t> colinfo, reads;
+    std::vector<NodeRec> nodes;
+    std::vector<uint32_t> preds;
+    uint64_t scratch_words = 0, ops_total = 0, n_edges = 0;
+    std::vector<uint8_t> store, slow;
+    for (uint32_t i = 0; i < n; ++i) {
+        const vgk_gssw_problem& p = problems[i];
+        const vgk_graph& g = p.graph;
+        ProbDesc& d = probs[i];
+        const uint32_t mode = p.flags & 15u;
+        if (mode != VGK_GSSW_LOCAL && mode != VGK_GSSW_PINNED) return VGK_EINVAL;
+        if (mode == VGK_GSSW_PINNED && !p.pinning) return VGK_EINVAL;
+        if (p.flags & VGK_GSSW_TRACEBACK) b->want_tb = true;
+        d.flags = p.flags; d.L = p.read_len; d.n_nodes = g.n_nodes;
+        d.node_off = (uint32_t)nodes.size();
+        d.read_off = (uint32_t)reads.size();
+        for (uint32_t r = 0; r < p.read_len; ++r) reads.push_back((uint8_t)nt_read(p.read[r]));
+        // which nodes need their last column saved / need a scratch-seeded first column
+        store.assign(g.n_nodes, 0); slow.assign(g.n_nodes, 0);
+        for (uint32_t v = 0; v < g.n_nodes; ++v) {
+            const uint32_t pb = g.pred_off[v], pe = g.pred_off[v + 1];
+            if (pe < pb || g.node_len[v] == 0) return VGK_EINVAL;
+            for (uint32_t k = pb; k < pe; ++k) if (g.pred_idx[k] >= v) return VGK_EINVAL;   // not topological
+            const bool chain = (pe - pb == 1) && g.pred_idx[pb] + 1 == v;
+            slow[v] = (v > 0 && !chain) ? 1 : 0;
+            if (slow[v]) for (uint32_t k = pb; k < pe; ++k) store[g.pred_idx[k]] = 1;
+            if (mode == VGK_GSSW_PINNED && p.pinning[v]) store[v] = 1;
+            n_edges += pe - pb;
+        }
+        while (colinfo.size() & 3u) colinfo.push_back(CI_INVALID);
+        d.col_off = (uint32_t)colinfo.size();
+        uint32_t col = 0, slots = 0, seq_pos = 0;
+        for (uint32_t v = 0; v < g.n_nodes; ++v) {
+            NodeRec nr;
+            nr.col_start = col; nr.col_end = col + g.node_len[v];
+            nr.pred_begin = (uint32_t)preds.size(); nr.n_pred = g.pred_off[v + 1] - g.pred_off[v];
+            for (uint32_t k = g.pred_off[v]; k < g.pred_off[v + 1]; ++k) preds.push_back(g.pred_idx[k]);
+            nr.slot = store[v] ? (int32_t)slots++ : -1;
+            nr.pinning = (mode == VGK_GSSW_PINNED && p.pinning[v]) ? 1u : 0u;
+            nodes.push_back(nr);
+            for (uint32_t k = 0; k < g.node_len[v]; ++k, ++seq_pos) {
+                uint8_t ci = (uint8_t)nt_ref(g.seq[seq_pos]);
+                if (k == 0) { ci |= CI_NODE_START; if (slow[v]) ci |= CI_SEED_SLOW; }
+                if (k + 1 == g.node_len[v] && store[v]) ci |= CI_STORE_END;
+                colinfo.push_back(ci);
+            }
+            col = nr.col_end;
+        }
+        if (col >= (1u << 20)) return VGK_ETOOBIG;
+        d.R = col; d.n_slots = slots;
+        d.scratch_off = (uint32_t)scratch_words;
+        scratch_words += (uint64_t)slots * Lpad;
+        if (scratch_words >= (1ull << 32)) return VGK_ETOOBIG;
+        d.ops_cap = ops_per_problem ? ops_per_problem : (p.read_len + col + 2);
+        if (!(p.flags & VGK_GSSW_TRACEBACK)) d.ops_cap = 0;
+        d.ops_off = (uint32_t)ops_total;
+        ops_total += d.ops_cap;
+        if (ops_total >= (1ull << 32)) return VGK_ETOOBIG;
+        d.pad = 0;
+        b->cells += (uint64_t)col * p.read_len;
+        b->in_bytes += (uint64_t)p.read_len + col + 8ull * g.n_nodes + 4ull * (g.pred_off[g.n_nodes] - g.pred_off[0]);
+    }
+    for (int k = 0; k < 8; ++k) colinfo.push_back(CI_INVALID);   // leaders prefetch one word ahead
+
+    std::vector<WaveDesc> waves(n_waves);
+    uint64_t tb_recs = 0;
+    for (uint32_t w = 0; w < n_waves; ++w) {
+        uint32_t rmax = 0;
+        for (uint32_t q = 0; q < gpw; ++q) {
+            const uint32_t pair = w * gpw + q;
+            for (uint32_t h = 0; h < 2; ++h) { const uint32_t i = 2 * pair + h; if (i < n) rmax = std::max(rmax, probs[i].R); }
+        }
+        waves[w].first_pair = w * gpw;
+        waves[w].n_steps = rmax ? rmax + G - 1 : 0;
+        waves[w].tb_off = tb_recs;
+        if (b->want_tb) tb_recs += (uint64_t)waves[w].n_steps * 64;
+    }
+
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GsswParams& P = b->P;
+    int rc;
+    // on failure release whatever was allocated (vgk_batch_free takes the context lock itself)
+    auto fail = [&](int code) { vgk_batch* t = hb.release(); ctx->mu.unlock(); vgk_batch_free(t); ctx->mu.lock(); return code; };
+    if ((rc = to_device(b, probs, P.probs))) return fail(rc);
+    if ((rc = to_device(b, colinfo, P.colinfo))) return fail(rc);
+    if ((rc = to_device(b, reads, P.reads, 8))) return fail(rc);
+    if ((rc = to_device(b, nodes, P.nodes))) return fail(rc);
+    if ((rc = to_device(b, preds, P.preds, 1))) return fail(rc);
+    if ((rc = to_device(b, waves, P.waves))) return fail(rc);
+    if ((rc = dev_alloc(b, (size_t)scratch_words + 16, P.scratch))) return fail(rc);
+    if ((rc = dev_alloc(b, (size_t)tb_recs * 4 + 4, P.tb))) return fail(rc);
+    if ((rc = dev_alloc(b, (size_t)n + 1, P.best))) return fail(rc);
+    if ((rc = dev_alloc(b, (size_t)n + 1, P.results))) return fail(rc);
+    if ((rc = dev_alloc(b, (size_t)ops_total + 1, P.ops))) return fail(rc);
+    P.n_problems = n; P.n_pairs = n_pairs; P.n_waves = n_waves; P.G = G; P.groups_per_wave = gpw; P.Lpad = Lpad;
+    for (int q = 0; q < 5; ++q) P.prof4[q] = ctx->prof4[q];
+    P.bias = ctx->bias; P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend; P.bonus = ctx->sc.full_length_bonus;
+    P.want_tb = b->want_tb ? 1 : 0;
+    std::memcpy(P.matrix, ctx->sc.matrix, 25);
+    b->ops_total = ops_total;
+    if ((rc = ctx->be->sync())) return fail(rc);     // inputs are resident in HBM when pack returns
+    *out = hb.release();
+    return VGK_OK;
+}
+
+int vgk_gssw_run(vgk_batch* b) {
+    if (!b) return VGK_EINVAL;
+    std::lock_guard<std::mutex> lk(b->ctx->mu);
+    int rc = b->ctx->be->zero(b->P.best, ((size_t)b->n + 1) * sizeof(unsigned long long));
+    if (rc) return rc;
+    rc = b->ctx->be->run_gssw(b->P, true);
+    if (rc == VGK_OK) b->ran = true;
+    return rc;
+}
+
+int vgk_batch_sync(vgk_batch* b) {
+    if (!b) return VGK_EINVAL;
+    std::lock_guard<std::mutex> lk(b->ctx->mu);
+    return b->ctx->be->sync();
+}
+
+int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+    if (!b || !results) return VGK_EINVAL;
+    if (!b->ran) { int rc = vgk_gssw_run(b); if (rc) return rc; }
+    std::lock_guard<std::mutex> lk(b->ctx->mu);
+    int rc = b->ctx->be->download(results, b->P.results, (size_t)b->n * sizeof(vgk_result));
+    if (rc) return rc;
+    std::vector<vgk_op> all;
+    if (b->want_tb && b->ops_total) {
+        all.resize(b->ops_total);
+        rc = b->ctx->be->download(all.data(), b->P.ops, (size_t)b->ops_total * sizeof(vgk_op));
+        if (rc) return rc;
+    }
+    size_t w = 0; uint64_t alg = 0;
+    for (uint32_t i = 0; i < b->n; ++i) {
+        vgk_result& r = results[i];
+        const ProbDesc& d = b->probs[i];
+        if (r.status == VGK_OK && r.n_ops) {
+            if (!ops || w + r.n_ops > ops_cap) { r.status = VGK_EOPS; r.n_ops = 0; r.ops_begin = (uint32_t)w; continue; }
+            std::memcpy(ops + w, all.data() + r.ops_begin, (size_t)r.n_ops * sizeof(vgk_op));
+            r.ops_begin = (uint32_t)w; w += r.n_ops;
+        } else { r.n_ops = 0; r.ops_begin = (uint32_t)w; }
+        alg += 16 + 2ull * r.n_ops + ((d.flags & VGK_GSSW_TRACEBACK) ? (uint64_t)d.L * d.R : 0);
+    }
+    b->alg_bytes = b->in_bytes + alg;
+    if (ops_written) *ops_written = w;
+    return VGK_OK;
+}
+
+int vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
+                   vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+    vgk_batch* b = nullptr;
+    int rc = vgk_gssw_pack(ctx, problems, n, 0, &b);
+    if (rc) return rc;
+    rc = vgk_gssw_run(b);
+    if (!rc) rc = vgk_gssw_fetch(b, results, ops, ops_cap, ops_written);
+    vgk_batch_free(b);
+    return rc;
+}
+
+double vgk_batch_kernel_ms(vgk_batch* b, int which) {
+    if (!b) return 0.0;
+    std::lock_guard<std::mutex> lk(b->ctx->mu);
+    if (which == 0 || which == 1) return b->ctx->be->last_ms(which);
+    return b->ctx->be->last_ms(0) + b->ctx->be->last_ms(1);
+}
+uint64_t vgk_batch_cells(vgk_batch* b) { return b ? b->cells : 0; }
+uint64_t vgk_batch_alg_bytes(vgk_batch* b) {
+    if (!b) return 0;
+    if (b->alg_bytes) return b->alg_bytes;
+    uint64_t alg = b->in_bytes;      // before fetch: everything except the 2 B / emitted op term
+    for (const ProbDesc& d : b->probs) alg += 16 + ((d.flags & VGK_GSSW_TRACEBACK) ? (uint64_t)d.L * d.R : 0);
+    return alg;
+}
+uint64_t vgk_batch_device_bytes(vgk_batch* b) { return b ? b->dev_bytes : 0; }
+
+}  // extern "C"
