@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py — reads/sec aligned (150 bp) on N MI355X, next to the CPU path.
+
+One "step" = one pass of the hot path (batched graph Smith-Waterman with
+traceback: fill kernel + traceback kernel) over one batch of synthetic reads
+whose packed inputs are already resident in HBM.  Workload = BASELINE.json
+configs[1]: linear 1 Mbp synthetic graph (32 bp nodes), 150 bp reads, 384-416 bp
+windows, LOCAL alignment with traceback, default vg scoring 1/4/6/1/5.
+
+Multi-GPU: reads shard embarrassingly (one process per GPU, no data-path
+collective); every rank aligns its own batch of the same size -> weak scaling.
+torch is used only for process-group plumbing (barrier, max-reduce of the time).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (configs[1]: 1M)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="reads for the CPU baseline leg (0 = auto, ~15 s)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch   # first, so its bundled HIP runtime is the one the engine library binds to
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    import numpy as np
+    from vg_amd import capi, workloads
+
+    eng_lib = os.path.join(ROOT, "vg_amd", "libvgamd.so")
+    if not os.path.exists(eng_lib):
+        raise SystemExit("vg_amd/libvgamd.so missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback)")
+    eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), device=local_rank, lib=eng_lib)
+    dev_name, cus, hbm = eng.device_info()
+
+    # same reference everywhere; each rank draws its own reads (shard of the read stream)
+    wl = workloads.LinearWorkload(args.reads, seed=43 + rank)
+    OPS_PER = 48
+    t0 = time.time()
+    batch = eng.pack(wl, OPS_PER)          # host packing + H2D: inputs resident in HBM from here on
+    t_pack = time.time() - t0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run()
+    batch.sync()
+    barrier()
+    fill_ms, walk_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run()                        # fill + traceback kernels, async on the engine stream
+        # per-launch kernel durations from HIP events on the launch stream (synchronises this step)
+        fill_ms.append(batch.kernel_ms(0)); walk_ms.append(batch.kernel_ms(1))
+    batch.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # results of the last step: parity spot-check against the oracle + exact algorithmic bytes
+    res, ops = batch.fetch()
+    alg_bytes = batch.alg_bytes()
+    cells = batch.cells()
+    dev_bytes = batch.device_bytes()
+    n_bad = int((res["status"] != 0).sum())
+
+    cpu = None
+    parity = None
+    if rank == 0 and not args.no_cpu:
+        ora_lib = os.path.join(ROOT, "oracle", "libvgoracle.so")
+        ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=ora_lib)     # the checker / CPU baseline leg
+        cores = os.cpu_count() or 1
+        k = args.cpu_sample
+        if k <= 0:
+            probe = wl.subset(min(args.reads, 64 * cores))
+            with ora.pack(probe, OPS_PER) as pb:
+                tp = time.perf_counter(); pb.run(); tp = time.perf_counter() - tp
+            k = int(min(args.reads, max(probe.n, 15.0 * probe.n / max(tp, 1e-6))))
+        sample = wl.subset(k)
+        with ora.pack(sample, OPS_PER) as ob:
+            tc = time.perf_counter(); ob.run(); tc = time.perf_counter() - tc
+            ores, oops = ob.fetch()
+        cpu = {"value": k / tc, "unit": "reads/s", "cores": cores, "kind": "port",
+               "sample": "first %d reads of the same batch, oracle/vgo_gssw.c scalar int32 DP + traceback, OpenMP over reads" % k}
+        # vectorised bit-exact comparison (score, status, end cell, first offset, every CIGAR element)
+        hdr = np.ones(k, dtype=bool)
+        for f in ("score", "status", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
+            hdr &= res[f][:k] == ores[f][:k]
+        same = int(hdr.sum())
+        if hdr.all():
+            tot = int(ores["n_ops"].sum())
+            a = ops[:tot].view(np.uint64); b = oops[:tot].view(np.uint64)
+            bad_ops = a != b
+            if bad_ops.any():
+                owner = np.repeat(np.arange(k), ores["n_ops"])
+                same = k - len(np.unique(owner[bad_ops]))
+        parity = {"checked": k, "identical": same}
+    batch.free()
+
+    if rank == 0:
+        total_reads = args.reads * world * args.steps
+        value = total_reads / elapsed
+        fill_avg = sum(fill_ms) / len(fill_ms)
+        achieved = alg_bytes / (fill_avg * 1e-3) / 1e9
+        out = {
+            "metric": "reads/sec aligned (150 bp)", "value": value, "unit": "reads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "configs[1]: linear 1 Mbp graph (32 bp nodes), %d x 150 bp reads per GPU, "
+                                   "384-416 bp windows, gssw LOCAL + traceback, scores 1/4/6/1/5" % args.reads,
+                       "reads_per_gpu_per_step": args.reads, "parallelism": "read-sharded x%d" % world,
+                       "device": dev_name, "compute_units": cus},
+            "roofline": {"bound": "hbm", "kernel": "gssw_fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": fill_avg,
+                         "traceback_kernel_ms": sum(walk_ms) / len(walk_ms),
+                         "gcups_fill": cells / (fill_avg * 1e-3) / 1e9},
+            "cpu_baseline": cpu,
+            "parity": parity,
+            "problems_failed": n_bad,
+            "hbm_footprint_bytes": dev_bytes,
+            "pack_seconds": t_pack,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

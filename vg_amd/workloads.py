@@ -1,0 +1,117 @@
+"""Synthetic workloads for bench.py and the full-size tests.
+
+config 2 ("linear-1Mbp"): an i.i.d. uniform 1,000,000 bp reference chopped into
+32 bp nodes (a chain DAG), N reads x 150 bp from uniform positions, forward
+strand, substitutions 1 %, indels 0.1 % (geometric length, mean 2).  Per read the
+host extracts the window [start-117, start+150+117) snapped outward to whole
+nodes (R = 384 bp = 12 nodes away from the ends) — the >= 75 bp flank `vg map`
+adds via longest_detectable_gap (src/mapper.cpp:2440, src/alignment_scorer.cpp:264-271).
+All problems point into ONE shared reference array (no per-read copies): the C ABI
+takes plain pointers, so windows may overlap freely.
+"""
+import numpy as np
+
+from . import capi
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+NODE = 32
+FLANK = 117
+
+
+def make_reference(length=1_000_000, seed=42):
+    rng = np.random.default_rng(seed)
+    return ACGT[rng.integers(0, 4, length)]
+
+
+class LinearWorkload:
+    """Holds the numpy arenas and the vgk_gssw_problem array for config 2."""
+
+    def __init__(self, n_reads, read_len=150, ref_len=1_000_000, seed=43, ref_seed=42,
+                 sub_rate=0.01, indel_rate=0.001, flags=capi.VGK_GSSW_LOCAL | capi.VGK_GSSW_TRACEBACK):
+        rng = np.random.default_rng(seed)
+        self.ref = make_reference(ref_len, ref_seed)
+        self.n = n_reads
+        self.read_len = read_len
+        n_ref_nodes = ref_len // NODE
+        # sample a little more reference than the read needs so deletions can be absorbed
+        span = read_len + 16
+        start = rng.integers(0, ref_len - span, n_reads)
+        reads = np.empty((n_reads, read_len), dtype=np.uint8)
+        CH = 65536                                              # chunked to bound host memory
+        for c0 in range(0, n_reads, CH):
+            c1 = min(n_reads, c0 + CH)
+            m = c1 - c0
+            src = self.ref[start[c0:c1, None] + np.arange(span)[None, :]]   # (m, span) template bases
+            # substitutions (to a uniformly random base, as vg sim does)
+            sub = rng.random((m, span)) < sub_rate
+            src[sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
+            reads[c0:c1] = src[:, :read_len]
+            # indels: rare -> per-read fix-up loop over the affected reads only
+            ev = rng.random((m, read_len)) < indel_rate
+            for r in np.nonzero(ev.any(axis=1))[0]:
+                tmpl = src[r]
+                out = []
+                i = 0
+                evr = ev[r]
+                while len(out) < read_len and i < span:
+                    if i < read_len and evr[i]:
+                        ln = int(rng.geometric(0.5))
+                        if rng.random() < 0.5:
+                            out.extend(ACGT[rng.integers(0, 4, ln)])   # insertion
+                        else:
+                            i += ln                                    # deletion
+                            continue
+                    out.append(tmpl[i]); i += 1
+                while len(out) < read_len:
+                    out.append(ACGT[rng.integers(0, 4)])
+                reads[c0 + r] = np.array(out[:read_len], dtype=np.uint8)
+        self.reads = reads.reshape(-1)
+        self.start = start
+        # windows snapped outward to whole nodes, clipped to the reference
+        first = np.maximum((start - FLANK) // NODE, 0)
+        last = np.minimum((start + read_len + FLANK + NODE - 1) // NODE, n_ref_nodes)   # exclusive
+        n_nodes = (last - first).astype(np.int64)
+        self.first_node = first
+        self.n_nodes = n_nodes
+        max_nodes = int(n_nodes.max())
+        # shared templates: every node is 32 bp; chain predecessors
+        self.node_len_t = np.full(max_nodes, NODE, dtype=np.uint32)
+        self.pred_off_t = np.concatenate([[0], np.arange(0, max_nodes)]).astype(np.uint32)  # [0,0,1,2,...]
+        self.pred_idx_t = np.arange(max_nodes, dtype=np.uint32)                              # node v -> v-1
+        arr = np.zeros(n_reads, dtype=capi.PROBLEM_DT)
+        arr["read"] = self.reads.ctypes.data + np.arange(n_reads, dtype=np.int64) * read_len
+        arr["read_len"] = read_len
+        arr["flags"] = flags
+        g = arr["graph"]
+        g["n_nodes"] = n_nodes
+        g["node_len"] = self.node_len_t.ctypes.data
+        g["seq"] = self.ref.ctypes.data + first * NODE
+        g["pred_off"] = self.pred_off_t.ctypes.data
+        g["pred_idx"] = self.pred_idx_t.ctypes.data
+        arr["graph"] = g
+        self.array = arr
+        self.R = n_nodes * NODE
+
+    @property
+    def ptr(self):
+        return self.array.ctypes.data
+
+    # duck-typing the bits of capi.ProblemSet that Engine/Batch use
+    @property
+    def read_off(self):
+        return np.arange(self.n + 1, dtype=np.int64) * self.read_len
+
+    @property
+    def seq_off(self):
+        return np.concatenate([[0], np.cumsum(self.R)])
+
+    def subset(self, k):
+        """First k problems as an independent view (same arenas)."""
+        s = object.__new__(LinearWorkload)
+        s.__dict__.update(self.__dict__)
+        s.n = k; s.array = self.array[:k]; s.R = self.R[:k]; s.n_nodes = self.n_nodes[:k]
+        s.start = self.start[:k]; s.first_node = self.first_node[:k]
+        return s
+
+    def cells(self):
+        return int((self.R * self.read_len).sum())
