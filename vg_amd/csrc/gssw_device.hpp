@@ -193,27 +193,25 @@ template <int HALF>
 VGK_HD void seed_from_scratch(Lane& s, const GsswParams& P, uint32_t prob, uint32_t node, uint32_t& diag0) {
     const ProbDesc& d = P.probs[prob];
     const NodeRec& nr = P.nodes[d.node_off + node];
-    uint32_t sh[K], se[K], sd = 0;
+    const uint32_t keep = HALF == 0 ? 0xffff0000u : 0x0000ffffu;     // the other read's half stays
 #pragma unroll
-    for (int m = 0; m < K; ++m) { sh[m] = 0; se[m] = 0; }
+    for (int m = 0; m < K; ++m) { s.H[m] &= keep; s.E[m] &= keep; }
+    diag0 &= keep;
     for (uint32_t k = 0; k < nr.n_pred; ++k) {
         const NodeRec& pr = P.nodes[d.node_off + P.preds[nr.pred_begin + k]];
         const uint32_t* base = P.scratch + d.scratch_off + (uint32_t)pr.slot * P.Lpad + s.g * K;
 #pragma unroll
         for (int m = 0; m < K; ++m) {
-            uint32_t v = scratch_load(base + m);
-            uint32_t h = v & 0xffffu, e = v >> 16;
-            sh[m] = h > sh[m] ? h : sh[m];
-            se[m] = e > se[m] ? e : se[m];
+            const uint32_t v = scratch_load(base + m);     // lo16 = H, hi16 = E-next of the predecessor's last column
+            // a packed max against a value whose other half is 0 leaves the other read untouched
+            s.H[m] = pk_max(s.H[m], HALF == 0 ? (v & 0xffffu) : (v << 16));
+            s.E[m] = pk_max(s.E[m], HALF == 0 ? (v >> 16) : (v & 0xffff0000u));
         }
-        if (s.g > 0) { uint32_t h = scratch_load(base - 1) & 0xffffu; sd = h > sd ? h : sd; }
+        if (s.g > 0) {
+            const uint32_t v = scratch_load(base - 1);
+            diag0 = pk_max(diag0, HALF == 0 ? (v & 0xffffu) : (v << 16));
+        }
     }
-#pragma unroll
-    for (int m = 0; m < K; ++m) {
-        if (HALF == 0) { s.H[m] = set_lo(s.H[m], sh[m]); s.E[m] = set_lo(s.E[m], se[m]); }
-        else           { s.H[m] = set_hi(s.H[m], sh[m]); s.E[m] = set_hi(s.E[m], se[m]); }
-    }
-    diag0 = (HALF == 0) ? set_lo(diag0, sd) : set_hi(diag0, sd);
 }
 
 template <int HALF>
@@ -235,7 +233,13 @@ VGK_HD void store_to_scratch(const Lane& s, const GsswParams& P, uint32_t prob, 
 template <bool REFN>
 VGK_HD void lane_rows(Lane& s, const GsswParams& P, uint32_t sel, uint32_t diag0, uint32_t rf,
                       bool nA, bool nB, uint32_t acc[4], uint32_t& colkey) {
-    const uint32_t bias2 = rep2(P.bias), go2 = rep2(P.go), ge2 = rep2(P.ge);
+    uint32_t bias2 = rep2(P.bias), go2 = rep2(P.go), ge2 = rep2(P.ge);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The rare N variant must stay a separate branch: with opaque copies of its inputs the
+    // optimiser cannot hoist "common" permutes/subtracts of all 16 rows above the branch
+    // (that hoisting cost 32 live VGPRs and spilled the hot loop).
+    if (REFN) asm volatile("" : "+v"(sel), "+v"(bias2), "+v"(go2), "+v"(ge2));
+#endif
     const uint32_t one = s.one, sixteen = 0x00100010u;
     uint32_t f = rf, d = diag0, ck = 0;
 #pragma unroll
