@@ -8,7 +8,7 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 CXX      ?= g++
 CC       ?= gcc
 ARCH     ?= gfx950
-HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Wall -Wno-unused-function
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Wall -Wno-unused-function -Wno-unused-value
 CXXFLAGS ?= -O2 -std=c++17 -fPIC -Iinclude -Wall
 CFLAGS   ?= -O3 -march=x86-64-v2 -std=c11 -fPIC -fopenmp -Iinclude -Wall
 

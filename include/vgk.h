@@ -151,7 +151,8 @@ int  vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
 /* batch introspection (used by bench.py for the roofline line) */
 void     vgk_batch_free(vgk_batch* batch);
 int      vgk_batch_sync(vgk_batch* batch);
-double   vgk_batch_kernel_ms(vgk_batch* batch, int which /* 0 = fill, 1 = traceback, -1 = all */);
+double   vgk_batch_kernel_ms(vgk_batch* batch, int which /* 0 = fill kernels (sum over launches), 1 = traceback tail after the last
+                                                               fill, 2 = number of fill launches, -1 = fill + traceback */);
 uint64_t vgk_batch_cells(vgk_batch* batch);          /* DP cells computed per run            */
 uint64_t vgk_batch_alg_bytes(vgk_batch* batch);      /* algorithmic bytes per run */
 uint64_t vgk_batch_device_bytes(vgk_batch* batch);   /* HBM footprint of the batch            */

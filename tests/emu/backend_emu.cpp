@@ -23,9 +23,10 @@ public:
     int download(void* d, const void* s, size_t n) override { std::memcpy(d, s, n); return VGK_OK; }
     int zero(void* d, size_t n) override { std::memset(d, 0, n); return VGK_OK; }
     int sync() override { return VGK_OK; }
-    int run_gssw(const GsswParams& P, bool walk) override {
-        std::vector<Lane> lanes(64);
+    template <int K> void fill(const GsswParams& P) {
+        std::vector<Lane<K>> lanes(64);
         std::vector<uint32_t> oh(64), of(64), oi(64);
+        constexpr uint32_t REC = K / 4;
         for (uint32_t w = 0; w < P.n_waves; ++w) {
             const WaveDesc wd = P.waves[w];
             for (uint32_t l = 0; l < 64; ++l) lane_init(lanes[l], P, wd, l);
@@ -34,7 +35,7 @@ public:
                 for (uint32_t l = 0; l < 64; ++l) {
                     if ((t & 3u) == 0) lane_prefetch(lanes[l], P, t);
                     const uint32_t rh = l ? oh[l - 1] : 0, rf = l ? of[l - 1] : 0, ri = l ? oi[l - 1] : 0;
-                    uint32_t* tb = P.want_tb ? P.tb + (wd.tb_off + (uint64_t)t * 64 + l) * 4 : nullptr;
+                    uint32_t* tb = P.want_tb ? P.tb + tb_record(wd.tb_off, t, l) * REC : nullptr;
                     lane_step(lanes[l], P, t, rh, rf, ri, tb);
                 }
             }
@@ -43,10 +44,18 @@ public:
                 if (lane_best(lanes[l], half, prob, key) && key > P.best[prob]) P.best[prob] = key;
             }
         }
-        if (walk) for (uint32_t i = 0; i < P.n_problems; ++i) walk_one(P, i);
+    }
+    int run_gssw(const GsswParams& P, bool walk) override {
+        switch (P.K) {
+            case 16: fill<16>(P); break;
+            case 20: fill<20>(P); break;
+            case 24: fill<24>(P); break;
+            default: return VGK_EINVAL;
+        }
+        if (walk) for (uint32_t i = 0; i < P.n_problems; ++i) walk_one(P, i, P.best[i]);
         return VGK_OK;
     }
-    double last_ms(int) const override { return 0.0; }
+    double last_ms(int which) const override { return which == 2 ? 1.0 : 0.0; }
 };
 
 Backend* make_backend(int, std::string&) { return new EmuBackend(); }

@@ -24,7 +24,7 @@ public:
     virtual int   sync() = 0;
     // gssw kernels; timings (ms, HIP events on the launch stream) of the last run
     virtual int   run_gssw(const GsswParams& p, bool walk) = 0;
-    virtual double last_ms(int which) const = 0;           // 0 = fill, 1 = traceback
+    virtual double last_ms(int which) const = 0;           // 0 = fill (all launches), 1 = traceback tail, 2 = number of fill launches
 };
 
 // returns nullptr and sets err when the device cannot be used

@@ -2,6 +2,7 @@
 // There is deliberately no CPU fallback here: if no HIP device answers,
 // make_backend() fails and vgk_create() returns VGK_ENODEV.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <string>
 #include "backend.hpp"
 
@@ -14,43 +15,72 @@ static __device__ __forceinline__ uint32_t from_lane_above(uint32_t x) {
 
 // Fill: 4 independent wavefronts per workgroup; each wavefront owns
 // floor(64/G) read pairs for the whole skewed sweep.  No LDS, no barriers.
-__global__ __launch_bounds__(256, 4) void gssw_fill_kernel(const GsswParams P) {
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+// Occupancy: K = 16 fits 128 VGPRs (4 waves/SIMD); K = 20/24 keep 4K+ state registers per
+// lane and run 3 waves/SIMD (<= 168 VGPRs) rather than spill in the hot loop.
+template <int K>
+__global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const GsswParams P) {
+    const uint32_t wave = P.wave_begin + blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    if (wave >= P.n_waves) return;
+    if (wave >= P.wave_begin + P.wave_count) return;
     const WaveDesc wd = P.waves[wave];
-    Lane s;
+    Lane<K> s;
     lane_init(s, P, wd, lane);
     asm volatile("" : "+v"(s.one));   // keep min(x,1) a packed min instead of cmp+cndmask
-    uint32_t* tb = P.want_tb ? P.tb + (wd.tb_off + lane) * 4u : nullptr;
+    constexpr uint32_t REC = K / 4;   // dwords per (step, lane) traceback record
+    uint32_t* tb = P.want_tb ? P.tb : nullptr;
     for (uint32_t t = 0; t < wd.n_steps; ++t) {
         if ((t & 3u) == 0) lane_prefetch(s, P, t);
         const uint32_t rh = from_lane_above(s.out_h);
         const uint32_t rf = from_lane_above(s.out_f);
         const uint32_t ri = from_lane_above(s.info);
-        lane_step(s, P, t, rh, rf, ri, tb ? tb + (size_t)t * 256u : nullptr);
+        lane_step(s, P, t, rh, rf, ri, tb ? tb + tb_record(wd.tb_off, t, lane) * REC : nullptr);
     }
+    if (!P.fused) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t prob; unsigned long long key;
+            if (lane_best(s, half, prob, key)) atomicMax(&P.best[prob], key);
+        }
+        return;
+    }
+    // Fused traceback: the wavefront that filled a read pair also walks it back while its
+    // traceback codes are still in L2 / Infinity Cache.  The walk is a latency-bound pointer
+    // chase (one lane per read); the other wavefronts resident on the SIMD keep the VALU busy.
+    __shared__ unsigned long long wbest[4][128];
+    unsigned long long* mine = wbest[threadIdx.x >> 6];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        uint32_t prob; unsigned long long key;
-        if (lane_best(s, half, prob, key)) atomicMax(&P.best[prob], key);
+        uint32_t prob; unsigned long long key = 0;
+        if (!lane_best(s, half, prob, key)) key = 0;
+        mine[lane * 2 + half] = key;
+    }
+    __threadfence();      // this wave's traceback codes / scratch columns -> visible to its walker lanes
+    const uint32_t n_slots = 2u * P.groups_per_wave;
+    for (uint32_t slot = lane; slot < n_slots; slot += 64u) {
+        const uint32_t q = slot >> 1, half = slot & 1u;
+        const uint32_t prob = 2u * (wd.first_pair + q) + half;
+        if (prob >= P.n_problems) continue;
+        unsigned long long key = 0;
+        for (uint32_t g = 0; g < P.G; ++g) { const unsigned long long k = mine[(q * P.G + g) * 2 + half]; key = k > key ? k : key; }
+        walk_one(P, prob, key);
     }
 }
 
 __global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P.n_problems) walk_one(P, i);
+    const uint32_t i = P.prob_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.prob_begin + P.prob_count) walk_one(P, i, P.best[i]);
 }
 
 class HipBackend final : public Backend {
 public:
-    int dev = 0; hipStream_t stream = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, stream2 = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipDeviceProp_t prop;
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
     ~HipBackend() override {
         hipSetDevice(dev);
         for (auto& e : ev) if (e) hipEventDestroy(e);
         if (stream) hipStreamDestroy(stream);
+        if (stream2) hipStreamDestroy(stream2);
     }
     const char* name() const override { return prop.name; }
     int compute_units() const override { return prop.multiProcessorCount; }
@@ -79,15 +109,50 @@ public:
         hipSetDevice(dev);
         return hipStreamSynchronize(stream) == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
-    int run_gssw(const GsswParams& p, bool walk) override {
+    int launch_fill(const GsswParams& p) {
+        const dim3 grid((p.wave_count + 3) / 4), block(256);
+        switch (p.K) {
+            case 16: hipLaunchKernelGGL(gssw_fill_kernel<16>, grid, block, 0, stream, p); break;
+            case 20: hipLaunchKernelGGL(gssw_fill_kernel<20>, grid, block, 0, stream, p); break;
+            case 24: hipLaunchKernelGGL(gssw_fill_kernel<24>, grid, block, 0, stream, p); break;
+            default: return VGK_EINVAL;
+        }
+        return VGK_OK;
+    }
+    // Fill is VALU-bound, the traceback walk is a latency-bound pointer chase: the batch is cut
+    // into chunks of whole wavefronts and walk(chunk c) runs on a second stream underneath
+    // fill(chunk c+1).  With fused = 1 every wavefront walks its own reads inside the fill kernel.
+    int run_gssw(const GsswParams& p0, bool walk) override {
         hipSetDevice(dev);
-        if (p.n_waves == 0) { ms_fill = ms_walk = 0; pending = false; return VGK_OK; }
+        if (p0.n_waves == 0) { ms_fill = ms_walk = 0; pending = false; n_launches = 1; return VGK_OK; }
+        GsswParams p = p0;
+        const bool split = walk && !p.fused;
+        uint32_t chunk = p.n_waves;
+        // Measured on MI355X: overlapping walk(c) with fill(c+1) on a second stream
+        // slows the VALU-bound fill more than it hides (27.1 vs 30.0 M reads/s at 400k reads), so the
+        // default is one chunk = fill then walk; VGAMD_CHUNK_WAVES=<n> enables the chunk pipeline.
+        if (split) if (const char* e = getenv("VGAMD_CHUNK_WAVES")) { const int v = atoi(e); if (v > 0) chunk = (uint32_t)v; }
+        n_launches = 0;
         hipEventRecord(ev[0], stream);
-        hipLaunchKernelGGL(gssw_fill_kernel, dim3((p.n_waves + 3) / 4), dim3(256), 0, stream, p);
+        for (uint32_t w0 = 0; w0 < p.n_waves; w0 += chunk) {
+            p.wave_begin = w0; p.wave_count = (p.n_waves - w0 < chunk) ? p.n_waves - w0 : chunk;
+            p.prob_begin = 2u * p.groups_per_wave * w0;
+            const uint32_t pend = 2u * p.groups_per_wave * (w0 + p.wave_count);
+            p.prob_count = (pend < p.n_problems ? pend : p.n_problems) - p.prob_begin;
+            int rc = launch_fill(p);
+            if (rc) return rc;
+            ++n_launches;
+            if (split) {
+                hipEventRecord(ev[3], stream);
+                hipStreamWaitEvent(stream2, ev[3], 0);
+                hipLaunchKernelGGL(gssw_walk_kernel, dim3((p.prob_count + 255) / 256), dim3(256), 0, stream2, p);
+            }
+        }
         hipEventRecord(ev[1], stream);
-        timed_walk = walk;
-        if (walk) {
-            hipLaunchKernelGGL(gssw_walk_kernel, dim3((p.n_problems + 255) / 256), dim3(256), 0, stream, p);
+        timed_walk = split;
+        if (split) {
+            hipEventRecord(ev[3], stream2);
+            hipStreamWaitEvent(stream, ev[3], 0);
             hipEventRecord(ev[2], stream);
         }
         pending = true;
@@ -103,7 +168,7 @@ public:
             if (timed_walk) hipEventElapsedTime(&self->ms_walk, ev[1], ev[2]);
             self->pending = false;
         }
-        return which == 0 ? ms_fill : ms_walk;
+        return which == 0 ? ms_fill : which == 1 ? ms_walk : (double)n_launches;
     }
 };
 
@@ -116,7 +181,8 @@ Backend* make_backend(int device, std::string& err) {
     b->dev = device;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&b->prop, device) != hipSuccess) {
         err = "cannot select HIP device"; delete b; return nullptr; }
-    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { err = "cannot create HIP stream"; delete b; return nullptr; }
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess) { err = "cannot create HIP stream"; delete b; return nullptr; }
     for (auto& ev : b->ev) if (hipEventCreate(&ev) != hipSuccess) { err = "cannot create HIP event"; delete b; return nullptr; }
     return b;
 }

@@ -6,16 +6,19 @@
 // MI355X mapping (see DESIGN.md §3 for the full rationale):
 //   * two reads share every 32-bit register (lo/hi unsigned 16-bit halves), so
 //     each packed VALU instruction (v_pk_*_u16) advances two DP cells;
-//   * a read pair is spread over G = ceil(L/16) adjacent lanes, lane g owning
-//     16 consecutive read rows; floor(64/G) pairs share one wavefront;
+//   * a read pair is spread over G = ceil(L/K) adjacent lanes, lane g owning
+//     K consecutive read rows (K = 16, 20 or 24, chosen per batch so that the
+//     wavefront's 64 lanes and the padded rows are used best; 150 bp reads run
+//     with K = 20: 8 lanes per pair, 8 pairs = 16 reads per wavefront);
+//     floor(64/G) pairs share one wavefront;
 //   * lanes run a skewed wavefront: at step t lane g computes graph column
 //     t-g, taking the vertical-gap value F and the diagonal H of the row above
 //     from lane g-1 with one DPP wave_shr:1 each — no LDS, no barriers;
 //   * the unsigned, bias-shifted arithmetic and saturating subtracts reproduce
 //     gssw's (SSW's) zero-floored E/F/H exactly;
-//   * per cell a 4-bit traceback code is produced; 16 rows x 2 reads = 16 B per
+//   * per cell a 4-bit traceback code is produced; K rows x 2 reads = K bytes per
 //     lane per step, stored step-major so every wave store is one contiguous
-//     1 KiB burst;
+//     burst of 64*K bytes;
 //   * node boundaries that are not simple chain links go through a small
 //     HBM scratch of per-node last columns (H and next-column E), which the
 //     traceback also uses to choose predecessors.
@@ -29,7 +32,7 @@
 
 namespace vgk {
 
-constexpr int K = 16;   // read rows per lane
+constexpr int KMAX = 24;   // most read rows per lane any instantiation uses
 
 // per-column info byte
 enum : uint32_t {
@@ -66,7 +69,7 @@ struct NodeRec {
 };
 
 struct WaveDesc {
-    uint64_t tb_off;       // first 16-byte traceback record of this wave
+    uint64_t tb_off;       // first traceback record (K/4 dwords each) of this wave
     uint32_t n_steps;
     uint32_t first_pair;
 };
@@ -78,12 +81,15 @@ struct GsswParams {
     const NodeRec*  nodes;
     const uint32_t* preds;
     uint32_t*       scratch;    // per (slot,row): lo16 = H of the node's last column, hi16 = E for the column after it
-    uint32_t*       tb;         // 4 dwords per (step, lane)
+    uint32_t*       tb;         // K/4 dwords per (step, lane)
     const WaveDesc* waves;
     unsigned long long* best;   // LOCAL mode: per read, max over cells of key64(score, col, row)
     vgk_result*     results;
     vgk_op*         ops;
     uint32_t n_problems, n_pairs, n_waves;
+    uint32_t wave_begin, wave_count;   // this launch covers waves [wave_begin, wave_begin + wave_count)
+    uint32_t prob_begin, prob_count;   // ... and the traceback launch these reads
+    uint32_t K;                 // read rows per lane (16, 20 or 24)
     uint32_t G;                 // lanes per read pair
     uint32_t groups_per_wave;   // 64 / G
     uint32_t Lpad;              // G*K rows per scratch slot
@@ -92,6 +98,7 @@ struct GsswParams {
     uint32_t go, ge;
     int32_t  bonus;             // full-length bonus
     int32_t  want_tb;           // any problem wants traceback -> store codes
+    int32_t  fused;             // 1 = each wavefront traces its own reads back at the end of the fill kernel
     int8_t   matrix[25];
 };
 
@@ -112,6 +119,7 @@ VGK_HD unsigned long long key64(uint32_t score, uint32_t col, uint32_t row) {
 // ---------------------------------------------------------------------------
 // per-lane state of the fill
 // ---------------------------------------------------------------------------
+template <int K>
 struct Lane {
     uint32_t H[K];      // H of the last processed column          {B:A}
     uint32_t E[K];      // E for the next column                   {B:A}
@@ -129,7 +137,8 @@ struct Lane {
     uint32_t one;                   // 0x00010001 kept opaque to the optimiser (see lane_rows)
 };
 
-VGK_HD void lane_init(Lane& s, const GsswParams& P, const WaveDesc& wd, uint32_t lane_id) {
+template <int K>
+VGK_HD void lane_init(Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint32_t lane_id) {
     const uint32_t q = lane_id / P.G;
     s.g = lane_id - q * P.G;
     const uint32_t pair = wd.first_pair + q;
@@ -162,7 +171,8 @@ VGK_HD void lane_init(Lane& s, const GsswParams& P, const WaveDesc& wd, uint32_t
 // Group leaders (g == 0) pull the column-info stream 4 columns at a time, one
 // word ahead, so the HBM/L2 latency of the load hides behind four steps of DP.
 // Call at every step with (t & 3) == 0, before lane_step.
-VGK_HD void lane_prefetch(Lane& s, const GsswParams& P, uint32_t t) {
+template <int K>
+VGK_HD void lane_prefetch(Lane<K>& s, const GsswParams& P, uint32_t t) {
     if (s.g != 0) return;
     s.ciA = s.ciA_n; s.ciB = s.ciB_n;
     if (t + 4 < s.RA) s.ciA_n = *(const uint32_t*)(P.colinfo + s.colA + t + 4);
@@ -170,7 +180,8 @@ VGK_HD void lane_prefetch(Lane& s, const GsswParams& P, uint32_t t) {
 }
 
 // fresh column info for the group leader at step t: {infoB<<16 | infoA}
-VGK_HD uint32_t fetch_info(const Lane& s, const GsswParams& P, uint32_t t) {
+template <int K>
+VGK_HD uint32_t fetch_info(const Lane<K>& s, const GsswParams& P, uint32_t t) {
     (void)P;
     const uint32_t sh = 8 * (t & 3u);
     const uint32_t ia = t < s.RA ? (s.ciA >> sh) & 0xffu : (uint32_t)CI_INVALID;
@@ -189,8 +200,8 @@ static inline uint32_t scratch_load(const uint32_t* p) { return *p; }
 
 // SEED_SLOW: seed column = element-wise max over the predecessors' saved last
 // columns (gssw_create_seed_*); HALF = 0 for read A (low halves), 1 for read B.
-template <int HALF>
-VGK_HD void seed_from_scratch(Lane& s, const GsswParams& P, uint32_t prob, uint32_t node, uint32_t& diag0) {
+template <int HALF, int K>
+VGK_HD void seed_from_scratch(Lane<K>& s, const GsswParams& P, uint32_t prob, uint32_t node, uint32_t& diag0) {
     const ProbDesc& d = P.probs[prob];
     const NodeRec& nr = P.nodes[d.node_off + node];
     const uint32_t keep = HALF == 0 ? 0xffff0000u : 0x0000ffffu;     // the other read's half stays
@@ -214,8 +225,8 @@ VGK_HD void seed_from_scratch(Lane& s, const GsswParams& P, uint32_t prob, uint3
     }
 }
 
-template <int HALF>
-VGK_HD void store_to_scratch(const Lane& s, const GsswParams& P, uint32_t prob, uint32_t node) {
+template <int HALF, int K>
+VGK_HD void store_to_scratch(const Lane<K>& s, const GsswParams& P, uint32_t prob, uint32_t node) {
     const ProbDesc& d = P.probs[prob];
     const NodeRec& nr = P.nodes[d.node_off + node];
     uint32_t* base = P.scratch + d.scratch_off + (uint32_t)nr.slot * P.Lpad + s.g * K;
@@ -227,57 +238,74 @@ VGK_HD void store_to_scratch(const Lane& s, const GsswParams& P, uint32_t prob, 
     }
 }
 
-// The 16 rows of one lane for one column.  REFN = some half sees an N in the graph
-// (rare): the profile permute cannot express score 0, patch it per row.
-// Returns the four traceback dwords in acc[0..3] and the column key maximum.
-template <bool REFN>
-VGK_HD void lane_rows(Lane& s, const GsswParams& P, uint32_t sel, uint32_t diag0, uint32_t rf,
-                      bool nA, bool nB, uint32_t acc[4], uint32_t& colkey) {
+// best-cell key of a row: score*32 + (31 - row_in_lane), so one packed max keeps
+// the best score and, on ties, the smallest row (scores stay below 2047).
+constexpr uint32_t KEY_SHIFT = 5, KEY_LOW = 31;
+
+// One row (compile-time index M) of one lane for one column.  REFN = some half sees
+// an N in the graph (rare): the profile permute cannot express score 0, patch it.
+template <int K, int M, bool REFN>
+VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, uint32_t go2, uint32_t ge2,
+                     bool nA, bool nB, uint32_t& f, uint32_t& d, uint32_t* acc, uint32_t& ck) {
+    uint32_t sb = byte_perm(s.PB[M], s.PA[M], sel);
+    if (REFN) {
+        const uint32_t row = s.g * K + M;
+        if (nA) sb = set_lo(sb, row < s.LA ? P.bias + row_bonus(P, row, s.LA, s.flagsA) : 0u);
+        if (nB) sb = set_hi(sb, row < s.LB ? P.bias + row_bonus(P, row, s.LB, s.flagsB) : 0u);
+    }
+    const uint32_t old = s.H[M];
+    const uint32_t t4 = pk_subs(pk_add(d, sb), bias2);     // max(0, diag + s)
+    const uint32_t e = s.E[M];
+    const uint32_t h = pk_max(pk_max(t4, e), f);
+    const uint32_t gg = pk_subs(h, go2);                   // max(0, H - go)
+    const uint32_t e2 = pk_subs(e, ge2), f2 = pk_subs(f, ge2);
+    const uint32_t en = pk_max(gg, e2), fn = pk_max(gg, f2);
+    // traceback code: bit0 = H not from diagonal, bit1 = H not from E (then F),
+    // bit2 = next-column E is an extension, bit3 = next-row F is an extension.
+    // min(x, 1) with an opaque `one` keeps each flag at 2 packed ops; the merges are v_pk_mad_u16.
+    const uint32_t one = s.one;
+    const uint32_t nd = pk_min(pk_sub(h, t4), one);
+    const uint32_t ne = pk_min(pk_sub(h, e), one);
+    const uint32_t eb = pk_min(pk_subs(e2, gg), one);
+    const uint32_t fb = pk_min(pk_subs(f2, gg), one);
+    uint32_t code = pk_mul_add_imm<2>(ne, nd);
+    code = pk_mul_add_imm<4>(eb, code);
+    code = pk_mul_add_imm<8>(fb, code);
+    acc[M >> 2] = (M & 3) == 0 ? code : pk_mul_add_imm<16>(acc[M >> 2], code);
+    const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(h, 0x00010001u << KEY_SHIFT);
+    ck = M == 0 ? key : pk_max(ck, key);
+    s.H[M] = h; s.E[M] = en; f = fn; d = old;
+}
+
+template <int K, int M, bool REFN>
+VGK_HD void lane_rows_from(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, uint32_t go2, uint32_t ge2,
+                           bool nA, bool nB, uint32_t& f, uint32_t& d, uint32_t* acc, uint32_t& ck) {
+    lane_row<K, M, REFN>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+    if constexpr (M + 1 < K) lane_rows_from<K, M + 1, REFN>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+}
+
+// The K rows of one lane for one column; returns the K/4 traceback dwords and the column key maximum.
+template <int K, bool REFN>
+VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t diag0, uint32_t rf,
+                      bool nA, bool nB, uint32_t* acc, uint32_t& colkey) {
     uint32_t bias2 = rep2(P.bias), go2 = rep2(P.go), ge2 = rep2(P.ge);
 #if defined(__HIP_DEVICE_COMPILE__)
     // The rare N variant must stay a separate branch: with opaque copies of its inputs the
-    // optimiser cannot hoist "common" permutes/subtracts of all 16 rows above the branch
+    // optimiser cannot hoist "common" permutes/subtracts of all rows above the branch
     // (that hoisting cost 32 live VGPRs and spilled the hot loop).
     if (REFN) asm volatile("" : "+v"(sel), "+v"(bias2), "+v"(go2), "+v"(ge2));
 #endif
-    const uint32_t one = s.one, sixteen = 0x00100010u;
     uint32_t f = rf, d = diag0, ck = 0;
-#pragma unroll
-    for (int m = 0; m < K; ++m) {
-        uint32_t sb = byte_perm(s.PB[m], s.PA[m], sel);
-        if (REFN) {
-            const uint32_t row = s.g * K + m;
-            if (nA) sb = set_lo(sb, row < s.LA ? P.bias + row_bonus(P, row, s.LA, s.flagsA) : 0u);
-            if (nB) sb = set_hi(sb, row < s.LB ? P.bias + row_bonus(P, row, s.LB, s.flagsB) : 0u);
-        }
-        const uint32_t old = s.H[m];
-        const uint32_t t4 = pk_subs(pk_add(d, sb), bias2);     // max(0, diag + s)
-        const uint32_t e = s.E[m];
-        const uint32_t h = pk_max(pk_max(t4, e), f);
-        const uint32_t gg = pk_subs(h, go2);                   // max(0, H - go)
-        const uint32_t e2 = pk_subs(e, ge2), f2 = pk_subs(f, ge2);
-        const uint32_t en = pk_max(gg, e2), fn = pk_max(gg, f2);
-        // traceback code: bit0 = H not from diagonal, bit1 = H not from E (then F),
-        // bit2 = next-column E is an extension, bit3 = next-row F is an extension.
-        // min(x, 1) with an opaque `one` keeps this as 2 packed ops per flag.
-        const uint32_t nd = pk_min(pk_sub(h, t4), one);
-        const uint32_t ne = pk_min(pk_sub(h, e), one);
-        const uint32_t eb = pk_min(pk_subs(e2, gg), one);
-        const uint32_t fb = pk_min(pk_subs(f2, gg), one);
-        const uint32_t code = nd | (ne << 1) | (eb << 2) | (fb << 3);
-        acc[m >> 2] = (m & 3) == 0 ? code : pk_mad(acc[m >> 2], sixteen, code);
-        const uint32_t key = pk_mad(h, sixteen, rep2(15 - m));
-        ck = m == 0 ? key : pk_max(ck, key);
-        s.H[m] = h; s.E[m] = en; f = fn; d = old;
-    }
+    lane_rows_from<K, 0, REFN>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
     s.out_h = s.H[K - 1]; s.out_f = f;
     colkey = ck;
 }
 
 // One step of one lane.  rh/rf/rinfo are lane-1's out_h/out_f/info from the
 // previous step (ignored by group leaders, which start a fresh column).
-// tbrec = this (step, lane)'s 4-dword traceback record, or nullptr.
-VGK_HD void lane_step(Lane& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tbrec) {
+// tbrec = this (step, lane)'s K/4-dword traceback record, or nullptr.
+template <int K>
+VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tbrec) {
     if (s.g == 0) { rh = 0; rf = 0; rinfo = fetch_info(s, P, t); }
     s.info = rinfo;
     const uint32_t ia = rinfo & 0xffu, ib = (rinfo >> 16) & 0xffu;
@@ -286,21 +314,24 @@ VGK_HD void lane_step(Lane& s, const GsswParams& P, uint32_t t, uint32_t rh, uin
         uint32_t diag0 = s.prev_rh;
         if (vA && (ia & CI_NODE_START)) s.nodeA += 1;
         if (vB && (ib & CI_NODE_START)) s.nodeB += 1;
-        if (vA && (ia & CI_SEED_SLOW)) seed_from_scratch<0>(s, P, s.probA, s.nodeA, diag0);
-        if (vB && (ib & CI_SEED_SLOW)) seed_from_scratch<1>(s, P, s.probB, s.nodeB, diag0);
+        if (vA && (ia & CI_SEED_SLOW)) seed_from_scratch<0, K>(s, P, s.probA, s.nodeA, diag0);
+        if (vB && (ib & CI_SEED_SLOW)) seed_from_scratch<1, K>(s, P, s.probB, s.nodeB, diag0);
         // selector: byte0 <- PA[baseA], byte2 <- PB[baseB] (bytes 4..7 of the permute), bytes 1,3 <- 0
         const uint32_t sel = (rinfo & 0x00030003u) | 0x0c040c00u;
         const bool nA = vA && (ia & CI_BASE_MASK) == 4, nB = vB && (ib & CI_BASE_MASK) == 4;
-        uint32_t acc[4], colkey;
-        if (nA || nB) lane_rows<true>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
-        else          lane_rows<false>(s, P, sel, diag0, rf, false, false, acc, colkey);
-        if (tbrec) { tbrec[0] = acc[0]; tbrec[1] = acc[1]; tbrec[2] = acc[2]; tbrec[3] = acc[3]; }
+        uint32_t acc[K / 4], colkey;
+        if (nA || nB) lane_rows<K, true>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
+        else          lane_rows<K, false>(s, P, sel, diag0, rf, false, false, acc, colkey);
+        if (tbrec) {
+#pragma unroll
+            for (int j = 0; j < K / 4; ++j) tbrec[j] = acc[j];
+        }
         // local end cell: first column with the best score, smallest row (SSW end_ref/end_read rule)
         const uint32_t klo = colkey & 0xffffu, khi = colkey >> 16;
-        if (vA && (klo >> 4) > (s.best_lo >> 4)) { s.best_lo = klo; s.step_lo = t; }
-        if (vB && (khi >> 4) > (s.best_hi >> 4)) { s.best_hi = khi; s.step_hi = t; }
-        if (vA && (ia & CI_STORE_END)) store_to_scratch<0>(s, P, s.probA, s.nodeA);
-        if (vB && (ib & CI_STORE_END)) store_to_scratch<1>(s, P, s.probB, s.nodeB);
+        if (vA && (klo >> KEY_SHIFT) > (s.best_lo >> KEY_SHIFT)) { s.best_lo = klo; s.step_lo = t; }
+        if (vB && (khi >> KEY_SHIFT) > (s.best_hi >> KEY_SHIFT)) { s.best_hi = khi; s.step_hi = t; }
+        if (vA && (ia & CI_STORE_END)) store_to_scratch<0, K>(s, P, s.probA, s.nodeA);
+        if (vB && (ib & CI_STORE_END)) store_to_scratch<1, K>(s, P, s.probB, s.nodeB);
     } else {
         s.out_h = 0; s.out_f = 0;
     }
@@ -308,43 +339,76 @@ VGK_HD void lane_step(Lane& s, const GsswParams& P, uint32_t t, uint32_t rh, uin
 }
 
 // after the last step: publish this lane's best cell (LOCAL mode)
-VGK_HD bool lane_best(const Lane& s, int half, uint32_t& prob, unsigned long long& key) {
+template <int K>
+VGK_HD bool lane_best(const Lane<K>& s, int half, uint32_t& prob, unsigned long long& key) {
     const uint32_t b = half ? s.best_hi : s.best_lo, st = half ? s.step_hi : s.step_lo;
     prob = half ? s.probB : s.probA;
-    if (prob == 0xffffffffu || (b >> 4) == 0) return false;
+    if (prob == 0xffffffffu || (b >> KEY_SHIFT) == 0) return false;
     const uint32_t L = half ? s.LB : s.LA, flags = half ? s.flagsB : s.flagsA;
     if ((flags & 15u) != VGK_GSSW_LOCAL) return false;
-    const uint32_t row = s.g * K + (15 - (b & 15u));
+    const uint32_t row = s.g * K + (KEY_LOW - (b & KEY_LOW));
     if (row >= L) return false;   // cannot win, but never report a padding row
-    key = key64(b >> 4, st - s.g, row);
+    key = key64(b >> KEY_SHIFT, st - s.g, row);
     return true;
 }
 
 // ---------------------------------------------------------------------------
 // traceback walker: one thread per read
 // ---------------------------------------------------------------------------
+// Record index of (step t, lane) inside a wave's traceback region.  Two layouts were
+// measured on MI355X: step-major (fill stores one contiguous burst per
+// step) and blocked (8 consecutive steps of a lane adjacent, kinder to the walker's
+// diagonal moves but 3-10 % slower fill stores).
+#ifndef VGK_TB_BLOCKED
+#define VGK_TB_BLOCKED 0
+#endif
+VGK_HD uint64_t tb_record(uint64_t tb_off, uint32_t t, uint32_t lane) {
+#if VGK_TB_BLOCKED
+    return tb_off + ((uint64_t)(t >> 3) * 64u + lane) * 8u + (t & 7u);
+#else
+    return tb_off + (uint64_t)t * 64u + lane;     // step-major: one contiguous burst per wave store
+#endif
+}
+
 struct Walker {
     const GsswParams& P; const ProbDesc& d; uint32_t half, lane0; uint64_t tb_off;
     VGK_HD uint32_t code(uint32_t r, uint32_t c) const {
-        const uint32_t g = r / K, t = c + g, j = (r & 15u) >> 2, i = r & 3u;
-        const uint32_t w = P.tb[(tb_off + (uint64_t)t * 64 + lane0 + g) * 4 + j];
+        const uint32_t g = r / P.K, m = r - g * P.K, t = c + g, j = m >> 2, i = m & 3u;
+        const uint32_t w = P.tb[tb_record(tb_off, t, lane0 + g) * (P.K >> 2) + j];
         return (w >> (16 * half + 4 * (3 - i))) & 15u;
     }
+    // aligned-dword caches of the read codes and the column-info bytes: the walk moves one
+    // row / one column at a time, so each cached word serves up to four steps
+    mutable uint32_t rd_word = 0, rd_base = 0xffffffffu, ci_word = 0, ci_base = 0xffffffffu;
+    VGK_HD uint32_t read_code(uint32_t r) const {
+        const uint32_t a = d.read_off + r, b = a & ~3u;
+        if (b != rd_base) { rd_base = b; rd_word = *(const uint32_t*)(P.reads + b); }
+        return (rd_word >> (8 * (a & 3u))) & 0xffu;
+    }
+    VGK_HD uint32_t col_base(uint32_t c) const {
+        const uint32_t a = d.col_off + c, b = a & ~3u;
+        if (b != ci_base) { ci_base = b; ci_word = *(const uint32_t*)(P.colinfo + b); }
+        return (ci_word >> (8 * (a & 3u))) & CI_BASE_MASK;
+    }
     VGK_HD int32_t score(uint32_t r, uint32_t c) const {
-        const uint32_t base = P.colinfo[d.col_off + c] & CI_BASE_MASK, q = P.reads[d.read_off + r];
-        return (int32_t)P.matrix[5 * base + q] + (int32_t)row_bonus(P, r, d.L, d.flags);
+        const uint32_t base = col_base(c), q = read_code(r);
+        // profile word of read base q (wave-uniform table, per-thread select), byte = reference base
+        uint32_t w = P.prof4[0];
+        w = q == 1 ? P.prof4[1] : w; w = q == 2 ? P.prof4[2] : w; w = q == 3 ? P.prof4[3] : w; w = q == 4 ? P.prof4[4] : w;
+        const int32_t s = base < 4 ? (int32_t)((w >> (8 * base)) & 0xffu) - (int32_t)P.bias : 0;
+        return s + (int32_t)row_bonus(P, r, d.L, d.flags);
     }
     VGK_HD uint32_t saved(const NodeRec& n, uint32_t r) const { return P.scratch[d.scratch_off + (uint32_t)n.slot * P.Lpad + r]; }
 };
 
-VGK_HD void walk_one(const GsswParams& P, uint32_t i) {
+VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
     const ProbDesc& d = P.probs[i];
     vgk_result res;
     res.score = 0; res.status = VGK_OK; res.end_node = -1; res.end_offset = -1; res.end_read = -1;
     res.first_offset = 0; res.n_ops = 0; res.ops_begin = d.ops_off;
     const uint32_t pair = i >> 1;
     const uint32_t wave = pair / P.groups_per_wave, slot = pair - wave * P.groups_per_wave;
-    Walker w{P, d, i & 1u, slot * P.G, P.waves[wave].tb_off};
+    Walker w{P, d, i & 1u, slot * P.G, P.waves[wave].tb_off, 0u, 0xffffffffu, 0u, 0xffffffffu};
     const NodeRec* nodes = P.nodes + d.node_off;
     const bool pinned = (d.flags & 15u) == VGK_GSSW_PINNED;
     const int32_t go = (int32_t)P.go, ge = (int32_t)P.ge;
@@ -360,7 +424,7 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i) {
         }
         if (have) c = nodes[node].col_end - 1;
     } else {
-        const unsigned long long k = P.best[i];
+        const unsigned long long k = best_key;
         cur = (int32_t)(k >> 40);
         if (cur > 0) {
             have = true;
@@ -372,46 +436,65 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i) {
         }
     }
     if (pinned && !have) { res.status = VGK_EINVAL; P.results[i] = res; return; }
-    if (cur >= 4095) { res.status = VGK_EOVERFLOW; P.results[i] = res; return; }
+    if (cur >= 2047) { res.status = VGK_EOVERFLOW; P.results[i] = res; return; }
     if (!have || cur <= 0) { P.results[i] = res; return; }     // score 0: the caller synthesises soft clips
     res.score = cur; res.end_node = (int32_t)node; res.end_offset = (int32_t)(c - nodes[node].col_start); res.end_read = r;
     if (!(d.flags & VGK_GSSW_TRACEBACK)) { P.results[i] = res; return; }
 
-    // ops are produced back to front into the tail of this read's window
+    // CIGAR elements are produced back to front into the tail of this read's window.  The run being
+    // built lives in registers (rn, ro, rl) and is written once, when a different (node, op) starts.
     vgk_op* ops = P.ops + d.ops_off;
     uint32_t pos = d.ops_cap;   // first used slot
     int32_t status = VGK_OK;
+    uint32_t rn = 0, ro = 0xffu, rl = 0;
+#define VGK_FLUSH() do { if (rl) { if (pos == 0) status = VGK_EOPS; else { --pos; \
+        ops[pos].node = rn; ops[pos].len = (uint16_t)rl; ops[pos].op = (uint8_t)ro; ops[pos].pad = 0; } } } while (0)
 #define VGK_PUSH(NODE, OP, LEN) do { \
-        if (pos < d.ops_cap && ops[pos].node == (uint32_t)(NODE) && ops[pos].op == (uint8_t)(OP)) ops[pos].len = (uint16_t)(ops[pos].len + (LEN)); \
-        else if (pos == 0) { status = VGK_EOPS; } \
-        else { --pos; ops[pos].node = (uint32_t)(NODE); ops[pos].op = (uint8_t)(OP); ops[pos].len = (uint16_t)(LEN); ops[pos].pad = 0; } } while (0)
+        if (rl && rn == (uint32_t)(NODE) && ro == (uint32_t)(OP)) rl += (LEN); \
+        else { VGK_FLUSH(); rn = (uint32_t)(NODE); ro = (uint32_t)(OP); rl = (LEN); } } while (0)
 
     if (r < (int32_t)d.L - 1) VGK_PUSH(node, VGK_OP_S, d.L - 1 - (uint32_t)r);
     enum { ST_H, ST_E, ST_F } st = ST_H;
     uint32_t first_c = c;
-    // every iteration consumes a read base, a graph base or changes state once: bounded by 2(L+R)+2
+    uint32_t node_start = nodes[node].col_start;
+    // every iteration consumes a read base, a graph base or changes state once: bounded by 2(L+R)+4
     for (uint32_t guard = 0; guard < 2 * (d.L + d.R) + 4 && status == VGK_OK; ++guard) {
-        const bool first = (c == nodes[node].col_start);
+        const bool first = (c == node_start);
+        (void)first;
         if (st == ST_H) {
             if (cur == 0) break;
-            const uint32_t fl = w.code((uint32_t)r, c);
-            if (!(fl & 1u)) {
+            // Alignments are mostly diagonal runs: fetch the codes and scores of the next (up to) four
+            // diagonal cells together so their memory latencies overlap, then consume them in order.
+            const uint32_t room = c - node_start + 1, rows = (uint32_t)r + 1;
+            uint32_t nspec = room < rows ? room : rows; nspec = nspec < 4 ? nspec : 4;
+            uint32_t fl[4]; int32_t sc[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                fl[k] = 1u; sc[k] = 0;
+                if (k < nspec) { fl[k] = w.code((uint32_t)r - k, c - k); sc[k] = w.score((uint32_t)r - k, c - k); }
+            }
+            if (fl[0] & 1u) { st = (fl[0] & 2u) ? ST_F : ST_E; continue; }
+            bool stop = false;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (stop || k >= nspec || (fl[k] & 1u) || cur == 0) { stop = true; continue; }
                 VGK_PUSH(node, VGK_OP_M, 1); first_c = c;
-                cur -= w.score((uint32_t)r, c); r -= 1;
-                if (r < 0 || cur == 0) break;
-                if (!first) c -= 1;
+                cur -= sc[k]; r -= 1;
+                if (r < 0 || cur == 0) { stop = true; continue; }
+                if (c != node_start) c -= 1;
                 else {
                     const NodeRec& nr = nodes[node];
                     int32_t found = -1;
                     if (nr.n_pred == 1) found = (int32_t)P.preds[nr.pred_begin];
-                    else for (uint32_t k = 0; k < nr.n_pred; ++k) {
-                        const uint32_t p = P.preds[nr.pred_begin + k];
+                    else for (uint32_t kk = 0; kk < nr.n_pred; ++kk) {
+                        const uint32_t p = P.preds[nr.pred_begin + kk];
                         if ((int32_t)(w.saved(nodes[p], (uint32_t)r) & 0xffffu) == cur) { found = (int32_t)p; break; } }
-                    if (found < 0) { status = VGK_EINVAL; break; }
-                    node = (uint32_t)found; c = nodes[node].col_end - 1;
+                    if (found < 0) { status = VGK_EINVAL; stop = true; continue; }
+                    node = (uint32_t)found; c = nodes[node].col_end - 1; node_start = nodes[node].col_start;
+                    stop = true;      // speculation never crosses a node boundary
                 }
-            } else if (!(fl & 2u)) st = ST_E;
-            else st = ST_F;
+            }
+            if (r < 0 || cur == 0) break;
         } else if (st == ST_E) {
             VGK_PUSH(node, VGK_OP_D, 1); first_c = c;
             uint32_t pnode = node, pc = c - 1;
@@ -423,7 +506,7 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i) {
                     const uint32_t p = P.preds[nr.pred_begin + k];
                     if ((int32_t)(w.saved(nodes[p], (uint32_t)r) >> 16) == cur) { found = (int32_t)p; break; } }
                 if (found < 0) { status = VGK_EINVAL; break; }
-                pnode = (uint32_t)found; pc = nodes[pnode].col_end - 1;
+                pnode = (uint32_t)found; pc = nodes[pnode].col_end - 1; node_start = nodes[pnode].col_start;
             }
             if (!(w.code((uint32_t)r, pc) & 4u)) { st = ST_H; cur += go; } else cur += ge;
             c = pc; node = pnode;
@@ -435,11 +518,13 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i) {
         }
     }
     if (status == VGK_OK && r >= 0) VGK_PUSH(node, VGK_OP_S, (uint32_t)r + 1);
+    if (status == VGK_OK) VGK_FLUSH();
 #undef VGK_PUSH
+#undef VGK_FLUSH
     res.status = status;
     if (status == VGK_OK) {
         res.n_ops = d.ops_cap - pos; res.ops_begin = d.ops_off + pos;
-        res.first_offset = (int32_t)(first_c - nodes[node].col_start);
+        res.first_offset = (int32_t)(first_c - node_start);
     }
     P.results[i] = res;
 }

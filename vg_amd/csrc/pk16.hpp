@@ -28,6 +28,13 @@ static __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { retu
 static __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return as_u(as_v(a) * as_v(b) + as_v(c)); }
 // byte permute: selector byte k picks byte (sel&7) of {hi:lo} = {a:b}; 0x0c -> 0x00
 static __device__ __forceinline__ uint32_t byte_perm(uint32_t a, uint32_t b, uint32_t sel) { return __builtin_amdgcn_perm(a, b, sel); }
+// a*M + c per half, M an inline constant: exactly one v_pk_mad_u16 (hipcc otherwise
+// expands small-constant multiplies into shift + SDWA-or sequences)
+template <int M> static __device__ __forceinline__ uint32_t pk_mul_add_imm(uint32_t a, uint32_t c) {
+    uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "n"(M), "v"(c)); return r; }
+// a*b + C per half, b a wave-uniform packed multiplier, C an inline constant
+template <int C> static __device__ __forceinline__ uint32_t pk_mad_add_imm(uint32_t a, uint32_t b) {
+    uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "s"(b), "n"(C)); return r; }
 #else
 static inline uint32_t pk_lo(uint32_t x) { return x & 0xffffu; }
 static inline uint32_t pk_hi(uint32_t x) { return x >> 16; }
@@ -39,6 +46,8 @@ static inline uint32_t pk_subs(uint32_t a, uint32_t b) { return pk_mk(sat_sub16(
 static inline uint32_t pk_max(uint32_t a, uint32_t b) { return pk_mk(pk_lo(a) > pk_lo(b) ? pk_lo(a) : pk_lo(b), pk_hi(a) > pk_hi(b) ? pk_hi(a) : pk_hi(b)); }
 static inline uint32_t pk_min(uint32_t a, uint32_t b) { return pk_mk(pk_lo(a) < pk_lo(b) ? pk_lo(a) : pk_lo(b), pk_hi(a) < pk_hi(b) ? pk_hi(a) : pk_hi(b)); }
 static inline uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return pk_mk(pk_lo(a) * pk_lo(b) + pk_lo(c), pk_hi(a) * pk_hi(b) + pk_hi(c)); }
+template <int M> static inline uint32_t pk_mul_add_imm(uint32_t a, uint32_t c) { return pk_mad(a, (uint32_t)M * 0x00010001u, c); }
+template <int C> static inline uint32_t pk_mad_add_imm(uint32_t a, uint32_t b) { return pk_mad(a, b, (uint32_t)C * 0x00010001u); }
 static inline uint32_t byte_perm(uint32_t a, uint32_t b, uint32_t sel) {
     uint64_t src = ((uint64_t)a << 32) | b;
     uint32_t out = 0;

@@ -6,6 +6,7 @@
 // unordered_map — but emits flat arrays: a per-column info byte stream (base code +
 // node-boundary flags), a node table, a predecessor CSR and a per-read descriptor.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -139,10 +140,21 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         if (problems[i].read_len == 0 || !problems[i].read || problems[i].graph.n_nodes == 0) return VGK_EINVAL;
         maxL = std::max(maxL, problems[i].read_len);
     }
+    if (maxL > 1024) return VGK_ETOOLONG;
+    // rows per lane: the instantiation (16, 20, 24) that spends the fewest issued instructions per
+    // useful DP cell: (K*c_row + c_step) per step buys floor(64/G)*2*L cells, G = ceil(L/K)
+    uint32_t K = 16; double best_cost = 1e30;
+    uint32_t forced = 0;
+    if (const char* e = std::getenv("VGAMD_ROWS_PER_LANE")) forced = (uint32_t)std::atoi(e);
+    for (uint32_t k : {16u, 20u, 24u}) {
+        const uint32_t g = (maxL + k - 1) / k;
+        if (g > 64) continue;
+        const double cost = (k * 25.0 + 60.0) / ((64 / g) * 2.0 * maxL);
+        if ((forced == k) || (!forced && cost < best_cost)) { best_cost = forced == k ? -1 : cost; K = k; }
+    }
     const uint32_t G = (maxL + K - 1) / K;
-    if (G > 64) return VGK_ETOOLONG;
-    // best-cell keys pack score*16 + row: keep every reachable score below 4095
-    if ((int64_t)maxL * std::max(ctx->max_score, 0) + 2 * (int64_t)ctx->sc.full_length_bonus > 4094) return VGK_EUNSUPPORTED;
+    // best-cell keys pack score*32 + row: keep every reachable score below 2047
+    if ((int64_t)maxL * std::max(ctx->max_score, 0) + 2 * (int64_t)ctx->sc.full_length_bonus > 2046) return VGK_EUNSUPPORTED;
     const uint32_t gpw = 64 / G, Lpad = G * K;
     const uint32_t n_pairs = (n + 1) / 2, n_waves = (n_pairs + gpw - 1) / gpw;
 
@@ -223,7 +235,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         waves[w].first_pair = w * gpw;
         waves[w].n_steps = rmax ? rmax + G - 1 : 0;
         waves[w].tb_off = tb_recs;
-        if (b->want_tb) tb_recs += (uint64_t)waves[w].n_steps * 64;
+        if (b->want_tb) tb_recs += (uint64_t)((waves[w].n_steps + 7) & ~7u) * 64;   // records of K/4 dwords, steps in blocks of 8
     }
 
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -238,14 +250,17 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     if ((rc = to_device(b, preds, P.preds, 1))) return fail(rc);
     if ((rc = to_device(b, waves, P.waves))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)scratch_words + 16, P.scratch))) return fail(rc);
-    if ((rc = dev_alloc(b, (size_t)tb_recs * 4 + 4, P.tb))) return fail(rc);
+    if ((rc = dev_alloc(b, (size_t)tb_recs * (K / 4) + 4, P.tb))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)n + 1, P.best))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)n + 1, P.results))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)ops_total + 1, P.ops))) return fail(rc);
-    P.n_problems = n; P.n_pairs = n_pairs; P.n_waves = n_waves; P.G = G; P.groups_per_wave = gpw; P.Lpad = Lpad;
+    P.wave_begin = 0; P.wave_count = n_waves; P.prob_begin = 0; P.prob_count = n;
+    P.n_problems = n; P.n_pairs = n_pairs; P.n_waves = n_waves; P.K = K; P.G = G; P.groups_per_wave = gpw; P.Lpad = Lpad;
     for (int q = 0; q < 5; ++q) P.prof4[q] = ctx->prof4[q];
     P.bias = ctx->bias; P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend; P.bonus = ctx->sc.full_length_bonus;
     P.want_tb = b->want_tb ? 1 : 0;
+    P.fused = 0;
+    if (const char* e = std::getenv("VGAMD_FUSED_TRACEBACK")) P.fused = std::atoi(e) ? 1 : 0;
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = ops_total;
     if ((rc = ctx->be->sync())) return fail(rc);     // inputs are resident in HBM when pack returns
@@ -311,7 +326,7 @@ int vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
 double vgk_batch_kernel_ms(vgk_batch* b, int which) {
     if (!b) return 0.0;
     std::lock_guard<std::mutex> lk(b->ctx->mu);
-    if (which == 0 || which == 1) return b->ctx->be->last_ms(which);
+    if (which == 0 || which == 1 || which == 2) return b->ctx->be->last_ms(which);
     return b->ctx->be->last_ms(0) + b->ctx->be->last_ms(1);
 }
 uint64_t vgk_batch_cells(vgk_batch* b) { return b ? b->cells : 0; }
