@@ -35,9 +35,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from vg_amd import shard
+    rank, local_rank, world = shard.env_rank()
     import torch   # first, so its bundled HIP runtime is the one the engine library binds to
     dist = None
     if world > 1:

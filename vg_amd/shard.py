@@ -1,0 +1,34 @@
+"""Read-stream sharding across the GPUs of one node.
+
+Every (read, subgraph) problem is independent, so the stream is cut into
+contiguous blocks, one per rank (one process per GPU); there is NO data-path
+collective.  torch.distributed is used only for the barrier / MAX-reduce of the
+timing in bench.py and for gathering results in tests.
+"""
+import os
+
+
+def env_rank():
+    """(rank, local_rank, world_size) as torch.distributed.run exports them."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous block [begin, end) of a stream of n_total problems for `rank`; sizes differ by <= 1."""
+    base, extra = divmod(n_total, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def align_shard(engine, problems, rank, world, ops_per_problem=0):
+    """Align this rank's block of `problems` (a list of problem dicts) and return
+    (begin, results, cigars) with results as a numpy record array."""
+    from . import capi
+    begin, end = shard_range(len(problems), rank, world)
+    if end == begin:
+        return begin, None, []
+    ps = capi.ProblemSet.from_lists(problems[begin:end])
+    res, ops = engine.align(ps, ops_per_problem)
+    cigars = [capi.cigar_string(res[i], ops) if res["score"][i] > 0 else "" for i in range(ps.n)]
+    return begin, res, cigars
