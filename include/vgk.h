@@ -10,13 +10,13 @@
  *                             gssw_graph_trace_back /
  *                             gssw_graph_trace_back_pinned_multi
  *                             (src/aligner.cpp:30-85, 396-435, 537-557, 575-611)
- *   vgk_xdrop_*     replaces  dz_init / dz_pack_query_* / dz_extend / dz_trace
+ *   vgk_gssw_* with mode VGK_XDROP_PINNED
+ *                   replaces  dz_init / dz_pack_query_* / dz_extend / dz_trace
  *                             as driven by DozeuInterface::align_pinned
  *                             (src/dozeu_interface.cpp:210-307, 687-766)
- *   vgk_banded_*    replaces  BandedGlobalAligner<IntType>::align
- *                             (src/banded_global_aligner.cpp:250-742, 2295-2423)
- *   vgk_gapless_*   replaces  GaplessExtender match_initial/forward/backward +
- *                             set_score (src/gbwt_extender.cpp:201-296)
+ *   (planned, not in this ABI version: banded global alignment replacing
+ *    BandedGlobalAligner<IntType>::align, gapless extension replacing
+ *    GaplessExtender::match_*)
  *
  * Everything is plain pointers and sizes.  All "graphs" handed over are DAGs
  * whose nodes are ALREADY in the topological order the reference would use
@@ -110,6 +110,12 @@ typedef struct vgk_result {
 enum { VGK_GSSW_LOCAL       = 0,  /* Aligner::align: bonus at both ends (src/aligner.cpp:399-402) */
        VGK_GSSW_PINNED      = 1,  /* Aligner::align_pinned (right-pinned; the caller reverses
                                      graph+read for pin_left, src/aligner.cpp:365-383)            */
+       VGK_XDROP_PINNED     = 2,  /* Aligner::align_pinned(..., xdrop = true): dozeu semantics
+                                     (DozeuInterface::align_pinned, src/dozeu_interface.cpp:724-766):
+                                     LEFT-pinned semi-global extension from every source node, bonus
+                                     on consuming the last read base only, no local restart; the
+                                     caller reverses graph+read for a right pin.  Runs on the same
+                                     kernels and entry points as the gssw modes.                  */
        VGK_GSSW_TRACEBACK   = 16  /* OR-ed in: produce CIGAR; otherwise score + end only
                                      (src/aligner.cpp:550-557)                                    */ };
 
@@ -120,6 +126,9 @@ typedef struct vgk_gssw_problem {
     vgk_graph      graph;
     const uint8_t* pinning;      /* PINNED only: [n_nodes] 1 = pinning node
                                     (identify_pinning_points, src/aligner.cpp:87-118)  */
+    uint32_t       max_gap_length; /* XDROP only: dozeu max_gap_length (dz_align_init; clamped to >= 1,
+                                      src/aligner.cpp:638) — bounds the leading insertion         */
+    uint32_t       reserved;
 } vgk_gssw_problem;
 
 typedef struct vgk_ctx   vgk_ctx;     /* one per (device, scoring) — like one Aligner      */

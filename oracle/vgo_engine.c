@@ -15,6 +15,12 @@
 
 int vgo_gssw_align(const vgk_scoring* sc, const vgk_gssw_problem* p,
                    vgk_result* res, vgk_op* ops, uint32_t ops_cap);
+int vgo_xdrop_pinned_align(const vgk_scoring* sc, const vgk_gssw_problem* p,
+                           vgk_result* res, vgk_op* ops, uint32_t ops_cap);
+static int vgo_dispatch(const vgk_scoring* sc, const vgk_gssw_problem* p, vgk_result* res, vgk_op* ops, uint32_t ops_cap) {
+    return (p->flags & 15u) == VGK_XDROP_PINNED ? vgo_xdrop_pinned_align(sc, p, res, ops, ops_cap)
+                                                : vgo_gssw_align(sc, p, res, ops, ops_cap);
+}
 
 struct vgk_ctx { vgk_scoring sc; };
 struct vgk_batch {
@@ -85,7 +91,7 @@ int vgk_gssw_run(vgk_batch* b) {
     if (!b) return VGK_EINVAL;
     #pragma omp parallel for schedule(dynamic, 16)
     for (int64_t i = 0; i < (int64_t)b->n; ++i)
-        vgo_gssw_align(&b->ctx->sc, &b->probs[i], &b->res[i], b->ops + (size_t)i * b->ops_per, b->ops_per);
+        vgo_dispatch(&b->ctx->sc, &b->probs[i], &b->res[i], b->ops + (size_t)i * b->ops_per, b->ops_per);
     b->ran = 1; return VGK_OK;
 }
 

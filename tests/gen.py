@@ -75,6 +75,16 @@ def random_problem(rng, max_nodes=10, max_node_len=12, max_read=120, mode=None, 
         mode = capi.VGK_GSSW_PINNED if rng.random() < 0.4 else capi.VGK_GSSW_LOCAL
     flags = mode | (capi.VGK_GSSW_TRACEBACK if traceback else 0)
     pinning = None
+    if mode == capi.VGK_XDROP_PINNED:
+        # dozeu pinned extension: reads that start at a source node make the interesting cases
+        if rng.random() < 0.7:
+            src = [v for v, pr in enumerate(preds) if not pr]
+            v = src[int(rng.integers(0, len(src)))]
+            walk = random_walk_read(rng, nodes[v:v + 1] + nodes[v + 1:], [[]] + [[q - v for q in pr if q >= v] for pr in preds[v + 1:]], L)
+            # restart the walk at offset 0 of the source: simplest is to take the source sequence then continue
+            read = (nodes[v] + read)[:max(1, L)] if rng.random() < 0.5 else walk
+        return {"read": read, "nodes": nodes, "preds": preds, "flags": flags, "pinning": None,
+                "max_gap": int(rng.integers(0, 60))}
     if mode == capi.VGK_GSSW_PINNED:
         has_succ = [False] * n_nodes
         for v, pr in enumerate(preds):

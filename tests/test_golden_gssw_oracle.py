@@ -47,3 +47,30 @@ def test_oracle_matches_reference_pinned_alignment_unit_tests():
     cases = _cases("ref_pinned_alignment.json", {"align_pinned"})
     assert len(cases) >= 28
     assert run_group(cases, ORACLE_LIB) >= 400
+
+
+def _run_xdrop(case, engine_lib):
+    al = HostAligner(engine_lib, tuple(case["scores"]))
+    args = case["args"]          # [graph, pin_left, xdrop, max_gap?]
+    max_gap = args[3] if len(args) > 3 and isinstance(args[3], int) else 40
+    return al.run(case["nodes"], case["edges"], case["read"], "align_pinned_xdrop", pin_left=bool(args[1]), max_alt_alns=max_gap)
+
+
+def xdrop_pinned_cases():
+    return [c for c in load_golden("ref_xdrop_aligner.json")
+            if c["call"] == "align_pinned" and not c["qual_adj"] and len(c["args"]) >= 3 and c["args"][2] is True]
+
+
+def run_xdrop_group(engine_lib):
+    n = 0
+    cases = xdrop_pinned_cases()
+    for c in cases:
+        aln = _run_xdrop(c, engine_lib)
+        check_expectations(c, aln, {c["aln"]: aln["score"]})
+        n += len(c["expect"])
+    return len(cases), n
+
+
+def test_oracle_matches_reference_xdrop_pinned_unit_tests():
+    ncase, nexp = run_xdrop_group(ORACLE_LIB)
+    assert ncase >= 15 and nexp >= 80

@@ -60,3 +60,15 @@ def test_emulated_kernel_matches_oracle_long_reads_and_scoring(emu_lib):
     compare(emu_lib, ORACLE_LIB, problems, capi.Scoring.simple(2, 3, 5, 2, 7))
     problems = [random_problem(rng, max_nodes=6, max_node_len=8, max_read=40) for _ in range(100)]
     compare(emu_lib, ORACLE_LIB, problems, capi.Scoring.simple(1, 4, 6, 1, 0))
+
+
+def test_emulated_xdrop_pinned_matches_oracle(emu_lib):
+    rng = np.random.default_rng(4242)
+    problems = [random_problem(rng, mode=capi.VGK_XDROP_PINNED) for _ in range(600)]
+    problems += [random_problem(rng, mode=capi.VGK_XDROP_PINNED, with_n=0.2, max_read=300, max_node_len=40) for _ in range(100)]
+    problems += [random_problem(rng, mode=capi.VGK_XDROP_PINNED, traceback=False) for _ in range(100)]
+    res = compare(emu_lib, ORACLE_LIB, problems)
+    assert (res["score"] > 0).sum() > 300
+    # mixed batch: all three modes side by side in the same wavefronts
+    mixed = [random_problem(rng, mode=m) for m in (capi.VGK_GSSW_LOCAL, capi.VGK_GSSW_PINNED, capi.VGK_XDROP_PINNED) * 100]
+    compare(emu_lib, ORACLE_LIB, mixed)

@@ -58,3 +58,20 @@ def test_reference_unit_test_vectors_through_host_shim_on_hip():
     assert run_group(cases, ENGINE_LIB) >= 40
     cases = _cases("ref_pinned_alignment.json", {"align_pinned"})
     assert run_group(cases, ENGINE_LIB) >= 400
+
+
+def test_hip_xdrop_pinned_matches_oracle_and_mixes_with_gssw_modes():
+    rng = np.random.default_rng(4242)
+    problems = [random_problem(rng, mode=capi.VGK_XDROP_PINNED) for _ in range(2000)]
+    problems += [random_problem(rng, mode=capi.VGK_XDROP_PINNED, with_n=0.2, max_read=300, max_node_len=40) for _ in range(300)]
+    problems += [random_problem(rng, mode=capi.VGK_XDROP_PINNED, traceback=False) for _ in range(200)]
+    res = compare(ENGINE_LIB, ORACLE_LIB, problems)
+    assert (res["score"] > 0).sum() > 1000
+    mixed = [random_problem(rng, mode=m) for m in (capi.VGK_GSSW_LOCAL, capi.VGK_GSSW_PINNED, capi.VGK_XDROP_PINNED) * 300]
+    compare(ENGINE_LIB, ORACLE_LIB, mixed)
+
+
+def test_reference_xdrop_unit_test_vectors_through_host_shim_on_hip():
+    from test_golden_gssw_oracle import run_xdrop_group
+    ncase, nexp = run_xdrop_group(ENGINE_LIB)
+    assert ncase >= 15 and nexp >= 80

@@ -57,7 +57,7 @@ class HostAligner:
             for a, b in edges:
                 assert self.h.vgh_graph_add_edge(g, a, b) == 0
             buf = ctypes.create_string_buffer(1 << 20)
-            code = {"align": 0, "align_score": 1, "align_pinned": 2, "align_pinned_multi": 3}[call]
+            code = {"align": 0, "align_score": 1, "align_pinned": 2, "align_pinned_multi": 3, "align_pinned_xdrop": 4}[call]
             rc = self.h.vgh_align(self.ptr, g, read.encode(), code, int(pin_left), max_alt_alns, buf, len(buf))
             if rc != 0:
                 raise RuntimeError(self.h.vgh_last_error().decode())

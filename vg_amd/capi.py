@@ -16,6 +16,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libvgamd.so")
 VGK_OK = 0
 VGK_GSSW_LOCAL = 0
 VGK_GSSW_PINNED = 1
+VGK_XDROP_PINNED = 2
 VGK_GSSW_TRACEBACK = 16
 OP_M, OP_I, OP_D, OP_S = 0, 1, 2, 3
 OP_CHARS = "MIDS"
@@ -23,11 +24,12 @@ OP_CHARS = "MIDS"
 # struct layouts (must match include/vgk.h)
 GRAPH_DT = np.dtype([("n_nodes", "<u4"), ("_pad", "<u4"), ("node_len", "<u8"), ("seq", "<u8"),
                      ("pred_off", "<u8"), ("pred_idx", "<u8")])
-PROBLEM_DT = np.dtype([("read", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), ("graph", GRAPH_DT), ("pinning", "<u8")])
+PROBLEM_DT = np.dtype([("read", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), ("graph", GRAPH_DT), ("pinning", "<u8"),
+                       ("max_gap_length", "<u4"), ("reserved", "<u4")])
 RESULT_DT = np.dtype([("score", "<i4"), ("status", "<i4"), ("end_node", "<i4"), ("end_offset", "<i4"),
                       ("end_read", "<i4"), ("first_offset", "<i4"), ("n_ops", "<u4"), ("ops_begin", "<u4")])
 OP_DT = np.dtype([("node", "<u4"), ("len", "<u2"), ("op", "u1"), ("pad", "u1")])
-assert GRAPH_DT.itemsize == 40 and PROBLEM_DT.itemsize == 64 and RESULT_DT.itemsize == 32 and OP_DT.itemsize == 8
+assert GRAPH_DT.itemsize == 40 and PROBLEM_DT.itemsize == 72 and RESULT_DT.itemsize == 32 and OP_DT.itemsize == 8
 
 
 class Scoring(ctypes.Structure):
@@ -86,7 +88,8 @@ class ProblemSet:
     pred_idx  : uint32 predecessor indices, graph i's edges start at edge_off[i]
     """
 
-    def __init__(self, reads, read_off, node_len, node_off, seq, seq_off, pred_off, pred_idx, edge_off, flags, pinning=None):
+    def __init__(self, reads, read_off, node_len, node_off, seq, seq_off, pred_off, pred_idx, edge_off, flags, pinning=None,
+                 max_gap=None):
         self.reads = np.ascontiguousarray(reads, dtype=np.uint8)
         self.read_off = np.asarray(read_off, dtype=np.int64)
         self.node_len = np.ascontiguousarray(node_len, dtype=np.uint32)
@@ -113,6 +116,8 @@ class ProblemSet:
         arr["graph"] = g
         if self.pinning is not None:
             arr["pinning"] = self.pinning.ctypes.data + self.node_off[:-1]
+        if max_gap is not None:
+            arr["max_gap_length"] = np.asarray(max_gap, dtype=np.uint32)
         self.array = arr
 
     @property
@@ -138,7 +143,7 @@ class ProblemSet:
             pinning.extend(p["pinning"] if p.get("pinning") is not None else [0] * len(nl))
         cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.uint8)
         return cls(cat(reads), read_off, node_len, node_off, cat(seq), seq_off, pred_off, pred_idx, edge_off, flags,
-                   pinning if any_pin else None)
+                   pinning if any_pin else None, [p.get("max_gap", 40) for p in problems])
 
 
 class Engine:

@@ -34,6 +34,11 @@ namespace vgk {
 
 constexpr int KMAX = 24;   // most read rows per lane any instantiation uses
 
+// X-drop (dozeu) mode has no zero floor.  Its scores are carried with a constant offset so that the
+// same unsigned saturating arithmetic applies: a value that saturates at 0 stands for "< -XOFF",
+// which can never rejoin an optimal path as long as L*max_score + bonus < XOFF (checked at pack time).
+constexpr uint32_t XOFF = 1023;
+
 // per-column info byte
 enum : uint32_t {
     CI_BASE_MASK  = 7,     // 0..3 = ACGT, 4 = N
@@ -56,7 +61,7 @@ struct ProbDesc {          // one per read
     uint32_t flags;        // VGK_GSSW_*
     uint32_t ops_off;      // first vgk_op of this read's output window
     uint32_t ops_cap;
-    uint32_t pad;
+    uint32_t max_gap;      // XDROP: leading-insertion cells of the root column (dz_align_init), multiple of 8
 };
 
 struct NodeRec {
@@ -93,7 +98,7 @@ struct GsswParams {
     uint32_t G;                 // lanes per read pair
     uint32_t groups_per_wave;   // 64 / G
     uint32_t Lpad;              // G*K rows per scratch slot
-    uint32_t prof4[5];          // per read base q: byte r = matrix[5r+q] + bias, r = 0..3
+    uint32_t prof4[6];          // per read base q: byte r = matrix[5r+q] + bias, r = 0..3; [5] = 0 (X-drop row 0: consumes nothing)
     uint32_t bias;
     uint32_t go, ge;
     int32_t  bonus;             // full-length bonus
@@ -105,10 +110,12 @@ struct GsswParams {
 VGK_HD uint32_t rep2(uint32_t x) { return (x & 0xffffu) * 0x00010001u; }
 
 VGK_HD uint32_t row_bonus(const GsswParams& P, uint32_t row, uint32_t L, uint32_t flags) {
-    // start bonus on read base 0; end bonus on base L-1 unless pinned (src/aligner.cpp:401-402)
+    // gssw: start bonus on read base 0; end bonus on base L-1 unless pinned (src/aligner.cpp:401-402).
+    // dozeu: one bonus, on consuming the last packed query base (row L-1 of the L = len+1 rows).
+    const uint32_t mode = flags & 15u;
     uint32_t b = 0;
-    if (row == 0) b += (uint32_t)P.bonus;
-    if (row + 1 == L && (flags & 15u) != VGK_GSSW_PINNED) b += (uint32_t)P.bonus;
+    if (row == 0 && mode != VGK_XDROP_PINNED) b += (uint32_t)P.bonus;
+    if (row + 1 == L && mode != VGK_GSSW_PINNED) b += (uint32_t)P.bonus;
     return b;
 }
 
@@ -208,6 +215,26 @@ VGK_HD void seed_from_scratch(Lane<K>& s, const GsswParams& P, uint32_t prob, ui
 #pragma unroll
     for (int m = 0; m < K; ++m) { s.H[m] &= keep; s.E[m] &= keep; }
     diag0 &= keep;
+    if (nr.n_pred == 0 && (d.flags & 15u) == VGK_XDROP_PINNED) {
+        // dozeu root column (dz_align_init): nothing consumed = 0, i leading inserted bases = -(go + (i-1) ge)
+        // for i <= max_gap cells, unreachable beyond; E of the next column opens a deletion from it.
+#pragma unroll
+        for (int m = 0; m <= K; ++m) {
+            const uint32_t row = s.g * K + m - 1;               // m = 0 is the row above this lane's block
+            uint32_t h = 0;
+            if (m > 0 || s.g > 0) {
+                if (row == 0) h = XOFF;
+                else if (row <= d.max_gap) { const uint32_t pen = P.go + (row - 1) * P.ge; h = pen < XOFF ? XOFF - pen : 0; }
+            }
+            if (m == 0) { diag0 |= HALF == 0 ? h : (h << 16); }
+            else {
+                const uint32_t e = h > P.go ? h - P.go : 0;
+                s.H[m - 1] |= HALF == 0 ? h : (h << 16);
+                s.E[m - 1] |= HALF == 0 ? e : (e << 16);
+            }
+        }
+        return;
+    }
     for (uint32_t k = 0; k < nr.n_pred; ++k) {
         const NodeRec& pr = P.nodes[d.node_off + P.preds[nr.pred_begin + k]];
         const uint32_t* base = P.scratch + d.scratch_off + (uint32_t)pr.slot * P.Lpad + s.g * K;
@@ -345,7 +372,7 @@ VGK_HD bool lane_best(const Lane<K>& s, int half, uint32_t& prob, unsigned long 
     prob = half ? s.probB : s.probA;
     if (prob == 0xffffffffu || (b >> KEY_SHIFT) == 0) return false;
     const uint32_t L = half ? s.LB : s.LA, flags = half ? s.flagsB : s.flagsA;
-    if ((flags & 15u) != VGK_GSSW_LOCAL) return false;
+    if ((flags & 15u) == VGK_GSSW_PINNED) return false;
     const uint32_t row = s.g * K + (KEY_LOW - (b & KEY_LOW));
     if (row >= L) return false;   // cannot win, but never report a padding row
     key = key64(b >> KEY_SHIFT, st - s.g, row);
@@ -411,7 +438,9 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
     Walker w{P, d, i & 1u, slot * P.G, P.waves[wave].tb_off, 0u, 0xffffffffu, 0u, 0xffffffffu};
     const NodeRec* nodes = P.nodes + d.node_off;
     const bool pinned = (d.flags & 15u) == VGK_GSSW_PINNED;
+    const bool xdrop = (d.flags & 15u) == VGK_XDROP_PINNED;   // rows = consumed read bases 0..len, scores carry XOFF
     const int32_t go = (int32_t)P.go, ge = (int32_t)P.ge;
+    const int32_t zero = xdrop ? (int32_t)XOFF : 0;            // representation of score 0
 
     int32_t cur = 0; uint32_t c = 0, node = 0; int32_t r = 0;
     bool have = false;
@@ -437,8 +466,9 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
     }
     if (pinned && !have) { res.status = VGK_EINVAL; P.results[i] = res; return; }
     if (cur >= 2047) { res.status = VGK_EOVERFLOW; P.results[i] = res; return; }
-    if (!have || cur <= 0) { P.results[i] = res; return; }     // score 0: the caller synthesises soft clips
-    res.score = cur; res.end_node = (int32_t)node; res.end_offset = (int32_t)(c - nodes[node].col_start); res.end_read = r;
+    if (!have || cur <= zero) { P.results[i] = res; return; }  // score 0: the caller synthesises soft clips / full insertion
+    res.score = cur - zero; res.end_node = (int32_t)node; res.end_offset = (int32_t)(c - nodes[node].col_start);
+    res.end_read = xdrop ? r - 1 : r;
     if (!(d.flags & VGK_GSSW_TRACEBACK)) { P.results[i] = res; return; }
 
     // CIGAR elements are produced back to front into the tail of this read's window.  The run being
@@ -455,6 +485,7 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
 
     if (r < (int32_t)d.L - 1) VGK_PUSH(node, VGK_OP_S, d.L - 1 - (uint32_t)r);
     enum { ST_H, ST_E, ST_F } st = ST_H;
+    bool at_root = false;
     uint32_t first_c = c;
     uint32_t node_start = nodes[node].col_start;
     // every iteration consumes a read base, a graph base or changes state once: bounded by 2(L+R)+4
@@ -462,7 +493,7 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
         const bool first = (c == node_start);
         (void)first;
         if (st == ST_H) {
-            if (cur == 0) break;
+            if (!xdrop && cur == 0) break;
             // Alignments are mostly diagonal runs: fetch the codes and scores of the next (up to) four
             // diagonal cells together so their memory latencies overlap, then consume them in order.
             const uint32_t room = c - node_start + 1, rows = (uint32_t)r + 1;
@@ -477,13 +508,17 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
             bool stop = false;
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
-                if (stop || k >= nspec || (fl[k] & 1u) || cur == 0) { stop = true; continue; }
+                if (stop || k >= nspec || (fl[k] & 1u) || (!xdrop && cur == 0)) { stop = true; continue; }
                 VGK_PUSH(node, VGK_OP_M, 1); first_c = c;
                 cur -= sc[k]; r -= 1;
-                if (r < 0 || cur == 0) { stop = true; continue; }
+                if (r < 0 || (!xdrop && cur == 0)) { stop = true; continue; }
                 if (c != node_start) c -= 1;
                 else {
                     const NodeRec& nr = nodes[node];
+                    if (xdrop && nr.n_pred == 0) {       // back at the dozeu root: r read bases are a leading insertion
+                        if (r > 0) VGK_PUSH(node, VGK_OP_I, (uint32_t)r);
+                        at_root = true; stop = true; continue;
+                    }
                     int32_t found = -1;
                     if (nr.n_pred == 1) found = (int32_t)P.preds[nr.pred_begin];
                     else for (uint32_t kk = 0; kk < nr.n_pred; ++kk) {
@@ -494,12 +529,16 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
                     stop = true;      // speculation never crosses a node boundary
                 }
             }
-            if (r < 0 || cur == 0) break;
+            if (at_root || r < 0 || (!xdrop && cur == 0)) break;
         } else if (st == ST_E) {
             VGK_PUSH(node, VGK_OP_D, 1); first_c = c;
             uint32_t pnode = node, pc = c - 1;
             if (first) {
                 const NodeRec& nr = nodes[node];
+                if (xdrop && nr.n_pred == 0) {           // deletion opened straight from the root column
+                    if (r > 0) VGK_PUSH(node, VGK_OP_I, (uint32_t)r);
+                    at_root = true; break;
+                }
                 int32_t found = -1;
                 if (nr.n_pred == 1) found = (int32_t)P.preds[nr.pred_begin];
                 else for (uint32_t k = 0; k < nr.n_pred; ++k) {
@@ -517,7 +556,8 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
             r -= 1;
         }
     }
-    if (status == VGK_OK && r >= 0) VGK_PUSH(node, VGK_OP_S, (uint32_t)r + 1);
+    if (xdrop && status == VGK_OK && !at_root) status = VGK_EINVAL;     // a dozeu path always ends at the root
+    if (!xdrop && status == VGK_OK && r >= 0) VGK_PUSH(node, VGK_OP_S, (uint32_t)r + 1);
     if (status == VGK_OK) VGK_FLUSH();
 #undef VGK_PUSH
 #undef VGK_FLUSH

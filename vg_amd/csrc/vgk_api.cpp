@@ -22,7 +22,7 @@ struct vgk_ctx {
     std::unique_ptr<Backend> be;
     std::mutex mu;                 // one stream per context: batches on one context serialise
     uint32_t bias = 1; int32_t max_score = 0;
-    uint32_t prof4[5];
+    uint32_t prof4[6];
 };
 
 struct vgk_batch {
@@ -103,6 +103,7 @@ int vgk_create(int device, const vgk_scoring* scoring, vgk_ctx** out) {
         for (int r = 0; r < 4; ++r) w |= (uint32_t)(scoring->matrix[5 * r + q] + bias) << (8 * r);
         c->prof4[q] = w;
     }
+    c->prof4[5] = 0;     // X-drop row 0 ("nothing consumed"): no diagonal move can enter it
     *out = c;
     return VGK_OK;
 }
@@ -138,7 +139,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     uint32_t maxL = 1;
     for (uint32_t i = 0; i < n; ++i) {
         if (problems[i].read_len == 0 || !problems[i].read || problems[i].graph.n_nodes == 0) return VGK_EINVAL;
-        maxL = std::max(maxL, problems[i].read_len);
+        maxL = std::max(maxL, problems[i].read_len + ((problems[i].flags & 15u) == VGK_XDROP_PINNED ? 1u : 0u));
     }
     if (maxL > 1024) return VGK_ETOOLONG;
     // rows per lane: the instantiation (16, 20, 24) that spends the fewest issued instructions per
@@ -170,13 +171,18 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         const vgk_graph& g = p.graph;
         ProbDesc& d = probs[i];
         const uint32_t mode = p.flags & 15u;
-        if (mode != VGK_GSSW_LOCAL && mode != VGK_GSSW_PINNED) return VGK_EINVAL;
+        if (mode != VGK_GSSW_LOCAL && mode != VGK_GSSW_PINNED && mode != VGK_XDROP_PINNED) return VGK_EINVAL;
+        const bool xdrop = mode == VGK_XDROP_PINNED;
+        // offset arithmetic of the X-drop mode: every reachable gain must stay below XOFF
+        if (xdrop && (int64_t)p.read_len * std::max(ctx->max_score, 0) + ctx->sc.full_length_bonus >= (int64_t)XOFF) return VGK_EUNSUPPORTED;
         if (mode == VGK_GSSW_PINNED && !p.pinning) return VGK_EINVAL;
         if (p.flags & VGK_GSSW_TRACEBACK) b->want_tb = true;
-        d.flags = p.flags; d.L = p.read_len; d.n_nodes = g.n_nodes;
+        d.flags = p.flags; d.L = p.read_len + (xdrop ? 1u : 0u); d.n_nodes = g.n_nodes;
         d.node_off = (uint32_t)nodes.size();
         d.read_off = (uint32_t)reads.size();
+        if (xdrop) reads.push_back(5);      // row 0 = no read base consumed yet
         for (uint32_t r = 0; r < p.read_len; ++r) reads.push_back((uint8_t)nt_read(p.read[r]));
+        d.max_gap = xdrop ? ((std::max<uint32_t>(p.max_gap_length, 1u) + 7u) & ~7u) : 0u;
         // which nodes need their last column saved / need a scratch-seeded first column
         store.assign(g.n_nodes, 0); slow.assign(g.n_nodes, 0);
         for (uint32_t v = 0; v < g.n_nodes; ++v) {
@@ -184,7 +190,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
             if (pe < pb || g.node_len[v] == 0) return VGK_EINVAL;
             for (uint32_t k = pb; k < pe; ++k) if (g.pred_idx[k] >= v) return VGK_EINVAL;   // not topological
             const bool chain = (pe - pb == 1) && g.pred_idx[pb] + 1 == v;
-            slow[v] = (v > 0 && !chain) ? 1 : 0;
+            slow[v] = ((v > 0 || xdrop) && !chain) ? 1 : 0;      // X-drop: node 0 starts from the root column
             if (slow[v]) for (uint32_t k = pb; k < pe; ++k) store[g.pred_idx[k]] = 1;
             if (mode == VGK_GSSW_PINNED && p.pinning[v]) store[v] = 1;
             n_edges += pe - pb;
@@ -218,8 +224,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         d.ops_off = (uint32_t)ops_total;
         ops_total += d.ops_cap;
         if (ops_total >= (1ull << 32)) return VGK_ETOOBIG;
-        d.pad = 0;
-        b->cells += (uint64_t)col * p.read_len;
+        b->cells += (uint64_t)col * d.L;
         b->in_bytes += (uint64_t)p.read_len + col + 8ull * g.n_nodes + 4ull * (g.pred_off[g.n_nodes] - g.pred_off[0]);
     }
     for (int k = 0; k < 8; ++k) colinfo.push_back(CI_INVALID);   // leaders prefetch one word ahead
@@ -256,7 +261,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     if ((rc = dev_alloc(b, (size_t)ops_total + 1, P.ops))) return fail(rc);
     P.wave_begin = 0; P.wave_count = n_waves; P.prob_begin = 0; P.prob_count = n;
     P.n_problems = n; P.n_pairs = n_pairs; P.n_waves = n_waves; P.K = K; P.G = G; P.groups_per_wave = gpw; P.Lpad = Lpad;
-    for (int q = 0; q < 5; ++q) P.prof4[q] = ctx->prof4[q];
+    for (int q = 0; q < 6; ++q) P.prof4[q] = ctx->prof4[q];
     P.bias = ctx->bias; P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend; P.bonus = ctx->sc.full_length_bonus;
     P.want_tb = b->want_tb ? 1 : 0;
     P.fused = 0;

@@ -270,9 +270,147 @@ void Aligner::align(Alignment& alignment, const HandleGraph& g, const std::vecto
 }
 
 void Aligner::align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left, bool xdrop,
-                           uint16_t /*xdrop_max_gap_length*/) const {
-    if (xdrop) throw std::runtime_error("vgamd: X-drop pinned alignment is not wired into this build of the host shim");
-    align_internal(alignment, nullptr, g, true, pin_left, 1, true);
+                           uint16_t xdrop_max_gap_length) const {
+    if (!xdrop) { align_internal(alignment, nullptr, g, true, pin_left, 1, true); return; }
+    // dozeu declines to produce an alignment when the gap is set to 0 (src/aligner.cpp:637-638)
+    xdrop_max_gap_length = std::max<uint16_t>(xdrop_max_gap_length, 1);
+    // wrap the graph so that empty pinning points are handled correctly (src/aligner.cpp:640-641)
+    DozeuPinningOverlay overlay(&g, !pin_left);
+    if (overlay.get_node_count() == 0 && g.get_node_count() != 0) {
+        // only empty pinning nodes: infer the soft clip from the pinning point (src/aligner.cpp:643-668)
+        g.for_each_handle([&](const handle_t& handle) {
+            bool can_pin = g.follow_edges(handle, pin_left, [&](const handle_t&) { return false; });
+            if (can_pin) {
+                alignment.path.mapping.emplace_back();
+                Mapping& mapping = alignment.path.mapping.back();
+                mapping.position.node_id = g.get_id(handle); mapping.position.is_reverse = false;
+                mapping.position.offset = pin_left ? 0 : (int64_t)g.get_length(handle);
+                mapping.rank = 1;
+                Edit e; e.from_length = 0; e.to_length = (int32_t)alignment.sequence.size(); e.sequence = alignment.sequence;
+                mapping.edit.push_back(e);
+                alignment.score = 0;
+                return false;
+            }
+            return true;
+        });
+        return;
+    }
+    xdrop_align_pinned(alignment, overlay, pin_left, scorer->full_length_bonus, xdrop_max_gap_length);
+    if (overlay.performed_duplications()) {
+        // the overlay is not a strict subset of the underlying graph: translate duplicate ids back (src/aligner.cpp:673-680)
+        for (Mapping& m : alignment.path.mapping) {
+            handle_t under = overlay.get_underlying_handle(overlay.get_handle(m.position.node_id));
+            m.position.node_id = g.get_id(under); m.position.is_reverse = g.get_is_reverse(under);
+        }
+    }
+}
+
+void Aligner::xdrop_align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left,
+                                 int8_t /*full_length_bonus: the engine context carries the scorer's bonus*/,
+                                 uint16_t max_gap_length) const {
+    std::vector<handle_t> order = handlealgs::lazier_topological_order(&g);     // lazy_topological_order in the reference (:728)
+    if (order.empty()) return;
+    // The engine extends left to right from every source node.  A right pin is the same problem on the
+    // reversed graph and read (dozeu walks the node strings backwards with a reverse-packed query, :178-185, :282-283).
+    ReverseGraph reversed_graph(&g, false);
+    const HandleGraph* run_graph = &g;
+    std::string run_seq = alignment.sequence;
+    if (!pin_left) { run_graph = &reversed_graph; std::reverse(run_seq.begin(), run_seq.end()); }
+    // dozeu sees raw get_sequence(); the packed graph is only a transport for (order, lengths, edges, bases)
+    std::vector<handle_t> run_order = handlealgs::lazier_topological_order(run_graph);
+    PackedGraph pg;
+    pg.order = run_order;
+    std::unordered_map<handle_t, uint32_t, handle_hash> index;
+    for (uint32_t i = 0; i < run_order.size(); ++i) index[run_order[i]] = i;
+    pg.pred_off.push_back(0);
+    for (uint32_t i = 0; i < run_order.size(); ++i) {
+        std::string s = run_graph->get_sequence(run_order[i]);
+        pg.node_len.push_back((uint32_t)s.size()); pg.seq += s;
+        run_graph->follow_edges_v(run_order[i], true, [&](const handle_t& prev) { auto it = index.find(prev); if (it != index.end()) pg.pred_idx.push_back(it->second); });
+        pg.pred_off.push_back((uint32_t)pg.pred_idx.size());
+    }
+    // head position = first tip in the pin direction in the (forward) order (:738-755); used when nothing aligns
+    handle_t head = order.front(); bool have_head = false;
+    for (const handle_t& h : order) {
+        if (g.follow_edges(h, pin_left, [](const handle_t&) { return false; })) { head = h; have_head = true; break; }
+    }
+    alignment.clear_path();
+    vgk_result res{}; std::vector<vgk_op> ops;
+    if (!run_seq.empty()) {
+        vgk_gssw_problem prob{};
+        prob.read = run_seq.data(); prob.read_len = (uint32_t)run_seq.size();
+        prob.flags = VGK_XDROP_PINNED | VGK_GSSW_TRACEBACK;
+        prob.graph = pg.view(); prob.max_gap_length = max_gap_length;
+        ops.resize(prob.read_len + pg.seq.size() + pg.order.size() + 4);
+        size_t written = 0;
+        int rc = engine->gssw_align(ctx, &prob, 1, &res, ops.data(), ops.size(), &written);
+        if (rc != VGK_OK || res.status != VGK_OK)
+            throw std::runtime_error(std::string("vgamd: xdrop engine failed: ") + engine->strerror(rc ? rc : res.status));
+        ops.resize(res.n_ops);
+    }
+    alignment.score = res.score;
+    if (res.score == 0 || ops.empty()) {
+        // no alignment scoring anything other than 0: full-length insertion at the head (:344-359)
+        if (!have_head) return;
+        alignment.path.mapping.emplace_back();
+        Mapping& m = alignment.path.mapping.back();
+        m.position.node_id = g.get_id(head); m.position.is_reverse = g.get_is_reverse(head);
+        m.position.offset = pin_left ? 0 : (int64_t)g.get_length(head);
+        m.rank = 1;
+        Edit e; e.from_length = 0; e.to_length = (int32_t)alignment.sequence.size(); e.sequence = alignment.sequence;
+        m.edit.push_back(e);
+        return;
+    }
+    if (!pin_left) unreverse_ops(ops, res, pg.node_len);
+    // dozeu path -> vg Path (calculate_and_save_alignment): matches merged, every mismatching base its own edit,
+    // the unaligned read end an insertion (merged into a leading insertion, separate when trailing)
+    const std::string& query = alignment.sequence;
+    size_t to_pos = 0, matches = 0;
+    int from_pos = res.first_offset;
+    uint32_t i = 0; bool first_node = true;
+    while (i < ops.size()) {
+        uint32_t node = ops[i].node, j = i;
+        while (j < ops.size() && ops[j].node == node) ++j;
+        const handle_t h = pg.order[node];
+        const std::string node_seq = g.get_sequence(h);
+        alignment.path.mapping.emplace_back();
+        Mapping& mapping = alignment.path.mapping.back();
+        if (!first_node) from_pos = 0;
+        first_node = false;
+        mapping.position.node_id = g.get_id(h); mapping.position.is_reverse = g.get_is_reverse(h);
+        mapping.position.offset = from_pos; mapping.rank = (int64_t)alignment.path.mapping.size();
+        for (uint32_t k = i; k < j; ++k) {
+            const int32_t len = ops[k].len;
+            switch (ops[k].op) {
+                case VGK_OP_M: {
+                    int run = 0;
+                    for (int t = 0; t < len; ++t) {
+                        if (node_seq[from_pos + t] == query[to_pos + t]) { ++run; ++matches; }
+                        else {
+                            if (run) { Edit e; e.from_length = e.to_length = run; mapping.edit.push_back(e); run = 0; }
+                            Edit e; e.from_length = e.to_length = 1; e.sequence = query.substr(to_pos + t, 1); mapping.edit.push_back(e);
+                        }
+                    }
+                    if (run) { Edit e; e.from_length = e.to_length = run; mapping.edit.push_back(e); }
+                    from_pos += len; to_pos += len;
+                } break;
+                case VGK_OP_D: { Edit e; e.from_length = len; e.to_length = 0; mapping.edit.push_back(e); from_pos += len; } break;
+                case VGK_OP_I:
+                case VGK_OP_S: {
+                    // a leading clip merges with an adjacent path insertion (state machine of :498-507); a trailing one is pushed on its own (:520-526)
+                    const bool merge_prev = !mapping.edit.empty() && edit_is_insertion(mapping.edit.back()) &&
+                                            !(ops[k].op == VGK_OP_S && k + 1 == ops.size());
+                    if (merge_prev) { Edit& e = mapping.edit.back(); e.to_length += len; e.sequence += query.substr(to_pos, len); }
+                    else { Edit e; e.from_length = 0; e.to_length = len; e.sequence = query.substr(to_pos, len); mapping.edit.push_back(e); }
+                    to_pos += len;
+                } break;
+                default: throw std::runtime_error("vgamd: unsupported cigar op from engine");
+            }
+        }
+        i = j;
+    }
+    alignment.identity = query.empty() ? 0.0 : (double)matches / (double)query.size();
+    alignment.query_position = 0;
 }
 
 void Aligner::align_pinned_multi(Alignment& alignment, std::vector<Alignment>& alt_alignments, const HandleGraph& g,

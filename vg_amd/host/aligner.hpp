@@ -104,6 +104,9 @@ public:
 private:
     void align_internal(Alignment& alignment, std::vector<Alignment>* multi_alignments, const HandleGraph& g,
                         bool pinned, bool pin_left, int32_t max_alt_alns, bool traceback_aln) const;
+    // DozeuInterface::align_pinned + calculate_and_save_alignment (src/dozeu_interface.cpp:724-766, 338-572)
+    void xdrop_align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left,
+                            int8_t full_length_bonus, uint16_t max_gap_length) const;
 };
 
 // nonATGCNtoN (reference: src/utility.cpp:323-332)

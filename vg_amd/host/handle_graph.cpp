@@ -70,6 +70,86 @@ bool NullMaskingGraph::for_each_handle(const std::function<bool(const handle_t&)
     return g_->for_each_handle([&](const handle_t& n) { return g_->get_length(n) > 0 ? it(n) : true; });
 }
 
+DozeuPinningOverlay::DozeuPinningOverlay(const HandleGraph* g, bool sinks) : graph(g), preserve_sinks(sinks) {
+    std::vector<handle_t> empty_nodes;
+    uint64_t min_handle = ~0ull;
+    graph->for_each_handle_v([&](const handle_t& h) {
+        for (handle_t x : {h, graph->flip(h)}) { min_handle = std::min<uint64_t>(min_handle, (uint64_t)x.v); max_handle = std::max<uint64_t>(max_handle, (uint64_t)x.v); }
+        if (graph->get_length(h) == 0) empty_nodes.push_back(h);
+    });
+    num_null_nodes = empty_nodes.size();
+    handle_val_range = graph->get_node_count() ? max_handle - min_handle + 1 : 0;
+    for (const handle_t& empty : empty_nodes) {
+        // an empty node with nothing on its pinning side is a pinning tip; its neighbours inherit that role
+        bool should_preserve = graph->follow_edges(empty, !preserve_sinks, [&](const handle_t&) { return false; });
+        if (!should_preserve) continue;
+        graph->follow_edges_v(empty, preserve_sinks, [&](const handle_t& next) {
+            bool must_duplicate = !graph->follow_edges(next, !preserve_sinks, [&](const handle_t& prev) { return prev == empty; });
+            if (must_duplicate) duplicated_handles.insert(next);
+        });
+    }
+}
+
+bool DozeuPinningOverlay::has_node(nid_t id) const {
+    if (is_a_duplicate_id(id)) {
+        nid_t under = get_underlying_id(id);
+        return graph->has_node(under) && duplicated_handles.count(graph->get_handle(under));
+    }
+    return graph->has_node(id) && graph->get_length(graph->get_handle(id)) != 0;
+}
+
+handle_t DozeuPinningOverlay::get_handle(nid_t id, bool is_reverse) const {
+    if (is_a_duplicate_id(id)) return get_duplicate_handle(graph->get_handle(get_underlying_id(id), is_reverse));
+    return graph->get_handle(id, is_reverse);
+}
+
+nid_t DozeuPinningOverlay::get_id(const handle_t& h) const {
+    if (is_a_duplicate_handle(h)) return graph->get_id(get_underlying_handle(h)) + (graph->max_node_id() - graph->min_node_id() + 1);
+    return graph->get_id(h);
+}
+
+bool DozeuPinningOverlay::get_is_reverse(const handle_t& h) const { return graph->get_is_reverse(get_underlying_handle(h)); }
+
+handle_t DozeuPinningOverlay::flip(const handle_t& h) const {
+    if (is_a_duplicate_handle(h)) return get_duplicate_handle(graph->flip(get_underlying_handle(h)));
+    return graph->flip(h);
+}
+
+handle_t DozeuPinningOverlay::get_underlying_handle(const handle_t& h) const {
+    return is_a_duplicate_handle(h) ? handle_t{(int64_t)((uint64_t)h.v - handle_val_range)} : h;
+}
+
+bool DozeuPinningOverlay::follow_edges(const handle_t& handle, bool go_left, const std::function<bool(const handle_t&)>& it) const {
+    handle_t to_iterate = handle;
+    if (is_a_duplicate_handle(handle)) {
+        if (preserve_sinks != (go_left != get_is_reverse(handle))) return true;     // the duplicate is a tip on its pinning side
+        to_iterate = get_underlying_handle(handle);
+    }
+    return graph->follow_edges(to_iterate, go_left, [&](const handle_t& next) {
+        bool keep_going = true;
+        if (graph->get_length(next) > 0) {
+            keep_going = it(next);
+            handle_t fwd = graph->get_is_reverse(next) ? graph->flip(next) : next;
+            if (keep_going && duplicated_handles.count(fwd)) {
+                if (preserve_sinks != (go_left != graph->get_is_reverse(next))) keep_going = it(get_duplicate_handle(next));
+            }
+        }
+        return keep_going;
+    });
+}
+
+bool DozeuPinningOverlay::for_each_handle(const std::function<bool(const handle_t&)>& it) const {
+    bool keep_going = graph->for_each_handle([&](const handle_t& h) { return graph->get_length(h) > 0 ? it(h) : true; });
+    for (auto i = duplicated_handles.begin(); i != duplicated_handles.end() && keep_going; ++i) keep_going = it(get_duplicate_handle(*i));
+    return keep_going;
+}
+
+nid_t DozeuPinningOverlay::max_node_id() const {
+    nid_t m = graph->max_node_id();
+    for (const handle_t& h : duplicated_handles) m = std::max(m, get_id(get_duplicate_handle(h)));
+    return m;
+}
+
 namespace handlealgs {
 
 std::vector<handle_t> lazier_topological_order(const HandleGraph* g) {

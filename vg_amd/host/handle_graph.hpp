@@ -116,6 +116,36 @@ private:
     const HandleGraph* g_; size_t nulls_ = 0;
 };
 
+// DozeuPinningOverlay: removes empty nodes and duplicates any neighbour of an empty tip that would
+// otherwise lose its tip status, so that dozeu can pin on it (reference: src/dozeu_pinning_overlay.cpp,
+// used at src/aligner.cpp:641).  Duplicate handles / ids live above the underlying ranges.
+class DozeuPinningOverlay : public HandleGraph {
+public:
+    DozeuPinningOverlay(const HandleGraph* graph, bool preserve_sinks);
+    bool performed_duplications() const { return !duplicated_handles.empty(); }
+    bool has_node(nid_t id) const override;
+    handle_t get_handle(nid_t id, bool is_reverse = false) const override;
+    nid_t get_id(const handle_t& h) const override;
+    bool get_is_reverse(const handle_t& h) const override;
+    handle_t flip(const handle_t& h) const override;
+    size_t get_length(const handle_t& h) const override { return graph->get_length(get_underlying_handle(h)); }
+    std::string get_sequence(const handle_t& h) const override { return graph->get_sequence(get_underlying_handle(h)); }
+    bool follow_edges(const handle_t& h, bool go_left, const std::function<bool(const handle_t&)>& it) const override;
+    bool for_each_handle(const std::function<bool(const handle_t&)>& it) const override;
+    size_t get_node_count() const override { return graph->get_node_count() - num_null_nodes + duplicated_handles.size(); }
+    nid_t min_node_id() const override { return graph->min_node_id(); }
+    nid_t max_node_id() const override;
+    handle_t get_underlying_handle(const handle_t& h) const;
+private:
+    bool is_a_duplicate_handle(const handle_t& h) const { return (uint64_t)h.v > max_handle; }
+    bool is_a_duplicate_id(nid_t id) const { return id > graph->max_node_id(); }
+    nid_t get_underlying_id(nid_t id) const { return id - (graph->max_node_id() - graph->min_node_id() + 1); }
+    handle_t get_duplicate_handle(const handle_t& h) const { return handle_t{(int64_t)((uint64_t)h.v + handle_val_range)}; }
+    const HandleGraph* graph; bool preserve_sinks;
+    std::set<handle_t> duplicated_handles;          // forward handles of duplicated nodes (ordered: deterministic iteration)
+    size_t num_null_nodes = 0; uint64_t max_handle = 0, handle_val_range = 0;
+};
+
 namespace handlealgs {
 // Kahn's algorithm, always expanding the smallest ready handle (the ordered
 // "s" map of vg's topological sort); on a DAG with forward handles this is what

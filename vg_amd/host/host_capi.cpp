@@ -48,7 +48,8 @@ static int emit(const Alignment& aln, char* out, size_t cap) {
     return 0;
 }
 
-// call: 0 = align(traceback), 1 = align(score only), 2 = align_pinned, 3 = align_pinned_multi (primary only reported)
+// call: 0 = align(traceback), 1 = align(score only), 2 = align_pinned, 3 = align_pinned_multi (primary only reported),
+//       4 = align_pinned(xdrop = true, max_gap = max_alt_alns argument)
 int vgh_align(vgh_aligner* a, vgh_graph* g, const char* read, int call, int pin_left, int max_alt_alns,
               char* json_out, size_t json_cap) {
     try {
@@ -58,6 +59,7 @@ int vgh_align(vgh_aligner* a, vgh_graph* g, const char* read, int call, int pin_
             case 1: a->a->align(aln, g->g, false); break;
             case 2: a->a->align_pinned(aln, g->g, pin_left != 0); break;
             case 3: { std::vector<Alignment> alts; a->a->align_pinned_multi(aln, alts, g->g, pin_left != 0, max_alt_alns); } break;
+            case 4: a->a->align_pinned(aln, g->g, pin_left != 0, true, (uint16_t)max_alt_alns); break;
             default: g_last_error = "unknown call"; return -1;
         }
         return emit(aln, json_out, json_cap);
