@@ -23,7 +23,7 @@ public:
     int download(void* d, const void* s, size_t n) override { std::memcpy(d, s, n); return VGK_OK; }
     int zero(void* d, size_t n) override { std::memset(d, 0, n); return VGK_OK; }
     int sync() override { return VGK_OK; }
-    template <int K> void fill(const GsswParams& P) {
+    template <int K, bool S8> void fill(const GsswParams& P) {
         std::vector<Lane<K>> lanes(64);
         std::vector<uint32_t> oh(64), of(64), oi(64);
         constexpr uint32_t REC = K / 4;
@@ -36,7 +36,7 @@ public:
                     if ((t & 3u) == 0) lane_prefetch(lanes[l], P, t);
                     const uint32_t rh = l ? oh[l - 1] : 0, rf = l ? of[l - 1] : 0, ri = l ? oi[l - 1] : 0;
                     uint32_t* tb = P.want_tb ? P.tb + tb_record(wd.tb_off, t, l) * REC : nullptr;
-                    lane_step(lanes[l], P, t, rh, rf, ri, tb);
+                    lane_step<K, S8>(lanes[l], P, t, rh, rf, ri, tb);
                 }
             }
             for (uint32_t l = 0; l < 64; ++l) for (int half = 0; half < 2; ++half) {
@@ -47,9 +47,9 @@ public:
     }
     int run_gssw(const GsswParams& P, bool walk) override {
         switch (P.K) {
-            case 16: fill<16>(P); break;
-            case 20: fill<20>(P); break;
-            case 24: fill<24>(P); break;
+            case 16: if (P.scale == 8) fill<16, true>(P); else fill<16, false>(P); break;
+            case 20: if (P.scale == 8) fill<20, true>(P); else fill<20, false>(P); break;
+            case 24: if (P.scale == 8) fill<24, true>(P); else fill<24, false>(P); break;
             default: return VGK_EINVAL;
         }
         if (walk) for (uint32_t i = 0; i < P.n_problems; ++i) walk_one(P, i, P.best[i]);

@@ -27,6 +27,16 @@ __global__ void k_max16(uint32_t* p)   { BODY("v_max_u16 %0, %0, %1") }
 __global__ void k_lshlor(uint32_t* p)  { BODY("v_lshl_or_b32 %0, %0, 1, %1") }
 __global__ void k_fma(uint32_t* p)     { BODY("v_fma_f32 %0, %0, %1, %2") }
 __global__ void k_pkfma(uint32_t* p)   { BODY("v_pk_fma_f16 %0, %0, %1, %2") }
+__global__ void k_and(uint32_t* p)     { BODY("v_and_b32 %0, %0, %1") }
+__global__ void k_or(uint32_t* p)      { BODY("v_or_b32 %0, %0, %1") }
+__global__ void k_bfi(uint32_t* p)     { BODY("v_bfi_b32 %0, %0, %1, %2") }
+__global__ void k_mov(uint32_t* p)     { BODY("v_mov_b32 %0, %1") }
+__global__ void k_lshl(uint32_t* p)    { BODY("v_lshlrev_b32 %0, 3, %0") }
+__global__ void k_andor(uint32_t* p)   { BODY("v_and_or_b32 %0, %0, %1, %2") }
+__global__ void k_min16(uint32_t* p)   { BODY("v_min_u16 %0, %0, %1") }
+__global__ void k_sub16(uint32_t* p)   { BODY("v_sub_u16 %0, %0, %1") }
+__global__ void k_add16s(uint32_t* p)  { BODY("v_add_u16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1") }
+__global__ void k_pklshl(uint32_t* p)  { BODY("v_pk_lshlrev_b16 %0, 3, %0 op_sel_hi:[0,1]") }
 template <class F> void run(const char* name, F f, uint32_t* d, int per_iter) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int blocks = 256 * 8;   // 8 blocks of 256 threads per CU = 8 waves per SIMD
@@ -43,5 +53,8 @@ int main() {
     run("add_u32", k_add, d, 1); run("max_u32", k_max, d, 1); run("max3_u32", k_max3, d, 1); run("sub_clamp", k_subc, d, 1);
     run("perm_b32", k_perm, d, 1); run("bfe_i32", k_bfe, d, 1); run("cmp+addc", k_cmp, d, 2); run("max_u16", k_max16, d, 1);
     run("lshl_or", k_lshlor, d, 1); run("fma_f32", k_fma, d, 1); run("pk_fma_f16", k_pkfma, d, 1);
+    run("and_b32", k_and, d, 1); run("or_b32", k_or, d, 1); run("bfi_b32", k_bfi, d, 1); run("mov_b32", k_mov, d, 1);
+    run("lshlrev_b32", k_lshl, d, 1); run("and_or_b32", k_andor, d, 1); run("min_u16", k_min16, d, 1); run("sub_u16", k_sub16, d, 1);
+    run("add_u16_sdwa", k_add16s, d, 1); run("pk_lshlrev", k_pklshl, d, 1);
     return 0;
 }

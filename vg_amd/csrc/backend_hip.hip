@@ -17,7 +17,7 @@ static __device__ __forceinline__ uint32_t from_lane_above(uint32_t x) {
 // floor(64/G) read pairs for the whole skewed sweep.  No LDS, no barriers.
 // Occupancy: K = 16 fits 128 VGPRs (4 waves/SIMD); K = 20/24 keep 4K+ state registers per
 // lane and run 3 waves/SIMD (<= 168 VGPRs) rather than spill in the hot loop.
-template <int K>
+template <int K, bool S8>
 __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const GsswParams P) {
     const uint32_t wave = P.wave_begin + blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
         const uint32_t rh = from_lane_above(s.out_h);
         const uint32_t rf = from_lane_above(s.out_f);
         const uint32_t ri = from_lane_above(s.info);
-        lane_step(s, P, t, rh, rf, ri, tb ? tb + tb_record(wd.tb_off, t, lane) * REC : nullptr);
+        lane_step<K, S8>(s, P, t, rh, rf, ri, tb ? tb + tb_record(wd.tb_off, t, lane) * REC : nullptr);
     }
     if (!P.fused) {
 #pragma unroll
@@ -111,10 +111,11 @@ public:
     }
     int launch_fill(const GsswParams& p) {
         const dim3 grid((p.wave_count + 3) / 4), block(256);
+        const bool s8 = p.scale == 8;
         switch (p.K) {
-            case 16: hipLaunchKernelGGL(gssw_fill_kernel<16>, grid, block, 0, stream, p); break;
-            case 20: hipLaunchKernelGGL(gssw_fill_kernel<20>, grid, block, 0, stream, p); break;
-            case 24: hipLaunchKernelGGL(gssw_fill_kernel<24>, grid, block, 0, stream, p); break;
+            case 16: if (s8) hipLaunchKernelGGL((gssw_fill_kernel<16, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<16, false>), grid, block, 0, stream, p); break;
+            case 20: if (s8) hipLaunchKernelGGL((gssw_fill_kernel<20, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<20, false>), grid, block, 0, stream, p); break;
+            case 24: if (s8) hipLaunchKernelGGL((gssw_fill_kernel<24, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<24, false>), grid, block, 0, stream, p); break;
             default: return VGK_EINVAL;
         }
         return VGK_OK;

@@ -104,6 +104,10 @@ struct GsswParams {
     int32_t  bonus;             // full-length bonus
     int32_t  want_tb;           // any problem wants traceback -> store codes
     int32_t  fused;             // 1 = each wavefront traces its own reads back at the end of the fill kernel
+    uint32_t scale;             // 1 or 8: every DP quantity above (prof4, bias, go, ge, bonus, xoff, scratch) is pre-multiplied.
+                                // With 8, non-zero score differences are >= 8, so min(diff, 1|2|4|8) yields the four traceback
+                                // bits already weighted and they merge with full-rate ORs instead of v_pk_mad.
+    uint32_t xoff;              // XOFF * scale
     int8_t   matrix[25];
 };
 
@@ -223,8 +227,8 @@ VGK_HD void seed_from_scratch(Lane<K>& s, const GsswParams& P, uint32_t prob, ui
             const uint32_t row = s.g * K + m - 1;               // m = 0 is the row above this lane's block
             uint32_t h = 0;
             if (m > 0 || s.g > 0) {
-                if (row == 0) h = XOFF;
-                else if (row <= d.max_gap) { const uint32_t pen = P.go + (row - 1) * P.ge; h = pen < XOFF ? XOFF - pen : 0; }
+                if (row == 0) h = P.xoff;
+                else if (row <= d.max_gap) { const uint32_t pen = P.go + (row - 1) * P.ge; h = pen < P.xoff ? P.xoff - pen : 0; }
             }
             if (m == 0) { diag0 |= HALF == 0 ? h : (h << 16); }
             else {
@@ -271,7 +275,7 @@ constexpr uint32_t KEY_SHIFT = 5, KEY_LOW = 31;
 
 // One row (compile-time index M) of one lane for one column.  REFN = some half sees
 // an N in the graph (rare): the profile permute cannot express score 0, patch it.
-template <int K, int M, bool REFN>
+template <int K, int M, bool REFN, bool S8>
 VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, uint32_t go2, uint32_t ge2,
                      bool nA, bool nB, uint32_t& f, uint32_t& d, uint32_t* acc, uint32_t& ck) {
     uint32_t sb = byte_perm(s.PB[M], s.PA[M], sel);
@@ -281,7 +285,7 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
         if (nB) sb = set_hi(sb, row < s.LB ? P.bias + row_bonus(P, row, s.LB, s.flagsB) : 0u);
     }
     const uint32_t old = s.H[M];
-    const uint32_t t4 = pk_subs(pk_add(d, sb), bias2);     // max(0, diag + s)
+    const uint32_t t4 = pk_subs(pk_add_nc(d, sb), bias2);  // max(0, diag + s); the sum stays far below 2^16 per half
     const uint32_t e = s.E[M];
     const uint32_t h = pk_max(pk_max(t4, e), f);
     const uint32_t gg = pk_subs(h, go2);                   // max(0, H - go)
@@ -289,30 +293,33 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
     const uint32_t en = pk_max(gg, e2), fn = pk_max(gg, f2);
     // traceback code: bit0 = H not from diagonal, bit1 = H not from E (then F),
     // bit2 = next-column E is an extension, bit3 = next-row F is an extension.
-    // min(x, 1) with an opaque `one` keeps each flag at 2 packed ops; the merges are v_pk_mad_u16.
+    // min(x, 1) with an opaque `one` keeps each flag at 2 ops; the merges are v_pk_mad_u16, or — with scores
+    // scaled by 8, where a non-zero difference is >= 8 — min(x, 1|2|4|8) yields the weighted bit directly.
     const uint32_t one = s.one;
-    const uint32_t nd = pk_min(pk_sub(h, t4), one);
-    const uint32_t ne = pk_min(pk_sub(h, e), one);
-    const uint32_t eb = pk_min(pk_subs(e2, gg), one);
-    const uint32_t fb = pk_min(pk_subs(f2, gg), one);
-    uint32_t code = pk_mul_add_imm<2>(ne, nd);
-    code = pk_mul_add_imm<4>(eb, code);
-    code = pk_mul_add_imm<8>(fb, code);
+    // every difference below has a >= b in both halves (h, en, fn are maxima over the subtrahend), so the
+    // full-rate 32-bit subtract is exact on the packed pair
+    const uint32_t nd = pk_min(pk_sub_nb(h, t4), one);
+    const uint32_t ne = pk_min(pk_sub_nb(h, e), S8 ? 0x00020002u : one);
+    const uint32_t eb = pk_min(pk_sub_nb(en, gg), S8 ? 0x00040004u : one);     // next-column E != H - go  <=>  extension won strictly
+    const uint32_t fb = pk_min(pk_sub_nb(fn, gg), S8 ? 0x00080008u : one);
+    uint32_t code;
+    if (S8) code = nd | ne | eb | fb;                      // bits arrive weighted 1,2,4,8
+    else { code = pk_mul_add_imm<2>(ne, nd); code = pk_mul_add_imm<4>(eb, code); code = pk_mul_add_imm<8>(fb, code); }
     acc[M >> 2] = (M & 3) == 0 ? code : pk_mul_add_imm<16>(acc[M >> 2], code);
-    const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(h, 0x00010001u << KEY_SHIFT);
+    const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(h, S8 ? (0x00010001u << (KEY_SHIFT - 3)) : (0x00010001u << KEY_SHIFT));
     ck = M == 0 ? key : pk_max(ck, key);
     s.H[M] = h; s.E[M] = en; f = fn; d = old;
 }
 
-template <int K, int M, bool REFN>
+template <int K, int M, bool REFN, bool S8>
 VGK_HD void lane_rows_from(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, uint32_t go2, uint32_t ge2,
                            bool nA, bool nB, uint32_t& f, uint32_t& d, uint32_t* acc, uint32_t& ck) {
-    lane_row<K, M, REFN>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
-    if constexpr (M + 1 < K) lane_rows_from<K, M + 1, REFN>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+    lane_row<K, M, REFN, S8>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+    if constexpr (M + 1 < K) lane_rows_from<K, M + 1, REFN, S8>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
 }
 
 // The K rows of one lane for one column; returns the K/4 traceback dwords and the column key maximum.
-template <int K, bool REFN>
+template <int K, bool REFN, bool S8>
 VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t diag0, uint32_t rf,
                       bool nA, bool nB, uint32_t* acc, uint32_t& colkey) {
     uint32_t bias2 = rep2(P.bias), go2 = rep2(P.go), ge2 = rep2(P.ge);
@@ -323,7 +330,7 @@ VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t di
     if (REFN) asm volatile("" : "+v"(sel), "+v"(bias2), "+v"(go2), "+v"(ge2));
 #endif
     uint32_t f = rf, d = diag0, ck = 0;
-    lane_rows_from<K, 0, REFN>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+    lane_rows_from<K, 0, REFN, S8>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
     s.out_h = s.H[K - 1]; s.out_f = f;
     colkey = ck;
 }
@@ -331,7 +338,7 @@ VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t di
 // One step of one lane.  rh/rf/rinfo are lane-1's out_h/out_f/info from the
 // previous step (ignored by group leaders, which start a fresh column).
 // tbrec = this (step, lane)'s K/4-dword traceback record, or nullptr.
-template <int K>
+template <int K, bool S8>
 VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tbrec) {
     if (s.g == 0) { rh = 0; rf = 0; rinfo = fetch_info(s, P, t); }
     s.info = rinfo;
@@ -347,8 +354,8 @@ VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, 
         const uint32_t sel = (rinfo & 0x00030003u) | 0x0c040c00u;
         const bool nA = vA && (ia & CI_BASE_MASK) == 4, nB = vB && (ib & CI_BASE_MASK) == 4;
         uint32_t acc[K / 4], colkey;
-        if (nA || nB) lane_rows<K, true>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
-        else          lane_rows<K, false>(s, P, sel, diag0, rf, false, false, acc, colkey);
+        if (nA || nB) lane_rows<K, true, S8>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
+        else          lane_rows<K, false, S8>(s, P, sel, diag0, rf, false, false, acc, colkey);
         if (tbrec) {
 #pragma unroll
             for (int j = 0; j < K / 4; ++j) tbrec[j] = acc[j];
@@ -440,7 +447,8 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
     const bool pinned = (d.flags & 15u) == VGK_GSSW_PINNED;
     const bool xdrop = (d.flags & 15u) == VGK_XDROP_PINNED;   // rows = consumed read bases 0..len, scores carry XOFF
     const int32_t go = (int32_t)P.go, ge = (int32_t)P.ge;
-    const int32_t zero = xdrop ? (int32_t)XOFF : 0;            // representation of score 0
+    const int32_t S = (int32_t)P.scale;                        // walker arithmetic runs in the kernels' scaled units
+    const int32_t zero = xdrop ? (int32_t)P.xoff : 0;          // representation of score 0
 
     int32_t cur = 0; uint32_t c = 0, node = 0; int32_t r = 0;
     bool have = false;
@@ -454,7 +462,7 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
         if (have) c = nodes[node].col_end - 1;
     } else {
         const unsigned long long k = best_key;
-        cur = (int32_t)(k >> 40);
+        cur = (int32_t)(k >> 40) * S;
         if (cur > 0) {
             have = true;
             c = 0xFFFFFu - (uint32_t)((k >> 20) & 0xFFFFFu);
@@ -465,9 +473,9 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
         }
     }
     if (pinned && !have) { res.status = VGK_EINVAL; P.results[i] = res; return; }
-    if (cur >= 2047) { res.status = VGK_EOVERFLOW; P.results[i] = res; return; }
+    if (cur >= 2047 * S) { res.status = VGK_EOVERFLOW; P.results[i] = res; return; }
     if (!have || cur <= zero) { P.results[i] = res; return; }  // score 0: the caller synthesises soft clips / full insertion
-    res.score = cur - zero; res.end_node = (int32_t)node; res.end_offset = (int32_t)(c - nodes[node].col_start);
+    res.score = (cur - zero) / S; res.end_node = (int32_t)node; res.end_offset = (int32_t)(c - nodes[node].col_start);
     res.end_read = xdrop ? r - 1 : r;
     if (!(d.flags & VGK_GSSW_TRACEBACK)) { P.results[i] = res; return; }
 
@@ -504,6 +512,9 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
                 fl[k] = 1u; sc[k] = 0;
                 if (k < nspec) { fl[k] = w.code((uint32_t)r - k, c - k); sc[k] = w.score((uint32_t)r - k, c - k); }
             }
+#if defined(VGK_DEBUG_WALK) && !defined(__HIP_DEVICE_COMPILE__)
+            printf("H r=%d c=%u cur=%d nspec=%u fl=%u %u %u %u sc=%d %d %d %d\n", r, c, cur, nspec, fl[0], fl[1], fl[2], fl[3], sc[0], sc[1], sc[2], sc[3]);
+#endif
             if (fl[0] & 1u) { st = (fl[0] & 2u) ? ST_F : ST_E; continue; }
             bool stop = false;
 #pragma unroll

@@ -63,6 +63,12 @@ static inline uint32_t byte_perm(uint32_t a, uint32_t b, uint32_t sel) {
 }
 #endif
 
+// Full-width adds / subtracts that are exact on packed halves when no carry / borrow can cross:
+// pk_add_nc needs lo(a)+lo(b) < 2^16, pk_sub_nb needs every half of a >= the same half of b.
+// v_add_u32 / v_sub_u32 issue at twice the rate of the v_pk_* forms on gfx950 (tools/valu_rate.hip).
+VGK_HD uint32_t pk_add_nc(uint32_t a, uint32_t b) { return a + b; }
+VGK_HD uint32_t pk_sub_nb(uint32_t a, uint32_t b) { return a - b; }
+
 // replace the low / high 16-bit half
 VGK_HD uint32_t set_lo(uint32_t x, uint32_t v) { return (x & 0xffff0000u) | (v & 0xffffu); }
 VGK_HD uint32_t set_hi(uint32_t x, uint32_t v) { return (x & 0x0000ffffu) | (v << 16); }

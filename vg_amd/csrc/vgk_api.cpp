@@ -261,8 +261,12 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     if ((rc = dev_alloc(b, (size_t)ops_total + 1, P.ops))) return fail(rc);
     P.wave_begin = 0; P.wave_count = n_waves; P.prob_begin = 0; P.prob_count = n;
     P.n_problems = n; P.n_pairs = n_pairs; P.n_waves = n_waves; P.K = K; P.G = G; P.groups_per_wave = gpw; P.Lpad = Lpad;
-    for (int q = 0; q < 6; ++q) P.prof4[q] = ctx->prof4[q];
-    P.bias = ctx->bias; P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend; P.bonus = ctx->sc.full_length_bonus;
+    // scale 8 whenever the scaled profile bytes still fit (they do for vg's default 1/4/6/1/5): see GsswParams::scale
+    uint32_t S = ((ctx->max_score + (int)ctx->bias + 2 * ctx->sc.full_length_bonus) * 8 <= 255) ? 8u : 1u;
+    if (const char* e = std::getenv("VGAMD_SCORE_SCALE")) S = std::atoi(e) == 8 && S == 8 ? 8u : 1u;
+    for (int q = 0; q < 6; ++q) P.prof4[q] = ctx->prof4[q] * S;      // bytes stay < 256, no carries between them
+    P.bias = ctx->bias * S; P.go = ctx->sc.gap_open * S; P.ge = ctx->sc.gap_extend * S; P.bonus = ctx->sc.full_length_bonus * (int32_t)S;
+    P.scale = S; P.xoff = XOFF * S;
     P.want_tb = b->want_tb ? 1 : 0;
     P.fused = 0;
     if (const char* e = std::getenv("VGAMD_FUSED_TRACEBACK")) P.fused = std::atoi(e) ? 1 : 0;
