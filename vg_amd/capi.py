@@ -124,6 +124,13 @@ class ProblemSet:
     def ptr(self):
         return self.array.ctypes.data
 
+    def subset(self, k):
+        """First k problems (same arenas, no copies)."""
+        s = object.__new__(ProblemSet)
+        s.__dict__.update(self.__dict__)
+        s.n = k; s.array = self.array[:k]; s.read_off = self.read_off[:k + 1]; s.seq_off = self.seq_off[:k + 1]
+        return s
+
     @classmethod
     def from_lists(cls, problems):
         """problems: list of dicts {read: str, nodes: [str], preds: [[int]], flags: int, pinning: [0/1]|None}."""

@@ -115,3 +115,99 @@ class LinearWorkload:
 
     def cells(self):
         return int((self.R * self.read_len).sum())
+
+
+class TailWorkload:
+    """config 3 stand-in: giraffe-style tail alignments (pinned X-drop) on a variation graph.
+
+    One long synthetic haplotype graph is built once: 24-32 bp chain nodes, SNP bubbles (two 1-bp
+    alternatives) every ~snp_every bp and insertion bubbles (chain -> inserted node -> chain, plus the
+    skipping edge) every ~indel_every bp.  Each problem is a window of consecutive nodes starting at
+    a chain node (the pin), deep enough for the tail plus its longest detectable gap
+    (search_limit = tail + gap, src/minimizer_mapper.cpp:5809-5816); the read tail is a walk from the
+    pin through random alternatives with 1 % substitutions.  Mode VGK_XDROP_PINNED, left pin.
+    """
+
+    def __init__(self, n_reads, seed=77, graph_bp=2_000_000, snp_every=100, indel_every=1000, max_tail=121,
+                 flags=capi.VGK_XDROP_PINNED | capi.VGK_GSSW_TRACEBACK):
+        rng = np.random.default_rng(seed)
+        # ---- global graph -------------------------------------------------------------------------
+        seqs, preds, kind = [], [], []           # kind: 0 chain, 1 snp alt, 2 insertion
+        pos = 0
+        last_chain = -1
+        while pos < graph_bp:
+            ln = int(rng.integers(24, 33))
+            seqs.append(ACGT[rng.integers(0, 4, ln)]); kind.append(0)
+            v = len(seqs) - 1
+            if last_chain < 0:
+                preds.append([])
+            else:
+                preds.append(list(pending))
+            pending = [v]
+            pos += ln
+            r = rng.random()
+            if r < ln / snp_every:                       # SNP bubble after this chain node
+                a = len(seqs); seqs.append(ACGT[rng.integers(0, 4, 1)]); kind.append(1); preds.append([v])
+                b = len(seqs); seqs.append(ACGT[rng.integers(0, 4, 1)]); kind.append(1); preds.append([v])
+                pending = [a, b]; pos += 1
+            elif r < ln / snp_every + ln / indel_every:  # insertion: v -> ins -> next, and v -> next
+                k = int(rng.integers(1, 21))
+                a = len(seqs); seqs.append(ACGT[rng.integers(0, 4, k)]); kind.append(2); preds.append([v])
+                pending = [v, a]
+            last_chain = v
+        self.g_seq = np.concatenate(seqs)
+        g_len = np.array([len(s) for s in seqs], dtype=np.uint32)
+        g_off = np.concatenate([[0], np.cumsum(g_len)]).astype(np.int64)
+        kind = np.array(kind)
+        succ = [[] for _ in seqs]
+        for v, pr in enumerate(preds):
+            for p in pr:
+                succ[p].append(v)
+        chain_idx = np.nonzero(kind == 0)[0]
+        chain_idx = chain_idx[chain_idx < len(seqs) - 64]
+        # ---- problems -----------------------------------------------------------------------------
+        tails = rng.integers(1, max_tail + 1, n_reads)
+        starts = chain_idx[rng.integers(0, len(chain_idx), n_reads)]
+        gap = np.maximum((tails * 1 + 5 - 6) // 1 + 1, 1)                     # longest_detectable_gap with 1/4/6/1/5
+        depth_bp = tails + np.minimum(gap, tails)                             # = 2t for t <= 75 (SURVEY a8)
+        reads, read_off, node_len, node_off, pred_off, pred_idx, edge_off, seq_chunks, seq_off = [], [0], [], [0], [], [], [0], [], [0]
+        max_gap = []
+        for i in range(n_reads):
+            a = int(starts[i]); need = int(depth_bp[i]); v = a; bp = 0
+            while bp < need and v < len(seqs) - 1:
+                if kind[v] != 1 or kind[v - 1] != 1:      # count a bubble's depth once
+                    bp += int(g_len[v])
+                v += 1
+            while kind[v] != 0:                           # never cut a window inside a bubble
+                v += 1
+            b = v                                         # window = nodes [a, b)
+            node_len.append(g_len[a:b]); node_off.append(node_off[-1] + (b - a))
+            off = [0]
+            for u in range(a, b):
+                pr = [p - a for p in preds[u] if p >= a]
+                pred_idx.extend(pr); off.append(off[-1] + len(pr))
+            pred_off.extend(off); edge_off.append(edge_off[-1] + off[-1])
+            seq_chunks.append((int(g_off[a]), int(g_off[b]))); seq_off.append(seq_off[-1] + int(g_off[b] - g_off[a]))
+            # read tail: random walk from the pin
+            out = []; u = a; o = 0
+            while len(out) < tails[i]:
+                if o >= g_len[u]:
+                    nx = [w for w in succ[u] if w < b]
+                    if not nx:
+                        break
+                    u = nx[int(rng.integers(0, len(nx)))]; o = 0
+                    continue
+                out.append(self.g_seq[g_off[u] + o]); o += 1
+            out = np.array(out, dtype=np.uint8)
+            sub = rng.random(len(out)) < 0.01
+            out[sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
+            reads.append(out); read_off.append(read_off[-1] + len(out))
+            max_gap.append(int(min(gap[i], 65535)))
+        seq = np.concatenate([self.g_seq[s:e] for s, e in seq_chunks])
+        self.ps = capi.ProblemSet(np.concatenate(reads), read_off, np.concatenate(node_len), node_off, seq, seq_off,
+                                  pred_off, pred_idx, edge_off, np.full(n_reads, flags, dtype=np.uint32), None, max_gap)
+        self.n = n_reads
+        self.tails = tails
+
+    def cells(self):
+        return int(((np.diff(self.ps.read_off) + 1) * np.diff(self.ps.seq_off)).sum())
