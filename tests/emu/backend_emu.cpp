@@ -27,7 +27,7 @@ public:
         std::vector<Lane<K>> lanes(64);
         std::vector<uint32_t> oh(64), of(64), oi(64);
         constexpr uint32_t REC = K / 4;
-        for (uint32_t w = 0; w < P.n_waves; ++w) {
+        for (uint32_t w = P.wave_begin; w < P.wave_begin + P.wave_count; ++w) {
             const WaveDesc wd = P.waves[w];
             for (uint32_t l = 0; l < 64; ++l) lane_init(lanes[l], P, wd, l);
             for (uint32_t t = 0; t < wd.n_steps; ++t) {
@@ -35,7 +35,7 @@ public:
                 for (uint32_t l = 0; l < 64; ++l) {
                     if ((t & 3u) == 0) lane_prefetch(lanes[l], P, t);
                     const uint32_t rh = l ? oh[l - 1] : 0, rf = l ? of[l - 1] : 0, ri = l ? oi[l - 1] : 0;
-                    uint32_t* tb = P.want_tb ? P.tb + tb_record(wd.tb_off, t, l) * REC : nullptr;
+                    uint32_t* tb = P.want_tb ? P.tb + tb_dword(wd.tb_off, t, l, REC) : nullptr;
                     lane_step<K, S8>(lanes[l], P, t, rh, rf, ri, tb);
                 }
             }
@@ -45,12 +45,18 @@ public:
             }
         }
     }
-    int run_gssw(const GsswParams& P, bool walk) override {
-        switch (P.K) {
-            case 16: if (P.scale == 8) fill<16, true>(P); else fill<16, false>(P); break;
-            case 20: if (P.scale == 8) fill<20, true>(P); else fill<20, false>(P); break;
-            case 24: if (P.scale == 8) fill<24, true>(P); else fill<24, false>(P); break;
-            default: return VGK_EINVAL;
+    int run_gssw(const GsswParams& P0, const FillLaunch* launches, uint32_t n, bool walk) override {
+        GsswParams P = P0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const FillLaunch& L = launches[i];
+            P.K = L.K; P.G = L.G; P.groups_per_wave = L.groups_per_wave; P.Lpad = L.Lpad;
+            P.wave_begin = L.wave_begin; P.wave_count = L.wave_count; P.pair_end = L.pair_end;
+            switch (P.K) {
+                case 16: if (P.scale == 8) fill<16, true>(P); else fill<16, false>(P); break;
+                case 20: if (P.scale == 8) fill<20, true>(P); else fill<20, false>(P); break;
+                case 24: if (P.scale == 8) fill<24, true>(P); else fill<24, false>(P); break;
+                default: return VGK_EINVAL;
+            }
         }
         if (walk) for (uint32_t i = 0; i < P.n_problems; ++i) walk_one(P, i, P.best[i]);
         return VGK_OK;

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
         const uint32_t rh = from_lane_above(s.out_h);
         const uint32_t rf = from_lane_above(s.out_f);
         const uint32_t ri = from_lane_above(s.info);
-        lane_step<K, S8>(s, P, t, rh, rf, ri, tb ? tb + tb_record(wd.tb_off, t, lane) * REC : nullptr);
+        lane_step<K, S8>(s, P, t, rh, rf, ri, tb ? tb + tb_dword(wd.tb_off, t, lane, REC) : nullptr);
     }
     if (!P.fused) {
 #pragma unroll
@@ -58,8 +58,9 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
     const uint32_t n_slots = 2u * P.groups_per_wave;
     for (uint32_t slot = lane; slot < n_slots; slot += 64u) {
         const uint32_t q = slot >> 1, half = slot & 1u;
-        const uint32_t prob = 2u * (wd.first_pair + q) + half;
-        if (prob >= P.n_problems) continue;
+        if (wd.first_pair + q >= P.pair_end) continue;
+        const uint32_t prob = P.order[2u * (wd.first_pair + q) + half];
+        if (prob == 0xffffffffu) continue;
         unsigned long long key = 0;
         for (uint32_t g = 0; g < P.G; ++g) { const unsigned long long k = mine[(q * P.G + g) * 2 + half]; key = k > key ? k : key; }
         walk_one(P, prob, key);
@@ -67,20 +68,19 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
 }
 
 __global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P) {
-    const uint32_t i = P.prob_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P.prob_begin + P.prob_count) walk_one(P, i, P.best[i]);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.n_problems) walk_one(P, i, P.best[i]);
 }
 
 class HipBackend final : public Backend {
 public:
-    int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, stream2 = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int dev = 0; int n_launches = 1; hipStream_t stream = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipDeviceProp_t prop;
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
     ~HipBackend() override {
         hipSetDevice(dev);
         for (auto& e : ev) if (e) hipEventDestroy(e);
         if (stream) hipStreamDestroy(stream);
-        if (stream2) hipStreamDestroy(stream2);
     }
     const char* name() const override { return prop.name; }
     int compute_units() const override { return prop.multiProcessorCount; }
@@ -120,40 +120,27 @@ public:
         }
         return VGK_OK;
     }
-    // Fill is VALU-bound, the traceback walk is a latency-bound pointer chase: the batch is cut
-    // into chunks of whole wavefronts and walk(chunk c) runs on a second stream underneath
-    // fill(chunk c+1).  With fused = 1 every wavefront walks its own reads inside the fill kernel.
-    int run_gssw(const GsswParams& p0, bool walk) override {
+    // One fill launch per length bucket (its own K x G lane geometry), then one traceback launch over all
+    // reads.  (Running walk(c) under fill(c+1) on a second stream, and fusing the walk into the fill kernel,
+    // were both measured slower than this plain sequence on MI355X — DESIGN.md §5; `fused` is kept as an option.)
+    int run_gssw(const GsswParams& p0, const FillLaunch* launches, uint32_t n, bool walk) override {
         hipSetDevice(dev);
-        if (p0.n_waves == 0) { ms_fill = ms_walk = 0; pending = false; n_launches = 1; return VGK_OK; }
+        n_launches = n ? (int)n : 1;
+        if (p0.n_problems == 0 || n == 0) { ms_fill = ms_walk = 0; pending = false; return VGK_OK; }
         GsswParams p = p0;
-        const bool split = walk && !p.fused;
-        uint32_t chunk = p.n_waves;
-        // Measured on MI355X: overlapping walk(c) with fill(c+1) on a second stream
-        // slows the VALU-bound fill more than it hides (27.1 vs 30.0 M reads/s at 400k reads), so the
-        // default is one chunk = fill then walk; VGAMD_CHUNK_WAVES=<n> enables the chunk pipeline.
-        if (split) if (const char* e = getenv("VGAMD_CHUNK_WAVES")) { const int v = atoi(e); if (v > 0) chunk = (uint32_t)v; }
-        n_launches = 0;
         hipEventRecord(ev[0], stream);
-        for (uint32_t w0 = 0; w0 < p.n_waves; w0 += chunk) {
-            p.wave_begin = w0; p.wave_count = (p.n_waves - w0 < chunk) ? p.n_waves - w0 : chunk;
-            p.prob_begin = 2u * p.groups_per_wave * w0;
-            const uint32_t pend = 2u * p.groups_per_wave * (w0 + p.wave_count);
-            p.prob_count = (pend < p.n_problems ? pend : p.n_problems) - p.prob_begin;
+        for (uint32_t i = 0; i < n; ++i) {
+            const FillLaunch& L = launches[i];
+            p.K = L.K; p.G = L.G; p.groups_per_wave = L.groups_per_wave; p.Lpad = L.Lpad;
+            p.wave_begin = L.wave_begin; p.wave_count = L.wave_count; p.pair_end = L.pair_end;
+            if (L.wave_count == 0) continue;
             int rc = launch_fill(p);
             if (rc) return rc;
-            ++n_launches;
-            if (split) {
-                hipEventRecord(ev[3], stream);
-                hipStreamWaitEvent(stream2, ev[3], 0);
-                hipLaunchKernelGGL(gssw_walk_kernel, dim3((p.prob_count + 255) / 256), dim3(256), 0, stream2, p);
-            }
         }
         hipEventRecord(ev[1], stream);
-        timed_walk = split;
-        if (split) {
-            hipEventRecord(ev[3], stream2);
-            hipStreamWaitEvent(stream, ev[3], 0);
+        timed_walk = walk && !p.fused;
+        if (timed_walk) {
+            hipLaunchKernelGGL(gssw_walk_kernel, dim3((p.n_problems + 255) / 256), dim3(256), 0, stream, p);
             hipEventRecord(ev[2], stream);
         }
         pending = true;
@@ -182,8 +169,7 @@ Backend* make_backend(int device, std::string& err) {
     b->dev = device;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&b->prop, device) != hipSuccess) {
         err = "cannot select HIP device"; delete b; return nullptr; }
-    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess) { err = "cannot create HIP stream"; delete b; return nullptr; }
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { err = "cannot create HIP stream"; delete b; return nullptr; }
     for (auto& ev : b->ev) if (hipEventCreate(&ev) != hipSuccess) { err = "cannot create HIP event"; delete b; return nullptr; }
     return b;
 }

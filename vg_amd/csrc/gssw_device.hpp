@@ -62,6 +62,11 @@ struct ProbDesc {          // one per read
     uint32_t ops_off;      // first vgk_op of this read's output window
     uint32_t ops_cap;
     uint32_t max_gap;      // XDROP: leading-insertion cells of the root column (dz_align_init), multiple of 8
+    // where the fill put this read (reads are bucketed by length; each bucket has its own K x G geometry)
+    uint32_t wave;         // wavefront (index into waves[])
+    uint32_t lane0;        // first lane of the read pair's lane group inside that wavefront
+    uint32_t geom;         // K | G << 8 | half << 16   (half: 0 = low 16-bit halves, 1 = high)
+    uint32_t Lpad;         // G*K rows per scratch slot
 };
 
 struct NodeRec {
@@ -74,7 +79,7 @@ struct NodeRec {
 };
 
 struct WaveDesc {
-    uint64_t tb_off;       // first traceback record (K/4 dwords each) of this wave
+    uint64_t tb_off;       // first traceback dword of this wave (records of K/4 dwords, step-major)
     uint32_t n_steps;
     uint32_t first_pair;
 };
@@ -88,12 +93,14 @@ struct GsswParams {
     uint32_t*       scratch;    // per (slot,row): lo16 = H of the node's last column, hi16 = E for the column after it
     uint32_t*       tb;         // K/4 dwords per (step, lane)
     const WaveDesc* waves;
+    const uint32_t* order;      // read pairs: pair p = reads order[2p] (low halves) and order[2p+1] (high halves), 0xffffffff = none
     unsigned long long* best;   // LOCAL mode: per read, max over cells of key64(score, col, row)
     vgk_result*     results;
     vgk_op*         ops;
     uint32_t n_problems, n_pairs, n_waves;
-    uint32_t wave_begin, wave_count;   // this launch covers waves [wave_begin, wave_begin + wave_count)
-    uint32_t prob_begin, prob_count;   // ... and the traceback launch these reads
+    // per fill launch (one launch per length bucket):
+    uint32_t wave_begin, wave_count;   // waves [wave_begin, wave_begin + wave_count)
+    uint32_t pair_end;                 // pairs of this bucket end here
     uint32_t K;                 // read rows per lane (16, 20 or 24)
     uint32_t G;                 // lanes per read pair
     uint32_t groups_per_wave;   // 64 / G
@@ -153,9 +160,9 @@ VGK_HD void lane_init(Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint3
     const uint32_t q = lane_id / P.G;
     s.g = lane_id - q * P.G;
     const uint32_t pair = wd.first_pair + q;
-    const bool live = (q < P.groups_per_wave) && (pair < P.n_pairs);
-    s.probA = live ? 2 * pair : 0xffffffffu;
-    s.probB = (live && 2 * pair + 1 < P.n_problems) ? 2 * pair + 1 : 0xffffffffu;
+    const bool live = (q < P.groups_per_wave) && (pair < P.pair_end);
+    s.probA = live ? P.order[2 * pair] : 0xffffffffu;
+    s.probB = live ? P.order[2 * pair + 1] : 0xffffffffu;
     s.LA = s.LB = 0; s.flagsA = s.flagsB = 0; s.RA = s.RB = 0; s.colA = s.colB = 0;
     s.ciA = s.ciB = s.ciA_n = s.ciB_n = 0;
     uint32_t roA = 0, roB = 0;
@@ -389,26 +396,18 @@ VGK_HD bool lane_best(const Lane<K>& s, int half, uint32_t& prob, unsigned long 
 // ---------------------------------------------------------------------------
 // traceback walker: one thread per read
 // ---------------------------------------------------------------------------
-// Record index of (step t, lane) inside a wave's traceback region.  Two layouts were
-// measured on MI355X: step-major (fill stores one contiguous burst per
-// step) and blocked (8 consecutive steps of a lane adjacent, kinder to the walker's
-// diagonal moves but 3-10 % slower fill stores).
-#ifndef VGK_TB_BLOCKED
-#define VGK_TB_BLOCKED 0
-#endif
-VGK_HD uint64_t tb_record(uint64_t tb_off, uint32_t t, uint32_t lane) {
-#if VGK_TB_BLOCKED
-    return tb_off + ((uint64_t)(t >> 3) * 64u + lane) * 8u + (t & 7u);
-#else
-    return tb_off + (uint64_t)t * 64u + lane;     // step-major: one contiguous burst per wave store
-#endif
+// Dword index of (step t, lane)'s traceback record: step-major, so every wave store is one contiguous
+// burst of 64*K bytes.  (A layout with 8 consecutive steps of a lane adjacent was measured: kinder to the
+// walker's diagonal moves but 3-10 % slower fill stores and no faster overall — DESIGN.md §5.)
+VGK_HD uint64_t tb_dword(uint64_t tb_off, uint32_t t, uint32_t lane, uint32_t rec_dwords) {
+    return tb_off + ((uint64_t)t * 64u + lane) * rec_dwords;
 }
 
 struct Walker {
-    const GsswParams& P; const ProbDesc& d; uint32_t half, lane0; uint64_t tb_off;
+    const GsswParams& P; const ProbDesc& d; uint32_t half, lane0, K; uint64_t tb_off;
     VGK_HD uint32_t code(uint32_t r, uint32_t c) const {
-        const uint32_t g = r / P.K, m = r - g * P.K, t = c + g, j = m >> 2, i = m & 3u;
-        const uint32_t w = P.tb[tb_record(tb_off, t, lane0 + g) * (P.K >> 2) + j];
+        const uint32_t g = r / K, m = r - g * K, t = c + g, j = m >> 2, i = m & 3u;
+        const uint32_t w = P.tb[tb_dword(tb_off, t, lane0 + g, K >> 2) + j];
         return (w >> (16 * half + 4 * (3 - i))) & 15u;
     }
     // aligned-dword caches of the read codes and the column-info bytes: the walk moves one
@@ -432,7 +431,7 @@ struct Walker {
         const int32_t s = base < 4 ? (int32_t)((w >> (8 * base)) & 0xffu) - (int32_t)P.bias : 0;
         return s + (int32_t)row_bonus(P, r, d.L, d.flags);
     }
-    VGK_HD uint32_t saved(const NodeRec& n, uint32_t r) const { return P.scratch[d.scratch_off + (uint32_t)n.slot * P.Lpad + r]; }
+    VGK_HD uint32_t saved(const NodeRec& n, uint32_t r) const { return P.scratch[d.scratch_off + (uint32_t)n.slot * d.Lpad + r]; }
 };
 
 VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
@@ -440,9 +439,7 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
     vgk_result res;
     res.score = 0; res.status = VGK_OK; res.end_node = -1; res.end_offset = -1; res.end_read = -1;
     res.first_offset = 0; res.n_ops = 0; res.ops_begin = d.ops_off;
-    const uint32_t pair = i >> 1;
-    const uint32_t wave = pair / P.groups_per_wave, slot = pair - wave * P.groups_per_wave;
-    Walker w{P, d, i & 1u, slot * P.G, P.waves[wave].tb_off, 0u, 0xffffffffu, 0u, 0xffffffffu};
+    Walker w{P, d, (d.geom >> 16) & 1u, d.lane0, d.geom & 0xffu, P.waves[d.wave].tb_off, 0u, 0xffffffffu, 0u, 0xffffffffu};
     const NodeRec* nodes = P.nodes + d.node_off;
     const bool pinned = (d.flags & 15u) == VGK_GSSW_PINNED;
     const bool xdrop = (d.flags & 15u) == VGK_XDROP_PINNED;   // rows = consumed read bases 0..len, scores carry XOFF

@@ -34,6 +34,7 @@ struct vgk_batch {
     uint64_t cells = 0, in_bytes = 0, dev_bytes = 0, alg_bytes = 0;
     uint64_t ops_total = 0;
     std::vector<ProbDesc> probs;   // kept for fetch()
+    std::vector<FillLaunch> launches;   // one per length bucket
 };
 
 static inline int nt_read(char ch) {   // gssw_create_nt_table: case-insensitive ACGT, else N
@@ -142,22 +143,24 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         maxL = std::max(maxL, problems[i].read_len + ((problems[i].flags & 15u) == VGK_XDROP_PINNED ? 1u : 0u));
     }
     if (maxL > 1024) return VGK_ETOOLONG;
-    // rows per lane: the instantiation (16, 20, 24) that spends the fewest issued instructions per
-    // useful DP cell: (K*c_row + c_step) per step buys floor(64/G)*2*L cells, G = ceil(L/K)
-    uint32_t K = 16; double best_cost = 1e30;
-    uint32_t forced = 0;
-    if (const char* e = std::getenv("VGAMD_ROWS_PER_LANE")) forced = (uint32_t)std::atoi(e);
-    for (uint32_t k : {16u, 20u, 24u}) {
-        const uint32_t g = (maxL + k - 1) / k;
-        if (g > 64) continue;
-        const double cost = (k * 25.0 + 60.0) / ((64 / g) * 2.0 * maxL);
-        if ((forced == k) || (!forced && cost < best_cost)) { best_cost = forced == k ? -1 : cost; K = k; }
-    }
-    const uint32_t G = (maxL + K - 1) / K;
     // best-cell keys pack score*32 + row: keep every reachable score below 2047
     if ((int64_t)maxL * std::max(ctx->max_score, 0) + 2 * (int64_t)ctx->sc.full_length_bonus > 2046) return VGK_EUNSUPPORTED;
-    const uint32_t gpw = 64 / G, Lpad = G * K;
-    const uint32_t n_pairs = (n + 1) / 2, n_waves = (n_pairs + gpw - 1) / gpw;
+    uint32_t forced = 0;
+    if (const char* e = std::getenv("VGAMD_ROWS_PER_LANE")) forced = (uint32_t)std::atoi(e);
+    // Lane geometry for a read of `rows` DP rows: rows per lane K (16, 20, 24) and lanes per pair G = ceil(rows/K),
+    // the instantiation that spends the fewest issued instructions per useful cell:
+    // (K*c_row + c_step) per step buys floor(64/G)*2*rows cells.
+    auto geometry = [&](uint32_t rows, uint32_t& K, uint32_t& G) {
+        double best_cost = 1e30; K = 16;
+        for (uint32_t k : {16u, 20u, 24u}) {
+            const uint32_t g = (rows + k - 1) / k;
+            if (g > 64) continue;
+            const double cost = (k * 25.0 + 60.0) / ((64 / g) * 2.0 * rows);
+            if (forced == k) { K = k; break; }
+            if (!forced && cost < best_cost) { best_cost = cost; K = k; }
+        }
+        G = (rows + K - 1) / K;
+    };
 
     std::vector<ProbDesc>& probs = b->probs;
     probs.resize(n);
@@ -216,8 +219,10 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         }
         if (col >= (1u << 20)) return VGK_ETOOBIG;
         d.R = col; d.n_slots = slots;
+        uint32_t pK, pG; geometry(d.L, pK, pG);
+        d.geom = pK | (pG << 8); d.Lpad = pG * pK; d.wave = 0; d.lane0 = 0;
         d.scratch_off = (uint32_t)scratch_words;
-        scratch_words += (uint64_t)slots * Lpad;
+        scratch_words += (uint64_t)slots * d.Lpad;
         if (scratch_words >= (1ull << 32)) return VGK_ETOOBIG;
         d.ops_cap = ops_per_problem ? ops_per_problem : (p.read_len + col + 2);
         if (!(p.flags & VGK_GSSW_TRACEBACK)) d.ops_cap = 0;
@@ -229,19 +234,52 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     }
     for (int k = 0; k < 8; ++k) colinfo.push_back(CI_INVALID);   // leaders prefetch one word ahead
 
-    std::vector<WaveDesc> waves(n_waves);
-    uint64_t tb_recs = 0;
-    for (uint32_t w = 0; w < n_waves; ++w) {
-        uint32_t rmax = 0;
-        for (uint32_t q = 0; q < gpw; ++q) {
-            const uint32_t pair = w * gpw + q;
-            for (uint32_t h = 0; h < 2; ++h) { const uint32_t i = 2 * pair + h; if (i < n) rmax = std::max(rmax, probs[i].R); }
+    // ---- length buckets: reads with the same (K, G) geometry share wavefronts; inside a bucket reads are sorted by
+    //      graph size so that the pairs of a wavefront finish together.  One fill launch per bucket.
+    std::vector<uint32_t> idx(n);
+    for (uint32_t i = 0; i < n; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
+        if ((probs[x].geom & 0xffffu) != (probs[y].geom & 0xffffu)) return (probs[x].geom & 0xffffu) < (probs[y].geom & 0xffffu);
+        return probs[x].R > probs[y].R; });
+    std::vector<uint32_t> order;              // pairs
+    std::vector<WaveDesc> waves;
+    std::vector<FillLaunch>& launches = b->launches;
+    uint64_t tb_dwords = 0;
+    for (uint32_t s0 = 0; s0 < n;) {
+        uint32_t s1 = s0;
+        const uint32_t gk = probs[idx[s0]].geom & 0xffffu;
+        while (s1 < n && (probs[idx[s1]].geom & 0xffffu) == gk) ++s1;
+        FillLaunch L{};
+        L.K = gk & 0xffu; L.G = gk >> 8; L.groups_per_wave = 64 / L.G; L.Lpad = L.G * L.K;
+        L.wave_begin = (uint32_t)waves.size();
+        const uint32_t pair0 = (uint32_t)(order.size() / 2);
+        for (uint32_t k = s0; k < s1; k += 2) {
+            order.push_back(idx[k]);
+            order.push_back(k + 1 < s1 ? idx[k + 1] : 0xffffffffu);
         }
-        waves[w].first_pair = w * gpw;
-        waves[w].n_steps = rmax ? rmax + G - 1 : 0;
-        waves[w].tb_off = tb_recs;
-        if (b->want_tb) tb_recs += (uint64_t)((waves[w].n_steps + 7) & ~7u) * 64;   // records of K/4 dwords, steps in blocks of 8
+        const uint32_t pair1 = (uint32_t)(order.size() / 2);
+        L.pair_end = pair1;
+        for (uint32_t pw = pair0; pw < pair1; pw += L.groups_per_wave) {
+            WaveDesc wd{};
+            wd.first_pair = pw;
+            uint32_t rmax = 0;
+            for (uint32_t q = 0; q < L.groups_per_wave && pw + q < pair1; ++q)
+                for (uint32_t h = 0; h < 2; ++h) {
+                    const uint32_t i = order[2 * (pw + q) + h];
+                    if (i == 0xffffffffu) continue;
+                    rmax = std::max(rmax, probs[i].R);
+                    probs[i].wave = (uint32_t)waves.size(); probs[i].lane0 = q * L.G; probs[i].geom = gk | (h << 16);
+                }
+            wd.n_steps = rmax ? rmax + L.G - 1 : 0;
+            wd.tb_off = tb_dwords;
+            if (b->want_tb) tb_dwords += (uint64_t)wd.n_steps * 64 * (L.K / 4);
+            waves.push_back(wd);
+        }
+        L.wave_count = (uint32_t)waves.size() - L.wave_begin;
+        launches.push_back(L);
+        s0 = s1;
     }
+    const uint32_t n_pairs = (uint32_t)(order.size() / 2), n_waves = (uint32_t)waves.size();
 
     std::lock_guard<std::mutex> lk(ctx->mu);
     GsswParams& P = b->P;
@@ -254,13 +292,14 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     if ((rc = to_device(b, nodes, P.nodes))) return fail(rc);
     if ((rc = to_device(b, preds, P.preds, 1))) return fail(rc);
     if ((rc = to_device(b, waves, P.waves))) return fail(rc);
+    if ((rc = to_device(b, order, P.order, 2))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)scratch_words + 16, P.scratch))) return fail(rc);
-    if ((rc = dev_alloc(b, (size_t)tb_recs * (K / 4) + 4, P.tb))) return fail(rc);
+    if ((rc = dev_alloc(b, (size_t)tb_dwords + 4, P.tb))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)n + 1, P.best))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)n + 1, P.results))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)ops_total + 1, P.ops))) return fail(rc);
-    P.wave_begin = 0; P.wave_count = n_waves; P.prob_begin = 0; P.prob_count = n;
-    P.n_problems = n; P.n_pairs = n_pairs; P.n_waves = n_waves; P.K = K; P.G = G; P.groups_per_wave = gpw; P.Lpad = Lpad;
+    P.wave_begin = 0; P.wave_count = 0; P.pair_end = 0;          // set per fill launch from b->launches
+    P.n_problems = n; P.n_pairs = n_pairs; P.n_waves = n_waves; P.K = 0; P.G = 0; P.groups_per_wave = 0; P.Lpad = 0;
     // scale 8 whenever the scaled profile bytes still fit (they do for vg's default 1/4/6/1/5): see GsswParams::scale
     uint32_t S = ((ctx->max_score + (int)ctx->bias + 2 * ctx->sc.full_length_bonus) * 8 <= 255) ? 8u : 1u;
     if (const char* e = std::getenv("VGAMD_SCORE_SCALE")) S = std::atoi(e) == 8 && S == 8 ? 8u : 1u;
@@ -282,7 +321,7 @@ int vgk_gssw_run(vgk_batch* b) {
     std::lock_guard<std::mutex> lk(b->ctx->mu);
     int rc = b->ctx->be->zero(b->P.best, ((size_t)b->n + 1) * sizeof(unsigned long long));
     if (rc) return rc;
-    rc = b->ctx->be->run_gssw(b->P, true);
+    rc = b->ctx->be->run_gssw(b->P, b->launches.data(), (uint32_t)b->launches.size(), true);
     if (rc == VGK_OK) b->ran = true;
     return rc;
 }
