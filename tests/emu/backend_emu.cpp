@@ -49,8 +49,7 @@ public:
         GsswParams P = P0;
         for (uint32_t i = 0; i < n; ++i) {
             const FillLaunch& L = launches[i];
-            P.K = L.K; P.G = L.G; P.groups_per_wave = L.groups_per_wave; P.Lpad = L.Lpad;
-            P.wave_begin = L.wave_begin; P.wave_count = L.wave_count; P.pair_end = L.pair_end;
+            P.K = L.K; P.wave_begin = L.wave_begin; P.wave_count = L.wave_count;
             switch (P.K) {
                 case 16: if (P.scale == 8) fill<16, true>(P); else fill<16, false>(P); break;
                 case 20: if (P.scale == 8) fill<20, true>(P); else fill<20, false>(P); break;

@@ -10,7 +10,7 @@
 
 namespace vgk {
 
-struct FillLaunch { uint32_t K, G, groups_per_wave, Lpad, wave_begin, wave_count, pair_end; };
+struct FillLaunch { uint32_t K, wave_begin, wave_count; };
 
 class Backend {
 public:
@@ -24,7 +24,7 @@ public:
     virtual int   download(void* dst, const void* src, size_t bytes) = 0;   // synchronous
     virtual int   zero(void* dst, size_t bytes) = 0;                        // async on the stream
     virtual int   sync() = 0;
-    // gssw kernels: one fill launch per length bucket (geometry in `launches`), then one traceback
+    // gssw kernels: one fill launch per rows-per-lane instantiation (`launches`), then one traceback
     // launch over all reads; timings (ms, HIP events on the launch stream) of the last run
     virtual int   run_gssw(const GsswParams& p, const FillLaunch* launches, uint32_t n_launches, bool walk) = 0;
     virtual double last_ms(int which) const = 0;           // 0 = fill (all launches), 1 = traceback tail, 2 = number of fill launches

@@ -55,14 +55,14 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
         mine[lane * 2 + half] = key;
     }
     __threadfence();      // this wave's traceback codes / scratch columns -> visible to its walker lanes
-    const uint32_t n_slots = 2u * P.groups_per_wave;
+    const uint32_t n_slots = 2u * (64u / wd.G);
     for (uint32_t slot = lane; slot < n_slots; slot += 64u) {
         const uint32_t q = slot >> 1, half = slot & 1u;
-        if (wd.first_pair + q >= P.pair_end) continue;
+        if (wd.first_pair + q >= wd.pair_end) continue;
         const uint32_t prob = P.order[2u * (wd.first_pair + q) + half];
         if (prob == 0xffffffffu) continue;
         unsigned long long key = 0;
-        for (uint32_t g = 0; g < P.G; ++g) { const unsigned long long k = mine[(q * P.G + g) * 2 + half]; key = k > key ? k : key; }
+        for (uint32_t g = 0; g < wd.G; ++g) { const unsigned long long k = mine[(q * wd.G + g) * 2 + half]; key = k > key ? k : key; }
         walk_one(P, prob, key);
     }
 }
@@ -120,7 +120,7 @@ public:
         }
         return VGK_OK;
     }
-    // One fill launch per length bucket (its own K x G lane geometry), then one traceback launch over all
+    // One fill launch per rows-per-lane instantiation K (lanes-per-pair G is a per-wavefront value), then one traceback launch over all
     // reads.  (Running walk(c) under fill(c+1) on a second stream, and fusing the walk into the fill kernel,
     // were both measured slower than this plain sequence on MI355X — DESIGN.md §5; `fused` is kept as an option.)
     int run_gssw(const GsswParams& p0, const FillLaunch* launches, uint32_t n, bool walk) override {
@@ -131,8 +131,7 @@ public:
         hipEventRecord(ev[0], stream);
         for (uint32_t i = 0; i < n; ++i) {
             const FillLaunch& L = launches[i];
-            p.K = L.K; p.G = L.G; p.groups_per_wave = L.groups_per_wave; p.Lpad = L.Lpad;
-            p.wave_begin = L.wave_begin; p.wave_count = L.wave_count; p.pair_end = L.pair_end;
+            p.K = L.K; p.wave_begin = L.wave_begin; p.wave_count = L.wave_count;
             if (L.wave_count == 0) continue;
             int rc = launch_fill(p);
             if (rc) return rc;

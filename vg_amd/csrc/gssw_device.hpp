@@ -82,6 +82,8 @@ struct WaveDesc {
     uint64_t tb_off;       // first traceback dword of this wave (records of K/4 dwords, step-major)
     uint32_t n_steps;
     uint32_t first_pair;
+    uint32_t G;            // lanes per read pair in this wavefront (length buckets differ)
+    uint32_t pair_end;     // pairs of this wavefront's bucket end here
 };
 
 struct GsswParams {
@@ -98,13 +100,9 @@ struct GsswParams {
     vgk_result*     results;
     vgk_op*         ops;
     uint32_t n_problems, n_pairs, n_waves;
-    // per fill launch (one launch per length bucket):
+    // per fill launch (one launch per rows-per-lane instantiation K; lanes-per-pair G varies per wavefront):
     uint32_t wave_begin, wave_count;   // waves [wave_begin, wave_begin + wave_count)
-    uint32_t pair_end;                 // pairs of this bucket end here
-    uint32_t K;                 // read rows per lane (16, 20 or 24)
-    uint32_t G;                 // lanes per read pair
-    uint32_t groups_per_wave;   // 64 / G
-    uint32_t Lpad;              // G*K rows per scratch slot
+    uint32_t K;                 // read rows per lane (16, 20 or 24) of this fill launch
     uint32_t prof4[6];          // per read base q: byte r = matrix[5r+q] + bias, r = 0..3; [5] = 0 (X-drop row 0: consumes nothing)
     uint32_t bias;
     uint32_t go, ge;
@@ -148,6 +146,7 @@ struct Lane {
     uint32_t best_lo, best_hi, step_lo, step_hi;
     uint32_t nodeA, nodeB;
     uint32_t g;                     // lane index inside the group
+    uint32_t Lpad;                  // rows per scratch slot of this wavefront's bucket (G*K)
     uint32_t probA, probB;          // read indices or 0xffffffff
     uint32_t LA, LB, flagsA, flagsB;
     uint32_t RA, RB, colA, colB;    // graph columns and column-info stream offsets
@@ -157,10 +156,11 @@ struct Lane {
 
 template <int K>
 VGK_HD void lane_init(Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint32_t lane_id) {
-    const uint32_t q = lane_id / P.G;
-    s.g = lane_id - q * P.G;
+    const uint32_t q = lane_id / wd.G;
+    s.g = lane_id - q * wd.G;
+    s.Lpad = wd.G * K;
     const uint32_t pair = wd.first_pair + q;
-    const bool live = (q < P.groups_per_wave) && (pair < P.pair_end);
+    const bool live = (q < 64u / wd.G) && (pair < wd.pair_end);
     s.probA = live ? P.order[2 * pair] : 0xffffffffu;
     s.probB = live ? P.order[2 * pair + 1] : 0xffffffffu;
     s.LA = s.LB = 0; s.flagsA = s.flagsB = 0; s.RA = s.RB = 0; s.colA = s.colB = 0;
@@ -248,7 +248,7 @@ VGK_HD void seed_from_scratch(Lane<K>& s, const GsswParams& P, uint32_t prob, ui
     }
     for (uint32_t k = 0; k < nr.n_pred; ++k) {
         const NodeRec& pr = P.nodes[d.node_off + P.preds[nr.pred_begin + k]];
-        const uint32_t* base = P.scratch + d.scratch_off + (uint32_t)pr.slot * P.Lpad + s.g * K;
+        const uint32_t* base = P.scratch + d.scratch_off + (uint32_t)pr.slot * s.Lpad + s.g * K;
 #pragma unroll
         for (int m = 0; m < K; ++m) {
             const uint32_t v = scratch_load(base + m);     // lo16 = H, hi16 = E-next of the predecessor's last column
@@ -267,7 +267,7 @@ template <int HALF, int K>
 VGK_HD void store_to_scratch(const Lane<K>& s, const GsswParams& P, uint32_t prob, uint32_t node) {
     const ProbDesc& d = P.probs[prob];
     const NodeRec& nr = P.nodes[d.node_off + node];
-    uint32_t* base = P.scratch + d.scratch_off + (uint32_t)nr.slot * P.Lpad + s.g * K;
+    uint32_t* base = P.scratch + d.scratch_off + (uint32_t)nr.slot * s.Lpad + s.g * K;
 #pragma unroll
     for (int m = 0; m < K; ++m) {
         uint32_t h = HALF == 0 ? (s.H[m] & 0xffffu) : (s.H[m] >> 16);

@@ -235,11 +235,12 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     for (int k = 0; k < 8; ++k) colinfo.push_back(CI_INVALID);   // leaders prefetch one word ahead
 
     // ---- length buckets: reads with the same (K, G) geometry share wavefronts; inside a bucket reads are sorted by
-    //      graph size so that the pairs of a wavefront finish together.  One fill launch per bucket.
+    //      graph size so that the pairs of a wavefront finish together.  One fill launch per K; G is per wavefront.
+    auto gkey = [&](uint32_t i) { return ((probs[i].geom & 0xffu) << 8) | ((probs[i].geom >> 8) & 0xffu); };   // (K, G)
     std::vector<uint32_t> idx(n);
     for (uint32_t i = 0; i < n; ++i) idx[i] = i;
     std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
-        if ((probs[x].geom & 0xffffu) != (probs[y].geom & 0xffffu)) return (probs[x].geom & 0xffffu) < (probs[y].geom & 0xffffu);
+        if (gkey(x) != gkey(y)) return gkey(x) < gkey(y);
         return probs[x].R > probs[y].R; });
     std::vector<uint32_t> order;              // pairs
     std::vector<WaveDesc> waves;
@@ -247,36 +248,33 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     uint64_t tb_dwords = 0;
     for (uint32_t s0 = 0; s0 < n;) {
         uint32_t s1 = s0;
-        const uint32_t gk = probs[idx[s0]].geom & 0xffffu;
-        while (s1 < n && (probs[idx[s1]].geom & 0xffffu) == gk) ++s1;
-        FillLaunch L{};
-        L.K = gk & 0xffu; L.G = gk >> 8; L.groups_per_wave = 64 / L.G; L.Lpad = L.G * L.K;
-        L.wave_begin = (uint32_t)waves.size();
+        const uint32_t gk = gkey(idx[s0]);
+        while (s1 < n && gkey(idx[s1]) == gk) ++s1;
+        const uint32_t K = gk >> 8, G = gk & 0xffu, gpw = 64 / G;
+        if (launches.empty() || launches.back().K != K) launches.push_back(FillLaunch{K, (uint32_t)waves.size(), 0});
         const uint32_t pair0 = (uint32_t)(order.size() / 2);
         for (uint32_t k = s0; k < s1; k += 2) {
             order.push_back(idx[k]);
             order.push_back(k + 1 < s1 ? idx[k + 1] : 0xffffffffu);
         }
         const uint32_t pair1 = (uint32_t)(order.size() / 2);
-        L.pair_end = pair1;
-        for (uint32_t pw = pair0; pw < pair1; pw += L.groups_per_wave) {
+        for (uint32_t pw = pair0; pw < pair1; pw += gpw) {
             WaveDesc wd{};
-            wd.first_pair = pw;
+            wd.first_pair = pw; wd.G = G; wd.pair_end = pair1;
             uint32_t rmax = 0;
-            for (uint32_t q = 0; q < L.groups_per_wave && pw + q < pair1; ++q)
+            for (uint32_t q = 0; q < gpw && pw + q < pair1; ++q)
                 for (uint32_t h = 0; h < 2; ++h) {
                     const uint32_t i = order[2 * (pw + q) + h];
                     if (i == 0xffffffffu) continue;
                     rmax = std::max(rmax, probs[i].R);
-                    probs[i].wave = (uint32_t)waves.size(); probs[i].lane0 = q * L.G; probs[i].geom = gk | (h << 16);
+                    probs[i].wave = (uint32_t)waves.size(); probs[i].lane0 = q * G; probs[i].geom = K | (G << 8) | (h << 16);
                 }
-            wd.n_steps = rmax ? rmax + L.G - 1 : 0;
+            wd.n_steps = rmax ? rmax + G - 1 : 0;
             wd.tb_off = tb_dwords;
-            if (b->want_tb) tb_dwords += (uint64_t)wd.n_steps * 64 * (L.K / 4);
+            if (b->want_tb) tb_dwords += (uint64_t)wd.n_steps * 64 * (K / 4);
             waves.push_back(wd);
         }
-        L.wave_count = (uint32_t)waves.size() - L.wave_begin;
-        launches.push_back(L);
+        launches.back().wave_count = (uint32_t)waves.size() - launches.back().wave_begin;
         s0 = s1;
     }
     const uint32_t n_pairs = (uint32_t)(order.size() / 2), n_waves = (uint32_t)waves.size();
@@ -298,8 +296,8 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     if ((rc = dev_alloc(b, (size_t)n + 1, P.best))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)n + 1, P.results))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)ops_total + 1, P.ops))) return fail(rc);
-    P.wave_begin = 0; P.wave_count = 0; P.pair_end = 0;          // set per fill launch from b->launches
-    P.n_problems = n; P.n_pairs = n_pairs; P.n_waves = n_waves; P.K = 0; P.G = 0; P.groups_per_wave = 0; P.Lpad = 0;
+    P.wave_begin = 0; P.wave_count = 0; P.K = 0;                 // set per fill launch from b->launches
+    P.n_problems = n; P.n_pairs = n_pairs; P.n_waves = n_waves;
     // scale 8 whenever the scaled profile bytes still fit (they do for vg's default 1/4/6/1/5): see GsswParams::scale
     uint32_t S = ((ctx->max_score + (int)ctx->bias + 2 * ctx->sc.full_length_bonus) * 8 <= 255) ? 8u : 1u;
     if (const char* e = std::getenv("VGAMD_SCORE_SCALE")) S = std::atoi(e) == 8 && S == 8 ? 8u : 1u;
