@@ -74,12 +74,13 @@ __global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P) {
 
 class HipBackend final : public Backend {
 public:
-    int dev = 0; int n_launches = 1; hipStream_t stream = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipDeviceProp_t prop;
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
     ~HipBackend() override {
         hipSetDevice(dev);
         for (auto& e : ev) if (e) hipEventDestroy(e);
+        for (int i = 0; i < 2; ++i) { if (side[i]) hipStreamDestroy(side[i]); if (side_done[i]) hipEventDestroy(side_done[i]); }
         if (stream) hipStreamDestroy(stream);
     }
     const char* name() const override { return prop.name; }
@@ -109,7 +110,7 @@ public:
         hipSetDevice(dev);
         return hipStreamSynchronize(stream) == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
-    int launch_fill(const GsswParams& p) {
+    int launch_fill(const GsswParams& p, hipStream_t stream) {
         const dim3 grid((p.wave_count + 3) / 4), block(256);
         const bool s8 = p.scale == 8;
         switch (p.K) {
@@ -129,12 +130,17 @@ public:
         if (p0.n_problems == 0 || n == 0) { ms_fill = ms_walk = 0; pending = false; return VGK_OK; }
         GsswParams p = p0;
         hipEventRecord(ev[0], stream);
+        // the (up to three) rows-per-lane instantiations are independent: side streams let a small bucket's
+        // launch fill the CUs another bucket leaves idle; everything joins `stream` again before the walk
         for (uint32_t i = 0; i < n; ++i) {
             const FillLaunch& L = launches[i];
             p.K = L.K; p.wave_begin = L.wave_begin; p.wave_count = L.wave_count;
             if (L.wave_count == 0) continue;
-            int rc = launch_fill(p);
+            hipStream_t st = (i == 0 || i > 2) ? stream : side[i - 1];
+            if (st != stream) hipStreamWaitEvent(st, ev[0], 0);
+            int rc = launch_fill(p, st);
             if (rc) return rc;
+            if (st != stream) { hipEventRecord(side_done[i - 1], st); hipStreamWaitEvent(stream, side_done[i - 1], 0); }
         }
         hipEventRecord(ev[1], stream);
         timed_walk = walk && !p.fused;
@@ -169,6 +175,9 @@ Backend* make_backend(int device, std::string& err) {
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&b->prop, device) != hipSuccess) {
         err = "cannot select HIP device"; delete b; return nullptr; }
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { err = "cannot create HIP stream"; delete b; return nullptr; }
+    for (int i = 0; i < 2; ++i)
+        if (hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&b->side_done[i], hipEventDisableTiming) != hipSuccess) { err = "cannot create HIP side stream"; delete b; return nullptr; }
     for (auto& ev : b->ev) if (hipEventCreate(&ev) != hipSuccess) { err = "cannot create HIP event"; delete b; return nullptr; }
     return b;
 }
