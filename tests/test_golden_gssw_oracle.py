@@ -5,7 +5,7 @@ src/unittest/pinned_alignment.cpp.  CPU only: the host shim is bound to the
 oracle library explicitly here (the product binds the HIP library)."""
 import pytest
 
-from util import HostAligner, ORACLE_LIB, check_expectations, load_golden
+from util import HostAligner, ORACLE_LIB, check_expectations, load_golden, run_align_xdrop
 
 
 def _cases(fname, calls):
@@ -74,3 +74,26 @@ def run_xdrop_group(engine_lib):
 def test_oracle_matches_reference_xdrop_pinned_unit_tests():
     ncase, nexp = run_xdrop_group(ORACLE_LIB)
     assert ncase >= 15 and nexp >= 80
+
+
+def seeded_xdrop_cases():
+    return [c for c in load_golden("ref_xdrop_aligner.json")
+            if c["call"] == "align_xdrop" and not c["qual_adj"] and isinstance(c["args"][1], dict) and c["nodes"]]
+
+
+def run_seeded_xdrop_group(engine_lib):
+    n = 0
+    cases = seeded_xdrop_cases()
+    for c in cases:
+        al = HostAligner(engine_lib, tuple(c["scores"]))
+        args = c["args"]           # [graph, {mems}, reverse_complemented, max_gap?]
+        max_gap = args[3] if len(args) > 3 and isinstance(args[3], int) else 40
+        aln = run_align_xdrop(al, c["nodes"], c["edges"], c["read"], args[1]["mems"], bool(args[2]), max_gap)
+        check_expectations(c, aln, {c["aln"]: aln["score"]})
+        n += len(c["expect"])
+    return len(cases), n
+
+
+def test_oracle_matches_reference_seeded_xdrop_unit_tests():
+    ncase, nexp = run_seeded_xdrop_group(ORACLE_LIB)
+    assert ncase >= 7 and nexp >= 20

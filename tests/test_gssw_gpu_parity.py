@@ -75,3 +75,9 @@ def test_reference_xdrop_unit_test_vectors_through_host_shim_on_hip():
     from test_golden_gssw_oracle import run_xdrop_group
     ncase, nexp = run_xdrop_group(ENGINE_LIB)
     assert ncase >= 15 and nexp >= 80
+
+
+def test_reference_seeded_xdrop_unit_test_vectors_through_host_shim_on_hip():
+    from test_golden_gssw_oracle import run_seeded_xdrop_group
+    ncase, nexp = run_seeded_xdrop_group(ENGINE_LIB)
+    assert ncase >= 7 and nexp >= 20

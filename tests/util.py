@@ -32,6 +32,8 @@ def host():
         h.vgh_aligner_destroy.argtypes = [ctypes.c_void_p]
         h.vgh_align.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+        h.vgh_align_xdrop.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
         _host = h
     return _host
 
@@ -64,6 +66,29 @@ class HostAligner:
             return json.loads(buf.value.decode())
         finally:
             self.h.vgh_graph_destroy(g)
+
+
+def run_align_xdrop(aligner, nodes, edges, read, mems, reverse_complemented, max_gap=40):
+    """Aligner::align_xdrop through the host shim; mems = [{begin, end, nodes: [[id, offset, is_rev]]}]."""
+    h = aligner.h
+    g = h.vgh_graph_create()
+    try:
+        for nid, seq in nodes:
+            assert h.vgh_graph_add_node(g, nid, seq.encode()) == 0
+        for a, b in edges:
+            assert h.vgh_graph_add_edge(g, a, b) == 0
+        flat = []
+        for m in mems:
+            hit = m["nodes"][-1]
+            flat += [m["begin"], m["end"], hit[0], hit[1], int(hit[2])]
+        arr = (ctypes.c_int64 * max(1, len(flat)))(*flat)
+        buf = ctypes.create_string_buffer(1 << 20)
+        rc = h.vgh_align_xdrop(aligner.ptr, g, read.encode(), arr, len(mems), int(reverse_complemented), max_gap, buf, len(buf))
+        if rc != 0:
+            raise RuntimeError(h.vgh_last_error().decode())
+        return json.loads(buf.value.decode())
+    finally:
+        h.vgh_graph_destroy(g)
 
 
 def check_expectations(case, aln, sibling_scores=None):

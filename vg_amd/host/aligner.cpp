@@ -449,3 +449,233 @@ std::string alignment_to_json(const Alignment& a) {
 }
 
 }  // namespace vgamd
+
+// ---------------------------------------------------------------------------------------------------------
+// Seeded two-pass X-drop alignment (DozeuInterface::align, src/dozeu_interface.cpp:608-685): a first pinned
+// extension from the seed finds the "head" (position of the maximum), a second pinned extension from the
+// head in the opposite direction is traced back.  Both passes run on the engine's VGK_XDROP_PINNED mode over
+// a sub-DAG cut at the start position (dozeu is handed `seq + ref_offset`, src/dozeu_interface.cpp:236-243).
+// ---------------------------------------------------------------------------------------------------------
+namespace vgamd {
+
+Aligner::Extension Aligner::xdrop_extend(const HandleGraph& g, const std::vector<handle_t>& order, size_t node_index,
+                                         size_t ref_offset, const std::string& read, size_t query_offset,
+                                         bool right_to_left, bool traceback, uint16_t max_gap_length) const {
+    Extension ext;
+    ext.end_node = node_index; ext.end_ref_offset = ref_offset; ext.end_query = query_offset;
+    std::unordered_map<handle_t, size_t, handle_hash> index_of;
+    for (size_t i = 0; i < order.size(); ++i) index_of[order[i]] = i;
+    // the part of the start node that lies in the extension direction, and the read part to consume
+    std::string start_seq = g.get_sequence(order[node_index]);
+    std::string query;
+    if (!right_to_left) { start_seq = start_seq.substr(ref_offset); query = read.substr(query_offset); }
+    else { start_seq = start_seq.substr(0, ref_offset); std::reverse(start_seq.begin(), start_seq.end());
+           query = read.substr(0, query_offset); std::reverse(query.begin(), query.end()); }
+    if (query.empty()) return ext;
+    // nodes reachable from the start, in extension order (the caller's order, reversed for a leftward pass)
+    std::vector<char> reach(order.size(), 0);
+    reach[node_index] = 1;
+    std::vector<size_t> sub;                       // sub index -> index in `order`
+    const int64_t inc = right_to_left ? -1 : 1;
+    for (int64_t i = (int64_t)node_index; i >= 0 && i < (int64_t)order.size(); i += inc) {
+        if (i != (int64_t)node_index) {
+            bool r = false;
+            g.follow_edges_v(order[i], !right_to_left, [&](const handle_t& nb) { auto it = index_of.find(nb); if (it != index_of.end() && reach[it->second]) r = true; });
+            reach[i] = r;
+        }
+        if (reach[i]) sub.push_back((size_t)i);
+    }
+    const bool skip_start = start_seq.empty();     // pinned exactly at the node's end: its neighbours start from the root
+    PackedGraph pg;
+    std::unordered_map<size_t, uint32_t> sub_of;
+    std::vector<size_t> kept;
+    for (size_t i : sub) { if (i == node_index && skip_start) continue; sub_of[i] = (uint32_t)kept.size(); kept.push_back(i); }
+    if (kept.empty()) return ext;
+    pg.pred_off.push_back(0);
+    for (size_t i : kept) {
+        std::string s = (i == node_index) ? start_seq : g.get_sequence(order[i]);
+        if (right_to_left && i != node_index) std::reverse(s.begin(), s.end());
+        if (s.empty()) throw std::runtime_error("vgamd: empty node inside an X-drop extension (mask it with DozeuPinningOverlay first)");
+        pg.order.push_back(order[i]); pg.node_len.push_back((uint32_t)s.size()); pg.seq += s;
+        if (i != node_index) g.follow_edges_v(order[i], !right_to_left, [&](const handle_t& nb) {
+            auto it = index_of.find(nb);
+            if (it == index_of.end() || !reach[it->second]) return;
+            auto st = sub_of.find(it->second);
+            if (st != sub_of.end()) pg.pred_idx.push_back(st->second);      // (a skipped start node leaves its neighbours as sources)
+        });
+        pg.pred_off.push_back((uint32_t)pg.pred_idx.size());
+    }
+    vgk_gssw_problem prob{};
+    prob.read = query.data(); prob.read_len = (uint32_t)query.size();
+    prob.flags = VGK_XDROP_PINNED | (traceback ? VGK_GSSW_TRACEBACK : 0);
+    prob.graph = pg.view(); prob.max_gap_length = std::max<uint16_t>(max_gap_length, 1);
+    vgk_result res{}; std::vector<vgk_op> ops(prob.read_len + pg.seq.size() + kept.size() + 4);
+    size_t written = 0;
+    int rc = engine->gssw_align(ctx, &prob, 1, &res, ops.data(), ops.size(), &written);
+    if (rc != VGK_OK || res.status != VGK_OK)
+        throw std::runtime_error(std::string("vgamd: xdrop engine failed: ") + engine->strerror(rc ? rc : res.status));
+    ops.resize(res.n_ops);
+    ext.score = res.score;
+    if (res.score <= 0) return ext;
+    // position of the maximum, back in the caller's coordinates (exclusive ends / remaining prefix lengths)
+    const size_t en = kept[(size_t)res.end_node];
+    const size_t used = (size_t)res.end_offset + 1;               // bases of that node consumed in extension direction
+    ext.end_node = en;
+    if (!right_to_left) { ext.end_ref_offset = (en == node_index ? ref_offset : 0) + used; ext.end_query = query_offset + (size_t)res.end_read + 1; }
+    else { ext.end_ref_offset = (en == node_index ? ref_offset : g.get_length(order[en])) - used; ext.end_query = query_offset - ((size_t)res.end_read + 1); }
+    if (!traceback) return ext;
+    // ops -> mappings in read order.  A leftward pass ran on reversed strings: flip it back (as for a right pin).
+    if (right_to_left) unreverse_ops(ops, res, pg.node_len);
+    size_t to_pos = right_to_left ? 0 : query_offset;
+    int from_pos = right_to_left ? res.first_offset : 0;
+    uint32_t i = 0; bool first_node = true;
+    while (i < ops.size()) {
+        uint32_t node = ops[i].node, j = i;
+        while (j < ops.size() && ops[j].node == node) ++j;
+        const size_t oi = kept[node];
+        const std::string node_seq = g.get_sequence(order[oi]);
+        // where this mapping starts on the original node
+        int node_from;
+        if (!right_to_left) node_from = (first_node && oi == node_index) ? (int)ref_offset : 0;
+        else node_from = first_node ? from_pos : 0;
+        first_node = false;
+        ext.mappings.emplace_back();
+        Mapping& mapping = ext.mappings.back();
+        mapping.position.node_id = g.get_id(order[oi]); mapping.position.is_reverse = g.get_is_reverse(order[oi]);
+        mapping.position.offset = node_from;
+        int fp = node_from;
+        for (uint32_t k = i; k < j; ++k) {
+            const int32_t len = ops[k].len;
+            switch (ops[k].op) {
+                case VGK_OP_M: {
+                    int run = 0;
+                    for (int t = 0; t < len; ++t) {
+                        if (node_seq[fp + t] == read[to_pos + t]) { ++run; ++ext.matches; }
+                        else {
+                            if (run) { Edit e; e.from_length = e.to_length = run; mapping.edit.push_back(e); run = 0; }
+                            Edit e; e.from_length = e.to_length = 1; e.sequence = read.substr(to_pos + t, 1); mapping.edit.push_back(e);
+                        }
+                    }
+                    if (run) { Edit e; e.from_length = e.to_length = run; mapping.edit.push_back(e); }
+                    fp += len; to_pos += len;
+                } break;
+                case VGK_OP_D: { Edit e; e.from_length = len; e.to_length = 0; mapping.edit.push_back(e); fp += len; } break;
+                case VGK_OP_I:
+                case VGK_OP_S: {
+                    const bool merge_prev = !mapping.edit.empty() && edit_is_insertion(mapping.edit.back());
+                    if (merge_prev) { Edit& e = mapping.edit.back(); e.to_length += len; e.sequence += read.substr(to_pos, len); }
+                    else { Edit e; e.from_length = 0; e.to_length = len; e.sequence = read.substr(to_pos, len); mapping.edit.push_back(e); }
+                    to_pos += len;
+                } break;
+                default: throw std::runtime_error("vgamd: unsupported cigar op from engine");
+            }
+        }
+        i = j;
+    }
+    return ext;
+}
+
+void Aligner::align_xdrop(Alignment& alignment, const HandleGraph& g, const std::vector<MaximalExactMatch>& mems,
+                          bool reverse_complemented, uint16_t max_gap_length) const {
+    align_xdrop(alignment, g, handlealgs::lazier_topological_order(&g), mems, reverse_complemented, max_gap_length);
+}
+
+void Aligner::align_xdrop(Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& order,
+                          const std::vector<MaximalExactMatch>& mems, bool reverse_complemented, uint16_t max_gap_length) const {
+    xdrop_align(alignment, g, order, mems, reverse_complemented, max_gap_length);
+    if (!alignment.has_path() && mems.empty()) {
+        // dozeu couldn't find an alignment, probably because its seeding heuristic failed: fall back on gssw
+        // (bonus at both ends there, once in dozeu — known inconsistency, src/aligner.cpp:848-854)
+        align(alignment, g, order);
+    }
+}
+
+void Aligner::xdrop_align(Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& order,
+                          const std::vector<MaximalExactMatch>& mems, bool reverse_complemented, uint16_t max_gap_length) const {
+    const std::string& read = alignment.sequence;
+    const bool direction = reverse_complemented;
+    alignment.clear_path();
+    if (order.empty() || read.empty()) return;
+    std::unordered_map<handle_t, size_t, handle_hash> index_of;
+    for (size_t i = 0; i < order.size(); ++i) index_of[order[i]] = i;
+
+    // ---- head position (src/dozeu_interface.cpp:629-673)
+    size_t head_node = 0, head_ref = 0, head_query = 0;
+    bool have_head = false;
+    if (mems.empty()) {
+        // scan_seed_position (:143-208): locate the best match of the 15-base read end nearest the far side.
+        // dz_scan's exact rules are in the missing dozeu source [PARITY-UNPINNED]; the engine's local mode on
+        // the same 15 bases finds the same maximum position whenever the best hit is an end-to-end match.
+        const size_t qlen = read.size(), scan_len = std::min<size_t>(qlen, 15);
+        std::string tail = direction ? read.substr(0, scan_len) : read.substr(qlen - scan_len);
+        PackedGraph pg; pg.order = order; pg.pred_off.push_back(0);
+        const HandleGraph* sg = &g; ReverseGraph rg(&g, false);
+        std::vector<handle_t> run_order = order;
+        if (direction) { sg = &rg; std::reverse(run_order.begin(), run_order.end()); std::reverse(tail.begin(), tail.end()); pg.order = run_order; }
+        std::unordered_map<handle_t, uint32_t, handle_hash> ridx;
+        for (uint32_t i = 0; i < run_order.size(); ++i) ridx[run_order[i]] = i;
+        for (uint32_t i = 0; i < run_order.size(); ++i) {
+            std::string s = sg->get_sequence(run_order[i]);
+            pg.node_len.push_back((uint32_t)s.size()); pg.seq += s;
+            sg->follow_edges_v(run_order[i], true, [&](const handle_t& p) { auto it = ridx.find(p); if (it != ridx.end() && it->second < i) pg.pred_idx.push_back(it->second); });
+            pg.pred_off.push_back((uint32_t)pg.pred_idx.size());
+        }
+        vgk_gssw_problem prob{};
+        prob.read = tail.data(); prob.read_len = (uint32_t)tail.size(); prob.flags = VGK_GSSW_LOCAL; prob.graph = pg.view();
+        vgk_result res{}; size_t written = 0;
+        int rc = engine->gssw_align(ctx, &prob, 1, &res, nullptr, 0, &written);
+        if (rc != VGK_OK || res.status != VGK_OK)
+            throw std::runtime_error(std::string("vgamd: scan failed: ") + engine->strerror(rc ? rc : res.status));
+        if (res.score > 0) {
+            have_head = true;
+            const handle_t h = run_order[(size_t)res.end_node];
+            head_node = index_of.at(h);
+            const size_t used = (size_t)res.end_offset + 1, qused = (size_t)res.end_read + 1;
+            if (!direction) { head_ref = used; head_query = (qlen - scan_len) + qused; }
+            else { head_ref = g.get_length(h) - used; head_query = scan_len - qused; }
+        }
+        if (!have_head) return;      // scan failed: path stays empty, the caller falls back to gssw (src/aligner.cpp:848-854)
+    } else {
+        // calculate_seed_position (:75-114)
+        const MaximalExactMatch& seed = direction ? mems.back() : mems.front();
+        const MaximalExactMatch::Hit& hit = direction ? seed.nodes.front() : seed.nodes.back();
+        const size_t sn = index_of.at(g.get_handle(hit.id, hit.is_reverse));
+        const size_t sref = direction ? g.get_length(order[sn]) - hit.offset : hit.offset;
+        const size_t squery = direction ? read.size() - seed.begin : seed.begin;
+        // "upward" extension from the seed; its maximum is the head (:654-672)
+        Extension up = xdrop_extend(g, order, sn, sref, read, squery, direction, false, max_gap_length);
+        head_node = up.end_node; head_ref = up.end_ref_offset; head_query = up.end_query; have_head = true;
+    }
+    // ---- downward extension from the head + traceback (align_downward, :687-722)
+    Extension down = xdrop_extend(g, order, head_node, head_ref, read, head_query, !direction, true, max_gap_length);
+    alignment.score = down.score;
+    alignment.query_position = 0;
+    if (down.score <= 0 || down.mappings.empty()) {
+        // full-length insertion at the head position (:344-359)
+        alignment.score = 0;
+        alignment.path.mapping.emplace_back();
+        Mapping& m = alignment.path.mapping.back();
+        m.position.node_id = g.get_id(order[head_node]); m.position.is_reverse = g.get_is_reverse(order[head_node]);
+        m.position.offset = (int64_t)head_ref; m.rank = 1;
+        Edit e; e.from_length = 0; e.to_length = (int32_t)read.size(); e.sequence = read; m.edit.push_back(e);
+        return;
+    }
+    alignment.path.mapping = std::move(down.mappings);
+    for (size_t i = 0; i < alignment.path.mapping.size(); ++i) alignment.path.mapping[i].rank = (int64_t)i + 1;
+    // the read part on the far side of the head was never shown to dozeu: it becomes an insertion (:498-526)
+    if (!direction) {            // aligned read[0, head_query); the rest trails
+        if (head_query < read.size()) {
+            Edit e; e.from_length = 0; e.to_length = (int32_t)(read.size() - head_query); e.sequence = read.substr(head_query);
+            alignment.path.mapping.back().edit.push_back(e);
+        }
+    } else if (head_query > 0) { // aligned read[head_query, end); the part before it leads
+        Mapping& m = alignment.path.mapping.front();
+        if (!m.edit.empty() && edit_is_insertion(m.edit.front())) {
+            m.edit.front().to_length += (int32_t)head_query; m.edit.front().sequence = read.substr(0, head_query) + m.edit.front().sequence;
+        } else { Edit e; e.from_length = 0; e.to_length = (int32_t)head_query; e.sequence = read.substr(0, head_query); m.edit.insert(m.edit.begin(), e); }
+    }
+    alignment.identity = (double)down.matches / (double)read.size();
+    // dozeu found nothing useful and there were no MEMs: gssw fallback happens in the caller's wrapper below
+}
+
+}  // namespace vgamd

@@ -39,6 +39,15 @@ struct MatrixAlignmentScorer {
     vgk_scoring as_vgk() const;
 };
 
+// MaximalExactMatch as the aligner sees it (reference: src/mem.hpp:25-65; fields read at
+// src/dozeu_interface.cpp:91-110): a read interval and its graph hits (gcsa::Node = id, offset, strand).
+struct MaximalExactMatch {
+    size_t begin = 0, end = 0;                      // [begin, end) in the read
+    struct Hit { nid_t id; size_t offset; bool is_reverse; };
+    std::vector<Hit> nodes;
+    size_t length() const { return end - begin; }
+};
+
 class BaseAligner {
 public:
     virtual ~BaseAligner() = default;
@@ -100,8 +109,27 @@ public:
                       uint16_t xdrop_max_gap_length = default_xdrop_max_gap_length) const override;
     void align_pinned_multi(Alignment& alignment, std::vector<Alignment>& alt_alignments, const HandleGraph& g,
                             bool pin_left, int32_t max_alt_alns) const override;
+    // two-pass seeded X-drop alignment (src/aligner.cpp:833-855 -> DozeuInterface::align, src/dozeu_interface.cpp:608-685)
+    void align_xdrop(Alignment& alignment, const HandleGraph& g, const std::vector<MaximalExactMatch>& mems,
+                     bool reverse_complemented, uint16_t max_gap_length = default_xdrop_max_gap_length) const;
+    void align_xdrop(Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& order,
+                     const std::vector<MaximalExactMatch>& mems, bool reverse_complemented,
+                     uint16_t max_gap_length = default_xdrop_max_gap_length) const;
 
 private:
+    // one pinned X-drop extension from an interior graph position (node index in `order`, offset in that node)
+    // towards the right (right_to_left = false) or the left; dozeu's extend over do_poa (src/dozeu_interface.cpp:210-307)
+    struct Extension {
+        int32_t score = 0;
+        size_t end_node = 0, end_ref_offset = 0, end_query = 0;   // position of the maximum, in `order` / read coordinates
+        std::vector<Mapping> mappings;                              // traceback (only when requested), already in read order
+        size_t matches = 0;
+    };
+    void xdrop_align(Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& order,
+                     const std::vector<MaximalExactMatch>& mems, bool reverse_complemented, uint16_t max_gap_length) const;
+    Extension xdrop_extend(const HandleGraph& g, const std::vector<handle_t>& order, size_t node_index, size_t ref_offset,
+                           const std::string& read, size_t query_offset, bool right_to_left, bool traceback,
+                           uint16_t max_gap_length) const;
     void align_internal(Alignment& alignment, std::vector<Alignment>* multi_alignments, const HandleGraph& g,
                         bool pinned, bool pin_left, int32_t max_alt_alns, bool traceback_aln) const;
     // DozeuInterface::align_pinned + calculate_and_save_alignment (src/dozeu_interface.cpp:724-766, 338-572)

@@ -66,4 +66,20 @@ int vgh_align(vgh_aligner* a, vgh_graph* g, const char* read, int call, int pin_
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }
 
+// Aligner::align_xdrop with MEMs given as flat records [begin, end, node_id, offset, is_reverse] x n_mems
+int vgh_align_xdrop(vgh_aligner* a, vgh_graph* g, const char* read, const int64_t* mems, int n_mems,
+                    int reverse_complemented, int max_gap, char* json_out, size_t json_cap) {
+    try {
+        Alignment aln; aln.sequence = read;
+        std::vector<MaximalExactMatch> ms;
+        for (int i = 0; i < n_mems; ++i) {
+            MaximalExactMatch m; m.begin = (size_t)mems[5 * i]; m.end = (size_t)mems[5 * i + 1];
+            m.nodes.push_back({mems[5 * i + 2], (size_t)mems[5 * i + 3], mems[5 * i + 4] != 0});
+            ms.push_back(m);
+        }
+        a->a->align_xdrop(aln, g->g, ms, reverse_complemented != 0, (uint16_t)max_gap);
+        return emit(aln, json_out, json_cap);
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
 }  // extern "C"
