@@ -129,7 +129,15 @@ typedef struct vgk_gssw_problem {
     uint32_t       max_gap_length; /* XDROP only: dozeu max_gap_length (dz_align_init; clamped to >= 1,
                                       src/aligner.cpp:638) — bounds the leading insertion         */
     uint32_t       reserved;
+    const uint8_t* qual;         /* quality-adjusted contexts only: [read_len] raw phred bytes (not ASCII-33),
+                                    as in Alignment.quality (src/aligner.cpp:942-952)              */
 } vgk_gssw_problem;
+
+/* ---- quality-adjusted scoring (QualAdjAlignmentScorer, src/alignment_scorer.cpp:419-513) ------------- */
+typedef struct vgk_qual_adj {
+    const int8_t* matrix;    /* [256][25]: index 25*qual + 5*nt[ref] + nt[read]  (src/banded_global_aligner.cpp:685) */
+    const int8_t* bonuses;   /* [256]: full-length bonus by the quality of the end base (:494-513, :555-563)          */
+} vgk_qual_adj;
 
 typedef struct vgk_ctx   vgk_ctx;     /* one per (device, scoring) — like one Aligner      */
 typedef struct vgk_batch vgk_batch;   /* packed problems resident in HBM                   */
@@ -140,6 +148,9 @@ const char* vgk_strerror(int code);
 /* Create/destroy an engine bound to HIP device `device`.  Mirrors constructing
  * an Aligner (src/aligner.hpp:164-168); thread-safe for concurrent batches. */
 int  vgk_create(int device, const vgk_scoring* scoring, vgk_ctx** out);
+/* Same for a QualAdjAligner (src/aligner.hpp:218-258): every problem must then carry `qual`; the bonus at a read
+ * end is bonuses[quality of that end base] (gssw: both ends / unpinned end; X-drop: the far end). */
+int  vgk_create_qual_adj(int device, const vgk_scoring* scoring, const vgk_qual_adj* qual_adj, vgk_ctx** out);
 void vgk_destroy(vgk_ctx* ctx);
 int  vgk_device_info(vgk_ctx* ctx, char* name_out, size_t name_cap,
                      int* compute_units, size_t* hbm_bytes);

@@ -13,16 +13,18 @@
 #include <string.h>
 #include "../include/vgk.h"
 
-int vgo_gssw_align(const vgk_scoring* sc, const vgk_gssw_problem* p,
-                   vgk_result* res, vgk_op* ops, uint32_t ops_cap);
-int vgo_xdrop_pinned_align(const vgk_scoring* sc, const vgk_gssw_problem* p,
-                           vgk_result* res, vgk_op* ops, uint32_t ops_cap);
-static int vgo_dispatch(const vgk_scoring* sc, const vgk_gssw_problem* p, vgk_result* res, vgk_op* ops, uint32_t ops_cap) {
-    return (p->flags & 15u) == VGK_XDROP_PINNED ? vgo_xdrop_pinned_align(sc, p, res, ops, ops_cap)
-                                                : vgo_gssw_align(sc, p, res, ops, ops_cap);
-}
+int vgo_gssw_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p,
+                     vgk_result* res, vgk_op* ops, uint32_t ops_cap);
+int vgo_xdrop_pinned_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p,
+                             vgk_result* res, vgk_op* ops, uint32_t ops_cap);
 
-struct vgk_ctx { vgk_scoring sc; };
+struct vgk_ctx { vgk_scoring sc; int has_qa; vgk_qual_adj qa; int8_t qmat[256 * 25]; int8_t qbon[256]; };
+
+static int vgo_dispatch(const vgk_ctx* c, const vgk_gssw_problem* p, vgk_result* res, vgk_op* ops, uint32_t ops_cap) {
+    const vgk_qual_adj* qa = c->has_qa ? &c->qa : NULL;
+    return (p->flags & 15u) == VGK_XDROP_PINNED ? vgo_xdrop_pinned_align_q(&c->sc, qa, p, res, ops, ops_cap)
+                                                : vgo_gssw_align_q(&c->sc, qa, p, res, ops, ops_cap);
+}
 struct vgk_batch {
     vgk_ctx* ctx; const vgk_gssw_problem* probs; uint32_t n; uint32_t ops_per;
     vgk_result* res; vgk_op* ops; int ran; uint64_t cells;
@@ -52,6 +54,14 @@ int vgk_create(int device, const vgk_scoring* scoring, vgk_ctx** out) {
     vgk_ctx* c = (vgk_ctx*)calloc(1, sizeof *c);
     if (!c) return VGK_ENOMEM;
     c->sc = *scoring; *out = c; return VGK_OK;
+}
+int vgk_create_qual_adj(int device, const vgk_scoring* scoring, const vgk_qual_adj* qa, vgk_ctx** out) {
+    if (!qa || !qa->matrix || !qa->bonuses) return VGK_EINVAL;
+    int rc = vgk_create(device, scoring, out);
+    if (rc) return rc;
+    memcpy((*out)->qmat, qa->matrix, sizeof (*out)->qmat); memcpy((*out)->qbon, qa->bonuses, sizeof (*out)->qbon);
+    (*out)->has_qa = 1; (*out)->qa.matrix = (*out)->qmat; (*out)->qa.bonuses = (*out)->qbon;
+    return VGK_OK;
 }
 void vgk_destroy(vgk_ctx* ctx) { free(ctx); }
 
@@ -91,7 +101,7 @@ int vgk_gssw_run(vgk_batch* b) {
     if (!b) return VGK_EINVAL;
     #pragma omp parallel for schedule(dynamic, 16)
     for (int64_t i = 0; i < (int64_t)b->n; ++i)
-        vgo_dispatch(&b->ctx->sc, &b->probs[i], &b->res[i], b->ops + (size_t)i * b->ops_per, b->ops_per);
+        vgo_dispatch(b->ctx, &b->probs[i], &b->res[i], b->ops + (size_t)i * b->ops_per, b->ops_per);
     b->ran = 1; return VGK_OK;
 }
 

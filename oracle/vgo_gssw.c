@@ -71,8 +71,15 @@ static void reverse_ops(vgk_op* a, uint32_t n) {
 /* Align one read to one DAG.  `ops` receives up to ops_cap elements in forward
  * (read) order.  Returns VGK_OK or a VGK_E* code; per-problem status is also
  * stored in res->status. */
+int vgo_gssw_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p,
+                     vgk_result* res, vgk_op* ops, uint32_t ops_cap);
 int vgo_gssw_align(const vgk_scoring* sc, const vgk_gssw_problem* p,
-                   vgk_result* res, vgk_op* ops, uint32_t ops_cap)
+                   vgk_result* res, vgk_op* ops, uint32_t ops_cap) { return vgo_gssw_align_q(sc, NULL, p, res, ops, ops_cap); }
+
+/* qa != NULL: quality-adjusted scoring (gssw_graph_fill_pinned_qual_adj, src/aligner.cpp:942-952): the substitution
+ * score depends on the read base's quality, the end bonuses on the qualities of the end bases. */
+int vgo_gssw_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p,
+                     vgk_result* res, vgk_op* ops, uint32_t ops_cap)
 {
     const int L = (int)p->read_len;
     const vgk_graph* g = &p->graph;
@@ -80,8 +87,9 @@ int vgo_gssw_align(const vgk_scoring* sc, const vgk_gssw_problem* p,
     const int go = sc->gap_open, ge = sc->gap_extend;
     const int pinned = (p->flags & 15) == VGK_GSSW_PINNED;
     const int want_tb = (p->flags & VGK_GSSW_TRACEBACK) != 0;
-    const int start_bonus = sc->full_length_bonus;
-    const int end_bonus = pinned ? 0 : sc->full_length_bonus;   /* src/aligner.cpp:402 */
+    if (qa && !p->qual) { memset(res, 0, sizeof *res); res->status = VGK_EINVAL; return VGK_EINVAL; }
+    const int start_bonus = qa ? qa->bonuses[p->qual[0]] : sc->full_length_bonus;
+    const int end_bonus = pinned ? 0 : (qa ? qa->bonuses[p->qual[L > 0 ? L - 1 : 0]] : sc->full_length_bonus);   /* src/aligner.cpp:402 */
 
     memset(res, 0, sizeof *res);
     res->end_node = -1; res->end_offset = -1; res->end_read = -1;
@@ -114,7 +122,7 @@ int vgo_gssw_align(const vgk_scoring* sc, const vgk_gssw_problem* p,
     int32_t* seedH = (int32_t*)malloc(sizeof(int32_t) * (size_t)L);
     int32_t* seedE = (int32_t*)malloc(sizeof(int32_t) * (size_t)L);
 
-#define SCORE(r, c) ((int)sc->matrix[5 * rf[c] + rd[r]] + ((r) == 0 ? start_bonus : 0) + ((r) == L - 1 ? end_bonus : 0))
+#define SCORE(r, c) ((int)(qa ? qa->matrix[25 * p->qual[r] + 5 * rf[c] + rd[r]] : sc->matrix[5 * rf[c] + rd[r]]) + ((r) == 0 ? start_bonus : 0) + ((r) == L - 1 ? end_bonus : 0))
 
     int32_t best = 0; int best_c = -1, best_r = -1;
     for (int n = 0; n < nV; ++n) {

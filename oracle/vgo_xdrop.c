@@ -52,13 +52,22 @@ static inline int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
 #define IDX(c, i) ((size_t)(c) * (size_t)(L + 1) + (size_t)(i))
 
 /* Left-pinned extension; rows i = 0..L count consumed query bases. */
+int vgo_xdrop_pinned_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p,
+                             vgk_result* res, vgk_op* ops, uint32_t ops_cap);
 int vgo_xdrop_pinned_align(const vgk_scoring* sc, const vgk_gssw_problem* p,
-                           vgk_result* res, vgk_op* ops, uint32_t ops_cap)
+                           vgk_result* res, vgk_op* ops, uint32_t ops_cap) { return vgo_xdrop_pinned_align_q(sc, NULL, p, res, ops, ops_cap); }
+
+/* qa != NULL: QualAdjXdropAligner (src/qual_adj_xdrop_aligner.cpp:74-135); the single bonus is the quality-adjusted
+ * one of the far-end base (src/aligner.cpp:1164-1167). */
+int vgo_xdrop_pinned_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p,
+                             vgk_result* res, vgk_op* ops, uint32_t ops_cap)
 {
     const int L = (int)p->read_len;
     const vgk_graph* g = &p->graph;
     const int nV = (int)g->n_nodes;
-    const int go = sc->gap_open, ge = sc->gap_extend, bonus = sc->full_length_bonus;
+    if (qa && !p->qual) { memset(res, 0, sizeof *res); res->status = VGK_EINVAL; return VGK_EINVAL; }
+    const int go = sc->gap_open, ge = sc->gap_extend;
+    const int bonus = qa ? (L > 0 ? qa->bonuses[p->qual[L - 1]] : 0) : sc->full_length_bonus;
     int max_gap = (int)p->max_gap_length; if (max_gap < 1) max_gap = 1;
     const int gap_cells = (max_gap + 7) & ~7;
     const int want_tb = (p->flags & VGK_GSSW_TRACEBACK) != 0;
@@ -95,7 +104,7 @@ int vgo_xdrop_pinned_align(const vgk_scoring* sc, const vgk_gssw_problem* p,
         rootH[i] = i == 0 ? 0 : (i <= gap_cells ? -(go + (i - 1) * ge) : NEG);
         rootE[i] = rootH[i] > NEG ? rootH[i] - go : NEG;      /* E of the column after the root */
     }
-#define SCORE(i, c) ((int)sc->matrix[5 * rf[c] + rd[(i) - 1]] + ((i) == L ? bonus : 0))
+#define SCORE(i, c) ((int)(qa ? qa->matrix[25 * p->qual[(i) - 1] + 5 * rf[c] + rd[(i) - 1]] : sc->matrix[5 * rf[c] + rd[(i) - 1]]) + ((i) == L ? bonus : 0))
 
     int32_t best = 0; int best_c = -1, best_i = 0;
     for (int n = 0; n < nV; ++n) {

@@ -97,3 +97,32 @@ def run_seeded_xdrop_group(engine_lib):
 def test_oracle_matches_reference_seeded_xdrop_unit_tests():
     ncase, nexp = run_seeded_xdrop_group(ORACLE_LIB)
     assert ncase >= 7 and nexp >= 20
+
+
+def qual_adj_cases():
+    out = []
+    for f in ("ref_pinned_alignment.json", "ref_xdrop_aligner.json"):
+        out += [c for c in load_golden(f) if c["qual_adj"] and c["call"] == "align_pinned" and c["quality"]]
+    return out
+
+
+def run_qual_adj_group(engine_lib):
+    n = 0
+    cases = qual_adj_cases()
+    for c in cases:
+        al = HostAligner(engine_lib, tuple(c["scores"]), qual_adj=True)
+        args = c["args"]           # [graph, pin_left, xdrop?, max_gap?]
+        xdrop = len(args) > 2 and args[2] is True
+        if xdrop:
+            max_gap = args[3] if len(args) > 3 and isinstance(args[3], int) else 40
+            aln = al.run(c["nodes"], c["edges"], c["read"], "align_pinned_xdrop", pin_left=bool(args[1]), max_alt_alns=max_gap, quality=c["quality"])
+        else:
+            aln = al.run(c["nodes"], c["edges"], c["read"], "align_pinned", pin_left=bool(args[1]), quality=c["quality"])
+        check_expectations(c, aln, {c["aln"]: aln["score"]})
+        n += len(c["expect"])
+    return len(cases), n
+
+
+def test_oracle_matches_reference_quality_adjusted_unit_tests():
+    ncase, nexp = run_qual_adj_group(ORACLE_LIB)
+    assert ncase >= 12 and nexp >= 90

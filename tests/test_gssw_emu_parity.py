@@ -72,3 +72,26 @@ def test_emulated_xdrop_pinned_matches_oracle(emu_lib):
     # mixed batch: all three modes side by side in the same wavefronts
     mixed = [random_problem(rng, mode=m) for m in (capi.VGK_GSSW_LOCAL, capi.VGK_GSSW_PINNED, capi.VGK_XDROP_PINNED) * 100]
     compare(emu_lib, ORACLE_LIB, mixed)
+
+
+def test_emulated_quality_adjusted_contexts_match_oracle(emu_lib):
+    from qualadj import qual_adj_tables
+    tables = qual_adj_tables(1, 4, 5)
+    assert tables[0][25 * 40 + 0] == 1 and tables[0][25 * 40 + 1] == -4 and tables[0][25 * 2 + 0] == 0   # Q40 ~ base scores, Q2 = 0
+    rng = np.random.default_rng(31337)
+    problems = []
+    for mode in (capi.VGK_GSSW_LOCAL, capi.VGK_GSSW_PINNED, capi.VGK_XDROP_PINNED) * 150:
+        p = random_problem(rng, mode=mode, with_n=0.1)
+        q = rng.choice(np.array([2, 5, 10, 20, 30, 40], dtype=np.uint8), size=len(p["read"]))
+        p["qual"] = q
+        problems.append(p)
+    ps = problem_set(problems)
+    sc = capi.Scoring.simple()
+    ra, oa = capi.Engine(sc, lib=emu_lib, qual_adj=tables).align(ps)
+    rb, ob = capi.Engine(sc, lib=ORACLE_LIB, qual_adj=tables).align(ps)
+    rc, _ = capi.Engine(sc, lib=ORACLE_LIB).align(ps)                 # plain scoring must differ somewhere
+    assert (rb["score"] != rc["score"]).sum() > 50
+    for i in range(ps.n):
+        assert ra["status"][i] == rb["status"][i] == 0 and ra["score"][i] == rb["score"][i], i
+        if ra["score"][i] > 0:
+            assert capi.cigar_string(ra[i], oa) == capi.cigar_string(rb[i], ob), i

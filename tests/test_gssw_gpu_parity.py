@@ -81,3 +81,25 @@ def test_reference_seeded_xdrop_unit_test_vectors_through_host_shim_on_hip():
     from test_golden_gssw_oracle import run_seeded_xdrop_group
     ncase, nexp = run_seeded_xdrop_group(ENGINE_LIB)
     assert ncase >= 7 and nexp >= 20
+
+
+def test_hip_quality_adjusted_contexts_match_oracle_and_reference_vectors():
+    from qualadj import qual_adj_tables
+    from test_golden_gssw_oracle import run_qual_adj_group
+    tables = qual_adj_tables(1, 4, 5)
+    rng = np.random.default_rng(31337)
+    problems = []
+    for mode in (capi.VGK_GSSW_LOCAL, capi.VGK_GSSW_PINNED, capi.VGK_XDROP_PINNED) * 400:
+        p = random_problem(rng, mode=mode, with_n=0.1)
+        p["qual"] = rng.choice(np.array([2, 5, 10, 20, 30, 40], dtype=np.uint8), size=len(p["read"]))
+        problems.append(p)
+    ps = problem_set(problems)
+    sc = capi.Scoring.simple()
+    ra, oa = capi.Engine(sc, lib=ENGINE_LIB, qual_adj=tables).align(ps)
+    rb, ob = capi.Engine(sc, lib=ORACLE_LIB, qual_adj=tables).align(ps)
+    for i in range(ps.n):
+        assert ra["status"][i] == rb["status"][i] == 0 and ra["score"][i] == rb["score"][i], i
+        if ra["score"][i] > 0:
+            assert capi.cigar_string(ra[i], oa) == capi.cigar_string(rb[i], ob), i
+    ncase, nexp = run_qual_adj_group(ENGINE_LIB)
+    assert ncase >= 12 and nexp >= 90

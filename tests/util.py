@@ -32,6 +32,10 @@ def host():
         h.vgh_aligner_destroy.argtypes = [ctypes.c_void_p]
         h.vgh_align.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+        h.vgh_qual_adj_aligner_create.restype = ctypes.c_void_p
+        h.vgh_qual_adj_aligner_create.argtypes = [ctypes.c_char_p] + [ctypes.c_int] * 6
+        h.vgh_align_q.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
         h.vgh_align_xdrop.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
         _host = h
@@ -41,9 +45,10 @@ def host():
 class HostAligner:
     """Drives the C++ host shim (vg_amd/host) the way src/unittest/*.cpp drives vg's Aligner."""
 
-    def __init__(self, engine_lib, scores=(1, 4, 6, 1, 5), device=0):
+    def __init__(self, engine_lib, scores=(1, 4, 6, 1, 5), device=0, qual_adj=False):
         self.h = host()
-        self.ptr = self.h.vgh_aligner_create(engine_lib.encode() if engine_lib else None, device, *scores)
+        make = self.h.vgh_qual_adj_aligner_create if qual_adj else self.h.vgh_aligner_create
+        self.ptr = make(engine_lib.encode() if engine_lib else None, device, *scores)
         if not self.ptr:
             raise RuntimeError(self.h.vgh_last_error().decode())
 
@@ -51,7 +56,7 @@ class HostAligner:
         if getattr(self, "ptr", None):
             self.h.vgh_aligner_destroy(self.ptr)
 
-    def run(self, nodes, edges, read, call, pin_left=False, max_alt_alns=1):
+    def run(self, nodes, edges, read, call, pin_left=False, max_alt_alns=1, quality=None):
         g = self.h.vgh_graph_create()
         try:
             for nid, seq in nodes:
@@ -60,7 +65,11 @@ class HostAligner:
                 assert self.h.vgh_graph_add_edge(g, a, b) == 0
             buf = ctypes.create_string_buffer(1 << 20)
             code = {"align": 0, "align_score": 1, "align_pinned": 2, "align_pinned_multi": 3, "align_pinned_xdrop": 4}[call]
-            rc = self.h.vgh_align(self.ptr, g, read.encode(), code, int(pin_left), max_alt_alns, buf, len(buf))
+            if quality is not None:
+                q = bytes(bytearray(int(x) for x in quality))
+                rc = self.h.vgh_align_q(self.ptr, g, read.encode(), q, code, int(pin_left), max_alt_alns, buf, len(buf))
+            else:
+                rc = self.h.vgh_align(self.ptr, g, read.encode(), code, int(pin_left), max_alt_alns, buf, len(buf))
             if rc != 0:
                 raise RuntimeError(self.h.vgh_last_error().decode())
             return json.loads(buf.value.decode())

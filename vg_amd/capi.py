@@ -25,11 +25,11 @@ OP_CHARS = "MIDS"
 GRAPH_DT = np.dtype([("n_nodes", "<u4"), ("_pad", "<u4"), ("node_len", "<u8"), ("seq", "<u8"),
                      ("pred_off", "<u8"), ("pred_idx", "<u8")])
 PROBLEM_DT = np.dtype([("read", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), ("graph", GRAPH_DT), ("pinning", "<u8"),
-                       ("max_gap_length", "<u4"), ("reserved", "<u4")])
+                       ("max_gap_length", "<u4"), ("reserved", "<u4"), ("qual", "<u8")])
 RESULT_DT = np.dtype([("score", "<i4"), ("status", "<i4"), ("end_node", "<i4"), ("end_offset", "<i4"),
                       ("end_read", "<i4"), ("first_offset", "<i4"), ("n_ops", "<u4"), ("ops_begin", "<u4")])
 OP_DT = np.dtype([("node", "<u4"), ("len", "<u2"), ("op", "u1"), ("pad", "u1")])
-assert GRAPH_DT.itemsize == 40 and PROBLEM_DT.itemsize == 72 and RESULT_DT.itemsize == 32 and OP_DT.itemsize == 8
+assert GRAPH_DT.itemsize == 40 and PROBLEM_DT.itemsize == 80 and RESULT_DT.itemsize == 32 and OP_DT.itemsize == 8
 
 
 class Scoring(ctypes.Structure):
@@ -47,6 +47,10 @@ class Scoring(ctypes.Structure):
         return s
 
 
+class QualAdj(ctypes.Structure):
+    _fields_ = [("matrix", ctypes.c_void_p), ("bonuses", ctypes.c_void_p)]
+
+
 class VgkError(RuntimeError):
     pass
 
@@ -62,6 +66,7 @@ def load_library(path=None):
     lib.vgk_strerror.restype = ctypes.c_char_p
     lib.vgk_strerror.argtypes = [ctypes.c_int]
     lib.vgk_create.argtypes = [ctypes.c_int, ctypes.POINTER(Scoring), ctypes.POINTER(vp)]
+    lib.vgk_create_qual_adj.argtypes = [ctypes.c_int, ctypes.POINTER(Scoring), ctypes.POINTER(QualAdj), ctypes.POINTER(vp)]
     lib.vgk_destroy.argtypes = [vp]
     lib.vgk_device_info.argtypes = [vp, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(sz)]
     lib.vgk_gssw_pack.argtypes = [vp, vp, u32, u32, ctypes.POINTER(vp)]
@@ -89,7 +94,7 @@ class ProblemSet:
     """
 
     def __init__(self, reads, read_off, node_len, node_off, seq, seq_off, pred_off, pred_idx, edge_off, flags, pinning=None,
-                 max_gap=None):
+                 max_gap=None, quals=None):
         self.reads = np.ascontiguousarray(reads, dtype=np.uint8)
         self.read_off = np.asarray(read_off, dtype=np.int64)
         self.node_len = np.ascontiguousarray(node_len, dtype=np.uint32)
@@ -118,6 +123,9 @@ class ProblemSet:
             arr["pinning"] = self.pinning.ctypes.data + self.node_off[:-1]
         if max_gap is not None:
             arr["max_gap_length"] = np.asarray(max_gap, dtype=np.uint32)
+        self.quals = None if quals is None else np.ascontiguousarray(quals, dtype=np.uint8)   # raw phred, same layout as reads
+        if self.quals is not None:
+            arr["qual"] = self.quals.ctypes.data + self.read_off[:-1]
         self.array = arr
 
     @property
@@ -149,18 +157,28 @@ class ProblemSet:
             flags.append(p["flags"])
             pinning.extend(p["pinning"] if p.get("pinning") is not None else [0] * len(nl))
         cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.uint8)
+        quals = None
+        if any(p.get("qual") is not None for p in problems):
+            quals = np.concatenate([np.asarray(p["qual"], dtype=np.uint8) for p in problems])
         return cls(cat(reads), read_off, node_len, node_off, cat(seq), seq_off, pred_off, pred_idx, edge_off, flags,
-                   pinning if any_pin else None, [p.get("max_gap", 40) for p in problems])
+                   pinning if any_pin else None, [p.get("max_gap", 40) for p in problems], quals)
 
 
 class Engine:
     """One engine context = one (device, scoring) pair, like one vg Aligner."""
 
-    def __init__(self, scoring=None, device=0, lib=None):
+    def __init__(self, scoring=None, device=0, lib=None, qual_adj=None):
+        """qual_adj = (matrix int8[256*25], bonuses int8[256]) makes a quality-adjusted context (QualAdjAligner)."""
         self.lib = load_library(lib) if (lib is None or isinstance(lib, str)) else lib
         self.scoring = scoring or Scoring.simple()
         h = ctypes.c_void_p()
-        rc = self.lib.vgk_create(device, ctypes.byref(self.scoring), ctypes.byref(h))
+        if qual_adj is not None:
+            self._qm = np.ascontiguousarray(qual_adj[0], dtype=np.int8); self._qb = np.ascontiguousarray(qual_adj[1], dtype=np.int8)
+            assert self._qm.size == 256 * 25 and self._qb.size == 256
+            qa = QualAdj(self._qm.ctypes.data, self._qb.ctypes.data)
+            rc = self.lib.vgk_create_qual_adj(device, ctypes.byref(self.scoring), ctypes.byref(qa), ctypes.byref(h))
+        else:
+            rc = self.lib.vgk_create(device, ctypes.byref(self.scoring), ctypes.byref(h))
         if rc != VGK_OK:
             raise VgkError("vgk_create: %s" % self.lib.vgk_strerror(rc).decode())
         self.h = h

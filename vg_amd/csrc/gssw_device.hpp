@@ -67,6 +67,11 @@ struct ProbDesc {          // one per read
     uint32_t lane0;        // first lane of the read pair's lane group inside that wavefront
     uint32_t geom;         // K | G << 8 | half << 16   (half: 0 = low 16-bit halves, 1 = high)
     uint32_t Lpad;         // G*K rows per scratch slot
+    // scoring of this read: full-length bonuses actually in force (0 where the mode grants none; quality-adjusted
+    // contexts take them from the end bases' qualities), and — quality-adjusted only — its per-row profile words
+    uint32_t bonus_start, bonus_end;   // pre-multiplied by the score scale
+    uint32_t prof_off;                 // first per-row profile dword in `prof`, or 0xffffffff (profile = prof4[base])
+    uint32_t pad;
 };
 
 struct NodeRec {
@@ -90,6 +95,7 @@ struct GsswParams {
     const ProbDesc* probs;
     const uint8_t*  colinfo;
     const uint8_t*  reads;
+    const uint32_t* prof;       // quality-adjusted contexts: per read row 4 biased score bytes (ref A,C,G,T), bonus included
     const NodeRec*  nodes;
     const uint32_t* preds;
     uint32_t*       scratch;    // per (slot,row): lo16 = H of the node's last column, hi16 = E for the column after it
@@ -106,7 +112,7 @@ struct GsswParams {
     uint32_t prof4[6];          // per read base q: byte r = matrix[5r+q] + bias, r = 0..3; [5] = 0 (X-drop row 0: consumes nothing)
     uint32_t bias;
     uint32_t go, ge;
-    int32_t  bonus;             // full-length bonus
+    int32_t  bonus;             // full-length bonus (plain contexts; per-read values live in ProbDesc)
     int32_t  want_tb;           // any problem wants traceback -> store codes
     int32_t  fused;             // 1 = each wavefront traces its own reads back at the end of the fill kernel
     uint32_t scale;             // 1 or 8: every DP quantity above (prof4, bias, go, ge, bonus, xoff, scratch) is pre-multiplied.
@@ -118,14 +124,11 @@ struct GsswParams {
 
 VGK_HD uint32_t rep2(uint32_t x) { return (x & 0xffffu) * 0x00010001u; }
 
-VGK_HD uint32_t row_bonus(const GsswParams& P, uint32_t row, uint32_t L, uint32_t flags) {
-    // gssw: start bonus on read base 0; end bonus on base L-1 unless pinned (src/aligner.cpp:401-402).
-    // dozeu: one bonus, on consuming the last packed query base (row L-1 of the L = len+1 rows).
-    const uint32_t mode = flags & 15u;
-    uint32_t b = 0;
-    if (row == 0 && mode != VGK_XDROP_PINNED) b += (uint32_t)P.bonus;
-    if (row + 1 == L && mode != VGK_GSSW_PINNED) b += (uint32_t)P.bonus;
-    return b;
+// gssw: start bonus on read base 0; end bonus on base L-1 unless pinned (src/aligner.cpp:401-402).
+// dozeu: one bonus, on consuming the last packed query base (row L-1 of the L = len+1 rows).
+// The host resolves which apply (and their quality-adjusted values) into ProbDesc::bonus_start / bonus_end.
+VGK_HD uint32_t row_bonus(uint32_t bonus_start, uint32_t bonus_end, uint32_t row, uint32_t L) {
+    return (row == 0 ? bonus_start : 0u) + (row + 1 == L ? bonus_end : 0u);
 }
 
 VGK_HD unsigned long long key64(uint32_t score, uint32_t col, uint32_t row) {
@@ -149,6 +152,7 @@ struct Lane {
     uint32_t Lpad;                  // rows per scratch slot of this wavefront's bucket (G*K)
     uint32_t probA, probB;          // read indices or 0xffffffff
     uint32_t LA, LB, flagsA, flagsB;
+    uint32_t bsA, beA, bsB, beB;    // full-length bonuses in force for read A / B
     uint32_t RA, RB, colA, colB;    // graph columns and column-info stream offsets
     uint32_t ciA, ciB, ciA_n, ciB_n;  // leader only: info bytes of columns [4k,4k+4) and the prefetched next word
     uint32_t one;                   // 0x00010001 kept opaque to the optimiser (see lane_rows)
@@ -165,9 +169,12 @@ VGK_HD void lane_init(Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint3
     s.probB = live ? P.order[2 * pair + 1] : 0xffffffffu;
     s.LA = s.LB = 0; s.flagsA = s.flagsB = 0; s.RA = s.RB = 0; s.colA = s.colB = 0;
     s.ciA = s.ciB = s.ciA_n = s.ciB_n = 0;
-    uint32_t roA = 0, roB = 0;
-    if (s.probA != 0xffffffffu) { const ProbDesc& d = P.probs[s.probA]; s.LA = d.L; s.flagsA = d.flags; roA = d.read_off; s.RA = d.R; s.colA = d.col_off; }
-    if (s.probB != 0xffffffffu) { const ProbDesc& d = P.probs[s.probB]; s.LB = d.L; s.flagsB = d.flags; roB = d.read_off; s.RB = d.R; s.colB = d.col_off; }
+    uint32_t roA = 0, roB = 0, poA = 0xffffffffu, poB = 0xffffffffu;
+    s.bsA = s.beA = s.bsB = s.beB = 0;
+    if (s.probA != 0xffffffffu) { const ProbDesc& d = P.probs[s.probA]; s.LA = d.L; s.flagsA = d.flags; roA = d.read_off; s.RA = d.R; s.colA = d.col_off;
+                                   s.bsA = d.bonus_start; s.beA = d.bonus_end; poA = d.prof_off; }
+    if (s.probB != 0xffffffffu) { const ProbDesc& d = P.probs[s.probB]; s.LB = d.L; s.flagsB = d.flags; roB = d.read_off; s.RB = d.R; s.colB = d.col_off;
+                                   s.bsB = d.bonus_start; s.beB = d.bonus_end; poB = d.prof_off; }
     if (s.g == 0) {   // streams are padded with 8 readable bytes, so these loads never run off the arena
         if (s.probA != 0xffffffffu) s.ciA_n = *(const uint32_t*)(P.colinfo + s.colA);
         if (s.probB != 0xffffffffu) s.ciB_n = *(const uint32_t*)(P.colinfo + s.colB);
@@ -176,8 +183,8 @@ VGK_HD void lane_init(Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint3
     for (int m = 0; m < K; ++m) {
         const uint32_t row = s.g * K + m;
         uint32_t pa = 0, pb = 0;
-        if (row < s.LA) pa = P.prof4[P.reads[roA + row]] + 0x01010101u * row_bonus(P, row, s.LA, s.flagsA);
-        if (row < s.LB) pb = P.prof4[P.reads[roB + row]] + 0x01010101u * row_bonus(P, row, s.LB, s.flagsB);
+        if (row < s.LA) pa = poA != 0xffffffffu ? P.prof[poA + row] : P.prof4[P.reads[roA + row]] + 0x01010101u * row_bonus(s.bsA, s.beA, row, s.LA);
+        if (row < s.LB) pb = poB != 0xffffffffu ? P.prof[poB + row] : P.prof4[P.reads[roB + row]] + 0x01010101u * row_bonus(s.bsB, s.beB, row, s.LB);
         s.PA[m] = pa; s.PB[m] = pb; s.H[m] = 0; s.E[m] = 0;
     }
     s.out_h = 0; s.out_f = 0; s.info = CI_INVALID2; s.prev_rh = 0;
@@ -288,8 +295,8 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
     uint32_t sb = byte_perm(s.PB[M], s.PA[M], sel);
     if (REFN) {
         const uint32_t row = s.g * K + M;
-        if (nA) sb = set_lo(sb, row < s.LA ? P.bias + row_bonus(P, row, s.LA, s.flagsA) : 0u);
-        if (nB) sb = set_hi(sb, row < s.LB ? P.bias + row_bonus(P, row, s.LB, s.flagsB) : 0u);
+        if (nA) sb = set_lo(sb, row < s.LA ? P.bias + row_bonus(s.bsA, s.beA, row, s.LA) : 0u);
+        if (nB) sb = set_hi(sb, row < s.LB ? P.bias + row_bonus(s.bsB, s.beB, row, s.LB) : 0u);
     }
     const uint32_t old = s.H[M];
     const uint32_t t4 = pk_subs(pk_add_nc(d, sb), bias2);  // max(0, diag + s); the sum stays far below 2^16 per half
@@ -424,12 +431,16 @@ struct Walker {
         return (ci_word >> (8 * (a & 3u))) & CI_BASE_MASK;
     }
     VGK_HD int32_t score(uint32_t r, uint32_t c) const {
-        const uint32_t base = col_base(c), q = read_code(r);
+        const uint32_t base = col_base(c);
+        const int32_t bonus = (int32_t)row_bonus(d.bonus_start, d.bonus_end, r, d.L);
+        if (base >= 4) return bonus;                      // N scores 0 (+ bonus)
+        if (d.prof_off != 0xffffffffu)                    // quality-adjusted: per-row profile word, bonus already inside
+            return (int32_t)((P.prof[d.prof_off + r] >> (8 * base)) & 0xffu) - (int32_t)P.bias;
+        const uint32_t q = read_code(r);
         // profile word of read base q (wave-uniform table, per-thread select), byte = reference base
         uint32_t w = P.prof4[0];
         w = q == 1 ? P.prof4[1] : w; w = q == 2 ? P.prof4[2] : w; w = q == 3 ? P.prof4[3] : w; w = q == 4 ? P.prof4[4] : w;
-        const int32_t s = base < 4 ? (int32_t)((w >> (8 * base)) & 0xffu) - (int32_t)P.bias : 0;
-        return s + (int32_t)row_bonus(P, r, d.L, d.flags);
+        return (int32_t)((w >> (8 * base)) & 0xffu) - (int32_t)P.bias + bonus;
     }
     VGK_HD uint32_t saved(const NodeRec& n, uint32_t r) const { return P.scratch[d.scratch_off + (uint32_t)n.slot * d.Lpad + r]; }
 };

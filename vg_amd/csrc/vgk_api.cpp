@@ -21,8 +21,11 @@ struct vgk_ctx {
     vgk_scoring sc;
     std::unique_ptr<Backend> be;
     std::mutex mu;                 // one stream per context: batches on one context serialise
-    uint32_t bias = 1; int32_t max_score = 0;
+    uint32_t bias = 1; int32_t max_score = 0; int32_t max_bonus = 0;
     uint32_t prof4[6];
+    uint32_t scale = 1;            // 8 when the scaled profile bytes still fit (GsswParams::scale)
+    bool has_qa = false;           // quality-adjusted (QualAdjAligner) context
+    std::vector<int8_t> qmat, qbon;
 };
 
 struct vgk_batch {
@@ -85,20 +88,28 @@ const char* vgk_strerror(int code) {
     }
 }
 
-int vgk_create(int device, const vgk_scoring* scoring, vgk_ctx** out) {
+static int create_ctx(int device, const vgk_scoring* scoring, const vgk_qual_adj* qa, vgk_ctx** out) {
     if (!scoring || !out) return VGK_EINVAL;
     *out = nullptr;
-    int mn = 0, mx = 0;
+    int mn = 0, mx = 0, mb = scoring->full_length_bonus;
     for (int i = 0; i < 25; ++i) { mn = std::min<int>(mn, scoring->matrix[i]); mx = std::max<int>(mx, scoring->matrix[i]); }
+    if (qa) {
+        if (!qa->matrix || !qa->bonuses) return VGK_EINVAL;
+        for (int i = 0; i < 256 * 25; ++i) { mn = std::min<int>(mn, qa->matrix[i]); mx = std::max<int>(mx, qa->matrix[i]); }
+        for (int i = 0; i < 256; ++i) { if (qa->bonuses[i] < 0) return VGK_EUNSUPPORTED; mb = std::max<int>(mb, qa->bonuses[i]); }
+    }
     const int bias = std::max(1, -mn);
     // profile bytes hold score + bias + (up to two) bonuses; see gssw_device.hpp
-    if (scoring->full_length_bonus < 0 || mx + bias + 2 * scoring->full_length_bonus > 255) return VGK_EUNSUPPORTED;
+    if (scoring->full_length_bonus < 0 || mx + bias + 2 * mb > 255) return VGK_EUNSUPPORTED;
     std::string err;
     Backend* be = make_backend(device, err);
     if (!be) return VGK_ENODEV;
     vgk_ctx* c = new (std::nothrow) vgk_ctx();
     if (!c) { delete be; return VGK_ENOMEM; }
-    c->sc = *scoring; c->be.reset(be); c->bias = (uint32_t)bias; c->max_score = mx;
+    c->sc = *scoring; c->be.reset(be); c->bias = (uint32_t)bias; c->max_score = mx; c->max_bonus = mb;
+    c->scale = ((mx + bias + 2 * mb) * 8 <= 255) ? 8u : 1u;
+    if (const char* e = std::getenv("VGAMD_SCORE_SCALE")) c->scale = (std::atoi(e) == 8 && c->scale == 8) ? 8u : 1u;
+    if (qa) { c->has_qa = true; c->qmat.assign(qa->matrix, qa->matrix + 256 * 25); c->qbon.assign(qa->bonuses, qa->bonuses + 256); }
     for (int q = 0; q < 5; ++q) {
         uint32_t w = 0;
         for (int r = 0; r < 4; ++r) w |= (uint32_t)(scoring->matrix[5 * r + q] + bias) << (8 * r);
@@ -107,6 +118,12 @@ int vgk_create(int device, const vgk_scoring* scoring, vgk_ctx** out) {
     c->prof4[5] = 0;     // X-drop row 0 ("nothing consumed"): no diagonal move can enter it
     *out = c;
     return VGK_OK;
+}
+
+int vgk_create(int device, const vgk_scoring* scoring, vgk_ctx** out) { return create_ctx(device, scoring, nullptr, out); }
+int vgk_create_qual_adj(int device, const vgk_scoring* scoring, const vgk_qual_adj* qual_adj, vgk_ctx** out) {
+    if (!qual_adj) return VGK_EINVAL;
+    return create_ctx(device, scoring, qual_adj, out);
 }
 
 void vgk_destroy(vgk_ctx* ctx) { delete ctx; }
@@ -144,7 +161,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     }
     if (maxL > 1024) return VGK_ETOOLONG;
     // best-cell keys pack score*32 + row: keep every reachable score below 2047
-    if ((int64_t)maxL * std::max(ctx->max_score, 0) + 2 * (int64_t)ctx->sc.full_length_bonus > 2046) return VGK_EUNSUPPORTED;
+    if ((int64_t)maxL * std::max(ctx->max_score, 0) + 2 * (int64_t)ctx->max_bonus > 2046) return VGK_EUNSUPPORTED;
     uint32_t forced = 0;
     if (const char* e = std::getenv("VGAMD_ROWS_PER_LANE")) forced = (uint32_t)std::atoi(e);
     // Lane geometry for a read of `rows` DP rows: rows per lane K (16, 20, 24) and lanes per pair G = ceil(rows/K),
@@ -165,6 +182,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     std::vector<ProbDesc>& probs = b->probs;
     probs.resize(n);
     std::vector<uint8_t> colinfo, reads;
+    std::vector<uint32_t> prof;
     std::vector<NodeRec> nodes;
     std::vector<uint32_t> preds;
     uint64_t scratch_words = 0, ops_total = 0, n_edges = 0;
@@ -177,7 +195,8 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         if (mode != VGK_GSSW_LOCAL && mode != VGK_GSSW_PINNED && mode != VGK_XDROP_PINNED) return VGK_EINVAL;
         const bool xdrop = mode == VGK_XDROP_PINNED;
         // offset arithmetic of the X-drop mode: every reachable gain must stay below XOFF
-        if (xdrop && (int64_t)p.read_len * std::max(ctx->max_score, 0) + ctx->sc.full_length_bonus >= (int64_t)XOFF) return VGK_EUNSUPPORTED;
+        if (xdrop && (int64_t)p.read_len * std::max(ctx->max_score, 0) + ctx->max_bonus >= (int64_t)XOFF) return VGK_EUNSUPPORTED;
+        if (ctx->has_qa && !p.qual) return VGK_EINVAL;
         if (mode == VGK_GSSW_PINNED && !p.pinning) return VGK_EINVAL;
         if (p.flags & VGK_GSSW_TRACEBACK) b->want_tb = true;
         d.flags = p.flags; d.L = p.read_len + (xdrop ? 1u : 0u); d.n_nodes = g.n_nodes;
@@ -186,6 +205,27 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         if (xdrop) reads.push_back(5);      // row 0 = no read base consumed yet
         for (uint32_t r = 0; r < p.read_len; ++r) reads.push_back((uint8_t)nt_read(p.read[r]));
         d.max_gap = xdrop ? ((std::max<uint32_t>(p.max_gap_length, 1u) + 7u) & ~7u) : 0u;
+        {   // which full-length bonuses this problem grants, and their values (src/aligner.cpp:401-402, 942-952, 1164-1167)
+            const uint32_t S = ctx->scale;
+            const int first_b = ctx->has_qa ? ctx->qbon[p.qual[0]] : ctx->sc.full_length_bonus;
+            const int last_b = ctx->has_qa ? ctx->qbon[p.qual[p.read_len - 1]] : ctx->sc.full_length_bonus;
+            d.bonus_start = xdrop ? 0u : (uint32_t)first_b * S;
+            d.bonus_end = (mode == VGK_GSSW_PINNED) ? 0u : (uint32_t)last_b * S;
+            d.prof_off = 0xffffffffu; d.pad = 0;
+            if (ctx->has_qa) {
+                d.prof_off = (uint32_t)prof.size();
+                if (xdrop) prof.push_back(0);          // row 0 = nothing consumed
+                for (uint32_t r = 0; r < p.read_len; ++r) {
+                    const int code = nt_read(p.read[r]);
+                    uint32_t w = 0;
+                    for (int b4 = 0; b4 < 4; ++b4)
+                        w |= (uint32_t)((ctx->qmat[25 * p.qual[r] + 5 * b4 + code] + (int)ctx->bias) * (int)S) << (8 * b4);
+                    const uint32_t row = r + (xdrop ? 1u : 0u);
+                    w += 0x01010101u * row_bonus(d.bonus_start, d.bonus_end, row, d.L);
+                    prof.push_back(w);
+                }
+            }
+        }
         // which nodes need their last column saved / need a scratch-seeded first column
         store.assign(g.n_nodes, 0); slow.assign(g.n_nodes, 0);
         for (uint32_t v = 0; v < g.n_nodes; ++v) {
@@ -287,6 +327,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     if ((rc = to_device(b, probs, P.probs))) return fail(rc);
     if ((rc = to_device(b, colinfo, P.colinfo))) return fail(rc);
     if ((rc = to_device(b, reads, P.reads, 8))) return fail(rc);
+    if ((rc = to_device(b, prof, P.prof, 4))) return fail(rc);
     if ((rc = to_device(b, nodes, P.nodes))) return fail(rc);
     if ((rc = to_device(b, preds, P.preds, 1))) return fail(rc);
     if ((rc = to_device(b, waves, P.waves))) return fail(rc);
@@ -298,9 +339,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     if ((rc = dev_alloc(b, (size_t)ops_total + 1, P.ops))) return fail(rc);
     P.wave_begin = 0; P.wave_count = 0; P.K = 0;                 // set per fill launch from b->launches
     P.n_problems = n; P.n_pairs = n_pairs; P.n_waves = n_waves;
-    // scale 8 whenever the scaled profile bytes still fit (they do for vg's default 1/4/6/1/5): see GsswParams::scale
-    uint32_t S = ((ctx->max_score + (int)ctx->bias + 2 * ctx->sc.full_length_bonus) * 8 <= 255) ? 8u : 1u;
-    if (const char* e = std::getenv("VGAMD_SCORE_SCALE")) S = std::atoi(e) == 8 && S == 8 ? 8u : 1u;
+    const uint32_t S = ctx->scale;     // 8 whenever the scaled profile bytes still fit (vg's default 1/4/6/1/5 does)
     for (int q = 0; q < 6; ++q) P.prof4[q] = ctx->prof4[q] * S;      // bytes stay < 256, no carries between them
     P.bias = ctx->bias * S; P.go = ctx->sc.gap_open * S; P.ge = ctx->sc.gap_extend * S; P.bonus = ctx->sc.full_length_bonus * (int32_t)S;
     P.scale = S; P.xoff = XOFF * S;

@@ -1,5 +1,6 @@
 #include "aligner.hpp"
 #include <algorithm>
+#include <cmath>
 #include <sstream>
 #include <stdexcept>
 
@@ -33,10 +34,84 @@ vgk_scoring MatrixAlignmentScorer::as_vgk() const {
     return s;
 }
 
-GSSWAligner::GSSWAligner(std::unique_ptr<MatrixAlignmentScorer> owned_scorer, std::shared_ptr<EngineApi> eng, int device)
+double QualAdjAlignmentScorer::recover_log_base(const double matrix[16], double gc_content, double tol) {
+    double nt_freqs[4] = {0.5 * (1 - gc_content), 0.5 * gc_content, 0.5 * gc_content, 0.5 * (1 - gc_content)};
+    auto partition = [&](double lambda) {
+        double p = 0.0;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) p += nt_freqs[i] * nt_freqs[j] * std::exp(lambda * matrix[i * 4 + j]);
+        return p;
+    };
+    // verify_valid_log_odds_score_matrix (:101-117)
+    bool positive = false; double expected = 0.0;
+    for (int i = 0; i < 16; ++i) positive = positive || matrix[i] > 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) expected += nt_freqs[i] * nt_freqs[j] * matrix[i * 4 + j];
+    if (!positive || !(expected < 0.0))
+        throw std::invalid_argument("error:[AlignmentScorer] Score matrix is invalid. Must have a negative expected score against random sequence.");
+    double lower_bound, upper_bound, lambda = 1.0;
+    double part = partition(lambda);
+    if (part < 1.0) {
+        lower_bound = lambda;
+        while (part <= 1.0) { lower_bound = lambda; lambda *= 2.0; part = partition(lambda); }
+        upper_bound = lambda;
+    } else {
+        upper_bound = lambda;
+        while (part >= 1.0) { upper_bound = lambda; lambda /= 2.0; part = partition(lambda); }
+        lower_bound = lambda;
+    }
+    while (upper_bound / lower_bound - 1.0 > tol) {
+        lambda = 0.5 * (lower_bound + upper_bound);
+        if (partition(lambda) < 1.0) lower_bound = lambda; else upper_bound = lambda;
+    }
+    return 0.5 * (lower_bound + upper_bound);
+}
+
+QualAdjAlignmentScorer::QualAdjAlignmentScorer(const int8_t* m4, int8_t go, int8_t ge, int8_t bonus, double gc_content)
+    : MatrixAlignmentScorer(m4, go, ge, bonus) {
+    constexpr uint32_t max_qual = 255;
+    double dm[16];
+    for (int i = 0; i < 16; ++i) dm[i] = (double)m4[i];
+    log_base = recover_log_base(dm, gc_content);
+    double nt_freqs[4] = {0.5 * (1 - gc_content), 0.5 * gc_content, 0.5 * gc_content, 0.5 * (1 - gc_content)};
+    // qual_adjusted_matrix (:438-492)
+    double align_prob[16], align_complement_prob[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) align_prob[i * 4 + j] = std::exp(log_base * m4[i * 4 + j]) * nt_freqs[i] * nt_freqs[j];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        align_complement_prob[i * 4 + j] = 0.0;
+        for (int k = 0; k < 4; ++k) if (k != j) align_complement_prob[i * 4 + j] += align_prob[i * 4 + k];
+    }
+    int lowest_meaningful_qual = (int)std::ceil(-10.0 * std::log10(0.75));
+    qual_adj_matrix.assign(25 * (max_qual + 1), 0);
+    for (uint32_t q = 0; q <= max_qual; ++q) {
+        double err = std::pow(10.0, -((double)q) / 10.0);
+        for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) {
+            int8_t score;
+            if (i == 4 || j == 4 || (int)q < lowest_meaningful_qual) score = 0;
+            else score = (int8_t)std::round(std::log(((1.0 - err) * align_prob[i * 4 + j] + (err / 3.0) * align_complement_prob[i * 4 + j])
+                                                   / (nt_freqs[i] * ((1.0 - err) * nt_freqs[j] + (err / 3.0) * (1.0 - nt_freqs[j])))) / log_base);
+            qual_adj_matrix[q * 25 + i * 5 + j] = score;
+        }
+    }
+    // qual_adjusted_bonuses (:494-513)
+    double p_full_len = std::exp(log_base * bonus) / (1.0 + std::exp(log_base * bonus));
+    qual_adj_full_length_bonuses.assign(max_qual + 1, 0);
+    ++lowest_meaningful_qual;      // the reference's "hack": Illumina's minimum quality 2 scores zero
+    for (uint32_t q = (uint32_t)lowest_meaningful_qual; q <= max_qual; ++q) {
+        double err = std::pow(10.0, -((double)q) / 10.0);
+        double score = std::log(((1.0 - err * 4.0 / 3.0) * p_full_len + (err * 4.0 / 3.0) * (1.0 - p_full_len)) / (1.0 - p_full_len)) / log_base;
+        qual_adj_full_length_bonuses[q] = (int8_t)std::round(score);
+    }
+}
+
+GSSWAligner::GSSWAligner(std::unique_ptr<MatrixAlignmentScorer> owned_scorer, std::shared_ptr<EngineApi> eng, int device,
+                         const QualAdjAlignmentScorer* qual_adj)
     : scorer(std::move(owned_scorer)), engine(eng ? eng : load_engine()) {
     vgk_scoring s = scorer->as_vgk();
-    int rc = engine->create(device, &s, &ctx);
+    int rc;
+    if (qual_adj) {
+        qual_adjusted = true;
+        vgk_qual_adj qa{qual_adj->qual_adj_matrix.data(), qual_adj->qual_adj_full_length_bonuses.data()};
+        rc = engine->create_qual_adj(device, &s, &qa, &ctx);
+    } else rc = engine->create(device, &s, &ctx);
     if (rc != VGK_OK) throw std::runtime_error(std::string("vgamd: cannot create engine context: ") + engine->strerror(rc));
 }
 
@@ -144,6 +219,28 @@ Aligner::Aligner(const int8_t* score_matrix, int8_t gap_open, int8_t gap_extensi
                  double /*gc_content*/, std::shared_ptr<EngineApi> eng, int device)
     : GSSWAligner(std::make_unique<MatrixAlignmentScorer>(score_matrix, gap_open, gap_extension, full_length_bonus), eng, device) {}
 
+Aligner::Aligner(std::unique_ptr<MatrixAlignmentScorer> owned_scorer, std::shared_ptr<EngineApi> eng, int device,
+                 const QualAdjAlignmentScorer* qual_adj)
+    : GSSWAligner(std::move(owned_scorer), eng, device, qual_adj) {}
+
+static std::unique_ptr<QualAdjAlignmentScorer> make_qual_scorer(const int8_t* m, int8_t go, int8_t ge, int8_t b, double gc) {
+    return std::make_unique<QualAdjAlignmentScorer>(m, go, ge, b, gc);
+}
+
+QualAdjAligner::QualAdjAligner(const int8_t* score_matrix, int8_t gap_open, int8_t gap_extension, int8_t full_length_bonus,
+                               double gc_content, std::shared_ptr<EngineApi> eng, int device)
+    : QualAdjAligner(make_qual_scorer(score_matrix, gap_open, gap_extension, full_length_bonus, gc_content).release(), eng, device) {}
+
+QualAdjAligner::QualAdjAligner(QualAdjAlignmentScorer* owned, std::shared_ptr<EngineApi> eng, int device)
+    : Aligner(std::unique_ptr<MatrixAlignmentScorer>(owned), eng, device, owned) {}
+
+// the reads of a quality-adjusted aligner must carry one quality per base (the reference asserts, src/banded_global_aligner.cpp:1981-1987)
+static const uint8_t* quality_of(bool qual_adjusted, const std::string& quality, size_t read_len) {
+    if (!qual_adjusted) return nullptr;
+    if (quality.size() != read_len) throw std::invalid_argument("error:[QualAdjAligner] quality-adjusted alignment needs one base quality per read base");
+    return reinterpret_cast<const uint8_t*>(quality.data());
+}
+
 // unreverse_graph_mapping (src/aligner.cpp:255-300) on the flat op list
 static void unreverse_ops(std::vector<vgk_op>& ops, vgk_result& res, const std::vector<uint32_t>& node_len) {
     std::reverse(ops.begin(), ops.end());      // reverses node order and the elements inside each node at once
@@ -168,10 +265,14 @@ void Aligner::align_internal(Alignment& alignment, std::vector<Alignment>* multi
     std::string reversed_sequence;
     const HandleGraph* oriented_graph = &g;
     const std::string* align_sequence = &alignment.sequence;
+    std::string reversed_quality;
+    const std::string* align_quality = &alignment.quality;
     if (pin_left) {
         oriented_graph = &reversed_graph;
         reversed_sequence.assign(alignment.sequence.rbegin(), alignment.sequence.rend());
         align_sequence = &reversed_sequence;
+        reversed_quality.assign(alignment.quality.rbegin(), alignment.quality.rend());
+        align_quality = &reversed_quality;
     }
     std::unordered_set<nid_t> pinning_ids;
     std::unique_ptr<NullMaskingGraph> null_masked_graph;
@@ -190,6 +291,7 @@ void Aligner::align_internal(Alignment& alignment, std::vector<Alignment>* multi
         std::vector<uint8_t> pin_mask;
         vgk_gssw_problem prob{};
         prob.read = align_sequence->data(); prob.read_len = (uint32_t)align_sequence->size();
+        prob.qual = quality_of(qual_adjusted, *align_quality, align_sequence->size());
         prob.flags = (pinned ? VGK_GSSW_PINNED : VGK_GSSW_LOCAL) | (traceback_aln ? VGK_GSSW_TRACEBACK : 0);
         prob.graph = pg.view();
         if (pinned) {
@@ -251,6 +353,7 @@ void Aligner::align(Alignment& alignment, const HandleGraph& g, const std::vecto
     PackedGraph pg = create_packed_graph(g, topological_order);
     vgk_gssw_problem prob{};
     prob.read = alignment.sequence.data(); prob.read_len = (uint32_t)alignment.sequence.size();
+    prob.qual = quality_of(qual_adjusted, alignment.quality, alignment.sequence.size());
     prob.flags = VGK_GSSW_LOCAL | VGK_GSSW_TRACEBACK;
     prob.graph = pg.view();
     vgk_result res{};
@@ -314,8 +417,8 @@ void Aligner::xdrop_align_pinned(Alignment& alignment, const HandleGraph& g, boo
     // reversed graph and read (dozeu walks the node strings backwards with a reverse-packed query, :178-185, :282-283).
     ReverseGraph reversed_graph(&g, false);
     const HandleGraph* run_graph = &g;
-    std::string run_seq = alignment.sequence;
-    if (!pin_left) { run_graph = &reversed_graph; std::reverse(run_seq.begin(), run_seq.end()); }
+    std::string run_seq = alignment.sequence, run_qual = alignment.quality;
+    if (!pin_left) { run_graph = &reversed_graph; std::reverse(run_seq.begin(), run_seq.end()); std::reverse(run_qual.begin(), run_qual.end()); }
     // dozeu sees raw get_sequence(); the packed graph is only a transport for (order, lengths, edges, bases)
     std::vector<handle_t> run_order = handlealgs::lazier_topological_order(run_graph);
     PackedGraph pg;
@@ -339,6 +442,7 @@ void Aligner::xdrop_align_pinned(Alignment& alignment, const HandleGraph& g, boo
     if (!run_seq.empty()) {
         vgk_gssw_problem prob{};
         prob.read = run_seq.data(); prob.read_len = (uint32_t)run_seq.size();
+        prob.qual = quality_of(qual_adjusted, run_qual, run_seq.size());
         prob.flags = VGK_XDROP_PINNED | VGK_GSSW_TRACEBACK;
         prob.graph = pg.view(); prob.max_gap_length = max_gap_length;
         ops.resize(prob.read_len + pg.seq.size() + pg.order.size() + 4);
@@ -459,7 +563,7 @@ std::string alignment_to_json(const Alignment& a) {
 namespace vgamd {
 
 Aligner::Extension Aligner::xdrop_extend(const HandleGraph& g, const std::vector<handle_t>& order, size_t node_index,
-                                         size_t ref_offset, const std::string& read, size_t query_offset,
+                                         size_t ref_offset, const std::string& read, const std::string& quality, size_t query_offset,
                                          bool right_to_left, bool traceback, uint16_t max_gap_length) const {
     Extension ext;
     ext.end_node = node_index; ext.end_ref_offset = ref_offset; ext.end_query = query_offset;
@@ -467,10 +571,12 @@ Aligner::Extension Aligner::xdrop_extend(const HandleGraph& g, const std::vector
     for (size_t i = 0; i < order.size(); ++i) index_of[order[i]] = i;
     // the part of the start node that lies in the extension direction, and the read part to consume
     std::string start_seq = g.get_sequence(order[node_index]);
-    std::string query;
-    if (!right_to_left) { start_seq = start_seq.substr(ref_offset); query = read.substr(query_offset); }
+    std::string query, qqual;
+    const bool have_q = qual_adjusted && quality.size() == read.size();
+    if (!right_to_left) { start_seq = start_seq.substr(ref_offset); query = read.substr(query_offset); if (have_q) qqual = quality.substr(query_offset); }
     else { start_seq = start_seq.substr(0, ref_offset); std::reverse(start_seq.begin(), start_seq.end());
-           query = read.substr(0, query_offset); std::reverse(query.begin(), query.end()); }
+           query = read.substr(0, query_offset); std::reverse(query.begin(), query.end());
+           if (have_q) { qqual = quality.substr(0, query_offset); std::reverse(qqual.begin(), qqual.end()); } }
     if (query.empty()) return ext;
     // nodes reachable from the start, in extension order (the caller's order, reversed for a leftward pass)
     std::vector<char> reach(order.size(), 0);
@@ -507,6 +613,7 @@ Aligner::Extension Aligner::xdrop_extend(const HandleGraph& g, const std::vector
     }
     vgk_gssw_problem prob{};
     prob.read = query.data(); prob.read_len = (uint32_t)query.size();
+    prob.qual = quality_of(qual_adjusted, qqual, query.size());
     prob.flags = VGK_XDROP_PINNED | (traceback ? VGK_GSSW_TRACEBACK : 0);
     prob.graph = pg.view(); prob.max_gap_length = std::max<uint16_t>(max_gap_length, 1);
     vgk_result res{}; std::vector<vgk_op> ops(prob.read_len + pg.seq.size() + kept.size() + 4);
@@ -608,10 +715,12 @@ void Aligner::xdrop_align(Alignment& alignment, const HandleGraph& g, const std:
         // the same 15 bases finds the same maximum position whenever the best hit is an end-to-end match.
         const size_t qlen = read.size(), scan_len = std::min<size_t>(qlen, 15);
         std::string tail = direction ? read.substr(0, scan_len) : read.substr(qlen - scan_len);
+        std::string tail_q;
+        if (qual_adjusted && alignment.quality.size() == qlen) tail_q = direction ? alignment.quality.substr(0, scan_len) : alignment.quality.substr(qlen - scan_len);
         PackedGraph pg; pg.order = order; pg.pred_off.push_back(0);
         const HandleGraph* sg = &g; ReverseGraph rg(&g, false);
         std::vector<handle_t> run_order = order;
-        if (direction) { sg = &rg; std::reverse(run_order.begin(), run_order.end()); std::reverse(tail.begin(), tail.end()); pg.order = run_order; }
+        if (direction) { sg = &rg; std::reverse(run_order.begin(), run_order.end()); std::reverse(tail.begin(), tail.end()); std::reverse(tail_q.begin(), tail_q.end()); pg.order = run_order; }
         std::unordered_map<handle_t, uint32_t, handle_hash> ridx;
         for (uint32_t i = 0; i < run_order.size(); ++i) ridx[run_order[i]] = i;
         for (uint32_t i = 0; i < run_order.size(); ++i) {
@@ -622,6 +731,7 @@ void Aligner::xdrop_align(Alignment& alignment, const HandleGraph& g, const std:
         }
         vgk_gssw_problem prob{};
         prob.read = tail.data(); prob.read_len = (uint32_t)tail.size(); prob.flags = VGK_GSSW_LOCAL; prob.graph = pg.view();
+        prob.qual = quality_of(qual_adjusted, tail_q, tail.size());
         vgk_result res{}; size_t written = 0;
         int rc = engine->gssw_align(ctx, &prob, 1, &res, nullptr, 0, &written);
         if (rc != VGK_OK || res.status != VGK_OK)
@@ -643,11 +753,11 @@ void Aligner::xdrop_align(Alignment& alignment, const HandleGraph& g, const std:
         const size_t sref = direction ? g.get_length(order[sn]) - hit.offset : hit.offset;
         const size_t squery = direction ? read.size() - seed.begin : seed.begin;
         // "upward" extension from the seed; its maximum is the head (:654-672)
-        Extension up = xdrop_extend(g, order, sn, sref, read, squery, direction, false, max_gap_length);
+        Extension up = xdrop_extend(g, order, sn, sref, read, alignment.quality, squery, direction, false, max_gap_length);
         head_node = up.end_node; head_ref = up.end_ref_offset; head_query = up.end_query; have_head = true;
     }
     // ---- downward extension from the head + traceback (align_downward, :687-722)
-    Extension down = xdrop_extend(g, order, head_node, head_ref, read, head_query, !direction, true, max_gap_length);
+    Extension down = xdrop_extend(g, order, head_node, head_ref, read, alignment.quality, head_query, !direction, true, max_gap_length);
     alignment.score = down.score;
     alignment.query_position = 0;
     if (down.score <= 0 || down.mappings.empty()) {

@@ -48,6 +48,16 @@ struct MaximalExactMatch {
     size_t length() const { return end - begin; }
 };
 
+// QualAdjAlignmentScorer (reference: src/alignment_scorer.cpp:419-513): 5x5xQ table indexed
+// 25*qual + 5*nt[ref] + nt[read] and the quality-adjusted full-length bonuses, from the recovered log base.
+struct QualAdjAlignmentScorer : MatrixAlignmentScorer {
+    std::vector<int8_t> qual_adj_matrix;               // [256][25]
+    std::vector<int8_t> qual_adj_full_length_bonuses;  // [256]
+    double log_base = 0.0;
+    QualAdjAlignmentScorer(const int8_t* score_matrix_4x4, int8_t go, int8_t ge, int8_t bonus, double gc_content);
+    static double recover_log_base(const double matrix[16], double gc_content, double tol = 1e-12);   // :30-99
+};
+
 class BaseAligner {
 public:
     virtual ~BaseAligner() = default;
@@ -56,7 +66,9 @@ public:
 
 class GSSWAligner : public BaseAligner {
 protected:
-    GSSWAligner(std::unique_ptr<MatrixAlignmentScorer> owned_scorer, std::shared_ptr<EngineApi> engine, int device);
+    GSSWAligner(std::unique_ptr<MatrixAlignmentScorer> owned_scorer, std::shared_ptr<EngineApi> engine, int device,
+                const QualAdjAlignmentScorer* qual_adj = nullptr);
+    bool qual_adjusted = false;        // quality-adjusted context: every problem carries Alignment.quality
     ~GSSWAligner() override;
 
     // what create_gssw_graph hands to gssw (src/aligner.cpp:30-85): nodes in
@@ -100,6 +112,10 @@ public:
             double gc_content = 0.5,
             std::shared_ptr<EngineApi> engine = nullptr,   // nullptr = the HIP product library
             int device = 0);
+protected:
+    Aligner(std::unique_ptr<MatrixAlignmentScorer> owned_scorer, std::shared_ptr<EngineApi> engine, int device,
+            const QualAdjAlignmentScorer* qual_adj);
+public:
 
     // local alignment, bonus at both ends (src/aligner.cpp:566-569)
     void align(Alignment& alignment, const HandleGraph& g, bool traceback_aln) const override;
@@ -128,13 +144,28 @@ private:
     void xdrop_align(Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& order,
                      const std::vector<MaximalExactMatch>& mems, bool reverse_complemented, uint16_t max_gap_length) const;
     Extension xdrop_extend(const HandleGraph& g, const std::vector<handle_t>& order, size_t node_index, size_t ref_offset,
-                           const std::string& read, size_t query_offset, bool right_to_left, bool traceback,
-                           uint16_t max_gap_length) const;
+                           const std::string& read, const std::string& quality, size_t query_offset, bool right_to_left,
+                           bool traceback, uint16_t max_gap_length) const;
     void align_internal(Alignment& alignment, std::vector<Alignment>* multi_alignments, const HandleGraph& g,
                         bool pinned, bool pin_left, int32_t max_alt_alns, bool traceback_aln) const;
     // DozeuInterface::align_pinned + calculate_and_save_alignment (src/dozeu_interface.cpp:724-766, 338-572)
     void xdrop_align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left,
                             int8_t full_length_bonus, uint16_t max_gap_length) const;
+};
+
+// QualAdjAligner (reference: src/aligner.hpp:218-258, src/aligner.cpp:859-1348): the same calls with scores and
+// bonuses adjusted by base quality.  Reads must carry raw phred qualities (Alignment.quality).
+class QualAdjAligner : public Aligner {
+public:
+    QualAdjAligner(const int8_t* score_matrix = default_score_matrix,
+                   int8_t gap_open = default_gap_open,
+                   int8_t gap_extension = default_gap_extension,
+                   int8_t full_length_bonus = default_full_length_bonus,
+                   double gc_content = 0.5,
+                   std::shared_ptr<EngineApi> engine = nullptr,
+                   int device = 0);
+private:
+    QualAdjAligner(QualAdjAlignmentScorer* owned, std::shared_ptr<EngineApi> engine, int device);
 };
 
 // nonATGCNtoN (reference: src/utility.cpp:323-332)

@@ -34,6 +34,7 @@ std::shared_ptr<EngineApi> load_engine(const std::string& path) {
     bind(dl, "vgk_abi_version", api->abi_version);
     bind(dl, "vgk_strerror", api->strerror);
     bind(dl, "vgk_create", api->create);
+    bind(dl, "vgk_create_qual_adj", api->create_qual_adj);
     bind(dl, "vgk_destroy", api->destroy);
     bind(dl, "vgk_gssw_align", api->gssw_align);
     bind(dl, "vgk_gssw_pack", api->gssw_pack);

@@ -17,6 +17,7 @@ struct EngineApi {
     decltype(&vgk_abi_version) abi_version = nullptr;
     decltype(&vgk_strerror) strerror = nullptr;
     decltype(&vgk_create) create = nullptr;
+    decltype(&vgk_create_qual_adj) create_qual_adj = nullptr;
     decltype(&vgk_destroy) destroy = nullptr;
     decltype(&vgk_gssw_align) gssw_align = nullptr;
     decltype(&vgk_gssw_pack) gssw_pack = nullptr;

@@ -28,16 +28,26 @@ int vgh_graph_add_edge(vgh_graph* g, int64_t from, int64_t to) {
 
 // engine_lib: NULL/"" = the HIP product library (fails loudly without it);
 // tests may pass the oracle's path to exercise the host logic on a CPU box.
-vgh_aligner* vgh_aligner_create(const char* engine_lib, int device, int match, int mismatch,
-                                int gap_open, int gap_extend, int full_length_bonus) {
+static vgh_aligner* make_aligner(const char* engine_lib, int device, int match, int mismatch,
+                                 int gap_open, int gap_extend, int full_length_bonus, bool qual_adj) {
     try {
         int8_t m[16];
         for (int i = 0; i < 16; ++i) m[i] = (i % 5 == 0) ? (int8_t)match : (int8_t)-mismatch;   // src/aligner.cpp:1395-1413
         auto eng = load_engine(engine_lib ? engine_lib : "");
         auto* h = new vgh_aligner();
-        h->a = std::make_unique<Aligner>(m, (int8_t)gap_open, (int8_t)gap_extend, (int8_t)full_length_bonus, 0.5, eng, device);
+        if (qual_adj) h->a = std::make_unique<QualAdjAligner>(m, (int8_t)gap_open, (int8_t)gap_extend, (int8_t)full_length_bonus, 0.5, eng, device);
+        else h->a = std::make_unique<Aligner>(m, (int8_t)gap_open, (int8_t)gap_extend, (int8_t)full_length_bonus, 0.5, eng, device);
         return h;
     } catch (std::exception& e) { g_last_error = e.what(); return nullptr; }
+}
+vgh_aligner* vgh_aligner_create(const char* engine_lib, int device, int match, int mismatch,
+                                int gap_open, int gap_extend, int full_length_bonus) {
+    return make_aligner(engine_lib, device, match, mismatch, gap_open, gap_extend, full_length_bonus, false);
+}
+// AlignerClient::get_qual_adj_aligner(): quality-adjusted twin; reads then need qualities (vgh_align_q)
+vgh_aligner* vgh_qual_adj_aligner_create(const char* engine_lib, int device, int match, int mismatch,
+                                         int gap_open, int gap_extend, int full_length_bonus) {
+    return make_aligner(engine_lib, device, match, mismatch, gap_open, gap_extend, full_length_bonus, true);
 }
 void vgh_aligner_destroy(vgh_aligner* a) { delete a; }
 
@@ -50,10 +60,18 @@ static int emit(const Alignment& aln, char* out, size_t cap) {
 
 // call: 0 = align(traceback), 1 = align(score only), 2 = align_pinned, 3 = align_pinned_multi (primary only reported),
 //       4 = align_pinned(xdrop = true, max_gap = max_alt_alns argument)
+int vgh_align_q(vgh_aligner* a, vgh_graph* g, const char* read, const uint8_t* qual, int call, int pin_left, int max_alt_alns,
+                char* json_out, size_t json_cap);
 int vgh_align(vgh_aligner* a, vgh_graph* g, const char* read, int call, int pin_left, int max_alt_alns,
               char* json_out, size_t json_cap) {
+    return vgh_align_q(a, g, read, nullptr, call, pin_left, max_alt_alns, json_out, json_cap);
+}
+// same with raw phred base qualities (one per read base) for a quality-adjusted aligner
+int vgh_align_q(vgh_aligner* a, vgh_graph* g, const char* read, const uint8_t* qual, int call, int pin_left, int max_alt_alns,
+                char* json_out, size_t json_cap) {
     try {
         Alignment aln; aln.sequence = read;
+        if (qual) aln.quality.assign(reinterpret_cast<const char*>(qual), aln.sequence.size());
         switch (call) {
             case 0: a->a->align(aln, g->g, true); break;
             case 1: a->a->align(aln, g->g, false); break;
