@@ -397,15 +397,45 @@ int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_ca
     return VGK_OK;
 }
 
+// Rough HBM footprint of one problem (dominated by the 4-bit traceback codes) — used to cut oversize calls into
+// sub-batches that fit the device (288 GB on MI355X holds ~8M of the 150 bp x 400 bp problems at once).
+static uint64_t problem_device_bytes(const vgk_gssw_problem& p) {
+    uint64_t R = 0;
+    for (uint32_t v = 0; v < p.graph.n_nodes; ++v) R += p.graph.node_len[v];
+    const uint64_t rows = ((uint64_t)p.read_len + 24) / 4 * 4 + 4;
+    return rows * (R + 64) / 2 + 16 * (p.read_len + R) + 64ull * p.graph.n_nodes + 512;
+}
+
 int vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
                    vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
-    vgk_batch* b = nullptr;
-    int rc = vgk_gssw_pack(ctx, problems, n, 0, &b);
-    if (rc) return rc;
-    rc = vgk_gssw_run(b);
-    if (!rc) rc = vgk_gssw_fetch(b, results, ops, ops_cap, ops_written);
-    vgk_batch_free(b);
-    return rc;
+    if (!ctx || (!problems && n) || !results) return VGK_EINVAL;
+    uint64_t budget = ctx->be->memory_bytes();
+    budget = budget ? budget / 2 : (8ull << 30);          // leave half of HBM to the caller / other contexts
+    if (const char* e = std::getenv("VGAMD_MAX_BATCH_BYTES")) budget = std::strtoull(e, nullptr, 10);
+    size_t w_total = 0;
+    uint32_t begin = 0;
+    while (begin < n || (n == 0 && begin == 0)) {
+        uint32_t end = begin; uint64_t bytes = 0;
+        while (end < n) {
+            const uint64_t pb = problem_device_bytes(problems[end]);
+            if (end > begin && bytes + pb > budget) break;
+            bytes += pb; ++end;
+        }
+        vgk_batch* b = nullptr;
+        int rc = vgk_gssw_pack(ctx, problems + begin, end - begin, 0, &b);
+        if (rc) return rc;
+        rc = vgk_gssw_run(b);
+        size_t w = 0;
+        if (!rc) rc = vgk_gssw_fetch(b, results + begin, ops ? ops + w_total : nullptr, ops_cap - w_total, &w);
+        vgk_batch_free(b);
+        if (rc) return rc;
+        for (uint32_t i = begin; i < end; ++i) results[i].ops_begin += (uint32_t)w_total;   // indices into the caller's whole op array
+        w_total += w;
+        if (end == begin) break;
+        begin = end;
+    }
+    if (ops_written) *ops_written = w_total;
+    return VGK_OK;
 }
 
 double vgk_batch_kernel_ms(vgk_batch* b, int which) {
