@@ -446,7 +446,7 @@ struct Walker {
 };
 
 VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
-    const ProbDesc& d = P.probs[i];
+    const ProbDesc d = P.probs[i];      // by value: keeps the descriptor in registers across the walk's global stores
     vgk_result res;
     res.score = 0; res.status = VGK_OK; res.end_node = -1; res.end_offset = -1; res.end_read = -1;
     res.first_offset = 0; res.n_ops = 0; res.ops_begin = d.ops_off;
