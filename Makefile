@@ -26,8 +26,9 @@ oracle: oracle/libvgoracle.so
 # the C-ABI/packing layer is plain C++; only backend_hip.hip carries device code
 vg_amd/libvgamd.so: $(LIB_SRCS) $(LIB_HDRS)
 	$(CXX) $(CXXFLAGS) -O3 -c vg_amd/csrc/vgk_api.cpp -o vg_amd/csrc/vgk_api.o
+	$(CXX) $(CXXFLAGS) -O3 -c vg_amd/csrc/banded_api.cpp -o vg_amd/csrc/banded_api.o
 	$(HIPCC) $(HIPFLAGS) -c vg_amd/csrc/backend_hip.hip -o vg_amd/csrc/backend_hip.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ vg_amd/csrc/vgk_api.o vg_amd/csrc/backend_hip.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ vg_amd/csrc/vgk_api.o vg_amd/csrc/banded_api.o vg_amd/csrc/backend_hip.o
 
 vg_amd/libvgamd_host.so: $(HOST_SRCS) $(HOST_HDRS)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRCS) -ldl
@@ -42,6 +43,6 @@ clean:
 
 # test-only: CPU lock-step emulation of the HIP lane code behind the same C ABI
 emu: tests/emu/libvgamd_emu.so
-tests/emu/libvgamd_emu.so: vg_amd/csrc/vgk_api.cpp tests/emu/backend_emu.cpp $(LIB_HDRS)
-	$(CXX) -O2 -g -std=c++17 -fPIC -Iinclude -Wall -shared -o $@ vg_amd/csrc/vgk_api.cpp tests/emu/backend_emu.cpp
+tests/emu/libvgamd_emu.so: vg_amd/csrc/vgk_api.cpp vg_amd/csrc/banded_api.cpp tests/emu/backend_emu.cpp $(LIB_HDRS)
+	$(CXX) -O2 -g -std=c++17 -fPIC -Iinclude -Wall -shared -o $@ vg_amd/csrc/vgk_api.cpp vg_amd/csrc/banded_api.cpp tests/emu/backend_emu.cpp -lpthread
 .PHONY: emu

@@ -168,6 +168,36 @@ int  vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
                     vgk_result* results, vgk_op* ops, size_t ops_cap,
                     size_t* ops_written);
 
+/* ---- banded global alignment (BandedGlobalAligner, src/banded_global_aligner.cpp) -------------------
+ * Replaces, inside Aligner::align_global_banded / QualAdjAligner::align_global_banded (src/aligner.cpp:699-760,
+ * :1189-1248), the construction of BandedGlobalAligner<IntType> (:1961-2110: band geometry, masking, cell budget)
+ * and its align() (:2296-2326: fill of the three band matrices per node, choice of the end cell, traceback).
+ * The primary alignment only (max_multi_alns == 1).  The graph is handed over in the order
+ * handlealgs::lazier_topological_order gives (:1976); predecessors in follow_edges(node, true) order (:2032-2036),
+ * which the traceback's tie rules depend on.  Nodes may be empty (node_len 0).  The read must not be empty —
+ * vg routes empty reads to DeletionAligner before it gets here (src/aligner.cpp:703-706).
+ * Result per problem: score, status (VGK_OK, VGK_ENOBAND = NoAlignmentInBandException, VGK_ETOOBIG =
+ * BandMatricesTooBigException), and one (node, op, len) run per edit from the first node of the path to the last;
+ * an empty node on the path contributes one op of length 0.  Every alignment starts at offset 0 of its first node
+ * and ends at the end of its last (global), so end_node / end_offset / first_offset are left 0. */
+#define VGK_BANDED_PERMISSIVE 1u      /* permissive_banding (:2196-2208)                                  */
+typedef struct vgk_banded_problem {
+    const char*    read;              /* alignment.sequence()                                            */
+    const uint8_t* qual;              /* alignment.quality(), raw phred bytes; NULL unless the context is quality-adjusted */
+    uint32_t       read_len;
+    uint32_t       flags;             /* VGK_BANDED_PERMISSIVE                                            */
+    vgk_graph      graph;
+    int32_t        band_padding;      /* (:2203-2218)                                                     */
+    uint32_t       reserved;
+    uint64_t       max_cells;         /* cell budget (:1999-2015); 0 = unlimited                          */
+} vgk_banded_problem;
+
+int  vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n,
+                      vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written);
+/* timing of the last vgk_banded_align call on this context: 0 = fill kernel ms, 1 = traceback kernel ms,
+ * 2 = band cells filled, 3 = algorithmic bytes */
+double vgk_banded_last(vgk_ctx* ctx, int which);
+
 /* batch introspection (used by bench.py for the roofline line) */
 void     vgk_batch_free(vgk_batch* batch);
 int      vgk_batch_sync(vgk_batch* batch);

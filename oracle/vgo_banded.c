@@ -1,0 +1,442 @@
+/*
+ * vgo_banded.c — CPU ORACLE for vg's banded global graph aligner.
+ *
+ * TEST INFRASTRUCTURE ONLY (see vgo_engine.c): never linked or loaded by the product path.
+ *
+ * A restatement, in absolute (read row r, node column j) coordinates, of the algorithm in the
+ * reference's src/banded_global_aligner.cpp:
+ *   - band geometry and masking          find_banded_paths           (:2174-2268), path_lengths_to_sinks (:2122-2170)
+ *   - shortest lead-deletion lengths     shortest_seq_paths          (:2271-2293)
+ *   - cell budget                        BandMatricesTooBigException (:1999-2015)
+ *   - three-matrix fill                  BAMatrix::fill_matrix       (:251-742)
+ *   - choice of the end cell             AltTracebackStack ctor      (:2426-2563), insert_traceback (:2691-2740)
+ *   - traceback inside a node            BAMatrix::traceback         (:756-1126)
+ *   - traceback across an edge           BAMatrix::traceback_over_edge (:1129-1780)
+ *   - edits                              BABuilder                   (:44-205)
+ * Only the primary alignment (max_multi_alns == 1) is produced.
+ *
+ * The band of a node is the set of diagonals d = r - j in [top, bot]; the reference stores it as a
+ * rectangle whose row k is diagonal top + k, and so do we (cell (r, j) lives at row r - j - top).
+ *
+ * Parity status: pinned on the reference's own known-answer tests (src/unittest/banded_global_aligner.cpp,
+ * transcribed to tests/golden/ref_banded_global_aligner.json).  One tie rule cannot be pinned:
+ * PARITY-UNPINNED(sink order) — among several sink nodes with equal best scores the reference keeps the
+ * first one it meets while iterating an unordered_set<BAMatrix*> (pointer hash order, :2332-2336, :2442);
+ * we iterate sinks in topological order.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/vgk.h"
+
+#define NEG (-(1 << 28))
+#define LIVE(v) ((v) > NEG / 2)
+
+enum { MM = 0, IC = 1, IR = 2 };       /* match, insert-column (graph base vs gap), insert-row (read base vs gap) */
+
+typedef struct {
+    int64_t top, bot;                  /* inclusive diagonals */
+    int64_t len, cum;                  /* node length; shortest sequence from any source to the node's left edge */
+    int     masked;
+    size_t  off;                       /* offset of the node's H x len rectangle in each matrix */
+    const char* seq;
+} BNode;
+
+typedef struct { int seed; int path_off, path_len; } SeedRef;   /* a non-empty predecessor reached through path[] of empty nodes */
+
+typedef struct {
+    const vgk_banded_problem* p;
+    const int8_t* mat; const int8_t* qmat;      /* 25 or 256x25 */
+    int go, ge;
+    int64_t L;
+    BNode* nd;
+    int32_t *M, *Ic, *Ir;
+    /* flattened seeds of the node being looked at */
+    SeedRef* seeds; int n_seeds, cap_seeds;
+    int* pool; int n_pool, cap_pool;
+    int as_source; int src_path_off, src_path_len;
+    /* reversed edit runs */
+    vgk_op* runs; size_t n_runs, cap_runs;
+} B;
+
+static int nt5(char c) {
+    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2;
+                 case 'T': case 't': return 3; default: return 4; }
+}
+/* substitution score of read base r against base j of node n (aligner.cpp scorer tables; fill_matrix :341-347) */
+static inline int sub(const B* b, const BNode* n, int64_t r, int64_t j) {
+    int g = nt5(n->seq[j]), q = nt5(b->p->read[r]);
+    return b->qmat ? b->qmat[25 * (int)b->p->qual[r] + 5 * g + q] : b->mat[5 * g + q];
+}
+static inline size_t at(const BNode* n, int64_t r, int64_t j) { return n->off + (size_t)(r - j - n->top) * (size_t)n->len + (size_t)j; }
+static inline int in_band(const B* b, const BNode* n, int64_t r, int64_t j) {
+    return r >= 0 && r < b->L && r - j >= n->top && r - j <= n->bot;
+}
+static inline int max2(int a, int c) { return a > c ? a : c; }
+static inline int best3(const B* b, size_t i) { return max2(max2(b->M[i], b->Ir[i]), b->Ic[i]); }
+static inline int open_col(const B* b, size_t i) { return max2(max2(b->M[i] - b->go, b->Ir[i] - b->go), b->Ic[i] - b->ge); }
+static inline int open_row(const B* b, size_t i) { return max2(max2(b->M[i] - b->go, b->Ir[i] - b->ge), b->Ic[i] - b->go); }
+
+/* ---- flattened predecessor lists: the LIFO walk both fill_matrix (:305-330) and traceback_over_edge (:1226-1262, :1311-1330) do ---- */
+static int pool_push(B* b, const int* src, int n, int extra) {
+    if (b->n_pool + n + 1 > b->cap_pool) { b->cap_pool = (b->n_pool + n + 1) * 2 + 64; b->pool = (int*)realloc(b->pool, sizeof(int) * b->cap_pool); }
+    int off = b->n_pool;
+    for (int i = 0; i < n; ++i) b->pool[b->n_pool++] = src[i];
+    if (extra >= 0) b->pool[b->n_pool++] = extra;
+    return off;
+}
+static void flatten_seeds(B* b, int node) {
+    const vgk_graph* g = &b->p->graph;
+    b->n_seeds = 0; b->n_pool = 0; b->src_path_off = 0; b->src_path_len = 0;
+    b->as_source = g->pred_off[node] == g->pred_off[node + 1];
+    /* explicit stack of (node, path offset, path length) */
+    int cap = 64, top = 0; int* st = (int*)malloc(sizeof(int) * 3 * cap);
+    for (uint32_t e = g->pred_off[node]; e < g->pred_off[node + 1]; ++e) {
+        if (top == cap) { cap *= 2; st = (int*)realloc(st, sizeof(int) * 3 * cap); }
+        st[3 * top] = (int)g->pred_idx[e]; st[3 * top + 1] = 0; st[3 * top + 2] = 0; ++top;
+    }
+    while (top) {
+        --top; int s = st[3 * top], poff = st[3 * top + 1], plen = st[3 * top + 2];
+        if (b->nd[s].masked) continue;
+        if (b->nd[s].len == 0) {
+            int noff = pool_push(b, b->pool + poff, plen, s);
+            if (g->pred_off[s] == g->pred_off[s + 1]) { b->as_source = 1; b->src_path_off = noff; b->src_path_len = plen + 1; }
+            for (uint32_t e = g->pred_off[s]; e < g->pred_off[s + 1]; ++e) {
+                if (top == cap) { cap *= 2; st = (int*)realloc(st, sizeof(int) * 3 * cap); }
+                st[3 * top] = (int)g->pred_idx[e]; st[3 * top + 1] = noff; st[3 * top + 2] = plen + 1; ++top;
+            }
+            continue;
+        }
+        if (b->n_seeds == b->cap_seeds) { b->cap_seeds = b->cap_seeds * 2 + 16; b->seeds = (SeedRef*)realloc(b->seeds, sizeof(SeedRef) * b->cap_seeds); }
+        b->seeds[b->n_seeds].seed = s; b->seeds[b->n_seeds].path_off = poff; b->seeds[b->n_seeds].path_len = plen; ++b->n_seeds;
+    }
+    free(st);
+}
+
+/* ---- fill (fill_matrix :251-742) ---- */
+static void fill_node(B* b, int node) {
+    BNode* n = &b->nd[node];
+    if (n->len == 0) return;
+    const int go = b->go, ge = b->ge; const int64_t L = b->L;
+    int64_t lo0 = n->top < 0 ? 0 : n->top, hi0 = n->bot >= L ? L - 1 : n->bot;
+    for (int64_t r = lo0; r <= hi0; ++r) { b->M[at(n, r, 0)] = NEG; b->Ic[at(n, r, 0)] = NEG; }
+    if (lo0 <= hi0) b->Ir[at(n, lo0, 0)] = NEG;
+    flatten_seeds(b, node);
+    for (int si = 0; si < b->n_seeds; ++si) {
+        const BNode* s = &b->nd[b->seeds[si].seed];
+        int64_t snt = s->top + s->len, snb = s->bot + s->len;          /* diagonals this seed reaches in column 0 */
+        int64_t lo = snt < 0 ? 0 : snt, hi = snb >= L ? L - 1 : snb;
+        int64_t ext = s->cum + s->len, sj = s->len - 1;
+        if (lo > hi) continue;
+        /* first row (:343-377) */
+        size_t i = at(n, lo, 0);
+        int ms = sub(b, n, lo, 0);
+        if (snt < 0) {
+            b->M[i]  = max2(b->M[i], ms - go - (int)(ext - 1) * ge);
+            b->Ir[i] = max2(b->Ir[i], -2 * go - (int)ext * ge);
+        } else if (snt == 0) {
+            b->M[i]  = max2(b->M[i], ms - go - (int)(ext - 1) * ge);
+        } else {
+            b->M[i]  = max2(b->M[i], ms + best3(b, at(s, lo - 1, sj)));
+        }
+        if (snt < snb) b->Ic[i] = max2(b->Ic[i], open_col(b, at(s, lo, sj)));
+        /* interior rows (:379-400) */
+        for (int64_t r = lo + 1; r < hi; ++r) {
+            i = at(n, r, 0);
+            b->M[i]  = max2(b->M[i], sub(b, n, r, 0) + best3(b, at(s, r - 1, sj)));
+            b->Ic[i] = max2(b->Ic[i], open_col(b, at(s, r, sj)));
+        }
+        /* last row (:403-429): the column gap only exists when the band was cut by the bottom of the matrix */
+        if (hi != lo) {
+            i = at(n, hi, 0);
+            b->M[i] = max2(b->M[i], sub(b, n, hi, 0) + best3(b, at(s, hi - 1, sj)));
+            if (snb >= L) b->Ic[i] = max2(b->Ic[i], open_col(b, at(s, hi, sj)));
+        }
+    }
+    if (b->as_source) {
+        /* implied lead gaps of a source column (:433-476) */
+        size_t i = at(n, 0, 0);
+        b->M[i] = b->qmat ? max2(b->M[i], sub(b, n, 0, 0)) : sub(b, n, 0, 0);
+        b->Ir[i] = max2(b->Ir[i], -2 * go);
+        b->Ic[i] = max2(b->Ic[i], -2 * go);
+        for (int64_t r = 1; r <= hi0; ++r) {
+            i = at(n, r, 0); size_t up = at(n, r - 1, 0);
+            b->M[i]  = max2(b->M[i], sub(b, n, r, 0) - go - (int)(r - 1) * ge);
+            b->Ir[i] = open_row(b, up);
+            b->Ic[i] = max2(b->Ic[i], -2 * go - (int)r * ge);
+        }
+        b->Ic[i] = NEG;
+    } else {
+        for (int64_t r = lo0 + 1; r <= hi0; ++r) b->Ir[at(n, r, 0)] = open_row(b, at(n, r - 1, 0));
+    }
+    /* remaining columns (:492-590) */
+    int64_t H = n->bot - n->top + 1;
+    for (int64_t j = 1; j < n->len; ++j) {
+        int64_t lo = n->top + j < 0 ? 0 : n->top + j, hi = n->bot + j >= L ? L - 1 : n->bot + j;
+        if (lo > hi) continue;
+        size_t i = at(n, lo, j);
+        int ms = sub(b, n, lo, j);
+        b->M[i]  = n->top + j <= 0 ? ms - go - (int)(n->cum + j - 1) * ge : ms + best3(b, at(n, lo - 1, j - 1));
+        b->Ir[i] = n->top + j <  0 ? -2 * go - (int)(n->cum + j) * ge : NEG;
+        b->Ic[i] = H != 1 ? open_col(b, at(n, lo, j - 1)) : NEG;
+        for (int64_t r = lo + 1; r < hi; ++r) {
+            i = at(n, r, j);
+            b->M[i]  = sub(b, n, r, j) + best3(b, at(n, r - 1, j - 1));
+            b->Ir[i] = open_row(b, at(n, r - 1, j));
+            b->Ic[i] = open_col(b, at(n, r, j - 1));
+        }
+        if (hi > lo) {
+            i = at(n, hi, j);
+            b->M[i]  = sub(b, n, hi, j) + best3(b, at(n, hi - 1, j - 1));
+            b->Ir[i] = open_row(b, at(n, hi - 1, j));
+            b->Ic[i] = n->bot + j >= L ? open_col(b, at(n, hi, j - 1)) : NEG;
+        }
+    }
+}
+
+/* ---- edits (BABuilder :44-205), built back to front ---- */
+static void emit(B* b, int node, int op, int inc) {
+    if (b->n_runs && b->runs[b->n_runs - 1].node == (uint32_t)node) {
+        vgk_op* c = &b->runs[b->n_runs - 1];
+        if (c->op == op) { c->len = (uint16_t)(c->len + inc); return; }
+        if (c->len == 0 && b->nd[node].len == 0) { c->op = (uint8_t)op; c->len = (uint16_t)inc; return; }   /* empty node: the zero edit is replaced (:69-72) */
+    }
+    if (b->n_runs == b->cap_runs) { b->cap_runs = b->cap_runs * 2 + 64; b->runs = (vgk_op*)realloc(b->runs, sizeof(vgk_op) * b->cap_runs); }
+    vgk_op* c = &b->runs[b->n_runs++];
+    c->node = (uint32_t)node; c->op = (uint8_t)op; c->len = (uint16_t)inc; c->pad = 0;
+}
+static int op_of(int mat) { return mat == MM ? VGK_OP_M : mat == IR ? VGK_OP_I : VGK_OP_D; }
+
+/* pick the source state of a transition in the reference's order match, insert-col, insert-row (:812 `prev_mats`) */
+static int pick(const B* b, size_t i, int cur, int dm, int dc, int dr) {
+    if (cur == b->M[i] + dm) return MM;
+    if (LIVE(b->Ic[i]) && cur == b->Ic[i] + dc) return IC;
+    if (LIVE(b->Ir[i]) && cur == b->Ir[i] + dr) return IR;
+    return -1;
+}
+
+static int traceback(B* b, int node, int mat) {
+    const int go = b->go, ge = b->ge;
+    BNode* n = &b->nd[node];
+    int64_t r = b->L - 1, j = n->len - 1;
+    int lead = 0;
+    for (;;) {
+        n = &b->nd[node];
+        /* inside the node (:775-1112) */
+        while ((j > 0 || mat == IR) && !lead) {
+            emit(b, node, op_of(mat), 1);
+            if (mat == MM) {
+                if (r == 0) { mat = IC; --j; r = -1; lead = 1; break; }
+                int src = pick(b, at(n, r - 1, j - 1), b->M[at(n, r, j)], sub(b, n, r, j), sub(b, n, r, j), sub(b, n, r, j));
+                if (src < 0) return VGK_EINVAL;
+                mat = src; --r; --j;
+            } else if (mat == IR) {
+                if (r == 0) { lead = 1; r = -1; break; }
+                int src = pick(b, at(n, r - 1, j), b->Ir[at(n, r, j)], -go, -go, -ge);
+                if (src < 0) return VGK_EINVAL;
+                mat = src; --r;
+            } else {
+                int src = pick(b, at(n, r, j - 1), b->Ic[at(n, r, j)], -go, -ge, -go);
+                if (src < 0) return VGK_EINVAL;
+                mat = src; --j;
+            }
+        }
+        if (lead) { mat = IC; while (j > 0) { emit(b, node, VGK_OP_D, 1); --j; } }     /* (:1114-1124) */
+
+        /* across the left edge (:1129-1780) */
+        flatten_seeds(b, node);
+        int found = -1, fmat = MM, flead = lead;
+        if (lead) {
+            emit(b, node, VGK_OP_D, 1);
+            for (int si = 0; si < b->n_seeds && found < 0; ++si) {
+                const BNode* s = &b->nd[b->seeds[si].seed];
+                if ((int64_t)ge * (s->cum + s->len - n->cum) == 0) found = si;
+            }
+            if (found < 0) {
+                if (!b->as_source) return VGK_EINVAL;
+                for (int k = 0; k < b->src_path_len; ++k) emit(b, b->pool[b->src_path_off + k], VGK_OP_D, 0);
+                return VGK_OK;
+            }
+        } else {
+            emit(b, node, op_of(mat), 1);
+            int cur = mat == MM ? b->M[at(n, r, 0)] : b->Ic[at(n, r, 0)];
+            int ms = mat == MM ? sub(b, n, r, 0) : 0;
+            for (int si = 0; si < b->n_seeds && found < 0; ++si) {
+                const BNode* s = &b->nd[b->seeds[si].seed];
+                int64_t snt = s->top + s->len, snb = s->bot + s->len, sj = s->len - 1;
+                if (r > snb - (mat == IC) || r < snt) continue;
+                if (mat == MM) {
+                    if (r == 0) {          /* the diagonal neighbour is the implied lead-gap row (:1352-1372) */
+                        if (cur == -go - (int)(s->cum + s->len - 1) * ge + ms) { found = si; fmat = IC; flead = 1; }
+                        continue;
+                    }
+                    int src = pick(b, at(s, r - 1, sj), cur, ms, ms, ms);
+                    if (src >= 0) { found = si; fmat = src; }
+                } else {
+                    int src = pick(b, at(s, r, sj), cur, -go, -ge, -go);
+                    if (src >= 0) { found = si; fmat = src; }
+                }
+            }
+            if (found < 0) {
+                if (!b->as_source) return VGK_EINVAL;
+                int64_t ins;                 /* read bases inserted before the first graph base (:1655-1720) */
+                if (mat == MM) { if (cur != (r > 0 ? -go - (int)(r - 1) * ge : 0) + ms) return VGK_EINVAL; ins = r; }
+                else           { if (cur != -go - (int)r * ge - go) return VGK_EINVAL; ins = r + 1; }
+                for (int k = 0; k < b->src_path_len; ++k) emit(b, b->pool[b->src_path_off + k], VGK_OP_D, 0);
+                int end_node = b->src_path_len ? b->pool[b->src_path_off + b->src_path_len - 1] : node;
+                for (int64_t k = 0; k < ins; ++k) emit(b, end_node, VGK_OP_I, 1);
+                return VGK_OK;
+            }
+        }
+        const SeedRef* sr = &b->seeds[found];
+        for (int k = 0; k < sr->path_len; ++k) emit(b, b->pool[sr->path_off + k], op_of(mat), 0);
+        if (!lead) { if (mat == MM) --r; mat = fmat; lead = flead; }
+        node = sr->seed; j = b->nd[node].len - 1;
+    }
+}
+
+int vgo_banded_align(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_banded_problem* p,
+                     vgk_result* res, vgk_op* ops, uint32_t ops_cap) {
+    memset(res, 0, sizeof *res);
+    const vgk_graph* g = &p->graph;
+    const int N = (int)g->n_nodes; const int64_t L = p->read_len;
+    if (!N || !L) { res->status = VGK_EINVAL; return VGK_EINVAL; }
+    if (qa && !p->qual) { res->status = VGK_EINVAL; return VGK_EINVAL; }
+    B b; memset(&b, 0, sizeof b);
+    b.p = p; b.mat = sc->matrix; b.qmat = qa ? qa->matrix : NULL; b.go = sc->gap_open; b.ge = sc->gap_extend; b.L = L;
+    b.nd = (BNode*)calloc((size_t)N, sizeof(BNode));
+    int rc = VGK_OK;
+    /* successor lists */
+    uint32_t* succ_off = (uint32_t*)calloc((size_t)N + 1, sizeof(uint32_t));
+    uint32_t* succ = (uint32_t*)malloc(sizeof(uint32_t) * (g->pred_off[N] + 1));
+    for (int v = 0; v < N; ++v) for (uint32_t e = g->pred_off[v]; e < g->pred_off[v + 1]; ++e) ++succ_off[g->pred_idx[e] + 1];
+    for (int v = 0; v < N; ++v) succ_off[v + 1] += succ_off[v];
+    { uint32_t* fillp = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(N + 1)); memcpy(fillp, succ_off, sizeof(uint32_t) * (size_t)(N + 1));
+      for (int v = 0; v < N; ++v) for (uint32_t e = g->pred_off[v]; e < g->pred_off[v + 1]; ++e) succ[fillp[g->pred_idx[e]]++] = (uint32_t)v;
+      free(fillp); }
+    size_t soff = 0;
+    for (int v = 0; v < N; ++v) { b.nd[v].len = g->node_len[v]; b.nd[v].seq = g->seq + soff; soff += g->node_len[v]; }
+    /* path lengths to sinks (:2122-2170) */
+    int64_t* shortest = (int64_t*)malloc(sizeof(int64_t) * (size_t)N); int64_t* longest = (int64_t*)calloc((size_t)N, sizeof(int64_t));
+    for (int v = 0; v < N; ++v) shortest[v] = succ_off[v] == succ_off[v + 1] ? 0 : INT64_MAX;
+    for (int v = N - 1; v >= 0; --v) {
+        int64_t lg = longest[v] + b.nd[v].len, sh = shortest[v] + b.nd[v].len;
+        for (uint32_t e = g->pred_off[v]; e < g->pred_off[v + 1]; ++e) {
+            uint32_t u = g->pred_idx[e];
+            if (longest[u] < lg) longest[u] = lg;
+            if (shortest[u] > sh) shortest[u] = sh;
+        }
+    }
+    /* band ends and masking (:2174-2268) */
+    const int permissive = (p->flags & VGK_BANDED_PERMISSIVE) != 0; const int64_t pad = p->band_padding;
+    for (int v = 0; v < N; ++v) { b.nd[v].top = INT64_MAX; b.nd[v].bot = INT64_MIN; }
+    for (int v = 0; v < N; ++v) if (g->pred_off[v] == g->pred_off[v + 1]) {
+        if (permissive) {
+            int64_t t = L - (b.nd[v].len + longest[v]) - pad, u = L - (b.nd[v].len + shortest[v]) + pad;
+            b.nd[v].top = t < -pad ? t : -pad; b.nd[v].bot = u > pad ? u : pad;
+        } else { b.nd[v].top = -pad; b.nd[v].bot = pad; }
+    }
+    uint64_t total_cells = 0;
+    for (int v = 0; v < N; ++v) {
+        BNode* n = &b.nd[v];
+        if (n->top > n->bot) { n->masked = 1; continue; }          /* never reached from an unmasked node */
+        int64_t et = n->top + n->len, eb = n->bot + n->len;
+        if (et + shortest[v] > L || eb + longest[v] < L) { n->masked = 1; continue; }
+        for (uint32_t e = succ_off[v]; e < succ_off[v + 1]; ++e) {
+            BNode* o = &b.nd[succ[e]];
+            if (et < o->top) o->top = et;
+            if (eb > o->bot) o->bot = eb;
+        }
+        total_cells += (uint64_t)(n->bot - n->top + 1) * (uint64_t)n->len;
+    }
+    if (p->max_cells && total_cells > p->max_cells) { rc = VGK_ETOOBIG; goto done; }
+    /* shortest sequence leading to each node (:2271-2293) */
+    for (int v = 0; v < N; ++v) b.nd[v].cum = g->pred_off[v] == g->pred_off[v + 1] ? 0 : INT64_MAX;
+    for (int v = 0; v < N; ++v) {
+        int64_t through = b.nd[v].cum + b.nd[v].len;
+        for (uint32_t e = succ_off[v]; e < succ_off[v + 1]; ++e) if (through < b.nd[succ[e]].cum) b.nd[succ[e]].cum = through;
+    }
+    if (!permissive) {
+        int any = 0;
+        for (int v = 0; v < N; ++v) if (succ_off[v] == succ_off[v + 1] && !b.nd[v].masked) any = 1;
+        if (!any) { rc = VGK_ENOBAND; goto done; }
+    }
+    {
+        size_t cells = 0;
+        for (int v = 0; v < N; ++v) if (!b.nd[v].masked) { b.nd[v].off = cells; cells += (size_t)(b.nd[v].bot - b.nd[v].top + 1) * (size_t)b.nd[v].len; }
+        b.M = (int32_t*)malloc(sizeof(int32_t) * (cells + 1)); b.Ic = (int32_t*)malloc(sizeof(int32_t) * (cells + 1)); b.Ir = (int32_t*)malloc(sizeof(int32_t) * (cells + 1));
+        if (!b.M || !b.Ic || !b.Ir) { rc = VGK_ENOMEM; goto done; }
+        for (size_t i = 0; i <= cells; ++i) { b.M[i] = NEG; b.Ic[i] = NEG; b.Ir[i] = NEG; }
+    }
+    for (int v = 0; v < N; ++v) if (!b.nd[v].masked) fill_node(&b, v);
+
+    /* choose where the traceback starts (:2426-2563): sinks, looking through empty sinks to their predecessors; on
+       equal scores the first candidate met stays (insert_traceback :2697-2703), within a node in the order match,
+       insert-row, insert-col (:2522-2552); a source-to-sink chain of empty nodes competes with the whole read inserted
+       and wins ties (next_is_empty :2611-2613). */
+    {
+        int have = 0, best = 0, bnode = -1, bmat = MM; int* bprefix = NULL; int bplen = 0;
+        int have_empty = 0; int* eprefix = NULL; int eplen = 0;
+        int cap = 64; int* st = (int*)malloc(sizeof(int) * cap); int* path = (int*)malloc(sizeof(int) * (size_t)(N + 1)); int plen = 0;
+        for (int v = 0; v < N; ++v) {
+            if (succ_off[v] != succ_off[v + 1] || b.nd[v].masked) continue;
+            int top = 0; st[top++] = v; plen = 0;
+            while (top) {
+                int u = st[--top];
+                if (u < 0) { --plen; continue; }
+                if (b.nd[u].masked) continue;
+                if (b.nd[u].len == 0) {
+                    path[plen++] = u;
+                    if (top + 2 + (int)(g->pred_off[u + 1] - g->pred_off[u]) > cap) { cap = cap * 2 + (int)(g->pred_off[u + 1] - g->pred_off[u]); st = (int*)realloc(st, sizeof(int) * cap); }
+                    st[top++] = -1;
+                    if (g->pred_off[u] == g->pred_off[u + 1]) {
+                        if (!have_empty) { have_empty = 1; eplen = plen; eprefix = (int*)malloc(sizeof(int) * (size_t)plen); memcpy(eprefix, path, sizeof(int) * (size_t)plen); }
+                        continue;
+                    }
+                    for (uint32_t e = g->pred_off[u]; e < g->pred_off[u + 1]; ++e) st[top++] = (int)g->pred_idx[e];
+                    continue;
+                }
+                const BNode* n = &b.nd[u];
+                if (!in_band(&b, n, L - 1, n->len - 1)) continue;
+                size_t i = at(n, L - 1, n->len - 1);
+                const int cand[3] = { b.M[i], b.Ir[i], b.Ic[i] }; const int cmat[3] = { MM, IR, IC };
+                for (int k = 0; k < 3; ++k) if (LIVE(cand[k]) && (!have || cand[k] > best)) {
+                    have = 1; best = cand[k]; bnode = u; bmat = cmat[k];
+                    free(bprefix); bplen = plen; bprefix = (int*)malloc(sizeof(int) * (size_t)(plen + 1)); memcpy(bprefix, path, sizeof(int) * (size_t)plen);
+                }
+            }
+        }
+        free(st); free(path);
+        int empty_score = -b.go - (int)(L - 1) * b.ge;
+        size_t n_out = 0;
+        if (have_empty && (!have || empty_score >= best)) {
+            /* the read is one insertion on the first node of the empty chain (next_empty_alignment :2616-2668) */
+            res->score = empty_score;
+            for (int k = eplen - 1; k >= 0; --k) {      /* path[] runs sink-first; the alignment runs source-first */
+                if (n_out >= ops_cap) { rc = VGK_EOPS; break; }
+                vgk_op o; o.node = (uint32_t)eprefix[k]; o.pad = 0;
+                if (k == eplen - 1) { o.op = VGK_OP_I; o.len = (uint16_t)L; } else { o.op = VGK_OP_M; o.len = 0; }
+                ops[n_out++] = o;
+            }
+        } else if (!have) {
+            rc = VGK_ENOBAND;
+        } else {
+            rc = traceback(&b, bnode, bmat);
+            if (rc == VGK_OK) {
+                res->score = best;
+                if (b.n_runs + (size_t)bplen > ops_cap) rc = VGK_EOPS;
+                else {
+                    for (size_t k = b.n_runs; k-- > 0;) { vgk_op o = b.runs[k]; if (o.len == 0) o.op = VGK_OP_M; ops[n_out++] = o; }
+                    for (int k = bplen - 1; k >= 0; --k) { vgk_op o; o.node = (uint32_t)bprefix[k]; o.op = VGK_OP_M; o.len = 0; o.pad = 0; ops[n_out++] = o; }
+                }
+            }
+        }
+        res->n_ops = (uint32_t)n_out; res->ops_begin = 0;
+        free(bprefix); free(eprefix);
+    }
+done:
+    res->status = rc;
+    free(b.M); free(b.Ic); free(b.Ir); free(b.nd); free(b.seeds); free(b.pool); free(b.runs);
+    free(succ_off); free(succ); free(shortest); free(longest);
+    return rc;
+}

@@ -18,6 +18,9 @@ int vgo_gssw_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gs
 int vgo_xdrop_pinned_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p,
                              vgk_result* res, vgk_op* ops, uint32_t ops_cap);
 
+int vgo_banded_align(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_banded_problem* p,
+                     vgk_result* res, vgk_op* ops, uint32_t ops_cap);
+
 struct vgk_ctx { vgk_scoring sc; int has_qa; vgk_qual_adj qa; int8_t qmat[256 * 25]; int8_t qbon[256]; };
 
 static int vgo_dispatch(const vgk_ctx* c, const vgk_gssw_problem* p, vgk_result* res, vgk_op* ops, uint32_t ops_cap) {
@@ -130,6 +133,22 @@ int vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
     vgk_batch_free(b);
     return rc;
 }
+
+int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n,
+                     vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+    if (!ctx || (!problems && n) || !results) return VGK_EINVAL;
+    const vgk_qual_adj* qa = ctx->has_qa ? &ctx->qa : NULL;
+    size_t used = 0; int rc = VGK_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        size_t room = ops_cap - used;
+        vgo_banded_align(&ctx->sc, qa, &problems[i], &results[i], ops ? ops + used : NULL, room > 0xffffffffu ? 0xffffffffu : (uint32_t)room);
+        if (results[i].status == VGK_EOPS) rc = VGK_EOPS;
+        results[i].ops_begin = (uint32_t)used; used += results[i].n_ops;
+    }
+    if (ops_written) *ops_written = used;
+    return rc;
+}
+double vgk_banded_last(vgk_ctx* ctx, int which) { (void)ctx; (void)which; return 0.0; }
 
 void vgk_batch_free(vgk_batch* b) { if (b) { free(b->res); free(b->ops); free(b); } }
 int  vgk_batch_sync(vgk_batch* b) { (void)b; return VGK_OK; }

@@ -4,16 +4,63 @@
 // wave_shr:1 exchange replaced by reading the previous step's values of lane-1.
 // It lets the kernel logic be debugged in a container without a GPU.  It is
 // never built into, nor loaded by, the product library.
+#include <pthread.h>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../vg_amd/csrc/backend.hpp"
 
 namespace vgk {
 
+// banded kernels: one CPU thread per lane, the cross-lane primitives of banded_device.hpp through a barrier
+struct XlShared { pthread_barrier_t bar; int32_t buf[64]; };
+struct XlEmu {
+    XlShared* sh; uint32_t lane;
+    int32_t exchange(int32_t v, int mode) {
+        sh->buf[lane] = v;
+        pthread_barrier_wait(&sh->bar);
+        int32_t out = BNEG;
+        if (mode == 0) { if (lane < 63) out = sh->buf[lane + 1]; }
+        else if (mode == 1) { if (lane > 0) out = sh->buf[lane - 1]; }
+        else for (uint32_t l = 0; l < lane; ++l) out = bmax(out, sh->buf[l]);
+        pthread_barrier_wait(&sh->bar);
+        return out;
+    }
+    int32_t up(int32_t v) { return exchange(v, 0); }
+    int32_t down(int32_t v) { return exchange(v, 1); }
+    int32_t scan_excl(int32_t v) { return exchange(v, 2); }
+    void fence() { pthread_barrier_wait(&sh->bar); }
+};
+template <int R> static void banded_fill_emu(const BandedParams& P, uint32_t begin, uint32_t count) {
+    XlShared sh; pthread_barrier_init(&sh.bar, nullptr, 64);
+    std::vector<std::thread> ts;
+    for (uint32_t lane = 0; lane < 64; ++lane) ts.emplace_back([&, lane]() {
+        XlEmu xl{&sh, lane};
+        for (uint32_t i = 0; i < count; ++i) { const BProb pb = P.probs[P.order[begin + i]]; banded_fill_lane<R>(P, pb, lane, xl); xl.fence(); }
+    });
+    for (auto& t : ts) t.join();
+    pthread_barrier_destroy(&sh.bar);
+}
+
 class EmuBackend final : public Backend {
 public:
+    int run_banded(const BandedParams& P, const BandedLaunch* launches, uint32_t n) override {
+        for (uint32_t i = 0; i < n; ++i) {
+            const BandedLaunch& L = launches[i];
+            switch (L.R) {
+                case 1: banded_fill_emu<1>(P, L.begin, L.count); break;
+                case 2: banded_fill_emu<2>(P, L.begin, L.count); break;
+                case 4: banded_fill_emu<4>(P, L.begin, L.count); break;
+                case 8: banded_fill_emu<8>(P, L.begin, L.count); break;
+                case 16: banded_fill_emu<16>(P, L.begin, L.count); break;
+                default: return VGK_EINVAL;
+            }
+        }
+        for (uint32_t i = 0; i < P.n; ++i) banded_walk_one(P, i);
+        return VGK_OK;
+    }
     const char* name() const override { return "cpu-lockstep-emulator"; }
     int compute_units() const override { return 0; }
     size_t memory_bytes() const override { return 0; }

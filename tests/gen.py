@@ -96,3 +96,40 @@ def random_problem(rng, max_nodes=10, max_node_len=12, max_read=120, mode=None, 
 
 def problem_set(problems):
     return capi.ProblemSet.from_lists(problems)
+
+
+def random_banded_problem(rng, max_nodes=8, max_node_len=8, max_read=40, p_empty=0.15, wide=False):
+    """A banded-global problem: DAG that may hold empty nodes, a read sampled from a source-to-sink walk."""
+    n_nodes = int(rng.integers(1, max_nodes + 1))
+    nodes, preds = random_dag(rng, n_nodes, max_node_len)
+    nodes = ["" if rng.random() < p_empty else s for s in nodes]
+    succ = [[] for _ in nodes]
+    for v, pr in enumerate(preds):
+        for p in pr:
+            succ[p].append(v)
+    sources = [v for v, pr in enumerate(preds) if not pr]
+    v = sources[int(rng.integers(0, len(sources)))]
+    walk = []
+    while True:
+        walk.append(nodes[v])
+        if not succ[v]:
+            break
+        v = succ[v][int(rng.integers(0, len(succ[v])))]
+    ref = "".join(walk)
+    out = []
+    for c in ref:
+        r = rng.random()
+        if r < 0.08:
+            out.append(BASES[int(rng.integers(0, 4))])
+        elif r < 0.12:
+            continue
+        elif r < 0.16:
+            out.append(BASES[int(rng.integers(0, 4))]); out.append(c)
+        else:
+            out.append(c)
+    if rng.random() < 0.2 or not out:
+        out = [BASES[i] for i in rng.integers(0, 4, int(rng.integers(1, max_read + 1)))]
+    read = "".join(out[:max_read])
+    return dict(read=read, nodes=nodes, preds=preds,
+                band_padding=(len(read) + sum(len(s) for s in nodes) + 2) if wide else int(rng.integers(0, 6)),
+                permissive=True if wide else bool(rng.random() < 0.7))

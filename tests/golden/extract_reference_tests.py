@@ -340,6 +340,37 @@ def handle_statement(st, env):
     if m:
         env.edges.append([env.node_var[m.group(1)], env.node_var[m.group(2)]])
         return
+    m = re.fullmatch(r"(?:Node\*|handle_t|auto) (\w+) = graph\.create_handle\(\s*\"([^\"]*)\", (\d+)\)", st)
+    if m:      # explicit node id
+        nid = int(m.group(3))
+        env.nodes.append([nid, m.group(2)])
+        env.node_var[m.group(1)] = nid
+        return
+    m = re.fullmatch(r"string graph_json = R\"\((.*)\)\"", st, re.S)
+    if m:      # vg::io::json2graph input: nodes with ids, edges with optional from_start / to_end
+        import json as _json
+        gj = _json.loads(m.group(1))
+        for n in gj.get("node", []):
+            env.nodes.append([int(n["id"]), n.get("sequence", "")])
+        for e in gj.get("edge", []):
+            fs, te = bool(e.get("from_start")), bool(e.get("to_end"))
+            if fs != te:
+                raise ValueError("reversing edge")
+            a, b = int(e["from"]), int(e["to"])
+            env.edges.append([b, a] if fs else [a, b])
+        return
+    m = re.fullmatch(r"(\w+)\.set_quality\(string_quality_short_to_char\((\w+)\)\)", st)
+    if m and m.group(1) in env.aln_seq:      # adds 33 to every byte (src/alignment.cpp string_quality_short_to_char)
+        env.aln_qual[m.group(1)] = ("raw", [ord(c) + 33 for c in env.strings[m.group(2)]])
+        return
+    m = re.fullmatch(r"graph\.create_edge\((\w+), (\w+), true, true\)", st)
+    if m:      # from the end of a reversed to the start of b reversed == b forward -> a forward
+        env.edges.append([env.node_var[m.group(2)], env.node_var[m.group(1)]])
+        return
+    m = re.fullmatch(r"(\w+) = (\"[^\"]*\"|string\(.+\))", st)
+    if m and m.group(1) in env.strings:       # re-assignment between two alignments of one SECTION
+        env.strings[m.group(1)] = eval_str(m.group(2), env)
+        return
     m = re.fullmatch(r"(?:const )?(?:std::)?string (\w+) = (.+)", st)
     if m:
         try:
@@ -427,8 +458,13 @@ def handle_statement(st, env):
     m = re.fullmatch(r"(\w+)(?:\.|->)(align\w*)\((.*)\)", st)
     if m and m.group(1) in env.aligners:
         args = [a.strip() for a in m.group(3).split(",")]
-        call = {"aligner": m.group(1), "call": m.group(2), "aln": args[0], "raw_args": args[1:]}
+        aln = args[0]
+        qual = env.aln_qual.get(aln)
+        call = {"aligner": m.group(1), "call": m.group(2), "aln": aln, "raw_args": args[1:],
+                "read": env.aln_seq.get(aln), "quality": qual, "args": [resolve_arg(a, env) for a in args[1:]],
+                "expect": [], "nodes": [list(n) for n in env.nodes], "edges": [list(e) for e in env.edges]}
         env.calls.append(call)
+        env.expects[aln] = call["expect"]      # REQUIREs that follow describe this call until the next one on the same object
         return
     m = re.fullmatch(r"REQUIRE\((.+)\)", st)
     if m:
@@ -461,23 +497,23 @@ def cases_from_file(fname):
         env = run_program(prog)
         for call in env.calls:
             aln = call["aln"]
-            if aln not in env.aln_seq or env.aln_seq[aln] is None:
+            if call["read"] is None:
                 continue
             src, qual_adj = env.aligners[call["aligner"]]
-            qual = env.aln_qual.get(aln)
+            qual = call["quality"]
             case = {
                 "source": "src/unittest/%s:%d" % (fname, line),
                 "name": " / ".join(title_path),
-                "nodes": env.nodes,
-                "edges": env.edges,
-                "read": env.aln_seq[aln],
+                "nodes": call["nodes"],
+                "edges": call["edges"],
+                "read": call["read"],
                 "quality": (qual[1] if qual and qual[0] == "raw" else ([ord(c) for c in qual[1]] if qual else None)),
                 "scores": env.sources.get(src, DEFAULT_SCORES),
                 "qual_adj": qual_adj,
                 "call": call["call"],
-                "args": [resolve_arg(a, env) for a in call["raw_args"]],
+                "args": call["args"],
                 "aln": aln,
-                "expect": env.expects.get(aln, []),
+                "expect": call["expect"],
                 "unparsed": env.unparsed,
             }
             cases.append(case)

@@ -1,0 +1,236 @@
+"""Banded global alignment: the oracle against the reference's own unit-test vectors
+(src/unittest/banded_global_aligner.cpp) through the host shim, plus properties that do not depend on the reference:
+the reported score is the score of the reported path, and with a band wide enough to hold every cell it equals the
+best unbanded global alignment over all source-to-sink walks."""
+import itertools
+
+import numpy as np
+import pytest
+
+import gen
+import util
+from vg_amd import capi
+
+
+def banded_cases():
+    return [c for c in util.load_golden("ref_banded_global_aligner.json") if c["call"] == "align_global_banded"]
+
+
+def run_banded_case(case, engine_lib):
+    args = case["args"]
+    pad = args[1]
+    permissive = args[2] if len(args) > 2 else True
+    al = util.HostAligner(engine_lib, scores=tuple(case["scores"]), qual_adj=case["qual_adj"])
+    aln = al.run(case["nodes"], case["edges"], case["read"], "align_global_banded", pin_left=permissive, max_alt_alns=pad,
+                 quality=case["quality"])
+    util.check_expectations(case, aln)
+    # the REQUIREs the transcriber leaves out are all "is a global alignment" (e.g. :62, :2513): every mapping starts at
+    # offset 0 and covers its whole node, and the edits spell the whole read
+    lens = dict((n, len(s)) for n, s in case["nodes"])
+    maps = aln["path"]["mapping"]
+    for m in maps:
+        assert m["position"]["offset"] == 0
+        assert sum(e["from_length"] for e in m["edit"]) == lens[m["position"]["node_id"]], case["source"]
+    assert sum(e["to_length"] for m in maps for e in m["edit"]) == len(case["read"]), case["source"]
+    edges = set(map(tuple, case["edges"]))
+    for a, b in zip(maps, maps[1:]):
+        assert (a["position"]["node_id"], b["position"]["node_id"]) in edges, case["source"]
+    if case["source"].endswith(":3516"):      # "does not produce empty edits when there is an insertion an empty node"
+        assert all(e["from_length"] or e["to_length"] for m in maps for e in m["edit"])
+    return aln
+
+
+def test_oracle_matches_reference_banded_global_unit_tests():
+    cases = banded_cases()
+    assert len(cases) >= 50
+    for c in cases:
+        run_banded_case(c, util.ORACLE_LIB)
+
+
+def test_shim_maps_band_failures_to_the_reference_exceptions():
+    al = util.HostAligner(util.ORACLE_LIB)
+    # a read far longer than the only walk cannot end inside a non-permissive band (NoAlignmentInBandException, :2094-2108)
+    with pytest.raises(RuntimeError, match="cannot align to graph within band"):
+        al.run([[1, "ACGT"]], [], "ACGTACGTACGTACGTACGT", "align_global_banded", pin_left=False, max_alt_alns=1)
+    # empty read: DeletionAligner (src/aligner.cpp:703-706) takes the shortest walk as one deletion
+    aln = al.run([[1, "AC"], [2, "GGG"], [3, "T"], [4, "A"]], [[1, 2], [1, 3], [2, 4], [3, 4]], "", "align_global_banded",
+                 pin_left=True, max_alt_alns=1)
+    assert [m["position"]["node_id"] for m in aln["path"]["mapping"]] == [1, 3, 4]
+    assert aln["score"] == -6 - 3 * 1
+
+
+# ---- reference-independent properties ----------------------------------------------------------------------------
+
+def path_score(problem, res, ops, sc=(1, 4, 6, 1)):
+    """Score of an op list under affine gaps; a gap that runs on across node boundaries is opened once."""
+    match, mismatch, go, ge = sc
+    read = problem["read"]; nodes = problem["nodes"]
+    o = ops[res["ops_begin"]:res["ops_begin"] + res["n_ops"]]
+    score = 0; rp = 0; prev = None; cur_node = None; npos = 0
+    for e in o:
+        node, ln, op = int(e["node"]), int(e["len"]), int(e["op"])
+        if node != cur_node:
+            if cur_node is not None:
+                assert npos == len(nodes[cur_node]), "mapping does not cover its node"
+                assert cur_node in problem["preds"][node], "not an edge"
+            else:
+                assert not problem["preds"][node], "does not start at a source"
+            cur_node = node; npos = 0
+        if ln == 0:
+            continue
+        if op == capi.OP_M:
+            for k in range(ln):
+                a, b = nodes[node][npos + k], read[rp + k]
+                score += 0 if "N" in (a, b) else (match if a == b else -mismatch)
+            npos += ln; rp += ln
+        elif op == capi.OP_I:
+            score -= (ge * ln) if prev == capi.OP_I else (go + ge * (ln - 1)); rp += ln
+        else:
+            score -= (ge * ln) if prev == capi.OP_D else (go + ge * (ln - 1)); npos += ln
+        prev = op
+    assert cur_node is not None and npos == len(nodes[cur_node])
+    succ_of_last = [v for v, pr in enumerate(problem["preds"]) if cur_node in pr]
+    assert not succ_of_last, "does not end at a sink"
+    assert rp == len(read)
+    return score
+
+
+def best_global_over_walks(problem, sc=(1, 4, 6, 1)):
+    match, mismatch, go, ge = sc
+    nodes, preds, read = problem["nodes"], problem["preds"], problem["read"]
+    succ = [[] for _ in nodes]
+    for v, pr in enumerate(preds):
+        for p in pr:
+            succ[p].append(v)
+    best = None
+    NEG = -10 ** 9
+
+    def gotoh(ref):
+        n, m = len(read), len(ref)
+        M = np.full((n + 1, m + 1), NEG); X = np.full((n + 1, m + 1), NEG); Y = np.full((n + 1, m + 1), NEG)
+        M[0, 0] = 0
+        for i in range(1, n + 1):
+            X[i, 0] = -go - (i - 1) * ge
+        for j in range(1, m + 1):
+            Y[0, j] = -go - (j - 1) * ge
+        for i in range(1, n + 1):
+            for j in range(1, m + 1):
+                a, b = ref[j - 1], read[i - 1]
+                s = 0 if "N" in (a, b) else (match if a == b else -mismatch)
+                M[i, j] = s + max(M[i - 1, j - 1], X[i - 1, j - 1], Y[i - 1, j - 1])
+                X[i, j] = max(M[i - 1, j] - go, X[i - 1, j] - ge, Y[i - 1, j] - go)
+                Y[i, j] = max(M[i, j - 1] - go, Y[i, j - 1] - ge, X[i, j - 1] - go)
+        return max(M[n, m], X[n, m], Y[n, m])
+
+    def walk(v, acc):
+        nonlocal best
+        acc = acc + nodes[v]
+        if not succ[v]:
+            s = gotoh(acc)
+            best = s if best is None else max(best, s)
+            return
+        for w in succ[v]:
+            walk(w, acc)
+
+    for v, pr in enumerate(preds):
+        if not pr:
+            walk(v, "")
+    return int(best)
+
+
+def random_banded_set(seed, n, **kw):
+    rng = np.random.default_rng(seed)
+    return [gen.random_banded_problem(rng, **kw) for _ in range(n)]
+
+
+def test_oracle_banded_score_is_the_score_of_its_path():
+    problems = random_banded_set(11, 400)
+    eng = capi.Engine(lib=util.ORACLE_LIB)
+    res, ops = eng.banded_align(capi.BandedSet.from_lists(problems))
+    ok = 0
+    for p, r in zip(problems, res):
+        assert r["status"] in (0, -8), r["status"]          # VGK_OK or VGK_ENOBAND (non-permissive bands may hold no alignment)
+        if r["status"] == 0:
+            assert path_score(p, r, ops) == r["score"]
+            ok += 1
+    assert ok > 300
+
+
+def test_oracle_wide_band_equals_unbanded_optimum_over_all_walks():
+    problems = random_banded_set(12, 120, max_nodes=6, max_node_len=5, max_read=14, wide=True)
+    eng = capi.Engine(lib=util.ORACLE_LIB)
+    res, ops = eng.banded_align(capi.BandedSet.from_lists(problems))
+    for p, r in zip(problems, res):
+        assert r["status"] == 0
+        assert path_score(p, r, ops) == r["score"]
+        assert r["score"] == best_global_over_walks(p), p
+
+
+# ---- the kernels' lane code stepped on the CPU (tests/emu), and the HIP engine on an MI355X ---------------------------
+
+def _same(problems, ref, got):
+    (ro, oo), (re_, oe) = ref, got
+    bad = []
+    for i, (a, b) in enumerate(zip(ro, re_)):
+        sa = oo[a["ops_begin"]:a["ops_begin"] + a["n_ops"]]; sb = oe[b["ops_begin"]:b["ops_begin"] + b["n_ops"]]
+        if not (a["status"] == b["status"] and a["score"] == b["score"] and a["n_ops"] == b["n_ops"] and (sa == sb).all()):
+            bad.append((i, problems[i], a, b))
+    return bad
+
+
+def mixed_band_problems(seed, n, pad_lo, pad_hi, max_read=300, max_node_len=40):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        p = gen.random_banded_problem(rng, max_nodes=10, max_node_len=max_node_len, max_read=max_read, p_empty=0.1)
+        p["band_padding"] = int(rng.integers(pad_lo, pad_hi)); p["permissive"] = bool(rng.random() < 0.8)
+        out.append(p)
+    return out
+
+
+def test_emulated_banded_kernels_match_reference_unit_tests_and_oracle():
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    emu = util.EMU_LIB
+    for c in banded_cases():
+        run_banded_case(c, emu)
+    problems = random_banded_set(21, 40) + mixed_band_problems(22, 6, 30, 200)      # the second lot needs 2..8 band rows per lane
+    bs = capi.BandedSet.from_lists(problems)
+    ref = capi.Engine(lib=util.ORACLE_LIB).banded_align(bs)
+    got = capi.Engine(lib=emu).banded_align(bs)
+    assert not _same(problems, ref, got)
+
+
+@pytest.mark.gpu
+def test_hip_banded_matches_reference_unit_tests():
+    for c in banded_cases():
+        run_banded_case(c, util.ENGINE_LIB)
+
+
+@pytest.mark.gpu
+def test_hip_banded_matches_oracle_on_random_problems():
+    problems = random_banded_set(31, 3000) + mixed_band_problems(32, 400, 30, 200) + mixed_band_problems(33, 40, 200, 480, max_read=600)
+    bs = capi.BandedSet.from_lists(problems)
+    ref = capi.Engine(lib=util.ORACLE_LIB).banded_align(bs)
+    eng = capi.Engine()
+    got = eng.banded_align(bs)
+    bad = _same(problems, ref, got)
+    assert not bad, bad[:2]
+    assert (ref[0]["status"] == 0).sum() > 3000
+    for p, r in list(zip(problems, got[0]))[:500]:
+        if r["status"] == 0:
+            assert path_score(p, r, got[1]) == r["score"]
+
+
+@pytest.mark.gpu
+def test_hip_banded_quality_adjusted_matches_oracle():
+    import qualadj
+    rng = np.random.default_rng(41)
+    problems = random_banded_set(42, 600)
+    for p in problems:
+        p["qual"] = rng.integers(0, 41, len(p["read"])).astype(np.uint8)
+    qa = qualadj.qual_adj_tables()
+    bs = capi.BandedSet.from_lists(problems)
+    ref = capi.Engine(lib=util.ORACLE_LIB, qual_adj=qa).banded_align(bs)
+    got = capi.Engine(qual_adj=qa).banded_align(bs)
+    assert not _same(problems, ref, got)

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_LIB = os.path.join(ROOT, "oracle", "libvgoracle.so")
 HOST_LIB = os.path.join(ROOT, "vg_amd", "libvgamd_host.so")
 ENGINE_LIB = os.path.join(ROOT, "vg_amd", "libvgamd.so")
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libvgamd_emu.so")      # CPU lock-step emulation of the kernels
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -64,7 +65,8 @@ class HostAligner:
             for a, b in edges:
                 assert self.h.vgh_graph_add_edge(g, a, b) == 0
             buf = ctypes.create_string_buffer(1 << 20)
-            code = {"align": 0, "align_score": 1, "align_pinned": 2, "align_pinned_multi": 3, "align_pinned_xdrop": 4}[call]
+            code = {"align": 0, "align_score": 1, "align_pinned": 2, "align_pinned_multi": 3, "align_pinned_xdrop": 4,
+                    "align_global_banded": 5}[call]
             if quality is not None:
                 q = bytes(bytearray(int(x) for x in quality))
                 rc = self.h.vgh_align_q(self.ptr, g, read.encode(), q, code, int(pin_left), max_alt_alns, buf, len(buf))

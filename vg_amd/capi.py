@@ -29,6 +29,10 @@ PROBLEM_DT = np.dtype([("read", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), (
 RESULT_DT = np.dtype([("score", "<i4"), ("status", "<i4"), ("end_node", "<i4"), ("end_offset", "<i4"),
                       ("end_read", "<i4"), ("first_offset", "<i4"), ("n_ops", "<u4"), ("ops_begin", "<u4")])
 OP_DT = np.dtype([("node", "<u4"), ("len", "<u2"), ("op", "u1"), ("pad", "u1")])
+BANDED_DT = np.dtype([("read", "<u8"), ("qual", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), ("graph", GRAPH_DT),
+                      ("band_padding", "<i4"), ("reserved", "<u4"), ("max_cells", "<u8")])
+VGK_BANDED_PERMISSIVE = 1
+assert BANDED_DT.itemsize == 80
 assert GRAPH_DT.itemsize == 40 and PROBLEM_DT.itemsize == 80 and RESULT_DT.itemsize == 32 and OP_DT.itemsize == 8
 
 
@@ -77,6 +81,9 @@ def load_library(path=None):
     lib.vgk_batch_sync.argtypes = [vp]
     lib.vgk_batch_kernel_ms.restype = ctypes.c_double
     lib.vgk_batch_kernel_ms.argtypes = [vp, ctypes.c_int]
+    lib.vgk_banded_align.argtypes = [vp, vp, u32, vp, vp, sz, ctypes.POINTER(sz)]
+    lib.vgk_banded_last.restype = ctypes.c_double
+    lib.vgk_banded_last.argtypes = [vp, ctypes.c_int]
     for f in ("vgk_batch_cells", "vgk_batch_alg_bytes", "vgk_batch_device_bytes"):
         getattr(lib, f).restype = ctypes.c_uint64
         getattr(lib, f).argtypes = [vp]
@@ -164,6 +171,29 @@ class ProblemSet:
                    pinning if any_pin else None, [p.get("max_gap", 40) for p in problems], quals)
 
 
+class BandedSet(ProblemSet):
+    """A batch of banded-global problems (vgk_banded_problem) over the same arenas as ProblemSet.
+    problems: list of dicts {read, nodes: [str] (may be empty strings), preds, band_padding, permissive, max_cells?, qual?}."""
+
+    @classmethod
+    def from_lists(cls, problems):
+        base = ProblemSet.from_lists([dict(p, flags=0, pinning=None) for p in problems])
+        s = object.__new__(cls)
+        s.__dict__.update(base.__dict__)
+        arr = np.zeros(s.n, dtype=BANDED_DT)
+        for k in ("read", "read_len", "graph"):
+            arr[k] = base.array[k]
+        arr["qual"] = base.array["qual"]
+        arr["flags"] = [VGK_BANDED_PERMISSIVE if p.get("permissive", True) else 0 for p in problems]
+        arr["band_padding"] = [p.get("band_padding", 1) for p in problems]
+        arr["max_cells"] = [p.get("max_cells", 0) for p in problems]
+        s.array = arr
+        return s
+
+    def subset(self, k):
+        raise NotImplementedError
+
+
 class Engine:
     """One engine context = one (device, scoring) pair, like one vg Aligner."""
 
@@ -207,6 +237,19 @@ class Engine:
         with self.pack(ps, ops_per_problem) as b:
             b.run()
             return b.fetch()
+
+    def banded_align(self, bs):
+        """vgk_banded_align over a BandedSet -> (results, ops); per-problem failures are reported in results['status']."""
+        res = np.zeros(bs.n, dtype=RESULT_DT)
+        cap = int(np.diff(bs.read_off).sum() + np.diff(bs.seq_off).sum() + 2 * len(bs.node_len) + 8 * bs.n)
+        ops = np.zeros(max(cap, 1), dtype=OP_DT)
+        written = ctypes.c_size_t()
+        self._check(self.lib.vgk_banded_align(self.h, bs.ptr, bs.n, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written)),
+                    "vgk_banded_align")
+        return res, ops[:written.value]
+
+    def banded_last(self, which):
+        return self.lib.vgk_banded_last(self.h, which)
 
 
 class Batch:

@@ -7,10 +7,12 @@
 #include <stdint.h>
 #include <string>
 #include "gssw_device.hpp"
+#include "banded_device.hpp"
 
 namespace vgk {
 
 struct FillLaunch { uint32_t K, wave_begin, wave_count; };
+struct BandedLaunch { uint32_t R, begin, count; };     // problems order[begin, begin+count) with R band rows per lane
 
 class Backend {
 public:
@@ -27,7 +29,11 @@ public:
     // gssw kernels: one fill launch per rows-per-lane instantiation (`launches`), then one traceback
     // launch over all reads; timings (ms, HIP events on the launch stream) of the last run
     virtual int   run_gssw(const GsswParams& p, const FillLaunch* launches, uint32_t n_launches, bool walk) = 0;
-    virtual double last_ms(int which) const = 0;           // 0 = fill (all launches), 1 = traceback tail, 2 = number of fill launches
+    virtual double last_ms(int which) const = 0;           // 0 = fill (all launches), 1 = traceback tail, 2 = number of fill launches,
+                                                           // 3 / 4 = banded fill / banded traceback of the last run_banded
+    // banded global alignment: one fill launch per rows-per-lane instantiation (one wavefront per problem), then one
+    // traceback launch (one thread per problem) over p.n problems
+    virtual int   run_banded(const BandedParams& p, const BandedLaunch* launches, uint32_t n_launches) = 0;
 };
 
 // returns nullptr and sets err when the device cannot be used

@@ -72,14 +72,47 @@ __global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P) {
     if (i < P.n_problems) walk_one(P, i, P.best[i]);
 }
 
+// ---- banded global alignment (banded_device.hpp): cross-lane primitives on DPP ------------------------------------
+struct XlDpp {
+    static __device__ __forceinline__ int32_t dpp_up(int32_t v)   { return __builtin_amdgcn_update_dpp(BNEG, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
+    static __device__ __forceinline__ int32_t dpp_down(int32_t v) { return __builtin_amdgcn_update_dpp(BNEG, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+    __device__ __forceinline__ int32_t up(int32_t v) const { return dpp_up(v); }
+    __device__ __forceinline__ int32_t down(int32_t v) const { return dpp_down(v); }
+    // exclusive max-scan over the 64 lanes: row_shr 1/2/4/8 inside each row of 16, then row_bcast:15 and row_bcast:31
+    __device__ __forceinline__ int32_t scan_excl(int32_t v) const {
+        v = bmax(v, __builtin_amdgcn_update_dpp(BNEG, v, 0x111, 0xf, 0xf, false));
+        v = bmax(v, __builtin_amdgcn_update_dpp(BNEG, v, 0x112, 0xf, 0xf, false));
+        v = bmax(v, __builtin_amdgcn_update_dpp(BNEG, v, 0x114, 0xf, 0xf, false));
+        v = bmax(v, __builtin_amdgcn_update_dpp(BNEG, v, 0x118, 0xf, 0xf, false));
+        v = bmax(v, __builtin_amdgcn_update_dpp(BNEG, v, 0x142, 0xa, 0xf, false));
+        v = bmax(v, __builtin_amdgcn_update_dpp(BNEG, v, 0x143, 0xc, 0xf, false));
+        return dpp_down(v);
+    }
+    __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+};
+
+template <int R>
+__global__ void __launch_bounds__(64) banded_fill_kernel(const BandedParams P, const uint32_t begin) {
+    const BProb pb = P.probs[P.order[begin + blockIdx.x]];
+    XlDpp xl;
+    banded_fill_lane<R>(P, pb, threadIdx.x, xl);
+}
+
+__global__ void __launch_bounds__(64) banded_walk_kernel(const BandedParams P) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i < P.n) banded_walk_one(P, i);
+}
+
 class HipBackend final : public Backend {
 public:
     int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipDeviceProp_t prop;
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
+    float ms_bfill = 0.f, ms_bwalk = 0.f; hipEvent_t bev[3] = {nullptr, nullptr, nullptr};
     ~HipBackend() override {
         hipSetDevice(dev);
         for (auto& e : ev) if (e) hipEventDestroy(e);
+        for (auto& e : bev) if (e) hipEventDestroy(e);
         for (int i = 0; i < 2; ++i) { if (side[i]) hipStreamDestroy(side[i]); if (side_done[i]) hipEventDestroy(side_done[i]); }
         if (stream) hipStreamDestroy(stream);
     }
@@ -151,7 +184,35 @@ public:
         pending = true;
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
+    int run_banded(const BandedParams& p, const BandedLaunch* launches, uint32_t n) override {
+        hipSetDevice(dev);
+        ms_bfill = ms_bwalk = 0.f;
+        if (p.n == 0) return VGK_OK;
+        hipEventRecord(bev[0], stream);
+        for (uint32_t i = 0; i < n; ++i) {
+            const BandedLaunch& L = launches[i];
+            if (!L.count) continue;
+            const dim3 grid(L.count), block(64);
+            switch (L.R) {
+                case 1:  hipLaunchKernelGGL((banded_fill_kernel<1>),  grid, block, 0, stream, p, L.begin); break;
+                case 2:  hipLaunchKernelGGL((banded_fill_kernel<2>),  grid, block, 0, stream, p, L.begin); break;
+                case 4:  hipLaunchKernelGGL((banded_fill_kernel<4>),  grid, block, 0, stream, p, L.begin); break;
+                case 8:  hipLaunchKernelGGL((banded_fill_kernel<8>),  grid, block, 0, stream, p, L.begin); break;
+                case 16: hipLaunchKernelGGL((banded_fill_kernel<16>), grid, block, 0, stream, p, L.begin); break;
+                default: return VGK_EINVAL;
+            }
+        }
+        hipEventRecord(bev[1], stream);
+        hipLaunchKernelGGL(banded_walk_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
+        hipEventRecord(bev[2], stream);
+        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
+        hipEventElapsedTime(&ms_bfill, bev[0], bev[1]);
+        hipEventElapsedTime(&ms_bwalk, bev[1], bev[2]);
+        return VGK_OK;
+    }
     double last_ms(int which) const override {
+        if (which == 3) return ms_bfill;
+        if (which == 4) return ms_bwalk;
         HipBackend* self = const_cast<HipBackend*>(this);
         if (self->pending) {
             hipSetDevice(dev);
@@ -178,6 +239,7 @@ Backend* make_backend(int device, std::string& err) {
     for (int i = 0; i < 2; ++i)
         if (hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&b->side_done[i], hipEventDisableTiming) != hipSuccess) { err = "cannot create HIP side stream"; delete b; return nullptr; }
+    for (auto& ev : b->bev) if (hipEventCreate(&ev) != hipSuccess) { err = "cannot create HIP event"; delete b; return nullptr; }
     for (auto& ev : b->ev) if (hipEventCreate(&ev) != hipSuccess) { err = "cannot create HIP event"; delete b; return nullptr; }
     return b;
 }

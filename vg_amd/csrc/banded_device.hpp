@@ -1,0 +1,357 @@
+// banded_device.hpp — banded global graph alignment on one wavefront per problem
+// (replaces BAMatrix::fill_matrix / traceback / traceback_over_edge of the reference's
+// src/banded_global_aligner.cpp:251-742, :756-1126, :1129-1780).
+//
+// Mapping.  The band of a node is the set of diagonals d = r - j in [top, bot] (r = read row, j = node
+// column).  Lane l of the wave owns the R consecutive band rows k = l*R .. l*R+R-1 (k = d - top), so
+//   * the match state M(r,j) = s + max(M,Ic,Ir)(r-1,j-1) reads the lane's own previous column,
+//   * the column gap Ic(r,j) (graph base against a gap) reads row k+1 of the previous column — the next
+//     register of the lane, or lane l+1 through one DPP wave_shl:1,
+//   * the row gap Ir(r,j) (read base against a gap) runs down the column: a max-plus prefix scan over
+//     the band rows (serial inside a lane, DPP row_shr / row_bcast across lanes),
+// and the whole wave walks the node's columns together, which keeps node boundaries wave-uniform.
+// Per cell one byte of traceback goes to HBM (2 bits per state: which state the optimum came from, in
+// the reference's preference order match, insert-column, insert-row :812); per node the last column of
+// the three matrices (int32) stays in HBM for the successors and for the traceback across edges.
+//
+// The same code is stepped on the CPU by tests/emu (one thread per lane, cross-lane primitives through a
+// barrier) — test infrastructure only.
+#pragma once
+#include <stdint.h>
+#include "pk16.hpp"
+#include "../../include/vgk.h"
+
+namespace vgk {
+
+constexpr int32_t BNEG = -(1 << 28);
+VGK_HD bool blive(int32_t v) { return v > BNEG / 2; }
+enum : uint32_t { BM = 0, BIC = 1, BIR = 2 };
+
+struct BNode {                 // one per graph node of a problem
+    int32_t  top, bot;         // inclusive diagonals (undefined when masked)
+    int32_t  len, cum;         // bases; shortest sequence from a source to the node's left edge (:2271-2293)
+    uint32_t seq_off;          // node bases, relative to the problem's graph_off
+    uint32_t seed_off;         // first flattened predecessor, relative to the problem's seed_base
+    uint16_t n_seeds;
+    uint8_t  as_source;        // no predecessor, or joined to a source through empty nodes (:301, :313-318)
+    uint8_t  masked;
+    uint32_t tb_off;           // bytes, relative to the problem's tb_base: len columns of Hpad bytes
+    uint32_t last_off;         // int32 elements, relative to the problem's last_base: M | Ic | Ir, Hpad each
+    uint32_t src_path_off;     // empty nodes between this node and the source it is joined to (relative to pool_base)
+    uint32_t src_path_len;
+};
+struct BSeed {                 // a non-empty, unmasked predecessor reached through path[] of empty nodes, in the LIFO
+    uint32_t node;             // order the reference pops them (:305-330, :1226-1262, :1311-1330)
+    uint32_t path_off, path_len;
+};
+struct BStart { uint32_t node; };      // candidate end nodes (non-empty), in the order the reference inserts them (:2442-2556)
+struct BProb {
+    uint32_t L, n_nodes;
+    uint32_t node_base, seed_base, pool_base, start_base, n_starts;
+    uint32_t read_off, graph_off;      // codes 0..4; qualities share read_off
+    uint32_t Hpad;                     // 64 * rows per lane
+    uint64_t tb_base, last_base;
+    uint64_t ops_off; uint32_t ops_cap;
+    uint32_t pad;
+};
+struct BResult { int32_t score; int32_t status; uint32_t start; uint32_t n_ops; uint32_t ops_begin; uint32_t pad[3]; };
+
+struct BandedParams {
+    const BProb*   probs;
+    const uint32_t* order;             // problem indices grouped by rows-per-lane class (one fill launch each)
+    uint32_t       n;                  // problems
+    const BNode*   nodes;
+    const BSeed*   seeds;
+    const uint32_t* pool;
+    const BStart*  starts;
+    const uint8_t* reads;              // codes
+    const uint8_t* quals;              // raw phred (quality-adjusted contexts only)
+    const uint8_t* graph;              // codes
+    const int8_t*  mat;                // 25, or 256*25 when quals != nullptr
+    int32_t        go, ge;
+    uint8_t*       tb;
+    int32_t*       last;
+    vgk_op*        ops;
+    BResult*       results;
+};
+
+VGK_HD int32_t bmax(int32_t a, int32_t b) { return a > b ? a : b; }
+VGK_HD int32_t bsub(const BandedParams& P, const BProb& pb, uint32_t g, int64_t r) {
+    const uint32_t rd = P.reads[pb.read_off + r];
+    return P.quals ? P.mat[25u * P.quals[pb.read_off + r] + 5u * g + rd] : P.mat[5u * g + rd];
+}
+
+// the R traceback bytes of a lane are contiguous (and R-aligned): dword stores when R >= 4
+template <int R> VGK_HD void store_codes(uint8_t* dst, const uint8_t (&codes)[R]) {
+    if (R >= 4) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+        for (int q = 0; q < R / 4; ++q)
+            d[q] = (uint32_t)codes[4 * q] | ((uint32_t)codes[4 * q + 1] << 8) | ((uint32_t)codes[4 * q + 2] << 16) | ((uint32_t)codes[4 * q + 3] << 24);
+    } else for (int i = 0; i < R; ++i) dst[i] = codes[i];
+}
+
+// ---- fill: lane code.  XL supplies the cross-lane primitives:
+//   int32 up(int32 v)        value of lane+1 (BNEG for the last lane)
+//   int32 down(int32 v)      value of lane-1 (BNEG for lane 0)
+//   int32 scan_excl(int32 v) max over lanes < this one (BNEG for lane 0)
+template <int R, class XL>
+VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, uint32_t lane, XL& xl) {
+    const int32_t go = P.go, ge = P.ge, L = (int32_t)pb.L;
+    const BNode* nodes = P.nodes + pb.node_base;
+    int32_t* last = P.last + pb.last_base;
+    uint8_t* tb = P.tb + pb.tb_base;
+    int32_t M[R], Ic[R], Ir[R];
+    for (uint32_t v = 0; v < pb.n_nodes; ++v) {
+        const BNode nd = nodes[v];
+        if (nd.masked || nd.len == 0) continue;
+        const int32_t H = nd.bot - nd.top + 1;
+        const uint8_t* seq = P.graph + pb.graph_off + nd.seq_off;
+        uint8_t* tbn = tb + nd.tb_off;
+        // ---- column 0: gather from the predecessors' last columns (:333-430) and the implied lead gaps (:433-476)
+        {
+            const uint32_t g = seq[0];
+            const int32_t hi0 = nd.bot >= L ? L - 1 : nd.bot;
+            int32_t ir0[R];
+            for (int i = 0; i < R; ++i) {
+                const int32_t k = (int32_t)lane * R + i, r = k + nd.top;
+                const bool valid = k < H && r >= 0 && r < L;
+                int32_t m = BNEG, ic = BNEG, ir = BNEG;
+                if (valid) {
+                    const int32_t ms = bsub(P, pb, g, r);
+                    for (uint32_t si = 0; si < nd.n_seeds; ++si) {
+                        const BNode sd = nodes[P.seeds[pb.seed_base + nd.seed_off + si].node];
+                        const int32_t snt = sd.top + sd.len, snb = sd.bot + sd.len;
+                        const int32_t lo = snt < 0 ? 0 : snt, hi = snb >= L ? L - 1 : snb;
+                        if (r < lo || r > hi) continue;
+                        const int32_t ext = sd.cum + sd.len;
+                        const int32_t* sl = last + sd.last_off;
+                        if (r == lo && snt <= 0) {
+                            m = bmax(m, ms - go - (ext - 1) * ge);
+                            if (snt < 0) ir = bmax(ir, -2 * go - ext * ge);
+                        } else {
+                            const int32_t ks = r - snt;
+                            m = bmax(m, ms + bmax(bmax(sl[ks], sl[2 * pb.Hpad + ks]), sl[pb.Hpad + ks]));
+                        }
+                        if (r <= snb - 1) {
+                            const int32_t ks = r - snt + 1;
+                            ic = bmax(ic, bmax(bmax(sl[ks] - go, sl[2 * pb.Hpad + ks] - go), sl[pb.Hpad + ks] - ge));
+                        }
+                    }
+                    if (nd.as_source) {
+                        if (r == 0) { m = P.quals ? bmax(m, ms) : ms; ir = bmax(ir, -2 * go); ic = bmax(ic, -2 * go); }
+                        else { m = bmax(m, ms - go - (r - 1) * ge); ic = bmax(ic, -2 * go - r * ge); }
+                        if (r == hi0) ic = BNEG;
+                    }
+                }
+                M[i] = m; Ic[i] = ic; ir0[i] = ir;
+            }
+            // row gaps down the column: Ir(r) = max(ir0(r), max_{r'<r} Y(r') - (r-1)*ge), Y(r') = max(max(M,Ic)(r') - go, ir0(r') - ge) + r'*ge
+            int32_t run = BNEG, pre[R];
+            for (int i = 0; i < R; ++i) {
+                const int32_t r = (int32_t)lane * R + i + nd.top;
+                pre[i] = run;
+                run = bmax(run, bmax(bmax(M[i], Ic[i]) - go, ir0[i] - ge) + r * ge);
+            }
+            const int32_t excl = xl.scan_excl(run);
+            int32_t upM = xl.down(M[R - 1]), upIc = xl.down(Ic[R - 1]);
+            uint8_t codes[R];
+            for (int i = 0; i < R; ++i) {
+                const int32_t k = (int32_t)lane * R + i, r = k + nd.top;
+                const bool valid = k < H && r >= 0 && r < L;
+                const int32_t scanned = bmax(excl, pre[i]) - (r - 1) * ge;
+                int32_t ir = bmax(ir0[i], scanned);
+                const uint32_t code = ir == upM - go ? BM : ir == upIc - go ? BIC : BIR;
+                if (!valid) { ir = BNEG; M[i] = BNEG; Ic[i] = BNEG; }
+                Ir[i] = ir;
+                upM = M[i]; upIc = Ic[i];
+                codes[i] = (uint8_t)(code << 2);
+            }
+            store_codes<R>(tbn + lane * R, codes);
+        }
+        // ---- the other columns (:492-590)
+        for (int32_t j = 1; j < nd.len; ++j) {
+            const uint32_t g = seq[j];
+            // row k+1 of the previous column, for the column gap
+            const int32_t nxM = xl.up(M[0]), nxIc = xl.up(Ic[0]), nxIr = xl.up(Ir[0]);
+            int32_t nM[R], nIc[R], ir0[R];
+            uint32_t code_mc[R];
+            for (int i = 0; i < R; ++i) {
+                const int32_t k = (int32_t)lane * R + i, r = k + nd.top + j;
+                const bool valid = k < H && r >= 0 && r < L;
+                const int32_t bM = i + 1 < R ? M[i + 1 < R ? i + 1 : 0] : nxM, bIc = i + 1 < R ? Ic[i + 1 < R ? i + 1 : 0] : nxIc,
+                              bIr = i + 1 < R ? Ir[i + 1 < R ? i + 1 : 0] : nxIr;
+                int32_t m = BNEG, ic = BNEG, ir = BNEG; uint32_t cm = 3, cc = 0;
+                if (valid) {
+                    const int32_t ms = bsub(P, pb, g, r);
+                    if (r == 0) {                         // implied lead gap along the top edge (:507-526)
+                        m = ms - go - (nd.cum + j - 1) * ge;
+                        if (nd.top + j < 0) ir = -2 * go - (nd.cum + j) * ge;
+                    } else {
+                        const int32_t b3 = bmax(bmax(M[i], Ic[i]), Ir[i]);
+                        m = ms + b3;
+                        cm = b3 == M[i] ? BM : b3 == Ic[i] ? BIC : BIR;
+                    }
+                    ic = bmax(bmax(bM - go, bIr - go), bIc - ge);
+                    cc = ic == bM - go ? BM : ic == bIc - ge ? BIC : BIR;
+                }
+                nM[i] = m; nIc[i] = ic; ir0[i] = ir; code_mc[i] = cm | (cc << 4);
+            }
+            int32_t run = BNEG, pre[R];
+            for (int i = 0; i < R; ++i) {
+                const int32_t r = (int32_t)lane * R + i + nd.top + j;
+                pre[i] = run;
+                run = bmax(run, bmax(bmax(nM[i], nIc[i]) - go, ir0[i] - ge) + r * ge);
+            }
+            const int32_t excl = xl.scan_excl(run);
+            int32_t upM = xl.down(nM[R - 1]), upIc = xl.down(nIc[R - 1]);
+            uint8_t codes[R];
+            for (int i = 0; i < R; ++i) {
+                const int32_t k = (int32_t)lane * R + i, r = k + nd.top + j;
+                const bool valid = k < H && r >= 0 && r < L;
+                const int32_t scanned = bmax(excl, pre[i]) - (r - 1) * ge;
+                int32_t ir = bmax(ir0[i], scanned);
+                const uint32_t cr = ir == upM - go ? BM : ir == upIc - go ? BIC : BIR;
+                if (!valid) ir = BNEG;
+                upM = nM[i]; upIc = nIc[i];
+                M[i] = nM[i]; Ic[i] = nIc[i]; Ir[i] = ir;
+                codes[i] = (uint8_t)(code_mc[i] | (cr << 2));
+            }
+            store_codes<R>(tbn + (size_t)j * pb.Hpad + lane * R, codes);
+        }
+        // ---- keep the last column for the successors and the traceback
+        int32_t* nl = last + nd.last_off;
+        for (int i = 0; i < R; ++i) {
+            const uint32_t k = lane * R + i;
+            nl[k] = M[i]; nl[pb.Hpad + k] = Ic[i]; nl[2 * pb.Hpad + k] = Ir[i];
+        }
+        xl.fence();        // successors read these through memory
+    }
+}
+
+// ---- traceback: one thread per problem (BAMatrix::traceback :756-1126, traceback_over_edge :1129-1780, BABuilder :44-205)
+struct BWalker {
+    vgk_op* end; vgk_op* cur; vgk_op* floor;      // ops are written back to front
+    bool overflow;
+};
+VGK_HD void bemit(BWalker& w, const BNode* nodes, uint32_t node, uint32_t op, uint32_t inc) {
+    if (w.cur != w.end && w.cur->node == node) {
+        if (w.cur->op == op) { w.cur->len = (uint16_t)(w.cur->len + inc); return; }
+        if (w.cur->len == 0 && nodes[node].len == 0) { w.cur->op = (uint8_t)op; w.cur->len = (uint16_t)inc; return; }   // (:69-72)
+    }
+    if (w.cur == w.floor) { w.overflow = true; return; }
+    --w.cur;
+    w.cur->node = node; w.cur->op = (uint8_t)op; w.cur->len = (uint16_t)inc; w.cur->pad = 0;
+}
+VGK_HD uint32_t bop(uint32_t mat) { return mat == BM ? VGK_OP_M : mat == BIR ? VGK_OP_I : VGK_OP_D; }
+// source state of a transition out of a predecessor's last column, in the reference's order
+VGK_HD int bpick(const int32_t* sl, uint32_t Hpad, int32_t ks, int32_t cur, int32_t dm, int32_t dc, int32_t dr) {
+    if (cur == sl[ks] + dm) return BM;
+    if (blive(sl[Hpad + ks]) && cur == sl[Hpad + ks] + dc) return BIC;
+    if (blive(sl[2 * Hpad + ks]) && cur == sl[2 * Hpad + ks] + dr) return BIR;
+    return -1;
+}
+
+VGK_HD void banded_walk_one(const BandedParams& P, uint32_t pi) {
+    const BProb pb = P.probs[pi];
+    BResult& res = P.results[pi];
+    const BNode* nodes = P.nodes + pb.node_base;
+    const int32_t* last = P.last + pb.last_base;
+    const uint8_t* tb = P.tb + pb.tb_base;
+    const int32_t go = P.go, ge = P.ge, L = (int32_t)pb.L;
+    // where the traceback starts (:2442-2556): first strictly better candidate wins, match before insert-row before insert-col
+    bool have = false; int32_t best = 0; uint32_t bnode = 0, bmat = BM, bstart = 0;
+    for (uint32_t c = 0; c < pb.n_starts; ++c) {
+        const uint32_t u = P.starts[pb.start_base + c].node;
+        const BNode n = nodes[u];
+        const int32_t k = (L - 1) - (n.len - 1) - n.top;
+        if (k < 0 || k > n.bot - n.top) continue;
+        const int32_t* nl = last + n.last_off;
+        const int32_t cand[3] = { nl[k], nl[2 * pb.Hpad + k], nl[pb.Hpad + k] };
+        const uint32_t cmat[3] = { BM, BIR, BIC };
+        for (int q = 0; q < 3; ++q) if (blive(cand[q]) && (!have || cand[q] > best)) { have = true; best = cand[q]; bnode = u; bmat = cmat[q]; bstart = c; }
+    }
+    res.start = bstart; res.n_ops = 0; res.ops_begin = 0;
+    if (!have) { res.score = 0; res.status = VGK_ENOBAND; return; }
+    res.score = best;
+    BWalker w; w.end = P.ops + pb.ops_off + pb.ops_cap; w.cur = w.end; w.floor = P.ops + pb.ops_off; w.overflow = false;
+    uint32_t node = bnode, mat = bmat; int32_t r = L - 1, j = nodes[node].len - 1, cur = best;
+    bool lead = false; int status = VGK_OK;
+    for (;;) {
+        const BNode n = nodes[node];
+        const uint8_t* seq = P.graph + pb.graph_off + n.seq_off;
+        const uint8_t* tbn = tb + n.tb_off;
+        while ((j > 0 || mat == BIR) && !lead) {
+            bemit(w, nodes, node, bop(mat), 1);
+            const uint32_t code = tbn[(size_t)j * pb.Hpad + (r - j - n.top)];
+            if (mat == BM) {
+                if (r == 0) { mat = BIC; --j; r = -1; lead = true; break; }
+                cur -= bsub(P, pb, seq[j], r);
+                mat = code & 3u; --r; --j;
+            } else if (mat == BIR) {
+                if (r == 0) { lead = true; r = -1; break; }
+                const uint32_t src = (code >> 2) & 3u;
+                cur += src == BIR ? ge : go; mat = src; --r;
+            } else {
+                const uint32_t src = (code >> 4) & 3u;
+                cur += src == BIC ? ge : go; mat = src; --j;
+            }
+        }
+        if (lead) { mat = BIC; while (j > 0) { bemit(w, nodes, node, VGK_OP_D, 1); --j; } }
+        const BSeed* seeds = P.seeds + pb.seed_base + n.seed_off;
+        const uint32_t* pool = P.pool + pb.pool_base;
+        int found = -1; uint32_t fmat = BM; bool flead = lead; int32_t ms = 0;
+        if (lead) {
+            bemit(w, nodes, node, VGK_OP_D, 1);
+            for (uint32_t si = 0; si < n.n_seeds && found < 0; ++si) {
+                const BNode s = nodes[seeds[si].node];
+                if ((int64_t)ge * (s.cum + s.len - n.cum) == 0) found = (int)si;
+            }
+            if (found < 0) {
+                if (!n.as_source) { status = VGK_EINVAL; break; }
+                for (uint32_t q = 0; q < n.src_path_len; ++q) bemit(w, nodes, pool[n.src_path_off + q], VGK_OP_D, 0);
+                break;
+            }
+        } else {
+            bemit(w, nodes, node, bop(mat), 1);
+            ms = mat == BM ? bsub(P, pb, seq[0], r) : 0;
+            for (uint32_t si = 0; si < n.n_seeds && found < 0; ++si) {
+                const BNode s = nodes[seeds[si].node];
+                const int32_t snt = s.top + s.len, snb = s.bot + s.len;
+                if (r > snb - (mat == BIC ? 1 : 0) || r < snt) continue;
+                const int32_t* sl = last + s.last_off;
+                if (mat == BM) {
+                    if (r == 0) { if (cur == -go - (s.cum + s.len - 1) * ge + ms) { found = (int)si; fmat = BIC; flead = true; } continue; }
+                    const int src = bpick(sl, pb.Hpad, r - snt, cur, ms, ms, ms);
+                    if (src >= 0) { found = (int)si; fmat = (uint32_t)src; }
+                } else {
+                    const int src = bpick(sl, pb.Hpad, r - snt + 1, cur, -go, -ge, -go);
+                    if (src >= 0) { found = (int)si; fmat = (uint32_t)src; }
+                }
+            }
+            if (found < 0) {
+                if (!n.as_source) { status = VGK_EINVAL; break; }
+                int32_t ins;
+                if (mat == BM) { if (cur != (r > 0 ? -go - (r - 1) * ge : 0) + ms) { status = VGK_EINVAL; break; } ins = r; }
+                else           { if (cur != -go - r * ge - go) { status = VGK_EINVAL; break; } ins = r + 1; }
+                for (uint32_t q = 0; q < n.src_path_len; ++q) bemit(w, nodes, pool[n.src_path_off + q], VGK_OP_D, 0);
+                const uint32_t end_node = n.src_path_len ? pool[n.src_path_off + n.src_path_len - 1] : node;
+                for (int32_t q = 0; q < ins; ++q) bemit(w, nodes, end_node, VGK_OP_I, 1);
+                break;
+            }
+        }
+        const BSeed sr = seeds[found];
+        for (uint32_t q = 0; q < sr.path_len; ++q) bemit(w, nodes, pool[sr.path_off + q], bop(mat), 0);
+        if (!lead) {        // the running score becomes the value of the predecessor's cell we step into
+            if (mat == BM) { cur -= ms; --r; }
+            else cur += fmat == BIC ? ge : go;
+            mat = fmat; lead = flead;
+        }
+        node = sr.node; j = nodes[node].len - 1;
+    }
+    if (w.overflow && status == VGK_OK) status = VGK_EOPS;
+    res.status = status;
+    res.n_ops = (uint32_t)(w.end - w.cur);
+    res.ops_begin = (uint32_t)(w.cur - (P.ops + pb.ops_off));
+}
+
+}  // namespace vgk

@@ -1,0 +1,20 @@
+// ctx.hpp — the engine context shared by the C-ABI translation units (vgk_api.cpp, banded_api.cpp).
+#pragma once
+#include <memory>
+#include <mutex>
+#include <vector>
+#include "backend.hpp"
+
+struct vgk_ctx {
+    vgk_scoring sc;
+    std::unique_ptr<vgk::Backend> be;
+    std::mutex mu;                 // one stream per context: batches on one context serialise
+    uint32_t bias = 1; int32_t max_score = 0; int32_t max_bonus = 0;
+    uint32_t prof4[6];
+    uint32_t scale = 1;            // 8 when the scaled profile bytes still fit (GsswParams::scale)
+    bool has_qa = false;           // quality-adjusted (QualAdjAligner) context
+    std::vector<int8_t> qmat, qbon;
+    // last vgk_banded_align call: kernel times (ms), band cells, algorithmic bytes
+    double banded_ms[2] = {0, 0}; uint64_t banded_cells = 0, banded_bytes = 0;
+};
+

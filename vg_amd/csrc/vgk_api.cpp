@@ -14,19 +14,9 @@
 #include <string>
 #include <vector>
 #include "backend.hpp"
+#include "ctx.hpp"
 
 using namespace vgk;
-
-struct vgk_ctx {
-    vgk_scoring sc;
-    std::unique_ptr<Backend> be;
-    std::mutex mu;                 // one stream per context: batches on one context serialise
-    uint32_t bias = 1; int32_t max_score = 0; int32_t max_bonus = 0;
-    uint32_t prof4[6];
-    uint32_t scale = 1;            // 8 when the scaled profile bytes still fit (GsswParams::scale)
-    bool has_qa = false;           // quality-adjusted (QualAdjAligner) context
-    std::vector<int8_t> qmat, qbon;
-};
 
 struct vgk_batch {
     vgk_ctx* ctx = nullptr;

@@ -128,14 +128,14 @@ GSSWAligner::PackedGraph GSSWAligner::create_packed_graph(const HandleGraph& g) 
     return create_packed_graph(g, handlealgs::lazier_topological_order(&g));
 }
 
-GSSWAligner::PackedGraph GSSWAligner::create_packed_graph(const HandleGraph& g, const std::vector<handle_t>& order) const {
+GSSWAligner::PackedGraph GSSWAligner::create_packed_graph(const HandleGraph& g, const std::vector<handle_t>& order, bool raw_sequence) const {
     PackedGraph pg;
     pg.order = order;
     std::unordered_map<handle_t, uint32_t, handle_hash> index;
     for (uint32_t i = 0; i < order.size(); ++i) index[order[i]] = i;
     pg.pred_off.push_back(0);
     for (uint32_t i = 0; i < order.size(); ++i) {
-        std::string s = nonATGCNtoN(g.get_sequence(order[i]));
+        std::string s = raw_sequence ? g.get_sequence(order[i]) : nonATGCNtoN(g.get_sequence(order[i]));
         pg.node_len.push_back((uint32_t)s.size());
         pg.seq += s;
         bool bad = false;
@@ -528,6 +528,109 @@ static void json_escape(std::ostringstream& o, const std::string& s) {
     o << '"';
     for (char c : s) { if (c == '"' || c == '\\') o << '\\'; o << c; }
     o << '"';
+}
+
+// ---- banded global alignment (src/aligner.cpp:699-760, :1189-1248) -------------------------------------------------
+void DeletionAligner::align(Alignment& aln, const HandleGraph& graph) const {
+    if (!aln.sequence.empty()) throw std::invalid_argument("error: DeletionAligner can only be used for alignments of empty strings");
+    aln.clear_path();
+    std::vector<handle_t> order = handlealgs::lazier_topological_order(&graph);
+    if (order.empty()) { aln.score = 0; return; }
+    std::unordered_map<handle_t, size_t, handle_hash> index_of;
+    for (size_t i = 0; i < order.size(); ++i) index_of[order[i]] = i;
+    // shortest distance to the left side of every node, and the sinks with the length of the walk through them (:57-113)
+    const size_t inf = std::numeric_limits<size_t>::max();
+    std::vector<size_t> dists(order.size(), inf);
+    size_t best_sink = inf, best_dist = inf;
+    for (size_t i = 0; i < order.size(); ++i) {
+        if (dists[i] == inf) dists[i] = 0;
+        size_t thru = dists[i] + graph.get_length(order[i]);
+        bool is_sink = true;
+        graph.follow_edges_v(order[i], false, [&](const handle_t& next) { size_t j = index_of.at(next); dists[j] = std::min(dists[j], thru); is_sink = false; });
+        if (is_sink && thru < best_dist) { best_dist = thru; best_sink = i; }     // the min-heap keeps the lowest (dist, sink) (:117-132, :195-205)
+    }
+    // walk back along the first predecessor that realises each distance (:140-163)
+    std::vector<handle_t> trace;
+    for (size_t at = best_sink; at != inf;) {
+        trace.push_back(order[at]);
+        size_t next = inf;
+        graph.follow_edges_v(order[at], true, [&](const handle_t& prev) {
+            size_t idx = index_of.at(prev);
+            if (next == inf && dists[idx] + graph.get_length(prev) == dists[at]) next = idx;
+        });
+        at = next;
+    }
+    int64_t total = 0;
+    for (auto it = trace.rbegin(); it != trace.rend(); ++it) {
+        aln.path.mapping.emplace_back();
+        Mapping& m = aln.path.mapping.back();
+        m.position.node_id = graph.get_id(*it); m.position.is_reverse = graph.get_is_reverse(*it);
+        Edit e; e.from_length = (int32_t)graph.get_length(*it); e.to_length = 0; m.edit.push_back(e);
+        total += e.from_length;
+    }
+    aln.score = total ? -gap_open - (int32_t)(total - 1) * gap_extension : 0;
+}
+
+void Aligner::align_global_banded(Alignment& alignment, const HandleGraph& g, int32_t band_padding, bool permissive_banding,
+                                  uint64_t max_cells) const {
+    if (alignment.sequence.empty()) {                       // (:703-706)
+        DeletionAligner(scorer->gap_open, scorer->gap_extension).align(alignment, g);
+        return;
+    }
+    // BandedGlobalAligner's constructor takes the graph in lazier_topological_order and the raw node sequences (:1976, :255)
+    PackedGraph pg = create_packed_graph(g, handlealgs::lazier_topological_order(&g), /*raw_sequence=*/true);
+    vgk_banded_problem p{};
+    p.read = alignment.sequence.c_str(); p.read_len = (uint32_t)alignment.sequence.size();
+    p.qual = quality_of(qual_adjusted, alignment.quality, alignment.sequence.size());
+    p.flags = permissive_banding ? VGK_BANDED_PERMISSIVE : 0u;
+    p.graph = pg.view(); p.band_padding = band_padding;
+    p.max_cells = max_cells == std::numeric_limits<uint64_t>::max() ? 0 : max_cells;
+    vgk_result res{};
+    std::vector<vgk_op> ops(alignment.sequence.size() + pg.seq.size() + 2 * pg.order.size() + 8);
+    size_t n_ops = 0;
+    int rc = engine->banded_align(ctx, &p, 1, &res, ops.data(), ops.size(), &n_ops);
+    if (res.status == VGK_ENOBAND) throw NoAlignmentInBandException();
+    if (res.status == VGK_ETOOBIG) throw BandMatricesTooBigException("error:[BandedGlobalAligner] band matrices exceed the limit of " + std::to_string(max_cells) + " cells");
+    if (rc != VGK_OK || res.status != VGK_OK) throw std::runtime_error(std::string("vgamd: banded global alignment failed: ") + engine->strerror(rc ? rc : res.status));
+    // BABuilder's edits (src/banded_global_aligner.cpp:102-205): one mapping per node at offset 0, matches split from
+    // mismatches by comparing the raw sequences, an empty edit on an empty node
+    alignment.clear_path();
+    alignment.score = res.score;
+    const std::string& read = alignment.sequence;
+    size_t to_pos = 0;
+    for (uint32_t i = 0; i < res.n_ops;) {
+        uint32_t node = ops[i].node, j = i;
+        while (j < res.n_ops && ops[j].node == node) ++j;
+        const handle_t h = pg.order[node];
+        const std::string node_seq = g.get_sequence(h);
+        alignment.path.mapping.emplace_back();
+        Mapping& mapping = alignment.path.mapping.back();
+        mapping.position.node_id = g.get_id(h); mapping.position.offset = 0;
+        mapping.rank = (int64_t)alignment.path.mapping.size();
+        size_t from_pos = 0;
+        for (uint32_t k = i; k < j; ++k) {
+            const size_t len = ops[k].len;
+            if (len == 0) { mapping.edit.emplace_back(); continue; }
+            switch (ops[k].op) {
+                case VGK_OP_M:
+                    for (size_t a = 0; a < len;) {
+                        const bool matching = node_seq[from_pos + a] == read[to_pos + a];
+                        size_t b = a + 1;
+                        while (b < len && (node_seq[from_pos + b] == read[to_pos + b]) == matching) ++b;
+                        Edit e; e.from_length = e.to_length = (int32_t)(b - a);
+                        if (!matching) e.sequence = read.substr(to_pos + a, b - a);
+                        mapping.edit.push_back(e);
+                        a = b;
+                    }
+                    from_pos += len; to_pos += len; break;
+                case VGK_OP_I: { Edit e; e.from_length = 0; e.to_length = (int32_t)len; e.sequence = read.substr(to_pos, len); mapping.edit.push_back(e); to_pos += len; } break;
+                case VGK_OP_D: { Edit e; e.from_length = (int32_t)len; e.to_length = 0; mapping.edit.push_back(e); from_pos += len; } break;
+                default: throw std::runtime_error("vgamd: unsupported op from the banded engine");
+            }
+        }
+        i = j;
+    }
+    alignment.identity = identity(alignment.path);
 }
 
 std::string alignment_to_json(const Alignment& a) {

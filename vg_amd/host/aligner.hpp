@@ -7,6 +7,7 @@
 #pragma once
 #include <limits>
 #include <memory>
+#include <stdexcept>
 #include <unordered_set>
 #include <vector>
 #include "alignment.hpp"
@@ -58,6 +59,26 @@ struct QualAdjAlignmentScorer : MatrixAlignmentScorer {
     static double recover_log_base(const double matrix[16], double gc_content, double tol = 1e-12);   // :30-99
 };
 
+// thrown by align_global_banded (reference: src/banded_global_aligner.hpp:31-43)
+class NoAlignmentInBandException : public std::exception {
+public:
+    const char* what() const noexcept override { return "error:[BandedGlobalAligner] cannot align to graph within band, consider permissive banding"; }
+};
+class BandMatricesTooBigException : public std::runtime_error {
+public:
+    using std::runtime_error::runtime_error;
+};
+
+// DeletionAligner (reference: src/deletion_aligner.cpp:18-25, :57-113, :201-218): the global alignment of an EMPTY read,
+// i.e. the shortest source-to-sink walk scored as one deletion.  Pure graph bookkeeping, so it stays on the host.
+class DeletionAligner {
+public:
+    DeletionAligner(int8_t gap_open, int8_t gap_extension) : gap_open(gap_open), gap_extension(gap_extension) {}
+    void align(Alignment& aln, const HandleGraph& graph) const;
+private:
+    int8_t gap_open, gap_extension;
+};
+
 class BaseAligner {
 public:
     virtual ~BaseAligner() = default;
@@ -80,7 +101,7 @@ protected:
         vgk_graph view() const;
     };
     PackedGraph create_packed_graph(const HandleGraph& g) const;
-    PackedGraph create_packed_graph(const HandleGraph& g, const std::vector<handle_t>& topological_order) const;
+    PackedGraph create_packed_graph(const HandleGraph& g, const std::vector<handle_t>& topological_order, bool raw_sequence = false) const;
     std::unordered_set<nid_t> identify_pinning_points(const HandleGraph& graph) const;   // src/aligner.cpp:87-118
 
     // gssw_mapping_to_alignment (src/aligner.cpp:120-241) over the engine's op list
@@ -125,6 +146,10 @@ public:
                       uint16_t xdrop_max_gap_length = default_xdrop_max_gap_length) const override;
     void align_pinned_multi(Alignment& alignment, std::vector<Alignment>& alt_alignments, const HandleGraph& g,
                             bool pin_left, int32_t max_alt_alns) const override;
+    // banded global alignment from any source to any sink (src/aligner.cpp:699-760, :1189-1248); throws
+    // NoAlignmentInBandException / BandMatricesTooBigException like the reference
+    void align_global_banded(Alignment& alignment, const HandleGraph& g, int32_t band_padding = 0, bool permissive_banding = true,
+                             uint64_t max_cells = std::numeric_limits<uint64_t>::max()) const;
     // two-pass seeded X-drop alignment (src/aligner.cpp:833-855 -> DozeuInterface::align, src/dozeu_interface.cpp:608-685)
     void align_xdrop(Alignment& alignment, const HandleGraph& g, const std::vector<MaximalExactMatch>& mems,
                      bool reverse_complemented, uint16_t max_gap_length = default_xdrop_max_gap_length) const;

@@ -41,6 +41,7 @@ std::shared_ptr<EngineApi> load_engine(const std::string& path) {
     bind(dl, "vgk_gssw_run", api->gssw_run);
     bind(dl, "vgk_gssw_fetch", api->gssw_fetch);
     bind(dl, "vgk_batch_free", api->batch_free);
+    bind(dl, "vgk_banded_align", api->banded_align);
     if (api->abi_version() != VGK_ABI_VERSION) throw std::runtime_error("vgamd engine: ABI version mismatch in " + p);
     return api;
 }

@@ -24,6 +24,7 @@ struct EngineApi {
     decltype(&vgk_gssw_run) gssw_run = nullptr;
     decltype(&vgk_gssw_fetch) gssw_fetch = nullptr;
     decltype(&vgk_batch_free) batch_free = nullptr;
+    decltype(&vgk_banded_align) banded_align = nullptr;
     ~EngineApi();
 };
 

@@ -60,6 +60,7 @@ static int emit(const Alignment& aln, char* out, size_t cap) {
 
 // call: 0 = align(traceback), 1 = align(score only), 2 = align_pinned, 3 = align_pinned_multi (primary only reported),
 //       4 = align_pinned(xdrop = true, max_gap = max_alt_alns argument)
+//       5 = align_global_banded(band_padding = max_alt_alns argument, permissive_banding = pin_left argument)
 int vgh_align_q(vgh_aligner* a, vgh_graph* g, const char* read, const uint8_t* qual, int call, int pin_left, int max_alt_alns,
                 char* json_out, size_t json_cap);
 int vgh_align(vgh_aligner* a, vgh_graph* g, const char* read, int call, int pin_left, int max_alt_alns,
@@ -78,6 +79,7 @@ int vgh_align_q(vgh_aligner* a, vgh_graph* g, const char* read, const uint8_t* q
             case 2: a->a->align_pinned(aln, g->g, pin_left != 0); break;
             case 3: { std::vector<Alignment> alts; a->a->align_pinned_multi(aln, alts, g->g, pin_left != 0, max_alt_alns); } break;
             case 4: a->a->align_pinned(aln, g->g, pin_left != 0, true, (uint16_t)max_alt_alns); break;
+            case 5: a->a->align_global_banded(aln, g->g, max_alt_alns, pin_left != 0); break;
             default: g_last_error = "unknown call"; return -1;
         }
         return emit(aln, json_out, json_cap);
