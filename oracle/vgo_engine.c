@@ -138,13 +138,28 @@ int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t 
                      vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
     if (!ctx || (!problems && n) || !results) return VGK_EINVAL;
     const vgk_qual_adj* qa = ctx->has_qa ? &ctx->qa : NULL;
+    /* every problem into its own scratch slot (OpenMP over problems), then compacted in order */
+    size_t* slot = (size_t*)malloc(sizeof(size_t) * ((size_t)n + 1));
+    if (!slot) return VGK_ENOMEM;
+    slot[0] = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t R = 0; for (uint32_t v = 0; v < problems[i].graph.n_nodes; ++v) R += problems[i].graph.node_len[v];
+        slot[i + 1] = slot[i] + problems[i].read_len + R + 2u * problems[i].graph.n_nodes + 8;
+    }
+    vgk_op* scratch = (vgk_op*)malloc(sizeof(vgk_op) * (slot[n] + 1));
+    if (!scratch) { free(slot); return VGK_ENOMEM; }
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (uint32_t i = 0; i < n; ++i)
+        vgo_banded_align(&ctx->sc, qa, &problems[i], &results[i], scratch + slot[i], (uint32_t)(slot[i + 1] - slot[i]));
     size_t used = 0; int rc = VGK_OK;
     for (uint32_t i = 0; i < n; ++i) {
-        size_t room = ops_cap - used;
-        vgo_banded_align(&ctx->sc, qa, &problems[i], &results[i], ops ? ops + used : NULL, room > 0xffffffffu ? 0xffffffffu : (uint32_t)room);
-        if (results[i].status == VGK_EOPS) rc = VGK_EOPS;
+        if (results[i].status == VGK_OK) {
+            if (!ops || used + results[i].n_ops > ops_cap) { results[i].status = VGK_EOPS; results[i].n_ops = 0; rc = VGK_EOPS; }
+            else memcpy(ops + used, scratch + slot[i], sizeof(vgk_op) * results[i].n_ops);
+        }
         results[i].ops_begin = (uint32_t)used; used += results[i].n_ops;
     }
+    free(scratch); free(slot);
     if (ops_written) *ops_written = used;
     return rc;
 }

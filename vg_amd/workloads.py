@@ -117,6 +117,34 @@ class LinearWorkload:
         return int((self.R * self.read_len).sum())
 
 
+def build_variation_graph(rng, graph_bp, snp_every, indel_every):
+    """24-32 bp chain nodes, SNP bubbles (two 1-bp alternatives) and insertion bubbles; nodes come out in topological order."""
+    seqs, preds, kind = [], [], []           # kind: 0 chain, 1 snp alt, 2 insertion
+    pos = 0
+    last_chain = -1
+    while pos < graph_bp:
+        ln = int(rng.integers(24, 33))
+        seqs.append(ACGT[rng.integers(0, 4, ln)]); kind.append(0)
+        v = len(seqs) - 1
+        if last_chain < 0:
+            preds.append([])
+        else:
+            preds.append(list(pending))
+        pending = [v]
+        pos += ln
+        r = rng.random()
+        if r < ln / snp_every:                       # SNP bubble after this chain node
+            a = len(seqs); seqs.append(ACGT[rng.integers(0, 4, 1)]); kind.append(1); preds.append([v])
+            b = len(seqs); seqs.append(ACGT[rng.integers(0, 4, 1)]); kind.append(1); preds.append([v])
+            pending = [a, b]; pos += 1
+        elif r < ln / snp_every + ln / indel_every:  # insertion: v -> ins -> next, and v -> next
+            k = int(rng.integers(1, 21))
+            a = len(seqs); seqs.append(ACGT[rng.integers(0, 4, k)]); kind.append(2); preds.append([v])
+            pending = [v, a]
+        last_chain = v
+    return seqs, preds, kind
+
+
 class TailWorkload:
     """config 3 stand-in: giraffe-style tail alignments (pinned X-drop) on a variation graph.
 
@@ -131,30 +159,7 @@ class TailWorkload:
     def __init__(self, n_reads, seed=77, graph_bp=2_000_000, snp_every=100, indel_every=1000, max_tail=121,
                  flags=capi.VGK_XDROP_PINNED | capi.VGK_GSSW_TRACEBACK):
         rng = np.random.default_rng(seed)
-        # ---- global graph -------------------------------------------------------------------------
-        seqs, preds, kind = [], [], []           # kind: 0 chain, 1 snp alt, 2 insertion
-        pos = 0
-        last_chain = -1
-        while pos < graph_bp:
-            ln = int(rng.integers(24, 33))
-            seqs.append(ACGT[rng.integers(0, 4, ln)]); kind.append(0)
-            v = len(seqs) - 1
-            if last_chain < 0:
-                preds.append([])
-            else:
-                preds.append(list(pending))
-            pending = [v]
-            pos += ln
-            r = rng.random()
-            if r < ln / snp_every:                       # SNP bubble after this chain node
-                a = len(seqs); seqs.append(ACGT[rng.integers(0, 4, 1)]); kind.append(1); preds.append([v])
-                b = len(seqs); seqs.append(ACGT[rng.integers(0, 4, 1)]); kind.append(1); preds.append([v])
-                pending = [a, b]; pos += 1
-            elif r < ln / snp_every + ln / indel_every:  # insertion: v -> ins -> next, and v -> next
-                k = int(rng.integers(1, 21))
-                a = len(seqs); seqs.append(ACGT[rng.integers(0, 4, k)]); kind.append(2); preds.append([v])
-                pending = [v, a]
-            last_chain = v
+        seqs, preds, kind = build_variation_graph(rng, graph_bp, snp_every, indel_every)
         self.g_seq = np.concatenate(seqs)
         g_len = np.array([len(s) for s in seqs], dtype=np.uint32)
         g_off = np.concatenate([[0], np.cumsum(g_len)]).astype(np.int64)
@@ -211,3 +216,61 @@ class TailWorkload:
 
     def cells(self):
         return int(((np.diff(self.ps.read_off) + 1) * np.diff(self.ps.seq_off)).sum())
+
+
+class BandedWorkload:
+    """config 5 stand-in: the "middle" connections of long-read chaining — a global alignment between two anchors with
+    BandedGlobalAligner (src/minimizer_mapper_from_chains.cpp:3773).  Each problem is a window of the variation graph from
+    one chain node to another, 30..max_len bp long (giraffe's hifi preset connects anchors up to 233 bp apart and allows
+    500 bp gaps, src/subcommand/giraffe_main.cpp:996-1000); the read is a source-to-sink walk through the window with HiFi-like
+    errors (0.5 % substitutions, 0.3 % indels); band padding = floor(sqrt(L)) + 1 (algorithms::pad_band_random_walk's
+    defaults, src/algorithms/pad_band.hpp:21-23), permissive banding as the caller asks."""
+
+    def __init__(self, n_reads, seed=99, graph_bp=1_000_000, snp_every=100, indel_every=1000, max_len=500):
+        rng = np.random.default_rng(seed)
+        seqs, preds, kind = build_variation_graph(rng, graph_bp, snp_every, indel_every)
+        g_len = np.array([len(s) for s in seqs], dtype=np.int64)
+        kind = np.array(kind)
+        succ = [[] for _ in seqs]
+        for v, pr in enumerate(preds):
+            for p in pr:
+                succ[p].append(v)
+        chain_idx = np.nonzero(kind == 0)[0]
+        chain_idx = chain_idx[chain_idx < len(seqs) - 64]
+        target = rng.integers(30, max_len + 1, n_reads)
+        starts = chain_idx[rng.integers(0, len(chain_idx), n_reads)]
+        problems = []
+        for i in range(n_reads):
+            a = int(starts[i]); v = a; bp = 0
+            while bp < target[i] and v < len(seqs) - 2:
+                if kind[v] != 1 or kind[v - 1] != 1:
+                    bp += int(g_len[v])
+                v += 1
+            while kind[v] != 0:
+                v += 1
+            b = v + 1                                      # window = nodes [a, b), ends on a chain node: one source, one sink
+            nodes = [seqs[u].tobytes().decode() for u in range(a, b)]
+            pr = [[p - a for p in preds[u] if p >= a] for u in range(a, b)]
+            out = []; u = a
+            while True:
+                out.extend(seqs[u].tolist())
+                nx = [w for w in succ[u] if w < b]
+                if not nx:
+                    break
+                u = nx[int(rng.integers(0, len(nx)))]
+            read = []
+            for c in out:
+                r = rng.random()
+                if r < 0.005:
+                    read.append(int(ACGT[rng.integers(0, 4)]))
+                elif r < 0.0065:
+                    continue
+                elif r < 0.008:
+                    read.append(int(ACGT[rng.integers(0, 4)])); read.append(c)
+                else:
+                    read.append(c)
+            read = bytes(read).decode() if read else "A"
+            problems.append(dict(read=read, nodes=nodes, preds=pr, band_padding=int(np.sqrt(len(read))) + 1, permissive=True))
+        self.problems = problems
+        self.bs = capi.BandedSet.from_lists(problems)
+        self.n = n_reads
