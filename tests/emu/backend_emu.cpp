@@ -33,12 +33,16 @@ struct XlEmu {
     int32_t scan_excl(int32_t v) { return exchange(v, 2); }
     void fence() { pthread_barrier_wait(&sh->bar); }
 };
-template <int R> static void banded_fill_emu(const BandedParams& P, uint32_t begin, uint32_t count) {
+template <int R, bool QA> static void banded_fill_emu(const BandedParams& P, uint32_t begin, uint32_t count) {
     XlShared sh; pthread_barrier_init(&sh.bar, nullptr, 64);
     std::vector<std::thread> ts;
     for (uint32_t lane = 0; lane < 64; ++lane) ts.emplace_back([&, lane]() {
         XlEmu xl{&sh, lane};
-        for (uint32_t i = 0; i < count; ++i) { const BProb pb = P.probs[P.order[begin + i]]; banded_fill_lane<R>(P, pb, lane, xl); xl.fence(); }
+        for (uint32_t i = 0; i < count; ++i) {
+            const BProb pb = P.probs[P.order[begin + i]];
+            BSrc src; src.rd = P.reads + pb.read_off; src.q = QA ? P.quals + pb.read_off : nullptr; src.graph = P.graph + pb.graph_off; src.mat = P.mat;
+            banded_fill_lane<R, QA>(P, pb, src, lane, xl); xl.fence();
+        }
     });
     for (auto& t : ts) t.join();
     pthread_barrier_destroy(&sh.bar);
@@ -50,11 +54,11 @@ public:
         for (uint32_t i = 0; i < n; ++i) {
             const BandedLaunch& L = launches[i];
             switch (L.R) {
-                case 1: banded_fill_emu<1>(P, L.begin, L.count); break;
-                case 2: banded_fill_emu<2>(P, L.begin, L.count); break;
-                case 4: banded_fill_emu<4>(P, L.begin, L.count); break;
-                case 8: banded_fill_emu<8>(P, L.begin, L.count); break;
-                case 16: banded_fill_emu<16>(P, L.begin, L.count); break;
+                case 1: if (P.quals) banded_fill_emu<1, true>(P, L.begin, L.count); else banded_fill_emu<1, false>(P, L.begin, L.count); break;
+                case 2: if (P.quals) banded_fill_emu<2, true>(P, L.begin, L.count); else banded_fill_emu<2, false>(P, L.begin, L.count); break;
+                case 4: if (P.quals) banded_fill_emu<4, true>(P, L.begin, L.count); else banded_fill_emu<4, false>(P, L.begin, L.count); break;
+                case 8: if (P.quals) banded_fill_emu<8, true>(P, L.begin, L.count); else banded_fill_emu<8, false>(P, L.begin, L.count); break;
+                case 16: if (P.quals) banded_fill_emu<16, true>(P, L.begin, L.count); else banded_fill_emu<16, false>(P, L.begin, L.count); break;
                 default: return VGK_EINVAL;
             }
         }

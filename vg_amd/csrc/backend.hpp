@@ -12,7 +12,8 @@
 namespace vgk {
 
 struct FillLaunch { uint32_t K, wave_begin, wave_count; };
-struct BandedLaunch { uint32_t R, begin, count; };     // problems order[begin, begin+count) with R band rows per lane
+struct BandedLaunch { uint32_t R, begin, count, lds_bytes; };     // problems order[begin, begin+count) with R band rows per lane;
+                                                                  // lds_bytes = LDS staging area the largest of them needs (0: read from HBM)
 
 class Backend {
 public:

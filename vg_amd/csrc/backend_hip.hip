@@ -91,11 +91,38 @@ struct XlDpp {
     __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 };
 
-template <int R>
+template <int R, bool QA, bool LDS>
 __global__ void __launch_bounds__(64) banded_fill_kernel(const BandedParams P, const uint32_t begin) {
+    extern __shared__ uint8_t smem[];
     const BProb pb = P.probs[P.order[begin + blockIdx.x]];
+    BSrc src;
+    if (LDS) {       // stage what every column reads — score table, read, qualities, graph bases — into LDS once
+        constexpr uint32_t MAT = QA ? 6400u : 32u;
+        int8_t* smat = reinterpret_cast<int8_t*>(smem);
+        uint8_t* srd = smem + MAT; uint8_t* sq = srd + pb.L; uint8_t* sg = QA ? sq + pb.L : sq;
+        for (uint32_t i = threadIdx.x; i < (QA ? 6400u : 25u); i += 64) smat[i] = P.mat[i];
+        for (uint32_t i = threadIdx.x; i < pb.L; i += 64) { srd[i] = P.reads[pb.read_off + i]; if (QA) sq[i] = P.quals[pb.read_off + i]; }
+        for (uint32_t i = threadIdx.x; i < pb.graph_len; i += 64) sg[i] = P.graph[pb.graph_off + i];
+        __syncthreads();
+        src.rd = srd; src.q = sq; src.graph = sg; src.mat = smat;
+    } else {
+        src.rd = P.reads + pb.read_off; src.q = QA ? P.quals + pb.read_off : nullptr; src.graph = P.graph + pb.graph_off; src.mat = P.mat;
+    }
     XlDpp xl;
-    banded_fill_lane<R>(P, pb, threadIdx.x, xl);
+    banded_fill_lane<R, QA>(P, pb, src, threadIdx.x, xl);
+}
+
+template <int R>
+static void launch_banded_fill(const BandedParams& p, const BandedLaunch& L, hipStream_t stream) {
+    const dim3 grid(L.count), block(64);
+    const bool qa = p.quals != nullptr;
+    if (L.lds_bytes) {
+        if (qa) hipLaunchKernelGGL((banded_fill_kernel<R, true, true>), grid, block, L.lds_bytes, stream, p, L.begin);
+        else    hipLaunchKernelGGL((banded_fill_kernel<R, false, true>), grid, block, L.lds_bytes, stream, p, L.begin);
+    } else {
+        if (qa) hipLaunchKernelGGL((banded_fill_kernel<R, true, false>), grid, block, 0, stream, p, L.begin);
+        else    hipLaunchKernelGGL((banded_fill_kernel<R, false, false>), grid, block, 0, stream, p, L.begin);
+    }
 }
 
 __global__ void __launch_bounds__(64) banded_walk_kernel(const BandedParams P) {
@@ -192,13 +219,12 @@ public:
         for (uint32_t i = 0; i < n; ++i) {
             const BandedLaunch& L = launches[i];
             if (!L.count) continue;
-            const dim3 grid(L.count), block(64);
             switch (L.R) {
-                case 1:  hipLaunchKernelGGL((banded_fill_kernel<1>),  grid, block, 0, stream, p, L.begin); break;
-                case 2:  hipLaunchKernelGGL((banded_fill_kernel<2>),  grid, block, 0, stream, p, L.begin); break;
-                case 4:  hipLaunchKernelGGL((banded_fill_kernel<4>),  grid, block, 0, stream, p, L.begin); break;
-                case 8:  hipLaunchKernelGGL((banded_fill_kernel<8>),  grid, block, 0, stream, p, L.begin); break;
-                case 16: hipLaunchKernelGGL((banded_fill_kernel<16>), grid, block, 0, stream, p, L.begin); break;
+                case 1:  launch_banded_fill<1>(p, L, stream); break;
+                case 2:  launch_banded_fill<2>(p, L, stream); break;
+                case 4:  launch_banded_fill<4>(p, L, stream); break;
+                case 8:  launch_banded_fill<8>(p, L, stream); break;
+                case 16: launch_banded_fill<16>(p, L, stream); break;
                 default: return VGK_EINVAL;
             }
         }

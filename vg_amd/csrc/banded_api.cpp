@@ -5,11 +5,20 @@
 // sequences, one BAMatrix per node with its seed pointers) becomes flat tables for the wavefront
 // kernels in banded_device.hpp; the predecessor lists are flattened here, once, in the LIFO order the
 // reference's fill and traceback pop them, with the empty nodes each one is reached through.
+//
+// A batch is prepared in three passes: (1) per-problem geometry and tables, in parallel over host
+// threads; (2) prefix sums that place every problem in the shared arenas and cut the batch into
+// sub-batches that fit the device budget; (3) parallel copy into the arenas.  Device scratch (traceback
+// bytes, last columns, op slots) is cached on the context between calls.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 #include "ctx.hpp"
 
@@ -22,39 +31,56 @@ inline uint8_t nt_code(char ch) {      // gssw_create_nt_table: case-insensitive
                   case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
 }
 
-struct HostProblem {                   // what the host keeps of a problem until the results come back
+struct Span { uint64_t off = 0; uint32_t len = 0; };
+struct Prep {                          // one problem after pass 1; its tables live in the preparing thread's Store
     int status = VGK_OK;
     bool on_device = false;
-    std::vector<std::vector<uint32_t>> start_prefix;   // per start candidate: empty sink-side nodes, sink first (:2455-2480)
-    bool have_empty_walk = false;                       // a source-to-sink chain of empty nodes (:2464-2472)
-    std::vector<uint32_t> empty_walk;                   // sink first
-    uint32_t R = 1;
-    uint64_t cells = 0;
+    uint32_t R = 1, Hpad = 64, thread = 0;
+    uint64_t cells = 0, bases = 0, tb_bytes = 0, last_elems = 0;
+    uint32_t ops_cap = 0;
+    Span nodes, seeds, pool, starts;   // starts: candidate end nodes; start_prefix[k] = the empty sink-side nodes of candidate k, sink first (:2455-2480)
+    bool have_empty_walk = false;      // a source-to-sink chain of empty nodes (:2464-2472)
+    Span empty_walk;                   // in Store::prefix, sink first
+    uint32_t arena = 0;                // index inside its sub-batch
+    uint32_t need = 0;                 // ops this problem hands back
+    bool use_empty_walk = false;
+};
+struct Store {                         // per-thread flat tables of pass 1
+    std::vector<BNode> nodes; std::vector<BSeed> seeds; std::vector<uint32_t> pool, starts, prefix;
+    std::vector<Span> start_prefix;    // parallel to starts
 };
 
-struct Arena {
-    std::vector<BProb> probs; std::vector<BNode> nodes; std::vector<BSeed> seeds; std::vector<uint32_t> pool;
-    std::vector<BStart> starts; std::vector<uint8_t> reads, quals, graph;
-    uint64_t tb_bytes = 0, last_elems = 0, ops_total = 0;
-    std::vector<uint32_t> owner;       // arena problem -> index into the caller's array
+struct Scratch {                       // per-thread reusable buffers of pass 1
+    std::vector<int64_t> len, shortest, longest, top, bot, cum;
+    std::vector<uint8_t> masked;
+    std::vector<uint32_t> succ_off, succ, fill;
+    struct Item { uint32_t node, path_off, path_len; };
+    std::vector<Item> stack;
+    std::vector<int64_t> st; std::vector<uint32_t> path;
 };
 
 // Band geometry of one problem (find_banded_paths :2174-2268, path_lengths_to_sinks :2122-2170, shortest_seq_paths :2271-2293)
-// and the tables the kernels need.  Returns the per-problem status; appends to the arena only when the problem runs.
-int prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, HostProblem& hp, Arena& A) {
+// and the tables the kernels need.
+void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch& S, Store& T) {
     const vgk_graph& g = p.graph;
     const uint32_t N = g.n_nodes; const int64_t L = p.read_len;
-    if (!N || !L || !p.read || !g.node_len || !g.pred_off || (!g.seq && N)) return VGK_EINVAL;
-    if (ctx->has_qa && !p.qual) return VGK_EINVAL;
-    for (uint32_t v = 0; v < N; ++v) for (uint32_t e = g.pred_off[v]; e < g.pred_off[v + 1]; ++e) if (g.pred_idx[e] >= v) return VGK_EINVAL;
-    std::vector<std::vector<uint32_t>> succ(N);
-    for (uint32_t v = 0; v < N; ++v) for (uint32_t e = g.pred_off[v]; e < g.pred_off[v + 1]; ++e) succ[g.pred_idx[e]].push_back(v);
-    auto is_source = [&](uint32_t v) { return g.pred_off[v] == g.pred_off[v + 1]; };
+    if (!N || !L || !p.read || !g.node_len || !g.pred_off || !g.seq || (ctx->has_qa && !p.qual)) { hp.status = VGK_EINVAL; return; }
+    for (uint32_t v = 0; v < N; ++v) for (uint32_t e = g.pred_off[v]; e < g.pred_off[v + 1]; ++e) if (g.pred_idx[e] >= v) { hp.status = VGK_EINVAL; return; }
     const int64_t inf = std::numeric_limits<int64_t>::max();
-    std::vector<int64_t> len(N), shortest(N), longest(N, 0), top(N, inf), bot(N, std::numeric_limits<int64_t>::min()), cum(N);
-    std::vector<uint8_t> masked(N, 0);
+    S.succ_off.assign(N + 1, 0);
+    for (uint32_t v = 0; v < N; ++v) for (uint32_t e = g.pred_off[v]; e < g.pred_off[v + 1]; ++e) ++S.succ_off[g.pred_idx[e] + 1];
+    for (uint32_t v = 0; v < N; ++v) S.succ_off[v + 1] += S.succ_off[v];
+    S.succ.resize(S.succ_off[N] + 1);
+    S.fill.assign(S.succ_off.begin(), S.succ_off.end() - 1);
+    for (uint32_t v = 0; v < N; ++v) for (uint32_t e = g.pred_off[v]; e < g.pred_off[v + 1]; ++e) S.succ[S.fill[g.pred_idx[e]]++] = v;
+    auto is_source = [&](uint32_t v) { return g.pred_off[v] == g.pred_off[v + 1]; };
+    auto is_sink = [&](uint32_t v) { return S.succ_off[v] == S.succ_off[v + 1]; };
+    S.len.resize(N); S.shortest.resize(N); S.longest.assign(N, 0); S.top.assign(N, inf); S.bot.assign(N, std::numeric_limits<int64_t>::min());
+    S.cum.resize(N); S.masked.assign(N, 0);
+    auto &len = S.len, &shortest = S.shortest, &longest = S.longest, &top = S.top, &bot = S.bot, &cum = S.cum; auto& masked = S.masked;
     uint64_t total_bases = 0;
-    for (uint32_t v = 0; v < N; ++v) { len[v] = g.node_len[v]; total_bases += g.node_len[v]; shortest[v] = succ[v].empty() ? 0 : inf; }
+    for (uint32_t v = 0; v < N; ++v) { len[v] = g.node_len[v]; total_bases += g.node_len[v]; shortest[v] = is_sink(v) ? 0 : inf; }
+    hp.bases = total_bases;
     for (uint32_t v = N; v-- > 0;)
         for (uint32_t e = g.pred_off[v]; e < g.pred_off[v + 1]; ++e) {
             const uint32_t u = g.pred_idx[e];
@@ -73,165 +99,145 @@ int prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, HostProblem& hp, Ar
         if (top[v] > bot[v]) { masked[v] = 1; continue; }                  // no unmasked walk reaches it
         const int64_t et = top[v] + len[v], eb = bot[v] + len[v];
         if (et + shortest[v] > L || eb + longest[v] < L) { masked[v] = 1; continue; }
-        for (uint32_t w : succ[v]) { top[w] = std::min(top[w], et); bot[w] = std::max(bot[w], eb); }
+        for (uint32_t e = S.succ_off[v]; e < S.succ_off[v + 1]; ++e) { const uint32_t w = S.succ[e]; top[w] = std::min(top[w], et); bot[w] = std::max(bot[w], eb); }
         cells += (uint64_t)(bot[v] - top[v] + 1) * (uint64_t)len[v];
         if (len[v]) max_h = std::max(max_h, bot[v] - top[v] + 1);
     }
     hp.cells = cells;
-    if (p.max_cells && cells > p.max_cells) return VGK_ETOOBIG;
+    if (p.max_cells && cells > p.max_cells) { hp.status = VGK_ETOOBIG; return; }
     for (uint32_t v = 0; v < N; ++v) cum[v] = is_source(v) ? 0 : inf;
-    for (uint32_t v = 0; v < N; ++v) for (uint32_t w : succ[v]) cum[w] = std::min(cum[w], cum[v] + len[v]);
+    for (uint32_t v = 0; v < N; ++v) {
+        if (cum[v] == inf) continue;
+        for (uint32_t e = S.succ_off[v]; e < S.succ_off[v + 1]; ++e) cum[S.succ[e]] = std::min(cum[S.succ[e]], cum[v] + len[v]);
+    }
     if (!permissive) {
         bool any = false;
-        for (uint32_t v = 0; v < N; ++v) if (succ[v].empty() && !masked[v]) any = true;
-        if (!any) return VGK_ENOBAND;
+        for (uint32_t v = 0; v < N; ++v) if (is_sink(v) && !masked[v]) any = true;
+        if (!any) { hp.status = VGK_ENOBAND; return; }
     }
     uint32_t R = 1; while ((int64_t)R * 64 < max_h) R *= 2;
-    if (R > 16 || L > (1 << 24) || total_bases > (1u << 24)) return VGK_ETOOBIG;       // engine limit: bands up to 1024 diagonals
-    hp.R = R;
-    const uint32_t Hpad = 64 * R;
+    if (R > 16 || L > (1 << 24) || total_bases > (1u << 24)) { hp.status = VGK_ETOOBIG; return; }      // engine limit: bands up to 1024 diagonals
+    hp.R = R; hp.Hpad = 64 * R;
+    const uint32_t Hpad = hp.Hpad;
 
-    BProb pb{};
-    pb.L = (uint32_t)L; pb.n_nodes = N; pb.Hpad = Hpad;
-    pb.node_base = (uint32_t)A.nodes.size(); pb.seed_base = (uint32_t)A.seeds.size(); pb.pool_base = (uint32_t)A.pool.size();
-    pb.start_base = (uint32_t)A.starts.size(); pb.read_off = (uint32_t)A.reads.size(); pb.graph_off = (uint32_t)A.graph.size();
-    pb.tb_base = A.tb_bytes; pb.last_base = A.last_elems;
-    if (A.nodes.size() + N > 0xfffffff0u || A.reads.size() + (uint64_t)L > 0xfffffff0u || A.graph.size() + total_bases > 0xfffffff0u) return VGK_ETOOBIG;
-
-    // flattened predecessor lists
-    const size_t keep_nodes = A.nodes.size(), keep_seeds = A.seeds.size();
-    auto fail = [&](int code) { A.nodes.resize(keep_nodes); A.seeds.resize(keep_seeds); return code; };
+    // node records with the flattened predecessor lists
     uint64_t tb_off = 0, last_off = 0; uint32_t seq_off = 0;
-    std::vector<uint32_t> pool_local;       // relative to pool_base; slot 0.. hold paths
-    struct Item { uint32_t node, path_off, path_len; };
-    std::vector<Item> stack;
+    int64_t prev_filled = -1;              // the node the wave will have in its registers when it reaches v
+    const size_t keep_nodes = T.nodes.size(), keep_seeds = T.seeds.size(), keep_pool = T.pool.size();
+    auto fail = [&](int code) { T.nodes.resize(keep_nodes); T.seeds.resize(keep_seeds); T.pool.resize(keep_pool); hp.status = code; };
+    T.nodes.resize(keep_nodes + N);
     for (uint32_t v = 0; v < N; ++v) {
         BNode nd{};
         nd.top = masked[v] ? 0 : (int32_t)top[v]; nd.bot = masked[v] ? -1 : (int32_t)bot[v];
         nd.len = (int32_t)len[v]; nd.cum = masked[v] || cum[v] == inf ? 0 : (int32_t)cum[v];
         nd.seq_off = seq_off; seq_off += (uint32_t)len[v];
         nd.masked = masked[v];
-        nd.seed_off = (uint32_t)(A.seeds.size() - pb.seed_base);
+        nd.seed_off = (uint32_t)(T.seeds.size() - keep_seeds);
         if (!masked[v] && len[v]) {
             nd.as_source = is_source(v);
-            stack.clear();
-            for (uint32_t e = g.pred_off[v]; e < g.pred_off[v + 1]; ++e) stack.push_back({g.pred_idx[e], 0, 0});
+            S.stack.clear();
+            for (uint32_t e = g.pred_off[v]; e < g.pred_off[v + 1]; ++e) S.stack.push_back({g.pred_idx[e], 0, 0});
             uint32_t n_seeds = 0;
-            while (!stack.empty()) {
-                const Item it = stack.back(); stack.pop_back();
+            while (!S.stack.empty()) {
+                const Scratch::Item it = S.stack.back(); S.stack.pop_back();
                 if (masked[it.node]) continue;
                 if (len[it.node] == 0) {
-                    const uint32_t noff = (uint32_t)pool_local.size();
-                    for (uint32_t q = 0; q < it.path_len; ++q) pool_local.push_back(pool_local[it.path_off + q]);
-                    pool_local.push_back(it.node);
+                    const uint32_t noff = (uint32_t)(T.pool.size() - keep_pool);
+                    for (uint32_t q = 0; q < it.path_len; ++q) T.pool.push_back(T.pool[keep_pool + it.path_off + q]);
+                    T.pool.push_back(it.node);
                     if (is_source(it.node)) { nd.as_source = 1; nd.src_path_off = noff; nd.src_path_len = it.path_len + 1; }
-                    for (uint32_t e = g.pred_off[it.node]; e < g.pred_off[it.node + 1]; ++e) stack.push_back({g.pred_idx[e], noff, it.path_len + 1});
+                    for (uint32_t e = g.pred_off[it.node]; e < g.pred_off[it.node + 1]; ++e) S.stack.push_back({g.pred_idx[e], noff, it.path_len + 1});
                     continue;
                 }
-                A.seeds.push_back({it.node, it.path_off, it.path_len}); ++n_seeds;
+                T.seeds.push_back({it.node, it.path_off, it.path_len}); ++n_seeds;
             }
-            if (n_seeds > 0xffff) return fail(VGK_ETOOBIG);
+            if (n_seeds > 0xffff) { fail(VGK_ETOOBIG); return; }
             nd.n_seeds = (uint16_t)n_seeds;
+            if (n_seeds == 1 && !nd.as_source) {
+                const BSeed& sd = T.seeds.back();
+                nd.chain = sd.path_len == 0 && (int64_t)sd.node == prev_filled && top[v] == top[sd.node] + len[sd.node] && bot[v] == bot[sd.node] + len[sd.node];
+            }
+            prev_filled = v;
             nd.tb_off = (uint32_t)tb_off; nd.last_off = (uint32_t)last_off;
             tb_off += (uint64_t)len[v] * Hpad; last_off += 3ull * Hpad;
-            if (tb_off > 0xfffffff0ull) return fail(VGK_ETOOBIG);
+            if (tb_off > 0xfffffff0ull) { fail(VGK_ETOOBIG); return; }
         }
-        A.nodes.push_back(nd);
+        T.nodes[keep_nodes + v] = nd;
     }
-    A.pool.insert(A.pool.end(), pool_local.begin(), pool_local.end());
+    hp.nodes = {keep_nodes, N}; hp.seeds = {keep_seeds, (uint32_t)(T.seeds.size() - keep_seeds)}; hp.pool = {keep_pool, (uint32_t)(T.pool.size() - keep_pool)};
+    hp.starts.off = T.starts.size();
     // where a traceback may start (:2442-2556): every sink in topological order (PARITY-UNPINNED: the reference iterates an
     // unordered_set of matrix pointers), looking through empty sinks to their predecessors depth-first, last predecessor first
-    {
-        std::vector<int64_t> st; std::vector<uint32_t> path;
-        for (uint32_t v = 0; v < N; ++v) {
-            if (!succ[v].empty() || masked[v]) continue;
-            st.assign(1, v); path.clear();
-            while (!st.empty()) {
-                const int64_t u = st.back(); st.pop_back();
-                if (u < 0) { path.pop_back(); continue; }
-                if (masked[u]) continue;
-                if (len[u] == 0) {
-                    path.push_back((uint32_t)u); st.push_back(-1);
-                    if (is_source((uint32_t)u)) { if (!hp.have_empty_walk) { hp.have_empty_walk = true; hp.empty_walk = path; } continue; }
-                    for (uint32_t e = g.pred_off[u]; e < g.pred_off[u + 1]; ++e) st.push_back(g.pred_idx[e]);
+    for (uint32_t v = 0; v < N; ++v) {
+        if (!is_sink(v) || masked[v]) continue;
+        S.st.assign(1, v); S.path.clear();
+        while (!S.st.empty()) {
+            const int64_t u = S.st.back(); S.st.pop_back();
+            if (u < 0) { S.path.pop_back(); continue; }
+            if (masked[u]) continue;
+            if (len[u] == 0) {
+                S.path.push_back((uint32_t)u); S.st.push_back(-1);
+                if (is_source((uint32_t)u)) {
+                    if (!hp.have_empty_walk) { hp.have_empty_walk = true; hp.empty_walk = {T.prefix.size(), (uint32_t)S.path.size()}; T.prefix.insert(T.prefix.end(), S.path.begin(), S.path.end()); }
                     continue;
                 }
-                A.starts.push_back({(uint32_t)u}); hp.start_prefix.push_back(path);
+                for (uint32_t e = g.pred_off[u]; e < g.pred_off[u + 1]; ++e) S.st.push_back(g.pred_idx[e]);
+                continue;
             }
+            T.starts.push_back((uint32_t)u); T.start_prefix.push_back({T.prefix.size(), (uint32_t)S.path.size()});
+            T.prefix.insert(T.prefix.end(), S.path.begin(), S.path.end());
         }
     }
-    pb.n_starts = (uint32_t)(A.starts.size() - pb.start_base);
-    for (int64_t i = 0; i < L; ++i) A.reads.push_back(nt_code(p.read[i]));
-    if (ctx->has_qa) A.quals.insert(A.quals.end(), p.qual, p.qual + L);
-    for (uint64_t i = 0; i < total_bases; ++i) A.graph.push_back(nt_code(g.seq[i]));
-    pb.ops_off = A.ops_total; pb.ops_cap = (uint32_t)(L + total_bases + 2ull * N + 8);
-    A.ops_total += pb.ops_cap;
-    A.tb_bytes += (tb_off + 255) & ~255ull; A.last_elems += last_off;
-    A.probs.push_back(pb);
+    hp.starts.len = (uint32_t)(T.starts.size() - hp.starts.off);
+    hp.tb_bytes = (tb_off + 255) & ~255ull; hp.last_elems = last_off;
+    hp.ops_cap = (uint32_t)(L + total_bases + 2ull * N + 8);
     hp.on_device = true;
-    return VGK_OK;
 }
 
-template <class T> int to_dev(Backend* be, std::vector<void*>& held, const std::vector<T>& v, const T*& out) {
-    void* d = be->alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+constexpr unsigned MAX_THREADS = 32;
+// run f(i, thread) for i in [0, n) on a few host threads
+template <class F> void parallel_for(uint32_t n, F f) {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned T = std::min<unsigned>(hw ? hw : 1, MAX_THREADS);
+    if (const char* e = std::getenv("VGAMD_HOST_THREADS")) T = (unsigned)std::min<int>(MAX_THREADS, std::max(1, std::atoi(e)));
+    if (n < 256 || T <= 1) { for (uint32_t i = 0; i < n; ++i) f(i, 0u); return; }
+    std::atomic<uint32_t> next{0};
+    std::vector<std::thread> ts;
+    for (unsigned t = 0; t < T; ++t) ts.emplace_back([&, t]() {
+        for (;;) { const uint32_t b = next.fetch_add(64); if (b >= n) break; for (uint32_t i = b; i < std::min(n, b + 64); ++i) f(i, t); }
+    });
+    for (auto& t : ts) t.join();
+}
+
+// device scratch cached on the context (grow-only)
+void* ensure(vgk_ctx* ctx, int slot, uint64_t bytes) {
+    vgk_ctx::DevBuf& b = ctx->scratch[slot];
+    if (b.p && b.bytes >= bytes) return b.p;
+    if (b.p) { ctx->be->sync(); ctx->be->release(b.p); b.p = nullptr; b.bytes = 0; }
+    const uint64_t want = std::max<uint64_t>(bytes + bytes / 4, 4096);
+    b.p = ctx->be->alloc(want); b.bytes = want;
+    if (!b.p) { b.p = ctx->be->alloc(bytes); b.bytes = b.p ? bytes : 0; }
+    return b.p;
+}
+template <class T> int stage(vgk_ctx* ctx, int slot, const T* v, size_t count, const T*& out) {
+    void* d = ensure(ctx, slot, std::max<size_t>(count, 1) * sizeof(T));
     if (!d) return VGK_ENOMEM;
-    held.push_back(d);
-    if (!v.empty()) { int rc = be->upload(d, v.data(), v.size() * sizeof(T)); if (rc) return rc; }
+    if (count) { int rc = ctx->be->upload(d, v, count * sizeof(T)); if (rc) return rc; }
     out = (const T*)d;
     return VGK_OK;
 }
-
-// run one arena on the device and scatter the results
-int run_arena(vgk_ctx* ctx, Arena& A, std::vector<HostProblem>& hps, const vgk_banded_problem* problems,
-              std::vector<BResult>& results, std::vector<vgk_op>& ops) {
-    Backend* be = ctx->be.get();
-    std::vector<void*> held;
-    auto cleanup = [&](int rc) { for (void* d : held) be->release(d); return rc; };
-    const uint32_t n = (uint32_t)A.probs.size();
-    if (!n) return VGK_OK;
-    // launches: one per rows-per-lane class, long problems first inside a class
-    std::vector<uint32_t> order(n);
-    for (uint32_t i = 0; i < n; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        const uint32_t ra = hps[A.owner[a]].R, rb = hps[A.owner[b]].R;
-        if (ra != rb) return ra < rb;
-        return hps[A.owner[a]].cells > hps[A.owner[b]].cells;
-    });
-    std::vector<BandedLaunch> launches;
-    for (uint32_t i = 0; i < n;) {
-        uint32_t j = i; const uint32_t R = hps[A.owner[order[i]]].R;
-        while (j < n && hps[A.owner[order[j]]].R == R) ++j;
-        launches.push_back({R, i, j - i});
-        i = j;
-    }
-    BandedParams P{};
-    int rc;
-    if ((rc = to_dev(be, held, A.probs, P.probs))) return cleanup(rc);
-    if ((rc = to_dev(be, held, order, P.order))) return cleanup(rc);
-    if ((rc = to_dev(be, held, A.nodes, P.nodes))) return cleanup(rc);
-    if ((rc = to_dev(be, held, A.seeds, P.seeds))) return cleanup(rc);
-    if ((rc = to_dev(be, held, A.pool, P.pool))) return cleanup(rc);
-    if ((rc = to_dev(be, held, A.starts, P.starts))) return cleanup(rc);
-    if ((rc = to_dev(be, held, A.reads, P.reads))) return cleanup(rc);
-    if (ctx->has_qa) { if ((rc = to_dev(be, held, A.quals, P.quals))) return cleanup(rc); }
-    if ((rc = to_dev(be, held, A.graph, P.graph))) return cleanup(rc);
-    std::vector<int8_t> mat = ctx->has_qa ? ctx->qmat : std::vector<int8_t>(ctx->sc.matrix, ctx->sc.matrix + 25);
-    if ((rc = to_dev(be, held, mat, P.mat))) return cleanup(rc);
-    P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend; P.n = n;
-    auto dev_alloc = [&](uint64_t bytes) -> void* { void* d = be->alloc(bytes); if (d) held.push_back(d); return d; };
-    P.tb = (uint8_t*)dev_alloc(std::max<uint64_t>(A.tb_bytes, 256));
-    P.last = (int32_t*)dev_alloc(std::max<uint64_t>(A.last_elems, 64) * sizeof(int32_t));
-    P.ops = (vgk_op*)dev_alloc(std::max<uint64_t>(A.ops_total, 1) * sizeof(vgk_op));
-    P.results = (BResult*)dev_alloc((size_t)n * sizeof(BResult));
-    if (!P.tb || !P.last || !P.ops || !P.results) return cleanup(VGK_ENOMEM);
-    if ((rc = be->run_banded(P, launches.data(), (uint32_t)launches.size()))) return cleanup(rc);
-    results.resize(n); ops.resize(std::max<uint64_t>(A.ops_total, 1));
-    if ((rc = be->download(results.data(), P.results, (size_t)n * sizeof(BResult)))) return cleanup(rc);
-    if ((rc = be->download(ops.data(), P.ops, (size_t)A.ops_total * sizeof(vgk_op)))) return cleanup(rc);
-    ctx->banded_ms[0] += be->last_ms(3); ctx->banded_ms[1] += be->last_ms(4);
-    (void)problems;
-    return cleanup(VGK_OK);
-}
+// host arenas kept on the context between calls: uninitialised storage, so a warm call neither zero-fills nor page-faults
+template <class T> struct RawBuf {
+    T* p = nullptr; size_t cap = 0;
+    T* get(size_t n) { if (n > cap) { std::free(p); cap = n + n / 4 + 64; p = (T*)std::malloc(cap * sizeof(T)); } return p; }
+    ~RawBuf() { std::free(p); }
+};
+struct HostArenas {
+    RawBuf<BProb> probs; RawBuf<BNode> nodes; RawBuf<BSeed> seeds; RawBuf<uint32_t> pool, order; RawBuf<BStart> starts;
+    RawBuf<uint8_t> reads, quals, graph; RawBuf<BResult> dres; RawBuf<vgk_op> dops;
+};
+enum { S_PROBS, S_ORDER, S_NODES, S_SEEDS, S_POOL, S_STARTS, S_READS, S_QUALS, S_GRAPH, S_MAT, S_TB, S_LAST, S_OPS, S_DENSE, S_RESULTS, S_COUNT };
+static_assert(S_COUNT <= sizeof(vgk_ctx::scratch) / sizeof(vgk_ctx::DevBuf), "scratch slots");
 
 }  // namespace
 
@@ -245,58 +251,174 @@ int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t 
     uint64_t budget = ctx->be->memory_bytes() / 2;
     if (const char* e = std::getenv("VGAMD_MAX_BATCH_BYTES")) budget = std::strtoull(e, nullptr, 10);
     if (!budget) budget = 1ull << 30;
+    Backend* be = ctx->be.get();
+    const bool qa = ctx->has_qa;
+    if (!ctx->banded_host) ctx->banded_host = std::make_shared<HostArenas>();
+    HostArenas& H = *static_cast<HostArenas*>(ctx->banded_host.get());
+
+    const bool timing = std::getenv("VGAMD_BANDED_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_last = now();
+    auto lap = [&](const char* what) { if (!timing) return; auto t = now(); std::fprintf(stderr, "[vgk_banded_align] %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
+    // pass 1: geometry and tables of every problem
+    std::vector<Prep> hps(n);
+    std::vector<Scratch> scratch(MAX_THREADS); std::vector<Store> store(MAX_THREADS);
+    parallel_for(n, [&](uint32_t i, unsigned t) { hps[i].thread = t; prepare(ctx, problems[i], hps[i], scratch[t], store[t]); });
+    lap("prepare");
+
     size_t used = 0; int rc_all = VGK_OK;
-    std::vector<HostProblem> hps(n);
+    std::vector<uint32_t> owner;
     uint32_t i = 0;
     while (i < n) {
-        // cut a sub-batch that fits the budget
-        Arena A; uint32_t j = i;
+        // pass 2: place a sub-batch that fits the budget
+        owner.clear();
+        uint64_t n_nodes = 0, n_seeds = 0, n_pool = 0, n_starts = 0, n_read = 0, n_graph = 0, tb_bytes = 0, last_elems = 0, ops_total = 0;
+        uint32_t j = i;
         for (; j < n; ++j) {
-            const uint64_t before = A.tb_bytes + A.last_elems * 4 + A.ops_total * sizeof(vgk_op);
-            if (j > i && before > budget) break;
-            hps[j].status = prepare(ctx, problems[j], hps[j], A);
-            if (hps[j].on_device) A.owner.push_back(j);
+            const Prep& hp = hps[j];
+            if (!hp.on_device) continue;
+            const vgk_banded_problem& p = problems[j];
+            if (!owner.empty() && (tb_bytes + hp.tb_bytes + (last_elems + hp.last_elems) * 4 + (ops_total + hp.ops_cap) * 2 * sizeof(vgk_op) > budget ||
+                                   n_nodes + p.graph.n_nodes > 0xfffffff0ull || n_read + p.read_len > 0xfffffff0ull || n_graph + hp.bases > 0xfffffff0ull)) break;
+            n_nodes += p.graph.n_nodes; n_seeds += hp.seeds.len; n_pool += hp.pool.len; n_starts += hp.starts.len;
+            n_read += p.read_len; n_graph += hp.bases; tb_bytes += hp.tb_bytes; last_elems += hp.last_elems; ops_total += hp.ops_cap;
+            owner.push_back(j);
         }
-        std::vector<BResult> dres; std::vector<vgk_op> dops;
-        int rc = run_arena(ctx, A, hps, problems, dres, dops);
-        if (rc) return rc;
-        // results in the caller's order; the empty-walk rule and the empty sink prefixes are host bookkeeping (:2611-2668, :196-203)
-        uint32_t a = 0;
-        for (uint32_t q = i; q < j; ++q) {
-            vgk_result& r = results[q];
+        const uint32_t m = (uint32_t)owner.size();
+        BProb* probs = H.probs.get(m);
+        {
+            uint64_t a_nodes = 0, a_seeds = 0, a_pool = 0, a_starts = 0, a_read = 0, a_graph = 0, a_tb = 0, a_last = 0, a_ops = 0;
+            for (uint32_t a = 0; a < m; ++a) {
+                Prep& hp = hps[owner[a]]; const vgk_banded_problem& p = problems[owner[a]];
+                BProb pb{};
+                pb.L = p.read_len; pb.n_nodes = p.graph.n_nodes; pb.Hpad = hp.Hpad; pb.graph_len = (uint32_t)hp.bases;
+                pb.node_base = (uint32_t)a_nodes; pb.seed_base = (uint32_t)a_seeds; pb.pool_base = (uint32_t)a_pool; pb.start_base = (uint32_t)a_starts;
+                pb.n_starts = hp.starts.len; pb.read_off = (uint32_t)a_read; pb.graph_off = (uint32_t)a_graph;
+                pb.tb_base = a_tb; pb.last_base = a_last; pb.ops_off = a_ops; pb.ops_cap = hp.ops_cap;
+                a_nodes += pb.n_nodes; a_seeds += hp.seeds.len; a_pool += hp.pool.len; a_starts += hp.starts.len;
+                a_read += pb.L; a_graph += hp.bases; a_tb += hp.tb_bytes; a_last += hp.last_elems; a_ops += hp.ops_cap;
+                hp.arena = a; probs[a] = pb;
+            }
+        }
+        lap("place");
+        BResult* dres = H.dres.get(m + 1);
+        const vgk_op* dops = nullptr;
+        if (m) {
+            // pass 3: copy into the arenas
+            BNode* nodes = H.nodes.get(n_nodes); BSeed* seeds = H.seeds.get(n_seeds); uint32_t* pool = H.pool.get(n_pool); BStart* starts = H.starts.get(n_starts);
+            uint8_t* reads = H.reads.get(n_read); uint8_t* quals = qa ? H.quals.get(n_read) : nullptr; uint8_t* graph = H.graph.get(n_graph);
+            parallel_for(m, [&](uint32_t a, unsigned) {
+                const Prep& hp = hps[owner[a]]; const BProb& pb = probs[a]; const vgk_banded_problem& p = problems[owner[a]];
+                const Store& T = store[hp.thread];
+                std::copy(T.nodes.begin() + hp.nodes.off, T.nodes.begin() + hp.nodes.off + hp.nodes.len, nodes + pb.node_base);
+                std::copy(T.seeds.begin() + hp.seeds.off, T.seeds.begin() + hp.seeds.off + hp.seeds.len, seeds + pb.seed_base);
+                std::copy(T.pool.begin() + hp.pool.off, T.pool.begin() + hp.pool.off + hp.pool.len, pool + pb.pool_base);
+                for (uint32_t q = 0; q < hp.starts.len; ++q) starts[pb.start_base + q].node = T.starts[hp.starts.off + q];
+                uint8_t* rd = reads + pb.read_off;
+                for (uint32_t q = 0; q < pb.L; ++q) rd[q] = nt_code(p.read[q]);
+                if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
+                uint8_t* gr = graph + pb.graph_off;
+                for (uint32_t q = 0; q < pb.graph_len; ++q) gr[q] = nt_code(p.graph.seq[q]);
+            });
+            lap("arenas");
+            // launches: one per rows-per-lane class; inside a class the problems with the most cells first (counting sort on log2(cells))
+            uint32_t* order = H.order.get(m);
+            std::vector<BandedLaunch> launches;
+            {
+                auto key = [&](uint32_t a) { const Prep& hp = hps[owner[a]]; uint32_t r = 0; while ((1u << r) < hp.R) ++r;
+                                             uint32_t lg = 0; while ((hp.cells >> lg) > 1 && lg < 63) ++lg; return r * 64 + (63 - lg); };
+                std::vector<uint32_t> count(5 * 64 + 1, 0);
+                for (uint32_t a = 0; a < m; ++a) ++count[key(a) + 1];
+                for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
+                std::vector<uint32_t> at(count.begin(), count.end() - 1);
+                for (uint32_t a = 0; a < m; ++a) order[at[key(a)]++] = a;
+                for (uint32_t r = 0; r < 5; ++r) {
+                    const uint32_t lo = count[r * 64], hi = count[(r + 1) * 64];
+                    if (lo == hi) continue;
+                    // LDS staging area: score table | read codes | qualities | graph codes of the largest problem of the launch
+                    uint64_t lds = 0;
+                    for (uint32_t b = lo; b < hi; ++b) { const BProb& pb = probs[order[b]]; lds = std::max<uint64_t>(lds, (qa ? 6400u : 32u) + (uint64_t)pb.L * (qa ? 2 : 1) + pb.graph_len + 16); }
+                    launches.push_back({1u << r, lo, hi - lo, lds <= 40 * 1024 ? (uint32_t)lds : 0u});
+                }
+            }
+            lap("sort");
+            BandedParams P{};
+            int rc;
+            const int8_t* mat = qa ? ctx->qmat.data() : ctx->sc.matrix;
+            if ((rc = stage(ctx, S_PROBS, (const BProb*)probs, m, P.probs)) || (rc = stage(ctx, S_ORDER, (const uint32_t*)order, m, P.order)) ||
+                (rc = stage(ctx, S_NODES, (const BNode*)nodes, n_nodes, P.nodes)) || (rc = stage(ctx, S_SEEDS, (const BSeed*)seeds, n_seeds, P.seeds)) ||
+                (rc = stage(ctx, S_POOL, (const uint32_t*)pool, n_pool, P.pool)) || (rc = stage(ctx, S_STARTS, (const BStart*)starts, n_starts, P.starts)) ||
+                (rc = stage(ctx, S_READS, (const uint8_t*)reads, n_read, P.reads)) || (qa && (rc = stage(ctx, S_QUALS, (const uint8_t*)quals, n_read, P.quals))) ||
+                (rc = stage(ctx, S_GRAPH, (const uint8_t*)graph, n_graph, P.graph)) || (rc = stage(ctx, S_MAT, mat, qa ? 6400 : 25, P.mat))) return rc;
+            lap("h2d");
+            P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend; P.n = m;
+            P.tb = (uint8_t*)ensure(ctx, S_TB, std::max<uint64_t>(tb_bytes, 256));
+            P.last = (int32_t*)ensure(ctx, S_LAST, std::max<uint64_t>(last_elems, 64) * sizeof(int32_t));
+            P.ops = (vgk_op*)ensure(ctx, S_OPS, std::max<uint64_t>(ops_total, 1) * sizeof(vgk_op));
+            P.dense = (vgk_op*)ensure(ctx, S_DENSE, std::max<uint64_t>(ops_total, 1) * sizeof(vgk_op));
+            uint8_t* rblock = (uint8_t*)ensure(ctx, S_RESULTS, (size_t)m * sizeof(BResult) + 64);
+            if (!P.tb || !P.last || !P.ops || !P.dense || !rblock) return VGK_ENOMEM;
+            P.dense_count = (unsigned long long*)rblock; P.results = (BResult*)(rblock + 64);
+            if ((rc = be->zero(rblock, 64))) return rc;
+            lap("scratch");
+            if ((rc = be->run_banded(P, launches.data(), (uint32_t)launches.size()))) return rc;
+            lap("kernels");
+            unsigned long long dense_n = 0;
+            if ((rc = be->download(&dense_n, P.dense_count, sizeof dense_n))) return rc;
+            if ((rc = be->download(dres, P.results, (size_t)m * sizeof(BResult)))) return rc;
+            vgk_op* hd = H.dops.get(dense_n + 1);
+            if (dense_n && (rc = be->download(hd, P.dense, (size_t)dense_n * sizeof(vgk_op)))) return rc;
+            dops = hd;
+            ctx->banded_ms[0] += be->last_ms(3); ctx->banded_ms[1] += be->last_ms(4);
+            lap("d2h");
+        }
+        // results in the caller's order; the empty-walk rule and the empty sink prefixes are host bookkeeping (:2611-2668, :196-203):
+        // sizes first, then a prefix sum, then every problem writes its own slice
+        parallel_for(j - i, [&](uint32_t k, unsigned) {
+            const uint32_t q = i + k; Prep& hp = hps[q]; vgk_result& r = results[q];
             std::memset(&r, 0, sizeof r);
-            r.ops_begin = (uint32_t)used;
-            HostProblem& hp = hps[q];
-            if (!hp.on_device) { r.status = hp.status; continue; }
-            const BProb& pb = A.probs[a]; const BResult& dr = dres[a]; ++a;
-            ctx->banded_cells += hp.cells;
-            const vgk_banded_problem& p = problems[q];
-            uint64_t bases = 0; for (uint32_t v = 0; v < p.graph.n_nodes; ++v) bases += p.graph.node_len[v];
-            ctx->banded_bytes += p.read_len + bases + 8ull * p.graph.n_nodes + 4ull * p.graph.pred_off[p.graph.n_nodes] + hp.cells + 16 + 2ull * dr.n_ops;
+            hp.need = 0;
+            if (!hp.on_device) { r.status = hp.status; return; }
+            const BResult& dr = dres[hp.arena]; const vgk_banded_problem& p = problems[q];
             const int32_t empty_score = -ctx->sc.gap_open - (int32_t)(p.read_len - 1) * ctx->sc.gap_extend;
             const bool have = dr.status != VGK_ENOBAND;
-            std::vector<vgk_op> out;
-            if (hp.have_empty_walk && (!have || empty_score >= dr.score)) {
-                r.score = empty_score; r.status = VGK_OK;
-                for (size_t k = hp.empty_walk.size(); k-- > 0;) {
-                    vgk_op o{}; o.node = hp.empty_walk[k];
-                    if (k + 1 == hp.empty_walk.size()) { o.op = VGK_OP_I; o.len = (uint16_t)p.read_len; } else { o.op = VGK_OP_M; o.len = 0; }
-                    out.push_back(o);
-                }
-            } else if (dr.status != VGK_OK) {
-                r.status = dr.status;
-            } else {
-                r.score = dr.score; r.status = VGK_OK;
-                const vgk_op* src = dops.data() + pb.ops_off + dr.ops_begin;
-                for (uint32_t k = 0; k < dr.n_ops; ++k) { vgk_op o = src[k]; if (o.len == 0) o.op = VGK_OP_M; out.push_back(o); }
-                const std::vector<uint32_t>& prefix = hp.start_prefix[dr.start];
-                for (size_t k = prefix.size(); k-- > 0;) { vgk_op o{}; o.node = prefix[k]; o.op = VGK_OP_M; o.len = 0; out.push_back(o); }
+            hp.use_empty_walk = hp.have_empty_walk && (!have || empty_score >= dr.score);
+            if (hp.use_empty_walk) { hp.need = hp.empty_walk.len; r.score = empty_score; r.status = VGK_OK; }
+            else if (dr.status != VGK_OK) r.status = dr.status;
+            else { hp.need = dr.n_ops + store[hp.thread].start_prefix[hp.starts.off + dr.start].len; r.score = dr.score; r.status = VGK_OK; }
+        });
+        for (uint32_t q = i; q < j; ++q) {
+            Prep& hp = hps[q]; vgk_result& r = results[q];
+            r.ops_begin = (uint32_t)used;
+            if (hp.on_device) {
+                const vgk_banded_problem& p = problems[q];
+                ctx->banded_cells += hp.cells;
+                ctx->banded_bytes += p.read_len + hp.bases + 8ull * p.graph.n_nodes + 4ull * p.graph.pred_off[p.graph.n_nodes] + hp.cells + 16 + 2ull * dres[hp.arena].n_ops;
             }
-            if (r.status == VGK_OK) {
-                if (used + out.size() > ops_cap || !ops) { r.status = VGK_EOPS; rc_all = VGK_EOPS; }
-                else { std::copy(out.begin(), out.end(), ops + used); r.n_ops = (uint32_t)out.size(); used += out.size(); }
-            }
+            if (r.status != VGK_OK) continue;
+            if (!ops || used + hp.need > ops_cap) { r.status = VGK_EOPS; rc_all = VGK_EOPS; hp.need = 0; continue; }
+            r.n_ops = hp.need; used += hp.need;
         }
+        parallel_for(j - i, [&](uint32_t k, unsigned) {
+            const uint32_t q = i + k; const Prep& hp = hps[q]; const vgk_result& r = results[q];
+            if (r.status != VGK_OK || !r.n_ops) return;
+            const Store& T = store[hp.thread];
+            vgk_op* out = ops + r.ops_begin;
+            if (hp.use_empty_walk) {
+                for (uint32_t e = hp.empty_walk.len; e-- > 0;) {
+                    vgk_op o{}; o.node = T.prefix[hp.empty_walk.off + e];
+                    if (e + 1 == hp.empty_walk.len) { o.op = VGK_OP_I; o.len = (uint16_t)problems[q].read_len; } else { o.op = VGK_OP_M; o.len = 0; }
+                    *out++ = o;
+                }
+            } else {
+                const BResult& dr = dres[hp.arena];
+                const vgk_op* src = dops + dr.ops_begin;
+                for (uint32_t e = 0; e < dr.n_ops; ++e) { vgk_op o = src[e]; if (o.len == 0) o.op = VGK_OP_M; *out++ = o; }
+                const Span pre = T.start_prefix[hp.starts.off + dr.start];
+                for (uint32_t e = pre.len; e-- > 0;) { vgk_op o{}; o.node = T.prefix[pre.off + e]; o.op = VGK_OP_M; o.len = 0; *out++ = o; }
+            }
+        });
+        lap("results");
         i = j;
     }
     if (ops_written) *ops_written = used;

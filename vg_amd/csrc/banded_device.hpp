@@ -39,6 +39,8 @@ struct BNode {                 // one per graph node of a problem
     uint32_t last_off;         // int32 elements, relative to the problem's last_base: M | Ic | Ir, Hpad each
     uint32_t src_path_off;     // empty nodes between this node and the source it is joined to (relative to pool_base)
     uint32_t src_path_len;
+    uint32_t chain;            // 1: the only predecessor is the previous non-empty unmasked node in the order, reached directly, and the
+                               // band is that node's band carried over: column 0 continues from the registers / traceback bytes
 };
 struct BSeed {                 // a non-empty, unmasked predecessor reached through path[] of empty nodes, in the LIFO
     uint32_t node;             // order the reference pops them (:305-330, :1226-1262, :1311-1330)
@@ -52,7 +54,7 @@ struct BProb {
     uint32_t Hpad;                     // 64 * rows per lane
     uint64_t tb_base, last_base;
     uint64_t ops_off; uint32_t ops_cap;
-    uint32_t pad;
+    uint32_t graph_len;                // bases of the whole graph
 };
 struct BResult { int32_t score; int32_t status; uint32_t start; uint32_t n_ops; uint32_t ops_begin; uint32_t pad[3]; };
 
@@ -71,11 +73,20 @@ struct BandedParams {
     int32_t        go, ge;
     uint8_t*       tb;
     int32_t*       last;
-    vgk_op*        ops;
+    vgk_op*        ops;               // per-problem slots the traceback writes back to front
+    vgk_op*        dense;             // the finished op lists, packed (BResult::ops_begin indexes this)
+    unsigned long long* dense_count;  // ops in `dense` so far
     BResult*       results;
 };
 
 VGK_HD int32_t bmax(int32_t a, int32_t b) { return a > b ? a : b; }
+VGK_HD unsigned long long bump(unsigned long long* counter, unsigned long long n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(counter, n);
+#else
+    const unsigned long long at = *counter; *counter += n; return at;      // the CPU emulation walks one problem at a time
+#endif
+}
 VGK_HD int32_t bsub(const BandedParams& P, const BProb& pb, uint32_t g, int64_t r) {
     const uint32_t rd = P.reads[pb.read_off + r];
     return P.quals ? P.mat[25u * P.quals[pb.read_off + r] + 5u * g + rd] : P.mat[5u * g + rd];
@@ -90,34 +101,102 @@ template <int R> VGK_HD void store_codes(uint8_t* dst, const uint8_t (&codes)[R]
     } else for (int i = 0; i < R; ++i) dst[i] = codes[i];
 }
 
+// Where the lane code reads the problem's read codes, qualities, graph codes and score table from: LDS copies made by
+// the kernel's prologue when they fit, the HBM arenas otherwise (and in the CPU emulation).
+struct BSrc { const uint8_t* rd; const uint8_t* q; const uint8_t* graph; const int8_t* mat; };
+template <bool QA> VGK_HD int32_t bsub(const BSrc& s, uint32_t g, int32_t r) {
+    const uint32_t rd = s.rd[r];
+    return QA ? s.mat[25u * s.q[r] + 5u * g + rd] : s.mat[5u * g + rd];
+}
+
 // ---- fill: lane code.  XL supplies the cross-lane primitives:
 //   int32 up(int32 v)        value of lane+1 (BNEG for the last lane)
 //   int32 down(int32 v)      value of lane-1 (BNEG for lane 0)
 //   int32 scan_excl(int32 v) max over lanes < this one (BNEG for lane 0)
-template <int R, class XL>
-VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, uint32_t lane, XL& xl) {
+template <int R, bool QA, class XL>
+VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc& src, uint32_t lane, XL& xl) {
     const int32_t go = P.go, ge = P.ge, L = (int32_t)pb.L;
     const BNode* nodes = P.nodes + pb.node_base;
     int32_t* last = P.last + pb.last_base;
     uint8_t* tb = P.tb + pb.tb_base;
     int32_t M[R], Ic[R], Ir[R];
+    for (int i = 0; i < R; ++i) { M[i] = BNEG; Ic[i] = BNEG; Ir[i] = BNEG; }
     for (uint32_t v = 0; v < pb.n_nodes; ++v) {
         const BNode nd = nodes[v];
         if (nd.masked || nd.len == 0) continue;
         const int32_t H = nd.bot - nd.top + 1;
-        const uint8_t* seq = P.graph + pb.graph_off + nd.seq_off;
+        const uint8_t* seq = src.graph + nd.seq_off;
         uint8_t* tbn = tb + nd.tb_off;
-        // ---- column 0: gather from the predecessors' last columns (:333-430) and the implied lead gaps (:433-476)
-        {
+        const int32_t k0 = (int32_t)lane * R;
+
+        // the row gaps of a column and its traceback bytes, given the column's M / Ic and the lead-gap seeds ir0 of Ir:
+        //   Ir(r) = max(ir0(r), max_{r'<r} Y(r') - (r-1)*ge),  Y(r') = max(max(M,Ic)(r') - go, ir0(r') - ge) + r'*ge
+        auto finish_column = [&](int32_t j, const int32_t (&nM)[R], const int32_t (&nIc)[R], const int32_t (&ir0)[R], const uint32_t (&code_mc)[R]) {
+            int32_t run = BNEG, pre[R];
+            for (int i = 0; i < R; ++i) {
+                const int32_t r = k0 + i + nd.top + j;
+                pre[i] = run;
+                run = bmax(run, bmax(bmax(nM[i], nIc[i]) - go, ir0[i] - ge) + r * ge);
+            }
+            const int32_t excl = xl.scan_excl(run);
+            int32_t upM = xl.down(nM[R - 1]), upIc = xl.down(nIc[R - 1]);
+            uint8_t codes[R];
+            for (int i = 0; i < R; ++i) {
+                const int32_t k = k0 + i, r = k + nd.top + j;
+                const bool valid = k < H && r >= 0 && r < L;
+                int32_t ir = bmax(ir0[i], bmax(excl, pre[i]) - (r - 1) * ge);
+                const uint32_t cr = ir == upM - go ? BM : ir == upIc - go ? BIC : BIR;
+                if (!valid) ir = BNEG;
+                upM = nM[i]; upIc = nIc[i];
+                M[i] = nM[i]; Ic[i] = nIc[i]; Ir[i] = ir;
+                codes[i] = (uint8_t)(code_mc[i] | (cr << 2));
+            }
+            store_codes<R>(tbn + (size_t)j * pb.Hpad + k0, codes);
+        };
+        // a column whose left neighbours are the registers: columns 1.. of a node (:492-590), and column 0 of a node whose
+        // only predecessor is the node this wave has just finished, with the band carried straight over (BNode::chain)
+        auto column = [&](int32_t j) {
+            const uint32_t g = seq[j];
+            const int32_t nxM = xl.up(M[0]), nxIc = xl.up(Ic[0]), nxIr = xl.up(Ir[0]);      // row k+1 of the previous column
+            int32_t nM[R], nIc[R], ir0[R];
+            uint32_t code_mc[R];
+            for (int i = 0; i < R; ++i) {
+                const int32_t k = k0 + i, r = k + nd.top + j;
+                const bool valid = k < H && r >= 0 && r < L;
+                const int32_t bM = i + 1 < R ? M[i + 1 < R ? i + 1 : 0] : nxM, bIc = i + 1 < R ? Ic[i + 1 < R ? i + 1 : 0] : nxIc,
+                              bIr = i + 1 < R ? Ir[i + 1 < R ? i + 1 : 0] : nxIr;
+                int32_t m = BNEG, ic = BNEG, ir = BNEG; uint32_t cm = 3, cc = 0;
+                if (valid) {
+                    const int32_t ms = bsub<QA>(src, g, r);
+                    if (r == 0) {                         // implied lead gap along the top edge (:507-526, :352-366)
+                        m = ms - go - (nd.cum + j - 1) * ge;
+                        if (nd.top + j < 0) ir = -2 * go - (nd.cum + j) * ge;
+                    } else {
+                        const int32_t b3 = bmax(bmax(M[i], Ic[i]), Ir[i]);
+                        m = ms + b3;
+                        cm = b3 == M[i] ? BM : b3 == Ic[i] ? BIC : BIR;
+                    }
+                    ic = bmax(bmax(bM - go, bIr - go), bIc - ge);
+                    cc = ic == bM - go ? BM : ic == bIc - ge ? BIC : BIR;
+                }
+                nM[i] = m; nIc[i] = ic; ir0[i] = ir; code_mc[i] = cm | (cc << 4);
+            }
+            finish_column(j, nM, nIc, ir0, code_mc);
+        };
+
+        if (nd.chain) column(0);
+        else {
+            // ---- column 0: gather from the predecessors' last columns (:333-430) and the implied lead gaps (:433-476)
             const uint32_t g = seq[0];
             const int32_t hi0 = nd.bot >= L ? L - 1 : nd.bot;
-            int32_t ir0[R];
+            int32_t nM[R], nIc[R], ir0[R];
+            uint32_t code_mc[R];
             for (int i = 0; i < R; ++i) {
-                const int32_t k = (int32_t)lane * R + i, r = k + nd.top;
+                const int32_t k = k0 + i, r = k + nd.top;
                 const bool valid = k < H && r >= 0 && r < L;
                 int32_t m = BNEG, ic = BNEG, ir = BNEG;
                 if (valid) {
-                    const int32_t ms = bsub(P, pb, g, r);
+                    const int32_t ms = bsub<QA>(src, g, r);
                     for (uint32_t si = 0; si < nd.n_seeds; ++si) {
                         const BNode sd = nodes[P.seeds[pb.seed_base + nd.seed_off + si].node];
                         const int32_t snt = sd.top + sd.len, snb = sd.bot + sd.len;
@@ -138,86 +217,16 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, uint32_t la
                         }
                     }
                     if (nd.as_source) {
-                        if (r == 0) { m = P.quals ? bmax(m, ms) : ms; ir = bmax(ir, -2 * go); ic = bmax(ic, -2 * go); }
+                        if (r == 0) { m = QA ? bmax(m, ms) : ms; ir = bmax(ir, -2 * go); ic = bmax(ic, -2 * go); }
                         else { m = bmax(m, ms - go - (r - 1) * ge); ic = bmax(ic, -2 * go - r * ge); }
                         if (r == hi0) ic = BNEG;
                     }
                 }
-                M[i] = m; Ic[i] = ic; ir0[i] = ir;
+                nM[i] = m; nIc[i] = ic; ir0[i] = ir; code_mc[i] = 0;
             }
-            // row gaps down the column: Ir(r) = max(ir0(r), max_{r'<r} Y(r') - (r-1)*ge), Y(r') = max(max(M,Ic)(r') - go, ir0(r') - ge) + r'*ge
-            int32_t run = BNEG, pre[R];
-            for (int i = 0; i < R; ++i) {
-                const int32_t r = (int32_t)lane * R + i + nd.top;
-                pre[i] = run;
-                run = bmax(run, bmax(bmax(M[i], Ic[i]) - go, ir0[i] - ge) + r * ge);
-            }
-            const int32_t excl = xl.scan_excl(run);
-            int32_t upM = xl.down(M[R - 1]), upIc = xl.down(Ic[R - 1]);
-            uint8_t codes[R];
-            for (int i = 0; i < R; ++i) {
-                const int32_t k = (int32_t)lane * R + i, r = k + nd.top;
-                const bool valid = k < H && r >= 0 && r < L;
-                const int32_t scanned = bmax(excl, pre[i]) - (r - 1) * ge;
-                int32_t ir = bmax(ir0[i], scanned);
-                const uint32_t code = ir == upM - go ? BM : ir == upIc - go ? BIC : BIR;
-                if (!valid) { ir = BNEG; M[i] = BNEG; Ic[i] = BNEG; }
-                Ir[i] = ir;
-                upM = M[i]; upIc = Ic[i];
-                codes[i] = (uint8_t)(code << 2);
-            }
-            store_codes<R>(tbn + lane * R, codes);
+            finish_column(0, nM, nIc, ir0, code_mc);
         }
-        // ---- the other columns (:492-590)
-        for (int32_t j = 1; j < nd.len; ++j) {
-            const uint32_t g = seq[j];
-            // row k+1 of the previous column, for the column gap
-            const int32_t nxM = xl.up(M[0]), nxIc = xl.up(Ic[0]), nxIr = xl.up(Ir[0]);
-            int32_t nM[R], nIc[R], ir0[R];
-            uint32_t code_mc[R];
-            for (int i = 0; i < R; ++i) {
-                const int32_t k = (int32_t)lane * R + i, r = k + nd.top + j;
-                const bool valid = k < H && r >= 0 && r < L;
-                const int32_t bM = i + 1 < R ? M[i + 1 < R ? i + 1 : 0] : nxM, bIc = i + 1 < R ? Ic[i + 1 < R ? i + 1 : 0] : nxIc,
-                              bIr = i + 1 < R ? Ir[i + 1 < R ? i + 1 : 0] : nxIr;
-                int32_t m = BNEG, ic = BNEG, ir = BNEG; uint32_t cm = 3, cc = 0;
-                if (valid) {
-                    const int32_t ms = bsub(P, pb, g, r);
-                    if (r == 0) {                         // implied lead gap along the top edge (:507-526)
-                        m = ms - go - (nd.cum + j - 1) * ge;
-                        if (nd.top + j < 0) ir = -2 * go - (nd.cum + j) * ge;
-                    } else {
-                        const int32_t b3 = bmax(bmax(M[i], Ic[i]), Ir[i]);
-                        m = ms + b3;
-                        cm = b3 == M[i] ? BM : b3 == Ic[i] ? BIC : BIR;
-                    }
-                    ic = bmax(bmax(bM - go, bIr - go), bIc - ge);
-                    cc = ic == bM - go ? BM : ic == bIc - ge ? BIC : BIR;
-                }
-                nM[i] = m; nIc[i] = ic; ir0[i] = ir; code_mc[i] = cm | (cc << 4);
-            }
-            int32_t run = BNEG, pre[R];
-            for (int i = 0; i < R; ++i) {
-                const int32_t r = (int32_t)lane * R + i + nd.top + j;
-                pre[i] = run;
-                run = bmax(run, bmax(bmax(nM[i], nIc[i]) - go, ir0[i] - ge) + r * ge);
-            }
-            const int32_t excl = xl.scan_excl(run);
-            int32_t upM = xl.down(nM[R - 1]), upIc = xl.down(nIc[R - 1]);
-            uint8_t codes[R];
-            for (int i = 0; i < R; ++i) {
-                const int32_t k = (int32_t)lane * R + i, r = k + nd.top + j;
-                const bool valid = k < H && r >= 0 && r < L;
-                const int32_t scanned = bmax(excl, pre[i]) - (r - 1) * ge;
-                int32_t ir = bmax(ir0[i], scanned);
-                const uint32_t cr = ir == upM - go ? BM : ir == upIc - go ? BIC : BIR;
-                if (!valid) ir = BNEG;
-                upM = nM[i]; upIc = nIc[i];
-                M[i] = nM[i]; Ic[i] = nIc[i]; Ir[i] = ir;
-                codes[i] = (uint8_t)(code_mc[i] | (cr << 2));
-            }
-            store_codes<R>(tbn + (size_t)j * pb.Hpad + lane * R, codes);
-        }
+        for (int32_t j = 1; j < nd.len; ++j) column(j);
         // ---- keep the last column for the successors and the traceback
         int32_t* nl = last + nd.last_off;
         for (int i = 0; i < R; ++i) {
@@ -298,6 +307,19 @@ VGK_HD void banded_walk_one(const BandedParams& P, uint32_t pi) {
         }
         if (lead) { mat = BIC; while (j > 0) { bemit(w, nodes, node, VGK_OP_D, 1); --j; } }
         const BSeed* seeds = P.seeds + pb.seed_base + n.seed_off;
+        if (n.chain && !lead) {       // the only predecessor continues this band: column 0 reads its traceback byte like any column
+            bemit(w, nodes, node, bop(mat), 1);
+            const uint32_t code = tbn[r - n.top];
+            if (mat == BM) {
+                if (r == 0) { mat = BIC; lead = true; r = -1; }
+                else { cur -= bsub(P, pb, seq[0], r); mat = code & 3u; --r; }
+            } else {
+                const uint32_t src = (code >> 4) & 3u;
+                cur += src == BIC ? ge : go; mat = src;
+            }
+            node = seeds[0].node; j = nodes[node].len - 1;
+            continue;
+        }
         const uint32_t* pool = P.pool + pb.pool_base;
         int found = -1; uint32_t fmat = BM; bool flead = lead; int32_t ms = 0;
         if (lead) {
@@ -350,8 +372,12 @@ VGK_HD void banded_walk_one(const BandedParams& P, uint32_t pi) {
     }
     if (w.overflow && status == VGK_OK) status = VGK_EOPS;
     res.status = status;
-    res.n_ops = (uint32_t)(w.end - w.cur);
-    res.ops_begin = (uint32_t)(w.cur - (P.ops + pb.ops_off));
+    // pack the finished list behind the others: only what was written travels back to the host
+    const uint32_t n_ops = status == VGK_OK ? (uint32_t)(w.end - w.cur) : 0u;
+    const unsigned long long at = n_ops ? bump(P.dense_count, n_ops) : 0ull;
+    for (uint32_t q = 0; q < n_ops; ++q) P.dense[at + q] = w.cur[q];
+    res.n_ops = n_ops;
+    res.ops_begin = (uint32_t)at;
 }
 
 }  // namespace vgk

@@ -16,5 +16,10 @@ struct vgk_ctx {
     std::vector<int8_t> qmat, qbon;
     // last vgk_banded_align call: kernel times (ms), band cells, algorithmic bytes
     double banded_ms[2] = {0, 0}; uint64_t banded_cells = 0, banded_bytes = 0;
+    // device scratch kept between vgk_banded_align calls (grow-only; released with the context)
+    struct DevBuf { void* p = nullptr; uint64_t bytes = 0; };
+    DevBuf scratch[16];
+    std::shared_ptr<void> banded_host;      // host staging arenas of banded_api.cpp
+    ~vgk_ctx() { if (be) for (DevBuf& b : scratch) if (b.p) be->release(b.p); }
 };
 
