@@ -80,12 +80,16 @@ struct XlDpp {
     __device__ __forceinline__ int32_t down(int32_t v) const { return dpp_down(v); }
     // exclusive max-scan over the 64 lanes: row_shr 1/2/4/8 inside each row of 16, then row_bcast:15 and row_bcast:31
     __device__ __forceinline__ int32_t scan_excl(int32_t v) const {
-        v = bmax(v, __builtin_amdgcn_update_dpp(BNEG, v, 0x111, 0xf, 0xf, false));
-        v = bmax(v, __builtin_amdgcn_update_dpp(BNEG, v, 0x112, 0xf, 0xf, false));
-        v = bmax(v, __builtin_amdgcn_update_dpp(BNEG, v, 0x114, 0xf, 0xf, false));
-        v = bmax(v, __builtin_amdgcn_update_dpp(BNEG, v, 0x118, 0xf, 0xf, false));
-        v = bmax(v, __builtin_amdgcn_update_dpp(BNEG, v, 0x142, 0xa, 0xf, false));
-        v = bmax(v, __builtin_amdgcn_update_dpp(BNEG, v, 0x143, 0xc, 0xf, false));
+        // v_max_i32_dpp with the destination tied to both sources: a lane whose DPP source does not exist is disabled and
+        // keeps its value, which is the identity we want — one instruction per step instead of mov_dpp + max + constant.
+        // (s_nop: 2 wait states between a VALU write and a DPP read of the same VGPR; 5 after an EXEC write.)
+        asm volatile("s_nop 4\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                     "s_nop 1" : "+v"(v));
         return dpp_down(v);
     }
     __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }

@@ -159,7 +159,7 @@ void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch&
             }
             prev_filled = v;
             nd.tb_off = (uint32_t)tb_off; nd.last_off = (uint32_t)last_off;
-            tb_off += (uint64_t)len[v] * Hpad; last_off += 3ull * Hpad;
+            tb_off += (uint64_t)len[v] * Hpad; last_off += 5ull * Hpad;
             if (tb_off > 0xfffffff0ull) { fail(VGK_ETOOBIG); return; }
         }
         T.nodes[keep_nodes + v] = nd;

@@ -36,7 +36,7 @@ struct BNode {                 // one per graph node of a problem
     uint8_t  as_source;        // no predecessor, or joined to a source through empty nodes (:301, :313-318)
     uint8_t  masked;
     uint32_t tb_off;           // bytes, relative to the problem's tb_base: len columns of Hpad bytes
-    uint32_t last_off;         // int32 elements, relative to the problem's last_base: M | Ic | Ir, Hpad each
+    uint32_t last_off;         // int32 elements, relative to the problem's last_base: last column M | Ic | Ir, first column M | Ic, Hpad each
     uint32_t src_path_off;     // empty nodes between this node and the source it is joined to (relative to pool_base)
     uint32_t src_path_len;
     uint32_t chain;            // 1: the only predecessor is the previous non-empty unmasked node in the order, reached directly, and the
@@ -160,26 +160,25 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
             const int32_t nxM = xl.up(M[0]), nxIc = xl.up(Ic[0]), nxIr = xl.up(Ir[0]);      // row k+1 of the previous column
             int32_t nM[R], nIc[R], ir0[R];
             uint32_t code_mc[R];
+            const int32_t lead_m = -go - (nd.cum + j - 1) * ge;                              // implied lead gap along the top edge (:507-526, :352-366)
+            const int32_t lead_ir = nd.top + j < 0 ? -2 * go - (nd.cum + j) * ge : BNEG;
             for (int i = 0; i < R; ++i) {
                 const int32_t k = k0 + i, r = k + nd.top + j;
                 const bool valid = k < H && r >= 0 && r < L;
                 const int32_t bM = i + 1 < R ? M[i + 1 < R ? i + 1 : 0] : nxM, bIc = i + 1 < R ? Ic[i + 1 < R ? i + 1 : 0] : nxIc,
                               bIr = i + 1 < R ? Ir[i + 1 < R ? i + 1 : 0] : nxIr;
-                int32_t m = BNEG, ic = BNEG, ir = BNEG; uint32_t cm = 3, cc = 0;
-                if (valid) {
-                    const int32_t ms = bsub<QA>(src, g, r);
-                    if (r == 0) {                         // implied lead gap along the top edge (:507-526, :352-366)
-                        m = ms - go - (nd.cum + j - 1) * ge;
-                        if (nd.top + j < 0) ir = -2 * go - (nd.cum + j) * ge;
-                    } else {
-                        const int32_t b3 = bmax(bmax(M[i], Ic[i]), Ir[i]);
-                        m = ms + b3;
-                        cm = b3 == M[i] ? BM : b3 == Ic[i] ? BIC : BIR;
-                    }
-                    ic = bmax(bmax(bM - go, bIr - go), bIc - ge);
-                    cc = ic == bM - go ? BM : ic == bIc - ge ? BIC : BIR;
-                }
-                nM[i] = m; nIc[i] = ic; ir0[i] = ir; code_mc[i] = cm | (cc << 4);
+                // branch-free: out-of-matrix rows read a clamped read base and are overwritten with -inf below
+                const int32_t rc = r < 0 ? 0 : r >= L ? L - 1 : r;
+                const int32_t ms = bsub<QA>(src, g, rc);
+                const int32_t b3 = bmax(bmax(M[i], Ic[i]), Ir[i]);
+                const uint32_t cm = b3 == M[i] ? BM : b3 == Ic[i] ? BIC : BIR;
+                const int32_t icv = bmax(bmax(bM - go, bIr - go), bIc - ge);
+                const uint32_t cc = icv == bM - go ? BM : icv == bIc - ge ? BIC : BIR;
+                const bool top_row = r == 0;
+                nM[i] = valid ? (top_row ? ms + lead_m : ms + b3) : BNEG;
+                nIc[i] = valid ? icv : BNEG;
+                ir0[i] = valid && top_row ? lead_ir : BNEG;
+                code_mc[i] = cm | (cc << 4);
             }
             finish_column(j, nM, nIc, ir0, code_mc);
         };
@@ -225,6 +224,9 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
                 nM[i] = m; nIc[i] = ic; ir0[i] = ir; code_mc[i] = 0;
             }
             finish_column(0, nM, nIc, ir0, code_mc);
+            // the traceback re-examines the predecessors from this column (traceback_over_edge): keep its M and Ic
+            int32_t* nf = last + nd.last_off + 3 * pb.Hpad;
+            for (int i = 0; i < R; ++i) { nf[k0 + i] = M[i]; nf[pb.Hpad + k0 + i] = Ic[i]; }
         }
         for (int32_t j = 1; j < nd.len; ++j) column(j);
         // ---- keep the last column for the successors and the traceback
@@ -239,17 +241,23 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
 
 // ---- traceback: one thread per problem (BAMatrix::traceback :756-1126, traceback_over_edge :1129-1780, BABuilder :44-205)
 struct BWalker {
-    vgk_op* end; vgk_op* cur; vgk_op* floor;      // ops are written back to front
+    vgk_op* end; vgk_op* cur; vgk_op* floor;      // finished runs are written back to front
+    uint32_t node, op, len; bool open;            // the run being grown lives in registers
     bool overflow;
 };
-VGK_HD void bemit(BWalker& w, const BNode* nodes, uint32_t node, uint32_t op, uint32_t inc) {
-    if (w.cur != w.end && w.cur->node == node) {
-        if (w.cur->op == op) { w.cur->len = (uint16_t)(w.cur->len + inc); return; }
-        if (w.cur->len == 0 && nodes[node].len == 0) { w.cur->op = (uint8_t)op; w.cur->len = (uint16_t)inc; return; }   // (:69-72)
-    }
+VGK_HD void bflush(BWalker& w) {
+    if (!w.open) return;
     if (w.cur == w.floor) { w.overflow = true; return; }
     --w.cur;
-    w.cur->node = node; w.cur->op = (uint8_t)op; w.cur->len = (uint16_t)inc; w.cur->pad = 0;
+    w.cur->node = w.node; w.cur->op = (uint8_t)w.op; w.cur->len = (uint16_t)w.len; w.cur->pad = 0;
+}
+VGK_HD void bemit(BWalker& w, const BNode* nodes, uint32_t node, uint32_t op, uint32_t inc) {
+    if (w.open && w.node == node) {
+        if (w.op == op) { w.len += inc; return; }
+        if (w.len == 0 && nodes[node].len == 0) { w.op = op; w.len = inc; return; }   // an empty node's zero edit is replaced (:69-72)
+    }
+    bflush(w);
+    w.node = node; w.op = op; w.len = inc; w.open = true;
 }
 VGK_HD uint32_t bop(uint32_t mat) { return mat == BM ? VGK_OP_M : mat == BIR ? VGK_OP_I : VGK_OP_D; }
 // source state of a transition out of a predecessor's last column, in the reference's order
@@ -283,40 +291,44 @@ VGK_HD void banded_walk_one(const BandedParams& P, uint32_t pi) {
     if (!have) { res.score = 0; res.status = VGK_ENOBAND; return; }
     res.score = best;
     BWalker w; w.end = P.ops + pb.ops_off + pb.ops_cap; w.cur = w.end; w.floor = P.ops + pb.ops_off; w.overflow = false;
-    uint32_t node = bnode, mat = bmat; int32_t r = L - 1, j = nodes[node].len - 1, cur = best;
+    w.open = false; w.node = 0; w.op = 0; w.len = 0;
+    uint32_t node = bnode, mat = bmat; int32_t r = L - 1, j = nodes[node].len - 1;
     bool lead = false; int status = VGK_OK;
     for (;;) {
         const BNode n = nodes[node];
         const uint8_t* seq = P.graph + pb.graph_off + n.seq_off;
         const uint8_t* tbn = tb + n.tb_off;
+        // a run of matches walks up one band row: its bytes sit Hpad apart, so four of them are fetched at once
+        int32_t ck = -1, cj = -1; uint32_t c4[4] = {0, 0, 0, 0};
+        auto code_at = [&](int32_t jj, int32_t kk) -> uint32_t {
+            if (kk != ck || jj > cj || jj <= cj - 4) {
+                ck = kk; cj = jj;
+                for (int q = 0; q < 4; ++q) c4[q] = jj - q >= 0 ? tbn[(size_t)(jj - q) * pb.Hpad + kk] : 0u;
+            }
+            return c4[cj - jj];
+        };
         while ((j > 0 || mat == BIR) && !lead) {
             bemit(w, nodes, node, bop(mat), 1);
-            const uint32_t code = tbn[(size_t)j * pb.Hpad + (r - j - n.top)];
+            const uint32_t code = code_at(j, r - j - n.top);
             if (mat == BM) {
                 if (r == 0) { mat = BIC; --j; r = -1; lead = true; break; }
-                cur -= bsub(P, pb, seq[j], r);
                 mat = code & 3u; --r; --j;
             } else if (mat == BIR) {
                 if (r == 0) { lead = true; r = -1; break; }
-                const uint32_t src = (code >> 2) & 3u;
-                cur += src == BIR ? ge : go; mat = src; --r;
+                mat = (code >> 2) & 3u; --r;
             } else {
-                const uint32_t src = (code >> 4) & 3u;
-                cur += src == BIC ? ge : go; mat = src; --j;
+                mat = (code >> 4) & 3u; --j;
             }
         }
         if (lead) { mat = BIC; while (j > 0) { bemit(w, nodes, node, VGK_OP_D, 1); --j; } }
         const BSeed* seeds = P.seeds + pb.seed_base + n.seed_off;
         if (n.chain && !lead) {       // the only predecessor continues this band: column 0 reads its traceback byte like any column
             bemit(w, nodes, node, bop(mat), 1);
-            const uint32_t code = tbn[r - n.top];
+            const uint32_t code = code_at(0, r - n.top);
             if (mat == BM) {
                 if (r == 0) { mat = BIC; lead = true; r = -1; }
-                else { cur -= bsub(P, pb, seq[0], r); mat = code & 3u; --r; }
-            } else {
-                const uint32_t src = (code >> 4) & 3u;
-                cur += src == BIC ? ge : go; mat = src;
-            }
+                else { mat = code & 3u; --r; }
+            } else mat = (code >> 4) & 3u;
             node = seeds[0].node; j = nodes[node].len - 1;
             continue;
         }
@@ -336,6 +348,8 @@ VGK_HD void banded_walk_one(const BandedParams& P, uint32_t pi) {
         } else {
             bemit(w, nodes, node, bop(mat), 1);
             ms = mat == BM ? bsub(P, pb, seq[0], r) : 0;
+            // the value of the cell we stand on: the fill kept column 0 of M and Ic for exactly this
+            const int32_t cur = (last + n.last_off)[(mat == BM ? 3 : 4) * pb.Hpad + (r - n.top)];
             for (uint32_t si = 0; si < n.n_seeds && found < 0; ++si) {
                 const BNode s = nodes[seeds[si].node];
                 const int32_t snt = s.top + s.len, snb = s.bot + s.len;
@@ -363,13 +377,10 @@ VGK_HD void banded_walk_one(const BandedParams& P, uint32_t pi) {
         }
         const BSeed sr = seeds[found];
         for (uint32_t q = 0; q < sr.path_len; ++q) bemit(w, nodes, pool[sr.path_off + q], bop(mat), 0);
-        if (!lead) {        // the running score becomes the value of the predecessor's cell we step into
-            if (mat == BM) { cur -= ms; --r; }
-            else cur += fmat == BIC ? ge : go;
-            mat = fmat; lead = flead;
-        }
+        if (!lead) { if (mat == BM) --r; mat = fmat; lead = flead; }
         node = sr.node; j = nodes[node].len - 1;
     }
+    bflush(w);
     if (w.overflow && status == VGK_OK) status = VGK_EOPS;
     res.status = status;
     // pack the finished list behind the others: only what was written travels back to the host
