@@ -220,17 +220,21 @@ public:
         ms_bfill = ms_bwalk = 0.f;
         if (p.n == 0) return VGK_OK;
         hipEventRecord(bev[0], stream);
+        // the rows-per-lane classes are independent: the small ones run on the side streams under the big one
         for (uint32_t i = 0; i < n; ++i) {
             const BandedLaunch& L = launches[i];
             if (!L.count) continue;
+            hipStream_t st = (i == 0 || i > 2) ? stream : side[i - 1];
+            if (st != stream) hipStreamWaitEvent(st, bev[0], 0);
             switch (L.R) {
-                case 1:  launch_banded_fill<1>(p, L, stream); break;
-                case 2:  launch_banded_fill<2>(p, L, stream); break;
-                case 4:  launch_banded_fill<4>(p, L, stream); break;
-                case 8:  launch_banded_fill<8>(p, L, stream); break;
-                case 16: launch_banded_fill<16>(p, L, stream); break;
+                case 1:  launch_banded_fill<1>(p, L, st); break;
+                case 2:  launch_banded_fill<2>(p, L, st); break;
+                case 4:  launch_banded_fill<4>(p, L, st); break;
+                case 8:  launch_banded_fill<8>(p, L, st); break;
+                case 16: launch_banded_fill<16>(p, L, st); break;
                 default: return VGK_EINVAL;
             }
+            if (st != stream) { hipEventRecord(side_done[i - 1], st); hipStreamWaitEvent(stream, side_done[i - 1], 0); }
         }
         hipEventRecord(bev[1], stream);
         hipLaunchKernelGGL(banded_walk_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);

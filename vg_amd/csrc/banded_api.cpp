@@ -158,8 +158,11 @@ void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch&
                 nd.chain = sd.path_len == 0 && (int64_t)sd.node == prev_filled && top[v] == top[sd.node] + len[sd.node] && bot[v] == bot[sd.node] + len[sd.node];
             }
             prev_filled = v;
-            nd.tb_off = (uint32_t)tb_off; nd.last_off = (uint32_t)last_off;
-            tb_off += (uint64_t)len[v] * Hpad; last_off += 5ull * Hpad;
+            if (!nd.chain) for (uint32_t q = 0; q < n_seeds; ++q) T.nodes[keep_nodes + T.seeds[T.seeds.size() - 1 - q].node].keep_last = 1;
+            const uint32_t granule = std::max<uint32_t>(R, 4), H = (uint32_t)(bot[v] - top[v] + 1);
+            nd.stride = (H + granule - 1) / granule * granule;
+            nd.tb_off = (uint32_t)tb_off;
+            tb_off += (uint64_t)len[v] * nd.stride;
             if (tb_off > 0xfffffff0ull) { fail(VGK_ETOOBIG); return; }
         }
         T.nodes[keep_nodes + v] = nd;
@@ -189,6 +192,13 @@ void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch&
         }
     }
     hp.starts.len = (uint32_t)(T.starts.size() - hp.starts.off);
+    for (uint32_t q = 0; q < hp.starts.len; ++q) T.nodes[keep_nodes + T.starts[hp.starts.off + q]].keep_last = 1;
+    // last / first columns only where a traceback or a successor will read them
+    for (uint32_t v = 0; v < N; ++v) {
+        BNode& nd = T.nodes[keep_nodes + v];
+        if (nd.masked || nd.len == 0 || (nd.chain && !nd.keep_last)) continue;
+        nd.last_off = (uint32_t)last_off; last_off += 5ull * nd.stride;
+    }
     hp.tb_bytes = (tb_off + 255) & ~255ull; hp.last_elems = last_off;
     hp.ops_cap = (uint32_t)(L + total_bases + 2ull * N + 8);
     hp.on_device = true;

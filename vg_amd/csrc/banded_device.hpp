@@ -35,10 +35,14 @@ struct BNode {                 // one per graph node of a problem
     uint16_t n_seeds;
     uint8_t  as_source;        // no predecessor, or joined to a source through empty nodes (:301, :313-318)
     uint8_t  masked;
-    uint32_t tb_off;           // bytes, relative to the problem's tb_base: len columns of Hpad bytes
-    uint32_t last_off;         // int32 elements, relative to the problem's last_base: last column M | Ic | Ir, first column M | Ic, Hpad each
+    uint32_t tb_off;           // bytes, relative to the problem's tb_base: len columns of `stride` bytes
+    uint32_t last_off;         // int32 elements, relative to the problem's last_base: last column M | Ic | Ir, first column M | Ic,
+                               // `stride` each (only for nodes with keep_last / without chain)
+    uint32_t stride;           // band height rounded up to the store granule (4, or the rows per lane)
     uint32_t src_path_off;     // empty nodes between this node and the source it is joined to (relative to pool_base)
     uint32_t src_path_len;
+    uint32_t keep_last;        // 1: some traceback may examine this node's last column (it is a predecessor of a non-chain node,
+                               // or a candidate end node): store it
     uint32_t chain;            // 1: the only predecessor is the previous non-empty unmasked node in the order, reached directly, and the
                                // band is that node's band carried over: column 0 continues from the registers / traceback bytes
 };
@@ -151,7 +155,7 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
                 M[i] = nM[i]; Ic[i] = nIc[i]; Ir[i] = ir;
                 codes[i] = (uint8_t)(code_mc[i] | (cr << 2));
             }
-            store_codes<R>(tbn + (size_t)j * pb.Hpad + k0, codes);
+            if (k0 < (int32_t)nd.stride) store_codes<R>(tbn + (size_t)j * nd.stride + k0, codes);
         };
         // a column whose left neighbours are the registers: columns 1.. of a node (:492-590), and column 0 of a node whose
         // only predecessor is the node this wave has just finished, with the band carried straight over (BNode::chain)
@@ -208,11 +212,11 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
                             if (snt < 0) ir = bmax(ir, -2 * go - ext * ge);
                         } else {
                             const int32_t ks = r - snt;
-                            m = bmax(m, ms + bmax(bmax(sl[ks], sl[2 * pb.Hpad + ks]), sl[pb.Hpad + ks]));
+                            m = bmax(m, ms + bmax(bmax(sl[ks], sl[2 * sd.stride + ks]), sl[sd.stride + ks]));
                         }
                         if (r <= snb - 1) {
                             const int32_t ks = r - snt + 1;
-                            ic = bmax(ic, bmax(bmax(sl[ks] - go, sl[2 * pb.Hpad + ks] - go), sl[pb.Hpad + ks] - ge));
+                            ic = bmax(ic, bmax(bmax(sl[ks] - go, sl[2 * sd.stride + ks] - go), sl[sd.stride + ks] - ge));
                         }
                     }
                     if (nd.as_source) {
@@ -225,15 +229,17 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
             }
             finish_column(0, nM, nIc, ir0, code_mc);
             // the traceback re-examines the predecessors from this column (traceback_over_edge): keep its M and Ic
-            int32_t* nf = last + nd.last_off + 3 * pb.Hpad;
-            for (int i = 0; i < R; ++i) { nf[k0 + i] = M[i]; nf[pb.Hpad + k0 + i] = Ic[i]; }
+            int32_t* nf = last + nd.last_off + 3 * nd.stride;
+            for (int i = 0; i < R; ++i) if (k0 + i < (int32_t)nd.stride) { nf[k0 + i] = M[i]; nf[nd.stride + k0 + i] = Ic[i]; }
         }
         for (int32_t j = 1; j < nd.len; ++j) column(j);
         // ---- keep the last column for the successors and the traceback
-        int32_t* nl = last + nd.last_off;
-        for (int i = 0; i < R; ++i) {
-            const uint32_t k = lane * R + i;
-            nl[k] = M[i]; nl[pb.Hpad + k] = Ic[i]; nl[2 * pb.Hpad + k] = Ir[i];
+        if (nd.keep_last) {
+            int32_t* nl = last + nd.last_off;
+            for (int i = 0; i < R; ++i) {
+                const uint32_t k = lane * R + i;
+                if (k < nd.stride) { nl[k] = M[i]; nl[nd.stride + k] = Ic[i]; nl[2 * nd.stride + k] = Ir[i]; }
+            }
         }
         xl.fence();        // successors read these through memory
     }
@@ -283,7 +289,7 @@ VGK_HD void banded_walk_one(const BandedParams& P, uint32_t pi) {
         const int32_t k = (L - 1) - (n.len - 1) - n.top;
         if (k < 0 || k > n.bot - n.top) continue;
         const int32_t* nl = last + n.last_off;
-        const int32_t cand[3] = { nl[k], nl[2 * pb.Hpad + k], nl[pb.Hpad + k] };
+        const int32_t cand[3] = { nl[k], nl[2 * n.stride + k], nl[n.stride + k] };
         const uint32_t cmat[3] = { BM, BIR, BIC };
         for (int q = 0; q < 3; ++q) if (blive(cand[q]) && (!have || cand[q] > best)) { have = true; best = cand[q]; bnode = u; bmat = cmat[q]; bstart = c; }
     }
@@ -298,12 +304,12 @@ VGK_HD void banded_walk_one(const BandedParams& P, uint32_t pi) {
         const BNode n = nodes[node];
         const uint8_t* seq = P.graph + pb.graph_off + n.seq_off;
         const uint8_t* tbn = tb + n.tb_off;
-        // a run of matches walks up one band row: its bytes sit Hpad apart, so four of them are fetched at once
+        // a run of matches walks up one band row: its bytes sit one stride apart, so four of them are fetched at once
         int32_t ck = -1, cj = -1; uint32_t c4[4] = {0, 0, 0, 0};
         auto code_at = [&](int32_t jj, int32_t kk) -> uint32_t {
             if (kk != ck || jj > cj || jj <= cj - 4) {
                 ck = kk; cj = jj;
-                for (int q = 0; q < 4; ++q) c4[q] = jj - q >= 0 ? tbn[(size_t)(jj - q) * pb.Hpad + kk] : 0u;
+                for (int q = 0; q < 4; ++q) c4[q] = jj - q >= 0 ? tbn[(size_t)(jj - q) * n.stride + kk] : 0u;
             }
             return c4[cj - jj];
         };
@@ -349,7 +355,7 @@ VGK_HD void banded_walk_one(const BandedParams& P, uint32_t pi) {
             bemit(w, nodes, node, bop(mat), 1);
             ms = mat == BM ? bsub(P, pb, seq[0], r) : 0;
             // the value of the cell we stand on: the fill kept column 0 of M and Ic for exactly this
-            const int32_t cur = (last + n.last_off)[(mat == BM ? 3 : 4) * pb.Hpad + (r - n.top)];
+            const int32_t cur = (last + n.last_off)[(mat == BM ? 3 : 4) * n.stride + (r - n.top)];
             for (uint32_t si = 0; si < n.n_seeds && found < 0; ++si) {
                 const BNode s = nodes[seeds[si].node];
                 const int32_t snt = s.top + s.len, snb = s.bot + s.len;
@@ -357,10 +363,10 @@ VGK_HD void banded_walk_one(const BandedParams& P, uint32_t pi) {
                 const int32_t* sl = last + s.last_off;
                 if (mat == BM) {
                     if (r == 0) { if (cur == -go - (s.cum + s.len - 1) * ge + ms) { found = (int)si; fmat = BIC; flead = true; } continue; }
-                    const int src = bpick(sl, pb.Hpad, r - snt, cur, ms, ms, ms);
+                    const int src = bpick(sl, s.stride, r - snt, cur, ms, ms, ms);
                     if (src >= 0) { found = (int)si; fmat = (uint32_t)src; }
                 } else {
-                    const int src = bpick(sl, pb.Hpad, r - snt + 1, cur, -go, -ge, -go);
+                    const int src = bpick(sl, s.stride, r - snt + 1, cur, -go, -ge, -go);
                     if (src >= 0) { found = (int)si; fmat = (uint32_t)src; }
                 }
             }
