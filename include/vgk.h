@@ -198,6 +198,61 @@ int  vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t
  * 2 = band cells filled, 3 = algorithmic bytes */
 double vgk_banded_last(vgk_ctx* ctx, int which);
 
+/* ---- haplotype-consistent gapless extension (GaplessExtender, src/gbwt_extender.cpp:533-737) ---------
+ * Replaces GaplessExtender::extend(cluster, sequence, cache, max_mismatches, overlap_threshold, trim)
+ * (src/gbwt_extender.hpp:205): for every seed of a cluster the best gapless extension along the indexed haplotypes
+ * (best-first over `follow_paths`, mismatch limits :605-607 / :649-651), then either the non-overlapping full-length
+ * extensions or the trimmed, de-duplicated partial ones.
+ * The haplotype index stands in for the GBWTGraph the reference walks (gbwt / gbwtgraph are absent submodules): node
+ * sequences plus the threads as lists of oriented nodes (2 * node index + is_reverse).  Node indices must follow the
+ * order of the graph's node ids (the order of `follow_paths` is the order of the GBWT node encoding).  Threads must be
+ * acyclic as oriented-node sequences. */
+typedef struct vgk_haplotypes {
+    uint32_t        n_nodes;
+    const uint32_t* node_len;
+    const char*     seq;             /* forward strands of all nodes, concatenated */
+    uint32_t        n_threads;
+    const uint32_t* thread_off;      /* n_threads + 1 offsets into thread_nodes */
+    const uint32_t* thread_nodes;    /* oriented nodes along each thread */
+} vgk_haplotypes;
+typedef struct vgk_haplo vgk_haplo;  /* the index, resident in HBM */
+int  vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* haplotypes, vgk_haplo** out);
+void vgk_haplo_destroy(vgk_haplo* index);
+
+typedef struct vgk_seed {            /* GaplessExtender::seed_type (src/gbwt_extender.hpp:33): (handle, read_offset - node_offset) */
+    uint32_t node;                   /* oriented node */
+    int32_t  diff;
+} vgk_seed;
+#define VGK_GAPLESS_TRIM 1u          /* extend(..., trim = true) */
+typedef struct vgk_gapless_problem {
+    const char*     read;            /* masked by the engine like ReadMasker (:160-176): non-ACGT never matches */
+    uint32_t        read_len;
+    uint32_t        n_seeds;
+    const vgk_seed* seeds;           /* visited in this order (the reference iterates a hash set: order unpinned) */
+    uint32_t        max_mismatches;  /* GaplessExtender::MAX_MISMATCHES = 4 */
+    uint32_t        flags;
+    double          overlap_threshold;   /* GaplessExtender::OVERLAP_THRESHOLD = 0.8 */
+} vgk_gapless_problem;
+typedef struct vgk_extension {       /* GaplessExtension (src/gbwt_extender.hpp:30-90) */
+    uint32_t path_begin, path_len;   /* oriented nodes, in the `nodes` output array */
+    uint32_t offset;                 /* in the first node */
+    uint32_t read_begin, read_end;   /* read_interval */
+    uint32_t mism_begin, n_mismatches;   /* mismatch_positions, in the `mismatches` output array */
+    int32_t  score;
+    uint8_t  left_full, right_full, pad[2];
+    uint32_t state[6];               /* forward node, range first, last; backward node, range first, last */
+} vgk_extension;
+typedef struct vgk_gapless_result {
+    int32_t  status;
+    uint32_t ext_begin, n_ext;       /* in the `extensions` output array */
+    uint32_t full_length;            /* GaplessExtender::full_length_extensions() of the set */
+} vgk_gapless_result;
+int  vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_problem* problems, uint32_t n,
+                        vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
+                        uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap,
+                        size_t written[3] /* extensions, nodes, mismatches */);
+double vgk_gapless_last_ms(vgk_ctx* ctx);    /* kernel time of the last vgk_gapless_extend call on this context */
+
 /* batch introspection (used by bench.py for the roofline line) */
 void     vgk_batch_free(vgk_batch* batch);
 int      vgk_batch_sync(vgk_batch* batch);

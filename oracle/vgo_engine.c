@@ -21,6 +21,12 @@ int vgo_xdrop_pinned_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, cons
 int vgo_banded_align(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_banded_problem* p,
                      vgk_result* res, vgk_op* ops, uint32_t ops_cap);
 
+int vgo_haplo_create(const vgk_haplotypes* d, vgk_haplo** out);
+void vgo_haplo_destroy(vgk_haplo* h);
+int vgo_gapless_extend(const vgk_scoring* sc, const vgk_haplo* h, const vgk_gapless_problem* p, vgk_gapless_result* res,
+                       vgk_extension* ext_out, uint32_t ext_cap, uint32_t* nodes_out, uint32_t nodes_cap,
+                       uint32_t* mism_out, uint32_t mism_cap, uint32_t* n_nodes_out, uint32_t* n_mism_out);
+
 struct vgk_ctx { vgk_scoring sc; int has_qa; vgk_qual_adj qa; int8_t qmat[256 * 25]; int8_t qbon[256]; };
 
 static int vgo_dispatch(const vgk_ctx* c, const vgk_gssw_problem* p, vgk_result* res, vgk_op* ops, uint32_t ops_cap) {
@@ -164,6 +170,28 @@ int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t 
     return rc;
 }
 double vgk_banded_last(vgk_ctx* ctx, int which) { (void)ctx; (void)which; return 0.0; }
+
+int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* haplotypes, vgk_haplo** out) { (void)ctx; return vgo_haplo_create(haplotypes, out); }
+void vgk_haplo_destroy(vgk_haplo* index) { vgo_haplo_destroy(index); }
+double vgk_gapless_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }
+int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_problem* problems, uint32_t n,
+                       vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
+                       uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) {
+    if (!ctx || !index || (!problems && n) || (!results && n)) return VGK_EINVAL;
+    size_t ne = 0, nn = 0, nm = 0; int rc = VGK_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t wn = 0, wm = 0;
+        const size_t ce = ext_cap - ne, cn = nodes_cap - nn, cm = mism_cap - nm;
+        int r = vgo_gapless_extend(&ctx->sc, index, &problems[i], &results[i], extensions + ne, ce > 0xffffffffu ? 0xffffffffu : (uint32_t)ce,
+                                   nodes + nn, cn > 0xffffffffu ? 0xffffffffu : (uint32_t)cn, mismatches + nm, cm > 0xffffffffu ? 0xffffffffu : (uint32_t)cm, &wn, &wm);
+        if (r == VGK_EOPS) rc = VGK_EOPS;
+        results[i].ext_begin = (uint32_t)ne;
+        for (uint32_t k = 0; k < results[i].n_ext; ++k) { extensions[ne + k].path_begin += (uint32_t)nn; extensions[ne + k].mism_begin += (uint32_t)nm; }
+        ne += results[i].n_ext; nn += wn; nm += wm;
+    }
+    if (written) { written[0] = ne; written[1] = nn; written[2] = nm; }
+    return rc;
+}
 
 void vgk_batch_free(vgk_batch* b) { if (b) { free(b->res); free(b->ops); free(b); } }
 int  vgk_batch_sync(vgk_batch* b) { (void)b; return VGK_OK; }

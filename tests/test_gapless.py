@@ -1,0 +1,229 @@
+"""Haplotype-consistent gapless extension: the oracle against the reference's known-answer tests
+(src/unittest/gbwt_extender.cpp:868-1158, transcribed by hand below with their line numbers)."""
+import numpy as np
+import pytest
+
+import util
+from vg_amd import capi
+
+# the toy graph GA(T|GGG)TA(C|A)A and its three threads (src/unittest/gbwt_extender.cpp:31-92)
+TOY_NODES = ["G", "A", "T", "GGG", "T", "A", "C", "A", "A"]          # ids 1..9
+ALT_PATH = [1, 2, 4, 5, 6, 8, 9]
+SHORT_PATH = [1, 4, 5, 6, 7, 9]
+
+
+def oriented(node_id, is_reverse=False):
+    return 2 * (node_id - 1) + int(is_reverse)
+
+
+def toy_index(eng):
+    threads = [[oriented(i) for i in t] for t in (SHORT_PATH, ALT_PATH, SHORT_PATH)]
+    return eng.haplo_index(TOY_NODES, threads)
+
+
+def seed(pos, read_offset):
+    node_id, is_reverse, offset = pos
+    return (oriented(node_id, is_reverse), read_offset - offset)      # GaplessExtender::to_seed (gbwt_extender.hpp:160-163)
+
+
+def extension_as_mappings(read, e, nodes, mism, node_seqs):
+    """GaplessExtension::to_path (src/gbwt_extender.cpp:105-151) in the tests' notation: [((id, rev, offset), edits)] with
+    edits like "1A1" = 1 match, mismatch to read base A, 1 match."""
+    out = []
+    ro = int(e["read_begin"]); no = int(e["offset"])
+    mm = list(mism[e["mism_begin"]:e["mism_begin"] + e["n_mismatches"]])
+    for k in range(e["path_len"]):
+        o = int(nodes[e["path_begin"] + k])
+        ln = len(node_seqs[o // 2])
+        limit = min(ro + ln - no, int(e["read_end"]))
+        edits = ""
+        while mm and mm[0] < limit:
+            if ro < mm[0]:
+                edits += str(mm[0] - ro)
+            edits += read[mm[0]]
+            ro = mm[0] + 1; mm.pop(0)
+        if ro < limit:
+            edits += str(limit - ro); ro = limit
+        out.append(((o // 2 + 1, bool(o & 1), no), edits))
+        no = 0
+    return out
+
+
+def correct_score(e, match=1, mismatch=4, bonus=5):                   # (:124-130)
+    n = int(e["read_end"] - e["read_begin"]); m = int(e["n_mismatches"])
+    return (n - m) * match - m * mismatch + (int(e["left_full"]) + int(e["right_full"])) * bonus
+
+
+def run(eng, index, seeds, read, error_bound, overlap_threshold=0.8):
+    problem = dict(read=read, seeds=[seed(p, r) for p, r in seeds], max_mismatches=error_bound, overlap_threshold=overlap_threshold)
+    res, ext, nodes, mism = eng.gapless_extend(index, [problem])
+    assert res["status"][0] == 0
+    return [ext[i] for i in range(res["ext_begin"][0], res["ext_begin"][0] + res["n_ext"][0])], nodes, mism
+
+
+def full_length_match(eng, index, seeds, read, correct, error_bound):            # (:499-527)
+    exts, nodes, mism = run(eng, index, seeds, read, error_bound)
+    if not correct:
+        for e in exts:
+            if e["left_full"] and e["right_full"]:
+                assert e["n_mismatches"] > error_bound
+        return
+    assert len(exts) == 1
+    e = exts[0]
+    assert e["read_end"] > e["read_begin"] and e["left_full"] and e["right_full"] and e["n_mismatches"] <= error_bound
+    assert e["score"] == correct_score(e)
+    assert extension_as_mappings(read, e, nodes, mism, TOY_NODES) == correct
+
+
+def full_length_matches(eng, index, seeds, read, corrects, error_bound, overlap_threshold):   # (:529-544)
+    exts, nodes, mism = run(eng, index, seeds, read, error_bound, overlap_threshold)
+    assert len(exts) == len(corrects)
+    for e, c in zip(exts, corrects):
+        assert e["left_full"] and e["right_full"] and e["n_mismatches"] <= error_bound
+        assert e["score"] == correct_score(e)
+        assert extension_as_mappings(read, e, nodes, mism, TOY_NODES) == c
+
+
+def partial_matches(eng, index, seeds, read, corrects, offsets, error_bound, node_seqs=TOY_NODES):   # (:546-564)
+    exts, nodes, mism = run(eng, index, seeds, read, error_bound)
+    assert len(exts) == len(corrects)
+    for e, c, off in zip(exts, corrects, offsets):
+        assert e["read_end"] > e["read_begin"]
+        if e["left_full"] and e["right_full"]:
+            assert e["n_mismatches"] > error_bound
+        assert e["read_begin"] == off
+        assert e["score"] == correct_score(e)
+        assert extension_as_mappings(read, e, nodes, mism, node_seqs) == c
+
+
+def reference_gapless_cases(eng):
+    index = toy_index(eng)
+    F, T = False, True
+    # "Full-length alignments" (:868-1001)
+    full_length_match(eng, index, [((4, F, 2), 0), ((6, F, 0), 2)], "GTACA",                                         # :880
+                      [((4, F, 2), "1"), ((5, F, 0), "1"), ((6, F, 0), "1"), ((7, F, 0), "1"), ((9, F, 0), "1")], 0)
+    errors = [((1, F, 0), "1"), ((4, F, 0), "1A1"), ((5, F, 0), "1"), ((6, F, 0), "1"), ((7, F, 0), "1")]
+    full_length_match(eng, index, [((5, F, 0), 4), ((4, F, 2), 3)], "GGAGTAC", errors, 1)                            # :897
+    full_length_match(eng, index, [((5, F, 0), 4), ((4, F, 2), 3), ((2, F, 0), 0)], "GGAGTAC", errors, 1)            # :914
+    full_length_match(eng, index, [((5, T, 0), 2), ((6, T, 0), 1)], "GTACT",                                         # :932
+                      [((7, T, 0), "1"), ((6, T, 0), "1"), ((5, T, 0), "1"), ((4, T, 0), "1T")], 1)
+    full_length_match(eng, index, [((5, F, 0), 4), ((4, F, 2), 3)], "AGAGTAC", [], 1)                                # :948
+    seeds = [((2, F, 0), 1), ((4, F, 0), 2), ((4, F, 0), 1)]
+    best = [((1, F, 0), "1"), ((2, F, 0), "1"), ((4, F, 0), "2A")]
+    second = [((1, F, 0), "1"), ((4, F, 0), "A2"), ((5, F, 0), "A")]
+    full_length_matches(eng, index, seeds, "GAGGA", [best, second], 2, 0.9)                                          # :959
+    full_length_matches(eng, index, seeds, "GAGGA", [best], 2, 0.1)                                                  # :983
+    # "Local alignments" (:1005-1120)
+    partial_matches(eng, index, [((4, F, 0), 1), ((2, F, 0), 7), ((5, F, 0), 11), ((7, F, 0), 15), ((6, F, 0), 20)],  # :1017
+                    "AGGGxCGAGxGTAxACAAxTAA",
+                    [[((2, F, 0), "1"), ((4, F, 0), "3")],
+                     [((1, F, 0), "1"), ((2, F, 0), "1"), ((4, F, 0), "1")],
+                     [((4, F, 2), "1"), ((5, F, 0), "1"), ((6, F, 0), "1")],
+                     [((6, F, 0), "1"), ((7, F, 0), "1"), ((9, F, 0), "1")],
+                     [((5, F, 0), "1"), ((6, F, 0), "1"), ((8, F, 0), "1")]],
+                    [0, 6, 10, 14, 19], 0)
+    partial_matches(eng, index, [((4, F, 2), 4)], "xAGxGTAx", [[((4, F, 2), "1"), ((5, F, 0), "1"), ((6, F, 0), "1")]], [4], 0)   # :1063
+    trimmed = [[((2, F, 0), "1"), ((4, F, 0), "3"), ((5, F, 0), "1")]]
+    partial_matches(eng, index, [((4, F, 2), 4)], "xAGGGTxAx", trimmed, [1], 1)                                      # :1082
+    partial_matches(eng, index, [((2, F, 0), 1), ((4, F, 2), 4)], "xAGGGTxAx", trimmed, [1], 1)                      # :1101
+    # "Non-ACGT characters do not match" (:1124-1156)
+    one = eng.haplo_index(["NNNGATTACANNN"], [[0]])
+    partial_matches(eng, one, [((1, F, 5), 4)], "NNGATTACANN", [[((1, F, 3), "7")]], [2], 0, node_seqs=["NNNGATTACANNN"])
+
+
+def test_oracle_matches_reference_gapless_extender_unit_tests():
+    reference_gapless_cases(capi.Engine(lib=util.ORACLE_LIB))
+
+
+# ---- random haplotype graphs: the engine against the oracle ----------------------------------------------------------
+
+def random_haplotype_case(rng, n_reads=40, n_haplotypes=4, chain_nodes=14):
+    """A bubble chain with n_haplotypes random threads; reads sampled from a thread (either strand) with substitutions;
+    seeds at true positions plus a few false ones."""
+    bases = "ACGT"
+    nodes, chain, bubbles = [], [], []
+    for c in range(chain_nodes):
+        nodes.append("".join(bases[i] for i in rng.integers(0, 4, int(rng.integers(3, 12)))))
+        chain.append(len(nodes) - 1)
+        if c + 1 < chain_nodes and rng.random() < 0.6:
+            alts = []
+            for _ in range(int(rng.integers(2, 4))):
+                nodes.append("".join(bases[i] for i in rng.integers(0, 4, int(rng.integers(1, 4)))))
+                alts.append(len(nodes) - 1)
+            if rng.random() < 0.3:
+                alts.append(None)                      # a deletion allele: skip the bubble
+            bubbles.append(alts)
+        else:
+            bubbles.append(None)
+    threads = []
+    for _ in range(n_haplotypes):
+        t = []
+        first = int(rng.integers(0, 3)); last = chain_nodes - int(rng.integers(0, 3))
+        for c in range(first, last):
+            t.append(2 * chain[c])
+            if c + 1 < last and bubbles[c]:
+                a = bubbles[c][int(rng.integers(0, len(bubbles[c])))]
+                if a is not None:
+                    t.append(2 * a)
+        threads.append(t)
+
+    def comp(s):
+        return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+    problems = []
+    for _ in range(n_reads):
+        t = threads[int(rng.integers(0, len(threads)))]
+        if rng.random() < 0.5:
+            t = [o ^ 1 for o in reversed(t)]
+        seq = "".join(nodes[o // 2] if not o & 1 else comp(nodes[o // 2]) for o in t)
+        starts = np.cumsum([0] + [len(nodes[o // 2]) for o in t])
+        L = int(rng.integers(5, min(60, len(seq)) + 1)); a = int(rng.integers(0, len(seq) - L + 1))
+        read = list(seq[a:a + L])
+        for k in range(L):
+            r = rng.random()
+            if r < 0.06:
+                read[k] = bases[int(rng.integers(0, 4))]
+            elif r < 0.07:
+                read[k] = "N"
+        seeds = []
+        for _ in range(int(rng.integers(1, 6))):
+            ro = int(rng.integers(0, L)); g = a + ro
+            k = int(np.searchsorted(starts, g, side="right") - 1)
+            seeds.append((t[k], ro - (g - int(starts[k]))))
+        if rng.random() < 0.3:                          # a false seed
+            o = int(rng.integers(0, 2 * len(nodes)))
+            seeds.append((o, int(rng.integers(0, L)) - int(rng.integers(0, len(nodes[o // 2])))))
+        seeds = list(dict.fromkeys(seeds))              # a cluster is a set
+        problems.append(dict(read="".join(read), seeds=seeds, max_mismatches=int(rng.integers(0, 5)),
+                             overlap_threshold=float(rng.choice([0.1, 0.8, 0.9])), trim=bool(rng.random() < 0.8)))
+    return nodes, threads, problems
+
+
+def compare_engines(lib, seeds, n_reads=40):
+    ora = capi.Engine(lib=util.ORACLE_LIB); eng = capi.Engine(lib=lib) if lib else capi.Engine()
+    total = 0; full = 0
+    for s in seeds:
+        rng = np.random.default_rng(s)
+        nodes, threads, problems = random_haplotype_case(rng, n_reads=n_reads)
+        a = ora.gapless_extend(ora.haplo_index(nodes, threads), problems)
+        b = eng.gapless_extend(eng.haplo_index(nodes, threads), problems)
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and len(x) == len(y) and (x == y).all(), (s, x[:3], y[:3])
+        assert (a[0]["status"] == 0).all()
+        total += int(a[0]["n_ext"].sum()); full += int(a[0]["full_length"].sum())
+    return total, full
+
+
+def test_emulated_gapless_kernel_matches_reference_unit_tests_and_oracle():
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    reference_gapless_cases(capi.Engine(lib=util.EMU_LIB))
+    total, full = compare_engines(util.EMU_LIB, range(100, 140))
+    assert total > 1500 and full > 300
+
+
+@pytest.mark.gpu
+def test_hip_gapless_matches_reference_unit_tests_and_oracle():
+    reference_gapless_cases(capi.Engine())
+    total, full = compare_engines(None, range(200, 260), n_reads=400)
+    assert total > 20000 and full > 4000

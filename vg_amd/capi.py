@@ -32,6 +32,15 @@ OP_DT = np.dtype([("node", "<u4"), ("len", "<u2"), ("op", "u1"), ("pad", "u1")])
 BANDED_DT = np.dtype([("read", "<u8"), ("qual", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), ("graph", GRAPH_DT),
                       ("band_padding", "<i4"), ("reserved", "<u4"), ("max_cells", "<u8")])
 VGK_BANDED_PERMISSIVE = 1
+SEED_DT = np.dtype([("node", "<u4"), ("diff", "<i4")])
+GAPLESS_DT = np.dtype([("read", "<u8"), ("read_len", "<u4"), ("n_seeds", "<u4"), ("seeds", "<u8"), ("max_mismatches", "<u4"),
+                       ("flags", "<u4"), ("overlap_threshold", "<f8")])
+EXT_DT = np.dtype([("path_begin", "<u4"), ("path_len", "<u4"), ("offset", "<u4"), ("read_begin", "<u4"), ("read_end", "<u4"),
+                   ("mism_begin", "<u4"), ("n_mismatches", "<u4"), ("score", "<i4"), ("left_full", "u1"), ("right_full", "u1"),
+                   ("pad", "u1", 2), ("state", "<u4", 6)])
+GAPLESS_RESULT_DT = np.dtype([("status", "<i4"), ("ext_begin", "<u4"), ("n_ext", "<u4"), ("full_length", "<u4")])
+VGK_GAPLESS_TRIM = 1
+assert GAPLESS_DT.itemsize == 40 and EXT_DT.itemsize == 60 and GAPLESS_RESULT_DT.itemsize == 16
 assert BANDED_DT.itemsize == 80
 assert GRAPH_DT.itemsize == 40 and PROBLEM_DT.itemsize == 80 and RESULT_DT.itemsize == 32 and OP_DT.itemsize == 8
 
@@ -49,6 +58,11 @@ class Scoring(ctypes.Structure):
             s.matrix[i] = 0 if (r == 4 or c == 4) else (match if r == c else -mismatch)
         s.gap_open, s.gap_extend, s.full_length_bonus = gap_open, gap_extend, bonus
         return s
+
+
+class Haplotypes(ctypes.Structure):
+    _fields_ = [("n_nodes", ctypes.c_uint32), ("node_len", ctypes.c_void_p), ("seq", ctypes.c_void_p),
+                ("n_threads", ctypes.c_uint32), ("thread_off", ctypes.c_void_p), ("thread_nodes", ctypes.c_void_p)]
 
 
 class QualAdj(ctypes.Structure):
@@ -82,6 +96,9 @@ def load_library(path=None):
     lib.vgk_batch_kernel_ms.restype = ctypes.c_double
     lib.vgk_batch_kernel_ms.argtypes = [vp, ctypes.c_int]
     lib.vgk_banded_align.argtypes = [vp, vp, u32, vp, vp, sz, ctypes.POINTER(sz)]
+    lib.vgk_haplo_create.argtypes = [vp, ctypes.POINTER(Haplotypes), ctypes.POINTER(vp)]
+    lib.vgk_haplo_destroy.argtypes = [vp]
+    lib.vgk_gapless_extend.argtypes = [vp, vp, vp, u32, vp, vp, sz, vp, sz, vp, sz, ctypes.POINTER(sz * 3)]
     lib.vgk_banded_last.restype = ctypes.c_double
     lib.vgk_banded_last.argtypes = [vp, ctypes.c_int]
     for f in ("vgk_batch_cells", "vgk_batch_alg_bytes", "vgk_batch_device_bytes"):
@@ -250,6 +267,64 @@ class Engine:
 
     def banded_last(self, which):
         return self.lib.vgk_banded_last(self.h, which)
+
+    def haplo_index(self, nodes, threads):
+        """nodes: [str] in node-id order; threads: [[oriented node = 2 * index + is_reverse]].  -> HaploIndex"""
+        return HaploIndex(self, nodes, threads)
+
+    def gapless_extend(self, index, problems):
+        """problems: list of dicts {read, seeds: [(oriented node, read_offset - node_offset)], max_mismatches?, overlap_threshold?,
+        trim?}.  -> (results, extensions, nodes, mismatches) as numpy arrays laid out like include/vgk.h."""
+        n = len(problems)
+        reads = [np.frombuffer(p["read"].encode(), dtype=np.uint8) for p in problems]
+        read_off = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+        read_buf = np.concatenate(reads) if n and read_off[-1] else np.zeros(1, np.uint8)
+        seed_off = np.concatenate([[0], np.cumsum([len(p["seeds"]) for p in problems])]).astype(np.int64)
+        seeds = np.zeros(max(int(seed_off[-1]), 1), dtype=SEED_DT)
+        k = 0
+        for p in problems:
+            for node, diff in p["seeds"]:
+                seeds[k] = (node, diff); k += 1
+        arr = np.zeros(n, dtype=GAPLESS_DT)
+        arr["read"] = read_buf.ctypes.data + read_off[:-1]
+        arr["read_len"] = np.diff(read_off)
+        arr["n_seeds"] = np.diff(seed_off)
+        arr["seeds"] = seeds.ctypes.data + 8 * seed_off[:-1]
+        arr["max_mismatches"] = [p.get("max_mismatches", 4) for p in problems]
+        arr["flags"] = [VGK_GAPLESS_TRIM if p.get("trim", True) else 0 for p in problems]
+        arr["overlap_threshold"] = [p.get("overlap_threshold", 0.8) for p in problems]
+        res = np.zeros(n, dtype=GAPLESS_RESULT_DT)
+        ext_cap = int(seed_off[-1]) + 1
+        node_cap = int(sum(len(p["seeds"]) * (len(p["read"]) + 2) for p in problems)) + 1
+        mism_cap = int(sum(len(p["seeds"]) * len(p["read"]) for p in problems)) + 1
+        ext = np.zeros(ext_cap, dtype=EXT_DT); nodes = np.zeros(node_cap, dtype=np.uint32); mism = np.zeros(mism_cap, dtype=np.uint32)
+        written = (ctypes.c_size_t * 3)()
+        self._check(self.lib.vgk_gapless_extend(self.h, index.h, arr.ctypes.data, n, res.ctypes.data, ext.ctypes.data, ext_cap,
+                                                nodes.ctypes.data, node_cap, mism.ctypes.data, mism_cap, ctypes.byref(written)),
+                    "vgk_gapless_extend")
+        return res, ext[:written[0]], nodes[:written[1]], mism[:written[2]]
+
+
+class HaploIndex:
+    """The haplotype index the gapless extender walks (stands in for vg's GBWTGraph)."""
+
+    def __init__(self, eng, nodes, threads):
+        self.eng = eng
+        self.nodes = list(nodes)
+        self._len = np.array([len(s) for s in nodes], dtype=np.uint32)
+        self._seq = np.frombuffer("".join(nodes).encode(), dtype=np.uint8).copy()
+        self._toff = np.concatenate([[0], np.cumsum([len(t) for t in threads])]).astype(np.uint32)
+        self._tn = np.array([o for t in threads for o in t] or [0], dtype=np.uint32)
+        d = Haplotypes(len(nodes), self._len.ctypes.data, self._seq.ctypes.data, len(threads), self._toff.ctypes.data, self._tn.ctypes.data)
+        h = ctypes.c_void_p()
+        eng._check(eng.lib.vgk_haplo_create(eng.h, ctypes.byref(d), ctypes.byref(h)), "vgk_haplo_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.eng.lib.vgk_haplo_destroy(self.h); self.h = None
+
+    __del__ = close
 
 
 class Batch:

@@ -8,6 +8,7 @@
 #include <string>
 #include "gssw_device.hpp"
 #include "banded_device.hpp"
+#include "gapless_device.hpp"
 
 namespace vgk {
 
@@ -35,6 +36,8 @@ public:
     // banded global alignment: one fill launch per rows-per-lane instantiation (one wavefront per problem), then one
     // traceback launch (one thread per problem) over p.n problems
     virtual int   run_banded(const BandedParams& p, const BandedLaunch* launches, uint32_t n_launches) = 0;
+    // gapless extension: `threads` resident threads (one scratch slab each) stride over p.n reads; last_ms(5) = kernel ms
+    virtual int   run_gapless(const GaplessParams& p, uint32_t threads) = 0;
 };
 
 // returns nullptr and sets err when the device cannot be used

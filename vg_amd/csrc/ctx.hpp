@@ -16,6 +16,7 @@ struct vgk_ctx {
     std::vector<int8_t> qmat, qbon;
     // last vgk_banded_align call: kernel times (ms), band cells, algorithmic bytes
     double banded_ms[2] = {0, 0}; uint64_t banded_cells = 0, banded_bytes = 0;
+    double gapless_ms = 0;         // kernel time of the last vgk_gapless_extend call
     // device scratch kept between vgk_banded_align calls (grow-only; released with the context)
     struct DevBuf { void* p = nullptr; uint64_t bytes = 0; };
     DevBuf scratch[16];

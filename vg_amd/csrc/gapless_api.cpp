@@ -1,0 +1,222 @@
+// gapless_api.cpp — vgk_haplo_create / vgk_gapless_extend: the host half of haplotype-consistent gapless extension.
+//
+// The index: what the reference gets from GBWTGraph (node sequences in both orientations + GBWT records) is built
+// here from the caller's threads in uncompressed form and kept in HBM.  The visits of an oriented node are laid down
+// in GBWT order — by (predecessor node, rank in the predecessor's record), threads that start at the node first in
+// thread order — by delivering every finished record to its successors, which needs the threads to be acyclic as
+// oriented-node sequences.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "ctx.hpp"
+
+using namespace vgk;
+
+struct vgk_haplo {
+    vgk_ctx* ctx = nullptr;
+    GIndex dev{};                       // device pointers
+    std::vector<void*> held;
+    uint32_t n_oriented = 0;
+    std::vector<uint32_t> len;          // host copy, for validation
+};
+
+namespace {
+
+char complement(char c) {
+    switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+                 case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a'; default: return c; }
+}
+template <class T> int put(vgk_haplo* h, const std::vector<T>& v, const T*& out) {
+    void* d = h->ctx->be->alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (!d) return VGK_ENOMEM;
+    h->held.push_back(d);
+    if (!v.empty()) { int rc = h->ctx->be->upload(d, v.data(), v.size() * sizeof(T)); if (rc) return rc; }
+    out = (const T*)d;
+    return VGK_OK;
+}
+struct Arrival { int32_t pred; uint32_t order, seq, pos; };
+
+}  // namespace
+
+extern "C" {
+
+int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
+    if (!ctx || !d || !out || !d->n_nodes || !d->node_len || !d->seq || (d->n_threads && (!d->thread_off || !d->thread_nodes))) return VGK_EINVAL;
+    *out = nullptr;
+    const uint32_t N = d->n_nodes, O = 2 * N, S = 2 * d->n_threads;
+    for (uint32_t t = 0; t < d->n_threads; ++t) for (uint32_t k = d->thread_off[t]; k < d->thread_off[t + 1]; ++k) if (d->thread_nodes[k] >= O) return VGK_EINVAL;
+    // both strands of every node
+    std::vector<uint32_t> len(O), seq_off(O);
+    uint64_t total = 0; for (uint32_t i = 0; i < N; ++i) total += d->node_len[i];
+    if (2 * total > 0xfffffff0ull) return VGK_ETOOBIG;
+    std::vector<char> seq(2 * total);
+    { uint32_t at = 0, rat = (uint32_t)total;
+      for (uint32_t i = 0; i < N; ++i) {
+          const uint32_t L = d->node_len[i];
+          len[2 * i] = len[2 * i + 1] = L; seq_off[2 * i] = at; seq_off[2 * i + 1] = rat;
+          for (uint32_t k = 0; k < L; ++k) { seq[at + k] = d->seq[at + k]; seq[rat + k] = complement(d->seq[at + L - 1 - k]); }
+          at += L; rat += L;
+      } }
+    // sequences: thread t forward = 2t, reverse complement = 2t + 1
+    std::vector<uint32_t> soff(S + 1, 0);
+    for (uint32_t t = 0; t < d->n_threads; ++t) { const uint32_t n = d->thread_off[t + 1] - d->thread_off[t]; soff[2 * t + 1] = soff[2 * t] + n; soff[2 * t + 2] = soff[2 * t + 1] + n; }
+    const uint32_t V = soff[S];
+    std::vector<int32_t> sn(V);
+    for (uint32_t t = 0; t < d->n_threads; ++t) {
+        const uint32_t n = d->thread_off[t + 1] - d->thread_off[t];
+        for (uint32_t k = 0; k < n; ++k) { const uint32_t o = d->thread_nodes[d->thread_off[t] + k]; sn[soff[2 * t] + k] = (int32_t)o; sn[soff[2 * t + 1] + (n - 1 - k)] = (int32_t)(o ^ 1u); }
+    }
+    std::vector<uint32_t> count(O, 0), body_off(O + 1, 0);
+    for (uint32_t i = 0; i < V; ++i) ++count[sn[i]];
+    for (uint32_t o = 0; o < O; ++o) body_off[o + 1] = body_off[o] + count[o];
+    std::vector<Arrival> arr(V);
+    std::vector<uint32_t> got(O, 0), queue;
+    for (uint32_t s = 0; s < S; ++s) if (soff[s + 1] > soff[s]) { const int32_t o = sn[soff[s]]; arr[body_off[o] + got[o]++] = {-1, s, s, 0}; }
+    uint32_t with_visits = 0;
+    for (uint32_t o = 0; o < O; ++o) { if (count[o]) ++with_visits; if (count[o] && got[o] == count[o]) queue.push_back(o); }
+    std::vector<int32_t> succ(V);
+    for (size_t qh = 0; qh < queue.size(); ++qh) {
+        const uint32_t o = queue[qh];
+        Arrival* a = arr.data() + body_off[o];
+        std::sort(a, a + count[o], [](const Arrival& x, const Arrival& y) { return x.pred != y.pred ? x.pred < y.pred : x.order < y.order; });
+        for (uint32_t i = 0; i < count[o]; ++i) {
+            const uint32_t slen = soff[a[i].seq + 1] - soff[a[i].seq];
+            const int32_t w = a[i].pos + 1 < slen ? sn[soff[a[i].seq] + a[i].pos + 1] : -1;
+            succ[body_off[o] + i] = w;
+            if (w < 0) continue;
+            arr[body_off[w] + got[w]++] = {(int32_t)o, i, a[i].seq, a[i].pos + 1};
+            if (got[w] == count[w]) queue.push_back((uint32_t)w);
+        }
+    }
+    if (queue.size() != with_visits) return VGK_EINVAL;                     // a cycle among the threads
+    std::vector<uint32_t> edge_off(O + 1, 0), body(V), edge_base;
+    std::vector<int32_t> edge_to;
+    for (uint32_t o = 0; o < O; ++o) {
+        std::vector<int32_t> e(succ.begin() + body_off[o], succ.begin() + body_off[o + 1]);
+        std::sort(e.begin(), e.end()); e.erase(std::unique(e.begin(), e.end()), e.end());
+        for (uint32_t i = 0; i < count[o]; ++i) body[body_off[o] + i] = (uint32_t)(std::lower_bound(e.begin(), e.end(), succ[body_off[o] + i]) - e.begin());
+        edge_to.insert(edge_to.end(), e.begin(), e.end());
+        edge_off[o + 1] = (uint32_t)edge_to.size();
+    }
+    edge_base.assign(edge_to.size() + 1, 0);
+    for (uint32_t w = 0; w < O; ++w) {
+        const Arrival* a = arr.data() + body_off[w];
+        for (uint32_t i = 0; i < count[w]; ++i) if (a[i].pred >= 0 && (!i || a[i - 1].pred != a[i].pred)) {
+            const uint32_t o = (uint32_t)a[i].pred;
+            const int32_t* first = edge_to.data() + edge_off[o]; const int32_t* last = edge_to.data() + edge_off[o + 1];
+            edge_base[(uint32_t)(std::lower_bound(first, last, (int32_t)w) - edge_to.data())] = i;
+        }
+    }
+    vgk_haplo* h = new vgk_haplo();
+    h->ctx = ctx; h->n_oriented = O; h->len = len;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    int rc;
+    h->dev.n_oriented = O;
+    if ((rc = put(h, len, h->dev.len)) || (rc = put(h, seq_off, h->dev.seq_off)) || (rc = put(h, seq, h->dev.seq)) || (rc = put(h, count, h->dev.count)) ||
+        (rc = put(h, edge_off, h->dev.edge_off)) || (rc = put(h, edge_to, h->dev.edge_to)) || (rc = put(h, edge_base, h->dev.edge_base)) ||
+        (rc = put(h, body_off, h->dev.body_off)) || (rc = put(h, body, h->dev.body)) || (rc = ctx->be->sync())) {
+        for (void* p : h->held) ctx->be->release(p);
+        delete h; return rc;
+    }
+    *out = h;
+    return VGK_OK;
+}
+
+void vgk_haplo_destroy(vgk_haplo* h) {
+    if (!h) return;
+    { std::lock_guard<std::mutex> lock(h->ctx->mu); for (void* p : h->held) h->ctx->be->release(p); }
+    delete h;
+}
+
+int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_problem* problems, uint32_t n,
+                       vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
+                       uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) {
+    if (!ctx || !index || index->ctx != ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
+    if (written) written[0] = written[1] = written[2] = 0;
+    if (!n) return VGK_OK;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    Backend* be = ctx->be.get();
+    // pack: masked reads (ReadMasker, src/gbwt_extender.cpp:160-176), seeds
+    std::vector<GProb> probs(n);
+    uint64_t n_read = 0, n_seed = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const vgk_gapless_problem& p = problems[i];
+        if ((p.read_len && !p.read) || (p.n_seeds && !p.seeds)) return VGK_EINVAL;
+        probs[i] = {(uint32_t)n_read, p.read_len, (uint32_t)n_seed, p.n_seeds, p.max_mismatches, p.flags, p.overlap_threshold};
+        n_read += p.read_len; n_seed += p.n_seeds;
+        if (n_read > 0xfffffff0ull || n_seed > 0xfffffff0ull) return VGK_ETOOBIG;
+    }
+    std::vector<char> reads(n_read + 1); std::vector<vgk_seed> seeds(n_seed + 1);
+    for (uint32_t i = 0; i < n; ++i) {
+        const vgk_gapless_problem& p = problems[i];
+        char* r = reads.data() + probs[i].read_off;
+        for (uint32_t k = 0; k < p.read_len; ++k) { const char c = p.read[k]; r[k] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'X'; }
+        if (p.n_seeds) std::memcpy(seeds.data() + probs[i].seed_off, p.seeds, sizeof(vgk_seed) * p.n_seeds);
+    }
+    std::vector<void*> held;
+    auto cleanup = [&](int rc) { for (void* d : held) be->release(d); return rc; };
+    auto dev = [&](const void* src, size_t bytes) -> void* {
+        void* d = be->alloc(std::max<size_t>(bytes, 16)); if (!d) return nullptr; held.push_back(d);
+        if (src && bytes && be->upload(d, src, bytes)) return nullptr;
+        return d;
+    };
+    GaplessParams P{};
+    P.index = index->dev; P.n = n;
+    P.probs = (const GProb*)dev(probs.data(), sizeof(GProb) * n);
+    P.reads = (const char*)dev(reads.data(), reads.size());
+    P.seeds = (const vgk_seed*)dev(seeds.data(), sizeof(vgk_seed) * seeds.size());
+    P.match = ctx->sc.matrix[0]; P.mismatch = -ctx->sc.matrix[1]; P.bonus = ctx->sc.full_length_bonus;
+    // dense outputs: at most one extension per seed; nodes / mismatches sized generously and checked on the device
+    const uint64_t cap_e = n_seed + 1, cap_n = std::min<uint64_t>(n_seed * G_PATH, std::max<uint64_t>(n_seed * 16 + 1024, nodes_cap)) + 1,
+                   cap_m = std::min<uint64_t>(n_seed * G_MISM, std::max<uint64_t>(n_seed * 8 + 1024, mism_cap)) + 1;
+    P.caps[0] = cap_e; P.caps[1] = cap_n; P.caps[2] = cap_m;
+    const uint32_t threads = (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max(1, be->compute_units()) * 256);      // resident threads = scratch slabs
+    P.scratch = (GScratch*)dev(nullptr, sizeof(GScratch) * (size_t)threads);
+    P.results = (vgk_gapless_result*)dev(nullptr, sizeof(vgk_gapless_result) * n);
+    P.ext = (vgk_extension*)dev(nullptr, sizeof(vgk_extension) * cap_e);
+    P.nodes = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_n);
+    P.mism = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_m);
+    P.counters = (unsigned long long*)dev(nullptr, 64);
+    if (!P.probs || !P.reads || !P.seeds || !P.scratch || !P.results || !P.ext || !P.nodes || !P.mism || !P.counters) return cleanup(VGK_ENOMEM);
+    int rc;
+    if ((rc = be->zero(P.counters, 64))) return cleanup(rc);
+    if ((rc = be->run_gapless(P, threads))) return cleanup(rc);
+    unsigned long long counters[3] = {0, 0, 0};
+    std::vector<vgk_gapless_result> dres(n);
+    if ((rc = be->download(counters, P.counters, sizeof counters))) return cleanup(rc);
+    if ((rc = be->download(dres.data(), P.results, sizeof(vgk_gapless_result) * n))) return cleanup(rc);
+    const uint64_t ne = std::min<uint64_t>(counters[0], cap_e), nn = std::min<uint64_t>(counters[1], cap_n), nm = std::min<uint64_t>(counters[2], cap_m);
+    std::vector<vgk_extension> dext(ne + 1); std::vector<uint32_t> dnodes(nn + 1), dmism(nm + 1);
+    if (ne && (rc = be->download(dext.data(), P.ext, sizeof(vgk_extension) * ne))) return cleanup(rc);
+    if (nn && (rc = be->download(dnodes.data(), P.nodes, sizeof(uint32_t) * nn))) return cleanup(rc);
+    if (nm && (rc = be->download(dmism.data(), P.mism, sizeof(uint32_t) * nm))) return cleanup(rc);
+    ctx->gapless_ms = be->last_ms(5);
+    // the device packs sets in completion order; hand them back in problem order
+    size_t we = 0, wn = 0, wm = 0; int rc_all = VGK_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        vgk_gapless_result r = dres[i];
+        const uint32_t src = r.ext_begin;
+        r.ext_begin = (uint32_t)we;
+        if (r.status == VGK_OK) {
+            size_t need_n = 0, need_m = 0;
+            for (uint32_t k = 0; k < r.n_ext; ++k) { need_n += dext[src + k].path_len; need_m += dext[src + k].n_mismatches; }
+            if (we + r.n_ext > ext_cap || wn + need_n > nodes_cap || wm + need_m > mism_cap || !extensions || !nodes || !mismatches) { r.status = VGK_EOPS; r.n_ext = 0; rc_all = VGK_EOPS; }
+            else for (uint32_t k = 0; k < r.n_ext; ++k) {
+                vgk_extension x = dext[src + k];
+                std::memcpy(nodes + wn, dnodes.data() + x.path_begin, sizeof(uint32_t) * x.path_len);
+                std::memcpy(mismatches + wm, dmism.data() + x.mism_begin, sizeof(uint32_t) * x.n_mismatches);
+                x.path_begin = (uint32_t)wn; x.mism_begin = (uint32_t)wm;
+                extensions[we++] = x; wn += x.path_len; wm += x.n_mismatches;
+            }
+        } else { r.n_ext = 0; if (r.status == VGK_EOPS) rc_all = VGK_EOPS; }
+        results[i] = r;
+    }
+    if (written) { written[0] = we; written[1] = wn; written[2] = wm; }
+    return cleanup(rc_all);
+}
+
+double vgk_gapless_last_ms(vgk_ctx* ctx) { return ctx ? ctx->gapless_ms : 0.0; }
+
+}  // extern "C"

@@ -1,0 +1,416 @@
+// gapless_device.hpp — haplotype-consistent gapless seed extension, one thread per read
+// (replaces GaplessExtender::extend of the reference's src/gbwt_extender.cpp:533-737 with its helpers
+// match_initial / match_forward / match_backward :213-296, set_score :201-209, handle_full_length :301-329,
+// remove_duplicates :332-365, find_mismatches :368-387, trim_mismatches :421-529).
+//
+// The haplotype index is resident in HBM in uncompressed form (per oriented node: visit count, outgoing edges in
+// node order with the rank offset into the successor's record, and per visit the edge it leaves through), which
+// turns GBWT's LF-mapping into a short scan over at most #haplotypes entries — a read-only, cache-friendly
+// gather instead of the CPU's compressed-record decode.  Everything a read needs while it is being extended
+// (the best-first queue, the tree of partial extensions, the per-seed winners) lives in a fixed scratch slab per
+// thread; finished extension sets are packed behind each other with atomic bumps.
+//
+// The same code runs on the CPU under tests/emu (test infrastructure only).
+#pragma once
+#include <stdint.h>
+#include "pk16.hpp"
+#include "../../include/vgk.h"
+
+namespace vgk {
+
+struct GIndex {                       // device pointers
+    uint32_t n_oriented;
+    const uint32_t* len;              // per oriented node
+    const uint32_t* seq_off;          // per oriented node, into seq
+    const char*     seq;              // forward strands, then reverse complements
+    const uint32_t* count;            // haplotype visits per oriented node
+    const uint32_t* edge_off;         // n_oriented + 1
+    const int32_t*  edge_to;          // successor or -1 (a thread ends), ascending
+    const uint32_t* edge_base;        // where this node's visits start in the successor's record
+    const uint32_t* body_off;         // n_oriented + 1
+    const uint32_t* body;             // per visit: index of the edge it leaves through
+};
+struct GProb { uint32_t read_off, read_len, seed_off, n_seeds, max_mm, flags; double overlap; };
+
+struct GState { int32_t fn, flo, fhi, bn, blo, bhi; };      // forward / backward strand: node, visit range [lo, hi]
+VGK_HD bool gs_empty(const GState& s) { return s.flo > s.fhi; }
+VGK_HD uint32_t gs_size(const GState& s) { return s.flo > s.fhi ? 0u : (uint32_t)(s.fhi - s.flo + 1); }
+VGK_HD GState gs_flip(const GState& s) { GState r = { s.bn, s.blo, s.bhi, s.fn, s.flo, s.fhi }; return r; }
+VGK_HD GState gs_find(const GIndex& h, int32_t node) {
+    GState s = { node, 0, (int32_t)h.count[node] - 1, node ^ 1, 0, (int32_t)h.count[node ^ 1] - 1 };
+    return s;
+}
+VGK_HD int32_t g_rkey(int32_t x) { return x < 0 ? -1 : (x ^ 1); }
+// bdExtendForward: follow the visits of the forward range that leave through `to`
+VGK_HD GState gs_extend(const GIndex& h, const GState& s, int32_t to) {
+    const uint32_t o = (uint32_t)s.fn;
+    const uint32_t* body = h.body + h.body_off[o];
+    const int32_t* et = h.edge_to + h.edge_off[o];
+    const uint32_t ne = h.edge_off[o + 1] - h.edge_off[o];
+    uint32_t e = 0; while (e < ne && et[e] != to) ++e;
+    GState r = s; r.fn = to;
+    if (e == ne || gs_empty(s)) { r.flo = 0; r.fhi = -1; r.bhi = r.blo - 1; return r; }
+    int32_t before = 0, inside = 0, rev_off = 0;
+    for (int32_t i = 0; i <= s.fhi; ++i) {
+        const uint32_t b = body[i];
+        if (b == e) { if (i < s.flo) ++before; else ++inside; }
+        else if (i >= s.flo && g_rkey(et[b]) < g_rkey(to)) ++rev_off;
+    }
+    r.flo = (int32_t)h.edge_base[h.edge_off[o] + e] + before; r.fhi = r.flo + inside - 1;
+    r.blo = s.blo + rev_off; r.bhi = r.blo + inside - 1;
+    return r;
+}
+
+// ---- per-thread scratch ----
+constexpr int G_POOL = 160;          // partial extensions alive per seed (tree nodes + queue)
+constexpr int G_SEEDS = 32;          // seeds per cluster the engine takes
+constexpr int G_PATH = 48;           // nodes per extension
+constexpr int G_MISM = 48;           // mismatches per extension
+
+struct GEntry {                      // a partial extension; its path is the chain of `parent`s
+    int32_t  parent, node;           // node added by this step (or -1: same path as the parent)
+    uint32_t offset, r0, r1;
+    int32_t  score;
+    uint32_t internal, old, number;
+    GState   state;
+    uint8_t  front;                  // the node was added in front of the path
+    uint8_t  left_full, right_full, left_max, right_max, pad[3];
+};
+struct GExt {                        // a finished per-seed winner
+    uint32_t offset, r0, r1, internal;
+    int32_t  score;
+    GState   state;
+    uint8_t  left_full, right_full, pad[2];
+    uint32_t path_len, n_mism;
+    int32_t  path[G_PATH];
+    uint32_t mism[G_MISM];
+};
+struct GScratch { GEntry pool[G_POOL]; uint16_t heap[G_POOL]; GExt res[G_SEEDS]; };
+
+struct GaplessParams {
+    GIndex index;
+    const GProb* probs; uint32_t n;
+    const char* reads;                // masked: ACGT or X
+    const vgk_seed* seeds;
+    int32_t match, mismatch, bonus;
+    GScratch* scratch;                // one per resident thread
+    vgk_gapless_result* results;      // per problem (ext_begin indexes `ext`)
+    vgk_extension* ext; uint32_t* nodes; uint32_t* mism;
+    unsigned long long* counters;     // [0] extensions, [1] nodes, [2] mismatches handed out
+    unsigned long long caps[3];
+};
+
+VGK_HD unsigned long long g_bump(unsigned long long* counter, unsigned long long n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(counter, n);
+#else
+    const unsigned long long at = *counter; *counter += n; return at;
+#endif
+}
+
+struct GCtx { const GaplessParams* P; const char* seq; uint32_t L; };
+
+VGK_HD void g_set_score(const GCtx& c, GEntry& e) {                                   // (:201-209)
+    e.score = (int32_t)((e.r1 - e.r0) * (uint32_t)c.P->match) - (int32_t)(e.internal * (uint32_t)(c.P->match + c.P->mismatch))
+            + e.left_full * c.P->bonus + e.right_full * c.P->bonus;
+}
+VGK_HD bool g_less(const GEntry& x, const GEntry& y) { return x.score < y.score || (x.score == y.score && x.number < y.number); }
+VGK_HD void g_heap_push(GScratch& s, uint32_t& hn, uint16_t idx) {
+    uint32_t i = hn++; s.heap[i] = idx;
+    while (i) { const uint32_t p = (i - 1) / 2; if (!g_less(s.pool[s.heap[p]], s.pool[s.heap[i]])) break;
+                const uint16_t t = s.heap[p]; s.heap[p] = s.heap[i]; s.heap[i] = t; i = p; }
+}
+VGK_HD uint16_t g_heap_pop(GScratch& s, uint32_t& hn) {
+    const uint16_t top = s.heap[0]; s.heap[0] = s.heap[--hn];
+    uint32_t i = 0;
+    for (;;) { const uint32_t l = 2 * i + 1, r = l + 1; uint32_t m = i;
+        if (l < hn && g_less(s.pool[s.heap[m]], s.pool[s.heap[l]])) m = l;
+        if (r < hn && g_less(s.pool[s.heap[m]], s.pool[s.heap[r]])) m = r;
+        if (m == i) break;
+        const uint16_t t = s.heap[m]; s.heap[m] = s.heap[i]; s.heap[i] = t; i = m; }
+    return top;
+}
+// path of a pool entry, front to back; returns its length or -1 when it does not fit
+VGK_HD int g_path(const GScratch& s, int32_t idx, int32_t* out) {
+    int32_t fwd[G_PATH]; int nf = 0, nb = 0;
+    for (int32_t i = idx; i >= 0; i = s.pool[i].parent) {
+        const GEntry& e = s.pool[i];
+        if (e.node < 0) continue;
+        if (e.front) { if (nb >= G_PATH) return -1; out[nb++] = e.node; }      // the latest front node is the first of the path
+        else { if (nf >= G_PATH) return -1; fwd[nf++] = e.node; }              // collected back to front
+    }
+    if (nb + nf > G_PATH) return -1;
+    for (int k = 0; k < nf; ++k) out[nb + k] = fwd[nf - 1 - k];
+    return nb + nf;
+}
+VGK_HD bool gx_full(const GExt& e) { return e.left_full && e.right_full; }
+VGK_HD bool gx_contains(const GIndex& h, const GExt& e, int32_t node, int64_t diff) {             // (:17-41)
+    uint32_t read_offset = e.r0, node_offset = e.offset;
+    for (uint32_t i = 0; i < e.path_len; ++i) {
+        const uint32_t a = h.len[e.path[i]] - node_offset, b = e.r1 - read_offset; const uint32_t len = a < b ? a : b;
+        if (e.path[i] == node && (int64_t)read_offset - (int64_t)node_offset == diff) return true;
+        read_offset += len; node_offset = 0;
+    }
+    return false;
+}
+VGK_HD uint32_t gx_overlap(const GIndex& h, const GExt& x, const GExt& y) {                        // (:69-103)
+    uint32_t result = 0, xp = x.r0, yp = y.r0, xi = 0, yi = 0, xo = x.offset, yo = y.offset;
+    while (xp < x.r1 && yp < y.r1) {
+        if (xp == yp && x.path[xi] == y.path[yi] && xo == yo) {
+            uint32_t len = h.len[x.path[xi]] - xo;
+            if (x.r1 - xp < len) len = x.r1 - xp;
+            if (y.r1 - yp < len) len = y.r1 - yp;
+            result += len; xp += len; yp += len; ++xi; ++yi; xo = yo = 0;
+        } else if (xp <= yp) { xp += h.len[x.path[xi]] - xo; ++xi; xo = 0; }
+        else { yp += h.len[y.path[yi]] - yo; ++yi; yo = 0; }
+    }
+    return result;
+}
+VGK_HD bool gs_eq(const GState& a, const GState& b) { return a.fn == b.fn && a.flo == b.flo && a.fhi == b.fhi && a.bn == b.bn && a.blo == b.blo && a.bhi == b.bhi; }
+VGK_HD bool gx_eq(const GExt& a, const GExt& b) { return a.r0 == b.r0 && a.r1 == b.r1 && gs_eq(a.state, b.state) && a.offset == b.offset; }
+VGK_HD bool gx_dup_less(const GExt& a, const GExt& b) {                                            // (:333-349)
+    if (a.r0 != b.r0) return a.r0 < b.r0;
+    if (a.r1 != b.r1) return a.r1 < b.r1;
+    if (a.state.bn != b.state.bn) return a.state.bn < b.state.bn;
+    if (a.state.fn != b.state.fn) return a.state.fn < b.state.fn;
+    if (a.state.blo != b.state.blo) return a.state.blo < b.state.blo;
+    if (a.state.bhi != b.state.bhi) return a.state.bhi < b.state.bhi;
+    if (a.state.flo != b.state.flo) return a.state.flo < b.state.flo;
+    if (a.state.fhi != b.state.fhi) return a.state.fhi < b.state.fhi;
+    return a.offset < b.offset;
+}
+VGK_HD bool gx_full_less(const GExt& a, const GExt& b) {                                           // (:302-307)
+    if (gx_full(a) && gx_full(b)) return a.internal < b.internal;
+    return gx_full(a) && !gx_full(b);
+}
+// stable insertion sort of an index permutation (the sets are small; moving 500-byte records would not pay)
+template <class Less> VGK_HD void gx_sort(const GExt* v, uint8_t* order, uint32_t n, Less less) {
+    for (uint32_t i = 1; i < n; ++i) { const uint8_t x = order[i]; uint32_t j = i; while (j && less(v[x], v[order[j - 1]])) { order[j] = order[j - 1]; --j; } order[j] = x; }
+}
+VGK_HD uint32_t gx_remove_duplicates(const GExt* v, uint8_t* order, uint32_t n) {                  // (:332-365)
+    gx_sort(v, order, n, [](const GExt& a, const GExt& b) { return gx_dup_less(a, b); });
+    uint32_t tail = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const GExt& e = v[order[i]];
+        if (e.r1 == e.r0) continue;
+        if (tail == 0 || !gx_eq(e, v[order[tail - 1]])) order[tail++] = order[i];
+    }
+    return tail;
+}
+VGK_HD void gx_find_mismatches(const GCtx& c, GExt& e, bool& overflow) {                            // (:368-387)
+    e.n_mism = 0;
+    if (!e.internal) return;
+    const GIndex& h = c.P->index;
+    uint32_t node_offset = e.offset, read_offset = e.r0;
+    for (uint32_t i = 0; i < e.path_len; ++i) {
+        const char* t = h.seq + h.seq_off[e.path[i]]; const uint32_t tl = h.len[e.path[i]];
+        while (node_offset < tl && read_offset < e.r1) {
+            if (t[node_offset] != c.seq[read_offset]) { if (e.n_mism >= G_MISM) { overflow = true; return; } e.mism[e.n_mism++] = read_offset; }
+            ++node_offset; ++read_offset;
+        }
+        node_offset = 0;
+    }
+}
+VGK_HD bool gx_trim(const GCtx& c, GExt& e) {                                                       // (:421-529)
+    if (!e.n_mism) return false;
+    const GIndex& h = c.P->index; const int32_t match = c.P->match, mismatch = c.P->mismatch, bonus = c.P->bonus;
+    uint32_t mi = 0, c0 = e.r0, c1 = e.mism[0];
+    int32_t cur = (int32_t)(c1 - c0) * match + (e.left_full ? bonus : 0);
+    uint32_t b0 = c0, b1 = c1; int32_t best = cur;
+    while (mi < e.n_mism) {
+        if (cur >= mismatch) { ++c1; cur -= mismatch; }
+        else { c0 = c1 = e.mism[mi] + 1; cur = 0; }
+        ++mi;
+        if (mi == e.n_mism) { cur += (int32_t)(e.r1 - c1) * match; c1 = e.r1; if (e.right_full) cur += bonus; }
+        else { cur += (int32_t)(e.mism[mi] - c1) * match; c1 = e.mism[mi]; }
+        if (cur > best || (cur > 0 && cur == best && c1 - c0 > b1 - b0)) { b0 = c0; b1 = c1; best = cur; }
+    }
+    if (b0 == e.r0 && b1 == e.r1) return false;
+    if (b1 == b0) { e.path_len = 0; e.r0 = b0; e.r1 = b1; e.n_mism = 0; e.score = 0; e.left_full = e.right_full = 0; return true; }
+    if (b0 > e.r0) e.left_full = 0;
+    if (b1 < e.r1) e.right_full = 0;
+    uint32_t node_offset = e.offset, read_offset = e.r0;
+    e.r0 = b0; e.r1 = b1; e.score = best;
+    uint32_t head = 0;
+    while (head < e.path_len) {
+        const uint32_t nl = h.len[e.path[head]];
+        read_offset += nl - node_offset; node_offset = 0;
+        if (read_offset > e.r0) { e.offset = nl - (read_offset - e.r0); break; }
+        ++head;
+    }
+    uint32_t tail = head + 1;
+    while (read_offset < e.r1) { read_offset += h.len[e.path[tail]]; ++tail; }
+    if (head > 0 || tail < e.path_len) {
+        for (uint32_t k = 0; k < tail - head; ++k) e.path[k] = e.path[head + k];
+        e.path_len = tail - head;
+        GState s = gs_find(h, e.path[0]);                                                          // bd_find
+        for (uint32_t k = 1; k < e.path_len; ++k) s = gs_extend(h, s, e.path[k]);
+        e.state = s;
+    }
+    uint32_t mh = 0; while (mh < e.n_mism && e.mism[mh] < e.r0) ++mh;
+    uint32_t mt = mh; while (mt < e.n_mism && e.mism[mt] < e.r1) ++mt;
+    for (uint32_t k = 0; k < mt - mh; ++k) e.mism[k] = e.mism[mh + k];
+    e.n_mism = mt - mh;
+    return true;
+}
+
+// one read: every seed's best extension, then the set rules
+VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S) {
+    const GProb pb = P.probs[pi];
+    const GIndex& h = P.index;
+    vgk_gapless_result& out = P.results[pi];
+    out.status = VGK_OK; out.ext_begin = 0; out.n_ext = 0; out.full_length = 0;
+    if (!pb.read_len || !pb.n_seeds) return;
+    if (pb.n_seeds > (uint32_t)G_SEEDS) { out.status = VGK_ETOOBIG; return; }
+    GCtx c; c.P = &P; c.seq = P.reads + pb.read_off; c.L = pb.read_len;
+    const uint32_t L = pb.read_len, max_mm = pb.max_mm;
+    uint32_t n_res = 0, best_alignment = 0xffffffffu;
+    int status = VGK_OK;
+    for (uint32_t si = 0; si < pb.n_seeds && status == VGK_OK; ++si) {
+        const vgk_seed sd = P.seeds[pb.seed_off + si];
+        const int32_t snode = (int32_t)sd.node; const int64_t diff = sd.diff;
+        if ((uint32_t)snode >= h.n_oriented) { status = VGK_EINVAL; break; }
+        if (best_alignment < n_res && S.res[best_alignment].internal == 0 && gx_contains(h, S.res[best_alignment], snode, diff)) continue;
+        const uint32_t read_offset = diff < 0 ? 0u : (uint32_t)diff, node_offset = diff < 0 ? (uint32_t)(-diff) : 0u;
+        if (read_offset > L || node_offset > h.len[snode]) { status = VGK_EINVAL; break; }
+        uint32_t np = 0, hn = 0, number = 0;
+        int32_t best = -1;
+        {   // the seed node itself: any number of mismatches (:213-237)
+            GEntry& m = S.pool[np];
+            m.parent = -1; m.node = snode; m.front = 0; m.offset = node_offset; m.r0 = m.r1 = read_offset; m.internal = 0;
+            m.left_full = m.right_full = m.left_max = m.right_max = 0; m.state = gs_find(h, snode);
+            const char* t = h.seq + h.seq_off[snode];
+            uint32_t no = node_offset, left = L - m.r1 < h.len[snode] - no ? L - m.r1 : h.len[snode] - no;
+            while (left--) { if (c.seq[m.r1] != t[no]) ++m.internal; ++m.r1; ++no; }
+            m.old = m.internal;
+            if (m.r0 == 0) m.left_full = m.left_max = 1;
+            if (m.r1 >= L) m.right_full = m.right_max = 1;
+            g_set_score(c, m); m.number = number++;
+            g_heap_push(S, hn, (uint16_t)np); ++np;
+        }
+        while (hn) {
+            const uint16_t ci = g_heap_pop(S, hn);
+            if (!S.pool[ci].right_max) {
+                uint32_t num_ext = 0;
+                const GEntry cur = S.pool[ci];
+                const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
+                const uint32_t o = (uint32_t)cur.state.fn;
+                for (uint32_t e = h.edge_off[o]; e < h.edge_off[o + 1]; ++e) {
+                    const int32_t w = h.edge_to[e]; if (w < 0) continue;
+                    const GState ns = gs_extend(h, cur.state, w);
+                    if (gs_empty(ns)) continue;
+                    if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
+                    GEntry& nx = S.pool[np]; nx = cur; nx.parent = ci; nx.node = w; nx.front = 0; nx.state = ns;
+                    const char* t = h.seq + h.seq_off[w];                                           // match_forward (:239-266)
+                    uint32_t no = 0, left = L - nx.r1 < h.len[w] ? L - nx.r1 : h.len[w];
+                    while (left) { if (c.seq[nx.r1] != t[no]) { if (nx.internal + 1 >= limit) break; ++nx.internal; } ++nx.r1; ++no; --left; }
+                    if (no == 0) continue;
+                    if (nx.r1 >= L) { nx.right_full = nx.right_max = 1; nx.old = nx.internal; }
+                    else if (no < h.len[w]) { nx.right_max = 1; nx.old = nx.internal; }
+                    g_set_score(c, nx); nx.number = number++;
+                    num_ext += gs_size(ns);
+                    g_heap_push(S, hn, (uint16_t)np); ++np;
+                }
+                if (status != VGK_OK) break;
+                if (num_ext < gs_size(cur.state)) {                                               // some haplotype ends here: keep it (:633-637)
+                    if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
+                    GEntry& nx = S.pool[np]; nx = cur; nx.parent = ci; nx.node = -1; nx.right_max = 1; nx.old = nx.internal; nx.number = number++;
+                    g_heap_push(S, hn, (uint16_t)np); ++np;
+                }
+                continue;
+            }
+            if (!S.pool[ci].left_max) {
+                bool found = false;
+                const GEntry cur = S.pool[ci];
+                const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
+                const uint32_t o = (uint32_t)cur.state.bn;
+                for (uint32_t e = h.edge_off[o]; e < h.edge_off[o + 1]; ++e) {
+                    const int32_t x = h.edge_to[e]; if (x < 0) continue;
+                    const GState ns = gs_flip(gs_extend(h, gs_flip(cur.state), x));              // bdExtendBackward
+                    if (gs_empty(ns)) continue;
+                    const int32_t w = ns.bn ^ 1;
+                    if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
+                    GEntry& nx = S.pool[np]; nx = cur; nx.parent = ci; nx.node = w; nx.front = 1; nx.state = ns; nx.offset = h.len[w];
+                    const char* t = h.seq + h.seq_off[w];                                           // match_backward (:268-296)
+                    uint32_t left = nx.r0 < nx.offset ? nx.r0 : nx.offset;
+                    while (left) { if (c.seq[nx.r0 - 1] != t[nx.offset - 1]) { if (nx.internal + 1 >= limit) break; ++nx.internal; } --nx.r0; --nx.offset; --left; }
+                    if (nx.offset >= h.len[w]) continue;
+                    if (nx.r0 == 0) nx.left_full = nx.left_max = 1;
+                    else if (nx.offset > 0) nx.left_max = 1;
+                    g_set_score(c, nx); nx.number = number++;
+                    g_heap_push(S, hn, (uint16_t)np); ++np;
+                    found = true;
+                }
+                if (status != VGK_OK) break;
+                if (found) continue;
+                S.pool[ci].left_max = 1;
+            }
+            if (best < 0 || S.pool[best].score < S.pool[ci].score) best = ci;
+        }
+        if (status != VGK_OK) break;
+        if (best >= 0 && S.pool[best].r1 > S.pool[best].r0) {
+            const GEntry& b = S.pool[best];
+            GExt& r = S.res[n_res];
+            const int plen = g_path(S, best, r.path);
+            if (plen < 0) { status = VGK_ETOOBIG; break; }
+            r.path_len = (uint32_t)plen; r.offset = b.offset; r.r0 = b.r0; r.r1 = b.r1; r.internal = b.internal; r.score = b.score; r.state = b.state;
+            r.left_full = b.left_full; r.right_full = b.right_full; r.n_mism = 0;
+            if (gx_full(r) && (best_alignment >= n_res || r.internal < S.res[best_alignment].internal)) best_alignment = n_res;
+            ++n_res;
+        }
+    }
+    if (status != VGK_OK) { out.status = status; return; }
+    uint8_t order[G_SEEDS];
+    for (uint32_t i = 0; i < n_res; ++i) order[i] = (uint8_t)i;
+    bool overflow = false;
+    uint32_t n_out = n_res;
+    if (best_alignment < n_res && S.res[best_alignment].internal <= max_mm) {
+        // the non-overlapping full-length extensions, fewest mismatches first (:301-329)
+        gx_sort(S.res, order, n_res, [](const GExt& a, const GExt& b) { return gx_full_less(a, b); });
+        uint32_t tail = 0;
+        for (uint32_t i = 0; i < n_res; ++i) {
+            const GExt& e = S.res[order[i]];
+            if (!gx_full(e)) break;
+            bool ov = false;
+            for (uint32_t prev = 0; prev < tail && !ov; ++prev) {
+                const GExt& q = S.res[order[prev]];
+                ov = (double)gx_overlap(h, e, q) > pb.overlap * (double)(q.r1 - q.r0);
+            }
+            if (!ov) order[tail++] = order[i];
+        }
+        n_out = tail;
+        for (uint32_t i = 0; i < n_out; ++i) gx_find_mismatches(c, S.res[order[i]], overflow);
+        out.full_length = 1;
+    } else {
+        n_out = gx_remove_duplicates(S.res, order, n_res);
+        for (uint32_t i = 0; i < n_out; ++i) gx_find_mismatches(c, S.res[order[i]], overflow);
+        if (!overflow && (pb.flags & VGK_GAPLESS_TRIM)) {
+            bool trimmed = false;
+            for (uint32_t i = 0; i < n_out; ++i) trimmed |= gx_trim(c, S.res[order[i]]);
+            if (trimmed) n_out = gx_remove_duplicates(S.res, order, n_out);
+        }
+    }
+    if (overflow) { out.status = VGK_ETOOBIG; return; }
+    // hand the set out
+    uint32_t nn = 0, nm = 0;
+    for (uint32_t i = 0; i < n_out; ++i) { nn += S.res[order[i]].path_len; nm += S.res[order[i]].n_mism; }
+    const unsigned long long e0 = g_bump(P.counters + 0, n_out), n0 = g_bump(P.counters + 1, nn), m0 = g_bump(P.counters + 2, nm);
+    if (e0 + n_out > P.caps[0] || n0 + nn > P.caps[1] || m0 + nm > P.caps[2]) { out.status = VGK_EOPS; return; }
+    out.ext_begin = (uint32_t)e0; out.n_ext = n_out;
+    uint32_t na = 0, ma = 0;
+    for (uint32_t i = 0; i < n_out; ++i) {
+        const GExt& e = S.res[order[i]];
+        vgk_extension x;
+        x.path_begin = (uint32_t)(n0 + na); x.path_len = e.path_len; x.offset = e.offset; x.read_begin = e.r0; x.read_end = e.r1;
+        x.mism_begin = (uint32_t)(m0 + ma); x.n_mismatches = e.n_mism; x.score = e.score; x.left_full = e.left_full; x.right_full = e.right_full;
+        x.pad[0] = x.pad[1] = 0;
+        x.state[0] = (uint32_t)e.state.fn; x.state[1] = (uint32_t)e.state.flo; x.state[2] = (uint32_t)e.state.fhi;
+        x.state[3] = (uint32_t)e.state.bn; x.state[4] = (uint32_t)e.state.blo; x.state[5] = (uint32_t)e.state.bhi;
+        P.ext[e0 + i] = x;
+        for (uint32_t k = 0; k < e.path_len; ++k) P.nodes[n0 + na + k] = (uint32_t)e.path[k];
+        for (uint32_t k = 0; k < e.n_mism; ++k) P.mism[m0 + ma + k] = e.mism[k];
+        na += e.path_len; ma += e.n_mism;
+    }
+}
+
+}  // namespace vgk
