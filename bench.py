@@ -25,6 +25,67 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
+    """giraffe's gapless-extension stage (secondary line).  vgk_gapless_extend is a one-call API (pack + H2D + kernel + D2H +
+    reordering), so `value` is its END-TO-END rate from host buffers; the kernel-only figure comes from HIP events."""
+    import numpy as np
+    from vg_amd import capi, workloads
+    n = min(args.reads, 1_000_000)
+    wl = workloads.GaplessWorkload(n, seed=123 + rank)
+    index = eng.haplo_index(wl.nodes, wl.threads)          # the haplotype index is resident in HBM from here on
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.gapless_extend(index, wl.gs)
+    barrier()
+    kms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.gapless_extend(index, wl.gs)
+        kms.append(eng.gapless_last_ms())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res, ext, nodes, mism = out
+    cpu = parity = None
+    if rank == 0 and not args.no_cpu:
+        ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
+        oidx = ora.haplo_index(wl.nodes, wl.threads)
+        tc = time.perf_counter(); o = ora.gapless_extend(oidx, wl.gs); tc = time.perf_counter() - tc
+        cpu = {"value": n / tc, "unit": "reads/s", "cores": os.cpu_count() or 1, "kind": "port",
+               "sample": "the same %d reads, oracle/vgo_gapless.c (scalar best-first extension over the uncompressed haplotype index), OpenMP over reads" % n}
+        same = all(len(a) == len(b) and bool((a == b).all()) for a, b in zip(o, out))
+        parity = {"checked": n, "identical": n if same else int((o[0] == res).sum())}
+    if rank == 0:
+        k = sum(kms) / len(kms)
+        ns = np.diff(wl.gs.seed_off); rl = np.diff(wl.gs.read_off)
+        alg_bytes = float((rl * (1 + ns) + 8 * ns).sum() + 60 * len(ext) + 4 * len(nodes) + 4 * len(mism))
+        achieved = alg_bytes / (k * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "reads/sec gapless-extended (150 bp, %.1f seeds per read)" % float(ns.mean()), "value": n * world * args.steps / elapsed,
+            "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1 Mbp variation graph, 8 random haplotype threads, %d x 150 bp reads per GPU from either strand with 1 %% "
+                                   "substitutions, seeds at true positions; GaplessExtender semantics (max 4 mismatches, overlap 0.8, trim)" % n,
+                       "timed_region": "vgk_gapless_extend end to end (pack + H2D + kernel + D2H)", "parallelism": "read-sharded x%d" % world,
+                       "device": dev_name, "compute_units": cus},
+            "roofline": {"bound": "hbm", "kernel": "gapless_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
+                         "kernel_only_reads_per_s": n / (k * 1e-3)},
+            "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum()),
+            "full_length_fraction": float(res["full_length"].mean())}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
     """configs[4] stand-in (secondary line, not the headline metric).  vgk_banded_align is a one-call API — host band
     geometry + H2D + fill + traceback + D2H — so `value` here is the END-TO-END rate of that call from host buffers
@@ -98,10 +159,11 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (configs[1]: 1M)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads for the CPU baseline leg (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--workload", choices=["linear", "tails", "banded"], default="linear",
+    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless"], default="linear",
                     help="linear = BASELINE.json configs[1] (the headline metric); tails = configs[2] stand-in: "
                          "giraffe-style pinned X-drop tail alignments on a variation graph; banded = configs[4] stand-in: "
-                         "banded global alignments between chained anchors")
+                         "banded global alignments between chained anchors; gapless = giraffe's first stage: "
+                         "haplotype-consistent gapless extension of seeds")
     args = ap.parse_args()
 
     from vg_amd import shard
@@ -127,6 +189,8 @@ def main():
 
     if args.workload == "banded":
         return bench_banded(args, eng, rank, world, dist, torch, dev_name, cus)
+    if args.workload == "gapless":
+        return bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus)
 
     # same reference everywhere; each rank draws its own reads (shard of the read stream)
     if args.workload == "tails":

@@ -178,17 +178,36 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
                        vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
                        uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) {
     if (!ctx || !index || (!problems && n) || (!results && n)) return VGK_EINVAL;
+    /* every problem into its own scratch slots (OpenMP over problems), then compacted in order */
+    size_t* se = (size_t*)malloc(sizeof(size_t) * ((size_t)n + 1)); size_t* sn = (size_t*)malloc(sizeof(size_t) * ((size_t)n + 1));
+    size_t* sm = (size_t*)malloc(sizeof(size_t) * ((size_t)n + 1));
+    uint32_t* wn = (uint32_t*)calloc((size_t)n + 1, sizeof(uint32_t)); uint32_t* wm = (uint32_t*)calloc((size_t)n + 1, sizeof(uint32_t));
+    se[0] = sn[0] = sm[0] = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        se[i + 1] = se[i] + problems[i].n_seeds; sn[i + 1] = sn[i] + (size_t)problems[i].n_seeds * (problems[i].read_len + 2);
+        sm[i + 1] = sm[i] + (size_t)problems[i].n_seeds * problems[i].read_len;
+    }
+    vgk_extension* te = (vgk_extension*)malloc(sizeof(vgk_extension) * (se[n] + 1));
+    uint32_t* tn = (uint32_t*)malloc(sizeof(uint32_t) * (sn[n] + 1)); uint32_t* tm = (uint32_t*)malloc(sizeof(uint32_t) * (sm[n] + 1));
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (uint32_t i = 0; i < n; ++i)
+        vgo_gapless_extend(&ctx->sc, index, &problems[i], &results[i], te + se[i], (uint32_t)(se[i + 1] - se[i]), tn + sn[i], (uint32_t)(sn[i + 1] - sn[i]),
+                           tm + sm[i], (uint32_t)(sm[i + 1] - sm[i]), &wn[i], &wm[i]);
     size_t ne = 0, nn = 0, nm = 0; int rc = VGK_OK;
     for (uint32_t i = 0; i < n; ++i) {
-        uint32_t wn = 0, wm = 0;
-        const size_t ce = ext_cap - ne, cn = nodes_cap - nn, cm = mism_cap - nm;
-        int r = vgo_gapless_extend(&ctx->sc, index, &problems[i], &results[i], extensions + ne, ce > 0xffffffffu ? 0xffffffffu : (uint32_t)ce,
-                                   nodes + nn, cn > 0xffffffffu ? 0xffffffffu : (uint32_t)cn, mismatches + nm, cm > 0xffffffffu ? 0xffffffffu : (uint32_t)cm, &wn, &wm);
-        if (r == VGK_EOPS) rc = VGK_EOPS;
-        results[i].ext_begin = (uint32_t)ne;
-        for (uint32_t k = 0; k < results[i].n_ext; ++k) { extensions[ne + k].path_begin += (uint32_t)nn; extensions[ne + k].mism_begin += (uint32_t)nm; }
-        ne += results[i].n_ext; nn += wn; nm += wm;
+        vgk_gapless_result* r = &results[i];
+        if (r->status == VGK_OK && (ne + r->n_ext > ext_cap || nn + wn[i] > nodes_cap || nm + wm[i] > mism_cap)) { r->status = VGK_EOPS; r->n_ext = 0; rc = VGK_EOPS; }
+        r->ext_begin = (uint32_t)ne;
+        if (r->status != VGK_OK) { r->n_ext = 0; continue; }
+        for (uint32_t k = 0; k < r->n_ext; ++k) {
+            vgk_extension x = te[se[i] + k];
+            x.path_begin += (uint32_t)nn; x.mism_begin += (uint32_t)nm;
+            extensions[ne + k] = x;
+        }
+        memcpy(nodes + nn, tn + sn[i], sizeof(uint32_t) * wn[i]); memcpy(mismatches + nm, tm + sm[i], sizeof(uint32_t) * wm[i]);
+        ne += r->n_ext; nn += wn[i]; nm += wm[i];
     }
+    free(se); free(sn); free(sm); free(wn); free(wm); free(te); free(tn); free(tm);
     if (written) { written[0] = ne; written[1] = nn; written[2] = nm; }
     return rc;
 }

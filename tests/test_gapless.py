@@ -227,3 +227,64 @@ def test_hip_gapless_matches_reference_unit_tests_and_oracle():
     reference_gapless_cases(capi.Engine())
     total, full = compare_engines(None, range(200, 260), n_reads=400)
     assert total > 20000 and full > 4000
+
+
+# ---- the C++ host shim (vg_amd/host/gbwt_extender.hpp), driven like src/unittest/gbwt_extender.cpp drives vg's class ------
+
+def shim_extend(engine_lib, read, seeds, error_bound, overlap_threshold=0.8):
+    import ctypes, json
+    h = util.host()
+    h.vgh_gapless_create.restype = ctypes.c_void_p
+    h.vgh_gapless_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), ctypes.c_int]
+    h.vgh_gapless_destroy.argtypes = [ctypes.c_void_p]
+    h.vgh_gapless_extend.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                     ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    al = util.HostAligner(engine_lib)
+    g = h.vgh_graph_create()
+    try:
+        for i, s in enumerate(TOY_NODES):
+            assert h.vgh_graph_add_node(g, i + 1, s.encode()) == 0
+        for a, b in [(1, 2), (1, 4), (1, 6), (2, 3), (2, 4), (3, 5), (4, 5), (5, 6), (6, 7), (6, 8), (7, 9), (8, 9)]:
+            assert h.vgh_graph_add_edge(g, a, b) == 0
+        threads = [SHORT_PATH, ALT_PATH, SHORT_PATH]
+        flat = [2 * n for t in threads for n in t]; off = np.concatenate([[0], np.cumsum([len(t) for t in threads])])
+        x = h.vgh_gapless_create(al.ptr, g, (ctypes.c_int64 * len(flat))(*flat), (ctypes.c_int32 * len(off))(*[int(v) for v in off]), len(threads))
+        assert x, h.vgh_last_error().decode()
+        try:
+            sd = [v for (node_id, rev, offset), ro in seeds for v in (node_id, int(rev), offset, ro)]
+            buf = ctypes.create_string_buffer(1 << 16)
+            rc = h.vgh_gapless_extend(x, read.encode(), (ctypes.c_int64 * len(sd))(*sd), len(seeds), error_bound, overlap_threshold, 1, buf, len(buf))
+            assert rc == 0, h.vgh_last_error().decode()
+            return json.loads(buf.value.decode())
+        finally:
+            h.vgh_gapless_destroy(x)
+    finally:
+        h.vgh_graph_destroy(g)
+
+
+def shim_cases(engine_lib):
+    F = False
+    # "read matches with errors" (:897): one full-length extension with one mismatch that contains both seeds
+    out = shim_extend(engine_lib, "GGAGTAC", [((5, F, 0), 4), ((4, F, 2), 3)], 1)
+    assert out["full_length"] and len(out["extensions"]) == 1
+    e = out["extensions"][0]
+    assert e["left_full"] and e["right_full"] and e["mismatches"] == 1 and e["contains_all_seeds"]
+    assert e["alignment"]["score"] == 6 * 1 - 4 + 2 * 5
+    maps = e["alignment"]["path"]["mapping"]
+    assert [m["position"]["node_id"] for m in maps] == [1, 4, 5, 6, 7]
+    assert [(x["from_length"], x["to_length"], x["sequence"]) for x in maps[1]["edit"]] == [(1, 1, ""), (1, 1, "A"), (1, 1, "")]
+    # "trim right flank" (:1082): a partial extension starting at read offset 1
+    out = shim_extend(engine_lib, "xAGGGTxAx", [((4, F, 2), 4)], 1)
+    assert not out["full_length"] and len(out["extensions"]) == 1
+    e = out["extensions"][0]
+    assert e["read_begin"] == 1 and e["read_end"] == 6 and not e["left_full"] and not e["right_full"]
+    assert [m["position"]["node_id"] for m in e["alignment"]["path"]["mapping"]] == [2, 4, 5]
+
+
+def test_host_shim_gapless_extender_on_the_oracle():
+    shim_cases(util.ORACLE_LIB)
+
+
+@pytest.mark.gpu
+def test_host_shim_gapless_extender_on_hip():
+    shim_cases(util.ENGINE_LIB)

@@ -99,6 +99,8 @@ def load_library(path=None):
     lib.vgk_haplo_create.argtypes = [vp, ctypes.POINTER(Haplotypes), ctypes.POINTER(vp)]
     lib.vgk_haplo_destroy.argtypes = [vp]
     lib.vgk_gapless_extend.argtypes = [vp, vp, vp, u32, vp, vp, sz, vp, sz, vp, sz, ctypes.POINTER(sz * 3)]
+    lib.vgk_gapless_last_ms.restype = ctypes.c_double
+    lib.vgk_gapless_last_ms.argtypes = [vp]
     lib.vgk_banded_last.restype = ctypes.c_double
     lib.vgk_banded_last.argtypes = [vp, ctypes.c_int]
     for f in ("vgk_batch_cells", "vgk_batch_alg_bytes", "vgk_batch_device_bytes"):
@@ -273,36 +275,57 @@ class Engine:
         return HaploIndex(self, nodes, threads)
 
     def gapless_extend(self, index, problems):
-        """problems: list of dicts {read, seeds: [(oriented node, read_offset - node_offset)], max_mismatches?, overlap_threshold?,
-        trim?}.  -> (results, extensions, nodes, mismatches) as numpy arrays laid out like include/vgk.h."""
-        n = len(problems)
+        """problems: a GaplessSet, or a list of dicts {read, seeds: [(oriented node, read_offset - node_offset)], max_mismatches?,
+        overlap_threshold?, trim?}.  -> (results, extensions, nodes, mismatches) as numpy arrays laid out like include/vgk.h."""
+        gs = problems if isinstance(problems, GaplessSet) else GaplessSet.from_lists(problems)
+        res = np.zeros(gs.n, dtype=GAPLESS_RESULT_DT)
+        ext = np.zeros(gs.ext_cap, dtype=EXT_DT); nodes = np.zeros(gs.node_cap, dtype=np.uint32); mism = np.zeros(gs.mism_cap, dtype=np.uint32)
+        written = (ctypes.c_size_t * 3)()
+        self._check(self.lib.vgk_gapless_extend(self.h, index.h, gs.array.ctypes.data, gs.n, res.ctypes.data, ext.ctypes.data, gs.ext_cap,
+                                                nodes.ctypes.data, gs.node_cap, mism.ctypes.data, gs.mism_cap, ctypes.byref(written)),
+                    "vgk_gapless_extend")
+        return res, ext[:written[0]], nodes[:written[1]], mism[:written[2]]
+
+    def gapless_last_ms(self):
+        return self.lib.vgk_gapless_last_ms(self.h)
+
+
+class GaplessSet:
+    """A batch of gapless-extension problems (vgk_gapless_problem) over shared numpy arenas."""
+
+    def __init__(self, reads, read_off, seeds, seed_off, max_mismatches=4, overlap_threshold=0.8, trim=True, node_cap=None, mism_cap=None):
+        self.reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        self.read_off = np.asarray(read_off, dtype=np.int64)
+        self.seeds = np.ascontiguousarray(seeds, dtype=SEED_DT)
+        self.seed_off = np.asarray(seed_off, dtype=np.int64)
+        n = self.n = len(self.read_off) - 1
+        arr = np.zeros(n, dtype=GAPLESS_DT)
+        arr["read"] = self.reads.ctypes.data + self.read_off[:-1]
+        arr["read_len"] = np.diff(self.read_off)
+        arr["n_seeds"] = np.diff(self.seed_off)
+        arr["seeds"] = self.seeds.ctypes.data + 8 * self.seed_off[:-1]
+        arr["max_mismatches"] = max_mismatches
+        arr["flags"] = np.where(np.broadcast_to(np.asarray(trim), (n,)), VGK_GAPLESS_TRIM, 0)
+        arr["overlap_threshold"] = overlap_threshold
+        self.array = arr
+        rl = np.diff(self.read_off); ns = np.diff(self.seed_off)
+        self.ext_cap = int(ns.sum()) + 1
+        self.node_cap = int(node_cap if node_cap is not None else (ns * (rl + 2)).sum()) + 1
+        self.mism_cap = int(mism_cap if mism_cap is not None else (ns * rl).sum()) + 1
+
+    @classmethod
+    def from_lists(cls, problems):
         reads = [np.frombuffer(p["read"].encode(), dtype=np.uint8) for p in problems]
         read_off = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
-        read_buf = np.concatenate(reads) if n and read_off[-1] else np.zeros(1, np.uint8)
+        read_buf = np.concatenate(reads) if len(reads) and read_off[-1] else np.zeros(1, np.uint8)
         seed_off = np.concatenate([[0], np.cumsum([len(p["seeds"]) for p in problems])]).astype(np.int64)
         seeds = np.zeros(max(int(seed_off[-1]), 1), dtype=SEED_DT)
         k = 0
         for p in problems:
             for node, diff in p["seeds"]:
                 seeds[k] = (node, diff); k += 1
-        arr = np.zeros(n, dtype=GAPLESS_DT)
-        arr["read"] = read_buf.ctypes.data + read_off[:-1]
-        arr["read_len"] = np.diff(read_off)
-        arr["n_seeds"] = np.diff(seed_off)
-        arr["seeds"] = seeds.ctypes.data + 8 * seed_off[:-1]
-        arr["max_mismatches"] = [p.get("max_mismatches", 4) for p in problems]
-        arr["flags"] = [VGK_GAPLESS_TRIM if p.get("trim", True) else 0 for p in problems]
-        arr["overlap_threshold"] = [p.get("overlap_threshold", 0.8) for p in problems]
-        res = np.zeros(n, dtype=GAPLESS_RESULT_DT)
-        ext_cap = int(seed_off[-1]) + 1
-        node_cap = int(sum(len(p["seeds"]) * (len(p["read"]) + 2) for p in problems)) + 1
-        mism_cap = int(sum(len(p["seeds"]) * len(p["read"]) for p in problems)) + 1
-        ext = np.zeros(ext_cap, dtype=EXT_DT); nodes = np.zeros(node_cap, dtype=np.uint32); mism = np.zeros(mism_cap, dtype=np.uint32)
-        written = (ctypes.c_size_t * 3)()
-        self._check(self.lib.vgk_gapless_extend(self.h, index.h, arr.ctypes.data, n, res.ctypes.data, ext.ctypes.data, ext_cap,
-                                                nodes.ctypes.data, node_cap, mism.ctypes.data, mism_cap, ctypes.byref(written)),
-                    "vgk_gapless_extend")
-        return res, ext[:written[0]], nodes[:written[1]], mism[:written[2]]
+        return cls(read_buf, read_off, seeds, seed_off, [p.get("max_mismatches", 4) for p in problems],
+                   [p.get("overlap_threshold", 0.8) for p in problems], [p.get("trim", True) for p in problems])
 
 
 class HaploIndex:

@@ -119,6 +119,10 @@ public:
 
     std::unique_ptr<MatrixAlignmentScorer> scorer;
 
+    // the engine binding, for the extenders that are constructed around an Aligner (src/gbwt_extender.hpp:156)
+    const EngineApi& engine_api() const { return *engine; }
+    vgk_ctx* engine_context() const { return ctx; }
+
 protected:
     std::shared_ptr<EngineApi> engine;
     vgk_ctx* ctx = nullptr;

@@ -1,0 +1,104 @@
+// gbwt_extender.hpp — host-side mirror of vg's haplotype-aware gapless seed extension
+// (reference: src/gbwt_extender.hpp:30-217, src/gbwt_extender.cpp:17-176, :533-737).  `GaplessExtender::extend`
+// hands the per-seed best-first searches and the set rules to the MI355X engine (vgk_gapless_extend); the value
+// type `GaplessExtension` keeps the reference's members and helpers.
+//
+// gbwt / gbwtgraph are empty submodules in the reference snapshot, so `HaplotypeGraph` stands in for
+// gbwtgraph::GBWTGraph: node sequences plus the haplotype threads, indexed on the device when an extender is built.
+#pragma once
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+#include "aligner.hpp"
+
+namespace vgamd {
+
+// What gbwtgraph::GBWTGraph(gbwt_index, graph) is to the extender: the nodes the threads touch and the threads.
+class HaplotypeGraph : public HandleGraph {
+public:
+    HaplotypeGraph(const HandleGraph& graph, const std::vector<std::vector<handle_t>>& threads);
+    bool has_node(nid_t id) const override { return index_of_.count(id) != 0; }
+    size_t get_length(const handle_t& h) const override { return seqs_[index_of_.at(get_id(h))].size(); }
+    std::string get_sequence(const handle_t& h) const override;
+    bool follow_edges(const handle_t& h, bool go_left, const std::function<bool(const handle_t&)>& it) const override;
+    bool for_each_handle(const std::function<bool(const handle_t&)>& it) const override;
+    size_t get_node_count() const override { return ids_.size(); }
+    nid_t min_node_id() const override { return ids_.empty() ? 0 : ids_.front(); }
+    nid_t max_node_id() const override { return ids_.empty() ? 0 : ids_.back(); }
+    // the engine's view: nodes in id order, oriented node = 2 * index + is_reverse
+    uint32_t oriented(const handle_t& h) const { return 2u * (uint32_t)index_of_.at(get_id(h)) + (get_is_reverse(h) ? 1u : 0u); }
+    handle_t handle_of(uint32_t oriented_node) const { return get_handle(ids_[oriented_node >> 1], oriented_node & 1u); }
+    const std::vector<std::string>& sequences() const { return seqs_; }
+    const std::vector<std::vector<uint32_t>>& threads() const { return threads_; }
+private:
+    std::vector<nid_t> ids_;                          // ascending
+    std::vector<std::string> seqs_;
+    std::unordered_map<nid_t, size_t> index_of_;
+    std::vector<std::vector<uint32_t>> threads_;      // oriented nodes
+    std::set<std::pair<int64_t, int64_t>> edges_;     // oriented node pairs that some thread crosses
+};
+
+// src/gbwt_extender.hpp:30-90
+struct GaplessExtension {
+    typedef std::pair<handle_t, int64_t> seed_type;          // (handle, read_offset - node_offset)
+    struct SearchState { int64_t node = 0; std::pair<size_t, size_t> range{0, 0}; };
+    struct BidirectionalState { SearchState forward, backward; bool operator==(const BidirectionalState& o) const {
+        return forward.node == o.forward.node && forward.range == o.forward.range && backward.node == o.backward.node && backward.range == o.backward.range; } };
+
+    std::vector<handle_t>     path;
+    size_t                    offset = 0;
+    BidirectionalState        state;                          // the engine's oriented-node numbering
+    std::pair<size_t, size_t> read_interval{0, 0};
+    std::vector<size_t>       mismatch_positions;
+    int32_t                   score = 0;
+    bool                      left_full = false, right_full = false;
+
+    size_t length() const { return read_interval.second - read_interval.first; }
+    bool empty() const { return length() == 0; }
+    bool full() const { return left_full & right_full; }
+    bool exact() const { return mismatch_positions.empty(); }
+    size_t mismatches() const { return mismatch_positions.size(); }
+    bool contains(const HandleGraph& graph, const seed_type& seed) const;
+    Position starting_position(const HandleGraph& graph) const;
+    Position tail_position(const HandleGraph& graph) const;
+    size_t tail_offset(const HandleGraph& graph) const;
+    size_t overlap(const HandleGraph& graph, const GaplessExtension& another) const;
+    Path to_path(const HandleGraph& graph, const std::string& sequence) const;
+    bool operator<(const GaplessExtension& another) const { return score < another.score; }
+    bool operator==(const GaplessExtension& another) const { return read_interval == another.read_interval && state == another.state && offset == another.offset; }
+    bool operator!=(const GaplessExtension& another) const { return !(*this == another); }
+};
+
+// src/gbwt_extender.hpp:140-217
+class GaplessExtender {
+public:
+    typedef GaplessExtension::seed_type seed_type;
+    // the reference's cluster is a hash set of seeds; here an ordered list of distinct seeds, visited in that order
+    typedef std::vector<seed_type> cluster_type;
+    constexpr static size_t MAX_MISMATCHES = 4;
+    constexpr static double OVERLAP_THRESHOLD = 0.8;
+
+    GaplessExtender(const HaplotypeGraph& graph, const Aligner& aligner);    // uploads the haplotype index
+    ~GaplessExtender();
+    GaplessExtender(const GaplessExtender&) = delete;
+    GaplessExtender& operator=(const GaplessExtender&) = delete;
+
+    static seed_type to_seed(const HandleGraph& graph, const Position& pos, size_t read_offset) {
+        return seed_type(graph.get_handle(pos.node_id, pos.is_reverse), (int64_t)read_offset - pos.offset);
+    }
+    static handle_t get_handle(seed_type seed) { return seed.first; }
+    static size_t get_node_offset(seed_type seed) { return seed.second < 0 ? (size_t)(-seed.second) : 0; }
+    static size_t get_read_offset(seed_type seed) { return seed.second < 0 ? 0 : (size_t)seed.second; }
+
+    std::vector<GaplessExtension> extend(const cluster_type& cluster, std::string sequence, size_t max_mismatches = MAX_MISMATCHES,
+                                         double overlap_threshold = OVERLAP_THRESHOLD, bool trim = true) const;
+    static bool full_length_extensions(const std::vector<GaplessExtension>& result, size_t max_mismatches = MAX_MISMATCHES);
+
+    const HaplotypeGraph* graph;
+    const Aligner*        aligner;
+private:
+    vgk_haplo* index = nullptr;
+};
+
+}  // namespace vgamd

@@ -5,6 +5,7 @@
 #include <memory>
 #include <string>
 #include "aligner.hpp"
+#include "gbwt_extender.hpp"
 
 using namespace vgamd;
 
@@ -99,6 +100,50 @@ int vgh_align_xdrop(vgh_aligner* a, vgh_graph* g, const char* read, const int64_
         }
         a->a->align_xdrop(aln, g->g, ms, reverse_complemented != 0, (uint16_t)max_gap);
         return emit(aln, json_out, json_cap);
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// ---- GaplessExtender (src/gbwt_extender.hpp:140-217) over a HaplotypeGraph built from `g` and explicit threads ----------
+struct vgh_extender { std::unique_ptr<HaplotypeGraph> graph; std::unique_ptr<GaplessExtender> ext; };
+// threads: oriented node ids (2 * id + is_reverse), thread t = thread_nodes[thread_off[t] .. thread_off[t + 1])
+vgh_extender* vgh_gapless_create(vgh_aligner* a, vgh_graph* g, const int64_t* thread_nodes, const int32_t* thread_off, int n_threads) {
+    try {
+        std::vector<std::vector<handle_t>> threads((size_t)n_threads);
+        for (int t = 0; t < n_threads; ++t) for (int32_t k = thread_off[t]; k < thread_off[t + 1]; ++k) threads[t].push_back(g->g.get_handle(thread_nodes[k] >> 1, thread_nodes[k] & 1));
+        auto* h = new vgh_extender();
+        h->graph = std::make_unique<HaplotypeGraph>(g->g, threads);
+        h->ext = std::make_unique<GaplessExtender>(*h->graph, *a->a);
+        return h;
+    } catch (std::exception& e) { g_last_error = e.what(); return nullptr; }
+}
+void vgh_gapless_destroy(vgh_extender* e) { delete e; }
+// seeds: [node id, is_reverse, node offset, read offset] x n_seeds; JSON out: one object per extension
+int vgh_gapless_extend(vgh_extender* x, const char* read, const int64_t* seeds, int n_seeds, int max_mismatches, double overlap_threshold,
+                       int trim, char* json_out, size_t json_cap) {
+    try {
+        GaplessExtender::cluster_type cluster;
+        for (int i = 0; i < n_seeds; ++i) {
+            Position pos; pos.node_id = seeds[4 * i]; pos.is_reverse = seeds[4 * i + 1] != 0; pos.offset = seeds[4 * i + 2];
+            cluster.push_back(GaplessExtender::to_seed(*x->graph, pos, (size_t)seeds[4 * i + 3]));
+        }
+        const std::string sequence(read);
+        auto result = x->ext->extend(cluster, sequence, (size_t)max_mismatches, overlap_threshold, trim != 0);
+        std::string js = "{\"full_length\":";
+        js += GaplessExtender::full_length_extensions(result, (size_t)max_mismatches) ? "true" : "false";
+        js += ",\"extensions\":[";
+        for (size_t i = 0; i < result.size(); ++i) {
+            const GaplessExtension& e = result[i];
+            Alignment aln; aln.sequence = sequence; aln.path = e.to_path(*x->graph, sequence); aln.score = e.score;
+            bool all = true; for (const auto& s : cluster) all = all && e.contains(*x->graph, s);
+            if (i) js += ',';
+            js += "{\"alignment\":" + alignment_to_json(aln) + ",\"read_begin\":" + std::to_string(e.read_interval.first) + ",\"read_end\":" + std::to_string(e.read_interval.second) +
+                  ",\"mismatches\":" + std::to_string(e.mismatches()) + ",\"left_full\":" + (e.left_full ? "true" : "false") + ",\"right_full\":" + (e.right_full ? "true" : "false") +
+                  ",\"contains_all_seeds\":" + (all ? "true" : "false") + ",\"tail_offset\":" + std::to_string(e.tail_offset(*x->graph)) + "}";
+        }
+        js += "]}";
+        if (js.size() + 1 > json_cap) { g_last_error = "json buffer too small"; return -2; }
+        std::memcpy(json_out, js.c_str(), js.size() + 1);
+        return 0;
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }
 

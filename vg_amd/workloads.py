@@ -274,3 +274,73 @@ class BandedWorkload:
         self.problems = problems
         self.bs = capi.BandedSet.from_lists(problems)
         self.n = n_reads
+
+
+class GaplessWorkload:
+    """giraffe's first extension stage (configs[2]/[3]): haplotype-consistent gapless extension of minimizer seeds
+    (MinimizerMapper::extend_seed_group -> GaplessExtender::extend, src/minimizer_mapper.cpp:4784).  A variation graph with
+    `n_haplotypes` random threads (every SNP / insertion allele chosen independently); 150 bp reads sampled from a thread on either
+    strand with 1 % substitutions; `seeds_per_read` seeds at true positions (distinct read offsets), as a minimizer index
+    would report for an error-free k-mer."""
+
+    def __init__(self, n_reads, seed=123, graph_bp=1_000_000, n_haplotypes=8, read_len=150, seeds_per_read=6, snp_every=100, indel_every=1000):
+        rng = np.random.default_rng(seed)
+        seqs, preds, kind = build_variation_graph(rng, graph_bp, snp_every, indel_every)
+        n_nodes = len(seqs)
+        kind = np.array(kind)
+        lens = np.array([len(s) for s in seqs], dtype=np.int64)
+        succ = [[] for _ in seqs]
+        for v, pr in enumerate(preds):
+            for p in pr:
+                succ[p].append(v)
+        self.nodes = [s.tobytes().decode() for s in seqs]
+        # threads: walk from node 0, pick a random successor at every branch
+        threads = []
+        for _ in range(n_haplotypes):
+            t = [0]; v = 0
+            while succ[v]:
+                v = succ[v][int(rng.integers(0, len(succ[v])))]
+                t.append(v)
+            threads.append(np.array(t, dtype=np.int64))
+        self.threads = [list((2 * t).astype(int)) for t in threads]
+        comp = np.zeros(256, dtype=np.uint8); comp[:] = np.arange(256)
+        for a, b in zip(b"ACGT", b"TGCA"):
+            comp[a] = b
+        hap_seq = [np.concatenate([seqs[v] for v in t]) for t in threads]
+        hap_start = [np.concatenate([[0], np.cumsum(lens[t])]) for t in threads]
+        which = rng.integers(0, n_haplotypes, n_reads)
+        rev = rng.random(n_reads) < 0.5
+        reads = np.zeros((n_reads, read_len), dtype=np.uint8)
+        seeds = np.zeros(n_reads * seeds_per_read, dtype=capi.SEED_DT)
+        for hidx in range(n_haplotypes):
+            sel = np.nonzero(which == hidx)[0]
+            if not len(sel):
+                continue
+            hs = hap_seq[hidx]; st = hap_start[hidx]; t = threads[hidx]
+            a = rng.integers(0, len(hs) - read_len, len(sel))
+            fw = hs[a[:, None] + np.arange(read_len)[None, :]]                   # forward-strand window of every read
+            r = rev[sel]
+            rd = np.where(r[:, None], comp[fw[:, ::-1]], fw)
+            sub = rng.random(rd.shape) < 0.01
+            rd = np.where(sub, ACGT[rng.integers(0, 4, rd.shape)], rd)
+            reads[sel] = rd
+            ro = np.sort(np.argsort(rng.random((len(sel), read_len)), axis=1)[:, :seeds_per_read], axis=1)   # distinct read offsets
+            g = np.where(r[:, None], a[:, None] + read_len - 1 - ro, a[:, None] + ro)                        # forward-strand base hit by the seed
+            k = np.searchsorted(st, g, side="right") - 1
+            node = t[k]; off = g - st[k]
+            off_o = np.where(r[:, None], lens[node] - 1 - off, off)                                          # offset on the read's strand
+            flat = (sel[:, None] * seeds_per_read + np.arange(seeds_per_read)[None, :]).ravel()
+            seeds["node"][flat] = (2 * node + r[:, None]).ravel()
+            seeds["diff"][flat] = (ro - off_o).ravel()
+        # a cluster is a set: drop seeds that repeat (same node and diagonal) inside a read
+        keep = np.ones(len(seeds), dtype=bool)
+        s2 = seeds.reshape(n_reads, seeds_per_read)
+        for i in range(1, seeds_per_read):
+            for j in range(i):
+                keep.reshape(n_reads, seeds_per_read)[:, i] &= ~((s2["node"][:, i] == s2["node"][:, j]) & (s2["diff"][:, i] == s2["diff"][:, j]))
+        counts = keep.reshape(n_reads, seeds_per_read).sum(axis=1)
+        seed_off = np.concatenate([[0], np.cumsum(counts)])
+        self.gs = capi.GaplessSet(reads.ravel(), np.arange(n_reads + 1) * read_len, seeds[keep], seed_off,
+                                  node_cap=int(counts.sum()) * 16, mism_cap=int(counts.sum()) * 12)
+        self.n = n_reads
+        self.read_len = read_len
