@@ -21,6 +21,7 @@
 #include <thread>
 #include <vector>
 #include "ctx.hpp"
+#include "host_parallel.hpp"
 
 using namespace vgk;
 
@@ -204,31 +205,8 @@ void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch&
     hp.on_device = true;
 }
 
-constexpr unsigned MAX_THREADS = 32;
-// run f(i, thread) for i in [0, n) on a few host threads
-template <class F> void parallel_for(uint32_t n, F f) {
-    unsigned hw = std::thread::hardware_concurrency();
-    unsigned T = std::min<unsigned>(hw ? hw : 1, MAX_THREADS);
-    if (const char* e = std::getenv("VGAMD_HOST_THREADS")) T = (unsigned)std::min<int>(MAX_THREADS, std::max(1, std::atoi(e)));
-    if (n < 256 || T <= 1) { for (uint32_t i = 0; i < n; ++i) f(i, 0u); return; }
-    std::atomic<uint32_t> next{0};
-    std::vector<std::thread> ts;
-    for (unsigned t = 0; t < T; ++t) ts.emplace_back([&, t]() {
-        for (;;) { const uint32_t b = next.fetch_add(64); if (b >= n) break; for (uint32_t i = b; i < std::min(n, b + 64); ++i) f(i, t); }
-    });
-    for (auto& t : ts) t.join();
-}
-
 // device scratch cached on the context (grow-only)
-void* ensure(vgk_ctx* ctx, int slot, uint64_t bytes) {
-    vgk_ctx::DevBuf& b = ctx->scratch[slot];
-    if (b.p && b.bytes >= bytes) return b.p;
-    if (b.p) { ctx->be->sync(); ctx->be->release(b.p); b.p = nullptr; b.bytes = 0; }
-    const uint64_t want = std::max<uint64_t>(bytes + bytes / 4, 4096);
-    b.p = ctx->be->alloc(want); b.bytes = want;
-    if (!b.p) { b.p = ctx->be->alloc(bytes); b.bytes = b.p ? bytes : 0; }
-    return b.p;
-}
+inline void* ensure(vgk_ctx* ctx, int slot, uint64_t bytes) { return ctx->ensure_scratch(slot, bytes); }
 template <class T> int stage(vgk_ctx* ctx, int slot, const T* v, size_t count, const T*& out) {
     void* d = ensure(ctx, slot, std::max<size_t>(count, 1) * sizeof(T));
     if (!d) return VGK_ENOMEM;

@@ -19,7 +19,16 @@ struct vgk_ctx {
     double gapless_ms = 0;         // kernel time of the last vgk_gapless_extend call
     // device scratch kept between vgk_banded_align calls (grow-only; released with the context)
     struct DevBuf { void* p = nullptr; uint64_t bytes = 0; };
-    DevBuf scratch[16];
+    DevBuf scratch[32];            // 0..14 banded_api.cpp, 15.. gapless_api.cpp
+    void* ensure_scratch(int slot, uint64_t bytes) {
+        DevBuf& b = scratch[slot];
+        if (b.p && b.bytes >= bytes) return b.p;
+        if (b.p) { be->sync(); be->release(b.p); b.p = nullptr; b.bytes = 0; }
+        const uint64_t want = bytes + bytes / 4 > 4096 ? bytes + bytes / 4 : 4096;
+        b.p = be->alloc(want); b.bytes = want;
+        if (!b.p) { b.p = be->alloc(bytes); b.bytes = b.p ? bytes : 0; }
+        return b.p;
+    }
     std::shared_ptr<void> banded_host;      // host staging arenas of banded_api.cpp
     ~vgk_ctx() { if (be) for (DevBuf& b : scratch) if (b.p) be->release(b.p); }
 };

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 #include "ctx.hpp"
+#include "host_parallel.hpp"
 
 using namespace vgk;
 
@@ -51,12 +52,12 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
     std::vector<uint32_t> len(O), seq_off(O);
     uint64_t total = 0; for (uint32_t i = 0; i < N; ++i) total += d->node_len[i];
     if (2 * total > 0xfffffff0ull) return VGK_ETOOBIG;
-    std::vector<char> seq(2 * total);
-    { uint32_t at = 0, rat = (uint32_t)total;
+    std::vector<char> seq(2 * total + 16, 0);       // 8 bytes of padding at either end: the kernel compares eight bases per load
+    { uint32_t at = 8, rat = (uint32_t)total + 8;
       for (uint32_t i = 0; i < N; ++i) {
           const uint32_t L = d->node_len[i];
           len[2 * i] = len[2 * i + 1] = L; seq_off[2 * i] = at; seq_off[2 * i + 1] = rat;
-          for (uint32_t k = 0; k < L; ++k) { seq[at + k] = d->seq[at + k]; seq[rat + k] = complement(d->seq[at + L - 1 - k]); }
+          for (uint32_t k = 0; k < L; ++k) { seq[at + k] = d->seq[at - 8 + k]; seq[rat + k] = complement(d->seq[at - 8 + L - 1 - k]); }
           at += L; rat += L;
       } }
     // sequences: thread t forward = 2t, reverse complement = 2t + 1
@@ -144,21 +145,22 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     for (uint32_t i = 0; i < n; ++i) {
         const vgk_gapless_problem& p = problems[i];
         if ((p.read_len && !p.read) || (p.n_seeds && !p.seeds)) return VGK_EINVAL;
-        probs[i] = {(uint32_t)n_read, p.read_len, (uint32_t)n_seed, p.n_seeds, p.max_mismatches, p.flags, p.overlap_threshold};
+        probs[i] = {(uint32_t)n_read + 8, p.read_len, (uint32_t)n_seed, p.n_seeds, p.max_mismatches, p.flags, p.overlap_threshold};
         n_read += p.read_len; n_seed += p.n_seeds;
         if (n_read > 0xfffffff0ull || n_seed > 0xfffffff0ull) return VGK_ETOOBIG;
     }
-    std::vector<char> reads(n_read + 1); std::vector<vgk_seed> seeds(n_seed + 1);
-    for (uint32_t i = 0; i < n; ++i) {
+    std::vector<char> reads(n_read + 16, 0); std::vector<vgk_seed> seeds(n_seed + 1);     // 8 bytes of padding at either end
+    parallel_for(n, [&](uint32_t i, unsigned) {
         const vgk_gapless_problem& p = problems[i];
         char* r = reads.data() + probs[i].read_off;
         for (uint32_t k = 0; k < p.read_len; ++k) { const char c = p.read[k]; r[k] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'X'; }
         if (p.n_seeds) std::memcpy(seeds.data() + probs[i].seed_off, p.seeds, sizeof(vgk_seed) * p.n_seeds);
-    }
-    std::vector<void*> held;
-    auto cleanup = [&](int rc) { for (void* d : held) be->release(d); return rc; };
+    });
+    // device buffers are kept on the context between calls (grow-only)
+    int next_slot = 16;
+    auto cleanup = [&](int rc) { return rc; };
     auto dev = [&](const void* src, size_t bytes) -> void* {
-        void* d = be->alloc(std::max<size_t>(bytes, 16)); if (!d) return nullptr; held.push_back(d);
+        void* d = ctx->ensure_scratch(next_slot++, std::max<size_t>(bytes, 16)); if (!d) return nullptr;
         if (src && bytes && be->upload(d, src, bytes)) return nullptr;
         return d;
     };
@@ -172,8 +174,11 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     const uint64_t cap_e = n_seed + 1, cap_n = std::min<uint64_t>(n_seed * G_PATH, std::max<uint64_t>(n_seed * 16 + 1024, nodes_cap)) + 1,
                    cap_m = std::min<uint64_t>(n_seed * G_MISM, std::max<uint64_t>(n_seed * 8 + 1024, mism_cap)) + 1;
     P.caps[0] = cap_e; P.caps[1] = cap_n; P.caps[2] = cap_m;
-    const uint32_t threads = (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max(1, be->compute_units()) * 256);      // resident threads = scratch slabs
-    P.scratch = (GScratch*)dev(nullptr, sizeof(GScratch) * (size_t)threads);
+    // resident threads = scratch slabs: as many as the kernel's register footprint lets the device hold (12 wavefronts per CU)
+    const uint32_t threads = (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max(1, be->compute_units()) * 768);
+    { vgk_ctx::DevBuf& b = ctx->scratch[15];
+      const uint64_t want = sizeof(GScratch) * (uint64_t)threads;
+      (void)b; P.scratch = (GScratch*)ctx->ensure_scratch(15, want); }
     P.results = (vgk_gapless_result*)dev(nullptr, sizeof(vgk_gapless_result) * n);
     P.ext = (vgk_extension*)dev(nullptr, sizeof(vgk_extension) * cap_e);
     P.nodes = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_n);
@@ -193,26 +198,40 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     if (nn && (rc = be->download(dnodes.data(), P.nodes, sizeof(uint32_t) * nn))) return cleanup(rc);
     if (nm && (rc = be->download(dmism.data(), P.mism, sizeof(uint32_t) * nm))) return cleanup(rc);
     ctx->gapless_ms = be->last_ms(5);
-    // the device packs sets in completion order; hand them back in problem order
-    size_t we = 0, wn = 0, wm = 0; int rc_all = VGK_OK;
+    // the device packs sets in completion order; hand them back in problem order: sizes, a prefix sum, then parallel copies
+    std::vector<uint64_t> oe(n + 1, 0), on(n + 1, 0), om(n + 1, 0);
+    parallel_for(n, [&](uint32_t i, unsigned) {
+        const vgk_gapless_result& r = dres[i];
+        if (r.status != VGK_OK) return;
+        uint64_t need_n = 0, need_m = 0;
+        for (uint32_t k = 0; k < r.n_ext; ++k) { need_n += dext[r.ext_begin + k].path_len; need_m += dext[r.ext_begin + k].n_mismatches; }
+        oe[i + 1] = r.n_ext; on[i + 1] = need_n; om[i + 1] = need_m;
+    });
+    int rc_all = VGK_OK;
     for (uint32_t i = 0; i < n; ++i) {
+        if (dres[i].status == VGK_OK && (oe[i] + oe[i + 1] > ext_cap || on[i] + on[i + 1] > nodes_cap || om[i] + om[i + 1] > mism_cap || !extensions || !nodes || !mismatches)) {
+            dres[i].status = VGK_EOPS; oe[i + 1] = on[i + 1] = om[i + 1] = 0;
+        }
+        if (dres[i].status == VGK_EOPS) rc_all = VGK_EOPS;
+        oe[i + 1] += oe[i]; on[i + 1] += on[i]; om[i + 1] += om[i];
+    }
+    parallel_for(n, [&](uint32_t i, unsigned) {
         vgk_gapless_result r = dres[i];
         const uint32_t src = r.ext_begin;
-        r.ext_begin = (uint32_t)we;
+        r.ext_begin = (uint32_t)oe[i];
         if (r.status == VGK_OK) {
-            size_t need_n = 0, need_m = 0;
-            for (uint32_t k = 0; k < r.n_ext; ++k) { need_n += dext[src + k].path_len; need_m += dext[src + k].n_mismatches; }
-            if (we + r.n_ext > ext_cap || wn + need_n > nodes_cap || wm + need_m > mism_cap || !extensions || !nodes || !mismatches) { r.status = VGK_EOPS; r.n_ext = 0; rc_all = VGK_EOPS; }
-            else for (uint32_t k = 0; k < r.n_ext; ++k) {
+            uint64_t wn = on[i], wm = om[i];
+            for (uint32_t k = 0; k < r.n_ext; ++k) {
                 vgk_extension x = dext[src + k];
                 std::memcpy(nodes + wn, dnodes.data() + x.path_begin, sizeof(uint32_t) * x.path_len);
                 std::memcpy(mismatches + wm, dmism.data() + x.mism_begin, sizeof(uint32_t) * x.n_mismatches);
                 x.path_begin = (uint32_t)wn; x.mism_begin = (uint32_t)wm;
-                extensions[we++] = x; wn += x.path_len; wm += x.n_mismatches;
+                extensions[oe[i] + k] = x; wn += x.path_len; wm += x.n_mismatches;
             }
-        } else { r.n_ext = 0; if (r.status == VGK_EOPS) rc_all = VGK_EOPS; }
+        } else r.n_ext = 0;
         results[i] = r;
-    }
+    });
+    const size_t we = oe[n], wn = on[n], wm = om[n];
     if (written) { written[0] = we; written[1] = wn; written[2] = wm; }
     return cleanup(rc_all);
 }

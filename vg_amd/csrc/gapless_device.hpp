@@ -110,6 +110,40 @@ VGK_HD unsigned long long g_bump(unsigned long long* counter, unsigned long long
 
 struct GCtx { const GaplessParams* P; const char* seq; uint32_t L; };
 
+// Eight bases per compare, like the reference's memcpy'd uint64 words (:219-224).  Both buffers carry 8 bytes of padding at
+// either end, so a word that straddles the end of the data stays inside the allocation.
+VGK_HD uint64_t g_load8(const char* p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
+// forward: compare a[0..left) with b[0..left); stops BEFORE the mismatch that would reach `limit`; returns the bases consumed
+VGK_HD uint32_t g_match_fwd(const char* a, const char* b, uint32_t left, uint32_t& internal, uint32_t limit) {
+    uint32_t n = 0;
+    while (n < left) {
+        const uint64_t wa = g_load8(a + n), wb = g_load8(b + n);
+        const uint32_t len = left - n < 8 ? left - n : 8;
+        if (len == 8 && wa == wb) { n += 8; continue; }
+        uint64_t x = wa ^ wb;
+        for (uint32_t i = 0; i < len; ++i, x >>= 8) {
+            if (x & 0xff) { if (internal + 1 >= limit) return n; ++internal; }
+            ++n;
+        }
+    }
+    return n;
+}
+// backward: compare a[-1], a[-2], ... with b[-1], b[-2], ... for up to `left` bases
+VGK_HD uint32_t g_match_bwd(const char* a, const char* b, uint32_t left, uint32_t& internal, uint32_t limit) {
+    uint32_t n = 0;
+    while (n < left) {
+        const uint64_t wa = g_load8(a - n - 8), wb = g_load8(b - n - 8);
+        const uint32_t len = left - n < 8 ? left - n : 8;
+        if (len == 8 && wa == wb) { n += 8; continue; }
+        uint64_t x = wa ^ wb;
+        for (uint32_t i = 0; i < len; ++i, x <<= 8) {
+            if (x >> 56) { if (internal + 1 >= limit) return n; ++internal; }
+            ++n;
+        }
+    }
+    return n;
+}
+
 VGK_HD void g_set_score(const GCtx& c, GEntry& e) {                                   // (:201-209)
     e.score = (int32_t)((e.r1 - e.r0) * (uint32_t)c.P->match) - (int32_t)(e.internal * (uint32_t)(c.P->match + c.P->mismatch))
             + e.left_full * c.P->bonus + e.right_full * c.P->bonus;
@@ -280,8 +314,8 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
             m.parent = -1; m.node = snode; m.front = 0; m.offset = node_offset; m.r0 = m.r1 = read_offset; m.internal = 0;
             m.left_full = m.right_full = m.left_max = m.right_max = 0; m.state = gs_find(h, snode);
             const char* t = h.seq + h.seq_off[snode];
-            uint32_t no = node_offset, left = L - m.r1 < h.len[snode] - no ? L - m.r1 : h.len[snode] - no;
-            while (left--) { if (c.seq[m.r1] != t[no]) ++m.internal; ++m.r1; ++no; }
+            const uint32_t left = L - m.r1 < h.len[snode] - node_offset ? L - m.r1 : h.len[snode] - node_offset;
+            m.r1 += g_match_fwd(c.seq + m.r1, t + node_offset, left, m.internal, 0xffffffffu);
             m.old = m.internal;
             if (m.r0 == 0) m.left_full = m.left_max = 1;
             if (m.r1 >= L) m.right_full = m.right_max = 1;
@@ -302,8 +336,8 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
                     if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
                     GEntry& nx = S.pool[np]; nx = cur; nx.parent = ci; nx.node = w; nx.front = 0; nx.state = ns;
                     const char* t = h.seq + h.seq_off[w];                                           // match_forward (:239-266)
-                    uint32_t no = 0, left = L - nx.r1 < h.len[w] ? L - nx.r1 : h.len[w];
-                    while (left) { if (c.seq[nx.r1] != t[no]) { if (nx.internal + 1 >= limit) break; ++nx.internal; } ++nx.r1; ++no; --left; }
+                    const uint32_t no = g_match_fwd(c.seq + nx.r1, t, L - nx.r1 < h.len[w] ? L - nx.r1 : h.len[w], nx.internal, limit);
+                    nx.r1 += no;
                     if (no == 0) continue;
                     if (nx.r1 >= L) { nx.right_full = nx.right_max = 1; nx.old = nx.internal; }
                     else if (no < h.len[w]) { nx.right_max = 1; nx.old = nx.internal; }
@@ -332,8 +366,8 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
                     if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
                     GEntry& nx = S.pool[np]; nx = cur; nx.parent = ci; nx.node = w; nx.front = 1; nx.state = ns; nx.offset = h.len[w];
                     const char* t = h.seq + h.seq_off[w];                                           // match_backward (:268-296)
-                    uint32_t left = nx.r0 < nx.offset ? nx.r0 : nx.offset;
-                    while (left) { if (c.seq[nx.r0 - 1] != t[nx.offset - 1]) { if (nx.internal + 1 >= limit) break; ++nx.internal; } --nx.r0; --nx.offset; --left; }
+                    const uint32_t back = g_match_bwd(c.seq + nx.r0, t + nx.offset, nx.r0 < nx.offset ? nx.r0 : nx.offset, nx.internal, limit);
+                    nx.r0 -= back; nx.offset -= back;
                     if (nx.offset >= h.len[w]) continue;
                     if (nx.r0 == 0) nx.left_full = nx.left_max = 1;
                     else if (nx.offset > 0) nx.left_max = 1;

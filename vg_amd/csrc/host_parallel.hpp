@@ -1,0 +1,27 @@
+// host_parallel.hpp — a few host threads for the packing / unpacking loops of the C-ABI layer.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+namespace vgk {
+
+constexpr unsigned MAX_THREADS = 32;
+// run f(i, thread) for i in [0, n) on a few host threads
+template <class F> inline void parallel_for(uint32_t n, F f) {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned T = std::min<unsigned>(hw ? hw : 1, MAX_THREADS);
+    if (const char* e = std::getenv("VGAMD_HOST_THREADS")) T = (unsigned)std::min<int>(MAX_THREADS, std::max(1, std::atoi(e)));
+    if (n < 256 || T <= 1) { for (uint32_t i = 0; i < n; ++i) f(i, 0u); return; }
+    std::atomic<uint32_t> next{0};
+    std::vector<std::thread> ts;
+    for (unsigned t = 0; t < T; ++t) ts.emplace_back([&, t]() {
+        for (;;) { const uint32_t b = next.fetch_add(64); if (b >= n) break; for (uint32_t i = b; i < std::min(n, b + 64); ++i) f(i, t); }
+    });
+    for (auto& t : ts) t.join();
+}
+
+
+}  // namespace vgk
