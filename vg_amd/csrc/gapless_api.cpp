@@ -110,14 +110,24 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
             edge_base[(uint32_t)(std::lower_bound(first, last, (int32_t)w) - edge_to.data())] = i;
         }
     }
+    // one padded record per oriented node (layout in gapless_device.hpp)
+    std::vector<uint32_t> rec_off(O + 1, 0), rec;
+    for (uint32_t o = 0; o < O; ++o) {
+        rec_off[o] = (uint32_t)rec.size();
+        const uint32_t ne = edge_off[o + 1] - edge_off[o];
+        rec.push_back(count[o]); rec.push_back(ne); rec.push_back(len[o]); rec.push_back(seq_off[o]);
+        for (uint32_t e = edge_off[o]; e < edge_off[o + 1]; ++e) { rec.push_back((uint32_t)edge_to[e]); rec.push_back(edge_base[e]); }
+        for (uint32_t i = 0; i < count[o]; ++i) rec.push_back(body[body_off[o] + i]);
+        while (rec.size() % 16) rec.push_back(0);
+        if (rec.size() > 0xfffffff0ull) return VGK_ETOOBIG;
+    }
+    rec_off[O] = (uint32_t)rec.size();
     vgk_haplo* h = new vgk_haplo();
     h->ctx = ctx; h->n_oriented = O; h->len = len;
     std::lock_guard<std::mutex> lock(ctx->mu);
     int rc;
     h->dev.n_oriented = O;
-    if ((rc = put(h, len, h->dev.len)) || (rc = put(h, seq_off, h->dev.seq_off)) || (rc = put(h, seq, h->dev.seq)) || (rc = put(h, count, h->dev.count)) ||
-        (rc = put(h, edge_off, h->dev.edge_off)) || (rc = put(h, edge_to, h->dev.edge_to)) || (rc = put(h, edge_base, h->dev.edge_base)) ||
-        (rc = put(h, body_off, h->dev.body_off)) || (rc = put(h, body, h->dev.body)) || (rc = ctx->be->sync())) {
+    if ((rc = put(h, rec_off, h->dev.rec_off)) || (rc = put(h, rec, h->dev.rec)) || (rc = put(h, seq, h->dev.seq)) || (rc = ctx->be->sync())) {
         for (void* p : h->held) ctx->be->release(p);
         delete h; return rc;
     }

@@ -18,18 +18,18 @@
 
 namespace vgk {
 
+// One record per oriented node, padded to a multiple of 16 words so that a hop touches one or two cache lines:
+//   word 0 visit count | 1 outgoing edges | 2 node length | 3 offset of the node's bases in `seq`
+//   then per edge (ascending successor): successor (or -1: a thread ends) , where this node's visits start in the successor's record
+//   then per visit: the index of the edge it leaves through
 struct GIndex {                       // device pointers
     uint32_t n_oriented;
-    const uint32_t* len;              // per oriented node
-    const uint32_t* seq_off;          // per oriented node, into seq
-    const char*     seq;              // forward strands, then reverse complements
-    const uint32_t* count;            // haplotype visits per oriented node
-    const uint32_t* edge_off;         // n_oriented + 1
-    const int32_t*  edge_to;          // successor or -1 (a thread ends), ascending
-    const uint32_t* edge_base;        // where this node's visits start in the successor's record
-    const uint32_t* body_off;         // n_oriented + 1
-    const uint32_t* body;             // per visit: index of the edge it leaves through
+    const uint32_t* rec_off;          // per oriented node, in words
+    const uint32_t* rec;
+    const char*     seq;              // forward strands, then reverse complements (8 bytes of padding at either end)
 };
+VGK_HD const uint32_t* g_rec(const GIndex& h, uint32_t o) { return h.rec + h.rec_off[o]; }
+VGK_HD uint32_t g_len(const GIndex& h, int32_t o) { return g_rec(h, (uint32_t)o)[2]; }
 struct GProb { uint32_t read_off, read_len, seed_off, n_seeds, max_mm, flags; double overlap; };
 
 struct GState { int32_t fn, flo, fhi, bn, blo, bhi; };      // forward / backward strand: node, visit range [lo, hi]
@@ -37,26 +37,26 @@ VGK_HD bool gs_empty(const GState& s) { return s.flo > s.fhi; }
 VGK_HD uint32_t gs_size(const GState& s) { return s.flo > s.fhi ? 0u : (uint32_t)(s.fhi - s.flo + 1); }
 VGK_HD GState gs_flip(const GState& s) { GState r = { s.bn, s.blo, s.bhi, s.fn, s.flo, s.fhi }; return r; }
 VGK_HD GState gs_find(const GIndex& h, int32_t node) {
-    GState s = { node, 0, (int32_t)h.count[node] - 1, node ^ 1, 0, (int32_t)h.count[node ^ 1] - 1 };
+    GState s = { node, 0, (int32_t)g_rec(h, (uint32_t)node)[0] - 1, node ^ 1, 0, (int32_t)g_rec(h, (uint32_t)node ^ 1u)[0] - 1 };
     return s;
 }
 VGK_HD int32_t g_rkey(int32_t x) { return x < 0 ? -1 : (x ^ 1); }
 // bdExtendForward: follow the visits of the forward range that leave through `to`
 VGK_HD GState gs_extend(const GIndex& h, const GState& s, int32_t to) {
     const uint32_t o = (uint32_t)s.fn;
-    const uint32_t* body = h.body + h.body_off[o];
-    const int32_t* et = h.edge_to + h.edge_off[o];
-    const uint32_t ne = h.edge_off[o + 1] - h.edge_off[o];
-    uint32_t e = 0; while (e < ne && et[e] != to) ++e;
+    const uint32_t* rec = g_rec(h, o);
+    const uint32_t ne = rec[1];
+    const uint32_t* body = rec + 4 + 2 * ne;
+    uint32_t e = 0; while (e < ne && (int32_t)rec[4 + 2 * e] != to) ++e;
     GState r = s; r.fn = to;
     if (e == ne || gs_empty(s)) { r.flo = 0; r.fhi = -1; r.bhi = r.blo - 1; return r; }
     int32_t before = 0, inside = 0, rev_off = 0;
     for (int32_t i = 0; i <= s.fhi; ++i) {
         const uint32_t b = body[i];
         if (b == e) { if (i < s.flo) ++before; else ++inside; }
-        else if (i >= s.flo && g_rkey(et[b]) < g_rkey(to)) ++rev_off;
+        else if (i >= s.flo && g_rkey((int32_t)rec[4 + 2 * b]) < g_rkey(to)) ++rev_off;
     }
-    r.flo = (int32_t)h.edge_base[h.edge_off[o] + e] + before; r.fhi = r.flo + inside - 1;
+    r.flo = (int32_t)rec[5 + 2 * e] + before; r.fhi = r.flo + inside - 1;
     r.blo = s.blo + rev_off; r.bhi = r.blo + inside - 1;
     return r;
 }
@@ -85,7 +85,7 @@ struct GExt {                        // a finished per-seed winner
     int32_t  path[G_PATH];
     uint32_t mism[G_MISM];
 };
-struct GScratch { GEntry pool[G_POOL]; uint16_t heap[G_POOL]; GExt res[G_SEEDS]; };
+struct GScratch { uint64_t heap[G_POOL]; GEntry pool[G_POOL]; GExt res[G_SEEDS]; };
 
 struct GaplessParams {
     GIndex index;
@@ -148,20 +148,27 @@ VGK_HD void g_set_score(const GCtx& c, GEntry& e) {                             
     e.score = (int32_t)((e.r1 - e.r0) * (uint32_t)c.P->match) - (int32_t)(e.internal * (uint32_t)(c.P->match + c.P->mismatch))
             + e.left_full * c.P->bonus + e.right_full * c.P->bonus;
 }
-VGK_HD bool g_less(const GEntry& x, const GEntry& y) { return x.score < y.score || (x.score == y.score && x.number < y.number); }
+// The queue orders (score, insertion number) — highest score first, the later insertion among equals (:567-571).  Its keys
+// carry both and the pool index, so sifting touches only the small key array, never the pool entries themselves.
+VGK_HD uint64_t g_key(const GEntry& e, uint32_t idx) { return ((uint64_t)((uint32_t)e.score ^ 0x80000000u) << 32) | ((uint64_t)e.number << 16) | idx; }
 VGK_HD void g_heap_push(GScratch& s, uint32_t& hn, uint16_t idx) {
-    uint32_t i = hn++; s.heap[i] = idx;
-    while (i) { const uint32_t p = (i - 1) / 2; if (!g_less(s.pool[s.heap[p]], s.pool[s.heap[i]])) break;
-                const uint16_t t = s.heap[p]; s.heap[p] = s.heap[i]; s.heap[i] = t; i = p; }
+    const uint64_t key = g_key(s.pool[idx], idx);
+    uint32_t i = hn++;
+    while (i) { const uint32_t p = (i - 1) / 2; if (s.heap[p] >= key) break; s.heap[i] = s.heap[p]; i = p; }
+    s.heap[i] = key;
 }
 VGK_HD uint16_t g_heap_pop(GScratch& s, uint32_t& hn) {
-    const uint16_t top = s.heap[0]; s.heap[0] = s.heap[--hn];
+    const uint16_t top = (uint16_t)(s.heap[0] & 0xffffu);
+    const uint64_t last = s.heap[--hn];
     uint32_t i = 0;
-    for (;;) { const uint32_t l = 2 * i + 1, r = l + 1; uint32_t m = i;
-        if (l < hn && g_less(s.pool[s.heap[m]], s.pool[s.heap[l]])) m = l;
-        if (r < hn && g_less(s.pool[s.heap[m]], s.pool[s.heap[r]])) m = r;
-        if (m == i) break;
-        const uint16_t t = s.heap[m]; s.heap[m] = s.heap[i]; s.heap[i] = t; i = m; }
+    for (;;) {
+        const uint32_t l = 2 * i + 1, r = l + 1;
+        if (l >= hn) break;
+        const uint32_t m = (r < hn && s.heap[r] > s.heap[l]) ? r : l;
+        if (s.heap[m] <= last) break;
+        s.heap[i] = s.heap[m]; i = m;
+    }
+    if (hn) s.heap[i] = last;
     return top;
 }
 // path of a pool entry, front to back; returns its length or -1 when it does not fit
@@ -181,7 +188,7 @@ VGK_HD bool gx_full(const GExt& e) { return e.left_full && e.right_full; }
 VGK_HD bool gx_contains(const GIndex& h, const GExt& e, int32_t node, int64_t diff) {             // (:17-41)
     uint32_t read_offset = e.r0, node_offset = e.offset;
     for (uint32_t i = 0; i < e.path_len; ++i) {
-        const uint32_t a = h.len[e.path[i]] - node_offset, b = e.r1 - read_offset; const uint32_t len = a < b ? a : b;
+        const uint32_t a = g_len(h, e.path[i]) - node_offset, b = e.r1 - read_offset; const uint32_t len = a < b ? a : b;
         if (e.path[i] == node && (int64_t)read_offset - (int64_t)node_offset == diff) return true;
         read_offset += len; node_offset = 0;
     }
@@ -191,12 +198,12 @@ VGK_HD uint32_t gx_overlap(const GIndex& h, const GExt& x, const GExt& y) {     
     uint32_t result = 0, xp = x.r0, yp = y.r0, xi = 0, yi = 0, xo = x.offset, yo = y.offset;
     while (xp < x.r1 && yp < y.r1) {
         if (xp == yp && x.path[xi] == y.path[yi] && xo == yo) {
-            uint32_t len = h.len[x.path[xi]] - xo;
+            uint32_t len = g_len(h, x.path[xi]) - xo;
             if (x.r1 - xp < len) len = x.r1 - xp;
             if (y.r1 - yp < len) len = y.r1 - yp;
             result += len; xp += len; yp += len; ++xi; ++yi; xo = yo = 0;
-        } else if (xp <= yp) { xp += h.len[x.path[xi]] - xo; ++xi; xo = 0; }
-        else { yp += h.len[y.path[yi]] - yo; ++yi; yo = 0; }
+        } else if (xp <= yp) { xp += g_len(h, x.path[xi]) - xo; ++xi; xo = 0; }
+        else { yp += g_len(h, y.path[yi]) - yo; ++yi; yo = 0; }
     }
     return result;
 }
@@ -237,7 +244,7 @@ VGK_HD void gx_find_mismatches(const GCtx& c, GExt& e, bool& overflow) {        
     const GIndex& h = c.P->index;
     uint32_t node_offset = e.offset, read_offset = e.r0;
     for (uint32_t i = 0; i < e.path_len; ++i) {
-        const char* t = h.seq + h.seq_off[e.path[i]]; const uint32_t tl = h.len[e.path[i]];
+        const char* t = h.seq + g_rec(h, (uint32_t)(e.path[i]))[3]; const uint32_t tl = g_len(h, e.path[i]);
         while (node_offset < tl && read_offset < e.r1) {
             if (t[node_offset] != c.seq[read_offset]) { if (e.n_mism >= G_MISM) { overflow = true; return; } e.mism[e.n_mism++] = read_offset; }
             ++node_offset; ++read_offset;
@@ -267,13 +274,13 @@ VGK_HD bool gx_trim(const GCtx& c, GExt& e) {                                   
     e.r0 = b0; e.r1 = b1; e.score = best;
     uint32_t head = 0;
     while (head < e.path_len) {
-        const uint32_t nl = h.len[e.path[head]];
+        const uint32_t nl = g_len(h, e.path[head]);
         read_offset += nl - node_offset; node_offset = 0;
         if (read_offset > e.r0) { e.offset = nl - (read_offset - e.r0); break; }
         ++head;
     }
     uint32_t tail = head + 1;
-    while (read_offset < e.r1) { read_offset += h.len[e.path[tail]]; ++tail; }
+    while (read_offset < e.r1) { read_offset += g_len(h, e.path[tail]); ++tail; }
     if (head > 0 || tail < e.path_len) {
         for (uint32_t k = 0; k < tail - head; ++k) e.path[k] = e.path[head + k];
         e.path_len = tail - head;
@@ -306,15 +313,15 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
         if ((uint32_t)snode >= h.n_oriented) { status = VGK_EINVAL; break; }
         if (best_alignment < n_res && S.res[best_alignment].internal == 0 && gx_contains(h, S.res[best_alignment], snode, diff)) continue;
         const uint32_t read_offset = diff < 0 ? 0u : (uint32_t)diff, node_offset = diff < 0 ? (uint32_t)(-diff) : 0u;
-        if (read_offset > L || node_offset > h.len[snode]) { status = VGK_EINVAL; break; }
+        if (read_offset > L || node_offset > g_len(h, snode)) { status = VGK_EINVAL; break; }
         uint32_t np = 0, hn = 0, number = 0;
         int32_t best = -1;
         {   // the seed node itself: any number of mismatches (:213-237)
             GEntry& m = S.pool[np];
             m.parent = -1; m.node = snode; m.front = 0; m.offset = node_offset; m.r0 = m.r1 = read_offset; m.internal = 0;
             m.left_full = m.right_full = m.left_max = m.right_max = 0; m.state = gs_find(h, snode);
-            const char* t = h.seq + h.seq_off[snode];
-            const uint32_t left = L - m.r1 < h.len[snode] - node_offset ? L - m.r1 : h.len[snode] - node_offset;
+            const char* t = h.seq + g_rec(h, (uint32_t)(snode))[3];
+            const uint32_t left = L - m.r1 < g_len(h, snode) - node_offset ? L - m.r1 : g_len(h, snode) - node_offset;
             m.r1 += g_match_fwd(c.seq + m.r1, t + node_offset, left, m.internal, 0xffffffffu);
             m.old = m.internal;
             if (m.r0 == 0) m.left_full = m.left_max = 1;
@@ -329,18 +336,19 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
                 const GEntry cur = S.pool[ci];
                 const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
                 const uint32_t o = (uint32_t)cur.state.fn;
-                for (uint32_t e = h.edge_off[o]; e < h.edge_off[o + 1]; ++e) {
-                    const int32_t w = h.edge_to[e]; if (w < 0) continue;
+                const uint32_t* orec = g_rec(h, o);
+                for (uint32_t e = 0; e < orec[1]; ++e) {
+                    const int32_t w = (int32_t)orec[4 + 2 * e]; if (w < 0) continue;
                     const GState ns = gs_extend(h, cur.state, w);
                     if (gs_empty(ns)) continue;
                     if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
                     GEntry& nx = S.pool[np]; nx = cur; nx.parent = ci; nx.node = w; nx.front = 0; nx.state = ns;
-                    const char* t = h.seq + h.seq_off[w];                                           // match_forward (:239-266)
-                    const uint32_t no = g_match_fwd(c.seq + nx.r1, t, L - nx.r1 < h.len[w] ? L - nx.r1 : h.len[w], nx.internal, limit);
+                    const char* t = h.seq + g_rec(h, (uint32_t)(w))[3];                                           // match_forward (:239-266)
+                    const uint32_t no = g_match_fwd(c.seq + nx.r1, t, L - nx.r1 < g_len(h, w) ? L - nx.r1 : g_len(h, w), nx.internal, limit);
                     nx.r1 += no;
                     if (no == 0) continue;
                     if (nx.r1 >= L) { nx.right_full = nx.right_max = 1; nx.old = nx.internal; }
-                    else if (no < h.len[w]) { nx.right_max = 1; nx.old = nx.internal; }
+                    else if (no < g_len(h, w)) { nx.right_max = 1; nx.old = nx.internal; }
                     g_set_score(c, nx); nx.number = number++;
                     num_ext += gs_size(ns);
                     g_heap_push(S, hn, (uint16_t)np); ++np;
@@ -358,17 +366,18 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
                 const GEntry cur = S.pool[ci];
                 const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
                 const uint32_t o = (uint32_t)cur.state.bn;
-                for (uint32_t e = h.edge_off[o]; e < h.edge_off[o + 1]; ++e) {
-                    const int32_t x = h.edge_to[e]; if (x < 0) continue;
+                const uint32_t* orec = g_rec(h, o);
+                for (uint32_t e = 0; e < orec[1]; ++e) {
+                    const int32_t x = (int32_t)orec[4 + 2 * e]; if (x < 0) continue;
                     const GState ns = gs_flip(gs_extend(h, gs_flip(cur.state), x));              // bdExtendBackward
                     if (gs_empty(ns)) continue;
                     const int32_t w = ns.bn ^ 1;
                     if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
-                    GEntry& nx = S.pool[np]; nx = cur; nx.parent = ci; nx.node = w; nx.front = 1; nx.state = ns; nx.offset = h.len[w];
-                    const char* t = h.seq + h.seq_off[w];                                           // match_backward (:268-296)
+                    GEntry& nx = S.pool[np]; nx = cur; nx.parent = ci; nx.node = w; nx.front = 1; nx.state = ns; nx.offset = g_len(h, w);
+                    const char* t = h.seq + g_rec(h, (uint32_t)(w))[3];                                           // match_backward (:268-296)
                     const uint32_t back = g_match_bwd(c.seq + nx.r0, t + nx.offset, nx.r0 < nx.offset ? nx.r0 : nx.offset, nx.internal, limit);
                     nx.r0 -= back; nx.offset -= back;
-                    if (nx.offset >= h.len[w]) continue;
+                    if (nx.offset >= g_len(h, w)) continue;
                     if (nx.r0 == 0) nx.left_full = nx.left_max = 1;
                     else if (nx.offset > 0) nx.left_max = 1;
                     g_set_score(c, nx); nx.number = number++;
