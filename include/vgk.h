@@ -197,6 +197,9 @@ int  vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t
 /* timing of the last vgk_banded_align call on this context: 0 = fill kernel ms, 1 = traceback kernel ms,
  * 2 = band cells filled, 3 = algorithmic bytes */
 double vgk_banded_last(vgk_ctx* ctx, int which);
+/* Launch the kernels of the last vgk_banded_align call again on its inputs, which stay resident in HBM (the counterpart of
+ * vgk_gssw_run for this path; results stay on the device).  VGK_EINVAL unless that call fitted one sub-batch. */
+int    vgk_banded_rerun(vgk_ctx* ctx);
 
 /* ---- haplotype-consistent gapless extension (GaplessExtender, src/gbwt_extender.cpp:533-737) ---------
  * Replaces GaplessExtender::extend(cluster, sequence, cache, max_mismatches, overlap_threshold, trim)
@@ -251,6 +254,7 @@ int  vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_
                         vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
                         uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap,
                         size_t written[3] /* extensions, nodes, mismatches */);
+int    vgk_gapless_rerun(vgk_ctx* ctx);      /* launch the kernel of the last vgk_gapless_extend call again on its resident inputs */
 double vgk_gapless_last_ms(vgk_ctx* ctx);    /* kernel time of the last vgk_gapless_extend call on this context */
 
 /* batch introspection (used by bench.py for the roofline line) */

@@ -101,6 +101,8 @@ def load_library(path=None):
     lib.vgk_gapless_extend.argtypes = [vp, vp, vp, u32, vp, vp, sz, vp, sz, vp, sz, ctypes.POINTER(sz * 3)]
     lib.vgk_gapless_last_ms.restype = ctypes.c_double
     lib.vgk_gapless_last_ms.argtypes = [vp]
+    lib.vgk_banded_rerun.argtypes = [vp]
+    lib.vgk_gapless_rerun.argtypes = [vp]
     lib.vgk_banded_last.restype = ctypes.c_double
     lib.vgk_banded_last.argtypes = [vp, ctypes.c_int]
     for f in ("vgk_batch_cells", "vgk_batch_alg_bytes", "vgk_batch_device_bytes"):
@@ -266,6 +268,12 @@ class Engine:
         self._check(self.lib.vgk_banded_align(self.h, bs.ptr, bs.n, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written)),
                     "vgk_banded_align")
         return res, ops[:written.value]
+
+    def banded_rerun(self):
+        self._check(self.lib.vgk_banded_rerun(self.h), "vgk_banded_rerun")
+
+    def gapless_rerun(self):
+        self._check(self.lib.vgk_gapless_rerun(self.h), "vgk_gapless_rerun")
 
     def banded_last(self, which):
         return self.lib.vgk_banded_last(self.h, which)

@@ -235,7 +235,7 @@ int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t 
                      vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
     if (!ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    ctx->banded_ms[0] = ctx->banded_ms[1] = 0; ctx->banded_cells = 0; ctx->banded_bytes = 0;
+    ctx->banded_ms[0] = ctx->banded_ms[1] = 0; ctx->banded_cells = 0; ctx->banded_bytes = 0; ctx->banded_last_valid = false;
     uint64_t budget = ctx->be->memory_bytes() / 2;
     if (const char* e = std::getenv("VGAMD_MAX_BATCH_BYTES")) budget = std::strtoull(e, nullptr, 10);
     if (!budget) budget = 1ull << 30;
@@ -351,6 +351,7 @@ int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t 
             lap("scratch");
             if ((rc = be->run_banded(P, launches.data(), (uint32_t)launches.size()))) return rc;
             lap("kernels");
+            ctx->banded_last = P; ctx->banded_last_launches = launches; ctx->banded_last_valid = (i == 0 && j == n);     // the whole call in one sub-batch
             unsigned long long dense_n = 0;
             if ((rc = be->download(&dense_n, P.dense_count, sizeof dense_n))) return rc;
             if ((rc = be->download(dres, P.results, (size_t)m * sizeof(BResult)))) return rc;
@@ -411,6 +412,18 @@ int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t 
     }
     if (ops_written) *ops_written = used;
     return rc_all;
+}
+
+int vgk_banded_rerun(vgk_ctx* ctx) {
+    if (!ctx) return VGK_EINVAL;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->banded_last_valid) return VGK_EINVAL;
+    Backend* be = ctx->be.get();
+    int rc;
+    if ((rc = be->zero(ctx->banded_last.dense_count, 64))) return rc;
+    if ((rc = be->run_banded(ctx->banded_last, ctx->banded_last_launches.data(), (uint32_t)ctx->banded_last_launches.size()))) return rc;
+    ctx->banded_ms[0] = be->last_ms(3); ctx->banded_ms[1] = be->last_ms(4);
+    return VGK_OK;
 }
 
 double vgk_banded_last(vgk_ctx* ctx, int which) {

@@ -17,6 +17,9 @@ struct vgk_ctx {
     // last vgk_banded_align call: kernel times (ms), band cells, algorithmic bytes
     double banded_ms[2] = {0, 0}; uint64_t banded_cells = 0, banded_bytes = 0;
     double gapless_ms = 0;         // kernel time of the last vgk_gapless_extend call
+    // the last batch of either call stays resident in the cached device buffers: what a re-run needs to launch it again
+    vgk::BandedParams banded_last{}; std::vector<vgk::BandedLaunch> banded_last_launches; bool banded_last_valid = false;
+    vgk::GaplessParams gapless_last{}; uint32_t gapless_last_threads = 0; bool gapless_last_valid = false;
     // device scratch kept between vgk_banded_align calls (grow-only; released with the context)
     struct DevBuf { void* p = nullptr; uint64_t bytes = 0; };
     DevBuf scratch[32];            // 0..14 banded_api.cpp, 15.. gapless_api.cpp

@@ -148,6 +148,7 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     if (written) written[0] = written[1] = written[2] = 0;
     if (!n) return VGK_OK;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->gapless_last_valid = false;
     Backend* be = ctx->be.get();
     // pack: masked reads (ReadMasker, src/gbwt_extender.cpp:160-176), seeds
     std::vector<GProb> probs(n);
@@ -198,6 +199,7 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     int rc;
     if ((rc = be->zero(P.counters, 64))) return cleanup(rc);
     if ((rc = be->run_gapless(P, threads))) return cleanup(rc);
+    ctx->gapless_last = P; ctx->gapless_last_threads = threads; ctx->gapless_last_valid = true;
     unsigned long long counters[3] = {0, 0, 0};
     std::vector<vgk_gapless_result> dres(n);
     if ((rc = be->download(counters, P.counters, sizeof counters))) return cleanup(rc);
@@ -244,6 +246,17 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     const size_t we = oe[n], wn = on[n], wm = om[n];
     if (written) { written[0] = we; written[1] = wn; written[2] = wm; }
     return cleanup(rc_all);
+}
+
+int vgk_gapless_rerun(vgk_ctx* ctx) {
+    if (!ctx) return VGK_EINVAL;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->gapless_last_valid) return VGK_EINVAL;
+    int rc;
+    if ((rc = ctx->be->zero(ctx->gapless_last.counters, 64))) return rc;
+    if ((rc = ctx->be->run_gapless(ctx->gapless_last, ctx->gapless_last_threads))) return rc;
+    ctx->gapless_ms = ctx->be->last_ms(5);
+    return VGK_OK;
 }
 
 double vgk_gapless_last_ms(vgk_ctx* ctx) { return ctx ? ctx->gapless_ms : 0.0; }
