@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(64) banded_walk_kernel(const BandedParams P) {
 }
 
 // ---- gapless extension (gapless_device.hpp): resident threads stride over the reads, one scratch slab per thread
-__global__ void __launch_bounds__(64) gapless_kernel(const GaplessParams P, const uint32_t threads) {
+__global__ void __launch_bounds__(64, 4) gapless_kernel(const GaplessParams P, const uint32_t threads) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t >= threads) return;
     for (uint32_t i = t; i < P.n; i += threads) gapless_extend_one(P, i, P.scratch[t]);

@@ -185,8 +185,10 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     const uint64_t cap_e = n_seed + 1, cap_n = std::min<uint64_t>(n_seed * G_PATH, std::max<uint64_t>(n_seed * 16 + 1024, nodes_cap)) + 1,
                    cap_m = std::min<uint64_t>(n_seed * G_MISM, std::max<uint64_t>(n_seed * 8 + 1024, mism_cap)) + 1;
     P.caps[0] = cap_e; P.caps[1] = cap_n; P.caps[2] = cap_m;
-    // resident threads = scratch slabs: as many as the kernel's register footprint lets the device hold (12 wavefronts per CU)
-    const uint32_t threads = (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max(1, be->compute_units()) * 768);
+    // resident threads = scratch slabs: as many as the kernel's register footprint lets the device hold
+    uint64_t per_cu = 1024;          // 16 wavefronts per CU: the kernel is built for at most 128 VGPRs (__launch_bounds__(64, 4))
+    if (const char* e = std::getenv("VGAMD_GAPLESS_THREADS_PER_CU")) per_cu = (uint64_t)std::max(64, std::atoi(e));
+    const uint32_t threads = (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max(1, be->compute_units()) * per_cu);
     { vgk_ctx::DevBuf& b = ctx->scratch[15];
       const uint64_t want = sizeof(GScratch) * (uint64_t)threads;
       (void)b; P.scratch = (GScratch*)ctx->ensure_scratch(15, want); }
