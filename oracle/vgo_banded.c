@@ -302,6 +302,8 @@ int vgo_banded_align(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_ba
     const int N = (int)g->n_nodes; const int64_t L = p->read_len;
     if (!N || !L) { res->status = VGK_EINVAL; return VGK_EINVAL; }
     if (qa && !p->qual) { res->status = VGK_EINVAL; return VGK_EINVAL; }
+    for (int v = 0; v < N; ++v) for (uint32_t e = g->pred_off[v]; e < g->pred_off[v + 1]; ++e)
+        if (g->pred_idx[e] >= (uint32_t)v) { res->status = VGK_EINVAL; return VGK_EINVAL; }      /* not in topological order */
     B b; memset(&b, 0, sizeof b);
     b.p = p; b.mat = sc->matrix; b.qmat = qa ? qa->matrix : NULL; b.go = sc->gap_open; b.ge = sc->gap_extend; b.L = L;
     b.nd = (BNode*)calloc((size_t)N, sizeof(BNode));

@@ -72,3 +72,52 @@ def test_invalid_input_is_rejected_with_codes(emu_lib):
         capi.Engine(capi.Scoring.simple(100, 120, 6, 1, 30), lib=emu_lib)
     res, ops = eng.align(problem_set([ok]))                    # the context is still usable afterwards
     assert res["score"][0] == 4 + 10
+
+
+def test_banded_call_is_split_into_sub_batches_and_rejects_bad_input(emu_lib, monkeypatch):
+    import gen
+    rng = np.random.default_rng(10)
+    problems = [gen.random_banded_problem(rng) for _ in range(24)]
+    bs = capi.BandedSet.from_lists(problems)
+    whole = capi.Engine(lib=emu_lib).banded_align(bs)
+    monkeypatch.setenv("VGAMD_MAX_BATCH_BYTES", "30000")
+    cut = capi.Engine(lib=emu_lib).banded_align(bs)
+    for a, b in zip(whole, cut):
+        assert (a == b).all()
+    # rerun needs a single resident sub-batch
+    eng = capi.Engine(lib=emu_lib)
+    eng.banded_align(bs)
+    with pytest.raises(capi.VgkError):
+        eng.banded_rerun()
+    monkeypatch.delenv("VGAMD_MAX_BATCH_BYTES")
+    eng = capi.Engine(lib=emu_lib)
+    first = eng.banded_align(bs)
+    eng.banded_rerun()                                               # same kernels on the resident inputs: nothing to fetch, must not fail
+    again = eng.banded_align(bs)
+    for a, b in zip(first, again):
+        assert (a == b).all()
+    # per-problem errors never abort the batch: a backward edge, an empty read, a budget of one cell
+    bad = [dict(read="ACGT", nodes=["AC", "GT"], preds=[[1], []], band_padding=1),
+           dict(read="", nodes=["ACGT"], preds=[[]], band_padding=1),
+           dict(read="ACGTACGT", nodes=["ACGTACGT"], preds=[[]], band_padding=2, max_cells=1),
+           dict(read="ACGT", nodes=["ACGT"], preds=[[]], band_padding=1)]
+    res, ops = capi.Engine(lib=emu_lib).banded_align(capi.BandedSet.from_lists(bad))
+    assert list(res["status"]) == [-1, -1, -7, 0] and res["score"][3] == 4
+    ores, _ = capi.Engine(lib=ORACLE_LIB).banded_align(capi.BandedSet.from_lists(bad))
+    assert list(ores["status"]) == list(res["status"])
+
+
+def test_gapless_limits_and_bad_input_are_reported_per_problem(emu_lib):
+    eng = capi.Engine(lib=emu_lib)
+    index = eng.haplo_index(["ACGTACGTAC", "GGGTTTAAAC"], [[0, 2]])
+    ok = dict(read="ACGTACGTACGGG", seeds=[(0, 0)])
+    too_many = dict(read="ACGTACGTAC", seeds=[(0, -k) for k in range(10)] + [(2, -k) for k in range(10)] + [(1, -k) for k in range(10)] + [(3, -k) for k in range(4)])
+    out_of_range = dict(read="ACGT", seeds=[(99, 0)])
+    no_seeds = dict(read="ACGT", seeds=[])
+    res, ext, nodes, mism = eng.gapless_extend(index, [ok, too_many, out_of_range, no_seeds, ok])
+    assert list(res["status"]) == [0, -7, -1, 0, 0]
+    assert list(res["n_ext"]) == [1, 0, 0, 0, 1] and res["full_length"][0] == 1
+    assert ext["score"][0] == 13 + 10 and list(nodes[:2]) == [0, 2]
+    # a cyclic thread cannot be indexed
+    with pytest.raises(capi.VgkError):
+        eng.haplo_index(["AC", "GT"], [[0, 2, 0]])
