@@ -59,7 +59,7 @@ def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
         elapsed = float(t.item())
     res, ext, nodes, mism = out
     cpu = parity = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:      # the CPU leg (checker + baseline) runs at N = 1 only
         ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
         oidx = ora.haplo_index(wl.nodes, wl.threads)
         tc = time.perf_counter(); o = ora.gapless_extend(oidx, wl.gs); tc = time.perf_counter() - tc
@@ -123,7 +123,7 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     cpu = parity = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:      # the CPU leg (checker + baseline) runs at N = 1 only
         ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
         tc = time.perf_counter(); ores, oops = ora.banded_align(wl.bs); tc = time.perf_counter() - tc
         cpu = {"value": n / tc, "unit": "alignments/s", "cores": os.cpu_count() or 1, "kind": "port",
@@ -245,7 +245,7 @@ def main():
 
     cpu = None
     parity = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:      # the CPU leg (checker + baseline) runs at N = 1 only
         ora_lib = os.path.join(ROOT, "oracle", "libvgoracle.so")
         ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=ora_lib)     # the checker / CPU baseline leg
         cores = os.cpu_count() or 1
