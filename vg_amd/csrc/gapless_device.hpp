@@ -85,7 +85,40 @@ struct GExt {                        // a finished per-seed winner
     int32_t  path[G_PATH];
     uint32_t mism[G_MISM];
 };
-struct GScratch { uint64_t heap[G_POOL]; GEntry pool[G_POOL]; GExt res[G_SEEDS]; };
+// what the pool stores of an entry: 40 bytes (reads and nodes up to 65 535 bases, up to 65 535 visits per node)
+struct GPacked {
+    int16_t  parent; uint16_t number;
+    int32_t  node;
+    uint16_t offset, r0, r1, internal, old;
+    uint8_t  flags, pad;                  // front | left_full << 1 | right_full << 2 | left_max << 3 | right_max << 4
+    int32_t  score;
+    int32_t  fn, bn;
+    uint16_t flo, fhi, blo, bhi;          // an empty range is stored as [1, 0]
+};
+VGK_HD GPacked g_pack(const GEntry& e) {
+    GPacked p;
+    p.parent = (int16_t)e.parent; p.number = (uint16_t)e.number; p.node = e.node;
+    p.offset = (uint16_t)e.offset; p.r0 = (uint16_t)e.r0; p.r1 = (uint16_t)e.r1; p.internal = (uint16_t)e.internal; p.old = (uint16_t)e.old;
+    p.flags = (uint8_t)(e.front | (e.left_full << 1) | (e.right_full << 2) | (e.left_max << 3) | (e.right_max << 4)); p.pad = 0;
+    p.score = e.score; p.fn = e.state.fn; p.bn = e.state.bn;
+    const bool fe = e.state.flo > e.state.fhi, be = e.state.blo > e.state.bhi;
+    p.flo = fe ? 1 : (uint16_t)e.state.flo; p.fhi = fe ? 0 : (uint16_t)e.state.fhi;
+    p.blo = be ? 1 : (uint16_t)e.state.blo; p.bhi = be ? 0 : (uint16_t)e.state.bhi;
+    return p;
+}
+VGK_HD GEntry g_unpack(const GPacked& p) {
+    GEntry e;
+    e.parent = p.parent; e.number = p.number; e.node = p.node;
+    e.offset = p.offset; e.r0 = p.r0; e.r1 = p.r1; e.internal = p.internal; e.old = p.old;
+    e.front = p.flags & 1; e.left_full = (p.flags >> 1) & 1; e.right_full = (p.flags >> 2) & 1; e.left_max = (p.flags >> 3) & 1; e.right_max = (p.flags >> 4) & 1;
+    e.pad[0] = e.pad[1] = e.pad[2] = 0;
+    e.score = p.score;
+    e.state.fn = p.fn; e.state.bn = p.bn;
+    const bool fe = p.flo > p.fhi, be = p.blo > p.bhi;           // only a node no haplotype visits has empty ranges, and those are [0, -1]
+    e.state.flo = fe ? 0 : p.flo; e.state.fhi = fe ? -1 : (int32_t)p.fhi; e.state.blo = be ? 0 : p.blo; e.state.bhi = be ? -1 : (int32_t)p.bhi;
+    return e;
+}
+struct GScratch { uint64_t heap[G_POOL]; GPacked pool[G_POOL]; GExt res[G_SEEDS]; };
 
 struct GaplessParams {
     GIndex index;
@@ -151,8 +184,8 @@ VGK_HD void g_set_score(const GCtx& c, GEntry& e) {                             
 // The queue orders (score, insertion number) — highest score first, the later insertion among equals (:567-571).  Its keys
 // carry both and the pool index, so sifting touches only the small key array, never the pool entries themselves.
 VGK_HD uint64_t g_key(const GEntry& e, uint32_t idx) { return ((uint64_t)((uint32_t)e.score ^ 0x80000000u) << 32) | ((uint64_t)e.number << 16) | idx; }
-VGK_HD void g_heap_push(GScratch& s, uint32_t& hn, uint16_t idx) {
-    const uint64_t key = g_key(s.pool[idx], idx);
+VGK_HD void g_heap_push(GScratch& s, uint32_t& hn, const GEntry& e, uint16_t idx) {
+    const uint64_t key = g_key(e, idx);
     uint32_t i = hn++;
     while (i) { const uint32_t p = (i - 1) / 2; if (s.heap[p] >= key) break; s.heap[i] = s.heap[p]; i = p; }
     s.heap[i] = key;
@@ -175,9 +208,9 @@ VGK_HD uint16_t g_heap_pop(GScratch& s, uint32_t& hn) {
 VGK_HD int g_path(const GScratch& s, int32_t idx, int32_t* out) {
     int32_t fwd[G_PATH]; int nf = 0, nb = 0;
     for (int32_t i = idx; i >= 0; i = s.pool[i].parent) {
-        const GEntry& e = s.pool[i];
+        const GPacked& e = s.pool[i];
         if (e.node < 0) continue;
-        if (e.front) { if (nb >= G_PATH) return -1; out[nb++] = e.node; }      // the latest front node is the first of the path
+        if (e.flags & 1) { if (nb >= G_PATH) return -1; out[nb++] = e.node; }      // the latest front node is the first of the path
         else { if (nf >= G_PATH) return -1; fwd[nf++] = e.node; }              // collected back to front
     }
     if (nb + nf > G_PATH) return -1;
@@ -316,10 +349,11 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
         if (read_offset > L || node_offset > g_len(h, snode)) { status = VGK_EINVAL; break; }
         uint32_t np = 0, hn = 0, number = 0;
         int32_t best = -1;
+        GEntry best_e; best_e.score = 0; best_e.r0 = best_e.r1 = 0;
         {   // the seed node itself: any number of mismatches (:213-237)
-            GEntry& m = S.pool[np];
+            GEntry m;
             m.parent = -1; m.node = snode; m.front = 0; m.offset = node_offset; m.r0 = m.r1 = read_offset; m.internal = 0;
-            m.left_full = m.right_full = m.left_max = m.right_max = 0; m.state = gs_find(h, snode);
+            m.left_full = m.right_full = m.left_max = m.right_max = 0; m.pad[0] = m.pad[1] = m.pad[2] = 0; m.state = gs_find(h, snode);
             const char* t = h.seq + g_rec(h, (uint32_t)(snode))[3];
             const uint32_t left = L - m.r1 < g_len(h, snode) - node_offset ? L - m.r1 : g_len(h, snode) - node_offset;
             m.r1 += g_match_fwd(c.seq + m.r1, t + node_offset, left, m.internal, 0xffffffffu);
@@ -327,13 +361,14 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
             if (m.r0 == 0) m.left_full = m.left_max = 1;
             if (m.r1 >= L) m.right_full = m.right_max = 1;
             g_set_score(c, m); m.number = number++;
-            g_heap_push(S, hn, (uint16_t)np); ++np;
+            S.pool[np] = g_pack(m);
+            g_heap_push(S, hn, m, (uint16_t)np); ++np;
         }
         while (hn) {
             const uint16_t ci = g_heap_pop(S, hn);
-            if (!S.pool[ci].right_max) {
+            GEntry cur = g_unpack(S.pool[ci]);
+            if (!cur.right_max) {
                 uint32_t num_ext = 0;
-                const GEntry cur = S.pool[ci];
                 const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
                 const uint32_t o = (uint32_t)cur.state.fn;
                 const uint32_t* orec = g_rec(h, o);
@@ -342,7 +377,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
                     const GState ns = gs_extend(h, cur.state, w);
                     if (gs_empty(ns)) continue;
                     if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
-                    GEntry& nx = S.pool[np]; nx = cur; nx.parent = ci; nx.node = w; nx.front = 0; nx.state = ns;
+                    GEntry nx = cur; nx.parent = ci; nx.node = w; nx.front = 0; nx.state = ns;
                     const char* t = h.seq + g_rec(h, (uint32_t)(w))[3];                                           // match_forward (:239-266)
                     const uint32_t no = g_match_fwd(c.seq + nx.r1, t, L - nx.r1 < g_len(h, w) ? L - nx.r1 : g_len(h, w), nx.internal, limit);
                     nx.r1 += no;
@@ -351,19 +386,20 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
                     else if (no < g_len(h, w)) { nx.right_max = 1; nx.old = nx.internal; }
                     g_set_score(c, nx); nx.number = number++;
                     num_ext += gs_size(ns);
-                    g_heap_push(S, hn, (uint16_t)np); ++np;
+                    S.pool[np] = g_pack(nx);
+                    g_heap_push(S, hn, nx, (uint16_t)np); ++np;
                 }
                 if (status != VGK_OK) break;
                 if (num_ext < gs_size(cur.state)) {                                               // some haplotype ends here: keep it (:633-637)
                     if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
-                    GEntry& nx = S.pool[np]; nx = cur; nx.parent = ci; nx.node = -1; nx.right_max = 1; nx.old = nx.internal; nx.number = number++;
-                    g_heap_push(S, hn, (uint16_t)np); ++np;
+                    GEntry nx = cur; nx.parent = ci; nx.node = -1; nx.right_max = 1; nx.old = nx.internal; nx.number = number++;
+                    S.pool[np] = g_pack(nx);
+                    g_heap_push(S, hn, nx, (uint16_t)np); ++np;
                 }
                 continue;
             }
-            if (!S.pool[ci].left_max) {
+            if (!cur.left_max) {
                 bool found = false;
-                const GEntry cur = S.pool[ci];
                 const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
                 const uint32_t o = (uint32_t)cur.state.bn;
                 const uint32_t* orec = g_rec(h, o);
@@ -373,7 +409,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
                     if (gs_empty(ns)) continue;
                     const int32_t w = ns.bn ^ 1;
                     if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
-                    GEntry& nx = S.pool[np]; nx = cur; nx.parent = ci; nx.node = w; nx.front = 1; nx.state = ns; nx.offset = g_len(h, w);
+                    GEntry nx = cur; nx.parent = ci; nx.node = w; nx.front = 1; nx.state = ns; nx.offset = g_len(h, w);
                     const char* t = h.seq + g_rec(h, (uint32_t)(w))[3];                                           // match_backward (:268-296)
                     const uint32_t back = g_match_bwd(c.seq + nx.r0, t + nx.offset, nx.r0 < nx.offset ? nx.r0 : nx.offset, nx.internal, limit);
                     nx.r0 -= back; nx.offset -= back;
@@ -381,18 +417,19 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
                     if (nx.r0 == 0) nx.left_full = nx.left_max = 1;
                     else if (nx.offset > 0) nx.left_max = 1;
                     g_set_score(c, nx); nx.number = number++;
-                    g_heap_push(S, hn, (uint16_t)np); ++np;
+                    S.pool[np] = g_pack(nx);
+                    g_heap_push(S, hn, nx, (uint16_t)np); ++np;
                     found = true;
                 }
                 if (status != VGK_OK) break;
                 if (found) continue;
-                S.pool[ci].left_max = 1;
+                cur.left_max = 1;
             }
-            if (best < 0 || S.pool[best].score < S.pool[ci].score) best = ci;
+            if (best < 0 || best_e.score < cur.score) { best = ci; best_e = cur; }
         }
         if (status != VGK_OK) break;
-        if (best >= 0 && S.pool[best].r1 > S.pool[best].r0) {
-            const GEntry& b = S.pool[best];
+        if (best >= 0 && best_e.r1 > best_e.r0) {
+            const GEntry& b = best_e;
             GExt& r = S.res[n_res];
             const int plen = g_path(S, best, r.path);
             if (plen < 0) { status = VGK_ETOOBIG; break; }
