@@ -163,7 +163,9 @@ int  vgk_gssw_pack (vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
 int  vgk_gssw_run  (vgk_batch* batch);
 int  vgk_gssw_fetch(vgk_batch* batch, vgk_result* results /* [n] */,
                     vgk_op* ops, size_t ops_cap, size_t* ops_written);
-/* one-call convenience = pack + run + fetch + free */
+/* one-call convenience = pack + run + fetch + free, in sub-batches that fit half of HBM.  Problems the kernels cannot take
+ * (VGK_ETOOLONG, VGK_EUNSUPPORTED, VGK_EINVAL) are answered in their own result's status and the rest of the call goes
+ * ahead; vgk_gssw_pack itself refuses a batch that holds such a problem. */
 int  vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
                     vgk_result* results, vgk_op* ops, size_t ops_cap,
                     size_t* ops_written);

@@ -121,3 +121,27 @@ def test_gapless_limits_and_bad_input_are_reported_per_problem(emu_lib):
     # a cyclic thread cannot be indexed
     with pytest.raises(capi.VgkError):
         eng.haplo_index(["AC", "GT"], [[0, 2, 0]])
+
+
+def test_gssw_align_answers_out_of_range_problems_per_problem(emu_lib):
+    import ctypes
+    rng = np.random.default_rng(12)
+    good = [random_problem(rng, max_read=60) for _ in range(6)]
+    long_read = dict(good[0], read="ACGT" * 300)                      # 1200 bases: beyond the kernels' 1024 rows
+    problems = good[:3] + [long_read] + good[3:]
+    ps = problem_set(problems)
+    eng = capi.Engine(lib=emu_lib)
+    res = np.zeros(ps.n, dtype=capi.RESULT_DT)
+    cap = int(np.diff(ps.read_off).sum() + np.diff(ps.seq_off).sum() + 2 * ps.n)
+    ops = np.zeros(cap, dtype=capi.OP_DT)
+    written = ctypes.c_size_t()
+    assert eng.lib.vgk_gssw_align(eng.h, ps.ptr, ps.n, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written)) == 0
+    assert res["status"][3] == -4                                      # VGK_ETOOLONG for that read only
+    ref = capi.Engine(lib=ORACLE_LIB).align(problem_set(good))
+    keep = [0, 1, 2, 4, 5, 6]
+    for k, i in enumerate(keep):
+        assert res["score"][i] == ref[0]["score"][k] and res["status"][i] == 0
+        assert capi.cigar_string(res[i], ops) == capi.cigar_string(ref[0][k], ref[1])
+    # the strict batch API still refuses the whole batch
+    with pytest.raises(capi.VgkError):
+        eng.pack(ps)

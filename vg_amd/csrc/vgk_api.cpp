@@ -396,32 +396,64 @@ static uint64_t problem_device_bytes(const vgk_gssw_problem& p) {
     return rows * (R + 64) / 2 + 16 * (p.read_len + R) + 64ull * p.graph.n_nodes + 512;
 }
 
+// the limits vgk_gssw_pack enforces on a whole batch, per problem: what the kernels cannot take is reported in that
+// problem's status and the rest of the call goes ahead (the caller keeps its CPU path for those reads)
+static int problem_limit_status(const vgk_ctx* ctx, const vgk_gssw_problem& p) {
+    if (p.read_len == 0 || !p.read || p.graph.n_nodes == 0) return VGK_EINVAL;
+    const uint32_t mode = p.flags & 15u;
+    const bool xdrop = mode == VGK_XDROP_PINNED;
+    const uint32_t rows = p.read_len + (xdrop ? 1u : 0u);
+    if (rows > 1024) return VGK_ETOOLONG;
+    if ((int64_t)rows * std::max(ctx->max_score, 0) + 2 * (int64_t)ctx->max_bonus > 2046) return VGK_EUNSUPPORTED;
+    if (xdrop && (int64_t)p.read_len * std::max(ctx->max_score, 0) + ctx->max_bonus >= (int64_t)XOFF) return VGK_EUNSUPPORTED;
+    return VGK_OK;
+}
+
 int vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
                    vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
     if (!ctx || (!problems && n) || !results) return VGK_EINVAL;
     uint64_t budget = ctx->be->memory_bytes();
     budget = budget ? budget / 2 : (8ull << 30);          // leave half of HBM to the caller / other contexts
     if (const char* e = std::getenv("VGAMD_MAX_BATCH_BYTES")) budget = std::strtoull(e, nullptr, 10);
+    // problems outside the kernels' range are answered here; the others run in sub-batches that fit the budget
+    std::vector<uint32_t> runnable; runnable.reserve(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const int st = problem_limit_status(ctx, problems[i]);
+        if (st == VGK_OK) runnable.push_back(i);
+        else { std::memset(&results[i], 0, sizeof results[i]); results[i].status = st; }
+    }
+    const bool all = runnable.size() == n;
+    std::vector<vgk_gssw_problem> sub_problems; std::vector<vgk_result> sub_results;
     size_t w_total = 0;
-    uint32_t begin = 0;
-    while (begin < n || (n == 0 && begin == 0)) {
-        uint32_t end = begin; uint64_t bytes = 0;
-        while (end < n) {
-            const uint64_t pb = problem_device_bytes(problems[end]);
+    size_t begin = 0;
+    while (begin < runnable.size()) {
+        size_t end = begin; uint64_t bytes = 0;
+        while (end < runnable.size()) {
+            const uint64_t pb = problem_device_bytes(problems[runnable[end]]);
             if (end > begin && bytes + pb > budget) break;
             bytes += pb; ++end;
         }
+        const uint32_t m = (uint32_t)(end - begin);
+        const vgk_gssw_problem* batch_problems = problems + begin;      // contiguous when nothing was filtered out
+        vgk_result* batch_results = results + begin;
+        if (!all) {
+            sub_problems.resize(m); sub_results.resize(m);
+            for (uint32_t k = 0; k < m; ++k) sub_problems[k] = problems[runnable[begin + k]];
+            batch_problems = sub_problems.data(); batch_results = sub_results.data();
+        }
         vgk_batch* b = nullptr;
-        int rc = vgk_gssw_pack(ctx, problems + begin, end - begin, 0, &b);
+        int rc = vgk_gssw_pack(ctx, batch_problems, m, 0, &b);
         if (rc) return rc;
         rc = vgk_gssw_run(b);
         size_t w = 0;
-        if (!rc) rc = vgk_gssw_fetch(b, results + begin, ops ? ops + w_total : nullptr, ops_cap - w_total, &w);
+        if (!rc) rc = vgk_gssw_fetch(b, batch_results, ops ? ops + w_total : nullptr, ops_cap - w_total, &w);
         vgk_batch_free(b);
         if (rc) return rc;
-        for (uint32_t i = begin; i < end; ++i) results[i].ops_begin += (uint32_t)w_total;   // indices into the caller's whole op array
+        for (uint32_t k = 0; k < m; ++k) {
+            batch_results[k].ops_begin += (uint32_t)w_total;             // indices into the caller's whole op array
+            if (!all) results[runnable[begin + k]] = batch_results[k];
+        }
         w_total += w;
-        if (end == begin) break;
         begin = end;
     }
     if (ops_written) *ops_written = w_total;
