@@ -196,6 +196,13 @@ typedef struct vgk_banded_problem {
 
 int  vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n,
                       vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written);
+/* The k best alignments of every problem (Aligner::align_global_banded_multi, src/aligner.cpp:763-831: the constructor with
+ * max_multi_alns and the AltTracebackStack of src/banded_global_aligner.cpp:2426-2790): results[i * max_alt_alns + k] is the
+ * k-th best alignment of problem i, k < n_alignments[i], scores in descending order; a problem that fails has n_alignments 0 and
+ * its status in results[i * max_alt_alns].  The fill runs on the device; the enumeration of alternates walks the device-filled
+ * matrices on host threads. */
+int  vgk_banded_align_multi(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n, uint32_t max_alt_alns,
+                            vgk_result* results, uint32_t* n_alignments, vgk_op* ops, size_t ops_cap, size_t* ops_written);
 /* timing of the last vgk_banded_align call on this context: 0 = fill kernel ms, 1 = traceback kernel ms,
  * 2 = band cells filled, 3 = algorithmic bytes */
 double vgk_banded_last(vgk_ctx* ctx, int which);

@@ -57,6 +57,7 @@ typedef struct {
     int as_source; int src_path_off, src_path_len;
     /* reversed edit runs */
     vgk_op* runs; size_t n_runs, cap_runs;
+    struct Stack* st;                  /* alternate tracebacks */
 } B;
 
 static int nt5(char c) {
@@ -207,16 +208,96 @@ static void emit(B* b, int node, int op, int inc) {
 }
 static int op_of(int mat) { return mat == MM ? VGK_OP_M : mat == IR ? VGK_OP_I : VGK_OP_D; }
 
-/* pick the source state of a transition in the reference's order match, insert-col, insert-row (:812 `prev_mats`) */
-static int pick(const B* b, size_t i, int cur, int dm, int dc, int dr) {
-    if (cur == b->M[i] + dm) return MM;
-    if (LIVE(b->Ic[i]) && cur == b->Ic[i] + dc) return IC;
-    if (LIVE(b->Ir[i]) && cur == b->Ir[i] + dr) return IR;
-    return -1;
+/* ---- the stack of alternate tracebacks (AltTracebackStack :2426-2790) ----
+ * A traceback is the list of its deflections: the first names the start (end node, matrix), each later one a cell where the
+ * traceback leaves the optimal choice for a named predecessor state.  The stack keeps up to `max` of them in descending score
+ * order, equal scores in the order they were found. */
+typedef struct { int from_node; int64_t r, j; int to_node, to_mat; } Defl;
+typedef struct { Defl* d; int n; int score; int* prefix; int plen; } Trace;
+typedef struct Stack {
+    Trace* v; int n; int max;
+    int cur, cur_defl;              /* the traceback being traced, its next unconsumed deflection */
+    int** empty_paths; int* empty_len; int n_empty, next_empty;   /* source-to-sink chains of empty nodes, sink first */
+    int empty_score;
+} Stack;
+
+static void trace_free(Trace* t) { free(t->d); free(t->prefix); t->d = NULL; t->prefix = NULL; }
+static void stack_pop_back(Stack* st) { trace_free(&st->v[st->n - 1]); --st->n; }
+/* insert_traceback (:2691-2740) */
+static void stack_insert(Stack* st, const Defl* prefix_d, int n_prefix, int score, Defl last, const int* empty_prefix, int plen) {
+    int pos = st->n;                                   /* after every element with score >= the new one */
+    while (pos > 0 && score > st->v[pos - 1].score) --pos;
+    if (st->n && pos == st->n && st->n >= st->max) return;
+    st->v = (Trace*)realloc(st->v, sizeof(Trace) * (size_t)(st->n + 1));
+    memmove(st->v + pos + 1, st->v + pos, sizeof(Trace) * (size_t)(st->n - pos));
+    Trace* t = &st->v[pos];
+    t->d = (Defl*)malloc(sizeof(Defl) * (size_t)(n_prefix + 1)); if (n_prefix) memcpy(t->d, prefix_d, sizeof(Defl) * (size_t)n_prefix);
+    t->d[n_prefix] = last; t->n = n_prefix + 1; t->score = score;
+    t->prefix = (int*)malloc(sizeof(int) * (size_t)(plen + 1)); if (plen) memcpy(t->prefix, empty_prefix, sizeof(int) * (size_t)plen); t->plen = plen;
+    ++st->n;
+    if (st->n > st->max) stack_pop_back(st);
+}
+/* propose_deflection (:2671-2689) */
+static void propose(B* b, int alt_score, int from_node, int64_t r, int64_t j, int to_node, int to_mat) {
+    Stack* st = b->st;
+    Trace* c = &st->v[st->cur];
+    if (st->cur_defl != c->n) return;                  /* only once the prescribed deflections are used up */
+    if (alt_score <= st->v[st->n - 1].score && st->n >= st->max) return;
+    Defl last = { from_node, r, j, to_node, to_mat };
+    /* copy what stack_insert needs first: the realloc may move the current trace */
+    Defl* pd = (Defl*)malloc(sizeof(Defl) * (size_t)(c->n + 1)); memcpy(pd, c->d, sizeof(Defl) * (size_t)c->n);
+    int* pp = (int*)malloc(sizeof(int) * (size_t)(c->plen + 1)); if (c->plen) memcpy(pp, c->prefix, sizeof(int) * (size_t)c->plen);
+    const int n = c->n, plen = c->plen;
+    stack_insert(st, pd, n, alt_score, last, pp, plen);
+    free(pd); free(pp);
+}
+static int at_deflection(const B* b, int node, int64_t r, int64_t j) {
+    const Stack* st = b->st; const Trace* c = &st->v[st->cur];
+    return st->cur_defl < c->n && c->d[st->cur_defl].from_node == node && c->d[st->cur_defl].r == r && c->d[st->cur_defl].j == j;
+}
+/* the three predecessor states of a transition, in the reference's order match, insert-col, insert-row (:812): the first
+   that explains `cur` is taken, every other live one is proposed as a deflection (:830-886 and its siblings) */
+static int pick_and_propose(B* b, size_t i, int cur, int dm, int dc, int dr, int from_node, int64_t r, int64_t j, int to_node) {
+    const int S = b->st->v[b->st->cur].score;
+    int found = -1;
+    { const int src = b->M[i], diff = cur - (src + dm);
+      if (diff == 0) found = MM; else if (LIVE(src)) propose(b, S - diff, from_node, r, j, to_node, MM); }
+    { const int src = b->Ic[i]; if (LIVE(src)) { const int diff = cur - (src + dc);
+      if (found < 0 && diff == 0) found = IC; else propose(b, S - diff, from_node, r, j, to_node, IC); } }
+    { const int src = b->Ir[i]; if (LIVE(src)) { const int diff = cur - (src + dr);
+      if (found < 0 && diff == 0) found = IR; else propose(b, S - diff, from_node, r, j, to_node, IR); } }
+    return found;
+}
+
+/* where a deflection across an edge lands: the predecessors are searched in their own order, each through its empty nodes
+   depth-first (:1163-1196); the empty nodes on the way are written to path[] */
+static int find_deflect_seed(const B* b, int node, int target, int* path, int* plen) {
+    const vgk_graph* g = &b->p->graph;
+    int cap = 64, top; int* st = (int*)malloc(sizeof(int) * cap);
+    int found = 0;
+    for (uint32_t e0 = g->pred_off[node]; e0 < g->pred_off[node + 1] && !found; ++e0) {
+        top = 0; st[top++] = (int)g->pred_idx[e0]; *plen = 0;
+        while (top) {
+            const int s = st[--top];
+            if (s < 0) { --*plen; continue; }
+            if (b->nd[s].masked) continue;
+            if (s == target) { found = 1; break; }
+            if (b->nd[s].len == 0) {
+                path[(*plen)++] = s;
+                if (top + 2 + (int)(g->pred_off[s + 1] - g->pred_off[s]) > cap) { cap = cap * 2 + (int)(g->pred_off[s + 1] - g->pred_off[s]); st = (int*)realloc(st, sizeof(int) * cap); }
+                st[top++] = -1;
+                for (uint32_t e = g->pred_off[s]; e < g->pred_off[s + 1]; ++e) st[top++] = (int)g->pred_idx[e];
+            }
+        }
+    }
+    free(st);
+    return found;
 }
 
 static int traceback(B* b, int node, int mat) {
     const int go = b->go, ge = b->ge;
+    Stack* st = b->st;
+    const int S = st->v[st->cur].score;
     BNode* n = &b->nd[node];
     int64_t r = b->L - 1, j = n->len - 1;
     int lead = 0;
@@ -225,18 +306,24 @@ static int traceback(B* b, int node, int mat) {
         /* inside the node (:775-1112) */
         while ((j > 0 || mat == IR) && !lead) {
             emit(b, node, op_of(mat), 1);
+            if (at_deflection(b, node, r, j)) {           /* (:789-809) */
+                if (mat == MM) { --r; --j; } else if (mat == IR) --r; else --j;
+                mat = st->v[st->cur].d[st->cur_defl++].to_mat;
+                continue;
+            }
             if (mat == MM) {
                 if (r == 0) { mat = IC; --j; r = -1; lead = 1; break; }
-                int src = pick(b, at(n, r - 1, j - 1), b->M[at(n, r, j)], sub(b, n, r, j), sub(b, n, r, j), sub(b, n, r, j));
+                const int ms = sub(b, n, r, j);
+                int src = pick_and_propose(b, at(n, r - 1, j - 1), b->M[at(n, r, j)], ms, ms, ms, node, r, j, node);
                 if (src < 0) return VGK_EINVAL;
                 mat = src; --r; --j;
             } else if (mat == IR) {
                 if (r == 0) { lead = 1; r = -1; break; }
-                int src = pick(b, at(n, r - 1, j), b->Ir[at(n, r, j)], -go, -go, -ge);
+                int src = pick_and_propose(b, at(n, r - 1, j), b->Ir[at(n, r, j)], -go, -go, -ge, node, r, j, node);
                 if (src < 0) return VGK_EINVAL;
                 mat = src; --r;
             } else {
-                int src = pick(b, at(n, r, j - 1), b->Ic[at(n, r, j)], -go, -ge, -go);
+                int src = pick_and_propose(b, at(n, r, j - 1), b->Ic[at(n, r, j)], -go, -ge, -go, node, r, j, node);
                 if (src < 0) return VGK_EINVAL;
                 mat = src; --j;
             }
@@ -244,13 +331,27 @@ static int traceback(B* b, int node, int mat) {
         if (lead) { mat = IC; while (j > 0) { emit(b, node, VGK_OP_D, 1); --j; } }     /* (:1114-1124) */
 
         /* across the left edge (:1129-1780) */
+        if (at_deflection(b, node, r, 0)) {               /* (:1158-1222) */
+            emit(b, node, op_of(mat), 1);
+            const Defl d = st->v[st->cur].d[st->cur_defl++];
+            int* path = (int*)malloc(sizeof(int) * (size_t)(b->p->graph.n_nodes + 1)); int plen = 0;
+            if (!find_deflect_seed(b, node, d.to_node, path, &plen)) { free(path); return VGK_EINVAL; }
+            for (int k = 0; k < plen; ++k) emit(b, path[k], op_of(mat), 0);
+            free(path);
+            if (r == 0 && mat == MM) lead = 1;
+            if (mat == MM) --r;                             /* a column gap stays in its row */
+            mat = d.to_mat; node = d.to_node; j = b->nd[node].len - 1;
+            continue;
+        }
         flatten_seeds(b, node);
         int found = -1, fmat = MM, flead = lead;
         if (lead) {
             emit(b, node, VGK_OP_D, 1);
-            for (int si = 0; si < b->n_seeds && found < 0; ++si) {
+            for (int si = 0; si < b->n_seeds; ++si) {
                 const BNode* s = &b->nd[b->seeds[si].seed];
-                if ((int64_t)ge * (s->cum + s->len - n->cum) == 0) found = si;
+                const int diff = (int)((int64_t)ge * (s->cum + s->len - n->cum));
+                if (diff == 0 && found < 0) found = si;
+                else propose(b, S - diff, node, r, 0, b->seeds[si].seed, IC);
             }
             if (found < 0) {
                 if (!b->as_source) return VGK_EINVAL;
@@ -261,20 +362,34 @@ static int traceback(B* b, int node, int mat) {
             emit(b, node, op_of(mat), 1);
             int cur = mat == MM ? b->M[at(n, r, 0)] : b->Ic[at(n, r, 0)];
             int ms = mat == MM ? sub(b, n, r, 0) : 0;
-            for (int si = 0; si < b->n_seeds && found < 0; ++si) {
-                const BNode* s = &b->nd[b->seeds[si].seed];
+            for (int si = 0; si < b->n_seeds; ++si) {
+                const int seed = b->seeds[si].seed;
+                const BNode* s = &b->nd[seed];
                 int64_t snt = s->top + s->len, snb = s->bot + s->len, sj = s->len - 1;
                 if (r > snb - (mat == IC) || r < snt) continue;
                 if (mat == MM) {
                     if (r == 0) {          /* the diagonal neighbour is the implied lead-gap row (:1352-1372) */
-                        if (cur == -go - (int)(s->cum + s->len - 1) * ge + ms) { found = si; fmat = IC; flead = 1; }
+                        const int diff = cur - (-go - (int)(s->cum + s->len - 1) * ge + ms);
+                        if (diff == 0 && found < 0) { found = si; fmat = IC; flead = 1; }
+                        else propose(b, S - diff, node, r, 0, seed, IC);
                         continue;
                     }
-                    int src = pick(b, at(s, r - 1, sj), cur, ms, ms, ms);
-                    if (src >= 0) { found = si; fmat = src; }
+                    /* (:1374-1430): every state of every predecessor is looked at; the first exact one wins */
+                    { const size_t i = at(s, r - 1, sj);
+                      { const int src = b->M[i], diff = cur - (src + ms);
+                        if (diff == 0 && found < 0) { found = si; fmat = MM; } else if (LIVE(src)) propose(b, S - diff, node, r, 0, seed, MM); }
+                      { const int src = b->Ic[i]; if (LIVE(src)) { const int diff = cur - (src + ms);
+                        if (diff == 0 && found < 0) { found = si; fmat = IC; } else propose(b, S - diff, node, r, 0, seed, IC); } }
+                      { const int src = b->Ir[i]; if (LIVE(src)) { const int diff = cur - (src + ms);
+                        if (diff == 0 && found < 0) { found = si; fmat = IR; } else propose(b, S - diff, node, r, 0, seed, IR); } } }
                 } else {
-                    int src = pick(b, at(s, r, sj), cur, -go, -ge, -go);
-                    if (src >= 0) { found = si; fmat = src; }
+                    const size_t i = at(s, r, sj);
+                    { const int src = b->M[i], diff = cur - (src - go);
+                      if (diff == 0 && found < 0) { found = si; fmat = MM; } else if (LIVE(src)) propose(b, S - diff, node, r, 0, seed, MM); }
+                    { const int src = b->Ic[i]; if (LIVE(src)) { const int diff = cur - (src - ge);
+                      if (diff == 0 && found < 0) { found = si; fmat = IC; } else propose(b, S - diff, node, r, 0, seed, IC); } }
+                    { const int src = b->Ir[i]; if (LIVE(src)) { const int diff = cur - (src - go);
+                      if (diff == 0 && found < 0) { found = si; fmat = IR; } else propose(b, S - diff, node, r, 0, seed, IR); } }
                 }
             }
             if (found < 0) {
@@ -295,8 +410,13 @@ static int traceback(B* b, int node, int mat) {
     }
 }
 
-int vgo_banded_align(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_banded_problem* p,
-                     vgk_result* res, vgk_op* ops, uint32_t ops_cap) {
+/* Up to max_alns alignments in descending score order (BandedGlobalAligner::traceback :2329-2423); results[k].ops_begin
+   indexes `ops`.  Returns the status of the problem (also in results[0].status). */
+int vgo_banded_align_multi(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_banded_problem* p, uint32_t max_alns,
+                           vgk_result* results, uint32_t* n_alns, vgk_op* ops, uint32_t ops_cap) {
+    vgk_result* res = &results[0];
+    *n_alns = 0;
+    if (!max_alns) return VGK_EINVAL;
     memset(res, 0, sizeof *res);
     const vgk_graph* g = &p->graph;
     const int N = (int)g->n_nodes; const int64_t L = p->read_len;
@@ -372,73 +492,97 @@ int vgo_banded_align(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_ba
     }
     for (int v = 0; v < N; ++v) if (!b.nd[v].masked) fill_node(&b, v);
 
-    /* choose where the traceback starts (:2426-2563): sinks, looking through empty sinks to their predecessors; on
-       equal scores the first candidate met stays (insert_traceback :2697-2703), within a node in the order match,
-       insert-row, insert-col (:2522-2552); a source-to-sink chain of empty nodes competes with the whole read inserted
-       and wins ties (next_is_empty :2611-2613). */
+    /* the stack starts with the end cells (:2426-2563): sinks in topological order [PARITY-UNPINNED: the reference walks an
+       unordered_set of matrix pointers], looking through empty sinks to their predecessors; per end node match, insert-row,
+       insert-col (:2522-2552).  Chains of empty nodes from a source to a sink are kept aside: each is the whole read inserted. */
     {
-        int have = 0, best = 0, bnode = -1, bmat = MM; int* bprefix = NULL; int bplen = 0;
-        int have_empty = 0; int* eprefix = NULL; int eplen = 0;
-        int cap = 64; int* st = (int*)malloc(sizeof(int) * cap); int* path = (int*)malloc(sizeof(int) * (size_t)(N + 1)); int plen = 0;
+        Stack st; memset(&st, 0, sizeof st); st.max = (int)max_alns; st.empty_score = -b.go - (int)(L - 1) * b.ge;
+        b.st = &st;
+        int cap = 64; int* stk = (int*)malloc(sizeof(int) * cap); int* path = (int*)malloc(sizeof(int) * (size_t)(N + 1)); int plen = 0;
         for (int v = 0; v < N; ++v) {
             if (succ_off[v] != succ_off[v + 1] || b.nd[v].masked) continue;
-            int top = 0; st[top++] = v; plen = 0;
+            int top = 0; stk[top++] = v; plen = 0;
             while (top) {
-                int u = st[--top];
+                int u = stk[--top];
                 if (u < 0) { --plen; continue; }
                 if (b.nd[u].masked) continue;
                 if (b.nd[u].len == 0) {
                     path[plen++] = u;
-                    if (top + 2 + (int)(g->pred_off[u + 1] - g->pred_off[u]) > cap) { cap = cap * 2 + (int)(g->pred_off[u + 1] - g->pred_off[u]); st = (int*)realloc(st, sizeof(int) * cap); }
-                    st[top++] = -1;
+                    if (top + 2 + (int)(g->pred_off[u + 1] - g->pred_off[u]) > cap) { cap = cap * 2 + (int)(g->pred_off[u + 1] - g->pred_off[u]); stk = (int*)realloc(stk, sizeof(int) * cap); }
+                    stk[top++] = -1;
                     if (g->pred_off[u] == g->pred_off[u + 1]) {
-                        if (!have_empty) { have_empty = 1; eplen = plen; eprefix = (int*)malloc(sizeof(int) * (size_t)plen); memcpy(eprefix, path, sizeof(int) * (size_t)plen); }
+                        st.empty_paths = (int**)realloc(st.empty_paths, sizeof(int*) * (size_t)(st.n_empty + 1)); st.empty_len = (int*)realloc(st.empty_len, sizeof(int) * (size_t)(st.n_empty + 1));
+                        st.empty_paths[st.n_empty] = (int*)malloc(sizeof(int) * (size_t)plen); memcpy(st.empty_paths[st.n_empty], path, sizeof(int) * (size_t)plen);
+                        st.empty_len[st.n_empty++] = plen;
                         continue;
                     }
-                    for (uint32_t e = g->pred_off[u]; e < g->pred_off[u + 1]; ++e) st[top++] = (int)g->pred_idx[e];
+                    for (uint32_t e = g->pred_off[u]; e < g->pred_off[u + 1]; ++e) stk[top++] = (int)g->pred_idx[e];
                     continue;
                 }
                 const BNode* n = &b.nd[u];
                 if (!in_band(&b, n, L - 1, n->len - 1)) continue;
                 size_t i = at(n, L - 1, n->len - 1);
                 const int cand[3] = { b.M[i], b.Ir[i], b.Ic[i] }; const int cmat[3] = { MM, IR, IC };
-                for (int k = 0; k < 3; ++k) if (LIVE(cand[k]) && (!have || cand[k] > best)) {
-                    have = 1; best = cand[k]; bnode = u; bmat = cmat[k];
-                    free(bprefix); bplen = plen; bprefix = (int*)malloc(sizeof(int) * (size_t)(plen + 1)); memcpy(bprefix, path, sizeof(int) * (size_t)plen);
+                for (int k = 0; k < 3; ++k) if (LIVE(cand[k])) {
+                    Defl start = { u, L - 1, n->len - 1, u, cmat[k] };
+                    stack_insert(&st, NULL, 0, cand[k], start, path, plen);
                 }
             }
         }
-        free(st); free(path);
-        int empty_score = -b.go - (int)(L - 1) * b.ge;
-        size_t n_out = 0;
-        if (have_empty && (!have || empty_score >= best)) {
-            /* the read is one insertion on the first node of the empty chain (next_empty_alignment :2616-2668) */
-            res->score = empty_score;
-            for (int k = eplen - 1; k >= 0; --k) {      /* path[] runs sink-first; the alignment runs source-first */
-                if (n_out >= ops_cap) { rc = VGK_EOPS; break; }
-                vgk_op o; o.node = (uint32_t)eprefix[k]; o.pad = 0;
-                if (k == eplen - 1) { o.op = VGK_OP_I; o.len = (uint16_t)L; } else { o.op = VGK_OP_M; o.len = 0; }
-                ops[n_out++] = o;
-            }
-        } else if (!have) {
-            rc = VGK_ENOBAND;
-        } else {
-            rc = traceback(&b, bnode, bmat);
-            if (rc == VGK_OK) {
-                res->score = best;
-                if (b.n_runs + (size_t)bplen > ops_cap) rc = VGK_EOPS;
-                else {
-                    for (size_t k = b.n_runs; k-- > 0;) { vgk_op o = b.runs[k]; if (o.len == 0) o.op = VGK_OP_M; ops[n_out++] = o; }
-                    for (int k = bplen - 1; k >= 0; --k) { vgk_op o; o.node = (uint32_t)bprefix[k]; o.op = VGK_OP_M; o.len = 0; o.pad = 0; ops[n_out++] = o; }
+        free(stk); free(path);
+        /* one alignment per turn (:2346-2421) */
+        size_t n_out = 0; uint32_t made = 0;
+        if (!st.n && !st.n_empty) rc = VGK_ENOBAND;
+        while (rc == VGK_OK && (st.cur < st.n || st.next_empty < st.n_empty)) {
+            vgk_result* out = &results[made]; memset(out, 0, sizeof *out); out->ops_begin = (uint32_t)n_out;
+            const int take_empty = st.cur >= st.n ? 1 : (st.empty_score >= st.v[st.cur].score && st.next_empty < st.n_empty);
+            if (take_empty) {
+                /* the read is one insertion on the first node of the chain (next_empty_alignment :2616-2668) */
+                const int* ep = st.empty_paths[st.next_empty]; const int el = st.empty_len[st.next_empty]; ++st.next_empty;
+                out->score = st.empty_score;
+                if (n_out + (size_t)el > ops_cap) { rc = VGK_EOPS; break; }
+                for (int k = el - 1; k >= 0; --k) {      /* path[] runs sink-first; the alignment runs source-first */
+                    vgk_op o; o.node = (uint32_t)ep[k]; o.pad = 0;
+                    if (k == el - 1) { o.op = VGK_OP_I; o.len = (uint16_t)L; } else { o.op = VGK_OP_M; o.len = 0; }
+                    ops[n_out++] = o;
                 }
+                --st.max;
+                if (st.n > st.max) { if (st.cur == st.n - 1) { stack_pop_back(&st); st.next_empty = st.n_empty; } else stack_pop_back(&st); }
+            } else {
+                const Trace* t = &st.v[st.cur];
+                st.cur_defl = 1;                           /* the first deflection names the start (:2574-2587) */
+                b.n_runs = 0;
+                rc = traceback(&b, t->d[0].from_node, t->d[0].to_mat);
+                if (rc != VGK_OK) break;
+                t = &st.v[st.cur];
+                out->score = t->score;
+                if (n_out + b.n_runs + (size_t)t->plen > ops_cap) { rc = VGK_EOPS; break; }
+                for (size_t k = b.n_runs; k-- > 0;) { vgk_op o = b.runs[k]; if (o.len == 0) o.op = VGK_OP_M; ops[n_out++] = o; }
+                for (int k = t->plen - 1; k >= 0; --k) { vgk_op o; o.node = (uint32_t)t->prefix[k]; o.op = VGK_OP_M; o.len = 0; o.pad = 0; ops[n_out++] = o; }
+                ++st.cur;
+                if (st.cur >= st.n) st.next_empty = st.n_empty;          /* (:2604-2608) */
             }
+            out->n_ops = (uint32_t)(n_out - out->ops_begin); out->status = VGK_OK;
+            ++made;
+            if (made >= max_alns) break;
         }
-        res->n_ops = (uint32_t)n_out; res->ops_begin = 0;
-        free(bprefix); free(eprefix);
+        if (rc == VGK_OK && !made) rc = VGK_ENOBAND;
+        *n_alns = rc == VGK_OK ? made : 0;
+        for (int k = 0; k < st.n; ++k) trace_free(&st.v[k]);
+        free(st.v);
+        for (int k = 0; k < st.n_empty; ++k) free(st.empty_paths[k]);
+        free(st.empty_paths); free(st.empty_len);
+        b.st = NULL;
     }
 done:
-    res->status = rc;
+    if (rc != VGK_OK) { memset(res, 0, sizeof *res); res->status = rc; }
     free(b.M); free(b.Ic); free(b.Ir); free(b.nd); free(b.seeds); free(b.pool); free(b.runs);
     free(succ_off); free(succ); free(shortest); free(longest);
     return rc;
+}
+
+int vgo_banded_align(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_banded_problem* p,
+                     vgk_result* res, vgk_op* ops, uint32_t ops_cap) {
+    uint32_t n = 0;
+    return vgo_banded_align_multi(sc, qa, p, 1, res, &n, ops, ops_cap);
 }

@@ -169,6 +169,25 @@ int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t 
     if (ops_written) *ops_written = used;
     return rc;
 }
+int vgo_banded_align_multi(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_banded_problem* p, uint32_t max_alns,
+                           vgk_result* results, uint32_t* n_alns, vgk_op* ops, uint32_t ops_cap);
+int vgk_banded_align_multi(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n, uint32_t max_alt_alns,
+                           vgk_result* results, uint32_t* n_alignments, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+    if (!ctx || (!problems && n) || !results || !n_alignments || !max_alt_alns) return VGK_EINVAL;
+    const vgk_qual_adj* qa = ctx->has_qa ? &ctx->qa : NULL;
+    size_t used = 0; int rc = VGK_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        vgk_result* r = results + (size_t)i * max_alt_alns;
+        const size_t room = ops_cap - used;
+        int st = vgo_banded_align_multi(&ctx->sc, qa, &problems[i], max_alt_alns, r, &n_alignments[i], ops ? ops + used : NULL, room > 0xffffffffu ? 0xffffffffu : (uint32_t)room);
+        if (st == VGK_EOPS) rc = VGK_EOPS;
+        size_t w = 0;
+        for (uint32_t k = 0; k < n_alignments[i]; ++k) { r[k].ops_begin += (uint32_t)used; w += r[k].n_ops; }
+        used += w;
+    }
+    if (ops_written) *ops_written = used;
+    return rc;
+}
 double vgk_banded_last(vgk_ctx* ctx, int which) { (void)ctx; (void)which; return 0.0; }
 
 int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* haplotypes, vgk_haplo** out) { (void)ctx; return vgo_haplo_create(haplotypes, out); }

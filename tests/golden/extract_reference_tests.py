@@ -167,6 +167,8 @@ class Env:
         self.expects = {}        # aln var -> list
         self.unparsed = []
         self.mems = {}           # mem vector var -> list of dict
+        self.alternatives = {}   # 'first' -> [expectation...]: what one of the returned alignments must look like (is_first_opt ... found_first_opt)
+        self.alt_scores = []     # REQUIRE(alt_aln.score() == N) inside the loop over the returned alignments
 
 
 DEFAULT_SCORES = [1, 4, 6, 1, 5]
@@ -466,6 +468,20 @@ def handle_statement(st, env):
         env.calls.append(call)
         env.expects[aln] = call["expect"]      # REQUIREs that follow describe this call until the next one on the same object
         return
+    m = re.fullmatch(r"is_(\w+)_opt = is_\1_opt && \((.+)\)", st)
+    if m:      # one condition of "some returned alignment is this one" (src/unittest/banded_global_aligner.cpp:1811-1862)
+        saved = dict(env.path_alias); env.path_alias["path"] = "__alt__"; env.aln_seq.setdefault("__alt__", "")
+        try:
+            r = parse_require(m.group(2), env)
+        finally:
+            env.path_alias = saved
+        if r is not None:
+            env.alternatives.setdefault(m.group(1), []).append(r[1])
+        return
+    m = re.fullmatch(r"REQUIRE\(alt_aln\.score\(\) == (.+)\)", st)
+    if m:
+        env.alt_scores.append(eval_int(m.group(1), env))
+        return
     m = re.fullmatch(r"REQUIRE\((.+)\)", st)
     if m:
         r = parse_require(m.group(1), env)
@@ -514,6 +530,8 @@ def cases_from_file(fname):
                 "args": call["args"],
                 "aln": aln,
                 "expect": call["expect"],
+                "alternatives": env.alternatives if call["call"].endswith("_multi") else {},
+                "alt_scores": env.alt_scores if call["call"].endswith("_multi") else [],
                 "unparsed": env.unparsed,
             }
             cases.append(case)

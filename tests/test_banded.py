@@ -239,3 +239,80 @@ def test_hip_banded_quality_adjusted_matches_oracle():
     ref = capi.Engine(lib=util.ORACLE_LIB, qual_adj=qa).banded_align(bs)
     got = capi.Engine(qual_adj=qa).banded_align(bs)
     assert not _same(problems, ref, got)
+
+
+# ---- k-best alignments (align_global_banded_multi) ------------------------------------------------------------------
+
+def multi_cases():
+    return [c for c in util.load_golden("ref_banded_global_aligner.json") if c["call"] == "align_global_banded_multi"]
+
+
+def shim_banded_multi(engine_lib, case, max_alns, pad, permissive):
+    import ctypes, json
+    h = util.host()
+    h.vgh_align_banded_multi.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_char_p, ctypes.c_size_t]
+    al = util.HostAligner(engine_lib, scores=tuple(case["scores"]), qual_adj=case["qual_adj"])
+    g = h.vgh_graph_create()
+    try:
+        for nid, seq in case["nodes"]:
+            assert h.vgh_graph_add_node(g, nid, seq.encode()) == 0
+        for a, b in case["edges"]:
+            assert h.vgh_graph_add_edge(g, a, b) == 0
+        buf = ctypes.create_string_buffer(1 << 22)
+        q = bytes(bytearray(int(x) for x in case["quality"])) if case["quality"] is not None else None
+        rc = h.vgh_align_banded_multi(al.ptr, g, case["read"].encode(), q, max_alns, pad, int(permissive), buf, len(buf))
+        assert rc == 0, h.vgh_last_error().decode()
+        return json.loads(buf.value.decode())
+    finally:
+        h.vgh_graph_destroy(g)
+
+
+def satisfies(case, aln, expectations):
+    try:
+        util.check_expectations(dict(case, expect=expectations), aln)
+        return True
+    except (AssertionError, IndexError, KeyError):
+        return False
+
+
+def run_multi_case(case, engine_lib):
+    args = case["args"]
+    max_alns = args[2]
+    if isinstance(args[3], int):
+        pad, permissive = args[3], args[4]
+    else:      # pad_band_min_random_walk(1.0, 2000, 16)(aln, graph) (src/algorithms/pad_band.cpp:16-45)
+        size = min(len(case["read"]), sum(len(s) for _, s in case["nodes"]))
+        pad, permissive = min(16, int(1.0 * np.sqrt(size)) + 1), args[-1]
+    out = shim_banded_multi(engine_lib, case, max_alns, pad, permissive)
+    alts = out["alternates"]
+    assert 1 <= len(alts) <= max_alns
+    assert out["primary"]["path"] == alts[0]["path"] and out["primary"]["score"] == alts[0]["score"]      # (:1745-1761)
+    lens = dict((n, len(s)) for n, s in case["nodes"])
+    edges = set(map(tuple, case["edges"]))
+    seen = set()
+    for k, a in enumerate(alts):
+        maps = a["path"]["mapping"]
+        for m in maps:                                                                                   # every one is a global alignment
+            assert m["position"]["offset"] == 0 and sum(e["from_length"] for e in m["edit"]) == lens[m["position"]["node_id"]], (case["source"], k)
+        assert sum(e["to_length"] for m in maps for e in m["edit"]) == len(case["read"])
+        for x, y in zip(maps, maps[1:]):
+            assert (x["position"]["node_id"], y["position"]["node_id"]) in edges
+        if k:
+            assert a["score"] <= alts[k - 1]["score"]                                                    # descending scores (:1716-1717)
+        key = repr(a["path"])
+        assert key not in seen, (case["source"], "duplicate alternate")                                  # (:2332-2368)
+        seen.add(key)
+    for name, exps in case["alternatives"].items():                                                      # found_<name>_opt
+        assert any(satisfies(case, a, exps) for a in alts), (case["source"], name, [a["score"] for a in alts])
+    for sc in case["alt_scores"]:
+        assert all(a["score"] == sc for a in alts), (case["source"], sc, [a["score"] for a in alts])
+    util.check_expectations(case, out["primary"])
+    return out
+
+
+def test_oracle_matches_reference_banded_multi_alignment_unit_tests():
+    cases = multi_cases()
+    assert len(cases) == 13
+    for c in cases:
+        run_multi_case(c, util.ORACLE_LIB)

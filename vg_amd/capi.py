@@ -101,6 +101,7 @@ def load_library(path=None):
     lib.vgk_gapless_extend.argtypes = [vp, vp, vp, u32, vp, vp, sz, vp, sz, vp, sz, ctypes.POINTER(sz * 3)]
     lib.vgk_gapless_last_ms.restype = ctypes.c_double
     lib.vgk_gapless_last_ms.argtypes = [vp]
+    lib.vgk_banded_align_multi.argtypes = [vp, vp, u32, u32, vp, vp, vp, sz, ctypes.POINTER(sz)]
     lib.vgk_banded_rerun.argtypes = [vp]
     lib.vgk_gapless_rerun.argtypes = [vp]
     lib.vgk_banded_last.restype = ctypes.c_double
@@ -268,6 +269,17 @@ class Engine:
         self._check(self.lib.vgk_banded_align(self.h, bs.ptr, bs.n, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written)),
                     "vgk_banded_align")
         return res, ops[:written.value]
+
+    def banded_align_multi(self, bs, max_alt_alns):
+        """vgk_banded_align_multi -> (results [n, max_alt_alns], n_alignments [n], ops)"""
+        res = np.zeros((bs.n, max_alt_alns), dtype=RESULT_DT)
+        cnt = np.zeros(bs.n, dtype=np.uint32)
+        cap = int((np.diff(bs.read_off).sum() + np.diff(bs.seq_off).sum() + 2 * len(bs.node_len) + 8 * bs.n) * max_alt_alns)
+        ops = np.zeros(max(cap, 1), dtype=OP_DT)
+        written = ctypes.c_size_t()
+        self._check(self.lib.vgk_banded_align_multi(self.h, bs.ptr, bs.n, max_alt_alns, res.ctypes.data, cnt.ctypes.data, ops.ctypes.data, cap,
+                                                    ctypes.byref(written)), "vgk_banded_align_multi")
+        return res, cnt, ops[:written.value]
 
     def banded_rerun(self):
         self._check(self.lib.vgk_banded_rerun(self.h), "vgk_banded_rerun")

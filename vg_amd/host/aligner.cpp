@@ -1,5 +1,6 @@
 #include "aligner.hpp"
 #include <algorithm>
+#include <set>
 #include <cmath>
 #include <sstream>
 #include <stdexcept>
@@ -571,6 +572,70 @@ void DeletionAligner::align(Alignment& aln, const HandleGraph& graph) const {
     aln.score = total ? -gap_open - (int32_t)(total - 1) * gap_extension : 0;
 }
 
+// The k shortest source-to-sink walks as pure deletions (src/deletion_aligner.cpp:27-41, :115-199): a min-heap of (distance,
+// deflections) as in the reference; walks with equal distance come out in the order of their deflection lists.
+void DeletionAligner::align_multi(Alignment& aln, std::vector<Alignment>& alt_alns, const HandleGraph& graph, int32_t max_alt_alns) const {
+    if (!aln.sequence.empty()) throw std::invalid_argument("error: DeletionAligner can only be used for alignments of empty strings");
+    std::vector<handle_t> order = handlealgs::lazier_topological_order(&graph);
+    std::unordered_map<handle_t, size_t, handle_hash> index_of;
+    for (size_t i = 0; i < order.size(); ++i) index_of[order[i]] = i;
+    const size_t inf = std::numeric_limits<size_t>::max();
+    std::vector<size_t> dists(order.size(), inf);
+    std::vector<std::pair<size_t, size_t>> sinks;
+    for (size_t i = 0; i < order.size(); ++i) {
+        if (dists[i] == inf) dists[i] = 0;
+        const size_t thru = dists[i] + graph.get_length(order[i]);
+        bool is_sink = true;
+        graph.follow_edges_v(order[i], false, [&](const handle_t& next) { size_t j = index_of.at(next); dists[j] = std::min(dists[j], thru); is_sink = false; });
+        if (is_sink) sinks.emplace_back(i, thru);
+    }
+    typedef std::vector<std::pair<size_t, size_t>> deflections_t;
+    std::multiset<std::pair<size_t, deflections_t>> heap;           // min and max at either end, like structures::MinMaxHeap
+    std::vector<std::vector<handle_t>> traces;
+    auto propose = [&](size_t from, size_t to, size_t dist, const deflections_t& curr) {
+        if (heap.size() + traces.size() < (size_t)max_alt_alns || (!heap.empty() && std::prev(heap.end())->first > dist)) {
+            deflections_t d = curr; d.emplace_back(from, to);
+            heap.emplace(dist, std::move(d));
+            if (heap.size() + traces.size() > (size_t)max_alt_alns) heap.erase(std::prev(heap.end()));
+        }
+    };
+    for (auto& sink : sinks) propose(order.size(), sink.first, sink.second, deflections_t());
+    while (!heap.empty()) {
+        const size_t trace_dist = heap.begin()->first; const deflections_t deflections = heap.begin()->second;
+        heap.erase(heap.begin());
+        traces.emplace_back();
+        size_t deflxn = 0;
+        auto get_next = [&](size_t at) -> size_t {
+            if (deflxn < deflections.size() && at == deflections[deflxn].first) return deflections[deflxn++].second;
+            size_t next = inf; const size_t dist_here = dists[at];
+            graph.follow_edges_v(order[at], true, [&](const handle_t& prev) {
+                const size_t idx = index_of.at(prev), dist_thru = dists[idx] + graph.get_length(prev);
+                if (next == inf && dist_thru == dist_here) next = idx;
+                else if (deflxn == deflections.size()) propose(at, idx, trace_dist - dist_here + dist_thru, deflections);
+            });
+            return next;
+        };
+        for (size_t tracer = get_next(order.size()); tracer != inf; tracer = get_next(tracer)) traces.back().push_back(order[tracer]);
+    }
+    if (order.empty() && max_alt_alns > 0) traces.emplace_back();
+    for (const auto& trace : traces) {
+        alt_alns.emplace_back();
+        Alignment& a = alt_alns.back();
+        a.sequence = aln.sequence; a.quality = aln.quality;
+        int64_t total = 0;
+        for (auto it = trace.rbegin(); it != trace.rend(); ++it) {
+            a.path.mapping.emplace_back();
+            Mapping& m = a.path.mapping.back();
+            m.position.node_id = graph.get_id(*it); m.position.is_reverse = graph.get_is_reverse(*it);
+            Edit e; e.from_length = (int32_t)graph.get_length(*it); e.to_length = 0; m.edit.push_back(e);
+            total += e.from_length;
+        }
+        a.score = total ? -gap_open - (int32_t)(total - 1) * gap_extension : 0;
+    }
+    if (alt_alns.empty()) return;
+    aln.path = alt_alns.front().path; aln.score = alt_alns.front().score;
+}
+
 void Aligner::align_global_banded(Alignment& alignment, const HandleGraph& g, int32_t band_padding, bool permissive_banding,
                                   uint64_t max_cells) const {
     if (alignment.sequence.empty()) {                       // (:703-706)
@@ -592,8 +657,45 @@ void Aligner::align_global_banded(Alignment& alignment, const HandleGraph& g, in
     if (res.status == VGK_ENOBAND) throw NoAlignmentInBandException();
     if (res.status == VGK_ETOOBIG) throw BandMatricesTooBigException("error:[BandedGlobalAligner] band matrices exceed the limit of " + std::to_string(max_cells) + " cells");
     if (rc != VGK_OK || res.status != VGK_OK) throw std::runtime_error(std::string("vgamd: banded global alignment failed: ") + engine->strerror(rc ? rc : res.status));
-    // BABuilder's edits (src/banded_global_aligner.cpp:102-205): one mapping per node at offset 0, matches split from
-    // mismatches by comparing the raw sequences, an empty edit on an empty node
+    banded_ops_to_alignment(pg.order, g, res, ops.data() + res.ops_begin, alignment);
+}
+
+void Aligner::align_global_banded_multi(Alignment& alignment, std::vector<Alignment>& alt_alignments, const HandleGraph& g, int32_t max_alt_alns,
+                                        int32_t band_padding, bool permissive_banding, uint64_t max_cells) const {
+    if (!alt_alignments.empty()) throw std::invalid_argument("error:[Aligner] alternate alignment vector must be empty before aligning");   // (:691-694)
+    if (max_alt_alns <= 0) throw std::invalid_argument("error:[Aligner] cannot do multi-alignment with max_alt_alns <= 0");
+    if (alignment.sequence.empty()) {                       // (:767-771)
+        DeletionAligner(scorer->gap_open, scorer->gap_extension).align_multi(alignment, alt_alignments, g, max_alt_alns);
+        return;
+    }
+    PackedGraph pg = create_packed_graph(g, handlealgs::lazier_topological_order(&g), /*raw_sequence=*/true);
+    vgk_banded_problem p{};
+    p.read = alignment.sequence.c_str(); p.read_len = (uint32_t)alignment.sequence.size();
+    p.qual = quality_of(qual_adjusted, alignment.quality, alignment.sequence.size());
+    p.flags = permissive_banding ? VGK_BANDED_PERMISSIVE : 0u;
+    p.graph = pg.view(); p.band_padding = band_padding;
+    p.max_cells = max_cells == std::numeric_limits<uint64_t>::max() ? 0 : max_cells;
+    std::vector<vgk_result> res((size_t)max_alt_alns);
+    std::vector<vgk_op> ops((alignment.sequence.size() + pg.seq.size() + 2 * pg.order.size() + 8) * (size_t)max_alt_alns);
+    uint32_t n_alns = 0; size_t n_ops = 0;
+    int rc = engine->banded_align_multi(ctx, &p, 1, (uint32_t)max_alt_alns, res.data(), &n_alns, ops.data(), ops.size(), &n_ops);
+    if (res[0].status == VGK_ENOBAND) throw NoAlignmentInBandException();
+    if (res[0].status == VGK_ETOOBIG) throw BandMatricesTooBigException("error:[BandedGlobalAligner] band matrices exceed the limit of " + std::to_string(max_cells) + " cells");
+    if (rc != VGK_OK || n_alns == 0) throw std::runtime_error(std::string("vgamd: banded global multi-alignment failed: ") + engine->strerror(rc ? rc : res[0].status));
+    // the optimal alignment goes into both the main object and the first position of the vector (:2414-2419)
+    for (uint32_t k = 0; k < n_alns; ++k) {
+        alt_alignments.emplace_back();
+        Alignment& a = alt_alignments.back();
+        a.sequence = alignment.sequence; a.quality = alignment.quality;
+        banded_ops_to_alignment(pg.order, g, res[k], ops.data() + res[k].ops_begin, a);
+    }
+    alignment.path = alt_alignments.front().path; alignment.score = alt_alignments.front().score; alignment.identity = alt_alignments.front().identity;
+}
+
+// BABuilder's edits (src/banded_global_aligner.cpp:102-205): one mapping per node at offset 0, matches split from
+// mismatches by comparing the raw sequences, an empty edit on an empty node
+void GSSWAligner::banded_ops_to_alignment(const std::vector<handle_t>& order, const HandleGraph& g, const vgk_result& res, const vgk_op* ops,
+                                          Alignment& alignment) {
     alignment.clear_path();
     alignment.score = res.score;
     const std::string& read = alignment.sequence;
@@ -601,7 +703,7 @@ void Aligner::align_global_banded(Alignment& alignment, const HandleGraph& g, in
     for (uint32_t i = 0; i < res.n_ops;) {
         uint32_t node = ops[i].node, j = i;
         while (j < res.n_ops && ops[j].node == node) ++j;
-        const handle_t h = pg.order[node];
+        const handle_t h = order[node];
         const std::string node_seq = g.get_sequence(h);
         alignment.path.mapping.emplace_back();
         Mapping& mapping = alignment.path.mapping.back();

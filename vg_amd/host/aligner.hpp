@@ -75,6 +75,7 @@ class DeletionAligner {
 public:
     DeletionAligner(int8_t gap_open, int8_t gap_extension) : gap_open(gap_open), gap_extension(gap_extension) {}
     void align(Alignment& aln, const HandleGraph& graph) const;
+    void align_multi(Alignment& aln, std::vector<Alignment>& alt_alns, const HandleGraph& graph, int32_t max_alt_alns) const;
 private:
     int8_t gap_open, gap_extension;
 };
@@ -107,6 +108,9 @@ protected:
     // gssw_mapping_to_alignment (src/aligner.cpp:120-241) over the engine's op list
     void ops_to_alignment(const PackedGraph& pg, const HandleGraph& seq_source, const vgk_result& res,
                           const vgk_op* ops, Alignment& alignment) const;
+    // BABuilder's Path (src/banded_global_aligner.cpp:102-205) over the banded engine's op list
+    static void banded_ops_to_alignment(const std::vector<handle_t>& order, const HandleGraph& g, const vgk_result& res, const vgk_op* ops,
+                                        Alignment& alignment);
 
 public:
     GSSWAligner(const GSSWAligner&) = delete;
@@ -154,6 +158,10 @@ public:
     // NoAlignmentInBandException / BandMatricesTooBigException like the reference
     void align_global_banded(Alignment& alignment, const HandleGraph& g, int32_t band_padding = 0, bool permissive_banding = true,
                              uint64_t max_cells = std::numeric_limits<uint64_t>::max()) const;
+    // the k best global alignments, best first; the best also in `alignment` (src/aligner.cpp:763-831)
+    void align_global_banded_multi(Alignment& alignment, std::vector<Alignment>& alt_alignments, const HandleGraph& g, int32_t max_alt_alns,
+                                   int32_t band_padding = 0, bool permissive_banding = true,
+                                   uint64_t max_cells = std::numeric_limits<uint64_t>::max()) const;
     // two-pass seeded X-drop alignment (src/aligner.cpp:833-855 -> DozeuInterface::align, src/dozeu_interface.cpp:608-685)
     void align_xdrop(Alignment& alignment, const HandleGraph& g, const std::vector<MaximalExactMatch>& mems,
                      bool reverse_complemented, uint16_t max_gap_length = default_xdrop_max_gap_length) const;

@@ -42,6 +42,7 @@ std::shared_ptr<EngineApi> load_engine(const std::string& path) {
     bind(dl, "vgk_gssw_fetch", api->gssw_fetch);
     bind(dl, "vgk_batch_free", api->batch_free);
     bind(dl, "vgk_banded_align", api->banded_align);
+    bind(dl, "vgk_banded_align_multi", api->banded_align_multi);
     bind(dl, "vgk_haplo_create", api->haplo_create);
     bind(dl, "vgk_haplo_destroy", api->haplo_destroy);
     bind(dl, "vgk_gapless_extend", api->gapless_extend);

@@ -25,6 +25,7 @@ struct EngineApi {
     decltype(&vgk_gssw_fetch) gssw_fetch = nullptr;
     decltype(&vgk_batch_free) batch_free = nullptr;
     decltype(&vgk_banded_align) banded_align = nullptr;
+    decltype(&vgk_banded_align_multi) banded_align_multi = nullptr;
     decltype(&vgk_haplo_create) haplo_create = nullptr;
     decltype(&vgk_haplo_destroy) haplo_destroy = nullptr;
     decltype(&vgk_gapless_extend) gapless_extend = nullptr;

@@ -87,6 +87,23 @@ int vgh_align_q(vgh_aligner* a, vgh_graph* g, const char* read, const uint8_t* q
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }
 
+// Aligner::align_global_banded_multi: JSON out = {"primary": alignment, "alternates": [alignment...]}
+int vgh_align_banded_multi(vgh_aligner* a, vgh_graph* g, const char* read, const uint8_t* qual, int max_alt_alns, int band_padding, int permissive,
+                           char* json_out, size_t json_cap) {
+    try {
+        Alignment aln; aln.sequence = read;
+        if (qual) aln.quality.assign(reinterpret_cast<const char*>(qual), aln.sequence.size());
+        std::vector<Alignment> alts;
+        a->a->align_global_banded_multi(aln, alts, g->g, max_alt_alns, band_padding, permissive != 0);
+        std::string js = "{\"primary\":" + alignment_to_json(aln) + ",\"alternates\":[";
+        for (size_t i = 0; i < alts.size(); ++i) { if (i) js += ','; js += alignment_to_json(alts[i]); }
+        js += "]}";
+        if (js.size() + 1 > json_cap) { g_last_error = "json buffer too small"; return -2; }
+        std::memcpy(json_out, js.c_str(), js.size() + 1);
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
 // Aligner::align_xdrop with MEMs given as flat records [begin, end, node_id, offset, is_reverse] x n_mems
 int vgh_align_xdrop(vgh_aligner* a, vgh_graph* g, const char* read, const int64_t* mems, int n_mems,
                     int reverse_complemented, int max_gap, char* json_out, size_t json_cap) {
