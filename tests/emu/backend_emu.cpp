@@ -66,7 +66,7 @@ public:
                 default: return VGK_EINVAL;
             }
         }
-        for (uint32_t i = 0; i < P.n; ++i) banded_walk_one(P, i);
+        if (!P.scores) for (uint32_t i = 0; i < P.n; ++i) banded_walk_one(P, i);
         return VGK_OK;
     }
     const char* name() const override { return "cpu-lockstep-emulator"; }

@@ -316,3 +316,38 @@ def test_oracle_matches_reference_banded_multi_alignment_unit_tests():
     assert len(cases) == 13
     for c in cases:
         run_multi_case(c, util.ORACLE_LIB)
+
+
+def compare_multi(engine_lib, problems, k):
+    bs = capi.BandedSet.from_lists(problems)
+    ro, co, oo = capi.Engine(lib=util.ORACLE_LIB).banded_align_multi(bs, k)
+    rg, cg, og = (capi.Engine(lib=engine_lib) if engine_lib else capi.Engine()).banded_align_multi(bs, k)
+    assert (co == cg).all(), np.nonzero(co != cg)[0][:5]
+    total = 0
+    for i in range(bs.n):
+        if co[i] == 0:
+            assert ro[i][0]["status"] == rg[i][0]["status"], i
+        for a in range(co[i]):
+            x, y = ro[i][a], rg[i][a]
+            assert x["score"] == y["score"] and x["n_ops"] == y["n_ops"], (i, a)
+            assert (oo[x["ops_begin"]:x["ops_begin"] + x["n_ops"]] == og[y["ops_begin"]:y["ops_begin"] + y["n_ops"]]).all(), (i, a)
+            assert path_score(problems[i], y, og) == y["score"]
+            if a:
+                assert y["score"] <= rg[i][a - 1]["score"]
+            total += 1
+    return total
+
+
+def test_emulated_banded_multi_matches_reference_unit_tests_and_oracle():
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    for c in multi_cases():
+        run_multi_case(c, util.EMU_LIB)
+    assert compare_multi(util.EMU_LIB, random_banded_set(51, 30), 5) > 60
+
+
+@pytest.mark.gpu
+def test_hip_banded_multi_matches_reference_unit_tests_and_oracle():
+    for c in multi_cases():
+        run_multi_case(c, util.ENGINE_LIB)
+    assert compare_multi(None, random_banded_set(52, 1500) + mixed_band_problems(53, 60, 30, 200), 6) > 5000

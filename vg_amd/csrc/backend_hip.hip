@@ -245,7 +245,7 @@ public:
             if (st != stream) { hipEventRecord(side_done[i - 1], st); hipStreamWaitEvent(stream, side_done[i - 1], 0); }
         }
         hipEventRecord(bev[1], stream);
-        hipLaunchKernelGGL(banded_walk_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
+        if (!p.scores) hipLaunchKernelGGL(banded_walk_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);      // k-best mode: the host walks the score matrices
         hipEventRecord(bev[2], stream);
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         hipEventElapsedTime(&ms_bfill, bev[0], bev[1]);

@@ -41,7 +41,8 @@ struct Prep {                          // one problem after pass 1; its tables l
     uint32_t ops_cap = 0;
     Span nodes, seeds, pool, starts;   // starts: candidate end nodes; start_prefix[k] = the empty sink-side nodes of candidate k, sink first (:2455-2480)
     bool have_empty_walk = false;      // a source-to-sink chain of empty nodes (:2464-2472)
-    Span empty_walk;                   // in Store::prefix, sink first
+    Span empty_walk;                   // in Store::prefix, sink first (the first chain found)
+    std::vector<Span> empty_walks;     // every chain, for the k-best mode (:2464-2472)
     uint32_t arena = 0;                // index inside its sub-batch
     uint32_t need = 0;                 // ops this problem hands back
     bool use_empty_walk = false;
@@ -182,7 +183,9 @@ void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch&
             if (len[u] == 0) {
                 S.path.push_back((uint32_t)u); S.st.push_back(-1);
                 if (is_source((uint32_t)u)) {
-                    if (!hp.have_empty_walk) { hp.have_empty_walk = true; hp.empty_walk = {T.prefix.size(), (uint32_t)S.path.size()}; T.prefix.insert(T.prefix.end(), S.path.begin(), S.path.end()); }
+                    hp.empty_walks.push_back({T.prefix.size(), (uint32_t)S.path.size()});
+                    if (!hp.have_empty_walk) { hp.have_empty_walk = true; hp.empty_walk = hp.empty_walks.back(); }
+                    T.prefix.insert(T.prefix.end(), S.path.begin(), S.path.end());
                     continue;
                 }
                 for (uint32_t e = g.pred_off[u]; e < g.pred_off[u + 1]; ++e) S.st.push_back(g.pred_idx[e]);
@@ -222,18 +225,252 @@ template <class T> struct RawBuf {
 };
 struct HostArenas {
     RawBuf<BProb> probs; RawBuf<BNode> nodes; RawBuf<BSeed> seeds; RawBuf<uint32_t> pool, order; RawBuf<BStart> starts;
-    RawBuf<uint8_t> reads, quals, graph; RawBuf<BResult> dres; RawBuf<vgk_op> dops;
+    RawBuf<uint8_t> reads, quals, graph; RawBuf<BResult> dres; RawBuf<vgk_op> dops; RawBuf<int32_t> scores;
 };
 enum { S_PROBS, S_ORDER, S_NODES, S_SEEDS, S_POOL, S_STARTS, S_READS, S_QUALS, S_GRAPH, S_MAT, S_TB, S_LAST, S_OPS, S_DENSE, S_RESULTS, S_COUNT };
-static_assert(S_COUNT <= sizeof(vgk_ctx::scratch) / sizeof(vgk_ctx::DevBuf), "scratch slots");
+constexpr int S_SCORES = 31;          // k-best mode: the full score matrices (slots 15..30 belong to gapless_api.cpp)
+static_assert(S_COUNT <= 15 && S_SCORES < (int)(sizeof(vgk_ctx::scratch) / sizeof(vgk_ctx::DevBuf)), "scratch slots");
+
+// ---- k-best alignments: the alternate-traceback stack of the reference (AltTracebackStack, src/banded_global_aligner.cpp:2426-2790)
+// walked on the host over the score matrices the fill kernel left in HBM.  A traceback is the list of its deflections — the first
+// names the start, every later one a cell where it leaves the optimal choice for a named predecessor state; the stack keeps up to
+// `max` of them in descending score order, equal scores in the order they were found.
+struct Defl { int32_t from_node; int64_t r, j; int32_t to_node, to_mat; };
+struct Trace { std::vector<Defl> d; int32_t score; Span prefix; };
+
+struct MultiTracer {
+    const vgk_ctx* ctx; const vgk_banded_problem& p; const Prep& hp; const Store& T; const int32_t* sc;
+    std::vector<Trace> stack; size_t cur = 0, cur_defl = 0; int64_t max = 1;
+    std::vector<vgk_op> runs;                      // back to front
+    int32_t go, ge; int64_t L;
+
+    const BNode& nd(int32_t v) const { return T.nodes[hp.nodes.off + v]; }
+    static bool live(int32_t v) { return v > BNEG / 2; }
+    int32_t val(int32_t v, uint32_t state, int64_t r, int64_t j) const {
+        const BNode& n = nd(v);
+        return sc[3 * ((size_t)n.tb_off + (size_t)j * n.stride) + (size_t)state * n.stride + (size_t)(r - j - n.top)];
+    }
+    int32_t sub(int32_t v, int64_t r, int64_t j) const {
+        const uint32_t g = nt_code(p.graph.seq[nd(v).seq_off + j]), q = nt_code(p.read[r]);
+        return ctx->has_qa ? ctx->qmat[25u * p.qual[r] + 5u * g + q] : ctx->sc.matrix[5u * g + q];
+    }
+    void emit(int32_t node, uint32_t op, uint32_t inc) {                       // BABuilder (:44-100)
+        if (!runs.empty() && runs.back().node == (uint32_t)node) {
+            vgk_op& c = runs.back();
+            if (c.op == op) { c.len = (uint16_t)(c.len + inc); return; }
+            if (c.len == 0 && nd(node).len == 0) { c.op = (uint8_t)op; c.len = (uint16_t)inc; return; }
+        }
+        vgk_op c{}; c.node = (uint32_t)node; c.op = (uint8_t)op; c.len = (uint16_t)inc; runs.push_back(c);
+    }
+    static uint32_t op_of(uint32_t mat) { return mat == BM ? VGK_OP_M : mat == BIR ? VGK_OP_I : VGK_OP_D; }
+    void insert(const std::vector<Defl>& prefix_d, int32_t score, const Defl& last, Span prefix) {          // insert_traceback (:2691-2740)
+        size_t pos = stack.size();
+        while (pos > 0 && score > stack[pos - 1].score) --pos;
+        if (!stack.empty() && pos == stack.size() && (int64_t)stack.size() >= max) return;
+        Trace t; t.d = prefix_d; t.d.push_back(last); t.score = score; t.prefix = prefix;
+        stack.insert(stack.begin() + pos, std::move(t));
+        if ((int64_t)stack.size() > max) stack.pop_back();
+    }
+    void propose(int32_t alt, int32_t from_node, int64_t r, int64_t j, int32_t to_node, uint32_t to_mat) {  // propose_deflection (:2671-2689)
+        if (cur_defl != stack[cur].d.size()) return;
+        if (alt <= stack.back().score && (int64_t)stack.size() >= max) return;
+        const std::vector<Defl> d = stack[cur].d; const Span pre = stack[cur].prefix;
+        insert(d, alt, Defl{from_node, r, j, to_node, (int32_t)to_mat}, pre);
+    }
+    bool at_deflection(int32_t node, int64_t r, int64_t j) const {
+        const Trace& c = stack[cur];
+        return cur_defl < c.d.size() && c.d[cur_defl].from_node == node && c.d[cur_defl].r == r && c.d[cur_defl].j == j;
+    }
+    // the three predecessor states in the reference's order; the first that explains `cur` is taken, every other live one proposed
+    int pick(int32_t v, int64_t r, int64_t j, int32_t cur_val, int32_t dm, int32_t dc, int32_t dr, int32_t from_node, int64_t fr, int64_t fj) {
+        const int32_t S = stack[cur].score;
+        int found = -1;
+        { const int32_t src = val(v, BM, r, j), diff = cur_val - (src + dm);
+          if (diff == 0) found = BM; else if (live(src)) propose(S - diff, from_node, fr, fj, from_node, BM); }
+        { const int32_t src = val(v, BIC, r, j); if (live(src)) { const int32_t diff = cur_val - (src + dc);
+          if (found < 0 && diff == 0) found = BIC; else propose(S - diff, from_node, fr, fj, from_node, BIC); } }
+        { const int32_t src = val(v, BIR, r, j); if (live(src)) { const int32_t diff = cur_val - (src + dr);
+          if (found < 0 && diff == 0) found = BIR; else propose(S - diff, from_node, fr, fj, from_node, BIR); } }
+        return found;
+    }
+    // where a deflection across an edge lands: predecessors in their own order, each through its empty nodes depth-first (:1163-1196)
+    bool find_deflect_seed(int32_t node, int32_t target, std::vector<int32_t>& path) const {
+        const vgk_graph& g = p.graph;
+        std::vector<int64_t> st;
+        for (uint32_t e0 = g.pred_off[node]; e0 < g.pred_off[node + 1]; ++e0) {
+            st.assign(1, g.pred_idx[e0]); path.clear();
+            while (!st.empty()) {
+                const int64_t s = st.back(); st.pop_back();
+                if (s < 0) { path.pop_back(); continue; }
+                if (nd((int32_t)s).masked) continue;
+                if (s == target) return true;
+                if (nd((int32_t)s).len == 0) {
+                    path.push_back((int32_t)s); st.push_back(-1);
+                    for (uint32_t e = g.pred_off[s]; e < g.pred_off[s + 1]; ++e) st.push_back(g.pred_idx[e]);
+                }
+            }
+        }
+        return false;
+    }
+    // one traceback (BAMatrix::traceback :756-1126 + traceback_over_edge :1129-1780), following stack[cur]'s deflections
+    int trace() {
+        const int32_t S = stack[cur].score;
+        int32_t node = stack[cur].d[0].from_node; uint32_t mat = (uint32_t)stack[cur].d[0].to_mat;
+        int64_t r = L - 1, j = nd(node).len - 1;
+        bool lead = false;
+        std::vector<int32_t> dpath;
+        for (;;) {
+            const BNode& n = nd(node);
+            while ((j > 0 || mat == BIR) && !lead) {
+                emit(node, op_of(mat), 1);
+                if (at_deflection(node, r, j)) {
+                    if (mat == BM) { --r; --j; } else if (mat == BIR) --r; else --j;
+                    mat = (uint32_t)stack[cur].d[cur_defl++].to_mat;
+                    continue;
+                }
+                if (mat == BM) {
+                    if (r == 0) { mat = BIC; --j; r = -1; lead = true; break; }
+                    const int32_t ms = sub(node, r, j);
+                    const int src = pick(node, r - 1, j - 1, val(node, BM, r, j), ms, ms, ms, node, r, j);
+                    if (src < 0) return VGK_EINVAL;
+                    mat = (uint32_t)src; --r; --j;
+                } else if (mat == BIR) {
+                    if (r == 0) { lead = true; r = -1; break; }
+                    const int src = pick(node, r - 1, j, val(node, BIR, r, j), -go, -go, -ge, node, r, j);
+                    if (src < 0) return VGK_EINVAL;
+                    mat = (uint32_t)src; --r;
+                } else {
+                    const int src = pick(node, r, j - 1, val(node, BIC, r, j), -go, -ge, -go, node, r, j);
+                    if (src < 0) return VGK_EINVAL;
+                    mat = (uint32_t)src; --j;
+                }
+            }
+            if (lead) { mat = BIC; while (j > 0) { emit(node, VGK_OP_D, 1); --j; } }
+            if (at_deflection(node, r, 0)) {                                                   // (:1158-1222)
+                emit(node, op_of(mat), 1);
+                const Defl d = stack[cur].d[cur_defl++];
+                if (!find_deflect_seed(node, d.to_node, dpath)) return VGK_EINVAL;
+                for (int32_t e : dpath) emit(e, op_of(mat), 0);
+                if (r == 0 && mat == BM) lead = true;
+                if (mat == BM) --r;
+                mat = (uint32_t)d.to_mat; node = d.to_node; j = nd(node).len - 1;
+                continue;
+            }
+            const BSeed* seeds = T.seeds.data() + hp.seeds.off + n.seed_off;
+            const uint32_t* pool = T.pool.data() + hp.pool.off;
+            int found = -1; uint32_t fmat = BM; bool flead = lead;
+            if (lead) {
+                emit(node, VGK_OP_D, 1);
+                for (uint32_t si = 0; si < n.n_seeds; ++si) {
+                    const BNode& sd = nd((int32_t)seeds[si].node);
+                    const int32_t diff = (int32_t)((int64_t)ge * (sd.cum + sd.len - n.cum));
+                    if (diff == 0 && found < 0) found = (int)si;
+                    else propose(S - diff, node, r, 0, (int32_t)seeds[si].node, BIC);
+                }
+                if (found < 0) {
+                    if (!n.as_source) return VGK_EINVAL;
+                    for (uint32_t q = 0; q < n.src_path_len; ++q) emit((int32_t)pool[n.src_path_off + q], VGK_OP_D, 0);
+                    return VGK_OK;
+                }
+            } else {
+                emit(node, op_of(mat), 1);
+                const int32_t cur_val = val(node, mat == BM ? BM : BIC, r, 0);
+                const int32_t ms = mat == BM ? sub(node, r, 0) : 0;
+                for (uint32_t si = 0; si < n.n_seeds; ++si) {
+                    const int32_t seed = (int32_t)seeds[si].node;
+                    const BNode& sd = nd(seed);
+                    const int64_t snt = sd.top + sd.len, snb = sd.bot + sd.len, sj = sd.len - 1;
+                    if (r > snb - (mat == BIC ? 1 : 0) || r < snt) continue;
+                    if (mat == BM && r == 0) {
+                        const int32_t diff = cur_val - (-go - (sd.cum + sd.len - 1) * ge + ms);
+                        if (diff == 0 && found < 0) { found = (int)si; fmat = BIC; flead = true; }
+                        else propose(S - diff, node, r, 0, seed, BIC);
+                        continue;
+                    }
+                    const int64_t sr = mat == BM ? r - 1 : r;
+                    const int32_t dm = mat == BM ? ms : -go, dc = mat == BM ? ms : -ge, dr = mat == BM ? ms : -go;
+                    { const int32_t src = val(seed, BM, sr, sj), diff = cur_val - (src + dm);
+                      if (diff == 0 && found < 0) { found = (int)si; fmat = BM; } else if (live(src)) propose(S - diff, node, r, 0, seed, BM); }
+                    { const int32_t src = val(seed, BIC, sr, sj); if (live(src)) { const int32_t diff = cur_val - (src + dc);
+                      if (diff == 0 && found < 0) { found = (int)si; fmat = BIC; } else propose(S - diff, node, r, 0, seed, BIC); } }
+                    { const int32_t src = val(seed, BIR, sr, sj); if (live(src)) { const int32_t diff = cur_val - (src + dr);
+                      if (diff == 0 && found < 0) { found = (int)si; fmat = BIR; } else propose(S - diff, node, r, 0, seed, BIR); } }
+                }
+                if (found < 0) {
+                    if (!n.as_source) return VGK_EINVAL;
+                    int64_t ins;
+                    if (mat == BM) { if (cur_val != (r > 0 ? -go - (int32_t)(r - 1) * ge : 0) + ms) return VGK_EINVAL; ins = r; }
+                    else           { if (cur_val != -go - (int32_t)r * ge - go) return VGK_EINVAL; ins = r + 1; }
+                    for (uint32_t q = 0; q < n.src_path_len; ++q) emit((int32_t)pool[n.src_path_off + q], VGK_OP_D, 0);
+                    const int32_t end_node = n.src_path_len ? (int32_t)pool[n.src_path_off + n.src_path_len - 1] : node;
+                    for (int64_t q = 0; q < ins; ++q) emit(end_node, VGK_OP_I, 1);
+                    return VGK_OK;
+                }
+            }
+            const BSeed& sr = seeds[found];
+            for (uint32_t q = 0; q < sr.path_len; ++q) emit((int32_t)pool[sr.path_off + q], op_of(mat), 0);
+            if (!lead) { if (mat == BM) --r; mat = fmat; lead = flead; }
+            node = (int32_t)sr.node; j = nd(node).len - 1;
+        }
+    }
+    // all alignments of the problem, best first (BandedGlobalAligner::traceback :2329-2423)
+    int run(uint32_t max_alns, std::vector<vgk_result>& results, std::vector<vgk_op>& ops) {
+        go = ctx->sc.gap_open; ge = ctx->sc.gap_extend; L = p.read_len; max = max_alns;
+        for (uint32_t c = 0; c < hp.starts.len; ++c) {
+            const int32_t u = (int32_t)T.starts[hp.starts.off + c];
+            const BNode& n = nd(u);
+            const int64_t k = (L - 1) - (n.len - 1) - n.top;
+            if (k < 0 || k > n.bot - n.top) continue;
+            const int32_t cand[3] = { val(u, BM, L - 1, n.len - 1), val(u, BIR, L - 1, n.len - 1), val(u, BIC, L - 1, n.len - 1) };
+            const uint32_t cmat[3] = { BM, BIR, BIC };
+            for (int q = 0; q < 3; ++q) if (live(cand[q])) insert({}, cand[q], Defl{u, L - 1, n.len - 1, u, (int32_t)cmat[q]}, T.start_prefix[hp.starts.off + c]);
+        }
+        const int32_t empty_score = -go - (int32_t)(L - 1) * ge;
+        size_t next_empty = 0, n_empty = hp.empty_walks.size();
+        if (stack.empty() && !n_empty) return VGK_ENOBAND;
+        while (cur < stack.size() || next_empty < n_empty) {
+            vgk_result out{}; out.ops_begin = (uint32_t)ops.size();
+            const bool take_empty = cur >= stack.size() ? true : (empty_score >= stack[cur].score && next_empty < n_empty);
+            if (take_empty) {                                                                  // next_empty_alignment (:2616-2668)
+                const Span w = hp.empty_walks[next_empty++];
+                out.score = empty_score;
+                for (uint32_t e = w.len; e-- > 0;) {
+                    vgk_op o{}; o.node = T.prefix[w.off + e];
+                    if (e + 1 == w.len) { o.op = VGK_OP_I; o.len = (uint16_t)L; } else { o.op = VGK_OP_M; o.len = 0; }
+                    ops.push_back(o);
+                }
+                --max;
+                if ((int64_t)stack.size() > max) { if (cur + 1 == stack.size()) { stack.pop_back(); next_empty = n_empty; } else stack.pop_back(); }
+            } else {
+                cur_defl = 1; runs.clear();
+                const int rc = trace();
+                if (rc != VGK_OK) return rc;
+                out.score = stack[cur].score;
+                for (size_t q = runs.size(); q-- > 0;) { vgk_op o = runs[q]; if (o.len == 0) o.op = VGK_OP_M; ops.push_back(o); }
+                const Span pre = stack[cur].prefix;
+                for (uint32_t e = pre.len; e-- > 0;) { vgk_op o{}; o.node = T.prefix[pre.off + e]; o.op = VGK_OP_M; o.len = 0; ops.push_back(o); }
+                ++cur;
+                if (cur >= stack.size()) next_empty = n_empty;
+            }
+            out.n_ops = (uint32_t)(ops.size() - out.ops_begin); out.status = VGK_OK;
+            results.push_back(out);
+            if (results.size() >= max_alns) break;
+        }
+        return results.empty() ? VGK_ENOBAND : VGK_OK;
+    }
+};
 
 }  // namespace
 
 extern "C" {
 
-int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n,
-                     vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+// max_alt_alns == 0: the primary alignment, traced on the device; otherwise the k best, enumerated on the host over the
+// device-filled score matrices (results[i * max_alt_alns + k], n_alignments[i])
+static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n, uint32_t max_alt_alns,
+                             vgk_result* results, uint32_t* n_alignments, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
     if (!ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
+    const bool multi = max_alt_alns > 0;
+    if (multi && !n_alignments) return VGK_EINVAL;
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->banded_ms[0] = ctx->banded_ms[1] = 0; ctx->banded_cells = 0; ctx->banded_bytes = 0; ctx->banded_last_valid = false;
     uint64_t budget = ctx->be->memory_bytes() / 2;
@@ -266,7 +503,7 @@ int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t 
             const Prep& hp = hps[j];
             if (!hp.on_device) continue;
             const vgk_banded_problem& p = problems[j];
-            if (!owner.empty() && (tb_bytes + hp.tb_bytes + (last_elems + hp.last_elems) * 4 + (ops_total + hp.ops_cap) * 2 * sizeof(vgk_op) > budget ||
+            if (!owner.empty() && ((tb_bytes + hp.tb_bytes) * (multi ? 13 : 1) + (last_elems + hp.last_elems) * 4 + (ops_total + hp.ops_cap) * 2 * sizeof(vgk_op) > budget ||
                                    n_nodes + p.graph.n_nodes > 0xfffffff0ull || n_read + p.read_len > 0xfffffff0ull || n_graph + hp.bases > 0xfffffff0ull)) break;
             n_nodes += p.graph.n_nodes; n_seeds += hp.seeds.len; n_pool += hp.pool.len; n_starts += hp.starts.len;
             n_read += p.read_len; n_graph += hp.bases; tb_bytes += hp.tb_bytes; last_elems += hp.last_elems; ops_total += hp.ops_cap;
@@ -345,21 +582,52 @@ int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t 
             P.ops = (vgk_op*)ensure(ctx, S_OPS, std::max<uint64_t>(ops_total, 1) * sizeof(vgk_op));
             P.dense = (vgk_op*)ensure(ctx, S_DENSE, std::max<uint64_t>(ops_total, 1) * sizeof(vgk_op));
             uint8_t* rblock = (uint8_t*)ensure(ctx, S_RESULTS, (size_t)m * sizeof(BResult) + 64);
-            if (!P.tb || !P.last || !P.ops || !P.dense || !rblock) return VGK_ENOMEM;
+            if (multi) P.scores = (int32_t*)ensure(ctx, S_SCORES, std::max<uint64_t>(tb_bytes, 256) * 3 * sizeof(int32_t));
+            if (!P.tb || !P.last || !P.ops || !P.dense || !rblock || (multi && !P.scores)) return VGK_ENOMEM;
             P.dense_count = (unsigned long long*)rblock; P.results = (BResult*)(rblock + 64);
             if ((rc = be->zero(rblock, 64))) return rc;
             lap("scratch");
             if ((rc = be->run_banded(P, launches.data(), (uint32_t)launches.size()))) return rc;
             lap("kernels");
             ctx->banded_last = P; ctx->banded_last_launches = launches; ctx->banded_last_valid = (i == 0 && j == n);     // the whole call in one sub-batch
-            unsigned long long dense_n = 0;
-            if ((rc = be->download(&dense_n, P.dense_count, sizeof dense_n))) return rc;
-            if ((rc = be->download(dres, P.results, (size_t)m * sizeof(BResult)))) return rc;
-            vgk_op* hd = H.dops.get(dense_n + 1);
-            if (dense_n && (rc = be->download(hd, P.dense, (size_t)dense_n * sizeof(vgk_op)))) return rc;
-            dops = hd;
-            ctx->banded_ms[0] += be->last_ms(3); ctx->banded_ms[1] += be->last_ms(4);
-            lap("d2h");
+            if (multi) {
+                // k-best: every problem's alternates are enumerated on a host thread over its score matrices
+                int32_t* hs = H.scores.get(tb_bytes * 3 + 1);
+                if ((rc = be->download(hs, P.scores, (size_t)tb_bytes * 3 * sizeof(int32_t)))) return rc;
+                ctx->banded_ms[0] += be->last_ms(3);
+                lap("d2h");
+                std::vector<std::vector<vgk_result>> pres(m); std::vector<std::vector<vgk_op>> pops(m); std::vector<int> pstat(m, VGK_OK);
+                parallel_for(m, [&](uint32_t a, unsigned) {
+                    const Prep& hp = hps[owner[a]];
+                    MultiTracer mt{ctx, problems[owner[a]], hp, store[hp.thread], hs + 3 * probs[a].tb_base};
+                    pstat[a] = mt.run(max_alt_alns, pres[a], pops[a]);
+                });
+                for (uint32_t a = 0; a < m; ++a) {
+                    const uint32_t q = owner[a]; vgk_result* r = results + (size_t)q * max_alt_alns;
+                    ctx->banded_cells += hps[q].cells;
+                    n_alignments[q] = 0;
+                    if (pstat[a] != VGK_OK) { std::memset(r, 0, sizeof *r); r->status = pstat[a]; continue; }
+                    if (!ops || used + pops[a].size() > ops_cap) { std::memset(r, 0, sizeof *r); r->status = VGK_EOPS; rc_all = VGK_EOPS; continue; }
+                    for (size_t k = 0; k < pres[a].size(); ++k) { r[k] = pres[a][k]; r[k].ops_begin += (uint32_t)used; }
+                    std::copy(pops[a].begin(), pops[a].end(), ops + used); used += pops[a].size();
+                    n_alignments[q] = (uint32_t)pres[a].size();
+                }
+                lap("results");
+            } else {
+                unsigned long long dense_n = 0;
+                if ((rc = be->download(&dense_n, P.dense_count, sizeof dense_n))) return rc;
+                if ((rc = be->download(dres, P.results, (size_t)m * sizeof(BResult)))) return rc;
+                vgk_op* hd = H.dops.get(dense_n + 1);
+                if (dense_n && (rc = be->download(hd, P.dense, (size_t)dense_n * sizeof(vgk_op)))) return rc;
+                dops = hd;
+                ctx->banded_ms[0] += be->last_ms(3); ctx->banded_ms[1] += be->last_ms(4);
+                lap("d2h");
+            }
+        }
+        if (multi) {       // problems that never reached the device carry their status; the rest was written above
+            for (uint32_t q = i; q < j; ++q) if (!hps[q].on_device) { vgk_result* r = results + (size_t)q * max_alt_alns; std::memset(r, 0, sizeof *r); r->status = hps[q].status; n_alignments[q] = 0; }
+            i = j;
+            continue;
         }
         // results in the caller's order; the empty-walk rule and the empty sink prefixes are host bookkeeping (:2611-2668, :196-203):
         // sizes first, then a prefix sum, then every problem writes its own slice
@@ -412,6 +680,17 @@ int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t 
     }
     if (ops_written) *ops_written = used;
     return rc_all;
+}
+
+int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n,
+                     vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+    return banded_align_impl(ctx, problems, n, 0, results, nullptr, ops, ops_cap, ops_written);
+}
+
+int vgk_banded_align_multi(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n, uint32_t max_alt_alns,
+                           vgk_result* results, uint32_t* n_alignments, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+    if (!max_alt_alns) return VGK_EINVAL;
+    return banded_align_impl(ctx, problems, n, max_alt_alns, results, n_alignments, ops, ops_cap, ops_written);
 }
 
 int vgk_banded_rerun(vgk_ctx* ctx) {

@@ -76,6 +76,7 @@ struct BandedParams {
     const int8_t*  mat;                // 25, or 256*25 when quals != nullptr
     int32_t        go, ge;
     uint8_t*       tb;
+    int32_t*       scores;            // k-best mode only: every cell's M | Ic | Ir (int32, `stride` each per column), 3 x the traceback layout
     int32_t*       last;
     vgk_op*        ops;               // per-problem slots the traceback writes back to front
     vgk_op*        dense;             // the finished op lists, packed (BResult::ops_begin indexes this)
@@ -156,6 +157,10 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
                 codes[i] = (uint8_t)(code_mc[i] | (cr << 2));
             }
             if (k0 < (int32_t)nd.stride) store_codes<R>(tbn + (size_t)j * nd.stride + k0, codes);
+            if (P.scores) {         // the alternate tracebacks need score differences, not just sources (AltTracebackStack)
+                int32_t* sc = P.scores + 3 * (pb.tb_base + nd.tb_off + (size_t)j * nd.stride);
+                for (int i = 0; i < R; ++i) if (k0 + i < (int32_t)nd.stride) { sc[k0 + i] = M[i]; sc[nd.stride + k0 + i] = Ic[i]; sc[2 * nd.stride + k0 + i] = Ir[i]; }
+            }
         };
         // a column whose left neighbours are the registers: columns 1.. of a node (:492-590), and column 0 of a node whose
         // only predecessor is the node this wave has just finished, with the band carried straight over (BNode::chain)
