@@ -15,6 +15,7 @@
 #include <vector>
 #include "backend.hpp"
 #include "ctx.hpp"
+#include "host_parallel.hpp"
 
 using namespace vgk;
 
@@ -169,31 +170,41 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         G = (rows + K - 1) / K;
     };
 
+    // Three passes over the problems, the first and the last on host threads: (1) validate and size every problem, (2) prefix sums
+    // place it in the shared arenas, (3) encode it at its offsets.
     std::vector<ProbDesc>& probs = b->probs;
     probs.resize(n);
-    std::vector<uint8_t> colinfo, reads;
-    std::vector<uint32_t> prof;
-    std::vector<NodeRec> nodes;
-    std::vector<uint32_t> preds;
-    uint64_t scratch_words = 0, ops_total = 0, n_edges = 0;
-    std::vector<uint8_t> store, slow;
-    for (uint32_t i = 0; i < n; ++i) {
+    struct Sizes { uint32_t reads = 0, prof = 0, cols = 0, nodes = 0, preds = 0; int status = VGK_OK; bool want_tb = false; };
+    std::vector<Sizes> sizes(n);
+    struct Flags { std::vector<uint8_t> store, slow; };
+    std::vector<Flags> thread_flags(MAX_THREADS);
+    // store[v]: the node's last column is saved for a successor / the pinned end; slow[v]: its first column is seeded from scratch
+    auto node_flags = [&](const vgk_gssw_problem& p, bool xdrop, uint32_t mode, Flags& f) -> int {
+        const vgk_graph& g = p.graph;
+        f.store.assign(g.n_nodes, 0); f.slow.assign(g.n_nodes, 0);
+        for (uint32_t v = 0; v < g.n_nodes; ++v) {
+            const uint32_t pb = g.pred_off[v], pe = g.pred_off[v + 1];
+            if (pe < pb || g.node_len[v] == 0) return VGK_EINVAL;
+            for (uint32_t k = pb; k < pe; ++k) if (g.pred_idx[k] >= v) return VGK_EINVAL;   // not topological
+            const bool chain = (pe - pb == 1) && g.pred_idx[pb] + 1 == v;
+            f.slow[v] = ((v > 0 || xdrop) && !chain) ? 1 : 0;      // X-drop: node 0 starts from the root column
+            if (f.slow[v]) for (uint32_t k = pb; k < pe; ++k) f.store[g.pred_idx[k]] = 1;
+            if (mode == VGK_GSSW_PINNED && p.pinning[v]) f.store[v] = 1;
+        }
+        return VGK_OK;
+    };
+    parallel_for(n, [&](uint32_t i, unsigned t) {
         const vgk_gssw_problem& p = problems[i];
         const vgk_graph& g = p.graph;
-        ProbDesc& d = probs[i];
+        ProbDesc& d = probs[i]; Sizes& z = sizes[i];
         const uint32_t mode = p.flags & 15u;
-        if (mode != VGK_GSSW_LOCAL && mode != VGK_GSSW_PINNED && mode != VGK_XDROP_PINNED) return VGK_EINVAL;
+        if (mode != VGK_GSSW_LOCAL && mode != VGK_GSSW_PINNED && mode != VGK_XDROP_PINNED) { z.status = VGK_EINVAL; return; }
         const bool xdrop = mode == VGK_XDROP_PINNED;
         // offset arithmetic of the X-drop mode: every reachable gain must stay below XOFF
-        if (xdrop && (int64_t)p.read_len * std::max(ctx->max_score, 0) + ctx->max_bonus >= (int64_t)XOFF) return VGK_EUNSUPPORTED;
-        if (ctx->has_qa && !p.qual) return VGK_EINVAL;
-        if (mode == VGK_GSSW_PINNED && !p.pinning) return VGK_EINVAL;
-        if (p.flags & VGK_GSSW_TRACEBACK) b->want_tb = true;
+        if (xdrop && (int64_t)p.read_len * std::max(ctx->max_score, 0) + ctx->max_bonus >= (int64_t)XOFF) { z.status = VGK_EUNSUPPORTED; return; }
+        if ((ctx->has_qa && !p.qual) || (mode == VGK_GSSW_PINNED && !p.pinning) || !g.node_len || !g.pred_off || !g.seq) { z.status = VGK_EINVAL; return; }
+        z.want_tb = (p.flags & VGK_GSSW_TRACEBACK) != 0;
         d.flags = p.flags; d.L = p.read_len + (xdrop ? 1u : 0u); d.n_nodes = g.n_nodes;
-        d.node_off = (uint32_t)nodes.size();
-        d.read_off = (uint32_t)reads.size();
-        if (xdrop) reads.push_back(5);      // row 0 = no read base consumed yet
-        for (uint32_t r = 0; r < p.read_len; ++r) reads.push_back((uint8_t)nt_read(p.read[r]));
         d.max_gap = xdrop ? ((std::max<uint32_t>(p.max_gap_length, 1u) + 7u) & ~7u) : 0u;
         {   // which full-length bonuses this problem grants, and their values (src/aligner.cpp:401-402, 942-952, 1164-1167)
             const uint32_t S = ctx->scale;
@@ -202,67 +213,88 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
             d.bonus_start = xdrop ? 0u : (uint32_t)first_b * S;
             d.bonus_end = (mode == VGK_GSSW_PINNED) ? 0u : (uint32_t)last_b * S;
             d.prof_off = 0xffffffffu; d.pad = 0;
-            if (ctx->has_qa) {
-                d.prof_off = (uint32_t)prof.size();
-                if (xdrop) prof.push_back(0);          // row 0 = nothing consumed
-                for (uint32_t r = 0; r < p.read_len; ++r) {
-                    const int code = nt_read(p.read[r]);
-                    uint32_t w = 0;
-                    for (int b4 = 0; b4 < 4; ++b4)
-                        w |= (uint32_t)((ctx->qmat[25 * p.qual[r] + 5 * b4 + code] + (int)ctx->bias) * (int)S) << (8 * b4);
-                    const uint32_t row = r + (xdrop ? 1u : 0u);
-                    w += 0x01010101u * row_bonus(d.bonus_start, d.bonus_end, row, d.L);
-                    prof.push_back(w);
-                }
+        }
+        Flags& f = thread_flags[t];
+        if ((z.status = node_flags(p, xdrop, mode, f)) != VGK_OK) return;
+        uint64_t col = 0; uint32_t slots = 0;
+        for (uint32_t v = 0; v < g.n_nodes; ++v) { col += g.node_len[v]; slots += f.store[v]; }
+        if (col >= (1u << 20)) { z.status = VGK_ETOOBIG; return; }
+        d.R = (uint32_t)col; d.n_slots = slots;
+        uint32_t pK, pG; geometry(d.L, pK, pG);
+        d.geom = pK | (pG << 8); d.Lpad = pG * pK; d.wave = 0; d.lane0 = 0;
+        d.ops_cap = ops_per_problem ? ops_per_problem : (p.read_len + d.R + 2);
+        if (!(p.flags & VGK_GSSW_TRACEBACK)) d.ops_cap = 0;
+        z.reads = d.L; z.prof = ctx->has_qa ? d.L : 0; z.cols = d.R; z.nodes = g.n_nodes; z.preds = g.pred_off[g.n_nodes] - g.pred_off[0];
+    });
+    uint64_t scratch_words = 0, ops_total = 0, n_reads = 0, n_prof = 0, n_cols = 0, n_nodes = 0, n_preds = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (sizes[i].status != VGK_OK) return sizes[i].status;
+        ProbDesc& d = probs[i]; const Sizes& z = sizes[i];
+        if (z.want_tb) b->want_tb = true;
+        d.node_off = (uint32_t)n_nodes; d.read_off = (uint32_t)n_reads;
+        if (ctx->has_qa) d.prof_off = (uint32_t)n_prof;
+        n_cols = (n_cols + 3) & ~3ull;                       // every problem's column stream starts on a dword
+        d.col_off = (uint32_t)n_cols;
+        d.scratch_off = (uint32_t)scratch_words; scratch_words += (uint64_t)d.n_slots * d.Lpad;
+        d.ops_off = (uint32_t)ops_total; ops_total += d.ops_cap;
+        n_nodes += z.nodes; n_reads += z.reads; n_prof += z.prof; n_cols += z.cols; n_preds += z.preds;
+        if (scratch_words >= (1ull << 32) || ops_total >= (1ull << 32) || n_cols >= (1ull << 32) || n_reads >= (1ull << 32) || n_nodes >= (1ull << 32) || n_preds >= (1ull << 32)) return VGK_ETOOBIG;
+        b->cells += (uint64_t)d.R * d.L;
+        b->in_bytes += (uint64_t)problems[i].read_len + d.R + 8ull * z.nodes + 4ull * z.preds;
+    }
+    std::vector<uint8_t> colinfo(n_cols + 8, (uint8_t)CI_INVALID), reads(n_reads);     // + 8: leaders prefetch one word ahead
+    std::vector<uint32_t> prof(n_prof);
+    std::vector<NodeRec> nodes(n_nodes);
+    std::vector<uint32_t> preds(n_preds);
+    {   // pred_begin is an offset into the shared predecessor arena
+        uint64_t at = 0;
+        for (uint32_t i = 0; i < n; ++i) { sizes[i].preds = (uint32_t)at; at += problems[i].graph.pred_off[problems[i].graph.n_nodes] - problems[i].graph.pred_off[0]; }
+    }
+    parallel_for(n, [&](uint32_t i, unsigned t) {
+        const vgk_gssw_problem& p = problems[i];
+        const vgk_graph& g = p.graph;
+        const ProbDesc& d = probs[i];
+        const uint32_t mode = p.flags & 15u; const bool xdrop = mode == VGK_XDROP_PINNED;
+        uint8_t* rd = reads.data() + d.read_off;
+        if (xdrop) *rd++ = 5;                                  // row 0 = no read base consumed yet
+        for (uint32_t r = 0; r < p.read_len; ++r) rd[r] = (uint8_t)nt_read(p.read[r]);
+        if (ctx->has_qa) {
+            const uint32_t S = ctx->scale;
+            uint32_t* pf = prof.data() + d.prof_off;
+            if (xdrop) *pf++ = 0;                              // row 0 = nothing consumed
+            for (uint32_t r = 0; r < p.read_len; ++r) {
+                const int code = nt_read(p.read[r]);
+                uint32_t w = 0;
+                for (int b4 = 0; b4 < 4; ++b4)
+                    w |= (uint32_t)((ctx->qmat[25 * p.qual[r] + 5 * b4 + code] + (int)ctx->bias) * (int)S) << (8 * b4);
+                const uint32_t row = r + (xdrop ? 1u : 0u);
+                w += 0x01010101u * row_bonus(d.bonus_start, d.bonus_end, row, d.L);
+                pf[r] = w;
             }
         }
-        // which nodes need their last column saved / need a scratch-seeded first column
-        store.assign(g.n_nodes, 0); slow.assign(g.n_nodes, 0);
-        for (uint32_t v = 0; v < g.n_nodes; ++v) {
-            const uint32_t pb = g.pred_off[v], pe = g.pred_off[v + 1];
-            if (pe < pb || g.node_len[v] == 0) return VGK_EINVAL;
-            for (uint32_t k = pb; k < pe; ++k) if (g.pred_idx[k] >= v) return VGK_EINVAL;   // not topological
-            const bool chain = (pe - pb == 1) && g.pred_idx[pb] + 1 == v;
-            slow[v] = ((v > 0 || xdrop) && !chain) ? 1 : 0;      // X-drop: node 0 starts from the root column
-            if (slow[v]) for (uint32_t k = pb; k < pe; ++k) store[g.pred_idx[k]] = 1;
-            if (mode == VGK_GSSW_PINNED && p.pinning[v]) store[v] = 1;
-            n_edges += pe - pb;
-        }
-        while (colinfo.size() & 3u) colinfo.push_back(CI_INVALID);
-        d.col_off = (uint32_t)colinfo.size();
-        uint32_t col = 0, slots = 0, seq_pos = 0;
+        Flags& f = thread_flags[t];
+        node_flags(p, xdrop, mode, f);
+        uint8_t* ci_out = colinfo.data() + d.col_off;
+        NodeRec* nrs = nodes.data() + d.node_off;
+        uint32_t* pr = preds.data() + sizes[i].preds;
+        uint32_t col = 0, slots = 0, seq_pos = 0, np = 0;
         for (uint32_t v = 0; v < g.n_nodes; ++v) {
             NodeRec nr;
             nr.col_start = col; nr.col_end = col + g.node_len[v];
-            nr.pred_begin = (uint32_t)preds.size(); nr.n_pred = g.pred_off[v + 1] - g.pred_off[v];
-            for (uint32_t k = g.pred_off[v]; k < g.pred_off[v + 1]; ++k) preds.push_back(g.pred_idx[k]);
-            nr.slot = store[v] ? (int32_t)slots++ : -1;
+            nr.pred_begin = sizes[i].preds + np; nr.n_pred = g.pred_off[v + 1] - g.pred_off[v];
+            for (uint32_t k = g.pred_off[v]; k < g.pred_off[v + 1]; ++k) pr[np++] = g.pred_idx[k];
+            nr.slot = f.store[v] ? (int32_t)slots++ : -1;
             nr.pinning = (mode == VGK_GSSW_PINNED && p.pinning[v]) ? 1u : 0u;
-            nodes.push_back(nr);
+            nrs[v] = nr;
             for (uint32_t k = 0; k < g.node_len[v]; ++k, ++seq_pos) {
                 uint8_t ci = (uint8_t)nt_ref(g.seq[seq_pos]);
-                if (k == 0) { ci |= CI_NODE_START; if (slow[v]) ci |= CI_SEED_SLOW; }
-                if (k + 1 == g.node_len[v] && store[v]) ci |= CI_STORE_END;
-                colinfo.push_back(ci);
+                if (k == 0) { ci |= CI_NODE_START; if (f.slow[v]) ci |= CI_SEED_SLOW; }
+                if (k + 1 == g.node_len[v] && f.store[v]) ci |= CI_STORE_END;
+                ci_out[col + k] = ci;
             }
             col = nr.col_end;
         }
-        if (col >= (1u << 20)) return VGK_ETOOBIG;
-        d.R = col; d.n_slots = slots;
-        uint32_t pK, pG; geometry(d.L, pK, pG);
-        d.geom = pK | (pG << 8); d.Lpad = pG * pK; d.wave = 0; d.lane0 = 0;
-        d.scratch_off = (uint32_t)scratch_words;
-        scratch_words += (uint64_t)slots * d.Lpad;
-        if (scratch_words >= (1ull << 32)) return VGK_ETOOBIG;
-        d.ops_cap = ops_per_problem ? ops_per_problem : (p.read_len + col + 2);
-        if (!(p.flags & VGK_GSSW_TRACEBACK)) d.ops_cap = 0;
-        d.ops_off = (uint32_t)ops_total;
-        ops_total += d.ops_cap;
-        if (ops_total >= (1ull << 32)) return VGK_ETOOBIG;
-        b->cells += (uint64_t)col * d.L;
-        b->in_bytes += (uint64_t)p.read_len + col + 8ull * g.n_nodes + 4ull * (g.pred_off[g.n_nodes] - g.pred_off[0]);
-    }
-    for (int k = 0; k < 8; ++k) colinfo.push_back(CI_INVALID);   // leaders prefetch one word ahead
+    });
 
     // ---- length buckets: reads with the same (K, G) geometry share wavefronts; inside a bucket reads are sorted by
     //      graph size so that the pairs of a wavefront finish together.  One fill launch per K; G is per wavefront.
