@@ -63,6 +63,7 @@ public:
                 case 4: if (P.quals) banded_fill_emu<4, true>(P, L.begin, L.count); else banded_fill_emu<4, false>(P, L.begin, L.count); break;
                 case 8: if (P.quals) banded_fill_emu<8, true>(P, L.begin, L.count); else banded_fill_emu<8, false>(P, L.begin, L.count); break;
                 case 16: if (P.quals) banded_fill_emu<16, true>(P, L.begin, L.count); else banded_fill_emu<16, false>(P, L.begin, L.count); break;
+                case 32: if (P.quals) banded_fill_emu<32, true>(P, L.begin, L.count); else banded_fill_emu<32, false>(P, L.begin, L.count); break;
                 default: return VGK_EINVAL;
             }
         }

@@ -195,6 +195,10 @@ def test_emulated_banded_kernels_match_reference_unit_tests_and_oracle():
     for c in banded_cases():
         run_banded_case(c, emu)
     problems = random_banded_set(21, 40) + mixed_band_problems(22, 6, 30, 200)      # the second lot needs 2..8 band rows per lane
+    rng = np.random.default_rng(23)                                                   # and one band of 1681 diagonals: 32 rows per lane
+    wide = "".join("ACGT"[i] for i in rng.integers(0, 4, 60))
+    problems.append(dict(read="".join("ACGT"[i] for i in rng.integers(0, 4, 700)), nodes=[wide[:20], wide[20:40], wide[40:]], preds=[[], [0], [1]],
+                         band_padding=520, permissive=True))
     bs = capi.BandedSet.from_lists(problems)
     ref = capi.Engine(lib=util.ORACLE_LIB).banded_align(bs)
     got = capi.Engine(lib=emu).banded_align(bs)
@@ -215,7 +219,7 @@ def test_hip_banded_matches_oracle_on_random_problems():
     eng = capi.Engine()
     got = eng.banded_align(bs)
     bad = _same(problems, ref, got)
-    # engine limit: bands taller than 1024 diagonals are refused with VGK_ETOOBIG, which the shim raises as
+    # engine limit: bands taller than 2048 diagonals are refused with VGK_ETOOBIG, which the shim raises as
     # BandMatricesTooBigException like a max_cells overflow; only the widest paddings of the third lot can get there
     too_big = [b for b in bad if b[3]["status"] == -7 and b[0] >= 3400]
     assert len(too_big) <= 8

@@ -46,7 +46,7 @@ for qa in (None, qualadj.qual_adj_tables()):
     bs = capi.BandedSet.from_lists(problems)
     got = capi.Engine(qual_adj=qa).banded_align(bs); ref = capi.Engine(lib=ORA, qual_adj=qa).banded_align(bs)
     bad = [b for b in test_banded._same(problems, ref, got) if b[3]["status"] != -7]
-    print("banded qual_adj=%s: %d problems, %d differ, %d refused (band > 1024)" % (qa is not None, len(problems), len(bad), int((got[0]["status"] == -7).sum()))); fails += len(bad)
+    print("banded qual_adj=%s: %d problems, %d differ, %d refused (band > 2048)" % (qa is not None, len(problems), len(bad), int((got[0]["status"] == -7).sum()))); fails += len(bad)
 
 # gapless
 total, full = test_gapless.compare_engines(None, range(seed * 1000, seed * 1000 + 150), n_reads=600)

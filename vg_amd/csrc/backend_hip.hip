@@ -240,6 +240,7 @@ public:
                 case 4:  launch_banded_fill<4>(p, L, st); break;
                 case 8:  launch_banded_fill<8>(p, L, st); break;
                 case 16: launch_banded_fill<16>(p, L, st); break;
+                case 32: launch_banded_fill<32>(p, L, st); break;
                 default: return VGK_EINVAL;
             }
             if (st != stream) { hipEventRecord(side_done[i - 1], st); hipStreamWaitEvent(stream, side_done[i - 1], 0); }

@@ -118,7 +118,7 @@ void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch&
         if (!any) { hp.status = VGK_ENOBAND; return; }
     }
     uint32_t R = 1; while ((int64_t)R * 64 < max_h) R *= 2;
-    if (R > 16 || L > (1 << 24) || total_bases > (1u << 24)) { hp.status = VGK_ETOOBIG; return; }      // engine limit: bands up to 1024 diagonals
+    if (R > 32 || L > (1 << 24) || total_bases > (1u << 24)) { hp.status = VGK_ETOOBIG; return; }      // engine limit: bands up to 2048 diagonals
     hp.R = R; hp.Hpad = 64 * R;
     const uint32_t Hpad = hp.Hpad;
 
@@ -552,12 +552,12 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
             {
                 auto key = [&](uint32_t a) { const Prep& hp = hps[owner[a]]; uint32_t r = 0; while ((1u << r) < hp.R) ++r;
                                              uint32_t lg = 0; while ((hp.cells >> lg) > 1 && lg < 63) ++lg; return r * 64 + (63 - lg); };
-                std::vector<uint32_t> count(5 * 64 + 1, 0);
+                std::vector<uint32_t> count(6 * 64 + 1, 0);
                 for (uint32_t a = 0; a < m; ++a) ++count[key(a) + 1];
                 for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
                 std::vector<uint32_t> at(count.begin(), count.end() - 1);
                 for (uint32_t a = 0; a < m; ++a) order[at[key(a)]++] = a;
-                for (uint32_t r = 0; r < 5; ++r) {
+                for (uint32_t r = 0; r < 6; ++r) {
                     const uint32_t lo = count[r * 64], hi = count[(r + 1) * 64];
                     if (lo == hi) continue;
                     // LDS staging area: score table | read codes | qualities | graph codes of the largest problem of the launch
