@@ -254,95 +254,168 @@ static void unreverse_ops(std::vector<vgk_op>& ops, vgk_result& res, const std::
     res.first_offset = (int32_t)node_len[first] - (int32_t)aligned - (n_nodes == 1 ? res.first_offset : 0);
 }
 
-void Aligner::align_internal(Alignment& alignment, std::vector<Alignment>* multi_alignments, const HandleGraph& g,
-                             bool pinned, bool pin_left, int32_t max_alt_alns, bool traceback_aln) const {
+// align_internal (src/aligner.cpp:344-564) in two halves, so that many calls can share one engine launch (AlignmentBatch):
+// prepare_job builds the oriented / null-masked view, the packed graph and the engine problem; finish_job turns the
+// engine's result into the Alignment exactly as the reference does after gssw returns.
+struct Aligner::Job {
+    Alignment* alignment = nullptr; const HandleGraph* g = nullptr;
+    bool pinned = false, pin_left = false, traceback = true;
+    std::unique_ptr<ReverseGraph> reversed_graph; std::unique_ptr<NullMaskingGraph> null_masked_graph;
+    const HandleGraph* oriented_graph = nullptr; const HandleGraph* align_graph = nullptr;
+    std::string reversed_sequence, reversed_quality;
+    PackedGraph pg; std::vector<uint8_t> pin_mask;
+    bool has_problem = false; vgk_gssw_problem prob{};
+    // banded global jobs (align_global_banded) use the same carrier
+    bool banded = false; vgk_banded_problem bprob{}; uint64_t max_cells = 0;
+};
+
+std::unique_ptr<Aligner::Job> Aligner::prepare_job(Alignment& alignment, const HandleGraph& g, bool pinned, bool pin_left, bool traceback_aln) const {
     // input contract (the reference prints and exit(1)s: src/aligner.cpp:348-363; we throw)
     if (pin_left && !pinned) throw std::invalid_argument("error:[Aligner] cannot choose pinned end in non-pinned alignment");
-    if (multi_alignments && !pinned) throw std::invalid_argument("error:[Aligner] multiple traceback is not implemented in local alignment, only pinned and global");
-    if (!multi_alignments && max_alt_alns != 1) throw std::invalid_argument("error:[Aligner] cannot specify maximum number of alignments in single alignment");
-    if (max_alt_alns <= 0) throw std::invalid_argument("error:[Aligner] cannot do less than 1 alignment");
-
-    ReverseGraph reversed_graph(&g, false);
-    std::string reversed_sequence;
-    const HandleGraph* oriented_graph = &g;
+    auto job = std::make_unique<Job>();
+    Job& j = *job;
+    j.alignment = &alignment; j.g = &g; j.pinned = pinned; j.pin_left = pin_left; j.traceback = traceback_aln;
+    j.oriented_graph = &g;
     const std::string* align_sequence = &alignment.sequence;
-    std::string reversed_quality;
     const std::string* align_quality = &alignment.quality;
     if (pin_left) {
-        oriented_graph = &reversed_graph;
-        reversed_sequence.assign(alignment.sequence.rbegin(), alignment.sequence.rend());
-        align_sequence = &reversed_sequence;
-        reversed_quality.assign(alignment.quality.rbegin(), alignment.quality.rend());
-        align_quality = &reversed_quality;
+        j.reversed_graph = std::make_unique<ReverseGraph>(&g, false);
+        j.oriented_graph = j.reversed_graph.get();
+        j.reversed_sequence.assign(alignment.sequence.rbegin(), alignment.sequence.rend());
+        align_sequence = &j.reversed_sequence;
+        j.reversed_quality.assign(alignment.quality.rbegin(), alignment.quality.rend());
+        align_quality = &j.reversed_quality;
     }
     std::unordered_set<nid_t> pinning_ids;
-    std::unique_ptr<NullMaskingGraph> null_masked_graph;
-    const HandleGraph* align_graph = oriented_graph;
+    j.align_graph = j.oriented_graph;
     if (pinned) {
-        pinning_ids = identify_pinning_points(*oriented_graph);
-        null_masked_graph = std::make_unique<NullMaskingGraph>(oriented_graph);
-        align_graph = null_masked_graph.get();
+        pinning_ids = identify_pinning_points(*j.oriented_graph);
+        j.null_masked_graph = std::make_unique<NullMaskingGraph>(j.oriented_graph);
+        j.align_graph = j.null_masked_graph.get();
     }
-
-    PackedGraph pg = create_packed_graph(*align_graph);
-    vgk_result res{};
-    std::vector<vgk_op> ops;
-    bool did_dp = false;
-    if (!pg.order.empty() && !align_sequence->empty()) {
-        std::vector<uint8_t> pin_mask;
-        vgk_gssw_problem prob{};
+    j.pg = create_packed_graph(*j.align_graph);
+    if (!j.pg.order.empty() && !align_sequence->empty()) {
+        vgk_gssw_problem& prob = j.prob;
         prob.read = align_sequence->data(); prob.read_len = (uint32_t)align_sequence->size();
         prob.qual = quality_of(qual_adjusted, *align_quality, align_sequence->size());
         prob.flags = (pinned ? VGK_GSSW_PINNED : VGK_GSSW_LOCAL) | (traceback_aln ? VGK_GSSW_TRACEBACK : 0);
-        prob.graph = pg.view();
+        prob.graph = j.pg.view();
         if (pinned) {
-            pin_mask.resize(pg.order.size());
-            for (size_t i = 0; i < pg.order.size(); ++i) pin_mask[i] = pinning_ids.count(align_graph->get_id(pg.order[i])) ? 1 : 0;
-            prob.pinning = pin_mask.data();
+            j.pin_mask.resize(j.pg.order.size());
+            for (size_t i = 0; i < j.pg.order.size(); ++i) j.pin_mask[i] = pinning_ids.count(j.align_graph->get_id(j.pg.order[i])) ? 1 : 0;
+            prob.pinning = j.pin_mask.data();
         }
-        ops.resize(prob.read_len + pg.seq.size() + pg.order.size() + 4);
-        size_t written = 0;
-        int rc = engine->gssw_align(ctx, &prob, 1, &res, ops.data(), ops.size(), &written);
-        if (rc != VGK_OK) throw std::runtime_error(std::string("vgamd: gssw engine failed: ") + engine->strerror(rc));
-        if (res.status != VGK_OK) throw std::runtime_error(std::string("vgamd: gssw problem failed: ") + engine->strerror(res.status));
-        ops.resize(res.n_ops);
-        did_dp = true;
+        j.has_problem = true;
     }
+    return job;
+}
 
-    if (traceback_aln) {
-        if (pinned) {
+void Aligner::finish_job(Job& j, vgk_result res, std::vector<vgk_op> ops, std::vector<Alignment>* multi_alignments, int32_t max_alt_alns) const {
+    Alignment& alignment = *j.alignment; const HandleGraph& g = *j.g;
+    const bool did_dp = j.has_problem;
+    if (did_dp && res.status != VGK_OK) throw std::runtime_error(std::string("vgamd: gssw problem failed: ") + engine->strerror(res.status));
+    if (j.traceback) {
+        if (j.pinned) {
             if (did_dp && res.score > 0) {
-                if (pin_left) unreverse_ops(ops, res, pg.node_len);
+                if (j.pin_left) unreverse_ops(ops, res, j.pg.node_len);
                 // after un-reversal the cigar refers to the forward sequences of g
-                ops_to_alignment(pg, g, res, ops.data(), alignment);
+                ops_to_alignment(j.pg, g, res, ops.data(), alignment);
                 if (multi_alignments) multi_alignments->emplace_back(alignment);   // alternates: see DESIGN.md (k-best not yet on device)
             } else if (g.get_node_count() > 0) {
                 // no positive-score traceback: synthesise soft clips at the id-sorted tail nodes.
                 // The reference writes every alternate into `alignment` (src/aligner.cpp:505-520); reproduced as is.
-                auto pinning_points = handlealgs::tail_nodes(oriented_graph);
+                auto pinning_points = handlealgs::tail_nodes(j.oriented_graph);
                 std::sort(pinning_points.begin(), pinning_points.end(), [&](const handle_t& a, const handle_t& b) {
-                    return oriented_graph->get_id(a) < oriented_graph->get_id(b); });
+                    return j.oriented_graph->get_id(a) < j.oriented_graph->get_id(b); });
                 for (size_t i = 0; i < (size_t)max_alt_alns && i < pinning_points.size(); i++) {
                     if (multi_alignments) multi_alignments->emplace_back();
                     handle_t& pinning_point = pinning_points[i];
                     alignment.path.mapping.emplace_back();
                     Mapping& mapping = alignment.path.mapping.back();
                     mapping.rank = 1;
-                    mapping.position.node_id = oriented_graph->get_id(pinning_point);
-                    mapping.position.offset = pin_left ? 0 : (int64_t)oriented_graph->get_length(pinning_point);
+                    mapping.position.node_id = j.oriented_graph->get_id(pinning_point);
+                    mapping.position.offset = j.pin_left ? 0 : (int64_t)j.oriented_graph->get_length(pinning_point);
                     Edit e; e.to_length = (int32_t)alignment.sequence.length(); e.sequence = alignment.sequence;
                     mapping.edit.push_back(e);
                     if (i == 0 && multi_alignments) multi_alignments->back() = alignment;
                 }
             }
         } else {
-            ops_to_alignment(pg, g, res, ops.data(), alignment);
+            ops_to_alignment(j.pg, g, res, ops.data(), alignment);
         }
     } else {
         alignment.score = res.score;
         alignment.path.mapping.emplace_back();
         Position& p = alignment.path.mapping.back().position;
-        if (res.end_node >= 0) { p.node_id = align_graph->get_id(pg.order[res.end_node]); p.offset = res.end_offset; }
+        if (res.end_node >= 0) { p.node_id = j.align_graph->get_id(j.pg.order[res.end_node]); p.offset = res.end_offset; }
+    }
+}
+
+void Aligner::align_internal(Alignment& alignment, std::vector<Alignment>* multi_alignments, const HandleGraph& g,
+                             bool pinned, bool pin_left, int32_t max_alt_alns, bool traceback_aln) const {
+    if (multi_alignments && !pinned) throw std::invalid_argument("error:[Aligner] multiple traceback is not implemented in local alignment, only pinned and global");
+    if (!multi_alignments && max_alt_alns != 1) throw std::invalid_argument("error:[Aligner] cannot specify maximum number of alignments in single alignment");
+    if (max_alt_alns <= 0) throw std::invalid_argument("error:[Aligner] cannot do less than 1 alignment");
+    auto job = prepare_job(alignment, g, pinned, pin_left, traceback_aln);
+    vgk_result res{};
+    std::vector<vgk_op> ops;
+    if (job->has_problem) {
+        ops.resize(job->prob.read_len + job->pg.seq.size() + job->pg.order.size() + 4);
+        size_t written = 0;
+        int rc = engine->gssw_align(ctx, &job->prob, 1, &res, ops.data(), ops.size(), &written);
+        if (rc != VGK_OK) throw std::runtime_error(std::string("vgamd: gssw engine failed: ") + engine->strerror(rc));
+        ops.resize(res.n_ops);
+    }
+    finish_job(*job, res, std::move(ops), multi_alignments, max_alt_alns);
+}
+
+// ---- AlignmentBatch: many Aligner calls, one engine launch per kernel family (the deferred-submission shim) -------
+AlignmentBatch::AlignmentBatch(const Aligner& aligner) : aligner(aligner) {}
+AlignmentBatch::~AlignmentBatch() = default;
+void AlignmentBatch::align(Alignment& alignment, const HandleGraph& g, bool traceback_aln) { jobs.push_back(aligner.prepare_job(alignment, g, false, false, traceback_aln)); }
+void AlignmentBatch::align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left) { jobs.push_back(aligner.prepare_job(alignment, g, true, pin_left, true)); }
+void AlignmentBatch::align_global_banded(Alignment& alignment, const HandleGraph& g, int32_t band_padding, bool permissive_banding, uint64_t max_cells) {
+    jobs.push_back(aligner.prepare_banded_job(alignment, g, band_padding, permissive_banding, max_cells));
+}
+size_t AlignmentBatch::size() const { return jobs.size(); }
+void AlignmentBatch::flush() {
+    std::vector<std::unique_ptr<Aligner::Job>> run; run.swap(jobs);
+    // gssw family
+    std::vector<vgk_gssw_problem> probs; std::vector<size_t> owner;
+    size_t cap = 0;
+    for (size_t i = 0; i < run.size(); ++i) if (!run[i]->banded && run[i]->has_problem) {
+        probs.push_back(run[i]->prob); owner.push_back(i);
+        cap += run[i]->prob.read_len + run[i]->pg.seq.size() + run[i]->pg.order.size() + 4;
+    }
+    std::vector<vgk_result> res(probs.size()); std::vector<vgk_op> ops(cap + 1);
+    if (!probs.empty()) {
+        size_t written = 0;
+        int rc = aligner.engine_api().gssw_align(aligner.engine_context(), probs.data(), (uint32_t)probs.size(), res.data(), ops.data(), ops.size(), &written);
+        if (rc != VGK_OK) throw std::runtime_error(std::string("vgamd: gssw engine failed: ") + aligner.engine_api().strerror(rc));
+    }
+    // banded family
+    std::vector<vgk_banded_problem> bprobs; std::vector<size_t> bowner;
+    size_t bcap = 0;
+    for (size_t i = 0; i < run.size(); ++i) if (run[i]->banded && run[i]->has_problem) {
+        bprobs.push_back(run[i]->bprob); bowner.push_back(i);
+        bcap += run[i]->bprob.read_len + run[i]->pg.seq.size() + 2 * run[i]->pg.order.size() + 8;
+    }
+    std::vector<vgk_result> bres(bprobs.size()); std::vector<vgk_op> bops(bcap + 1);
+    if (!bprobs.empty()) {
+        size_t written = 0;
+        int rc = aligner.engine_api().banded_align(aligner.engine_context(), bprobs.data(), (uint32_t)bprobs.size(), bres.data(), bops.data(), bops.size(), &written);
+        if (rc != VGK_OK) throw std::runtime_error(std::string("vgamd: banded engine failed: ") + aligner.engine_api().strerror(rc));
+    }
+    // apply: problems that had nothing to run (empty read / empty graph) still go through the result code
+    std::vector<const vgk_result*> rof(run.size(), nullptr);
+    for (size_t k = 0; k < owner.size(); ++k) rof[owner[k]] = &res[k];
+    for (size_t k = 0; k < bowner.size(); ++k) rof[bowner[k]] = &bres[k];
+    for (size_t i = 0; i < run.size(); ++i) {
+        Aligner::Job& j = *run[i];
+        if (j.banded) { aligner.finish_banded_job(j, rof[i] ? *rof[i] : vgk_result{}, rof[i] ? bops.data() + rof[i]->ops_begin : nullptr); continue; }
+        vgk_result r{}; std::vector<vgk_op> o;
+        if (rof[i]) { r = *rof[i]; o.assign(ops.begin() + r.ops_begin, ops.begin() + r.ops_begin + r.n_ops); r.ops_begin = 0; }
+        aligner.finish_job(j, r, std::move(o), nullptr, 1);
     }
 }
 
@@ -636,28 +709,45 @@ void DeletionAligner::align_multi(Alignment& aln, std::vector<Alignment>& alt_al
     aln.path = alt_alns.front().path; aln.score = alt_alns.front().score;
 }
 
-void Aligner::align_global_banded(Alignment& alignment, const HandleGraph& g, int32_t band_padding, bool permissive_banding,
-                                  uint64_t max_cells) const {
-    if (alignment.sequence.empty()) {                       // (:703-706)
-        DeletionAligner(scorer->gap_open, scorer->gap_extension).align(alignment, g);
-        return;
-    }
+std::unique_ptr<Aligner::Job> Aligner::prepare_banded_job(Alignment& alignment, const HandleGraph& g, int32_t band_padding, bool permissive_banding,
+                                                          uint64_t max_cells) const {
+    auto job = std::make_unique<Job>();
+    Job& j = *job;
+    j.alignment = &alignment; j.g = &g; j.banded = true; j.max_cells = max_cells;
+    if (alignment.sequence.empty()) return job;                      // DeletionAligner's case: nothing for the engine (:703-706)
     // BandedGlobalAligner's constructor takes the graph in lazier_topological_order and the raw node sequences (:1976, :255)
-    PackedGraph pg = create_packed_graph(g, handlealgs::lazier_topological_order(&g), /*raw_sequence=*/true);
-    vgk_banded_problem p{};
+    j.pg = create_packed_graph(g, handlealgs::lazier_topological_order(&g), /*raw_sequence=*/true);
+    vgk_banded_problem& p = j.bprob;
     p.read = alignment.sequence.c_str(); p.read_len = (uint32_t)alignment.sequence.size();
     p.qual = quality_of(qual_adjusted, alignment.quality, alignment.sequence.size());
     p.flags = permissive_banding ? VGK_BANDED_PERMISSIVE : 0u;
-    p.graph = pg.view(); p.band_padding = band_padding;
+    p.graph = j.pg.view(); p.band_padding = band_padding;
     p.max_cells = max_cells == std::numeric_limits<uint64_t>::max() ? 0 : max_cells;
-    vgk_result res{};
-    std::vector<vgk_op> ops(alignment.sequence.size() + pg.seq.size() + 2 * pg.order.size() + 8);
-    size_t n_ops = 0;
-    int rc = engine->banded_align(ctx, &p, 1, &res, ops.data(), ops.size(), &n_ops);
+    j.has_problem = true;
+    return job;
+}
+
+void Aligner::finish_banded_job(Job& j, const vgk_result& res, const vgk_op* ops) const {
+    Alignment& alignment = *j.alignment;
+    if (!j.has_problem) { DeletionAligner(scorer->gap_open, scorer->gap_extension).align(alignment, *j.g); return; }
     if (res.status == VGK_ENOBAND) throw NoAlignmentInBandException();
-    if (res.status == VGK_ETOOBIG) throw BandMatricesTooBigException("error:[BandedGlobalAligner] band matrices exceed the limit of " + std::to_string(max_cells) + " cells");
-    if (rc != VGK_OK || res.status != VGK_OK) throw std::runtime_error(std::string("vgamd: banded global alignment failed: ") + engine->strerror(rc ? rc : res.status));
-    banded_ops_to_alignment(pg.order, g, res, ops.data() + res.ops_begin, alignment);
+    if (res.status == VGK_ETOOBIG) throw BandMatricesTooBigException("error:[BandedGlobalAligner] band matrices exceed the limit of " + std::to_string(j.max_cells) + " cells");
+    if (res.status != VGK_OK) throw std::runtime_error(std::string("vgamd: banded global alignment failed: ") + engine->strerror(res.status));
+    banded_ops_to_alignment(j.pg.order, *j.g, res, ops, alignment);
+}
+
+void Aligner::align_global_banded(Alignment& alignment, const HandleGraph& g, int32_t band_padding, bool permissive_banding,
+                                  uint64_t max_cells) const {
+    auto job = prepare_banded_job(alignment, g, band_padding, permissive_banding, max_cells);
+    vgk_result res{};
+    std::vector<vgk_op> ops;
+    if (job->has_problem) {
+        ops.resize(alignment.sequence.size() + job->pg.seq.size() + 2 * job->pg.order.size() + 8);
+        size_t n_ops = 0;
+        int rc = engine->banded_align(ctx, &job->bprob, 1, &res, ops.data(), ops.size(), &n_ops);
+        if (rc != VGK_OK && res.status == VGK_OK) throw std::runtime_error(std::string("vgamd: banded global alignment failed: ") + engine->strerror(rc));
+    }
+    finish_banded_job(*job, res, ops.data() + res.ops_begin);
 }
 
 void Aligner::align_global_banded_multi(Alignment& alignment, std::vector<Alignment>& alt_alignments, const HandleGraph& g, int32_t max_alt_alns,

@@ -169,6 +169,13 @@ public:
                      const std::vector<MaximalExactMatch>& mems, bool reverse_complemented,
                      uint16_t max_gap_length = default_xdrop_max_gap_length) const;
 
+    // the two halves of an alignment call, for AlignmentBatch
+    struct Job;
+    std::unique_ptr<Job> prepare_job(Alignment& alignment, const HandleGraph& g, bool pinned, bool pin_left, bool traceback_aln) const;
+    void finish_job(Job& job, vgk_result res, std::vector<vgk_op> ops, std::vector<Alignment>* multi_alignments, int32_t max_alt_alns) const;
+    std::unique_ptr<Job> prepare_banded_job(Alignment& alignment, const HandleGraph& g, int32_t band_padding, bool permissive_banding, uint64_t max_cells) const;
+    void finish_banded_job(Job& job, const vgk_result& res, const vgk_op* ops) const;
+
 private:
     // one pinned X-drop extension from an interior graph position (node index in `order`, offset in that node)
     // towards the right (right_to_left = false) or the left; dozeu's extend over do_poa (src/dozeu_interface.cpp:210-307)
@@ -203,6 +210,25 @@ public:
                    int device = 0);
 private:
     QualAdjAligner(QualAdjAlignmentScorer* owned, std::shared_ptr<EngineApi> engine, int device);
+};
+
+// Deferred submission: giraffe / map call the aligner once per read from many threads, the engine wants thousands of
+// problems per launch.  An AlignmentBatch takes the same calls, keeps the prepared problems, and flush() runs them in one engine call
+// per kernel family and fills every Alignment exactly as the direct call would have.  The Alignment objects and the graphs must
+// stay alive until flush().  Not thread-safe: one batch per submitting thread, or an external lock.
+class AlignmentBatch {
+public:
+    explicit AlignmentBatch(const Aligner& aligner);
+    ~AlignmentBatch();
+    void align(Alignment& alignment, const HandleGraph& g, bool traceback_aln);
+    void align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left);
+    void align_global_banded(Alignment& alignment, const HandleGraph& g, int32_t band_padding = 0, bool permissive_banding = true,
+                             uint64_t max_cells = std::numeric_limits<uint64_t>::max());
+    size_t size() const;
+    void flush();
+private:
+    const Aligner& aligner;
+    std::vector<std::unique_ptr<Aligner::Job>> jobs;
 };
 
 // nonATGCNtoN (reference: src/utility.cpp:323-332)

@@ -2,6 +2,7 @@
 // languages (the pytest suite via ctypes, or a future binding) can drive the
 // mirrored Aligner interface exactly like src/unittest/*.cpp drives vg's.
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <string>
 #include "aligner.hpp"
@@ -118,6 +119,40 @@ int vgh_align_xdrop(vgh_aligner* a, vgh_graph* g, const char* read, const int64_
         a->a->align_xdrop(aln, g->g, ms, reverse_complemented != 0, (uint16_t)max_gap);
         return emit(aln, json_out, json_cap);
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// ---- AlignmentBatch: the same calls, deferred; one engine launch per kernel family at flush ------------------------------------------
+struct vgh_batch { std::unique_ptr<AlignmentBatch> b; std::deque<Alignment> alns; };
+vgh_batch* vgh_batch_create(vgh_aligner* a) { auto* h = new vgh_batch(); h->b = std::make_unique<AlignmentBatch>(*a->a); return h; }
+void vgh_batch_destroy(vgh_batch* b) { delete b; }
+// call codes as in vgh_align: 0 align(traceback), 1 align(score only), 2 align_pinned, 5 align_global_banded(band_padding = arg, permissive = pin_left)
+int vgh_batch_add(vgh_batch* b, vgh_graph* g, const char* read, const uint8_t* qual, int call, int pin_left, int arg) {
+    try {
+        b->alns.emplace_back();
+        Alignment& aln = b->alns.back(); aln.sequence = read;
+        if (qual) aln.quality.assign(reinterpret_cast<const char*>(qual), aln.sequence.size());
+        switch (call) {
+            case 0: b->b->align(aln, g->g, true); break;
+            case 1: b->b->align(aln, g->g, false); break;
+            case 2: b->b->align_pinned(aln, g->g, pin_left != 0); break;
+            case 5: b->b->align_global_banded(aln, g->g, arg, pin_left != 0); break;
+            default: b->alns.pop_back(); g_last_error = "unknown call"; return -1;
+        }
+        return 0;
+    } catch (std::exception& e) { b->alns.pop_back(); g_last_error = e.what(); return -1; }
+}
+// runs everything added so far; JSON out = [alignment, ...] in submission order
+int vgh_batch_flush(vgh_batch* b, char* json_out, size_t json_cap) {
+    try {
+        b->b->flush();
+        std::string js = "[";
+        for (size_t i = 0; i < b->alns.size(); ++i) { if (i) js += ','; js += alignment_to_json(b->alns[i]); }
+        js += "]";
+        b->alns.clear();
+        if (js.size() + 1 > json_cap) { g_last_error = "json buffer too small"; return -2; }
+        std::memcpy(json_out, js.c_str(), js.size() + 1);
+        return 0;
+    } catch (std::exception& e) { b->alns.clear(); g_last_error = e.what(); return -1; }
 }
 
 // ---- GaplessExtender (src/gbwt_extender.hpp:140-217) over a HaplotypeGraph built from `g` and explicit threads ----------
