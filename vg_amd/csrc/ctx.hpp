@@ -33,6 +33,7 @@ struct vgk_ctx {
         return b.p;
     }
     std::shared_ptr<void> banded_host;      // host staging arenas of banded_api.cpp
+    std::shared_ptr<void> gapless_host;     // and of gapless_api.cpp
     ~vgk_ctx() { if (be) for (DevBuf& b : scratch) if (b.p) be->release(b.p); }
 };
 

@@ -25,6 +25,14 @@ struct vgk_haplo {
 
 namespace {
 
+// host staging kept on the context between calls: uninitialised storage, so a warm call neither zero-fills nor page-faults
+template <class T> struct RawBuf {
+    T* p = nullptr; size_t cap = 0;
+    T* get(size_t n) { if (n > cap) { std::free(p); cap = n + n / 4 + 64; p = (T*)std::malloc(cap * sizeof(T)); } return p; }
+    ~RawBuf() { std::free(p); }
+};
+struct GaplessHost { RawBuf<char> reads; RawBuf<vgk_seed> seeds; RawBuf<vgk_gapless_result> dres; RawBuf<vgk_extension> dext; RawBuf<uint32_t> dnodes, dmism; };
+
 char complement(char c) {
     switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
                  case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a'; default: return c; }
@@ -160,12 +168,15 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
         n_read += p.read_len; n_seed += p.n_seeds;
         if (n_read > 0xfffffff0ull || n_seed > 0xfffffff0ull) return VGK_ETOOBIG;
     }
-    std::vector<char> reads(n_read + 16, 0); std::vector<vgk_seed> seeds(n_seed + 1);     // 8 bytes of padding at either end
+    if (!ctx->gapless_host) ctx->gapless_host = std::make_shared<GaplessHost>();
+    GaplessHost& H = *static_cast<GaplessHost*>(ctx->gapless_host.get());
+    char* reads = H.reads.get(n_read + 16); vgk_seed* seeds = H.seeds.get(n_seed + 1);     // 8 bytes of padding at either end
+    std::memset(reads, 0, 8); std::memset(reads + 8 + n_read, 0, 8);
     parallel_for(n, [&](uint32_t i, unsigned) {
         const vgk_gapless_problem& p = problems[i];
-        char* r = reads.data() + probs[i].read_off;
+        char* r = reads + probs[i].read_off;
         for (uint32_t k = 0; k < p.read_len; ++k) { const char c = p.read[k]; r[k] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'X'; }
-        if (p.n_seeds) std::memcpy(seeds.data() + probs[i].seed_off, p.seeds, sizeof(vgk_seed) * p.n_seeds);
+        if (p.n_seeds) std::memcpy(seeds + probs[i].seed_off, p.seeds, sizeof(vgk_seed) * p.n_seeds);
     });
     // device buffers are kept on the context between calls (grow-only)
     int next_slot = 16;
@@ -178,8 +189,8 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     GaplessParams P{};
     P.index = index->dev; P.n = n;
     P.probs = (const GProb*)dev(probs.data(), sizeof(GProb) * n);
-    P.reads = (const char*)dev(reads.data(), reads.size());
-    P.seeds = (const vgk_seed*)dev(seeds.data(), sizeof(vgk_seed) * seeds.size());
+    P.reads = (const char*)dev(reads, n_read + 16);
+    P.seeds = (const vgk_seed*)dev(seeds, sizeof(vgk_seed) * (n_seed + 1));
     P.match = ctx->sc.matrix[0]; P.mismatch = -ctx->sc.matrix[1]; P.bonus = ctx->sc.full_length_bonus;
     // dense outputs: at most one extension per seed; nodes / mismatches sized generously and checked on the device
     const uint64_t cap_e = n_seed + 1, cap_n = std::min<uint64_t>(n_seed * G_PATH, std::max<uint64_t>(n_seed * 16 + 1024, nodes_cap)) + 1,
@@ -203,14 +214,14 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     if ((rc = be->run_gapless(P, threads))) return cleanup(rc);
     ctx->gapless_last = P; ctx->gapless_last_threads = threads; ctx->gapless_last_valid = true;
     unsigned long long counters[3] = {0, 0, 0};
-    std::vector<vgk_gapless_result> dres(n);
+    vgk_gapless_result* dres = H.dres.get(n);
     if ((rc = be->download(counters, P.counters, sizeof counters))) return cleanup(rc);
-    if ((rc = be->download(dres.data(), P.results, sizeof(vgk_gapless_result) * n))) return cleanup(rc);
+    if ((rc = be->download(dres, P.results, sizeof(vgk_gapless_result) * n))) return cleanup(rc);
     const uint64_t ne = std::min<uint64_t>(counters[0], cap_e), nn = std::min<uint64_t>(counters[1], cap_n), nm = std::min<uint64_t>(counters[2], cap_m);
-    std::vector<vgk_extension> dext(ne + 1); std::vector<uint32_t> dnodes(nn + 1), dmism(nm + 1);
-    if (ne && (rc = be->download(dext.data(), P.ext, sizeof(vgk_extension) * ne))) return cleanup(rc);
-    if (nn && (rc = be->download(dnodes.data(), P.nodes, sizeof(uint32_t) * nn))) return cleanup(rc);
-    if (nm && (rc = be->download(dmism.data(), P.mism, sizeof(uint32_t) * nm))) return cleanup(rc);
+    vgk_extension* dext = H.dext.get(ne + 1); uint32_t* dnodes = H.dnodes.get(nn + 1); uint32_t* dmism = H.dmism.get(nm + 1);
+    if (ne && (rc = be->download(dext, P.ext, sizeof(vgk_extension) * ne))) return cleanup(rc);
+    if (nn && (rc = be->download(dnodes, P.nodes, sizeof(uint32_t) * nn))) return cleanup(rc);
+    if (nm && (rc = be->download(dmism, P.mism, sizeof(uint32_t) * nm))) return cleanup(rc);
     ctx->gapless_ms = be->last_ms(5);
     // the device packs sets in completion order; hand them back in problem order: sizes, a prefix sum, then parallel copies
     std::vector<uint64_t> oe(n + 1, 0), on(n + 1, 0), om(n + 1, 0);
@@ -237,8 +248,8 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
             uint64_t wn = on[i], wm = om[i];
             for (uint32_t k = 0; k < r.n_ext; ++k) {
                 vgk_extension x = dext[src + k];
-                std::memcpy(nodes + wn, dnodes.data() + x.path_begin, sizeof(uint32_t) * x.path_len);
-                std::memcpy(mismatches + wm, dmism.data() + x.mism_begin, sizeof(uint32_t) * x.n_mismatches);
+                std::memcpy(nodes + wn, dnodes + x.path_begin, sizeof(uint32_t) * x.path_len);
+                std::memcpy(mismatches + wm, dmism + x.mism_begin, sizeof(uint32_t) * x.n_mismatches);
                 x.path_begin = (uint32_t)wn; x.mism_begin = (uint32_t)wm;
                 extensions[oe[i] + k] = x; wn += x.path_len; wm += x.n_mismatches;
             }
