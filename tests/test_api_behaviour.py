@@ -111,7 +111,7 @@ def test_gapless_limits_and_bad_input_are_reported_per_problem(emu_lib):
     eng = capi.Engine(lib=emu_lib)
     index = eng.haplo_index(["ACGTACGTAC", "GGGTTTAAAC"], [[0, 2]])
     ok = dict(read="ACGTACGTACGGG", seeds=[(0, 0)])
-    too_many = dict(read="ACGTACGTAC", seeds=[(0, -k) for k in range(10)] + [(2, -k) for k in range(10)] + [(1, -k) for k in range(10)] + [(3, -k) for k in range(4)])
+    too_many = dict(read="ACGTACGTAC", seeds=[(o, -k) for o in range(4) for k in range(10)] + [(o, k) for o in range(4) for k in range(1, 8)])      # 68 seeds: beyond the 64 the kernel takes
     out_of_range = dict(read="ACGT", seeds=[(99, 0)])
     no_seeds = dict(read="ACGT", seeds=[])
     res, ext, nodes, mism = eng.gapless_extend(index, [ok, too_many, out_of_range, no_seeds, ok])

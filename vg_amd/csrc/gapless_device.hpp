@@ -63,7 +63,7 @@ VGK_HD GState gs_extend(const GIndex& h, const GState& s, int32_t to) {
 
 // ---- per-thread scratch ----
 constexpr int G_POOL = 160;          // partial extensions alive per seed (tree nodes + queue)
-constexpr int G_SEEDS = 32;          // seeds per cluster the engine takes
+constexpr int G_SEEDS = 64;          // seeds per cluster the engine takes
 constexpr int G_PATH = 48;           // nodes per extension
 constexpr int G_MISM = 48;           // mismatches per extension
 
