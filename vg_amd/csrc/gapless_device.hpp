@@ -83,8 +83,7 @@ struct GExt {                        // a finished per-seed winner
     uint8_t  left_full, right_full, pad[2];
     uint32_t path_len, n_mism;
     int32_t  path[G_PATH];
-    uint32_t mism[G_MISM];
-};
+};                                    // mismatch positions are recomputed where they are needed: they would double the slab
 // what the pool stores of an entry: 40 bytes (reads and nodes up to 65 535 bases, up to 65 535 visits per node)
 struct GPacked {
     int16_t  parent; uint16_t number;
@@ -271,7 +270,8 @@ VGK_HD uint32_t gx_remove_duplicates(const GExt* v, uint8_t* order, uint32_t n) 
     }
     return tail;
 }
-VGK_HD void gx_find_mismatches(const GCtx& c, GExt& e, bool& overflow) {                            // (:368-387)
+// the mismatch positions of an extension into mm[] (at most G_MISM); sets e.n_mism
+VGK_HD void gx_find_mismatches(const GCtx& c, GExt& e, uint32_t* mm, bool& overflow) {             // (:368-387)
     e.n_mism = 0;
     if (!e.internal) return;
     const GIndex& h = c.P->index;
@@ -279,24 +279,24 @@ VGK_HD void gx_find_mismatches(const GCtx& c, GExt& e, bool& overflow) {        
     for (uint32_t i = 0; i < e.path_len; ++i) {
         const char* t = h.seq + g_rec(h, (uint32_t)(e.path[i]))[3]; const uint32_t tl = g_len(h, e.path[i]);
         while (node_offset < tl && read_offset < e.r1) {
-            if (t[node_offset] != c.seq[read_offset]) { if (e.n_mism >= G_MISM) { overflow = true; return; } e.mism[e.n_mism++] = read_offset; }
+            if (t[node_offset] != c.seq[read_offset]) { if (e.n_mism >= G_MISM) { overflow = true; return; } mm[e.n_mism++] = read_offset; }
             ++node_offset; ++read_offset;
         }
         node_offset = 0;
     }
 }
-VGK_HD bool gx_trim(const GCtx& c, GExt& e) {                                                       // (:421-529)
+VGK_HD bool gx_trim(const GCtx& c, GExt& e, uint32_t* mm) {                                         // (:421-529)
     if (!e.n_mism) return false;
     const GIndex& h = c.P->index; const int32_t match = c.P->match, mismatch = c.P->mismatch, bonus = c.P->bonus;
-    uint32_t mi = 0, c0 = e.r0, c1 = e.mism[0];
+    uint32_t mi = 0, c0 = e.r0, c1 = mm[0];
     int32_t cur = (int32_t)(c1 - c0) * match + (e.left_full ? bonus : 0);
     uint32_t b0 = c0, b1 = c1; int32_t best = cur;
     while (mi < e.n_mism) {
         if (cur >= mismatch) { ++c1; cur -= mismatch; }
-        else { c0 = c1 = e.mism[mi] + 1; cur = 0; }
+        else { c0 = c1 = mm[mi] + 1; cur = 0; }
         ++mi;
         if (mi == e.n_mism) { cur += (int32_t)(e.r1 - c1) * match; c1 = e.r1; if (e.right_full) cur += bonus; }
-        else { cur += (int32_t)(e.mism[mi] - c1) * match; c1 = e.mism[mi]; }
+        else { cur += (int32_t)(mm[mi] - c1) * match; c1 = mm[mi]; }
         if (cur > best || (cur > 0 && cur == best && c1 - c0 > b1 - b0)) { b0 = c0; b1 = c1; best = cur; }
     }
     if (b0 == e.r0 && b1 == e.r1) return false;
@@ -321,9 +321,9 @@ VGK_HD bool gx_trim(const GCtx& c, GExt& e) {                                   
         for (uint32_t k = 1; k < e.path_len; ++k) s = gs_extend(h, s, e.path[k]);
         e.state = s;
     }
-    uint32_t mh = 0; while (mh < e.n_mism && e.mism[mh] < e.r0) ++mh;
-    uint32_t mt = mh; while (mt < e.n_mism && e.mism[mt] < e.r1) ++mt;
-    for (uint32_t k = 0; k < mt - mh; ++k) e.mism[k] = e.mism[mh + k];
+    uint32_t mh = 0; while (mh < e.n_mism && mm[mh] < e.r0) ++mh;
+    uint32_t mt = mh; while (mt < e.n_mism && mm[mt] < e.r1) ++mt;
+    for (uint32_t k = 0; k < mt - mh; ++k) mm[k] = mm[mh + k];
     e.n_mism = mt - mh;
     return true;
 }
@@ -459,16 +459,18 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
             if (!ov) order[tail++] = order[i];
         }
         n_out = tail;
-        for (uint32_t i = 0; i < n_out; ++i) gx_find_mismatches(c, S.res[order[i]], overflow);
+        uint32_t mm[G_MISM];
+        for (uint32_t i = 0; i < n_out; ++i) gx_find_mismatches(c, S.res[order[i]], mm, overflow);      // counts, for the output sizes
         out.full_length = 1;
     } else {
         n_out = gx_remove_duplicates(S.res, order, n_res);
-        for (uint32_t i = 0; i < n_out; ++i) gx_find_mismatches(c, S.res[order[i]], overflow);
-        if (!overflow && (pb.flags & VGK_GAPLESS_TRIM)) {
-            bool trimmed = false;
-            for (uint32_t i = 0; i < n_out; ++i) trimmed |= gx_trim(c, S.res[order[i]]);
-            if (trimmed) n_out = gx_remove_duplicates(S.res, order, n_out);
+        uint32_t mm[G_MISM];
+        bool trimmed = false;
+        for (uint32_t i = 0; i < n_out && !overflow; ++i) {
+            gx_find_mismatches(c, S.res[order[i]], mm, overflow);
+            if (!overflow && (pb.flags & VGK_GAPLESS_TRIM)) trimmed |= gx_trim(c, S.res[order[i]], mm);
         }
+        if (trimmed) n_out = gx_remove_duplicates(S.res, order, n_out);
     }
     if (overflow) { out.status = VGK_ETOOBIG; return; }
     // hand the set out
@@ -488,7 +490,11 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
         x.state[3] = (uint32_t)e.state.bn; x.state[4] = (uint32_t)e.state.blo; x.state[5] = (uint32_t)e.state.bhi;
         P.ext[e0 + i] = x;
         for (uint32_t k = 0; k < e.path_len; ++k) P.nodes[n0 + na + k] = (uint32_t)e.path[k];
-        for (uint32_t k = 0; k < e.n_mism; ++k) P.mism[m0 + ma + k] = e.mism[k];
+        if (e.n_mism) {                           // written straight to the output
+            GExt& me = S.res[order[i]]; const uint32_t expect = me.n_mism; bool ov = false;
+            gx_find_mismatches(c, me, P.mism + m0 + ma, ov);
+            (void)expect;
+        }
         na += e.path_len; ma += e.n_mism;
     }
 }
