@@ -51,7 +51,7 @@ template <int R, bool QA> static void banded_fill_emu(const BandedParams& P, uin
 class EmuBackend final : public Backend {
 public:
     int run_gapless(const GaplessParams& P, uint32_t threads) override {
-        for (uint32_t t = 0; t < threads; ++t) for (uint32_t i = t; i < P.n; i += threads) gapless_extend_one(P, i, P.scratch[t]);
+        for (uint32_t t = 0; t < threads; ++t) for (uint32_t i = t; i < P.n; i += threads) gapless_extend_one(P, i, P.scratch[t], P.cold[t]);
         return VGK_OK;
     }
     int run_banded(const BandedParams& P, const BandedLaunch* launches, uint32_t n) override {

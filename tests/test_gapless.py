@@ -214,10 +214,33 @@ def compare_engines(lib, seeds, n_reads=40):
     return total, full
 
 
+def many_partial_extensions_case():
+    """One read whose 14 seeds each give a distinct partial extension (more winners than the kernel's hot scratch slab holds)."""
+    rng = np.random.default_rng(77)
+    nodes = ["".join("ACGT"[i] for i in rng.integers(0, 4, 9)) for _ in range(30)]
+    threads = [[2 * i for i in range(30)]]
+    chunks, seeds, pos = [], [], 0
+    for k in range(14):
+        chunks.append(nodes[2 * k][1:8]); seeds.append((2 * (2 * k), pos - 1)); pos += 7          # bases 1..7 of every other node
+        chunks.append("x"); pos += 1
+    return nodes, threads, [dict(read="".join(chunks), seeds=seeds, max_mismatches=0)]
+
+
+def check_many_partial_extensions(lib):
+    nodes, threads, problems = many_partial_extensions_case()
+    ora = capi.Engine(lib=util.ORACLE_LIB); eng = capi.Engine(lib=lib) if lib else capi.Engine()
+    a = ora.gapless_extend(ora.haplo_index(nodes, threads), problems)
+    b = eng.gapless_extend(eng.haplo_index(nodes, threads), problems)
+    assert a[0]["n_ext"][0] == 14 and not a[0]["full_length"][0]
+    for x, y in zip(a, b):
+        assert len(x) == len(y) and (x == y).all()
+
+
 def test_emulated_gapless_kernel_matches_reference_unit_tests_and_oracle():
     import subprocess
     subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
     reference_gapless_cases(capi.Engine(lib=util.EMU_LIB))
+    check_many_partial_extensions(util.EMU_LIB)
     total, full = compare_engines(util.EMU_LIB, range(100, 140))
     assert total > 1500 and full > 300
 
@@ -225,6 +248,7 @@ def test_emulated_gapless_kernel_matches_reference_unit_tests_and_oracle():
 @pytest.mark.gpu
 def test_hip_gapless_matches_reference_unit_tests_and_oracle():
     reference_gapless_cases(capi.Engine())
+    check_many_partial_extensions(None)
     total, full = compare_engines(None, range(200, 260), n_reads=400)
     assert total > 20000 and full > 4000
 

@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(64) banded_walk_kernel(const BandedParams P) {
 __global__ void __launch_bounds__(64, 4) gapless_kernel(const GaplessParams P, const uint32_t threads) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t >= threads) return;
-    for (uint32_t i = t; i < P.n; i += threads) gapless_extend_one(P, i, P.scratch[t]);
+    for (uint32_t i = t; i < P.n; i += threads) gapless_extend_one(P, i, P.scratch[t], P.cold[t]);
 }
 
 class HipBackend final : public Backend {

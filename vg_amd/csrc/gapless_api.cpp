@@ -202,13 +202,14 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     const uint32_t threads = (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max(1, be->compute_units()) * per_cu);
     { vgk_ctx::DevBuf& b = ctx->scratch[15];
       const uint64_t want = sizeof(GScratch) * (uint64_t)threads;
-      (void)b; P.scratch = (GScratch*)ctx->ensure_scratch(15, want); }
+      (void)b; P.scratch = (GScratch*)ctx->ensure_scratch(15, want);
+      P.cold = (GCold*)ctx->ensure_scratch(30, sizeof(GCold) * (uint64_t)threads); }
     P.results = (vgk_gapless_result*)dev(nullptr, sizeof(vgk_gapless_result) * n);
     P.ext = (vgk_extension*)dev(nullptr, sizeof(vgk_extension) * cap_e);
     P.nodes = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_n);
     P.mism = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_m);
     P.counters = (unsigned long long*)dev(nullptr, 64);
-    if (!P.probs || !P.reads || !P.seeds || !P.scratch || !P.results || !P.ext || !P.nodes || !P.mism || !P.counters) return cleanup(VGK_ENOMEM);
+    if (!P.probs || !P.reads || !P.seeds || !P.scratch || !P.cold || !P.results || !P.ext || !P.nodes || !P.mism || !P.counters) return cleanup(VGK_ENOMEM);
     int rc;
     if ((rc = be->zero(P.counters, 64))) return cleanup(rc);
     if ((rc = be->run_gapless(P, threads))) return cleanup(rc);

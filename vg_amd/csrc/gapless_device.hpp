@@ -117,7 +117,16 @@ VGK_HD GEntry g_unpack(const GPacked& p) {
     e.state.flo = fe ? 0 : p.flo; e.state.fhi = fe ? -1 : (int32_t)p.fhi; e.state.blo = be ? 0 : p.blo; e.state.bhi = be ? -1 : (int32_t)p.bhi;
     return e;
 }
-struct GScratch { uint64_t heap[G_POOL]; GPacked pool[G_POOL]; GExt res[G_SEEDS]; };
+// Per-thread scratch in two slabs: the hot one (queue keys, the pool of the seed being extended, the first few per-seed winners) stays
+// small, because the kernel's speed follows the address spread of what the resident threads touch (measured: 47 M reads/s with a
+// 15.9 KB slab, 38 M with 23.8 KB); winners beyond G_HOT — rare: most clusters resolve into one or two extensions — go to a cold slab.
+constexpr int G_HOT = 8;
+struct GScratch { uint64_t heap[G_POOL]; GPacked pool[G_POOL]; GExt res[G_HOT]; };
+struct GCold { GExt res[G_SEEDS - G_HOT]; };
+struct GRes {                          // the G_SEEDS winners of a read as one array
+    GExt* hot; GExt* cold;
+    VGK_HD GExt& operator[](uint32_t i) const { return i < (uint32_t)G_HOT ? hot[i] : cold[i - G_HOT]; }
+};
 
 struct GaplessParams {
     GIndex index;
@@ -126,6 +135,7 @@ struct GaplessParams {
     const vgk_seed* seeds;
     int32_t match, mismatch, bonus;
     GScratch* scratch;                // one per resident thread
+    GCold*    cold;                   // likewise
     vgk_gapless_result* results;      // per problem (ext_begin indexes `ext`)
     vgk_extension* ext; uint32_t* nodes; uint32_t* mism;
     unsigned long long* counters;     // [0] extensions, [1] nodes, [2] mismatches handed out
@@ -257,10 +267,10 @@ VGK_HD bool gx_full_less(const GExt& a, const GExt& b) {                        
     return gx_full(a) && !gx_full(b);
 }
 // stable insertion sort of an index permutation (the sets are small; moving 500-byte records would not pay)
-template <class Less> VGK_HD void gx_sort(const GExt* v, uint8_t* order, uint32_t n, Less less) {
+template <class Less> VGK_HD void gx_sort(const GRes& v, uint8_t* order, uint32_t n, Less less) {
     for (uint32_t i = 1; i < n; ++i) { const uint8_t x = order[i]; uint32_t j = i; while (j && less(v[x], v[order[j - 1]])) { order[j] = order[j - 1]; --j; } order[j] = x; }
 }
-VGK_HD uint32_t gx_remove_duplicates(const GExt* v, uint8_t* order, uint32_t n) {                  // (:332-365)
+VGK_HD uint32_t gx_remove_duplicates(const GRes& v, uint8_t* order, uint32_t n) {                  // (:332-365)
     gx_sort(v, order, n, [](const GExt& a, const GExt& b) { return gx_dup_less(a, b); });
     uint32_t tail = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -329,7 +339,8 @@ VGK_HD bool gx_trim(const GCtx& c, GExt& e, uint32_t* mm) {                     
 }
 
 // one read: every seed's best extension, then the set rules
-VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S) {
+VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S, GCold& C) {
+    const GRes RES{S.res, C.res};
     const GProb pb = P.probs[pi];
     const GIndex& h = P.index;
     vgk_gapless_result& out = P.results[pi];
@@ -344,7 +355,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
         const vgk_seed sd = P.seeds[pb.seed_off + si];
         const int32_t snode = (int32_t)sd.node; const int64_t diff = sd.diff;
         if ((uint32_t)snode >= h.n_oriented) { status = VGK_EINVAL; break; }
-        if (best_alignment < n_res && S.res[best_alignment].internal == 0 && gx_contains(h, S.res[best_alignment], snode, diff)) continue;
+        if (best_alignment < n_res && RES[best_alignment].internal == 0 && gx_contains(h, RES[best_alignment], snode, diff)) continue;
         const uint32_t read_offset = diff < 0 ? 0u : (uint32_t)diff, node_offset = diff < 0 ? (uint32_t)(-diff) : 0u;
         if (read_offset > L || node_offset > g_len(h, snode)) { status = VGK_EINVAL; break; }
         uint32_t np = 0, hn = 0, number = 0;
@@ -430,12 +441,12 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
         if (status != VGK_OK) break;
         if (best >= 0 && best_e.r1 > best_e.r0) {
             const GEntry& b = best_e;
-            GExt& r = S.res[n_res];
+            GExt& r = RES[n_res];
             const int plen = g_path(S, best, r.path);
             if (plen < 0) { status = VGK_ETOOBIG; break; }
             r.path_len = (uint32_t)plen; r.offset = b.offset; r.r0 = b.r0; r.r1 = b.r1; r.internal = b.internal; r.score = b.score; r.state = b.state;
             r.left_full = b.left_full; r.right_full = b.right_full; r.n_mism = 0;
-            if (gx_full(r) && (best_alignment >= n_res || r.internal < S.res[best_alignment].internal)) best_alignment = n_res;
+            if (gx_full(r) && (best_alignment >= n_res || r.internal < RES[best_alignment].internal)) best_alignment = n_res;
             ++n_res;
         }
     }
@@ -444,44 +455,44 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
     for (uint32_t i = 0; i < n_res; ++i) order[i] = (uint8_t)i;
     bool overflow = false;
     uint32_t n_out = n_res;
-    if (best_alignment < n_res && S.res[best_alignment].internal <= max_mm) {
+    if (best_alignment < n_res && RES[best_alignment].internal <= max_mm) {
         // the non-overlapping full-length extensions, fewest mismatches first (:301-329)
-        gx_sort(S.res, order, n_res, [](const GExt& a, const GExt& b) { return gx_full_less(a, b); });
+        gx_sort(RES, order, n_res, [](const GExt& a, const GExt& b) { return gx_full_less(a, b); });
         uint32_t tail = 0;
         for (uint32_t i = 0; i < n_res; ++i) {
-            const GExt& e = S.res[order[i]];
+            const GExt& e = RES[order[i]];
             if (!gx_full(e)) break;
             bool ov = false;
             for (uint32_t prev = 0; prev < tail && !ov; ++prev) {
-                const GExt& q = S.res[order[prev]];
+                const GExt& q = RES[order[prev]];
                 ov = (double)gx_overlap(h, e, q) > pb.overlap * (double)(q.r1 - q.r0);
             }
             if (!ov) order[tail++] = order[i];
         }
         n_out = tail;
         uint32_t mm[G_MISM];
-        for (uint32_t i = 0; i < n_out; ++i) gx_find_mismatches(c, S.res[order[i]], mm, overflow);      // counts, for the output sizes
+        for (uint32_t i = 0; i < n_out; ++i) gx_find_mismatches(c, RES[order[i]], mm, overflow);      // counts, for the output sizes
         out.full_length = 1;
     } else {
-        n_out = gx_remove_duplicates(S.res, order, n_res);
+        n_out = gx_remove_duplicates(RES, order, n_res);
         uint32_t mm[G_MISM];
         bool trimmed = false;
         for (uint32_t i = 0; i < n_out && !overflow; ++i) {
-            gx_find_mismatches(c, S.res[order[i]], mm, overflow);
-            if (!overflow && (pb.flags & VGK_GAPLESS_TRIM)) trimmed |= gx_trim(c, S.res[order[i]], mm);
+            gx_find_mismatches(c, RES[order[i]], mm, overflow);
+            if (!overflow && (pb.flags & VGK_GAPLESS_TRIM)) trimmed |= gx_trim(c, RES[order[i]], mm);
         }
-        if (trimmed) n_out = gx_remove_duplicates(S.res, order, n_out);
+        if (trimmed) n_out = gx_remove_duplicates(RES, order, n_out);
     }
     if (overflow) { out.status = VGK_ETOOBIG; return; }
     // hand the set out
     uint32_t nn = 0, nm = 0;
-    for (uint32_t i = 0; i < n_out; ++i) { nn += S.res[order[i]].path_len; nm += S.res[order[i]].n_mism; }
+    for (uint32_t i = 0; i < n_out; ++i) { nn += RES[order[i]].path_len; nm += RES[order[i]].n_mism; }
     const unsigned long long e0 = g_bump(P.counters + 0, n_out), n0 = g_bump(P.counters + 1, nn), m0 = g_bump(P.counters + 2, nm);
     if (e0 + n_out > P.caps[0] || n0 + nn > P.caps[1] || m0 + nm > P.caps[2]) { out.status = VGK_EOPS; return; }
     out.ext_begin = (uint32_t)e0; out.n_ext = n_out;
     uint32_t na = 0, ma = 0;
     for (uint32_t i = 0; i < n_out; ++i) {
-        const GExt& e = S.res[order[i]];
+        const GExt& e = RES[order[i]];
         vgk_extension x;
         x.path_begin = (uint32_t)(n0 + na); x.path_len = e.path_len; x.offset = e.offset; x.read_begin = e.r0; x.read_end = e.r1;
         x.mism_begin = (uint32_t)(m0 + ma); x.n_mismatches = e.n_mism; x.score = e.score; x.left_full = e.left_full; x.right_full = e.right_full;
@@ -491,7 +502,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S)
         P.ext[e0 + i] = x;
         for (uint32_t k = 0; k < e.path_len; ++k) P.nodes[n0 + na + k] = (uint32_t)e.path[k];
         if (e.n_mism) {                           // written straight to the output
-            GExt& me = S.res[order[i]]; const uint32_t expect = me.n_mism; bool ov = false;
+            GExt& me = RES[order[i]]; const uint32_t expect = me.n_mism; bool ov = false;
             gx_find_mismatches(c, me, P.mism + m0 + ma, ov);
             (void)expect;
         }
