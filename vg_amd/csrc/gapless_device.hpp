@@ -121,7 +121,7 @@ VGK_HD GEntry g_unpack(const GPacked& p) {
 // small, because the kernel's speed follows the address spread of what the resident threads touch (measured: 47 M reads/s with a
 // 15.9 KB slab, 38 M with 23.8 KB); winners beyond G_HOT — rare: most clusters resolve into one or two extensions — go to a cold slab.
 constexpr int G_HOT = 8;
-struct GScratch { uint64_t heap[G_POOL]; GPacked pool[G_POOL]; GExt res[G_HOT]; };
+struct GScratch { uint64_t heap[G_POOL]; GPacked pool[G_POOL]; GExt res[G_HOT]; uint8_t order[G_SEEDS]; };      // order[]: the permutation the set rules sort
 struct GCold { GExt res[G_SEEDS - G_HOT]; };
 struct GRes {                          // the G_SEEDS winners of a read as one array
     GExt* hot; GExt* cold;
@@ -451,7 +451,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
         }
     }
     if (status != VGK_OK) { out.status = status; return; }
-    uint8_t order[G_SEEDS];
+    uint8_t* order = S.order;            // (a private array of this size makes the compiler spill hundreds of registers)
     for (uint32_t i = 0; i < n_res; ++i) order[i] = (uint8_t)i;
     bool overflow = false;
     uint32_t n_out = n_res;
