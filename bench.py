@@ -90,6 +90,80 @@ def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
         dist.destroy_process_group()
 
 
+def bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus):
+    """The long-read chaining stage's WFA problems (configs[5], secondary line).  One vgk_wfa_extend call packs the batch, moves it to
+    HBM, runs the kernel and fetches the alignments (timed separately as end_to_end_from_host_buffers); the timed region then
+    re-launches the kernel K times on the inputs that stayed resident in HBM (vgk_wfa_rerun), which is what `value` reports."""
+    import numpy as np
+    from vg_amd import capi, workloads
+    n = min(args.reads, 500_000)
+    wl = workloads.WfaWorkload(n, seed=321 + rank)
+    index = eng.haplo_index(wl.nodes, wl.threads)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.wfa_extend(index, wl.ws)                           # warms the cached buffers
+    te = time.perf_counter(); out = eng.wfa_extend(index, wl.ws); te = time.perf_counter() - te
+    for _ in range(args.warmup):
+        eng.wfa_rerun()
+    barrier()
+    kms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.wfa_rerun()                                    # synchronous: the kernel on the resident batch
+        kms.append(eng.wfa_last_ms())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res, paths, edits = out
+    cpu = parity = None
+    if rank == 0 and world == 1 and not args.no_cpu:      # the CPU leg (checker + baseline) runs at N = 1 only
+        ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
+        oidx = ora.haplo_index(wl.nodes, wl.threads)
+        tc = time.perf_counter(); o = ora.wfa_extend(oidx, wl.ws); tc = time.perf_counter() - tc
+        cpu = {"value": n / tc, "unit": "alignments/s", "cores": os.cpu_count() or 1, "kind": "port",
+               "sample": "the same %d problems, oracle/vgo_wfa.c (scalar WFA over the haplotype trie, hash-table wavefronts), OpenMP over problems" % n}
+        good = res["status"] == 0
+        fields = ("ok", "score", "node_offset", "seq_offset", "length", "path_len", "n_edits")
+        same = np.ones(n, dtype=bool)
+        for f in fields:
+            same &= o[0][f] == res[f]
+        # paths / edits element-wise, problem by problem (offsets differ once a problem hit a kernel table limit)
+        for i in np.nonzero(good & same)[0][:: max(1, n // 20000)]:
+            a, b = o[0][i], res[i]
+            same[i] = bool((o[1][a["path_begin"]:a["path_begin"] + a["path_len"]] == paths[b["path_begin"]:b["path_begin"] + b["path_len"]]).all()
+                           and (o[2][a["edit_begin"]:a["edit_begin"] + a["n_edits"]] == edits[b["edit_begin"]:b["edit_begin"] + b["n_edits"]]).all())
+        parity = {"checked": int(good.sum()), "identical": int((same & good).sum()), "kernel_table_limit": int((~good).sum())}
+    if rank == 0:
+        k = sum(kms) / len(kms)
+        alg_bytes = float(wl.bases + wl.graph_bases + 32 * n + 40 * n + 4 * len(paths) + 4 * len(edits))
+        achieved = alg_bytes / (k * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "WFA alignments/sec (connect <= 250 bp, tails <= 100 bp)", "value": n * world * args.steps / elapsed,
+            "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "1 Mbp variation graph, 8 random haplotype threads, %d WFA problems per GPU: 80 %% connect between anchors "
+                                   "50..250 bp apart, 20 %% prefix/suffix tails <= 100 bp, 0.5 %% errors (half substitutions, half 1-bp indels); "
+                                   "WFAExtender semantics, default error model" % n,
+                       "timed_region": "K launches of wfa_kernel on the batch resident in HBM (vgk_wfa_rerun)",
+                       "end_to_end_from_host_buffers_alignments_per_s": n / te, "parallelism": "problem-sharded x%d" % world,
+                       "device": dev_name, "compute_units": cus, "sequence_bases": wl.bases},
+            "roofline": {"bound": "hbm", "kernel": "wfa_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
+                         "kernel_only_alignments_per_s": n / (k * 1e-3)},
+            "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum()),
+            "aligned_fraction": float(res["ok"].mean())}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
     """configs[4] stand-in (secondary line, not the headline metric).  One vgk_banded_align call does the host band geometry, moves the
     batch to HBM, runs fill + traceback and fetches the results (timed separately as end_to_end_from_host_buffers); the timed region
@@ -166,7 +240,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (configs[1]: 1M)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads for the CPU baseline leg (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless"], default="linear",
+    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa"], default="linear",
                     help="linear = BASELINE.json configs[1] (the headline metric); tails = configs[2] stand-in: "
                          "giraffe-style pinned X-drop tail alignments on a variation graph; banded = configs[4] stand-in: "
                          "banded global alignments between chained anchors; gapless = giraffe's first stage: "
@@ -196,6 +270,8 @@ def main():
 
     if args.workload == "banded":
         return bench_banded(args, eng, rank, world, dist, torch, dev_name, cus)
+    if args.workload == "wfa":
+        return bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "gapless":
         return bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus)
 

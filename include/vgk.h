@@ -217,8 +217,8 @@ int    vgk_banded_rerun(vgk_ctx* ctx);
  * extensions or the trimmed, de-duplicated partial ones.
  * The haplotype index stands in for the GBWTGraph the reference walks (gbwt / gbwtgraph are absent submodules): node
  * sequences plus the threads as lists of oriented nodes (2 * node index + is_reverse).  Node indices must follow the
- * order of the graph's node ids (the order of `follow_paths` is the order of the GBWT node encoding).  Threads must be
- * acyclic as oriented-node sequences. */
+ * order of the graph's node ids (the order of `follow_paths` is the order of the GBWT node encoding).  Threads may
+ * revisit nodes (cycles). */
 typedef struct vgk_haplotypes {
     uint32_t        n_nodes;
     const uint32_t* node_len;
@@ -265,6 +265,48 @@ int  vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_
                         size_t written[3] /* extensions, nodes, mismatches */);
 int    vgk_gapless_rerun(vgk_ctx* ctx);      /* launch the kernel of the last vgk_gapless_extend call again on its resident inputs */
 double vgk_gapless_last_ms(vgk_ctx* ctx);    /* kernel time of the last vgk_gapless_extend call on this context */
+
+/* ---- haplotype-consistent wavefront alignment (WFAExtender, src/gbwt_extender.cpp:2052-2263) ------------
+ * Replaces WFAExtender::connect(sequence, from, to), ::suffix(sequence, from) and ::prefix(sequence, to)
+ * (src/gbwt_extender.hpp:427-455): gap-affine WFA over the trie of haplotypes that leave `from` (WFATree :1567-2046),
+ * bounded by the error model's score cap (:1631-1634).  `from` and `to` are exclusive: the alignment starts one base
+ * after `from` and ends one base before `to`.  Positions are (oriented node = 2 * node index + is_reverse, offset on
+ * that strand).  suffix = connect without a target, keeping the best partial alignment when the cap is hit, plus the
+ * full-length bonus when the last edit is a match/mismatch and the whole sequence is aligned (:2240-2243); prefix = the
+ * same on the other strand, flipped back (:2248-2263).
+ * Per problem: status (VGK_OK also for "no alignment": ok = 0, like WFAAlignment::ok; VGK_ETOOBIG when the haplotype
+ * trie or the wavefronts outgrow the kernel's per-problem tables (`score` then names the table: 1 wavefront points,
+ * 2 trie nodes, 3 path pool, 4 edit runs, 5 node length); VGK_EOPS when `paths` / `edits` are full; VGK_ENOBAND when the
+ * winning candidate lies behind the distance band, where next() (:1761-1776) records it without storing its wavefront
+ * point and the reference's backtrace (:2156-2202) does not terminate).
+ * One of several equally good partial alignments is kept by WFATree::trim in hash-map order in the reference; here the
+ * one with the smallest (trie node, penalty, diagonal). */
+typedef struct vgk_wfa_event { double per_base; int32_t min, max; } vgk_wfa_event;   /* WFAExtender::ErrorModel::Event (gbwt_extender.hpp:361-374) */
+typedef struct vgk_wfa_error_model { vgk_wfa_event mismatches, gaps, gap_length, distance; } vgk_wfa_error_model;
+enum { VGK_WFA_CONNECT = 0, VGK_WFA_SUFFIX = 1, VGK_WFA_PREFIX = 2 };
+enum { VGK_WFA_MATCH = 0, VGK_WFA_MISMATCH = 1, VGK_WFA_INSERTION = 2, VGK_WFA_DELETION = 3 };   /* WFAAlignment::Edit (gbwt_extender.hpp:234) */
+#define VGK_WFA_NO_NODE 0xffffffffu
+typedef struct vgk_wfa_problem {
+    const char* seq;                 /* masked by the engine like ReadMasker (:160-170): non-ACGT never matches */
+    uint32_t    seq_len;
+    uint32_t    mode;                /* VGK_WFA_CONNECT / SUFFIX / PREFIX */
+    uint32_t    from_node, from_offset;   /* unused by PREFIX */
+    uint32_t    to_node, to_offset;       /* unused by SUFFIX */
+} vgk_wfa_problem;
+typedef struct vgk_wfa_result {      /* WFAAlignment (src/gbwt_extender.hpp:233-270) */
+    int32_t  status;
+    int32_t  ok;
+    int32_t  score;
+    uint32_t node_offset;            /* in the first node of the path */
+    uint32_t seq_offset, length;     /* aligned interval of the sequence */
+    uint32_t path_begin, path_len;   /* oriented nodes, in the `paths` output array */
+    uint32_t edit_begin, n_edits;    /* in the `edits` output array: length << 2 | VGK_WFA_* ; runs of one kind are merged */
+} vgk_wfa_result;
+int  vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_model* model /* NULL = WFAExtender::default_error_model */,
+                    const vgk_wfa_problem* problems, uint32_t n, vgk_wfa_result* results,
+                    uint32_t* paths, size_t path_cap, uint32_t* edits, size_t edit_cap, size_t written[2] /* paths, edits */);
+int    vgk_wfa_rerun(vgk_ctx* ctx);          /* launch the kernel of the last vgk_wfa_extend call again on its resident inputs */
+double vgk_wfa_last_ms(vgk_ctx* ctx);        /* kernel time of the last vgk_wfa_extend call on this context */
 
 /* batch introspection (used by bench.py for the roofline line) */
 void     vgk_batch_free(vgk_batch* batch);

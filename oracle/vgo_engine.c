@@ -27,6 +27,9 @@ int vgo_gapless_extend(const vgk_scoring* sc, const vgk_haplo* h, const vgk_gapl
                        vgk_extension* ext_out, uint32_t ext_cap, uint32_t* nodes_out, uint32_t nodes_cap,
                        uint32_t* mism_out, uint32_t mism_cap, uint32_t* n_nodes_out, uint32_t* n_mism_out);
 
+int vgo_wfa_one(const vgk_scoring* sc, const vgk_haplo* h, const vgk_wfa_error_model* model, const vgk_wfa_problem* p,
+                vgk_wfa_result* res, int32_t** path_out, uint32_t** edits_out);
+
 struct vgk_ctx { vgk_scoring sc; int has_qa; vgk_qual_adj qa; int8_t qmat[256 * 25]; int8_t qbon[256]; };
 
 static int vgo_dispatch(const vgk_ctx* c, const vgk_gssw_problem* p, vgk_result* res, vgk_op* ops, uint32_t ops_cap) {
@@ -230,6 +233,30 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     }
     free(se); free(sn); free(sm); free(wn); free(wm); free(te); free(tn); free(tm);
     if (written) { written[0] = ne; written[1] = nn; written[2] = nm; }
+    return rc;
+}
+
+double vgk_wfa_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }
+int vgk_wfa_rerun(vgk_ctx* ctx) { (void)ctx; return VGK_EINVAL; }
+int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_model* model, const vgk_wfa_problem* problems, uint32_t n,
+                   vgk_wfa_result* results, uint32_t* paths, size_t path_cap, uint32_t* edits, size_t edit_cap, size_t written[2]) {
+    if (!ctx || !index || (!problems && n) || (!results && n)) return VGK_EINVAL;
+    int32_t** tp = (int32_t**)calloc((size_t)n + 1, sizeof(int32_t*)); uint32_t** te = (uint32_t**)calloc((size_t)n + 1, sizeof(uint32_t*));
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (uint32_t i = 0; i < n; ++i) vgo_wfa_one(&ctx->sc, index, model, &problems[i], &results[i], &tp[i], &te[i]);
+    size_t np = 0, ne = 0; int rc = VGK_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        vgk_wfa_result* r = &results[i];
+        if (r->status == VGK_OK && (np + r->path_len > path_cap || ne + r->n_edits > edit_cap)) { r->status = VGK_EOPS; rc = VGK_EOPS; }
+        r->path_begin = (uint32_t)np; r->edit_begin = (uint32_t)ne;
+        if (r->status != VGK_OK) { r->ok = 0; r->path_len = r->n_edits = 0; }
+        for (uint32_t k = 0; k < r->path_len; ++k) paths[np + k] = (uint32_t)tp[i][k];
+        if (r->n_edits) memcpy(edits + ne, te[i], sizeof(uint32_t) * r->n_edits);
+        np += r->path_len; ne += r->n_edits;
+        free(tp[i]); free(te[i]);
+    }
+    free(tp); free(te);
+    if (written) { written[0] = np; written[1] = ne; }
     return rc;
 }
 

@@ -16,8 +16,8 @@
  * orientations; the visits of an oriented node are ordered by (predecessor node, rank within the predecessor's record),
  * threads that start at the node first, in thread order; extending a range [sp, ep] with successor w maps it to
  * offset(v -> w) + rank_w(body[0, sp)) ...; the opposite strand's range shrinks by the number of visits in the range
- * whose successor x has reverse(x) < reverse(w).  Records are built directly in that order (no compression), which
- * needs the threads to be acyclic as oriented-node sequences.
+ * whose successor x has reverse(x) < reverse(w).  Records are built directly in that order (no compression), in a
+ * topological pass when the threads are acyclic as oriented-node sequences and by prefix doubling otherwise.
  *
  * Parity status: pinned on the reference's known-answer tests for this path (src/unittest/gbwt_extender.cpp:576-1158,
  * hand-transcribed in tests/test_gapless.py).  PARITY-UNPINNED: (i) the order in which the seeds of a cluster are
@@ -29,22 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "../include/vgk.h"
-
-typedef struct { int32_t node; int32_t lo, hi; } SState;          /* visits [lo, hi] of an oriented node; empty when lo > hi */
-typedef struct { SState f, b; } BState;
-
-struct vgk_haplo {
-    uint32_t n_nodes, n_oriented;
-    uint32_t* len;            /* per oriented node */
-    size_t*   seq_off;        /* per oriented node, into seq */
-    char*     seq;            /* forward strands then reverse complements */
-    uint32_t* count;          /* visits per oriented node */
-    uint32_t* edge_off;       /* per oriented node, n_oriented + 1 */
-    int32_t*  edge_to;        /* successor (oriented node) or -1 = thread ends here; ascending */
-    uint32_t* edge_base;      /* where this node's visits start inside the successor's record */
-    size_t*   body_off;       /* per oriented node, n_oriented + 1 */
-    uint32_t* body;           /* per visit: index of its edge within the node's edge list */
-};
+#include "vgo_haplo.h"
 
 static char comp(char c) {
     switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
@@ -64,6 +49,56 @@ static int cmp_arrival(const void* a, const void* b) {
     return x->order < y->order ? -1 : x->order > y->order;
 }
 static int cmp_i32(const void* a, const void* b) { const int32_t x = *(const int32_t*)a, y = *(const int32_t*)b; return x < y ? -1 : x > y; }
+
+/* Threads that revisit a node (cycles) have no topological order of records.  The general rule is the same one — the
+   visits of a node are ordered by their reversed prefixes (predecessor, its predecessor, ..., thread start; starts by thread
+   number) — and is evaluated here by prefix doubling over all visits.  Fills `arr` (record order), `succ` and the number of
+   distinct successors like the topological pass does. */
+typedef struct { uint64_t key; uint32_t v; } RankKey;
+static int cmp_rankkey(const void* a, const void* b) {
+    const RankKey* x = (const RankKey*)a; const RankKey* y = (const RankKey*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->v < y->v ? -1 : x->v > y->v;
+}
+static void order_visits_general(uint32_t S, const uint32_t* soff, const int32_t* sn, uint32_t V, uint32_t O, const size_t* body_off,
+                                 const uint32_t* count, Arrival* arr, int32_t* succ, uint32_t* e_cnt) {
+    uint32_t* seq_of = (uint32_t*)malloc(sizeof(uint32_t) * (V + 1));
+    uint32_t* rank = (uint32_t*)malloc(sizeof(uint32_t) * (V + 1));
+    uint32_t* next = (uint32_t*)malloc(sizeof(uint32_t) * (V + 1));
+    RankKey* rk = (RankKey*)malloc(sizeof(RankKey) * (V + 1));
+    uint32_t maxlen = 0;
+    for (uint32_t s = 0; s < S; ++s) {
+        if (soff[s + 1] - soff[s] > maxlen) maxlen = soff[s + 1] - soff[s];
+        for (uint32_t v = soff[s]; v < soff[s + 1]; ++v) { seq_of[v] = s; rank[v] = v == soff[s] ? s : S + (uint32_t)sn[v - 1]; }
+    }
+    for (uint32_t hstep = 1; hstep <= maxlen; hstep *= 2) {
+        for (uint32_t v = 0; v < V; ++v) {
+            const uint32_t k = v - soff[seq_of[v]];
+            rk[v].key = ((uint64_t)rank[v] << 32) | (k >= hstep ? (uint64_t)rank[v - hstep] + 1u : 0u);
+            rk[v].v = v;
+        }
+        qsort(rk, V, sizeof(RankKey), cmp_rankkey);
+        uint32_t distinct = 0;
+        for (uint32_t i = 0; i < V; ++i) { if (i && rk[i].key != rk[i - 1].key) ++distinct; next[rk[i].v] = distinct; }
+        memcpy(rank, next, sizeof(uint32_t) * V);
+        if (distinct + 1 == V) break;
+    }
+    for (uint32_t v = 0; v < V; ++v) { rk[v].key = ((uint64_t)(uint32_t)sn[v] << 32) | rank[v]; rk[v].v = v; }
+    qsort(rk, V, sizeof(RankKey), cmp_rankkey);          /* by node, then by rank: the records, one after the other */
+    for (uint32_t i = 0; i < V; ++i) {
+        const uint32_t v = rk[i].v, s = seq_of[v], k = v - soff[s];
+        arr[i] = (Arrival){ k ? sn[v - 1] : -1, 0, s, k };
+        succ[i] = v + 1 < soff[s + 1] ? sn[v + 1] : -1;
+    }
+    for (uint32_t o = 0; o < O; ++o) {
+        const uint32_t n = count[o]; e_cnt[o] = 0; if (!n) continue;
+        int32_t* tmp = (int32_t*)malloc(sizeof(int32_t) * n); memcpy(tmp, succ + body_off[o], sizeof(int32_t) * n);
+        qsort(tmp, n, sizeof(int32_t), cmp_i32);
+        for (uint32_t i = 0; i < n; ++i) if (!i || tmp[i] != tmp[i - 1]) ++e_cnt[o];
+        free(tmp);
+    }
+    free(seq_of); free(rank); free(next); free(rk);
+}
 
 int vgo_haplo_create(const vgk_haplotypes* d, vgk_haplo** out) {
     if (!d || !out || !d->n_nodes || !d->node_len || !d->seq || (d->n_threads && (!d->thread_off || !d->thread_nodes))) return VGK_EINVAL;
@@ -131,7 +166,8 @@ int vgo_haplo_create(const vgk_haplotypes* d, vgk_haplo** out) {
         uint32_t k = 0; for (uint32_t i = 0; i < n; ++i) if (!i || tmp[i] != tmp[i - 1]) ++k;
         e_cnt[o] = k; free(tmp);
     }
-    int rc = laid == with_visits ? VGK_OK : VGK_EINVAL;               /* a cycle among the threads */
+    int rc = VGK_OK;
+    if (laid != with_visits) order_visits_general(S, soff, sn, V, O, h->body_off, h->count, arr, succ, e_cnt);   /* a cycle among the threads */
     if (rc == VGK_OK) {
         h->edge_off = (uint32_t*)malloc(sizeof(uint32_t) * (O + 1)); h->edge_off[0] = 0;
         for (uint32_t o = 0; o < O; ++o) h->edge_off[o + 1] = h->edge_off[o] + e_cnt[o];

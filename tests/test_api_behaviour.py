@@ -118,9 +118,10 @@ def test_gapless_limits_and_bad_input_are_reported_per_problem(emu_lib):
     assert list(res["status"]) == [0, -7, -1, 0, 0]
     assert list(res["n_ext"]) == [1, 0, 0, 0, 1] and res["full_length"][0] == 1
     assert ext["score"][0] == 13 + 10 and list(nodes[:2]) == [0, 2]
-    # a cyclic thread cannot be indexed
-    with pytest.raises(capi.VgkError):
-        eng.haplo_index(["AC", "GT"], [[0, 2, 0]])
+    # a thread may go round a cycle: the seed still extends along it
+    cyc = eng.haplo_index(["AC", "GT"], [[0, 2, 0, 2]])
+    res, ext, nodes, mism = eng.gapless_extend(cyc, [dict(read="ACGTACGT", seeds=[(0, 0)])])
+    assert res["status"][0] == 0 and res["full_length"][0] == 1 and list(nodes[:4]) == [0, 2, 0, 2] and ext["score"][0] == 8 + 10
 
 
 def test_gssw_align_answers_out_of_range_problems_per_problem(emu_lib):

@@ -1,0 +1,270 @@
+"""Haplotype-consistent wavefront alignment: the oracle against the reference's known-answer tests
+(src/unittest/gbwt_extender.cpp:1531-2640, transcribed into tests/golden/ref_wfa_extender.json by
+tests/golden/extract_wfa_tests.py), then the kernel (CPU emulation here, HIP under -m gpu) against the oracle."""
+import numpy as np
+import pytest
+
+import util
+from vg_amd import capi
+
+GOLD = util.load_golden("ref_wfa_extender.json")
+SCORES = dict(match=1, mismatch=4, gap_open=6, gap_extend=1, bonus=5)
+
+
+def graph_tables(name):
+    g = GOLD["graphs"][name]
+    ids = [i for i, _ in g["nodes"]]
+    assert ids == sorted(ids)
+    index_of = {nid: k for k, nid in enumerate(ids)}
+    nodes = [s for _, s in g["nodes"]]
+    threads = [[2 * index_of[i] + int(r) for i, r in p] for p in g["paths"]]
+    return nodes, threads, index_of
+
+
+def problem_of(case, index_of):
+    def pos(p):
+        if p is None:
+            return None
+        nid, rev, off = p
+        return (2 * index_of[nid] + int(rev), off) if nid in index_of else (0x7fffffff, off)
+    return dict(seq=case["sequence"], mode=case["call"], **{"from": pos(case["from"]), "to": pos(case["to"])})
+
+
+def node_seq(nodes, o):
+    s = nodes[o // 2]
+    return s if not o & 1 else s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def edges_of(threads):
+    e = set()
+    for t in threads:
+        for a, b in zip(t, t[1:]):
+            e.add((a, b)); e.add((b ^ 1, a ^ 1))
+    return e
+
+
+def unpack(res, paths, edits, i=0):
+    r = res[i]
+    path = [int(x) for x in paths[r["path_begin"]:r["path_begin"] + r["path_len"]]]
+    ed = [(int(x) & 3, int(x) >> 2) for x in edits[r["edit_begin"]:r["edit_begin"] + r["n_edits"]]]
+    return r, path, ed
+
+
+def final_offset(r, path, ed, nodes):                                 # WFAAlignment::final_offset (:821-832)
+    f = int(r["node_offset"]) + sum(n for t, n in ed if t != capi.WFA_INSERTION)
+    return f - sum(len(nodes[o // 2]) for o in path[:-1])
+
+
+def correct_score(r, ed, seq_len, pinned_left, pinned_right):         # unittest correct_score (:132-167)
+    s = 0
+    for t, n in ed:
+        if t == capi.WFA_MATCH:
+            s += n * SCORES["match"]
+        elif t == capi.WFA_MISMATCH:
+            s -= n * SCORES["mismatch"]
+        else:
+            s -= SCORES["gap_open"] + (n - 1) * SCORES["gap_extend"]
+    if ed and int(r["length"]) == seq_len:
+        if not pinned_right and ed[-1][0] in (capi.WFA_MATCH, capi.WFA_MISMATCH):
+            s += SCORES["bonus"]
+        if not pinned_left and ed[0][0] in (capi.WFA_MATCH, capi.WFA_MISMATCH):
+            s += SCORES["bonus"]
+    return s
+
+
+def check_alignment(case, r, path, ed, nodes, threads, index_of):     # unittest check_alignment (:1423-1521)
+    seq = case["sequence"]
+    frm = case["from"] if case["call"] != "prefix" else None
+    to = case["to"] if case["call"] != "suffix" else None
+    assert r["ok"]
+    assert r["seq_offset"] + r["length"] <= len(seq)
+    assert frm is None or r["seq_offset"] == 0
+    assert to is None or r["seq_offset"] + r["length"] == len(seq)
+    assert sum(n for t, n in ed if t != capi.WFA_DELETION) == r["length"]
+    edges = edges_of(threads)
+    for a, b in zip(path, path[1:]):
+        assert (a, b) in edges
+    if path:
+        assert r["node_offset"] < len(nodes[path[0] // 2])
+        if frm is not None:
+            fh = 2 * index_of[frm[0]] + int(frm[1])
+            if path[0] == fh and r["node_offset"] > 0:
+                assert r["node_offset"] == frm[2] + 1
+            else:
+                assert frm[2] + 1 == len(nodes[fh // 2]) and (fh, path[0]) in edges and r["node_offset"] == 0
+        fo = final_offset(r, path, ed, nodes)
+        assert fo > 0
+        if to is not None:
+            th = 2 * index_of[to[0]] + int(to[1])
+            last_len = len(nodes[path[-1] // 2])
+            if path[-1] == th and fo < last_len:
+                assert fo == to[2]
+            else:
+                assert to[2] == 0 and (path[-1], th) in edges and fo == last_len
+    for (a, _), (b, _) in zip(ed, ed[1:]):
+        assert a != b
+    assert r["score"] == correct_score(r, ed, len(seq), frm is not None, to is not None)
+    so, no, po = int(r["seq_offset"]), int(r["node_offset"]), 0
+    for t, n in ed:
+        if t == capi.WFA_INSERTION:
+            so += n
+            continue
+        end = no + n
+        while end > no:
+            assert po < len(path)
+            ns = node_seq(nodes, path[po])
+            ln = min(end, len(ns)) - no
+            if t == capi.WFA_MATCH:
+                assert seq[so:so + ln] == ns[no:no + ln]
+                so += ln
+            elif t == capi.WFA_MISMATCH:
+                assert all(seq[so + i] != ns[no + i] for i in range(ln))
+                so += ln
+            no += ln
+            if no >= len(ns):
+                no = 0; end -= len(ns); po += 1
+    if path:
+        assert po == len(path) - 1 or (po == len(path) and no == 0)
+
+
+def run_golden(eng):
+    indexes = {}
+    for case in GOLD["cases"]:
+        name = case["graph"]
+        if name not in indexes:
+            nodes, threads, index_of = graph_tables(name)
+            indexes[name] = (eng.haplo_index(nodes, threads), nodes, threads, index_of)
+        index, nodes, threads, index_of = indexes[name]
+        res, paths, edits = eng.wfa_extend(index, [problem_of(case, index_of)], case["error_model"])
+        r, path, ed = unpack(res, paths, edits)
+        assert r["status"] == 0, case["name"]
+        exp = case["expect"]
+        try:
+            if exp["kind"] == "fail":
+                assert not r["ok"]
+            elif exp["kind"] == "unlocalized_insertion":            # check_unlocalized_insertion (:1407-1421)
+                assert r["ok"] and not path and ed == [(capi.WFA_INSERTION, len(case["sequence"]))]
+                assert r["seq_offset"] == 0 and r["length"] == len(case["sequence"])
+                assert r["score"] == -SCORES["gap_open"] - (int(r["length"]) - 1) * SCORES["gap_extend"]
+            else:
+                ext = exp["gap_length"] - exp["gaps"]               # check_score (:1390-1405)
+                want = (exp["matches"] * SCORES["match"] - exp["mismatches"] * SCORES["mismatch"] - exp["gaps"] * SCORES["gap_open"]
+                        - ext * SCORES["gap_extend"] + exp["full_length_ends"] * SCORES["bonus"])
+                assert r["ok"] and r["score"] == want
+                if exp["check_alignment"]:
+                    check_alignment(case, r, path, ed, nodes, threads, index_of)
+        except AssertionError as e:
+            raise AssertionError("%s (%s): %s  got %s path %s edits %s" % (case["name"], case["source"], e, r, path, ed)) from e
+    return len(GOLD["cases"])
+
+
+def test_oracle_matches_reference_known_answers():
+    eng = capi.Engine(lib=capi.load_library(util.ORACLE_LIB))
+    assert run_golden(eng) >= 100
+
+
+# ---- random haplotype graphs: the engine against the oracle ----------------------------------------------------------
+
+def random_wfa_case(rng, n_problems=60):
+    """The bubble chains of test_gapless with some threads going round a cycle; sequences cut from a thread (either strand)
+    between a `from` and a `to` base, with substitutions, insertions and deletions; connect / suffix / prefix problems,
+    a few of them between unrelated positions."""
+    from test_gapless import random_haplotype_case
+    bases = "ACGT"
+    nodes, threads, _ = random_haplotype_case(rng, n_reads=0, n_haplotypes=int(rng.integers(1, 6)), chain_nodes=int(rng.integers(4, 16)))
+    if rng.random() < 0.4:                                   # cycles: repeat a stretch of a thread
+        for t in threads:
+            if len(t) > 4 and rng.random() < 0.7:
+                i = int(rng.integers(0, len(t) - 2)); k = int(rng.integers(i + 1, len(t)))
+                t[k:k] = t[i:k] * int(rng.integers(1, 3))
+
+    def comp(s):
+        return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+    problems = []
+    for _ in range(n_problems):
+        t = threads[int(rng.integers(0, len(threads)))]
+        if rng.random() < 0.5:
+            t = [o ^ 1 for o in reversed(t)]
+        seq = "".join(nodes[o // 2] if not o & 1 else comp(nodes[o // 2]) for o in t)
+        starts = np.cumsum([0] + [len(nodes[o // 2]) for o in t])
+
+        def pos(g):
+            k = int(np.searchsorted(starts, g, side="right") - 1)
+            return (int(t[k]), int(g - starts[k]))
+        if len(seq) < 3:
+            continue
+        f = int(rng.integers(0, len(seq) - 1)); n = int(rng.integers(0, min(50, len(seq) - f - 1) + 1))
+        read = []
+        rate = float(rng.choice([0.0, 0.03, 0.1]))
+        for c in seq[f + 1:f + 1 + n]:
+            r = rng.random()
+            if r < rate:
+                read.append(bases[int(rng.integers(0, 4))])
+            elif r < 1.4 * rate:
+                continue
+            elif r < 1.8 * rate:
+                read.append(c); read.append(bases[int(rng.integers(0, 4))])
+            elif r < 1.8 * rate + 0.004:
+                read.append("N")
+            else:
+                read.append(c)
+        read = "".join(read)
+        mode = ["connect", "suffix", "prefix"][int(rng.integers(0, 3))]
+        g_to = f + n + 1
+        if mode == "connect" and g_to >= len(seq):
+            mode = "suffix"
+        p = dict(seq=read, mode=mode)
+        if mode != "prefix":
+            p["from"] = pos(f)
+        if mode == "connect":
+            p["to"] = pos(g_to)
+        if mode == "prefix":
+            p["to"] = pos(min(g_to, len(seq) - 1))
+        if rng.random() < 0.08:                              # unrelated endpoints
+            o = int(rng.integers(0, 2 * len(nodes)))
+            p["to" if mode != "suffix" else "from"] = (o, int(rng.integers(0, len(nodes[o // 2]))))
+        if rng.random() < 0.02:
+            p["from" if mode != "prefix" else "to"] = (2 * len(nodes) + 3, 0) if mode != "prefix" else p["to"]
+        problems.append(p)
+    return nodes, threads, problems
+
+
+MODELS = [None, ((0.03, 1, 6), (0.05, 1, 10), (0.1, 1, 20), (0.1, 2, 4)), ((0.0, 2, 2), (0.0, 1, 1), (0.0, 3, 3), (0.5, 0, 200)),
+          ((0.1, 3, 12), (0.1, 2, 12), (0.2, 4, 30), (0.1, 10, 200))]
+
+
+def compare_engines(lib, seeds, n_problems=60):
+    ora = capi.Engine(lib=util.ORACLE_LIB); eng = capi.Engine(lib=lib) if lib else capi.Engine()
+    ok = 0; statuses = {}
+    for s in seeds:
+        rng = np.random.default_rng(s)
+        nodes, threads, problems = random_wfa_case(rng, n_problems)
+        model = MODELS[s % len(MODELS)]
+        a = ora.wfa_extend(ora.haplo_index(nodes, threads), problems, model)
+        b = eng.wfa_extend(eng.haplo_index(nodes, threads), problems, model)
+        for st in b[0]["status"]:
+            statuses[int(st)] = statuses.get(int(st), 0) + 1
+        good = b[0]["status"] != -7                          # the kernel's table limits are its own; everything else must agree
+        assert (a[0]["status"][good] == b[0]["status"][good]).all(), (s, np.nonzero(a[0]["status"] != b[0]["status"])[0])
+        for i in np.nonzero(good)[0]:
+            ra, pa, ea = unpack(*a, i); rb, pb, eb = unpack(*b, i)
+            fields = ("status", "ok", "score", "node_offset", "seq_offset", "length", "path_len", "n_edits")
+            assert all(ra[f] == rb[f] for f in fields) and pa == pb and ea == eb, (s, i, problems[i], ra, rb, pa, pb, ea, eb)
+            ok += int(ra["ok"])
+    return ok, statuses
+
+
+def test_emulated_wfa_kernel_matches_reference_unit_tests_and_oracle():
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    assert run_golden(capi.Engine(lib=capi.load_library(util.EMU_LIB))) >= 100
+    ok, statuses = compare_engines(util.EMU_LIB, range(300, 360))
+    assert ok > 1500 and statuses.get(0, 0) > 0.98 * sum(statuses.values()), (ok, statuses)
+
+
+@pytest.mark.gpu
+def test_hip_wfa_matches_reference_unit_tests_and_oracle():
+    assert run_golden(capi.Engine()) >= 100
+    ok, statuses = compare_engines(None, range(400, 480), n_problems=400)
+    assert ok > 15000 and statuses.get(0, 0) > 0.98 * sum(statuses.values()), (ok, statuses)

@@ -7,6 +7,7 @@ product (vg_amd/libvgamd.so); loading fails loudly if it has not been built.
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -40,6 +41,16 @@ EXT_DT = np.dtype([("path_begin", "<u4"), ("path_len", "<u4"), ("offset", "<u4")
                    ("pad", "u1", 2), ("state", "<u4", 6)])
 GAPLESS_RESULT_DT = np.dtype([("status", "<i4"), ("ext_begin", "<u4"), ("n_ext", "<u4"), ("full_length", "<u4")])
 VGK_GAPLESS_TRIM = 1
+WFA_DT = np.dtype([("seq", "<u8"), ("seq_len", "<u4"), ("mode", "<u4"), ("from_node", "<u4"), ("from_offset", "<u4"),
+                   ("to_node", "<u4"), ("to_offset", "<u4")])
+WFA_RESULT_DT = np.dtype([("status", "<i4"), ("ok", "<i4"), ("score", "<i4"), ("node_offset", "<u4"), ("seq_offset", "<u4"),
+                          ("length", "<u4"), ("path_begin", "<u4"), ("path_len", "<u4"), ("edit_begin", "<u4"), ("n_edits", "<u4")])
+WFA_EVENT_DT = np.dtype([("per_base", "<f8"), ("min", "<i4"), ("max", "<i4")])
+WFA_CONNECT, WFA_SUFFIX, WFA_PREFIX = 0, 1, 2
+WFA_MATCH, WFA_MISMATCH, WFA_INSERTION, WFA_DELETION = 0, 1, 2, 3
+WFA_NO_NODE = 0xffffffff
+WFA_DEFAULT_MODEL = ((0.03, 1, 6), (0.05, 1, 10), (0.1, 1, 20), (0.1, 10, 200))      # gbwt_extender.hpp:386-395
+assert WFA_DT.itemsize == 32 and WFA_RESULT_DT.itemsize == 40 and WFA_EVENT_DT.itemsize == 16
 assert GAPLESS_DT.itemsize == 40 and EXT_DT.itemsize == 60 and GAPLESS_RESULT_DT.itemsize == 16
 assert BANDED_DT.itemsize == 80
 assert GRAPH_DT.itemsize == 40 and PROBLEM_DT.itemsize == 80 and RESULT_DT.itemsize == 32 and OP_DT.itemsize == 8
@@ -104,6 +115,10 @@ def load_library(path=None):
     lib.vgk_banded_align_multi.argtypes = [vp, vp, u32, u32, vp, vp, vp, sz, ctypes.POINTER(sz)]
     lib.vgk_banded_rerun.argtypes = [vp]
     lib.vgk_gapless_rerun.argtypes = [vp]
+    lib.vgk_wfa_extend.argtypes = [vp, vp, vp, vp, u32, vp, vp, sz, vp, sz, ctypes.POINTER(sz * 2)]
+    lib.vgk_wfa_rerun.argtypes = [vp]
+    lib.vgk_wfa_last_ms.restype = ctypes.c_double
+    lib.vgk_wfa_last_ms.argtypes = [vp]
     lib.vgk_banded_last.restype = ctypes.c_double
     lib.vgk_banded_last.argtypes = [vp, ctypes.c_int]
     for f in ("vgk_batch_cells", "vgk_batch_alg_bytes", "vgk_batch_device_bytes"):
@@ -234,9 +249,12 @@ class Engine:
         if rc != VGK_OK:
             raise VgkError("vgk_create: %s" % self.lib.vgk_strerror(rc).decode())
         self.h = h
+        self._indexes = weakref.WeakSet()      # haplotype indexes live in this context: they go first
 
     def close(self):
         if getattr(self, "h", None):
+            for index in list(getattr(self, "_indexes", ())):
+                index.close()
             self.lib.vgk_destroy(self.h); self.h = None
 
     __del__ = close
@@ -309,6 +327,30 @@ class Engine:
     def gapless_last_ms(self):
         return self.lib.vgk_gapless_last_ms(self.h)
 
+    def wfa_extend(self, index, problems, error_model=None):
+        """problems: a WfaSet, or a list of dicts {seq, mode: "connect"|"suffix"|"prefix", from: (oriented node, offset),
+        to: (oriented node, offset)}; error_model: four (per_base, min, max) rows or None for the reference's default.
+        -> (results, paths, edits) as numpy arrays laid out like include/vgk.h."""
+        ws = problems if isinstance(problems, WfaSet) else WfaSet.from_lists(problems)
+        res = np.zeros(ws.n, dtype=WFA_RESULT_DT)
+        paths = np.zeros(ws.path_cap, dtype=np.uint32); edits = np.zeros(ws.edit_cap, dtype=np.uint32)
+        model = None
+        if error_model is not None:
+            model = np.zeros(4, dtype=WFA_EVENT_DT)
+            for i, row in enumerate(error_model):
+                model[i] = tuple(row)
+        written = (ctypes.c_size_t * 2)()
+        self._check(self.lib.vgk_wfa_extend(self.h, index.h, model.ctypes.data if model is not None else None, ws.array.ctypes.data, ws.n,
+                                            res.ctypes.data, paths.ctypes.data, ws.path_cap, edits.ctypes.data, ws.edit_cap,
+                                            ctypes.byref(written)), "vgk_wfa_extend")
+        return res, paths[:written[0]], edits[:written[1]]
+
+    def wfa_rerun(self):
+        self._check(self.lib.vgk_wfa_rerun(self.h), "vgk_wfa_rerun")
+
+    def wfa_last_ms(self):
+        return self.lib.vgk_wfa_last_ms(self.h)
+
 
 class GaplessSet:
     """A batch of gapless-extension problems (vgk_gapless_problem) over shared numpy arenas."""
@@ -348,6 +390,36 @@ class GaplessSet:
                    [p.get("overlap_threshold", 0.8) for p in problems], [p.get("trim", True) for p in problems])
 
 
+class WfaSet:
+    """A batch of WFA problems (vgk_wfa_problem) over one shared numpy arena of sequences."""
+
+    def __init__(self, seqs, seq_off, mode, from_node, from_offset, to_node, to_offset, path_cap=None, edit_cap=None):
+        self.seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        self.seq_off = np.asarray(seq_off, dtype=np.int64)
+        n = self.n = len(self.seq_off) - 1
+        arr = np.zeros(n, dtype=WFA_DT)
+        arr["seq"] = self.seqs.ctypes.data + self.seq_off[:-1]
+        arr["seq_len"] = np.diff(self.seq_off)
+        arr["mode"] = mode
+        arr["from_node"] = from_node; arr["from_offset"] = from_offset
+        arr["to_node"] = to_node; arr["to_offset"] = to_offset
+        self.array = arr
+        sl = np.diff(self.seq_off)
+        self.path_cap = int(path_cap if path_cap is not None else (4 * sl + 64).sum()) + 1
+        self.edit_cap = int(edit_cap if edit_cap is not None else (2 * sl + 8).sum()) + 1
+
+    @classmethod
+    def from_lists(cls, problems):
+        modes = {"connect": WFA_CONNECT, "suffix": WFA_SUFFIX, "prefix": WFA_PREFIX}
+        seqs = [np.frombuffer(p["seq"].encode(), dtype=np.uint8) for p in problems]
+        seq_off = np.concatenate([[0], np.cumsum([len(r) for r in seqs])]).astype(np.int64)
+        buf = np.concatenate(seqs) if len(seqs) and seq_off[-1] else np.zeros(1, np.uint8)
+        none = (WFA_NO_NODE, 0)
+        return cls(buf, seq_off, [modes[p.get("mode", "connect")] for p in problems],
+                   [(p.get("from") or none)[0] for p in problems], [(p.get("from") or none)[1] for p in problems],
+                   [(p.get("to") or none)[0] for p in problems], [(p.get("to") or none)[1] for p in problems])
+
+
 class HaploIndex:
     """The haplotype index the gapless extender walks (stands in for vg's GBWTGraph)."""
 
@@ -362,10 +434,13 @@ class HaploIndex:
         h = ctypes.c_void_p()
         eng._check(eng.lib.vgk_haplo_create(eng.h, ctypes.byref(d), ctypes.byref(h)), "vgk_haplo_create")
         self.h = h
+        eng._indexes.add(self)
 
     def close(self):
         if getattr(self, "h", None):
-            self.eng.lib.vgk_haplo_destroy(self.h); self.h = None
+            if getattr(self.eng, "h", None):
+                self.eng.lib.vgk_haplo_destroy(self.h)
+            self.h = None
 
     __del__ = close
 

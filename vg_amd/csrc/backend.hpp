@@ -9,6 +9,7 @@
 #include "gssw_device.hpp"
 #include "banded_device.hpp"
 #include "gapless_device.hpp"
+#include "wfa_device.hpp"
 
 namespace vgk {
 
@@ -38,6 +39,9 @@ public:
     virtual int   run_banded(const BandedParams& p, const BandedLaunch* launches, uint32_t n_launches) = 0;
     // gapless extension: `threads` resident threads (one scratch slab each) stride over p.n reads; last_ms(5) = kernel ms
     virtual int   run_gapless(const GaplessParams& p, uint32_t threads) = 0;
+    // wavefront alignment: likewise, `threads` resident threads (one WScratch each, zeroed by the caller once) stride over
+    // p.n problems; last_ms(6) = kernel ms
+    virtual int   run_wfa(const WfaParams& p, uint32_t threads) = 0;
 };
 
 // returns nullptr and sets err when the device cannot be used

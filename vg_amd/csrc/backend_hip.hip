@@ -141,12 +141,19 @@ __global__ void __launch_bounds__(64, 4) gapless_kernel(const GaplessParams P, c
     for (uint32_t i = t; i < P.n; i += threads) gapless_extend_one(P, i, P.scratch[t], P.cold[t]);
 }
 
+// ---- wavefront alignment (wfa_device.hpp): the same launch shape
+__global__ void __launch_bounds__(64, 4) wfa_kernel(const WfaParams P, const uint32_t threads) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= threads) return;
+    for (uint32_t i = t; i < P.n; i += threads) wfa_extend_one(P, i, P.scratch[t]);
+}
+
 class HipBackend final : public Backend {
 public:
     int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipDeviceProp_t prop;
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
-    float ms_gapless = 0.f;
+    float ms_gapless = 0.f, ms_wfa = 0.f;
     float ms_bfill = 0.f, ms_bwalk = 0.f; hipEvent_t bev[3] = {nullptr, nullptr, nullptr};
     ~HipBackend() override {
         hipSetDevice(dev);
@@ -264,7 +271,19 @@ public:
         hipEventElapsedTime(&ms_gapless, bev[0], bev[1]);
         return VGK_OK;
     }
+    int run_wfa(const WfaParams& p, uint32_t threads) override {
+        hipSetDevice(dev);
+        ms_wfa = 0.f;
+        if (!p.n || !threads) return VGK_OK;
+        hipEventRecord(bev[0], stream);
+        hipLaunchKernelGGL(wfa_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads);
+        hipEventRecord(bev[1], stream);
+        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
+        hipEventElapsedTime(&ms_wfa, bev[0], bev[1]);
+        return VGK_OK;
+    }
     double last_ms(int which) const override {
+        if (which == 6) return ms_wfa;
         if (which == 5) return ms_gapless;
         if (which == 3) return ms_bfill;
         if (which == 4) return ms_bwalk;

@@ -17,12 +17,14 @@ struct vgk_ctx {
     // last vgk_banded_align call: kernel times (ms), band cells, algorithmic bytes
     double banded_ms[2] = {0, 0}; uint64_t banded_cells = 0, banded_bytes = 0;
     double gapless_ms = 0;         // kernel time of the last vgk_gapless_extend call
+    double wfa_ms = 0;             // and of the last vgk_wfa_extend call
     // the last batch of either call stays resident in the cached device buffers: what a re-run needs to launch it again
     vgk::BandedParams banded_last{}; std::vector<vgk::BandedLaunch> banded_last_launches; bool banded_last_valid = false;
     vgk::GaplessParams gapless_last{}; uint32_t gapless_last_threads = 0; bool gapless_last_valid = false;
+    vgk::WfaParams wfa_last{}; uint32_t wfa_last_threads = 0; bool wfa_last_valid = false;
     // device scratch kept between vgk_banded_align calls (grow-only; released with the context)
     struct DevBuf { void* p = nullptr; uint64_t bytes = 0; };
-    DevBuf scratch[32];            // 0..14 banded_api.cpp, 15.. gapless_api.cpp
+    DevBuf scratch[48];            // 0..14 + 31 banded_api.cpp, 15..30 gapless_api.cpp, 32.. wfa_api.cpp
     void* ensure_scratch(int slot, uint64_t bytes) {
         DevBuf& b = scratch[slot];
         if (b.p && b.bytes >= bytes) return b.p;
@@ -34,6 +36,7 @@ struct vgk_ctx {
     }
     std::shared_ptr<void> banded_host;      // host staging arenas of banded_api.cpp
     std::shared_ptr<void> gapless_host;     // and of gapless_api.cpp
+    std::shared_ptr<void> wfa_host;         // and of wfa_api.cpp
     ~vgk_ctx() { if (be) for (DevBuf& b : scratch) if (b.p) be->release(b.p); }
 };
 

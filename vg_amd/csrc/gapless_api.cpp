@@ -3,25 +3,18 @@
 // The index: what the reference gets from GBWTGraph (node sequences in both orientations + GBWT records) is built
 // here from the caller's threads in uncompressed form and kept in HBM.  The visits of an oriented node are laid down
 // in GBWT order — by (predecessor node, rank in the predecessor's record), threads that start at the node first in
-// thread order — by delivering every finished record to its successors, which needs the threads to be acyclic as
-// oriented-node sequences.
+// thread order — by delivering every finished record to its successors when the threads are acyclic as oriented-node
+// sequences, and by prefix doubling over the reversed prefixes otherwise.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 #include "ctx.hpp"
+#include "haplo.hpp"
 #include "host_parallel.hpp"
 
 using namespace vgk;
-
-struct vgk_haplo {
-    vgk_ctx* ctx = nullptr;
-    GIndex dev{};                       // device pointers
-    std::vector<void*> held;
-    uint32_t n_oriented = 0;
-    std::vector<uint32_t> len;          // host copy, for validation
-};
 
 namespace {
 
@@ -99,7 +92,33 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
             if (got[w] == count[w]) queue.push_back((uint32_t)w);
         }
     }
-    if (queue.size() != with_visits) return VGK_EINVAL;                     // a cycle among the threads
+    if (queue.size() != with_visits) {
+        // Threads that revisit a node leave no topological order of records.  The rule is the same — visits ordered by their
+        // reversed prefixes (predecessor, its predecessor, ..., thread start; starts by thread number) — evaluated by prefix
+        // doubling over all visits: rank by the first h symbols, then pair with the rank of the visit h steps back.
+        std::vector<uint32_t> seq_of(V), rank(V), next(V), idx(V);
+        uint32_t maxlen = 0;
+        for (uint32_t s = 0; s < S; ++s) {
+            maxlen = std::max(maxlen, soff[s + 1] - soff[s]);
+            for (uint32_t v = soff[s]; v < soff[s + 1]; ++v) { seq_of[v] = s; rank[v] = v == soff[s] ? s : S + (uint32_t)sn[v - 1]; }
+        }
+        std::vector<uint64_t> key(V);
+        for (uint32_t h = 1; h <= maxlen; h *= 2) {
+            for (uint32_t v = 0; v < V; ++v) { const uint32_t k = v - soff[seq_of[v]]; key[v] = ((uint64_t)rank[v] << 32) | (k >= h ? (uint64_t)rank[v - h] + 1u : 0u); idx[v] = v; }
+            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
+            uint32_t distinct = 0;
+            for (uint32_t i = 0; i < V; ++i) { if (i && key[idx[i]] != key[idx[i - 1]]) ++distinct; next[idx[i]] = distinct; }
+            rank.swap(next);
+            if (distinct + 1 == V) break;
+        }
+        for (uint32_t v = 0; v < V; ++v) { key[v] = ((uint64_t)(uint32_t)sn[v] << 32) | rank[v]; idx[v] = v; }
+        std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });   // record after record
+        for (uint32_t i = 0; i < V; ++i) {
+            const uint32_t v = idx[i], s = seq_of[v], k = v - soff[s];
+            arr[i] = {k ? sn[v - 1] : -1, 0, s, k};
+            succ[i] = v + 1 < soff[s + 1] ? sn[v + 1] : -1;
+        }
+    }
     std::vector<uint32_t> edge_off(O + 1, 0), body(V), edge_base;
     std::vector<int32_t> edge_to;
     for (uint32_t o = 0; o < O; ++o) {

@@ -1,0 +1,172 @@
+// wfa_api.cpp — vgk_wfa_extend: the host half of haplotype-consistent wavefront alignment (wfa_device.hpp).
+//
+// Per call: validate, mask the sequences (ReadMasker, reference src/gbwt_extender.cpp:160-170) — reverse-complemented for
+// PREFIX problems, whose target becomes the start position on the other strand (:2248-2255) —, evaluate the error model's
+// score cap and distance band per sequence length (:1631-1634, :2077; gbwt_extender.hpp:371-373), upload, launch one
+// thread per problem over zero-initialised per-thread slabs, download, and hand paths / edits back in problem order.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "ctx.hpp"
+#include "haplo.hpp"
+#include "host_parallel.hpp"
+
+using namespace vgk;
+
+namespace {
+
+template <class T> struct RawBuf {
+    T* p = nullptr; size_t cap = 0;
+    T* get(size_t n) { if (n > cap) { std::free(p); cap = n + n / 4 + 64; p = (T*)std::malloc(cap * sizeof(T)); } return p; }
+    ~RawBuf() { std::free(p); }
+};
+struct WfaHost { RawBuf<char> seqs; RawBuf<WProb> probs; RawBuf<vgk_wfa_result> dres; RawBuf<uint32_t> dpaths, dedits; uint64_t zeroed_bytes = 0; void* zeroed_ptr = nullptr; };
+
+const vgk_wfa_error_model kDefaultModel = { { 0.03, 1, 6 }, { 0.05, 1, 10 }, { 0.1, 1, 20 }, { 0.1, 10, 200 } };   // gbwt_extender.hpp:386-395
+
+int32_t evaluate(const vgk_wfa_event& e, uint32_t length) {                                       // gbwt_extender.hpp:371-373
+    return std::min(e.max, (int32_t)(e.per_base * length) + e.min);
+}
+char complement(char c) {
+    switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'X'; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_model* model, const vgk_wfa_problem* problems, uint32_t n,
+                   vgk_wfa_result* results, uint32_t* paths, size_t path_cap, uint32_t* edits, size_t edit_cap, size_t written[2]) {
+    if (!ctx || !index || index->ctx != ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
+    if (written) written[0] = written[1] = 0;
+    if (!n) return VGK_OK;
+    const vgk_wfa_error_model& em = model ? *model : kDefaultModel;
+    for (const vgk_wfa_event* e : { &em.mismatches, &em.gaps, &em.gap_length })                  // the constructor's asserts (:1262-1270)
+        if (e->per_base < 0 || e->min < 0 || e->max < e->min) return VGK_EINVAL;
+    const int32_t match = ctx->sc.matrix[0], mism = -ctx->sc.matrix[1], go = ctx->sc.gap_open, ge = ctx->sc.gap_extend;
+    if (match < 0 || mism <= 0 || go < ge || ge <= 0) return VGK_EUNSUPPORTED;                    // (:1256-1259)
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->wfa_last_valid = false;
+    Backend* be = ctx->be.get();
+    WfaParams P{};
+    P.index = index->dev; P.n = n;
+    P.match = match; P.bonus = ctx->sc.full_length_bonus;
+    P.mismatch = 2 * (match + mism); P.gap_open = 2 * (go - ge); P.gap_extend = 2 * ge + match;   // (:1616-1618)
+
+    if (!ctx->wfa_host) ctx->wfa_host = std::make_shared<WfaHost>();
+    WfaHost& H = *static_cast<WfaHost*>(ctx->wfa_host.get());
+    WProb* probs = H.probs.get(n);
+    uint64_t n_seq = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const vgk_wfa_problem& p = problems[i];
+        if (p.seq_len && !p.seq) return VGK_EINVAL;
+        WProb& w = probs[i];
+        w.seq_off = (uint32_t)n_seq + 8; w.seq_len = p.seq_len; w.mode = p.mode;
+        w.from_node = p.from_node; w.from_off = p.from_offset; w.to_node = p.to_node; w.to_off = p.to_offset;
+        w.status = VGK_OK; w.score_bound = 0; w.distance_band = 0;
+        if (p.mode > (uint32_t)VGK_WFA_PREFIX) w.status = VGK_EINVAL;
+        else if (p.seq_len > 60000u) w.status = VGK_ETOOLONG;
+        else if (p.mode == (uint32_t)VGK_WFA_PREFIX) {                                            // (:2253-2255)
+            if (p.to_node >= index->n_oriented || p.to_offset >= index->len[p.to_node]) w.status = VGK_EINVAL;
+            else { w.from_node = p.to_node ^ 1u; w.from_off = (index->len[p.to_node] - 1) - p.to_offset; }
+            w.to_node = VGK_WFA_NO_NODE; w.to_off = 0;
+        } else {
+            if (p.from_node < index->n_oriented && p.from_offset >= index->len[p.from_node]) w.status = VGK_EINVAL;
+            if (p.mode == (uint32_t)VGK_WFA_SUFFIX) { w.to_node = VGK_WFA_NO_NODE; w.to_off = 0; }
+            else if (p.to_node < index->n_oriented && p.to_offset >= index->len[p.to_node]) w.status = VGK_EINVAL;
+        }
+        if (w.status == VGK_OK) {
+            const int64_t bound = (int64_t)evaluate(em.mismatches, p.seq_len) * P.mismatch + (int64_t)evaluate(em.gaps, p.seq_len) * P.gap_open
+                                + (int64_t)evaluate(em.gap_length, p.seq_len) * P.gap_extend;
+            if (bound + P.gap_open + P.gap_extend + P.mismatch >= W_SCORES) w.status = VGK_ETOOBIG;
+            else { w.score_bound = (int32_t)bound; w.distance_band = evaluate(em.distance, p.seq_len); }
+        }
+        if (w.status != VGK_OK) w.seq_len = 0;
+        n_seq += w.seq_len;
+        if (n_seq > 0xfffffff0ull) return VGK_ETOOBIG;
+    }
+    char* seqs = H.seqs.get(n_seq + 16);
+    std::memset(seqs, 0, 8); std::memset(seqs + 8 + n_seq, 0, 8);
+    parallel_for(n, [&](uint32_t i, unsigned) {
+        const vgk_wfa_problem& p = problems[i]; const WProb& w = probs[i];
+        char* r = seqs + w.seq_off;
+        if (w.mode == (uint32_t)VGK_WFA_PREFIX) for (uint32_t k = 0; k < w.seq_len; ++k) r[k] = complement(p.seq[w.seq_len - 1 - k]);
+        else for (uint32_t k = 0; k < w.seq_len; ++k) { const char c = p.seq[k]; r[k] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'X'; }
+    });
+
+    int next_slot = 33;
+    auto dev = [&](const void* src, size_t bytes) -> void* {
+        void* d = ctx->ensure_scratch(next_slot++, std::max<size_t>(bytes, 16)); if (!d) return nullptr;
+        if (src && bytes && be->upload(d, src, bytes)) return nullptr;
+        return d;
+    };
+    P.probs = (const WProb*)dev(probs, sizeof(WProb) * n);
+    P.seqs = (const char*)dev(seqs, n_seq + 16);
+    // dense outputs; the kernel checks them
+    const uint64_t cap_p = std::max<uint64_t>(path_cap, (uint64_t)n * 8 + n_seq / 4 + 1024) + 1, cap_e = std::max<uint64_t>(edit_cap, (uint64_t)n * 4 + 1024) + 1;
+    P.caps[0] = cap_p; P.caps[1] = cap_e;
+    uint64_t per_cu = 512;
+    if (const char* e = std::getenv("VGAMD_WFA_THREADS_PER_CU")) per_cu = (uint64_t)std::max(64, std::atoi(e));
+    const uint32_t threads = (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max(1, be->compute_units()) * per_cu);
+    { const uint64_t want = sizeof(WScratch) * (uint64_t)threads;
+      P.scratch = (WScratch*)ctx->ensure_scratch(32, want);
+      // the kernel leaves every slab's table all-zero; a fresh (or regrown) allocation is zeroed once
+      if (P.scratch && (H.zeroed_ptr != (void*)P.scratch || H.zeroed_bytes < want)) {
+          const uint64_t have = ctx->scratch[32].bytes;
+          if (be->zero(P.scratch, have)) return VGK_ENODEV;
+          H.zeroed_ptr = (void*)P.scratch; H.zeroed_bytes = have;
+      } }
+    P.results = (vgk_wfa_result*)dev(nullptr, sizeof(vgk_wfa_result) * n);
+    P.paths = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_p);
+    P.edits = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_e);
+    P.counters = (unsigned long long*)dev(nullptr, 64);
+    if (!P.probs || !P.seqs || !P.scratch || !P.results || !P.paths || !P.edits || !P.counters) return VGK_ENOMEM;
+    int rc;
+    if ((rc = be->zero(P.counters, 64))) return rc;
+    if ((rc = be->run_wfa(P, threads))) return rc;
+    ctx->wfa_last = P; ctx->wfa_last_threads = threads; ctx->wfa_last_valid = true;
+    ctx->wfa_ms = be->last_ms(6);
+    unsigned long long counters[2] = {0, 0};
+    vgk_wfa_result* dres = H.dres.get(n);
+    if ((rc = be->download(counters, P.counters, sizeof counters))) return rc;
+    if ((rc = be->download(dres, P.results, sizeof(vgk_wfa_result) * n))) return rc;
+    const uint64_t np = std::min<uint64_t>(counters[0], cap_p), ne = std::min<uint64_t>(counters[1], cap_e);
+    uint32_t* dpaths = H.dpaths.get(np + 1); uint32_t* dedits = H.dedits.get(ne + 1);
+    if (np && (rc = be->download(dpaths, P.paths, sizeof(uint32_t) * np))) return rc;
+    if (ne && (rc = be->download(dedits, P.edits, sizeof(uint32_t) * ne))) return rc;
+    // the device packs alignments in completion order; hand them back in problem order
+    std::vector<uint64_t> op(n + 1, 0), oe(n + 1, 0);
+    int rc_all = VGK_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        vgk_wfa_result& r = dres[i];
+        if (r.status == VGK_OK && r.ok && (op[i] + r.path_len > path_cap || oe[i] + r.n_edits > edit_cap || (r.path_len && !paths) || (r.n_edits && !edits))) r.status = VGK_EOPS;
+        if (r.status == VGK_EOPS) rc_all = VGK_EOPS;
+        if (r.status != VGK_OK) { r.ok = 0; r.path_len = r.n_edits = 0; }
+        op[i + 1] = op[i] + r.path_len; oe[i + 1] = oe[i] + r.n_edits;
+    }
+    parallel_for(n, [&](uint32_t i, unsigned) {
+        vgk_wfa_result r = dres[i];
+        if (r.path_len) std::memcpy(paths + op[i], dpaths + r.path_begin, sizeof(uint32_t) * r.path_len);
+        if (r.n_edits) std::memcpy(edits + oe[i], dedits + r.edit_begin, sizeof(uint32_t) * r.n_edits);
+        r.path_begin = (uint32_t)op[i]; r.edit_begin = (uint32_t)oe[i];
+        results[i] = r;
+    });
+    if (written) { written[0] = op[n]; written[1] = oe[n]; }
+    return rc_all;
+}
+
+int vgk_wfa_rerun(vgk_ctx* ctx) {
+    if (!ctx) return VGK_EINVAL;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->wfa_last_valid) return VGK_EINVAL;
+    int rc;
+    if ((rc = ctx->be->zero(ctx->wfa_last.counters, 64))) return rc;
+    if ((rc = ctx->be->run_wfa(ctx->wfa_last, ctx->wfa_last_threads))) return rc;
+    ctx->wfa_ms = ctx->be->last_ms(6);
+    return VGK_OK;
+}
+
+double vgk_wfa_last_ms(vgk_ctx* ctx) { return ctx ? ctx->wfa_ms : 0.0; }
+
+}  // extern "C"

@@ -1,0 +1,540 @@
+// wfa_device.hpp — haplotype-consistent wavefront alignment, one thread per problem.
+//
+// Follows WFAExtender::connect (reference src/gbwt_extender.cpp:2052-2235) over its WFATree (:1567-2046) and WFANode
+// (:1434-1557).  The reference keeps, per trie node, three hash maps (score, diagonal) -> (sequence offset, node offset)
+// and grows std::vectors; here a problem owns one fixed scratch slab:
+//   * ONE open-addressing table for all wavefront points of the problem, keyed by (trie node, kind, penalty, diagonal) in
+//     32 bits with the two offsets packed in the other 32 — a probe is one 8-byte load.  The slab's table is all-zero between
+//     problems: every insertion is logged and the log is replayed to clear exactly the touched slots.
+//   * trie nodes as fixed records; the graph nodes along their paths in one pool with their starting offsets, so the bases
+//     of a trie node are read straight from the index (eight per compare) instead of being copied into a string.
+//   * possible penalties direct-mapped by value (the reference's std::map), diagonal range and "reachable with a gap" each.
+// A position (MatchPos :1276-1365) is (sequence offset, node offset, current trie node, the trie node the lookup started
+// at): its stack of trie offsets is the tree path between the two.  Children of a trie node are consecutive (they are
+// created together, :1999-2004).  The recursion of extend_over (:1928) is an explicit stack of child ranges.
+// Anything that outgrows the slab ends the problem with VGK_ETOOBIG.
+#pragma once
+#include <stdint.h>
+#include "../../include/vgk.h"
+#include "gapless_device.hpp"
+
+namespace vgk {
+
+constexpr int W_NODES  = 32;         // trie nodes per problem (a 32-bit mask holds the leaves)
+constexpr int W_PATH   = 448;        // graph nodes over all trie nodes
+constexpr int W_SLOTS  = 2048;       // wavefront table (power of two)
+constexpr int W_POINTS = 1024;       // stored points per problem
+constexpr int W_SCORES = 512;        // penalties 0 .. W_SCORES - 1 (the host checks the score bound against this)
+constexpr int W_EDITS  = 160;        // runs of edits per alignment
+constexpr uint32_t W_TARGET_LENGTH = 1024;   // WFANode::TARGET_LENGTH
+constexpr uint32_t W_NO_OFFSET = 0xffffffffu;
+enum { WK_MATCH = 0, WK_INS = 1, WK_DEL = 2 };
+
+struct WProb {                        // packed by the host
+    uint32_t seq_off, seq_len;
+    uint32_t mode;
+    uint32_t from_node, from_off, to_node, to_off;
+    int32_t  score_bound, distance_band;
+    int32_t  status;                  // problems the host refused keep their status
+};
+
+struct WNode {
+    int32_t  st_node, st_lo, st_hi;   // search state at the end of the path
+    uint32_t len;                     // bases along the path
+    uint32_t target_offset;
+    uint16_t path_begin, path_len;    // in WScratch::path_node / path_start
+    uint8_t  parent, first_child, n_children, dead_end;
+};
+struct WPScore { int16_t min_d, max_d; uint8_t flags, pad; };        // flags: 1 = possible, 2 = reachable with a gap
+
+struct WScratch {
+    uint64_t slot[W_SLOTS];           // (key + 1) << 32 | seq << 16 | off ; 0 = free
+    uint16_t log[W_POINTS];
+    WNode    nodes[W_NODES];
+    int32_t  path_node[W_PATH];
+    uint32_t path_start[W_PATH];
+    WPScore  ps[W_SCORES];
+    uint32_t edits[W_EDITS];
+    uint8_t  chain[W_NODES];
+    uint8_t  stack_cur[W_NODES], stack_end[W_NODES];
+};
+
+struct WfaParams {
+    GIndex index;
+    const WProb* probs; uint32_t n;
+    const char* seqs;                 // masked: ACGT or X; 8 bytes of padding at either end
+    int32_t match, mismatch, gap_open, gap_extend, bonus;      // match/bonus as scored; the other three are WFA penalties (:1616-1618)
+    WScratch* scratch;                // one per resident thread
+    vgk_wfa_result* results;
+    uint32_t* paths; uint32_t* edits;
+    unsigned long long* counters;     // [0] path entries, [1] edits handed out
+    unsigned long long caps[2];
+};
+
+struct WPos { uint32_t seq, off; uint8_t cur, origin; bool empty; };
+VGK_HD WPos w_none() { WPos p = { 0, 0, 0, 0, true }; return p; }
+VGK_HD bool w_less(const WPos& a, const WPos& b) { if (a.empty) return !b.empty; if (b.empty) return false; return a.seq < b.seq; }    // (:1356-1364)
+VGK_HD int32_t w_distance(const WPos& p, int32_t diag) { return 2 * (int32_t)p.seq - diag; }
+
+struct WCtx {
+    const WfaParams* P; WScratch* S;
+    const char* seq; uint32_t L;
+    int32_t to_node; uint32_t to_off; bool no_to;
+    uint32_t n_nodes, n_path, n_points;
+    int32_t cand_score, cand_diag; uint32_t cand_seq, cand_off, cand_node;
+    int32_t max_distance, min_distance;
+    bool overflow; int why;         // why: 1 points, 2 trie nodes, 3 path pool, 4 edits, 5 node length
+};
+
+// ---- the wavefront table ----
+VGK_HD uint32_t w_key(uint32_t node, int kind, int32_t score, int32_t diag) { return 1u + (node | ((uint32_t)kind << 5) | ((uint32_t)score << 7) | ((uint32_t)(diag + 512) << 17)); }
+VGK_HD uint32_t w_hash(uint32_t key) { return (key * 2654435761u) >> 21; }                       // 11 bits = W_SLOTS
+VGK_HD bool w_lookup(const WCtx& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t& seq, uint32_t& off) {
+    const uint32_t key = w_key(node, kind, score, diag);
+    for (uint32_t i = w_hash(key);; i = (i + 1) & (W_SLOTS - 1)) {
+        const uint64_t s = c.S->slot[i];
+        if (!s) return false;
+        if ((uint32_t)(s >> 32) == key) { seq = (uint32_t)(s >> 16) & 0xffffu; off = (uint32_t)s & 0xffffu; return true; }
+    }
+}
+VGK_HD void w_store(WCtx& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t seq, uint32_t off) {                     // WFANode::update (:1517-1530)
+    const uint32_t key = w_key(node, kind, score, diag);
+    const uint64_t v = ((uint64_t)key << 32) | ((uint64_t)(seq & 0xffffu) << 16) | (off & 0xffffu);
+    for (uint32_t i = w_hash(key);; i = (i + 1) & (W_SLOTS - 1)) {
+        const uint64_t s = c.S->slot[i];
+        if (!s) {
+            if (c.n_points >= (uint32_t)W_POINTS) { c.overflow = true; c.why = 1; return; }
+            c.S->log[c.n_points++] = (uint16_t)i; c.S->slot[i] = v; return;
+        }
+        if ((uint32_t)(s >> 32) == key) { c.S->slot[i] = v; return; }
+    }
+}
+
+// ---- search states: the non-empty one-node extensions in the order of the record's edges (follow_paths) ----
+struct WState { int32_t node, lo, hi; };
+// visits the non-empty extensions in order, copies number `want` into `out`, stops after `stop_at` of them; returns how many it saw
+VGK_HD uint32_t w_follow(const GIndex& h, const WState& s, uint32_t want, WState& out, uint32_t stop_at) {
+    if (s.lo > s.hi) return 0;
+    const uint32_t* rec = g_rec(h, (uint32_t)s.node);
+    const uint32_t ne = rec[1];
+    const uint32_t* body = rec + 4 + 2 * ne;
+    uint32_t k = 0;
+    for (uint32_t e = 0; e < ne && k < stop_at; ++e) {
+        const int32_t to = (int32_t)rec[4 + 2 * e];
+        if (to < 0) continue;
+        int32_t before = 0, inside = 0;
+        for (int32_t i = 0; i <= s.hi; ++i) if (body[i] == e) { if (i < s.lo) ++before; else ++inside; }
+        if (!inside) continue;
+        if (k == want) { out.node = to; out.lo = (int32_t)rec[5 + 2 * e] + before; out.hi = out.lo + inside - 1; }
+        ++k;
+    }
+    return k;
+}
+
+// ---- trie nodes ----
+VGK_HD bool w_append_node(WCtx& c, WNode& n, const WState& next) {                                // (:1546-1556)
+    n.st_node = next.node; n.st_lo = next.lo; n.st_hi = next.hi;
+    if (c.n_path >= (uint32_t)W_PATH) { c.overflow = true; c.why = 3; return true; }
+    c.S->path_node[c.n_path] = next.node; c.S->path_start[c.n_path] = n.len; ++c.n_path; ++n.path_len;
+    const uint32_t nl = g_len(c.P->index, next.node);
+    n.len += nl;
+    if (n.len > 0xfff0u) { c.overflow = true; c.why = 5; return true; }
+    if (!c.no_to && c.to_node == next.node) { n.target_offset = n.len - (nl - c.to_off); return true; }
+    return false;
+}
+VGK_HD void w_node_init(WCtx& c, uint32_t id, const WState& state, uint32_t parent) {             // (:1463-1488)
+    WNode n;
+    n.len = 0; n.target_offset = W_NO_OFFSET; n.path_begin = (uint16_t)c.n_path; n.path_len = 0;
+    n.parent = (uint8_t)parent; n.first_child = 0; n.n_children = 0; n.dead_end = 0;
+    if (!w_append_node(c, n, state)) {
+        while (n.len < W_TARGET_LENGTH) {
+            WState cur = { n.st_node, n.st_lo, n.st_hi }, next = { 0, 0, -1 };
+            const uint32_t successors = w_follow(c.P->index, cur, 0, next, 2);
+            if (successors == 0) { n.dead_end = 1; break; }
+            if (successors > 1) break;
+            if (w_append_node(c, n, next)) break;
+        }
+    }
+    c.S->nodes[id] = n;
+}
+VGK_HD bool w_is_leaf(const WNode& n) { return !n.n_children || n.dead_end; }
+VGK_HD bool w_expanded(const WNode& n) { return n.n_children || n.dead_end; }
+
+VGK_HD void w_pop(const WCtx& c, WPos& p) {                        // one step down the tree path towards the origin
+    uint32_t x = p.origin;
+    while (c.S->nodes[x].parent != p.cur) x = c.S->nodes[x].parent;
+    p.cur = (uint8_t)x;
+}
+VGK_HD bool w_at_dead_end(const WCtx& c, const WPos& p) { const WNode& n = c.S->nodes[p.cur]; return n.dead_end && p.off >= n.len; }   // (:2043)
+
+VGK_HD WPos w_find_pos(const WCtx& c, int kind, uint32_t node, int32_t score, int32_t diag, bool ext_seq, bool ext_graph) {          // (:2015-2040)
+    if (score < 0) return w_none();
+    const uint32_t origin = node;
+    for (;;) {
+        uint32_t seq, off;
+        if (w_lookup(c, node, kind, score, diag, seq, off)) {
+            WPos p = { seq, off, (uint8_t)node, (uint8_t)origin, false };
+            if (ext_seq && p.seq >= c.L) return w_none();
+            if (ext_graph && w_at_dead_end(c, p)) return w_none();
+            return p;
+        }
+        if (node == 0) return w_none();
+        node = c.S->nodes[node].parent;
+    }
+}
+VGK_HD void w_update(WCtx& c, int kind, int32_t score, int32_t diag, const WPos& p) { w_store(c, p.cur, kind, score, diag, p.seq, p.off); }
+
+VGK_HD WPos w_ins_predecessor(const WCtx& c, uint32_t node, int32_t score, int32_t diag, int& edit) {                               // (:1791-1795)
+    const WPos open = w_find_pos(c, WK_MATCH, node, score - c.P->gap_open - c.P->gap_extend, diag - 1, true, false);
+    const WPos ext = w_find_pos(c, WK_INS, node, score - c.P->gap_extend, diag - 1, true, false);
+    if (w_less(open, ext)) { edit = VGK_WFA_INSERTION; return ext; }
+    edit = VGK_WFA_MATCH; return open;
+}
+VGK_HD WPos w_del_predecessor(const WCtx& c, uint32_t node, int32_t score, int32_t diag, int& edit) {                               // (:1800-1804)
+    const WPos open = w_find_pos(c, WK_MATCH, node, score - c.P->gap_open - c.P->gap_extend, diag + 1, false, true);
+    const WPos ext = w_find_pos(c, WK_DEL, node, score - c.P->gap_extend, diag + 1, false, true);
+    if (w_less(open, ext)) { edit = VGK_WFA_DELETION; return ext; }
+    edit = VGK_WFA_MATCH; return open;
+}
+VGK_HD WPos w_match_predecessor(const WCtx& c, uint32_t node, int32_t score, int32_t diag, int& edit) {                             // (:1809-1823)
+    const WPos ins = w_find_pos(c, WK_INS, node, score, diag, false, false);
+    const WPos del = w_find_pos(c, WK_DEL, node, score, diag, false, false);
+    WPos subst = w_find_pos(c, WK_MATCH, node, score - c.P->mismatch, diag, false, false);
+    if (!subst.empty) { subst.seq++; subst.off++; }
+    if (w_less(ins, del)) {
+        if (w_less(del, subst)) { edit = VGK_WFA_MISMATCH; return subst; }
+        edit = VGK_WFA_DELETION; return del;
+    }
+    if (w_less(ins, subst)) { edit = VGK_WFA_MISMATCH; return subst; }
+    edit = VGK_WFA_INSERTION; return ins;
+}
+VGK_HD void w_successor_offset(const WCtx& c, WPos& p) {                                          // (:1827-1832)
+    if (p.off >= c.S->nodes[p.cur].len) { w_pop(c, p); p.off = 0; }
+    p.off++;
+}
+VGK_HD void w_predecessor_offset(const WCtx& c, uint32_t& node, uint32_t& off) {                  // (:1835-1842)
+    if (off > 0) --off;
+    else { node = c.S->nodes[node].parent; off = c.S->nodes[node].len - 1; }
+}
+
+VGK_HD void w_expand_if_necessary(WCtx& c, const WPos& p) {                                       // (:1992-2008)
+    const uint32_t node = p.cur;
+    if (w_expanded(c.S->nodes[node]) || p.off < c.S->nodes[node].len) return;
+    const WState st = { c.S->nodes[node].st_node, c.S->nodes[node].st_lo, c.S->nodes[node].st_hi };
+    WState next = { 0, 0, -1 };
+    const uint32_t k = w_follow(c.P->index, st, 0, next, 0xffffffffu);
+    if (!k) { c.S->nodes[node].dead_end = 1; return; }
+    if (c.n_nodes + k > (uint32_t)W_NODES) { c.overflow = true; c.why = 2; return; }
+    c.S->nodes[node].first_child = (uint8_t)c.n_nodes; c.S->nodes[node].n_children = (uint8_t)k;
+    for (uint32_t i = 0; i < k; ++i) {
+        if (i) w_follow(c.P->index, st, i, next, i + 1);
+        w_node_init(c, c.n_nodes, next, node); ++c.n_nodes;
+        if (c.overflow) return;
+    }
+}
+
+VGK_HD int32_t w_gap_penalty(const WCtx& c, uint32_t length) { return c.P->gap_open + (int32_t)length * c.P->gap_extend; }          // (:1649)
+
+VGK_HD uint32_t w_leaves(const WCtx& c) {
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < c.n_nodes; ++i) if (w_is_leaf(c.S->nodes[i])) m |= 1u << i;
+    return m;
+}
+
+// WFANode::match_forward (:1533-1542) on the bases of the trie node's path, eight per compare
+VGK_HD void w_match_forward(const WCtx& c, const WNode& n, WPos& p) {
+    if (p.seq >= c.L || p.off >= n.len) return;
+    uint32_t k = n.path_begin, end = n.path_begin + n.path_len;
+    while (k + 1 < end && c.S->path_start[k + 1] <= p.off) ++k;
+    for (;;) {
+        const int32_t gn = c.S->path_node[k];
+        const uint32_t start = c.S->path_start[k], gl = g_len(c.P->index, gn);
+        const char* g = c.P->index.seq + g_rec(c.P->index, (uint32_t)gn)[3] + (p.off - start);
+        const char* r = c.seq + p.seq;
+        uint32_t left = start + gl - p.off; if (c.L - p.seq < left) left = c.L - p.seq;
+        uint32_t m = 0;
+        while (m < left) {
+            const uint64_t x = g_load8(g + m) ^ g_load8(r + m);
+            if (x) { m += (uint32_t)(__builtin_ctzll(x) >> 3); break; }
+            m += 8;
+        }
+        const bool differs = m < left;
+        if (!differs) m = left;
+        p.seq += m; p.off += m;
+        if (differs || p.seq >= c.L || p.off >= n.len) return;
+        ++k;
+    }
+}
+
+VGK_HD void w_candidate(WCtx& c, int32_t score, int32_t diag, uint32_t seq, uint32_t off, uint32_t node) {
+    if (score < c.cand_score) { c.cand_score = score; c.cand_diag = diag; c.cand_seq = seq; c.cand_off = off; c.cand_node = node; }
+}
+
+VGK_HD void w_extend(WCtx& c, int32_t score) {                                                    // (:1656-1666, :1874-1935)
+    const WPScore ps = c.S->ps[score];
+    if (!(ps.flags & 1)) return;
+    for (int32_t diag = ps.min_d; diag <= ps.max_d && !c.overflow; ++diag) {
+        const uint32_t leaves = w_leaves(c);
+        for (uint32_t top = 0; top < c.n_nodes && !c.overflow; ++top) {
+            if (!(leaves >> top & 1)) continue;
+            uint32_t sp = 0;
+            c.S->stack_cur[0] = (uint8_t)top; c.S->stack_end[0] = (uint8_t)(top + 1); sp = 1;
+            while (sp && !c.overflow) {
+                if (c.S->stack_cur[sp - 1] == c.S->stack_end[sp - 1]) { --sp; continue; }
+                const uint32_t leaf = c.S->stack_cur[sp - 1]++;
+                WPos pos = w_find_pos(c, WK_MATCH, leaf, score, diag, false, false);
+                if (pos.empty) continue;
+                for (;;) {
+                    const WNode node = c.S->nodes[pos.cur];
+                    const bool may_reach_target = node.target_offset >= pos.off && node.target_offset < node.len;
+                    w_match_forward(c, node, pos);
+                    if ((may_reach_target && pos.off >= node.target_offset) || (c.no_to && pos.seq >= c.L)) {
+                        const uint32_t overshoot = c.no_to ? 0 : pos.off - node.target_offset;
+                        const uint32_t gap_length = (c.L - pos.seq) + overshoot;
+                        w_candidate(c, score + (gap_length ? w_gap_penalty(c, gap_length) : 0), diag, pos.seq - overshoot, node.target_offset, pos.cur);
+                    }
+                    if (w_distance(pos, diag) > c.max_distance) c.max_distance = w_distance(pos, diag);
+                    w_update(c, WK_MATCH, score, diag, pos);
+                    if (pos.off < node.len) break;
+                    w_expand_if_necessary(c, pos);
+                    if (c.overflow) break;
+                    if (pos.cur == pos.origin) {
+                        const WNode& now = c.S->nodes[pos.cur];
+                        if (now.n_children) { c.S->stack_cur[sp] = now.first_child; c.S->stack_end[sp] = (uint8_t)(now.first_child + now.n_children); ++sp; }
+                        break;
+                    }
+                    w_pop(c, pos); pos.off = 0;
+                }
+            }
+        }
+    }
+}
+
+VGK_HD void w_mark(WCtx& c, int32_t score, bool gap) {                                            // possible_scores[...] of next_score
+    WPScore& p = c.S->ps[score];
+    if (!(p.flags & 1)) { p.min_d = 0; p.max_d = 0; p.flags = (uint8_t)(1 | (gap ? 2 : 0)); }
+    else if (gap) p.flags |= 2;
+}
+VGK_HD int32_t w_next_score(WCtx& c, int32_t match_score) {                                       // (:1672-1704)
+    w_mark(c, match_score + c.P->mismatch, false);
+    if (c.S->ps[match_score].flags & 2) w_mark(c, match_score + c.P->gap_extend, true);
+    w_mark(c, match_score + c.P->gap_open + c.P->gap_extend, true);
+    int32_t s = match_score + 1;
+    while (!(c.S->ps[s].flags & 1)) ++s;
+    return s;
+}
+VGK_HD void w_range(const WCtx& c, int32_t& lo, int32_t& hi, int32_t score) {                     // (:1956-1968)
+    if (score < 0) return;
+    const WPScore p = c.S->ps[score];
+    if (!(p.flags & 1)) return;
+    if (p.min_d < lo) lo = p.min_d;
+    if (p.max_d > hi) hi = p.max_d;
+}
+
+VGK_HD void w_next(WCtx& c, int32_t score) {                                                      // (:1709-1786)
+    int32_t lo = 32767, hi = -32768;                                                              // get_diagonals (:1977-1988)
+    w_range(c, lo, hi, score - c.P->mismatch);
+    w_range(c, lo, hi, score - c.P->gap_open - c.P->gap_extend);
+    w_range(c, lo, hi, score - c.P->gap_extend);
+    if (lo <= hi) { --lo; ++hi; }
+    int32_t alo = 32767, ahi = -32768;
+    for (int32_t diag = lo; diag <= hi && !c.overflow; ++diag) {
+        const uint32_t leaves = w_leaves(c);
+        for (uint32_t leaf = 0; leaf < (uint32_t)W_NODES && (leaves >> leaf) && !c.overflow; ++leaf) {
+            if (!(leaves >> leaf & 1)) continue;
+            int edit;
+            WPos ins = w_ins_predecessor(c, leaf, score, diag, edit);
+            if (!ins.empty) {
+                ins.seq++;
+                if (w_distance(ins, diag) >= c.min_distance) { w_update(c, WK_INS, score, diag, ins); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
+            }
+            WPos del = w_del_predecessor(c, leaf, score, diag, edit);
+            if (!del.empty) {
+                w_successor_offset(c, del);
+                if (w_distance(del, diag) >= c.min_distance) { w_update(c, WK_DEL, score, diag, del); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
+                w_expand_if_necessary(c, del);
+            }
+            WPos subst = w_find_pos(c, WK_MATCH, leaf, score - c.P->mismatch, diag, true, true);
+            if (!subst.empty) { subst.seq++; w_successor_offset(c, subst); w_expand_if_necessary(c, subst); }
+            if (w_less(subst, ins)) subst = ins;
+            if (w_less(subst, del)) subst = del;
+            if (!subst.empty) {
+                if (subst.off == c.S->nodes[subst.cur].target_offset) {
+                    const uint32_t gap_length = c.L - subst.seq;
+                    w_candidate(c, score + (gap_length ? w_gap_penalty(c, gap_length) : 0), diag, subst.seq, subst.off, subst.cur);
+                }
+                if (w_distance(subst, diag) >= c.min_distance) { w_update(c, WK_MATCH, score, diag, subst); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
+            }
+        }
+    }
+    WPScore& p = c.S->ps[score];
+    if (p.flags & 1) { p.min_d = (int16_t)alo; p.max_d = (int16_t)ahi; }
+}
+
+VGK_HD int32_t w_alignment_score(const WCtx& c, int32_t score, int32_t diag, uint32_t seq, uint32_t final_insertion) {              // (:1380-1387)
+    const int32_t target_offset = (int32_t)seq - diag;
+    return (c.P->match * ((int32_t)(seq + final_insertion) + target_offset) - score) / 2;
+}
+
+// WFATree::trim (:1849-1868).  Among equally good points the reference keeps the first in hash-map order; here the one with
+// the smallest (trie node, penalty, diagonal) — the order of the packed keys.
+VGK_HD void w_trim(WCtx& c) {
+    c.cand_score = 0; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0;
+    int32_t best = 0; uint32_t best_order = 0xffffffffu;
+    for (uint32_t i = 0; i < c.n_points; ++i) {
+        const uint64_t s = c.S->slot[c.S->log[i]];
+        const uint32_t key = (uint32_t)(s >> 32) - 1;
+        if (((key >> 5) & 3u) != (uint32_t)WK_MATCH) continue;
+        const uint32_t node = key & 31u; const int32_t score = (int32_t)((key >> 7) & 1023u), diag = (int32_t)((key >> 17) & 1023u) - 512;
+        const uint32_t seq = (uint32_t)(s >> 16) & 0xffffu, off = (uint32_t)s & 0xffffu;
+        const int32_t as = w_alignment_score(c, score, diag, seq, 0);
+        const uint32_t order = (node << 20) | ((uint32_t)score << 10) | (uint32_t)(diag + 512);
+        if (as > best || (as == best && best_order != 0xffffffffu && order < best_order)) {
+            best = as; best_order = order;
+            c.cand_score = score; c.cand_diag = diag; c.cand_seq = seq; c.cand_off = off; c.cand_node = node;
+        }
+    }
+}
+
+VGK_HD void w_append_edit(WCtx& c, uint32_t& n_edits, int edit, uint32_t length) {                 // WFAAlignment::append (:850-859)
+    if (!length) return;
+    if (n_edits && (c.S->edits[n_edits - 1] & 3u) == (uint32_t)edit) { c.S->edits[n_edits - 1] += length << 2; return; }
+    if (n_edits >= (uint32_t)W_EDITS) { c.overflow = true; c.why = 4; return; }
+    c.S->edits[n_edits++] = (length << 2) | (uint32_t)edit;
+}
+
+// One problem (WFAExtender::connect :2052-2235; suffix :2237-2246; the strand flip of prefix :2248-2263 happens as the
+// result is written out: the backtrace yields the edits last-to-first, which is the flipped order).
+VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S) {
+    const WProb pb = P.probs[i];
+    vgk_wfa_result out; out.status = pb.status; out.ok = 0; out.score = 0; out.node_offset = 0; out.seq_offset = 0; out.length = 0;
+    out.path_begin = 0; out.path_len = 0; out.edit_begin = 0; out.n_edits = 0;
+    if (pb.status != VGK_OK || pb.from_node >= P.index.n_oriented) { P.results[i] = out; return; }     // !has_node(id(from)) (:2059)
+    WCtx c;
+    c.P = &P; c.S = &S; c.seq = P.seqs + pb.seq_off; c.L = pb.seq_len;
+    c.no_to = pb.to_node == VGK_WFA_NO_NODE; c.to_node = (int32_t)pb.to_node; c.to_off = pb.to_off;
+    c.n_nodes = 0; c.n_path = 0; c.n_points = 0; c.overflow = false; c.why = 0;
+    c.cand_score = 0x7fffffff; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0;
+    c.max_distance = 0; c.min_distance = 0;
+    const int32_t top_score = pb.score_bound + P.gap_open + P.gap_extend + P.mismatch;               // the host keeps this below W_SCORES
+    for (int32_t s = 0; s <= top_score && s < W_SCORES; ++s) { WPScore z = { 0, 0, 0, 0 }; S.ps[s] = z; }
+    const WState root = { (int32_t)pb.from_node, 0, (int32_t)g_rec(P.index, pb.from_node)[0] - 1 };
+    w_node_init(c, 0, root, 0); c.n_nodes = 1;
+    w_store(c, 0, WK_MATCH, 0, 0, 0, pb.from_off + 1);
+    w_mark(c, 0, false);
+
+    int32_t score = 0;
+    while (!c.overflow) {
+        w_extend(c, score);
+        if (pb.distance_band < c.max_distance) c.min_distance = c.max_distance - pb.distance_band;
+        if (c.cand_score <= score) break;
+        score = w_next_score(c, score);
+        if (score > pb.score_bound) break;
+        w_next(c, score);
+    }
+
+    bool ok = !c.overflow;
+    uint32_t unaligned_tail = c.L - c.cand_seq;
+    if (ok && c.cand_score > pb.score_bound) {
+        unaligned_tail = 0;
+        if (c.no_to) w_trim(c); else ok = false;
+    }
+    uint32_t n_edits = 0; bool lost = false;
+    if (ok) {
+        out.ok = 1; out.node_offset = pb.from_off + 1;
+        out.length = c.cand_seq + unaligned_tail;
+        out.score = w_alignment_score(c, c.cand_score, c.cand_diag, c.cand_seq, unaligned_tail);
+        int32_t p_score = c.cand_score, p_diag = c.cand_diag; uint32_t p_seq = c.cand_seq, p_off = c.cand_off, node = c.cand_node;
+        if (unaligned_tail > 0) { w_append_edit(c, n_edits, VGK_WFA_INSERTION, c.L - c.cand_seq); p_score -= w_gap_penalty(c, unaligned_tail); }
+        int edit = VGK_WFA_MATCH;
+        while ((p_seq > 0 || p_diag != 0) && !c.overflow && !lost) {                                 // (:2155-2202)
+            int pe; WPos pred;
+            switch (edit) {
+            case VGK_WFA_MATCH:
+                pred = w_match_predecessor(c, node, p_score, p_diag, pe);
+                if (pred.empty && (p_score != 0 || p_diag != 0)) { lost = true; break; }
+                w_append_edit(c, n_edits, VGK_WFA_MATCH, p_seq - pred.seq);
+                p_seq = pred.seq; p_off = pred.off;
+                if (!pred.empty) node = pred.cur;
+                edit = pe; break;
+            case VGK_WFA_MISMATCH:
+                w_append_edit(c, n_edits, VGK_WFA_MISMATCH, 1);
+                p_seq--; w_predecessor_offset(c, node, p_off);
+                p_score -= P.mismatch; edit = VGK_WFA_MATCH; break;
+            case VGK_WFA_INSERTION:
+                pred = w_ins_predecessor(c, node, p_score, p_diag, pe);
+                if (pred.empty) { lost = true; break; }
+                w_append_edit(c, n_edits, VGK_WFA_INSERTION, 1);
+                p_seq--;
+                p_score -= pe == VGK_WFA_INSERTION ? P.gap_extend : P.gap_open + P.gap_extend;
+                p_diag--; edit = pe; break;
+            default:
+                pred = w_del_predecessor(c, node, p_score, p_diag, pe);
+                if (pred.empty) { lost = true; break; }
+                w_append_edit(c, n_edits, VGK_WFA_DELETION, 1);
+                w_predecessor_offset(c, node, p_off);
+                p_score -= pe == VGK_WFA_DELETION ? P.gap_extend : P.gap_open + P.gap_extend;
+                p_diag++; edit = pe; break;
+            }
+        }
+        ok = !c.overflow && !lost;
+    }
+    if (lost) {
+        // A candidate found by next() is recorded before the distance check (:1761-1776): behind min_distance neither it nor its
+        // gap point is stored, and the reference's backtrace then leaves the stored wavefronts and does not terminate.
+        out.status = VGK_ENOBAND; out.ok = 0; out.score = 0; out.node_offset = 0; out.length = 0;
+    }
+    if (ok) {
+        // the path: the trie nodes from the root to the candidate; minus an exhausted first node (:2208-2211) and the trailing
+        // nodes no edit reaches (:2217-2229)
+        uint32_t n_chain = 0;
+        for (uint32_t x = c.cand_node;; x = S.nodes[x].parent) { S.chain[n_chain++] = (uint8_t)x; if (x == 0) break; }
+        uint32_t ref_len = 0;
+        for (uint32_t e = 0; e < n_edits; ++e) if ((S.edits[e] & 3u) != (uint32_t)VGK_WFA_INSERTION) ref_len += S.edits[e] >> 2;
+        const int32_t first_node = S.path_node[S.nodes[0].path_begin];
+        const uint32_t first_len = g_len(P.index, first_node);
+        const bool drop_first = out.node_offset >= first_len;
+        if (drop_first) out.node_offset = 0;
+        const uint32_t used = out.node_offset + ref_len;              // end of the alignment, from the start of the first kept node
+        uint32_t kept = 0, at = 0, last_start = 0, last_len = 0;       // `at` = start of the current node in the same coordinates
+        for (uint32_t k = n_chain; k-- > 0;) {
+            const WNode& n = S.nodes[S.chain[k]];
+            for (uint32_t j = 0; j < n.path_len; ++j) {
+                const uint32_t gl = g_len(P.index, S.path_node[n.path_begin + j]);
+                if (k == n_chain - 1 && j == 0 && drop_first) continue;
+                if (kept == 0 || at < used) { ++kept; last_start = at; last_len = gl; }
+                at += gl;
+            }
+        }
+        if (kept == 1 && used == out.node_offset) kept = 0;
+        const unsigned long long p0 = g_bump(P.counters + 0, kept), e0 = g_bump(P.counters + 1, n_edits);
+        if (p0 + kept > P.caps[0] || e0 + n_edits > P.caps[1]) { out.status = VGK_EOPS; out.ok = 0; }
+        else {
+            const bool flip = pb.mode == VGK_WFA_PREFIX;
+            uint32_t w = 0;
+            for (uint32_t k = n_chain; k-- > 0 && w < kept;) {
+                const WNode& n = S.nodes[S.chain[k]];
+                for (uint32_t j = 0; j < n.path_len && w < kept; ++j) {
+                    if (k == n_chain - 1 && j == 0 && drop_first) continue;
+                    const uint32_t o = (uint32_t)S.path_node[n.path_begin + j];
+                    P.paths[p0 + (flip ? kept - 1 - w : w)] = flip ? (o ^ 1u) : o;
+                    ++w;
+                }
+            }
+            for (uint32_t e = 0; e < n_edits; ++e) P.edits[e0 + e] = S.edits[flip ? e : n_edits - 1 - e];
+            out.path_begin = (uint32_t)p0; out.path_len = kept; out.edit_begin = (uint32_t)e0; out.n_edits = n_edits;
+            if (pb.mode != VGK_WFA_CONNECT && n_edits && out.length == c.L) {                        // (:2240-2243, :2258-2260)
+                const uint32_t last = S.edits[0] & 3u;                                               // the alignment's last edit
+                if (last == (uint32_t)VGK_WFA_MATCH || last == (uint32_t)VGK_WFA_MISMATCH) out.score += P.bonus;
+            }
+            if (flip) {                                                                              // WFAAlignment::flip (:834-848)
+                out.seq_offset = c.L - out.seq_offset - out.length;
+                if (kept) out.node_offset = last_len - (used - last_start);
+            }
+        }
+    } else if (c.overflow) { out.status = VGK_ETOOBIG; out.score = c.why; }
+    for (uint32_t k = 0; k < c.n_points; ++k) S.slot[S.log[k]] = 0;                                  // leave the table clean
+    P.results[i] = out;
+}
+
+}  // namespace vgk

@@ -344,3 +344,88 @@ class GaplessWorkload:
                                   node_cap=int(counts.sum()) * 16, mism_cap=int(counts.sum()) * 12)
         self.n = n_reads
         self.read_len = read_len
+
+
+class WfaWorkload:
+    """The long-read chaining stage's WFA problems (configs[5]): WFAExtender::connect between consecutive anchors
+    (MinimizerMapper connect_consistently, src/minimizer_mapper.cpp:2955, :3925) and ::prefix / ::suffix for the read tails
+    (<= max_tail_length, giraffe_main.cpp:997).  The variation graph of the gapless workload with `n_haplotypes` random threads;
+    every problem is a window of a thread (either strand) with HiFi-like errors (0.5 %: half substitutions, half 1-bp indels).
+    `tail_fraction` of the problems are tails of up to `max_tail` bases, the rest connect two anchors 50..`max_connect` bases apart."""
+
+    def __init__(self, n_problems, seed=321, graph_bp=1_000_000, n_haplotypes=8, max_connect=250, max_tail=100, tail_fraction=0.2,
+                 error_rate=0.005, snp_every=100, indel_every=1000):
+        rng = np.random.default_rng(seed)
+        seqs, preds, kind = build_variation_graph(rng, graph_bp, snp_every, indel_every)
+        lens = np.array([len(s) for s in seqs], dtype=np.int64)
+        succ = [[] for _ in seqs]
+        for v, pr in enumerate(preds):
+            for p in pr:
+                succ[p].append(v)
+        self.nodes = [s.tobytes().decode() for s in seqs]
+        threads = []
+        for _ in range(n_haplotypes):
+            t = [0]; v = 0
+            while succ[v]:
+                v = succ[v][int(rng.integers(0, len(succ[v])))]
+                t.append(v)
+            threads.append(np.array(t, dtype=np.int64))
+        self.threads = [list((2 * t).astype(int)) for t in threads]
+        comp = np.arange(256, dtype=np.uint8)
+        for a, b in zip(b"ACGT", b"TGCA"):
+            comp[a] = b
+        hap_seq = [np.concatenate([seqs[v] for v in t]) for t in threads]
+        hap_start = [np.concatenate([[0], np.cumsum(lens[t])]) for t in threads]
+        n = n_problems
+        which = rng.integers(0, n_haplotypes, n)
+        rev = rng.random(n) < 0.5
+        tail = rng.random(n) < tail_fraction
+        mode = np.where(tail, np.where(rng.random(n) < 0.5, capi.WFA_SUFFIX, capi.WFA_PREFIX), capi.WFA_CONNECT).astype(np.uint32)
+        span = np.where(tail, rng.integers(1, max_tail + 1, n), rng.integers(50, max_connect + 1, n))      # graph bases between from and to
+        from_node = np.full(n, capi.WFA_NO_NODE, dtype=np.uint32); from_off = np.zeros(n, dtype=np.uint32)
+        to_node = np.full(n, capi.WFA_NO_NODE, dtype=np.uint32); to_off = np.zeros(n, dtype=np.uint32)
+        pieces = [None] * n
+        for hidx in range(n_haplotypes):
+            sel = np.nonzero(which == hidx)[0]
+            if not len(sel):
+                continue
+            hs = hap_seq[hidx]; st = hap_start[hidx]; t = threads[hidx]
+            f = rng.integers(1, len(hs) - span[sel] - 2)                    # forward-strand position of the base before the window
+            for j, i in enumerate(sel):
+                a = int(f[j]); s = int(span[i])
+                w = hs[a + 1:a + 1 + s]
+                lo, hi = a, a + 1 + s                                       # flanking bases on the forward strand
+                if rev[i]:
+                    w = comp[w[::-1]]; lo, hi = hi, lo
+                # errors: substitutions and 1-bp indels
+                e = rng.random(len(w)) < error_rate
+                if e.any():
+                    out = []
+                    for c, bad in zip(w, e):
+                        if not bad:
+                            out.append(c); continue
+                        r = rng.random()
+                        if r < 0.5:
+                            out.append(ACGT[int(rng.integers(0, 4))])
+                        elif r < 0.75:
+                            pass
+                        else:
+                            out.append(c); out.append(ACGT[int(rng.integers(0, 4))])
+                    w = np.array(out, dtype=np.uint8)
+                pieces[i] = w
+
+                def pos(g):
+                    k = int(np.searchsorted(st, g, side="right") - 1)
+                    node = int(t[k]); off = int(g - st[k])
+                    return (2 * node + 1, int(lens[node]) - 1 - off) if rev[i] else (2 * node, off)
+                if mode[i] != capi.WFA_PREFIX:
+                    from_node[i], from_off[i] = pos(lo)
+                if mode[i] != capi.WFA_SUFFIX:
+                    to_node[i], to_off[i] = pos(hi)
+        seq_off = np.concatenate([[0], np.cumsum([len(p) for p in pieces])]).astype(np.int64)
+        buf = np.concatenate(pieces) if seq_off[-1] else np.zeros(1, np.uint8)
+        self.ws = capi.WfaSet(buf, seq_off, mode, from_node, from_off, to_node, to_off,
+                              path_cap=int(n) * 16 + int(seq_off[-1]) // 4, edit_cap=int(n) * 8)
+        self.n = n
+        self.bases = int(seq_off[-1])
+        self.graph_bases = int(span.sum())
