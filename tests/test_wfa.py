@@ -268,3 +268,78 @@ def test_hip_wfa_matches_reference_unit_tests_and_oracle():
     assert run_golden(capi.Engine()) >= 100
     ok, statuses = compare_engines(None, range(400, 480), n_problems=400)
     assert ok > 15000 and statuses.get(0, 0) > 0.98 * sum(statuses.values()), (ok, statuses)
+
+
+# ---- the C++ host shim (vg_amd/host/gbwt_extender.hpp: WFAExtender, WFAAlignment), driven like the reference's unit tests ----
+
+def shim_golden(engine_lib):
+    """Every known-answer case through WFAExtender::connect / suffix / prefix of the host shim: the reference's own checks
+    on the returned WFAAlignment, plus WFAAlignment::to_path consistency."""
+    import ctypes, json
+    h = util.host()
+    h.vgh_wfa_create.restype = ctypes.c_void_p
+    h.vgh_wfa_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), ctypes.c_int,
+                                 ctypes.POINTER(ctypes.c_double)]
+    h.vgh_wfa_destroy.argtypes = [ctypes.c_void_p]
+    h.vgh_wfa_align.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                ctypes.c_char_p, ctypes.c_size_t]
+    al = util.HostAligner(engine_lib)
+    checked = 0
+    for case in GOLD["cases"]:
+        gdef = GOLD["graphs"][case["graph"]]
+        nodes, threads, index_of = graph_tables(case["graph"])
+        g = h.vgh_graph_create()
+        try:
+            for nid, s in gdef["nodes"]:
+                assert h.vgh_graph_add_node(g, nid, s.encode()) == 0
+            flat = [2 * i + int(r) for p in gdef["paths"] for i, r in p]
+            off = np.concatenate([[0], np.cumsum([len(p) for p in gdef["paths"]])])
+            model = [float(v) for row in case["error_model"] for v in row]
+            x = h.vgh_wfa_create(al.ptr, g, (ctypes.c_int64 * len(flat))(*flat), (ctypes.c_int32 * len(off))(*[int(v) for v in off]), len(gdef["paths"]),
+                                 (ctypes.c_double * 12)(*model))
+            assert x, h.vgh_last_error().decode()
+            try:
+                def pos(p):
+                    return (ctypes.c_int64 * 3)(p[0], int(p[1]), p[2]) if p is not None else None
+                buf = ctypes.create_string_buffer(1 << 16)
+                kind = {"connect": 0, "suffix": 1, "prefix": 2}[case["call"]]
+                rc = h.vgh_wfa_align(x, kind, case["sequence"].encode(), pos(case["from"]), pos(case["to"]), buf, len(buf))
+                assert rc == 0, h.vgh_last_error().decode()
+                out = json.loads(buf.value.decode())
+            finally:
+                h.vgh_wfa_destroy(x)
+        finally:
+            h.vgh_graph_destroy(g)
+        exp = case["expect"]
+        if exp["kind"] == "fail":
+            assert not out["ok"], case["name"]
+            continue
+        assert out["ok"], case["name"]
+        r = dict(ok=1, score=out["score"], node_offset=out["node_offset"], seq_offset=out["seq_offset"], length=out["length"])
+        path = [2 * index_of[i] + int(rev) for i, rev in out["path"]]
+        ed = [tuple(e) for e in out["edits"]]
+        if exp["kind"] == "unlocalized_insertion":
+            assert out["unlocalized_insertion"] and not path and ed == [(capi.WFA_INSERTION, len(case["sequence"]))]
+        else:
+            ext = exp["gap_length"] - exp["gaps"]
+            assert out["score"] == (exp["matches"] * SCORES["match"] - exp["mismatches"] * SCORES["mismatch"] - exp["gaps"] * SCORES["gap_open"]
+                                    - ext * SCORES["gap_extend"] + exp["full_length_ends"] * SCORES["bonus"]), case["name"]
+            if exp["check_alignment"]:
+                check_alignment(case, r, path, ed, nodes, threads, index_of)
+        # WFAAlignment::to_path: one mapping per path node, edits add up to the aligned interval
+        maps = out["alignment"]["path"].get("mapping", [])
+        if path:
+            assert [m["position"]["node_id"] for m in maps] == [i for i, _ in out["path"]]
+            assert maps[0]["position"].get("offset", 0) == out["node_offset"]
+        assert sum(e.get("to_length", 0) for m in maps for e in m["edit"]) == out["length"]
+        checked += 1
+    return checked
+
+
+def test_host_shim_wfa_extender_on_the_oracle():
+    assert shim_golden(util.ORACLE_LIB) > 80
+
+
+@pytest.mark.gpu
+def test_host_shim_wfa_extender_on_hip():
+    assert shim_golden(util.ENGINE_LIB) > 80

@@ -29,6 +29,7 @@ struct EngineApi {
     decltype(&vgk_haplo_create) haplo_create = nullptr;
     decltype(&vgk_haplo_destroy) haplo_destroy = nullptr;
     decltype(&vgk_gapless_extend) gapless_extend = nullptr;
+    decltype(&vgk_wfa_extend) wfa_extend = nullptr;
     ~EngineApi();
 };
 

@@ -6,6 +6,7 @@
 // gbwt / gbwtgraph are empty submodules in the reference snapshot, so `HaplotypeGraph` stands in for
 // gbwtgraph::GBWTGraph: node sequences plus the haplotype threads, indexed on the device when an extender is built.
 #pragma once
+#include <algorithm>
 #include <memory>
 #include <string>
 #include <utility>
@@ -97,6 +98,69 @@ public:
 
     const HaplotypeGraph* graph;
     const Aligner*        aligner;
+private:
+    vgk_haplo* index = nullptr;
+};
+
+// src/gbwt_extender.hpp:233-307
+struct WFAAlignment {
+    enum Edit { match, mismatch, insertion, deletion };
+
+    static WFAAlignment from_extension(const GaplessExtension& extension);
+    static WFAAlignment make_unlocalized_insertion(size_t sequence_offset, size_t length, int score);
+    static WFAAlignment make_empty();
+
+    std::vector<handle_t> path;
+    std::vector<std::pair<Edit, uint32_t>> edits;
+    uint32_t node_offset = 0;
+    uint32_t seq_offset = 0;
+    uint32_t length = 0;
+    int32_t  score = 0;
+    bool     ok = false;
+
+    operator bool() const { return ok; }
+    bool empty() const { return path.empty() && edits.empty(); }
+    bool unlocalized_insertion() const;
+    int64_t final_offset(const HandleGraph& graph) const;
+    void flip(const HandleGraph& graph, const std::string& sequence);
+    void append(Edit edit, uint32_t length);
+    void join(const WFAAlignment& second);
+    Path to_path(const HandleGraph& graph, const std::string& sequence) const;
+};
+
+// src/gbwt_extender.hpp:346-461.  connect / suffix / prefix run on the MI355X engine (vgk_wfa_extend); the batch overload
+// hands a whole set of problems over in one call, which is how the engine is meant to be fed.
+class WFAExtender {
+public:
+    struct ErrorModel {
+        struct Event {
+            double per_base; int32_t min, max;
+            int32_t evaluate(size_t length) const { return std::min(max, (int32_t)(per_base * length) + min); }
+        };
+        Event mismatches, gaps, gap_length, distance;
+        constexpr static Event default_mismatches() { return {0.03, 1, 6}; }
+        constexpr static Event default_gaps() { return {0.05, 1, 10}; }
+        constexpr static Event default_gap_length() { return {0.1, 1, 20}; }
+        constexpr static Event default_distance() { return {0.1, 10, 200}; }
+    };
+    static const ErrorModel default_error_model;
+
+    WFAExtender(const HaplotypeGraph& graph, const Aligner& aligner, const ErrorModel& error_model = default_error_model);   // uploads the haplotype index
+    ~WFAExtender();
+    WFAExtender(const WFAExtender&) = delete;
+    WFAExtender& operator=(const WFAExtender&) = delete;
+
+    // `from` and `to` are exclusive: the alignment starts one base after `from` and ends one base before `to`
+    WFAAlignment connect(std::string sequence, Position from, Position to) const;
+    WFAAlignment suffix(const std::string& sequence, Position from) const;
+    WFAAlignment prefix(const std::string& sequence, Position to) const;
+
+    struct Problem { enum Kind { CONNECT, SUFFIX, PREFIX } kind; std::string sequence; Position from, to; };
+    std::vector<WFAAlignment> extend(const std::vector<Problem>& problems) const;      // one engine call for all of them
+
+    const HaplotypeGraph* graph;
+    const Aligner*        aligner;
+    const ErrorModel*     error_model;
 private:
     vgk_haplo* index = nullptr;
 };

@@ -199,4 +199,50 @@ int vgh_gapless_extend(vgh_extender* x, const char* read, const int64_t* seeds, 
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }
 
+// ---- WFAExtender (src/gbwt_extender.hpp:346-461) -------------------------------------------------------------------------
+struct vgh_wfa { std::unique_ptr<HaplotypeGraph> graph; WFAExtender::ErrorModel model; std::unique_ptr<WFAExtender> ext; };
+// model: 4 x (per_base, min, max) for mismatches, gaps, gap_length, distance; nullptr = the default model
+vgh_wfa* vgh_wfa_create(vgh_aligner* a, vgh_graph* g, const int64_t* thread_nodes, const int32_t* thread_off, int n_threads, const double* model) {
+    try {
+        std::vector<std::vector<handle_t>> threads((size_t)n_threads);
+        for (int t = 0; t < n_threads; ++t) for (int32_t k = thread_off[t]; k < thread_off[t + 1]; ++k) threads[t].push_back(g->g.get_handle(thread_nodes[k] >> 1, thread_nodes[k] & 1));
+        auto* h = new vgh_wfa();
+        h->graph = std::make_unique<HaplotypeGraph>(g->g, threads);
+        h->model = WFAExtender::default_error_model;
+        if (model) {
+            WFAExtender::ErrorModel::Event* ev[4] = { &h->model.mismatches, &h->model.gaps, &h->model.gap_length, &h->model.distance };
+            for (int i = 0; i < 4; ++i) { ev[i]->per_base = model[3 * i]; ev[i]->min = (int32_t)model[3 * i + 1]; ev[i]->max = (int32_t)model[3 * i + 2]; }
+        }
+        h->ext = std::make_unique<WFAExtender>(*h->graph, *a->a, h->model);
+        return h;
+    } catch (std::exception& e) { g_last_error = e.what(); return nullptr; }
+}
+void vgh_wfa_destroy(vgh_wfa* w) { delete w; }
+// kind: 0 connect, 1 suffix, 2 prefix; from / to: [node id, is_reverse, offset]
+int vgh_wfa_align(vgh_wfa* w, int kind, const char* seq, const int64_t* from, const int64_t* to, char* json_out, size_t json_cap) {
+    try {
+        Position f, t;
+        if (from) { f.node_id = from[0]; f.is_reverse = from[1] != 0; f.offset = from[2]; }
+        if (to) { t.node_id = to[0]; t.is_reverse = to[1] != 0; t.offset = to[2]; }
+        const std::string sequence(seq);
+        WFAAlignment r = kind == 0 ? w->ext->connect(sequence, f, t) : kind == 1 ? w->ext->suffix(sequence, f) : w->ext->prefix(sequence, t);
+        std::string js = std::string("{\"ok\":") + (r ? "true" : "false") + ",\"score\":" + std::to_string(r.score) + ",\"node_offset\":" + std::to_string(r.node_offset) +
+                         ",\"seq_offset\":" + std::to_string(r.seq_offset) + ",\"length\":" + std::to_string(r.length) + ",\"empty\":" + (r.empty() ? "true" : "false") +
+                         ",\"unlocalized_insertion\":" + (r.unlocalized_insertion() ? "true" : "false") + ",\"path\":[";
+        for (size_t i = 0; i < r.path.size(); ++i) js += std::string(i ? "," : "") + "[" + std::to_string(w->graph->get_id(r.path[i])) + "," + (w->graph->get_is_reverse(r.path[i]) ? "1" : "0") + "]";
+        js += "],\"edits\":[";
+        for (size_t i = 0; i < r.edits.size(); ++i) js += std::string(i ? "," : "") + "[" + std::to_string((int)r.edits[i].first) + "," + std::to_string(r.edits[i].second) + "]";
+        js += "]";
+        if (r) {
+            js += ",\"final_offset\":" + std::to_string(r.final_offset(*w->graph));
+            Alignment aln; aln.sequence = sequence; aln.path = r.to_path(*w->graph, sequence); aln.score = r.score;
+            js += ",\"alignment\":" + alignment_to_json(aln);
+        }
+        js += "}";
+        if (js.size() + 1 > json_cap) { g_last_error = "json buffer too small"; return -2; }
+        std::memcpy(json_out, js.c_str(), js.size() + 1);
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
 }  // extern "C"
