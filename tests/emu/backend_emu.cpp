@@ -51,7 +51,7 @@ template <int R, bool QA> static void banded_fill_emu(const BandedParams& P, uin
 class EmuBackend final : public Backend {
 public:
     int run_wfa(const WfaParams& P, uint32_t threads) override {
-        for (uint32_t t = 0; t < threads; ++t) for (uint32_t i = t; i < P.n; i += threads) wfa_extend_one(P, i, P.scratch[t]);
+        for (uint32_t t = 0; t < threads; ++t) wfa_thread(P, t);
         return VGK_OK;
     }
     int run_gapless(const GaplessParams& P, uint32_t threads) override {

@@ -144,8 +144,7 @@ __global__ void __launch_bounds__(64, 4) gapless_kernel(const GaplessParams P, c
 // ---- wavefront alignment (wfa_device.hpp): the same launch shape
 __global__ void __launch_bounds__(64, 4) wfa_kernel(const WfaParams P, const uint32_t threads) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= threads) return;
-    for (uint32_t i = t; i < P.n; i += threads) wfa_extend_one(P, i, P.scratch[t]);
+    if (t < threads) wfa_thread(P, t);
 }
 
 class HipBackend final : public Backend {

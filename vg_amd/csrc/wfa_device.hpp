@@ -6,12 +6,22 @@
 //   * ONE open-addressing table for all wavefront points of the problem, keyed by (trie node, kind, penalty, diagonal) in
 //     32 bits with the two offsets packed in the other 32 — a probe is one 8-byte load.  The slab's table is all-zero between
 //     problems: every insertion is logged and the log is replayed to clear exactly the touched slots.
-//   * trie nodes as fixed records; the graph nodes along their paths in one pool with their starting offsets, so the bases
-//     of a trie node are read straight from the index (eight per compare) instead of being copied into a string.
+//   * trie nodes as fixed records; the graph nodes along their paths are chained through one pool with their starting offsets,
+//     so the bases of a trie node are read straight from the index (eight per compare) instead of being copied into a string.
+//   * LAZY trie nodes.  WFANode's constructor walks a non-branching path for up to 1024 bases (:1470-1487) although a tail of
+//     100 bases needs four nodes of it; every step is a dependent record fetch from HBM.  Here a trie node grows one graph
+//     node at a time, exactly when a position asks whether it is past the node's end (w_past_end): the walk rule, the
+//     1024-base stop, the target and the dead-end flag are evaluated by the same code, just later, and nothing observes a
+//     node's length except through that question — so the results are those of the eager walk (the oracle walks eagerly).
 //   * possible penalties direct-mapped by value (the reference's std::map), diagonal range and "reachable with a gap" each.
 // A position (MatchPos :1276-1365) is (sequence offset, node offset, current trie node, the trie node the lookup started
 // at): its stack of trie offsets is the tree path between the two.  Children of a trie node are consecutive (they are
 // created together, :1999-2004).  The recursion of extend_over (:1928) is an explicit stack of child ranges.
+//   * The work per problem is heavily skewed (an exact match costs a handful of table probes, the median 7, the 99th percentile
+//     270, the maximum beyond 4000) and a wavefront runs as long as its slowest lane, so problems are handed out one at a time
+//     from a device counter instead of in fixed strides: a thread stuck on a slow problem holds nobody else's.  (Measured and
+//     dropped: budgeted passes that defer slow problems to a later, compacted launch — every wavefront still waits for a lane
+//     that runs into the budget, and the deferred problems run twice.)
 // Anything that outgrows the slab ends the problem with VGK_ETOOBIG.
 #pragma once
 #include <stdint.h>
@@ -21,7 +31,7 @@
 namespace vgk {
 
 constexpr int W_NODES  = 32;         // trie nodes per problem (a 32-bit mask holds the leaves)
-constexpr int W_PATH   = 448;        // graph nodes over all trie nodes
+constexpr int W_PATH   = 256;        // graph nodes over all trie nodes
 constexpr int W_SLOTS  = 2048;       // wavefront table (power of two)
 constexpr int W_POINTS = 1024;       // stored points per problem
 constexpr int W_SCORES = 512;        // penalties 0 .. W_SCORES - 1 (the host checks the score bound against this)
@@ -39,12 +49,15 @@ struct WProb {                        // packed by the host
 };
 
 struct WNode {
-    int32_t  st_node, st_lo, st_hi;   // search state at the end of the path
-    uint32_t len;                     // bases along the path
+    int32_t  st_node, st_lo, st_hi;   // search state at the end of the (materialised) path
+    uint32_t len;                     // bases along the materialised path
     uint32_t target_offset;
-    uint16_t path_begin, path_len;    // in WScratch::path_node / path_start
+    uint16_t path_head, path_tail;    // chain through WScratch::path_next
     uint8_t  parent, first_child, n_children, dead_end;
+    uint8_t  complete, pad[3];        // the walk has ended: branch, dead end, target, or 1024 bases
+    uint32_t ancestors;               // bit per trie node on the way to the root, this node included
 };
+constexpr uint16_t W_NIL = 0xffffu;
 struct WPScore { int16_t min_d, max_d; uint8_t flags, pad; };        // flags: 1 = possible, 2 = reachable with a gap
 
 struct WScratch {
@@ -52,7 +65,8 @@ struct WScratch {
     uint16_t log[W_POINTS];
     WNode    nodes[W_NODES];
     int32_t  path_node[W_PATH];
-    uint32_t path_start[W_PATH];
+    uint16_t path_start[W_PATH];      // offset of the graph node inside its trie node
+    uint16_t path_next[W_PATH];
     WPScore  ps[W_SCORES];
     uint32_t edits[W_EDITS];
     uint8_t  chain[W_NODES];
@@ -67,7 +81,7 @@ struct WfaParams {
     WScratch* scratch;                // one per resident thread
     vgk_wfa_result* results;
     uint32_t* paths; uint32_t* edits;
-    unsigned long long* counters;     // [0] path entries, [1] edits handed out
+    unsigned long long* counters;     // [0] path entries, [1] edits handed out, [2] next problem
     unsigned long long caps[2];
 };
 
@@ -87,15 +101,25 @@ struct WCtx {
 };
 
 // ---- the wavefront table ----
+// Hashed by (kind, penalty, diagonal) WITHOUT the trie node, so the points every trie node holds for one wavefront cell sit in one
+// probe sequence: "the deepest ancestor of this leaf that has the cell" (WFATree::find_pos walks leaf -> root, one hash_map each)
+// is a single scan to the first free slot, picking the largest trie node whose bit is set in the leaf's ancestor mask — trie
+// nodes are numbered in creation order, so a deeper ancestor has the larger number.
 VGK_HD uint32_t w_key(uint32_t node, int kind, int32_t score, int32_t diag) { return 1u + (node | ((uint32_t)kind << 5) | ((uint32_t)score << 7) | ((uint32_t)(diag + 512) << 17)); }
-VGK_HD uint32_t w_hash(uint32_t key) { return (key * 2654435761u) >> 21; }                       // 11 bits = W_SLOTS
-VGK_HD bool w_lookup(const WCtx& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t& seq, uint32_t& off) {
-    const uint32_t key = w_key(node, kind, score, diag);
-    for (uint32_t i = w_hash(key);; i = (i + 1) & (W_SLOTS - 1)) {
+VGK_HD uint32_t w_hash(uint32_t key) { return (((key - 1u) >> 5) * 2654435761u) >> 21; }         // 11 bits = W_SLOTS; the node bits stay out
+VGK_HD bool w_lookup(WCtx& c, uint32_t ancestors, int kind, int32_t score, int32_t diag, uint32_t& node, uint32_t& seq, uint32_t& off) {
+    const uint32_t cell = (w_key(0, kind, score, diag) - 1u) >> 5;
+    bool found = false; uint32_t best = 0;
+    for (uint32_t i = w_hash(w_key(0, kind, score, diag));; i = (i + 1) & (W_SLOTS - 1)) {
         const uint64_t s = c.S->slot[i];
-        if (!s) return false;
-        if ((uint32_t)(s >> 32) == key) { seq = (uint32_t)(s >> 16) & 0xffffu; off = (uint32_t)s & 0xffffu; return true; }
+        if (!s) break;
+        const uint32_t key = (uint32_t)(s >> 32) - 1u, holder = key & 31u;
+        if ((key >> 5) == cell && ((ancestors >> holder) & 1u) && (!found || holder > best)) {
+            found = true; best = holder; seq = (uint32_t)(s >> 16) & 0xffffu; off = (uint32_t)s & 0xffffu;
+        }
     }
+    node = best;
+    return found;
 }
 VGK_HD void w_store(WCtx& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t seq, uint32_t off) {                     // WFANode::update (:1517-1530)
     const uint32_t key = w_key(node, kind, score, diag);
@@ -135,27 +159,41 @@ VGK_HD uint32_t w_follow(const GIndex& h, const WState& s, uint32_t want, WState
 VGK_HD bool w_append_node(WCtx& c, WNode& n, const WState& next) {                                // (:1546-1556)
     n.st_node = next.node; n.st_lo = next.lo; n.st_hi = next.hi;
     if (c.n_path >= (uint32_t)W_PATH) { c.overflow = true; c.why = 3; return true; }
-    c.S->path_node[c.n_path] = next.node; c.S->path_start[c.n_path] = n.len; ++c.n_path; ++n.path_len;
+    const uint16_t at = (uint16_t)c.n_path++;
+    c.S->path_node[at] = next.node; c.S->path_start[at] = (uint16_t)n.len; c.S->path_next[at] = W_NIL;
+    if (n.path_head == W_NIL) n.path_head = at; else c.S->path_next[n.path_tail] = at;
+    n.path_tail = at;
     const uint32_t nl = g_len(c.P->index, next.node);
     n.len += nl;
     if (n.len > 0xfff0u) { c.overflow = true; c.why = 5; return true; }
     if (!c.no_to && c.to_node == next.node) { n.target_offset = n.len - (nl - c.to_off); return true; }
     return false;
 }
-VGK_HD void w_node_init(WCtx& c, uint32_t id, const WState& state, uint32_t parent) {             // (:1463-1488)
+VGK_HD void w_node_init(WCtx& c, uint32_t id, const WState& state, uint32_t parent) {             // (:1463-1468); the walk itself is w_grow
     WNode n;
-    n.len = 0; n.target_offset = W_NO_OFFSET; n.path_begin = (uint16_t)c.n_path; n.path_len = 0;
-    n.parent = (uint8_t)parent; n.first_child = 0; n.n_children = 0; n.dead_end = 0;
-    if (!w_append_node(c, n, state)) {
-        while (n.len < W_TARGET_LENGTH) {
-            WState cur = { n.st_node, n.st_lo, n.st_hi }, next = { 0, 0, -1 };
-            const uint32_t successors = w_follow(c.P->index, cur, 0, next, 2);
-            if (successors == 0) { n.dead_end = 1; break; }
-            if (successors > 1) break;
-            if (w_append_node(c, n, next)) break;
-        }
+    n.len = 0; n.target_offset = W_NO_OFFSET; n.path_head = n.path_tail = W_NIL;
+    n.parent = (uint8_t)parent; n.first_child = 0; n.n_children = 0; n.dead_end = 0; n.pad[0] = n.pad[1] = n.pad[2] = 0;
+    n.ancestors = (id ? c.S->nodes[parent].ancestors : 0u) | (1u << id);
+    n.complete = w_append_node(c, n, state) ? 1 : 0;
+    c.S->nodes[id] = n;
+}
+// one turn of the constructor's loop (:1470-1487)
+VGK_HD void w_grow(WCtx& c, uint32_t id) {
+    WNode n = c.S->nodes[id];
+    if (n.len >= W_TARGET_LENGTH) n.complete = 1;
+    else {
+        const WState cur = { n.st_node, n.st_lo, n.st_hi }; WState next = { 0, 0, -1 };
+        const uint32_t successors = w_follow(c.P->index, cur, 0, next, 2);
+        if (successors == 0) { n.dead_end = 1; n.complete = 1; }
+        else if (successors > 1) n.complete = 1;
+        else if (w_append_node(c, n, next)) n.complete = 1;
     }
     c.S->nodes[id] = n;
+}
+// is `off` at or past the end of the trie node?  Grows the node until that is known.
+VGK_HD bool w_past_end(WCtx& c, uint32_t id, uint32_t off) {
+    while (!c.S->nodes[id].complete && c.S->nodes[id].len <= off) w_grow(c, id);
+    return off >= c.S->nodes[id].len;
 }
 VGK_HD bool w_is_leaf(const WNode& n) { return !n.n_children || n.dead_end; }
 VGK_HD bool w_expanded(const WNode& n) { return n.n_children || n.dead_end; }
@@ -165,38 +203,35 @@ VGK_HD void w_pop(const WCtx& c, WPos& p) {                        // one step d
     while (c.S->nodes[x].parent != p.cur) x = c.S->nodes[x].parent;
     p.cur = (uint8_t)x;
 }
-VGK_HD bool w_at_dead_end(const WCtx& c, const WPos& p) { const WNode& n = c.S->nodes[p.cur]; return n.dead_end && p.off >= n.len; }   // (:2043)
+VGK_HD bool w_at_dead_end(WCtx& c, const WPos& p) { return w_past_end(c, p.cur, p.off) && c.S->nodes[p.cur].dead_end; }   // (:2043)
 
-VGK_HD WPos w_find_pos(const WCtx& c, int kind, uint32_t node, int32_t score, int32_t diag, bool ext_seq, bool ext_graph) {          // (:2015-2040)
+VGK_HD WPos w_find_pos(WCtx& c, int kind, uint32_t node, int32_t score, int32_t diag, bool ext_seq, bool ext_graph) {                 // (:2015-2040)
     if (score < 0) return w_none();
-    const uint32_t origin = node;
-    for (;;) {
-        uint32_t seq, off;
-        if (w_lookup(c, node, kind, score, diag, seq, off)) {
-            WPos p = { seq, off, (uint8_t)node, (uint8_t)origin, false };
-            if (ext_seq && p.seq >= c.L) return w_none();
-            if (ext_graph && w_at_dead_end(c, p)) return w_none();
-            return p;
-        }
-        if (node == 0) return w_none();
-        node = c.S->nodes[node].parent;
-    }
+    // no point of this penalty was ever stored outside the diagonal range its wavefront ended up with (next :1780-1785, extend :1662)
+    const WPScore ps = c.S->ps[score];
+    if (!(ps.flags & 1) || diag < ps.min_d || diag > ps.max_d) return w_none();
+    uint32_t holder, seq, off;
+    if (!w_lookup(c, c.S->nodes[node].ancestors, kind, score, diag, holder, seq, off)) return w_none();
+    WPos p = { seq, off, (uint8_t)holder, (uint8_t)node, false };
+    if (ext_seq && p.seq >= c.L) return w_none();
+    if (ext_graph && w_at_dead_end(c, p)) return w_none();
+    return p;
 }
 VGK_HD void w_update(WCtx& c, int kind, int32_t score, int32_t diag, const WPos& p) { w_store(c, p.cur, kind, score, diag, p.seq, p.off); }
 
-VGK_HD WPos w_ins_predecessor(const WCtx& c, uint32_t node, int32_t score, int32_t diag, int& edit) {                               // (:1791-1795)
+VGK_HD WPos w_ins_predecessor(WCtx& c, uint32_t node, int32_t score, int32_t diag, int& edit) {                               // (:1791-1795)
     const WPos open = w_find_pos(c, WK_MATCH, node, score - c.P->gap_open - c.P->gap_extend, diag - 1, true, false);
     const WPos ext = w_find_pos(c, WK_INS, node, score - c.P->gap_extend, diag - 1, true, false);
     if (w_less(open, ext)) { edit = VGK_WFA_INSERTION; return ext; }
     edit = VGK_WFA_MATCH; return open;
 }
-VGK_HD WPos w_del_predecessor(const WCtx& c, uint32_t node, int32_t score, int32_t diag, int& edit) {                               // (:1800-1804)
+VGK_HD WPos w_del_predecessor(WCtx& c, uint32_t node, int32_t score, int32_t diag, int& edit) {                               // (:1800-1804)
     const WPos open = w_find_pos(c, WK_MATCH, node, score - c.P->gap_open - c.P->gap_extend, diag + 1, false, true);
     const WPos ext = w_find_pos(c, WK_DEL, node, score - c.P->gap_extend, diag + 1, false, true);
     if (w_less(open, ext)) { edit = VGK_WFA_DELETION; return ext; }
     edit = VGK_WFA_MATCH; return open;
 }
-VGK_HD WPos w_match_predecessor(const WCtx& c, uint32_t node, int32_t score, int32_t diag, int& edit) {                             // (:1809-1823)
+VGK_HD WPos w_match_predecessor(WCtx& c, uint32_t node, int32_t score, int32_t diag, int& edit) {                             // (:1809-1823)
     const WPos ins = w_find_pos(c, WK_INS, node, score, diag, false, false);
     const WPos del = w_find_pos(c, WK_DEL, node, score, diag, false, false);
     WPos subst = w_find_pos(c, WK_MATCH, node, score - c.P->mismatch, diag, false, false);
@@ -208,8 +243,8 @@ VGK_HD WPos w_match_predecessor(const WCtx& c, uint32_t node, int32_t score, int
     if (w_less(ins, subst)) { edit = VGK_WFA_MISMATCH; return subst; }
     edit = VGK_WFA_INSERTION; return ins;
 }
-VGK_HD void w_successor_offset(const WCtx& c, WPos& p) {                                          // (:1827-1832)
-    if (p.off >= c.S->nodes[p.cur].len) { w_pop(c, p); p.off = 0; }
+VGK_HD void w_successor_offset(WCtx& c, WPos& p) {                                                // (:1827-1832)
+    if (w_past_end(c, p.cur, p.off)) { w_pop(c, p); p.off = 0; }
     p.off++;
 }
 VGK_HD void w_predecessor_offset(const WCtx& c, uint32_t& node, uint32_t& off) {                  // (:1835-1842)
@@ -219,7 +254,7 @@ VGK_HD void w_predecessor_offset(const WCtx& c, uint32_t& node, uint32_t& off) {
 
 VGK_HD void w_expand_if_necessary(WCtx& c, const WPos& p) {                                       // (:1992-2008)
     const uint32_t node = p.cur;
-    if (w_expanded(c.S->nodes[node]) || p.off < c.S->nodes[node].len) return;
+    if (c.S->nodes[node].n_children || !w_past_end(c, node, p.off) || c.S->nodes[node].dead_end) return;
     const WState st = { c.S->nodes[node].st_node, c.S->nodes[node].st_lo, c.S->nodes[node].st_hi };
     WState next = { 0, 0, -1 };
     const uint32_t k = w_follow(c.P->index, st, 0, next, 0xffffffffu);
@@ -241,11 +276,11 @@ VGK_HD uint32_t w_leaves(const WCtx& c) {
     return m;
 }
 
-// WFANode::match_forward (:1533-1542) on the bases of the trie node's path, eight per compare
-VGK_HD void w_match_forward(const WCtx& c, const WNode& n, WPos& p) {
-    if (p.seq >= c.L || p.off >= n.len) return;
-    uint32_t k = n.path_begin, end = n.path_begin + n.path_len;
-    while (k + 1 < end && c.S->path_start[k + 1] <= p.off) ++k;
+// WFANode::match_forward (:1533-1542) on the bases of the trie node's path, eight per compare; the node grows as the match runs into its end
+VGK_HD void w_match_forward(WCtx& c, WPos& p) {
+    if (p.seq >= c.L || w_past_end(c, p.cur, p.off)) return;
+    uint32_t k = c.S->nodes[p.cur].path_head;
+    while (c.S->path_next[k] != W_NIL && c.S->path_start[c.S->path_next[k]] <= p.off) k = c.S->path_next[k];
     for (;;) {
         const int32_t gn = c.S->path_node[k];
         const uint32_t start = c.S->path_start[k], gl = g_len(c.P->index, gn);
@@ -261,8 +296,8 @@ VGK_HD void w_match_forward(const WCtx& c, const WNode& n, WPos& p) {
         const bool differs = m < left;
         if (!differs) m = left;
         p.seq += m; p.off += m;
-        if (differs || p.seq >= c.L || p.off >= n.len) return;
-        ++k;
+        if (differs || p.seq >= c.L || w_past_end(c, p.cur, p.off) || c.overflow) return;
+        k = c.S->path_next[k];
     }
 }
 
@@ -285,9 +320,11 @@ VGK_HD void w_extend(WCtx& c, int32_t score) {                                  
                 WPos pos = w_find_pos(c, WK_MATCH, leaf, score, diag, false, false);
                 if (pos.empty) continue;
                 for (;;) {
+                    const uint32_t off_before = pos.off;
+                    w_match_forward(c, pos);
+                    const bool at_end = w_past_end(c, pos.cur, pos.off);                            // the node is as long as this position needs from here on
                     const WNode node = c.S->nodes[pos.cur];
-                    const bool may_reach_target = node.target_offset >= pos.off && node.target_offset < node.len;
-                    w_match_forward(c, node, pos);
+                    const bool may_reach_target = node.target_offset != W_NO_OFFSET && node.target_offset >= off_before;      // a set target lies inside the node
                     if ((may_reach_target && pos.off >= node.target_offset) || (c.no_to && pos.seq >= c.L)) {
                         const uint32_t overshoot = c.no_to ? 0 : pos.off - node.target_offset;
                         const uint32_t gap_length = (c.L - pos.seq) + overshoot;
@@ -295,7 +332,7 @@ VGK_HD void w_extend(WCtx& c, int32_t score) {                                  
                     }
                     if (w_distance(pos, diag) > c.max_distance) c.max_distance = w_distance(pos, diag);
                     w_update(c, WK_MATCH, score, diag, pos);
-                    if (pos.off < node.len) break;
+                    if (!at_end) break;
                     w_expand_if_necessary(c, pos);
                     if (c.overflow) break;
                     if (pos.cur == pos.origin) {
@@ -359,6 +396,7 @@ VGK_HD void w_next(WCtx& c, int32_t score) {                                    
             if (w_less(subst, ins)) subst = ins;
             if (w_less(subst, del)) subst = del;
             if (!subst.empty) {
+                w_past_end(c, subst.cur, subst.off);                                                 // a target right at the materialised end shows itself
                 if (subst.off == c.S->nodes[subst.cur].target_offset) {
                     const uint32_t gap_length = c.L - subst.seq;
                     w_candidate(c, score + (gap_length ? w_gap_penalty(c, gap_length) : 0), diag, subst.seq, subst.off, subst.cur);
@@ -491,7 +529,7 @@ VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S) {
         for (uint32_t x = c.cand_node;; x = S.nodes[x].parent) { S.chain[n_chain++] = (uint8_t)x; if (x == 0) break; }
         uint32_t ref_len = 0;
         for (uint32_t e = 0; e < n_edits; ++e) if ((S.edits[e] & 3u) != (uint32_t)VGK_WFA_INSERTION) ref_len += S.edits[e] >> 2;
-        const int32_t first_node = S.path_node[S.nodes[0].path_begin];
+        const int32_t first_node = S.path_node[S.nodes[0].path_head];
         const uint32_t first_len = g_len(P.index, first_node);
         const bool drop_first = out.node_offset >= first_len;
         if (drop_first) out.node_offset = 0;
@@ -499,9 +537,9 @@ VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S) {
         uint32_t kept = 0, at = 0, last_start = 0, last_len = 0;       // `at` = start of the current node in the same coordinates
         for (uint32_t k = n_chain; k-- > 0;) {
             const WNode& n = S.nodes[S.chain[k]];
-            for (uint32_t j = 0; j < n.path_len; ++j) {
-                const uint32_t gl = g_len(P.index, S.path_node[n.path_begin + j]);
-                if (k == n_chain - 1 && j == 0 && drop_first) continue;
+            for (uint32_t j = n.path_head; j != W_NIL; j = S.path_next[j]) {
+                const uint32_t gl = g_len(P.index, S.path_node[j]);
+                if (k == n_chain - 1 && j == n.path_head && drop_first) continue;
                 if (kept == 0 || at < used) { ++kept; last_start = at; last_len = gl; }
                 at += gl;
             }
@@ -514,9 +552,9 @@ VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S) {
             uint32_t w = 0;
             for (uint32_t k = n_chain; k-- > 0 && w < kept;) {
                 const WNode& n = S.nodes[S.chain[k]];
-                for (uint32_t j = 0; j < n.path_len && w < kept; ++j) {
-                    if (k == n_chain - 1 && j == 0 && drop_first) continue;
-                    const uint32_t o = (uint32_t)S.path_node[n.path_begin + j];
+                for (uint32_t j = n.path_head; j != W_NIL && w < kept; j = S.path_next[j]) {
+                    if (k == n_chain - 1 && j == n.path_head && drop_first) continue;
+                    const uint32_t o = (uint32_t)S.path_node[j];
                     P.paths[p0 + (flip ? kept - 1 - w : w)] = flip ? (o ^ 1u) : o;
                     ++w;
                 }
@@ -535,6 +573,14 @@ VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S) {
     } else if (c.overflow) { out.status = VGK_ETOOBIG; out.score = c.why; }
     for (uint32_t k = 0; k < c.n_points; ++k) S.slot[S.log[k]] = 0;                                  // leave the table clean
     P.results[i] = out;
+}
+// one resident thread: problems are handed out one at a time
+VGK_HD void wfa_thread(const WfaParams& P, uint32_t t) {
+    for (;;) {
+        const unsigned long long i = g_bump(P.counters + 2, 1);
+        if (i >= P.n) break;
+        wfa_extend_one(P, (uint32_t)i, P.scratch[t]);
+    }
 }
 
 }  // namespace vgk
