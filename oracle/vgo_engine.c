@@ -241,6 +241,9 @@ int vgk_wfa_rerun(vgk_ctx* ctx) { (void)ctx; return VGK_EINVAL; }
 int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_model* model, const vgk_wfa_problem* problems, uint32_t n,
                    vgk_wfa_result* results, uint32_t* paths, size_t path_cap, uint32_t* edits, size_t edit_cap, size_t written[2]) {
     if (!ctx || !index || (!problems && n) || (!results && n)) return VGK_EINVAL;
+    if (model) { const vgk_wfa_event* ev[3] = { &model->mismatches, &model->gaps, &model->gap_length };
+                 for (int k = 0; k < 3; ++k) if (ev[k]->per_base < 0 || ev[k]->min < 0 || ev[k]->max < ev[k]->min) return VGK_EINVAL; }   /* the constructor's asserts (:1262-1270) */
+    if (ctx->sc.matrix[0] < 0 || ctx->sc.matrix[1] >= 0 || ctx->sc.gap_open < ctx->sc.gap_extend || ctx->sc.gap_extend == 0) return VGK_EUNSUPPORTED;   /* (:1256-1259) */
     int32_t** tp = (int32_t**)calloc((size_t)n + 1, sizeof(int32_t*)); uint32_t** te = (uint32_t**)calloc((size_t)n + 1, sizeof(uint32_t*));
     #pragma omp parallel for schedule(dynamic, 64)
     for (uint32_t i = 0; i < n; ++i) vgo_wfa_one(&ctx->sc, index, model, &problems[i], &results[i], &tp[i], &te[i]);

@@ -508,12 +508,15 @@ int vgo_wfa_one(const vgk_scoring* sc, const vgk_haplo* h, const vgk_wfa_error_m
     Out out; memset(&out, 0, sizeof out);
     uint32_t from_node = p->from_node, from_off = p->from_offset, to_node = p->to_node, to_off = p->to_offset;
     if (p->mode == VGK_WFA_PREFIX) {                                                              /* :2248-2263 */
-        if (p->to_node >= h->n_oriented) { free(seq); res->status = VGK_EINVAL; return VGK_EINVAL; }
+        if (p->to_node >= h->n_oriented || p->to_offset >= h->len[p->to_node]) { free(seq); res->status = VGK_EINVAL; return VGK_EINVAL; }
         from_node = p->to_node ^ 1u; from_off = (h->len[p->to_node] - 1) - p->to_offset;          /* reverse_base_pos, types.hpp:89 */
         to_node = VGK_WFA_NO_NODE; to_off = 0;
         for (uint32_t i = 0; i < L; ++i) seq[i] = mask_base(comp_base(p->seq[L - 1 - i]));
     } else {
         if (p->mode == VGK_WFA_SUFFIX) { to_node = VGK_WFA_NO_NODE; to_off = 0; }
+        if ((from_node < h->n_oriented && from_off >= h->len[from_node]) || (to_node < h->n_oriented && to_off >= h->len[to_node])) {
+            free(seq); res->status = VGK_EINVAL; return VGK_EINVAL;                               /* a position past its node */
+        }
         for (uint32_t i = 0; i < L; ++i) seq[i] = mask_base(p->seq[i]);
     }
     const int ok = wfa_connect(sc, h, em, seq, L, from_node, from_off, to_node, to_off, res, &out);

@@ -146,3 +146,40 @@ def test_gssw_align_answers_out_of_range_problems_per_problem(emu_lib):
     # the strict batch API still refuses the whole batch
     with pytest.raises(capi.VgkError):
         eng.pack(ps)
+
+
+def test_wfa_bad_input_limits_and_rerun(emu_lib):
+    import ctypes
+    for lib in (emu_lib, ORACLE_LIB):
+        eng = capi.Engine(lib=lib)
+        index = eng.haplo_index(["ACGTACGTAC", "GGGTTTAAAC"], [[0, 2]])
+        ok = dict(seq="GTACGTACGG", mode="connect", **{"from": (0, 1), "to": (2, 2)})
+        bad_offset = dict(ok, **{"from": (0, 10)})                      # offset past the node
+        no_such_from = dict(seq="ACGT", mode="suffix", **{"from": (99, 0)})   # !has_node(from): an alignment that is not ok (:2059-2064)
+        bad_prefix = dict(seq="ACGT", mode="prefix", to=(99, 0))          # prefix needs the target node's length
+        empty = dict(seq="", mode="connect", **{"from": (0, 8), "to": (2, 1)})
+        res, paths, edits = eng.wfa_extend(index, [ok, bad_offset, no_such_from, bad_prefix, empty, ok])
+        assert list(res["status"]) == [0, -1, 0, -1, 0, 0], lib
+        assert list(res["ok"]) == [1, 0, 0, 0, 1, 1]
+        assert res["score"][0] == 10 and res["score"][5] == 10 and list(paths[:2]) == [0, 2]
+        assert res["score"][4] == -(6 + 1) and res["n_edits"][4] == 1 and int(edits[res["edit_begin"][4]]) == (2 << 2 | capi.WFA_DELETION)
+        # an error model that does not make sense, scoring WFA cannot convert
+        with pytest.raises(capi.VgkError):
+            eng.wfa_extend(index, [ok], ((0.1, 2, 1), (0.05, 1, 10), (0.1, 1, 20), (0.1, 10, 200)))
+        with pytest.raises(capi.VgkError):
+            e2 = capi.Engine(capi.Scoring.simple(1, 4, 1, 2, 5), lib=lib)      # gap_open < gap_extend
+            e2.wfa_extend(e2.haplo_index(["ACGT"], [[0]]), [dict(seq="A", mode="suffix", **{"from": (0, 0)})])
+        # a score cap beyond the kernel's penalty table is refused for that problem only
+        if lib == emu_lib:
+            big = ((1.0, 50, 50), (0.05, 1, 10), (0.1, 1, 20), (0.1, 10, 200))
+            r2, _, _ = eng.wfa_extend(index, [ok], big)
+            assert r2["status"][0] == -7
+            # output arrays too small: VGK_EOPS for the call and the problem that did not fit
+            ws = capi.WfaSet.from_lists([ok, ok]); ws.path_cap = 3; ws.edit_cap = 8
+            r3 = np.zeros(2, dtype=capi.WFA_RESULT_DT); p3 = np.zeros(3, np.uint32); e3 = np.zeros(8, np.uint32); w = (ctypes.c_size_t * 2)()
+            rc = eng.lib.vgk_wfa_extend(eng.h, index.h, None, ws.array.ctypes.data, 2, r3.ctypes.data, p3.ctypes.data, 3, e3.ctypes.data, 8, ctypes.byref(w))
+            assert rc == -6 and list(r3["status"]) == [0, -6] and w[0] == 2
+            eng.wfa_extend(index, [ok, ok]); eng.wfa_rerun(); assert eng.wfa_last_ms() >= 0.0
+        else:
+            with pytest.raises(capi.VgkError):
+                eng.wfa_rerun()                                              # nothing is resident on the CPU

@@ -58,16 +58,18 @@ struct WNode {
     uint32_t ancestors;               // bit per trie node on the way to the root, this node included
 };
 constexpr uint16_t W_NIL = 0xffffu;
-struct WPScore { int16_t min_d, max_d; uint8_t flags, pad; };        // flags: 1 = possible, 2 = reachable with a gap
+struct WPScore { int16_t min_d, max_d; uint8_t flags; };             // flags: 1 = possible, 2 = reachable with a gap
 
 struct WScratch {
     uint64_t slot[W_SLOTS];           // (key + 1) << 32 | seq << 16 | off ; 0 = free
     uint16_t log[W_POINTS];
     WNode    nodes[W_NODES];
+    uint32_t node_end[W_NODES];       // copy of nodes[i].len | complete << 31: what "is this offset past the node's end?" reads
     int32_t  path_node[W_PATH];
     uint16_t path_start[W_PATH];      // offset of the graph node inside its trie node
     uint16_t path_next[W_PATH];
-    WPScore  ps[W_SCORES];
+    uint32_t ps_range[W_SCORES];      // possible penalties: min diagonal | max diagonal << 16 (int16 each) ...
+    uint8_t  ps_flags[W_SCORES];      // ... and flags; only the flags are cleared per problem
     uint32_t edits[W_EDITS];
     uint8_t  chain[W_NODES];
     uint8_t  stack_cur[W_NODES], stack_end[W_NODES];
@@ -95,10 +97,20 @@ struct WCtx {
     const char* seq; uint32_t L;
     int32_t to_node; uint32_t to_off; bool no_to;
     uint32_t n_nodes, n_path, n_points;
+    uint32_t leaves;                  // trie nodes without children (WFANode::is_leaf: a dead end has none either)
     int32_t cand_score, cand_diag; uint32_t cand_seq, cand_off, cand_node;
     int32_t max_distance, min_distance;
     bool overflow; int why;         // why: 1 points, 2 trie nodes, 3 path pool, 4 edits, 5 node length
 };
+
+// ---- possible penalties (the reference's possible_scores map, :1596-1606), direct-mapped by value ----
+VGK_HD WPScore w_ps(const WCtx& c, int32_t score) {
+    WPScore p; p.flags = c.S->ps_flags[score];
+    const uint32_t r = c.S->ps_range[score];
+    p.min_d = (int16_t)(r & 0xffffu); p.max_d = (int16_t)(r >> 16);
+    return p;
+}
+VGK_HD void w_ps_set_range(WCtx& c, int32_t score, int32_t lo, int32_t hi) { c.S->ps_range[score] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
 
 // ---- the wavefront table ----
 // Hashed by (kind, penalty, diagonal) WITHOUT the trie node, so the points every trie node holds for one wavefront cell sit in one
@@ -174,8 +186,9 @@ VGK_HD void w_node_init(WCtx& c, uint32_t id, const WState& state, uint32_t pare
     n.len = 0; n.target_offset = W_NO_OFFSET; n.path_head = n.path_tail = W_NIL;
     n.parent = (uint8_t)parent; n.first_child = 0; n.n_children = 0; n.dead_end = 0; n.pad[0] = n.pad[1] = n.pad[2] = 0;
     n.ancestors = (id ? c.S->nodes[parent].ancestors : 0u) | (1u << id);
+    c.leaves |= 1u << id;
     n.complete = w_append_node(c, n, state) ? 1 : 0;
-    c.S->nodes[id] = n;
+    c.S->nodes[id] = n; c.S->node_end[id] = n.len | ((uint32_t)n.complete << 31);
 }
 // one turn of the constructor's loop (:1470-1487)
 VGK_HD void w_grow(WCtx& c, uint32_t id) {
@@ -188,34 +201,43 @@ VGK_HD void w_grow(WCtx& c, uint32_t id) {
         else if (successors > 1) n.complete = 1;
         else if (w_append_node(c, n, next)) n.complete = 1;
     }
-    c.S->nodes[id] = n;
+    c.S->nodes[id] = n; c.S->node_end[id] = n.len | ((uint32_t)n.complete << 31);
 }
 // is `off` at or past the end of the trie node?  Grows the node until that is known.
 VGK_HD bool w_past_end(WCtx& c, uint32_t id, uint32_t off) {
-    while (!c.S->nodes[id].complete && c.S->nodes[id].len <= off) w_grow(c, id);
-    return off >= c.S->nodes[id].len;
+    uint32_t e = c.S->node_end[id];
+    while (!(e >> 31) && (e & 0x7fffffffu) <= off) { w_grow(c, id); e = c.S->node_end[id]; }
+    return off >= (e & 0x7fffffffu);
 }
-VGK_HD bool w_is_leaf(const WNode& n) { return !n.n_children || n.dead_end; }
-VGK_HD bool w_expanded(const WNode& n) { return n.n_children || n.dead_end; }
 
-VGK_HD void w_pop(const WCtx& c, WPos& p) {                        // one step down the tree path towards the origin
-    uint32_t x = p.origin;
-    while (c.S->nodes[x].parent != p.cur) x = c.S->nodes[x].parent;
-    p.cur = (uint8_t)x;
+VGK_HD void w_pop(const WCtx& c, WPos& p) {                        // one step down the tree path towards the origin:
+    const uint32_t below = c.S->nodes[p.origin].ancestors & ~((2u << p.cur) - 1u);     // the origin's ancestors numbered above the current node;
+    p.cur = (uint8_t)__builtin_ctz(below);                         // trie nodes are numbered in creation order, so the nearest one is the child
 }
 VGK_HD bool w_at_dead_end(WCtx& c, const WPos& p) { return w_past_end(c, p.cur, p.off) && c.S->nodes[p.cur].dead_end; }   // (:2043)
 
-VGK_HD WPos w_find_pos(WCtx& c, int kind, uint32_t node, int32_t score, int32_t diag, bool ext_seq, bool ext_graph) {                 // (:2015-2040)
-    if (score < 0) return w_none();
-    // no point of this penalty was ever stored outside the diagonal range its wavefront ended up with (next :1780-1785, extend :1662)
-    const WPScore ps = c.S->ps[score];
-    if (!(ps.flags & 1) || diag < ps.min_d || diag > ps.max_d) return w_none();
+// A source wavefront: one penalty and the diagonal range its points were stored in.  No point of a penalty was ever stored
+// outside the range its wavefront ended up with (next :1780-1785, extend :1662), so a lookup outside it needs no probe.
+struct WSrc { int32_t score; int32_t lo, hi; };                   // lo > hi: nothing stored
+VGK_HD WSrc w_src(const WCtx& c, int32_t score) {
+    WSrc s = { score, 1, 0 };
+    if (score < 0) return s;
+    const WPScore ps = w_ps(c, score);
+    if (ps.flags & 1) { s.lo = ps.min_d; s.hi = ps.max_d; }
+    return s;
+}
+// WFATree::find_pos (:2015-2040) from a trie node with the given ancestor mask
+VGK_HD WPos w_find_in(WCtx& c, int kind, const WSrc& src, uint32_t ancestors, uint32_t origin, int32_t diag, bool ext_seq, bool ext_graph) {
+    if (diag < src.lo || diag > src.hi) return w_none();
     uint32_t holder, seq, off;
-    if (!w_lookup(c, c.S->nodes[node].ancestors, kind, score, diag, holder, seq, off)) return w_none();
-    WPos p = { seq, off, (uint8_t)holder, (uint8_t)node, false };
+    if (!w_lookup(c, ancestors, kind, src.score, diag, holder, seq, off)) return w_none();
+    WPos p = { seq, off, (uint8_t)holder, (uint8_t)origin, false };
     if (ext_seq && p.seq >= c.L) return w_none();
     if (ext_graph && w_at_dead_end(c, p)) return w_none();
     return p;
+}
+VGK_HD WPos w_find_pos(WCtx& c, int kind, uint32_t node, int32_t score, int32_t diag, bool ext_seq, bool ext_graph) {
+    return w_find_in(c, kind, w_src(c, score), c.S->nodes[node].ancestors, node, diag, ext_seq, ext_graph);
 }
 VGK_HD void w_update(WCtx& c, int kind, int32_t score, int32_t diag, const WPos& p) { w_store(c, p.cur, kind, score, diag, p.seq, p.off); }
 
@@ -230,6 +252,17 @@ VGK_HD WPos w_del_predecessor(WCtx& c, uint32_t node, int32_t score, int32_t dia
     const WPos ext = w_find_pos(c, WK_DEL, node, score - c.P->gap_extend, diag + 1, false, true);
     if (w_less(open, ext)) { edit = VGK_WFA_DELETION; return ext; }
     edit = VGK_WFA_MATCH; return open;
+}
+// the same two with the source wavefronts and the leaf's ancestor mask already loaded (they do not change inside next())
+VGK_HD WPos w_ins_source(WCtx& c, const WSrc& open_src, const WSrc& ext_src, uint32_t anc, uint32_t leaf, int32_t diag) {
+    const WPos open = w_find_in(c, WK_MATCH, open_src, anc, leaf, diag - 1, true, false);
+    const WPos ext = w_find_in(c, WK_INS, ext_src, anc, leaf, diag - 1, true, false);
+    return w_less(open, ext) ? ext : open;
+}
+VGK_HD WPos w_del_source(WCtx& c, const WSrc& open_src, const WSrc& ext_src, uint32_t anc, uint32_t leaf, int32_t diag) {
+    const WPos open = w_find_in(c, WK_MATCH, open_src, anc, leaf, diag + 1, false, true);
+    const WPos ext = w_find_in(c, WK_DEL, ext_src, anc, leaf, diag + 1, false, true);
+    return w_less(open, ext) ? ext : open;
 }
 VGK_HD WPos w_match_predecessor(WCtx& c, uint32_t node, int32_t score, int32_t diag, int& edit) {                             // (:1809-1823)
     const WPos ins = w_find_pos(c, WK_INS, node, score, diag, false, false);
@@ -249,7 +282,7 @@ VGK_HD void w_successor_offset(WCtx& c, WPos& p) {                              
 }
 VGK_HD void w_predecessor_offset(const WCtx& c, uint32_t& node, uint32_t& off) {                  // (:1835-1842)
     if (off > 0) --off;
-    else { node = c.S->nodes[node].parent; off = c.S->nodes[node].len - 1; }
+    else { node = c.S->nodes[node].parent; off = (c.S->node_end[node] & 0x7fffffffu) - 1; }
 }
 
 VGK_HD void w_expand_if_necessary(WCtx& c, const WPos& p) {                                       // (:1992-2008)
@@ -261,6 +294,7 @@ VGK_HD void w_expand_if_necessary(WCtx& c, const WPos& p) {                     
     if (!k) { c.S->nodes[node].dead_end = 1; return; }
     if (c.n_nodes + k > (uint32_t)W_NODES) { c.overflow = true; c.why = 2; return; }
     c.S->nodes[node].first_child = (uint8_t)c.n_nodes; c.S->nodes[node].n_children = (uint8_t)k;
+    c.leaves &= ~(1u << node);
     for (uint32_t i = 0; i < k; ++i) {
         if (i) w_follow(c.P->index, st, i, next, i + 1);
         w_node_init(c, c.n_nodes, next, node); ++c.n_nodes;
@@ -269,12 +303,6 @@ VGK_HD void w_expand_if_necessary(WCtx& c, const WPos& p) {                     
 }
 
 VGK_HD int32_t w_gap_penalty(const WCtx& c, uint32_t length) { return c.P->gap_open + (int32_t)length * c.P->gap_extend; }          // (:1649)
-
-VGK_HD uint32_t w_leaves(const WCtx& c) {
-    uint32_t m = 0;
-    for (uint32_t i = 0; i < c.n_nodes; ++i) if (w_is_leaf(c.S->nodes[i])) m |= 1u << i;
-    return m;
-}
 
 // WFANode::match_forward (:1533-1542) on the bases of the trie node's path, eight per compare; the node grows as the match runs into its end
 VGK_HD void w_match_forward(WCtx& c, WPos& p) {
@@ -306,10 +334,11 @@ VGK_HD void w_candidate(WCtx& c, int32_t score, int32_t diag, uint32_t seq, uint
 }
 
 VGK_HD void w_extend(WCtx& c, int32_t score) {                                                    // (:1656-1666, :1874-1935)
-    const WPScore ps = c.S->ps[score];
+    const WPScore ps = w_ps(c, score);
     if (!(ps.flags & 1)) return;
+    const WSrc here = { score, ps.min_d, ps.max_d };
     for (int32_t diag = ps.min_d; diag <= ps.max_d && !c.overflow; ++diag) {
-        const uint32_t leaves = w_leaves(c);
+        const uint32_t leaves = c.leaves;
         for (uint32_t top = 0; top < c.n_nodes && !c.overflow; ++top) {
             if (!(leaves >> top & 1)) continue;
             uint32_t sp = 0;
@@ -317,18 +346,18 @@ VGK_HD void w_extend(WCtx& c, int32_t score) {                                  
             while (sp && !c.overflow) {
                 if (c.S->stack_cur[sp - 1] == c.S->stack_end[sp - 1]) { --sp; continue; }
                 const uint32_t leaf = c.S->stack_cur[sp - 1]++;
-                WPos pos = w_find_pos(c, WK_MATCH, leaf, score, diag, false, false);
+                WPos pos = w_find_in(c, WK_MATCH, here, c.S->nodes[leaf].ancestors, leaf, diag, false, false);
                 if (pos.empty) continue;
                 for (;;) {
                     const uint32_t off_before = pos.off;
                     w_match_forward(c, pos);
                     const bool at_end = w_past_end(c, pos.cur, pos.off);                            // the node is as long as this position needs from here on
-                    const WNode node = c.S->nodes[pos.cur];
-                    const bool may_reach_target = node.target_offset != W_NO_OFFSET && node.target_offset >= off_before;      // a set target lies inside the node
-                    if ((may_reach_target && pos.off >= node.target_offset) || (c.no_to && pos.seq >= c.L)) {
-                        const uint32_t overshoot = c.no_to ? 0 : pos.off - node.target_offset;
+                    const uint32_t target_offset = c.no_to ? W_NO_OFFSET : c.S->nodes[pos.cur].target_offset;
+                    const bool may_reach_target = target_offset != W_NO_OFFSET && target_offset >= off_before;      // a set target lies inside the node
+                    if ((may_reach_target && pos.off >= target_offset) || (c.no_to && pos.seq >= c.L)) {
+                        const uint32_t overshoot = c.no_to ? 0 : pos.off - target_offset;
                         const uint32_t gap_length = (c.L - pos.seq) + overshoot;
-                        w_candidate(c, score + (gap_length ? w_gap_penalty(c, gap_length) : 0), diag, pos.seq - overshoot, node.target_offset, pos.cur);
+                        w_candidate(c, score + (gap_length ? w_gap_penalty(c, gap_length) : 0), diag, pos.seq - overshoot, target_offset, pos.cur);
                     }
                     if (w_distance(pos, diag) > c.max_distance) c.max_distance = w_distance(pos, diag);
                     w_update(c, WK_MATCH, score, diag, pos);
@@ -348,21 +377,21 @@ VGK_HD void w_extend(WCtx& c, int32_t score) {                                  
 }
 
 VGK_HD void w_mark(WCtx& c, int32_t score, bool gap) {                                            // possible_scores[...] of next_score
-    WPScore& p = c.S->ps[score];
-    if (!(p.flags & 1)) { p.min_d = 0; p.max_d = 0; p.flags = (uint8_t)(1 | (gap ? 2 : 0)); }
-    else if (gap) p.flags |= 2;
+    const uint8_t f = c.S->ps_flags[score];
+    if (!(f & 1)) { w_ps_set_range(c, score, 0, 0); c.S->ps_flags[score] = (uint8_t)(1 | (gap ? 2 : 0)); }
+    else if (gap && !(f & 2)) c.S->ps_flags[score] = (uint8_t)(f | 2);
 }
 VGK_HD int32_t w_next_score(WCtx& c, int32_t match_score) {                                       // (:1672-1704)
     w_mark(c, match_score + c.P->mismatch, false);
-    if (c.S->ps[match_score].flags & 2) w_mark(c, match_score + c.P->gap_extend, true);
+    if (c.S->ps_flags[match_score] & 2) w_mark(c, match_score + c.P->gap_extend, true);
     w_mark(c, match_score + c.P->gap_open + c.P->gap_extend, true);
     int32_t s = match_score + 1;
-    while (!(c.S->ps[s].flags & 1)) ++s;
+    while (!(c.S->ps_flags[s] & 1)) ++s;
     return s;
 }
 VGK_HD void w_range(const WCtx& c, int32_t& lo, int32_t& hi, int32_t score) {                     // (:1956-1968)
     if (score < 0) return;
-    const WPScore p = c.S->ps[score];
+    const WPScore p = w_ps(c, score);
     if (!(p.flags & 1)) return;
     if (p.min_d < lo) lo = p.min_d;
     if (p.max_d > hi) hi = p.max_d;
@@ -375,29 +404,30 @@ VGK_HD void w_next(WCtx& c, int32_t score) {                                    
     w_range(c, lo, hi, score - c.P->gap_extend);
     if (lo <= hi) { --lo; ++hi; }
     int32_t alo = 32767, ahi = -32768;
+    const WSrc src_mismatch = w_src(c, score - c.P->mismatch), src_open = w_src(c, score - c.P->gap_open - c.P->gap_extend), src_extend = w_src(c, score - c.P->gap_extend);
     for (int32_t diag = lo; diag <= hi && !c.overflow; ++diag) {
-        const uint32_t leaves = w_leaves(c);
+        const uint32_t leaves = c.leaves;
         for (uint32_t leaf = 0; leaf < (uint32_t)W_NODES && (leaves >> leaf) && !c.overflow; ++leaf) {
             if (!(leaves >> leaf & 1)) continue;
-            int edit;
-            WPos ins = w_ins_predecessor(c, leaf, score, diag, edit);
+            const uint32_t anc = c.S->nodes[leaf].ancestors;
+            WPos ins = w_ins_source(c, src_open, src_extend, anc, leaf, diag);
             if (!ins.empty) {
                 ins.seq++;
                 if (w_distance(ins, diag) >= c.min_distance) { w_update(c, WK_INS, score, diag, ins); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
             }
-            WPos del = w_del_predecessor(c, leaf, score, diag, edit);
+            WPos del = w_del_source(c, src_open, src_extend, anc, leaf, diag);
             if (!del.empty) {
                 w_successor_offset(c, del);
                 if (w_distance(del, diag) >= c.min_distance) { w_update(c, WK_DEL, score, diag, del); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
                 w_expand_if_necessary(c, del);
             }
-            WPos subst = w_find_pos(c, WK_MATCH, leaf, score - c.P->mismatch, diag, true, true);
+            WPos subst = w_find_in(c, WK_MATCH, src_mismatch, anc, leaf, diag, true, true);
             if (!subst.empty) { subst.seq++; w_successor_offset(c, subst); w_expand_if_necessary(c, subst); }
             if (w_less(subst, ins)) subst = ins;
             if (w_less(subst, del)) subst = del;
             if (!subst.empty) {
-                w_past_end(c, subst.cur, subst.off);                                                 // a target right at the materialised end shows itself
-                if (subst.off == c.S->nodes[subst.cur].target_offset) {
+                if (!c.no_to) w_past_end(c, subst.cur, subst.off);                                   // a target right at the materialised end shows itself
+                if (!c.no_to && subst.off == c.S->nodes[subst.cur].target_offset) {
                     const uint32_t gap_length = c.L - subst.seq;
                     w_candidate(c, score + (gap_length ? w_gap_penalty(c, gap_length) : 0), diag, subst.seq, subst.off, subst.cur);
                 }
@@ -405,8 +435,7 @@ VGK_HD void w_next(WCtx& c, int32_t score) {                                    
             }
         }
     }
-    WPScore& p = c.S->ps[score];
-    if (p.flags & 1) { p.min_d = (int16_t)alo; p.max_d = (int16_t)ahi; }
+    if (c.S->ps_flags[score] & 1) w_ps_set_range(c, score, alo, ahi);
 }
 
 VGK_HD int32_t w_alignment_score(const WCtx& c, int32_t score, int32_t diag, uint32_t seq, uint32_t final_insertion) {              // (:1380-1387)
@@ -451,11 +480,11 @@ VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S) {
     WCtx c;
     c.P = &P; c.S = &S; c.seq = P.seqs + pb.seq_off; c.L = pb.seq_len;
     c.no_to = pb.to_node == VGK_WFA_NO_NODE; c.to_node = (int32_t)pb.to_node; c.to_off = pb.to_off;
-    c.n_nodes = 0; c.n_path = 0; c.n_points = 0; c.overflow = false; c.why = 0;
+    c.n_nodes = 0; c.n_path = 0; c.n_points = 0; c.leaves = 0; c.overflow = false; c.why = 0;
     c.cand_score = 0x7fffffff; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0;
     c.max_distance = 0; c.min_distance = 0;
     const int32_t top_score = pb.score_bound + P.gap_open + P.gap_extend + P.mismatch;               // the host keeps this below W_SCORES
-    for (int32_t s = 0; s <= top_score && s < W_SCORES; ++s) { WPScore z = { 0, 0, 0, 0 }; S.ps[s] = z; }
+    for (int32_t s = 0; s <= top_score && s < W_SCORES; s += 8) { uint64_t z = 0; __builtin_memcpy(S.ps_flags + s, &z, 8); }   // W_SCORES is a multiple of 8
     const WState root = { (int32_t)pb.from_node, 0, (int32_t)g_rec(P.index, pb.from_node)[0] - 1 };
     w_node_init(c, 0, root, 0); c.n_nodes = 1;
     w_store(c, 0, WK_MATCH, 0, 0, 0, pb.from_off + 1);
