@@ -14,9 +14,14 @@
  *                   replaces  dz_init / dz_pack_query_* / dz_extend / dz_trace
  *                             as driven by DozeuInterface::align_pinned
  *                             (src/dozeu_interface.cpp:210-307, 687-766)
- *   (planned, not in this ABI version: banded global alignment replacing
- *    BandedGlobalAligner<IntType>::align, gapless extension replacing
- *    GaplessExtender::match_*)
+ *   vgk_banded_*    replaces  BandedGlobalAligner<IntType>(...).align(...) as driven by
+ *                             Aligner::align_global_banded / _multi
+ *                             (src/aligner.cpp:662-760, src/banded_global_aligner.cpp:250-742)
+ *   vgk_haplo_*, vgk_gapless_extend
+ *                   replaces  GaplessExtender::extend over a GBWTGraph
+ *                             (src/gbwt_extender.cpp:533-737)
+ *   vgk_wfa_extend  replaces  WFAExtender::connect / prefix / suffix
+ *                             (src/gbwt_extender.cpp:2052-2263)
  *
  * Everything is plain pointers and sizes.  All "graphs" handed over are DAGs
  * whose nodes are ALREADY in the topological order the reference would use
