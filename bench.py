@@ -24,6 +24,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+# HBM bytes per unit of work of the dominant kernel, from the PMC passes committed under profiles/r01 (rocprofv3 --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE in separate runs of this very command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py
+# cannot read counters itself, so `roofline.traffic` = this figure x the units of one launch; re-measure with tools/prof_*.sh.
+PMC_BYTES_PER_UNIT = {
+    "linear": (2 * 700895 + 13686638) * 1024 / 400000,      # pmc_{FETCH,WRITE}_SIZE_400k.csv: gssw_fill_kernel, 400 000 reads
+    "banded": (2 * 389251 + 2244533) * 1024 / 100000,        # pmc_*_banded_100k.csv: the three banded_fill_kernel classes, 100 000 problems
+    "gapless": (2 * 24365259 + 6277288) * 1024 / 1000000,    # pmc_*_gapless_1M.csv: gapless_kernel, 1 000 000 reads
+    "wfa": (2 * 4813000 + 1975000) * 1024 / 500000,          # pmc_*_wfa_500k.csv: wfa_kernel, 500 000 problems
+}
+
 
 def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
     """giraffe's gapless-extension stage (secondary line).  One vgk_gapless_extend call packs the batch, moves it to HBM, runs the kernel
@@ -82,7 +92,7 @@ def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
                        "end_to_end_from_host_buffers_reads_per_s": n / te, "parallelism": "read-sharded x%d" % world,
                        "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "kernel": "gapless_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["gapless"] * n, "traffic_source": "rocprofv3 PMC passes in profiles/r01, scaled by reads", "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
                          "kernel_only_reads_per_s": n / (k * 1e-3)},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum()),
             "full_length_fraction": float(res["full_length"].mean())}))
@@ -156,7 +166,7 @@ def bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus):
                        "end_to_end_from_host_buffers_alignments_per_s": n / te, "parallelism": "problem-sharded x%d" % world,
                        "device": dev_name, "compute_units": cus, "sequence_bases": wl.bases},
             "roofline": {"bound": "hbm", "kernel": "wfa_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["wfa"] * n, "traffic_source": "rocprofv3 PMC passes in profiles/r01, scaled by problems", "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
                          "kernel_only_alignments_per_s": n / (k * 1e-3)},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum()),
             "aligned_fraction": float(res["ok"].mean())}))
@@ -224,7 +234,7 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
                        "end_to_end_from_host_buffers_alignments_per_s": n / te,
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "kernel": "banded_fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": fill,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["banded"] * n, "traffic_source": "rocprofv3 PMC passes in profiles/r01, scaled by problems", "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": fill,
                          "traceback_ms": walk, "band_cells": cells, "gcups_fill": cells / (fill * 1e-3) / 1e9,
                          "kernel_only_alignments_per_s": n / ((fill + walk) * 1e-3)},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum())}))
@@ -372,7 +382,9 @@ def main():
                        "reads_per_gpu_per_step": args.reads, "parallelism": "read-sharded x%d" % world,
                        "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "kernel": "gssw_fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None if tails else PMC_BYTES_PER_UNIT["linear"] * args.reads / n_launch,
+                         "traffic_source": None if tails else "rocprofv3 PMC passes in profiles/r01, scaled by reads",
                          "alg_bytes_per_launch": alg_bytes / n_launch, "avg_launch_ms": fill_avg,
                          "launches_per_step": n_launch,
                          "traceback_tail_ms": sum(walk_ms) / len(walk_ms),
