@@ -323,7 +323,7 @@ def main():
         elapsed = float(t.item())
 
     # results of the last step: parity spot-check against the oracle + exact algorithmic bytes
-    res, ops = batch.fetch()
+    tf = time.perf_counter(); res, ops = batch.fetch(); t_fetch = time.perf_counter() - tf
     alg_bytes = batch.alg_bytes()
     cells = batch.cells()
     dev_bytes = batch.device_bytes()
@@ -393,7 +393,9 @@ def main():
             "parity": parity,
             "problems_failed": n_bad,
             "hbm_footprint_bytes": dev_bytes,
-            "pack_seconds": t_pack,
+            "pack_seconds": t_pack, "fetch_seconds": t_fetch,
+            # one batch from host buffers: pack (validate + encode + H2D) + one run + fetch (D2H of results and CIGAR ops)
+            "end_to_end_from_host_buffers_per_s": args.reads / (t_pack + 1e-3 * elapsed / args.steps + t_fetch),
         }
         print(json.dumps(out))
     if dist is not None:

@@ -79,6 +79,8 @@ public:
     size_t memory_bytes() const override { return 0; }
     void* alloc(size_t bytes) override { return std::calloc(bytes ? bytes : 16, 1); }
     void release(void* p) override { std::free(p); }
+    void* host_alloc(size_t bytes) override { return std::malloc(bytes ? bytes : 16); }
+    void host_release(void* p) override { std::free(p); }
     int upload(void* d, const void* s, size_t n) override { std::memcpy(d, s, n); return VGK_OK; }
     int download(void* d, const void* s, size_t n) override { std::memcpy(d, s, n); return VGK_OK; }
     int zero(void* d, size_t n) override { std::memset(d, 0, n); return VGK_OK; }

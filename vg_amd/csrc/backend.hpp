@@ -25,6 +25,8 @@ public:
     virtual size_t memory_bytes() const = 0;
     virtual void* alloc(size_t bytes) = 0;                 // device memory (nullptr on failure)
     virtual void  release(void* p) = 0;
+    virtual void* host_alloc(size_t bytes) = 0;            // page-locked host staging memory (uninitialised; nullptr on failure)
+    virtual void  host_release(void* p) = 0;
     virtual int   upload(void* dst, const void* src, size_t bytes) = 0;     // async on the stream
     virtual int   download(void* dst, const void* src, size_t bytes) = 0;   // synchronous
     virtual int   zero(void* dst, size_t bytes) = 0;                        // async on the stream

@@ -171,6 +171,13 @@ public:
         return p;
     }
     void release(void* p) override { if (p) { hipSetDevice(dev); hipFree(p); } }
+    void* host_alloc(size_t bytes) override {
+        hipSetDevice(dev);
+        void* p = nullptr;
+        if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return nullptr;
+        return p;
+    }
+    void host_release(void* p) override { if (p) { hipSetDevice(dev); hipHostFree(p); } }
     int upload(void* dst, const void* src, size_t bytes) override {
         hipSetDevice(dev);
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream) == hipSuccess ? VGK_OK : VGK_ENODEV;

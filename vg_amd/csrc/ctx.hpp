@@ -34,6 +34,25 @@ struct vgk_ctx {
         if (!b.p) { b.p = be->alloc(bytes); b.bytes = b.p ? bytes : 0; }
         return b.p;
     }
+    // page-locked staging arenas of vgk_gssw_pack, handed out per pack (callers may pack concurrently) and kept for the next one
+    struct Staging {
+        vgk::Backend* be = nullptr; void* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; uint64_t bytes[5] = {0, 0, 0, 0, 0};
+        void* get(int k, uint64_t want) {
+            if (bytes[k] >= want) return p[k];
+            if (p[k]) be->host_release(p[k]);
+            bytes[k] = want + want / 4 + 4096; p[k] = be->host_alloc(bytes[k]);
+            if (!p[k]) bytes[k] = 0;
+            return p[k];
+        }
+        ~Staging() { for (void* q : p) if (q) be->host_release(q); }
+    };
+    std::mutex staging_mu; std::vector<std::unique_ptr<Staging>> staging_free;
+    std::unique_ptr<Staging> staging_acquire() {
+        std::lock_guard<std::mutex> lock(staging_mu);
+        if (staging_free.empty()) { auto s = std::make_unique<Staging>(); s->be = be.get(); return s; }
+        auto s = std::move(staging_free.back()); staging_free.pop_back(); return s;
+    }
+    void staging_release(std::unique_ptr<Staging> s) { std::lock_guard<std::mutex> lock(staging_mu); if (staging_free.size() < 4) staging_free.push_back(std::move(s)); }
     std::shared_ptr<void> banded_host;      // host staging arenas of banded_api.cpp
     std::shared_ptr<void> gapless_host;     // and of gapless_api.cpp
     std::shared_ptr<void> wfa_host;         // and of wfa_api.cpp

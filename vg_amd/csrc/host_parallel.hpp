@@ -8,11 +8,11 @@
 
 namespace vgk {
 
-constexpr unsigned MAX_THREADS = 32;
+constexpr unsigned MAX_THREADS = 128;
 // run f(i, thread) for i in [0, n) on a few host threads
 template <class F> inline void parallel_for(uint32_t n, F f) {
     unsigned hw = std::thread::hardware_concurrency();
-    unsigned T = std::min<unsigned>(hw ? hw : 1, MAX_THREADS);
+    unsigned T = std::min<unsigned>(hw ? hw : 1, 32u);
     if (const char* e = std::getenv("VGAMD_HOST_THREADS")) T = (unsigned)std::min<int>(MAX_THREADS, std::max(1, std::atoi(e)));
     if (n < 256 || T <= 1) { for (uint32_t i = 0; i < n; ++i) f(i, 0u); return; }
     std::atomic<uint32_t> next{0};

@@ -6,6 +6,8 @@
 // unordered_map — but emits flat arrays: a per-column info byte stream (base code +
 // node-boundary flags), a node table, a predecessor CSR and a per-read descriptor.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -50,6 +52,16 @@ static int to_device(vgk_batch* b, const std::vector<T>& v, const T*& out, size_
     return VGK_OK;
 }
 
+template <class T>
+static int to_device(vgk_batch* b, const T* v, size_t count, const T*& out, size_t extra = 0) {      // from a staging arena
+    const size_t bytes = (count + extra) * sizeof(T);
+    void* p = b->ctx->be->alloc(bytes);
+    if (!p) return VGK_ENOMEM;
+    b->dev.push_back(p); b->dev_bytes += bytes;
+    if (count) { int rc = b->ctx->be->upload(p, v, count * sizeof(T)); if (rc) return rc; }
+    out = (const T*)p;
+    return VGK_OK;
+}
 template <class T>
 static int dev_alloc(vgk_batch* b, size_t count, T*& out) {
     void* p = b->ctx->be->alloc(count * sizeof(T));
@@ -172,6 +184,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
 
     // Three passes over the problems, the first and the last on host threads: (1) validate and size every problem, (2) prefix sums
     // place it in the shared arenas, (3) encode it at its offsets.
+    auto T0 = std::chrono::steady_clock::now(); auto lap = [&](const char* w) { if (std::getenv("VGAMD_TIMING")) { auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "[pack] %s %.1f ms\n", w, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
     std::vector<ProbDesc>& probs = b->probs;
     probs.resize(n);
     struct Sizes { uint32_t reads = 0, prof = 0, cols = 0, nodes = 0, preds = 0; int status = VGK_OK; bool want_tb = false; };
@@ -242,10 +255,18 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         b->cells += (uint64_t)d.R * d.L;
         b->in_bytes += (uint64_t)problems[i].read_len + d.R + 8ull * z.nodes + 4ull * z.preds;
     }
-    std::vector<uint8_t> colinfo(n_cols + 8, (uint8_t)CI_INVALID), reads(n_reads);     // + 8: leaders prefetch one word ahead
-    std::vector<uint32_t> prof(n_prof);
-    std::vector<NodeRec> nodes(n_nodes);
-    std::vector<uint32_t> preds(n_preds);
+    // the shared arenas are page-locked staging buffers kept on the context: no zero-fill, no page faults, full-rate DMA
+    struct StagingLease {
+        vgk_ctx* ctx; std::unique_ptr<vgk_ctx::Staging> s;
+        ~StagingLease() { if (s) ctx->staging_release(std::move(s)); }
+    } lease{ctx, ctx->staging_acquire()};
+    uint8_t* colinfo = (uint8_t*)lease.s->get(0, n_cols + 8);            // + 8: leaders prefetch one word ahead
+    uint8_t* reads = (uint8_t*)lease.s->get(1, n_reads + 8);
+    uint32_t* prof = (uint32_t*)lease.s->get(2, sizeof(uint32_t) * (n_prof + 4));
+    NodeRec* nodes = (NodeRec*)lease.s->get(3, sizeof(NodeRec) * (n_nodes + 1));
+    uint32_t* preds = (uint32_t*)lease.s->get(4, sizeof(uint32_t) * (n_preds + 1));
+    if (!colinfo || !reads || !prof || !nodes || !preds) return VGK_ENOMEM;
+    std::memset(colinfo + n_cols, CI_INVALID, 8);
     {   // pred_begin is an offset into the shared predecessor arena
         uint64_t at = 0;
         for (uint32_t i = 0; i < n; ++i) { sizes[i].preds = (uint32_t)at; at += problems[i].graph.pred_off[problems[i].graph.n_nodes] - problems[i].graph.pred_off[0]; }
@@ -255,12 +276,12 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         const vgk_graph& g = p.graph;
         const ProbDesc& d = probs[i];
         const uint32_t mode = p.flags & 15u; const bool xdrop = mode == VGK_XDROP_PINNED;
-        uint8_t* rd = reads.data() + d.read_off;
+        uint8_t* rd = reads + d.read_off;
         if (xdrop) *rd++ = 5;                                  // row 0 = no read base consumed yet
         for (uint32_t r = 0; r < p.read_len; ++r) rd[r] = (uint8_t)nt_read(p.read[r]);
         if (ctx->has_qa) {
             const uint32_t S = ctx->scale;
-            uint32_t* pf = prof.data() + d.prof_off;
+            uint32_t* pf = prof + d.prof_off;
             if (xdrop) *pf++ = 0;                              // row 0 = nothing consumed
             for (uint32_t r = 0; r < p.read_len; ++r) {
                 const int code = nt_read(p.read[r]);
@@ -274,9 +295,9 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         }
         Flags& f = thread_flags[t];
         node_flags(p, xdrop, mode, f);
-        uint8_t* ci_out = colinfo.data() + d.col_off;
-        NodeRec* nrs = nodes.data() + d.node_off;
-        uint32_t* pr = preds.data() + sizes[i].preds;
+        uint8_t* ci_out = colinfo + d.col_off;
+        NodeRec* nrs = nodes + d.node_off;
+        uint32_t* pr = preds + sizes[i].preds;
         uint32_t col = 0, slots = 0, seq_pos = 0, np = 0;
         for (uint32_t v = 0; v < g.n_nodes; ++v) {
             NodeRec nr;
@@ -294,16 +315,19 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
             }
             col = nr.col_end;
         }
+        for (uint32_t c = d.col_off + col; c & 3u; ++c) colinfo[c] = (uint8_t)CI_INVALID;      // pad to the next problem's dword
     });
 
     // ---- length buckets: reads with the same (K, G) geometry share wavefronts; inside a bucket reads are sorted by
     //      graph size so that the pairs of a wavefront finish together.  One fill launch per K; G is per wavefront.
+    lap("pass3");
     auto gkey = [&](uint32_t i) { return ((probs[i].geom & 0xffu) << 8) | ((probs[i].geom >> 8) & 0xffu); };   // (K, G)
     std::vector<uint32_t> idx(n);
     for (uint32_t i = 0; i < n; ++i) idx[i] = i;
     std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
         if (gkey(x) != gkey(y)) return gkey(x) < gkey(y);
         return probs[x].R > probs[y].R; });
+    lap("sort");
     std::vector<uint32_t> order;              // pairs
     std::vector<WaveDesc> waves;
     std::vector<FillLaunch>& launches = b->launches;
@@ -341,24 +365,27 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     }
     const uint32_t n_pairs = (uint32_t)(order.size() / 2), n_waves = (uint32_t)waves.size();
 
+    lap("waves");
     std::lock_guard<std::mutex> lk(ctx->mu);
     GsswParams& P = b->P;
     int rc;
     // on failure release whatever was allocated (vgk_batch_free takes the context lock itself)
     auto fail = [&](int code) { vgk_batch* t = hb.release(); ctx->mu.unlock(); vgk_batch_free(t); ctx->mu.lock(); return code; };
     if ((rc = to_device(b, probs, P.probs))) return fail(rc);
-    if ((rc = to_device(b, colinfo, P.colinfo))) return fail(rc);
-    if ((rc = to_device(b, reads, P.reads, 8))) return fail(rc);
-    if ((rc = to_device(b, prof, P.prof, 4))) return fail(rc);
-    if ((rc = to_device(b, nodes, P.nodes))) return fail(rc);
-    if ((rc = to_device(b, preds, P.preds, 1))) return fail(rc);
+    if ((rc = to_device(b, colinfo, n_cols + 8, P.colinfo))) return fail(rc);
+    if ((rc = to_device(b, reads, n_reads, P.reads, 8))) return fail(rc);
+    if ((rc = to_device(b, prof, n_prof, P.prof, 4))) return fail(rc);
+    if ((rc = to_device(b, nodes, n_nodes, P.nodes))) return fail(rc);
+    if ((rc = to_device(b, preds, n_preds, P.preds, 1))) return fail(rc);
     if ((rc = to_device(b, waves, P.waves))) return fail(rc);
     if ((rc = to_device(b, order, P.order, 2))) return fail(rc);
+    lap("uploads");
     if ((rc = dev_alloc(b, (size_t)scratch_words + 16, P.scratch))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)tb_dwords + 4, P.tb))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)n + 1, P.best))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)n + 1, P.results))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)ops_total + 1, P.ops))) return fail(rc);
+    lap("allocs");
     P.wave_begin = 0; P.wave_count = 0; P.K = 0;                 // set per fill launch from b->launches
     P.n_problems = n; P.n_pairs = n_pairs; P.n_waves = n_waves;
     const uint32_t S = ctx->scale;     // 8 whenever the scaled profile bytes still fit (vg's default 1/4/6/1/5 does)
@@ -371,6 +398,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = ops_total;
     if ((rc = ctx->be->sync())) return fail(rc);     // inputs are resident in HBM when pack returns
+    lap("sync");
     *out = hb.release();
     return VGK_OK;
 }
