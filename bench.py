@@ -395,7 +395,7 @@ def main():
             "hbm_footprint_bytes": dev_bytes,
             "pack_seconds": t_pack, "fetch_seconds": t_fetch,
             # one batch from host buffers: pack (validate + encode + H2D) + one run + fetch (D2H of results and CIGAR ops)
-            "end_to_end_from_host_buffers_per_s": args.reads / (t_pack + 1e-3 * elapsed / args.steps + t_fetch),
+            "end_to_end_from_host_buffers_per_s": args.reads / (t_pack + elapsed / args.steps + t_fetch),
         }
         print(json.dumps(out))
     if dist is not None:
