@@ -218,11 +218,6 @@ template <class T> int stage(vgk_ctx* ctx, int slot, const T* v, size_t count, c
     return VGK_OK;
 }
 // host arenas kept on the context between calls: uninitialised storage, so a warm call neither zero-fills nor page-faults
-template <class T> struct RawBuf {
-    T* p = nullptr; size_t cap = 0;
-    T* get(size_t n) { if (n > cap) { std::free(p); cap = n + n / 4 + 64; p = (T*)std::malloc(cap * sizeof(T)); } return p; }
-    ~RawBuf() { std::free(p); }
-};
 struct HostArenas {
     RawBuf<BProb> probs; RawBuf<BNode> nodes; RawBuf<BSeed> seeds; RawBuf<uint32_t> pool, order; RawBuf<BStart> starts;
     RawBuf<uint8_t> reads, quals, graph; RawBuf<BResult> dres; RawBuf<vgk_op> dops; RawBuf<int32_t> scores;

@@ -18,12 +18,6 @@ using namespace vgk;
 
 namespace {
 
-// host staging kept on the context between calls: uninitialised storage, so a warm call neither zero-fills nor page-faults
-template <class T> struct RawBuf {
-    T* p = nullptr; size_t cap = 0;
-    T* get(size_t n) { if (n > cap) { std::free(p); cap = n + n / 4 + 64; p = (T*)std::malloc(cap * sizeof(T)); } return p; }
-    ~RawBuf() { std::free(p); }
-};
 struct GaplessHost { RawBuf<char> reads; RawBuf<vgk_seed> seeds; RawBuf<vgk_gapless_result> dres; RawBuf<vgk_extension> dext; RawBuf<uint32_t> dnodes, dmism; };
 
 char complement(char c) {

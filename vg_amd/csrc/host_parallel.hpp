@@ -23,5 +23,11 @@ template <class F> inline void parallel_for(uint32_t n, F f) {
     for (auto& t : ts) t.join();
 }
 
+// host staging kept on the context between calls: uninitialised storage, so a warm call neither zero-fills nor page-faults
+template <class T> struct RawBuf {
+    T* p = nullptr; size_t cap = 0;
+    T* get(size_t n) { if (n > cap) { std::free(p); cap = n + n / 4 + 64; p = (T*)std::malloc(cap * sizeof(T)); } return p; }
+    ~RawBuf() { std::free(p); }
+};
 
 }  // namespace vgk

@@ -16,11 +16,6 @@ using namespace vgk;
 
 namespace {
 
-template <class T> struct RawBuf {
-    T* p = nullptr; size_t cap = 0;
-    T* get(size_t n) { if (n > cap) { std::free(p); cap = n + n / 4 + 64; p = (T*)std::malloc(cap * sizeof(T)); } return p; }
-    ~RawBuf() { std::free(p); }
-};
 struct WfaHost { RawBuf<char> seqs; RawBuf<WProb> probs; RawBuf<vgk_wfa_result> dres; RawBuf<uint32_t> dpaths, dedits; uint64_t zeroed_bytes = 0; void* zeroed_ptr = nullptr; };
 
 const vgk_wfa_error_model kDefaultModel = { { 0.03, 1, 6 }, { 0.05, 1, 10 }, { 0.1, 1, 20 }, { 0.1, 10, 200 } };   // gbwt_extender.hpp:386-395
