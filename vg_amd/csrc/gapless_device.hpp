@@ -199,6 +199,12 @@ VGK_HD void g_heap_push(GScratch& s, uint32_t& hn, const GEntry& e, uint16_t idx
     while (i) { const uint32_t p = (i - 1) / 2; if (s.heap[p] >= key) break; s.heap[i] = s.heap[p]; i = p; }
     s.heap[i] = key;
 }
+// a new entry: the better of it and the held-back candidate stays in registers, the other one goes to the queue
+VGK_HD void g_offer(GScratch& s, uint32_t& hn, bool& have_cand, GEntry& cand, uint16_t& cand_idx, const GEntry& e, uint16_t idx) {
+    if (!have_cand) { cand = e; cand_idx = idx; have_cand = true; }
+    else if (g_key(e, idx) > g_key(cand, cand_idx)) { g_heap_push(s, hn, cand, cand_idx); cand = e; cand_idx = idx; }
+    else g_heap_push(s, hn, e, idx);
+}
 VGK_HD uint16_t g_heap_pop(GScratch& s, uint32_t& hn) {
     const uint16_t top = (uint16_t)(s.heap[0] & 0xffffu);
     const uint64_t last = s.heap[--hn];
@@ -359,6 +365,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
         const uint32_t read_offset = diff < 0 ? 0u : (uint32_t)diff, node_offset = diff < 0 ? (uint32_t)(-diff) : 0u;
         if (read_offset > L || node_offset > g_len(h, snode)) { status = VGK_EINVAL; break; }
         uint32_t np = 0, hn = 0, number = 0;
+        bool have_cand = false; GEntry cand; uint16_t cand_idx = 0;
         int32_t best = -1;
         GEntry best_e; best_e.score = 0; best_e.r0 = best_e.r1 = 0;
         {   // the seed node itself: any number of mismatches (:213-237)
@@ -373,11 +380,19 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
             if (m.r1 >= L) m.right_full = m.right_max = 1;
             g_set_score(c, m); m.number = number++;
             S.pool[np] = g_pack(m);
-            g_heap_push(S, hn, m, (uint16_t)np); ++np;
+            cand = m; cand_idx = (uint16_t)np; have_cand = true; ++np;
         }
-        while (hn) {
-            const uint16_t ci = g_heap_pop(S, hn);
-            GEntry cur = g_unpack(S.pool[ci]);
+        // The queue pops (score, insertion number) maxima.  The best entry created by an expansion is held back in registers
+        // (`cand`): when it beats the queue's top — always, on a non-branching stretch — it is the next one popped, and the
+        // round trip through the slab (key push, key pop, 40-byte entry load) is skipped; otherwise it joins the queue first.
+        while (hn || have_cand) {
+            uint16_t ci; GEntry cur;
+            if (have_cand && (hn == 0 || g_key(cand, cand_idx) > S.heap[0])) { ci = cand_idx; cur = cand; have_cand = false; }
+            else {
+                if (have_cand) { g_heap_push(S, hn, cand, cand_idx); have_cand = false; }
+                ci = g_heap_pop(S, hn);
+                cur = g_unpack(S.pool[ci]);
+            }
             if (!cur.right_max) {
                 uint32_t num_ext = 0;
                 const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
@@ -398,14 +413,14 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
                     g_set_score(c, nx); nx.number = number++;
                     num_ext += gs_size(ns);
                     S.pool[np] = g_pack(nx);
-                    g_heap_push(S, hn, nx, (uint16_t)np); ++np;
+                    g_offer(S, hn, have_cand, cand, cand_idx, nx, (uint16_t)np); ++np;
                 }
                 if (status != VGK_OK) break;
                 if (num_ext < gs_size(cur.state)) {                                               // some haplotype ends here: keep it (:633-637)
                     if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
                     GEntry nx = cur; nx.parent = ci; nx.node = -1; nx.right_max = 1; nx.old = nx.internal; nx.number = number++;
                     S.pool[np] = g_pack(nx);
-                    g_heap_push(S, hn, nx, (uint16_t)np); ++np;
+                    g_offer(S, hn, have_cand, cand, cand_idx, nx, (uint16_t)np); ++np;
                 }
                 continue;
             }
@@ -429,7 +444,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
                     else if (nx.offset > 0) nx.left_max = 1;
                     g_set_score(c, nx); nx.number = number++;
                     S.pool[np] = g_pack(nx);
-                    g_heap_push(S, hn, nx, (uint16_t)np); ++np;
+                    g_offer(S, hn, have_cand, cand, cand_idx, nx, (uint16_t)np); ++np;
                     found = true;
                 }
                 if (status != VGK_OK) break;
