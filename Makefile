@@ -29,8 +29,9 @@ vg_amd/libvgamd.so: $(LIB_SRCS) $(LIB_HDRS)
 	$(CXX) $(CXXFLAGS) -O3 -c vg_amd/csrc/banded_api.cpp -o vg_amd/csrc/banded_api.o
 	$(CXX) $(CXXFLAGS) -O3 -c vg_amd/csrc/gapless_api.cpp -o vg_amd/csrc/gapless_api.o
 	$(CXX) $(CXXFLAGS) -O3 -c vg_amd/csrc/wfa_api.cpp -o vg_amd/csrc/wfa_api.o
+	$(CXX) $(CXXFLAGS) -O3 -c vg_amd/csrc/gssw_multi_api.cpp -o vg_amd/csrc/gssw_multi_api.o
 	$(HIPCC) $(HIPFLAGS) -c vg_amd/csrc/backend_hip.hip -o vg_amd/csrc/backend_hip.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ vg_amd/csrc/vgk_api.o vg_amd/csrc/banded_api.o vg_amd/csrc/gapless_api.o vg_amd/csrc/wfa_api.o vg_amd/csrc/backend_hip.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ vg_amd/csrc/vgk_api.o vg_amd/csrc/banded_api.o vg_amd/csrc/gapless_api.o vg_amd/csrc/wfa_api.o vg_amd/csrc/gssw_multi_api.o vg_amd/csrc/backend_hip.o
 
 vg_amd/libvgamd_host.so: $(HOST_SRCS) $(HOST_HDRS)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRCS) -ldl
@@ -45,6 +46,6 @@ clean:
 
 # test-only: CPU lock-step emulation of the HIP lane code behind the same C ABI
 emu: tests/emu/libvgamd_emu.so
-tests/emu/libvgamd_emu.so: vg_amd/csrc/vgk_api.cpp vg_amd/csrc/banded_api.cpp vg_amd/csrc/gapless_api.cpp vg_amd/csrc/wfa_api.cpp tests/emu/backend_emu.cpp $(LIB_HDRS)
-	$(CXX) -O2 -g -std=c++17 -fPIC -Iinclude -Wall -shared -o $@ vg_amd/csrc/vgk_api.cpp vg_amd/csrc/banded_api.cpp vg_amd/csrc/gapless_api.cpp vg_amd/csrc/wfa_api.cpp tests/emu/backend_emu.cpp -lpthread
+tests/emu/libvgamd_emu.so: vg_amd/csrc/vgk_api.cpp vg_amd/csrc/banded_api.cpp vg_amd/csrc/gapless_api.cpp vg_amd/csrc/wfa_api.cpp vg_amd/csrc/gssw_multi_api.cpp tests/emu/backend_emu.cpp $(LIB_HDRS)
+	$(CXX) -O2 -g -std=c++17 -fPIC -Iinclude -Wall -shared -o $@ vg_amd/csrc/vgk_api.cpp vg_amd/csrc/banded_api.cpp vg_amd/csrc/gapless_api.cpp vg_amd/csrc/wfa_api.cpp vg_amd/csrc/gssw_multi_api.cpp tests/emu/backend_emu.cpp -lpthread
 .PHONY: emu

@@ -174,6 +174,15 @@ int  vgk_gssw_fetch(vgk_batch* batch, vgk_result* results /* [n] */,
 int  vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
                     vgk_result* results, vgk_op* ops, size_t ops_cap,
                     size_t* ops_written);
+/* k-best pinned alignments (Aligner::align_pinned_multi -> gssw_graph_trace_back_pinned_multi, src/aligner.cpp:423-435, :455-480).
+ * Every problem must be VGK_GSSW_PINNED.  results[i * max_alt_alns + k] is the k-th best alignment of problem i (k <
+ * n_alignments[i] <= max_alt_alns), scores non-increasing and > 0, the first one the alignment vgk_gssw_align returns; a problem
+ * that failed has n_alignments[i] = 0 and its status in results[i * max_alt_alns].  The device fills and keeps the H / E / F
+ * matrices, the alternates are enumerated over them on host threads (deflections from earlier tracebacks, best first — gssw's
+ * own rules are not in the reference snapshot: DESIGN.md §13). */
+int  vgk_gssw_align_multi(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, uint32_t max_alt_alns,
+                          vgk_result* results /* [n * max_alt_alns] */, uint32_t* n_alignments /* [n] */,
+                          vgk_op* ops, size_t ops_cap, size_t* ops_written);
 
 /* ---- banded global alignment (BandedGlobalAligner, src/banded_global_aligner.cpp) -------------------
  * Replaces, inside Aligner::align_global_banded / QualAdjAligner::align_global_banded (src/aligner.cpp:699-760,

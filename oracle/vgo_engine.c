@@ -30,6 +30,9 @@ int vgo_gapless_extend(const vgk_scoring* sc, const vgk_haplo* h, const vgk_gapl
 int vgo_wfa_one(const vgk_scoring* sc, const vgk_haplo* h, const vgk_wfa_error_model* model, const vgk_wfa_problem* p,
                 vgk_wfa_result* res, int32_t** path_out, uint32_t** edits_out);
 
+int vgo_gssw_pinned_multi(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p, uint32_t max_alt_alns,
+                          vgk_result** results_out, uint32_t* n_out, vgk_op** ops_out, uint32_t* n_ops_out);
+
 struct vgk_ctx { vgk_scoring sc; int has_qa; vgk_qual_adj qa; int8_t qmat[256 * 25]; int8_t qbon[256]; };
 
 static int vgo_dispatch(const vgk_ctx* c, const vgk_gssw_problem* p, vgk_result* res, vgk_op* ops, uint32_t ops_cap) {
@@ -260,6 +263,34 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     }
     free(tp); free(te);
     if (written) { written[0] = np; written[1] = ne; }
+    return rc;
+}
+
+int vgk_gssw_align_multi(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, uint32_t max_alt_alns,
+                         vgk_result* results, uint32_t* n_alignments, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+    if (!ctx || (!problems && n) || (!results && n) || (!n_alignments && n) || !max_alt_alns) return VGK_EINVAL;
+    vgk_result** tr = (vgk_result**)calloc((size_t)n + 1, sizeof(vgk_result*)); vgk_op** to = (vgk_op**)calloc((size_t)n + 1, sizeof(vgk_op*));
+    uint32_t* tn = (uint32_t*)calloc((size_t)n + 1, sizeof(uint32_t)); uint32_t* tno = (uint32_t*)calloc((size_t)n + 1, sizeof(uint32_t));
+    int* st = (int*)calloc((size_t)n + 1, sizeof(int));
+    const vgk_qual_adj* qa = ctx->has_qa ? &ctx->qa : NULL;
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (uint32_t i = 0; i < n; ++i) st[i] = vgo_gssw_pinned_multi(&ctx->sc, qa, &problems[i], max_alt_alns, &tr[i], &tn[i], &to[i], &tno[i]);
+    size_t used = 0; int rc = VGK_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        vgk_result* r = results + (size_t)i * max_alt_alns;
+        memset(r, 0, sizeof(vgk_result) * max_alt_alns);
+        n_alignments[i] = 0;
+        if (st[i] != VGK_OK) r->status = st[i];
+        else if (used + tno[i] > ops_cap || (tno[i] && !ops)) { r->status = VGK_EOPS; rc = VGK_EOPS; }
+        else {
+            for (uint32_t k = 0; k < tn[i]; ++k) { r[k] = tr[i][k]; r[k].ops_begin += (uint32_t)used; }
+            if (tno[i]) memcpy(ops + used, to[i], sizeof(vgk_op) * tno[i]);
+            used += tno[i]; n_alignments[i] = tn[i];
+        }
+        free(tr[i]); free(to[i]);
+    }
+    free(tr); free(to); free(tn); free(tno); free(st);
+    if (ops_written) *ops_written = used;
     return rc;
 }
 

@@ -50,6 +50,10 @@ template <int R, bool QA> static void banded_fill_emu(const BandedParams& P, uin
 
 class EmuBackend final : public Backend {
 public:
+    int run_gssw_matrix(const GsswMatrixParams& P) override {
+        for (uint32_t i = 0; i < P.n; ++i) gssw_matrix_one(P, i);
+        return VGK_OK;
+    }
     int run_wfa(const WfaParams& P, uint32_t threads) override {
         for (uint32_t t = 0; t < threads; ++t) wfa_thread(P, t);
         return VGK_OK;

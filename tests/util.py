@@ -64,7 +64,7 @@ class HostAligner:
                 assert self.h.vgh_graph_add_node(g, nid, seq.encode()) == 0
             for a, b in edges:
                 assert self.h.vgh_graph_add_edge(g, a, b) == 0
-            buf = ctypes.create_string_buffer(1 << 20)
+            buf = ctypes.create_string_buffer(1 << 20 if max_alt_alns <= 100 else 1 << 26)
             code = {"align": 0, "align_score": 1, "align_pinned": 2, "align_pinned_multi": 3, "align_pinned_xdrop": 4,
                     "align_global_banded": 5}[call]
             if quality is not None:

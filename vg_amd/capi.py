@@ -113,6 +113,7 @@ def load_library(path=None):
     lib.vgk_gapless_last_ms.restype = ctypes.c_double
     lib.vgk_gapless_last_ms.argtypes = [vp]
     lib.vgk_banded_align_multi.argtypes = [vp, vp, u32, u32, vp, vp, vp, sz, ctypes.POINTER(sz)]
+    lib.vgk_gssw_align_multi.argtypes = [vp, vp, u32, u32, vp, vp, vp, sz, ctypes.POINTER(sz)]
     lib.vgk_banded_rerun.argtypes = [vp]
     lib.vgk_gapless_rerun.argtypes = [vp]
     lib.vgk_wfa_extend.argtypes = [vp, vp, vp, vp, u32, vp, vp, sz, vp, sz, ctypes.POINTER(sz * 2)]
@@ -277,6 +278,16 @@ class Engine:
         with self.pack(ps, ops_per_problem) as b:
             b.run()
             return b.fetch()
+
+    def align_multi(self, ps, max_alt_alns):
+        """vgk_gssw_align_multi over a ProblemSet of pinned problems -> (results [n, max_alt_alns], n_alignments [n], ops)."""
+        res = np.zeros((ps.n, max_alt_alns), dtype=RESULT_DT); cnt = np.zeros(ps.n, dtype=np.uint32)
+        cap = int((np.diff(ps.read_off).sum() + np.diff(ps.seq_off).sum() + 4 * ps.n) * max_alt_alns)
+        ops = np.zeros(max(cap, 1), dtype=OP_DT)
+        written = ctypes.c_size_t()
+        self._check(self.lib.vgk_gssw_align_multi(self.h, ps.ptr, ps.n, max_alt_alns, res.ctypes.data, cnt.ctypes.data, ops.ctypes.data, cap,
+                                                  ctypes.byref(written)), "vgk_gssw_align_multi")
+        return res, cnt, ops[:written.value]
 
     def banded_align(self, bs):
         """vgk_banded_align over a BandedSet -> (results, ops); per-problem failures are reported in results['status']."""

@@ -10,6 +10,7 @@
 #include "banded_device.hpp"
 #include "gapless_device.hpp"
 #include "wfa_device.hpp"
+#include "gssw_matrix_device.hpp"
 
 namespace vgk {
 
@@ -44,6 +45,8 @@ public:
     // wavefront alignment: likewise, `threads` resident threads (one WScratch each, zeroed by the caller once) stride over
     // p.n problems; last_ms(6) = kernel ms
     virtual int   run_wfa(const WfaParams& p, uint32_t threads) = 0;
+    // pinned gssw fill that keeps H / E / F of every cell (k-best tracebacks): one thread per problem
+    virtual int   run_gssw_matrix(const GsswMatrixParams& p) = 0;
 };
 
 // returns nullptr and sets err when the device cannot be used

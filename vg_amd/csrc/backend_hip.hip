@@ -147,6 +147,12 @@ __global__ void __launch_bounds__(64, 4) wfa_kernel(const WfaParams P, const uin
     if (t < threads) wfa_thread(P, t);
 }
 
+// ---- pinned gssw fill with full matrices (gssw_matrix_device.hpp)
+__global__ void __launch_bounds__(64) gssw_matrix_kernel(const GsswMatrixParams P) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i < P.n) gssw_matrix_one(P, i);
+}
+
 class HipBackend final : public Backend {
 public:
     int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -275,6 +281,13 @@ public:
         hipEventRecord(bev[1], stream);
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         hipEventElapsedTime(&ms_gapless, bev[0], bev[1]);
+        return VGK_OK;
+    }
+    int run_gssw_matrix(const GsswMatrixParams& p) override {
+        hipSetDevice(dev);
+        if (!p.n) return VGK_OK;
+        hipLaunchKernelGGL(gssw_matrix_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
+        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         return VGK_OK;
     }
     int run_wfa(const WfaParams& p, uint32_t threads) override {

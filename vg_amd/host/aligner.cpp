@@ -359,6 +359,27 @@ void Aligner::align_internal(Alignment& alignment, std::vector<Alignment>* multi
     auto job = prepare_job(alignment, g, pinned, pin_left, traceback_aln);
     vgk_result res{};
     std::vector<vgk_op> ops;
+    if (job->has_problem && multi_alignments && max_alt_alns > 1) {
+        // k-best pinned tracebacks (src/aligner.cpp:423-435, :455-480): the engine returns them best first, all with score > 0
+        const size_t per = job->prob.read_len + job->pg.seq.size() + job->pg.order.size() + 4;
+        std::vector<vgk_result> all((size_t)max_alt_alns); std::vector<vgk_op> all_ops(per * (size_t)max_alt_alns + 1);
+        uint32_t count = 0; size_t written = 0;
+        int rc = engine->gssw_align_multi(ctx, &job->prob, 1, (uint32_t)max_alt_alns, all.data(), &count, all_ops.data(), all_ops.size(), &written);
+        if (rc != VGK_OK) throw std::runtime_error(std::string("vgamd: gssw engine failed: ") + engine->strerror(rc));
+        if (all[0].status != VGK_OK) throw std::runtime_error(std::string("vgamd: gssw problem failed: ") + engine->strerror(all[0].status));
+        if (count > 0) { res = all[0]; ops.assign(all_ops.begin() + res.ops_begin, all_ops.begin() + res.ops_begin + res.n_ops); res.ops_begin = 0; }
+        finish_job(*job, res, std::move(ops), multi_alignments, max_alt_alns);
+        for (uint32_t k = 1; k < count; ++k) {
+            vgk_result r = all[k];
+            std::vector<vgk_op> o(all_ops.begin() + r.ops_begin, all_ops.begin() + r.ops_begin + r.n_ops); r.ops_begin = 0;
+            if (pin_left) unreverse_ops(o, r, job->pg.node_len);
+            multi_alignments->emplace_back();
+            Alignment& next = multi_alignments->back();
+            next.sequence = alignment.sequence; next.quality = alignment.quality;
+            ops_to_alignment(job->pg, g, r, o.data(), next);
+        }
+        return;
+    }
     if (job->has_problem) {
         ops.resize(job->prob.read_len + job->pg.seq.size() + job->pg.order.size() + 4);
         size_t written = 0;

@@ -37,6 +37,7 @@ std::shared_ptr<EngineApi> load_engine(const std::string& path) {
     bind(dl, "vgk_create_qual_adj", api->create_qual_adj);
     bind(dl, "vgk_destroy", api->destroy);
     bind(dl, "vgk_gssw_align", api->gssw_align);
+    bind(dl, "vgk_gssw_align_multi", api->gssw_align_multi);
     bind(dl, "vgk_gssw_pack", api->gssw_pack);
     bind(dl, "vgk_gssw_run", api->gssw_run);
     bind(dl, "vgk_gssw_fetch", api->gssw_fetch);

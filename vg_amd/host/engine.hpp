@@ -20,6 +20,7 @@ struct EngineApi {
     decltype(&vgk_create_qual_adj) create_qual_adj = nullptr;
     decltype(&vgk_destroy) destroy = nullptr;
     decltype(&vgk_gssw_align) gssw_align = nullptr;
+    decltype(&vgk_gssw_align_multi) gssw_align_multi = nullptr;
     decltype(&vgk_gssw_pack) gssw_pack = nullptr;
     decltype(&vgk_gssw_run) gssw_run = nullptr;
     decltype(&vgk_gssw_fetch) gssw_fetch = nullptr;

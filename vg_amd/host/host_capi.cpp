@@ -79,7 +79,15 @@ int vgh_align_q(vgh_aligner* a, vgh_graph* g, const char* read, const uint8_t* q
             case 0: a->a->align(aln, g->g, true); break;
             case 1: a->a->align(aln, g->g, false); break;
             case 2: a->a->align_pinned(aln, g->g, pin_left != 0); break;
-            case 3: { std::vector<Alignment> alts; a->a->align_pinned_multi(aln, alts, g->g, pin_left != 0, max_alt_alns); } break;
+            case 3: {
+                std::vector<Alignment> alts; a->a->align_pinned_multi(aln, alts, g->g, pin_left != 0, max_alt_alns);
+                std::string js = "[";                         // every alternate, best first
+                for (size_t k = 0; k < alts.size(); ++k) js += std::string(k ? "," : "") + alignment_to_json(alts[k]);
+                js += "]";
+                if (js.size() + 1 > json_cap) { g_last_error = "json buffer too small"; return -2; }
+                std::memcpy(json_out, js.c_str(), js.size() + 1);
+                return 0;
+            }
             case 4: a->a->align_pinned(aln, g->g, pin_left != 0, true, (uint16_t)max_alt_alns); break;
             case 5: a->a->align_global_banded(aln, g->g, max_alt_alns, pin_left != 0); break;
             default: g_last_error = "unknown call"; return -1;
