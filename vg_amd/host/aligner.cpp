@@ -320,7 +320,7 @@ void Aligner::finish_job(Job& j, vgk_result res, std::vector<vgk_op> ops, std::v
                 if (j.pin_left) unreverse_ops(ops, res, j.pg.node_len);
                 // after un-reversal the cigar refers to the forward sequences of g
                 ops_to_alignment(j.pg, g, res, ops.data(), alignment);
-                if (multi_alignments) multi_alignments->emplace_back(alignment);   // alternates: see DESIGN.md (k-best not yet on device)
+                if (multi_alignments) multi_alignments->emplace_back(alignment);   // the alternates follow in align_internal
             } else if (g.get_node_count() > 0) {
                 // no positive-score traceback: synthesise soft clips at the id-sorted tail nodes.
                 // The reference writes every alternate into `alignment` (src/aligner.cpp:505-520); reproduced as is.

@@ -60,7 +60,7 @@ static int emit(const Alignment& aln, char* out, size_t cap) {
     return 0;
 }
 
-// call: 0 = align(traceback), 1 = align(score only), 2 = align_pinned, 3 = align_pinned_multi (primary only reported),
+// call: 0 = align(traceback), 1 = align(score only), 2 = align_pinned, 3 = align_pinned_multi (JSON list of all alternates),
 //       4 = align_pinned(xdrop = true, max_gap = max_alt_alns argument)
 //       5 = align_global_banded(band_padding = max_alt_alns argument, permissive_banding = pin_left argument)
 int vgh_align_q(vgh_aligner* a, vgh_graph* g, const char* read, const uint8_t* qual, int call, int pin_left, int max_alt_alns,
