@@ -183,3 +183,22 @@ def test_wfa_bad_input_limits_and_rerun(emu_lib):
         else:
             with pytest.raises(capi.VgkError):
                 eng.wfa_rerun()                                              # nothing is resident on the CPU
+
+
+def test_pinned_multi_bad_input_and_sub_batches(emu_lib, monkeypatch):
+    rng = np.random.default_rng(14)
+    good = [random_problem(rng, max_nodes=6, max_node_len=8, max_read=30, mode=capi.VGK_GSSW_PINNED) for _ in range(12)]
+    local = random_problem(rng, max_nodes=4, max_node_len=8, max_read=20, mode=capi.VGK_GSSW_LOCAL)      # not a pinned problem
+    problems = good[:5] + [local] + good[5:]
+    ps = problem_set(problems)
+    for lib in (emu_lib, ORACLE_LIB):
+        res, cnt, ops = capi.Engine(lib=lib).align_multi(ps, 4)
+        assert res[5, 0]["status"] == -1 and cnt[5] == 0
+        assert all(res[i, 0]["status"] == 0 for i in range(ps.n) if i != 5)
+    whole = capi.Engine(lib=emu_lib).align_multi(ps, 4)
+    monkeypatch.setenv("VGAMD_MAX_BATCH_BYTES", "20000")           # a few problems' matrices per sub-batch
+    cut = capi.Engine(lib=emu_lib).align_multi(ps, 4)
+    for a, b in zip(whole, cut):
+        assert (a == b).all()
+    with pytest.raises(capi.VgkError):
+        capi.Engine(lib=emu_lib).align_multi(ps, 0)
