@@ -121,7 +121,10 @@ VGK_HD GEntry g_unpack(const GPacked& p) {
 // small, because the kernel's speed follows the address spread of what the resident threads touch (measured: 47 M reads/s with a
 // 15.9 KB slab, 38 M with 23.8 KB); winners beyond G_HOT — rare: most clusters resolve into one or two extensions — go to a cold slab.
 constexpr int G_HOT = 8;
-struct GScratch { uint64_t heap[G_POOL]; GPacked pool[G_POOL]; GExt res[G_HOT]; uint8_t order[G_SEEDS]; };      // order[]: the permutation the set rules sort
+// What the path of an entry needs, for every entry: 8 bytes.  The 40-byte packed entry is written only when an entry actually
+// waits in the queue; on a non-branching stretch every new entry is the held-back candidate and is popped from registers.
+struct GLink { int32_t node; int16_t parent; uint8_t front, pad; };
+struct GScratch { uint64_t heap[G_POOL]; GPacked pool[G_POOL]; GLink link[G_POOL]; GExt res[G_HOT]; uint8_t order[G_SEEDS]; };      // order[]: the permutation the set rules sort
 struct GCold { GExt res[G_SEEDS - G_HOT]; };
 struct GRes {                          // the G_SEEDS winners of a read as one array
     GExt* hot; GExt* cold;
@@ -195,10 +198,12 @@ VGK_HD void g_set_score(const GCtx& c, GEntry& e) {                             
 VGK_HD uint64_t g_key(const GEntry& e, uint32_t idx) { return ((uint64_t)((uint32_t)e.score ^ 0x80000000u) << 32) | ((uint64_t)e.number << 16) | idx; }
 VGK_HD void g_heap_push(GScratch& s, uint32_t& hn, const GEntry& e, uint16_t idx) {
     const uint64_t key = g_key(e, idx);
+    s.pool[idx] = g_pack(e);                                       // it will be popped from the slab
     uint32_t i = hn++;
     while (i) { const uint32_t p = (i - 1) / 2; if (s.heap[p] >= key) break; s.heap[i] = s.heap[p]; i = p; }
     s.heap[i] = key;
 }
+VGK_HD GLink g_link(const GEntry& e) { GLink l; l.node = e.node; l.parent = (int16_t)e.parent; l.front = e.front; l.pad = 0; return l; }
 // a new entry: the better of it and the held-back candidate stays in registers, the other one goes to the queue
 VGK_HD void g_offer(GScratch& s, uint32_t& hn, bool& have_cand, GEntry& cand, uint16_t& cand_idx, const GEntry& e, uint16_t idx) {
     if (!have_cand) { cand = e; cand_idx = idx; have_cand = true; }
@@ -222,10 +227,10 @@ VGK_HD uint16_t g_heap_pop(GScratch& s, uint32_t& hn) {
 // path of a pool entry, front to back; returns its length or -1 when it does not fit
 VGK_HD int g_path(const GScratch& s, int32_t idx, int32_t* out) {
     int32_t fwd[G_PATH]; int nf = 0, nb = 0;
-    for (int32_t i = idx; i >= 0; i = s.pool[i].parent) {
-        const GPacked& e = s.pool[i];
+    for (int32_t i = idx; i >= 0; i = s.link[i].parent) {
+        const GLink e = s.link[i];
         if (e.node < 0) continue;
-        if (e.flags & 1) { if (nb >= G_PATH) return -1; out[nb++] = e.node; }      // the latest front node is the first of the path
+        if (e.front) { if (nb >= G_PATH) return -1; out[nb++] = e.node; }      // the latest front node is the first of the path
         else { if (nf >= G_PATH) return -1; fwd[nf++] = e.node; }              // collected back to front
     }
     if (nb + nf > G_PATH) return -1;
@@ -379,7 +384,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
             if (m.r0 == 0) m.left_full = m.left_max = 1;
             if (m.r1 >= L) m.right_full = m.right_max = 1;
             g_set_score(c, m); m.number = number++;
-            S.pool[np] = g_pack(m);
+            S.link[np] = g_link(m);
             cand = m; cand_idx = (uint16_t)np; have_cand = true; ++np;
         }
         // The queue pops (score, insertion number) maxima.  The best entry created by an expansion is held back in registers
@@ -412,14 +417,14 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
                     else if (no < g_len(h, w)) { nx.right_max = 1; nx.old = nx.internal; }
                     g_set_score(c, nx); nx.number = number++;
                     num_ext += gs_size(ns);
-                    S.pool[np] = g_pack(nx);
+                    S.link[np] = g_link(nx);
                     g_offer(S, hn, have_cand, cand, cand_idx, nx, (uint16_t)np); ++np;
                 }
                 if (status != VGK_OK) break;
                 if (num_ext < gs_size(cur.state)) {                                               // some haplotype ends here: keep it (:633-637)
                     if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
                     GEntry nx = cur; nx.parent = ci; nx.node = -1; nx.right_max = 1; nx.old = nx.internal; nx.number = number++;
-                    S.pool[np] = g_pack(nx);
+                    S.link[np] = g_link(nx);
                     g_offer(S, hn, have_cand, cand, cand_idx, nx, (uint16_t)np); ++np;
                 }
                 continue;
@@ -443,7 +448,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
                     if (nx.r0 == 0) nx.left_full = nx.left_max = 1;
                     else if (nx.offset > 0) nx.left_max = 1;
                     g_set_score(c, nx); nx.number = number++;
-                    S.pool[np] = g_pack(nx);
+                    S.link[np] = g_link(nx);
                     g_offer(S, hn, have_cand, cand, cand_idx, nx, (uint16_t)np); ++np;
                     found = true;
                 }
