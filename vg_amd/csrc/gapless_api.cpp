@@ -138,7 +138,12 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
         const uint32_t ne = edge_off[o + 1] - edge_off[o];
         rec.push_back(count[o]); rec.push_back(ne); rec.push_back(len[o]); rec.push_back(seq_off[o]);
         for (uint32_t e = edge_off[o]; e < edge_off[o + 1]; ++e) { rec.push_back((uint32_t)edge_to[e]); rec.push_back(edge_base[e]); }
-        for (uint32_t i = 0; i < count[o]; ++i) rec.push_back(body[body_off[o] + i]);
+        if (ne > 255) return VGK_ETOOBIG;                                   // the body holds edge numbers as bytes
+        for (uint32_t i = 0; i < count[o]; i += 4) {
+            uint32_t w = 0;
+            for (uint32_t k = 0; k < 4 && i + k < count[o]; ++k) w |= body[body_off[o] + i + k] << (8 * k);
+            rec.push_back(w);
+        }
         while (rec.size() % 16) rec.push_back(0);
         if (rec.size() > 0xfffffff0ull) return VGK_ETOOBIG;
     }

@@ -21,7 +21,7 @@ namespace vgk {
 // One record per oriented node, padded to a multiple of 16 words so that a hop touches one or two cache lines:
 //   word 0 visit count | 1 outgoing edges | 2 node length | 3 offset of the node's bases in `seq`
 //   then per edge (ascending successor): successor (or -1: a thread ends) , where this node's visits start in the successor's record
-//   then per visit: the index of the edge it leaves through
+//   then per visit: the number of the edge it leaves through, one byte each (a record of 16 visits and 2 edges is one 64-byte line)
 struct GIndex {                       // device pointers
     uint32_t n_oriented;
     const uint32_t* rec_off;          // per oriented node, in words
@@ -41,6 +41,35 @@ VGK_HD GState gs_find(const GIndex& h, int32_t node) {
     return s;
 }
 VGK_HD int32_t g_rkey(int32_t x) { return x < 0 ? -1 : (x ^ 1); }
+VGK_HD uint32_t g_body(const uint32_t* body, uint32_t i) { return (body[i >> 2] >> (8 * (i & 3u))) & 0xffu; }
+// One pass over the visits [0, hi] of a record with at most four edges: how many leave through each edge before the range
+// [lo, hi] and inside it, 16 bits per edge (a node has at most 65 535 visits).  Every extension of the state follows from these.
+struct GCounts { uint64_t before, inside; };
+VGK_HD GCounts g_counts(const uint32_t* rec, int32_t lo, int32_t hi) {
+    const uint32_t* body = rec + 4 + 2 * rec[1];
+    GCounts c = { 0, 0 };
+    for (int32_t i = 0; i <= hi; i += 4) {
+        uint32_t w = body[i >> 2];
+        for (int32_t k = 0; k < 4 && i + k <= hi; ++k, w >>= 8) {
+            const uint64_t one = 1ull << (16 * (w & 3u));
+            if (i + k < lo) c.before += one; else c.inside += one;
+        }
+    }
+    return c;
+}
+VGK_HD uint32_t g_count_of(uint64_t packed, uint32_t e) { return (uint32_t)(packed >> (16 * e)) & 0xffffu; }
+// bdExtendForward through edge number e of the forward node's record, from the counts
+VGK_HD GState gs_extend_counted(const uint32_t* rec, const GState& s, uint32_t e, const GCounts& cn) {
+    const int32_t to = (int32_t)rec[4 + 2 * e];
+    GState r = s; r.fn = to;
+    const int32_t inside = (int32_t)g_count_of(cn.inside, e);
+    if (!inside) { r.flo = 0; r.fhi = -1; r.bhi = r.blo - 1; return r; }
+    int32_t rev_off = 0;
+    for (uint32_t x = 0; x < rec[1]; ++x) if (x != e && g_rkey((int32_t)rec[4 + 2 * x]) < g_rkey(to)) rev_off += (int32_t)g_count_of(cn.inside, x);
+    r.flo = (int32_t)rec[5 + 2 * e] + (int32_t)g_count_of(cn.before, e); r.fhi = r.flo + inside - 1;
+    r.blo = s.blo + rev_off; r.bhi = r.blo + inside - 1;
+    return r;
+}
 // bdExtendForward: follow the visits of the forward range that leave through `to`
 VGK_HD GState gs_extend(const GIndex& h, const GState& s, int32_t to) {
     const uint32_t o = (uint32_t)s.fn;
@@ -50,9 +79,10 @@ VGK_HD GState gs_extend(const GIndex& h, const GState& s, int32_t to) {
     uint32_t e = 0; while (e < ne && (int32_t)rec[4 + 2 * e] != to) ++e;
     GState r = s; r.fn = to;
     if (e == ne || gs_empty(s)) { r.flo = 0; r.fhi = -1; r.bhi = r.blo - 1; return r; }
+    if (ne <= 4) return gs_extend_counted(rec, s, e, g_counts(rec, s.flo, s.fhi));
     int32_t before = 0, inside = 0, rev_off = 0;
     for (int32_t i = 0; i <= s.fhi; ++i) {
-        const uint32_t b = body[i];
+        const uint32_t b = g_body(body, (uint32_t)i);
         if (b == e) { if (i < s.flo) ++before; else ++inside; }
         else if (i >= s.flo && g_rkey((int32_t)rec[4 + 2 * b]) < g_rkey(to)) ++rev_off;
     }
@@ -403,9 +433,11 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
                 const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
                 const uint32_t o = (uint32_t)cur.state.fn;
                 const uint32_t* orec = g_rec(h, o);
+                const bool few = orec[1] <= 4 && !gs_empty(cur.state);
+                const GCounts cn = few ? g_counts(orec, cur.state.flo, cur.state.fhi) : GCounts{0, 0};
                 for (uint32_t e = 0; e < orec[1]; ++e) {
                     const int32_t w = (int32_t)orec[4 + 2 * e]; if (w < 0) continue;
-                    const GState ns = gs_extend(h, cur.state, w);
+                    const GState ns = few ? gs_extend_counted(orec, cur.state, e, cn) : gs_extend(h, cur.state, w);
                     if (gs_empty(ns)) continue;
                     if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
                     GEntry nx = cur; nx.parent = ci; nx.node = w; nx.front = 0; nx.state = ns;
@@ -434,9 +466,12 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
                 const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
                 const uint32_t o = (uint32_t)cur.state.bn;
                 const uint32_t* orec = g_rec(h, o);
+                const GState flipped = gs_flip(cur.state);
+                const bool few = orec[1] <= 4 && !gs_empty(flipped);
+                const GCounts cn = few ? g_counts(orec, flipped.flo, flipped.fhi) : GCounts{0, 0};
                 for (uint32_t e = 0; e < orec[1]; ++e) {
                     const int32_t x = (int32_t)orec[4 + 2 * e]; if (x < 0) continue;
-                    const GState ns = gs_flip(gs_extend(h, gs_flip(cur.state), x));              // bdExtendBackward
+                    const GState ns = gs_flip(few ? gs_extend_counted(orec, flipped, e, cn) : gs_extend(h, flipped, x));   // bdExtendBackward
                     if (gs_empty(ns)) continue;
                     const int32_t w = ns.bn ^ 1;
                     if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
