@@ -131,28 +131,37 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
             edge_base[(uint32_t)(std::lower_bound(first, last, (int32_t)w) - edge_to.data())] = i;
         }
     }
-    // one padded record per oriented node (layout in gapless_device.hpp)
+    // one padded record per oriented node (layout in gapless_device.hpp): sizes first, so that every edge can name its successor's record
     std::vector<uint32_t> rec_off(O + 1, 0), rec;
+    { uint64_t at = 0;
+      for (uint32_t o = 0; o < O; ++o) {
+          const uint32_t ne = edge_off[o + 1] - edge_off[o];
+          if (ne > 255 || count[o] > 65535 || len[o] > 65535) return VGK_ETOOBIG;      // edge numbers are bytes, ranks and lengths 16 bits
+          rec_off[o] = (uint32_t)at;
+          at += (4 + 4ull * ne + (count[o] + 3) / 4 + 15) / 16 * 16;
+          if (at > 0xfffffff0ull) return VGK_ETOOBIG;
+      }
+      rec_off[O] = (uint32_t)at; rec.assign(at, 0); }
     for (uint32_t o = 0; o < O; ++o) {
-        rec_off[o] = (uint32_t)rec.size();
+        uint32_t* r = rec.data() + rec_off[o];
         const uint32_t ne = edge_off[o + 1] - edge_off[o];
-        rec.push_back(count[o]); rec.push_back(ne); rec.push_back(len[o]); rec.push_back(seq_off[o]);
-        for (uint32_t e = edge_off[o]; e < edge_off[o + 1]; ++e) { rec.push_back((uint32_t)edge_to[e]); rec.push_back(edge_base[e]); }
-        if (ne > 255) return VGK_ETOOBIG;                                   // the body holds edge numbers as bytes
-        for (uint32_t i = 0; i < count[o]; i += 4) {
-            uint32_t w = 0;
-            for (uint32_t k = 0; k < 4 && i + k < count[o]; ++k) w |= body[body_off[o] + i + k] << (8 * k);
-            rec.push_back(w);
+        r[0] = count[o]; r[1] = ne; r[2] = len[o]; r[3] = seq_off[o];
+        for (uint32_t k = 0; k < ne; ++k) {
+            const int32_t to = edge_to[edge_off[o] + k];
+            r[4 + 4 * k] = (uint32_t)to;
+            r[5 + 4 * k] = edge_base[edge_off[o] + k] | (to >= 0 ? len[(uint32_t)to] << 16 : 0u);
+            r[6 + 4 * k] = to >= 0 ? seq_off[(uint32_t)to] : 0u;
+            r[7 + 4 * k] = to >= 0 ? rec_off[(uint32_t)to] : 0u;
         }
-        while (rec.size() % 16) rec.push_back(0);
-        if (rec.size() > 0xfffffff0ull) return VGK_ETOOBIG;
+        uint32_t* visits = r + 4 + 4 * ne;
+        for (uint32_t i = 0; i < count[o]; ++i) visits[i >> 2] |= body[body_off[o] + i] << (8 * (i & 3u));
     }
     rec_off[O] = (uint32_t)rec.size();
     vgk_haplo* h = new vgk_haplo();
     h->ctx = ctx; h->n_oriented = O; h->len = len;
     std::lock_guard<std::mutex> lock(ctx->mu);
     int rc;
-    h->dev.n_oriented = O;
+    h->dev.n_oriented = O; h->dev.strand_shift = (uint32_t)total;
     if ((rc = put(h, rec_off, h->dev.rec_off)) || (rc = put(h, rec, h->dev.rec)) || (rc = put(h, seq, h->dev.seq)) || (rc = ctx->be->sync())) {
         for (void* p : h->held) ctx->be->release(p);
         delete h; return rc;

@@ -20,16 +20,26 @@ namespace vgk {
 
 // One record per oriented node, padded to a multiple of 16 words so that a hop touches one or two cache lines:
 //   word 0 visit count | 1 outgoing edges | 2 node length | 3 offset of the node's bases in `seq`
-//   then per edge (ascending successor): successor (or -1: a thread ends) , where this node's visits start in the successor's record
+//   then per edge (ascending successor), four words: successor (or -1: a thread ends) | where this node's visits start in the
+//     successor's record (low 16 bits) and the successor's length (high 16) | offset of the successor's bases in `seq` | offset of
+//     the successor's record — everything a hop needs to start comparing bases and to fetch the next record without first
+//     reading the successor's own record through rec_off (two dependent loads saved per hop)
 //   then per visit: the number of the edge it leaves through, one byte each (a record of 16 visits and 2 edges is one 64-byte line)
 struct GIndex {                       // device pointers
     uint32_t n_oriented;
     const uint32_t* rec_off;          // per oriented node, in words
     const uint32_t* rec;
+    uint32_t        strand_shift;     // offset of a node's reverse-complement bases = offset of its forward bases + strand_shift
     const char*     seq;              // forward strands, then reverse complements (8 bytes of padding at either end)
 };
 VGK_HD const uint32_t* g_rec(const GIndex& h, uint32_t o) { return h.rec + h.rec_off[o]; }
 VGK_HD uint32_t g_len(const GIndex& h, int32_t o) { return g_rec(h, (uint32_t)o)[2]; }
+VGK_HD int32_t  ge_to(const uint32_t* rec, uint32_t e) { return (int32_t)rec[4 + 4 * e]; }
+VGK_HD uint32_t ge_base(const uint32_t* rec, uint32_t e) { return rec[5 + 4 * e] & 0xffffu; }
+VGK_HD uint32_t ge_len(const uint32_t* rec, uint32_t e) { return rec[5 + 4 * e] >> 16; }
+VGK_HD uint32_t ge_seq(const uint32_t* rec, uint32_t e) { return rec[6 + 4 * e]; }
+VGK_HD uint32_t ge_rec(const uint32_t* rec, uint32_t e) { return rec[7 + 4 * e]; }
+VGK_HD const uint32_t* g_visits(const uint32_t* rec) { return rec + 4 + 4 * rec[1]; }
 struct GProb { uint32_t read_off, read_len, seed_off, n_seeds, max_mm, flags; double overlap; };
 
 struct GState { int32_t fn, flo, fhi, bn, blo, bhi; };      // forward / backward strand: node, visit range [lo, hi]
@@ -46,7 +56,7 @@ VGK_HD uint32_t g_body(const uint32_t* body, uint32_t i) { return (body[i >> 2] 
 // [lo, hi] and inside it, 16 bits per edge (a node has at most 65 535 visits).  Every extension of the state follows from these.
 struct GCounts { uint64_t before, inside; };
 VGK_HD GCounts g_counts(const uint32_t* rec, int32_t lo, int32_t hi) {
-    const uint32_t* body = rec + 4 + 2 * rec[1];
+    const uint32_t* body = g_visits(rec);
     GCounts c = { 0, 0 };
     for (int32_t i = 0; i <= hi; i += 4) {
         uint32_t w = body[i >> 2];
@@ -60,13 +70,13 @@ VGK_HD GCounts g_counts(const uint32_t* rec, int32_t lo, int32_t hi) {
 VGK_HD uint32_t g_count_of(uint64_t packed, uint32_t e) { return (uint32_t)(packed >> (16 * e)) & 0xffffu; }
 // bdExtendForward through edge number e of the forward node's record, from the counts
 VGK_HD GState gs_extend_counted(const uint32_t* rec, const GState& s, uint32_t e, const GCounts& cn) {
-    const int32_t to = (int32_t)rec[4 + 2 * e];
+    const int32_t to = ge_to(rec, e);
     GState r = s; r.fn = to;
     const int32_t inside = (int32_t)g_count_of(cn.inside, e);
     if (!inside) { r.flo = 0; r.fhi = -1; r.bhi = r.blo - 1; return r; }
     int32_t rev_off = 0;
-    for (uint32_t x = 0; x < rec[1]; ++x) if (x != e && g_rkey((int32_t)rec[4 + 2 * x]) < g_rkey(to)) rev_off += (int32_t)g_count_of(cn.inside, x);
-    r.flo = (int32_t)rec[5 + 2 * e] + (int32_t)g_count_of(cn.before, e); r.fhi = r.flo + inside - 1;
+    for (uint32_t x = 0; x < rec[1]; ++x) if (x != e && g_rkey(ge_to(rec, x)) < g_rkey(to)) rev_off += (int32_t)g_count_of(cn.inside, x);
+    r.flo = (int32_t)ge_base(rec, e) + (int32_t)g_count_of(cn.before, e); r.fhi = r.flo + inside - 1;
     r.blo = s.blo + rev_off; r.bhi = r.blo + inside - 1;
     return r;
 }
@@ -75,8 +85,8 @@ VGK_HD GState gs_extend(const GIndex& h, const GState& s, int32_t to) {
     const uint32_t o = (uint32_t)s.fn;
     const uint32_t* rec = g_rec(h, o);
     const uint32_t ne = rec[1];
-    const uint32_t* body = rec + 4 + 2 * ne;
-    uint32_t e = 0; while (e < ne && (int32_t)rec[4 + 2 * e] != to) ++e;
+    const uint32_t* body = g_visits(rec);
+    uint32_t e = 0; while (e < ne && ge_to(rec, e) != to) ++e;
     GState r = s; r.fn = to;
     if (e == ne || gs_empty(s)) { r.flo = 0; r.fhi = -1; r.bhi = r.blo - 1; return r; }
     if (ne <= 4) return gs_extend_counted(rec, s, e, g_counts(rec, s.flo, s.fhi));
@@ -84,9 +94,9 @@ VGK_HD GState gs_extend(const GIndex& h, const GState& s, int32_t to) {
     for (int32_t i = 0; i <= s.fhi; ++i) {
         const uint32_t b = g_body(body, (uint32_t)i);
         if (b == e) { if (i < s.flo) ++before; else ++inside; }
-        else if (i >= s.flo && g_rkey((int32_t)rec[4 + 2 * b]) < g_rkey(to)) ++rev_off;
+        else if (i >= s.flo && g_rkey(ge_to(rec, b)) < g_rkey(to)) ++rev_off;
     }
-    r.flo = (int32_t)rec[5 + 2 * e] + before; r.fhi = r.flo + inside - 1;
+    r.flo = (int32_t)ge_base(rec, e) + before; r.fhi = r.flo + inside - 1;
     r.blo = s.blo + rev_off; r.bhi = r.blo + inside - 1;
     return r;
 }
@@ -105,7 +115,9 @@ struct GEntry {                      // a partial extension; its path is the cha
     GState   state;
     uint8_t  front;                  // the node was added in front of the path
     uint8_t  left_full, right_full, left_max, right_max, pad[3];
-};
+    uint32_t frec, brec;             // offsets of the records of state.fn / state.bn when known (they come with the edge that was followed;
+};                                   // G_NO_REC after a reload from the pool, which does not keep them)
+constexpr uint32_t G_NO_REC = 0xffffffffu;
 struct GExt {                        // a finished per-seed winner
     uint32_t offset, r0, r1, internal;
     int32_t  score;
@@ -140,7 +152,7 @@ VGK_HD GEntry g_unpack(const GPacked& p) {
     e.parent = p.parent; e.number = p.number; e.node = p.node;
     e.offset = p.offset; e.r0 = p.r0; e.r1 = p.r1; e.internal = p.internal; e.old = p.old;
     e.front = p.flags & 1; e.left_full = (p.flags >> 1) & 1; e.right_full = (p.flags >> 2) & 1; e.left_max = (p.flags >> 3) & 1; e.right_max = (p.flags >> 4) & 1;
-    e.pad[0] = e.pad[1] = e.pad[2] = 0;
+    e.pad[0] = e.pad[1] = e.pad[2] = 0; e.frec = e.brec = G_NO_REC;
     e.score = p.score;
     e.state.fn = p.fn; e.state.bn = p.bn;
     const bool fe = p.flo > p.fhi, be = p.blo > p.bhi;           // only a node no haplotype visits has empty ranges, and those are [0, -1]
@@ -406,7 +418,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
         {   // the seed node itself: any number of mismatches (:213-237)
             GEntry m;
             m.parent = -1; m.node = snode; m.front = 0; m.offset = node_offset; m.r0 = m.r1 = read_offset; m.internal = 0;
-            m.left_full = m.right_full = m.left_max = m.right_max = 0; m.pad[0] = m.pad[1] = m.pad[2] = 0; m.state = gs_find(h, snode);
+            m.left_full = m.right_full = m.left_max = m.right_max = 0; m.pad[0] = m.pad[1] = m.pad[2] = 0; m.state = gs_find(h, snode); m.frec = m.brec = G_NO_REC;
             const char* t = h.seq + g_rec(h, (uint32_t)(snode))[3];
             const uint32_t left = L - m.r1 < g_len(h, snode) - node_offset ? L - m.r1 : g_len(h, snode) - node_offset;
             m.r1 += g_match_fwd(c.seq + m.r1, t + node_offset, left, m.internal, 0xffffffffu);
@@ -431,22 +443,22 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
             if (!cur.right_max) {
                 uint32_t num_ext = 0;
                 const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
-                const uint32_t o = (uint32_t)cur.state.fn;
-                const uint32_t* orec = g_rec(h, o);
+                if (cur.frec == G_NO_REC) cur.frec = h.rec_off[(uint32_t)cur.state.fn];
+                const uint32_t* orec = h.rec + cur.frec;
                 const bool few = orec[1] <= 4 && !gs_empty(cur.state);
                 const GCounts cn = few ? g_counts(orec, cur.state.flo, cur.state.fhi) : GCounts{0, 0};
                 for (uint32_t e = 0; e < orec[1]; ++e) {
-                    const int32_t w = (int32_t)orec[4 + 2 * e]; if (w < 0) continue;
+                    const int32_t w = ge_to(orec, e); if (w < 0) continue;
                     const GState ns = few ? gs_extend_counted(orec, cur.state, e, cn) : gs_extend(h, cur.state, w);
                     if (gs_empty(ns)) continue;
                     if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
-                    GEntry nx = cur; nx.parent = ci; nx.node = w; nx.front = 0; nx.state = ns;
-                    const char* t = h.seq + g_rec(h, (uint32_t)(w))[3];                                           // match_forward (:239-266)
-                    const uint32_t no = g_match_fwd(c.seq + nx.r1, t, L - nx.r1 < g_len(h, w) ? L - nx.r1 : g_len(h, w), nx.internal, limit);
+                    GEntry nx = cur; nx.parent = ci; nx.node = w; nx.front = 0; nx.state = ns; nx.frec = ge_rec(orec, e);
+                    const char* t = h.seq + ge_seq(orec, e); const uint32_t wl = ge_len(orec, e);            // match_forward (:239-266)
+                    const uint32_t no = g_match_fwd(c.seq + nx.r1, t, L - nx.r1 < wl ? L - nx.r1 : wl, nx.internal, limit);
                     nx.r1 += no;
                     if (no == 0) continue;
                     if (nx.r1 >= L) { nx.right_full = nx.right_max = 1; nx.old = nx.internal; }
-                    else if (no < g_len(h, w)) { nx.right_max = 1; nx.old = nx.internal; }
+                    else if (no < wl) { nx.right_max = 1; nx.old = nx.internal; }
                     g_set_score(c, nx); nx.number = number++;
                     num_ext += gs_size(ns);
                     S.link[np] = g_link(nx);
@@ -464,22 +476,23 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
             if (!cur.left_max) {
                 bool found = false;
                 const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
-                const uint32_t o = (uint32_t)cur.state.bn;
-                const uint32_t* orec = g_rec(h, o);
+                if (cur.brec == G_NO_REC) cur.brec = h.rec_off[(uint32_t)cur.state.bn];
+                const uint32_t* orec = h.rec + cur.brec;
                 const GState flipped = gs_flip(cur.state);
                 const bool few = orec[1] <= 4 && !gs_empty(flipped);
                 const GCounts cn = few ? g_counts(orec, flipped.flo, flipped.fhi) : GCounts{0, 0};
                 for (uint32_t e = 0; e < orec[1]; ++e) {
-                    const int32_t x = (int32_t)orec[4 + 2 * e]; if (x < 0) continue;
+                    const int32_t x = ge_to(orec, e); if (x < 0) continue;
                     const GState ns = gs_flip(few ? gs_extend_counted(orec, flipped, e, cn) : gs_extend(h, flipped, x));   // bdExtendBackward
                     if (gs_empty(ns)) continue;
                     const int32_t w = ns.bn ^ 1;
                     if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
-                    GEntry nx = cur; nx.parent = ci; nx.node = w; nx.front = 1; nx.state = ns; nx.offset = g_len(h, w);
-                    const char* t = h.seq + g_rec(h, (uint32_t)(w))[3];                                           // match_backward (:268-296)
+                    const uint32_t wl = ge_len(orec, e);                                                  // w is the other strand of x: same length,
+                    const char* t = h.seq + ((x & 1) ? ge_seq(orec, e) - h.strand_shift : ge_seq(orec, e) + h.strand_shift);   // bases one strand_shift away
+                    GEntry nx = cur; nx.parent = ci; nx.node = w; nx.front = 1; nx.state = ns; nx.offset = wl; nx.brec = ge_rec(orec, e);   // match_backward (:268-296)
                     const uint32_t back = g_match_bwd(c.seq + nx.r0, t + nx.offset, nx.r0 < nx.offset ? nx.r0 : nx.offset, nx.internal, limit);
                     nx.r0 -= back; nx.offset -= back;
-                    if (nx.offset >= g_len(h, w)) continue;
+                    if (nx.offset >= wl) continue;
                     if (nx.r0 == 0) nx.left_full = nx.left_max = 1;
                     else if (nx.offset > 0) nx.left_max = 1;
                     g_set_score(c, nx); nx.number = number++;

@@ -153,18 +153,18 @@ VGK_HD uint32_t w_follow(const GIndex& h, const WState& s, uint32_t want, WState
     if (s.lo > s.hi) return 0;
     const uint32_t* rec = g_rec(h, (uint32_t)s.node);
     const uint32_t ne = rec[1];
-    const uint32_t* body = rec + 4 + 2 * ne;
+    const uint32_t* body = g_visits(rec);
     const bool few = ne <= 4;
     const GCounts cn = few ? g_counts(rec, s.lo, s.hi) : GCounts{0, 0};     // one pass over the visits serves every edge
     uint32_t k = 0;
     for (uint32_t e = 0; e < ne && k < stop_at; ++e) {
-        const int32_t to = (int32_t)rec[4 + 2 * e];
+        const int32_t to = ge_to(rec, e);
         if (to < 0) continue;
         int32_t before = 0, inside = 0;
         if (few) { before = (int32_t)g_count_of(cn.before, e); inside = (int32_t)g_count_of(cn.inside, e); }
         else for (int32_t i = 0; i <= s.hi; ++i) if (g_body(body, (uint32_t)i) == e) { if (i < s.lo) ++before; else ++inside; }
         if (!inside) continue;
-        if (k == want) { out.node = to; out.lo = (int32_t)rec[5 + 2 * e] + before; out.hi = out.lo + inside - 1; }
+        if (k == want) { out.node = to; out.lo = (int32_t)ge_base(rec, e) + before; out.hi = out.lo + inside - 1; }
         ++k;
     }
     return k;
