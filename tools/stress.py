@@ -51,5 +51,12 @@ for qa in (None, qualadj.qual_adj_tables()):
 # gapless
 total, full = test_gapless.compare_engines(None, range(seed * 1000, seed * 1000 + 150), n_reads=600)
 print("gapless: %d extensions over 90000 reads identical (%d full-length sets)" % (total, full))
+# WFA (incl. cyclic threads, custom error models) and the k-best pinned tracebacks
+import test_wfa
+import test_pinned_multi
+ok, statuses = test_wfa.compare_engines(None, range(seed * 1000, seed * 1000 + 120), n_problems=500)
+print("wfa: %d alignments identical; statuses %s" % (ok, statuses))
+total = test_pinned_multi.compare_engines(None, range(seed * 1000, seed * 1000 + 60), n_problems=150, max_alt=40)
+print("pinned k-best: %d alternates identical, none twice" % total)
 print("FAILURES", fails)
 sys.exit(1 if fails else 0)
