@@ -254,7 +254,7 @@ def main():
                     help="linear = BASELINE.json configs[1] (the headline metric); tails = configs[2] stand-in: "
                          "giraffe-style pinned X-drop tail alignments on a variation graph; banded = configs[4] stand-in: "
                          "banded global alignments between chained anchors; gapless = giraffe's first stage: "
-                         "haplotype-consistent gapless extension of seeds")
+                         "haplotype-consistent gapless extension of seeds; wfa = the long-read chaining stage's WFA connects and tails")
     args = ap.parse_args()
 
     from vg_amd import shard
