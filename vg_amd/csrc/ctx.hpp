@@ -36,7 +36,7 @@ struct vgk_ctx {
     }
     // page-locked staging arenas of vgk_gssw_pack, handed out per pack (callers may pack concurrently) and kept for the next one
     struct Staging {
-        vgk::Backend* be = nullptr; void* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; uint64_t bytes[5] = {0, 0, 0, 0, 0};
+        vgk::Backend* be = nullptr; void* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; uint64_t bytes[6] = {0, 0, 0, 0, 0, 0};   // [5]: the CIGAR ops on their way back
         void* get(int k, uint64_t want) {
             if (bytes[k] >= want) return p[k];
             if (p[k]) be->host_release(p[k]);

@@ -322,11 +322,21 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     //      graph size so that the pairs of a wavefront finish together.  One fill launch per K; G is per wavefront.
     lap("pass3");
     auto gkey = [&](uint32_t i) { return ((probs[i].geom & 0xffu) << 8) | ((probs[i].geom >> 8) & 0xffu); };   // (K, G)
+    // stable order by (K, G) ascending, then graph size descending: two counting-sort passes over 16-bit digits (sizes beyond 65 535
+    // columns share the last digit value; the order only balances wavefronts, it never changes a result)
     std::vector<uint32_t> idx(n);
-    for (uint32_t i = 0; i < n; ++i) idx[i] = i;
-    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
-        if (gkey(x) != gkey(y)) return gkey(x) < gkey(y);
-        return probs[x].R > probs[y].R; });
+    {
+        std::vector<uint32_t> tmp(n), count(65537);
+        auto low = [&](uint32_t i) { return 0xffffu - std::min<uint32_t>(probs[i].R, 0xffffu); };
+        std::fill(count.begin(), count.end(), 0u);
+        for (uint32_t i = 0; i < n; ++i) ++count[low(i) + 1];
+        for (uint32_t k = 0; k < 65536; ++k) count[k + 1] += count[k];
+        for (uint32_t i = 0; i < n; ++i) tmp[count[low(i)]++] = i;
+        std::fill(count.begin(), count.end(), 0u);
+        for (uint32_t i = 0; i < n; ++i) ++count[gkey(i) + 1];
+        for (uint32_t k = 0; k < 65536; ++k) count[k + 1] += count[k];
+        for (uint32_t i = 0; i < n; ++i) idx[count[gkey(tmp[i])]++] = tmp[i];
+    }
     lap("sort");
     std::vector<uint32_t> order;              // pairs
     std::vector<WaveDesc> waves;
@@ -425,23 +435,37 @@ int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_ca
     std::lock_guard<std::mutex> lk(b->ctx->mu);
     int rc = b->ctx->be->download(results, b->P.results, (size_t)b->n * sizeof(vgk_result));
     if (rc) return rc;
-    std::vector<vgk_op> all;
+    // the per-problem op slots come back through a page-locked staging buffer (no zero-fill, full-rate DMA) ...
+    struct StagingLease {
+        vgk_ctx* ctx; std::unique_ptr<vgk_ctx::Staging> s;
+        ~StagingLease() { if (s) ctx->staging_release(std::move(s)); }
+    } lease{b->ctx, nullptr};
+    const vgk_op* all = nullptr;
     if (b->want_tb && b->ops_total) {
-        all.resize(b->ops_total);
-        rc = b->ctx->be->download(all.data(), b->P.ops, (size_t)b->ops_total * sizeof(vgk_op));
+        lease.s = b->ctx->staging_acquire();
+        vgk_op* buf = (vgk_op*)lease.s->get(5, (uint64_t)b->ops_total * sizeof(vgk_op));
+        if (!buf) return VGK_ENOMEM;
+        rc = b->ctx->be->download(buf, b->P.ops, (size_t)b->ops_total * sizeof(vgk_op));
         if (rc) return rc;
+        all = buf;
     }
+    // ... and are packed behind each other in the caller's order: sizes, a prefix sum, then parallel copies
     size_t w = 0; uint64_t alg = 0;
+    std::vector<uint32_t> src(b->n);
     for (uint32_t i = 0; i < b->n; ++i) {
         vgk_result& r = results[i];
         const ProbDesc& d = b->probs[i];
+        src[i] = r.ops_begin;
         if (r.status == VGK_OK && r.n_ops) {
             if (!ops || w + r.n_ops > ops_cap) { r.status = VGK_EOPS; r.n_ops = 0; r.ops_begin = (uint32_t)w; continue; }
-            std::memcpy(ops + w, all.data() + r.ops_begin, (size_t)r.n_ops * sizeof(vgk_op));
             r.ops_begin = (uint32_t)w; w += r.n_ops;
         } else { r.n_ops = 0; r.ops_begin = (uint32_t)w; }
         alg += 16 + 2ull * r.n_ops + ((d.flags & VGK_GSSW_TRACEBACK) ? (uint64_t)d.L * d.R : 0);
     }
+    if (all) parallel_for(b->n, [&](uint32_t i, unsigned) {
+        const vgk_result& r = results[i];
+        if (r.status == VGK_OK && r.n_ops) std::memcpy(ops + r.ops_begin, all + src[i], (size_t)r.n_ops * sizeof(vgk_op));
+    });
     b->alg_bytes = b->in_bytes + alg;
     if (ops_written) *ops_written = w;
     return VGK_OK;
