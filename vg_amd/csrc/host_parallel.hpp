@@ -2,24 +2,98 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdlib>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
+#include <unistd.h>
 
 namespace vgk {
 
 constexpr unsigned MAX_THREADS = 128;
+
+// Worker threads that stay around between calls: a pack / unpack loop over a thousand problems takes less time than starting
+// 32 threads does.  One job at a time; a caller that finds the pool busy (several callers packing at once) starts its own
+// threads instead, and a process that was forked after the pool came up gets a new pool.
+class WorkerPool {
+public:
+    static WorkerPool& get() {
+        static std::mutex guard;
+        static std::unique_ptr<WorkerPool> pool;
+        std::lock_guard<std::mutex> lock(guard);
+        if (!pool || pool->owner != getpid()) { if (pool) (void)pool.release(); pool.reset(new WorkerPool()); }    // a forked child cannot use (or join) the parent's threads
+        return *pool;
+    }
+    // runs job(t) for t in [0, T) — t = 0 on the calling thread — and returns when all are done; false = pool busy, nothing ran
+    bool try_run(unsigned T, const std::function<void(unsigned)>& job) {
+        std::unique_lock<std::mutex> one(submit, std::try_to_lock);
+        if (!one.owns_lock()) return false;
+        {
+            std::lock_guard<std::mutex> lock(m);
+            while (threads.size() + 1 < T) { const unsigned id = (unsigned)threads.size() + 1; threads.emplace_back([this, id] { work(id); }); }
+            current = &job; want = T; pending = T - 1; ++epoch;
+        }
+        cv_start.notify_all();
+        job(0);
+        std::unique_lock<std::mutex> lock(m);
+        cv_done.wait(lock, [this] { return pending == 0; });
+        current = nullptr;
+        return true;
+    }
+    ~WorkerPool() {
+        if (owner != getpid()) { for (auto& t : threads) t.detach(); return; }
+        { std::lock_guard<std::mutex> lock(m); stop = true; ++epoch; }
+        cv_start.notify_all();
+        for (auto& t : threads) t.join();
+    }
+private:
+    WorkerPool() : owner(getpid()) {}
+    void work(unsigned id) {
+        uint64_t seen;
+        { std::lock_guard<std::mutex> lock(m); seen = epoch - 1; }       // the job that created this thread is its first
+        for (;;) {
+            const std::function<void(unsigned)>* job = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv_start.wait(lock, [&] { return epoch != seen; });
+                seen = epoch;
+                if (stop) return;
+                if (id < want) job = current;
+            }
+            if (job) {
+                (*job)(id);
+                std::lock_guard<std::mutex> lock(m);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+    pid_t owner;
+    std::mutex submit, m;
+    std::condition_variable cv_start, cv_done;
+    std::vector<std::thread> threads;
+    const std::function<void(unsigned)>* current = nullptr;
+    uint64_t epoch = 0; unsigned want = 0, pending = 0; bool stop = false;
+};
+
 // run f(i, thread) for i in [0, n) on a few host threads
 template <class F> inline void parallel_for(uint32_t n, F f) {
     unsigned hw = std::thread::hardware_concurrency();
     unsigned T = std::min<unsigned>(hw ? hw : 1, 32u);
     if (const char* e = std::getenv("VGAMD_HOST_THREADS")) T = (unsigned)std::min<int>(MAX_THREADS, std::max(1, std::atoi(e)));
     if (n < 256 || T <= 1) { for (uint32_t i = 0; i < n; ++i) f(i, 0u); return; }
+    T = std::min<unsigned>(T, (n + 63) / 64);                      // no more threads than blocks of work
     std::atomic<uint32_t> next{0};
-    std::vector<std::thread> ts;
-    for (unsigned t = 0; t < T; ++t) ts.emplace_back([&, t]() {
+    const std::function<void(unsigned)> body = [&](unsigned t) {
         for (;;) { const uint32_t b = next.fetch_add(64); if (b >= n) break; for (uint32_t i = b; i < std::min(n, b + 64); ++i) f(i, t); }
-    });
+    };
+    if (T <= 1) { body(0); return; }
+    if (WorkerPool::get().try_run(T, body)) return;
+    std::vector<std::thread> ts;                                     // the pool is busy with another caller's loop
+    for (unsigned t = 1; t < T; ++t) ts.emplace_back([&body, t]() { body(t); });
+    body(0);
     for (auto& t : ts) t.join();
 }
 
