@@ -35,6 +35,7 @@ inline uint8_t nt_code(char ch) {      // gssw_create_nt_table: case-insensitive
 struct Span { uint64_t off = 0; uint32_t len = 0; };
 struct Prep {                          // one problem after pass 1; its tables live in the preparing thread's Store
     int status = VGK_OK;
+    uint32_t order_key = 0;
     bool on_device = false;
     uint32_t R = 1, Hpad = 64, thread = 0;
     uint64_t cells = 0, bases = 0, tb_bytes = 0, last_elems = 0;
@@ -120,7 +121,9 @@ void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch&
     uint32_t R = 1; while ((int64_t)R * 64 < max_h) R *= 2;
     if (R > 32 || L > (1 << 24) || total_bases > (1u << 24)) { hp.status = VGK_ETOOBIG; return; }      // engine limit: bands up to 2048 diagonals
     hp.R = R; hp.Hpad = 64 * R;
-    const uint32_t Hpad = hp.Hpad;
+    { uint32_t r = 0; while ((1u << r) < R) ++r;                  // launch order: rows-per-lane class, then most cells first (by log2)
+      uint32_t lg = 0; while ((hp.cells >> lg) > 1 && lg < 63) ++lg;
+      hp.order_key = r * 64 + (63 - lg); }
 
     // node records with the flattened predecessor lists
     uint64_t tb_off = 0, last_off = 0; uint32_t seq_off = 0;
@@ -545,8 +548,7 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
             uint32_t* order = H.order.get(m);
             std::vector<BandedLaunch> launches;
             {
-                auto key = [&](uint32_t a) { const Prep& hp = hps[owner[a]]; uint32_t r = 0; while ((1u << r) < hp.R) ++r;
-                                             uint32_t lg = 0; while ((hp.cells >> lg) > 1 && lg < 63) ++lg; return r * 64 + (63 - lg); };
+                auto key = [&](uint32_t a) { return hps[owner[a]].order_key; };
                 std::vector<uint32_t> count(6 * 64 + 1, 0);
                 for (uint32_t a = 0; a < m; ++a) ++count[key(a) + 1];
                 for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
