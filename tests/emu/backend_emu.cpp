@@ -55,7 +55,7 @@ public:
         return VGK_OK;
     }
     int run_wfa(const WfaParams& P, uint32_t threads) override {
-        for (uint32_t t = 0; t < threads; ++t) wfa_thread(P, t);
+        for (uint32_t t = 0; t < threads; ++t) wfa_thread(P, t, nullptr, 1);
         return VGK_OK;
     }
     int run_gapless(const GaplessParams& P, uint32_t threads) override {

@@ -143,8 +143,9 @@ __global__ void __launch_bounds__(64, 4) gapless_kernel(const GaplessParams P, c
 
 // ---- wavefront alignment (wfa_device.hpp): the same launch shape
 __global__ void __launch_bounds__(64, 4) wfa_kernel(const WfaParams P, const uint32_t threads) {
+    __shared__ uint32_t node_end[W_NODES * 64];                    // [trie node][lane]: conflict-free, 8 KB per wavefront
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
-    if (t < threads) wfa_thread(P, t);
+    if (t < threads) wfa_thread(P, t, node_end + threadIdx.x, 64);
 }
 
 // ---- pinned gssw fill with full matrices (gssw_matrix_device.hpp)

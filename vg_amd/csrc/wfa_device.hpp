@@ -64,7 +64,8 @@ struct WScratch {
     uint64_t slot[W_SLOTS];           // (key + 1) << 32 | seq << 16 | off ; 0 = free
     uint16_t log[W_POINTS];
     WNode    nodes[W_NODES];
-    uint32_t node_end[W_NODES];       // copy of nodes[i].len | complete << 31: what "is this offset past the node's end?" reads
+    uint32_t node_end[W_NODES];       // nodes[i].len | complete << 31: what "is this offset past the node's end?" reads — the most frequent
+                                      // question of all; the HIP kernel keeps these words in LDS instead (WCtx::end / end_stride)
     int32_t  path_node[W_PATH];
     uint16_t path_start[W_PATH];      // offset of the graph node inside its trie node
     uint16_t path_next[W_PATH];
@@ -94,6 +95,7 @@ VGK_HD int32_t w_distance(const WPos& p, int32_t diag) { return 2 * (int32_t)p.s
 
 struct WCtx {
     const WfaParams* P; WScratch* S;
+    uint32_t* end; uint32_t end_stride;                           // node_end word of trie node i at end[i * end_stride]
     const char* seq; uint32_t L;
     int32_t to_node; uint32_t to_off; bool no_to;
     uint32_t n_nodes, n_path, n_points;
@@ -191,7 +193,7 @@ VGK_HD void w_node_init(WCtx& c, uint32_t id, const WState& state, uint32_t pare
     n.ancestors = (id ? c.S->nodes[parent].ancestors : 0u) | (1u << id);
     c.leaves |= 1u << id;
     n.complete = w_append_node(c, n, state) ? 1 : 0;
-    c.S->nodes[id] = n; c.S->node_end[id] = n.len | ((uint32_t)n.complete << 31);
+    c.S->nodes[id] = n; c.end[id * c.end_stride] = n.len | ((uint32_t)n.complete << 31);
 }
 // one turn of the constructor's loop (:1470-1487)
 VGK_HD void w_grow(WCtx& c, uint32_t id) {
@@ -204,12 +206,12 @@ VGK_HD void w_grow(WCtx& c, uint32_t id) {
         else if (successors > 1) n.complete = 1;
         else if (w_append_node(c, n, next)) n.complete = 1;
     }
-    c.S->nodes[id] = n; c.S->node_end[id] = n.len | ((uint32_t)n.complete << 31);
+    c.S->nodes[id] = n; c.end[id * c.end_stride] = n.len | ((uint32_t)n.complete << 31);
 }
 // is `off` at or past the end of the trie node?  Grows the node until that is known.
 VGK_HD bool w_past_end(WCtx& c, uint32_t id, uint32_t off) {
-    uint32_t e = c.S->node_end[id];
-    while (!(e >> 31) && (e & 0x7fffffffu) <= off) { w_grow(c, id); e = c.S->node_end[id]; }
+    uint32_t e = c.end[id * c.end_stride];
+    while (!(e >> 31) && (e & 0x7fffffffu) <= off) { w_grow(c, id); e = c.end[id * c.end_stride]; }
     return off >= (e & 0x7fffffffu);
 }
 
@@ -285,7 +287,7 @@ VGK_HD void w_successor_offset(WCtx& c, WPos& p) {                              
 }
 VGK_HD void w_predecessor_offset(const WCtx& c, uint32_t& node, uint32_t& off) {                  // (:1835-1842)
     if (off > 0) --off;
-    else { node = c.S->nodes[node].parent; off = (c.S->node_end[node] & 0x7fffffffu) - 1; }
+    else { node = c.S->nodes[node].parent; off = (c.end[node * c.end_stride] & 0x7fffffffu) - 1; }
 }
 
 VGK_HD void w_expand_if_necessary(WCtx& c, const WPos& p) {                                       // (:1992-2008)
@@ -475,13 +477,13 @@ VGK_HD void w_append_edit(WCtx& c, uint32_t& n_edits, int edit, uint32_t length)
 
 // One problem (WFAExtender::connect :2052-2235; suffix :2237-2246; the strand flip of prefix :2248-2263 happens as the
 // result is written out: the backtrace yields the edits last-to-first, which is the flipped order).
-VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S) {
+VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S, uint32_t* end, uint32_t end_stride) {
     const WProb pb = P.probs[i];
     vgk_wfa_result out; out.status = pb.status; out.ok = 0; out.score = 0; out.node_offset = 0; out.seq_offset = 0; out.length = 0;
     out.path_begin = 0; out.path_len = 0; out.edit_begin = 0; out.n_edits = 0;
     if (pb.status != VGK_OK || pb.from_node >= P.index.n_oriented) { P.results[i] = out; return; }     // !has_node(id(from)) (:2059)
     WCtx c;
-    c.P = &P; c.S = &S; c.seq = P.seqs + pb.seq_off; c.L = pb.seq_len;
+    c.P = &P; c.S = &S; c.end = end; c.end_stride = end_stride; c.seq = P.seqs + pb.seq_off; c.L = pb.seq_len;
     c.no_to = pb.to_node == VGK_WFA_NO_NODE; c.to_node = (int32_t)pb.to_node; c.to_off = pb.to_off;
     c.n_nodes = 0; c.n_path = 0; c.n_points = 0; c.leaves = 0; c.overflow = false; c.why = 0;
     c.cand_score = 0x7fffffff; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0;
@@ -606,12 +608,13 @@ VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S) {
     for (uint32_t k = 0; k < c.n_points; ++k) S.slot[S.log[k]] = 0;                                  // leave the table clean
     P.results[i] = out;
 }
-// one resident thread: problems are handed out one at a time
-VGK_HD void wfa_thread(const WfaParams& P, uint32_t t) {
+// one resident thread: problems are handed out one at a time.  `end` = W_NODES words for this thread's node ends, `end_stride`
+// words apart (LDS in the HIP kernel, lane-interleaved; the slab's own array otherwise)
+VGK_HD void wfa_thread(const WfaParams& P, uint32_t t, uint32_t* end, uint32_t end_stride) {
     for (;;) {
         const unsigned long long i = g_bump(P.counters + 2, 1);
         if (i >= P.n) break;
-        wfa_extend_one(P, (uint32_t)i, P.scratch[t]);
+        wfa_extend_one(P, (uint32_t)i, P.scratch[t], end ? end : P.scratch[t].node_end, end ? end_stride : 1u);
     }
 }
 
