@@ -414,7 +414,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
         uint32_t np = 0, hn = 0, number = 0;
         bool have_cand = false; GEntry cand; uint16_t cand_idx = 0;
         int32_t best = -1;
-        GEntry best_e; best_e.score = 0; best_e.r0 = best_e.r1 = 0;
+        GEntry best_e; best_e.score = 0; best_e.r0 = best_e.r1 = 0; best_e.offset = 0; best_e.internal = 0; best_e.left_full = best_e.right_full = 0;
         {   // the seed node itself: any number of mismatches (:213-237)
             GEntry m;
             m.parent = -1; m.node = snode; m.front = 0; m.offset = node_offset; m.r0 = m.r1 = read_offset; m.internal = 0;

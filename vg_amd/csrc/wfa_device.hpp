@@ -234,7 +234,7 @@ VGK_HD WSrc w_src(const WCtx& c, int32_t score) {
 // WFATree::find_pos (:2015-2040) from a trie node with the given ancestor mask
 VGK_HD WPos w_find_in(WCtx& c, int kind, const WSrc& src, uint32_t ancestors, uint32_t origin, int32_t diag, bool ext_seq, bool ext_graph) {
     if (diag < src.lo || diag > src.hi) return w_none();
-    uint32_t holder, seq, off;
+    uint32_t holder = 0, seq = 0, off = 0;
     if (!w_lookup(c, ancestors, kind, src.score, diag, holder, seq, off)) return w_none();
     WPos p = { seq, off, (uint8_t)holder, (uint8_t)origin, false };
     if (ext_seq && p.seq >= c.L) return w_none();
