@@ -5,6 +5,19 @@
 #include <vector>
 #include "backend.hpp"
 
+// page-locked host staging kept on the context between calls: uninitialised, no page faults, full-rate DMA in both directions
+template <class T> struct PinnedBuf {
+    vgk::Backend* be = nullptr; T* p = nullptr; size_t cap = 0;
+    T* get(vgk::Backend* b, size_t n) {
+        if (n > cap || !p) { if (p) be->host_release(p); be = b; cap = n + n / 4 + 64; p = (T*)b->host_alloc(cap * sizeof(T)); if (!p) cap = 0; }
+        return p;
+    }
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { if (p) be->host_release(p); }
+};
+
 struct vgk_ctx {
     vgk_scoring sc;
     std::unique_ptr<vgk::Backend> be;

@@ -18,7 +18,7 @@ using namespace vgk;
 
 namespace {
 
-struct GaplessHost { RawBuf<char> reads; RawBuf<vgk_seed> seeds; RawBuf<vgk_gapless_result> dres; RawBuf<vgk_extension> dext; RawBuf<uint32_t> dnodes, dmism; };
+struct GaplessHost { PinnedBuf<char> reads; PinnedBuf<vgk_seed> seeds; PinnedBuf<vgk_gapless_result> dres; PinnedBuf<vgk_extension> dext; PinnedBuf<uint32_t> dnodes, dmism; };
 
 char complement(char c) {
     switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
@@ -197,7 +197,8 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     }
     if (!ctx->gapless_host) ctx->gapless_host = std::make_shared<GaplessHost>();
     GaplessHost& H = *static_cast<GaplessHost*>(ctx->gapless_host.get());
-    char* reads = H.reads.get(n_read + 16); vgk_seed* seeds = H.seeds.get(n_seed + 1);     // 8 bytes of padding at either end
+    char* reads = H.reads.get(be, n_read + 16); vgk_seed* seeds = H.seeds.get(be, n_seed + 1);
+    if (!reads || !seeds) return VGK_ENOMEM;     // 8 bytes of padding at either end
     std::memset(reads, 0, 8); std::memset(reads + 8 + n_read, 0, 8);
     parallel_for(n, [&](uint32_t i, unsigned) {
         const vgk_gapless_problem& p = problems[i];
@@ -242,11 +243,13 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     if ((rc = be->run_gapless(P, threads))) return cleanup(rc);
     ctx->gapless_last = P; ctx->gapless_last_threads = threads; ctx->gapless_last_valid = true;
     unsigned long long counters[3] = {0, 0, 0};
-    vgk_gapless_result* dres = H.dres.get(n);
+    vgk_gapless_result* dres = H.dres.get(be, n);
+    if (!dres) return cleanup(VGK_ENOMEM);
     if ((rc = be->download(counters, P.counters, sizeof counters))) return cleanup(rc);
     if ((rc = be->download(dres, P.results, sizeof(vgk_gapless_result) * n))) return cleanup(rc);
     const uint64_t ne = std::min<uint64_t>(counters[0], cap_e), nn = std::min<uint64_t>(counters[1], cap_n), nm = std::min<uint64_t>(counters[2], cap_m);
-    vgk_extension* dext = H.dext.get(ne + 1); uint32_t* dnodes = H.dnodes.get(nn + 1); uint32_t* dmism = H.dmism.get(nm + 1);
+    vgk_extension* dext = H.dext.get(be, ne + 1); uint32_t* dnodes = H.dnodes.get(be, nn + 1); uint32_t* dmism = H.dmism.get(be, nm + 1);
+    if (!dext || !dnodes || !dmism) return cleanup(VGK_ENOMEM);
     if (ne && (rc = be->download(dext, P.ext, sizeof(vgk_extension) * ne))) return cleanup(rc);
     if (nn && (rc = be->download(dnodes, P.nodes, sizeof(uint32_t) * nn))) return cleanup(rc);
     if (nm && (rc = be->download(dmism, P.mism, sizeof(uint32_t) * nm))) return cleanup(rc);

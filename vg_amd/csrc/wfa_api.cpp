@@ -16,7 +16,7 @@ using namespace vgk;
 
 namespace {
 
-struct WfaHost { RawBuf<char> seqs; RawBuf<WProb> probs; RawBuf<vgk_wfa_result> dres; RawBuf<uint32_t> dpaths, dedits; uint64_t zeroed_bytes = 0; void* zeroed_ptr = nullptr; };
+struct WfaHost { PinnedBuf<char> seqs; PinnedBuf<WProb> probs; PinnedBuf<vgk_wfa_result> dres; PinnedBuf<uint32_t> dpaths, dedits; uint64_t zeroed_bytes = 0; void* zeroed_ptr = nullptr; };
 
 const vgk_wfa_error_model kDefaultModel = { { 0.03, 1, 6 }, { 0.05, 1, 10 }, { 0.1, 1, 20 }, { 0.1, 10, 200 } };   // gbwt_extender.hpp:386-395
 
@@ -51,7 +51,8 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
 
     if (!ctx->wfa_host) ctx->wfa_host = std::make_shared<WfaHost>();
     WfaHost& H = *static_cast<WfaHost*>(ctx->wfa_host.get());
-    WProb* probs = H.probs.get(n);
+    WProb* probs = H.probs.get(be, n);
+    if (!probs) return VGK_ENOMEM;
     uint64_t n_seq = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const vgk_wfa_problem& p = problems[i];
@@ -81,7 +82,8 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
         n_seq += w.seq_len;
         if (n_seq > 0xfffffff0ull) return VGK_ETOOBIG;
     }
-    char* seqs = H.seqs.get(n_seq + 16);
+    char* seqs = H.seqs.get(be, n_seq + 16);
+    if (!seqs) return VGK_ENOMEM;
     std::memset(seqs, 0, 8); std::memset(seqs + 8 + n_seq, 0, 8);
     parallel_for(n, [&](uint32_t i, unsigned) {
         const vgk_wfa_problem& p = problems[i]; const WProb& w = probs[i];
@@ -123,11 +125,13 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     ctx->wfa_last = P; ctx->wfa_last_threads = threads; ctx->wfa_last_valid = true;
     ctx->wfa_ms = be->last_ms(6);
     unsigned long long counters[2] = {0, 0};
-    vgk_wfa_result* dres = H.dres.get(n);
+    vgk_wfa_result* dres = H.dres.get(be, n);
+    if (!dres) return VGK_ENOMEM;
     if ((rc = be->download(counters, P.counters, sizeof counters))) return rc;
     if ((rc = be->download(dres, P.results, sizeof(vgk_wfa_result) * n))) return rc;
     const uint64_t np = std::min<uint64_t>(counters[0], cap_p), ne = std::min<uint64_t>(counters[1], cap_e);
-    uint32_t* dpaths = H.dpaths.get(np + 1); uint32_t* dedits = H.dedits.get(ne + 1);
+    uint32_t* dpaths = H.dpaths.get(be, np + 1); uint32_t* dedits = H.dedits.get(be, ne + 1);
+    if (!dpaths || !dedits) return VGK_ENOMEM;
     if (np && (rc = be->download(dpaths, P.paths, sizeof(uint32_t) * np))) return rc;
     if (ne && (rc = be->download(dedits, P.edits, sizeof(uint32_t) * ne))) return rc;
     // the device packs alignments in completion order; hand them back in problem order
