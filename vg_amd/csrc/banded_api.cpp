@@ -222,8 +222,8 @@ template <class T> int stage(vgk_ctx* ctx, int slot, const T* v, size_t count, c
 }
 // host arenas kept on the context between calls: uninitialised storage, so a warm call neither zero-fills nor page-faults
 struct HostArenas {
-    RawBuf<BProb> probs; RawBuf<BNode> nodes; RawBuf<BSeed> seeds; RawBuf<uint32_t> pool, order; RawBuf<BStart> starts;
-    RawBuf<uint8_t> reads, quals, graph; RawBuf<BResult> dres; RawBuf<vgk_op> dops; RawBuf<int32_t> scores;
+    PinnedBuf<BProb> probs; PinnedBuf<BNode> nodes; PinnedBuf<BSeed> seeds; PinnedBuf<uint32_t> pool, order; PinnedBuf<BStart> starts;
+    PinnedBuf<uint8_t> reads, quals, graph; PinnedBuf<BResult> dres; PinnedBuf<vgk_op> dops; PinnedBuf<int32_t> scores;
 };
 enum { S_PROBS, S_ORDER, S_NODES, S_SEEDS, S_POOL, S_STARTS, S_READS, S_QUALS, S_GRAPH, S_MAT, S_TB, S_LAST, S_OPS, S_DENSE, S_RESULTS, S_COUNT };
 constexpr int S_SCORES = 31;          // k-best mode: the full score matrices (slots 15..30 belong to gapless_api.cpp)
@@ -508,7 +508,8 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
             owner.push_back(j);
         }
         const uint32_t m = (uint32_t)owner.size();
-        BProb* probs = H.probs.get(m);
+        BProb* probs = H.probs.get(be, m);
+        if (!probs) return VGK_ENOMEM;
         {
             uint64_t a_nodes = 0, a_seeds = 0, a_pool = 0, a_starts = 0, a_read = 0, a_graph = 0, a_tb = 0, a_last = 0, a_ops = 0;
             for (uint32_t a = 0; a < m; ++a) {
@@ -524,12 +525,14 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
             }
         }
         lap("place");
-        BResult* dres = H.dres.get(m + 1);
+        BResult* dres = H.dres.get(be, m + 1);
+        if (!dres) return VGK_ENOMEM;
         const vgk_op* dops = nullptr;
         if (m) {
             // pass 3: copy into the arenas
-            BNode* nodes = H.nodes.get(n_nodes); BSeed* seeds = H.seeds.get(n_seeds); uint32_t* pool = H.pool.get(n_pool); BStart* starts = H.starts.get(n_starts);
-            uint8_t* reads = H.reads.get(n_read); uint8_t* quals = qa ? H.quals.get(n_read) : nullptr; uint8_t* graph = H.graph.get(n_graph);
+            BNode* nodes = H.nodes.get(be, n_nodes); BSeed* seeds = H.seeds.get(be, n_seeds); uint32_t* pool = H.pool.get(be, n_pool); BStart* starts = H.starts.get(be, n_starts);
+            uint8_t* reads = H.reads.get(be, n_read); uint8_t* quals = qa ? H.quals.get(be, n_read) : nullptr; uint8_t* graph = H.graph.get(be, n_graph);
+            if (!nodes || !seeds || !pool || !starts || !reads || (qa && !quals) || !graph) return VGK_ENOMEM;
             parallel_for(m, [&](uint32_t a, unsigned) {
                 const Prep& hp = hps[owner[a]]; const BProb& pb = probs[a]; const vgk_banded_problem& p = problems[owner[a]];
                 const Store& T = store[hp.thread];
@@ -545,7 +548,8 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
             });
             lap("arenas");
             // launches: one per rows-per-lane class; inside a class the problems with the most cells first (counting sort on log2(cells))
-            uint32_t* order = H.order.get(m);
+            uint32_t* order = H.order.get(be, m);
+            if (!order) return VGK_ENOMEM;
             std::vector<BandedLaunch> launches;
             {
                 auto key = [&](uint32_t a) { return hps[owner[a]].order_key; };
@@ -589,7 +593,8 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
             ctx->banded_last = P; ctx->banded_last_launches = launches; ctx->banded_last_valid = (i == 0 && j == n);     // the whole call in one sub-batch
             if (multi) {
                 // k-best: every problem's alternates are enumerated on a host thread over its score matrices
-                int32_t* hs = H.scores.get(tb_bytes * 3 + 1);
+                int32_t* hs = H.scores.get(be, tb_bytes * 3 + 1);
+                if (!hs) return VGK_ENOMEM;
                 if ((rc = be->download(hs, P.scores, (size_t)tb_bytes * 3 * sizeof(int32_t)))) return rc;
                 ctx->banded_ms[0] += be->last_ms(3);
                 lap("d2h");
@@ -614,7 +619,8 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
                 unsigned long long dense_n = 0;
                 if ((rc = be->download(&dense_n, P.dense_count, sizeof dense_n))) return rc;
                 if ((rc = be->download(dres, P.results, (size_t)m * sizeof(BResult)))) return rc;
-                vgk_op* hd = H.dops.get(dense_n + 1);
+                vgk_op* hd = H.dops.get(be, dense_n + 1);
+                if (!hd) return VGK_ENOMEM;
                 if (dense_n && (rc = be->download(hd, P.dense, (size_t)dense_n * sizeof(vgk_op)))) return rc;
                 dops = hd;
                 ctx->banded_ms[0] += be->last_ms(3); ctx->banded_ms[1] += be->last_ms(4);
