@@ -299,6 +299,29 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
         if (nB) sb = set_hi(sb, row < s.LB ? P.bias + row_bonus(s.bsB, s.beB, row, s.LB) : 0u);
     }
     const uint32_t old = s.H[M];
+    if constexpr (S8) {
+        // Scores scaled by 8 leave the three low bits of every value free, and they survive the subtraction of (scaled) constants.
+        // Candidates carry a tag there, so the source of a maximum is read off the maximum instead of being recomputed from four
+        // differences: H candidates 4 (diagonal) > 3 (E) > <= 1 (F) — ties go diagonal, then E, as in the untagged build —, gap
+        // candidates 1 (opened from H) > 0 (extended) — ties go to the open.  The constants absorb the tags (t - (bias - 4) etc.);
+        // E and F inputs are normalised by an OR before they are extended; H is stored clean (it feeds the diagonal sum, the
+        // end-cell key and the next gap open).  A saturated 0 has no tag: cells worth 0 are never walked.
+        const uint32_t t4 = pk_subs(pk_add_nc(d, sb), bias2 - 0x00040004u);
+        const uint32_t ei = s.E[M] | 0x00030003u;
+        const uint32_t h = pk_max(pk_max(t4, ei), f);
+        const uint32_t hc = h & 0xfff8fff8u;
+        const uint32_t gg = pk_subs(hc, go2 - 0x00010001u);
+        const uint32_t e2 = pk_subs(ei, ge2 + 0x00030003u), f2 = pk_subs(f | 0x00010001u, ge2 + 0x00010001u);
+        const uint32_t en = pk_max(gg, e2), fn = pk_max(gg, f2);
+        // traceback code: bit0 = next-column E was opened, bits 1-2 = H source (2 diagonal, 1 E, 0 F), bit3 = next-row F was opened
+        uint32_t code = (en & 0x00010001u) | (h & 0x00060006u);
+        code |= (fn & 0x00010001u) << 3;
+        acc[M >> 2] = (M & 3) == 0 ? code : pk_mul_add_imm<16>(acc[M >> 2], code);
+        const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(hc, 0x00010001u << (KEY_SHIFT - 3));
+        ck = M == 0 ? key : pk_max(ck, key);
+        s.H[M] = hc; s.E[M] = en; f = fn; d = old;
+        return;
+    }
     const uint32_t t4 = pk_subs(pk_add_nc(d, sb), bias2);  // max(0, diag + s); the sum stays far below 2^16 per half
     const uint32_t e = s.E[M];
     const uint32_t h = pk_max(pk_max(t4, e), f);
@@ -307,20 +330,17 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
     const uint32_t en = pk_max(gg, e2), fn = pk_max(gg, f2);
     // traceback code: bit0 = H not from diagonal, bit1 = H not from E (then F),
     // bit2 = next-column E is an extension, bit3 = next-row F is an extension.
-    // min(x, 1) with an opaque `one` keeps each flag at 2 ops; the merges are v_pk_mad_u16, or — with scores
-    // scaled by 8, where a non-zero difference is >= 8 — min(x, 1|2|4|8) yields the weighted bit directly.
+    // min(x, 1) with an opaque `one` keeps each flag at 2 ops; the merges are v_pk_mad_u16.
     const uint32_t one = s.one;
     // every difference below has a >= b in both halves (h, en, fn are maxima over the subtrahend), so the
     // full-rate 32-bit subtract is exact on the packed pair
     const uint32_t nd = pk_min(pk_sub_nb(h, t4), one);
-    const uint32_t ne = pk_min(pk_sub_nb(h, e), S8 ? 0x00020002u : one);
-    const uint32_t eb = pk_min(pk_sub_nb(en, gg), S8 ? 0x00040004u : one);     // next-column E != H - go  <=>  extension won strictly
-    const uint32_t fb = pk_min(pk_sub_nb(fn, gg), S8 ? 0x00080008u : one);
-    uint32_t code;
-    if (S8) code = nd | ne | eb | fb;                      // bits arrive weighted 1,2,4,8
-    else { code = pk_mul_add_imm<2>(ne, nd); code = pk_mul_add_imm<4>(eb, code); code = pk_mul_add_imm<8>(fb, code); }
+    const uint32_t ne = pk_min(pk_sub_nb(h, e), one);
+    const uint32_t eb = pk_min(pk_sub_nb(en, gg), one);     // next-column E != H - go  <=>  extension won strictly
+    const uint32_t fb = pk_min(pk_sub_nb(fn, gg), one);
+    uint32_t code = pk_mul_add_imm<2>(ne, nd); code = pk_mul_add_imm<4>(eb, code); code = pk_mul_add_imm<8>(fb, code);
     acc[M >> 2] = (M & 3) == 0 ? code : pk_mul_add_imm<16>(acc[M >> 2], code);
-    const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(h, S8 ? (0x00010001u << (KEY_SHIFT - 3)) : (0x00010001u << KEY_SHIFT));
+    const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(h, 0x00010001u << KEY_SHIFT);
     ck = M == 0 ? key : pk_max(ck, key);
     s.H[M] = h; s.E[M] = en; f = fn; d = old;
 }
@@ -412,10 +432,15 @@ VGK_HD uint64_t tb_dword(uint64_t tb_off, uint32_t t, uint32_t lane, uint32_t re
 
 struct Walker {
     const GsswParams& P; const ProbDesc& d; uint32_t half, lane0, K; uint64_t tb_off;
+    // bit0 = H not from the diagonal, bit1 = H from F (else E), bit2 = next-column E is an extension, bit3 = next-row F is an extension
     VGK_HD uint32_t code(uint32_t r, uint32_t c) const {
         const uint32_t g = r / K, m = r - g * K, t = c + g, j = m >> 2, i = m & 3u;
         const uint32_t w = P.tb[tb_dword(tb_off, t, lane0 + g, K >> 2) + j];
-        return (w >> (16 * half + 4 * (3 - i))) & 15u;
+        const uint32_t raw = (w >> (16 * half + 4 * (3 - i))) & 15u;
+        if (P.scale != 8) return raw;
+        // the x8 build stores the tags of the maxima (lane_row): bit0 = E opened, bits 1-2 = H source (2 diagonal, 1 E, 0 F), bit3 = F opened
+        const uint32_t src = (raw >> 1) & 3u;
+        return (src != 2u ? 1u : 0u) | (src == 0u ? 2u : 0u) | ((raw & 1u) ? 0u : 4u) | ((raw & 8u) ? 0u : 8u);
     }
     // aligned-dword caches of the read codes and the column-info bytes: the walk moves one
     // row / one column at a time, so each cached word serves up to four steps
@@ -443,6 +468,10 @@ struct Walker {
         return (int32_t)((w >> (8 * base)) & 0xffu) - (int32_t)P.bias + bonus;
     }
     VGK_HD uint32_t saved(const NodeRec& n, uint32_t r) const { return P.scratch[d.scratch_off + (uint32_t)n.slot * d.Lpad + r]; }
+    VGK_HD int32_t saved_e(const NodeRec& n, uint32_t r) const {      // E for the next column, without the x8 build's "opened" tag
+        const uint32_t v = saved(n, r) >> 16;
+        return (int32_t)(P.scale == 8 ? v & ~7u : v);
+    }
 };
 
 VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
@@ -562,7 +591,7 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
                 if (nr.n_pred == 1) found = (int32_t)P.preds[nr.pred_begin];
                 else for (uint32_t k = 0; k < nr.n_pred; ++k) {
                     const uint32_t p = P.preds[nr.pred_begin + k];
-                    if ((int32_t)(w.saved(nodes[p], (uint32_t)r) >> 16) == cur) { found = (int32_t)p; break; } }
+                    if (w.saved_e(nodes[p], (uint32_t)r) == cur) { found = (int32_t)p; break; } }
                 if (found < 0) { status = VGK_EINVAL; break; }
                 pnode = (uint32_t)found; pc = nodes[pnode].col_end - 1; node_start = nodes[pnode].col_start;
             }
