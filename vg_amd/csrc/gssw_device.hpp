@@ -314,8 +314,8 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
         const uint32_t e2 = pk_subs(ei, ge2 + 0x00030003u), f2 = pk_subs(f | 0x00010001u, ge2 + 0x00010001u);
         const uint32_t en = pk_max(gg, e2), fn = pk_max(gg, f2);
         // traceback code: bit0 = next-column E was opened, bits 1-2 = H source (2 diagonal, 1 E, 0 F), bit3 = next-row F was opened
-        uint32_t code = (en & 0x00010001u) | (h & 0x00060006u);
-        code |= (fn & 0x00010001u) << 3;
+        uint32_t code = bit_select<0x00010001u>(en, h) & 0x00070007u;
+        code = shl_or<3>(fn & 0x00010001u, code);
         acc[M >> 2] = (M & 3) == 0 ? code : pk_mul_add_imm<16>(acc[M >> 2], code);
         const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(hc, 0x00010001u << (KEY_SHIFT - 3));
         ck = M == 0 ? key : pk_max(ck, key);

@@ -35,7 +35,14 @@ template <int M> static __device__ __forceinline__ uint32_t pk_mul_add_imm(uint3
 // a*b + C per half, b a wave-uniform packed multiplier, C an inline constant
 template <int C> static __device__ __forceinline__ uint32_t pk_mad_add_imm(uint32_t a, uint32_t b) {
     uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "s"(b), "n"(C)); return r; }
+// (mask & a) | (~mask & b) and (a << N) | c as the single instructions they are (hipcc splits them into and / shift / or3 chains)
+template <uint32_t MASK> static __device__ __forceinline__ uint32_t bit_select(uint32_t a, uint32_t b) {
+    uint32_t r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(MASK), "v"(a), "v"(b)); return r; }
+template <int N> static __device__ __forceinline__ uint32_t shl_or(uint32_t a, uint32_t c) {
+    uint32_t r; asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(N), "v"(c)); return r; }
 #else
+template <uint32_t MASK> static inline uint32_t bit_select(uint32_t a, uint32_t b) { return (MASK & a) | (~MASK & b); }
+template <int N> static inline uint32_t shl_or(uint32_t a, uint32_t c) { return (a << N) | c; }
 static inline uint32_t pk_lo(uint32_t x) { return x & 0xffffu; }
 static inline uint32_t pk_hi(uint32_t x) { return x >> 16; }
 static inline uint32_t pk_mk(uint32_t lo, uint32_t hi) { return (lo & 0xffffu) | (hi << 16); }
