@@ -430,6 +430,10 @@ VGK_HD uint64_t tb_dword(uint64_t tb_off, uint32_t t, uint32_t lane, uint32_t re
     return tb_off + ((uint64_t)t * 64u + lane) * rec_dwords;
 }
 
+#ifndef VGK_WALK_SPEC
+#define VGK_WALK_SPEC 8
+#endif
+constexpr uint32_t W_SPEC = VGK_WALK_SPEC;      // diagonal cells fetched together
 struct Walker {
     const GsswParams& P; const ProbDesc& d; uint32_t half, lane0, K; uint64_t tb_off;
     // bit0 = H not from the diagonal, bit1 = H from F (else E), bit2 = next-column E is an extension, bit3 = next-row F is an extension
@@ -542,20 +546,20 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
             // Alignments are mostly diagonal runs: fetch the codes and scores of the next (up to) four
             // diagonal cells together so their memory latencies overlap, then consume them in order.
             const uint32_t room = c - node_start + 1, rows = (uint32_t)r + 1;
-            uint32_t nspec = room < rows ? room : rows; nspec = nspec < 4 ? nspec : 4;
-            uint32_t fl[4]; int32_t sc[4];
+            uint32_t nspec = room < rows ? room : rows; nspec = nspec < W_SPEC ? nspec : W_SPEC;
+            uint32_t fl[W_SPEC]; int32_t sc[W_SPEC];
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
+            for (uint32_t k = 0; k < W_SPEC; ++k) {
                 fl[k] = 1u; sc[k] = 0;
                 if (k < nspec) { fl[k] = w.code((uint32_t)r - k, c - k); sc[k] = w.score((uint32_t)r - k, c - k); }
             }
 #if defined(VGK_DEBUG_WALK) && !defined(__HIP_DEVICE_COMPILE__)
-            printf("H r=%d c=%u cur=%d nspec=%u fl=%u %u %u %u sc=%d %d %d %d\n", r, c, cur, nspec, fl[0], fl[1], fl[2], fl[3], sc[0], sc[1], sc[2], sc[3]);
+            printf("H r=%d c=%u cur=%d nspec=%u fl=%u %u sc=%d %d\n", r, c, cur, nspec, fl[0], fl[1], sc[0], sc[1]);
 #endif
             if (fl[0] & 1u) { st = (fl[0] & 2u) ? ST_F : ST_E; continue; }
             bool stop = false;
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
+            for (uint32_t k = 0; k < W_SPEC; ++k) {
                 if (stop || k >= nspec || (fl[k] & 1u) || (!xdrop && cur == 0)) { stop = true; continue; }
                 VGK_PUSH(node, VGK_OP_M, 1); first_c = c;
                 cur -= sc[k]; r -= 1;
