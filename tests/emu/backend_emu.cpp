@@ -92,7 +92,7 @@ public:
     template <int K, bool S8> void fill(const GsswParams& P) {
         std::vector<Lane<K>> lanes(64);
         std::vector<uint32_t> oh(64), of(64), oi(64);
-        constexpr uint32_t REC = K / 4;
+        constexpr uint32_t REC = (K + 3) / 4;
         for (uint32_t w = P.wave_begin; w < P.wave_begin + P.wave_count; ++w) {
             const WaveDesc wd = P.waves[w];
             for (uint32_t l = 0; l < 64; ++l) lane_init(lanes[l], P, wd, l);
@@ -118,6 +118,7 @@ public:
             P.K = L.K; P.wave_begin = L.wave_begin; P.wave_count = L.wave_count;
             switch (P.K) {
                 case 16: if (P.scale == 8) fill<16, true>(P); else fill<16, false>(P); break;
+                case 19: if (P.scale == 8) fill<19, true>(P); else fill<19, false>(P); break;
                 case 20: if (P.scale == 8) fill<20, true>(P); else fill<20, false>(P); break;
                 case 24: if (P.scale == 8) fill<24, true>(P); else fill<24, false>(P); break;
                 default: return VGK_EINVAL;

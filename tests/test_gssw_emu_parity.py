@@ -95,3 +95,23 @@ def test_emulated_quality_adjusted_contexts_match_oracle(emu_lib):
         assert ra["status"][i] == rb["status"][i] == 0 and ra["score"][i] == rb["score"][i], i
         if ra["score"][i] > 0:
             assert capi.cigar_string(ra[i], oa) == capi.cigar_string(rb[i], ob), i
+
+
+def every_lane_geometry(lib):
+    """Each rows-per-lane instantiation (VGAMD_ROWS_PER_LANE forces one for every read) against the oracle, all three modes mixed;
+    19 is the one whose last traceback dword holds three rows."""
+    rng = np.random.default_rng(4242)
+    problems = [random_problem(rng, max_nodes=10, max_node_len=24, max_read=160, with_n=0.05) for _ in range(120)]
+    problems += [random_problem(rng, max_nodes=8, max_node_len=16, max_read=60, mode=capi.VGK_GSSW_PINNED) for _ in range(60)]
+    problems += [random_problem(rng, max_nodes=8, max_node_len=16, max_read=60, mode=capi.VGK_XDROP_PINNED) for _ in range(60)]
+    try:
+        for k in (16, 19, 20, 24):
+            os.environ["VGAMD_ROWS_PER_LANE"] = str(k)
+            compare(lib, ORACLE_LIB, problems)
+            compare(lib, ORACLE_LIB, problems[:60], capi.Scoring.simple(3, 5, 7, 2, 9))      # scores too large for the x8 build
+    finally:
+        os.environ.pop("VGAMD_ROWS_PER_LANE", None)
+
+
+def test_emulated_kernel_matches_oracle_in_every_lane_geometry(emu_lib):
+    every_lane_geometry(emu_lib)

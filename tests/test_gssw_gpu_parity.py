@@ -103,3 +103,8 @@ def test_hip_quality_adjusted_contexts_match_oracle_and_reference_vectors():
             assert capi.cigar_string(ra[i], oa) == capi.cigar_string(rb[i], ob), i
     ncase, nexp = run_qual_adj_group(ENGINE_LIB)
     assert ncase >= 12 and nexp >= 90
+
+
+def test_hip_matches_oracle_in_every_lane_geometry():
+    from test_gssw_emu_parity import every_lane_geometry
+    every_lane_geometry(ENGINE_LIB)

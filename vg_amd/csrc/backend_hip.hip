@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
     Lane<K> s;
     lane_init(s, P, wd, lane);
     asm volatile("" : "+v"(s.one));   // keep min(x,1) a packed min instead of cmp+cndmask
-    constexpr uint32_t REC = K / 4;   // dwords per (step, lane) traceback record
+    constexpr uint32_t REC = (K + 3) / 4;   // dwords per (step, lane) traceback record
     uint32_t* tb = P.want_tb ? P.tb : nullptr;
     for (uint32_t t = 0; t < wd.n_steps; ++t) {
         if ((t & 3u) == 0) lane_prefetch(s, P, t);
@@ -207,6 +207,7 @@ public:
         const bool s8 = p.scale == 8;
         switch (p.K) {
             case 16: if (s8) hipLaunchKernelGGL((gssw_fill_kernel<16, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<16, false>), grid, block, 0, stream, p); break;
+            case 19: if (s8) hipLaunchKernelGGL((gssw_fill_kernel<19, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<19, false>), grid, block, 0, stream, p); break;
             case 20: if (s8) hipLaunchKernelGGL((gssw_fill_kernel<20, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<20, false>), grid, block, 0, stream, p); break;
             case 24: if (s8) hipLaunchKernelGGL((gssw_fill_kernel<24, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<24, false>), grid, block, 0, stream, p); break;
             default: return VGK_EINVAL;

@@ -84,7 +84,7 @@ struct NodeRec {
 };
 
 struct WaveDesc {
-    uint64_t tb_off;       // first traceback dword of this wave (records of K/4 dwords, step-major)
+    uint64_t tb_off;       // first traceback dword of this wave (records of ceil(K/4) dwords, step-major)
     uint32_t n_steps;
     uint32_t first_pair;
     uint32_t G;            // lanes per read pair in this wavefront (length buckets differ)
@@ -99,7 +99,7 @@ struct GsswParams {
     const NodeRec*  nodes;
     const uint32_t* preds;
     uint32_t*       scratch;    // per (slot,row): lo16 = H of the node's last column, hi16 = E for the column after it
-    uint32_t*       tb;         // K/4 dwords per (step, lane)
+    uint32_t*       tb;         // ceil(K/4) dwords per (step, lane)
     const WaveDesc* waves;
     const uint32_t* order;      // read pairs: pair p = reads order[2p] (low halves) and order[2p+1] (high halves), 0xffffffff = none
     unsigned long long* best;   // LOCAL mode: per read, max over cells of key64(score, col, row)
@@ -371,7 +371,7 @@ VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t di
 
 // One step of one lane.  rh/rf/rinfo are lane-1's out_h/out_f/info from the
 // previous step (ignored by group leaders, which start a fresh column).
-// tbrec = this (step, lane)'s K/4-dword traceback record, or nullptr.
+// tbrec = this (step, lane)'s ceil(K/4)-dword traceback record, or nullptr.
 template <int K, bool S8>
 VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tbrec) {
     if (s.g == 0) { rh = 0; rf = 0; rinfo = fetch_info(s, P, t); }
@@ -387,12 +387,12 @@ VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, 
         // selector: byte0 <- PA[baseA], byte2 <- PB[baseB] (bytes 4..7 of the permute), bytes 1,3 <- 0
         const uint32_t sel = (rinfo & 0x00030003u) | 0x0c040c00u;
         const bool nA = vA && (ia & CI_BASE_MASK) == 4, nB = vB && (ib & CI_BASE_MASK) == 4;
-        uint32_t acc[K / 4], colkey;
+        uint32_t acc[(K + 3) / 4], colkey;
         if (nA || nB) lane_rows<K, true, S8>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
         else          lane_rows<K, false, S8>(s, P, sel, diag0, rf, false, false, acc, colkey);
         if (tbrec) {
 #pragma unroll
-            for (int j = 0; j < K / 4; ++j) tbrec[j] = acc[j];
+            for (int j = 0; j < (K + 3) / 4; ++j) tbrec[j] = acc[j];
         }
         // local end cell: first column with the best score, smallest row (SSW end_ref/end_read rule)
         const uint32_t klo = colkey & 0xffffu, khi = colkey >> 16;
@@ -439,8 +439,9 @@ struct Walker {
     // bit0 = H not from the diagonal, bit1 = H from F (else E), bit2 = next-column E is an extension, bit3 = next-row F is an extension
     VGK_HD uint32_t code(uint32_t r, uint32_t c) const {
         const uint32_t g = r / K, m = r - g * K, t = c + g, j = m >> 2, i = m & 3u;
-        const uint32_t w = P.tb[tb_dword(tb_off, t, lane0 + g, K >> 2) + j];
-        const uint32_t raw = (w >> (16 * half + 4 * (3 - i))) & 15u;
+        const uint32_t w = P.tb[tb_dword(tb_off, t, lane0 + g, (K + 3) >> 2) + j];
+        const uint32_t last = (4 * j + 3 < K ? 4 * j + 3 : K - 1) - 4 * j;      // a lane's last dword holds K % 4 rows when K is no multiple of 4
+        const uint32_t raw = (w >> (16 * half + 4 * (last - i))) & 15u;
         if (P.scale != 8) return raw;
         // the x8 build stores the tags of the maxima (lane_row): bit0 = E opened, bits 1-2 = H source (2 diagonal, 1 E, 0 F), bit3 = F opened
         const uint32_t src = (raw >> 1) & 3u;

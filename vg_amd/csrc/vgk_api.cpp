@@ -167,14 +167,17 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     if ((int64_t)maxL * std::max(ctx->max_score, 0) + 2 * (int64_t)ctx->max_bonus > 2046) return VGK_EUNSUPPORTED;
     uint32_t forced = 0;
     if (const char* e = std::getenv("VGAMD_ROWS_PER_LANE")) forced = (uint32_t)std::atoi(e);
-    // Lane geometry for a read of `rows` DP rows: rows per lane K (16, 20, 24) and lanes per pair G = ceil(rows/K),
+    // Lane geometry for a read of `rows` DP rows: rows per lane K (16, 19, 20, 24) and lanes per pair G = ceil(rows/K),
     // the instantiation that spends the fewest issued instructions per useful cell:
     // (K*c_row + c_step) per step buys floor(64/G)*2*rows cells.
     auto geometry = [&](uint32_t rows, uint32_t& K, uint32_t& G) {
         double best_cost = 1e30; K = 16;
-        for (uint32_t k : {16u, 20u, 24u}) {
+        for (uint32_t k : {16u, 19u, 20u, 24u}) {
             const uint32_t g = (rows + k - 1) / k;
             if (g > 64) continue;
+            // 19 rows per lane fit a 150 bp read into 8 lanes with 2 padding rows instead of 10; for short reads a fourth
+            // launch bucket costs more than the rows it saves (tails workload: 48.9 vs 52.3 M alignments/s)
+            if (k == 19 && rows < 128 && forced != k) continue;
             const double cost = (k * 25.0 + 60.0) / ((64 / g) * 2.0 * rows);
             if (forced == k) { K = k; break; }
             if (!forced && cost < best_cost) { best_cost = cost; K = k; }
@@ -367,7 +370,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
                 }
             wd.n_steps = rmax ? rmax + G - 1 : 0;
             wd.tb_off = tb_dwords;
-            if (b->want_tb) tb_dwords += (uint64_t)wd.n_steps * 64 * (K / 4);
+            if (b->want_tb) tb_dwords += (uint64_t)wd.n_steps * 64 * ((K + 3) / 4);
             waves.push_back(wd);
         }
         launches.back().wave_count = (uint32_t)waves.size() - launches.back().wave_begin;
