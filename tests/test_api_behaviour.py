@@ -202,3 +202,26 @@ def test_pinned_multi_bad_input_and_sub_batches(emu_lib, monkeypatch):
         assert (a == b).all()
     with pytest.raises(capi.VgkError):
         capi.Engine(lib=emu_lib).align_multi(ps, 0)
+
+
+def test_device_arenas_of_freed_batches_are_reused_without_leaking_state(emu_lib):
+    """A freed batch's device arenas go to a pool on the context and serve the next pack (a 35 GB allocation costs about a second on
+    the GPU); the next batch must not see anything of the previous one — smaller batch, other modes, then a larger one."""
+    rng = np.random.default_rng(31)
+    ora = capi.Engine(lib=ORACLE_LIB)
+    eng = capi.Engine(lib=emu_lib)
+    sets = [problem_set([random_problem(rng, max_nodes=12, max_node_len=20, max_read=150) for _ in range(200)]),
+            problem_set([random_problem(rng, max_read=40, mode=capi.VGK_XDROP_PINNED) for _ in range(150)]),
+            problem_set([random_problem(rng, max_read=60, traceback=False) for _ in range(90)]),
+            problem_set([random_problem(rng, max_nodes=14, max_node_len=24, max_read=200) for _ in range(260)])]
+    for round_ in range(2):
+        for ps in sets:
+            ra, oa = eng.align(ps)
+            rb, ob = ora.align(ps)
+            assert _same(ra, oa, rb, ob, ps.n), round_
+    # two batches alive at once take different arenas
+    with eng.pack(sets[0], 0) as a, eng.pack(sets[3], 0) as b:
+        a.run(); b.run()
+        ra, oa = a.fetch(); rb, ob = b.fetch()
+    ea, eoa = ora.align(sets[0]); eb, eob = ora.align(sets[3])
+    assert _same(ra, oa, ea, eoa, sets[0].n) and _same(rb, ob, eb, eob, sets[3].n)

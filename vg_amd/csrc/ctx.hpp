@@ -45,7 +45,40 @@ struct vgk_ctx {
         const uint64_t want = bytes + bytes / 4 > 4096 ? bytes + bytes / 4 : 4096;
         b.p = be->alloc(want); b.bytes = want;
         if (!b.p) { b.p = be->alloc(bytes); b.bytes = b.p ? bytes : 0; }
+        if (!b.p && !dev_pool.empty()) {                  // the pooled arenas of freed gssw batches go first
+            be->sync(); while (!dev_pool.empty()) dev_pool_drop(dev_pool.size() - 1);
+            b.p = be->alloc(bytes); b.bytes = b.p ? bytes : 0;
+        }
         return b.p;
+    }
+    // Device arenas of freed gssw batches, kept for the next pack (callers hold `mu`): allocating the 35 GB of a million-read batch
+    // takes the runtime 0.9-1.8 s, more than packing, aligning and fetching it.  Requests are rounded up by an eighth so that the
+    // next, slightly larger batch still fits; a block serves requests down to half its size; at most 24 blocks / half of HBM stay.
+    struct Pooled { void* p; uint64_t bytes; };
+    std::vector<Pooled> dev_pool; uint64_t dev_pool_bytes = 0;
+    void dev_pool_drop(size_t k) { be->release(dev_pool[k].p); dev_pool_bytes -= dev_pool[k].bytes; dev_pool.erase(dev_pool.begin() + (long)k); }
+    void* dev_take(uint64_t bytes, uint64_t& got) {
+        size_t best = dev_pool.size();
+        for (size_t k = 0; k < dev_pool.size(); ++k)
+            if (dev_pool[k].bytes >= bytes && dev_pool[k].bytes / 2 <= bytes + 4096 && (best == dev_pool.size() || dev_pool[k].bytes < dev_pool[best].bytes)) best = k;
+        if (best != dev_pool.size()) {
+            void* p = dev_pool[best].p; got = dev_pool[best].bytes;
+            dev_pool_bytes -= got; dev_pool.erase(dev_pool.begin() + (long)best);
+            return p;
+        }
+        got = bytes + bytes / 8 + 256;
+        void* p = be->alloc(got);
+        if (!p) {                                         // make room: give the pooled blocks back, then ask for what is needed only
+            be->sync();
+            while (!dev_pool.empty()) dev_pool_drop(dev_pool.size() - 1);
+            got = bytes ? bytes : 16; p = be->alloc(got);
+        }
+        return p;
+    }
+    void dev_give(void* p, uint64_t bytes) {
+        dev_pool.push_back({p, bytes}); dev_pool_bytes += bytes;
+        const uint64_t limit = be->memory_bytes() ? be->memory_bytes() / 2 : (1ull << 30);
+        while (!dev_pool.empty() && (dev_pool.size() > 24 || dev_pool_bytes > limit)) dev_pool_drop(0);     // oldest first
     }
     // page-locked staging arenas of vgk_gssw_pack, handed out per pack (callers may pack concurrently) and kept for the next one
     struct Staging {
@@ -70,6 +103,6 @@ struct vgk_ctx {
     std::shared_ptr<void> gapless_host;     // and of gapless_api.cpp
     std::shared_ptr<void> wfa_host;         // and of wfa_api.cpp
     std::shared_ptr<void> multi_host;       // and of gssw_multi_api.cpp
-    ~vgk_ctx() { if (be) for (DevBuf& b : scratch) if (b.p) be->release(b.p); }
+    ~vgk_ctx() { if (be) { for (DevBuf& b : scratch) if (b.p) be->release(b.p); for (Pooled& q : dev_pool) be->release(q.p); } }
 };
 

@@ -26,7 +26,7 @@ struct vgk_batch {
     uint32_t n = 0;
     bool want_tb = false, ran = false;
     GsswParams P{};
-    std::vector<void*> dev;        // every device allocation of this batch
+    std::vector<vgk_ctx::Pooled> dev;   // every device allocation of this batch (back to the context's pool when the batch is freed)
     uint64_t cells = 0, in_bytes = 0, dev_bytes = 0, alg_bytes = 0;
     uint64_t ops_total = 0;
     std::vector<ProbDesc> probs;   // kept for fetch()
@@ -44,9 +44,10 @@ static inline int nt_ref(char ch) {    // after nonATGCNtoN (src/aligner.cpp:39)
 template <class T>
 static int to_device(vgk_batch* b, const std::vector<T>& v, const T*& out, size_t extra = 0) {
     const size_t bytes = (v.size() + extra) * sizeof(T);
-    void* p = b->ctx->be->alloc(bytes);
+    uint64_t got = 0;
+    void* p = b->ctx->dev_take(bytes, got);
     if (!p) return VGK_ENOMEM;
-    b->dev.push_back(p); b->dev_bytes += bytes;
+    b->dev.push_back({p, got}); b->dev_bytes += bytes;
     if (!v.empty()) { int rc = b->ctx->be->upload(p, v.data(), v.size() * sizeof(T)); if (rc) return rc; }
     out = (const T*)p;
     return VGK_OK;
@@ -55,18 +56,20 @@ static int to_device(vgk_batch* b, const std::vector<T>& v, const T*& out, size_
 template <class T>
 static int to_device(vgk_batch* b, const T* v, size_t count, const T*& out, size_t extra = 0) {      // from a staging arena
     const size_t bytes = (count + extra) * sizeof(T);
-    void* p = b->ctx->be->alloc(bytes);
+    uint64_t got = 0;
+    void* p = b->ctx->dev_take(bytes, got);
     if (!p) return VGK_ENOMEM;
-    b->dev.push_back(p); b->dev_bytes += bytes;
+    b->dev.push_back({p, got}); b->dev_bytes += bytes;
     if (count) { int rc = b->ctx->be->upload(p, v, count * sizeof(T)); if (rc) return rc; }
     out = (const T*)p;
     return VGK_OK;
 }
 template <class T>
 static int dev_alloc(vgk_batch* b, size_t count, T*& out) {
-    void* p = b->ctx->be->alloc(count * sizeof(T));
+    uint64_t got = 0;
+    void* p = b->ctx->dev_take(count * sizeof(T), got);
     if (!p) return VGK_ENOMEM;
-    b->dev.push_back(p); b->dev_bytes += count * sizeof(T);
+    b->dev.push_back({p, got}); b->dev_bytes += count * sizeof(T);
     out = (T*)p;
     return VGK_OK;
 }
@@ -144,7 +147,7 @@ void vgk_batch_free(vgk_batch* b) {
     {
         std::lock_guard<std::mutex> lk(b->ctx->mu);
         b->ctx->be->sync();
-        for (void* p : b->dev) b->ctx->be->release(p);
+        for (const vgk_ctx::Pooled& q : b->dev) b->ctx->dev_give(q.p, q.bytes);
     }
     delete b;
 }
