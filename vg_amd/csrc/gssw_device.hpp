@@ -426,8 +426,13 @@ VGK_HD bool lane_best(const Lane<K>& s, int half, uint32_t& prob, unsigned long 
 // Dword index of (step t, lane)'s traceback record: step-major, so every wave store is one contiguous
 // burst of 64*K bytes.  (A layout with 8 consecutive steps of a lane adjacent was measured: kinder to the
 // walker's diagonal moves but 3-10 % slower fill stores and no faster overall — DESIGN.md §5.)
+#ifndef VGK_TB_TILE
+#define VGK_TB_TILE 1
+#endif
+constexpr uint32_t TB_TILE = VGK_TB_TILE;       // consecutive steps of a lane that lie next to each other
 VGK_HD uint64_t tb_dword(uint64_t tb_off, uint32_t t, uint32_t lane, uint32_t rec_dwords) {
-    return tb_off + ((uint64_t)t * 64u + lane) * rec_dwords;
+    if (TB_TILE == 1) return tb_off + ((uint64_t)t * 64u + lane) * rec_dwords;
+    return tb_off + (((uint64_t)(t / TB_TILE) * 64u + lane) * TB_TILE + t % TB_TILE) * rec_dwords;
 }
 
 #ifndef VGK_WALK_SPEC

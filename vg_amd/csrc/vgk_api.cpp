@@ -373,7 +373,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
                 }
             wd.n_steps = rmax ? rmax + G - 1 : 0;
             wd.tb_off = tb_dwords;
-            if (b->want_tb) tb_dwords += (uint64_t)wd.n_steps * 64 * ((K + 3) / 4);
+            if (b->want_tb) tb_dwords += (uint64_t)((wd.n_steps + TB_TILE - 1) / TB_TILE * TB_TILE) * 64 * ((K + 3) / 4);
             waves.push_back(wd);
         }
         launches.back().wave_count = (uint32_t)waves.size() - launches.back().wave_begin;
