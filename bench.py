@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # --pmc WRITE_SIZE in separate runs of this very command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py
 # cannot read counters itself, so `roofline.traffic` = this figure x the units of one launch; re-measure with tools/prof_*.sh.
 PMC_BYTES_PER_UNIT = {
-    "linear": (2 * 705750 + 13624139) * 1024 / 400000,      # pmc_{FETCH,WRITE}_SIZE_400k.csv: gssw_fill_kernel, 400 000 reads
+    "linear": (2 * 711837 + 13580389) * 1024 / 400000,      # pmc_{FETCH,WRITE}_SIZE_400k.csv: gssw_fill_kernel, 400 000 reads
     "banded": (2 * 389251 + 2244533) * 1024 / 100000,        # pmc_*_banded_100k.csv: the three banded_fill_kernel classes, 100 000 problems
     "gapless": (2 * 16202932 + 3269559) * 1024 / 1000000,    # pmc_*_gapless_1M.csv: gapless_kernel, 1 000 000 reads
     "wfa": (2 * 4385189 + 1828176) * 1024 / 500000,          # pmc_*_wfa_500k.csv: wfa_kernel, 500 000 problems
@@ -250,6 +250,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (configs[1]: 1M)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads for the CPU baseline leg (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the warm / double-buffered end-to-end legs (profiling runs)")
     ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa"], default="linear",
                     help="linear = BASELINE.json configs[1] (the headline metric); tails = configs[2] stand-in: "
                          "giraffe-style pinned X-drop tail alignments on a variation graph; banded = configs[4] stand-in: "
@@ -363,24 +364,26 @@ def main():
     batch.free()
     # steady state from host buffers: three more batches, each packed, run once and fetched in turn on the warm context
     # (page-locked staging and device arenas are reused; nothing overlaps — pack, kernels and fetch are serial here)
-    tw = time.perf_counter()
-    for _ in range(3):
-        with eng.pack(wl, OPS_PER) as wb:
-            wb.run(); wb.fetch()
-    t_warm = (time.perf_counter() - tw) / 3
-    # the same with the next batch packed on a second host thread while this one runs and is fetched (double buffering: what a
-    # caller that streams reads does; the C ABI's pack / run / fetch split exists for it)
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(1) as ex:
-        nxt = ex.submit(eng.pack, wl, OPS_PER)
-        for k in range(6):                     # the first two fill the pipeline (and allocate the second set of device arenas)
-            if k == 2:
-                tp = time.perf_counter()
-            pb = nxt.result()
-            if k + 1 < 6:
-                nxt = ex.submit(eng.pack, wl, OPS_PER)
-            pb.run(); pb.fetch(); pb.free()
-        t_pipe = (time.perf_counter() - tp) / 4
+    t_warm = t_pipe = None
+    if not args.no_e2e:
+        tw = time.perf_counter()
+        for _ in range(3):
+            with eng.pack(wl, OPS_PER) as wb:
+                wb.run(); wb.fetch()
+        t_warm = (time.perf_counter() - tw) / 3
+        # the same with the next batch packed on a second host thread while this one runs and is fetched (double buffering: what a
+        # caller that streams reads does; the C ABI's pack / run / fetch split exists for it)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(1) as ex:
+            nxt = ex.submit(eng.pack, wl, OPS_PER)
+            for k in range(6):                     # the first two fill the pipeline (and allocate the second set of device arenas)
+                if k == 2:
+                    tp = time.perf_counter()
+                pb = nxt.result()
+                if k + 1 < 6:
+                    nxt = ex.submit(eng.pack, wl, OPS_PER)
+                pb.run(); pb.fetch(); pb.free()
+            t_pipe = (time.perf_counter() - tp) / 4
 
     if rank == 0:
         total_reads = args.reads * world * args.steps
@@ -416,8 +419,8 @@ def main():
             "pack_seconds": t_pack, "fetch_seconds": t_fetch,
             # one batch from host buffers: pack (validate + encode + H2D) + one run + fetch (D2H of results and CIGAR ops)
             "end_to_end_from_host_buffers_per_s": args.reads / (t_pack + elapsed / args.steps + t_fetch),
-            "end_to_end_warm_per_s": args.reads / t_warm,
-            "end_to_end_double_buffered_per_s": args.reads / t_pipe,
+            "end_to_end_warm_per_s": args.reads / t_warm if t_warm else None,
+            "end_to_end_double_buffered_per_s": args.reads / t_pipe if t_pipe else None,
         }
         print(json.dumps(out))
     if dist is not None:
