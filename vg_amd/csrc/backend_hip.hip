@@ -8,9 +8,9 @@
 
 namespace vgk {
 
-// one DPP wave_shr:1 — lane l receives lane l-1's value (lane 0 receives 0)
+// one DPP wave_shr:1 — lane l receives lane l-1's value (lane 0 receives 0: bound_ctrl, so no old value has to be set up)
 static __device__ __forceinline__ uint32_t from_lane_above(uint32_t x) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 }
 
 // Fill: 4 independent wavefronts per workgroup; each wavefront owns

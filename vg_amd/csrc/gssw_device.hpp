@@ -396,8 +396,9 @@ VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, 
         }
         // local end cell: first column with the best score, smallest row (SSW end_ref/end_read rule)
         const uint32_t klo = colkey & 0xffffu, khi = colkey >> 16;
-        if (vA && (klo >> KEY_SHIFT) > (s.best_lo >> KEY_SHIFT)) { s.best_lo = klo; s.step_lo = t; }
-        if (vB && (khi >> KEY_SHIFT) > (s.best_hi >> KEY_SHIFT)) { s.best_hi = khi; s.step_hi = t; }
+        const bool upA = vA & ((klo >> KEY_SHIFT) > (s.best_lo >> KEY_SHIFT)), upB = vB & ((khi >> KEY_SHIFT) > (s.best_hi >> KEY_SHIFT));   // selects, no branches
+        s.best_lo = upA ? klo : s.best_lo; s.step_lo = upA ? t : s.step_lo;
+        s.best_hi = upB ? khi : s.best_hi; s.step_hi = upB ? t : s.step_hi;
         if (vA && (ia & CI_STORE_END)) store_to_scratch<0, K>(s, P, s.probA, s.nodeA);
         if (vB && (ib & CI_STORE_END)) store_to_scratch<1, K>(s, P, s.probB, s.nodeB);
     } else {
