@@ -365,7 +365,7 @@ def main():
     # steady state from host buffers: three more batches, each packed, run once and fetched in turn on the warm context
     # (page-locked staging and device arenas are reused; nothing overlaps — pack, kernels and fetch are serial here)
     t_warm = t_pipe = None
-    if not args.no_e2e:
+    if world == 1 and not args.no_e2e:        # like the CPU leg: reported at N = 1 only
         tw = time.perf_counter()
         for _ in range(3):
             with eng.pack(wl, OPS_PER) as wb:
