@@ -376,14 +376,14 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(1) as ex:
             nxt = ex.submit(eng.pack, wl, OPS_PER)
-            for k in range(6):                     # the first two fill the pipeline (and allocate the second set of device arenas)
-                if k == 2:
+            for k in range(10):                    # the first four fill the pipeline (second set of device arenas, staging buffers)
+                if k == 4:
                     tp = time.perf_counter()
                 pb = nxt.result()
-                if k + 1 < 6:
+                if k + 1 < 10:
                     nxt = ex.submit(eng.pack, wl, OPS_PER)
                 pb.run(); pb.fetch(); pb.free()
-            t_pipe = (time.perf_counter() - tp) / 4
+            t_pipe = (time.perf_counter() - tp) / 6
 
     if rank == 0:
         total_reads = args.reads * world * args.steps

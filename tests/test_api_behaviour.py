@@ -225,3 +225,19 @@ def test_device_arenas_of_freed_batches_are_reused_without_leaking_state(emu_lib
         ra, oa = a.fetch(); rb, ob = b.fetch()
     ea, eoa = ora.align(sets[0]); eb, eob = ora.align(sets[3])
     assert _same(ra, oa, ea, eoa, sets[0].n) and _same(rb, ob, eb, eob, sets[3].n)
+
+
+def test_large_batch_goes_through_the_threaded_packing_paths(emu_lib):
+    """140 000 small problems: enough for the chunked prefix sums, the threaded wave description and the threaded copies of
+    vgk_gssw_pack / vgk_gssw_fetch to run on several host threads (smaller batches take their serial branches)."""
+    rng = np.random.default_rng(77)
+    base = [random_problem(rng, max_nodes=3, max_node_len=6, max_read=int(rng.choice([4, 9, 17, 30]))) for _ in range(61)]
+    base += [random_problem(rng, max_nodes=3, max_node_len=6, max_read=12, mode=capi.VGK_XDROP_PINNED) for _ in range(18)]
+    base += [random_problem(rng, max_nodes=2, max_node_len=5, max_read=8, traceback=False) for _ in range(18)]
+    problems = [base[i % len(base)] for i in range(140000)]
+    ps = problem_set(problems)
+    ra, oa = capi.Engine(lib=emu_lib).align(ps)
+    rb, ob = capi.Engine(lib=ORACLE_LIB).align(ps)
+    for f in ("score", "status", "end_node", "end_offset", "end_read", "first_offset", "n_ops", "ops_begin"):
+        assert (ra[f] == rb[f]).all(), f
+    assert len(oa) == len(ob) and (oa.view(np.uint64) == ob.view(np.uint64)).all()

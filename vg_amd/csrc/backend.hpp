@@ -30,11 +30,24 @@ public:
     virtual void  host_release(void* p) = 0;
     virtual int   upload(void* dst, const void* src, size_t bytes) = 0;     // async on the stream
     virtual int   download(void* dst, const void* src, size_t bytes) = 0;   // synchronous
+    // uploads that need not queue behind the kernels of another batch (vgk_gssw_pack while the previous batch runs): a copy
+    // stream of their own; sync_side() waits for them only
+    virtual int   upload_side(void* dst, const void* src, size_t bytes) { return upload(dst, src, bytes); }
+    virtual int   sync_side() { return sync(); }
     virtual int   zero(void* dst, size_t bytes) = 0;                        // async on the stream
     virtual int   sync() = 0;
     // gssw kernels: one fill launch per rows-per-lane instantiation (`launches`), then one traceback
     // launch over all reads; timings (ms, HIP events on the launch stream) of the last run
     virtual int   run_gssw(const GsswParams& p, const FillLaunch* launches, uint32_t n_launches, bool walk) = 0;
+    // Results on their way back (vgk_gssw_fetch): the CIGAR ops sit in per-problem slots of ops_per_problem entries, of which a
+    // read uses a handful; they are packed behind each other on the device, in problem order, so that only what was written
+    // crosses PCIe.  ops_offsets: offs[i] = position of problem i's first op inside its block of OPS_SCAN_BLOCK problems,
+    // sums[b] = position of block b's first op, *total = all ops (synchronises).  ops_gather: out_res[i] = res[i] with
+    // ops_begin rewritten (n_ops = 0 when the problem failed), out_ops = the packed ops (async on the stream).
+    // A backend without them returns VGK_EUNSUPPORTED and the caller packs on the host.
+    static constexpr uint32_t OPS_SCAN_BLOCK = 1024;
+    virtual int   ops_offsets(const vgk_result*, uint32_t, uint32_t*, uint32_t*, uint64_t*) { return VGK_EUNSUPPORTED; }
+    virtual int   ops_gather(const vgk_result*, const vgk_op*, uint32_t, const uint32_t*, const uint32_t*, vgk_result*, vgk_op*) { return VGK_EUNSUPPORTED; }
     virtual double last_ms(int which) const = 0;           // 0 = fill (all launches), 1 = traceback tail, 2 = number of fill launches,
                                                            // 3 / 4 = banded fill / banded traceback of the last run_banded
     // banded global alignment: one fill launch per rows-per-lane instantiation (one wavefront per problem), then one

@@ -72,6 +72,69 @@ __global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P) {
     if (i < P.n_problems) walk_one(P, i, P.best[i]);
 }
 
+// ---- CIGAR ops on their way back: exclusive prefix sums of the per-problem op counts, then a gather ------------------
+// One block scans OPS_SCAN_BLOCK = 1024 problems (4 per thread): wave-level inclusive scans on DPP-backed shuffles, the four
+// wave totals through LDS.
+static __device__ __forceinline__ uint32_t ops_of(const vgk_result* res, uint32_t i, uint32_t n) {
+    return (i < n && res[i].status == VGK_OK) ? res[i].n_ops : 0u;
+}
+__global__ __launch_bounds__(256) void ops_scan_kernel(const vgk_result* res, uint32_t n, uint32_t* offs, uint32_t* sums) {
+    __shared__ uint32_t wave_total[4];
+    const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) * 4u, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t c0 = ops_of(res, i0, n), c1 = ops_of(res, i0 + 1, n), c2 = ops_of(res, i0 + 2, n), c3 = ops_of(res, i0 + 3, n);
+    uint32_t incl = c0 + c1 + c2 + c3;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+    if (lane == 63) wave_total[w] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < w; ++k) before += wave_total[k];
+    uint32_t at = before + incl - (c0 + c1 + c2 + c3);
+    if (i0 < n) offs[i0] = at;
+    at += c0; if (i0 + 1 < n) offs[i0 + 1] = at;
+    at += c1; if (i0 + 2 < n) offs[i0 + 2] = at;
+    at += c2; if (i0 + 3 < n) offs[i0 + 3] = at;
+    if (threadIdx.x == 255) sums[blockIdx.x] = before + incl;
+}
+// one block turns the block totals into block starts (exclusive) and the grand total
+__global__ __launch_bounds__(256) void ops_sums_kernel(uint32_t* sums, uint32_t n_blocks, unsigned long long* total) {
+    __shared__ uint32_t wave_total[4];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < n_blocks; base += 256u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t c = i < n_blocks ? sums[i] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+        if (lane == 63) wave_total[w] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < w; ++k) before += wave_total[k];
+        const unsigned long long start = carry + before + incl - c;
+        if (i < n_blocks) sums[i] = (uint32_t)start;         // the caller has checked that all ops fit 32 bits
+        __syncthreads();
+        if (threadIdx.x == 255) carry += before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(256) void ops_gather_kernel(const vgk_result* res, const vgk_op* ops, uint32_t n, const uint32_t* offs,
+                                                         const uint32_t* sums, vgk_result* out_res, vgk_op* out_ops) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vgk_result r = res[i];
+    const uint32_t at = sums[i / Backend::OPS_SCAN_BLOCK] + offs[i];
+    if (r.status == VGK_OK && r.n_ops) {
+        const vgk_op* from = ops + r.ops_begin;
+        for (uint32_t k = 0; k < r.n_ops; ++k) out_ops[at + k] = from[k];
+    } else r.n_ops = 0;
+    r.ops_begin = at;
+    out_res[i] = r;
+}
+
 // ---- banded global alignment (banded_device.hpp): cross-lane primitives on DPP ------------------------------------
 struct XlDpp {
     static __device__ __forceinline__ int32_t dpp_up(int32_t v)   { return __builtin_amdgcn_update_dpp(BNEG, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
@@ -156,7 +219,7 @@ __global__ void __launch_bounds__(64) gssw_matrix_kernel(const GsswMatrixParams 
 
 class HipBackend final : public Backend {
 public:
-    int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, copy = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipDeviceProp_t prop;
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
     float ms_gapless = 0.f, ms_wfa = 0.f;
@@ -167,6 +230,7 @@ public:
         for (auto& e : bev) if (e) hipEventDestroy(e);
         for (int i = 0; i < 2; ++i) { if (side[i]) hipStreamDestroy(side[i]); if (side_done[i]) hipEventDestroy(side_done[i]); }
         if (stream) hipStreamDestroy(stream);
+        if (copy) hipStreamDestroy(copy);
     }
     const char* name() const override { return prop.name; }
     int compute_units() const override { return prop.multiProcessorCount; }
@@ -188,6 +252,14 @@ public:
     int upload(void* dst, const void* src, size_t bytes) override {
         hipSetDevice(dev);
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream) == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int upload_side(void* dst, const void* src, size_t bytes) override {
+        hipSetDevice(dev);
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, copy) == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int sync_side() override {
+        hipSetDevice(dev);
+        return hipStreamSynchronize(copy) == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int download(void* dst, const void* src, size_t bytes) override {
         hipSetDevice(dev);
@@ -242,6 +314,23 @@ public:
             hipEventRecord(ev[2], stream);
         }
         pending = true;
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int ops_offsets(const vgk_result* res, uint32_t n, uint32_t* offs, uint32_t* sums, uint64_t* total) override {
+        hipSetDevice(dev);
+        const uint32_t blocks = (n + OPS_SCAN_BLOCK - 1) / OPS_SCAN_BLOCK;
+        unsigned long long* total_dev = (unsigned long long*)(sums + ((blocks + 2) & ~1u));       // 8-byte aligned, behind the block sums
+        hipLaunchKernelGGL(ops_scan_kernel, dim3(blocks), dim3(256), 0, stream, res, n, offs, sums);
+        hipLaunchKernelGGL(ops_sums_kernel, dim3(1), dim3(256), 0, stream, sums, blocks, total_dev);
+        unsigned long long t = 0;
+        if (hipMemcpyAsync(&t, total_dev, sizeof t, hipMemcpyDeviceToHost, stream) != hipSuccess) return VGK_ENODEV;
+        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
+        *total = t;
+        return VGK_OK;
+    }
+    int ops_gather(const vgk_result* res, const vgk_op* ops, uint32_t n, const uint32_t* offs, const uint32_t* sums, vgk_result* out_res, vgk_op* out_ops) override {
+        hipSetDevice(dev);
+        hipLaunchKernelGGL(ops_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, res, ops, n, offs, sums, out_res, out_ops);
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_banded(const BandedParams& p, const BandedLaunch* launches, uint32_t n) override {
@@ -330,7 +419,7 @@ Backend* make_backend(int device, std::string& err) {
     b->dev = device;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&b->prop, device) != hipSuccess) {
         err = "cannot select HIP device"; delete b; return nullptr; }
-    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { err = "cannot create HIP stream"; delete b; return nullptr; }
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking) != hipSuccess) { err = "cannot create HIP stream"; delete b; return nullptr; }
     for (int i = 0; i < 2; ++i)
         if (hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&b->side_done[i], hipEventDisableTiming) != hipSuccess) { err = "cannot create HIP side stream"; delete b; return nullptr; }

@@ -82,7 +82,7 @@ struct vgk_ctx {
     }
     // page-locked staging arenas of vgk_gssw_pack, handed out per pack (callers may pack concurrently) and kept for the next one
     struct Staging {
-        vgk::Backend* be = nullptr; void* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; uint64_t bytes[6] = {0, 0, 0, 0, 0, 0};   // [5]: the CIGAR ops on their way back
+        vgk::Backend* be = nullptr; void* p[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; uint64_t bytes[7] = {0, 0, 0, 0, 0, 0, 0};   // [5]: results and CIGAR ops on their way back, [6]: per-problem sizes while packing
         void* get(int k, uint64_t want) {
             if (bytes[k] >= want) return p[k];
             if (p[k]) be->host_release(p[k]);
@@ -99,10 +99,27 @@ struct vgk_ctx {
         auto s = std::move(staging_free.back()); staging_free.pop_back(); return s;
     }
     void staging_release(std::unique_ptr<Staging> s) { std::lock_guard<std::mutex> lock(staging_mu); if (staging_free.size() < 4) staging_free.push_back(std::move(s)); }
+    // page-locked blocks that held the problem descriptors of freed batches (a batch keeps them until it is freed): no page
+    // faults while the next batch is packed, no unmapping when it is freed, full-rate DMA
+    std::vector<Pooled> host_pool;
+    void* host_take(uint64_t bytes, uint64_t& got) {
+        {
+            std::lock_guard<std::mutex> lock(staging_mu);
+            for (size_t k = 0; k < host_pool.size(); ++k)
+                if (host_pool[k].bytes >= bytes && host_pool[k].bytes / 2 <= bytes + 4096) { void* p = host_pool[k].p; got = host_pool[k].bytes; host_pool.erase(host_pool.begin() + (long)k); return p; }
+        }
+        got = bytes + bytes / 8 + 256;
+        return be->host_alloc(got);
+    }
+    void host_give(void* p, uint64_t bytes) {
+        std::lock_guard<std::mutex> lock(staging_mu);
+        host_pool.push_back({p, bytes});
+        while (host_pool.size() > 4) { be->host_release(host_pool.front().p); host_pool.erase(host_pool.begin()); }
+    }
     std::shared_ptr<void> banded_host;      // host staging arenas of banded_api.cpp
     std::shared_ptr<void> gapless_host;     // and of gapless_api.cpp
     std::shared_ptr<void> wfa_host;         // and of wfa_api.cpp
     std::shared_ptr<void> multi_host;       // and of gssw_multi_api.cpp
-    ~vgk_ctx() { if (be) { for (DevBuf& b : scratch) if (b.p) be->release(b.p); for (Pooled& q : dev_pool) be->release(q.p); } }
+    ~vgk_ctx() { if (be) { for (DevBuf& b : scratch) if (b.p) be->release(b.p); for (Pooled& q : dev_pool) be->release(q.p); for (Pooled& q : host_pool) be->host_release(q.p); } }
 };
 

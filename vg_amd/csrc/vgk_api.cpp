@@ -27,10 +27,13 @@ struct vgk_batch {
     bool want_tb = false, ran = false;
     GsswParams P{};
     std::vector<vgk_ctx::Pooled> dev;   // every device allocation of this batch (back to the context's pool when the batch is freed)
-    uint64_t cells = 0, in_bytes = 0, dev_bytes = 0, alg_bytes = 0;
+    uint64_t cells = 0, tb_cells = 0, in_bytes = 0, dev_bytes = 0, alg_bytes = 0;
     uint64_t ops_total = 0;
-    std::vector<ProbDesc> probs;   // kept for fetch()
+    ProbDesc* probs = nullptr; uint64_t probs_bytes = 0;   // kept for fetch(): a page-locked block from the context's pool, back to it with the batch
+    ~vgk_batch() { if (probs && ctx) ctx->host_give(probs, probs_bytes); }
     std::vector<FillLaunch> launches;   // one per length bucket
+    struct Upload { void* dst; const void* src; size_t bytes; };
+    std::vector<Upload> uploads;        // queued by to_device under the context lock, issued by vgk_gssw_pack outside it
 };
 
 static inline int nt_read(char ch) {   // gssw_create_nt_table: case-insensitive ACGT, else N
@@ -48,7 +51,7 @@ static int to_device(vgk_batch* b, const std::vector<T>& v, const T*& out, size_
     void* p = b->ctx->dev_take(bytes, got);
     if (!p) return VGK_ENOMEM;
     b->dev.push_back({p, got}); b->dev_bytes += bytes;
-    if (!v.empty()) { int rc = b->ctx->be->upload(p, v.data(), v.size() * sizeof(T)); if (rc) return rc; }
+    if (!v.empty()) b->uploads.push_back({p, v.data(), v.size() * sizeof(T)});
     out = (const T*)p;
     return VGK_OK;
 }
@@ -60,7 +63,7 @@ static int to_device(vgk_batch* b, const T* v, size_t count, const T*& out, size
     void* p = b->ctx->dev_take(bytes, got);
     if (!p) return VGK_ENOMEM;
     b->dev.push_back({p, got}); b->dev_bytes += bytes;
-    if (count) { int rc = b->ctx->be->upload(p, v, count * sizeof(T)); if (rc) return rc; }
+    if (count) b->uploads.push_back({p, v, count * sizeof(T)});
     out = (const T*)p;
     return VGK_OK;
 }
@@ -160,14 +163,6 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     vgk_batch* b = hb.get();
     b->ctx = ctx; b->n = n;
 
-    uint32_t maxL = 1;
-    for (uint32_t i = 0; i < n; ++i) {
-        if (problems[i].read_len == 0 || !problems[i].read || problems[i].graph.n_nodes == 0) return VGK_EINVAL;
-        maxL = std::max(maxL, problems[i].read_len + ((problems[i].flags & 15u) == VGK_XDROP_PINNED ? 1u : 0u));
-    }
-    if (maxL > 1024) return VGK_ETOOLONG;
-    // best-cell keys pack score*32 + row: keep every reachable score below 2047
-    if ((int64_t)maxL * std::max(ctx->max_score, 0) + 2 * (int64_t)ctx->max_bonus > 2046) return VGK_EUNSUPPORTED;
     uint32_t forced = 0;
     if (const char* e = std::getenv("VGAMD_ROWS_PER_LANE")) forced = (uint32_t)std::atoi(e);
     // Lane geometry for a read of `rows` DP rows: rows per lane K (16, 19, 20, 24) and lanes per pair G = ceil(rows/K),
@@ -191,10 +186,17 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     // Three passes over the problems, the first and the last on host threads: (1) validate and size every problem, (2) prefix sums
     // place it in the shared arenas, (3) encode it at its offsets.
     auto T0 = std::chrono::steady_clock::now(); auto lap = [&](const char* w) { if (std::getenv("VGAMD_TIMING")) { auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "[pack] %s %.1f ms\n", w, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
-    std::vector<ProbDesc>& probs = b->probs;
-    probs.resize(n);
-    struct Sizes { uint32_t reads = 0, prof = 0, cols = 0, nodes = 0, preds = 0; int status = VGK_OK; bool want_tb = false; };
-    std::vector<Sizes> sizes(n);
+    // per-problem descriptors and sizes live in uninitialised storage: the packing threads initialise (and fault in) their own parts
+    struct StagingLease {
+        vgk_ctx* ctx; std::unique_ptr<vgk_ctx::Staging> s;
+        ~StagingLease() { if (s) ctx->staging_release(std::move(s)); }
+    } lease{ctx, ctx->staging_acquire()};
+    b->probs = (ProbDesc*)ctx->host_take((uint64_t)std::max<uint32_t>(n, 1u) * sizeof(ProbDesc), b->probs_bytes);
+    ProbDesc* probs = b->probs;
+    struct Sizes { uint32_t reads = 0, prof = 0, cols = 0, nodes = 0, preds = 0, pred_at = 0; int status = VGK_OK; bool want_tb = false, malformed = false; };
+    Sizes* sizes = (Sizes*)lease.s->get(6, (uint64_t)std::max<uint32_t>(n, 1u) * sizeof(Sizes));
+    if (!probs || !sizes) return VGK_ENOMEM;
+    std::vector<uint32_t> thread_maxL(MAX_THREADS, 1u);
     struct Flags { std::vector<uint8_t> store, slow; };
     std::vector<Flags> thread_flags(MAX_THREADS);
     // store[v]: the node's last column is saved for a successor / the pinned end; slow[v]: its first column is seeded from scratch
@@ -212,11 +214,15 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         }
         return VGK_OK;
     };
+    lap("setup");
     parallel_for(n, [&](uint32_t i, unsigned t) {
         const vgk_gssw_problem& p = problems[i];
         const vgk_graph& g = p.graph;
         ProbDesc& d = probs[i]; Sizes& z = sizes[i];
+        d = ProbDesc{}; z = Sizes();
+        if (p.read_len == 0 || !p.read || g.n_nodes == 0) { z.status = VGK_EINVAL; z.malformed = true; return; }
         const uint32_t mode = p.flags & 15u;
+        thread_maxL[t] = std::max(thread_maxL[t], p.read_len + (mode == VGK_XDROP_PINNED ? 1u : 0u));
         if (mode != VGK_GSSW_LOCAL && mode != VGK_GSSW_PINNED && mode != VGK_XDROP_PINNED) { z.status = VGK_EINVAL; return; }
         const bool xdrop = mode == VGK_XDROP_PINNED;
         // offset arithmetic of the X-drop mode: every reachable gain must stay below XOFF
@@ -245,27 +251,64 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         if (!(p.flags & VGK_GSSW_TRACEBACK)) d.ops_cap = 0;
         z.reads = d.L; z.prof = ctx->has_qa ? d.L : 0; z.cols = d.R; z.nodes = g.n_nodes; z.preds = g.pred_off[g.n_nodes] - g.pred_off[0];
     });
-    uint64_t scratch_words = 0, ops_total = 0, n_reads = 0, n_prof = 0, n_cols = 0, n_nodes = 0, n_preds = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        if (sizes[i].status != VGK_OK) return sizes[i].status;
-        ProbDesc& d = probs[i]; const Sizes& z = sizes[i];
-        if (z.want_tb) b->want_tb = true;
-        d.node_off = (uint32_t)n_nodes; d.read_off = (uint32_t)n_reads;
-        if (ctx->has_qa) d.prof_off = (uint32_t)n_prof;
-        n_cols = (n_cols + 3) & ~3ull;                       // every problem's column stream starts on a dword
-        d.col_off = (uint32_t)n_cols;
-        d.scratch_off = (uint32_t)scratch_words; scratch_words += (uint64_t)d.n_slots * d.Lpad;
-        d.ops_off = (uint32_t)ops_total; ops_total += d.ops_cap;
-        n_nodes += z.nodes; n_reads += z.reads; n_prof += z.prof; n_cols += z.cols; n_preds += z.preds;
-        if (scratch_words >= (1ull << 32) || ops_total >= (1ull << 32) || n_cols >= (1ull << 32) || n_reads >= (1ull << 32) || n_nodes >= (1ull << 32) || n_preds >= (1ull << 32)) return VGK_ETOOBIG;
-        b->cells += (uint64_t)d.R * d.L;
-        b->in_bytes += (uint64_t)problems[i].read_len + d.R + 8ull * z.nodes + 4ull * z.preds;
+    lap("pass1");
+    // whole-batch checks first, in the order a serial scan would report them: a malformed problem, then the longest read
+    {
+        uint32_t maxL = 1;
+        for (uint32_t m : thread_maxL) maxL = std::max(maxL, m);
+        // (malformed problems are found below, chunk by chunk, before anything else is reported)
+        std::atomic<bool> malformed{false};
+        parallel_chunks(n, [&](uint32_t lo, uint32_t hi, uint32_t) { for (uint32_t i = lo; i < hi; ++i) if (sizes[i].malformed) { malformed.store(true, std::memory_order_relaxed); break; } });
+        if (malformed.load()) return VGK_EINVAL;
+        if (maxL > 1024) return VGK_ETOOLONG;
+        // best-cell keys pack score*32 + row: keep every reachable score below 2047
+        if ((int64_t)maxL * std::max(ctx->max_score, 0) + 2 * (int64_t)ctx->max_bonus > 2046) return VGK_EUNSUPPORTED;
     }
+    // Offsets into the shared arenas: prefix sums over the problems, in chunks — totals per chunk on the host threads, a serial
+    // scan over the chunk totals, then the offsets inside every chunk on the host threads again.
+    struct Totals { uint64_t scratch = 0, ops = 0, reads = 0, prof = 0, cols = 0, nodes = 0, preds = 0, cells = 0, tb_cells = 0, in_bytes = 0; int status = VGK_OK; bool want_tb = false; };
+    const uint32_t n_chunks = chunk_count(n);
+    std::vector<Totals> chunk_tot(n_chunks), chunk_at(n_chunks);
+    parallel_chunks(n, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+        Totals t;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const Sizes& z = sizes[i]; const ProbDesc& d = probs[i];
+            if (z.status != VGK_OK) { t.status = z.status; break; }               // the first failing problem of the chunk
+            t.want_tb |= z.want_tb;
+            t.scratch += (uint64_t)d.n_slots * d.Lpad; t.ops += d.ops_cap;
+            t.nodes += z.nodes; t.reads += z.reads; t.prof += z.prof; t.cols += (z.cols + 3ull) & ~3ull; t.preds += z.preds;   // every column stream starts on a dword
+            t.cells += (uint64_t)d.R * d.L;
+            if (d.flags & VGK_GSSW_TRACEBACK) t.tb_cells += (uint64_t)d.R * d.L;
+            t.in_bytes += (uint64_t)problems[i].read_len + d.R + 8ull * z.nodes + 4ull * z.preds;
+        }
+        chunk_tot[c] = t;
+    });
+    Totals all;
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const Totals& t = chunk_tot[c];
+        if (t.status != VGK_OK) return t.status;
+        chunk_at[c] = all;
+        all.scratch += t.scratch; all.ops += t.ops; all.nodes += t.nodes; all.reads += t.reads; all.prof += t.prof; all.cols += t.cols; all.preds += t.preds;
+        all.cells += t.cells; all.tb_cells += t.tb_cells; all.in_bytes += t.in_bytes; all.want_tb |= t.want_tb;
+    }
+    const uint64_t scratch_words = all.scratch, ops_total = all.ops, n_reads = all.reads, n_prof = all.prof, n_cols = all.cols, n_nodes = all.nodes, n_preds = all.preds;
+    if (scratch_words >= (1ull << 32) || ops_total >= (1ull << 32) || n_cols >= (1ull << 32) || n_reads >= (1ull << 32) || n_nodes >= (1ull << 32) || n_preds >= (1ull << 32)) return VGK_ETOOBIG;
+    b->want_tb = all.want_tb; b->cells = all.cells; b->tb_cells = all.tb_cells; b->in_bytes = all.in_bytes;
+    parallel_chunks(n, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+        Totals at = chunk_at[c];
+        for (uint32_t i = lo; i < hi; ++i) {
+            ProbDesc& d = probs[i]; Sizes& z = sizes[i];
+            d.node_off = (uint32_t)at.nodes; d.read_off = (uint32_t)at.reads;
+            if (ctx->has_qa) d.prof_off = (uint32_t)at.prof;
+            d.col_off = (uint32_t)at.cols;
+            d.scratch_off = (uint32_t)at.scratch; d.ops_off = (uint32_t)at.ops;
+            z.pred_at = (uint32_t)at.preds;                   // pred_begin is an offset into the shared predecessor arena
+            at.scratch += (uint64_t)d.n_slots * d.Lpad; at.ops += d.ops_cap;
+            at.nodes += z.nodes; at.reads += z.reads; at.prof += z.prof; at.cols += (z.cols + 3ull) & ~3ull; at.preds += z.preds;
+        }
+    });
     // the shared arenas are page-locked staging buffers kept on the context: no zero-fill, no page faults, full-rate DMA
-    struct StagingLease {
-        vgk_ctx* ctx; std::unique_ptr<vgk_ctx::Staging> s;
-        ~StagingLease() { if (s) ctx->staging_release(std::move(s)); }
-    } lease{ctx, ctx->staging_acquire()};
+    lap("prefix");
     uint8_t* colinfo = (uint8_t*)lease.s->get(0, n_cols + 8);            // + 8: leaders prefetch one word ahead
     uint8_t* reads = (uint8_t*)lease.s->get(1, n_reads + 8);
     uint32_t* prof = (uint32_t*)lease.s->get(2, sizeof(uint32_t) * (n_prof + 4));
@@ -273,10 +316,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     uint32_t* preds = (uint32_t*)lease.s->get(4, sizeof(uint32_t) * (n_preds + 1));
     if (!colinfo || !reads || !prof || !nodes || !preds) return VGK_ENOMEM;
     std::memset(colinfo + n_cols, CI_INVALID, 8);
-    {   // pred_begin is an offset into the shared predecessor arena
-        uint64_t at = 0;
-        for (uint32_t i = 0; i < n; ++i) { sizes[i].preds = (uint32_t)at; at += problems[i].graph.pred_off[problems[i].graph.n_nodes] - problems[i].graph.pred_off[0]; }
-    }
+    lap("staging");
     parallel_for(n, [&](uint32_t i, unsigned t) {
         const vgk_gssw_problem& p = problems[i];
         const vgk_graph& g = p.graph;
@@ -303,12 +343,12 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         node_flags(p, xdrop, mode, f);
         uint8_t* ci_out = colinfo + d.col_off;
         NodeRec* nrs = nodes + d.node_off;
-        uint32_t* pr = preds + sizes[i].preds;
+        uint32_t* pr = preds + sizes[i].pred_at;
         uint32_t col = 0, slots = 0, seq_pos = 0, np = 0;
         for (uint32_t v = 0; v < g.n_nodes; ++v) {
             NodeRec nr;
             nr.col_start = col; nr.col_end = col + g.node_len[v];
-            nr.pred_begin = sizes[i].preds + np; nr.n_pred = g.pred_off[v + 1] - g.pred_off[v];
+            nr.pred_begin = sizes[i].pred_at + np; nr.n_pred = g.pred_off[v + 1] - g.pred_off[v];
             for (uint32_t k = g.pred_off[v]; k < g.pred_off[v + 1]; ++k) pr[np++] = g.pred_idx[k];
             nr.slot = f.store[v] ? (int32_t)slots++ : -1;
             nr.pinning = (mode == VGK_GSSW_PINNED && p.pinning[v]) ? 1u : 0u;
@@ -344,50 +384,59 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         for (uint32_t i = 0; i < n; ++i) idx[count[gkey(tmp[i])]++] = tmp[i];
     }
     lap("sort");
-    std::vector<uint32_t> order;              // pairs
-    std::vector<WaveDesc> waves;
+    // buckets of equal (K, G) are runs of idx; a bucket's reads pair up in order and its pairs fill wavefronts of 64 / G pairs.
+    // The bucket bounds are found serially (there are few), the wavefronts are then described on the host threads.
+    struct Bucket { uint32_t s0, s1, K, G, pair0, pair1, wave0; };
+    std::vector<Bucket> buckets;
     std::vector<FillLaunch>& launches = b->launches;
-    uint64_t tb_dwords = 0;
+    uint32_t n_pairs = 0, n_waves = 0;
     for (uint32_t s0 = 0; s0 < n;) {
-        uint32_t s1 = s0;
         const uint32_t gk = gkey(idx[s0]);
-        while (s1 < n && gkey(idx[s1]) == gk) ++s1;
-        const uint32_t K = gk >> 8, G = gk & 0xffu, gpw = 64 / G;
-        if (launches.empty() || launches.back().K != K) launches.push_back(FillLaunch{K, (uint32_t)waves.size(), 0});
-        const uint32_t pair0 = (uint32_t)(order.size() / 2);
-        for (uint32_t k = s0; k < s1; k += 2) {
-            order.push_back(idx[k]);
-            order.push_back(k + 1 < s1 ? idx[k + 1] : 0xffffffffu);
-        }
-        const uint32_t pair1 = (uint32_t)(order.size() / 2);
-        for (uint32_t pw = pair0; pw < pair1; pw += gpw) {
-            WaveDesc wd{};
-            wd.first_pair = pw; wd.G = G; wd.pair_end = pair1;
-            uint32_t rmax = 0;
-            for (uint32_t q = 0; q < gpw && pw + q < pair1; ++q)
-                for (uint32_t h = 0; h < 2; ++h) {
-                    const uint32_t i = order[2 * (pw + q) + h];
-                    if (i == 0xffffffffu) continue;
-                    rmax = std::max(rmax, probs[i].R);
-                    probs[i].wave = (uint32_t)waves.size(); probs[i].lane0 = q * G; probs[i].geom = K | (G << 8) | (h << 16);
-                }
-            wd.n_steps = rmax ? rmax + G - 1 : 0;
-            wd.tb_off = tb_dwords;
-            if (b->want_tb) tb_dwords += (uint64_t)((wd.n_steps + TB_TILE - 1) / TB_TILE * TB_TILE) * 64 * ((K + 3) / 4);
-            waves.push_back(wd);
-        }
-        launches.back().wave_count = (uint32_t)waves.size() - launches.back().wave_begin;
+        uint32_t lo = s0, hi = n;                              // first position whose key differs (idx is sorted by key)
+        while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (gkey(idx[mid]) == gk) lo = mid; else hi = mid; }
+        const uint32_t s1 = hi, K = gk >> 8, G = gk & 0xffu, gpw = 64 / G;
+        Bucket bk{s0, s1, K, G, n_pairs, n_pairs + (s1 - s0 + 1) / 2, n_waves};
+        if (launches.empty() || launches.back().K != K) launches.push_back(FillLaunch{K, n_waves, 0});
+        n_pairs = bk.pair1; n_waves += (bk.pair1 - bk.pair0 + gpw - 1) / gpw;
+        launches.back().wave_count = n_waves - launches.back().wave_begin;
+        buckets.push_back(bk);
         s0 = s1;
     }
-    const uint32_t n_pairs = (uint32_t)(order.size() / 2), n_waves = (uint32_t)waves.size();
+    std::vector<uint32_t> order((size_t)2 * n_pairs);        // pairs
+    std::vector<WaveDesc> waves(n_waves);
+    parallel_for(n_waves, [&](uint32_t w, unsigned) {
+        size_t bi = 0;
+        while (bi + 1 < buckets.size() && buckets[bi + 1].wave0 <= w) ++bi;
+        const Bucket& bk = buckets[bi];
+        const uint32_t gpw = 64 / bk.G, pw = bk.pair0 + (w - bk.wave0) * gpw;
+        WaveDesc wd{};
+        wd.first_pair = pw; wd.G = bk.G; wd.pair_end = bk.pair1;
+        uint32_t rmax = 0;
+        for (uint32_t q = 0; q < gpw && pw + q < bk.pair1; ++q)
+            for (uint32_t h = 0; h < 2; ++h) {
+                const uint32_t k = bk.s0 + 2 * (pw + q - bk.pair0) + h;
+                const uint32_t i = k < bk.s1 ? idx[k] : 0xffffffffu;
+                order[2 * (size_t)(pw + q) + h] = i;
+                if (i == 0xffffffffu) continue;
+                rmax = std::max(rmax, probs[i].R);
+                probs[i].wave = w; probs[i].lane0 = q * bk.G; probs[i].geom = bk.K | (bk.G << 8) | (h << 16);
+            }
+        wd.n_steps = rmax ? rmax + bk.G - 1 : 0;
+        wd.tb_off = b->want_tb ? (uint64_t)((wd.n_steps + TB_TILE - 1) / TB_TILE * TB_TILE) * 64 * ((bk.K + 3) / 4) : 0;   // size for now
+        waves[w] = wd;
+    });
+    uint64_t tb_dwords = 0;
+    for (WaveDesc& wd : waves) { const uint64_t size = wd.tb_off; wd.tb_off = tb_dwords; tb_dwords += size; }
 
     lap("waves");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    // device arenas come from the context (under its lock); the copies then run on the backend's copy stream without the lock,
+    // so that a caller can pack the next batch while the previous one runs and is fetched
+    std::unique_lock<std::mutex> lk(ctx->mu);
     GsswParams& P = b->P;
     int rc;
     // on failure release whatever was allocated (vgk_batch_free takes the context lock itself)
-    auto fail = [&](int code) { vgk_batch* t = hb.release(); ctx->mu.unlock(); vgk_batch_free(t); ctx->mu.lock(); return code; };
-    if ((rc = to_device(b, probs, P.probs))) return fail(rc);
+    auto fail = [&](int code) { vgk_batch* t = hb.release(); if (lk.owns_lock()) lk.unlock(); vgk_batch_free(t); return code; };
+    if ((rc = to_device(b, (const ProbDesc*)probs, (size_t)n, P.probs))) return fail(rc);
     if ((rc = to_device(b, colinfo, n_cols + 8, P.colinfo))) return fail(rc);
     if ((rc = to_device(b, reads, n_reads, P.reads, 8))) return fail(rc);
     if ((rc = to_device(b, prof, n_prof, P.prof, 4))) return fail(rc);
@@ -395,13 +444,14 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     if ((rc = to_device(b, preds, n_preds, P.preds, 1))) return fail(rc);
     if ((rc = to_device(b, waves, P.waves))) return fail(rc);
     if ((rc = to_device(b, order, P.order, 2))) return fail(rc);
-    lap("uploads");
     if ((rc = dev_alloc(b, (size_t)scratch_words + 16, P.scratch))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)tb_dwords + 4, P.tb))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)n + 1, P.best))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)n + 1, P.results))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)ops_total + 1, P.ops))) return fail(rc);
     lap("allocs");
+    lk.unlock();
+    for (const vgk_batch::Upload& u : b->uploads) if ((rc = ctx->be->upload_side(u.dst, u.src, u.bytes))) return fail(rc);
     P.wave_begin = 0; P.wave_count = 0; P.K = 0;                 // set per fill launch from b->launches
     P.n_problems = n; P.n_pairs = n_pairs; P.n_waves = n_waves;
     const uint32_t S = ctx->scale;     // 8 whenever the scaled profile bytes still fit (vg's default 1/4/6/1/5 does)
@@ -413,8 +463,9 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     if (const char* e = std::getenv("VGAMD_FUSED_TRACEBACK")) P.fused = std::atoi(e) ? 1 : 0;
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = ops_total;
-    if ((rc = ctx->be->sync())) return fail(rc);     // inputs are resident in HBM when pack returns
-    lap("sync");
+    if ((rc = ctx->be->sync_side())) return fail(rc);     // inputs are resident in HBM when pack returns (the uploads have their own stream)
+    b->uploads.clear();
+    lap("uploads");
     *out = hb.release();
     return VGK_OK;
 }
@@ -431,15 +482,63 @@ int vgk_gssw_run(vgk_batch* b) {
 
 int vgk_batch_sync(vgk_batch* b) {
     if (!b) return VGK_EINVAL;
-    std::lock_guard<std::mutex> lk(b->ctx->mu);
-    return b->ctx->be->sync();
+    return b->ctx->be->sync();        // a wait on the stream, without the context lock: another thread may be packing the next batch
+}
+
+// The usual way back: the ops are packed behind each other on the device (a read uses a handful of its ops_per_problem slots),
+// results and ops cross PCIe once into page-locked staging, and host threads copy them into the caller's arrays.  Returns
+// VGK_EUNSUPPORTED when the host path has to do it (no packing kernels, or the ops do not fit the caller's array).
+static int fetch_packed_on_device(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+    vgk_ctx* ctx = b->ctx; Backend* be = ctx->be.get();
+    const uint32_t n = b->n;
+    if (!n) return VGK_EUNSUPPORTED;
+    const uint32_t blocks = (n + Backend::OPS_SCAN_BLOCK - 1) / Backend::OPS_SCAN_BLOCK;
+    std::vector<vgk_ctx::Pooled> mine;
+    auto take = [&](uint64_t bytes) -> void* { uint64_t got = 0; void* p = ctx->dev_take(bytes, got); if (p) mine.push_back({p, got}); return p; };
+    struct GiveBack { vgk_ctx* ctx; std::vector<vgk_ctx::Pooled>& v; ~GiveBack() { ctx->be->sync(); for (auto& q : v) ctx->dev_give(q.p, q.bytes); } } give_back{ctx, mine};
+    uint32_t* offs = (uint32_t*)take((uint64_t)n * 4);
+    uint32_t* sums = (uint32_t*)take(((uint64_t)blocks + 8) * 4);
+    if (!offs || !sums) return VGK_ENOMEM;
+    uint64_t total = 0;
+    int rc = be->ops_offsets(b->P.results, n, offs, sums, &total);
+    if (rc) return rc;                                                   // VGK_EUNSUPPORTED included
+    if (total && (!ops || total > ops_cap || !b->want_tb)) return VGK_EUNSUPPORTED;
+    vgk_result* out_res = (vgk_result*)take((uint64_t)n * sizeof(vgk_result));
+    vgk_op* out_ops = (vgk_op*)take((total + 1) * sizeof(vgk_op));
+    if (!out_res || !out_ops) return VGK_ENOMEM;
+    if ((rc = be->ops_gather(b->P.results, b->P.ops, n, offs, sums, out_res, out_ops))) return rc;
+    struct StagingLease {
+        vgk_ctx* ctx; std::unique_ptr<vgk_ctx::Staging> s;
+        ~StagingLease() { if (s) ctx->staging_release(std::move(s)); }
+    } lease{ctx, ctx->staging_acquire()};
+    const uint64_t res_bytes = (uint64_t)n * sizeof(vgk_result), ops_bytes = total * sizeof(vgk_op);
+    uint8_t* stage = (uint8_t*)lease.s->get(5, res_bytes + ops_bytes);
+    if (!stage) return VGK_ENOMEM;
+    if ((rc = be->download(stage, out_res, res_bytes))) return rc;
+    if (ops_bytes && (rc = be->download(stage + res_bytes, out_ops, ops_bytes))) return rc;
+    auto copy_out = [](void* dst, const uint8_t* src, uint64_t bytes) {
+        const uint64_t chunk = 16384;
+        parallel_for((uint32_t)((bytes + chunk - 1) / chunk), [&](uint32_t c, unsigned) {
+            const uint64_t at = (uint64_t)c * chunk;
+            std::memcpy((uint8_t*)dst + at, src + at, (size_t)std::min(chunk, bytes - at));
+        });
+    };
+    copy_out(results, stage, res_bytes);
+    if (ops_bytes) copy_out(ops, stage + res_bytes, ops_bytes);
+    b->alg_bytes = b->in_bytes + 16ull * n + 2ull * total + b->tb_cells;
+    if (ops_written) *ops_written = (size_t)total;
+    return VGK_OK;
 }
 
 int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
     if (!b || !results) return VGK_EINVAL;
     if (!b->ran) { int rc = vgk_gssw_run(b); if (rc) return rc; }
+    { int rc = b->ctx->be->sync(); if (rc) return rc; }        // wait for the kernels before taking the context lock (see vgk_batch_sync)
     std::lock_guard<std::mutex> lk(b->ctx->mu);
-    int rc = b->ctx->be->download(results, b->P.results, (size_t)b->n * sizeof(vgk_result));
+    int rc = fetch_packed_on_device(b, results, ops, ops_cap, ops_written);
+    if (rc != VGK_EUNSUPPORTED) return rc;
+    // host path (a backend without the packing kernels, or a caller whose op array is too small: per-problem VGK_EOPS)
+    rc = b->ctx->be->download(results, b->P.results, (size_t)b->n * sizeof(vgk_result));
     if (rc) return rc;
     // the per-problem op slots come back through a page-locked staging buffer (no zero-fill, full-rate DMA) ...
     struct StagingLease {
@@ -561,7 +660,7 @@ uint64_t vgk_batch_alg_bytes(vgk_batch* b) {
     if (!b) return 0;
     if (b->alg_bytes) return b->alg_bytes;
     uint64_t alg = b->in_bytes;      // before fetch: everything except the 2 B / emitted op term
-    for (const ProbDesc& d : b->probs) alg += 16 + ((d.flags & VGK_GSSW_TRACEBACK) ? (uint64_t)d.L * d.R : 0);
+    for (uint32_t i = 0; i < b->n; ++i) { const ProbDesc& d = b->probs[i]; alg += 16 + ((d.flags & VGK_GSSW_TRACEBACK) ? (uint64_t)d.L * d.R : 0); }
     return alg;
 }
 uint64_t vgk_batch_device_bytes(vgk_batch* b) { return b ? b->dev_bytes : 0; }
