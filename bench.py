@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # --pmc WRITE_SIZE in separate runs of this very command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py
 # cannot read counters itself, so `roofline.traffic` = this figure x the units of one launch; re-measure with tools/prof_*.sh.
 PMC_BYTES_PER_UNIT = {
-    "linear": (2 * 711837 + 13580389) * 1024 / 400000,      # pmc_{FETCH,WRITE}_SIZE_400k.csv: gssw_fill_kernel, 400 000 reads
+    "linear": (2 * 703386 + 13574138) * 1024 / 400000,      # pmc_{FETCH,WRITE}_SIZE_400k.csv: gssw_fill_kernel, 400 000 reads
     "banded": (2 * 389251 + 2244533) * 1024 / 100000,        # pmc_*_banded_100k.csv: the three banded_fill_kernel classes, 100 000 problems
     "gapless": (2 * 16202932 + 3269559) * 1024 / 1000000,    # pmc_*_gapless_1M.csv: gapless_kernel, 1 000 000 reads
     "wfa": (2 * 4385189 + 1828176) * 1024 / 500000,          # pmc_*_wfa_500k.csv: wfa_kernel, 500 000 problems
