@@ -367,6 +367,27 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     // ---- length buckets: reads with the same (K, G) geometry share wavefronts; inside a bucket reads are sorted by
     //      graph size so that the pairs of a wavefront finish together.  One fill launch per K; G is per wavefront.
     lap("pass3");
+    // The encoded arenas (0.9 of the 1.0 GB that goes to HBM) start their way there now, on the copy stream, and travel while the
+    // host orders the reads and describes the wavefronts.  Device arenas come from the context (under its lock); the copies run
+    // without it, so that a caller can pack the next batch while the previous one runs and is fetched.
+    GsswParams& P = b->P;
+    int rc;
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    // on failure release whatever was allocated (vgk_batch_free takes the context lock itself)
+    auto fail = [&](int code) { vgk_batch* t = hb.release(); if (lk.owns_lock()) lk.unlock(); vgk_batch_free(t); return code; };
+    auto issue_uploads = [&]() -> int {
+        for (const vgk_batch::Upload& u : b->uploads) { const int e = ctx->be->upload_side(u.dst, u.src, u.bytes); if (e) return e; }
+        b->uploads.clear();
+        return VGK_OK;
+    };
+    if ((rc = to_device(b, colinfo, n_cols + 8, P.colinfo))) return fail(rc);
+    if ((rc = to_device(b, reads, n_reads, P.reads, 8))) return fail(rc);
+    if ((rc = to_device(b, prof, n_prof, P.prof, 4))) return fail(rc);
+    if ((rc = to_device(b, nodes, n_nodes, P.nodes))) return fail(rc);
+    if ((rc = to_device(b, preds, n_preds, P.preds, 1))) return fail(rc);
+    lk.unlock();
+    if ((rc = issue_uploads())) return fail(rc);
+    lap("arenas");
     auto gkey = [&](uint32_t i) { return ((probs[i].geom & 0xffu) << 8) | ((probs[i].geom >> 8) & 0xffu); };   // (K, G)
     // stable order by (K, G) ascending, then graph size descending: two counting-sort passes over 16-bit digits (sizes beyond 65 535
     // columns share the last digit value; the order only balances wavefronts, it never changes a result)
@@ -429,19 +450,9 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     for (WaveDesc& wd : waves) { const uint64_t size = wd.tb_off; wd.tb_off = tb_dwords; tb_dwords += size; }
 
     lap("waves");
-    // device arenas come from the context (under its lock); the copies then run on the backend's copy stream without the lock,
-    // so that a caller can pack the next batch while the previous one runs and is fetched
-    std::unique_lock<std::mutex> lk(ctx->mu);
-    GsswParams& P = b->P;
-    int rc;
-    // on failure release whatever was allocated (vgk_batch_free takes the context lock itself)
-    auto fail = [&](int code) { vgk_batch* t = hb.release(); if (lk.owns_lock()) lk.unlock(); vgk_batch_free(t); return code; };
+    // the descriptors (their wave / lane fields are final now), the wavefronts and the order follow; the output arenas are allocated
+    lk.lock();
     if ((rc = to_device(b, (const ProbDesc*)probs, (size_t)n, P.probs))) return fail(rc);
-    if ((rc = to_device(b, colinfo, n_cols + 8, P.colinfo))) return fail(rc);
-    if ((rc = to_device(b, reads, n_reads, P.reads, 8))) return fail(rc);
-    if ((rc = to_device(b, prof, n_prof, P.prof, 4))) return fail(rc);
-    if ((rc = to_device(b, nodes, n_nodes, P.nodes))) return fail(rc);
-    if ((rc = to_device(b, preds, n_preds, P.preds, 1))) return fail(rc);
     if ((rc = to_device(b, waves, P.waves))) return fail(rc);
     if ((rc = to_device(b, order, P.order, 2))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)scratch_words + 16, P.scratch))) return fail(rc);
@@ -451,7 +462,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     if ((rc = dev_alloc(b, (size_t)ops_total + 1, P.ops))) return fail(rc);
     lap("allocs");
     lk.unlock();
-    for (const vgk_batch::Upload& u : b->uploads) if ((rc = ctx->be->upload_side(u.dst, u.src, u.bytes))) return fail(rc);
+    if ((rc = issue_uploads())) return fail(rc);
     P.wave_begin = 0; P.wave_count = 0; P.K = 0;                 // set per fill launch from b->launches
     P.n_problems = n; P.n_pairs = n_pairs; P.n_waves = n_waves;
     const uint32_t S = ctx->scale;     // 8 whenever the scaled profile bytes still fit (vg's default 1/4/6/1/5 does)
@@ -464,7 +475,6 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = ops_total;
     if ((rc = ctx->be->sync_side())) return fail(rc);     // inputs are resident in HBM when pack returns (the uploads have their own stream)
-    b->uploads.clear();
     lap("uploads");
     *out = hb.release();
     return VGK_OK;
