@@ -160,8 +160,10 @@ void vgk_destroy(vgk_ctx* ctx);
 int  vgk_device_info(vgk_ctx* ctx, char* name_out, size_t name_cap,
                      int* compute_units, size_t* hbm_bytes);
 
-/* gssw path.  pack = validate + encode + H2D; run = kernels only (asynchronous
- * on the batch's HIP stream, bracketed by HIP events); fetch = wait + D2H. */
+/* gssw path.  pack = validate + encode + H2D (host threads; the copies run on a copy stream of their own, so another
+ * thread may pack the next batch while this one runs); run = kernels only (asynchronous on the context's HIP stream,
+ * bracketed by HIP events); fetch = wait + the CIGAR ops packed behind each other on the device + D2H.  Freed batches leave
+ * their device arenas and page-locked blocks with the context for the next pack (released by vgk_destroy). */
 int  vgk_gssw_pack (vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
                     uint32_t ops_per_problem /* 0 = engine default */,
                     vgk_batch** out);
