@@ -374,7 +374,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     int rc;
     std::unique_lock<std::mutex> lk(ctx->mu);
     // on failure release whatever was allocated (vgk_batch_free takes the context lock itself)
-    auto fail = [&](int code) { vgk_batch* t = hb.release(); if (lk.owns_lock()) lk.unlock(); vgk_batch_free(t); return code; };
+    auto fail = [&](int code) { vgk_batch* t = hb.release(); if (lk.owns_lock()) lk.unlock(); ctx->be->sync_side(); vgk_batch_free(t); return code; };   // (copies in flight must land before the arenas go back to the pool)
     auto issue_uploads = [&]() -> int {
         for (const vgk_batch::Upload& u : b->uploads) { const int e = ctx->be->upload_side(u.dst, u.src, u.bytes); if (e) return e; }
         b->uploads.clear();
