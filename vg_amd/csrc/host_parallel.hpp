@@ -97,6 +97,22 @@ template <class F> inline void parallel_for(uint32_t n, F f) {
     for (auto& t : ts) t.join();
 }
 
+// a few coarse tasks (slices of a sort, say) on the same threads: task(i) for i in [0, count), whatever the count
+template <class F> inline void parallel_tasks(uint32_t count, F task) {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned T = std::min<unsigned>(hw ? hw : 1, 48u);
+    if (const char* e = std::getenv("VGAMD_HOST_THREADS")) T = (unsigned)std::min<int>(MAX_THREADS, std::max(1, std::atoi(e)));
+    T = std::min<unsigned>(T, count);
+    if (T <= 1) { for (uint32_t i = 0; i < count; ++i) task(i); return; }
+    std::atomic<uint32_t> next{0};
+    const std::function<void(unsigned)> body = [&](unsigned) { for (;;) { const uint32_t i = next.fetch_add(1); if (i >= count) break; task(i); } };
+    if (WorkerPool::get().try_run(T, body)) return;
+    std::vector<std::thread> ts;
+    for (unsigned t = 1; t < T; ++t) ts.emplace_back([&body, t]() { body(t); });
+    body(0);
+    for (auto& t : ts) t.join();
+}
+
 // the same over fixed chunks of the index range: f(lo, hi, chunk) — for two-level prefix sums and reductions
 constexpr uint32_t CHUNK = 512;
 inline uint32_t chunk_count(uint32_t n) { return (n + CHUNK - 1) / CHUNK; }

@@ -393,16 +393,48 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     // columns share the last digit value; the order only balances wavefronts, it never changes a result)
     std::vector<uint32_t> idx(n);
     {
-        std::vector<uint32_t> tmp(n), count(65537);
-        auto low = [&](uint32_t i) { return 0xffffu - std::min<uint32_t>(probs[i].R, 0xffffu); };
-        std::fill(count.begin(), count.end(), 0u);
-        for (uint32_t i = 0; i < n; ++i) ++count[low(i) + 1];
-        for (uint32_t k = 0; k < 65536; ++k) count[k + 1] += count[k];
-        for (uint32_t i = 0; i < n; ++i) tmp[count[low(i)]++] = i;
-        std::fill(count.begin(), count.end(), 0u);
-        for (uint32_t i = 0; i < n; ++i) ++count[gkey(i) + 1];
-        for (uint32_t k = 0; k < 65536; ++k) count[k + 1] += count[k];
-        for (uint32_t i = 0; i < n; ++i) idx[count[gkey(tmp[i])]++] = tmp[i];
+        // one stable counting-sort pass src -> dst by key(i) in [0, 65536): on the host threads when the keys present span few
+        // values (slices of the input, one histogram per slice, offsets by (value, slice)), else serially
+        auto pass = [&](const uint32_t* src, uint32_t* dst, auto key) {
+            constexpr uint32_t SLICES = 64, MAX_RANGE = 8192;
+            uint32_t lo_k = 0xffffffffu, hi_k = 0;
+            if (n >= 65536) {
+                std::vector<uint32_t> mn(SLICES, 0xffffffffu), mx(SLICES, 0);
+                parallel_tasks(SLICES, [&](uint32_t sl) {
+                    const uint64_t a0 = (uint64_t)n * sl / SLICES, a1 = (uint64_t)n * (sl + 1) / SLICES;
+                    uint32_t a = 0xffffffffu, b2 = 0;
+                    for (uint64_t k = a0; k < a1; ++k) { const uint32_t v = key(src ? src[k] : (uint32_t)k); a = std::min(a, v); b2 = std::max(b2, v); }
+                    mn[sl] = a; mx[sl] = b2;
+                });
+                for (uint32_t sl = 0; sl < SLICES; ++sl) { lo_k = std::min(lo_k, mn[sl]); hi_k = std::max(hi_k, mx[sl]); }
+            }
+            if (n >= 65536 && hi_k - lo_k < MAX_RANGE) {
+                const uint32_t range = hi_k - lo_k + 1;
+                std::vector<uint32_t> hist((size_t)SLICES * range, 0u);
+                auto each_slice = [&](auto body) { parallel_tasks(SLICES, body); };
+                each_slice([&](uint32_t sl) {
+                    uint32_t* h = hist.data() + (size_t)sl * range;
+                    const uint64_t a0 = (uint64_t)n * sl / SLICES, a1 = (uint64_t)n * (sl + 1) / SLICES;
+                    for (uint64_t k = a0; k < a1; ++k) ++h[key(src ? src[k] : (uint32_t)k) - lo_k];
+                });
+                uint32_t at = 0;
+                for (uint32_t v = 0; v < range; ++v)
+                    for (uint32_t sl = 0; sl < SLICES; ++sl) { uint32_t& c = hist[(size_t)sl * range + v]; const uint32_t cnt = c; c = at; at += cnt; }
+                each_slice([&](uint32_t sl) {
+                    uint32_t* h = hist.data() + (size_t)sl * range;
+                    const uint64_t a0 = (uint64_t)n * sl / SLICES, a1 = (uint64_t)n * (sl + 1) / SLICES;
+                    for (uint64_t k = a0; k < a1; ++k) { const uint32_t i = src ? src[k] : (uint32_t)k; dst[h[key(i) - lo_k]++] = i; }
+                });
+                return;
+            }
+            std::vector<uint32_t> count(65537, 0u);
+            for (uint32_t k = 0; k < n; ++k) ++count[key(src ? src[k] : k) + 1];
+            for (uint32_t k = 0; k < 65536; ++k) count[k + 1] += count[k];
+            for (uint32_t k = 0; k < n; ++k) { const uint32_t i = src ? src[k] : k; dst[count[key(i)]++] = i; }
+        };
+        std::vector<uint32_t> tmp(n);
+        pass(nullptr, tmp.data(), [&](uint32_t i) { return 0xffffu - std::min<uint32_t>(probs[i].R, 0xffffu); });
+        pass(tmp.data(), idx.data(), gkey);
     }
     lap("sort");
     // buckets of equal (K, G) are runs of idx; a bucket's reads pair up in order and its pairs fill wavefronts of 64 / G pairs.
