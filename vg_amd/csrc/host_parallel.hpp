@@ -20,13 +20,16 @@ constexpr unsigned MAX_THREADS = 128;
 // threads instead, and a process that was forked after the pool came up gets a new pool.
 class WorkerPool {
 public:
-    static WorkerPool& get() {
+    // two pools: a caller that packs the next batch while another thread fetches the previous one finds the second one free
+    static WorkerPool& get(int which = 0) {
         static std::mutex guard;
-        static std::unique_ptr<WorkerPool> pool;
+        static std::unique_ptr<WorkerPool> pools[2];
+        std::unique_ptr<WorkerPool>& pool = pools[which & 1];
         std::lock_guard<std::mutex> lock(guard);
         if (!pool || pool->owner != getpid()) { if (pool) (void)pool.release(); pool.reset(new WorkerPool()); }    // a forked child cannot use (or join) the parent's threads
         return *pool;
     }
+    static bool run_on_any(unsigned T, const std::function<void(unsigned)>& job) { return get(0).try_run(T, job) || get(1).try_run(T, job); }
     // runs job(t) for t in [0, T) — t = 0 on the calling thread — and returns when all are done; false = pool busy, nothing ran
     bool try_run(unsigned T, const std::function<void(unsigned)>& job) {
         std::unique_lock<std::mutex> one(submit, std::try_to_lock);
@@ -90,7 +93,7 @@ template <class F> inline void parallel_for(uint32_t n, F f) {
         for (;;) { const uint32_t b = next.fetch_add(64); if (b >= n) break; for (uint32_t i = b; i < std::min(n, b + 64); ++i) f(i, t); }
     };
     if (T <= 1) { body(0); return; }
-    if (WorkerPool::get().try_run(T, body)) return;
+    if (WorkerPool::run_on_any(T, body)) return;
     std::vector<std::thread> ts;                                     // the pool is busy with another caller's loop
     for (unsigned t = 1; t < T; ++t) ts.emplace_back([&body, t]() { body(t); });
     body(0);
@@ -106,7 +109,7 @@ template <class F> inline void parallel_tasks(uint32_t count, F task) {
     if (T <= 1) { for (uint32_t i = 0; i < count; ++i) task(i); return; }
     std::atomic<uint32_t> next{0};
     const std::function<void(unsigned)> body = [&](unsigned) { for (;;) { const uint32_t i = next.fetch_add(1); if (i >= count) break; task(i); } };
-    if (WorkerPool::get().try_run(T, body)) return;
+    if (WorkerPool::run_on_any(T, body)) return;
     std::vector<std::thread> ts;
     for (unsigned t = 1; t < T; ++t) ts.emplace_back([&body, t]() { body(t); });
     body(0);
