@@ -34,6 +34,9 @@ public:
     // stream of their own; sync_side() waits for them only
     virtual int   upload_side(void* dst, const void* src, size_t bytes) { return upload(dst, src, bytes); }
     virtual int   sync_side() { return sync(); }
+    // wait for the stream by polling an event, without sitting in a blocking runtime call: another thread's copies and launches
+    // (the next batch being packed) go through meanwhile
+    virtual int   sync_polling() { return sync(); }
     virtual int   zero(void* dst, size_t bytes) = 0;                        // async on the stream
     virtual int   sync() = 0;
     // gssw kernels: one fill launch per rows-per-lane instantiation (`launches`), then one traceback

@@ -1,6 +1,8 @@
 // backend_hip.hip — HIP runtime plumbing + the gfx950 kernel entry points.
 // There is deliberately no CPU fallback here: if no HIP device answers,
 // make_backend() fails and vgk_create() returns VGK_ENODEV.
+#include <chrono>
+#include <thread>
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <string>
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(64) gssw_matrix_kernel(const GsswMatrixParams 
 
 class HipBackend final : public Backend {
 public:
-    int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, copy = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int dev = 0; int n_launches = 1; hipEvent_t poll_ev = nullptr; hipStream_t stream = nullptr, copy = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipDeviceProp_t prop;
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
     float ms_gapless = 0.f, ms_wfa = 0.f;
@@ -231,6 +233,7 @@ public:
         for (int i = 0; i < 2; ++i) { if (side[i]) hipStreamDestroy(side[i]); if (side_done[i]) hipEventDestroy(side_done[i]); }
         if (stream) hipStreamDestroy(stream);
         if (copy) hipStreamDestroy(copy);
+        if (poll_ev) hipEventDestroy(poll_ev);
     }
     const char* name() const override { return prop.name; }
     int compute_units() const override { return prop.multiProcessorCount; }
@@ -256,6 +259,17 @@ public:
     int upload_side(void* dst, const void* src, size_t bytes) override {
         hipSetDevice(dev);
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, copy) == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int sync_polling() override {
+        hipSetDevice(dev);
+        if (!poll_ev && hipEventCreateWithFlags(&poll_ev, hipEventDisableTiming) != hipSuccess) return sync();
+        if (hipEventRecord(poll_ev, stream) != hipSuccess) return sync();
+        for (;;) {
+            const hipError_t e = hipEventQuery(poll_ev);
+            if (e == hipSuccess) return VGK_OK;
+            if (e != hipErrorNotReady) { (void)hipGetLastError(); return VGK_ENODEV; }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
     }
     int sync_side() override {
         hipSetDevice(dev);

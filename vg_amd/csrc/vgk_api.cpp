@@ -575,7 +575,7 @@ static int fetch_packed_on_device(vgk_batch* b, vgk_result* results, vgk_op* ops
 int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
     if (!b || !results) return VGK_EINVAL;
     if (!b->ran) { int rc = vgk_gssw_run(b); if (rc) return rc; }
-    { int rc = b->ctx->be->sync(); if (rc) return rc; }        // wait for the kernels before taking the context lock (see vgk_batch_sync)
+    { int rc = b->ctx->be->sync_polling(); if (rc) return rc; }        // wait for the kernels before taking the context lock, and outside blocking runtime calls
     std::lock_guard<std::mutex> lk(b->ctx->mu);
     int rc = fetch_packed_on_device(b, results, ops, ops_cap, ops_written);
     if (rc != VGK_EUNSUPPORTED) return rc;
