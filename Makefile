@@ -23,15 +23,15 @@ lib: vg_amd/libvgamd.so
 host: vg_amd/libvgamd_host.so
 oracle: oracle/libvgoracle.so
 
-# the C-ABI/packing layer is plain C++; only backend_hip.hip carries device code
-vg_amd/libvgamd.so: $(LIB_SRCS) $(LIB_HDRS)
-	$(CXX) $(CXXFLAGS) -O3 -c vg_amd/csrc/vgk_api.cpp -o vg_amd/csrc/vgk_api.o
-	$(CXX) $(CXXFLAGS) -O3 -c vg_amd/csrc/banded_api.cpp -o vg_amd/csrc/banded_api.o
-	$(CXX) $(CXXFLAGS) -O3 -c vg_amd/csrc/gapless_api.cpp -o vg_amd/csrc/gapless_api.o
-	$(CXX) $(CXXFLAGS) -O3 -c vg_amd/csrc/wfa_api.cpp -o vg_amd/csrc/wfa_api.o
-	$(CXX) $(CXXFLAGS) -O3 -c vg_amd/csrc/gssw_multi_api.cpp -o vg_amd/csrc/gssw_multi_api.o
-	$(HIPCC) $(HIPFLAGS) -c vg_amd/csrc/backend_hip.hip -o vg_amd/csrc/backend_hip.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ vg_amd/csrc/vgk_api.o vg_amd/csrc/banded_api.o vg_amd/csrc/gapless_api.o vg_amd/csrc/wfa_api.o vg_amd/csrc/gssw_multi_api.o vg_amd/csrc/backend_hip.o
+# the C-ABI/packing layer is plain C++; only the .hip files carry device code
+LIB_CPP_OBJS := $(patsubst %.cpp,%.o,$(wildcard vg_amd/csrc/*.cpp))
+LIB_HIP_OBJS := $(patsubst %.hip,%.o,$(wildcard vg_amd/csrc/*.hip))
+vg_amd/csrc/%.o: vg_amd/csrc/%.cpp $(LIB_HDRS)
+	$(CXX) $(CXXFLAGS) -O3 -c $< -o $@
+vg_amd/csrc/%.o: vg_amd/csrc/%.hip $(LIB_HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+vg_amd/libvgamd.so: $(LIB_CPP_OBJS) $(LIB_HIP_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIB_CPP_OBJS) $(LIB_HIP_OBJS)
 
 vg_amd/libvgamd_host.so: $(HOST_SRCS) $(HOST_HDRS)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRCS) -ldl
@@ -40,12 +40,19 @@ oracle/libvgoracle.so: $(ORACLE_SRCS) include/vgk.h oracle/vgo_haplo.h
 	$(CC) $(CFLAGS) -shared -o $@ $(ORACLE_SRCS)
 
 clean:
-	rm -f vg_amd/libvgamd.so vg_amd/libvgamd_host.so oracle/libvgoracle.so
+	rm -f vg_amd/csrc/*.o vg_amd/libvgamd.so vg_amd/libvgamd_host.so oracle/libvgoracle.so
 
 .PHONY: all lib host oracle clean
 
 # test-only: CPU lock-step emulation of the HIP lane code behind the same C ABI
 emu: tests/emu/libvgamd_emu.so
-tests/emu/libvgamd_emu.so: vg_amd/csrc/vgk_api.cpp vg_amd/csrc/banded_api.cpp vg_amd/csrc/gapless_api.cpp vg_amd/csrc/wfa_api.cpp vg_amd/csrc/gssw_multi_api.cpp tests/emu/backend_emu.cpp $(LIB_HDRS)
-	$(CXX) -O2 -g -std=c++17 -fPIC -Iinclude -Wall -shared -o $@ vg_amd/csrc/vgk_api.cpp vg_amd/csrc/banded_api.cpp vg_amd/csrc/gapless_api.cpp vg_amd/csrc/wfa_api.cpp vg_amd/csrc/gssw_multi_api.cpp tests/emu/backend_emu.cpp -lpthread
+EMU_OBJS := $(patsubst vg_amd/csrc/%.cpp,tests/emu/obj/%.o,$(wildcard vg_amd/csrc/*.cpp)) tests/emu/obj/backend_emu.o
+tests/emu/obj/%.o: vg_amd/csrc/%.cpp $(LIB_HDRS)
+	@mkdir -p tests/emu/obj
+	$(CXX) -O2 -g -std=c++17 -fPIC -Iinclude -Wall -c $< -o $@
+tests/emu/obj/backend_emu.o: tests/emu/backend_emu.cpp $(LIB_HDRS)
+	@mkdir -p tests/emu/obj
+	$(CXX) -O2 -g -std=c++17 -fPIC -Iinclude -Wall -c $< -o $@
+tests/emu/libvgamd_emu.so: $(EMU_OBJS)
+	$(CXX) -shared -o $@ $(EMU_OBJS) -lpthread
 .PHONY: emu

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define VGK_ABI_VERSION 1
+#define VGK_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -176,6 +176,33 @@ int  vgk_gssw_fetch(vgk_batch* batch, vgk_result* results /* [n] */,
 int  vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
                     vgk_result* results, vgk_op* ops, size_t ops_cap,
                     size_t* ops_written);
+/* ---- one graph resident in HBM, problems as windows of it (device-side packing) --------------------------------------
+ * `vg map` aligns every read against a subgraph cut out of ONE graph around its seed cluster (the id range around the MEMs,
+ * src/mapper.cpp:2445-2518) and converts that subgraph node by node on the CPU (create_gssw_graph, src/aligner.cpp:30-85).
+ * When the graph is a DAG whose node order is topological, such a subgraph is a run of consecutive nodes: the graph is
+ * handed over once (vgk_graph_create), a problem shrinks to {read, first node, node count} = the induced subgraph on
+ * nodes [first_node, first_node + n_nodes) (edges that enter the window from outside are dropped, exactly as in the
+ * extracted subgraph), and vgk_gssw_pack_windows derives everything the kernels read from the resident tables ON THE
+ * DEVICE: the host copies two flat buffers (reads, problems) and touches no problem.  Results are those of vgk_gssw_pack on
+ * the same induced subgraphs; op.node counts from the window's first node.
+ * Modes: VGK_GSSW_LOCAL and VGK_XDROP_PINNED (| VGK_GSSW_TRACEBACK); plain contexts only (quality-adjusted: VGK_EUNSUPPORTED).
+ * Nodes must be non-empty and at most 65535 bases long. */
+typedef struct vgk_dgraph vgk_dgraph;
+int  vgk_graph_create(vgk_ctx* ctx, const vgk_graph* graph, vgk_dgraph** out);
+void vgk_graph_destroy(vgk_dgraph* graph);
+typedef struct vgk_window_problem {
+    uint64_t read_off;        /* offset of the read in `reads`                                   */
+    uint32_t read_len;
+    uint32_t flags;           /* VGK_GSSW_*                                                      */
+    uint32_t first_node;      /* the window: nodes [first_node, first_node + n_nodes)            */
+    uint32_t n_nodes;
+    uint32_t max_gap_length;  /* XDROP only (see vgk_gssw_problem)                               */
+    uint32_t reserved;
+} vgk_window_problem;
+/* A batch for vgk_gssw_run / vgk_gssw_fetch / vgk_batch_free like one from vgk_gssw_pack.  The first malformed or
+ * out-of-range problem (in index order) decides the return code, as a serial scan would. */
+int  vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* graph, const char* reads, size_t reads_bytes,
+                           const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out);
 /* k-best pinned alignments (Aligner::align_pinned_multi -> gssw_graph_trace_back_pinned_multi, src/aligner.cpp:423-435, :455-480).
  * Every problem must be VGK_GSSW_PINNED.  results[i * max_alt_alns + k] is the k-th best alignment of problem i (k <
  * n_alignments[i] <= max_alt_alns), scores non-increasing and > 0, the first one the alignment vgk_gssw_align returns; a problem

@@ -43,6 +43,8 @@ static int vgo_dispatch(const vgk_ctx* c, const vgk_gssw_problem* p, vgk_result*
 struct vgk_batch {
     vgk_ctx* ctx; const vgk_gssw_problem* probs; uint32_t n; uint32_t ops_per;
     vgk_result* res; vgk_op* ops; int ran; uint64_t cells;
+    /* window batches own the problems built for them */
+    vgk_gssw_problem* own_probs; char* own_reads; uint32_t* own_pred_off; uint32_t* own_pred_idx;
 };
 
 int vgk_abi_version(void) { return VGK_ABI_VERSION; }
@@ -294,7 +296,89 @@ int vgk_gssw_align_multi(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
     return rc;
 }
 
-void vgk_batch_free(vgk_batch* b) { if (b) { free(b->res); free(b->ops); free(b); } }
+void vgk_batch_free(vgk_batch* b) { if (b) { free(b->res); free(b->ops); free(b->own_probs); free(b->own_reads); free(b->own_pred_off); free(b->own_pred_idx); free(b); } }
+
+/* ---- windows of one graph (vgk_graph_create / vgk_gssw_pack_windows) ---------------------------------------------------
+ * The oracle's reading of "a window is the induced subgraph on nodes [first, first + n)": every problem gets its own
+ * predecessor CSR with the edges from outside the window dropped and the indices re-based, then runs through the ordinary
+ * per-problem oracle.  (The engine derives its arenas from resident tables instead; the two constructions share nothing.) */
+struct vgk_dgraph { uint32_t n_nodes; uint32_t* node_len; uint64_t* seq_off; char* seq; uint32_t* pred_off; uint32_t* pred_idx; };
+int vgk_graph_create(vgk_ctx* ctx, const vgk_graph* g, vgk_dgraph** out) {
+    if (!ctx || !g || !out || !g->n_nodes || !g->node_len || !g->seq || !g->pred_off) return VGK_EINVAL;
+    *out = NULL;
+    const uint32_t n = g->n_nodes;
+    uint64_t bases = 0;
+    for (uint32_t v = 0; v < n; ++v) {
+        if (g->node_len[v] == 0 || g->pred_off[v + 1] < g->pred_off[v]) return VGK_EINVAL;
+        if (g->node_len[v] > 65535u) return VGK_ETOOBIG;
+        for (uint32_t k = g->pred_off[v]; k < g->pred_off[v + 1]; ++k) if (!g->pred_idx || g->pred_idx[k] >= v) return VGK_EINVAL;
+        bases += g->node_len[v];
+    }
+    if (bases >= (1ull << 32) - 16) return VGK_ETOOBIG;
+    vgk_dgraph* d = (vgk_dgraph*)calloc(1, sizeof *d);
+    if (!d) return VGK_ENOMEM;
+    const uint32_t ne = g->pred_off[n] - g->pred_off[0];
+    d->n_nodes = n;
+    d->node_len = (uint32_t*)malloc(sizeof(uint32_t) * n); d->seq_off = (uint64_t*)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+    d->seq = (char*)malloc(bases + 1); d->pred_off = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1)); d->pred_idx = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)ne + 1));
+    if (!d->node_len || !d->seq_off || !d->seq || !d->pred_off || !d->pred_idx) { vgk_graph_destroy(d); return VGK_ENOMEM; }
+    memcpy(d->node_len, g->node_len, sizeof(uint32_t) * n); memcpy(d->seq, g->seq, bases);
+    d->seq_off[0] = 0;
+    for (uint32_t v = 0; v < n; ++v) d->seq_off[v + 1] = d->seq_off[v] + g->node_len[v];
+    for (uint32_t v = 0; v <= n; ++v) d->pred_off[v] = g->pred_off[v] - g->pred_off[0];
+    if (ne) memcpy(d->pred_idx, g->pred_idx + g->pred_off[0], sizeof(uint32_t) * ne);
+    *out = d; return VGK_OK;
+}
+void vgk_graph_destroy(vgk_dgraph* d) { if (d) { free(d->node_len); free(d->seq_off); free(d->seq); free(d->pred_off); free(d->pred_idx); free(d); } }
+
+int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* g, const char* reads, size_t reads_bytes,
+                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out) {
+    if (!ctx || !g || !out || (!problems && n) || (!reads && reads_bytes)) return VGK_EINVAL;
+    *out = NULL;
+    if (ctx->has_qa) return VGK_EUNSUPPORTED;
+    int maxs = 0;
+    for (int k = 0; k < 25; ++k) if (ctx->sc.matrix[k] > maxs) maxs = ctx->sc.matrix[k];
+    uint64_t tot_nodes = 0, tot_edges = 0;
+    for (uint32_t i = 0; i < n; ++i) {      /* the first problem that fails decides, with the engine's codes */
+        const vgk_window_problem* p = &problems[i];
+        const uint32_t mode = p->flags & 15u;
+        const uint32_t rows = p->read_len + (mode == VGK_XDROP_PINNED ? 1u : 0u);
+        if (p->read_len == 0 || p->n_nodes == 0 || (uint64_t)p->first_node + p->n_nodes > g->n_nodes || p->read_off + p->read_len > reads_bytes) return VGK_EINVAL;
+        if (mode != VGK_GSSW_LOCAL && mode != VGK_XDROP_PINNED) return VGK_EINVAL;
+        if (rows > 1024) return VGK_ETOOLONG;
+        if ((int64_t)rows * maxs + 2 * (int64_t)ctx->sc.full_length_bonus > 2046) return VGK_EUNSUPPORTED;
+        if (mode == VGK_XDROP_PINNED && (int64_t)p->read_len * maxs + ctx->sc.full_length_bonus >= 1023) return VGK_EUNSUPPORTED;
+        if (g->seq_off[p->first_node + p->n_nodes] - g->seq_off[p->first_node] >= (1u << 20)) return VGK_ETOOBIG;
+        tot_nodes += p->n_nodes; tot_edges += g->pred_off[p->first_node + p->n_nodes] - g->pred_off[p->first_node];
+    }
+    vgk_gssw_problem* pr = (vgk_gssw_problem*)calloc(n ? n : 1, sizeof *pr);
+    uint32_t* po = (uint32_t*)malloc(sizeof(uint32_t) * (tot_nodes + n + 1)); uint32_t* pi = (uint32_t*)malloc(sizeof(uint32_t) * (tot_edges + 1));
+    char* rd = (char*)malloc(reads_bytes + 1);
+    if (!pr || !po || !pi || !rd) { free(pr); free(po); free(pi); free(rd); return VGK_ENOMEM; }
+    if (reads_bytes) memcpy(rd, reads, reads_bytes);
+    uint64_t at_o = 0, at_e = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const vgk_window_problem* p = &problems[i];
+        vgk_gssw_problem* q = &pr[i];
+        q->read = rd + p->read_off; q->read_len = p->read_len; q->flags = p->flags; q->max_gap_length = p->max_gap_length;
+        q->graph.n_nodes = p->n_nodes; q->graph.node_len = g->node_len + p->first_node; q->graph.seq = g->seq + g->seq_off[p->first_node];
+        q->graph.pred_off = po + at_o; q->graph.pred_idx = pi + at_e;
+        uint32_t ne = 0;
+        for (uint32_t k = 0; k < p->n_nodes; ++k) {
+            const uint32_t v = p->first_node + k;
+            po[at_o + k] = ne;
+            for (uint32_t e = g->pred_off[v]; e < g->pred_off[v + 1]; ++e)
+                if (g->pred_idx[e] >= p->first_node) pi[at_e + ne++] = g->pred_idx[e] - p->first_node;
+        }
+        po[at_o + p->n_nodes] = ne;
+        at_o += p->n_nodes + 1; at_e += ne;
+    }
+    vgk_batch* b = NULL;
+    int rc = vgk_gssw_pack(ctx, pr, n, ops_per_problem, &b);
+    if (rc) { free(pr); free(po); free(pi); free(rd); return rc; }
+    b->own_probs = pr; b->own_reads = rd; b->own_pred_off = po; b->own_pred_idx = pi;
+    *out = b; return VGK_OK;
+}
 int  vgk_batch_sync(vgk_batch* b) { (void)b; return VGK_OK; }
 double vgk_batch_kernel_ms(vgk_batch* b, int which) { (void)b; (void)which; return 0.0; }
 uint64_t vgk_batch_cells(vgk_batch* b) { return b ? b->cells : 0; }

@@ -6,6 +6,7 @@
 // never built into, nor loaded by, the product library.
 #include <pthread.h>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -89,6 +90,37 @@ public:
     int download(void* d, const void* s, size_t n) override { std::memcpy(d, s, n); return VGK_OK; }
     int zero(void* d, size_t n) override { std::memset(d, 0, n); return VGK_OK; }
     int sync() override { return VGK_OK; }
+    // device-side packing of window problems: the same per-problem / per-wavefront functions, in loops
+    int fill_side(void* d, int byte, size_t n) override { std::memset(d, byte, n); return VGK_OK; }
+    int win_stage1(const WinParams& P, void*, size_t) override {
+        WinAcc acc; win_acc_clear(acc);
+        for (uint32_t i = 0; i < P.n; ++i) win_size_one(P, i, acc);
+        win_acc_flush(P, acc);
+        const uint32_t n1 = P.n + 1;
+        for (uint32_t k = 0; k < WIN_COLS; ++k) {
+            P.sizes[k * n1 + P.n] = 0;
+            uint32_t at = 0;
+            for (uint32_t i = 0; i < n1; ++i) { P.offs[k * n1 + i] = at; at += P.sizes[k * n1 + i]; }
+        }
+        return VGK_OK;
+    }
+    int win_stage2(const WinParams& P, void*, size_t) override {
+        if (!P.n) return VGK_OK;
+        std::vector<uint32_t> perm(P.n);
+        for (uint32_t i = 0; i < P.n; ++i) perm[i] = i;
+        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return (P.key[a] & 0x1ffffffu) < (P.key[b] & 0x1ffffffu); });
+        for (uint32_t j = 0; j < P.n; ++j) { P.key_sorted[j] = P.key[perm[j]]; P.idx_sorted[j] = P.idx[perm[j]]; }
+        std::memset(P.bucket_first, 0xff, sizeof(uint32_t) * WIN_BUCKETS);
+        std::memset(P.wave_tb, 0, sizeof(unsigned long long) * ((size_t)P.n_waves_cap + 1));
+        for (uint32_t j = 0; j < P.n; ++j) win_bucket_first_one(P, j);
+        win_buckets(P);
+        for (uint32_t w = 0; w < P.n_waves_cap; ++w) win_wave_one(P, w);
+        unsigned long long at = 0;
+        for (uint32_t w = 0; w <= P.n_waves_cap; ++w) { const unsigned long long s = P.wave_tb[w]; P.wave_tb[w] = at; at += s; }
+        for (uint32_t w = 0; w < P.n_waves_cap; ++w) win_wave_tb_one(P, w);
+        for (uint32_t i = 0; i < P.n; ++i) win_emit_one(P, i, 0, 1);
+        return VGK_OK;
+    }
     template <int K, bool S8> void fill(const GsswParams& P) {
         std::vector<Lane<K>> lanes(64);
         std::vector<uint32_t> oh(64), of(64), oi(64);

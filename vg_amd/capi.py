@@ -30,6 +30,9 @@ PROBLEM_DT = np.dtype([("read", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), (
 RESULT_DT = np.dtype([("score", "<i4"), ("status", "<i4"), ("end_node", "<i4"), ("end_offset", "<i4"),
                       ("end_read", "<i4"), ("first_offset", "<i4"), ("n_ops", "<u4"), ("ops_begin", "<u4")])
 OP_DT = np.dtype([("node", "<u4"), ("len", "<u2"), ("op", "u1"), ("pad", "u1")])
+WINDOW_DT = np.dtype([("read_off", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), ("first_node", "<u4"), ("n_nodes", "<u4"),
+                      ("max_gap_length", "<u4"), ("reserved", "<u4")])
+assert WINDOW_DT.itemsize == 32
 BANDED_DT = np.dtype([("read", "<u8"), ("qual", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), ("graph", GRAPH_DT),
                       ("band_padding", "<i4"), ("reserved", "<u4"), ("max_cells", "<u8")])
 VGK_BANDED_PERMISSIVE = 1
@@ -103,6 +106,9 @@ def load_library(path=None):
     lib.vgk_gssw_fetch.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz)]
     lib.vgk_gssw_align.argtypes = [vp, vp, u32, vp, vp, sz, ctypes.POINTER(sz)]
     lib.vgk_batch_free.argtypes = [vp]
+    lib.vgk_graph_create.argtypes = [vp, vp, ctypes.POINTER(vp)]
+    lib.vgk_graph_destroy.argtypes = [vp]
+    lib.vgk_gssw_pack_windows.argtypes = [vp, vp, vp, sz, vp, u32, u32, ctypes.POINTER(vp)]
     lib.vgk_batch_sync.argtypes = [vp]
     lib.vgk_batch_kernel_ms.restype = ctypes.c_double
     lib.vgk_batch_kernel_ms.argtypes = [vp, ctypes.c_int]
@@ -274,6 +280,22 @@ class Engine:
         self._check(self.lib.vgk_gssw_pack(self.h, ps.ptr, ps.n, ops_per_problem, ctypes.byref(b)), "vgk_gssw_pack")
         return Batch(self, b, ps, ops_per_problem)
 
+    def graph(self, node_len, seq, pred_off, pred_idx):
+        """One DAG (nodes in topological order, predecessor CSR) resident in HBM -> ResidentGraph."""
+        return ResidentGraph(self, node_len, seq, pred_off, pred_idx)
+
+    def pack_windows(self, graph, ws, ops_per_problem=0):
+        """vgk_gssw_pack_windows: ws = WindowSet (reads + windows of `graph`); packed on the device."""
+        b = ctypes.c_void_p()
+        self._check(self.lib.vgk_gssw_pack_windows(self.h, graph.h, ws.reads.ctypes.data, ws.reads.size, ws.array.ctypes.data, ws.n,
+                                                   ops_per_problem, ctypes.byref(b)), "vgk_gssw_pack_windows")
+        return Batch(self, b, ws, ops_per_problem)
+
+    def align_windows(self, graph, ws, ops_per_problem=0):
+        with self.pack_windows(graph, ws, ops_per_problem) as b:
+            b.run()
+            return b.fetch()
+
     def align(self, ps, ops_per_problem=0):
         with self.pack(ps, ops_per_problem) as b:
             b.run()
@@ -361,6 +383,55 @@ class Engine:
 
     def wfa_last_ms(self):
         return self.lib.vgk_wfa_last_ms(self.h)
+
+
+class ResidentGraph:
+    """vgk_dgraph: one topologically ordered DAG kept in HBM; problems name windows (runs of consecutive nodes) of it."""
+
+    def __init__(self, eng, node_len, seq, pred_off, pred_idx):
+        self.eng = eng
+        self.node_len = np.ascontiguousarray(node_len, dtype=np.uint32)
+        self.seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        self.pred_off = np.ascontiguousarray(pred_off, dtype=np.uint32)
+        self.pred_idx = np.ascontiguousarray(pred_idx if len(pred_idx) else np.zeros(1, np.uint32), dtype=np.uint32)
+        self.col = np.concatenate([[0], np.cumsum(self.node_len, dtype=np.int64)])
+        g = np.zeros(1, dtype=GRAPH_DT)
+        g["n_nodes"] = len(self.node_len); g["node_len"] = self.node_len.ctypes.data; g["seq"] = self.seq.ctypes.data
+        g["pred_off"] = self.pred_off.ctypes.data; g["pred_idx"] = self.pred_idx.ctypes.data
+        h = ctypes.c_void_p()
+        eng._check(eng.lib.vgk_graph_create(eng.h, g.ctypes.data, ctypes.byref(h)), "vgk_graph_create")
+        self.h = h
+        eng._indexes.add(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.eng, "h", None):
+                self.eng.lib.vgk_graph_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class WindowSet:
+    """A batch of window problems (vgk_window_problem): reads in one flat ASCII array, read i = reads[read_off[i]:read_off[i+1]],
+    aligned against nodes [first_node[i], first_node[i] + n_nodes[i]) of a ResidentGraph."""
+
+    def __init__(self, reads, read_off, first_node, n_nodes, flags, max_gap=None, cols=None):
+        self.reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        self.read_off = np.asarray(read_off, dtype=np.int64)
+        n = self.n = len(self.read_off) - 1
+        arr = np.zeros(n, dtype=WINDOW_DT)
+        arr["read_off"] = self.read_off[:-1]; arr["read_len"] = np.diff(self.read_off)
+        arr["flags"] = flags; arr["first_node"] = first_node; arr["n_nodes"] = n_nodes
+        if max_gap is not None:
+            arr["max_gap_length"] = np.asarray(max_gap, dtype=np.uint32)
+        self.array = arr
+        self.cols = None if cols is None else np.asarray(cols, dtype=np.int64)      # graph bases per window (sizes the default op array)
+
+    @property
+    def seq_off(self):
+        c = self.cols if self.cols is not None else np.zeros(self.n, dtype=np.int64)
+        return np.concatenate([[0], np.cumsum(c)])
 
 
 class GaplessSet:
@@ -488,14 +559,20 @@ class Batch:
     def device_bytes(self):
         return self.eng.lib.vgk_batch_device_bytes(self.h)
 
-    def fetch(self):
+    def fetch(self, into=None):
+        """-> (results, ops).  `into` = (results, ops) arrays of an earlier fetch of a batch of the same shape, written again
+        (a streaming caller keeps its output buffers; fresh numpy arrays cost a page fault per 4 KB touched)."""
         n = self.ps.n
-        res = np.zeros(n, dtype=RESULT_DT)
         if self.ops_per:
             cap = n * self.ops_per
         else:
             cap = int(np.diff(self.ps.read_off).sum() + np.diff(self.ps.seq_off).sum() + 2 * n)
-        ops = np.zeros(max(cap, 1), dtype=OP_DT)
+        if into is not None:
+            res, ops = into[0], (into[1].base if into[1].base is not None else into[1])
+            assert len(res) == n and len(ops) >= max(cap, 1)
+        else:
+            res = np.zeros(n, dtype=RESULT_DT)
+            ops = np.zeros(max(cap, 1), dtype=OP_DT)
         written = ctypes.c_size_t()
         self.eng._check(self.eng.lib.vgk_gssw_fetch(self.h, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written)),
                         "vgk_gssw_fetch")

@@ -11,6 +11,7 @@
 #include "gapless_device.hpp"
 #include "wfa_device.hpp"
 #include "gssw_matrix_device.hpp"
+#include "gssw_pack_device.hpp"
 
 namespace vgk {
 
@@ -38,6 +39,15 @@ public:
     // (the next batch being packed) go through meanwhile
     virtual int   sync_polling() { return sync(); }
     virtual int   zero(void* dst, size_t bytes) = 0;                        // async on the stream
+    // device-side packing of window problems (gssw_pack_device.hpp), asynchronous on the side (copy) stream like upload_side:
+    // stage 1 = per-problem sizes + their prefix sums + totals, stage 2 = launch order, wavefronts, the arenas the kernels read.
+    // win_tmp_bytes = device scratch both stages need (`tmp`); download_side / fill_side = synchronous copy back / async byte fill
+    // on that stream.
+    virtual size_t win_tmp_bytes(uint32_t n, uint32_t n_waves_cap) { (void)n; (void)n_waves_cap; return 16; }
+    virtual int   win_stage1(const WinParams& P, void* tmp, size_t tmp_bytes) = 0;
+    virtual int   win_stage2(const WinParams& P, void* tmp, size_t tmp_bytes) = 0;
+    virtual int   download_side(void* dst, const void* src, size_t bytes) { return download(dst, src, bytes); }
+    virtual int   fill_side(void* dst, int byte, size_t bytes) = 0;
     virtual int   sync() = 0;
     // gssw kernels: one fill launch per rows-per-lane instantiation (`launches`), then one traceback
     // launch over all reads; timings (ms, HIP events on the launch stream) of the last run

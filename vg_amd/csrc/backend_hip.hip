@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <string>
 #include "backend.hpp"
+#include "pack_hip.hpp"
 
 namespace vgk {
 
@@ -287,6 +288,18 @@ public:
     int sync() override {
         hipSetDevice(dev);
         return hipStreamSynchronize(stream) == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    size_t win_tmp_bytes(uint32_t n, uint32_t n_waves_cap) override { hipSetDevice(dev); return hip_win_tmp_bytes(n, n_waves_cap); }
+    int win_stage1(const WinParams& P, void* tmp, size_t tmp_bytes) override { hipSetDevice(dev); return hip_win_stage1(P, tmp, tmp_bytes, copy); }
+    int win_stage2(const WinParams& P, void* tmp, size_t tmp_bytes) override { hipSetDevice(dev); return hip_win_stage2(P, tmp, tmp_bytes, copy); }
+    int download_side(void* dst, const void* src, size_t bytes) override {
+        hipSetDevice(dev);
+        if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, copy) != hipSuccess) return VGK_ENODEV;
+        return hipStreamSynchronize(copy) == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int fill_side(void* dst, int byte, size_t bytes) override {
+        hipSetDevice(dev);
+        return hipMemsetAsync(dst, byte, bytes, copy) == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int launch_fill(const GsswParams& p, hipStream_t stream) {
         const dim3 grid((p.wave_count + 3) / 4), block(256);

@@ -1,0 +1,65 @@
+// batch.hpp — a packed gssw batch resident in HBM, shared by the translation units that build one (vgk_api.cpp: per-problem
+// graphs packed on the host; window_api.cpp: windows of a resident graph packed on the device).
+#pragma once
+#include <vector>
+#include "backend.hpp"
+#include "ctx.hpp"
+
+using namespace vgk;
+
+struct vgk_batch {
+    vgk_ctx* ctx = nullptr;
+    uint32_t n = 0;
+    bool want_tb = false, ran = false;
+    GsswParams P{};
+    std::vector<vgk_ctx::Pooled> dev;   // every device allocation of this batch (back to the context's pool when the batch is freed)
+    uint64_t cells = 0, tb_cells = 0, in_bytes = 0, dev_bytes = 0, alg_bytes = 0;
+    uint64_t ops_total = 0;
+    ProbDesc* probs = nullptr; uint64_t probs_bytes = 0;   // kept for fetch(): a page-locked block from the context's pool, back to it with the batch
+    ~vgk_batch() { if (probs && ctx) ctx->host_give(probs, probs_bytes); }
+    std::vector<FillLaunch> launches;   // one per length bucket
+    struct Upload { void* dst; const void* src; size_t bytes; };
+    std::vector<Upload> uploads;        // queued by to_device under the context lock, issued by vgk_gssw_pack outside it
+};
+
+inline int nt_read(char ch) {   // gssw_create_nt_table: case-insensitive ACGT, else N
+    switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1;
+                  case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+inline int nt_ref(char ch) {    // after nonATGCNtoN (src/aligner.cpp:39): upper-case ACGT only
+    switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
+}
+
+template <class T>
+inline int to_device(vgk_batch* b, const std::vector<T>& v, const T*& out, size_t extra = 0) {
+    const size_t bytes = (v.size() + extra) * sizeof(T);
+    uint64_t got = 0;
+    void* p = b->ctx->dev_take(bytes, got);
+    if (!p) return VGK_ENOMEM;
+    b->dev.push_back({p, got}); b->dev_bytes += bytes;
+    if (!v.empty()) b->uploads.push_back({p, v.data(), v.size() * sizeof(T)});
+    out = (const T*)p;
+    return VGK_OK;
+}
+
+template <class T>
+inline int to_device(vgk_batch* b, const T* v, size_t count, const T*& out, size_t extra = 0) {      // from a staging arena
+    const size_t bytes = (count + extra) * sizeof(T);
+    uint64_t got = 0;
+    void* p = b->ctx->dev_take(bytes, got);
+    if (!p) return VGK_ENOMEM;
+    b->dev.push_back({p, got}); b->dev_bytes += bytes;
+    if (count) b->uploads.push_back({p, v, count * sizeof(T)});
+    out = (const T*)p;
+    return VGK_OK;
+}
+template <class T>
+inline int dev_alloc(vgk_batch* b, size_t count, T*& out) {
+    uint64_t got = 0;
+    void* p = b->ctx->dev_take(count * sizeof(T), got);
+    if (!p) return VGK_ENOMEM;
+    b->dev.push_back({p, got}); b->dev_bytes += count * sizeof(T);
+    out = (T*)p;
+    return VGK_OK;
+}
+

@@ -1,0 +1,10 @@
+// pack_hip.hpp — entry points of pack_hip.hip (device-side packing of window problems), called by backend_hip.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gssw_pack_device.hpp"
+
+namespace vgk {
+size_t hip_win_tmp_bytes(uint32_t n, uint32_t n_waves_cap);                               // scratch the sort / scans need
+int    hip_win_stage1(const WinParams& P, void* tmp, size_t tmp_bytes, hipStream_t st);   // sizes + their prefix sums
+int    hip_win_stage2(const WinParams& P, void* tmp, size_t tmp_bytes, hipStream_t st);   // order, wavefronts, arenas
+}

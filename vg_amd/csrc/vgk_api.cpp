@@ -19,63 +19,7 @@
 #include "ctx.hpp"
 #include "host_parallel.hpp"
 
-using namespace vgk;
-
-struct vgk_batch {
-    vgk_ctx* ctx = nullptr;
-    uint32_t n = 0;
-    bool want_tb = false, ran = false;
-    GsswParams P{};
-    std::vector<vgk_ctx::Pooled> dev;   // every device allocation of this batch (back to the context's pool when the batch is freed)
-    uint64_t cells = 0, tb_cells = 0, in_bytes = 0, dev_bytes = 0, alg_bytes = 0;
-    uint64_t ops_total = 0;
-    ProbDesc* probs = nullptr; uint64_t probs_bytes = 0;   // kept for fetch(): a page-locked block from the context's pool, back to it with the batch
-    ~vgk_batch() { if (probs && ctx) ctx->host_give(probs, probs_bytes); }
-    std::vector<FillLaunch> launches;   // one per length bucket
-    struct Upload { void* dst; const void* src; size_t bytes; };
-    std::vector<Upload> uploads;        // queued by to_device under the context lock, issued by vgk_gssw_pack outside it
-};
-
-static inline int nt_read(char ch) {   // gssw_create_nt_table: case-insensitive ACGT, else N
-    switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1;
-                  case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
-}
-static inline int nt_ref(char ch) {    // after nonATGCNtoN (src/aligner.cpp:39): upper-case ACGT only
-    switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
-}
-
-template <class T>
-static int to_device(vgk_batch* b, const std::vector<T>& v, const T*& out, size_t extra = 0) {
-    const size_t bytes = (v.size() + extra) * sizeof(T);
-    uint64_t got = 0;
-    void* p = b->ctx->dev_take(bytes, got);
-    if (!p) return VGK_ENOMEM;
-    b->dev.push_back({p, got}); b->dev_bytes += bytes;
-    if (!v.empty()) b->uploads.push_back({p, v.data(), v.size() * sizeof(T)});
-    out = (const T*)p;
-    return VGK_OK;
-}
-
-template <class T>
-static int to_device(vgk_batch* b, const T* v, size_t count, const T*& out, size_t extra = 0) {      // from a staging arena
-    const size_t bytes = (count + extra) * sizeof(T);
-    uint64_t got = 0;
-    void* p = b->ctx->dev_take(bytes, got);
-    if (!p) return VGK_ENOMEM;
-    b->dev.push_back({p, got}); b->dev_bytes += bytes;
-    if (count) b->uploads.push_back({p, v, count * sizeof(T)});
-    out = (const T*)p;
-    return VGK_OK;
-}
-template <class T>
-static int dev_alloc(vgk_batch* b, size_t count, T*& out) {
-    uint64_t got = 0;
-    void* p = b->ctx->dev_take(count * sizeof(T), got);
-    if (!p) return VGK_ENOMEM;
-    b->dev.push_back({p, got}); b->dev_bytes += count * sizeof(T);
-    out = (T*)p;
-    return VGK_OK;
-}
+#include "batch.hpp"
 
 extern "C" {
 
@@ -165,23 +109,8 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
 
     uint32_t forced = 0;
     if (const char* e = std::getenv("VGAMD_ROWS_PER_LANE")) forced = (uint32_t)std::atoi(e);
-    // Lane geometry for a read of `rows` DP rows: rows per lane K (16, 19, 20, 24) and lanes per pair G = ceil(rows/K),
-    // the instantiation that spends the fewest issued instructions per useful cell:
-    // (K*c_row + c_step) per step buys floor(64/G)*2*rows cells.
-    auto geometry = [&](uint32_t rows, uint32_t& K, uint32_t& G) {
-        double best_cost = 1e30; K = 16;
-        for (uint32_t k : {16u, 19u, 20u, 24u}) {
-            const uint32_t g = (rows + k - 1) / k;
-            if (g > 64) continue;
-            // 19 rows per lane fit a 150 bp read into 8 lanes with 2 padding rows instead of 10; for short reads a fourth
-            // launch bucket costs more than the rows it saves (tails workload: 48.9 vs 52.3 M alignments/s)
-            if (k == 19 && rows < 128 && forced != k) continue;
-            const double cost = (k * 25.0 + 60.0) / ((64 / g) * 2.0 * rows);
-            if (forced == k) { K = k; break; }
-            if (!forced && cost < best_cost) { best_cost = cost; K = k; }
-        }
-        G = (rows + K - 1) / K;
-    };
+    // lane geometry (rows per lane K, lanes per pair G) of a read: gssw_pack_device.hpp, shared with the device-side packer
+    auto geometry = [&](uint32_t rows, uint32_t& K, uint32_t& G) { lane_geometry(rows, forced, K, G); };
 
     // Three passes over the problems, the first and the last on host threads: (1) validate and size every problem, (2) prefix sums
     // place it in the shared arenas, (3) encode it at its offsets.
@@ -205,7 +134,8 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         f.store.assign(g.n_nodes, 0); f.slow.assign(g.n_nodes, 0);
         for (uint32_t v = 0; v < g.n_nodes; ++v) {
             const uint32_t pb = g.pred_off[v], pe = g.pred_off[v + 1];
-            if (pe < pb || g.node_len[v] == 0) return VGK_EINVAL;
+            if (pe < pb || g.node_len[v] == 0 || (pe > pb && !g.pred_idx)) return VGK_EINVAL;
+            if (g.node_len[v] > 65535u) return VGK_ETOOBIG;      // vgk_op.len is 16 bits: a run inside one node must fit (vg chops nodes to <= 1024 bp)
             for (uint32_t k = pb; k < pe; ++k) if (g.pred_idx[k] >= v) return VGK_EINVAL;   // not topological
             const bool chain = (pe - pb == 1) && g.pred_idx[pb] + 1 == v;
             f.slow[v] = ((v > 0 || xdrop) && !chain) ? 1 : 0;      // X-drop: node 0 starts from the root column
@@ -599,9 +529,16 @@ int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_ca
     // ... and are packed behind each other in the caller's order: sizes, a prefix sum, then parallel copies
     size_t w = 0; uint64_t alg = 0;
     std::vector<uint32_t> src(b->n);
+    std::vector<ProbDesc> fetched;          // batches packed on the device keep no host copy of the descriptors
+    const ProbDesc* descs = b->probs;
+    if (!descs && b->n) {
+        fetched.resize(b->n);
+        if ((rc = b->ctx->be->download(fetched.data(), b->P.probs, (size_t)b->n * sizeof(ProbDesc)))) return rc;
+        descs = fetched.data();
+    }
     for (uint32_t i = 0; i < b->n; ++i) {
         vgk_result& r = results[i];
-        const ProbDesc& d = b->probs[i];
+        const ProbDesc& d = descs[i];
         src[i] = r.ops_begin;
         if (r.status == VGK_OK && r.n_ops) {
             if (!ops || w + r.n_ops > ops_cap) { r.status = VGK_EOPS; r.n_ops = 0; r.ops_begin = (uint32_t)w; continue; }
@@ -702,6 +639,7 @@ uint64_t vgk_batch_alg_bytes(vgk_batch* b) {
     if (!b) return 0;
     if (b->alg_bytes) return b->alg_bytes;
     uint64_t alg = b->in_bytes;      // before fetch: everything except the 2 B / emitted op term
+    if (!b->probs) return alg + 16ull * b->n + b->tb_cells;
     for (uint32_t i = 0; i < b->n; ++i) { const ProbDesc& d = b->probs[i]; alg += 16 + ((d.flags & VGK_GSSW_TRACEBACK) ? (uint64_t)d.L * d.R : 0); }
     return alg;
 }

@@ -1,0 +1,253 @@
+// window_api.cpp — vgk_graph_create / vgk_gssw_pack_windows: one graph resident in HBM, problems as windows of it, packed
+// on the device (gssw_pack_device.hpp).
+//
+// This is the part of vg's per-read work that sits between "the seeds say the read belongs near here" and "fill the DP":
+// Mapper::align_cluster / align_maybe_flip cut a subgraph around the cluster (src/mapper.cpp:2445-2518) and
+// GSSWAligner::create_gssw_graph converts it (src/aligner.cpp:30-85).  With the graph resident the host's share per read is
+// 32 + read_len bytes of memcpy into page-locked staging; everything else is derived by kernels from the resident tables.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <vector>
+#include "batch.hpp"
+#include "host_parallel.hpp"
+
+struct vgk_dgraph {
+    vgk_ctx* ctx = nullptr;
+    WinGraph g{};
+    std::vector<void*> dev;          // device allocations (released with the graph)
+    uint64_t dev_bytes = 0;
+};
+
+namespace {
+
+inline int ref_code(char ch) {      // after nonATGCNtoN (src/aligner.cpp:39): upper-case ACGT only
+    switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
+}
+
+struct Lap {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); const bool on = std::getenv("VGAMD_TIMING") != nullptr;
+    void operator()(const char* what) {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pack_windows] %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int vgk_graph_create(vgk_ctx* ctx, const vgk_graph* graph, vgk_dgraph** out) {
+    if (!ctx || !graph || !out) return VGK_EINVAL;
+    *out = nullptr;
+    const vgk_graph& g = *graph;
+    if (g.n_nodes == 0 || !g.node_len || !g.seq || !g.pred_off) return VGK_EINVAL;
+    const uint32_t n = g.n_nodes;
+    if (g.pred_off[n] > g.pred_off[0] && !g.pred_idx) return VGK_EINVAL;
+    // columns, flags and slots of the WHOLE graph, as vgk_gssw_pack computes them per problem (node_flags in vgk_api.cpp):
+    // slow[v] = the node's first column is seeded from its predecessors' saved last columns (anything but the plain chain link
+    // to v - 1); store[v] = some successor seeds from v's last column
+    std::vector<uint32_t> col((size_t)n + 1), slot((size_t)n + 1);
+    std::vector<uint8_t> slow(n, 0), store(n, 0);
+    uint64_t cols = 0;
+    for (uint32_t v = 0; v < n; ++v) {
+        const uint32_t pb = g.pred_off[v], pe = g.pred_off[v + 1];
+        if (pe < pb || g.node_len[v] == 0) return VGK_EINVAL;
+        if (g.node_len[v] > 65535u) return VGK_ETOOBIG;
+        for (uint32_t k = pb; k < pe; ++k) if (g.pred_idx[k] >= v) return VGK_EINVAL;       // not topological
+        const bool chain = (pe - pb == 1) && g.pred_idx[pb] + 1 == v;
+        slow[v] = (v > 0 && !chain) ? 1 : 0;
+        if (slow[v]) for (uint32_t k = pb; k < pe; ++k) store[g.pred_idx[k]] = 1;
+        col[v] = (uint32_t)cols; cols += g.node_len[v];
+        if (cols >= (1ull << 32) - 16) return VGK_ETOOBIG;
+    }
+    col[n] = (uint32_t)cols;
+    uint32_t s = 0;
+    for (uint32_t v = 0; v < n; ++v) { slot[v] = s; s += store[v]; }
+    slot[n] = s;
+    std::vector<uint8_t> info((size_t)cols + 8, (uint8_t)CI_INVALID);
+    parallel_for(n, [&](uint32_t v, unsigned) {
+        const uint32_t len = g.node_len[v]; const char* sq = g.seq + col[v]; uint8_t* o = info.data() + col[v];
+        for (uint32_t k = 0; k < len; ++k) o[k] = (uint8_t)ref_code(sq[k]);
+        o[0] |= CI_NODE_START | (slow[v] ? CI_SEED_SLOW : 0);
+        if (store[v]) o[len - 1] |= CI_STORE_END;
+    });
+    std::unique_ptr<vgk_dgraph> dg(new (std::nothrow) vgk_dgraph());
+    if (!dg) return VGK_ENOMEM;
+    dg->ctx = ctx;
+    Backend* be = ctx->be.get();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto put = [&](const void* src, size_t bytes, const void*& dst) -> int {
+        void* p = be->alloc(bytes ? bytes : 16);
+        if (!p) return VGK_ENOMEM;
+        dg->dev.push_back(p); dg->dev_bytes += bytes;
+        dst = p;
+        return bytes ? be->upload(p, src, bytes) : VGK_OK;
+    };
+    const void *d_col = nullptr, *d_info = nullptr, *d_po = nullptr, *d_pi = nullptr, *d_slot = nullptr;
+    const size_t n_edges = g.pred_off[n] - g.pred_off[0];
+    std::vector<uint32_t> po((size_t)n + 1);
+    for (uint32_t v = 0; v <= n; ++v) po[v] = g.pred_off[v] - g.pred_off[0];
+    int rc = put(col.data(), col.size() * 4, d_col);
+    if (!rc) rc = put(info.data(), info.size(), d_info);
+    if (!rc) rc = put(po.data(), po.size() * 4, d_po);
+    if (!rc) rc = put(n_edges ? g.pred_idx + g.pred_off[0] : nullptr, n_edges * 4, d_pi);
+    if (!rc) rc = put(slot.data(), slot.size() * 4, d_slot);
+    if (!rc) rc = be->sync();         // the host vectors go away
+    if (rc) { for (void* p : dg->dev) be->release(p); return rc; }
+    dg->g.col = (const uint32_t*)d_col; dg->g.info = (const uint8_t*)d_info; dg->g.pred_off = (const uint32_t*)d_po;
+    dg->g.pred_idx = (const uint32_t*)d_pi; dg->g.slot = (const uint32_t*)d_slot; dg->g.n_nodes = n; dg->g.n_cols = (uint32_t)cols;
+    *out = dg.release();
+    return VGK_OK;
+}
+
+void vgk_graph_destroy(vgk_dgraph* dg) {
+    if (!dg) return;
+    {
+        std::lock_guard<std::mutex> lk(dg->ctx->mu);
+        dg->ctx->be->sync(); dg->ctx->be->sync_side();
+        for (void* p : dg->dev) dg->ctx->be->release(p);
+    }
+    delete dg;
+}
+
+int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
+                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out) {
+    if (!ctx || !dg || dg->ctx != ctx || !out || (!problems && n) || (!reads && reads_bytes)) return VGK_EINVAL;
+    *out = nullptr;
+    if (ctx->has_qa) return VGK_EUNSUPPORTED;
+    Lap lap;
+    std::unique_ptr<vgk_batch> hb(new (std::nothrow) vgk_batch());
+    if (!hb) return VGK_ENOMEM;
+    vgk_batch* b = hb.get();
+    b->ctx = ctx; b->n = n;
+    Backend* be = ctx->be.get();
+    GsswParams& P = b->P;
+    P = GsswParams{};
+    struct StagingLease {
+        vgk_ctx* ctx; std::unique_ptr<vgk_ctx::Staging> s;
+        ~StagingLease() { if (s) ctx->staging_release(std::move(s)); }
+    } lease{ctx, ctx->staging_acquire()};
+    // device memory that only the packing itself needs goes back to the pool when this function returns
+    std::vector<vgk_ctx::Pooled> temp;
+    struct TempGuard {
+        vgk_ctx* ctx; std::vector<vgk_ctx::Pooled>& v;
+        ~TempGuard() { if (v.empty()) return; ctx->be->sync_side(); std::lock_guard<std::mutex> lk(ctx->mu); for (auto& q : v) ctx->dev_give(q.p, q.bytes); }
+    } temp_guard{ctx, temp};
+    auto fail = [&](int code) { vgk_batch* t = hb.release(); ctx->be->sync_side(); vgk_batch_free(t); return code; };
+    auto take_temp = [&](uint64_t bytes) -> void* { uint64_t got = 0; void* p = ctx->dev_take(bytes ? bytes : 16, got); if (p) temp.push_back({p, got}); return p; };
+    auto take_keep = [&](uint64_t bytes) -> void* { uint64_t got = 0; void* p = ctx->dev_take(bytes ? bytes : 16, got); if (p) { b->dev.push_back({p, got}); b->dev_bytes += bytes; } return p; };
+
+    const uint32_t n1 = n + 1;
+    const uint32_t waves_cap = n / 2 + WIN_BUCKETS + 1;
+    WinParams W{};
+    W.g = dg->g; W.n = n; W.raw_bytes = reads_bytes; W.ops_per_problem = ops_per_problem;
+    W.forced_k = 0;
+    if (const char* e = std::getenv("VGAMD_ROWS_PER_LANE")) W.forced_k = (uint32_t)std::atoi(e);
+    W.max_score = ctx->max_score; W.max_bonus = ctx->max_bonus; W.scale = ctx->scale; W.bonus = ctx->sc.full_length_bonus;
+    W.n_waves_cap = waves_cap;
+    void* tmp = nullptr; size_t tmp_bytes = be->win_tmp_bytes(n, waves_cap);
+    int rc;
+    rc = VGK_OK;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        W.problems = (const vgk_window_problem*)take_temp((uint64_t)n * sizeof(vgk_window_problem));
+        W.raw_reads = (const uint8_t*)take_temp(reads_bytes + 8);
+        W.sizes = (uint32_t*)take_temp((uint64_t)WIN_COLS * n1 * 4); W.offs = (uint32_t*)take_temp((uint64_t)WIN_COLS * n1 * 4);
+        W.key = (uint32_t*)take_temp((uint64_t)n * 4); W.idx = (uint32_t*)take_temp((uint64_t)n * 4);
+        W.key_sorted = (uint32_t*)take_temp((uint64_t)n * 4); W.idx_sorted = (uint32_t*)take_temp((uint64_t)n * 4);
+        W.totals = (WinTotals*)take_temp(sizeof(WinTotals));
+        W.bucket_first = (uint32_t*)take_temp(sizeof(uint32_t) * WIN_BUCKETS); W.buckets = (WinBucket*)take_temp(sizeof(WinBucket) * WIN_BUCKETS);
+        W.wave_tb = (unsigned long long*)take_temp(((uint64_t)waves_cap + 1) * 8);
+        tmp = take_temp(tmp_bytes);
+        W.probs = (ProbDesc*)take_keep((uint64_t)std::max<uint32_t>(n, 1u) * sizeof(ProbDesc));
+        if (!W.problems || !W.raw_reads || !W.sizes || !W.offs || !W.key || !W.idx || !W.key_sorted || !W.idx_sorted || !W.totals ||
+            !W.bucket_first || !W.buckets || !W.wave_tb || !tmp || !W.probs) rc = VGK_ENOMEM;
+    }
+    if (rc) return fail(rc);          // (outside the block: fail() takes the context lock itself)
+    lap("device buffers");
+    // the two flat inputs: host threads copy them into page-locked staging, slice by slice, and each slice starts its way to HBM
+    // as soon as it is there (the caller's buffers are pageable: a direct copy would be staged by the runtime on one thread)
+    {
+        WinTotals zero{}; zero.first_bad = ~0ull;
+        WinTotals* tz = (WinTotals*)lease.s->get(2, sizeof(WinTotals));
+        if (!tz) return fail(VGK_ENOMEM);
+        *tz = zero;
+        if ((rc = be->upload_side(W.totals, tz, sizeof(WinTotals)))) return fail(rc);
+    }
+    auto staged_upload = [&](int slot, void* dst, const void* src, uint64_t bytes) -> int {
+        if (!bytes) return VGK_OK;
+        uint8_t* st = (uint8_t*)lease.s->get(slot, bytes);
+        if (!st) return VGK_ENOMEM;
+        const uint64_t SLICE = 16ull << 20, PIECE = 256ull << 10;
+        for (uint64_t at = 0; at < bytes; at += SLICE) {
+            const uint64_t len = std::min(SLICE, bytes - at);
+            parallel_for((uint32_t)((len + PIECE - 1) / PIECE), [&](uint32_t c, unsigned) {
+                const uint64_t o = at + (uint64_t)c * PIECE;
+                std::memcpy(st + o, (const uint8_t*)src + o, (size_t)std::min(PIECE, at + len - o));
+            });
+            const int e = be->upload_side((uint8_t*)dst + at, st + at, len);
+            if (e) return e;
+        }
+        return VGK_OK;
+    };
+    if ((rc = staged_upload(1, (void*)W.problems, problems, (uint64_t)n * sizeof(vgk_window_problem)))) return fail(rc);
+    lap("problems staged");
+    if ((rc = be->win_stage1(W, tmp, tmp_bytes))) return fail(rc);         // needs the problems only: runs while the reads travel
+    if ((rc = staged_upload(0, (void*)W.raw_reads, reads, reads_bytes))) return fail(rc);
+    lap("reads staged");
+    WinTotals T;
+    if ((rc = be->download_side(&T, W.totals, sizeof T))) return fail(rc);
+    lap("stage 1 (sizes)");
+    if (T.first_bad != ~0ull) return fail(-(int)(T.first_bad & 0xffu));
+    for (uint32_t k = 0; k < WIN_COLS; ++k) if (T.tot[k] >= (1ull << 32)) return fail(VGK_ETOOBIG);
+    b->want_tb = T.want_tb != 0; b->cells = T.cells; b->tb_cells = T.tb_cells; b->in_bytes = T.in_bytes;
+    W.want_tb = b->want_tb ? 1 : 0;
+    uint8_t* colinfo; uint8_t* rd; NodeRec* nodes; uint32_t* preds; WaveDesc* waves; uint32_t* order;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        colinfo = (uint8_t*)take_keep(T.tot[WS_COLS] + 8); rd = (uint8_t*)take_keep(T.tot[WS_READS] + 8);
+        nodes = (NodeRec*)take_keep((T.tot[WS_NODES] + 1) * sizeof(NodeRec)); preds = (uint32_t*)take_keep((T.tot[WS_PREDS] + 1) * 4);
+        waves = (WaveDesc*)take_keep((uint64_t)waves_cap * sizeof(WaveDesc)); order = (uint32_t*)take_keep(((uint64_t)waves_cap * 2 + 2) * 4);
+        rc = dev_alloc(b, (size_t)T.tot[WS_SCRATCH] + 16, P.scratch);
+        if (!rc) rc = dev_alloc(b, (size_t)n + 1, P.best);
+        if (!rc) rc = dev_alloc(b, (size_t)n + 1, P.results);
+        if (!rc) rc = dev_alloc(b, (size_t)T.tot[WS_OPS] + 1, P.ops);
+        if (!rc && (!colinfo || !rd || !nodes || !preds || !waves || !order)) rc = VGK_ENOMEM;
+    }
+    if (rc) return fail(rc);
+    W.colinfo = colinfo; W.reads = rd; W.nodes = nodes; W.preds = preds; W.waves = waves; W.order = order;
+    if ((rc = be->fill_side(colinfo + T.tot[WS_COLS], (int)CI_INVALID, 8))) return fail(rc);      // leaders prefetch one word ahead
+    if ((rc = be->win_stage2(W, tmp, tmp_bytes))) return fail(rc);
+    if ((rc = be->download_side(&T, W.totals, sizeof T))) return fail(rc);
+    lap("stage 2 (order, waves, arenas)");
+    if (T.n_waves > waves_cap || T.n_launches > 4) return fail(VGK_EINVAL);
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        rc = dev_alloc(b, (size_t)T.tb_dwords + 4, P.tb);
+    }
+    if (rc) return fail(rc);
+    for (uint32_t k = 0; k < T.n_launches; ++k) b->launches.push_back(FillLaunch{T.launch_K[k], T.launch_begin[k], T.launch_count[k]});
+    P.probs = W.probs; P.colinfo = colinfo; P.reads = rd; P.prof = nullptr; P.nodes = nodes; P.preds = preds; P.waves = waves; P.order = order;
+    P.wave_begin = 0; P.wave_count = 0; P.K = 0;
+    P.n_problems = n; P.n_pairs = T.n_pairs; P.n_waves = T.n_waves;
+    const uint32_t S = ctx->scale;
+    for (int q = 0; q < 6; ++q) P.prof4[q] = ctx->prof4[q] * S;
+    P.bias = ctx->bias * S; P.go = ctx->sc.gap_open * S; P.ge = ctx->sc.gap_extend * S; P.bonus = ctx->sc.full_length_bonus * (int32_t)S;
+    P.scale = S; P.xoff = XOFF * S;
+    P.want_tb = b->want_tb ? 1 : 0;
+    P.fused = 0;
+    std::memcpy(P.matrix, ctx->sc.matrix, 25);
+    b->ops_total = T.tot[WS_OPS];
+    lap("done");
+    *out = hb.release();
+    return VGK_OK;
+}
+
+}  // extern "C"

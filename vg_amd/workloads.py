@@ -91,10 +91,22 @@ class LinearWorkload:
         arr["graph"] = g
         self.array = arr
         self.R = n_nodes * NODE
+        self.flags = flags
 
     @property
     def ptr(self):
         return self.array.ctypes.data
+
+    def graph_arrays(self):
+        """The whole reference as ONE graph (node_len, seq, pred_off, pred_idx) for vgk_graph_create: a chain of 32 bp nodes."""
+        n = len(self.ref) // NODE
+        pred_off = np.concatenate([[0], np.arange(0, n)]).astype(np.uint32)
+        return np.full(n, NODE, dtype=np.uint32), self.ref[:n * NODE], pred_off, np.arange(max(n - 1, 1), dtype=np.uint32)
+
+    def windows(self):
+        """The same problems as windows of that graph (vgk_gssw_pack_windows): {read, first node, node count}."""
+        return capi.WindowSet(self.reads[:self.n * self.read_len], np.arange(self.n + 1, dtype=np.int64) * self.read_len,
+                              self.first_node, self.n_nodes, self.flags, cols=self.R)
 
     # duck-typing the bits of capi.ProblemSet that Engine/Batch use
     @property
