@@ -424,6 +424,9 @@ int vgo_banded_align_multi(const vgk_scoring* sc, const vgk_qual_adj* qa, const 
     if (qa && !p->qual) { res->status = VGK_EINVAL; return VGK_EINVAL; }
     for (int v = 0; v < N; ++v) for (uint32_t e = g->pred_off[v]; e < g->pred_off[v + 1]; ++e)
         if (g->pred_idx[e] >= (uint32_t)v) { res->status = VGK_EINVAL; return VGK_EINVAL; }      /* not in topological order */
+    /* vgk_op.len is 16 bits (include/vgk.h): the ABI cannot express a longer run, so both sides refuse such problems */
+    for (int v = 0; v < N; ++v) if (g->node_len[v] > 65535u) { res->status = VGK_ETOOBIG; return VGK_ETOOBIG; }
+    if (L > 65535) { res->status = VGK_ETOOBIG; return VGK_ETOOBIG; }
     B b; memset(&b, 0, sizeof b);
     b.p = p; b.mat = sc->matrix; b.qmat = qa ? qa->matrix : NULL; b.go = sc->gap_open; b.ge = sc->gap_extend; b.L = L;
     b.nd = (BNode*)calloc((size_t)N, sizeof(BNode));

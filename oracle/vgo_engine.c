@@ -122,6 +122,17 @@ int vgk_gssw_run(vgk_batch* b) {
     b->ran = 1; return VGK_OK;
 }
 
+/* bench.py's cpu_baseline leg: the same batch through the SIMD restatement (vgo_gssw_fast.c).  Not part of the C ABI. */
+int vgo_gssw_fast_batch(const vgk_scoring* sc, const vgk_gssw_problem* probs, uint32_t n, vgk_result* results, vgk_op* ops, uint32_t ops_per_problem);
+int vgo_gssw_run_fast(vgk_batch* b) {
+    if (!b) return VGK_EINVAL;
+    if (b->ctx->has_qa) return VGK_EUNSUPPORTED;
+    int rc = vgo_gssw_fast_batch(&b->ctx->sc, b->probs, b->n, b->res, b->ops, b->ops_per);
+    if (rc == VGK_EUNSUPPORTED) return rc;
+    for (uint32_t i = 0; i < b->n; ++i) b->res[i].ops_begin = 0;
+    b->ran = 1; return VGK_OK;
+}
+
 int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
     if (!b || !results) return VGK_EINVAL;
     if (!b->ran) { int rc = vgk_gssw_run(b); if (rc) return rc; }
@@ -384,3 +395,4 @@ double vgk_batch_kernel_ms(vgk_batch* b, int which) { (void)b; (void)which; retu
 uint64_t vgk_batch_cells(vgk_batch* b) { return b ? b->cells : 0; }
 uint64_t vgk_batch_alg_bytes(vgk_batch* b) { (void)b; return 0; }
 uint64_t vgk_batch_device_bytes(vgk_batch* b) { (void)b; return 0; }
+uint64_t vgk_batch_wave_steps(vgk_batch* b) { (void)b; return 0; }

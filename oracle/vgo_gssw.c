@@ -100,6 +100,7 @@ int vgo_gssw_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gs
     col0[0] = 0;
     for (int n = 0; n < nV; ++n) {
         if (g->node_len[n] == 0) { free(col0); res->status = VGK_EINVAL; return VGK_EINVAL; }
+        if (g->node_len[n] > 65535u) { free(col0); res->status = VGK_ETOOBIG; return VGK_ETOOBIG; }   /* vgk_op.len is 16 bits: a run inside one node must fit */
         col0[n + 1] = col0[n] + (int)g->node_len[n];
         for (uint32_t k = g->pred_off[n]; k < g->pred_off[n + 1]; ++k)
             if ((int)g->pred_idx[k] >= n) { free(col0); res->status = VGK_EINVAL; return VGK_EINVAL; }

@@ -60,8 +60,16 @@ def batch_vs_direct(engine_lib):
         for g in graphs:
             h.vgh_graph_destroy(g)
     assert len(out) == len(keep)
+    checked = 0
     for k, got in zip(keep, out):
         assert got == direct[k], (jobs[k][0]["source"], jobs[k][1])
+        # ... and what came back through the batch satisfies the reference's own REQUIREs for the case (not merely "equals the
+        # direct call"): expectations that refer to a sibling alignment's score are resolved against the direct runs of the group
+        c = jobs[k][0]
+        siblings = {jobs[j][0]["aln"]: direct[j]["score"] for j in keep if jobs[j][0]["source"] == c["source"]}
+        util.check_expectations(c, got, siblings)
+        checked += len(c["expect"])
+    assert checked > 300
     return len(keep)
 
 

@@ -241,3 +241,22 @@ def test_large_batch_goes_through_the_threaded_packing_paths(emu_lib):
     for f in ("score", "status", "end_node", "end_offset", "end_read", "first_offset", "n_ops", "ops_begin"):
         assert (ra[f] == rb[f]).all(), f
     assert len(oa) == len(ob) and (oa.view(np.uint64) == ob.view(np.uint64)).all()
+
+
+def test_runs_longer_than_a_16_bit_op_length_are_refused_not_wrapped(emu_lib):
+    """vgk_op.len is uint16: a 70000 bp node with an identical read used to come back as one op of length 70000 mod 65536
+    (ADVICE r1).  Engine and oracle now answer VGK_ETOOBIG; a caller keeps its CPU path for such problems (vg chops nodes to
+    <= 1024 bp, so none arise from vg graphs)."""
+    big = "ACGT" * 17500
+    banded = [dict(read=big, nodes=[big], preds=[[]], band_padding=1), dict(read="ACGT", nodes=["ACGT"], preds=[[]], band_padding=1)]
+    for lib in (emu_lib, ORACLE_LIB):
+        res, _ = capi.Engine(lib=lib).banded_align(capi.BandedSet.from_lists(banded))
+        assert list(res["status"]) == [-7, 0], lib
+    bs = capi.BandedSet.from_lists([dict(read=big, nodes=["AC", "GT"], preds=[[], [0]], band_padding=1)])      # the read alone is too long
+    for lib in (emu_lib, ORACLE_LIB):
+        assert capi.Engine(lib=lib).banded_align(bs)[0]["status"][0] == -7
+    gssw = {"read": "ACGTACGT", "nodes": [big], "preds": [[]], "flags": 16, "pinning": None}
+    with pytest.raises(capi.VgkError, match="too big"):
+        capi.Engine(lib=emu_lib).align(problem_set([gssw]))
+    res, _ = capi.Engine(lib=ORACLE_LIB).align(problem_set([gssw]))
+    assert res["status"][0] == -7

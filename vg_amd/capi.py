@@ -128,7 +128,7 @@ def load_library(path=None):
     lib.vgk_wfa_last_ms.argtypes = [vp]
     lib.vgk_banded_last.restype = ctypes.c_double
     lib.vgk_banded_last.argtypes = [vp, ctypes.c_int]
-    for f in ("vgk_batch_cells", "vgk_batch_alg_bytes", "vgk_batch_device_bytes"):
+    for f in ("vgk_batch_cells", "vgk_batch_alg_bytes", "vgk_batch_device_bytes", "vgk_batch_wave_steps"):
         getattr(lib, f).restype = ctypes.c_uint64
         getattr(lib, f).argtypes = [vp]
     return lib
@@ -558,6 +558,9 @@ class Batch:
 
     def device_bytes(self):
         return self.eng.lib.vgk_batch_device_bytes(self.h)
+
+    def wave_steps(self):
+        return self.eng.lib.vgk_batch_wave_steps(self.h)
 
     def fetch(self, into=None):
         """-> (results, ops).  `into` = (results, ops) arrays of an earlier fetch of a batch of the same shape, written again

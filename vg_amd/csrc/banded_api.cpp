@@ -68,7 +68,15 @@ void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch&
     const vgk_graph& g = p.graph;
     const uint32_t N = g.n_nodes; const int64_t L = p.read_len;
     if (!N || !L || !p.read || !g.node_len || !g.pred_off || !g.seq || (ctx->has_qa && !p.qual)) { hp.status = VGK_EINVAL; return; }
-    for (uint32_t v = 0; v < N; ++v) for (uint32_t e = g.pred_off[v]; e < g.pred_off[v + 1]; ++e) if (g.pred_idx[e] >= v) { hp.status = VGK_EINVAL; return; }
+    if (g.pred_off[N] > g.pred_off[0] && !g.pred_idx) { hp.status = VGK_EINVAL; return; }
+    for (uint32_t v = 0; v < N; ++v) {
+        if (g.pred_off[v + 1] < g.pred_off[v]) { hp.status = VGK_EINVAL; return; }                 // offsets must not decrease (they size the successor lists)
+        for (uint32_t e = g.pred_off[v]; e < g.pred_off[v + 1]; ++e) if (g.pred_idx[e] >= v) { hp.status = VGK_EINVAL; return; }
+        // vgk_op.len is 16 bits: one run (a match inside a node, the insertion of a whole read on an empty walk) must fit.  vg chops
+        // nodes to <= 1024 bp and calls this aligner on stretches between anchors; the caller keeps its CPU path beyond.
+        if (g.node_len[v] > 65535u) { hp.status = VGK_ETOOBIG; return; }
+    }
+    if (L > 65535) { hp.status = VGK_ETOOBIG; return; }
     const int64_t inf = std::numeric_limits<int64_t>::max();
     S.succ_off.assign(N + 1, 0);
     for (uint32_t v = 0; v < N; ++v) for (uint32_t e = g.pred_off[v]; e < g.pred_off[v + 1]; ++e) ++S.succ_off[g.pred_idx[e] + 1];

@@ -15,6 +15,7 @@ struct vgk_batch {
     std::vector<vgk_ctx::Pooled> dev;   // every device allocation of this batch (back to the context's pool when the batch is freed)
     uint64_t cells = 0, tb_cells = 0, in_bytes = 0, dev_bytes = 0, alg_bytes = 0;
     uint64_t ops_total = 0;
+    uint64_t wave_steps = 0;            // sum over wavefronts of their fill steps
     ProbDesc* probs = nullptr; uint64_t probs_bytes = 0;   // kept for fetch(): a page-locked block from the context's pool, back to it with the batch
     ~vgk_batch() { if (probs && ctx) ctx->host_give(probs, probs_bytes); }
     std::vector<FillLaunch> launches;   // one per length bucket

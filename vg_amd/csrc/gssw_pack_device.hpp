@@ -60,6 +60,7 @@ struct WinTotals {               // one per pack, device memory, zeroed before t
     unsigned long long cells, tb_cells, in_bytes;
     unsigned long long first_bad;          // min over failing problems of (index << 8 | -status), ~0 = none
     unsigned long long tb_dwords;
+    unsigned long long wave_steps;         // sum over wavefronts of their steps (one step = one column for every lane)
     uint32_t max_rows, want_tb;
     uint32_t n_pairs, n_waves, n_buckets, n_launches;
     uint32_t launch_K[4], launch_begin[4], launch_count[4];
@@ -154,7 +155,7 @@ VGK_HD void win_size_one(const WinParams& P, uint32_t i, WinAcc& acc) {
         d.bonus_end = (uint32_t)P.bonus * P.scale;      // (pinned windows are not offered: the end bonus always applies)
         const bool tb = (p.flags & VGK_GSSW_TRACEBACK) != 0;
         d.ops_cap = tb ? (P.ops_per_problem ? P.ops_per_problem : p.read_len + R + 2u) : 0u;
-        const uint32_t s[WIN_COLS] = {(R + 3u) & ~3u, p.n_nodes, n_preds, rows, slots * d.Lpad, d.ops_cap};
+        const uint32_t s[WIN_COLS] = {(R + 3u) & ~3u, p.n_nodes, n_preds, (rows + 3u) & ~3u, slots * d.Lpad, d.ops_cap};
         for (uint32_t k = 0; k < WIN_COLS; ++k) { P.sizes[k * n1 + i] = s[k]; acc.tot[k] += s[k]; }
         acc.cells += (unsigned long long)R * rows;
         if (tb) { acc.tb_cells += (unsigned long long)R * rows; acc.want_tb = 1; }
@@ -213,6 +214,7 @@ VGK_HD void win_wave_one(const WinParams& P, uint32_t w) {
             d.wave = w; d.lane0 = q * bk.G; d.geom = bk.K | (bk.G << 8) | (h << 16);
         }
     wd.n_steps = rmax ? rmax + bk.G - 1 : 0;
+    if (wd.n_steps) acc_add(&P.totals->wave_steps, wd.n_steps);
     P.waves[w] = wd;
     P.wave_tb[w] = P.want_tb ? (unsigned long long)((wd.n_steps + TB_TILE - 1) / TB_TILE * TB_TILE) * 64ull * ((bk.K + 3) / 4) : 0ull;
 }
@@ -246,20 +248,34 @@ VGK_HD void win_emit_one(const WinParams& P, uint32_t i, uint32_t lane, uint32_t
         nr.pinning = 0;
         P.nodes[node_off + k] = nr;
     }
-    // column info: the resident bytes; the window's first column starts a source node (gssw: fresh registers; dozeu: the root column)
+    // column info: the resident bytes, four columns per lane and store (the arena is padded: reading a few bytes past the window
+    // is safe); the window's first column starts a source node (gssw: fresh registers; dozeu: the root column)
     const uint32_t R = d.R, R4 = (R + 3u) & ~3u;
-    for (uint32_t c = lane; c < R4; c += lanes) {
-        uint32_t ci = (uint32_t)CI_INVALID;
-        if (c < R) {
-            ci = P.g.info[col0 + c];
-            if (c == 0) ci = (ci & ~(uint32_t)CI_SEED_SLOW) | CI_NODE_START | (xdrop ? (uint32_t)CI_SEED_SLOW : 0u);
+    for (uint32_t c = 4u * lane; c < R4; c += 4u * lanes) {
+        uint32_t w = 0;
+        for (uint32_t j = 0; j < 4; ++j) {
+            uint32_t ci = (uint32_t)CI_INVALID;
+            if (c + j < R) {
+                ci = P.g.info[col0 + c + j];
+                if (c + j == 0) ci = (ci & ~(uint32_t)CI_SEED_SLOW) | CI_NODE_START | (xdrop ? (uint32_t)CI_SEED_SLOW : 0u);
+            }
+            w |= ci << (8 * j);
         }
-        P.colinfo[col_off + c] = (uint8_t)ci;
+        *(uint32_t*)(P.colinfo + col_off + c) = w;         // col_off is a multiple of 4
     }
-    // read codes; X-drop problems get row 0 = "no read base consumed yet"
-    const uint32_t lead = xdrop ? 1u : 0u;
-    if (xdrop && lane == 0) P.reads[read_off] = 5;
-    for (uint32_t r = lane; r < p.read_len; r += lanes) P.reads[read_off + lead + r] = (uint8_t)win_nt_read(P.raw_reads[p.read_off + r]);
+    // read codes, four per lane and store; X-drop problems get row 0 = "no read base consumed yet"
+    const uint32_t lead = xdrop ? 1u : 0u, rows4 = (d.L + 3u) & ~3u;
+    for (uint32_t r = 4u * lane; r < rows4; r += 4u * lanes) {
+        uint32_t w = 0;
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t row = r + j;
+            uint32_t code = 0;
+            if (row < lead) code = 5;
+            else if (row < d.L) code = win_nt_read(P.raw_reads[p.read_off + row - lead]);
+            w |= code << (8 * j);
+        }
+        *(uint32_t*)(P.reads + read_off + r) = w;          // read_off is a multiple of 4 (sizes are padded)
+    }
     if (lane == 0) {
         d.col_off = col_off; d.node_off = node_off; d.read_off = read_off;
         d.scratch_off = P.offs[WS_SCRATCH * n1 + i]; d.ops_off = P.offs[WS_OPS * n1 + i];

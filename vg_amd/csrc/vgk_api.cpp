@@ -409,7 +409,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         waves[w] = wd;
     });
     uint64_t tb_dwords = 0;
-    for (WaveDesc& wd : waves) { const uint64_t size = wd.tb_off; wd.tb_off = tb_dwords; tb_dwords += size; }
+    for (WaveDesc& wd : waves) { const uint64_t size = wd.tb_off; wd.tb_off = tb_dwords; tb_dwords += size; b->wave_steps += wd.n_steps; }
 
     lap("waves");
     // the descriptors (their wave / lane fields are final now), the wavefronts and the order follow; the output arenas are allocated
@@ -644,5 +644,6 @@ uint64_t vgk_batch_alg_bytes(vgk_batch* b) {
     return alg;
 }
 uint64_t vgk_batch_device_bytes(vgk_batch* b) { return b ? b->dev_bytes : 0; }
+uint64_t vgk_batch_wave_steps(vgk_batch* b) { return b ? b->wave_steps : 0; }
 
 }  // extern "C"

@@ -188,7 +188,7 @@ int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
         const uint64_t SLICE = 16ull << 20, PIECE = 256ull << 10;
         for (uint64_t at = 0; at < bytes; at += SLICE) {
             const uint64_t len = std::min(SLICE, bytes - at);
-            parallel_for((uint32_t)((len + PIECE - 1) / PIECE), [&](uint32_t c, unsigned) {
+            parallel_tasks((uint32_t)((len + PIECE - 1) / PIECE), [&](uint32_t c) {
                 const uint64_t o = at + (uint64_t)c * PIECE;
                 std::memcpy(st + o, (const uint8_t*)src + o, (size_t)std::min(PIECE, at + len - o));
             });
@@ -244,7 +244,7 @@ int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     P.want_tb = b->want_tb ? 1 : 0;
     P.fused = 0;
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
-    b->ops_total = T.tot[WS_OPS];
+    b->ops_total = T.tot[WS_OPS]; b->wave_steps = T.wave_steps;
     lap("done");
     *out = hb.release();
     return VGK_OK;

@@ -96,6 +96,25 @@ int vgh_align_q(vgh_aligner* a, vgh_graph* g, const char* read, const uint8_t* q
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }
 
+// Aligner::align(alignment, graph, topological_order) (src/aligner.hpp:180-181): the order names oriented nodes (2 * id + is_reverse)
+// of a subgraph that may hold both strands; only a plain Aligner has this overload.
+int vgh_align_order(vgh_aligner* a, vgh_graph* g, const char* read, const int64_t* order, int n_order, char* json_out, size_t json_cap) {
+    try {
+        Aligner* plain = dynamic_cast<Aligner*>(a->a.get());
+        if (!plain) { g_last_error = "align(order) needs a plain Aligner"; return -1; }
+        Alignment aln; aln.sequence = read;
+        std::vector<handle_t> topological_order;
+        for (int i = 0; i < n_order; ++i) topological_order.push_back(g->g.get_handle(order[i] >> 1, order[i] & 1));
+        plain->align(aln, g->g, topological_order);
+        return emit(aln, json_out, json_cap);
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// MatrixAlignmentScorer::longest_detectable_gap (src/alignment_scorer.cpp:264-271) of the aligner's scorer
+int64_t vgh_longest_detectable_gap(vgh_aligner* a, int64_t read_length, int64_t read_pos) {
+    return (int64_t)a->a->scorer->longest_detectable_gap((size_t)read_length, (size_t)read_pos);
+}
+
 // Aligner::align_global_banded_multi: JSON out = {"primary": alignment, "alternates": [alignment...]}
 int vgh_align_banded_multi(vgh_aligner* a, vgh_graph* g, const char* read, const uint8_t* qual, int max_alt_alns, int band_padding, int permissive,
                            char* json_out, size_t json_cap) {

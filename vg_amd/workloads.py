@@ -18,6 +18,17 @@ NODE = 32
 FLANK = 117
 
 
+def longest_detectable_gap(read_length, read_pos, match=1, gap_open=6, gap_extend=1, bonus=5):
+    """EditAlignmentScorer::longest_detectable_gap (src/alignment_scorer.cpp:264-271); vectorised over numpy arrays.  C++ integer
+    division truncates towards zero."""
+    read_length = np.asarray(read_length, dtype=np.int64); read_pos = np.asarray(read_pos, dtype=np.int64)
+    overhang = np.minimum(read_pos, read_length - read_pos)
+    numer = match * overhang + bonus - gap_open
+    gap = np.where(numer >= 0, numer // gap_extend, -((-numer) // gap_extend)) + 1
+    out = np.where((gap >= 0) & (overhang > 0), gap, 0)
+    return int(out) if out.ndim == 0 else out
+
+
 def make_reference(length=1_000_000, seed=42):
     rng = np.random.default_rng(seed)
     return ACGT[rng.integers(0, 4, length)]
@@ -185,7 +196,9 @@ class TailWorkload:
         # ---- problems -----------------------------------------------------------------------------
         tails = rng.integers(1, max_tail + 1, n_reads)
         starts = chain_idx[rng.integers(0, len(chain_idx), n_reads)]
-        gap = np.maximum((tails * 1 + 5 - 6) // 1 + 1, 1)                     # longest_detectable_gap with 1/4/6/1/5
+        # giraffe: max_gap = longest_detectable_gap(read length, tail length) with the tail's end as the read position
+        # (src/minimizer_mapper.cpp:5809-5816); for a tail of t bases off a read of >= 2 t that is the overhang t
+        gap = np.maximum(longest_detectable_gap(2 * tails, tails), 1)
         depth_bp = tails + np.minimum(gap, tails)                             # = 2t for t <= 75
         reads, read_off, node_len, node_off, pred_off, pred_idx, edge_off, seq_chunks, seq_off = [], [0], [], [0], [], [], [0], [], [0]
         max_gap = []
