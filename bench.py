@@ -7,9 +7,12 @@ whose packed inputs are already resident in HBM.  Workload = BASELINE.json
 configs[1]: linear 1 Mbp synthetic graph (32 bp nodes), 150 bp reads, 384-416 bp
 windows, LOCAL alignment with traceback, default vg scoring 1/4/6/1/5.
 
-Multi-GPU: reads shard embarrassingly (one process per GPU, no data-path
-collective); every rank aligns its own batch of the same size -> weak scaling.
-torch is used only for process-group plumbing (barrier, max-reduce of the time).
+Multi-GPU: ONE read stream of reads-per-GPU x N reads is cut into contiguous shards
+(vg_amd/shard.py, pairs kept together), one process per GPU, no data-path collective
+-> weak scaling.  torch is used only for process-group plumbing (barrier, max-reduce
+of the times).  Besides the resident-kernel rate (`value`) every rank also streams its
+shard from host buffers (pack + kernels + fetch), with the host's packing threads
+divided among the ranks; the slowest rank sets `end_to_end_*_per_s`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -273,6 +276,8 @@ def main():
 
     import numpy as np
     from vg_amd import capi, workloads
+    if world > 1:      # N ranks share one host: each gets its share of the packing / unpacking threads
+        os.environ["VGAMD_HOST_THREADS"] = str(shard.host_threads_per_rank(world))
 
     eng_lib = os.path.join(ROOT, "vg_amd", "libvgamd.so")
     if not os.path.exists(eng_lib):
@@ -287,13 +292,15 @@ def main():
     if args.workload == "gapless":
         return bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus)
 
-    # same reference everywhere; each rank draws its own reads (shard of the read stream)
+    # ONE read stream of reads-per-GPU x N reads (weak scaling: the work per GPU is fixed), cut into contiguous shards with the two
+    # reads of a pair kept together (shard.shard_range); every rank materialises its own shard only
     if args.workload == "tails":
         n_tails = min(args.reads, 200_000)          # per-problem graphs are built in Python: keep generation short
         wl = workloads.TailWorkload(n_tails, seed=77 + rank).ps
         args.reads = n_tails
     else:
-        wl = workloads.LinearWorkload(args.reads, seed=43 + rank)
+        lo, hi = shard.shard_range(args.reads * world, rank, world, group=2)
+        wl = workloads.LinearWorkload(hi - lo, stream_begin=lo)
     OPS_PER = 48
     # configs[1]: the reference graph is resident in HBM once (vgk_graph_create) and every read is a window of it, packed by
     # kernels (vgk_gssw_pack_windows); --host-pack (and the tails workload) hand over one explicit graph per problem instead
@@ -402,7 +409,9 @@ def main():
     # steady state from host buffers: three more batches, each packed, run once and fetched in turn on the warm context
     # (page-locked staging and device arenas are reused; nothing overlaps — pack, kernels and fetch are serial here)
     t_warm = t_pipe = None
-    if world == 1 and not args.no_e2e:        # like the CPU leg: reported at N = 1 only
+    if dist is not None:
+        barrier()                                  # all ranks start their streaming legs together: they share the host
+    if not args.no_e2e:        # every rank streams its shard from host buffers; the slowest rank sets the rate
         def touched(a):                            # a second set of output arrays, pages already faulted in
             z = np.empty_like(a); z.view(np.uint8)[:] = 0
             return z
@@ -420,15 +429,26 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(1) as ex:
             nxt = ex.submit(pack)
-            for k in range(12):                    # the first four fill the pipeline (second set of device arenas, staging buffers)
-                if k == 4:
-                    tp = time.perf_counter()
-                pb = nxt.result()
-                if k + 1 < 12:
-                    nxt = ex.submit(pack)
-                pb.run(); pb.fetch(into=out_bufs[k & 1]); pb.free()
+            prev = None
+            for k in range(13):                    # the first four fill the pipeline (third set of device arenas, staging buffers)
+                if k == 5:
+                    tp = time.perf_counter()       # (batch 4 is in flight: 8 batches complete between here and the end)
+                pb = None
+                if k < 12:
+                    pb = nxt.result()
+                    if k + 1 < 12:
+                        nxt = ex.submit(pack)
+                    pb.run()                       # queued behind the previous batch's kernels: the GPU does not idle while that one is fetched
+                if prev is not None:
+                    prev.fetch(into=out_bufs[k & 1]); prev.free()
+                prev = pb
             t_pipe = (time.perf_counter() - tp) / 8
 
+    if dist is not None and t_warm is not None:
+        barrier()
+        t = torch.tensor([t_warm, t_pipe], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_warm, t_pipe = float(t[0].item()), float(t[1].item())
     if rank == 0:
         total_reads = args.reads * world * args.steps
         value = total_reads / elapsed
@@ -475,8 +495,11 @@ def main():
             "pack_seconds": t_pack, "fetch_seconds": t_fetch,
             # one batch from host buffers: pack (validate + encode + H2D) + one run + fetch (D2H of results and CIGAR ops)
             "end_to_end_from_host_buffers_per_s": args.reads / (t_pack + elapsed / args.steps + t_fetch),
-            "end_to_end_warm_per_s": args.reads / t_warm if t_warm else None,
-            "end_to_end_double_buffered_per_s": args.reads / t_pipe if t_pipe else None,
+            # whole-job rates from host buffers (all ranks' reads / the slowest rank's time per batch): pack + kernels + fetch in turn,
+            # and with the next batch packed and queued while this one runs and is fetched
+            "end_to_end_warm_per_s": args.reads * world / t_warm if t_warm else None,
+            "end_to_end_double_buffered_per_s": args.reads * world / t_pipe if t_pipe else None,
+            "host_threads_per_rank": int(os.environ.get("VGAMD_HOST_THREADS", "0")) or min(os.cpu_count() or 1, 48),
         }
         print(json.dumps(out))
     if dist is not None:

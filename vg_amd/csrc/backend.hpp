@@ -35,10 +35,18 @@ public:
     // stream of their own; sync_side() waits for them only
     virtual int   upload_side(void* dst, const void* src, size_t bytes) { return upload(dst, src, bytes); }
     virtual int   sync_side() { return sync(); }
-    // wait for the stream by polling an event, without sitting in a blocking runtime call: another thread's copies and launches
-    // (the next batch being packed) go through meanwhile
-    virtual int   sync_polling() { return sync(); }
     virtual int   zero(void* dst, size_t bytes) = 0;                        // async on the stream
+    // A batch's own completion event, and a third stream for the way back.  vgk_gssw_run records the batch's event behind its
+    // kernels; vgk_gssw_fetch waits for THAT (polling: no blocking runtime call, no shared poll event), packs the CIGAR ops and
+    // copies back on the fetch stream — so a caller may queue the next batch's kernels before it fetches this one and the GPU
+    // never idles between batches.  (Backends without streams: everything is synchronous, the defaults do.)
+    virtual void* event_create() { return nullptr; }
+    virtual void  event_destroy(void* ev) { (void)ev; }
+    virtual int   event_record(void* ev) { (void)ev; return VGK_OK; }               // on the main stream
+    virtual int   event_wait(void* ev) { (void)ev; return sync(); }                 // host waits, polling
+    virtual int   fetch_after(void* ev) { (void)ev; return VGK_OK; }                // fetch-stream work queued from now on runs after ev
+    virtual int   sync_fetch() { return sync(); }
+    virtual int   download_fetch(void* dst, const void* src, size_t bytes) { return download(dst, src, bytes); }   // synchronous, fetch stream
     // device-side packing of window problems (gssw_pack_device.hpp), asynchronous on the side (copy) stream like upload_side:
     // stage 1 = per-problem sizes + their prefix sums + totals, stage 2 = launch order, wavefronts, the arenas the kernels read.
     // win_tmp_bytes = device scratch both stages need (`tmp`); download_side / fill_side = synchronous copy back / async byte fill

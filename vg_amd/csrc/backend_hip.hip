@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(64) gssw_matrix_kernel(const GsswMatrixParams 
 
 class HipBackend final : public Backend {
 public:
-    int dev = 0; int n_launches = 1; hipEvent_t poll_ev = nullptr; hipStream_t stream = nullptr, copy = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, copy = nullptr, fetch = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipDeviceProp_t prop;
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
     float ms_gapless = 0.f, ms_wfa = 0.f;
@@ -234,7 +234,7 @@ public:
         for (int i = 0; i < 2; ++i) { if (side[i]) hipStreamDestroy(side[i]); if (side_done[i]) hipEventDestroy(side_done[i]); }
         if (stream) hipStreamDestroy(stream);
         if (copy) hipStreamDestroy(copy);
-        if (poll_ev) hipEventDestroy(poll_ev);
+        if (fetch) hipStreamDestroy(fetch);
     }
     const char* name() const override { return prop.name; }
     int compute_units() const override { return prop.multiProcessorCount; }
@@ -261,16 +261,40 @@ public:
         hipSetDevice(dev);
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, copy) == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
-    int sync_polling() override {
+    void* event_create() override {
         hipSetDevice(dev);
-        if (!poll_ev && hipEventCreateWithFlags(&poll_ev, hipEventDisableTiming) != hipSuccess) return sync();
-        if (hipEventRecord(poll_ev, stream) != hipSuccess) return sync();
+        hipEvent_t e = nullptr;
+        return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? (void*)e : nullptr;
+    }
+    void event_destroy(void* ev) override { if (ev) { hipSetDevice(dev); hipEventDestroy((hipEvent_t)ev); } }
+    int event_record(void* ev) override {
+        if (!ev) return VGK_OK;
+        hipSetDevice(dev);
+        return hipEventRecord((hipEvent_t)ev, stream) == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int event_wait(void* ev) override {
+        if (!ev) return sync();
+        hipSetDevice(dev);
         for (;;) {
-            const hipError_t e = hipEventQuery(poll_ev);
+            const hipError_t e = hipEventQuery((hipEvent_t)ev);
             if (e == hipSuccess) return VGK_OK;
             if (e != hipErrorNotReady) { (void)hipGetLastError(); return VGK_ENODEV; }
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
+    }
+    int fetch_after(void* ev) override {
+        if (!ev) return VGK_OK;
+        hipSetDevice(dev);
+        return hipStreamWaitEvent(fetch, (hipEvent_t)ev, 0) == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int sync_fetch() override {
+        hipSetDevice(dev);
+        return hipStreamSynchronize(fetch) == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int download_fetch(void* dst, const void* src, size_t bytes) override {
+        hipSetDevice(dev);
+        if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, fetch) != hipSuccess) return VGK_ENODEV;
+        return hipStreamSynchronize(fetch) == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int sync_side() override {
         hipSetDevice(dev);
@@ -347,17 +371,17 @@ public:
         hipSetDevice(dev);
         const uint32_t blocks = (n + OPS_SCAN_BLOCK - 1) / OPS_SCAN_BLOCK;
         unsigned long long* total_dev = (unsigned long long*)(sums + ((blocks + 2) & ~1u));       // 8-byte aligned, behind the block sums
-        hipLaunchKernelGGL(ops_scan_kernel, dim3(blocks), dim3(256), 0, stream, res, n, offs, sums);
-        hipLaunchKernelGGL(ops_sums_kernel, dim3(1), dim3(256), 0, stream, sums, blocks, total_dev);
+        hipLaunchKernelGGL(ops_scan_kernel, dim3(blocks), dim3(256), 0, fetch, res, n, offs, sums);
+        hipLaunchKernelGGL(ops_sums_kernel, dim3(1), dim3(256), 0, fetch, sums, blocks, total_dev);
         unsigned long long t = 0;
-        if (hipMemcpyAsync(&t, total_dev, sizeof t, hipMemcpyDeviceToHost, stream) != hipSuccess) return VGK_ENODEV;
-        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
+        if (hipMemcpyAsync(&t, total_dev, sizeof t, hipMemcpyDeviceToHost, fetch) != hipSuccess) return VGK_ENODEV;
+        if (hipStreamSynchronize(fetch) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         *total = t;
         return VGK_OK;
     }
     int ops_gather(const vgk_result* res, const vgk_op* ops, uint32_t n, const uint32_t* offs, const uint32_t* sums, vgk_result* out_res, vgk_op* out_ops) override {
         hipSetDevice(dev);
-        hipLaunchKernelGGL(ops_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, res, ops, n, offs, sums, out_res, out_ops);
+        hipLaunchKernelGGL(ops_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, fetch, res, ops, n, offs, sums, out_res, out_ops);
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_banded(const BandedParams& p, const BandedLaunch* launches, uint32_t n) override {
@@ -446,7 +470,8 @@ Backend* make_backend(int device, std::string& err) {
     b->dev = device;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&b->prop, device) != hipSuccess) {
         err = "cannot select HIP device"; delete b; return nullptr; }
-    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking) != hipSuccess) { err = "cannot create HIP stream"; delete b; return nullptr; }
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&b->fetch, hipStreamNonBlocking) != hipSuccess) { err = "cannot create HIP stream"; delete b; return nullptr; }
     for (int i = 0; i < 2; ++i)
         if (hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&b->side_done[i], hipEventDisableTiming) != hipSuccess) { err = "cannot create HIP side stream"; delete b; return nullptr; }

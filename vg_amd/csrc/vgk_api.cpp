@@ -91,9 +91,12 @@ int vgk_device_info(vgk_ctx* ctx, char* name_out, size_t name_cap, int* cus, siz
 
 void vgk_batch_free(vgk_batch* b) {
     if (!b) return;
+    // only THIS batch's work has to be over before its arenas go back to the pool: its kernels (the event behind them) and
+    // whatever a fetch queued on the fetch stream — not the kernels of a later batch that may already be queued
+    if (b->done) b->ctx->be->event_wait(b->done); else b->ctx->be->sync();
+    b->ctx->be->sync_fetch();
     {
         std::lock_guard<std::mutex> lk(b->ctx->mu);
-        b->ctx->be->sync();
         for (const vgk_ctx::Pooled& q : b->dev) b->ctx->dev_give(q.p, q.bytes);
     }
     delete b;
@@ -448,7 +451,11 @@ int vgk_gssw_run(vgk_batch* b) {
     int rc = b->ctx->be->zero(b->P.best, ((size_t)b->n + 1) * sizeof(unsigned long long));
     if (rc) return rc;
     rc = b->ctx->be->run_gssw(b->P, b->launches.data(), (uint32_t)b->launches.size(), true);
-    if (rc == VGK_OK) b->ran = true;
+    if (rc == VGK_OK) {
+        b->ran = true;
+        if (!b->done) b->done = b->ctx->be->event_create();
+        rc = b->ctx->be->event_record(b->done);
+    }
     return rc;
 }
 
@@ -466,8 +473,8 @@ static int fetch_packed_on_device(vgk_batch* b, vgk_result* results, vgk_op* ops
     if (!n) return VGK_EUNSUPPORTED;
     const uint32_t blocks = (n + Backend::OPS_SCAN_BLOCK - 1) / Backend::OPS_SCAN_BLOCK;
     std::vector<vgk_ctx::Pooled> mine;
-    auto take = [&](uint64_t bytes) -> void* { uint64_t got = 0; void* p = ctx->dev_take(bytes, got); if (p) mine.push_back({p, got}); return p; };
-    struct GiveBack { vgk_ctx* ctx; std::vector<vgk_ctx::Pooled>& v; ~GiveBack() { ctx->be->sync(); for (auto& q : v) ctx->dev_give(q.p, q.bytes); } } give_back{ctx, mine};
+    auto take = [&](uint64_t bytes) -> void* { std::lock_guard<std::mutex> lk(ctx->mu); uint64_t got = 0; void* p = ctx->dev_take(bytes, got); if (p) mine.push_back({p, got}); return p; };
+    struct GiveBack { vgk_ctx* ctx; std::vector<vgk_ctx::Pooled>& v; ~GiveBack() { ctx->be->sync_fetch(); std::lock_guard<std::mutex> lk(ctx->mu); for (auto& q : v) ctx->dev_give(q.p, q.bytes); } } give_back{ctx, mine};
     uint32_t* offs = (uint32_t*)take((uint64_t)n * 4);
     uint32_t* sums = (uint32_t*)take(((uint64_t)blocks + 8) * 4);
     if (!offs || !sums) return VGK_ENOMEM;
@@ -486,8 +493,8 @@ static int fetch_packed_on_device(vgk_batch* b, vgk_result* results, vgk_op* ops
     const uint64_t res_bytes = (uint64_t)n * sizeof(vgk_result), ops_bytes = total * sizeof(vgk_op);
     uint8_t* stage = (uint8_t*)lease.s->get(5, res_bytes + ops_bytes);
     if (!stage) return VGK_ENOMEM;
-    if ((rc = be->download(stage, out_res, res_bytes))) return rc;
-    if (ops_bytes && (rc = be->download(stage + res_bytes, out_ops, ops_bytes))) return rc;
+    if ((rc = be->download_fetch(stage, out_res, res_bytes))) return rc;
+    if (ops_bytes && (rc = be->download_fetch(stage + res_bytes, out_ops, ops_bytes))) return rc;
     auto copy_out = [](void* dst, const uint8_t* src, uint64_t bytes) {
         const uint64_t chunk = 16384;
         parallel_for((uint32_t)((bytes + chunk - 1) / chunk), [&](uint32_t c, unsigned) {
@@ -505,10 +512,14 @@ static int fetch_packed_on_device(vgk_batch* b, vgk_result* results, vgk_op* ops
 int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
     if (!b || !results) return VGK_EINVAL;
     if (!b->ran) { int rc = vgk_gssw_run(b); if (rc) return rc; }
-    { int rc = b->ctx->be->sync_polling(); if (rc) return rc; }        // wait for the kernels before taking the context lock, and outside blocking runtime calls
-    std::lock_guard<std::mutex> lk(b->ctx->mu);
-    int rc = fetch_packed_on_device(b, results, ops, ops_cap, ops_written);
+    // wait for THIS batch's kernels (its own event; polling, outside blocking runtime calls and outside the context lock); the
+    // packing of the ops and the copies back then run on the fetch stream, beside whatever batch the caller has queued next
+    { int rc = b->done ? b->ctx->be->event_wait(b->done) : b->ctx->be->sync(); if (rc) return rc; }
+    int rc = b->ctx->be->fetch_after(b->done);
+    if (rc) return rc;
+    rc = fetch_packed_on_device(b, results, ops, ops_cap, ops_written);       // takes the context lock for its arenas only
     if (rc != VGK_EUNSUPPORTED) return rc;
+    std::lock_guard<std::mutex> lk(b->ctx->mu);
     // host path (a backend without the packing kernels, or a caller whose op array is too small: per-problem VGK_EOPS)
     rc = b->ctx->be->download(results, b->P.results, (size_t)b->n * sizeof(vgk_result));
     if (rc) return rc;

@@ -14,11 +14,21 @@ def env_rank():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def shard_range(n_total, rank, world):
-    """Contiguous block [begin, end) of a stream of n_total problems for `rank`; sizes differ by <= 1."""
-    base, extra = divmod(n_total, world)
+def shard_range(n_total, rank, world, group=1):
+    """Contiguous block [begin, end) of a stream of n_total problems for `rank`.  Cuts fall on multiples of `group` (2 keeps the
+    two reads of a pair on one GPU); block sizes differ by at most `group`."""
+    n_groups = (n_total + group - 1) // group
+    base, extra = divmod(n_groups, world)
     begin = rank * base + min(rank, extra)
-    return begin, begin + base + (1 if rank < extra else 0)
+    end = begin + base + (1 if rank < extra else 0)
+    return min(begin * group, n_total), min(end * group, n_total)
+
+
+def host_threads_per_rank(world, cores=None):
+    """Packing / unpacking threads one rank may use when `world` ranks share the host (bench.py caps VGAMD_HOST_THREADS with it):
+    the engine's default is min(cores, 48) per process, which 8 ranks would oversubscribe."""
+    cores = cores or os.cpu_count() or 1
+    return max(1, min(48, cores // max(world, 1)))
 
 
 def align_shard(engine, problems, rank, world, ops_per_problem=0):

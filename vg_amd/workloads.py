@@ -37,26 +37,30 @@ def make_reference(length=1_000_000, seed=42):
 class LinearWorkload:
     """Holds the numpy arenas and the vgk_gssw_problem array for config 2."""
 
+    STREAM_CHUNK = 65536      # reads of the global stream are generated chunk by chunk, chunk c from the seed (seed, c)
+
     def __init__(self, n_reads, read_len=150, ref_len=1_000_000, seed=43, ref_seed=42,
-                 sub_rate=0.01, indel_rate=0.001, flags=capi.VGK_GSSW_LOCAL | capi.VGK_GSSW_TRACEBACK):
-        rng = np.random.default_rng(seed)
+                 sub_rate=0.01, indel_rate=0.001, flags=capi.VGK_GSSW_LOCAL | capi.VGK_GSSW_TRACEBACK, stream_begin=0):
+        """Reads [stream_begin, stream_begin + n_reads) of ONE global read stream: any cut of the stream into shards (bench.py
+        --gpus N through shard.shard_range) sees the same reads as a single process that takes it whole."""
         self.ref = make_reference(ref_len, ref_seed)
         self.n = n_reads
         self.read_len = read_len
         n_ref_nodes = ref_len // NODE
         # sample a little more reference than the read needs so deletions can be absorbed
         span = read_len + 16
-        start = rng.integers(0, ref_len - span, n_reads)
-        reads = np.empty((n_reads, read_len), dtype=np.uint8)
-        CH = 65536                                              # chunked to bound host memory
-        for c0 in range(0, n_reads, CH):
-            c1 = min(n_reads, c0 + CH)
-            m = c1 - c0
-            src = self.ref[start[c0:c1, None] + np.arange(span)[None, :]]   # (m, span) template bases
+        CH = self.STREAM_CHUNK
+        starts, read_blocks = [], []
+        for c in range(stream_begin // CH, (stream_begin + max(n_reads, 1) - 1) // CH + 1):
+            rng = np.random.default_rng([seed, c])
+            m = CH
+            start_c = rng.integers(0, ref_len - span, m)
+            reads_c = np.empty((m, read_len), dtype=np.uint8)
+            src = self.ref[start_c[:, None] + np.arange(span)[None, :]]   # (m, span) template bases
             # substitutions (to a uniformly random base, as vg sim does)
             sub = rng.random((m, span)) < sub_rate
             src[sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
-            reads[c0:c1] = src[:, :read_len]
+            reads_c[:] = src[:, :read_len]
             # indels: rare -> per-read fix-up loop over the affected reads only
             ev = rng.random((m, read_len)) < indel_rate
             for r in np.nonzero(ev.any(axis=1))[0]:
@@ -75,7 +79,13 @@ class LinearWorkload:
                     out.append(tmpl[i]); i += 1
                 while len(out) < read_len:
                     out.append(ACGT[rng.integers(0, 4)])
-                reads[c0 + r] = np.array(out[:read_len], dtype=np.uint8)
+                reads_c[r] = np.array(out[:read_len], dtype=np.uint8)
+            lo = max(stream_begin - c * CH, 0); hi = min(stream_begin + n_reads - c * CH, CH)
+            starts.append(start_c[lo:hi]); read_blocks.append(reads_c[lo:hi])
+        start = np.concatenate(starts) if starts else np.zeros(0, dtype=np.int64)
+        reads = np.concatenate(read_blocks) if read_blocks else np.zeros((0, read_len), dtype=np.uint8)
+        if n_reads == 0:
+            start = start[:0]; reads = reads[:0]
         self.reads = reads.reshape(-1)
         self.start = start
         # windows snapped outward to whole nodes, clipped to the reference
