@@ -62,4 +62,4 @@ def test_shard_ranges_cover_the_stream_exactly():
             pairs = [shard_range(n, r, world, group=2) for r in range(world)]       # read pairs stay on one rank
             assert pairs[0][0] == 0 and pairs[-1][1] == n
             assert all(pairs[i][1] == pairs[i + 1][0] and (pairs[i][1] % 2 == 0 or pairs[i][1] == n) for i in range(world - 1))
-            assert max(e - b for b, e in pairs) - min(e - b for b, e in pairs) <= 2
+            assert max(e - b for b, e in pairs) - min(e - b for b, e in pairs) <= 3      # one pair, plus the odd read at the end of the stream
