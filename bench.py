@@ -43,7 +43,7 @@ def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
     and fetches the extension sets (timed separately as end_to_end_from_host_buffers); the timed region then re-launches the kernel
     K times on the inputs that stayed resident in HBM (vgk_gapless_rerun), which is what `value` reports."""
     import numpy as np
-    from vg_amd import capi, workloads
+    from vg_amd import capi, shard, workloads
     n = min(args.reads, 1_000_000)
     wl = workloads.GaplessWorkload(n, seed=123 + rank)
     index = eng.haplo_index(wl.nodes, wl.threads)          # the haplotype index is resident in HBM from here on
@@ -74,9 +74,10 @@ def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu:      # the CPU leg (checker + baseline) runs at N = 1 only
         ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
+        ora.lib.vgo_set_threads(shard.usable_cpus())
         oidx = ora.haplo_index(wl.nodes, wl.threads)
         tc = time.perf_counter(); o = ora.gapless_extend(oidx, wl.gs); tc = time.perf_counter() - tc
-        cpu = {"value": n / tc, "unit": "reads/s", "cores": os.cpu_count() or 1, "kind": "port",
+        cpu = {"value": n / tc, "unit": "reads/s", "cores": shard.usable_cpus(), "kind": "port",
                "sample": "the same %d reads, oracle/vgo_gapless.c (scalar best-first extension over the uncompressed haplotype index), OpenMP over reads" % n}
         same = all(len(a) == len(b) and bool((a == b).all()) for a, b in zip(o, out))
         parity = {"checked": n, "identical": n if same else int((o[0] == res).sum())}
@@ -108,7 +109,7 @@ def bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus):
     HBM, runs the kernel and fetches the alignments (timed separately as end_to_end_from_host_buffers); the timed region then
     re-launches the kernel K times on the inputs that stayed resident in HBM (vgk_wfa_rerun), which is what `value` reports."""
     import numpy as np
-    from vg_amd import capi, workloads
+    from vg_amd import capi, shard, workloads
     n = min(args.reads, 500_000)
     wl = workloads.WfaWorkload(n, seed=321 + rank)
     index = eng.haplo_index(wl.nodes, wl.threads)
@@ -139,9 +140,10 @@ def bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus):
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu:      # the CPU leg (checker + baseline) runs at N = 1 only
         ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
+        ora.lib.vgo_set_threads(shard.usable_cpus())
         oidx = ora.haplo_index(wl.nodes, wl.threads)
         tc = time.perf_counter(); o = ora.wfa_extend(oidx, wl.ws); tc = time.perf_counter() - tc
-        cpu = {"value": n / tc, "unit": "alignments/s", "cores": os.cpu_count() or 1, "kind": "port",
+        cpu = {"value": n / tc, "unit": "alignments/s", "cores": shard.usable_cpus(), "kind": "port",
                "sample": "the same %d problems, oracle/vgo_wfa.c (scalar WFA over the haplotype trie, hash-table wavefronts), OpenMP over problems" % n}
         good = res["status"] == 0
         fields = ("ok", "score", "node_offset", "seq_offset", "length", "path_len", "n_edits")
@@ -182,7 +184,7 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
     batch to HBM, runs fill + traceback and fetches the results (timed separately as end_to_end_from_host_buffers); the timed region
     then re-launches the kernels K times on the inputs that stayed resident in HBM (vgk_banded_rerun), which is what `value` reports."""
     import numpy as np
-    from vg_amd import capi, workloads
+    from vg_amd import capi, shard, workloads
     n = min(args.reads, 100_000)
     wl = workloads.BandedWorkload(n, seed=99 + rank)
 
@@ -212,8 +214,9 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu:      # the CPU leg (checker + baseline) runs at N = 1 only
         ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
+        ora.lib.vgo_set_threads(shard.usable_cpus())
         tc = time.perf_counter(); ores, oops = ora.banded_align(wl.bs); tc = time.perf_counter() - tc
-        cpu = {"value": n / tc, "unit": "alignments/s", "cores": os.cpu_count() or 1, "kind": "port",
+        cpu = {"value": n / tc, "unit": "alignments/s", "cores": shard.usable_cpus(), "kind": "port",
                "sample": "the same %d problems, oracle/vgo_banded.c scalar int32 three-matrix DP + traceback, OpenMP over problems" % n}
         hdr = (res["score"] == ores["score"]) & (res["status"] == ores["status"]) & (res["n_ops"] == ores["n_ops"])
         same = int(hdr.sum())
@@ -352,7 +355,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:      # the CPU leg (checker + baseline) runs at N = 1 only
         ora_lib = os.path.join(ROOT, "oracle", "libvgoracle.so")
         ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=ora_lib)     # the checker / CPU baseline leg
-        cores = os.cpu_count() or 1
+        cores = shard.usable_cpus()          # the affinity mask cut by the cgroup quota: what the CPU leg can really use
+        ora.lib.vgo_set_threads(cores)
         k = args.cpu_sample
         if k <= 0:
             probe = wl.subset(min(args.reads, 64 * cores))
@@ -400,7 +404,8 @@ def main():
             if same_fast == kf:
                 cpu = {"value": kf / tfast, "unit": "reads/s", "cores": cores, "kind": "port",
                        "impl": "restated CPU, SIMD int16 (oracle/vgo_gssw_fast.c: AVX2 rows, per-thread arenas, 1 B/cell traceback, OpenMP dynamic)",
-                       "cpu_model": model, "gcups": fs.cells() / tfast / 1e9, "gcups_per_hw_thread": fs.cells() / tfast / 1e9 / cores,
+                       "cpu_model": model, "host_hw_threads": os.cpu_count(), "cores_note": "cores = CPUs this container may use (affinity and cgroup quota), one OpenMP thread each",
+                       "gcups": fs.cells() / tfast / 1e9, "gcups_per_core": fs.cells() / tfast / 1e9 / cores,
                        "sample": "%d problems of the same batch (DP + traceback, packing excluded), all %d identical to the engine's results" % (kf, kf),
                        "scalar_checker_reads_per_s": k / tc}
             else:
@@ -499,7 +504,7 @@ def main():
             # and with the next batch packed and queued while this one runs and is fetched
             "end_to_end_warm_per_s": args.reads * world / t_warm if t_warm else None,
             "end_to_end_double_buffered_per_s": args.reads * world / t_pipe if t_pipe else None,
-            "host_threads_per_rank": int(os.environ.get("VGAMD_HOST_THREADS", "0")) or min(os.cpu_count() or 1, 48),
+            "host_threads_per_rank": int(os.environ.get("VGAMD_HOST_THREADS", "0")) or min(shard.usable_cpus(), 48),
         }
         print(json.dumps(out))
     if dist is not None:

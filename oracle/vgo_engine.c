@@ -122,6 +122,10 @@ int vgk_gssw_run(vgk_batch* b) {
     b->ran = 1; return VGK_OK;
 }
 
+/* threads of the OpenMP loops below (bench.py sets the CPUs the container may really use; the default is every hardware thread) */
+#include <omp.h>
+void vgo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+
 /* bench.py's cpu_baseline leg: the same batch through the SIMD restatement (vgo_gssw_fast.c).  Not part of the C ABI. */
 int vgo_gssw_fast_batch(const vgk_scoring* sc, const vgk_gssw_problem* probs, uint32_t n, vgk_result* results, vgk_op* ops, uint32_t ops_per_problem);
 int vgo_gssw_run_fast(vgk_batch* b) {

@@ -24,10 +24,28 @@ def shard_range(n_total, rank, world, group=1):
     return min(begin * group, n_total), min(end * group, n_total)
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask cut by the cgroup CPU quota (a container on a 256-thread host is often
+    given far fewer CPUs' worth of time; os.cpu_count() does not see that)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def host_threads_per_rank(world, cores=None):
     """Packing / unpacking threads one rank may use when `world` ranks share the host (bench.py caps VGAMD_HOST_THREADS with it):
     the engine's default is min(cores, 48) per process, which 8 ranks would oversubscribe."""
-    cores = cores or os.cpu_count() or 1
+    cores = cores or usable_cpus()
     return max(1, min(48, cores // max(world, 1)))
 
 
