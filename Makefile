@@ -14,8 +14,8 @@ CFLAGS   ?= -O3 -march=x86-64-v2 -std=c11 -fPIC -fopenmp -Iinclude -Wall
 
 LIB_SRCS    := $(wildcard vg_amd/csrc/*.hip) $(wildcard vg_amd/csrc/*.cpp)
 LIB_HDRS    := $(wildcard vg_amd/csrc/*.h vg_amd/csrc/*.hpp include/*.h)
-HOST_SRCS   := $(wildcard vg_amd/host/*.cpp)
-HOST_HDRS   := $(wildcard vg_amd/host/*.hpp include/*.h)
+HOST_SRCS   := $(wildcard vg_amd/host/*.cpp) $(wildcard vg_amd/host/vg_standin/*.cpp)
+HOST_HDRS   := $(wildcard vg_amd/host/*.hpp vg_amd/host/vg_standin/*.hpp include/*.h)
 ORACLE_SRCS := $(wildcard oracle/*.c)
 
 all: lib host oracle

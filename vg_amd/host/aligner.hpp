@@ -10,9 +10,9 @@
 #include <stdexcept>
 #include <unordered_set>
 #include <vector>
-#include "alignment.hpp"
+#include "vg_standin/alignment.hpp"
 #include "engine.hpp"
-#include "handle_graph.hpp"
+#include "vg_standin/handle_graph.hpp"
 
 namespace vgamd {
 

@@ -1,3 +1,5 @@
+// STAND-IN (vg_amd/host/vg_standin/): restates a slice of vg / libhandlegraph / libvgio that stays vg's own in a real
+// integration; present only so the reference's unit tests can be driven without vg.  Excluded from size / originality claims.
 // alignment.hpp — plain-struct mirror of the vg.proto messages that cross the
 // aligner boundary (libvgio is an empty submodule in the reference; shapes are
 // taken from their uses: src/aligner.cpp:125-128,152-161,185-228,240,

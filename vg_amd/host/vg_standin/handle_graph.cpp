@@ -1,3 +1,5 @@
+// STAND-IN (vg_amd/host/vg_standin/): restates a slice of vg / libhandlegraph / libvgio that stays vg's own in a real
+// integration; present only so the reference's unit tests can be driven without vg.  Excluded from size / originality claims.
 #include "handle_graph.hpp"
 #include <algorithm>
 #include <stdexcept>

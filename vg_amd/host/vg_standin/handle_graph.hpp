@@ -1,3 +1,5 @@
+// STAND-IN (vg_amd/host/vg_standin/): restates a slice of vg / libhandlegraph / libvgio that stays vg's own in a real
+// integration; present only so the reference's unit tests can be driven without vg.  Excluded from size / originality claims.
 // handle_graph.hpp — the slice of libhandlegraph's read-only HandleGraph
 // interface that vg's alignment hot path touches (reference: src/handle.hpp:8-40;
 // used by src/aligner.cpp:30-118, src/dozeu_interface.cpp:210-307,
