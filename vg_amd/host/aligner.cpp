@@ -158,6 +158,10 @@ struct Aligner::Job {
     bool has_problem = false; vgk_gssw_problem prob{};
     // banded global jobs (align_global_banded) use the same carrier
     bool banded = false; vgk_banded_problem bprob{}; uint64_t max_cells = 0;
+    // pinned X-drop jobs (align_pinned(..., xdrop = true)): the overlay the pass runs on, the read as the engine sees it, the head position
+    bool xdrop = false, answered = false;
+    std::unique_ptr<DozeuPinningOverlay> overlay; std::string run_seq, run_qual;
+    handle_t head{}; bool have_head = false;
 };
 
 std::unique_ptr<Aligner::Job> Aligner::prepare_job(Alignment& alignment, const HandleGraph& g, bool pinned, bool pin_left, bool traceback_aln) const {
@@ -282,16 +286,48 @@ void Aligner::align_internal(Alignment& alignment, std::vector<Alignment>* multi
 }
 
 // ---- AlignmentBatch: many Aligner calls, one engine launch per kernel family (the deferred-submission shim) -------
-AlignmentBatch::AlignmentBatch(const Aligner& aligner) : aligner(aligner) {}
-AlignmentBatch::~AlignmentBatch() = default;
-void AlignmentBatch::align(Alignment& alignment, const HandleGraph& g, bool traceback_aln) { jobs.push_back(aligner.prepare_job(alignment, g, false, false, traceback_aln)); }
-void AlignmentBatch::align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left) { jobs.push_back(aligner.prepare_job(alignment, g, true, pin_left, true)); }
-void AlignmentBatch::align_global_banded(Alignment& alignment, const HandleGraph& g, int32_t band_padding, bool permissive_banding, uint64_t max_cells) {
-    jobs.push_back(aligner.prepare_banded_job(alignment, g, band_padding, permissive_banding, max_cells));
+AlignmentBatch::AlignmentBatch(const Aligner& aligner, size_t max_pending) : AlignmentBatch(std::vector<const Aligner*>{&aligner}, max_pending) {}
+AlignmentBatch::AlignmentBatch(const std::vector<const Aligner*>& per_device, size_t max_pending) : aligners(per_device), max_pending(max_pending) {
+    if (aligners.empty()) throw std::invalid_argument("AlignmentBatch: no aligner");
+    for (size_t i = 0; i < aligners.size(); ++i) device_mu.emplace_back(new std::mutex());
 }
-size_t AlignmentBatch::size() const { return jobs.size(); }
+AlignmentBatch::~AlignmentBatch() = default;
+void AlignmentBatch::submit(std::unique_ptr<Aligner::Job> job) {
+    std::vector<std::unique_ptr<Aligner::Job>> full; size_t device = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        jobs.push_back(std::move(job));
+        if (max_pending && jobs.size() >= max_pending) { full.swap(jobs); device = next_device++ % aligners.size(); ++in_flight; ++n_flushes; }
+    }
+    if (!full.empty()) run(full, device);            // the submission that filled the batch runs it
+}
+void AlignmentBatch::align(Alignment& alignment, const HandleGraph& g, bool traceback_aln) { submit(aligners[0]->prepare_job(alignment, g, false, false, traceback_aln)); }
+void AlignmentBatch::align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left, bool xdrop, uint16_t xdrop_max_gap_length) {
+    submit(xdrop ? aligners[0]->prepare_xdrop_job(alignment, g, pin_left, xdrop_max_gap_length) : aligners[0]->prepare_job(alignment, g, true, pin_left, true));
+}
+void AlignmentBatch::align_global_banded(Alignment& alignment, const HandleGraph& g, int32_t band_padding, bool permissive_banding, uint64_t max_cells) {
+    submit(aligners[0]->prepare_banded_job(alignment, g, band_padding, permissive_banding, max_cells));
+}
+size_t AlignmentBatch::size() const { std::lock_guard<std::mutex> lk(mu); return jobs.size(); }
 void AlignmentBatch::flush() {
-    std::vector<std::unique_ptr<Aligner::Job>> run; run.swap(jobs);
+    std::vector<std::unique_ptr<Aligner::Job>> mine; size_t device = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!jobs.empty()) { mine.swap(jobs); device = next_device++ % aligners.size(); ++in_flight; ++n_flushes; }
+    }
+    if (!mine.empty()) run(mine, device);
+    std::unique_lock<std::mutex> lk(mu);             // ... and whatever other threads' flushes still have in the engine
+    idle.wait(lk, [this] { return in_flight == 0; });
+    if (failure) { std::exception_ptr f = failure; failure = nullptr; std::rethrow_exception(f); }
+}
+void AlignmentBatch::run(std::vector<std::unique_ptr<Aligner::Job>>& run, size_t device) {
+    struct Done {                                    // in_flight goes down however this ends
+        AlignmentBatch* b; std::exception_ptr err;
+        ~Done() { std::lock_guard<std::mutex> lk(b->mu); if (err && !b->failure) b->failure = err; if (--b->in_flight == 0) b->idle.notify_all(); }
+    } done{this, nullptr};
+    try {
+    const Aligner& aligner = *aligners[device];
+    std::lock_guard<std::mutex> on_device(*device_mu[device]);      // one flush at a time per device; other devices run beside it
     // gssw family
     std::vector<vgk_gssw_problem> probs; std::vector<size_t> owner;
     size_t cap = 0;
@@ -327,8 +363,10 @@ void AlignmentBatch::flush() {
         if (j.banded) { aligner.finish_banded_job(j, rof[i] ? *rof[i] : vgk_result{}, rof[i] ? bops.data() + rof[i]->ops_begin : nullptr); continue; }
         vgk_result r{}; std::vector<vgk_op> o;
         if (rof[i]) { r = *rof[i]; o.assign(ops.begin() + r.ops_begin, ops.begin() + r.ops_begin + r.n_ops); r.ops_begin = 0; }
+        if (j.xdrop) { aligner.finish_xdrop_job(j, r, std::move(o)); continue; }
         aligner.finish_job(j, r, std::move(o), nullptr, 1);
     }
+    } catch (...) { done.err = std::current_exception(); }
 }
 
 void Aligner::align(Alignment& alignment, const HandleGraph& g, bool traceback_aln) const {
@@ -361,10 +399,30 @@ void Aligner::align(Alignment& alignment, const HandleGraph& g, const std::vecto
 void Aligner::align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left, bool xdrop,
                            uint16_t xdrop_max_gap_length) const {
     if (!xdrop) { align_internal(alignment, nullptr, g, true, pin_left, 1, true); return; }
+    auto job = prepare_xdrop_job(alignment, g, pin_left, xdrop_max_gap_length);
+    vgk_result res{}; std::vector<vgk_op> ops;
+    if (job->has_problem) {
+        ops.resize(job->prob.read_len + job->pg.seq.size() + job->pg.order.size() + 4);
+        size_t written = 0;
+        int rc = engine->gssw_align(ctx, &job->prob, 1, &res, ops.data(), ops.size(), &written);
+        if (rc != VGK_OK) throw std::runtime_error(std::string("vgamd: xdrop engine failed: ") + engine->strerror(rc));
+        ops.resize(res.n_ops);
+    }
+    finish_xdrop_job(*job, res, std::move(ops));
+}
+
+// Aligner::align_pinned's xdrop branch (src/aligner.cpp:628-682) + DozeuInterface::align_pinned (src/dozeu_interface.cpp:724-766) up
+// to the engine call: everything that needs only the host.  The job keeps the overlay, the (possibly reversed) read and the
+// packed graph alive until finish_xdrop_job.
+std::unique_ptr<Aligner::Job> Aligner::prepare_xdrop_job(Alignment& alignment, const HandleGraph& g, bool pin_left, uint16_t xdrop_max_gap_length) const {
+    auto job = std::make_unique<Job>();
+    Job& j = *job;
+    j.alignment = &alignment; j.g = &g; j.pinned = true; j.pin_left = pin_left; j.traceback = true; j.xdrop = true;
     // dozeu declines to produce an alignment when the gap is set to 0 (src/aligner.cpp:637-638)
     xdrop_max_gap_length = std::max<uint16_t>(xdrop_max_gap_length, 1);
     // wrap the graph so that empty pinning points are handled correctly (src/aligner.cpp:640-641)
-    DozeuPinningOverlay overlay(&g, !pin_left);
+    j.overlay = std::make_unique<DozeuPinningOverlay>(&g, !pin_left);
+    const DozeuPinningOverlay& overlay = *j.overlay;
     if (overlay.get_node_count() == 0 && g.get_node_count() != 0) {
         // only empty pinning nodes: infer the soft clip from the pinning point (src/aligner.cpp:643-668)
         g.for_each_handle([&](const handle_t& handle) {
@@ -382,125 +440,130 @@ void Aligner::align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_
             }
             return true;
         });
-        return;
+        j.answered = true;
+        return job;
     }
-    xdrop_align_pinned(alignment, overlay, pin_left, scorer->full_length_bonus, xdrop_max_gap_length);
-    if (overlay.performed_duplications()) {
-        // the overlay is not a strict subset of the underlying graph: translate duplicate ids back (src/aligner.cpp:673-680)
-        for (Mapping& m : alignment.path.mapping) {
-            handle_t under = overlay.get_underlying_handle(overlay.get_handle(m.position.node_id));
-            m.position.node_id = g.get_id(under); m.position.is_reverse = g.get_is_reverse(under);
-        }
-    }
-}
-
-void Aligner::xdrop_align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left,
-                                 int8_t /*full_length_bonus: the engine context carries the scorer's bonus*/,
-                                 uint16_t max_gap_length) const {
-    std::vector<handle_t> order = handlealgs::lazier_topological_order(&g);     // lazy_topological_order in the reference (:728)
-    if (order.empty()) return;
+    std::vector<handle_t> order = handlealgs::lazier_topological_order(&overlay);     // lazy_topological_order in the reference (:728)
+    if (order.empty()) { j.answered = true; return job; }
     // The engine extends left to right from every source node.  A right pin is the same problem on the
     // reversed graph and read (dozeu walks the node strings backwards with a reverse-packed query, :178-185, :282-283).
-    ReverseGraph reversed_graph(&g, false);
-    const HandleGraph* run_graph = &g;
-    std::string run_seq = alignment.sequence, run_qual = alignment.quality;
-    if (!pin_left) { run_graph = &reversed_graph; std::reverse(run_seq.begin(), run_seq.end()); std::reverse(run_qual.begin(), run_qual.end()); }
+    const HandleGraph* run_graph = &overlay;
+    j.run_seq = alignment.sequence; j.run_qual = alignment.quality;
+    if (!pin_left) {
+        j.reversed_graph = std::make_unique<ReverseGraph>(&overlay, false);
+        run_graph = j.reversed_graph.get();
+        std::reverse(j.run_seq.begin(), j.run_seq.end()); std::reverse(j.run_qual.begin(), j.run_qual.end());
+    }
     // dozeu sees raw get_sequence(); the packed graph is only a transport for (order, lengths, edges, bases)
     std::vector<handle_t> run_order = handlealgs::lazier_topological_order(run_graph);
-    PackedGraph pg;
+    PackedGraph& pg = j.pg;
     pg.order = run_order;
     std::unordered_map<handle_t, uint32_t, handle_hash> index;
     for (uint32_t i = 0; i < run_order.size(); ++i) index[run_order[i]] = i;
     pg.pred_off.push_back(0);
     for (uint32_t i = 0; i < run_order.size(); ++i) {
-        std::string s = run_graph->get_sequence(run_order[i]);
-        pg.node_len.push_back((uint32_t)s.size()); pg.seq += s;
+        std::string sq = run_graph->get_sequence(run_order[i]);
+        pg.node_len.push_back((uint32_t)sq.size()); pg.seq += sq;
         run_graph->follow_edges_v(run_order[i], true, [&](const handle_t& prev) { auto it = index.find(prev); if (it != index.end()) pg.pred_idx.push_back(it->second); });
         pg.pred_off.push_back((uint32_t)pg.pred_idx.size());
     }
     // head position = first tip in the pin direction in the (forward) order (:738-755); used when nothing aligns
-    handle_t head = order.front(); bool have_head = false;
+    j.head = order.front();
     for (const handle_t& h : order) {
-        if (g.follow_edges(h, pin_left, [](const handle_t&) { return false; })) { head = h; have_head = true; break; }
+        if (overlay.follow_edges(h, pin_left, [](const handle_t&) { return false; })) { j.head = h; j.have_head = true; break; }
     }
-    alignment.clear_path();
-    vgk_result res{}; std::vector<vgk_op> ops;
-    if (!run_seq.empty()) {
-        vgk_gssw_problem prob{};
-        prob.read = run_seq.data(); prob.read_len = (uint32_t)run_seq.size();
-        prob.qual = quality_of(qual_adjusted, run_qual, run_seq.size());
+    if (!j.run_seq.empty()) {
+        vgk_gssw_problem& prob = j.prob;
+        prob.read = j.run_seq.data(); prob.read_len = (uint32_t)j.run_seq.size();
+        prob.qual = quality_of(qual_adjusted, j.run_qual, j.run_seq.size());
         prob.flags = VGK_XDROP_PINNED | VGK_GSSW_TRACEBACK;
-        prob.graph = pg.view(); prob.max_gap_length = max_gap_length;
-        ops.resize(prob.read_len + pg.seq.size() + pg.order.size() + 4);
-        size_t written = 0;
-        int rc = engine->gssw_align(ctx, &prob, 1, &res, ops.data(), ops.size(), &written);
-        if (rc != VGK_OK || res.status != VGK_OK)
-            throw std::runtime_error(std::string("vgamd: xdrop engine failed: ") + engine->strerror(rc ? rc : res.status));
-        ops.resize(res.n_ops);
+        prob.graph = pg.view(); prob.max_gap_length = xdrop_max_gap_length;
+        j.has_problem = true;
     }
+    return job;
+}
+
+// DozeuInterface::calculate_and_save_alignment (src/dozeu_interface.cpp:338-572) + the id translation after duplications
+// (src/aligner.cpp:673-680)
+void Aligner::finish_xdrop_job(Job& j, vgk_result res, std::vector<vgk_op> ops) const {
+    if (j.answered) return;
+    Alignment& alignment = *j.alignment;
+    const DozeuPinningOverlay& g = *j.overlay;          // the graph the pass ran on
+    const bool pin_left = j.pin_left;
+    const PackedGraph& pg = j.pg;
+    if (j.has_problem && res.status != VGK_OK) throw std::runtime_error(std::string("vgamd: xdrop engine failed: ") + engine->strerror(res.status));
+    alignment.clear_path();
     alignment.score = res.score;
     if (res.score == 0 || ops.empty()) {
         // no alignment scoring anything other than 0: full-length insertion at the head (:344-359)
-        if (!have_head) return;
-        alignment.path.mapping.emplace_back();
-        Mapping& m = alignment.path.mapping.back();
-        m.position.node_id = g.get_id(head); m.position.is_reverse = g.get_is_reverse(head);
-        m.position.offset = pin_left ? 0 : (int64_t)g.get_length(head);
-        m.rank = 1;
-        Edit e; e.from_length = 0; e.to_length = (int32_t)alignment.sequence.size(); e.sequence = alignment.sequence;
-        m.edit.push_back(e);
-        return;
-    }
-    if (!pin_left) unreverse_ops(ops, res, pg.node_len);
-    // dozeu path -> vg Path (calculate_and_save_alignment): matches merged, every mismatching base its own edit,
-    // the unaligned read end an insertion (merged into a leading insertion, separate when trailing)
-    const std::string& query = alignment.sequence;
-    size_t to_pos = 0, matches = 0;
-    int from_pos = res.first_offset;
-    uint32_t i = 0; bool first_node = true;
-    while (i < ops.size()) {
-        uint32_t node = ops[i].node, j = i;
-        while (j < ops.size() && ops[j].node == node) ++j;
-        const handle_t h = pg.order[node];
-        const std::string node_seq = g.get_sequence(h);
-        alignment.path.mapping.emplace_back();
-        Mapping& mapping = alignment.path.mapping.back();
-        if (!first_node) from_pos = 0;
-        first_node = false;
-        mapping.position.node_id = g.get_id(h); mapping.position.is_reverse = g.get_is_reverse(h);
-        mapping.position.offset = from_pos; mapping.rank = (int64_t)alignment.path.mapping.size();
-        for (uint32_t k = i; k < j; ++k) {
-            const int32_t len = ops[k].len;
-            switch (ops[k].op) {
-                case VGK_OP_M: {
-                    int run = 0;
-                    for (int t = 0; t < len; ++t) {
-                        if (node_seq[from_pos + t] == query[to_pos + t]) { ++run; ++matches; }
-                        else {
-                            if (run) { Edit e; e.from_length = e.to_length = run; mapping.edit.push_back(e); run = 0; }
-                            Edit e; e.from_length = e.to_length = 1; e.sequence = query.substr(to_pos + t, 1); mapping.edit.push_back(e);
-                        }
-                    }
-                    if (run) { Edit e; e.from_length = e.to_length = run; mapping.edit.push_back(e); }
-                    from_pos += len; to_pos += len;
-                } break;
-                case VGK_OP_D: { Edit e; e.from_length = len; e.to_length = 0; mapping.edit.push_back(e); from_pos += len; } break;
-                case VGK_OP_I:
-                case VGK_OP_S: {
-                    // a leading clip merges with an adjacent path insertion (state machine of :498-507); a trailing one is pushed on its own (:520-526)
-                    const bool merge_prev = !mapping.edit.empty() && edit_is_insertion(mapping.edit.back()) &&
-                                            !(ops[k].op == VGK_OP_S && k + 1 == ops.size());
-                    if (merge_prev) { Edit& e = mapping.edit.back(); e.to_length += len; e.sequence += query.substr(to_pos, len); }
-                    else { Edit e; e.from_length = 0; e.to_length = len; e.sequence = query.substr(to_pos, len); mapping.edit.push_back(e); }
-                    to_pos += len;
-                } break;
-                default: throw std::runtime_error("vgamd: unsupported cigar op from engine");
-            }
+        if (j.have_head) {
+            alignment.path.mapping.emplace_back();
+            Mapping& m = alignment.path.mapping.back();
+            m.position.node_id = g.get_id(j.head); m.position.is_reverse = g.get_is_reverse(j.head);
+            m.position.offset = pin_left ? 0 : (int64_t)g.get_length(j.head);
+            m.rank = 1;
+            Edit e; e.from_length = 0; e.to_length = (int32_t)alignment.sequence.size(); e.sequence = alignment.sequence;
+            m.edit.push_back(e);
         }
-        i = j;
+    } else {
+        if (!pin_left) unreverse_ops(ops, res, pg.node_len);
+        // dozeu path -> vg Path (calculate_and_save_alignment): matches merged, every mismatching base its own edit,
+        // the unaligned read end an insertion (merged into a leading insertion, separate when trailing)
+        const std::string& query = alignment.sequence;
+        size_t to_pos = 0, matches = 0;
+        int from_pos = res.first_offset;
+        uint32_t i = 0; bool first_node = true;
+        while (i < ops.size()) {
+            uint32_t node = ops[i].node, j = i;
+            while (j < ops.size() && ops[j].node == node) ++j;
+            const handle_t h = pg.order[node];
+            const std::string node_seq = g.get_sequence(h);
+            alignment.path.mapping.emplace_back();
+            Mapping& mapping = alignment.path.mapping.back();
+            if (!first_node) from_pos = 0;
+            first_node = false;
+            mapping.position.node_id = g.get_id(h); mapping.position.is_reverse = g.get_is_reverse(h);
+            mapping.position.offset = from_pos; mapping.rank = (int64_t)alignment.path.mapping.size();
+            for (uint32_t k = i; k < j; ++k) {
+                const int32_t len = ops[k].len;
+                switch (ops[k].op) {
+                    case VGK_OP_M: {
+                        int run = 0;
+                        for (int t = 0; t < len; ++t) {
+                            if (node_seq[from_pos + t] == query[to_pos + t]) { ++run; ++matches; }
+                            else {
+                                if (run) { Edit e; e.from_length = e.to_length = run; mapping.edit.push_back(e); run = 0; }
+                                Edit e; e.from_length = e.to_length = 1; e.sequence = query.substr(to_pos + t, 1); mapping.edit.push_back(e);
+                            }
+                        }
+                        if (run) { Edit e; e.from_length = e.to_length = run; mapping.edit.push_back(e); }
+                        from_pos += len; to_pos += len;
+                    } break;
+                    case VGK_OP_D: { Edit e; e.from_length = len; e.to_length = 0; mapping.edit.push_back(e); from_pos += len; } break;
+                    case VGK_OP_I:
+                    case VGK_OP_S: {
+                        // a leading clip merges with an adjacent path insertion (state machine of :498-507); a trailing one is pushed on its own (:520-526)
+                        const bool merge_prev = !mapping.edit.empty() && edit_is_insertion(mapping.edit.back()) &&
+                                                !(ops[k].op == VGK_OP_S && k + 1 == ops.size());
+                        if (merge_prev) { Edit& e = mapping.edit.back(); e.to_length += len; e.sequence += query.substr(to_pos, len); }
+                        else { Edit e; e.from_length = 0; e.to_length = len; e.sequence = query.substr(to_pos, len); mapping.edit.push_back(e); }
+                        to_pos += len;
+                    } break;
+                    default: throw std::runtime_error("vgamd: unsupported cigar op from engine");
+                }
+            }
+            i = j;
+        }
+        alignment.identity = query.empty() ? 0.0 : (double)matches / (double)query.size();
+        alignment.query_position = 0;
     }
-    alignment.identity = query.empty() ? 0.0 : (double)matches / (double)query.size();
-    alignment.query_position = 0;
+    if (g.performed_duplications()) {
+        // the overlay is not a strict subset of the underlying graph: translate duplicate ids back (src/aligner.cpp:673-680)
+        for (Mapping& m : alignment.path.mapping) {
+            handle_t under = g.get_underlying_handle(g.get_handle(m.position.node_id));
+            m.position.node_id = j.g->get_id(under); m.position.is_reverse = j.g->get_is_reverse(under);
+        }
+    }
 }
 
 void Aligner::align_pinned_multi(Alignment& alignment, std::vector<Alignment>& alt_alignments, const HandleGraph& g,

@@ -6,7 +6,10 @@
 // parity tests read like src/unittest/{aligner,pinned_alignment}.cpp.
 #pragma once
 #include <limits>
+#include <condition_variable>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <unordered_set>
 #include <vector>
@@ -175,6 +178,10 @@ public:
     void finish_job(Job& job, vgk_result res, std::vector<vgk_op> ops, std::vector<Alignment>* multi_alignments, int32_t max_alt_alns) const;
     std::unique_ptr<Job> prepare_banded_job(Alignment& alignment, const HandleGraph& g, int32_t band_padding, bool permissive_banding, uint64_t max_cells) const;
     void finish_banded_job(Job& job, const vgk_result& res, const vgk_op* ops) const;
+    // align_pinned(..., xdrop = true) split the same way: DozeuPinningOverlay + DozeuInterface::align_pinned up to the engine call
+    // (src/aligner.cpp:628-682, src/dozeu_interface.cpp:724-766), then calculate_and_save_alignment + the id translation (:338-572)
+    std::unique_ptr<Job> prepare_xdrop_job(Alignment& alignment, const HandleGraph& g, bool pin_left, uint16_t xdrop_max_gap_length) const;
+    void finish_xdrop_job(Job& job, vgk_result res, std::vector<vgk_op> ops) const;
 
 private:
     // one pinned X-drop extension from an interior graph position (node index in `order`, offset in that node)
@@ -192,9 +199,6 @@ private:
                            bool traceback, uint16_t max_gap_length) const;
     void align_internal(Alignment& alignment, std::vector<Alignment>* multi_alignments, const HandleGraph& g,
                         bool pinned, bool pin_left, int32_t max_alt_alns, bool traceback_aln) const;
-    // DozeuInterface::align_pinned + calculate_and_save_alignment (src/dozeu_interface.cpp:724-766, 338-572)
-    void xdrop_align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left,
-                            int8_t full_length_bonus, uint16_t max_gap_length) const;
 };
 
 // QualAdjAligner (reference: src/aligner.hpp:218-258, src/aligner.cpp:859-1348): the same calls with scores and
@@ -212,23 +216,40 @@ private:
     QualAdjAligner(QualAdjAlignmentScorer* owned, std::shared_ptr<EngineApi> engine, int device);
 };
 
-// Deferred submission: giraffe / map call the aligner once per read from many threads, the engine wants thousands of
-// problems per launch.  An AlignmentBatch takes the same calls, keeps the prepared problems, and flush() runs them in one engine call
-// per kernel family and fills every Alignment exactly as the direct call would have.  The Alignment objects and the graphs must
-// stay alive until flush().  Not thread-safe: one batch per submitting thread, or an external lock.
+// Deferred submission: giraffe / map call the aligner once per read from many OpenMP threads
+// (src/subcommand/giraffe_main.cpp:2416-2471), the engine wants thousands of problems per launch.  An AlignmentBatch takes the same
+// calls from any number of threads, keeps the prepared problems, and a flush runs them in one engine call per kernel family and
+// fills every Alignment exactly as the direct call would have.  The Alignment objects and the graphs must stay alive until the
+// flush that runs them has returned.
+//   * submission is thread-safe (the host-side preparation of a problem runs on the submitting thread, outside the lock);
+//   * `max_pending` > 0: the submission that makes the batch that large flushes it (on the submitting thread);
+//   * several devices: one Aligner (= one engine context) per device, successive flushes go to them in turn, and flushes on
+//     different devices run concurrently when different threads trigger them (vg is ONE process with many threads: this is the
+//     multi-GPU path inside it; bench.py's one-process-per-GPU sharding is the other);
+//   * flush() returns when everything submitted before it — by any thread — has been answered.
 class AlignmentBatch {
 public:
-    explicit AlignmentBatch(const Aligner& aligner);
+    explicit AlignmentBatch(const Aligner& aligner, size_t max_pending = 0);
+    AlignmentBatch(const std::vector<const Aligner*>& per_device, size_t max_pending = 0);      // same scoring on every one
     ~AlignmentBatch();
     void align(Alignment& alignment, const HandleGraph& g, bool traceback_aln);
-    void align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left);
+    void align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left, bool xdrop = false,
+                      uint16_t xdrop_max_gap_length = default_xdrop_max_gap_length);
     void align_global_banded(Alignment& alignment, const HandleGraph& g, int32_t band_padding = 0, bool permissive_banding = true,
                              uint64_t max_cells = std::numeric_limits<uint64_t>::max());
     size_t size() const;
+    size_t flushes() const { return n_flushes; }
     void flush();
 private:
-    const Aligner& aligner;
+    void submit(std::unique_ptr<Aligner::Job> job);
+    void run(std::vector<std::unique_ptr<Aligner::Job>>& jobs, size_t device);
+    std::vector<const Aligner*> aligners;
+    size_t max_pending;
+    mutable std::mutex mu; std::condition_variable idle;
     std::vector<std::unique_ptr<Aligner::Job>> jobs;
+    std::vector<std::unique_ptr<std::mutex>> device_mu;
+    size_t next_device = 0, in_flight = 0, n_flushes = 0;
+    std::exception_ptr failure;
 };
 
 // nonATGCNtoN (reference: src/utility.cpp:323-332)

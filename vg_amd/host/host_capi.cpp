@@ -1,6 +1,7 @@
 // host_capi.cpp — a small C surface over the C++ host shim so that other
 // languages (the pytest suite via ctypes, or a future binding) can drive the
 // mirrored Aligner interface exactly like src/unittest/*.cpp drives vg's.
+#include <algorithm>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -151,8 +152,18 @@ int vgh_align_xdrop(vgh_aligner* a, vgh_graph* g, const char* read, const int64_
 // ---- AlignmentBatch: the same calls, deferred; one engine launch per kernel family at flush ------------------------------------------
 struct vgh_batch { std::unique_ptr<AlignmentBatch> b; std::deque<Alignment> alns; };
 vgh_batch* vgh_batch_create(vgh_aligner* a) { auto* h = new vgh_batch(); h->b = std::make_unique<AlignmentBatch>(*a->a); return h; }
+// one aligner (engine context) per device, flushes go to them in turn; max_pending > 0: the submission that fills the batch flushes it
+vgh_batch* vgh_batch_create_multi(vgh_aligner** aligners, int n, int max_pending) {
+    try {
+        std::vector<const Aligner*> per_device;
+        for (int i = 0; i < n; ++i) per_device.push_back(aligners[i]->a.get());
+        auto* h = new vgh_batch(); h->b = std::make_unique<AlignmentBatch>(per_device, (size_t)std::max(max_pending, 0)); return h;
+    } catch (std::exception& e) { g_last_error = e.what(); return nullptr; }
+}
+int vgh_batch_flushes(vgh_batch* b) { return (int)b->b->flushes(); }
 void vgh_batch_destroy(vgh_batch* b) { delete b; }
-// call codes as in vgh_align: 0 align(traceback), 1 align(score only), 2 align_pinned, 5 align_global_banded(band_padding = arg, permissive = pin_left)
+// call codes as in vgh_align: 0 align(traceback), 1 align(score only), 2 align_pinned, 4 align_pinned(xdrop = true, max_gap = arg),
+// 5 align_global_banded(band_padding = arg, permissive = pin_left)
 int vgh_batch_add(vgh_batch* b, vgh_graph* g, const char* read, const uint8_t* qual, int call, int pin_left, int arg) {
     try {
         b->alns.emplace_back();
@@ -162,6 +173,7 @@ int vgh_batch_add(vgh_batch* b, vgh_graph* g, const char* read, const uint8_t* q
             case 0: b->b->align(aln, g->g, true); break;
             case 1: b->b->align(aln, g->g, false); break;
             case 2: b->b->align_pinned(aln, g->g, pin_left != 0); break;
+            case 4: b->b->align_pinned(aln, g->g, pin_left != 0, true, (uint16_t)arg); break;
             case 5: b->b->align_global_banded(aln, g->g, arg, pin_left != 0); break;
             default: b->alns.pop_back(); g_last_error = "unknown call"; return -1;
         }
