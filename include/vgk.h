@@ -308,6 +308,7 @@ int  vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_
                         size_t written[3] /* extensions, nodes, mismatches */);
 int    vgk_gapless_rerun(vgk_ctx* ctx);      /* launch the kernel of the last vgk_gapless_extend call again on its resident inputs */
 double vgk_gapless_last_ms(vgk_ctx* ctx);    /* kernel time of the last vgk_gapless_extend call on this context */
+uint64_t vgk_gapless_last_retried(vgk_ctx* ctx);   /* reads of that call whose search outgrew the fast (in-LDS) kernel and ran in the slab kernel */
 
 /* ---- haplotype-consistent wavefront alignment (WFAExtender, src/gbwt_extender.cpp:2052-2263) ------------
  * Replaces WFAExtender::connect(sequence, from, to), ::suffix(sequence, from) and ::prefix(sequence, to)

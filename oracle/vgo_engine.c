@@ -216,6 +216,7 @@ double vgk_banded_last(vgk_ctx* ctx, int which) { (void)ctx; (void)which; return
 int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* haplotypes, vgk_haplo** out) { (void)ctx; return vgo_haplo_create(haplotypes, out); }
 void vgk_haplo_destroy(vgk_haplo* index) { vgo_haplo_destroy(index); }
 double vgk_gapless_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }
+uint64_t vgk_gapless_last_retried(vgk_ctx* ctx) { (void)ctx; return 0; }
 int vgk_gapless_rerun(vgk_ctx* ctx) { (void)ctx; return VGK_EINVAL; }     /* nothing is resident on the CPU */
 int vgk_banded_rerun(vgk_ctx* ctx) { (void)ctx; return VGK_EINVAL; }
 int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_problem* problems, uint32_t n,

@@ -60,7 +60,13 @@ public:
         return VGK_OK;
     }
     int run_gapless(const GaplessParams& P, uint32_t threads) override {
-        for (uint32_t t = 0; t < threads; ++t) for (uint32_t i = t; i < P.n; i += threads) gapless_extend_one(P, i, P.scratch[t], P.cold[t]);
+        // the fast store first (here a plain local array, stride 1), then the slab store for the reads that outgrew it — as on the device
+        const bool slab_only = std::getenv("VGAMD_GAPLESS_SLAB_ONLY") != nullptr;
+        std::vector<uint32_t> lds(G_FAST_DW);
+        for (uint32_t t = 0; t < threads; ++t) for (uint32_t i = t; i < P.n; i += threads) {
+            if (!slab_only) { GStoreLds Q{lds.data(), 1u, P.scratch[t], 0u}; gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]); }
+            if (slab_only || P.results[i].status == G_RETRY) { GStoreSlab Q{P.scratch[t]}; gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]); }
+        }
         return VGK_OK;
     }
     int run_banded(const BandedParams& P, const BandedLaunch* launches, uint32_t n) override {

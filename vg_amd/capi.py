@@ -360,6 +360,11 @@ class Engine:
     def gapless_last_ms(self):
         return self.lib.vgk_gapless_last_ms(self.h)
 
+    def gapless_last_retried(self):
+        self.lib.vgk_gapless_last_retried.restype = ctypes.c_uint64
+        self.lib.vgk_gapless_last_retried.argtypes = [ctypes.c_void_p]
+        return self.lib.vgk_gapless_last_retried(self.h)
+
     def wfa_extend(self, index, problems, error_model=None):
         """problems: a WfaSet, or a list of dicts {seq, mode: "connect"|"suffix"|"prefix", from: (oriented node, offset),
         to: (oriented node, offset)}; error_model: four (per_base, min, max) rows or None for the reference's default.

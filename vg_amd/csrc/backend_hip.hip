@@ -201,10 +201,24 @@ __global__ void __launch_bounds__(64) banded_walk_kernel(const BandedParams P) {
 }
 
 // ---- gapless extension (gapless_device.hpp): resident threads stride over the reads, one scratch slab per thread
-__global__ void __launch_bounds__(64, 4) gapless_kernel(const GaplessParams P, const uint32_t threads) {
+// Two passes.  The fast kernel keeps the queue of a seed's search in LDS (lane-interleaved dwords: no bank conflicts,
+// no HBM traffic; 35 dwords per thread) and only the write-once path links in the thread's slab; a search whose queue outgrows the LDS slots marks its read
+// G_RETRY and the slab kernel (the whole search in the thread's 11 KB HBM slab, round 1's kernel) runs exactly those reads again.
+__global__ void __launch_bounds__(64, 4) gapless_kernel(const GaplessParams P, const uint32_t threads, const int retry_only) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t >= threads) return;
-    for (uint32_t i = t; i < P.n; i += threads) gapless_extend_one(P, i, P.scratch[t], P.cold[t]);
+    GStoreSlab Q{P.scratch[t]};
+    for (uint32_t i = t; i < P.n; i += threads) {
+        if (retry_only && P.results[i].status != G_RETRY) continue;
+        gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]);
+    }
+}
+__global__ void __launch_bounds__(64) gapless_fast_kernel(const GaplessParams P, const uint32_t threads) {
+    __shared__ uint32_t lds[64 * G_FAST_DW];
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= threads) return;
+    GStoreLds Q{lds + threadIdx.x, 64u, P.scratch[t], 0u};
+    for (uint32_t i = t; i < P.n; i += threads) gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]);
 }
 
 // ---- wavefront alignment (wfa_device.hpp): the same launch shape
@@ -419,7 +433,11 @@ public:
         ms_gapless = 0.f;
         if (!p.n || !threads) return VGK_OK;
         hipEventRecord(bev[0], stream);
-        hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads);
+        if (std::getenv("VGAMD_GAPLESS_SLAB_ONLY")) hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads, 0);
+        else {
+            hipLaunchKernelGGL(gapless_fast_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads);
+            hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads, 1);
+        }
         hipEventRecord(bev[1], stream);
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         hipEventElapsedTime(&ms_gapless, bev[0], bev[1]);

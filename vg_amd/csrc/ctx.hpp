@@ -30,6 +30,7 @@ struct vgk_ctx {
     // last vgk_banded_align call: kernel times (ms), band cells, algorithmic bytes
     double banded_ms[2] = {0, 0}; uint64_t banded_cells = 0, banded_bytes = 0;
     double gapless_ms = 0;         // kernel time of the last vgk_gapless_extend call
+    uint64_t gapless_retried = 0;  // reads of that call whose search outgrew the fast kernel's LDS store and ran in the slab kernel
     double wfa_ms = 0;             // and of the last vgk_wfa_extend call
     // the last batch of either call stays resident in the cached device buffers: what a re-run needs to launch it again
     vgk::BandedParams banded_last{}; std::vector<vgk::BandedLaunch> banded_last_launches; bool banded_last_valid = false;

@@ -162,6 +162,8 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     int rc;
     h->dev.n_oriented = O; h->dev.strand_shift = (uint32_t)total;
+    h->dev.max_node_len = 0; h->dev.max_visits = 0;          // what the fast kernel's compact entries have to hold (gapless_device.hpp)
+    for (uint32_t o = 0; o < O; ++o) { h->dev.max_node_len = std::max(h->dev.max_node_len, len[o]); h->dev.max_visits = std::max(h->dev.max_visits, count[o]); }
     if ((rc = put(h, rec_off, h->dev.rec_off)) || (rc = put(h, rec, h->dev.rec)) || (rc = put(h, seq, h->dev.seq)) || (rc = ctx->be->sync())) {
         for (void* p : h->held) ctx->be->release(p);
         delete h; return rc;
@@ -242,7 +244,7 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     if ((rc = be->zero(P.counters, 64))) return cleanup(rc);
     if ((rc = be->run_gapless(P, threads))) return cleanup(rc);
     ctx->gapless_last = P; ctx->gapless_last_threads = threads; ctx->gapless_last_valid = true;
-    unsigned long long counters[3] = {0, 0, 0};
+    unsigned long long counters[4] = {0, 0, 0, 0};
     vgk_gapless_result* dres = H.dres.get(be, n);
     if (!dres) return cleanup(VGK_ENOMEM);
     if ((rc = be->download(counters, P.counters, sizeof counters))) return cleanup(rc);
@@ -253,7 +255,7 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     if (ne && (rc = be->download(dext, P.ext, sizeof(vgk_extension) * ne))) return cleanup(rc);
     if (nn && (rc = be->download(dnodes, P.nodes, sizeof(uint32_t) * nn))) return cleanup(rc);
     if (nm && (rc = be->download(dmism, P.mism, sizeof(uint32_t) * nm))) return cleanup(rc);
-    ctx->gapless_ms = be->last_ms(5);
+    ctx->gapless_ms = be->last_ms(5); ctx->gapless_retried = counters[3];
     // the device packs sets in completion order; hand them back in problem order: sizes, a prefix sum, then parallel copies
     std::vector<uint64_t> oe(n + 1, 0), on(n + 1, 0), om(n + 1, 0);
     parallel_for(n, [&](uint32_t i, unsigned) {
@@ -304,5 +306,6 @@ int vgk_gapless_rerun(vgk_ctx* ctx) {
 }
 
 double vgk_gapless_last_ms(vgk_ctx* ctx) { return ctx ? ctx->gapless_ms : 0.0; }
+uint64_t vgk_gapless_last_retried(vgk_ctx* ctx) { return ctx ? ctx->gapless_retried : 0; }
 
 }  // extern "C"

@@ -31,6 +31,7 @@ struct GIndex {                       // device pointers
     const uint32_t* rec;
     uint32_t        strand_shift;     // offset of a node's reverse-complement bases = offset of its forward bases + strand_shift
     const char*     seq;              // forward strands, then reverse complements (8 bytes of padding at either end)
+    uint32_t        max_node_len, max_visits;      // over the whole index: what the compact in-LDS entries of the fast kernel can hold
 };
 VGK_HD const uint32_t* g_rec(const GIndex& h, uint32_t o) { return h.rec + h.rec_off[o]; }
 VGK_HD uint32_t g_len(const GIndex& h, int32_t o) { return g_rec(h, (uint32_t)o)[2]; }
@@ -183,7 +184,7 @@ struct GaplessParams {
     GCold*    cold;                   // likewise
     vgk_gapless_result* results;      // per problem (ext_begin indexes `ext`)
     vgk_extension* ext; uint32_t* nodes; uint32_t* mism;
-    unsigned long long* counters;     // [0] extensions, [1] nodes, [2] mismatches handed out
+    unsigned long long* counters;     // [0] extensions, [1] nodes, [2] mismatches handed out, [3] reads the fast kernel passed on to the slab kernel
     unsigned long long caps[3];
 };
 
@@ -236,41 +237,126 @@ VGK_HD void g_set_score(const GCtx& c, GEntry& e) {                             
             + e.left_full * c.P->bonus + e.right_full * c.P->bonus;
 }
 // The queue orders (score, insertion number) — highest score first, the later insertion among equals (:567-571).  Its keys
-// carry both and the pool index, so sifting touches only the small key array, never the pool entries themselves.
+// carry both and an index, so sifting touches only the small key array, never the entries themselves.
 VGK_HD uint64_t g_key(const GEntry& e, uint32_t idx) { return ((uint64_t)((uint32_t)e.score ^ 0x80000000u) << 32) | ((uint64_t)e.number << 16) | idx; }
-VGK_HD void g_heap_push(GScratch& s, uint32_t& hn, const GEntry& e, uint16_t idx) {
-    const uint64_t key = g_key(e, idx);
-    s.pool[idx] = g_pack(e);                                       // it will be popped from the slab
-    uint32_t i = hn++;
-    while (i) { const uint32_t p = (i - 1) / 2; if (s.heap[p] >= key) break; s.heap[i] = s.heap[p]; i = p; }
-    s.heap[i] = key;
-}
 VGK_HD GLink g_link(const GEntry& e) { GLink l; l.node = e.node; l.parent = (int16_t)e.parent; l.front = e.front; l.pad = 0; return l; }
-// a new entry: the better of it and the held-back candidate stays in registers, the other one goes to the queue
-VGK_HD void g_offer(GScratch& s, uint32_t& hn, bool& have_cand, GEntry& cand, uint16_t& cand_idx, const GEntry& e, uint16_t idx) {
-    if (!have_cand) { cand = e; cand_idx = idx; have_cand = true; }
-    else if (g_key(e, idx) > g_key(cand, cand_idx)) { g_heap_push(s, hn, cand, cand_idx); cand = e; cand_idx = idx; }
-    else g_heap_push(s, hn, e, idx);
+
+// ---- where a seed's search keeps its state ------------------------------------------------------------------------------
+// Two stores behind one interface.  GStoreSlab: everything in the per-thread slab in HBM (round 1's layout; an entry that waits in
+// the queue sits at its own index: 40 bytes x 160).  GStoreLds, the fast kernel's: the QUEUE — the partial extensions that wait while
+// a better one is being extended, rarely more than three — in LDS, lane-interleaved dwords, an entry packed into 20 bytes (which
+// needs reads and nodes of at most 255 bases and at most 254 visits per node); the path links stay in the slab, where they are
+// 8 bytes written once, behind each other, and read once for the winner.  What made the slab kernel move 42 x its algorithmic
+// bytes was the queue: 40-byte entries and 8-byte keys scattered over an 11 KB slab per thread, 2.9 GB over the resident threads.
+// A search whose queue outgrows the LDS slots makes the read G_RETRY: the slab kernel runs it again.
+// Index field of a queue key: entry number in the low byte, slot in the byte above.
+constexpr int32_t  G_RETRY = 1;                  // vgk_gapless_result::status of a read the fast kernel hands to the slab kernel
+#ifndef VGK_GAPLESS_FAST_QUEUE
+#define VGK_GAPLESS_FAST_QUEUE 5
+#endif
+constexpr uint32_t G_FAST_QUEUE = VGK_GAPLESS_FAST_QUEUE;       // at most 32
+constexpr uint32_t G_FAST_DW = 2 * G_FAST_QUEUE + 5 * G_FAST_QUEUE;      // dwords of LDS per thread
+
+struct GStoreSlab {
+    GScratch& s;
+    static constexpr uint32_t ENTRIES = (uint32_t)G_POOL;
+    static constexpr int32_t  FULL = VGK_ETOOBIG;
+    VGK_HD void begin_seed() {}
+    VGK_HD uint64_t heap_get(uint32_t i) const { return s.heap[i]; }
+    VGK_HD void heap_set(uint32_t i, uint64_t k) { s.heap[i] = k; }
+    VGK_HD bool slot_take(uint32_t entry, uint32_t& idx) { idx = entry; return true; }
+    VGK_HD void slot_free(uint32_t) {}
+    VGK_HD uint32_t entry_of(uint32_t idx) const { return idx; }
+    VGK_HD void pool_set(uint32_t idx, const GEntry& e) { s.pool[idx] = g_pack(e); }
+    VGK_HD GEntry pool_get(const GCtx&, uint32_t idx, uint64_t) const { return g_unpack(s.pool[idx]); }
+    VGK_HD void link_set(uint32_t i, const GEntry& e) { s.link[i] = g_link(e); }
+    VGK_HD GLink link_get(uint32_t i) const { return s.link[i]; }
+};
+
+struct GStoreLds {
+    uint32_t* base; uint32_t stride;             // dword k of this thread = base[k * stride]
+    GScratch& s;                                 // the thread's slab: path links only
+    uint32_t free_slots;
+    static constexpr uint32_t ENTRIES = (uint32_t)G_POOL;
+    static constexpr int32_t  FULL = G_RETRY;
+    static constexpr uint32_t HEAP0 = 0, POOL0 = 2 * G_FAST_QUEUE;
+    VGK_HD uint32_t& dw(uint32_t k) const { return base[k * stride]; }
+    VGK_HD void begin_seed() { free_slots = (1u << G_FAST_QUEUE) - 1u; }
+    VGK_HD uint64_t heap_get(uint32_t i) const { return (uint64_t)dw(HEAP0 + 2 * i) | ((uint64_t)dw(HEAP0 + 2 * i + 1) << 32); }
+    VGK_HD void heap_set(uint32_t i, uint64_t k) { dw(HEAP0 + 2 * i) = (uint32_t)k; dw(HEAP0 + 2 * i + 1) = (uint32_t)(k >> 32); }
+    VGK_HD bool slot_take(uint32_t entry, uint32_t& idx) {
+        if (!free_slots) return false;
+        uint32_t slot = 0; while (!((free_slots >> slot) & 1u)) ++slot;
+        free_slots &= ~(1u << slot); idx = (slot << 8) | entry; return true;
+    }
+    VGK_HD void slot_free(uint32_t idx) { free_slots |= 1u << (idx >> 8); }
+    VGK_HD uint32_t entry_of(uint32_t idx) const { return idx & 0xffu; }
+    // 20 bytes: offset r0 r1 internal | old flags score16 | fn | bn | flo fhi blo bhi (an empty range is [1, 0])
+    VGK_HD void pool_set(uint32_t idx, const GEntry& e) {
+        const uint32_t k = POOL0 + 5 * (idx >> 8);
+        const uint32_t flags = (uint32_t)(e.front | (e.left_full << 1) | (e.right_full << 2) | (e.left_max << 3) | (e.right_max << 4));
+        const bool fe = e.state.flo > e.state.fhi, be = e.state.blo > e.state.bhi;
+        dw(k) = e.offset | (e.r0 << 8) | (e.r1 << 16) | (e.internal << 24);
+        dw(k + 1) = e.old | (flags << 8) | ((uint32_t)(uint16_t)(int16_t)e.score << 16);
+        dw(k + 2) = (uint32_t)e.state.fn; dw(k + 3) = (uint32_t)e.state.bn;
+        dw(k + 4) = (fe ? 1u : (uint32_t)e.state.flo) | ((fe ? 0u : (uint32_t)e.state.fhi) << 8) | ((be ? 1u : (uint32_t)e.state.blo) << 16) | ((be ? 0u : (uint32_t)e.state.bhi) << 24);
+    }
+    VGK_HD GEntry pool_get(const GCtx&, uint32_t idx, uint64_t key) const {
+        const uint32_t k = POOL0 + 5 * (idx >> 8);
+        const uint32_t a = dw(k), b = dw(k + 1), r = dw(k + 4);
+        GEntry e;
+        e.parent = -1; e.node = -1; e.number = (uint32_t)(key >> 16) & 0xffffu;
+        e.offset = a & 0xffu; e.r0 = (a >> 8) & 0xffu; e.r1 = (a >> 16) & 0xffu; e.internal = a >> 24;
+        e.old = b & 0xffu; const uint32_t fl = (b >> 8) & 0xffu; e.score = (int32_t)(int16_t)(uint16_t)(b >> 16);
+        e.front = fl & 1; e.left_full = (fl >> 1) & 1; e.right_full = (fl >> 2) & 1; e.left_max = (fl >> 3) & 1; e.right_max = (fl >> 4) & 1;
+        e.pad[0] = e.pad[1] = e.pad[2] = 0; e.frec = e.brec = G_NO_REC;
+        e.state.fn = (int32_t)dw(k + 2); e.state.bn = (int32_t)dw(k + 3);
+        const uint32_t flo = r & 0xffu, fhi = (r >> 8) & 0xffu, blo = (r >> 16) & 0xffu, bhi = r >> 24;
+        const bool fe = flo > fhi, be = blo > bhi;
+        e.state.flo = fe ? 0 : (int32_t)flo; e.state.fhi = fe ? -1 : (int32_t)fhi; e.state.blo = be ? 0 : (int32_t)blo; e.state.bhi = be ? -1 : (int32_t)bhi;
+        return e;
+    }
+    VGK_HD void link_set(uint32_t i, const GEntry& e) { s.link[i] = g_link(e); }
+    VGK_HD GLink link_get(uint32_t i) const { return s.link[i]; }
+};
+
+template <class ST> VGK_HD bool g_heap_push(ST& S, uint32_t& hn, const GEntry& e, uint32_t entry) {
+    uint32_t idx;
+    if (!S.slot_take(entry, idx)) return false;
+    const uint64_t key = g_key(e, idx);
+    S.pool_set(idx, e);                                            // it will be popped from the store
+    uint32_t i = hn++;
+    while (i) { const uint32_t p = (i - 1) / 2; const uint64_t pk = S.heap_get(p); if (pk >= key) break; S.heap_set(i, pk); i = p; }
+    S.heap_set(i, key);
+    return true;
 }
-VGK_HD uint16_t g_heap_pop(GScratch& s, uint32_t& hn) {
-    const uint16_t top = (uint16_t)(s.heap[0] & 0xffffu);
-    const uint64_t last = s.heap[--hn];
+// a new entry: the better of it and the held-back candidate stays in registers, the other one goes to the queue
+template <class ST> VGK_HD bool g_offer(ST& S, uint32_t& hn, bool& have_cand, GEntry& cand, uint32_t& cand_idx, const GEntry& e, uint32_t idx) {
+    if (!have_cand) { cand = e; cand_idx = idx; have_cand = true; return true; }
+    if (g_key(e, idx) > g_key(cand, cand_idx)) { const bool ok = g_heap_push(S, hn, cand, cand_idx); cand = e; cand_idx = idx; return ok; }
+    return g_heap_push(S, hn, e, idx);
+}
+template <class ST> VGK_HD uint64_t g_heap_pop(ST& S, uint32_t& hn) {
+    const uint64_t top = S.heap_get(0);
+    const uint64_t last = S.heap_get(--hn);
     uint32_t i = 0;
     for (;;) {
         const uint32_t l = 2 * i + 1, r = l + 1;
         if (l >= hn) break;
-        const uint32_t m = (r < hn && s.heap[r] > s.heap[l]) ? r : l;
-        if (s.heap[m] <= last) break;
-        s.heap[i] = s.heap[m]; i = m;
+        const uint64_t kl = S.heap_get(l), kr = r < hn ? S.heap_get(r) : 0;
+        const uint32_t m = (r < hn && kr > kl) ? r : l; const uint64_t km = m == r ? kr : kl;
+        if (km <= last) break;
+        S.heap_set(i, km); i = m;
     }
-    if (hn) s.heap[i] = last;
+    if (hn) S.heap_set(i, last);
     return top;
 }
-// path of a pool entry, front to back; returns its length or -1 when it does not fit
-VGK_HD int g_path(const GScratch& s, int32_t idx, int32_t* out) {
+// path of an entry, front to back; returns its length or -1 when it does not fit
+template <class ST> VGK_HD int g_path(const ST& S, int32_t idx, int32_t* out) {
     int32_t fwd[G_PATH]; int nf = 0, nb = 0;
-    for (int32_t i = idx; i >= 0; i = s.link[i].parent) {
-        const GLink e = s.link[i];
+    for (int32_t i = idx; i >= 0;) {
+        const GLink e = S.link_get((uint32_t)i);
+        i = e.parent;
         if (e.node < 0) continue;
         if (e.front) { if (nb >= G_PATH) return -1; out[nb++] = e.node; }      // the latest front node is the first of the path
         else { if (nf >= G_PATH) return -1; fwd[nf++] = e.node; }              // collected back to front
@@ -391,8 +477,10 @@ VGK_HD bool gx_trim(const GCtx& c, GExt& e, uint32_t* mm) {                     
     return true;
 }
 
-// one read: every seed's best extension, then the set rules
-VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S, GCold& C) {
+// one read: every seed's best extension, then the set rules.  ST = where a seed's search lives (GStoreSlab / GStoreLds); the
+// winners and the permutation the set rules sort stay in the thread's HBM slab either way (written once per seed).
+template <class ST>
+VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, ST& Q, GScratch& S, GCold& C) {
     const GRes RES{S.res, C.res};
     const GProb pb = P.probs[pi];
     const GIndex& h = P.index;
@@ -400,6 +488,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
     out.status = VGK_OK; out.ext_begin = 0; out.n_ext = 0; out.full_length = 0;
     if (!pb.read_len || !pb.n_seeds) return;
     if (pb.n_seeds > (uint32_t)G_SEEDS) { out.status = VGK_ETOOBIG; return; }
+    if (ST::FULL == G_RETRY && (pb.read_len > 255u || P.index.max_node_len > 255u || P.index.max_visits > 254u)) { out.status = G_RETRY; g_bump(P.counters + 3, 1); return; }   // beyond the compact entries
     GCtx c; c.P = &P; c.seq = P.reads + pb.read_off; c.L = pb.read_len;
     const uint32_t L = pb.read_len, max_mm = pb.max_mm;
     uint32_t n_res = 0, best_alignment = 0xffffffffu;
@@ -412,7 +501,8 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
         const uint32_t read_offset = diff < 0 ? 0u : (uint32_t)diff, node_offset = diff < 0 ? (uint32_t)(-diff) : 0u;
         if (read_offset > L || node_offset > g_len(h, snode)) { status = VGK_EINVAL; break; }
         uint32_t np = 0, hn = 0, number = 0;
-        bool have_cand = false; GEntry cand; uint16_t cand_idx = 0;
+        bool have_cand = false; GEntry cand; uint32_t cand_idx = 0;
+        Q.begin_seed();
         int32_t best = -1;
         GEntry best_e; best_e.score = 0; best_e.r0 = best_e.r1 = 0; best_e.offset = 0; best_e.internal = 0; best_e.left_full = best_e.right_full = 0;
         {   // the seed node itself: any number of mismatches (:213-237)
@@ -426,19 +516,21 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
             if (m.r0 == 0) m.left_full = m.left_max = 1;
             if (m.r1 >= L) m.right_full = m.right_max = 1;
             g_set_score(c, m); m.number = number++;
-            S.link[np] = g_link(m);
-            cand = m; cand_idx = (uint16_t)np; have_cand = true; ++np;
+            Q.link_set(np, m);
+            cand = m; cand_idx = np; have_cand = true; ++np;
         }
         // The queue pops (score, insertion number) maxima.  The best entry created by an expansion is held back in registers
         // (`cand`): when it beats the queue's top — always, on a non-branching stretch — it is the next one popped, and the
         // round trip through the slab (key push, key pop, 40-byte entry load) is skipped; otherwise it joins the queue first.
         while (hn || have_cand) {
-            uint16_t ci; GEntry cur;
-            if (have_cand && (hn == 0 || g_key(cand, cand_idx) > S.heap[0])) { ci = cand_idx; cur = cand; have_cand = false; }
+            uint32_t ci; GEntry cur;
+            if (have_cand && (hn == 0 || g_key(cand, cand_idx) > Q.heap_get(0))) { ci = cand_idx; cur = cand; have_cand = false; }
             else {
-                if (have_cand) { g_heap_push(S, hn, cand, cand_idx); have_cand = false; }
-                ci = g_heap_pop(S, hn);
-                cur = g_unpack(S.pool[ci]);
+                if (have_cand) { if (!g_heap_push(Q, hn, cand, cand_idx)) { status = ST::FULL; break; } have_cand = false; }
+                const uint64_t top = g_heap_pop(Q, hn);
+                const uint32_t idx = (uint32_t)(top & 0xffffu);
+                cur = Q.pool_get(c, idx, top); Q.slot_free(idx);
+                ci = Q.entry_of(idx);
             }
             if (!cur.right_max) {
                 uint32_t num_ext = 0;
@@ -451,8 +543,8 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
                     const int32_t w = ge_to(orec, e); if (w < 0) continue;
                     const GState ns = few ? gs_extend_counted(orec, cur.state, e, cn) : gs_extend(h, cur.state, w);
                     if (gs_empty(ns)) continue;
-                    if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
-                    GEntry nx = cur; nx.parent = ci; nx.node = w; nx.front = 0; nx.state = ns; nx.frec = ge_rec(orec, e);
+                    if (np >= ST::ENTRIES) { status = ST::FULL; break; }
+                    GEntry nx = cur; nx.parent = (int32_t)ci; nx.node = w; nx.front = 0; nx.state = ns; nx.frec = ge_rec(orec, e);
                     const char* t = h.seq + ge_seq(orec, e); const uint32_t wl = ge_len(orec, e);            // match_forward (:239-266)
                     const uint32_t no = g_match_fwd(c.seq + nx.r1, t, L - nx.r1 < wl ? L - nx.r1 : wl, nx.internal, limit);
                     nx.r1 += no;
@@ -461,15 +553,17 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
                     else if (no < wl) { nx.right_max = 1; nx.old = nx.internal; }
                     g_set_score(c, nx); nx.number = number++;
                     num_ext += gs_size(ns);
-                    S.link[np] = g_link(nx);
-                    g_offer(S, hn, have_cand, cand, cand_idx, nx, (uint16_t)np); ++np;
+                    Q.link_set(np, nx);
+                    if (!g_offer(Q, hn, have_cand, cand, cand_idx, nx, np)) { status = ST::FULL; break; }
+                    ++np;
                 }
                 if (status != VGK_OK) break;
                 if (num_ext < gs_size(cur.state)) {                                               // some haplotype ends here: keep it (:633-637)
-                    if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
-                    GEntry nx = cur; nx.parent = ci; nx.node = -1; nx.right_max = 1; nx.old = nx.internal; nx.number = number++;
-                    S.link[np] = g_link(nx);
-                    g_offer(S, hn, have_cand, cand, cand_idx, nx, (uint16_t)np); ++np;
+                    if (np >= ST::ENTRIES) { status = ST::FULL; break; }
+                    GEntry nx = cur; nx.parent = (int32_t)ci; nx.node = -1; nx.right_max = 1; nx.old = nx.internal; nx.number = number++;
+                    Q.link_set(np, nx);
+                    if (!g_offer(Q, hn, have_cand, cand, cand_idx, nx, np)) { status = ST::FULL; break; }
+                    ++np;
                 }
                 continue;
             }
@@ -486,31 +580,32 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
                     const GState ns = gs_flip(few ? gs_extend_counted(orec, flipped, e, cn) : gs_extend(h, flipped, x));   // bdExtendBackward
                     if (gs_empty(ns)) continue;
                     const int32_t w = ns.bn ^ 1;
-                    if (np >= (uint32_t)G_POOL) { status = VGK_ETOOBIG; break; }
+                    if (np >= ST::ENTRIES) { status = ST::FULL; break; }
                     const uint32_t wl = ge_len(orec, e);                                                  // w is the other strand of x: same length,
                     const char* t = h.seq + ((x & 1) ? ge_seq(orec, e) - h.strand_shift : ge_seq(orec, e) + h.strand_shift);   // bases one strand_shift away
-                    GEntry nx = cur; nx.parent = ci; nx.node = w; nx.front = 1; nx.state = ns; nx.offset = wl; nx.brec = ge_rec(orec, e);   // match_backward (:268-296)
+                    GEntry nx = cur; nx.parent = (int32_t)ci; nx.node = w; nx.front = 1; nx.state = ns; nx.offset = wl; nx.brec = ge_rec(orec, e);   // match_backward (:268-296)
                     const uint32_t back = g_match_bwd(c.seq + nx.r0, t + nx.offset, nx.r0 < nx.offset ? nx.r0 : nx.offset, nx.internal, limit);
                     nx.r0 -= back; nx.offset -= back;
                     if (nx.offset >= wl) continue;
                     if (nx.r0 == 0) nx.left_full = nx.left_max = 1;
                     else if (nx.offset > 0) nx.left_max = 1;
                     g_set_score(c, nx); nx.number = number++;
-                    S.link[np] = g_link(nx);
-                    g_offer(S, hn, have_cand, cand, cand_idx, nx, (uint16_t)np); ++np;
+                    Q.link_set(np, nx);
+                    if (!g_offer(Q, hn, have_cand, cand, cand_idx, nx, np)) { status = ST::FULL; break; }
+                    ++np;
                     found = true;
                 }
                 if (status != VGK_OK) break;
                 if (found) continue;
                 cur.left_max = 1;
             }
-            if (best < 0 || best_e.score < cur.score) { best = ci; best_e = cur; }
+            if (best < 0 || best_e.score < cur.score) { best = (int32_t)ci; best_e = cur; }
         }
         if (status != VGK_OK) break;
         if (best >= 0 && best_e.r1 > best_e.r0) {
             const GEntry& b = best_e;
             GExt& r = RES[n_res];
-            const int plen = g_path(S, best, r.path);
+            const int plen = g_path(Q, best, r.path);
             if (plen < 0) { status = VGK_ETOOBIG; break; }
             r.path_len = (uint32_t)plen; r.offset = b.offset; r.r0 = b.r0; r.r1 = b.r1; r.internal = b.internal; r.score = b.score; r.state = b.state;
             r.left_full = b.left_full; r.right_full = b.right_full; r.n_mism = 0;
@@ -518,7 +613,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, GScratch& S,
             ++n_res;
         }
     }
-    if (status != VGK_OK) { out.status = status; return; }
+    if (status != VGK_OK) { out.status = status; if (status == G_RETRY) g_bump(P.counters + 3, 1); return; }
     uint8_t* order = S.order;            // (a private array of this size makes the compiler spill hundreds of registers)
     for (uint32_t i = 0; i < n_res; ++i) order[i] = (uint8_t)i;
     bool overflow = false;
