@@ -63,7 +63,8 @@ public:
         // the fast store first (here a plain local array, stride 1), then the slab store for the reads that outgrew it — as on the device
         const bool slab_only = std::getenv("VGAMD_GAPLESS_SLAB_ONLY") != nullptr;
         std::vector<uint32_t> lds(G_FAST_DW);
-        for (uint32_t t = 0; t < threads; ++t) for (uint32_t i = t; i < P.n; i += threads) {
+        for (uint32_t t = 0; t < threads; ++t) for (uint32_t k = t; k < P.n; k += threads) {
+            const uint32_t i = P.order[k];
             if (!slab_only) { GStoreLds Q{lds.data(), 1u, P.scratch[t], 0u}; gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]); }
             if (slab_only || P.results[i].status == G_RETRY) { GStoreSlab Q{P.scratch[t]}; gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]); }
         }

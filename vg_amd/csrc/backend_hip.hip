@@ -208,17 +208,18 @@ __global__ void __launch_bounds__(64, 4) gapless_kernel(const GaplessParams P, c
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t >= threads) return;
     GStoreSlab Q{P.scratch[t]};
-    for (uint32_t i = t; i < P.n; i += threads) {
+    for (uint32_t k = t; k < P.n; k += threads) {
+        const uint32_t i = P.order[k];
         if (retry_only && P.results[i].status != G_RETRY) continue;
         gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]);
     }
 }
-__global__ void __launch_bounds__(64) gapless_fast_kernel(const GaplessParams P, const uint32_t threads) {
+__global__ void __launch_bounds__(64, 4) gapless_fast_kernel(const GaplessParams P, const uint32_t threads) {
     __shared__ uint32_t lds[64 * G_FAST_DW];
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t >= threads) return;
     GStoreLds Q{lds + threadIdx.x, 64u, P.scratch[t], 0u};
-    for (uint32_t i = t; i < P.n; i += threads) gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]);
+    for (uint32_t k = t; k < P.n; k += threads) gapless_extend_one(P, P.order[k], Q, P.scratch[t], P.cold[t]);
 }
 
 // ---- wavefront alignment (wfa_device.hpp): the same launch shape

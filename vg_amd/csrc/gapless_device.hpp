@@ -177,6 +177,8 @@ struct GRes {                          // the G_SEEDS winners of a read as one a
 struct GaplessParams {
     GIndex index;
     const GProb* probs; uint32_t n;
+    const uint32_t* order;            // the order the threads take the problems in: sorted by the node of the first seed, so that the reads of a
+                                      // wavefront (and of the wavefronts around it) walk the same few records and bases of the index
     const char* reads;                // masked: ACGT or X
     const vgk_seed* seeds;
     int32_t match, mismatch, bonus;
