@@ -100,6 +100,25 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     };
     P.probs = (const WProb*)dev(probs, sizeof(WProb) * n);
     P.seqs = (const char*)dev(seqs, n_seq + 16);
+    // Hand-out order.  Threads take problems one at a time from a counter, so the order decides two things: problems that sit next to
+    // each other in the graph run at the same time and find each other's records and bases in the L2 (mode 1), and long problems —
+    // the expensive ones: the cost grows with the errors a sequence can hold — start first instead of leaving a tail of a few late
+    // stragglers (mode 2; 3 = length classes of 32 bases, longest first, by node inside a class).  Results do not depend on it.
+    std::vector<uint32_t> order(n);
+    {
+        int mode = 3;
+        if (const char* e = std::getenv("VGAMD_WFA_ORDER")) mode = std::atoi(e);
+        std::vector<uint64_t> key(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            const WProb& w = probs[i];
+            const uint64_t node = (w.mode == (uint32_t)VGK_WFA_PREFIX ? w.to_node : w.from_node) / 2, len = w.seq_len;
+            const uint64_t cls = mode == 2 ? (0xffffffffull - len) : mode == 3 ? (0xffffffffull - len / 32) : 0;
+            key[i] = mode == 0 ? i : (cls << 32) | (mode == 2 ? 0 : (node & 0xffffffffull));
+            order[i] = i;
+        }
+        if (mode) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+    }
+    P.order = (const uint32_t*)dev(order.data(), sizeof(uint32_t) * n);
     // dense outputs; the kernel checks them
     const uint64_t cap_p = std::max<uint64_t>(path_cap, (uint64_t)n * 8 + n_seq / 4 + 1024) + 1, cap_e = std::max<uint64_t>(edit_cap, (uint64_t)n * 4 + 1024) + 1;
     P.caps[0] = cap_p; P.caps[1] = cap_e;
@@ -118,7 +137,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     P.paths = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_p);
     P.edits = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_e);
     P.counters = (unsigned long long*)dev(nullptr, 64);
-    if (!P.probs || !P.seqs || !P.scratch || !P.results || !P.paths || !P.edits || !P.counters) return VGK_ENOMEM;
+    if (!P.probs || !P.seqs || !P.order || !P.scratch || !P.results || !P.paths || !P.edits || !P.counters) return VGK_ENOMEM;
     int rc;
     if ((rc = be->zero(P.counters, 64))) return rc;
     if ((rc = be->run_wfa(P, threads))) return rc;

@@ -79,6 +79,7 @@ struct WScratch {
 struct WfaParams {
     GIndex index;
     const WProb* probs; uint32_t n;
+    const uint32_t* order;            // the order problems are handed out in (longest sequences first, neighbours in the graph together)
     const char* seqs;                 // masked: ACGT or X; 8 bytes of padding at either end
     int32_t match, mismatch, gap_open, gap_extend, bonus;      // match/bonus as scored; the other three are WFA penalties (:1616-1618)
     WScratch* scratch;                // one per resident thread
@@ -612,9 +613,9 @@ VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S, uint32_t
 // words apart (LDS in the HIP kernel, lane-interleaved; the slab's own array otherwise)
 VGK_HD void wfa_thread(const WfaParams& P, uint32_t t, uint32_t* end, uint32_t end_stride) {
     for (;;) {
-        const unsigned long long i = g_bump(P.counters + 2, 1);
-        if (i >= P.n) break;
-        wfa_extend_one(P, (uint32_t)i, P.scratch[t], end ? end : P.scratch[t].node_end, end ? end_stride : 1u);
+        const unsigned long long k = g_bump(P.counters + 2, 1);
+        if (k >= P.n) break;
+        wfa_extend_one(P, P.order[k], P.scratch[t], end ? end : P.scratch[t].node_end, end ? end_stride : 1u);
     }
 }
 
