@@ -341,6 +341,34 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    one_stream = {"ms_per_step": 1e3 * elapsed / args.steps, "fill_ms": sum(fill_ms) / len(fill_ms), "traceback_ms": sum(walk_ms) / len(walk_ms),
+                  "reads_per_s": args.reads * world * args.steps / elapsed}
+    # Steady state of a streaming caller: consecutive batches alternate between the context's two launch lanes (streams), so the
+    # traceback of one batch — bound by memory latency — runs under the fill of the next — bound by VALU issue.  Two batches are
+    # resident (the same reads packed twice); step i runs batch i mod 2; exactly K steps between the barriers.
+    two_lane = None
+    if windows or args.workload == "tails":
+        batch2 = pack()
+        if batch2.lane() != batch.lane():
+            pair = (batch, batch2)
+            for k in range(max(args.warmup, 2)):
+                pair[k & 1].run()
+            batch.sync(); batch2.sync()
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                pair[k & 1].run()
+            batch.sync(); batch2.sync()
+            barrier()
+            e2 = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([e2], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                e2 = float(t.item())
+            # the last launch on either lane, timed by HIP events on its own stream while the other lane was busy
+            two_lane = {"ms_per_step": 1e3 * e2 / args.steps, "reads_per_s": args.reads * world * args.steps / e2,
+                        "fill_ms_under_overlap": [pair[0].kernel_ms(0), pair[1].kernel_ms(0)], "traceback_ms_under_overlap": [pair[0].kernel_ms(1), pair[1].kernel_ms(1)]}
+        batch2.free()
 
     # results of the last step: parity spot-check against the oracle + exact algorithmic bytes
     tf = time.perf_counter(); res, ops = batch.fetch(); t_fetch = time.perf_counter() - tf
@@ -457,6 +485,14 @@ def main():
     if rank == 0:
         total_reads = args.reads * world * args.steps
         value = total_reads / elapsed
+        ms_per_step = 1e3 * elapsed / args.steps
+        timed_region = "K runs of one resident batch on one stream: fill kernel, then traceback kernel"
+        if two_lane and two_lane["reads_per_s"] > value:
+            value = two_lane["reads_per_s"]; ms_per_step = two_lane["ms_per_step"]
+            # the roofline figures below then come from the same region: the fill launches as timed by HIP events on their own lanes
+            # while the other lane's traceback ran beside them (the last launch of either lane)
+            fill_ms = list(two_lane["fill_ms_under_overlap"]); walk_ms = list(two_lane["traceback_ms_under_overlap"])
+            timed_region = "K steps over two resident batches on the context's two launch lanes (step i = batch i mod 2): the traceback of one step runs under the fill of the next"
         fill_step = sum(fill_ms) / len(fill_ms)          # all fill launches of one step
         fill_avg = fill_step / n_launch                  # average duration of one fill launch
         achieved = (alg_bytes / n_launch) / (fill_avg * 1e-3) / 1e9
@@ -473,12 +509,13 @@ def main():
             "metric": "tail alignments/sec (pinned X-drop, 1-121 bp)" if tails else "reads/sec aligned (150 bp)",
             "value": value, "unit": "alignments/s" if tails else "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": ("configs[2] stand-in: 2 Mbp variation graph (SNP + insertion bubbles), %d tails of 1-121 bp "
                                     "per GPU, left-pinned X-drop (dozeu semantics) + traceback, scores 1/4/6/1/5" % args.reads) if tails else
                                    ("configs[1]: linear 1 Mbp graph (32 bp nodes), %d x 150 bp reads per GPU, "
                                     "384-416 bp windows, gssw LOCAL + traceback, scores 1/4/6/1/5" % args.reads),
+                       "timed_region": timed_region, "one_stream": one_stream, "two_lanes": two_lane,
                        "reads_per_gpu_per_step": args.reads, "parallelism": "read-sharded x%d" % world,
                        "device": dev_name, "compute_units": cus},
             # `achieved / peak / frac` price the kernel's ALGORITHMIC bytes against the HBM peak, as the contract asks; the kernel's

@@ -360,6 +360,8 @@ double   vgk_batch_kernel_ms(vgk_batch* batch, int which /* 0 = fill kernels (su
 uint64_t vgk_batch_cells(vgk_batch* batch);          /* DP cells computed per run            */
 uint64_t vgk_batch_alg_bytes(vgk_batch* batch);      /* algorithmic bytes per run */
 uint64_t vgk_batch_device_bytes(vgk_batch* batch);   /* HBM footprint of the batch            */
+int      vgk_batch_lane(vgk_batch* batch);           /* launch lane (stream) of the batch: consecutive batches of a context alternate between
+                                                        two, so that one batch's traceback runs under the next one's fill */
 uint64_t vgk_batch_wave_steps(vgk_batch* batch);     /* fill steps summed over the batch's wavefronts (one step = one graph column for
                                                         each of a wavefront's 64 lanes): the unit of the VALU-issue model in DESIGN.md */
 

@@ -401,3 +401,4 @@ uint64_t vgk_batch_cells(vgk_batch* b) { return b ? b->cells : 0; }
 uint64_t vgk_batch_alg_bytes(vgk_batch* b) { (void)b; return 0; }
 uint64_t vgk_batch_device_bytes(vgk_batch* b) { (void)b; return 0; }
 uint64_t vgk_batch_wave_steps(vgk_batch* b) { (void)b; return 0; }
+int vgk_batch_lane(vgk_batch* b) { (void)b; return 0; }

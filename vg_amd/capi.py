@@ -564,6 +564,11 @@ class Batch:
     def device_bytes(self):
         return self.eng.lib.vgk_batch_device_bytes(self.h)
 
+    def lane(self):
+        """launch lane (stream) of this batch: consecutive batches of a context alternate between two"""
+        self.eng.lib.vgk_batch_lane.argtypes = [ctypes.c_void_p]
+        return self.eng.lib.vgk_batch_lane(self.h)
+
     def wave_steps(self):
         return self.eng.lib.vgk_batch_wave_steps(self.h)
 

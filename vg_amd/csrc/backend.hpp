@@ -60,6 +60,18 @@ public:
     // gssw kernels: one fill launch per rows-per-lane instantiation (`launches`), then one traceback
     // launch over all reads; timings (ms, HIP events on the launch stream) of the last run
     virtual int   run_gssw(const GsswParams& p, const FillLaunch* launches, uint32_t n_launches, bool walk) = 0;
+    // The same on launch lane `lane` (0 or 1), which also zeroes the batch's best-cell keys first and records `done` behind the
+    // kernels.  Two lanes = two streams: consecutive batches of a streaming caller alternate between them, so the traceback of
+    // batch k (bound by memory latency, few registers) runs under the fill of batch k + 1 (bound by VALU issue) and the fill's
+    // last, partly empty round of wavefronts overlaps the next launch.  Backends with one stream ignore the lane.
+    virtual int   run_gssw_on(int lane, const GsswParams& p, const FillLaunch* launches, uint32_t n_launches, bool walk, void* done) {
+        (void)lane;
+        int rc = zero(p.best, ((size_t)p.n_problems + 1) * sizeof(unsigned long long));
+        if (!rc) rc = run_gssw(p, launches, n_launches, walk);
+        if (!rc) rc = event_record(done);
+        return rc;
+    }
+    virtual double last_ms_on(int lane, int which) const { (void)lane; return last_ms(which); }
     // Results on their way back (vgk_gssw_fetch): the CIGAR ops sit in per-problem slots of ops_per_problem entries, of which a
     // read uses a handful; they are packed behind each other on the device, in problem order, so that only what was written
     // crosses PCIe.  ops_offsets: offs[i] = position of problem i's first op inside its block of OPS_SCAN_BLOCK problems,

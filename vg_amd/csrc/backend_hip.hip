@@ -238,6 +238,7 @@ __global__ void __launch_bounds__(64) gssw_matrix_kernel(const GsswMatrixParams 
 class HipBackend final : public Backend {
 public:
     int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, copy = nullptr, fetch = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t alt = nullptr; hipEvent_t evb[3] = {nullptr, nullptr, nullptr}; float ms_fill_b = 0.f, ms_walk_b = 0.f; bool pending_b = false, timed_walk_b = false, lane1_on_main = true;   // launch lane 1
     hipDeviceProp_t prop;
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
     float ms_gapless = 0.f, ms_wfa = 0.f;
@@ -250,6 +251,8 @@ public:
         if (stream) hipStreamDestroy(stream);
         if (copy) hipStreamDestroy(copy);
         if (fetch) hipStreamDestroy(fetch);
+        if (alt) hipStreamDestroy(alt);
+        for (auto& e : evb) if (e) hipEventDestroy(e);
     }
     const char* name() const override { return prop.name; }
     int compute_units() const override { return prop.multiProcessorCount; }
@@ -382,6 +385,46 @@ public:
         pending = true;
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
+    // lane 1: a second launch stream with timing events of its own, for batches with a single fill launch (several rows-per-lane
+    // launches share the side streams and stay on lane 0)
+    int run_gssw_on(int lane, const GsswParams& p0, const FillLaunch* launches, uint32_t n, bool walk, void* done) override {
+        hipSetDevice(dev);
+        if (lane != 1 || n != 1 || p0.n_problems == 0) {
+            if (lane == 1) lane1_on_main = true;
+            if (hipMemsetAsync(p0.best, 0, ((size_t)p0.n_problems + 1) * sizeof(unsigned long long), stream) != hipSuccess) return VGK_ENODEV;
+            int rc = run_gssw(p0, launches, n, walk);
+            if (!rc && done) rc = hipEventRecord((hipEvent_t)done, stream) == hipSuccess ? VGK_OK : VGK_ENODEV;
+            return rc;
+        }
+        lane1_on_main = false;
+        if (hipMemsetAsync(p0.best, 0, ((size_t)p0.n_problems + 1) * sizeof(unsigned long long), alt) != hipSuccess) return VGK_ENODEV;
+        GsswParams p = p0;
+        p.K = launches[0].K; p.wave_begin = launches[0].wave_begin; p.wave_count = launches[0].wave_count;
+        hipEventRecord(evb[0], alt);
+        if (p.wave_count) { const int rc = launch_fill(p, alt); if (rc) return rc; }
+        hipEventRecord(evb[1], alt);
+        timed_walk_b = walk && !p.fused;
+        if (timed_walk_b) {
+            hipLaunchKernelGGL(gssw_walk_kernel, dim3((p.n_problems + 255) / 256), dim3(256), 0, alt, p);
+            hipEventRecord(evb[2], alt);
+        }
+        pending_b = true;
+        if (done && hipEventRecord((hipEvent_t)done, alt) != hipSuccess) return VGK_ENODEV;
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    double last_ms_on(int lane, int which) const override {
+        if (lane != 1 || lane1_on_main || which > 2 || which < 0) return last_ms(which);
+        HipBackend* self = const_cast<HipBackend*>(this);
+        if (self->pending_b) {
+            hipSetDevice(dev);
+            hipStreamSynchronize(alt);
+            hipEventElapsedTime(&self->ms_fill_b, evb[0], evb[1]);
+            self->ms_walk_b = 0.f;
+            if (timed_walk_b) hipEventElapsedTime(&self->ms_walk_b, evb[1], evb[2]);
+            self->pending_b = false;
+        }
+        return which == 0 ? ms_fill_b : which == 1 ? ms_walk_b : 1.0;
+    }
     int ops_offsets(const vgk_result* res, uint32_t n, uint32_t* offs, uint32_t* sums, uint64_t* total) override {
         hipSetDevice(dev);
         const uint32_t blocks = (n + OPS_SCAN_BLOCK - 1) / OPS_SCAN_BLOCK;
@@ -490,12 +533,13 @@ Backend* make_backend(int device, std::string& err) {
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&b->prop, device) != hipSuccess) {
         err = "cannot select HIP device"; delete b; return nullptr; }
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&b->fetch, hipStreamNonBlocking) != hipSuccess) { err = "cannot create HIP stream"; delete b; return nullptr; }
+        hipStreamCreateWithFlags(&b->fetch, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->alt, hipStreamNonBlocking) != hipSuccess) { err = "cannot create HIP stream"; delete b; return nullptr; }
     for (int i = 0; i < 2; ++i)
         if (hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&b->side_done[i], hipEventDisableTiming) != hipSuccess) { err = "cannot create HIP side stream"; delete b; return nullptr; }
     for (auto& ev : b->bev) if (hipEventCreate(&ev) != hipSuccess) { err = "cannot create HIP event"; delete b; return nullptr; }
     for (auto& ev : b->ev) if (hipEventCreate(&ev) != hipSuccess) { err = "cannot create HIP event"; delete b; return nullptr; }
+    for (auto& ev : b->evb) if (hipEventCreate(&ev) != hipSuccess) { err = "cannot create HIP event"; delete b; return nullptr; }
     return b;
 }
 

@@ -17,6 +17,7 @@ struct vgk_batch {
     uint64_t ops_total = 0;
     uint64_t wave_steps = 0;            // sum over wavefronts of their fill steps
     ProbDesc* probs = nullptr; uint64_t probs_bytes = 0;   // kept for fetch(): a page-locked block from the context's pool, back to it with the batch
+    int lane = 0;                       // launch lane (stream) of this batch: consecutive batches of a context alternate (Backend::run_gssw_on)
     void* done = nullptr;               // recorded behind this batch's kernels by vgk_gssw_run (Backend::event_*)
     ~vgk_batch() { if (probs && ctx) ctx->host_give(probs, probs_bytes); if (done && ctx) ctx->be->event_destroy(done); }
     std::vector<FillLaunch> launches;   // one per length bucket

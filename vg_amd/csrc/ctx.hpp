@@ -21,7 +21,8 @@ template <class T> struct PinnedBuf {
 struct vgk_ctx {
     vgk_scoring sc;
     std::unique_ptr<vgk::Backend> be;
-    std::mutex mu;                 // one stream per context: batches on one context serialise
+    std::mutex mu;                 // guards the pools and the launch order of a context
+    uint32_t batch_seq = 0;        // batches packed so far: their launch lanes alternate
     uint32_t bias = 1; int32_t max_score = 0; int32_t max_bonus = 0;
     uint32_t prof4[6];
     uint32_t scale = 1;            // 8 when the scaled profile bytes still fit (GsswParams::scale)

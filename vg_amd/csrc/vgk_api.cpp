@@ -306,6 +306,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     GsswParams& P = b->P;
     int rc;
     std::unique_lock<std::mutex> lk(ctx->mu);
+    b->lane = (std::getenv("VGAMD_ONE_STREAM") ? 0 : (int)(ctx->batch_seq++ & 1u));
     // on failure release whatever was allocated (vgk_batch_free takes the context lock itself)
     auto fail = [&](int code) { vgk_batch* t = hb.release(); if (lk.owns_lock()) lk.unlock(); ctx->be->sync_side(); vgk_batch_free(t); return code; };   // (copies in flight must land before the arenas go back to the pool)
     auto issue_uploads = [&]() -> int {
@@ -448,20 +449,15 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
 int vgk_gssw_run(vgk_batch* b) {
     if (!b) return VGK_EINVAL;
     std::lock_guard<std::mutex> lk(b->ctx->mu);
-    int rc = b->ctx->be->zero(b->P.best, ((size_t)b->n + 1) * sizeof(unsigned long long));
-    if (rc) return rc;
-    rc = b->ctx->be->run_gssw(b->P, b->launches.data(), (uint32_t)b->launches.size(), true);
-    if (rc == VGK_OK) {
-        b->ran = true;
-        if (!b->done) b->done = b->ctx->be->event_create();
-        rc = b->ctx->be->event_record(b->done);
-    }
+    if (!b->done) b->done = b->ctx->be->event_create();
+    const int rc = b->ctx->be->run_gssw_on(b->lane, b->P, b->launches.data(), (uint32_t)b->launches.size(), true, b->done);
+    if (rc == VGK_OK) b->ran = true;
     return rc;
 }
 
 int vgk_batch_sync(vgk_batch* b) {
     if (!b) return VGK_EINVAL;
-    return b->ctx->be->sync();        // a wait on the stream, without the context lock: another thread may be packing the next batch
+    return b->done ? b->ctx->be->event_wait(b->done) : b->ctx->be->sync();        // this batch's kernels; no context lock: another thread may be packing the next batch
 }
 
 // The usual way back: the ops are packed behind each other on the device (a read uses a handful of its ops_per_problem slots),
@@ -642,8 +638,8 @@ int vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
 double vgk_batch_kernel_ms(vgk_batch* b, int which) {
     if (!b) return 0.0;
     std::lock_guard<std::mutex> lk(b->ctx->mu);
-    if (which == 0 || which == 1 || which == 2) return b->ctx->be->last_ms(which);
-    return b->ctx->be->last_ms(0) + b->ctx->be->last_ms(1);
+    if (which == 0 || which == 1 || which == 2) return b->ctx->be->last_ms_on(b->lane, which);
+    return b->ctx->be->last_ms_on(b->lane, 0) + b->ctx->be->last_ms_on(b->lane, 1);
 }
 uint64_t vgk_batch_cells(vgk_batch* b) { return b ? b->cells : 0; }
 uint64_t vgk_batch_alg_bytes(vgk_batch* b) {
@@ -656,5 +652,6 @@ uint64_t vgk_batch_alg_bytes(vgk_batch* b) {
 }
 uint64_t vgk_batch_device_bytes(vgk_batch* b) { return b ? b->dev_bytes : 0; }
 uint64_t vgk_batch_wave_steps(vgk_batch* b) { return b ? b->wave_steps : 0; }
+int      vgk_batch_lane(vgk_batch* b) { return b ? b->lane : 0; }
 
 }  // extern "C"

@@ -166,6 +166,7 @@ int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
         W.bucket_first = (uint32_t*)take_temp(sizeof(uint32_t) * WIN_BUCKETS); W.buckets = (WinBucket*)take_temp(sizeof(WinBucket) * WIN_BUCKETS);
         W.wave_tb = (unsigned long long*)take_temp(((uint64_t)waves_cap + 1) * 8);
         tmp = take_temp(tmp_bytes);
+        b->lane = (std::getenv("VGAMD_ONE_STREAM") ? 0 : (int)(ctx->batch_seq++ & 1u));
         W.probs = (ProbDesc*)take_keep((uint64_t)std::max<uint32_t>(n, 1u) * sizeof(ProbDesc));
         if (!W.problems || !W.raw_reads || !W.sizes || !W.offs || !W.key || !W.idx || !W.key_sorted || !W.idx_sorted || !W.totals ||
             !W.bucket_first || !W.buckets || !W.wave_tb || !tmp || !W.probs) rc = VGK_ENOMEM;
