@@ -239,6 +239,9 @@ class HipBackend final : public Backend {
 public:
     int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, copy = nullptr, fetch = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t alt = nullptr; hipEvent_t evb[3] = {nullptr, nullptr, nullptr}; float ms_fill_b = 0.f, ms_walk_b = 0.f; bool pending_b = false, timed_walk_b = false, lane1_on_main = true;   // launch lane 1
+    hipEvent_t fill_done[2] = {nullptr, nullptr}; bool fill_done_set[2] = {false, false};
+    const bool fills_take_turns = std::getenv("VGAMD_FILLS_TAKE_TURNS") != nullptr;   // experiment: a lane's fill waits for the other lane's fill, so that only a traceback
+                                                                                     // runs beside a fill — no faster than one stream (the traceback takes the fill's wave slots); off
     hipDeviceProp_t prop;
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
     float ms_gapless = 0.f, ms_wfa = 0.f;
@@ -253,6 +256,7 @@ public:
         if (fetch) hipStreamDestroy(fetch);
         if (alt) hipStreamDestroy(alt);
         for (auto& e : evb) if (e) hipEventDestroy(e);
+        for (auto& e : fill_done) if (e) hipEventDestroy(e);
     }
     const char* name() const override { return prop.name; }
     int compute_units() const override { return prop.multiProcessorCount; }
@@ -363,6 +367,7 @@ public:
         n_launches = n ? (int)n : 1;
         if (p0.n_problems == 0 || n == 0) { ms_fill = ms_walk = 0; pending = false; return VGK_OK; }
         GsswParams p = p0;
+        if (fills_take_turns && fill_done_set[1]) hipStreamWaitEvent(stream, fill_done[1], 0);       // (measured: DESIGN.md §5)
         hipEventRecord(ev[0], stream);
         // the (up to three) rows-per-lane instantiations are independent: side streams let a small bucket's
         // launch fill the CUs another bucket leaves idle; everything joins `stream` again before the walk
@@ -377,6 +382,7 @@ public:
             if (st != stream) { hipEventRecord(side_done[i - 1], st); hipStreamWaitEvent(stream, side_done[i - 1], 0); }
         }
         hipEventRecord(ev[1], stream);
+        hipEventRecord(fill_done[0], stream); fill_done_set[0] = true;
         timed_walk = walk && !p.fused;
         if (timed_walk) {
             hipLaunchKernelGGL(gssw_walk_kernel, dim3((p.n_problems + 255) / 256), dim3(256), 0, stream, p);
@@ -400,9 +406,11 @@ public:
         if (hipMemsetAsync(p0.best, 0, ((size_t)p0.n_problems + 1) * sizeof(unsigned long long), alt) != hipSuccess) return VGK_ENODEV;
         GsswParams p = p0;
         p.K = launches[0].K; p.wave_begin = launches[0].wave_begin; p.wave_count = launches[0].wave_count;
+        if (fills_take_turns && fill_done_set[0]) hipStreamWaitEvent(alt, fill_done[0], 0);
         hipEventRecord(evb[0], alt);
         if (p.wave_count) { const int rc = launch_fill(p, alt); if (rc) return rc; }
         hipEventRecord(evb[1], alt);
+        hipEventRecord(fill_done[1], alt); fill_done_set[1] = true;
         timed_walk_b = walk && !p.fused;
         if (timed_walk_b) {
             hipLaunchKernelGGL(gssw_walk_kernel, dim3((p.n_problems + 255) / 256), dim3(256), 0, alt, p);
@@ -540,6 +548,7 @@ Backend* make_backend(int device, std::string& err) {
     for (auto& ev : b->bev) if (hipEventCreate(&ev) != hipSuccess) { err = "cannot create HIP event"; delete b; return nullptr; }
     for (auto& ev : b->ev) if (hipEventCreate(&ev) != hipSuccess) { err = "cannot create HIP event"; delete b; return nullptr; }
     for (auto& ev : b->evb) if (hipEventCreate(&ev) != hipSuccess) { err = "cannot create HIP event"; delete b; return nullptr; }
+    for (auto& ev : b->fill_done) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { err = "cannot create HIP event"; delete b; return nullptr; }
     return b;
 }
 
