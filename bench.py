@@ -248,12 +248,116 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
         dist.destroy_process_group()
 
 
+def bench_tails(args, eng, rank, world, dist, torch, dev_name, cus):
+    """configs[2] at its stated size (secondary line): a chr22-scale SNP + indel graph (50.8 Mbp, ~1.7 M nodes) resident in HBM on both
+    strands, 10 M reads with BOTH tails (1-121 bp) aligned left-pinned X-drop (right tails against the reverse-complement strand, as
+    giraffe does) — 20 M window problems, packed on the device in batches of <= 5 M that all stay resident.  One step = the fill +
+    traceback kernels of every batch."""
+    import numpy as np
+    from vg_amd import capi, shard, workloads
+    n_reads = args.reads if args.reads else 10_000_000
+    OPS_PER = 32
+    g = workloads.VariationGraph()
+    strands = [(g, 7 + 2 * rank), (g.reverse_complement(), 8 + 2 * rank)]
+    t0 = time.perf_counter()
+    batches, sets = [], []
+    for graph, seed in strands:
+        dg = eng.graph(*graph.arrays())
+        tails = workloads.GraphTails(graph, n_reads, seed=seed)
+        for lo in range(0, n_reads, 5_000_000):
+            ws = tails.subset(min(5_000_000, n_reads - lo), lo)
+            sets.append((graph, tails, lo, ws, dg))
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for graph, tails, lo, ws, dg in sets:
+        batches.append(eng.pack_windows(dg, ws, OPS_PER))
+    t_pack = time.perf_counter() - t0
+    n_tails = sum(b.ps.n for b in batches)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        for b in batches:
+            b.run()
+    for b in batches:
+        b.sync()
+    barrier()
+    fill_ms, walk_ms, launches = [], [], 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for b in batches:
+            b.run()
+            fill_ms.append(b.kernel_ms(0)); walk_ms.append(b.kernel_ms(1)); launches += max(1, int(round(b.kernel_ms(2))))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tf = time.perf_counter()
+    outs = [b.fetch() for b in batches]
+    t_fetch = time.perf_counter() - tf
+    alg_bytes = sum(b.alg_bytes() for b in batches); cells = sum(b.cells() for b in batches); dev_bytes = sum(b.device_bytes() for b in batches)
+    n_bad = int(sum((r["status"] != 0).sum() for r, _ in outs))
+    cpu = parity = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
+        cores = shard.usable_cpus(); ora.lib.vgo_set_threads(cores)
+        checked = same = 0; tc = 0.0; k = args.cpu_sample or 100_000
+        for (graph, tails, lo, ws, dg), (res, ops) in zip((sets[0], sets[len(sets) // 2]), (outs[0], outs[len(sets) // 2])):      # one batch of either strand
+            sub = tails.subset(min(k, ws.n), lo)
+            og = ora.graph(*graph.arrays())
+            with ora.pack_windows(og, sub, OPS_PER) as ob:
+                t1 = time.perf_counter(); ob.run(); tc += time.perf_counter() - t1
+                ores, oops = ob.fetch()
+            hdr = np.ones(sub.n, dtype=bool)
+            for f in ("score", "status", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
+                hdr &= res[f][:sub.n] == ores[f]
+            good = int(hdr.sum())
+            if hdr.all():
+                tot = int(ores["n_ops"].sum())
+                bad = ops[:tot].view(np.uint64) != oops[:tot].view(np.uint64)
+                if bad.any():
+                    good = sub.n - len(np.unique(np.repeat(np.arange(sub.n), ores["n_ops"])[bad]))
+            checked += sub.n; same += good
+        cpu = {"value": checked / tc, "unit": "alignments/s", "cores": cores, "kind": "port", "impl": "scalar int32 checker (oracle/vgo_xdrop.c), OpenMP over problems",
+               "sample": "%d tails of either strand, the induced subgraphs built by the oracle itself" % (checked // 2)}
+        parity = {"checked": checked, "identical": same}
+    if rank == 0:
+        fill_step = sum(fill_ms) / args.steps; fill_avg = sum(fill_ms) / max(launches, 1)
+        achieved = (alg_bytes * args.steps / max(launches, 1)) / (fill_avg * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "tail alignments/sec (pinned X-drop, 1-121 bp, both tails of every read)", "value": n_tails * world * args.steps / elapsed,
+            "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "configs[2]: chr22-scale graph (50 818 468 bp, 41 %% GC, SNPs 1/1000, indels 1-20 bp 1/10 000, <= 32 bp nodes: %d nodes), "
+                                   "%d reads per GPU with both tails (1-121 bp, 1 %% substitutions, walks of two haplotypes), left-pinned X-drop (dozeu "
+                                   "semantics; right tails on the reverse-complement strand) + traceback, windows of the resident graph, scores 1/4/6/1/5" % (g.n_nodes, n_reads),
+                       "tails_per_gpu_per_step": n_tails, "batches_resident": len(batches), "parallelism": "read-sharded x%d" % world,
+                       "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
+            "roofline": {"bound": "valu", "kernel": "gssw_fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "alg_bytes_per_step": alg_bytes, "fill_launches_per_step": launches // args.steps, "avg_launch_ms": fill_avg,
+                         "fill_ms_per_step": fill_step, "traceback_ms_per_step": sum(walk_ms) / args.steps, "gcups_fill": cells / (fill_step * 1e-3) / 1e9},
+            "cpu_baseline": cpu, "parity": parity, "problems_failed": n_bad, "hbm_footprint_bytes": dev_bytes,
+            "packing": "windows of the resident graph, packed on the device (vgk_gssw_pack_windows)", "pack_seconds": t_pack, "fetch_seconds": t_fetch,
+            "end_to_end_from_host_buffers_per_s": n_tails / (t_pack + elapsed / args.steps + t_fetch)}))
+    for b in batches:
+        b.free()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (configs[1]: 1M)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (0 = the configuration's own size: configs[1] 1M reads; tails: 10M reads = 20M tails)")
+    ap.add_argument("--tails-per-problem-graphs", action="store_true", help="tails workload: round 1's stand-in (200k tails on a 2 Mbp graph, one explicit graph per problem, host packer)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads for the CPU baseline leg (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--host-pack", action="store_true", help="linear workload: one explicit graph per problem, packed on host threads (vgk_gssw_pack) instead of windows of the resident graph packed on the device")
@@ -288,6 +392,10 @@ def main():
     eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), device=local_rank, lib=eng_lib)
     dev_name, cus, hbm = eng.device_info()
 
+    if args.workload == "tails" and not args.tails_per_problem_graphs:
+        return bench_tails(args, eng, rank, world, dist, torch, dev_name, cus)
+    if not args.reads:
+        args.reads = 1_000_000
     if args.workload == "banded":
         return bench_banded(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "wfa":

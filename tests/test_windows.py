@@ -190,3 +190,26 @@ def test_bench_windows_on_the_gpu_equal_per_problem_graphs():
     for f in ("status", "score", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
         assert (rw[f] == rp[f]).all(), f
     assert (ow.view(np.uint64) == op.view(np.uint64)).all()
+
+
+def tails_both_strands(lib, ref_len, n, sample):
+    """configs[2] in miniature: giraffe-style tails on either strand of a SNP + indel graph, as windows; engine = oracle."""
+    g = workloads.VariationGraph(ref_len=ref_len)
+    for graph, seed in ((g, 7), (g.reverse_complement(), 8)):
+        tails = workloads.GraphTails(graph, n, seed=seed)
+        sub = tails.subset(sample)
+        eng = capi.Engine(lib=lib); ora = capi.Engine(lib=ORACLE_LIB)
+        ra, oa = eng.align_windows(eng.graph(*graph.arrays()), sub, 48)
+        rb, ob = ora.align_windows(ora.graph(*graph.arrays()), sub, 48)
+        assert_same(ra, oa, rb, ob, "tails on a variation graph")
+        assert (ra["status"] == 0).all()
+        assert (ra["score"] >= tails.tails[:sample] - 10).mean() > 0.98          # a tail follows a haplotype: nearly all of it aligns
+
+
+def test_tails_on_a_variation_graph_as_windows(emu_lib):
+    tails_both_strands(emu_lib, 300_000, 4000, 1500)
+
+
+@pytest.mark.gpu
+def test_tails_on_a_variation_graph_as_windows_on_the_gpu():
+    tails_both_strands(ENGINE_LIB, 2_000_000, 60_000, 20_000)

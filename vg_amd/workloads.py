@@ -464,3 +464,187 @@ class WfaWorkload:
         self.n = n
         self.bases = int(seq_off[-1])
         self.graph_bases = int(span.sum())
+
+
+# ---- configs[2] at its stated size: a chr22-scale SNP + indel graph, giraffe-style tails as windows of the resident graph ----------
+def _comp_table():
+    t = np.arange(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        t[a] = b
+    return t
+
+
+class VariationGraph:
+    """a synthetic reference (uniform ACGT, 41 % GC, seed 22) with SNPs at 1/1000 and indels of 1-20 bp at
+    1/10 000 (seed 23; sites closer than 40 bp to the previous one are dropped so that bubbles never nest), as a DAG of <= 32 bp
+    nodes in topological order, plus two haplotypes that carry each variant with p = 0.5.  Built with numpy array operations only
+    (50.8 Mbp: ~1.7 M nodes in a few seconds).
+
+    node kinds: 0 backbone, 1 SNP alt allele (placed right after its 1-bp reference allele), 2 inserted sequence (placed right
+    before the backbone node it precedes).  Edges: backbone chain; both alleles of a SNP share predecessors and successors; an
+    insertion hangs between its neighbours, which stay joined; a deletion adds an edge over the deleted backbone nodes."""
+
+    def __init__(self, ref_len=50_818_468, seed=22, var_seed=23, snp_rate=1e-3, indel_rate=1e-4, gc=0.41):
+        rng = np.random.default_rng(seed)
+        p = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])
+        ref = ACGT[rng.choice(4, size=ref_len, p=p).astype(np.uint8)]
+        rng = np.random.default_rng(var_seed)
+        n_var = rng.binomial(ref_len, snp_rate + indel_rate)
+        pos = np.sort(rng.integers(64, ref_len - 64, n_var))
+        keep = np.ones(len(pos), dtype=bool); keep[1:] = np.diff(pos) >= 40
+        # (dropping a site can bring its neighbours within 40 bp of each other only if they already were: one pass is enough)
+        pos = pos[keep]
+        kind = np.where(rng.random(len(pos)) < snp_rate / (snp_rate + indel_rate), 0, np.where(rng.random(len(pos)) < 0.5, 1, 2))   # 0 SNP, 1 insertion, 2 deletion
+        vlen = np.where(kind == 0, 1, rng.integers(1, 21, len(pos)))
+        # backbone cuts: every 32 bp, and around every variant (SNP: the base itself; deletion: the deleted stretch; insertion: before pos)
+        cuts = np.concatenate([np.arange(0, ref_len, NODE), pos, pos[kind == 0] + 1, (pos + vlen)[kind == 2], [ref_len]])
+        cuts = np.unique(cuts)
+        b_start, b_end = cuts[:-1], cuts[1:]
+        nb = len(b_start)
+        # extra nodes: SNP alt (after backbone node starting at pos) and insertion (before backbone node starting at pos)
+        snp_pos = pos[kind == 0]; ins_pos = pos[kind == 1]; ins_len = vlen[kind == 1]; del_pos = pos[kind == 2]; del_len = vlen[kind == 2]
+        snp_b = np.searchsorted(b_start, snp_pos); ins_b = np.searchsorted(b_start, ins_pos)
+        alt = ACGT[(np.searchsorted(ACGT, ref[snp_pos]) + rng.integers(1, 4, len(snp_pos))) % 4]
+        ins_seq = ACGT[rng.integers(0, 4, int(ins_len.sum()))]
+        # order keys: backbone node i -> 3 i + 1, its SNP alt -> 3 i + 2, an insertion before it -> 3 i
+        keys = np.concatenate([3 * np.arange(nb) + 1, 3 * snp_b + 2, 3 * ins_b])
+        order = np.argsort(keys, kind="stable")
+        n = len(keys)
+        new_index = np.empty(n, dtype=np.int64); new_index[order] = np.arange(n)
+        bb = new_index[:nb]; alt_idx = new_index[nb:nb + len(snp_b)]; ins_idx = new_index[nb + len(snp_b):]
+        node_len = np.empty(n, dtype=np.uint32)
+        node_len[bb] = (b_end - b_start).astype(np.uint32); node_len[alt_idx] = 1; node_len[ins_idx] = ins_len
+        col = np.concatenate([[0], np.cumsum(node_len, dtype=np.int64)])
+        seq = np.empty(int(col[-1]), dtype=np.uint8)
+        # backbone bases land at their node's columns: one scatter through a per-base offset (column of base x = col[bb[node of x]] + x - start)
+        base_node = np.repeat(np.arange(nb), b_end - b_start)
+        seq[col[bb][base_node] + (np.arange(ref_len) - b_start[base_node])] = ref
+        seq[col[alt_idx]] = alt
+        ins_off = np.concatenate([[0], np.cumsum(ins_len)])
+        ins_node = np.repeat(np.arange(len(ins_len)), ins_len)
+        seq[col[ins_idx][ins_node] + (np.arange(len(ins_seq)) - ins_off[ins_node])] = ins_seq
+        # predecessors.  prev(i) = backbone i - 1; a SNP at backbone s: alt shares s's predecessors, and s + 1 also follows the alt;
+        # an insertion before backbone j: ins follows j - 1 (and the alt of j - 1 — cannot be: sites are >= 40 bp apart), j follows ins too;
+        # a deletion [p, p + k): backbone node starting at p + k also follows the backbone node ending at p
+        src = [bb[:-1]]; dst = [bb[1:]]
+        src.append(bb[snp_b - 1]); dst.append(alt_idx)                   # into the alt
+        src.append(alt_idx); dst.append(bb[snp_b + 1])                   # out of the alt
+        src.append(bb[ins_b - 1]); dst.append(ins_idx)
+        src.append(ins_idx); dst.append(bb[ins_b])
+        del_from = np.searchsorted(b_start, del_pos) - 1; del_to = np.searchsorted(b_start, del_pos + del_len)
+        src.append(bb[del_from]); dst.append(bb[del_to])
+        src = np.concatenate(src); dst = np.concatenate(dst)
+        assert (src < dst).all()
+        e = np.lexsort((src, dst))                                        # grouped by destination, predecessors ascending
+        dst, src = dst[e], src[e]
+        self.node_len = node_len; self.seq = seq; self.col = col
+        self.pred_off = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n))]).astype(np.uint32)
+        self.pred_idx = src.astype(np.uint32)
+        self.n_nodes = n
+        self.plain = np.zeros(n, dtype=bool); self.plain[bb] = True      # plain backbone nodes: pins start there ...
+        self.plain[bb[snp_b]] = False; self.plain[bb[ins_b]] = False; self.plain[bb[np.minimum(snp_b + 1, nb - 1)]] = False   # ... but not at or right after a bubble
+        # haplotypes: which variants each carries; as base arrays + per-base (node, offset)
+        self.haps = []
+        for h in range(2):
+            has_snp = rng.random(len(snp_b)) < 0.5; has_ins = rng.random(len(ins_b)) < 0.5; has_del = rng.random(len(del_from)) < 0.5
+            on = np.ones(n, dtype=bool)                                    # nodes on the haplotype's walk
+            on[alt_idx] = has_snp; on[bb[snp_b]] = ~has_snp; on[ins_idx] = has_ins
+            skip = np.zeros(nb + 1, dtype=np.int64)                        # deleted backbone nodes: (del_from, del_to) exclusive
+            np.add.at(skip, del_from[has_del] + 1, 1); np.add.at(skip, del_to[has_del], -1)
+            on[bb[np.cumsum(skip[:nb]) > 0]] = False
+            nodes_on = np.nonzero(on)[0]
+            start = np.concatenate([[0], np.cumsum(node_len[nodes_on], dtype=np.int64)])
+            hseq = np.empty(int(start[-1]), dtype=np.uint8)
+            rep = np.repeat(np.arange(len(nodes_on)), node_len[nodes_on])
+            hseq[:] = seq[col[nodes_on][rep] + (np.arange(len(hseq)) - start[rep])]
+            hap_pos = np.full(n, -1, dtype=np.int64); hap_pos[nodes_on] = start[:-1]          # where a node starts on this haplotype (-1: not on it)
+            self.haps.append((hseq, hap_pos))
+
+    def arrays(self):
+        return self.node_len, self.seq, self.pred_off, self.pred_idx
+
+    def reverse_complement(self):
+        """The other strand as a graph of its own (node i -> n - 1 - i, sequences reverse-complemented, edges flipped): right tails
+        are left-pinned problems on it (src/minimizer_mapper.cpp:5665, :5720-5725)."""
+        n = self.n_nodes
+        g = object.__new__(VariationGraph)
+        g.n_nodes = n
+        g.node_len = self.node_len[::-1].copy()
+        g.seq = _comp_table()[self.seq[::-1]]
+        g.col = np.concatenate([[0], np.cumsum(g.node_len, dtype=np.int64)])
+        dst = np.repeat(np.arange(n), np.diff(self.pred_off.astype(np.int64)))     # forward edges src -> dst
+        src = self.pred_idx.astype(np.int64)
+        rs, rd = n - 1 - dst, n - 1 - src                                           # flipped: (n-1-dst) -> (n-1-src)
+        e = np.lexsort((rs, rd)); rs, rd = rs[e], rd[e]
+        g.pred_off = np.concatenate([[0], np.cumsum(np.bincount(rd, minlength=n))]).astype(np.uint32)
+        g.pred_idx = rs.astype(np.uint32)
+        g.plain = self.plain[::-1].copy()
+        g.haps = []
+        comp = _comp_table()
+        for hseq, hap_pos in self.haps:
+            on = hap_pos >= 0
+            ends = np.where(on, hap_pos + self.node_len, -1)
+            rp = np.where(on[::-1], len(hseq) - ends[::-1], -1)
+            g.haps.append((comp[hseq[::-1]], rp))
+        # a node right BEFORE a bubble on the forward strand is right after it here
+        prev_bad = np.zeros(n, dtype=bool); prev_bad[1:] = ~g.plain[:-1]
+        g.plain &= ~prev_bad
+        return g
+
+
+class GraphTails:
+    """n tails of 1..max_tail bases against `graph`: each starts at a plain backbone node (the pin) on one of the two haplotypes,
+    follows that haplotype with 1 % substitutions, and is aligned left-pinned X-drop against the window of nodes that covers
+    tail + longest_detectable_gap(2 tail, tail) more bases (src/minimizer_mapper.cpp:5809-5816) — as vgk_window_problem's."""
+
+    def __init__(self, graph, n, seed=7, max_tail=121, sub_rate=0.01, flags=capi.VGK_XDROP_PINNED | capi.VGK_GSSW_TRACEBACK):
+        rng = np.random.default_rng(seed)
+        tails = rng.integers(1, max_tail + 1, n)
+        h = rng.integers(0, 2, n)
+        cand = np.nonzero(graph.plain)[0]
+        cand = cand[cand < graph.n_nodes - 64]
+        pin = cand[rng.integers(0, len(cand), n)]
+        for k in range(2):                                       # the pin must lie on the chosen haplotype: flip the haplotype, else redraw
+            off = np.where(h == 0, graph.haps[0][1][pin], graph.haps[1][1][pin])
+            bad = off < 0
+            h[bad] ^= 1
+        off = np.where(h == 0, graph.haps[0][1][pin], graph.haps[1][1][pin])
+        bad = off < 0
+        while bad.any():                                         # (a plain node deleted on both haplotypes: rare)
+            pin[bad] = cand[rng.integers(0, len(cand), int(bad.sum()))]
+            off = np.where(h == 0, graph.haps[0][1][pin], graph.haps[1][1][pin]); bad = off < 0
+        read_off = np.concatenate([[0], np.cumsum(tails)]).astype(np.int64)
+        reads = np.empty(int(read_off[-1]), dtype=np.uint8)
+        CH = 262144                                              # fixed-width gathers, chunk by chunk (bounds host memory), then compacted
+        ar = np.arange(max_tail, dtype=np.int64)[None, :]
+        for c0 in range(0, n, CH):
+            c1 = min(n, c0 + CH)
+            t = tails[c0:c1]; m = ar < t[:, None]
+            block = np.empty((c1 - c0, max_tail), dtype=np.uint8)
+            for hh in (0, 1):
+                sel = np.nonzero(h[c0:c1] == hh)[0]
+                hseq = graph.haps[hh][0]
+                block[sel] = hseq[np.minimum(off[c0:c1][sel, None] + ar, len(hseq) - 1)]
+            sub = rng.random(block.shape) < sub_rate
+            block[sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
+            reads[read_off[c0]:read_off[c1]] = block[m]
+        gap = np.maximum(longest_detectable_gap(2 * tails, tails), 1)
+        depth = tails + np.minimum(gap, tails)
+        # the window: nodes from the pin up to the first whose end is >= depth columns past the pin's start, plus the 20-base
+        # insertion / 1-base alleles a walk of that depth may pass (columns count every node, so this over-covers slightly)
+        last = np.searchsorted(graph.col, graph.col[pin] + depth + 24, side="left")
+        last = np.minimum(last, graph.n_nodes)
+        n_nodes = (last - pin).astype(np.int64)
+        self.graph = graph; self.n = n; self.tails = tails
+        self.cols = graph.col[pin + n_nodes] - graph.col[pin]
+        self.ws = capi.WindowSet(reads, read_off, pin, n_nodes, flags, max_gap=np.minimum(gap, 65535), cols=self.cols)
+
+    def cells(self):
+        return int(((self.tails + 1) * self.cols).sum())
+
+    def subset(self, k, begin=0):
+        """problems [begin, begin + k) as a WindowSet over the same arenas"""
+        ws = self.ws
+        s = object.__new__(capi.WindowSet)
+        s.reads = ws.reads; s.read_off = ws.read_off[begin:begin + k + 1]; s.n = k; s.array = ws.array[begin:begin + k]; s.cols = ws.cols[begin:begin + k]
+        return s
