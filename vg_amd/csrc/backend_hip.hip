@@ -70,9 +70,15 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
     }
 }
 
-__global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P.n_problems) walk_one(P, i, P.best[i]);
+// One thread per read, in the order the fill placed the reads (order[] = the reads of wavefront 0, pair by pair, then wavefront 1 ...):
+// the threads of a walker wavefront then read traceback records that one or two fill wavefronts wrote next to each other, and the two
+// reads of a pair — whose codes share every dword — sit in neighbouring lanes.
+__global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P, const int in_fill_order) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!in_fill_order) { if (k < P.n_problems) walk_one(P, k, P.best[k]); return; }
+    if (k >= 2u * P.n_pairs) return;
+    const uint32_t i = P.order[k];
+    if (i != 0xffffffffu) walk_one(P, i, P.best[i]);
 }
 
 // ---- CIGAR ops on their way back: exclusive prefix sums of the per-problem op counts, then a gather ------------------
@@ -240,6 +246,7 @@ public:
     int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, copy = nullptr, fetch = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t alt = nullptr; hipEvent_t evb[3] = {nullptr, nullptr, nullptr}; float ms_fill_b = 0.f, ms_walk_b = 0.f; bool pending_b = false, timed_walk_b = false, lane1_on_main = true;   // launch lane 1
     hipEvent_t fill_done[2] = {nullptr, nullptr}; bool fill_done_set[2] = {false, false};
+    const bool walk_in_fill_order = std::getenv("VGAMD_WALK_PROBLEM_ORDER") == nullptr;
     const bool fills_take_turns = std::getenv("VGAMD_FILLS_TAKE_TURNS") != nullptr;   // experiment: a lane's fill waits for the other lane's fill, so that only a traceback
                                                                                      // runs beside a fill — no faster than one stream (the traceback takes the fill's wave slots); off
     hipDeviceProp_t prop;
@@ -385,7 +392,7 @@ public:
         hipEventRecord(fill_done[0], stream); fill_done_set[0] = true;
         timed_walk = walk && !p.fused;
         if (timed_walk) {
-            hipLaunchKernelGGL(gssw_walk_kernel, dim3((p.n_problems + 255) / 256), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL(gssw_walk_kernel, dim3((2 * p.n_pairs + 255) / 256), dim3(256), 0, stream, p, walk_in_fill_order ? 1 : 0);
             hipEventRecord(ev[2], stream);
         }
         pending = true;
@@ -413,7 +420,7 @@ public:
         hipEventRecord(fill_done[1], alt); fill_done_set[1] = true;
         timed_walk_b = walk && !p.fused;
         if (timed_walk_b) {
-            hipLaunchKernelGGL(gssw_walk_kernel, dim3((p.n_problems + 255) / 256), dim3(256), 0, alt, p);
+            hipLaunchKernelGGL(gssw_walk_kernel, dim3((2 * p.n_pairs + 255) / 256), dim3(256), 0, alt, p, walk_in_fill_order ? 1 : 0);
             hipEventRecord(evb[2], alt);
         }
         pending_b = true;
