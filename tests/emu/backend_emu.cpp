@@ -25,6 +25,7 @@ struct XlEmu {
         int32_t out = BNEG;
         if (mode == 0) { if (lane < 63) out = sh->buf[lane + 1]; }
         else if (mode == 1) { if (lane > 0) out = sh->buf[lane - 1]; }
+        else if (mode == 3) { for (uint32_t l = 0; l < 64; ++l) out = bmax(out, sh->buf[l]); }
         else for (uint32_t l = 0; l < lane; ++l) out = bmax(out, sh->buf[l]);
         pthread_barrier_wait(&sh->bar);
         return out;
@@ -33,6 +34,7 @@ struct XlEmu {
     int32_t down(int32_t v) { return exchange(v, 1); }
     int32_t scan_excl(int32_t v) { return exchange(v, 2); }
     void fence() { pthread_barrier_wait(&sh->bar); }
+    bool any(int32_t flag) { return exchange(flag ? 1 : BNEG, 3) > 0; }
 };
 template <int R, bool QA> static void banded_fill_emu(const BandedParams& P, uint32_t begin, uint32_t count) {
     XlShared sh; pthread_barrier_init(&sh.bar, nullptr, 64);
@@ -51,8 +53,20 @@ template <int R, bool QA> static void banded_fill_emu(const BandedParams& P, uin
 
 class EmuBackend final : public Backend {
 public:
+    // the wavefront form (64 threads as lanes, the banded emulation's cross-lane primitives); the one-thread form for go < ge
+    template <int R> static void matrix_wave_emu(const GsswMatrixParams& P, uint32_t lo, uint32_t hi) {
+        XlShared sh; pthread_barrier_init(&sh.bar, nullptr, 64);
+        std::vector<std::thread> ts;
+        for (uint32_t lane = 0; lane < 64; ++lane) ts.emplace_back([&, lane]() {
+            XlEmu xl{&sh, lane};
+            for (uint32_t i = 0; i < P.n; ++i) { if (P.probs[i].L <= lo || P.probs[i].L > hi) continue; gssw_matrix_wave_lane<R>(P, i, lane, xl); xl.fence(); }
+        });
+        for (auto& t : ts) t.join();
+        pthread_barrier_destroy(&sh.bar);
+    }
     int run_gssw_matrix(const GsswMatrixParams& P) override {
-        for (uint32_t i = 0; i < P.n; ++i) gssw_matrix_one(P, i);
+        if (P.go < P.ge || std::getenv("VGAMD_MATRIX_THREADS")) { for (uint32_t i = 0; i < P.n; ++i) gssw_matrix_one(P, i); return VGK_OK; }
+        matrix_wave_emu<2>(P, 0, 128); matrix_wave_emu<4>(P, 128, 256); matrix_wave_emu<8>(P, 256, 512); matrix_wave_emu<16>(P, 512, 1024);
         return VGK_OK;
     }
     int run_wfa(const WfaParams& P, uint32_t threads) override {

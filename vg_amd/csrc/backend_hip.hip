@@ -165,6 +165,7 @@ struct XlDpp {
         return dpp_down(v);
     }
     __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+    __device__ __forceinline__ bool any(int32_t flag) const { return __ballot(flag != 0) != 0ull; }
 };
 
 template <int R, bool QA, bool LDS>
@@ -235,10 +236,19 @@ __global__ void __launch_bounds__(64, 4) wfa_kernel(const WfaParams P, const uin
     if (t < threads) wfa_thread(P, t, node_end + threadIdx.x, 64);
 }
 
-// ---- pinned gssw fill with full matrices (gssw_matrix_device.hpp)
+// ---- pinned gssw fill with full matrices (gssw_matrix_device.hpp): one wavefront per problem, R read rows per lane; the
+//      one-thread-per-problem form remains for scorings with gap_open < gap_extend
 __global__ void __launch_bounds__(64) gssw_matrix_kernel(const GsswMatrixParams P) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i < P.n) gssw_matrix_one(P, i);
+}
+template <int R>
+__global__ void __launch_bounds__(64) gssw_matrix_wave_kernel(const GsswMatrixParams P, const uint32_t rows_lo, const uint32_t rows_hi) {
+    const uint32_t i = blockIdx.x;
+    const uint32_t L = P.probs[i].L;
+    if (L <= rows_lo || L > rows_hi) return;           // another rows-per-lane class takes this problem
+    XlDpp xl;
+    gssw_matrix_wave_lane<R>(P, i, threadIdx.x, xl);
 }
 
 class HipBackend final : public Backend {
@@ -505,7 +515,13 @@ public:
     int run_gssw_matrix(const GsswMatrixParams& p) override {
         hipSetDevice(dev);
         if (!p.n) return VGK_OK;
-        hipLaunchKernelGGL(gssw_matrix_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
+        if (p.go < p.ge || std::getenv("VGAMD_MATRIX_THREADS")) hipLaunchKernelGGL(gssw_matrix_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
+        else {      // one launch per rows-per-lane class; a wavefront whose problem belongs to another class returns at once
+            hipLaunchKernelGGL((gssw_matrix_wave_kernel<2>), dim3(p.n), dim3(64), 0, stream, p, 0u, 128u);
+            hipLaunchKernelGGL((gssw_matrix_wave_kernel<4>), dim3(p.n), dim3(64), 0, stream, p, 128u, 256u);
+            hipLaunchKernelGGL((gssw_matrix_wave_kernel<8>), dim3(p.n), dim3(64), 0, stream, p, 256u, 512u);
+            hipLaunchKernelGGL((gssw_matrix_wave_kernel<16>), dim3(p.n), dim3(64), 0, stream, p, 512u, 1024u);
+        }
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         return VGK_OK;
     }

@@ -7,6 +7,12 @@
 //   E[r][c] = max(0, H[r][c-1] - go, E[r][c-1] - ge)   F[r][c] = max(0, H[r-1][c] - go, F[r-1][c] - ge)
 //   H[r][c] = max(H[r-1][c-1] + s(r, c), E[r][c], F[r][c]);   "c-1" at a node's first column = element-wise max over the
 //   predecessors' last columns (gssw_create_seed_*); bonus at read row 0 only (pinned: the other end is the pinned one).
+// Two fills produce the same matrices: gssw_matrix_one (one thread per problem, the plain loops — kept for scorings with
+// gap_open < gap_extend, where the column scan below does not apply, and as the emulator's cross-check) and
+// gssw_matrix_wave_lane (one WAVEFRONT per problem: lane l owns the R consecutive read rows l*R .., a column is one step of the
+// whole wave, the previous column lives in registers, and the vertical gap F comes from a max-plus prefix scan over the rows —
+// F[r] = max(0, max_{r' < r} (Ht[r'] + r' ge) - go - (r - 1) ge) with Ht = max(diagonal + s, E), exact for go >= ge — serial inside
+// a lane and one DPP scan across lanes, as in the banded kernel).  Cells leave as coalesced runs of 64 R int32 per plane.
 // The alternates are enumerated on the host over these matrices (gssw_multi_api.cpp).
 #pragma once
 #include <stdint.h>
@@ -80,6 +86,85 @@ VGK_HD void gssw_matrix_one(const GsswMatrixParams& P, uint32_t i) {
         }
     }
     pb.status = status;
+}
+
+// XL = the cross-lane primitives of banded_device.hpp (down, scan_excl, fence).  Rows beyond the read compute harmless values that
+// are never stored (they only read rows above them).
+constexpr int32_t MNEG = -(1 << 28);
+template <int R, class XL>
+VGK_HD void gssw_matrix_wave_lane(const GsswMatrixParams& P, uint32_t i, uint32_t lane, XL& xl) {
+    MProb& pb = P.probs[i];
+    const int32_t L = (int32_t)pb.L, go = P.go, ge = P.ge;
+    const uint64_t plane = (uint64_t)pb.R * pb.L;
+    int32_t* H = P.cells + pb.mat_off; int32_t* E = H + plane; int32_t* F = E + plane;
+    const uint8_t* rd = P.reads + pb.read_off; const uint8_t* ql = P.quals ? P.quals + pb.read_off : nullptr;
+    const uint8_t* gr = P.graph + pb.graph_off;
+    const MNode* nodes = P.nodes + pb.node_off;
+    const int32_t r0 = (int32_t)lane * R;
+    // the lane's rows: score of each row against the five reference codes (the query profile: bonus at read row 0 folded in)
+    int32_t prof[R][5];
+    for (int k = 0; k < R; ++k) {
+        const int32_t r = r0 + k;
+        for (int g = 0; g < 5; ++g)
+            prof[k][g] = r < L ? (int32_t)(ql ? P.mat[25 * ql[r] + 5 * g + rd[r]] : P.mat[5 * g + rd[r]]) + (r == 0 ? pb.start_bonus : 0) : 0;
+    }
+    int32_t Hp[R], Ep[R];               // previous column: H, and E of that column (the next column's E derives from both)
+    int32_t overflow = 0;
+    for (uint32_t v = 0; v < pb.n_nodes; ++v) {
+        const MNode nd = nodes[v];
+        for (uint32_t c = nd.col_start; c < nd.col_end; ++c) {
+            const bool first = c == nd.col_start;
+            int32_t e[R], dg[R];                                   // this column's E, and the diagonal H (previous column, row above)
+            if (!first) {
+                int32_t up = xl.down(Hp[R - 1]);                   // previous column, last row of the lane above
+                if (lane == 0) up = 0;
+                for (int k = 0; k < R; ++k) {
+                    const int32_t a = Hp[k] - go, b = Ep[k] - ge; int32_t x = a > b ? a : b; e[k] = x > 0 ? x : 0;
+                    dg[k] = k ? Hp[k - 1] : up;
+                }
+            } else {
+                // the node's first column: element-wise max over the predecessors' last columns (gssw_create_seed_*), read back from
+                // the matrices (the wave wrote them; fenced at the end of every column of a node's last column below)
+                for (int k = 0; k < R; ++k) { e[k] = 0; dg[k] = 0; }
+                for (uint32_t q = 0; q < nd.n_pred; ++q) {
+                    const uint64_t pc = (uint64_t)(nodes[P.preds[nd.pred_begin + q]].col_end - 1) * pb.L;
+                    for (int k = 0; k < R; ++k) {
+                        const int32_t r = r0 + k;
+                        if (r < L) {
+                            const int32_t ph = H[pc + r], pe = E[pc + r];
+                            const int32_t a = ph - go, b = pe - ge; int32_t x = a > b ? a : b; x = x > 0 ? x : 0;
+                            if (x > e[k]) e[k] = x;
+                        }
+                        if (r >= 1 && r - 1 < L) { const int32_t ph = H[pc + r - 1]; if (ph > dg[k]) dg[k] = ph; }
+                    }
+                }
+            }
+            const uint32_t ref = gr[c];
+            int32_t ht[R], pre[R], run = MNEG;
+            for (int k = 0; k < R; ++k) {
+                const int32_t r = r0 + k;
+                int32_t h = (r == 0 ? 0 : dg[k]) + prof[k][ref];
+                if (e[k] > h) h = e[k];
+                ht[k] = h;
+                pre[k] = run;
+                const int32_t gk = h + r * ge;
+                run = gk > run ? gk : run;
+            }
+            const int32_t excl = xl.scan_excl(run);                // max over the rows of the lanes above (MNEG for lane 0)
+            for (int k = 0; k < R; ++k) {
+                const int32_t r = r0 + k;
+                const int32_t pm = excl > pre[k] ? excl : pre[k];
+                int32_t f = pm - go - (r - 1) * ge; f = (r > 0 && f > 0) ? f : 0;
+                const int32_t h = ht[k] > f ? ht[k] : f;
+                if (h >= 32767) overflow = 1;                       // gssw's int16 limit
+                if (r < L) { const uint64_t at = (uint64_t)c * pb.L + r; H[at] = h; E[at] = e[k]; F[at] = f; }
+                Hp[k] = h; Ep[k] = e[k];
+            }
+        }
+        xl.fence();                                                // successors read this node's last column through memory
+    }
+    if (xl.any(overflow) && lane == 0) pb.status = VGK_EOVERFLOW;
+    else if (lane == 0) pb.status = VGK_OK;
 }
 
 }  // namespace vgk
