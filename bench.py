@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+RDEV = "cpu" if os.environ.get("VGAMD_BENCH_ONE_DEVICE") == "1" else "cuda"      # where the max-reduce of the times lives (gloo in the one-device check)
 
 # HBM bytes per unit of work of the dominant kernel, from the PMC passes committed under profiles/r01 (rocprofv3 --pmc FETCH_SIZE and
 # --pmc WRITE_SIZE in separate runs of this very command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py
@@ -67,7 +68,7 @@ def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     res, ext, nodes, mism = out
@@ -133,7 +134,7 @@ def bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     res, paths, edits = out
@@ -208,7 +209,7 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     cpu = parity = None
@@ -295,7 +296,7 @@ def bench_tails(args, eng, rank, world, dist, torch, dev_name, cus):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tf = time.perf_counter()
@@ -373,7 +374,17 @@ def main():
     rank, local_rank, world = shard.env_rank()
     import torch   # first, so its bundled HIP runtime is the one the engine library binds to
     dist = None
-    if world > 1:
+    # VGAMD_BENCH_ONE_DEVICE=1: a functional check of the N > 1 code path on a box with ONE GPU (every rank on device 0, gloo for
+    # the barrier / max-reduce, since RCCL refuses two ranks on one device).  Not a measurement.
+    one_device = world > 1 and os.environ.get("VGAMD_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
+    if world > 1 and one_device:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -446,7 +457,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     one_stream = {"ms_per_step": 1e3 * elapsed / args.steps, "fill_ms": sum(fill_ms) / len(fill_ms), "traceback_ms": sum(walk_ms) / len(walk_ms),
@@ -470,7 +481,7 @@ def main():
             barrier()
             e2 = time.perf_counter() - t0
             if dist is not None:
-                t = torch.tensor([e2], dtype=torch.float64, device="cuda")
+                t = torch.tensor([e2], dtype=torch.float64, device=RDEV)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 e2 = float(t.item())
             # the last launch on either lane, timed by HIP events on its own stream while the other lane was busy
@@ -587,7 +598,7 @@ def main():
 
     if dist is not None and t_warm is not None:
         barrier()
-        t = torch.tensor([t_warm, t_pipe], dtype=torch.float64, device="cuda")
+        t = torch.tensor([t_warm, t_pipe], dtype=torch.float64, device=RDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_warm, t_pipe = float(t[0].item()), float(t[1].item())
     if rank == 0:
