@@ -312,3 +312,45 @@ def test_host_shim_gapless_extender_on_the_oracle():
 @pytest.mark.gpu
 def test_host_shim_gapless_extender_on_hip():
     shim_cases(util.ENGINE_LIB)
+
+
+def many_haplotypes(lib, n_haplotypes=300):
+    """Hundreds of haplotypes over a small bubble chain: the visits of a node leave through the same edge in long runs, so the
+    engine's index stores most record bodies run-length encoded (GBWT's own form; gapless_device.hpp) — the oracle's index stays
+    uncompressed, and both must give the same extensions."""
+    rng = np.random.default_rng(77)
+    tot = 0
+    for rep in range(4):
+        nodes, threads, problems = random_haplotype_case(rng, n_reads=150, n_haplotypes=n_haplotypes, chain_nodes=18)
+        eng = capi.Engine(lib=lib); ora = capi.Engine(lib=util.ORACLE_LIB)
+        a = eng.gapless_extend(eng.haplo_index(nodes, threads), problems)
+        b = ora.gapless_extend(ora.haplo_index(nodes, threads), problems)
+        # problem by problem (with this much diversity a search may outgrow the engine's per-seed limits: VGK_ETOOBIG for that read, none
+        # of the others moves)
+        (ra, ea, na, ma), (rb, eb, nb, mb) = a, b
+        declined = 0
+        for i in range(len(ra)):
+            if ra["status"][i] != 0:
+                assert ra["status"][i] == -7; declined += 1; continue
+            assert rb["status"][i] == 0 and ra["n_ext"][i] == rb["n_ext"][i] and ra["full_length"][i] == rb["full_length"][i], (rep, i)
+            for k in range(ra["n_ext"][i]):
+                x, y = ea[ra["ext_begin"][i] + k], eb[rb["ext_begin"][i] + k]
+                for f in ("path_len", "offset", "read_begin", "read_end", "n_mismatches", "score", "left_full", "right_full"):
+                    assert x[f] == y[f], (rep, i, k, f)
+                assert (x["state"] == y["state"]).all(), (rep, i, k)
+                assert (na[x["path_begin"]:x["path_begin"] + x["path_len"]] == nb[y["path_begin"]:y["path_begin"] + y["path_len"]]).all()
+                assert (ma[x["mism_begin"]:x["mism_begin"] + x["n_mismatches"]] == mb[y["mism_begin"]:y["mism_begin"] + y["n_mismatches"]]).all()
+        assert declined <= 3
+        tot += int(ra["n_ext"].sum())
+    assert tot > 300
+
+
+def test_run_length_encoded_records_with_many_haplotypes(monkeypatch):
+    many_haplotypes(util.EMU_LIB)
+    monkeypatch.setenv("VGAMD_HAPLO_NO_RLE", "1")        # the byte-per-visit form of the same index gives the same answers
+    many_haplotypes(util.EMU_LIB)
+
+
+@pytest.mark.gpu
+def test_run_length_encoded_records_with_many_haplotypes_on_the_gpu():
+    many_haplotypes(util.ENGINE_LIB, 2000)

@@ -131,21 +131,27 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
             edge_base[(uint32_t)(std::lower_bound(first, last, (int32_t)w) - edge_to.data())] = i;
         }
     }
-    // one padded record per oriented node (layout in gapless_device.hpp): sizes first, so that every edge can name its successor's record
-    std::vector<uint32_t> rec_off(O + 1, 0), rec;
+    // one padded record per oriented node (layout in gapless_device.hpp): sizes first, so that every edge can name its successor's
+    // record.  The visit body of a record is stored as bytes or run-length encoded (one word per run), whichever is smaller.
+    std::vector<uint32_t> rec_off(O + 1, 0), rec, runs_of(O, 0);
+    const bool allow_rle = std::getenv("VGAMD_HAPLO_NO_RLE") == nullptr;
     { uint64_t at = 0;
       for (uint32_t o = 0; o < O; ++o) {
           const uint32_t ne = edge_off[o + 1] - edge_off[o];
           if (ne > 255 || count[o] > 65535 || len[o] > 65535) return VGK_ETOOBIG;      // edge numbers are bytes, ranks and lengths 16 bits
+          uint32_t runs = 0;
+          for (uint32_t i = 0; i < count[o]; ++i) if (!i || body[body_off[o] + i] != body[body_off[o] + i - 1]) ++runs;
+          const bool rle = allow_rle && runs && 4ull * runs < (count[o] + 3) / 4 * 4;
+          runs_of[o] = rle ? runs : 0;
           rec_off[o] = (uint32_t)at;
-          at += (4 + 4ull * ne + (count[o] + 3) / 4 + 15) / 16 * 16;
+          at += (4 + 4ull * ne + (rle ? runs : (count[o] + 3) / 4) + 15) / 16 * 16;
           if (at > 0xfffffff0ull) return VGK_ETOOBIG;
       }
       rec_off[O] = (uint32_t)at; rec.assign(at, 0); }
     for (uint32_t o = 0; o < O; ++o) {
         uint32_t* r = rec.data() + rec_off[o];
         const uint32_t ne = edge_off[o + 1] - edge_off[o];
-        r[0] = count[o]; r[1] = ne; r[2] = len[o]; r[3] = seq_off[o];
+        r[0] = count[o]; r[1] = ne | (runs_of[o] ? 0x80000000u : 0u); r[2] = len[o]; r[3] = seq_off[o];
         for (uint32_t k = 0; k < ne; ++k) {
             const int32_t to = edge_to[edge_off[o] + k];
             r[4 + 4 * k] = (uint32_t)to;
@@ -154,7 +160,14 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
             r[7 + 4 * k] = to >= 0 ? rec_off[(uint32_t)to] : 0u;
         }
         uint32_t* visits = r + 4 + 4 * ne;
-        for (uint32_t i = 0; i < count[o]; ++i) visits[i >> 2] |= body[body_off[o] + i] << (8 * (i & 3u));
+        if (runs_of[o]) {
+            uint32_t k = 0;
+            for (uint32_t i = 0; i < count[o];) {
+                uint32_t j = i; while (j < count[o] && body[body_off[o] + j] == body[body_off[o] + i]) ++j;
+                visits[k++] = body[body_off[o] + i] | ((j - i) << 8);
+                i = j;
+            }
+        } else for (uint32_t i = 0; i < count[o]; ++i) visits[i >> 2] |= body[body_off[o] + i] << (8 * (i & 3u));
     }
     rec_off[O] = (uint32_t)rec.size();
     vgk_haplo* h = new vgk_haplo();

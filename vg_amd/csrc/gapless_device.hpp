@@ -25,6 +25,10 @@ namespace vgk {
 //     the successor's record — everything a hop needs to start comparing bases and to fetch the next record without first
 //     reading the successor's own record through rec_off (two dependent loads saved per hop)
 //   then per visit: the number of the edge it leaves through, one byte each (a record of 16 visits and 2 edges is one 64-byte line)
+//   — or, when word 1 has bit 31 set, the same sequence RUN-LENGTH encoded like a GBWT record body: one word per run, edge number in
+//   the low byte, run length above it.  Thousands of haplotypes that share a path leave a node through the same edge in long runs
+//   (the visits are sorted by where they came from), so a record of 5000 visits is typically a handful of words instead of 5 KB, and
+//   extending a search state is a walk over those runs.  The builder picks whichever form is smaller per record.
 struct GIndex {                       // device pointers
     uint32_t n_oriented;
     const uint32_t* rec_off;          // per oriented node, in words
@@ -40,7 +44,9 @@ VGK_HD uint32_t ge_base(const uint32_t* rec, uint32_t e) { return rec[5 + 4 * e]
 VGK_HD uint32_t ge_len(const uint32_t* rec, uint32_t e) { return rec[5 + 4 * e] >> 16; }
 VGK_HD uint32_t ge_seq(const uint32_t* rec, uint32_t e) { return rec[6 + 4 * e]; }
 VGK_HD uint32_t ge_rec(const uint32_t* rec, uint32_t e) { return rec[7 + 4 * e]; }
-VGK_HD const uint32_t* g_visits(const uint32_t* rec) { return rec + 4 + 4 * rec[1]; }
+VGK_HD uint32_t g_ne(const uint32_t* rec) { return rec[1] & 0xffffu; }          // outgoing edges
+VGK_HD bool g_rle(const uint32_t* rec) { return (rec[1] >> 31) != 0; }         // the visit body is run-length encoded
+VGK_HD const uint32_t* g_visits(const uint32_t* rec) { return rec + 4 + 4 * g_ne(rec); }
 struct GProb { uint32_t read_off, read_len, seed_off, n_seeds, max_mm, flags; double overlap; };
 
 struct GState { int32_t fn, flo, fhi, bn, blo, bhi; };      // forward / backward strand: node, visit range [lo, hi]
@@ -59,6 +65,17 @@ struct GCounts { uint64_t before, inside; };
 VGK_HD GCounts g_counts(const uint32_t* rec, int32_t lo, int32_t hi) {
     const uint32_t* body = g_visits(rec);
     GCounts c = { 0, 0 };
+    if (g_rle(rec)) {
+        int32_t pos = 0;
+        for (uint32_t k = 0; pos <= hi; ++k) {
+            const uint32_t run = body[k]; const int32_t len = (int32_t)(run >> 8), end = pos + len;      // visits [pos, end)
+            const int32_t b = (end < lo ? end : lo) - pos, last = end - 1 < hi ? end - 1 : hi, first = pos > lo ? pos : lo;
+            if (b > 0) c.before += (uint64_t)b << (16 * (run & 3u));
+            if (last >= first) c.inside += (uint64_t)(last - first + 1) << (16 * (run & 3u));
+            pos = end;
+        }
+        return c;
+    }
     for (int32_t i = 0; i <= hi; i += 4) {
         uint32_t w = body[i >> 2];
         for (int32_t k = 0; k < 4 && i + k <= hi; ++k, w >>= 8) {
@@ -76,7 +93,7 @@ VGK_HD GState gs_extend_counted(const uint32_t* rec, const GState& s, uint32_t e
     const int32_t inside = (int32_t)g_count_of(cn.inside, e);
     if (!inside) { r.flo = 0; r.fhi = -1; r.bhi = r.blo - 1; return r; }
     int32_t rev_off = 0;
-    for (uint32_t x = 0; x < rec[1]; ++x) if (x != e && g_rkey(ge_to(rec, x)) < g_rkey(to)) rev_off += (int32_t)g_count_of(cn.inside, x);
+    for (uint32_t x = 0; x < g_ne(rec); ++x) if (x != e && g_rkey(ge_to(rec, x)) < g_rkey(to)) rev_off += (int32_t)g_count_of(cn.inside, x);
     r.flo = (int32_t)ge_base(rec, e) + (int32_t)g_count_of(cn.before, e); r.fhi = r.flo + inside - 1;
     r.blo = s.blo + rev_off; r.bhi = r.blo + inside - 1;
     return r;
@@ -85,13 +102,24 @@ VGK_HD GState gs_extend_counted(const uint32_t* rec, const GState& s, uint32_t e
 VGK_HD GState gs_extend(const GIndex& h, const GState& s, int32_t to) {
     const uint32_t o = (uint32_t)s.fn;
     const uint32_t* rec = g_rec(h, o);
-    const uint32_t ne = rec[1];
+    const uint32_t ne = g_ne(rec);
     const uint32_t* body = g_visits(rec);
     uint32_t e = 0; while (e < ne && ge_to(rec, e) != to) ++e;
     GState r = s; r.fn = to;
     if (e == ne || gs_empty(s)) { r.flo = 0; r.fhi = -1; r.bhi = r.blo - 1; return r; }
     if (ne <= 4) return gs_extend_counted(rec, s, e, g_counts(rec, s.flo, s.fhi));
     int32_t before = 0, inside = 0, rev_off = 0;
+    if (g_rle(rec)) {
+        int32_t pos = 0;
+        for (uint32_t k = 0; pos <= s.fhi; ++k) {
+            const uint32_t run = body[k], b = run & 0xffu; const int32_t end = pos + (int32_t)(run >> 8);
+            const int32_t nb = (end < s.flo ? end : s.flo) - pos, last = end - 1 < s.fhi ? end - 1 : s.fhi, first = pos > s.flo ? pos : s.flo;
+            const int32_t in = last >= first ? last - first + 1 : 0;
+            if (b == e) { if (nb > 0) before += nb; inside += in; }
+            else if (in && g_rkey(ge_to(rec, b)) < g_rkey(to)) rev_off += in;
+            pos = end;
+        }
+    } else
     for (int32_t i = 0; i <= s.fhi; ++i) {
         const uint32_t b = g_body(body, (uint32_t)i);
         if (b == e) { if (i < s.flo) ++before; else ++inside; }
@@ -539,9 +567,9 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, ST& Q, GScra
                 const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
                 if (cur.frec == G_NO_REC) cur.frec = h.rec_off[(uint32_t)cur.state.fn];
                 const uint32_t* orec = h.rec + cur.frec;
-                const bool few = orec[1] <= 4 && !gs_empty(cur.state);
+                const bool few = g_ne(orec) <= 4 && !gs_empty(cur.state);
                 const GCounts cn = few ? g_counts(orec, cur.state.flo, cur.state.fhi) : GCounts{0, 0};
-                for (uint32_t e = 0; e < orec[1]; ++e) {
+                for (uint32_t e = 0; e < g_ne(orec); ++e) {
                     const int32_t w = ge_to(orec, e); if (w < 0) continue;
                     const GState ns = few ? gs_extend_counted(orec, cur.state, e, cn) : gs_extend(h, cur.state, w);
                     if (gs_empty(ns)) continue;
@@ -575,9 +603,9 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, ST& Q, GScra
                 if (cur.brec == G_NO_REC) cur.brec = h.rec_off[(uint32_t)cur.state.bn];
                 const uint32_t* orec = h.rec + cur.brec;
                 const GState flipped = gs_flip(cur.state);
-                const bool few = orec[1] <= 4 && !gs_empty(flipped);
+                const bool few = g_ne(orec) <= 4 && !gs_empty(flipped);
                 const GCounts cn = few ? g_counts(orec, flipped.flo, flipped.fhi) : GCounts{0, 0};
-                for (uint32_t e = 0; e < orec[1]; ++e) {
+                for (uint32_t e = 0; e < g_ne(orec); ++e) {
                     const int32_t x = ge_to(orec, e); if (x < 0) continue;
                     const GState ns = gs_flip(few ? gs_extend_counted(orec, flipped, e, cn) : gs_extend(h, flipped, x));   // bdExtendBackward
                     if (gs_empty(ns)) continue;

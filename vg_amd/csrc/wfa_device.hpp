@@ -155,9 +155,10 @@ struct WState { int32_t node, lo, hi; };
 VGK_HD uint32_t w_follow(const GIndex& h, const WState& s, uint32_t want, WState& out, uint32_t stop_at) {
     if (s.lo > s.hi) return 0;
     const uint32_t* rec = g_rec(h, (uint32_t)s.node);
-    const uint32_t ne = rec[1];
+    const uint32_t ne = g_ne(rec);
     const uint32_t* body = g_visits(rec);
     const bool few = ne <= 4;
+    const bool rle = g_rle(rec);
     const GCounts cn = few ? g_counts(rec, s.lo, s.hi) : GCounts{0, 0};     // one pass over the visits serves every edge
     uint32_t k = 0;
     for (uint32_t e = 0; e < ne && k < stop_at; ++e) {
@@ -165,6 +166,18 @@ VGK_HD uint32_t w_follow(const GIndex& h, const WState& s, uint32_t want, WState
         if (to < 0) continue;
         int32_t before = 0, inside = 0;
         if (few) { before = (int32_t)g_count_of(cn.before, e); inside = (int32_t)g_count_of(cn.inside, e); }
+        else if (rle) {
+            int32_t pos = 0;
+            for (uint32_t k = 0; pos <= s.hi; ++k) {
+                const uint32_t run = body[k]; const int32_t end = pos + (int32_t)(run >> 8);
+                if ((run & 0xffu) == e) {
+                    const int32_t nb = (end < s.lo ? end : s.lo) - pos, last = end - 1 < s.hi ? end - 1 : s.hi, first = pos > s.lo ? pos : s.lo;
+                    if (nb > 0) before += nb;
+                    if (last >= first) inside += last - first + 1;
+                }
+                pos = end;
+            }
+        }
         else for (int32_t i = 0; i <= s.hi; ++i) if (g_body(body, (uint32_t)i) == e) { if (i < s.lo) ++before; else ++inside; }
         if (!inside) continue;
         if (k == want) { out.node = to; out.lo = (int32_t)ge_base(rec, e) + before; out.hi = out.lo + inside - 1; }
