@@ -203,6 +203,21 @@ typedef struct vgk_window_problem {
  * out-of-range problem (in index order) decides the return code, as a serial scan would. */
 int  vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* graph, const char* reads, size_t reads_bytes,
                            const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out);
+/* ---- X-drop with dozeu's band (src/dozeu_interface.cpp:226, :261-283; src/xdrop_aligner.cpp:95-109) ------------------------------
+ * VGK_XDROP_PINNED through vgk_gssw_* keeps every cell: it returns the exact semi-global optimum, which is dozeu's answer whenever
+ * dozeu's band contains the optimal path.  This entry point restates the band itself [PARITY-UNPINNED: dozeu's source is not in the
+ * reference snapshot; the rules below are this engine's reading of the published algorithm, stated identically in
+ * oracle/vgo_xdrop.c]: rows are grouped in dozeu's 8-cell vectors; a column keeps the vectors from the first to the last one that
+ * holds a cell within xt = (gap_open - gap_extend) + gap_extend * max_gap_length of the best score reached so far on the way to
+ * that column (the maximum over the predecessors' fronts, updated after every column); cells outside are unreachable from then on;
+ * a node whose incoming fronts are all empty is skipped.  Everything else — root column, seeds, bonus, end cell, traceback
+ * preferences — is as in VGK_XDROP_PINNED.  Problems must be VGK_XDROP_PINNED (| VGK_GSSW_TRACEBACK); reads up to 511 bases.
+ * stats (nullable): [0] cells inside the bands, [1] cells of the full read x graph rectangles.
+ * One wavefront per problem fills the columns (one 8-row vector per lane), the matrices come back and host threads trace. */
+int  vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
+                          vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written, uint64_t stats[2]);
+double vgk_xdrop_band_last_ms(vgk_ctx* ctx);     /* fill-kernel time of the last vgk_xdrop_band_align call on this context */
+
 /* k-best pinned alignments (Aligner::align_pinned_multi -> gssw_graph_trace_back_pinned_multi, src/aligner.cpp:423-435, :455-480).
  * Every problem must be VGK_GSSW_PINNED.  results[i * max_alt_alns + k] is the k-th best alignment of problem i (k <
  * n_alignments[i] <= max_alt_alns), scores non-increasing and > 0, the first one the alignment vgk_gssw_align returns; a problem

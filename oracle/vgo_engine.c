@@ -122,6 +122,41 @@ int vgk_gssw_run(vgk_batch* b) {
     b->ran = 1; return VGK_OK;
 }
 
+int vgo_xdrop_band_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p,
+                           vgk_result* res, vgk_op* ops, uint32_t ops_cap, uint64_t* stats);
+int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
+                         vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written, uint64_t stats[2]) {
+    if (!ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
+    for (uint32_t i = 0; i < n; ++i) if ((problems[i].flags & 15u) != VGK_XDROP_PINNED) return VGK_EINVAL;
+    size_t* slot = (size_t*)malloc(sizeof(size_t) * ((size_t)n + 1));
+    slot[0] = 0;
+    for (uint32_t i = 0; i < n; ++i) slot[i + 1] = slot[i] + default_ops(&problems[i]);
+    vgk_op* scratch = (vgk_op*)malloc(sizeof(vgk_op) * (slot[n] + 1));
+    uint64_t s0 = 0, s1 = 0;
+    const vgk_qual_adj* qa = ctx->has_qa ? &ctx->qa : NULL;
+    #pragma omp parallel for schedule(dynamic, 16) reduction(+:s0, s1)
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t st[2] = {0, 0};
+        if (problems[i].read_len > 511) { memset(&results[i], 0, sizeof results[i]); results[i].status = VGK_ETOOLONG; continue; }
+        vgo_xdrop_band_align_q(&ctx->sc, qa, &problems[i], &results[i], scratch + slot[i], (uint32_t)(slot[i + 1] - slot[i]), st);
+        s0 += st[0]; s1 += st[1];
+    }
+    size_t used = 0; int rc = VGK_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (results[i].status == VGK_OK && results[i].n_ops) {
+            if (!ops || used + results[i].n_ops > ops_cap) { results[i].status = VGK_EOPS; results[i].n_ops = 0; rc = VGK_EOPS; }
+            else memcpy(ops + used, scratch + slot[i], sizeof(vgk_op) * results[i].n_ops);
+        } else results[i].n_ops = 0;
+        results[i].ops_begin = (uint32_t)used; used += results[i].n_ops;
+    }
+    free(scratch); free(slot);
+    if (ops_written) *ops_written = used;
+    if (stats) { stats[0] = s0; stats[1] = s1; }
+    return rc;
+}
+
+double vgk_xdrop_band_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }
+
 /* threads of the OpenMP loops below (bench.py sets the CPUs the container may really use; the default is every hardware thread) */
 #include <omp.h>
 void vgo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }

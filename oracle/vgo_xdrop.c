@@ -59,8 +59,18 @@ int vgo_xdrop_pinned_align(const vgk_scoring* sc, const vgk_gssw_problem* p,
 
 /* qa != NULL: QualAdjXdropAligner (src/qual_adj_xdrop_aligner.cpp:74-135); the single bonus is the quality-adjusted
  * one of the far-end base (src/aligner.cpp:1164-1167). */
+static int xdrop_core(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p,
+                      vgk_result* res, vgk_op* ops, uint32_t ops_cap, int band, uint64_t* stats);
 int vgo_xdrop_pinned_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p,
-                             vgk_result* res, vgk_op* ops, uint32_t ops_cap)
+                             vgk_result* res, vgk_op* ops, uint32_t ops_cap) { return xdrop_core(sc, qa, p, res, ops, ops_cap, 0, NULL); }
+/* The same with dozeu's band [PARITY-UNPINNED, see include/vgk.h vgk_xdrop_band_align]: after every column the front shrinks to the
+ * 8-row vectors between the first and the last one holding a cell >= (best so far on the way here) - xt; cells outside become
+ * unreachable.  stats[0] += cells inside the bands, stats[1] += (L + 1) * R. */
+int vgo_xdrop_band_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p,
+                           vgk_result* res, vgk_op* ops, uint32_t ops_cap, uint64_t* stats) { return xdrop_core(sc, qa, p, res, ops, ops_cap, 1, stats); }
+
+static int xdrop_core(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p,
+                      vgk_result* res, vgk_op* ops, uint32_t ops_cap, int band, uint64_t* stats)
 {
     const int L = (int)p->read_len;
     const vgk_graph* g = &p->graph;
@@ -108,14 +118,21 @@ int vgo_xdrop_pinned_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, cons
 #define SCORE(i, c) ((int)(qa ? qa->matrix[25 * p->qual[(i) - 1] + 5 * rf[c] + rd[(i) - 1]] : sc->matrix[5 * rf[c] + rd[(i) - 1]]) + ((i) == L ? bonus : 0))
 
     int32_t best = 0; int best_c = -1, best_i = 0;
+    const int32_t xt = (go - ge) + ge * max_gap;                 /* dozeu's x-drop threshold (dz_align_init) */
+    int32_t* node_fmax = (int32_t*)malloc(sizeof(int32_t) * (size_t)nV);      /* band mode: best score on the way to the end of each node */
+    uint64_t in_band = 0;
     for (int n = 0; n < nV; ++n) {
         const int npred = (int)(g->pred_off[n + 1] - g->pred_off[n]);
+        int32_t fmax = 0;                                        /* the root's best: nothing consumed, score 0 */
+        int front_live = 0;
         if (npred == 0) { memcpy(seedH, rootH, sizeof(int32_t) * (size_t)(L + 1)); memcpy(seedE, rootE, sizeof(int32_t) * (size_t)(L + 1)); }
         else {
+            fmax = NEG;
             for (int i = 0; i <= L; ++i) { seedH[i] = NEG; seedE[i] = NEG; }
             for (uint32_t k = g->pred_off[n]; k < g->pred_off[n + 1]; ++k) {
                 const int pc = col0[g->pred_idx[k] + 1] - 1;
                 for (int i = 0; i <= L; ++i) { seedH[i] = imax(seedH[i], H[IDX(pc, i)]); seedE[i] = imax(seedE[i], En[IDX(pc, i)]); }
+                fmax = imax(fmax, node_fmax[g->pred_idx[k]]);
             }
         }
         for (int c = col0[n]; c < col0[n + 1]; ++c) {
@@ -134,11 +151,31 @@ int vgo_xdrop_pinned_align_q(const vgk_scoring* sc, const vgk_qual_adj* qa, cons
                 H[IDX(c, i)] = h; E[IDX(c, i)] = e; F[IDX(c, i)] = f;
                 int32_t en = imax(h - go, e - ge); if (en < NEG) en = NEG;
                 En[IDX(c, i)] = en;
-                if (h > colmax) { colmax = h; colmax_i = i; }
+                if (!band && h > colmax) { colmax = h; colmax_i = i; }
+            }
+            if (band) {
+                /* the front of this column: 8-row vectors from the first to the last one with a cell >= fmax - xt */
+                const int nb = (L + 8) / 8; int sb = nb, eb = 0;
+                for (int b = 0; b < nb; ++b) {
+                    int alive = 0;
+                    for (int i = 8 * b; i < 8 * b + 8 && i <= L; ++i) if (H[IDX(c, i)] > NEG / 2 && H[IDX(c, i)] >= fmax - xt) alive = 1;
+                    if (alive) { if (b < sb) sb = b; eb = b + 1; }
+                }
+                for (int i = 0; i <= L; ++i) {
+                    const int b = i / 8;
+                    if (b < sb || b >= eb) { H[IDX(c, i)] = E[IDX(c, i)] = F[IDX(c, i)] = En[IDX(c, i)] = NEG; continue; }
+                    ++in_band;
+                    if (H[IDX(c, i)] > colmax) { colmax = H[IDX(c, i)]; colmax_i = i; }
+                }
+                fmax = imax(fmax, colmax);
+                front_live = eb > sb;
             }
             if (colmax > best) { best = colmax; best_c = c; best_i = colmax_i; }
         }
+        node_fmax[n] = (!band || front_live) ? fmax : NEG;        /* an empty front is not merged into its successors (src/dozeu_interface.cpp:261-269) */
     }
+    free(node_fmax);
+    if (stats) { stats[0] += in_band; stats[1] += (uint64_t)(L + 1) * (uint64_t)R; }
 
     int rc = VGK_OK;
     if (best >= 32767) { rc = VGK_EOVERFLOW; goto done; }

@@ -16,7 +16,7 @@
 namespace vgk {
 
 // banded kernels: one CPU thread per lane, the cross-lane primitives of banded_device.hpp through a barrier
-struct XlShared { pthread_barrier_t bar; int32_t buf[64]; };
+struct XlShared { pthread_barrier_t bar; int32_t buf[64]; unsigned long long wide[64]; };
 struct XlEmu {
     XlShared* sh; uint32_t lane;
     int32_t exchange(int32_t v, int mode) {
@@ -35,6 +35,21 @@ struct XlEmu {
     int32_t scan_excl(int32_t v) { return exchange(v, 2); }
     void fence() { pthread_barrier_wait(&sh->bar); }
     bool any(int32_t flag) { return exchange(flag ? 1 : BNEG, 3) > 0; }
+    unsigned long long ballot(bool flag) {
+        sh->buf[lane] = flag ? 1 : 0;
+        pthread_barrier_wait(&sh->bar);
+        unsigned long long m = 0; for (uint32_t l = 0; l < 64; ++l) if (sh->buf[l]) m |= 1ull << l;
+        pthread_barrier_wait(&sh->bar);
+        return m;
+    }
+    int32_t reduce_max(int32_t v) { return exchange(v, 3); }
+    unsigned long long reduce_add(unsigned long long v) {
+        sh->wide[lane] = v;
+        pthread_barrier_wait(&sh->bar);
+        unsigned long long t = 0; for (uint32_t l = 0; l < 64; ++l) t += sh->wide[l];
+        pthread_barrier_wait(&sh->bar);
+        return t;
+    }
 };
 template <int R, bool QA> static void banded_fill_emu(const BandedParams& P, uint32_t begin, uint32_t count) {
     XlShared sh; pthread_barrier_init(&sh.bar, nullptr, 64);
@@ -63,6 +78,17 @@ public:
         });
         for (auto& t : ts) t.join();
         pthread_barrier_destroy(&sh.bar);
+    }
+    int run_xdrop_band(const GsswMatrixParams& P) override {
+        XlShared sh; pthread_barrier_init(&sh.bar, nullptr, 64);
+        std::vector<std::thread> ts;
+        for (uint32_t lane = 0; lane < 64; ++lane) ts.emplace_back([&, lane]() {
+            XlEmu xl{&sh, lane};
+            for (uint32_t i = 0; i < P.n; ++i) { xdrop_band_wave_lane(P, i, lane, xl); xl.fence(); }
+        });
+        for (auto& t : ts) t.join();
+        pthread_barrier_destroy(&sh.bar);
+        return VGK_OK;
     }
     int run_gssw_matrix(const GsswMatrixParams& P) override {
         if (P.go < P.ge || std::getenv("VGAMD_MATRIX_THREADS")) { for (uint32_t i = 0; i < P.n; ++i) gssw_matrix_one(P, i); return VGK_OK; }

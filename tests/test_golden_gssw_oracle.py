@@ -126,3 +126,29 @@ def run_qual_adj_group(engine_lib):
 def test_oracle_matches_reference_quality_adjusted_unit_tests():
     ncase, nexp = run_qual_adj_group(ORACLE_LIB)
     assert ncase >= 12 and nexp >= 90
+
+
+# ---- X-drop with dozeu's band restated (vgk_xdrop_band_align; PARITY-UNPINNED) -------------------------------------------------------
+def run_xdrop_cases_with_band(engine_lib):
+    """Every reference X-drop case (pinned and seeded, src/unittest/xdrop_aligner.cpp) through the shim with the banded extension
+    switched on: the reference's answers are those of an extension whose band contains the optimum, so they must not change."""
+    import ctypes
+    import util
+    h = util.host()
+    h.vgh_aligner_set_xdrop_band.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    n = 0
+    for c in xdrop_pinned_cases():
+        al = HostAligner(engine_lib, tuple(c["scores"])); h.vgh_aligner_set_xdrop_band(al.ptr, 1)
+        args = c["args"]; max_gap = args[3] if len(args) > 3 and isinstance(args[3], int) else 40
+        aln = al.run(c["nodes"], c["edges"], c["read"], "align_pinned_xdrop", pin_left=bool(args[1]), max_alt_alns=max_gap)
+        check_expectations(c, aln, {c["aln"]: aln["score"]}); n += 1
+    for c in seeded_xdrop_cases():
+        al = HostAligner(engine_lib, tuple(c["scores"])); h.vgh_aligner_set_xdrop_band(al.ptr, 1)
+        args = c["args"]; max_gap = args[3] if len(args) > 3 and isinstance(args[3], int) else 40
+        aln = run_align_xdrop(al, c["nodes"], c["edges"], c["read"], args[1]["mems"], bool(args[2]), max_gap)
+        check_expectations(c, aln, {c["aln"]: aln["score"]}); n += 1
+    return n
+
+
+def test_reference_xdrop_cases_hold_with_the_band_on_the_oracle():
+    assert run_xdrop_cases_with_band(ORACLE_LIB) >= 22

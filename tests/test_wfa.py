@@ -165,13 +165,13 @@ def test_oracle_matches_reference_known_answers():
 
 # ---- random haplotype graphs: the engine against the oracle ----------------------------------------------------------
 
-def random_wfa_case(rng, n_problems=60):
+def random_wfa_case(rng, n_problems=60, n_haplotypes=None):
     """The bubble chains of test_gapless with some threads going round a cycle; sequences cut from a thread (either strand)
     between a `from` and a `to` base, with substitutions, insertions and deletions; connect / suffix / prefix problems,
     a few of them between unrelated positions."""
     from test_gapless import random_haplotype_case
     bases = "ACGT"
-    nodes, threads, _ = random_haplotype_case(rng, n_reads=0, n_haplotypes=int(rng.integers(1, 6)), chain_nodes=int(rng.integers(4, 16)))
+    nodes, threads, _ = random_haplotype_case(rng, n_reads=0, n_haplotypes=n_haplotypes or int(rng.integers(1, 6)), chain_nodes=int(rng.integers(4, 16)))
     if rng.random() < 0.4:                                   # cycles: repeat a stretch of a thread
         for t in threads:
             if len(t) > 4 and rng.random() < 0.7:
@@ -343,3 +343,25 @@ def test_host_shim_wfa_extender_on_the_oracle():
 @pytest.mark.gpu
 def test_host_shim_wfa_extender_on_hip():
     assert shim_golden(util.ENGINE_LIB) > 80
+
+
+def test_wfa_over_run_length_encoded_records(monkeypatch):
+    """Hundreds of haplotypes: the engine's index stores most visit bodies run-length encoded (gapless_device.hpp); WFA's walk over the
+    haplotype trie (w_follow) must give what the oracle's uncompressed index gives, problem by problem."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    n_ok = 0
+    for seed in (1, 2, 3):
+        nodes, threads, wp = random_wfa_case(np.random.default_rng(seed), 80, n_haplotypes=250)
+        eng = capi.Engine(lib=util.EMU_LIB); ora = capi.Engine(lib=util.ORACLE_LIB)
+        (ra, pa, ea), (rb, pb, eb) = eng.wfa_extend(eng.haplo_index(nodes, threads), wp), ora.wfa_extend(ora.haplo_index(nodes, threads), wp)
+        for i in range(len(ra)):
+            if ra["status"][i] != 0:
+                assert ra["status"][i] == -7      # a kernel table limit: the caller's DP path takes the problem
+                continue
+            for f in ("ok", "score", "node_offset", "seq_offset", "length", "path_len", "n_edits"):
+                assert ra[f][i] == rb[f][i], (seed, i, f)
+            assert (pa[ra["path_begin"][i]:ra["path_begin"][i] + ra["path_len"][i]] == pb[rb["path_begin"][i]:rb["path_begin"][i] + rb["path_len"][i]]).all()
+            assert (ea[ra["edit_begin"][i]:ra["edit_begin"][i] + ra["n_edits"][i]] == eb[rb["edit_begin"][i]:rb["edit_begin"][i] + rb["n_edits"][i]]).all()
+            n_ok += 1
+    assert n_ok > 150

@@ -1,0 +1,79 @@
+"""X-drop extension with dozeu's band restated (vgk_xdrop_band_align).  dozeu's source is not in the reference
+snapshot, so the band rules are this engine's reading of the published algorithm [PARITY-UNPINNED]; what CAN be checked:
+  * engine (wavefront kernel + host traceback) == oracle (oracle/vgo_xdrop.c, band mode), bit for bit, incl. the cells kept;
+  * a banded score never exceeds the exact extension's, and equals it when max_gap_length is generous;
+  * every reference X-drop unit test still passes with the band switched on (their optima lie inside dozeu's band);
+  * bad input is answered per problem."""
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+from gen import problem_set, random_problem
+from test_golden_gssw_oracle import run_xdrop_cases_with_band
+from vg_amd import capi
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    return util.EMU_LIB
+
+
+def random_xdrop_set(seed, n, max_gap=None, **kw):
+    rng = np.random.default_rng(seed)
+    probs = [random_problem(rng, mode=capi.VGK_XDROP_PINNED, **kw) for _ in range(n)]
+    if max_gap is not None:
+        for p in probs:
+            p["max_gap"] = max_gap
+    return problem_set(probs)
+
+
+def same(a, b):
+    (ra, oa, sa), (rb, ob, sb) = a, b
+    for f in ("status", "score", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
+        assert (ra[f] == rb[f]).all(), f
+    assert len(oa) == len(ob) and (oa.view(np.uint64) == ob.view(np.uint64)).all()
+    assert sa == sb
+
+
+def band_vs_oracle(lib, n, max_read=110):
+    for seed, mg in ((1, None), (2, 1), (3, 3), (4, 12), (5, 200)):
+        ps = random_xdrop_set(seed, n, mg, max_nodes=12, max_node_len=16, max_read=max_read, with_n=0.05)
+        eng = capi.Engine(lib=lib); ora = capi.Engine(lib=util.ORACLE_LIB)
+        band = eng.xdrop_band_align(ps)
+        same(band, ora.xdrop_band_align(ps))
+        exact, _ = ora.align(ps)
+        assert (band[0]["score"] <= exact["score"]).all()
+        if mg == 200:
+            assert (band[0]["score"] == exact["score"]).all()
+        if mg == 1:
+            assert band[2][0] < 0.2 * band[2][1]               # a tight x-drop keeps a sliver of the rectangle
+    sc = capi.Scoring.simple(2, 3, 5, 2, 7)
+    ps = random_xdrop_set(9, n // 2, None, max_nodes=8, max_node_len=30, max_read=2 * max_read + 30)
+    same(capi.Engine(sc, lib=lib).xdrop_band_align(ps), capi.Engine(sc, lib=util.ORACLE_LIB).xdrop_band_align(ps))
+
+
+def test_emulated_banded_xdrop_equals_the_oracle(emu_lib):
+    band_vs_oracle(emu_lib, 40, max_read=60)          # (the lock-step emulation pays a barrier per cross-lane step: kept small; the gpu test is the big one)
+
+
+def test_reference_xdrop_cases_hold_with_the_band_on_the_emulated_engine(emu_lib):
+    assert run_xdrop_cases_with_band(emu_lib) >= 22
+
+
+def test_banded_xdrop_bad_input(emu_lib):
+    ok = {"read": "ACGTACGT", "nodes": ["ACGT", "ACGT"], "preds": [[], [0]], "flags": capi.VGK_XDROP_PINNED | 16, "pinning": None, "max_gap": 10}
+    for lib in (emu_lib, util.ORACLE_LIB):
+        eng = capi.Engine(lib=lib)
+        res, ops, _ = eng.xdrop_band_align(problem_set([ok, dict(ok, read="A" * 600), dict(ok, preds=[[1], []])]))
+        assert list(res["status"]) == [0, -4, -1] and res["score"][0] == 8 + 5
+        with pytest.raises(capi.VgkError):                          # a batch of the wrong mode is refused whole
+            eng.xdrop_band_align(problem_set([dict(ok, flags=16)]))
+
+
+@pytest.mark.gpu
+def test_banded_xdrop_on_hip_equals_the_oracle():
+    band_vs_oracle(util.ENGINE_LIB, 1500)
+    assert run_xdrop_cases_with_band(util.ENGINE_LIB) >= 22

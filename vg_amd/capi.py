@@ -106,6 +106,7 @@ def load_library(path=None):
     lib.vgk_gssw_fetch.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz)]
     lib.vgk_gssw_align.argtypes = [vp, vp, u32, vp, vp, sz, ctypes.POINTER(sz)]
     lib.vgk_batch_free.argtypes = [vp]
+    lib.vgk_xdrop_band_align.argtypes = [vp, vp, u32, vp, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64 * 2)]
     lib.vgk_graph_create.argtypes = [vp, vp, ctypes.POINTER(vp)]
     lib.vgk_graph_destroy.argtypes = [vp]
     lib.vgk_gssw_pack_windows.argtypes = [vp, vp, vp, sz, vp, u32, u32, ctypes.POINTER(vp)]
@@ -300,6 +301,16 @@ class Engine:
         with self.pack(ps, ops_per_problem) as b:
             b.run()
             return b.fetch()
+
+    def xdrop_band_align(self, ps):
+        """vgk_xdrop_band_align over a ProblemSet of VGK_XDROP_PINNED problems -> (results, ops, (cells in band, cells of the rectangles))."""
+        res = np.zeros(ps.n, dtype=RESULT_DT)
+        cap = int(np.diff(ps.read_off).sum() + np.diff(ps.seq_off).sum() + len(ps.node_len) + 4 * ps.n)
+        ops = np.zeros(max(cap, 1), dtype=OP_DT)
+        written = ctypes.c_size_t(); stats = (ctypes.c_uint64 * 2)()
+        self._check(self.lib.vgk_xdrop_band_align(self.h, ps.ptr, ps.n, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written), ctypes.byref(stats)),
+                    "vgk_xdrop_band_align")
+        return res, ops[:written.value], (int(stats[0]), int(stats[1]))
 
     def align_multi(self, ps, max_alt_alns):
         """vgk_gssw_align_multi over a ProblemSet of pinned problems -> (results [n, max_alt_alns], n_alignments [n], ops)."""

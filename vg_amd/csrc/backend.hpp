@@ -93,6 +93,9 @@ public:
     virtual int   run_wfa(const WfaParams& p, uint32_t threads) = 0;
     // pinned gssw fill that keeps H / E / F of every cell (k-best tracebacks): one thread per problem
     virtual int   run_gssw_matrix(const GsswMatrixParams& p) = 0;
+    // X-drop with dozeu's band (vgk_xdrop_band_align): one wavefront per problem, the matrices stay for the host's traceback;
+    // last_ms(7) = kernel ms
+    virtual int   run_xdrop_band(const GsswMatrixParams& p) = 0;
 };
 
 // returns nullptr and sets err when the device cannot be used

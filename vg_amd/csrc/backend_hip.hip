@@ -166,6 +166,17 @@ struct XlDpp {
     }
     __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
     __device__ __forceinline__ bool any(int32_t flag) const { return __ballot(flag != 0) != 0ull; }
+    __device__ __forceinline__ unsigned long long ballot(bool flag) const { return __ballot(flag); }
+    __device__ __forceinline__ int32_t reduce_max(int32_t v) const {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const int32_t o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+        return v;
+    }
+    __device__ __forceinline__ unsigned long long reduce_add(unsigned long long v) const {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+        return v;
+    }
 };
 
 template <int R, bool QA, bool LDS>
@@ -242,6 +253,10 @@ __global__ void __launch_bounds__(64) gssw_matrix_kernel(const GsswMatrixParams 
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i < P.n) gssw_matrix_one(P, i);
 }
+__global__ void __launch_bounds__(64) xdrop_band_kernel(const GsswMatrixParams P) {
+    XlDpp xl;
+    xdrop_band_wave_lane(P, blockIdx.x, threadIdx.x, xl);
+}
 template <int R>
 __global__ void __launch_bounds__(64) gssw_matrix_wave_kernel(const GsswMatrixParams P, const uint32_t rows_lo, const uint32_t rows_hi) {
     const uint32_t i = blockIdx.x;
@@ -261,7 +276,7 @@ public:
                                                                                      // runs beside a fill — no faster than one stream (the traceback takes the fill's wave slots); off
     hipDeviceProp_t prop;
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
-    float ms_gapless = 0.f, ms_wfa = 0.f;
+    float ms_gapless = 0.f, ms_wfa = 0.f, ms_xband = 0.f;
     float ms_bfill = 0.f, ms_bwalk = 0.f; hipEvent_t bev[3] = {nullptr, nullptr, nullptr};
     ~HipBackend() override {
         hipSetDevice(dev);
@@ -525,6 +540,17 @@ public:
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         return VGK_OK;
     }
+    int run_xdrop_band(const GsswMatrixParams& p) override {
+        hipSetDevice(dev);
+        ms_xband = 0.f;
+        if (!p.n) return VGK_OK;
+        hipEventRecord(bev[0], stream);
+        hipLaunchKernelGGL(xdrop_band_kernel, dim3(p.n), dim3(64), 0, stream, p);
+        hipEventRecord(bev[1], stream);
+        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
+        hipEventElapsedTime(&ms_xband, bev[0], bev[1]);
+        return VGK_OK;
+    }
     int run_wfa(const WfaParams& p, uint32_t threads) override {
         hipSetDevice(dev);
         ms_wfa = 0.f;
@@ -538,6 +564,7 @@ public:
     }
     double last_ms(int which) const override {
         if (which == 6) return ms_wfa;
+        if (which == 7) return ms_xband;
         if (which == 5) return ms_gapless;
         if (which == 3) return ms_bfill;
         if (which == 4) return ms_bwalk;

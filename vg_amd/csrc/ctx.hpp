@@ -39,7 +39,7 @@ struct vgk_ctx {
     vgk::WfaParams wfa_last{}; uint32_t wfa_last_threads = 0; bool wfa_last_valid = false;
     // device scratch kept between vgk_banded_align calls (grow-only; released with the context)
     struct DevBuf { void* p = nullptr; uint64_t bytes = 0; };
-    DevBuf scratch[48];            // 0..14 + 31 banded_api.cpp, 15..30 gapless_api.cpp, 32..39 wfa_api.cpp, 40..47 gssw_multi_api.cpp
+    DevBuf scratch[52];            // 0..14 + 31 banded_api.cpp, 15..30 gapless_api.cpp, 32..39 wfa_api.cpp, 40..47 gssw_multi_api.cpp / xdrop_band_api.cpp (+ 48, 49)
     void* ensure_scratch(int slot, uint64_t bytes) {
         DevBuf& b = scratch[slot];
         if (b.p && b.bytes >= bytes) return b.p;
@@ -122,6 +122,8 @@ struct vgk_ctx {
     std::shared_ptr<void> gapless_host;     // and of gapless_api.cpp
     std::shared_ptr<void> wfa_host;         // and of wfa_api.cpp
     std::shared_ptr<void> multi_host;       // and of gssw_multi_api.cpp
+    std::shared_ptr<void> xband_host;       // and of xdrop_band_api.cpp
+    double xband_ms = 0;                    // kernel time of the last vgk_xdrop_band_align call
     ~vgk_ctx() { if (be) { for (DevBuf& b : scratch) if (b.p) be->release(b.p); for (Pooled& q : dev_pool) be->release(q.p); for (Pooled& q : host_pool) be->host_release(q.p); } }
 };
 

@@ -404,7 +404,8 @@ void Aligner::align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_
     if (job->has_problem) {
         ops.resize(job->prob.read_len + job->pg.seq.size() + job->pg.order.size() + 4);
         size_t written = 0;
-        int rc = engine->gssw_align(ctx, &job->prob, 1, &res, ops.data(), ops.size(), &written);
+        int rc = xdrop_band ? engine->xdrop_band_align(ctx, &job->prob, 1, &res, ops.data(), ops.size(), &written, nullptr)
+                            : engine->gssw_align(ctx, &job->prob, 1, &res, ops.data(), ops.size(), &written);
         if (rc != VGK_OK) throw std::runtime_error(std::string("vgamd: xdrop engine failed: ") + engine->strerror(rc));
         ops.resize(res.n_ops);
     }
@@ -888,7 +889,8 @@ Aligner::Extension Aligner::xdrop_extend(const HandleGraph& g, const std::vector
     prob.graph = pg.view(); prob.max_gap_length = std::max<uint16_t>(max_gap_length, 1);
     vgk_result res{}; std::vector<vgk_op> ops(prob.read_len + pg.seq.size() + kept.size() + 4);
     size_t written = 0;
-    int rc = engine->gssw_align(ctx, &prob, 1, &res, ops.data(), ops.size(), &written);
+    int rc = xdrop_band ? engine->xdrop_band_align(ctx, &prob, 1, &res, ops.data(), ops.size(), &written, nullptr)
+                        : engine->gssw_align(ctx, &prob, 1, &res, ops.data(), ops.size(), &written);
     if (rc != VGK_OK || res.status != VGK_OK)
         throw std::runtime_error(std::string("vgamd: xdrop engine failed: ") + engine->strerror(rc ? rc : res.status));
     ops.resize(res.n_ops);

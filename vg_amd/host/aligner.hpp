@@ -125,6 +125,9 @@ public:
                                     bool pin_left, int32_t max_alt_alns) const = 0;
 
     std::unique_ptr<MatrixAlignmentScorer> scorer;
+    // X-drop calls (align_pinned(..., xdrop = true), align_xdrop) with dozeu's band restated (vgk_xdrop_band_align) instead of the
+    // exact extension that keeps every cell (the default; the two agree whenever the band contains the optimal path).  PARITY-UNPINNED.
+    mutable bool xdrop_band = false;
 
     // the engine binding, for the extenders that are constructed around an Aligner (src/gbwt_extender.hpp:156)
     const EngineApi& engine_api() const { return *engine; }

@@ -48,6 +48,7 @@ std::shared_ptr<EngineApi> load_engine(const std::string& path) {
     bind(dl, "vgk_haplo_destroy", api->haplo_destroy);
     bind(dl, "vgk_gapless_extend", api->gapless_extend);
     bind(dl, "vgk_wfa_extend", api->wfa_extend);
+    bind(dl, "vgk_xdrop_band_align", api->xdrop_band_align);
     if (api->abi_version() != VGK_ABI_VERSION) throw std::runtime_error("vgamd engine: ABI version mismatch in " + p);
     return api;
 }

@@ -31,6 +31,7 @@ struct EngineApi {
     decltype(&vgk_haplo_destroy) haplo_destroy = nullptr;
     decltype(&vgk_gapless_extend) gapless_extend = nullptr;
     decltype(&vgk_wfa_extend) wfa_extend = nullptr;
+    decltype(&vgk_xdrop_band_align) xdrop_band_align = nullptr;
     ~EngineApi();
 };
 

@@ -53,6 +53,8 @@ vgh_aligner* vgh_qual_adj_aligner_create(const char* engine_lib, int device, int
     return make_aligner(engine_lib, device, match, mismatch, gap_open, gap_extend, full_length_bonus, true);
 }
 void vgh_aligner_destroy(vgh_aligner* a) { delete a; }
+// X-drop calls with dozeu's band restated instead of the exact extension (GSSWAligner::xdrop_band)
+void vgh_aligner_set_xdrop_band(vgh_aligner* a, int on) { a->a->xdrop_band = on != 0; }
 
 static int emit(const Alignment& aln, char* out, size_t cap) {
     std::string js = alignment_to_json(aln);
