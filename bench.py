@@ -352,6 +352,49 @@ def bench_tails(args, eng, rank, world, dist, torch, dev_name, cus):
         dist.destroy_process_group()
 
 
+def bench_xdrop_band(args, eng, rank, world, dist, torch, dev_name, cus):
+    """Row a10 (secondary line): the round-1 tails stand-in (giraffe-style pinned tails on a 2 Mbp variation graph, one explicit graph
+    per problem) through vgk_xdrop_band_align — dozeu's band restated [PARITY-UNPINNED] — next to the exact extension of the same
+    problems.  Reports the cells the band keeps, the kernel time, and how often the banded score equals the exact one."""
+    import ctypes
+    import numpy as np
+    from vg_amd import capi, shard, workloads
+    n = min(args.reads or 200_000, 200_000)
+    ps = workloads.TailWorkload(n, seed=77 + rank).ps
+    eng.lib.vgk_xdrop_band_last_ms.restype = ctypes.c_double; eng.lib.vgk_xdrop_band_last_ms.argtypes = [ctypes.c_void_p]
+    eng.xdrop_band_align(ps)                                         # warms the cached buffers
+    t0 = time.perf_counter(); res, ops, st = eng.xdrop_band_align(ps); t_band = time.perf_counter() - t0
+    k_ms = eng.lib.vgk_xdrop_band_last_ms(eng.h)
+    t0 = time.perf_counter(); eres, eops = eng.align(ps, 48); t_exact = time.perf_counter() - t0
+    parity = cpu = None
+    if not args.no_cpu:
+        ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
+        ora.lib.vgo_set_threads(shard.usable_cpus())
+        k = min(n, args.cpu_sample or 50_000)
+        sub = ps.subset(k)
+        t0 = time.perf_counter(); ores, oops, ost = ora.xdrop_band_align(sub); tc = time.perf_counter() - t0
+        good = np.ones(k, dtype=bool)
+        for f in ("score", "status", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
+            good &= res[f][:k] == ores[f]
+        tot = int(ores["n_ops"].sum())
+        if good.all() and (ops[:tot].view(np.uint64) != oops.view(np.uint64)).any():
+            good[:] = False
+        parity = {"checked": k, "identical": int(good.sum())}
+        cpu = {"value": k / tc, "unit": "alignments/s", "cores": shard.usable_cpus(), "kind": "port", "impl": "scalar int32 checker with the band (oracle/vgo_xdrop.c)", "sample": "first %d problems" % k}
+    print(json.dumps({
+        "metric": "tail alignments/sec, X-drop with dozeu's band restated (host-inclusive: pack + fill kernel + D2H of the matrices + host traceback)",
+        "value": n / t_band, "unit": "alignments/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * t_band, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+        "config": {"workload": "round-1 tails stand-in: 2 Mbp variation graph, %d tails of 1-121 bp, left-pinned, one explicit graph per problem; vgk_xdrop_band_align [PARITY-UNPINNED]" % n,
+                   "device": dev_name, "compute_units": cus},
+        "band": {"cells_in_band": st[0], "cells_of_the_rectangles": st[1], "fraction_kept": st[0] / max(st[1], 1), "fill_kernel_ms": k_ms,
+                 "banded_score_equals_exact": float((res["score"] == eres["score"]).mean()), "banded_score_never_higher": bool((res["score"] <= eres["score"]).all()),
+                 "exact_path_same_problems_host_inclusive_per_s": n / t_exact},
+        "roofline": None, "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum())}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -363,7 +406,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--host-pack", action="store_true", help="linear workload: one explicit graph per problem, packed on host threads (vgk_gssw_pack) instead of windows of the resident graph packed on the device")
     ap.add_argument("--no-e2e", action="store_true", help="skip the warm / double-buffered end-to-end legs (profiling runs)")
-    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa"], default="linear",
+    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband"], default="linear",
                     help="linear = BASELINE.json configs[1] (the headline metric); tails = configs[2] stand-in: "
                          "giraffe-style pinned X-drop tail alignments on a variation graph; banded = configs[4] stand-in: "
                          "banded global alignments between chained anchors; gapless = giraffe's first stage: "
@@ -403,6 +446,8 @@ def main():
     eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), device=local_rank, lib=eng_lib)
     dev_name, cus, hbm = eng.device_info()
 
+    if args.workload == "xband":
+        return bench_xdrop_band(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "tails" and not args.tails_per_problem_graphs:
         return bench_tails(args, eng, rank, world, dist, torch, dev_name, cus)
     if not args.reads:
