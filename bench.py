@@ -28,15 +28,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 RDEV = "cpu" if os.environ.get("VGAMD_BENCH_ONE_DEVICE") == "1" else "cuda"      # where the max-reduce of the times lives (gloo in the one-device check)
 
-# HBM bytes per unit of work of the dominant kernel, from the PMC passes committed under profiles/r01 (rocprofv3 --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE in separate runs of this very command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py
-# cannot read counters itself, so `roofline.traffic` = this figure x the units of one launch; re-measure with tools/prof_*.sh.
+# HBM bytes per unit of work of the dominant kernel: STORED constants from the PMC passes committed under profiles/r02 (rocprofv3 --pmc
+# FETCH_SIZE and --pmc WRITE_SIZE in separate runs of the same workload; KiB per launch, FETCH_SIZE doubled as MI355X_MICROARCH.md
+# prescribes for gfx950).  bench.py cannot read counters itself, so `roofline.traffic` = this figure x the units of one launch and
+# `traffic_source` says so; re-measure with tools/collect_r02.sh.
 PMC_BYTES_PER_UNIT = {
-    "linear": (2 * 703386 + 13574138) * 1024 / 400000,      # pmc_{FETCH,WRITE}_SIZE_400k.csv: gssw_fill_kernel, 400 000 reads
-    "banded": (2 * 389251 + 2244533) * 1024 / 100000,        # pmc_*_banded_100k.csv: the three banded_fill_kernel classes, 100 000 problems
-    "gapless": (2 * 16202932 + 3269559) * 1024 / 1000000,    # pmc_*_gapless_1M.csv: gapless_kernel, 1 000 000 reads
-    "wfa": (2 * 4385189 + 1828176) * 1024 / 500000,          # pmc_*_wfa_500k.csv: wfa_kernel, 500 000 problems
+    "linear": (2 * 704590 + 13574060) * 1024 / 400000,       # pmc_{fetch,write}_400k.csv: gssw_fill_kernel<19,true>, 400 000 reads per launch (unchanged since r01)
+    "banded": (2 * 390611 + 2244073) * 1024 / 100000,         # pmc_*_banded_100k.csv: the banded_fill_kernel classes, 100 000 problems
+    "gapless": (2 * 6135420 + 2654011) * 1024 / 1000000,      # pmc_*_gapless_1M.csv: gapless_fast_kernel + gapless_kernel, 1 000 000 reads (r01: 2 x 16 202 932 + 3 269 559)
+    "wfa": (2 * 4094544 + 1914811) * 1024 / 500000,           # pmc_*_wfa_500k.csv: wfa_kernel, 500 000 problems
 }
+TRAFFIC_SOURCE = "stored constant from the rocprofv3 PMC passes in profiles/r02 (not measured in this run), scaled by the units of one launch"
 
 
 def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
@@ -96,8 +98,8 @@ def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
                        "timed_region": "K launches of gapless_kernel on the batch resident in HBM (vgk_gapless_rerun)",
                        "end_to_end_from_host_buffers_reads_per_s": n / te, "parallelism": "read-sharded x%d" % world,
                        "device": dev_name, "compute_units": cus},
-            "roofline": {"bound": "hbm", "kernel": "gapless_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["gapless"] * n, "traffic_source": "rocprofv3 PMC passes in profiles/r01, scaled by reads", "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
+            "roofline": {"bound": "hbm", "limiter": "memory latency and divergent instruction issue, not bandwidth (DESIGN.md §11): `frac` prices the algorithmic bytes against the HBM peak as the contract asks", "kernel": "gapless_fast_kernel (+ gapless_kernel for reads that outgrow it)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["gapless"] * n, "traffic_source": TRAFFIC_SOURCE, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
                          "kernel_only_reads_per_s": n / (k * 1e-3)},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum()),
             "full_length_fraction": float(res["full_length"].mean())}))
@@ -171,8 +173,8 @@ def bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus):
                        "timed_region": "K launches of wfa_kernel on the batch resident in HBM (vgk_wfa_rerun)",
                        "end_to_end_from_host_buffers_alignments_per_s": n / te, "parallelism": "problem-sharded x%d" % world,
                        "device": dev_name, "compute_units": cus, "sequence_bases": wl.bases},
-            "roofline": {"bound": "hbm", "kernel": "wfa_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["wfa"] * n, "traffic_source": "rocprofv3 PMC passes in profiles/r01, scaled by problems", "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
+            "roofline": {"bound": "hbm", "limiter": "memory latency on each thread's dependent chain and lane divergence, not bandwidth (DESIGN.md §12)", "kernel": "wfa_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["wfa"] * n, "traffic_source": TRAFFIC_SOURCE, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
                          "kernel_only_alignments_per_s": n / (k * 1e-3)},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum()),
             "aligned_fraction": float(res["ok"].mean())}))
@@ -240,8 +242,8 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
                        "timed_region": "K runs of the fill launches + traceback kernel on the batch resident in HBM (vgk_banded_rerun)",
                        "end_to_end_from_host_buffers_alignments_per_s": n / te,
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus},
-            "roofline": {"bound": "hbm", "kernel": "banded_fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["banded"] * n, "traffic_source": "rocprofv3 PMC passes in profiles/r01, scaled by problems", "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": fill,
+            "roofline": {"bound": "hbm", "limiter": "VALU issue: ~64 VALU + 30 SALU per wave-column of <= 64 cells (DESIGN.md §10)", "kernel": "banded_fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["banded"] * n, "traffic_source": TRAFFIC_SOURCE, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": fill,
                          "traceback_ms": walk, "band_cells": cells, "gcups_fill": cells / (fill * 1e-3) / 1e9,
                          "kernel_only_alignments_per_s": n / ((fill + walk) * 1e-3)},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum())}))
@@ -405,7 +407,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads for the CPU baseline leg (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--host-pack", action="store_true", help="linear workload: one explicit graph per problem, packed on host threads (vgk_gssw_pack) instead of windows of the resident graph packed on the device")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the warm / double-buffered end-to-end legs (profiling runs)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the legs that overlap launches — the two-lane steady state and the warm / double-buffered end-to-end legs — so that a profiler's per-kernel averages are each kernel's own")
     ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband"], default="linear",
                     help="linear = BASELINE.json configs[1] (the headline metric); tails = configs[2] stand-in: "
                          "giraffe-style pinned X-drop tail alignments on a variation graph; banded = configs[4] stand-in: "
@@ -511,7 +513,7 @@ def main():
     # traceback of one batch — bound by memory latency — runs under the fill of the next — bound by VALU issue.  Two batches are
     # resident (the same reads packed twice); step i runs batch i mod 2; exactly K steps between the barriers.
     two_lane = None
-    if windows or args.workload == "tails":
+    if (windows or args.workload == "tails") and not args.no_e2e:      # (profiling runs skip the legs that overlap launches)
         batch2 = pack()
         if batch2.lane() != batch.lane():
             pair = (batch, batch2)
@@ -685,7 +687,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "valu": valu,
                          "traffic": None if tails else PMC_BYTES_PER_UNIT["linear"] * args.reads / n_launch,
-                         "traffic_source": None if tails else "rocprofv3 PMC passes in profiles/r01, scaled by reads",
+                         "traffic_source": None if tails else TRAFFIC_SOURCE,
                          "alg_bytes_per_launch": alg_bytes / n_launch, "avg_launch_ms": fill_avg,
                          "launches_per_step": n_launch,
                          "traceback_tail_ms": sum(walk_ms) / len(walk_ms),

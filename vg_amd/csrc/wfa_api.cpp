@@ -108,15 +108,28 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     {
         int mode = 3;
         if (const char* e = std::getenv("VGAMD_WFA_ORDER")) mode = std::atoi(e);
-        std::vector<uint64_t> key(n);
-        for (uint32_t i = 0; i < n; ++i) {
-            const WProb& w = probs[i];
-            const uint64_t node = (w.mode == (uint32_t)VGK_WFA_PREFIX ? w.to_node : w.from_node) / 2, len = w.seq_len;
-            const uint64_t cls = mode == 2 ? (0xffffffffull - len) : mode == 3 ? (0xffffffffull - len / 32) : 0;
-            key[i] = mode == 0 ? i : (cls << 32) | (mode == 2 ? 0 : (node & 0xffffffffull));
-            order[i] = i;
+        // two stable counting-sort passes (node, then length class): O(n), a few ms per million problems
+        const uint32_t n_nodes = index->n_oriented / 2 + 1;
+        auto node_of = [&](uint32_t i) { const WProb& w = probs[i]; const uint32_t v = (w.mode == (uint32_t)VGK_WFA_PREFIX ? w.to_node : w.from_node) / 2; return v < n_nodes ? v : n_nodes - 1; };
+        auto class_of = [&](uint32_t i) -> uint32_t {          // longest first: class 0 = the longest sequences
+            const uint32_t len = probs[i].seq_len, c = mode == 2 ? len : mode == 3 ? len / 32 : 0;
+            return 0xffffu - (c < 0xffffu ? c : 0xffffu);
+        };
+        for (uint32_t i = 0; i < n; ++i) order[i] = i;
+        if (mode == 1 || mode == 3) {
+            std::vector<uint32_t> start(n_nodes + 1, 0), tmp(n);
+            for (uint32_t i = 0; i < n; ++i) ++start[node_of(i) + 1];
+            for (uint32_t v = 0; v < n_nodes; ++v) start[v + 1] += start[v];
+            for (uint32_t i = 0; i < n; ++i) tmp[start[node_of(i)]++] = i;
+            order.swap(tmp);
         }
-        if (mode) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+        if (mode == 2 || mode == 3) {
+            std::vector<uint32_t> start(0x10001, 0), tmp(n);
+            for (uint32_t k = 0; k < n; ++k) ++start[class_of(order[k]) + 1];
+            for (uint32_t c = 0; c < 0x10000; ++c) start[c + 1] += start[c];
+            for (uint32_t k = 0; k < n; ++k) tmp[start[class_of(order[k])]++] = order[k];
+            order.swap(tmp);
+        }
     }
     P.order = (const uint32_t*)dev(order.data(), sizeof(uint32_t) * n);
     // dense outputs; the kernel checks them
