@@ -103,6 +103,27 @@ public:
         // the fast store first (here a plain local array, stride 1), then the slab store for the reads that outgrew it — as on the device
         const bool slab_only = std::getenv("VGAMD_GAPLESS_SLAB_ONLY") != nullptr;
         std::vector<uint32_t> lds(G_FAST_DW);
+        if (!slab_only && !std::getenv("VGAMD_GAPLESS_NESTED")) {
+            // the flat form: a lane takes reads from the counter until there are none (here the lanes run one after another, so lane t takes
+            // every (threads)-th share by stopping after its part), then the rules kernel, then the slab kernel for the G_RETRY reads
+            struct Wave {
+                uint32_t left;
+                GProf* prof() const { return nullptr; }
+                int vote(bool idle, bool searching) const { return idle ? 1 : searching ? 2 : 0; }
+                uint32_t next_read(const GaplessParams& p) { if (!left) return 0xffffffffu; const unsigned long long k = p.counters[4]; if (k >= p.n) return 0xffffffffu; ++p.counters[4]; --left; return (uint32_t)k; }
+            };
+            for (uint32_t t = 0; t < threads; ++t) {
+                Wave w{(P.n + threads - 1) / threads};
+                GStoreLds Q{lds.data(), 1u, P.scratch[t], 0u};
+                gapless_search_lane(P, Q, P.scratch[t], w);
+            }
+            for (uint32_t t = 0; t < threads; ++t) for (uint32_t k = t; k < P.n; k += threads) gapless_rules_one(P, P.order[k], P.scratch[t].order);
+            for (uint32_t t = 0; t < threads; ++t) for (uint32_t k = t; k < P.n; k += threads) {
+                const uint32_t i = P.order[k];
+                if (P.results[i].status == G_RETRY) { GStoreSlab Q{P.scratch[t]}; gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]); }
+            }
+            return VGK_OK;
+        }
         for (uint32_t t = 0; t < threads; ++t) for (uint32_t k = t; k < P.n; k += threads) {
             const uint32_t i = P.order[k];
             if (!slab_only) { GStoreLds Q{lds.data(), 1u, P.scratch[t], 0u}; gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]); }

@@ -240,6 +240,43 @@ __global__ void __launch_bounds__(64, 4) gapless_fast_kernel(const GaplessParams
     for (uint32_t k = t; k < P.n; k += threads) gapless_extend_one(P, P.order[k], Q, P.scratch[t], P.cold[t]);
 }
 
+// The flat form (gapless_device.hpp, "the flat form"): lanes take reads from a counter and never wait for another lane's search; the
+// rules over the winners run in their own kernel.  Reads whose queue outgrew the LDS slots go to the slab kernel as before.
+struct GWaveDev {
+    GProf* p; uint32_t min_idle;
+    __device__ GProf* prof() const { return p; }
+    __device__ int vote(bool idle, bool searching) const {
+        const unsigned long long bi = __ballot(idle), bs = __ballot(searching);
+        if (!(bi | bs)) return 0;
+        return ((uint32_t)__popcll(bi) >= min_idle || !bs) ? 1 : 2;
+    }
+    __device__ uint32_t next_read(const GaplessParams& P) const {
+        const unsigned long long k = atomicAdd(P.counters + 4, 1ull);
+        return k < (unsigned long long)P.n ? (uint32_t)k : 0xffffffffu;
+    }
+};
+template <int VAR> __global__ void __launch_bounds__(64, 4) gapless_search_kernel(const GaplessParams P, const uint32_t threads) {
+    __shared__ uint32_t lds[64 * G_FAST_DW];
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= threads) return;
+    GStoreLdsT<VAR> Q{lds + threadIdx.x, 64u, P.scratch[t], 0u};
+#if defined(VGAMD_GAPLESS_PROF)
+    GProf prof; prof.start();
+    GWaveDev wave{&prof, P.flat_min_idle};
+    gapless_search_lane(P, Q, P.scratch[t], wave);
+    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 12; ++i) atomicAdd(P.counters + 8 + i, prof.acc[i]);
+#else
+    GWaveDev wave{nullptr, P.flat_min_idle};
+    gapless_search_lane(P, Q, P.scratch[t], wave);
+#endif
+}
+__global__ void __launch_bounds__(64, 6) gapless_rules_kernel(const GaplessParams P) {
+    __shared__ uint8_t order[64 * G_SEEDS];           // the permutation the rules sort, per lane
+    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= P.n) return;
+    gapless_rules_one(P, P.order[k], order + threadIdx.x * G_SEEDS);
+}
+
 // ---- wavefront alignment (wfa_device.hpp): the same launch shape
 __global__ void __launch_bounds__(64, 4) wfa_kernel(const WfaParams P, const uint32_t threads) {
     __shared__ uint32_t node_end[W_NODES * 64];                    // [trie node][lane]: conflict-free, 8 KB per wavefront
@@ -518,8 +555,19 @@ public:
         if (!p.n || !threads) return VGK_OK;
         hipEventRecord(bev[0], stream);
         if (std::getenv("VGAMD_GAPLESS_SLAB_ONLY")) hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads, 0);
-        else {
+        else if (std::getenv("VGAMD_GAPLESS_NESTED")) {
             hipLaunchKernelGGL(gapless_fast_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads);
+            hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads, 1);
+        } else {
+            const char* ve = std::getenv("VGAMD_GAPLESS_VARIANT"); const int var = ve ? std::atoi(ve) : VGK_GAPLESS_VARIANT;
+            const dim3 grid((threads + 63) / 64);
+            switch (var & 3) {
+                case 0: hipLaunchKernelGGL(gapless_search_kernel<0>, grid, dim3(64), 0, stream, p, threads); break;
+                case 1: hipLaunchKernelGGL(gapless_search_kernel<1>, grid, dim3(64), 0, stream, p, threads); break;
+                case 2: hipLaunchKernelGGL(gapless_search_kernel<2>, grid, dim3(64), 0, stream, p, threads); break;
+                default: hipLaunchKernelGGL(gapless_search_kernel<3>, grid, dim3(64), 0, stream, p, threads); break;
+            }
+            hipLaunchKernelGGL(gapless_rules_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
             hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads, 1);
         }
         hipEventRecord(bev[1], stream);

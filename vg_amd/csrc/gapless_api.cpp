@@ -252,6 +252,8 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     // dense outputs: at most one extension per seed; nodes / mismatches sized generously and checked on the device
     const uint64_t cap_e = n_seed + 1, cap_n = std::min<uint64_t>(n_seed * G_PATH, std::max<uint64_t>(n_seed * 16 + 1024, nodes_cap)) + 1,
                    cap_m = std::min<uint64_t>(n_seed * G_MISM, std::max<uint64_t>(n_seed * 8 + 1024, mism_cap)) + 1;
+    P.flat_min_idle = G_FLAT_MIN_IDLE;
+    if (const char* e = std::getenv("VGAMD_GAPLESS_MIN_IDLE")) P.flat_min_idle = (uint32_t)std::max(1, std::atoi(e));
     P.caps[0] = cap_e; P.caps[1] = cap_n; P.caps[2] = cap_m;
     // resident threads = scratch slabs: as many as the kernel's register footprint lets the device hold
     uint64_t per_cu = 1024;          // 16 wavefronts per CU: the kernel is built for at most 128 VGPRs (__launch_bounds__(64, 4))
@@ -265,10 +267,11 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     P.ext = (vgk_extension*)dev(nullptr, sizeof(vgk_extension) * cap_e);
     P.nodes = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_n);
     P.mism = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_m);
-    P.counters = (unsigned long long*)dev(nullptr, 64);
-    if (!P.probs || !P.reads || !P.seeds || !P.order || !P.scratch || !P.cold || !P.results || !P.ext || !P.nodes || !P.mism || !P.counters) return cleanup(VGK_ENOMEM);
+    P.counters = (unsigned long long*)dev(nullptr, 256);
+    P.winners = (GExt*)dev(nullptr, sizeof(GExt) * (n_seed + 1));          // the searches' winners wait here for the rules kernel (248 B each; only the used ones are touched)
+    if (!P.winners || !P.probs || !P.reads || !P.seeds || !P.order || !P.scratch || !P.cold || !P.results || !P.ext || !P.nodes || !P.mism || !P.counters) return cleanup(VGK_ENOMEM);
     int rc;
-    if ((rc = be->zero(P.counters, 64))) return cleanup(rc);
+    if ((rc = be->zero(P.counters, 256))) return cleanup(rc);
     if ((rc = be->run_gapless(P, threads))) return cleanup(rc);
     ctx->gapless_last = P; ctx->gapless_last_threads = threads; ctx->gapless_last_valid = true;
     unsigned long long counters[4] = {0, 0, 0, 0};
@@ -283,6 +286,10 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     if (nn && (rc = be->download(dnodes, P.nodes, sizeof(uint32_t) * nn))) return cleanup(rc);
     if (nm && (rc = be->download(dmism, P.mism, sizeof(uint32_t) * nm))) return cleanup(rc);
     ctx->gapless_ms = be->last_ms(5); ctx->gapless_retried = counters[3];
+#if defined(VGAMD_GAPLESS_PROF)
+    { unsigned long long sec[20] = {0}; be->download(sec, P.counters + 8, sizeof(unsigned long long) * 12);
+      std::fprintf(stderr, "gapless sections (wave cycles):"); for (int i = 0; i < 12; ++i) std::fprintf(stderr, " [%d]=%llu", i, sec[i]); std::fprintf(stderr, "\n"); }
+#endif
     // the device packs sets in completion order; hand them back in problem order: sizes, a prefix sum, then parallel copies
     std::vector<uint64_t> oe(n + 1, 0), on(n + 1, 0), om(n + 1, 0);
     parallel_for(n, [&](uint32_t i, unsigned) {
@@ -326,7 +333,7 @@ int vgk_gapless_rerun(vgk_ctx* ctx) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (!ctx->gapless_last_valid) return VGK_EINVAL;
     int rc;
-    if ((rc = ctx->be->zero(ctx->gapless_last.counters, 64))) return rc;
+    if ((rc = ctx->be->zero(ctx->gapless_last.counters, 256))) return rc;
     if ((rc = ctx->be->run_gapless(ctx->gapless_last, ctx->gapless_last_threads))) return rc;
     ctx->gapless_ms = ctx->be->last_ms(5);
     return VGK_OK;

@@ -98,6 +98,72 @@ VGK_HD GState gs_extend_counted(const uint32_t* rec, const GState& s, uint32_t e
     r.blo = s.blo + rev_off; r.bhi = r.blo + inside - 1;
     return r;
 }
+// The first 64-byte line of a record, fetched with four 16-byte loads issued back to back.  A hop that had to read the header,
+// then (knowing the edge count) the edges and the visit bytes, then the bases, waited three times for memory; nearly every
+// record of a variation graph — one or two edges, a handful of visits or runs — lies in that line entirely, and what does not is
+// still read from memory.  (Records start on 16-word boundaries.)
+struct alignas(16) GQuad { uint32_t x, y, z, w; };
+VGK_HD GQuad g_quad(const uint32_t* p) { GQuad q; __builtin_memcpy(&q, __builtin_assume_aligned(p, 16), 16); return q; }
+struct GRecView {
+    const uint32_t* rec; GQuad h, e0, e1, e2;                  // header, then words 4..15: the first three edges — or, behind the last edge, the visit bytes
+    VGK_HD uint32_t ne() const { return h.y & 0xffffu; }
+    VGK_HD bool rle() const { return (h.y >> 31) != 0; }
+    VGK_HD GQuad edge(uint32_t e) const { return e == 0 ? e0 : e == 1 ? e1 : e == 2 ? e2 : g_quad(rec + 4 + 4 * e); }      // {to, base | len << 16, seq, rec}
+    VGK_HD int32_t to(uint32_t e) const { return (int32_t)(e == 0 ? e0.x : e == 1 ? e1.x : e == 2 ? e2.x : rec[4 + 4 * e]); }
+};
+struct GRecMem {                                                   // the same interface over plain loads
+    const uint32_t* rec;
+    VGK_HD uint32_t ne() const { return g_ne(rec); }
+    VGK_HD bool rle() const { return g_rle(rec); }
+    VGK_HD GQuad edge(uint32_t e) const { GQuad q; q.x = rec[4 + 4 * e]; q.y = rec[5 + 4 * e]; q.z = rec[6 + 4 * e]; q.w = rec[7 + 4 * e]; return q; }
+    VGK_HD int32_t to(uint32_t e) const { return ge_to(rec, e); }
+};
+VGK_HD GCounts g_counts(const GRecMem& v, int32_t lo, int32_t hi) { return g_counts(v.rec, lo, hi); }
+template <bool LINE> struct GViewOf { using type = GRecMem; VGK_HD static GRecMem make(const uint32_t* rec) { return GRecMem{rec}; } };
+VGK_HD GRecView g_view(const uint32_t* rec) { GRecView v; v.rec = rec; v.h = g_quad(rec); v.e0 = g_quad(rec + 4); v.e1 = g_quad(rec + 8); v.e2 = g_quad(rec + 12); return v; }
+VGK_HD GCounts g_counts(const GRecView& v, int32_t lo, int32_t hi) {
+    const uint32_t ne = v.ne();
+    if (ne <= 2 && hi >= 0) {
+        const uint64_t body = ne == 0 ? ((uint64_t)v.e0.y << 32 | v.e0.x) : ne == 1 ? ((uint64_t)v.e1.y << 32 | v.e1.x) : ((uint64_t)v.e2.y << 32 | v.e2.x);
+        if (!v.rle()) {
+            if (hi < 8) {                                               // the visit bytes [0, hi] are in the line
+                GCounts c = { 0, 0 };
+                uint64_t w = body;
+                for (int32_t i = 0; i <= hi; ++i, w >>= 8) { const uint64_t one = 1ull << (16 * (uint32_t)(w & 3u)); if (i < lo) c.before += one; else c.inside += one; }
+                return c;
+            }
+        } else {
+            const uint32_t r0 = (uint32_t)body, r1 = (uint32_t)(body >> 32);
+            const int32_t l0 = (int32_t)(r0 >> 8), l1 = (int32_t)(r1 >> 8);
+            if (hi < l0 + l1) {                                         // ... or the runs that cover them
+                GCounts c = { 0, 0 };
+                int32_t pos = 0;
+                for (int k = 0; k < 2 && pos <= hi; ++k) {
+                    const uint32_t run = k ? r1 : r0; const int32_t end = pos + (k ? l1 : l0);
+                    const int32_t b = (end < lo ? end : lo) - pos, last = end - 1 < hi ? end - 1 : hi, first = pos > lo ? pos : lo;
+                    if (b > 0) c.before += (uint64_t)b << (16 * (run & 3u));
+                    if (last >= first) c.inside += (uint64_t)(last - first + 1) << (16 * (run & 3u));
+                    pos = end;
+                }
+                return c;
+            }
+        }
+    }
+    return g_counts(v.rec, lo, hi);
+}
+template <class V> VGK_HD GState gs_extend_counted(const V& v, const GState& s, uint32_t e, const GQuad& ed, const GCounts& cn) {
+    const int32_t to = (int32_t)ed.x;
+    GState r = s; r.fn = to;
+    const int32_t inside = (int32_t)g_count_of(cn.inside, e);
+    if (!inside) { r.flo = 0; r.fhi = -1; r.bhi = r.blo - 1; return r; }
+    int32_t rev_off = 0;
+    const uint32_t ne = v.ne();
+    for (uint32_t x = 0; x < ne; ++x) if (x != e && g_rkey(v.to(x)) < g_rkey(to)) rev_off += (int32_t)g_count_of(cn.inside, x);
+    r.flo = (int32_t)(ed.y & 0xffffu) + (int32_t)g_count_of(cn.before, e); r.fhi = r.flo + inside - 1;
+    r.blo = s.blo + rev_off; r.bhi = r.blo + inside - 1;
+    return r;
+}
+template <> struct GViewOf<true> { using type = GRecView; VGK_HD static GRecView make(const uint32_t* rec) { return g_view(rec); } };
 // bdExtendForward: follow the visits of the forward range that leave through `to`
 VGK_HD GState gs_extend(const GIndex& h, const GState& s, int32_t to) {
     const uint32_t o = (uint32_t)s.fn;
@@ -155,6 +221,38 @@ struct GExt {                        // a finished per-seed winner
     uint32_t path_len, n_mism;
     int32_t  path[G_PATH];
 };                                    // mismatch positions are recomputed where they are needed: they would double the slab
+// What a search keeps in registers between steps — the held-back candidate and the best finished entry so far — is kept in packed
+// words: as plain GEntry copies (26 registers each, the byte flags one register apiece) they pushed the kernel past its 128
+// registers and into scratch memory.  Same limits as the pool's packed entries: 16-bit read and node offsets and visit ranks.
+struct GLean { uint32_t rr, oi, of, pn, fr, br, frec, brec; int32_t score, node, fn, bn; };      // 12 words
+struct GBest { uint32_t rr, oi, fr, br, full; int32_t score, fn, bn; };                             // 8 words: what the winner keeps
+VGK_HD uint32_t g_range(int32_t lo, int32_t hi) { return lo > hi ? 1u : ((uint32_t)lo | ((uint32_t)hi << 16)); }      // an empty range is stored as [1, 0]
+VGK_HD void g_unrange(uint32_t w, int32_t& lo, int32_t& hi) { const uint32_t a = w & 0xffffu, b = w >> 16; const bool e = a > b; lo = e ? 0 : (int32_t)a; hi = e ? -1 : (int32_t)b; }
+VGK_HD GLean g_lean(const GEntry& e) {
+    GLean l;
+    l.rr = e.r0 | (e.r1 << 16); l.oi = e.offset | (e.internal << 16);
+    l.of = e.old | ((uint32_t)(e.front | (e.left_full << 1) | (e.right_full << 2) | (e.left_max << 3) | (e.right_max << 4)) << 16);
+    l.pn = ((uint32_t)e.parent & 0xffffu) | (e.number << 16);
+    l.fr = g_range(e.state.flo, e.state.fhi); l.br = g_range(e.state.blo, e.state.bhi); l.frec = e.frec; l.brec = e.brec;
+    l.score = e.score; l.node = e.node; l.fn = e.state.fn; l.bn = e.state.bn;
+    return l;
+}
+VGK_HD GEntry g_fat(const GLean& l) {
+    GEntry e;
+    e.r0 = l.rr & 0xffffu; e.r1 = l.rr >> 16; e.offset = l.oi & 0xffffu; e.internal = l.oi >> 16; e.old = l.of & 0xffffu;
+    const uint32_t fl = l.of >> 16;
+    e.front = fl & 1; e.left_full = (fl >> 1) & 1; e.right_full = (fl >> 2) & 1; e.left_max = (fl >> 3) & 1; e.right_max = (fl >> 4) & 1; e.pad[0] = e.pad[1] = e.pad[2] = 0;
+    e.parent = (int32_t)(int16_t)(uint16_t)(l.pn & 0xffffu); e.number = l.pn >> 16;
+    g_unrange(l.fr, e.state.flo, e.state.fhi); g_unrange(l.br, e.state.blo, e.state.bhi); e.frec = l.frec; e.brec = l.brec;
+    e.score = l.score; e.node = l.node; e.state.fn = l.fn; e.state.bn = l.bn;
+    return e;
+}
+VGK_HD GBest g_best(const GEntry& e) {
+    GBest b;
+    b.rr = e.r0 | (e.r1 << 16); b.oi = e.offset | (e.internal << 16); b.fr = g_range(e.state.flo, e.state.fhi); b.br = g_range(e.state.blo, e.state.bhi);
+    b.full = (uint32_t)e.left_full | ((uint32_t)e.right_full << 1); b.score = e.score; b.fn = e.state.fn; b.bn = e.state.bn;
+    return b;
+}
 // what the pool stores of an entry: 40 bytes (reads and nodes up to 65 535 bases, up to 65 535 visits per node)
 struct GPacked {
     int16_t  parent; uint16_t number;
@@ -195,7 +293,8 @@ constexpr int G_HOT = 8;
 // What the path of an entry needs, for every entry: 8 bytes.  The 40-byte packed entry is written only when an entry actually
 // waits in the queue; on a non-branching stretch every new entry is the held-back candidate and is popped from registers.
 struct GLink { int32_t node; int16_t parent; uint8_t front, pad; };
-struct GScratch { uint64_t heap[G_POOL]; GPacked pool[G_POOL]; GLink link[G_POOL]; GExt res[G_HOT]; uint8_t order[G_SEEDS]; };      // order[]: the permutation the set rules sort
+struct GScratch { uint64_t heap[G_POOL]; GPacked pool[G_POOL]; GLink link[G_POOL]; GExt res[G_HOT]; uint8_t order[G_SEEDS]; int32_t diag[G_PATH]; };      // diag[]: flat form, see gx_diagonals
+//      // order[]: the permutation the set rules sort
 struct GCold { GExt res[G_SEEDS - G_HOT]; };
 struct GRes {                          // the G_SEEDS winners of a read as one array
     GExt* hot; GExt* cold;
@@ -210,11 +309,13 @@ struct GaplessParams {
     const char* reads;                // masked: ACGT or X
     const vgk_seed* seeds;
     int32_t match, mismatch, bonus;
+    uint32_t  flat_min_idle;          // flat form: lanes without a search that make a wavefront run the branch that begins one
+    GExt*     winners;                // flat form: room for one per seed of the batch (a read's winners start at its seed_off)
     GScratch* scratch;                // one per resident thread
     GCold*    cold;                   // likewise
     vgk_gapless_result* results;      // per problem (ext_begin indexes `ext`)
     vgk_extension* ext; uint32_t* nodes; uint32_t* mism;
-    unsigned long long* counters;     // [0] extensions, [1] nodes, [2] mismatches handed out, [3] reads the fast kernel passed on to the slab kernel
+    unsigned long long* counters;     // [0] extensions, [1] nodes, [2] mismatches handed out, [3] reads the fast kernel passed on to the slab kernel, [4] reads handed to lanes (flat form)
     unsigned long long caps[3];
 };
 
@@ -231,33 +332,84 @@ struct GCtx { const GaplessParams* P; const char* seq; uint32_t L; };
 // Eight bases per compare, like the reference's memcpy'd uint64 words (:219-224).  Both buffers carry 8 bytes of padding at
 // either end, so a word that straddles the end of the data stays inside the allocation.
 VGK_HD uint64_t g_load8(const char* p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
+// A word that differs is not walked byte by byte: the bytes that differ are marked with one bit each, counted, and taken in one
+// step when the mismatch budget covers them — in a wavefront some lane has a mismatch in nearly every word, and a byte loop that one
+// lane needs is paid by all 64.  Only the word in which the budget runs out is searched for the stopping position.
+VGK_HD uint64_t g_nzbytes(uint64_t x) { const uint64_t L = 0x7f7f7f7f7f7f7f7full; return (((x & L) + L) | x) & ~L; }      // bit 7 of every nonzero byte
+#if defined(__HIP_DEVICE_COMPILE__)
+VGK_HD uint32_t g_pop64(uint64_t x) { return (uint32_t)__popcll(x); }
+VGK_HD uint32_t g_ctz64(uint64_t x) { return (uint32_t)__ffsll((unsigned long long)x) - 1u; }
+VGK_HD uint32_t g_clz64(uint64_t x) { return (uint32_t)__clzll((long long)x); }
+#else
+VGK_HD uint32_t g_pop64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+VGK_HD uint32_t g_ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
+VGK_HD uint32_t g_clz64(uint64_t x) { return (uint32_t)__builtin_clzll(x); }
+#endif
 // forward: compare a[0..left) with b[0..left); stops BEFORE the mismatch that would reach `limit`; returns the bases consumed
-VGK_HD uint32_t g_match_fwd(const char* a, const char* b, uint32_t left, uint32_t& internal, uint32_t limit) {
+template <bool BATCH = false> VGK_HD uint32_t g_match_fwd(const char* a, const char* b, uint32_t left, uint32_t& internal, uint32_t limit) {
     uint32_t n = 0;
     while (n < left) {
         const uint64_t wa = g_load8(a + n), wb = g_load8(b + n);
         const uint32_t len = left - n < 8 ? left - n : 8;
-        if (len == 8 && wa == wb) { n += 8; continue; }
-        uint64_t x = wa ^ wb;
-        for (uint32_t i = 0; i < len; ++i, x >>= 8) {
-            if (x & 0xff) { if (internal + 1 >= limit) return n; ++internal; }
-            ++n;
+        uint64_t m = g_nzbytes(wa ^ wb);
+        if (len < 8) m &= (1ull << (8 * len)) - 1ull;                       // the first `len` bytes are the low ones
+        if (m) {
+            const uint32_t cnt = g_pop64(m), allowed = limit > internal + 1 ? limit - 1 - internal : 0u;
+            if (cnt > allowed) {                                            // the budget runs out inside this word: at mismatch number allowed + 1
+                for (uint32_t k = 0; k < allowed; ++k) m &= m - 1;
+                internal += allowed;
+                return n + (g_ctz64(m) >> 3);
+            }
+            internal += cnt;
         }
+        n += len;
     }
     return n;
 }
 // backward: compare a[-1], a[-2], ... with b[-1], b[-2], ... for up to `left` bases
-VGK_HD uint32_t g_match_bwd(const char* a, const char* b, uint32_t left, uint32_t& internal, uint32_t limit) {
+template <bool BATCH = false> VGK_HD uint32_t g_match_bwd(const char* a, const char* b, uint32_t left, uint32_t& internal, uint32_t limit) {
     uint32_t n = 0;
     while (n < left) {
         const uint64_t wa = g_load8(a - n - 8), wb = g_load8(b - n - 8);
         const uint32_t len = left - n < 8 ? left - n : 8;
-        if (len == 8 && wa == wb) { n += 8; continue; }
-        uint64_t x = wa ^ wb;
-        for (uint32_t i = 0; i < len; ++i, x <<= 8) {
-            if (x >> 56) { if (internal + 1 >= limit) return n; ++internal; }
-            ++n;
+        uint64_t m = g_nzbytes(wa ^ wb);
+        if (len < 8) m &= ~0ull << (8 * (8 - len));                         // the first `len` bytes are the high ones
+        if (m) {
+            const uint32_t cnt = g_pop64(m), allowed = limit > internal + 1 ? limit - 1 - internal : 0u;
+            if (cnt > allowed) {
+                for (uint32_t k = 0; k < allowed; ++k) m &= ~(1ull << (63u - g_clz64(m)));
+                internal += allowed;
+                return n + (g_clz64(m) >> 3);
+            }
+            internal += cnt;
         }
+        n += len;
+    }
+    return n;
+}
+
+// either way through one body: backward, the words are fetched from below the pointers and byte-swapped, so that the first base
+// compared is the low byte as it is forward
+VGK_HD uint64_t g_bswap64(uint64_t x) { return __builtin_bswap64(x); }
+VGK_HD uint32_t g_match_dir(const char* a, const char* b, uint32_t left, uint32_t& internal, uint32_t limit, bool back) {
+    uint32_t n = 0;
+    while (n < left) {
+        const int64_t at = back ? -(int64_t)n - 8 : (int64_t)n;
+        uint64_t x = g_load8(a + at) ^ g_load8(b + at);
+        if (back) x = g_bswap64(x);
+        const uint32_t len = left - n < 8 ? left - n : 8;
+        uint64_t m = g_nzbytes(x);
+        if (len < 8) m &= (1ull << (8 * len)) - 1ull;
+        if (m) {
+            const uint32_t cnt = g_pop64(m), allowed = limit > internal + 1 ? limit - 1 - internal : 0u;
+            if (cnt > allowed) {
+                for (uint32_t k = 0; k < allowed; ++k) m &= m - 1;
+                internal += allowed;
+                return n + (g_ctz64(m) >> 3);
+            }
+            internal += cnt;
+        }
+        n += len;
     }
     return n;
 }
@@ -269,6 +421,7 @@ VGK_HD void g_set_score(const GCtx& c, GEntry& e) {                             
 // The queue orders (score, insertion number) — highest score first, the later insertion among equals (:567-571).  Its keys
 // carry both and an index, so sifting touches only the small key array, never the entries themselves.
 VGK_HD uint64_t g_key(const GEntry& e, uint32_t idx) { return ((uint64_t)((uint32_t)e.score ^ 0x80000000u) << 32) | ((uint64_t)e.number << 16) | idx; }
+VGK_HD uint64_t g_key(const GLean& e, uint32_t idx) { return ((uint64_t)((uint32_t)e.score ^ 0x80000000u) << 32) | ((uint64_t)(e.pn >> 16) << 16) | idx; }
 VGK_HD GLink g_link(const GEntry& e) { GLink l; l.node = e.node; l.parent = (int16_t)e.parent; l.front = e.front; l.pad = 0; return l; }
 
 // ---- where a seed's search keeps its state ------------------------------------------------------------------------------
@@ -289,6 +442,7 @@ constexpr uint32_t G_FAST_DW = 2 * G_FAST_QUEUE + 5 * G_FAST_QUEUE;      // dwor
 
 struct GStoreSlab {
     GScratch& s;
+    static constexpr int VARIANT = 0;
     static constexpr uint32_t ENTRIES = (uint32_t)G_POOL;
     static constexpr int32_t  FULL = VGK_ETOOBIG;
     VGK_HD void begin_seed() {}
@@ -303,7 +457,8 @@ struct GStoreSlab {
     VGK_HD GLink link_get(uint32_t i) const { return s.link[i]; }
 };
 
-struct GStoreLds {
+template <int VAR> struct GStoreLdsT {
+    static constexpr int VARIANT = VAR;
     uint32_t* base; uint32_t stride;             // dword k of this thread = base[k * stride]
     GScratch& s;                                 // the thread's slab: path links only
     uint32_t free_slots;
@@ -350,6 +505,11 @@ struct GStoreLds {
     VGK_HD GLink link_get(uint32_t i) const { return s.link[i]; }
 };
 
+#ifndef VGK_GAPLESS_VARIANT
+#define VGK_GAPLESS_VARIANT 0
+#endif
+using GStoreLds = GStoreLdsT<VGK_GAPLESS_VARIANT>;
+
 template <class ST> VGK_HD bool g_heap_push(ST& S, uint32_t& hn, const GEntry& e, uint32_t entry) {
     uint32_t idx;
     if (!S.slot_take(entry, idx)) return false;
@@ -361,9 +521,9 @@ template <class ST> VGK_HD bool g_heap_push(ST& S, uint32_t& hn, const GEntry& e
     return true;
 }
 // a new entry: the better of it and the held-back candidate stays in registers, the other one goes to the queue
-template <class ST> VGK_HD bool g_offer(ST& S, uint32_t& hn, bool& have_cand, GEntry& cand, uint32_t& cand_idx, const GEntry& e, uint32_t idx) {
-    if (!have_cand) { cand = e; cand_idx = idx; have_cand = true; return true; }
-    if (g_key(e, idx) > g_key(cand, cand_idx)) { const bool ok = g_heap_push(S, hn, cand, cand_idx); cand = e; cand_idx = idx; return ok; }
+template <class ST> VGK_HD bool g_offer(ST& S, uint32_t& hn, bool& have_cand, GLean& cand, uint32_t& cand_idx, const GEntry& e, uint32_t idx) {
+    if (!have_cand) { cand = g_lean(e); cand_idx = idx; have_cand = true; return true; }
+    if (g_key(e, idx) > g_key(cand, cand_idx)) { const bool ok = g_heap_push(S, hn, g_fat(cand), cand_idx); cand = g_lean(e); cand_idx = idx; return ok; }
     return g_heap_push(S, hn, e, idx);
 }
 template <class ST> VGK_HD uint64_t g_heap_pop(ST& S, uint32_t& hn) {
@@ -405,6 +565,21 @@ VGK_HD bool gx_contains(const GIndex& h, const GExt& e, int32_t node, int64_t di
     }
     return false;
 }
+// The same test against the diagonals (read offset - node offset) of the path's nodes, computed once when an extension becomes the
+// best: gx_contains reads two dependent words per path node to learn its length, for every seed it is asked about.
+VGK_HD void gx_diagonals(const GIndex& h, const GExt& e, int32_t* diag) {
+    uint32_t read_offset = e.r0, node_offset = e.offset;
+    for (uint32_t i = 0; i < e.path_len; ++i) {
+        const uint32_t a = g_len(h, e.path[i]) - node_offset, b = e.r1 - read_offset; const uint32_t len = a < b ? a : b;
+        diag[i] = (int32_t)read_offset - (int32_t)node_offset;
+        read_offset += len; node_offset = 0;
+    }
+}
+VGK_HD bool gx_contains_diag(const GExt& e, const int32_t* diag, int32_t node, int64_t diff) {
+    bool hit = false;
+    for (uint32_t i = 0; i < e.path_len; ++i) hit |= e.path[i] == node && (int64_t)diag[i] == diff;
+    return hit;
+}
 VGK_HD uint32_t gx_overlap(const GIndex& h, const GExt& x, const GExt& y) {                        // (:69-103)
     uint32_t result = 0, xp = x.r0, yp = y.r0, xi = 0, yi = 0, xo = x.offset, yo = y.offset;
     while (xp < x.r1 && yp < y.r1) {
@@ -436,10 +611,10 @@ VGK_HD bool gx_full_less(const GExt& a, const GExt& b) {                        
     return gx_full(a) && !gx_full(b);
 }
 // stable insertion sort of an index permutation (the sets are small; moving 500-byte records would not pay)
-template <class Less> VGK_HD void gx_sort(const GRes& v, uint8_t* order, uint32_t n, Less less) {
+template <class RESV, class Less> VGK_HD void gx_sort(const RESV& v, uint8_t* order, uint32_t n, Less less) {
     for (uint32_t i = 1; i < n; ++i) { const uint8_t x = order[i]; uint32_t j = i; while (j && less(v[x], v[order[j - 1]])) { order[j] = order[j - 1]; --j; } order[j] = x; }
 }
-VGK_HD uint32_t gx_remove_duplicates(const GRes& v, uint8_t* order, uint32_t n) {                  // (:332-365)
+template <class RESV> VGK_HD uint32_t gx_remove_duplicates(const RESV& v, uint8_t* order, uint32_t n) {                  // (:332-365)
     gx_sort(v, order, n, [](const GExt& a, const GExt& b) { return gx_dup_less(a, b); });
     uint32_t tail = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -455,11 +630,20 @@ VGK_HD void gx_find_mismatches(const GCtx& c, GExt& e, uint32_t* mm, bool& overf
     if (!e.internal) return;
     const GIndex& h = c.P->index;
     uint32_t node_offset = e.offset, read_offset = e.r0;
-    for (uint32_t i = 0; i < e.path_len; ++i) {
-        const char* t = h.seq + g_rec(h, (uint32_t)(e.path[i]))[3]; const uint32_t tl = g_len(h, e.path[i]);
-        while (node_offset < tl && read_offset < e.r1) {
-            if (t[node_offset] != c.seq[read_offset]) { if (e.n_mism >= G_MISM) { overflow = true; return; } mm[e.n_mism++] = read_offset; }
-            ++node_offset; ++read_offset;
+    for (uint32_t i = 0; i < e.path_len && read_offset < e.r1; ++i) {
+        const uint32_t* rec = g_rec(h, (uint32_t)(e.path[i]));
+        const char* t = h.seq + rec[3]; const uint32_t tl = rec[2];
+        uint32_t left = tl - node_offset < e.r1 - read_offset ? tl - node_offset : e.r1 - read_offset;
+        while (left) {                                                       // eight bases per compare; the positions come out of the mask of differing bytes
+            const uint32_t len = left < 8 ? left : 8;
+            uint64_t m = g_nzbytes(g_load8(t + node_offset) ^ g_load8(c.seq + read_offset));
+            if (len < 8) m &= (1ull << (8 * len)) - 1ull;
+            while (m) {
+                if (e.n_mism >= G_MISM) { overflow = true; return; }
+                mm[e.n_mism++] = read_offset + (g_ctz64(m) >> 3);
+                m &= m - 1;
+            }
+            node_offset += len; read_offset += len; left -= len;
         }
         node_offset = 0;
     }
@@ -507,144 +691,169 @@ VGK_HD bool gx_trim(const GCtx& c, GExt& e, uint32_t* mm) {                     
     return true;
 }
 
-// one read: every seed's best extension, then the set rules.  ST = where a seed's search lives (GStoreSlab / GStoreLds); the
-// winners and the permutation the set rules sort stay in the thread's HBM slab either way (written once per seed).
+// ---- one seed's search, cut into begin / step / end so that a kernel can run it as ONE flat loop -----------------------------------
+// GaplessExtender::extend is "for every seed: a best-first search; then rules over the set of winners".  A thread that runs the
+// nested loops waits, at the end of every search, for the slowest lane of its wavefront; a thread that runs `begin` when it has no
+// search, else one `step`, in a single loop, never waits: lanes of a wavefront work on different seeds (of different reads) but on
+// the same instruction — the loop body is the expansion of one partial extension.  A seed's search does not depend on the other
+// seeds of its cluster; the one rule that couples them ("skip a seed that the best exact full-length extension so far already
+// contains", :545-549) only decides whether a winner is USED, and is applied afterwards, in seed order, by gapless_finish_read.
+// Section timing for kernel work (-DVGAMD_GAPLESS_PROF): wave cycles per section of the flat loop, summed into counters[8 + section]
+#if defined(VGAMD_GAPLESS_PROF) && defined(__HIPCC__)
+struct GProf { unsigned long long t0, acc[12]; __device__ void start() { t0 = __builtin_readcyclecounter(); for (int i = 0; i < 12; ++i) acc[i] = 0; } __device__ void tick(int s) { const unsigned long long t = __builtin_readcyclecounter(); acc[s] += t - t0; t0 = t; } };
+#define G_TICK(prof, s) do { if (prof) (prof)->tick(s); } while (0)
+#else
+struct GProf {};
+#define G_TICK(prof, s) do { } while (0)
+#endif
+struct GSearch {
+    GProf* prof;
+    uint32_t np, hn, number; bool have_cand; GLean cand; uint32_t cand_idx; int32_t best; GBest best_e;
+    uint32_t L, max_mm;
+};
+constexpr int32_t G_BADNODE = 2, G_BADOFF = 3;          // winner statuses (beside VGK_OK, VGK_ETOOBIG, G_RETRY): a seed node out of range (checked
+                                                        // before the skip rule), a seed offset out of range (checked after it)
+// winner record of a seed = GExt with pad[0] = 1 when there is an extension, pad[1] = status
 template <class ST>
-VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, ST& Q, GScratch& S, GCold& C) {
-    const GRes RES{S.res, C.res};
-    const GProb pb = P.probs[pi];
+VGK_HD int g_search_begin(const GaplessParams& P, const GCtx& c, const GProb& pb, uint32_t si, ST& Q, GSearch& s) {
+    const GIndex& h = P.index;
+    const vgk_seed sd = P.seeds[pb.seed_off + si];
+    const int32_t snode = (int32_t)sd.node; const int64_t diff = sd.diff;
+    if ((uint32_t)snode >= h.n_oriented) return G_BADNODE;
+    const uint32_t L = pb.read_len;
+    const uint32_t read_offset = diff < 0 ? 0u : (uint32_t)diff, node_offset = diff < 0 ? (uint32_t)(-diff) : 0u;
+    const uint32_t ro_f = h.rec_off[(uint32_t)snode], ro_b = h.rec_off[(uint32_t)snode ^ 1u];
+    const GQuad hf = g_quad(h.rec + ro_f), hb = g_quad(h.rec + ro_b);           // {visits, edges, length, bases} of the seed node on either strand
+    const uint32_t slen = hf.z;
+    if (read_offset > L || node_offset > slen) return G_BADOFF;
+    s.np = 0; s.hn = 0; s.number = 0; s.have_cand = false; s.cand_idx = 0; s.best = -1; s.L = L; s.max_mm = pb.max_mm;
+    s.best_e.score = 0; s.best_e.rr = 0;
+    Q.begin_seed();
+    // the seed node itself: any number of mismatches (:213-237)
+    GEntry m;
+    m.parent = -1; m.node = snode; m.front = 0; m.offset = node_offset; m.r0 = m.r1 = read_offset; m.internal = 0;
+    m.left_full = m.right_full = m.left_max = m.right_max = 0; m.pad[0] = m.pad[1] = m.pad[2] = 0; m.frec = ro_f; m.brec = ro_b;
+    m.state.fn = snode; m.state.flo = 0; m.state.fhi = (int32_t)hf.x - 1; m.state.bn = snode ^ 1; m.state.blo = 0; m.state.bhi = (int32_t)hb.x - 1;      // gs_find
+    const char* t = h.seq + hf.w;
+    const uint32_t left = L - m.r1 < slen - node_offset ? L - m.r1 : slen - node_offset;
+    m.r1 += g_match_fwd<(ST::VARIANT & 2) != 0>(c.seq + m.r1, t + node_offset, left, m.internal, 0xffffffffu);
+    m.old = m.internal;
+    if (m.r0 == 0) m.left_full = m.left_max = 1;
+    if (m.r1 >= L) m.right_full = m.right_max = 1;
+    g_set_score(c, m); m.number = s.number++;
+    Q.link_set(s.np, m);
+    s.cand = g_lean(m); s.cand_idx = s.np; s.have_cand = true; ++s.np;
+    return VGK_OK;
+}
+// one pop + expansion; VGK_OK = go on (or the queue ran dry: check g_search_live), else the status that ends the search
+// The queue pops (score, insertion number) maxima.  The best entry created by an expansion is held back in registers (`cand`): when
+// it beats the queue's top — always, on a non-branching stretch — it is the next one popped and the round trip through the store
+// is skipped; otherwise it joins the queue first.
+VGK_HD bool g_search_live(const GSearch& s) { return s.hn || s.have_cand; }
+template <class ST>
+VGK_HD int g_search_step(const GaplessParams& P, const GCtx& c, ST& Q, GSearch& s) {
+    const GIndex& h = P.index;
+    const uint32_t L = s.L, max_mm = s.max_mm;
+    uint32_t ci; GEntry cur;
+    if (s.have_cand && (s.hn == 0 || g_key(s.cand, s.cand_idx) > Q.heap_get(0))) { ci = s.cand_idx; cur = g_fat(s.cand); s.have_cand = false; }
+    else {
+        if (s.have_cand) { if (!g_heap_push(Q, s.hn, g_fat(s.cand), s.cand_idx)) return ST::FULL; s.have_cand = false; }
+        const uint64_t top = g_heap_pop(Q, s.hn);
+        const uint32_t idx = (uint32_t)(top & 0xffffu);
+        cur = Q.pool_get(c, idx, top); Q.slot_free(idx);
+        ci = Q.entry_of(idx);
+    }
+    G_TICK(s.prof, 2);
+    // One expansion, to the right while the entry can grow there, else to the left (:590-700).  The two directions run through the
+    // same instructions — which record, which state, which way the bases are compared are data — because in a wavefront there are
+    // always lanes going either way, and two code paths would each be paid by all of them.
+    const bool right = !cur.right_max;
+    if (right || !cur.left_max) {
+        uint32_t num_ext = 0; bool found = false;
+        const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
+        uint32_t ri = right ? cur.frec : cur.brec;
+        if (ri == G_NO_REC) { ri = h.rec_off[(uint32_t)(right ? cur.state.fn : cur.state.bn)]; if (right) cur.frec = ri; else cur.brec = ri; }
+        const auto orec = GViewOf<(ST::VARIANT & 1) != 0>::make(h.rec + ri);
+        const uint32_t ne = orec.ne();
+        const GState from = right ? cur.state : gs_flip(cur.state);
+        const bool few = ne <= 4 && !gs_empty(from);
+        const GCounts cn = few ? g_counts(orec, from.flo, from.fhi) : GCounts{0, 0};
+        for (uint32_t e = 0; e < ne; ++e) {
+            const GQuad ed = orec.edge(e);
+            const int32_t x = (int32_t)ed.x; if (x < 0) continue;
+            GState ns = few ? gs_extend_counted(orec, from, e, ed, cn) : gs_extend(h, from, x);
+            if (!right) ns = gs_flip(ns);                                                        // bdExtendBackward
+            G_TICK(s.prof, 7);
+            if (gs_empty(ns)) continue;
+            if (s.np >= ST::ENTRIES) return ST::FULL;
+            const uint32_t wl = ed.y >> 16;
+            // match_forward (:239-266) over the successor's bases from their start / match_backward (:268-296) over the bases of the other
+            // strand of x (same length, one strand_shift away) from their end
+            const char* t = right ? h.seq + ed.z : h.seq + ((x & 1) ? ed.z - h.strand_shift : ed.z + h.strand_shift) + wl;
+            GEntry nx = cur; nx.parent = (int32_t)ci; nx.node = right ? x : (ns.bn ^ 1); nx.front = right ? 0 : 1; nx.state = ns;
+            if (right) nx.frec = ed.w; else { nx.brec = ed.w; nx.offset = wl; }
+            const uint32_t room = right ? (L - nx.r1 < wl ? L - nx.r1 : wl) : (nx.r0 < wl ? nx.r0 : wl);
+            const uint32_t no = g_match_dir(c.seq + (right ? nx.r1 : nx.r0), t, room, nx.internal, limit, !right);
+            G_TICK(s.prof, 8);
+            if (right) {
+                nx.r1 += no;
+                if (no == 0) continue;
+                if (nx.r1 >= L) { nx.right_full = nx.right_max = 1; nx.old = nx.internal; }
+                else if (no < wl) { nx.right_max = 1; nx.old = nx.internal; }
+            } else {
+                nx.r0 -= no; nx.offset -= no;
+                if (nx.offset >= wl) continue;
+                if (nx.r0 == 0) nx.left_full = nx.left_max = 1;
+                else if (nx.offset > 0) nx.left_max = 1;
+            }
+            g_set_score(c, nx); nx.number = s.number++;
+            num_ext += gs_size(ns);
+            Q.link_set(s.np, nx);
+            if (!g_offer(Q, s.hn, s.have_cand, s.cand, s.cand_idx, nx, s.np)) return ST::FULL;
+            ++s.np;
+            found = true;
+            G_TICK(s.prof, 9);
+        }
+        if (right) {
+            if (num_ext < gs_size(cur.state)) {                                           // some haplotype ends here: keep it (:633-637)
+                if (s.np >= ST::ENTRIES) return ST::FULL;
+                GEntry nx = cur; nx.parent = (int32_t)ci; nx.node = -1; nx.right_max = 1; nx.old = nx.internal; nx.number = s.number++;
+                Q.link_set(s.np, nx);
+                if (!g_offer(Q, s.hn, s.have_cand, s.cand, s.cand_idx, nx, s.np)) return ST::FULL;
+                ++s.np;
+            }
+            G_TICK(s.prof, 3);
+            return VGK_OK;
+        }
+        G_TICK(s.prof, 4);
+        if (found) return VGK_OK;
+        cur.left_max = 1;
+    }
+    if (s.best < 0 || s.best_e.score < cur.score) { s.best = (int32_t)ci; s.best_e = g_best(cur); }
+    G_TICK(s.prof, 5);
+    return VGK_OK;
+}
+// the winner of a finished search into `r` (pad[0] = 1 when there is one); VGK_ETOOBIG when its path does not fit
+template <class ST>
+VGK_HD int g_search_end(const ST& Q, const GSearch& s, GExt& r) {
+    r.pad[0] = 0; r.pad[1] = 0; r.path_len = 0; r.n_mism = 0;
+    const GBest& b = s.best_e;
+    if (!(s.best >= 0 && (b.rr >> 16) > (b.rr & 0xffffu))) return VGK_OK;
+    const int plen = g_path(Q, s.best, r.path);
+    if (plen < 0) return VGK_ETOOBIG;
+    r.path_len = (uint32_t)plen; r.offset = b.oi & 0xffffu; r.r0 = b.rr & 0xffffu; r.r1 = b.rr >> 16; r.internal = b.oi >> 16; r.score = b.score;
+    r.state.fn = b.fn; r.state.bn = b.bn; g_unrange(b.fr, r.state.flo, r.state.fhi); g_unrange(b.br, r.state.blo, r.state.bhi);
+    r.left_full = (uint8_t)(b.full & 1u); r.right_full = (uint8_t)((b.full >> 1) & 1u); r.n_mism = 0; r.pad[0] = 1;
+    return VGK_OK;
+}
+
+// The rules over a read's winners (the second half of GaplessExtender::extend): RES(i) = the i-th USED winner, n_res of them, in seed
+// order; best_alignment as the seed loop left it.  `order` = n_res bytes of scratch for the permutation the rules sort.
+template <class RESV>
+VGK_HD void gapless_set_rules(const GaplessParams& P, uint32_t pi, const GProb& pb, const GCtx& c, const RESV& RES, uint32_t n_res, uint32_t best_alignment, uint8_t* order) {
     const GIndex& h = P.index;
     vgk_gapless_result& out = P.results[pi];
-    out.status = VGK_OK; out.ext_begin = 0; out.n_ext = 0; out.full_length = 0;
-    if (!pb.read_len || !pb.n_seeds) return;
-    if (pb.n_seeds > (uint32_t)G_SEEDS) { out.status = VGK_ETOOBIG; return; }
-    if (ST::FULL == G_RETRY && (pb.read_len > 255u || P.index.max_node_len > 255u || P.index.max_visits > 254u)) { out.status = G_RETRY; g_bump(P.counters + 3, 1); return; }   // beyond the compact entries
-    GCtx c; c.P = &P; c.seq = P.reads + pb.read_off; c.L = pb.read_len;
-    const uint32_t L = pb.read_len, max_mm = pb.max_mm;
-    uint32_t n_res = 0, best_alignment = 0xffffffffu;
-    int status = VGK_OK;
-    for (uint32_t si = 0; si < pb.n_seeds && status == VGK_OK; ++si) {
-        const vgk_seed sd = P.seeds[pb.seed_off + si];
-        const int32_t snode = (int32_t)sd.node; const int64_t diff = sd.diff;
-        if ((uint32_t)snode >= h.n_oriented) { status = VGK_EINVAL; break; }
-        if (best_alignment < n_res && RES[best_alignment].internal == 0 && gx_contains(h, RES[best_alignment], snode, diff)) continue;
-        const uint32_t read_offset = diff < 0 ? 0u : (uint32_t)diff, node_offset = diff < 0 ? (uint32_t)(-diff) : 0u;
-        if (read_offset > L || node_offset > g_len(h, snode)) { status = VGK_EINVAL; break; }
-        uint32_t np = 0, hn = 0, number = 0;
-        bool have_cand = false; GEntry cand; uint32_t cand_idx = 0;
-        Q.begin_seed();
-        int32_t best = -1;
-        GEntry best_e; best_e.score = 0; best_e.r0 = best_e.r1 = 0; best_e.offset = 0; best_e.internal = 0; best_e.left_full = best_e.right_full = 0;
-        {   // the seed node itself: any number of mismatches (:213-237)
-            GEntry m;
-            m.parent = -1; m.node = snode; m.front = 0; m.offset = node_offset; m.r0 = m.r1 = read_offset; m.internal = 0;
-            m.left_full = m.right_full = m.left_max = m.right_max = 0; m.pad[0] = m.pad[1] = m.pad[2] = 0; m.state = gs_find(h, snode); m.frec = m.brec = G_NO_REC;
-            const char* t = h.seq + g_rec(h, (uint32_t)(snode))[3];
-            const uint32_t left = L - m.r1 < g_len(h, snode) - node_offset ? L - m.r1 : g_len(h, snode) - node_offset;
-            m.r1 += g_match_fwd(c.seq + m.r1, t + node_offset, left, m.internal, 0xffffffffu);
-            m.old = m.internal;
-            if (m.r0 == 0) m.left_full = m.left_max = 1;
-            if (m.r1 >= L) m.right_full = m.right_max = 1;
-            g_set_score(c, m); m.number = number++;
-            Q.link_set(np, m);
-            cand = m; cand_idx = np; have_cand = true; ++np;
-        }
-        // The queue pops (score, insertion number) maxima.  The best entry created by an expansion is held back in registers
-        // (`cand`): when it beats the queue's top — always, on a non-branching stretch — it is the next one popped, and the
-        // round trip through the slab (key push, key pop, 40-byte entry load) is skipped; otherwise it joins the queue first.
-        while (hn || have_cand) {
-            uint32_t ci; GEntry cur;
-            if (have_cand && (hn == 0 || g_key(cand, cand_idx) > Q.heap_get(0))) { ci = cand_idx; cur = cand; have_cand = false; }
-            else {
-                if (have_cand) { if (!g_heap_push(Q, hn, cand, cand_idx)) { status = ST::FULL; break; } have_cand = false; }
-                const uint64_t top = g_heap_pop(Q, hn);
-                const uint32_t idx = (uint32_t)(top & 0xffffu);
-                cur = Q.pool_get(c, idx, top); Q.slot_free(idx);
-                ci = Q.entry_of(idx);
-            }
-            if (!cur.right_max) {
-                uint32_t num_ext = 0;
-                const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
-                if (cur.frec == G_NO_REC) cur.frec = h.rec_off[(uint32_t)cur.state.fn];
-                const uint32_t* orec = h.rec + cur.frec;
-                const bool few = g_ne(orec) <= 4 && !gs_empty(cur.state);
-                const GCounts cn = few ? g_counts(orec, cur.state.flo, cur.state.fhi) : GCounts{0, 0};
-                for (uint32_t e = 0; e < g_ne(orec); ++e) {
-                    const int32_t w = ge_to(orec, e); if (w < 0) continue;
-                    const GState ns = few ? gs_extend_counted(orec, cur.state, e, cn) : gs_extend(h, cur.state, w);
-                    if (gs_empty(ns)) continue;
-                    if (np >= ST::ENTRIES) { status = ST::FULL; break; }
-                    GEntry nx = cur; nx.parent = (int32_t)ci; nx.node = w; nx.front = 0; nx.state = ns; nx.frec = ge_rec(orec, e);
-                    const char* t = h.seq + ge_seq(orec, e); const uint32_t wl = ge_len(orec, e);            // match_forward (:239-266)
-                    const uint32_t no = g_match_fwd(c.seq + nx.r1, t, L - nx.r1 < wl ? L - nx.r1 : wl, nx.internal, limit);
-                    nx.r1 += no;
-                    if (no == 0) continue;
-                    if (nx.r1 >= L) { nx.right_full = nx.right_max = 1; nx.old = nx.internal; }
-                    else if (no < wl) { nx.right_max = 1; nx.old = nx.internal; }
-                    g_set_score(c, nx); nx.number = number++;
-                    num_ext += gs_size(ns);
-                    Q.link_set(np, nx);
-                    if (!g_offer(Q, hn, have_cand, cand, cand_idx, nx, np)) { status = ST::FULL; break; }
-                    ++np;
-                }
-                if (status != VGK_OK) break;
-                if (num_ext < gs_size(cur.state)) {                                               // some haplotype ends here: keep it (:633-637)
-                    if (np >= ST::ENTRIES) { status = ST::FULL; break; }
-                    GEntry nx = cur; nx.parent = (int32_t)ci; nx.node = -1; nx.right_max = 1; nx.old = nx.internal; nx.number = number++;
-                    Q.link_set(np, nx);
-                    if (!g_offer(Q, hn, have_cand, cand, cand_idx, nx, np)) { status = ST::FULL; break; }
-                    ++np;
-                }
-                continue;
-            }
-            if (!cur.left_max) {
-                bool found = false;
-                const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
-                if (cur.brec == G_NO_REC) cur.brec = h.rec_off[(uint32_t)cur.state.bn];
-                const uint32_t* orec = h.rec + cur.brec;
-                const GState flipped = gs_flip(cur.state);
-                const bool few = g_ne(orec) <= 4 && !gs_empty(flipped);
-                const GCounts cn = few ? g_counts(orec, flipped.flo, flipped.fhi) : GCounts{0, 0};
-                for (uint32_t e = 0; e < g_ne(orec); ++e) {
-                    const int32_t x = ge_to(orec, e); if (x < 0) continue;
-                    const GState ns = gs_flip(few ? gs_extend_counted(orec, flipped, e, cn) : gs_extend(h, flipped, x));   // bdExtendBackward
-                    if (gs_empty(ns)) continue;
-                    const int32_t w = ns.bn ^ 1;
-                    if (np >= ST::ENTRIES) { status = ST::FULL; break; }
-                    const uint32_t wl = ge_len(orec, e);                                                  // w is the other strand of x: same length,
-                    const char* t = h.seq + ((x & 1) ? ge_seq(orec, e) - h.strand_shift : ge_seq(orec, e) + h.strand_shift);   // bases one strand_shift away
-                    GEntry nx = cur; nx.parent = (int32_t)ci; nx.node = w; nx.front = 1; nx.state = ns; nx.offset = wl; nx.brec = ge_rec(orec, e);   // match_backward (:268-296)
-                    const uint32_t back = g_match_bwd(c.seq + nx.r0, t + nx.offset, nx.r0 < nx.offset ? nx.r0 : nx.offset, nx.internal, limit);
-                    nx.r0 -= back; nx.offset -= back;
-                    if (nx.offset >= wl) continue;
-                    if (nx.r0 == 0) nx.left_full = nx.left_max = 1;
-                    else if (nx.offset > 0) nx.left_max = 1;
-                    g_set_score(c, nx); nx.number = number++;
-                    Q.link_set(np, nx);
-                    if (!g_offer(Q, hn, have_cand, cand, cand_idx, nx, np)) { status = ST::FULL; break; }
-                    ++np;
-                    found = true;
-                }
-                if (status != VGK_OK) break;
-                if (found) continue;
-                cur.left_max = 1;
-            }
-            if (best < 0 || best_e.score < cur.score) { best = (int32_t)ci; best_e = cur; }
-        }
-        if (status != VGK_OK) break;
-        if (best >= 0 && best_e.r1 > best_e.r0) {
-            const GEntry& b = best_e;
-            GExt& r = RES[n_res];
-            const int plen = g_path(Q, best, r.path);
-            if (plen < 0) { status = VGK_ETOOBIG; break; }
-            r.path_len = (uint32_t)plen; r.offset = b.offset; r.r0 = b.r0; r.r1 = b.r1; r.internal = b.internal; r.score = b.score; r.state = b.state;
-            r.left_full = b.left_full; r.right_full = b.right_full; r.n_mism = 0;
-            if (gx_full(r) && (best_alignment >= n_res || r.internal < RES[best_alignment].internal)) best_alignment = n_res;
-            ++n_res;
-        }
-    }
-    if (status != VGK_OK) { out.status = status; if (status == G_RETRY) g_bump(P.counters + 3, 1); return; }
-    uint8_t* order = S.order;            // (a private array of this size makes the compiler spill hundreds of registers)
+    const uint32_t max_mm = pb.max_mm;
     for (uint32_t i = 0; i < n_res; ++i) order[i] = (uint8_t)i;
     bool overflow = false;
     uint32_t n_out = n_res;
@@ -694,13 +903,129 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, ST& Q, GScra
         x.state[3] = (uint32_t)e.state.bn; x.state[4] = (uint32_t)e.state.blo; x.state[5] = (uint32_t)e.state.bhi;
         P.ext[e0 + i] = x;
         for (uint32_t k = 0; k < e.path_len; ++k) P.nodes[n0 + na + k] = (uint32_t)e.path[k];
-        if (e.n_mism) {                           // written straight to the output
-            GExt& me = RES[order[i]]; const uint32_t expect = me.n_mism; bool ov = false;
-            gx_find_mismatches(c, me, P.mism + m0 + ma, ov);
-            (void)expect;
-        }
+        if (e.n_mism) { GExt& me = RES[order[i]]; bool ov = false; gx_find_mismatches(c, me, P.mism + m0 + ma, ov); }      // written straight to the output
         na += e.path_len; ma += e.n_mism;
     }
+}
+
+// one read, the nested form: every seed's search in turn (skipping seeds the best exact full-length extension so far contains), then
+// the rules.  ST = where a seed's search lives (GStoreSlab / GStoreLds); the winners and the permutation sit in the thread's slab.
+template <class ST>
+VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, ST& Q, GScratch& S, GCold& C) {
+    const GRes RES{S.res, C.res};
+    const GProb pb = P.probs[pi];
+    const GIndex& h = P.index;
+    vgk_gapless_result& out = P.results[pi];
+    out.status = VGK_OK; out.ext_begin = 0; out.n_ext = 0; out.full_length = 0;
+    if (!pb.read_len || !pb.n_seeds) return;
+    if (pb.n_seeds > (uint32_t)G_SEEDS) { out.status = VGK_ETOOBIG; return; }
+    if (ST::FULL == G_RETRY && (pb.read_len > 255u || P.index.max_node_len > 255u || P.index.max_visits > 254u)) { out.status = G_RETRY; g_bump(P.counters + 3, 1); return; }   // beyond the compact entries
+    GCtx c; c.P = &P; c.seq = P.reads + pb.read_off; c.L = pb.read_len;
+    uint32_t n_res = 0, best_alignment = 0xffffffffu;
+    int status = VGK_OK;
+    for (uint32_t si = 0; si < pb.n_seeds && status == VGK_OK; ++si) {
+        const vgk_seed sd = P.seeds[pb.seed_off + si];
+        if (sd.node >= h.n_oriented) { status = VGK_EINVAL; break; }
+        if (best_alignment < n_res && RES[best_alignment].internal == 0 && gx_contains(h, RES[best_alignment], (int32_t)sd.node, sd.diff)) continue;
+        GSearch s; s.prof = nullptr;
+        const int b = g_search_begin(P, c, pb, si, Q, s);
+        if (b != VGK_OK) { status = VGK_EINVAL; break; }
+        while (status == VGK_OK && g_search_live(s)) status = g_search_step(P, c, Q, s);
+        if (status != VGK_OK) break;
+        GExt& r = RES[n_res];
+        if ((status = g_search_end(Q, s, r)) != VGK_OK) break;
+        if (r.pad[0]) {
+            if (gx_full(r) && (best_alignment >= n_res || r.internal < RES[best_alignment].internal)) best_alignment = n_res;
+            ++n_res;
+        }
+    }
+    if (status != VGK_OK) { out.status = status; if (status == G_RETRY) g_bump(P.counters + 3, 1); return; }
+    gapless_set_rules(P, pi, pb, c, RES, n_res, best_alignment, S.order);
+}
+
+// ---- the flat form ----------------------------------------------------------------------------------------------------------------------
+// One loop per lane: "no search in hand -> take the next seed of my read (or the next read of the batch) and begin; else one step".
+// Measured on the bench's reads, the nested form keeps a quarter of a wavefront's lanes busy: searches take 5..60 steps and reads
+// have 1..6 of them, and every lane waits for the slowest of its 64 at the end of every search and of every read.  Here a lane
+// never waits for another's search.  The branch that begins a search is run for the whole wavefront only when `G_FLAT_MIN_IDLE`
+// lanes want it (or nobody is stepping), so its cost is shared.  The winners go to HBM (P.winners, the read's seed_off + k for its
+// k-th winner) and the rules over them run in a second kernel (gapless_rules_one), one read per lane: they are short and alike.
+// Between the two, vgk_gapless_result carries the read's state: status, n_ext = winners, ext_begin = best_alignment.
+constexpr uint32_t G_FLAT_MIN_IDLE = 12;
+struct GWinArr { GExt* base; VGK_HD GExt& operator[](uint32_t i) const { return base[i]; } };
+// W: next_read(P) -> position in P.order or 0xffffffff; vote(idle, searching) -> 0 = every lane is done, 1 = idle lanes act now, 2 = only step
+template <class ST, class W>
+VGK_HD void gapless_search_lane(const GaplessParams& P, ST& Q, GScratch& S, W& wave) {
+    const GIndex& h = P.index;
+    constexpr uint32_t NONE = 0xffffffffu;
+    uint32_t pi = NONE, si = 0, n_res = 0, best_alignment = NONE; int status = VGK_OK;
+    GProb pb; pb.n_seeds = 0; pb.read_len = 0; pb.seed_off = 0; pb.read_off = 0; pb.max_mm = 0; pb.flags = 0; pb.overlap = 0;
+    GCtx c; c.P = &P; c.seq = P.reads; c.L = 0;
+    GSearch s; s.hn = 0; s.have_cand = false; s.prof = wave.prof();
+    bool searching = false, done = false;
+    for (;;) {
+        const bool idle = !searching && !done;
+        const int v = wave.vote(idle, searching);
+        if (v == 0) break;
+        G_TICK(s.prof, 0);
+        if (v == 1 && idle) {
+            for (;;) {
+                if (pi == NONE || status != VGK_OK || si >= pb.n_seeds) {
+                    if (pi != NONE) {                                                        // this read's searches are over
+                        vgk_gapless_result& out = P.results[pi];
+                        out.status = status; out.n_ext = n_res; out.ext_begin = best_alignment; out.full_length = 0;
+                        if (status == G_RETRY) g_bump(P.counters + 3, 1);
+                    }
+                    const uint32_t k = wave.next_read(P);
+                    if (k == NONE) { done = true; pi = NONE; break; }
+                    pi = P.order[k]; pb = P.probs[pi]; si = 0; n_res = 0; best_alignment = NONE; status = VGK_OK;
+                    c.seq = P.reads + pb.read_off; c.L = pb.read_len;
+                    if (!pb.read_len || !pb.n_seeds) si = pb.n_seeds;
+                    else if (pb.n_seeds > (uint32_t)G_SEEDS) status = VGK_ETOOBIG;
+                    else if (ST::FULL == G_RETRY && (pb.read_len > 255u || h.max_node_len > 255u || h.max_visits > 254u)) status = G_RETRY;
+                    continue;
+                }
+                const vgk_seed sd = P.seeds[pb.seed_off + si];
+                if (sd.node >= h.n_oriented) { status = VGK_EINVAL; continue; }
+                if (best_alignment != NONE) {
+                    const GExt& ba = P.winners[pb.seed_off + best_alignment];
+                    if (ba.internal == 0 && gx_contains_diag(ba, S.diag, (int32_t)sd.node, sd.diff)) { ++si; continue; }
+                }
+                if (g_search_begin(P, c, pb, si, Q, s) != VGK_OK) { status = VGK_EINVAL; continue; }
+                ++si; searching = true;
+                break;
+            }
+        }
+        G_TICK(s.prof, 1);
+        if (searching) {
+            status = g_search_step(P, c, Q, s);
+            if (status != VGK_OK) searching = false;
+            else if (!g_search_live(s)) {
+                searching = false;
+                GExt& r = P.winners[pb.seed_off + n_res];
+                status = g_search_end(Q, s, r);
+                if (status == VGK_OK && r.pad[0]) {
+                    if (gx_full(r) && (best_alignment == NONE || r.internal < P.winners[pb.seed_off + best_alignment].internal)) {
+                        best_alignment = n_res;
+                        if (r.internal == 0) gx_diagonals(h, r, S.diag);
+                    }
+                    ++n_res;
+                }
+                G_TICK(s.prof, 6);
+            }
+        }
+    }
+}
+// the rules of one read over the winners its searches left
+VGK_HD void gapless_rules_one(const GaplessParams& P, uint32_t pi, uint8_t* order) {
+    const GProb pb = P.probs[pi];
+    vgk_gapless_result& out = P.results[pi];
+    const uint32_t n_res = out.n_ext, best_alignment = out.ext_begin;
+    out.ext_begin = 0; out.n_ext = 0; out.full_length = 0;
+    if (out.status != VGK_OK || !pb.read_len || !pb.n_seeds) return;           // an error, or a read for the slab kernel (G_RETRY), or nothing to do
+    GCtx c; c.P = &P; c.seq = P.reads + pb.read_off; c.L = pb.read_len;
+    const GWinArr RES{P.winners + pb.seed_off};
+    gapless_set_rules(P, pi, pb, c, RES, n_res, best_alignment, order);
 }
 
 }  // namespace vgk
