@@ -35,7 +35,8 @@ RDEV = "cpu" if os.environ.get("VGAMD_BENCH_ONE_DEVICE") == "1" else "cuda"     
 PMC_BYTES_PER_UNIT = {
     "linear": (2 * 704590 + 13574060) * 1024 / 400000,       # pmc_{fetch,write}_400k.csv: gssw_fill_kernel<19,true>, 400 000 reads per launch (unchanged since r01)
     "banded": (2 * 390611 + 2244073) * 1024 / 100000,         # pmc_*_banded_100k.csv: the banded_fill_kernel classes, 100 000 problems
-    "gapless": (2 * 6135420 + 2654011) * 1024 / 1000000,      # pmc_*_gapless_1M.csv: gapless_fast_kernel + gapless_kernel, 1 000 000 reads (r01: 2 x 16 202 932 + 3 269 559)
+    "gapless": (2 * 11460323 + 2860944) * 1024 / 1000000,     # pmc_*_gapless_1M.csv: gapless_search_kernel + gapless_rules_kernel + gapless_kernel, 1 000 000 reads
+                                                              # (the nested kernel earlier in r02: 2 x 6 135 420 + 2 654 011; r01: 2 x 16 202 932 + 3 269 559)
     "wfa": (2 * 4094544 + 1914811) * 1024 / 500000,           # pmc_*_wfa_500k.csv: wfa_kernel, 500 000 problems
 }
 TRAFFIC_SOURCE = "stored constant from the rocprofv3 PMC passes in profiles/r02 (not measured in this run), scaled by the units of one launch"
@@ -47,7 +48,7 @@ def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
     K times on the inputs that stayed resident in HBM (vgk_gapless_rerun), which is what `value` reports."""
     import numpy as np
     from vg_amd import capi, shard, workloads
-    n = min(args.reads, 1_000_000)
+    n = min(args.reads, int(os.environ.get("VGAMD_GAPLESS_MAX_READS", "1000000")))
     wl = workloads.GaplessWorkload(n, seed=123 + rank)
     index = eng.haplo_index(wl.nodes, wl.threads)          # the haplotype index is resident in HBM from here on
 
@@ -95,10 +96,10 @@ def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "1 Mbp variation graph, 8 random haplotype threads, %d x 150 bp reads per GPU from either strand with 1 %% "
                                    "substitutions, seeds at true positions; GaplessExtender semantics (max 4 mismatches, overlap 0.8, trim)" % n,
-                       "timed_region": "K launches of gapless_kernel on the batch resident in HBM (vgk_gapless_rerun)",
+                       "timed_region": "K launches of the three gapless kernels (search, rules, slab retries) on the batch resident in HBM (vgk_gapless_rerun)",
                        "end_to_end_from_host_buffers_reads_per_s": n / te, "parallelism": "read-sharded x%d" % world,
                        "device": dev_name, "compute_units": cus},
-            "roofline": {"bound": "hbm", "limiter": "memory latency and divergent instruction issue, not bandwidth (DESIGN.md §11): `frac` prices the algorithmic bytes against the HBM peak as the contract asks", "kernel": "gapless_fast_kernel (+ gapless_kernel for reads that outgrow it)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "limiter": "memory latency (a lane owns 128 B of L2: every hop fetches its record, bases and read words from beyond it) and divergent instruction issue, not bandwidth (DESIGN.md §11): `frac` prices the algorithmic bytes against the HBM peak as the contract asks", "kernel": "gapless_search_kernel + gapless_rules_kernel (+ gapless_kernel for reads that outgrow the LDS queue)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["gapless"] * n, "traffic_source": TRAFFIC_SOURCE, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
                          "kernel_only_reads_per_s": n / (k * 1e-3)},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum()),

@@ -103,7 +103,7 @@ public:
         // the fast store first (here a plain local array, stride 1), then the slab store for the reads that outgrew it — as on the device
         const bool slab_only = std::getenv("VGAMD_GAPLESS_SLAB_ONLY") != nullptr;
         std::vector<uint32_t> lds(G_FAST_DW);
-        if (!slab_only && !std::getenv("VGAMD_GAPLESS_NESTED")) {
+        if (!slab_only) {
             // the flat form: a lane takes reads from the counter until there are none (here the lanes run one after another, so lane t takes
             // every (threads)-th share by stopping after its part), then the rules kernel, then the slab kernel for the G_RETRY reads
             struct Wave {
@@ -124,11 +124,7 @@ public:
             }
             return VGK_OK;
         }
-        for (uint32_t t = 0; t < threads; ++t) for (uint32_t k = t; k < P.n; k += threads) {
-            const uint32_t i = P.order[k];
-            if (!slab_only) { GStoreLds Q{lds.data(), 1u, P.scratch[t], 0u}; gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]); }
-            if (slab_only || P.results[i].status == G_RETRY) { GStoreSlab Q{P.scratch[t]}; gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]); }
-        }
+        for (uint32_t t = 0; t < threads; ++t) for (uint32_t k = t; k < P.n; k += threads) { GStoreSlab Q{P.scratch[t]}; gapless_extend_one(P, P.order[k], Q, P.scratch[t], P.cold[t]); }
         return VGK_OK;
     }
     int run_banded(const BandedParams& P, const BandedLaunch* launches, uint32_t n) override {

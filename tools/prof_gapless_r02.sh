@@ -6,10 +6,10 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-gprof}
 mkdir -p $OUT
 B="python $GRAFT_REPO_ROOT/bench.py --workload gapless --reads 1000000 --no-cpu"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o gapless -- $B --steps 3 --warmup 1 > $OUT/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o gapless -- $B --steps 1 --warmup 0 > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o gapless -- $B --steps 1 --warmup 0 > $OUT/write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/sq -o gapless -- $B --steps 1 --warmup 0 > $OUT/sq.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o gapless -- $B --steps 3 --warmup 1 > $OUT/stats.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o gapless -- $B --steps 1 --warmup 0 > $OUT/fetch.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o gapless -- $B --steps 1 --warmup 0 > $OUT/write.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/sq -o gapless -- $B --steps 1 --warmup 0 > $OUT/sq.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 for what in ("fetch", "write", "sq"):

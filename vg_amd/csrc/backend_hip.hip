@@ -218,10 +218,12 @@ __global__ void __launch_bounds__(64) banded_walk_kernel(const BandedParams P) {
     if (i < P.n) banded_walk_one(P, i);
 }
 
-// ---- gapless extension (gapless_device.hpp): resident threads stride over the reads, one scratch slab per thread
-// Two passes.  The fast kernel keeps the queue of a seed's search in LDS (lane-interleaved dwords: no bank conflicts,
-// no HBM traffic; 35 dwords per thread) and only the write-once path links in the thread's slab; a search whose queue outgrows the LDS slots marks its read
-// G_RETRY and the slab kernel (the whole search in the thread's 11 KB HBM slab, round 1's kernel) runs exactly those reads again.
+// ---- gapless extension (gapless_device.hpp): resident threads, one scratch slab per thread
+// Three kernels.  gapless_search_kernel runs every read's searches as one flat loop per lane, the queue of a search in LDS
+// (lane-interleaved dwords: no bank conflicts, no HBM traffic; 35 dwords per thread) and only the write-once path links in the
+// thread's slab; gapless_rules_kernel applies the set rules to the winners, one read per lane; a search whose queue outgrows the LDS
+// slots marks its read G_RETRY and the slab kernel below (nested loops, the whole search in the thread's 11 KB HBM slab, round 1's
+// kernel) runs exactly those reads again.
 __global__ void __launch_bounds__(64, 4) gapless_kernel(const GaplessParams P, const uint32_t threads, const int retry_only) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t >= threads) return;
@@ -232,14 +234,6 @@ __global__ void __launch_bounds__(64, 4) gapless_kernel(const GaplessParams P, c
         gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]);
     }
 }
-__global__ void __launch_bounds__(64, 4) gapless_fast_kernel(const GaplessParams P, const uint32_t threads) {
-    __shared__ uint32_t lds[64 * G_FAST_DW];
-    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= threads) return;
-    GStoreLds Q{lds + threadIdx.x, 64u, P.scratch[t], 0u};
-    for (uint32_t k = t; k < P.n; k += threads) gapless_extend_one(P, P.order[k], Q, P.scratch[t], P.cold[t]);
-}
-
 // The flat form (gapless_device.hpp, "the flat form"): lanes take reads from a counter and never wait for another lane's search; the
 // rules over the winners run in their own kernel.  Reads whose queue outgrew the LDS slots go to the slab kernel as before.
 struct GWaveDev {
@@ -255,11 +249,11 @@ struct GWaveDev {
         return k < (unsigned long long)P.n ? (uint32_t)k : 0xffffffffu;
     }
 };
-template <int VAR> __global__ void __launch_bounds__(64, 4) gapless_search_kernel(const GaplessParams P, const uint32_t threads) {
+__global__ void __launch_bounds__(64, 4) gapless_search_kernel(const GaplessParams P, const uint32_t threads) {
     __shared__ uint32_t lds[64 * G_FAST_DW];
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t >= threads) return;
-    GStoreLdsT<VAR> Q{lds + threadIdx.x, 64u, P.scratch[t], 0u};
+    GStoreLds Q{lds + threadIdx.x, 64u, P.scratch[t], 0u};
 #if defined(VGAMD_GAPLESS_PROF)
     GProf prof; prof.start();
     GWaveDev wave{&prof, P.flat_min_idle};
@@ -555,18 +549,8 @@ public:
         if (!p.n || !threads) return VGK_OK;
         hipEventRecord(bev[0], stream);
         if (std::getenv("VGAMD_GAPLESS_SLAB_ONLY")) hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads, 0);
-        else if (std::getenv("VGAMD_GAPLESS_NESTED")) {
-            hipLaunchKernelGGL(gapless_fast_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads);
-            hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads, 1);
-        } else {
-            const char* ve = std::getenv("VGAMD_GAPLESS_VARIANT"); const int var = ve ? std::atoi(ve) : VGK_GAPLESS_VARIANT;
-            const dim3 grid((threads + 63) / 64);
-            switch (var & 3) {
-                case 0: hipLaunchKernelGGL(gapless_search_kernel<0>, grid, dim3(64), 0, stream, p, threads); break;
-                case 1: hipLaunchKernelGGL(gapless_search_kernel<1>, grid, dim3(64), 0, stream, p, threads); break;
-                case 2: hipLaunchKernelGGL(gapless_search_kernel<2>, grid, dim3(64), 0, stream, p, threads); break;
-                default: hipLaunchKernelGGL(gapless_search_kernel<3>, grid, dim3(64), 0, stream, p, threads); break;
-            }
+        else {
+            hipLaunchKernelGGL(gapless_search_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads);
             hipLaunchKernelGGL(gapless_rules_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
             hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads, 1);
         }

@@ -98,59 +98,18 @@ VGK_HD GState gs_extend_counted(const uint32_t* rec, const GState& s, uint32_t e
     r.blo = s.blo + rev_off; r.bhi = r.blo + inside - 1;
     return r;
 }
-// The first 64-byte line of a record, fetched with four 16-byte loads issued back to back.  A hop that had to read the header,
-// then (knowing the edge count) the edges and the visit bytes, then the bases, waited three times for memory; nearly every
-// record of a variation graph — one or two edges, a handful of visits or runs — lies in that line entirely, and what does not is
-// still read from memory.  (Records start on 16-word boundaries.)
+// A record's words are read where they are needed; an edge is one 16-byte load.  (Fetching the whole first 64-byte line of the record up
+// front, four 16-byte loads issued together, was measured: 7.8 ms against 7.0 ms for the search kernel — DESIGN.md §11.)
 struct alignas(16) GQuad { uint32_t x, y, z, w; };
 VGK_HD GQuad g_quad(const uint32_t* p) { GQuad q; __builtin_memcpy(&q, __builtin_assume_aligned(p, 16), 16); return q; }
-struct GRecView {
-    const uint32_t* rec; GQuad h, e0, e1, e2;                  // header, then words 4..15: the first three edges — or, behind the last edge, the visit bytes
-    VGK_HD uint32_t ne() const { return h.y & 0xffffu; }
-    VGK_HD bool rle() const { return (h.y >> 31) != 0; }
-    VGK_HD GQuad edge(uint32_t e) const { return e == 0 ? e0 : e == 1 ? e1 : e == 2 ? e2 : g_quad(rec + 4 + 4 * e); }      // {to, base | len << 16, seq, rec}
-    VGK_HD int32_t to(uint32_t e) const { return (int32_t)(e == 0 ? e0.x : e == 1 ? e1.x : e == 2 ? e2.x : rec[4 + 4 * e]); }
-};
-struct GRecMem {                                                   // the same interface over plain loads
+struct GRecMem {
     const uint32_t* rec;
     VGK_HD uint32_t ne() const { return g_ne(rec); }
     VGK_HD bool rle() const { return g_rle(rec); }
-    VGK_HD GQuad edge(uint32_t e) const { GQuad q; q.x = rec[4 + 4 * e]; q.y = rec[5 + 4 * e]; q.z = rec[6 + 4 * e]; q.w = rec[7 + 4 * e]; return q; }
+    VGK_HD GQuad edge(uint32_t e) const { return g_quad(rec + 4 + 4 * e); }                           // one 16-byte load
     VGK_HD int32_t to(uint32_t e) const { return ge_to(rec, e); }
 };
 VGK_HD GCounts g_counts(const GRecMem& v, int32_t lo, int32_t hi) { return g_counts(v.rec, lo, hi); }
-template <bool LINE> struct GViewOf { using type = GRecMem; VGK_HD static GRecMem make(const uint32_t* rec) { return GRecMem{rec}; } };
-VGK_HD GRecView g_view(const uint32_t* rec) { GRecView v; v.rec = rec; v.h = g_quad(rec); v.e0 = g_quad(rec + 4); v.e1 = g_quad(rec + 8); v.e2 = g_quad(rec + 12); return v; }
-VGK_HD GCounts g_counts(const GRecView& v, int32_t lo, int32_t hi) {
-    const uint32_t ne = v.ne();
-    if (ne <= 2 && hi >= 0) {
-        const uint64_t body = ne == 0 ? ((uint64_t)v.e0.y << 32 | v.e0.x) : ne == 1 ? ((uint64_t)v.e1.y << 32 | v.e1.x) : ((uint64_t)v.e2.y << 32 | v.e2.x);
-        if (!v.rle()) {
-            if (hi < 8) {                                               // the visit bytes [0, hi] are in the line
-                GCounts c = { 0, 0 };
-                uint64_t w = body;
-                for (int32_t i = 0; i <= hi; ++i, w >>= 8) { const uint64_t one = 1ull << (16 * (uint32_t)(w & 3u)); if (i < lo) c.before += one; else c.inside += one; }
-                return c;
-            }
-        } else {
-            const uint32_t r0 = (uint32_t)body, r1 = (uint32_t)(body >> 32);
-            const int32_t l0 = (int32_t)(r0 >> 8), l1 = (int32_t)(r1 >> 8);
-            if (hi < l0 + l1) {                                         // ... or the runs that cover them
-                GCounts c = { 0, 0 };
-                int32_t pos = 0;
-                for (int k = 0; k < 2 && pos <= hi; ++k) {
-                    const uint32_t run = k ? r1 : r0; const int32_t end = pos + (k ? l1 : l0);
-                    const int32_t b = (end < lo ? end : lo) - pos, last = end - 1 < hi ? end - 1 : hi, first = pos > lo ? pos : lo;
-                    if (b > 0) c.before += (uint64_t)b << (16 * (run & 3u));
-                    if (last >= first) c.inside += (uint64_t)(last - first + 1) << (16 * (run & 3u));
-                    pos = end;
-                }
-                return c;
-            }
-        }
-    }
-    return g_counts(v.rec, lo, hi);
-}
 template <class V> VGK_HD GState gs_extend_counted(const V& v, const GState& s, uint32_t e, const GQuad& ed, const GCounts& cn) {
     const int32_t to = (int32_t)ed.x;
     GState r = s; r.fn = to;
@@ -163,7 +122,6 @@ template <class V> VGK_HD GState gs_extend_counted(const V& v, const GState& s, 
     r.blo = s.blo + rev_off; r.bhi = r.blo + inside - 1;
     return r;
 }
-template <> struct GViewOf<true> { using type = GRecView; VGK_HD static GRecView make(const uint32_t* rec) { return g_view(rec); } };
 // bdExtendForward: follow the visits of the forward range that leave through `to`
 VGK_HD GState gs_extend(const GIndex& h, const GState& s, int32_t to) {
     const uint32_t o = (uint32_t)s.fn;
@@ -346,7 +304,7 @@ VGK_HD uint32_t g_ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
 VGK_HD uint32_t g_clz64(uint64_t x) { return (uint32_t)__builtin_clzll(x); }
 #endif
 // forward: compare a[0..left) with b[0..left); stops BEFORE the mismatch that would reach `limit`; returns the bases consumed
-template <bool BATCH = false> VGK_HD uint32_t g_match_fwd(const char* a, const char* b, uint32_t left, uint32_t& internal, uint32_t limit) {
+VGK_HD uint32_t g_match_fwd(const char* a, const char* b, uint32_t left, uint32_t& internal, uint32_t limit) {
     uint32_t n = 0;
     while (n < left) {
         const uint64_t wa = g_load8(a + n), wb = g_load8(b + n);
@@ -367,7 +325,7 @@ template <bool BATCH = false> VGK_HD uint32_t g_match_fwd(const char* a, const c
     return n;
 }
 // backward: compare a[-1], a[-2], ... with b[-1], b[-2], ... for up to `left` bases
-template <bool BATCH = false> VGK_HD uint32_t g_match_bwd(const char* a, const char* b, uint32_t left, uint32_t& internal, uint32_t limit) {
+VGK_HD uint32_t g_match_bwd(const char* a, const char* b, uint32_t left, uint32_t& internal, uint32_t limit) {
     uint32_t n = 0;
     while (n < left) {
         const uint64_t wa = g_load8(a - n - 8), wb = g_load8(b - n - 8);
@@ -442,7 +400,7 @@ constexpr uint32_t G_FAST_DW = 2 * G_FAST_QUEUE + 5 * G_FAST_QUEUE;      // dwor
 
 struct GStoreSlab {
     GScratch& s;
-    static constexpr int VARIANT = 0;
+
     static constexpr uint32_t ENTRIES = (uint32_t)G_POOL;
     static constexpr int32_t  FULL = VGK_ETOOBIG;
     VGK_HD void begin_seed() {}
@@ -457,8 +415,7 @@ struct GStoreSlab {
     VGK_HD GLink link_get(uint32_t i) const { return s.link[i]; }
 };
 
-template <int VAR> struct GStoreLdsT {
-    static constexpr int VARIANT = VAR;
+struct GStoreLds {
     uint32_t* base; uint32_t stride;             // dword k of this thread = base[k * stride]
     GScratch& s;                                 // the thread's slab: path links only
     uint32_t free_slots;
@@ -501,14 +458,9 @@ template <int VAR> struct GStoreLdsT {
         e.state.flo = fe ? 0 : (int32_t)flo; e.state.fhi = fe ? -1 : (int32_t)fhi; e.state.blo = be ? 0 : (int32_t)blo; e.state.bhi = be ? -1 : (int32_t)bhi;
         return e;
     }
-    VGK_HD void link_set(uint32_t i, const GEntry& e) { s.link[i] = g_link(e); }
+    VGK_HD void link_set(uint32_t i, const GEntry& e) { s.link[i] = g_link(e); }      // (streaming stores/loads for the links, to spare the caches: measured, no fewer bytes fetched and 6 % slower)
     VGK_HD GLink link_get(uint32_t i) const { return s.link[i]; }
 };
-
-#ifndef VGK_GAPLESS_VARIANT
-#define VGK_GAPLESS_VARIANT 0
-#endif
-using GStoreLds = GStoreLdsT<VGK_GAPLESS_VARIANT>;
 
 template <class ST> VGK_HD bool g_heap_push(ST& S, uint32_t& hn, const GEntry& e, uint32_t entry) {
     uint32_t idx;
@@ -736,7 +688,7 @@ VGK_HD int g_search_begin(const GaplessParams& P, const GCtx& c, const GProb& pb
     m.state.fn = snode; m.state.flo = 0; m.state.fhi = (int32_t)hf.x - 1; m.state.bn = snode ^ 1; m.state.blo = 0; m.state.bhi = (int32_t)hb.x - 1;      // gs_find
     const char* t = h.seq + hf.w;
     const uint32_t left = L - m.r1 < slen - node_offset ? L - m.r1 : slen - node_offset;
-    m.r1 += g_match_fwd<(ST::VARIANT & 2) != 0>(c.seq + m.r1, t + node_offset, left, m.internal, 0xffffffffu);
+    m.r1 += g_match_fwd(c.seq + m.r1, t + node_offset, left, m.internal, 0xffffffffu);
     m.old = m.internal;
     if (m.r0 == 0) m.left_full = m.left_max = 1;
     if (m.r1 >= L) m.right_full = m.right_max = 1;
@@ -773,7 +725,7 @@ VGK_HD int g_search_step(const GaplessParams& P, const GCtx& c, ST& Q, GSearch& 
         const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
         uint32_t ri = right ? cur.frec : cur.brec;
         if (ri == G_NO_REC) { ri = h.rec_off[(uint32_t)(right ? cur.state.fn : cur.state.bn)]; if (right) cur.frec = ri; else cur.brec = ri; }
-        const auto orec = GViewOf<(ST::VARIANT & 1) != 0>::make(h.rec + ri);
+        const GRecMem orec{h.rec + ri};
         const uint32_t ne = orec.ne();
         const GState from = right ? cur.state : gs_flip(cur.state);
         const bool few = ne <= 4 && !gs_empty(from);
