@@ -114,7 +114,7 @@ def bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus):
     re-launches the kernel K times on the inputs that stayed resident in HBM (vgk_wfa_rerun), which is what `value` reports."""
     import numpy as np
     from vg_amd import capi, shard, workloads
-    n = min(args.reads, 500_000)
+    n = min(args.reads, int(os.environ.get("VGAMD_WFA_MAX_PROBLEMS", "500000")))
     wl = workloads.WfaWorkload(n, seed=321 + rank)
     index = eng.haplo_index(wl.nodes, wl.threads)
 
