@@ -252,6 +252,115 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
         dist.destroy_process_group()
 
 
+def bench_forest(args, eng, rank, world, dist, torch, dev_name, cus):
+    """giraffe's tail path behind the gapless extension (secondary line): per tail a GBWT search state + cut ->
+    the tail forest walked on the device (vgk_tail_forest) and left in HBM as a resident graph -> the trees as window problems, packed on
+    the device (vgk_gssw_pack_windows) -> left-pinned X-drop fill + traceback.  One step = all of that for the whole batch, from the
+    host's problem arrays (20 B + the tail's bases per tail) to results resident in HBM."""
+    import numpy as np
+    from vg_amd import capi, shard, workloads
+    n = args.reads if args.reads else 1_000_000
+    OPS_PER = 32
+    t0 = time.perf_counter()
+    wl = workloads.TailForestWorkload(n, seed=99 + rank)
+    t_gen = time.perf_counter() - t0
+    index = eng.haplo_index(wl.nodes, wl.threads)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(keep=False):
+        t = [time.perf_counter()]
+        res, forest = eng.tail_forest(index, wl.problems); t.append(time.perf_counter())
+        fms = eng.tail_last_ms()
+        ws = wl.windows(res); t.append(time.perf_counter())
+        b = eng.pack_windows(forest.graph, ws, OPS_PER); t.append(time.perf_counter())
+        b.run(); b.sync(); t.append(time.perf_counter())
+        out = (res, forest, b, fms, np.diff(t))
+        if not keep:
+            b.free(); forest.close()
+        return out
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    barrier()
+    parts = []; fms = []; fill_ms = []; walk_ms = []
+    t0 = time.perf_counter()
+    last = None
+    for k in range(args.steps):
+        if last is not None:
+            last[2].free(); last[1].close()
+        last = step(keep=True)
+        parts.append(last[4]); fms.append(last[3]); fill_ms.append(last[2].kernel_ms(0)); walk_ms.append(last[2].kernel_ms(1))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res, forest, b, _, _ = last
+    r, ops = b.fetch()
+    n_bad = int((r["status"] != 0).sum() + (res["status"] != 0).sum())
+    tree_nodes = int(res["n_nodes"].sum()); tree_bases = int(res["bases"].sum()); cells = b.cells(); alg_fill = b.alg_bytes()
+    cpu = parity = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
+        cores = shard.usable_cpus(); ora.lib.vgo_set_threads(cores)
+        k = min(n, args.cpu_sample or 50_000)
+        oidx = ora.haplo_index(wl.nodes, wl.threads)
+        t1 = time.perf_counter()
+        ores, oforest = ora.tail_forest(oidx, wl.problems[:k]); t_walk = time.perf_counter() - t1
+        ows = wl.windows(ores, 0, k)
+        with ora.pack_windows(oforest.graph, ows, OPS_PER) as ob:
+            t1 = time.perf_counter(); ob.run(); t_align = time.perf_counter() - t1
+            orr, oops = ob.fetch()
+        same = np.ones(k, dtype=bool)
+        for f in ("status", "first_node", "n_nodes", "n_trees", "root_trim", "bases"):
+            same &= res[f][:k] == ores[f]
+        pa, na, la = forest.fetch(); pb, nb, lb = oforest.fetch()
+        m = int(ores["n_nodes"].sum())
+        forest_same = bool((pa[:m] == pb).all() and (na[:m] == nb).all() and (la[:m] == lb).all())
+        for f in ("score", "status", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
+            same &= r[f][:k] == orr[f]
+        tot = int(orr["n_ops"].sum())
+        ops_same = bool((ops[:tot].view(np.uint64) == oops[:tot].view(np.uint64)).all()) if same.all() else False
+        cpu = {"value": k / (t_walk + t_align), "unit": "tails/s", "cores": cores, "kind": "port",
+               "impl": "oracle/vgo_tail.c (dfs_gbwt restated, one thread) + oracle/vgo_xdrop.c (scalar int32 checker, OpenMP over problems)",
+               "sample": "the first %d tails: forests %.2f s on one core, alignments %.2f s on %d" % (k, t_walk, t_align, cores)}
+        parity = {"checked": k, "identical": int(same.sum()) if (forest_same and ops_same) else int(same.sum()) - 1, "forests_identical": forest_same, "ops_identical": ops_same}
+    if rank == 0:
+        parts = np.array(parts).mean(axis=0) * 1e3
+        # algorithmic bytes of the forest stage: the problem in, per tree node its record's header + edges read once (48 B), (parent, node, length, cut)
+        # written and read once (32 B), its bases read and their column-info bytes written (2 B per base), the graph tables (16 B), the result out
+        alg_forest = 20 * n + 24 * n + tree_nodes * (48 + 32 + 16) + 2 * tree_bases
+        fm = float(np.mean(fms))
+        achieved = alg_forest / (fm * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "read tails/sec: tail forest (GBWT walk) + left-pinned X-drop alignment against it", "value": n * world * args.steps / elapsed,
+            "unit": "tails/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "1 Mbp variation graph, 8 random haplotype threads; %d tails per GPU (1-121 bp, 1 %% substitutions) starting inside a node of a thread on either "
+                                   "strand with the state of all the node's visits; walk distance = tail + longest detectable gap of a 150 bp read; get_tail_forest + "
+                                   "align_pinned(xdrop) semantics, scores 1/4/6/1/5" % n,
+                       "timed_region": "per step: vgk_tail_forest (problems up, two walks + graph tables on the device, results down), WindowSet on the host, "
+                                       "vgk_gssw_pack_windows, fill + traceback kernels; results stay in HBM",
+                       "tree_nodes_per_tail": tree_nodes / n, "tree_bases_per_tail": tree_bases / n, "parallelism": "tail-sharded x%d" % world, "device": dev_name, "compute_units": cus,
+                       "generation_seconds": t_gen},
+            "stage_ms": {"tail_forest_call": float(parts[0]), "tail_forest_device": fm, "window_set_host": float(parts[1]), "pack_windows": float(parts[2]),
+                         "fill_and_traceback": float(parts[3]), "fill_kernel": float(np.mean(fill_ms)), "traceback_kernel": float(np.mean(walk_ms))},
+            "roofline": {"bound": "hbm", "kernel": "tail_walk_kernel x 2 + forest_flags_kernel + forest_emit_kernel + 4 rocPRIM scans (the forest stage)",
+                         "limiter": "memory latency: one lane per tail chases records through a 20 KB stack slab (DESIGN.md §17)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": alg_forest, "avg_launch_ms": fm, "fill_alg_bytes": alg_fill, "gcups_fill": cells / (float(np.mean(fill_ms)) * 1e-3) / 1e9},
+            "cpu_baseline": cpu, "parity": parity, "problems_failed": n_bad}))
+    b.free(); forest.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def bench_tails(args, eng, rank, world, dist, torch, dev_name, cus):
     """configs[2] at its stated size (secondary line): a chr22-scale SNP + indel graph (50.8 Mbp, ~1.7 M nodes) resident in HBM on both
     strands, 10 M reads with BOTH tails (1-121 bp) aligned left-pinned X-drop (right tails against the reverse-complement strand, as
@@ -409,7 +518,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--host-pack", action="store_true", help="linear workload: one explicit graph per problem, packed on host threads (vgk_gssw_pack) instead of windows of the resident graph packed on the device")
     ap.add_argument("--no-e2e", action="store_true", help="skip the legs that overlap launches — the two-lane steady state and the warm / double-buffered end-to-end legs — so that a profiler's per-kernel averages are each kernel's own")
-    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband"], default="linear",
+    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband", "forest"], default="linear",
                     help="linear = BASELINE.json configs[1] (the headline metric); tails = configs[2] stand-in: "
                          "giraffe-style pinned X-drop tail alignments on a variation graph; banded = configs[4] stand-in: "
                          "banded global alignments between chained anchors; gapless = giraffe's first stage: "
@@ -449,6 +558,8 @@ def main():
     eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), device=local_rank, lib=eng_lib)
     dev_name, cus, hbm = eng.device_info()
 
+    if args.workload == "forest":
+        return bench_forest(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "xband":
         return bench_xdrop_band(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "tails" and not args.tails_per_problem_graphs:

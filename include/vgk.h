@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define VGK_ABI_VERSION 2
+#define VGK_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -203,6 +203,47 @@ typedef struct vgk_window_problem {
  * out-of-range problem (in index order) decides the return code, as a serial scan would. */
 int  vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* graph, const char* reads, size_t reads_bytes,
                            const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out);
+/* ---- tail forests: the subgraphs giraffe aligns read tails to (MinimizerMapper::get_tail_forest, src/minimizer_mapper.cpp:5745-5860;
+ * dfs_gbwt :5909-6013) ---------------------------------------------------------------------------------------------------------------
+ * For an extension that does not reach an end of the read, giraffe walks the haplotypes that continue it — a depth-first search over
+ * the GBWT from the extension's search state, out to (longest detectable gap + tail length) bases — and collects the nodes it enters
+ * as a tree of (parent, handle) pairs: the haplotype-consistent subgraph the tail is then aligned to, pinned at the root
+ * (get_best_alignment_against_any_tree :5626-5741 -> align_pinned on a TreeSubgraph).  When the cut lies at the very end of the start
+ * node the root is not entered and every child of it starts a tree of its own (a forest).
+ * vgk_tail_forest does that walk on the device, over the haplotype index of vgk_haplo_create, for a batch of tails; the trees stay in
+ * HBM and are turned THERE into one resident graph (vgk_forest_graph) in which every tree is a run of consecutive nodes in entry
+ * order — which is a topological order, and the order TreeSubgraph numbers its nodes in — so that the alignments are window problems
+ * of that graph (vgk_gssw_pack_windows, VGK_XDROP_PINNED): first_node = the tree's first node, n_nodes = its size.  The root of a tree
+ * carries only the bases behind the cut.  Children are entered in the order the reference's stack pops them: the node's outgoing
+ * edges from the last to the first.
+ * Per problem: VGK_EINVAL for a node or cut outside the index, VGK_ETOOBIG when the walk's stack outgrows the kernel's (512 frames).
+ * [PARITY-UNPINNED: the reference holds no test vectors for get_tail_forest; pinned here by an independent construction from the
+ * thread lists in tests/test_tail_forest.py.] */
+typedef struct vgk_tail_problem {
+    uint32_t node;            /* the search state the walk starts from: oriented node ...                                          */
+    int32_t  lo, hi;          /* ... and its range of visits (vgk_extension.state[0..2] for a right tail, [3..5] for a left tail)   */
+    uint32_t offset;          /* the cut on that node: its bases [offset, length) belong to the tail (from.offset(), :5758-5775)     */
+    uint32_t walk_distance;   /* the search limit in bases (:5816)                                                                  */
+} vgk_tail_problem;
+typedef struct vgk_tail_result {
+    int32_t  status;
+    uint32_t first_node;      /* the problem's tree nodes are [first_node, first_node + n_nodes) of the forest                      */
+    uint32_t n_nodes, n_trees;
+    uint32_t root_trim;       /* bases cut off its root(s): `offset`, or 0 when the root was skipped (:5800, :5838)                  */
+    uint32_t bases;           /* bases of its tree nodes together (the caller's max_dozeu_cells test, :5693)                        */
+} vgk_tail_result;
+typedef struct vgk_forest vgk_forest;
+typedef struct vgk_haplo vgk_haplo;   /* the haplotype index (vgk_haplo_create, below) */
+int      vgk_tail_forest(vgk_ctx* ctx, const vgk_haplo* index, const vgk_tail_problem* problems, uint32_t n,
+                         vgk_tail_result* results, vgk_forest** out);
+uint64_t vgk_forest_size(const vgk_forest* forest);                      /* tree nodes over all problems */
+/* per tree node (each array nullable): its parent (index in the forest, -1 = the root of a tree), the oriented node of the index
+ * it stands for (TreeSubgraph::translate_down), its length in the forest graph (the root's: what is left behind the cut) */
+int      vgk_forest_fetch(const vgk_forest* forest, int32_t* parent, uint32_t* node, uint32_t* length);
+const vgk_dgraph* vgk_forest_graph(const vgk_forest* forest);            /* owned by the forest */
+void     vgk_forest_destroy(vgk_forest* forest);
+double   vgk_tail_last_ms(vgk_ctx* ctx);                                 /* device time of the last vgk_tail_forest call: walks + graph construction */
+
 /* ---- X-drop with dozeu's band (src/dozeu_interface.cpp:226, :261-283; src/xdrop_aligner.cpp:95-109) ------------------------------
  * VGK_XDROP_PINNED through vgk_gssw_* keeps every cell: it returns the exact semi-global optimum, which is dozeu's answer whenever
  * dozeu's band contains the optimal path.  This entry point restates the band itself [PARITY-UNPINNED: dozeu's source is not in the

@@ -437,3 +437,57 @@ uint64_t vgk_batch_alg_bytes(vgk_batch* b) { (void)b; return 0; }
 uint64_t vgk_batch_device_bytes(vgk_batch* b) { (void)b; return 0; }
 uint64_t vgk_batch_wave_steps(vgk_batch* b) { (void)b; return 0; }
 int vgk_batch_lane(vgk_batch* b) { (void)b; return 0; }
+
+/* ---- tail forests (vgo_tail.c) behind the engine's entry points: the walks, then the forest as one graph through the oracle's
+ * own vgk_graph_create (node lengths, the bases behind the cuts copied out of the index, one predecessor per non-root node) ---- */
+int vgo_tail_forest(const vgk_haplo* h, const vgk_tail_problem* pb, vgk_tail_result* out, int32_t** parent, uint32_t** node, uint32_t** len, size_t* n, size_t* cap);
+void vgo_tail_copy_bases(const vgk_haplo* h, uint32_t node, uint32_t trim, uint32_t len, char* dst);
+struct vgk_forest { size_t n; int32_t* parent; uint32_t* node; uint32_t* len; vgk_dgraph* graph; };
+void vgk_forest_destroy(vgk_forest* f) { if (f) { free(f->parent); free(f->node); free(f->len); vgk_graph_destroy(f->graph); free(f); } }
+int vgk_tail_forest(vgk_ctx* ctx, const vgk_haplo* index, const vgk_tail_problem* problems, uint32_t n, vgk_tail_result* results, vgk_forest** out) {
+    if (!ctx || !index || !out || (n && (!problems || !results))) return VGK_EINVAL;
+    *out = NULL;
+    vgk_forest* f = (vgk_forest*)calloc(1, sizeof *f);
+    if (!f) return VGK_ENOMEM;
+    size_t cap = 0;
+    uint32_t* trim = NULL; size_t trim_cap = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const size_t before = f->n;
+        const int rc = vgo_tail_forest(index, &problems[i], &results[i], &f->parent, &f->node, &f->len, &f->n, &cap);
+        if (rc) { free(trim); vgk_forest_destroy(f); return rc; }
+        if (f->n > trim_cap) { trim_cap = 2 * f->n + 64; uint32_t* q = (uint32_t*)realloc(trim, sizeof(uint32_t) * trim_cap); if (!q) { free(trim); vgk_forest_destroy(f); return VGK_ENOMEM; } trim = q; }
+        for (size_t v = before; v < f->n; ++v) trim[v] = 0;
+        /* the root of the walk (if it was entered: it is the problem's first tree node and no other root exists then) carries the cut */
+        if (f->n > before && results[i].root_trim) trim[before] = results[i].root_trim;
+    }
+    if (f->n) {
+        size_t bases = 0, ne = 0;
+        for (size_t v = 0; v < f->n; ++v) { bases += f->len[v]; ne += f->parent[v] >= 0; }
+        char* seq = (char*)malloc(bases + 1); uint32_t* po = (uint32_t*)malloc(sizeof(uint32_t) * (f->n + 1)); uint32_t* pi = (uint32_t*)malloc(sizeof(uint32_t) * (ne + 1));
+        if (!seq || !po || !pi) { free(seq); free(po); free(pi); free(trim); vgk_forest_destroy(f); return VGK_ENOMEM; }
+        size_t at = 0, e = 0;
+        for (size_t v = 0; v < f->n; ++v) {
+            vgo_tail_copy_bases(index, f->node[v], trim[v], f->len[v], seq + at); at += f->len[v];
+            po[v] = (uint32_t)e;
+            if (f->parent[v] >= 0) pi[e++] = (uint32_t)f->parent[v];
+        }
+        po[f->n] = (uint32_t)e;
+        vgk_graph g; g.n_nodes = (uint32_t)f->n; g.node_len = f->len; g.seq = seq; g.pred_off = po; g.pred_idx = pi;
+        const int rc = vgk_graph_create(ctx, &g, &f->graph);
+        free(seq); free(po); free(pi);
+        if (rc) { free(trim); vgk_forest_destroy(f); return rc; }
+    }
+    free(trim);
+    *out = f;
+    return VGK_OK;
+}
+uint64_t vgk_forest_size(const vgk_forest* f) { return f ? f->n : 0; }
+int vgk_forest_fetch(const vgk_forest* f, int32_t* parent, uint32_t* node, uint32_t* length) {
+    if (!f) return VGK_EINVAL;
+    if (parent) memcpy(parent, f->parent, sizeof(int32_t) * f->n);
+    if (node) memcpy(node, f->node, sizeof(uint32_t) * f->n);
+    if (length) memcpy(length, f->len, sizeof(uint32_t) * f->n);
+    return VGK_OK;
+}
+const vgk_dgraph* vgk_forest_graph(const vgk_forest* f) { return f ? f->graph : NULL; }
+double vgk_tail_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }

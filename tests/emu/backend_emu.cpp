@@ -95,6 +95,14 @@ public:
         matrix_wave_emu<2>(P, 0, 128); matrix_wave_emu<4>(P, 128, 256); matrix_wave_emu<8>(P, 256, 512); matrix_wave_emu<16>(P, 512, 1024);
         return VGK_OK;
     }
+    int run_tail(const TailParams& P, uint32_t threads) override {
+        for (uint32_t t = 0; t < threads; ++t) for (uint32_t i = t; i < P.n; i += threads) tail_walk_one(P, i, P.scratch[t]);
+        return VGK_OK;
+    }
+    int scan_u32(const uint32_t* in, uint32_t* out, uint32_t n) override { uint32_t s = 0; for (uint32_t k = 0; k < n; ++k) { const uint32_t v = in[k]; out[k] = s; s += v; } return VGK_OK; }
+    int forest_flags(const ForestParams& P) override { for (uint32_t v = 0; v < P.n_nodes; ++v) forest_flags_one(P, v); return VGK_OK; }
+    int forest_emit(const ForestParams& P) override { for (uint32_t v = 0; v < P.n_nodes; ++v) forest_emit_one(P, v); return VGK_OK; }
+    int fill(void* d, int byte, size_t n) override { std::memset(d, byte, n); return VGK_OK; }
     int run_wfa(const WfaParams& P, uint32_t threads) override {
         for (uint32_t t = 0; t < threads; ++t) wfa_thread(P, t, nullptr, 1);
         return VGK_OK;

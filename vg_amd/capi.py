@@ -368,6 +368,20 @@ class Engine:
                     "vgk_gapless_extend")
         return res, ext[:written[0]], nodes[:written[1]], mism[:written[2]]
 
+    def tail_forest(self, index, problems):
+        """vgk_tail_forest: problems = numpy array of TAIL_DT (search state node / lo / hi, cut offset, walk distance) or a list of
+        such tuples.  -> (results as TAIL_RESULT_DT, Forest)"""
+        pr = np.ascontiguousarray(problems, dtype=TAIL_DT) if isinstance(problems, np.ndarray) else np.array([tuple(p) for p in problems], dtype=TAIL_DT)
+        res = np.zeros(max(len(pr), 1), dtype=TAIL_RESULT_DT)
+        h = ctypes.c_void_p()
+        self.lib.vgk_tail_forest.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        self._check(self.lib.vgk_tail_forest(self.h, index.h, pr.ctypes.data, len(pr), res.ctypes.data, ctypes.byref(h)), "vgk_tail_forest")
+        return res[:len(pr)], Forest(self, h)
+
+    def tail_last_ms(self):
+        self.lib.vgk_tail_last_ms.restype = ctypes.c_double; self.lib.vgk_tail_last_ms.argtypes = [ctypes.c_void_p]
+        return self.lib.vgk_tail_last_ms(self.h)
+
     def gapless_last_ms(self):
         return self.lib.vgk_gapless_last_ms(self.h)
 
@@ -399,6 +413,45 @@ class Engine:
 
     def wfa_last_ms(self):
         return self.lib.vgk_wfa_last_ms(self.h)
+
+
+TAIL_DT = np.dtype([("node", "<u4"), ("lo", "<i4"), ("hi", "<i4"), ("offset", "<u4"), ("walk_distance", "<u4")])
+TAIL_RESULT_DT = np.dtype([("status", "<i4"), ("first_node", "<u4"), ("n_nodes", "<u4"), ("n_trees", "<u4"), ("root_trim", "<u4"), ("bases", "<u4")])
+
+
+class Forest:
+    """vgk_forest: the tail forests of a batch of tails, resident in HBM; `.graph` is the forest as one ResidentGraph-like handle
+    whose windows are the trees (usable with Engine.pack_windows / align_windows)."""
+
+    class _Graph:
+        def __init__(self, h):
+            self.h = h
+
+    def __init__(self, eng, h):
+        self.eng = eng; self.h = h
+        lib = eng.lib
+        lib.vgk_forest_size.restype = ctypes.c_uint64; lib.vgk_forest_size.argtypes = [ctypes.c_void_p]
+        lib.vgk_forest_graph.restype = ctypes.c_void_p; lib.vgk_forest_graph.argtypes = [ctypes.c_void_p]
+        lib.vgk_forest_fetch.argtypes = [ctypes.c_void_p] * 4
+        lib.vgk_forest_destroy.argtypes = [ctypes.c_void_p]; lib.vgk_forest_destroy.restype = None
+        self.size = int(lib.vgk_forest_size(h))
+        g = lib.vgk_forest_graph(h)
+        self.graph = Forest._Graph(ctypes.c_void_p(g)) if g else None
+        eng._indexes.add(self)
+
+    def fetch(self):
+        """-> (parent, node, length) per tree node: parent = index in the forest or -1, node = oriented node of the index"""
+        parent = np.zeros(max(self.size, 1), dtype=np.int32); node = np.zeros(max(self.size, 1), dtype=np.uint32); length = np.zeros(max(self.size, 1), dtype=np.uint32)
+        self.eng._check(self.eng.lib.vgk_forest_fetch(self.h, parent.ctypes.data, node.ctypes.data, length.ctypes.data), "vgk_forest_fetch")
+        return parent[:self.size], node[:self.size], length[:self.size]
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.eng, "h", None):
+                self.eng.lib.vgk_forest_destroy(self.h)
+            self.h = None; self.graph = None
+
+    __del__ = close
 
 
 class ResidentGraph:

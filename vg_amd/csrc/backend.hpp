@@ -12,6 +12,7 @@
 #include "wfa_device.hpp"
 #include "gssw_matrix_device.hpp"
 #include "gssw_pack_device.hpp"
+#include "tail_device.hpp"
 
 namespace vgk {
 
@@ -96,6 +97,17 @@ public:
     // X-drop with dozeu's band (vgk_xdrop_band_align): one wavefront per problem, the matrices stay for the host's traceback;
     // last_ms(7) = kernel ms
     virtual int   run_xdrop_band(const GsswMatrixParams& p) = 0;
+    // tail forests (tail_device.hpp), everything asynchronous on the main stream: one pass of the walks (p.pass; `threads` resident
+    // lanes, one TScratch each, take the problems in turn); exclusive prefix sums of n 32-bit values (out[k] = in[0] + ... + in[k-1]);
+    // the two per-node stages that turn the forest into the packer's tables; a byte fill; a stopwatch around all of it
+    // (watch(0) ... watch(1), watch_ms() after a sync)
+    virtual int   run_tail(const TailParams& p, uint32_t threads) = 0;
+    virtual int   scan_u32(const uint32_t* in, uint32_t* out, uint32_t n) = 0;
+    virtual int   forest_flags(const ForestParams& p) = 0;
+    virtual int   forest_emit(const ForestParams& p) = 0;
+    virtual int   fill(void* dst, int byte, size_t bytes) = 0;
+    virtual void  watch(int which) { (void)which; }
+    virtual double watch_ms() { return 0.0; }
 };
 
 // returns nullptr and sets err when the device cannot be used

@@ -271,6 +271,21 @@ __global__ void __launch_bounds__(64, 6) gapless_rules_kernel(const GaplessParam
     gapless_rules_one(P, P.order[k], order + threadIdx.x * G_SEEDS);
 }
 
+// ---- tail forests (tail_device.hpp): resident lanes take the tails in turn for the walks; one lane per tree node for the graph tables
+__global__ void __launch_bounds__(64) tail_walk_kernel(const TailParams P, const uint32_t threads) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= threads) return;
+    for (uint32_t i = t; i < P.n; i += threads) tail_walk_one(P, i, P.scratch[t]);
+}
+__global__ void __launch_bounds__(256) forest_flags_kernel(const ForestParams P) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v < P.n_nodes) forest_flags_one(P, v);
+}
+__global__ void __launch_bounds__(256) forest_emit_kernel(const ForestParams P) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v < P.n_nodes) forest_emit_one(P, v);
+}
+
 // ---- wavefront alignment (wfa_device.hpp): the same launch shape
 __global__ void __launch_bounds__(64, 4) wfa_kernel(const WfaParams P, const uint32_t threads) {
     __shared__ uint32_t node_end[W_NODES * 64];                    // [trie node][lane]: conflict-free, 8 KB per wavefront
@@ -309,10 +324,12 @@ public:
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
     float ms_gapless = 0.f, ms_wfa = 0.f, ms_xband = 0.f;
     float ms_bfill = 0.f, ms_bwalk = 0.f; hipEvent_t bev[3] = {nullptr, nullptr, nullptr};
+    void* scan_tmp = nullptr; size_t scan_tmp_bytes = 0;      // rocPRIM's scratch for scan_u32 (grow-only)
     ~HipBackend() override {
         hipSetDevice(dev);
         for (auto& e : ev) if (e) hipEventDestroy(e);
         for (auto& e : bev) if (e) hipEventDestroy(e);
+        if (scan_tmp) hipFree(scan_tmp);
         for (int i = 0; i < 2; ++i) { if (side[i]) hipStreamDestroy(side[i]); if (side_done[i]) hipEventDestroy(side_done[i]); }
         if (stream) hipStreamDestroy(stream);
         if (copy) hipStreamDestroy(copy);
@@ -583,6 +600,41 @@ public:
         hipEventElapsedTime(&ms_xband, bev[0], bev[1]);
         return VGK_OK;
     }
+    int run_tail(const TailParams& p, uint32_t threads) override {
+        hipSetDevice(dev);
+        if (!p.n || !threads) return VGK_OK;
+        hipLaunchKernelGGL(tail_walk_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int scan_u32(const uint32_t* in, uint32_t* out, uint32_t n) override {
+        hipSetDevice(dev);
+        if (!n) return VGK_OK;
+        const size_t need = hip_scan_tmp_bytes(n);
+        if (need > scan_tmp_bytes) {
+            if (scan_tmp) { hipStreamSynchronize(stream); hipFree(scan_tmp); scan_tmp = nullptr; scan_tmp_bytes = 0; }
+            if (hipMalloc(&scan_tmp, need + need / 4) != hipSuccess) return VGK_ENOMEM;
+            scan_tmp_bytes = need + need / 4;
+        }
+        return hip_scan_u32(in, out, n, scan_tmp, scan_tmp_bytes, stream);
+    }
+    int forest_flags(const ForestParams& p) override {
+        hipSetDevice(dev);
+        if (!p.n_nodes) return VGK_OK;
+        hipLaunchKernelGGL(forest_flags_kernel, dim3((p.n_nodes + 255) / 256), dim3(256), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int forest_emit(const ForestParams& p) override {
+        hipSetDevice(dev);
+        if (!p.n_nodes) return VGK_OK;
+        hipLaunchKernelGGL(forest_emit_kernel, dim3((p.n_nodes + 255) / 256), dim3(256), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int fill(void* dst, int byte, size_t bytes) override {
+        hipSetDevice(dev);
+        return hipMemsetAsync(dst, byte, bytes, stream) == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    void watch(int which) override { hipSetDevice(dev); hipEventRecord(bev[which ? 1 : 0], stream); }
+    double watch_ms() override { float ms = 0.f; hipEventElapsedTime(&ms, bev[0], bev[1]); return ms; }
     int run_wfa(const WfaParams& p, uint32_t threads) override {
         hipSetDevice(dev);
         ms_wfa = 0.f;

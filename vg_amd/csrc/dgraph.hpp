@@ -1,0 +1,12 @@
+// dgraph.hpp — the resident graph handle shared by window_api.cpp (which builds it from a caller's arrays) and tail_api.cpp (which
+// builds it on the device from a tail forest).
+#pragma once
+#include <vector>
+#include "ctx.hpp"
+
+struct vgk_dgraph {
+    vgk_ctx* ctx = nullptr;
+    vgk::WinGraph g{};
+    std::vector<void*> dev;          // device allocations (released with the graph)
+    uint64_t dev_bytes = 0;
+};

@@ -101,4 +101,15 @@ int hip_win_stage2(const WinParams& P, void* tmp, size_t tmp_bytes, hipStream_t 
     return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
 }
 
+size_t hip_scan_tmp_bytes(uint32_t n) {
+    size_t b = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, (hipStream_t)0);
+    return b + 256;
+}
+int hip_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, void* tmp, size_t tmp_bytes, hipStream_t st) {
+    size_t bytes = tmp_bytes;
+    if (hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, n, st) != hipSuccess) return VGK_ENODEV;
+    return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+}
+
 }  // namespace vgk

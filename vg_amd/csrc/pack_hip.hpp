@@ -7,4 +7,6 @@ namespace vgk {
 size_t hip_win_tmp_bytes(uint32_t n, uint32_t n_waves_cap);                               // scratch the sort / scans need
 int    hip_win_stage1(const WinParams& P, void* tmp, size_t tmp_bytes, hipStream_t st);   // sizes + their prefix sums
 int    hip_win_stage2(const WinParams& P, void* tmp, size_t tmp_bytes, hipStream_t st);   // order, wavefronts, arenas
+size_t hip_scan_tmp_bytes(uint32_t n);                                                    // a plain exclusive prefix sum of n 32-bit values (rocPRIM)
+int    hip_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, void* tmp, size_t tmp_bytes, hipStream_t st);
 }

@@ -15,14 +15,9 @@
 #include <new>
 #include <vector>
 #include "batch.hpp"
+#include "dgraph.hpp"
 #include "host_parallel.hpp"
 
-struct vgk_dgraph {
-    vgk_ctx* ctx = nullptr;
-    WinGraph g{};
-    std::vector<void*> dev;          // device allocations (released with the graph)
-    uint64_t dev_bytes = 0;
-};
 
 namespace {
 

@@ -648,3 +648,72 @@ class GraphTails:
         s = object.__new__(capi.WindowSet)
         s.reads = ws.reads; s.read_off = ws.read_off[begin:begin + k + 1]; s.n = k; s.array = ws.array[begin:begin + k]; s.cols = ws.cols[begin:begin + k]
         return s
+
+
+class TailForestWorkload:
+    """giraffe's tail path from the extension onward (configs[2]/[3], the part behind GaplessExtender): for every tail a GBWT search
+    state + cut (the end of a gapless extension), the walk distance (tail + longest detectable gap, src/minimizer_mapper.cpp:5816)
+    and the tail's bases.  A variation graph with `n_haplotypes` random threads (as GaplessWorkload); a tail starts at a random
+    position of a random thread on either strand, with the state of ALL visits of that node (get_state(handle): the widest forest
+    the walk can produce there), and follows the thread with 1 % substitutions for 1..max_tail bases.  Cuts never fall on a node's
+    end, so every problem yields exactly one tree (a skipped root yields a forest; tests/test_tail_forest.py covers those)."""
+
+    def __init__(self, n_tails, seed=99, graph_bp=1_000_000, n_haplotypes=8, read_len=150, max_tail=121, snp_every=100, indel_every=1000):
+        rng = np.random.default_rng(seed)
+        seqs, preds, kind = build_variation_graph(rng, graph_bp, snp_every, indel_every)
+        lens = np.array([len(s) for s in seqs], dtype=np.int64)
+        succ = [[] for _ in seqs]
+        for v, pr in enumerate(preds):
+            for p in pr:
+                succ[p].append(v)
+        self.nodes = [s.tobytes().decode() for s in seqs]
+        threads = []
+        for _ in range(n_haplotypes):
+            t = [0]; v = 0
+            while succ[v]:
+                v = succ[v][int(rng.integers(0, len(succ[v])))]
+                t.append(v)
+            threads.append(np.array(t, dtype=np.int64))
+        self.threads = [list((2 * t).astype(int)) for t in threads]
+        comp = np.arange(256, dtype=np.uint8)
+        for a, b in zip(b"ACGT", b"TGCA"):
+            comp[a] = b
+        counts = np.zeros(2 * len(seqs), dtype=np.int64)
+        for t in threads:
+            c = np.bincount(t, minlength=len(seqs))
+            counts[0::2] += c; counts[1::2] += c          # the reverse thread visits the other strand of the same nodes
+        which = rng.integers(0, n_haplotypes, n_tails); rev = rng.random(n_tails) < 0.5
+        tail_len = rng.integers(1, max_tail + 1, n_tails)
+        probs = np.zeros(n_tails, dtype=capi.TAIL_DT)
+        tails = np.zeros((n_tails, max_tail), dtype=np.uint8)
+        for hidx in range(n_haplotypes):
+            for strand in (0, 1):
+                sel = np.nonzero((which == hidx) & (rev == bool(strand)))[0]
+                if not len(sel):
+                    continue
+                t = threads[hidx]
+                if strand:
+                    t = t[::-1]
+                hs = np.concatenate([seqs[v] if not strand else comp[seqs[v][::-1]] for v in t])
+                st = np.concatenate([[0], np.cumsum(lens[t])])
+                a = rng.integers(1, len(hs) - max_tail - 1, len(sel))             # the tail's first base on this strand of the thread
+                k = np.searchsorted(st, a, side="right") - 1
+                off = a - st[k]                                                   # cut: bases [off, len) of the node belong to the tail
+                node = 2 * t[k] + strand
+                probs["node"][sel] = node; probs["lo"][sel] = 0; probs["hi"][sel] = counts[node] - 1; probs["offset"][sel] = off
+                w = hs[a[:, None] + np.arange(max_tail)[None, :]]
+                sub = rng.random(w.shape) < 0.01
+                tails[sel] = np.where(sub, ACGT[rng.integers(0, 4, w.shape)], w)
+        gap = longest_detectable_gap(read_len, tail_len)
+        probs["walk_distance"] = tail_len + gap
+        self.problems = probs; self.tail_len = tail_len; self.max_gap = gap; self.n = n_tails
+        keep = np.arange(max_tail)[None, :] < tail_len[:, None]
+        self.reads = tails[keep]                                                  # flat, tail i = reads[read_off[i]:read_off[i+1]]
+        self.read_off = np.concatenate([[0], np.cumsum(tail_len)])
+
+    def windows(self, results, lo=0, hi=None):
+        """the X-drop problems of tails [lo, hi) once their forests exist: one tree each = nodes [first_node, first_node + n_nodes)"""
+        hi = self.n if hi is None else hi
+        r = results[lo:hi]
+        return capi.WindowSet(self.reads[self.read_off[lo]:self.read_off[hi]], self.read_off[lo:hi + 1] - self.read_off[lo], r["first_node"], r["n_nodes"],
+                              capi.VGK_XDROP_PINNED | capi.VGK_GSSW_TRACEBACK, self.max_gap[lo:hi], cols=r["bases"])
