@@ -8,5 +8,6 @@ struct vgk_dgraph {
     vgk_ctx* ctx = nullptr;
     vgk::WinGraph g{};
     std::vector<void*> dev;          // device allocations (released with the graph)
+    std::vector<uint64_t> dev_size;  // when as long as `dev`: the blocks came from the context's pool of device arenas and go back there
     uint64_t dev_bytes = 0;
 };

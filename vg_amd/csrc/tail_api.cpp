@@ -36,8 +36,10 @@ int vgk_tail_forest(vgk_ctx* ctx, const vgk_haplo* index, const vgk_tail_problem
     Backend* be = ctx->be.get();
     std::lock_guard<std::mutex> lk(ctx->mu);
     // what belongs to the call goes to the context's cached scratch; what belongs to the forest is owned by its graph
-    auto keep = [&](size_t bytes) -> void* { void* p = be->alloc(bytes ? bytes : 16); if (p) { dg->dev.push_back(p); dg->dev_bytes += bytes; } return p; };
-    auto fail = [&](int rc) { be->sync(); for (void* p : dg->dev) be->release(p); dg->dev.clear(); return rc; };
+    // (from the context's pool of device arenas, like a batch's: a forest lives for one batch of tails, and hipMalloc / hipFree cost
+    // more than the walks)
+    auto keep = [&](size_t bytes) -> void* { uint64_t got = 0; void* p = ctx->dev_take(bytes ? bytes : 16, got); if (p) { dg->dev.push_back(p); dg->dev_size.push_back(got); dg->dev_bytes += bytes; } return p; };
+    auto fail = [&](int rc) { be->sync(); for (size_t k = 0; k < dg->dev.size(); ++k) ctx->dev_give(dg->dev[k], dg->dev_size[k]); dg->dev.clear(); dg->dev_size.clear(); return rc; };
     TailParams P{};
     P.index = index->dev; P.n = n;
     const uint32_t per_cu = 512;

@@ -107,7 +107,8 @@ void vgk_graph_destroy(vgk_dgraph* dg) {
     {
         std::lock_guard<std::mutex> lk(dg->ctx->mu);
         dg->ctx->be->sync(); dg->ctx->be->sync_side();
-        for (void* p : dg->dev) dg->ctx->be->release(p);
+        if (dg->dev_size.size() == dg->dev.size()) for (size_t k = 0; k < dg->dev.size(); ++k) dg->ctx->dev_give(dg->dev[k], dg->dev_size[k]);
+        else for (void* p : dg->dev) dg->ctx->be->release(p);
     }
     delete dg;
 }
