@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <cstdlib>
 #include <functional>
 #include <memory>
@@ -60,19 +61,33 @@ public:
     }
     static bool run_on_any(unsigned T, const std::function<void(unsigned)>& job) { return get(0).try_run(T, job) || get(1).try_run(T, job); }
     // runs job(t) for t in [0, T) — t = 0 on the calling thread — and returns when all are done; false = pool busy, nothing ran
+    // A loop body that itself calls parallel_for finds inside_job() set and runs its inner loop on its own thread: the pool's submit
+    // lock is not re-entrant.  A body that throws (bad_alloc from a growing vector, say) is caught on whichever thread it ran; the
+    // call still waits for every worker before the first exception is rethrown on the caller, so no worker is left running a job
+    // whose captures are gone.
+    static bool& inside_job() { static thread_local bool in = false; return in; }
     bool try_run(unsigned T, const std::function<void(unsigned)>& job) {
+        if (inside_job()) return false;
         std::unique_lock<std::mutex> one(submit, std::try_to_lock);
         if (!one.owns_lock()) return false;
         {
             std::lock_guard<std::mutex> lock(m);
             while (threads.size() + 1 < T) { const unsigned id = (unsigned)threads.size() + 1; threads.emplace_back([this, id] { work(id); }); }
-            current = &job; want = T; pending = T - 1; ++epoch;
+            current = &job; want = T; pending = T - 1; failed = nullptr; ++epoch;
         }
         cv_start.notify_all();
-        job(0);
-        std::unique_lock<std::mutex> lock(m);
-        cv_done.wait(lock, [this] { return pending == 0; });
-        current = nullptr;
+        std::exception_ptr mine;
+        inside_job() = true;
+        try { job(0); } catch (...) { mine = std::current_exception(); }
+        inside_job() = false;
+        std::exception_ptr first;
+        {
+            std::unique_lock<std::mutex> lock(m);
+            cv_done.wait(lock, [this] { return pending == 0; });
+            current = nullptr;
+            first = mine ? mine : failed; failed = nullptr;
+        }
+        if (first) std::rethrow_exception(first);
         return true;
     }
     ~WorkerPool() {
@@ -96,8 +111,12 @@ private:
                 if (id < want) job = current;
             }
             if (job) {
-                (*job)(id);
+                std::exception_ptr err;
+                inside_job() = true;
+                try { (*job)(id); } catch (...) { err = std::current_exception(); }
+                inside_job() = false;
                 std::lock_guard<std::mutex> lock(m);
+                if (err && !failed) failed = err;
                 if (--pending == 0) cv_done.notify_all();
             }
         }
@@ -108,14 +127,31 @@ private:
     std::vector<std::thread> threads;
     const std::function<void(unsigned)>* current = nullptr;
     uint64_t epoch = 0; unsigned want = 0, pending = 0; bool stop = false;
+    std::exception_ptr failed;                     // the first exception a worker's share of the current job threw
 };
+
+// threads of the call's own (the pools are busy): the same contract as WorkerPool::try_run — every thread is joined before the first
+// exception any of them threw is rethrown on the caller
+inline void run_on_own_threads(unsigned T, const std::function<void(unsigned)>& body) {
+    std::mutex em; std::exception_ptr first;
+    auto guarded = [&](unsigned t) {
+        WorkerPool::inside_job() = true;
+        try { body(t); } catch (...) { std::lock_guard<std::mutex> lock(em); if (!first) first = std::current_exception(); }
+        WorkerPool::inside_job() = false;
+    };
+    std::vector<std::thread> ts;
+    for (unsigned t = 1; t < T; ++t) ts.emplace_back(guarded, t);
+    guarded(0);
+    for (auto& t : ts) t.join();
+    if (first) std::rethrow_exception(first);
+}
 
 // run f(i, thread) for i in [0, n) on a few host threads
 template <class F> inline void parallel_for(uint32_t n, F f) {
     unsigned hw = usable_cpus();
     unsigned T = std::min<unsigned>(hw ? hw : 1, 48u);       // never more than 48: beyond that the loops are bound by memory, not by threads
     if (const char* e = std::getenv("VGAMD_HOST_THREADS")) T = (unsigned)std::min<int>(MAX_THREADS, std::max(1, std::atoi(e)));
-    if (n < 256 || T <= 1) { for (uint32_t i = 0; i < n; ++i) f(i, 0u); return; }
+    if (n < 256 || T <= 1 || WorkerPool::inside_job()) { for (uint32_t i = 0; i < n; ++i) f(i, 0u); return; }      // (a nested loop runs on the thread that reached it)
     T = std::min<unsigned>(T, (n + 63) / 64);                      // no more threads than blocks of work
     std::atomic<uint32_t> next{0};
     const std::function<void(unsigned)> body = [&](unsigned t) {
@@ -123,10 +159,7 @@ template <class F> inline void parallel_for(uint32_t n, F f) {
     };
     if (T <= 1) { body(0); return; }
     if (WorkerPool::run_on_any(T, body)) return;
-    std::vector<std::thread> ts;                                     // the pool is busy with another caller's loop
-    for (unsigned t = 1; t < T; ++t) ts.emplace_back([&body, t]() { body(t); });
-    body(0);
-    for (auto& t : ts) t.join();
+    run_on_own_threads(T, body);                                     // the pool is busy with another caller's loop
 }
 
 // a few coarse tasks (slices of a sort, say) on the same threads: task(i) for i in [0, count), whatever the count
@@ -135,14 +168,11 @@ template <class F> inline void parallel_tasks(uint32_t count, F task) {
     unsigned T = std::min<unsigned>(hw ? hw : 1, 48u);
     if (const char* e = std::getenv("VGAMD_HOST_THREADS")) T = (unsigned)std::min<int>(MAX_THREADS, std::max(1, std::atoi(e)));
     T = std::min<unsigned>(T, count);
-    if (T <= 1) { for (uint32_t i = 0; i < count; ++i) task(i); return; }
+    if (T <= 1 || WorkerPool::inside_job()) { for (uint32_t i = 0; i < count; ++i) task(i); return; }
     std::atomic<uint32_t> next{0};
     const std::function<void(unsigned)> body = [&](unsigned) { for (;;) { const uint32_t i = next.fetch_add(1); if (i >= count) break; task(i); } };
     if (WorkerPool::run_on_any(T, body)) return;
-    std::vector<std::thread> ts;
-    for (unsigned t = 1; t < T; ++t) ts.emplace_back([&body, t]() { body(t); });
-    body(0);
-    for (auto& t : ts) t.join();
+    run_on_own_threads(T, body);
 }
 
 // the same over fixed chunks of the index range: f(lo, hi, chunk) — for two-level prefix sums and reductions

@@ -568,7 +568,10 @@ static uint64_t problem_device_bytes(const vgk_gssw_problem& p) {
     uint64_t R = 0;
     for (uint32_t v = 0; v < p.graph.n_nodes; ++v) R += p.graph.node_len[v];
     const uint64_t rows = ((uint64_t)p.read_len + 24) / 4 * 4 + 4;
-    return rows * (R + 64) / 2 + 16 * (p.read_len + R) + 64ull * p.graph.n_nodes + 512;
+    // traceback codes + inputs + the scratch of saved last columns (4 bytes per padded row for every node that may be stored: all of
+    // them on a variant-dense graph) + descriptors; the arenas come from dev_take, which rounds every request up by an eighth
+    const uint64_t bytes = rows * (R + 64) / 2 + 16 * (p.read_len + R) + (4 * rows + 64) * p.graph.n_nodes + 512;
+    return bytes + bytes / 8;
 }
 
 // the limits vgk_gssw_pack enforces on a whole batch, per problem: what the kernels cannot take is reported in that
@@ -618,6 +621,10 @@ int vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
         }
         vgk_batch* b = nullptr;
         int rc = vgk_gssw_pack(ctx, batch_problems, m, 0, &b);
+        if (rc == VGK_ENOMEM && m > 1) {                                 // the estimate was too low for these graphs: half as many at a time
+            budget = std::max<uint64_t>(bytes / 2, 1);
+            continue;
+        }
         if (rc) return rc;
         rc = vgk_gssw_run(b);
         size_t w = 0;
