@@ -252,6 +252,75 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
         dist.destroy_process_group()
 
 
+def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
+    """configs[2]'s alignment stage as giraffe runs it (secondary line): seeds -> haplotype-consistent gapless extension -> for the
+    clusters no full-length extension resolves, tail forests -> the trees as left-pinned X-drop windows -> total scores
+    (vg_amd/pipeline.py; src/minimizer_mapper.cpp:5480-5535).  One step = the whole stage for the batch FROM HOST BUFFERS: every call
+    uploads its inputs and the extension sets come back to the host, where the tails are derived (numpy)."""
+    import numpy as np
+    from vg_amd import capi, pipeline, shard, workloads
+    n = args.reads if args.reads else 1_000_000
+    inserted = 0.1
+    t0 = time.perf_counter()
+    wl = workloads.GaplessWorkload(n, seed=123 + rank, inserted_reads=inserted)
+    t_gen = time.perf_counter() - t0
+    olen = np.repeat(np.array([len(s) for s in wl.nodes]), 2)
+    index = eng.haplo_index(wl.nodes, wl.threads)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        out = pipeline.align_stage(eng, index, olen, wl.gs)
+        if "forest" in out:
+            out["forest"].close()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pipeline.align_stage(eng, index, olen, wl.gs)
+        if "forest" in out:
+            out["forest"].close()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res = out["res"]; n_tails = len(out["tails"]["problems"])
+    cpu = parity = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
+        cores = shard.usable_cpus(); ora.lib.vgo_set_threads(cores)
+        k = min(n, args.cpu_sample or 200_000)
+        sub = capi.GaplessSet(wl.gs.reads[:wl.gs.read_off[k]], wl.gs.read_off[:k + 1], wl.gs.seeds[:wl.gs.seed_off[k]], wl.gs.seed_off[:k + 1])
+        oidx = ora.haplo_index(wl.nodes, wl.threads)
+        t1 = time.perf_counter(); o = pipeline.align_stage(ora, oidx, olen, sub); tc = time.perf_counter() - t1
+        same = int((o["read_score"] == out["read_score"][:k]).sum())
+        cpu = {"value": k / tc, "unit": "reads/s", "cores": cores, "kind": "port",
+               "impl": "the same pipeline over the oracle: vgo_gapless.c (OpenMP over reads), vgo_tail.c (one thread), vgo_xdrop.c (OpenMP over problems)",
+               "sample": "the first %d reads of the batch" % k}
+        parity = {"checked": k, "identical": same, "what": "per-read best total score (extension + both tails); tests/test_giraffe_stage.py compares every intermediate product"}
+    if rank == 0:
+        open_reads = int((res["full_length"] == 0).sum())
+        print(json.dumps({
+            "metric": "reads/sec through giraffe's alignment stage (gapless extension; tail forests + pinned X-drop for unresolved clusters)",
+            "value": n * world * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 / u16", "data": "synthetic",
+            "config": {"workload": "1 Mbp variation graph, 8 random haplotype threads, %d x 150 bp reads per GPU from either strand, 1 %% substitutions, %d %% of the reads with one "
+                                   "inserted base, 4.0 seeds per read at true positions; GaplessExtender + get_tail_forest + align_pinned(xdrop) semantics, scores 1/4/6/1/5" % (n, int(100 * inserted)),
+                       "timed_region": "vg_amd/pipeline.py align_stage per step, from host buffers: vgk_gapless_extend, tails derived on the host, vgk_tail_forest, "
+                                       "vgk_gssw_pack_windows + run + fetch, totals", "reads_without_full_length_extension": open_reads, "tails": n_tails,
+                       "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
+            "roofline": {"bound": "hbm", "kernel": "gapless_search_kernel (the stage's largest kernel)", "limiter": "host glue and PCIe round trips between the stages, then memory latency (DESIGN.md §11, §17)",
+                         "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
+            "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum())}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def bench_forest(args, eng, rank, world, dist, torch, dev_name, cus):
     """giraffe's tail path behind the gapless extension (secondary line): per tail a GBWT search state + cut ->
     the tail forest walked on the device (vgk_tail_forest) and left in HBM as a resident graph -> the trees as window problems, packed on
@@ -518,7 +587,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--host-pack", action="store_true", help="linear workload: one explicit graph per problem, packed on host threads (vgk_gssw_pack) instead of windows of the resident graph packed on the device")
     ap.add_argument("--no-e2e", action="store_true", help="skip the legs that overlap launches — the two-lane steady state and the warm / double-buffered end-to-end legs — so that a profiler's per-kernel averages are each kernel's own")
-    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband", "forest"], default="linear",
+    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband", "forest", "giraffe"], default="linear",
                     help="linear = BASELINE.json configs[1] (the headline metric); tails = configs[2] stand-in: "
                          "giraffe-style pinned X-drop tail alignments on a variation graph; banded = configs[4] stand-in: "
                          "banded global alignments between chained anchors; gapless = giraffe's first stage: "
@@ -558,6 +627,8 @@ def main():
     eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), device=local_rank, lib=eng_lib)
     dev_name, cus, hbm = eng.device_info()
 
+    if args.workload == "giraffe":
+        return bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "forest":
         return bench_forest(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "xband":

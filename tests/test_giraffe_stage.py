@@ -1,0 +1,58 @@
+"""giraffe's alignment stage as one pipeline over the engine (vg_amd/pipeline.py): seeds -> gapless extensions -> for clusters no
+full-length extension resolves, tail forests -> the trees as X-drop windows -> total scores (src/minimizer_mapper.cpp:5480-5535).
+Every intermediate product of the engine (emulated here, the MI355X in the gpu test) must equal the oracle's: extension sets,
+search states, forests, window alignments with their CIGAR ops, per-read totals."""
+import subprocess
+
+import numpy as np
+import pytest
+
+from util import EMU_LIB, ENGINE_LIB, ORACLE_LIB, ROOT
+from vg_amd import capi, pipeline, workloads
+from test_windows import assert_same
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    subprocess.check_call(["make", "-s", "emu"], cwd=ROOT)
+    return EMU_LIB
+
+
+def run_stage(lib, n, seed, graph_bp, inserted):
+    wl = workloads.GaplessWorkload(n, seed=seed, graph_bp=graph_bp, inserted_reads=inserted)
+    olen = np.repeat(np.array([len(s) for s in wl.nodes]), 2)
+    outs = []
+    for which in (lib, ORACLE_LIB):
+        eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=which)
+        outs.append(pipeline.align_stage(eng, eng.haplo_index(wl.nodes, wl.threads), olen, wl.gs))
+    a, b = outs
+    for f in ("status", "n_ext", "full_length"):
+        assert (a["res"][f] == b["res"][f]).all(), f
+    ne = int(a["res"]["n_ext"].sum())
+    for f in ("offset", "read_begin", "read_end", "score", "left_full", "right_full", "state", "path_len"):
+        assert (a["ext"][f][:ne] == b["ext"][f][:ne]).all(), f
+    for f in ("status", "first_node", "n_nodes", "n_trees", "root_trim", "bases"):
+        assert (a["tail_results"][f] == b["tail_results"][f]).all(), f
+    for x, y in zip(a["forest"].fetch(), b["forest"].fetch()):
+        assert (x == y).all()
+    assert_same(a["tail_alignments"], a["tail_ops"], b["tail_alignments"], b["tail_ops"], "tails against their trees")
+    for k in ("tail_score", "ext_total", "read_score"):
+        assert (a[k] == b[k]).all(), k
+    return wl, a
+
+
+def test_alignment_stage_equals_the_oracles(emu_lib):
+    wl, a = run_stage(emu_lib, 1500, 9, 60000, 0.4)
+    res, t = a["res"], a["tails"]
+    assert 300 < int((res["full_length"] == 0).sum()) < 900 and len(t["problems"]) > 500
+    assert (a["tail_results"]["n_trees"] > 1).any()                         # cuts at a node's end: forests
+    # a read with one inserted base: everything matches but the gap (150 - 1 matches + 2 bonuses - open - extend ... minus substitutions)
+    open_reads = res["full_length"] == 0
+    assert np.median(a["read_score"][open_reads]) >= 140
+    assert (a["read_score"][~open_reads] >= a["read_score"][open_reads].min()).all()
+
+
+@pytest.mark.gpu
+def test_alignment_stage_on_the_gpu_equals_the_oracles():
+    wl, a = run_stage(ENGINE_LIB, 30000, 10, 400000, 0.3)
+    assert len(a["tails"]["problems"]) > 10000

@@ -318,7 +318,9 @@ class GaplessWorkload:
     strand with 1 % substitutions; `seeds_per_read` seeds at true positions (distinct read offsets), as a minimizer index
     would report for an error-free k-mer."""
 
-    def __init__(self, n_reads, seed=123, graph_bp=1_000_000, n_haplotypes=8, read_len=150, seeds_per_read=6, snp_every=100, indel_every=1000):
+    def __init__(self, n_reads, seed=123, graph_bp=1_000_000, n_haplotypes=8, read_len=150, seeds_per_read=6, snp_every=100, indel_every=1000, inserted_reads=0.0):
+        """inserted_reads: fraction of the reads that carry one extra base at a random position (a sequencing insertion): no gapless
+        extension covers such a read, so its cluster leaves tails (the giraffe workload)"""
         rng = np.random.default_rng(seed)
         seqs, preds, kind = build_variation_graph(rng, graph_bp, snp_every, indel_every)
         n_nodes = len(seqs)
@@ -366,7 +368,21 @@ class GaplessWorkload:
             off_o = np.where(r[:, None], lens[node] - 1 - off, off)                                          # offset on the read's strand
             flat = (sel[:, None] * seeds_per_read + np.arange(seeds_per_read)[None, :]).ravel()
             seeds["node"][flat] = (2 * node + r[:, None]).ravel()
-            seeds["diff"][flat] = (ro - off_o).ravel()
+            diff = ro - off_o
+            if inserted_reads > 0:
+                ins = rng.random(len(sel)) < inserted_reads
+                p = rng.integers(20, read_len - 20, len(sel))
+                col = np.arange(read_len)[None, :]
+                src = np.where(col > p[:, None], col - 1, col)                    # read' = read[:p] + X + read[p:-1]
+                shifted = np.take_along_axis(rd, src, axis=1)
+                shifted[np.arange(len(sel)), p] = ACGT[rng.integers(0, 4, len(sel))]
+                reads[sel] = np.where(ins[:, None], shifted, rd)
+                moved = ins[:, None] & (ro >= p[:, None])                         # the bases behind the insertion sit one read position later
+                diff = diff + moved
+                gone = moved & (ro + 1 >= read_len)
+                diff = np.where(gone, diff[:, :1], diff)                          # (a seed pushed off the read: repeat the first one; the de-duplication drops it)
+                seeds["node"][flat] = np.where(gone, (2 * node + r[:, None])[:, :1], 2 * node + r[:, None]).ravel()
+            seeds["diff"][flat] = diff.ravel()
         # a cluster is a set: drop seeds that repeat (same node and diagonal) inside a read
         keep = np.ones(len(seeds), dtype=bool)
         s2 = seeds.reshape(n_reads, seeds_per_read)
