@@ -273,14 +273,16 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
             dist.barrier()
         torch.cuda.synchronize()
 
+    stage = pipeline.align_stage if os.environ.get("VGAMD_GIRAFFE_NUMPY_GLUE") else pipeline.align_stage_native      # the glue in the host shim (C++) or in numpy
     for _ in range(max(1, args.warmup)):
-        out = pipeline.align_stage(eng, index, olen, wl.gs)
+        out = stage(eng, index, olen, wl.gs)
         if "forest" in out:
             out["forest"].close()
     barrier()
     t0 = time.perf_counter()
+    timing = {}
     for _ in range(args.steps):
-        out = pipeline.align_stage(eng, index, olen, wl.gs)
+        out = stage(eng, index, olen, wl.gs, timing=timing)
         if "forest" in out:
             out["forest"].close()
     barrier()
@@ -289,7 +291,7 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
         t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    res = out["res"]; n_tails = len(out["tails"]["problems"])
+    res = out["res"]; n_tails = out["stats"][0] if "stats" in out else len(out["tails"]["problems"])
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu:
         ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
@@ -311,8 +313,9 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 / u16", "data": "synthetic",
             "config": {"workload": "1 Mbp variation graph, 8 random haplotype threads, %d x 150 bp reads per GPU from either strand, 1 %% substitutions, %d %% of the reads with one "
                                    "inserted base, 4.0 seeds per read at true positions; GaplessExtender + get_tail_forest + align_pinned(xdrop) semantics, scores 1/4/6/1/5" % (n, int(100 * inserted)),
-                       "timed_region": "vg_amd/pipeline.py align_stage per step, from host buffers: vgk_gapless_extend, tails derived on the host, vgk_tail_forest, "
-                                       "vgk_gssw_pack_windows + run + fetch, totals", "reads_without_full_length_extension": open_reads, "tails": n_tails,
+                       "timed_region": "per step, from host buffers: vgk_gapless_extend (results back on the host), then the host shim's run_tail_stage (vg_amd/host/tail_stage.cpp): "
+                                       "tails derived on host threads, vgk_tail_forest, one window per tree, vgk_gssw_pack_windows + run + fetch, totals", "reads_without_full_length_extension": open_reads, "tails": n_tails,
+                       "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()},
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
             "roofline": {"bound": "hbm", "kernel": "gapless_search_kernel (the stage's largest kernel)", "limiter": "host glue and PCIe round trips between the stages, then memory latency (DESIGN.md §11, §17)",
                          "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},

@@ -38,6 +38,11 @@ def run_stage(lib, n, seed, graph_bp, inserted):
     assert_same(a["tail_alignments"], a["tail_ops"], b["tail_alignments"], b["tail_ops"], "tails against their trees")
     for k in ("tail_score", "ext_total", "read_score"):
         assert (a[k] == b[k]).all(), k
+    # the same stage with the glue in the host shim (vg_amd/host/tail_stage.cpp) instead of numpy
+    eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=lib)
+    c = pipeline.align_stage_native(eng, eng.haplo_index(wl.nodes, wl.threads), olen, wl.gs)
+    assert (c["ext_total"] == a["ext_total"][:len(c["ext_total"])]).all() and (c["read_score"] == a["read_score"]).all()
+    assert c["stats"][0] == len(a["tails"]["problems"]) and c["stats"][1] == len(a["owner"]) and c["stats"][3] == 0
     return wl, a
 
 

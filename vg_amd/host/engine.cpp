@@ -49,6 +49,12 @@ std::shared_ptr<EngineApi> load_engine(const std::string& path) {
     bind(dl, "vgk_gapless_extend", api->gapless_extend);
     bind(dl, "vgk_wfa_extend", api->wfa_extend);
     bind(dl, "vgk_xdrop_band_align", api->xdrop_band_align);
+    bind(dl, "vgk_gssw_pack_windows", api->gssw_pack_windows);
+    bind(dl, "vgk_tail_forest", api->tail_forest);
+    bind(dl, "vgk_forest_fetch", api->forest_fetch);
+    bind(dl, "vgk_forest_graph", api->forest_graph);
+    bind(dl, "vgk_forest_size", api->forest_size);
+    bind(dl, "vgk_forest_destroy", api->forest_destroy);
     if (api->abi_version() != VGK_ABI_VERSION) throw std::runtime_error("vgamd engine: ABI version mismatch in " + p);
     return api;
 }

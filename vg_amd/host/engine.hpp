@@ -32,6 +32,12 @@ struct EngineApi {
     decltype(&vgk_gapless_extend) gapless_extend = nullptr;
     decltype(&vgk_wfa_extend) wfa_extend = nullptr;
     decltype(&vgk_xdrop_band_align) xdrop_band_align = nullptr;
+    decltype(&vgk_gssw_pack_windows) gssw_pack_windows = nullptr;
+    decltype(&vgk_tail_forest) tail_forest = nullptr;
+    decltype(&vgk_forest_fetch) forest_fetch = nullptr;
+    decltype(&vgk_forest_graph) forest_graph = nullptr;
+    decltype(&vgk_forest_size) forest_size = nullptr;
+    decltype(&vgk_forest_destroy) forest_destroy = nullptr;
     ~EngineApi();
 };
 

@@ -7,6 +7,7 @@
 #include <memory>
 #include <string>
 #include "aligner.hpp"
+#include "tail_stage.hpp"
 #include "gbwt_extender.hpp"
 
 using namespace vgamd;
@@ -282,6 +283,27 @@ int vgh_wfa_align(vgh_wfa* w, int kind, const char* seq, const int64_t* from, co
         js += "}";
         if (js.size() + 1 > json_cap) { g_last_error = "json buffer too small"; return -2; }
         std::memcpy(json_out, js.c_str(), js.size() + 1);
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// The tails of a batch of gapless extensions (tail_stage.hpp) on an engine context and index the caller created through the C ABI of
+// the same engine library.  ext_total: one per extension, read_score: one per read, stats: tails, trees, tree nodes, failed; ms[6].
+int vgh_tail_stage(const char* engine_lib, void* ctx, const void* index, const char* reads, const uint64_t* read_off, uint32_t n_reads,
+                   const void* res, const void* ext, const uint32_t* nodes, const uint32_t* oriented_len, const int32_t scoring[4],
+                   uint32_t ops_per_problem, int32_t* ext_total, uint64_t n_ext, int32_t* read_score, uint64_t stats[4], double ms[6]) {
+    try {
+        auto api = load_engine(engine_lib ? engine_lib : "");
+        TailStageInput in{reads, read_off, n_reads, (const vgk_gapless_result*)res, (const vgk_extension*)ext, nodes, oriented_len,
+                          scoring[0], scoring[1], scoring[2], scoring[3], ops_per_problem};
+        TailStageOutput out;
+        const int rc = run_tail_stage(*api, (vgk_ctx*)ctx, (const vgk_haplo*)index, in, out);
+        if (rc) { g_last_error = api->strerror(rc); return rc; }
+        if (out.ext_total.size() > n_ext) { g_last_error = "ext_total too small"; return VGK_EINVAL; }
+        std::copy(out.ext_total.begin(), out.ext_total.end(), ext_total);
+        std::copy(out.read_score.begin(), out.read_score.end(), read_score);
+        if (stats) { stats[0] = out.n_tails; stats[1] = out.n_trees; stats[2] = out.tree_nodes; stats[3] = out.failed; }
+        if (ms) for (int k = 0; k < 6; ++k) ms[k] = out.ms[k];
         return 0;
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }

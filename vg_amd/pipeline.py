@@ -4,6 +4,9 @@ of the forest graph (vgk_gssw_pack_windows), left-pinned X-drop -> the extension
 
 Host-side glue only (numpy, vectorised): which tails exist, where they start, what their bases are.  It is what a maintainer's patch
 of MinimizerMapper::extension_to_alignment's caller would do per batch, and it is what bench.py --workload giraffe times."""
+import ctypes
+import os
+
 import numpy as np
 
 from . import capi, workloads
@@ -53,14 +56,21 @@ def tails_of_extensions(oriented_len, read_off, res, ext, nodes, scoring=(1, 6, 
 
 def tail_sequences(reads, read_off, t):
     """the tails' bases, flat: a right tail as it is, a left tail reverse-complemented (:5660) -> (bases, offsets)"""
-    ln = t["end"] - t["begin"]
+    ln = (t["end"] - t["begin"]).astype(np.int64)
     off = np.concatenate([[0], np.cumsum(ln)])
-    which = np.repeat(np.arange(len(ln)), ln)
-    k = np.arange(off[-1]) - off[which]
-    base = read_off[t["read"]][which]
-    pos = np.where(t["left"][which], t["end"][which] - 1 - k, t["begin"][which] + k)
-    b = reads[base + pos]
-    return np.where(t["left"][which], _COMP[b], b), off
+    left = t["left"]
+    base = read_off[t["read"]]
+    start = np.where(left, base + t["end"] - 1, base + t["begin"])               # first base taken, then forward (right tail) or backward (left tail)
+    step = np.where(left, -1, 1)
+    # position k of tail i = start[i] + step[i] * k: one running index built from per-tail increments
+    inc = np.repeat(step, ln)
+    first = off[:-1][ln > 0]
+    inc[first] = start[ln > 0] - np.concatenate([[0], (start + step * (ln - 1))[ln > 0][:-1]])
+    idx = np.cumsum(inc)
+    b = reads[idx]
+    lm = np.repeat(left, ln)
+    b[lm] = _COMP[b[lm]]
+    return b, off
 
 
 def tree_windows(res, forest, seq, seq_off, gap):
@@ -77,25 +87,41 @@ def tree_windows(res, forest, seq, seq_off, gap):
         owner = has[np.searchsorted(res["first_node"][has], first, side="right") - 1]
         csum = np.concatenate([[0], np.cumsum(length, dtype=np.int64)])
         cols = csum[first + count] - csum[first]
+    if len(owner) == len(seq_off) - 1 and (owner == np.arange(len(owner))).all():
+        return capi.WindowSet(seq, seq_off, first, count, flags, gap, cols=cols), owner       # every tail has one tree: its bases as they lie
     ln = np.diff(seq_off)[owner]
     off = np.concatenate([[0], np.cumsum(ln)])
-    which = np.repeat(np.arange(len(owner)), ln)
-    bases = seq[seq_off[owner][which] + (np.arange(off[-1]) - off[which])]
+    inc = np.ones(off[-1], dtype=np.int64)
+    nz = ln > 0
+    last = seq_off[owner] + ln - 1
+    inc[off[:-1][nz]] = seq_off[owner][nz] - np.concatenate([[0], last[nz][:-1]])
+    bases = seq[np.cumsum(inc)]
     return capi.WindowSet(bases, off, first, count, flags, gap[owner], cols=cols), owner
 
 
-def align_stage(eng, index, oriented_len, gs, ops_per_problem=32):
+def align_stage(eng, index, oriented_len, gs, ops_per_problem=32, timing=None):
     """The whole stage for one batch of clusters (a GaplessSet).  -> dict: the extension outputs, the tails, per tail its best tree's
-    score, per extension its total score, per read the best total; `forest`, `batch` results for parity checks."""
-    res, ext, nodes, mism = eng.gapless_extend(index, gs)
-    t = tails_of_extensions(oriented_len, gs.read_off, res, ext, nodes)
+    score, per extension its total score, per read the best total; `forest`, `batch` results for parity checks.  timing: a dict that
+    collects seconds per step."""
+    import time
+    t0 = [time.perf_counter()]
+
+    def lap(what):
+        if timing is not None:
+            t = time.perf_counter(); timing[what] = timing.get(what, 0.0) + t - t0[0]; t0[0] = t
+
+    res, ext, nodes, mism = eng.gapless_extend(index, gs); lap("gapless_extend")
+    t = tails_of_extensions(oriented_len, gs.read_off, res, ext, nodes); lap("tails_of_extensions (host)")
     out = dict(res=res, ext=ext, nodes=nodes, mism=mism, tails=t)
     total = ext["score"].astype(np.int64).copy()
     if len(t["problems"]):
-        tres, forest = eng.tail_forest(index, t["problems"])
-        seq, seq_off = tail_sequences(gs.reads, gs.read_off, t)
-        ws, owner = tree_windows(tres, forest, seq, seq_off, t["gap"])
-        r, ops = eng.align_windows(forest.graph, ws, ops_per_problem)
+        tres, forest = eng.tail_forest(index, t["problems"]); lap("tail_forest")
+        seq, seq_off = tail_sequences(gs.reads, gs.read_off, t); lap("tail_sequences (host)")
+        ws, owner = tree_windows(tres, forest, seq, seq_off, t["gap"]); lap("tree_windows (host)")
+        with eng.pack_windows(forest.graph, ws, ops_per_problem) as b:
+            lap("pack_windows")
+            b.run(); b.sync(); lap("fill + traceback")
+            r, ops = b.fetch(); lap("fetch")
         best = np.zeros(len(t["problems"]), dtype=np.int64)                       # a tail nothing aligns to is a soft clip: 0 (:5632-5648)
         np.maximum.at(best, owner, np.where(r["status"] == 0, r["score"], 0))
         np.add.at(total, t["ext"], best)
@@ -103,5 +129,51 @@ def align_stage(eng, index, oriented_len, gs, ops_per_problem=32):
     read_of_ext = np.repeat(np.arange(len(res)), res["n_ext"])
     best_read = np.zeros(len(res), dtype=np.int64)
     np.maximum.at(best_read, read_of_ext, total[:len(read_of_ext)])
-    out.update(ext_total=total, read_score=best_read)
+    out.update(ext_total=total, read_score=best_read); lap("totals (host)")
     return out
+
+
+# ---- the same stage with the host glue in C++ (vg_amd/host/tail_stage.cpp, part of the host shim) ---------------------------------
+_HOST = None
+
+
+def _host_lib():
+    global _HOST
+    if _HOST is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvgamd_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError("vg_amd/libvgamd_host.so missing: run `make host`")
+        h = ctypes.CDLL(path)
+        h.vgh_tail_stage.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        h.vgh_last_error.restype = ctypes.c_char_p
+        _HOST = h
+    return _HOST
+
+
+def align_stage_native(eng, index, oriented_len, gs, ops_per_problem=32, scoring=(1, 6, 1, 5), timing=None):
+    """align_stage with everything behind the gapless extension done by the host shim's run_tail_stage (C++ threads instead of numpy)
+    -> dict(res, ext, nodes, ext_total, read_score, stats = (tails, trees, tree nodes, failed), stage_ms)"""
+    import time
+    t0 = time.perf_counter()
+    res, ext, nodes, mism = eng.gapless_extend(index, gs)
+    t1 = time.perf_counter()
+    h = _host_lib()
+    n_ext = int(res["n_ext"].sum())
+    read_off = np.ascontiguousarray(gs.read_off, dtype=np.uint64); olen = np.ascontiguousarray(oriented_len, dtype=np.uint32)
+    ext_total = np.zeros(max(n_ext, 1), dtype=np.int32); read_score = np.zeros(max(gs.n, 1), dtype=np.int32)
+    sc = np.array(scoring, dtype=np.int32); stats = np.zeros(4, dtype=np.uint64); ms = np.zeros(6, dtype=np.float64)
+    ext = np.ascontiguousarray(ext); nodes = np.ascontiguousarray(nodes)
+    rc = h.vgh_tail_stage(eng.lib._name.encode(), eng.h, index.h, gs.reads.ctypes.data, read_off.ctypes.data, gs.n, res.ctypes.data, ext.ctypes.data,
+                          nodes.ctypes.data, olen.ctypes.data, sc.ctypes.data, ops_per_problem, ext_total.ctypes.data, len(ext_total), read_score.ctypes.data,
+                          stats.ctypes.data, ms.ctypes.data)
+    if rc:
+        raise RuntimeError("vgh_tail_stage: " + (h.vgh_last_error() or b"?").decode())
+    t2 = time.perf_counter()
+    if timing is not None:
+        for k, v in (("gapless_extend", t1 - t0), ("tail stage (host shim, total)", t2 - t1)):
+            timing[k] = timing.get(k, 0.0) + v
+        for k, v in zip(("tails derived (host)", "tail_forest", "windows + bases (host)", "pack_windows", "fill + traceback + fetch", "totals (host)"), ms):
+            timing[k] = timing.get(k, 0.0) + v * 1e-3
+    return dict(res=res, ext=ext, nodes=nodes, ext_total=ext_total[:n_ext], read_score=read_score[:gs.n], stats=tuple(int(x) for x in stats))
