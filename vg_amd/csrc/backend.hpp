@@ -89,6 +89,10 @@ public:
     virtual int   run_banded(const BandedParams& p, const BandedLaunch* launches, uint32_t n_launches) = 0;
     // gapless extension: `threads` resident threads (one scratch slab each) stride over p.n reads; last_ms(5) = kernel ms
     virtual int   run_gapless(const GaplessParams& p, uint32_t threads) = 0;
+    // the sets of a gapless batch in problem order (gapless_device.hpp): stage 1 = sizes per read, stage 2 = the gather (the prefix sums
+    // in between are scan_u32's); mask_reads = ReadMasker over a byte range in place.  All asynchronous on the main stream.
+    virtual int   gapless_order(const GOrderParams& p, int stage) = 0;
+    virtual int   mask_reads(char* reads, size_t bytes) = 0;
     // wavefront alignment: likewise, `threads` resident threads (one WScratch each, zeroed by the caller once) stride over
     // p.n problems; last_ms(6) = kernel ms
     virtual int   run_wfa(const WfaParams& p, uint32_t threads) = 0;

@@ -271,6 +271,23 @@ __global__ void __launch_bounds__(64, 6) gapless_rules_kernel(const GaplessParam
     gapless_rules_one(P, P.order[k], order + threadIdx.x * G_SEEDS);
 }
 
+__global__ void __launch_bounds__(256) gapless_order_kernel(const GOrderParams P, const int stage) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.n) return;
+    if (stage == 1) g_order_sizes_one(P, i); else g_order_gather_one(P, i);
+}
+__global__ void __launch_bounds__(256) mask_reads_kernel(char* reads, const size_t bytes) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i >= bytes) return;
+    if (i + 16 <= bytes) {
+        uint4 w = *reinterpret_cast<const uint4*>(reads + i);
+        char* c = reinterpret_cast<char*>(&w);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c[k] = g_mask_base(c[k]);
+        *reinterpret_cast<uint4*>(reads + i) = w;
+    } else for (size_t k = i; k < bytes; ++k) reads[k] = g_mask_base(reads[k]);
+}
+
 // ---- tail forests (tail_device.hpp): resident lanes take the tails in turn for the walks; one lane per tree node for the graph tables
 __global__ void __launch_bounds__(64) tail_walk_kernel(const TailParams P, const uint32_t threads) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
@@ -599,6 +616,18 @@ public:
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         hipEventElapsedTime(&ms_xband, bev[0], bev[1]);
         return VGK_OK;
+    }
+    int gapless_order(const GOrderParams& p, int stage) override {
+        hipSetDevice(dev);
+        if (!p.n) return VGK_OK;
+        hipLaunchKernelGGL(gapless_order_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p, stage);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int mask_reads(char* reads, size_t bytes) override {
+        hipSetDevice(dev);
+        if (!bytes) return VGK_OK;
+        hipLaunchKernelGGL(mask_reads_kernel, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, stream, reads, bytes);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_tail(const TailParams& p, uint32_t threads) override {
         hipSetDevice(dev);

@@ -6,6 +6,8 @@
 // thread order — by delivering every finished record to its successors when the threads are acyclic as oriented-node
 // sequences, and by prefix doubling over the reversed prefixes otherwise.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -15,6 +17,18 @@
 #include "host_parallel.hpp"
 
 using namespace vgk;
+
+namespace {
+struct GLap {                     // VGAMD_TIMING=1: where a vgk_gapless_extend call spends its time on the host
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); const bool on = std::getenv("VGAMD_TIMING") != nullptr;
+    void operator()(const char* what) {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gapless_extend] %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t;
+    }
+};
+}  // namespace
+
 
 namespace {
 
@@ -200,6 +214,7 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->gapless_last_valid = false;
     Backend* be = ctx->be.get();
+    GLap lap;
     // pack: masked reads (ReadMasker, src/gbwt_extender.cpp:160-176), seeds
     std::vector<GProb> probs(n);
     uint64_t n_read = 0, n_seed = 0;
@@ -215,12 +230,12 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     char* reads = H.reads.get(be, n_read + 16); vgk_seed* seeds = H.seeds.get(be, n_seed + 1);
     if (!reads || !seeds) return VGK_ENOMEM;     // 8 bytes of padding at either end
     std::memset(reads, 0, 8); std::memset(reads + 8 + n_read, 0, 8);
-    parallel_for(n, [&](uint32_t i, unsigned) {
+    parallel_for(n, [&](uint32_t i, unsigned) {                       // (the masking itself happens on the device, over the uploaded bytes)
         const vgk_gapless_problem& p = problems[i];
-        char* r = reads + probs[i].read_off;
-        for (uint32_t k = 0; k < p.read_len; ++k) { const char c = p.read[k]; r[k] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'X'; }
+        if (p.read_len) std::memcpy(reads + probs[i].read_off, p.read, p.read_len);
         if (p.n_seeds) std::memcpy(seeds + probs[i].seed_off, p.seeds, sizeof(vgk_seed) * p.n_seeds);
     });
+    lap("reads masked, seeds copied");
     // device buffers are kept on the context between calls (grow-only)
     int next_slot = 16;
     auto cleanup = [&](int rc) { return rc; };
@@ -233,6 +248,7 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     P.index = index->dev; P.n = n;
     P.probs = (const GProb*)dev(probs.data(), sizeof(GProb) * n);
     P.reads = (const char*)dev(reads, n_read + 16);
+    if (P.reads && (be->mask_reads(const_cast<char*>(P.reads), n_read + 16) || be->zero(const_cast<char*>(P.reads), 8) || be->zero(const_cast<char*>(P.reads) + 8 + n_read, 8))) return VGK_ENODEV;
     P.seeds = (const vgk_seed*)dev(seeds, sizeof(vgk_seed) * (n_seed + 1));
     // processing order: by the node of the first seed (a counting sort; reads without seeds last).  Results do not depend on it —
     // problems are independent and the sets are handed back in problem order below — but reads that sit next to each other in a
@@ -272,58 +288,85 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     if (!P.winners || !P.probs || !P.reads || !P.seeds || !P.order || !P.scratch || !P.cold || !P.results || !P.ext || !P.nodes || !P.mism || !P.counters) return cleanup(VGK_ENOMEM);
     int rc;
     if ((rc = be->zero(P.counters, 256))) return cleanup(rc);
+    lap("order, uploads queued");
     if ((rc = be->run_gapless(P, threads))) return cleanup(rc);
+    lap("uploads + kernels");
     ctx->gapless_last = P; ctx->gapless_last_threads = threads; ctx->gapless_last_valid = true;
     unsigned long long counters[4] = {0, 0, 0, 0};
-    vgk_gapless_result* dres = H.dres.get(be, n);
-    if (!dres) return cleanup(VGK_ENOMEM);
     if ((rc = be->download(counters, P.counters, sizeof counters))) return cleanup(rc);
-    if ((rc = be->download(dres, P.results, sizeof(vgk_gapless_result) * n))) return cleanup(rc);
-    const uint64_t ne = std::min<uint64_t>(counters[0], cap_e), nn = std::min<uint64_t>(counters[1], cap_n), nm = std::min<uint64_t>(counters[2], cap_m);
-    vgk_extension* dext = H.dext.get(be, ne + 1); uint32_t* dnodes = H.dnodes.get(be, nn + 1); uint32_t* dmism = H.dmism.get(be, nm + 1);
-    if (!dext || !dnodes || !dmism) return cleanup(VGK_ENOMEM);
-    if (ne && (rc = be->download(dext, P.ext, sizeof(vgk_extension) * ne))) return cleanup(rc);
-    if (nn && (rc = be->download(dnodes, P.nodes, sizeof(uint32_t) * nn))) return cleanup(rc);
-    if (nm && (rc = be->download(dmism, P.mism, sizeof(uint32_t) * nm))) return cleanup(rc);
     ctx->gapless_ms = be->last_ms(5); ctx->gapless_retried = counters[3];
 #if defined(VGAMD_GAPLESS_PROF)
     { unsigned long long sec[20] = {0}; be->download(sec, P.counters + 8, sizeof(unsigned long long) * 12);
       std::fprintf(stderr, "gapless sections (wave cycles):"); for (int i = 0; i < 12; ++i) std::fprintf(stderr, " [%d]=%llu", i, sec[i]); std::fprintf(stderr, "\n"); }
 #endif
-    // the device packs sets in completion order; hand them back in problem order: sizes, a prefix sum, then parallel copies
-    std::vector<uint64_t> oe(n + 1, 0), on(n + 1, 0), om(n + 1, 0);
-    parallel_for(n, [&](uint32_t i, unsigned) {
-        const vgk_gapless_result& r = dres[i];
-        if (r.status != VGK_OK) return;
-        uint64_t need_n = 0, need_m = 0;
-        for (uint32_t k = 0; k < r.n_ext; ++k) { need_n += dext[r.ext_begin + k].path_len; need_m += dext[r.ext_begin + k].n_mismatches; }
-        oe[i + 1] = r.n_ext; on[i + 1] = need_n; om[i + 1] = need_m;
-    });
+    const uint64_t ne = std::min<uint64_t>(counters[0], cap_e), nn = std::min<uint64_t>(counters[1], cap_n), nm = std::min<uint64_t>(counters[2], cap_m);
+    // the device packed the sets in completion order; they go back in problem order: sizes, prefix sums and the gather on the device
+    // (gapless_device.hpp), then three contiguous arrays come down through page-locked staging
+    GOrderParams O{};
+    O.n = n; O.res = P.results; O.ext = P.ext; O.nodes = P.nodes; O.mism = P.mism;
+    uint32_t* tab = (uint32_t*)ctx->ensure_scratch(26, sizeof(uint32_t) * 6 * ((size_t)n + 1));
+    O.res_out = (vgk_gapless_result*)ctx->ensure_scratch(27, sizeof(vgk_gapless_result) * (size_t)n);
+    O.ext_out = (vgk_extension*)ctx->ensure_scratch(28, sizeof(vgk_extension) * (ne + 1));
+    O.nodes_out = (uint32_t*)ctx->ensure_scratch(29, sizeof(uint32_t) * (nn + nm + 2));
+    if (!tab || !O.res_out || !O.ext_out || !O.nodes_out) return cleanup(VGK_ENOMEM);
+    O.mism_out = O.nodes_out + nn + 1;
+    const size_t n1 = (size_t)n + 1;
+    O.size_e = tab; O.size_n = tab + n1; O.size_m = tab + 2 * n1; O.off_e = tab + 3 * n1; O.off_n = tab + 4 * n1; O.off_m = tab + 5 * n1;
+    if ((rc = be->zero(tab, sizeof(uint32_t) * 3 * n1))) return cleanup(rc);
+    if ((rc = be->gapless_order(O, 1))) return cleanup(rc);
+    for (int k = 0; k < 3; ++k) if ((rc = be->scan_u32(tab + k * n1, tab + (3 + k) * n1, (uint32_t)n1))) return cleanup(rc);
+    if ((rc = be->gapless_order(O, 2))) return cleanup(rc);
+    uint32_t tot[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) if ((rc = be->download(&tot[k], tab + (3 + k) * n1 + n, sizeof(uint32_t)))) return cleanup(rc);
+    const size_t we = tot[0], wn = tot[1], wm = tot[2];
     int rc_all = VGK_OK;
-    for (uint32_t i = 0; i < n; ++i) {
-        if (dres[i].status == VGK_OK && (oe[i] + oe[i + 1] > ext_cap || on[i] + on[i + 1] > nodes_cap || om[i] + om[i + 1] > mism_cap || !extensions || !nodes || !mismatches)) {
-            dres[i].status = VGK_EOPS; oe[i + 1] = on[i + 1] = om[i + 1] = 0;
-        }
-        if (dres[i].status == VGK_EOPS) rc_all = VGK_EOPS;
-        oe[i + 1] += oe[i]; on[i + 1] += on[i]; om[i + 1] += om[i];
-    }
-    parallel_for(n, [&](uint32_t i, unsigned) {
-        vgk_gapless_result r = dres[i];
-        const uint32_t src = r.ext_begin;
-        r.ext_begin = (uint32_t)oe[i];
-        if (r.status == VGK_OK) {
-            uint64_t wn = on[i], wm = om[i];
-            for (uint32_t k = 0; k < r.n_ext; ++k) {
-                vgk_extension x = dext[src + k];
-                std::memcpy(nodes + wn, dnodes + x.path_begin, sizeof(uint32_t) * x.path_len);
-                std::memcpy(mismatches + wm, dmism + x.mism_begin, sizeof(uint32_t) * x.n_mismatches);
-                x.path_begin = (uint32_t)wn; x.mism_begin = (uint32_t)wm;
-                extensions[oe[i] + k] = x; wn += x.path_len; wm += x.n_mismatches;
+    vgk_gapless_result* dres = H.dres.get(be, n);
+    vgk_extension* dext = H.dext.get(be, we + 1); uint32_t* dnodes = H.dnodes.get(be, wn + 1); uint32_t* dmism = H.dmism.get(be, wm + 1);
+    if (!dres || !dext || !dnodes || !dmism) return cleanup(VGK_ENOMEM);
+    if ((rc = be->download(dres, O.res_out, sizeof(vgk_gapless_result) * n))) return cleanup(rc);
+    const bool fits = we <= ext_cap && wn <= nodes_cap && wm <= mism_cap && (we == 0 || (extensions && nodes && mismatches));
+    if (fits) {
+        if (we && (rc = be->download(dext, O.ext_out, sizeof(vgk_extension) * we))) return cleanup(rc);
+        if (wn && (rc = be->download(dnodes, O.nodes_out, sizeof(uint32_t) * wn))) return cleanup(rc);
+        if (wm && (rc = be->download(dmism, O.mism_out, sizeof(uint32_t) * wm))) return cleanup(rc);
+        lap("ordered on the device, downloads");
+        // out of the staging buffers in slices, on the host threads
+        struct Span { char* dst; const char* src; size_t bytes; };
+        const Span spans[4] = {{(char*)results, (const char*)dres, sizeof(vgk_gapless_result) * n}, {(char*)extensions, (const char*)dext, sizeof(vgk_extension) * we},
+                               {(char*)nodes, (const char*)dnodes, sizeof(uint32_t) * wn}, {(char*)mismatches, (const char*)dmism, sizeof(uint32_t) * wm}};
+        std::vector<Span> slices;
+        for (const Span& sp : spans) for (size_t at = 0; at < sp.bytes; at += (size_t)8 << 20) slices.push_back({sp.dst + at, sp.src + at, std::min<size_t>((size_t)8 << 20, sp.bytes - at)});
+        parallel_tasks((uint32_t)slices.size(), [&](uint32_t k) { std::memcpy(slices[k].dst, slices[k].src, slices[k].bytes); });
+    } else {
+        // the caller's arrays are too small: the reads whose sets fit behind each other get theirs, the others VGK_EOPS (rare; on the host)
+        if (we && (rc = be->download(dext, O.ext_out, sizeof(vgk_extension) * we))) return cleanup(rc);
+        if (wn && (rc = be->download(dnodes, O.nodes_out, sizeof(uint32_t) * wn))) return cleanup(rc);
+        if (wm && (rc = be->download(dmism, O.mism_out, sizeof(uint32_t) * wm))) return cleanup(rc);
+        uint64_t ae = 0, an = 0, am = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            vgk_gapless_result r = dres[i];
+            if (r.status == VGK_OK) {
+                uint64_t need_n = 0, need_m = 0;
+                for (uint32_t k = 0; k < r.n_ext; ++k) { need_n += dext[r.ext_begin + k].path_len; need_m += dext[r.ext_begin + k].n_mismatches; }
+                if (ae + r.n_ext > ext_cap || an + need_n > nodes_cap || am + need_m > mism_cap || !extensions || !nodes || !mismatches) { r.status = VGK_EOPS; r.n_ext = 0; rc_all = VGK_EOPS; }
+                else {
+                    for (uint32_t k = 0; k < r.n_ext; ++k) {
+                        vgk_extension x = dext[r.ext_begin + k];
+                        std::memcpy(nodes + an, dnodes + x.path_begin, sizeof(uint32_t) * x.path_len);
+                        std::memcpy(mismatches + am, dmism + x.mism_begin, sizeof(uint32_t) * x.n_mismatches);
+                        x.path_begin = (uint32_t)an; x.mism_begin = (uint32_t)am; an += x.path_len; am += x.n_mismatches;
+                        extensions[ae + k] = x;
+                    }
+                    const uint32_t begin = (uint32_t)ae; ae += r.n_ext; r.ext_begin = begin;
+                }
             }
-        } else r.n_ext = 0;
-        results[i] = r;
-    });
-    const size_t we = oe[n], wn = on[n], wm = om[n];
+            if (r.status != VGK_OK) r.ext_begin = (uint32_t)ae;
+            results[i] = r;
+        }
+        if (written) { written[0] = ae; written[1] = an; written[2] = am; }
+        return cleanup(rc_all);
+    }
+    lap("sets copied out");
     if (written) { written[0] = we; written[1] = wn; written[2] = wm; }
     return cleanup(rc_all);
 }

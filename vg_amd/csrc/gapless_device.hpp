@@ -980,4 +980,40 @@ VGK_HD void gapless_rules_one(const GaplessParams& P, uint32_t pi, uint8_t* orde
     gapless_set_rules(P, pi, pb, c, RES, n_res, best_alignment, order);
 }
 
+// ---- the sets in problem order ------------------------------------------------------------------------------------------------------
+// The rules kernel packs finished sets behind each other in completion order.  The caller gets them in problem order; that
+// re-ordering was a pass over a million reads on the host with scattered copies into fresh pages (30 of the 55 ms of a call).  Here:
+// per read the sizes of its set, three prefix sums, one gather — the host then copies three contiguous arrays.
+struct GOrderParams {
+    uint32_t n; const vgk_gapless_result* res; const vgk_extension* ext; const uint32_t* nodes; const uint32_t* mism;
+    uint32_t* size_e; uint32_t* size_n; uint32_t* size_m;                  // [n + 1] each, the last entry 0: the scans' inputs
+    const uint32_t* off_e; const uint32_t* off_n; const uint32_t* off_m;    // their exclusive prefix sums
+    vgk_gapless_result* res_out; vgk_extension* ext_out; uint32_t* nodes_out; uint32_t* mism_out;
+};
+VGK_HD void g_order_sizes_one(const GOrderParams& P, uint32_t i) {
+    const vgk_gapless_result r = P.res[i];
+    uint32_t nn = 0, nm = 0;
+    if (r.status == VGK_OK) for (uint32_t k = 0; k < r.n_ext; ++k) { nn += P.ext[r.ext_begin + k].path_len; nm += P.ext[r.ext_begin + k].n_mismatches; }
+    P.size_e[i] = r.status == VGK_OK ? r.n_ext : 0u; P.size_n[i] = nn; P.size_m[i] = nm;
+}
+VGK_HD void g_order_gather_one(const GOrderParams& P, uint32_t i) {
+    vgk_gapless_result r = P.res[i];
+    const uint32_t src = r.ext_begin;
+    r.ext_begin = P.off_e[i];
+    if (r.status == VGK_OK) {
+        uint32_t wn = P.off_n[i], wm = P.off_m[i];
+        for (uint32_t k = 0; k < r.n_ext; ++k) {
+            vgk_extension x = P.ext[src + k];
+            for (uint32_t j = 0; j < x.path_len; ++j) P.nodes_out[wn + j] = P.nodes[x.path_begin + j];
+            for (uint32_t j = 0; j < x.n_mismatches; ++j) P.mism_out[wm + j] = P.mism[x.mism_begin + j];
+            x.path_begin = wn; x.mism_begin = wm;
+            P.ext_out[r.ext_begin + k] = x;
+            wn += x.path_len; wm += x.n_mismatches;
+        }
+    } else r.n_ext = 0;
+    P.res_out[i] = r;
+}
+// ReadMasker (src/gbwt_extender.cpp:160-176) on the device: anything but ACGT never matches
+VGK_HD char g_mask_base(char c) { return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'X'; }
+
 }  // namespace vgk
