@@ -252,6 +252,70 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
         dist.destroy_process_group()
 
 
+def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
+    """configs[4] as reads (secondary line): 15 kbp HiFi-like reads cut at their anchors; every stretch between anchors through
+    WFAExtender (connect / prefix / suffix), the connects it gives up on through BandedGlobalAligner between the two anchors
+    (vg_amd/pipeline.py chain_stage; src/minimizer_mapper.cpp:2955-3100).  One step = both calls for the whole batch from host buffers."""
+    import numpy as np
+    from vg_amd import capi, pipeline, shard, workloads
+    n = args.reads if args.reads else 4000
+    t0 = time.perf_counter()
+    wl = workloads.LongReadWorkload(n, seed=515 + rank)
+    t_gen = time.perf_counter() - t0
+    index = eng.haplo_index(wl.nodes, wl.threads)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        out = pipeline.chain_stage(eng, index, wl)
+    barrier()
+    timing = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pipeline.chain_stage(eng, index, wl, timing=timing)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    cpu = parity = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
+        cores = shard.usable_cpus(); ora.lib.vgo_set_threads(cores)
+        oidx = ora.haplo_index(wl.nodes, wl.threads)
+        t1 = time.perf_counter(); o = pipeline.chain_stage(ora, oidx, wl); tc = time.perf_counter() - t1
+        same = int((o["chain_score"] == out["chain_score"]).sum())
+        cpu = {"value": n / tc, "unit": "reads/s", "cores": cores, "kind": "port", "impl": "the same two calls over the oracle: vgo_wfa.c, vgo_banded.c (OpenMP over problems)",
+               "sample": "all %d reads" % n}
+        parity = {"checked": n, "identical": same, "what": "per-read chain score (anchors + every stretch between them); the engine sends the connects its WFA tables "
+                  "cannot hold to the banded aligner, the oracle's WFA has no such limit: equal scores are the check that both routes find the optimum"}
+    if rank == 0:
+        res = out["wfa"]
+        print(json.dumps({
+            "metric": "15 kbp reads/sec through the chain alignment stage (WFA between anchors, banded global alignment as fallback)",
+            "value": n * world * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+            "config": {"workload": "configs[4]: 1 Mbp variation graph, 8 random haplotype threads, %d reads of 15 000 bp per GPU on either strand, error-free 29-mer anchors every "
+                                   "120-400 bp, 0.5 %% errors between them (half substitutions, half 1-bp indels), 1 %% of the connects with a 25-60 bp insertion; "
+                                   "WFAExtender connect / prefix / suffix with the default error model, BandedGlobalAligner (permissive band) for what it rejects" % n,
+                       "timed_region": "per step, from host buffers: vgk_wfa_extend over every stretch, the fallback problems built on the host, vgk_banded_align",
+                       "problems": wl.n, "problems_per_read": wl.n / n, "read_bases": wl.read_bases, "bases_per_s": wl.read_bases * world * args.steps / elapsed,
+                       "wfa_ok": int((res["ok"] != 0).sum()), "fallbacks": int(len(out["failed"])), "wfa_declined_by_engine_tables": int((res["status"] != 0).sum()),
+                       "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()}, "wfa_kernel_ms": eng.lib.vgk_wfa_last_ms(eng.h) if hasattr(eng.lib, "vgk_wfa_last_ms") else None,
+                       "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
+            "roofline": {"bound": "hbm", "kernel": "wfa_kernel", "limiter": "the critical path of the slowest problem of a launch, then memory latency (DESIGN.md §16)",
+                         "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
+            "cpu_baseline": cpu, "parity": parity,
+            "problems_failed": int((out["banded"]["status"] != 0).sum()) if "banded" in out else 0}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
     """configs[2]'s alignment stage as giraffe runs it (secondary line): seeds -> haplotype-consistent gapless extension -> for the
     clusters no full-length extension resolves, tail forests -> the trees as left-pinned X-drop windows -> total scores
@@ -590,7 +654,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--host-pack", action="store_true", help="linear workload: one explicit graph per problem, packed on host threads (vgk_gssw_pack) instead of windows of the resident graph packed on the device")
     ap.add_argument("--no-e2e", action="store_true", help="skip the legs that overlap launches — the two-lane steady state and the warm / double-buffered end-to-end legs — so that a profiler's per-kernel averages are each kernel's own")
-    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband", "forest", "giraffe"], default="linear",
+    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband", "forest", "giraffe", "longread"], default="linear",
                     help="linear = BASELINE.json configs[1] (the headline metric); tails = configs[2] stand-in: "
                          "giraffe-style pinned X-drop tail alignments on a variation graph; banded = configs[4] stand-in: "
                          "banded global alignments between chained anchors; gapless = giraffe's first stage: "
@@ -630,6 +694,8 @@ def main():
     eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), device=local_rank, lib=eng_lib)
     dev_name, cus, hbm = eng.device_info()
 
+    if args.workload == "longread":
+        return bench_longread(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "giraffe":
         return bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "forest":

@@ -177,3 +177,32 @@ def align_stage_native(eng, index, oriented_len, gs, ops_per_problem=32, scoring
         for k, v in zip(("tails derived (host)", "tail_forest", "windows + bases (host)", "pack_windows", "fill + traceback + fetch", "totals (host)"), ms):
             timing[k] = timing.get(k, 0.0) + v * 1e-3
     return dict(res=res, ext=ext, nodes=nodes, ext_total=ext_total[:n_ext], read_score=read_score[:gs.n], stats=tuple(int(x) for x in stats))
+
+
+# ---- configs[4]: a long read cut at its anchors (workloads.LongReadWorkload) -------------------------------------------------------
+def chain_stage(eng, index, wl, match=1, timing=None):
+    """Every stretch between anchors through WFAExtender (vgk_wfa_extend: connect / prefix / suffix); the connects it gives up on —
+    score cap, tables — through BandedGlobalAligner between the two anchors (vgk_banded_align), as giraffe's chain alignment does
+    (src/minimizer_mapper.cpp:2955-3100).  -> dict: wfa results, the fallback's results, per-read chain score."""
+    import time
+    t0 = [time.perf_counter()]
+
+    def lap(what):
+        if timing is not None:
+            t = time.perf_counter(); timing[what] = timing.get(what, 0.0) + t - t0[0]; t0[0] = t
+
+    res, paths, edits = eng.wfa_extend(index, wl.ws); lap("wfa_extend")
+    mode = wl.ws.array["mode"]
+    failed = np.nonzero((mode == capi.WFA_CONNECT) & ((res["status"] != 0) | (res["ok"] == 0)))[0]
+    score = np.where((res["status"] == 0) & (res["ok"] != 0), res["score"], 0).astype(np.int64)
+    out = dict(wfa=res, failed=failed)
+    if len(failed):
+        bs = capi.BandedSet.from_lists([wl.between(int(i)) for i in failed]); lap("fallback problems (host)")
+        bres, bops = eng.banded_align(bs); lap("banded_align")
+        score[failed] = np.where(bres["status"] == 0, bres["score"], 0)
+        out.update(banded=bres, banded_ops=bops)
+    chain = np.zeros(wl.n_reads, dtype=np.int64)
+    np.add.at(chain, wl.read_of, score)
+    chain += wl.anchor_bases * match
+    out.update(segment_score=score, chain_score=chain); lap("totals (host)")
+    return out

@@ -733,3 +733,120 @@ class TailForestWorkload:
         r = results[lo:hi]
         return capi.WindowSet(self.reads[self.read_off[lo]:self.read_off[hi]], self.read_off[lo:hi + 1] - self.read_off[lo], r["first_node"], r["n_nodes"],
                               capi.VGK_XDROP_PINNED | capi.VGK_GSSW_TRACEBACK, self.max_gap[lo:hi], cols=r["bases"])
+
+
+class LongReadWorkload:
+    """configs[4] as reads, not as loose windows: `n_reads` HiFi-like reads of `read_len` bases, each a walk along a haplotype
+    thread (either strand) cut at ANCHORS — error-free 29-mers every 120-400 bases, what the chaining stage hands on — so that a read
+    becomes: prefix, anchor, connect, anchor, ..., connect, anchor, suffix.  The stretches between anchors carry 0.5 % errors (half
+    substitutions, half 1-bp indels); `sv_fraction` of the connects additionally carry a 25-60 bp insertion, which WFAExtender's
+    score cap rejects: those fall back to BandedGlobalAligner between the two anchors, as MinimizerMapper does
+    (src/minimizer_mapper.cpp:2955-3100, :3925).  Problems are laid out read by read; `read_of[i]` names problem i's read."""
+
+    def __init__(self, n_reads, seed=515, graph_bp=1_000_000, n_haplotypes=8, read_len=15_000, anchor_len=29, min_gap=120, max_gap=400,
+                 error_rate=0.005, sv_fraction=0.01, snp_every=100, indel_every=1000):
+        rng = np.random.default_rng(seed)
+        seqs, preds, kind = build_variation_graph(rng, graph_bp, snp_every, indel_every)
+        lens = np.array([len(s) for s in seqs], dtype=np.int64)
+        succ = [[] for _ in seqs]
+        for v, pr in enumerate(preds):
+            for p in pr:
+                succ[p].append(v)
+        self.nodes = [s.tobytes().decode() for s in seqs]
+        self.preds = preds; self.lens = lens
+        threads = []
+        for _ in range(n_haplotypes):
+            t = [0]; v = 0
+            while succ[v]:
+                v = succ[v][int(rng.integers(0, len(succ[v])))]
+                t.append(v)
+            threads.append(np.array(t, dtype=np.int64))
+        self.threads = [list((2 * t).astype(int)) for t in threads]
+        comp = _comp_table()
+        hap_seq = [np.concatenate([seqs[v] for v in t]) for t in threads]
+        hap_start = [np.concatenate([[0], np.cumsum(lens[t])]) for t in threads]
+        pieces, mode, fn, fo, tn, to, read_of, span, truth = [], [], [], [], [], [], [], [], []
+        self.anchor_bases = np.zeros(n_reads, dtype=np.int64)
+        for r in range(n_reads):
+            h = int(rng.integers(0, n_haplotypes)); rev = bool(rng.random() < 0.5)
+            hs, st, t = hap_seq[h], hap_start[h], threads[h]
+            a0 = int(rng.integers(1, len(hs) - read_len - 400))
+            # forward-strand segmentation: [tail][anchor][gap][anchor]...[anchor][tail]
+            cuts = [a0 + int(rng.integers(20, 100))]
+            while cuts[-1] + anchor_len + max_gap + anchor_len + 100 < a0 + read_len:
+                cuts.append(cuts[-1] + anchor_len + int(rng.integers(min_gap, max_gap + 1)))
+            anchors = [(c, c + anchor_len) for c in cuts]              # [begin, end) on the forward strand
+            end = a0 + read_len
+            segs = [("tail0", a0, anchors[0][0])] + [("connect", anchors[i][1], anchors[i + 1][0]) for i in range(len(anchors) - 1)] + [("tail1", anchors[-1][1], end)]
+            if rev:
+                segs = segs[::-1]
+            self.anchor_bases[r] = anchor_len * len(anchors)
+
+            def pos(g):
+                k = int(np.searchsorted(st, g, side="right") - 1)
+                node = int(t[k]); off = int(g - st[k])
+                return (2 * node + 1, int(lens[node]) - 1 - off) if rev else (2 * node, off)
+            for what, lo, hi in segs:
+                w = hs[lo:hi]
+                if rev:
+                    w = comp[w[::-1]]
+                e = rng.random(len(w)) < error_rate
+                if e.any():
+                    out = []
+                    for c, bad in zip(w, e):
+                        if not bad:
+                            out.append(c); continue
+                        x = rng.random()
+                        if x < 0.5:
+                            out.append(ACGT[int(rng.integers(0, 4))])
+                        elif x >= 0.75:
+                            out.append(c); out.append(ACGT[int(rng.integers(0, 4))])
+                    w = np.array(out, dtype=np.uint8) if out else np.zeros(0, np.uint8)
+                if what == "connect" and rng.random() < sv_fraction:
+                    at = int(rng.integers(0, len(w) + 1))
+                    w = np.concatenate([w[:at], ACGT[rng.integers(0, 4, int(rng.integers(25, 61)))], w[at:]])
+                # on the read's strand the segment lies between the bases flanking it: from = the base before, to = the base after (exclusive)
+                before, after = (lo - 1, hi) if not rev else (hi, lo - 1)
+                first_on_read = (what == "tail0") != rev                # the read's own first segment has no anchor before it
+                last_on_read = (what == "tail1") != rev
+                if first_on_read and what != "connect":
+                    mode.append(capi.WFA_PREFIX); fn.append(capi.WFA_NO_NODE); fo.append(0); p = pos(after); tn.append(p[0]); to.append(p[1])
+                elif last_on_read and what != "connect":
+                    mode.append(capi.WFA_SUFFIX); p = pos(before); fn.append(p[0]); fo.append(p[1]); tn.append(capi.WFA_NO_NODE); to.append(0)
+                else:
+                    mode.append(capi.WFA_CONNECT); p = pos(before); fn.append(p[0]); fo.append(p[1]); p = pos(after); tn.append(p[0]); to.append(p[1])
+                pieces.append(w); read_of.append(r); span.append(hi - lo); truth.append((lo, hi, rev, h))
+        seq_off = np.concatenate([[0], np.cumsum([len(p) for p in pieces])]).astype(np.int64)
+        buf = np.concatenate(pieces) if seq_off[-1] else np.zeros(1, np.uint8)
+        n = len(pieces)
+        self.ws = capi.WfaSet(buf, seq_off, np.array(mode, dtype=np.uint32), np.array(fn, dtype=np.uint32), np.array(fo, dtype=np.uint32),
+                              np.array(tn, dtype=np.uint32), np.array(to, dtype=np.uint32), path_cap=n * 24 + int(seq_off[-1]) // 4, edit_cap=n * 12)
+        self.n = n; self.n_reads = n_reads; self.read_of = np.array(read_of); self.span = np.array(span); self.truth = truth
+        self.read_bases = int(seq_off[-1]) + int(self.anchor_bases.sum())
+        self.hap_start = hap_start; self.thread_nodes = threads
+
+    def between(self, i):
+        """the graph between problem i's anchors as a banded-global problem on the FORWARD strand: every node of the topological order from
+        the node of the first flanking base to the node of the last, the outer two cut at the flanks; the sequence reverse-complemented
+        when the read runs on the other strand (BandedGlobalAligner aligns end to end, so the strand is free to choose)"""
+        lo, hi, rev, h = self.truth[i]
+        st, t = self.hap_start[h], self.thread_nodes[h]
+        ka = int(np.searchsorted(st, lo - 1, side="right") - 1); kb = int(np.searchsorted(st, hi, side="right") - 1)
+        va, vb = int(t[ka]), int(t[kb])
+        oa = lo - 1 - int(st[ka]) + 1                                   # first base kept on the first node
+        ob = hi - int(st[kb])                                           # bases kept on the last node
+        nodes = []
+        for v in range(va, vb + 1):
+            s = self.nodes[v]
+            if v == va and v == vb:
+                s = s[oa:ob]
+            elif v == va:
+                s = s[oa:]
+            elif v == vb:
+                s = s[:ob]
+            nodes.append(s)
+        preds = [[p - va for p in self.preds[v] if va <= p] for v in range(va, vb + 1)]
+        seq = self.ws.seqs[self.ws.seq_off[i]:self.ws.seq_off[i + 1]]
+        if rev:
+            seq = _comp_table()[seq[::-1]]
+        return dict(read=seq.tobytes().decode(), nodes=nodes, preds=preds, band_padding=int(np.sqrt(max(len(seq), 1))) + 1 + 64, permissive=True)
