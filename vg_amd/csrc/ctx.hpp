@@ -33,6 +33,7 @@ struct vgk_ctx {
     double gapless_ms = 0;         // kernel time of the last vgk_gapless_extend call
     uint64_t gapless_retried = 0;  // reads of that call whose search outgrew the fast kernel's LDS store and ran in the slab kernel
     double wfa_ms = 0;             // and of the last vgk_wfa_extend call
+    uint32_t wfa_point_budget = 0; // vgk_wfa_set_point_budget (0 = the table's size)
     double tail_ms = 0;            // device time of the last vgk_tail_forest call
     // the last batch of either call stays resident in the cached device buffers: what a re-run needs to launch it again
     vgk::BandedParams banded_last{}; std::vector<vgk::BandedLaunch> banded_last_launches; bool banded_last_valid = false;

@@ -87,6 +87,7 @@ struct WfaParams {
     uint32_t* paths; uint32_t* edits;
     unsigned long long* counters;     // [0] path entries, [1] edits handed out, [2] next problem
     unsigned long long caps[2];
+    uint32_t max_points;              // stored wavefront points after which a problem is given up (<= W_POINTS; vgk_wfa_set_point_budget)
 };
 
 struct WPos { uint32_t seq, off; uint8_t cur, origin; bool empty; };
@@ -142,7 +143,7 @@ VGK_HD void w_store(WCtx& c, uint32_t node, int kind, int32_t score, int32_t dia
     for (uint32_t i = w_hash(key);; i = (i + 1) & (W_SLOTS - 1)) {
         const uint64_t s = c.S->slot[i];
         if (!s) {
-            if (c.n_points >= (uint32_t)W_POINTS) { c.overflow = true; c.why = 1; return; }
+            if (c.n_points >= c.P->max_points) { c.overflow = true; c.why = 1; return; }
             c.S->log[c.n_points++] = (uint16_t)i; c.S->slot[i] = v; return;
         }
         if ((uint32_t)(s >> 32) == key) { c.S->slot[i] = v; return; }

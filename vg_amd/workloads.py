@@ -829,6 +829,9 @@ class LongReadWorkload:
         """the graph between problem i's anchors as a banded-global problem on the FORWARD strand: every node of the topological order from
         the node of the first flanking base to the node of the last, the outer two cut at the flanks; the sequence reverse-complemented
         when the read runs on the other strand (BandedGlobalAligner aligns end to end, so the strand is free to choose)"""
+        cache = self.__dict__.setdefault("_between", {})          # (the extraction between two anchors is the caller's — vg's extract_connecting_graph; once per problem here)
+        if i in cache:
+            return cache[i]
         lo, hi, rev, h = self.truth[i]
         st, t = self.hap_start[h], self.thread_nodes[h]
         ka = int(np.searchsorted(st, lo - 1, side="right") - 1); kb = int(np.searchsorted(st, hi, side="right") - 1)
@@ -849,4 +852,5 @@ class LongReadWorkload:
         seq = self.ws.seqs[self.ws.seq_off[i]:self.ws.seq_off[i + 1]]
         if rev:
             seq = _comp_table()[seq[::-1]]
-        return dict(read=seq.tobytes().decode(), nodes=nodes, preds=preds, band_padding=int(np.sqrt(max(len(seq), 1))) + 1 + 64, permissive=True)
+        cache[i] = dict(read=seq.tobytes().decode(), nodes=nodes, preds=preds, band_padding=int(np.sqrt(max(len(seq), 1))) + 1 + 64, permissive=True)
+        return cache[i]
