@@ -6,11 +6,11 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-prof_r02}
 mkdir -p $OUT
 B="python $GRAFT_REPO_ROOT/bench.py --no-cpu"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r02 -- $B --steps 3 --warmup 1 --no-e2e > $OUT/stats.log 2>&1     # (the streaming legs overlap launches: their wall times are not per-kernel times)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r02 -- $B --steps 3 --warmup 1 --no-e2e > $OUT/stats.log 2>&1     # (the streaming legs overlap launches: their wall times are not per-kernel times)
 # hardware counters: separate passes, kernel-trace only (HBM bytes per MI355X_MICROARCH.md §HBM)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o r02 -- $B --steps 1 --warmup 0 --no-e2e --reads 400000 > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o r02 -- $B --steps 1 --warmup 0 --no-e2e --reads 400000 > $OUT/write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -o r02 -- $B --steps 1 --warmup 0 --no-e2e --reads 400000 > $OUT/sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o r02 -- $B --steps 1 --warmup 0 --no-e2e --reads 400000 > $OUT/fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o r02 -- $B --steps 1 --warmup 0 --no-e2e --reads 400000 > $OUT/write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -o r02 -- $B --steps 1 --warmup 0 --no-e2e --reads 400000 > $OUT/sq.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 for what in ("fetch", "write", "sq"):
