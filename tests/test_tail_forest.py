@@ -283,3 +283,21 @@ def test_forests_on_the_gpu_equal_the_trie_of_thread_continuations():
 def test_tails_of_gapless_extensions_through_their_forests_on_the_gpu():
     n_tails, n_trees = run_tails_through_forests(ENGINE_LIB, 12, 1500)
     assert n_tails > 700
+
+
+def test_a_walk_deeper_than_the_kernels_stack_is_declined(emu_lib):
+    """600 one-base nodes in a row and a walk of 1000 bases: the path alone is deeper than the kernel's 512 frames -> VGK_ETOOBIG for
+    that tail only; the oracle (a stack that grows) answers it; the other tails of the batch are untouched."""
+    nodes = ["ACGT"[i % 4] for i in range(600)] + ["ACGTACGTAC"]
+    threads = [[2 * i for i in range(601)]]
+    probs = [(0, 0, 0, 0, 40), (0, 0, 0, 0, 1000), (2 * 10, 0, 0, 0, 25)]
+    eng = capi.Engine(lib=emu_lib); ora = capi.Engine(lib=ORACLE_LIB)
+    res, forest = eng.tail_forest(eng.haplo_index(nodes, threads), probs)
+    ores, oforest = ora.tail_forest(ora.haplo_index(nodes, threads), probs)
+    assert list(ores["status"]) == [0, 0, 0] and ores["n_nodes"][1] == 601
+    assert res["status"][1] == -7 and res["n_nodes"][1] == 0
+    for i in (0, 2):
+        assert res["status"][i] == 0 and res["n_nodes"][i] == ores["n_nodes"][i] == (40 if i == 0 else 25)
+    assert res["first_node"][2] == res["n_nodes"][0] and forest.size == 65
+    p, n, l = forest.fetch()
+    assert list(n[:40]) == [2 * i for i in range(40)] and list(p[:40]) == [-1] + list(range(39))

@@ -65,6 +65,7 @@ VGK_HD bool t_follow(const uint32_t* rec, int32_t lo, int32_t hi, uint32_t e, bo
 VGK_HD void tail_walk_one(const TailParams& P, uint32_t i, TScratch& S) {
     const GIndex& h = P.index;
     const vgk_tail_problem pb = P.probs[i];
+    if (P.pass == 2 && P.results[i].status != VGK_OK) return;                // declined in the sizing pass: it has no room in the forest, and its result stands
     vgk_tail_result out; out.status = VGK_OK; out.first_node = P.pass == 2 ? P.first[i] : 0u; out.n_nodes = 0; out.n_trees = 0; out.root_trim = 0; out.bases = 0;
     auto done = [&]() { if (P.pass == 1) P.counts[i] = out.status == VGK_OK ? out.n_nodes : 0u; if (out.status != VGK_OK) { out.n_nodes = 0; out.n_trees = 0; out.bases = 0; } P.results[i] = out; };
     if (pb.node >= h.n_oriented) { out.status = VGK_EINVAL; done(); return; }
