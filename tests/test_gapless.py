@@ -354,3 +354,21 @@ def test_run_length_encoded_records_with_many_haplotypes(monkeypatch):
 @pytest.mark.gpu
 def test_run_length_encoded_records_with_many_haplotypes_on_the_gpu():
     many_haplotypes(util.ENGINE_LIB, 2000)
+
+
+def test_output_arrays_too_small_are_reported_not_overrun():
+    """the caller's extension array holds 20 of the ~55 extensions: VGK_EOPS from the engine (emulated) and from the oracle alike"""
+    import subprocess
+    from util import EMU_LIB, ORACLE_LIB, ROOT
+    from vg_amd import workloads
+    subprocess.check_call(["make", "-s", "emu"], cwd=ROOT)
+    wl = workloads.GaplessWorkload(50, seed=5, graph_bp=30000)
+    for lib in (EMU_LIB, ORACLE_LIB):
+        eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=lib)
+        idx = eng.haplo_index(wl.nodes, wl.threads)
+        res, ext, _, _ = eng.gapless_extend(idx, wl.gs)
+        assert len(ext) > 20
+        small = workloads.GaplessWorkload(50, seed=5, graph_bp=30000).gs
+        small.ext_cap = 20
+        with pytest.raises(capi.VgkError, match="too small"):
+            eng.gapless_extend(idx, small)
