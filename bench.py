@@ -347,19 +347,39 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
         torch.cuda.synchronize()
 
     stage = pipeline.align_stage if os.environ.get("VGAMD_GIRAFFE_NUMPY_GLUE") else pipeline.align_stage_native      # the glue in the host shim (C++) or in numpy
-    for _ in range(max(1, args.warmup)):
-        out = stage(eng, index, olen, wl.gs)
+    from_reads = bool(os.environ.get("VGAMD_GIRAFFE_FROM_READS"))         # start from the bare reads: minimizer seeding on the device makes the clusters
+    mindex = None; seeds_per_read = None; t_index = 0.0
+    if from_reads:
+        t1 = time.perf_counter(); mindex = eng.minimizer_index(wl.nodes, wl.threads); t_index = time.perf_counter() - t1
+
+    def one_step(timing=None):
+        gs = wl.gs
+        if from_reads:
+            t1 = time.perf_counter()
+            seed_off, seeds, mins = eng.minimizer_seeds(mindex, index, wl.gs.reads, wl.gs.read_off)
+            t2 = time.perf_counter()
+            gs = capi.GaplessSet(wl.gs.reads, wl.gs.read_off, seeds, seed_off, node_cap=len(seeds) * 16, mism_cap=len(seeds) * 12)
+            if timing is not None:
+                timing["minimizer_seeds"] = timing.get("minimizer_seeds", 0.0) + t2 - t1
+                timing["minimizer_seeds (device)"] = timing.get("minimizer_seeds (device)", 0.0) + eng.minimizer_last_ms() * 1e-3
+                timing["clusters assembled (host)"] = timing.get("clusters assembled (host)", 0.0) + time.perf_counter() - t2
+        out = stage(eng, index, olen, gs, timing=timing)
         if "forest" in out:
             out["forest"].close()
+        out["gs"] = gs
+        return out
+
+    for _ in range(max(1, args.warmup)):
+        out = one_step()
     barrier()
     t0 = time.perf_counter()
     timing = {}
     for _ in range(args.steps):
-        out = stage(eng, index, olen, wl.gs, timing=timing)
-        if "forest" in out:
-            out["forest"].close()
+        out = one_step(timing)
     barrier()
     elapsed = time.perf_counter() - t0
+    if from_reads:
+        seeds_per_read = float(np.diff(out["gs"].seed_off).mean())
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -370,9 +390,15 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
         ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
         cores = shard.usable_cpus(); ora.lib.vgo_set_threads(cores)
         k = min(n, args.cpu_sample or 200_000)
-        sub = capi.GaplessSet(wl.gs.reads[:wl.gs.read_off[k]], wl.gs.read_off[:k + 1], wl.gs.seeds[:wl.gs.seed_off[k]], wl.gs.seed_off[:k + 1])
         oidx = ora.haplo_index(wl.nodes, wl.threads)
-        t1 = time.perf_counter(); o = pipeline.align_stage(ora, oidx, olen, sub); tc = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        if from_reads:
+            omi = ora.minimizer_index(wl.nodes, wl.threads); t1 = time.perf_counter()
+            so, sd, _ = ora.minimizer_seeds(omi, oidx, wl.gs.reads[:wl.gs.read_off[k]], wl.gs.read_off[:k + 1])
+            sub = capi.GaplessSet(wl.gs.reads[:wl.gs.read_off[k]], wl.gs.read_off[:k + 1], sd, so, node_cap=len(sd) * 16, mism_cap=len(sd) * 12)
+        else:
+            sub = capi.GaplessSet(wl.gs.reads[:wl.gs.read_off[k]], wl.gs.read_off[:k + 1], wl.gs.seeds[:wl.gs.seed_off[k]], wl.gs.seed_off[:k + 1])
+        o = pipeline.align_stage(ora, oidx, olen, sub); tc = time.perf_counter() - t1
         same = int((o["read_score"] == out["read_score"][:k]).sum())
         cpu = {"value": k / tc, "unit": "reads/s", "cores": cores, "kind": "port",
                "impl": "the same pipeline over the oracle: vgo_gapless.c (OpenMP over reads), vgo_tail.c (one thread), vgo_xdrop.c (OpenMP over problems)",
@@ -388,6 +414,7 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
                                    "inserted base, 4.0 seeds per read at true positions; GaplessExtender + get_tail_forest + align_pinned(xdrop) semantics, scores 1/4/6/1/5" % (n, int(100 * inserted)),
                        "timed_region": "per step, from host buffers: vgk_gapless_extend (results back on the host), then the host shim's run_tail_stage (vg_amd/host/tail_stage.cpp): "
                                        "tails derived on host threads, vgk_tail_forest, one window per tree, vgk_gssw_pack_windows + run + fetch, totals", "reads_without_full_length_extension": open_reads, "tails": n_tails,
+                       "clusters_from": "minimizer seeding on the device (k 29, w 11; %.1f seeds per read; index of %d minimizer k-mers built in %.1f s)" % (seeds_per_read, mindex.keys, t_index) if from_reads else "seeds given (true positions)",
                        "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()},
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
             "roofline": {"bound": "hbm", "kernel": "gapless_search_kernel (the stage's largest kernel)", "limiter": "host glue and PCIe round trips between the stages, then memory latency (DESIGN.md §11, §17)",

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define VGK_ABI_VERSION 3
+#define VGK_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -365,6 +365,27 @@ int  vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_
 int    vgk_gapless_rerun(vgk_ctx* ctx);      /* launch the kernel of the last vgk_gapless_extend call again on its resident inputs */
 double vgk_gapless_last_ms(vgk_ctx* ctx);    /* kernel time of the last vgk_gapless_extend call on this context */
 uint64_t vgk_gapless_last_retried(vgk_ctx* ctx);   /* reads of that call whose search outgrew the fast (in-LDS) kernel and ran in the slab kernel */
+
+/* ---- minimizer seeding (MinimizerMapper::find_minimizers / find_seeds over gbwtgraph::MinimizerIndex, src/minimizer_mapper.cpp:3918-3965,
+ * :4109-4290): the step that produces the clusters vgk_gapless_extend takes ------------------------------------------------------
+ * vgk_minimizer_index_create indexes the (k, w)-minimizers of every haplotype thread (k <= 31, w <= 32; giraffe's defaults 29, 11)
+ * with the graph positions they start at; vgk_minimizer_seeds finds the minimizers of a batch of reads on the device, looks each up
+ * and turns every hit into a seed (oriented node, read offset - node offset) on the strand the read reads forward on.  Per read the
+ * seeds come in the order of their minimizers' read offsets; a (node, diagonal) pair hit twice is reported once (a cluster is a set);
+ * minimizers with more than `hit_cap` hits give no seeds (hard_hit_cap); at most 64 seeds per read (what a cluster of the extension
+ * stage holds).  [PARITY-UNPINNED: gbwtgraph is not in the reference snapshot; vg_amd/csrc/minimizer_device.hpp states the scheme
+ * restated here — 2-bit keys, Wang's 64-bit hash, the smaller-hash orientation canonical, leftmost minimum per window.  Seed
+ * SCORING and the downsampling / hit-cap policies of find_seeds (:4140-4290), and the clustering of seeds by graph distance
+ * (SnarlDistanceIndexClusterer), are the caller's.] */
+typedef struct vgk_minimizer_index vgk_minimizer_index;
+int  vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* haplotypes, uint32_t k, uint32_t w, vgk_minimizer_index** out);
+void vgk_minimizer_index_destroy(vgk_minimizer_index* index);
+uint64_t vgk_minimizer_index_keys(const vgk_minimizer_index* index);      /* distinct minimizer k-mers */
+/* reads: flat, read i = reads[read_off[i], read_off[i + 1]).  seed_off[n + 1] and, nullable, minimizers[n] (minimizers per read) are
+ * filled always; seeds up to seeds_cap (VGK_EOPS when that is too small; *written = the number needed). */
+int  vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* index, const vgk_haplo* graph, const char* reads, const uint64_t* read_off, uint32_t n,
+                         uint32_t hit_cap, uint32_t* seed_off, uint32_t* minimizers, vgk_seed* seeds, size_t seeds_cap, size_t* written);
+double vgk_minimizer_last_ms(vgk_ctx* ctx);                              /* device time of the last vgk_minimizer_seeds call */
 
 /* ---- haplotype-consistent wavefront alignment (WFAExtender, src/gbwt_extender.cpp:2052-2263) ------------
  * Replaces WFAExtender::connect(sequence, from, to), ::suffix(sequence, from) and ::prefix(sequence, to)

@@ -1,0 +1,147 @@
+/*
+ * vgo_minimizer.c — CPU ORACLE for minimizer seeding (first half).
+ *
+ * TEST INFRASTRUCTURE ONLY (see vgo_engine.c): never linked or loaded by the product path.
+ *
+ * What MinimizerMapper::find_minimizers / find_seeds (src/minimizer_mapper.cpp:3918-3965, :4109-4290) get from gbwtgraph's
+ * MinimizerIndex — minimizer_regions(sequence) and find(minimizer) — restated from the published scheme [prior knowledge; gbwtgraph is
+ * an un-vendored submodule, absent from the snapshot]: k-mers as 2-bit keys, Thomas Wang's 64-bit hash, the orientation with the
+ * smaller hash canonical, the leftmost smallest candidate of every window of w k-mers, each position once; the index files the
+ * minimizers of every haplotype thread under the position their canonical orientation starts at.  Written the plain way — every
+ * window scanned in full, the index a sorted array searched by bisection — where the engine keeps a ring and a hash table.
+ *
+ * Parity status: PARITY-UNPINNED against the reference (no vectors for this path in the snapshot).  tests/test_minimizer.py pins this
+ * file and the engine on a third, brute-force construction in Python and on the property that matters downstream: every seed of a
+ * read sampled from a haplotype lies on the read's true diagonal.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/vgk.h"
+
+typedef struct { uint64_t key, hash; uint32_t node, offset; } Entry;
+struct vgk_minimizer_index { uint32_t k, w, n_nodes; uint32_t* node_len; Entry* e; size_t n; uint64_t n_keys; };
+
+static uint64_t wang(uint64_t key) {
+    key = (~key) + (key << 21); key ^= key >> 24; key = (key + (key << 3)) + (key << 8); key ^= key >> 14;
+    key = (key + (key << 2)) + (key << 4); key ^= key >> 28; key += key << 31;
+    return key;
+}
+static int code(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+static char comp(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
+
+/* canonical k-mer at seq[p, p + k): 0 when it holds a character that is not ACGT */
+static int kmer_at(const char* seq, uint32_t p, uint32_t k, uint64_t* key, uint64_t* hash, int* reverse) {
+    uint64_t f = 0, r = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        const int x = code(seq[p + i]); if (x < 0) return 0;
+        f = (f << 2) | (uint64_t)x;
+        r |= (uint64_t)(3 - x) << (2 * i);
+    }
+    const uint64_t hf = wang(f), hr = wang(r);
+    *reverse = hr < hf; *hash = *reverse ? hr : hf; *key = *reverse ? r : f;
+    return 1;
+}
+/* minimizers of seq[0, L): for every window of w k-mers the leftmost smallest candidate; positions ascending, each once */
+typedef void (*emit_fn)(void* ctx, uint32_t p, uint64_t key, uint64_t hash, int reverse);
+static void minimizers(const char* seq, uint32_t L, uint32_t k, uint32_t w, emit_fn emit, void* ctx) {
+    if (L < k + w - 1) return;
+    const uint32_t n = L - k + 1;
+    uint64_t* key = (uint64_t*)malloc(sizeof(uint64_t) * n); uint64_t* hash = (uint64_t*)malloc(sizeof(uint64_t) * n);
+    int* rev = (int*)malloc(sizeof(int) * n); char* ok = (char*)malloc(n);
+    for (uint32_t p = 0; p < n; ++p) ok[p] = (char)kmer_at(seq, p, k, &key[p], &hash[p], &rev[p]);
+    int64_t last = -1;
+    for (uint32_t s = 0; s + w <= n; ++s) {
+        int64_t best = -1;
+        for (uint32_t p = s; p < s + w; ++p) if (ok[p] && (best < 0 || hash[p] < hash[best])) best = p;
+        if (best >= 0 && best != last) { emit(ctx, (uint32_t)best, key[best], hash[best], rev[best]); last = best; }
+    }
+    free(key); free(hash); free(rev); free(ok);
+}
+
+typedef struct { Entry* e; size_t n, cap; const uint32_t* tn; const uint64_t* start; const uint32_t* step; const uint32_t* node_len; uint32_t k; int oom; } Build;
+static void build_emit(void* c, uint32_t p, uint64_t key, uint64_t hash, int reverse) {
+    Build* b = (Build*)c;
+    if (b->n == b->cap) { const size_t cap = b->cap ? 2 * b->cap : 1024; Entry* q = (Entry*)realloc(b->e, sizeof(Entry) * cap); if (!q) { b->oom = 1; return; } b->e = q; b->cap = cap; }
+    Entry* e = &b->e[b->n++]; e->key = key; e->hash = hash;
+    if (!reverse) { const uint32_t x = b->step[p]; e->node = b->tn[x]; e->offset = (uint32_t)(p - b->start[x]); }
+    else { const uint32_t q = p + b->k - 1, x = b->step[q]; e->node = b->tn[x] ^ 1u; e->offset = b->node_len[b->tn[x] >> 1] - 1 - (uint32_t)(q - b->start[x]); }
+}
+static int cmp_entry(const void* a, const void* b) {
+    const Entry* x = (const Entry*)a; const Entry* y = (const Entry*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    if (x->node != y->node) return x->node < y->node ? -1 : 1;
+    return x->offset < y->offset ? -1 : x->offset > y->offset;
+}
+
+void vgk_minimizer_index_destroy(vgk_minimizer_index* ix) { if (ix) { free(ix->node_len); free(ix->e); free(ix); } }
+int vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* d, uint32_t k, uint32_t w, vgk_minimizer_index** out) {
+    if (!ctx || !d || !out || !d->n_nodes || !d->node_len || !d->seq || (d->n_threads && (!d->thread_off || !d->thread_nodes))) return VGK_EINVAL;
+    if (k == 0 || k > 31 || w == 0 || w > 32) return VGK_EINVAL;
+    *out = NULL;
+    uint64_t* node_at = (uint64_t*)malloc(sizeof(uint64_t) * ((size_t)d->n_nodes + 1));
+    node_at[0] = 0; for (uint32_t i = 0; i < d->n_nodes; ++i) node_at[i + 1] = node_at[i] + d->node_len[i];
+    Build b; memset(&b, 0, sizeof b); b.node_len = d->node_len; b.k = k;
+    for (uint32_t t = 0; t < d->n_threads; ++t) {
+        const uint32_t* tn = d->thread_nodes + d->thread_off[t]; const uint32_t len = d->thread_off[t + 1] - d->thread_off[t];
+        size_t bases = 0;
+        for (uint32_t x = 0; x < len; ++x) { if (tn[x] >= 2 * d->n_nodes) { free(node_at); free(b.e); return VGK_EINVAL; } bases += d->node_len[tn[x] >> 1]; }
+        char* seq = (char*)malloc(bases + 1); uint32_t* step = (uint32_t*)malloc(sizeof(uint32_t) * (bases + 1)); uint64_t* start = (uint64_t*)malloc(sizeof(uint64_t) * ((size_t)len + 1));
+        size_t at = 0;
+        for (uint32_t x = 0; x < len; ++x) {
+            const uint32_t o = tn[x], v = o >> 1, L = d->node_len[v]; const char* s = d->seq + node_at[v];
+            start[x] = at;
+            for (uint32_t i = 0; i < L; ++i) { seq[at] = (o & 1) ? comp(s[L - 1 - i]) : s[i]; step[at] = x; ++at; }
+        }
+        b.tn = tn; b.start = start; b.step = step;
+        minimizers(seq, (uint32_t)bases, k, w, build_emit, &b);
+        free(seq); free(step); free(start);
+        if (b.oom) { free(node_at); free(b.e); return VGK_ENOMEM; }
+    }
+    free(node_at);
+    qsort(b.e, b.n, sizeof(Entry), cmp_entry);
+    size_t m = 0;
+    for (size_t i = 0; i < b.n; ++i) if (i == 0 || cmp_entry(&b.e[i], &b.e[m - 1]) != 0) b.e[m++] = b.e[i];
+    vgk_minimizer_index* ix = (vgk_minimizer_index*)calloc(1, sizeof *ix);
+    ix->k = k; ix->w = w; ix->n_nodes = d->n_nodes; ix->e = b.e; ix->n = m;
+    ix->node_len = (uint32_t*)malloc(sizeof(uint32_t) * d->n_nodes); memcpy(ix->node_len, d->node_len, sizeof(uint32_t) * d->n_nodes);
+    for (size_t i = 0; i < m; ++i) if (i == 0 || ix->e[i].key != ix->e[i - 1].key) ++ix->n_keys;
+    *out = ix;
+    return VGK_OK;
+}
+uint64_t vgk_minimizer_index_keys(const vgk_minimizer_index* ix) { return ix ? ix->n_keys : 0; }
+
+typedef struct { const vgk_minimizer_index* ix; uint32_t hit_cap; vgk_seed seeds[64]; uint32_t n_seeds, n_min; } Query;
+static void query_emit(void* c, uint32_t p, uint64_t key, uint64_t hash, int reverse) {
+    Query* q = (Query*)c; const vgk_minimizer_index* ix = q->ix; (void)hash;
+    ++q->n_min;
+    size_t lo = 0, hi = ix->n;                                             /* first entry with this key */
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (ix->e[mid].key < key) lo = mid + 1; else hi = mid; }
+    size_t end = lo; while (end < ix->n && ix->e[end].key == key) ++end;
+    if (end == lo || end - lo > q->hit_cap) return;
+    for (size_t h = lo; h < end && q->n_seeds < 64; ++h) {
+        vgk_seed s;
+        if (!reverse) { s.node = ix->e[h].node; s.diff = (int32_t)p - (int32_t)ix->e[h].offset; }
+        else { s.node = ix->e[h].node ^ 1u; s.diff = (int32_t)(p + ix->k - 1) - (int32_t)(ix->node_len[ix->e[h].node >> 1] - 1 - ix->e[h].offset); }
+        int dup = 0;
+        for (uint32_t j = 0; j < q->n_seeds && !dup; ++j) dup = q->seeds[j].node == s.node && q->seeds[j].diff == s.diff;
+        if (!dup) q->seeds[q->n_seeds++] = s;
+    }
+}
+int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_haplo* graph, const char* reads, const uint64_t* read_off, uint32_t n,
+                        uint32_t hit_cap, uint32_t* seed_off, uint32_t* mins, vgk_seed* seeds, size_t seeds_cap, size_t* written) {
+    if (!ctx || !ix || !graph || (n && (!reads || !read_off || !seed_off))) return VGK_EINVAL;
+    if (written) *written = 0;
+    size_t total = 0; int rc = VGK_OK;
+    if (seed_off) seed_off[0] = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        Query q; q.ix = ix; q.hit_cap = hit_cap ? hit_cap : 0xffffffffu; q.n_seeds = 0; q.n_min = 0;
+        minimizers(reads + read_off[i], (uint32_t)(read_off[i + 1] - read_off[i]), ix->k, ix->w, query_emit, &q);
+        if (mins) mins[i] = q.n_min;
+        if (total + q.n_seeds <= seeds_cap && seeds) memcpy(seeds + total, q.seeds, sizeof(vgk_seed) * q.n_seeds); else if (q.n_seeds) rc = VGK_EOPS;
+        total += q.n_seeds; seed_off[i + 1] = (uint32_t)total;
+    }
+    if (written) *written = total;
+    return rc;
+}
+double vgk_minimizer_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }

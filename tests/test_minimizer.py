@@ -1,0 +1,174 @@
+"""Minimizer seeding (vgk_minimizer_index_create / vgk_minimizer_seeds): the (k, w)-minimizers of reads, looked up in the index of the
+haplotype threads' minimizers, as seeds of the extension stage (MinimizerMapper::find_minimizers / find_seeds over gbwtgraph's
+MinimizerIndex, src/minimizer_mapper.cpp:3918-3965, :4109-4290).  [PARITY-UNPINNED against the reference: gbwtgraph is not in the
+snapshot.]  Three constructions: this file's brute force (every k-mer hashed, every window scanned, the index a dict), the oracle's
+(oracle/vgo_minimizer.c), the engine's (ring + hash table on the device; the emulator here, the MI355X in the gpu test) — and the
+property the next stage relies on: a seed of a read sampled from a haplotype lies on the read's true diagonal."""
+import subprocess
+
+import numpy as np
+import pytest
+
+from util import EMU_LIB, ENGINE_LIB, ORACLE_LIB, ROOT
+from vg_amd import capi, workloads
+
+M64 = (1 << 64) - 1
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    subprocess.check_call(["make", "-s", "emu"], cwd=ROOT)
+    return EMU_LIB
+
+
+def wang(key):
+    key = (~key + (key << 21)) & M64; key ^= key >> 24; key = (key + (key << 3) + (key << 8)) & M64; key ^= key >> 14
+    key = (key + (key << 2) + (key << 4)) & M64; key ^= key >> 28; key = (key + (key << 31)) & M64
+    return key
+
+
+CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
+COMP = str.maketrans("ACGT", "TGCA")
+
+
+def canonical(kmer):
+    if any(c not in CODE for c in kmer):
+        return None
+    f = 0
+    for c in kmer:
+        f = (f << 2) | CODE[c]
+    r = 0
+    for c in kmer.translate(COMP)[::-1]:
+        r = (r << 2) | CODE[c]
+    hf, hr = wang(f), wang(r)
+    return (hr, r, True) if hr < hf else (hf, f, False)
+
+
+def minimizers(seq, k, w):
+    """[(offset, key, reverse)]: leftmost smallest canonical hash of every window of w k-mers, each offset once"""
+    n = len(seq) - k + 1
+    if len(seq) < k + w - 1:
+        return []
+    km = [canonical(seq[p:p + k]) for p in range(n)]
+    out = []
+    for s in range(n - w + 1):
+        best = None
+        for p in range(s, s + w):
+            if km[p] is not None and (best is None or km[p][0] < km[best][0]):
+                best = p
+        if best is not None and (not out or out[-1][0] != best):
+            out.append((best, km[best][1], km[best][2]))
+    return out
+
+
+def oriented_seq(nodes, o):
+    return nodes[o >> 1] if not (o & 1) else nodes[o >> 1].translate(COMP)[::-1]
+
+
+def build_index(nodes, threads, k, w):
+    index = {}
+    for t in threads:
+        seq = "".join(oriented_seq(nodes, o) for o in t)
+        where = [(x, b) for x, o in enumerate(t) for b in range(len(nodes[o >> 1]))]
+        for p, key, rev in minimizers(seq, k, w):
+            if not rev:
+                x, b = where[p]; pos = (t[x], b)
+            else:
+                x, b = where[p + k - 1]; pos = (t[x] ^ 1, len(nodes[t[x] >> 1]) - 1 - b)
+            index.setdefault(key, set()).add(pos)
+    return {key: sorted(v) for key, v in index.items()}
+
+
+def seeds_of(read, index, nodes, k, w, hit_cap):
+    out = []
+    for p, key, rev in minimizers(read, k, w):
+        hits = index.get(key, [])
+        if not hits or len(hits) > hit_cap:
+            continue
+        for node, off in hits:
+            s = (node, p - off) if not rev else (node ^ 1, (p + k - 1) - (len(nodes[node >> 1]) - 1 - off))
+            if s not in out and len(out) < 64:
+                out.append(s)
+    return out
+
+
+def sample_reads(rng, nodes, threads, n, L, error=0.01, with_n=0.02):
+    reads, truth = [], []
+    for _ in range(n):
+        t = threads[int(rng.integers(0, len(threads)))]
+        if rng.random() < 0.5:
+            t = [o ^ 1 for o in reversed(t)]
+        seq = "".join(oriented_seq(nodes, o) for o in t)
+        a = int(rng.integers(0, len(seq) - L))
+        rd = list(seq[a:a + L])
+        for i in range(L):
+            if rng.random() < error:
+                rd[i] = "ACGT"[int(rng.integers(0, 4))]
+        if rng.random() < with_n:
+            rd[int(rng.integers(0, L))] = "N"
+        reads.append("".join(rd)); truth.append((t, a))
+    return reads, truth
+
+
+def run(lib, seed, k, w, n_reads, hit_cap=500):
+    wl = workloads.GaplessWorkload(4, seed=seed, graph_bp=8000, n_haplotypes=4, snp_every=40, indel_every=300)
+    rng = np.random.default_rng(seed)
+    reads, truth = sample_reads(rng, wl.nodes, wl.threads, n_reads, 100)
+    reads += ["ACGT" * 5, "", "A" * (k + w - 2)]                       # too short for a window: no minimizers
+    index = build_index(wl.nodes, wl.threads, k, w)
+    expected = [seeds_of(r, index, wl.nodes, k, w, hit_cap) for r in reads]
+    flat = np.frombuffer("".join(reads).encode(), dtype=np.uint8); off = np.concatenate([[0], np.cumsum([len(r) for r in reads])])
+    eng = capi.Engine(lib=lib)
+    mi = eng.minimizer_index(wl.nodes, wl.threads, k, w); hi = eng.haplo_index(wl.nodes, wl.threads)
+    assert mi.keys == len(index)
+    seed_off, seeds, mins = eng.minimizer_seeds(mi, hi, flat, off, hit_cap)
+    for i, exp in enumerate(expected):
+        got = [(int(s["node"]), int(s["diff"])) for s in seeds[seed_off[i]:seed_off[i + 1]]]
+        assert got == exp, "read %d: %s vs %s" % (i, got[:6], exp[:6])
+        assert mins[i] == len(minimizers(reads[i], k, w))
+    # nearly every seed of a sampled read lies on its true diagonal (base j of the read is base a + j of the thread it came from); the rest
+    # are hits that are just as true on another haplotype: the other allele of a SNP whose alleles agree with the read, a k-mer that ends on the
+    # first base behind an insertion the read carries
+    lens = [len(s) for s in wl.nodes]
+    on_diagonal = total = with_seeds = 0
+    for i, (t, a) in enumerate(truth):
+        starts = np.concatenate([[0], np.cumsum([lens[o >> 1] for o in t])])
+        want = {(o, int(starts[x]) - a) for x, o in enumerate(t)}       # node o's first base is thread base starts[x] = read offset starts[x] - a; diff = read - node offset
+        got = expected[i]
+        with_seeds += bool(got)
+        for node, diff in got:
+            total += 1
+            on_diagonal += (node, diff) in want
+    assert with_seeds > 0.9 * n_reads and on_diagonal > 0.9 * total, (with_seeds, on_diagonal, total)
+    return eng, mi, hi
+
+
+@pytest.mark.parametrize("lib_name", ["oracle", "emu"])
+def test_seeds_equal_the_brute_force_construction(lib_name, emu_lib):
+    lib = ORACLE_LIB if lib_name == "oracle" else emu_lib
+    run(lib, 1, 15, 6, 120)
+    run(lib, 2, 29, 11, 60)
+    run(lib, 3, 11, 4, 60, hit_cap=2)
+
+
+def test_seeds_feed_the_extension_stage(emu_lib):
+    """reads -> seeds -> gapless extension: the clusters the seeding makes resolve the reads (error-free reads: full-length extensions)"""
+    wl = workloads.GaplessWorkload(4, seed=5, graph_bp=20000, n_haplotypes=4)
+    rng = np.random.default_rng(5)
+    reads, truth = sample_reads(rng, wl.nodes, wl.threads, 150, 150, error=0.0, with_n=0.0)
+    flat = np.frombuffer("".join(reads).encode(), dtype=np.uint8); off = np.concatenate([[0], np.cumsum([len(r) for r in reads])])
+    for lib in (emu_lib, ORACLE_LIB):
+        eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=lib)
+        mi = eng.minimizer_index(wl.nodes, wl.threads); hi = eng.haplo_index(wl.nodes, wl.threads)
+        seed_off, seeds, mins = eng.minimizer_seeds(mi, hi, flat, off)
+        assert (np.diff(seed_off) > 0).all() and (mins >= 150 // 11 - 2).all()
+        gs = capi.GaplessSet(flat, off, seeds, seed_off)
+        res, ext, nodes, mism = eng.gapless_extend(hi, gs)
+        assert (res["status"] == 0).all() and (res["full_length"] == 1).all()
+        assert (ext["score"][res["ext_begin"]] == 150 + 10).all()
+
+
+@pytest.mark.gpu
+def test_seeds_on_the_gpu_equal_the_brute_force_construction():
+    run(ENGINE_LIB, 7, 29, 11, 400)
+    run(ENGINE_LIB, 8, 15, 6, 400)

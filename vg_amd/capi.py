@@ -368,6 +368,27 @@ class Engine:
                     "vgk_gapless_extend")
         return res, ext[:written[0]], nodes[:written[1]], mism[:written[2]]
 
+    def minimizer_index(self, nodes, threads, k=29, w=11):
+        return MinimizerIndex(self, nodes, threads, k, w)
+
+    def minimizer_seeds(self, mindex, hindex, reads, read_off, hit_cap=500):
+        """vgk_minimizer_seeds: reads flat (uint8), read i = reads[read_off[i]:read_off[i+1]] -> (seed_off [n+1], seeds as SEED_DT, minimizers per read)"""
+        reads = np.ascontiguousarray(reads, dtype=np.uint8); off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        n = len(off) - 1
+        seed_off = np.zeros(n + 1, dtype=np.uint32); mins = np.zeros(max(n, 1), dtype=np.uint32)
+        cap = 64 * max(n, 1)
+        seeds = np.zeros(cap, dtype=SEED_DT)
+        written = ctypes.c_size_t()
+        self.lib.vgk_minimizer_seeds.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        self._check(self.lib.vgk_minimizer_seeds(self.h, mindex.h, hindex.h, reads.ctypes.data, off.ctypes.data, n, hit_cap, seed_off.ctypes.data, mins.ctypes.data,
+                                                 seeds.ctypes.data, cap, ctypes.byref(written)), "vgk_minimizer_seeds")
+        return seed_off, seeds[:written.value], mins[:n]
+
+    def minimizer_last_ms(self):
+        self.lib.vgk_minimizer_last_ms.restype = ctypes.c_double; self.lib.vgk_minimizer_last_ms.argtypes = [ctypes.c_void_p]
+        return self.lib.vgk_minimizer_last_ms(self.h)
+
     def tail_forest(self, index, problems):
         """vgk_tail_forest: problems = numpy array of TAIL_DT (search state node / lo / hi, cut offset, walk distance) or a list of
         such tuples.  -> (results as TAIL_RESULT_DT, Forest)"""
@@ -455,6 +476,34 @@ class Forest:
             if getattr(self.eng, "h", None):
                 self.eng.lib.vgk_forest_destroy(self.h)
             self.h = None; self.graph = None
+
+    __del__ = close
+
+
+class MinimizerIndex:
+    """vgk_minimizer_index: the (k, w)-minimizers of the haplotype threads with their graph positions, resident in HBM."""
+
+    def __init__(self, eng, nodes, threads, k=29, w=11):
+        self.eng = eng; self.k, self.w = k, w
+        self._len = np.array([len(s) for s in nodes], dtype=np.uint32)
+        self._seq = np.frombuffer("".join(nodes).encode(), dtype=np.uint8).copy()
+        self._toff = np.concatenate([[0], np.cumsum([len(t) for t in threads])]).astype(np.uint32)
+        self._tn = np.array([o for t in threads for o in t] or [0], dtype=np.uint32)
+        d = Haplotypes(len(nodes), self._len.ctypes.data, self._seq.ctypes.data, len(threads), self._toff.ctypes.data, self._tn.ctypes.data)
+        h = ctypes.c_void_p()
+        eng.lib.vgk_minimizer_index_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+        eng._check(eng.lib.vgk_minimizer_index_create(eng.h, ctypes.byref(d), k, w, ctypes.byref(h)), "vgk_minimizer_index_create")
+        self.h = h
+        eng.lib.vgk_minimizer_index_keys.restype = ctypes.c_uint64; eng.lib.vgk_minimizer_index_keys.argtypes = [ctypes.c_void_p]
+        self.keys = int(eng.lib.vgk_minimizer_index_keys(h))
+        eng._indexes.add(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.eng, "h", None):
+                self.eng.lib.vgk_minimizer_index_destroy.argtypes = [ctypes.c_void_p]; self.eng.lib.vgk_minimizer_index_destroy.restype = None
+                self.eng.lib.vgk_minimizer_index_destroy(self.h)
+            self.h = None
 
     __del__ = close
 

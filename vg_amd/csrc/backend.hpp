@@ -13,6 +13,7 @@
 #include "gssw_matrix_device.hpp"
 #include "gssw_pack_device.hpp"
 #include "tail_device.hpp"
+#include "minimizer_device.hpp"
 
 namespace vgk {
 
@@ -105,6 +106,7 @@ public:
     // lanes, one TScratch each, take the problems in turn); exclusive prefix sums of n 32-bit values (out[k] = in[0] + ... + in[k-1]);
     // the two per-node stages that turn the forest into the packer's tables; a byte fill; a stopwatch around all of it
     // (watch(0) ... watch(1), watch_ms() after a sync)
+    virtual int   run_minimizer(const MinimizerParams& p) = 0;            // minimizer_device.hpp: one lane per read, pass p.pass
     virtual int   run_tail(const TailParams& p, uint32_t threads) = 0;
     virtual int   scan_u32(const uint32_t* in, uint32_t* out, uint32_t n) = 0;
     virtual int   forest_flags(const ForestParams& p) = 0;

@@ -288,6 +288,12 @@ __global__ void __launch_bounds__(256) mask_reads_kernel(char* reads, const size
     } else for (size_t k = i; k < bytes; ++k) reads[k] = g_mask_base(reads[k]);
 }
 
+// ---- minimizer seeding (minimizer_device.hpp): one lane per read
+__global__ void __launch_bounds__(64) minimizer_kernel(const MinimizerParams P) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i < P.n) minimizer_one(P, i);
+}
+
 // ---- tail forests (tail_device.hpp): resident lanes take the tails in turn for the walks; one lane per tree node for the graph tables
 __global__ void __launch_bounds__(64) tail_walk_kernel(const TailParams P, const uint32_t threads) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
@@ -627,6 +633,12 @@ public:
         hipSetDevice(dev);
         if (!bytes) return VGK_OK;
         hipLaunchKernelGGL(mask_reads_kernel, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, stream, reads, bytes);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int run_minimizer(const MinimizerParams& p) override {
+        hipSetDevice(dev);
+        if (!p.n) return VGK_OK;
+        hipLaunchKernelGGL(minimizer_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_tail(const TailParams& p, uint32_t threads) override {

@@ -34,6 +34,7 @@ struct vgk_ctx {
     uint64_t gapless_retried = 0;  // reads of that call whose search outgrew the fast kernel's LDS store and ran in the slab kernel
     double wfa_ms = 0;             // and of the last vgk_wfa_extend call
     uint32_t wfa_point_budget = 0; // vgk_wfa_set_point_budget (0 = the table's size)
+    double minimizer_ms = 0;       // device time of the last vgk_minimizer_seeds call
     double tail_ms = 0;            // device time of the last vgk_tail_forest call
     // the last batch of either call stays resident in the cached device buffers: what a re-run needs to launch it again
     vgk::BandedParams banded_last{}; std::vector<vgk::BandedLaunch> banded_last_launches; bool banded_last_valid = false;
@@ -41,7 +42,7 @@ struct vgk_ctx {
     vgk::WfaParams wfa_last{}; uint32_t wfa_last_threads = 0; bool wfa_last_valid = false;
     // device scratch kept between vgk_banded_align calls (grow-only; released with the context)
     struct DevBuf { void* p = nullptr; uint64_t bytes = 0; };
-    DevBuf scratch[56];            // 0..14 + 31 banded_api.cpp, 15..30 gapless_api.cpp, 32..39 wfa_api.cpp, 40..47 gssw_multi_api.cpp / xdrop_band_api.cpp (+ 48, 49), 50..54 tail_api.cpp
+    DevBuf scratch[60];            // 0..14 + 31 banded_api.cpp, 15..30 gapless_api.cpp, 32..39 wfa_api.cpp, 40..47 gssw_multi_api.cpp / xdrop_band_api.cpp (+ 48, 49), 50..54 tail_api.cpp, 55..58 minimizer_api.cpp
     void* ensure_scratch(int slot, uint64_t bytes) {
         DevBuf& b = scratch[slot];
         if (b.p && b.bytes >= bytes) return b.p;

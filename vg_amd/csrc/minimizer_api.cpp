@@ -1,0 +1,153 @@
+// minimizer_api.cpp — vgk_minimizer_index_create / vgk_minimizer_seeds (minimizer_device.hpp): the minimizer index of the haplotype
+// threads built on host threads and kept in HBM; the reads' minimizers, lookups and seeds on the device.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <vector>
+#include "ctx.hpp"
+#include "haplo.hpp"
+#include "host_parallel.hpp"
+#include "minimizer_device.hpp"
+
+using namespace vgk;
+
+struct vgk_minimizer_index {
+    vgk_ctx* ctx = nullptr;
+    MzIndex dev{};
+    std::vector<void*> held;
+    uint64_t n_keys = 0, n_pos = 0;
+};
+
+namespace {
+char mz_comp(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } }
+struct Entry { uint64_t key, hash; uint32_t node, offset; };
+}
+
+extern "C" {
+
+int vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* d, uint32_t k, uint32_t w, vgk_minimizer_index** out) {
+    if (!ctx || !d || !out || !d->n_nodes || !d->node_len || !d->seq || (d->n_threads && (!d->thread_off || !d->thread_nodes))) return VGK_EINVAL;
+    if (k == 0 || k > MZ_MAX_K || w == 0 || w > MZ_MAX_W) return VGK_EINVAL;
+    *out = nullptr;
+    const uint32_t N = d->n_nodes;
+    std::vector<uint64_t> node_at((size_t)N + 1, 0);
+    for (uint32_t i = 0; i < N; ++i) node_at[i + 1] = node_at[i] + d->node_len[i];
+    for (uint32_t t = 0; t < d->n_threads; ++t) for (uint32_t x = d->thread_off[t]; x < d->thread_off[t + 1]; ++x) if (d->thread_nodes[x] >= 2 * N) return VGK_EINVAL;
+    // the minimizers of every thread, read along the thread; a reverse-canonical one is filed under the position its
+    // reverse complement starts at: the k-mer's last base, seen from the other strand
+    std::vector<std::vector<Entry>> per_thread(d->n_threads);
+    parallel_tasks(d->n_threads, [&](uint32_t t) {
+        const uint32_t* tn = d->thread_nodes + d->thread_off[t]; const uint32_t len = d->thread_off[t + 1] - d->thread_off[t];
+        size_t bases = 0;
+        for (uint32_t x = 0; x < len; ++x) bases += d->node_len[tn[x] >> 1];
+        std::vector<char> seq(bases); std::vector<uint32_t> step(bases);          // step[b] = index in the thread of the node that holds base b
+        std::vector<uint64_t> start((size_t)len + 1, 0);
+        size_t at = 0;
+        for (uint32_t x = 0; x < len; ++x) {
+            const uint32_t o = tn[x], v = o >> 1, L = d->node_len[v]; const char* s = d->seq + node_at[v];
+            start[x] = at;
+            for (uint32_t b = 0; b < L; ++b) { seq[at] = (o & 1) ? mz_comp(s[L - 1 - b]) : s[b]; step[at] = x; ++at; }
+        }
+        start[len] = at;
+        std::vector<Entry>& outv = per_thread[t];
+        mz_minimizers(seq.data(), (uint32_t)std::min<size_t>(bases, 0xffffffffu), k, w, [&](uint32_t p, const MzKmer& m) {
+            Entry e; e.key = m.key; e.hash = m.hash;
+            if (!m.reverse) { const uint32_t x = step[p]; e.node = tn[x]; e.offset = (uint32_t)(p - start[x]); }
+            else { const size_t q = (size_t)p + k - 1; const uint32_t x = step[q]; const uint32_t L = d->node_len[tn[x] >> 1]; e.node = tn[x] ^ 1u; e.offset = L - 1 - (uint32_t)(q - start[x]); }
+            outv.push_back(e);
+        });
+    });
+    std::vector<Entry> all;
+    for (auto& v : per_thread) { all.insert(all.end(), v.begin(), v.end()); std::vector<Entry>().swap(v); }
+    std::sort(all.begin(), all.end(), [](const Entry& a, const Entry& b) { return a.key != b.key ? a.key < b.key : a.node != b.node ? a.node < b.node : a.offset < b.offset; });
+    all.erase(std::unique(all.begin(), all.end(), [](const Entry& a, const Entry& b) { return a.key == b.key && a.node == b.node && a.offset == b.offset; }), all.end());
+    uint64_t n_keys = 0;
+    for (size_t i = 0; i < all.size(); ++i) if (i == 0 || all[i].key != all[i - 1].key) ++n_keys;
+    uint64_t cap = 16; while (cap < 2 * n_keys + 2) cap <<= 1;
+    if (cap > (1ull << 31)) return VGK_ETOOBIG;
+    std::vector<MzSlot> slots(cap, MzSlot{0, 0, 0});
+    std::vector<MzPos> pos(all.size() + 1);
+    for (size_t i = 0; i < all.size();) {
+        size_t j = i; while (j < all.size() && all[j].key == all[i].key) { pos[j] = MzPos{all[j].node, all[j].offset}; ++j; }
+        uint32_t s = (uint32_t)all[i].hash & (uint32_t)(cap - 1);
+        while (slots[s].count) s = (s + 1) & (uint32_t)(cap - 1);
+        slots[s] = MzSlot{all[i].key, (uint32_t)i, (uint32_t)(j - i)};
+        i = j;
+    }
+    std::unique_ptr<vgk_minimizer_index> ix(new (std::nothrow) vgk_minimizer_index());
+    if (!ix) return VGK_ENOMEM;
+    ix->ctx = ctx; ix->n_keys = n_keys; ix->n_pos = all.size();
+    Backend* be = ctx->be.get();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    void* ds = be->alloc(sizeof(MzSlot) * cap); void* dp = be->alloc(sizeof(MzPos) * pos.size());
+    if (ds) ix->held.push_back(ds);
+    if (dp) ix->held.push_back(dp);
+    int rc = (ds && dp) ? VGK_OK : VGK_ENOMEM;
+    if (!rc) rc = be->upload(ds, slots.data(), sizeof(MzSlot) * cap);
+    if (!rc) rc = be->upload(dp, pos.data(), sizeof(MzPos) * pos.size());
+    if (!rc) rc = be->sync();
+    if (rc) { for (void* p : ix->held) be->release(p); return rc; }
+    ix->dev.slots = (const MzSlot*)ds; ix->dev.mask = (uint32_t)(cap - 1); ix->dev.pos = (const MzPos*)dp; ix->dev.k = k; ix->dev.w = w;
+    *out = ix.release();
+    return VGK_OK;
+}
+
+void vgk_minimizer_index_destroy(vgk_minimizer_index* ix) {
+    if (!ix) return;
+    { std::lock_guard<std::mutex> lk(ix->ctx->mu); ix->ctx->be->sync(); for (void* p : ix->held) ix->ctx->be->release(p); }
+    delete ix;
+}
+uint64_t vgk_minimizer_index_keys(const vgk_minimizer_index* ix) { return ix ? ix->n_keys : 0; }
+
+int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_haplo* graph, const char* reads, const uint64_t* read_off, uint32_t n,
+                        uint32_t hit_cap, uint32_t* seed_off, uint32_t* minimizers, vgk_seed* seeds, size_t seeds_cap, size_t* written) {
+    if (!ctx || !ix || !graph || ix->ctx != ctx || graph->ctx != ctx || (n && (!reads || !read_off || !seed_off))) return VGK_EINVAL;
+    if (written) *written = 0;
+    if (!n) { if (seed_off) seed_off[0] = 0; return VGK_OK; }
+    for (uint32_t i = 0; i < n; ++i) if (read_off[i + 1] < read_off[i]) return VGK_EINVAL;
+    const uint64_t bytes = read_off[n] - read_off[0];
+    if (bytes > 0xfffffff0ull) return VGK_ETOOBIG;
+    Backend* be = ctx->be.get();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    char* d_reads = (char*)ctx->ensure_scratch(55, bytes + 16);
+    uint64_t* d_off = (uint64_t*)ctx->ensure_scratch(56, sizeof(uint64_t) * ((size_t)n + 1));
+    uint32_t* d_tab = (uint32_t*)ctx->ensure_scratch(57, sizeof(uint32_t) * 3 * ((size_t)n + 1));
+    if (!d_reads || !d_off || !d_tab) return VGK_ENOMEM;
+    const size_t n1 = (size_t)n + 1;
+    std::vector<uint64_t> rel(n1);
+    for (size_t i = 0; i < n1; ++i) rel[i] = read_off[i] - read_off[0];
+    MinimizerParams P{};
+    P.index = ix->dev; P.graph = graph->dev; P.reads = d_reads; P.read_off = d_off; P.n = n; P.hit_cap = hit_cap ? hit_cap : 0xffffffffu;
+    P.counts = d_tab; P.mins = d_tab + n1; P.first = d_tab + 2 * n1;
+    be->watch(0);
+    int rc = be->upload(d_reads, reads + read_off[0], bytes);
+    if (!rc) rc = be->upload(d_off, rel.data(), sizeof(uint64_t) * n1);
+    if (!rc) rc = be->zero(d_tab, sizeof(uint32_t) * 3 * n1);
+    P.pass = 1;
+    if (!rc) rc = be->run_minimizer(P);
+    if (!rc) rc = be->scan_u32(d_tab, d_tab + 2 * n1, (uint32_t)n1);
+    if (!rc) rc = be->download(seed_off, d_tab + 2 * n1, sizeof(uint32_t) * n1);      // synchronises (rel[] may go)
+    if (!rc && minimizers) rc = be->download(minimizers, d_tab + n1, sizeof(uint32_t) * n);
+    if (rc) return rc;
+    const size_t total = seed_off[n];
+    if (written) *written = total;
+    if (total > seeds_cap || (total && !seeds)) return VGK_EOPS;
+    if (total) {
+        vgk_seed* d_seeds = (vgk_seed*)ctx->ensure_scratch(58, sizeof(vgk_seed) * total);
+        if (!d_seeds) return VGK_ENOMEM;
+        P.seeds = d_seeds; P.pass = 2;
+        rc = be->run_minimizer(P);
+        be->watch(1);
+        if (!rc) rc = be->download(seeds, d_seeds, sizeof(vgk_seed) * total);
+        if (rc) return rc;
+    } else { be->watch(1); be->sync(); }
+    ctx->minimizer_ms = be->watch_ms();
+    return VGK_OK;
+}
+
+double vgk_minimizer_last_ms(vgk_ctx* ctx) { return ctx ? ctx->minimizer_ms : 0.0; }
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// minimizer_device.hpp — minimizer seeding: the step before the extension stage (first half).
+// Replaces, for a batch of reads, what MinimizerMapper::find_minimizers / find_seeds get from gbwtgraph's MinimizerIndex
+// (src/minimizer_mapper.cpp:3918-3965, :4109-4290: minimizer_regions(sequence), find(minimizer), one seed per hit):
+// the (k, w)-minimizers of every read and, for each, the graph positions of that k-mer on the haplotypes.
+//
+// [PARITY-UNPINNED] gbwtgraph is an un-vendored submodule, absent from the snapshot; this is its published scheme restated:
+//   * a k-mer (k <= 31) is its bases packed two bits each (A C G T = 0 1 2 3), first base in the highest bits; a k-mer with any other
+//     character is no candidate;
+//   * its hash is Thomas Wang's 64-bit integer hash of that key; a k-mer stands for itself and its reverse complement: the
+//     orientation with the smaller hash is the canonical one (equal hashes — palindromes — forward);
+//   * the minimizer of a window of w consecutive k-mers is the candidate with the smallest canonical hash, the leftmost among equals;
+//     a sequence shorter than k + w - 1 bases has none; every (position) is reported once, in read order;
+//   * the index holds the minimizers of every haplotype path, keyed by the canonical key, with the graph position where the
+//     canonical-orientation k-mer starts (the forward k-mer's first base, or the flipped position of its last base).
+// A hit becomes a seed of the extension stage (vgk_seed: oriented node + read offset - node offset) on the strand the READ reads
+// forward on: for a forward-canonical minimizer at read offset p the hit itself; for a reverse-canonical one the hit flipped,
+// paired with the k-mer's last read base p + k - 1.
+//
+// The same code runs in the index builder (host), under tests/emu (test infrastructure only) and in the kernels.
+#pragma once
+#include <stdint.h>
+#include "gapless_device.hpp"
+#include "../../include/vgk.h"
+
+namespace vgk {
+
+constexpr uint32_t MZ_MAX_K = 31, MZ_MAX_W = 32, MZ_MAX_SEEDS = 64;      // (64 = the seeds a cluster of the extension stage may hold)
+VGK_HD uint64_t mz_hash(uint64_t key) {                 // Thomas Wang's 64-bit mix
+    key = (~key) + (key << 21); key ^= key >> 24; key = (key + (key << 3)) + (key << 8); key ^= key >> 14;
+    key = (key + (key << 2)) + (key << 4); key ^= key >> 28; key += key << 31;
+    return key;
+}
+VGK_HD int mz_code(char c) { switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; } }
+
+// the k-mers of a sequence, one base at a time: forward and reverse-complement keys, how many valid bases in a row
+struct MzRoll {
+    uint64_t fwd, rev, mask; uint32_t k, valid;
+    VGK_HD void init(uint32_t kk) { k = kk; mask = kk == 32 ? ~0ull : ((1ull << (2 * kk)) - 1ull); fwd = rev = 0; valid = 0; }
+    VGK_HD void push(char c) {
+        const int x = mz_code(c);
+        if (x < 0) { valid = 0; fwd = rev = 0; return; }
+        fwd = ((fwd << 2) | (uint64_t)x) & mask;
+        rev = (rev >> 2) | ((uint64_t)(3 - x) << (2 * (k - 1)));
+        ++valid;
+    }
+    VGK_HD bool full() const { return valid >= k; }
+};
+struct MzKmer { uint64_t hash, key; bool reverse; };                     // canonical
+VGK_HD MzKmer mz_canonical(const MzRoll& r) {
+    const uint64_t hf = mz_hash(r.fwd), hr = mz_hash(r.rev);
+    MzKmer m; m.reverse = hr < hf; m.hash = m.reverse ? hr : hf; m.key = m.reverse ? r.rev : r.fwd;
+    return m;
+}
+
+// The minimizers of seq[0, L): calls out(start offset of the k-mer, canonical k-mer) for each, in order of offset.
+// A ring of the last w candidates (hash, or "none"); the current minimum is tracked and re-found when it leaves the window.
+template <class OUT>
+VGK_HD void mz_minimizers(const char* seq, uint32_t L, uint32_t k, uint32_t w, OUT out) {
+    if (L < k + w - 1 || k == 0 || k > MZ_MAX_K || w == 0 || w > MZ_MAX_W) return;
+    constexpr uint64_t NONE = ~0ull;
+    uint64_t ring_hash[MZ_MAX_W], ring_key[MZ_MAX_W]; uint8_t ring_rev[MZ_MAX_W];
+    MzRoll roll; roll.init(k);
+    for (uint32_t i = 0; i + 1 < k; ++i) roll.push(seq[i]);
+    const uint32_t n_kmers = L - k + 1;
+    int64_t best = -1;                                                    // k-mer index of the current window's minimizer
+    int64_t reported = -1;
+    for (uint32_t j = 0; j < n_kmers; ++j) {
+        roll.push(seq[j + k - 1]);
+        const uint32_t slot = j % w;
+        if (roll.full()) { const MzKmer m = mz_canonical(roll); ring_hash[slot] = m.hash; ring_key[slot] = m.key; ring_rev[slot] = m.reverse ? 1 : 0; }
+        else { ring_hash[slot] = NONE; ring_key[slot] = 0; ring_rev[slot] = 0; }
+        // window = k-mers [j - w + 1, j]
+        if (best >= 0 && best + (int64_t)w <= (int64_t)j) best = -1;       // the minimum slid out
+        if (best < 0) {
+            const uint32_t lo = j + 1 >= w ? j + 1 - w : 0;
+            for (uint32_t i = lo; i <= j; ++i) { const uint64_t h = ring_hash[i % w]; if (h != NONE && (best < 0 || h < ring_hash[best % w])) best = i; }
+        } else if (ring_hash[slot] != NONE && ring_hash[slot] < ring_hash[best % w]) best = j;
+        if (j + 1 >= w && best >= 0 && best != reported) {
+            MzKmer m; m.hash = ring_hash[best % w]; m.key = ring_key[best % w]; m.reverse = ring_rev[best % w] != 0;
+            out((uint32_t)best, m);
+            reported = best;
+        }
+    }
+}
+
+// ---- the index on the device: open addressing, linear probing --------------------------------------------------------------------
+struct MzSlot { uint64_t key; uint32_t first, count; };                  // count == 0: free
+struct MzPos { uint32_t node, offset; };
+struct MzIndex { const MzSlot* slots; uint32_t mask; const MzPos* pos; uint32_t k, w; };
+VGK_HD bool mz_find(const MzIndex& x, const MzKmer& m, uint32_t& first, uint32_t& count) {
+    for (uint32_t s = (uint32_t)m.hash & x.mask;; s = (s + 1) & x.mask) {
+        const MzSlot e = x.slots[s];
+        if (!e.count) return false;
+        if (e.key == m.key) { first = e.first; count = e.count; return true; }
+    }
+}
+
+struct MinimizerParams {
+    MzIndex index; GIndex graph;                                          // graph: node lengths (for the flip of reverse hits)
+    const char* reads; const uint64_t* read_off; uint32_t n;
+    uint32_t hit_cap;                                                      // minimizers with more hits give no seeds (hard_hit_cap, :4180)
+    uint32_t* counts;                                                      // pass 1: seeds per read ([n + 1], last 0); minimizers per read in mins[]
+    uint32_t* mins;
+    const uint32_t* first;                                                 // pass 2: exclusive prefix sums of counts
+    vgk_seed* seeds; int pass;
+};
+// one read: count its seeds (pass 1) or write them (pass 2), in order of the minimizers' read offsets, a minimizer's hits in index order.
+// A cluster is a SET of seeds (GaplessExtender::cluster_type is a hash set, src/gbwt_extender.hpp:143): a (node, diagonal) pair that
+// a second minimizer of the read hits again is reported once; seeds beyond MZ_MAX_SEEDS are dropped.
+VGK_HD void minimizer_one(const MinimizerParams& P, uint32_t i) {
+    const uint64_t a = P.read_off[i]; const uint32_t L = (uint32_t)(P.read_off[i + 1] - a);
+    uint32_t n_seeds = 0, n_min = 0;
+    vgk_seed* dst = P.pass == 2 ? P.seeds + P.first[i] : nullptr;
+    const uint32_t k = P.index.k;
+    uint64_t seen[MZ_MAX_SEEDS];
+    mz_minimizers(P.reads + a, L, k, P.index.w, [&](uint32_t p, const MzKmer& m) {
+        ++n_min;
+        uint32_t first = 0, count = 0;
+        if (!mz_find(P.index, m, first, count) || count > P.hit_cap) return;
+        for (uint32_t h = 0; h < count && n_seeds < MZ_MAX_SEEDS; ++h) {
+            const MzPos q = P.index.pos[first + h];
+            vgk_seed s;
+            if (!m.reverse) { s.node = q.node; s.diff = (int32_t)p - (int32_t)q.offset; }
+            else { s.node = q.node ^ 1u; s.diff = (int32_t)(p + k - 1) - (int32_t)(g_len(P.graph, (int32_t)q.node) - 1 - q.offset); }
+            const uint64_t key = ((uint64_t)s.node << 32) | (uint32_t)s.diff;
+            bool dup = false;
+            for (uint32_t j = 0; j < n_seeds && !dup; ++j) dup = seen[j] == key;
+            if (dup) continue;
+            seen[n_seeds] = key;
+            if (dst) dst[n_seeds] = s;
+            ++n_seeds;
+        }
+    });
+    if (P.pass == 1) { P.counts[i] = n_seeds; if (P.mins) P.mins[i] = n_min; }
+}
+
+}  // namespace vgk
