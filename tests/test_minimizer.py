@@ -110,10 +110,10 @@ def sample_reads(rng, nodes, threads, n, L, error=0.01, with_n=0.02):
     return reads, truth
 
 
-def run(lib, seed, k, w, n_reads, hit_cap=500):
+def run(lib, seed, k, w, n_reads, hit_cap=500, L=100):
     wl = workloads.GaplessWorkload(4, seed=seed, graph_bp=8000, n_haplotypes=4, snp_every=40, indel_every=300)
     rng = np.random.default_rng(seed)
-    reads, truth = sample_reads(rng, wl.nodes, wl.threads, n_reads, 100)
+    reads, truth = sample_reads(rng, wl.nodes, wl.threads, n_reads, L)
     reads += ["ACGT" * 5, "", "A" * (k + w - 2)]                       # too short for a window: no minimizers
     index = build_index(wl.nodes, wl.threads, k, w)
     expected = [seeds_of(r, index, wl.nodes, k, w, hit_cap) for r in reads]
@@ -149,6 +149,8 @@ def test_seeds_equal_the_brute_force_construction(lib_name, emu_lib):
     run(lib, 1, 15, 6, 120)
     run(lib, 2, 29, 11, 60)
     run(lib, 3, 11, 4, 60, hit_cap=2)
+    run(lib, 4, 31, 32, 40)
+    run(lib, 5, 21, 7, 20, L=1500)
 
 
 def test_seeds_feed_the_extension_stage(emu_lib):
@@ -172,3 +174,5 @@ def test_seeds_feed_the_extension_stage(emu_lib):
 def test_seeds_on_the_gpu_equal_the_brute_force_construction():
     run(ENGINE_LIB, 7, 29, 11, 400)
     run(ENGINE_LIB, 8, 15, 6, 400)
+    run(ENGINE_LIB, 9, 31, 32, 150)                 # the widest window the kernel takes
+    run(ENGINE_LIB, 10, 21, 7, 60, L=1500)          # many rounds per read, more than 64 distinct seeds

@@ -288,10 +288,137 @@ __global__ void __launch_bounds__(256) mask_reads_kernel(char* reads, const size
     } else for (size_t k = i; k < bytes; ++k) reads[k] = g_mask_base(reads[k]);
 }
 
-// ---- minimizer seeding (minimizer_device.hpp): one lane per read
-__global__ void __launch_bounds__(64) minimizer_kernel(const MinimizerParams P) {
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i < P.n) minimizer_one(P, i);
+// ---- minimizer seeding (minimizer_device.hpp): one wavefront per read, one lane per k-mer position
+// Rounds of 64 k-mer positions, 65 - w of them new (a round's first w - 1 lanes only complete the windows that end behind them).
+// Per round every lane builds the forward and reverse keys of ITS k-mer from unaligned 8-byte loads, hashes both and keeps the
+// canonical one; whether a k-mer is a candidate is k consecutive set bits in the ballots of "this base is ACGT"; the minimum of the w
+// candidates ending at a lane — (hash, position) lexicographic = the leftmost smallest — comes from doubling steps over lane
+// shuffles plus one combining step; a window reports its minimum when that lies behind everything reported before (window minima
+// move right only): a prefix maximum.  The round's reported minimizers (at most 65 - w) are compacted into LDS by ballot + popcount,
+// one lane each probes the table, and their hits become seeds in order, a (node, diagonal) pair the read already has being dropped by
+// one ballot over the seeds kept so far.  Results are those of minimizer_one, which the emulator and the index builder run.
+struct MzMin { uint64_t key; uint32_t hash_lo; uint32_t pos_rev; };        // pos_rev = read offset << 1 | reverse
+// Four reads per workgroup, one wavefront each (no workgroup barrier anywhere: a wavefront's LDS operations complete in order, the
+// fence only keeps the compiler from moving them).  The seeds go to slots of MZ_MAX_SEEDS per read; minimizer_gather_kernel packs
+// them behind each other once the prefix sums of the counts are known — one pass over the reads instead of a counting and a writing one.
+#define MZ_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+__global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P, vgk_seed* slots) {
+    __shared__ MzMin mins_all[4][64];
+    __shared__ unsigned long long seen_all[4][MZ_MAX_SEEDS];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t i = blockIdx.x * 4u + wv;
+    if (i >= P.n) return;
+    MzMin* mins = mins_all[wv]; unsigned long long* seen = seen_all[wv];
+    const uint64_t a = P.read_off[i]; const uint32_t L = (uint32_t)(P.read_off[i + 1] - a);
+    const uint32_t k = P.index.k, w = P.index.w;
+    const char* rd = P.reads + a;
+    vgk_seed* dst = slots + (size_t)i * MZ_MAX_SEEDS;
+    uint32_t n_min = 0, n_seeds = 0;
+    if (L >= k + w - 1) {
+        const uint32_t n_kmers = L - k + 1, step = 65 - w;
+        const uint64_t kmask = (1ull << (2 * k)) - 1ull;                   // k <= 31
+        const unsigned long long need = (1ull << k) - 1ull;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        uint32_t last_plus1 = 0;                                            // 1 + the last reported position (0: none yet)
+        for (uint32_t base = 0; base + w - 1 < n_kmers; base += step) {
+            const uint32_t q = base + lane;                                 // this lane's k-mer position = the end of its window
+            // The 2-bit codes of bases base .. base + 127 as two bit planes held in four ballots; a lane's k-mer is k consecutive positions
+            // from bit `lane` on: funnel-shifted out of the planes, interleaved once into the reverse-complement key's layout (base t at
+            // bits 2t), from which the forward key is the same pairs in reverse order.  No per-base loop, no byte loads beyond two per lane.
+            const char c0 = q < L ? rd[q] : 'N', c1 = q + 64 < L ? rd[q + 64] : 'N';
+            const int x0 = mz_code(c0), x1 = mz_code(c1);
+            const unsigned long long v0 = __ballot(x0 >= 0), v1 = __ballot(x1 >= 0);
+            const unsigned long long lo0 = __ballot(x0 & 1), lo1 = __ballot(x1 & 1), hi0 = __ballot((x0 >> 1) & 1), hi1 = __ballot((x1 >> 1) & 1);      // (x < 0: both bits set, and the k-mer is no candidate)
+            auto from_lane = [&](unsigned long long a0, unsigned long long a1) { return lane ? ((a0 >> lane) | (a1 << (64 - lane))) : a0; };
+            const unsigned long long vbits = from_lane(v0, v1);
+            const bool valid = q < n_kmers && (vbits & need) == need;
+            const uint32_t b_lo = (uint32_t)(from_lane(lo0, lo1) & need), b_hi = (uint32_t)(from_lane(hi0, hi1) & need);
+            auto spread = [](uint32_t v) {                                  // bit t -> bit 2t
+                uint64_t z = v;
+                z = (z | (z << 16)) & 0x0000ffff0000ffffull; z = (z | (z << 8)) & 0x00ff00ff00ff00ffull; z = (z | (z << 4)) & 0x0f0f0f0f0f0f0f0full;
+                z = (z | (z << 2)) & 0x3333333333333333ull; z = (z | (z << 1)) & 0x5555555555555555ull;
+                return z;
+            };
+            const uint64_t pairs = spread(b_lo) | (spread(b_hi) << 1);       // base t's code at bits 2t, 2t + 1
+            uint64_t rev = ~pairs & kmask;                                   // complement of every base, the k-mer's last base in the highest pair
+            uint64_t br = __builtin_bitreverse64(pairs);                     // pairs in reverse order, the two bits of a pair swapped
+            br = ((br >> 1) & 0x5555555555555555ull) | ((br & 0x5555555555555555ull) << 1);
+            uint64_t fwd = (br >> (64 - 2 * k)) & kmask;                      // base 0 in the highest pair
+            if (!valid) { fwd = 0; rev = 0; }
+            const uint64_t hf = mz_hash(fwd), hr = mz_hash(rev);
+            const bool reverse = hr < hf;
+            const uint64_t my_hash = reverse ? hr : hf, my_key = reverse ? rev : fwd;
+            uint64_t h = valid ? my_hash : ~0ull;                           // ~0: no candidate
+            uint32_t hp = q;
+            uint32_t span = 1;
+            while (2 * span <= w) {
+                const uint64_t oh = __shfl_up(h, span, 64); const uint32_t op = __shfl_up(hp, span, 64);
+                if (lane >= span && (oh < h || (oh == h && op < hp))) { h = oh; hp = op; }
+                span *= 2;
+            }
+            if (span < w) {
+                const uint32_t d = w - span;
+                const uint64_t oh = __shfl_up(h, d, 64); const uint32_t op = __shfl_up(hp, d, 64);
+                if (lane >= d && (oh < h || (oh == h && op < hp))) { h = oh; hp = op; }
+            }
+            const bool ends = lane >= w - 1 && q < n_kmers && h != ~0ull;   // a complete window with a candidate
+            uint32_t run = ends ? hp + 1 : 0u;                              // prefix maximum of the minima so far in this round
+            for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(run, d, 64); if (lane >= d && o > run) run = o; }
+            uint32_t before = __shfl_up(run, 1, 64); if (lane == 0) before = 0;
+            if (last_plus1 > before) before = last_plus1;
+            const bool report = ends && hp + 1 > before;
+            const uint32_t owner = hp - base;                               // the lane that built the minimum's k-mer (inside this round for every complete window)
+            const uint64_t okey = __shfl(my_key, owner & 63u, 64), ohash = __shfl(my_hash, owner & 63u, 64);
+            const uint32_t orev = __shfl((uint32_t)reverse, owner & 63u, 64);
+            const unsigned long long rb = __ballot(report);
+            const uint32_t n_round = (uint32_t)__popcll(rb);
+            if (report) { MzMin& mm = mins[__popcll(rb & below)]; mm.key = okey; mm.hash_lo = (uint32_t)ohash; mm.pos_rev = (hp << 1) | orev; }
+            const uint32_t round_max = __shfl(run, 63, 64);
+            if (round_max > last_plus1) last_plus1 = round_max;
+            n_min += n_round;
+            MZ_WAVE_SYNC();
+            // this round's minimizers: one lane each probes the table; then their hits in order
+            uint32_t first = 0, count = 0, p = 0, rv = 0;
+            if (lane < n_round && n_seeds < MZ_MAX_SEEDS) {
+                const MzMin mm = mins[lane];
+                MzKmer km; km.key = mm.key; km.hash = mm.hash_lo; km.reverse = (mm.pos_rev & 1u) != 0;
+                p = mm.pos_rev >> 1; rv = mm.pos_rev & 1u;
+                if (!mz_find(P.index, km, first, count) || count > P.hit_cap) count = 0;
+            }
+            const unsigned long long hb = __ballot(count != 0);
+            for (unsigned long long todo = hb; todo && n_seeds < MZ_MAX_SEEDS; todo &= todo - 1) {
+                const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+                const uint32_t cj = __shfl(count, j, 64), fj = __shfl(first, j, 64), pj = __shfl(p, j, 64), rj = __shfl(rv, j, 64);
+                for (uint32_t h0 = 0; h0 < cj && n_seeds < MZ_MAX_SEEDS; h0 += 64) {
+                    unsigned long long key = 0; vgk_seed sd; sd.node = 0; sd.diff = 0;
+                    if (h0 + lane < cj) {
+                        const MzPos qp = P.index.pos[fj + h0 + lane];
+                        if (!rj) { sd.node = qp.node; sd.diff = (int32_t)pj - (int32_t)qp.offset; }
+                        else { sd.node = qp.node ^ 1u; sd.diff = (int32_t)(pj + k - 1) - (int32_t)(g_len(P.graph, (int32_t)qp.node) - 1 - qp.offset); }
+                        key = ((unsigned long long)sd.node << 32) | (uint32_t)sd.diff;
+                    }
+                    const uint32_t in_group = cj - h0 < 64 ? cj - h0 : 64;
+                    for (uint32_t x = 0; x < in_group && n_seeds < MZ_MAX_SEEDS; ++x) {      // in hit order; all lanes agree on every decision
+                        const unsigned long long kx = __shfl(key, x, 64);
+                        const bool dup = __ballot(lane < n_seeds && seen[lane] == kx) != 0ull;
+                        if (!dup) {
+                            if (lane == x) { seen[n_seeds] = key; dst[n_seeds] = sd; }
+                            ++n_seeds;
+                            MZ_WAVE_SYNC();
+                        }
+                    }
+                }
+            }
+            MZ_WAVE_SYNC();
+        }
+    }
+    if (lane == 0) { P.counts[i] = n_seeds; if (P.mins) P.mins[i] = n_min; }
+}
+__global__ void __launch_bounds__(256) minimizer_gather_kernel(const MinimizerParams P, const vgk_seed* slots) {
+    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (i >= P.n) return;
+    const uint32_t at = P.first[i], cnt = P.first[i + 1] - at;
+    if (lane < cnt) P.seeds[at + lane] = slots[(size_t)i * MZ_MAX_SEEDS + lane];
 }
 
 // ---- tail forests (tail_device.hpp): resident lanes take the tails in turn for the walks; one lane per tree node for the graph tables
@@ -348,11 +475,13 @@ public:
     float ms_gapless = 0.f, ms_wfa = 0.f, ms_xband = 0.f;
     float ms_bfill = 0.f, ms_bwalk = 0.f; hipEvent_t bev[3] = {nullptr, nullptr, nullptr};
     void* scan_tmp = nullptr; size_t scan_tmp_bytes = 0;      // rocPRIM's scratch for scan_u32 (grow-only)
+    void* mz_slots = nullptr; size_t mz_slots_bytes = 0;      // per-read seed slots of run_minimizer (grow-only)
     ~HipBackend() override {
         hipSetDevice(dev);
         for (auto& e : ev) if (e) hipEventDestroy(e);
         for (auto& e : bev) if (e) hipEventDestroy(e);
         if (scan_tmp) hipFree(scan_tmp);
+        if (mz_slots) hipFree(mz_slots);
         for (int i = 0; i < 2; ++i) { if (side[i]) hipStreamDestroy(side[i]); if (side_done[i]) hipEventDestroy(side_done[i]); }
         if (stream) hipStreamDestroy(stream);
         if (copy) hipStreamDestroy(copy);
@@ -638,7 +767,14 @@ public:
     int run_minimizer(const MinimizerParams& p) override {
         hipSetDevice(dev);
         if (!p.n) return VGK_OK;
-        hipLaunchKernelGGL(minimizer_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
+        const size_t need = sizeof(vgk_seed) * (size_t)p.n * MZ_MAX_SEEDS;       // a slot of MZ_MAX_SEEDS seeds per read between the two launches
+        if (need > mz_slots_bytes) {
+            if (mz_slots) { hipStreamSynchronize(stream); hipFree(mz_slots); mz_slots = nullptr; mz_slots_bytes = 0; }
+            if (hipMalloc(&mz_slots, need + need / 8) != hipSuccess) return VGK_ENOMEM;
+            mz_slots_bytes = need + need / 8;
+        }
+        if (p.pass == 1) hipLaunchKernelGGL(minimizer_kernel, dim3((p.n + 3) / 4), dim3(256), 0, stream, p, (vgk_seed*)mz_slots);
+        else hipLaunchKernelGGL(minimizer_gather_kernel, dim3((p.n + 3) / 4), dim3(256), 0, stream, p, (const vgk_seed*)mz_slots);
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_tail(const TailParams& p, uint32_t threads) override {

