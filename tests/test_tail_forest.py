@@ -301,3 +301,34 @@ def test_a_walk_deeper_than_the_kernels_stack_is_declined(emu_lib):
     assert res["first_node"][2] == res["n_nodes"][0] and forest.size == 65
     p, n, l = forest.fetch()
     assert list(n[:40]) == [2 * i for i in range(40)] and list(p[:40]) == [-1] + list(range(39))
+
+
+@pytest.mark.parametrize("lib_name", ["oracle", "emu"])
+def test_forests_over_run_length_records_and_nodes_with_many_edges(lib_name, emu_lib):
+    """300 haplotypes (the index stores the visit bodies run-length encoded) and a site with six alleles (more than the four edges the
+    one-pass count handles): the other two branches of the kernel's follow step"""
+    lib = ORACLE_LIB if lib_name == "oracle" else emu_lib
+    rng = np.random.default_rng(31)
+    # a chain with three multi-allelic sites: backbone nodes B_i, between them 6 / 2 / 5 alternative nodes
+    nodes, sites, at = [], [], 0
+    for n_alt in (6, 2, 5):
+        nodes.append("".join("ACGT"[int(x)] for x in rng.integers(0, 4, 20))); b = len(nodes) - 1
+        alts = []
+        for _ in range(n_alt):
+            nodes.append("".join("ACGT"[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 6))))); alts.append(len(nodes) - 1)
+        sites.append((b, alts))
+    nodes.append("ACGTACGTACGTACGTTTGA"); last = len(nodes) - 1
+    threads = []
+    for _ in range(300):
+        t = []
+        for b, alts in sites:
+            t += [2 * b, 2 * alts[int(rng.integers(0, len(alts)))]]
+        threads.append(t + [2 * last])
+    lens = np.repeat(np.array([len(s) for s in nodes]), 2)
+    allt = both_orientations(threads)
+    counts = visit_counts(allt, len(lens))
+    probs = whole_node_problems(rng, lens, counts, 200)
+    expected = [trie_forest(lens, p[0], continuations_of_node(allt, p[0]), p[3], p[4]) for p in probs]
+    eng = capi.Engine(lib=lib)
+    check_forest(eng, eng.haplo_index(nodes, threads), probs, expected)
+    assert max(len(e) for e in expected) >= 14                       # the whole bubble structure behind the first backbone node
