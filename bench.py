@@ -349,21 +349,28 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
     stage = pipeline.align_stage if os.environ.get("VGAMD_GIRAFFE_NUMPY_GLUE") else pipeline.align_stage_native      # the glue in the host shim (C++) or in numpy
     from_reads = bool(os.environ.get("VGAMD_GIRAFFE_FROM_READS"))         # start from the bare reads: minimizer seeding on the device makes the clusters
     mindex = None; seeds_per_read = None; t_index = 0.0
+    stay = from_reads and not os.environ.get("VGAMD_GIRAFFE_SEEDS_VIA_HOST") and stage is pipeline.align_stage_native      # the clusters stay on the device between seeding and extension
+    step_seed_off = [None]
     if from_reads:
         t1 = time.perf_counter(); mindex = eng.minimizer_index(wl.nodes, wl.threads); t_index = time.perf_counter() - t1
 
     def one_step(timing=None):
         gs = wl.gs
+        seeded = None
         if from_reads:
             t1 = time.perf_counter()
-            seed_off, seeds, mins = eng.minimizer_seeds(mindex, index, wl.gs.reads, wl.gs.read_off)
+            seed_off, seeds, mins = eng.minimizer_seeds(mindex, index, wl.gs.reads, wl.gs.read_off, keep_on_device=stay)
             t2 = time.perf_counter()
-            gs = capi.GaplessSet(wl.gs.reads, wl.gs.read_off, seeds, seed_off, node_cap=len(seeds) * 16, mism_cap=len(seeds) * 12)
+            if stay:
+                seeded = int(seed_off[-1]); step_seed_off[0] = seed_off
+            else:
+                gs = capi.GaplessSet(wl.gs.reads, wl.gs.read_off, seeds, seed_off, node_cap=len(seeds) * 16, mism_cap=len(seeds) * 12)
+                step_seed_off[0] = gs.seed_off
             if timing is not None:
                 timing["minimizer_seeds"] = timing.get("minimizer_seeds", 0.0) + t2 - t1
                 timing["minimizer_seeds (device)"] = timing.get("minimizer_seeds (device)", 0.0) + eng.minimizer_last_ms() * 1e-3
                 timing["clusters assembled (host)"] = timing.get("clusters assembled (host)", 0.0) + time.perf_counter() - t2
-        out = stage(eng, index, olen, gs, timing=timing)
+        out = stage(eng, index, olen, gs, timing=timing, seeded=seeded) if seeded is not None else stage(eng, index, olen, gs, timing=timing)
         if "forest" in out:
             out["forest"].close()
         out["gs"] = gs
@@ -379,7 +386,7 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
     barrier()
     elapsed = time.perf_counter() - t0
     if from_reads:
-        seeds_per_read = float(np.diff(out["gs"].seed_off).mean())
+        seeds_per_read = float(np.diff(step_seed_off[0]).mean())
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -414,7 +421,8 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
                                    "inserted base, 4.0 seeds per read at true positions; GaplessExtender + get_tail_forest + align_pinned(xdrop) semantics, scores 1/4/6/1/5" % (n, int(100 * inserted)),
                        "timed_region": "per step, from host buffers: vgk_gapless_extend (results back on the host), then the host shim's run_tail_stage (vg_amd/host/tail_stage.cpp): "
                                        "tails derived on host threads, vgk_tail_forest, one window per tree, vgk_gssw_pack_windows + run + fetch, totals", "reads_without_full_length_extension": open_reads, "tails": n_tails,
-                       "clusters_from": "minimizer seeding on the device (k 29, w 11; %.1f seeds per read; index of %d minimizer k-mers built in %.1f s)" % (seeds_per_read, mindex.keys, t_index) if from_reads else "seeds given (true positions)",
+                       "clusters_from": ("minimizer seeding on the device (k 29, w 11; %.1f seeds per read; index of %d minimizer k-mers built in %.1f s); %s" % (seeds_per_read, mindex.keys, t_index,
+                                          "reads and seeds stay in HBM for the extension (vgk_gapless_extend_seeded)" if stay else "seeds via the host")) if from_reads else "seeds given (true positions)",
                        "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()},
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
             "roofline": {"bound": "hbm", "kernel": "gapless_search_kernel (the stage's largest kernel)", "limiter": "host glue and PCIe round trips between the stages, then memory latency (DESIGN.md §11, §17)",

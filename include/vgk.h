@@ -382,10 +382,18 @@ int  vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* haplotypes, 
 void vgk_minimizer_index_destroy(vgk_minimizer_index* index);
 uint64_t vgk_minimizer_index_keys(const vgk_minimizer_index* index);      /* distinct minimizer k-mers */
 /* reads: flat, read i = reads[read_off[i], read_off[i + 1]).  seed_off[n + 1] and, nullable, minimizers[n] (minimizers per read) are
- * filled always; seeds up to seeds_cap (VGK_EOPS when that is too small; *written = the number needed). */
+ * filled always; seeds up to seeds_cap (VGK_EOPS when that is too small; *written = the number needed); seeds = NULL with seeds_cap = 0
+ * leaves them on the device only (for vgk_gapless_extend_seeded). */
 int  vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* index, const vgk_haplo* graph, const char* reads, const uint64_t* read_off, uint32_t n,
                          uint32_t hit_cap, uint32_t* seed_off, uint32_t* minimizers, vgk_seed* seeds, size_t seeds_cap, size_t* written);
 double vgk_minimizer_last_ms(vgk_ctx* ctx);                              /* device time of the last vgk_minimizer_seeds call */
+/* The clusters of the last vgk_minimizer_seeds call on this context, extended as vgk_gapless_extend would extend them — without the
+ * reads or the seeds crossing PCIe again: they are still in HBM (reads masked and padded as the extension kernels want them), and the
+ * problem descriptors and the hand-out order are made there.  `index` must be the haplotype index that call was given; one
+ * max_mismatches / overlap_threshold / flags (VGK_GAPLESS_TRIM) for all reads.  Outputs as vgk_gapless_extend. */
+int  vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max_mismatches, double overlap_threshold, uint32_t flags,
+                               vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
+                               uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]);
 
 /* ---- haplotype-consistent wavefront alignment (WFAExtender, src/gbwt_extender.cpp:2052-2263) ------------
  * Replaces WFAExtender::connect(sequence, from, to), ::suffix(sequence, from) and ::prefix(sequence, to)

@@ -492,3 +492,12 @@ int vgk_forest_fetch(const vgk_forest* f, int32_t* parent, uint32_t* node, uint3
 }
 const vgk_dgraph* vgk_forest_graph(const vgk_forest* f) { return f ? f->graph : NULL; }
 double vgk_tail_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }
+
+/* the oracle keeps nothing between calls: the seeded form is not available on it (callers use vgk_gapless_extend) */
+int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max_mismatches, double overlap_threshold, uint32_t flags,
+                              vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
+                              uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) {
+    (void)ctx; (void)index; (void)max_mismatches; (void)overlap_threshold; (void)flags; (void)results; (void)extensions; (void)ext_cap;
+    (void)nodes; (void)nodes_cap; (void)mismatches; (void)mism_cap; (void)written;
+    return VGK_EUNSUPPORTED;
+}

@@ -96,6 +96,15 @@ public:
         return VGK_OK;
     }
     int gapless_order(const GOrderParams& P, int stage) override { for (uint32_t i = 0; i < P.n; ++i) { if (stage == 1) g_order_sizes_one(P, i); else g_order_gather_one(P, i); } return VGK_OK; }
+    int gapless_seeded(const GSeededParams& P) override { for (uint32_t i = 0; i < P.n; ++i) g_seeded_one(P, i); return VGK_OK; }
+    int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint32_t n, int bits) override {
+        std::vector<uint32_t> order(n);
+        for (uint32_t i = 0; i < n; ++i) order[i] = i;
+        const uint32_t mask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (kin[a] & mask) < (kin[b] & mask); });
+        for (uint32_t i = 0; i < n; ++i) { kout[i] = kin[order[i]]; vout[i] = vin[order[i]]; }
+        return VGK_OK;
+    }
     int mask_reads(char* reads, size_t bytes) override { for (size_t k = 0; k < bytes; ++k) reads[k] = g_mask_base(reads[k]); return VGK_OK; }
     int run_minimizer(const MinimizerParams& P) override { for (uint32_t i = 0; i < P.n; ++i) minimizer_one(P, i); return VGK_OK; }
     int run_tail(const TailParams& P, uint32_t threads) override {

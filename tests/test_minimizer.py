@@ -176,3 +176,44 @@ def test_seeds_on_the_gpu_equal_the_brute_force_construction():
     run(ENGINE_LIB, 8, 15, 6, 400)
     run(ENGINE_LIB, 9, 31, 32, 150)                 # the widest window the kernel takes
     run(ENGINE_LIB, 10, 21, 7, 60, L=1500)          # many rounds per read, more than 64 distinct seeds
+
+
+def seeded_equals_via_host(lib, n_reads, seed):
+    """vgk_gapless_extend_seeded (clusters left on the device by the seeding) = vgk_gapless_extend on the same seeds brought through the host,
+    byte for byte; and the stage built on it gives the oracle pipeline's per-read totals"""
+    from vg_amd import pipeline
+    wl = workloads.GaplessWorkload(4, seed=seed, graph_bp=30000, n_haplotypes=4)
+    rng = np.random.default_rng(seed)
+    reads, truth = sample_reads(rng, wl.nodes, wl.threads, n_reads, 150, error=0.01, with_n=0.05)
+    reads[3] = reads[3][:70] + "ACG" + reads[3][70:147]                     # an insertion: tails for the stage below
+    flat = np.frombuffer("".join(reads).encode(), dtype=np.uint8); off = np.concatenate([[0], np.cumsum([len(r) for r in reads])])
+    eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=lib)
+    mi = eng.minimizer_index(wl.nodes, wl.threads); hi = eng.haplo_index(wl.nodes, wl.threads)
+    seed_off, seeds, _ = eng.minimizer_seeds(mi, hi, flat, off)
+    via_host = eng.gapless_extend(hi, capi.GaplessSet(flat, off, seeds, seed_off))
+    so2, none, _ = eng.minimizer_seeds(mi, hi, flat, off, keep_on_device=True)
+    assert (so2 == seed_off).all() and len(none) == 0
+    seeded = eng.gapless_extend_seeded(hi, len(reads), int(seed_off[-1]))
+    for x, y in zip(seeded, via_host):
+        assert x.tobytes() == y.tobytes()
+    # without a seeding call before it, or with another index, the seeded form refuses
+    eng2 = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=lib)
+    with pytest.raises(capi.VgkError):
+        eng2.gapless_extend_seeded(eng2.haplo_index(wl.nodes, wl.threads), len(reads), 10)
+    olen = np.repeat(np.array([len(s) for s in wl.nodes]), 2)
+    gs = capi.GaplessSet(flat, off, seeds, seed_off)
+    eng.minimizer_seeds(mi, hi, flat, off, keep_on_device=True)
+    a = pipeline.align_stage_native(eng, hi, olen, gs, seeded=int(seed_off[-1]))
+    ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=ORACLE_LIB)
+    oso, oseeds, _ = ora.minimizer_seeds(ora.minimizer_index(wl.nodes, wl.threads), ora.haplo_index(wl.nodes, wl.threads), flat, off)
+    b = pipeline.align_stage(ora, ora.haplo_index(wl.nodes, wl.threads), olen, capi.GaplessSet(flat, off, oseeds, oso))
+    assert (a["read_score"] == b["read_score"]).all()
+
+
+def test_clusters_that_stay_on_the_device(emu_lib):
+    seeded_equals_via_host(emu_lib, 200, 21)
+
+
+@pytest.mark.gpu
+def test_clusters_that_stay_on_the_device_on_the_gpu():
+    seeded_equals_via_host(ENGINE_LIB, 5000, 22)

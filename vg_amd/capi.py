@@ -371,19 +371,20 @@ class Engine:
     def minimizer_index(self, nodes, threads, k=29, w=11):
         return MinimizerIndex(self, nodes, threads, k, w)
 
-    def minimizer_seeds(self, mindex, hindex, reads, read_off, hit_cap=500):
-        """vgk_minimizer_seeds: reads flat (uint8), read i = reads[read_off[i]:read_off[i+1]] -> (seed_off [n+1], seeds as SEED_DT, minimizers per read)"""
+    def minimizer_seeds(self, mindex, hindex, reads, read_off, hit_cap=500, keep_on_device=False):
+        """vgk_minimizer_seeds: reads flat (uint8), read i = reads[read_off[i]:read_off[i+1]] -> (seed_off [n+1], seeds as SEED_DT, minimizers per read);
+        keep_on_device: the seeds stay in HBM for gapless_extend_seeded (an empty seeds array comes back)"""
         reads = np.ascontiguousarray(reads, dtype=np.uint8); off = np.ascontiguousarray(read_off, dtype=np.uint64)
         n = len(off) - 1
         seed_off = np.zeros(n + 1, dtype=np.uint32); mins = np.zeros(max(n, 1), dtype=np.uint32)
-        cap = 64 * max(n, 1)
-        seeds = np.zeros(cap, dtype=SEED_DT)
+        cap = 0 if keep_on_device else 64 * max(n, 1)
+        seeds = np.zeros(max(cap, 1), dtype=SEED_DT)
         written = ctypes.c_size_t()
         self.lib.vgk_minimizer_seeds.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         self._check(self.lib.vgk_minimizer_seeds(self.h, mindex.h, hindex.h, reads.ctypes.data, off.ctypes.data, n, hit_cap, seed_off.ctypes.data, mins.ctypes.data,
-                                                 seeds.ctypes.data, cap, ctypes.byref(written)), "vgk_minimizer_seeds")
-        return seed_off, seeds[:written.value], mins[:n]
+                                                 None if keep_on_device else seeds.ctypes.data, cap, ctypes.byref(written)), "vgk_minimizer_seeds")
+        return seed_off, seeds[:0 if keep_on_device else written.value], mins[:n]
 
     def minimizer_last_ms(self):
         self.lib.vgk_minimizer_last_ms.restype = ctypes.c_double; self.lib.vgk_minimizer_last_ms.argtypes = [ctypes.c_void_p]
@@ -402,6 +403,19 @@ class Engine:
     def tail_last_ms(self):
         self.lib.vgk_tail_last_ms.restype = ctypes.c_double; self.lib.vgk_tail_last_ms.argtypes = [ctypes.c_void_p]
         return self.lib.vgk_tail_last_ms(self.h)
+
+    def gapless_extend_seeded(self, index, n_reads, n_seeds, max_mismatches=4, overlap_threshold=0.8, trim=True, read_len=150):
+        """vgk_gapless_extend_seeded: extend the clusters the last minimizer_seeds call left on the device -> as gapless_extend"""
+        res = np.zeros(max(n_reads, 1), dtype=GAPLESS_RESULT_DT)
+        ext_cap = n_seeds + 1; node_cap = n_seeds * 16 + 1024; mism_cap = n_seeds * 12 + 1024
+        ext = np.zeros(ext_cap, dtype=EXT_DT); nodes = np.zeros(node_cap, dtype=np.uint32); mism = np.zeros(mism_cap, dtype=np.uint32)
+        written = (ctypes.c_size_t * 3)()
+        self.lib.vgk_gapless_extend_seeded.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_double, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                                       ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        self._check(self.lib.vgk_gapless_extend_seeded(self.h, index.h, max_mismatches, overlap_threshold, VGK_GAPLESS_TRIM if trim else 0, res.ctypes.data,
+                                                       ext.ctypes.data, ext_cap, nodes.ctypes.data, node_cap, mism.ctypes.data, mism_cap, ctypes.byref(written)),
+                    "vgk_gapless_extend_seeded")
+        return res[:n_reads], ext[:written[0]], nodes[:written[1]], mism[:written[2]]
 
     def gapless_last_ms(self):
         return self.lib.vgk_gapless_last_ms(self.h)

@@ -94,6 +94,10 @@ public:
     // in between are scan_u32's); mask_reads = ReadMasker over a byte range in place.  All asynchronous on the main stream.
     virtual int   gapless_order(const GOrderParams& p, int stage) = 0;
     virtual int   mask_reads(char* reads, size_t bytes) = 0;
+    // clusters left on the device by the seeding: problem descriptors + hand-out keys (g_seeded_one), and a stable sort of (key, value)
+    // pairs by the low `bits` bits of the key
+    virtual int   gapless_seeded(const GSeededParams& p) = 0;
+    virtual int   sort_pairs_u32(const uint32_t* key_in, uint32_t* key_out, const uint32_t* val_in, uint32_t* val_out, uint32_t n, int bits) = 0;
     // wavefront alignment: likewise, `threads` resident threads (one WScratch each, zeroed by the caller once) stride over
     // p.n problems; last_ms(6) = kernel ms
     virtual int   run_wfa(const WfaParams& p, uint32_t threads) = 0;

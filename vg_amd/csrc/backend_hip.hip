@@ -276,6 +276,10 @@ __global__ void __launch_bounds__(256) gapless_order_kernel(const GOrderParams P
     if (i >= P.n) return;
     if (stage == 1) g_order_sizes_one(P, i); else g_order_gather_one(P, i);
 }
+__global__ void __launch_bounds__(256) gapless_seeded_kernel(const GSeededParams P) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < P.n) g_seeded_one(P, i);
+}
 __global__ void __launch_bounds__(256) mask_reads_kernel(char* reads, const size_t bytes) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
     if (i >= bytes) return;
@@ -757,6 +761,23 @@ public:
         if (!p.n) return VGK_OK;
         hipLaunchKernelGGL(gapless_order_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p, stage);
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int gapless_seeded(const GSeededParams& p) override {
+        hipSetDevice(dev);
+        if (!p.n) return VGK_OK;
+        hipLaunchKernelGGL(gapless_seeded_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint32_t n, int bits) override {
+        hipSetDevice(dev);
+        if (!n) return VGK_OK;
+        const size_t need = hip_sort_tmp_bytes(n);
+        if (need > scan_tmp_bytes) {
+            if (scan_tmp) { hipStreamSynchronize(stream); hipFree(scan_tmp); scan_tmp = nullptr; scan_tmp_bytes = 0; }
+            if (hipMalloc(&scan_tmp, need + need / 4) != hipSuccess) return VGK_ENOMEM;
+            scan_tmp_bytes = need + need / 4;
+        }
+        return hip_sort_pairs_u32(kin, kout, vin, vout, n, bits, scan_tmp, scan_tmp_bytes, stream);
     }
     int mask_reads(char* reads, size_t bytes) override {
         hipSetDevice(dev);

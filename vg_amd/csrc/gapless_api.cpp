@@ -205,65 +205,18 @@ void vgk_haplo_destroy(vgk_haplo* h) {
     delete h;
 }
 
-int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_problem* problems, uint32_t n,
-                       vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
-                       uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) {
-    if (!ctx || !index || index->ctx != ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
-    if (written) written[0] = written[1] = written[2] = 0;
-    if (!n) return VGK_OK;
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    ctx->gapless_last_valid = false;
+// Everything behind "the inputs are on the device": the three kernels, the sets put in problem order on the device, the way back.
+// P carries index, probs, reads, seeds, order, n; n_seed = seeds of the whole batch; `slot` = the next free scratch slot.
+static int gapless_run_and_fetch(vgk_ctx* ctx, GaplessParams& P, uint32_t n, uint64_t n_seed, int next_slot, GaplessHost& H, GLap& lap,
+                                 vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
+                                 uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) {
     Backend* be = ctx->be.get();
-    GLap lap;
-    // pack: masked reads (ReadMasker, src/gbwt_extender.cpp:160-176), seeds
-    std::vector<GProb> probs(n);
-    uint64_t n_read = 0, n_seed = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        const vgk_gapless_problem& p = problems[i];
-        if ((p.read_len && !p.read) || (p.n_seeds && !p.seeds)) return VGK_EINVAL;
-        probs[i] = {(uint32_t)n_read + 8, p.read_len, (uint32_t)n_seed, p.n_seeds, p.max_mismatches, p.flags, p.overlap_threshold};
-        n_read += p.read_len; n_seed += p.n_seeds;
-        if (n_read > 0xfffffff0ull || n_seed > 0xfffffff0ull) return VGK_ETOOBIG;
-    }
-    if (!ctx->gapless_host) ctx->gapless_host = std::make_shared<GaplessHost>();
-    GaplessHost& H = *static_cast<GaplessHost*>(ctx->gapless_host.get());
-    char* reads = H.reads.get(be, n_read + 16); vgk_seed* seeds = H.seeds.get(be, n_seed + 1);
-    if (!reads || !seeds) return VGK_ENOMEM;     // 8 bytes of padding at either end
-    std::memset(reads, 0, 8); std::memset(reads + 8 + n_read, 0, 8);
-    parallel_for(n, [&](uint32_t i, unsigned) {                       // (the masking itself happens on the device, over the uploaded bytes)
-        const vgk_gapless_problem& p = problems[i];
-        if (p.read_len) std::memcpy(reads + probs[i].read_off, p.read, p.read_len);
-        if (p.n_seeds) std::memcpy(seeds + probs[i].seed_off, p.seeds, sizeof(vgk_seed) * p.n_seeds);
-    });
-    lap("reads masked, seeds copied");
-    // device buffers are kept on the context between calls (grow-only)
-    int next_slot = 16;
     auto cleanup = [&](int rc) { return rc; };
     auto dev = [&](const void* src, size_t bytes) -> void* {
         void* d = ctx->ensure_scratch(next_slot++, std::max<size_t>(bytes, 16)); if (!d) return nullptr;
         if (src && bytes && be->upload(d, src, bytes)) return nullptr;
         return d;
     };
-    GaplessParams P{};
-    P.index = index->dev; P.n = n;
-    P.probs = (const GProb*)dev(probs.data(), sizeof(GProb) * n);
-    P.reads = (const char*)dev(reads, n_read + 16);
-    if (P.reads && (be->mask_reads(const_cast<char*>(P.reads), n_read + 16) || be->zero(const_cast<char*>(P.reads), 8) || be->zero(const_cast<char*>(P.reads) + 8 + n_read, 8))) return VGK_ENODEV;
-    P.seeds = (const vgk_seed*)dev(seeds, sizeof(vgk_seed) * (n_seed + 1));
-    // processing order: by the node of the first seed (a counting sort; reads without seeds last).  Results do not depend on it —
-    // problems are independent and the sets are handed back in problem order below — but reads that sit next to each other in a
-    // wavefront now walk the same records and bases, which the L2 then serves (FETCH_SIZE per million reads: see DESIGN.md §11)
-    std::vector<uint32_t> order(n);
-    {
-        const uint32_t buckets = index->n_oriented / 2 + 2;
-        std::vector<uint32_t> start(buckets + 1, 0);
-        auto key = [&](uint32_t i) { const vgk_gapless_problem& p = problems[i]; const uint32_t v = p.n_seeds ? p.seeds[0].node / 2 : buckets - 1; return v < buckets - 1 ? v : buckets - 1; };
-        for (uint32_t i = 0; i < n; ++i) ++start[key(i) + 1];
-        for (uint32_t b = 0; b < buckets; ++b) start[b + 1] += start[b];
-        for (uint32_t i = 0; i < n; ++i) order[start[key(i)]++] = i;
-    }
-    if (std::getenv("VGAMD_GAPLESS_UNSORTED")) for (uint32_t i = 0; i < n; ++i) order[i] = i;
-    P.order = (const uint32_t*)dev(order.data(), sizeof(uint32_t) * n);
     P.match = ctx->sc.matrix[0]; P.mismatch = -ctx->sc.matrix[1]; P.bonus = ctx->sc.full_length_bonus;
     // dense outputs: at most one extension per seed; nodes / mismatches sized generously and checked on the device
     const uint64_t cap_e = n_seed + 1, cap_n = std::min<uint64_t>(n_seed * G_PATH, std::max<uint64_t>(n_seed * 16 + 1024, nodes_cap)) + 1,
@@ -369,6 +322,108 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     lap("sets copied out");
     if (written) { written[0] = we; written[1] = wn; written[2] = wm; }
     return cleanup(rc_all);
+}
+
+
+int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_problem* problems, uint32_t n,
+                       vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
+                       uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) {
+    if (!ctx || !index || index->ctx != ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
+    if (written) written[0] = written[1] = written[2] = 0;
+    if (!n) return VGK_OK;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->gapless_last_valid = false;
+    Backend* be = ctx->be.get();
+    GLap lap;
+    // pack: masked reads (ReadMasker, src/gbwt_extender.cpp:160-176), seeds
+    std::vector<GProb> probs(n);
+    uint64_t n_read = 0, n_seed = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const vgk_gapless_problem& p = problems[i];
+        if ((p.read_len && !p.read) || (p.n_seeds && !p.seeds)) return VGK_EINVAL;
+        probs[i] = {(uint32_t)n_read + 8, p.read_len, (uint32_t)n_seed, p.n_seeds, p.max_mismatches, p.flags, p.overlap_threshold};
+        n_read += p.read_len; n_seed += p.n_seeds;
+        if (n_read > 0xfffffff0ull || n_seed > 0xfffffff0ull) return VGK_ETOOBIG;
+    }
+    if (!ctx->gapless_host) ctx->gapless_host = std::make_shared<GaplessHost>();
+    GaplessHost& H = *static_cast<GaplessHost*>(ctx->gapless_host.get());
+    char* reads = H.reads.get(be, n_read + 16); vgk_seed* seeds = H.seeds.get(be, n_seed + 1);
+    if (!reads || !seeds) return VGK_ENOMEM;     // 8 bytes of padding at either end
+    std::memset(reads, 0, 8); std::memset(reads + 8 + n_read, 0, 8);
+    parallel_for(n, [&](uint32_t i, unsigned) {                       // (the masking itself happens on the device, over the uploaded bytes)
+        const vgk_gapless_problem& p = problems[i];
+        if (p.read_len) std::memcpy(reads + probs[i].read_off, p.read, p.read_len);
+        if (p.n_seeds) std::memcpy(seeds + probs[i].seed_off, p.seeds, sizeof(vgk_seed) * p.n_seeds);
+    });
+    lap("reads masked, seeds copied");
+    // device buffers are kept on the context between calls (grow-only)
+    int next_slot = 16;
+    auto cleanup = [&](int rc) { return rc; };
+    auto dev = [&](const void* src, size_t bytes) -> void* {
+        void* d = ctx->ensure_scratch(next_slot++, std::max<size_t>(bytes, 16)); if (!d) return nullptr;
+        if (src && bytes && be->upload(d, src, bytes)) return nullptr;
+        return d;
+    };
+    GaplessParams P{};
+    P.index = index->dev; P.n = n;
+    P.probs = (const GProb*)dev(probs.data(), sizeof(GProb) * n);
+    P.reads = (const char*)dev(reads, n_read + 16);
+    if (P.reads && (be->mask_reads(const_cast<char*>(P.reads), n_read + 16) || be->zero(const_cast<char*>(P.reads), 8) || be->zero(const_cast<char*>(P.reads) + 8 + n_read, 8))) return VGK_ENODEV;
+    P.seeds = (const vgk_seed*)dev(seeds, sizeof(vgk_seed) * (n_seed + 1));
+    // processing order: by the node of the first seed (a counting sort; reads without seeds last).  Results do not depend on it —
+    // problems are independent and the sets are handed back in problem order below — but reads that sit next to each other in a
+    // wavefront now walk the same records and bases, which the L2 then serves (FETCH_SIZE per million reads: see DESIGN.md §11)
+    std::vector<uint32_t> order(n);
+    {
+        const uint32_t buckets = index->n_oriented / 2 + 2;
+        std::vector<uint32_t> start(buckets + 1, 0);
+        auto key = [&](uint32_t i) { const vgk_gapless_problem& p = problems[i]; const uint32_t v = p.n_seeds ? p.seeds[0].node / 2 : buckets - 1; return v < buckets - 1 ? v : buckets - 1; };
+        for (uint32_t i = 0; i < n; ++i) ++start[key(i) + 1];
+        for (uint32_t b = 0; b < buckets; ++b) start[b + 1] += start[b];
+        for (uint32_t i = 0; i < n; ++i) order[start[key(i)]++] = i;
+    }
+    if (std::getenv("VGAMD_GAPLESS_UNSORTED")) for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    P.order = (const uint32_t*)dev(order.data(), sizeof(uint32_t) * n);
+    return gapless_run_and_fetch(ctx, P, n, n_seed, next_slot, H, lap, results, extensions, ext_cap, nodes, nodes_cap, mismatches, mism_cap, written);
+}
+
+// The clusters of the last vgk_minimizer_seeds call, extended without leaving the device in between: the reads it uploaded (masked,
+// padded), the seeds it found and their offsets per read are still in HBM; the problem descriptors and the hand-out order are made
+// there too (a kernel + a radix sort).  One setting of max_mismatches / overlap_threshold / flags for the whole batch.
+int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max_mismatches, double overlap_threshold, uint32_t flags,
+                              vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
+                              uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) {
+    if (!ctx || !index || index->ctx != ctx) return VGK_EINVAL;
+    if (written) written[0] = written[1] = written[2] = 0;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->seeded.valid || ctx->seeded.graph != index) return VGK_EINVAL;
+    const uint32_t n = ctx->seeded.n;
+    if (!n) return VGK_OK;
+    if (!results) return VGK_EINVAL;
+    ctx->gapless_last_valid = false;
+    Backend* be = ctx->be.get();
+    GLap lap;
+    if (!ctx->gapless_host) ctx->gapless_host = std::make_shared<GaplessHost>();
+    GaplessHost& H = *static_cast<GaplessHost*>(ctx->gapless_host.get());
+    const uint64_t n_seed = ctx->seeded.n_seeds;
+    int next_slot = 16;
+    GProb* d_probs = (GProb*)ctx->ensure_scratch(next_slot++, sizeof(GProb) * (size_t)n);
+    uint32_t* d_sort = (uint32_t*)ctx->ensure_scratch(next_slot++, sizeof(uint32_t) * 4 * (size_t)n);      // key, index, sorted key, order
+    if (!d_probs || !d_sort) return VGK_ENOMEM;
+    const uint32_t buckets = index->n_oriented / 2 + 2;
+    int bits = 1; while ((1u << bits) < buckets && bits < 32) ++bits;
+    GSeededParams S{};
+    S.n = n; S.read_off = ctx->seeded.read_off; S.seed_off = ctx->seeded.seed_off; S.seeds = ctx->seeded.seeds;
+    S.max_mm = max_mismatches; S.flags = flags; S.overlap = overlap_threshold; S.buckets = buckets;
+    S.probs = d_probs; S.key = d_sort; S.idx = d_sort + n;
+    int rc = be->gapless_seeded(S);
+    if (!rc) rc = be->sort_pairs_u32(d_sort, d_sort + 2 * (size_t)n, d_sort + n, d_sort + 3 * (size_t)n, n, bits);
+    if (rc) return rc;
+    GaplessParams P{};
+    P.index = index->dev; P.n = n;
+    P.probs = d_probs; P.reads = ctx->seeded.reads; P.seeds = ctx->seeded.seeds; P.order = d_sort + 3 * (size_t)n;
+    lap("descriptors and order on the device");
+    return gapless_run_and_fetch(ctx, P, n, n_seed, next_slot, H, lap, results, extensions, ext_cap, nodes, nodes_cap, mismatches, mism_cap, written);
 }
 
 int vgk_gapless_rerun(vgk_ctx* ctx) {

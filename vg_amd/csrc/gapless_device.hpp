@@ -1016,4 +1016,22 @@ VGK_HD void g_order_gather_one(const GOrderParams& P, uint32_t i) {
 // ReadMasker (src/gbwt_extender.cpp:160-176) on the device: anything but ACGT never matches
 VGK_HD char g_mask_base(char c) { return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'X'; }
 
+// ---- clusters that never left the device (vgk_gapless_extend_seeded): the problem descriptors and the hand-out keys from what
+//      vgk_minimizer_seeds left in HBM
+struct GSeededParams {
+    uint32_t n; const uint64_t* read_off;       // reads relative to the first; the read buffer carries 8 bytes of padding in front
+    const uint32_t* seed_off; const vgk_seed* seeds;
+    uint32_t max_mm, flags; double overlap; uint32_t buckets;
+    GProb* probs; uint32_t* key; uint32_t* idx;
+};
+VGK_HD void g_seeded_one(const GSeededParams& P, uint32_t i) {
+    GProb pb;
+    pb.read_off = (uint32_t)P.read_off[i] + 8u; pb.read_len = (uint32_t)(P.read_off[i + 1] - P.read_off[i]);
+    pb.seed_off = P.seed_off[i]; pb.n_seeds = P.seed_off[i + 1] - P.seed_off[i];
+    pb.max_mm = P.max_mm; pb.flags = P.flags; pb.overlap = P.overlap;
+    P.probs[i] = pb;
+    const uint32_t v = pb.n_seeds ? P.seeds[pb.seed_off].node / 2u : P.buckets - 1u;       // the hand-out order: by the node of the first seed, reads without seeds last
+    P.key[i] = v < P.buckets - 1u ? v : P.buckets - 1u; P.idx[i] = i;
+}
+
 }  // namespace vgk

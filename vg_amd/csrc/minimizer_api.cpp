@@ -112,7 +112,8 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
     if (bytes > 0xfffffff0ull) return VGK_ETOOBIG;
     Backend* be = ctx->be.get();
     std::lock_guard<std::mutex> lk(ctx->mu);
-    char* d_reads = (char*)ctx->ensure_scratch(55, bytes + 16);
+    ctx->seeded.valid = false;
+    char* d_reads = (char*)ctx->ensure_scratch(55, bytes + 32);              // 8 bytes of padding at either end, as the extension kernels want them
     uint64_t* d_off = (uint64_t*)ctx->ensure_scratch(56, sizeof(uint64_t) * ((size_t)n + 1));
     uint32_t* d_tab = (uint32_t*)ctx->ensure_scratch(57, sizeof(uint32_t) * 3 * ((size_t)n + 1));
     if (!d_reads || !d_off || !d_tab) return VGK_ENOMEM;
@@ -120,9 +121,12 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
     std::vector<uint64_t> rel(n1);
     for (size_t i = 0; i < n1; ++i) rel[i] = read_off[i] - read_off[0];
     MinimizerParams P{};
-    P.index = ix->dev; P.graph = graph->dev; P.reads = d_reads; P.read_off = d_off; P.n = n; P.hit_cap = hit_cap ? hit_cap : 0xffffffffu;
+    P.index = ix->dev; P.graph = graph->dev; P.reads = d_reads + 8; P.read_off = d_off; P.n = n; P.hit_cap = hit_cap ? hit_cap : 0xffffffffu;
     P.counts = d_tab; P.mins = d_tab + n1; P.first = d_tab + 2 * n1;
-    int rc = be->upload(d_reads, reads + read_off[0], bytes);
+    int rc = be->upload(d_reads + 8, reads + read_off[0], bytes);
+    if (!rc) rc = be->mask_reads(d_reads, bytes + 16);                       // ReadMasker once, for the seeding (anything but ACGT is no k-mer) and the extension
+    if (!rc) rc = be->zero(d_reads, 8);
+    if (!rc) rc = be->zero(d_reads + 8 + bytes, 8);
     if (!rc) rc = be->upload(d_off, rel.data(), sizeof(uint64_t) * n1);
     if (!rc) rc = be->zero(d_tab, sizeof(uint32_t) * 3 * n1);
     be->watch(0);                                                          // (the stopwatch covers the kernels and scans, not the reads' way up)
@@ -134,17 +138,20 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
     if (rc) return rc;
     const size_t total = seed_off[n];
     if (written) *written = total;
-    if (total > seeds_cap || (total && !seeds)) return VGK_EOPS;
+    const bool keep_on_device = !seeds && !seeds_cap;                         // the caller goes on with vgk_gapless_extend_seeded: the seeds need not come down
+    if (!keep_on_device && (total > seeds_cap || (total && !seeds))) return VGK_EOPS;
     if (total) {
         vgk_seed* d_seeds = (vgk_seed*)ctx->ensure_scratch(58, sizeof(vgk_seed) * total);
         if (!d_seeds) return VGK_ENOMEM;
         P.seeds = d_seeds; P.pass = 2;
         rc = be->run_minimizer(P);
         be->watch(1);
-        if (!rc) rc = be->download(seeds, d_seeds, sizeof(vgk_seed) * total);
+        if (!rc) rc = keep_on_device ? be->sync() : be->download(seeds, d_seeds, sizeof(vgk_seed) * total);
         if (rc) return rc;
     } else { be->watch(1); be->sync(); }
     ctx->minimizer_ms = be->watch_ms();
+    ctx->seeded.valid = true; ctx->seeded.n = n; ctx->seeded.reads = d_reads; ctx->seeded.bytes = bytes; ctx->seeded.read_off = d_off;
+    ctx->seeded.seed_off = d_tab + 2 * n1; ctx->seeded.seeds = P.seeds; ctx->seeded.n_seeds = total; ctx->seeded.graph = graph;
     return VGK_OK;
 }
 

@@ -101,6 +101,16 @@ int hip_win_stage2(const WinParams& P, void* tmp, size_t tmp_bytes, hipStream_t 
     return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
 }
 
+size_t hip_sort_tmp_bytes(uint32_t n) {
+    size_t b = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32, (hipStream_t)0);
+    return b + 256;
+}
+int hip_sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint32_t n, int bits, void* tmp, size_t tmp_bytes, hipStream_t st) {
+    size_t bytes = tmp_bytes;
+    if (hipcub::DeviceRadixSort::SortPairs(tmp, bytes, kin, kout, vin, vout, n, 0, bits, st) != hipSuccess) return VGK_ENODEV;
+    return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+}
 size_t hip_scan_tmp_bytes(uint32_t n) {
     size_t b = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, (hipStream_t)0);

@@ -152,12 +152,15 @@ def _host_lib():
     return _HOST
 
 
-def align_stage_native(eng, index, oriented_len, gs, ops_per_problem=32, scoring=(1, 6, 1, 5), timing=None):
+def align_stage_native(eng, index, oriented_len, gs, ops_per_problem=32, scoring=(1, 6, 1, 5), timing=None, seeded=None):
     """align_stage with everything behind the gapless extension done by the host shim's run_tail_stage (C++ threads instead of numpy)
     -> dict(res, ext, nodes, ext_total, read_score, stats = (tails, trees, tree nodes, failed), stage_ms)"""
     import time
     t0 = time.perf_counter()
-    res, ext, nodes, mism = eng.gapless_extend(index, gs)
+    if seeded is not None:          # the clusters are on the device already (minimizer_seeds(keep_on_device=True)): seeded = number of seeds
+        res, ext, nodes, mism = eng.gapless_extend_seeded(index, gs.n, int(seeded))
+    else:
+        res, ext, nodes, mism = eng.gapless_extend(index, gs)
     t1 = time.perf_counter()
     h = _host_lib()
     n_ext = int(res["n_ext"].sum())
