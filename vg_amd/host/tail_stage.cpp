@@ -10,10 +10,9 @@
 namespace vgamd {
 namespace {
 
-template <class F> void for_chunks(size_t n, F f) {                       // f(lo, hi, chunk) on a few threads, chunks in index order
+template <class F> void for_chunks(size_t n, F f, size_t chunk = 4096) {                       // f(lo, hi, chunk) on a few threads, chunks in index order
     unsigned T = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* e = std::getenv("VGAMD_HOST_THREADS")) T = (unsigned)std::max(1, std::atoi(e));
-    const size_t chunk = 4096;
     const size_t chunks = (n + chunk - 1) / chunk;
     if (chunks <= 1 || T <= 1) { for (size_t c = 0; c < chunks; ++c) f(c * chunk, std::min(n, (c + 1) * chunk), c); return; }
     std::atomic<size_t> next{0};
@@ -41,8 +40,8 @@ double ms_since(Clock::time_point& t0) { const auto t = Clock::now(); const doub
 int run_tail_stage(const EngineApi& api, vgk_ctx* ctx, const vgk_haplo* index, const TailStageInput& in, TailStageOutput& out) {
     auto t0 = Clock::now();
     const uint32_t n = in.n_reads;
-    uint64_t n_ext = 0;
-    for (uint32_t i = 0; i < n; ++i) n_ext = std::max<uint64_t>(n_ext, in.res[i].n_ext ? (uint64_t)in.res[i].ext_begin + in.res[i].n_ext : 0);
+    // (the sets come in problem order, as vgk_gapless_extend hands them back: the last read's end is the number of extensions)
+    const uint64_t n_ext = n ? (uint64_t)in.res[n - 1].ext_begin + in.res[n - 1].n_ext : 0;
     std::vector<uint32_t> read_of(n_ext);
     for_chunks(n, [&](size_t lo, size_t hi, size_t) { for (size_t i = lo; i < hi; ++i) for (uint32_t k = 0; k < in.res[i].n_ext; ++k) read_of[in.res[i].ext_begin + k] = (uint32_t)i; });
     // which tails exist: right tails of every extension first, then left tails (two passes over the extensions, each in index order)
@@ -73,13 +72,19 @@ int run_tail_stage(const EngineApi& api, vgk_ctx* ctx, const vgk_haplo* index, c
             }
         }
     });
-    std::vector<Tail> tails; std::vector<vgk_tail_problem> problems;
-    for (size_t c = 0; c < chunks; ++c) { tails.insert(tails.end(), part_r[c].begin(), part_r[c].end()); problems.insert(problems.end(), prob_r[c].begin(), prob_r[c].end()); }
-    for (size_t c = 0; c < chunks; ++c) { tails.insert(tails.end(), part_l[c].begin(), part_l[c].end()); problems.insert(problems.end(), prob_l[c].begin(), prob_l[c].end()); }
-    const size_t nt = tails.size();
+    std::vector<size_t> at_r(chunks + 1, 0), at_l(chunks + 1, 0);
+    for (size_t c = 0; c < chunks; ++c) { at_r[c + 1] = at_r[c] + part_r[c].size(); at_l[c + 1] = at_l[c] + part_l[c].size(); }
+    const size_t nt = at_r[chunks] + at_l[chunks];
+    std::vector<Tail> tails(nt); std::vector<vgk_tail_problem> problems(nt);
+    for_chunks(chunks, [&](size_t lo, size_t hi, size_t) {
+        for (size_t c = lo; c < hi; ++c) {
+            std::copy(part_r[c].begin(), part_r[c].end(), tails.begin() + (long)at_r[c]); std::copy(prob_r[c].begin(), prob_r[c].end(), problems.begin() + (long)at_r[c]);
+            std::copy(part_l[c].begin(), part_l[c].end(), tails.begin() + (long)(at_r[chunks] + at_l[c])); std::copy(prob_l[c].begin(), prob_l[c].end(), problems.begin() + (long)(at_r[chunks] + at_l[c]));
+        }
+    }, 8);
     out.n_tails = nt; out.tail_score.assign(nt, 0);
     out.ext_total.resize(n_ext);
-    for (size_t e = 0; e < n_ext; ++e) out.ext_total[e] = in.ext[e].score;
+    for_chunks(n_ext, [&](size_t lo, size_t hi, size_t) { for (size_t e = lo; e < hi; ++e) out.ext_total[e] = in.ext[e].score; });
     out.ms[0] = ms_since(t0);
     if (nt) {
         std::vector<vgk_tail_result> tres(nt);
@@ -141,8 +146,14 @@ int run_tail_stage(const EngineApi& api, vgk_ctx* ctx, const vgk_haplo* index, c
         api.forest_destroy(forest);
         for (size_t i = 0; i < nt; ++i) out.ext_total[tails[i].ext] += out.tail_score[i];
     }
-    out.read_score.assign(n, 0);
-    for (size_t e = 0; e < n_ext; ++e) out.read_score[read_of[e]] = std::max(out.read_score[read_of[e]], out.ext_total[e]);
+    out.read_score.resize(n);
+    for_chunks(n, [&](size_t lo, size_t hi, size_t) {
+        for (size_t i = lo; i < hi; ++i) {
+            int32_t best = 0;
+            for (uint32_t k = 0; k < in.res[i].n_ext; ++k) best = std::max(best, out.ext_total[in.res[i].ext_begin + k]);
+            out.read_score[i] = best;
+        }
+    });
     out.ms[5] = ms_since(t0);
     return VGK_OK;
 }
