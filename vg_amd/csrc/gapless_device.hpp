@@ -809,6 +809,9 @@ VGK_HD void gapless_set_rules(const GaplessParams& P, uint32_t pi, const GProb& 
     for (uint32_t i = 0; i < n_res; ++i) order[i] = (uint8_t)i;
     bool overflow = false;
     uint32_t n_out = n_res;
+    // the mismatch positions of the extension looked at last stay in mm[]: for the usual set of one extension the output below copies
+    // them instead of walking the path against the read a second time (that walk was 40 % of what the rules kernel fetched)
+    uint32_t mm[G_MISM]; uint32_t mm_owner = 0xffffffffu;
     if (best_alignment < n_res && RES[best_alignment].internal <= max_mm) {
         // the non-overlapping full-length extensions, fewest mismatches first (:301-329)
         gx_sort(RES, order, n_res, [](const GExt& a, const GExt& b) { return gx_full_less(a, b); });
@@ -824,15 +827,13 @@ VGK_HD void gapless_set_rules(const GaplessParams& P, uint32_t pi, const GProb& 
             if (!ov) order[tail++] = order[i];
         }
         n_out = tail;
-        uint32_t mm[G_MISM];
-        for (uint32_t i = 0; i < n_out; ++i) gx_find_mismatches(c, RES[order[i]], mm, overflow);      // counts, for the output sizes
+        for (uint32_t i = 0; i < n_out; ++i) { gx_find_mismatches(c, RES[order[i]], mm, overflow); mm_owner = order[i]; }      // counts, for the output sizes
         out.full_length = 1;
     } else {
         n_out = gx_remove_duplicates(RES, order, n_res);
-        uint32_t mm[G_MISM];
         bool trimmed = false;
         for (uint32_t i = 0; i < n_out && !overflow; ++i) {
-            gx_find_mismatches(c, RES[order[i]], mm, overflow);
+            gx_find_mismatches(c, RES[order[i]], mm, overflow); mm_owner = order[i];
             if (!overflow && (pb.flags & VGK_GAPLESS_TRIM)) trimmed |= gx_trim(c, RES[order[i]], mm);
         }
         if (trimmed) n_out = gx_remove_duplicates(RES, order, n_out);
@@ -855,7 +856,10 @@ VGK_HD void gapless_set_rules(const GaplessParams& P, uint32_t pi, const GProb& 
         x.state[3] = (uint32_t)e.state.bn; x.state[4] = (uint32_t)e.state.blo; x.state[5] = (uint32_t)e.state.bhi;
         P.ext[e0 + i] = x;
         for (uint32_t k = 0; k < e.path_len; ++k) P.nodes[n0 + na + k] = (uint32_t)e.path[k];
-        if (e.n_mism) { GExt& me = RES[order[i]]; bool ov = false; gx_find_mismatches(c, me, P.mism + m0 + ma, ov); }      // written straight to the output
+        if (e.n_mism) {
+            if (order[i] == mm_owner) for (uint32_t k = 0; k < e.n_mism; ++k) P.mism[m0 + ma + k] = mm[k];
+            else { GExt& me = RES[order[i]]; bool ov = false; gx_find_mismatches(c, me, P.mism + m0 + ma, ov); }      // written straight to the output
+        }
         na += e.path_len; ma += e.n_mism;
     }
 }
