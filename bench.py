@@ -347,6 +347,7 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
         torch.cuda.synchronize()
 
     stage = pipeline.align_stage if os.environ.get("VGAMD_GIRAFFE_NUMPY_GLUE") else pipeline.align_stage_native      # the glue in the host shim (C++) or in numpy
+    device_tails = not os.environ.get("VGAMD_GIRAFFE_HOST_TAILS") and stage is pipeline.align_stage_native          # ... or no glue: vgk_tail_stage on the device
     from_reads = bool(os.environ.get("VGAMD_GIRAFFE_FROM_READS"))         # start from the bare reads: minimizer seeding on the device makes the clusters
     mindex = None; seeds_per_read = None; t_index = 0.0
     stay = from_reads and not os.environ.get("VGAMD_GIRAFFE_SEEDS_VIA_HOST") and stage is pipeline.align_stage_native      # the clusters stay on the device between seeding and extension
@@ -370,7 +371,10 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
                 timing["minimizer_seeds"] = timing.get("minimizer_seeds", 0.0) + t2 - t1
                 timing["minimizer_seeds (device)"] = timing.get("minimizer_seeds (device)", 0.0) + eng.minimizer_last_ms() * 1e-3
                 timing["clusters assembled (host)"] = timing.get("clusters assembled (host)", 0.0) + time.perf_counter() - t2
-        out = stage(eng, index, olen, gs, timing=timing, seeded=seeded) if seeded is not None else stage(eng, index, olen, gs, timing=timing)
+        if device_tails:
+            out = pipeline.align_stage_device(eng, index, gs, timing=timing, seeded=seeded)
+        else:
+            out = stage(eng, index, olen, gs, timing=timing, seeded=seeded) if seeded is not None else stage(eng, index, olen, gs, timing=timing)
         if "forest" in out:
             out["forest"].close()
         out["gs"] = gs
@@ -419,8 +423,10 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 / u16", "data": "synthetic",
             "config": {"workload": "1 Mbp variation graph, 8 random haplotype threads, %d x 150 bp reads per GPU from either strand, 1 %% substitutions, %d %% of the reads with one "
                                    "inserted base, 4.0 seeds per read at true positions; GaplessExtender + get_tail_forest + align_pinned(xdrop) semantics, scores 1/4/6/1/5" % (n, int(100 * inserted)),
-                       "timed_region": "per step, from host buffers: vgk_gapless_extend (results back on the host), then the host shim's run_tail_stage (vg_amd/host/tail_stage.cpp): "
-                                       "tails derived on host threads, vgk_tail_forest, one window per tree, vgk_gssw_pack_windows + run + fetch, totals", "reads_without_full_length_extension": open_reads, "tails": n_tails,
+                       "timed_region": ("per step, from host buffers: vgk_gapless_extend (the extension sets back on the host), then vgk_tail_stage: tails derived, forest, one window per tree, "
+                                        "window packing, fill + traceback, best tree per tail and totals, all on the device from what the extension call left in HBM") if device_tails else
+                                       ("per step, from host buffers: vgk_gapless_extend (results back on the host), then the host shim's run_tail_stage (vg_amd/host/tail_stage.cpp): "
+                                        "tails derived on host threads, vgk_tail_forest, one window per tree, vgk_gssw_pack_windows + run + fetch, totals"), "reads_without_full_length_extension": open_reads, "tails": n_tails,
                        "clusters_from": ("minimizer seeding on the device (k 29, w 11; %.1f seeds per read; index of %d minimizer k-mers built in %.1f s); %s" % (seeds_per_read, mindex.keys, t_index,
                                           "reads and seeds stay in HBM for the extension (vgk_gapless_extend_seeded)" if stay else "seeds via the host")) if from_reads else "seeds given (true positions)",
                        "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()},

@@ -243,6 +243,17 @@ int      vgk_forest_fetch(const vgk_forest* forest, int32_t* parent, uint32_t* n
 const vgk_dgraph* vgk_forest_graph(const vgk_forest* forest);            /* owned by the forest */
 void     vgk_forest_destroy(vgk_forest* forest);
 double   vgk_tail_last_ms(vgk_ctx* ctx);                                 /* device time of the last vgk_tail_forest call: walks + graph construction */
+/* The tails of the extension sets the last vgk_gapless_extend / vgk_gapless_extend_seeded call on this context produced, aligned, without
+ * the sets, the trees or the tails' bases crossing PCIe: what MinimizerMapper does per extension at src/minimizer_mapper.cpp:5480-5535
+ * (get_tail_forest for either open end of every extension of a read without a full-length extension, get_best_alignment_against_any_tree,
+ * the total score) as kernels over what that call left in HBM — tails derived from the extensions' search states, one forest, one window
+ * per tree, left-pinned X-drop, the best tree of a tail, the totals.  ext_total[e] = extension e's score + the best alignment of either
+ * open tail (a tail nothing aligns to, or one the engine declines, adds 0: the soft clip); read_score[i] = the best total of read i.
+ * stats (nullable): tails, trees, tree nodes, tails + windows the engine declined.  The alignments themselves (paths, CIGARs) of the tails
+ * are not returned by this entry point: vg_amd/host/tail_stage.cpp does the same through vgk_tail_forest + vgk_gssw_pack_windows and
+ * keeps them. */
+int      vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score, uint64_t stats[4]);
+double   vgk_tail_stage_last_ms(vgk_ctx* ctx, int which);             /* 0 tails derived, 1 forest, 2 windows packed, 3 kernels + totals */
 
 /* ---- X-drop with dozeu's band (src/dozeu_interface.cpp:226, :261-283; src/xdrop_aligner.cpp:95-109) ------------------------------
  * VGK_XDROP_PINNED through vgk_gssw_* keeps every cell: it returns the exact semi-global optimum, which is dozeu's answer whenever

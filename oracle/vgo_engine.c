@@ -501,3 +501,9 @@ int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max
     (void)nodes; (void)nodes_cap; (void)mismatches; (void)mism_cap; (void)written;
     return VGK_EUNSUPPORTED;
 }
+
+int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score, uint64_t stats[4]) {
+    (void)ctx; (void)index; (void)ops_per_problem; (void)ext_total; (void)ext_cap; (void)read_score; (void)stats;
+    return VGK_EUNSUPPORTED;                                             /* the oracle keeps nothing between calls: tests use the host-side stage */
+}
+double vgk_tail_stage_last_ms(vgk_ctx* ctx, int which) { (void)ctx; (void)which; return 0.0; }

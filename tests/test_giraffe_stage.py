@@ -43,6 +43,9 @@ def run_stage(lib, n, seed, graph_bp, inserted):
     c = pipeline.align_stage_native(eng, eng.haplo_index(wl.nodes, wl.threads), olen, wl.gs)
     assert (c["ext_total"] == a["ext_total"][:len(c["ext_total"])]).all() and (c["read_score"] == a["read_score"]).all()
     assert c["stats"][0] == len(a["tails"]["problems"]) and c["stats"][1] == len(a["owner"]) and c["stats"][3] == 0
+    # ... and with everything behind the extension on the device (vgk_tail_stage)
+    d = pipeline.align_stage_device(eng, eng.haplo_index(wl.nodes, wl.threads), wl.gs)
+    assert (d["ext_total"] == c["ext_total"]).all() and (d["read_score"] == c["read_score"]).all() and d["stats"] == c["stats"]
     return wl, a
 
 
@@ -61,3 +64,15 @@ def test_alignment_stage_equals_the_oracles(emu_lib):
 def test_alignment_stage_on_the_gpu_equals_the_oracles():
     wl, a = run_stage(ENGINE_LIB, 30000, 10, 400000, 0.3)
     assert len(a["tails"]["problems"]) > 10000
+
+
+def test_device_tail_stage_needs_the_sets_of_an_extension_call(emu_lib):
+    wl = workloads.GaplessWorkload(50, seed=3, graph_bp=20000)
+    eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=emu_lib)
+    idx = eng.haplo_index(wl.nodes, wl.threads)
+    with pytest.raises(capi.VgkError):
+        eng.tail_stage(idx, 50, 10)                                      # nothing extended yet on this context
+    res, ext, _, _ = eng.gapless_extend(idx, wl.gs)
+    et, rs, stats = eng.tail_stage(idx, wl.gs.n, int(res["n_ext"].sum()))
+    assert stats[0] == 0 and (et == ext["score"][:len(et)]).all()        # every cluster resolved: no tails, totals = the extensions' scores
+    assert (rs == np.maximum.reduceat(et, res["ext_begin"][res["n_ext"] > 0])).all() if (res["n_ext"] > 0).all() else True

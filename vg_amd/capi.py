@@ -400,6 +400,18 @@ class Engine:
         self._check(self.lib.vgk_tail_forest(self.h, index.h, pr.ctypes.data, len(pr), res.ctypes.data, ctypes.byref(h)), "vgk_tail_forest")
         return res[:len(pr)], Forest(self, h)
 
+    def tail_stage(self, index, n_reads, n_ext, ops_per_problem=32):
+        """vgk_tail_stage over the sets the last gapless_extend / gapless_extend_seeded call left on the device
+        -> (ext_total [n_ext], read_score [n_reads], (tails, trees, tree nodes, declined))"""
+        ext_total = np.zeros(max(n_ext, 1), dtype=np.int32); read_score = np.zeros(max(n_reads, 1), dtype=np.int32); stats = np.zeros(4, dtype=np.uint64)
+        self.lib.vgk_tail_stage.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        self._check(self.lib.vgk_tail_stage(self.h, index.h, ops_per_problem, ext_total.ctypes.data, len(ext_total), read_score.ctypes.data, stats.ctypes.data), "vgk_tail_stage")
+        return ext_total[:n_ext], read_score[:n_reads], tuple(int(x) for x in stats)
+
+    def tail_stage_last_ms(self):
+        self.lib.vgk_tail_stage_last_ms.restype = ctypes.c_double; self.lib.vgk_tail_stage_last_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        return [self.lib.vgk_tail_stage_last_ms(self.h, k) for k in range(4)]
+
     def tail_last_ms(self):
         self.lib.vgk_tail_last_ms.restype = ctypes.c_double; self.lib.vgk_tail_last_ms.argtypes = [ctypes.c_void_p]
         return self.lib.vgk_tail_last_ms(self.h)

@@ -112,6 +112,7 @@ public:
     // (watch(0) ... watch(1), watch_ms() after a sync)
     virtual int   run_minimizer(const MinimizerParams& p) = 0;            // minimizer_device.hpp: one lane per read, pass p.pass
     virtual int   run_tail(const TailParams& p, uint32_t threads) = 0;
+    virtual int   run_tail_stage(const TStageParams& p, int what) = 0;     // one of the per-item stages of vgk_tail_stage (tail_device.hpp: TS_*)
     virtual int   scan_u32(const uint32_t* in, uint32_t* out, uint32_t n) = 0;
     virtual int   forest_flags(const ForestParams& p) = 0;
     virtual int   forest_emit(const ForestParams& p) = 0;

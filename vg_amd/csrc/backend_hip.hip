@@ -431,6 +431,10 @@ __global__ void __launch_bounds__(64) tail_walk_kernel(const TailParams P, const
     if (t >= threads) return;
     for (uint32_t i = t; i < P.n; i += threads) tail_walk_one(P, i, P.scratch[t]);
 }
+__global__ void __launch_bounds__(256) tail_stage_kernel(const TStageParams P, const int what, const uint32_t items) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < items) tstage_one(P, what, i);
+}
 __global__ void __launch_bounds__(256) forest_flags_kernel(const ForestParams P) {
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     if (v < P.n_nodes) forest_flags_one(P, v);
@@ -796,6 +800,13 @@ public:
         }
         if (p.pass == 1) hipLaunchKernelGGL(minimizer_kernel, dim3((p.n + 3) / 4), dim3(256), 0, stream, p, (vgk_seed*)mz_slots);
         else hipLaunchKernelGGL(minimizer_gather_kernel, dim3((p.n + 3) / 4), dim3(256), 0, stream, p, (const vgk_seed*)mz_slots);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int run_tail_stage(const TStageParams& p, int what) override {
+        hipSetDevice(dev);
+        const uint32_t items = tstage_items(p, what);
+        if (!items) return VGK_OK;
+        hipLaunchKernelGGL(tail_stage_kernel, dim3((items + 255) / 256), dim3(256), 0, stream, p, what, items);
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_tail(const TailParams& p, uint32_t threads) override {

@@ -38,7 +38,12 @@ struct vgk_ctx {
     // vgk_gapless_extend_seeded takes its clusters from there
     struct Seeded { bool valid = false; uint32_t n = 0; const char* reads = nullptr; uint64_t bytes = 0; const uint64_t* read_off = nullptr;
                     const uint32_t* seed_off = nullptr; const vgk_seed* seeds = nullptr; uint64_t n_seeds = 0; const void* graph = nullptr; } seeded;
+    // what the last vgk_gapless_extend(_seeded) call left in HBM: its inputs (descriptors, masked reads) and its sets in problem order —
+    // vgk_tail_stage derives the tails from there
+    struct Sets { bool valid = false; uint32_t n = 0; uint64_t n_ext = 0; const void* probs = nullptr; const char* reads = nullptr;
+                  const void* res = nullptr; const void* ext = nullptr; const uint32_t* nodes = nullptr; const void* index = nullptr; } sets;
     double minimizer_ms = 0;       // device time of the last vgk_minimizer_seeds call
+    double tail_stage_ms[4] = {0, 0, 0, 0};   // last vgk_tail_stage: tails derived | forest | windows packed | kernels + totals
     double tail_ms = 0;            // device time of the last vgk_tail_forest call
     // the last batch of either call stays resident in the cached device buffers: what a re-run needs to launch it again
     vgk::BandedParams banded_last{}; std::vector<vgk::BandedLaunch> banded_last_launches; bool banded_last_valid = false;

@@ -272,6 +272,8 @@ static int gapless_run_and_fetch(vgk_ctx* ctx, GaplessParams& P, uint32_t n, uin
     uint32_t tot[3] = {0, 0, 0};
     for (int k = 0; k < 3; ++k) if ((rc = be->download(&tot[k], tab + (3 + k) * n1 + n, sizeof(uint32_t)))) return cleanup(rc);
     const size_t we = tot[0], wn = tot[1], wm = tot[2];
+    ctx->sets.valid = true; ctx->sets.n = n; ctx->sets.n_ext = tot[0]; ctx->sets.probs = P.probs; ctx->sets.reads = P.reads;
+    ctx->sets.res = O.res_out; ctx->sets.ext = O.ext_out; ctx->sets.nodes = O.nodes_out; ctx->sets.index = nullptr;
     int rc_all = VGK_OK;
     vgk_gapless_result* dres = H.dres.get(be, n);
     vgk_extension* dext = H.dext.get(be, we + 1); uint32_t* dnodes = H.dnodes.get(be, wn + 1); uint32_t* dmism = H.dmism.get(be, wm + 1);
@@ -332,7 +334,7 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     if (written) written[0] = written[1] = written[2] = 0;
     if (!n) return VGK_OK;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    ctx->gapless_last_valid = false;
+    ctx->gapless_last_valid = false; ctx->sets.valid = false;
     Backend* be = ctx->be.get();
     GLap lap;
     // pack: masked reads (ReadMasker, src/gbwt_extender.cpp:160-176), seeds
@@ -400,7 +402,7 @@ int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max
     const uint32_t n = ctx->seeded.n;
     if (!n) return VGK_OK;
     if (!results) return VGK_EINVAL;
-    ctx->gapless_last_valid = false;
+    ctx->gapless_last_valid = false; ctx->sets.valid = false;
     Backend* be = ctx->be.get();
     GLap lap;
     if (!ctx->gapless_host) ctx->gapless_host = std::make_shared<GaplessHost>();

@@ -32,6 +32,7 @@ struct TailParams {
     uint32_t* node;                   //   the oriented node of the index
     uint32_t* len;                    //   its length in the forest graph
     uint32_t* trim;                   //   bases cut off its start (the root's cut)
+    uint32_t* owner;                  //   (nullable) the problem it belongs to
     TScratch* scratch;                // one per resident lane
     int pass;
 };
@@ -89,6 +90,7 @@ VGK_HD void tail_walk_one(const TailParams& P, uint32_t i, TScratch& S) {
                     const uint32_t at = out.first_node + count;
                     P.parent[at] = par < 0 ? -1 : (int32_t)(out.first_node + (uint32_t)par);
                     P.node[at] = (uint32_t)f.node; P.len[at] = node_length; P.trim[at] = is_root ? pb.offset : 0u;
+                    if (P.owner) P.owner[at] = i;
                 }
                 ++count; out.bases += node_length;
             } else f.self = -1;
@@ -147,6 +149,135 @@ VGK_HD void forest_emit_one(const ForestParams& P, uint32_t v) {
     for (uint32_t k = 0; k < len; ++k) o[k] = (uint8_t)t_ref_code(sq[k]);
     o[0] |= (uint8_t)(CI_NODE_START | (P.slow[v] ? CI_SEED_SLOW : 0));
     if (P.store[v]) o[len - 1] |= (uint8_t)CI_STORE_END;
+}
+
+// ---- the tails of a batch of extension sets, on the device (vgk_tail_stage) -------------------------------------------------------
+// What vg_amd/host/tail_stage.cpp does on host threads — which tails exist, their cuts and walk distances from the extensions' search
+// states, the tails' bases, one window per tree, best tree per tail, totals (src/minimizer_mapper.cpp:5480-5535) — as lane code over the
+// extension sets vgk_gapless_extend left in HBM.  Order of the tails: the right tails by extension, then the left tails, as there.
+struct TMeta { uint32_t ext, read, begin, end, left, gap; };
+struct TStageParams {
+    GIndex index;
+    uint32_t n_reads, n_ext;
+    const GProb* probs; const char* reads;                        // the extension stage's inputs (masked reads, padded)
+    const vgk_gapless_result* res; const vgk_extension* ext; const uint32_t* nodes;      // its sets, in problem order
+    int32_t match, gap_open, gap_extend, bonus;
+    uint32_t* read_of;                                            // [n_ext]
+    uint32_t* cnt_r; uint32_t* cnt_l; const uint32_t* off_r; const uint32_t* off_l; uint32_t total_r;      // [n_ext + 1] each
+    vgk_tail_problem* problems; TMeta* meta; uint32_t n_tails;
+    uint32_t* tail_len; const uint32_t* seq_off; char* seq;       // [n_tails + 1]; the tails' bases behind each other
+    // trees -> windows
+    const vgk_tail_result* tres; const int32_t* parent; const uint32_t* owner; uint32_t n_nodes;
+    uint32_t* is_root; const uint32_t* root_off; uint32_t* root_pos; uint32_t n_trees;      // [n_nodes + 1]
+    vgk_window_problem* windows; uint32_t* win_owner;
+    // scores
+    const vgk_result* wres; int32_t* tail_score; int32_t* ext_total; int32_t* read_score; unsigned long long* failed;
+};
+VGK_HD int64_t t_longest_gap(const TStageParams& P, int64_t read_length, int64_t read_pos) {     // EditAlignmentScorer::longest_detectable_gap (src/alignment_scorer.cpp:264-271)
+    const int64_t overhang = read_pos < read_length - read_pos ? read_pos : read_length - read_pos;
+    const int64_t gap = (P.match * overhang + P.bonus - P.gap_open) / P.gap_extend + 1;
+    return (gap >= 0 && overhang > 0) ? gap : 0;
+}
+VGK_HD char t_comp(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return c; } }
+// stage 0, per read: which read an extension belongs to; its total starts as its own score
+VGK_HD void tstage_reads_one(const TStageParams& P, uint32_t i) {
+    const vgk_gapless_result r = P.res[i];
+    for (uint32_t k = 0; k < r.n_ext; ++k) { P.read_of[r.ext_begin + k] = i; P.ext_total[r.ext_begin + k] = P.ext[r.ext_begin + k].score; }
+}
+VGK_HD bool tstage_open(const TStageParams& P, uint32_t e, const vgk_extension& x) {
+    const vgk_gapless_result r = P.res[P.read_of[e]];
+    return r.status == VGK_OK && !r.full_length && x.path_len;      // full-length sets are scored as they are (:5440)
+}
+// stage 1, per extension: does it have a right / a left tail
+VGK_HD void tstage_count_one(const TStageParams& P, uint32_t e) {
+    const vgk_extension x = P.ext[e];
+    const bool open = tstage_open(P, e, x);
+    P.cnt_r[e] = open && !x.right_full ? 1u : 0u; P.cnt_l[e] = open && !x.left_full ? 1u : 0u;
+}
+// stage 2, per extension: its tail problems
+VGK_HD void tstage_tails_one(const TStageParams& P, uint32_t e) {
+    const vgk_extension x = P.ext[e];
+    if (!tstage_open(P, e, x)) return;
+    const uint32_t r = P.read_of[e];
+    const int64_t L = (int64_t)P.probs[r].read_len;
+    if (!x.right_full) {                                           // look right from the end, forward state (:5768-5775)
+        uint64_t before_last = 0;
+        for (uint32_t k = 0; k + 1 < x.path_len; ++k) before_last += g_len(P.index, (int32_t)P.nodes[x.path_begin + k]);
+        const int64_t tail = L - x.read_end, gap = t_longest_gap(P, L, tail);
+        const uint32_t at = P.off_r[e];
+        vgk_tail_problem p; p.node = x.state[0]; p.lo = (int32_t)x.state[1]; p.hi = (int32_t)x.state[2];
+        p.offset = (uint32_t)(x.offset + (x.read_end - x.read_begin) - before_last); p.walk_distance = (uint32_t)(tail + gap);
+        P.problems[at] = p;
+        TMeta m; m.ext = e; m.read = r; m.begin = x.read_end; m.end = (uint32_t)L; m.left = 0; m.gap = (uint32_t)gap;
+        P.meta[at] = m; P.tail_len[at] = m.end - m.begin;
+    }
+    if (!x.left_full) {                                            // look the other way from the start, backward state (:5756-5766)
+        const uint32_t first = P.nodes[x.path_begin] ^ 1u;
+        const int64_t tail = x.read_begin, gap = t_longest_gap(P, L, tail);
+        const uint32_t at = P.total_r + P.off_l[e];
+        vgk_tail_problem p; p.node = x.state[3]; p.lo = (int32_t)x.state[4]; p.hi = (int32_t)x.state[5];
+        p.offset = g_len(P.index, (int32_t)first) - x.offset; p.walk_distance = (uint32_t)(tail + gap);
+        P.problems[at] = p;
+        TMeta m; m.ext = e; m.read = r; m.begin = 0; m.end = x.read_begin; m.left = 1; m.gap = (uint32_t)gap;
+        P.meta[at] = m; P.tail_len[at] = m.end - m.begin;
+    }
+}
+// stage 3, per tail: its bases — a right tail as it lies in the read, a left tail reverse-complemented (:5660)
+VGK_HD void tstage_bases_one(const TStageParams& P, uint32_t t) {
+    const TMeta m = P.meta[t];
+    const char* rd = P.reads + P.probs[m.read].read_off; char* dst = P.seq + P.seq_off[t];
+    const uint32_t len = m.end - m.begin;
+    if (!m.left) for (uint32_t k = 0; k < len; ++k) dst[k] = rd[m.begin + k];
+    else for (uint32_t k = 0; k < len; ++k) dst[k] = t_comp(rd[m.end - 1 - k]);
+    P.tail_score[t] = 0;
+}
+// stage 4, per tree node: is it the root of a tree; stage 5, per root: where; stage 6, per tree: its window problem
+VGK_HD void tstage_root_flag_one(const TStageParams& P, uint32_t v) { P.is_root[v] = P.parent[v] < 0 ? 1u : 0u; }
+VGK_HD void tstage_root_pos_one(const TStageParams& P, uint32_t v) { if (P.parent[v] < 0) P.root_pos[P.root_off[v]] = v; }
+VGK_HD void tstage_window_one(const TStageParams& P, uint32_t w) {
+    const uint32_t v = P.root_pos[w], t = P.owner[v];
+    const uint32_t end = P.tres[t].first_node + P.tres[t].n_nodes;
+    const uint32_t nxt = w + 1 < P.n_trees ? P.root_pos[w + 1] : P.n_nodes;
+    vgk_window_problem q; q.read_off = P.seq_off[t]; q.read_len = P.seq_off[t + 1] - P.seq_off[t]; q.flags = VGK_XDROP_PINNED | VGK_GSSW_TRACEBACK;
+    q.first_node = v; q.n_nodes = (nxt < end ? nxt : end) - v; q.max_gap_length = P.meta[t].gap; q.reserved = 0;
+    P.windows[w] = q; P.win_owner[w] = t;
+}
+// stage 7, per window: the best tree of a tail (nothing aligned = the soft clip, 0; :5632-5648); stage 8, per tail: into its extension's
+// total; stage 9, per read: the best total
+#if defined(__HIP_DEVICE_COMPILE__)
+VGK_HD void t_atomic_max(int32_t* p, int32_t v) { atomicMax(p, v); }
+VGK_HD void t_atomic_add(int32_t* p, int32_t v) { atomicAdd(p, v); }
+#else
+VGK_HD void t_atomic_max(int32_t* p, int32_t v) { if (v > *p) *p = v; }
+VGK_HD void t_atomic_add(int32_t* p, int32_t v) { *p += v; }
+#endif
+VGK_HD void tstage_best_one(const TStageParams& P, uint32_t w) {
+    const vgk_result r = P.wres[w];
+    if (r.status != VGK_OK) { g_bump(P.failed, 1); return; }
+    t_atomic_max(P.tail_score + P.win_owner[w], r.score);
+}
+VGK_HD void tstage_total_one(const TStageParams& P, uint32_t t) {
+    if (P.tres[t].status != VGK_OK) g_bump(P.failed, 1);
+    t_atomic_add(P.ext_total + P.meta[t].ext, P.tail_score[t]);
+}
+VGK_HD void tstage_read_one(const TStageParams& P, uint32_t i) {
+    const vgk_gapless_result r = P.res[i];
+    int32_t best = 0;
+    for (uint32_t k = 0; k < r.n_ext; ++k) { const int32_t v = P.ext_total[r.ext_begin + k]; best = v > best ? v : best; }
+    P.read_score[i] = best;
+}
+enum { TS_READS = 0, TS_COUNT, TS_TAILS, TS_BASES, TS_ROOT_FLAG, TS_ROOT_POS, TS_WINDOW, TS_BEST, TS_TOTAL, TS_READ };
+VGK_HD uint32_t tstage_items(const TStageParams& P, int what) {
+    switch (what) { case TS_READS: case TS_READ: return P.n_reads; case TS_COUNT: case TS_TAILS: return P.n_ext; case TS_BASES: case TS_TOTAL: return P.n_tails;
+                    case TS_ROOT_FLAG: case TS_ROOT_POS: return P.n_nodes; default: return P.n_trees; }
+}
+VGK_HD void tstage_one(const TStageParams& P, int what, uint32_t i) {
+    switch (what) {
+        case TS_READS: tstage_reads_one(P, i); break; case TS_COUNT: tstage_count_one(P, i); break; case TS_TAILS: tstage_tails_one(P, i); break;
+        case TS_BASES: tstage_bases_one(P, i); break; case TS_ROOT_FLAG: tstage_root_flag_one(P, i); break; case TS_ROOT_POS: tstage_root_pos_one(P, i); break;
+        case TS_WINDOW: tstage_window_one(P, i); break; case TS_BEST: tstage_best_one(P, i); break; case TS_TOTAL: tstage_total_one(P, i); break;
+        default: tstage_read_one(P, i); break;
+    }
 }
 
 }  // namespace vgk

@@ -113,8 +113,10 @@ void vgk_graph_destroy(vgk_dgraph* dg) {
     delete dg;
 }
 
-int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
-                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out) {
+// `on_device`: reads and problems are device arrays already (vgk_tail_stage builds them there) and the caller has waited for the
+// kernels that wrote them; nothing is staged.
+int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
+                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out, bool on_device) {
     if (!ctx || !dg || dg->ctx != ctx || !out || (!problems && n) || (!reads && reads_bytes)) return VGK_EINVAL;
     *out = nullptr;
     if (ctx->has_qa) return VGK_EUNSUPPORTED;
@@ -153,8 +155,8 @@ int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     rc = VGK_OK;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        W.problems = (const vgk_window_problem*)take_temp((uint64_t)n * sizeof(vgk_window_problem));
-        W.raw_reads = (const uint8_t*)take_temp(reads_bytes + 8);
+        W.problems = on_device ? problems : (const vgk_window_problem*)take_temp((uint64_t)n * sizeof(vgk_window_problem));
+        W.raw_reads = on_device ? (const uint8_t*)reads : (const uint8_t*)take_temp(reads_bytes + 8);
         W.sizes = (uint32_t*)take_temp((uint64_t)WIN_COLS * n1 * 4); W.offs = (uint32_t*)take_temp((uint64_t)WIN_COLS * n1 * 4);
         W.key = (uint32_t*)take_temp((uint64_t)n * 4); W.idx = (uint32_t*)take_temp((uint64_t)n * 4);
         W.key_sorted = (uint32_t*)take_temp((uint64_t)n * 4); W.idx_sorted = (uint32_t*)take_temp((uint64_t)n * 4);
@@ -194,10 +196,10 @@ int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
         }
         return VGK_OK;
     };
-    if ((rc = staged_upload(1, (void*)W.problems, problems, (uint64_t)n * sizeof(vgk_window_problem)))) return fail(rc);
+    if (!on_device && (rc = staged_upload(1, (void*)W.problems, problems, (uint64_t)n * sizeof(vgk_window_problem)))) return fail(rc);
     lap("problems staged");
     if ((rc = be->win_stage1(W, tmp, tmp_bytes))) return fail(rc);         // needs the problems only: runs while the reads travel
-    if ((rc = staged_upload(0, (void*)W.raw_reads, reads, reads_bytes))) return fail(rc);
+    if (!on_device && (rc = staged_upload(0, (void*)W.raw_reads, reads, reads_bytes))) return fail(rc);
     lap("reads staged");
     WinTotals T;
     if ((rc = be->download_side(&T, W.totals, sizeof T))) return fail(rc);
@@ -245,6 +247,11 @@ int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     lap("done");
     *out = hb.release();
     return VGK_OK;
+}
+
+int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
+                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out) {
+    return vgk_pack_windows_impl(ctx, dg, reads, reads_bytes, problems, n, ops_per_problem, out, false);
 }
 
 }  // extern "C"

@@ -209,3 +209,23 @@ def chain_stage(eng, index, wl, match=1, timing=None):
     chain += wl.anchor_bases * match
     out.update(segment_score=score, chain_score=chain); lap("totals (host)")
     return out
+
+
+def align_stage_device(eng, index, gs, ops_per_problem=32, timing=None, seeded=None):
+    """The stage with everything behind the extension on the device too (vgk_tail_stage): the extension sets come back for the caller, the
+    tails are derived, walked, packed and aligned from what the extension call left in HBM.  -> dict(res, ext, nodes, ext_total, read_score, stats)"""
+    import time
+    t0 = time.perf_counter()
+    if seeded is not None:
+        res, ext, nodes, mism = eng.gapless_extend_seeded(index, gs.n, int(seeded))
+    else:
+        res, ext, nodes, mism = eng.gapless_extend(index, gs)
+    t1 = time.perf_counter()
+    ext_total, read_score, stats = eng.tail_stage(index, gs.n, int(res["n_ext"].sum()), ops_per_problem)
+    t2 = time.perf_counter()
+    if timing is not None:
+        for k, v in (("gapless_extend", t1 - t0), ("tail stage (device, total)", t2 - t1)):
+            timing[k] = timing.get(k, 0.0) + v
+        for k, v in zip(("tails derived (device)", "tail forest (device)", "windows packed (device)", "fill + traceback + totals"), eng.tail_stage_last_ms()):
+            timing[k] = timing.get(k, 0.0) + v * 1e-3
+    return dict(res=res, ext=ext, nodes=nodes, ext_total=ext_total, read_score=read_score, stats=stats)
