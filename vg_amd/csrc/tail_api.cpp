@@ -4,6 +4,8 @@
 // The host's share is the problem array up (20 B per tail) and the result array down (24 B per tail) plus two 4-byte totals that
 // size the device allocations; the trees, their bases and the packer's tables never leave HBM (vgk_forest_fetch copies the
 // (parent, node, length) triples out for the caller that wants to translate alignments back — TreeSubgraph::translate_down).
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -157,6 +159,8 @@ int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_proble
     std::vector<vgk_ctx::Pooled> temp;                                     // device blocks of this call: back to the pool at the end
     auto take = [&](uint64_t bytes) -> void* { uint64_t got = 0; void* p = ctx->dev_take(bytes ? bytes : 16, got); if (p) temp.push_back({p, got}); return p; };
     auto done = [&](int rc) { be->sync(); for (auto& q : temp) ctx->dev_give(q.p, q.bytes); return rc; };
+    struct Wall { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); const bool on = std::getenv("VGAMD_TIMING") != nullptr;
+                  void operator()(const char* what) { if (!on) return; const auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "[tail_stage] %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t; } } wall;
     TStageParams S{};
     S.index = index->dev; S.n_reads = n; S.n_ext = (uint32_t)n_ext;
     S.probs = (const GProb*)ctx->sets.probs; S.reads = ctx->sets.reads;
@@ -182,6 +186,7 @@ int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_proble
     if (rc) return done(rc);
     const uint32_t nt = tot_rl[0] + tot_rl[1];
     S.total_r = tot_rl[0]; S.n_tails = nt;
+    wall("counted");
     uint64_t n_trees = 0, tree_nodes = 0;
     unsigned long long failed = 0;
     if (nt) {
@@ -203,9 +208,11 @@ int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_proble
         S.seq = d_seq;
         rc = be->run_tail_stage(S, TS_BASES);
         be->watch(1); if (!rc) rc = be->sync(); ctx->tail_stage_ms[0] = be->watch_ms(); be->watch(0);
+        wall("tails + bases");
         vgk_forest* forest = nullptr;
         if (!rc) rc = tail_forest_core(ctx, index, d_probs, d_tres, nt, true, &forest);
         if (rc) return done(rc);
+        wall("forest");
         auto drop_forest = [&]() { vgk_dgraph* g = forest->graph; be->sync(); for (size_t k = 0; k < g->dev.size(); ++k) ctx->dev_give(g->dev[k], g->dev_size[k]); delete g; delete forest; };
         tree_nodes = forest->n_nodes;
         S.parent = forest->parent; S.owner = forest->owner; S.n_nodes = (uint32_t)forest->n_nodes;
@@ -232,7 +239,9 @@ int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_proble
             vgk_batch* b = nullptr;
             if (!rc) { lk.unlock(); rc = vgk_pack_windows_impl(ctx, forest->graph, d_seq, seq_bytes, d_win, nw, ops_per_problem, &b, true); lk.lock(); }
             be->watch(1); be->sync(); ctx->tail_stage_ms[2] = be->watch_ms();
+            wall("windows packed");
             if (!rc) { lk.unlock(); rc = vgk_gssw_run(b); if (!rc) rc = vgk_batch_sync(b); lk.lock(); }
+            wall("fill + traceback");
             be->watch(0);
             if (!rc) { S.wres = b->P.results; rc = be->run_tail_stage(S, TS_BEST); }
             if (!rc) rc = be->sync();
@@ -250,7 +259,10 @@ int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_proble
     if (!rc) rc = be->download(&failed, d_failed, sizeof failed);
     be->watch(1); be->sync(); ctx->tail_stage_ms[3] = be->watch_ms();
     if (stats) { stats[0] = nt; stats[1] = n_trees; stats[2] = tree_nodes; stats[3] = failed; }
-    return done(rc);
+    wall("totals down");
+    rc = done(rc);
+    wall("blocks back to the pool");
+    return rc;
 }
 double vgk_tail_stage_last_ms(vgk_ctx* ctx, int which) { return ctx && which >= 0 && which < 4 ? ctx->tail_stage_ms[which] : 0.0; }
 
