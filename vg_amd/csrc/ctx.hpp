@@ -67,7 +67,7 @@ struct vgk_ctx {
     }
     // Device arenas of freed gssw batches, kept for the next pack (callers hold `mu`): allocating the 35 GB of a million-read batch
     // takes the runtime 0.9-1.8 s, more than packing, aligning and fetching it.  Requests are rounded up by an eighth so that the
-    // next, slightly larger batch still fits; a block serves requests down to half its size; at most 64 blocks / half of HBM stay (two batches in flight hold 13 arenas each, a fetch 4 more).
+    // next, slightly larger batch still fits; a block serves requests down to half its size; at most 192 blocks / half of HBM stay (a batch holds 13 arenas, a fetch 4 more, a forest 9, a tail stage 13 and the packer 13 temporaries: with 64 the stage of §17 kept dropping and re-allocating blocks).
     struct Pooled { void* p; uint64_t bytes; };
     std::vector<Pooled> dev_pool; uint64_t dev_pool_bytes = 0;
     void dev_pool_drop(size_t k) { be->release(dev_pool[k].p); dev_pool_bytes -= dev_pool[k].bytes; dev_pool.erase(dev_pool.begin() + (long)k); }
@@ -92,7 +92,7 @@ struct vgk_ctx {
     void dev_give(void* p, uint64_t bytes) {
         dev_pool.push_back({p, bytes}); dev_pool_bytes += bytes;
         const uint64_t limit = be->memory_bytes() ? be->memory_bytes() / 2 : (1ull << 30);
-        while (!dev_pool.empty() && (dev_pool.size() > 64 || dev_pool_bytes > limit)) dev_pool_drop(0);     // oldest first
+        while (!dev_pool.empty() && (dev_pool.size() > 192 || dev_pool_bytes > limit)) dev_pool_drop(0);     // oldest first
     }
     // page-locked staging arenas of vgk_gssw_pack, handed out per pack (callers may pack concurrently) and kept for the next one
     struct Staging {
