@@ -332,3 +332,74 @@ def test_forests_over_run_length_records_and_nodes_with_many_edges(lib_name, emu
     eng = capi.Engine(lib=lib)
     check_forest(eng, eng.haplo_index(nodes, threads), probs, expected)
     assert max(len(e) for e in expected) >= 14                       # the whole bubble structure behind the first backbone node
+
+
+def shim_tail_forests(engine_lib):
+    """MinimizerMapper::get_tail_forest as the host shim offers it (GaplessExtender::get_tail_forest, reference-shaped: a vector of
+    (parent, handle) trees with their root trim) on the toy graph of the reference's extender tests: the partial extension of
+    "trim right flank" (src/unittest/gbwt_extender.cpp:1082) has a tail on either side; the trees must be the tries of the threads'
+    continuations."""
+    import ctypes, json
+    import util
+    from test_gapless import TOY_NODES, SHORT_PATH, ALT_PATH
+    h = util.host()
+    h.vgh_gapless_create.restype = ctypes.c_void_p
+    h.vgh_gapless_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), ctypes.c_int]
+    h.vgh_gapless_destroy.argtypes = [ctypes.c_void_p]
+    h.vgh_gapless_tail_forest.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    al = util.HostAligner(engine_lib)
+    g = h.vgh_graph_create()
+    try:
+        for i, s in enumerate(TOY_NODES):
+            assert h.vgh_graph_add_node(g, i + 1, s.encode()) == 0
+        for a, b in [(1, 2), (1, 4), (1, 6), (2, 3), (2, 4), (3, 5), (4, 5), (5, 6), (6, 7), (6, 8), (7, 9), (8, 9)]:
+            assert h.vgh_graph_add_edge(g, a, b) == 0
+        threads = [SHORT_PATH, ALT_PATH, SHORT_PATH]
+        flat = [2 * n for t in threads for n in t]; off = np.concatenate([[0], np.cumsum([len(t) for t in threads])])
+        x = h.vgh_gapless_create(al.ptr, g, (ctypes.c_int64 * len(flat))(*flat), (ctypes.c_int32 * len(off))(*[int(v) for v in off]), len(threads))
+        assert x, h.vgh_last_error().decode()
+        try:
+            read = "xAGGGTxAx"; seeds = [((4, False, 2), 4)]
+            sd = [v for (node_id, rev, offset), ro in seeds for v in (node_id, int(rev), offset, ro)]
+            out = {}
+            for left in (0, 1):
+                buf = ctypes.create_string_buffer(1 << 16)
+                rc = h.vgh_gapless_tail_forest(x, read.encode(), (ctypes.c_int64 * len(sd))(*sd), len(seeds), 1, 0, left, buf, len(buf))
+                assert rc == 0, h.vgh_last_error().decode()
+                out[left] = json.loads(buf.value.decode())
+        finally:
+            h.vgh_gapless_destroy(x)
+    finally:
+        h.vgh_graph_destroy(g)
+    # expectation: the extension covers read [1, 6) on nodes 2, 4, 5 (the reference's REQUIREs); oriented node = 2 * (id - 1) + is_reverse
+    lens = np.repeat(np.array([len(s) for s in TOY_NODES]), 2)
+    allt = both_orientations([[2 * (n - 1) for n in t] for t in threads])
+    path = [2 * (2 - 1), 2 * (4 - 1), 2 * (5 - 1)]
+    L = len(read)
+    for left, tail_len, p in ((0, L - 6, path), (1, 1, [q ^ 1 for q in reversed(path)])):
+        gap = workloads.longest_detectable_gap(L, tail_len, 1, 6, 1, 5)
+        assert out[left]["gap"] == gap and not out[left]["left_full"] and not out[left]["right_full"]
+        conts = continuations_of_path(allt, p)
+        got = out[left]["trees"]
+        # rebuild the expectation with the cut the shim used: the root trim it reports (0 when the root was skipped)
+        for cut in range(0, int(lens[p[-1]]) + 1):
+            exp = trie_forest(lens, p[-1], conts, cut, tail_len + gap)
+            trees, cur = [], None
+            for par, node, ln in exp:
+                if par < 0:
+                    cur = []; trees.append(cur); base = len([1 for t in trees[:-1] for _ in t])
+                cur.append([par - base if par >= 0 else -1, (node >> 1) + 1, node & 1])
+            if [t["tree"] for t in got] == trees and all(t["root_trim"] == (cut if cut < lens[p[-1]] else 0) for t in got):
+                break
+        else:
+            raise AssertionError("no cut on node %d reproduces the shim's forest %s" % (p[-1], got))
+        assert len(got) >= 1
+
+
+def test_host_shim_get_tail_forest_on_the_oracle():
+    shim_tail_forests(ORACLE_LIB)
+
+
+@pytest.mark.gpu
+def test_host_shim_get_tail_forest_on_hip():
+    shim_tail_forests(ENGINE_LIB)

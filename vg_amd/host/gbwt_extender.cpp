@@ -85,6 +85,46 @@ std::vector<GaplessExtension> GaplessExtender::extend(const cluster_type& cluste
     }
     return result;
 }
+std::vector<GaplessExtender::TailTree> GaplessExtender::get_tail_forest(const GaplessExtension& extended_seed, size_t read_length, bool left_tails,
+                                                                        size_t* longest_detectable_gap) const {
+    std::vector<TailTree> to_return;
+    if (extended_seed.path.empty()) return to_return;
+    // the position to read out of the extension on this tail, the tail's length, the search state to start from (:5756-5782)
+    vgk_tail_problem p{};
+    size_t tail_length;
+    if (left_tails) {
+        const handle_t first = graph->flip(extended_seed.path.front());          // look right from the start, then the other way
+        p.offset = (uint32_t)(graph->get_length(first) - extended_seed.offset);
+        p.node = (uint32_t)extended_seed.state.backward.node; p.lo = (int32_t)extended_seed.state.backward.range.first; p.hi = (int32_t)extended_seed.state.backward.range.second;
+        tail_length = extended_seed.read_interval.first;
+    } else {
+        size_t before_last = 0;
+        for (size_t k = 0; k + 1 < extended_seed.path.size(); ++k) before_last += graph->get_length(extended_seed.path[k]);
+        p.offset = (uint32_t)(extended_seed.offset + extended_seed.length() - before_last);      // tail_position: behind the last matched base
+        p.node = (uint32_t)extended_seed.state.forward.node; p.lo = (int32_t)extended_seed.state.forward.range.first; p.hi = (int32_t)extended_seed.state.forward.range.second;
+        tail_length = read_length - extended_seed.read_interval.second;
+    }
+    if (tail_length == 0) return to_return;                                      // (:5784-5787)
+    size_t gap_limit;
+    if (!longest_detectable_gap) longest_detectable_gap = &gap_limit;
+    *longest_detectable_gap = aligner->scorer->longest_detectable_gap(read_length, tail_length);   // (:5809)
+    p.walk_distance = (uint32_t)(*longest_detectable_gap + tail_length);         // (:5816)
+    vgk_tail_result r{};
+    vgk_forest* forest = nullptr;
+    const EngineApi& api = aligner->engine_api();
+    const int rc = api.tail_forest(aligner->engine_context(), index, &p, 1, &r, &forest);
+    if (rc != VGK_OK || r.status != VGK_OK) { if (forest) api.forest_destroy(forest); throw std::runtime_error(std::string("vgamd: tail forest failed: ") + api.strerror(rc ? rc : r.status)); }
+    std::vector<int32_t> parent(r.n_nodes + 1); std::vector<uint32_t> node(r.n_nodes + 1);
+    const int rc2 = r.n_nodes ? api.forest_fetch(forest, parent.data(), node.data(), nullptr) : VGK_OK;
+    api.forest_destroy(forest);
+    if (rc2 != VGK_OK) throw std::runtime_error(std::string("vgamd: tail forest failed: ") + api.strerror(rc2));
+    size_t tree_start = 0;
+    for (uint32_t v = 0; v < r.n_nodes; ++v) {
+        if (parent[v] < 0) { to_return.emplace_back(); to_return.back().root_trim = r.root_trim; tree_start = v; }      // nothing open above it: a new tree (:5826-5838)
+        to_return.back().tree.emplace_back(parent[v] < 0 ? -1 : (int64_t)parent[v] - (int64_t)tree_start, graph->handle_of(node[v]));
+    }
+    return to_return;
+}
 bool GaplessExtender::full_length_extensions(const std::vector<GaplessExtension>& result, size_t max_mismatches) {
     return !result.empty() && result.front().full() && result.front().mismatches() <= max_mismatches;      // src/gbwt_extender.cpp:741-743
 }

@@ -96,6 +96,13 @@ public:
                                          double overlap_threshold = OVERLAP_THRESHOLD, bool trim = true) const;
     static bool full_length_extensions(const std::vector<GaplessExtension>& result, size_t max_mismatches = MAX_MISMATCHES);
 
+    // MinimizerMapper::get_tail_forest (src/minimizer_mapper.cpp:5745-5860; a member of the mapper there, here beside the extender whose
+    // haplotype index the walk reads): the trees a tail of `extended_seed` can align to, each as the (parent index, handle) list and the
+    // root trim that TreeSubgraph's constructor takes (:5838); *longest_detectable_gap as the reference computes it (:5809).  The walk
+    // itself (dfs_gbwt :5909-6013) runs on the engine (vgk_tail_forest).
+    struct TailTree { std::vector<std::pair<int64_t, handle_t>> tree; size_t root_trim = 0; };
+    std::vector<TailTree> get_tail_forest(const GaplessExtension& extended_seed, size_t read_length, bool left_tails, size_t* longest_detectable_gap = nullptr) const;
+
     const HaplotypeGraph* graph;
     const Aligner*        aligner;
 private:

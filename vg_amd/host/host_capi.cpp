@@ -241,6 +241,38 @@ int vgh_gapless_extend(vgh_extender* x, const char* read, const int64_t* seeds, 
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }
 
+// get_tail_forest of extension number `which` of the set extend() returns for this cluster; JSON out:
+// {"gap": n, "trees": [{"root_trim": n, "tree": [[parent, node id, is_reverse], ...]}, ...]}
+int vgh_gapless_tail_forest(vgh_extender* x, const char* read, const int64_t* seeds, int n_seeds, int max_mismatches, int which, int left_tails, char* json_out, size_t json_cap) {
+    try {
+        GaplessExtender::cluster_type cluster;
+        for (int i = 0; i < n_seeds; ++i) {
+            Position pos; pos.node_id = seeds[4 * i]; pos.is_reverse = seeds[4 * i + 1] != 0; pos.offset = seeds[4 * i + 2];
+            cluster.push_back(GaplessExtender::to_seed(*x->graph, pos, (size_t)seeds[4 * i + 3]));
+        }
+        const std::string sequence(read);
+        auto result = x->ext->extend(cluster, sequence, (size_t)max_mismatches, GaplessExtender::OVERLAP_THRESHOLD, true);
+        if (which < 0 || (size_t)which >= result.size()) { g_last_error = "no such extension"; return -3; }
+        size_t gap = 0;
+        auto forest = x->ext->get_tail_forest(result[(size_t)which], sequence.size(), left_tails != 0, &gap);
+        std::string js = "{\"gap\":" + std::to_string(gap) + ",\"left_full\":" + (result[(size_t)which].left_full ? "true" : "false") + ",\"right_full\":" +
+                         (result[(size_t)which].right_full ? "true" : "false") + ",\"trees\":[";
+        for (size_t t = 0; t < forest.size(); ++t) {
+            if (t) js += ',';
+            js += "{\"root_trim\":" + std::to_string(forest[t].root_trim) + ",\"tree\":[";
+            for (size_t k = 0; k < forest[t].tree.size(); ++k) {
+                if (k) js += ',';
+                js += "[" + std::to_string(forest[t].tree[k].first) + "," + std::to_string(x->graph->get_id(forest[t].tree[k].second)) + "," + (x->graph->get_is_reverse(forest[t].tree[k].second) ? "1" : "0") + "]";
+            }
+            js += "]}";
+        }
+        js += "]}";
+        if (js.size() + 1 > json_cap) { g_last_error = "json buffer too small"; return -2; }
+        std::memcpy(json_out, js.c_str(), js.size() + 1);
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
 // ---- WFAExtender (src/gbwt_extender.hpp:346-461) -------------------------------------------------------------------------
 struct vgh_wfa { std::unique_ptr<HaplotypeGraph> graph; WFAExtender::ErrorModel model; std::unique_ptr<WFAExtender> ext; };
 // model: 4 x (per_base, min, max) for mismatches, gaps, gap_length, distance; nullptr = the default model
