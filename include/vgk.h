@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define VGK_ABI_VERSION 4
+#define VGK_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -340,6 +340,13 @@ typedef struct vgk_haplotypes {
 typedef struct vgk_haplo vgk_haplo;  /* the index, resident in HBM */
 int  vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* haplotypes, vgk_haplo** out);
 void vgk_haplo_destroy(vgk_haplo* index);
+/* The same index from the image of a GBWT file (what the reference loads with gbwt_helper's load_gbwt and reaches through
+ * gbwtgraph::GBWTGraph): simple-sds serialization (header flag 0x4 — what current `vg gbwt` writes; SDSL-serialized and unidirectional
+ * files: VGK_EUNSUPPORTED), bidirectional.  The even sequences are followed out of the file's records and become the threads; GBWT
+ * node (offset + 1) + o becomes oriented node o, so n_nodes must be (alphabet_size - offset - 1) / 2 and node_len / seq describe those
+ * nodes in id order.  Malformed or truncated image: VGK_EINVAL.  [gbwt is an absent submodule: format as published, pinned on the
+ * reference's test/primers/y.gbwt — tests/test_gbwt_file.py.] */
+int  vgk_haplo_create_gbwt(vgk_ctx* ctx, const void* gbwt, size_t bytes, uint32_t n_nodes, const uint32_t* node_len, const char* seq, vgk_haplo** out);
 
 typedef struct vgk_seed {            /* GaplessExtender::seed_type (src/gbwt_extender.hpp:33): (handle, read_offset - node_offset) */
     uint32_t node;                   /* oriented node */
@@ -379,19 +386,26 @@ uint64_t vgk_gapless_last_retried(vgk_ctx* ctx);   /* reads of that call whose s
 
 /* ---- minimizer seeding (MinimizerMapper::find_minimizers / find_seeds over gbwtgraph::MinimizerIndex, src/minimizer_mapper.cpp:3918-3965,
  * :4109-4290): the step that produces the clusters vgk_gapless_extend takes ------------------------------------------------------
- * vgk_minimizer_index_create indexes the (k, w)-minimizers of every haplotype thread (k <= 31, w <= 32; giraffe's defaults 29, 11)
+ * vgk_minimizer_index_create indexes the (k, w)-minimizers of every haplotype thread (k <= 31, w <= 64; giraffe's defaults 29, 11 for short reads and 31, 50 for long ones)
  * with the graph positions they start at; vgk_minimizer_seeds finds the minimizers of a batch of reads on the device, looks each up
  * and turns every hit into a seed (oriented node, read offset - node offset) on the strand the read reads forward on.  Per read the
  * seeds come in the order of their minimizers' read offsets; a (node, diagonal) pair hit twice is reported once (a cluster is a set);
  * minimizers with more than `hit_cap` hits give no seeds (hard_hit_cap); at most 64 seeds per read (what a cluster of the extension
- * stage holds).  [PARITY-UNPINNED: gbwtgraph is not in the reference snapshot; vg_amd/csrc/minimizer_device.hpp states the scheme
- * restated here — 2-bit keys, Wang's 64-bit hash, the smaller-hash orientation canonical, leftmost minimum per window.  Seed
+ * stage holds).  [gbwtgraph is not in the reference snapshot; vg_amd/csrc/minimizer_device.hpp states the scheme
+ * restated here — 2-bit keys, Wang's 64-bit hash, the smaller-hash orientation canonical, leftmost minimum per window.  It is PINNED on the
+ * one MinimizerIndex the reference keeps (test/primers/y.min, k = 31, w = 50: all 62 keys and positions reproduced from y.gg + y.gbwt,
+ * tests/test_minimizer.py); what a read's minimizers turn into below that — seed orientation, de-duplication — is PARITY-UNPINNED.  Seed
  * SCORING and the downsampling / hit-cap policies of find_seeds (:4140-4290), and the clustering of seeds by graph distance
  * (SnarlDistanceIndexClusterer), are the caller's.] */
 typedef struct vgk_minimizer_index vgk_minimizer_index;
 int  vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* haplotypes, uint32_t k, uint32_t w, vgk_minimizer_index** out);
 void vgk_minimizer_index_destroy(vgk_minimizer_index* index);
 uint64_t vgk_minimizer_index_keys(const vgk_minimizer_index* index);      /* distinct minimizer k-mers */
+/* What the index holds, as gbwtgraph's MinimizerIndex would hold it: (canonical key, oriented node, offset on that strand) for every
+ * indexed occurrence, sorted by key, then node, then offset.  vgk_minimizer_index_fetch: VGK_EOPS when cap < vgk_minimizer_index_hits. */
+typedef struct vgk_minimizer_hit { uint64_t key; uint32_t node, offset; } vgk_minimizer_hit;
+uint64_t vgk_minimizer_index_hits(const vgk_minimizer_index* index);
+int  vgk_minimizer_index_fetch(const vgk_minimizer_index* index, vgk_minimizer_hit* hits, size_t cap);
 /* reads: flat, read i = reads[read_off[i], read_off[i + 1]).  seed_off[n + 1] and, nullable, minimizers[n] (minimizers per read) are
  * filled always; seeds up to seeds_cap (VGK_EOPS when that is too small; *written = the number needed); seeds = NULL with seeds_cap = 0
  * leaves them on the device only (for vgk_gapless_extend_seeded). */

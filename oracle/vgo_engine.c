@@ -493,6 +493,13 @@ int vgk_forest_fetch(const vgk_forest* f, int32_t* parent, uint32_t* node, uint3
 const vgk_dgraph* vgk_forest_graph(const vgk_forest* f) { return f ? f->graph : NULL; }
 double vgk_tail_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }
 
+/* reading a GBWT file is the engine's; the independent decoder the tests hold against it is tests/golden/extract_primers_fixture.py,
+ * and the oracle's index is built from the threads that script extracts */
+int vgk_haplo_create_gbwt(vgk_ctx* ctx, const void* gbwt, size_t bytes, uint32_t n_nodes, const uint32_t* node_len, const char* seq, vgk_haplo** out) {
+    (void)ctx; (void)gbwt; (void)bytes; (void)n_nodes; (void)node_len; (void)seq; if (out) *out = NULL;
+    return VGK_EUNSUPPORTED;
+}
+
 /* the oracle keeps nothing between calls: the seeded form is not available on it (callers use vgk_gapless_extend) */
 int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max_mismatches, double overlap_threshold, uint32_t flags,
                               vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,

@@ -77,7 +77,7 @@ static int cmp_entry(const void* a, const void* b) {
 void vgk_minimizer_index_destroy(vgk_minimizer_index* ix) { if (ix) { free(ix->node_len); free(ix->e); free(ix); } }
 int vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* d, uint32_t k, uint32_t w, vgk_minimizer_index** out) {
     if (!ctx || !d || !out || !d->n_nodes || !d->node_len || !d->seq || (d->n_threads && (!d->thread_off || !d->thread_nodes))) return VGK_EINVAL;
-    if (k == 0 || k > 31 || w == 0 || w > 32) return VGK_EINVAL;
+    if (k == 0 || k > 31 || w == 0 || w > 64) return VGK_EINVAL;
     *out = NULL;
     uint64_t* node_at = (uint64_t*)malloc(sizeof(uint64_t) * ((size_t)d->n_nodes + 1));
     node_at[0] = 0; for (uint32_t i = 0; i < d->n_nodes; ++i) node_at[i + 1] = node_at[i] + d->node_len[i];
@@ -110,6 +110,13 @@ int vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* d, uint32_t k
     return VGK_OK;
 }
 uint64_t vgk_minimizer_index_keys(const vgk_minimizer_index* ix) { return ix ? ix->n_keys : 0; }
+uint64_t vgk_minimizer_index_hits(const vgk_minimizer_index* ix) { return ix ? ix->n : 0; }
+int vgk_minimizer_index_fetch(const vgk_minimizer_index* ix, vgk_minimizer_hit* hits, size_t cap) {
+    if (!ix || (!hits && cap)) return VGK_EINVAL;
+    if (cap < ix->n) return VGK_EOPS;
+    for (size_t i = 0; i < ix->n; ++i) { hits[i].key = ix->e[i].key; hits[i].node = ix->e[i].node; hits[i].offset = ix->e[i].offset; }
+    return VGK_OK;
+}
 
 typedef struct { const vgk_minimizer_index* ix; uint32_t hit_cap; vgk_seed seeds[64]; uint32_t n_seeds, n_min; } Query;
 static void query_emit(void* c, uint32_t p, uint64_t key, uint64_t hash, int reverse) {

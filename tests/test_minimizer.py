@@ -1,9 +1,12 @@
 """Minimizer seeding (vgk_minimizer_index_create / vgk_minimizer_seeds): the (k, w)-minimizers of reads, looked up in the index of the
 haplotype threads' minimizers, as seeds of the extension stage (MinimizerMapper::find_minimizers / find_seeds over gbwtgraph's
-MinimizerIndex, src/minimizer_mapper.cpp:3918-3965, :4109-4290).  [PARITY-UNPINNED against the reference: gbwtgraph is not in the
-snapshot.]  Three constructions: this file's brute force (every k-mer hashed, every window scanned, the index a dict), the oracle's
+MinimizerIndex, src/minimizer_mapper.cpp:3918-3965, :4109-4290).  gbwtgraph is not in the snapshot; the scheme is pinned on the one
+MinimizerIndex file the reference keeps (test/primers/y.min -> tests/golden/ref_primers_y.json, last tests of this file); what becomes
+of a read's minimizers after the lookup is PARITY-UNPINNED.  Three constructions: this file's brute force (every k-mer hashed, every window scanned, the index a dict), the oracle's
 (oracle/vgo_minimizer.c), the engine's (ring + hash table on the device; the emulator here, the MI355X in the gpu test) — and the
 property the next stage relies on: a seed of a read sampled from a haplotype lies on the read's true diagonal."""
+import json
+import os
 import subprocess
 
 import numpy as np
@@ -150,6 +153,7 @@ def test_seeds_equal_the_brute_force_construction(lib_name, emu_lib):
     run(lib, 2, 29, 11, 60)
     run(lib, 3, 11, 4, 60, hit_cap=2)
     run(lib, 4, 31, 32, 40)
+    run(lib, 6, 25, 64, 20, L=250)
     run(lib, 5, 21, 7, 20, L=1500)
 
 
@@ -174,7 +178,7 @@ def test_seeds_feed_the_extension_stage(emu_lib):
 def test_seeds_on_the_gpu_equal_the_brute_force_construction():
     run(ENGINE_LIB, 7, 29, 11, 400)
     run(ENGINE_LIB, 8, 15, 6, 400)
-    run(ENGINE_LIB, 9, 31, 32, 150)                 # the widest window the kernel takes
+    run(ENGINE_LIB, 9, 31, 32, 150)
     run(ENGINE_LIB, 10, 21, 7, 60, L=1500)          # many rounds per read, more than 64 distinct seeds
 
 
@@ -217,3 +221,75 @@ def test_clusters_that_stay_on_the_device(emu_lib):
 @pytest.mark.gpu
 def test_clusters_that_stay_on_the_device_on_the_gpu():
     seeded_equals_via_host(ENGINE_LIB, 5000, 22)
+
+
+# ---- pinned on the reference's own index file ------------------------------------------------------------------------------------
+def primers_fixture():
+    """test/primers/y.{gbwt,gg,min} of the reference, decoded by tests/golden/extract_primers_fixture.py"""
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_primers_y.json")))
+    nodes = fx["node_sequences"]
+    first = fx["gbwt_header"]["offset"] + 1                                  # GBWT node of (first node id, forward)
+    threads = [[x - first for x in t] for t in fx["gbwt_threads"][0::2]]    # the odd sequences are the even ones on the other strand
+    mi = fx["minimizer_index"]
+    want = sorted((e["key"], 2 * (e["id"] - first // 2) + e["is_reverse"], e["offset"]) for e in mi["entries"])
+    return fx, nodes, threads, mi["k"], mi["w"], want
+
+
+def index_equals_the_reference_file(lib):
+    fx, nodes, threads, k, w, want = primers_fixture()
+    assert (k, w) == (31, 50) and len(want) == 62
+    eng = capi.Engine(lib=lib)
+    mi = eng.minimizer_index(nodes, threads, k, w)
+    hits = mi.fetch()
+    got = [(int(h["key"]), int(h["node"]), int(h["offset"])) for h in hits]
+    assert got == want
+    assert mi.keys == 62
+    # the file's hash table: a key sits in the first free cell from hash & (capacity - 1) on, in insertion order — so every key's
+    # cell is at or cyclically behind its home cell, and every cell between the two is taken
+    cap = fx["minimizer_index"]["capacity"]
+    taken = {e["cell"] for e in fx["minimizer_index"]["entries"]}
+    for e in fx["minimizer_index"]["entries"]:
+        home = wang(e["key"]) & (cap - 1)
+        c = home
+        while c != e["cell"]:
+            assert c in taken; c = (c + 1) & (cap - 1)
+    return eng, mi, nodes, threads, k, w
+
+
+@pytest.mark.parametrize("lib_name", ["oracle", "emu"])
+def test_index_of_the_primers_graph_is_the_reference_minimizer_index(lib_name, emu_lib):
+    """y.min (gbwtgraph's MinimizerIndex of the graph in y.gg / y.gbwt, k = 31, w = 50) holds 62 keys with one position each: the
+    index built here from the same graph and haplotypes holds exactly those keys at exactly those positions"""
+    index_equals_the_reference_file(ORACLE_LIB if lib_name == "oracle" else emu_lib)
+    fx, nodes, threads, k, w, want = primers_fixture()
+    mine = build_index(nodes, threads, k, w)                               # this file's brute force agrees as well
+    assert sorted((key, n, o) for key, v in mine.items() for n, o in v) == want
+
+
+def wide_window_seeds(lib, n_reads=40):
+    """k = 31, w = 50 (the long-read parameters of the file) through the seeding path: engine = brute force"""
+    eng, mi, nodes, threads, k, w = index_equals_the_reference_file(lib)
+    rng = np.random.default_rng(11)
+    reads, truth = sample_reads(rng, nodes, threads, n_reads, 400, error=0.005, with_n=0.05)
+    index = build_index(nodes, threads, k, w)
+    flat = np.frombuffer("".join(reads).encode(), dtype=np.uint8); off = np.concatenate([[0], np.cumsum([len(r) for r in reads])])
+    hi = eng.haplo_index(nodes, threads)
+    seed_off, seeds, mins = eng.minimizer_seeds(mi, hi, flat, off, 500)
+    some = 0
+    for i, r in enumerate(reads):
+        got = [(int(s["node"]), int(s["diff"])) for s in seeds[seed_off[i]:seed_off[i + 1]]]
+        assert got == seeds_of(r, index, nodes, k, w, 500)
+        assert mins[i] == len(minimizers(r, k, w))
+        some += bool(got)
+    assert some > n_reads // 2
+
+
+@pytest.mark.parametrize("lib_name", ["oracle", "emu"])
+def test_seeds_with_the_wide_window_of_the_reference_file(lib_name, emu_lib):
+    wide_window_seeds(ORACLE_LIB if lib_name == "oracle" else emu_lib)
+
+
+@pytest.mark.gpu
+def test_reference_minimizer_index_and_wide_window_on_the_gpu():
+    wide_window_seeds(ENGINE_LIB, 200)
+    run(ENGINE_LIB, 12, 31, 64, 80, L=300)          # the widest window the kernel takes

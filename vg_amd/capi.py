@@ -37,6 +37,7 @@ BANDED_DT = np.dtype([("read", "<u8"), ("qual", "<u8"), ("read_len", "<u4"), ("f
                       ("band_padding", "<i4"), ("reserved", "<u4"), ("max_cells", "<u8")])
 VGK_BANDED_PERMISSIVE = 1
 SEED_DT = np.dtype([("node", "<u4"), ("diff", "<i4")])
+MINIMIZER_HIT_DT = np.dtype([("key", "<u8"), ("node", "<u4"), ("offset", "<u4")])
 GAPLESS_DT = np.dtype([("read", "<u8"), ("read_len", "<u4"), ("n_seeds", "<u4"), ("seeds", "<u8"), ("max_mismatches", "<u4"),
                        ("flags", "<u4"), ("overlap_threshold", "<f8")])
 EXT_DT = np.dtype([("path_begin", "<u4"), ("path_len", "<u4"), ("offset", "<u4"), ("read_begin", "<u4"), ("read_end", "<u4"),
@@ -356,6 +357,10 @@ class Engine:
         """nodes: [str] in node-id order; threads: [[oriented node = 2 * index + is_reverse]].  -> HaploIndex"""
         return HaploIndex(self, nodes, threads)
 
+    def haplo_index_from_gbwt(self, nodes, gbwt_bytes):
+        """vgk_haplo_create_gbwt: the index from the image of a (simple-sds, bidirectional) GBWT file"""
+        return HaploIndex(self, nodes, gbwt=gbwt_bytes)
+
     def gapless_extend(self, index, problems):
         """problems: a GaplessSet, or a list of dicts {read, seeds: [(oriented node, read_offset - node_offset)], max_mismatches?,
         overlap_threshold?, trim?}.  -> (results, extensions, nodes, mismatches) as numpy arrays laid out like include/vgk.h."""
@@ -524,6 +529,16 @@ class MinimizerIndex:
         self.keys = int(eng.lib.vgk_minimizer_index_keys(h))
         eng._indexes.add(self)
 
+    def fetch(self):
+        """vgk_minimizer_index_fetch: every indexed occurrence as (key, oriented node, offset), sorted"""
+        lib = self.eng.lib
+        lib.vgk_minimizer_index_hits.restype = ctypes.c_uint64; lib.vgk_minimizer_index_hits.argtypes = [ctypes.c_void_p]
+        n = int(lib.vgk_minimizer_index_hits(self.h))
+        hits = np.zeros(max(n, 1), dtype=MINIMIZER_HIT_DT)
+        lib.vgk_minimizer_index_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        self.eng._check(lib.vgk_minimizer_index_fetch(self.h, hits.ctypes.data, n), "vgk_minimizer_index_fetch")
+        return hits[:n]
+
     def close(self):
         if getattr(self, "h", None):
             if getattr(self.eng, "h", None):
@@ -654,11 +669,20 @@ class WfaSet:
 class HaploIndex:
     """The haplotype index the gapless extender walks (stands in for vg's GBWTGraph)."""
 
-    def __init__(self, eng, nodes, threads):
+    def __init__(self, eng, nodes, threads=None, gbwt=None):
+        """threads: [[oriented node]]; or gbwt: the bytes of a GBWT file (vgk_haplo_create_gbwt)"""
         self.eng = eng
         self.nodes = list(nodes)
         self._len = np.array([len(s) for s in nodes], dtype=np.uint32)
         self._seq = np.frombuffer("".join(nodes).encode(), dtype=np.uint8).copy()
+        if gbwt is not None:
+            h = ctypes.c_void_p()
+            eng.lib.vgk_haplo_create_gbwt.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            eng._check(eng.lib.vgk_haplo_create_gbwt(eng.h, bytes(gbwt), len(gbwt), len(nodes), self._len.ctypes.data, self._seq.ctypes.data, ctypes.byref(h)),
+                       "vgk_haplo_create_gbwt")
+            self.h = h
+            eng._indexes.add(self)
+            return
         self._toff = np.concatenate([[0], np.cumsum([len(t) for t in threads])]).astype(np.uint32)
         self._tn = np.array([o for t in threads for o in t] or [0], dtype=np.uint32)
         d = Haplotypes(len(nodes), self._len.ctypes.data, self._seq.ctypes.data, len(threads), self._toff.ctypes.data, self._tn.ctypes.data)

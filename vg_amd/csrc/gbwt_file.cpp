@@ -1,0 +1,178 @@
+// gbwt_file.cpp — vgk_haplo_create_gbwt: the haplotype index from the file `vg gbwt` writes (the GBWT the
+// reference's GaplessExtender / WFAExtender search lives in a gbwt::GBWT loaded from such a file, src/gbwt_helper.cpp, and is reached
+// through gbwtgraph::GBWTGraph).
+//
+// gbwt is an absent submodule; what is decoded here is its published file format, simple-sds serialization (header flag 0x4, what
+// current gbwt writes by default), pinned on the one GBWT the reference keeps for its own tests (test/primers/y.gbwt; decoded
+// independently by tests/golden/extract_primers_fixture.py, compared in tests/test_gbwt_file.py):
+//   header   tag 0x6B376B37, version, sequences, size, offset, alphabet_size, flags              (2 x u32, 5 x u64)
+//   tags     a string array: sparse vector + byte vector + int vector                            (skipped)
+//   BWT      sparse vector (Elias-Fano) of the records' start offsets + the byte array of all records
+//   record   ByteCode outdegree; per edge ByteCode (successor - previous successor), ByteCode offset; then runs (rank of the edge,
+//            length): one byte  rank + outdegree * (length - 1)  with the length continued in a ByteCode when it reaches
+//            256 / outdegree, or two ByteCodes when the outdegree is >= 255
+//   (document-array samples and metadata follow; not needed)
+// Record 0 is the endmarker: its i-th visit starts sequence i.  Sequences are followed with LF (the visit's edge and its rank among
+// the visits taking that edge, plus the edge's offset) until they return to the endmarker.  In a bidirectional GBWT sequence 2i + 1
+// is sequence 2i on the other strand, which is exactly what vgk_haplo_create derives from a thread itself: the even sequences become
+// the threads, and the index built from them holds the file's records again (the test compares search states with the file's).
+#include <cstring>
+#include <vector>
+#include "ctx.hpp"
+#include "haplo.hpp"
+#include "host_parallel.hpp"
+
+namespace {
+
+struct Cursor {
+    const uint8_t* p; size_t n, at = 0; bool ok = true;
+    uint64_t u64() { if (at + 8 > n) { ok = false; return 0; } uint64_t v; std::memcpy(&v, p + at, 8); at += 8; return v; }
+    uint32_t u32() { if (at + 4 > n) { ok = false; return 0; } uint32_t v; std::memcpy(&v, p + at, 4); at += 4; return v; }
+    const uint8_t* words(uint64_t count) {
+        if (count > (n - at) / 8) { ok = false; return nullptr; }
+        const uint8_t* q = p + at; at += 8 * (size_t)count; return q;
+    }
+    void skip_option() { const uint64_t w = u64(); words(w); }
+};
+struct Bits {                                 // a RawVector: bit length + words
+    const uint8_t* w = nullptr; uint64_t bits = 0;
+    bool get(uint64_t i) const { return (w[i >> 3] >> (i & 7)) & 1; }
+    uint64_t field(uint64_t at, uint32_t width) const {                    // width <= 64, little-endian bit order
+        uint64_t v = 0;
+        for (uint32_t b = 0; b < width; ++b) v |= (uint64_t)get(at + b) << b;
+        return v;
+    }
+};
+bool read_raw(Cursor& c, Bits& out) {
+    out.bits = c.u64(); const uint64_t n = c.u64();
+    if (!c.ok || out.bits > 64 * n) { c.ok = false; return false; }
+    out.w = c.words(n);
+    return c.ok;
+}
+// IntVector: length, width, RawVector
+bool read_int_vector(Cursor& c, Bits& data, uint64_t& len, uint64_t& width) {
+    len = c.u64(); width = c.u64();
+    if (!read_raw(c, data) || width > 64 || data.bits != len * width) { c.ok = false; return false; }
+    return true;
+}
+// SparseVector: universe; high bits as a BitVector (ones, RawVector, three optional support structures); low bits as an IntVector.
+// The i-th one of `high` at position p stands for the value ((p - i) << width) | low[i].
+bool read_sparse(Cursor& c, uint64_t& universe, std::vector<uint64_t>* values) {
+    universe = c.u64();
+    const uint64_t ones = c.u64();
+    Bits high; if (!read_raw(c, high)) return false;
+    c.skip_option(); c.skip_option(); c.skip_option();
+    Bits low; uint64_t len = 0, width = 0;
+    if (!read_int_vector(c, low, len, width) || len != ones) { c.ok = false; return false; }
+    if (values) {
+        values->clear(); values->reserve((size_t)ones);
+        uint64_t i = 0;
+        for (uint64_t p = 0; p < high.bits && i < ones; ++p) if (high.get(p)) { values->push_back(((p - i) << width) | low.field(i * width, (uint32_t)width)); ++i; }
+        if (i != ones) { c.ok = false; return false; }
+    }
+    return c.ok;
+}
+bool read_bytes(Cursor& c, const uint8_t*& data, uint64_t& len) {
+    len = c.u64();
+    if (!c.ok || len > c.n - c.at) { c.ok = false; return false; }
+    data = c.words((len + 7) / 8);
+    return c.ok;
+}
+
+struct Body { const uint8_t* b; size_t end; };
+inline bool byte_code(const Body& s, size_t& i, uint64_t& v) {
+    v = 0;
+    for (uint32_t shift = 0; shift < 64; shift += 7) {
+        if (i >= s.end) return false;
+        const uint8_t c = s.b[i++];
+        v |= (uint64_t)(c & 0x7f) << shift;
+        if (!(c & 0x80)) return true;
+    }
+    return false;
+}
+struct Edge { uint64_t node, offset; };
+// One LF step inside the record [lo, hi): the visit `i` of the record leaves along which edge, and as which visit of the successor.
+// edges is scratch.  false: the record is malformed or has fewer than i + 1 visits.
+bool lf(const uint8_t* body, size_t lo, size_t hi, uint64_t i, std::vector<Edge>& edges, uint64_t& next_node, uint64_t& next_i) {
+    const Body s{body, hi};
+    size_t at = lo; uint64_t sigma;
+    if (!byte_code(s, at, sigma) || sigma == 0 || sigma > hi - lo) return false;
+    edges.resize((size_t)sigma);
+    uint64_t node = 0;
+    for (uint64_t e = 0; e < sigma; ++e) {
+        uint64_t delta, off;
+        if (!byte_code(s, at, delta) || !byte_code(s, at, off)) return false;
+        node += delta; edges[(size_t)e] = Edge{node, off};
+    }
+    const uint64_t continues = sigma < 255 ? 256 / sigma : 0;
+    uint64_t seen = 0;
+    while (at < hi) {
+        uint64_t rank, length;
+        if (continues == 0) { if (!byte_code(s, at, rank) || !byte_code(s, at, length)) return false; ++length; }
+        else {
+            const uint8_t code = body[at++];
+            rank = code % sigma; length = code / sigma + 1;
+            if (length >= continues) { uint64_t more; if (!byte_code(s, at, more)) return false; length += more; }
+        }
+        if (rank >= sigma) return false;
+        if (i < seen + length) { next_node = edges[(size_t)rank].node; next_i = edges[(size_t)rank].offset + (i - seen); return true; }
+        edges[(size_t)rank].offset += length; seen += length;
+    }
+    return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vgk_haplo_create_gbwt(vgk_ctx* ctx, const void* gbwt, size_t bytes, uint32_t n_nodes, const uint32_t* node_len, const char* seq, vgk_haplo** out) {
+    if (!ctx || !gbwt || !out || !n_nodes || !node_len || !seq) return VGK_EINVAL;
+    *out = nullptr;
+    Cursor c{(const uint8_t*)gbwt, bytes};
+    const uint32_t tag = c.u32(); c.u32();
+    const uint64_t sequences = c.u64(), size = c.u64(), offset = c.u64(), alphabet = c.u64(), flags = c.u64();
+    if (!c.ok || tag != 0x6B376B37u) return VGK_EINVAL;
+    if (!(flags & 0x4u)) return VGK_EUNSUPPORTED;                           // SDSL serialization (older files): `vg gbwt` rewrites them
+    if (!(flags & 0x1u)) return VGK_EUNSUPPORTED;                           // unidirectional: the extenders need both strands
+    if (alphabet <= offset + 1 || ((offset + 1) & 1) || alphabet - offset - 1 != 2ull * n_nodes || (sequences & 1) || size > 0xfffffff0ull) return VGK_EINVAL;
+    uint64_t universe = 0;
+    if (!read_sparse(c, universe, nullptr)) return VGK_EINVAL;               // tags: index ...
+    { const uint8_t* a; uint64_t n; if (!read_bytes(c, a, n)) return VGK_EINVAL; }      // ... alphabet ...
+    { Bits d; uint64_t n, w; if (!read_int_vector(c, d, n, w)) return VGK_EINVAL; }     // ... symbols
+    std::vector<uint64_t> starts;
+    if (!read_sparse(c, universe, &starts)) return VGK_EINVAL;
+    const uint8_t* body = nullptr; uint64_t body_len = 0;
+    if (!read_bytes(c, body, body_len) || body_len != universe || starts.size() != alphabet - offset) return VGK_EINVAL;
+    for (size_t r = 0; r < starts.size(); ++r) if (starts[r] > body_len || (r && starts[r] < starts[r - 1])) return VGK_EINVAL;
+    starts.push_back(body_len);
+
+    // the even sequences, one host task each: (endmarker, s) -> first node -> ... -> endmarker
+    const uint32_t n_threads = (uint32_t)(sequences / 2);
+    std::vector<std::vector<uint32_t>> walks(n_threads);
+    std::vector<int> status(n_threads, VGK_OK);
+    vgk::parallel_tasks(n_threads, [&](uint32_t t) {
+        std::vector<Edge> edges;
+        std::vector<uint32_t>& walk = walks[t];
+        uint64_t node = 0, i = 2ull * t;
+        for (uint64_t steps = 0;; ++steps) {
+            const uint64_t rec = node == 0 ? 0 : node - offset;
+            uint64_t nn, ni;
+            if (steps > size || !lf(body, (size_t)starts[(size_t)rec], (size_t)starts[(size_t)rec + 1], i, edges, nn, ni)) { status[t] = VGK_EINVAL; return; }
+            if (nn == 0) return;
+            if (nn <= offset || nn >= alphabet) { status[t] = VGK_EINVAL; return; }
+            walk.push_back((uint32_t)(nn - offset - 1));
+            node = nn; i = ni;
+        }
+    });
+    for (int rc : status) if (rc) return rc;
+    std::vector<uint32_t> thread_off((size_t)n_threads + 1, 0), thread_nodes;
+    for (uint32_t t = 0; t < n_threads; ++t) thread_off[t + 1] = thread_off[t] + (uint32_t)walks[t].size();
+    thread_nodes.reserve(thread_off[n_threads]);
+    for (auto& w : walks) thread_nodes.insert(thread_nodes.end(), w.begin(), w.end());
+    vgk_haplotypes d{};
+    d.n_nodes = n_nodes; d.node_len = node_len; d.seq = seq;
+    d.n_threads = n_threads; d.thread_off = thread_off.data(); d.thread_nodes = thread_nodes.data();
+    return vgk_haplo_create(ctx, &d, out);
+}
+
+}  // extern "C"

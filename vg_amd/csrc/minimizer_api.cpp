@@ -19,6 +19,7 @@ struct vgk_minimizer_index {
     MzIndex dev{};
     std::vector<void*> held;
     uint64_t n_keys = 0, n_pos = 0;
+    std::vector<vgk_minimizer_hit> hits;      // what the index holds (vgk_minimizer_index_fetch)
 };
 
 namespace {
@@ -80,6 +81,8 @@ int vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* d, uint32_t k
     std::unique_ptr<vgk_minimizer_index> ix(new (std::nothrow) vgk_minimizer_index());
     if (!ix) return VGK_ENOMEM;
     ix->ctx = ctx; ix->n_keys = n_keys; ix->n_pos = all.size();
+    ix->hits.resize(all.size());
+    for (size_t i = 0; i < all.size(); ++i) ix->hits[i] = vgk_minimizer_hit{all[i].key, all[i].node, all[i].offset};
     Backend* be = ctx->be.get();
     std::lock_guard<std::mutex> lk(ctx->mu);
     void* ds = be->alloc(sizeof(MzSlot) * cap); void* dp = be->alloc(sizeof(MzPos) * pos.size());
@@ -101,6 +104,13 @@ void vgk_minimizer_index_destroy(vgk_minimizer_index* ix) {
     delete ix;
 }
 uint64_t vgk_minimizer_index_keys(const vgk_minimizer_index* ix) { return ix ? ix->n_keys : 0; }
+uint64_t vgk_minimizer_index_hits(const vgk_minimizer_index* ix) { return ix ? ix->hits.size() : 0; }
+int vgk_minimizer_index_fetch(const vgk_minimizer_index* ix, vgk_minimizer_hit* hits, size_t cap) {
+    if (!ix || (!hits && cap)) return VGK_EINVAL;
+    if (cap < ix->hits.size()) return VGK_EOPS;
+    if (!ix->hits.empty()) std::memcpy(hits, ix->hits.data(), sizeof(vgk_minimizer_hit) * ix->hits.size());
+    return VGK_OK;
+}
 
 int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_haplo* graph, const char* reads, const uint64_t* read_off, uint32_t n,
                         uint32_t hit_cap, uint32_t* seed_off, uint32_t* minimizers, vgk_seed* seeds, size_t seeds_cap, size_t* written) {

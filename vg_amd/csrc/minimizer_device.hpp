@@ -24,7 +24,7 @@
 
 namespace vgk {
 
-constexpr uint32_t MZ_MAX_K = 31, MZ_MAX_W = 32, MZ_MAX_SEEDS = 64;      // (64 = the seeds a cluster of the extension stage may hold)
+constexpr uint32_t MZ_MAX_K = 31, MZ_MAX_W = 64, MZ_MAX_SEEDS = 64;      // (64 = the seeds a cluster of the extension stage may hold)
 VGK_HD uint64_t mz_hash(uint64_t key) {                 // Thomas Wang's 64-bit mix
     key = (~key) + (key << 21); key ^= key >> 24; key = (key + (key << 3)) + (key << 8); key ^= key >> 14;
     key = (key + (key << 2)) + (key << 4); key ^= key >> 28; key += key << 31;
