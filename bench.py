@@ -348,6 +348,7 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
 
     stage = pipeline.align_stage if os.environ.get("VGAMD_GIRAFFE_NUMPY_GLUE") else pipeline.align_stage_native      # the glue in the host shim (C++) or in numpy
     device_tails = not os.environ.get("VGAMD_GIRAFFE_HOST_TAILS") and stage is pipeline.align_stage_native          # ... or no glue: vgk_tail_stage on the device
+    with_alignments = device_tails and bool(os.environ.get("VGAMD_GIRAFFE_ALIGNED"))      # vgk_tail_stage_aligned: the tails' winning alignments come back too
     from_reads = bool(os.environ.get("VGAMD_GIRAFFE_FROM_READS"))         # start from the bare reads: minimizer seeding on the device makes the clusters
     mindex = None; seeds_per_read = None; t_index = 0.0
     stay = from_reads and not os.environ.get("VGAMD_GIRAFFE_SEEDS_VIA_HOST") and stage is pipeline.align_stage_native      # the clusters stay on the device between seeding and extension
@@ -372,7 +373,7 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
                 timing["minimizer_seeds (device)"] = timing.get("minimizer_seeds (device)", 0.0) + eng.minimizer_last_ms() * 1e-3
                 timing["clusters assembled (host)"] = timing.get("clusters assembled (host)", 0.0) + time.perf_counter() - t2
         if device_tails:
-            out = pipeline.align_stage_device(eng, index, gs, timing=timing, seeded=seeded)
+            out = pipeline.align_stage_device(eng, index, gs, timing=timing, seeded=seeded, aligned=with_alignments)
         else:
             out = stage(eng, index, olen, gs, timing=timing, seeded=seeded) if seeded is not None else stage(eng, index, olen, gs, timing=timing)
         if "forest" in out:
@@ -415,6 +416,19 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
                "impl": "the same pipeline over the oracle: vgo_gapless.c (OpenMP over reads), vgo_tail.c (one thread), vgo_xdrop.c (OpenMP over problems)",
                "sample": "the first %d reads of the batch" % k}
         parity = {"checked": k, "identical": same, "what": "per-read best total score (extension + both tails); tests/test_giraffe_stage.py compares every intermediate product"}
+        if with_alignments and not from_reads:
+            # the tails of the first k reads are a prefix of the right tails and a prefix of the left tails (both in extension order)
+            want = pipeline.winning_alignments(o)
+            tl, tops = out["tails"], out["tail_ops"]
+            ne_k = int(o["res"]["n_ext"].sum())
+            mine = [x for x in tl if x["ext"] < ne_k]
+            ok = len(mine) == len(want)
+            same_aln = 0
+            for x, wrow in zip(mine, want):
+                ops = tops[x["ops_begin"]:x["ops_begin"] + x["n_ops"]]
+                got = (int(x["ext"]), int(x["left"]), int(x["read_begin"]), int(x["read_end"]), int(x["score"]), int(x["first_offset"]), [(int(q["node"]), int(q["op"]), int(q["len"])) for q in ops])
+                same_aln += got == wrow
+            parity["tail_alignments_checked"] = len(want); parity["tail_alignments_identical"] = same_aln if ok else 0
     if rank == 0:
         open_reads = int((res["full_length"] == 0).sum())
         print(json.dumps({
@@ -430,6 +444,7 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
                        "clusters_from": ("minimizer seeding on the device (k 29, w 11; %.1f seeds per read; index of %d minimizer k-mers built in %.1f s); %s" % (seeds_per_read, mindex.keys, t_index,
                                           "reads and seeds stay in HBM for the extension (vgk_gapless_extend_seeded)" if stay else "seeds via the host")) if from_reads else "seeds given (true positions)",
                        "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()},
+                       "tail_alignments": ("returned: per tail the best tree's alignment, chosen on the device (vgk_tail_stage_aligned); %d tails, %d ops per step" % (len(out["tails"]), len(out["tail_ops"]))) if with_alignments else "scores only (vgk_tail_stage)",
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
             "roofline": {"bound": "hbm", "kernel": "gapless_search_kernel (the stage's largest kernel)", "limiter": "host glue and PCIe round trips between the stages, then memory latency (DESIGN.md §11, §17)",
                          "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},

@@ -249,10 +249,28 @@ double   vgk_tail_last_ms(vgk_ctx* ctx);                                 /* devi
  * the total score) as kernels over what that call left in HBM — tails derived from the extensions' search states, one forest, one window
  * per tree, left-pinned X-drop, the best tree of a tail, the totals.  ext_total[e] = extension e's score + the best alignment of either
  * open tail (a tail nothing aligns to, or one the engine declines, adds 0: the soft clip); read_score[i] = the best total of read i.
- * stats (nullable): tails, trees, tree nodes, tails + windows the engine declined.  The alignments themselves (paths, CIGARs) of the tails
- * are not returned by this entry point: vg_amd/host/tail_stage.cpp does the same through vgk_tail_forest + vgk_gssw_pack_windows and
- * keeps them. */
+ * stats (nullable): tails, trees, tree nodes, tails + windows the engine declined.  This entry point returns scores only (giraffe ranks
+ * its extensions by them before it builds alignments); vgk_tail_stage_aligned returns the tails' alignments as well. */
 int      vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score, uint64_t stats[4]);
+/* The same, and per tail the alignment of its best tree — what get_best_alignment_against_any_tree (:5626-5741) hands back, chosen on the
+ * device: only the winners' ops cross PCIe, with their nodes already translated from tree nodes to oriented nodes of the index
+ * (TreeSubgraph::translate_down).  Tails come in the order right tails (by extension), then left tails.  A right tail's ops run along
+ * the read; a LEFT tail's are those of the reverse-complemented tail on the other strand, running from the extension outwards — the
+ * alignment the reference has before it reverse-complements it back (:5726).  score 0 / n_ops 0: the soft clip (nothing aligned better).
+ * Of several trees with the best score the first one wins (the reference asks deterministic_beats, a hash of the alignments: unpinned).
+ * written (nullable): tails, ops — set also on VGK_EOPS (tails_cap or ops_cap too small). */
+typedef struct vgk_tail_alignment {
+    uint32_t ext;             /* the extension it belongs to (index into that call's `extensions`)                                   */
+    uint32_t left;            /* 0: the right tail, read bases [read_begin, read_end) behind the extension; 1: the left tail before it */
+    uint32_t read_begin, read_end;
+    int32_t  score;
+    int32_t  status;          /* the tail's forest status (VGK_OK, VGK_ETOOBIG: walk declined -> soft clip)                           */
+    uint32_t ops_begin, n_ops;    /* in `ops`                                                                                          */
+    uint32_t first_offset;    /* where on the first op's node (on that strand) the alignment starts                                   */
+    uint32_t n_trees;         /* trees the tail was aligned to                                                                        */
+} vgk_tail_alignment;
+int      vgk_tail_stage_aligned(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score,
+                                vgk_tail_alignment* tails, size_t tails_cap, vgk_op* ops, size_t ops_cap, size_t written[2], uint64_t stats[4]);
 double   vgk_tail_stage_last_ms(vgk_ctx* ctx, int which);             /* 0 tails derived, 1 forest, 2 windows packed, 3 kernels + totals */
 
 /* ---- X-drop with dozeu's band (src/dozeu_interface.cpp:226, :261-283; src/xdrop_aligner.cpp:95-109) ------------------------------

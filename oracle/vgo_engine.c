@@ -513,4 +513,9 @@ int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_proble
     (void)ctx; (void)index; (void)ops_per_problem; (void)ext_total; (void)ext_cap; (void)read_score; (void)stats;
     return VGK_EUNSUPPORTED;                                             /* the oracle keeps nothing between calls: tests use the host-side stage */
 }
+int vgk_tail_stage_aligned(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score,
+                           vgk_tail_alignment* tails, size_t tails_cap, vgk_op* ops, size_t ops_cap, size_t written[2], uint64_t stats[4]) {
+    (void)ctx; (void)index; (void)ops_per_problem; (void)ext_total; (void)ext_cap; (void)read_score; (void)tails; (void)tails_cap; (void)ops; (void)ops_cap; (void)written; (void)stats;
+    return VGK_EUNSUPPORTED;                                             /* as vgk_tail_stage: the tests assemble the stage from the oracle's entry points */
+}
 double vgk_tail_stage_last_ms(vgk_ctx* ctx, int which) { (void)ctx; (void)which; return 0.0; }

@@ -46,6 +46,23 @@ def run_stage(lib, n, seed, graph_bp, inserted):
     # ... and with everything behind the extension on the device (vgk_tail_stage)
     d = pipeline.align_stage_device(eng, eng.haplo_index(wl.nodes, wl.threads), wl.gs)
     assert (d["ext_total"] == c["ext_total"]).all() and (d["read_score"] == c["read_score"]).all() and d["stats"] == c["stats"]
+    # ... and the tails' alignments chosen on the device (vgk_tail_stage_aligned) = the best tree's alignment of the ORACLE's pipeline
+    e = pipeline.align_stage_device(eng, eng.haplo_index(wl.nodes, wl.threads), wl.gs, aligned=True)
+    assert (e["ext_total"] == c["ext_total"]).all() and (e["read_score"] == c["read_score"]).all() and e["stats"] == c["stats"]
+    want = pipeline.winning_alignments(b)
+    tails, tops = e["tails"], e["tail_ops"]
+    assert len(tails) == len(want)
+    for i, wrow in enumerate(want):
+        tl = tails[i]
+        ops = tops[tl["ops_begin"]:tl["ops_begin"] + tl["n_ops"]]
+        got = (int(tl["ext"]), int(tl["left"]), int(tl["read_begin"]), int(tl["read_end"]), int(tl["score"]), int(tl["first_offset"]),
+               [(int(x["node"]), int(x["op"]), int(x["len"])) for x in ops])
+        assert got == wrow, (i, got, wrow)
+    # the ops of a tail spell a walk of the graph that the tail's bases fit: the aligned read bases add up to at most the tail
+    for tl in tails:
+        ops = tops[tl["ops_begin"]:tl["ops_begin"] + tl["n_ops"]]
+        used = int(ops["len"][ops["op"] != capi.OP_D].sum()) if len(ops) else 0
+        assert used <= tl["read_end"] - tl["read_begin"]
     return wl, a
 
 
@@ -76,3 +93,25 @@ def test_device_tail_stage_needs_the_sets_of_an_extension_call(emu_lib):
     et, rs, stats = eng.tail_stage(idx, wl.gs.n, int(res["n_ext"].sum()))
     assert stats[0] == 0 and (et == ext["score"][:len(et)]).all()        # every cluster resolved: no tails, totals = the extensions' scores
     assert (rs == np.maximum.reduceat(et, res["ext_begin"][res["n_ext"] > 0])).all() if (res["n_ext"] > 0).all() else True
+    et2, rs2, tails, ops, stats2 = eng.tail_stage_aligned(idx, wl.gs.n, int(res["n_ext"].sum()))
+    assert len(tails) == 0 and len(ops) == 0 and (et2 == et).all()
+
+
+def test_aligned_tail_stage_reports_the_sizes_it_needs(emu_lib):
+    import ctypes
+    wl = workloads.GaplessWorkload(300, seed=4, graph_bp=30000, inserted_reads=0.5)
+    eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=emu_lib)
+    idx = eng.haplo_index(wl.nodes, wl.threads)
+    res, ext, _, _ = eng.gapless_extend(idx, wl.gs)
+    n_ext = int(res["n_ext"].sum())
+    et, rs, tails, ops, stats = eng.tail_stage_aligned(idx, wl.gs.n, n_ext)
+    assert len(tails) > 50 and len(ops) > len(tails)
+    ext_total = np.zeros(n_ext, dtype=np.int32); read_score = np.zeros(wl.gs.n, dtype=np.int32)
+    small_t = np.zeros(10, dtype=capi.TAIL_ALIGNMENT_DT); small_o = np.zeros(10, dtype=capi.OP_DT); big_t = np.zeros(len(tails), dtype=capi.TAIL_ALIGNMENT_DT)
+    written = (ctypes.c_size_t * 2)()
+    call = lambda t, o: eng.lib.vgk_tail_stage_aligned(eng.h, idx.h, 32, ext_total.ctypes.data, n_ext, read_score.ctypes.data, t.ctypes.data, len(t),
+                                                       o.ctypes.data, len(o), ctypes.byref(written), None)
+    assert call(small_t, small_o) == -6 and written[0] == len(tails)                 # VGK_EOPS: the tails do not fit
+    assert call(big_t, small_o) == -6 and (written[0], written[1]) == (len(tails), len(ops))     # ... the ops do not fit
+    big_o = np.zeros(len(ops), dtype=capi.OP_DT)
+    assert call(big_t, big_o) == 0 and (big_t == tails).all() and (big_o == ops).all()

@@ -38,6 +38,8 @@ BANDED_DT = np.dtype([("read", "<u8"), ("qual", "<u8"), ("read_len", "<u4"), ("f
 VGK_BANDED_PERMISSIVE = 1
 SEED_DT = np.dtype([("node", "<u4"), ("diff", "<i4")])
 MINIMIZER_HIT_DT = np.dtype([("key", "<u8"), ("node", "<u4"), ("offset", "<u4")])
+TAIL_ALIGNMENT_DT = np.dtype([("ext", "<u4"), ("left", "<u4"), ("read_begin", "<u4"), ("read_end", "<u4"), ("score", "<i4"), ("status", "<i4"),
+                              ("ops_begin", "<u4"), ("n_ops", "<u4"), ("first_offset", "<u4"), ("n_trees", "<u4")])
 GAPLESS_DT = np.dtype([("read", "<u8"), ("read_len", "<u4"), ("n_seeds", "<u4"), ("seeds", "<u8"), ("max_mismatches", "<u4"),
                        ("flags", "<u4"), ("overlap_threshold", "<f8")])
 EXT_DT = np.dtype([("path_begin", "<u4"), ("path_len", "<u4"), ("offset", "<u4"), ("read_begin", "<u4"), ("read_end", "<u4"),
@@ -412,6 +414,18 @@ class Engine:
         self.lib.vgk_tail_stage.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
         self._check(self.lib.vgk_tail_stage(self.h, index.h, ops_per_problem, ext_total.ctypes.data, len(ext_total), read_score.ctypes.data, stats.ctypes.data), "vgk_tail_stage")
         return ext_total[:n_ext], read_score[:n_reads], tuple(int(x) for x in stats)
+
+    def tail_stage_aligned(self, index, n_reads, n_ext, ops_per_problem=32):
+        """vgk_tail_stage_aligned -> (ext_total, read_score, tails as TAIL_ALIGNMENT_DT, ops as OP_DT, stats)"""
+        ext_total = np.zeros(max(n_ext, 1), dtype=np.int32); read_score = np.zeros(max(n_reads, 1), dtype=np.int32); stats = np.zeros(4, dtype=np.uint64)
+        tails_cap = 2 * max(n_ext, 1)
+        tails = np.zeros(tails_cap, dtype=TAIL_ALIGNMENT_DT); ops = np.zeros(tails_cap * ops_per_problem + 1, dtype=OP_DT)
+        written = (ctypes.c_size_t * 2)()
+        self.lib.vgk_tail_stage_aligned.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        self._check(self.lib.vgk_tail_stage_aligned(self.h, index.h, ops_per_problem, ext_total.ctypes.data, len(ext_total), read_score.ctypes.data,
+                                                    tails.ctypes.data, tails_cap, ops.ctypes.data, len(ops), ctypes.byref(written), stats.ctypes.data), "vgk_tail_stage_aligned")
+        return ext_total[:n_ext], read_score[:n_reads], tails[:written[0]], ops[:written[1]], tuple(int(x) for x in stats)
 
     def tail_stage_last_ms(self):
         self.lib.vgk_tail_stage_last_ms.restype = ctypes.c_double; self.lib.vgk_tail_stage_last_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]

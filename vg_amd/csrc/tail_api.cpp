@@ -148,8 +148,12 @@ void vgk_forest_destroy(vgk_forest* f) {
 // the end, one int per extension and one per read.
 int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
                           const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out, bool on_device);
-int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score, uint64_t stats[4]) {
+}  // extern "C"
+// aligned / tails_cap / ops / ops_cap / written: vgk_tail_stage_aligned's outputs (all null / 0 for vgk_tail_stage)
+static int tail_stage_impl(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score, uint64_t stats[4],
+                           const bool want_aligned, vgk_tail_alignment* aligned, size_t tails_cap, vgk_op* ops, size_t ops_cap, size_t* written) {
     if (!ctx || !index || index->ctx != ctx) return VGK_EINVAL;
+    if (written) written[0] = written[1] = 0;
     if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
     Backend* be = ctx->be.get();
     std::unique_lock<std::mutex> lk(ctx->mu);
@@ -198,6 +202,18 @@ int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_proble
         if (!d_probs || !d_tres || !d_meta || !d_len || !d_tscore) return done(VGK_ENOMEM);
         S.problems = d_probs; S.meta = d_meta; S.tail_len = d_len; S.seq_off = d_len + t1; S.tail_score = d_tscore; S.tres = d_tres;
         rc = be->zero(d_len, sizeof(uint32_t) * 2 * t1);
+        uint32_t* d_ops_tab = nullptr;
+        if (want_aligned) {
+            if (written) written[0] = nt;
+            if (nt > tails_cap || !aligned) return done(VGK_EOPS);
+            S.tail_best = (unsigned long long*)take(sizeof(unsigned long long) * t1);
+            d_ops_tab = (uint32_t*)take(sizeof(uint32_t) * 2 * t1);
+            S.aligned = (vgk_tail_alignment*)take(sizeof(vgk_tail_alignment) * t1);
+            if (!S.tail_best || !d_ops_tab || !S.aligned) return done(VGK_ENOMEM);
+            S.ops_cnt = d_ops_tab; S.ops_off = d_ops_tab + t1;
+            if (!rc) rc = be->zero(S.tail_best, sizeof(unsigned long long) * t1);
+            if (!rc) rc = be->zero(d_ops_tab, sizeof(uint32_t) * 2 * t1);
+        }
         if (!rc) rc = be->run_tail_stage(S, TS_TAILS);
         if (!rc) rc = be->scan_u32(d_len, d_len + t1, (uint32_t)t1);
         uint32_t seq_bytes = 0;
@@ -215,7 +231,7 @@ int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_proble
         wall("forest");
         auto drop_forest = [&]() { vgk_dgraph* g = forest->graph; be->sync(); for (size_t k = 0; k < g->dev.size(); ++k) ctx->dev_give(g->dev[k], g->dev_size[k]); delete g; delete forest; };
         tree_nodes = forest->n_nodes;
-        S.parent = forest->parent; S.owner = forest->owner; S.n_nodes = (uint32_t)forest->n_nodes;
+        S.parent = forest->parent; S.owner = forest->owner; S.n_nodes = (uint32_t)forest->n_nodes; S.forest_node = forest->node;
         const size_t v1 = (size_t)forest->n_nodes + 1;
         uint32_t* d_root = (uint32_t*)take(sizeof(uint32_t) * 3 * v1);
         if (!d_root) { drop_forest(); return done(VGK_ENOMEM); }
@@ -228,6 +244,23 @@ int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_proble
         be->watch(1); if (!rc) rc = be->sync(); ctx->tail_stage_ms[1] = be->watch_ms(); be->watch(0);
         if (rc) { drop_forest(); return done(rc); }
         n_trees = nw; S.n_trees = nw;
+        // vgk_tail_stage_aligned: per tail the winning tree's ops, packed behind each other, nodes translated; then down
+        auto winners_down = [&](const vgk_op* window_ops) -> int {
+            S.wops = window_ops;
+            int r2 = be->run_tail_stage(S, TS_OPS_COUNT);
+            if (!r2) r2 = be->scan_u32(S.ops_cnt, d_ops_tab + t1, (uint32_t)t1);
+            uint32_t n_ops = 0;
+            if (!r2) r2 = be->download(&n_ops, S.ops_off + nt, sizeof(uint32_t));
+            if (r2) return r2;
+            if (written) written[1] = n_ops;
+            if (n_ops > ops_cap || (n_ops && !ops)) return VGK_EOPS;
+            S.out_ops = (vgk_op*)take(sizeof(vgk_op) * ((size_t)n_ops + 1));
+            if (!S.out_ops) return VGK_ENOMEM;
+            r2 = be->run_tail_stage(S, TS_OPS_COPY);
+            if (!r2) r2 = be->download(aligned, S.aligned, sizeof(vgk_tail_alignment) * nt);
+            if (!r2 && n_ops) r2 = be->download(ops, S.out_ops, sizeof(vgk_op) * n_ops);
+            return r2;
+        };
         if (nw) {
             vgk_window_problem* d_win = (vgk_window_problem*)take(sizeof(vgk_window_problem) * (size_t)nw);
             uint32_t* d_wown = (uint32_t*)take(sizeof(uint32_t) * (size_t)nw);
@@ -244,8 +277,12 @@ int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_proble
             wall("fill + traceback");
             be->watch(0);
             if (!rc) { S.wres = b->P.results; rc = be->run_tail_stage(S, TS_BEST); }
+            if (!rc && want_aligned) rc = winners_down(b->P.ops);
             if (!rc) rc = be->sync();
             if (b) { lk.unlock(); vgk_batch_free(b); lk.lock(); }
+            if (rc) { drop_forest(); return done(rc); }
+        } else if (want_aligned) {
+            rc = winners_down(nullptr);
             if (rc) { drop_forest(); return done(rc); }
         }
         rc = be->run_tail_stage(S, TS_TOTAL);
@@ -263,6 +300,14 @@ int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_proble
     rc = done(rc);
     wall("blocks back to the pool");
     return rc;
+}
+extern "C" {
+int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score, uint64_t stats[4]) {
+    return tail_stage_impl(ctx, index, ops_per_problem, ext_total, ext_cap, read_score, stats, false, nullptr, 0, nullptr, 0, nullptr);
+}
+int vgk_tail_stage_aligned(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score,
+                           vgk_tail_alignment* tails, size_t tails_cap, vgk_op* ops, size_t ops_cap, size_t written[2], uint64_t stats[4]) {
+    return tail_stage_impl(ctx, index, ops_per_problem, ext_total, ext_cap, read_score, stats, true, tails, tails_cap, ops, ops_cap, written);
 }
 double vgk_tail_stage_last_ms(vgk_ctx* ctx, int which) { return ctx && which >= 0 && which < 4 ? ctx->tail_stage_ms[which] : 0.0; }
 

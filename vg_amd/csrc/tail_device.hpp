@@ -172,6 +172,12 @@ struct TStageParams {
     vgk_window_problem* windows; uint32_t* win_owner;
     // scores
     const vgk_result* wres; int32_t* tail_score; int32_t* ext_total; int32_t* read_score; unsigned long long* failed;
+    // the winning tree's alignment per tail (vgk_tail_stage_aligned)
+    unsigned long long* tail_best;                                 // [n_tails]: (score << 32) | (0xffffffff - window): the best tree, the first among equals; 0 = the soft clip
+    const uint32_t* forest_node;                                   // [n_nodes]: oriented graph node of every tree node (TreeSubgraph::translate_down)
+    const vgk_op* wops;                                            // the window batch's op slots (vgk_result::ops_begin indexes it)
+    uint32_t* ops_cnt; const uint32_t* ops_off;                    // [n_tails + 1]
+    vgk_tail_alignment* aligned; vgk_op* out_ops;
 };
 VGK_HD int64_t t_longest_gap(const TStageParams& P, int64_t read_length, int64_t read_pos) {     // EditAlignmentScorer::longest_detectable_gap (src/alignment_scorer.cpp:264-271)
     const int64_t overhang = read_pos < read_length - read_pos ? read_pos : read_length - read_pos;
@@ -246,15 +252,53 @@ VGK_HD void tstage_window_one(const TStageParams& P, uint32_t w) {
 // total; stage 9, per read: the best total
 #if defined(__HIP_DEVICE_COMPILE__)
 VGK_HD void t_atomic_max(int32_t* p, int32_t v) { atomicMax(p, v); }
+VGK_HD void t_atomic_max(unsigned long long* p, unsigned long long v) { atomicMax(p, v); }
 VGK_HD void t_atomic_add(int32_t* p, int32_t v) { atomicAdd(p, v); }
 #else
 VGK_HD void t_atomic_max(int32_t* p, int32_t v) { if (v > *p) *p = v; }
+VGK_HD void t_atomic_max(unsigned long long* p, unsigned long long v) { if (v > *p) *p = v; }
 VGK_HD void t_atomic_add(int32_t* p, int32_t v) { *p += v; }
 #endif
 VGK_HD void tstage_best_one(const TStageParams& P, uint32_t w) {
     const vgk_result r = P.wres[w];
     if (r.status != VGK_OK) { g_bump(P.failed, 1); return; }
     t_atomic_max(P.tail_score + P.win_owner[w], r.score);
+    // which tree it was: a later tree replaces the best so far only with a strictly better score (equal scores: the reference asks
+    // deterministic_beats, :5715 — a hash of the alignments; here the first tree), and the soft clip is kept unless a tree scores > 0
+    if (P.tail_best && r.score > 0) t_atomic_max(P.tail_best + P.win_owner[w], ((unsigned long long)(uint32_t)r.score << 32) | (0xffffffffu - w));
+}
+// stages 10, 11 (vgk_tail_stage_aligned), per tail: the size of the winning alignment, then the alignment itself with its nodes
+// translated from tree nodes to the graph's oriented nodes
+VGK_HD bool tstage_winner(const TStageParams& P, uint32_t t, uint32_t& w) {
+    const unsigned long long b = P.tail_best[t];
+    if (!b) return false;
+    w = 0xffffffffu - (uint32_t)(b & 0xffffffffull);
+    return true;
+}
+VGK_HD void tstage_ops_count_one(const TStageParams& P, uint32_t t) {
+    uint32_t w;
+    P.ops_cnt[t] = tstage_winner(P, t, w) ? P.wres[w].n_ops : 0u;
+}
+VGK_HD void tstage_ops_copy_one(const TStageParams& P, uint32_t t) {
+    const TMeta m = P.meta[t];
+    vgk_tail_alignment a;
+    a.ext = m.ext; a.left = m.left; a.read_begin = m.begin; a.read_end = m.end;
+    a.score = 0; a.status = P.tres[t].status; a.ops_begin = P.ops_off[t]; a.n_ops = 0; a.first_offset = 0; a.n_trees = P.tres[t].n_trees;
+    uint32_t w;
+    if (tstage_winner(P, t, w)) {
+        const vgk_result r = P.wres[w];
+        const vgk_window_problem q = P.windows[w];
+        a.score = r.score; a.n_ops = r.n_ops;
+        vgk_op* dst = P.out_ops + P.ops_off[t];
+        for (uint32_t k = 0; k < r.n_ops; ++k) {
+            vgk_op o = P.wops[r.ops_begin + k];
+            const uint32_t v = q.first_node + o.node;
+            if (k == 0) a.first_offset = (uint32_t)r.first_offset + (P.parent[v] < 0 ? P.tres[t].root_trim : 0u);
+            o.node = P.forest_node[v];
+            dst[k] = o;
+        }
+    }
+    P.aligned[t] = a;
 }
 VGK_HD void tstage_total_one(const TStageParams& P, uint32_t t) {
     if (P.tres[t].status != VGK_OK) g_bump(P.failed, 1);
@@ -266,9 +310,9 @@ VGK_HD void tstage_read_one(const TStageParams& P, uint32_t i) {
     for (uint32_t k = 0; k < r.n_ext; ++k) { const int32_t v = P.ext_total[r.ext_begin + k]; best = v > best ? v : best; }
     P.read_score[i] = best;
 }
-enum { TS_READS = 0, TS_COUNT, TS_TAILS, TS_BASES, TS_ROOT_FLAG, TS_ROOT_POS, TS_WINDOW, TS_BEST, TS_TOTAL, TS_READ };
+enum { TS_READS = 0, TS_COUNT, TS_TAILS, TS_BASES, TS_ROOT_FLAG, TS_ROOT_POS, TS_WINDOW, TS_BEST, TS_TOTAL, TS_READ, TS_OPS_COUNT, TS_OPS_COPY };
 VGK_HD uint32_t tstage_items(const TStageParams& P, int what) {
-    switch (what) { case TS_READS: case TS_READ: return P.n_reads; case TS_COUNT: case TS_TAILS: return P.n_ext; case TS_BASES: case TS_TOTAL: return P.n_tails;
+    switch (what) { case TS_READS: case TS_READ: return P.n_reads; case TS_COUNT: case TS_TAILS: return P.n_ext; case TS_BASES: case TS_TOTAL: case TS_OPS_COUNT: case TS_OPS_COPY: return P.n_tails;
                     case TS_ROOT_FLAG: case TS_ROOT_POS: return P.n_nodes; default: return P.n_trees; }
 }
 VGK_HD void tstage_one(const TStageParams& P, int what, uint32_t i) {
@@ -276,6 +320,7 @@ VGK_HD void tstage_one(const TStageParams& P, int what, uint32_t i) {
         case TS_READS: tstage_reads_one(P, i); break; case TS_COUNT: tstage_count_one(P, i); break; case TS_TAILS: tstage_tails_one(P, i); break;
         case TS_BASES: tstage_bases_one(P, i); break; case TS_ROOT_FLAG: tstage_root_flag_one(P, i); break; case TS_ROOT_POS: tstage_root_pos_one(P, i); break;
         case TS_WINDOW: tstage_window_one(P, i); break; case TS_BEST: tstage_best_one(P, i); break; case TS_TOTAL: tstage_total_one(P, i); break;
+        case TS_OPS_COUNT: tstage_ops_count_one(P, i); break; case TS_OPS_COPY: tstage_ops_copy_one(P, i); break;
         default: tstage_read_one(P, i); break;
     }
 }

@@ -211,9 +211,10 @@ def chain_stage(eng, index, wl, match=1, timing=None):
     return out
 
 
-def align_stage_device(eng, index, gs, ops_per_problem=32, timing=None, seeded=None):
+def align_stage_device(eng, index, gs, ops_per_problem=32, timing=None, seeded=None, aligned=False):
     """The stage with everything behind the extension on the device too (vgk_tail_stage): the extension sets come back for the caller, the
-    tails are derived, walked, packed and aligned from what the extension call left in HBM.  -> dict(res, ext, nodes, ext_total, read_score, stats)"""
+    tails are derived, walked, packed and aligned from what the extension call left in HBM.  -> dict(res, ext, nodes, ext_total, read_score, stats); aligned:
+    also the tails' winning alignments (vgk_tail_stage_aligned: `tails`, `tail_ops`)"""
     import time
     t0 = time.perf_counter()
     if seeded is not None:
@@ -221,11 +222,46 @@ def align_stage_device(eng, index, gs, ops_per_problem=32, timing=None, seeded=N
     else:
         res, ext, nodes, mism = eng.gapless_extend(index, gs)
     t1 = time.perf_counter()
-    ext_total, read_score, stats = eng.tail_stage(index, gs.n, int(res["n_ext"].sum()), ops_per_problem)
+    tails = tail_ops = None
+    if aligned:
+        ext_total, read_score, tails, tail_ops, stats = eng.tail_stage_aligned(index, gs.n, int(res["n_ext"].sum()), ops_per_problem)
+    else:
+        ext_total, read_score, stats = eng.tail_stage(index, gs.n, int(res["n_ext"].sum()), ops_per_problem)
     t2 = time.perf_counter()
     if timing is not None:
         for k, v in (("gapless_extend", t1 - t0), ("tail stage (device, total)", t2 - t1)):
             timing[k] = timing.get(k, 0.0) + v
         for k, v in zip(("tails derived (device)", "tail forest (device)", "windows packed (device)", "fill + traceback + totals"), eng.tail_stage_last_ms()):
             timing[k] = timing.get(k, 0.0) + v * 1e-3
-    return dict(res=res, ext=ext, nodes=nodes, ext_total=ext_total, read_score=read_score, stats=stats)
+    return dict(res=res, ext=ext, nodes=nodes, ext_total=ext_total, read_score=read_score, stats=stats, tails=tails, tail_ops=tail_ops)
+
+
+def winning_alignments(out):
+    """From align_stage's output (every tree's alignment): per tail what vgk_tail_stage_aligned reports — the best tree's alignment, the
+    first among equals, nothing for a soft clip; nodes translated to oriented nodes of the index.  -> list of (ext, left, read_begin,
+    read_end, score, first_offset, [(node, op, len)])"""
+    t = out["tails"]
+    nt = len(t["problems"])
+    rows = [None] * nt
+    if "tail_alignments" not in out:
+        return [(int(t["ext"][i]), int(t["left"][i]), int(t["begin"][i]), int(t["end"][i]), 0, 0, []) for i in range(nt)]
+    r, ops, owner, tres = out["tail_alignments"], out["tail_ops"], out["owner"], out["tail_results"]
+    parent, fnode, _ = out["forest"].fetch()
+    first_node = out["windows"].array["first_node"]
+    best = {}
+    for w in range(len(owner)):
+        if r["status"][w] == 0 and r["score"][w] > 0 and (owner[w] not in best or r["score"][w] > r["score"][best[owner[w]]]):
+            best[int(owner[w])] = w
+    for i in range(nt):
+        row = [int(t["ext"][i]), int(t["left"][i]), int(t["begin"][i]), int(t["end"][i]), 0, 0, []]
+        if i in best:
+            w = best[i]
+            base = int(first_node[w])
+            o = ops[r["ops_begin"][w]:r["ops_begin"][w] + r["n_ops"][w]]
+            row[4] = int(r["score"][w])
+            if len(o):
+                v0 = base + int(o["node"][0])
+                row[5] = int(r["first_offset"][w]) + (int(tres["root_trim"][i]) if parent[v0] < 0 else 0)
+            row[6] = [(int(fnode[base + int(x["node"])]), int(x["op"]), int(x["len"])) for x in o]
+        rows[i] = tuple(row)
+    return rows
