@@ -32,6 +32,9 @@ struct XlEmu {
     }
     int32_t up(int32_t v) { return exchange(v, 0); }
     int32_t down(int32_t v) { return exchange(v, 1); }
+    int32_t up_sub(int32_t old, int32_t v, int32_t s) { const int32_t o = exchange(v, 0); return lane < 63 ? o - s : old; }
+    int32_t down_sub(int32_t old, int32_t v, int32_t s) { const int32_t o = exchange(v, 1); return lane > 0 ? o - s : old; }
+    int32_t in_lanes(int32_t s) { return s; }
     int32_t scan_excl(int32_t v) { return exchange(v, 2); }
     void fence() { pthread_barrier_wait(&sh->bar); }
     bool any(int32_t flag) { return exchange(flag ? 1 : BNEG, 3) > 0; }
@@ -59,7 +62,11 @@ template <int R, bool QA> static void banded_fill_emu(const BandedParams& P, uin
         for (uint32_t i = 0; i < count; ++i) {
             const BProb pb = P.probs[P.order[begin + i]];
             BSrc src; src.rd = P.reads + pb.read_off; src.q = QA ? P.quals + pb.read_off : nullptr; src.graph = P.graph + pb.graph_off; src.mat = P.mat;
-            banded_fill_lane<R, QA>(P, pb, src, lane, xl); xl.fence();
+            src.rows = reinterpret_cast<const uint64_t*>(P.mat + BMAT_ROWS_AT);
+            constexpr bool FAST = !QA && R <= 4;                            // the kernel's choice for problems staged in LDS; both paths give the same cells
+            if (FAST && (i & 1) == 0) banded_fill_lane<R, QA, FAST>(P, pb, src, lane, xl);
+            else banded_fill_lane<R, QA, false>(P, pb, src, lane, xl);
+            xl.fence();
         }
     });
     for (auto& t : ts) t.join();

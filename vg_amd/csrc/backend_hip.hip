@@ -150,6 +150,17 @@ struct XlDpp {
     static __device__ __forceinline__ int32_t dpp_down(int32_t v) { return __builtin_amdgcn_update_dpp(BNEG, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
     __device__ __forceinline__ int32_t up(int32_t v) const { return dpp_up(v); }
     __device__ __forceinline__ int32_t down(int32_t v) const { return dpp_down(v); }
+    // lane +- 1's value minus s in ONE instruction; the lane without that neighbour has no DPP source, is skipped and keeps `old`
+    // (s_nop: 2 wait states between a VALU write and a DPP read of the same VGPR)
+    __device__ __forceinline__ int32_t up_sub(int32_t old, int32_t v, int32_t s) const {
+        asm volatile("s_nop 1\n\tv_sub_u32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(v), "v"(s));
+        return old;
+    }
+    __device__ __forceinline__ int32_t down_sub(int32_t old, int32_t v, int32_t s) const {
+        asm volatile("s_nop 1\n\tv_sub_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(v), "v"(s));
+        return old;
+    }
+    __device__ __forceinline__ int32_t in_lanes(int32_t s) const { int32_t v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
     // exclusive max-scan over the 64 lanes: row_shr 1/2/4/8 inside each row of 16, then row_bcast:15 and row_bcast:31
     __device__ __forceinline__ int32_t scan_excl(int32_t v) const {
         // v_max_i32_dpp with the destination tied to both sources: a lane whose DPP source does not exist is disabled and
@@ -184,7 +195,16 @@ __global__ void __launch_bounds__(64) banded_fill_kernel(const BandedParams P, c
     extern __shared__ uint8_t smem[];
     const BProb pb = P.probs[P.order[begin + blockIdx.x]];
     BSrc src;
-    if (LDS) {       // stage what every column reads — score table, read, qualities, graph bases — into LDS once
+    constexpr bool FAST = LDS && !QA && R <= 4;
+    if (FAST) {      // the FAST score path (banded_device.hpp): padded copies of the read and graph codes, the table rows in scalar registers
+        uint8_t* srd = smem + 48;                                            // 8 B of padding in front (windows start up to 8 rows early) ...
+        uint8_t* sg = smem + ((48u + pb.L + 16u + 3u) & ~3u);                // ... and behind (a window is three dwords); graph codes dword-aligned
+        for (uint32_t i = threadIdx.x; i < 48; i += 64) smem[i] = i < 40 ? (uint8_t)P.mat[BMAT_ROWS_AT + i] : (uint8_t)0;      // the table rows as 64-bit words, then the padding
+        for (uint32_t i = threadIdx.x; i < pb.L + 16u; i += 64) srd[i] = i < pb.L ? P.reads[pb.read_off + i] : (uint8_t)0;
+        for (uint32_t i = threadIdx.x; i < pb.graph_len + 8u; i += 64) sg[i] = i < pb.graph_len ? P.graph[pb.graph_off + i] : (uint8_t)0;
+        __syncthreads();
+        src.rd = srd; src.q = nullptr; src.graph = sg; src.mat = P.mat; src.rows = reinterpret_cast<const uint64_t*>(smem);
+    } else if (LDS) {       // stage what every column reads — score table, read, qualities, graph bases — into LDS once
         constexpr uint32_t MAT = QA ? 6400u : 32u;
         int8_t* smat = reinterpret_cast<int8_t*>(smem);
         uint8_t* srd = smem + MAT; uint8_t* sq = srd + pb.L; uint8_t* sg = QA ? sq + pb.L : sq;
@@ -197,7 +217,7 @@ __global__ void __launch_bounds__(64) banded_fill_kernel(const BandedParams P, c
         src.rd = P.reads + pb.read_off; src.q = QA ? P.quals + pb.read_off : nullptr; src.graph = P.graph + pb.graph_off; src.mat = P.mat;
     }
     XlDpp xl;
-    banded_fill_lane<R, QA>(P, pb, src, threadIdx.x, xl);
+    banded_fill_lane<R, QA, FAST>(P, pb, src, threadIdx.x, xl);
 }
 
 template <int R>

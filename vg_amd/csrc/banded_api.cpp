@@ -571,19 +571,26 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
                     if (lo == hi) continue;
                     // LDS staging area: score table | read codes | qualities | graph codes of the largest problem of the launch
                     uint64_t lds = 0;
-                    for (uint32_t b = lo; b < hi; ++b) { const BProb& pb = probs[order[b]]; lds = std::max<uint64_t>(lds, (qa ? 6400u : 32u) + (uint64_t)pb.L * (qa ? 2 : 1) + pb.graph_len + 16); }
+                    for (uint32_t b = lo; b < hi; ++b) { const BProb& pb = probs[order[b]]; lds = std::max<uint64_t>(lds, (qa ? 6400u : 32u) + (uint64_t)pb.L * (qa ? 2 : 1) + pb.graph_len + 96); }
                     launches.push_back({1u << r, lo, hi - lo, lds <= 40 * 1024 ? (uint32_t)lds : 0u});
                 }
             }
             lap("sort");
             BandedParams P{};
             int rc;
-            const int8_t* mat = qa ? ctx->qmat.data() : ctx->sc.matrix;
+            // plain contexts: the table, and behind it its rows as 64-bit words for the kernel's byte permute (banded_device.hpp BMAT_ROWS_AT)
+            int8_t* mat_rows = ctx->banded_mat_rows;                            // (lives as long as the asynchronous upload needs it)
+            std::memset(mat_rows, 0, BMAT_BYTES);
+            if (!qa) {
+                std::memcpy(mat_rows, ctx->sc.matrix, 25);
+                for (int g = 0; g < 5; ++g) std::memcpy(mat_rows + BMAT_ROWS_AT + 8 * g, ctx->sc.matrix + 5 * g, 5);
+            }
+            const int8_t* mat = qa ? ctx->qmat.data() : mat_rows;
             if ((rc = stage(ctx, S_PROBS, (const BProb*)probs, m, P.probs)) || (rc = stage(ctx, S_ORDER, (const uint32_t*)order, m, P.order)) ||
                 (rc = stage(ctx, S_NODES, (const BNode*)nodes, n_nodes, P.nodes)) || (rc = stage(ctx, S_SEEDS, (const BSeed*)seeds, n_seeds, P.seeds)) ||
                 (rc = stage(ctx, S_POOL, (const uint32_t*)pool, n_pool, P.pool)) || (rc = stage(ctx, S_STARTS, (const BStart*)starts, n_starts, P.starts)) ||
                 (rc = stage(ctx, S_READS, (const uint8_t*)reads, n_read, P.reads)) || (qa && (rc = stage(ctx, S_QUALS, (const uint8_t*)quals, n_read, P.quals))) ||
-                (rc = stage(ctx, S_GRAPH, (const uint8_t*)graph, n_graph, P.graph)) || (rc = stage(ctx, S_MAT, mat, qa ? 6400 : 25, P.mat))) return rc;
+                (rc = stage(ctx, S_GRAPH, (const uint8_t*)graph, n_graph, P.graph)) || (rc = stage(ctx, S_MAT, mat, qa ? 6400 : BMAT_BYTES, P.mat))) return rc;
             lap("h2d");
             P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend; P.n = m;
             P.tb = (uint8_t*)ensure(ctx, S_TB, std::max<uint64_t>(tb_bytes, 256));

@@ -18,6 +18,7 @@
 // barrier) — test infrastructure only.
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 #include "pk16.hpp"
 #include "../../include/vgk.h"
 
@@ -108,24 +109,77 @@ template <int R> VGK_HD void store_codes(uint8_t* dst, const uint8_t (&codes)[R]
 
 // Where the lane code reads the problem's read codes, qualities, graph codes and score table from: LDS copies made by
 // the kernel's prologue when they fit, the HBM arenas otherwise (and in the CPU emulation).
-struct BSrc { const uint8_t* rd; const uint8_t* q; const uint8_t* graph; const int8_t* mat; };
+struct BSrc { const uint8_t* rd; const uint8_t* q; const uint8_t* graph; const int8_t* mat; const uint64_t* rows; };      // rows: FAST only
+constexpr uint32_t BMAT_ROWS_AT = 32, BMAT_BYTES = 72;    // plain contexts: the 25 table bytes, then at byte 32 row g as one 64-bit word (byte c = score of read code c)
 template <bool QA> VGK_HD int32_t bsub(const BSrc& s, uint32_t g, int32_t r) {
     const uint32_t rd = s.rd[r];
     return QA ? s.mat[25u * s.q[r] + 5u * g + rd] : s.mat[5u * g + rd];
+}
+// ---- the FAST score path (plain 5 x 5 table, <= 4 rows per lane): no table or read lookups per cell.  Every four columns a lane
+// fetches the eight read codes from its first row on (a column later the lane's rows lie one base further) and the wave the four graph
+// bases; per column ONE byte permute turns the lane's four read codes into their four scores against the column's base — the table
+// row of that base is one 64-bit word fetched with a wave-uniform address (BMAT_ROWS_AT).  On the device the codes come out of padded LDS copies (kernel prologue) by
+// aligned dword reads and a byte funnel; the CPU emulation reads the arenas byte by byte.  Rows outside the read get arbitrary
+// scores: the lane code masks them.
+VGK_HD uint32_t b_perm(uint32_t hi, uint32_t lo, uint32_t sel) {        // byte i of the result = byte sel.byte[i] of {hi, lo} (selectors 0..7)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const uint64_t t = ((uint64_t)hi << 32) | lo; uint32_t out = 0;
+    for (int i = 0; i < 4; ++i) { const uint32_t b = (sel >> (8 * i)) & 0xffu; out |= (b < 8 ? (uint32_t)((t >> (8 * b)) & 0xffu) : 0u) << (8 * i); }
+    return out;
+#endif
+}
+VGK_HD uint32_t b_bytes_from(uint64_t win, uint32_t c) {                  // bytes c .. c + 3 of the window, c < 4
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte((uint32_t)(win >> 32), (uint32_t)win, c);
+#else
+    return (uint32_t)(win >> (8 * c));
+#endif
+}
+VGK_HD uint64_t b_read_window(const BSrc& s, int32_t r0, int32_t L) {    // read codes of rows r0 .. r0 + 7
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int32_t rc = r0 < -8 ? -8 : r0 > L - 1 ? L - 1 : r0;           // (all of the lane's rows outside the read: any window will do)
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(s.rd + (rc & ~3));
+    const uint32_t a = w[0], b = w[1], c = w[2], sh = (uint32_t)rc & 3u;
+    return ((uint64_t)__builtin_amdgcn_alignbyte(c, b, sh) << 32) | __builtin_amdgcn_alignbyte(b, a, sh);
+#else
+    uint64_t v = 0;
+    for (int b = 0; b < 8; ++b) { const int32_t r = r0 + b; if (r >= 0 && r < L) v |= (uint64_t)s.rd[r] << (8 * b); }
+    return v;
+#endif
+}
+VGK_HD uint32_t b_graph_word(const BSrc& s, uint32_t at, uint32_t graph_len) {      // graph codes at .. at + 3 (wave-uniform)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(s.graph + (at & ~3u));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_alignbyte(w[1], w[0], at & 3u));
+#else
+    uint32_t v = 0;
+    for (uint32_t b = 0; b < 4; ++b) if (at + b < graph_len) v |= (uint32_t)s.graph[at + b] << (8 * b);
+    return v;
+#endif
 }
 
 // ---- fill: lane code.  XL supplies the cross-lane primitives:
 //   int32 up(int32 v)        value of lane+1 (BNEG for the last lane)
 //   int32 down(int32 v)      value of lane-1 (BNEG for lane 0)
+//   int32 up_sub(int32 old, int32 v, int32 s)     value of lane+1 minus s; the last lane returns `old`
+//   int32 down_sub(int32 old, int32 v, int32 s)   value of lane-1 minus s; lane 0 returns `old`
+//   int32 in_lanes(int32 s)  s, as a per-lane value (the DPP instructions take no scalar operand)
 //   int32 scan_excl(int32 v) max over lanes < this one (BNEG for lane 0)
-template <int R, bool QA, class XL>
+template <int R, bool QA, bool FAST, class XL>
 VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc& src, uint32_t lane, XL& xl) {
+    static_assert(!FAST || (!QA && R <= 4), "the FAST score path: plain table, at most four rows per lane");
     const int32_t go = P.go, ge = P.ge, L = (int32_t)pb.L;
     const BNode* nodes = P.nodes + pb.node_base;
     int32_t* last = P.last + pb.last_base;
     uint8_t* tb = P.tb + pb.tb_base;
     int32_t M[R], Ic[R], Ir[R];
     for (int i = 0; i < R; ++i) { M[i] = BNEG; Ic[i] = BNEG; Ir[i] = BNEG; }
+    // what the lanes without a neighbour (the last one looking at lane + 1, the first one looking at lane - 1) see: -inf, kept in the
+    // destination registers of the cross-lane subtractions from column to column (XL::up_sub / down_sub leave those lanes alone)
+    int32_t keep_nxM = BNEG, keep_nxIc = BNEG, keep_nxIr = BNEG, keep_upM = BNEG, keep_upIc = BNEG;
+    const int32_t vgo = xl.in_lanes(go), vge = xl.in_lanes(ge);
     for (uint32_t v = 0; v < pb.n_nodes; ++v) {
         const BNode nd = nodes[v];
         if (nd.masked || nd.len == 0) continue;
@@ -136,23 +190,29 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
 
         // the row gaps of a column and its traceback bytes, given the column's M / Ic and the lead-gap seeds ir0 of Ir:
         //   Ir(r) = max(ir0(r), max_{r'<r} Y(r') - (r-1)*ge),  Y(r') = max(max(M,Ic)(r') - go, ir0(r') - ge) + r'*ge
-        auto finish_column = [&](int32_t j, const int32_t (&nM)[R], const int32_t (&nIc)[R], const int32_t (&ir0)[R], const uint32_t (&code_mc)[R]) {
+        // EDGE = false: a column all of whose band rows lie strictly inside the read (0 < r < L): no lead gaps (ir0 = -inf everywhere),
+        // no row tests — the node decides that once for all its columns.
+        auto finish_column = [&](auto edge, int32_t j, const int32_t (&nM)[R], const int32_t (&nIc)[R], const int32_t (&ir0)[R], const uint32_t (&code_mc)[R]) {
+            constexpr bool EDGE = decltype(edge)::value;
             int32_t run = BNEG, pre[R];
             for (int i = 0; i < R; ++i) {
                 const int32_t r = k0 + i + nd.top + j;
                 pre[i] = run;
-                run = bmax(run, bmax(bmax(nM[i], nIc[i]) - go, ir0[i] - ge) + r * ge);
+                const int32_t open = bmax(nM[i], nIc[i]) - go;
+                run = bmax(run, (EDGE ? bmax(open, ir0[i] - ge) : open) + r * ge);
             }
             const int32_t excl = xl.scan_excl(run);
-            int32_t upM = xl.down(nM[R - 1]), upIc = xl.down(nIc[R - 1]);
+            // the cells above, a gap opening away: the previous lane's last row, then the lane's own rows
+            int32_t upM = keep_upM = xl.down_sub(keep_upM, nM[R - 1], vgo), upIc = keep_upIc = xl.down_sub(keep_upIc, nIc[R - 1], vgo);
             uint8_t codes[R];
             for (int i = 0; i < R; ++i) {
                 const int32_t k = k0 + i, r = k + nd.top + j;
-                const bool valid = k < H && r >= 0 && r < L;
-                int32_t ir = bmax(ir0[i], bmax(excl, pre[i]) - (r - 1) * ge);
-                const uint32_t cr = ir == upM - go ? BM : ir == upIc - go ? BIC : BIR;
+                const bool valid = EDGE ? (k < H && r >= 0 && r < L) : k < H;
+                const int32_t from_above = bmax(excl, pre[i]) - (r - 1) * ge;
+                int32_t ir = EDGE ? bmax(ir0[i], from_above) : from_above;
+                const uint32_t cr = ir == upM ? BM : ir == upIc ? BIC : BIR;
                 if (!valid) ir = BNEG;
-                upM = nM[i]; upIc = nIc[i];
+                if (i + 1 < R) { upM = nM[i] - go; upIc = nIc[i] - go; }
                 M[i] = nM[i]; Ic[i] = nIc[i]; Ir[i] = ir;
                 codes[i] = (uint8_t)(code_mc[i] | (cr << 2));
             }
@@ -164,35 +224,65 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
         };
         // a column whose left neighbours are the registers: columns 1.. of a node (:492-590), and column 0 of a node whose
         // only predecessor is the node this wave has just finished, with the band carried straight over (BNode::chain)
-        auto column = [&](int32_t j) {
-            const uint32_t g = seq[j];
-            const int32_t nxM = xl.up(M[0]), nxIc = xl.up(Ic[0]), nxIr = xl.up(Ir[0]);      // row k+1 of the previous column
+        auto column = [&](auto edge, int32_t j, const int32_t (&msv)[R]) {  // msv: the rows' substitution scores against the column's base
+            constexpr bool EDGE = decltype(edge)::value;
+            // row k+1 of the previous column, a gap opening / extension away (the next lane's first row; the lane's own rows below)
+            const int32_t nxM = keep_nxM = xl.up_sub(keep_nxM, M[0], vgo), nxIc = keep_nxIc = xl.up_sub(keep_nxIc, Ic[0], vge), nxIr = keep_nxIr = xl.up_sub(keep_nxIr, Ir[0], vgo);
             int32_t nM[R], nIc[R], ir0[R];
             uint32_t code_mc[R];
             const int32_t lead_m = -go - (nd.cum + j - 1) * ge;                              // implied lead gap along the top edge (:507-526, :352-366)
             const int32_t lead_ir = nd.top + j < 0 ? -2 * go - (nd.cum + j) * ge : BNEG;
             for (int i = 0; i < R; ++i) {
                 const int32_t k = k0 + i, r = k + nd.top + j;
-                const bool valid = k < H && r >= 0 && r < L;
-                const int32_t bM = i + 1 < R ? M[i + 1 < R ? i + 1 : 0] : nxM, bIc = i + 1 < R ? Ic[i + 1 < R ? i + 1 : 0] : nxIc,
-                              bIr = i + 1 < R ? Ir[i + 1 < R ? i + 1 : 0] : nxIr;
-                // branch-free: out-of-matrix rows read a clamped read base and are overwritten with -inf below
-                const int32_t rc = r < 0 ? 0 : r >= L ? L - 1 : r;
-                const int32_t ms = bsub<QA>(src, g, rc);
+                const bool valid = EDGE ? (k < H && r >= 0 && r < L) : k < H;
+                const int32_t oM = i + 1 < R ? M[i + 1 < R ? i + 1 : 0] - go : nxM, oIc = i + 1 < R ? Ic[i + 1 < R ? i + 1 : 0] - ge : nxIc,
+                              oIr = i + 1 < R ? Ir[i + 1 < R ? i + 1 : 0] - go : nxIr;
+                const int32_t ms = msv[i];
                 const int32_t b3 = bmax(bmax(M[i], Ic[i]), Ir[i]);
                 const uint32_t cm = b3 == M[i] ? BM : b3 == Ic[i] ? BIC : BIR;
-                const int32_t icv = bmax(bmax(bM - go, bIr - go), bIc - ge);
-                const uint32_t cc = icv == bM - go ? BM : icv == bIc - ge ? BIC : BIR;
-                const bool top_row = r == 0;
+                const int32_t icv = bmax(bmax(oM, oIr), oIc);
+                const uint32_t cc = icv == oM ? BM : icv == oIc ? BIC : BIR;
+                const bool top_row = EDGE && r == 0;
                 nM[i] = valid ? (top_row ? ms + lead_m : ms + b3) : BNEG;
                 nIc[i] = valid ? icv : BNEG;
                 ir0[i] = valid && top_row ? lead_ir : BNEG;
                 code_mc[i] = cm | (cc << 4);
             }
-            finish_column(j, nM, nIc, ir0, code_mc);
+            finish_column(edge, j, nM, nIc, ir0, code_mc);
         };
+        // every band row of every column of the node strictly inside the read?
+        const bool interior = nd.top >= 1 && nd.bot + nd.len - 1 < L;
 
-        if (nd.chain) column(0);
+        // columns [j, len) of the node.  Scores looked up cell by cell (quality-adjusted tables, tall lanes, the emulation of those), or
+        // the FAST path above.  The loop exists once per kind of node (interior / touching an edge of the read): no per-column choice.
+        auto columns_of = [&](auto edge, int32_t j) {
+            if (!FAST) {
+                for (; j < nd.len; ++j) {
+                    const uint32_t g = seq[j];
+                    int32_t msv[R];
+                    for (int i = 0; i < R; ++i) {
+                        const int32_t r = k0 + i + nd.top + j;
+                        const int32_t rc = r < 0 ? 0 : r >= L ? L - 1 : r;       // branch-free: out-of-matrix rows read a clamped read base and are masked
+                        msv[i] = bsub<QA>(src, g, rc);
+                    }
+                    column(edge, j, msv);
+                }
+                return;
+            }
+            uint64_t win = 0; uint32_t g4 = 0;
+            for (uint32_t c = 0; j < nd.len; ++j, c = (c + 1) & 3u) {       // (not unrolled: four columns in flight cost 25 VGPRs and three waves per SIMD)
+                if (c == 0) { win = b_read_window(src, k0 + nd.top + j, L); g4 = b_graph_word(src, nd.seq_off + (uint32_t)j, pb.graph_len); }
+                const uint32_t g = (g4 >> (8 * c)) & 0xffu;
+                const uint64_t row = src.rows[g];
+                const uint32_t sc4 = b_perm((uint32_t)(row >> 32), (uint32_t)row, b_bytes_from(win, c));
+                int32_t msv[R];
+                for (int i = 0; i < R; ++i) msv[i] = (int32_t)(int8_t)(uint8_t)(sc4 >> (8 * i));
+                column(edge, j, msv);
+            }
+        };
+        auto columns_from = [&](int32_t j) { if (interior) columns_of(std::false_type(), j); else columns_of(std::true_type(), j); };
+
+        if (nd.chain) columns_from(0);
         else {
             // ---- column 0: gather from the predecessors' last columns (:333-430) and the implied lead gaps (:433-476)
             const uint32_t g = seq[0];
@@ -232,12 +322,12 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
                 }
                 nM[i] = m; nIc[i] = ic; ir0[i] = ir; code_mc[i] = 0;
             }
-            finish_column(0, nM, nIc, ir0, code_mc);
+            finish_column(std::true_type(), 0, nM, nIc, ir0, code_mc);
             // the traceback re-examines the predecessors from this column (traceback_over_edge): keep its M and Ic
             int32_t* nf = last + nd.last_off + 3 * nd.stride;
             for (int i = 0; i < R; ++i) if (k0 + i < (int32_t)nd.stride) { nf[k0 + i] = M[i]; nf[nd.stride + k0 + i] = Ic[i]; }
         }
-        for (int32_t j = 1; j < nd.len; ++j) column(j);
+        if (!nd.chain) columns_from(1);
         // ---- keep the last column for the successors and the traceback
         if (nd.keep_last) {
             int32_t* nl = last + nd.last_off;
