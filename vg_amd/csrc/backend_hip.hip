@@ -175,6 +175,17 @@ struct XlDpp {
                      "s_nop 1" : "+v"(v));
         return dpp_down(v);
     }
+    // the same with the last step's destination kept by the caller: lane 0 has no source and keeps `old`
+    __device__ __forceinline__ int32_t scan_excl_keep(int32_t old, int32_t v) const {
+        asm volatile("s_nop 4\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_mov_b32_dpp %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v), "+v"(old));
+        return old;
+    }
     __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
     __device__ __forceinline__ bool any(int32_t flag) const { return __ballot(flag != 0) != 0ull; }
     __device__ __forceinline__ unsigned long long ballot(bool flag) const { return __ballot(flag); }

@@ -165,6 +165,7 @@ VGK_HD uint32_t b_graph_word(const BSrc& s, uint32_t at, uint32_t graph_len) {  
 //   int32 down(int32 v)      value of lane-1 (BNEG for lane 0)
 //   int32 up_sub(int32 old, int32 v, int32 s)     value of lane+1 minus s; the last lane returns `old`
 //   int32 down_sub(int32 old, int32 v, int32 s)   value of lane-1 minus s; lane 0 returns `old`
+//   int32 scan_excl_keep(int32 old, int32 v)      max over lanes < this one; lane 0 returns `old`
 //   int32 in_lanes(int32 s)  s, as a per-lane value (the DPP instructions take no scalar operand)
 //   int32 scan_excl(int32 v) max over lanes < this one (BNEG for lane 0)
 template <int R, bool QA, bool FAST, class XL>
@@ -178,7 +179,7 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
     for (int i = 0; i < R; ++i) { M[i] = BNEG; Ic[i] = BNEG; Ir[i] = BNEG; }
     // what the lanes without a neighbour (the last one looking at lane + 1, the first one looking at lane - 1) see: -inf, kept in the
     // destination registers of the cross-lane subtractions from column to column (XL::up_sub / down_sub leave those lanes alone)
-    int32_t keep_nxM = BNEG, keep_nxIc = BNEG, keep_nxIr = BNEG, keep_upM = BNEG, keep_upIc = BNEG;
+    int32_t keep_nxM = BNEG, keep_nxIc = BNEG, keep_nxIr = BNEG, keep_upM = BNEG, keep_upIc = BNEG, keep_excl = BNEG;
     const int32_t vgo = xl.in_lanes(go), vge = xl.in_lanes(ge);
     for (uint32_t v = 0; v < pb.n_nodes; ++v) {
         const BNode nd = nodes[v];
@@ -187,6 +188,8 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
         const uint8_t* seq = src.graph + nd.seq_off;
         uint8_t* tbn = tb + nd.tb_off;
         const int32_t k0 = (int32_t)lane * R;
+        int32_t kge[R];                                     // (row of the lane's i-th band row in column 0) * ge
+        for (int i = 0; i < R; ++i) kge[i] = (k0 + i + nd.top) * ge;
 
         // the row gaps of a column and its traceback bytes, given the column's M / Ic and the lead-gap seeds ir0 of Ir:
         //   Ir(r) = max(ir0(r), max_{r'<r} Y(r') - (r-1)*ge),  Y(r') = max(max(M,Ic)(r') - go, ir0(r') - ge) + r'*ge
@@ -194,21 +197,24 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
         // no row tests — the node decides that once for all its columns.
         auto finish_column = [&](auto edge, int32_t j, const int32_t (&nM)[R], const int32_t (&nIc)[R], const int32_t (&ir0)[R], const uint32_t (&code_mc)[R]) {
             constexpr bool EDGE = decltype(edge)::value;
+            // (-inf is any value below BNEG / 2: nothing here is clamped back to BNEG — a dead cell drifts by a gap or substitution score per
+            // column, far from the threshold for any graph the 16-bit run lengths admit — so the first row of a lane and the first lane need no max)
+            const int32_t jge = j * ge;
             int32_t run = BNEG, pre[R];
             for (int i = 0; i < R; ++i) {
-                const int32_t r = k0 + i + nd.top + j;
                 pre[i] = run;
                 const int32_t open = bmax(nM[i], nIc[i]) - go;
-                run = bmax(run, (EDGE ? bmax(open, ir0[i] - ge) : open) + r * ge);
+                const int32_t y = (EDGE ? bmax(open, ir0[i] - ge) : open) + kge[i] + jge;      // + r * ge
+                run = i == 0 ? y : bmax(run, y);
             }
-            const int32_t excl = xl.scan_excl(run);
+            const int32_t excl = keep_excl = xl.scan_excl_keep(keep_excl, run);
             // the cells above, a gap opening away: the previous lane's last row, then the lane's own rows
             int32_t upM = keep_upM = xl.down_sub(keep_upM, nM[R - 1], vgo), upIc = keep_upIc = xl.down_sub(keep_upIc, nIc[R - 1], vgo);
             uint8_t codes[R];
             for (int i = 0; i < R; ++i) {
                 const int32_t k = k0 + i, r = k + nd.top + j;
                 const bool valid = EDGE ? (k < H && r >= 0 && r < L) : k < H;
-                const int32_t from_above = bmax(excl, pre[i]) - (r - 1) * ge;
+                const int32_t from_above = (i == 0 ? excl : bmax(excl, pre[i])) + (ge - kge[i]) - jge;      // - (r - 1) * ge
                 int32_t ir = EDGE ? bmax(ir0[i], from_above) : from_above;
                 const uint32_t cr = ir == upM ? BM : ir == upIc ? BIC : BIR;
                 if (!valid) ir = BNEG;
@@ -216,7 +222,7 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
                 M[i] = nM[i]; Ic[i] = nIc[i]; Ir[i] = ir;
                 codes[i] = (uint8_t)(code_mc[i] | (cr << 2));
             }
-            if (k0 < (int32_t)nd.stride) store_codes<R>(tbn + (size_t)j * nd.stride + k0, codes);
+            if (k0 < (int32_t)nd.stride) store_codes<R>(tbn + (size_t)j * nd.stride + (uint32_t)k0, codes);
             if (P.scores) {         // the alternate tracebacks need score differences, not just sources (AltTracebackStack)
                 int32_t* sc = P.scores + 3 * (pb.tb_base + nd.tb_off + (size_t)j * nd.stride);
                 for (int i = 0; i < R; ++i) if (k0 + i < (int32_t)nd.stride) { sc[k0 + i] = M[i]; sc[nd.stride + k0 + i] = Ic[i]; sc[2 * nd.stride + k0 + i] = Ir[i]; }
@@ -243,9 +249,11 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
                 const int32_t icv = bmax(bmax(oM, oIr), oIc);
                 const uint32_t cc = icv == oM ? BM : icv == oIc ? BIC : BIR;
                 const bool top_row = EDGE && r == 0;
-                nM[i] = valid ? (top_row ? ms + lead_m : ms + b3) : BNEG;
-                nIc[i] = valid ? icv : BNEG;
-                ir0[i] = valid && top_row ? lead_ir : BNEG;
+                // (inside the read the rows behind the band's last one need no mask here: they hold -inf — the node's first column and the
+                // Ir mask of finish_column see to that — and -inf plus a score stays -inf)
+                nM[i] = !EDGE ? ms + b3 : valid ? (top_row ? ms + lead_m : ms + b3) : BNEG;
+                nIc[i] = !EDGE || valid ? icv : BNEG;
+                ir0[i] = EDGE && valid && top_row ? lead_ir : BNEG;
                 code_mc[i] = cm | (cc << 4);
             }
             finish_column(edge, j, nM, nIc, ir0, code_mc);
