@@ -34,7 +34,7 @@ RDEV = "cpu" if os.environ.get("VGAMD_BENCH_ONE_DEVICE") == "1" else "cuda"     
 # `traffic_source` says so; re-measure with tools/collect_r02.sh.
 PMC_BYTES_PER_UNIT = {
     "linear": (2 * 704590 + 13574060) * 1024 / 400000,       # pmc_{fetch,write}_400k.csv: gssw_fill_kernel<19,true>, 400 000 reads per launch (unchanged since r01)
-    "banded": (2 * 390611 + 2244073) * 1024 / 100000,         # pmc_*_banded_100k.csv: the banded_fill_kernel classes, 100 000 problems
+    "banded": (2 * 406349 + 2245028) * 1024 / 100000,         # pmc_*_banded_100k.csv: the banded_fill_kernel classes, 100 000 problems
     "gapless": (2 * 11460323 + 2860944) * 1024 / 1000000,     # pmc_*_gapless_1M.csv: gapless_search_kernel + gapless_rules_kernel + gapless_kernel, 1 000 000 reads
                                                               # (the nested kernel earlier in r02: 2 x 6 135 420 + 2 654 011; r01: 2 x 16 202 932 + 3 269 559)
     "wfa": (2 * 4094544 + 1914811) * 1024 / 500000,           # pmc_*_wfa_500k.csv: wfa_kernel, 500 000 problems
@@ -243,7 +243,7 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
                        "timed_region": "K runs of the fill launches + traceback kernel on the batch resident in HBM (vgk_banded_rerun)",
                        "end_to_end_from_host_buffers_alignments_per_s": n / te,
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus},
-            "roofline": {"bound": "hbm", "limiter": "VALU issue: ~64 VALU + 30 SALU per wave-column of <= 64 cells (DESIGN.md §10)", "kernel": "banded_fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "limiter": "VALU issue: 1.74 G VALU wave-instructions per launch = 2.8 ms on 1024 SIMDs; ~41 VALU per wave-column of <= 64 cells inside the read, plus the per-node work (DESIGN.md §10)", "kernel": "banded_fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["banded"] * n, "traffic_source": TRAFFIC_SOURCE, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": fill,
                          "traceback_ms": walk, "band_cells": cells, "gcups_fill": cells / (fill * 1e-3) / 1e9,
                          "kernel_only_alignments_per_s": n / ((fill + walk) * 1e-3)},

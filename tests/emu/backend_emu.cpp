@@ -35,6 +35,8 @@ struct XlEmu {
     int32_t up_sub(int32_t old, int32_t v, int32_t s) { const int32_t o = exchange(v, 0); return lane < 63 ? o - s : old; }
     int32_t down_sub(int32_t old, int32_t v, int32_t s) { const int32_t o = exchange(v, 1); return lane > 0 ? o - s : old; }
     int32_t in_lanes(int32_t s) { return s; }
+    int32_t scalar(int32_t s) { return s; }
+    int32_t add3(int32_t a, int32_t b, int32_t s) { return a + b + s; }
     int32_t scan_excl_keep(int32_t old, int32_t v) { const int32_t o = exchange(v, 2); return lane > 0 ? o : old; }
     int32_t scan_excl(int32_t v) { return exchange(v, 2); }
     void fence() { pthread_barrier_wait(&sh->bar); }

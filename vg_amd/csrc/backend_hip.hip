@@ -160,6 +160,8 @@ struct XlDpp {
         asm volatile("s_nop 1\n\tv_sub_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(v), "v"(s));
         return old;
     }
+    __device__ __forceinline__ int32_t scalar(int32_t s) const { int32_t o; const int32_t u = __builtin_amdgcn_readfirstlane(s); asm volatile("s_mov_b32 %0, %1" : "=s"(o) : "s"(u)); return o; }
+    __device__ __forceinline__ int32_t add3(int32_t a, int32_t b, int32_t s) const { int32_t o; asm("v_add3_u32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "s"(s)); return o; }
     __device__ __forceinline__ int32_t in_lanes(int32_t s) const { int32_t v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
     // exclusive max-scan over the 64 lanes: row_shr 1/2/4/8 inside each row of 16, then row_bcast:15 and row_bcast:31
     __device__ __forceinline__ int32_t scan_excl(int32_t v) const {

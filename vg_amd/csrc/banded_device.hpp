@@ -166,6 +166,8 @@ VGK_HD uint32_t b_graph_word(const BSrc& s, uint32_t at, uint32_t graph_len) {  
 //   int32 up_sub(int32 old, int32 v, int32 s)     value of lane+1 minus s; the last lane returns `old`
 //   int32 down_sub(int32 old, int32 v, int32 s)   value of lane-1 minus s; lane 0 returns `old`
 //   int32 scan_excl_keep(int32 old, int32 v)      max over lanes < this one; lane 0 returns `old`
+//   int32 scalar(int32 s)    s, wave-uniform, opaque to the optimiser
+//   int32 add3(int32 a, int32 b, int32 s)   a + b + s with s wave-uniform, as one instruction
 //   int32 in_lanes(int32 s)  s, as a per-lane value (the DPP instructions take no scalar operand)
 //   int32 scan_excl(int32 v) max over lanes < this one (BNEG for lane 0)
 template <int R, bool QA, bool FAST, class XL>
@@ -199,7 +201,7 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
             constexpr bool EDGE = decltype(edge)::value;
             // (-inf is any value below BNEG / 2: nothing here is clamped back to BNEG — a dead cell drifts by a gap or substitution score per
             // column, far from the threshold for any graph the 16-bit run lengths admit — so the first row of a lane and the first lane need no max)
-            const int32_t jge = j * ge;
+            const int32_t jge = xl.scalar(j * ge);             // (kept a scalar: as a per-lane running sum it costs two VALU per column)
             int32_t run = BNEG, pre[R];
             for (int i = 0; i < R; ++i) {
                 pre[i] = run;
@@ -214,7 +216,7 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
             for (int i = 0; i < R; ++i) {
                 const int32_t k = k0 + i, r = k + nd.top + j;
                 const bool valid = EDGE ? (k < H && r >= 0 && r < L) : k < H;
-                const int32_t from_above = (i == 0 ? excl : bmax(excl, pre[i])) + (ge - kge[i]) - jge;      // - (r - 1) * ge
+                const int32_t from_above = xl.add3(i == 0 ? excl : bmax(excl, pre[i]), ge - kge[i], -jge);      // - (r - 1) * ge
                 int32_t ir = EDGE ? bmax(ir0[i], from_above) : from_above;
                 const uint32_t cr = ir == upM ? BM : ir == upIc ? BIC : BIR;
                 if (!valid) ir = BNEG;
@@ -258,14 +260,12 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
             }
             finish_column(edge, j, nM, nIc, ir0, code_mc);
         };
-        // every band row of every column of the node strictly inside the read?
-        const bool interior = nd.top >= 1 && nd.bot + nd.len - 1 < L;
 
         // columns [j, len) of the node.  Scores looked up cell by cell (quality-adjusted tables, tall lanes, the emulation of those), or
         // the FAST path above.  The loop exists once per kind of node (interior / touching an edge of the read): no per-column choice.
-        auto columns_of = [&](auto edge, int32_t j) {
+        auto columns_of = [&](auto edge, int32_t j, const int32_t jend) {
             if (!FAST) {
-                for (; j < nd.len; ++j) {
+                for (; j < jend; ++j) {
                     const uint32_t g = seq[j];
                     int32_t msv[R];
                     for (int i = 0; i < R; ++i) {
@@ -278,7 +278,7 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
                 return;
             }
             uint64_t win = 0; uint32_t g4 = 0;
-            for (uint32_t c = 0; j < nd.len; ++j, c = (c + 1) & 3u) {       // (not unrolled: four columns in flight cost 25 VGPRs and three waves per SIMD)
+            for (uint32_t c = 0; j < jend; ++j, c = (c + 1) & 3u) {       // (not unrolled: four columns in flight cost 25 VGPRs and three waves per SIMD)
                 if (c == 0) { win = b_read_window(src, k0 + nd.top + j, L); g4 = b_graph_word(src, nd.seq_off + (uint32_t)j, pb.graph_len); }
                 const uint32_t g = (g4 >> (8 * c)) & 0xffu;
                 const uint64_t row = src.rows[g];
@@ -288,7 +288,14 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
                 column(edge, j, msv);
             }
         };
-        auto columns_from = [&](int32_t j) { if (interior) columns_of(std::false_type(), j); else columns_of(std::true_type(), j); };
+        // columns [j, len): those whose band rows all lie strictly inside the read (0 < top + j, bot + j < L) run without the row tests
+        auto columns_from = [&](int32_t j) {
+            const int32_t a = j > 1 - nd.top ? j : 1 - nd.top, b = nd.len < L - nd.bot ? nd.len : L - nd.bot;
+            if (a >= b) { columns_of(std::true_type(), j, nd.len); return; }
+            if (j < a) columns_of(std::true_type(), j, a);
+            columns_of(std::false_type(), a, b);
+            if (b < nd.len) columns_of(std::true_type(), b, nd.len);
+        };
 
         if (nd.chain) columns_from(0);
         else {
