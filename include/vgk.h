@@ -365,6 +365,12 @@ void vgk_haplo_destroy(vgk_haplo* index);
  * nodes in id order.  Malformed or truncated image: VGK_EINVAL.  [gbwt is an absent submodule: format as published, pinned on the
  * reference's test/primers/y.gbwt — tests/test_gbwt_file.py.] */
 int  vgk_haplo_create_gbwt(vgk_ctx* ctx, const void* gbwt, size_t bytes, uint32_t n_nodes, const uint32_t* node_len, const char* seq, vgk_haplo** out);
+/* A GBZ image (gbwtgraph's container of a GBWT and the graph's node sequences — what `vg giraffe -Z` loads; simple-sds serialization)
+ * decoded into the plain form vgk_haplo_create and vgk_minimizer_index_create take: nodes in id order with their forward sequences,
+ * the even GBWT sequences as threads.  Needs no context (host work only); the result owns its arrays: vgk_haplotypes_free.
+ * [Pinned on the reference's test/primers/y.giraffe.gbz: sequences = those of y.gg, threads = those of y.gbwt — tests/test_gbwt_file.py.] */
+int  vgk_gbz_load(const void* gbz, size_t bytes, vgk_haplotypes** out);
+void vgk_haplotypes_free(vgk_haplotypes* haplotypes);
 
 typedef struct vgk_seed {            /* GaplessExtender::seed_type (src/gbwt_extender.hpp:33): (handle, read_offset - node_offset) */
     uint32_t node;                   /* oriented node */

@@ -500,6 +500,9 @@ int vgk_haplo_create_gbwt(vgk_ctx* ctx, const void* gbwt, size_t bytes, uint32_t
     return VGK_EUNSUPPORTED;
 }
 
+int vgk_gbz_load(const void* gbz, size_t bytes, vgk_haplotypes** out) { (void)gbz; (void)bytes; if (out) *out = NULL; return VGK_EUNSUPPORTED; }     /* file formats are the engine's */
+void vgk_haplotypes_free(vgk_haplotypes* h) { (void)h; }
+
 /* the oracle keeps nothing between calls: the seeded form is not available on it (callers use vgk_gapless_extend) */
 int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max_mismatches, double overlap_threshold, uint32_t flags,
                               vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,

@@ -4,6 +4,8 @@
   y.gbwt   the haplotype index (GBWT, simple-sds serialization: header flag 0x4), 6 sequences = 3 haplotypes x 2 orientations
   y.gg     the GBWTGraph of the same graph: the sequences of its 66 nodes
   y.min    gbwtgraph's MinimizerIndex of that graph (k = 31, w = 50): 62 keys with one graph position each
+  y.giraffe.gbz   the same GBWT and graph in gbwtgraph's GBZ container (carried as bytes only: what the engine's loader is held to
+                  is the decoding of y.gbwt and y.gg below)
 
 They are the only artefacts of gbwt / gbwtgraph (absent submodules) the snapshot holds, so they are what pins
   * the haplotype index (vgk_haplo_create, vgk_haplo_create_gbwt): record contents and search states,
@@ -172,6 +174,7 @@ def main():
         "source": "test/primers/y.gbwt, y.gg, y.min of the reference (decoded by tests/golden/extract_primers_fixture.py)",
         "gbwt_header": header, "gbwt_records": records, "gbwt_threads": threads,
         "gbwt_file_hex": gbwt.hex(),
+        "gbz_file_hex": open(os.path.join(d, "y.giraffe.gbz"), "rb").read().hex(),      # the same graph and haplotypes as one GBZ container (not decoded here)
         "node_sequences": nodes,             # node id i + 1 (GBWT node 2 * (i + 1) + is_reverse)
         "minimizer_index": minimizers,
     }

@@ -159,6 +159,20 @@ def test_index_read_from_the_reference_gbwt(emu_lib):
         eng.haplo_index_from_gbwt(nodes, bytes(broken))
 
 
+def test_gbz_container_decodes_to_the_graph_and_the_haplotypes(emu_lib):
+    """y.giraffe.gbz holds the graph of y.gg and the haplotypes of y.gbwt: the engine's GBZ loader must hand back exactly what the golden
+    script decoded from those two OTHER files"""
+    fx, nodes, threads, image, first = fixture()
+    eng = capi.Engine(lib=emu_lib)
+    gbz = bytes.fromhex(fx["gbz_file_hex"])
+    got_nodes, got_threads = eng.gbz_load(gbz)
+    assert got_nodes == nodes
+    assert got_threads == threads
+    for bad in (gbz[:100], gbz[:0x840], gbz[:-700], b"GBZ " + b"\0" * 60, gbz[:0xc8] + b"\0" * 8 + gbz[0xd0:]):
+        with pytest.raises(capi.VgkError):
+            eng.gbz_load(bad)
+
+
 @pytest.mark.gpu
 def test_index_read_from_the_reference_gbwt_on_the_gpu():
     check(ENGINE_LIB, 400)

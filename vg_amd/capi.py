@@ -359,6 +359,26 @@ class Engine:
         """nodes: [str] in node-id order; threads: [[oriented node = 2 * index + is_reverse]].  -> HaploIndex"""
         return HaploIndex(self, nodes, threads)
 
+    def gbz_load(self, gbz_bytes):
+        """vgk_gbz_load: a GBZ image -> (node sequences [str], threads [[oriented node]])"""
+        lib = self.lib
+        out = ctypes.POINTER(Haplotypes)()
+        lib.vgk_gbz_load.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+        self._check(lib.vgk_gbz_load(bytes(gbz_bytes), len(gbz_bytes), ctypes.byref(out)), "vgk_gbz_load")
+        try:
+            h = out.contents
+            lens = np.ctypeslib.as_array(ctypes.cast(h.node_len, ctypes.POINTER(ctypes.c_uint32)), (h.n_nodes,)).copy()
+            seq = ctypes.string_at(h.seq, int(lens.sum())).decode()
+            at = [0] + [int(x) for x in np.cumsum(lens.astype(np.int64))]
+            nodes = [seq[at[i]:at[i + 1]] for i in range(h.n_nodes)]
+            toff = np.ctypeslib.as_array(ctypes.cast(h.thread_off, ctypes.POINTER(ctypes.c_uint32)), (h.n_threads + 1,)).copy()
+            tn = np.ctypeslib.as_array(ctypes.cast(h.thread_nodes, ctypes.POINTER(ctypes.c_uint32)), (max(int(toff[-1]), 1),)).copy()
+            threads = [[int(x) for x in tn[toff[t]:toff[t + 1]]] for t in range(h.n_threads)]
+        finally:
+            lib.vgk_haplotypes_free.argtypes = [ctypes.c_void_p]; lib.vgk_haplotypes_free.restype = None
+            lib.vgk_haplotypes_free(out)
+        return nodes, threads
+
     def haplo_index_from_gbwt(self, nodes, gbwt_bytes):
         """vgk_haplo_create_gbwt: the index from the image of a (simple-sds, bidirectional) GBWT file"""
         return HaploIndex(self, nodes, gbwt=gbwt_bytes)

@@ -17,6 +17,9 @@
 // is sequence 2i on the other strand, which is exactly what vgk_haplo_create derives from a thread itself: the even sequences become
 // the threads, and the index built from them holds the file's records again (the test compares search states with the file's).
 #include <cstring>
+#include <memory>
+#include <new>
+#include <string>
 #include <vector>
 #include "ctx.hpp"
 #include "haplo.hpp"
@@ -121,20 +124,16 @@ bool lf(const uint8_t* body, size_t lo, size_t hi, uint64_t i, std::vector<Edge>
     return false;
 }
 
-}  // namespace
-
-extern "C" {
-
-int vgk_haplo_create_gbwt(vgk_ctx* ctx, const void* gbwt, size_t bytes, uint32_t n_nodes, const uint32_t* node_len, const char* seq, vgk_haplo** out) {
-    if (!ctx || !gbwt || !out || !n_nodes || !node_len || !seq) return VGK_EINVAL;
-    *out = nullptr;
-    Cursor c{(const uint8_t*)gbwt, bytes};
+// The GBWT at the cursor: header, tags, BWT -> the even sequences as threads of oriented nodes (GBWT node (offset + 1) + o -> o).
+// whole: also step over what follows the BWT (document-array samples, metadata: both optional structures with a size in front).
+int read_gbwt(Cursor& c, bool whole, uint32_t& n_nodes, std::vector<uint32_t>& thread_off, std::vector<uint32_t>& thread_nodes) {
     const uint32_t tag = c.u32(); c.u32();
     const uint64_t sequences = c.u64(), size = c.u64(), offset = c.u64(), alphabet = c.u64(), flags = c.u64();
     if (!c.ok || tag != 0x6B376B37u) return VGK_EINVAL;
     if (!(flags & 0x4u)) return VGK_EUNSUPPORTED;                           // SDSL serialization (older files): `vg gbwt` rewrites them
     if (!(flags & 0x1u)) return VGK_EUNSUPPORTED;                           // unidirectional: the extenders need both strands
-    if (alphabet <= offset + 1 || ((offset + 1) & 1) || alphabet - offset - 1 != 2ull * n_nodes || (sequences & 1) || size > 0xfffffff0ull) return VGK_EINVAL;
+    if (alphabet <= offset + 1 || ((offset + 1) & 1) || ((alphabet - offset - 1) & 1) || alphabet - offset - 1 > 0xfffffff0ull || (sequences & 1) || size > 0xfffffff0ull) return VGK_EINVAL;
+    n_nodes = (uint32_t)((alphabet - offset - 1) / 2);
     uint64_t universe = 0;
     if (!read_sparse(c, universe, nullptr)) return VGK_EINVAL;               // tags: index ...
     { const uint8_t* a; uint64_t n; if (!read_bytes(c, a, n)) return VGK_EINVAL; }      // ... alphabet ...
@@ -145,6 +144,7 @@ int vgk_haplo_create_gbwt(vgk_ctx* ctx, const void* gbwt, size_t bytes, uint32_t
     if (!read_bytes(c, body, body_len) || body_len != universe || starts.size() != alphabet - offset) return VGK_EINVAL;
     for (size_t r = 0; r < starts.size(); ++r) if (starts[r] > body_len || (r && starts[r] < starts[r - 1])) return VGK_EINVAL;
     starts.push_back(body_len);
+    if (whole) { c.skip_option(); c.skip_option(); if (!c.ok) return VGK_EINVAL; }
 
     // the even sequences, one host task each: (endmarker, s) -> first node -> ... -> endmarker
     const uint32_t n_threads = (uint32_t)(sequences / 2);
@@ -165,14 +165,74 @@ int vgk_haplo_create_gbwt(vgk_ctx* ctx, const void* gbwt, size_t bytes, uint32_t
         }
     });
     for (int rc : status) if (rc) return rc;
-    std::vector<uint32_t> thread_off((size_t)n_threads + 1, 0), thread_nodes;
+    thread_off.assign((size_t)n_threads + 1, 0); thread_nodes.clear();
     for (uint32_t t = 0; t < n_threads; ++t) thread_off[t + 1] = thread_off[t] + (uint32_t)walks[t].size();
     thread_nodes.reserve(thread_off[n_threads]);
     for (auto& w : walks) thread_nodes.insert(thread_nodes.end(), w.begin(), w.end());
+    return VGK_OK;
+}
+
+struct Loaded { vgk_haplotypes h; std::vector<uint32_t> node_len, thread_off, thread_nodes; std::string seq; };
+
+}  // namespace
+
+extern "C" {
+
+int vgk_haplo_create_gbwt(vgk_ctx* ctx, const void* gbwt, size_t bytes, uint32_t n_nodes, const uint32_t* node_len, const char* seq, vgk_haplo** out) {
+    if (!ctx || !gbwt || !out || !n_nodes || !node_len || !seq) return VGK_EINVAL;
+    *out = nullptr;
+    Cursor c{(const uint8_t*)gbwt, bytes};
+    uint32_t nodes_in_file = 0; std::vector<uint32_t> thread_off, thread_nodes;
+    const int rc = read_gbwt(c, false, nodes_in_file, thread_off, thread_nodes);
+    if (rc) return rc;
+    if (nodes_in_file != n_nodes) return VGK_EINVAL;
     vgk_haplotypes d{};
     d.n_nodes = n_nodes; d.node_len = node_len; d.seq = seq;
-    d.n_threads = n_threads; d.thread_off = thread_off.data(); d.thread_nodes = thread_nodes.data();
+    d.n_threads = (uint32_t)(thread_off.size() - 1); d.thread_off = thread_off.data(); d.thread_nodes = thread_nodes.data();
     return vgk_haplo_create(ctx, &d, out);
 }
+
+// GBZ (gbwtgraph's container, what `vg giraffe -Z` takes): 'GBZ ' header, tags, the GBWT whole, then the GBWTGraph — header (tag
+// 0x6B3764AF, version, nodes, flags) and the node sequences, forward strands only, as a compressed string array: sparse vector of the
+// strings' start offsets, the alphabet, the symbols as an int vector over it.  (Segment names / translation follow: not needed.)
+int vgk_gbz_load(const void* gbz, size_t bytes, vgk_haplotypes** out) {
+    if (!gbz || !out) return VGK_EINVAL;
+    *out = nullptr;
+    Cursor c{(const uint8_t*)gbz, bytes};
+    const uint32_t tag = c.u32(); c.u32(); c.u64();
+    if (!c.ok || tag != 0x205A4247u) return VGK_EINVAL;
+    uint64_t universe = 0;
+    if (!read_sparse(c, universe, nullptr)) return VGK_EINVAL;               // the container's tags
+    { const uint8_t* a; uint64_t n; if (!read_bytes(c, a, n)) return VGK_EINVAL; }
+    { Bits d; uint64_t n, w; if (!read_int_vector(c, d, n, w)) return VGK_EINVAL; }
+    std::unique_ptr<Loaded> L(new (std::nothrow) Loaded());
+    if (!L) return VGK_ENOMEM;
+    uint32_t n_nodes = 0;
+    int rc = read_gbwt(c, true, n_nodes, L->thread_off, L->thread_nodes);
+    if (rc) return rc;
+    const uint32_t gtag = c.u32(); c.u32();
+    const uint64_t nodes = c.u64(), gflags = c.u64();
+    if (!c.ok || gtag != 0x6B3764AFu || nodes != n_nodes) return VGK_EINVAL;
+    if (!(gflags & 0x2u)) return VGK_EUNSUPPORTED;                          // SDSL-serialized graph
+    std::vector<uint64_t> starts;
+    if (!read_sparse(c, universe, &starts) || starts.size() != nodes) return VGK_EINVAL;
+    const uint8_t* alpha = nullptr; uint64_t n_alpha = 0;
+    if (!read_bytes(c, alpha, n_alpha)) return VGK_EINVAL;
+    Bits sym; uint64_t n_sym = 0, width = 0;
+    if (!read_int_vector(c, sym, n_sym, width) || n_sym > 0xfffffff0ull) return VGK_EINVAL;
+    L->seq.resize((size_t)n_sym);
+    for (uint64_t i = 0; i < n_sym; ++i) { const uint64_t s = width ? sym.field(i * width, (uint32_t)width) : 0; if (s >= n_alpha) return VGK_EINVAL; L->seq[(size_t)i] = (char)alpha[s]; }
+    L->node_len.resize(n_nodes);
+    for (uint32_t v = 0; v < n_nodes; ++v) {
+        const uint64_t a = starts[v], b = v + 1 < n_nodes ? starts[v + 1] : n_sym;
+        if (a > b || b > n_sym) return VGK_EINVAL;
+        L->node_len[v] = (uint32_t)(b - a);
+    }
+    L->h.n_nodes = n_nodes; L->h.node_len = L->node_len.data(); L->h.seq = L->seq.data();
+    L->h.n_threads = (uint32_t)(L->thread_off.size() - 1); L->h.thread_off = L->thread_off.data(); L->h.thread_nodes = L->thread_nodes.data();
+    *out = &L.release()->h;                                                  // (h is the first member: vgk_haplotypes_free casts back)
+    return VGK_OK;
+}
+void vgk_haplotypes_free(vgk_haplotypes* h) { delete reinterpret_cast<Loaded*>(h); }
 
 }  // extern "C"
