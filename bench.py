@@ -356,6 +356,8 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
     if from_reads:
         t1 = time.perf_counter(); mindex = eng.minimizer_index(wl.nodes, wl.threads); t_index = time.perf_counter() - t1
 
+    eng.reuse_outputs = True            # the loop consumes a step's outputs before the next step: one set of output arrays, reused (capi.Engine._out)
+
     def one_step(timing=None):
         gs = wl.gs
         seeded = None

@@ -355,6 +355,18 @@ class Engine:
     def banded_last(self, which):
         return self.lib.vgk_banded_last(self.h, which)
 
+    def _out(self, name, n, dtype):
+        """an output array of n elements.  reuse_outputs = True (a caller that consumes one call's outputs before the next call, like
+        bench.py's steady-state loops — or any C caller with its own buffers): one array per output is kept and grown, so a call neither
+        allocates nor page-faults hundreds of MB; the arrays a call returns are then views that the next call overwrites."""
+        if not getattr(self, "reuse_outputs", False):
+            return np.zeros(n, dtype=dtype)
+        cache = self.__dict__.setdefault("_out_cache", {})
+        a = cache.get(name)
+        if a is None or len(a) < n or a.dtype != dtype:
+            a = cache[name] = np.zeros(max(n, 1), dtype=dtype)
+        return a[:n]
+
     def haplo_index(self, nodes, threads):
         """nodes: [str] in node-id order; threads: [[oriented node = 2 * index + is_reverse]].  -> HaploIndex"""
         return HaploIndex(self, nodes, threads)
@@ -387,8 +399,8 @@ class Engine:
         """problems: a GaplessSet, or a list of dicts {read, seeds: [(oriented node, read_offset - node_offset)], max_mismatches?,
         overlap_threshold?, trim?}.  -> (results, extensions, nodes, mismatches) as numpy arrays laid out like include/vgk.h."""
         gs = problems if isinstance(problems, GaplessSet) else GaplessSet.from_lists(problems)
-        res = np.zeros(gs.n, dtype=GAPLESS_RESULT_DT)
-        ext = np.zeros(gs.ext_cap, dtype=EXT_DT); nodes = np.zeros(gs.node_cap, dtype=np.uint32); mism = np.zeros(gs.mism_cap, dtype=np.uint32)
+        res = self._out("g_res", gs.n, GAPLESS_RESULT_DT)
+        ext = self._out("g_ext", gs.ext_cap, EXT_DT); nodes = self._out("g_nodes", gs.node_cap, np.uint32); mism = self._out("g_mism", gs.mism_cap, np.uint32)
         written = (ctypes.c_size_t * 3)()
         self._check(self.lib.vgk_gapless_extend(self.h, index.h, gs.array.ctypes.data, gs.n, res.ctypes.data, ext.ctypes.data, gs.ext_cap,
                                                 nodes.ctypes.data, gs.node_cap, mism.ctypes.data, gs.mism_cap, ctypes.byref(written)),
@@ -403,9 +415,9 @@ class Engine:
         keep_on_device: the seeds stay in HBM for gapless_extend_seeded (an empty seeds array comes back)"""
         reads = np.ascontiguousarray(reads, dtype=np.uint8); off = np.ascontiguousarray(read_off, dtype=np.uint64)
         n = len(off) - 1
-        seed_off = np.zeros(n + 1, dtype=np.uint32); mins = np.zeros(max(n, 1), dtype=np.uint32)
+        seed_off = self._out("mz_off", n + 1, np.uint32); mins = self._out("mz_mins", max(n, 1), np.uint32)
         cap = 0 if keep_on_device else 64 * max(n, 1)
-        seeds = np.zeros(max(cap, 1), dtype=SEED_DT)
+        seeds = self._out("mz_seeds", max(cap, 1), SEED_DT)
         written = ctypes.c_size_t()
         self.lib.vgk_minimizer_seeds.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
@@ -430,16 +442,16 @@ class Engine:
     def tail_stage(self, index, n_reads, n_ext, ops_per_problem=32):
         """vgk_tail_stage over the sets the last gapless_extend / gapless_extend_seeded call left on the device
         -> (ext_total [n_ext], read_score [n_reads], (tails, trees, tree nodes, declined))"""
-        ext_total = np.zeros(max(n_ext, 1), dtype=np.int32); read_score = np.zeros(max(n_reads, 1), dtype=np.int32); stats = np.zeros(4, dtype=np.uint64)
+        ext_total = self._out("ts_ext", max(n_ext, 1), np.int32); read_score = self._out("ts_read", max(n_reads, 1), np.int32); stats = np.zeros(4, dtype=np.uint64)
         self.lib.vgk_tail_stage.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
         self._check(self.lib.vgk_tail_stage(self.h, index.h, ops_per_problem, ext_total.ctypes.data, len(ext_total), read_score.ctypes.data, stats.ctypes.data), "vgk_tail_stage")
         return ext_total[:n_ext], read_score[:n_reads], tuple(int(x) for x in stats)
 
     def tail_stage_aligned(self, index, n_reads, n_ext, ops_per_problem=32):
         """vgk_tail_stage_aligned -> (ext_total, read_score, tails as TAIL_ALIGNMENT_DT, ops as OP_DT, stats)"""
-        ext_total = np.zeros(max(n_ext, 1), dtype=np.int32); read_score = np.zeros(max(n_reads, 1), dtype=np.int32); stats = np.zeros(4, dtype=np.uint64)
+        ext_total = self._out("ts_ext", max(n_ext, 1), np.int32); read_score = self._out("ts_read", max(n_reads, 1), np.int32); stats = np.zeros(4, dtype=np.uint64)
         tails_cap = 2 * max(n_ext, 1)
-        tails = np.zeros(tails_cap, dtype=TAIL_ALIGNMENT_DT); ops = np.zeros(tails_cap * ops_per_problem + 1, dtype=OP_DT)
+        tails = self._out("ts_tails", tails_cap, TAIL_ALIGNMENT_DT); ops = self._out("ts_ops", tails_cap * ops_per_problem + 1, OP_DT)
         written = (ctypes.c_size_t * 2)()
         self.lib.vgk_tail_stage_aligned.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                                     ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
@@ -457,9 +469,9 @@ class Engine:
 
     def gapless_extend_seeded(self, index, n_reads, n_seeds, max_mismatches=4, overlap_threshold=0.8, trim=True, read_len=150):
         """vgk_gapless_extend_seeded: extend the clusters the last minimizer_seeds call left on the device -> as gapless_extend"""
-        res = np.zeros(max(n_reads, 1), dtype=GAPLESS_RESULT_DT)
+        res = self._out("gs_res", max(n_reads, 1), GAPLESS_RESULT_DT)
         ext_cap = n_seeds + 1; node_cap = n_seeds * 16 + 1024; mism_cap = n_seeds * 12 + 1024
-        ext = np.zeros(ext_cap, dtype=EXT_DT); nodes = np.zeros(node_cap, dtype=np.uint32); mism = np.zeros(mism_cap, dtype=np.uint32)
+        ext = self._out("gs_ext", ext_cap, EXT_DT); nodes = self._out("gs_nodes", node_cap, np.uint32); mism = self._out("gs_mism", mism_cap, np.uint32)
         written = (ctypes.c_size_t * 3)()
         self.lib.vgk_gapless_extend_seeded.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_double, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
                                                        ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
