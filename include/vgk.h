@@ -377,6 +377,11 @@ typedef struct vgk_seed {            /* GaplessExtender::seed_type (src/gbwt_ext
     int32_t  diff;
 } vgk_seed;
 #define VGK_GAPLESS_TRIM 1u          /* extend(..., trim = true) */
+#define VGK_GAPLESS_DEFER 2u         /* vgk_gapless_extend_seeded only: return as soon as the sets are laid out on the device and their sizes
+                                        (`written`) are known; the copies into results / extensions / nodes / mismatches run on a side stream and
+                                        are complete when the NEXT vgk_tail_stage / vgk_tail_stage_aligned call on the context returns — they
+                                        travel while that call keeps the device busy — or after vgk_gapless_fetch_deferred.  The arrays must
+                                        stay valid until then.  (Arrays too small: not deferred, VGK_EOPS as usual.) */
 typedef struct vgk_gapless_problem {
     const char*     read;            /* masked by the engine like ReadMasker (:160-176): non-ACGT never matches */
     uint32_t        read_len;
@@ -404,6 +409,7 @@ int  vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_
                         vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
                         uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap,
                         size_t written[3] /* extensions, nodes, mismatches */);
+int    vgk_gapless_fetch_deferred(vgk_ctx* ctx);   /* wait for and finish the copies of a VGK_GAPLESS_DEFER call (no-op when none is pending) */
 int    vgk_gapless_rerun(vgk_ctx* ctx);      /* launch the kernel of the last vgk_gapless_extend call again on its resident inputs */
 double vgk_gapless_last_ms(vgk_ctx* ctx);    /* kernel time of the last vgk_gapless_extend call on this context */
 uint64_t vgk_gapless_last_retried(vgk_ctx* ctx);   /* reads of that call whose search outgrew the fast (in-LDS) kernel and ran in the slab kernel */

@@ -500,6 +500,7 @@ int vgk_haplo_create_gbwt(vgk_ctx* ctx, const void* gbwt, size_t bytes, uint32_t
     return VGK_EUNSUPPORTED;
 }
 
+int vgk_gapless_fetch_deferred(vgk_ctx* ctx) { (void)ctx; return VGK_OK; }
 int vgk_gbz_load(const void* gbz, size_t bytes, vgk_haplotypes** out) { (void)gbz; (void)bytes; if (out) *out = NULL; return VGK_EUNSUPPORTED; }     /* file formats are the engine's */
 void vgk_haplotypes_free(vgk_haplotypes* h) { (void)h; }
 

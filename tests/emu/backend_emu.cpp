@@ -116,7 +116,10 @@ public:
         return VGK_OK;
     }
     int mask_reads(char* reads, size_t bytes) override { for (size_t k = 0; k < bytes; ++k) reads[k] = g_mask_base(reads[k]); return VGK_OK; }
-    int run_minimizer(const MinimizerParams& P) override { for (uint32_t i = 0; i < P.n; ++i) minimizer_one(P, i); return VGK_OK; }
+    int run_minimizer(const MinimizerParams& P) override {
+        if (P.pass == 1) { for (uint32_t i = P.lo; i < P.hi; ++i) minimizer_one(P, i); } else for (uint32_t i = 0; i < P.n; ++i) minimizer_one(P, i);
+        return VGK_OK;
+    }
     int run_tail_stage(const TStageParams& P, int what) override { const uint32_t items = tstage_items(P, what); for (uint32_t i = 0; i < items; ++i) tstage_one(P, what, i); return VGK_OK; }
     int run_tail(const TailParams& P, uint32_t threads) override {
         for (uint32_t t = 0; t < threads; ++t) for (uint32_t i = t; i < P.n; i += threads) tail_walk_one(P, i, P.scratch[t]);

@@ -212,6 +212,23 @@ def seeded_equals_via_host(lib, n_reads, seed):
     oso, oseeds, _ = ora.minimizer_seeds(ora.minimizer_index(wl.nodes, wl.threads), ora.haplo_index(wl.nodes, wl.threads), flat, off)
     b = pipeline.align_stage(ora, ora.haplo_index(wl.nodes, wl.threads), olen, capi.GaplessSet(flat, off, oseeds, oso))
     assert (a["read_score"] == b["read_score"]).all()
+    # VGK_GAPLESS_DEFER: the sets come down while the tail stage runs; complete (and the same bytes) when that call returns ...
+    eng.minimizer_seeds(mi, hi, flat, off, keep_on_device=True)
+    c = pipeline.align_stage_device(eng, hi, gs, seeded=int(seed_off[-1]))
+    for name, y in zip(("res", "ext", "nodes"), via_host):
+        assert c[name].tobytes() == y.tobytes(), name
+    assert (c["read_score"] == b["read_score"]).all()
+    # ... or after vgk_gapless_fetch_deferred; a call that is not followed by either is finished by the next extension call
+    eng.minimizer_seeds(mi, hi, flat, off, keep_on_device=True)
+    d = eng.gapless_extend_seeded(hi, len(reads), int(seed_off[-1]), defer=True)
+    eng.gapless_fetch_deferred()
+    for x, y in zip(d, via_host):
+        assert x.tobytes() == y.tobytes()
+    eng.minimizer_seeds(mi, hi, flat, off, keep_on_device=True)
+    e = eng.gapless_extend_seeded(hi, len(reads), int(seed_off[-1]), defer=True)
+    eng.gapless_extend(hi, capi.GaplessSet(flat, off, seeds, seed_off))
+    for x, y in zip(e, via_host):
+        assert x.tobytes() == y.tobytes()
 
 
 def test_clusters_that_stay_on_the_device(emu_lib):

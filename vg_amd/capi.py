@@ -47,6 +47,7 @@ EXT_DT = np.dtype([("path_begin", "<u4"), ("path_len", "<u4"), ("offset", "<u4")
                    ("pad", "u1", 2), ("state", "<u4", 6)])
 GAPLESS_RESULT_DT = np.dtype([("status", "<i4"), ("ext_begin", "<u4"), ("n_ext", "<u4"), ("full_length", "<u4")])
 VGK_GAPLESS_TRIM = 1
+VGK_GAPLESS_DEFER = 2
 WFA_DT = np.dtype([("seq", "<u8"), ("seq_len", "<u4"), ("mode", "<u4"), ("from_node", "<u4"), ("from_offset", "<u4"),
                    ("to_node", "<u4"), ("to_offset", "<u4")])
 WFA_RESULT_DT = np.dtype([("status", "<i4"), ("ok", "<i4"), ("score", "<i4"), ("node_offset", "<u4"), ("seq_offset", "<u4"),
@@ -467,18 +468,24 @@ class Engine:
         self.lib.vgk_tail_last_ms.restype = ctypes.c_double; self.lib.vgk_tail_last_ms.argtypes = [ctypes.c_void_p]
         return self.lib.vgk_tail_last_ms(self.h)
 
-    def gapless_extend_seeded(self, index, n_reads, n_seeds, max_mismatches=4, overlap_threshold=0.8, trim=True, read_len=150):
-        """vgk_gapless_extend_seeded: extend the clusters the last minimizer_seeds call left on the device -> as gapless_extend"""
+    def gapless_extend_seeded(self, index, n_reads, n_seeds, max_mismatches=4, overlap_threshold=0.8, trim=True, read_len=150, defer=False):
+        """vgk_gapless_extend_seeded: extend the clusters the last minimizer_seeds call left on the device -> as gapless_extend.
+        defer (VGK_GAPLESS_DEFER): the arrays come back sized but are FILLED only when the next tail_stage / tail_stage_aligned call (or
+        gapless_fetch_deferred) returns"""
         res = self._out("gs_res", max(n_reads, 1), GAPLESS_RESULT_DT)
         ext_cap = n_seeds + 1; node_cap = n_seeds * 16 + 1024; mism_cap = n_seeds * 12 + 1024
         ext = self._out("gs_ext", ext_cap, EXT_DT); nodes = self._out("gs_nodes", node_cap, np.uint32); mism = self._out("gs_mism", mism_cap, np.uint32)
         written = (ctypes.c_size_t * 3)()
         self.lib.vgk_gapless_extend_seeded.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_double, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
                                                        ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
-        self._check(self.lib.vgk_gapless_extend_seeded(self.h, index.h, max_mismatches, overlap_threshold, VGK_GAPLESS_TRIM if trim else 0, res.ctypes.data,
+        self._check(self.lib.vgk_gapless_extend_seeded(self.h, index.h, max_mismatches, overlap_threshold, (VGK_GAPLESS_TRIM if trim else 0) | (VGK_GAPLESS_DEFER if defer else 0), res.ctypes.data,
                                                        ext.ctypes.data, ext_cap, nodes.ctypes.data, node_cap, mism.ctypes.data, mism_cap, ctypes.byref(written)),
                     "vgk_gapless_extend_seeded")
         return res[:n_reads], ext[:written[0]], nodes[:written[1]], mism[:written[2]]
+
+    def gapless_fetch_deferred(self):
+        self.lib.vgk_gapless_fetch_deferred.argtypes = [ctypes.c_void_p]
+        self._check(self.lib.vgk_gapless_fetch_deferred(self.h), "vgk_gapless_fetch_deferred")
 
     def gapless_last_ms(self):
         return self.lib.vgk_gapless_last_ms(self.h)

@@ -49,6 +49,7 @@ public:
     virtual int   fetch_after(void* ev) { (void)ev; return VGK_OK; }                // fetch-stream work queued from now on runs after ev
     virtual int   sync_fetch() { return sync(); }
     virtual int   download_fetch(void* dst, const void* src, size_t bytes) { return download(dst, src, bytes); }   // synchronous, fetch stream
+    virtual int   download_fetch_async(void* dst, const void* src, size_t bytes) { return download(dst, src, bytes); }   // queued on the fetch stream (dst page-locked); sync_fetch waits
     // device-side packing of window problems (gssw_pack_device.hpp), asynchronous on the side (copy) stream like upload_side:
     // stage 1 = per-problem sizes + their prefix sums + totals, stage 2 = launch order, wavefronts, the arenas the kernels read.
     // win_tmp_bytes = device scratch both stages need (`tmp`); download_side / fill_side = synchronous copy back / async byte fill

@@ -343,8 +343,8 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
     __shared__ MzMin mins_all[4][64];
     __shared__ unsigned long long seen_all[4][MZ_MAX_SEEDS];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t i = blockIdx.x * 4u + wv;
-    if (i >= P.n) return;
+    const uint32_t i = P.lo + blockIdx.x * 4u + wv;
+    if (i >= P.hi) return;
     MzMin* mins = mins_all[wv]; unsigned long long* seen = seen_all[wv];
     const uint64_t a = P.read_off[i]; const uint32_t L = (uint32_t)(P.read_off[i + 1] - a);
     const uint32_t k = P.index.k, w = P.index.w;
@@ -591,6 +591,10 @@ public:
         if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, fetch) != hipSuccess) return VGK_ENODEV;
         return hipStreamSynchronize(fetch) == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
+    int download_fetch_async(void* dst, const void* src, size_t bytes) override {
+        hipSetDevice(dev);
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, fetch) == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
     int sync_side() override {
         hipSetDevice(dev);
         return hipStreamSynchronize(copy) == hipSuccess ? VGK_OK : VGK_ENODEV;
@@ -831,7 +835,7 @@ public:
             if (hipMalloc(&mz_slots, need + need / 8) != hipSuccess) return VGK_ENOMEM;
             mz_slots_bytes = need + need / 8;
         }
-        if (p.pass == 1) hipLaunchKernelGGL(minimizer_kernel, dim3((p.n + 3) / 4), dim3(256), 0, stream, p, (vgk_seed*)mz_slots);
+        if (p.pass == 1) { if (p.hi > p.lo) hipLaunchKernelGGL(minimizer_kernel, dim3((p.hi - p.lo + 3) / 4), dim3(256), 0, stream, p, (vgk_seed*)mz_slots); }
         else hipLaunchKernelGGL(minimizer_gather_kernel, dim3((p.n + 3) / 4), dim3(256), 0, stream, p, (const vgk_seed*)mz_slots);
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }

@@ -43,6 +43,11 @@ struct vgk_ctx {
     // vgk_tail_stage derives the tails from there
     struct Sets { bool valid = false; uint32_t n = 0; uint64_t n_ext = 0; const void* probs = nullptr; const char* reads = nullptr;
                   const void* res = nullptr; const void* ext = nullptr; const uint32_t* nodes = nullptr; const void* index = nullptr; } sets;
+    // VGK_GAPLESS_DEFER: the sets of that call are still on their way down (fetch stream -> page-locked staging) and have yet to be
+    // copied into the caller's arrays; finished by vgk_tail_stage*, vgk_gapless_fetch_deferred, or the next extension call
+    struct DeferredSpan { char* dst; const char* src; size_t bytes; };
+    struct Deferred { bool pending = false; DeferredSpan spans[4] = {}; void* ev = nullptr; } deferred;
+    int finish_deferred();
     double minimizer_ms = 0;       // device time of the last vgk_minimizer_seeds call
     double tail_stage_ms[4] = {0, 0, 0, 0};   // last vgk_tail_stage: tails derived | forest | windows packed | kernels + totals
     double tail_ms = 0;            // device time of the last vgk_tail_forest call
@@ -137,6 +142,6 @@ struct vgk_ctx {
     std::shared_ptr<void> multi_host;       // and of gssw_multi_api.cpp
     std::shared_ptr<void> xband_host;       // and of xdrop_band_api.cpp
     double xband_ms = 0;                    // kernel time of the last vgk_xdrop_band_align call
-    ~vgk_ctx() { if (be) { for (DevBuf& b : scratch) if (b.p) be->release(b.p); for (Pooled& q : dev_pool) be->release(q.p); for (Pooled& q : host_pool) be->host_release(q.p); } }
+    ~vgk_ctx() { if (be) { if (deferred.pending) be->sync_fetch(); if (deferred.ev) be->event_destroy(deferred.ev); for (DevBuf& b : scratch) if (b.p) be->release(b.p); for (Pooled& q : dev_pool) be->release(q.p); for (Pooled& q : host_pool) be->host_release(q.p); } }
 };
 

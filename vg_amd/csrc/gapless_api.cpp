@@ -50,6 +50,18 @@ struct Arrival { int32_t pred; uint32_t order, seq, pos; };
 
 }  // namespace
 
+// the sets of a VGK_GAPLESS_DEFER call: wait for the copies, then out of the staging buffers in slices on the host threads (context lock held)
+int vgk_ctx::finish_deferred() {
+    if (!deferred.pending) return VGK_OK;
+    deferred.pending = false;
+    const int rc = be->sync_fetch();
+    if (rc) return rc;
+    std::vector<DeferredSpan> slices;
+    for (const DeferredSpan& sp : deferred.spans) for (size_t at = 0; at < sp.bytes; at += (size_t)8 << 20) slices.push_back({sp.dst + at, sp.src + at, std::min<size_t>((size_t)8 << 20, sp.bytes - at)});
+    parallel_tasks((uint32_t)slices.size(), [&](uint32_t k) { std::memcpy(slices[k].dst, slices[k].src, slices[k].bytes); });
+    return VGK_OK;
+}
+
 extern "C" {
 
 int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
@@ -209,9 +221,10 @@ void vgk_haplo_destroy(vgk_haplo* h) {
 // P carries index, probs, reads, seeds, order, n; n_seed = seeds of the whole batch; `slot` = the next free scratch slot.
 static int gapless_run_and_fetch(vgk_ctx* ctx, GaplessParams& P, uint32_t n, uint64_t n_seed, int next_slot, GaplessHost& H, GLap& lap,
                                  vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
-                                 uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) {
+                                 uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3], const bool defer = false) {
     Backend* be = ctx->be.get();
     auto cleanup = [&](int rc) { return rc; };
+    { const int rc0 = ctx->finish_deferred(); if (rc0) return rc0; }         // (an earlier call's sets still on their way use the same staging)
     auto dev = [&](const void* src, size_t bytes) -> void* {
         void* d = ctx->ensure_scratch(next_slot++, std::max<size_t>(bytes, 16)); if (!d) return nullptr;
         if (src && bytes && be->upload(d, src, bytes)) return nullptr;
@@ -278,8 +291,26 @@ static int gapless_run_and_fetch(vgk_ctx* ctx, GaplessParams& P, uint32_t n, uin
     vgk_gapless_result* dres = H.dres.get(be, n);
     vgk_extension* dext = H.dext.get(be, we + 1); uint32_t* dnodes = H.dnodes.get(be, wn + 1); uint32_t* dmism = H.dmism.get(be, wm + 1);
     if (!dres || !dext || !dnodes || !dmism) return cleanup(VGK_ENOMEM);
-    if ((rc = be->download(dres, O.res_out, sizeof(vgk_gapless_result) * n))) return cleanup(rc);
     const bool fits = we <= ext_cap && wn <= nodes_cap && wm <= mism_cap && (we == 0 || (extensions && nodes && mismatches));
+    if (fits && defer) {
+        // VGK_GAPLESS_DEFER: the copies down are queued on the fetch stream behind the gather kernels and run while the caller's next
+        // call (vgk_tail_stage*) keeps the device busy; that call copies them out of the staging buffers when it is done
+        if (!ctx->deferred.ev) ctx->deferred.ev = be->event_create();
+        if ((rc = be->event_record(ctx->deferred.ev)) || (rc = be->fetch_after(ctx->deferred.ev))) return cleanup(rc);
+        if ((rc = be->download_fetch_async(dres, O.res_out, sizeof(vgk_gapless_result) * n))) return cleanup(rc);
+        if (we && (rc = be->download_fetch_async(dext, O.ext_out, sizeof(vgk_extension) * we))) return cleanup(rc);
+        if (wn && (rc = be->download_fetch_async(dnodes, O.nodes_out, sizeof(uint32_t) * wn))) return cleanup(rc);
+        if (wm && (rc = be->download_fetch_async(dmism, O.mism_out, sizeof(uint32_t) * wm))) return cleanup(rc);
+        ctx->deferred.spans[0] = {(char*)results, (const char*)dres, sizeof(vgk_gapless_result) * n};
+        ctx->deferred.spans[1] = {(char*)extensions, (const char*)dext, sizeof(vgk_extension) * we};
+        ctx->deferred.spans[2] = {(char*)nodes, (const char*)dnodes, sizeof(uint32_t) * wn};
+        ctx->deferred.spans[3] = {(char*)mismatches, (const char*)dmism, sizeof(uint32_t) * wm};
+        ctx->deferred.pending = true;
+        lap("ordered on the device, downloads queued");
+        if (written) { written[0] = we; written[1] = wn; written[2] = wm; }
+        return cleanup(VGK_OK);
+    }
+    if ((rc = be->download(dres, O.res_out, sizeof(vgk_gapless_result) * n))) return cleanup(rc);
     if (fits) {
         if (we && (rc = be->download(dext, O.ext_out, sizeof(vgk_extension) * we))) return cleanup(rc);
         if (wn && (rc = be->download(dnodes, O.nodes_out, sizeof(uint32_t) * wn))) return cleanup(rc);
@@ -326,6 +357,12 @@ static int gapless_run_and_fetch(vgk_ctx* ctx, GaplessParams& P, uint32_t n, uin
     return cleanup(rc_all);
 }
 
+
+int vgk_gapless_fetch_deferred(vgk_ctx* ctx) {
+    if (!ctx) return VGK_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ctx->finish_deferred();
+}
 
 int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_problem* problems, uint32_t n,
                        vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
@@ -416,7 +453,7 @@ int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max
     int bits = 1; while ((1u << bits) < buckets && bits < 32) ++bits;
     GSeededParams S{};
     S.n = n; S.read_off = ctx->seeded.read_off; S.seed_off = ctx->seeded.seed_off; S.seeds = ctx->seeded.seeds;
-    S.max_mm = max_mismatches; S.flags = flags; S.overlap = overlap_threshold; S.buckets = buckets;
+    S.max_mm = max_mismatches; S.flags = flags & ~(uint32_t)VGK_GAPLESS_DEFER; S.overlap = overlap_threshold; S.buckets = buckets;
     S.probs = d_probs; S.key = d_sort; S.idx = d_sort + n;
     int rc = be->gapless_seeded(S);
     if (!rc) rc = be->sort_pairs_u32(d_sort, d_sort + 2 * (size_t)n, d_sort + n, d_sort + 3 * (size_t)n, n, bits);
@@ -425,7 +462,7 @@ int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max
     P.index = index->dev; P.n = n;
     P.probs = d_probs; P.reads = ctx->seeded.reads; P.seeds = ctx->seeded.seeds; P.order = d_sort + 3 * (size_t)n;
     lap("descriptors and order on the device");
-    return gapless_run_and_fetch(ctx, P, n, n_seed, next_slot, H, lap, results, extensions, ext_cap, nodes, nodes_cap, mismatches, mism_cap, written);
+    return gapless_run_and_fetch(ctx, P, n, n_seed, next_slot, H, lap, results, extensions, ext_cap, nodes, nodes_cap, mismatches, mism_cap, written, (flags & VGK_GAPLESS_DEFER) != 0);
 }
 
 int vgk_gapless_rerun(vgk_ctx* ctx) {

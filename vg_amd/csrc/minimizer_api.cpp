@@ -133,15 +133,22 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
     MinimizerParams P{};
     P.index = ix->dev; P.graph = graph->dev; P.reads = d_reads + 8; P.read_off = d_off; P.n = n; P.hit_cap = hit_cap ? hit_cap : 0xffffffffu;
     P.counts = d_tab; P.mins = d_tab + n1; P.first = d_tab + 2 * n1;
-    int rc = be->upload(d_reads + 8, reads + read_off[0], bytes);
-    if (!rc) rc = be->mask_reads(d_reads, bytes + 16);                       // ReadMasker once, for the seeding (anything but ACGT is no k-mer) and the extension
+    int rc = be->upload(d_off, rel.data(), sizeof(uint64_t) * n1);
+    if (!rc) rc = be->zero(d_tab, sizeof(uint32_t) * 3 * n1);
     if (!rc) rc = be->zero(d_reads, 8);
     if (!rc) rc = be->zero(d_reads + 8 + bytes, 8);
-    if (!rc) rc = be->upload(d_off, rel.data(), sizeof(uint64_t) * n1);
-    if (!rc) rc = be->zero(d_tab, sizeof(uint32_t) * 3 * n1);
-    be->watch(0);                                                          // (the stopwatch covers the kernels and scans, not the reads' way up)
+    be->watch(0);                                                          // (the stopwatch covers copies, kernels and scans from here on)
+    // The reads go up in slices on the copy stream; a slice is masked (ReadMasker once, for the seeding — anything but ACGT is no k-mer —
+    // and the extension) and its minimizers found on the main stream while the next slice travels.
     P.pass = 1;
-    if (!rc) rc = be->run_minimizer(P);
+    const uint32_t slices = n >= (1u << 16) ? 4u : 1u;
+    for (uint32_t c = 0; c < slices && !rc; ++c) {
+        const uint32_t lo = (uint32_t)((uint64_t)n * c / slices), hi = (uint32_t)((uint64_t)n * (c + 1) / slices);
+        const uint64_t a = rel[lo], b = rel[hi];
+        if (b > a) { rc = be->upload_side(d_reads + 8 + a, reads + read_off[0] + a, b - a); if (!rc) rc = be->sync_side(); if (!rc) { const uint64_t from = (8 + a) & ~15ull; rc = be->mask_reads(d_reads + from, 8 + b - from); } }      // (from a 16-byte boundary: the few bytes before `a` are the previous slice's, masked already — masking is idempotent)
+        P.lo = lo; P.hi = hi;
+        if (!rc) rc = be->run_minimizer(P);
+    }
     if (!rc) rc = be->scan_u32(d_tab, d_tab + 2 * n1, (uint32_t)n1);
     if (!rc) rc = be->download(seed_off, d_tab + 2 * n1, sizeof(uint32_t) * n1);      // synchronises (rel[] may go)
     if (!rc && minimizers) rc = be->download(minimizers, d_tab + n1, sizeof(uint32_t) * n);

@@ -103,6 +103,7 @@ struct MinimizerParams {
     uint32_t* mins;
     const uint32_t* first;                                                 // pass 2: exclusive prefix sums of counts
     vgk_seed* seeds; int pass;
+    uint32_t lo, hi;                                                       // pass 1 over reads [lo, hi): the reads go up in slices, a slice's kernel runs under the next slice's copy
 };
 // one read: count its seeds (pass 1) or write them (pass 2), in order of the minimizers' read offsets, a minimizer's hits in index order.
 // A cluster is a SET of seeds (GaplessExtender::cluster_type is a hash set, src/gbwt_extender.hpp:143): a (node, diagonal) pair that

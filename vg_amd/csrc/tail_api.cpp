@@ -303,11 +303,15 @@ static int tail_stage_impl(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_pe
 }
 extern "C" {
 int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score, uint64_t stats[4]) {
-    return tail_stage_impl(ctx, index, ops_per_problem, ext_total, ext_cap, read_score, stats, false, nullptr, 0, nullptr, 0, nullptr);
+    int rc = tail_stage_impl(ctx, index, ops_per_problem, ext_total, ext_cap, read_score, stats, false, nullptr, 0, nullptr, 0, nullptr);
+    if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); const int rc2 = ctx->finish_deferred(); if (!rc) rc = rc2; }       // the sets of a VGK_GAPLESS_DEFER call came down meanwhile
+    return rc;
 }
 int vgk_tail_stage_aligned(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score,
                            vgk_tail_alignment* tails, size_t tails_cap, vgk_op* ops, size_t ops_cap, size_t written[2], uint64_t stats[4]) {
-    return tail_stage_impl(ctx, index, ops_per_problem, ext_total, ext_cap, read_score, stats, true, tails, tails_cap, ops, ops_cap, written);
+    int rc = tail_stage_impl(ctx, index, ops_per_problem, ext_total, ext_cap, read_score, stats, true, tails, tails_cap, ops, ops_cap, written);
+    if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); const int rc2 = ctx->finish_deferred(); if (!rc) rc = rc2; }
+    return rc;
 }
 double vgk_tail_stage_last_ms(vgk_ctx* ctx, int which) { return ctx && which >= 0 && which < 4 ? ctx->tail_stage_ms[which] : 0.0; }
 

@@ -218,15 +218,16 @@ def align_stage_device(eng, index, gs, ops_per_problem=32, timing=None, seeded=N
     import time
     t0 = time.perf_counter()
     if seeded is not None:
-        res, ext, nodes, mism = eng.gapless_extend_seeded(index, gs.n, int(seeded))
+        # (deferred: the sets come down on a side stream while the tail stage runs; `ext` is sized already, filled when that call returns)
+        res, ext, nodes, mism = eng.gapless_extend_seeded(index, gs.n, int(seeded), defer=True)
     else:
         res, ext, nodes, mism = eng.gapless_extend(index, gs)
     t1 = time.perf_counter()
     tails = tail_ops = None
     if aligned:
-        ext_total, read_score, tails, tail_ops, stats = eng.tail_stage_aligned(index, gs.n, int(res["n_ext"].sum()), ops_per_problem)
+        ext_total, read_score, tails, tail_ops, stats = eng.tail_stage_aligned(index, gs.n, len(ext), ops_per_problem)
     else:
-        ext_total, read_score, stats = eng.tail_stage(index, gs.n, int(res["n_ext"].sum()), ops_per_problem)
+        ext_total, read_score, stats = eng.tail_stage(index, gs.n, len(ext), ops_per_problem)
     t2 = time.perf_counter()
     if timing is not None:
         for k, v in (("gapless_extend", t1 - t0), ("tail stage (device, total)", t2 - t1)):
