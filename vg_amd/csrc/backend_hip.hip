@@ -313,6 +313,12 @@ __global__ void __launch_bounds__(256) gapless_seeded_kernel(const GSeededParams
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < P.n) g_seeded_one(P, i);
 }
+// hipMemsetAsync's fill kernel was measured at ~30 GB/s for the stage's 22 MB table (0.7 ms per step): large clears go through this one
+__global__ void __launch_bounds__(256) zero_kernel(uint4* dst, const size_t vecs, unsigned char* tail, const uint32_t tail_bytes) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < vecs; i += stride) dst[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < tail_bytes) tail[threadIdx.x] = 0;
+}
 __global__ void __launch_bounds__(256) mask_reads_kernel(char* reads, const size_t bytes) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
     if (i >= bytes) return;
@@ -606,6 +612,12 @@ public:
     }
     int zero(void* dst, size_t bytes) override {
         hipSetDevice(dev);
+        if (bytes >= ((size_t)1 << 18) && ((uintptr_t)dst & 15u) == 0) {
+            const size_t vecs = bytes / 16;
+            const unsigned blocks = (unsigned)std::min<size_t>((vecs + 255) / 256, (size_t)std::max(1, prop.multiProcessorCount) * 8);
+            hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, stream, (uint4*)dst, vecs, (unsigned char*)dst + vecs * 16, (uint32_t)(bytes - vecs * 16));
+            return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+        }
         return hipMemsetAsync(dst, 0, bytes, stream) == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int sync() override {
