@@ -154,7 +154,7 @@ public:
             for (uint32_t t = 0; t < threads; ++t) for (uint32_t k = t; k < P.n; k += threads) gapless_rules_one(P, P.order[k], P.scratch[t].order);
             for (uint32_t t = 0; t < threads; ++t) for (uint32_t k = t; k < P.n; k += threads) {
                 const uint32_t i = P.order[k];
-                if (P.results[i].status == G_RETRY) { GStoreSlab Q{P.scratch[t]}; gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]); }
+                if (P.retry ? P.retry[i] != 0 : P.results[i].status == G_RETRY) { GStoreSlab Q{P.scratch[t]}; gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]); }
             }
             return VGK_OK;
         }

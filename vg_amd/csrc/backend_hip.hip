@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(64, 4) gapless_kernel(const GaplessParams P, c
     GStoreSlab Q{P.scratch[t]};
     for (uint32_t k = t; k < P.n; k += threads) {
         const uint32_t i = P.order[k];
-        if (retry_only && P.results[i].status != G_RETRY) continue;
+        if (retry_only && !(P.retry ? P.retry[i] != 0 : P.results[i].status == G_RETRY)) continue;
         gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]);
     }
 }
@@ -777,8 +777,14 @@ public:
         if (std::getenv("VGAMD_GAPLESS_SLAB_ONLY")) hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads, 0);
         else {
             hipLaunchKernelGGL(gapless_search_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads);
+            // the rules over the searched reads and the slab kernel over the few G_RETRY reads touch different reads (the rules skip
+            // G_RETRY, the slab kernel everything else; both take output space from the same atomic counters): side by side
+            hipEventRecord(side_done[0], stream);
+            hipStreamWaitEvent(side[0], side_done[0], 0);
+            hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, side[0], p, threads, 1);
+            hipEventRecord(side_done[1], side[0]);
             hipLaunchKernelGGL(gapless_rules_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
-            hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads, 1);
+            hipStreamWaitEvent(stream, side_done[1], 0);
         }
         hipEventRecord(bev[1], stream);
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;

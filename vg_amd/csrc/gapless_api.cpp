@@ -250,10 +250,12 @@ static int gapless_run_and_fetch(vgk_ctx* ctx, GaplessParams& P, uint32_t n, uin
     P.nodes = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_n);
     P.mism = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_m);
     P.counters = (unsigned long long*)dev(nullptr, 256);
+    P.retry = (uint8_t*)ctx->ensure_scratch(31, (size_t)n + 16);
     P.winners = (GExt*)dev(nullptr, sizeof(GExt) * (n_seed + 1));          // the searches' winners wait here for the rules kernel (248 B each; only the used ones are touched)
     if (!P.winners || !P.probs || !P.reads || !P.seeds || !P.order || !P.scratch || !P.cold || !P.results || !P.ext || !P.nodes || !P.mism || !P.counters) return cleanup(VGK_ENOMEM);
     int rc;
     if ((rc = be->zero(P.counters, 256))) return cleanup(rc);
+    if (!P.retry || (rc = be->zero(P.retry, (size_t)n + 16))) return cleanup(rc ? rc : VGK_ENOMEM);
     lap("order, uploads queued");
     if ((rc = be->run_gapless(P, threads))) return cleanup(rc);
     lap("uploads + kernels");

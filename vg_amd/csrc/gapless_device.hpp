@@ -273,6 +273,8 @@ struct GaplessParams {
     GCold*    cold;                   // likewise
     vgk_gapless_result* results;      // per problem (ext_begin indexes `ext`)
     vgk_extension* ext; uint32_t* nodes; uint32_t* mism;
+    uint8_t* retry;                   // [n]: 1 = the flat search handed the read to the slab kernel (kept apart from results[].status, which that kernel
+                                      // rewrites while the rules kernel runs beside it)
     unsigned long long* counters;     // [0] extensions, [1] nodes, [2] mismatches handed out, [3] reads the fast kernel passed on to the slab kernel, [4] reads handed to lanes (flat form)
     unsigned long long caps[3];
 };
@@ -930,7 +932,7 @@ VGK_HD void gapless_search_lane(const GaplessParams& P, ST& Q, GScratch& S, W& w
                     if (pi != NONE) {                                                        // this read's searches are over
                         vgk_gapless_result& out = P.results[pi];
                         out.status = status; out.n_ext = n_res; out.ext_begin = best_alignment; out.full_length = 0;
-                        if (status == G_RETRY) g_bump(P.counters + 3, 1);
+                        if (status == G_RETRY) { g_bump(P.counters + 3, 1); if (P.retry) P.retry[pi] = 1; }
                     }
                     const uint32_t k = wave.next_read(P);
                     if (k == NONE) { done = true; pi = NONE; break; }
@@ -974,11 +976,12 @@ VGK_HD void gapless_search_lane(const GaplessParams& P, ST& Q, GScratch& S, W& w
 }
 // the rules of one read over the winners its searches left
 VGK_HD void gapless_rules_one(const GaplessParams& P, uint32_t pi, uint8_t* order) {
+    if (P.retry && P.retry[pi]) return;                                        // the slab kernel's read (it may be at work on it right now): hands off
     const GProb pb = P.probs[pi];
     vgk_gapless_result& out = P.results[pi];
     const uint32_t n_res = out.n_ext, best_alignment = out.ext_begin;
     out.ext_begin = 0; out.n_ext = 0; out.full_length = 0;
-    if (out.status != VGK_OK || !pb.read_len || !pb.n_seeds) return;           // an error, or a read for the slab kernel (G_RETRY), or nothing to do
+    if (out.status != VGK_OK || !pb.read_len || !pb.n_seeds) return;           // an error, or nothing to do
     GCtx c; c.P = &P; c.seq = P.reads + pb.read_off; c.L = pb.read_len;
     const GWinArr RES{P.winners + pb.seed_off};
     gapless_set_rules(P, pi, pb, c, RES, n_res, best_alignment, order);
