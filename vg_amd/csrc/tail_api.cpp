@@ -270,7 +270,12 @@ static int tail_stage_impl(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_pe
             if (!rc) rc = be->run_tail_stage(S, TS_WINDOW);
             if (!rc) rc = be->sync();                                          // the packer runs on the copy stream
             vgk_batch* b = nullptr;
+            // The trees of a batch of reads are a few hundred thousand small problems: split over three rows-per-lane classes they make three
+            // launches that each leave the device half empty and finish at different times (measured: 4.7 ms; one class, K = 20: 3.8 ms).
+            // A million and more (bench.py --workload forest) fill it per class, and the per-problem choice wins again (35.5 vs 37.7 ms).
+            ctx->win_k_hint = nw < 400000u ? 20u : 0u;
             if (!rc) { lk.unlock(); rc = vgk_pack_windows_impl(ctx, forest->graph, d_seq, seq_bytes, d_win, nw, ops_per_problem, &b, true); lk.lock(); }
+            ctx->win_k_hint = 0;
             be->watch(1); be->sync(); ctx->tail_stage_ms[2] = be->watch_ms();
             wall("windows packed");
             if (!rc) { lk.unlock(); rc = vgk_gssw_run(b); if (!rc) rc = vgk_batch_sync(b); lk.lock(); }

@@ -146,7 +146,7 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     const uint32_t waves_cap = n / 2 + WIN_BUCKETS + 1;
     WinParams W{};
     W.g = dg->g; W.n = n; W.raw_bytes = reads_bytes; W.ops_per_problem = ops_per_problem;
-    W.forced_k = 0;
+    W.forced_k = ctx->win_k_hint;                 // (vgk_tail_stage: one rows-per-lane class for a batch too small to fill the device three times over)
     if (const char* e = std::getenv("VGAMD_ROWS_PER_LANE")) W.forced_k = (uint32_t)std::atoi(e);
     W.max_score = ctx->max_score; W.max_bonus = ctx->max_bonus; W.scale = ctx->scale; W.bonus = ctx->sc.full_length_bonus;
     W.n_waves_cap = waves_cap;
