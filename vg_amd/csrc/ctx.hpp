@@ -43,11 +43,13 @@ struct vgk_ctx {
     // what the last vgk_gapless_extend(_seeded) call left in HBM: its inputs (descriptors, masked reads) and its sets in problem order —
     // vgk_tail_stage derives the tails from there
     struct Sets { bool valid = false; uint32_t n = 0; uint64_t n_ext = 0; const void* probs = nullptr; const char* reads = nullptr;
-                  const void* res = nullptr; const void* ext = nullptr; const uint32_t* nodes = nullptr; const void* index = nullptr; } sets;
+                  const void* res = nullptr; const void* ext = nullptr; const uint32_t* nodes = nullptr; const void* index = nullptr;
+                  const uint32_t* read_of = nullptr; } sets;      // read_of[e]: the read extension e belongs to
     // VGK_GAPLESS_DEFER: the sets of that call are still on their way down (fetch stream -> page-locked staging) and have yet to be
     // copied into the caller's arrays; finished by vgk_tail_stage*, vgk_gapless_fetch_deferred, or the next extension call
     struct DeferredSpan { char* dst; const char* src; size_t bytes; };
-    struct Deferred { bool pending = false; DeferredSpan spans[4] = {}; void* ev = nullptr; } deferred;
+    struct Deferred { bool pending = false, queued = false; DeferredSpan spans[4] = {}; const void* from[4] = {}; void* ev = nullptr; } deferred;
+    int start_deferred();          // queue the copies on the fetch stream (behind everything the main stream holds now)
     int finish_deferred();
     double minimizer_ms = 0;       // device time of the last vgk_minimizer_seeds call
     double tail_stage_ms[4] = {0, 0, 0, 0};   // last vgk_tail_stage: tails derived | forest | windows packed | kernels + totals

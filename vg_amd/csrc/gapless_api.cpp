@@ -51,10 +51,20 @@ struct Arrival { int32_t pred; uint32_t order, seq, pos; };
 }  // namespace
 
 // the sets of a VGK_GAPLESS_DEFER call: wait for the copies, then out of the staging buffers in slices on the host threads (context lock held)
+int vgk_ctx::start_deferred() {
+    if (!deferred.pending || deferred.queued) return VGK_OK;
+    deferred.queued = true;
+    if (!deferred.ev) deferred.ev = be->event_create();
+    int rc = be->event_record(deferred.ev);
+    if (!rc) rc = be->fetch_after(deferred.ev);
+    for (int k = 0; k < 4 && !rc; ++k) if (deferred.spans[k].bytes) rc = be->download_fetch_async(const_cast<char*>(deferred.spans[k].src), deferred.from[k], deferred.spans[k].bytes);
+    return rc;
+}
 int vgk_ctx::finish_deferred() {
     if (!deferred.pending) return VGK_OK;
+    int rc = start_deferred();
     deferred.pending = false;
-    const int rc = be->sync_fetch();
+    if (!rc) rc = be->sync_fetch();
     if (rc) return rc;
     std::vector<DeferredSpan> slices;
     for (const DeferredSpan& sp : deferred.spans) for (size_t at = 0; at < sp.bytes; at += (size_t)8 << 20) slices.push_back({sp.dst + at, sp.src + at, std::min<size_t>((size_t)8 << 20, sp.bytes - at)});
@@ -276,7 +286,8 @@ static int gapless_run_and_fetch(vgk_ctx* ctx, GaplessParams& P, uint32_t n, uin
     O.res_out = (vgk_gapless_result*)ctx->ensure_scratch(27, sizeof(vgk_gapless_result) * (size_t)n);
     O.ext_out = (vgk_extension*)ctx->ensure_scratch(28, sizeof(vgk_extension) * (ne + 1));
     O.nodes_out = (uint32_t*)ctx->ensure_scratch(29, sizeof(uint32_t) * (nn + nm + 2));
-    if (!tab || !O.res_out || !O.ext_out || !O.nodes_out) return cleanup(VGK_ENOMEM);
+    O.read_of = (uint32_t*)ctx->ensure_scratch(59, sizeof(uint32_t) * (ne + 1));
+    if (!tab || !O.res_out || !O.ext_out || !O.nodes_out || !O.read_of) return cleanup(VGK_ENOMEM);
     O.mism_out = O.nodes_out + nn + 1;
     const size_t n1 = (size_t)n + 1;
     O.size_e = tab; O.size_n = tab + n1; O.size_m = tab + 2 * n1; O.off_e = tab + 3 * n1; O.off_n = tab + 4 * n1; O.off_m = tab + 5 * n1;
@@ -288,7 +299,7 @@ static int gapless_run_and_fetch(vgk_ctx* ctx, GaplessParams& P, uint32_t n, uin
     for (int k = 0; k < 3; ++k) if ((rc = be->download(&tot[k], tab + (3 + k) * n1 + n, sizeof(uint32_t)))) return cleanup(rc);
     const size_t we = tot[0], wn = tot[1], wm = tot[2];
     ctx->sets.valid = true; ctx->sets.n = n; ctx->sets.n_ext = tot[0]; ctx->sets.probs = P.probs; ctx->sets.reads = P.reads;
-    ctx->sets.res = O.res_out; ctx->sets.ext = O.ext_out; ctx->sets.nodes = O.nodes_out; ctx->sets.index = nullptr;
+    ctx->sets.res = O.res_out; ctx->sets.ext = O.ext_out; ctx->sets.nodes = O.nodes_out; ctx->sets.index = nullptr; ctx->sets.read_of = O.read_of;
     int rc_all = VGK_OK;
     vgk_gapless_result* dres = H.dres.get(be, n);
     vgk_extension* dext = H.dext.get(be, we + 1); uint32_t* dnodes = H.dnodes.get(be, wn + 1); uint32_t* dmism = H.dmism.get(be, wm + 1);
@@ -297,12 +308,10 @@ static int gapless_run_and_fetch(vgk_ctx* ctx, GaplessParams& P, uint32_t n, uin
     if (fits && defer) {
         // VGK_GAPLESS_DEFER: the copies down are queued on the fetch stream behind the gather kernels and run while the caller's next
         // call (vgk_tail_stage*) keeps the device busy; that call copies them out of the staging buffers when it is done
-        if (!ctx->deferred.ev) ctx->deferred.ev = be->event_create();
-        if ((rc = be->event_record(ctx->deferred.ev)) || (rc = be->fetch_after(ctx->deferred.ev))) return cleanup(rc);
-        if ((rc = be->download_fetch_async(dres, O.res_out, sizeof(vgk_gapless_result) * n))) return cleanup(rc);
-        if (we && (rc = be->download_fetch_async(dext, O.ext_out, sizeof(vgk_extension) * we))) return cleanup(rc);
-        if (wn && (rc = be->download_fetch_async(dnodes, O.nodes_out, sizeof(uint32_t) * wn))) return cleanup(rc);
-        if (wm && (rc = be->download_fetch_async(dmism, O.mism_out, sizeof(uint32_t) * wm))) return cleanup(rc);
+        // (queued by vgk_tail_stage just before its fill kernels — VALU-bound, indifferent to the DMA; the small kernels before them ran
+        // twice as long beside the copies — or by whoever finishes the deferral first)
+        ctx->deferred.from[0] = O.res_out; ctx->deferred.from[1] = O.ext_out; ctx->deferred.from[2] = O.nodes_out; ctx->deferred.from[3] = O.mism_out;
+        ctx->deferred.queued = false;
         ctx->deferred.spans[0] = {(char*)results, (const char*)dres, sizeof(vgk_gapless_result) * n};
         ctx->deferred.spans[1] = {(char*)extensions, (const char*)dext, sizeof(vgk_extension) * we};
         ctx->deferred.spans[2] = {(char*)nodes, (const char*)dnodes, sizeof(uint32_t) * wn};

@@ -996,6 +996,7 @@ struct GOrderParams {
     uint32_t* size_e; uint32_t* size_n; uint32_t* size_m;                  // [n + 1] each, the last entry 0: the scans' inputs
     const uint32_t* off_e; const uint32_t* off_n; const uint32_t* off_m;    // their exclusive prefix sums
     vgk_gapless_result* res_out; vgk_extension* ext_out; uint32_t* nodes_out; uint32_t* mism_out;
+    uint32_t* read_of;                                                      // [extensions]: the read an extension belongs to (for vgk_tail_stage; nullable)
 };
 VGK_HD void g_order_sizes_one(const GOrderParams& P, uint32_t i) {
     const vgk_gapless_result r = P.res[i];
@@ -1015,6 +1016,7 @@ VGK_HD void g_order_gather_one(const GOrderParams& P, uint32_t i) {
             for (uint32_t j = 0; j < x.n_mismatches; ++j) P.mism_out[wm + j] = P.mism[x.mism_begin + j];
             x.path_begin = wn; x.mism_begin = wm;
             P.ext_out[r.ext_begin + k] = x;
+            if (P.read_of) P.read_of[r.ext_begin + k] = i;
             wn += x.path_len; wm += x.n_mismatches;
         }
     } else r.n_ext = 0;

@@ -171,19 +171,18 @@ static int tail_stage_impl(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_pe
     S.res = (const vgk_gapless_result*)ctx->sets.res; S.ext = (const vgk_extension*)ctx->sets.ext; S.nodes = ctx->sets.nodes;
     S.match = ctx->sc.matrix[0]; S.gap_open = ctx->sc.gap_open; S.gap_extend = ctx->sc.gap_extend; S.bonus = ctx->sc.full_length_bonus;
     const size_t e1 = (size_t)n_ext + 1;
-    uint32_t* tab = (uint32_t*)take(sizeof(uint32_t) * 5 * e1);
+    uint32_t* tab = (uint32_t*)take(sizeof(uint32_t) * 4 * e1);
     int32_t* d_ext_total = (int32_t*)take(sizeof(int32_t) * e1); int32_t* d_read_score = (int32_t*)take(sizeof(int32_t) * ((size_t)n + 1));
     unsigned long long* d_failed = (unsigned long long*)take(64);
     if (!tab || !d_ext_total || !d_read_score || !d_failed) return done(VGK_ENOMEM);
-    S.read_of = tab; S.cnt_r = tab + e1; S.cnt_l = tab + 2 * e1; S.off_r = tab + 3 * e1; S.off_l = tab + 4 * e1;
+    S.read_of = ctx->sets.read_of; S.cnt_r = tab; S.cnt_l = tab + e1; S.off_r = tab + 2 * e1; S.off_l = tab + 3 * e1;
     S.ext_total = d_ext_total; S.read_score = d_read_score; S.failed = d_failed;
     be->watch(0);
-    int rc = be->zero(tab, sizeof(uint32_t) * 5 * e1);
+    int rc = S.read_of ? be->zero(tab, sizeof(uint32_t) * 4 * e1) : VGK_EINVAL;
     if (!rc) rc = be->zero(d_failed, 64);
-    if (!rc) rc = be->run_tail_stage(S, TS_READS);
     if (!rc) rc = be->run_tail_stage(S, TS_COUNT);
-    if (!rc) rc = be->scan_u32(S.cnt_r, tab + 3 * e1, (uint32_t)e1);
-    if (!rc) rc = be->scan_u32(S.cnt_l, tab + 4 * e1, (uint32_t)e1);
+    if (!rc) rc = be->scan_u32(S.cnt_r, tab + 2 * e1, (uint32_t)e1);
+    if (!rc) rc = be->scan_u32(S.cnt_l, tab + 3 * e1, (uint32_t)e1);
     uint32_t tot_rl[2] = {0, 0};
     if (!rc) rc = be->download(&tot_rl[0], S.off_r + n_ext, sizeof(uint32_t));
     if (!rc) rc = be->download(&tot_rl[1], S.off_l + n_ext, sizeof(uint32_t));
@@ -278,6 +277,7 @@ static int tail_stage_impl(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_pe
             ctx->win_k_hint = 0;
             be->watch(1); be->sync(); ctx->tail_stage_ms[2] = be->watch_ms();
             wall("windows packed");
+            if (!rc) rc = ctx->start_deferred();                                // the extension sets of a VGK_GAPLESS_DEFER call travel under the fills
             if (!rc) { lk.unlock(); rc = vgk_gssw_run(b); if (!rc) rc = vgk_batch_sync(b); lk.lock(); }
             wall("fill + traceback");
             be->watch(0);

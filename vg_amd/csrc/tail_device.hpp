@@ -162,7 +162,7 @@ struct TStageParams {
     const GProb* probs; const char* reads;                        // the extension stage's inputs (masked reads, padded)
     const vgk_gapless_result* res; const vgk_extension* ext; const uint32_t* nodes;      // its sets, in problem order
     int32_t match, gap_open, gap_extend, bonus;
-    uint32_t* read_of;                                            // [n_ext]
+    const uint32_t* read_of;                                      // [n_ext]: the read an extension belongs to (the extension call's gather kernel wrote it)
     uint32_t* cnt_r; uint32_t* cnt_l; const uint32_t* off_r; const uint32_t* off_l; uint32_t total_r;      // [n_ext + 1] each
     vgk_tail_problem* problems; TMeta* meta; uint32_t n_tails;
     uint32_t* tail_len; const uint32_t* seq_off; char* seq;       // [n_tails + 1]; the tails' bases behind each other
@@ -185,20 +185,16 @@ VGK_HD int64_t t_longest_gap(const TStageParams& P, int64_t read_length, int64_t
     return (gap >= 0 && overhang > 0) ? gap : 0;
 }
 VGK_HD char t_comp(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return c; } }
-// stage 0, per read: which read an extension belongs to; its total starts as its own score
-VGK_HD void tstage_reads_one(const TStageParams& P, uint32_t i) {
-    const vgk_gapless_result r = P.res[i];
-    for (uint32_t k = 0; k < r.n_ext; ++k) { P.read_of[r.ext_begin + k] = i; P.ext_total[r.ext_begin + k] = P.ext[r.ext_begin + k].score; }
-}
 VGK_HD bool tstage_open(const TStageParams& P, uint32_t e, const vgk_extension& x) {
     const vgk_gapless_result r = P.res[P.read_of[e]];
     return r.status == VGK_OK && !r.full_length && x.path_len;      // full-length sets are scored as they are (:5440)
 }
-// stage 1, per extension: does it have a right / a left tail
+// stage 1, per extension: does it have a right / a left tail (stage 0, the extension -> read table, is the extension call's: read_of)
 VGK_HD void tstage_count_one(const TStageParams& P, uint32_t e) {
     const vgk_extension x = P.ext[e];
     const bool open = tstage_open(P, e, x);
     P.cnt_r[e] = open && !x.right_full ? 1u : 0u; P.cnt_l[e] = open && !x.left_full ? 1u : 0u;
+    P.ext_total[e] = x.score;                                      // the total starts as the extension's own score
 }
 // stage 2, per extension: its tail problems
 VGK_HD void tstage_tails_one(const TStageParams& P, uint32_t e) {
@@ -310,14 +306,14 @@ VGK_HD void tstage_read_one(const TStageParams& P, uint32_t i) {
     for (uint32_t k = 0; k < r.n_ext; ++k) { const int32_t v = P.ext_total[r.ext_begin + k]; best = v > best ? v : best; }
     P.read_score[i] = best;
 }
-enum { TS_READS = 0, TS_COUNT, TS_TAILS, TS_BASES, TS_ROOT_FLAG, TS_ROOT_POS, TS_WINDOW, TS_BEST, TS_TOTAL, TS_READ, TS_OPS_COUNT, TS_OPS_COPY };
+enum { TS_COUNT = 1, TS_TAILS, TS_BASES, TS_ROOT_FLAG, TS_ROOT_POS, TS_WINDOW, TS_BEST, TS_TOTAL, TS_READ, TS_OPS_COUNT, TS_OPS_COPY };
 VGK_HD uint32_t tstage_items(const TStageParams& P, int what) {
-    switch (what) { case TS_READS: case TS_READ: return P.n_reads; case TS_COUNT: case TS_TAILS: return P.n_ext; case TS_BASES: case TS_TOTAL: case TS_OPS_COUNT: case TS_OPS_COPY: return P.n_tails;
+    switch (what) { case TS_READ: return P.n_reads; case TS_COUNT: case TS_TAILS: return P.n_ext; case TS_BASES: case TS_TOTAL: case TS_OPS_COUNT: case TS_OPS_COPY: return P.n_tails;
                     case TS_ROOT_FLAG: case TS_ROOT_POS: return P.n_nodes; default: return P.n_trees; }
 }
 VGK_HD void tstage_one(const TStageParams& P, int what, uint32_t i) {
     switch (what) {
-        case TS_READS: tstage_reads_one(P, i); break; case TS_COUNT: tstage_count_one(P, i); break; case TS_TAILS: tstage_tails_one(P, i); break;
+        case TS_COUNT: tstage_count_one(P, i); break; case TS_TAILS: tstage_tails_one(P, i); break;
         case TS_BASES: tstage_bases_one(P, i); break; case TS_ROOT_FLAG: tstage_root_flag_one(P, i); break; case TS_ROOT_POS: tstage_root_pos_one(P, i); break;
         case TS_WINDOW: tstage_window_one(P, i); break; case TS_BEST: tstage_best_one(P, i); break; case TS_TOTAL: tstage_total_one(P, i); break;
         case TS_OPS_COUNT: tstage_ops_count_one(P, i); break; case TS_OPS_COPY: tstage_ops_copy_one(P, i); break;
