@@ -394,6 +394,34 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
     elapsed = time.perf_counter() - t0
     if from_reads:
         seeds_per_read = float(np.diff(step_seed_off[0]).mean())
+    # Steady state of a caller that keeps two batches in flight (vg's many-threads-one-process pattern): two engine contexts, one host
+    # thread each, the same stage on alternate batches — one context's seeding (VALU-bound) runs under the other's extension (issue- and
+    # latency-bound) and its copies under the other's kernels.  Reported beside `value`, which stays the one-batch-at-a-time rate.
+    two_contexts = None
+    if from_reads and stay and device_tails and world == 1 and not os.environ.get("VGAMD_GIRAFFE_ONE_CONTEXT"):
+        import threading
+        eng_b = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5)); eng_b.reuse_outputs = True
+        index_b = eng_b.haplo_index(wl.nodes, wl.threads); mindex_b = eng_b.minimizer_index(wl.nodes, wl.threads)
+        lanes = [(eng, index, mindex), (eng_b, index_b, mindex_b)]
+
+        def lane_steps(lane, count, sink):
+            e, hi, mi = lane
+            for _ in range(count):
+                so, _, _ = e.minimizer_seeds(mi, hi, wl.gs.reads, wl.gs.read_off, keep_on_device=True)
+                sink.append(pipeline.align_stage_device(e, hi, wl.gs, seeded=int(so[-1]), aligned=with_alignments))
+        for lane in lanes:
+            lane_steps(lane, 1, [])                                       # warm both contexts
+        per_lane = max(1, (args.steps + 1) // 2)
+        sinks = [[], []]
+        barrier()
+        t1 = time.perf_counter()
+        th = [threading.Thread(target=lane_steps, args=(lanes[k], per_lane, sinks[k])) for k in range(2)]
+        for t in th: t.start()
+        for t in th: t.join()
+        barrier()
+        t_two = time.perf_counter() - t1
+        same = all((s[-1]["read_score"] == out["read_score"]).all() for s in sinks)
+        two_contexts = {"batches": 2 * per_lane, "ms_per_batch": 1e3 * t_two / (2 * per_lane), "reads_per_s": n * 2 * per_lane / t_two, "read_scores_equal_to_the_serial_run": bool(same)}
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -446,6 +474,7 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
                        "clusters_from": ("minimizer seeding on the device (k 29, w 11; %.1f seeds per read; index of %d minimizer k-mers built in %.1f s); %s" % (seeds_per_read, mindex.keys, t_index,
                                           "reads and seeds stay in HBM for the extension (vgk_gapless_extend_seeded)" if stay else "seeds via the host")) if from_reads else "seeds given (true positions)",
                        "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()},
+                       "two_contexts_in_flight": two_contexts,
                        "tail_alignments": ("returned: per tail the best tree's alignment, chosen on the device (vgk_tail_stage_aligned); %d tails, %d ops per step" % (len(out["tails"]), len(out["tail_ops"]))) if with_alignments else "scores only (vgk_tail_stage)",
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
             "roofline": {"bound": "hbm", "kernel": "gapless_search_kernel (the stage's largest kernel)", "limiter": "host glue and PCIe round trips between the stages, then memory latency (DESIGN.md §11, §17)",
