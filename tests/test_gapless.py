@@ -1,5 +1,7 @@
 """Haplotype-consistent gapless extension: the oracle against the reference's known-answer tests
 (src/unittest/gbwt_extender.cpp:868-1158, transcribed by hand below with their line numbers)."""
+import subprocess
+
 import numpy as np
 import pytest
 
@@ -372,3 +374,30 @@ def test_output_arrays_too_small_are_reported_not_overrun():
         small.ext_cap = 20
         with pytest.raises(capi.VgkError, match="too small"):
             eng.gapless_extend(idx, small)
+
+
+def test_reads_gathered_or_uploaded_in_a_row_give_the_same_sets(monkeypatch):
+    """vgk_gapless_extend uploads reads and seeds straight from the caller's buffers when they lie behind each other in problem order
+    (GaplessSet builds them so) and gathers them into staging otherwise (VGAMD_GAPLESS_GATHER forces that path): same results, and a
+    batch whose reads are NOT in a row (problem order reversed over the same buffers) takes the gather path by itself"""
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    rng = np.random.default_rng(77)
+    nodes, threads, problems = random_haplotype_case(rng, n_reads=300)
+    eng = capi.Engine(lib=util.EMU_LIB)
+    idx = eng.haplo_index(nodes, threads)
+    gs = capi.GaplessSet.from_lists(problems)
+    a = eng.gapless_extend(idx, gs)
+    monkeypatch.setenv("VGAMD_GAPLESS_GATHER", "1")
+    b = eng.gapless_extend(idx, gs)
+    monkeypatch.delenv("VGAMD_GAPLESS_GATHER")
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()
+    back = capi.GaplessSet.from_lists(problems)
+    back.array[:] = back.array[::-1].copy()                            # same buffers, problems in reverse order: no longer in a row
+    c = eng.gapless_extend(idx, back)
+    ra, rc = a[0], c[0][::-1]
+    assert (ra["status"] == rc["status"]).all() and (ra["n_ext"] == rc["n_ext"]).all() and (ra["full_length"] == rc["full_length"]).all()
+    for i in range(len(ra)):
+        ea = a[1][ra["ext_begin"][i]:ra["ext_begin"][i] + ra["n_ext"][i]]; ec = c[1][rc["ext_begin"][i]:rc["ext_begin"][i] + rc["n_ext"][i]]
+        for f in ("offset", "read_begin", "read_end", "score", "path_len", "n_mismatches", "state"):
+            assert (ea[f] == ec[f]).all(), (i, f)

@@ -388,24 +388,49 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     // pack: masked reads (ReadMasker, src/gbwt_extender.cpp:160-176), seeds
     std::vector<GProb> probs(n);
     uint64_t n_read = 0, n_seed = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        const vgk_gapless_problem& p = problems[i];
-        if ((p.read_len && !p.read) || (p.n_seeds && !p.seeds)) return VGK_EINVAL;
-        probs[i] = {(uint32_t)n_read + 8, p.read_len, (uint32_t)n_seed, p.n_seeds, p.max_mismatches, p.flags, p.overlap_threshold};
-        n_read += p.read_len; n_seed += p.n_seeds;
+    // a batch caller's reads (and seeds) usually lie behind each other in one buffer, in problem order: then they go up as they are,
+    // straight from the caller's memory; otherwise they are gathered into page-locked staging first
+    bool reads_in_a_row = true, seeds_in_a_row = true; const char* read0 = nullptr; const vgk_seed* seed0 = nullptr;
+    {   // in slices on the host threads: sizes per slice, their prefix sums, then the descriptors
+        const uint32_t slices = std::min<uint32_t>(64u, (n + 16383u) / 16384u);
+        std::vector<uint64_t> sr((size_t)slices + 1, 0), ss((size_t)slices + 1, 0); std::vector<int> bad(slices, 0);
+        auto lo_of = [&](uint32_t c) { return (uint32_t)((uint64_t)n * c / slices); };
+        parallel_tasks(slices, [&](uint32_t c) {
+            uint64_t r = 0, s = 0;
+            for (uint32_t i = lo_of(c); i < lo_of(c + 1); ++i) { const vgk_gapless_problem& p = problems[i]; if ((p.read_len && !p.read) || (p.n_seeds && !p.seeds)) bad[c] = 1; r += p.read_len; s += p.n_seeds; }
+            sr[c + 1] = r; ss[c + 1] = s;
+        });
+        for (uint32_t c = 0; c < slices; ++c) { if (bad[c]) return VGK_EINVAL; sr[c + 1] += sr[c]; ss[c + 1] += ss[c]; }
+        n_read = sr[slices]; n_seed = ss[slices];
         if (n_read > 0xfffffff0ull || n_seed > 0xfffffff0ull) return VGK_ETOOBIG;
+        for (uint32_t i = 0; i < n && (!read0 || !seed0); ++i) {               // where the first read / seed lies (usually problem 0)
+            if (!read0 && problems[i].read_len) read0 = problems[i].read;      // (valid as the common base only if everything before it is empty: checked below)
+            if (!seed0 && problems[i].n_seeds) seed0 = problems[i].seeds;
+        }
+        std::vector<int> gap_r(slices, 0), gap_s(slices, 0);
+        parallel_tasks(slices, [&](uint32_t c) {
+            uint64_t r = sr[c], s = ss[c];
+            for (uint32_t i = lo_of(c); i < lo_of(c + 1); ++i) {
+                const vgk_gapless_problem& p = problems[i];
+                probs[i] = {(uint32_t)r + 8, p.read_len, (uint32_t)s, p.n_seeds, p.max_mismatches, p.flags, p.overlap_threshold};
+                if (p.read_len && p.read != read0 + r) gap_r[c] = 1;
+                if (p.n_seeds && p.seeds != seed0 + s) gap_s[c] = 1;
+                r += p.read_len; s += p.n_seeds;
+            }
+        });
+        for (uint32_t c = 0; c < slices; ++c) { if (gap_r[c]) reads_in_a_row = false; if (gap_s[c]) seeds_in_a_row = false; }
     }
+    if (std::getenv("VGAMD_GAPLESS_GATHER")) reads_in_a_row = seeds_in_a_row = false;
     if (!ctx->gapless_host) ctx->gapless_host = std::make_shared<GaplessHost>();
     GaplessHost& H = *static_cast<GaplessHost*>(ctx->gapless_host.get());
-    char* reads = H.reads.get(be, n_read + 16); vgk_seed* seeds = H.seeds.get(be, n_seed + 1);
-    if (!reads || !seeds) return VGK_ENOMEM;     // 8 bytes of padding at either end
-    std::memset(reads, 0, 8); std::memset(reads + 8 + n_read, 0, 8);
-    parallel_for(n, [&](uint32_t i, unsigned) {                       // (the masking itself happens on the device, over the uploaded bytes)
+    char* reads = reads_in_a_row ? nullptr : H.reads.get(be, n_read + 16); vgk_seed* seeds = seeds_in_a_row ? nullptr : H.seeds.get(be, n_seed + 1);
+    if ((!reads_in_a_row && !reads) || (!seeds_in_a_row && !seeds)) return VGK_ENOMEM;
+    if (!reads_in_a_row || !seeds_in_a_row) parallel_for(n, [&](uint32_t i, unsigned) {      // (the masking itself happens on the device, over the uploaded bytes)
         const vgk_gapless_problem& p = problems[i];
-        if (p.read_len) std::memcpy(reads + probs[i].read_off, p.read, p.read_len);
-        if (p.n_seeds) std::memcpy(seeds + probs[i].seed_off, p.seeds, sizeof(vgk_seed) * p.n_seeds);
+        if (reads && p.read_len) std::memcpy(reads + probs[i].read_off, p.read, p.read_len);
+        if (seeds && p.n_seeds) std::memcpy(seeds + probs[i].seed_off, p.seeds, sizeof(vgk_seed) * p.n_seeds);
     });
-    lap("reads masked, seeds copied");
+    lap("descriptors; reads and seeds gathered unless they lie in a row");
     // device buffers are kept on the context between calls (grow-only)
     int next_slot = 16;
     auto cleanup = [&](int rc) { return rc; };
@@ -417,23 +442,31 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     GaplessParams P{};
     P.index = index->dev; P.n = n;
     P.probs = (const GProb*)dev(probs.data(), sizeof(GProb) * n);
-    P.reads = (const char*)dev(reads, n_read + 16);
+    P.reads = (const char*)dev(nullptr, n_read + 16);                  // 8 bytes of padding at either end
+    if (P.reads && n_read && be->upload(const_cast<char*>(P.reads) + 8, reads_in_a_row ? read0 : reads + 8, n_read)) return VGK_ENODEV;
     if (P.reads && (be->mask_reads(const_cast<char*>(P.reads), n_read + 16) || be->zero(const_cast<char*>(P.reads), 8) || be->zero(const_cast<char*>(P.reads) + 8 + n_read, 8))) return VGK_ENODEV;
-    P.seeds = (const vgk_seed*)dev(seeds, sizeof(vgk_seed) * (n_seed + 1));
+    P.seeds = (const vgk_seed*)dev(nullptr, sizeof(vgk_seed) * (n_seed + 1));
+    if (P.seeds && n_seed && be->upload(const_cast<vgk_seed*>(P.seeds), seeds_in_a_row ? seed0 : seeds, sizeof(vgk_seed) * n_seed)) return VGK_ENODEV;
     // processing order: by the node of the first seed (a counting sort; reads without seeds last).  Results do not depend on it —
     // problems are independent and the sets are handed back in problem order below — but reads that sit next to each other in a
     // wavefront now walk the same records and bases, which the L2 then serves (FETCH_SIZE per million reads: see DESIGN.md §11)
-    std::vector<uint32_t> order(n);
-    {
+    // (made on the device from the uploaded descriptors and seeds: a kernel for the keys and a stable radix sort, as for the seeded form)
+    if (!P.probs || !P.reads || !P.seeds) return VGK_ENOMEM;
+    uint32_t* d_sort = (uint32_t*)ctx->ensure_scratch(next_slot++, sizeof(uint32_t) * 4 * (size_t)n);       // key, index, sorted key, order
+    if (!d_sort) return VGK_ENOMEM;
+    if (std::getenv("VGAMD_GAPLESS_UNSORTED")) {
+        std::vector<uint32_t> order(n); for (uint32_t i = 0; i < n; ++i) order[i] = i;
+        if (be->upload(d_sort + 3 * (size_t)n, order.data(), sizeof(uint32_t) * n) || be->sync()) return VGK_ENODEV;
+    } else {
         const uint32_t buckets = index->n_oriented / 2 + 2;
-        std::vector<uint32_t> start(buckets + 1, 0);
-        auto key = [&](uint32_t i) { const vgk_gapless_problem& p = problems[i]; const uint32_t v = p.n_seeds ? p.seeds[0].node / 2 : buckets - 1; return v < buckets - 1 ? v : buckets - 1; };
-        for (uint32_t i = 0; i < n; ++i) ++start[key(i) + 1];
-        for (uint32_t b = 0; b < buckets; ++b) start[b + 1] += start[b];
-        for (uint32_t i = 0; i < n; ++i) order[start[key(i)]++] = i;
+        int bits = 1; while ((1u << bits) < buckets && bits < 32) ++bits;
+        GSeededParams S{};
+        S.n = n; S.read_off = nullptr; S.seeds = P.seeds; S.buckets = buckets; S.probs = const_cast<GProb*>(P.probs); S.key = d_sort; S.idx = d_sort + n;
+        int rc = be->gapless_seeded(S);
+        if (!rc) rc = be->sort_pairs_u32(d_sort, d_sort + 2 * (size_t)n, d_sort + n, d_sort + 3 * (size_t)n, n, bits);
+        if (rc) return rc;
     }
-    if (std::getenv("VGAMD_GAPLESS_UNSORTED")) for (uint32_t i = 0; i < n; ++i) order[i] = i;
-    P.order = (const uint32_t*)dev(order.data(), sizeof(uint32_t) * n);
+    P.order = d_sort + 3 * (size_t)n;
     return gapless_run_and_fetch(ctx, P, n, n_seed, next_slot, H, lap, results, extensions, ext_cap, nodes, nodes_cap, mismatches, mism_cap, written);
 }
 

@@ -1035,10 +1035,12 @@ struct GSeededParams {
 };
 VGK_HD void g_seeded_one(const GSeededParams& P, uint32_t i) {
     GProb pb;
-    pb.read_off = (uint32_t)P.read_off[i] + 8u; pb.read_len = (uint32_t)(P.read_off[i + 1] - P.read_off[i]);
-    pb.seed_off = P.seed_off[i]; pb.n_seeds = P.seed_off[i + 1] - P.seed_off[i];
-    pb.max_mm = P.max_mm; pb.flags = P.flags; pb.overlap = P.overlap;
-    P.probs[i] = pb;
+    if (P.read_off) {
+        pb.read_off = (uint32_t)P.read_off[i] + 8u; pb.read_len = (uint32_t)(P.read_off[i + 1] - P.read_off[i]);
+        pb.seed_off = P.seed_off[i]; pb.n_seeds = P.seed_off[i + 1] - P.seed_off[i];
+        pb.max_mm = P.max_mm; pb.flags = P.flags; pb.overlap = P.overlap;
+        P.probs[i] = pb;
+    } else pb = P.probs[i];                            // the descriptors came from the host (vgk_gapless_extend): only the hand-out keys are made here
     const uint32_t v = pb.n_seeds ? P.seeds[pb.seed_off].node / 2u : P.buckets - 1u;       // the hand-out order: by the node of the first seed, reads without seeds last
     P.key[i] = v < P.buckets - 1u ? v : P.buckets - 1u; P.idx[i] = i;
 }
