@@ -377,7 +377,8 @@ typedef struct vgk_seed {            /* GaplessExtender::seed_type (src/gbwt_ext
     int32_t  diff;
 } vgk_seed;
 #define VGK_GAPLESS_TRIM 1u          /* extend(..., trim = true) */
-#define VGK_GAPLESS_DEFER 2u         /* vgk_gapless_extend_seeded only: return as soon as the sets are laid out on the device and their sizes
+#define VGK_GAPLESS_DEFER 2u         /* vgk_gapless_extend_seeded (in `flags`) and vgk_gapless_extend (in the flags of problems[0]: it is a
+                                        property of the call): return as soon as the sets are laid out on the device and their sizes
                                         (`written`) are known; the copies into results / extensions / nodes / mismatches run on a side stream and
                                         are complete when the NEXT vgk_tail_stage / vgk_tail_stage_aligned call on the context returns — they
                                         travel while that call keeps the device busy — or after vgk_gapless_fetch_deferred.  The arrays must

@@ -396,16 +396,22 @@ class Engine:
         """vgk_haplo_create_gbwt: the index from the image of a (simple-sds, bidirectional) GBWT file"""
         return HaploIndex(self, nodes, gbwt=gbwt_bytes)
 
-    def gapless_extend(self, index, problems):
+    def gapless_extend(self, index, problems, defer=False):
         """problems: a GaplessSet, or a list of dicts {read, seeds: [(oriented node, read_offset - node_offset)], max_mismatches?,
         overlap_threshold?, trim?}.  -> (results, extensions, nodes, mismatches) as numpy arrays laid out like include/vgk.h."""
         gs = problems if isinstance(problems, GaplessSet) else GaplessSet.from_lists(problems)
         res = self._out("g_res", gs.n, GAPLESS_RESULT_DT)
         ext = self._out("g_ext", gs.ext_cap, EXT_DT); nodes = self._out("g_nodes", gs.node_cap, np.uint32); mism = self._out("g_mism", gs.mism_cap, np.uint32)
         written = (ctypes.c_size_t * 3)()
-        self._check(self.lib.vgk_gapless_extend(self.h, index.h, gs.array.ctypes.data, gs.n, res.ctypes.data, ext.ctypes.data, gs.ext_cap,
-                                                nodes.ctypes.data, gs.node_cap, mism.ctypes.data, gs.mism_cap, ctypes.byref(written)),
-                    "vgk_gapless_extend")
+        if defer and gs.n:                                   # VGK_GAPLESS_DEFER rides on the first problem's flags (filled when the next tail_stage* call returns)
+            gs.array["flags"][0] |= VGK_GAPLESS_DEFER
+        try:
+            self._check(self.lib.vgk_gapless_extend(self.h, index.h, gs.array.ctypes.data, gs.n, res.ctypes.data, ext.ctypes.data, gs.ext_cap,
+                                                    nodes.ctypes.data, gs.node_cap, mism.ctypes.data, gs.mism_cap, ctypes.byref(written)),
+                        "vgk_gapless_extend")
+        finally:
+            if defer and gs.n:
+                gs.array["flags"][0] &= ~np.uint32(VGK_GAPLESS_DEFER)
         return res, ext[:written[0]], nodes[:written[1]], mism[:written[2]]
 
     def minimizer_index(self, nodes, threads, k=29, w=11):

@@ -412,7 +412,7 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
             uint64_t r = sr[c], s = ss[c];
             for (uint32_t i = lo_of(c); i < lo_of(c + 1); ++i) {
                 const vgk_gapless_problem& p = problems[i];
-                probs[i] = {(uint32_t)r + 8, p.read_len, (uint32_t)s, p.n_seeds, p.max_mismatches, p.flags, p.overlap_threshold};
+                probs[i] = {(uint32_t)r + 8, p.read_len, (uint32_t)s, p.n_seeds, p.max_mismatches, p.flags & ~(uint32_t)VGK_GAPLESS_DEFER, p.overlap_threshold};
                 if (p.read_len && p.read != read0 + r) gap_r[c] = 1;
                 if (p.n_seeds && p.seeds != seed0 + s) gap_s[c] = 1;
                 r += p.read_len; s += p.n_seeds;
@@ -467,7 +467,8 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
         if (rc) return rc;
     }
     P.order = d_sort + 3 * (size_t)n;
-    return gapless_run_and_fetch(ctx, P, n, n_seed, next_slot, H, lap, results, extensions, ext_cap, nodes, nodes_cap, mismatches, mism_cap, written);
+    return gapless_run_and_fetch(ctx, P, n, n_seed, next_slot, H, lap, results, extensions, ext_cap, nodes, nodes_cap, mismatches, mism_cap, written,
+                                 (problems[0].flags & VGK_GAPLESS_DEFER) != 0);        // (a property of the call, carried by its first problem)
 }
 
 // The clusters of the last vgk_minimizer_seeds call, extended without leaving the device in between: the reads it uploaded (masked,

@@ -221,7 +221,7 @@ def align_stage_device(eng, index, gs, ops_per_problem=32, timing=None, seeded=N
         # (deferred: the sets come down on a side stream while the tail stage runs; `ext` is sized already, filled when that call returns)
         res, ext, nodes, mism = eng.gapless_extend_seeded(index, gs.n, int(seeded), defer=True)
     else:
-        res, ext, nodes, mism = eng.gapless_extend(index, gs)
+        res, ext, nodes, mism = eng.gapless_extend(index, gs, defer=True)
     t1 = time.perf_counter()
     tails = tail_ops = None
     if aligned:
