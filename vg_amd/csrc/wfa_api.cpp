@@ -54,9 +54,15 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     WProb* probs = H.probs.get(be, n);
     if (!probs) return VGK_ENOMEM;
     uint64_t n_seq = 0;
-    for (uint32_t i = 0; i < n; ++i) {
+    // validation and descriptors in slices on the host threads; the sequence offsets from the slices' prefix sums afterwards
+    const uint32_t slices = std::min<uint32_t>(64u, (n + 8191u) / 8192u);
+    auto lo_of = [&](uint32_t c) { return (uint32_t)((uint64_t)n * c / slices); };
+    std::vector<uint64_t> slice_seq((size_t)slices + 1, 0); std::vector<int> slice_bad(slices, 0);
+    parallel_tasks(slices, [&](uint32_t c) {
+    uint64_t n_seq = 0;                                                              // (of this slice)
+    for (uint32_t i = lo_of(c); i < lo_of(c + 1); ++i) {
         const vgk_wfa_problem& p = problems[i];
-        if (p.seq_len && !p.seq) return VGK_EINVAL;
+        if (p.seq_len && !p.seq) { slice_bad[c] = 1; return; }
         WProb& w = probs[i];
         w.seq_off = (uint32_t)n_seq + 8; w.seq_len = p.seq_len; w.mode = p.mode;
         w.from_node = p.from_node; w.from_off = p.from_offset; w.to_node = p.to_node; w.to_off = p.to_offset;
@@ -80,8 +86,13 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
         }
         if (w.status != VGK_OK) w.seq_len = 0;
         n_seq += w.seq_len;
-        if (n_seq > 0xfffffff0ull) return VGK_ETOOBIG;
     }
+    slice_seq[c + 1] = n_seq;
+    });
+    for (uint32_t c = 0; c < slices; ++c) { if (slice_bad[c]) return VGK_EINVAL; slice_seq[c + 1] += slice_seq[c]; }
+    n_seq = slice_seq[slices];
+    if (n_seq > 0xfffffff0ull) return VGK_ETOOBIG;
+    parallel_tasks(slices, [&](uint32_t c) { const uint32_t add = (uint32_t)slice_seq[c]; if (add) for (uint32_t i = lo_of(c); i < lo_of(c + 1); ++i) probs[i].seq_off += add; });
     char* seqs = H.seqs.get(be, n_seq + 16);
     if (!seqs) return VGK_ENOMEM;
     std::memset(seqs, 0, 8); std::memset(seqs + 8 + n_seq, 0, 8);
@@ -104,10 +115,28 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     // each other in the graph run at the same time and find each other's records and bases in the L2 (mode 1), and long problems —
     // the expensive ones: the cost grows with the errors a sequence can hold — start first instead of leaving a tail of a few late
     // stragglers (mode 2; 3 = length classes of 32 bases, longest first, by node inside a class).  Results do not depend on it.
+    int mode = 3;
+    if (const char* e = std::getenv("VGAMD_WFA_ORDER")) mode = std::atoi(e);
+    const uint32_t n_graph_nodes = index->n_oriented / 2 + 1;
+    if (mode == 3 && n_graph_nodes <= (1u << 21)) {
+        // the default order as ONE stable radix sort on the device: key = length class (longest first, 11 bits) | node (21 bits); the
+        // keys are filled on the host threads, the sorted indices never come back (the two host counting sorts cost 5-8 ms per 500 k)
+        uint32_t* d_sort = (uint32_t*)ctx->ensure_scratch(next_slot++, sizeof(uint32_t) * 4 * (size_t)n);       // key, index, sorted key, order
+        if (!d_sort) return VGK_ENOMEM;
+        std::vector<uint32_t> keys(2 * (size_t)n);
+        parallel_for(n, [&](uint32_t i, unsigned) {
+            const WProb& w = probs[i];
+            const uint32_t v = (w.mode == (uint32_t)VGK_WFA_PREFIX ? w.to_node : w.from_node) / 2, node = v < n_graph_nodes ? v : n_graph_nodes - 1;
+            const uint32_t c = w.seq_len / 32;
+            keys[i] = ((2047u - (c < 2047u ? c : 2047u)) << 21) | node; keys[(size_t)n + i] = i;
+        });
+        if (be->upload(d_sort, keys.data(), sizeof(uint32_t) * 2 * (size_t)n)) return VGK_ENODEV;
+        if (int rc0 = be->sort_pairs_u32(d_sort, d_sort + 2 * (size_t)n, d_sort + n, d_sort + 3 * (size_t)n, n, 32)) return rc0;
+        if (be->sync()) return VGK_ENODEV;                                       // (keys goes out of scope)
+        P.order = d_sort + 3 * (size_t)n;
+    } else {
     std::vector<uint32_t> order(n);
     {
-        int mode = 3;
-        if (const char* e = std::getenv("VGAMD_WFA_ORDER")) mode = std::atoi(e);
         // two stable counting-sort passes (node, then length class): O(n), a few ms per million problems
         const uint32_t n_nodes = index->n_oriented / 2 + 1;
         auto node_of = [&](uint32_t i) { const WProb& w = probs[i]; const uint32_t v = (w.mode == (uint32_t)VGK_WFA_PREFIX ? w.to_node : w.from_node) / 2; return v < n_nodes ? v : n_nodes - 1; };
@@ -132,6 +161,8 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
         }
     }
     P.order = (const uint32_t*)dev(order.data(), sizeof(uint32_t) * n);
+    if (P.order && be->sync()) return VGK_ENODEV;                                // (order goes out of scope)
+    }
     // dense outputs; the kernel checks them
     const uint64_t cap_p = std::max<uint64_t>(path_cap, (uint64_t)n * 8 + n_seq / 4 + 1024) + 1, cap_e = std::max<uint64_t>(edit_cap, (uint64_t)n * 4 + 1024) + 1;
     P.caps[0] = cap_p; P.caps[1] = cap_e;
