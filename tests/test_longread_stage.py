@@ -44,3 +44,29 @@ def test_chain_stage_equals_the_oracles(emu_lib):
 def test_chain_stage_on_the_gpu_with_fallbacks_equals_the_oracles():
     wl, a = run(ENGINE_LIB, 60, 15000, 5, 0.02)
     assert len(a["failed"]) > 10 and (a["banded"]["status"] == 0).all()
+
+
+def fallbacks_picked_from_flat_connects(lib, n_reads, read_len, seed):
+    """chain_stage with the connects' subgraphs kept flat (LongReadWorkload.prepare_connects + BandedSet.select) = chain_stage assembling the
+    fallback batch problem by problem; a small WFA point budget makes sure there ARE fallbacks"""
+    outs = []
+    for flat in (False, True):
+        wl = workloads.LongReadWorkload(n_reads, seed=seed, graph_bp=150_000, read_len=read_len, sv_fraction=0.05)
+        if flat:
+            wl.prepare_connects()
+        eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=lib)
+        eng.wfa_set_point_budget(64)
+        outs.append(pipeline.chain_stage(eng, eng.haplo_index(wl.nodes, wl.threads), wl))
+    a, b = outs
+    assert len(a["failed"]) >= 3 and (a["failed"] == b["failed"]).all()
+    assert a["banded"].tobytes() == b["banded"].tobytes() and a["banded_ops"].tobytes() == b["banded_ops"].tobytes()
+    assert (a["chain_score"] == b["chain_score"]).all()
+
+
+def test_fallback_batch_picked_from_flat_connects(emu_lib):
+    fallbacks_picked_from_flat_connects(emu_lib, 8, 5000, 9)
+
+
+@pytest.mark.gpu
+def test_fallback_batch_picked_from_flat_connects_on_the_gpu():
+    fallbacks_picked_from_flat_connects(ENGINE_LIB, 40, 15000, 10)

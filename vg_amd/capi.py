@@ -242,6 +242,18 @@ class BandedSet(ProblemSet):
     def subset(self, k):
         raise NotImplementedError
 
+    def select(self, idx):
+        """the problems idx of this set as a set of their own over the SAME arenas (only the problem structs are copied): a caller that
+        keeps its extracted subgraphs flat picks a batch out of them without touching a base"""
+        idx = np.asarray(idx, dtype=np.int64)
+        s = object.__new__(type(self))
+        s.__dict__.update(self.__dict__)
+        s._arenas_of = self                                         # (keeps the arenas alive)
+        s.array = np.ascontiguousarray(self.array[idx]); s.n = len(idx)
+        rl = np.diff(self.read_off)[idx]; sl = np.diff(self.seq_off)[idx]; nn = self.array["graph"]["n_nodes"][idx].astype(np.int64)
+        s.ops_cap = int(rl.sum() + sl.sum() + 2 * nn.sum() + 8 * s.n)
+        return s
+
 
 class Engine:
     """One engine context = one (device, scoring) pair, like one vg Aligner."""
@@ -329,7 +341,9 @@ class Engine:
     def banded_align(self, bs):
         """vgk_banded_align over a BandedSet -> (results, ops); per-problem failures are reported in results['status']."""
         res = np.zeros(bs.n, dtype=RESULT_DT)
-        cap = int(np.diff(bs.read_off).sum() + np.diff(bs.seq_off).sum() + 2 * len(bs.node_len) + 8 * bs.n)
+        cap = getattr(bs, "ops_cap", None)
+        if cap is None:
+            cap = int(np.diff(bs.read_off).sum() + np.diff(bs.seq_off).sum() + 2 * len(bs.node_len) + 8 * bs.n)
         ops = np.zeros(max(cap, 1), dtype=OP_DT)
         written = ctypes.c_size_t()
         self._check(self.lib.vgk_banded_align(self.h, bs.ptr, bs.n, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written)),

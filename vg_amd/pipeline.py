@@ -200,7 +200,11 @@ def chain_stage(eng, index, wl, match=1, timing=None):
     score = np.where((res["status"] == 0) & (res["ok"] != 0), res["score"], 0).astype(np.int64)
     out = dict(wfa=res, failed=failed, declined_tails=np.nonzero((mode != capi.WFA_CONNECT) & (res["status"] != 0))[0])      # (a tail the engine declines scores 0 here: vg's own route for it is the pinned X-drop of §17)
     if len(failed):
-        bs = capi.BandedSet.from_lists([wl.between(int(i)) for i in failed]); lap("fallback problems (host)")
+        if getattr(wl, "connects", None) is not None:                 # the caller keeps the subgraphs between its anchors flat: pick the batch out of them
+            bs = wl.connects.select(wl.connect_row[failed])
+        else:
+            bs = capi.BandedSet.from_lists([wl.between(int(i)) for i in failed])
+        lap("fallback problems (host)")
         bres, bops = eng.banded_align(bs); lap("banded_align")
         score[failed] = np.where(bres["status"] == 0, bres["score"], 0)
         out.update(banded=bres, banded_ops=bops)

@@ -825,6 +825,16 @@ class LongReadWorkload:
         self.read_bases = int(seq_off[-1]) + int(self.anchor_bases.sum())
         self.hap_start = hap_start; self.thread_nodes = threads
 
+    def prepare_connects(self):
+        """every connect's graph between its anchors (between()) laid out once in one flat BandedSet: `connects`, `connect_row[i]` = problem
+        i's row in it (-1: not a connect).  What a caller holds after vg's extract_connecting_graph; chain_stage picks its fallback batch
+        out of it with BandedSet.select."""
+        from . import capi
+        mode = self.ws.array["mode"]
+        idx = np.nonzero(mode == capi.WFA_CONNECT)[0]
+        self.connects = capi.BandedSet.from_lists([self.between(int(i)) for i in idx])
+        self.connect_row = np.full(len(mode), -1, dtype=np.int64); self.connect_row[idx] = np.arange(len(idx))
+
     def between(self, i):
         """the graph between problem i's anchors as a banded-global problem on the FORWARD strand: every node of the topological order from
         the node of the first flanking base to the node of the last, the outer two cut at the flanks; the sequence reverse-complemented
