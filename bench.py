@@ -265,8 +265,9 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
         wl.prepare_connects()               # the graphs between the anchors, extracted once and kept flat: a step picks its fallback batch out of them
     t_gen = time.perf_counter() - t0
     index = eng.haplo_index(wl.nodes, wl.threads)
-    budget = int(os.environ.get("VGAMD_WFA_POINT_BUDGET", "256"))             # give up early on what will outgrow the tables: it goes to the banded aligner anyway
-    eng.wfa_set_point_budget(budget)
+    budget = int(os.environ.get("VGAMD_WFA_POINT_BUDGET", "128"))             # give up early on what will outgrow the tables: it goes to the banded aligner anyway
+    tail_budget = int(os.environ.get("VGAMD_WFA_TAIL_BUDGET", "512"))           # prefixes / suffixes have no banded fallback in this stage: a budget of their own
+    eng.wfa_set_point_budgets(budget, tail_budget)
 
     def barrier():
         torch.cuda.synchronize()
@@ -316,7 +317,7 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
                        "timed_region": "per step, from host buffers: vgk_wfa_extend over every stretch, the fallback batch picked out of the connects' subgraphs, kept flat (the subgraph between two anchors is extracted "
                                        "once per problem, outside the steps: vg's extract_connecting_graph), vgk_banded_align",
                        "problems": wl.n, "problems_per_read": wl.n / n, "read_bases": wl.read_bases, "bases_per_s": wl.read_bases * world * args.steps / elapsed,
-                       "wfa_ok": int((res["ok"] != 0).sum()), "fallbacks": int(len(out["failed"])), "wfa_point_budget": budget or 1024, "wfa_declined_by_engine_tables": int((res["status"] != 0).sum()),
+                       "wfa_ok": int((res["ok"] != 0).sum()), "fallbacks": int(len(out["failed"])), "wfa_point_budget": budget or 1024, "wfa_tail_point_budget": tail_budget or 1024, "wfa_declined_by_engine_tables": int((res["status"] != 0).sum()),
                        "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()}, "wfa_kernel_ms": eng.lib.vgk_wfa_last_ms(eng.h) if hasattr(eng.lib, "vgk_wfa_last_ms") else None,
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
             "roofline": {"bound": "hbm", "kernel": "wfa_kernel", "limiter": "the critical path of the slowest problem of a launch, then memory latency (DESIGN.md §16)",

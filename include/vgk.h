@@ -498,6 +498,9 @@ double vgk_wfa_last_ms(vgk_ctx* ctx);        /* kernel time of the last vgk_wfa_
  * caller takes the route it takes for every declined problem (BandedGlobalAligner between the anchors, as vg does
  * when WFAExtender fails).  0 = the table's size (the default).  Results of the problems that stay within the budget do not change. */
 int    vgk_wfa_set_point_budget(vgk_ctx* ctx, uint32_t points);
+/* The same with one budget for connects — which have that fallback — and one for prefixes / suffixes, which a caller wants answered
+ * (vgk_wfa_set_point_budget(p) = vgk_wfa_set_point_budgets(p, p)). */
+int    vgk_wfa_set_point_budgets(vgk_ctx* ctx, uint32_t connect_points, uint32_t tail_points);
 
 /* batch introspection (used by bench.py for the roofline line) */
 void     vgk_batch_free(vgk_batch* batch);

@@ -533,6 +533,10 @@ class Engine:
                                             ctypes.byref(written)), "vgk_wfa_extend")
         return res, paths[:written[0]], edits[:written[1]]
 
+    def wfa_set_point_budgets(self, connect_points, tail_points):
+        self.lib.vgk_wfa_set_point_budgets.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+        self._check(self.lib.vgk_wfa_set_point_budgets(self.h, connect_points, tail_points), "vgk_wfa_set_point_budgets")
+
     def wfa_set_point_budget(self, points):
         """problems that store more than `points` wavefront points are declined (VGK_ETOOBIG) early; 0 = the kernel's table size"""
         self.lib.vgk_wfa_set_point_budget.argtypes = [ctypes.c_void_p, ctypes.c_uint32]

@@ -167,6 +167,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     const uint64_t cap_p = std::max<uint64_t>(path_cap, (uint64_t)n * 8 + n_seq / 4 + 1024) + 1, cap_e = std::max<uint64_t>(edit_cap, (uint64_t)n * 4 + 1024) + 1;
     P.caps[0] = cap_p; P.caps[1] = cap_e;
     P.max_points = ctx->wfa_point_budget && ctx->wfa_point_budget < (uint32_t)W_POINTS ? ctx->wfa_point_budget : (uint32_t)W_POINTS;
+    P.max_points_tail = ctx->wfa_point_budget_tail && ctx->wfa_point_budget_tail < (uint32_t)W_POINTS ? ctx->wfa_point_budget_tail : (uint32_t)W_POINTS;
     uint64_t per_cu = 1024;         // 16 wavefronts per CU: the kernel is built for at most 128 VGPRs (__launch_bounds__(64, 4))
     if (const char* e = std::getenv("VGAMD_WFA_THREADS_PER_CU")) per_cu = (uint64_t)std::max(64, std::atoi(e));
     const uint32_t threads = (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max(1, be->compute_units()) * per_cu);
@@ -231,6 +232,11 @@ int vgk_wfa_rerun(vgk_ctx* ctx) {
 }
 
 double vgk_wfa_last_ms(vgk_ctx* ctx) { return ctx ? ctx->wfa_ms : 0.0; }
-int vgk_wfa_set_point_budget(vgk_ctx* ctx, uint32_t points) { if (!ctx) return VGK_EINVAL; std::lock_guard<std::mutex> lock(ctx->mu); ctx->wfa_point_budget = points; return VGK_OK; }
+int vgk_wfa_set_point_budget(vgk_ctx* ctx, uint32_t points) { return vgk_wfa_set_point_budgets(ctx, points, points); }
+int vgk_wfa_set_point_budgets(vgk_ctx* ctx, uint32_t connect_points, uint32_t tail_points) {
+    if (!ctx) return VGK_EINVAL;
+    std::lock_guard<std::mutex> lock(ctx->mu); ctx->wfa_point_budget = connect_points; ctx->wfa_point_budget_tail = tail_points;
+    return VGK_OK;
+}
 
 }  // extern "C"

@@ -87,7 +87,8 @@ struct WfaParams {
     uint32_t* paths; uint32_t* edits;
     unsigned long long* counters;     // [0] path entries, [1] edits handed out, [2] next problem
     unsigned long long caps[2];
-    uint32_t max_points;              // stored wavefront points after which a problem is given up (<= W_POINTS; vgk_wfa_set_point_budget)
+    uint32_t max_points;              // stored wavefront points after which a connect is given up (<= W_POINTS; vgk_wfa_set_point_budget) ...
+    uint32_t max_points_tail;         // ... and a prefix / suffix (vgk_wfa_set_point_budgets; a declined tail has no banded fallback between two anchors)
 };
 
 struct WPos { uint32_t seq, off; uint8_t cur, origin; bool empty; };
@@ -100,7 +101,7 @@ struct WCtx {
     uint32_t* end; uint32_t end_stride;                           // node_end word of trie node i at end[i * end_stride]
     const char* seq; uint32_t L;
     int32_t to_node; uint32_t to_off; bool no_to;
-    uint32_t n_nodes, n_path, n_points;
+    uint32_t n_nodes, n_path, n_points, max_points;
     uint32_t leaves;                  // trie nodes without children (WFANode::is_leaf: a dead end has none either)
     int32_t cand_score, cand_diag; uint32_t cand_seq, cand_off, cand_node;
     int32_t max_distance, min_distance;
@@ -143,7 +144,7 @@ VGK_HD void w_store(WCtx& c, uint32_t node, int kind, int32_t score, int32_t dia
     for (uint32_t i = w_hash(key);; i = (i + 1) & (W_SLOTS - 1)) {
         const uint64_t s = c.S->slot[i];
         if (!s) {
-            if (c.n_points >= c.P->max_points) { c.overflow = true; c.why = 1; return; }
+            if (c.n_points >= c.max_points) { c.overflow = true; c.why = 1; return; }
             c.S->log[c.n_points++] = (uint16_t)i; c.S->slot[i] = v; return;
         }
         if ((uint32_t)(s >> 32) == key) { c.S->slot[i] = v; return; }
@@ -501,6 +502,7 @@ VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S, uint32_t
     c.P = &P; c.S = &S; c.end = end; c.end_stride = end_stride; c.seq = P.seqs + pb.seq_off; c.L = pb.seq_len;
     c.no_to = pb.to_node == VGK_WFA_NO_NODE; c.to_node = (int32_t)pb.to_node; c.to_off = pb.to_off;
     c.n_nodes = 0; c.n_path = 0; c.n_points = 0; c.leaves = 0; c.overflow = false; c.why = 0;
+    c.max_points = c.no_to ? P.max_points_tail : P.max_points;
     c.cand_score = 0x7fffffff; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0;
     c.max_distance = 0; c.min_distance = 0;
     const int32_t top_score = pb.score_bound + P.gap_open + P.gap_extend + P.mismatch;               // the host keeps this below W_SCORES
