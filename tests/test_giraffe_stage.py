@@ -58,11 +58,53 @@ def run_stage(lib, n, seed, graph_bp, inserted):
         got = (int(tl["ext"]), int(tl["left"]), int(tl["read_begin"]), int(tl["read_end"]), int(tl["score"]), int(tl["first_offset"]),
                [(int(x["node"]), int(x["op"]), int(x["len"])) for x in ops])
         assert got == wrow, (i, got, wrow)
-    # the ops of a tail spell a walk of the graph that the tail's bases fit: the aligned read bases add up to at most the tail
+    # size-independent properties of every returned alignment: its read bases fit the tail (pinned at the extension: all of them unless
+    # the end is soft-clipped), it starts inside its first node, consecutive nodes are steps some haplotype takes, the graph bases it
+    # spends on a node fit the node, and re-scoring its ops against the sequences gives its score
+    lens = [len(s) for s in wl.nodes]
+    steps = set()
+    for t in wl.threads:
+        for x, y in zip(t[:-1], t[1:]):
+            steps.add((x, y)); steps.add((y ^ 1, x ^ 1))
+    comp = str.maketrans("ACGT", "TGCA")
+    oseq = lambda o: wl.nodes[o >> 1] if not (o & 1) else wl.nodes[o >> 1].translate(comp)[::-1]
+    reads_flat = wl.gs.reads.tobytes().decode(); roff = wl.gs.read_off
+    read_of_ext = np.repeat(np.arange(len(e["res"])), e["res"]["n_ext"])
+    rescored = 0
     for tl in tails:
         ops = tops[tl["ops_begin"]:tl["ops_begin"] + tl["n_ops"]]
-        used = int(ops["len"][ops["op"] != capi.OP_D].sum()) if len(ops) else 0
+        if not len(ops):
+            assert tl["score"] == 0
+            continue
+        used = int(ops["len"][ops["op"] != capi.OP_D].sum())
         assert used <= tl["read_end"] - tl["read_begin"]
+        assert tl["first_offset"] < lens[int(ops["node"][0]) >> 1] or int(ops["len"][0]) == 0
+        r = int(read_of_ext[tl["ext"]]); rd = reads_flat[roff[r]:roff[r + 1]]
+        tail = rd[tl["read_begin"]:tl["read_end"]]
+        if tl["left"]:
+            tail = tail.translate(comp)[::-1]
+        node = int(ops["node"][0]); off = int(tl["first_offset"]); at = 0; score = 0; prev_gap = None
+        for x in ops:
+            if int(x["node"]) != node:
+                assert (node, int(x["node"])) in steps, (node, int(x["node"]))
+                node = int(x["node"]); off = 0
+            n = int(x["len"]); kind = int(x["op"])
+            if kind == capi.OP_M:
+                g = oseq(node)[off:off + n]; assert len(g) == n
+                score += sum(1 if a == b and a in "ACGT" else -4 for a, b in zip(tail[at:at + n], g)); at += n; off += n; prev_gap = None
+            elif kind == capi.OP_I:
+                score -= (6 if prev_gap != kind else 1) + (n - 1); at += n; prev_gap = kind
+            elif kind == capi.OP_D:
+                assert off + n <= lens[node >> 1]
+                score -= (6 if prev_gap != kind else 1) + (n - 1); off += n; prev_gap = kind
+            else:
+                prev_gap = None                                        # a soft clip at the far end
+        if at == len(tail) and ops["op"][-1] == capi.OP_M:
+            score += 5                                                 # the full-length bonus at the tail's far end
+        if "N" not in tail:
+            assert score == tl["score"], (tl, ops, score)
+            rescored += 1
+    assert rescored > len(tails) // 2
     return wl, a
 
 
