@@ -426,6 +426,8 @@ class Engine:
         finally:
             if defer and gs.n:
                 gs.array["flags"][0] &= ~np.uint32(VGK_GAPLESS_DEFER)
+        if defer:
+            self._deferred_keep = (res, ext, nodes, mism)          # the engine still writes into them: alive until the deferral is finished
         return res, ext[:written[0]], nodes[:written[1]], mism[:written[2]]
 
     def minimizer_index(self, nodes, threads, k=29, w=11):
@@ -501,6 +503,8 @@ class Engine:
         self._check(self.lib.vgk_gapless_extend_seeded(self.h, index.h, max_mismatches, overlap_threshold, (VGK_GAPLESS_TRIM if trim else 0) | (VGK_GAPLESS_DEFER if defer else 0), res.ctypes.data,
                                                        ext.ctypes.data, ext_cap, nodes.ctypes.data, node_cap, mism.ctypes.data, mism_cap, ctypes.byref(written)),
                     "vgk_gapless_extend_seeded")
+        if defer:
+            self._deferred_keep = (res, ext, nodes, mism)          # the engine still writes into them: alive until the deferral is finished
         return res[:n_reads], ext[:written[0]], nodes[:written[1]], mism[:written[2]]
 
     def gapless_fetch_deferred(self):
