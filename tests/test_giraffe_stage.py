@@ -83,6 +83,23 @@ def run_stage(lib, n, seed, graph_bp, inserted):
         tail = rd[tl["read_begin"]:tl["read_end"]]
         if tl["left"]:
             tail = tail.translate(comp)[::-1]
+        # the tail's alignment continues its extension: it starts where the extension's matches stop — on the same node right behind the
+        # last matched base, or, when the match ran to the node's end, at the start of a node some haplotype steps to (a left tail:
+        # the same seen from the other strand, going outwards from the extension's first base)
+        x = e["ext"][tl["ext"]]
+        path = [int(v) for v in e["nodes"][x["path_begin"]:x["path_begin"] + x["path_len"]]]
+        matched = int(x["read_end"]) - int(x["read_begin"])
+        if not tl["left"]:
+            assert tl["read_begin"] == x["read_end"] and tl["read_end"] == len(rd)
+            last = path[-1]; cut = int(x["offset"]) + matched - sum(lens[v >> 1] for v in path[:-1])
+        else:
+            assert tl["read_begin"] == 0 and tl["read_end"] == x["read_begin"]
+            last = path[0] ^ 1; cut = lens[path[0] >> 1] - int(x["offset"])
+        first = int(ops["node"][0])
+        if cut < lens[last >> 1]:
+            assert first == last and tl["first_offset"] == cut, (tl, x, path)
+        else:
+            assert (last, first) in steps and tl["first_offset"] == 0, (tl, x, path)
         node = int(ops["node"][0]); off = int(tl["first_offset"]); at = 0; score = 0; prev_gap = None
         for x in ops:
             if int(x["node"]) != node:
