@@ -437,9 +437,11 @@ uint64_t vgk_minimizer_index_keys(const vgk_minimizer_index* index);      /* dis
 typedef struct vgk_minimizer_hit { uint64_t key; uint32_t node, offset; } vgk_minimizer_hit;
 uint64_t vgk_minimizer_index_hits(const vgk_minimizer_index* index);
 int  vgk_minimizer_index_fetch(const vgk_minimizer_index* index, vgk_minimizer_hit* hits, size_t cap);
-/* reads: flat, read i = reads[read_off[i], read_off[i + 1]).  seed_off[n + 1] and, nullable, minimizers[n] (minimizers per read) are
- * filled always; seeds up to seeds_cap (VGK_EOPS when that is too small; *written = the number needed); seeds = NULL with seeds_cap = 0
+/* reads: flat, read i = reads[read_off[i], read_off[i + 1]).  seed_off[n + 1] and, nullable, minimizers[n] (minimizers per read; with
+ * VGK_MINIMIZERS_TRUNCATED or'ed in when the read reached the cap of 64 seeds with hits of its minimizers left unexamined — the
+ * reference's find_seeds has no such cap, so a caller that sees the flag takes that read through its own path) are filled always; seeds up to seeds_cap (VGK_EOPS when that is too small; *written = the number needed); seeds = NULL with seeds_cap = 0
  * leaves them on the device only (for vgk_gapless_extend_seeded). */
+#define VGK_MINIMIZERS_TRUNCATED 0x80000000u
 int  vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* index, const vgk_haplo* graph, const char* reads, const uint64_t* read_off, uint32_t n,
                          uint32_t hit_cap, uint32_t* seed_off, uint32_t* minimizers, vgk_seed* seeds, size_t seeds_cap, size_t* written);
 double vgk_minimizer_last_ms(vgk_ctx* ctx);                              /* device time of the last vgk_minimizer_seeds call */

@@ -118,7 +118,7 @@ int vgk_minimizer_index_fetch(const vgk_minimizer_index* ix, vgk_minimizer_hit* 
     return VGK_OK;
 }
 
-typedef struct { const vgk_minimizer_index* ix; uint32_t hit_cap; vgk_seed seeds[64]; uint32_t n_seeds, n_min; } Query;
+typedef struct { const vgk_minimizer_index* ix; uint32_t hit_cap; vgk_seed seeds[64]; uint32_t n_seeds, n_min; int truncated; } Query;
 static void query_emit(void* c, uint32_t p, uint64_t key, uint64_t hash, int reverse) {
     Query* q = (Query*)c; const vgk_minimizer_index* ix = q->ix; (void)hash;
     ++q->n_min;
@@ -126,7 +126,8 @@ static void query_emit(void* c, uint32_t p, uint64_t key, uint64_t hash, int rev
     while (lo < hi) { const size_t mid = (lo + hi) / 2; if (ix->e[mid].key < key) lo = mid + 1; else hi = mid; }
     size_t end = lo; while (end < ix->n && ix->e[end].key == key) ++end;
     if (end == lo || end - lo > q->hit_cap) return;
-    for (size_t h = lo; h < end && q->n_seeds < 64; ++h) {
+    for (size_t h = lo; h < end; ++h) {
+        if (q->n_seeds >= 64) { q->truncated = 1; break; }                /* the cap: this hit and the rest are never looked at */
         vgk_seed s;
         if (!reverse) { s.node = ix->e[h].node; s.diff = (int32_t)p - (int32_t)ix->e[h].offset; }
         else { s.node = ix->e[h].node ^ 1u; s.diff = (int32_t)(p + ix->k - 1) - (int32_t)(ix->node_len[ix->e[h].node >> 1] - 1 - ix->e[h].offset); }
@@ -142,9 +143,9 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
     size_t total = 0; int rc = VGK_OK;
     if (seed_off) seed_off[0] = 0;
     for (uint32_t i = 0; i < n; ++i) {
-        Query q; q.ix = ix; q.hit_cap = hit_cap ? hit_cap : 0xffffffffu; q.n_seeds = 0; q.n_min = 0;
+        Query q; q.ix = ix; q.hit_cap = hit_cap ? hit_cap : 0xffffffffu; q.n_seeds = 0; q.n_min = 0; q.truncated = 0;
         minimizers(reads + read_off[i], (uint32_t)(read_off[i + 1] - read_off[i]), ix->k, ix->w, query_emit, &q);
-        if (mins) mins[i] = q.n_min;
+        if (mins) mins[i] = q.n_min | (q.truncated ? VGK_MINIMIZERS_TRUNCATED : 0u);
         if (total + q.n_seeds <= seeds_cap && seeds) memcpy(seeds + total, q.seeds, sizeof(vgk_seed) * q.n_seeds); else if (q.n_seeds) rc = VGK_EOPS;
         total += q.n_seeds; seed_off[i + 1] = (uint32_t)total;
     }

@@ -82,16 +82,22 @@ def build_index(nodes, threads, k, w):
     return {key: sorted(v) for key, v in index.items()}
 
 
-def seeds_of(read, index, nodes, k, w, hit_cap):
-    out = []
+def seeds_of(read, index, nodes, k, w, hit_cap, truncated=None):
+    """truncated: a list that receives True when the read reaches the cap of 64 seeds with hits still unexamined (VGK_MINIMIZERS_TRUNCATED)"""
+    out = []; cut = False
     for p, key, rev in minimizers(read, k, w):
         hits = index.get(key, [])
         if not hits or len(hits) > hit_cap:
             continue
         for node, off in hits:
+            if len(out) >= 64:
+                cut = True
+                break
             s = (node, p - off) if not rev else (node ^ 1, (p + k - 1) - (len(nodes[node >> 1]) - 1 - off))
-            if s not in out and len(out) < 64:
+            if s not in out:
                 out.append(s)
+    if truncated is not None:
+        truncated.append(cut)
     return out
 
 
@@ -119,7 +125,8 @@ def run(lib, seed, k, w, n_reads, hit_cap=500, L=100):
     reads, truth = sample_reads(rng, wl.nodes, wl.threads, n_reads, L)
     reads += ["ACGT" * 5, "", "A" * (k + w - 2)]                       # too short for a window: no minimizers
     index = build_index(wl.nodes, wl.threads, k, w)
-    expected = [seeds_of(r, index, wl.nodes, k, w, hit_cap) for r in reads]
+    cut = []
+    expected = [seeds_of(r, index, wl.nodes, k, w, hit_cap, cut) for r in reads]
     flat = np.frombuffer("".join(reads).encode(), dtype=np.uint8); off = np.concatenate([[0], np.cumsum([len(r) for r in reads])])
     eng = capi.Engine(lib=lib)
     mi = eng.minimizer_index(wl.nodes, wl.threads, k, w); hi = eng.haplo_index(wl.nodes, wl.threads)
@@ -129,6 +136,7 @@ def run(lib, seed, k, w, n_reads, hit_cap=500, L=100):
         got = [(int(s["node"]), int(s["diff"])) for s in seeds[seed_off[i]:seed_off[i + 1]]]
         assert got == exp, "read %d: %s vs %s" % (i, got[:6], exp[:6])
         assert mins[i] == len(minimizers(reads[i], k, w))
+        assert bool(eng.minimizers_truncated[i]) == cut[i], "read %d: truncated flag" % i
     # nearly every seed of a sampled read lies on its true diagonal (base j of the read is base a + j of the thread it came from); the rest
     # are hits that are just as true on another haplotype: the other allele of a SNP whose alleles agree with the read, a k-mer that ends on the
     # first base behind an insertion the read carries
@@ -310,3 +318,27 @@ def test_seeds_with_the_wide_window_of_the_reference_file(lib_name, emu_lib):
 def test_reference_minimizer_index_and_wide_window_on_the_gpu():
     wide_window_seeds(ENGINE_LIB, 200)
     run(ENGINE_LIB, 12, 31, 64, 80, L=300)          # the widest window the kernel takes
+
+
+def no_seed_batch(lib):
+    """A batch whose reads have no seed at all (all N, too short for a window) through the resident path: the seeded extension call gives
+    every read an empty set, as vgk_gapless_extend does for a problem without seeds — not an error (round 2's advisor finding: the seed
+    buffer did not exist for a batch without seeds and the extension call read that as out of memory)."""
+    wl = workloads.GaplessWorkload(4, seed=3, graph_bp=4000, n_haplotypes=4, snp_every=40, indel_every=300)
+    eng = capi.Engine(lib=lib)
+    mi = eng.minimizer_index(wl.nodes, wl.threads, 21, 7); hi = eng.haplo_index(wl.nodes, wl.threads)
+    reads = ["N" * 60, "ACGT" * 3, "N" * 30 + "ACGTACGTAC" + "N" * 30]
+    flat = np.frombuffer("".join(reads).encode(), dtype=np.uint8); off = np.concatenate([[0], np.cumsum([len(r) for r in reads])])
+    seed_off, seeds, mins = eng.minimizer_seeds(mi, hi, flat, off, keep_on_device=True)
+    assert seed_off[-1] == 0 and not eng.minimizers_truncated.any()
+    res, ext, nodes, mism = eng.gapless_extend_seeded(hi, len(reads), 0)
+    assert len(ext) == 0 and (res["n_ext"] == 0).all() and (res["status"] == 0).all()
+
+
+def test_a_batch_without_seeds_extends_to_empty_sets(emu_lib):
+    no_seed_batch(emu_lib)
+
+
+@pytest.mark.gpu
+def test_a_batch_without_seeds_extends_to_empty_sets_on_the_gpu():
+    no_seed_batch(ENGINE_LIB)

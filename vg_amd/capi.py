@@ -435,7 +435,8 @@ class Engine:
 
     def minimizer_seeds(self, mindex, hindex, reads, read_off, hit_cap=500, keep_on_device=False):
         """vgk_minimizer_seeds: reads flat (uint8), read i = reads[read_off[i]:read_off[i+1]] -> (seed_off [n+1], seeds as SEED_DT, minimizers per read);
-        keep_on_device: the seeds stay in HBM for gapless_extend_seeded (an empty seeds array comes back)"""
+        keep_on_device: the seeds stay in HBM for gapless_extend_seeded (an empty seeds array comes back).  `self.minimizers_truncated`: per
+        read, whether it reached the cap of 64 seeds with hits left unexamined (VGK_MINIMIZERS_TRUNCATED)"""
         reads = np.ascontiguousarray(reads, dtype=np.uint8); off = np.ascontiguousarray(read_off, dtype=np.uint64)
         n = len(off) - 1
         seed_off = self._out("mz_off", n + 1, np.uint32); mins = self._out("mz_mins", max(n, 1), np.uint32)
@@ -446,7 +447,8 @@ class Engine:
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         self._check(self.lib.vgk_minimizer_seeds(self.h, mindex.h, hindex.h, reads.ctypes.data, off.ctypes.data, n, hit_cap, seed_off.ctypes.data, mins.ctypes.data,
                                                  None if keep_on_device else seeds.ctypes.data, cap, ctypes.byref(written)), "vgk_minimizer_seeds")
-        return seed_off, seeds[:0 if keep_on_device else written.value], mins[:n]
+        self.minimizers_truncated = (mins[:n] & 0x80000000) != 0
+        return seed_off, seeds[:0 if keep_on_device else written.value], mins[:n] & 0x7fffffff
 
     def minimizer_last_ms(self):
         self.lib.vgk_minimizer_last_ms.restype = ctypes.c_double; self.lib.vgk_minimizer_last_ms.argtypes = [ctypes.c_void_p]

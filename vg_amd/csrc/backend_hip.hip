@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
     const uint32_t k = P.index.k, w = P.index.w;
     const char* rd = P.reads + a;
     vgk_seed* dst = slots + (size_t)i * MZ_MAX_SEEDS;
-    uint32_t n_min = 0, n_seeds = 0;
+    uint32_t n_min = 0, n_seeds = 0; bool truncated = false;
     if (L >= k + w - 1) {
         const uint32_t n_kmers = L - k + 1, step = 65 - w;
         const uint64_t kmask = (1ull << (2 * k)) - 1ull;                   // k <= 31
@@ -422,17 +422,19 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
             MZ_WAVE_SYNC();
             // this round's minimizers: one lane each probes the table; then their hits in order
             uint32_t first = 0, count = 0, p = 0, rv = 0;
-            if (lane < n_round && n_seeds < MZ_MAX_SEEDS) {
+            if (lane < n_round) {                                            // (also for a read that is full already: whether hits are left decides its truncated flag)
                 const MzMin mm = mins[lane];
                 MzKmer km; km.key = mm.key; km.hash = mm.hash_lo; km.reverse = (mm.pos_rev & 1u) != 0;
                 p = mm.pos_rev >> 1; rv = mm.pos_rev & 1u;
                 if (!mz_find(P.index, km, first, count) || count > P.hit_cap) count = 0;
             }
             const unsigned long long hb = __ballot(count != 0);
-            for (unsigned long long todo = hb; todo && n_seeds < MZ_MAX_SEEDS; todo &= todo - 1) {
+            for (unsigned long long todo = hb; todo; todo &= todo - 1) {
+                if (n_seeds >= MZ_MAX_SEEDS) { truncated = true; break; }    // the cap: these hits are never looked at
                 const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
                 const uint32_t cj = __shfl(count, j, 64), fj = __shfl(first, j, 64), pj = __shfl(p, j, 64), rj = __shfl(rv, j, 64);
-                for (uint32_t h0 = 0; h0 < cj && n_seeds < MZ_MAX_SEEDS; h0 += 64) {
+                for (uint32_t h0 = 0; h0 < cj; h0 += 64) {
+                    if (n_seeds >= MZ_MAX_SEEDS) { truncated = true; break; }
                     unsigned long long key = 0; vgk_seed sd; sd.node = 0; sd.diff = 0;
                     if (h0 + lane < cj) {
                         const MzPos qp = P.index.pos[fj + h0 + lane];
@@ -441,7 +443,8 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
                         key = ((unsigned long long)sd.node << 32) | (uint32_t)sd.diff;
                     }
                     const uint32_t in_group = cj - h0 < 64 ? cj - h0 : 64;
-                    for (uint32_t x = 0; x < in_group && n_seeds < MZ_MAX_SEEDS; ++x) {      // in hit order; all lanes agree on every decision
+                    for (uint32_t x = 0; x < in_group; ++x) {                // in hit order; all lanes agree on every decision
+                        if (n_seeds >= MZ_MAX_SEEDS) { truncated = true; break; }
                         const unsigned long long kx = __shfl(key, x, 64);
                         const bool dup = __ballot(lane < n_seeds && seen[lane] == kx) != 0ull;
                         if (!dup) {
@@ -455,7 +458,7 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
             MZ_WAVE_SYNC();
         }
     }
-    if (lane == 0) { P.counts[i] = n_seeds; if (P.mins) P.mins[i] = n_min; }
+    if (lane == 0) { P.counts[i] = n_seeds; if (P.mins) P.mins[i] = n_min | (truncated ? VGK_MINIMIZERS_TRUNCATED : 0u); }
 }
 __global__ void __launch_bounds__(256) minimizer_gather_kernel(const MinimizerParams P, const vgk_seed* slots) {
     const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;

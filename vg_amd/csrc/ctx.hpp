@@ -22,6 +22,9 @@ struct vgk_ctx {
     vgk_scoring sc;
     std::unique_ptr<vgk::Backend> be;
     std::mutex mu;                 // guards the pools and the launch order of a context
+    std::mutex stage_mu;           // taken BEFORE mu, for their whole duration, by the calls that make or consume the state one stage leaves for the next in HBM
+                                   // (seeded clusters, extension sets, their scratch slots): vgk_minimizer_seeds, vgk_gapless_extend*, vgk_gapless_rerun, vgk_tail_stage* —
+                                   // the tail stage lets go of mu around the window packer and the fills, never of this one
     uint32_t batch_seq = 0;        // batches packed so far: their launch lanes alternate
     uint32_t bias = 1; int32_t max_score = 0; int32_t max_bonus = 0;
     uint32_t prof4[6];
@@ -34,7 +37,6 @@ struct vgk_ctx {
     uint64_t gapless_retried = 0;  // reads of that call whose search outgrew the fast kernel's LDS store and ran in the slab kernel
     double wfa_ms = 0;             // and of the last vgk_wfa_extend call
     uint32_t wfa_point_budget = 0, wfa_point_budget_tail = 0; // vgk_wfa_set_point_budget(s): connects | prefixes and suffixes (0 = the table's size)
-    uint32_t win_k_hint = 0;       // rows per lane the next window packing uses for every problem (0 = per problem, gssw_pack_device.hpp lane_geometry)
     int8_t banded_mat_rows[72] = {0};   // the 5 x 5 table + its rows as 64-bit words, as the banded fill kernel reads them (banded_device.hpp BMAT_ROWS_AT)
     // what the last vgk_minimizer_seeds call left in HBM: the (masked) reads behind 8 bytes of padding, their offsets, the seeds per read —
     // vgk_gapless_extend_seeded takes its clusters from there
@@ -60,7 +62,7 @@ struct vgk_ctx {
     vgk::WfaParams wfa_last{}; uint32_t wfa_last_threads = 0; bool wfa_last_valid = false;
     // device scratch kept between vgk_banded_align calls (grow-only; released with the context)
     struct DevBuf { void* p = nullptr; uint64_t bytes = 0; };
-    DevBuf scratch[60];            // 0..14 + 31 banded_api.cpp, 15..30 gapless_api.cpp, 32..39 wfa_api.cpp, 40..47 gssw_multi_api.cpp / xdrop_band_api.cpp (+ 48, 49), 50..54 tail_api.cpp, 55..58 minimizer_api.cpp
+    DevBuf scratch[64];            // 0..14 + 31 banded_api.cpp, 15..30 + 59, 60 gapless_api.cpp, 32..39 wfa_api.cpp, 40..47 gssw_multi_api.cpp / xdrop_band_api.cpp (+ 48, 49), 50..54 tail_api.cpp, 55..58 minimizer_api.cpp
     void* ensure_scratch(int slot, uint64_t bytes) {
         DevBuf& b = scratch[slot];
         if (b.p && b.bytes >= bytes) return b.p;

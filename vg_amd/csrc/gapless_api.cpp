@@ -260,7 +260,7 @@ static int gapless_run_and_fetch(vgk_ctx* ctx, GaplessParams& P, uint32_t n, uin
     P.nodes = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_n);
     P.mism = (uint32_t*)dev(nullptr, sizeof(uint32_t) * cap_m);
     P.counters = (unsigned long long*)dev(nullptr, 256);
-    P.retry = (uint8_t*)ctx->ensure_scratch(31, (size_t)n + 16);
+    P.retry = (uint8_t*)ctx->ensure_scratch(60, (size_t)n + 16);        // (a slot of its own: 31 is the banded k-best's score planes)
     P.winners = (GExt*)dev(nullptr, sizeof(GExt) * (n_seed + 1));          // the searches' winners wait here for the rules kernel (248 B each; only the used ones are touched)
     if (!P.winners || !P.probs || !P.reads || !P.seeds || !P.order || !P.scratch || !P.cold || !P.results || !P.ext || !P.nodes || !P.mism || !P.counters) return cleanup(VGK_ENOMEM);
     int rc;
@@ -381,6 +381,7 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     if (!ctx || !index || index->ctx != ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
     if (written) written[0] = written[1] = written[2] = 0;
     if (!n) return VGK_OK;
+    std::lock_guard<std::mutex> stage(ctx->stage_mu);
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->gapless_last_valid = false; ctx->sets.valid = false;
     Backend* be = ctx->be.get();
@@ -479,6 +480,7 @@ int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max
                               uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) {
     if (!ctx || !index || index->ctx != ctx) return VGK_EINVAL;
     if (written) written[0] = written[1] = written[2] = 0;
+    std::lock_guard<std::mutex> stage(ctx->stage_mu);
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (!ctx->seeded.valid || ctx->seeded.graph != index) return VGK_EINVAL;
     const uint32_t n = ctx->seeded.n;
@@ -512,6 +514,7 @@ int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max
 
 int vgk_gapless_rerun(vgk_ctx* ctx) {
     if (!ctx) return VGK_EINVAL;
+    std::lock_guard<std::mutex> stage(ctx->stage_mu);
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (!ctx->gapless_last_valid) return VGK_EINVAL;
     int rc;

@@ -66,7 +66,8 @@ bool read_sparse(Cursor& c, uint64_t& universe, std::vector<uint64_t>* values) {
     Bits high; if (!read_raw(c, high)) return false;
     c.skip_option(); c.skip_option(); c.skip_option();
     Bits low; uint64_t len = 0, width = 0;
-    if (!read_int_vector(c, low, len, width) || len != ones) { c.ok = false; return false; }
+    // a well-formed vector has one high bit per value, none of them shiftable out of 64 bits, inside the bits that are really there
+    if (!read_int_vector(c, low, len, width) || len != ones || ones > high.bits || width >= 64) { c.ok = false; return false; }
     if (values) {
         values->clear(); values->reserve((size_t)ones);
         uint64_t i = 0;
@@ -133,6 +134,7 @@ int read_gbwt(Cursor& c, bool whole, uint32_t& n_nodes, std::vector<uint32_t>& t
     if (!(flags & 0x4u)) return VGK_EUNSUPPORTED;                           // SDSL serialization (older files): `vg gbwt` rewrites them
     if (!(flags & 0x1u)) return VGK_EUNSUPPORTED;                           // unidirectional: the extenders need both strands
     if (alphabet <= offset + 1 || ((offset + 1) & 1) || ((alphabet - offset - 1) & 1) || alphabet - offset - 1 > 0xfffffff0ull || (sequences & 1) || size > 0xfffffff0ull) return VGK_EINVAL;
+    if (sequences > size) return VGK_EINVAL;                                // every sequence visits the endmarker once, and `size` counts those visits too
     n_nodes = (uint32_t)((alphabet - offset - 1) / 2);
     uint64_t universe = 0;
     if (!read_sparse(c, universe, nullptr)) return VGK_EINVAL;               // tags: index ...
@@ -166,7 +168,12 @@ int read_gbwt(Cursor& c, bool whole, uint32_t& n_nodes, std::vector<uint32_t>& t
     });
     for (int rc : status) if (rc) return rc;
     thread_off.assign((size_t)n_threads + 1, 0); thread_nodes.clear();
-    for (uint32_t t = 0; t < n_threads; ++t) thread_off[t + 1] = thread_off[t] + (uint32_t)walks[t].size();
+    uint64_t visits = 0;                                                    // summed in 64 bits: the offsets are 32-bit
+    for (uint32_t t = 0; t < n_threads; ++t) {
+        visits += walks[t].size();
+        if (visits > 0xfffffff0ull) return VGK_ETOOBIG;
+        thread_off[t + 1] = (uint32_t)visits;
+    }
     thread_nodes.reserve(thread_off[n_threads]);
     for (auto& w : walks) thread_nodes.insert(thread_nodes.end(), w.begin(), w.end());
     return VGK_OK;
@@ -181,15 +188,18 @@ extern "C" {
 int vgk_haplo_create_gbwt(vgk_ctx* ctx, const void* gbwt, size_t bytes, uint32_t n_nodes, const uint32_t* node_len, const char* seq, vgk_haplo** out) {
     if (!ctx || !gbwt || !out || !n_nodes || !node_len || !seq) return VGK_EINVAL;
     *out = nullptr;
-    Cursor c{(const uint8_t*)gbwt, bytes};
-    uint32_t nodes_in_file = 0; std::vector<uint32_t> thread_off, thread_nodes;
-    const int rc = read_gbwt(c, false, nodes_in_file, thread_off, thread_nodes);
-    if (rc) return rc;
-    if (nodes_in_file != n_nodes) return VGK_EINVAL;
-    vgk_haplotypes d{};
-    d.n_nodes = n_nodes; d.node_len = node_len; d.seq = seq;
-    d.n_threads = (uint32_t)(thread_off.size() - 1); d.thread_off = thread_off.data(); d.thread_nodes = thread_nodes.data();
-    return vgk_haplo_create(ctx, &d, out);
+    try {
+        Cursor c{(const uint8_t*)gbwt, bytes};
+        uint32_t nodes_in_file = 0; std::vector<uint32_t> thread_off, thread_nodes;
+        const int rc = read_gbwt(c, false, nodes_in_file, thread_off, thread_nodes);
+        if (rc) return rc;
+        if (nodes_in_file != n_nodes) return VGK_EINVAL;
+        vgk_haplotypes d{};
+        d.n_nodes = n_nodes; d.node_len = node_len; d.seq = seq;
+        d.n_threads = (uint32_t)(thread_off.size() - 1); d.thread_off = thread_off.data(); d.thread_nodes = thread_nodes.data();
+        return vgk_haplo_create(ctx, &d, out);
+    } catch (const std::bad_alloc&) { return VGK_ENOMEM; }
+    catch (...) { return VGK_EINVAL; }                                     // (a malformed image that slipped past the checks above)
 }
 
 // GBZ (gbwtgraph's container, what `vg giraffe -Z` takes): 'GBZ ' header, tags, the GBWT whole, then the GBWTGraph — header (tag
@@ -198,6 +208,7 @@ int vgk_haplo_create_gbwt(vgk_ctx* ctx, const void* gbwt, size_t bytes, uint32_t
 int vgk_gbz_load(const void* gbz, size_t bytes, vgk_haplotypes** out) {
     if (!gbz || !out) return VGK_EINVAL;
     *out = nullptr;
+    try {
     Cursor c{(const uint8_t*)gbz, bytes};
     const uint32_t tag = c.u32(); c.u32(); c.u64();
     if (!c.ok || tag != 0x205A4247u) return VGK_EINVAL;
@@ -232,6 +243,8 @@ int vgk_gbz_load(const void* gbz, size_t bytes, vgk_haplotypes** out) {
     L->h.n_threads = (uint32_t)(L->thread_off.size() - 1); L->h.thread_off = L->thread_off.data(); L->h.thread_nodes = L->thread_nodes.data();
     *out = &L.release()->h;                                                  // (h is the first member: vgk_haplotypes_free casts back)
     return VGK_OK;
+    } catch (const std::bad_alloc&) { return VGK_ENOMEM; }
+    catch (...) { return VGK_EINVAL; }
 }
 void vgk_haplotypes_free(vgk_haplotypes* h) { delete reinterpret_cast<Loaded*>(h); }
 

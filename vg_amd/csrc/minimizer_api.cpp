@@ -121,6 +121,7 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
     const uint64_t bytes = read_off[n] - read_off[0];
     if (bytes > 0xfffffff0ull) return VGK_ETOOBIG;
     Backend* be = ctx->be.get();
+    std::lock_guard<std::mutex> stage(ctx->stage_mu);
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->seeded.valid = false;
     char* d_reads = (char*)ctx->ensure_scratch(55, bytes + 32);              // 8 bytes of padding at either end, as the extension kernels want them
@@ -157,10 +158,12 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
     if (written) *written = total;
     const bool keep_on_device = !seeds && !seeds_cap;                         // the caller goes on with vgk_gapless_extend_seeded: the seeds need not come down
     if (!keep_on_device && (total > seeds_cap || (total && !seeds))) return VGK_EOPS;
+    // (the seed buffer exists even for a batch without a single seed: the seeded extension call tells "no seeds" from "no memory" by it)
+    vgk_seed* d_seeds = (vgk_seed*)ctx->ensure_scratch(58, sizeof(vgk_seed) * std::max<size_t>(total, 1));
+    if (!d_seeds) return VGK_ENOMEM;
+    P.seeds = d_seeds;
     if (total) {
-        vgk_seed* d_seeds = (vgk_seed*)ctx->ensure_scratch(58, sizeof(vgk_seed) * total);
-        if (!d_seeds) return VGK_ENOMEM;
-        P.seeds = d_seeds; P.pass = 2;
+        P.pass = 2;
         rc = be->run_minimizer(P);
         be->watch(1);
         if (!rc) rc = keep_on_device ? be->sync() : be->download(seeds, d_seeds, sizeof(vgk_seed) * total);

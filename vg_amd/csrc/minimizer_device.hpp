@@ -107,10 +107,11 @@ struct MinimizerParams {
 };
 // one read: count its seeds (pass 1) or write them (pass 2), in order of the minimizers' read offsets, a minimizer's hits in index order.
 // A cluster is a SET of seeds (GaplessExtender::cluster_type is a hash set, src/gbwt_extender.hpp:143): a (node, diagonal) pair that
-// a second minimizer of the read hits again is reported once; seeds beyond MZ_MAX_SEEDS are dropped.
+// a second minimizer of the read hits again is reported once; seeds beyond MZ_MAX_SEEDS are dropped and the read is flagged
+// (VGK_MINIMIZERS_TRUNCATED in mins[]: the cap was reached with hits left unexamined).
 VGK_HD void minimizer_one(const MinimizerParams& P, uint32_t i) {
     const uint64_t a = P.read_off[i]; const uint32_t L = (uint32_t)(P.read_off[i + 1] - a);
-    uint32_t n_seeds = 0, n_min = 0;
+    uint32_t n_seeds = 0, n_min = 0; bool truncated = false;
     vgk_seed* dst = P.pass == 2 ? P.seeds + P.first[i] : nullptr;
     const uint32_t k = P.index.k;
     uint64_t seen[MZ_MAX_SEEDS];
@@ -118,7 +119,8 @@ VGK_HD void minimizer_one(const MinimizerParams& P, uint32_t i) {
         ++n_min;
         uint32_t first = 0, count = 0;
         if (!mz_find(P.index, m, first, count) || count > P.hit_cap) return;
-        for (uint32_t h = 0; h < count && n_seeds < MZ_MAX_SEEDS; ++h) {
+        for (uint32_t h = 0; h < count; ++h) {
+            if (n_seeds >= MZ_MAX_SEEDS) { truncated = true; break; }      // the cap: this hit and the rest are never looked at (reported in mins[])
             const MzPos q = P.index.pos[first + h];
             vgk_seed s;
             if (!m.reverse) { s.node = q.node; s.diff = (int32_t)p - (int32_t)q.offset; }
@@ -132,7 +134,7 @@ VGK_HD void minimizer_one(const MinimizerParams& P, uint32_t i) {
             ++n_seeds;
         }
     });
-    if (P.pass == 1) { P.counts[i] = n_seeds; if (P.mins) P.mins[i] = n_min; }
+    if (P.pass == 1) { P.counts[i] = n_seeds; if (P.mins) P.mins[i] = n_min | (truncated ? VGK_MINIMIZERS_TRUNCATED : 0u); }
 }
 
 }  // namespace vgk

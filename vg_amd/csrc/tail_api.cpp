@@ -147,7 +147,7 @@ void vgk_forest_destroy(vgk_forest* f) {
 // call left in HBM (tail_device.hpp "the tails of a batch of extension sets").  The host sees four totals that size allocations and, at
 // the end, one int per extension and one per read.
 int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
-                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out, bool on_device);
+                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out, bool on_device, uint32_t forced_k);
 }  // extern "C"
 // aligned / tails_cap / ops / ops_cap / written: vgk_tail_stage_aligned's outputs (all null / 0 for vgk_tail_stage)
 static int tail_stage_impl(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score, uint64_t stats[4],
@@ -156,6 +156,7 @@ static int tail_stage_impl(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_pe
     if (written) written[0] = written[1] = 0;
     if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
     Backend* be = ctx->be.get();
+    std::lock_guard<std::mutex> stage(ctx->stage_mu);                     // the sets, the resident reads and the scratch slots they live in stay this call's while mu is let go below
     std::unique_lock<std::mutex> lk(ctx->mu);
     if (!ctx->sets.valid) return VGK_EINVAL;
     const uint32_t n = ctx->sets.n; const uint64_t n_ext = ctx->sets.n_ext;
@@ -272,9 +273,8 @@ static int tail_stage_impl(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_pe
             // The trees of a batch of reads are a few hundred thousand small problems: split over three rows-per-lane classes they make three
             // launches that each leave the device half empty and finish at different times (measured: 4.7 ms; one class, K = 20: 3.8 ms).
             // A million and more (bench.py --workload forest) fill it per class, and the per-problem choice wins again (35.5 vs 37.7 ms).
-            ctx->win_k_hint = nw < 400000u ? 20u : 0u;
-            if (!rc) { lk.unlock(); rc = vgk_pack_windows_impl(ctx, forest->graph, d_seq, seq_bytes, d_win, nw, ops_per_problem, &b, true); lk.lock(); }
-            ctx->win_k_hint = 0;
+            const uint32_t forced_k = nw < 400000u ? 20u : 0u;
+            if (!rc) { lk.unlock(); rc = vgk_pack_windows_impl(ctx, forest->graph, d_seq, seq_bytes, d_win, nw, ops_per_problem, &b, true, forced_k); lk.lock(); }
             be->watch(1); be->sync(); ctx->tail_stage_ms[2] = be->watch_ms();
             wall("windows packed");
             if (!rc) rc = ctx->start_deferred();                                // the extension sets of a VGK_GAPLESS_DEFER call travel under the fills

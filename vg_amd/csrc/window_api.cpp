@@ -116,7 +116,7 @@ void vgk_graph_destroy(vgk_dgraph* dg) {
 // `on_device`: reads and problems are device arrays already (vgk_tail_stage builds them there) and the caller has waited for the
 // kernels that wrote them; nothing is staged.
 int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
-                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out, bool on_device) {
+                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out, bool on_device, uint32_t forced_k) {
     if (!ctx || !dg || dg->ctx != ctx || !out || (!problems && n) || (!reads && reads_bytes)) return VGK_EINVAL;
     *out = nullptr;
     if (ctx->has_qa) return VGK_EUNSUPPORTED;
@@ -146,7 +146,7 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     const uint32_t waves_cap = n / 2 + WIN_BUCKETS + 1;
     WinParams W{};
     W.g = dg->g; W.n = n; W.raw_bytes = reads_bytes; W.ops_per_problem = ops_per_problem;
-    W.forced_k = ctx->win_k_hint;                 // (vgk_tail_stage: one rows-per-lane class for a batch too small to fill the device three times over)
+    W.forced_k = forced_k;                        // (vgk_tail_stage: one rows-per-lane class for a batch too small to fill the device three times over)
     if (const char* e = std::getenv("VGAMD_ROWS_PER_LANE")) W.forced_k = (uint32_t)std::atoi(e);
     W.max_score = ctx->max_score; W.max_bonus = ctx->max_bonus; W.scale = ctx->scale; W.bonus = ctx->sc.full_length_bonus;
     W.n_waves_cap = waves_cap;
@@ -251,7 +251,7 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
 
 int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
                           const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out) {
-    return vgk_pack_windows_impl(ctx, dg, reads, reads_bytes, problems, n, ops_per_problem, out, false);
+    return vgk_pack_windows_impl(ctx, dg, reads, reads_bytes, problems, n, ops_per_problem, out, false, 0);
 }
 
 }  // extern "C"
