@@ -292,6 +292,11 @@ AlignmentBatch::AlignmentBatch(const std::vector<const Aligner*>& per_device, si
     for (size_t i = 0; i < aligners.size(); ++i) device_mu.emplace_back(new std::mutex());
 }
 AlignmentBatch::~AlignmentBatch() = default;
+std::exception_ptr AlignmentBatch::failure_of(const Alignment& alignment) const {
+    std::lock_guard<std::mutex> lk(mu);
+    auto found = job_failures.find(&alignment);
+    return found == job_failures.end() ? nullptr : found->second;
+}
 void AlignmentBatch::submit(std::unique_ptr<Aligner::Job> job) {
     std::vector<std::unique_ptr<Aligner::Job>> full; size_t device = 0;
     {
@@ -360,11 +365,19 @@ void AlignmentBatch::run(std::vector<std::unique_ptr<Aligner::Job>>& run, size_t
     for (size_t k = 0; k < bowner.size(); ++k) rof[bowner[k]] = &bres[k];
     for (size_t i = 0; i < run.size(); ++i) {
         Aligner::Job& j = *run[i];
-        if (j.banded) { aligner.finish_banded_job(j, rof[i] ? *rof[i] : vgk_result{}, rof[i] ? bops.data() + rof[i]->ops_begin : nullptr); continue; }
-        vgk_result r{}; std::vector<vgk_op> o;
-        if (rof[i]) { r = *rof[i]; o.assign(ops.begin() + r.ops_begin, ops.begin() + r.ops_begin + r.n_ops); r.ops_begin = 0; }
-        if (j.xdrop) { aligner.finish_xdrop_job(j, r, std::move(o)); continue; }
-        aligner.finish_job(j, r, std::move(o), nullptr, 1);
+        try {
+            if (j.banded) { aligner.finish_banded_job(j, rof[i] ? *rof[i] : vgk_result{}, rof[i] ? bops.data() + rof[i]->ops_begin : nullptr); continue; }
+            vgk_result r{}; std::vector<vgk_op> o;
+            if (rof[i]) { r = *rof[i]; o.assign(ops.begin() + r.ops_begin, ops.begin() + r.ops_begin + r.n_ops); r.ops_begin = 0; }
+            if (j.xdrop) { aligner.finish_xdrop_job(j, r, std::move(o)); continue; }
+            aligner.finish_job(j, r, std::move(o), nullptr, 1);
+        } catch (...) {
+            // what the direct call would have thrown at its caller (NoAlignmentInBandException, BandMatricesTooBigException, ...): with
+            // isolated failures it is kept for that caller (failure_of) and the other problems of the batch are still answered
+            if (!isolate_failures) throw;
+            std::lock_guard<std::mutex> lk(mu);
+            job_failures[j.alignment] = std::current_exception();
+        }
     }
     } catch (...) { done.err = std::current_exception(); }
 }

@@ -11,6 +11,7 @@
 #include <memory>
 #include <mutex>
 #include <stdexcept>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 #include "vg_standin/alignment.hpp"
@@ -243,6 +244,11 @@ public:
     size_t size() const;
     size_t flushes() const { return n_flushes; }
     void flush();
+    // Failures of single problems (the exceptions the direct calls throw: no alignment in the band, matrices too big, an engine limit)
+    // normally end the flush that meets one.  Isolated, each is kept for its own caller — failure_of(alignment) after the flush — and
+    // every other problem of the batch is still answered.  Set before submitting.
+    bool isolate_failures = false;
+    std::exception_ptr failure_of(const Alignment& alignment) const;
 private:
     void submit(std::unique_ptr<Aligner::Job> job);
     void run(std::vector<std::unique_ptr<Aligner::Job>>& jobs, size_t device);
@@ -253,6 +259,7 @@ private:
     std::vector<std::unique_ptr<std::mutex>> device_mu;
     size_t next_device = 0, in_flight = 0, n_flushes = 0;
     std::exception_ptr failure;
+    std::unordered_map<const Alignment*, std::exception_ptr> job_failures;
 };
 
 // nonATGCNtoN (reference: src/utility.cpp:323-332)

@@ -341,3 +341,107 @@ int vgh_tail_stage(const char* engine_lib, void* ctx, const void* index, const c
 }
 
 }  // extern "C"
+
+// ---- the graph between / beyond anchors (chain_alignment.hpp; MinimizerMapper::align_sequence_between and friends) ------------------
+#include "chain_alignment.hpp"
+extern "C" {
+
+// a bidirected graph, as the reference's tests build with HashGraph / json2graph
+struct vgh_bigraph { LocalGraph g; };
+vgh_bigraph* vgh_bigraph_create(void) { return new vgh_bigraph(); }
+void vgh_bigraph_destroy(vgh_bigraph* g) { delete g; }
+int vgh_bigraph_add_node(vgh_bigraph* g, int64_t id, const char* seq) {
+    try { g->g.create_handle(seq, id); return 0; } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+// vg's Edge message: from_start = the edge leaves the START of `from` (i.e. its reverse strand), to_end = it arrives at the END of `to`
+int vgh_bigraph_add_edge(vgh_bigraph* g, int64_t from, int from_start, int64_t to, int to_end) {
+    try { g->g.create_edge(g->g.get_handle(from, from_start != 0), g->g.get_handle(to, to_end != 0)); return 0; }
+    catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+static Position as_position(const int64_t* p) { Position q; if (p) { q.node_id = p[0]; q.is_reverse = p[1] != 0; q.offset = p[2]; } return q; }
+static int emit_string(const std::string& js, char* out, size_t cap) {
+    if (js.size() + 1 > cap) { g_last_error = "json buffer too small"; return -2; }
+    std::memcpy(out, js.c_str(), js.size() + 1);
+    return 0;
+}
+
+// left / right: [node id, is_reverse, offset], node id 0 (or NULL) = no anchor on that side.  JSON out: {"did_align": b, "alignment": {...}}
+// return 1: ChainAlignmentFailedError (message in vgh_last_error)
+int vgh_align_sequence_between(vgh_aligner* a, vgh_bigraph* g, const char* read, const int64_t* left, const int64_t* right, int64_t max_path_length,
+                               int64_t max_gap_length, int consistently, int64_t max_dp_cells, char* json_out, size_t json_cap) {
+    try {
+        Alignment aln; aln.sequence = read;
+        const size_t cells = max_dp_cells < 0 ? std::numeric_limits<size_t>::max() : (size_t)max_dp_cells;
+        const bool did = consistently ? align_sequence_between_consistently(as_position(left), as_position(right), (size_t)max_path_length, (size_t)max_gap_length, &g->g, a->a.get(), aln, nullptr, cells)
+                                      : align_sequence_between(as_position(left), as_position(right), (size_t)max_path_length, (size_t)max_gap_length, &g->g, a->a.get(), aln, nullptr, cells);
+        return emit_string(std::string("{\"did_align\":") + (did ? "true" : "false") + ",\"alignment\":" + alignment_to_json(aln) + "}", json_out, json_cap);
+    } catch (ChainAlignmentFailedError& e) { g_last_error = e.what(); return 1; }
+    catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// with_dagified_local_graph's view of one request.  JSON out: {"nodes": [[id, sequence, base id, base is_reverse], ...], "edges": [[from, to], ...],
+// "tips": [[id, is_reverse], ...], "left_anchor": [id, is_reverse] | null, "right_anchor": ...}
+int vgh_dagified_local_graph(vgh_bigraph* g, const int64_t* left, const int64_t* right, int64_t max_path_length, char* json_out, size_t json_cap) {
+    try {
+        std::string js;
+        with_dagified_local_graph(as_position(left), as_position(right), (size_t)max_path_length, g->g,
+            [&](LocalGraph& d, const handle_t& l, const handle_t& r, const std::function<std::pair<nid_t, bool>(const handle_t&)>& to_base) {
+                js = "{\"nodes\":[";
+                bool first = true;
+                d.for_each_handle_v([&](const handle_t& h) {
+                    const auto b = to_base(h);
+                    js += std::string(first ? "" : ",") + "[" + std::to_string(d.get_id(h)) + ",\"" + d.get_sequence(h) + "\"," + std::to_string(b.first) + "," + (b.second ? "1" : "0") + "]";
+                    first = false;
+                });
+                js += "],\"edges\":[";
+                first = true;
+                d.for_each_handle_v([&](const handle_t& h) { d.follow_edges_v(h, false, [&](const handle_t& n) {
+                    js += std::string(first ? "" : ",") + "[" + std::to_string(d.get_id(h)) + "," + std::to_string(d.get_id(n)) + "]"; first = false; }); });
+                js += "],\"tips\":[";
+                first = true;
+                for (const handle_t& t : handlealgs::find_tips(&d)) { js += std::string(first ? "" : ",") + "[" + std::to_string(d.get_id(t)) + "," + (d.get_is_reverse(t) ? "1" : "0") + "]"; first = false; }
+                auto anchor = [&](const int64_t* p, const handle_t& h) { return p && p[0] ? "[" + std::to_string(d.get_id(h)) + "," + (d.get_is_reverse(h) ? "1" : "0") + "]" : std::string("null"); };
+                js += "],\"left_anchor\":" + anchor(left, l) + ",\"right_anchor\":" + anchor(right, r) + "}";
+            });
+        return emit_string(js, json_out, json_cap);
+    } catch (ChainAlignmentFailedError& e) { g_last_error = e.what(); return 1; }
+    catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+int64_t vgh_longest_detectable_gap_in_range(vgh_aligner* a, int64_t read_length, int64_t begin, int64_t end) {
+    Alignment aln; aln.sequence.assign((size_t)read_length, 'A');
+    return (int64_t)longest_detectable_gap_in_range(aln, (size_t)begin, (size_t)end, a->a.get());
+}
+
+// ChainConnector: the same requests, many per engine flush
+struct vgh_connector { std::unique_ptr<ChainConnector> c; std::deque<Alignment> alns; };
+vgh_connector* vgh_connector_create(vgh_aligner* a, vgh_bigraph* g, int64_t max_dp_cells) {
+    auto* h = new vgh_connector();
+    h->c = std::make_unique<ChainConnector>(*a->a, g->g, max_dp_cells < 0 ? std::numeric_limits<size_t>::max() : (size_t)max_dp_cells);
+    return h;
+}
+void vgh_connector_destroy(vgh_connector* c) { delete c; }
+int vgh_connector_add(vgh_connector* c, const char* read, const int64_t* left, const int64_t* right, int64_t max_path_length, int64_t max_gap_length) {
+    c->alns.emplace_back(); c->alns.back().sequence = read;
+    return (int)c->c->add(as_position(left), as_position(right), (size_t)max_path_length, (size_t)max_gap_length, c->alns.back());
+}
+// JSON out: [{"status": n, "did_align": b, "message": "...", "alignment": {...}}, ...] for every request so far; ms[3]: extraction, engine flush, translation
+int vgh_connector_run(vgh_connector* c, int threads, double* ms, char* json_out, size_t json_cap) {
+    try {
+        c->c->run((unsigned)std::max(threads, 0));
+        if (ms) { ms[0] = c->c->last_extract_ms; ms[1] = c->c->last_align_ms; ms[2] = c->c->last_translate_ms; }
+        if (!json_out) return 0;
+        std::string js = "[";
+        for (size_t i = 0; i < c->alns.size(); ++i) {
+            const ChainConnector::Outcome& o = c->c->outcome(i);
+            std::string msg; for (char ch : o.message) if (ch != '"' && ch != '\\' && ch != '\n') msg += ch;
+            js += std::string(i ? "," : "") + "{\"status\":" + std::to_string((int)o.status) + ",\"did_align\":" + (o.did_align ? "true" : "false") + ",\"message\":\"" + msg +
+                  "\",\"alignment\":" + alignment_to_json(c->alns[i]) + "}";
+        }
+        js += "]";
+        return emit_string(js, json_out, json_cap);
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+}  // extern "C"
