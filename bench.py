@@ -254,20 +254,21 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
 
 def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
     """configs[4] as reads (secondary line): 15 kbp HiFi-like reads cut at their anchors; every stretch between anchors through
-    WFAExtender (connect / prefix / suffix), the connects it gives up on through BandedGlobalAligner between the two anchors
-    (vg_amd/pipeline.py chain_stage; src/minimizer_mapper.cpp:2955-3100).  One step = both calls for the whole batch from host buffers."""
+    WFAExtender (connect / prefix / suffix); what it declines through align_sequence_between_consistently — the local graph between /
+    beyond the anchors cut out of the haplotype graph, strands split, dagified, then BandedGlobalAligner (pinned X-drop for a tail)
+    (src/minimizer_mapper_from_chains.cpp:2900-3300, :3342-3920).  The whole stage is ONE call into the host shim (vgh_chain_stage,
+    vg_amd/host/chain_stage.cpp): one step = that call for the whole batch from host buffers, the extraction of the local graphs included.
+    The headline and the parity line run WITHOUT a WFA point budget (the reference's WFAExtender has none); the budgeted rate is reported
+    beside it, never instead."""
     import numpy as np
-    from vg_amd import capi, pipeline, shard, workloads
+    from vg_amd import pipeline, shard, workloads
     n = args.reads if args.reads else 4000
     t0 = time.perf_counter()
     wl = workloads.LongReadWorkload(n, seed=515 + rank)
-    if not os.environ.get("VGAMD_LONGREAD_ASSEMBLE_PER_STEP"):
-        wl.prepare_connects()               # the graphs between the anchors, extracted once and kept flat: a step picks its fallback batch out of them
     t_gen = time.perf_counter() - t0
-    index = eng.haplo_index(wl.nodes, wl.threads)
-    budget = int(os.environ.get("VGAMD_WFA_POINT_BUDGET", "128"))             # give up early on what will outgrow the tables: it goes to the banded aligner anyway
-    tail_budget = int(os.environ.get("VGAMD_WFA_TAIL_BUDGET", "512"))           # prefixes / suffixes have no banded fallback in this stage: a budget of their own
-    eng.wfa_set_point_budgets(budget, tail_budget)
+    threads = max(1, shard.usable_cpus() // max(world, 1))
+    stage = pipeline.ChainStage(wl, device=int(os.environ.get("LOCAL_RANK", "0")))
+    stage.set_point_budgets(0, 0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -275,55 +276,70 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(steps, timing=None):
+        barrier()
+        t = time.perf_counter()
+        for _ in range(steps):
+            o = stage.run(threads=threads, timing=timing)
+        barrier()
+        e = time.perf_counter() - t
+        if dist is not None:
+            tt = torch.tensor([e], dtype=torch.float64, device=RDEV)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e = float(tt.item())
+        return e, o
+
     for _ in range(max(1, args.warmup)):
-        out = pipeline.chain_stage(eng, index, wl)
-    barrier()
+        out = stage.run(threads=threads)
     timing = {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = pipeline.chain_stage(eng, index, wl, timing=timing)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, out = timed(args.steps, timing)
+    # the same with round 2's point budgets (connects give up at 128 stored wavefront points and go to the DP route at once, tails at 512)
+    budget = int(os.environ.get("VGAMD_WFA_POINT_BUDGET", "128")); tail_budget = int(os.environ.get("VGAMD_WFA_TAIL_BUDGET", "512"))
+    stage.set_point_budgets(budget, tail_budget)
+    stage.run(threads=threads)
+    b_timing = {}
+    b_elapsed, b_out = timed(args.steps, b_timing)
+    stage.set_point_budgets(0, 0)
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
-        cores = shard.usable_cpus(); ora.lib.vgo_set_threads(cores)
-        oidx = ora.haplo_index(wl.nodes, wl.threads)
-        t1 = time.perf_counter(); o = pipeline.chain_stage(ora, oidx, wl); tc = time.perf_counter() - t1
-        clean = np.ones(n, dtype=bool); clean[wl.read_of[out["declined_tails"]]] = False       # reads none of whose tails the engine declined
-        same = int((o["chain_score"][clean] == out["chain_score"][clean]).sum())
-        cpu = {"value": n / tc, "unit": "reads/s", "cores": cores, "kind": "port", "impl": "the same two calls over the oracle: vgo_wfa.c, vgo_banded.c (OpenMP over problems)",
+        ora = pipeline.ChainStage(wl, lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
+        cores = shard.usable_cpus()
+        import ctypes
+        ctypes.CDLL(os.path.join(ROOT, "oracle", "libvgoracle.so")).vgo_set_threads(cores)
+        t1 = time.perf_counter(); o = ora.run(threads=cores); tc = time.perf_counter() - t1
+        ora.close()
+        same = int((o["chain_score"] == out["chain_score"]).sum()); diff = o["chain_score"] != out["chain_score"]
+        b_same = int((o["chain_score"] == b_out["chain_score"]).sum())
+        cpu = {"value": n / tc, "unit": "reads/s", "cores": cores, "kind": "port", "impl": "the same stage (vgh_chain_stage) bound to the oracle: vgo_wfa.c, vgo_banded.c, vgo_xdrop.c (OpenMP over problems)",
                "sample": "all %d reads" % n}
-        diff = clean & (o["chain_score"] != out["chain_score"])
-        parity = {"checked": int(clean.sum()), "identical": same, "reads_with_a_declined_tail": int(n - clean.sum()),
-                  "differing_reads_where_the_fallback_scores_higher": int((out["chain_score"][diff] > o["chain_score"][diff]).sum()), "differing_reads": int(diff.sum()),
-                  "what": "per-read chain score (anchors + every stretch between them).  The engine sends the connects its WFA gives up on to the banded aligner; the "
-                          "oracle's WFA has no tables to outgrow and answers them itself.  Where both succeed the scores are equal; a read differs only where the banded "
-                          "aligner, which may cross between haplotypes, finds a better path than any haplotype offers (tests/test_longread_stage.py compares the WFA "
-                          "results field by field)"}
+        parity = {"checked": n, "identical": same, "wfa_point_budget": "none", "differing_reads": int(diff.sum()),
+                  "differing_reads_where_the_engine_scores_higher": int((out["chain_score"][diff] > o["chain_score"][diff]).sum()),
+                  "identical_with_point_budgets": b_same,
+                  "what": "per-read chain score (anchors + every link).  No point budget: a link leaves the WFA route only when the engine's tables decline it (VGK_ETOOBIG), "
+                          "which the oracle's WFA (no tables) never does; such a link takes align_sequence_between, which is not bound to haplotypes and can only score "
+                          "as high or higher"}
     if rank == 0:
-        res = out["wfa"]
         print(json.dumps({
-            "metric": "15 kbp reads/sec through the chain alignment stage (WFA between anchors, banded global alignment as fallback)",
+            "metric": "15 kbp reads/sec through the chain alignment stage (WFA between anchors; align_sequence_between — local graph extraction + banded global / pinned X-drop — for what WFA declines)",
             "value": n * world * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {"workload": "configs[4]: 1 Mbp variation graph, 8 random haplotype threads, %d reads of 15 000 bp per GPU on either strand, error-free 29-mer anchors every "
                                    "120-400 bp, 0.5 %% errors between them (half substitutions, half 1-bp indels), 1 %% of the connects with a 25-60 bp insertion; "
-                                   "WFAExtender connect / prefix / suffix with the default error model, BandedGlobalAligner (permissive band) for what it rejects" % n,
-                       "timed_region": "per step, from host buffers: vgk_wfa_extend over every stretch, the fallback batch picked out of the connects' subgraphs, kept flat (the subgraph between two anchors is extracted "
-                                       "once per problem, outside the steps: vg's extract_connecting_graph), vgk_banded_align",
+                                   "WFAExtender connect / prefix / suffix with the default error model and NO point budget; align_sequence_between_consistently for what it declines" % n,
+                       "timed_region": "per step, from host buffers, one vgh_chain_stage call: vgk_wfa_extend over every link; for the declined links extract_connecting_graph / "
+                                       "extract_extending_graph on the haplotype graph, strand split, dagify_from, tip trimming (host threads); one flush of banded-global / pinned X-drop problems; "
+                                       "translation back to the base graph; per-read totals",
                        "problems": wl.n, "problems_per_read": wl.n / n, "read_bases": wl.read_bases, "bases_per_s": wl.read_bases * world * args.steps / elapsed,
-                       "wfa_ok": int((res["ok"] != 0).sum()), "fallbacks": int(len(out["failed"])), "wfa_point_budget": budget or 1024, "wfa_tail_point_budget": tail_budget or 1024, "wfa_declined_by_engine_tables": int((res["status"] != 0).sum()),
-                       "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()}, "wfa_kernel_ms": eng.lib.vgk_wfa_last_ms(eng.h) if hasattr(eng.lib, "vgk_wfa_last_ms") else None,
+                       "links": out["stats"], "host_threads": threads,
+                       "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()}, "wfa_kernel_ms": out["wfa_kernel_ms"],
+                       "with_point_budgets": {"connect": budget, "tail": tail_budget, "reads_per_s": n * world * args.steps / b_elapsed, "ms_per_step": 1e3 * b_elapsed / args.steps,
+                                              "links": b_out["stats"], "stage_ms": {k: 1e3 * v / args.steps for k, v in b_timing.items()}, "wfa_kernel_ms": b_out["wfa_kernel_ms"]},
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
             "roofline": {"bound": "hbm", "kernel": "wfa_kernel", "limiter": "the critical path of the slowest problem of a launch, then memory latency (DESIGN.md §16)",
                          "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
             "cpu_baseline": cpu, "parity": parity,
-            "problems_failed": int((out["banded"]["status"] != 0).sum()) if "banded" in out else 0}))
+            "problems_failed": int(out["stats"]["failed"] + out["stats"]["no_graph"] + out["stats"]["too_big"])}))
+    stage.close()
     if dist is not None:
         dist.destroy_process_group()
 

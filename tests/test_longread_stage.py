@@ -70,3 +70,58 @@ def test_fallback_batch_picked_from_flat_connects(emu_lib):
 @pytest.mark.gpu
 def test_fallback_batch_picked_from_flat_connects_on_the_gpu():
     fallbacks_picked_from_flat_connects(ENGINE_LIB, 40, 15000, 10)
+
+
+# ---- the stage in the host shim (vg_amd/host/chain_stage.cpp): one call, the local graphs extracted inside it -------------------------
+def native_stage(lib, n_reads, read_len, seed, sv, budgets=None, threads=3):
+    """ChainStage (C++: WFA, then align_sequence_between_consistently for what WFA declines) on `lib` and on the oracle -> both outputs"""
+    wl = workloads.LongReadWorkload(n_reads, seed=seed, graph_bp=150_000, read_len=read_len, sv_fraction=sv)
+    outs = []
+    for which in (lib, ORACLE_LIB):
+        cs = pipeline.ChainStage(wl, lib=which)
+        if budgets and which != ORACLE_LIB:
+            cs.set_point_budgets(*budgets)
+        outs.append(cs.run(threads=threads))
+        cs.close()
+    return wl, outs[0], outs[1]
+
+
+def check_native(wl, a, b, min_declined):
+    assert a["stats"]["failed"] == 0 and a["stats"]["no_graph"] == 0 and a["stats"]["too_big"] == 0, a["stats"]
+    assert a["stats"]["declined"] >= min_declined and a["stats"]["between"] == a["stats"]["declined"]
+    # a link either WFA or the graph between its anchors answers; where both engines took the WFA route the scores are equal; a link that took
+    # the DP route scores at least what the haplotype-bound WFA of the oracle found for it (the local graph holds every haplotype's walk)
+    same_route = a["link_source"] == b["link_source"]
+    assert (a["link_score"][same_route] == b["link_score"][same_route]).all()
+    assert (a["link_score"][~same_route] >= b["link_score"][~same_route]).all()
+    assert (a["chain_score"] >= b["chain_score"]).all()
+    links = np.bincount(wl.read_of, weights=np.diff(wl.ws.seq_off), minlength=wl.n_reads)
+    assert (a["chain_score"] >= 0.8 * (wl.anchor_bases + links)).all()              # (a fifth of the connects may carry a 25-60 bp insertion)
+
+
+def test_native_chain_stage_equals_the_oracles(emu_lib):
+    wl, a, b = native_stage(emu_lib, 5, 2500, 4, 0.0)
+    assert (a["chain_score"] == b["chain_score"]).all() and (a["link_score"] == b["link_score"]).all()
+
+
+def test_native_chain_stage_with_declined_links(emu_lib):
+    wl, a, b = native_stage(emu_lib, 4, 2500, 6, 0.2, budgets=(48, 48))
+    check_native(wl, a, b, 4)
+    assert (a["link_source"][wl.ws.array["mode"] != capi.WFA_CONNECT] != 2).all()         # declined tails went through pinned X-drop, none is left unaligned
+
+
+def test_native_chain_stage_equals_the_python_pipeline(emu_lib):
+    """the same reads through round 2's Python glue (its own stand-in for the graph between two anchors: a run of the topological order)"""
+    wl, a, _ = native_stage(emu_lib, 5, 2500, 4, 0.1)
+    eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=emu_lib)
+    old = pipeline.chain_stage(eng, eng.haplo_index(wl.nodes, wl.threads), wl)
+    assert len(old["failed"]) == a["stats"]["declined"] > 0
+    assert (old["chain_score"] == a["chain_score"]).all()
+
+
+@pytest.mark.gpu
+def test_native_chain_stage_on_the_gpu():
+    wl, a, b = native_stage(ENGINE_LIB, 60, 15000, 5, 0.02, threads=8)
+    check_native(wl, a, b, 10)
+    wl, a, b = native_stage(ENGINE_LIB, 40, 15000, 11, 0.02, budgets=(64, 64), threads=8)
+    check_native(wl, a, b, 40)

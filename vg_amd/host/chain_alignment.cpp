@@ -224,29 +224,44 @@ Alignment reverse_complement_alignment(const Alignment& aln, const std::function
     return out;
 }
 
+namespace {
+// align_sequence_between_consistently's choice (:3872-3905): does this request run on the other strand, between the swapped anchors?
+bool runs_flipped(const Position& left_anchor, const Position& right_anchor, const Alignment& alignment, const Alignment& flipped) {
+    auto key = [](const Position& p) { return std::make_tuple(p.node_id, p.is_reverse, p.offset); };
+    if (key(left_anchor) < key(right_anchor)) return false;                    // unambiguously in order: as it is
+    if (key(left_anchor) == key(right_anchor) && flipped.sequence >= alignment.sequence) return false;     // a tie the sequence does not break either
+    return true;
+}
+Position turned(const Position& p, const HandleGraph* graph) {
+    Position r;
+    if (!is_empty(p)) { r.node_id = p.node_id; r.is_reverse = !p.is_reverse; r.offset = (int64_t)graph->get_length(graph->get_handle(p.node_id)) - p.offset; }
+    return r;
+}
+void check_one_piece(const Alignment& alignment) {
+    for (size_t i = 1; i < alignment.path.mapping.size(); ++i)
+        if (alignment.path.mapping[i].position.offset != 0) throw std::logic_error("align_sequence_between_consistently: an offset inside the path");
+}
+}  // namespace
+
 bool align_sequence_between_consistently(const Position& left_anchor, const Position& right_anchor, size_t max_path_length, size_t max_gap_length,
                                          const HandleGraph* graph, const Aligner* aligner, Alignment& alignment, const std::string* alignment_name,
                                          size_t max_dp_cells, const BandPaddingFunction& choose_band_padding) {
-    auto key = [](const Position& p) { return std::make_tuple(p.node_id, p.is_reverse, p.offset); };
-    if (key(left_anchor) < key(right_anchor))
-        return align_sequence_between(left_anchor, right_anchor, max_path_length, max_gap_length, graph, aligner, alignment, alignment_name, max_dp_cells, choose_band_padding);
     auto node_length = [&](nid_t id) -> int64_t { return (int64_t)graph->get_length(graph->get_handle(id)); };
     Alignment flipped = reverse_complement_alignment(alignment, node_length);
-    if (key(left_anchor) == key(right_anchor) && flipped.sequence >= alignment.sequence)      // a tie that the sequence does not break either
+    if (!runs_flipped(left_anchor, right_anchor, alignment, flipped))
         return align_sequence_between(left_anchor, right_anchor, max_path_length, max_gap_length, graph, aligner, alignment, alignment_name, max_dp_cells, choose_band_padding);
     // align the other strand between the swapped, turned-around anchors, then turn the answer back
-    auto turned = [&](const Position& p) { Position r; if (!is_empty(p)) { r.node_id = p.node_id; r.is_reverse = !p.is_reverse; r.offset = node_length(p.node_id) - p.offset; } return r; };
-    const bool result = align_sequence_between(turned(right_anchor), turned(left_anchor), max_path_length, max_gap_length, graph, aligner, flipped, alignment_name,
-                                               max_dp_cells, choose_band_padding);
+    const bool result = align_sequence_between(turned(right_anchor, graph), turned(left_anchor, graph), max_path_length, max_gap_length, graph, aligner, flipped,
+                                               alignment_name, max_dp_cells, choose_band_padding);
     alignment = reverse_complement_alignment(flipped, node_length);
-    for (size_t i = 1; i < alignment.path.mapping.size(); ++i)
-        if (alignment.path.mapping[i].position.offset != 0) throw std::logic_error("align_sequence_between_consistently: an offset inside the path");
+    check_one_piece(alignment);
     return result;
 }
 
 // ---- ChainConnector ---------------------------------------------------------------------------------------------------------------------
 struct ChainConnector::Request {
     Position left, right; size_t max_path_length, max_gap_length; Alignment* alignment;
+    Alignment* answer = nullptr; Alignment other_strand; bool flipped = false;   // a request that runs on the other strand: `alignment` is other_strand, `answer` the caller's
     std::unique_ptr<DagifiedLocalGraph> d; Route route = Route::SOFTCLIP; size_t band_padding = 0;
 };
 
@@ -254,9 +269,18 @@ ChainConnector::ChainConnector(const Aligner& aligner, const HandleGraph& graph,
     : aligner_(aligner), graph_(graph), max_dp_cells_(max_dp_cells), choose_band_padding_(std::move(choose_band_padding)) {}
 ChainConnector::~ChainConnector() = default;
 
-size_t ChainConnector::add(const Position& left_anchor, const Position& right_anchor, size_t max_path_length, size_t max_gap_length, Alignment& alignment) {
+size_t ChainConnector::add(const Position& left_anchor, const Position& right_anchor, size_t max_path_length, size_t max_gap_length, Alignment& alignment,
+                           bool consistently) {
     auto r = std::make_unique<Request>();
     r->left = left_anchor; r->right = right_anchor; r->max_path_length = max_path_length; r->max_gap_length = max_gap_length; r->alignment = &alignment;
+    if (consistently) {
+        auto node_length = [&](nid_t id) -> int64_t { return (int64_t)graph_.get_length(graph_.get_handle(id)); };
+        r->other_strand = reverse_complement_alignment(alignment, node_length);
+        if (runs_flipped(left_anchor, right_anchor, alignment, r->other_strand)) {
+            r->flipped = true; r->answer = &alignment; r->alignment = &r->other_strand;
+            r->left = turned(right_anchor, &graph_); r->right = turned(left_anchor, &graph_);
+        } else r->other_strand = Alignment();
+    }
     requests_.push_back(std::move(r));
     outcomes_.emplace_back();
     return requests_.size() - 1;
@@ -319,6 +343,13 @@ void ChainConnector::run(unsigned threads) {
         catch (std::exception& e) { o.status = FAILED; o.message = e.what(); }
         r.d.reset();
     });
+    for (size_t i = first; i < requests_.size(); ++i) {                           // answers found on the other strand are turned back
+        Request& r = *requests_[i];
+        if (!r.flipped) continue;
+        auto node_length = [&](nid_t id) -> int64_t { return (int64_t)graph_.get_length(graph_.get_handle(id)); };
+        *r.answer = reverse_complement_alignment(r.other_strand, node_length);
+        try { check_one_piece(*r.answer); } catch (std::exception& e) { outcomes_[i].status = FAILED; outcomes_[i].message = e.what(); }
+    }
     last_translate_ms = ms_since(t0);
 }
 

@@ -82,7 +82,9 @@ public:
     ChainConnector(const Aligner& aligner, const HandleGraph& graph, size_t max_dp_cells = std::numeric_limits<size_t>::max(),
                    BandPaddingFunction choose_band_padding = pad_band_random_walk());
     ~ChainConnector();
-    size_t add(const Position& left_anchor, const Position& right_anchor, size_t max_path_length, size_t max_gap_length, Alignment& alignment);
+    // consistently: answer as align_sequence_between_consistently does (the strand to align on chosen from the anchors, not the caller)
+    size_t add(const Position& left_anchor, const Position& right_anchor, size_t max_path_length, size_t max_gap_length, Alignment& alignment,
+               bool consistently = false);
     void run(unsigned threads = 0);
     size_t size() const { return requests_.size(); }
     const Outcome& outcome(size_t i) const { return outcomes_[i]; }

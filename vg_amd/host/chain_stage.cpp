@@ -1,0 +1,83 @@
+// chain_stage.cpp — see chain_stage.hpp.
+#include "chain_stage.hpp"
+#include <algorithm>
+#include <chrono>
+#include <deque>
+
+namespace vgamd {
+
+int run_chain_stage(const EngineApi& api, vgk_ctx* ctx, const vgk_haplo* index, const HaplotypeGraph& graph, const Aligner& aligner,
+                    const vgk_wfa_error_model* model, const ChainStageInput& in, ChainStageOutput& out) {
+    using clock = std::chrono::steady_clock;
+    auto t0 = clock::now();
+    auto lap = [&](int k) { const auto t = clock::now(); out.ms[k] += std::chrono::duration<double, std::milli>(t - t0).count(); t0 = t; };
+    const uint32_t n = in.n_links;
+    out.link_score.assign(n, 0); out.link_source.assign(n, ChainStageOutput::NONE); out.wfa_status.assign(n, VGK_OK);
+    out.chain_score.assign(in.n_reads, 0);
+    out.n_declined = out.n_between = out.n_no_graph = out.n_too_big = out.n_failed = 0;
+    for (double& m : out.ms) m = 0;
+    // 1. everything through WFAExtender, one engine call
+    std::vector<vgk_wfa_problem> problems(n);
+    uint64_t bases = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        vgk_wfa_problem& p = problems[i];
+        p.seq = in.seqs + in.seq_off[i]; p.seq_len = (uint32_t)(in.seq_off[i + 1] - in.seq_off[i]); p.mode = in.mode[i];
+        p.from_node = in.from_node[i]; p.from_offset = in.from_offset[i]; p.to_node = in.to_node[i]; p.to_offset = in.to_offset[i];
+        bases += p.seq_len;
+    }
+    std::vector<vgk_wfa_result> results(n);
+    std::vector<uint32_t> paths((size_t)n * 24 + bases / 4 + 64), edits((size_t)n * 12 + 64);
+    size_t written[2] = {0, 0};
+    int rc = n ? api.wfa_extend(ctx, index, model, problems.data(), n, results.data(), paths.data(), paths.size(), edits.data(), edits.size(), written) : VGK_OK;
+    if (rc != VGK_OK && rc != VGK_ETOOBIG) return rc;                         // (single declined problems are in results[].status)
+    lap(0);
+    // 2. the declined links as align_sequence_between requests
+    std::deque<Alignment> alignments; std::vector<uint32_t> link_of;
+    ChainConnector connector(aligner, graph, in.max_dp_cells);
+    auto position = [&](uint32_t oriented, int64_t offset) { Position p; const handle_t h = graph.handle_of(oriented); p.node_id = graph.get_id(h); p.is_reverse = graph.get_is_reverse(h); p.offset = offset; return p; };
+    for (uint32_t i = 0; i < n; ++i) {
+        const vgk_wfa_result& r = results[i];
+        if (r.status == VGK_OK && r.ok) { out.link_score[i] = r.score; out.link_source[i] = ChainStageOutput::WFA; continue; }
+        out.wfa_status[i] = r.status != VGK_OK ? r.status : VGK_ENOBAND;
+        ++out.n_declined;
+        const bool connect = in.mode[i] == VGK_WFA_CONNECT;
+        if (!connect && !in.dp_for_tails) continue;
+        // WFA's endpoints are the bases next to the link; align_sequence_between's are the gaps between bases (:3074: graph_end / graph_start)
+        const Position left = in.mode[i] == VGK_WFA_PREFIX ? Position() : position(in.from_node[i], (int64_t)in.from_offset[i] + 1);
+        const Position right = in.mode[i] == VGK_WFA_SUFFIX ? Position() : position(in.to_node[i], (int64_t)in.to_offset[i]);
+        const size_t link_length = problems[i].seq_len;
+        // the longest gap a read of this length can detect in this stretch (:3067, :2700, :3250)
+        Alignment whole; whole.sequence.assign(in.read_length ? in.read_length[i] : link_length, 'N');
+        const size_t begin = in.read_begin ? in.read_begin[i] : 0;
+        const size_t gap = std::min(connect ? in.max_middle_gap : in.max_tail_gap, longest_detectable_gap_in_range(whole, begin, begin + link_length, &aligner));
+        const size_t path_length = std::max<size_t>(in.graph_distance ? in.graph_distance[i] : link_length, link_length) + gap;
+        alignments.emplace_back();
+        alignments.back().sequence.assign(problems[i].seq, link_length);
+        connector.add(left, right, path_length, gap, alignments.back(), true);
+        link_of.push_back(i);
+    }
+    lap(1);
+    // 3. local graphs on the host threads, one flush of DP problems, answers back in base-graph space
+    if (!link_of.empty()) connector.run(in.threads);
+    out.ms[2] += connector.last_extract_ms; out.ms[3] += connector.last_align_ms;
+    t0 = clock::now();
+    for (size_t k = 0; k < link_of.size(); ++k) {
+        const uint32_t i = link_of[k];
+        const ChainConnector::Outcome& o = connector.outcome(k);
+        switch (o.status) {
+            case ChainConnector::ALIGNED:
+                if (alignments[k].path.mapping.empty() && !alignments[k].sequence.empty()) { ++out.n_too_big; break; }
+                out.link_score[i] = alignments[k].score; out.link_source[i] = ChainStageOutput::BETWEEN; ++out.n_between; break;
+            case ChainConnector::NO_GRAPH: ++out.n_no_graph; break;
+            case ChainConnector::TOO_BIG: ++out.n_too_big; break;
+            default: ++out.n_failed; break;
+        }
+    }
+    for (uint32_t i = 0; i < n; ++i) out.chain_score[in.read_of[i]] += out.link_score[i];
+    if (in.anchor_score) for (uint32_t r = 0; r < in.n_reads; ++r) out.chain_score[r] += in.anchor_score[r];
+    out.ms[4] += connector.last_translate_ms;
+    lap(4);
+    return VGK_OK;
+}
+
+}  // namespace vgamd

@@ -55,6 +55,8 @@ std::shared_ptr<EngineApi> load_engine(const std::string& path) {
     bind(dl, "vgk_forest_graph", api->forest_graph);
     bind(dl, "vgk_forest_size", api->forest_size);
     bind(dl, "vgk_forest_destroy", api->forest_destroy);
+    bind(dl, "vgk_wfa_set_point_budgets", api->wfa_set_point_budgets);
+    bind(dl, "vgk_wfa_last_ms", api->wfa_last_ms);
     if (api->abi_version() != VGK_ABI_VERSION) throw std::runtime_error("vgamd engine: ABI version mismatch in " + p);
     return api;
 }

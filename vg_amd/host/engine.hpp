@@ -38,6 +38,8 @@ struct EngineApi {
     decltype(&vgk_forest_graph) forest_graph = nullptr;
     decltype(&vgk_forest_size) forest_size = nullptr;
     decltype(&vgk_forest_destroy) forest_destroy = nullptr;
+    decltype(&vgk_wfa_set_point_budgets) wfa_set_point_budgets = nullptr;
+    decltype(&vgk_wfa_last_ms) wfa_last_ms = nullptr;
     ~EngineApi();
 };
 

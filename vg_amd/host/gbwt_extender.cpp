@@ -13,6 +13,10 @@ HaplotypeGraph::HaplotypeGraph(const HandleGraph& graph, const std::vector<std::
         for (const handle_t& h : t) threads_.back().push_back(2u * (uint32_t)index_of_.at(graph.get_id(h)) + (graph.get_is_reverse(h) ? 1u : 0u));
         for (size_t k = 0; k + 1 < t.size(); ++k) { edges_.insert({t[k].v, t[k + 1].v}); edges_.insert({t[k + 1].v ^ 1, t[k].v ^ 1}); }
     }
+    // adjacency by oriented node, neighbours in handle order (the order the sorted edge set lists them in)
+    next_.assign(2 * ids_.size(), {}); prev_.assign(2 * ids_.size(), {});
+    for (const auto& e : edges_) { next_[oriented(handle_t{e.first})].push_back(e.second); prev_[oriented(handle_t{e.second})].push_back(e.first); }
+    for (auto& v : prev_) std::sort(v.begin(), v.end());
 }
 static char complement_base(char c) {
     switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
@@ -26,10 +30,7 @@ std::string HaplotypeGraph::get_sequence(const handle_t& h) const {
     return r;
 }
 bool HaplotypeGraph::follow_edges(const handle_t& h, bool go_left, const std::function<bool(const handle_t&)>& it) const {
-    for (const auto& e : edges_) {
-        if (!go_left && e.first == h.v) { if (!it(handle_t{e.second})) return false; }
-        if (go_left && e.second == h.v) { if (!it(handle_t{e.first})) return false; }
-    }
+    for (int64_t x : (go_left ? prev_ : next_)[oriented(h)]) if (!it(handle_t{x})) return false;
     return true;
 }
 bool HaplotypeGraph::for_each_handle(const std::function<bool(const handle_t&)>& it) const {

@@ -37,7 +37,8 @@ private:
     std::vector<std::string> seqs_;
     std::unordered_map<nid_t, size_t> index_of_;
     std::vector<std::vector<uint32_t>> threads_;      // oriented nodes
-    std::set<std::pair<int64_t, int64_t>> edges_;     // oriented node pairs that some thread crosses
+    std::set<std::pair<int64_t, int64_t>> edges_;     // handle pairs that some thread crosses
+    std::vector<std::vector<int64_t>> next_, prev_;   // the same as adjacency lists, by oriented node
 };
 
 // src/gbwt_extender.hpp:30-90
@@ -168,6 +169,7 @@ public:
     const HaplotypeGraph* graph;
     const Aligner*        aligner;
     const ErrorModel*     error_model;
+    const vgk_haplo* engine_index() const { return index; }     // the haplotype index in HBM, for batch stages that call the engine themselves (chain_stage.hpp)
 private:
     vgk_haplo* index = nullptr;
 };

@@ -445,3 +445,40 @@ int vgh_connector_run(vgh_connector* c, int threads, double* ms, char* json_out,
 }
 
 }  // extern "C"
+
+// ---- the chain stage (chain_stage.hpp): every link of a batch of reads through WFA, the declined ones through align_sequence_between ----
+#include "chain_stage.hpp"
+extern "C" {
+// w: the WFA handle (haplotype graph + index + aligner) of vgh_wfa_create.  stats: declined, between, no graph, too big, failed; ms[5].
+int vgh_chain_stage(vgh_wfa* w, const char* seqs, const uint64_t* seq_off, uint32_t n_links, const uint32_t* mode, const uint32_t* from_node, const uint32_t* from_offset,
+                    const uint32_t* to_node, const uint32_t* to_offset, const uint32_t* read_of, uint32_t n_reads, const uint32_t* graph_distance,
+                    const uint32_t* read_begin, const uint32_t* read_length, const int64_t* anchor_score, int threads, int dp_for_tails,
+                    int32_t* link_score, uint8_t* link_source, int32_t* wfa_status, int64_t* chain_score, uint64_t stats[5], double ms[5]) {
+    try {
+        ChainStageInput in{};
+        in.seqs = seqs; in.seq_off = seq_off; in.n_links = n_links; in.mode = mode; in.from_node = from_node; in.from_offset = from_offset;
+        in.to_node = to_node; in.to_offset = to_offset; in.read_of = read_of; in.n_reads = n_reads; in.graph_distance = graph_distance;
+        in.read_begin = read_begin; in.read_length = read_length; in.anchor_score = anchor_score; in.threads = (unsigned)std::max(threads, 0);
+        in.dp_for_tails = dp_for_tails != 0;
+        ChainStageOutput out;
+        const Aligner& aligner = *w->ext->aligner;
+        const int rc = run_chain_stage(aligner.engine_api(), aligner.engine_context(), w->ext->engine_index(), *w->graph, aligner, nullptr, in, out);
+        if (rc) { g_last_error = aligner.engine_api().strerror(rc); return rc; }
+        std::copy(out.link_score.begin(), out.link_score.end(), link_score);
+        std::copy(out.link_source.begin(), out.link_source.end(), link_source);
+        if (wfa_status) std::copy(out.wfa_status.begin(), out.wfa_status.end(), wfa_status);
+        std::copy(out.chain_score.begin(), out.chain_score.end(), chain_score);
+        if (stats) { stats[0] = out.n_declined; stats[1] = out.n_between; stats[2] = out.n_no_graph; stats[3] = out.n_too_big; stats[4] = out.n_failed; }
+        if (ms) for (int k = 0; k < 5; ++k) ms[k] = out.ms[k];
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+}  // extern "C"
+extern "C" {
+// vgk_wfa_set_point_budgets on the context behind this WFA handle (0, 0 = no budget: the reference has none)
+int vgh_wfa_set_point_budgets(vgh_wfa* w, uint32_t connect_points, uint32_t tail_points) {
+    const Aligner& a = *w->ext->aligner;
+    return a.engine_api().wfa_set_point_budgets(a.engine_context(), connect_points, tail_points);
+}
+double vgh_wfa_last_kernel_ms(vgh_wfa* w) { const Aligner& a = *w->ext->aligner; return a.engine_api().wfa_last_ms(a.engine_context()); }
+}

@@ -270,3 +270,80 @@ def winning_alignments(out):
             row[6] = [(int(fnode[base + int(x["node"])]), int(x["op"]), int(x["len"])) for x in o]
         rows[i] = tuple(row)
     return rows
+
+
+# ---- configs[4] with the whole stage in the host shim (vg_amd/host/chain_stage.cpp) -----------------------------------------------------
+class ChainStage:
+    """MinimizerMapper's chain alignment for a batch of reads, in C++ behind one call (vgh_chain_stage): every link through WFAExtender;
+    what it declines through align_sequence_between_consistently — the local graph between / beyond the anchors cut out of the haplotype
+    graph (extract_connecting_graph / extract_extending_graph), strands split, dagified, tips trimmed, then BandedGlobalAligner or pinned
+    X-drop — all inside the call.  Owns a host-shim aligner (its own engine context), the haplotype graph and the WFA extender."""
+
+    def __init__(self, wl, lib=None, scores=(1, 4, 6, 1, 5), device=0):
+        h = _host_lib()
+        h.vgh_graph_create.restype = ctypes.c_void_p
+        h.vgh_graph_destroy.argtypes = [ctypes.c_void_p]
+        h.vgh_graph_add_node.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p]
+        h.vgh_graph_add_edge.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+        h.vgh_aligner_create.restype = ctypes.c_void_p
+        h.vgh_aligner_create.argtypes = [ctypes.c_char_p] + [ctypes.c_int] * 6
+        h.vgh_aligner_destroy.argtypes = [ctypes.c_void_p]
+        h.vgh_wfa_create.restype = ctypes.c_void_p
+        h.vgh_wfa_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        h.vgh_wfa_destroy.argtypes = [ctypes.c_void_p]
+        h.vgh_wfa_set_point_budgets.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+        h.vgh_wfa_last_kernel_ms.restype = ctypes.c_double; h.vgh_wfa_last_kernel_ms.argtypes = [ctypes.c_void_p]
+        h.vgh_chain_stage.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_uint32] + [ctypes.c_void_p] * 4 + \
+                                     [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6
+        self.h = h
+        self.aligner = h.vgh_aligner_create(lib.encode() if lib else None, device, *scores)
+        if not self.aligner:
+            raise RuntimeError("vgh_aligner_create: " + (h.vgh_last_error() or b"?").decode())
+        g = h.vgh_graph_create()                                        # node v of the workload is node id v + 1: oriented node 2 v + strand in the index
+        for v, s in enumerate(wl.nodes):
+            h.vgh_graph_add_node(g, v + 1, s.encode())
+        for v, preds in enumerate(wl.preds):
+            for p in preds:
+                h.vgh_graph_add_edge(g, p + 1, v + 1)
+        flat = np.concatenate([np.asarray(t, dtype=np.int64) for t in wl.threads])
+        tn = ((flat >> 1) + 1) * 2 + (flat & 1)                           # handles: (id << 1) | strand
+        toff = np.concatenate([[0], np.cumsum([len(t) for t in wl.threads])]).astype(np.int32)
+        self.wfa = h.vgh_wfa_create(self.aligner, g, np.ascontiguousarray(tn).ctypes.data, toff.ctypes.data, len(wl.threads), None)
+        h.vgh_graph_destroy(g)                                            # (the haplotype graph holds its own copy)
+        if not self.wfa:
+            raise RuntimeError("vgh_wfa_create: " + (h.vgh_last_error() or b"?").decode())
+        a = wl.ws.array
+        self.n = wl.n; self.n_reads = wl.n_reads
+        self.seqs = np.ascontiguousarray(wl.ws.seqs); self.seq_off = np.ascontiguousarray(wl.ws.seq_off, dtype=np.uint64)
+        self.fields = [np.ascontiguousarray(a[k], dtype=np.uint32) for k in ("mode", "from_node", "from_offset", "to_node", "to_offset")]
+        self.read_of = np.ascontiguousarray(wl.read_of, dtype=np.uint32)
+        self.graph_distance = np.ascontiguousarray(wl.span, dtype=np.uint32)
+        self.read_begin = np.ascontiguousarray(wl.link_begin, dtype=np.uint32); self.read_length = np.ascontiguousarray(wl.link_read_length, dtype=np.uint32)
+        self.anchor_score = np.ascontiguousarray(wl.anchor_bases, dtype=np.int64)
+
+    def set_point_budgets(self, connect, tail):
+        self.h.vgh_wfa_set_point_budgets(self.wfa, connect, tail)
+
+    def run(self, threads=0, dp_for_tails=True, timing=None):
+        link_score = np.zeros(self.n, dtype=np.int32); source = np.zeros(self.n, dtype=np.uint8); status = np.zeros(self.n, dtype=np.int32)
+        chain = np.zeros(self.n_reads, dtype=np.int64); stats = np.zeros(5, dtype=np.uint64); ms = np.zeros(5, dtype=np.float64)
+        rc = self.h.vgh_chain_stage(self.wfa, self.seqs.ctypes.data, self.seq_off.ctypes.data, self.n, *[f.ctypes.data for f in self.fields], self.read_of.ctypes.data,
+                                    self.n_reads, self.graph_distance.ctypes.data, self.read_begin.ctypes.data, self.read_length.ctypes.data, self.anchor_score.ctypes.data,
+                                    threads, int(dp_for_tails), link_score.ctypes.data, source.ctypes.data, status.ctypes.data, chain.ctypes.data, stats.ctypes.data, ms.ctypes.data)
+        if rc:
+            raise RuntimeError("vgh_chain_stage: " + (self.h.vgh_last_error() or b"?").decode())
+        if timing is not None:
+            for k, v in zip(("wfa_extend (all links)", "requests for the declined links", "local graphs: extract + split + dagify + trim (host threads)",
+                             "banded + X-drop flush", "translation + totals"), ms):
+                timing[k] = timing.get(k, 0.0) + v * 1e-3
+        return dict(link_score=link_score, link_source=source, wfa_status=status, chain_score=chain,
+                    stats=dict(zip(("declined", "between", "no_graph", "too_big", "failed"), (int(x) for x in stats))), wfa_kernel_ms=self.h.vgh_wfa_last_kernel_ms(self.wfa))
+
+    def close(self):
+        if getattr(self, "wfa", None):
+            self.h.vgh_wfa_destroy(self.wfa); self.wfa = None
+        if getattr(self, "aligner", None):
+            self.h.vgh_aligner_destroy(self.aligner); self.aligner = None
+
+    def __del__(self):
+        self.close()

@@ -766,6 +766,7 @@ class LongReadWorkload:
         hap_seq = [np.concatenate([seqs[v] for v in t]) for t in threads]
         hap_start = [np.concatenate([[0], np.cumsum(lens[t])]) for t in threads]
         pieces, mode, fn, fo, tn, to, read_of, span, truth = [], [], [], [], [], [], [], [], []
+        link_begin, read_total = [], []                                       # where a link starts in its read; its read's length (for longest_detectable_gap_in_range)
         self.anchor_bases = np.zeros(n_reads, dtype=np.int64)
         for r in range(n_reads):
             h = int(rng.integers(0, n_haplotypes)); rev = bool(rng.random() < 0.5)
@@ -781,6 +782,7 @@ class LongReadWorkload:
             if rev:
                 segs = segs[::-1]
             self.anchor_bases[r] = anchor_len * len(anchors)
+            pos_in_read = 0; first_link = len(pieces)
 
             def pos(g):
                 k = int(np.searchsorted(st, g, side="right") - 1)
@@ -816,12 +818,15 @@ class LongReadWorkload:
                 else:
                     mode.append(capi.WFA_CONNECT); p = pos(before); fn.append(p[0]); fo.append(p[1]); p = pos(after); tn.append(p[0]); to.append(p[1])
                 pieces.append(w); read_of.append(r); span.append(hi - lo); truth.append((lo, hi, rev, h))
+                link_begin.append(pos_in_read); pos_in_read += len(w) + anchor_len          # an anchor follows every link but the read's last
+            read_total += [pos_in_read - anchor_len] * (len(pieces) - first_link)
         seq_off = np.concatenate([[0], np.cumsum([len(p) for p in pieces])]).astype(np.int64)
         buf = np.concatenate(pieces) if seq_off[-1] else np.zeros(1, np.uint8)
         n = len(pieces)
         self.ws = capi.WfaSet(buf, seq_off, np.array(mode, dtype=np.uint32), np.array(fn, dtype=np.uint32), np.array(fo, dtype=np.uint32),
                               np.array(tn, dtype=np.uint32), np.array(to, dtype=np.uint32), path_cap=n * 24 + int(seq_off[-1]) // 4, edit_cap=n * 12)
         self.n = n; self.n_reads = n_reads; self.read_of = np.array(read_of); self.span = np.array(span); self.truth = truth
+        self.link_begin = np.array(link_begin, dtype=np.int64); self.link_read_length = np.array(read_total, dtype=np.int64)
         self.read_bases = int(seq_off[-1]) + int(self.anchor_bases.sum())
         self.hap_start = hap_start; self.thread_nodes = threads
 
