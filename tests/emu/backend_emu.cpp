@@ -5,6 +5,8 @@
 // It lets the kernel logic be debugged in a container without a GPU.  It is
 // never built into, nor loaded by, the product library.
 #include <pthread.h>
+#include <ucontext.h>
+#include <memory>
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
@@ -131,6 +133,65 @@ public:
     int fill(void* d, int byte, size_t n) override { std::memset(d, byte, n); return VGK_OK; }
     int run_wfa(const WfaParams& P, uint32_t threads) override {
         for (uint32_t t = 0; t < threads; ++t) wfa_thread(P, t, nullptr, 1);
+        return VGK_OK;
+    }
+    // the wavefront form: the 64 lanes of ONE resident wavefront (slab 0), which takes every problem in turn.  The lanes are 64 fibers of
+    // this thread, switched round-robin at every cross-lane operation: every lane executes the same sequence of such operations, so a
+    // lane that has deposited its value and yielded once finds everyone else's value there when its turn comes again (two buffers, by
+    // the parity of the operation's number: the lanes ahead are already depositing for the next one).  No OS threads, no barriers:
+    // ~50 x faster than the barrier emulation above, and deterministic.
+    struct FiberWave {
+        static constexpr int N = 64;
+        ucontext_t main_ctx, ctx[N]; std::vector<char> stack[N];
+        int current = 0;
+        int32_t buf[2][N]; unsigned long long wide[2][N]; uint32_t epoch[N];
+        const WwParams* P = nullptr; WwShared shared;
+        void yield() { const int me = current; current = (me + 1) % N; swapcontext(&ctx[me], &ctx[current]); }
+    };
+    struct WwXlEmu {
+        FiberWave* w; uint32_t lane;
+        int slot() { return (int)(w->epoch[lane]++ & 1u); }
+        unsigned long long ballot(bool flag) {
+            const int p = slot(); w->buf[p][lane] = flag ? 1 : 0; w->yield();
+            unsigned long long m = 0; for (uint32_t l = 0; l < 64; ++l) if (w->buf[p][l]) m |= 1ull << l;
+            return m;
+        }
+        uint32_t bcast(uint32_t v, uint32_t src) { const int p = slot(); w->buf[p][lane] = (int32_t)v; w->yield(); return (uint32_t)w->buf[p][src]; }
+        unsigned long long reduce_min_u64(unsigned long long v) {
+            const int p = slot(); w->wide[p][lane] = v; w->yield();
+            unsigned long long m = ~0ull; for (uint32_t l = 0; l < 64; ++l) m = w->wide[p][l] < m ? w->wide[p][l] : m;
+            return m;
+        }
+        int32_t reduce_max(int32_t v) {
+            const int p = slot(); w->buf[p][lane] = v; w->yield();
+            int32_t m = w->buf[p][0]; for (uint32_t l = 1; l < 64; ++l) m = w->buf[p][l] > m ? w->buf[p][l] : m;
+            return m;
+        }
+        void fence() { slot(); w->yield(); }
+        unsigned long long load64(const unsigned long long* p) { return *p; }
+        void store64(unsigned long long* p, unsigned long long v) { *p = v; }
+        unsigned long long cas64(unsigned long long* p, unsigned long long expect, unsigned long long desired) { const unsigned long long old = *p; if (old == expect) *p = desired; return old; }
+        uint32_t add32(uint32_t* p, uint32_t v) { const uint32_t old = *p; *p += v; return old; }
+    };
+    static void fiber_entry(unsigned lo, unsigned hi, unsigned lane) {
+        FiberWave* w = reinterpret_cast<FiberWave*>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+        WwXlEmu xl{w, lane};
+        wfa_wave(*w->P, 0, lane, w->shared, xl);
+    }
+    int run_wfa_wave(const WwParams& P, uint32_t waves) override {
+        if (!P.n_todo || !waves) return VGK_OK;
+        std::unique_ptr<FiberWave> w(new FiberWave());
+        w->P = &P;
+        for (int l = 0; l < FiberWave::N; ++l) {
+            w->epoch[l] = 0; w->stack[l].resize(512 * 1024);
+            getcontext(&w->ctx[l]);
+            w->ctx[l].uc_stack.ss_sp = w->stack[l].data(); w->ctx[l].uc_stack.ss_size = w->stack[l].size();
+            w->ctx[l].uc_link = l + 1 < FiberWave::N ? &w->ctx[l + 1] : &w->main_ctx;      // a lane that returns hands over to the next; the last one to the caller
+            const uintptr_t ptr = (uintptr_t)w.get();
+            makecontext(&w->ctx[l], (void (*)())fiber_entry, 3, (unsigned)(ptr & 0xffffffffu), (unsigned)(ptr >> 32), (unsigned)l);
+        }
+        w->current = 0;
+        swapcontext(&w->main_ctx, &w->ctx[0]);
         return VGK_OK;
     }
     int run_gapless(const GaplessParams& P, uint32_t threads) override {

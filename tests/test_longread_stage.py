@@ -112,8 +112,9 @@ def test_native_chain_stage_with_declined_links(emu_lib):
 
 def test_native_chain_stage_equals_the_python_pipeline(emu_lib):
     """the same reads through round 2's Python glue (its own stand-in for the graph between two anchors: a run of the topological order)"""
-    wl, a, _ = native_stage(emu_lib, 5, 2500, 4, 0.1)
+    wl, a, _ = native_stage(emu_lib, 5, 2500, 4, 0.1, budgets=(48, 48))          # (a point budget, so that there are declined links at all)
     eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=emu_lib)
+    eng.wfa_set_point_budget(48)
     old = pipeline.chain_stage(eng, eng.haplo_index(wl.nodes, wl.threads), wl)
     assert len(old["failed"]) == a["stats"]["declined"] > 0
     assert (old["chain_score"] == a["chain_score"]).all()

@@ -1,6 +1,8 @@
 """Haplotype-consistent wavefront alignment: the oracle against the reference's known-answer tests
 (src/unittest/gbwt_extender.cpp:1531-2640, transcribed into tests/golden/ref_wfa_extender.json by
 tests/golden/extract_wfa_tests.py), then the kernel (CPU emulation here, HIP under -m gpu) against the oracle."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -365,3 +367,80 @@ def test_wfa_over_run_length_encoded_records(monkeypatch):
             assert (ea[ra["edit_begin"][i]:ra["edit_begin"][i] + ra["n_edits"][i]] == eb[rb["edit_begin"][i]:rb["edit_begin"][i] + rb["n_edits"][i]]).all()
             n_ok += 1
     assert n_ok > 150
+
+
+# ---- the two forms of the kernel (one wavefront per problem — the default — and one thread per problem) and the wavefront form's two table sizes ----
+def test_thread_form_of_the_kernel_matches_the_oracle(monkeypatch):
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    monkeypatch.setenv("VGAMD_WFA_KERNEL", "thread")
+    assert run_golden(capi.Engine(lib=capi.load_library(util.EMU_LIB))) >= 100
+    ok, statuses = compare_engines(util.EMU_LIB, range(300, 330))
+    assert ok > 700 and statuses.get(0, 0) > 0.98 * sum(statuses.values()), (ok, statuses)
+
+
+def last_wave(eng, which):
+    eng.lib.vgk_wfa_last_wave.restype = ctypes.c_double
+    eng.lib.vgk_wfa_last_wave.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    return eng.lib.vgk_wfa_last_wave(eng.h, which)
+
+
+def retries_with_large_tables(lib, seeds, n_problems):
+    """small tables of 16 points: most problems outgrow them and run again with the large ones; every answer still equals the oracle's"""
+    ora = capi.Engine(lib=util.ORACLE_LIB); eng = capi.Engine(lib=lib) if lib else capi.Engine()
+    retried = answered = 0
+    for s in seeds:
+        nodes, threads, problems = random_wfa_case(np.random.default_rng(s), n_problems)
+        a = ora.wfa_extend(ora.haplo_index(nodes, threads), problems, MODELS[s % len(MODELS)])
+        b = eng.wfa_extend(eng.haplo_index(nodes, threads), problems, MODELS[s % len(MODELS)])
+        retried += int(last_wave(eng, 2))
+        for i in range(len(problems)):
+            if b[0]["status"][i] == -7:
+                continue
+            ra, pa, ea = unpack(*a, i); rb, pb, eb = unpack(*b, i)
+            assert all(ra[f] == rb[f] for f in ("status", "ok", "score", "node_offset", "seq_offset", "length", "path_len", "n_edits")) and pa == pb and ea == eb, (s, i)
+            answered += 1
+    return retried, answered
+
+
+def test_wave_form_runs_what_outgrows_the_small_tables_again(monkeypatch):
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    monkeypatch.setenv("VGAMD_WFA_SMALL_POINTS", "16")
+    retried, answered = retries_with_large_tables(util.EMU_LIB, range(500, 520), 60)
+    assert retried > 150 and answered > 1150, (retried, answered)
+
+
+def budgets_decline_the_same_problems(lib, monkeypatch, seeds=range(600, 612), n_problems=60):
+    """a caller's point budget ends the same problems in either form of the kernel, and leaves every other answer alone"""
+    for s in seeds:
+        nodes, threads, problems = random_wfa_case(np.random.default_rng(s), n_problems)
+        out = []
+        for form in ("wave", "thread"):
+            monkeypatch.setenv("VGAMD_WFA_KERNEL", form)
+            eng = capi.Engine(lib=lib) if lib else capi.Engine()
+            eng.wfa_set_point_budget(24)
+            out.append(eng.wfa_extend(eng.haplo_index(nodes, threads), problems, MODELS[s % len(MODELS)]))
+        a, b = out
+        assert (a[0]["status"] == b[0]["status"]).all(), s
+        assert (a[0]["status"] == -7).any()
+        for i in np.nonzero(a[0]["status"] == 0)[0]:
+            assert unpack(*a, i) == unpack(*b, i), (s, i)
+
+
+def test_point_budget_declines_the_same_problems_in_both_forms(monkeypatch):
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    budgets_decline_the_same_problems(util.EMU_LIB, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_both_forms_and_both_table_sizes_on_the_gpu(monkeypatch):
+    budgets_decline_the_same_problems(None, monkeypatch, seeds=range(700, 720), n_problems=300)
+    monkeypatch.setenv("VGAMD_WFA_KERNEL", "thread")
+    ok, statuses = compare_engines(None, range(440, 460), n_problems=400)
+    assert ok > 3500
+    monkeypatch.setenv("VGAMD_WFA_KERNEL", "wave")
+    monkeypatch.setenv("VGAMD_WFA_SMALL_POINTS", "16")
+    retried, answered = retries_with_large_tables(None, range(800, 820), 400)
+    assert retried > 1000 and answered > 7800, (retried, answered)

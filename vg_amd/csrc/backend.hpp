@@ -10,6 +10,7 @@
 #include "banded_device.hpp"
 #include "gapless_device.hpp"
 #include "wfa_device.hpp"
+#include "wfa_wave_device.hpp"
 #include "gssw_matrix_device.hpp"
 #include "gssw_pack_device.hpp"
 #include "tail_device.hpp"
@@ -102,6 +103,8 @@ public:
     // wavefront alignment: likewise, `threads` resident threads (one WScratch each, zeroed by the caller once) stride over
     // p.n problems; last_ms(6) = kernel ms
     virtual int   run_wfa(const WfaParams& p, uint32_t threads) = 0;
+    virtual int   run_wfa_wave(const WwParams& p, uint32_t waves) = 0;    // one wavefront per problem (wfa_wave_device.hpp); the time adds to last_ms(6)
+    virtual void  reset_wfa_ms() {}
     // pinned gssw fill that keeps H / E / F of every cell (k-best tracebacks): one thread per problem
     virtual int   run_gssw_matrix(const GsswMatrixParams& p) = 0;
     // X-drop with dozeu's band (vgk_xdrop_band_align): one wavefront per problem, the matrices stay for the host's traceback;

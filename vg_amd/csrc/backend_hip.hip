@@ -493,6 +493,36 @@ __global__ void __launch_bounds__(64, 4) wfa_kernel(const WfaParams P, const uin
     if (t < threads) wfa_thread(P, t, node_end + threadIdx.x, 64);
 }
 
+// ---- wavefront alignment, one wavefront per problem (wfa_wave_device.hpp): trie nodes, possible penalties and the lanes' work lists in
+//      LDS, the wavefront table / its log / the path pool in the wavefront's slab (workgroup-scope atomics: one wavefront = one workgroup)
+struct WwXlHip {
+    __device__ __forceinline__ unsigned long long ballot(bool flag) const { return __ballot(flag); }
+    __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src) const { return (uint32_t)__shfl((int)v, (int)src, 64); }
+    __device__ __forceinline__ unsigned long long reduce_min_u64(unsigned long long v) const {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const unsigned long long o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+        return v;
+    }
+    __device__ __forceinline__ int32_t reduce_max(int32_t v) const {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const int32_t o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+        return v;
+    }
+    __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+    __device__ __forceinline__ unsigned long long load64(const unsigned long long* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ __forceinline__ void store64(unsigned long long* p, unsigned long long v) const { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ __forceinline__ unsigned long long cas64(unsigned long long* p, unsigned long long expect, unsigned long long desired) const {
+        __hip_atomic_compare_exchange_strong(p, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return expect;                                                         // the value found there
+    }
+    __device__ __forceinline__ uint32_t add32(uint32_t* p, uint32_t v) const { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+};
+__global__ void __launch_bounds__(64) wfa_wave_kernel(const WwParams P) {
+    __shared__ WwShared sh;
+    WwXlHip xl;
+    wfa_wave(P, blockIdx.x, threadIdx.x, sh, xl);
+}
+
 // ---- pinned gssw fill with full matrices (gssw_matrix_device.hpp): one wavefront per problem, R read rows per lane; the
 //      one-thread-per-problem form remains for scorings with gap_open < gap_extend
 __global__ void __launch_bounds__(64) gssw_matrix_kernel(const GsswMatrixParams P) {
@@ -913,6 +943,18 @@ public:
         hipEventElapsedTime(&ms_wfa, bev[0], bev[1]);
         return VGK_OK;
     }
+    int run_wfa_wave(const WwParams& p, uint32_t waves) override {
+        hipSetDevice(dev);
+        if (!p.n_todo || !waves) return VGK_OK;
+        hipEventRecord(bev[0], stream);
+        hipLaunchKernelGGL(wfa_wave_kernel, dim3(waves), dim3(64), 0, stream, p);
+        hipEventRecord(bev[1], stream);
+        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
+        float ms = 0.f; hipEventElapsedTime(&ms, bev[0], bev[1]);
+        ms_wfa += ms;
+        return VGK_OK;
+    }
+    void reset_wfa_ms() override { ms_wfa = 0.f; }
     double last_ms(int which) const override {
         if (which == 6) return ms_wfa;
         if (which == 7) return ms_xband;

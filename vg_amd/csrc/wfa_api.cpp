@@ -16,7 +16,8 @@ using namespace vgk;
 
 namespace {
 
-struct WfaHost { PinnedBuf<char> seqs; PinnedBuf<WProb> probs; PinnedBuf<vgk_wfa_result> dres; PinnedBuf<uint32_t> dpaths, dedits; uint64_t zeroed_bytes = 0; void* zeroed_ptr = nullptr; };
+struct WfaHost { PinnedBuf<char> seqs; PinnedBuf<WProb> probs; PinnedBuf<vgk_wfa_result> dres; PinnedBuf<uint32_t> dpaths, dedits; uint64_t zeroed_bytes = 0; void* zeroed_ptr = nullptr;
+                 void* slab_ptr[2] = {nullptr, nullptr}; uint64_t slab_bytes[2] = {0, 0}, slab_shape[2] = {0, 0}; };
 
 const vgk_wfa_error_model kDefaultModel = { { 0.03, 1, 6 }, { 0.05, 1, 10 }, { 0.1, 1, 20 }, { 0.1, 10, 200 } };   // gbwt_extender.hpp:386-395
 
@@ -25,6 +26,75 @@ int32_t evaluate(const vgk_wfa_event& e, uint32_t length) {                     
 }
 char complement(char c) {
     switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'X'; }
+}
+
+// The wavefront form's slabs: per resident wavefront the table, its log, the path pool and the backtrace's edit runs, carved out of one
+// allocation per launch size; the table part must be all-zero before a launch (the kernel leaves it so).
+struct WaveSlabs { uint32_t waves, n_slots, max_points, path_cap; };
+int carve(vgk_ctx* ctx, WfaHost& H, int slot, int which, const WaveSlabs& z, WwParams& W) {
+    Backend* be = ctx->be.get();
+    const uint64_t w = z.waves;
+    const uint64_t b_slots = 8ull * z.n_slots * w, b_logs = 4ull * z.max_points * w, b_pn = 4ull * z.path_cap * w, b_ps = 2ull * z.path_cap * w, b_runs = 4ull * W_EDITS * w;
+    const uint64_t want = b_slots + b_logs + b_pn + 2 * b_ps + b_runs + 64;
+    char* base = (char*)ctx->ensure_scratch(slot, want);
+    if (!base) return VGK_ENOMEM;
+    if (H.slab_ptr[which] != base || H.slab_bytes[which] < want || H.slab_shape[which] != ((uint64_t)z.n_slots << 32 | z.waves)) {
+        if (be->zero(base, ctx->scratch[slot].bytes)) return VGK_ENODEV;
+        H.slab_ptr[which] = base; H.slab_bytes[which] = ctx->scratch[slot].bytes; H.slab_shape[which] = (uint64_t)z.n_slots << 32 | z.waves;
+    }
+    W.slots = (unsigned long long*)base; W.n_slots = z.n_slots;
+    W.logs = (uint32_t*)(base + b_slots); W.max_points = z.max_points;
+    W.path_node = (int32_t*)(base + b_slots + b_logs); W.path_start = (uint16_t*)(base + b_slots + b_logs + b_pn); W.path_next = (uint16_t*)(base + b_slots + b_logs + b_pn + b_ps);
+    W.path_cap = z.path_cap;
+    W.edit_runs = (uint32_t*)(base + b_slots + b_logs + b_pn + 2 * b_ps);
+    return VGK_OK;
+}
+// every problem with small tables; what outgrows them once more with large ones
+int launch_wave_form(vgk_ctx* ctx) {
+    Backend* be = ctx->be.get();
+    WwParams& A = ctx->wfa_wave_last[0]; WwParams& B = ctx->wfa_wave_last[1];
+    int rc;
+    be->reset_wfa_ms();
+    if ((rc = be->zero(A.n_declined, 16))) return rc;
+    if ((rc = be->run_wfa_wave(A, ctx->wfa_wave_waves[0]))) return rc;
+    ctx->wfa_wave_ms[0] = be->last_ms(6); ctx->wfa_wave_ms[1] = 0;
+    unsigned long long declined = 0;
+    if ((rc = be->download(&declined, A.n_declined, sizeof declined))) return rc;
+    ctx->wfa_wave_retried = declined;
+    if (declined) {
+        B.n_todo = (uint32_t)declined;
+        if ((rc = be->zero(B.base.counters + 2, 8))) return rc;                  // the hand-out counter starts over; paths / edits go on behind the first launch's
+        if ((rc = be->run_wfa_wave(B, (uint32_t)std::min<uint64_t>(declined, ctx->wfa_wave_waves[1])))) return rc;
+        ctx->wfa_wave_ms[1] = be->last_ms(6) - ctx->wfa_wave_ms[0];
+    }
+    ctx->wfa_ms = be->last_ms(6);
+    return VGK_OK;
+}
+int run_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P) {
+    Backend* be = ctx->be.get();
+    const uint32_t cus = (uint32_t)std::max(1, be->compute_units());
+    uint32_t per_cu[2] = {12, 8};
+    if (const char* e = std::getenv("VGAMD_WFA_WAVES_PER_CU")) per_cu[0] = (uint32_t)std::max(1, std::atoi(e));
+    // small tables: 256 points cover all but a percent or two of giraffe's links (median: a dozen points); large: what a link with a
+    // 60-base insertion under the default error model stores, several times over
+    WaveSlabs za{std::min<uint32_t>(P.n, cus * per_cu[0]), 512u, 256u, 128u}, zb{cus * per_cu[1], 32768u, 16384u, 2048u};
+    if (const char* e = std::getenv("VGAMD_WFA_SMALL_POINTS")) { za.max_points = (uint32_t)std::max(16, std::atoi(e)); za.n_slots = 64; while (za.n_slots < 2 * za.max_points) za.n_slots *= 2; }
+    WwParams A{}, B{};
+    A.base = P; B.base = P;
+    // a caller's point budget below the tables' own sizes ends a problem as before (vgk_wfa_set_point_budgets); 0 = none
+    A.base.max_points = B.base.max_points = ctx->wfa_point_budget ? ctx->wfa_point_budget : 0xffffffffu;
+    A.base.max_points_tail = B.base.max_points_tail = ctx->wfa_point_budget_tail ? ctx->wfa_point_budget_tail : 0xffffffffu;
+    int rc;
+    if ((rc = carve(ctx, H, 61, 0, za, A)) || (rc = carve(ctx, H, 62, 1, zb, B))) return rc;
+    char* extra = (char*)ctx->ensure_scratch(63, sizeof(uint32_t) * ((size_t)P.n + 8) + 16);
+    if (!extra) return VGK_ENOMEM;
+    A.todo = P.order; A.n_todo = P.n;
+    A.n_declined = (unsigned long long*)extra; A.declined = (uint32_t*)(extra + 16);
+    B.todo = A.declined; B.n_todo = 0; B.declined = nullptr; B.n_declined = nullptr;
+    ctx->wfa_wave_last[0] = A; ctx->wfa_wave_last[1] = B; ctx->wfa_wave_waves[0] = za.waves; ctx->wfa_wave_waves[1] = zb.waves;
+    if ((rc = launch_wave_form(ctx))) return rc;
+    ctx->wfa_wave_last_valid = true; ctx->wfa_last_valid = false;
+    return VGK_OK;
 }
 
 }  // namespace
@@ -168,9 +238,15 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     P.caps[0] = cap_p; P.caps[1] = cap_e;
     P.max_points = ctx->wfa_point_budget && ctx->wfa_point_budget < (uint32_t)W_POINTS ? ctx->wfa_point_budget : (uint32_t)W_POINTS;
     P.max_points_tail = ctx->wfa_point_budget_tail && ctx->wfa_point_budget_tail < (uint32_t)W_POINTS ? ctx->wfa_point_budget_tail : (uint32_t)W_POINTS;
+    // Two kernels answer the same problems with the same results: one WAVEFRONT per problem, the lanes being the diagonals
+    // (wfa_wave_device.hpp; the default), and one THREAD per problem (wfa_device.hpp; VGAMD_WFA_KERNEL=thread).
+    bool wave_form = true;
+    if (const char* e = std::getenv("VGAMD_WFA_KERNEL")) wave_form = std::strcmp(e, "thread") != 0;
     uint64_t per_cu = 1024;         // 16 wavefronts per CU: the kernel is built for at most 128 VGPRs (__launch_bounds__(64, 4))
     if (const char* e = std::getenv("VGAMD_WFA_THREADS_PER_CU")) per_cu = (uint64_t)std::max(64, std::atoi(e));
-    const uint32_t threads = (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max(1, be->compute_units()) * per_cu);
+    const uint32_t threads = wave_form ? 1u : (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max(1, be->compute_units()) * per_cu);
+    if (wave_form) P.scratch = reinterpret_cast<WScratch*>(ctx->ensure_scratch(32, 64));
+    else
     { const uint64_t want = sizeof(WScratch) * (uint64_t)threads;
       P.scratch = (WScratch*)ctx->ensure_scratch(32, want);
       // the kernel leaves every slab's table all-zero; a fresh (or regrown) allocation is zeroed once
@@ -186,9 +262,13 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     if (!P.probs || !P.seqs || !P.order || !P.scratch || !P.results || !P.paths || !P.edits || !P.counters) return VGK_ENOMEM;
     int rc;
     if ((rc = be->zero(P.counters, 64))) return rc;
-    if ((rc = be->run_wfa(P, threads))) return rc;
-    ctx->wfa_last = P; ctx->wfa_last_threads = threads; ctx->wfa_last_valid = true;
-    ctx->wfa_ms = be->last_ms(6);
+    if (wave_form) {
+        if ((rc = run_wave_form(ctx, H, P))) return rc;
+    } else {
+        if ((rc = be->run_wfa(P, threads))) return rc;
+        ctx->wfa_last = P; ctx->wfa_last_threads = threads; ctx->wfa_last_valid = true; ctx->wfa_wave_last_valid = false;
+        ctx->wfa_ms = be->last_ms(6);
+    }
     unsigned long long counters[2] = {0, 0};
     vgk_wfa_result* dres = H.dres.get(be, n);
     if (!dres) return VGK_ENOMEM;
@@ -223,6 +303,10 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
 int vgk_wfa_rerun(vgk_ctx* ctx) {
     if (!ctx) return VGK_EINVAL;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->wfa_wave_last_valid) {
+        if (int rc = ctx->be->zero(ctx->wfa_wave_last[0].base.counters, 64)) return rc;
+        return launch_wave_form(ctx);
+    }
     if (!ctx->wfa_last_valid) return VGK_EINVAL;
     int rc;
     if ((rc = ctx->be->zero(ctx->wfa_last.counters, 64))) return rc;
@@ -232,6 +316,8 @@ int vgk_wfa_rerun(vgk_ctx* ctx) {
 }
 
 double vgk_wfa_last_ms(vgk_ctx* ctx) { return ctx ? ctx->wfa_ms : 0.0; }
+// the wavefront form's two launches: 0 = ms of the small-table launch, 1 = ms of the large-table launch, 2 = problems the second one took
+double vgk_wfa_last_wave(vgk_ctx* ctx, int which) { return !ctx ? 0.0 : which == 0 ? ctx->wfa_wave_ms[0] : which == 1 ? ctx->wfa_wave_ms[1] : (double)ctx->wfa_wave_retried; }
 int vgk_wfa_set_point_budget(vgk_ctx* ctx, uint32_t points) { return vgk_wfa_set_point_budgets(ctx, points, points); }
 int vgk_wfa_set_point_budgets(vgk_ctx* ctx, uint32_t connect_points, uint32_t tail_points) {
     if (!ctx) return VGK_EINVAL;

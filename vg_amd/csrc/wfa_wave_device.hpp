@@ -1,0 +1,682 @@
+// wfa_wave_device.hpp — haplotype-consistent wavefront alignment, one WAVEFRONT per problem: the lanes are the diagonals.
+//
+// The algorithm is wfa_device.hpp's (WFAExtender::connect over a WFATree, reference src/gbwt_extender.cpp:1567-2235); what changes is
+// who does the work.  In the reference — and in the one-thread kernel — a penalty step is two loops over (diagonal, leaf of the
+// haplotype trie): extend() and next().  Nearly all of their body is pure: table lookups of wavefront points stored under smaller
+// penalties, a comparison of bases, one store under a key that no other (diagonal, leaf) pair writes differently.  Here every lane
+// takes one (diagonal, leaf) item of the step; the wavefront runs as long as its slowest ITEM instead of the sum of all of them, and
+// a launch as long as its slowest problem's critical path instead of that problem's whole work.
+//
+// What is NOT pure is the trie itself, and results depend on it in one way only: trie nodes are numbered in creation order, and the
+// number decides ties (which of two equally good candidates is met first, :1896; which equally good partial alignment trim keeps).
+// The rules that keep the numbering — and with it every result — identical to the sequential order:
+//   * an item's KEY is (diagonal, leaf) — the reference's iteration order (:1660-1663 per diagonal, get_leaves() in node order);
+//   * trie nodes are never grown lazily here: a node is walked when it is created, to its end (branch, dead end, target, 1024
+//     bases) or as far as any position of this problem can reach (sequence length + the deletions the score cap allows); a position
+//     that still reaches the walked end of an unfinished node ends the problem with VGK_ETOOBIG instead of a wrong answer;
+//   * children are created ("expansion", :1992-2008) by ONE lane at a time: an item that needs a node expanded blocks; when every
+//     lane is done or blocked, the blocked lane with the smallest key creates the children — every item with a smaller key is
+//     done by then, as in the sequential order — and it alone goes on as the reference's recursion does (extend_over on the new
+//     children, :1919-1925); lanes that find a node expanded by someone else take its children as items of their own, in node
+//     order behind every older leaf (which is where get_leaves() lists them for the following diagonals);
+//   * next() never needs the children it asks for: its expansions are applied after the chunk of items, in key order;
+//   * chunks of items hold whole diagonals, so a later chunk sees the trie exactly as the sequential loop would at its first diagonal;
+//   * lanes that share an ancestor repeat its work and store the same point under the same key: stores are idempotent (64-bit,
+//     compare-and-swap to claim a slot); nobody reads a point of the current penalty on another lane's diagonal.
+// Candidates carry their key and are merged by (penalty, key): the first among equals in the sequential order.
+//
+// Tables: per resident wavefront one slab in HBM — it is a few KB per problem and stays in the L2 of the wavefront's XCD — for the
+// wavefront table, its insertion log and the path pool; trie nodes, possible penalties and the lanes' work lists in LDS.  A launch
+// comes in two sizes: small tables for everyone, and the problems that outgrow them are collected and run again with large ones
+// (wfa_api.cpp); only what outgrows those as well is reported VGK_ETOOBIG.
+#pragma once
+#include "wfa_device.hpp"
+
+namespace vgk {
+
+constexpr int WW_QUEUE = 32;          // work-list entries per lane (trie nodes: each is queued at most once per item)
+
+struct WwParams {
+    WfaParams base;                   // index, problems, sequences, scoring, outputs, counters[2] = next problem to hand out
+    const uint32_t* todo; uint32_t n_todo;      // the problems of this launch, in hand-out order
+    unsigned long long* slots; uint32_t n_slots;   // per resident wavefront: n_slots (a power of two) table slots ...
+    uint32_t* logs; uint32_t max_points;            // ... max_points log entries (= points a problem may store) ...
+    int32_t* path_node; uint16_t* path_start; uint16_t* path_next; uint32_t path_cap;   // ... path_cap pool entries ...
+    uint32_t* edit_runs;                            // ... and W_EDITS edit runs for the backtrace
+    uint32_t* declined; unsigned long long* n_declined;   // problems that outgrew this launch's tables (nullable: they are reported VGK_ETOOBIG)
+};
+
+struct WwShared {                     // per wavefront, in LDS
+    WNode    nodes[W_NODES];
+    uint32_t ps_range[W_SCORES]; uint8_t ps_flags[W_SCORES];
+    uint8_t  queue[64][WW_QUEUE];     // per lane: origins found expanded by someone else, in node order (FIFO)
+    uint8_t  stack_cur[64][WW_QUEUE], stack_end[64][WW_QUEUE];    // per lane: child ranges of the expansions it made itself (the recursion)
+    int32_t  expanded_at[W_NODES];    // next(): the diagonal of the item whose request expanded the node in the current chunk
+    uint32_t n_nodes, n_path, n_points, leaves;
+};
+
+enum { WX_FETCH = 0, WX_MATCH = 1, WX_AFTER = 2, WX_BLOCKED = 3, WX_DONE = 4 };
+
+template <class XL> struct WwCtx {
+    const WwParams* P; WwShared* sh; XL* xl; uint32_t lane;
+    unsigned long long* slot; uint32_t mask; uint32_t* log; uint32_t max_points;
+    int32_t* path_node; uint16_t* path_start; uint16_t* path_next; uint32_t path_cap;
+    const char* seq; uint32_t L;
+    int32_t to_node; uint32_t to_off; bool no_to;
+    uint32_t grow_cap;                // bases a trie node is walked at its creation unless it ends earlier
+    int32_t min_distance;
+    // this lane's findings, merged after every phase
+    int32_t cand_score, cand_diag; uint32_t cand_seq, cand_off, cand_node, cand_leaf;
+    int32_t max_distance;
+    bool overflow; int why;           // why: 1 points, 2 trie nodes, 3 path pool, 4 edits, 5 node length, 6 walked end reached, 7 work list
+};
+
+// ---- possible penalties ----
+template <class XL> VGK_HD WPScore ww_ps(const WwCtx<XL>& c, int32_t score) {
+    WPScore p; p.flags = c.sh->ps_flags[score];
+    const uint32_t r = c.sh->ps_range[score];
+    p.min_d = (int16_t)(r & 0xffffu); p.max_d = (int16_t)(r >> 16);
+    return p;
+}
+template <class XL> VGK_HD WSrc ww_src(const WwCtx<XL>& c, int32_t score) {
+    WSrc s = { score, 1, 0 };
+    if (score < 0) return s;
+    const WPScore ps = ww_ps(c, score);
+    if (ps.flags & 1) { s.lo = ps.min_d; s.hi = ps.max_d; }
+    return s;
+}
+
+// ---- the wavefront table: w_key / the node-free hash of wfa_device.hpp over this launch's slot count ----
+template <class XL> VGK_HD uint32_t ww_hash(const WwCtx<XL>& c, uint32_t key) { return ((((key - 1u) >> 5) * 2654435761u) >> 8) & c.mask; }
+template <class XL> VGK_HD bool ww_lookup(WwCtx<XL>& c, uint32_t ancestors, int kind, int32_t score, int32_t diag, uint32_t& node, uint32_t& seq, uint32_t& off) {
+    const uint32_t cell = (w_key(0, kind, score, diag) - 1u) >> 5;
+    bool found = false; uint32_t best = 0;
+    for (uint32_t i = ww_hash(c, w_key(0, kind, score, diag));; i = (i + 1) & c.mask) {
+        const unsigned long long s = c.xl->load64(c.slot + i);
+        if (!s) break;
+        const uint32_t key = (uint32_t)(s >> 32) - 1u, holder = key & 31u;
+        if ((key >> 5) == cell && ((ancestors >> holder) & 1u) && (!found || holder > best)) {
+            found = true; best = holder; seq = (uint32_t)(s >> 16) & 0xffffu; off = (uint32_t)s & 0xffffu;
+        }
+    }
+    node = best;
+    return found;
+}
+template <class XL> VGK_HD void ww_store(WwCtx<XL>& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t seq, uint32_t off) {
+    const uint32_t key = w_key(node, kind, score, diag);
+    const unsigned long long v = ((unsigned long long)key << 32) | ((unsigned long long)(seq & 0xffffu) << 16) | (off & 0xffffu);
+    for (uint32_t i = ww_hash(c, key);; i = (i + 1) & c.mask) {
+        unsigned long long s = c.xl->load64(c.slot + i);
+        if (!s) {
+            s = c.xl->cas64(c.slot + i, 0ull, v);
+            if (!s) {                                                          // the slot is ours: a new point
+                const uint32_t at = c.xl->add32(&c.sh->n_points, 1u);
+                if (at >= c.max_points) { c.overflow = true; c.why = 1; return; }     // (the table is wiped whole after an overflow)
+                c.log[at] = i;
+                return;
+            }
+        }
+        if ((uint32_t)(s >> 32) == key) { c.xl->store64(c.slot + i, v); return; }
+    }
+}
+
+// ---- trie nodes (all of these read only; the trie changes in ww_node_create / ww_expand, one lane at a time) ----
+template <class XL> VGK_HD bool ww_past_end(WwCtx<XL>& c, uint32_t id, uint32_t off) {
+    const WNode& n = c.sh->nodes[id];
+    if (off < n.len) return false;
+    if (!n.complete) { c.overflow = true; c.why = 6; }                       // beyond what was walked: never guess
+    return true;
+}
+template <class XL> VGK_HD void ww_pop(const WwCtx<XL>& c, WPos& p) {
+    const uint32_t below = c.sh->nodes[p.origin].ancestors & ~((2u << p.cur) - 1u);
+    p.cur = (uint8_t)__builtin_ctz(below);
+}
+template <class XL> VGK_HD bool ww_at_dead_end(WwCtx<XL>& c, const WPos& p) { return ww_past_end(c, p.cur, p.off) && c.sh->nodes[p.cur].dead_end; }
+template <class XL> VGK_HD WPos ww_find_in(WwCtx<XL>& c, int kind, const WSrc& src, uint32_t ancestors, uint32_t origin, int32_t diag, bool ext_seq, bool ext_graph) {
+    if (diag < src.lo || diag > src.hi) return w_none();
+    uint32_t holder = 0, seq = 0, off = 0;
+    if (!ww_lookup(c, ancestors, kind, src.score, diag, holder, seq, off)) return w_none();
+    WPos p = { seq, off, (uint8_t)holder, (uint8_t)origin, false };
+    if (ext_seq && p.seq >= c.L) return w_none();
+    if (ext_graph && ww_at_dead_end(c, p)) return w_none();
+    return p;
+}
+template <class XL> VGK_HD WPos ww_find_pos(WwCtx<XL>& c, int kind, uint32_t node, int32_t score, int32_t diag, bool ext_seq, bool ext_graph) {
+    return ww_find_in(c, kind, ww_src(c, score), c.sh->nodes[node].ancestors, node, diag, ext_seq, ext_graph);
+}
+template <class XL> VGK_HD void ww_update(WwCtx<XL>& c, int kind, int32_t score, int32_t diag, const WPos& p) { ww_store(c, p.cur, kind, score, diag, p.seq, p.off); }
+template <class XL> VGK_HD void ww_successor_offset(WwCtx<XL>& c, WPos& p) {
+    if (ww_past_end(c, p.cur, p.off)) { ww_pop(c, p); p.off = 0; }
+    p.off++;
+}
+template <class XL> VGK_HD void ww_predecessor_offset(const WwCtx<XL>& c, uint32_t& node, uint32_t& off) {
+    if (off > 0) --off;
+    else { node = c.sh->nodes[node].parent; off = c.sh->nodes[node].len - 1; }
+}
+template <class XL> VGK_HD int32_t ww_gap_penalty(const WwCtx<XL>& c, uint32_t length) { return c.P->base.gap_open + (int32_t)length * c.P->base.gap_extend; }
+template <class XL> VGK_HD void ww_candidate(WwCtx<XL>& c, int32_t score, int32_t diag, uint32_t seq, uint32_t off, uint32_t node, uint32_t leaf) {
+    if (score < c.cand_score) { c.cand_score = score; c.cand_diag = diag; c.cand_seq = seq; c.cand_off = off; c.cand_node = node; c.cand_leaf = leaf; }
+}
+template <class XL> VGK_HD bool ww_wants_expansion(WwCtx<XL>& c, const WPos& p) {                 // the test of expand_if_necessary (:1995-1997)
+    const WNode& n = c.sh->nodes[p.cur];
+    return !n.n_children && !n.dead_end && ww_past_end(c, p.cur, p.off);
+}
+
+template <class XL> VGK_HD void ww_match_forward(WwCtx<XL>& c, WPos& p) {
+    if (p.seq >= c.L || ww_past_end(c, p.cur, p.off)) return;
+    const GIndex& h = c.P->base.index;
+    uint32_t k = c.sh->nodes[p.cur].path_head;
+    while (c.path_next[k] != W_NIL && c.path_start[c.path_next[k]] <= p.off) k = c.path_next[k];
+    for (;;) {
+        const int32_t gn = c.path_node[k];
+        const uint32_t start = c.path_start[k], gl = g_len(h, gn);
+        const char* g = h.seq + g_rec(h, (uint32_t)gn)[3] + (p.off - start);
+        const char* r = c.seq + p.seq;
+        uint32_t left = start + gl - p.off; if (c.L - p.seq < left) left = c.L - p.seq;
+        uint32_t m = 0;
+        while (m < left) {
+            const uint64_t x = g_load8(g + m) ^ g_load8(r + m);
+            if (x) { m += (uint32_t)(__builtin_ctzll(x) >> 3); break; }
+            m += 8;
+        }
+        const bool differs = m < left;
+        if (!differs) m = left;
+        p.seq += m; p.off += m;
+        if (differs || p.seq >= c.L || ww_past_end(c, p.cur, p.off) || c.overflow) return;
+        k = c.path_next[k];
+    }
+}
+
+// ---- changes to the trie: one lane, everyone else waiting at a fence ----
+template <class XL> VGK_HD bool ww_append_node(WwCtx<XL>& c, WNode& n, const WState& next) {
+    n.st_node = next.node; n.st_lo = next.lo; n.st_hi = next.hi;
+    if (c.sh->n_path >= c.path_cap) { c.overflow = true; c.why = 3; return true; }
+    const uint16_t at = (uint16_t)c.sh->n_path++;
+    c.path_node[at] = next.node; c.path_start[at] = (uint16_t)n.len; c.path_next[at] = W_NIL;
+    if (n.path_head == W_NIL) n.path_head = at; else c.path_next[n.path_tail] = at;
+    n.path_tail = at;
+    const uint32_t nl = g_len(c.P->base.index, next.node);
+    n.len += nl;
+    if (n.len > 0xfff0u) { c.overflow = true; c.why = 5; return true; }
+    if (!c.no_to && c.to_node == next.node) { n.target_offset = n.len - (nl - c.to_off); return true; }
+    return false;
+}
+// WFANode's constructor (:1463-1487), walked as far as this problem can look
+template <class XL> VGK_HD void ww_node_create(WwCtx<XL>& c, uint32_t id, const WState& state, uint32_t parent, uint32_t reach) {
+    WNode n;
+    n.len = 0; n.target_offset = W_NO_OFFSET; n.path_head = n.path_tail = W_NIL;
+    n.parent = (uint8_t)parent; n.first_child = 0; n.n_children = 0; n.dead_end = 0; n.pad[0] = n.pad[1] = n.pad[2] = 0;
+    n.ancestors = (id ? c.sh->nodes[parent].ancestors : 0u) | (1u << id);
+    c.sh->leaves |= 1u << id;
+    n.complete = ww_append_node(c, n, state) ? 1 : 0;
+    while (!n.complete && !c.overflow) {
+        if (n.len >= W_TARGET_LENGTH) { n.complete = 1; break; }
+        if (n.len >= reach) break;                                           // nothing of this problem gets further; the node stays unfinished
+        const WState cur = { n.st_node, n.st_lo, n.st_hi }; WState next = { 0, 0, -1 };
+        const uint32_t successors = w_follow(c.P->base.index, cur, 0, next, 2);
+        if (successors == 0) { n.dead_end = 1; n.complete = 1; }
+        else if (successors > 1) n.complete = 1;
+        else if (ww_append_node(c, n, next)) n.complete = 1;
+    }
+    c.sh->nodes[id] = n;
+}
+// expand_if_necessary (:1992-2008) for a node known to be at its end; -> whether this call made the children
+template <class XL> VGK_HD bool ww_expand(WwCtx<XL>& c, uint32_t node) {
+    if (c.sh->nodes[node].n_children || c.sh->nodes[node].dead_end) return false;
+    const WState st = { c.sh->nodes[node].st_node, c.sh->nodes[node].st_lo, c.sh->nodes[node].st_hi };
+    WState next = { 0, 0, -1 };
+    const uint32_t k = w_follow(c.P->base.index, st, 0, next, 0xffffffffu);
+    if (!k) { c.sh->nodes[node].dead_end = 1; return false; }
+    if (c.sh->n_nodes + k > (uint32_t)W_NODES) { c.overflow = true; c.why = 2; return false; }
+    c.sh->nodes[node].first_child = (uint8_t)c.sh->n_nodes; c.sh->nodes[node].n_children = (uint8_t)k;
+    c.sh->leaves &= ~(1u << node);
+    for (uint32_t i = 0; i < k; ++i) {
+        if (i) w_follow(c.P->base.index, st, i, next, i + 1);
+        ww_node_create(c, c.sh->n_nodes, next, node, c.grow_cap); ++c.sh->n_nodes;
+        if (c.overflow) return true;
+    }
+    return true;
+}
+
+// the lanes agree on whether anyone has failed; the reason of the lowest such lane is everyone's
+template <class XL> VGK_HD bool ww_any_overflow(WwCtx<XL>& c) {
+    const unsigned long long bad = c.xl->ballot(c.overflow);
+    if (!bad) return false;
+    const uint32_t who = (uint32_t)__builtin_ctzll(bad);
+    c.why = (int)c.xl->bcast((uint32_t)c.why, who); c.overflow = true;
+    return true;
+}
+VGK_HD uint32_t ww_nth_bit(uint32_t mask, uint32_t n) { for (; n; --n) mask &= mask - 1; return (uint32_t)__builtin_ctz(mask); }
+VGK_HD uint32_t ww_popcount(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
+
+// ---- extend(): an item runs until it is done or needs a node expanded ----
+struct WwItem { int st; uint32_t qh, qt, sp, key_leaf, blocked_on; WPos pos; bool creator; };
+
+template <class XL> VGK_HD void ww_extend_run(WwCtx<XL>& c, const WSrc& here, int32_t score, int32_t diag, WwItem& it) {
+    uint8_t* queue = c.sh->queue[c.lane]; uint8_t* scur = c.sh->stack_cur[c.lane]; uint8_t* send = c.sh->stack_end[c.lane];
+    for (;;) {
+        if (c.overflow) { it.st = WX_DONE; return; }
+        if (it.st == WX_FETCH) {
+            uint32_t leaf;
+            while (it.sp && scur[it.sp - 1] == send[it.sp - 1]) --it.sp;
+            if (it.sp) leaf = scur[it.sp - 1]++;                               // the recursion over children this item created itself
+            else if (it.qh < it.qt) { leaf = queue[it.qh++]; it.key_leaf = leaf; }    // the next leaf of this item's own
+            else { it.st = WX_DONE; return; }
+            it.pos = ww_find_in(c, WK_MATCH, here, c.sh->nodes[leaf].ancestors, leaf, diag, false, false);
+            if (it.pos.empty) continue;
+            it.st = WX_MATCH;
+        }
+        if (it.st == WX_MATCH) {
+            WPos& pos = it.pos;
+            const uint32_t off_before = pos.off;
+            ww_match_forward(c, pos);
+            const bool at_end = ww_past_end(c, pos.cur, pos.off);
+            const uint32_t target_offset = c.no_to ? W_NO_OFFSET : c.sh->nodes[pos.cur].target_offset;
+            const bool may_reach_target = target_offset != W_NO_OFFSET && target_offset >= off_before;
+            if ((may_reach_target && pos.off >= target_offset) || (c.no_to && pos.seq >= c.L)) {
+                const uint32_t overshoot = c.no_to ? 0 : pos.off - target_offset;
+                const uint32_t gap_length = (c.L - pos.seq) + overshoot;
+                ww_candidate(c, score + (gap_length ? ww_gap_penalty(c, gap_length) : 0), diag, pos.seq - overshoot, target_offset, pos.cur, it.key_leaf);
+            }
+            if (w_distance(pos, diag) > c.max_distance) c.max_distance = w_distance(pos, diag);
+            ww_update(c, WK_MATCH, score, diag, pos);
+            if (c.overflow) { it.st = WX_DONE; return; }
+            if (!at_end) { it.st = WX_FETCH; continue; }
+            it.creator = false;
+            if (!c.sh->nodes[pos.cur].n_children && !c.sh->nodes[pos.cur].dead_end) { it.st = WX_BLOCKED; it.blocked_on = pos.cur; return; }
+            it.st = WX_AFTER;
+        }
+        if (it.st == WX_AFTER) {                                               // at the end of a node that is expanded (or a dead end) by now
+            WPos& pos = it.pos;
+            if (pos.cur == pos.origin) {
+                const WNode& now = c.sh->nodes[pos.cur];
+                if (now.n_children) {
+                    if (it.creator) {                                           // the reference's recursion: the new children at once, in order
+                        if (it.sp >= (uint32_t)WW_QUEUE) { c.overflow = true; c.why = 7; it.st = WX_DONE; return; }
+                        scur[it.sp] = now.first_child; send[it.sp] = (uint8_t)(now.first_child + now.n_children); ++it.sp;
+                    } else {                                                    // someone with a smaller key made them: they are leaves of this diagonal, behind the older ones
+                        for (uint32_t k = 0; k < now.n_children; ++k) {
+                            if (it.qt >= (uint32_t)WW_QUEUE) { c.overflow = true; c.why = 7; it.st = WX_DONE; return; }
+                            queue[it.qt++] = (uint8_t)(now.first_child + k);
+                        }
+                    }
+                }
+                it.st = WX_FETCH; continue;
+            }
+            ww_pop(c, pos); pos.off = 0;
+            it.st = WX_MATCH; continue;
+        }
+        return;
+    }
+}
+
+// merge the lanes' candidates into every lane's copy of the best: smallest penalty, then the smallest key
+template <class XL> VGK_HD void ww_merge_candidates(WwCtx<XL>& c, int32_t& best_score, int32_t& best_diag, uint32_t& best_seq, uint32_t& best_off, uint32_t& best_node,
+                                                    int32_t diag_base) {
+    // (penalties are < 2^20 here or INT_MAX for "none"; diagonals within +-512 of diag_base)
+    const unsigned long long none = ~0ull;
+    unsigned long long key = none;
+    if (c.cand_score != 0x7fffffff)
+        key = ((unsigned long long)(uint32_t)c.cand_score << 32) | ((unsigned long long)(uint32_t)(c.cand_diag - diag_base + 1024) << 16) | ((unsigned long long)c.cand_leaf << 8) | c.lane;
+    const unsigned long long win = c.xl->reduce_min_u64(key);
+    if (win != none) {
+        const uint32_t who = (uint32_t)(win & 0xffu);
+        const int32_t s = (int32_t)c.xl->bcast((uint32_t)c.cand_score, who), d = (int32_t)c.xl->bcast((uint32_t)c.cand_diag, who);
+        const uint32_t q = c.xl->bcast(c.cand_seq, who), o = c.xl->bcast(c.cand_off, who), n = c.xl->bcast(c.cand_node, who);
+        if (s < best_score) { best_score = s; best_diag = d; best_seq = q; best_off = o; best_node = n; }
+    }
+    c.cand_score = 0x7fffffff;
+}
+
+template <class XL> VGK_HD void ww_extend(WwCtx<XL>& c, int32_t score, int32_t& best_score, int32_t& best_diag, uint32_t& best_seq, uint32_t& best_off, uint32_t& best_node) {
+    const WPScore ps = ww_ps(c, score);
+    if (!(ps.flags & 1)) return;
+    const WSrc here = { score, ps.min_d, ps.max_d };
+    for (int32_t diag0 = ps.min_d; diag0 <= ps.max_d;) {
+        const uint32_t leaves = c.sh->leaves, n_leaves = ww_popcount(leaves);
+        const uint32_t fit = 64u / n_leaves, left = (uint32_t)(ps.max_d - diag0 + 1), n_diag = fit < left ? fit : left;
+        WwItem it; it.st = WX_DONE; it.qh = it.qt = 0; it.sp = 0; it.key_leaf = 0; it.blocked_on = 0; it.creator = false; it.pos = w_none();
+        int32_t diag = diag0;
+        if (c.lane < n_diag * n_leaves) {
+            diag = diag0 + (int32_t)(c.lane / n_leaves);
+            const uint32_t top = ww_nth_bit(leaves, c.lane % n_leaves);
+            c.sh->queue[c.lane][0] = (uint8_t)top; it.qt = 1; it.st = WX_FETCH;
+        }
+        for (;;) {
+            if (it.st != WX_DONE && it.st != WX_BLOCKED) ww_extend_run(c, here, score, diag, it);
+            if (ww_any_overflow(c)) return;
+            const unsigned long long none = ~0ull;
+            const unsigned long long key = it.st == WX_BLOCKED ? (((unsigned long long)(uint32_t)(diag - diag0) << 16) | ((unsigned long long)it.key_leaf << 8) | c.lane) : none;
+            const unsigned long long first = c.xl->reduce_min_u64(key);
+            if (first == none) break;                                          // everyone is done
+            const uint32_t who = (uint32_t)(first & 0xffu);
+            const uint32_t node = c.xl->bcast(it.blocked_on, who);
+            bool made = false;
+            if (c.lane == who) made = ww_expand(c, node);
+            c.xl->fence();
+            if (ww_any_overflow(c)) return;                                    // (a trie that ran out of nodes is half made: nobody may look at it)
+            if (it.st == WX_BLOCKED && it.blocked_on == node) { it.st = WX_AFTER; it.creator = made; }
+        }
+        if (ww_any_overflow(c)) return;
+        diag0 += (int32_t)n_diag;
+    }
+    const int32_t far = c.xl->reduce_max(c.max_distance);
+    c.max_distance = far;
+    ww_merge_candidates(c, best_score, best_diag, best_seq, best_off, best_node, ps.min_d);
+}
+
+// ---- next() (:1709-1786): one item per lane, nothing to wait for ----
+template <class XL> VGK_HD void ww_next(WwCtx<XL>& c, int32_t score, int32_t& best_score, int32_t& best_diag, uint32_t& best_seq, uint32_t& best_off, uint32_t& best_node) {
+    const WfaParams& B = c.P->base;
+    int32_t lo = 32767, hi = -32768;
+    auto widen = [&](int32_t s) { if (s < 0) return; const WPScore p = ww_ps(c, s); if (!(p.flags & 1)) return; if (p.min_d < lo) lo = p.min_d; if (p.max_d > hi) hi = p.max_d; };
+    widen(score - B.mismatch); widen(score - B.gap_open - B.gap_extend); widen(score - B.gap_extend);
+    if (lo <= hi) { --lo; ++hi; }
+    int32_t alo = 32767, ahi = -32768;
+    const WSrc src_mismatch = ww_src(c, score - B.mismatch), src_open = ww_src(c, score - B.gap_open - B.gap_extend), src_extend = ww_src(c, score - B.gap_extend);
+    for (int32_t diag0 = lo; diag0 <= hi;) {
+        const uint32_t leaves = c.sh->leaves, n_leaves = ww_popcount(leaves);
+        const uint32_t fit = 64u / n_leaves, left = (uint32_t)(hi - diag0 + 1), n_diag = fit < left ? fit : left;
+        uint32_t want = W_NODES;                                               // the node this item asks to have expanded
+        int32_t diag = diag0; uint32_t leaf = 0; bool have_cand = false;
+        if (c.lane < n_diag * n_leaves) {
+            diag = diag0 + (int32_t)(c.lane / n_leaves);
+            leaf = ww_nth_bit(leaves, c.lane % n_leaves);
+            const uint32_t anc = c.sh->nodes[leaf].ancestors;
+            WPos ins;
+            { const WPos open = ww_find_in(c, WK_MATCH, src_open, anc, leaf, diag - 1, true, false), ext = ww_find_in(c, WK_INS, src_extend, anc, leaf, diag - 1, true, false);
+              ins = w_less(open, ext) ? ext : open; }
+            if (!ins.empty) {
+                ins.seq++;
+                if (w_distance(ins, diag) >= c.min_distance) { ww_update(c, WK_INS, score, diag, ins); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
+            }
+            WPos del;
+            { const WPos open = ww_find_in(c, WK_MATCH, src_open, anc, leaf, diag + 1, false, true), ext = ww_find_in(c, WK_DEL, src_extend, anc, leaf, diag + 1, false, true);
+              del = w_less(open, ext) ? ext : open; }
+            if (!del.empty) {
+                ww_successor_offset(c, del);
+                if (w_distance(del, diag) >= c.min_distance) { ww_update(c, WK_DEL, score, diag, del); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
+                if (ww_wants_expansion(c, del)) want = del.cur;
+            }
+            WPos subst = ww_find_in(c, WK_MATCH, src_mismatch, anc, leaf, diag, true, true);
+            if (!subst.empty) { subst.seq++; ww_successor_offset(c, subst); if (want == (uint32_t)W_NODES && ww_wants_expansion(c, subst)) want = subst.cur; }
+            if (w_less(subst, ins)) subst = ins;
+            if (w_less(subst, del)) subst = del;
+            if (!subst.empty && !c.overflow) {
+                if (!c.no_to) ww_past_end(c, subst.cur, subst.off);
+                if (!c.no_to && subst.off == c.sh->nodes[subst.cur].target_offset) {
+                    const uint32_t gap_length = c.L - subst.seq;
+                    const int32_t before = c.cand_score;
+                    ww_candidate(c, score + (gap_length ? ww_gap_penalty(c, gap_length) : 0), diag, subst.seq, subst.off, subst.cur, leaf);
+                    have_cand = c.cand_score != before;
+                }
+                if (w_distance(subst, diag) >= c.min_distance) { ww_update(c, WK_MATCH, score, diag, subst); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
+            }
+        }
+        if (ww_any_overflow(c)) return;
+        // the expansions this chunk asked for, in key order (= lane order); a node is expanded for the first item that asks
+        for (unsigned long long asking = c.xl->ballot(want != (uint32_t)W_NODES); asking; asking &= asking - 1) {
+            const uint32_t who = (uint32_t)__builtin_ctzll(asking);
+            const uint32_t node = c.xl->bcast(want, who);
+            const int32_t at = (int32_t)c.xl->bcast((uint32_t)diag, who);
+            if (c.lane == who && ww_expand(c, node)) c.sh->expanded_at[node] = at;
+            c.xl->fence();
+            if (ww_any_overflow(c)) return;
+        }
+        // A candidate of an item whose leaf was expanded by an item of an EARLIER diagonal of this chunk: sequentially that diagonal's
+        // items are the leaf's children (first the one made first), behind every older leaf.
+        if (have_cand && c.sh->nodes[leaf].n_children && c.sh->expanded_at[leaf] < diag) c.cand_leaf = c.sh->nodes[leaf].first_child;
+        diag0 += (int32_t)n_diag;
+        // (a lane holds at most one candidate per chunk, and chunks come in key order: merge chunk by chunk)
+        ww_merge_candidates(c, best_score, best_diag, best_seq, best_off, best_node, lo);
+    }
+    const int32_t rlo = -c.xl->reduce_max(-alo), rhi = c.xl->reduce_max(ahi);
+    if (c.lane == 0 && (c.sh->ps_flags[score] & 1)) c.sh->ps_range[score] = ((uint32_t)rlo & 0xffffu) | ((uint32_t)rhi << 16);
+    c.xl->fence();
+}
+
+// ---- the sequential rest, on lane 0: penalties, trim, backtrace, output (the code of wfa_device.hpp over this kernel's tables) ----
+template <class XL> VGK_HD void ww_mark(WwCtx<XL>& c, int32_t score, bool gap) {
+    const uint8_t f = c.sh->ps_flags[score];
+    if (!(f & 1)) { c.sh->ps_range[score] = 0; c.sh->ps_flags[score] = (uint8_t)(1 | (gap ? 2 : 0)); }
+    else if (gap && !(f & 2)) c.sh->ps_flags[score] = (uint8_t)(f | 2);
+}
+template <class XL> VGK_HD int32_t ww_next_score(WwCtx<XL>& c, int32_t match_score) {
+    const WfaParams& B = c.P->base;
+    ww_mark(c, match_score + B.mismatch, false);
+    if (c.sh->ps_flags[match_score] & 2) ww_mark(c, match_score + B.gap_extend, true);
+    ww_mark(c, match_score + B.gap_open + B.gap_extend, true);
+    int32_t s = match_score + 1;
+    while (!(c.sh->ps_flags[s] & 1)) ++s;
+    return s;
+}
+template <class XL> VGK_HD int32_t ww_alignment_score(const WwCtx<XL>& c, int32_t score, int32_t diag, uint32_t seq, uint32_t final_insertion) {
+    const int32_t target_offset = (int32_t)seq - diag;
+    return (c.P->base.match * ((int32_t)(seq + final_insertion) + target_offset) - score) / 2;
+}
+template <class XL> VGK_HD WPos ww_ins_predecessor(WwCtx<XL>& c, uint32_t node, int32_t score, int32_t diag, int& edit) {
+    const WfaParams& B = c.P->base;
+    const WPos open = ww_find_pos(c, WK_MATCH, node, score - B.gap_open - B.gap_extend, diag - 1, true, false);
+    const WPos ext = ww_find_pos(c, WK_INS, node, score - B.gap_extend, diag - 1, true, false);
+    if (w_less(open, ext)) { edit = VGK_WFA_INSERTION; return ext; }
+    edit = VGK_WFA_MATCH; return open;
+}
+template <class XL> VGK_HD WPos ww_del_predecessor(WwCtx<XL>& c, uint32_t node, int32_t score, int32_t diag, int& edit) {
+    const WfaParams& B = c.P->base;
+    const WPos open = ww_find_pos(c, WK_MATCH, node, score - B.gap_open - B.gap_extend, diag + 1, false, true);
+    const WPos ext = ww_find_pos(c, WK_DEL, node, score - B.gap_extend, diag + 1, false, true);
+    if (w_less(open, ext)) { edit = VGK_WFA_DELETION; return ext; }
+    edit = VGK_WFA_MATCH; return open;
+}
+template <class XL> VGK_HD WPos ww_match_predecessor(WwCtx<XL>& c, uint32_t node, int32_t score, int32_t diag, int& edit) {
+    const WPos ins = ww_find_pos(c, WK_INS, node, score, diag, false, false);
+    const WPos del = ww_find_pos(c, WK_DEL, node, score, diag, false, false);
+    WPos subst = ww_find_pos(c, WK_MATCH, node, score - c.P->base.mismatch, diag, false, false);
+    if (!subst.empty) { subst.seq++; subst.off++; }
+    if (w_less(ins, del)) {
+        if (w_less(del, subst)) { edit = VGK_WFA_MISMATCH; return subst; }
+        edit = VGK_WFA_DELETION; return del;
+    }
+    if (w_less(ins, subst)) { edit = VGK_WFA_MISMATCH; return subst; }
+    edit = VGK_WFA_INSERTION; return ins;
+}
+template <class XL> VGK_HD void ww_append_edit(WwCtx<XL>& c, uint32_t* runs, uint32_t& n_edits, int edit, uint32_t length) {
+    if (!length) return;
+    if (n_edits && (runs[n_edits - 1] & 3u) == (uint32_t)edit) { runs[n_edits - 1] += length << 2; return; }
+    if (n_edits >= (uint32_t)W_EDITS) { c.overflow = true; c.why = 4; return; }
+    runs[n_edits++] = (length << 2) | (uint32_t)edit;
+}
+
+// One problem on one wavefront.  `slab` = this wavefront's number among the resident ones.
+template <class XL> VGK_HD void wfa_wave_problem(const WwParams& P, uint32_t i, uint32_t slab, uint32_t lane, WwShared& sh, XL& xl) {
+    const WfaParams& B = P.base;
+    const WProb pb = B.probs[i];
+    vgk_wfa_result out; out.status = pb.status; out.ok = 0; out.score = 0; out.node_offset = 0; out.seq_offset = 0; out.length = 0;
+    out.path_begin = 0; out.path_len = 0; out.edit_begin = 0; out.n_edits = 0;
+    if (pb.status != VGK_OK || pb.from_node >= B.index.n_oriented) { if (lane == 0) B.results[i] = out; return; }
+    WwCtx<XL> c;
+    c.P = &P; c.sh = &sh; c.xl = &xl; c.lane = lane;
+    c.slot = P.slots + (size_t)slab * P.n_slots; c.mask = P.n_slots - 1; c.log = P.logs + (size_t)slab * P.max_points;
+    c.path_node = P.path_node + (size_t)slab * P.path_cap; c.path_start = P.path_start + (size_t)slab * P.path_cap; c.path_next = P.path_next + (size_t)slab * P.path_cap;
+    c.path_cap = P.path_cap;
+    c.seq = B.seqs + pb.seq_off; c.L = pb.seq_len;
+    c.no_to = pb.to_node == VGK_WFA_NO_NODE; c.to_node = (int32_t)pb.to_node; c.to_off = pb.to_off;
+    c.max_points = c.no_to ? (B.max_points_tail < P.max_points ? B.max_points_tail : P.max_points) : (B.max_points < P.max_points ? B.max_points : P.max_points);
+    // no position gets further into a trie node than the sequence plus the deletions the score cap pays for (+ where the root starts)
+    c.grow_cap = c.L + (uint32_t)(pb.score_bound / B.gap_extend) + 2u;
+    c.cand_score = 0x7fffffff; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0; c.cand_leaf = 0;
+    c.max_distance = 0; c.min_distance = 0; c.overflow = false; c.why = 0;
+    const int32_t top_score = pb.score_bound + B.gap_open + B.gap_extend + B.mismatch;
+    for (int32_t s = (int32_t)lane; s <= top_score && s < W_SCORES; s += 64) sh.ps_flags[s] = 0;
+    if (lane < (uint32_t)W_NODES) sh.expanded_at[lane] = 0;
+    if (lane == 0) {
+        sh.n_nodes = 0; sh.n_path = 0; sh.n_points = 0; sh.leaves = 0;
+        const WState root = { (int32_t)pb.from_node, 0, (int32_t)g_rec(B.index, pb.from_node)[0] - 1 };
+        ww_node_create(c, 0, root, 0, c.grow_cap + pb.from_off + 1); sh.n_nodes = 1;
+        if (!c.overflow) ww_store(c, 0, WK_MATCH, 0, 0, 0, pb.from_off + 1);
+        ww_mark(c, 0, false);
+    }
+    xl.fence();
+    int32_t best_score = 0x7fffffff, best_diag = 0; uint32_t best_seq = 0, best_off = 0, best_node = 0;
+    int32_t score = 0;
+    bool failed = ww_any_overflow(c);
+    while (!failed) {
+        ww_extend(c, score, best_score, best_diag, best_seq, best_off, best_node);
+        if ((failed = ww_any_overflow(c))) break;
+        if (pb.distance_band < c.max_distance) c.min_distance = c.max_distance - pb.distance_band;
+        if (best_score <= score) break;
+        int32_t next = 0;
+        if (lane == 0) next = ww_next_score(c, score);
+        xl.fence();
+        score = (int32_t)xl.bcast((uint32_t)next, 0);
+        if (score > pb.score_bound) break;
+        ww_next(c, score, best_score, best_diag, best_seq, best_off, best_node);
+        if ((failed = ww_any_overflow(c))) break;
+    }
+    // the rest is one chain of dependent lookups: lane 0
+    const uint32_t n_points = sh.n_points < c.max_points ? sh.n_points : c.max_points;
+    uint32_t* runs = P.edit_runs + (size_t)slab * W_EDITS;
+    if (lane == 0 && !failed) {
+        c.cand_score = best_score; c.cand_diag = best_diag; c.cand_seq = best_seq; c.cand_off = best_off; c.cand_node = best_node;
+        bool ok = true;
+        uint32_t unaligned_tail = c.L - c.cand_seq;
+        if (c.cand_score > pb.score_bound) {
+            unaligned_tail = 0;
+            if (c.no_to) {                                                     // WFATree::trim (:1849-1868), ties as in wfa_device.hpp
+                c.cand_score = 0; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0;
+                int32_t best = 0; uint32_t best_order = 0xffffffffu;
+                for (uint32_t k = 0; k < n_points; ++k) {
+                    const unsigned long long s = c.slot[c.log[k]];
+                    const uint32_t key = (uint32_t)(s >> 32) - 1;
+                    if (((key >> 5) & 3u) != (uint32_t)WK_MATCH) continue;
+                    const uint32_t node = key & 31u; const int32_t sc = (int32_t)((key >> 7) & 1023u), dg = (int32_t)((key >> 17) & 1023u) - 512;
+                    const uint32_t seq = (uint32_t)(s >> 16) & 0xffffu, off = (uint32_t)s & 0xffffu;
+                    const int32_t as = ww_alignment_score(c, sc, dg, seq, 0);
+                    const uint32_t order = (node << 20) | ((uint32_t)sc << 10) | (uint32_t)(dg + 512);
+                    if (as > best || (as == best && best_order != 0xffffffffu && order < best_order)) {
+                        best = as; best_order = order;
+                        c.cand_score = sc; c.cand_diag = dg; c.cand_seq = seq; c.cand_off = off; c.cand_node = node;
+                    }
+                }
+            } else ok = false;
+        }
+        uint32_t n_edits = 0; bool lost = false;
+        if (ok) {
+            out.ok = 1; out.node_offset = pb.from_off + 1;
+            out.length = c.cand_seq + unaligned_tail;
+            out.score = ww_alignment_score(c, c.cand_score, c.cand_diag, c.cand_seq, unaligned_tail);
+            int32_t p_score = c.cand_score, p_diag = c.cand_diag; uint32_t p_seq = c.cand_seq, p_off = c.cand_off, node = c.cand_node;
+            if (unaligned_tail > 0) { ww_append_edit(c, runs, n_edits, VGK_WFA_INSERTION, c.L - c.cand_seq); p_score -= ww_gap_penalty(c, unaligned_tail); }
+            int edit = VGK_WFA_MATCH;
+            while ((p_seq > 0 || p_diag != 0) && !c.overflow && !lost) {
+                int pe; WPos pred;
+                switch (edit) {
+                case VGK_WFA_MATCH:
+                    pred = ww_match_predecessor(c, node, p_score, p_diag, pe);
+                    if (pred.empty && (p_score != 0 || p_diag != 0)) { lost = true; break; }
+                    ww_append_edit(c, runs, n_edits, VGK_WFA_MATCH, p_seq - pred.seq);
+                    p_seq = pred.seq; p_off = pred.off;
+                    if (!pred.empty) node = pred.cur;
+                    edit = pe; break;
+                case VGK_WFA_MISMATCH:
+                    ww_append_edit(c, runs, n_edits, VGK_WFA_MISMATCH, 1);
+                    p_seq--; ww_predecessor_offset(c, node, p_off);
+                    p_score -= B.mismatch; edit = VGK_WFA_MATCH; break;
+                case VGK_WFA_INSERTION:
+                    pred = ww_ins_predecessor(c, node, p_score, p_diag, pe);
+                    if (pred.empty) { lost = true; break; }
+                    ww_append_edit(c, runs, n_edits, VGK_WFA_INSERTION, 1);
+                    p_seq--;
+                    p_score -= pe == VGK_WFA_INSERTION ? B.gap_extend : B.gap_open + B.gap_extend;
+                    p_diag--; edit = pe; break;
+                default:
+                    pred = ww_del_predecessor(c, node, p_score, p_diag, pe);
+                    if (pred.empty) { lost = true; break; }
+                    ww_append_edit(c, runs, n_edits, VGK_WFA_DELETION, 1);
+                    ww_predecessor_offset(c, node, p_off);
+                    p_score -= pe == VGK_WFA_DELETION ? B.gap_extend : B.gap_open + B.gap_extend;
+                    p_diag++; edit = pe; break;
+                }
+            }
+            ok = !c.overflow && !lost;
+        }
+        if (lost) { out.status = VGK_ENOBAND; out.ok = 0; out.score = 0; out.node_offset = 0; out.length = 0; }
+        if (ok) {
+            uint8_t* chain = sh.queue[0];                                      // (free again: the phases are over)
+            uint32_t n_chain = 0;
+            for (uint32_t x = c.cand_node;; x = sh.nodes[x].parent) { chain[n_chain++] = (uint8_t)x; if (x == 0) break; }
+            uint32_t ref_len = 0;
+            for (uint32_t e = 0; e < n_edits; ++e) if ((runs[e] & 3u) != (uint32_t)VGK_WFA_INSERTION) ref_len += runs[e] >> 2;
+            const int32_t first_node = c.path_node[sh.nodes[0].path_head];
+            const uint32_t first_len = g_len(B.index, first_node);
+            const bool drop_first = out.node_offset >= first_len;
+            if (drop_first) out.node_offset = 0;
+            const uint32_t used = out.node_offset + ref_len;
+            uint32_t kept = 0, at = 0, last_start = 0, last_len = 0;
+            for (uint32_t k = n_chain; k-- > 0;) {
+                const WNode& n = sh.nodes[chain[k]];
+                for (uint32_t j = n.path_head; j != W_NIL; j = c.path_next[j]) {
+                    const uint32_t gl = g_len(B.index, c.path_node[j]);
+                    if (k == n_chain - 1 && j == n.path_head && drop_first) continue;
+                    if (kept == 0 || at < used) { ++kept; last_start = at; last_len = gl; }
+                    at += gl;
+                }
+            }
+            if (kept == 1 && used == out.node_offset) kept = 0;
+            const unsigned long long p0 = g_bump(B.counters + 0, kept), e0 = g_bump(B.counters + 1, n_edits);
+            if (p0 + kept > B.caps[0] || e0 + n_edits > B.caps[1]) { out.status = VGK_EOPS; out.ok = 0; }
+            else {
+                const bool flip = pb.mode == VGK_WFA_PREFIX;
+                uint32_t w = 0;
+                for (uint32_t k = n_chain; k-- > 0 && w < kept;) {
+                    const WNode& n = sh.nodes[chain[k]];
+                    for (uint32_t j = n.path_head; j != W_NIL && w < kept; j = c.path_next[j]) {
+                        if (k == n_chain - 1 && j == n.path_head && drop_first) continue;
+                        const uint32_t o = (uint32_t)c.path_node[j];
+                        B.paths[p0 + (flip ? kept - 1 - w : w)] = flip ? (o ^ 1u) : o;
+                        ++w;
+                    }
+                }
+                for (uint32_t e = 0; e < n_edits; ++e) B.edits[e0 + e] = runs[flip ? e : n_edits - 1 - e];
+                out.path_begin = (uint32_t)p0; out.path_len = kept; out.edit_begin = (uint32_t)e0; out.n_edits = n_edits;
+                if (pb.mode != VGK_WFA_CONNECT && n_edits && out.length == c.L) {
+                    const uint32_t last = runs[0] & 3u;
+                    if (last == (uint32_t)VGK_WFA_MATCH || last == (uint32_t)VGK_WFA_MISMATCH) out.score += B.bonus;
+                }
+                if (flip) {
+                    out.seq_offset = c.L - out.seq_offset - out.length;
+                    if (kept) out.node_offset = last_len - (used - last_start);
+                }
+            }
+        } else if (c.overflow) failed = true;                                  // (the backtrace's edit runs: reported like any table that ran out)
+    }
+    failed = xl.ballot(failed) != 0ull;
+    if (lane == 0) {
+        if (failed) {
+            // tables of this launch's size were not enough: the large-table launch takes the problem — unless it was the caller's own
+            // point budget that ran out — or it is declined
+            const bool retry = P.declined && ((c.why == 1 && c.max_points == P.max_points) || c.why == 3);
+            if (retry) P.declined[g_bump(P.n_declined, 1)] = i;
+            out.status = VGK_ETOOBIG; out.ok = 0; out.score = c.why; out.node_offset = 0; out.length = 0;
+        }
+        B.results[i] = out;
+    }
+    // leave the table all-zero: the touched slots from the log, or everything when the log ran over
+    xl.fence();
+    if (sh.n_points > c.max_points) { for (uint32_t k = lane; k < P.n_slots; k += 64) c.slot[k] = 0; }
+    else for (uint32_t k = lane; k < n_points; k += 64) c.slot[c.log[k]] = 0;
+    xl.fence();
+}
+
+// one resident wavefront: problems are handed out one at a time
+template <class XL> VGK_HD void wfa_wave(const WwParams& P, uint32_t slab, uint32_t lane, WwShared& sh, XL& xl) {
+    for (;;) {
+        uint32_t k = 0;
+        if (lane == 0) k = (uint32_t)g_bump(P.base.counters + 2, 1);
+        k = xl.bcast(k, 0);
+        if (k >= P.n_todo) break;
+        wfa_wave_problem(P, P.todo[k], slab, lane, sh, xl);
+    }
+}
+
+}  // namespace vgk
