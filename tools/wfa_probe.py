@@ -43,3 +43,15 @@ elif stage == "longread":
     for k in range(3):
         out = cs.run(threads=8)
         say("run", k, out["stats"], "kernel ms", out["wfa_kernel_ms"])
+elif stage == "each":
+    ora = capi.Engine(lib=util.ORACLE_LIB); eng = capi.Engine()
+    s = int(sys.argv[2]); n = int(sys.argv[3]); lo = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    rng = np.random.default_rng(s)
+    nodes, threads, problems = T.random_wfa_case(rng, n)
+    model = T.MODELS[s % len(T.MODELS)]
+    a = ora.wfa_extend(ora.haplo_index(nodes, threads), problems, model)
+    idx = eng.haplo_index(nodes, threads)
+    for i in range(lo, n):
+        print("problem", i, problems[i]["mode"], len(problems[i]["seq"]), end=" ... ", flush=True)
+        b = eng.wfa_extend(idx, problems[i:i + 1], model)
+        print(int(b[0]["status"][0]), int(b[0]["score"][0]), "oracle", int(a[0]["status"][i]), int(a[0]["score"][i]), "retried", T.last_wave(eng, 2), flush=True)

@@ -68,7 +68,8 @@ template <class XL> struct WwCtx {
     // this lane's findings, merged after every phase
     int32_t cand_score, cand_diag; uint32_t cand_seq, cand_off, cand_node, cand_leaf;
     int32_t max_distance;
-    bool overflow; int why;           // why: 1 points, 2 trie nodes, 3 path pool, 4 edits, 5 node length, 6 walked end reached, 7 work list
+    bool overflow; int why;           // why: 1 points, 2 trie nodes, 3 path pool, 4 edits, 5 node length, 6 walked end reached, 7 work list,
+                                      // 8 table without a free slot, 9 broken path chain, 10 a loop ran past its bound (8-10: cannot happen; never hang)
 };
 
 // ---- possible penalties ----
@@ -91,7 +92,9 @@ template <class XL> VGK_HD uint32_t ww_hash(const WwCtx<XL>& c, uint32_t key) { 
 template <class XL> VGK_HD bool ww_lookup(WwCtx<XL>& c, uint32_t ancestors, int kind, int32_t score, int32_t diag, uint32_t& node, uint32_t& seq, uint32_t& off) {
     const uint32_t cell = (w_key(0, kind, score, diag) - 1u) >> 5;
     bool found = false; uint32_t best = 0;
+    uint32_t probes = 0;
     for (uint32_t i = ww_hash(c, w_key(0, kind, score, diag));; i = (i + 1) & c.mask) {
+        if (probes++ > c.mask) { c.overflow = true; c.why = 8; break; }         // a table without a free slot cannot be: say so instead of probing for ever
         const unsigned long long s = c.xl->load64(c.slot + i);
         if (!s) break;
         const uint32_t key = (uint32_t)(s >> 32) - 1u, holder = key & 31u;
@@ -105,9 +108,12 @@ template <class XL> VGK_HD bool ww_lookup(WwCtx<XL>& c, uint32_t ancestors, int 
 template <class XL> VGK_HD void ww_store(WwCtx<XL>& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t seq, uint32_t off) {
     const uint32_t key = w_key(node, kind, score, diag);
     const unsigned long long v = ((unsigned long long)key << 32) | ((unsigned long long)(seq & 0xffffu) << 16) | (off & 0xffffu);
+    uint32_t probes = 0;
     for (uint32_t i = ww_hash(c, key);; i = (i + 1) & c.mask) {
+        if (probes++ > c.mask) { c.overflow = true; c.why = 8; return; }
         unsigned long long s = c.xl->load64(c.slot + i);
         if (!s) {
+            if (c.sh->n_points >= c.max_points + 64u) { c.overflow = true; c.why = 1; return; }     // (someone's table has run over already: do not pile on)
             s = c.xl->cas64(c.slot + i, 0ull, v);
             if (!s) {                                                          // the slot is ours: a new point
                 const uint32_t at = c.xl->add32(&c.sh->n_points, 1u);
@@ -166,8 +172,10 @@ template <class XL> VGK_HD void ww_match_forward(WwCtx<XL>& c, WPos& p) {
     if (p.seq >= c.L || ww_past_end(c, p.cur, p.off)) return;
     const GIndex& h = c.P->base.index;
     uint32_t k = c.sh->nodes[p.cur].path_head;
-    while (c.path_next[k] != W_NIL && c.path_start[c.path_next[k]] <= p.off) k = c.path_next[k];
+    uint32_t hops = 0;
+    while (c.path_next[k] != W_NIL && c.path_start[c.path_next[k]] <= p.off && hops++ <= c.path_cap) k = c.path_next[k];
     for (;;) {
+        if (hops++ > 2 * c.path_cap || k >= c.path_cap) { c.overflow = true; c.why = 9; return; }       // a broken chain: never walk it for ever
         const int32_t gn = c.path_node[k];
         const uint32_t start = c.path_start[k], gl = g_len(h, gn);
         const char* g = h.seq + g_rec(h, (uint32_t)gn)[3] + (p.off - start);
@@ -209,7 +217,8 @@ template <class XL> VGK_HD void ww_node_create(WwCtx<XL>& c, uint32_t id, const 
     n.ancestors = (id ? c.sh->nodes[parent].ancestors : 0u) | (1u << id);
     c.sh->leaves |= 1u << id;
     n.complete = ww_append_node(c, n, state) ? 1 : 0;
-    while (!n.complete && !c.overflow) {
+    for (uint32_t hops = 0; !n.complete && !c.overflow; ++hops) {
+        if (hops > c.path_cap) { c.overflow = true; c.why = 9; break; }
         if (n.len >= W_TARGET_LENGTH) { n.complete = 1; break; }
         if (n.len >= reach) break;                                           // nothing of this problem gets further; the node stays unfinished
         const WState cur = { n.st_node, n.st_lo, n.st_hi }; WState next = { 0, 0, -1 };
@@ -254,7 +263,8 @@ struct WwItem { int st; uint32_t qh, qt, sp, key_leaf, blocked_on; WPos pos; boo
 
 template <class XL> VGK_HD void ww_extend_run(WwCtx<XL>& c, const WSrc& here, int32_t score, int32_t diag, WwItem& it) {
     uint8_t* queue = c.sh->queue[c.lane]; uint8_t* scur = c.sh->stack_cur[c.lane]; uint8_t* send = c.sh->stack_end[c.lane];
-    for (;;) {
+    for (uint32_t turns = 0;; ++turns) {
+        if (turns > 8u * W_NODES + 64u) { c.overflow = true; c.why = 10; }       // every trie node is visited a bounded number of times per item
         if (c.overflow) { it.st = WX_DONE; return; }
         if (it.st == WX_FETCH) {
             uint32_t leaf;
@@ -342,7 +352,8 @@ template <class XL> VGK_HD void ww_extend(WwCtx<XL>& c, int32_t score, int32_t& 
             const uint32_t top = ww_nth_bit(leaves, c.lane % n_leaves);
             c.sh->queue[c.lane][0] = (uint8_t)top; it.qt = 1; it.st = WX_FETCH;
         }
-        for (;;) {
+        for (uint32_t rounds = 0;; ++rounds) {
+            if (rounds > 64u * W_NODES) { c.overflow = true; c.why = 10; }
             if (it.st != WX_DONE && it.st != WX_BLOCKED) ww_extend_run(c, here, score, diag, it);
             if (ww_any_overflow(c)) return;
             const unsigned long long none = ~0ull;
@@ -447,7 +458,7 @@ template <class XL> VGK_HD int32_t ww_next_score(WwCtx<XL>& c, int32_t match_sco
     if (c.sh->ps_flags[match_score] & 2) ww_mark(c, match_score + B.gap_extend, true);
     ww_mark(c, match_score + B.gap_open + B.gap_extend, true);
     int32_t s = match_score + 1;
-    while (!(c.sh->ps_flags[s] & 1)) ++s;
+    while (s < W_SCORES - 1 && !(c.sh->ps_flags[s] & 1)) ++s;
     return s;
 }
 template <class XL> VGK_HD int32_t ww_alignment_score(const WwCtx<XL>& c, int32_t score, int32_t diag, uint32_t seq, uint32_t final_insertion) {
@@ -493,7 +504,7 @@ template <class XL> VGK_HD void wfa_wave_problem(const WwParams& P, uint32_t i, 
     const WProb pb = B.probs[i];
     vgk_wfa_result out; out.status = pb.status; out.ok = 0; out.score = 0; out.node_offset = 0; out.seq_offset = 0; out.length = 0;
     out.path_begin = 0; out.path_len = 0; out.edit_begin = 0; out.n_edits = 0;
-    if (pb.status != VGK_OK || pb.from_node >= B.index.n_oriented) { if (lane == 0) B.results[i] = out; return; }
+    if (pb.status != VGK_OK || pb.from_node >= B.index.n_oriented) { if (lane == 0) B.results[i] = out; xl.fence(); return; }
     WwCtx<XL> c;
     c.P = &P; c.sh = &sh; c.xl = &xl; c.lane = lane;
     c.slot = P.slots + (size_t)slab * P.n_slots; c.mask = P.n_slots - 1; c.log = P.logs + (size_t)slab * P.max_points;
@@ -568,7 +579,9 @@ template <class XL> VGK_HD void wfa_wave_problem(const WwParams& P, uint32_t i, 
             int32_t p_score = c.cand_score, p_diag = c.cand_diag; uint32_t p_seq = c.cand_seq, p_off = c.cand_off, node = c.cand_node;
             if (unaligned_tail > 0) { ww_append_edit(c, runs, n_edits, VGK_WFA_INSERTION, c.L - c.cand_seq); p_score -= ww_gap_penalty(c, unaligned_tail); }
             int edit = VGK_WFA_MATCH;
+            uint32_t steps = 0;
             while ((p_seq > 0 || p_diag != 0) && !c.overflow && !lost) {
+                if (steps++ > 4u * (c.L + 2048u)) { c.overflow = true; c.why = 10; break; }
                 int pe; WPos pred;
                 switch (edit) {
                 case VGK_WFA_MATCH:
