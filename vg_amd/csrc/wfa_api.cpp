@@ -17,7 +17,7 @@ using namespace vgk;
 namespace {
 
 struct WfaHost { PinnedBuf<char> seqs; PinnedBuf<WProb> probs; PinnedBuf<vgk_wfa_result> dres; PinnedBuf<uint32_t> dpaths, dedits; uint64_t zeroed_bytes = 0; void* zeroed_ptr = nullptr;
-                 void* slab_ptr[2] = {nullptr, nullptr}; uint64_t slab_bytes[2] = {0, 0}, slab_shape[2] = {0, 0}; };
+                 void* slab_ptr = nullptr; uint64_t slab_bytes = 0, slab_shape = 0; };
 
 const vgk_wfa_error_model kDefaultModel = { { 0.03, 1, 6 }, { 0.05, 1, 10 }, { 0.1, 1, 20 }, { 0.1, 10, 200 } };   // gbwt_extender.hpp:386-395
 
@@ -31,22 +31,21 @@ char complement(char c) {
 // The wavefront form's slabs: per resident wavefront the table, its log, the path pool and the backtrace's edit runs, carved out of one
 // allocation per launch size; the table part must be all-zero before a launch (the kernel leaves it so).
 struct WaveSlabs { uint32_t waves, n_slots, max_points, path_cap; };
-int carve(vgk_ctx* ctx, WfaHost& H, int slot, int which, const WaveSlabs& z, WwParams& W) {
+int carve(vgk_ctx* ctx, WfaHost& H, int slot, const WaveSlabs& z, WwParams& W) {
     Backend* be = ctx->be.get();
     const uint64_t w = z.waves;
-    const uint64_t b_slots = 8ull * z.n_slots * w, b_logs = 4ull * z.max_points * w, b_pn = 4ull * z.path_cap * w, b_ps = 2ull * z.path_cap * w, b_runs = 4ull * W_EDITS * w;
-    const uint64_t want = b_slots + b_logs + b_pn + 2 * b_ps + b_runs + 64;
+    const uint64_t b_slots = 8ull * z.n_slots * w, b_logs = 4ull * z.max_points * w, b_paths = sizeof(WwPath) * (uint64_t)z.path_cap * w, b_runs = 4ull * W_EDITS * w;
+    const uint64_t want = b_slots + b_logs + b_paths + b_runs + 64;
     char* base = (char*)ctx->ensure_scratch(slot, want);
     if (!base) return VGK_ENOMEM;
-    if (H.slab_ptr[which] != base || H.slab_bytes[which] < want || H.slab_shape[which] != ((uint64_t)z.n_slots << 32 | z.waves)) {
+    if (H.slab_ptr != base || H.slab_bytes < want || H.slab_shape != ((uint64_t)z.n_slots << 32 | z.waves)) {
         if (be->zero(base, ctx->scratch[slot].bytes)) return VGK_ENODEV;
-        H.slab_ptr[which] = base; H.slab_bytes[which] = ctx->scratch[slot].bytes; H.slab_shape[which] = (uint64_t)z.n_slots << 32 | z.waves;
+        H.slab_ptr = base; H.slab_bytes = ctx->scratch[slot].bytes; H.slab_shape = (uint64_t)z.n_slots << 32 | z.waves;
     }
     W.slots = (unsigned long long*)base; W.n_slots = z.n_slots;
-    W.logs = (uint32_t*)(base + b_slots); W.max_points = z.max_points;
-    W.path_node = (int32_t*)(base + b_slots + b_logs); W.path_start = (uint16_t*)(base + b_slots + b_logs + b_pn); W.path_next = (uint16_t*)(base + b_slots + b_logs + b_pn + b_ps);
-    W.path_cap = z.path_cap;
-    W.edit_runs = (uint32_t*)(base + b_slots + b_logs + b_pn + 2 * b_ps);
+    W.paths = (WwPath*)(base + b_slots); W.path_cap = z.path_cap;
+    W.logs = (uint32_t*)(base + b_slots + b_paths); W.max_points = z.max_points;
+    W.edit_runs = (uint32_t*)(base + b_slots + b_paths + b_logs);
     return VGK_OK;
 }
 // every problem with small tables; what outgrows them once more with large ones
@@ -75,23 +74,26 @@ int run_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P) {
     const uint32_t cus = (uint32_t)std::max(1, be->compute_units());
     uint32_t per_cu[2] = {12, 8};
     if (const char* e = std::getenv("VGAMD_WFA_WAVES_PER_CU")) per_cu[0] = (uint32_t)std::max(1, std::atoi(e));
-    // small tables: 256 points cover all but a percent or two of giraffe's links (median: a dozen points); large: what a link with a
-    // 60-base insertion under the default error model stores, several times over
-    WaveSlabs za{std::min<uint32_t>(P.n, cus * per_cu[0]), 512u, 256u, 128u}, zb{cus * per_cu[1], 32768u, 16384u, 2048u};
-    if (const char* e = std::getenv("VGAMD_WFA_SMALL_POINTS")) { za.max_points = (uint32_t)std::max(16, std::atoi(e)); za.n_slots = 64; while (za.n_slots < 2 * za.max_points) za.n_slots *= 2; }
+    // the small size keeps its tables in LDS (256 points cover all but a percent or two of giraffe's links; the median is a dozen); the
+    // large size: what a link with a 60-base insertion under the default error model stores, several times over
+    const uint32_t waves_small = std::min<uint32_t>(P.n, cus * per_cu[0]);
+    WaveSlabs zb{cus * per_cu[1], 32768u, 16384u, 2048u};
     WwParams A{}, B{};
-    A.base = P; B.base = P;
+    A.base = P; B.base = P; A.small = 1; B.small = 0;
     // a caller's point budget below the tables' own sizes ends a problem as before (vgk_wfa_set_point_budgets); 0 = none
     A.base.max_points = B.base.max_points = ctx->wfa_point_budget ? ctx->wfa_point_budget : 0xffffffffu;
     A.base.max_points_tail = B.base.max_points_tail = ctx->wfa_point_budget_tail ? ctx->wfa_point_budget_tail : 0xffffffffu;
+    if (const char* e = std::getenv("VGAMD_WFA_SMALL_POINTS")) {               // (tests: a smaller first size, so that more problems take the second)
+        A.small_points = (uint32_t)std::max(16, std::atoi(e));
+    }
     int rc;
-    if ((rc = carve(ctx, H, 61, 0, za, A)) || (rc = carve(ctx, H, 62, 1, zb, B))) return rc;
+    if ((rc = carve(ctx, H, 62, zb, B))) return rc;
     char* extra = (char*)ctx->ensure_scratch(63, sizeof(uint32_t) * ((size_t)P.n + 8) + 16);
     if (!extra) return VGK_ENOMEM;
     A.todo = P.order; A.n_todo = P.n;
     A.n_declined = (unsigned long long*)extra; A.declined = (uint32_t*)(extra + 16);
     B.todo = A.declined; B.n_todo = 0; B.declined = nullptr; B.n_declined = nullptr;
-    ctx->wfa_wave_last[0] = A; ctx->wfa_wave_last[1] = B; ctx->wfa_wave_waves[0] = za.waves; ctx->wfa_wave_waves[1] = zb.waves;
+    ctx->wfa_wave_last[0] = A; ctx->wfa_wave_last[1] = B; ctx->wfa_wave_waves[0] = waves_small; ctx->wfa_wave_waves[1] = zb.waves;
     if ((rc = launch_wave_form(ctx))) return rc;
     ctx->wfa_wave_last_valid = true; ctx->wfa_last_valid = false;
     return VGK_OK;

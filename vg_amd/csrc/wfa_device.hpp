@@ -154,9 +154,15 @@ VGK_HD void w_store(WCtx& c, uint32_t node, int kind, int32_t score, int32_t dia
 // ---- search states: the non-empty one-node extensions in the order of the record's edges (follow_paths) ----
 struct WState { int32_t node, lo, hi; };
 // visits the non-empty extensions in order, copies number `want` into `out`, stops after `stop_at` of them; returns how many it saw
+VGK_HD uint32_t w_follow_rec(const uint32_t* rec, const WState& s, uint32_t want, WState& out, uint32_t stop_at, uint32_t* edge_out);
 VGK_HD uint32_t w_follow(const GIndex& h, const WState& s, uint32_t want, WState& out, uint32_t stop_at) {
     if (s.lo > s.hi) return 0;
-    const uint32_t* rec = g_rec(h, (uint32_t)s.node);
+    uint32_t edge = 0;
+    return w_follow_rec(g_rec(h, (uint32_t)s.node), s, want, out, stop_at, &edge);
+}
+// the same over the node's record at hand; *edge_out: the edge extension number `want` leaves through
+VGK_HD uint32_t w_follow_rec(const uint32_t* rec, const WState& s, uint32_t want, WState& out, uint32_t stop_at, uint32_t* edge_out) {
+    if (s.lo > s.hi) return 0;
     const uint32_t ne = g_ne(rec);
     const uint32_t* body = g_visits(rec);
     const bool few = ne <= 4;
@@ -182,7 +188,7 @@ VGK_HD uint32_t w_follow(const GIndex& h, const WState& s, uint32_t want, WState
         }
         else for (int32_t i = 0; i <= s.hi; ++i) if (g_body(body, (uint32_t)i) == e) { if (i < s.lo) ++before; else ++inside; }
         if (!inside) continue;
-        if (k == want) { out.node = to; out.lo = (int32_t)ge_base(rec, e) + before; out.hi = out.lo + inside - 1; }
+        if (k == want) { out.node = to; out.lo = (int32_t)ge_base(rec, e) + before; out.hi = out.lo + inside - 1; *edge_out = e; }
         ++k;
     }
     return k;

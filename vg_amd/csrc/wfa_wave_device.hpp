@@ -25,42 +25,64 @@
 //     compare-and-swap to claim a slot); nobody reads a point of the current penalty on another lane's diagonal.
 // Candidates carry their key and are merged by (penalty, key): the first among equals in the sequential order.
 //
-// Tables: per resident wavefront one slab in HBM — it is a few KB per problem and stays in the L2 of the wavefront's XCD — for the
-// wavefront table, its insertion log and the path pool; trie nodes, possible penalties and the lanes' work lists in LDS.  A launch
-// comes in two sizes: small tables for everyone, and the problems that outgrow them are collected and run again with large ones
-// (wfa_api.cpp); only what outgrows those as well is reported VGK_ETOOBIG.
+// Tables.  The kernel comes in two sizes (template parameter SMALL).  The small one keeps EVERYTHING of a problem in LDS — wavefront table
+// (256 points), its insertion log, the path pool, the edit runs of the backtrace, trie nodes, possible penalties, the lanes' work lists:
+// 13 KB per wavefront, 12 wavefronts per CU — and runs every problem; a problem that outgrows it is collected and run again by the large
+// one, whose table, log and pool are a slab in HBM per resident wavefront (wfa_api.cpp); only what outgrows that as well is reported
+// VGK_ETOOBIG.  A path-pool entry carries what comparing bases needs (where the node's bases lie, how many), and the walk along a
+// non-branching path takes a successor's length, bases and record from the edge it follows (the index stores them there): one
+// dependent load per hop instead of three.
 #pragma once
 #include "wfa_device.hpp"
 
 namespace vgk {
 
-constexpr int WW_QUEUE = 32;          // work-list entries per lane (trie nodes: each is queued at most once per item)
+constexpr int WW_QUEUE_SMALL = 8, WW_QUEUE_LARGE = 32;     // work-list entries per lane (trie nodes: each is queued at most once per item)
+constexpr int WW_SMALL_SLOTS = 512, WW_SMALL_POINTS = 256, WW_SMALL_PATH = 128;
+
+struct WwNode {                       // WNode of wfa_device.hpp + where the record of the path's last graph node lies
+    int32_t  st_node, st_lo, st_hi; uint32_t st_rec;
+    uint32_t len, target_offset;
+    uint16_t path_head, path_tail;
+    uint8_t  parent, first_child, n_children, dead_end;
+    uint8_t  complete, pad[3];
+    uint32_t ancestors;
+};
+struct WwPath { int32_t node; uint32_t seq_off; uint16_t start, len, next, pad; };     // a graph node on a trie node's path: its bases at index.seq + seq_off
 
 struct WwParams {
     WfaParams base;                   // index, problems, sequences, scoring, outputs, counters[2] = next problem to hand out
     const uint32_t* todo; uint32_t n_todo;      // the problems of this launch, in hand-out order
-    unsigned long long* slots; uint32_t n_slots;   // per resident wavefront: n_slots (a power of two) table slots ...
+    uint32_t small;                   // which size of the kernel this launch is
+    uint32_t small_points;            // the small size's own point limit when below WW_SMALL_POINTS (0 = that; a test hook: more problems for the large size)
+    // the large size: per resident wavefront ...
+    unsigned long long* slots; uint32_t n_slots;   // ... n_slots (a power of two) table slots ...
     uint32_t* logs; uint32_t max_points;            // ... max_points log entries (= points a problem may store) ...
-    int32_t* path_node; uint16_t* path_start; uint16_t* path_next; uint32_t path_cap;   // ... path_cap pool entries ...
+    WwPath* paths; uint32_t path_cap;               // ... path_cap pool entries ...
     uint32_t* edit_runs;                            // ... and W_EDITS edit runs for the backtrace
     uint32_t* declined; unsigned long long* n_declined;   // problems that outgrew this launch's tables (nullable: they are reported VGK_ETOOBIG)
 };
 
-struct WwShared {                     // per wavefront, in LDS
-    WNode    nodes[W_NODES];
+template <bool SMALL> struct WwTables {};
+template <> struct WwTables<true> {   // the small size keeps its tables in LDS
+    unsigned long long slot[WW_SMALL_SLOTS]; uint16_t log[WW_SMALL_POINTS]; WwPath path[WW_SMALL_PATH]; uint32_t runs[W_EDITS];
+};
+template <bool SMALL> struct WwShared : WwTables<SMALL> {                     // per wavefront, in LDS
+    static constexpr int QUEUE = SMALL ? WW_QUEUE_SMALL : WW_QUEUE_LARGE;
+    WwNode   nodes[W_NODES];
     uint32_t ps_range[W_SCORES]; uint8_t ps_flags[W_SCORES];
-    uint8_t  queue[64][WW_QUEUE];     // per lane: origins found expanded by someone else, in node order (FIFO)
-    uint8_t  stack_cur[64][WW_QUEUE], stack_end[64][WW_QUEUE];    // per lane: child ranges of the expansions it made itself (the recursion)
+    uint8_t  queue[64][QUEUE];        // per lane: origins found expanded by someone else, in node order (FIFO)
+    uint8_t  stack_cur[64][QUEUE], stack_end[64][QUEUE];      // per lane: child ranges of the expansions it made itself (the recursion)
     int32_t  expanded_at[W_NODES];    // next(): the diagonal of the item whose request expanded the node in the current chunk
     uint32_t n_nodes, n_path, n_points, leaves;
 };
 
 enum { WX_FETCH = 0, WX_MATCH = 1, WX_AFTER = 2, WX_BLOCKED = 3, WX_DONE = 4 };
 
-template <class XL> struct WwCtx {
-    const WwParams* P; WwShared* sh; XL* xl; uint32_t lane;
-    unsigned long long* slot; uint32_t mask; uint32_t* log; uint32_t max_points;
-    int32_t* path_node; uint16_t* path_start; uint16_t* path_next; uint32_t path_cap;
+template <class XL, bool SMALL> struct WwCtx {
+    const WwParams* P; WwShared<SMALL>* sh; XL* xl; uint32_t lane;
+    unsigned long long* slot; uint32_t* log; WwPath* path; uint32_t* runs;      // the large size's slab (unused by the small one)
+    uint32_t mask, max_points, path_cap;
     const char* seq; uint32_t L;
     int32_t to_node; uint32_t to_off; bool no_to;
     uint32_t grow_cap;                // bases a trie node is walked at its creation unless it ends earlier
@@ -70,16 +92,21 @@ template <class XL> struct WwCtx {
     int32_t max_distance;
     bool overflow; int why;           // why: 1 points, 2 trie nodes, 3 path pool, 4 edits, 5 node length, 6 walked end reached, 7 work list,
                                       // 8 table without a free slot, 9 broken path chain, 10 a loop ran past its bound (8-10: cannot happen; never hang)
+    VGK_HD unsigned long long* tbl(uint32_t i) { if constexpr (SMALL) return sh->slot + i; else return slot + i; }
+    VGK_HD void log_put(uint32_t at, uint32_t i) { if constexpr (SMALL) sh->log[at] = (uint16_t)i; else log[at] = i; }
+    VGK_HD uint32_t log_at(uint32_t k) const { if constexpr (SMALL) return sh->log[k]; else return log[k]; }
+    VGK_HD WwPath& pth(uint32_t k) { if constexpr (SMALL) return sh->path[k]; else return path[k]; }
+    VGK_HD uint32_t* run_buf() { if constexpr (SMALL) return sh->runs; else return runs; }
 };
 
 // ---- possible penalties ----
-template <class XL> VGK_HD WPScore ww_ps(const WwCtx<XL>& c, int32_t score) {
+template <class XL, bool SMALL> VGK_HD WPScore ww_ps(const WwCtx<XL, SMALL>& c, int32_t score) {
     WPScore p; p.flags = c.sh->ps_flags[score];
     const uint32_t r = c.sh->ps_range[score];
     p.min_d = (int16_t)(r & 0xffffu); p.max_d = (int16_t)(r >> 16);
     return p;
 }
-template <class XL> VGK_HD WSrc ww_src(const WwCtx<XL>& c, int32_t score) {
+template <class XL, bool SMALL> VGK_HD WSrc ww_src(const WwCtx<XL, SMALL>& c, int32_t score) {
     WSrc s = { score, 1, 0 };
     if (score < 0) return s;
     const WPScore ps = ww_ps(c, score);
@@ -88,14 +115,14 @@ template <class XL> VGK_HD WSrc ww_src(const WwCtx<XL>& c, int32_t score) {
 }
 
 // ---- the wavefront table: w_key / the node-free hash of wfa_device.hpp over this launch's slot count ----
-template <class XL> VGK_HD uint32_t ww_hash(const WwCtx<XL>& c, uint32_t key) { return ((((key - 1u) >> 5) * 2654435761u) >> 8) & c.mask; }
-template <class XL> VGK_HD bool ww_lookup(WwCtx<XL>& c, uint32_t ancestors, int kind, int32_t score, int32_t diag, uint32_t& node, uint32_t& seq, uint32_t& off) {
+template <class XL, bool SMALL> VGK_HD uint32_t ww_hash(const WwCtx<XL, SMALL>& c, uint32_t key) { return ((((key - 1u) >> 5) * 2654435761u) >> 8) & c.mask; }
+template <class XL, bool SMALL> VGK_HD bool ww_lookup(WwCtx<XL, SMALL>& c, uint32_t ancestors, int kind, int32_t score, int32_t diag, uint32_t& node, uint32_t& seq, uint32_t& off) {
     const uint32_t cell = (w_key(0, kind, score, diag) - 1u) >> 5;
     bool found = false; uint32_t best = 0;
     uint32_t probes = 0;
     for (uint32_t i = ww_hash(c, w_key(0, kind, score, diag));; i = (i + 1) & c.mask) {
         if (probes++ > c.mask) { c.overflow = true; c.why = 8; break; }         // a table without a free slot cannot be: say so instead of probing for ever
-        const unsigned long long s = c.xl->load64(c.slot + i);
+        const unsigned long long s = c.xl->load64(c.tbl(i));
         if (!s) break;
         const uint32_t key = (uint32_t)(s >> 32) - 1u, holder = key & 31u;
         if ((key >> 5) == cell && ((ancestors >> holder) & 1u) && (!found || holder > best)) {
@@ -105,40 +132,40 @@ template <class XL> VGK_HD bool ww_lookup(WwCtx<XL>& c, uint32_t ancestors, int 
     node = best;
     return found;
 }
-template <class XL> VGK_HD void ww_store(WwCtx<XL>& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t seq, uint32_t off) {
+template <class XL, bool SMALL> VGK_HD void ww_store(WwCtx<XL, SMALL>& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t seq, uint32_t off) {
     const uint32_t key = w_key(node, kind, score, diag);
     const unsigned long long v = ((unsigned long long)key << 32) | ((unsigned long long)(seq & 0xffffu) << 16) | (off & 0xffffu);
     uint32_t probes = 0;
     for (uint32_t i = ww_hash(c, key);; i = (i + 1) & c.mask) {
         if (probes++ > c.mask) { c.overflow = true; c.why = 8; return; }
-        unsigned long long s = c.xl->load64(c.slot + i);
+        unsigned long long s = c.xl->load64(c.tbl(i));
         if (!s) {
             if (c.sh->n_points >= c.max_points + 64u) { c.overflow = true; c.why = 1; return; }     // (someone's table has run over already: do not pile on)
-            s = c.xl->cas64(c.slot + i, 0ull, v);
+            s = c.xl->cas64(c.tbl(i), 0ull, v);
             if (!s) {                                                          // the slot is ours: a new point
                 const uint32_t at = c.xl->add32(&c.sh->n_points, 1u);
                 if (at >= c.max_points) { c.overflow = true; c.why = 1; return; }     // (the table is wiped whole after an overflow)
-                c.log[at] = i;
+                c.log_put(at, i);
                 return;
             }
         }
-        if ((uint32_t)(s >> 32) == key) { c.xl->store64(c.slot + i, v); return; }
+        if ((uint32_t)(s >> 32) == key) { c.xl->store64(c.tbl(i), v); return; }
     }
 }
 
 // ---- trie nodes (all of these read only; the trie changes in ww_node_create / ww_expand, one lane at a time) ----
-template <class XL> VGK_HD bool ww_past_end(WwCtx<XL>& c, uint32_t id, uint32_t off) {
-    const WNode& n = c.sh->nodes[id];
+template <class XL, bool SMALL> VGK_HD bool ww_past_end(WwCtx<XL, SMALL>& c, uint32_t id, uint32_t off) {
+    const WwNode& n = c.sh->nodes[id];
     if (off < n.len) return false;
     if (!n.complete) { c.overflow = true; c.why = 6; }                       // beyond what was walked: never guess
     return true;
 }
-template <class XL> VGK_HD void ww_pop(const WwCtx<XL>& c, WPos& p) {
+template <class XL, bool SMALL> VGK_HD void ww_pop(const WwCtx<XL, SMALL>& c, WPos& p) {
     const uint32_t below = c.sh->nodes[p.origin].ancestors & ~((2u << p.cur) - 1u);
     p.cur = (uint8_t)__builtin_ctz(below);
 }
-template <class XL> VGK_HD bool ww_at_dead_end(WwCtx<XL>& c, const WPos& p) { return ww_past_end(c, p.cur, p.off) && c.sh->nodes[p.cur].dead_end; }
-template <class XL> VGK_HD WPos ww_find_in(WwCtx<XL>& c, int kind, const WSrc& src, uint32_t ancestors, uint32_t origin, int32_t diag, bool ext_seq, bool ext_graph) {
+template <class XL, bool SMALL> VGK_HD bool ww_at_dead_end(WwCtx<XL, SMALL>& c, const WPos& p) { return ww_past_end(c, p.cur, p.off) && c.sh->nodes[p.cur].dead_end; }
+template <class XL, bool SMALL> VGK_HD WPos ww_find_in(WwCtx<XL, SMALL>& c, int kind, const WSrc& src, uint32_t ancestors, uint32_t origin, int32_t diag, bool ext_seq, bool ext_graph) {
     if (diag < src.lo || diag > src.hi) return w_none();
     uint32_t holder = 0, seq = 0, off = 0;
     if (!ww_lookup(c, ancestors, kind, src.score, diag, holder, seq, off)) return w_none();
@@ -147,40 +174,39 @@ template <class XL> VGK_HD WPos ww_find_in(WwCtx<XL>& c, int kind, const WSrc& s
     if (ext_graph && ww_at_dead_end(c, p)) return w_none();
     return p;
 }
-template <class XL> VGK_HD WPos ww_find_pos(WwCtx<XL>& c, int kind, uint32_t node, int32_t score, int32_t diag, bool ext_seq, bool ext_graph) {
+template <class XL, bool SMALL> VGK_HD WPos ww_find_pos(WwCtx<XL, SMALL>& c, int kind, uint32_t node, int32_t score, int32_t diag, bool ext_seq, bool ext_graph) {
     return ww_find_in(c, kind, ww_src(c, score), c.sh->nodes[node].ancestors, node, diag, ext_seq, ext_graph);
 }
-template <class XL> VGK_HD void ww_update(WwCtx<XL>& c, int kind, int32_t score, int32_t diag, const WPos& p) { ww_store(c, p.cur, kind, score, diag, p.seq, p.off); }
-template <class XL> VGK_HD void ww_successor_offset(WwCtx<XL>& c, WPos& p) {
+template <class XL, bool SMALL> VGK_HD void ww_update(WwCtx<XL, SMALL>& c, int kind, int32_t score, int32_t diag, const WPos& p) { ww_store(c, p.cur, kind, score, diag, p.seq, p.off); }
+template <class XL, bool SMALL> VGK_HD void ww_successor_offset(WwCtx<XL, SMALL>& c, WPos& p) {
     if (ww_past_end(c, p.cur, p.off)) { ww_pop(c, p); p.off = 0; }
     p.off++;
 }
-template <class XL> VGK_HD void ww_predecessor_offset(const WwCtx<XL>& c, uint32_t& node, uint32_t& off) {
+template <class XL, bool SMALL> VGK_HD void ww_predecessor_offset(const WwCtx<XL, SMALL>& c, uint32_t& node, uint32_t& off) {
     if (off > 0) --off;
     else { node = c.sh->nodes[node].parent; off = c.sh->nodes[node].len - 1; }
 }
-template <class XL> VGK_HD int32_t ww_gap_penalty(const WwCtx<XL>& c, uint32_t length) { return c.P->base.gap_open + (int32_t)length * c.P->base.gap_extend; }
-template <class XL> VGK_HD void ww_candidate(WwCtx<XL>& c, int32_t score, int32_t diag, uint32_t seq, uint32_t off, uint32_t node, uint32_t leaf) {
+template <class XL, bool SMALL> VGK_HD int32_t ww_gap_penalty(const WwCtx<XL, SMALL>& c, uint32_t length) { return c.P->base.gap_open + (int32_t)length * c.P->base.gap_extend; }
+template <class XL, bool SMALL> VGK_HD void ww_candidate(WwCtx<XL, SMALL>& c, int32_t score, int32_t diag, uint32_t seq, uint32_t off, uint32_t node, uint32_t leaf) {
     if (score < c.cand_score) { c.cand_score = score; c.cand_diag = diag; c.cand_seq = seq; c.cand_off = off; c.cand_node = node; c.cand_leaf = leaf; }
 }
-template <class XL> VGK_HD bool ww_wants_expansion(WwCtx<XL>& c, const WPos& p) {                 // the test of expand_if_necessary (:1995-1997)
-    const WNode& n = c.sh->nodes[p.cur];
+template <class XL, bool SMALL> VGK_HD bool ww_wants_expansion(WwCtx<XL, SMALL>& c, const WPos& p) {                 // the test of expand_if_necessary (:1995-1997)
+    const WwNode& n = c.sh->nodes[p.cur];
     return !n.n_children && !n.dead_end && ww_past_end(c, p.cur, p.off);
 }
 
-template <class XL> VGK_HD void ww_match_forward(WwCtx<XL>& c, WPos& p) {
+template <class XL, bool SMALL> VGK_HD void ww_match_forward(WwCtx<XL, SMALL>& c, WPos& p) {
     if (p.seq >= c.L || ww_past_end(c, p.cur, p.off)) return;
     const GIndex& h = c.P->base.index;
     uint32_t k = c.sh->nodes[p.cur].path_head;
     uint32_t hops = 0;
-    while (c.path_next[k] != W_NIL && c.path_start[c.path_next[k]] <= p.off && hops++ <= c.path_cap) k = c.path_next[k];
+    while (c.pth(k).next != W_NIL && c.pth(c.pth(k).next).start <= p.off && hops++ <= c.path_cap) k = c.pth(k).next;
     for (;;) {
         if (hops++ > 2 * c.path_cap || k >= c.path_cap) { c.overflow = true; c.why = 9; return; }       // a broken chain: never walk it for ever
-        const int32_t gn = c.path_node[k];
-        const uint32_t start = c.path_start[k], gl = g_len(h, gn);
-        const char* g = h.seq + g_rec(h, (uint32_t)gn)[3] + (p.off - start);
+        const WwPath e = c.pth(k);                                             // one entry: where the node's bases lie and how many
+        const char* g = h.seq + e.seq_off + (p.off - e.start);
         const char* r = c.seq + p.seq;
-        uint32_t left = start + gl - p.off; if (c.L - p.seq < left) left = c.L - p.seq;
+        uint32_t left = (uint32_t)e.start + e.len - p.off; if (c.L - p.seq < left) left = c.L - p.seq;
         uint32_t m = 0;
         while (m < left) {
             const uint64_t x = g_load8(g + m) ^ g_load8(r + m);
@@ -191,38 +217,48 @@ template <class XL> VGK_HD void ww_match_forward(WwCtx<XL>& c, WPos& p) {
         if (!differs) m = left;
         p.seq += m; p.off += m;
         if (differs || p.seq >= c.L || ww_past_end(c, p.cur, p.off) || c.overflow) return;
-        k = c.path_next[k];
+        k = e.next;
     }
 }
 
 // ---- changes to the trie: one lane, everyone else waiting at a fence ----
-template <class XL> VGK_HD bool ww_append_node(WwCtx<XL>& c, WNode& n, const WState& next) {
-    n.st_node = next.node; n.st_lo = next.lo; n.st_hi = next.hi;
+// the graph node a walk steps to: its search state and, from the edge followed, its length, bases and record
+struct WwStep { WState state; uint32_t len, seq_off, rec; };
+template <class XL, bool SMALL> VGK_HD bool ww_append_node(WwCtx<XL, SMALL>& c, WwNode& n, const WwStep& next) {
+    n.st_node = next.state.node; n.st_lo = next.state.lo; n.st_hi = next.state.hi; n.st_rec = next.rec;
     if (c.sh->n_path >= c.path_cap) { c.overflow = true; c.why = 3; return true; }
     const uint16_t at = (uint16_t)c.sh->n_path++;
-    c.path_node[at] = next.node; c.path_start[at] = (uint16_t)n.len; c.path_next[at] = W_NIL;
-    if (n.path_head == W_NIL) n.path_head = at; else c.path_next[n.path_tail] = at;
+    WwPath e; e.node = next.state.node; e.seq_off = next.seq_off; e.start = (uint16_t)n.len; e.len = (uint16_t)next.len; e.next = W_NIL; e.pad = 0;
+    c.pth(at) = e;
+    if (n.path_head == W_NIL) n.path_head = at; else c.pth(n.path_tail).next = at;
     n.path_tail = at;
-    const uint32_t nl = g_len(c.P->base.index, next.node);
-    n.len += nl;
+    n.len += next.len;
     if (n.len > 0xfff0u) { c.overflow = true; c.why = 5; return true; }
-    if (!c.no_to && c.to_node == next.node) { n.target_offset = n.len - (nl - c.to_off); return true; }
+    if (!c.no_to && c.to_node == next.state.node) { n.target_offset = n.len - (next.len - c.to_off); return true; }
     return false;
 }
+// w_follow over a record that is already at hand; the step's length / bases / record come from the edge (gapless_device.hpp: record layout)
+template <class XL, bool SMALL> VGK_HD uint32_t ww_follow(WwCtx<XL, SMALL>& c, uint32_t rec_off, const WState& s, uint32_t want, WwStep& out, uint32_t stop_at) {
+    const uint32_t* rec = c.P->base.index.rec + rec_off;
+    uint32_t edge = 0;
+    const uint32_t k = w_follow_rec(rec, s, want, out.state, stop_at, &edge);
+    if (k > want) { out.len = ge_len(rec, edge); out.seq_off = ge_seq(rec, edge); out.rec = ge_rec(rec, edge); }
+    return k;
+}
 // WFANode's constructor (:1463-1487), walked as far as this problem can look
-template <class XL> VGK_HD void ww_node_create(WwCtx<XL>& c, uint32_t id, const WState& state, uint32_t parent, uint32_t reach) {
-    WNode n;
+template <class XL, bool SMALL> VGK_HD void ww_node_create(WwCtx<XL, SMALL>& c, uint32_t id, const WwStep& first, uint32_t parent, uint32_t reach) {
+    WwNode n;
     n.len = 0; n.target_offset = W_NO_OFFSET; n.path_head = n.path_tail = W_NIL;
     n.parent = (uint8_t)parent; n.first_child = 0; n.n_children = 0; n.dead_end = 0; n.pad[0] = n.pad[1] = n.pad[2] = 0;
     n.ancestors = (id ? c.sh->nodes[parent].ancestors : 0u) | (1u << id);
     c.sh->leaves |= 1u << id;
-    n.complete = ww_append_node(c, n, state) ? 1 : 0;
+    n.complete = ww_append_node(c, n, first) ? 1 : 0;
     for (uint32_t hops = 0; !n.complete && !c.overflow; ++hops) {
         if (hops > c.path_cap) { c.overflow = true; c.why = 9; break; }
         if (n.len >= W_TARGET_LENGTH) { n.complete = 1; break; }
         if (n.len >= reach) break;                                           // nothing of this problem gets further; the node stays unfinished
-        const WState cur = { n.st_node, n.st_lo, n.st_hi }; WState next = { 0, 0, -1 };
-        const uint32_t successors = w_follow(c.P->base.index, cur, 0, next, 2);
+        const WState cur = { n.st_node, n.st_lo, n.st_hi }; WwStep next; next.state.node = 0; next.state.lo = 0; next.state.hi = -1;
+        const uint32_t successors = ww_follow(c, n.st_rec, cur, 0, next, 2);
         if (successors == 0) { n.dead_end = 1; n.complete = 1; }
         else if (successors > 1) n.complete = 1;
         else if (ww_append_node(c, n, next)) n.complete = 1;
@@ -230,17 +266,18 @@ template <class XL> VGK_HD void ww_node_create(WwCtx<XL>& c, uint32_t id, const 
     c.sh->nodes[id] = n;
 }
 // expand_if_necessary (:1992-2008) for a node known to be at its end; -> whether this call made the children
-template <class XL> VGK_HD bool ww_expand(WwCtx<XL>& c, uint32_t node) {
+template <class XL, bool SMALL> VGK_HD bool ww_expand(WwCtx<XL, SMALL>& c, uint32_t node) {
     if (c.sh->nodes[node].n_children || c.sh->nodes[node].dead_end) return false;
     const WState st = { c.sh->nodes[node].st_node, c.sh->nodes[node].st_lo, c.sh->nodes[node].st_hi };
-    WState next = { 0, 0, -1 };
-    const uint32_t k = w_follow(c.P->base.index, st, 0, next, 0xffffffffu);
+    const uint32_t rec = c.sh->nodes[node].st_rec;
+    WwStep next; next.state.node = 0; next.state.lo = 0; next.state.hi = -1;
+    const uint32_t k = ww_follow(c, rec, st, 0, next, 0xffffffffu);
     if (!k) { c.sh->nodes[node].dead_end = 1; return false; }
     if (c.sh->n_nodes + k > (uint32_t)W_NODES) { c.overflow = true; c.why = 2; return false; }
     c.sh->nodes[node].first_child = (uint8_t)c.sh->n_nodes; c.sh->nodes[node].n_children = (uint8_t)k;
     c.sh->leaves &= ~(1u << node);
     for (uint32_t i = 0; i < k; ++i) {
-        if (i) w_follow(c.P->base.index, st, i, next, i + 1);
+        if (i) ww_follow(c, rec, st, i, next, i + 1);
         ww_node_create(c, c.sh->n_nodes, next, node, c.grow_cap); ++c.sh->n_nodes;
         if (c.overflow) return true;
     }
@@ -248,7 +285,7 @@ template <class XL> VGK_HD bool ww_expand(WwCtx<XL>& c, uint32_t node) {
 }
 
 // the lanes agree on whether anyone has failed; the reason of the lowest such lane is everyone's
-template <class XL> VGK_HD bool ww_any_overflow(WwCtx<XL>& c) {
+template <class XL, bool SMALL> VGK_HD bool ww_any_overflow(WwCtx<XL, SMALL>& c) {
     const unsigned long long bad = c.xl->ballot(c.overflow);
     if (!bad) return false;
     const uint32_t who = (uint32_t)__builtin_ctzll(bad);
@@ -261,7 +298,7 @@ VGK_HD uint32_t ww_popcount(uint32_t x) { return (uint32_t)__builtin_popcount(x)
 // ---- extend(): an item runs until it is done or needs a node expanded ----
 struct WwItem { int st; uint32_t qh, qt, sp, key_leaf, blocked_on; WPos pos; bool creator; };
 
-template <class XL> VGK_HD void ww_extend_run(WwCtx<XL>& c, const WSrc& here, int32_t score, int32_t diag, WwItem& it) {
+template <class XL, bool SMALL> VGK_HD void ww_extend_run(WwCtx<XL, SMALL>& c, const WSrc& here, int32_t score, int32_t diag, WwItem& it) {
     uint8_t* queue = c.sh->queue[c.lane]; uint8_t* scur = c.sh->stack_cur[c.lane]; uint8_t* send = c.sh->stack_end[c.lane];
     for (uint32_t turns = 0;; ++turns) {
         if (turns > 8u * W_NODES + 64u) { c.overflow = true; c.why = 10; }       // every trie node is visited a bounded number of times per item
@@ -299,14 +336,14 @@ template <class XL> VGK_HD void ww_extend_run(WwCtx<XL>& c, const WSrc& here, in
         if (it.st == WX_AFTER) {                                               // at the end of a node that is expanded (or a dead end) by now
             WPos& pos = it.pos;
             if (pos.cur == pos.origin) {
-                const WNode& now = c.sh->nodes[pos.cur];
+                const WwNode& now = c.sh->nodes[pos.cur];
                 if (now.n_children) {
                     if (it.creator) {                                           // the reference's recursion: the new children at once, in order
-                        if (it.sp >= (uint32_t)WW_QUEUE) { c.overflow = true; c.why = 7; it.st = WX_DONE; return; }
+                        if (it.sp >= (uint32_t)WwShared<SMALL>::QUEUE) { c.overflow = true; c.why = 7; it.st = WX_DONE; return; }
                         scur[it.sp] = now.first_child; send[it.sp] = (uint8_t)(now.first_child + now.n_children); ++it.sp;
                     } else {                                                    // someone with a smaller key made them: they are leaves of this diagonal, behind the older ones
                         for (uint32_t k = 0; k < now.n_children; ++k) {
-                            if (it.qt >= (uint32_t)WW_QUEUE) { c.overflow = true; c.why = 7; it.st = WX_DONE; return; }
+                            if (it.qt >= (uint32_t)WwShared<SMALL>::QUEUE) { c.overflow = true; c.why = 7; it.st = WX_DONE; return; }
                             queue[it.qt++] = (uint8_t)(now.first_child + k);
                         }
                     }
@@ -321,7 +358,7 @@ template <class XL> VGK_HD void ww_extend_run(WwCtx<XL>& c, const WSrc& here, in
 }
 
 // merge the lanes' candidates into every lane's copy of the best: smallest penalty, then the smallest key
-template <class XL> VGK_HD void ww_merge_candidates(WwCtx<XL>& c, int32_t& best_score, int32_t& best_diag, uint32_t& best_seq, uint32_t& best_off, uint32_t& best_node,
+template <class XL, bool SMALL> VGK_HD void ww_merge_candidates(WwCtx<XL, SMALL>& c, int32_t& best_score, int32_t& best_diag, uint32_t& best_seq, uint32_t& best_off, uint32_t& best_node,
                                                     int32_t diag_base) {
     // (penalties are < 2^20 here or INT_MAX for "none"; diagonals within +-512 of diag_base)
     const unsigned long long none = ~0ull;
@@ -338,7 +375,7 @@ template <class XL> VGK_HD void ww_merge_candidates(WwCtx<XL>& c, int32_t& best_
     c.cand_score = 0x7fffffff;
 }
 
-template <class XL> VGK_HD void ww_extend(WwCtx<XL>& c, int32_t score, int32_t& best_score, int32_t& best_diag, uint32_t& best_seq, uint32_t& best_off, uint32_t& best_node) {
+template <class XL, bool SMALL> VGK_HD void ww_extend(WwCtx<XL, SMALL>& c, int32_t score, int32_t& best_score, int32_t& best_diag, uint32_t& best_seq, uint32_t& best_off, uint32_t& best_node) {
     const WPScore ps = ww_ps(c, score);
     if (!(ps.flags & 1)) return;
     const WSrc here = { score, ps.min_d, ps.max_d };
@@ -377,7 +414,7 @@ template <class XL> VGK_HD void ww_extend(WwCtx<XL>& c, int32_t score, int32_t& 
 }
 
 // ---- next() (:1709-1786): one item per lane, nothing to wait for ----
-template <class XL> VGK_HD void ww_next(WwCtx<XL>& c, int32_t score, int32_t& best_score, int32_t& best_diag, uint32_t& best_seq, uint32_t& best_off, uint32_t& best_node) {
+template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t score, int32_t& best_score, int32_t& best_diag, uint32_t& best_seq, uint32_t& best_off, uint32_t& best_node) {
     const WfaParams& B = c.P->base;
     int32_t lo = 32767, hi = -32768;
     auto widen = [&](int32_t s) { if (s < 0) return; const WPScore p = ww_ps(c, s); if (!(p.flags & 1)) return; if (p.min_d < lo) lo = p.min_d; if (p.max_d > hi) hi = p.max_d; };
@@ -447,12 +484,12 @@ template <class XL> VGK_HD void ww_next(WwCtx<XL>& c, int32_t score, int32_t& be
 }
 
 // ---- the sequential rest, on lane 0: penalties, trim, backtrace, output (the code of wfa_device.hpp over this kernel's tables) ----
-template <class XL> VGK_HD void ww_mark(WwCtx<XL>& c, int32_t score, bool gap) {
+template <class XL, bool SMALL> VGK_HD void ww_mark(WwCtx<XL, SMALL>& c, int32_t score, bool gap) {
     const uint8_t f = c.sh->ps_flags[score];
     if (!(f & 1)) { c.sh->ps_range[score] = 0; c.sh->ps_flags[score] = (uint8_t)(1 | (gap ? 2 : 0)); }
     else if (gap && !(f & 2)) c.sh->ps_flags[score] = (uint8_t)(f | 2);
 }
-template <class XL> VGK_HD int32_t ww_next_score(WwCtx<XL>& c, int32_t match_score) {
+template <class XL, bool SMALL> VGK_HD int32_t ww_next_score(WwCtx<XL, SMALL>& c, int32_t match_score) {
     const WfaParams& B = c.P->base;
     ww_mark(c, match_score + B.mismatch, false);
     if (c.sh->ps_flags[match_score] & 2) ww_mark(c, match_score + B.gap_extend, true);
@@ -461,25 +498,25 @@ template <class XL> VGK_HD int32_t ww_next_score(WwCtx<XL>& c, int32_t match_sco
     while (s < W_SCORES - 1 && !(c.sh->ps_flags[s] & 1)) ++s;
     return s;
 }
-template <class XL> VGK_HD int32_t ww_alignment_score(const WwCtx<XL>& c, int32_t score, int32_t diag, uint32_t seq, uint32_t final_insertion) {
+template <class XL, bool SMALL> VGK_HD int32_t ww_alignment_score(const WwCtx<XL, SMALL>& c, int32_t score, int32_t diag, uint32_t seq, uint32_t final_insertion) {
     const int32_t target_offset = (int32_t)seq - diag;
     return (c.P->base.match * ((int32_t)(seq + final_insertion) + target_offset) - score) / 2;
 }
-template <class XL> VGK_HD WPos ww_ins_predecessor(WwCtx<XL>& c, uint32_t node, int32_t score, int32_t diag, int& edit) {
+template <class XL, bool SMALL> VGK_HD WPos ww_ins_predecessor(WwCtx<XL, SMALL>& c, uint32_t node, int32_t score, int32_t diag, int& edit) {
     const WfaParams& B = c.P->base;
     const WPos open = ww_find_pos(c, WK_MATCH, node, score - B.gap_open - B.gap_extend, diag - 1, true, false);
     const WPos ext = ww_find_pos(c, WK_INS, node, score - B.gap_extend, diag - 1, true, false);
     if (w_less(open, ext)) { edit = VGK_WFA_INSERTION; return ext; }
     edit = VGK_WFA_MATCH; return open;
 }
-template <class XL> VGK_HD WPos ww_del_predecessor(WwCtx<XL>& c, uint32_t node, int32_t score, int32_t diag, int& edit) {
+template <class XL, bool SMALL> VGK_HD WPos ww_del_predecessor(WwCtx<XL, SMALL>& c, uint32_t node, int32_t score, int32_t diag, int& edit) {
     const WfaParams& B = c.P->base;
     const WPos open = ww_find_pos(c, WK_MATCH, node, score - B.gap_open - B.gap_extend, diag + 1, false, true);
     const WPos ext = ww_find_pos(c, WK_DEL, node, score - B.gap_extend, diag + 1, false, true);
     if (w_less(open, ext)) { edit = VGK_WFA_DELETION; return ext; }
     edit = VGK_WFA_MATCH; return open;
 }
-template <class XL> VGK_HD WPos ww_match_predecessor(WwCtx<XL>& c, uint32_t node, int32_t score, int32_t diag, int& edit) {
+template <class XL, bool SMALL> VGK_HD WPos ww_match_predecessor(WwCtx<XL, SMALL>& c, uint32_t node, int32_t score, int32_t diag, int& edit) {
     const WPos ins = ww_find_pos(c, WK_INS, node, score, diag, false, false);
     const WPos del = ww_find_pos(c, WK_DEL, node, score, diag, false, false);
     WPos subst = ww_find_pos(c, WK_MATCH, node, score - c.P->base.mismatch, diag, false, false);
@@ -491,7 +528,7 @@ template <class XL> VGK_HD WPos ww_match_predecessor(WwCtx<XL>& c, uint32_t node
     if (w_less(ins, subst)) { edit = VGK_WFA_MISMATCH; return subst; }
     edit = VGK_WFA_INSERTION; return ins;
 }
-template <class XL> VGK_HD void ww_append_edit(WwCtx<XL>& c, uint32_t* runs, uint32_t& n_edits, int edit, uint32_t length) {
+template <class XL, bool SMALL> VGK_HD void ww_append_edit(WwCtx<XL, SMALL>& c, uint32_t* runs, uint32_t& n_edits, int edit, uint32_t length) {
     if (!length) return;
     if (n_edits && (runs[n_edits - 1] & 3u) == (uint32_t)edit) { runs[n_edits - 1] += length << 2; return; }
     if (n_edits >= (uint32_t)W_EDITS) { c.overflow = true; c.why = 4; return; }
@@ -499,20 +536,27 @@ template <class XL> VGK_HD void ww_append_edit(WwCtx<XL>& c, uint32_t* runs, uin
 }
 
 // One problem on one wavefront.  `slab` = this wavefront's number among the resident ones.
-template <class XL> VGK_HD void wfa_wave_problem(const WwParams& P, uint32_t i, uint32_t slab, uint32_t lane, WwShared& sh, XL& xl) {
+template <class XL, bool SMALL> VGK_HD void wfa_wave_problem(const WwParams& P, uint32_t i, uint32_t slab, uint32_t lane, WwShared<SMALL>& sh, XL& xl) {
     const WfaParams& B = P.base;
     const WProb pb = B.probs[i];
     vgk_wfa_result out; out.status = pb.status; out.ok = 0; out.score = 0; out.node_offset = 0; out.seq_offset = 0; out.length = 0;
     out.path_begin = 0; out.path_len = 0; out.edit_begin = 0; out.n_edits = 0;
     if (pb.status != VGK_OK || pb.from_node >= B.index.n_oriented) { if (lane == 0) B.results[i] = out; xl.fence(); return; }
-    WwCtx<XL> c;
+    WwCtx<XL, SMALL> c;
     c.P = &P; c.sh = &sh; c.xl = &xl; c.lane = lane;
-    c.slot = P.slots + (size_t)slab * P.n_slots; c.mask = P.n_slots - 1; c.log = P.logs + (size_t)slab * P.max_points;
-    c.path_node = P.path_node + (size_t)slab * P.path_cap; c.path_start = P.path_start + (size_t)slab * P.path_cap; c.path_next = P.path_next + (size_t)slab * P.path_cap;
-    c.path_cap = P.path_cap;
+    uint32_t own_points;                                                      // this launch's own limit (a caller's budget may lie below it)
+    if constexpr (SMALL) {
+        c.slot = nullptr; c.log = nullptr; c.path = nullptr; c.runs = nullptr;
+        c.mask = WW_SMALL_SLOTS - 1; c.path_cap = WW_SMALL_PATH;
+        own_points = P.small_points && P.small_points < (uint32_t)WW_SMALL_POINTS ? P.small_points : (uint32_t)WW_SMALL_POINTS;
+    } else {
+        c.slot = P.slots + (size_t)slab * P.n_slots; c.mask = P.n_slots - 1; c.log = P.logs + (size_t)slab * P.max_points;
+        c.path = P.paths + (size_t)slab * P.path_cap; c.path_cap = P.path_cap; c.runs = P.edit_runs + (size_t)slab * W_EDITS;
+        own_points = P.max_points;
+    }
     c.seq = B.seqs + pb.seq_off; c.L = pb.seq_len;
     c.no_to = pb.to_node == VGK_WFA_NO_NODE; c.to_node = (int32_t)pb.to_node; c.to_off = pb.to_off;
-    c.max_points = c.no_to ? (B.max_points_tail < P.max_points ? B.max_points_tail : P.max_points) : (B.max_points < P.max_points ? B.max_points : P.max_points);
+    { const uint32_t budget = c.no_to ? B.max_points_tail : B.max_points; c.max_points = budget < own_points ? budget : own_points; }
     // no position gets further into a trie node than the sequence plus the deletions the score cap pays for (+ where the root starts)
     c.grow_cap = c.L + (uint32_t)(pb.score_bound / B.gap_extend) + 2u;
     c.cand_score = 0x7fffffff; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0; c.cand_leaf = 0;
@@ -522,7 +566,9 @@ template <class XL> VGK_HD void wfa_wave_problem(const WwParams& P, uint32_t i, 
     if (lane < (uint32_t)W_NODES) sh.expanded_at[lane] = 0;
     if (lane == 0) {
         sh.n_nodes = 0; sh.n_path = 0; sh.n_points = 0; sh.leaves = 0;
-        const WState root = { (int32_t)pb.from_node, 0, (int32_t)g_rec(B.index, pb.from_node)[0] - 1 };
+        const uint32_t root_rec = B.index.rec_off[pb.from_node];
+        const uint32_t* rec = B.index.rec + root_rec;
+        WwStep root; root.state.node = (int32_t)pb.from_node; root.state.lo = 0; root.state.hi = (int32_t)rec[0] - 1; root.len = rec[2]; root.seq_off = rec[3]; root.rec = root_rec;
         ww_node_create(c, 0, root, 0, c.grow_cap + pb.from_off + 1); sh.n_nodes = 1;
         if (!c.overflow) ww_store(c, 0, WK_MATCH, 0, 0, 0, pb.from_off + 1);
         ww_mark(c, 0, false);
@@ -546,7 +592,7 @@ template <class XL> VGK_HD void wfa_wave_problem(const WwParams& P, uint32_t i, 
     }
     // the rest is one chain of dependent lookups: lane 0
     const uint32_t n_points = sh.n_points < c.max_points ? sh.n_points : c.max_points;
-    uint32_t* runs = P.edit_runs + (size_t)slab * W_EDITS;
+    uint32_t* runs = c.run_buf();
     if (lane == 0 && !failed) {
         c.cand_score = best_score; c.cand_diag = best_diag; c.cand_seq = best_seq; c.cand_off = best_off; c.cand_node = best_node;
         bool ok = true;
@@ -557,7 +603,7 @@ template <class XL> VGK_HD void wfa_wave_problem(const WwParams& P, uint32_t i, 
                 c.cand_score = 0; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0;
                 int32_t best = 0; uint32_t best_order = 0xffffffffu;
                 for (uint32_t k = 0; k < n_points; ++k) {
-                    const unsigned long long s = c.slot[c.log[k]];
+                    const unsigned long long s = xl.load64(c.tbl(c.log_at(k)));
                     const uint32_t key = (uint32_t)(s >> 32) - 1;
                     if (((key >> 5) & 3u) != (uint32_t)WK_MATCH) continue;
                     const uint32_t node = key & 31u; const int32_t sc = (int32_t)((key >> 7) & 1023u), dg = (int32_t)((key >> 17) & 1023u) - 512;
@@ -615,21 +661,20 @@ template <class XL> VGK_HD void wfa_wave_problem(const WwParams& P, uint32_t i, 
         }
         if (lost) { out.status = VGK_ENOBAND; out.ok = 0; out.score = 0; out.node_offset = 0; out.length = 0; }
         if (ok) {
-            uint8_t* chain = sh.queue[0];                                      // (free again: the phases are over)
+            uint8_t chain[W_NODES];
             uint32_t n_chain = 0;
             for (uint32_t x = c.cand_node;; x = sh.nodes[x].parent) { chain[n_chain++] = (uint8_t)x; if (x == 0) break; }
             uint32_t ref_len = 0;
             for (uint32_t e = 0; e < n_edits; ++e) if ((runs[e] & 3u) != (uint32_t)VGK_WFA_INSERTION) ref_len += runs[e] >> 2;
-            const int32_t first_node = c.path_node[sh.nodes[0].path_head];
-            const uint32_t first_len = g_len(B.index, first_node);
+            const uint32_t first_len = c.pth(sh.nodes[0].path_head).len;
             const bool drop_first = out.node_offset >= first_len;
             if (drop_first) out.node_offset = 0;
             const uint32_t used = out.node_offset + ref_len;
             uint32_t kept = 0, at = 0, last_start = 0, last_len = 0;
             for (uint32_t k = n_chain; k-- > 0;) {
-                const WNode& n = sh.nodes[chain[k]];
-                for (uint32_t j = n.path_head; j != W_NIL; j = c.path_next[j]) {
-                    const uint32_t gl = g_len(B.index, c.path_node[j]);
+                const WwNode& n = sh.nodes[chain[k]];
+                for (uint32_t j = n.path_head; j != W_NIL; j = c.pth(j).next) {
+                    const uint32_t gl = c.pth(j).len;
                     if (k == n_chain - 1 && j == n.path_head && drop_first) continue;
                     if (kept == 0 || at < used) { ++kept; last_start = at; last_len = gl; }
                     at += gl;
@@ -642,10 +687,10 @@ template <class XL> VGK_HD void wfa_wave_problem(const WwParams& P, uint32_t i, 
                 const bool flip = pb.mode == VGK_WFA_PREFIX;
                 uint32_t w = 0;
                 for (uint32_t k = n_chain; k-- > 0 && w < kept;) {
-                    const WNode& n = sh.nodes[chain[k]];
-                    for (uint32_t j = n.path_head; j != W_NIL && w < kept; j = c.path_next[j]) {
+                    const WwNode& n = sh.nodes[chain[k]];
+                    for (uint32_t j = n.path_head; j != W_NIL && w < kept; j = c.pth(j).next) {
                         if (k == n_chain - 1 && j == n.path_head && drop_first) continue;
-                        const uint32_t o = (uint32_t)c.path_node[j];
+                        const uint32_t o = (uint32_t)c.pth(j).node;
                         B.paths[p0 + (flip ? kept - 1 - w : w)] = flip ? (o ^ 1u) : o;
                         ++w;
                     }
@@ -668,7 +713,7 @@ template <class XL> VGK_HD void wfa_wave_problem(const WwParams& P, uint32_t i, 
         if (failed) {
             // tables of this launch's size were not enough: the large-table launch takes the problem — unless it was the caller's own
             // point budget that ran out — or it is declined
-            const bool retry = P.declined && ((c.why == 1 && c.max_points == P.max_points) || c.why == 3);
+            const bool retry = P.declined && ((c.why == 1 && c.max_points == own_points) || c.why == 3 || c.why == 7);
             if (retry) P.declined[g_bump(P.n_declined, 1)] = i;
             out.status = VGK_ETOOBIG; out.ok = 0; out.score = c.why; out.node_offset = 0; out.length = 0;
         }
@@ -676,19 +721,20 @@ template <class XL> VGK_HD void wfa_wave_problem(const WwParams& P, uint32_t i, 
     }
     // leave the table all-zero: the touched slots from the log, or everything when the log ran over
     xl.fence();
-    if (sh.n_points > c.max_points) { for (uint32_t k = lane; k < P.n_slots; k += 64) c.slot[k] = 0; }
-    else for (uint32_t k = lane; k < n_points; k += 64) c.slot[c.log[k]] = 0;
+    if (sh.n_points > c.max_points) { for (uint32_t k = lane; k <= c.mask; k += 64) *c.tbl(k) = 0; }
+    else for (uint32_t k = lane; k < n_points; k += 64) *c.tbl(c.log_at(k)) = 0;
     xl.fence();
 }
 
 // one resident wavefront: problems are handed out one at a time
-template <class XL> VGK_HD void wfa_wave(const WwParams& P, uint32_t slab, uint32_t lane, WwShared& sh, XL& xl) {
+template <class XL, bool SMALL> VGK_HD void wfa_wave(const WwParams& P, uint32_t slab, uint32_t lane, WwShared<SMALL>& sh, XL& xl) {
+    if constexpr (SMALL) { for (uint32_t k = lane; k < (uint32_t)WW_SMALL_SLOTS; k += 64) sh.slot[k] = 0; xl.fence(); }      // (LDS comes up with whatever was there)
     for (;;) {
         uint32_t k = 0;
         if (lane == 0) k = (uint32_t)g_bump(P.base.counters + 2, 1);
         k = xl.bcast(k, 0);
         if (k >= P.n_todo) break;
-        wfa_wave_problem(P, P.todo[k], slab, lane, sh, xl);
+        wfa_wave_problem<XL, SMALL>(P, P.todo[k], slab, lane, sh, xl);
     }
 }
 
