@@ -331,7 +331,7 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
                                        "translation back to the base graph; per-read totals",
                        "problems": wl.n, "problems_per_read": wl.n / n, "read_bases": wl.read_bases, "bases_per_s": wl.read_bases * world * args.steps / elapsed,
                        "links": out["stats"], "host_threads": threads,
-                       "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()}, "wfa_kernel_ms": out["wfa_kernel_ms"],
+                       "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()}, "wfa_kernel_ms": out["wfa_kernel_ms"], "wfa_launches": out["wfa_launches"],
                        "with_point_budgets": {"connect": budget, "tail": tail_budget, "reads_per_s": n * world * args.steps / b_elapsed, "ms_per_step": 1e3 * b_elapsed / args.steps,
                                               "links": b_out["stats"], "stage_ms": {k: 1e3 * v / args.steps for k, v in b_timing.items()}, "wfa_kernel_ms": b_out["wfa_kernel_ms"]},
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},

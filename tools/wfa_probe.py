@@ -55,3 +55,12 @@ elif stage == "each":
         print("problem", i, problems[i]["mode"], len(problems[i]["seq"]), end=" ... ", flush=True)
         b = eng.wfa_extend(idx, problems[i:i + 1], model)
         print(int(b[0]["status"][0]), int(b[0]["score"][0]), "oracle", int(a[0]["status"][i]), int(a[0]["score"][i]), "retried", T.last_wave(eng, 2), flush=True)
+elif stage == "launches":
+    from vg_amd import workloads
+    eng = capi.Engine()
+    n = int(sys.argv[2])
+    wl = workloads.WfaWorkload(n) if hasattr(workloads, "WfaWorkload") else None
+    idx = eng.haplo_index(wl.nodes, wl.threads)
+    for k in range(3):
+        res, paths, edits = eng.wfa_extend(idx, wl.ws)
+        say("call", k, "kernel ms", eng.wfa_last_ms(), "small", T.last_wave(eng, 0), "large", T.last_wave(eng, 1), "retried", T.last_wave(eng, 2), "ok", int((res["ok"] != 0).sum()), "declined", int((res["status"] != 0).sum()))

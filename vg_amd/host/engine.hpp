@@ -40,6 +40,7 @@ struct EngineApi {
     decltype(&vgk_forest_destroy) forest_destroy = nullptr;
     decltype(&vgk_wfa_set_point_budgets) wfa_set_point_budgets = nullptr;
     decltype(&vgk_wfa_last_ms) wfa_last_ms = nullptr;
+    decltype(&vgk_wfa_last_wave) wfa_last_wave = nullptr;
     ~EngineApi();
 };
 

@@ -481,4 +481,5 @@ int vgh_wfa_set_point_budgets(vgh_wfa* w, uint32_t connect_points, uint32_t tail
     return a.engine_api().wfa_set_point_budgets(a.engine_context(), connect_points, tail_points);
 }
 double vgh_wfa_last_kernel_ms(vgh_wfa* w) { const Aligner& a = *w->ext->aligner; return a.engine_api().wfa_last_ms(a.engine_context()); }
+double vgh_wfa_last_wave(vgh_wfa* w, int which) { const Aligner& a = *w->ext->aligner; return a.engine_api().wfa_last_wave(a.engine_context(), which); }
 }

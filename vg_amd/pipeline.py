@@ -293,6 +293,7 @@ class ChainStage:
         h.vgh_wfa_destroy.argtypes = [ctypes.c_void_p]
         h.vgh_wfa_set_point_budgets.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
         h.vgh_wfa_last_kernel_ms.restype = ctypes.c_double; h.vgh_wfa_last_kernel_ms.argtypes = [ctypes.c_void_p]
+        h.vgh_wfa_last_wave.restype = ctypes.c_double; h.vgh_wfa_last_wave.argtypes = [ctypes.c_void_p, ctypes.c_int]
         h.vgh_chain_stage.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_uint32] + [ctypes.c_void_p] * 4 + \
                                      [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6
         self.h = h
@@ -337,7 +338,8 @@ class ChainStage:
                              "banded + X-drop flush", "translation + totals"), ms):
                 timing[k] = timing.get(k, 0.0) + v * 1e-3
         return dict(link_score=link_score, link_source=source, wfa_status=status, chain_score=chain,
-                    stats=dict(zip(("declined", "between", "no_graph", "too_big", "failed"), (int(x) for x in stats))), wfa_kernel_ms=self.h.vgh_wfa_last_kernel_ms(self.wfa))
+                    stats=dict(zip(("declined", "between", "no_graph", "too_big", "failed"), (int(x) for x in stats))), wfa_kernel_ms=self.h.vgh_wfa_last_kernel_ms(self.wfa),
+                    wfa_launches=dict(small_tables_ms=self.h.vgh_wfa_last_wave(self.wfa, 0), large_tables_ms=self.h.vgh_wfa_last_wave(self.wfa, 1), problems_in_the_large_launch=int(self.h.vgh_wfa_last_wave(self.wfa, 2))))
 
     def close(self):
         if getattr(self, "wfa", None):
