@@ -494,7 +494,7 @@ int  vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mo
                     uint32_t* paths, size_t path_cap, uint32_t* edits, size_t edit_cap, size_t written[2] /* paths, edits */);
 int    vgk_wfa_rerun(vgk_ctx* ctx);          /* launch the kernel of the last vgk_wfa_extend call again on its resident inputs */
 double vgk_wfa_last_ms(vgk_ctx* ctx);        /* kernel time of the last vgk_wfa_extend call on this context */
-double vgk_wfa_last_wave(vgk_ctx* ctx, int which);   /* of that call: 0 = ms of the launch with small tables, 1 = ms of the launch with large ones, 2 = problems the latter took */
+double vgk_wfa_last_wave(vgk_ctx* ctx, int which);   /* of that call (wavefront form): 0 = ms of the launch, 2 = problems that outgrew the small tables (LDS) and were run again with the large ones (HBM) */
 /* A launch lasts as long as its slowest problem, and a problem that is going to outgrow the kernel's wavefront table (1024 stored
  * points) — a connect across a structural variant, say — is the slowest by far.  The budget makes the kernel give such a problem up
  * early: beyond `points` stored wavefront points it is reported VGK_ETOOBIG (score = 1) exactly as when the table is full, and the

@@ -145,7 +145,7 @@ public:
         ucontext_t main_ctx, ctx[N]; std::vector<char> stack[N];
         int current = 0;
         int32_t buf[2][N]; unsigned long long wide[2][N]; uint32_t epoch[N];
-        const WwParams* P = nullptr; WwShared<true> shared_small; WwShared<false> shared_large;
+        const WwParams* P = nullptr; WwSharedBoth shared;
         void yield() { const int me = current; current = (me + 1) % N; swapcontext(&ctx[me], &ctx[current]); }
     };
     struct WwXlEmu {
@@ -176,8 +176,7 @@ public:
     static void fiber_entry(unsigned lo, unsigned hi, unsigned lane) {
         FiberWave* w = reinterpret_cast<FiberWave*>(((uintptr_t)hi << 32) | (uintptr_t)lo);
         WwXlEmu xl{w, lane};
-        if (w->P->small) wfa_wave<WwXlEmu, true>(*w->P, 0, lane, w->shared_small, xl);
-        else wfa_wave<WwXlEmu, false>(*w->P, 0, lane, w->shared_large, xl);
+        wfa_wave(*w->P, 0, lane, w->shared, xl);
     }
     int run_wfa_wave(const WwParams& P, uint32_t waves) override {
         if (!P.n_todo || !waves) return VGK_OK;

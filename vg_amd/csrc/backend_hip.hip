@@ -517,11 +517,10 @@ struct WwXlHip {
     }
     __device__ __forceinline__ uint32_t add32(uint32_t* p, uint32_t v) const { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 };
-template <bool SMALL>
 __global__ void __launch_bounds__(64, 3) wfa_wave_kernel(const WwParams P) {
-    __shared__ WwShared<SMALL> sh;
+    __shared__ WwSharedBoth sh;
     WwXlHip xl;
-    wfa_wave<WwXlHip, SMALL>(P, blockIdx.x, threadIdx.x, sh, xl);
+    wfa_wave(P, blockIdx.x, threadIdx.x, sh, xl);
 }
 
 // ---- pinned gssw fill with full matrices (gssw_matrix_device.hpp): one wavefront per problem, R read rows per lane; the
@@ -948,8 +947,7 @@ public:
         hipSetDevice(dev);
         if (!p.n_todo || !waves) return VGK_OK;
         hipEventRecord(bev[0], stream);
-        if (p.small) hipLaunchKernelGGL(wfa_wave_kernel<true>, dim3(waves), dim3(64), 0, stream, p);
-        else hipLaunchKernelGGL(wfa_wave_kernel<false>, dim3(waves), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(wfa_wave_kernel, dim3(waves), dim3(64), 0, stream, p);
         hipEventRecord(bev[1], stream);
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         float ms = 0.f; hipEventElapsedTime(&ms, bev[0], bev[1]);

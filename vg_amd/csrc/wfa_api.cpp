@@ -48,52 +48,42 @@ int carve(vgk_ctx* ctx, WfaHost& H, int slot, const WaveSlabs& z, WwParams& W) {
     W.edit_runs = (uint32_t*)(base + b_slots + b_paths + b_logs);
     return VGK_OK;
 }
-// every problem with small tables; what outgrows them once more with large ones
+// one launch: every problem starts with the small tables in LDS; a wavefront runs what outgrows them again at once with its large slab
 int launch_wave_form(vgk_ctx* ctx) {
     Backend* be = ctx->be.get();
-    WwParams& A = ctx->wfa_wave_last[0]; WwParams& B = ctx->wfa_wave_last[1];
+    WwParams& A = ctx->wfa_wave_last[0];
     int rc;
     be->reset_wfa_ms();
     if ((rc = be->zero(A.n_declined, 16))) return rc;
     if ((rc = be->run_wfa_wave(A, ctx->wfa_wave_waves[0]))) return rc;
     ctx->wfa_wave_ms[0] = be->last_ms(6); ctx->wfa_wave_ms[1] = 0;
-    unsigned long long declined = 0;
-    if ((rc = be->download(&declined, A.n_declined, sizeof declined))) return rc;
-    ctx->wfa_wave_retried = declined;
-    if (declined) {
-        B.n_todo = (uint32_t)declined;
-        if ((rc = be->zero(B.base.counters + 2, 8))) return rc;                  // the hand-out counter starts over; paths / edits go on behind the first launch's
-        if ((rc = be->run_wfa_wave(B, (uint32_t)std::min<uint64_t>(declined, ctx->wfa_wave_waves[1])))) return rc;
-        ctx->wfa_wave_ms[1] = be->last_ms(6) - ctx->wfa_wave_ms[0];
-    }
+    unsigned long long taken_over = 0;
+    if ((rc = be->download(&taken_over, A.n_declined, sizeof taken_over))) return rc;
+    ctx->wfa_wave_retried = taken_over;
     ctx->wfa_ms = be->last_ms(6);
     return VGK_OK;
 }
 int run_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P) {
     Backend* be = ctx->be.get();
     const uint32_t cus = (uint32_t)std::max(1, be->compute_units());
-    uint32_t per_cu[2] = {12, 8};
-    if (const char* e = std::getenv("VGAMD_WFA_WAVES_PER_CU")) per_cu[0] = (uint32_t)std::max(1, std::atoi(e));
+    uint32_t per_cu = 12;                                                        // 13 KB of LDS and 168 VGPRs per wavefront
+    if (const char* e = std::getenv("VGAMD_WFA_WAVES_PER_CU")) per_cu = (uint32_t)std::max(1, std::atoi(e));
     // the small size keeps its tables in LDS (256 points cover all but a percent or two of giraffe's links; the median is a dozen); the
     // large size: what a link with a 60-base insertion under the default error model stores, several times over
-    const uint32_t waves_small = std::min<uint32_t>(P.n, cus * per_cu[0]);
-    WaveSlabs zb{cus * per_cu[1], 32768u, 16384u, 2048u};
-    WwParams A{}, B{};
-    A.base = P; B.base = P; A.small = 1; B.small = 0;
+    WaveSlabs z{std::min<uint32_t>(P.n, cus * per_cu), 32768u, 16384u, 2048u};
+    WwParams A{};
+    A.base = P;
     // a caller's point budget below the tables' own sizes ends a problem as before (vgk_wfa_set_point_budgets); 0 = none
-    A.base.max_points = B.base.max_points = ctx->wfa_point_budget ? ctx->wfa_point_budget : 0xffffffffu;
-    A.base.max_points_tail = B.base.max_points_tail = ctx->wfa_point_budget_tail ? ctx->wfa_point_budget_tail : 0xffffffffu;
-    if (const char* e = std::getenv("VGAMD_WFA_SMALL_POINTS")) {               // (tests: a smaller first size, so that more problems take the second)
-        A.small_points = (uint32_t)std::max(16, std::atoi(e));
-    }
+    A.base.max_points = ctx->wfa_point_budget ? ctx->wfa_point_budget : 0xffffffffu;
+    A.base.max_points_tail = ctx->wfa_point_budget_tail ? ctx->wfa_point_budget_tail : 0xffffffffu;
+    if (const char* e = std::getenv("VGAMD_WFA_SMALL_POINTS")) A.small_points = (uint32_t)std::max(16, std::atoi(e));     // (tests: more problems for the large size)
     int rc;
-    if ((rc = carve(ctx, H, 62, zb, B))) return rc;
-    char* extra = (char*)ctx->ensure_scratch(63, sizeof(uint32_t) * ((size_t)P.n + 8) + 16);
+    if ((rc = carve(ctx, H, 62, z, A))) return rc;
+    char* extra = (char*)ctx->ensure_scratch(63, 64);
     if (!extra) return VGK_ENOMEM;
     A.todo = P.order; A.n_todo = P.n;
-    A.n_declined = (unsigned long long*)extra; A.declined = (uint32_t*)(extra + 16);
-    B.todo = A.declined; B.n_todo = 0; B.declined = nullptr; B.n_declined = nullptr;
-    ctx->wfa_wave_last[0] = A; ctx->wfa_wave_last[1] = B; ctx->wfa_wave_waves[0] = waves_small; ctx->wfa_wave_waves[1] = zb.waves;
+    A.n_declined = (unsigned long long*)extra;
+    ctx->wfa_wave_last[0] = A; ctx->wfa_wave_waves[0] = z.waves;
     if ((rc = launch_wave_form(ctx))) return rc;
     ctx->wfa_wave_last_valid = true; ctx->wfa_last_valid = false;
     return VGK_OK;
@@ -318,7 +308,7 @@ int vgk_wfa_rerun(vgk_ctx* ctx) {
 }
 
 double vgk_wfa_last_ms(vgk_ctx* ctx) { return ctx ? ctx->wfa_ms : 0.0; }
-// the wavefront form's two launches: 0 = ms of the small-table launch, 1 = ms of the large-table launch, 2 = problems the second one took
+// the wavefront form: 0 = ms of the launch, 1 = 0 (the two sizes share one launch), 2 = problems the large size took over
 double vgk_wfa_last_wave(vgk_ctx* ctx, int which) { return !ctx ? 0.0 : which == 0 ? ctx->wfa_wave_ms[0] : which == 1 ? ctx->wfa_wave_ms[1] : (double)ctx->wfa_wave_retried; }
 int vgk_wfa_set_point_budget(vgk_ctx* ctx, uint32_t points) { return vgk_wfa_set_point_budgets(ctx, points, points); }
 int vgk_wfa_set_point_budgets(vgk_ctx* ctx, uint32_t connect_points, uint32_t tail_points) {

@@ -53,14 +53,13 @@ struct WwPath { int32_t node; uint32_t seq_off; uint16_t start, len, next, pad; 
 struct WwParams {
     WfaParams base;                   // index, problems, sequences, scoring, outputs, counters[2] = next problem to hand out
     const uint32_t* todo; uint32_t n_todo;      // the problems of this launch, in hand-out order
-    uint32_t small;                   // which size of the kernel this launch is
     uint32_t small_points;            // the small size's own point limit when below WW_SMALL_POINTS (0 = that; a test hook: more problems for the large size)
     // the large size: per resident wavefront ...
     unsigned long long* slots; uint32_t n_slots;   // ... n_slots (a power of two) table slots ...
     uint32_t* logs; uint32_t max_points;            // ... max_points log entries (= points a problem may store) ...
     WwPath* paths; uint32_t path_cap;               // ... path_cap pool entries ...
     uint32_t* edit_runs;                            // ... and W_EDITS edit runs for the backtrace
-    uint32_t* declined; unsigned long long* n_declined;   // problems that outgrew this launch's tables (nullable: they are reported VGK_ETOOBIG)
+    unsigned long long* n_declined;   // counts the problems the large size took over (nullable)
 };
 
 template <bool SMALL> struct WwTables {};
@@ -536,12 +535,13 @@ template <class XL, bool SMALL> VGK_HD void ww_append_edit(WwCtx<XL, SMALL>& c, 
 }
 
 // One problem on one wavefront.  `slab` = this wavefront's number among the resident ones.
-template <class XL, bool SMALL> VGK_HD void wfa_wave_problem(const WwParams& P, uint32_t i, uint32_t slab, uint32_t lane, WwShared<SMALL>& sh, XL& xl) {
+// -> true: the problem outgrew the small size's tables and the large size is to take it over (never from the large size itself)
+template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, uint32_t i, uint32_t slab, uint32_t lane, WwShared<SMALL>& sh, XL& xl) {
     const WfaParams& B = P.base;
     const WProb pb = B.probs[i];
     vgk_wfa_result out; out.status = pb.status; out.ok = 0; out.score = 0; out.node_offset = 0; out.seq_offset = 0; out.length = 0;
     out.path_begin = 0; out.path_len = 0; out.edit_begin = 0; out.n_edits = 0;
-    if (pb.status != VGK_OK || pb.from_node >= B.index.n_oriented) { if (lane == 0) B.results[i] = out; xl.fence(); return; }
+    if (pb.status != VGK_OK || pb.from_node >= B.index.n_oriented) { if (lane == 0) B.results[i] = out; xl.fence(); return false; }
     WwCtx<XL, SMALL> c;
     c.P = &P; c.sh = &sh; c.xl = &xl; c.lane = lane;
     uint32_t own_points;                                                      // this launch's own limit (a caller's budget may lie below it)
@@ -709,32 +709,42 @@ template <class XL, bool SMALL> VGK_HD void wfa_wave_problem(const WwParams& P, 
         } else if (c.overflow) failed = true;                                  // (the backtrace's edit runs: reported like any table that ran out)
     }
     failed = xl.ballot(failed) != 0ull;
+    // tables of the small size were not enough: the large size takes the problem over — unless it was the caller's own point budget that
+    // ran out —; what outgrows the large size is declined
+    bool retry = false;
     if (lane == 0) {
         if (failed) {
-            // tables of this launch's size were not enough: the large-table launch takes the problem — unless it was the caller's own
-            // point budget that ran out — or it is declined
-            const bool retry = P.declined && ((c.why == 1 && c.max_points == own_points) || c.why == 3 || c.why == 7);
-            if (retry) P.declined[g_bump(P.n_declined, 1)] = i;
+            retry = SMALL && ((c.why == 1 && c.max_points == own_points) || c.why == 3 || c.why == 7);
+            if (retry && P.n_declined) g_bump(P.n_declined, 1);
             out.status = VGK_ETOOBIG; out.ok = 0; out.score = c.why; out.node_offset = 0; out.length = 0;
         }
-        B.results[i] = out;
+        if (!retry) B.results[i] = out;
     }
+    retry = xl.bcast(retry ? 1u : 0u, 0) != 0u;
     // leave the table all-zero: the touched slots from the log, or everything when the log ran over
     xl.fence();
     if (sh.n_points > c.max_points) { for (uint32_t k = lane; k <= c.mask; k += 64) *c.tbl(k) = 0; }
     else for (uint32_t k = lane; k < n_points; k += 64) *c.tbl(c.log_at(k)) = 0;
     xl.fence();
+    return retry;
 }
 
-// one resident wavefront: problems are handed out one at a time
-template <class XL, bool SMALL> VGK_HD void wfa_wave(const WwParams& P, uint32_t slab, uint32_t lane, WwShared<SMALL>& sh, XL& xl) {
-    if constexpr (SMALL) { for (uint32_t k = lane; k < (uint32_t)WW_SMALL_SLOTS; k += 64) sh.slot[k] = 0; xl.fence(); }      // (LDS comes up with whatever was there)
+// One resident wavefront: problems are handed out one at a time; each starts in the small size (everything in LDS) and, if it outgrows
+// that, is run again at once by the same wavefront in the large size (its slab in HBM).  The two sizes share the wavefront's LDS.
+union WwSharedBoth { WwShared<true> small; WwShared<false> large; };
+template <class XL> VGK_HD void wfa_wave(const WwParams& P, uint32_t slab, uint32_t lane, WwSharedBoth& sh, XL& xl) {
+    bool table_clean = false;
     for (;;) {
         uint32_t k = 0;
         if (lane == 0) k = (uint32_t)g_bump(P.base.counters + 2, 1);
         k = xl.bcast(k, 0);
         if (k >= P.n_todo) break;
-        wfa_wave_problem<XL, SMALL>(P, P.todo[k], slab, lane, sh, xl);
+        if (!table_clean) {                                                  // (LDS comes up with whatever was there; the large size used it for its own lists)
+            for (uint32_t j = lane; j < (uint32_t)WW_SMALL_SLOTS; j += 64) sh.small.slot[j] = 0;
+            xl.fence(); table_clean = true;
+        }
+        const uint32_t i = P.todo[k];
+        if (wfa_wave_problem<XL, true>(P, i, slab, lane, sh.small, xl)) { wfa_wave_problem<XL, false>(P, i, slab, lane, sh.large, xl); table_clean = false; }
     }
 }
 
