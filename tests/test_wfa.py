@@ -369,7 +369,8 @@ def test_wfa_over_run_length_encoded_records(monkeypatch):
     assert n_ok > 150
 
 
-# ---- the two forms of the kernel (one wavefront per problem — the default — and one thread per problem) and the wavefront form's two table sizes ----
+# ---- the kernels: one thread per problem, one wavefront per problem (with its two table sizes), and the default, hybrid: the thread kernel for
+# the easy majority, the wavefront kernel for what it hands over ----
 def test_thread_form_of_the_kernel_matches_the_oracle(monkeypatch):
     import subprocess
     subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
@@ -403,9 +404,28 @@ def retries_with_large_tables(lib, seeds, n_problems):
     return retried, answered
 
 
+def test_wave_form_matches_the_oracle(monkeypatch):
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    monkeypatch.setenv("VGAMD_WFA_KERNEL", "wave")
+    assert run_golden(capi.Engine(lib=capi.load_library(util.EMU_LIB))) >= 100
+    ok, statuses = compare_engines(util.EMU_LIB, range(300, 340))
+    assert ok > 1000 and statuses.get(0, 0) > 0.98 * sum(statuses.values()), (ok, statuses)
+
+
+def test_hybrid_hands_over_at_a_few_points(monkeypatch):
+    """the thread kernel gives up at 12 stored points: most problems are then answered by the wavefront kernel, all as the oracle answers them"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    monkeypatch.setenv("VGAMD_WFA_HAND_OVER_POINTS", "12")
+    handed, answered = retries_with_large_tables(util.EMU_LIB, range(540, 560), 60)
+    assert handed > 200 and answered > 1150, (handed, answered)
+
+
 def test_wave_form_runs_what_outgrows_the_small_tables_again(monkeypatch):
     import subprocess
     subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    monkeypatch.setenv("VGAMD_WFA_KERNEL", "wave")
     monkeypatch.setenv("VGAMD_WFA_SMALL_POINTS", "16")
     retried, answered = retries_with_large_tables(util.EMU_LIB, range(500, 520), 60)
     assert retried > 150 and answered > 1150, (retried, answered)
@@ -416,16 +436,16 @@ def budgets_decline_the_same_problems(lib, monkeypatch, seeds=range(600, 612), n
     for s in seeds:
         nodes, threads, problems = random_wfa_case(np.random.default_rng(s), n_problems)
         out = []
-        for form in ("wave", "thread"):
+        for form in ("wave", "thread", "hybrid"):
             monkeypatch.setenv("VGAMD_WFA_KERNEL", form)
             eng = capi.Engine(lib=lib) if lib else capi.Engine()
             eng.wfa_set_point_budget(24)
             out.append(eng.wfa_extend(eng.haplo_index(nodes, threads), problems, MODELS[s % len(MODELS)]))
-        a, b = out
-        assert (a[0]["status"] == b[0]["status"]).all(), s
+        a, b, c = out
+        assert (a[0]["status"] == b[0]["status"]).all() and (a[0]["status"] == c[0]["status"]).all(), s
         assert (a[0]["status"] == -7).any()
         for i in np.nonzero(a[0]["status"] == 0)[0]:
-            assert unpack(*a, i) == unpack(*b, i), (s, i)
+            assert unpack(*a, i) == unpack(*b, i) == unpack(*c, i), (s, i)
 
 
 def test_point_budget_declines_the_same_problems_in_both_forms(monkeypatch):
@@ -441,6 +461,11 @@ def test_both_forms_and_both_table_sizes_on_the_gpu(monkeypatch):
     ok, statuses = compare_engines(None, range(440, 460), n_problems=400)
     assert ok > 3500
     monkeypatch.setenv("VGAMD_WFA_KERNEL", "wave")
+    ok, statuses = compare_engines(None, range(460, 480), n_problems=400)
+    assert ok > 3500
     monkeypatch.setenv("VGAMD_WFA_SMALL_POINTS", "16")
     retried, answered = retries_with_large_tables(None, range(800, 820), 400)
     assert retried > 1000 and answered > 7800, (retried, answered)
+    monkeypatch.delenv("VGAMD_WFA_SMALL_POINTS"); monkeypatch.setenv("VGAMD_WFA_KERNEL", "hybrid"); monkeypatch.setenv("VGAMD_WFA_HAND_OVER_POINTS", "12")
+    handed, answered = retries_with_large_tables(None, range(840, 860), 400)
+    assert handed > 1200 and answered > 7800, (handed, answered)

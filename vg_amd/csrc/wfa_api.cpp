@@ -58,19 +58,20 @@ int launch_wave_form(vgk_ctx* ctx) {
     if ((rc = be->run_wfa_wave(A, ctx->wfa_wave_waves[0]))) return rc;
     ctx->wfa_wave_ms[0] = be->last_ms(6); ctx->wfa_wave_ms[1] = 0;
     unsigned long long taken_over = 0;
-    if ((rc = be->download(&taken_over, A.n_declined, sizeof taken_over))) return rc;
-    ctx->wfa_wave_retried = taken_over;
+    if ((rc = be->download(&taken_over, A.n_todo_dev ? A.n_todo_dev : A.n_declined, sizeof taken_over))) return rc;
+    ctx->wfa_wave_retried = taken_over;                                           // hybrid: what the thread kernel handed over; else: what outgrew the small tables
     ctx->wfa_ms = be->last_ms(6);
     return VGK_OK;
 }
-int run_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P) {
+// after_threads: the problems are the thread kernel's hand-over list (its length is on the device only)
+int run_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P, bool after_threads) {
     Backend* be = ctx->be.get();
     const uint32_t cus = (uint32_t)std::max(1, be->compute_units());
     uint32_t per_cu = 12;                                                        // 13 KB of LDS and 168 VGPRs per wavefront
     if (const char* e = std::getenv("VGAMD_WFA_WAVES_PER_CU")) per_cu = (uint32_t)std::max(1, std::atoi(e));
     // the small size keeps its tables in LDS (256 points cover all but a percent or two of giraffe's links; the median is a dozen); the
     // large size: what a link with a 60-base insertion under the default error model stores, several times over
-    WaveSlabs z{std::min<uint32_t>(P.n, cus * per_cu), 32768u, 16384u, 2048u};
+    WaveSlabs z{after_threads ? cus * per_cu : std::min<uint32_t>(P.n, cus * per_cu), 32768u, 16384u, 2048u};
     WwParams A{};
     A.base = P;
     // a caller's point budget below the tables' own sizes ends a problem as before (vgk_wfa_set_point_budgets); 0 = none
@@ -81,7 +82,8 @@ int run_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P) {
     if ((rc = carve(ctx, H, 62, z, A))) return rc;
     char* extra = (char*)ctx->ensure_scratch(63, 64);
     if (!extra) return VGK_ENOMEM;
-    A.todo = P.order; A.n_todo = P.n;
+    A.todo = P.order; A.n_todo = P.n; A.n_todo_dev = nullptr;
+    if (after_threads) { A.todo = P.handed_over; A.n_todo = P.n; A.n_todo_dev = P.n_handed_over; A.base.handed_over = nullptr; }
     A.n_declined = (unsigned long long*)extra;
     ctx->wfa_wave_last[0] = A; ctx->wfa_wave_waves[0] = z.waves;
     if ((rc = launch_wave_form(ctx))) return rc;
@@ -232,11 +234,14 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     P.max_points_tail = ctx->wfa_point_budget_tail && ctx->wfa_point_budget_tail < (uint32_t)W_POINTS ? ctx->wfa_point_budget_tail : (uint32_t)W_POINTS;
     // Two kernels answer the same problems with the same results: one WAVEFRONT per problem, the lanes being the diagonals
     // (wfa_wave_device.hpp; the default), and one THREAD per problem (wfa_device.hpp; VGAMD_WFA_KERNEL=thread).
-    bool wave_form = true;
-    if (const char* e = std::getenv("VGAMD_WFA_KERNEL")) wave_form = std::strcmp(e, "thread") != 0;
+    // and the default is both (hybrid): the thread kernel, which works on 64 problems per instruction, for the easy majority — it gives a
+    // problem up at 128 stored points — and the wavefront kernel for what it hands over.
+    bool wave_form = false, hybrid = true;
+    if (const char* e = std::getenv("VGAMD_WFA_KERNEL")) { wave_form = std::strcmp(e, "wave") == 0; hybrid = std::strcmp(e, "hybrid") == 0; }
     uint64_t per_cu = 1024;         // 16 wavefronts per CU: the kernel is built for at most 128 VGPRs (__launch_bounds__(64, 4))
     if (const char* e = std::getenv("VGAMD_WFA_THREADS_PER_CU")) per_cu = (uint64_t)std::max(64, std::atoi(e));
     const uint32_t threads = wave_form ? 1u : (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max(1, be->compute_units()) * per_cu);
+    P.hand_over_points = 0; P.handed_over = nullptr; P.n_handed_over = nullptr;
     if (wave_form) P.scratch = reinterpret_cast<WScratch*>(ctx->ensure_scratch(32, 64));
     else
     { const uint64_t want = sizeof(WScratch) * (uint64_t)threads;
@@ -255,7 +260,23 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     int rc;
     if ((rc = be->zero(P.counters, 64))) return rc;
     if (wave_form) {
-        if ((rc = run_wave_form(ctx, H, P))) return rc;
+        if ((rc = run_wave_form(ctx, H, P, false))) return rc;
+    } else if (hybrid) {
+        uint32_t hand_over = 128;
+        if (const char* e = std::getenv("VGAMD_WFA_HAND_OVER_POINTS")) hand_over = (uint32_t)std::max(8, std::atoi(e));
+        char* extra = (char*)ctx->ensure_scratch(61, sizeof(uint32_t) * ((size_t)n + 8) + 16);
+        if (!extra) return VGK_ENOMEM;
+        P.hand_over_points = hand_over; P.n_handed_over = (unsigned long long*)extra; P.handed_over = (uint32_t*)(extra + 16);
+        if ((rc = be->zero(P.n_handed_over, 16))) return rc;
+        be->reset_wfa_ms();
+        if ((rc = be->run_wfa(P, threads))) return rc;
+        ctx->wfa_last = P; ctx->wfa_last_threads = threads;
+        const double ms_threads = be->last_ms(6);
+        if ((rc = be->zero(P.counters + 2, 8))) return rc;                       // the hand-out counter starts over; paths / edits go on behind the first launch's
+        if ((rc = run_wave_form(ctx, H, P, true))) return rc;
+        ctx->wfa_wave_ms[1] = ctx->wfa_wave_ms[0]; ctx->wfa_wave_ms[0] = ms_threads;
+        ctx->wfa_ms = ms_threads + ctx->wfa_wave_ms[1];
+        ctx->wfa_last_valid = true;                                                // (vgk_wfa_rerun: both launches again)
     } else {
         if ((rc = be->run_wfa(P, threads))) return rc;
         ctx->wfa_last = P; ctx->wfa_last_threads = threads; ctx->wfa_last_valid = true; ctx->wfa_wave_last_valid = false;
@@ -295,6 +316,18 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
 int vgk_wfa_rerun(vgk_ctx* ctx) {
     if (!ctx) return VGK_EINVAL;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->wfa_wave_last_valid && ctx->wfa_last_valid) {                         // hybrid: the thread kernel, then the wavefront kernel on what it hands over
+        Backend* be = ctx->be.get();
+        int rc;
+        if ((rc = be->zero(ctx->wfa_last.counters, 64)) || (rc = be->zero(ctx->wfa_last.n_handed_over, 16))) return rc;
+        be->reset_wfa_ms();
+        if ((rc = be->run_wfa(ctx->wfa_last, ctx->wfa_last_threads))) return rc;
+        const double ms_threads = be->last_ms(6);
+        if ((rc = be->zero(ctx->wfa_last.counters + 2, 8))) return rc;
+        if ((rc = launch_wave_form(ctx))) return rc;
+        ctx->wfa_wave_ms[1] = ctx->wfa_wave_ms[0]; ctx->wfa_wave_ms[0] = ms_threads; ctx->wfa_ms = ms_threads + ctx->wfa_wave_ms[1];
+        return VGK_OK;
+    }
     if (ctx->wfa_wave_last_valid) {
         if (int rc = ctx->be->zero(ctx->wfa_wave_last[0].base.counters, 64)) return rc;
         return launch_wave_form(ctx);
@@ -308,7 +341,8 @@ int vgk_wfa_rerun(vgk_ctx* ctx) {
 }
 
 double vgk_wfa_last_ms(vgk_ctx* ctx) { return ctx ? ctx->wfa_ms : 0.0; }
-// the wavefront form: 0 = ms of the launch, 1 = 0 (the two sizes share one launch), 2 = problems the large size took over
+// 0 = ms of the first launch (hybrid: the thread kernel; wave form: the only one), 1 = ms of the wavefront kernel behind the thread kernel (hybrid),
+// 2 = problems the thread kernel handed over (hybrid) / that outgrew the small tables (wave form)
 double vgk_wfa_last_wave(vgk_ctx* ctx, int which) { return !ctx ? 0.0 : which == 0 ? ctx->wfa_wave_ms[0] : which == 1 ? ctx->wfa_wave_ms[1] : (double)ctx->wfa_wave_retried; }
 int vgk_wfa_set_point_budget(vgk_ctx* ctx, uint32_t points) { return vgk_wfa_set_point_budgets(ctx, points, points); }
 int vgk_wfa_set_point_budgets(vgk_ctx* ctx, uint32_t connect_points, uint32_t tail_points) {

@@ -89,6 +89,9 @@ struct WfaParams {
     unsigned long long caps[2];
     uint32_t max_points;              // stored wavefront points after which a connect is given up (<= W_POINTS; vgk_wfa_set_point_budget) ...
     uint32_t max_points_tail;         // ... and a prefix / suffix (vgk_wfa_set_point_budgets; a declined tail has no banded fallback between two anchors)
+    // hybrid form: the thread kernel gives a problem up at `hand_over_points` stored points (when the caller's own budget lies above that)
+    // and lists it for the wavefront kernel (wfa_wave_device.hpp) instead of reporting it
+    uint32_t hand_over_points; uint32_t* handed_over; unsigned long long* n_handed_over;
 };
 
 struct WPos { uint32_t seq, off; uint8_t cur, origin; bool empty; };
@@ -509,6 +512,8 @@ VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S, uint32_t
     c.no_to = pb.to_node == VGK_WFA_NO_NODE; c.to_node = (int32_t)pb.to_node; c.to_off = pb.to_off;
     c.n_nodes = 0; c.n_path = 0; c.n_points = 0; c.leaves = 0; c.overflow = false; c.why = 0;
     c.max_points = c.no_to ? P.max_points_tail : P.max_points;
+    const bool hands_over = P.handed_over && P.hand_over_points < c.max_points;
+    if (hands_over) c.max_points = P.hand_over_points;
     c.cand_score = 0x7fffffff; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0;
     c.max_distance = 0; c.min_distance = 0;
     const int32_t top_score = pb.score_bound + P.gap_open + P.gap_extend + P.mismatch;               // the host keeps this below W_SCORES
@@ -629,6 +634,7 @@ VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S, uint32_t
         }
     } else if (c.overflow) { out.status = VGK_ETOOBIG; out.score = c.why; }
     for (uint32_t k = 0; k < c.n_points; ++k) S.slot[S.log[k]] = 0;                                  // leave the table clean
+    if (c.overflow && c.why == 1 && hands_over) { P.handed_over[g_bump(P.n_handed_over, 1)] = i; return; }     // the wavefront kernel answers this one
     P.results[i] = out;
 }
 // one resident thread: problems are handed out one at a time.  `end` = W_NODES words for this thread's node ends, `end_stride`

@@ -53,6 +53,7 @@ struct WwPath { int32_t node; uint32_t seq_off; uint16_t start, len, next, pad; 
 struct WwParams {
     WfaParams base;                   // index, problems, sequences, scoring, outputs, counters[2] = next problem to hand out
     const uint32_t* todo; uint32_t n_todo;      // the problems of this launch, in hand-out order
+    const unsigned long long* n_todo_dev;        // their number when only the device knows it (the thread kernel's hand-over list); else null
     uint32_t small_points;            // the small size's own point limit when below WW_SMALL_POINTS (0 = that; a test hook: more problems for the large size)
     // the large size: per resident wavefront ...
     unsigned long long* slots; uint32_t n_slots;   // ... n_slots (a power of two) table slots ...
@@ -734,11 +735,12 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
 union WwSharedBoth { WwShared<true> small; WwShared<false> large; };
 template <class XL> VGK_HD void wfa_wave(const WwParams& P, uint32_t slab, uint32_t lane, WwSharedBoth& sh, XL& xl) {
     bool table_clean = false;
+    const uint32_t n_todo = P.n_todo_dev ? (uint32_t)*P.n_todo_dev : P.n_todo;
     for (;;) {
         uint32_t k = 0;
         if (lane == 0) k = (uint32_t)g_bump(P.base.counters + 2, 1);
         k = xl.bcast(k, 0);
-        if (k >= P.n_todo) break;
+        if (k >= n_todo) break;
         if (!table_clean) {                                                  // (LDS comes up with whatever was there; the large size used it for its own lists)
             for (uint32_t j = lane; j < (uint32_t)WW_SMALL_SLOTS; j += 64) sh.small.slot[j] = 0;
             xl.fence(); table_clean = true;
