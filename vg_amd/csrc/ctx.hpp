@@ -64,7 +64,7 @@ struct vgk_ctx {
     double wfa_wave_ms[2] = {0, 0}; uint64_t wfa_wave_retried = 0;
     // device scratch kept between vgk_banded_align calls (grow-only; released with the context)
     struct DevBuf { void* p = nullptr; uint64_t bytes = 0; };
-    DevBuf scratch[64];            // 0..14 + 31 banded_api.cpp, 15..30 + 59, 60 gapless_api.cpp, 32..39 + 61..63 wfa_api.cpp, 40..47 gssw_multi_api.cpp / xdrop_band_api.cpp (+ 48, 49), 50..54 tail_api.cpp, 55..58 minimizer_api.cpp
+    DevBuf scratch[72];            // 0..14 + 31 banded_api.cpp, 15..30 + 59, 60 gapless_api.cpp, 32..39 + 61..63 wfa_api.cpp, 40..47 gssw_multi_api.cpp / xdrop_band_api.cpp (+ 48, 49), 50..54 tail_api.cpp, 55..58 minimizer_api.cpp
     void* ensure_scratch(int slot, uint64_t bytes) {
         DevBuf& b = scratch[slot];
         if (b.p && b.bytes >= bytes) return b.p;

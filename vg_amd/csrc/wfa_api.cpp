@@ -5,6 +5,7 @@
 // score cap and distance band per sequence length (:1631-1634, :2077; gbwt_extender.hpp:371-373), upload, launch one
 // thread per problem over zero-initialised per-thread slabs, download, and hand paths / edits back in problem order.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -60,6 +61,20 @@ int launch_wave_form(vgk_ctx* ctx) {
     unsigned long long taken_over = 0;
     if ((rc = be->download(&taken_over, A.n_todo_dev ? A.n_todo_dev : A.n_declined, sizeof taken_over))) return rc;
     ctx->wfa_wave_retried = taken_over;                                           // hybrid: what the thread kernel handed over; else: what outgrew the small tables
+    if (A.stats) {
+        std::vector<uint32_t> st(4 * (size_t)A.base.n);
+        if (!be->download(st.data(), A.stats, sizeof(uint32_t) * st.size())) {
+            std::vector<uint32_t> idx;
+            for (uint32_t i = 0; i < A.base.n; ++i) if (st[4 * i + 2]) idx.push_back(i);
+            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return st[4 * a + 2] > st[4 * b + 2]; });
+            unsigned long long chunks = 0, points = 0, steps = 0;
+            for (uint32_t i : idx) { chunks += st[4 * i + 2]; points += st[4 * i]; steps += st[4 * i + 1]; }
+            std::fprintf(stderr, "[wfa wave] %zu problems: %llu chunks, %llu points, %llu steps in all; heaviest (points, steps, chunks, trie nodes):", idx.size(), chunks, points, steps);
+            for (size_t k = 0; k < idx.size() && k < 8; ++k) std::fprintf(stderr, " (%u,%u,%u,%u)", st[4 * idx[k]], st[4 * idx[k] + 1], st[4 * idx[k] + 2], st[4 * idx[k] + 3]);
+            for (size_t q : {idx.size() / 100, idx.size() / 10, idx.size() / 2}) if (q < idx.size()) std::fprintf(stderr, " | rank %zu: (%u,%u,%u,%u)", q, st[4 * idx[q]], st[4 * idx[q] + 1], st[4 * idx[q] + 2], st[4 * idx[q] + 3]);
+            std::fprintf(stderr, "\n");
+        }
+    }
     ctx->wfa_ms = be->last_ms(6);
     return VGK_OK;
 }
@@ -85,6 +100,11 @@ int run_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P, bool after_threa
     A.todo = P.order; A.n_todo = P.n; A.n_todo_dev = nullptr;
     if (after_threads) { A.todo = P.handed_over; A.n_todo = P.n; A.n_todo_dev = P.n_handed_over; A.base.handed_over = nullptr; }
     A.n_declined = (unsigned long long*)extra;
+    A.stats = nullptr;
+    if (std::getenv("VGAMD_WFA_STATS")) {                                        // per-problem statistics, printed by the call (a debugging aid)
+        A.stats = (uint32_t*)ctx->ensure_scratch(64, sizeof(uint32_t) * 4 * ((size_t)P.n + 1));
+        if (!A.stats || be->zero(A.stats, sizeof(uint32_t) * 4 * ((size_t)P.n + 1))) return VGK_ENOMEM;
+    }
     ctx->wfa_wave_last[0] = A; ctx->wfa_wave_waves[0] = z.waves;
     if ((rc = launch_wave_form(ctx))) return rc;
     ctx->wfa_wave_last_valid = true; ctx->wfa_last_valid = false;
