@@ -36,6 +36,7 @@ struct vgk_ctx {
     double gapless_ms = 0;         // kernel time of the last vgk_gapless_extend call
     uint64_t gapless_retried = 0;  // reads of that call whose search outgrew the fast kernel's LDS store and ran in the slab kernel
     double wfa_ms = 0;             // and of the last vgk_wfa_extend call
+    int wfa_form = 0;              // vgk_wfa_set_form
     uint32_t wfa_point_budget = 0, wfa_point_budget_tail = 0; // vgk_wfa_set_point_budget(s): connects | prefixes and suffixes (0 = the table's size)
     int8_t banded_mat_rows[72] = {0};   // the 5 x 5 table + its rows as 64-bit words, as the banded fill kernel reads them (banded_device.hpp BMAT_ROWS_AT)
     // what the last vgk_minimizer_seeds call left in HBM: the (masked) reads behind 8 bytes of padding, their offsets, the seeds per read —

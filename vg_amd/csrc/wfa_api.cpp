@@ -256,7 +256,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     // (wfa_wave_device.hpp; the default), and one THREAD per problem (wfa_device.hpp; VGAMD_WFA_KERNEL=thread).
     // and the default is both (hybrid): the thread kernel, which works on 64 problems per instruction, for the easy majority — it gives a
     // problem up at 128 stored points — and the wavefront kernel for what it hands over.
-    bool wave_form = false, hybrid = true;
+    bool wave_form = ctx->wfa_form == VGK_WFA_FORM_WAVE, hybrid = ctx->wfa_form == VGK_WFA_FORM_HYBRID;       // vgk_wfa_set_form; the environment overrides (tests)
     if (const char* e = std::getenv("VGAMD_WFA_KERNEL")) { wave_form = std::strcmp(e, "wave") == 0; hybrid = std::strcmp(e, "hybrid") == 0; }
     uint64_t per_cu = 1024;         // 16 wavefronts per CU: the kernel is built for at most 128 VGPRs (__launch_bounds__(64, 4))
     if (const char* e = std::getenv("VGAMD_WFA_THREADS_PER_CU")) per_cu = (uint64_t)std::max(64, std::atoi(e));
@@ -364,6 +364,11 @@ double vgk_wfa_last_ms(vgk_ctx* ctx) { return ctx ? ctx->wfa_ms : 0.0; }
 // 0 = ms of the first launch (hybrid: the thread kernel; wave form: the only one), 1 = ms of the wavefront kernel behind the thread kernel (hybrid),
 // 2 = problems the thread kernel handed over (hybrid) / that outgrew the small tables (wave form)
 double vgk_wfa_last_wave(vgk_ctx* ctx, int which) { return !ctx ? 0.0 : which == 0 ? ctx->wfa_wave_ms[0] : which == 1 ? ctx->wfa_wave_ms[1] : (double)ctx->wfa_wave_retried; }
+int vgk_wfa_set_form(vgk_ctx* ctx, int form) {
+    if (!ctx || form < VGK_WFA_FORM_HYBRID || form > VGK_WFA_FORM_WAVE) return VGK_EINVAL;
+    std::lock_guard<std::mutex> lock(ctx->mu); ctx->wfa_form = form;
+    return VGK_OK;
+}
 int vgk_wfa_set_point_budget(vgk_ctx* ctx, uint32_t points) { return vgk_wfa_set_point_budgets(ctx, points, points); }
 int vgk_wfa_set_point_budgets(vgk_ctx* ctx, uint32_t connect_points, uint32_t tail_points) {
     if (!ctx) return VGK_EINVAL;

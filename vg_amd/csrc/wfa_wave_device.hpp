@@ -134,50 +134,16 @@ template <class XL, bool SMALL> VGK_HD bool ww_lookup(WwCtx<XL, SMALL>& c, uint3
     node = best;
     return found;
 }
-// The same lookup in two halves, so that an item's lookups travel together instead of one after the other: ww_probe issues the loads of
-// the first four slots of a cell's probe sequence (they are neighbours; most sequences end inside them), ww_resolve looks at what came
-// back and only walks on when none of the four was free.
-struct WwProbe { unsigned long long s[4]; uint32_t at; bool live; };
-template <class XL, bool SMALL> VGK_HD WwProbe ww_probe(WwCtx<XL, SMALL>& c, const WSrc& src, int kind, int32_t diag) {
-    WwProbe p; p.live = diag >= src.lo && diag <= src.hi; p.at = 0;
-    p.s[0] = p.s[1] = p.s[2] = p.s[3] = 0;
-    if (p.live) {
-        p.at = ww_hash(c, w_key(0, kind, src.score, diag));
-        for (uint32_t k = 0; k < 4; ++k) p.s[k] = c.xl->load64(c.tbl((p.at + k) & c.mask));
-    }
-    return p;
-}
-template <class XL, bool SMALL> VGK_HD WPos ww_resolve(WwCtx<XL, SMALL>& c, const WwProbe& p, int kind, const WSrc& src, uint32_t ancestors, uint32_t origin, int32_t diag,
-                                                       bool ext_seq, bool ext_graph) {
-    if (!p.live) return w_none();
-    const uint32_t cell = (w_key(0, kind, src.score, diag) - 1u) >> 5;
-    bool found = false, ended = false; uint32_t best = 0, seq = 0, off = 0;
-    auto look = [&](unsigned long long s) {
-        if (!s) { ended = true; return; }
-        const uint32_t key = (uint32_t)(s >> 32) - 1u, holder = key & 31u;
-        if ((key >> 5) == cell && ((ancestors >> holder) & 1u) && (!found || holder > best)) { found = true; best = holder; seq = (uint32_t)(s >> 16) & 0xffffu; off = (uint32_t)s & 0xffffu; }
-    };
-    for (uint32_t k = 0; k < 4 && !ended; ++k) look(p.s[k]);
-    uint32_t probes = 4;
-    for (uint32_t i = (p.at + 4) & c.mask; !ended; i = (i + 1) & c.mask) {
-        if (probes++ > c.mask) { c.overflow = true; c.why = 8; break; }
-        look(c.xl->load64(c.tbl(i)));
-    }
-    if (!found) return w_none();
-    WPos r = { seq, off, (uint8_t)best, (uint8_t)origin, false };
-    if (ext_seq && r.seq >= c.L) return w_none();
-    if (ext_graph && ww_at_dead_end(c, r)) return w_none();
-    return r;
-}
 template <class XL, bool SMALL> VGK_HD void ww_store(WwCtx<XL, SMALL>& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t seq, uint32_t off) {
     const uint32_t key = w_key(node, kind, score, diag);
     const unsigned long long v = ((unsigned long long)key << 32) | ((unsigned long long)(seq & 0xffffu) << 16) | (off & 0xffffu);
     uint32_t probes = 0;
     for (uint32_t i = ww_hash(c, key);; i = (i + 1) & c.mask) {
         if (probes++ > c.mask) { c.overflow = true; c.why = 8; return; }
-        if (c.sh->n_points >= c.max_points + 64u) { c.overflow = true; c.why = 1; return; }         // (someone's table has run over already: do not pile on)
-        unsigned long long s = c.xl->cas64(c.tbl(i), 0ull, v);                 // straight for the slot: most often it is free, and a taken one answers with its content
-        {
+        unsigned long long s = c.xl->load64(c.tbl(i));
+        if (!s) {
+            if (c.sh->n_points >= c.max_points + 64u) { c.overflow = true; c.why = 1; return; }     // (someone's table has run over already: do not pile on)
+            s = c.xl->cas64(c.tbl(i), 0ull, v);
             if (!s) {                                                          // the slot is ours: a new point
                 const uint32_t at = c.xl->add32(&c.sh->n_points, 1u);
                 if (at >= c.max_points) { c.overflow = true; c.why = 1; return; }     // (the table is wiped whole after an overflow)
@@ -469,25 +435,22 @@ template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t
             diag = diag0 + (int32_t)(c.lane / n_leaves);
             leaf = ww_nth_bit(leaves, c.lane % n_leaves);
             const uint32_t anc = c.sh->nodes[leaf].ancestors;
-            // the five source cells of this item, their loads in flight together
-            const WwProbe q_io = ww_probe(c, src_open, WK_MATCH, diag - 1), q_ie = ww_probe(c, src_extend, WK_INS, diag - 1),
-                          q_do = ww_probe(c, src_open, WK_MATCH, diag + 1), q_de = ww_probe(c, src_extend, WK_DEL, diag + 1), q_s = ww_probe(c, src_mismatch, WK_MATCH, diag);
             WPos ins;
-            { const WPos open = ww_resolve(c, q_io, WK_MATCH, src_open, anc, leaf, diag - 1, true, false), ext = ww_resolve(c, q_ie, WK_INS, src_extend, anc, leaf, diag - 1, true, false);
+            { const WPos open = ww_find_in(c, WK_MATCH, src_open, anc, leaf, diag - 1, true, false), ext = ww_find_in(c, WK_INS, src_extend, anc, leaf, diag - 1, true, false);
               ins = w_less(open, ext) ? ext : open; }
             if (!ins.empty) {
                 ins.seq++;
                 if (w_distance(ins, diag) >= c.min_distance) { ww_update(c, WK_INS, score, diag, ins); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
             }
             WPos del;
-            { const WPos open = ww_resolve(c, q_do, WK_MATCH, src_open, anc, leaf, diag + 1, false, true), ext = ww_resolve(c, q_de, WK_DEL, src_extend, anc, leaf, diag + 1, false, true);
+            { const WPos open = ww_find_in(c, WK_MATCH, src_open, anc, leaf, diag + 1, false, true), ext = ww_find_in(c, WK_DEL, src_extend, anc, leaf, diag + 1, false, true);
               del = w_less(open, ext) ? ext : open; }
             if (!del.empty) {
                 ww_successor_offset(c, del);
                 if (w_distance(del, diag) >= c.min_distance) { ww_update(c, WK_DEL, score, diag, del); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
                 if (ww_wants_expansion(c, del)) want = del.cur;
             }
-            WPos subst = ww_resolve(c, q_s, WK_MATCH, src_mismatch, anc, leaf, diag, true, true);
+            WPos subst = ww_find_in(c, WK_MATCH, src_mismatch, anc, leaf, diag, true, true);
             if (!subst.empty) { subst.seq++; ww_successor_offset(c, subst); if (want == (uint32_t)W_NODES && ww_wants_expansion(c, subst)) want = subst.cur; }
             if (w_less(subst, ins)) subst = ins;
             if (w_less(subst, del)) subst = del;
@@ -558,12 +521,9 @@ template <class XL, bool SMALL> VGK_HD WPos ww_del_predecessor(WwCtx<XL, SMALL>&
     edit = VGK_WFA_MATCH; return open;
 }
 template <class XL, bool SMALL> VGK_HD WPos ww_match_predecessor(WwCtx<XL, SMALL>& c, uint32_t node, int32_t score, int32_t diag, int& edit) {
-    const WSrc s_here = ww_src(c, score), s_sub = ww_src(c, score - c.P->base.mismatch);
-    const uint32_t anc = c.sh->nodes[node].ancestors;
-    const WwProbe q_i = ww_probe(c, s_here, WK_INS, diag), q_d = ww_probe(c, s_here, WK_DEL, diag), q_m = ww_probe(c, s_sub, WK_MATCH, diag);
-    const WPos ins = ww_resolve(c, q_i, WK_INS, s_here, anc, node, diag, false, false);
-    const WPos del = ww_resolve(c, q_d, WK_DEL, s_here, anc, node, diag, false, false);
-    WPos subst = ww_resolve(c, q_m, WK_MATCH, s_sub, anc, node, diag, false, false);
+    const WPos ins = ww_find_pos(c, WK_INS, node, score, diag, false, false);
+    const WPos del = ww_find_pos(c, WK_DEL, node, score, diag, false, false);
+    WPos subst = ww_find_pos(c, WK_MATCH, node, score - c.P->base.mismatch, diag, false, false);
     if (!subst.empty) { subst.seq++; subst.off++; }
     if (w_less(ins, del)) {
         if (w_less(del, subst)) { edit = VGK_WFA_MISMATCH; return subst; }

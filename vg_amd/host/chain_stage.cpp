@@ -16,7 +16,9 @@ int run_chain_stage(const EngineApi& api, vgk_ctx* ctx, const vgk_haplo* index, 
     out.chain_score.assign(in.n_reads, 0);
     out.n_declined = out.n_between = out.n_no_graph = out.n_too_big = out.n_failed = 0;
     for (double& m : out.ms) m = 0;
-    // 1. everything through WFAExtender, one engine call
+    // 1. everything through WFAExtender, one engine call.  A read's links are long and a percent of them carry a long gap: the wavefront kernel
+    //    throughout, so that the heavy ones start at once (include/vgk.h, vgk_wfa_set_form)
+    api.wfa_set_form(ctx, in.wfa_form);
     std::vector<vgk_wfa_problem> problems(n);
     uint64_t bases = 0;
     for (uint32_t i = 0; i < n; ++i) {

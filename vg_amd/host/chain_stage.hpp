@@ -26,6 +26,7 @@ struct ChainStageInput {
     size_t max_dp_cells = SIZE_MAX;
     size_t max_tail_gap = SIZE_MAX, max_middle_gap = SIZE_MAX;          // MinimizerMapper::max_tail_gap / max_middle_gap
     unsigned threads = 0;
+    int wfa_form = VGK_WFA_FORM_WAVE;                                   // vgk_wfa_set_form for the stage's WFA call
     bool dp_for_tails = true;                                           // a declined prefix / suffix goes to pinned X-drop (:2713, :3261); false: it scores 0
 };
 struct ChainStageOutput {

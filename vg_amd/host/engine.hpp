@@ -41,6 +41,7 @@ struct EngineApi {
     decltype(&vgk_wfa_set_point_budgets) wfa_set_point_budgets = nullptr;
     decltype(&vgk_wfa_last_ms) wfa_last_ms = nullptr;
     decltype(&vgk_wfa_last_wave) wfa_last_wave = nullptr;
+    decltype(&vgk_wfa_set_form) wfa_set_form = nullptr;
     ~EngineApi();
 };
 
