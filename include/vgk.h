@@ -489,6 +489,7 @@ typedef struct vgk_wfa_result {      /* WFAAlignment (src/gbwt_extender.hpp:233-
     uint32_t path_begin, path_len;   /* oriented nodes, in the `paths` output array */
     uint32_t edit_begin, n_edits;    /* in the `edits` output array: length << 2 | VGK_WFA_* ; runs of one kind are merged */
 } vgk_wfa_result;
+/* paths = edits = NULL with path_cap = edit_cap = 0: scores only — results[] without paths and edit runs (path_len = n_edits = 0), nothing else comes down */
 int  vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_model* model /* NULL = WFAExtender::default_error_model */,
                     const vgk_wfa_problem* problems, uint32_t n, vgk_wfa_result* results,
                     uint32_t* paths, size_t path_cap, uint32_t* edits, size_t edit_cap, size_t written[2] /* paths, edits */);

@@ -308,8 +308,10 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     #pragma omp parallel for schedule(dynamic, 64)
     for (uint32_t i = 0; i < n; ++i) vgo_wfa_one(&ctx->sc, index, model, &problems[i], &results[i], &tp[i], &te[i]);
     size_t np = 0, ne = 0; int rc = VGK_OK;
+    const int scores_only = !paths && !edits && !path_cap && !edit_cap;           /* (include/vgk.h: results without paths and edit runs) */
     for (uint32_t i = 0; i < n; ++i) {
         vgk_wfa_result* r = &results[i];
+        if (scores_only) { if (r->status != VGK_OK) r->ok = 0; r->path_begin = r->path_len = r->edit_begin = r->n_edits = 0; free(tp[i]); free(te[i]); continue; }
         if (r->status == VGK_OK && (np + r->path_len > path_cap || ne + r->n_edits > edit_cap)) { r->status = VGK_EOPS; rc = VGK_EOPS; }
         r->path_begin = (uint32_t)np; r->edit_begin = (uint32_t)ne;
         if (r->status != VGK_OK) { r->ok = 0; r->path_len = r->n_edits = 0; }

@@ -307,11 +307,17 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     if (!dres) return VGK_ENOMEM;
     if ((rc = be->download(counters, P.counters, sizeof counters))) return rc;
     if ((rc = be->download(dres, P.results, sizeof(vgk_wfa_result) * n))) return rc;
-    const uint64_t np = std::min<uint64_t>(counters[0], cap_p), ne = std::min<uint64_t>(counters[1], cap_e);
+    // a caller that wants scores only (no arrays, no room) gets just the results: the paths and edit runs stay on the device
+    const bool scores_only = !paths && !edits && !path_cap && !edit_cap;
+    const uint64_t np = scores_only ? 0 : std::min<uint64_t>(counters[0], cap_p), ne = scores_only ? 0 : std::min<uint64_t>(counters[1], cap_e);
     uint32_t* dpaths = H.dpaths.get(be, np + 1); uint32_t* dedits = H.dedits.get(be, ne + 1);
     if (!dpaths || !dedits) return VGK_ENOMEM;
     if (np && (rc = be->download(dpaths, P.paths, sizeof(uint32_t) * np))) return rc;
     if (ne && (rc = be->download(dedits, P.edits, sizeof(uint32_t) * ne))) return rc;
+    if (scores_only) {
+        parallel_for(n, [&](uint32_t i, unsigned) { vgk_wfa_result r = dres[i]; if (r.status != VGK_OK) r.ok = 0; r.path_begin = r.path_len = r.edit_begin = r.n_edits = 0; results[i] = r; });
+        return VGK_OK;
+    }
     // the device packs alignments in completion order; hand them back in problem order
     std::vector<uint64_t> op(n + 1, 0), oe(n + 1, 0);
     int rc_all = VGK_OK;

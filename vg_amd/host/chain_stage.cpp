@@ -28,9 +28,9 @@ int run_chain_stage(const EngineApi& api, vgk_ctx* ctx, const vgk_haplo* index, 
         bases += p.seq_len;
     }
     std::vector<vgk_wfa_result> results(n);
-    std::vector<uint32_t> paths((size_t)n * 24 + bases / 4 + 64), edits((size_t)n * 12 + 64);
     size_t written[2] = {0, 0};
-    int rc = n ? api.wfa_extend(ctx, index, model, problems.data(), n, results.data(), paths.data(), paths.size(), edits.data(), edits.size(), written) : VGK_OK;
+    (void)bases;
+    int rc = n ? api.wfa_extend(ctx, index, model, problems.data(), n, results.data(), nullptr, 0, nullptr, 0, written) : VGK_OK;        // scores only
     if (rc != VGK_OK && rc != VGK_ETOOBIG) return rc;                         // (single declined problems are in results[].status)
     lap(0);
     // 2. the declined links as align_sequence_between requests
