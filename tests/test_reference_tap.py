@@ -186,3 +186,58 @@ def test_longest_detectable_gap_matches_the_reference_formula():
     from vg_amd import workloads
     for t in (1, 5, 40, 75, 121):
         assert workloads.longest_detectable_gap(2 * t, t, 1, 6, 1, 5) == h.vgh_longest_detectable_gap(al.ptr, 2 * t, t)
+
+
+# ---- host arithmetic the aligner interface carries: MappingQualityCalculator (GSSWAligner::mapq_calc, src/aligner.hpp:148) and the scorer's
+# score_contiguous_alignment — the reference's own unit tests, src/unittest/aligner.cpp:347-442 ----
+def test_mapping_quality_estimation_is_robust():
+    """src/unittest/aligner.cpp:371-436: the element chosen by maximum_mapping_quality_exact / _approx"""
+    import ctypes
+    from util import host
+    h = host()
+    h.vgh_maximum_mapping_quality.restype = ctypes.c_double
+    h.vgh_maximum_mapping_quality.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+    for approx in (0, 1):
+        for scores, ok in (([10.0], {0}), ([0.0], {0}), ([-10.0], {0}), ([1.0, 5.0, 2.0, 5.0, 4.0], {1, 3})):
+            idx = ctypes.c_int64(-1)
+            q = h.vgh_maximum_mapping_quality((ctypes.c_double * len(scores))(*scores), len(scores), approx, ctypes.byref(idx))
+            assert idx.value in ok and q >= 0.0, (approx, scores, idx.value, q)
+    # the approximation and the exact value agree when one score stands far above the rest: 10 / ln 10 x the gap to the runner-up
+    s = [40.0, 10.0, 3.0]
+    q = [h.vgh_maximum_mapping_quality((ctypes.c_double * 3)(*s), 3, a, None) for a in (0, 1)]
+    assert abs(q[0] - q[1]) < 0.1 and abs(q[1] - 30.0 * 10.0 / np.log(10.0)) < 1e-9
+
+
+def test_full_length_bonus_is_applied_to_both_ends_by_rescoring():
+    """src/unittest/aligner.cpp:347-369: score_contiguous_alignment of the test's alignment is 129 without a bonus, 139 with 5 at either end"""
+    import ctypes
+    from util import HostAligner, ORACLE_LIB, host
+    seq = "ACCCCGTCTCTACTAAAAATACAAAAATTAGCCGGGTGTGGTGGCATGCACCTGTAATCCCAGCTACTGGGCATGCTGAGGTAGCAGAATCGCTTGAACCCAGGAGGAACCGGTTGCAGTGAGCCGAGATTGTGCCACTCCACTCCAG"
+    # (mapping, from_length, to_length, carries a sequence) as in the test's JSON: ten all-match mappings, one pure deletion node, then
+    # deletion / match / insertion "CCG" / match, then a match
+    edits = [(0, 4, 4, 0), (1, 1, 1, 0), (2, 3, 3, 0), (3, 1, 1, 0), (4, 32, 32, 0), (5, 32, 32, 0), (6, 8, 8, 0), (7, 1, 1, 0), (8, 24, 24, 0), (9, 1, 0, 0),
+             (10, 2, 0, 0), (10, 3, 3, 0), (10, 0, 3, 1), (10, 27, 27, 0), (11, 9, 9, 0)]
+    assert sum(e[2] for e in edits) == len(seq)
+    h = host()
+    h.vgh_score_contiguous_alignment.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
+    flat = (ctypes.c_int64 * (4 * len(edits)))(*[x for e in edits for x in e])
+    assert h.vgh_score_contiguous_alignment(HostAligner(ORACLE_LIB, (1, 4, 6, 1, 0)).ptr, seq.encode(), flat, len(edits)) == 129
+    assert h.vgh_score_contiguous_alignment(HostAligner(ORACLE_LIB, (1, 4, 6, 1, 5)).ptr, seq.encode(), flat, len(edits)) == 139
+
+
+def test_aligner_carries_a_mapping_quality_calculator():
+    """GSSWAligner::mapq_calc: built from the scorer's match / mismatch and the log base recovered from the matrix (1/4 scoring at 50 % GC)"""
+    import ctypes
+    from util import HostAligner, ORACLE_LIB, host
+    h = host()
+    h.vgh_log_base.restype = ctypes.c_double; h.vgh_log_base.argtypes = [ctypes.c_void_p]
+    h.vgh_compute_mapping_quality.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    al = HostAligner(ORACLE_LIB)
+    lam = h.vgh_log_base(al.ptr)
+    assert abs(0.25 * (np.exp(lam) + 3 * np.exp(-4 * lam)) - 1.0) < 1e-9 and lam > 0          # the partition function of a log-odds matrix is 1
+    s = [150.0, 140.0]
+    exact = h.vgh_compute_mapping_quality(al.ptr, (ctypes.c_double * 2)(*s), 2, 0, 0); fast = h.vgh_compute_mapping_quality(al.ptr, (ctypes.c_double * 2)(*s), 2, 1, 0)
+    assert fast == int(10.0 / np.log(10.0) * lam * 10.0) and abs(exact - fast) <= 1
+    # a lead the doubles cannot express any more is the largest quality there is (the reference's isinf branch, mapping_quality_calculator.cpp:66)
+    s = [150.0, 100.0]
+    assert h.vgh_compute_mapping_quality(al.ptr, (ctypes.c_double * 2)(*s), 2, 0, 0) == 2**31 - 1

@@ -108,8 +108,13 @@ void GSSWAligner::ops_to_alignment(const PackedGraph& pg, const HandleGraph& seq
 }
 
 Aligner::Aligner(const int8_t* score_matrix, int8_t gap_open, int8_t gap_extension, int8_t full_length_bonus,
-                 double /*gc_content*/, std::shared_ptr<EngineApi> eng, int device)
-    : GSSWAligner(std::make_unique<MatrixAlignmentScorer>(score_matrix, gap_open, gap_extension, full_length_bonus), eng, device) {}
+                 double gc_content, std::shared_ptr<EngineApi> eng, int device)
+    : GSSWAligner(std::make_unique<MatrixAlignmentScorer>(score_matrix, gap_open, gap_extension, full_length_bonus), eng, device) {
+    double dm[16];
+    for (int i = 0; i < 16; ++i) dm[i] = score_matrix[i];
+    scorer->log_base = QualAdjAlignmentScorer::recover_log_base(dm, gc_content);
+    mapq_calc = std::make_unique<MappingQualityCalculator>((double)scorer->match, (double)scorer->mismatch, scorer->log_base);
+}
 
 Aligner::Aligner(std::unique_ptr<MatrixAlignmentScorer> owned_scorer, std::shared_ptr<EngineApi> eng, int device,
                  const QualAdjAlignmentScorer* qual_adj)
@@ -124,7 +129,9 @@ QualAdjAligner::QualAdjAligner(const int8_t* score_matrix, int8_t gap_open, int8
     : QualAdjAligner(make_qual_scorer(score_matrix, gap_open, gap_extension, full_length_bonus, gc_content).release(), eng, device) {}
 
 QualAdjAligner::QualAdjAligner(QualAdjAlignmentScorer* owned, std::shared_ptr<EngineApi> eng, int device)
-    : Aligner(std::unique_ptr<MatrixAlignmentScorer>(owned), eng, device, owned) {}
+    : Aligner(std::unique_ptr<MatrixAlignmentScorer>(owned), eng, device, owned) {
+    mapq_calc = std::make_unique<MappingQualityCalculator>((double)scorer->match, (double)scorer->mismatch, scorer->log_base);
+}
 
 // the reads of a quality-adjusted aligner must carry one quality per base (the reference asserts, src/banded_global_aligner.cpp:1981-1987)
 static const uint8_t* quality_of(bool qual_adjusted, const std::string& quality, size_t read_len) {

@@ -17,6 +17,7 @@
 #include "vg_standin/alignment.hpp"
 #include "engine.hpp"
 #include "vg_standin/handle_graph.hpp"
+#include "vg_standin/mapping_quality.hpp"
 
 namespace vgamd {
 
@@ -41,6 +42,11 @@ struct MatrixAlignmentScorer {
     MatrixAlignmentScorer(const int8_t* score_matrix_4x4, int8_t go, int8_t ge, int8_t bonus);
     // reference: src/alignment_scorer.cpp:264-271
     size_t longest_detectable_gap(size_t read_length, size_t read_pos) const;
+    // re-score an alignment from its edits: matches, substitutions, gaps (a deletion that runs on across a node boundary opens once), the
+    // full-length bonus at either end that is not soft-clipped (src/alignment_scorer.cpp:158-238)
+    int32_t score_contiguous_alignment(const Alignment& aln, bool allow_left_bonus = true, bool allow_right_bonus = true) const;
+    double log_base = 0.0;              // recovered from the matrix and the GC content when the aligner is built (src/alignment_scorer.cpp:30-99)
+    double get_log_base() const { return log_base; }
     vgk_scoring as_vgk() const;
 };
 
@@ -58,7 +64,6 @@ struct MaximalExactMatch {
 struct QualAdjAlignmentScorer : MatrixAlignmentScorer {
     std::vector<int8_t> qual_adj_matrix;               // [256][25]
     std::vector<int8_t> qual_adj_full_length_bonuses;  // [256]
-    double log_base = 0.0;
     QualAdjAlignmentScorer(const int8_t* score_matrix_4x4, int8_t go, int8_t ge, int8_t bonus, double gc_content);
     static double recover_log_base(const double matrix[16], double gc_content, double tol = 1e-12);   // :30-99
 };
@@ -126,6 +131,7 @@ public:
                                     bool pin_left, int32_t max_alt_alns) const = 0;
 
     std::unique_ptr<MatrixAlignmentScorer> scorer;
+    std::unique_ptr<MappingQualityCalculator> mapq_calc;     // (src/aligner.hpp:148) host arithmetic on score vectors; untouched by the engine
     // X-drop calls (align_pinned(..., xdrop = true), align_xdrop) with dozeu's band restated (vgk_xdrop_band_align) instead of the
     // exact extension that keeps every cell (the default; the two agree whenever the band contains the optimal path).  PARITY-UNPINNED.
     mutable bool xdrop_band = false;

@@ -483,3 +483,33 @@ int vgh_wfa_set_point_budgets(vgh_wfa* w, uint32_t connect_points, uint32_t tail
 double vgh_wfa_last_kernel_ms(vgh_wfa* w) { const Aligner& a = *w->ext->aligner; return a.engine_api().wfa_last_ms(a.engine_context()); }
 double vgh_wfa_last_wave(vgh_wfa* w, int which) { const Aligner& a = *w->ext->aligner; return a.engine_api().wfa_last_wave(a.engine_context(), which); }
 }
+extern "C" {
+// MappingQualityCalculator::maximum_mapping_quality_exact / _approx (static): -> the mapping quality; *max_idx = the chosen element
+double vgh_maximum_mapping_quality(const double* scaled_scores, int n, int approx, int64_t* max_idx) {
+    std::vector<double> s(scaled_scores, scaled_scores + n);
+    size_t idx = 0;
+    const double q = approx ? MappingQualityCalculator::maximum_mapping_quality_approx(s, &idx) : MappingQualityCalculator::maximum_mapping_quality_exact(s, &idx);
+    if (max_idx) *max_idx = (int64_t)idx;
+    return q;
+}
+// the aligner's mapq_calc member over raw scores (scaled by the recovered log base); first: the first score instead of the best
+int32_t vgh_compute_mapping_quality(vgh_aligner* a, const double* scores, int n, int fast_approximation, int first) {
+    std::vector<double> s(scores, scores + n);
+    return first ? a->a->mapq_calc->compute_first_mapping_quality(s, fast_approximation != 0) : a->a->mapq_calc->compute_max_mapping_quality(s, fast_approximation != 0);
+}
+double vgh_log_base(vgh_aligner* a) { return a->a->scorer->get_log_base(); }
+// scorer->score_contiguous_alignment of an alignment given as flat mappings: edits[k] = {mapping index, from_length, to_length, has sequence}
+int32_t vgh_score_contiguous_alignment(vgh_aligner* a, const char* sequence, const int64_t* edits, int n_edits) {
+    Alignment aln; aln.sequence = sequence;
+    size_t at = 0;
+    for (int k = 0; k < n_edits; ++k) {
+        const size_t m = (size_t)edits[4 * k];
+        while (aln.path.mapping.size() <= m) aln.path.mapping.emplace_back();
+        Edit e; e.from_length = (int32_t)edits[4 * k + 1]; e.to_length = (int32_t)edits[4 * k + 2];
+        if (edits[4 * k + 3]) e.sequence = aln.sequence.substr(at, (size_t)e.to_length);
+        at += (size_t)e.to_length;
+        aln.path.mapping[m].edit.push_back(e);
+    }
+    return a->a->scorer->score_contiguous_alignment(aln);
+}
+}

@@ -31,6 +31,31 @@ size_t MatrixAlignmentScorer::longest_detectable_gap(size_t read_length, size_t 
     return gap_length >= 0 && overhang_length > 0 ? (size_t)gap_length : 0;
 }
 
+int32_t MatrixAlignmentScorer::score_contiguous_alignment(const Alignment& aln, bool allow_left_bonus, bool allow_right_bonus) const {
+    int32_t score = 0;
+    bool in_deletion = false;
+    const auto& maps = aln.path.mapping;
+    for (size_t i = 0; i < maps.size(); ++i) for (size_t j = 0; j < maps[i].edit.size(); ++j) {
+        const Edit& e = maps[i].edit[j];
+        const bool at_an_end = (i == 0 && j == 0) || (i + 1 == maps.size() && j + 1 == maps[i].edit.size());
+        if (edit_is_match(e)) { score += match * e.to_length; in_deletion = false; }
+        else if (edit_is_sub(e)) { score -= mismatch * e.to_length; in_deletion = false; }
+        else if (e.from_length > 0 && e.to_length == 0) { score -= in_deletion ? e.from_length * gap_extension : gap_open + (e.from_length - 1) * gap_extension; in_deletion = true; }
+        else if (e.from_length == 0 && e.to_length == 0) { /* an empty edit changes nothing, not even whether a deletion is running */ }
+        else if (edit_is_insertion(e) && !at_an_end) { score -= gap_open + (e.to_length - 1) * gap_extension; in_deletion = false; }
+        else in_deletion = false;                                              // a soft clip
+    }
+    auto clipped = [&](bool left) {
+        if (maps.empty()) return false;
+        const Mapping& m = left ? maps.front() : maps.back();
+        if (m.edit.empty()) return false;
+        return edit_is_insertion(left ? m.edit.front() : m.edit.back());
+    };
+    if (allow_left_bonus && !clipped(true)) score += full_length_bonus;
+    if (allow_right_bonus && !clipped(false)) score += full_length_bonus;
+    return score;
+}
+
 vgk_scoring MatrixAlignmentScorer::as_vgk() const {
     vgk_scoring s{};
     for (int i = 0; i < 25; ++i) s.matrix[i] = score_matrix[i];
