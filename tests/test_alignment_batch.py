@@ -131,17 +131,25 @@ def test_alignment_batch_takes_submissions_from_many_threads():
     ts = [threading.Thread(target=worker, args=(t, T)) for t in range(T)]
     [t.start() for t in ts]; [t.join() for t in ts]
     assert not errors
-    # the submissions themselves from four threads (ctypes releases the GIL inside the calls; the shim's own lock orders them) — the
-    # JSON comes back in submission order, so each thread remembers which case it submitted
-    order, lock = [], threading.Lock()
+    # the submissions themselves from four threads AT ONCE: every thread submits into result slots of its own, nothing on this side orders
+    # them (ctypes releases the GIL inside the calls) — the shim's own lock has to; small max_pending, so that submissions trigger flushes
+    # while other threads are still submitting
+    h.vgh_batch_reserve.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    h.vgh_batch_add_slot.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    h.vgh_batch_reserve(b, len(cases))
+    start = threading.Barrier(T)
 
     def submit(t):
-        for k in range(t, len(cases), T):
-            with lock:                  # (submission order = result order: keep the pair atomic on the Python side)
-                assert h.vgh_batch_add(b, graphs[k], cases[k]["read"].encode(), None, 2, int(bool(cases[k]["args"][1])), 1) == 0
-                order.append(k)
+        try:
+            start.wait()
+            for k in range(t, len(cases), T):
+                assert h.vgh_batch_add_slot(b, k, graphs[k], cases[k]["read"].encode(), 2, int(bool(cases[k]["args"][1])), 1) == 0, h.vgh_last_error().decode()
+        except Exception as e:          # pragma: no cover
+            errors.append(e)
     ts = [threading.Thread(target=submit, args=(t,)) for t in range(T)]
     [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errors, errors
+    order = list(range(len(cases)))
     buf = ctypes.create_string_buffer(1 << 24)
     assert h.vgh_batch_flush(b, buf, len(buf)) == 0, h.vgh_last_error().decode()
     out = json.loads(buf.value.decode())

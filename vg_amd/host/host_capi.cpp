@@ -513,3 +513,21 @@ int32_t vgh_score_contiguous_alignment(vgh_aligner* a, const char* sequence, con
     return a->a->scorer->score_contiguous_alignment(aln);
 }
 }
+extern "C" {
+// Submissions from many threads at once: the caller reserves n slots, every thread submits into slots of its own (no lock on the
+// caller's side: AlignmentBatch's own lock orders the submissions), the flush answers in slot order.
+int vgh_batch_reserve(vgh_batch* b, int n) { b->alns.clear(); b->alns.resize((size_t)n); return 0; }
+int vgh_batch_add_slot(vgh_batch* b, int slot, vgh_graph* g, const char* read, int call, int pin_left, int arg) {
+    try {
+        Alignment& aln = b->alns[(size_t)slot]; aln = Alignment(); aln.sequence = read;
+        switch (call) {
+            case 0: b->b->align(aln, g->g, true); break;
+            case 2: b->b->align_pinned(aln, g->g, pin_left != 0); break;
+            case 4: b->b->align_pinned(aln, g->g, pin_left != 0, true, (uint16_t)arg); break;
+            case 5: b->b->align_global_banded(aln, g->g, arg, pin_left != 0); break;
+            default: g_last_error = "unknown call"; return -1;
+        }
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+}
