@@ -344,6 +344,115 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
         dist.destroy_process_group()
 
 
+def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
+    """BASELINE.json configs[2] as the whole stage at its stated size (secondary line): the chr22-scale SNP + indel graph (50.8 Mbp, ~1.7 M
+    nodes, two haplotypes: SURVEY §8(d)) with its haplotype index and its minimizer index resident in HBM; 10 M bare reads of 150 bp, in
+    batches of 1 M, through minimizer seeding -> haplotype-consistent gapless extension -> tail forests -> the tails' X-drop alignments
+    (vgk_minimizer_seeds, vgk_gapless_extend_seeded, vgk_tail_stage_aligned).  One step = all batches, from host buffers."""
+    import numpy as np
+    from vg_amd import capi, pipeline, shard, workloads
+    n = args.reads if args.reads else 10_000_000
+    batch = min(n, 1_000_000)
+    t0 = time.perf_counter()
+    ref_len = int(os.environ.get("VGAMD_CONFIG2_REF_LEN", "0"))                  # (a smaller reference: functional checks only)
+    wl = workloads.Config2Workload(n, batch=batch, seed=31 + rank, graph=workloads.VariationGraph(ref_len=ref_len) if ref_len else None)
+    t_gen = time.perf_counter() - t0
+    graph = (wl.node_len, wl.seq)
+    t0 = time.perf_counter(); index = eng.haplo_index(graph, wl.threads); t_hindex = time.perf_counter() - t0
+    t0 = time.perf_counter(); mindex = eng.minimizer_index(graph, wl.threads); t_mindex = time.perf_counter() - t0
+    eng.reuse_outputs = True
+
+    class Batch:
+        def __init__(self, k): self.n = k
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kernel_ms = {"minimizer": 0.0, "gapless": 0.0, "tails derived": 0.0, "tail forest": 0.0, "windows packed": 0.0, "x-drop fill + traceback + totals": 0.0}
+
+    def one_step(timing=None, keep=None):
+        tot = {"seeds": 0, "ext": 0, "tails": 0, "trees": 0, "tree_nodes": 0, "failed": 0, "full_length": 0, "truncated": 0}
+        for b, (reads, off) in enumerate(wl.batches):
+            t1 = time.perf_counter()
+            seed_off, _, mins = eng.minimizer_seeds(mindex, index, reads, off, keep_on_device=True)
+            t2 = time.perf_counter()
+            out = pipeline.align_stage_device(eng, index, Batch(len(off) - 1), seeded=int(seed_off[-1]), aligned=True, timing=timing)
+            if timing is not None:
+                timing["minimizer_seeds"] = timing.get("minimizer_seeds", 0.0) + t2 - t1
+                kernel_ms["minimizer"] += eng.minimizer_last_ms(); kernel_ms["gapless"] += eng.gapless_last_ms()
+                for k, v in zip(("tails derived", "tail forest", "windows packed", "x-drop fill + traceback + totals"), eng.tail_stage_last_ms()):
+                    kernel_ms[k] += v
+            st = out["stats"]
+            tot["seeds"] += int(seed_off[-1]); tot["ext"] += len(out["ext"]); tot["tails"] += int(st[0]); tot["trees"] += int(st[1]); tot["tree_nodes"] += int(st[2]); tot["failed"] += int(st[3])
+            tot["full_length"] += int((out["res"]["full_length"] != 0).sum()); tot["truncated"] += int(eng.minimizers_truncated.sum())
+            if keep is not None and b == 0:
+                keep.update(read_score=out["read_score"].copy(), res=out["res"].copy(), ext=out["ext"].copy(), nodes=out["nodes"].copy(), seed_off=seed_off.copy())
+        return tot
+
+    for _ in range(max(1, args.warmup)):
+        one_step()
+    barrier()
+    timing = {}; first = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tot = one_step(timing, first)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    cpu = parity = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
+        cores = shard.usable_cpus(); ora.lib.vgo_set_threads(cores)
+        k = min(batch, args.cpu_sample or 200_000)
+        reads, off = wl.batches[0]
+        oidx = ora.haplo_index(graph, wl.threads); omi = ora.minimizer_index(graph, wl.threads)
+        olen = np.repeat(wl.node_len, 2)
+        t1 = time.perf_counter()
+        so, sd, _ = ora.minimizer_seeds(omi, oidx, reads[:off[k]], off[:k + 1])
+        sub = capi.GaplessSet(reads[:off[k]], off[:k + 1], sd, so, node_cap=len(sd) * 16, mism_cap=len(sd) * 12)
+        o = pipeline.align_stage(ora, oidx, olen, sub); tc = time.perf_counter() - t1
+        same = int((o["read_score"] == first["read_score"][:k]).sum())
+        cpu = {"value": k / tc, "unit": "reads/s", "cores": cores, "kind": "port",
+               "impl": "the same stage over the oracle: vgo_minimizer.c, vgo_gapless.c (OpenMP over reads), vgo_tail.c, vgo_xdrop.c (OpenMP over problems)",
+               "sample": "the first %d reads of the first batch" % k}
+        parity = {"checked": k, "identical": same, "what": "per-read best total score (extension + both tails' X-drop alignments); tests/test_giraffe_stage.py compares every intermediate product"}
+    if rank == 0:
+        steps = args.steps
+        # the stage's dominant kernel: the gapless search; its algorithmic bytes as in --workload gapless (the read once per seed, outputs)
+        ext, nodes, res = first["ext"], first["nodes"], first["res"]
+        ns = np.diff(first["seed_off"]).astype(np.int64); rl = wl.read_len
+        alg0 = float((rl * (1 + ns) + 8 * ns).sum() + 60 * len(ext) + 4 * len(nodes))          # batch 0
+        gap_ms = kernel_ms["gapless"] / steps / len(wl.batches)
+        achieved = alg0 / (gap_ms * 1e-3) / 1e9 if gap_ms else None
+        print(json.dumps({
+            "metric": "150 bp reads/sec through giraffe's alignment stage from bare reads on the chr22-scale graph (minimizer seeding, gapless extension, tail forests, X-drop tails with their alignments)",
+            "value": n * world * steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "configs[2]: chr22-scale graph (50 818 468 bp reference, 41 %% GC, SNPs 1/1000, indels of 1-20 bp 1/10 000, nodes <= 32 bp: %d nodes), two haplotypes carrying each "
+                                   "variant with p = 0.5; %d reads of 150 bp per GPU from the haplotypes on either strand, 1 %% substitutions, 10 %% of them with one inserted base; "
+                                   "k = 29, w = 11 minimizers, hit cap 500; max_mismatches 4; tails left-pinned X-drop against their haplotype trees, scores 1/4/6/1/5" % (len(wl.node_len), n),
+                       "timed_region": "per step, %d batches of %d reads from host buffers: vgk_minimizer_seeds (clusters stay in HBM) -> vgk_gapless_extend_seeded (sets come down under the "
+                                       "tail stage) -> vgk_tail_stage_aligned" % (len(wl.batches), batch),
+                       "per_step": {k: v / steps for k, v in tot.items()} if steps == 1 else tot,
+                       "ms_per_batch": 1e3 * elapsed / steps / len(wl.batches),
+                       "stage_ms_per_batch": {k: 1e3 * v / steps / len(wl.batches) for k, v in timing.items()},
+                       "kernel_ms_per_batch": {k: v / steps / len(wl.batches) for k, v in kernel_ms.items()},
+                       "index_seconds": {"graph + reads generated": t_gen, "haplotype index": t_hindex, "minimizer index": t_mindex, "minimizer keys": mindex.keys},
+                       "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus},
+            "roofline": {"bound": "hbm", "kernel": "gapless_search_kernel + gapless_rules_kernel (the stage's longest kernels)", "limiter": "memory latency and divergent issue, not bandwidth (DESIGN.md §11)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                         "traffic": None, "alg_bytes_per_launch": alg0, "avg_launch_ms": gap_ms},
+            "cpu_baseline": cpu, "parity": parity, "problems_failed": int(tot["failed"])}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
     """configs[2]'s alignment stage as giraffe runs it (secondary line): seeds -> haplotype-consistent gapless extension -> for the
     clusters no full-length extension resolves, tail forests -> the trees as left-pinned X-drop windows -> total scores
@@ -769,7 +878,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--host-pack", action="store_true", help="linear workload: one explicit graph per problem, packed on host threads (vgk_gssw_pack) instead of windows of the resident graph packed on the device")
     ap.add_argument("--no-e2e", action="store_true", help="skip the legs that overlap launches — the two-lane steady state and the warm / double-buffered end-to-end legs — so that a profiler's per-kernel averages are each kernel's own")
-    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband", "forest", "giraffe", "longread"], default="linear",
+    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband", "forest", "giraffe", "longread", "config2"], default="linear",
                     help="linear = BASELINE.json configs[1] (the headline metric); tails = configs[2] stand-in: "
                          "giraffe-style pinned X-drop tail alignments on a variation graph; banded = configs[4] stand-in: "
                          "banded global alignments between chained anchors; gapless = giraffe's first stage: "
@@ -813,6 +922,8 @@ def main():
 
     if args.workload == "longread":
         return bench_longread(args, eng, rank, world, dist, torch, dev_name, cus)
+    if args.workload == "config2":
+        return bench_config2(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "giraffe":
         return bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "forest":

@@ -599,10 +599,13 @@ class MinimizerIndex:
 
     def __init__(self, eng, nodes, threads, k=29, w=11):
         self.eng = eng; self.k, self.w = k, w
-        self._len = np.array([len(s) for s in nodes], dtype=np.uint32)
-        self._seq = np.frombuffer("".join(nodes).encode(), dtype=np.uint8).copy()
+        if isinstance(nodes, tuple):
+            self._len = np.ascontiguousarray(nodes[0], dtype=np.uint32); self._seq = np.ascontiguousarray(nodes[1], dtype=np.uint8); nodes = self._len
+        else:
+            self._len = np.array([len(s) for s in nodes], dtype=np.uint32)
+            self._seq = np.frombuffer("".join(nodes).encode(), dtype=np.uint8).copy()
         self._toff = np.concatenate([[0], np.cumsum([len(t) for t in threads])]).astype(np.uint32)
-        self._tn = np.array([o for t in threads for o in t] or [0], dtype=np.uint32)
+        self._tn = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.uint32) for t in threads]) if len(threads) and self._toff[-1] else np.zeros(1, np.uint32), dtype=np.uint32)
         d = Haplotypes(len(nodes), self._len.ctypes.data, self._seq.ctypes.data, len(threads), self._toff.ctypes.data, self._tn.ctypes.data)
         h = ctypes.c_void_p()
         eng.lib.vgk_minimizer_index_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
@@ -755,9 +758,14 @@ class HaploIndex:
     def __init__(self, eng, nodes, threads=None, gbwt=None):
         """threads: [[oriented node]]; or gbwt: the bytes of a GBWT file (vgk_haplo_create_gbwt)"""
         self.eng = eng
-        self.nodes = list(nodes)
-        self._len = np.array([len(s) for s in nodes], dtype=np.uint32)
-        self._seq = np.frombuffer("".join(nodes).encode(), dtype=np.uint8).copy()
+        if isinstance(nodes, tuple):                                   # (node lengths, concatenated forward bases) as arrays: graphs with millions of nodes
+            self.nodes = None
+            self._len = np.ascontiguousarray(nodes[0], dtype=np.uint32); self._seq = np.ascontiguousarray(nodes[1], dtype=np.uint8)
+            nodes = self._len
+        else:
+            self.nodes = list(nodes)
+            self._len = np.array([len(s) for s in nodes], dtype=np.uint32)
+            self._seq = np.frombuffer("".join(nodes).encode(), dtype=np.uint8).copy()
         if gbwt is not None:
             h = ctypes.c_void_p()
             eng.lib.vgk_haplo_create_gbwt.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -767,7 +775,7 @@ class HaploIndex:
             eng._indexes.add(self)
             return
         self._toff = np.concatenate([[0], np.cumsum([len(t) for t in threads])]).astype(np.uint32)
-        self._tn = np.array([o for t in threads for o in t] or [0], dtype=np.uint32)
+        self._tn = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.uint32) for t in threads]) if len(threads) and self._toff[-1] else np.zeros(1, np.uint32), dtype=np.uint32)
         d = Haplotypes(len(nodes), self._len.ctypes.data, self._seq.ctypes.data, len(threads), self._toff.ctypes.data, self._tn.ctypes.data)
         h = ctypes.c_void_p()
         eng._check(eng.lib.vgk_haplo_create(eng.h, ctypes.byref(d), ctypes.byref(h)), "vgk_haplo_create")

@@ -869,3 +869,44 @@ class LongReadWorkload:
             seq = _comp_table()[seq[::-1]]
         cache[i] = dict(read=seq.tobytes().decode(), nodes=nodes, preds=preds, band_padding=int(np.sqrt(max(len(seq), 1))) + 1 + 64, permissive=True)
         return cache[i]
+
+
+class Config2Workload:
+    """BASELINE.json configs[2] as a whole stage at its stated size: the chr22-scale SNP + indel graph of SURVEY §8(d) (VariationGraph: 50.8 Mbp,
+    ~1.7 M nodes of <= 32 bp, two haplotypes that carry each variant with p = 0.5) and `n_reads` reads of 150 bp sampled from the two
+    haplotypes on either strand, 1 % substitutions, `inserted_reads` of them with one extra base (a sequencing insertion: no gapless
+    extension covers such a read, its cluster leaves tails for the X-drop stage).  Nothing but the bare reads is given to the engine:
+    minimizer seeding, gapless extension, tail forests and the tails' X-drop alignments all run from the indexes of the graph.
+    Reads come in batches of `batch` (flat uint8 arrays + offsets), generated once."""
+
+    def __init__(self, n_reads, batch=1_000_000, seed=31, read_len=150, inserted_reads=0.1, graph=None):
+        g = graph if graph is not None else VariationGraph()
+        self.graph = g
+        self.node_len = g.node_len; self.seq = g.seq
+        self.threads = [(2 * np.nonzero(hap_pos >= 0)[0]).astype(np.uint32) for _, hap_pos in g.haps]
+        rng = np.random.default_rng(seed)
+        comp = _comp_table()
+        self.batches = []
+        col = np.arange(read_len)[None, :]
+        for lo in range(0, n_reads, batch):
+            n = min(batch, n_reads - lo)
+            which = rng.integers(0, 2, n); rev = rng.random(n) < 0.5
+            reads = np.empty((n, read_len), dtype=np.uint8)
+            for h in (0, 1):
+                sel = np.nonzero(which == h)[0]
+                hseq = g.haps[h][0]
+                a = rng.integers(0, len(hseq) - read_len, len(sel))
+                fw = hseq[a[:, None] + col]
+                rd = np.where(rev[sel][:, None], comp[fw[:, ::-1]], fw)
+                reads[sel] = rd
+            sub = rng.random(reads.shape) < 0.01
+            reads[sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
+            if inserted_reads > 0:
+                ins = np.nonzero(rng.random(n) < inserted_reads)[0]
+                p = rng.integers(20, read_len - 20, len(ins))
+                src = np.where(col > p[:, None], col - 1, col)                # read' = read[:p] + X + read[p:-1]
+                shifted = np.take_along_axis(reads[ins], src, axis=1)
+                shifted[np.arange(len(ins)), p] = ACGT[rng.integers(0, 4, len(ins))]
+                reads[ins] = shifted
+            self.batches.append((reads.ravel(), np.arange(n + 1, dtype=np.int64) * read_len))
+        self.n = n_reads; self.read_len = read_len
