@@ -301,8 +301,11 @@ void ChainConnector::run(unsigned threads) {
         work();
         for (auto& t : pool) t.join();
     };
-    // 1. the local graphs, on the host threads
+    // 1. the local graphs, on the host threads; each thread also submits its problems (the host half of a submission — topological order,
+    //    packing — runs on the submitting thread, outside the batch's lock)
     auto t0 = clock::now();
+    AlignmentBatch batch(aligner_);
+    batch.isolate_failures = true;
     on_threads([&](size_t i) {
         Request& r = *requests_[i]; Outcome& o = outcomes_[i];
         o = Outcome{};
@@ -311,21 +314,17 @@ void ChainConnector::run(unsigned threads) {
             o.trims = r.d->trim_tips();
             r.route = choose_route(r.left, r.right, *r.d, *r.alignment, max_dp_cells_, nullptr);
             if (r.route == Route::SOFTCLIP) { o.status = TOO_BIG; r.d.reset(); }
-            else if (r.route == Route::BANDED) r.band_padding = choose_band_padding_(*r.alignment, r.d->dagified);
+            else if (r.route == Route::BANDED) {
+                r.band_padding = choose_band_padding_(*r.alignment, r.d->dagified);
+                batch.align_global_banded(*r.alignment, r.d->dagified, (int32_t)r.band_padding, true, max_dp_cells_);
+            } else batch.align_pinned(*r.alignment, r.d->dagified, !is_empty(r.left), true, as_gap_limit(r.max_gap_length));
         } catch (ChainAlignmentFailedError& e) { o.status = NO_GRAPH; o.message = e.what(); r.d.reset(); }
+        catch (BandMatricesTooBigException& e) { r.alignment->path.mapping.clear(); o.status = TOO_BIG; o.message = e.what(); o.did_align = true; r.d.reset(); }   // (refused while it was being prepared)
         catch (std::exception& e) { o.status = FAILED; o.message = e.what(); r.d.reset(); }
     });
     last_extract_ms = ms_since(t0);
     // 2. every DP problem in one flush: one launch per kernel family
     t0 = clock::now();
-    AlignmentBatch batch(aligner_);
-    batch.isolate_failures = true;
-    for (size_t i = first; i < requests_.size(); ++i) {
-        Request& r = *requests_[i];
-        if (!r.d) continue;
-        if (r.route == Route::BANDED) batch.align_global_banded(*r.alignment, r.d->dagified, (int32_t)r.band_padding, true, max_dp_cells_);
-        else batch.align_pinned(*r.alignment, r.d->dagified, !is_empty(r.left), true, as_gap_limit(r.max_gap_length));
-    }
     batch.flush();
     last_align_ms = ms_since(t0);
     // 3. back into the base graph
@@ -343,13 +342,13 @@ void ChainConnector::run(unsigned threads) {
         catch (std::exception& e) { o.status = FAILED; o.message = e.what(); }
         r.d.reset();
     });
-    for (size_t i = first; i < requests_.size(); ++i) {                           // answers found on the other strand are turned back
+    on_threads([&](size_t i) {                                                    // answers found on the other strand are turned back
         Request& r = *requests_[i];
-        if (!r.flipped) continue;
+        if (!r.flipped) return;
         auto node_length = [&](nid_t id) -> int64_t { return (int64_t)graph_.get_length(graph_.get_handle(id)); };
         *r.answer = reverse_complement_alignment(r.other_strand, node_length);
         try { check_one_piece(*r.answer); } catch (std::exception& e) { outcomes_[i].status = FAILED; outcomes_[i].message = e.what(); }
-    }
+    });
     last_translate_ms = ms_since(t0);
 }
 
