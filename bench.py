@@ -911,8 +911,12 @@ def main():
     from vg_amd import capi, workloads
     if world > 1:      # N ranks share one host: each gets its share of the packing / unpacking threads
         os.environ["VGAMD_HOST_THREADS"] = str(shard.host_threads_per_rank(world))
+        try:           # ... and a leg that needs more host threads per rank than that share must not print a number at all
+            shard.check_host_thread_budget(args.workload, world)
+        except shard.HostThreadBudgetError as e:
+            raise SystemExit("bench.py: " + str(e))
 
-    eng_lib = os.path.join(ROOT, "vg_amd", "libvgamd.so")
+    eng_lib = os.environ.get("VGAMD_ENGINE_LIB") or os.path.join(ROOT, "vg_amd", "libvgamd.so")     # (the override is for kernel experiments: another build of the same library)
     if not os.path.exists(eng_lib):
         raise SystemExit("vg_amd/libvgamd.so missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback)")
     eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), device=local_rank, lib=eng_lib)

@@ -73,7 +73,14 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
 // One thread per read, in the order the fill placed the reads (order[] = the reads of wavefront 0, pair by pair, then wavefront 1 ...):
 // the threads of a walker wavefront then read traceback records that one or two fill wavefronts wrote next to each other, and the two
 // reads of a pair — whose codes share every dword — sit in neighbouring lanes.
+#ifndef VGK_WALK_WAVES
+#define VGK_WALK_WAVES 0
+#endif
+#if VGK_WALK_WAVES
+__global__ __launch_bounds__(256, VGK_WALK_WAVES) void gssw_walk_kernel(const GsswParams P, const int in_fill_order) {
+#else
 __global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P, const int in_fill_order) {
+#endif
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (!in_fill_order) { if (k < P.n_problems) walk_one(P, k, P.best[k]); return; }
     if (k >= 2u * P.n_pairs) return;

@@ -445,7 +445,11 @@ struct Walker {
     // bit0 = H not from the diagonal, bit1 = H from F (else E), bit2 = next-column E is an extension, bit3 = next-row F is an extension
     VGK_HD uint32_t code(uint32_t r, uint32_t c) const {
         const uint32_t g = r / K, m = r - g * K, t = c + g, j = m >> 2, i = m & 3u;
+#if defined(VGK_WALK_EXP) && VGK_WALK_EXP >= 1      // timing experiments only (results are wrong): the codes come out of a region that stays in L2 (1) / L1 (2, 3)
+        const uint32_t w = P.tb[tb_off + ((tb_dword(0, t, lane0 + g, (K + 3) >> 2) + j) & (VGK_WALK_EXP == 1 ? 0x3ffffu : 0xfffu))];
+#else
         const uint32_t w = P.tb[tb_dword(tb_off, t, lane0 + g, (K + 3) >> 2) + j];
+#endif
         const uint32_t last = (4 * j + 3 < K ? 4 * j + 3 : K - 1) - 4 * j;      // a lane's last dword holds K % 4 rows when K is no multiple of 4
         const uint32_t raw = (w >> (16 * half + 4 * (last - i))) & 15u;
         if (P.scale != 8) return raw;
@@ -467,6 +471,9 @@ struct Walker {
         return (ci_word >> (8 * (a & 3u))) & CI_BASE_MASK;
     }
     VGK_HD int32_t score(uint32_t r, uint32_t c) const {
+#if defined(VGK_WALK_EXP) && VGK_WALK_EXP == 3      // timing experiment: no loads of read / column bytes either
+        return (int32_t)((r ^ c) & 1u) * 5 - 4;
+#endif
         const uint32_t base = col_base(c);
         const int32_t bonus = (int32_t)row_bonus(d.bonus_start, d.bonus_end, r, d.L);
         if (base >= 4) return bonus;                      // N scores 0 (+ bonus)
