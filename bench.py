@@ -838,6 +838,23 @@ def bench_xdrop_band(args, eng, rank, world, dist, torch, dev_name, cus):
     t0 = time.perf_counter(); res, ops, st = eng.xdrop_band_align(ps); t_band = time.perf_counter() - t0
     k_ms = eng.lib.vgk_xdrop_band_last_ms(eng.h)
     t0 = time.perf_counter(); eres, eops = eng.align(ps, 48); t_exact = time.perf_counter() - t0
+    # band mode against exact mode, alignment by alignment: a tail counts as different when any header field
+    # or any CIGAR element differs.  Both op arrays are packed per problem (n_ops elements from ops_begin).
+    def same_alignment(ra, oa, rb, ob):
+        same = np.ones(len(ra), dtype=bool)
+        for f in ("score", "status", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
+            same &= ra[f] == rb[f]
+        idx = np.flatnonzero(same & (ra["n_ops"] > 0))
+        if len(idx):
+            cnt = ra["n_ops"][idx].astype(np.int64)
+            owner = np.repeat(np.arange(len(idx)), cnt)
+            within = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+            a = oa.view(np.uint64)[ra["ops_begin"][idx].astype(np.int64)[owner] + within]
+            b = ob.view(np.uint64)[rb["ops_begin"][idx].astype(np.int64)[owner] + within]
+            bad = np.unique(owner[a != b])
+            same[idx[bad]] = False
+        return same
+    band_same = same_alignment(res, ops, eres, eops)
     parity = cpu = None
     if not args.no_cpu:
         ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
@@ -861,6 +878,7 @@ def bench_xdrop_band(args, eng, rank, world, dist, torch, dev_name, cus):
                    "device": dev_name, "compute_units": cus},
         "band": {"cells_in_band": st[0], "cells_of_the_rectangles": st[1], "fraction_kept": st[0] / max(st[1], 1), "fill_kernel_ms": k_ms,
                  "banded_score_equals_exact": float((res["score"] == eres["score"]).mean()), "banded_score_never_higher": bool((res["score"] <= eres["score"]).all()),
+                 "tails_whose_band_mode_alignment_differs_from_exact_mode": int((~band_same).sum()), "of_them_with_the_same_score": int((~band_same & (res["score"] == eres["score"])).sum()),
                  "exact_path_same_problems_host_inclusive_per_s": n / t_exact},
         "roofline": None, "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum())}))
     if dist is not None:

@@ -292,11 +292,14 @@ double vgk_xdrop_band_last_ms(vgk_ctx* ctx);     /* fill-kernel time of the last
  * Every problem must be VGK_GSSW_PINNED.  results[i * max_alt_alns + k] is the k-th best alignment of problem i (k <
  * n_alignments[i] <= max_alt_alns), scores non-increasing and > 0, the first one the alignment vgk_gssw_align returns; a problem
  * that failed has n_alignments[i] = 0 and its status in results[i * max_alt_alns].  The device fills and keeps the H / E / F
- * matrices, the alternates are enumerated over them on host threads (deflections from earlier tracebacks, best first — gssw's
- * own rules are not in the reference snapshot: DESIGN.md §13). */
+ * matrices and enumerates the alternates over them, one lane per problem (deflections from earlier tracebacks, best first — gssw's
+ * own rules are not in the reference snapshot: DESIGN.md §13); only the alignments come back.  A problem the kernel's fixed tables
+ * cannot hold (a node with more than 15 predecessors, an alternate with more than 24 deflections, max_alt_alns > 62) is walked by a
+ * host thread over its own matrices under the same rules; vgk_gssw_multi_host_walks counts those of the last call. */
 int  vgk_gssw_align_multi(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, uint32_t max_alt_alns,
                           vgk_result* results /* [n * max_alt_alns] */, uint32_t* n_alignments /* [n] */,
                           vgk_op* ops, size_t ops_cap, size_t* ops_written);
+uint64_t vgk_gssw_multi_host_walks(const vgk_ctx* ctx);
 
 /* ---- banded global alignment (BandedGlobalAligner, src/banded_global_aligner.cpp) -------------------
  * Replaces, inside Aligner::align_global_banded / QualAdjAligner::align_global_banded (src/aligner.cpp:699-760,

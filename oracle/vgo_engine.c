@@ -294,6 +294,7 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
 
 double vgk_wfa_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }
 double vgk_wfa_last_wave(vgk_ctx* ctx, int which) { (void)ctx; (void)which; return 0.0; }
+uint64_t vgk_gssw_multi_host_walks(const vgk_ctx* ctx) { (void)ctx; return 0; }      /* (the oracle has no device: every problem is walked here) */
 int vgk_wfa_set_form(vgk_ctx* ctx, int form) { (void)ctx; (void)form; return VGK_OK; }
 int vgk_wfa_set_point_budget(vgk_ctx* ctx, uint32_t points) { (void)points; return ctx ? VGK_OK : VGK_EINVAL; }      /* the oracle has no tables to outgrow */
 int vgk_wfa_set_point_budgets(vgk_ctx* ctx, uint32_t connect_points, uint32_t tail_points) { (void)ctx; (void)connect_points; (void)tail_points; return VGK_OK; }

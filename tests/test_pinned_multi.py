@@ -4,6 +4,7 @@ gssw's own multi-traceback is not in the reference snapshot; what pins the behav
 src/unittest/pinned_alignment.cpp:1951-2530, transcribed by hand below (line numbers in the comments) and driven through the
 C++ host shim exactly like the reference drives vg's Aligner.  The HIP engine is then compared with the oracle on random
 problems, alternate by alternate."""
+import os
 import numpy as np
 import pytest
 
@@ -111,7 +112,7 @@ def test_oracle_has_the_reference_properties():
 
 # ---- random problems: the engine against the oracle, alternate by alternate ---------------------------------------------
 
-def compare_engines(lib, seeds, n_problems=40, max_alt=30):
+def compare_engines(lib, seeds, n_problems=40, max_alt=30, on_device=True):
     ora = capi.Engine(lib=util.ORACLE_LIB); eng = capi.Engine(lib=lib) if lib else capi.Engine()
     total = 0
     for s in seeds:
@@ -120,6 +121,10 @@ def compare_engines(lib, seeds, n_problems=40, max_alt=30):
         ps = problem_set(problems)
         ra, ca, oa = ora.align_multi(ps, max_alt)
         rb, cb, ob = eng.align_multi(ps, max_alt)
+        if on_device:              # the alternates were enumerated by the kernel (gssw_multi_device.hpp), none by a host thread
+            assert eng.multi_host_walks == 0, (s, eng.multi_host_walks)
+        else:
+            assert eng.multi_host_walks > 0
         assert (ca == cb).all(), (s, ca, cb)
         for i in range(ps.n):
             for k in range(int(ca[i])):
@@ -147,6 +152,14 @@ def test_emulated_pinned_multi_matches_oracle():
     assert reference_property_cases(util.EMU_LIB) > 100
     quality_adjusted_case(util.EMU_LIB)
     assert compare_engines(util.EMU_LIB, range(500, 520)) > 1500
+    # what the kernel's tables cannot hold goes to host threads under the same rules: more alternates than a lane's slot pool ...
+    assert compare_engines(util.EMU_LIB, range(520, 523), max_alt=80, on_device=False) > 300
+    # ... and (forced) every problem
+    os.environ["VGAMD_MULTI_HOST_WALK"] = "1"
+    try:
+        assert compare_engines(util.EMU_LIB, range(523, 526), on_device=False) > 200
+    finally:
+        del os.environ["VGAMD_MULTI_HOST_WALK"]
 
 
 @pytest.mark.gpu
@@ -154,3 +167,33 @@ def test_hip_pinned_multi_matches_oracle():
     assert reference_property_cases(util.ENGINE_LIB) > 100
     quality_adjusted_case(util.ENGINE_LIB)
     assert compare_engines(None, range(600, 640), n_problems=100) > 15000
+
+
+def declined_by_the_kernel_case(lib):
+    """A node with 17 predecessors is more than a lane's source table holds: the kernel answers VGK_ETOOBIG for that problem alone and a
+    host thread walks it (its matrices are the only ones copied back); the neighbours stay on the device; all equal the oracle."""
+    rng = np.random.default_rng(77)
+    wide = {"read": "ACGTACGTTG", "nodes": ["ACGTA", "ACGTT", "ACGAA", "ACTTA", "AGGTA", "CCGTA", "ACGTC", "ACGGA", "TCGTA", "ACGTG", "AAGTA",
+                                            "ACCTA", "ACGCA", "GCGTA", "ACGTA", "ATGTA", "ACGAT", "CGTTG"],
+            "preds": [[] for _ in range(17)] + [list(range(17))], "flags": capi.VGK_GSSW_PINNED | capi.VGK_GSSW_TRACEBACK, "pinning": [0] * 17 + [1]}
+    problems = [random_problem(rng, max_nodes=8, max_node_len=10, max_read=40, mode=capi.VGK_GSSW_PINNED) for _ in range(6)]
+    problems.insert(3, wide)
+    ps = problem_set(problems)
+    ora = capi.Engine(lib=util.ORACLE_LIB); eng = capi.Engine(lib=lib) if lib else capi.Engine()
+    ra, ca, oa = ora.align_multi(ps, 20)
+    rb, cb, ob = eng.align_multi(ps, 20)
+    assert eng.multi_host_walks == 1
+    assert (ca == cb).all() and ca[3] > 5
+    for i in range(ps.n):
+        for k in range(int(ca[i])):
+            assert ra[i, k]["score"] == rb[i, k]["score"] and ra[i, k]["first_offset"] == rb[i, k]["first_offset"]
+            assert capi.cigar_string(ra[i, k], oa) == capi.cigar_string(rb[i, k], ob), (i, k)
+
+
+def test_emulated_kernel_hands_what_it_cannot_hold_to_a_host_thread():
+    declined_by_the_kernel_case(util.EMU_LIB)
+
+
+@pytest.mark.gpu
+def test_hip_kernel_hands_what_it_cannot_hold_to_a_host_thread():
+    declined_by_the_kernel_case(None)

@@ -125,6 +125,7 @@ def load_library(path=None):
     lib.vgk_gapless_last_ms.argtypes = [vp]
     lib.vgk_banded_align_multi.argtypes = [vp, vp, u32, u32, vp, vp, vp, sz, ctypes.POINTER(sz)]
     lib.vgk_gssw_align_multi.argtypes = [vp, vp, u32, u32, vp, vp, vp, sz, ctypes.POINTER(sz)]
+    lib.vgk_gssw_multi_host_walks.argtypes = [vp]; lib.vgk_gssw_multi_host_walks.restype = ctypes.c_uint64
     lib.vgk_banded_rerun.argtypes = [vp]
     lib.vgk_gapless_rerun.argtypes = [vp]
     lib.vgk_wfa_extend.argtypes = [vp, vp, vp, vp, u32, vp, vp, sz, vp, sz, ctypes.POINTER(sz * 2)]
@@ -336,6 +337,7 @@ class Engine:
         written = ctypes.c_size_t()
         self._check(self.lib.vgk_gssw_align_multi(self.h, ps.ptr, ps.n, max_alt_alns, res.ctypes.data, cnt.ctypes.data, ops.ctypes.data, cap,
                                                   ctypes.byref(written)), "vgk_gssw_align_multi")
+        self.multi_host_walks = int(self.lib.vgk_gssw_multi_host_walks(self.h))      # problems whose alternates a host thread walked
         return res, cnt, ops[:written.value]
 
     def banded_align(self, bs):

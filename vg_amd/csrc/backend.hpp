@@ -12,6 +12,7 @@
 #include "wfa_device.hpp"
 #include "wfa_wave_device.hpp"
 #include "gssw_matrix_device.hpp"
+#include "gssw_multi_device.hpp"
 #include "gssw_pack_device.hpp"
 #include "tail_device.hpp"
 #include "minimizer_device.hpp"
@@ -107,6 +108,8 @@ public:
     virtual void  reset_wfa_ms() {}
     // pinned gssw fill that keeps H / E / F of every cell (k-best tracebacks): one thread per problem
     virtual int   run_gssw_matrix(const GsswMatrixParams& p) = 0;
+    // the k-best tracebacks over those matrices, one lane per problem (gssw_multi_device.hpp); synchronises
+    virtual int   run_gssw_multi(const GsswMultiParams& p) = 0;
     // X-drop with dozeu's band (vgk_xdrop_band_align): one wavefront per problem, the matrices stay for the host's traceback;
     // last_ms(7) = kernel ms
     virtual int   run_xdrop_band(const GsswMatrixParams& p) = 0;

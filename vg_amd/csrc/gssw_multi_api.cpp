@@ -2,7 +2,8 @@
 // src/aligner.cpp:423-435, :455-480).
 //
 // Device: the pinned fill with every cell's H / E / F kept (gssw_matrix_device.hpp), in sub-batches that fit the memory
-// budget.  Host: one thread per problem enumerates the alternates over the downloaded matrices, best first.
+// budget, then the alternates enumerated over them, one lane per problem (gssw_multi_device.hpp).  Host: a thread per problem
+// the kernel declines (or all of them when max_alt_alns > 62) walks the same rules over that problem's downloaded matrices.
 //
 // The enumeration (gssw's own is not in the reference snapshot — DESIGN.md §13; the oracle states the same rules): a traceback
 // is the walk of the single traceback's state machine over H / E / F.  The sources of a state come in a fixed order — H:
@@ -189,6 +190,8 @@ struct MultiHost { RawBuf<uint8_t> reads, quals, graph; RawBuf<MProb> probs; Raw
 
 extern "C" {
 
+uint64_t vgk_gssw_multi_host_walks(const vgk_ctx* ctx) { return ctx ? ctx->multi_host_walks : 0; }
+
 int vgk_gssw_align_multi(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, uint32_t max_alt_alns,
                          vgk_result* results, uint32_t* n_alignments, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
     if (!ctx || (!problems && n) || (!results && n) || (!n_alignments && n) || !max_alt_alns) return VGK_EINVAL;
@@ -202,6 +205,8 @@ int vgk_gssw_align_multi(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
     if (!ctx->multi_host) ctx->multi_host = std::make_shared<MultiHost>();
     MultiHost& Hs = *static_cast<MultiHost*>(ctx->multi_host.get());
     const bool qa = ctx->has_qa;
+    const bool on_device = max_alt_alns + 2 <= 64 && !std::getenv("VGAMD_MULTI_HOST_WALK");     // a lane's slot pool is a 64-bit mask
+    ctx->multi_host_walks = 0;
 
     // validation, per problem: failures are answered in the problem's first result
     std::vector<int> status(n, VGK_OK); std::vector<uint32_t> cols(n, 0);
@@ -226,13 +231,15 @@ int vgk_gssw_align_multi(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
     size_t used = 0; int rc_all = VGK_OK;
     for (uint32_t i = 0; i < n;) {
         // a sub-batch whose matrices fit the budget
-        uint64_t n_cells = 0, n_read = 0, n_graph = 0, n_nodes = 0, n_preds = 0;
+        uint64_t n_cells = 0, n_read = 0, n_graph = 0, n_nodes = 0, n_preds = 0, n_window = 0;
         uint32_t j = i; std::vector<uint32_t> owner;
         for (; j < n; ++j) {
             if (status[j] != VGK_OK) continue;
             const vgk_gssw_problem& p = problems[j];
             const uint64_t c3 = 3ull * cols[j] * p.read_len;
-            if (!owner.empty() && (n_cells + c3) * sizeof(int32_t) > budget) break;
+            const uint64_t w2 = on_device ? 2ull * max_alt_alns * ((uint64_t)cols[j] + p.read_len + 2) : 0;      // the walk's op window, in int32 units
+            if (!owner.empty() && ((n_cells + c3) * sizeof(int32_t) + n_window * 4 + w2 * 4 > budget || (n_window + w2) / 2 >= (1ull << 31))) break;
+            n_window += w2;
             n_cells += c3; n_read += p.read_len; n_graph += cols[j]; n_nodes += p.graph.n_nodes; n_preds += p.graph.pred_off[p.graph.n_nodes] - p.graph.pred_off[0];
             owner.push_back(j);
         }
@@ -280,15 +287,87 @@ int vgk_gssw_align_multi(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
             if (!P.probs || !P.reads || (qa && !P.quals) || !P.graph || !P.nodes || !P.preds || !P.mat || !P.cells) return VGK_ENOMEM;
             int rc;
             if ((rc = be->run_gssw_matrix(P))) return rc;
-            int32_t* cells = Hs.cells.get(n_cells + 1);
             if ((rc = be->download(probs, P.probs, sizeof(MProb) * m))) return rc;
-            if ((rc = be->download(cells, P.cells, sizeof(int32_t) * n_cells))) return rc;
-            // the alternates of every problem on a host thread over its matrices
-            parallel_for(m, [&](uint32_t a, unsigned) {
-                if (probs[a].status != VGK_OK) return;
-                Tracer t(ctx, problems[owner[a]], probs[a], cells + probs[a].mat_off);
-                t.run(max_alt_alns, pres[a], pops[a]);
-            });
+            // The alternates.  On the device (gssw_multi_device.hpp: one lane per problem walks its matrices where they lie; only the
+            // alignments come back) when the queue fits a lane's slot pool; a problem the kernel declines (VGK_ETOOBIG: a node with
+            // more predecessors, or an alternate with more deflections, than a slot holds) is walked by a host thread over its own
+            // matrices, which then are the only ones copied back.
+            std::vector<uint8_t> on_host(m, 1);
+            if (on_device) {
+                std::vector<uint8_t> pin(n_nodes + 1); std::vector<uint64_t> ops_off(m + 1, 0);
+                { uint64_t a_nodes = 0;
+                  for (uint32_t a = 0; a < m; ++a) {
+                      const vgk_gssw_problem& p = problems[owner[a]];
+                      for (uint32_t v = 0; v < p.graph.n_nodes; ++v) pin[a_nodes + v] = p.pinning[v] ? 1 : 0;
+                      a_nodes += p.graph.n_nodes;
+                      ops_off[a + 1] = ops_off[a] + (uint64_t)max_alt_alns * ((uint64_t)probs[a].L + probs[a].R + 2);
+                  } }
+                const uint64_t n_res = (uint64_t)m * max_alt_alns, slots = max_alt_alns + 2;
+                GsswMultiParams Q{};
+                Q.M = P; Q.max_alt = max_alt_alns;
+                Q.pinning = (const uint8_t*)dev(72, pin.data(), n_nodes);
+                Q.pool = (MtAlt*)dev(73, nullptr, sizeof(MtAlt) * slots * m);
+                Q.order = (uint32_t*)dev(74, nullptr, sizeof(uint32_t) * slots * m);
+                Q.results = (vgk_result*)dev(75, nullptr, sizeof(vgk_result) * n_res);
+                Q.n_alignments = (uint32_t*)dev(76, nullptr, sizeof(uint32_t) * m);
+                Q.status = (int32_t*)dev(77, nullptr, sizeof(int32_t) * m);
+                Q.ops = (vgk_op*)dev(78, nullptr, sizeof(vgk_op) * ops_off[m]);
+                Q.ops_off = (const uint64_t*)dev(79, ops_off.data(), sizeof(uint64_t) * m);
+                if (!Q.pinning || !Q.pool || !Q.order || !Q.results || !Q.n_alignments || !Q.status || !Q.ops || !Q.ops_off) return VGK_ENOMEM;
+                if ((rc = be->zero(Q.results, sizeof(vgk_result) * n_res))) return rc;
+                if ((rc = be->run_gssw_multi(Q))) return rc;
+                std::vector<int32_t> dstat(m); std::vector<uint32_t> dcnt(m);
+                if ((rc = be->download(dstat.data(), Q.status, sizeof(int32_t) * m))) return rc;
+                if ((rc = be->download(dcnt.data(), Q.n_alignments, sizeof(uint32_t) * m))) return rc;
+                // the ops packed behind each other on the device (the windows are mostly air), then results + ops back
+                std::vector<vgk_result> dres(n_res); std::vector<vgk_op> dops;
+                const uint32_t blocks = (uint32_t)((n_res + Backend::OPS_SCAN_BLOCK - 1) / Backend::OPS_SCAN_BLOCK);
+                uint32_t* offs = (uint32_t*)dev(80, nullptr, sizeof(uint32_t) * n_res);
+                uint32_t* sums = (uint32_t*)dev(81, nullptr, sizeof(uint32_t) * (blocks + 8));
+                uint64_t total = 0;
+                if (!offs || !sums) return VGK_ENOMEM;
+                rc = be->ops_offsets(Q.results, (uint32_t)n_res, offs, sums, &total);
+                if (rc == VGK_OK) {
+                    vgk_result* pres_d = (vgk_result*)dev(82, nullptr, sizeof(vgk_result) * n_res);
+                    vgk_op* pops_d = (vgk_op*)dev(83, nullptr, sizeof(vgk_op) * std::max<uint64_t>(total, 1));
+                    if (!pres_d || !pops_d) return VGK_ENOMEM;
+                    if ((rc = be->ops_gather(Q.results, Q.ops, (uint32_t)n_res, offs, sums, pres_d, pops_d))) return rc;
+                    if ((rc = be->sync_fetch())) return rc;
+                    dops.resize(total);
+                    if ((rc = be->download(dres.data(), pres_d, sizeof(vgk_result) * n_res))) return rc;
+                    if (total && (rc = be->download(dops.data(), pops_d, sizeof(vgk_op) * total))) return rc;
+                } else if (rc == VGK_EUNSUPPORTED) {               // (the emulator: no packing kernels — everything comes back as it lies)
+                    dops.resize(ops_off[m]);
+                    if ((rc = be->download(dres.data(), Q.results, sizeof(vgk_result) * n_res))) return rc;
+                    if (ops_off[m] && (rc = be->download(dops.data(), Q.ops, sizeof(vgk_op) * ops_off[m]))) return rc;
+                } else return rc;
+                for (uint32_t a = 0; a < m; ++a) {
+                    if (probs[a].status != VGK_OK || dstat[a] != VGK_OK) continue;
+                    on_host[a] = 0;
+                    pres[a].assign(dres.begin() + (size_t)a * max_alt_alns, dres.begin() + (size_t)a * max_alt_alns + dcnt[a]);
+                    for (vgk_result& r : pres[a]) {
+                        const uint32_t at = (uint32_t)pops[a].size();
+                        pops[a].insert(pops[a].end(), dops.begin() + r.ops_begin, dops.begin() + r.ops_begin + r.n_ops);
+                        r.ops_begin = at;
+                    }
+                }
+            }
+            // ... and the ones left to host threads, each over its own matrices
+            { std::vector<uint32_t> todo;
+              for (uint32_t a = 0; a < m; ++a) if (on_host[a] && probs[a].status == VGK_OK) todo.push_back(a);
+              ctx->multi_host_walks += todo.size();
+              if (!todo.empty()) {
+                  uint64_t need = 0; std::vector<uint64_t> at(todo.size());
+                  for (size_t k = 0; k < todo.size(); ++k) { at[k] = need; need += 3ull * probs[todo[k]].R * probs[todo[k]].L; }
+                  int32_t* cells = Hs.cells.get(need + 1);
+                  for (size_t k = 0; k < todo.size(); ++k)
+                      if ((rc = be->download(cells + at[k], P.cells + probs[todo[k]].mat_off, sizeof(int32_t) * 3ull * probs[todo[k]].R * probs[todo[k]].L))) return rc;
+                  parallel_for((uint32_t)todo.size(), [&](uint32_t k, unsigned) {
+                      const uint32_t a = todo[k];
+                      Tracer t(ctx, problems[owner[a]], probs[a], cells + at[k]);
+                      t.run(max_alt_alns, pres[a], pops[a]);
+                  });
+              } }
         }
         // results in the caller's order
         uint32_t a = 0;
