@@ -1,6 +1,8 @@
 // host_capi.cpp — a small C surface over the C++ host shim so that other
 // languages (the pytest suite via ctypes, or a future binding) can drive the
 // mirrored Aligner interface exactly like src/unittest/*.cpp drives vg's.
+#include <array>
+#include <set>
 #include <algorithm>
 #include <cstring>
 #include <deque>
@@ -344,6 +346,7 @@ int vgh_tail_stage(const char* engine_lib, void* ctx, const void* index, const c
 
 // ---- the graph between / beyond anchors (chain_alignment.hpp; MinimizerMapper::align_sequence_between and friends) ------------------
 #include "chain_alignment.hpp"
+#include "cluster_alignment.hpp"
 extern "C" {
 
 // a bidirected graph, as the reference's tests build with HashGraph / json2graph
@@ -407,6 +410,109 @@ int vgh_dagified_local_graph(vgh_bigraph* g, const int64_t* left, const int64_t*
         return emit_string(js, json_out, json_cap);
     } catch (ChainAlignmentFailedError& e) { g_last_error = e.what(); return 1; }
     catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// The graph algorithms of local_graph.hpp one by one, for the reference's own known-answer tests of them (src/unittest/dagify.cpp,
+// src/unittest/vg_algorithms.cpp).  what / args:
+//   "dagify" [min_preserved_path_length]                "dagify_from" [min_preserved_path_length, (node id, is_reverse) ...]
+//   "split_strands" []                                  "properties" []   (-> {"acyclic": b, "single_stranded": b})
+//   "extract_connecting" [max_len, id1, rev1, off1, id2, rev2, off2, strict_max_len]
+//   "extract_extending"  [max_dist, id, rev, off, backward, preserve_cycles_on_src_node]
+//   "extract_containing" [reversing_walk_length, n, (id, rev, off, forward length, backward length) x n]
+// JSON out: {"nodes": [[id, sequence, source id, source is_reverse], ...], "edges": [[from, from_start, to, to_end], ...] (each edge once),
+// "starts": [[id, is_reverse], ...], "acyclic": b, "single_stranded": b, "tips": [[id, is_reverse], ...]}
+int vgh_graph_algorithm(vgh_bigraph* g, const char* what, const int64_t* args, int n_args, char* json_out, size_t json_cap) {
+    try {
+        const std::string op = what;
+        LocalGraph out; const LocalGraph* shown = &out;
+        std::unordered_map<nid_t, std::pair<nid_t, bool>> src;
+        std::vector<handle_t> starts;
+        auto need = [&](int k) { if (n_args < k) throw std::invalid_argument("vgh_graph_algorithm: too few arguments for " + op); };
+        if (op == "dagify") { need(1); for (auto& kv : handlealgs::dagify(&g->g, &out, (size_t)args[0])) src[kv.first] = {kv.second, false}; }
+        else if (op == "dagify_from") {
+            need(3);
+            std::vector<handle_t> from;
+            for (int k = 1; k + 1 < n_args; k += 2) from.push_back(g->g.get_handle(args[k], args[k + 1] != 0));
+            auto d = handlealgs::dagify_from(&g->g, from, &out, (size_t)args[0]);
+            for (auto& kv : d.to_source) src[kv.first] = {kv.second, false};
+            starts = d.starts;
+        }
+        else if (op == "split_strands") src = handlealgs::split_strands(&g->g, &out);
+        else if (op == "properties") shown = &g->g;
+        else if (op == "extract_connecting") {
+            need(8);
+            auto r = extract_connecting_graph(&g->g, &out, args[0], as_position(args + 1), as_position(args + 4), args[7] != 0);
+            for (auto& kv : r.to_source) src[kv.first] = {kv.second, false};
+        }
+        else if (op == "extract_extending") {
+            need(6);
+            auto r = extract_extending_graph(&g->g, &out, args[0], as_position(args + 1), args[4] != 0, args[5] != 0);
+            for (auto& kv : r.to_source) src[kv.first] = {kv.second, false};
+        }
+        else if (op == "extract_containing") {
+            need(2);
+            const int n = (int)args[1]; need(2 + 5 * n);
+            std::vector<Position> pos; std::vector<size_t> fw, bw;
+            for (int k = 0; k < n; ++k) { const int64_t* a = args + 2 + 5 * k; pos.push_back(as_position(a)); fw.push_back((size_t)a[3]); bw.push_back((size_t)a[4]); }
+            extract_containing_graph(&g->g, &out, pos, fw, bw, (size_t)args[0]);
+        }
+        else throw std::invalid_argument("vgh_graph_algorithm: unknown algorithm " + op);
+        const LocalGraph& d = *shown;
+        std::string js = "{\"nodes\":[";
+        bool first = true;
+        d.for_each_handle_v([&](const handle_t& h) {
+            auto found = src.find(d.get_id(h));
+            const nid_t sid = found == src.end() ? d.get_id(h) : found->second.first; const bool srev = found != src.end() && found->second.second;
+            js += std::string(first ? "" : ",") + "[" + std::to_string(d.get_id(h)) + ",\"" + d.get_sequence(h) + "\"," + std::to_string(sid) + "," + (srev ? "1" : "0") + "]";
+            first = false;
+        });
+        js += "],\"edges\":[";
+        first = true;
+        std::set<std::array<int64_t, 4>> edges;                                        // (from, from_start, to, to_end), the smaller of an edge's two readings
+        d.for_each_handle_v([&](const handle_t& fwd) {
+            for (int rev = 0; rev < 2; ++rev) {
+                const handle_t h = rev ? d.flip(fwd) : fwd;
+                d.follow_edges_v(h, false, [&](const handle_t& n) {
+                    const std::array<int64_t, 4> a{d.get_id(h), d.get_is_reverse(h) ? 1 : 0, d.get_id(n), d.get_is_reverse(n) ? 1 : 0};
+                    const std::array<int64_t, 4> b{a[2], a[3] ? 0 : 1, a[0], a[1] ? 0 : 1};
+                    edges.insert(std::min(a, b));
+                });
+            }
+        });
+        for (const auto& e : edges) { js += std::string(first ? "" : ",") + "[" + std::to_string(e[0]) + "," + std::to_string(e[1]) + "," + std::to_string(e[2]) + "," + std::to_string(e[3]) + "]"; first = false; }
+        js += "],\"starts\":[";
+        first = true;
+        for (const handle_t& t : starts) { js += std::string(first ? "" : ",") + "[" + std::to_string(d.get_id(t)) + "," + (d.get_is_reverse(t) ? "1" : "0") + "]"; first = false; }
+        js += "],\"tips\":[";
+        first = true;
+        for (const handle_t& t : handlealgs::find_tips(&d)) { js += std::string(first ? "" : ",") + "[" + std::to_string(d.get_id(t)) + "," + (d.get_is_reverse(t) ? "1" : "0") + "]"; first = false; }
+        js += std::string("],\"acyclic\":") + (handlealgs::is_acyclic(&d) ? "true" : "false") + ",\"single_stranded\":" + (handlealgs::is_single_stranded(&d) ? "true" : "false") + "}";
+        return emit_string(js, json_out, json_cap);
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// Mapper::align_to_graph (cluster_alignment.hpp).  flags: 1 do_flip, 2 traceback, 4 pinned, 8 pin_left, 16 banded_global, 32 keep_bonuses.
+// JSON out: the alignment, positions on the caller's own nodes.
+int vgh_align_to_graph(vgh_aligner* a, vgh_bigraph* g, const char* read, int flags, char* json_out, size_t json_cap) {
+    try {
+        Alignment aln; aln.sequence = read;
+        const Alignment out = align_to_graph(aln, g->g, *a->a, flags & 1, flags & 2, flags & 4, flags & 8, flags & 16, flags & 32);
+        return emit_string(alignment_to_json(out), json_out, json_cap);
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+// cluster_subgraph_containing: seeds = n x (read begin, read end, node id, is_reverse, offset).  JSON out: like vgh_graph_algorithm.
+int vgh_cluster_subgraph(vgh_aligner* a, vgh_bigraph* g, int64_t read_length, const int64_t* seeds, int n, char* json_out, size_t json_cap) {
+    try {
+        Alignment aln; aln.sequence.assign((size_t)read_length, 'A');
+        std::vector<ClusterSeed> cluster;
+        for (int k = 0; k < n; ++k) { ClusterSeed s; s.begin = (size_t)seeds[5 * k]; s.end = (size_t)seeds[5 * k + 1]; s.start = as_position(seeds + 5 * k + 2); cluster.push_back(s); }
+        const LocalGraph d = cluster_subgraph_containing(g->g, aln, cluster, *a->a);
+        std::string js = "{\"nodes\":[";
+        bool first = true;
+        d.for_each_handle_v([&](const handle_t& h) { js += std::string(first ? "" : ",") + "[" + std::to_string(d.get_id(h)) + ",\"" + d.get_sequence(h) + "\"]"; first = false; });
+        js += "]}";
+        return emit_string(js, json_out, json_cap);
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }
 
 int64_t vgh_longest_detectable_gap_in_range(vgh_aligner* a, int64_t read_length, int64_t begin, int64_t end) {

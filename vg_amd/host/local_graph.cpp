@@ -173,34 +173,134 @@ std::unordered_map<handle_t, size_t, handle_hash> find_shortest_paths(const Hand
     return dist;
 }
 
+bool is_single_stranded(const HandleGraph* g) {
+    bool single = true;
+    g->for_each_handle_v([&](const handle_t& h) {
+        for (int left = 0; left < 2; ++left)
+            g->follow_edges_v(h, left == 1, [&](const handle_t& next) { if (g->get_is_reverse(next)) single = false; });
+    });
+    return single;
+}
+
+bool is_acyclic(const HandleGraph* g) {
+    // depth-first over oriented nodes; a walk that meets an oriented node still on its own stack closes a cycle
+    std::unordered_map<int64_t, uint8_t> colour;                               // 1 = on the stack, 2 = done
+    bool acyclic = true;
+    g->for_each_handle_v([&](const handle_t& fwd) {
+        for (int rev = 0; rev < 2 && acyclic; ++rev) {
+            const handle_t root = rev ? g->flip(fwd) : fwd;
+            if (colour.count(root.v)) continue;
+            struct Frame { handle_t h; std::vector<handle_t> next; size_t at; };
+            std::vector<Frame> stack;
+            auto open = [&](const handle_t& h) {
+                colour[h.v] = 1; stack.push_back({h, {}, 0});
+                g->follow_edges_v(h, false, [&](const handle_t& n) { stack.back().next.push_back(n); });
+            };
+            open(root);
+            while (!stack.empty() && acyclic) {
+                Frame& f = stack.back();
+                if (f.at == f.next.size()) { colour[f.h.v] = 2; stack.pop_back(); continue; }
+                const handle_t n = f.next[f.at++];
+                auto found = colour.find(n.v);
+                if (found == colour.end()) open(n);
+                else if (found->second == 1) acyclic = false;
+            }
+        }
+    });
+    return acyclic;
+}
+
+std::unordered_map<nid_t, std::pair<nid_t, bool>> split_strands(const HandleGraph* g, LocalGraph* into) {
+    if (into->get_node_count()) throw std::invalid_argument("split_strands: the output graph must be empty");
+    std::unordered_map<nid_t, std::pair<nid_t, bool>> to_source;
+    std::unordered_map<int64_t, handle_t> copy;                                // oriented node of g -> forward node of `into`
+    g->for_each_handle_v([&](const handle_t& h) {
+        for (int rev = 0; rev < 2; ++rev) {
+            const handle_t o = rev ? g->flip(h) : h;
+            const handle_t c = into->create_handle(g->get_sequence(o));
+            copy[o.v] = c; to_source[into->get_id(c)] = {g->get_id(h), rev == 1};
+        }
+    });
+    g->for_each_handle_v([&](const handle_t& h) {
+        for (int rev = 0; rev < 2; ++rev) {
+            const handle_t o = rev ? g->flip(h) : h;
+            g->follow_edges_v(o, false, [&](const handle_t& next) { into->create_edge(copy.at(o.v), copy.at(next.v)); });
+        }
+    });
+    return to_source;
+}
+
+namespace {
+Dagified dagify_impl(const HandleGraph* g, const std::vector<handle_t>& starts, bool whole_graph, LocalGraph* into, size_t min_preserved_path_length);
+}
 Dagified dagify_from(const HandleGraph* g, const std::vector<handle_t>& starts, LocalGraph* into, size_t min_preserved_path_length) {
-    if (into->get_node_count()) throw std::invalid_argument("dagify_from: the output graph must be empty");
+    return dagify_impl(g, starts, false, into, min_preserved_path_length);
+}
+std::unordered_map<nid_t, nid_t> dagify(const HandleGraph* g, LocalGraph* into, size_t min_preserved_path_length) {
+    return dagify_impl(g, {}, true, into, min_preserved_path_length).to_source;
+}
+namespace {
+Dagified dagify_impl(const HandleGraph* g, const std::vector<handle_t>& starts, bool whole_graph, LocalGraph* into, size_t min_preserved_path_length) {
+    if (into->get_node_count()) throw std::invalid_argument("dagify: the output graph must be empty");
     // 1. What the walks reach: a breadth-first search over (node, direction); direction 0 follows the edges, 1 runs against them.
     //    Nodes are numbered in the order they are first met; edges are kept as (index, index) along the forward strands.
+    //    A node is walked on ONE strand (the graph is single-stranded, though a node's strand may be its reverse).  The strands of a
+    //    whole connected component are fixed when a walk first touches it — the handle it is touched through runs WITH the edges —
+    //    by a search that ignores edge direction; a node that would need both strands is an error.  A later start on the other
+    //    orientation of a node of that component then names walks that run AGAINST the edges.
+    std::unordered_map<nid_t, uint8_t> strand_of;
+    auto orient_component = [&](const handle_t& first) {
+        std::deque<handle_t> q{first};
+        strand_of[g->get_id(first)] = g->get_is_reverse(first) ? 1 : 0;
+        while (!q.empty()) {
+            const handle_t h = q.front(); q.pop_front();
+            for (int left = 0; left < 2; ++left)
+                g->follow_edges_v(h, left == 1, [&](const handle_t& next) {
+                    const uint8_t along = g->get_is_reverse(next) ? 1 : 0;
+                    auto found = strand_of.find(g->get_id(next));
+                    if (found == strand_of.end()) { strand_of.emplace(g->get_id(next), along); q.push_back(next); }
+                    else if (found->second != along) throw std::runtime_error("dagify: node " + std::to_string(g->get_id(next)) + " is walked on both strands; split the strands first");
+                });
+        }
+    };
     std::unordered_map<nid_t, uint32_t> index_of;
     std::vector<nid_t> node_id;
-    std::vector<uint8_t> met;                                                  // bit d: met in direction d
+    std::vector<uint8_t> met;                                                  // bit d: met in direction d (0 with the edges, 1 against them)
+    std::vector<uint8_t> strand;
     std::vector<std::pair<uint32_t, uint32_t>> edges;
     std::set<std::pair<uint32_t, uint32_t>> have_edge;
     std::deque<std::pair<uint32_t, int>> todo;
     auto meet = [&](nid_t id, int dir) {
         auto found = index_of.find(id);
         uint32_t k;
-        if (found == index_of.end()) { k = (uint32_t)node_id.size(); index_of.emplace(id, k); node_id.push_back(id); met.push_back(0); }
+        if (found == index_of.end()) { k = (uint32_t)node_id.size(); index_of.emplace(id, k); node_id.push_back(id); met.push_back(0); strand.push_back(strand_of.at(id)); }
         else k = found->second;
         if (!(met[k] & (1 << dir))) { met[k] |= (uint8_t)(1 << dir); todo.emplace_back(k, dir); }
         return k;
     };
-    for (const handle_t& s : starts) meet(g->get_id(s), g->get_is_reverse(s) ? 1 : 0);
-    while (!todo.empty()) {
-        const uint32_t k = todo.front().first; const int dir = todo.front().second;
-        todo.pop_front();
-        g->follow_edges_v(g->get_handle(node_id[k], false), dir == 1, [&](const handle_t& next) {
-            if (g->get_is_reverse(next)) throw std::runtime_error("dagify_from: the graph joins a strand to a reverse strand; split its strands first");
-            const uint32_t j = meet(g->get_id(next), dir);
-            const auto e = dir == 0 ? std::make_pair(k, j) : std::make_pair(j, k);
-            if (have_edge.insert(e).second) edges.push_back(e);
+    auto walk_out = [&]() {
+        while (!todo.empty()) {
+            const uint32_t k = todo.front().first; const int dir = todo.front().second;
+            todo.pop_front();
+            g->follow_edges_v(g->get_handle(node_id[k], strand[k] != 0), dir == 1, [&](const handle_t& next) {
+                const uint32_t j = meet(g->get_id(next), dir);
+                const auto e = dir == 0 ? std::make_pair(k, j) : std::make_pair(j, k);
+                if (have_edge.insert(e).second) edges.push_back(e);
+            });
+        }
+    };
+    if (whole_graph) {          // dagify(): every node — in the graph's order, what a node's walks reach numbered before the next unmet node
+        g->for_each_handle_v([&](const handle_t& h) {
+            if (!strand_of.count(g->get_id(h))) orient_component(h);
+            meet(g->get_id(h), 0);
+            walk_out();
         });
+    } else {
+        for (const handle_t& s : starts) {
+            if (!strand_of.count(g->get_id(s))) orient_component(s);
+            meet(g->get_id(s), (g->get_is_reverse(s) ? 1 : 0) != strand_of.at(g->get_id(s)) ? 1 : 0);
+        }
+        walk_out();
     }
     const uint32_t n = (uint32_t)node_id.size();
     std::vector<std::vector<uint32_t>> out(n), in(n);
@@ -249,34 +349,38 @@ Dagified dagify_from(const HandleGraph* g, const std::vector<handle_t>& starts, 
         bool cyclic = m.size() > 1;
         for (uint32_t w : out[m[0]]) cyclic = cyclic || w == m[0];
         if (!cyclic) continue;
+        // below / here: bases walked from the END of the node a walk started on to the END of this copy (0 in layer 0: a walk may
+        // start on any of its nodes, and the node it starts on does not count — the contract of find_shortest_paths too).  The
+        // reference's known answers fix this reading: its 2-node loop of 2 + 2 bases takes 2 layers for 1 preserved base and 3 for 5
+        // (src/unittest/dagify.cpp:22-139, :140-268).
         std::unordered_map<uint32_t, size_t> below, here;
         for (uint32_t v : m) below[v] = 0;
         const size_t unreachable = SIZE_MAX / 4;
         for (;;) {
             size_t nearest = unreachable;
             for (uint32_t v : m) {                                             // ascending: in-layer predecessors are final
-                size_t best = unreachable;
+                size_t best = unreachable;                                     // ... to the START of this copy
                 for (uint32_t u : in[v]) {
                     if (comp[u] != c) continue;
                     const size_t from = u < v ? (here.count(u) ? here[u] : unreachable) : below[u];
-                    if (from < unreachable) best = std::min(best, from + len[u]);
+                    if (from < unreachable) best = std::min(best, from);
                 }
-                here[v] = best; nearest = std::min(nearest, best);
+                here[v] = best < unreachable ? best + len[v] : unreachable; nearest = std::min(nearest, best);
             }
             if (nearest >= min_preserved_path_length) break;
             ++layers[c]; copies += m.size();
             if (copies > 4000000u || layers[c] > min_preserved_path_length * m.size() + 1)
-                throw std::runtime_error("dagify_from: unrolling a cycle to " + std::to_string(min_preserved_path_length) + " bases takes too many copies");
+                throw std::runtime_error("dagify: unrolling a cycle to " + std::to_string(min_preserved_path_length) + " bases takes too many copies");
             below.swap(here); here.clear();
         }
     }
     // 4. The copies: layer 0 of every node in meeting order (so the starts come first), then the upper layers component by component.
     std::vector<std::vector<handle_t>> copy(n);
     Dagified result;
-    auto add = [&](uint32_t k) {
+    auto add = [&](uint32_t k) {                                               // (a copy keeps the node's forward strand; copy[] holds the handle walks pass it in)
         const handle_t h = into->create_handle(g->get_sequence(g->get_handle(node_id[k], false)));
         result.to_source[into->get_id(h)] = node_id[k];
-        copy[k].push_back(h);
+        copy[k].push_back(strand[k] ? into->flip(h) : h);
     };
     for (uint32_t k = 0; k < n; ++k) add(k);
     for (size_t c = 0; c < members.size(); ++c) for (uint32_t layer = 1; layer < layers[c]; ++layer) for (uint32_t v : members[c]) add(v);
@@ -288,11 +392,13 @@ Dagified dagify_from(const HandleGraph* g, const std::vector<handle_t>& starts, 
         else for (uint32_t layer = 0; layer + 1 < depth; ++layer) into->create_edge(copy[u][layer], copy[v][layer + 1]);
     }
     for (const handle_t& s : starts) {
-        const handle_t first = copy[index_of.at(g->get_id(s))][0];
-        result.starts.push_back(g->get_is_reverse(s) ? into->flip(first) : first);
+        const uint32_t k = index_of.at(g->get_id(s));
+        const handle_t first = copy[k][0];                                     // in the strand's orientation
+        result.starts.push_back((g->get_is_reverse(s) ? 1 : 0) != strand[k] ? into->flip(first) : first);
     }
     return result;
 }
+}  // namespace
 
 }  // namespace handlealgs
 
@@ -505,6 +611,54 @@ ExtendingGraph extract_extending_graph(const HandleGraph* source, LocalGraph* in
     result.cut_id = into->get_id(kept);
     if (result.to_source.size() != into->get_node_count()) throw std::logic_error("extract_extending_graph: translation and graph disagree");
     return result;
+}
+
+void extract_containing_graph(const HandleGraph* source, LocalGraph* into, const std::vector<Position>& positions,
+                              const std::vector<size_t>& forward_search_lengths, const std::vector<size_t>& backward_search_lengths,
+                              size_t reversing_walk_length) {
+    if (forward_search_lengths.size() != positions.size() || backward_search_lengths.size() != positions.size())
+        throw std::invalid_argument("extract_containing_graph: one forward and one backward search length per position");
+    if (into->get_node_count()) throw std::invalid_argument("extract_containing_graph: the output graph must be empty");
+    if (positions.empty()) return;
+    // One shortest-first search serves every position: a search that may go less far starts with the difference already spent
+    // (src/algorithms/extract_containing_graph.cpp:41-47).  The key of an oriented node is the distance walked when it is entered.
+    int64_t longest = 0;
+    for (size_t i = 0; i < positions.size(); ++i) longest = std::max<int64_t>(longest, (int64_t)std::max(forward_search_lengths[i], backward_search_lengths[i]));
+    // (the reference's queue re-prioritises: an oriented node is handed out once, at the smallest key pushed for it before that)
+    std::map<int64_t, int64_t> best; std::priority_queue<std::pair<int64_t, int64_t>, std::vector<std::pair<int64_t, int64_t>>, std::greater<std::pair<int64_t, int64_t>>> todo;
+    std::unordered_set<int64_t> done;
+    auto push = [&](const handle_t& h, int64_t dist) {
+        if (done.count(h.v)) return;
+        auto found = best.find(h.v);
+        if (found != best.end() && found->second <= dist) return;
+        best[h.v] = dist; todo.emplace(dist, h.v);
+    };
+    Harvest seen;
+    for (size_t i = 0; i < positions.size(); ++i) {
+        const Position& pos = positions[i];
+        const handle_t fwd = source->get_handle(pos.node_id, false);
+        seen.node(pos.node_id);
+        const int64_t dist_forward = -pos.offset + longest - (int64_t)forward_search_lengths[i];
+        const int64_t dist_backward = pos.offset - (int64_t)source->get_length(fwd) + longest - (int64_t)backward_search_lengths[i];
+        push(pos.is_reverse ? source->flip(fwd) : fwd, dist_forward);
+        push(pos.is_reverse ? fwd : source->flip(fwd), dist_backward);
+    }
+    while (!todo.empty()) {
+        const auto top = todo.top(); todo.pop();
+        if (done.count(top.second) || best[top.second] != top.first) continue;
+        done.insert(top.second);
+        const handle_t here{top.second};
+        seen.node(source->get_id(here));
+        const int64_t through = top.first + (int64_t)source->get_length(here);
+        if (through < longest)
+            source->follow_edges_v(here, false, [&](const handle_t& next) { seen.edges.emplace_back(here, next); push(next, through); });
+        if (reversing_walk_length > 0 && top.first > 0) {       // (not from a start: their keys are <= 0 ... as in the reference)
+            const handle_t flipped = source->flip(here);
+            source->follow_edges_v(flipped, false, [&](const handle_t& next) { seen.edges.emplace_back(flipped, next); push(next, longest - (int64_t)reversing_walk_length); });
+        }
+    }
+    for (nid_t id : seen.nodes) into->create_handle(source->get_sequence(source->get_handle(id, false)), id);
+    for (const edge_t& e : seen.edges) into->create_edge(same_in(into, source, e.first), same_in(into, source, e.second));
 }
 
 }  // namespace vgamd

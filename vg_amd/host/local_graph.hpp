@@ -10,10 +10,16 @@
 //   dagify_from                an acyclic graph holding every walk of up to a given length that leaves the given handles
 //   find_tips                  the handles nothing leads into
 //
-// The last two (and find_shortest_paths, which the strict pruning of the connecting graph uses) live in libhandlegraph, an empty
-// submodule of the reference snapshot: they are written here from their documented contracts, and whatever the contracts leave open
-// (node numbering, the order edges are listed in, how cycles are unrolled) is this file's own choice [PARITY-UNPINNED].  None of it
-// changes an alignment's score; it can only choose differently among equally good alignments.
+//   dagify / split_strands / is_acyclic / is_single_stranded / extract_containing_graph   what Mapper::align_to_graph strings together
+//                              (src/mapper.cpp:2425-2554, src/cluster.cpp:3832-3851; cluster_alignment.hpp)
+//
+// dagify, dagify_from, find_tips, split_strands (and find_shortest_paths, which the strict pruning of the connecting graph uses) live in
+// libhandlegraph, an empty submodule of the reference snapshot: they are written here from their documented contracts.  What the
+// reference's own unit tests hold about them IS checked (tests/test_graph_algorithms.py over tests/golden/ref_graph_algorithms.json:
+// src/unittest/dagify.cpp — 6 / 8 / 6 copies for the three small loops, which fixes how far a cycle is unrolled; every listed walk
+// preserved; dagify_from's tips — and the 39 extraction cases of src/unittest/vg_algorithms.cpp).  What those leave open (node
+// numbering, the order edges are listed in, which edges of a cycle climb to the next copy) is this file's own choice
+// [PARITY-UNPINNED]; none of it changes an alignment's score, it can only choose differently among equally good alignments.
 #pragma once
 #include <cstdint>
 #include <map>
@@ -99,6 +105,12 @@ std::unordered_map<handle_t, size_t, handle_hash> find_shortest_paths(const Hand
 // them; the extra copies that unroll a cycle follow.
 struct Dagified { std::unordered_map<nid_t, nid_t> to_source; std::vector<handle_t> starts; };
 Dagified dagify_from(const HandleGraph* g, const std::vector<handle_t>& starts, LocalGraph* into, size_t min_preserved_path_length);
+// the whole graph (handlealgs::dagify, as Mapper::align_cluster calls it: src/mapper.cpp:2508-2515): -> node of `into` -> node of g
+std::unordered_map<nid_t, nid_t> dagify(const HandleGraph* g, LocalGraph* into, size_t min_preserved_path_length);
+bool is_acyclic(const HandleGraph* g);                    // no directed walk returns to the oriented node it left (handlealgs::is_acyclic / is_directed_acyclic)
+bool is_single_stranded(const HandleGraph* g);            // no edge joins a forward strand to a reverse one (handlealgs::is_single_stranded)
+// every strand a forward node of a new graph (handlealgs::split_strands): -> node of `into` -> (node of g, is_reverse)
+std::unordered_map<nid_t, std::pair<nid_t, bool>> split_strands(const HandleGraph* g, LocalGraph* into);
 
 }  // namespace handlealgs
 
@@ -116,5 +128,12 @@ ConnectingGraph extract_connecting_graph(const HandleGraph* source, LocalGraph* 
 struct ExtendingGraph { std::unordered_map<nid_t, nid_t> to_source; nid_t cut_id = 0; };
 ExtendingGraph extract_extending_graph(const HandleGraph* source, LocalGraph* into, int64_t max_dist, const Position& pos, bool backward,
                                        bool preserve_cycles_on_src_node);
+
+// Everything within the given distances of any of the positions, forward and backward of each, whole nodes under their own ids
+// (behaviour of src/algorithms/extract_containing_graph.cpp; Mapper::align_cluster's cluster graph: src/cluster.cpp:3832-3851).
+// reversing_walk_length > 0 lets a walk turn around onto the other strand and run that much further.
+void extract_containing_graph(const HandleGraph* source, LocalGraph* into, const std::vector<Position>& positions,
+                              const std::vector<size_t>& forward_search_lengths, const std::vector<size_t>& backward_search_lengths,
+                              size_t reversing_walk_length = 0);
 
 }  // namespace vgamd
