@@ -31,22 +31,24 @@ char complement(char c) {
 
 // The wavefront form's slabs: per resident wavefront the table, its log, the path pool and the backtrace's edit runs, carved out of one
 // allocation per launch size; the table part must be all-zero before a launch (the kernel leaves it so).
-struct WaveSlabs { uint32_t waves, n_slots, max_points, path_cap; };
+struct WaveSlabs { uint32_t waves, n_slots, max_points, path_cap, mask_width; };
 int carve(vgk_ctx* ctx, WfaHost& H, int slot, const WaveSlabs& z, WwParams& W) {
     Backend* be = ctx->be.get();
     const uint64_t w = z.waves;
     const uint64_t b_slots = 8ull * z.n_slots * w, b_logs = 4ull * z.max_points * w, b_paths = sizeof(WwPath) * (uint64_t)z.path_cap * w, b_runs = 4ull * W_EDITS * w;
-    const uint64_t want = b_slots + b_logs + b_paths + b_runs + 64;
+    const uint64_t b_masks = 4ull * WW_MASK_ROWS * 3u * z.mask_width * w;           // the item filter's node sets (rows are cleared by the kernel before use)
+    const uint64_t want = b_slots + b_logs + b_paths + b_runs + b_masks + 64;
     char* base = (char*)ctx->ensure_scratch(slot, want);
     if (!base) return VGK_ENOMEM;
-    if (H.slab_ptr != base || H.slab_bytes < want || H.slab_shape != ((uint64_t)z.n_slots << 32 | z.waves)) {
+    if (H.slab_ptr != base || H.slab_bytes < want || H.slab_shape != ((uint64_t)z.n_slots << 32 | (uint64_t)z.mask_width << 20 | z.waves)) {
         if (be->zero(base, ctx->scratch[slot].bytes)) return VGK_ENODEV;
-        H.slab_ptr = base; H.slab_bytes = ctx->scratch[slot].bytes; H.slab_shape = (uint64_t)z.n_slots << 32 | z.waves;
+        H.slab_ptr = base; H.slab_bytes = ctx->scratch[slot].bytes; H.slab_shape = (uint64_t)z.n_slots << 32 | (uint64_t)z.mask_width << 20 | z.waves;
     }
     W.slots = (unsigned long long*)base; W.n_slots = z.n_slots;
     W.paths = (WwPath*)(base + b_slots); W.path_cap = z.path_cap;
     W.logs = (uint32_t*)(base + b_slots + b_paths); W.max_points = z.max_points;
     W.edit_runs = (uint32_t*)(base + b_slots + b_paths + b_logs);
+    W.node_masks = z.mask_width ? (uint32_t*)(base + b_slots + b_paths + b_logs + b_runs) : nullptr; W.mask_width = z.mask_width;
     return VGK_OK;
 }
 // one launch: every problem starts with the small tables in LDS; a wavefront runs what outgrows them again at once with its large slab
@@ -69,9 +71,11 @@ int launch_wave_form(vgk_ctx* ctx) {
             std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return st[4 * a + 2] > st[4 * b + 2]; });
             unsigned long long chunks = 0, points = 0, steps = 0;
             for (uint32_t i : idx) { chunks += st[4 * i + 2]; points += st[4 * i]; steps += st[4 * i + 1]; }
-            std::fprintf(stderr, "[wfa wave] %zu problems: %llu chunks, %llu points, %llu steps in all; heaviest (points, steps, chunks, trie nodes):", idx.size(), chunks, points, steps);
-            for (size_t k = 0; k < idx.size() && k < 8; ++k) std::fprintf(stderr, " (%u,%u,%u,%u)", st[4 * idx[k]], st[4 * idx[k] + 1], st[4 * idx[k] + 2], st[4 * idx[k] + 3]);
-            for (size_t q : {idx.size() / 100, idx.size() / 10, idx.size() / 2}) if (q < idx.size()) std::fprintf(stderr, " | rank %zu: (%u,%u,%u,%u)", q, st[4 * idx[q]], st[4 * idx[q] + 1], st[4 * idx[q] + 2], st[4 * idx[q] + 3]);
+            unsigned long long items = 0;
+            for (uint32_t i : idx) items += st[4 * i + 3] >> 8;
+            std::fprintf(stderr, "[wfa wave] %zu problems: %llu chunks, %llu points, %llu steps, %llu filtered items in all; heaviest (points, steps, chunks, trie nodes, items):", idx.size(), chunks, points, steps, items);
+            for (size_t k = 0; k < idx.size() && k < 8; ++k) std::fprintf(stderr, " (%u,%u,%u,%u,%u)", st[4 * idx[k]], st[4 * idx[k] + 1], st[4 * idx[k] + 2], st[4 * idx[k] + 3] & 255u, st[4 * idx[k] + 3] >> 8);
+            for (size_t q : {idx.size() / 100, idx.size() / 10, idx.size() / 2}) if (q < idx.size()) std::fprintf(stderr, " | rank %zu: (%u,%u,%u,%u,%u)", q, st[4 * idx[q]], st[4 * idx[q] + 1], st[4 * idx[q] + 2], st[4 * idx[q] + 3] & 255u, st[4 * idx[q] + 3] >> 8);
             std::fprintf(stderr, "\n");
         }
     }
@@ -86,7 +90,9 @@ int run_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P, bool after_threa
     if (const char* e = std::getenv("VGAMD_WFA_WAVES_PER_CU")) per_cu = (uint32_t)std::max(1, std::atoi(e));
     // the small size keeps its tables in LDS (256 points cover all but a percent or two of giraffe's links; the median is a dozen); the
     // large size: what a link with a 60-base insertion under the default error model stores, several times over
-    WaveSlabs z{after_threads ? cus * per_cu : std::min<uint32_t>(P.n, cus * per_cu), 32768u, 16384u, 2048u};
+    // (the item filter of the large size — wfa_wave_device.hpp, ww_chunk_of — keeps node sets for diagonals -256 .. 255; VGAMD_WFA_NO_FILTER
+    // switches it off for comparisons)
+    WaveSlabs z{after_threads ? cus * per_cu : std::min<uint32_t>(P.n, cus * per_cu), 32768u, 16384u, 2048u, std::getenv("VGAMD_WFA_NO_FILTER") ? 0u : 512u};
     WwParams A{};
     A.base = P;
     // a caller's point budget below the tables' own sizes ends a problem as before (vgk_wfa_set_point_budgets); 0 = none

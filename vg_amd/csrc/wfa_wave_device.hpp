@@ -59,12 +59,18 @@ struct WwParams {
     unsigned long long* slots; uint32_t n_slots;   // ... n_slots (a power of two) table slots ...
     uint32_t* logs; uint32_t max_points;            // ... max_points log entries (= points a problem may store) ...
     WwPath* paths; uint32_t path_cap;               // ... path_cap pool entries ...
+    uint32_t* node_masks; uint32_t mask_width;      // ... WW_MASK_ROWS x 3 x mask_width words: which trie nodes hold a point at (penalty mod WW_MASK_ROWS, kind, diagonal) — null: no item filter
     uint32_t* edit_runs;                            // ... and W_EDITS edit runs for the backtrace
     unsigned long long* n_declined;   // counts the problems the large size took over (nullable)
     uint32_t* stats;                  // nullable (VGAMD_WFA_STATS): per problem 4 words — stored points, penalty steps, chunks of items, trie nodes
 };
 
-template <bool SMALL> struct WwTables {};
+constexpr int WW_MASK_ROWS = 32;      // penalties whose node masks are kept at a time (a ring): more than any source wavefront lies back
+
+template <bool SMALL> struct WwTables {                                       // the large size: its tables are a slab in HBM; in LDS only ...
+    uint32_t sv[64];                  // ... a chunk in the making: per diagonal looked at, the leaves that have something to do there
+    uint32_t filter_off;              // ... and whether some diagonal has left the masks' width (then every item is looked at again, as in the small size)
+};
 template <> struct WwTables<true> {   // the small size keeps its tables in LDS
     unsigned long long slot[WW_SMALL_SLOTS]; uint16_t log[WW_SMALL_POINTS]; WwPath path[WW_SMALL_PATH]; uint32_t runs[W_EDITS];
 };
@@ -84,6 +90,7 @@ template <class XL, bool SMALL> struct WwCtx {
     const WwParams* P; WwShared<SMALL>* sh; XL* xl; uint32_t lane;
     unsigned long long* slot; uint32_t* log; WwPath* path; uint32_t* runs;      // the large size's slab (unused by the small one)
     uint32_t mask, max_points, path_cap;
+    uint32_t* masks; uint32_t mask_width;                                       // the item filter's node masks (large size; null = off)
     const char* seq; uint32_t L;
     int32_t to_node; uint32_t to_off; bool no_to;
     uint32_t grow_cap;                // bases a trie node is walked at its creation unless it ends earlier
@@ -91,7 +98,7 @@ template <class XL, bool SMALL> struct WwCtx {
     // this lane's findings, merged after every phase
     int32_t cand_score, cand_diag; uint32_t cand_seq, cand_off, cand_node, cand_leaf;
     int32_t max_distance;
-    uint32_t n_chunks, n_steps;       // (statistics)
+    uint32_t n_chunks, n_steps, n_items;      // (statistics)
     bool overflow; int why;           // why: 1 points, 2 trie nodes, 3 path pool, 4 edits, 5 node length, 6 walked end reached, 7 work list,
                                       // 8 table without a free slot, 9 broken path chain, 10 a loop ran past its bound (8-10: cannot happen; never hang)
     VGK_HD unsigned long long* tbl(uint32_t i) { if constexpr (SMALL) return sh->slot + i; else return slot + i; }
@@ -99,6 +106,12 @@ template <class XL, bool SMALL> struct WwCtx {
     VGK_HD uint32_t log_at(uint32_t k) const { if constexpr (SMALL) return sh->log[k]; else return log[k]; }
     VGK_HD WwPath& pth(uint32_t k) { if constexpr (SMALL) return sh->path[k]; else return path[k]; }
     VGK_HD uint32_t* run_buf() { if constexpr (SMALL) return sh->runs; else return runs; }
+    // the word that names the trie nodes holding a point of (kind, score, diag); null when the diagonal lies outside the masks
+    VGK_HD uint32_t* mask_word(int kind, int32_t score, int32_t diag) const {
+        const int32_t at = diag + (int32_t)(mask_width >> 1);
+        if (at < 0 || at >= (int32_t)mask_width) return nullptr;
+        return masks + ((size_t)((uint32_t)score % (uint32_t)WW_MASK_ROWS) * 3u + (uint32_t)kind) * mask_width + (uint32_t)at;
+    }
 };
 
 // ---- possible penalties ----
@@ -135,6 +148,12 @@ template <class XL, bool SMALL> VGK_HD bool ww_lookup(WwCtx<XL, SMALL>& c, uint3
     return found;
 }
 template <class XL, bool SMALL> VGK_HD void ww_store(WwCtx<XL, SMALL>& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t seq, uint32_t off) {
+    if constexpr (!SMALL) {
+        if (c.masks) {
+            uint32_t* w = c.mask_word(kind, score, diag);
+            if (w) c.xl->or32(w, 1u << node); else c.sh->filter_off = 1u;       // (read by everyone after the phase's fence)
+        }
+    }
     const uint32_t key = w_key(node, kind, score, diag);
     const unsigned long long v = ((unsigned long long)key << 32) | ((unsigned long long)(seq & 0xffffu) << 16) | (off & 0xffffu);
     uint32_t probes = 0;
@@ -297,6 +316,56 @@ template <class XL, bool SMALL> VGK_HD bool ww_any_overflow(WwCtx<XL, SMALL>& c)
 VGK_HD uint32_t ww_nth_bit(uint32_t mask, uint32_t n) { for (; n; --n) mask &= mask - 1; return (uint32_t)__builtin_ctz(mask); }
 VGK_HD uint32_t ww_popcount(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
 
+// ---- which items a chunk holds ----
+// The reference's step is two loops over a rectangle, (every diagonal of the wavefront) x (every leaf of the trie); with dozens of leaves
+// nine items in ten find no point to start from — a point lies on ONE trie node and serves only the leaves below it.  The large size keeps,
+// per (penalty, kind, diagonal), the set of trie nodes that hold a point (a 32-bit word, set by ww_store; WW_MASK_ROWS penalties at a time)
+// and looks at an item only if some node on its leaf's way to the root is in the sets its lookups would probe.  Items keep their order
+// (diagonal, then leaf), a chunk still holds whole diagonals — only more of them, up to 64 — and an item that is skipped is one the
+// full loop would have found nothing for: nothing observes the difference.  `m` = this lane's diagonal's (diag0 + lane) union of sets.
+template <class XL> VGK_HD uint32_t ww_chunk_of(WwCtx<XL, false>& c, int32_t diag0, int32_t hi, uint32_t m, int32_t& diag, uint32_t& leaf, bool& have) {
+    uint32_t sv = 0;
+    if (m) for (uint32_t rest = c.sh->leaves; rest; rest &= rest - 1) { const uint32_t l = (uint32_t)__builtin_ctz(rest); if (c.sh->nodes[l].ancestors & m) sv |= 1u << l; }
+    c.sh->sv[c.lane] = sv;
+    c.xl->fence();
+    uint32_t acc = 0, taken = 0;
+    have = false;
+    for (uint32_t j = 0; j < 64u && diag0 + (int32_t)j <= hi; ++j) {
+        const uint32_t w = c.sh->sv[j], cnt = (uint32_t)__builtin_popcount(w);
+        if (acc + cnt > 64u) break;                                            // (never the first diagonal: a trie has at most 32 leaves)
+        if (c.lane >= acc && c.lane < acc + cnt) {
+            have = true; diag = diag0 + (int32_t)j;
+            uint32_t rest = w; for (uint32_t n = c.lane - acc; n; --n) rest &= rest - 1;
+            leaf = (uint32_t)__builtin_ctz(rest);
+        }
+        acc += cnt; taken = j + 1;
+    }
+    c.xl->fence();                                                             // (sv belongs to the next chunk from here)
+    c.n_items += acc;
+    return taken;
+}
+template <class XL, bool SMALL> VGK_HD uint32_t ww_mask_at(WwCtx<XL, SMALL>& c, int kind, const WSrc& src, int32_t diag) {
+    if constexpr (SMALL) return 0xffffffffu;
+    else {
+        if (src.lo > src.hi || diag < src.lo || diag > src.hi) return 0u;
+        uint32_t* w = c.mask_word(kind, src.score, diag);
+        return w ? c.xl->load32(w) : 0xffffffffu;
+    }
+}
+// is the filter on for the coming chunk?  (the same answer on every lane: filter_off changes only between fences)
+template <class XL, bool SMALL> VGK_HD bool ww_filtering(WwCtx<XL, SMALL>& c) {
+    if constexpr (SMALL) return false;
+    else { if (!c.masks) return false; c.xl->fence(); return c.sh->filter_off == 0u; }
+}
+template <class XL, bool SMALL> VGK_HD void ww_clear_masks(WwCtx<XL, SMALL>& c, int32_t score) {       // a penalty's sets, before its first point is stored
+    if constexpr (!SMALL) {
+        if (!c.masks) return;
+        uint32_t* row = c.masks + (size_t)((uint32_t)score % (uint32_t)WW_MASK_ROWS) * 3u * c.mask_width;
+        for (uint32_t j = c.lane; j < 3u * c.mask_width; j += 64u) row[j] = 0u;
+        c.xl->fence();
+    }
+}
+
 // ---- extend(): an item runs until it is done or needs a node expanded ----
 struct WwItem { int st; uint32_t qh, qt, sp, key_leaf, blocked_on; WPos pos; bool creator; };
 
@@ -383,15 +452,19 @@ template <class XL, bool SMALL> VGK_HD void ww_extend(WwCtx<XL, SMALL>& c, int32
     const WSrc here = { score, ps.min_d, ps.max_d };
     for (int32_t diag0 = ps.min_d; diag0 <= ps.max_d;) {
         const uint32_t leaves = c.sh->leaves, n_leaves = ww_popcount(leaves);
-        const uint32_t fit = 64u / n_leaves, left = (uint32_t)(ps.max_d - diag0 + 1), n_diag = fit < left ? fit : left;
+        uint32_t n_diag;
         ++c.n_chunks;
         WwItem it; it.st = WX_DONE; it.qh = it.qt = 0; it.sp = 0; it.key_leaf = 0; it.blocked_on = 0; it.creator = false; it.pos = w_none();
         int32_t diag = diag0;
-        if (c.lane < n_diag * n_leaves) {
-            diag = diag0 + (int32_t)(c.lane / n_leaves);
-            const uint32_t top = ww_nth_bit(leaves, c.lane % n_leaves);
-            c.sh->queue[c.lane][0] = (uint8_t)top; it.qt = 1; it.st = WX_FETCH;
+        bool have = false; uint32_t top = 0;
+        if (ww_filtering(c)) {
+            if constexpr (!SMALL) n_diag = ww_chunk_of(c, diag0, ps.max_d, ww_mask_at(c, WK_MATCH, here, diag0 + (int32_t)c.lane), diag, top, have);
+        } else {
+            const uint32_t fit = 64u / n_leaves, left = (uint32_t)(ps.max_d - diag0 + 1);
+            n_diag = fit < left ? fit : left;
+            if (c.lane < n_diag * n_leaves) { have = true; diag = diag0 + (int32_t)(c.lane / n_leaves); top = ww_nth_bit(leaves, c.lane % n_leaves); }
         }
+        if (have) { c.sh->queue[c.lane][0] = (uint8_t)top; it.qt = 1; it.st = WX_FETCH; }
         for (uint32_t rounds = 0;; ++rounds) {
             if (rounds > 64u * W_NODES) { c.overflow = true; c.why = 10; }
             if (it.st != WX_DONE && it.st != WX_BLOCKED) ww_extend_run(c, here, score, diag, it);
@@ -425,15 +498,26 @@ template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t
     if (lo <= hi) { --lo; ++hi; }
     int32_t alo = 32767, ahi = -32768;
     const WSrc src_mismatch = ww_src(c, score - B.mismatch), src_open = ww_src(c, score - B.gap_open - B.gap_extend), src_extend = ww_src(c, score - B.gap_extend);
+    ww_clear_masks(c, score);
     for (int32_t diag0 = lo; diag0 <= hi;) {
         const uint32_t leaves = c.sh->leaves, n_leaves = ww_popcount(leaves);
-        const uint32_t fit = 64u / n_leaves, left = (uint32_t)(hi - diag0 + 1), n_diag = fit < left ? fit : left;
+        uint32_t n_diag;
         ++c.n_chunks;
         uint32_t want = W_NODES;                                               // the node this item asks to have expanded
-        int32_t diag = diag0; uint32_t leaf = 0; bool have_cand = false;
-        if (c.lane < n_diag * n_leaves) {
-            diag = diag0 + (int32_t)(c.lane / n_leaves);
-            leaf = ww_nth_bit(leaves, c.lane % n_leaves);
+        int32_t diag = diag0; uint32_t leaf = 0; bool have_cand = false, have = false;
+        if (ww_filtering(c)) {
+            if constexpr (!SMALL) {
+                const int32_t d = diag0 + (int32_t)c.lane;
+                const uint32_t m = d > hi ? 0u : ww_mask_at(c, WK_MATCH, src_mismatch, d) | ww_mask_at(c, WK_MATCH, src_open, d - 1) | ww_mask_at(c, WK_INS, src_extend, d - 1) |
+                                                 ww_mask_at(c, WK_MATCH, src_open, d + 1) | ww_mask_at(c, WK_DEL, src_extend, d + 1);
+                n_diag = ww_chunk_of(c, diag0, hi, m, diag, leaf, have);
+            }
+        } else {
+            const uint32_t fit = 64u / n_leaves, left = (uint32_t)(hi - diag0 + 1);
+            n_diag = fit < left ? fit : left;
+            if (c.lane < n_diag * n_leaves) { have = true; diag = diag0 + (int32_t)(c.lane / n_leaves); leaf = ww_nth_bit(leaves, c.lane % n_leaves); }
+        }
+        if (have) {
             const uint32_t anc = c.sh->nodes[leaf].ancestors;
             WPos ins;
             { const WPos open = ww_find_in(c, WK_MATCH, src_open, anc, leaf, diag - 1, true, false), ext = ww_find_in(c, WK_INS, src_extend, anc, leaf, diag - 1, true, false);
@@ -551,13 +635,17 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
     c.P = &P; c.sh = &sh; c.xl = &xl; c.lane = lane;
     uint32_t own_points;                                                      // this launch's own limit (a caller's budget may lie below it)
     if constexpr (SMALL) {
-        c.slot = nullptr; c.log = nullptr; c.path = nullptr; c.runs = nullptr;
+        c.slot = nullptr; c.log = nullptr; c.path = nullptr; c.runs = nullptr; c.masks = nullptr; c.mask_width = 0;
         c.mask = WW_SMALL_SLOTS - 1; c.path_cap = WW_SMALL_PATH;
         own_points = P.small_points && P.small_points < (uint32_t)WW_SMALL_POINTS ? P.small_points : (uint32_t)WW_SMALL_POINTS;
     } else {
         c.slot = P.slots + (size_t)slab * P.n_slots; c.mask = P.n_slots - 1; c.log = P.logs + (size_t)slab * P.max_points;
         c.path = P.paths + (size_t)slab * P.path_cap; c.path_cap = P.path_cap; c.runs = P.edit_runs + (size_t)slab * W_EDITS;
         own_points = P.max_points;
+        // the item filter needs every source wavefront of a step inside the ring of penalties it keeps
+        const bool ring_holds = B.mismatch < WW_MASK_ROWS && B.gap_open + B.gap_extend < WW_MASK_ROWS && B.gap_extend > 0;
+        c.masks = P.node_masks && ring_holds ? P.node_masks + (size_t)slab * WW_MASK_ROWS * 3u * P.mask_width : nullptr; c.mask_width = P.mask_width;
+        if (lane == 0) sh.filter_off = 0u;
     }
     c.seq = B.seqs + pb.seq_off; c.L = pb.seq_len;
     c.no_to = pb.to_node == VGK_WFA_NO_NODE; c.to_node = (int32_t)pb.to_node; c.to_off = pb.to_off;
@@ -565,10 +653,11 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
     // no position gets further into a trie node than the sequence plus the deletions the score cap pays for (+ where the root starts)
     c.grow_cap = c.L + (uint32_t)(pb.score_bound / B.gap_extend) + 2u;
     c.cand_score = 0x7fffffff; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0; c.cand_leaf = 0;
-    c.max_distance = 0; c.min_distance = 0; c.overflow = false; c.why = 0; c.n_chunks = 0; c.n_steps = 0;
+    c.max_distance = 0; c.min_distance = 0; c.overflow = false; c.why = 0; c.n_chunks = 0; c.n_steps = 0; c.n_items = 0;
     const int32_t top_score = pb.score_bound + B.gap_open + B.gap_extend + B.mismatch;
     for (int32_t s = (int32_t)lane; s <= top_score && s < W_SCORES; s += 64) sh.ps_flags[s] = 0;
     if (lane < (uint32_t)W_NODES) sh.expanded_at[lane] = 0;
+    ww_clear_masks(c, 0);
     if (lane == 0) {
         sh.n_nodes = 0; sh.n_path = 0; sh.n_points = 0; sh.leaves = 0;
         const uint32_t root_rec = B.index.rec_off[pb.from_node];
@@ -725,7 +814,7 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
             out.status = VGK_ETOOBIG; out.ok = 0; out.score = c.why; out.node_offset = 0; out.length = 0;
         }
         if (!retry) B.results[i] = out;
-        if (P.stats && !retry) { P.stats[4 * i] = sh.n_points; P.stats[4 * i + 1] = c.n_steps; P.stats[4 * i + 2] = c.n_chunks; P.stats[4 * i + 3] = sh.n_nodes; }
+        if (P.stats && !retry) { P.stats[4 * i] = sh.n_points; P.stats[4 * i + 1] = c.n_steps; P.stats[4 * i + 2] = c.n_chunks; P.stats[4 * i + 3] = sh.n_nodes | (c.n_items << 8); }      // (items: those the filter let through; 0 when every item is looked at)
     }
     retry = xl.bcast(retry ? 1u : 0u, 0) != 0u;
     // leave the table all-zero: the touched slots from the log, or everything when the log ran over
