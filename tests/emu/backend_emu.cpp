@@ -295,8 +295,9 @@ public:
                 for (uint32_t l = 0; l < 64; ++l) {
                     if ((t & 3u) == 0) lane_prefetch(lanes[l], P, t);
                     const uint32_t rh = l ? oh[l - 1] : 0, rf = l ? of[l - 1] : 0, ri = l ? oi[l - 1] : 0;
-                    uint32_t* tb = P.want_tb ? P.tb + tb_dword(wd.tb_off, t, l, REC) : nullptr;
-                    lane_step<K, S8>(lanes[l], P, t, rh, rf, ri, tb);
+                    uint32_t* tb_a = P.want_tb ? P.tb + tb_dword(wd.tb_off, t, l, REC, 0) : nullptr;
+                    uint32_t* tb_b = P.want_tb && REC > 4 ? P.tb + tb_dword(wd.tb_off, t, l, REC, 4) : nullptr;
+                    lane_step<K, S8>(lanes[l], P, t, rh, rf, ri, tb_a, tb_b);
                 }
             }
             for (uint32_t l = 0; l < 64; ++l) for (int half = 0; half < 2; ++half) {

@@ -17,11 +17,51 @@ static __device__ __forceinline__ uint32_t from_lane_above(uint32_t x) {
 }
 
 // Fill: 4 independent wavefronts per workgroup; each wavefront owns
-// floor(64/G) read pairs for the whole skewed sweep.  No LDS, no barriers.
+// floor(64/G) read pairs for the whole skewed sweep.  No barriers; LDS only as the staging buffer of the traceback records (below).
 // Occupancy: K = 16 fits 128 VGPRs (4 waves/SIMD); K = 20/24 keep 4K+ state registers per
 // lane and run 3 waves/SIMD (<= 168 VGPRs) rather than spill in the hot loop.
+// Traceback records on their way out (tiled layout, gssw_device.hpp): a wavefront keeps the records of TB_TILE = 8 steps in LDS — written
+// step-major, one 16-byte slot per lane and step (slot index XOR step: the flush below then reads conflict-free too) plus the part-B
+// dwords — and every eighth step copies the tile to HBM in the layout the walker reads: 8 + 2 (K = 19 / 20) whole-wave 1-KB bursts per
+// tile instead of two partial stores per step.  10 KB of LDS per wavefront (K = 19 / 20; 8 for K = 16, 12 for K = 24): 3 (4) wavefronts per
+// SIMD still fit a CU's 160 KB.  One wavefront owns its buffer and LDS executes a wavefront's instructions in order: no barrier.
+template <int K>
+struct TbStage {
+    static constexpr uint32_t REC = (K + 3) / 4, RB = REC - 4;                // dwords per record; of them in part B
+    static constexpr uint32_t DWORDS = TB_TILE * 64u * REC;
+    uint32_t* lds;                                                            // this wavefront's buffer: [8][64] x 16 B, then [8][64] x RB dwords
+    __device__ __forceinline__ uint32_t* slot_a(uint32_t t, uint32_t lane) const { const uint32_t s = t % TB_TILE; return lds + (s * 64u + (lane ^ s)) * 4u; }
+    __device__ __forceinline__ uint32_t* slot_b(uint32_t t, uint32_t lane) const { return lds + TB_TILE * 64u * 4u + ((t % TB_TILE) * 64u + lane) * RB; }
+    __device__ __forceinline__ void flush(uint32_t* tile, uint32_t lane) const {      // tile = where this tile starts in HBM
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t j = 0; j < TB_TILE; ++j) {                              // part A: 16-byte slot g of the tile = (lane g / 8, step g % 8)
+            const uint32_t g = j * 64u + lane, L = g / TB_TILE, s = g % TB_TILE;
+            const uint4 v = *reinterpret_cast<const uint4*>(lds + (s * 64u + (L ^ s)) * 4u);
+            reinterpret_cast<uint4*>(tile)[g] = v;
+        }
+        if constexpr (RB > 0) {
+            uint32_t* part_b = tile + TB_TILE * 64u * 4u;
+            const uint32_t* lb = lds + TB_TILE * 64u * 4u;
+#pragma unroll
+            for (uint32_t j = 0; j < 2u * RB; ++j) {                          // part B: dword d of it = (record d / RB, component d % RB), record r = (lane r / 8, step r % 8)
+                const uint32_t q = j * 64u + lane;
+                uint4 v; uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+                for (uint32_t c = 0; c < 4u; ++c) { const uint32_t d = 4u * q + c, r = d / RB, L = r / TB_TILE, st = r % TB_TILE; w[c] = lb[(st * 64u + L) * RB + d % RB]; }
+                reinterpret_cast<uint4*>(part_b)[q] = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
 template <int K, bool S8>
 __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const GsswParams P) {
+    constexpr uint32_t REC = (K + 3) / 4;   // dwords per (step, lane) traceback record
+    __shared__ __attribute__((aligned(16))) uint32_t stage_lds[4][TB_TILE > 1 ? TbStage<K>::DWORDS : 256u];      // (also the fused walk's best keys, below)
     const uint32_t wave = P.wave_begin + blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     if (wave >= P.wave_begin + P.wave_count) return;
@@ -29,14 +69,18 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
     Lane<K> s;
     lane_init(s, P, wd, lane);
     asm volatile("" : "+v"(s.one));   // keep min(x,1) a packed min instead of cmp+cndmask
-    constexpr uint32_t REC = (K + 3) / 4;   // dwords per (step, lane) traceback record
     uint32_t* tb = P.want_tb ? P.tb : nullptr;
+    TbStage<K> stage{stage_lds[threadIdx.x >> 6]};
     for (uint32_t t = 0; t < wd.n_steps; ++t) {
         if ((t & 3u) == 0) lane_prefetch(s, P, t);
         const uint32_t rh = from_lane_above(s.out_h);
         const uint32_t rf = from_lane_above(s.out_f);
         const uint32_t ri = from_lane_above(s.info);
-        lane_step<K, S8>(s, P, t, rh, rf, ri, tb ? tb + tb_dword(wd.tb_off, t, lane, REC) : nullptr);
+        if constexpr (TB_TILE > 1) {
+            lane_step<K, S8>(s, P, t, rh, rf, ri, tb ? stage.slot_a(t, lane) : nullptr, stage.slot_b(t, lane));
+            if (tb && ((t % TB_TILE) == TB_TILE - 1u || t + 1u == wd.n_steps)) stage.flush(tb + tb_tile_base(wd.tb_off, t, REC), lane);
+        } else
+            lane_step<K, S8>(s, P, t, rh, rf, ri, tb ? tb + tb_dword(wd.tb_off, t, lane, REC, 0) : nullptr, tb ? tb + tb_dword(wd.tb_off, t, lane, REC, 4) : nullptr);
     }
     if (!P.fused) {
 #pragma unroll
@@ -49,8 +93,7 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
     // Fused traceback: the wavefront that filled a read pair also walks it back while its
     // traceback codes are still in L2 / Infinity Cache.  The walk is a latency-bound pointer
     // chase (one lane per read); the other wavefronts resident on the SIMD keep the VALU busy.
-    __shared__ unsigned long long wbest[4][128];
-    unsigned long long* mine = wbest[threadIdx.x >> 6];
+    unsigned long long* mine = reinterpret_cast<unsigned long long*>(stage_lds[threadIdx.x >> 6]);      // 128 keys: 1 KB of the wavefront's staging buffer
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         uint32_t prob; unsigned long long key = 0;

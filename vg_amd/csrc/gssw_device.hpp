@@ -283,6 +283,27 @@ VGK_HD void store_to_scratch(const Lane<K>& s, const GsswParams& P, uint32_t pro
     }
 }
 
+// Where (step t, lane)'s traceback record lies.  Shipped: STEP-MAJOR (VGK_TB_TILED=0: every wave store one contiguous burst of 64*K
+// bytes; a walker's consecutive cells lie 64*K bytes apart).  Round 3 built and measured the TILED form (VGK_TB_TILED=1, tests and the
+// emulator run with either): walk 4.54 -> 3.75 ms per million reads, but the fill 20.09 -> 21.94 ms although its tiles go through LDS and
+// leave as whole bursts — a net loss of 1.05 ms per step, so it stays a build option.  Tiled: the records of TB_TILE = 8
+// consecutive steps of a lane lie next to each other, split in two parts: part A = the record's first four dwords (rows 0-15 of the lane; 8 steps x 16 B = one 128-byte line per
+// lane), part B = the rest (K = 19 / 20: one dword, K = 24: two).  A tile is [64 lanes x 8 steps x 16 B][64 lanes x 8 steps x part B].
+// The walk moves one step back per cell and stays in its lane for K rows: the eight cells it fetches together lie in one or two lines
+// instead of eight.  The fill writes a tile through LDS (backend_hip.hip) so that its global stores stay whole bursts.
+#ifndef VGK_TB_TILED
+#define VGK_TB_TILED 0
+#endif
+struct alignas(16) VgkU4 { uint32_t v[4]; };
+constexpr uint32_t TB_TILE = VGK_TB_TILED ? 8 : 1;      // consecutive steps of a lane that lie next to each other
+VGK_HD uint64_t tb_tile_base(uint64_t tb_off, uint32_t t, uint32_t rec_dwords) { return tb_off + (uint64_t)(t / TB_TILE) * (64u * TB_TILE * rec_dwords); }
+VGK_HD uint64_t tb_dword(uint64_t tb_off, uint32_t t, uint32_t lane, uint32_t rec_dwords, uint32_t j) {
+    if (TB_TILE == 1) return tb_off + ((uint64_t)t * 64u + lane) * rec_dwords + j;
+    const uint64_t base = tb_tile_base(tb_off, t, rec_dwords);
+    const uint32_t at = lane * TB_TILE + t % TB_TILE;
+    return j < 4u ? base + at * 4u + j : base + 64u * TB_TILE * 4u + at * (rec_dwords - 4u) + (j - 4u);
+}
+
 // best-cell key of a row: score*32 + (31 - row_in_lane), so one packed max keeps
 // the best score and, on ties, the smallest row (scores stay below 2047).
 constexpr uint32_t KEY_SHIFT = 5, KEY_LOW = 31;
@@ -371,9 +392,10 @@ VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t di
 
 // One step of one lane.  rh/rf/rinfo are lane-1's out_h/out_f/info from the
 // previous step (ignored by group leaders, which start a fresh column).
-// tbrec = this (step, lane)'s ceil(K/4)-dword traceback record, or nullptr.
+// tb_a / tb_b = where this (step, lane)'s ceil(K/4)-dword traceback record goes — its first four dwords and the rest (the two parts
+// of the tiled layout; in the step-major form tb_b = tb_a + 4) —, or nullptr.
 template <int K, bool S8>
-VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tbrec) {
+VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tb_a, uint32_t* tb_b) {
     if (s.g == 0) { rh = 0; rf = 0; rinfo = fetch_info(s, P, t); }
     s.info = rinfo;
     const uint32_t ia = rinfo & 0xffu, ib = (rinfo >> 16) & 0xffu;
@@ -390,9 +412,16 @@ VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, 
         uint32_t acc[(K + 3) / 4], colkey;
         if (nA || nB) lane_rows<K, true, S8>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
         else          lane_rows<K, false, S8>(s, P, sel, diag0, rf, false, false, acc, colkey);
-        if (tbrec) {
+        if (tb_a) {
+            if (TB_TILE > 1) {                                                 // part A is a 16-byte slot: one store
+                VgkU4 v; v.v[0] = acc[0]; v.v[1] = acc[1]; v.v[2] = acc[2]; v.v[3] = acc[3];
+                *reinterpret_cast<VgkU4*>(tb_a) = v;
 #pragma unroll
-            for (int j = 0; j < (K + 3) / 4; ++j) tbrec[j] = acc[j];
+                for (int j = 4; j < (K + 3) / 4; ++j) tb_b[j - 4] = acc[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < (K + 3) / 4; ++j) { if (j < 4) tb_a[j] = acc[j]; else tb_b[j - 4] = acc[j]; }
+            }
         }
         // local end cell: first column with the best score, smallest row (SSW end_ref/end_read rule)
         const uint32_t klo = colkey & 0xffffu, khi = colkey >> 16;
@@ -424,18 +453,6 @@ VGK_HD bool lane_best(const Lane<K>& s, int half, uint32_t& prob, unsigned long 
 // ---------------------------------------------------------------------------
 // traceback walker: one thread per read
 // ---------------------------------------------------------------------------
-// Dword index of (step t, lane)'s traceback record: step-major, so every wave store is one contiguous
-// burst of 64*K bytes.  (A layout with 8 consecutive steps of a lane adjacent was measured: kinder to the
-// walker's diagonal moves but 3-10 % slower fill stores and no faster overall — DESIGN.md §5.)
-#ifndef VGK_TB_TILE
-#define VGK_TB_TILE 1
-#endif
-constexpr uint32_t TB_TILE = VGK_TB_TILE;       // consecutive steps of a lane that lie next to each other
-VGK_HD uint64_t tb_dword(uint64_t tb_off, uint32_t t, uint32_t lane, uint32_t rec_dwords) {
-    if (TB_TILE == 1) return tb_off + ((uint64_t)t * 64u + lane) * rec_dwords;
-    return tb_off + (((uint64_t)(t / TB_TILE) * 64u + lane) * TB_TILE + t % TB_TILE) * rec_dwords;
-}
-
 #ifndef VGK_WALK_SPEC
 #define VGK_WALK_SPEC 8
 #endif
@@ -446,9 +463,9 @@ struct Walker {
     VGK_HD uint32_t code(uint32_t r, uint32_t c) const {
         const uint32_t g = r / K, m = r - g * K, t = c + g, j = m >> 2, i = m & 3u;
 #if defined(VGK_WALK_EXP) && VGK_WALK_EXP >= 1      // timing experiments only (results are wrong): the codes come out of a region that stays in L2 (1) / L1 (2, 3)
-        const uint32_t w = P.tb[tb_off + ((tb_dword(0, t, lane0 + g, (K + 3) >> 2) + j) & (VGK_WALK_EXP == 1 ? 0x3ffffu : 0xfffu))];
+        const uint32_t w = P.tb[tb_off + (tb_dword(0, t, lane0 + g, (K + 3) >> 2, j) & (VGK_WALK_EXP == 1 ? 0x3ffffu : 0xfffu))];
 #else
-        const uint32_t w = P.tb[tb_dword(tb_off, t, lane0 + g, (K + 3) >> 2) + j];
+        const uint32_t w = P.tb[tb_dword(tb_off, t, lane0 + g, (K + 3) >> 2, j)];
 #endif
         const uint32_t last = (4 * j + 3 < K ? 4 * j + 3 : K - 1) - 4 * j;      // a lane's last dword holds K % 4 rows when K is no multiple of 4
         const uint32_t raw = (w >> (16 * half + 4 * (last - i))) & 15u;
