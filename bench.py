@@ -32,14 +32,27 @@ RDEV = "cpu" if os.environ.get("VGAMD_BENCH_ONE_DEVICE") == "1" else "cuda"     
 # FETCH_SIZE and --pmc WRITE_SIZE in separate runs of the same workload; KiB per launch, FETCH_SIZE doubled as MI355X_MICROARCH.md
 # prescribes for gfx950).  bench.py cannot read counters itself, so `roofline.traffic` = this figure x the units of one launch and
 # `traffic_source` says so; re-measure with tools/collect_r02.sh.
-PMC_BYTES_PER_UNIT = {
-    "linear": (2 * 704590 + 13574060) * 1024 / 400000,       # pmc_{fetch,write}_400k.csv: gssw_fill_kernel<19,true>, 400 000 reads per launch (unchanged since r01)
-    "banded": (2 * 406349 + 2245028) * 1024 / 100000,         # pmc_*_banded_100k.csv: the banded_fill_kernel classes, 100 000 problems
-    "gapless": (2 * 11460323 + 2860944) * 1024 / 1000000,     # pmc_*_gapless_1M.csv: gapless_search_kernel + gapless_rules_kernel + gapless_kernel, 1 000 000 reads
-                                                              # (the nested kernel earlier in r02: 2 x 6 135 420 + 2 654 011; r01: 2 x 16 202 932 + 3 269 559)
-    "wfa": (2 * 4094544 + 1914811) * 1024 / 500000,           # pmc_*_wfa_500k.csv: wfa_kernel, 500 000 problems
-}
-TRAFFIC_SOURCE = "stored constant from the rocprofv3 PMC passes in profiles/r02 (not measured in this run), scaled by the units of one launch"
+def _pmc_constants():
+    """profiles/pmc_constants.json (tools/collect_r03.sh + tools/pmc_constants.py): per workload the counter bytes per unit and the commit
+    they were measured at; round 2's figures stand in for a workload the file does not hold."""
+    r02 = {"linear": (2 * 704590 + 13574060) * 1024 / 400000, "banded": (2 * 406349 + 2245028) * 1024 / 100000,
+           "gapless": (2 * 11460323 + 2860944) * 1024 / 1000000, "wfa": (2 * 4094544 + 1914811) * 1024 / 500000}
+    values = dict(r02); source = {k: "profiles/r02 (commit not recorded)" for k in r02}
+    try:
+        for k, v in json.load(open(os.path.join(ROOT, "profiles", "pmc_constants.json"))).items():
+            values[k] = v["bytes_per_unit"]; source[k] = "%s at commit %s" % (", ".join(v["files"]), v["commit"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return values, source
+
+
+PMC_BYTES_PER_UNIT, PMC_SOURCE = _pmc_constants()
+
+
+def traffic_source(workload):
+    return "stored constant from the rocprofv3 PMC passes %s (not measured in this run), scaled by the units of one launch" % PMC_SOURCE[workload]
+
+
 
 
 def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
@@ -100,7 +113,7 @@ def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
                        "end_to_end_from_host_buffers_reads_per_s": n / te, "parallelism": "read-sharded x%d" % world,
                        "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "limiter": "memory latency (a lane owns 128 B of L2: every hop fetches its record, bases and read words from beyond it) and divergent instruction issue, not bandwidth (DESIGN.md §11): `frac` prices the algorithmic bytes against the HBM peak as the contract asks", "kernel": "gapless_search_kernel + gapless_rules_kernel (+ gapless_kernel for reads that outgrow the LDS queue)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["gapless"] * n, "traffic_source": TRAFFIC_SOURCE, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["gapless"] * n, "traffic_source": traffic_source("gapless"), "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
                          "kernel_only_reads_per_s": n / (k * 1e-3)},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum()),
             "full_length_fraction": float(res["full_length"].mean())}))
@@ -174,8 +187,8 @@ def bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus):
                        "timed_region": "K launches of wfa_kernel on the batch resident in HBM (vgk_wfa_rerun)",
                        "end_to_end_from_host_buffers_alignments_per_s": n / te, "parallelism": "problem-sharded x%d" % world,
                        "device": dev_name, "compute_units": cus, "sequence_bases": wl.bases},
-            "roofline": {"bound": "hbm", "limiter": "memory latency on each thread's dependent chain and lane divergence, not bandwidth (DESIGN.md §12)", "kernel": "wfa_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["wfa"] * n, "traffic_source": TRAFFIC_SOURCE, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
+            "roofline": {"bound": "hbm", "limiter": "memory latency on each thread's dependent chain and lane divergence, not bandwidth (DESIGN.md §12)", "kernel": {"thread": "wfa_kernel", "wave": "wfa_wave_kernel"}.get(os.environ.get("VGAMD_WFA_KERNEL", ""), "wfa_kernel + wfa_wave_kernel (hybrid: a problem is handed to a wavefront at 128 points)"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["wfa"] * n, "traffic_source": traffic_source("wfa"), "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
                          "kernel_only_alignments_per_s": n / (k * 1e-3)},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum()),
             "aligned_fraction": float(res["ok"].mean())}))
@@ -244,7 +257,7 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
                        "end_to_end_from_host_buffers_alignments_per_s": n / te,
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "limiter": "VALU issue: 1.74 G VALU wave-instructions per launch = 2.8 ms on 1024 SIMDs; ~41 VALU per wave-column of <= 64 cells inside the read, plus the per-node work (DESIGN.md §10)", "kernel": "banded_fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["banded"] * n, "traffic_source": TRAFFIC_SOURCE, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": fill,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["banded"] * n, "traffic_source": traffic_source("banded"), "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": fill,
                          "traceback_ms": walk, "band_cells": cells, "gcups_fill": cells / (fill * 1e-3) / 1e9,
                          "kernel_only_alignments_per_s": n / ((fill + walk) * 1e-3)},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum())}))
@@ -335,7 +348,7 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
                        "with_point_budgets": {"connect": budget, "tail": tail_budget, "reads_per_s": n * world * args.steps / b_elapsed, "ms_per_step": 1e3 * b_elapsed / args.steps,
                                               "links": b_out["stats"], "stage_ms": {k: 1e3 * v / args.steps for k, v in b_timing.items()}, "wfa_kernel_ms": b_out["wfa_kernel_ms"]},
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
-            "roofline": {"bound": "hbm", "kernel": "wfa_kernel", "limiter": "the critical path of the slowest problem of a launch, then memory latency (DESIGN.md §16)",
+            "roofline": {"bound": "hbm", "kernel": "wfa_wave_kernel", "limiter": "the mass of easy links (12 wavefronts per CU, one link each) and the critical path of the heaviest one; memory latency, not bandwidth (DESIGN.md §21)",
                          "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
             "cpu_baseline": cpu, "parity": parity,
             "problems_failed": int(out["stats"]["failed"] + out["stats"]["no_graph"] + out["stats"]["too_big"])}))
@@ -1189,7 +1202,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "valu": valu,
                          "traffic": None if tails else PMC_BYTES_PER_UNIT["linear"] * args.reads / n_launch,
-                         "traffic_source": None if tails else TRAFFIC_SOURCE,
+                         "traffic_source": None if tails else traffic_source("linear"),
                          "alg_bytes_per_launch": alg_bytes / n_launch, "avg_launch_ms": fill_avg,
                          "launches_per_step": n_launch,
                          "traceback_tail_ms": sum(walk_ms) / len(walk_ms),

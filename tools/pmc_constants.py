@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""gpurun_out/r03_pmc/ (tools/collect_r03.sh) -> profiles/pmc_constants.json + the CSV summaries under profiles/rNN/.
+
+For every workload: FETCH_SIZE and WRITE_SIZE (KiB) of its roofline kernels, averaged per dispatch of the bench's launches and summed over
+the kernels of the group, with the units one launch processes and THE COMMIT the library was built from — bench.py quotes that commit
+beside `roofline.traffic`, so a constant that has gone stale behind a changed kernel shows."""
+import csv, glob, json, os, subprocess, sys, collections, shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "r03_pmc")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+GROUPS = {   # workload -> (units per launch, kernel-name fragments of its roofline kernels)
+    "linear": (400000, ["gssw_fill_kernel"]),
+    "banded": (100000, ["banded_fill_kernel"]),
+    "gapless": (1000000, ["gapless_search_kernel", "gapless_rules_kernel", "gapless_kernel("]),
+    "wfa": (500000, ["wfa_kernel", "wfa_wave_kernel"]),
+}
+
+
+def per_dispatch(path, counter, frags):
+    """sum over the group's kernels of (total counter value / dispatches of that kernel)"""
+    tot = collections.defaultdict(float); disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"]
+        if not any(f in k for f in frags):
+            continue
+        tot[k] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
+    return sum(tot[k] / len(disp[k]) for k in tot), {k.split("(")[0]: len(disp[k]) for k in tot}
+
+
+def main():
+    commit = subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT).decode().strip()
+    out_path = os.path.join(ROOT, "profiles", "pmc_constants.json")
+    table = json.load(open(out_path)) if os.path.exists(out_path) else {}
+    dst = os.path.join(ROOT, "profiles", ROUND)
+    os.makedirs(dst, exist_ok=True)
+    for name, (units, frags) in GROUPS.items():
+        vals = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            found = glob.glob(os.path.join(SRC, "%s_%s" % (counter, name), "**", "*counter_collection.csv"), recursive=True)
+            if not found:
+                print("missing", counter, name); break
+            vals[counter], dispatches = per_dispatch(found[0], counter, frags)
+            shutil.copy(found[0], os.path.join(dst, "pmc_%s_%s_%s.csv" % (counter.split("_")[0].lower(), name, ROUND)))
+        else:
+            table[name] = {"fetch_kib_per_launch": vals["FETCH_SIZE"], "write_kib_per_launch": vals["WRITE_SIZE"], "units_per_launch": units,
+                           "kernels": frags, "dispatches_averaged": dispatches, "commit": commit,
+                           "files": ["profiles/%s/pmc_fetch_%s_%s.csv" % (ROUND, name, ROUND), "profiles/%s/pmc_write_%s_%s.csv" % (ROUND, name, ROUND)],
+                           "bytes_per_unit": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / units}
+            print(name, table[name]["bytes_per_unit"], "B/unit", dispatches)
+        st = glob.glob(os.path.join(SRC, "stats_%s" % name, "**", "*kernel_stats.csv"), recursive=True)
+        if st:
+            shutil.copy(st[0], os.path.join(dst, "kernel_stats_%s_%s.csv" % (name, ROUND)))
+    json.dump(table, open(out_path, "w"), indent=1, sort_keys=True)
+    print("->", out_path)
+
+
+if __name__ == "__main__":
+    main()
