@@ -569,7 +569,7 @@ struct WwXlHip {
     __device__ __forceinline__ void or32(uint32_t* p, uint32_t v) const { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __device__ __forceinline__ uint32_t load32(const uint32_t* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 };
-__global__ void __launch_bounds__(64, 3) wfa_wave_kernel(const WwParams P) {
+__global__ void __launch_bounds__(64, VGK_WW_OCC) wfa_wave_kernel(const WwParams P) {
     __shared__ WwSharedBoth sh;
     WwXlHip xl;
     wfa_wave(P, blockIdx.x, threadIdx.x, sh, xl);

@@ -63,6 +63,7 @@ struct vgk_ctx {
     vgk::WfaParams wfa_last{}; uint32_t wfa_last_threads = 0; bool wfa_last_valid = false;
     vgk::WwParams wfa_wave_last[2] = {}; uint32_t wfa_wave_waves[2] = {0, 0}; bool wfa_wave_last_valid = false;    // the wavefront form: small-table launch, large-table launch
     double wfa_wave_ms[2] = {0, 0}; uint64_t wfa_wave_retried = 0;
+    std::vector<uint32_t> wfa_cost_hints;   // vgk_wfa_set_cost_hints: per problem of the NEXT vgk_wfa_extend, bases to add to its length when the hand-out order is made
     uint64_t multi_host_walks = 0;       // problems of the last vgk_gssw_align_multi whose alternates a host thread walked
     // device scratch kept between vgk_banded_align calls (grow-only; released with the context)
     struct DevBuf { void* p = nullptr; uint64_t bytes = 0; };

@@ -207,6 +207,11 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     // stragglers (mode 2; 3 = length classes of 32 bases, longest first, by node inside a class).  Results do not depend on it.
     int mode = 3;
     if (const char* e = std::getenv("VGAMD_WFA_ORDER")) mode = std::atoi(e);
+    // vgk_wfa_set_cost_hints: what the caller expects a problem to cost beyond its length (giraffe knows the graph distance between two
+    // anchors: a connect whose sequence is 40 bases longer than that holds a 40-base insertion and will fill the wavefront tables);
+    // used once, for this call's order only
+    std::vector<uint32_t> hint_store; hint_store.swap(ctx->wfa_cost_hints);
+    const uint32_t* hints = hint_store.size() == n ? hint_store.data() : nullptr;
     const uint32_t n_graph_nodes = index->n_oriented / 2 + 1;
     if (mode == 3 && n_graph_nodes <= (1u << 21)) {
         // the default order as ONE stable radix sort on the device: key = length class (longest first, 11 bits) | node (21 bits); the
@@ -217,7 +222,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
         parallel_for(n, [&](uint32_t i, unsigned) {
             const WProb& w = probs[i];
             const uint32_t v = (w.mode == (uint32_t)VGK_WFA_PREFIX ? w.to_node : w.from_node) / 2, node = v < n_graph_nodes ? v : n_graph_nodes - 1;
-            const uint32_t c = w.seq_len / 32;
+            const uint32_t c = (w.seq_len + (hints ? hints[i] : 0u)) / 32;       // (a caller's cost hint counts as that many more bases)
             keys[i] = ((2047u - (c < 2047u ? c : 2047u)) << 21) | node; keys[(size_t)n + i] = i;
         });
         if (be->upload(d_sort, keys.data(), sizeof(uint32_t) * 2 * (size_t)n)) return VGK_ENODEV;
@@ -231,7 +236,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
         const uint32_t n_nodes = index->n_oriented / 2 + 1;
         auto node_of = [&](uint32_t i) { const WProb& w = probs[i]; const uint32_t v = (w.mode == (uint32_t)VGK_WFA_PREFIX ? w.to_node : w.from_node) / 2; return v < n_nodes ? v : n_nodes - 1; };
         auto class_of = [&](uint32_t i) -> uint32_t {          // longest first: class 0 = the longest sequences
-            const uint32_t len = probs[i].seq_len, c = mode == 2 ? len : mode == 3 ? len / 32 : 0;
+            const uint32_t len = probs[i].seq_len + (hints ? hints[i] : 0u), c = mode == 2 ? len : mode == 3 ? len / 32 : 0;
             return 0xffffu - (c < 0xffffu ? c : 0xffffu);
         };
         for (uint32_t i = 0; i < n; ++i) order[i] = i;
@@ -376,6 +381,12 @@ double vgk_wfa_last_ms(vgk_ctx* ctx) { return ctx ? ctx->wfa_ms : 0.0; }
 // 0 = ms of the first launch (hybrid: the thread kernel; wave form: the only one), 1 = ms of the wavefront kernel behind the thread kernel (hybrid),
 // 2 = problems the thread kernel handed over (hybrid) / that outgrew the small tables (wave form)
 double vgk_wfa_last_wave(vgk_ctx* ctx, int which) { return !ctx ? 0.0 : which == 0 ? ctx->wfa_wave_ms[0] : which == 1 ? ctx->wfa_wave_ms[1] : (double)ctx->wfa_wave_retried; }
+int vgk_wfa_set_cost_hints(vgk_ctx* ctx, const uint32_t* extra_bases, uint32_t n) {
+    if (!ctx || (!extra_bases && n)) return VGK_EINVAL;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->wfa_cost_hints.assign(extra_bases, extra_bases + n);
+    return VGK_OK;
+}
 int vgk_wfa_set_form(vgk_ctx* ctx, int form) {
     if (!ctx || form < VGK_WFA_FORM_HYBRID || form > VGK_WFA_FORM_WAVE) return VGK_EINVAL;
     std::lock_guard<std::mutex> lock(ctx->mu); ctx->wfa_form = form;

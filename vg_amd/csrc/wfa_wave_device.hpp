@@ -37,8 +37,13 @@
 
 namespace vgk {
 
-constexpr int WW_QUEUE_SMALL = 8, WW_QUEUE_LARGE = 32;     // work-list entries per lane (trie nodes: each is queued at most once per item)
-constexpr int WW_SMALL_SLOTS = 512, WW_SMALL_POINTS = 256, WW_SMALL_PATH = 128;
+// VGK_WW_OCC = wavefronts per SIMD the kernel is built for: 3 (shipped: 168 VGPRs, 12.8 KB of LDS) or 4 (an experiment: 128 VGPRs and
+// smaller small-size tables so that 16 wavefronts fit a CU's LDS — DESIGN.md §21)
+#ifndef VGK_WW_OCC
+#define VGK_WW_OCC 3
+#endif
+constexpr int WW_QUEUE_SMALL = 8, WW_QUEUE_LARGE = VGK_WW_OCC >= 4 ? 20 : 32;     // work-list entries per lane (trie nodes: each is queued at most once per item)
+constexpr int WW_SMALL_SLOTS = VGK_WW_OCC >= 4 ? 256 : 512, WW_SMALL_POINTS = VGK_WW_OCC >= 4 ? 128 : 256, WW_SMALL_PATH = VGK_WW_OCC >= 4 ? 96 : 128;
 
 struct WwNode {                       // WNode of wfa_device.hpp + where the record of the path's last graph node lies
     int32_t  st_node, st_lo, st_hi; uint32_t st_rec;
