@@ -173,6 +173,7 @@ public:
         void store64(unsigned long long* p, unsigned long long v) { *p = v; }
         unsigned long long cas64(unsigned long long* p, unsigned long long expect, unsigned long long desired) { const unsigned long long old = *p; if (old == expect) *p = desired; return old; }
         uint32_t add32(uint32_t* p, uint32_t v) { const uint32_t old = *p; *p += v; return old; }
+        uint32_t clock_us() { return 0u; }
         void or32(uint32_t* p, uint32_t v) { *p |= v; }
         uint32_t load32(const uint32_t* p) { return *p; }
     };

@@ -566,6 +566,7 @@ struct WwXlHip {
         return expect;                                                         // the value found there
     }
     __device__ __forceinline__ uint32_t add32(uint32_t* p, uint32_t v) const { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ __forceinline__ uint32_t clock_us() const { return (uint32_t)(wall_clock64() / 100ull); }      // (the constant 100 MHz counter; statistics only)
     __device__ __forceinline__ void or32(uint32_t* p, uint32_t v) const { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __device__ __forceinline__ uint32_t load32(const uint32_t* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 };

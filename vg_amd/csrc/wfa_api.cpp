@@ -64,18 +64,18 @@ int launch_wave_form(vgk_ctx* ctx) {
     if ((rc = be->download(&taken_over, A.n_todo_dev ? A.n_todo_dev : A.n_declined, sizeof taken_over))) return rc;
     ctx->wfa_wave_retried = taken_over;                                           // hybrid: what the thread kernel handed over; else: what outgrew the small tables
     if (A.stats) {
-        std::vector<uint32_t> st(4 * (size_t)A.base.n);
+        std::vector<uint32_t> st(8 * (size_t)A.base.n);
         if (!be->download(st.data(), A.stats, sizeof(uint32_t) * st.size())) {
             std::vector<uint32_t> idx;
-            for (uint32_t i = 0; i < A.base.n; ++i) if (st[4 * i + 2]) idx.push_back(i);
-            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return st[4 * a + 2] > st[4 * b + 2]; });
+            for (uint32_t i = 0; i < A.base.n; ++i) if (st[8 * i + 2]) idx.push_back(i);
+            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return st[8 * a + 2] > st[8 * b + 2]; });
             unsigned long long chunks = 0, points = 0, steps = 0;
-            for (uint32_t i : idx) { chunks += st[4 * i + 2]; points += st[4 * i]; steps += st[4 * i + 1]; }
+            for (uint32_t i : idx) { chunks += st[8 * i + 2]; points += st[8 * i]; steps += st[8 * i + 1]; }
             unsigned long long items = 0;
-            for (uint32_t i : idx) items += st[4 * i + 3] >> 8;
-            std::fprintf(stderr, "[wfa wave] %zu problems: %llu chunks, %llu points, %llu steps, %llu filtered items in all; heaviest (points, steps, chunks, trie nodes, items):", idx.size(), chunks, points, steps, items);
-            for (size_t k = 0; k < idx.size() && k < 8; ++k) std::fprintf(stderr, " (%u,%u,%u,%u,%u)", st[4 * idx[k]], st[4 * idx[k] + 1], st[4 * idx[k] + 2], st[4 * idx[k] + 3] & 255u, st[4 * idx[k] + 3] >> 8);
-            for (size_t q : {idx.size() / 100, idx.size() / 10, idx.size() / 2}) if (q < idx.size()) std::fprintf(stderr, " | rank %zu: (%u,%u,%u,%u,%u)", q, st[4 * idx[q]], st[4 * idx[q] + 1], st[4 * idx[q] + 2], st[4 * idx[q] + 3] & 255u, st[4 * idx[q] + 3] >> 8);
+            for (uint32_t i : idx) items += st[8 * i + 3] >> 8;
+            std::fprintf(stderr, "[wfa wave] %zu problems: %llu chunks, %llu points, %llu steps, %llu filtered items in all; heaviest (points, steps, chunks, trie nodes, items; us in extend, next, between, after):", idx.size(), chunks, points, steps, items);
+            for (size_t k = 0; k < idx.size() && k < 8; ++k) std::fprintf(stderr, " (%u,%u,%u,%u,%u; %u,%u,%u,%u)", st[8 * idx[k]], st[8 * idx[k] + 1], st[8 * idx[k] + 2], st[8 * idx[k] + 3] & 255u, st[8 * idx[k] + 3] >> 8, st[8 * idx[k] + 4], st[8 * idx[k] + 5], st[8 * idx[k] + 6], st[8 * idx[k] + 7]);
+            for (size_t q : {idx.size() / 100, idx.size() / 10, idx.size() / 2}) if (q < idx.size()) std::fprintf(stderr, " | rank %zu: (%u,%u,%u,%u,%u)", q, st[8 * idx[q]], st[8 * idx[q] + 1], st[8 * idx[q] + 2], st[8 * idx[q] + 3] & 255u, st[8 * idx[q] + 3] >> 8);
             std::fprintf(stderr, "\n");
         }
     }
@@ -108,8 +108,8 @@ int run_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P, bool after_threa
     A.n_declined = (unsigned long long*)extra;
     A.stats = nullptr;
     if (std::getenv("VGAMD_WFA_STATS")) {                                        // per-problem statistics, printed by the call (a debugging aid)
-        A.stats = (uint32_t*)ctx->ensure_scratch(64, sizeof(uint32_t) * 4 * ((size_t)P.n + 1));
-        if (!A.stats || be->zero(A.stats, sizeof(uint32_t) * 4 * ((size_t)P.n + 1))) return VGK_ENOMEM;
+        A.stats = (uint32_t*)ctx->ensure_scratch(64, sizeof(uint32_t) * 8 * ((size_t)P.n + 1));
+        if (!A.stats || be->zero(A.stats, sizeof(uint32_t) * 8 * ((size_t)P.n + 1))) return VGK_ENOMEM;
     }
     ctx->wfa_wave_last[0] = A; ctx->wfa_wave_waves[0] = z.waves;
     if ((rc = launch_wave_form(ctx))) return rc;

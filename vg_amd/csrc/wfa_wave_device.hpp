@@ -67,13 +67,15 @@ struct WwParams {
     uint32_t* node_masks; uint32_t mask_width;      // ... WW_MASK_ROWS x 3 x mask_width words: which trie nodes hold a point at (penalty mod WW_MASK_ROWS, kind, diagonal) — null: no item filter
     uint32_t* edit_runs;                            // ... and W_EDITS edit runs for the backtrace
     unsigned long long* n_declined;   // counts the problems the large size took over (nullable)
-    uint32_t* stats;                  // nullable (VGAMD_WFA_STATS): per problem 4 words — stored points, penalty steps, chunks of items, trie nodes
+    uint32_t* stats;                  // nullable (VGAMD_WFA_STATS): per problem 8 words — stored points, penalty steps, chunks of items, trie nodes | items << 8,
+                                      // and microseconds (xl.clock_us) in extend(), next(), the penalty bookkeeping between them, everything after the loop
 };
 
 constexpr int WW_MASK_ROWS = 32;      // penalties whose node masks are kept at a time (a ring): more than any source wavefront lies back
 
 template <bool SMALL> struct WwTables {                                       // the large size: its tables are a slab in HBM; in LDS only ...
     uint32_t sv[64];                  // ... a chunk in the making: per diagonal looked at, the leaves that have something to do there
+    uint32_t src_mask[64][5];         // ... next(): per diagonal looked at, the node sets of its five source cells (an item probes only the cells that can answer)
     uint32_t filter_off;              // ... and whether some diagonal has left the masks' width (then every item is looked at again, as in the small size)
 };
 template <> struct WwTables<true> {   // the small size keeps its tables in LDS
@@ -104,6 +106,7 @@ template <class XL, bool SMALL> struct WwCtx {
     int32_t cand_score, cand_diag; uint32_t cand_seq, cand_off, cand_node, cand_leaf;
     int32_t max_distance;
     uint32_t n_chunks, n_steps, n_items;      // (statistics)
+    uint32_t us_extend, us_next, us_score;
     bool overflow; int why;           // why: 1 points, 2 trie nodes, 3 path pool, 4 edits, 5 node length, 6 walked end reached, 7 work list,
                                       // 8 table without a free slot, 9 broken path chain, 10 a loop ran past its bound (8-10: cannot happen; never hang)
     VGK_HD unsigned long long* tbl(uint32_t i) { if constexpr (SMALL) return sh->slot + i; else return slot + i; }
@@ -224,12 +227,17 @@ template <class XL, bool SMALL> VGK_HD bool ww_wants_expansion(WwCtx<XL, SMALL>&
 template <class XL, bool SMALL> VGK_HD void ww_match_forward(WwCtx<XL, SMALL>& c, WPos& p) {
     if (p.seq >= c.L || ww_past_end(c, p.cur, p.off)) return;
     const GIndex& h = c.P->base.index;
+    // the entry that holds offset p.off: a trie node's entries are made in one go when the node is walked (ww_node_create), so they lie
+    // next to each other in the pool with ascending starts — a binary search instead of a walk from the head (for the large size every
+    // step of that walk is a dependent load from the HBM slab, and a position 250 bases into a node sits eight entries down)
     uint32_t k = c.sh->nodes[p.cur].path_head;
     uint32_t hops = 0;
-    while (c.pth(k).next != W_NIL && c.pth(c.pth(k).next).start <= p.off && hops++ <= c.path_cap) k = c.pth(k).next;
+    { uint32_t hi = c.sh->nodes[p.cur].path_tail;
+      while (k < hi) { const uint32_t mid = (k + hi + 1) >> 1; if (c.pth(mid).start <= p.off) k = mid; else hi = mid - 1; } }
     for (;;) {
         if (hops++ > 2 * c.path_cap || k >= c.path_cap) { c.overflow = true; c.why = 9; return; }       // a broken chain: never walk it for ever
         const WwPath e = c.pth(k);                                             // one entry: where the node's bases lie and how many
+        if (p.off < e.start || p.off >= (uint32_t)e.start + e.len) { c.overflow = true; c.why = 9; return; }      // (not the entry of this offset: cannot happen)
         const char* g = h.seq + e.seq_off + (p.off - e.start);
         const char* r = c.seq + p.seq;
         uint32_t left = (uint32_t)e.start + e.len - p.off; if (c.L - p.seq < left) left = c.L - p.seq;
@@ -509,13 +517,18 @@ template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t
         uint32_t n_diag;
         ++c.n_chunks;
         uint32_t want = W_NODES;                                               // the node this item asks to have expanded
-        int32_t diag = diag0; uint32_t leaf = 0; bool have_cand = false, have = false;
+        int32_t diag = diag0; uint32_t leaf = 0; bool have_cand = false, have = false, filtered = false;
         if (ww_filtering(c)) {
             if constexpr (!SMALL) {
                 const int32_t d = diag0 + (int32_t)c.lane;
-                const uint32_t m = d > hi ? 0u : ww_mask_at(c, WK_MATCH, src_mismatch, d) | ww_mask_at(c, WK_MATCH, src_open, d - 1) | ww_mask_at(c, WK_INS, src_extend, d - 1) |
-                                                 ww_mask_at(c, WK_MATCH, src_open, d + 1) | ww_mask_at(c, WK_DEL, src_extend, d + 1);
-                n_diag = ww_chunk_of(c, diag0, hi, m, diag, leaf, have);
+                uint32_t mk[5] = {0u, 0u, 0u, 0u, 0u};
+                if (d <= hi) {
+                    mk[0] = ww_mask_at(c, WK_MATCH, src_mismatch, d); mk[1] = ww_mask_at(c, WK_MATCH, src_open, d - 1); mk[2] = ww_mask_at(c, WK_INS, src_extend, d - 1);
+                    mk[3] = ww_mask_at(c, WK_MATCH, src_open, d + 1); mk[4] = ww_mask_at(c, WK_DEL, src_extend, d + 1);
+                }
+                for (int k = 0; k < 5; ++k) c.sh->src_mask[c.lane][k] = mk[k];
+                n_diag = ww_chunk_of(c, diag0, hi, mk[0] | mk[1] | mk[2] | mk[3] | mk[4], diag, leaf, have);
+                filtered = true;
             }
         } else {
             const uint32_t fit = 64u / n_leaves, left = (uint32_t)(hi - diag0 + 1);
@@ -524,22 +537,26 @@ template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t
         }
         if (have) {
             const uint32_t anc = c.sh->nodes[leaf].ancestors;
+            // which of the five source cells hold a point on this leaf's way to the root (all, when every item is looked at): a cell
+            // that does not is not probed — the probe would walk its hash chain to the first free slot and find nothing
+            uint32_t has = 31u;
+            if constexpr (!SMALL) { if (filtered) { has = 0u; for (uint32_t k = 0; k < 5u; ++k) if (c.sh->src_mask[diag - diag0][k] & anc) has |= 1u << k; } }
             WPos ins;
-            { const WPos open = ww_find_in(c, WK_MATCH, src_open, anc, leaf, diag - 1, true, false), ext = ww_find_in(c, WK_INS, src_extend, anc, leaf, diag - 1, true, false);
+            { const WPos open = (has & 2u) ? ww_find_in(c, WK_MATCH, src_open, anc, leaf, diag - 1, true, false) : w_none(), ext = (has & 4u) ? ww_find_in(c, WK_INS, src_extend, anc, leaf, diag - 1, true, false) : w_none();
               ins = w_less(open, ext) ? ext : open; }
             if (!ins.empty) {
                 ins.seq++;
                 if (w_distance(ins, diag) >= c.min_distance) { ww_update(c, WK_INS, score, diag, ins); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
             }
             WPos del;
-            { const WPos open = ww_find_in(c, WK_MATCH, src_open, anc, leaf, diag + 1, false, true), ext = ww_find_in(c, WK_DEL, src_extend, anc, leaf, diag + 1, false, true);
+            { const WPos open = (has & 8u) ? ww_find_in(c, WK_MATCH, src_open, anc, leaf, diag + 1, false, true) : w_none(), ext = (has & 16u) ? ww_find_in(c, WK_DEL, src_extend, anc, leaf, diag + 1, false, true) : w_none();
               del = w_less(open, ext) ? ext : open; }
             if (!del.empty) {
                 ww_successor_offset(c, del);
                 if (w_distance(del, diag) >= c.min_distance) { ww_update(c, WK_DEL, score, diag, del); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
                 if (ww_wants_expansion(c, del)) want = del.cur;
             }
-            WPos subst = ww_find_in(c, WK_MATCH, src_mismatch, anc, leaf, diag, true, true);
+            WPos subst = (has & 1u) ? ww_find_in(c, WK_MATCH, src_mismatch, anc, leaf, diag, true, true) : w_none();
             if (!subst.empty) { subst.seq++; ww_successor_offset(c, subst); if (want == (uint32_t)W_NODES && ww_wants_expansion(c, subst)) want = subst.cur; }
             if (w_less(subst, ins)) subst = ins;
             if (w_less(subst, del)) subst = del;
@@ -658,7 +675,7 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
     // no position gets further into a trie node than the sequence plus the deletions the score cap pays for (+ where the root starts)
     c.grow_cap = c.L + (uint32_t)(pb.score_bound / B.gap_extend) + 2u;
     c.cand_score = 0x7fffffff; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0; c.cand_leaf = 0;
-    c.max_distance = 0; c.min_distance = 0; c.overflow = false; c.why = 0; c.n_chunks = 0; c.n_steps = 0; c.n_items = 0;
+    c.max_distance = 0; c.min_distance = 0; c.overflow = false; c.why = 0; c.n_chunks = 0; c.n_steps = 0; c.n_items = 0; c.us_extend = c.us_next = c.us_score = 0;
     const int32_t top_score = pb.score_bound + B.gap_open + B.gap_extend + B.mismatch;
     for (int32_t s = (int32_t)lane; s <= top_score && s < W_SCORES; s += 64) sh.ps_flags[s] = 0;
     if (lane < (uint32_t)W_NODES) sh.expanded_at[lane] = 0;
@@ -676,8 +693,12 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
     int32_t best_score = 0x7fffffff, best_diag = 0; uint32_t best_seq = 0, best_off = 0, best_node = 0;
     int32_t score = 0;
     bool failed = ww_any_overflow(c);
+    const bool timed = P.stats != nullptr;
+    uint32_t t_mark = timed ? xl.clock_us() : 0u;
+    auto lap = [&](uint32_t& into) { if (timed) { const uint32_t t = xl.clock_us(); into += t - t_mark; t_mark = t; } };
     while (!failed) {
         ww_extend(c, score, best_score, best_diag, best_seq, best_off, best_node);
+        lap(c.us_extend);
         if ((failed = ww_any_overflow(c))) break;
         if (pb.distance_band < c.max_distance) c.min_distance = c.max_distance - pb.distance_band;
         if (best_score <= score) break;
@@ -685,11 +706,14 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
         if (lane == 0) next = ww_next_score(c, score);
         xl.fence();
         score = (int32_t)xl.bcast((uint32_t)next, 0);
+        lap(c.us_score);
         if (score > pb.score_bound) break;
         ww_next(c, score, best_score, best_diag, best_seq, best_off, best_node);
+        lap(c.us_next);
         ++c.n_steps;
         if ((failed = ww_any_overflow(c))) break;
     }
+    const uint32_t t_loop_end = timed ? xl.clock_us() : 0u;
     // the rest is one chain of dependent lookups: lane 0
     const uint32_t n_points = sh.n_points < c.max_points ? sh.n_points : c.max_points;
     uint32_t* runs = c.run_buf();
@@ -819,7 +843,11 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
             out.status = VGK_ETOOBIG; out.ok = 0; out.score = c.why; out.node_offset = 0; out.length = 0;
         }
         if (!retry) B.results[i] = out;
-        if (P.stats && !retry) { P.stats[4 * i] = sh.n_points; P.stats[4 * i + 1] = c.n_steps; P.stats[4 * i + 2] = c.n_chunks; P.stats[4 * i + 3] = sh.n_nodes | (c.n_items << 8); }      // (items: those the filter let through; 0 when every item is looked at)
+        if (P.stats && !retry) {
+            uint32_t* st = P.stats + 8 * (size_t)i;
+            st[0] = sh.n_points; st[1] = c.n_steps; st[2] = c.n_chunks; st[3] = sh.n_nodes | (c.n_items << 8);      // (items: those the filter let through; 0 when every item is looked at)
+            st[4] = c.us_extend; st[5] = c.us_next; st[6] = c.us_score; st[7] = xl.clock_us() - t_loop_end;
+        }
     }
     retry = xl.bcast(retry ? 1u : 0u, 0) != 0u;
     // leave the table all-zero: the touched slots from the log, or everything when the log ran over
