@@ -169,6 +169,7 @@ public:
             return m;
         }
         void fence() { slot(); w->yield(); }
+        void fence_lds() { slot(); w->yield(); }
         unsigned long long load64(const unsigned long long* p) { return *p; }
         void store64(unsigned long long* p, unsigned long long v) { *p = v; }
         unsigned long long cas64(unsigned long long* p, unsigned long long expect, unsigned long long desired) { const unsigned long long old = *p; if (old == expect) *p = desired; return old; }

@@ -340,7 +340,7 @@ template <class XL> VGK_HD uint32_t ww_chunk_of(WwCtx<XL, false>& c, int32_t dia
     uint32_t sv = 0;
     if (m) for (uint32_t rest = c.sh->leaves; rest; rest &= rest - 1) { const uint32_t l = (uint32_t)__builtin_ctz(rest); if (c.sh->nodes[l].ancestors & m) sv |= 1u << l; }
     c.sh->sv[c.lane] = sv;
-    c.xl->fence();
+    c.xl->fence_lds();
     uint32_t acc = 0, taken = 0;
     have = false;
     for (uint32_t j = 0; j < 64u && diag0 + (int32_t)j <= hi; ++j) {
@@ -353,7 +353,7 @@ template <class XL> VGK_HD uint32_t ww_chunk_of(WwCtx<XL, false>& c, int32_t dia
         }
         acc += cnt; taken = j + 1;
     }
-    c.xl->fence();                                                             // (sv belongs to the next chunk from here)
+    c.xl->fence_lds();                                                         // (sv belongs to the next chunk from here)
     c.n_items += acc;
     return taken;
 }
@@ -368,7 +368,7 @@ template <class XL, bool SMALL> VGK_HD uint32_t ww_mask_at(WwCtx<XL, SMALL>& c, 
 // is the filter on for the coming chunk?  (the same answer on every lane: filter_off changes only between fences)
 template <class XL, bool SMALL> VGK_HD bool ww_filtering(WwCtx<XL, SMALL>& c) {
     if constexpr (SMALL) return false;
-    else { if (!c.masks) return false; c.xl->fence(); return c.sh->filter_off == 0u; }
+    else { if (!c.masks) return false; c.xl->fence_lds(); return c.sh->filter_off == 0u; }
 }
 template <class XL, bool SMALL> VGK_HD void ww_clear_masks(WwCtx<XL, SMALL>& c, int32_t score) {       // a penalty's sets, before its first point is stored
     if constexpr (!SMALL) {
