@@ -187,7 +187,7 @@ def bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus):
                        "timed_region": "K launches of wfa_kernel on the batch resident in HBM (vgk_wfa_rerun)",
                        "end_to_end_from_host_buffers_alignments_per_s": n / te, "parallelism": "problem-sharded x%d" % world,
                        "device": dev_name, "compute_units": cus, "sequence_bases": wl.bases},
-            "roofline": {"bound": "hbm", "limiter": "memory latency on each thread's dependent chain and lane divergence, not bandwidth (DESIGN.md §12)", "kernel": {"thread": "wfa_kernel", "wave": "wfa_wave_kernel"}.get(os.environ.get("VGAMD_WFA_KERNEL", ""), "wfa_kernel + wfa_wave_kernel (hybrid: a problem is handed to a wavefront at 128 points)"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "limiter": "memory latency on each thread's dependent chain and lane divergence, not bandwidth (DESIGN.md §12)", "kernel": {"thread": "wfa_kernel", "wave": "wfa_wave_kernel"}.get(os.environ.get("VGAMD_WFA_KERNEL", ""), "wfa_kernel + wfa_wave_kernel (hybrid: a problem is handed to a wavefront at 16 points)"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["wfa"] * n, "traffic_source": traffic_source("wfa"), "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
                          "kernel_only_alignments_per_s": n / (k * 1e-3)},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum()),

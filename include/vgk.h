@@ -511,7 +511,7 @@ int    vgk_wfa_set_point_budgets(vgk_ctx* ctx, uint32_t connect_points, uint32_t
 /* Three kernels answer vgk_wfa_extend with the same results (every tie included): one THREAD per problem (64 problems per instruction: the
  * easy majority's best), one WAVEFRONT per problem with the lanes as the (diagonal, haplotype) items of a penalty step and tables sized for
  * links with long gaps (a heavy problem's critical path is ~100 x shorter), and HYBRID (the default): the thread kernel hands what reaches
- * 128 stored points to the wavefront kernel.  A stage whose problems are long and often heavy (giraffe's long-read links) does better with
+ * 16 stored points (about the median problem's size) to the wavefront kernel.  A stage whose problems are long and often heavy (giraffe's long-read links) does better with
  * WAVE throughout: the heavy problems then start at once instead of behind the thread launch. */
 enum { VGK_WFA_FORM_HYBRID = 0, VGK_WFA_FORM_THREAD = 1, VGK_WFA_FORM_WAVE = 2 };
 int    vgk_wfa_set_form(vgk_ctx* ctx, int form);
