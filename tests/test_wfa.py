@@ -469,3 +469,28 @@ def test_both_forms_and_both_table_sizes_on_the_gpu(monkeypatch):
     monkeypatch.delenv("VGAMD_WFA_SMALL_POINTS"); monkeypatch.setenv("VGAMD_WFA_KERNEL", "hybrid"); monkeypatch.setenv("VGAMD_WFA_HAND_OVER_POINTS", "12")
     handed, answered = retries_with_large_tables(None, range(840, 860), 400)
     assert handed > 1200 and answered > 7800, (handed, answered)
+
+
+def cost_hints_change_the_order_only(lib):
+    """vgk_wfa_set_cost_hints: whatever the caller claims about the problems' costs — nothing, nonsense, a list of the wrong length — the
+    answers are the same; a hint list is used by one call."""
+    ora = capi.Engine(lib=util.ORACLE_LIB); eng = capi.Engine(lib=lib) if lib else capi.Engine()
+    rng = np.random.default_rng(4242)
+    nodes, threads, problems = random_wfa_case(rng, 300)
+    want = ora.wfa_extend(ora.haplo_index(nodes, threads), problems)
+    idx = eng.haplo_index(nodes, threads)
+    plain = eng.wfa_extend(idx, problems)
+    for hints in (rng.integers(0, 60000, len(problems)), np.zeros(len(problems)), rng.integers(0, 5000, len(problems) - 7)):
+        eng.wfa_set_cost_hints(hints)
+        got = eng.wfa_extend(idx, problems)
+        assert all(len(x) == len(y) and (x == y).all() for x, y in zip(got, plain))
+    assert (plain[0]["status"] == want[0]["status"]).all() and (plain[0]["score"] == want[0]["score"]).all()
+
+
+def test_emulated_cost_hints_change_the_order_only():
+    cost_hints_change_the_order_only(util.EMU_LIB)
+
+
+@pytest.mark.gpu
+def test_hip_cost_hints_change_the_order_only():
+    cost_hints_change_the_order_only(None)

@@ -541,6 +541,12 @@ class Engine:
                                             ctypes.byref(written)), "vgk_wfa_extend")
         return res, paths[:written[0]], edits[:written[1]]
 
+    def wfa_set_cost_hints(self, extra_bases):
+        """vgk_wfa_set_cost_hints: per problem of the NEXT wfa_extend, bases to add to its length when the hand-out order is made (order only)"""
+        a = np.ascontiguousarray(extra_bases, dtype=np.uint32)
+        self.lib.vgk_wfa_set_cost_hints.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+        self._check(self.lib.vgk_wfa_set_cost_hints(self.h, a.ctypes.data, len(a)), "vgk_wfa_set_cost_hints")
+
     def wfa_set_point_budgets(self, connect_points, tail_points):
         self.lib.vgk_wfa_set_point_budgets.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
         self._check(self.lib.vgk_wfa_set_point_budgets(self.h, connect_points, tail_points), "vgk_wfa_set_point_budgets")
