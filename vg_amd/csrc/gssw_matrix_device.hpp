@@ -43,6 +43,9 @@ struct GsswMatrixParams {
     int32_t* cells;
     int32_t* node_fmax;               // X-drop band only: per node (indexed like `nodes`), the best score on the way to the node's end
     unsigned long long* stats;        // X-drop band only: [0] cells inside the bands
+    // X-drop band only, nullable: the wavefront that filled a problem also picks its end cell and walks its traceback (lane 0, over the
+    // matrices it has just written) — results[i] as vgk_xdrop_band_align returns them, ops in a window of L + R + 3 elements from ops_off[i]
+    vgk_result* xb_results; vgk_op* xb_ops; const uint64_t* xb_ops_off; const uint8_t* xb_want_tb;
 };
 
 VGK_HD void gssw_matrix_one(const GsswMatrixParams& P, uint32_t i) {
@@ -204,6 +207,7 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     }
     int32_t Hp[R], Ep[R];
     unsigned long long in_band = 0;
+    int32_t best = 0, best_c = -1, best_v = 0;
     for (uint32_t v = 0; v < pb.n_nodes; ++v) {
         const MNode nd = nodes[v];
         bool front_live = false;
@@ -280,12 +284,98 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
             const int32_t colmax = xl.reduce_max(inside ? lane_max : MNEG);
             fmax = colmax > fmax ? colmax : fmax;
             front_live = live != 0;
+            if (colmax > best) { best = colmax; best_c = (int32_t)c; best_v = (int32_t)v; }      // the end cell's column: the first one that beats every earlier one
         }
         if (lane == 0) node_fmax[v] = front_live ? fmax : MNEG;      // an empty front is not merged into its successors (src/dozeu_interface.cpp:261-269)
         xl.fence();
     }
     const unsigned long long tot = xl.reduce_add(in_band);
     if (lane == 0) { pb.status = VGK_OK; bump_stat(P.stats, tot); }
+    if (!P.xb_results) return;
+    // ---- end cell and traceback, on the device (round 3; the host's BandTracer states the same rules: xdrop_band_api.cpp) ----
+    // first node in order / first column / smallest row with the best score; diagonal > deletion > insertion, gap open before extend,
+    // first explaining predecessor; the walk ends at the root.
+    int32_t best_i = 0x7fffffff;
+    if (best_c >= 0) for (int32_t i = (int32_t)lane; i < rows; i += 64) if (H[(uint64_t)best_c * (uint64_t)rows + i] == best && i < best_i) best_i = i;
+    best_i = -xl.reduce_max(-best_i);
+    if (lane != 0) return;
+    vgk_result res{};
+    res.end_node = -1; res.end_offset = -1; res.end_read = -1; res.status = VGK_OK; res.ops_begin = (uint32_t)P.xb_ops_off[pi];
+    if (best >= 32767) { res.status = VGK_EOVERFLOW; P.xb_results[pi] = res; return; }
+    if (best <= 0 || best_c < 0) { P.xb_results[pi] = res; return; }                       // the root wins: the caller writes the full-length insertion
+    res.score = best; res.end_node = best_v; res.end_offset = best_c - (int32_t)nodes[best_v].col_start; res.end_read = best_i - 1;
+    if (!P.xb_want_tb[pi]) { P.xb_results[pi] = res; return; }
+    vgk_op* ops = P.xb_ops + P.xb_ops_off[pi];
+    uint32_t n_ops = 0;
+    auto live = [](int32_t x) { return x > MNEG / 2; };
+    auto push = [&](int32_t node, int op, uint32_t len) {
+        if (!len) return;
+        if (n_ops && ops[n_ops - 1].node == (uint32_t)node && ops[n_ops - 1].op == (uint8_t)op) { ops[n_ops - 1].len = (uint16_t)(ops[n_ops - 1].len + len); return; }
+        vgk_op x{}; x.node = (uint32_t)node; x.op = (uint8_t)op; x.len = (uint16_t)len; ops[n_ops++] = x;
+    };
+    auto hc = [&](int32_t c, int32_t i) { return H[(uint64_t)c * (uint64_t)rows + i]; };
+    auto ec = [&](int32_t c, int32_t i) { return E[(uint64_t)c * (uint64_t)rows + i]; };
+    auto fc = [&](int32_t c, int32_t i) { return F[(uint64_t)c * (uint64_t)rows + i]; };
+    auto e_next = [&](int32_t c, int32_t i) { const int32_t a = live(hc(c, i)) ? hc(c, i) - go : MNEG, b = live(ec(c, i)) ? ec(c, i) - ge : MNEG; return a > b ? a : b; };     // E of the column after c
+    auto root_h = [&](int32_t i) { return i == 0 ? 0 : (i <= pb.gap_cells && i <= L ? -(go + (i - 1) * ge) : MNEG); };
+    auto score = [&](int32_t i, int32_t c) { return (int32_t)(ql ? P.mat[25 * ql[i - 1] + 5 * gr[c] + rd[i - 1]] : P.mat[5 * gr[c] + rd[i - 1]]) + (i == L ? pb.start_bonus : 0); };
+    int32_t c = best_c, i = best_i, n = best_v, cur = best;
+    int status = VGK_OK;
+    push(n, VGK_OP_S, (uint32_t)(L - i));
+    enum { ST_H, ST_E, ST_F } st = ST_H;
+    const uint32_t cap = pb.L + pb.R + 3u;
+    for (uint32_t guard = 0; status == VGK_OK; ++guard) {
+        if (guard > 2u * cap + 8u || n_ops + 2u > cap) { status = VGK_EINVAL; break; }     // (never: every step consumes a base or changes state once)
+        const MNode nd = nodes[n];
+        const bool first = (uint32_t)c == nd.col_start;
+        const uint32_t* pr = P.preds + nd.pred_begin;
+        if (st == ST_H) {
+            bool moved = false;
+            if (i > 0) {
+                int32_t d = first ? (nd.n_pred == 0 ? root_h(i - 1) : MNEG) : hc(c - 1, i - 1);
+                if (first) for (uint32_t k = 0; k < nd.n_pred; ++k) { const int32_t x = hc((int32_t)nodes[pr[k]].col_end - 1, i - 1); d = x > d ? x : d; }
+                if (live(d) && cur == d + score(i, c)) {
+                    push(n, VGK_OP_M, 1);
+                    cur = d; i -= 1; moved = true;
+                    if (!first) c -= 1;
+                    else if (nd.n_pred == 0) { push(n, VGK_OP_I, (uint32_t)i); break; }            // back at the root: leading insertion
+                    else {
+                        int32_t found = -1;
+                        for (uint32_t k = 0; k < nd.n_pred; ++k) { const int32_t q = (int32_t)nodes[pr[k]].col_end - 1; if (hc(q, i) == cur) { found = (int32_t)pr[k]; break; } }
+                        if (found < 0) { status = VGK_EINVAL; break; }
+                        n = found; c = (int32_t)nodes[n].col_end - 1;
+                    }
+                }
+            }
+            if (!moved) {
+                if (cur == ec(c, i)) st = ST_E;
+                else if (i > 0 && cur == fc(c, i)) st = ST_F;
+                else { status = VGK_EINVAL; break; }
+            }
+        } else if (st == ST_E) {
+            push(n, VGK_OP_D, 1);
+            if (first && nd.n_pred == 0) {                           // deletion opened straight from the root column
+                if (!live(root_h(i)) || root_h(i) - go != cur) { status = VGK_EINVAL; break; }
+                push(n, VGK_OP_I, (uint32_t)i); break;
+            }
+            int32_t q = c - 1, qn = n;
+            if (first) {
+                q = -1;
+                for (uint32_t k = 0; k < nd.n_pred; ++k) { const int32_t x = (int32_t)nodes[pr[k]].col_end - 1; if (e_next(x, i) == cur) { q = x; qn = (int32_t)pr[k]; break; } }
+                if (q < 0) { status = VGK_EINVAL; break; }
+            }
+            if (live(hc(q, i)) && hc(q, i) - go == cur) { st = ST_H; cur += go; } else cur += ge;
+            c = q; n = qn;
+        } else {
+            push(n, VGK_OP_I, 1);
+            if (i == 0) { status = VGK_EINVAL; break; }
+            if (live(hc(c, i - 1)) && hc(c, i - 1) - go == cur) { st = ST_H; cur += go; } else cur += ge;
+            i -= 1;
+        }
+    }
+    for (uint32_t a = 0, b = n_ops; a + 1 < b; ++a, --b) { const vgk_op t = ops[a]; ops[a] = ops[b - 1]; ops[b - 1] = t; }       // found back to front
+    res.status = status; res.n_ops = status == VGK_OK ? n_ops : 0; res.first_offset = 0;
+    P.xb_results[pi] = res;
 }
 
 }  // namespace vgk
