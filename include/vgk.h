@@ -283,7 +283,9 @@ double   vgk_tail_stage_last_ms(vgk_ctx* ctx, int which);             /* 0 tails
  * a node whose incoming fronts are all empty is skipped.  Everything else — root column, seeds, bonus, end cell, traceback
  * preferences — is as in VGK_XDROP_PINNED.  Problems must be VGK_XDROP_PINNED (| VGK_GSSW_TRACEBACK); reads up to 511 bases.
  * stats (nullable): [0] cells inside the bands, [1] cells of the full read x graph rectangles.
- * One wavefront per problem fills the columns (one 8-row vector per lane), the matrices come back and host threads trace. */
+ * The device fills the columns (one 8-row vector per lane; tails of up to 127 bases four to a wavefront, 16 lanes each, longer reads a
+ * wavefront each), picks the end cell and walks the traceback over the matrices it has just written; ops are packed on the device and
+ * only results and ops come back. */
 int  vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
                           vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written, uint64_t stats[2]);
 double vgk_xdrop_band_last_ms(vgk_ctx* ctx);     /* fill-kernel time of the last vgk_xdrop_band_align call on this context */

@@ -20,21 +20,22 @@ namespace vgk {
 // banded kernels: one CPU thread per lane, the cross-lane primitives of banded_device.hpp through a barrier
 struct XlShared { pthread_barrier_t bar; int32_t buf[64]; unsigned long long wide[64]; };
 struct XlEmu {
-    XlShared* sh; uint32_t lane;
+    XlShared* sh; uint32_t lane; uint32_t lanes = 64;          // lanes: how many run together (64, or one DPP row of 16)
+    uint32_t width() const { return lanes; }
     int32_t exchange(int32_t v, int mode) {
         sh->buf[lane] = v;
         pthread_barrier_wait(&sh->bar);
         int32_t out = BNEG;
-        if (mode == 0) { if (lane < 63) out = sh->buf[lane + 1]; }
+        if (mode == 0) { if (lane + 1 < lanes) out = sh->buf[lane + 1]; }
         else if (mode == 1) { if (lane > 0) out = sh->buf[lane - 1]; }
-        else if (mode == 3) { for (uint32_t l = 0; l < 64; ++l) out = bmax(out, sh->buf[l]); }
+        else if (mode == 3) { for (uint32_t l = 0; l < lanes; ++l) out = bmax(out, sh->buf[l]); }
         else for (uint32_t l = 0; l < lane; ++l) out = bmax(out, sh->buf[l]);
         pthread_barrier_wait(&sh->bar);
         return out;
     }
     int32_t up(int32_t v) { return exchange(v, 0); }
     int32_t down(int32_t v) { return exchange(v, 1); }
-    int32_t up_sub(int32_t old, int32_t v, int32_t s) { const int32_t o = exchange(v, 0); return lane < 63 ? o - s : old; }
+    int32_t up_sub(int32_t old, int32_t v, int32_t s) { const int32_t o = exchange(v, 0); return lane + 1 < lanes ? o - s : old; }
     int32_t down_sub(int32_t old, int32_t v, int32_t s) { const int32_t o = exchange(v, 1); return lane > 0 ? o - s : old; }
     int32_t in_lanes(int32_t s) { return s; }
     int32_t scalar(int32_t s) { return s; }
@@ -46,7 +47,7 @@ struct XlEmu {
     unsigned long long ballot(bool flag) {
         sh->buf[lane] = flag ? 1 : 0;
         pthread_barrier_wait(&sh->bar);
-        unsigned long long m = 0; for (uint32_t l = 0; l < 64; ++l) if (sh->buf[l]) m |= 1ull << l;
+        unsigned long long m = 0; for (uint32_t l = 0; l < lanes; ++l) if (sh->buf[l]) m |= 1ull << l;
         pthread_barrier_wait(&sh->bar);
         return m;
     }
@@ -54,7 +55,7 @@ struct XlEmu {
     unsigned long long reduce_add(unsigned long long v) {
         sh->wide[lane] = v;
         pthread_barrier_wait(&sh->bar);
-        unsigned long long t = 0; for (uint32_t l = 0; l < 64; ++l) t += sh->wide[l];
+        unsigned long long t = 0; for (uint32_t l = 0; l < lanes; ++l) t += sh->wide[l];
         pthread_barrier_wait(&sh->bar);
         return t;
     }
@@ -92,14 +93,20 @@ public:
         pthread_barrier_destroy(&sh.bar);
     }
     int run_xdrop_band(const GsswMatrixParams& P) override {
-        XlShared sh; pthread_barrier_init(&sh.bar, nullptr, 64);
-        std::vector<std::thread> ts;
-        for (uint32_t lane = 0; lane < 64; ++lane) ts.emplace_back([&, lane]() {
-            XlEmu xl{&sh, lane};
-            for (uint32_t i = 0; i < P.n; ++i) { xdrop_band_wave_lane(P, i, lane, xl); xl.fence(); }
-        });
-        for (auto& t : ts) t.join();
-        pthread_barrier_destroy(&sh.bar);
+        // the launch order's two classes: problems that run in one DPP row of 16 lanes (four to a wavefront on the GPU; here one after the
+        // other — the rows do not talk to each other), then the ones that take a whole wavefront
+        auto run = [&](uint32_t lanes, uint32_t begin, uint32_t count) {
+            if (!count) return;
+            XlShared sh; pthread_barrier_init(&sh.bar, nullptr, lanes);
+            std::vector<std::thread> ts;
+            for (uint32_t lane = 0; lane < lanes; ++lane) ts.emplace_back([&, lane]() {
+                XlEmu xl{&sh, lane, lanes};
+                for (uint32_t k = 0; k < count; ++k) { xdrop_band_wave_lane(P, P.xb_order ? P.xb_order[begin + k] : begin + k, lane, xl); xl.fence(); }
+            });
+            for (auto& t : ts) t.join();
+            pthread_barrier_destroy(&sh.bar);
+        };
+        if (P.xb_order) { run(16, 0, P.xb_n16); run(64, P.xb_n16, P.xb_n64); } else run(64, 0, P.n);
         return VGK_OK;
     }
     int run_gssw_matrix(const GsswMatrixParams& P) override {

@@ -238,6 +238,7 @@ struct XlDpp {
                      "s_nop 1\n\tv_mov_b32_dpp %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v), "+v"(old));
         return old;
     }
+    __device__ __forceinline__ uint32_t width() const { return 64u; }
     __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
     __device__ __forceinline__ bool any(int32_t flag) const { return __ballot(flag != 0) != 0ull; }
     __device__ __forceinline__ unsigned long long ballot(bool flag) const { return __ballot(flag); }
@@ -590,9 +591,42 @@ __global__ void __launch_bounds__(64) gssw_matrix_kernel(const GsswMatrixParams 
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i < P.n) gssw_matrix_one(P, i);
 }
+// The same primitives over ONE ROW of 16 lanes (a DPP row): four problems share a wavefront, each in a row of its own.  Rows run loops
+// of different lengths; a row is active or masked off as a whole, and nothing here reaches outside its row.
+struct XlDpp16 {
+    __device__ __forceinline__ uint32_t width() const { return 16u; }
+    __device__ __forceinline__ int32_t down(int32_t v) const { return __builtin_amdgcn_update_dpp(BNEG, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false); }
+    __device__ __forceinline__ int32_t scan_excl(int32_t v) const {       // exclusive max-scan over the row (XlDpp::scan_excl without the steps across rows)
+        asm volatile("s_nop 4\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1" : "+v"(v));
+        return down(v);
+    }
+    __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+    __device__ __forceinline__ unsigned long long ballot(bool flag) const { return (__ballot(flag) >> (threadIdx.x & 48u)) & 0xffffull; }
+    __device__ __forceinline__ bool any(int32_t flag) const { return ballot(flag != 0) != 0ull; }
+    __device__ __forceinline__ int32_t reduce_max(int32_t v) const {
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) { const int32_t o = __shfl_xor(v, d, 16); v = o > v ? o : v; }
+        return v;
+    }
+    __device__ __forceinline__ unsigned long long reduce_add(unsigned long long v) const {
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) v += __shfl_xor(v, d, 16);
+        return v;
+    }
+};
 __global__ void __launch_bounds__(64) xdrop_band_kernel(const GsswMatrixParams P) {
     XlDpp xl;
-    xdrop_band_wave_lane(P, blockIdx.x, threadIdx.x, xl);
+    xdrop_band_wave_lane(P, P.xb_order ? P.xb_order[P.xb_n16 + blockIdx.x] : blockIdx.x, threadIdx.x, xl);
+}
+__global__ void __launch_bounds__(64) xdrop_band_kernel16(const GsswMatrixParams P) {
+    const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 4);
+    if (slot >= P.xb_n16) return;
+    XlDpp16 xl;
+    xdrop_band_wave_lane(P, P.xb_order[slot], threadIdx.x & 15u, xl);
 }
 template <int R>
 __global__ void __launch_bounds__(64) gssw_matrix_wave_kernel(const GsswMatrixParams P, const uint32_t rows_lo, const uint32_t rows_hi) {
@@ -910,7 +944,10 @@ public:
         ms_xband = 0.f;
         if (!p.n) return VGK_OK;
         hipEventRecord(bev[0], stream);
-        hipLaunchKernelGGL(xdrop_band_kernel, dim3(p.n), dim3(64), 0, stream, p);
+        if (p.xb_order) {
+            if (p.xb_n16) hipLaunchKernelGGL(xdrop_band_kernel16, dim3((p.xb_n16 + 3) / 4), dim3(64), 0, stream, p);
+            if (p.xb_n64) hipLaunchKernelGGL(xdrop_band_kernel, dim3(p.xb_n64), dim3(64), 0, stream, p);
+        } else hipLaunchKernelGGL(xdrop_band_kernel, dim3(p.n), dim3(64), 0, stream, p);
         hipEventRecord(bev[1], stream);
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         hipEventElapsedTime(&ms_xband, bev[0], bev[1]);

@@ -46,6 +46,11 @@ struct GsswMatrixParams {
     // X-drop band only, nullable: the wavefront that filled a problem also picks its end cell and walks its traceback (lane 0, over the
     // matrices it has just written) — results[i] as vgk_xdrop_band_align returns them, ops in a window of L + R + 3 elements from ops_off[i]
     vgk_result* xb_results; vgk_op* xb_ops; const uint64_t* xb_ops_off; const uint8_t* xb_want_tb;
+    // X-drop band only: the launch order.  order[0 .. n16) = problems of at most 127 read bases (128 rows = 16 of dozeu's vectors): FOUR
+    // of them share a wavefront, 16 lanes each (giraffe's tails are 1-121 bases: a whole wavefront per tail left 48-60 lanes idle);
+    // order[n16 .. n16 + n64) = the longer ones, a wavefront each.  Inside a class by descending graph size, so that the four of a
+    // wavefront run about equally long.  Null: every problem a wavefront of its own, in the order given.
+    const uint32_t* xb_order; uint32_t xb_n16, xb_n64;
 };
 
 VGK_HD void gssw_matrix_one(const GsswMatrixParams& P, uint32_t i) {
@@ -296,7 +301,7 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     // first node in order / first column / smallest row with the best score; diagonal > deletion > insertion, gap open before extend,
     // first explaining predecessor; the walk ends at the root.
     int32_t best_i = 0x7fffffff;
-    if (best_c >= 0) for (int32_t i = (int32_t)lane; i < rows; i += 64) if (H[(uint64_t)best_c * (uint64_t)rows + i] == best && i < best_i) best_i = i;
+    if (best_c >= 0) for (int32_t i = (int32_t)lane; i < rows; i += (int32_t)xl.width()) if (H[(uint64_t)best_c * (uint64_t)rows + i] == best && i < best_i) best_i = i;
     best_i = -xl.reduce_max(-best_i);
     if (lane != 0) return;
     vgk_result res{};

@@ -129,6 +129,18 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
             std::vector<uint64_t> ops_off(m + 1, 0); std::vector<uint8_t> want(m);
             for (uint32_t a = 0; a < m; ++a) { ops_off[a + 1] = ops_off[a] + probs[a].L + probs[a].R + 3ull; want[a] = (problems[owner[a]].flags & VGK_GSSW_TRACEBACK) ? 1 : 0; }
             if (ops_off[m] >= (1ull << 32)) return VGK_ETOOBIG;
+            // launch order: tails of up to 127 bases four to a wavefront (16 lanes each), the longer ones a wavefront each; inside a class
+            // by descending graph size (a counting sort), so that the problems sharing a wavefront take about equally long
+            std::vector<uint32_t> order(m);
+            uint32_t n16 = 0;
+            { constexpr uint32_t B = 4096;
+              std::vector<uint32_t> count(2 * B + 1, 0);
+              auto bucket = [&](uint32_t a) { const uint32_t r = probs[a].R < B ? probs[a].R : B - 1; return (probs[a].L <= 127u ? 0u : B) + (B - 1 - r); };
+              for (uint32_t a = 0; a < m; ++a) { ++count[bucket(a) + 1]; if (probs[a].L <= 127u) ++n16; }
+              for (uint32_t b = 0; b < 2 * B; ++b) count[b + 1] += count[b];
+              for (uint32_t a = 0; a < m; ++a) order[count[bucket(a)]++] = a; }
+            P.xb_order = (const uint32_t*)dev(80, order.data(), sizeof(uint32_t) * m); P.xb_n16 = n16; P.xb_n64 = m - n16;
+            if (!P.xb_order) return VGK_ENOMEM;
             P.xb_results = (vgk_result*)dev(72, nullptr, sizeof(vgk_result) * m);
             P.xb_ops = (vgk_op*)dev(73, nullptr, sizeof(vgk_op) * ops_off[m]);
             P.xb_ops_off = (const uint64_t*)dev(74, ops_off.data(), sizeof(uint64_t) * m);
