@@ -848,6 +848,7 @@ def bench_xdrop_band(args, eng, rank, world, dist, torch, dev_name, cus):
     ps = workloads.TailWorkload(n, seed=77 + rank).ps
     eng.lib.vgk_xdrop_band_last_ms.restype = ctypes.c_double; eng.lib.vgk_xdrop_band_last_ms.argtypes = [ctypes.c_void_p]
     eng.xdrop_band_align(ps)                                         # warms the cached buffers
+    eng.xdrop_band_align(ps)                               # warms the context's cached device buffers, as the other workloads' first call does
     t0 = time.perf_counter(); res, ops, st = eng.xdrop_band_align(ps); t_band = time.perf_counter() - t0
     k_ms = eng.lib.vgk_xdrop_band_last_ms(eng.h)
     t0 = time.perf_counter(); eres, eops = eng.align(ps, 48); t_exact = time.perf_counter() - t0
@@ -884,7 +885,7 @@ def bench_xdrop_band(args, eng, rank, world, dist, torch, dev_name, cus):
         parity = {"checked": k, "identical": int(good.sum())}
         cpu = {"value": k / tc, "unit": "alignments/s", "cores": shard.usable_cpus(), "kind": "port", "impl": "scalar int32 checker with the band (oracle/vgo_xdrop.c)", "sample": "first %d problems" % k}
     print(json.dumps({
-        "metric": "tail alignments/sec, X-drop with dozeu's band restated (host-inclusive: pack + fill kernel + D2H of the matrices + host traceback)",
+        "metric": "tail alignments/sec, X-drop with dozeu's band restated (host-inclusive, second call on a warm context: pack + H2D + fill / end cell / traceback kernel + packed ops back)",
         "value": n / t_band, "unit": "alignments/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * t_band, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
         "config": {"workload": "round-1 tails stand-in: 2 Mbp variation graph, %d tails of 1-121 bp, left-pinned, one explicit graph per problem; vgk_xdrop_band_align [PARITY-UNPINNED]" % n,

@@ -103,6 +103,7 @@ VGK_HD void gssw_matrix_one(const GsswMatrixParams& P, uint32_t i) {
 // XL = the cross-lane primitives of banded_device.hpp (down, scan_excl, fence).  Rows beyond the read compute harmless values that
 // are never stored (they only read rows above them).
 constexpr int32_t MNEG = -(1 << 28);
+struct alignas(32) MVec8 { int32_t v[8]; };       // one of dozeu's 8-cell vectors as it lies in a plane of the band matrices
 VGK_HD void bump_stat(unsigned long long* p, unsigned long long v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicAdd(p, v);
@@ -197,7 +198,8 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     constexpr int R = 8;
     MProb& pb = P.probs[pi];
     const int32_t L = (int32_t)pb.L, rows = L + 1, go = P.go, ge = P.ge;
-    const uint64_t plane = (uint64_t)pb.R * (uint64_t)rows;
+    const int32_t stride = (rows + 7) & ~7;                     // a column's cells in memory: whole 8-row vectors, so that a lane stores its vector as two 16-byte words per plane
+    const uint64_t plane = (uint64_t)pb.R * (uint64_t)stride;
     int32_t* H = P.cells + pb.mat_off; int32_t* E = H + plane; int32_t* F = E + plane;
     const uint8_t* rd = P.reads + pb.read_off; const uint8_t* ql = P.quals ? P.quals + pb.read_off : nullptr;
     const uint8_t* gr = P.graph + pb.graph_off;
@@ -213,6 +215,7 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     int32_t Hp[R], Ep[R];
     unsigned long long in_band = 0;
     int32_t best = 0, best_c = -1, best_v = 0;
+    uint32_t ref_next = pb.R ? gr[0] : 0u;
     for (uint32_t v = 0; v < pb.n_nodes; ++v) {
         const MNode nd = nodes[v];
         bool front_live = false;
@@ -239,7 +242,7 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
             } else {
                 for (int k = 0; k < R; ++k) { e[k] = MNEG; dg[k] = MNEG; }
                 for (uint32_t q = 0; q < nd.n_pred; ++q) {
-                    const uint64_t pc = (uint64_t)(nodes[P.preds[nd.pred_begin + q]].col_end - 1) * (uint64_t)rows;
+                    const uint64_t pc = (uint64_t)(nodes[P.preds[nd.pred_begin + q]].col_end - 1) * (uint64_t)stride;
                     for (int k = 0; k < R; ++k) {
                         const int32_t i = i0 + k;
                         if (i <= L) {
@@ -251,11 +254,14 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
                     }
                 }
             }
-            const uint32_t ref = gr[c];
+            const uint32_t ref = ref_next;                      // (fetched while the previous column was computed: the columns of a problem lie in a row)
+            if (c + 1 < pb.R) ref_next = gr[c + 1];
             int32_t ht[R], pre[R], run = MNEG;
             for (int k = 0; k < R; ++k) {
                 const int32_t i = i0 + k;
-                int32_t h = (i >= 1 && dg[k] > MNEG / 2) ? dg[k] + prof[k][ref] : MNEG;
+                // the row's score against this column's base, by selects: indexing prof[k][ref] with a run-time ref would put the table in scratch memory
+                const int32_t sc = ref == 0 ? prof[k][0] : ref == 1 ? prof[k][1] : ref == 2 ? prof[k][2] : ref == 3 ? prof[k][3] : prof[k][4];
+                int32_t h = (i >= 1 && dg[k] > MNEG / 2) ? dg[k] + sc : MNEG;
                 if (e[k] > h) h = e[k];
                 ht[k] = h;
                 pre[k] = run;
@@ -281,10 +287,15 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
             if (live) { sb = 0; while (!((live >> sb) & 1ull)) ++sb; eb = 64; while (!((live >> (eb - 1)) & 1ull)) --eb; }
             const bool inside = lane >= sb && lane < eb;
             for (int k = 0; k < R; ++k) {
-                const int32_t i = i0 + k;
                 if (!inside) { hh[k] = MNEG; ff[k] = MNEG; e[k] = MNEG; }
-                if (i <= L) { const uint64_t at = (uint64_t)c * (uint64_t)rows + i; H[at] = hh[k]; E[at] = e[k]; F[at] = ff[k]; if (inside) ++in_band; }
                 Hp[k] = hh[k]; Ep[k] = e[k];
+            }
+            if (i0 < stride) {                                   // (rows beyond L inside the last vector hold "unreachable")
+                const uint64_t at = (uint64_t)c * (uint64_t)stride + (uint64_t)i0;
+                MVec8 vh, ve, vf;
+                for (int k = 0; k < R; ++k) { vh.v[k] = hh[k]; ve.v[k] = e[k]; vf.v[k] = ff[k]; }
+                *reinterpret_cast<MVec8*>(H + at) = vh; *reinterpret_cast<MVec8*>(E + at) = ve; *reinterpret_cast<MVec8*>(F + at) = vf;
+                if (inside) in_band += (unsigned long long)((L < i0 + 7 ? L : i0 + 7) - i0 + 1);
             }
             const int32_t colmax = xl.reduce_max(inside ? lane_max : MNEG);
             fmax = colmax > fmax ? colmax : fmax;
@@ -301,7 +312,7 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     // first node in order / first column / smallest row with the best score; diagonal > deletion > insertion, gap open before extend,
     // first explaining predecessor; the walk ends at the root.
     int32_t best_i = 0x7fffffff;
-    if (best_c >= 0) for (int32_t i = (int32_t)lane; i < rows; i += (int32_t)xl.width()) if (H[(uint64_t)best_c * (uint64_t)rows + i] == best && i < best_i) best_i = i;
+    if (best_c >= 0) for (int32_t i = (int32_t)lane; i < rows; i += (int32_t)xl.width()) if (H[(uint64_t)best_c * (uint64_t)stride + i] == best && i < best_i) best_i = i;
     best_i = -xl.reduce_max(-best_i);
     if (lane != 0) return;
     vgk_result res{};
@@ -318,9 +329,9 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
         if (n_ops && ops[n_ops - 1].node == (uint32_t)node && ops[n_ops - 1].op == (uint8_t)op) { ops[n_ops - 1].len = (uint16_t)(ops[n_ops - 1].len + len); return; }
         vgk_op x{}; x.node = (uint32_t)node; x.op = (uint8_t)op; x.len = (uint16_t)len; ops[n_ops++] = x;
     };
-    auto hc = [&](int32_t c, int32_t i) { return H[(uint64_t)c * (uint64_t)rows + i]; };
-    auto ec = [&](int32_t c, int32_t i) { return E[(uint64_t)c * (uint64_t)rows + i]; };
-    auto fc = [&](int32_t c, int32_t i) { return F[(uint64_t)c * (uint64_t)rows + i]; };
+    auto hc = [&](int32_t c, int32_t i) { return H[(uint64_t)c * (uint64_t)stride + i]; };
+    auto ec = [&](int32_t c, int32_t i) { return E[(uint64_t)c * (uint64_t)stride + i]; };
+    auto fc = [&](int32_t c, int32_t i) { return F[(uint64_t)c * (uint64_t)stride + i]; };
     auto e_next = [&](int32_t c, int32_t i) { const int32_t a = live(hc(c, i)) ? hc(c, i) - go : MNEG, b = live(ec(c, i)) ? ec(c, i) - ge : MNEG; return a > b ? a : b; };     // E of the column after c
     auto root_h = [&](int32_t i) { return i == 0 ? 0 : (i <= pb.gap_cells && i <= L ? -(go + (i - 1) * ge) : MNEG); };
     auto score = [&](int32_t i, int32_t c) { return (int32_t)(ql ? P.mat[25 * ql[i - 1] + 5 * gr[c] + rd[i - 1]] : P.mat[5 * gr[c] + rd[i - 1]]) + (i == L ? pb.start_bonus : 0); };

@@ -71,7 +71,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
         for (; j < n; ++j) {
             if (status[j] != VGK_OK) continue;
             const vgk_gssw_problem& p = problems[j];
-            const uint64_t c3 = 3ull * cols[j] * (p.read_len + 1ull);
+            const uint64_t c3 = 3ull * cols[j] * ((p.read_len + 8ull) & ~7ull);               // (a column is whole 8-row vectors)
             if (!owner.empty() && (n_cells + c3) * sizeof(int32_t) > budget) break;
             n_cells += c3; n_read += p.read_len; n_graph += cols[j]; n_nodes += p.graph.n_nodes; n_preds += p.graph.pred_off[p.graph.n_nodes] - p.graph.pred_off[0];
             owner.push_back(j);
@@ -90,7 +90,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
                 pb.read_off = (uint32_t)a_read; pb.graph_off = (uint32_t)a_graph; pb.node_off = (uint32_t)a_nodes; pb.mat_off = a_cells;
                 probs[a] = pb;
                 pred_at[a + 1] = pred_at[a] + (p.graph.pred_off[p.graph.n_nodes] - p.graph.pred_off[0]);
-                a_cells += 3ull * pb.R * (pb.L + 1ull); a_read += pb.L; a_graph += pb.R; a_nodes += pb.n_nodes;
+                a_cells += 3ull * pb.R * ((pb.L + 8ull) & ~7ull); a_read += pb.L; a_graph += pb.R; a_nodes += pb.n_nodes;
                 rect_total += (uint64_t)pb.R * (pb.L + 1ull);
               } }
             parallel_for(m, [&](uint32_t a, unsigned) {
@@ -127,7 +127,8 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
             // the wavefront that fills a problem also picks its end cell and walks its traceback (round 3): results and ops come back,
             // the matrices stay where they are
             std::vector<uint64_t> ops_off(m + 1, 0); std::vector<uint8_t> want(m);
-            for (uint32_t a = 0; a < m; ++a) { ops_off[a + 1] = ops_off[a] + probs[a].L + probs[a].R + 3ull; want[a] = (problems[owner[a]].flags & VGK_GSSW_TRACEBACK) ? 1 : 0; }
+            const bool no_tb = std::getenv("VGAMD_XBAND_SCORES_ONLY") != nullptr;      // (a measuring aid: the fill and the end cell without the walk)
+            for (uint32_t a = 0; a < m; ++a) { ops_off[a + 1] = ops_off[a] + probs[a].L + probs[a].R + 3ull; want[a] = (problems[owner[a]].flags & VGK_GSSW_TRACEBACK) && !no_tb ? 1 : 0; }
             if (ops_off[m] >= (1ull << 32)) return VGK_ETOOBIG;
             // launch order: tails of up to 127 bases four to a wavefront (16 lanes each), the longer ones a wavefront each; inside a class
             // by descending graph size (a counting sort), so that the problems sharing a wavefront take about equally long
