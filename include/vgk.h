@@ -297,7 +297,8 @@ double vgk_xdrop_band_last_ms(vgk_ctx* ctx);     /* fill-kernel time of the last
  * matrices and enumerates the alternates over them, one lane per problem (deflections from earlier tracebacks, best first — gssw's
  * own rules are not in the reference snapshot: DESIGN.md §13); only the alignments come back.  A problem the kernel's fixed tables
  * cannot hold (a node with more than 15 predecessors, an alternate with more than 24 deflections, max_alt_alns > 62) is walked by a
- * host thread over its own matrices under the same rules; vgk_gssw_multi_host_walks counts those of the last call. */
+ * host thread over its own matrices under the same rules; vgk_gssw_multi_host_walks counts those of the last k-best call (this one or
+ * vgk_banded_align_multi). */
 int  vgk_gssw_align_multi(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, uint32_t max_alt_alns,
                           vgk_result* results /* [n * max_alt_alns] */, uint32_t* n_alignments /* [n] */,
                           vgk_op* ops, size_t ops_cap, size_t* ops_written);
@@ -332,8 +333,10 @@ int  vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t
 /* The k best alignments of every problem (Aligner::align_global_banded_multi, src/aligner.cpp:763-831: the constructor with
  * max_multi_alns and the AltTracebackStack of src/banded_global_aligner.cpp:2426-2790): results[i * max_alt_alns + k] is the
  * k-th best alignment of problem i, k < n_alignments[i], scores in descending order; a problem that fails has n_alignments 0 and
- * its status in results[i * max_alt_alns].  The fill runs on the device; the enumeration of alternates walks the device-filled
- * matrices on host threads. */
+ * its status in results[i * max_alt_alns].  The fill runs on the device and so does the enumeration of the alternates (one lane per
+ * problem over the matrices the fill keeps; only the alignments come back).  What that walk declines — a problem with a chain of empty
+ * nodes from source to sink, a traceback with more than 24 deflections, max_alt_alns > 63 — a host thread walks over the problem's
+ * matrices under the same rules; vgk_gssw_multi_host_walks counts those of the last k-best call (pinned or banded). */
 int  vgk_banded_align_multi(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n, uint32_t max_alt_alns,
                             vgk_result* results, uint32_t* n_alignments, vgk_op* ops, size_t ops_cap, size_t* ops_written);
 /* timing of the last vgk_banded_align call on this context: 0 = fill kernel ms, 1 = traceback kernel ms,

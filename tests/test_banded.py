@@ -4,6 +4,7 @@ the reported score is the score of the reported path, and with a band wide enoug
 best unbanded global alignment over all source-to-sink walks."""
 import itertools
 
+import os
 import numpy as np
 import pytest
 
@@ -322,10 +323,13 @@ def test_oracle_matches_reference_banded_multi_alignment_unit_tests():
         run_multi_case(c, util.ORACLE_LIB)
 
 
-def compare_multi(engine_lib, problems, k):
+def compare_multi(engine_lib, problems, k, walked=None):
     bs = capi.BandedSet.from_lists(problems)
     ro, co, oo = capi.Engine(lib=util.ORACLE_LIB).banded_align_multi(bs, k)
-    rg, cg, og = (capi.Engine(lib=engine_lib) if engine_lib else capi.Engine()).banded_align_multi(bs, k)
+    eng = capi.Engine(lib=engine_lib) if engine_lib else capi.Engine()
+    rg, cg, og = eng.banded_align_multi(bs, k)
+    if walked is not None:
+        walked.append((eng.multi_host_walks, bs.n))      # how many of the problems a host thread walked (the rest: banded_multi_device.hpp)
     assert (co == cg).all(), np.nonzero(co != cg)[0][:5]
     total = 0
     for i in range(bs.n):
@@ -347,11 +351,21 @@ def test_emulated_banded_multi_matches_reference_unit_tests_and_oracle():
     subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
     for c in multi_cases():
         run_multi_case(c, util.EMU_LIB)
-    assert compare_multi(util.EMU_LIB, random_banded_set(51, 30), 5) > 60
+    walked = []
+    assert compare_multi(util.EMU_LIB, random_banded_set(51, 30), 5, walked) > 60
+    assert walked[0][0] < walked[0][1] // 2, walked        # most problems are enumerated by the kernel; what it declines (chains of empty nodes) by host threads
+    os.environ["VGAMD_MULTI_HOST_WALK"] = "1"                # ... and (forced) all of them on host threads: the same answers
+    try:
+        walked = []
+        assert compare_multi(util.EMU_LIB, random_banded_set(54, 20), 5, walked) > 40 and walked[0][0] >= walked[0][1] - 2      # (all that reached the device)
+    finally:
+        del os.environ["VGAMD_MULTI_HOST_WALK"]
 
 
 @pytest.mark.gpu
 def test_hip_banded_multi_matches_reference_unit_tests_and_oracle():
     for c in multi_cases():
         run_multi_case(c, util.ENGINE_LIB)
-    assert compare_multi(None, random_banded_set(52, 1500) + mixed_band_problems(53, 60, 30, 200), 6) > 5000
+    walked = []
+    assert compare_multi(None, random_banded_set(52, 1500) + mixed_band_problems(53, 60, 30, 200), 6, walked) > 5000
+    assert walked[0][0] < walked[0][1] // 2, walked

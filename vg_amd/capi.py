@@ -361,6 +361,7 @@ class Engine:
         written = ctypes.c_size_t()
         self._check(self.lib.vgk_banded_align_multi(self.h, bs.ptr, bs.n, max_alt_alns, res.ctypes.data, cnt.ctypes.data, ops.ctypes.data, cap,
                                                     ctypes.byref(written)), "vgk_banded_align_multi")
+        self.multi_host_walks = int(self.lib.vgk_gssw_multi_host_walks(self.h))      # problems whose alternates a host thread walked
         return res, cnt, ops[:written.value]
 
     def banded_rerun(self):

@@ -13,6 +13,7 @@
 #include "wfa_wave_device.hpp"
 #include "gssw_matrix_device.hpp"
 #include "gssw_multi_device.hpp"
+#include "banded_multi_device.hpp"
 #include "gssw_pack_device.hpp"
 #include "tail_device.hpp"
 #include "minimizer_device.hpp"
@@ -110,6 +111,8 @@ public:
     virtual int   run_gssw_matrix(const GsswMatrixParams& p) = 0;
     // the k-best tracebacks over those matrices, one lane per problem (gssw_multi_device.hpp); synchronises
     virtual int   run_gssw_multi(const GsswMultiParams& p) = 0;
+    // the k-best banded alignments over the kept score matrices, one lane per problem (banded_multi_device.hpp); synchronises
+    virtual int   run_banded_multi(const BandedMultiParams& q) = 0;
     // X-drop with dozeu's band (vgk_xdrop_band_align): one wavefront per problem, the matrices stay for the host's traceback;
     // last_ms(7) = kernel ms
     virtual int   run_xdrop_band(const GsswMatrixParams& p) = 0;

@@ -583,6 +583,10 @@ __global__ void __launch_bounds__(64, VGK_WW_OCC) wfa_wave_kernel(const WwParams
 // ---- pinned gssw fill with full matrices (gssw_matrix_device.hpp): one wavefront per problem, R read rows per lane; the
 //      one-thread-per-problem form remains for scorings with gap_open < gap_extend
 // the k-best tracebacks of vgk_gssw_align_multi over the kept matrices: one lane per problem (gssw_multi_device.hpp)
+__global__ void __launch_bounds__(64) banded_multi_kernel(const BandedMultiParams Q) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < Q.P.n) banded_multi_one(Q, a);
+}
 __global__ void __launch_bounds__(64) gssw_multi_kernel(const GsswMultiParams P) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P.M.n) gssw_multi_one(P, i);
@@ -929,6 +933,13 @@ public:
             hipLaunchKernelGGL((gssw_matrix_wave_kernel<8>), dim3(p.n), dim3(64), 0, stream, p, 256u, 512u);
             hipLaunchKernelGGL((gssw_matrix_wave_kernel<16>), dim3(p.n), dim3(64), 0, stream, p, 512u, 1024u);
         }
+        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
+        return VGK_OK;
+    }
+    int run_banded_multi(const BandedMultiParams& q) override {
+        hipSetDevice(dev);
+        if (!q.P.n) return VGK_OK;
+        hipLaunchKernelGGL(banded_multi_kernel, dim3((q.P.n + 63) / 64), dim3(64), 0, stream, q);
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         return VGK_OK;
     }

@@ -476,6 +476,7 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
                              vgk_result* results, uint32_t* n_alignments, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
     if (!ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
     const bool multi = max_alt_alns > 0;
+    if (multi) ctx->multi_host_walks = 0;
     if (multi && !n_alignments) return VGK_EINVAL;
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->banded_ms[0] = ctx->banded_ms[1] = 0; ctx->banded_cells = 0; ctx->banded_bytes = 0; ctx->banded_last_valid = false;
@@ -607,18 +608,94 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
             lap("kernels");
             ctx->banded_last = P; ctx->banded_last_launches = launches; ctx->banded_last_valid = (i == 0 && j == n);     // the whole call in one sub-batch
             if (multi) {
-                // k-best: every problem's alternates are enumerated on a host thread over its score matrices
-                int32_t* hs = H.scores.get(be, tb_bytes * 3 + 1);
-                if (!hs) return VGK_ENOMEM;
-                if ((rc = be->download(hs, P.scores, (size_t)tb_bytes * 3 * sizeof(int32_t)))) return rc;
+                // k-best.  Round 3: the alternates are enumerated by a kernel over the score matrices where they lie (banded_multi_device.hpp,
+                // one lane per problem); only what it declines — problems with chains of empty nodes from source to sink, tracebacks with more
+                // deflections than a slot holds — is walked by a host thread as before, and only then do the matrices come back.
                 ctx->banded_ms[0] += be->last_ms(3);
+                std::vector<std::vector<vgk_result>> pres(m); std::vector<std::vector<vgk_op>> pops(m); std::vector<int> pstat(m, VGK_ETOOBIG);
+                const bool on_device = max_alt_alns + 1 <= 64 && !std::getenv("VGAMD_MULTI_HOST_WALK");
+                if (on_device) {
+                    BandedMultiParams Q{};
+                    Q.P = P; Q.max_alt = max_alt_alns;
+                    std::vector<uint32_t> sp_off(n_starts + 1, 0), sp_len(n_starts + 1, 0), prefix; std::vector<uint8_t> host_only(m, 0); std::vector<uint64_t> ops_off(m + 1, 0);
+                    for (uint32_t a = 0; a < m; ++a) {
+                        const Prep& hp = hps[owner[a]]; const Store& T = store[hp.thread];
+                        host_only[a] = hp.empty_walks.empty() ? 0 : 1;
+                        for (uint32_t c = 0; c < hp.starts.len; ++c) {
+                            const Span pre = T.start_prefix[hp.starts.off + c];
+                            sp_off[probs[a].start_base + c] = (uint32_t)prefix.size(); sp_len[probs[a].start_base + c] = pre.len;
+                            prefix.insert(prefix.end(), T.prefix.begin() + (long)pre.off, T.prefix.begin() + (long)pre.off + pre.len);
+                        }
+                        ops_off[a + 1] = ops_off[a] + 2ull * max_alt_alns * probs[a].ops_cap;
+                    }
+                    if (ops_off[m] >= (1ull << 32)) return VGK_ETOOBIG;
+                    const uint64_t n_res = (uint64_t)m * max_alt_alns, slots = max_alt_alns + 1;
+                    auto up = [&](int slot, const void* src, size_t bytes) -> void* {
+                        void* d = ctx->ensure_scratch(slot, std::max<size_t>(bytes, 16)); if (!d) return nullptr;
+                        if (src && bytes && be->upload(d, src, bytes)) return nullptr;
+                        return d;
+                    };
+                    Q.pool = (BmTrace*)up(72, nullptr, sizeof(BmTrace) * slots * m); Q.order = (uint32_t*)up(73, nullptr, sizeof(uint32_t) * slots * m);
+                    Q.sp_off = (const uint32_t*)up(74, sp_off.data(), sizeof(uint32_t) * (n_starts + 1)); Q.sp_len = (const uint32_t*)up(75, sp_len.data(), sizeof(uint32_t) * (n_starts + 1));
+                    Q.prefix = (const uint32_t*)up(76, prefix.data(), sizeof(uint32_t) * prefix.size()); Q.host_only = (const uint8_t*)up(77, host_only.data(), m);
+                    Q.results = (vgk_result*)up(78, nullptr, sizeof(vgk_result) * n_res); Q.n_alignments = (uint32_t*)up(79, nullptr, sizeof(uint32_t) * m);
+                    Q.ops = (vgk_op*)up(80, nullptr, sizeof(vgk_op) * ops_off[m]); Q.ops_off = (const uint64_t*)up(81, ops_off.data(), sizeof(uint64_t) * m);
+                    Q.status = (int32_t*)up(82, nullptr, sizeof(int32_t) * m);
+                    if (!Q.pool || !Q.order || !Q.sp_off || !Q.sp_len || !Q.prefix || !Q.host_only || !Q.results || !Q.n_alignments || !Q.ops || !Q.ops_off || !Q.status) return VGK_ENOMEM;
+                    if ((rc = be->zero(Q.results, sizeof(vgk_result) * n_res))) return rc;
+                    if ((rc = be->run_banded_multi(Q))) return rc;
+                    std::vector<int32_t> dstat(m); std::vector<uint32_t> dcnt(m);
+                    if ((rc = be->download(dstat.data(), Q.status, sizeof(int32_t) * m))) return rc;
+                    if ((rc = be->download(dcnt.data(), Q.n_alignments, sizeof(uint32_t) * m))) return rc;
+                    std::vector<vgk_result> dres(n_res); std::vector<vgk_op> dops2;
+                    const uint32_t blocks = (uint32_t)((n_res + Backend::OPS_SCAN_BLOCK - 1) / Backend::OPS_SCAN_BLOCK);
+                    uint32_t* offs = (uint32_t*)up(83, nullptr, sizeof(uint32_t) * n_res);
+                    uint32_t* sums = (uint32_t*)up(84, nullptr, sizeof(uint32_t) * (blocks + 8));
+                    if (!offs || !sums) return VGK_ENOMEM;
+                    uint64_t total = 0;
+                    rc = be->ops_offsets(Q.results, (uint32_t)n_res, offs, sums, &total);
+                    if (rc == VGK_OK) {
+                        vgk_result* pres_d = (vgk_result*)up(85, nullptr, sizeof(vgk_result) * n_res);
+                        vgk_op* pops_d = (vgk_op*)up(86, nullptr, sizeof(vgk_op) * std::max<uint64_t>(total, 1));
+                        if (!pres_d || !pops_d) return VGK_ENOMEM;
+                        if ((rc = be->ops_gather(Q.results, Q.ops, (uint32_t)n_res, offs, sums, pres_d, pops_d))) return rc;
+                        if ((rc = be->sync_fetch())) return rc;
+                        dops2.resize(total);
+                        if ((rc = be->download(dres.data(), pres_d, sizeof(vgk_result) * n_res))) return rc;
+                        if (total && (rc = be->download(dops2.data(), pops_d, sizeof(vgk_op) * total))) return rc;
+                    } else if (rc == VGK_EUNSUPPORTED) {
+                        dops2.resize(ops_off[m]);
+                        if ((rc = be->download(dres.data(), Q.results, sizeof(vgk_result) * n_res))) return rc;
+                        if (ops_off[m] && (rc = be->download(dops2.data(), Q.ops, sizeof(vgk_op) * ops_off[m]))) return rc;
+                    } else return rc;
+                    for (uint32_t a = 0; a < m; ++a) {
+                        if (dstat[a] == VGK_ETOOBIG) continue;                       // a host thread walks this one
+                        pstat[a] = dstat[a];
+                        if (dstat[a] != VGK_OK) continue;
+                        pres[a].assign(dres.begin() + (size_t)a * max_alt_alns, dres.begin() + (size_t)a * max_alt_alns + dcnt[a]);
+                        for (vgk_result& r : pres[a]) {
+                            const uint32_t at = (uint32_t)pops[a].size();
+                            pops[a].insert(pops[a].end(), dops2.begin() + r.ops_begin, dops2.begin() + r.ops_begin + r.n_ops);
+                            r.ops_begin = at;
+                        }
+                    }
+                }
+                std::vector<uint32_t> todo;
+                for (uint32_t a = 0; a < m; ++a) if (pstat[a] == VGK_ETOOBIG) todo.push_back(a);
+                ctx->multi_host_walks += todo.size();
+                if (!todo.empty()) {
+                    int32_t* hs = H.scores.get(be, tb_bytes * 3 + 1);
+                    if (!hs) return VGK_ENOMEM;
+                    if ((rc = be->download(hs, P.scores, (size_t)tb_bytes * 3 * sizeof(int32_t)))) return rc;
+                    parallel_for((uint32_t)todo.size(), [&](uint32_t k, unsigned) {
+                        const uint32_t a = todo[k];
+                        const Prep& hp = hps[owner[a]];
+                        MultiTracer mt{ctx, problems[owner[a]], hp, store[hp.thread], hs + 3 * probs[a].tb_base};
+                        pres[a].clear(); pops[a].clear();
+                        pstat[a] = mt.run(max_alt_alns, pres[a], pops[a]);
+                    });
+                }
                 lap("d2h");
-                std::vector<std::vector<vgk_result>> pres(m); std::vector<std::vector<vgk_op>> pops(m); std::vector<int> pstat(m, VGK_OK);
-                parallel_for(m, [&](uint32_t a, unsigned) {
-                    const Prep& hp = hps[owner[a]];
-                    MultiTracer mt{ctx, problems[owner[a]], hp, store[hp.thread], hs + 3 * probs[a].tb_base};
-                    pstat[a] = mt.run(max_alt_alns, pres[a], pops[a]);
-                });
                 for (uint32_t a = 0; a < m; ++a) {
                     const uint32_t q = owner[a]; vgk_result* r = results + (size_t)q * max_alt_alns;
                     ctx->banded_cells += hps[q].cells;
