@@ -613,7 +613,10 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
                 // deflections than a slot holds — is walked by a host thread as before, and only then do the matrices come back.
                 ctx->banded_ms[0] += be->last_ms(3);
                 std::vector<std::vector<vgk_result>> pres(m); std::vector<std::vector<vgk_op>> pops(m); std::vector<int> pstat(m, VGK_ETOOBIG);
-                const bool on_device = max_alt_alns + 1 <= 64 && !std::getenv("VGAMD_MULTI_HOST_WALK");
+                // (the walk's op windows: two op lists per alternate; a sub-batch whose windows would not fit beside the matrices stays with the host threads)
+                uint64_t window_ops = 0;
+                for (uint32_t a = 0; a < m; ++a) window_ops += 2ull * max_alt_alns * probs[a].ops_cap;
+                const bool on_device = max_alt_alns + 1 <= 64 && !std::getenv("VGAMD_MULTI_HOST_WALK") && window_ops < (1ull << 32) && window_ops * sizeof(vgk_op) <= budget / 2;
                 if (on_device) {
                     BandedMultiParams Q{};
                     Q.P = P; Q.max_alt = max_alt_alns;
@@ -628,7 +631,6 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
                         }
                         ops_off[a + 1] = ops_off[a] + 2ull * max_alt_alns * probs[a].ops_cap;
                     }
-                    if (ops_off[m] >= (1ull << 32)) return VGK_ETOOBIG;
                     const uint64_t n_res = (uint64_t)m * max_alt_alns, slots = max_alt_alns + 1;
                     auto up = [&](int slot, const void* src, size_t bytes) -> void* {
                         void* d = ctx->ensure_scratch(slot, std::max<size_t>(bytes, 16)); if (!d) return nullptr;

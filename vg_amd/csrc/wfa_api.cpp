@@ -133,6 +133,8 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     if (match < 0 || mism <= 0 || go < ge || ge <= 0) return VGK_EUNSUPPORTED;                    // (:1256-1259)
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->wfa_last_valid = false;
+    // vgk_wfa_set_cost_hints: taken by THIS call whatever becomes of it (a call that fails below must not leave them to a later one)
+    std::vector<uint32_t> hint_store; hint_store.swap(ctx->wfa_cost_hints);
     Backend* be = ctx->be.get();
     WfaParams P{};
     P.index = index->dev; P.n = n;
@@ -209,8 +211,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     if (const char* e = std::getenv("VGAMD_WFA_ORDER")) mode = std::atoi(e);
     // vgk_wfa_set_cost_hints: what the caller expects a problem to cost beyond its length (giraffe knows the graph distance between two
     // anchors: a connect whose sequence is 40 bases longer than that holds a 40-base insertion and will fill the wavefront tables);
-    // used once, for this call's order only
-    std::vector<uint32_t> hint_store; hint_store.swap(ctx->wfa_cost_hints);
+    // used once, for this call's order only (taken off the context at the top of the call)
     const uint32_t* hints = hint_store.size() == n ? hint_store.data() : nullptr;
     const uint32_t n_graph_nodes = index->n_oriented / 2 + 1;
     if (mode == 3 && n_graph_nodes <= (1u << 21)) {
