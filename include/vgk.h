@@ -368,7 +368,8 @@ int  vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* haplotypes, vgk_haplo*
 void vgk_haplo_destroy(vgk_haplo* index);
 /* The same index from the image of a GBWT file (what the reference loads with gbwt_helper's load_gbwt and reaches through
  * gbwtgraph::GBWTGraph): simple-sds serialization (header flag 0x4 — what current `vg gbwt` writes; SDSL-serialized and unidirectional
- * files: VGK_EUNSUPPORTED), bidirectional.  The even sequences are followed out of the file's records and become the threads; GBWT
+ * files: VGK_EUNSUPPORTED), bidirectional.  The records are taken over as they lie in the file (edge lists and runs decoded once per
+ * record, in parallel; nothing is walked out with LF); GBWT
  * node (offset + 1) + o becomes oriented node o, so n_nodes must be (alphabet_size - offset - 1) / 2 and node_len / seq describe those
  * nodes in id order.  Malformed or truncated image: VGK_EINVAL.  [gbwt is an absent submodule: format as published, pinned on the
  * reference's test/primers/y.gbwt — tests/test_gbwt_file.py.] */

@@ -159,6 +159,29 @@ def test_index_read_from_the_reference_gbwt(emu_lib):
         eng.haplo_index_from_gbwt(nodes, bytes(broken))
 
 
+def test_records_taken_in_place_equal_the_walked_threads(emu_lib, monkeypatch):
+    """the default loader takes the records over as they lie in the file; VGAMD_GBWT_VIA_THREADS walks every sequence out with LF and builds
+    the index from those.  Same extensions, same search states; and no corrupted body byte may take the in-place decoder down"""
+    fx, nodes, threads, image, first = fixture()
+    eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=emu_lib)
+    problems = sample(nodes, threads, np.random.default_rng(11), 120, 50)
+    in_place = extend(eng, eng.haplo_index_from_gbwt(nodes, image), problems)
+    monkeypatch.setenv("VGAMD_GBWT_VIA_THREADS", "1")
+    assert in_place == extend(eng, eng.haplo_index_from_gbwt(nodes, image), problems)
+    monkeypatch.delenv("VGAMD_GBWT_VIA_THREADS")
+    rng = np.random.default_rng(5)
+    raised = 0
+    for _ in range(300):
+        broken = bytearray(image)
+        for _ in range(int(rng.integers(1, 4))):
+            broken[int(rng.integers(0x100, len(image)))] = int(rng.integers(0, 256))
+        try:
+            eng.haplo_index_from_gbwt(nodes, bytes(broken))
+        except capi.VgkError:
+            raised += 1
+    assert raised > 50
+
+
 def test_gbz_container_decodes_to_the_graph_and_the_haplotypes(emu_lib):
     """y.giraffe.gbz holds the graph of y.gg and the haplotypes of y.gbwt: the engine's GBZ loader must hand back exactly what the golden
     script decoded from those two OTHER files"""

@@ -74,23 +74,32 @@ int vgk_ctx::finish_deferred() {
 
 extern "C" {
 
+// both strands of every node, as the kernels read them: forward strands in node order, then the reverse complements (8 bytes of padding at
+// either end: the kernels compare eight bases per load)
+extern "C++" int vgk_haplo_strands(uint32_t N, const uint32_t* node_len, const char* fwd, std::vector<uint32_t>& len, std::vector<uint32_t>& seq_off, std::vector<char>& seq, uint64_t& total) {
+    const uint32_t O = 2 * N;
+    len.assign(O, 0); seq_off.assign(O, 0);
+    total = 0; for (uint32_t i = 0; i < N; ++i) total += node_len[i];
+    if (2 * total > 0xfffffff0ull) return VGK_ETOOBIG;
+    seq.assign(2 * total + 16, 0);
+    uint32_t at = 8, rat = (uint32_t)total + 8;
+    for (uint32_t i = 0; i < N; ++i) {
+        const uint32_t L = node_len[i];
+        len[2 * i] = len[2 * i + 1] = L; seq_off[2 * i] = at; seq_off[2 * i + 1] = rat;
+        for (uint32_t k = 0; k < L; ++k) { seq[at + k] = fwd[at - 8 + k]; seq[rat + k] = complement(fwd[at - 8 + L - 1 - k]); }
+        at += L; rat += L;
+    }
+    return VGK_OK;
+}
+
 int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
     if (!ctx || !d || !out || !d->n_nodes || !d->node_len || !d->seq || (d->n_threads && (!d->thread_off || !d->thread_nodes))) return VGK_EINVAL;
     *out = nullptr;
     const uint32_t N = d->n_nodes, O = 2 * N, S = 2 * d->n_threads;
     for (uint32_t t = 0; t < d->n_threads; ++t) for (uint32_t k = d->thread_off[t]; k < d->thread_off[t + 1]; ++k) if (d->thread_nodes[k] >= O) return VGK_EINVAL;
     // both strands of every node
-    std::vector<uint32_t> len(O), seq_off(O);
-    uint64_t total = 0; for (uint32_t i = 0; i < N; ++i) total += d->node_len[i];
-    if (2 * total > 0xfffffff0ull) return VGK_ETOOBIG;
-    std::vector<char> seq(2 * total + 16, 0);       // 8 bytes of padding at either end: the kernel compares eight bases per load
-    { uint32_t at = 8, rat = (uint32_t)total + 8;
-      for (uint32_t i = 0; i < N; ++i) {
-          const uint32_t L = d->node_len[i];
-          len[2 * i] = len[2 * i + 1] = L; seq_off[2 * i] = at; seq_off[2 * i + 1] = rat;
-          for (uint32_t k = 0; k < L; ++k) { seq[at + k] = d->seq[at - 8 + k]; seq[rat + k] = complement(d->seq[at - 8 + L - 1 - k]); }
-          at += L; rat += L;
-      } }
+    std::vector<uint32_t> len, seq_off; std::vector<char> seq; uint64_t total = 0;
+    if (int rc0 = vgk_haplo_strands(N, d->node_len, d->seq, len, seq_off, seq, total)) return rc0;
     // sequences: thread t forward = 2t, reverse complement = 2t + 1
     std::vector<uint32_t> soff(S + 1, 0);
     for (uint32_t t = 0; t < d->n_threads; ++t) { const uint32_t n = d->thread_off[t + 1] - d->thread_off[t]; soff[2 * t + 1] = soff[2 * t] + n; soff[2 * t + 2] = soff[2 * t + 1] + n; }
@@ -149,8 +158,9 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
             succ[i] = v + 1 < soff[s + 1] ? sn[v + 1] : -1;
         }
     }
-    std::vector<uint32_t> edge_off(O + 1, 0), body(V), edge_base;
-    std::vector<int32_t> edge_to;
+    HaploTables T;
+    std::vector<uint32_t>& edge_off = T.edge_off; std::vector<uint32_t>& body = T.body; std::vector<uint32_t>& edge_base = T.edge_base; std::vector<int32_t>& edge_to = T.edge_to;
+    edge_off.assign(O + 1, 0); body.assign(V, 0);
     for (uint32_t o = 0; o < O; ++o) {
         std::vector<int32_t> e(succ.begin() + body_off[o], succ.begin() + body_off[o + 1]);
         std::sort(e.begin(), e.end()); e.erase(std::unique(e.begin(), e.end()), e.end());
@@ -167,6 +177,17 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
             edge_base[(uint32_t)(std::lower_bound(first, last, (int32_t)w) - edge_to.data())] = i;
         }
     }
+    T.count.swap(count); T.body_off.swap(body_off);
+    return vgk_haplo_from_tables(ctx, O, len, seq_off, seq, (uint32_t)total, T, out);
+}
+
+// The records as the kernels read them, from the tables either builder makes (this file's, from threads; gbwt_file.cpp's, straight from
+// a GBWT's own records): per oriented node its visits (count), per visit the edge it leaves through (body, from body_off), its edges in
+// successor order (edge_to from edge_off; -1 = the path ends here, first) and per edge the rank of its first visit in the successor's record.
+extern "C++" int vgk_haplo_from_tables(vgk_ctx* ctx, uint32_t O, const std::vector<uint32_t>& len, const std::vector<uint32_t>& seq_off, const std::vector<char>& seq, uint32_t total,
+                          const HaploTables& T, vgk_haplo** out) {
+    const std::vector<uint32_t>& count = T.count; const std::vector<uint32_t>& body_off = T.body_off; const std::vector<uint32_t>& body = T.body;
+    const std::vector<uint32_t>& edge_off = T.edge_off; const std::vector<int32_t>& edge_to = T.edge_to; const std::vector<uint32_t>& edge_base = T.edge_base;
     // one padded record per oriented node (layout in gapless_device.hpp): sizes first, so that every edge can name its successor's
     // record.  The visit body of a record is stored as bytes or run-length encoded (one word per run), whichever is smaller.
     std::vector<uint32_t> rec_off(O + 1, 0), rec, runs_of(O, 0);

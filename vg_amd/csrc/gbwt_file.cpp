@@ -16,6 +16,7 @@
 // the visits taking that edge, plus the edge's offset) until they return to the endmarker.  In a bidirectional GBWT sequence 2i + 1
 // is sequence 2i on the other strand, which is exactly what vgk_haplo_create derives from a thread itself: the even sequences become
 // the threads, and the index built from them holds the file's records again (the test compares search states with the file's).
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -125,9 +126,10 @@ bool lf(const uint8_t* body, size_t lo, size_t hi, uint64_t i, std::vector<Edge>
     return false;
 }
 
-// The GBWT at the cursor: header, tags, BWT -> the even sequences as threads of oriented nodes (GBWT node (offset + 1) + o -> o).
+// The GBWT at the cursor: header, tags, BWT (GBWT node (offset + 1) + o <-> oriented node o; record 0 is the endmarker's).
 // whole: also step over what follows the BWT (document-array samples, metadata: both optional structures with a size in front).
-int read_gbwt(Cursor& c, bool whole, uint32_t& n_nodes, std::vector<uint32_t>& thread_off, std::vector<uint32_t>& thread_nodes) {
+struct Bwt { uint64_t sequences = 0, size = 0, offset = 0, alphabet = 0; uint32_t n_nodes = 0; std::vector<uint64_t> starts; const uint8_t* body = nullptr; uint64_t body_len = 0; };
+int read_bwt(Cursor& c, bool whole, Bwt& B) {
     const uint32_t tag = c.u32(); c.u32();
     const uint64_t sequences = c.u64(), size = c.u64(), offset = c.u64(), alphabet = c.u64(), flags = c.u64();
     if (!c.ok || tag != 0x6B376B37u) return VGK_EINVAL;
@@ -135,19 +137,30 @@ int read_gbwt(Cursor& c, bool whole, uint32_t& n_nodes, std::vector<uint32_t>& t
     if (!(flags & 0x1u)) return VGK_EUNSUPPORTED;                           // unidirectional: the extenders need both strands
     if (alphabet <= offset + 1 || ((offset + 1) & 1) || ((alphabet - offset - 1) & 1) || alphabet - offset - 1 > 0xfffffff0ull || (sequences & 1) || size > 0xfffffff0ull) return VGK_EINVAL;
     if (sequences > size) return VGK_EINVAL;                                // every sequence visits the endmarker once, and `size` counts those visits too
-    n_nodes = (uint32_t)((alphabet - offset - 1) / 2);
+    B.sequences = sequences; B.size = size; B.offset = offset; B.alphabet = alphabet;
+    B.n_nodes = (uint32_t)((alphabet - offset - 1) / 2);
+    std::vector<uint64_t>& starts = B.starts;
     uint64_t universe = 0;
     if (!read_sparse(c, universe, nullptr)) return VGK_EINVAL;               // tags: index ...
     { const uint8_t* a; uint64_t n; if (!read_bytes(c, a, n)) return VGK_EINVAL; }      // ... alphabet ...
     { Bits d; uint64_t n, w; if (!read_int_vector(c, d, n, w)) return VGK_EINVAL; }     // ... symbols
-    std::vector<uint64_t> starts;
     if (!read_sparse(c, universe, &starts)) return VGK_EINVAL;
     const uint8_t* body = nullptr; uint64_t body_len = 0;
     if (!read_bytes(c, body, body_len) || body_len != universe || starts.size() != alphabet - offset) return VGK_EINVAL;
     for (size_t r = 0; r < starts.size(); ++r) if (starts[r] > body_len || (r && starts[r] < starts[r - 1])) return VGK_EINVAL;
     starts.push_back(body_len);
+    B.body = body; B.body_len = body_len;
     if (whole) { c.skip_option(); c.skip_option(); if (!c.ok) return VGK_EINVAL; }
+    return VGK_OK;
+}
 
+// -> the even sequences as threads of oriented nodes: each followed with LF from the endmarker until it returns there
+int read_gbwt(Cursor& c, bool whole, uint32_t& n_nodes, std::vector<uint32_t>& thread_off, std::vector<uint32_t>& thread_nodes) {
+    Bwt B;
+    if (int rc = read_bwt(c, whole, B)) return rc;
+    n_nodes = B.n_nodes;
+    const uint64_t sequences = B.sequences, size = B.size, offset = B.offset, alphabet = B.alphabet;
+    const std::vector<uint64_t>& starts = B.starts; const uint8_t* body = B.body;
     // the even sequences, one host task each: (endmarker, s) -> first node -> ... -> endmarker
     const uint32_t n_threads = (uint32_t)(sequences / 2);
     std::vector<std::vector<uint32_t>> walks(n_threads);
@@ -179,6 +192,81 @@ int read_gbwt(Cursor& c, bool whole, uint32_t& n_nodes, std::vector<uint32_t>& t
     return VGK_OK;
 }
 
+// The records taken over as they are (round 3): a GBWT record already IS what the engine's index holds per oriented node — the visits in
+// GBWT order as runs of (edge, length), the edges in successor order, each with the rank of its first visit in the successor's record —
+// so the tables of vgk_haplo_from_tables are one decoding pass per record, on the host threads; no sequence is followed.
+int gbwt_tables(const Bwt& B, HaploTables& T) {
+    const uint32_t O = 2 * B.n_nodes;
+    T.count.assign(O, 0); T.body_off.assign(O + 1, 0); T.edge_off.assign(O + 1, 0);
+    std::vector<int> bad(O, 0);
+    auto decode = [&](uint32_t o, bool fill) {
+        const size_t lo = (size_t)B.starts[(size_t)o + 1], hi = (size_t)B.starts[(size_t)o + 2];
+        if (lo == hi) return;                                                // (a node no sequence visits)
+        const Body s{B.body, hi};
+        size_t at = lo; uint64_t sigma;
+        if (!byte_code(s, at, sigma) || sigma > hi - lo) { bad[o] = 1; return; }
+        if (sigma == 0) return;
+        if (sigma > 255) { bad[o] = 2; return; }                             // (edge numbers are bytes in the engine's records)
+        uint64_t node = 0;
+        for (uint64_t e = 0; e < sigma; ++e) {
+            uint64_t delta, off;
+            if (!byte_code(s, at, delta) || !byte_code(s, at, off)) { bad[o] = 1; return; }
+            node += delta;
+            if (node != 0 && (node <= B.offset || node >= B.alphabet)) { bad[o] = 1; return; }
+            if (e && delta == 0) { bad[o] = 1; return; }
+            if (off > 0xfffffff0ull) { bad[o] = 1; return; }
+            if (fill) { T.edge_to[T.edge_off[o] + e] = node == 0 ? -1 : (int32_t)(node - B.offset - 1); T.edge_base[T.edge_off[o] + e] = node == 0 ? 0u : (uint32_t)off; }
+        }
+        const uint64_t continues = sigma < 255 ? 256 / sigma : 0;
+        uint64_t seen = 0;
+        while (at < hi) {
+            uint64_t rank, length;
+            if (continues == 0) { if (!byte_code(s, at, rank) || !byte_code(s, at, length)) { bad[o] = 1; return; } ++length; }
+            else {
+                const uint8_t code = B.body[at++];
+                rank = code % sigma; length = code / sigma + 1;
+                if (length >= continues) { uint64_t more; if (!byte_code(s, at, more)) { bad[o] = 1; return; } length += more; }
+            }
+            if (rank >= sigma || length > 0xfffffff0ull - seen) { bad[o] = 1; return; }
+            if (fill) for (uint64_t k = 0; k < length; ++k) T.body[T.body_off[o] + seen + k] = (uint32_t)rank;
+            seen += length;
+        }
+        if (!fill) { T.count[o] = (uint32_t)seen; T.edge_off[o + 1] = (uint32_t)sigma; }
+    };
+    vgk::parallel_for(O, [&](uint32_t o, unsigned) { decode(o, false); });
+    for (uint32_t o = 0; o < O; ++o) if (bad[o]) return bad[o] == 2 ? VGK_ETOOBIG : VGK_EINVAL;
+    { // the endmarker's own record is not part of the index, but it must be what the header says: one visit per sequence, every edge a node
+      const Body s{B.body, (size_t)B.starts[1]};
+      size_t at = (size_t)B.starts[0]; uint64_t sigma = 0, node = 0, seen = 0;
+      if (!byte_code(s, at, sigma) || sigma > s.end - (size_t)B.starts[0] || (sigma == 0 && B.sequences)) return VGK_EINVAL;
+      for (uint64_t e = 0; e < sigma; ++e) {
+          uint64_t delta, off;
+          if (!byte_code(s, at, delta) || !byte_code(s, at, off)) return VGK_EINVAL;
+          node += delta;
+          if (node <= B.offset || node >= B.alphabet) return VGK_EINVAL;
+      }
+      const uint64_t continues = sigma && sigma < 255 ? 256 / sigma : 0;
+      while (sigma && at < s.end) {
+          uint64_t rank, length;
+          if (continues == 0) { if (!byte_code(s, at, rank) || !byte_code(s, at, length)) return VGK_EINVAL; ++length; }
+          else { const uint8_t code = B.body[at++]; rank = code % sigma; length = code / sigma + 1; if (length >= continues) { uint64_t more; if (!byte_code(s, at, more)) return VGK_EINVAL; length += more; } }
+          if (rank >= sigma || length > B.size) return VGK_EINVAL;
+          seen += length;
+      }
+      if (seen != B.sequences) return VGK_EINVAL; }
+    uint64_t visits = 0, edges = 0;
+    for (uint32_t o = 0; o < O; ++o) {
+        T.body_off[o] = (uint32_t)visits; visits += T.count[o];
+        const uint32_t ne = T.edge_off[o + 1]; T.edge_off[o] = (uint32_t)edges; edges += ne;
+        if (visits > 0xfffffff0ull || edges > 0xfffffff0ull) return VGK_ETOOBIG;
+    }
+    T.body_off[O] = (uint32_t)visits; T.edge_off[O] = (uint32_t)edges;
+    if (visits + B.sequences != B.size) return VGK_EINVAL;                   // `size` counts every visit, the endmarker's included
+    T.body.assign((size_t)visits, 0); T.edge_to.assign((size_t)edges, -1); T.edge_base.assign((size_t)edges + 1, 0);
+    vgk::parallel_for(O, [&](uint32_t o, unsigned) { decode(o, true); });
+    return VGK_OK;
+}
+
 struct Loaded { vgk_haplotypes h; std::vector<uint32_t> node_len, thread_off, thread_nodes; std::string seq; };
 
 }  // namespace
@@ -190,6 +278,18 @@ int vgk_haplo_create_gbwt(vgk_ctx* ctx, const void* gbwt, size_t bytes, uint32_t
     *out = nullptr;
     try {
         Cursor c{(const uint8_t*)gbwt, bytes};
+        if (!std::getenv("VGAMD_GBWT_VIA_THREADS")) {
+            // the file's records become the index's as they are (no sequence is followed: what a whole-genome GBWT needs)
+            Bwt B;
+            if (int rc = read_bwt(c, false, B)) return rc;
+            if (B.n_nodes != n_nodes) return VGK_EINVAL;
+            HaploTables T;
+            if (int rc = gbwt_tables(B, T)) return rc;
+            std::vector<uint32_t> len, seq_off; std::vector<char> strands; uint64_t total = 0;
+            if (int rc = vgk_haplo_strands(n_nodes, node_len, seq, len, seq_off, strands, total)) return rc;
+            return vgk_haplo_from_tables(ctx, 2 * n_nodes, len, seq_off, strands, (uint32_t)total, T, out);
+        }
+        // (the round-2 way, kept for comparison: every sequence followed with LF, the index rebuilt from the threads)
         uint32_t nodes_in_file = 0; std::vector<uint32_t> thread_off, thread_nodes;
         const int rc = read_gbwt(c, false, nodes_in_file, thread_off, thread_nodes);
         if (rc) return rc;

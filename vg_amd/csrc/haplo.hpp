@@ -10,3 +10,9 @@ struct vgk_haplo {
     uint32_t n_oriented = 0;
     std::vector<uint32_t> len;          // host copy, for validation
 };
+
+// What either index builder hands to vgk_haplo_from_tables (gapless_api.cpp): see there.
+struct HaploTables { std::vector<uint32_t> count, body_off, body, edge_off, edge_base; std::vector<int32_t> edge_to; };
+int vgk_haplo_strands(uint32_t n_nodes, const uint32_t* node_len, const char* fwd, std::vector<uint32_t>& len, std::vector<uint32_t>& seq_off, std::vector<char>& seq, uint64_t& total);
+int vgk_haplo_from_tables(vgk_ctx* ctx, uint32_t n_oriented, const std::vector<uint32_t>& len, const std::vector<uint32_t>& seq_off, const std::vector<char>& seq, uint32_t total,
+                          const HaploTables& T, vgk_haplo** out);
