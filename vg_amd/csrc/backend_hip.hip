@@ -626,7 +626,12 @@ __global__ void __launch_bounds__(64) xdrop_band_kernel(const GsswMatrixParams P
     XlDpp xl;
     xdrop_band_wave_lane(P, P.xb_order ? P.xb_order[P.xb_n16 + blockIdx.x] : blockIdx.x, threadIdx.x, xl);
 }
-__global__ void __launch_bounds__(64) xdrop_band_kernel16(const GsswMatrixParams P) {
+// three wavefronts per SIMD (168 VGPRs, five spilled dwords): 26.2 -> 21.0 ms per 200 000 tails against the compiler's own 175 VGPRs = two;
+// four (128 VGPRs, 38 spilled): the same 20.9 ms
+#ifndef VGK_XB_OCC
+#define VGK_XB_OCC 3
+#endif
+__global__ void __launch_bounds__(64, VGK_XB_OCC) xdrop_band_kernel16(const GsswMatrixParams P) {
     const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 4);
     if (slot >= P.xb_n16) return;
     XlDpp16 xl;

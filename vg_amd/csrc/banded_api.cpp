@@ -48,12 +48,15 @@ struct Prep {                          // one problem after pass 1; its tables l
     uint32_t need = 0;                 // ops this problem hands back
     bool use_empty_walk = false;
 };
-struct Store {                         // per-thread flat tables of pass 1
+// (Store and Scratch are written by one thread each while its neighbours in the array write theirs: a cache line of their own, or every
+// push_back's size update bounces the line between cores)
+struct alignas(128) Store {           // per-thread flat tables of pass 1
     std::vector<BNode> nodes; std::vector<BSeed> seeds; std::vector<uint32_t> pool, starts, prefix;
     std::vector<Span> start_prefix;    // parallel to starts
+    void clear() { nodes.clear(); seeds.clear(); pool.clear(); starts.clear(); prefix.clear(); start_prefix.clear(); }
 };
 
-struct Scratch {                       // per-thread reusable buffers of pass 1
+struct alignas(128) Scratch {         // per-thread reusable buffers of pass 1
     std::vector<int64_t> len, shortest, longest, top, bot, cum;
     std::vector<uint8_t> masked;
     std::vector<uint32_t> succ_off, succ, fill;
@@ -230,6 +233,7 @@ template <class T> int stage(vgk_ctx* ctx, int slot, const T* v, size_t count, c
 }
 // host arenas kept on the context between calls: uninitialised storage, so a warm call neither zero-fills nor page-faults
 struct HostArenas {
+    std::vector<Scratch> scratch; std::vector<Store> store;       // pass 1's per-thread tables: their memory stays mapped between calls
     PinnedBuf<BProb> probs; PinnedBuf<BNode> nodes; PinnedBuf<BSeed> seeds; PinnedBuf<uint32_t> pool, order; PinnedBuf<BStart> starts;
     PinnedBuf<uint8_t> reads, quals, graph; PinnedBuf<BResult> dres; PinnedBuf<vgk_op> dops; PinnedBuf<int32_t> scores;
 };
@@ -494,7 +498,9 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
     auto lap = [&](const char* what) { if (!timing) return; auto t = now(); std::fprintf(stderr, "[vgk_banded_align] %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
     // pass 1: geometry and tables of every problem
     std::vector<Prep> hps(n);
-    std::vector<Scratch> scratch(MAX_THREADS); std::vector<Store> store(MAX_THREADS);
+    if (H.store.empty()) { H.scratch.resize(MAX_THREADS); H.store.resize(MAX_THREADS); }
+    std::vector<Scratch>& scratch = H.scratch; std::vector<Store>& store = H.store;
+    for (Store& T : store) T.clear();
     parallel_for(n, [&](uint32_t i, unsigned t) { hps[i].thread = t; prepare(ctx, problems[i], hps[i], scratch[t], store[t]); });
     lap("prepare");
 

@@ -206,29 +206,55 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     const MNode* nodes = P.nodes + pb.node_off;
     int32_t* node_fmax = P.node_fmax + pb.node_off;
     const int32_t i0 = (int32_t)lane * R;
+    // "Unreachable" is any value at or below MNEG / 2.  Stored cells that nothing reaches hold MNEG (or MNEG plus a few hundred: an unreachable
+    // input plus scores stays unreachable for as many steps as a diagonal is long), live ones are above -2^16: the column arithmetic below
+    // needs no test of its inputs, only the front's ballot and the traceback's equalities look at liveness.  Rows beyond L inside the last
+    // vector get a profile and a vertical-gap cost of XB_OUT, which sends whatever reaches them below MNEG / 2.
+    constexpr int32_t XB_OUT = (1 << 27) + (1 << 16);
     int32_t prof[R][5];                                        // row i consumes read base i - 1; the bonus rides on the last one
+    int32_t fsub[R], gadd[R];                                  // F(i) = (max over rows j < i of H(j) + j ge) - fsub(i);  gadd(i) = i ge
     for (int k = 0; k < R; ++k) {
         const int32_t i = i0 + k;
         for (int g = 0; g < 5; ++g)
-            prof[k][g] = (i >= 1 && i <= L) ? (int32_t)(ql ? P.mat[25 * ql[i - 1] + 5 * g + rd[i - 1]] : P.mat[5 * g + rd[i - 1]]) + (i == L ? pb.start_bonus : 0) : 0;
+            prof[k][g] = (i >= 1 && i <= L) ? (int32_t)(ql ? P.mat[25 * ql[i - 1] + 5 * g + rd[i - 1]] : P.mat[5 * g + rd[i - 1]]) + (i == L ? pb.start_bonus : 0) : -XB_OUT;
+        fsub[k] = (i >= 1 && i <= L) ? go + (i - 1) * ge : XB_OUT;
+        gadd[k] = i * ge;
     }
     int32_t Hp[R], Ep[R];
     unsigned long long in_band = 0;
     int32_t best = 0, best_c = -1, best_v = 0;
     uint32_t ref_next = pb.R ? gr[0] : 0u;
-    for (uint32_t v = 0; v < pb.n_nodes; ++v) {
-        const MNode nd = nodes[v];
-        bool front_live = false;
-        int32_t fmax = 0;                                      // a source node: the root's best is "nothing consumed", 0
-        if (nd.n_pred) { fmax = MNEG; for (uint32_t q = 0; q < nd.n_pred; ++q) { const int32_t f = node_fmax[P.preds[nd.pred_begin + q]]; fmax = f > fmax ? f : fmax; } }
-        for (uint32_t c = nd.col_start; c < nd.col_end; ++c) {
+    const int32_t band_cells = i0 < stride ? (L < i0 + 7 ? L : i0 + 7) - i0 + 1 : 0;
+    // ONE loop over the problem's columns, node after node: the four problems of a wavefront (xdrop_band_kernel16) step through their
+    // columns side by side whatever their node boundaries — as two nested loops, a problem that had finished a 3-column node waited for
+    // its neighbour's 60-column one before starting its next.
+    {
+    uint32_t v = 0, c = 0;
+    MNode nd{}; nd.col_start = nd.col_end = 0;
+    bool front_live = false, entered = false;
+    int32_t fmax = 0;
+    for (;;) {
+        while (v < pb.n_nodes && (!entered || c == nd.col_end)) {
+            if (entered) {
+                if (lane == 0) node_fmax[v] = front_live ? fmax : MNEG;      // an empty front is not merged into its successors (src/dozeu_interface.cpp:261-269)
+                xl.fence();                                                  // successors read this node's last column through memory
+                ++v;
+                if (v >= pb.n_nodes) break;
+            }
+            entered = true;
+            nd = nodes[v]; c = nd.col_start; front_live = false;
+            fmax = 0;                                          // a source node: the root's best is "nothing consumed", 0
+            if (nd.n_pred) { fmax = MNEG; for (uint32_t q = 0; q < nd.n_pred; ++q) { const int32_t f = node_fmax[P.preds[nd.pred_begin + q]]; fmax = f > fmax ? f : fmax; } }
+        }
+        if (v >= pb.n_nodes) break;
+        {
             const bool first = c == nd.col_start;
             int32_t e[R], dg[R];
             if (!first) {
                 int32_t up = xl.down(Hp[R - 1]);
                 if (lane == 0) up = MNEG;
                 for (int k = 0; k < R; ++k) {
-                    const int32_t a = Hp[k] - go, b = Ep[k] - ge; int32_t x = a > b ? a : b; e[k] = x > MNEG / 2 ? x : MNEG;
+                    const int32_t a = Hp[k] - go, b = Ep[k] - ge; e[k] = a > b ? a : b;
                     dg[k] = k ? Hp[k - 1] : up;
                 }
             } else if (nd.n_pred == 0) {                       // dozeu's root column (dz_align_init): i leading inserted bases cost go + (i - 1) ge
@@ -258,27 +284,24 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
             if (c + 1 < pb.R) ref_next = gr[c + 1];
             int32_t ht[R], pre[R], run = MNEG;
             for (int k = 0; k < R; ++k) {
-                const int32_t i = i0 + k;
                 // the row's score against this column's base, by selects: indexing prof[k][ref] with a run-time ref would put the table in scratch memory
                 const int32_t sc = ref == 0 ? prof[k][0] : ref == 1 ? prof[k][1] : ref == 2 ? prof[k][2] : ref == 3 ? prof[k][3] : prof[k][4];
-                int32_t h = (i >= 1 && dg[k] > MNEG / 2) ? dg[k] + sc : MNEG;
+                int32_t h = dg[k] + sc;                           // (row 0 has no diagonal: its dg is MNEG)
                 if (e[k] > h) h = e[k];
                 ht[k] = h;
                 pre[k] = run;
-                const int32_t gk = h > MNEG / 2 ? h + i * ge : MNEG;
+                const int32_t gk = h + gadd[k];
                 run = gk > run ? gk : run;
             }
             const int32_t excl = xl.scan_excl(run);
+            const int32_t keep = fmax - pb.xt > MNEG / 2 ? fmax - pb.xt : MNEG / 2 + 1;      // live and within xt of the best so far
             int32_t hh[R], ff[R]; bool alive = false; int32_t lane_max = MNEG;
             for (int k = 0; k < R; ++k) {
-                const int32_t i = i0 + k;
                 const int32_t pm = excl > pre[k] ? excl : pre[k];
-                int32_t f = (i >= 1 && pm > MNEG / 2) ? pm - go - (i - 1) * ge : MNEG;
-                if (f < MNEG / 2) f = MNEG;
-                int32_t h = ht[k] > f ? ht[k] : f;
-                if (i > L) { h = MNEG; f = MNEG; e[k] = MNEG; }
+                const int32_t f = pm - fsub[k];
+                const int32_t h = ht[k] > f ? ht[k] : f;
                 hh[k] = h; ff[k] = f;
-                if (h > MNEG / 2 && h >= fmax - pb.xt) alive = true;
+                alive = alive || h >= keep;
                 if (h > lane_max) lane_max = h;
             }
             // the front: vectors from the first to the last live one
@@ -287,23 +310,24 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
             if (live) { sb = 0; while (!((live >> sb) & 1ull)) ++sb; eb = 64; while (!((live >> (eb - 1)) & 1ull)) --eb; }
             const bool inside = lane >= sb && lane < eb;
             for (int k = 0; k < R; ++k) {
-                if (!inside) { hh[k] = MNEG; ff[k] = MNEG; e[k] = MNEG; }
+                const bool cell = inside && i0 + k <= L;         // (rows beyond L inside the last vector hold "unreachable")
+                if (!cell) { hh[k] = MNEG; ff[k] = MNEG; e[k] = MNEG; }
                 Hp[k] = hh[k]; Ep[k] = e[k];
             }
-            if (i0 < stride) {                                   // (rows beyond L inside the last vector hold "unreachable")
+            if (i0 < stride) {
                 const uint64_t at = (uint64_t)c * (uint64_t)stride + (uint64_t)i0;
                 MVec8 vh, ve, vf;
                 for (int k = 0; k < R; ++k) { vh.v[k] = hh[k]; ve.v[k] = e[k]; vf.v[k] = ff[k]; }
                 *reinterpret_cast<MVec8*>(H + at) = vh; *reinterpret_cast<MVec8*>(E + at) = ve; *reinterpret_cast<MVec8*>(F + at) = vf;
-                if (inside) in_band += (unsigned long long)((L < i0 + 7 ? L : i0 + 7) - i0 + 1);
+                if (inside) in_band += (unsigned long long)band_cells;
             }
             const int32_t colmax = xl.reduce_max(inside ? lane_max : MNEG);
             fmax = colmax > fmax ? colmax : fmax;
             front_live = live != 0;
             if (colmax > best) { best = colmax; best_c = (int32_t)c; best_v = (int32_t)v; }      // the end cell's column: the first one that beats every earlier one
+            ++c;
         }
-        if (lane == 0) node_fmax[v] = front_live ? fmax : MNEG;      // an empty front is not merged into its successors (src/dozeu_interface.cpp:261-269)
-        xl.fence();
+    }
     }
     const unsigned long long tot = xl.reduce_add(in_band);
     if (lane == 0) { pb.status = VGK_OK; bump_stat(P.stats, tot); }
