@@ -597,7 +597,12 @@ __global__ void __launch_bounds__(64) gssw_matrix_kernel(const GsswMatrixParams 
 }
 // The same primitives over ONE ROW of 16 lanes (a DPP row): four problems share a wavefront, each in a row of its own.  Rows run loops
 // of different lengths; a row is active or masked off as a whole, and nothing here reaches outside its row.
+constexpr uint32_t XB_STAGE16 = 1024, XB_STAGE64 = 4096;          // graph bases staged in LDS per problem (xdrop_band_wave_lane)
 struct XlDpp16 {
+    uint8_t* stg;
+    __device__ __forceinline__ uint8_t* stage() const { return stg; }
+    __device__ __forceinline__ uint32_t stage_cap() const { return XB_STAGE16; }
+    __device__ __forceinline__ void stage_sync() const { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
     __device__ __forceinline__ uint32_t width() const { return 16u; }
     __device__ __forceinline__ int32_t down(int32_t v) const { return __builtin_amdgcn_update_dpp(BNEG, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false); }
     __device__ __forceinline__ int32_t scan_excl(int32_t v) const {       // exclusive max-scan over the row (XlDpp::scan_excl without the steps across rows)
@@ -611,9 +616,12 @@ struct XlDpp16 {
     __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
     __device__ __forceinline__ unsigned long long ballot(bool flag) const { return (__ballot(flag) >> (threadIdx.x & 48u)) & 0xffffull; }
     __device__ __forceinline__ bool any(int32_t flag) const { return ballot(flag != 0) != 0ull; }
-    __device__ __forceinline__ int32_t reduce_max(int32_t v) const {
-#pragma unroll
-        for (int d = 8; d > 0; d >>= 1) { const int32_t o = __shfl_xor(v, d, 16); v = o > v ? o : v; }
+    __device__ __forceinline__ int32_t reduce_max(int32_t v) const {      // rotations inside the row (row_ror): no trip through the LDS crossbar
+        int32_t o;
+        o = __builtin_amdgcn_update_dpp(v, v, 0x128 /* row_ror:8 */, 0xf, 0xf, false); v = o > v ? o : v;
+        o = __builtin_amdgcn_update_dpp(v, v, 0x124 /* row_ror:4 */, 0xf, 0xf, false); v = o > v ? o : v;
+        o = __builtin_amdgcn_update_dpp(v, v, 0x122 /* row_ror:2 */, 0xf, 0xf, false); v = o > v ? o : v;
+        o = __builtin_amdgcn_update_dpp(v, v, 0x121 /* row_ror:1 */, 0xf, 0xf, false); v = o > v ? o : v;
         return v;
     }
     __device__ __forceinline__ unsigned long long reduce_add(unsigned long long v) const {
@@ -622,8 +630,15 @@ struct XlDpp16 {
         return v;
     }
 };
+struct XlDppStaged : XlDpp {
+    uint8_t* stg;
+    __device__ __forceinline__ uint8_t* stage() const { return stg; }
+    __device__ __forceinline__ uint32_t stage_cap() const { return XB_STAGE64; }
+    __device__ __forceinline__ void stage_sync() const { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+};
 __global__ void __launch_bounds__(64) xdrop_band_kernel(const GsswMatrixParams P) {
-    XlDpp xl;
+    __shared__ uint8_t stg[XB_STAGE64];
+    XlDppStaged xl; xl.stg = stg;
     xdrop_band_wave_lane(P, P.xb_order ? P.xb_order[P.xb_n16 + blockIdx.x] : blockIdx.x, threadIdx.x, xl);
 }
 // three wavefronts per SIMD (168 VGPRs, five spilled dwords): 26.2 -> 21.0 ms per 200 000 tails against the compiler's own 175 VGPRs = two;
@@ -632,9 +647,10 @@ __global__ void __launch_bounds__(64) xdrop_band_kernel(const GsswMatrixParams P
 #define VGK_XB_OCC 3
 #endif
 __global__ void __launch_bounds__(64, VGK_XB_OCC) xdrop_band_kernel16(const GsswMatrixParams P) {
+    __shared__ uint8_t stg[4 * XB_STAGE16];
     const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 4);
     if (slot >= P.xb_n16) return;
-    XlDpp16 xl;
+    XlDpp16 xl; xl.stg = stg + (threadIdx.x >> 4) * XB_STAGE16;
     xdrop_band_wave_lane(P, P.xb_order[slot], threadIdx.x & 15u, xl);
 }
 template <int R>

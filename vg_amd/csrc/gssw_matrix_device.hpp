@@ -196,7 +196,8 @@ VGK_HD void gssw_matrix_wave_lane(const GsswMatrixParams& P, uint32_t i, uint32_
 template <class XL>
 VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_t lane, XL& xl) {
     constexpr int R = 8;
-    MProb& pb = P.probs[pi];
+    MProb& pb_out = P.probs[pi];
+    const MProb pb = pb_out;                                   // a copy in registers: read through the reference, every field would be loaded again after each store (and wait for it)
     const int32_t L = (int32_t)pb.L, rows = L + 1, go = P.go, ge = P.ge;
     const int32_t stride = (rows + 7) & ~7;                     // a column's cells in memory: whole 8-row vectors, so that a lane stores its vector as two 16-byte words per plane
     const uint64_t plane = (uint64_t)pb.R * (uint64_t)stride;
@@ -212,18 +213,29 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     // vector get a profile and a vertical-gap cost of XB_OUT, which sends whatever reaches them below MNEG / 2.
     constexpr int32_t XB_OUT = (1 << 27) + (1 << 16);
     int32_t prof[R][5];                                        // row i consumes read base i - 1; the bonus rides on the last one
-    int32_t fsub[R], gadd[R];                                  // F(i) = (max over rows j < i of H(j) + j ge) - fsub(i);  gadd(i) = i ge
+    int32_t fsub[R];                                           // F(i) = (max over rows j < i of H(j) + j ge) - fsub(i)
+    const int32_t i0ge = i0 * ge;
     for (int k = 0; k < R; ++k) {
         const int32_t i = i0 + k;
         for (int g = 0; g < 5; ++g)
             prof[k][g] = (i >= 1 && i <= L) ? (int32_t)(ql ? P.mat[25 * ql[i - 1] + 5 * g + rd[i - 1]] : P.mat[5 * g + rd[i - 1]]) + (i == L ? pb.start_bonus : 0) : -XB_OUT;
         fsub[k] = (i >= 1 && i <= L) ? go + (i - 1) * ge : XB_OUT;
-        gadd[k] = i * ge;
     }
     int32_t Hp[R], Ep[R];
     unsigned long long in_band = 0;
     int32_t best = 0, best_c = -1, best_v = 0;
-    uint32_t ref_next = pb.R ? gr[0] : 0u;
+    // The graph's bases come through LDS, a stretch of XL::stage_cap() columns at a time.  A global load per column would do more than
+    // cost its own latency: vmcnt counts loads and stores in one order, so waiting for ANY load waits for the previous column's six
+    // 16-byte stores to be acknowledged first — measured as 75 % of the wavefronts' cycles in s_waitcnt before this (SQ_WAIT_ANY).
+    uint8_t* const stage = xl.stage(); const uint32_t stage_cap = xl.stage_cap();
+    uint32_t stage_base = 0;
+    auto refill = [&](uint32_t from) {
+        xl.stage_sync();
+        for (uint32_t j = lane; j < stage_cap && from + j < pb.R; j += xl.width()) stage[j] = gr[from + j];
+        xl.stage_sync();
+        stage_base = from;
+    };
+    refill(0);
     const int32_t band_cells = i0 < stride ? (L < i0 + 7 ? L : i0 + 7) - i0 + 1 : 0;
     // ONE loop over the problem's columns, node after node: the four problems of a wavefront (xdrop_band_kernel16) step through their
     // columns side by side whatever their node boundaries — as two nested loops, a problem that had finished a 3-column node waited for
@@ -267,21 +279,22 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
                 }
             } else {
                 for (int k = 0; k < R; ++k) { e[k] = MNEG; dg[k] = MNEG; }
-                for (uint32_t q = 0; q < nd.n_pred; ++q) {
-                    const uint64_t pc = (uint64_t)(nodes[P.preds[nd.pred_begin + q]].col_end - 1) * (uint64_t)stride;
+                // a predecessor's last column as whole vectors (columns are stored padded to vectors, rows beyond L unreachable): five loads
+                // in flight and one wait, where row-by-row reads were two dozen round trips
+                if (i0 < stride) for (uint32_t q = 0; q < nd.n_pred; ++q) {
+                    const uint64_t pc = (uint64_t)(nodes[P.preds[nd.pred_begin + q]].col_end - 1) * (uint64_t)stride + (uint64_t)i0;
+                    const MVec8 ph = *reinterpret_cast<const MVec8*>(H + pc), pe = *reinterpret_cast<const MVec8*>(E + pc);
+                    const int32_t above = i0 >= 1 ? H[pc - 1] : MNEG;
                     for (int k = 0; k < R; ++k) {
-                        const int32_t i = i0 + k;
-                        if (i <= L) {
-                            const int32_t ph = H[pc + i], pe = E[pc + i];
-                            const int32_t a = ph - go, b = pe - ge; int32_t x = a > b ? a : b; x = x > MNEG / 2 ? x : MNEG;
-                            if (x > e[k]) e[k] = x;
-                        }
-                        if (i >= 1 && i - 1 <= L) { const int32_t ph = H[pc + i - 1]; if (ph > dg[k]) dg[k] = ph; }
+                        const int32_t a = ph.v[k] - go, b = pe.v[k] - ge; int32_t x = a > b ? a : b; x = x > MNEG / 2 ? x : MNEG;
+                        if (x > e[k]) e[k] = x;
+                        const int32_t d = k ? ph.v[k - 1] : above;
+                        if (d > dg[k]) dg[k] = d;
                     }
                 }
             }
-            const uint32_t ref = ref_next;                      // (fetched while the previous column was computed: the columns of a problem lie in a row)
-            if (c + 1 < pb.R) ref_next = gr[c + 1];
+            if (c - stage_base >= stage_cap) refill(c);       // (the columns of a problem are visited in ascending order)
+            const uint32_t ref = stage[c - stage_base];
             int32_t ht[R], pre[R], run = MNEG;
             for (int k = 0; k < R; ++k) {
                 // the row's score against this column's base, by selects: indexing prof[k][ref] with a run-time ref would put the table in scratch memory
@@ -290,7 +303,7 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
                 if (e[k] > h) h = e[k];
                 ht[k] = h;
                 pre[k] = run;
-                const int32_t gk = h + gadd[k];
+                const int32_t gk = h + i0ge + k * ge;
                 run = gk > run ? gk : run;
             }
             const int32_t excl = xl.scan_excl(run);
@@ -307,7 +320,7 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
             // the front: vectors from the first to the last live one
             const unsigned long long live = xl.ballot(alive);
             uint32_t sb = 64, eb = 0;
-            if (live) { sb = 0; while (!((live >> sb) & 1ull)) ++sb; eb = 64; while (!((live >> (eb - 1)) & 1ull)) --eb; }
+            if (live) { sb = (uint32_t)__builtin_ctzll(live); eb = 64u - (uint32_t)__builtin_clzll(live); }       // first and last set bit: one instruction each
             const bool inside = lane >= sb && lane < eb;
             for (int k = 0; k < R; ++k) {
                 const bool cell = inside && i0 + k <= L;         // (rows beyond L inside the last vector hold "unreachable")
@@ -330,7 +343,7 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     }
     }
     const unsigned long long tot = xl.reduce_add(in_band);
-    if (lane == 0) { pb.status = VGK_OK; bump_stat(P.stats, tot); }
+    if (lane == 0) { pb_out.status = VGK_OK; bump_stat(P.stats, tot); }
     if (!P.xb_results) return;
     // ---- end cell and traceback, on the device (round 3; the host's BandTracer states the same rules: xdrop_band_api.cpp) ----
     // first node in order / first column / smallest row with the best score; diagonal > deletion > insertion, gap open before extend,
