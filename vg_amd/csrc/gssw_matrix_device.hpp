@@ -201,7 +201,9 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     const int32_t L = (int32_t)pb.L, rows = L + 1, go = P.go, ge = P.ge;
     const int32_t stride = (rows + 7) & ~7;                     // a column's cells in memory: whole 8-row vectors, so that a lane stores its vector as two 16-byte words per plane
     const uint64_t plane = (uint64_t)pb.R * (uint64_t)stride;
-    int32_t* H = P.cells + pb.mat_off; int32_t* E = H + plane; int32_t* F = E + plane;
+    // two planes: H and E.  F is not kept — the traceback prefers the diagonal, then the deletion, so a cell that neither explains is
+    // an insertion, and the insertion state itself walks on H alone (a third plane was a third of the kernel's HBM writes)
+    int32_t* H = P.cells + pb.mat_off; int32_t* E = H + plane;
     const uint8_t* rd = P.reads + pb.read_off; const uint8_t* ql = P.quals ? P.quals + pb.read_off : nullptr;
     const uint8_t* gr = P.graph + pb.graph_off;
     const MNode* nodes = P.nodes + pb.node_off;
@@ -308,12 +310,12 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
             }
             const int32_t excl = xl.scan_excl(run);
             const int32_t keep = fmax - pb.xt > MNEG / 2 ? fmax - pb.xt : MNEG / 2 + 1;      // live and within xt of the best so far
-            int32_t hh[R], ff[R]; bool alive = false; int32_t lane_max = MNEG;
+            int32_t hh[R]; bool alive = false; int32_t lane_max = MNEG;
             for (int k = 0; k < R; ++k) {
                 const int32_t pm = excl > pre[k] ? excl : pre[k];
                 const int32_t f = pm - fsub[k];
                 const int32_t h = ht[k] > f ? ht[k] : f;
-                hh[k] = h; ff[k] = f;
+                hh[k] = h;
                 alive = alive || h >= keep;
                 if (h > lane_max) lane_max = h;
             }
@@ -324,14 +326,14 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
             const bool inside = lane >= sb && lane < eb;
             for (int k = 0; k < R; ++k) {
                 const bool cell = inside && i0 + k <= L;         // (rows beyond L inside the last vector hold "unreachable")
-                if (!cell) { hh[k] = MNEG; ff[k] = MNEG; e[k] = MNEG; }
+                if (!cell) { hh[k] = MNEG; e[k] = MNEG; }
                 Hp[k] = hh[k]; Ep[k] = e[k];
             }
             if (i0 < stride) {
                 const uint64_t at = (uint64_t)c * (uint64_t)stride + (uint64_t)i0;
-                MVec8 vh, ve, vf;
-                for (int k = 0; k < R; ++k) { vh.v[k] = hh[k]; ve.v[k] = e[k]; vf.v[k] = ff[k]; }
-                *reinterpret_cast<MVec8*>(H + at) = vh; *reinterpret_cast<MVec8*>(E + at) = ve; *reinterpret_cast<MVec8*>(F + at) = vf;
+                MVec8 vh, ve;
+                for (int k = 0; k < R; ++k) { vh.v[k] = hh[k]; ve.v[k] = e[k]; }
+                *reinterpret_cast<MVec8*>(H + at) = vh; *reinterpret_cast<MVec8*>(E + at) = ve;
                 if (inside) in_band += (unsigned long long)band_cells;
             }
             const int32_t colmax = xl.reduce_max(inside ? lane_max : MNEG);
@@ -368,7 +370,6 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     };
     auto hc = [&](int32_t c, int32_t i) { return H[(uint64_t)c * (uint64_t)stride + i]; };
     auto ec = [&](int32_t c, int32_t i) { return E[(uint64_t)c * (uint64_t)stride + i]; };
-    auto fc = [&](int32_t c, int32_t i) { return F[(uint64_t)c * (uint64_t)stride + i]; };
     auto e_next = [&](int32_t c, int32_t i) { const int32_t a = live(hc(c, i)) ? hc(c, i) - go : MNEG, b = live(ec(c, i)) ? ec(c, i) - ge : MNEG; return a > b ? a : b; };     // E of the column after c
     auto root_h = [&](int32_t i) { return i == 0 ? 0 : (i <= pb.gap_cells && i <= L ? -(go + (i - 1) * ge) : MNEG); };
     auto score = [&](int32_t i, int32_t c) { return (int32_t)(ql ? P.mat[25 * ql[i - 1] + 5 * gr[c] + rd[i - 1]] : P.mat[5 * gr[c] + rd[i - 1]]) + (i == L ? pb.start_bonus : 0); };
@@ -402,7 +403,7 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
             }
             if (!moved) {
                 if (cur == ec(c, i)) st = ST_E;
-                else if (i > 0 && cur == fc(c, i)) st = ST_F;
+                else if (i > 0) st = ST_F;                           // neither the diagonal nor the deletion: the vertical gap
                 else { status = VGK_EINVAL; break; }
             }
         } else if (st == ST_E) {

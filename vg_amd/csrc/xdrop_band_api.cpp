@@ -8,6 +8,8 @@
 // the default and the fast path.
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 #include "ctx.hpp"
@@ -24,7 +26,9 @@ inline uint8_t code_ref(char ch) {      // dozeu sees the raw node sequences; an
     switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
 }
 
-struct BandHost { RawBuf<uint8_t> reads, quals, graph; RawBuf<MProb> probs; RawBuf<MNode> nodes; RawBuf<uint32_t> preds; };
+// page-locked staging, kept between calls: the inputs go up and the results come down at the full DMA rate (pageable vectors cost ~7 of 13 host ms per 200 000 tails)
+struct BandHost { PinnedBuf<uint8_t> reads, quals, graph, want; PinnedBuf<MProb> probs; PinnedBuf<MNode> nodes; PinnedBuf<uint32_t> preds, order; PinnedBuf<uint64_t> ops_off;
+                  PinnedBuf<vgk_result> dres; PinnedBuf<vgk_op> dops; };
 
 }  // namespace
 
@@ -44,8 +48,12 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
     BandHost& Hs = *static_cast<BandHost*>(ctx->xband_host.get());
     uint64_t budget = be->memory_bytes() ? be->memory_bytes() / 4 : (1ull << 30);
     if (const char* e = std::getenv("VGAMD_MAX_BATCH_BYTES")) budget = std::strtoull(e, nullptr, 10);
+    const bool timing = std::getenv("VGAMD_XBAND_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; const auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "[vgk_xdrop_band_align] %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
     // per-problem checks; what fails is answered in its own status
     std::vector<int> status(n, VGK_OK); std::vector<uint64_t> cols(n, 0);
+    std::vector<uint32_t> n_pred_of(n, 0), len_of(n, 0), nodes_of(n, 0);      // (what the serial placing loops below need, side by side: no second walk through every problem's pointers)
     parallel_for(n, [&](uint32_t i, unsigned) {
         const vgk_gssw_problem& p = problems[i]; const vgk_graph& g = p.graph;
         int st = VGK_OK;
@@ -61,36 +69,39 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
             }
             if (st == VGK_OK && R * (p.read_len + 1ull) > (1ull << 28)) st = VGK_ETOOBIG;
             cols[i] = R;
+            if (st == VGK_OK) { n_pred_of[i] = g.pred_off[g.n_nodes] - g.pred_off[0]; len_of[i] = p.read_len; nodes_of[i] = g.n_nodes; }
         }
         status[i] = st;
     });
+    lap("check");
     size_t used = 0; int rc_all = VGK_OK; uint64_t in_band_total = 0, rect_total = 0; double ms = 0;
     for (uint32_t i = 0; i < n;) {
         uint64_t n_cells = 0, n_read = 0, n_graph = 0, n_nodes = 0, n_preds = 0;
         uint32_t j = i; std::vector<uint32_t> owner;
         for (; j < n; ++j) {
             if (status[j] != VGK_OK) continue;
-            const vgk_gssw_problem& p = problems[j];
-            const uint64_t c3 = 3ull * cols[j] * ((p.read_len + 8ull) & ~7ull);               // (a column is whole 8-row vectors)
+            const uint64_t c3 = 2ull * cols[j] * ((len_of[j] + 8ull) & ~7ull);               // H and E planes; a column is whole 8-row vectors
             if (!owner.empty() && (n_cells + c3) * sizeof(int32_t) > budget) break;
-            n_cells += c3; n_read += p.read_len; n_graph += cols[j]; n_nodes += p.graph.n_nodes; n_preds += p.graph.pred_off[p.graph.n_nodes] - p.graph.pred_off[0];
+            n_cells += c3; n_read += len_of[j]; n_graph += cols[j]; n_nodes += nodes_of[j]; n_preds += n_pred_of[j];
             owner.push_back(j);
         }
         const uint32_t m = (uint32_t)owner.size();
-        std::vector<vgk_result> dres(m); std::vector<vgk_op> dops;             // the sub-batch's results and packed ops as they come back
+        vgk_result* dres = Hs.dres.get(be, m + 1); vgk_op* dops = nullptr;       // the sub-batch's results and packed ops as they come back
+        if (!dres) return VGK_ENOMEM;
         if (m) {
-            MProb* probs = Hs.probs.get(m + 1);
-            uint8_t* reads = Hs.reads.get(n_read + 1); uint8_t* quals = qa ? Hs.quals.get(n_read + 1) : nullptr; uint8_t* graph = Hs.graph.get(n_graph + 1);
-            MNode* nodes = Hs.nodes.get(n_nodes + 1); uint32_t* preds = Hs.preds.get(n_preds + 1);
+            MProb* probs = Hs.probs.get(be, m + 1);
+            uint8_t* reads = Hs.reads.get(be, n_read + 1); uint8_t* quals = qa ? Hs.quals.get(be, n_read + 1) : nullptr; uint8_t* graph = Hs.graph.get(be, n_graph + 1);
+            MNode* nodes = Hs.nodes.get(be, n_nodes + 1); uint32_t* preds = Hs.preds.get(be, n_preds + 1);
+            if (!probs || !reads || (qa && !quals) || !graph || !nodes || !preds) return VGK_ENOMEM;
             std::vector<uint64_t> pred_at(m + 1, 0);                          // where a problem's predecessor lists start in the shared arena
             { uint64_t a_cells = 0, a_read = 0, a_graph = 0, a_nodes = 0;
               for (uint32_t a = 0; a < m; ++a) {                                // the places first (a running sum), the contents on the host threads
-                const vgk_gssw_problem& p = problems[owner[a]];
-                MProb pb{}; pb.L = p.read_len; pb.n_nodes = p.graph.n_nodes; pb.R = (uint32_t)cols[owner[a]];
+                const uint32_t q = owner[a];
+                MProb pb{}; pb.L = len_of[q]; pb.n_nodes = nodes_of[q]; pb.R = (uint32_t)cols[q];
                 pb.read_off = (uint32_t)a_read; pb.graph_off = (uint32_t)a_graph; pb.node_off = (uint32_t)a_nodes; pb.mat_off = a_cells;
                 probs[a] = pb;
-                pred_at[a + 1] = pred_at[a] + (p.graph.pred_off[p.graph.n_nodes] - p.graph.pred_off[0]);
-                a_cells += 3ull * pb.R * ((pb.L + 8ull) & ~7ull); a_read += pb.L; a_graph += pb.R; a_nodes += pb.n_nodes;
+                pred_at[a + 1] = pred_at[a] + n_pred_of[q];
+                a_cells += 2ull * pb.R * ((pb.L + 8ull) & ~7ull); a_read += pb.L; a_graph += pb.R; a_nodes += pb.n_nodes;
                 rect_total += (uint64_t)pb.R * (pb.L + 1ull);
               } }
             parallel_for(m, [&](uint32_t a, unsigned) {
@@ -108,6 +119,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
                 if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
                 for (uint32_t c = 0; c < pb.R; ++c) graph[pb.graph_off + c] = code_ref(p.graph.seq[c]);
             });
+            lap("pack");
             GsswMatrixParams P{};
             P.n = m; P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend;
             auto dev = [&](int slot, const void* src, size_t bytes) -> void* {
@@ -126,13 +138,16 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
             P.stats = (unsigned long long*)ctx->ensure_scratch(49, 64);
             // the wavefront that fills a problem also picks its end cell and walks its traceback (round 3): results and ops come back,
             // the matrices stay where they are
-            std::vector<uint64_t> ops_off(m + 1, 0); std::vector<uint8_t> want(m);
+            uint64_t* ops_off = Hs.ops_off.get(be, m + 1); uint8_t* want = Hs.want.get(be, m + 1);
+            if (!ops_off || !want) return VGK_ENOMEM;
+            ops_off[0] = 0;
             const bool no_tb = std::getenv("VGAMD_XBAND_SCORES_ONLY") != nullptr;      // (a measuring aid: the fill and the end cell without the walk)
             for (uint32_t a = 0; a < m; ++a) { ops_off[a + 1] = ops_off[a] + probs[a].L + probs[a].R + 3ull; want[a] = (problems[owner[a]].flags & VGK_GSSW_TRACEBACK) && !no_tb ? 1 : 0; }
             if (ops_off[m] >= (1ull << 32)) return VGK_ETOOBIG;
             // launch order: tails of up to 127 bases four to a wavefront (16 lanes each), the longer ones a wavefront each; inside a class
             // by descending graph size (a counting sort), so that the problems sharing a wavefront take about equally long
-            std::vector<uint32_t> order(m);
+            uint32_t* order = Hs.order.get(be, m + 1);
+            if (!order) return VGK_ENOMEM;
             uint32_t n16 = 0;
             { constexpr uint32_t B = 4096;
               std::vector<uint32_t> count(2 * B + 1, 0);
@@ -140,21 +155,23 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
               for (uint32_t a = 0; a < m; ++a) { ++count[bucket(a) + 1]; if (probs[a].L <= 127u) ++n16; }
               for (uint32_t b = 0; b < 2 * B; ++b) count[b + 1] += count[b];
               for (uint32_t a = 0; a < m; ++a) order[count[bucket(a)]++] = a; }
-            P.xb_order = (const uint32_t*)dev(80, order.data(), sizeof(uint32_t) * m); P.xb_n16 = n16; P.xb_n64 = m - n16;
+            P.xb_order = (const uint32_t*)dev(80, order, sizeof(uint32_t) * m); P.xb_n16 = n16; P.xb_n64 = m - n16;
             if (!P.xb_order) return VGK_ENOMEM;
             P.xb_results = (vgk_result*)dev(72, nullptr, sizeof(vgk_result) * m);
             P.xb_ops = (vgk_op*)dev(73, nullptr, sizeof(vgk_op) * ops_off[m]);
-            P.xb_ops_off = (const uint64_t*)dev(74, ops_off.data(), sizeof(uint64_t) * m);
-            P.xb_want_tb = (const uint8_t*)dev(75, want.data(), m);
+            P.xb_ops_off = (const uint64_t*)dev(74, ops_off, sizeof(uint64_t) * m);
+            P.xb_want_tb = (const uint8_t*)dev(75, want, m);
             if (!P.probs || !P.reads || (qa && !P.quals) || !P.graph || !P.nodes || !P.preds || !P.mat || !P.cells || !P.node_fmax || !P.stats ||
                 !P.xb_results || !P.xb_ops || !P.xb_ops_off || !P.xb_want_tb) return VGK_ENOMEM;
             int rc;
             if ((rc = be->zero(P.stats, 64))) return rc;
+            lap("h2d");
             if ((rc = be->run_xdrop_band(P))) return rc;
             ms += be->last_ms(7);
             unsigned long long in_band = 0;
             if ((rc = be->download(&in_band, P.stats, sizeof in_band))) return rc;
             in_band_total += in_band;
+            lap("kernel");
             // ops packed behind each other on the device, then results + ops back (a backend without the packing kernels hands the windows over)
             const uint32_t blocks = (m + Backend::OPS_SCAN_BLOCK - 1) / Backend::OPS_SCAN_BLOCK;
             uint32_t* offs = (uint32_t*)dev(76, nullptr, sizeof(uint32_t) * m);
@@ -168,29 +185,39 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
                 if (!pres_d || !pops_d) return VGK_ENOMEM;
                 if ((rc = be->ops_gather(P.xb_results, P.xb_ops, m, offs, sums, pres_d, pops_d))) return rc;
                 if ((rc = be->sync_fetch())) return rc;
-                dops.resize(total);
-                if ((rc = be->download(dres.data(), pres_d, sizeof(vgk_result) * m))) return rc;
-                if (total && (rc = be->download(dops.data(), pops_d, sizeof(vgk_op) * total))) return rc;
+                dops = Hs.dops.get(be, total + 1);
+                if (!dops) return VGK_ENOMEM;
+                if ((rc = be->download(dres, pres_d, sizeof(vgk_result) * m))) return rc;
+                if (total && (rc = be->download(dops, pops_d, sizeof(vgk_op) * total))) return rc;
                 // (ops_gather zeroes n_ops of failed problems and keeps their status)
             } else if (rc == VGK_EUNSUPPORTED) {
-                dops.resize(ops_off[m]);
-                if ((rc = be->download(dres.data(), P.xb_results, sizeof(vgk_result) * m))) return rc;
-                if (ops_off[m] && (rc = be->download(dops.data(), P.xb_ops, sizeof(vgk_op) * ops_off[m]))) return rc;
+                dops = Hs.dops.get(be, ops_off[m] + 1);
+                if (!dops) return VGK_ENOMEM;
+                if ((rc = be->download(dres, P.xb_results, sizeof(vgk_result) * m))) return rc;
+                if (ops_off[m] && (rc = be->download(dops, P.xb_ops, sizeof(vgk_op) * ops_off[m]))) return rc;
             } else return rc;
 
         }
+        lap("d2h");
+        // the caller's order: places first (a running sum), then every problem copies its own ops
+        std::vector<uint32_t> from(j - i, 0);
         uint32_t a = 0;
         for (uint32_t q = i; q < j; ++q) {
             vgk_result& r = results[q];
             if (status[q] != VGK_OK) { std::memset(&r, 0, sizeof r); r.status = status[q]; r.ops_begin = (uint32_t)used; continue; }
             const uint32_t mine = a++;
             r = dres[mine];
-            const vgk_op* from = r.n_ops ? dops.data() + r.ops_begin : nullptr;
+            from[q - i] = r.ops_begin;
             r.ops_begin = (uint32_t)used;
             if (r.status != VGK_OK) { r.n_ops = 0; continue; }
             if (used + r.n_ops > ops_cap || (!ops && r.n_ops)) { r.status = VGK_EOPS; r.n_ops = 0; rc_all = VGK_EOPS; continue; }
-            if (r.n_ops) { std::memcpy(ops + used, from, sizeof(vgk_op) * r.n_ops); used += r.n_ops; }
+            used += r.n_ops;
         }
+        parallel_for(j - i, [&](uint32_t k, unsigned) {
+            const vgk_result& r = results[i + k];
+            if (r.status == VGK_OK && r.n_ops) std::memcpy(ops + r.ops_begin, dops + from[k], sizeof(vgk_op) * r.n_ops);
+        });
+        lap("results");
         i = j;
     }
     ctx->xband_ms = ms;
