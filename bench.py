@@ -884,6 +884,15 @@ def bench_xdrop_band(args, eng, rank, world, dist, torch, dev_name, cus):
             good[:] = False
         parity = {"checked": k, "identical": int(good.sum())}
         cpu = {"value": k / tc, "unit": "alignments/s", "cores": shard.usable_cpus(), "kind": "port", "impl": "scalar int32 checker with the band (oracle/vgo_xdrop.c)", "sample": "first %d problems" % k}
+    # the kernel keeps two int32 planes (H, E) of every column, whole 8-row vectors: that, the inputs and the ops are its algorithmic bytes
+    L_of = np.diff(ps.read_off).astype(np.int64); cols_of = np.diff(ps.seq_off).astype(np.int64)
+    alg_bytes = float(8 * (cols_of * ((L_of + 8) & ~7)).sum() + L_of.sum() + cols_of.sum() + 8 * int(res["n_ops"].sum()))
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "xdrop_band_kernel16 (+ xdrop_band_kernel for reads over 127 bases): fill, end cell and traceback in one launch",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": PMC_BYTES_PER_UNIT["xband"] * n if "xband" in PMC_BYTES_PER_UNIT else None,
+                "traffic_source": traffic_source("xband") if "xband" in PMC_BYTES_PER_UNIT else None,
+                "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k_ms}
     print(json.dumps({
         "metric": "tail alignments/sec, X-drop with dozeu's band restated (host-inclusive, second call on a warm context: pack + H2D + fill / end cell / traceback kernel + packed ops back)",
         "value": n / t_band, "unit": "alignments/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * t_band, "higher_is_better": True,
@@ -894,7 +903,7 @@ def bench_xdrop_band(args, eng, rank, world, dist, torch, dev_name, cus):
                  "banded_score_equals_exact": float((res["score"] == eres["score"]).mean()), "banded_score_never_higher": bool((res["score"] <= eres["score"]).all()),
                  "tails_whose_band_mode_alignment_differs_from_exact_mode": int((~band_same).sum()), "of_them_with_the_same_score": int((~band_same & (res["score"] == eres["score"])).sum()),
                  "exact_path_same_problems_host_inclusive_per_s": n / t_exact},
-        "roofline": None, "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum())}))
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "problems_failed": int((res["status"] != 0).sum())}))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -14,6 +14,7 @@ GROUPS = {   # workload -> (units per launch, kernel-name fragments of its roofl
     "banded": (100000, ["banded_fill_kernel"]),
     "gapless": (1000000, ["gapless_search_kernel", "gapless_rules_kernel", "gapless_kernel("]),
     "wfa": (500000, ["wfa_kernel", "wfa_wave_kernel"]),
+    "xband": (200000, ["xdrop_band_kernel"]),
 }
 
 
@@ -36,7 +37,10 @@ def main():
     table = json.load(open(out_path)) if os.path.exists(out_path) else {}
     dst = os.path.join(ROOT, "profiles", ROUND)
     os.makedirs(dst, exist_ok=True)
+    only = set(sys.argv[2:])        # e.g. `pmc_constants.py r03 xband`: the other workloads keep their figures and the commit those were measured at
     for name, (units, frags) in GROUPS.items():
+        if only and name not in only:
+            continue
         vals = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             found = glob.glob(os.path.join(SRC, "%s_%s" % (counter, name), "**", "*counter_collection.csv"), recursive=True)
