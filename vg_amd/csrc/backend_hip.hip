@@ -653,6 +653,11 @@ __global__ void __launch_bounds__(64, VGK_XB_OCC) xdrop_band_kernel16(const Gssw
     XlDpp16 xl; xl.stg = stg + (threadIdx.x >> 4) * XB_STAGE16;
     xdrop_band_wave_lane(P, P.xb_order[slot], threadIdx.x & 15u, xl);
 }
+// the tracebacks of the X-drop band path, one lane per problem, in the fills' launch order (neighbours walk graphs of like size)
+__global__ void __launch_bounds__(64) xdrop_band_walk_kernel(const GsswMatrixParams P) {
+    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+    if (k < P.n) xdrop_band_walk_one(P, P.xb_order ? P.xb_order[k] : k);
+}
 template <int R>
 __global__ void __launch_bounds__(64) gssw_matrix_wave_kernel(const GsswMatrixParams P, const uint32_t rows_lo, const uint32_t rows_hi) {
     const uint32_t i = blockIdx.x;
@@ -980,6 +985,7 @@ public:
             if (p.xb_n16) hipLaunchKernelGGL(xdrop_band_kernel16, dim3((p.xb_n16 + 3) / 4), dim3(64), 0, stream, p);
             if (p.xb_n64) hipLaunchKernelGGL(xdrop_band_kernel, dim3(p.xb_n64), dim3(64), 0, stream, p);
         } else hipLaunchKernelGGL(xdrop_band_kernel, dim3(p.n), dim3(64), 0, stream, p);
+        if (p.xb_results) hipLaunchKernelGGL(xdrop_band_walk_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
         hipEventRecord(bev[1], stream);
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         hipEventElapsedTime(&ms_xband, bev[0], bev[1]);

@@ -27,6 +27,7 @@ struct MProb {
     uint64_t mat_off;                 // in cells: H at mat_off, E at mat_off + R*L, F at mat_off + 2*R*L; cell (c, r) at c*L + r
     int32_t  start_bonus;             // gssw: bonus at read row 0; X-drop band: the bonus on consuming the last read base
     int32_t  status;                  // out: VGK_OK or VGK_EOVERFLOW
+    int32_t  best, best_c, best_v, best_i;   // X-drop band: the end cell the fill found (score, column, node, row), for the walk kernel
     int32_t  gap_cells, xt;           // X-drop band only: rows of the root column that hold a leading insertion (max_gap_length rounded up to
                                       // dozeu's 8-cell vector), and the x-drop threshold (go - ge) + ge * max_gap_length
 };
@@ -347,13 +348,27 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     const unsigned long long tot = xl.reduce_add(in_band);
     if (lane == 0) { pb_out.status = VGK_OK; bump_stat(P.stats, tot); }
     if (!P.xb_results) return;
-    // ---- end cell and traceback, on the device (round 3; the host's BandTracer states the same rules: xdrop_band_api.cpp) ----
-    // first node in order / first column / smallest row with the best score; diagonal > deletion > insertion, gap open before extend,
-    // first explaining predecessor; the walk ends at the root.
+    // ---- end cell (round 3): first node in order / first column / smallest row with the best score.  The traceback from it is
+    // xdrop_band_walk_one's, a kernel of its own with one LANE per problem: walked by lane 0 of this wavefront, four walks (one per row of
+    // 16 lanes) kept a 166-VGPR wavefront resident for a quarter of the launch
     int32_t best_i = 0x7fffffff;
     if (best_c >= 0) for (int32_t i = (int32_t)lane; i < rows; i += (int32_t)xl.width()) if (H[(uint64_t)best_c * (uint64_t)stride + i] == best && i < best_i) best_i = i;
     best_i = -xl.reduce_max(-best_i);
-    if (lane != 0) return;
+    if (lane == 0) { pb_out.best = best; pb_out.best_c = best_c; pb_out.best_v = best_v; pb_out.best_i = best_i; }
+}
+
+// The traceback of one problem over the H / E columns its fill left in HBM (the host's BandTracer of round 2 stated the same rules):
+// diagonal > deletion > insertion, gap open before extend, first explaining predecessor; the walk ends at the root.
+VGK_HD void xdrop_band_walk_one(const GsswMatrixParams& P, uint32_t pi) {
+    const MProb pb = P.probs[pi];
+    const int32_t L = (int32_t)pb.L, rows = L + 1, go = P.go, ge = P.ge;
+    const int32_t stride = (rows + 7) & ~7;
+    const uint64_t plane = (uint64_t)pb.R * (uint64_t)stride;
+    const int32_t* H = P.cells + pb.mat_off; const int32_t* E = H + plane;
+    const uint8_t* rd = P.reads + pb.read_off; const uint8_t* ql = P.quals ? P.quals + pb.read_off : nullptr;
+    const uint8_t* gr = P.graph + pb.graph_off;
+    const MNode* nodes = P.nodes + pb.node_off;
+    const int32_t best = pb.best, best_c = pb.best_c, best_v = pb.best_v, best_i = pb.best_i;
     vgk_result res{};
     res.end_node = -1; res.end_offset = -1; res.end_read = -1; res.status = VGK_OK; res.ops_begin = (uint32_t)P.xb_ops_off[pi];
     if (best >= 32767) { res.status = VGK_EOVERFLOW; P.xb_results[pi] = res; return; }
@@ -378,9 +393,10 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     push(n, VGK_OP_S, (uint32_t)(L - i));
     enum { ST_H, ST_E, ST_F } st = ST_H;
     const uint32_t cap = pb.L + pb.R + 3u;
+    MNode nd = nodes[n]; int32_t nd_of = n;
     for (uint32_t guard = 0; status == VGK_OK; ++guard) {
         if (guard > 2u * cap + 8u || n_ops + 2u > cap) { status = VGK_EINVAL; break; }     // (never: every step consumes a base or changes state once)
-        const MNode nd = nodes[n];
+        if (n != nd_of) { nd = nodes[n]; nd_of = n; }              // (the node's record only when the walk enters another node)
         const bool first = (uint32_t)c == nd.col_start;
         const uint32_t* pr = P.preds + nd.pred_begin;
         if (st == ST_H) {
