@@ -884,9 +884,10 @@ def bench_xdrop_band(args, eng, rank, world, dist, torch, dev_name, cus):
             good[:] = False
         parity = {"checked": k, "identical": int(good.sum())}
         cpu = {"value": k / tc, "unit": "alignments/s", "cores": shard.usable_cpus(), "kind": "port", "impl": "scalar int32 checker with the band (oracle/vgo_xdrop.c)", "sample": "first %d problems" % k}
-    # the kernel keeps two int32 planes (H, E) of every column, whole 8-row vectors: that, the inputs and the ops are its algorithmic bytes
+    # the kernel keeps H and E (int32) of the cells inside the band, in whole 8-row vectors, and two bytes per column for the band's extent:
+    # that, the inputs and the ops are its algorithmic bytes
     L_of = np.diff(ps.read_off).astype(np.int64); cols_of = np.diff(ps.seq_off).astype(np.int64)
-    alg_bytes = float(8 * (cols_of * ((L_of + 8) & ~7)).sum() + L_of.sum() + cols_of.sum() + 8 * int(res["n_ops"].sum()))
+    alg_bytes = float(8 * st[0] + 3 * cols_of.sum() + L_of.sum() + 8 * int(res["n_ops"].sum()))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "xdrop_band_kernel16 (+ xdrop_band_kernel for reads over 127 bases): fill, end cell and traceback in one launch",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -52,6 +52,7 @@ struct GsswMatrixParams {
     // order[n16 .. n16 + n64) = the longer ones, a wavefront each.  Inside a class by descending graph size, so that the four of a
     // wavefront run about equally long.  Null: every problem a wavefront of its own, in the order given.
     const uint32_t* xb_order; uint32_t xb_n16, xb_n64;
+    uint16_t* xb_front;               // per column (a problem's at its graph_off): first vector of the front | one past the last << 8 — only those vectors are stored
 };
 
 VGK_HD void gssw_matrix_one(const GsswMatrixParams& P, uint32_t i) {
@@ -114,7 +115,8 @@ VGK_HD void bump_stat(unsigned long long* p, unsigned long long v) {
 }
 template <int R, class XL>
 VGK_HD void gssw_matrix_wave_lane(const GsswMatrixParams& P, uint32_t i, uint32_t lane, XL& xl) {
-    MProb& pb = P.probs[i];
+    MProb& pb_out = P.probs[i];
+    const MProb pb = pb_out;                                   // (in registers: through the reference every field is loaded again after each store)
     const int32_t L = (int32_t)pb.L, go = P.go, ge = P.ge;
     const uint64_t plane = (uint64_t)pb.R * pb.L;
     int32_t* H = P.cells + pb.mat_off; int32_t* E = H + plane; int32_t* F = E + plane;
@@ -184,8 +186,8 @@ VGK_HD void gssw_matrix_wave_lane(const GsswMatrixParams& P, uint32_t i, uint32_
         }
         xl.fence();                                                // successors read this node's last column through memory
     }
-    if (xl.any(overflow) && lane == 0) pb.status = VGK_EOVERFLOW;
-    else if (lane == 0) pb.status = VGK_OK;
+    if (xl.any(overflow) && lane == 0) pb_out.status = VGK_EOVERFLOW;
+    else if (lane == 0) pb_out.status = VGK_OK;
 }
 
 // ---- X-drop with dozeu's band (vgk_xdrop_band_align; the rules are stated in include/vgk.h and, identically, in oracle/vgo_xdrop.c) ----
@@ -209,6 +211,7 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     const uint8_t* gr = P.graph + pb.graph_off;
     const MNode* nodes = P.nodes + pb.node_off;
     int32_t* node_fmax = P.node_fmax + pb.node_off;
+    uint16_t* front = P.xb_front + pb.graph_off;            // what of a column is in memory: vectors [front & 255, front >> 8)
     const int32_t i0 = (int32_t)lane * R;
     // "Unreachable" is any value at or below MNEG / 2.  Stored cells that nothing reaches hold MNEG (or MNEG plus a few hundred: an unreachable
     // input plus scores stays unreachable for as many steps as a diagonal is long), live ones are above -2^16: the column arithmetic below
@@ -226,7 +229,7 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     }
     int32_t Hp[R], Ep[R];
     unsigned long long in_band = 0;
-    int32_t best = 0, best_c = -1, best_v = 0;
+    int32_t best = 0, best_c = -1, best_v = 0; uint32_t best_sb = 0, best_eb = 0;
     // The graph's bases come through LDS, a stretch of XL::stage_cap() columns at a time.  A global load per column would do more than
     // cost its own latency: vmcnt counts loads and stores in one order, so waiting for ANY load waits for the previous column's six
     // 16-byte stores to be acknowledged first — measured as 75 % of the wavefronts' cycles in s_waitcnt before this (SQ_WAIT_ANY).
@@ -285,9 +288,13 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
                 // a predecessor's last column as whole vectors (columns are stored padded to vectors, rows beyond L unreachable): five loads
                 // in flight and one wait, where row-by-row reads were two dozen round trips
                 if (i0 < stride) for (uint32_t q = 0; q < nd.n_pred; ++q) {
-                    const uint64_t pc = (uint64_t)(nodes[P.preds[nd.pred_begin + q]].col_end - 1) * (uint64_t)stride + (uint64_t)i0;
-                    const MVec8 ph = *reinterpret_cast<const MVec8*>(H + pc), pe = *reinterpret_cast<const MVec8*>(E + pc);
-                    const int32_t above = i0 >= 1 ? H[pc - 1] : MNEG;
+                    const uint32_t pcol = nodes[P.preds[nd.pred_begin + q]].col_end - 1;
+                    const uint64_t pc = (uint64_t)pcol * (uint64_t)stride + (uint64_t)i0;
+                    const uint32_t fr = front[pcol], fb = fr & 255u, fe = fr >> 8;       // vectors outside the stored front are unreachable
+                    MVec8 ph, pe;
+                    if (lane >= fb && lane < fe) { ph = *reinterpret_cast<const MVec8*>(H + pc); pe = *reinterpret_cast<const MVec8*>(E + pc); }
+                    else for (int k = 0; k < R; ++k) { ph.v[k] = MNEG; pe.v[k] = MNEG; }
+                    const int32_t above = (lane >= fb + 1 && lane < fe + 1) ? H[pc - 1] : MNEG;
                     for (int k = 0; k < R; ++k) {
                         const int32_t a = ph.v[k] - go, b = pe.v[k] - ge; int32_t x = a > b ? a : b; x = x > MNEG / 2 ? x : MNEG;
                         if (x > e[k]) e[k] = x;
@@ -330,17 +337,18 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
                 if (!cell) { hh[k] = MNEG; e[k] = MNEG; }
                 Hp[k] = hh[k]; Ep[k] = e[k];
             }
-            if (i0 < stride) {
+            if (inside && i0 < stride) {                         // only the front goes to memory; its extent beside it
                 const uint64_t at = (uint64_t)c * (uint64_t)stride + (uint64_t)i0;
                 MVec8 vh, ve;
                 for (int k = 0; k < R; ++k) { vh.v[k] = hh[k]; ve.v[k] = e[k]; }
                 *reinterpret_cast<MVec8*>(H + at) = vh; *reinterpret_cast<MVec8*>(E + at) = ve;
-                if (inside) in_band += (unsigned long long)band_cells;
+                in_band += (unsigned long long)band_cells;
             }
+            if (lane == 0) front[c] = (uint16_t)(live ? (sb | (eb << 8)) : 0u);
             const int32_t colmax = xl.reduce_max(inside ? lane_max : MNEG);
             fmax = colmax > fmax ? colmax : fmax;
             front_live = live != 0;
-            if (colmax > best) { best = colmax; best_c = (int32_t)c; best_v = (int32_t)v; }      // the end cell's column: the first one that beats every earlier one
+            if (colmax > best) { best = colmax; best_c = (int32_t)c; best_v = (int32_t)v; best_sb = sb; best_eb = eb; }      // the end cell's column: the first one that beats every earlier one
             ++c;
         }
     }
@@ -352,7 +360,7 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     // xdrop_band_walk_one's, a kernel of its own with one LANE per problem: walked by lane 0 of this wavefront, four walks (one per row of
     // 16 lanes) kept a 166-VGPR wavefront resident for a quarter of the launch
     int32_t best_i = 0x7fffffff;
-    if (best_c >= 0) for (int32_t i = (int32_t)lane; i < rows; i += (int32_t)xl.width()) if (H[(uint64_t)best_c * (uint64_t)stride + i] == best && i < best_i) best_i = i;
+    if (best_c >= 0) for (int32_t i = (int32_t)(8u * best_sb + lane); i < rows && i < (int32_t)(8u * best_eb); i += (int32_t)xl.width()) if (H[(uint64_t)best_c * (uint64_t)stride + i] == best && i < best_i) best_i = i;
     best_i = -xl.reduce_max(-best_i);
     if (lane == 0) { pb_out.best = best; pb_out.best_c = best_c; pb_out.best_v = best_v; pb_out.best_i = best_i; }
 }
@@ -383,8 +391,10 @@ VGK_HD void xdrop_band_walk_one(const GsswMatrixParams& P, uint32_t pi) {
         if (n_ops && ops[n_ops - 1].node == (uint32_t)node && ops[n_ops - 1].op == (uint8_t)op) { ops[n_ops - 1].len = (uint16_t)(ops[n_ops - 1].len + len); return; }
         vgk_op x{}; x.node = (uint32_t)node; x.op = (uint8_t)op; x.len = (uint16_t)len; ops[n_ops++] = x;
     };
-    auto hc = [&](int32_t c, int32_t i) { return H[(uint64_t)c * (uint64_t)stride + i]; };
-    auto ec = [&](int32_t c, int32_t i) { return E[(uint64_t)c * (uint64_t)stride + i]; };
+    const uint16_t* front = P.xb_front + pb.graph_off;
+    auto stored = [&](int32_t c, int32_t i) { const uint32_t fr = front[c], vec = (uint32_t)i >> 3; return vec >= (fr & 255u) && vec < (fr >> 8); };      // else: unreachable, and not in memory
+    auto hc = [&](int32_t c, int32_t i) { return stored(c, i) ? H[(uint64_t)c * (uint64_t)stride + i] : MNEG; };
+    auto ec = [&](int32_t c, int32_t i) { return stored(c, i) ? E[(uint64_t)c * (uint64_t)stride + i] : MNEG; };
     auto e_next = [&](int32_t c, int32_t i) { const int32_t a = live(hc(c, i)) ? hc(c, i) - go : MNEG, b = live(ec(c, i)) ? ec(c, i) - ge : MNEG; return a > b ? a : b; };     // E of the column after c
     auto root_h = [&](int32_t i) { return i == 0 ? 0 : (i <= pb.gap_cells && i <= L ? -(go + (i - 1) * ge) : MNEG); };
     auto score = [&](int32_t i, int32_t c) { return (int32_t)(ql ? P.mat[25 * ql[i - 1] + 5 * gr[c] + rd[i - 1]] : P.mat[5 * gr[c] + rd[i - 1]]) + (i == L ? pb.start_bonus : 0); };

@@ -136,6 +136,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
             P.cells = (int32_t*)dev(47, nullptr, sizeof(int32_t) * n_cells);
             P.node_fmax = (int32_t*)ctx->ensure_scratch(48, sizeof(int32_t) * (n_nodes + 1));
             P.stats = (unsigned long long*)ctx->ensure_scratch(49, 64);
+            P.xb_front = (uint16_t*)ctx->ensure_scratch(87, sizeof(uint16_t) * (n_graph + 1));
             // the wavefront that fills a problem also picks its end cell and walks its traceback (round 3): results and ops come back,
             // the matrices stay where they are
             uint64_t* ops_off = Hs.ops_off.get(be, m + 1); uint8_t* want = Hs.want.get(be, m + 1);
@@ -162,7 +163,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
             P.xb_ops_off = (const uint64_t*)dev(74, ops_off, sizeof(uint64_t) * m);
             P.xb_want_tb = (const uint8_t*)dev(75, want, m);
             if (!P.probs || !P.reads || (qa && !P.quals) || !P.graph || !P.nodes || !P.preds || !P.mat || !P.cells || !P.node_fmax || !P.stats ||
-                !P.xb_results || !P.xb_ops || !P.xb_ops_off || !P.xb_want_tb) return VGK_ENOMEM;
+                !P.xb_results || !P.xb_ops || !P.xb_ops_off || !P.xb_want_tb || !P.xb_front) return VGK_ENOMEM;
             int rc;
             if ((rc = be->zero(P.stats, 64))) return rc;
             lap("h2d");
