@@ -889,7 +889,7 @@ def bench_xdrop_band(args, eng, rank, world, dist, torch, dev_name, cus):
     L_of = np.diff(ps.read_off).astype(np.int64); cols_of = np.diff(ps.seq_off).astype(np.int64)
     alg_bytes = float(8 * st[0] + 3 * cols_of.sum() + L_of.sum() + 8 * int(res["n_ops"].sum()))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "xdrop_band_kernel16 (+ xdrop_band_kernel for reads over 127 bases): fill, end cell and traceback in one launch",
+    roofline = {"bound": "hbm", "kernel": "xdrop_band_kernel16 (+ xdrop_band_kernel for reads over 127 bases) + xdrop_band_walk_kernel: fill with end cell, then the tracebacks; one timed region",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": PMC_BYTES_PER_UNIT["xband"] * n if "xband" in PMC_BYTES_PER_UNIT else None,
                 "traffic_source": traffic_source("xband") if "xband" in PMC_BYTES_PER_UNIT else None,
