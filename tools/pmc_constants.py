@@ -14,7 +14,7 @@ GROUPS = {   # workload -> (units per launch, kernel-name fragments of its roofl
     "banded": (100000, ["banded_fill_kernel"]),
     "gapless": (1000000, ["gapless_search_kernel", "gapless_rules_kernel", "gapless_kernel("]),
     "wfa": (500000, ["wfa_kernel", "wfa_wave_kernel"]),
-    "xband": (200000, ["xdrop_band_kernel"]),
+    "xband": (200000, ["xdrop_band_kernel", "xdrop_band_walk_kernel"]),
 }
 
 
