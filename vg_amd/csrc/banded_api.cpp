@@ -38,7 +38,7 @@ struct Prep {                          // one problem after pass 1; its tables l
     uint32_t order_key = 0;
     bool on_device = false;
     uint32_t R = 1, Hpad = 64, thread = 0;
-    uint64_t cells = 0, bases = 0, tb_bytes = 0, last_elems = 0;
+    uint64_t cells = 0, bases = 0, tb_bytes = 0, last_elems = 0, in_bytes = 0;      // in_bytes: the problem's share of the call's algorithmic bytes (all but its ops)
     uint32_t ops_cap = 0;
     Span nodes, seeds, pool, starts;   // starts: candidate end nodes; start_prefix[k] = the empty sink-side nodes of candidate k, sink first (:2455-2480)
     bool have_empty_walk = false;      // a source-to-sink chain of empty nodes (:2464-2472)
@@ -219,6 +219,7 @@ void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch&
     }
     hp.tb_bytes = (tb_off + 255) & ~255ull; hp.last_elems = last_off;
     hp.ops_cap = (uint32_t)(L + total_bases + 2ull * N + 8);
+    hp.in_bytes = p.read_len + hp.bases + 8ull * N + 4ull * g.pred_off[N] + hp.cells + 16;       // (here, on the preparing thread: the serial loop over the results would miss the cache once per problem for pred_off[N])
     hp.on_device = true;
 }
 
@@ -750,11 +751,7 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
         for (uint32_t q = i; q < j; ++q) {
             Prep& hp = hps[q]; vgk_result& r = results[q];
             r.ops_begin = (uint32_t)used;
-            if (hp.on_device) {
-                const vgk_banded_problem& p = problems[q];
-                ctx->banded_cells += hp.cells;
-                ctx->banded_bytes += p.read_len + hp.bases + 8ull * p.graph.n_nodes + 4ull * p.graph.pred_off[p.graph.n_nodes] + hp.cells + 16 + 2ull * dres[hp.arena].n_ops;
-            }
+            if (hp.on_device) { ctx->banded_cells += hp.cells; ctx->banded_bytes += hp.in_bytes + 2ull * dres[hp.arena].n_ops; }
             if (r.status != VGK_OK) continue;
             if (!ops || used + hp.need > ops_cap) { r.status = VGK_EOPS; rc_all = VGK_EOPS; hp.need = 0; continue; }
             r.n_ops = hp.need; used += hp.need;
