@@ -18,13 +18,15 @@
 namespace vgk {
 
 // banded kernels: one CPU thread per lane, the cross-lane primitives of banded_device.hpp through a barrier
-struct XlShared { pthread_barrier_t bar; int32_t buf[64]; unsigned long long wide[64]; uint8_t stage[64]; };        // stage: a small one, so that tests refill it
+struct XlShared { pthread_barrier_t bar; int32_t buf[64]; unsigned long long wide[64]; uint8_t stage[64]; int32_t cache[2 * 2 * 64 * 8]; };        // stage: a small one, so that tests refill it
 struct XlEmu {
     XlShared* sh; uint32_t lane; uint32_t lanes = 64;          // lanes: how many run together (64, or one DPP row of 16)
     uint32_t width() const { return lanes; }
     uint8_t* stage() { return sh->stage; }
     uint32_t stage_cap() const { return 64; }
     void stage_sync() { pthread_barrier_wait(&sh->bar); }
+    int32_t* col_cache() { return sh->cache; }
+    void lds_sync() { pthread_barrier_wait(&sh->bar); }
     int32_t exchange(int32_t v, int mode) {
         sh->buf[lane] = v;
         pthread_barrier_wait(&sh->bar);

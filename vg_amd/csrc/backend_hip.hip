@@ -599,7 +599,9 @@ __global__ void __launch_bounds__(64) gssw_matrix_kernel(const GsswMatrixParams 
 // of different lengths; a row is active or masked off as a whole, and nothing here reaches outside its row.
 constexpr uint32_t XB_STAGE16 = 1024, XB_STAGE64 = 4096;          // graph bases staged in LDS per problem (xdrop_band_wave_lane)
 struct XlDpp16 {
-    uint8_t* stg;
+    uint8_t* stg; int32_t* cc;
+    __device__ __forceinline__ int32_t* col_cache() const { return cc; }
+    __device__ __forceinline__ void lds_sync() const { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
     __device__ __forceinline__ uint8_t* stage() const { return stg; }
     __device__ __forceinline__ uint32_t stage_cap() const { return XB_STAGE16; }
     __device__ __forceinline__ void stage_sync() const { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
@@ -631,14 +633,18 @@ struct XlDpp16 {
     }
 };
 struct XlDppStaged : XlDpp {
-    uint8_t* stg;
+    uint8_t* stg; int32_t* cc;
+    __device__ __forceinline__ uint32_t width() const { return 64u; }
+    __device__ __forceinline__ int32_t* col_cache() const { return cc; }
+    __device__ __forceinline__ void lds_sync() const { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
     __device__ __forceinline__ uint8_t* stage() const { return stg; }
     __device__ __forceinline__ uint32_t stage_cap() const { return XB_STAGE64; }
     __device__ __forceinline__ void stage_sync() const { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 };
 __global__ void __launch_bounds__(64) xdrop_band_kernel(const GsswMatrixParams P) {
     __shared__ uint8_t stg[XB_STAGE64];
-    XlDppStaged xl; xl.stg = stg;
+    __shared__ int32_t cc[2 * 2 * 64 * 8];                       // two last columns (H | E) of up to 512 rows
+    XlDppStaged xl; xl.stg = stg; xl.cc = cc;
     xdrop_band_wave_lane(P, P.xb_order ? P.xb_order[P.xb_n16 + blockIdx.x] : blockIdx.x, threadIdx.x, xl);
 }
 // three wavefronts per SIMD (168 VGPRs, five spilled dwords): 26.2 -> 21.0 ms per 200 000 tails against the compiler's own 175 VGPRs = two;
@@ -648,9 +654,10 @@ __global__ void __launch_bounds__(64) xdrop_band_kernel(const GsswMatrixParams P
 #endif
 __global__ void __launch_bounds__(64, VGK_XB_OCC) xdrop_band_kernel16(const GsswMatrixParams P) {
     __shared__ uint8_t stg[4 * XB_STAGE16];
+    __shared__ int32_t cc[4 * 2 * 2 * 16 * 8];                   // per problem: two last columns (H | E) of up to 128 rows
     const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 4);
     if (slot >= P.xb_n16) return;
-    XlDpp16 xl; xl.stg = stg + (threadIdx.x >> 4) * XB_STAGE16;
+    XlDpp16 xl; xl.stg = stg + (threadIdx.x >> 4) * XB_STAGE16; xl.cc = cc + (threadIdx.x >> 4) * (2 * 2 * 16 * 8);
     xdrop_band_wave_lane(P, P.xb_order[slot], threadIdx.x & 15u, xl);
 }
 // the tracebacks of the X-drop band path, one lane per problem, in the fills' launch order (neighbours walk graphs of like size)

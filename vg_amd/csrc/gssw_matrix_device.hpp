@@ -249,20 +249,39 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     {
     uint32_t v = 0, c = 0;
     MNode nd{}; nd.col_start = nd.col_end = 0;
-    bool front_live = false, entered = false;
+    bool front_live = false, entered = false, fenced = true;
     int32_t fmax = 0;
+    int32_t* const cache = xl.col_cache(); const uint32_t cache_w = xl.width() * 8u;      // two slots of H | E, one int per row of the wavefront (row of lanes)
+    int32_t tag0 = -1, tag1 = -1, cfm0 = MNEG, cfm1 = MNEG;                               // the node each slot holds and its node_fmax
     for (;;) {
         while (v < pb.n_nodes && (!entered || c == nd.col_end)) {
             if (entered) {
-                if (lane == 0) node_fmax[v] = front_live ? fmax : MNEG;      // an empty front is not merged into its successors (src/dozeu_interface.cpp:261-269)
-                xl.fence();                                                  // successors read this node's last column through memory
+                const int32_t nf = front_live ? fmax : MNEG;                 // an empty front is not merged into its successors (src/dozeu_interface.cpp:261-269)
+                if (lane == 0) node_fmax[v] = nf;
+                // The node's last column (the masked Hp / Ep) also goes into the LDS slot v & 1: the two nodes before a node are the
+                // predecessors of nearly every node of a variation graph (both sides of a SNP or an indel), and reading them back from
+                // memory meant waiting for this wavefront's own stores to be acknowledged and then for the loads.
+                { int32_t* ch = cache + (v & 1u) * 2u * cache_w;
+                  for (int k = 0; k < R; ++k) { ch[i0 + k] = Hp[k]; ch[cache_w + i0 + k] = Ep[k]; }
+                  if (v & 1u) { tag1 = (int32_t)v; cfm1 = nf; } else { tag0 = (int32_t)v; cfm0 = nf; } }
+                xl.lds_sync();
+                fenced = false;
                 ++v;
                 if (v >= pb.n_nodes) break;
             }
             entered = true;
             nd = nodes[v]; c = nd.col_start; front_live = false;
             fmax = 0;                                          // a source node: the root's best is "nothing consumed", 0
-            if (nd.n_pred) { fmax = MNEG; for (uint32_t q = 0; q < nd.n_pred; ++q) { const int32_t f = node_fmax[P.preds[nd.pred_begin + q]]; fmax = f > fmax ? f : fmax; } }
+            if (nd.n_pred) {
+                fmax = MNEG;
+                for (uint32_t q = 0; q < nd.n_pred; ++q) {
+                    const int32_t pr = (int32_t)P.preds[nd.pred_begin + q];
+                    int32_t f;
+                    if (pr == tag0) f = cfm0; else if (pr == tag1) f = cfm1;
+                    else { if (!fenced) { xl.fence(); fenced = true; } f = node_fmax[pr]; }       // an older node: through memory, once this wavefront's stores are there
+                    fmax = f > fmax ? f : fmax;
+                }
+            }
         }
         if (v >= pb.n_nodes) break;
         {
@@ -288,13 +307,20 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
                 // a predecessor's last column as whole vectors (columns are stored padded to vectors, rows beyond L unreachable): five loads
                 // in flight and one wait, where row-by-row reads were two dozen round trips
                 if (i0 < stride) for (uint32_t q = 0; q < nd.n_pred; ++q) {
-                    const uint32_t pcol = nodes[P.preds[nd.pred_begin + q]].col_end - 1;
-                    const uint64_t pc = (uint64_t)pcol * (uint64_t)stride + (uint64_t)i0;
-                    const uint32_t fr = front[pcol], fb = fr & 255u, fe = fr >> 8;       // vectors outside the stored front are unreachable
-                    MVec8 ph, pe;
-                    if (lane >= fb && lane < fe) { ph = *reinterpret_cast<const MVec8*>(H + pc); pe = *reinterpret_cast<const MVec8*>(E + pc); }
-                    else for (int k = 0; k < R; ++k) { ph.v[k] = MNEG; pe.v[k] = MNEG; }
-                    const int32_t above = (lane >= fb + 1 && lane < fe + 1) ? H[pc - 1] : MNEG;
+                    const int32_t pr = (int32_t)P.preds[nd.pred_begin + q];
+                    MVec8 ph, pe; int32_t above;
+                    if (pr == tag0 || pr == tag1) {                  // one of the two nodes before this one: its last column is in LDS
+                        const int32_t* ch = cache + (pr == tag1 ? 2u * cache_w : 0u);
+                        for (int k = 0; k < R; ++k) { ph.v[k] = ch[i0 + k]; pe.v[k] = ch[cache_w + i0 + k]; }
+                        above = i0 >= 1 ? ch[i0 - 1] : MNEG;
+                    } else {
+                        const uint32_t pcol = nodes[pr].col_end - 1;
+                        const uint64_t pc = (uint64_t)pcol * (uint64_t)stride + (uint64_t)i0;
+                        const uint32_t fr = front[pcol], fb = fr & 255u, fe = fr >> 8;       // vectors outside the stored front are unreachable
+                        if (lane >= fb && lane < fe) { ph = *reinterpret_cast<const MVec8*>(H + pc); pe = *reinterpret_cast<const MVec8*>(E + pc); }
+                        else for (int k = 0; k < R; ++k) { ph.v[k] = MNEG; pe.v[k] = MNEG; }
+                        above = (lane >= fb + 1 && lane < fe + 1) ? H[pc - 1] : MNEG;
+                    }
                     for (int k = 0; k < R; ++k) {
                         const int32_t a = ph.v[k] - go, b = pe.v[k] - ge; int32_t x = a > b ? a : b; x = x > MNEG / 2 ? x : MNEG;
                         if (x > e[k]) e[k] = x;
@@ -360,6 +386,7 @@ VGK_HD void xdrop_band_wave_lane(const GsswMatrixParams& P, uint32_t pi, uint32_
     // xdrop_band_walk_one's, a kernel of its own with one LANE per problem: walked by lane 0 of this wavefront, four walks (one per row of
     // 16 lanes) kept a 166-VGPR wavefront resident for a quarter of the launch
     int32_t best_i = 0x7fffffff;
+    xl.fence();                                                // (the end column is read back from memory, across lanes)
     if (best_c >= 0) for (int32_t i = (int32_t)(8u * best_sb + lane); i < rows && i < (int32_t)(8u * best_eb); i += (int32_t)xl.width()) if (H[(uint64_t)best_c * (uint64_t)stride + i] == best && i < best_i) best_i = i;
     best_i = -xl.reduce_max(-best_i);
     if (lane == 0) { pb_out.best = best; pb_out.best_c = best_c; pb_out.best_v = best_v; pb_out.best_i = best_i; }
