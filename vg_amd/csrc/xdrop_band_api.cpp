@@ -1,11 +1,12 @@
 // xdrop_band_api.cpp — vgk_xdrop_band_align: pinned X-drop extension WITH dozeu's band (include/vgk.h states the rules;
 // reference call sites src/dozeu_interface.cpp:226, :261-283, src/xdrop_aligner.cpp:95-109).
 //
-// Device: one wavefront per problem fills the H / E / F columns, one of dozeu's 8-cell vectors per lane, trimming the front after
-// every column, and — round 3 — then picks the end cell and walks the traceback over the matrices it has just written
-// (gssw_matrix_device.hpp: xdrop_band_wave_lane); the ops are packed on the device and only results and ops come back (round 2 copied
-// the matrices, 12 B per cell, and traced on host threads).  VGK_XDROP_PINNED through vgk_gssw_* (every cell kept, 4-bit codes) stays
-// the default and the fast path.
+// Device (gssw_matrix_device.hpp): xdrop_band_wave_lane fills a problem's columns — one of dozeu's 8-cell vectors per lane, four problems
+// of up to 127 read bases to a wavefront (a DPP row of 16 lanes each), the front trimmed after every column, only the front's H and E
+// vectors written (two bytes per column say where it lies), the last columns of the two nodes before a node kept in LDS — and finds the
+// end cell; xdrop_band_walk_one, a kernel of its own with one lane per problem, walks the traceback over what the fill left in HBM; the
+// ops are packed on the device and only results and ops come back (round 2 copied three planes and traced on host threads).  DESIGN.md
+// §15 has the measurements.  VGK_XDROP_PINNED through vgk_gssw_* (every cell kept, 4-bit codes) stays the default and the fast path.
 #include <algorithm>
 #include <cstdlib>
 #include <chrono>
