@@ -284,11 +284,11 @@ double   vgk_tail_stage_last_ms(vgk_ctx* ctx, int which);             /* 0 tails
  * preferences — is as in VGK_XDROP_PINNED.  Problems must be VGK_XDROP_PINNED (| VGK_GSSW_TRACEBACK); reads up to 511 bases.
  * stats (nullable): [0] cells inside the bands, [1] cells of the full read x graph rectangles.
  * The device fills the columns (one 8-row vector per lane; tails of up to 127 bases four to a wavefront, 16 lanes each, longer reads a
- * wavefront each), picks the end cell and walks the traceback over the matrices it has just written; ops are packed on the device and
- * only results and ops come back. */
+ * wavefront each; only a column's front is kept in HBM) and picks the end cell; a second kernel, one lane per problem, walks the
+ * tracebacks; ops are packed on the device and only results and ops come back.  VGAMD_XBAND_TIMING=1 prints the call's host laps. */
 int  vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
                           vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written, uint64_t stats[2]);
-double vgk_xdrop_band_last_ms(vgk_ctx* ctx);     /* fill-kernel time of the last vgk_xdrop_band_align call on this context */
+double vgk_xdrop_band_last_ms(vgk_ctx* ctx);     /* kernel time (fills + tracebacks) of the last vgk_xdrop_band_align call on this context */
 
 /* k-best pinned alignments (Aligner::align_pinned_multi -> gssw_graph_trace_back_pinned_multi, src/aligner.cpp:423-435, :455-480).
  * Every problem must be VGK_GSSW_PINNED.  results[i * max_alt_alns + k] is the k-th best alignment of problem i (k <
