@@ -84,6 +84,22 @@ def long_graphs_and_a_reused_context(lib, n):
         same(eng.xdrop_band_align(ps), ora.xdrop_band_align(ps))
 
 
+def quality_adjusted_band(lib, n):
+    """the same on a quality-adjusted context (QualAdjAligner's 25 x qualities table and per-quality bonus)"""
+    from qualadj import qual_adj_tables
+    qa = qual_adj_tables()
+    rng = np.random.default_rng(77)
+    probs = [random_problem(rng, mode=capi.VGK_XDROP_PINNED, max_nodes=12, max_node_len=16, max_read=90, with_n=0.03) for _ in range(n)]
+    for p in probs:
+        p["qual"] = rng.integers(0, 45, len(p["read"])).astype(np.uint8); p["max_gap"] = int(rng.integers(1, 30))
+    ps = problem_set(probs)
+    same(capi.Engine(lib=lib, qual_adj=qa).xdrop_band_align(ps), capi.Engine(lib=util.ORACLE_LIB, qual_adj=qa).xdrop_band_align(ps))
+
+
+def test_emulated_band_on_a_quality_adjusted_context(emu_lib):
+    quality_adjusted_band(emu_lib, 60)
+
+
 def test_emulated_band_with_long_graphs_and_a_reused_context(emu_lib):
     long_graphs_and_a_reused_context(emu_lib, 6)
 
@@ -93,3 +109,4 @@ def test_banded_xdrop_on_hip_equals_the_oracle():
     band_vs_oracle(util.ENGINE_LIB, 1500)
     assert run_xdrop_cases_with_band(util.ENGINE_LIB) >= 22
     long_graphs_and_a_reused_context(util.ENGINE_LIB, 300)
+    quality_adjusted_band(util.ENGINE_LIB, 1000)
