@@ -73,13 +73,13 @@ def test_banded_xdrop_bad_input(emu_lib):
             eng.xdrop_band_align(problem_set([dict(ok, flags=16)]))
 
 
-def long_graphs_and_a_reused_context(lib, n):
+def long_graphs_and_a_reused_context(lib, n, scale=1):
     """graphs of more columns than the kernels' LDS stage holds (1024 per problem with four to a wavefront, 4096 alone), read after read
     of every length class, and ONE context for all sets: only the front of a column is written, so whatever an earlier, larger set left
     in the matrices must not be taken for this set's cells"""
     eng = capi.Engine(lib=lib); ora = capi.Engine(lib=util.ORACLE_LIB)
-    for seed, kw, mg in ((31, dict(max_nodes=60, max_node_len=60, max_read=120), 30), (32, dict(max_nodes=40, max_node_len=140, max_read=400), 40),
-                         (33, dict(max_nodes=10, max_node_len=20, max_read=100), 4), (34, dict(max_nodes=60, max_node_len=60, max_read=126), None)):
+    for seed, kw, mg in ((31, dict(max_nodes=60 // scale, max_node_len=60, max_read=120), 30), (32, dict(max_nodes=40 // scale, max_node_len=140, max_read=400 // scale), 40),
+                         (33, dict(max_nodes=10, max_node_len=20, max_read=100), 4), (34, dict(max_nodes=60 // scale, max_node_len=60, max_read=126), None)):
         ps = random_xdrop_set(seed, n, mg, with_n=0.02, **kw)
         same(eng.xdrop_band_align(ps), ora.xdrop_band_align(ps))
 
@@ -101,7 +101,7 @@ def test_emulated_band_on_a_quality_adjusted_context(emu_lib):
 
 
 def test_emulated_band_with_long_graphs_and_a_reused_context(emu_lib):
-    long_graphs_and_a_reused_context(emu_lib, 6)
+    long_graphs_and_a_reused_context(emu_lib, 4, scale=3)          # (the emulator's LDS stage holds 64 columns: these graphs refill it many times over)
 
 
 @pytest.mark.gpu
