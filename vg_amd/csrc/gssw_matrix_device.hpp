@@ -424,7 +424,17 @@ VGK_HD void xdrop_band_walk_one(const GsswMatrixParams& P, uint32_t pi) {
     auto ec = [&](int32_t c, int32_t i) { return stored(c, i) ? E[(uint64_t)c * (uint64_t)stride + i] : MNEG; };
     auto e_next = [&](int32_t c, int32_t i) { const int32_t a = live(hc(c, i)) ? hc(c, i) - go : MNEG, b = live(ec(c, i)) ? ec(c, i) - ge : MNEG; return a > b ? a : b; };     // E of the column after c
     auto root_h = [&](int32_t i) { return i == 0 ? 0 : (i <= pb.gap_cells && i <= L ? -(go + (i - 1) * ge) : MNEG); };
-    auto score = [&](int32_t i, int32_t c) { return (int32_t)(ql ? P.mat[25 * ql[i - 1] + 5 * gr[c] + rd[i - 1]] : P.mat[5 * gr[c] + rd[i - 1]]) + (i == L ? pb.start_bonus : 0); };
+    // plain contexts: the 5 x 5 table in registers, a row per reference code in a 64-bit word — read from memory, the score was a third
+    // dependent round trip of every diagonal step (after the cell and the two codes)
+    uint64_t mrow[5] = {0, 0, 0, 0, 0};
+    if (!ql) for (int gq = 0; gq < 5; ++gq) for (int rq = 0; rq < 5; ++rq) mrow[gq] |= (uint64_t)(uint8_t)P.mat[5 * gq + rq] << (8 * rq);
+    auto score = [&](int32_t i, int32_t c) {
+        const uint32_t gc = gr[c], rc = rd[i - 1];
+        int32_t sc;
+        if (ql) sc = (int32_t)P.mat[25 * ql[i - 1] + 5 * gc + rc];
+        else { const uint64_t rw = gc == 0 ? mrow[0] : gc == 1 ? mrow[1] : gc == 2 ? mrow[2] : gc == 3 ? mrow[3] : mrow[4]; sc = (int32_t)(int8_t)(uint8_t)(rw >> (8u * rc)); }
+        return sc + (i == L ? pb.start_bonus : 0);
+    };
     int32_t c = best_c, i = best_i, n = best_v, cur = best;
     int status = VGK_OK;
     push(n, VGK_OP_S, (uint32_t)(L - i));
