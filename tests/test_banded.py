@@ -369,3 +369,36 @@ def test_hip_banded_multi_matches_reference_unit_tests_and_oracle():
     walked = []
     assert compare_multi(None, random_banded_set(52, 1500) + mixed_band_problems(53, 60, 30, 200), 6, walked) > 5000
     assert walked[0][0] < walked[0][1] // 2, walked
+
+
+# ---- DeletionAligner (src/unittest/deletion_aligner.cpp:17-103), reached as the reference reaches it: an empty read through
+#      align_global_banded / align_global_banded_multi (src/aligner.cpp:703-706, :1745-1761) -------------------------------------------
+
+def test_deletion_aligner_reference_case_through_the_shim():
+    """graph and expectations of "Deletion aligner finds optimal deletions" (:17-103): bubbles whose lengths are powers of two, so the
+    k best deletions come in binary counting order; DeletionAligner(6, 1) scores a walk of n bases -(n + 5)"""
+    lens = {1: 2, 2: 1, 3: 3, 4: 1, 5: 3, 6: 1, 7: 4, 8: 2, 9: 1, 10: 9}                                   # :39-48
+    case = {"nodes": [[i, "A" * n] for i, n in lens.items()],
+            "edges": [[1, 3], [2, 3], [3, 4], [3, 5], [4, 6], [5, 6], [6, 7], [6, 8], [7, 8], [8, 9], [8, 10]],   # :50-60
+            "read": "", "quality": None, "scores": [1, 4, 6, 1, 5], "qual_adj": False}
+    corrects = [[2, 3, 4, 6, 8, 9], [1, 3, 4, 6, 8, 9], [2, 3, 5, 6, 8, 9], [1, 3, 5, 6, 8, 9], [2, 3, 4, 6, 7, 8, 9], [1, 3, 4, 6, 7, 8, 9],
+                [2, 3, 5, 6, 7, 8, 9], [1, 3, 5, 6, 7, 8, 9], [2, 3, 4, 6, 8, 10], [1, 3, 4, 6, 8, 10], [2, 3, 5, 6, 8, 10], [1, 3, 5, 6, 8, 10],
+                [2, 3, 4, 6, 7, 8, 10], [1, 3, 4, 6, 7, 8, 10], [2, 3, 5, 6, 7, 8, 10]]                           # :78-94
+
+    def check(aln, walk):                                                                                 # check_aln, :21-35
+        maps = aln["path"]["mapping"]
+        assert [m["position"]["node_id"] for m in maps] == walk
+        total = 0
+        for m, v in zip(maps, walk):
+            assert not m["position"].get("is_reverse", False) and m["position"]["offset"] == 0
+            assert sum(e["from_length"] for e in m["edit"]) == lens[v] and sum(e["to_length"] for e in m["edit"]) == 0
+            total += lens[v]
+        assert aln["score"] == (-total - 5 if total else 0)
+
+    al = util.HostAligner(util.ORACLE_LIB, scores=(1, 4, 6, 1, 5))
+    check(al.run(case["nodes"], case["edges"], "", "align_global_banded", pin_left=True, max_alt_alns=1), corrects[0])        # "Single traceback works", :66-69
+    out = shim_banded_multi(util.ORACLE_LIB, case, 15, 1, True)                                                               # "Multi traceback works", :71-101
+    assert len(out["alternates"]) == 15
+    for aln, walk in zip(out["alternates"], corrects):
+        check(aln, walk)
+    check(out["primary"], corrects[0])
