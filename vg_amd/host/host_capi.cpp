@@ -369,6 +369,38 @@ static int emit_string(const std::string& js, char* out, size_t cap) {
     return 0;
 }
 
+// DozeuPinningOverlay (src/dozeu_pinning_overlay.hpp; the graph the X-drop aligner pins on: source / sink nodes without sequence are
+// dropped and what they fed is duplicated) over a vgh_graph, as JSON for the tests that transcribe src/unittest/dozeu_pinning_overlay.cpp:
+// {"performed_duplications": b, "node_count": n, "min_id": i, "max_id": i, "has_node": [ids in 1 .. 63 the overlay has],
+//  "handles": [{"id", "sequence", "underlying": [id, is_reverse], "flip_underlying": [id, is_reverse], "flip_flip_is_self": b,
+//               "right": [[id, rev]...], "left": [...], "flip_right": [...], "flip_left": [...]}]}   (follow_edges(h, false / true) of h and of flip(h))
+int vgh_pinning_overlay(vgh_graph* g, int preserve_sinks, char* json_out, size_t json_cap) {
+    try {
+        DozeuPinningOverlay overlay(&g->g, preserve_sinks != 0);
+        std::string js = "{\"performed_duplications\": ";
+        js += overlay.performed_duplications() ? "true" : "false";
+        js += ", \"node_count\": " + std::to_string(overlay.get_node_count()) + ", \"min_id\": " + std::to_string(overlay.min_node_id()) +
+              ", \"max_id\": " + std::to_string(overlay.max_node_id()) + ", \"has_node\": [";
+        bool firstn = true;
+        for (nid_t i = 1; i < 64; ++i) if (overlay.has_node(i)) { js += (firstn ? "" : ", ") + std::to_string(i); firstn = false; }
+        js += "], \"handles\": [";
+        auto side = [&](const handle_t& h) { return "[" + std::to_string(overlay.get_id(h)) + ", " + (overlay.get_is_reverse(h) ? "true" : "false") + "]"; };
+        auto under = [&](const handle_t& h) { const handle_t u = overlay.get_underlying_handle(h); return "[" + std::to_string(g->g.get_id(u)) + ", " + (g->g.get_is_reverse(u) ? "true" : "false") + "]"; };
+        auto edges = [&](const handle_t& h, bool left) { std::string e = "["; bool f = true; overlay.follow_edges(h, left, [&](const handle_t& n) { e += (f ? "" : ", ") + side(n); f = false; return true; }); return e + "]"; };
+        bool firsth = true;
+        overlay.for_each_handle([&](const handle_t& h) {
+            const handle_t r = overlay.flip(h);
+            js += std::string(firsth ? "" : ", ") + "{\"id\": " + std::to_string(overlay.get_id(h)) + ", \"sequence\": \"" + overlay.get_sequence(h) + "\", \"underlying\": " + under(h) +
+                  ", \"flip_underlying\": " + under(r) + ", \"flip_flip_is_self\": " + (overlay.flip(r) == h ? "true" : "false") +
+                  ", \"right\": " + edges(h, false) + ", \"left\": " + edges(h, true) + ", \"flip_right\": " + edges(r, false) + ", \"flip_left\": " + edges(r, true) + "}";
+            firsth = false;
+            return true;
+        });
+        js += "]}";
+        return emit_string(js, json_out, json_cap);
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
 // left / right: [node id, is_reverse, offset], node id 0 (or NULL) = no anchor on that side.  JSON out: {"did_align": b, "alignment": {...}}
 // return 1: ChainAlignmentFailedError (message in vgh_last_error)
 int vgh_align_sequence_between(vgh_aligner* a, vgh_bigraph* g, const char* read, const int64_t* left, const int64_t* right, int64_t max_path_length,
