@@ -347,6 +347,7 @@ int vgh_tail_stage(const char* engine_lib, void* ctx, const void* index, const c
 // ---- the graph between / beyond anchors (chain_alignment.hpp; MinimizerMapper::align_sequence_between and friends) ------------------
 #include "chain_alignment.hpp"
 #include "cluster_alignment.hpp"
+#include "rescue_fixups.hpp"
 extern "C" {
 
 // a bidirected graph, as the reference's tests build with HashGraph / json2graph
@@ -636,6 +637,24 @@ int32_t vgh_compute_mapping_quality(vgh_aligner* a, const double* scores, int n,
     return first ? a->a->mapq_calc->compute_first_mapping_quality(s, fast_approximation != 0) : a->a->mapq_calc->compute_max_mapping_quality(s, fast_approximation != 0);
 }
 double vgh_log_base(vgh_aligner* a) { return a->a->scorer->get_log_base(); }
+// MinimizerMapper::fix_dozeu_end_deletions over an alignment given flat: positions[m] = {node id, offset, is_reverse} per mapping,
+// edits[k] = {mapping index, from_length, to_length, has sequence}; JSON out = the alignment afterwards
+int vgh_fix_dozeu_end_deletions(const char* sequence, const int64_t* positions, int n_mappings, const int64_t* edits, int n_edits, char* json_out, size_t json_cap) {
+    try {
+        Alignment aln; aln.sequence = sequence;
+        aln.path.mapping.resize((size_t)n_mappings);
+        for (int m = 0; m < n_mappings; ++m) { Position& p = aln.path.mapping[(size_t)m].position; p.node_id = positions[3 * m]; p.offset = positions[3 * m + 1]; p.is_reverse = positions[3 * m + 2] != 0; }
+        size_t at = 0;
+        for (int k = 0; k < n_edits; ++k) {
+            Edit e; e.from_length = (int32_t)edits[4 * k + 1]; e.to_length = (int32_t)edits[4 * k + 2];
+            if (edits[4 * k + 3]) e.sequence = aln.sequence.substr(at, (size_t)e.to_length);
+            at += (size_t)e.to_length;
+            aln.path.mapping.at((size_t)edits[4 * k]).edit.push_back(e);
+        }
+        fix_dozeu_end_deletions(aln);
+        return emit(aln, json_out, json_cap);
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
 // scorer->score_contiguous_alignment of an alignment given as flat mappings: edits[k] = {mapping index, from_length, to_length, has sequence}
 int32_t vgh_score_contiguous_alignment(vgh_aligner* a, const char* sequence, const int64_t* edits, int n_edits) {
     Alignment aln; aln.sequence = sequence;
