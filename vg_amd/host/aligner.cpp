@@ -853,22 +853,24 @@ std::string alignment_to_json(const Alignment& a) {
 // ---------------------------------------------------------------------------------------------------------
 namespace vgamd {
 
-Aligner::Extension Aligner::xdrop_extend(const HandleGraph& g, const std::vector<handle_t>& order, size_t node_index,
-                                         size_t ref_offset, const std::string& read, const std::string& quality, size_t query_offset,
-                                         bool right_to_left, bool traceback, uint16_t max_gap_length) const {
-    Extension ext;
+void Aligner::xdrop_extend_prepare(const HandleGraph& g, const std::vector<handle_t>& order, size_t node_index, size_t ref_offset,
+                                   const std::string& read, const std::string& quality, size_t query_offset, bool right_to_left,
+                                   bool traceback, uint16_t max_gap_length, ExtensionJob& job) const {
+    job = ExtensionJob();
+    Extension& ext = job.ext;
     ext.end_node = node_index; ext.end_ref_offset = ref_offset; ext.end_query = query_offset;
+    job.node_index = node_index; job.ref_offset = ref_offset; job.query_offset = query_offset; job.right_to_left = right_to_left; job.traceback = traceback;
+    std::string& query = job.query; std::string& qqual = job.qqual; PackedGraph& pg = job.pg; std::vector<size_t>& kept = job.kept;
     std::unordered_map<handle_t, size_t, handle_hash> index_of;
     for (size_t i = 0; i < order.size(); ++i) index_of[order[i]] = i;
     // the part of the start node that lies in the extension direction, and the read part to consume
     std::string start_seq = g.get_sequence(order[node_index]);
-    std::string query, qqual;
     const bool have_q = qual_adjusted && quality.size() == read.size();
     if (!right_to_left) { start_seq = start_seq.substr(ref_offset); query = read.substr(query_offset); if (have_q) qqual = quality.substr(query_offset); }
     else { start_seq = start_seq.substr(0, ref_offset); std::reverse(start_seq.begin(), start_seq.end());
            query = read.substr(0, query_offset); std::reverse(query.begin(), query.end());
            if (have_q) { qqual = quality.substr(0, query_offset); std::reverse(qqual.begin(), qqual.end()); } }
-    if (query.empty()) return ext;
+    if (query.empty()) return;
     // nodes reachable from the start, in extension order (the caller's order, reversed for a leftward pass)
     std::vector<char> reach(order.size(), 0);
     reach[node_index] = 1;
@@ -883,11 +885,9 @@ Aligner::Extension Aligner::xdrop_extend(const HandleGraph& g, const std::vector
         if (reach[i]) sub.push_back((size_t)i);
     }
     const bool skip_start = start_seq.empty();     // pinned exactly at the node's end: its neighbours start from the root
-    PackedGraph pg;
     std::unordered_map<size_t, uint32_t> sub_of;
-    std::vector<size_t> kept;
     for (size_t i : sub) { if (i == node_index && skip_start) continue; sub_of[i] = (uint32_t)kept.size(); kept.push_back(i); }
-    if (kept.empty()) return ext;
+    if (kept.empty()) return;
     pg.pred_off.push_back(0);
     for (size_t i : kept) {
         std::string s = (i == node_index) ? start_seq : g.get_sequence(order[i]);
@@ -902,17 +902,21 @@ Aligner::Extension Aligner::xdrop_extend(const HandleGraph& g, const std::vector
         });
         pg.pred_off.push_back((uint32_t)pg.pred_idx.size());
     }
-    vgk_gssw_problem prob{};
+    vgk_gssw_problem& prob = job.prob;
     prob.read = query.data(); prob.read_len = (uint32_t)query.size();
     prob.qual = quality_of(qual_adjusted, qqual, query.size());
     prob.flags = VGK_XDROP_PINNED | (traceback ? VGK_GSSW_TRACEBACK : 0);
     prob.graph = pg.view(); prob.max_gap_length = std::max<uint16_t>(max_gap_length, 1);
-    vgk_result res{}; std::vector<vgk_op> ops(prob.read_len + pg.seq.size() + kept.size() + 4);
-    size_t written = 0;
-    int rc = xdrop_band ? engine->xdrop_band_align(ctx, &prob, 1, &res, ops.data(), ops.size(), &written, nullptr)
-                        : engine->gssw_align(ctx, &prob, 1, &res, ops.data(), ops.size(), &written);
-    if (rc != VGK_OK || res.status != VGK_OK)
-        throw std::runtime_error(std::string("vgamd: xdrop engine failed: ") + engine->strerror(rc ? rc : res.status));
+    job.runs = true;
+}
+
+Aligner::Extension Aligner::xdrop_extend_finish(const HandleGraph& g, const std::vector<handle_t>& order, const std::string& read, ExtensionJob& job,
+                                                const vgk_result& res_in, std::vector<vgk_op>& ops) const {
+    vgk_result res = res_in;                       // (a leftward pass flips its own copy back)
+    Extension ext = job.ext;
+    const size_t node_index = job.node_index, ref_offset = job.ref_offset, query_offset = job.query_offset; const bool right_to_left = job.right_to_left, traceback = job.traceback;
+    const PackedGraph& pg = job.pg; const std::vector<size_t>& kept = job.kept;
+    if (!job.runs) return ext;
     ops.resize(res.n_ops);
     ext.score = res.score;
     if (res.score <= 0) return ext;
@@ -972,6 +976,22 @@ Aligner::Extension Aligner::xdrop_extend(const HandleGraph& g, const std::vector
         i = j;
     }
     return ext;
+}
+
+
+Aligner::Extension Aligner::xdrop_extend(const HandleGraph& g, const std::vector<handle_t>& order, size_t node_index,
+                                         size_t ref_offset, const std::string& read, const std::string& quality, size_t query_offset,
+                                         bool right_to_left, bool traceback, uint16_t max_gap_length) const {
+    ExtensionJob job;
+    xdrop_extend_prepare(g, order, node_index, ref_offset, read, quality, query_offset, right_to_left, traceback, max_gap_length, job);
+    if (!job.runs) return job.ext;
+    vgk_result res{}; std::vector<vgk_op> ops(job.prob.read_len + job.pg.seq.size() + job.kept.size() + 4);
+    size_t written = 0;
+    int rc = xdrop_band ? engine->xdrop_band_align(ctx, &job.prob, 1, &res, ops.data(), ops.size(), &written, nullptr)
+                        : engine->gssw_align(ctx, &job.prob, 1, &res, ops.data(), ops.size(), &written);
+    if (rc != VGK_OK || res.status != VGK_OK)
+        throw std::runtime_error(std::string("vgamd: xdrop engine failed: ") + engine->strerror(rc ? rc : res.status));
+    return xdrop_extend_finish(g, order, read, job, res, ops);
 }
 
 void Aligner::align_xdrop(Alignment& alignment, const HandleGraph& g, const std::vector<MaximalExactMatch>& mems,

@@ -182,6 +182,15 @@ public:
                      const std::vector<MaximalExactMatch>& mems, bool reverse_complemented,
                      uint16_t max_gap_length = default_xdrop_max_gap_length) const;
 
+    // The same for many reads at once (what MinimizerMapper::attempt_rescue asks for read after read, src/minimizer_mapper.cpp:3385, :3426):
+    // every request's first pass — the scan for a head, or the extension from the seed towards it — goes to the engine in ONE call, every
+    // second pass (the traced extension from the head) in another; each alignment comes out as align_xdrop(..., order, ...) leaves it.
+    struct XdropRequest {
+        Alignment* alignment = nullptr; const HandleGraph* graph = nullptr; std::vector<handle_t> order;      // order empty: lazier_topological_order(graph)
+        std::vector<MaximalExactMatch> mems; bool reverse_complemented = false; uint16_t max_gap_length = default_xdrop_max_gap_length;
+    };
+    void align_xdrop_many(std::vector<XdropRequest>& requests) const;
+
     // the two halves of an alignment call, for AlignmentBatch
     struct Job;
     std::unique_ptr<Job> prepare_job(Alignment& alignment, const HandleGraph& g, bool pinned, bool pin_left, bool traceback_aln) const;
@@ -207,6 +216,23 @@ private:
     Extension xdrop_extend(const HandleGraph& g, const std::vector<handle_t>& order, size_t node_index, size_t ref_offset,
                            const std::string& read, const std::string& quality, size_t query_offset, bool right_to_left,
                            bool traceback, uint16_t max_gap_length) const;
+    // xdrop_extend in two halves around the engine call (a job must stay where it is between them: its problem points into it)
+    struct ExtensionJob {
+        Extension ext;                                  // the answer when nothing runs, and the start position
+        size_t node_index = 0, ref_offset = 0, query_offset = 0; bool right_to_left = false, traceback = false, runs = false;
+        std::string query, qqual; PackedGraph pg; std::vector<size_t> kept; vgk_gssw_problem prob{};
+    };
+    void xdrop_extend_prepare(const HandleGraph& g, const std::vector<handle_t>& order, size_t node_index, size_t ref_offset,
+                              const std::string& read, const std::string& quality, size_t query_offset, bool right_to_left,
+                              bool traceback, uint16_t max_gap_length, ExtensionJob& job) const;
+    Extension xdrop_extend_finish(const HandleGraph& g, const std::vector<handle_t>& order, const std::string& read, ExtensionJob& job,
+                                  const vgk_result& res, std::vector<vgk_op>& ops) const;
+    // the scan for a head when there is no seed (scan_seed_position), likewise
+    struct ScanJob { std::string tail, tail_q; PackedGraph pg; std::vector<handle_t> run_order; size_t scan_len = 0; vgk_gssw_problem prob{}; };
+    void xdrop_scan_prepare(const Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& order, bool direction, ScanJob& job) const;
+    // what follows the traced extension from the head (full-length insertion, the unseen read part, identity)
+    void xdrop_finish(Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& order, Extension& down, size_t head_node, size_t head_ref,
+                      size_t head_query, bool direction) const;
     void align_internal(Alignment& alignment, std::vector<Alignment>* multi_alignments, const HandleGraph& g,
                         bool pinned, bool pin_left, int32_t max_alt_alns, bool traceback_aln) const;
 };
