@@ -41,3 +41,83 @@ def test_nothing_but_deletions_clears_the_path_and_clean_alignments_are_left_alo
     # a deletion inside stays; one at the right end of the last mapping goes (:3552-3564)
     maps = fix_end_deletions("ACGT", [((7, 0, False), [(2, 2, False), (3, 0, False), (2, 2, False), (1, 0, False)])])["path"]["mapping"]
     assert [(e["from_length"], e["to_length"]) for e in maps[0]["edit"]] == [(2, 2), (3, 0), (2, 2)]
+
+
+# ---- Aligner::align_xdrop_many: the rescue alignments of many reads, their passes side by side (vg_amd/host/aligner.cpp) -------------
+
+def random_rescue_problems(seed, n):
+    """a small DAG per read, a read walked through it with a few errors, and (for most) a seed: an exact 10-mer of the read on its node"""
+    import numpy as np
+    from gen import random_dag, random_walk_read
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        nodes, preds = random_dag(rng, int(rng.integers(2, 8)), 14)
+        if any(len(s) == 0 for s in nodes):
+            continue
+        read = random_walk_read(rng, nodes, preds, int(rng.integers(20, 70)))
+        mems = []
+        if rng.random() < 0.7:                                           # a seed where a node holds 8 bases of the read verbatim
+            for v, s in enumerate(nodes):
+                hit = [(o, read.find(s[o:o + 8])) for o in range(0, max(1, len(s) - 7))] if len(s) >= 8 else []
+                hit = [(o, q) for o, q in hit if q >= 0]
+                if hit:
+                    o, q = hit[0]
+                    mems = [{"begin": q, "end": q + 8, "nodes": [[v + 1, o, False]]}]
+                    break
+        out.append({"nodes": [[v + 1, s] for v, s in enumerate(nodes)], "edges": [[p + 1, v + 1] for v, pr in enumerate(preds) for p in pr],
+                    "read": read, "mems": mems})
+    return out
+
+
+def xdrop_many(aligner, problems, reverse_complemented, max_gap, fixups):
+    h = aligner.h
+    h.vgh_align_xdrop_many.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int64),
+                                       ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    h.vgh_graph_create.restype = ctypes.c_void_p
+    graphs = []
+    try:
+        for p in problems:
+            g = h.vgh_graph_create(); graphs.append(g)
+            for nid, seq in p["nodes"]:
+                assert h.vgh_graph_add_node(ctypes.c_void_p(g), nid, seq.encode()) == 0
+            for a, b in p["edges"]:
+                assert h.vgh_graph_add_edge(ctypes.c_void_p(g), a, b) == 0
+        flat = [x for p in problems for m in p["mems"] for x in (m["begin"], m["end"], m["nodes"][-1][0], m["nodes"][-1][1], int(m["nodes"][-1][2]))]
+        counts = [len(p["mems"]) for p in problems]
+        n = len(problems)
+        buf = ctypes.create_string_buffer(1 << 22)
+        rc = h.vgh_align_xdrop_many(aligner.ptr, (ctypes.c_void_p * n)(*graphs), (ctypes.c_char_p * n)(*[p["read"].encode() for p in problems]),
+                                    (ctypes.c_int64 * max(1, len(flat)))(*flat), (ctypes.c_int * n)(*counts), n, int(reverse_complemented), max_gap, int(fixups),
+                                    buf, len(buf))
+        assert rc == 0, h.vgh_last_error().decode()
+        return json.loads(buf.value.decode())
+    finally:
+        for g in graphs:
+            h.vgh_graph_destroy(ctypes.c_void_p(g))
+
+
+def many_equals_direct(engine_lib, n):
+    al = util.HostAligner(engine_lib)
+    problems = random_rescue_problems(5, n)
+    for rc in (False, True):
+        direct = [util.run_align_xdrop(al, p["nodes"], p["edges"], p["read"], p["mems"], rc, 30) for p in problems]
+        many = xdrop_many(al, problems, rc, 30, False)
+        assert many == direct
+        assert sum(1 for a in many if a["path"]["mapping"]) > n // 2
+    fixed = xdrop_many(al, problems, False, 30, True)                      # with attempt_rescue's fix-ups behind it
+    for a in fixed:
+        maps = a["path"]["mapping"]
+        if maps:                                                          # no deletion is left at either end, the score is the scorer's own
+            assert maps[0]["edit"][0]["to_length"] > 0 and maps[-1]["edit"][-1]["to_length"] > 0
+            assert a["score"] > 0
+
+
+def test_align_xdrop_many_equals_the_direct_calls_on_the_oracle():
+    many_equals_direct(util.ORACLE_LIB, 60)
+
+
+def test_align_xdrop_many_equals_the_direct_calls_on_the_emulated_kernels():
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    many_equals_direct(util.EMU_LIB, 12)

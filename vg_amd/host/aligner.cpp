@@ -1009,67 +1009,37 @@ void Aligner::align_xdrop(Alignment& alignment, const HandleGraph& g, const std:
     }
 }
 
-void Aligner::xdrop_align(Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& order,
-                          const std::vector<MaximalExactMatch>& mems, bool reverse_complemented, uint16_t max_gap_length) const {
+// scan_seed_position (src/dozeu_interface.cpp:143-208): locate the best match of the 15-base read end nearest the far side.
+// dz_scan's exact rules are in the missing dozeu source [PARITY-UNPINNED]; the engine's local mode on
+// the same 15 bases finds the same maximum position whenever the best hit is an end-to-end match.
+void Aligner::xdrop_scan_prepare(const Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& order, bool direction, ScanJob& job) const {
+    job = ScanJob();
     const std::string& read = alignment.sequence;
-    const bool direction = reverse_complemented;
-    alignment.clear_path();
-    if (order.empty() || read.empty()) return;
-    std::unordered_map<handle_t, size_t, handle_hash> index_of;
-    for (size_t i = 0; i < order.size(); ++i) index_of[order[i]] = i;
-
-    // ---- head position (src/dozeu_interface.cpp:629-673)
-    size_t head_node = 0, head_ref = 0, head_query = 0;
-    bool have_head = false;
-    if (mems.empty()) {
-        // scan_seed_position (:143-208): locate the best match of the 15-base read end nearest the far side.
-        // dz_scan's exact rules are in the missing dozeu source [PARITY-UNPINNED]; the engine's local mode on
-        // the same 15 bases finds the same maximum position whenever the best hit is an end-to-end match.
-        const size_t qlen = read.size(), scan_len = std::min<size_t>(qlen, 15);
-        std::string tail = direction ? read.substr(0, scan_len) : read.substr(qlen - scan_len);
-        std::string tail_q;
-        if (qual_adjusted && alignment.quality.size() == qlen) tail_q = direction ? alignment.quality.substr(0, scan_len) : alignment.quality.substr(qlen - scan_len);
-        PackedGraph pg; pg.order = order; pg.pred_off.push_back(0);
-        const HandleGraph* sg = &g; ReverseGraph rg(&g, false);
-        std::vector<handle_t> run_order = order;
-        if (direction) { sg = &rg; std::reverse(run_order.begin(), run_order.end()); std::reverse(tail.begin(), tail.end()); std::reverse(tail_q.begin(), tail_q.end()); pg.order = run_order; }
-        std::unordered_map<handle_t, uint32_t, handle_hash> ridx;
-        for (uint32_t i = 0; i < run_order.size(); ++i) ridx[run_order[i]] = i;
-        for (uint32_t i = 0; i < run_order.size(); ++i) {
-            std::string s = sg->get_sequence(run_order[i]);
-            pg.node_len.push_back((uint32_t)s.size()); pg.seq += s;
-            sg->follow_edges_v(run_order[i], true, [&](const handle_t& p) { auto it = ridx.find(p); if (it != ridx.end() && it->second < i) pg.pred_idx.push_back(it->second); });
-            pg.pred_off.push_back((uint32_t)pg.pred_idx.size());
-        }
-        vgk_gssw_problem prob{};
-        prob.read = tail.data(); prob.read_len = (uint32_t)tail.size(); prob.flags = VGK_GSSW_LOCAL; prob.graph = pg.view();
-        prob.qual = quality_of(qual_adjusted, tail_q, tail.size());
-        vgk_result res{}; size_t written = 0;
-        int rc = engine->gssw_align(ctx, &prob, 1, &res, nullptr, 0, &written);
-        if (rc != VGK_OK || res.status != VGK_OK)
-            throw std::runtime_error(std::string("vgamd: scan failed: ") + engine->strerror(rc ? rc : res.status));
-        if (res.score > 0) {
-            have_head = true;
-            const handle_t h = run_order[(size_t)res.end_node];
-            head_node = index_of.at(h);
-            const size_t used = (size_t)res.end_offset + 1, qused = (size_t)res.end_read + 1;
-            if (!direction) { head_ref = used; head_query = (qlen - scan_len) + qused; }
-            else { head_ref = g.get_length(h) - used; head_query = scan_len - qused; }
-        }
-        if (!have_head) return;      // scan failed: path stays empty, the caller falls back to gssw (src/aligner.cpp:848-854)
-    } else {
-        // calculate_seed_position (:75-114)
-        const MaximalExactMatch& seed = direction ? mems.back() : mems.front();
-        const MaximalExactMatch::Hit& hit = direction ? seed.nodes.front() : seed.nodes.back();
-        const size_t sn = index_of.at(g.get_handle(hit.id, hit.is_reverse));
-        const size_t sref = direction ? g.get_length(order[sn]) - hit.offset : hit.offset;
-        const size_t squery = direction ? read.size() - seed.begin : seed.begin;
-        // "upward" extension from the seed; its maximum is the head (:654-672)
-        Extension up = xdrop_extend(g, order, sn, sref, read, alignment.quality, squery, direction, false, max_gap_length);
-        head_node = up.end_node; head_ref = up.end_ref_offset; head_query = up.end_query; have_head = true;
+    const size_t qlen = read.size(); job.scan_len = std::min<size_t>(qlen, 15);
+    std::string& tail = job.tail; std::string& tail_q = job.tail_q; PackedGraph& pg = job.pg;
+    tail = direction ? read.substr(0, job.scan_len) : read.substr(qlen - job.scan_len);
+    if (qual_adjusted && alignment.quality.size() == qlen) tail_q = direction ? alignment.quality.substr(0, job.scan_len) : alignment.quality.substr(qlen - job.scan_len);
+    pg.order = order; pg.pred_off.push_back(0);
+    const HandleGraph* sg = &g; ReverseGraph rg(&g, false);
+    std::vector<handle_t>& run_order = job.run_order; run_order = order;
+    if (direction) { sg = &rg; std::reverse(run_order.begin(), run_order.end()); std::reverse(tail.begin(), tail.end()); std::reverse(tail_q.begin(), tail_q.end()); pg.order = run_order; }
+    std::unordered_map<handle_t, uint32_t, handle_hash> ridx;
+    for (uint32_t i = 0; i < run_order.size(); ++i) ridx[run_order[i]] = i;
+    for (uint32_t i = 0; i < run_order.size(); ++i) {
+        std::string s = sg->get_sequence(run_order[i]);
+        pg.node_len.push_back((uint32_t)s.size()); pg.seq += s;
+        sg->follow_edges_v(run_order[i], true, [&](const handle_t& p) { auto it = ridx.find(p); if (it != ridx.end() && it->second < i) pg.pred_idx.push_back(it->second); });
+        pg.pred_off.push_back((uint32_t)pg.pred_idx.size());
     }
-    // ---- downward extension from the head + traceback (align_downward, :687-722)
-    Extension down = xdrop_extend(g, order, head_node, head_ref, read, alignment.quality, head_query, !direction, true, max_gap_length);
+    vgk_gssw_problem& prob = job.prob;
+    prob.read = tail.data(); prob.read_len = (uint32_t)tail.size(); prob.flags = VGK_GSSW_LOCAL; prob.graph = pg.view();
+    prob.qual = quality_of(qual_adjusted, tail_q, tail.size());
+}
+
+// what follows the traced extension from the head (align_downward's tail, src/dozeu_interface.cpp:687-722)
+void Aligner::xdrop_finish(Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& order, Extension& down, size_t head_node, size_t head_ref,
+                           size_t head_query, bool direction) const {
+    const std::string& read = alignment.sequence;
     alignment.score = down.score;
     alignment.query_position = 0;
     if (down.score <= 0 || down.mappings.empty()) {
@@ -1097,7 +1067,112 @@ void Aligner::xdrop_align(Alignment& alignment, const HandleGraph& g, const std:
         } else { Edit e; e.from_length = 0; e.to_length = (int32_t)head_query; e.sequence = read.substr(0, head_query); m.edit.insert(m.edit.begin(), e); }
     }
     alignment.identity = (double)down.matches / (double)read.size();
-    // dozeu found nothing useful and there were no MEMs: gssw fallback happens in the caller's wrapper below
+}
+
+void Aligner::xdrop_align(Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& order,
+                          const std::vector<MaximalExactMatch>& mems, bool reverse_complemented, uint16_t max_gap_length) const {
+    std::vector<XdropRequest> one(1);
+    one[0].alignment = &alignment; one[0].graph = &g; one[0].order = order; one[0].mems = mems; one[0].reverse_complemented = reverse_complemented; one[0].max_gap_length = max_gap_length;
+    xdrop_align_many(one);
+}
+
+// DozeuInterface::align (src/dozeu_interface.cpp:608-685) for many requests: the passes of all of them side by side.
+void Aligner::xdrop_align_many(std::vector<XdropRequest>& requests) const {
+    struct State { bool live = false, have_head = false, direction = false; size_t head_node = 0, head_ref = 0, head_query = 0;
+                   std::unordered_map<handle_t, size_t, handle_hash> index_of; std::unique_ptr<ScanJob> scan; std::unique_ptr<ExtensionJob> up, down; };
+    const size_t n = requests.size();
+    std::vector<State> st(n);
+    // one engine call over the problems of a pass; results and ops per problem come back through `take`
+    auto run = [&](std::vector<vgk_gssw_problem>& probs, bool band, std::vector<vgk_result>& res, std::vector<vgk_op>& ops, const char* what) {
+        res.assign(probs.size(), vgk_result{});
+        size_t cap = 16; for (const vgk_gssw_problem& p : probs) { size_t bases = 0; for (uint32_t v = 0; v < p.graph.n_nodes; ++v) bases += p.graph.node_len[v]; cap += p.read_len + bases + p.graph.n_nodes + 4; }
+        ops.assign(cap, vgk_op{});
+        size_t written = 0;
+        if (probs.empty()) return;
+        const int rc = band ? engine->xdrop_band_align(ctx, probs.data(), (uint32_t)probs.size(), res.data(), ops.data(), ops.size(), &written, nullptr)
+                            : engine->gssw_align(ctx, probs.data(), (uint32_t)probs.size(), res.data(), ops.data(), ops.size(), &written);
+        if (rc != VGK_OK) throw std::runtime_error(std::string("vgamd: ") + what + " failed: " + engine->strerror(rc));
+        for (const vgk_result& r : res) if (r.status != VGK_OK) throw std::runtime_error(std::string("vgamd: ") + what + " failed: " + engine->strerror(r.status));
+    };
+    auto ops_of = [](const vgk_result& r, const std::vector<vgk_op>& all) { return std::vector<vgk_op>(all.begin() + r.ops_begin, all.begin() + r.ops_begin + r.n_ops); };
+    // ---- first pass: the head position (:629-673) — a scan of the read's last bases, or the extension from the seed towards it
+    std::vector<vgk_gssw_problem> scans, ups; std::vector<size_t> scan_of, up_of;
+    for (size_t k = 0; k < n; ++k) {
+        XdropRequest& rq = requests[k]; State& s = st[k];
+        Alignment& alignment = *rq.alignment; const HandleGraph& g = *rq.graph;
+        if (rq.order.empty()) rq.order = handlealgs::lazier_topological_order(&g);
+        alignment.clear_path();
+        if (rq.order.empty() || alignment.sequence.empty()) continue;
+        s.live = true; s.direction = rq.reverse_complemented;
+        for (size_t i = 0; i < rq.order.size(); ++i) s.index_of[rq.order[i]] = i;
+        if (rq.mems.empty()) {
+            s.scan = std::make_unique<ScanJob>();
+            xdrop_scan_prepare(alignment, g, rq.order, s.direction, *s.scan);
+            scans.push_back(s.scan->prob); scan_of.push_back(k);
+        } else {
+            // calculate_seed_position (:75-114)
+            const MaximalExactMatch& seed = s.direction ? rq.mems.back() : rq.mems.front();
+            const MaximalExactMatch::Hit& hit = s.direction ? seed.nodes.front() : seed.nodes.back();
+            const size_t sn = s.index_of.at(g.get_handle(hit.id, hit.is_reverse));
+            const size_t sref = s.direction ? g.get_length(rq.order[sn]) - hit.offset : hit.offset;
+            const size_t squery = s.direction ? alignment.sequence.size() - seed.begin : seed.begin;
+            // "upward" extension from the seed; its maximum is the head (:654-672)
+            s.up = std::make_unique<ExtensionJob>();
+            xdrop_extend_prepare(g, rq.order, sn, sref, alignment.sequence, alignment.quality, squery, s.direction, false, rq.max_gap_length, *s.up);
+            if (s.up->runs) { ups.push_back(s.up->prob); up_of.push_back(k); }
+            else { s.head_node = s.up->ext.end_node; s.head_ref = s.up->ext.end_ref_offset; s.head_query = s.up->ext.end_query; s.have_head = true; }
+        }
+    }
+    std::vector<vgk_result> res; std::vector<vgk_op> ops;
+    run(scans, false, res, ops, "scan");
+    for (size_t q = 0; q < scan_of.size(); ++q) {
+        const size_t k = scan_of[q]; State& s = st[k]; const XdropRequest& rq = requests[k]; const vgk_result& r = res[q];
+        if (r.score <= 0) continue;      // scan failed: the path stays empty, the caller falls back to gssw (src/aligner.cpp:848-854)
+        const handle_t h = s.scan->run_order[(size_t)r.end_node];
+        const size_t qlen = rq.alignment->sequence.size(), scan_len = s.scan->scan_len;
+        s.have_head = true; s.head_node = s.index_of.at(h);
+        const size_t used = (size_t)r.end_offset + 1, qused = (size_t)r.end_read + 1;
+        if (!s.direction) { s.head_ref = used; s.head_query = (qlen - scan_len) + qused; }
+        else { s.head_ref = rq.graph->get_length(h) - used; s.head_query = scan_len - qused; }
+    }
+    run(ups, xdrop_band, res, ops, "xdrop engine");
+    for (size_t q = 0; q < up_of.size(); ++q) {
+        const size_t k = up_of[q]; State& s = st[k]; const XdropRequest& rq = requests[k];
+        std::vector<vgk_op> mine = ops_of(res[q], ops);
+        const Extension up = xdrop_extend_finish(*rq.graph, rq.order, rq.alignment->sequence, *s.up, res[q], mine);
+        s.head_node = up.end_node; s.head_ref = up.end_ref_offset; s.head_query = up.end_query; s.have_head = true;
+    }
+    // ---- second pass: the traced extension from the head the other way (align_downward, :687-722)
+    std::vector<vgk_gssw_problem> downs; std::vector<size_t> down_of;
+    for (size_t k = 0; k < n; ++k) {
+        State& s = st[k]; const XdropRequest& rq = requests[k];
+        if (!s.live || !s.have_head) continue;
+        s.down = std::make_unique<ExtensionJob>();
+        xdrop_extend_prepare(*rq.graph, rq.order, s.head_node, s.head_ref, rq.alignment->sequence, rq.alignment->quality, s.head_query, !s.direction, true, rq.max_gap_length, *s.down);
+        if (s.down->runs) { downs.push_back(s.down->prob); down_of.push_back(k); }
+    }
+    run(downs, xdrop_band, res, ops, "xdrop engine");
+    std::vector<char> answered(n, 0);
+    for (size_t q = 0; q < down_of.size(); ++q) {
+        const size_t k = down_of[q]; State& s = st[k]; const XdropRequest& rq = requests[k];
+        std::vector<vgk_op> mine = ops_of(res[q], ops);
+        Extension down = xdrop_extend_finish(*rq.graph, rq.order, rq.alignment->sequence, *s.down, res[q], mine);
+        xdrop_finish(*rq.alignment, *rq.graph, rq.order, down, s.head_node, s.head_ref, s.head_query, s.direction);
+        answered[k] = 1;
+    }
+    for (size_t k = 0; k < n; ++k) {
+        State& s = st[k]; const XdropRequest& rq = requests[k];
+        if (!s.live || !s.have_head || answered[k]) continue;
+        Extension down = s.down->ext;                                   // nothing ran: nothing of the read or the graph lies that way
+        xdrop_finish(*rq.alignment, *rq.graph, rq.order, down, s.head_node, s.head_ref, s.head_query, s.direction);
+    }
+}
+
+void Aligner::align_xdrop_many(std::vector<XdropRequest>& requests) const {
+    xdrop_align_many(requests);
+    for (XdropRequest& rq : requests)
+        if (!rq.alignment->has_path() && rq.mems.empty())        // dozeu's seeding heuristic failed: gssw instead (src/aligner.cpp:848-854)
+            align(*rq.alignment, *rq.graph, rq.order);
 }
 
 }  // namespace vgamd

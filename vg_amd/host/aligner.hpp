@@ -213,6 +213,7 @@ private:
     };
     void xdrop_align(Alignment& alignment, const HandleGraph& g, const std::vector<handle_t>& order,
                      const std::vector<MaximalExactMatch>& mems, bool reverse_complemented, uint16_t max_gap_length) const;
+    void xdrop_align_many(std::vector<XdropRequest>& requests) const;
     Extension xdrop_extend(const HandleGraph& g, const std::vector<handle_t>& order, size_t node_index, size_t ref_offset,
                            const std::string& read, const std::string& quality, size_t query_offset, bool right_to_left,
                            bool traceback, uint16_t max_gap_length) const;

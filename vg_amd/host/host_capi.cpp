@@ -11,6 +11,7 @@
 #include "aligner.hpp"
 #include "tail_stage.hpp"
 #include "gbwt_extender.hpp"
+#include "rescue_fixups.hpp"
 
 using namespace vgamd;
 
@@ -151,6 +152,38 @@ int vgh_align_xdrop(vgh_aligner* a, vgh_graph* g, const char* read, const int64_
         }
         a->a->align_xdrop(aln, g->g, ms, reverse_complemented != 0, (uint16_t)max_gap);
         return emit(aln, json_out, json_cap);
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// Aligner::align_xdrop_many: n reads, each with its graph and its MEMs (mems flat as above, n_mems[k] of them for read k), followed — as
+// MinimizerMapper::attempt_rescue follows align_xdrop — by fix_dozeu_score and fix_dozeu_end_deletions when `rescue_fixups` is set.
+// JSON out: a list of the n alignments.
+int vgh_align_xdrop_many(vgh_aligner* a, vgh_graph** graphs, const char** reads, const int64_t* mems, const int* n_mems, int n,
+                         int reverse_complemented, int max_gap, int rescue_fixups, char* json_out, size_t json_cap) {
+    try {
+        std::deque<Alignment> alns((size_t)n);
+        std::vector<Aligner::XdropRequest> requests((size_t)n);
+        size_t at = 0;
+        for (int k = 0; k < n; ++k) {
+            alns[(size_t)k].sequence = reads[k];
+            Aligner::XdropRequest& rq = requests[(size_t)k];
+            rq.alignment = &alns[(size_t)k]; rq.graph = &graphs[k]->g; rq.reverse_complemented = reverse_complemented != 0; rq.max_gap_length = (uint16_t)max_gap;
+            for (int i = 0; i < n_mems[k]; ++i, ++at) {
+                MaximalExactMatch m; m.begin = (size_t)mems[5 * at]; m.end = (size_t)mems[5 * at + 1];
+                m.nodes.push_back({mems[5 * at + 2], (size_t)mems[5 * at + 3], mems[5 * at + 4] != 0});
+                rq.mems.push_back(m);
+            }
+        }
+        a->a->align_xdrop_many(requests);
+        std::string js = "[";
+        for (int k = 0; k < n; ++k) {
+            if (rescue_fixups) { fix_dozeu_score(alns[(size_t)k], *a->a, graphs[k]->g, requests[(size_t)k].order); fix_dozeu_end_deletions(alns[(size_t)k]); }
+            js += std::string(k ? "," : "") + alignment_to_json(alns[(size_t)k]);
+        }
+        js += "]";
+        if (js.size() + 1 > json_cap) { g_last_error = "json buffer too small"; return -2; }
+        std::memcpy(json_out, js.c_str(), js.size() + 1);
+        return 0;
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }
 
