@@ -121,3 +121,11 @@ def test_align_xdrop_many_equals_the_direct_calls_on_the_emulated_kernels():
     import subprocess
     subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
     many_equals_direct(util.EMU_LIB, 12)
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_align_xdrop_many_equals_the_direct_calls_on_hip():
+    many_equals_direct(util.ENGINE_LIB, 200)
