@@ -129,3 +129,42 @@ import pytest
 @pytest.mark.gpu
 def test_align_xdrop_many_equals_the_direct_calls_on_hip():
     many_equals_direct(util.ENGINE_LIB, 200)
+
+
+def test_alignment_batch_defers_the_seeded_xdrop_beside_the_other_calls():
+    """AlignmentBatch::align_xdrop: requests wait for flush(), which answers them through align_xdrop_many — in one batch with plain local
+    alignments, every slot as the direct call leaves it"""
+    h = util.host()
+    h.vgh_batch_create.restype = ctypes.c_void_p; h.vgh_batch_create.argtypes = [ctypes.c_void_p]
+    h.vgh_batch_destroy.argtypes = [ctypes.c_void_p]
+    h.vgh_batch_reserve.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    h.vgh_batch_add_slot.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    h.vgh_batch_add_xdrop_slot.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    h.vgh_batch_flush.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    h.vgh_graph_create.restype = ctypes.c_void_p
+    al = util.HostAligner(util.ORACLE_LIB)
+    problems = random_rescue_problems(9, 30)
+    graphs = []
+    b = h.vgh_batch_create(al.ptr)
+    try:
+        assert h.vgh_batch_reserve(b, 2 * len(problems)) == 0
+        for k, p in enumerate(problems):
+            g = h.vgh_graph_create(); graphs.append(g)
+            for nid, seq in p["nodes"]:
+                assert h.vgh_graph_add_node(ctypes.c_void_p(g), nid, seq.encode()) == 0
+            for x, y in p["edges"]:
+                assert h.vgh_graph_add_edge(ctypes.c_void_p(g), x, y) == 0
+            flat = [x for m in p["mems"] for x in (m["begin"], m["end"], m["nodes"][-1][0], m["nodes"][-1][1], int(m["nodes"][-1][2]))]
+            assert h.vgh_batch_add_xdrop_slot(b, 2 * k, ctypes.c_void_p(g), p["read"].encode(), (ctypes.c_int64 * max(1, len(flat)))(*flat), len(p["mems"]), 0, 30) == 0
+            assert h.vgh_batch_add_slot(b, 2 * k + 1, ctypes.c_void_p(g), p["read"].encode(), 0, 0, 1) == 0, h.vgh_last_error().decode()      # call 0: align
+        buf = ctypes.create_string_buffer(1 << 22)
+        assert h.vgh_batch_flush(b, buf, len(buf)) == 0, h.vgh_last_error().decode()
+        out = json.loads(buf.value.decode())
+    finally:
+        h.vgh_batch_destroy(b)
+        for g in graphs:
+            h.vgh_graph_destroy(ctypes.c_void_p(g))
+    assert len(out) == 2 * len(problems)
+    for k, p in enumerate(problems):
+        assert out[2 * k] == util.run_align_xdrop(al, p["nodes"], p["edges"], p["read"], p["mems"], False, 30)
+        assert out[2 * k + 1] == al.run(p["nodes"], p["edges"], p["read"], "align")

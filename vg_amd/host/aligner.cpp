@@ -320,19 +320,25 @@ void AlignmentBatch::align_pinned(Alignment& alignment, const HandleGraph& g, bo
 void AlignmentBatch::align_global_banded(Alignment& alignment, const HandleGraph& g, int32_t band_padding, bool permissive_banding, uint64_t max_cells) {
     submit(aligners[0]->prepare_banded_job(alignment, g, band_padding, permissive_banding, max_cells));
 }
-size_t AlignmentBatch::size() const { std::lock_guard<std::mutex> lk(mu); return jobs.size(); }
+void AlignmentBatch::align_xdrop(Alignment& alignment, const HandleGraph& g, const std::vector<MaximalExactMatch>& mems, bool reverse_complemented, uint16_t max_gap_length) {
+    Aligner::XdropRequest rq;
+    rq.alignment = &alignment; rq.graph = &g; rq.mems = mems; rq.reverse_complemented = reverse_complemented; rq.max_gap_length = max_gap_length;
+    std::lock_guard<std::mutex> lk(mu);
+    xdrop_requests.push_back(std::move(rq));
+}
+size_t AlignmentBatch::size() const { std::lock_guard<std::mutex> lk(mu); return jobs.size() + xdrop_requests.size(); }
 void AlignmentBatch::flush() {
-    std::vector<std::unique_ptr<Aligner::Job>> mine; size_t device = 0;
+    std::vector<std::unique_ptr<Aligner::Job>> mine; std::vector<Aligner::XdropRequest> xmine; size_t device = 0;
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (!jobs.empty()) { mine.swap(jobs); device = next_device++ % aligners.size(); ++in_flight; ++n_flushes; }
+        if (!jobs.empty() || !xdrop_requests.empty()) { mine.swap(jobs); xmine.swap(xdrop_requests); device = next_device++ % aligners.size(); ++in_flight; ++n_flushes; }
     }
-    if (!mine.empty()) run(mine, device);
+    if (!mine.empty() || !xmine.empty()) run(mine, device, &xmine);
     std::unique_lock<std::mutex> lk(mu);             // ... and whatever other threads' flushes still have in the engine
     idle.wait(lk, [this] { return in_flight == 0; });
     if (failure) { std::exception_ptr f = failure; failure = nullptr; std::rethrow_exception(f); }
 }
-void AlignmentBatch::run(std::vector<std::unique_ptr<Aligner::Job>>& run, size_t device) {
+void AlignmentBatch::run(std::vector<std::unique_ptr<Aligner::Job>>& run, size_t device, std::vector<Aligner::XdropRequest>* xdrops) {
     struct Done {                                    // in_flight goes down however this ends
         AlignmentBatch* b; std::exception_ptr err;
         ~Done() { std::lock_guard<std::mutex> lk(b->mu); if (err && !b->failure) b->failure = err; if (--b->in_flight == 0) b->idle.notify_all(); }
@@ -386,6 +392,7 @@ void AlignmentBatch::run(std::vector<std::unique_ptr<Aligner::Job>>& run, size_t
             job_failures[j.alignment] = std::current_exception();
         }
     }
+    if (xdrops && !xdrops->empty()) aligner.align_xdrop_many(*xdrops);      // the seeded two-pass X-drops: two or three engine calls for all of them
     } catch (...) { done.err = std::current_exception(); }
 }
 

@@ -274,6 +274,10 @@ public:
                       uint16_t xdrop_max_gap_length = default_xdrop_max_gap_length);
     void align_global_banded(Alignment& alignment, const HandleGraph& g, int32_t band_padding = 0, bool permissive_banding = true,
                              uint64_t max_cells = std::numeric_limits<uint64_t>::max());
+    // Aligner::align_xdrop (the seeded two-pass X-drop of the rescue call sites, src/minimizer_mapper.cpp:3385, :3426), deferred: answered by
+    // the next flush() through Aligner::align_xdrop_many (a size-triggered flush leaves these waiting: their passes depend on each other)
+    void align_xdrop(Alignment& alignment, const HandleGraph& g, const std::vector<MaximalExactMatch>& mems, bool reverse_complemented,
+                     uint16_t max_gap_length = default_xdrop_max_gap_length);
     size_t size() const;
     size_t flushes() const { return n_flushes; }
     void flush();
@@ -284,11 +288,12 @@ public:
     std::exception_ptr failure_of(const Alignment& alignment) const;
 private:
     void submit(std::unique_ptr<Aligner::Job> job);
-    void run(std::vector<std::unique_ptr<Aligner::Job>>& jobs, size_t device);
+    void run(std::vector<std::unique_ptr<Aligner::Job>>& jobs, size_t device, std::vector<Aligner::XdropRequest>* xdrops = nullptr);
     std::vector<const Aligner*> aligners;
     size_t max_pending;
     mutable std::mutex mu; std::condition_variable idle;
     std::vector<std::unique_ptr<Aligner::Job>> jobs;
+    std::vector<Aligner::XdropRequest> xdrop_requests;
     std::vector<std::unique_ptr<std::mutex>> device_mu;
     size_t next_device = 0, in_flight = 0, n_flushes = 0;
     std::exception_ptr failure;

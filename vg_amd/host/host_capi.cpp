@@ -704,6 +704,22 @@ int32_t vgh_score_contiguous_alignment(vgh_aligner* a, const char* sequence, con
 }
 }
 extern "C" {
+// AlignmentBatch::align_xdrop: slot as in vgh_batch_add_slot; MEMs flat as in vgh_align_xdrop
+int vgh_batch_add_xdrop_slot(vgh_batch* b, int slot, vgh_graph* g, const char* read, const int64_t* mems, int n_mems, int reverse_complemented, int max_gap) {
+    try {
+        Alignment& aln = b->alns[(size_t)slot]; aln = Alignment(); aln.sequence = read;
+        std::vector<MaximalExactMatch> ms;
+        for (int i = 0; i < n_mems; ++i) {
+            MaximalExactMatch m; m.begin = (size_t)mems[5 * i]; m.end = (size_t)mems[5 * i + 1];
+            m.nodes.push_back({mems[5 * i + 2], (size_t)mems[5 * i + 3], mems[5 * i + 4] != 0});
+            ms.push_back(m);
+        }
+        b->b->align_xdrop(aln, g->g, ms, reverse_complemented != 0, (uint16_t)max_gap);
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+}
+extern "C" {
 // Submissions from many threads at once: the caller reserves n slots, every thread submits into slots of its own (no lock on the
 // caller's side: AlignmentBatch's own lock orders the submissions), the flush answers in slot order.
 int vgh_batch_reserve(vgh_batch* b, int n) { b->alns.clear(); b->alns.resize((size_t)n); return 0; }
