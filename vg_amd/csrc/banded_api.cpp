@@ -783,17 +783,17 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
 }
 
 int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n,
-                     vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+                     vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) try {
     return banded_align_impl(ctx, problems, n, 0, results, nullptr, ops, ops_cap, ops_written);
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 int vgk_banded_align_multi(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n, uint32_t max_alt_alns,
-                           vgk_result* results, uint32_t* n_alignments, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+                           vgk_result* results, uint32_t* n_alignments, vgk_op* ops, size_t ops_cap, size_t* ops_written) try {
     if (!max_alt_alns) return VGK_EINVAL;
     return banded_align_impl(ctx, problems, n, max_alt_alns, results, n_alignments, ops, ops_cap, ops_written);
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
-int vgk_banded_rerun(vgk_ctx* ctx) {
+int vgk_banded_rerun(vgk_ctx* ctx) try {
     if (!ctx) return VGK_EINVAL;
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (!ctx->banded_last_valid) return VGK_EINVAL;
@@ -803,7 +803,7 @@ int vgk_banded_rerun(vgk_ctx* ctx) {
     if ((rc = be->run_banded(ctx->banded_last, ctx->banded_last_launches.data(), (uint32_t)ctx->banded_last_launches.size()))) return rc;
     ctx->banded_ms[0] = be->last_ms(3); ctx->banded_ms[1] = be->last_ms(4);
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 double vgk_banded_last(vgk_ctx* ctx, int which) {
     if (!ctx) return 0.0;

@@ -92,7 +92,7 @@ extern "C++" int vgk_haplo_strands(uint32_t N, const uint32_t* node_len, const c
     return VGK_OK;
 }
 
-int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
+int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) try {
     if (!ctx || !d || !out || !d->n_nodes || !d->node_len || !d->seq || (d->n_threads && (!d->thread_off || !d->thread_nodes))) return VGK_EINVAL;
     *out = nullptr;
     const uint32_t N = d->n_nodes, O = 2 * N, S = 2 * d->n_threads;
@@ -179,7 +179,7 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) {
     }
     T.count.swap(count); T.body_off.swap(body_off);
     return vgk_haplo_from_tables(ctx, O, len, seq_off, seq, (uint32_t)total, T, out);
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 // The records as the kernels read them, from the tables either builder makes (this file's, from threads; gbwt_file.cpp's, straight from
 // a GBWT's own records): per oriented node its visits (count), per visit the edge it leaves through (body, from body_off), its edges in
@@ -390,15 +390,15 @@ static int gapless_run_and_fetch(vgk_ctx* ctx, GaplessParams& P, uint32_t n, uin
 }
 
 
-int vgk_gapless_fetch_deferred(vgk_ctx* ctx) {
+int vgk_gapless_fetch_deferred(vgk_ctx* ctx) try {
     if (!ctx) return VGK_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
     return ctx->finish_deferred();
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_problem* problems, uint32_t n,
                        vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
-                       uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) {
+                       uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) try {
     if (!ctx || !index || index->ctx != ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
     if (written) written[0] = written[1] = written[2] = 0;
     if (!n) return VGK_OK;
@@ -491,14 +491,14 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
     P.order = d_sort + 3 * (size_t)n;
     return gapless_run_and_fetch(ctx, P, n, n_seed, next_slot, H, lap, results, extensions, ext_cap, nodes, nodes_cap, mismatches, mism_cap, written,
                                  (problems[0].flags & VGK_GAPLESS_DEFER) != 0);        // (a property of the call, carried by its first problem)
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 // The clusters of the last vgk_minimizer_seeds call, extended without leaving the device in between: the reads it uploaded (masked,
 // padded), the seeds it found and their offsets per read are still in HBM; the problem descriptors and the hand-out order are made
 // there too (a kernel + a radix sort).  One setting of max_mismatches / overlap_threshold / flags for the whole batch.
 int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max_mismatches, double overlap_threshold, uint32_t flags,
                               vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
-                              uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) {
+                              uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) try {
     if (!ctx || !index || index->ctx != ctx) return VGK_EINVAL;
     if (written) written[0] = written[1] = written[2] = 0;
     std::lock_guard<std::mutex> stage(ctx->stage_mu);
@@ -531,9 +531,9 @@ int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max
     P.probs = d_probs; P.reads = ctx->seeded.reads; P.seeds = ctx->seeded.seeds; P.order = d_sort + 3 * (size_t)n;
     lap("descriptors and order on the device");
     return gapless_run_and_fetch(ctx, P, n, n_seed, next_slot, H, lap, results, extensions, ext_cap, nodes, nodes_cap, mismatches, mism_cap, written, (flags & VGK_GAPLESS_DEFER) != 0);
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
-int vgk_gapless_rerun(vgk_ctx* ctx) {
+int vgk_gapless_rerun(vgk_ctx* ctx) try {
     if (!ctx) return VGK_EINVAL;
     std::lock_guard<std::mutex> stage(ctx->stage_mu);
     std::lock_guard<std::mutex> lock(ctx->mu);
@@ -543,7 +543,7 @@ int vgk_gapless_rerun(vgk_ctx* ctx) {
     if ((rc = ctx->be->run_gapless(ctx->gapless_last, ctx->gapless_last_threads))) return rc;
     ctx->gapless_ms = ctx->be->last_ms(5);
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 double vgk_gapless_last_ms(vgk_ctx* ctx) { return ctx ? ctx->gapless_ms : 0.0; }
 uint64_t vgk_gapless_last_retried(vgk_ctx* ctx) { return ctx ? ctx->gapless_retried : 0; }

@@ -193,7 +193,7 @@ extern "C" {
 uint64_t vgk_gssw_multi_host_walks(const vgk_ctx* ctx) { return ctx ? ctx->multi_host_walks : 0; }
 
 int vgk_gssw_align_multi(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, uint32_t max_alt_alns,
-                         vgk_result* results, uint32_t* n_alignments, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+                         vgk_result* results, uint32_t* n_alignments, vgk_op* ops, size_t ops_cap, size_t* ops_written) try {
     if (!ctx || (!problems && n) || (!results && n) || (!n_alignments && n) || !max_alt_alns) return VGK_EINVAL;
     if (ops_written) *ops_written = 0;
     if (!n) return VGK_OK;
@@ -387,6 +387,6 @@ int vgk_gssw_align_multi(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
     }
     if (ops_written) *ops_written = used;
     return rc_all;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 }  // extern "C"

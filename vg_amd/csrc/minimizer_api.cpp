@@ -29,7 +29,7 @@ struct Entry { uint64_t key, hash; uint32_t node, offset; };
 
 extern "C" {
 
-int vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* d, uint32_t k, uint32_t w, vgk_minimizer_index** out) {
+int vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* d, uint32_t k, uint32_t w, vgk_minimizer_index** out) try {
     if (!ctx || !d || !out || !d->n_nodes || !d->node_len || !d->seq || (d->n_threads && (!d->thread_off || !d->thread_nodes))) return VGK_EINVAL;
     if (k == 0 || k > MZ_MAX_K || w == 0 || w > MZ_MAX_W) return VGK_EINVAL;
     *out = nullptr;
@@ -96,7 +96,7 @@ int vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* d, uint32_t k
     ix->dev.slots = (const MzSlot*)ds; ix->dev.mask = (uint32_t)(cap - 1); ix->dev.pos = (const MzPos*)dp; ix->dev.k = k; ix->dev.w = w;
     *out = ix.release();
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 void vgk_minimizer_index_destroy(vgk_minimizer_index* ix) {
     if (!ix) return;
@@ -105,15 +105,15 @@ void vgk_minimizer_index_destroy(vgk_minimizer_index* ix) {
 }
 uint64_t vgk_minimizer_index_keys(const vgk_minimizer_index* ix) { return ix ? ix->n_keys : 0; }
 uint64_t vgk_minimizer_index_hits(const vgk_minimizer_index* ix) { return ix ? ix->hits.size() : 0; }
-int vgk_minimizer_index_fetch(const vgk_minimizer_index* ix, vgk_minimizer_hit* hits, size_t cap) {
+int vgk_minimizer_index_fetch(const vgk_minimizer_index* ix, vgk_minimizer_hit* hits, size_t cap) try {
     if (!ix || (!hits && cap)) return VGK_EINVAL;
     if (cap < ix->hits.size()) return VGK_EOPS;
     if (!ix->hits.empty()) std::memcpy(hits, ix->hits.data(), sizeof(vgk_minimizer_hit) * ix->hits.size());
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_haplo* graph, const char* reads, const uint64_t* read_off, uint32_t n,
-                        uint32_t hit_cap, uint32_t* seed_off, uint32_t* minimizers, vgk_seed* seeds, size_t seeds_cap, size_t* written) {
+                        uint32_t hit_cap, uint32_t* seed_off, uint32_t* minimizers, vgk_seed* seeds, size_t seeds_cap, size_t* written) try {
     if (!ctx || !ix || !graph || ix->ctx != ctx || graph->ctx != ctx || (n && (!reads || !read_off || !seed_off))) return VGK_EINVAL;
     if (written) *written = 0;
     if (!n) { if (seed_off) seed_off[0] = 0; return VGK_OK; }
@@ -173,7 +173,7 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
     ctx->seeded.valid = true; ctx->seeded.n = n; ctx->seeded.reads = d_reads; ctx->seeded.bytes = bytes; ctx->seeded.read_off = d_off;
     ctx->seeded.seed_off = d_tab + 2 * n1; ctx->seeded.seeds = P.seeds; ctx->seeded.n_seeds = total; ctx->seeded.graph = graph;
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 double vgk_minimizer_last_ms(vgk_ctx* ctx) { return ctx ? ctx->minimizer_ms : 0.0; }
 

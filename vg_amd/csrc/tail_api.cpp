@@ -99,7 +99,7 @@ static int tail_forest_core(vgk_ctx* ctx, const vgk_haplo* index, const vgk_tail
 }
 
 int vgk_tail_forest(vgk_ctx* ctx, const vgk_haplo* index, const vgk_tail_problem* problems, uint32_t n,
-                    vgk_tail_result* results, vgk_forest** out) {
+                    vgk_tail_result* results, vgk_forest** out) try {
     if (!ctx || !index || !out || (n && (!problems || !results)) || index->ctx != ctx) return VGK_EINVAL;
     *out = nullptr;
     Backend* be = ctx->be.get();
@@ -119,11 +119,11 @@ int vgk_tail_forest(vgk_ctx* ctx, const vgk_haplo* index, const vgk_tail_problem
     ctx->tail_ms = be->watch_ms();
     *out = fo;
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 uint64_t vgk_forest_size(const vgk_forest* f) { return f ? f->n_nodes : 0; }
 
-int vgk_forest_fetch(const vgk_forest* f, int32_t* parent, uint32_t* node, uint32_t* length) {
+int vgk_forest_fetch(const vgk_forest* f, int32_t* parent, uint32_t* node, uint32_t* length) try {
     if (!f) return VGK_EINVAL;
     if (!f->n_nodes) return VGK_OK;
     std::lock_guard<std::mutex> lk(f->ctx->mu);
@@ -133,7 +133,7 @@ int vgk_forest_fetch(const vgk_forest* f, int32_t* parent, uint32_t* node, uint3
     if (!rc && node) rc = be->download(node, f->node, sizeof(uint32_t) * f->n_nodes);
     if (!rc && length) rc = be->download(length, f->len, sizeof(uint32_t) * f->n_nodes);
     return rc;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 const vgk_dgraph* vgk_forest_graph(const vgk_forest* f) { return f ? f->graph : nullptr; }
 
@@ -307,17 +307,17 @@ static int tail_stage_impl(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_pe
     return rc;
 }
 extern "C" {
-int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score, uint64_t stats[4]) {
+int vgk_tail_stage(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score, uint64_t stats[4]) try {
     int rc = tail_stage_impl(ctx, index, ops_per_problem, ext_total, ext_cap, read_score, stats, false, nullptr, 0, nullptr, 0, nullptr);
     if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); const int rc2 = ctx->finish_deferred(); if (!rc) rc = rc2; }       // the sets of a VGK_GAPLESS_DEFER call came down meanwhile
     return rc;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 int vgk_tail_stage_aligned(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score,
-                           vgk_tail_alignment* tails, size_t tails_cap, vgk_op* ops, size_t ops_cap, size_t written[2], uint64_t stats[4]) {
+                           vgk_tail_alignment* tails, size_t tails_cap, vgk_op* ops, size_t ops_cap, size_t written[2], uint64_t stats[4]) try {
     int rc = tail_stage_impl(ctx, index, ops_per_problem, ext_total, ext_cap, read_score, stats, true, tails, tails_cap, ops, ops_cap, written);
     if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); const int rc2 = ctx->finish_deferred(); if (!rc) rc = rc2; }
     return rc;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 double vgk_tail_stage_last_ms(vgk_ctx* ctx, int which) { return ctx && which >= 0 && which < 4 ? ctx->tail_stage_ms[which] : 0.0; }
 
 double vgk_tail_last_ms(vgk_ctx* ctx) { return ctx ? ctx->tail_ms : 0.0; }

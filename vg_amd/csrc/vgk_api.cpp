@@ -74,20 +74,20 @@ static int create_ctx(int device, const vgk_scoring* scoring, const vgk_qual_adj
 }
 
 int vgk_create(int device, const vgk_scoring* scoring, vgk_ctx** out) { return create_ctx(device, scoring, nullptr, out); }
-int vgk_create_qual_adj(int device, const vgk_scoring* scoring, const vgk_qual_adj* qual_adj, vgk_ctx** out) {
+int vgk_create_qual_adj(int device, const vgk_scoring* scoring, const vgk_qual_adj* qual_adj, vgk_ctx** out) try {
     if (!qual_adj) return VGK_EINVAL;
     return create_ctx(device, scoring, qual_adj, out);
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 void vgk_destroy(vgk_ctx* ctx) { delete ctx; }
 
-int vgk_device_info(vgk_ctx* ctx, char* name_out, size_t name_cap, int* cus, size_t* hbm) {
+int vgk_device_info(vgk_ctx* ctx, char* name_out, size_t name_cap, int* cus, size_t* hbm) try {
     if (!ctx) return VGK_EINVAL;
     if (name_out && name_cap) { std::strncpy(name_out, ctx->be->name(), name_cap - 1); name_out[name_cap - 1] = 0; }
     if (cus) *cus = ctx->be->compute_units();
     if (hbm) *hbm = ctx->be->memory_bytes();
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 void vgk_batch_free(vgk_batch* b) {
     if (!b) return;
@@ -102,7 +102,7 @@ void vgk_batch_free(vgk_batch* b) {
     delete b;
 }
 
-int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out) {
+int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out) try {
     if (!ctx || !out || (!problems && n)) return VGK_EINVAL;
     *out = nullptr;
     std::unique_ptr<vgk_batch> hb(new (std::nothrow) vgk_batch());
@@ -444,21 +444,21 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     lap("uploads");
     *out = hb.release();
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
-int vgk_gssw_run(vgk_batch* b) {
+int vgk_gssw_run(vgk_batch* b) try {
     if (!b) return VGK_EINVAL;
     std::lock_guard<std::mutex> lk(b->ctx->mu);
     if (!b->done) b->done = b->ctx->be->event_create();
     const int rc = b->ctx->be->run_gssw_on(b->lane, b->P, b->launches.data(), (uint32_t)b->launches.size(), true, b->done);
     if (rc == VGK_OK) b->ran = true;
     return rc;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
-int vgk_batch_sync(vgk_batch* b) {
+int vgk_batch_sync(vgk_batch* b) try {
     if (!b) return VGK_EINVAL;
     return b->done ? b->ctx->be->event_wait(b->done) : b->ctx->be->sync();        // this batch's kernels; no context lock: another thread may be packing the next batch
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 // The usual way back: the ops are packed behind each other on the device (a read uses a handful of its ops_per_problem slots),
 // results and ops cross PCIe once into page-locked staging, and host threads copy them into the caller's arrays.  Returns
@@ -505,7 +505,7 @@ static int fetch_packed_on_device(vgk_batch* b, vgk_result* results, vgk_op* ops
     return VGK_OK;
 }
 
-int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) try {
     if (!b || !results) return VGK_EINVAL;
     if (!b->ran) { int rc = vgk_gssw_run(b); if (rc) return rc; }
     // wait for THIS batch's kernels (its own event; polling, outside blocking runtime calls and outside the context lock); the
@@ -560,7 +560,7 @@ int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_ca
     b->alg_bytes = b->in_bytes + alg;
     if (ops_written) *ops_written = w;
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 // Rough HBM footprint of one problem (dominated by the 4-bit traceback codes) — used to cut oversize calls into
 // sub-batches that fit the device (288 GB on MI355X holds ~8M of the 150 bp x 400 bp problems at once).
@@ -588,7 +588,7 @@ static int problem_limit_status(const vgk_ctx* ctx, const vgk_gssw_problem& p) {
 }
 
 int vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
-                   vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+                   vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) try {
     if (!ctx || (!problems && n) || !results) return VGK_EINVAL;
     uint64_t budget = ctx->be->memory_bytes();
     budget = budget ? budget / 2 : (8ull << 30);          // leave half of HBM to the caller / other contexts
@@ -640,7 +640,7 @@ int vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
     }
     if (ops_written) *ops_written = w_total;
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 double vgk_batch_kernel_ms(vgk_batch* b, int which) {
     if (!b) return 0.0;

@@ -122,7 +122,7 @@ int run_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P, bool after_threa
 extern "C" {
 
 int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_model* model, const vgk_wfa_problem* problems, uint32_t n,
-                   vgk_wfa_result* results, uint32_t* paths, size_t path_cap, uint32_t* edits, size_t edit_cap, size_t written[2]) {
+                   vgk_wfa_result* results, uint32_t* paths, size_t path_cap, uint32_t* edits, size_t edit_cap, size_t written[2]) try {
     if (!ctx || !index || index->ctx != ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
     if (written) written[0] = written[1] = 0;
     if (!n) return VGK_OK;
@@ -349,9 +349,9 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     });
     if (written) { written[0] = op[n]; written[1] = oe[n]; }
     return rc_all;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
-int vgk_wfa_rerun(vgk_ctx* ctx) {
+int vgk_wfa_rerun(vgk_ctx* ctx) try {
     if (!ctx) return VGK_EINVAL;
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (ctx->wfa_wave_last_valid && ctx->wfa_last_valid) {                         // hybrid: the thread kernel, then the wavefront kernel on what it hands over
@@ -376,28 +376,28 @@ int vgk_wfa_rerun(vgk_ctx* ctx) {
     if ((rc = ctx->be->run_wfa(ctx->wfa_last, ctx->wfa_last_threads))) return rc;
     ctx->wfa_ms = ctx->be->last_ms(6);
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 double vgk_wfa_last_ms(vgk_ctx* ctx) { return ctx ? ctx->wfa_ms : 0.0; }
 // 0 = ms of the first launch (hybrid: the thread kernel; wave form: the only one), 1 = ms of the wavefront kernel behind the thread kernel (hybrid),
 // 2 = problems the thread kernel handed over (hybrid) / that outgrew the small tables (wave form)
 double vgk_wfa_last_wave(vgk_ctx* ctx, int which) { return !ctx ? 0.0 : which == 0 ? ctx->wfa_wave_ms[0] : which == 1 ? ctx->wfa_wave_ms[1] : (double)ctx->wfa_wave_retried; }
-int vgk_wfa_set_cost_hints(vgk_ctx* ctx, const uint32_t* extra_bases, uint32_t n) {
+int vgk_wfa_set_cost_hints(vgk_ctx* ctx, const uint32_t* extra_bases, uint32_t n) try {
     if (!ctx || (!extra_bases && n)) return VGK_EINVAL;
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->wfa_cost_hints.assign(extra_bases, extra_bases + n);
     return VGK_OK;
-}
-int vgk_wfa_set_form(vgk_ctx* ctx, int form) {
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
+int vgk_wfa_set_form(vgk_ctx* ctx, int form) try {
     if (!ctx || form < VGK_WFA_FORM_HYBRID || form > VGK_WFA_FORM_WAVE) return VGK_EINVAL;
     std::lock_guard<std::mutex> lock(ctx->mu); ctx->wfa_form = form;
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 int vgk_wfa_set_point_budget(vgk_ctx* ctx, uint32_t points) { return vgk_wfa_set_point_budgets(ctx, points, points); }
-int vgk_wfa_set_point_budgets(vgk_ctx* ctx, uint32_t connect_points, uint32_t tail_points) {
+int vgk_wfa_set_point_budgets(vgk_ctx* ctx, uint32_t connect_points, uint32_t tail_points) try {
     if (!ctx) return VGK_EINVAL;
     std::lock_guard<std::mutex> lock(ctx->mu); ctx->wfa_point_budget = connect_points; ctx->wfa_point_budget_tail = tail_points;
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 }  // extern "C"

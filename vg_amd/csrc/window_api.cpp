@@ -38,7 +38,7 @@ struct Lap {
 
 extern "C" {
 
-int vgk_graph_create(vgk_ctx* ctx, const vgk_graph* graph, vgk_dgraph** out) {
+int vgk_graph_create(vgk_ctx* ctx, const vgk_graph* graph, vgk_dgraph** out) try {
     if (!ctx || !graph || !out) return VGK_EINVAL;
     *out = nullptr;
     const vgk_graph& g = *graph;
@@ -100,7 +100,7 @@ int vgk_graph_create(vgk_ctx* ctx, const vgk_graph* graph, vgk_dgraph** out) {
     dg->g.pred_idx = (const uint32_t*)d_pi; dg->g.slot = (const uint32_t*)d_slot; dg->g.n_nodes = n; dg->g.n_cols = (uint32_t)cols;
     *out = dg.release();
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 void vgk_graph_destroy(vgk_dgraph* dg) {
     if (!dg) return;
@@ -116,7 +116,7 @@ void vgk_graph_destroy(vgk_dgraph* dg) {
 // `on_device`: reads and problems are device arrays already (vgk_tail_stage builds them there) and the caller has waited for the
 // kernels that wrote them; nothing is staged.
 int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
-                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out, bool on_device, uint32_t forced_k) {
+                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out, bool on_device, uint32_t forced_k) try {
     if (!ctx || !dg || dg->ctx != ctx || !out || (!problems && n) || (!reads && reads_bytes)) return VGK_EINVAL;
     *out = nullptr;
     if (ctx->has_qa) return VGK_EUNSUPPORTED;
@@ -247,11 +247,11 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     lap("done");
     *out = hb.release();
     return VGK_OK;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
-                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out) {
+                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out) try {
     return vgk_pack_windows_impl(ctx, dg, reads, reads_bytes, problems, n, ops_per_problem, out, false, 0);
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 }  // extern "C"

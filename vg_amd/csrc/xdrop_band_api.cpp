@@ -36,7 +36,7 @@ struct BandHost { PinnedBuf<uint8_t> reads, quals, graph, want; PinnedBuf<MProb>
 extern "C" {
 
 int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
-                         vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written, uint64_t stats[2]) {
+                         vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written, uint64_t stats[2]) try {
     if (!ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
     if (ops_written) *ops_written = 0;
     if (stats) stats[0] = stats[1] = 0;
@@ -226,7 +226,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
     if (ops_written) *ops_written = used;
     if (stats) { stats[0] = in_band_total; stats[1] = rect_total; }
     return rc_all;
-}
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 double vgk_xdrop_band_last_ms(vgk_ctx* ctx) { return ctx ? ctx->xband_ms : 0.0; }
 
