@@ -34,7 +34,8 @@
  * batch-first: pack N problems (host → HBM), run (kernels only), fetch
  * (HBM → host).  A batch of 1 gives the reference's synchronous semantics.
  *
- * Error model: return codes (0 = OK, <0 = VGK_E*), never exit()/abort();
+ * Error model: return codes (0 = OK, <0 = VGK_E*), never exit()/abort(), and no C++ exception crosses this boundary (an allocation
+ * that fails inside a call comes back as VGK_ENOMEM);
  * per-problem failures are reported in vgk_result.status.
  */
 #ifndef VGK_H
