@@ -97,6 +97,33 @@ public:
         for (auto& t : ts) t.join();
         pthread_barrier_destroy(&sh.bar);
     }
+    // the wide route: the 256 lanes of a problem's skewed wavefront stepped one after the other, the row above from lane - 1's previous step
+    template <int K> static void wide_fill(const WideParams& P, uint32_t i) {
+        const WideProb d = P.probs[i];
+        uint32_t* tb = (d.flags & VGK_GSSW_TRACEBACK) ? P.tb + d.tb_off : nullptr;
+        std::vector<WLane<K>> lanes(WIDE_LANES);
+        std::vector<int32_t> oh(WIDE_LANES), of(WIDE_LANES); std::vector<uint32_t> oi(WIDE_LANES);
+        for (uint32_t strip = 0; strip < d.n_strips; ++strip) {
+            for (uint32_t l = 0; l < WIDE_LANES; ++l) wide_lane_init<K>(lanes[l], P, d, strip, l);
+            const uint32_t rows_left = d.L - strip * WIDE_LANES * (uint32_t)K;
+            const uint32_t lanes_used = rows_left >= WIDE_LANES * (uint32_t)K ? WIDE_LANES : (rows_left + (uint32_t)K - 1u) / (uint32_t)K;
+            const uint32_t n_steps = d.R + lanes_used - 1u;
+            for (uint32_t t = 0; t < n_steps; ++t) {
+                for (uint32_t l = 0; l < WIDE_LANES; ++l) { oh[l] = lanes[l].out_h; of[l] = lanes[l].out_f; oi[l] = lanes[l].info; }
+                for (uint32_t l = 0; l < WIDE_LANES; ++l) {
+                    uint32_t* rec = tb ? tb + (uint64_t)strip * d.strip_dwords + ((uint64_t)t * WIDE_LANES + l) * (K / 8) : nullptr;
+                    wide_lane_step<K>(lanes[l], P, d, strip, l, t, l ? oh[l - 1] : 0, l ? of[l - 1] : 0, l ? oi[l - 1] : 0u, rec);
+                }
+            }
+            for (uint32_t l = 0; l < WIDE_LANES; ++l) { unsigned long long key; if (wide_lane_best<K>(lanes[l], d, l, key) && key > P.best[i]) P.best[i] = key; }
+        }
+    }
+    int run_gssw_wide(const WideParams& P, uint32_t n8, uint32_t n16) override {
+        for (uint32_t k = 0; k < n8; ++k) wide_fill<8>(P, P.order[k]);
+        for (uint32_t k = 0; k < n16; ++k) wide_fill<16>(P, P.order[n8 + k]);
+        for (uint32_t i = 0; i < P.n; ++i) wide_walk_one(P, i);
+        return VGK_OK;
+    }
     int run_xdrop_band(const GsswMatrixParams& P) override {
         // the launch order's two classes: problems that run in one DPP row of 16 lanes (four to a wavefront on the GPU; here one after the
         // other — the rows do not talk to each other), then the ones that take a whole wavefront

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libvgamd.so")
 
 VGK_OK = 0
+VGK_EINVAL, VGK_ENODEV, VGK_ENOMEM, VGK_ETOOLONG, VGK_EOVERFLOW, VGK_EOPS = -1, -2, -3, -4, -5, -6      # include/vgk.h
 VGK_GSSW_LOCAL = 0
 VGK_GSSW_PINNED = 1
 VGK_XDROP_PINNED = 2
@@ -318,6 +319,15 @@ class Engine:
         with self.pack(ps, ops_per_problem) as b:
             b.run()
             return b.fetch()
+
+    def align_call(self, ps):
+        """vgk_gssw_align (the one-call form: sub-batches, and the wide route for problems outside the packed kernels' range) -> (results, ops)."""
+        res = np.zeros(ps.n, dtype=RESULT_DT)
+        cap = int(np.diff(ps.read_off).sum() + np.diff(ps.seq_off).sum() + 4 * ps.n)
+        ops = np.zeros(max(cap, 1), dtype=OP_DT)
+        written = ctypes.c_size_t()
+        self._check(self.lib.vgk_gssw_align(self.h, ps.ptr, ps.n, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written)), "vgk_gssw_align")
+        return res, ops[:written.value]
 
     def xdrop_band_align(self, ps):
         """vgk_xdrop_band_align over a ProblemSet of VGK_XDROP_PINNED problems -> (results, ops, (cells in band, cells of the rectangles))."""

@@ -17,6 +17,7 @@
 #include "gssw_pack_device.hpp"
 #include "tail_device.hpp"
 #include "minimizer_device.hpp"
+#include "gssw_wide_device.hpp"
 
 namespace vgk {
 
@@ -113,6 +114,9 @@ public:
     virtual int   run_gssw_multi(const GsswMultiParams& p) = 0;
     // the k-best banded alignments over the kept score matrices, one lane per problem (banded_multi_device.hpp); synchronises
     virtual int   run_banded_multi(const BandedMultiParams& q) = 0;
+    // the wide route of vgk_gssw_align (gssw_wide_device.hpp): a workgroup of four wavefronts per problem, p.order[0 .. n8) with 8 rows
+    // per lane, p.order[n8 .. n8 + n16) with 16; then the tracebacks, one lane per problem.  Asynchronous on the main stream.
+    virtual int   run_gssw_wide(const WideParams& p, uint32_t n8, uint32_t n16) = 0;
     // X-drop with dozeu's band (vgk_xdrop_band_align): one wavefront per problem, the matrices stay for the host's traceback;
     // last_ms(7) = kernel ms
     virtual int   run_xdrop_band(const GsswMatrixParams& p) = 0;

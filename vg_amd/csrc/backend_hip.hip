@@ -674,6 +674,44 @@ __global__ void __launch_bounds__(64) gssw_matrix_wave_kernel(const GsswMatrixPa
     gssw_matrix_wave_lane<R>(P, i, threadIdx.x, xl);
 }
 
+// The wide route (gssw_wide_device.hpp): one workgroup of four wavefronts per problem; its 256 lanes run ONE skewed wavefront.  Inside a
+// wavefront the row above arrives by DPP; lane 0 of wavefronts 1-3 takes it from the three words the last lane of the wavefront before
+// left in LDS at the end of the previous step (double-buffered by step parity); one barrier per step keeps the four in step.
+template <int K>
+__global__ void __launch_bounds__(256) gssw_wide_kernel(const WideParams P) {
+    __shared__ int32_t xh[2][4], xf[2][4];
+    __shared__ uint32_t xi[2][4];
+    const uint32_t i = P.order[P.order_begin + blockIdx.x];
+    const WideProb d = P.probs[i];
+    const uint32_t lane = threadIdx.x, wv = lane >> 6, wl = lane & 63u;
+    uint32_t* tb = (d.flags & VGK_GSSW_TRACEBACK) ? P.tb + d.tb_off : nullptr;
+    for (uint32_t strip = 0; strip < d.n_strips; ++strip) {
+        WLane<K> s;
+        wide_lane_init<K>(s, P, d, strip, lane);
+        const uint32_t rows_left = d.L - strip * WIDE_LANES * (uint32_t)K;
+        const uint32_t lanes_used = rows_left >= WIDE_LANES * (uint32_t)K ? WIDE_LANES : (rows_left + (uint32_t)K - 1u) / (uint32_t)K;
+        const uint32_t n_steps = d.R + lanes_used - 1u;
+        for (uint32_t t = 0; t < n_steps; ++t) {
+            int32_t rh = (int32_t)from_lane_above((uint32_t)s.out_h);
+            int32_t rf = (int32_t)from_lane_above((uint32_t)s.out_f);
+            uint32_t ri = from_lane_above(s.info);
+            if (wl == 0 && wv > 0) { const uint32_t b = (t + 1u) & 1u; rh = xh[b][wv - 1]; rf = xf[b][wv - 1]; ri = xi[b][wv - 1]; }
+            uint32_t* rec = tb ? tb + (uint64_t)strip * d.strip_dwords + ((uint64_t)t * WIDE_LANES + lane) * (K / 8) : nullptr;
+            wide_lane_step<K>(s, P, d, strip, lane, t, rh, rf, ri, rec);
+            if (wl == 63u) { const uint32_t b = t & 1u; xh[b][wv] = s.out_h; xf[b][wv] = s.out_f; xi[b][wv] = s.info; }
+            __syncthreads();
+        }
+        unsigned long long key;
+        if (wide_lane_best<K>(s, d, lane, key)) atomicMax(&P.best[i], key);
+        __threadfence();            // this strip's carry row and saved columns -> the next strip's lanes
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(64) gssw_wide_walk_kernel(const WideParams P) {
+    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+    if (k < P.n) wide_walk_one(P, k);
+}
+
 class HipBackend final : public Backend {
 public:
     int dev = 0; int n_launches = 1; hipStream_t stream = nullptr, copy = nullptr, fetch = nullptr, side[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr}; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -982,6 +1020,15 @@ public:
         hipLaunchKernelGGL(gssw_multi_kernel, dim3((p.M.n + 63) / 64), dim3(64), 0, stream, p);
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         return VGK_OK;
+    }
+    int run_gssw_wide(const WideParams& p0, uint32_t n8, uint32_t n16) override {
+        hipSetDevice(dev);
+        if (!p0.n) return VGK_OK;
+        WideParams p = p0;
+        if (n8) { p.order_begin = 0; p.order_count = n8; hipLaunchKernelGGL(gssw_wide_kernel<8>, dim3(n8), dim3(256), 0, stream, p); }
+        if (n16) { p.order_begin = n8; p.order_count = n16; hipLaunchKernelGGL(gssw_wide_kernel<16>, dim3(n16), dim3(256), 0, stream, p); }
+        hipLaunchKernelGGL(gssw_wide_walk_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_xdrop_band(const GsswMatrixParams& p) override {
         hipSetDevice(dev);

@@ -20,6 +20,7 @@
 #include "host_parallel.hpp"
 
 #include "batch.hpp"
+#include "gssw_wide.hpp"
 
 extern "C" {
 
@@ -31,7 +32,7 @@ const char* vgk_strerror(int code) {
         case VGK_EINVAL: return "invalid argument";
         case VGK_ENODEV: return "no usable HIP device";
         case VGK_ENOMEM: return "out of memory";
-        case VGK_ETOOLONG: return "read too long for the engine (max 1024 bases)";
+        case VGK_ETOOLONG: return "read too long for the engine";
         case VGK_EOVERFLOW: return "score overflow";
         case VGK_EOPS: return "cigar buffer too small";
         case VGK_ETOOBIG: return "band matrices too big";
@@ -593,11 +594,13 @@ int vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
     uint64_t budget = ctx->be->memory_bytes();
     budget = budget ? budget / 2 : (8ull << 30);          // leave half of HBM to the caller / other contexts
     if (const char* e = std::getenv("VGAMD_MAX_BATCH_BYTES")) budget = std::strtoull(e, nullptr, 10);
-    // problems outside the kernels' range are answered here; the others run in sub-batches that fit the budget
-    std::vector<uint32_t> runnable; runnable.reserve(n);
+    // malformed problems are answered here; those outside the packed kernels' range (reads of more than 1024 rows, scores beyond 11
+    // bits) take the wide route at the end (gssw_wide_api.cpp); the others run in sub-batches that fit the budget
+    std::vector<uint32_t> runnable, wide; runnable.reserve(n);
     for (uint32_t i = 0; i < n; ++i) {
         const int st = problem_limit_status(ctx, problems[i]);
         if (st == VGK_OK) runnable.push_back(i);
+        else if (st == VGK_ETOOLONG || st == VGK_EUNSUPPORTED) wide.push_back(i);
         else { std::memset(&results[i], 0, sizeof results[i]); results[i].status = st; }
     }
     const bool all = runnable.size() == n;
@@ -637,6 +640,10 @@ int vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
         }
         w_total += w;
         begin = end;
+    }
+    if (!wide.empty()) {
+        const int rc = wide_align(ctx, problems, wide.data(), (uint32_t)wide.size(), results, ops, ops_cap, &w_total);
+        if (rc) return rc;
     }
     if (ops_written) *ops_written = w_total;
     return VGK_OK;
