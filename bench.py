@@ -920,6 +920,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--host-pack", action="store_true", help="linear workload: one explicit graph per problem, packed on host threads (vgk_gssw_pack) instead of windows of the resident graph packed on the device")
     ap.add_argument("--no-e2e", action="store_true", help="skip the legs that overlap launches — the two-lane steady state and the warm / double-buffered end-to-end legs — so that a profiler's per-kernel averages are each kernel's own")
+    ap.add_argument("--no-secondary", action="store_true", help="default (linear, one GPU) run: do not append the `secondary` records — the other kernel families' own bench lines, each run "
+                         "as `bench.py --workload X` in a process of its own after the headline has been measured")
     ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband", "forest", "giraffe", "longread", "config2"], default="linear",
                     help="linear = BASELINE.json configs[1] (the headline metric); tails = configs[2] stand-in: "
                          "giraffe-style pinned X-drop tail alignments on a variation graph; banded = configs[4] stand-in: "
@@ -1232,9 +1234,55 @@ def main():
             "end_to_end_double_buffered_per_s": args.reads * world / t_pipe if t_pipe else None,
             "host_threads_per_rank": int(os.environ.get("VGAMD_HOST_THREADS", "0")) or min(shard.usable_cpus(), 48),
         }
+        if world == 1 and args.workload == "linear" and not args.no_secondary and not args.no_cpu and os.environ.get("VGAMD_BENCH_SECONDARY", "1") != "0":
+            if windows:
+                graph.close()
+            eng.close()                                        # the headline is measured: its HBM goes back before the other legs start
+            out["secondary"] = secondary_records()
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+# The other kernel families' bench lines, appended to the default run's JSON line as `secondary` (the headline's keys and meaning are
+# untouched: it has been measured and its engine closed before these start).  Each is `bench.py --workload X` in a process of its own,
+# at a size that keeps the whole default run within a few minutes; a record keeps the line's metric, value, roofline, cpu_baseline and
+# parity.  A leg that fails or overruns its time limit leaves {"workload", "error"} — never a missing headline.
+SECONDARY = [
+    ("config2", ["--reads", "1000000", "--steps", "3", "--warmup", "1", "--cpu-sample", "50000"], 170),
+    ("gapless", ["--steps", "5", "--warmup", "2"], 90),
+    ("xband", ["--steps", "3", "--warmup", "1"], 90),
+    ("banded", ["--reads", "100000", "--steps", "5", "--warmup", "2"], 90),
+    ("wfa", ["--reads", "500000", "--steps", "5", "--warmup", "2"], 90),
+    ("longread", ["--steps", "3", "--warmup", "1"], 120),
+]
+
+
+def secondary_records():
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = []
+    for name, extra, limit in SECONDARY:
+        t0 = time.perf_counter()
+        rec = {"workload": name}
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", name] + extra, env=env, cwd=ROOT,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit, text=True)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not line:
+                rec["error"] = "rc %d: %s" % (p.returncode, (p.stderr or "").strip()[-300:])
+            else:
+                d = json.loads(line[-1])
+                cfg = d.get("config") or {}
+                rec.update({k: d.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "cpu_baseline", "parity", "problems_failed")})
+                rec["config"] = {k: cfg.get(k) for k in ("workload", "timed_region", "ms_per_batch", "kernel_ms_per_batch", "policies") if k in cfg}
+        except subprocess.TimeoutExpired:
+            rec["error"] = "time limit of %d s" % limit
+        except Exception as e:                                # (a leg must never take the headline down)
+            rec["error"] = "%s: %s" % (type(e).__name__, e)
+        rec["wall_s"] = round(time.perf_counter() - t0, 1)
+        out.append(rec)
+    return out
 
 
 if __name__ == "__main__":

@@ -522,6 +522,7 @@ int    vgk_wfa_set_point_budgets(vgk_ctx* ctx, uint32_t connect_points, uint32_t
  * WAVE throughout: the heavy problems then start at once instead of behind the thread launch. */
 enum { VGK_WFA_FORM_HYBRID = 0, VGK_WFA_FORM_THREAD = 1, VGK_WFA_FORM_WAVE = 2 };
 int    vgk_wfa_set_form(vgk_ctx* ctx, int form);
+int    vgk_wfa_get_form(vgk_ctx* ctx);          /* the form in force (a stage that changes it puts it back) */
 /* What the caller expects problem i of the NEXT vgk_wfa_extend call (of exactly n problems) to cost beyond its sequence length, in
  * bases: problems are handed to the kernels most expensive first, and a launch ends with its heaviest problem — one that starts last
  * adds its whole run to the launch.  giraffe knows the graph distance between the two anchors of a connect: a sequence 40 bases longer

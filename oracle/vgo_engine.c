@@ -296,6 +296,7 @@ double vgk_wfa_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }
 double vgk_wfa_last_wave(vgk_ctx* ctx, int which) { (void)ctx; (void)which; return 0.0; }
 uint64_t vgk_gssw_multi_host_walks(const vgk_ctx* ctx) { (void)ctx; return 0; }      /* (the oracle has no device: every problem is walked here) */
 int vgk_wfa_set_form(vgk_ctx* ctx, int form) { (void)ctx; (void)form; return VGK_OK; }
+int vgk_wfa_get_form(vgk_ctx* ctx) { (void)ctx; return 0; }
 int vgk_wfa_set_cost_hints(vgk_ctx* ctx, const uint32_t* extra_bases, uint32_t n) { (void)ctx; (void)extra_bases; (void)n; return VGK_OK; }   /* (no launch to order) */
 int vgk_wfa_set_point_budget(vgk_ctx* ctx, uint32_t points) { (void)points; return ctx ? VGK_OK : VGK_EINVAL; }      /* the oracle has no tables to outgrow */
 int vgk_wfa_set_point_budgets(vgk_ctx* ctx, uint32_t connect_points, uint32_t tail_points) { (void)ctx; (void)connect_points; (void)tail_points; return VGK_OK; }

@@ -128,8 +128,9 @@ def test_gssw_align_answers_out_of_range_problems_per_problem(emu_lib):
     import ctypes
     rng = np.random.default_rng(12)
     good = [random_problem(rng, max_read=60) for _ in range(6)]
-    long_read = dict(good[0], read="ACGT" * 300)                      # 1200 bases: beyond the kernels' 1024 rows
-    problems = good[:3] + [long_read] + good[3:]
+    long_read = dict(good[0], read="ACGT" * 300)                      # 1200 bases: beyond the packed kernels' 1024 rows -> the wide route answers it
+    huge_read = dict(good[0], read="ACGT" * 16384)                    # 65536 bases: beyond vgk_op's 16-bit run length -> declined, alone
+    problems = good[:3] + [long_read] + good[3:] + [huge_read]
     ps = problem_set(problems)
     eng = capi.Engine(lib=emu_lib)
     res = np.zeros(ps.n, dtype=capi.RESULT_DT)
@@ -137,8 +138,10 @@ def test_gssw_align_answers_out_of_range_problems_per_problem(emu_lib):
     ops = np.zeros(cap, dtype=capi.OP_DT)
     written = ctypes.c_size_t()
     assert eng.lib.vgk_gssw_align(eng.h, ps.ptr, ps.n, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written)) == 0
-    assert res["status"][3] == -4                                      # VGK_ETOOLONG for that read only
+    assert res["status"][7] == -4                                      # VGK_ETOOLONG for that read only
     ref = capi.Engine(lib=ORACLE_LIB).align(problem_set(good))
+    one = capi.Engine(lib=ORACLE_LIB).align(problem_set([long_read]))
+    assert res["status"][3] == 0 and res["score"][3] == one[0]["score"][0] and capi.cigar_string(res[3], ops) == capi.cigar_string(one[0][0], one[1])
     keep = [0, 1, 2, 4, 5, 6]
     for k, i in enumerate(keep):
         assert res["score"][i] == ref[0]["score"][k] and res["status"][i] == 0

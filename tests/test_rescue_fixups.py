@@ -6,15 +6,16 @@ import json
 import util
 
 
-def fix_end_deletions(sequence, mappings):
+def fix_end_deletions(sequence, mappings, as_written=False):
     """mappings: [((node id, offset, is_reverse), [(from_length, to_length, has_sequence), ...]), ...] -> the alignment afterwards (dict)"""
     h = util.host()
-    h.vgh_fix_dozeu_end_deletions.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int,
+    fn = h.vgh_fix_dozeu_end_deletions_as_written if as_written else h.vgh_fix_dozeu_end_deletions
+    fn.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int,
                                               ctypes.c_char_p, ctypes.c_size_t]
     pos = [x for (p, _) in mappings for x in (p[0], p[1], int(p[2]))]
     eds = [x for m, (_, edits) in enumerate(mappings) for e in edits for x in (m, e[0], e[1], int(e[2]))]
     buf = ctypes.create_string_buffer(1 << 16)
-    rc = h.vgh_fix_dozeu_end_deletions(sequence.encode(), (ctypes.c_int64 * max(1, len(pos)))(*pos), len(mappings),
+    rc = fn(sequence.encode(), (ctypes.c_int64 * max(1, len(pos)))(*pos), len(mappings),
                                        (ctypes.c_int64 * max(1, len(eds)))(*eds), len(eds) // 4, buf, len(buf))
     assert rc == 0, h.vgh_last_error().decode()
     return json.loads(buf.value.decode())
@@ -31,6 +32,23 @@ def test_reference_case_deletions_on_both_ends():
     assert len(maps[0]["edit"]) == 1                                                                   # :1177
     e = maps[0]["edit"][0]
     assert e["from_length"] == 1 and e["to_length"] == 1 and e.get("sequence", "") == ""              # :1178-1180
+
+
+def test_leading_deletion_where_mapping_and_edit_index_differ():
+    """The reference drops the leading edits from `mappings[j]`, j the EDIT index (src/minimizer_mapper.cpp:3541); its own test has i = j = 1.
+    Here i = 0, j = 1 (the first mapping opens with a deletion, a second mapping follows): the default takes mapping i — the deletion goes,
+    the offset moves past it, every read base is still consumed; the as-written form is kept for comparison and leaves the deletion in."""
+    aln_in = [((4, 2, False), [(3, 0, False), (2, 2, False)]), ((5, 0, False), [(1, 0, False), (2, 2, False)])]
+    maps = fix_end_deletions("ACGT", aln_in)["path"]["mapping"]
+    assert [(m["position"]["node_id"], m["position"]["offset"]) for m in maps] == [(4, 5), (5, 0)]
+    assert [[(e["from_length"], e["to_length"]) for e in m["edit"]] for m in maps] == [[(2, 2)], [(1, 0), (2, 2)]]
+    assert sum(e["to_length"] for m in maps for e in m["edit"]) == 4
+    written = fix_end_deletions("ACGT", aln_in, as_written=True)["path"]["mapping"]
+    assert [(e["from_length"], e["to_length"]) for e in written[0]["edit"]] == [(3, 0), (2, 2)]          # the leading deletion is still there
+    assert written[0]["position"]["offset"] == 2 + 1                                                      # and the offset moved by the WRONG mapping's edit
+    # i = j: both forms are the reference's tested behaviour
+    same = [((1, 3, False), [(2, 0, False)]), ((2, 0, False), [(2, 0, False), (1, 1, False), (1, 0, False)])]
+    assert fix_end_deletions("A", same) == fix_end_deletions("A", same, as_written=True)
 
 
 def test_nothing_but_deletions_clears_the_path_and_clean_alignments_are_left_alone():

@@ -481,9 +481,9 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
                              vgk_result* results, uint32_t* n_alignments, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
     if (!ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
     const bool multi = max_alt_alns > 0;
-    if (multi) ctx->multi_host_walks = 0;
     if (multi && !n_alignments) return VGK_EINVAL;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    if (multi) ctx->multi_host_walks = 0;
     ctx->banded_ms[0] = ctx->banded_ms[1] = 0; ctx->banded_cells = 0; ctx->banded_bytes = 0; ctx->banded_last_valid = false;
     uint64_t budget = ctx->be->memory_bytes() / 2;
     if (const char* e = std::getenv("VGAMD_MAX_BATCH_BYTES")) budget = std::strtoull(e, nullptr, 10);

@@ -219,6 +219,7 @@ int gbwt_tables(const Bwt& B, HaploTables& T) {
         }
         const uint64_t continues = sigma < 255 ? 256 / sigma : 0;
         uint64_t seen = 0;
+        uint64_t through[256] = {0};                                          // visits that leave over each edge
         while (at < hi) {
             uint64_t rank, length;
             if (continues == 0) { if (!byte_code(s, at, rank) || !byte_code(s, at, length)) { bad[o] = 1; return; } ++length; }
@@ -229,9 +230,23 @@ int gbwt_tables(const Bwt& B, HaploTables& T) {
             }
             if (rank >= sigma || length > 0xfffffff0ull - seen) { bad[o] = 1; return; }
             if (fill) for (uint64_t k = 0; k < length; ++k) T.body[T.body_off[o] + seen + k] = (uint32_t)rank;
-            seen += length;
+            seen += length; through[rank] += length;
         }
-        if (!fill) { T.count[o] = (uint32_t)seen; T.edge_off[o + 1] = (uint32_t)sigma; }
+        if (!fill) {
+            if (seen == 0) { bad[o] = 1; return; }                            // edges but no visit: not a record a GBWT writes
+            T.count[o] = (uint32_t)seen; T.edge_off[o + 1] = (uint32_t)sigma;
+            return;
+        }
+        // An edge's offset is the rank of its first visit in the successor's record, and the visits it carries follow from there: they must
+        // lie inside that record (every count is known since the first pass) — the kernels form their search ranges from exactly these
+        // numbers, and the engine's records keep the offset in 16 bits (vgk_haplo_from_tables).  A file that says otherwise is refused here.
+        for (uint64_t e = 0; e < sigma; ++e) {
+            const int32_t to = T.edge_to[T.edge_off[o] + e];
+            if (to < 0) continue;
+            const uint64_t base = T.edge_base[T.edge_off[o] + e];
+            if (base + through[e] > T.count[(uint32_t)to]) { bad[o] = 1; return; }
+            if (base > 65535u) { bad[o] = 2; return; }
+        }
     };
     vgk::parallel_for(O, [&](uint32_t o, unsigned) { decode(o, false); });
     for (uint32_t o = 0; o < O; ++o) if (bad[o]) return bad[o] == 2 ? VGK_ETOOBIG : VGK_EINVAL;
@@ -264,6 +279,7 @@ int gbwt_tables(const Bwt& B, HaploTables& T) {
     if (visits + B.sequences != B.size) return VGK_EINVAL;                   // `size` counts every visit, the endmarker's included
     T.body.assign((size_t)visits, 0); T.edge_to.assign((size_t)edges, -1); T.edge_base.assign((size_t)edges + 1, 0);
     vgk::parallel_for(O, [&](uint32_t o, unsigned) { decode(o, true); });
+    for (uint32_t o = 0; o < O; ++o) if (bad[o]) return bad[o] == 2 ? VGK_ETOOBIG : VGK_EINVAL;
     return VGK_OK;
 }
 

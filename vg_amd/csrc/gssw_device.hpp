@@ -304,6 +304,22 @@ VGK_HD uint64_t tb_dword(uint64_t tb_off, uint32_t t, uint32_t lane, uint32_t re
     return j < 4u ? base + at * 4u + j : base + 64u * TB_TILE * 4u + at * (rec_dwords - 4u) + (j - 4u);
 }
 
+// Build switches of the fill's hot row (kernel experiments: tools/build_variant.sh NAME -DVGK_...=1):
+//   VGK_ACC_SHLOR  the 4-bit codes of four rows are merged by the full-rate v_lshl_or_b32 instead of v_pk_mad_u16 (exact: a half holds at
+//                  most 16 bits of codes, nothing crosses into the other read's half)
+//   VGK_H_MAX3     H = max(diagonal, E, F) as one v_pk_maximum3_f16 on the bit patterns (pk16.hpp) instead of two v_pk_max_u16
+//   VGK_FILL_NOTB  timing experiment only (results are wrong): no traceback codes are built or stored — the bound on what a
+//                  traceback that does not tax the fill could gain
+#ifndef VGK_ACC_SHLOR
+#define VGK_ACC_SHLOR 0
+#endif
+#ifndef VGK_H_MAX3
+#define VGK_H_MAX3 0
+#endif
+#ifndef VGK_FILL_NOTB
+#define VGK_FILL_NOTB 0
+#endif
+
 // best-cell key of a row: score*32 + (31 - row_in_lane), so one packed max keeps
 // the best score and, on ties, the smallest row (scores stay below 2047).
 constexpr uint32_t KEY_SHIFT = 5, KEY_LOW = 31;
@@ -320,6 +336,20 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
         if (nB) sb = set_hi(sb, row < s.LB ? P.bias + row_bonus(s.bsB, s.beB, row, s.LB) : 0u);
     }
     const uint32_t old = s.H[M];
+#if VGK_FILL_NOTB
+    if constexpr (S8) {
+        const uint32_t t4 = pk_subs(pk_add_nc(d, sb), bias2);
+        const uint32_t e = s.E[M];
+        const uint32_t h = VGK_H_MAX3 ? pk_max3_f16(t4, e, f) : pk_max(pk_max(t4, e), f);
+        const uint32_t gg = pk_subs(h, go2);
+        const uint32_t en = pk_max(gg, pk_subs(e, ge2)), fn = pk_max(gg, pk_subs(f, ge2));
+        if ((M & 3) == 0) acc[M >> 2] = 0;
+        const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(h, 0x00010001u << (KEY_SHIFT - 3));
+        ck = M == 0 ? key : pk_max(ck, key);
+        s.H[M] = h; s.E[M] = en; f = fn; d = old;
+        return;
+    }
+#endif
     if constexpr (S8) {
         // Scores scaled by 8 leave the three low bits of every value free, and they survive the subtraction of (scaled) constants.
         // Candidates carry a tag there, so the source of a maximum is read off the maximum instead of being recomputed from four
@@ -329,7 +359,7 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
         // end-cell key and the next gap open).  A saturated 0 has no tag: cells worth 0 are never walked.
         const uint32_t t4 = pk_subs(pk_add_nc(d, sb), bias2 - 0x00040004u);
         const uint32_t ei = s.E[M] | 0x00030003u;
-        const uint32_t h = pk_max(pk_max(t4, ei), f);
+        const uint32_t h = VGK_H_MAX3 ? pk_max3_f16(t4, ei, f) : pk_max(pk_max(t4, ei), f);
         const uint32_t hc = h & 0xfff8fff8u;
         const uint32_t gg = pk_subs(hc, go2 - 0x00010001u);
         const uint32_t e2 = pk_subs(ei, ge2 + 0x00030003u), f2 = pk_subs(f | 0x00010001u, ge2 + 0x00010001u);
@@ -337,7 +367,7 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
         // traceback code: bit0 = next-column E was opened, bits 1-2 = H source (2 diagonal, 1 E, 0 F), bit3 = next-row F was opened
         uint32_t code = bit_select<0x00010001u>(en, h) & 0x00070007u;
         code = shl_or<3>(fn & 0x00010001u, code);
-        acc[M >> 2] = (M & 3) == 0 ? code : pk_mul_add_imm<16>(acc[M >> 2], code);
+        acc[M >> 2] = (M & 3) == 0 ? code : (VGK_ACC_SHLOR ? shl_or<4>(acc[M >> 2], code) : pk_mul_add_imm<16>(acc[M >> 2], code));
         const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(hc, 0x00010001u << (KEY_SHIFT - 3));
         ck = M == 0 ? key : pk_max(ck, key);
         s.H[M] = hc; s.E[M] = en; f = fn; d = old;
@@ -412,7 +442,7 @@ VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, 
         uint32_t acc[(K + 3) / 4], colkey;
         if (nA || nB) lane_rows<K, true, S8>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
         else          lane_rows<K, false, S8>(s, P, sel, diag0, rf, false, false, acc, colkey);
-        if (tb_a) {
+        if (tb_a && !VGK_FILL_NOTB) {
             if (TB_TILE > 1) {                                                 // part A is a 16-byte slot: one store
                 VgkU4 v; v.v[0] = acc[0]; v.v[1] = acc[1]; v.v[2] = acc[2]; v.v[3] = acc[3];
                 *reinterpret_cast<VgkU4*>(tb_a) = v;

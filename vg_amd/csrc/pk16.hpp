@@ -40,6 +40,11 @@ template <uint32_t MASK> static __device__ __forceinline__ uint32_t bit_select(u
     uint32_t r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(MASK), "v"(a), "v"(b)); return r; }
 template <int N> static __device__ __forceinline__ uint32_t shl_or(uint32_t a, uint32_t c) {
     uint32_t r; asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(N), "v"(c)); return r; }
+// max of three per half in ONE instruction: gfx950's v_pk_maximum3_f16 on the bit patterns.  Non-negative f16 values order like their
+// bit patterns, so for halves below 0x7c00 (no Inf / NaN; every DP quantity stays below 0x4000) this IS the unsigned 16-bit max3 —
+// provided denormals are not flushed (tools/pkmax3_check.hip verifies that on the device).
+static __device__ __forceinline__ uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 #else
 template <uint32_t MASK> static inline uint32_t bit_select(uint32_t a, uint32_t b) { return (MASK & a) | (~MASK & b); }
 template <int N> static inline uint32_t shl_or(uint32_t a, uint32_t c) { return (a << N) | c; }
@@ -53,6 +58,7 @@ static inline uint32_t pk_subs(uint32_t a, uint32_t b) { return pk_mk(sat_sub16(
 static inline uint32_t pk_max(uint32_t a, uint32_t b) { return pk_mk(pk_lo(a) > pk_lo(b) ? pk_lo(a) : pk_lo(b), pk_hi(a) > pk_hi(b) ? pk_hi(a) : pk_hi(b)); }
 static inline uint32_t pk_min(uint32_t a, uint32_t b) { return pk_mk(pk_lo(a) < pk_lo(b) ? pk_lo(a) : pk_lo(b), pk_hi(a) < pk_hi(b) ? pk_hi(a) : pk_hi(b)); }
 static inline uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return pk_mk(pk_lo(a) * pk_lo(b) + pk_lo(c), pk_hi(a) * pk_hi(b) + pk_hi(c)); }
+static inline uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t c) { return pk_max(pk_max(a, b), c); }
 template <int M> static inline uint32_t pk_mul_add_imm(uint32_t a, uint32_t c) { return pk_mad(a, (uint32_t)M * 0x00010001u, c); }
 template <int C> static inline uint32_t pk_mad_add_imm(uint32_t a, uint32_t b) { return pk_mad(a, b, (uint32_t)C * 0x00010001u); }
 static inline uint32_t byte_perm(uint32_t a, uint32_t b, uint32_t sel) {

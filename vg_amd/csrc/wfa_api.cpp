@@ -132,7 +132,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     const int32_t match = ctx->sc.matrix[0], mism = -ctx->sc.matrix[1], go = ctx->sc.gap_open, ge = ctx->sc.gap_extend;
     if (match < 0 || mism <= 0 || go < ge || ge <= 0) return VGK_EUNSUPPORTED;                    // (:1256-1259)
     std::lock_guard<std::mutex> lock(ctx->mu);
-    ctx->wfa_last_valid = false;
+    ctx->wfa_last_valid = false; ctx->wfa_wave_last_valid = false;            // (set again only by a call that got through: vgk_wfa_rerun must never relaunch over released buffers)
     // vgk_wfa_set_cost_hints: taken by THIS call whatever becomes of it (a call that fails below must not leave them to a later one)
     std::vector<uint32_t> hint_store; hint_store.swap(ctx->wfa_cost_hints);
     Backend* be = ctx->be.get();
@@ -393,6 +393,10 @@ int vgk_wfa_set_form(vgk_ctx* ctx, int form) try {
     std::lock_guard<std::mutex> lock(ctx->mu); ctx->wfa_form = form;
     return VGK_OK;
 } catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
+int vgk_wfa_get_form(vgk_ctx* ctx) {
+    if (!ctx) return VGK_EINVAL;
+    std::lock_guard<std::mutex> lock(ctx->mu); return ctx->wfa_form;
+}
 int vgk_wfa_set_point_budget(vgk_ctx* ctx, uint32_t points) { return vgk_wfa_set_point_budgets(ctx, points, points); }
 int vgk_wfa_set_point_budgets(vgk_ctx* ctx, uint32_t connect_points, uint32_t tail_points) try {
     if (!ctx) return VGK_EINVAL;

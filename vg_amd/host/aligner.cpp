@@ -305,13 +305,14 @@ std::exception_ptr AlignmentBatch::failure_of(const Alignment& alignment) const 
     return found == job_failures.end() ? nullptr : found->second;
 }
 void AlignmentBatch::submit(std::unique_ptr<Aligner::Job> job) {
-    std::vector<std::unique_ptr<Aligner::Job>> full; size_t device = 0;
+    std::vector<std::unique_ptr<Aligner::Job>> full; std::vector<Aligner::XdropRequest> xfull; size_t device = 0;
     {
         std::lock_guard<std::mutex> lk(mu);
         jobs.push_back(std::move(job));
-        if (max_pending && jobs.size() >= max_pending) { full.swap(jobs); device = next_device++ % aligners.size(); ++in_flight; ++n_flushes; }
+        // (the deferred seeded X-drops count like every other pending call, and go with the batch they filled)
+        if (max_pending && jobs.size() + xdrop_requests.size() >= max_pending) { full.swap(jobs); xfull.swap(xdrop_requests); device = next_device++ % aligners.size(); ++in_flight; ++n_flushes; }
     }
-    if (!full.empty()) run(full, device);            // the submission that filled the batch runs it
+    if (!full.empty() || !xfull.empty()) run(full, device, &xfull);            // the submission that filled the batch runs it
 }
 void AlignmentBatch::align(Alignment& alignment, const HandleGraph& g, bool traceback_aln) { submit(aligners[0]->prepare_job(alignment, g, false, false, traceback_aln)); }
 void AlignmentBatch::align_pinned(Alignment& alignment, const HandleGraph& g, bool pin_left, bool xdrop, uint16_t xdrop_max_gap_length) {
@@ -323,8 +324,13 @@ void AlignmentBatch::align_global_banded(Alignment& alignment, const HandleGraph
 void AlignmentBatch::align_xdrop(Alignment& alignment, const HandleGraph& g, const std::vector<MaximalExactMatch>& mems, bool reverse_complemented, uint16_t max_gap_length) {
     Aligner::XdropRequest rq;
     rq.alignment = &alignment; rq.graph = &g; rq.mems = mems; rq.reverse_complemented = reverse_complemented; rq.max_gap_length = max_gap_length;
-    std::lock_guard<std::mutex> lk(mu);
-    xdrop_requests.push_back(std::move(rq));
+    std::vector<std::unique_ptr<Aligner::Job>> full; std::vector<Aligner::XdropRequest> xfull; size_t device = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        xdrop_requests.push_back(std::move(rq));
+        if (max_pending && jobs.size() + xdrop_requests.size() >= max_pending) { full.swap(jobs); xfull.swap(xdrop_requests); device = next_device++ % aligners.size(); ++in_flight; ++n_flushes; }
+    }
+    if (!full.empty() || !xfull.empty()) run(full, device, &xfull);
 }
 size_t AlignmentBatch::size() const { std::lock_guard<std::mutex> lk(mu); return jobs.size() + xdrop_requests.size(); }
 void AlignmentBatch::flush() {
@@ -346,6 +352,13 @@ void AlignmentBatch::run(std::vector<std::unique_ptr<Aligner::Job>>& run, size_t
     try {
     const Aligner& aligner = *aligners[device];
     std::lock_guard<std::mutex> on_device(*device_mu[device]);      // one flush at a time per device; other devices run beside it
+    {   // a reused batch: what an Alignment failed with in an earlier run says nothing about this one
+        std::lock_guard<std::mutex> lk(mu);
+        if (!job_failures.empty()) {
+            for (const auto& j : run) job_failures.erase(j->alignment);
+            if (xdrops) for (const Aligner::XdropRequest& rq : *xdrops) job_failures.erase(rq.alignment);
+        }
+    }
     // gssw family
     std::vector<vgk_gssw_problem> probs; std::vector<size_t> owner;
     size_t cap = 0;
@@ -392,7 +405,19 @@ void AlignmentBatch::run(std::vector<std::unique_ptr<Aligner::Job>>& run, size_t
             job_failures[j.alignment] = std::current_exception();
         }
     }
-    if (xdrops && !xdrops->empty()) aligner.align_xdrop_many(*xdrops);      // the seeded two-pass X-drops: two or three engine calls for all of them
+    if (xdrops && !xdrops->empty()) {                // the seeded two-pass X-drops: two or three engine calls for all of them
+        try { aligner.align_xdrop_many(*xdrops); }
+        catch (...) {
+            // one request's failure fails the joint call: with isolated failures every request is answered on its own and only the
+            // failing ones keep their exception (failure_of), like the other calls of the batch
+            if (!isolate_failures) throw;
+            for (Aligner::XdropRequest& rq : *xdrops) {
+                std::vector<Aligner::XdropRequest> one; one.push_back(rq);
+                try { rq.alignment->clear_path(); aligner.align_xdrop_many(one); }
+                catch (...) { std::lock_guard<std::mutex> lk(mu); job_failures[rq.alignment] = std::current_exception(); }
+            }
+        }
+    }
     } catch (...) { done.err = std::current_exception(); }
 }
 

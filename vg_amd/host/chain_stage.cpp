@@ -18,7 +18,10 @@ int run_chain_stage(const EngineApi& api, vgk_ctx* ctx, const vgk_haplo* index, 
     for (double& m : out.ms) m = 0;
     // 1. everything through WFAExtender, one engine call.  A read's links are long and a percent of them carry a long gap: the wavefront kernel
     //    throughout, so that the heavy ones start at once (include/vgk.h, vgk_wfa_set_form)
-    api.wfa_set_form(ctx, in.wfa_form);
+    //    The aligner's context is shared: the form in force comes back after the call.
+    const int form_before = api.wfa_get_form ? api.wfa_get_form(ctx) : VGK_WFA_FORM_HYBRID;
+    struct RestoreForm { const EngineApi& api; vgk_ctx* ctx; int form; ~RestoreForm() { if (api.wfa_set_form && form >= 0) api.wfa_set_form(ctx, form); } } restore_form{api, ctx, form_before};
+    if (api.wfa_set_form) api.wfa_set_form(ctx, in.wfa_form);
     std::vector<vgk_wfa_problem> problems(n);
     uint64_t bases = 0;
     for (uint32_t i = 0; i < n; ++i) {

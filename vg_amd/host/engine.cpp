@@ -59,6 +59,7 @@ std::shared_ptr<EngineApi> load_engine(const std::string& path) {
     bind(dl, "vgk_wfa_last_ms", api->wfa_last_ms);
     bind(dl, "vgk_wfa_last_wave", api->wfa_last_wave);
     bind(dl, "vgk_wfa_set_form", api->wfa_set_form);
+    bind(dl, "vgk_wfa_get_form", api->wfa_get_form);
     bind(dl, "vgk_wfa_set_cost_hints", api->wfa_set_cost_hints);
     if (api->abi_version() != VGK_ABI_VERSION) throw std::runtime_error("vgamd engine: ABI version mismatch in " + p);
     return api;

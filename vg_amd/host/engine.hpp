@@ -42,6 +42,7 @@ struct EngineApi {
     decltype(&vgk_wfa_last_ms) wfa_last_ms = nullptr;
     decltype(&vgk_wfa_last_wave) wfa_last_wave = nullptr;
     decltype(&vgk_wfa_set_form) wfa_set_form = nullptr;
+    decltype(&vgk_wfa_get_form) wfa_get_form = nullptr;
     decltype(&vgk_wfa_set_cost_hints) wfa_set_cost_hints = nullptr;
     ~EngineApi();
 };

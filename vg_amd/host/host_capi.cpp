@@ -672,7 +672,15 @@ int32_t vgh_compute_mapping_quality(vgh_aligner* a, const double* scores, int n,
 double vgh_log_base(vgh_aligner* a) { return a->a->scorer->get_log_base(); }
 // MinimizerMapper::fix_dozeu_end_deletions over an alignment given flat: positions[m] = {node id, offset, is_reverse} per mapping,
 // edits[k] = {mapping index, from_length, to_length, has sequence}; JSON out = the alignment afterwards
+static int fix_end_deletions_flat(const char* sequence, const int64_t* positions, int n_mappings, const int64_t* edits, int n_edits, bool reference_indexing, char* json_out, size_t json_cap);
 int vgh_fix_dozeu_end_deletions(const char* sequence, const int64_t* positions, int n_mappings, const int64_t* edits, int n_edits, char* json_out, size_t json_cap) {
+    return fix_end_deletions_flat(sequence, positions, n_mappings, edits, n_edits, false, json_out, json_cap);
+}
+// the same with the reference's own indexing of the mappings (rescue_fixups.hpp)
+int vgh_fix_dozeu_end_deletions_as_written(const char* sequence, const int64_t* positions, int n_mappings, const int64_t* edits, int n_edits, char* json_out, size_t json_cap) {
+    return fix_end_deletions_flat(sequence, positions, n_mappings, edits, n_edits, true, json_out, json_cap);
+}
+static int fix_end_deletions_flat(const char* sequence, const int64_t* positions, int n_mappings, const int64_t* edits, int n_edits, bool reference_indexing, char* json_out, size_t json_cap) {
     try {
         Alignment aln; aln.sequence = sequence;
         aln.path.mapping.resize((size_t)n_mappings);
@@ -684,7 +692,7 @@ int vgh_fix_dozeu_end_deletions(const char* sequence, const int64_t* positions, 
             at += (size_t)e.to_length;
             aln.path.mapping.at((size_t)edits[4 * k]).edit.push_back(e);
         }
-        fix_dozeu_end_deletions(aln);
+        fix_dozeu_end_deletions(aln, reference_indexing);
         return emit(aln, json_out, json_cap);
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }

@@ -11,7 +11,7 @@ void fix_dozeu_score(Alignment& rescued_alignment, const Aligner& aligner, const
     else aligner.align(rescued_alignment, rescue_graph, topological_order);
 }
 
-void fix_dozeu_end_deletions(Alignment& alignment) {
+void fix_dozeu_end_deletions(Alignment& alignment, bool reference_indexing) {
     std::vector<Mapping>& mappings = alignment.path.mapping;
     // the first edit that consumes read bases: mapping i, edit j (:3521-3533)
     size_t i = 0, j = 0;
@@ -23,9 +23,11 @@ void fix_dozeu_end_deletions(Alignment& alignment) {
     if (i == mappings.size()) { alignment.clear_path(); return; }        // nothing but deletions (:3534-3537; the right-hand loop below finds nothing to do then)
     if (i != 0 || j != 0) {
         // The reference takes the edits to drop from `(*mappings)[j]` — the EDIT index used as a mapping index (:3541) — where mapping i is
-        // evidently meant; the two agree in its unit test (i = j = 1).  Kept as written wherever that element exists, so that the same
-        // input gives the same output; where it does not (the reference would read past the end), mapping i.
-        Mapping& from = j < mappings.size() ? mappings[j] : mappings[i];
+        // evidently meant; the two agree in its unit test (i = j = 1).  With i != j the reference erases from the wrong mapping and the
+        // result no longer consumes the read: the default here is the evident intent, mapping i (a valid alignment);
+        // reference_indexing = true keeps the line as written wherever that element exists (where it does not the reference reads past
+        // the end: mapping i then too).  [PARITY-UNPINNED for i != j: the reference holds no test there.]
+        Mapping& from = (reference_indexing && j < mappings.size()) ? mappings[j] : mappings[i];
         size_t removed = 0;
         const size_t drop = j < from.edit.size() ? j : from.edit.size();
         for (size_t k = 0; k < drop; ++k) removed += (size_t)from.edit[k].from_length;

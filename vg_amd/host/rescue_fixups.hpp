@@ -10,6 +10,8 @@ namespace vgamd {
 // MinimizerMapper::fix_dozeu_score (src/minimizer_mapper.cpp:3502-3517)
 void fix_dozeu_score(Alignment& rescued_alignment, const Aligner& aligner, const HandleGraph& rescue_graph, const std::vector<handle_t>& topological_order);
 // MinimizerMapper::fix_dozeu_end_deletions (src/minimizer_mapper.cpp:3519-3565)
-void fix_dozeu_end_deletions(Alignment& alignment);
+// (reference_indexing: the reference indexes the mappings with the EDIT index when it drops the leading deletion, :3541 — right only when
+//  the two agree; the default takes the mapping that holds the first read-consuming edit, which is what the code around it means)
+void fix_dozeu_end_deletions(Alignment& alignment, bool reference_indexing = false);
 
 }  // namespace vgamd
