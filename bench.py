@@ -385,39 +385,85 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
         torch.cuda.synchronize()
 
     kernel_ms = {"minimizer": 0.0, "gapless": 0.0, "tails derived": 0.0, "tail forest": 0.0, "windows packed": 0.0, "x-drop fill + traceback + totals": 0.0}
+    import threading
+    acc_lock = threading.Lock()
+
+    def run_batches(lane, which, tot, timing=None, keep=None):
+        """the batches `which` of a step on one engine context (lane = (engine, haplotype index, minimizer index))"""
+        e, hidx, midx = lane
+        for b in which:
+            reads, off = wl.batches[b]
+            t1 = time.perf_counter()
+            seed_off, _, mins = e.minimizer_seeds(midx, hidx, reads, off, keep_on_device=True)
+            t2 = time.perf_counter()
+            tm = {} if timing is not None else None
+            out = pipeline.align_stage_device(e, hidx, Batch(len(off) - 1), seeded=int(seed_off[-1]), aligned=True, timing=tm)
+            st = out["stats"]
+            with acc_lock:
+                if timing is not None:
+                    timing["minimizer_seeds"] = timing.get("minimizer_seeds", 0.0) + t2 - t1
+                    for k, v in tm.items():
+                        timing[k] = timing.get(k, 0.0) + v
+                    kernel_ms["minimizer"] += e.minimizer_last_ms(); kernel_ms["gapless"] += e.gapless_last_ms()
+                    for k, v in zip(("tails derived", "tail forest", "windows packed", "x-drop fill + traceback + totals"), e.tail_stage_last_ms()):
+                        kernel_ms[k] += v
+                tot["seeds"] += int(seed_off[-1]); tot["ext"] += len(out["ext"]); tot["tails"] += int(st[0]); tot["trees"] += int(st[1]); tot["tree_nodes"] += int(st[2]); tot["failed"] += int(st[3])
+                tot["full_length"] += int((out["res"]["full_length"] != 0).sum()); tot["truncated"] += int(e.minimizers_truncated.sum())
+                if keep is not None and b == 0:
+                    keep.update(read_score=out["read_score"].copy(), res=out["res"].copy(), ext=out["ext"].copy(), nodes=out["nodes"].copy(), seed_off=seed_off.copy())
+
+    def new_tot():
+        return {"seeds": 0, "ext": 0, "tails": 0, "trees": 0, "tree_nodes": 0, "failed": 0, "full_length": 0, "truncated": 0}
+
+    lanes = [(eng, index, mindex)]
 
     def one_step(timing=None, keep=None):
-        tot = {"seeds": 0, "ext": 0, "tails": 0, "trees": 0, "tree_nodes": 0, "failed": 0, "full_length": 0, "truncated": 0}
-        for b, (reads, off) in enumerate(wl.batches):
-            t1 = time.perf_counter()
-            seed_off, _, mins = eng.minimizer_seeds(mindex, index, reads, off, keep_on_device=True)
-            t2 = time.perf_counter()
-            out = pipeline.align_stage_device(eng, index, Batch(len(off) - 1), seeded=int(seed_off[-1]), aligned=True, timing=timing)
-            if timing is not None:
-                timing["minimizer_seeds"] = timing.get("minimizer_seeds", 0.0) + t2 - t1
-                kernel_ms["minimizer"] += eng.minimizer_last_ms(); kernel_ms["gapless"] += eng.gapless_last_ms()
-                for k, v in zip(("tails derived", "tail forest", "windows packed", "x-drop fill + traceback + totals"), eng.tail_stage_last_ms()):
-                    kernel_ms[k] += v
-            st = out["stats"]
-            tot["seeds"] += int(seed_off[-1]); tot["ext"] += len(out["ext"]); tot["tails"] += int(st[0]); tot["trees"] += int(st[1]); tot["tree_nodes"] += int(st[2]); tot["failed"] += int(st[3])
-            tot["full_length"] += int((out["res"]["full_length"] != 0).sum()); tot["truncated"] += int(eng.minimizers_truncated.sum())
-            if keep is not None and b == 0:
-                keep.update(read_score=out["read_score"].copy(), res=out["res"].copy(), ext=out["ext"].copy(), nodes=out["nodes"].copy(), seed_off=seed_off.copy())
+        """one context, one batch after the other"""
+        tot = new_tot()
+        run_batches(lanes[0], range(len(wl.batches)), tot, timing, keep)
         return tot
 
+    # Two batches in flight, the way vg itself calls an aligner (many threads, one process): a second engine context with its own copy of
+    # the two indexes, one host thread per context, alternate batches.  One context's seeding and copies run under the other's extension
+    # and tail kernels; every batch's results are what the one-context form gives (checked below).  This is the timed form when a step
+    # has two batches or more; `config.one_context` keeps the serial rate beside it.
+    pipelined = len(wl.batches) >= 2 and not os.environ.get("VGAMD_CONFIG2_ONE_CONTEXT")
+    if pipelined:
+        eng_b = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), device=eng.device, lib=eng.lib)          # (the same library, the same device)
+        eng_b.reuse_outputs = True
+        lanes.append((eng_b, eng_b.haplo_index(graph, wl.threads), eng_b.minimizer_index(graph, wl.threads)))
+
+    def one_step_pipelined(timing=None, keep=None):
+        tot = new_tot()
+        th = [threading.Thread(target=run_batches, args=(lanes[k], range(k, len(wl.batches), 2), tot, timing, keep)) for k in range(2)]
+        for t in th: t.start()
+        for t in th: t.join()
+        return tot
+
+    step_fn = one_step_pipelined if pipelined else one_step
     for _ in range(max(1, args.warmup)):
-        one_step()
+        step_fn()
     barrier()
     timing = {}; first = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tot = one_step(timing, first)
+        tot = step_fn(timing, first)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    one_context = None
+    if pipelined:
+        serial_first = {}
+        one_step()
+        barrier(); t1 = time.perf_counter()
+        for _ in range(max(1, args.steps // 2)):
+            one_step(None, serial_first)
+        barrier(); t_one = (time.perf_counter() - t1) / max(1, args.steps // 2)
+        one_context = {"ms_per_batch": 1e3 * t_one / len(wl.batches), "reads_per_s": n / t_one,
+                       "read_scores_equal_to_the_two_context_run": bool((serial_first["read_score"] == first["read_score"]).all())}
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu:
         ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
@@ -451,7 +497,9 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
                                    "variant with p = 0.5; %d reads of 150 bp per GPU from the haplotypes on either strand, 1 %% substitutions, 10 %% of them with one inserted base; "
                                    "k = 29, w = 11 minimizers, hit cap 500; max_mismatches 4; tails left-pinned X-drop against their haplotype trees, scores 1/4/6/1/5" % (len(wl.node_len), n),
                        "timed_region": "per step, %d batches of %d reads from host buffers: vgk_minimizer_seeds (clusters stay in HBM) -> vgk_gapless_extend_seeded (sets come down under the "
-                                       "tail stage) -> vgk_tail_stage_aligned" % (len(wl.batches), batch),
+                                       "tail stage) -> vgk_tail_stage_aligned%s" % (len(wl.batches), batch, "; two batches in flight: two engine contexts, one host thread each, alternate batches" if pipelined else ""),
+                       "one_context": one_context,
+                       "policies": "every minimizer of a read looked up, hit cap 500 (hard cap), no downsampling / score-based selection (find_seeds' policies: not built); clusters = all seeds of a read",
                        "per_step": {k: v / steps for k, v in tot.items()} if steps == 1 else tot,
                        "ms_per_batch": 1e3 * elapsed / steps / len(wl.batches),
                        "stage_ms_per_batch": {k: 1e3 * v / steps / len(wl.batches) for k, v in timing.items()},
@@ -1249,7 +1297,7 @@ def main():
 # at a size that keeps the whole default run within a few minutes; a record keeps the line's metric, value, roofline, cpu_baseline and
 # parity.  A leg that fails or overruns its time limit leaves {"workload", "error"} — never a missing headline.
 SECONDARY = [
-    ("config2", ["--reads", "1000000", "--steps", "3", "--warmup", "1", "--cpu-sample", "50000"], 170),
+    ("config2", ["--reads", "2000000", "--steps", "4", "--warmup", "2", "--cpu-sample", "50000"], 200),
     ("gapless", ["--steps", "5", "--warmup", "2"], 90),
     ("xband", ["--steps", "3", "--warmup", "1"], 90),
     ("banded", ["--reads", "100000", "--steps", "5", "--warmup", "2"], 90),

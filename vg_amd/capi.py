@@ -264,6 +264,7 @@ class Engine:
         """qual_adj = (matrix int8[256*25], bonuses int8[256]) makes a quality-adjusted context (QualAdjAligner)."""
         self.lib = load_library(lib) if (lib is None or isinstance(lib, str)) else lib
         self.scoring = scoring or Scoring.simple()
+        self.device = device
         h = ctypes.c_void_p()
         if qual_adj is not None:
             self._qm = np.ascontiguousarray(qual_adj[0], dtype=np.int8); self._qb = np.ascontiguousarray(qual_adj[1], dtype=np.int8)

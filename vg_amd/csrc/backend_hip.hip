@@ -399,10 +399,12 @@ struct MzMin { uint64_t key; uint32_t hash_lo; uint32_t pos_rev; };        // po
 __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P, vgk_seed* slots) {
     __shared__ MzMin mins_all[4][64];
     __shared__ unsigned long long seen_all[4][MZ_MAX_SEEDS];
+    __shared__ unsigned long long cand_all[4][64];                           // a round's candidate seeds, in hit order
+    __shared__ uint8_t own_all[4][64];                                       // the minimizer (lane) each of them belongs to
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t i = P.lo + blockIdx.x * 4u + wv;
     if (i >= P.hi) return;
-    MzMin* mins = mins_all[wv]; unsigned long long* seen = seen_all[wv];
+    MzMin* mins = mins_all[wv]; unsigned long long* seen = seen_all[wv]; unsigned long long* cand = cand_all[wv]; uint8_t* own = own_all[wv];
     const uint64_t a = P.read_off[i]; const uint32_t L = (uint32_t)(P.read_off[i + 1] - a);
     const uint32_t k = P.index.k, w = P.index.w;
     const char* rd = P.reads + a;
@@ -471,26 +473,57 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
             if (round_max > last_plus1) last_plus1 = round_max;
             n_min += n_round;
             MZ_WAVE_SYNC();
-            // this round's minimizers: one lane each probes the table; then their hits in order
-            uint32_t first = 0, count = 0, p = 0, rv = 0;
+            // this round's minimizers: one lane each probes the table (a key's single position comes with its slot); then ALL their hits at
+            // once — hit c of the round in lane c: an exclusive prefix sum of the counts, the owners spread through LDS, one load for the
+            // positions that are not in their slots, every candidate held against the seeds kept so far and the candidates before it
+            // (uniform LDS reads), the survivors ranked by ballot.  The result is the serial order's (minimizer_one): a candidate is looked
+            // at iff the read is not full when its turn comes, the first of equal (node, diagonal) pairs is kept.  A round with more than
+            // 64 hits takes the serial form below.
+            uint32_t first = 0, count = 0, p = 0, rv = 0; MzPos one{0u, 0u};
             if (lane < n_round) {                                            // (also for a read that is full already: whether hits are left decides its truncated flag)
                 const MzMin mm = mins[lane];
                 MzKmer km; km.key = mm.key; km.hash = mm.hash_lo; km.reverse = (mm.pos_rev & 1u) != 0;
                 p = mm.pos_rev >> 1; rv = mm.pos_rev & 1u;
-                if (!mz_find(P.index, km, first, count) || count > P.hit_cap) count = 0;
+                if (!mz_find(P.index, km, first, count, one) || count > P.hit_cap) count = 0;
             }
             const unsigned long long hb = __ballot(count != 0);
+            const uint32_t cc = count > 65u ? 65u : count;                   // (clamped: the sum must not wrap; a round within 64 hits has no clamped count)
+            uint32_t incl = cc;
+            for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+            const uint32_t total = __shfl(incl, 63, 64), excl = incl - cc;
+            if (hb && total <= 64u) {
+                for (uint32_t h0 = 0; h0 < count; ++h0) own[excl + h0] = (uint8_t)lane;
+                MZ_WAVE_SYNC();
+                const uint32_t j = lane < total ? own[lane] : 0u;
+                const uint32_t fj = __shfl(first, j, 64), ej = __shfl(excl, j, 64), pj = __shfl(p, j, 64), rj = __shfl(rv, j, 64);
+                MzPos qp; qp.node = __shfl(one.node, j, 64); qp.offset = __shfl(one.offset, j, 64);
+                if (lane < total && fj != MZ_ONE) qp = P.index.pos[fj + (lane - ej)];
+                const vgk_seed sd = mz_seed(qp, pj, rj != 0u, k);
+                const unsigned long long key = ((unsigned long long)sd.node << 32) | (uint32_t)sd.diff;
+                cand[lane] = key;
+                MZ_WAVE_SYNC();
+                bool dup = false;
+                for (uint32_t x = 0; x < n_seeds; ++x) dup |= seen[x] == key;
+                for (uint32_t x = 0; x + 1u < total; ++x) dup |= x < lane && cand[x] == key;
+                const bool keep = lane < total && !dup;
+                const unsigned long long kb = __ballot(keep);
+                const uint32_t rank = n_seeds + (uint32_t)__popcll(kb & below);      // seeds kept when this candidate's turn comes
+                if (keep && rank < MZ_MAX_SEEDS) { seen[rank] = key; dst[rank] = sd; }
+                if (__ballot(lane < total && rank >= MZ_MAX_SEEDS) != 0ull) truncated = true;      // the cap: that hit and the rest are never looked at
+                n_seeds += (uint32_t)__popcll(kb); if (n_seeds > MZ_MAX_SEEDS) n_seeds = MZ_MAX_SEEDS;
+            } else
             for (unsigned long long todo = hb; todo; todo &= todo - 1) {
                 if (n_seeds >= MZ_MAX_SEEDS) { truncated = true; break; }    // the cap: these hits are never looked at
                 const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
                 const uint32_t cj = __shfl(count, j, 64), fj = __shfl(first, j, 64), pj = __shfl(p, j, 64), rj = __shfl(rv, j, 64);
+                const uint32_t onode = __shfl(one.node, j, 64), ooff = __shfl(one.offset, j, 64);
                 for (uint32_t h0 = 0; h0 < cj; h0 += 64) {
                     if (n_seeds >= MZ_MAX_SEEDS) { truncated = true; break; }
                     unsigned long long key = 0; vgk_seed sd; sd.node = 0; sd.diff = 0;
                     if (h0 + lane < cj) {
-                        const MzPos qp = P.index.pos[fj + h0 + lane];
-                        if (!rj) { sd.node = qp.node; sd.diff = (int32_t)pj - (int32_t)qp.offset; }
-                        else { sd.node = qp.node ^ 1u; sd.diff = (int32_t)(pj + k - 1) - (int32_t)(g_len(P.graph, (int32_t)qp.node) - 1 - qp.offset); }
+                        MzPos qp; qp.node = onode; qp.offset = ooff;
+                        if (fj != MZ_ONE) qp = P.index.pos[fj + h0 + lane];
+                        sd = mz_seed(qp, pj, rj != 0u, k);
                         key = ((unsigned long long)sd.node << 32) | (uint32_t)sd.diff;
                     }
                     const uint32_t in_group = cj - h0 < 64 ? cj - h0 : 64;
@@ -691,6 +724,8 @@ __global__ void __launch_bounds__(256) gssw_wide_kernel(const WideParams P) {
         const uint32_t rows_left = d.L - strip * WIDE_LANES * (uint32_t)K;
         const uint32_t lanes_used = rows_left >= WIDE_LANES * (uint32_t)K ? WIDE_LANES : (rows_left + (uint32_t)K - 1u) / (uint32_t)K;
         const uint32_t n_steps = d.R + lanes_used - 1u;
+        if (wl == 63u) { xh[0][wv] = xh[1][wv] = s.out_h; xf[0][wv] = xf[1][wv] = s.out_f; xi[0][wv] = xi[1][wv] = s.info; }      // "no column yet" for the wavefront after this one
+        __syncthreads();
         for (uint32_t t = 0; t < n_steps; ++t) {
             int32_t rh = (int32_t)from_lane_above((uint32_t)s.out_h);
             int32_t rf = (int32_t)from_lane_above((uint32_t)s.out_f);

@@ -305,16 +305,19 @@ VGK_HD uint64_t tb_dword(uint64_t tb_off, uint32_t t, uint32_t lane, uint32_t re
 }
 
 // Build switches of the fill's hot row (kernel experiments: tools/build_variant.sh NAME -DVGK_...=1):
-//   VGK_ACC_SHLOR  the 4-bit codes of four rows are merged by the full-rate v_lshl_or_b32 instead of v_pk_mad_u16 (exact: a half holds at
-//                  most 16 bits of codes, nothing crosses into the other read's half)
-//   VGK_H_MAX3     H = max(diagonal, E, F) as one v_pk_maximum3_f16 on the bit patterns (pk16.hpp) instead of two v_pk_max_u16
+//   VGK_ACC_SHLOR  the 4-bit codes of four rows are merged by v_lshl_or_b32 instead of v_pk_mad_u16 (exact: a half holds at most 16 bits of
+//                  codes, nothing crosses into the other read's half): off — measured no gain (20.00 vs 20.01 ms; with a constant shift
+//                  v_lshl_or_b32 issues at the packed ops' rate, tools/pkmax3_check.hip)
+//   VGK_H_MAX3     H = max(diagonal, E, F) as one v_pk_maximum3_f16 on the bit patterns (pk16.hpp) instead of two v_pk_max_u16: ON — exact on
+//                  the device for every triple of halves below 0x7c00 (tools/pkmax3_check.hip: 0 of 1.2e10, denormals included), fill
+//                  20.0 -> 19.15 ms per million reads (profiles/r04)
 //   VGK_FILL_NOTB  timing experiment only (results are wrong): no traceback codes are built or stored — the bound on what a
 //                  traceback that does not tax the fill could gain
 #ifndef VGK_ACC_SHLOR
 #define VGK_ACC_SHLOR 0
 #endif
 #ifndef VGK_H_MAX3
-#define VGK_H_MAX3 0
+#define VGK_H_MAX3 1
 #endif
 #ifndef VGK_FILL_NOTB
 #define VGK_FILL_NOTB 0

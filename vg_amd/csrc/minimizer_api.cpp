@@ -37,6 +37,7 @@ int vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* d, uint32_t k
     std::vector<uint64_t> node_at((size_t)N + 1, 0);
     for (uint32_t i = 0; i < N; ++i) node_at[i + 1] = node_at[i] + d->node_len[i];
     for (uint32_t t = 0; t < d->n_threads; ++t) for (uint32_t x = d->thread_off[t]; x < d->thread_off[t + 1]; ++x) if (d->thread_nodes[x] >= 2 * N) return VGK_EINVAL;
+    for (uint32_t i = 0; i < N; ++i) if (d->node_len[i] > 65535u) return VGK_ETOOBIG;      // (a position's offset word holds the offset from either end in 16 bits each)
     // the minimizers of every thread, read along the thread; a reverse-canonical one is filed under the position its
     // reverse complement starts at: the k-mer's last base, seen from the other strand
     std::vector<std::vector<Entry>> per_thread(d->n_threads);
@@ -72,10 +73,12 @@ int vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* d, uint32_t k
     std::vector<MzSlot> slots(cap, MzSlot{0, 0, 0});
     std::vector<MzPos> pos(all.size() + 1);
     for (size_t i = 0; i < all.size();) {
-        size_t j = i; while (j < all.size() && all[j].key == all[i].key) { pos[j] = MzPos{all[j].node, all[j].offset}; ++j; }
+        size_t j = i; while (j < all.size() && all[j].key == all[i].key) { pos[j] = MzPos{all[j].node, mz_pack_offset(all[j].offset, d->node_len[all[j].node >> 1])}; ++j; }
         uint32_t s = (uint32_t)all[i].hash & (uint32_t)(cap - 1);
         while (slots[s].count) s = (s + 1) & (uint32_t)(cap - 1);
-        slots[s] = MzSlot{all[i].key, (uint32_t)i, (uint32_t)(j - i)};
+        // a key with one position keeps it in its slot (one request per lookup); its offset word must leave the flag bit free
+        if (j - i == 1 && !(pos[i].offset & MZ_INLINE)) slots[s] = MzSlot{all[i].key, pos[i].node, pos[i].offset | MZ_INLINE};
+        else slots[s] = MzSlot{all[i].key, (uint32_t)i, (uint32_t)(j - i)};
         i = j;
     }
     std::unique_ptr<vgk_minimizer_index> ix(new (std::nothrow) vgk_minimizer_index());

@@ -84,14 +84,33 @@ VGK_HD void mz_minimizers(const char* seq, uint32_t L, uint32_t k, uint32_t w, O
 }
 
 // ---- the index on the device: open addressing, linear probing --------------------------------------------------------------------
+// A key with ONE position — nearly every key of a genome-scale index — holds it in its slot (count = MZ_INLINE | offset word, first =
+// node): a lookup is then one 16-byte request instead of two dependent ones.  A position's offset word carries the offset in its low
+// 16 bits and the offset seen from the node's other end (length - 1 - offset) above them, so that a reverse-canonical hit is flipped
+// without a look at the node's length (nodes are at most 65535 bases long, as everywhere in the engine).
 struct MzSlot { uint64_t key; uint32_t first, count; };                  // count == 0: free
-struct MzPos { uint32_t node, offset; };
+struct MzPos { uint32_t node, offset; };                                 // offset: offset | flipped offset << 16
+constexpr uint32_t MZ_INLINE = 0x80000000u;                              // in a slot's count: the slot holds the key's one position (only for offset words below 2^31: nodes of less than 32768 bases)
+constexpr uint32_t MZ_ONE = 0xffffffffu;                                 // mz_find's `first` for such a key: the position is in `one`
 struct MzIndex { const MzSlot* slots; uint32_t mask; const MzPos* pos; uint32_t k, w; };
-VGK_HD bool mz_find(const MzIndex& x, const MzKmer& m, uint32_t& first, uint32_t& count) {
+VGK_HD uint32_t mz_pack_offset(uint32_t offset, uint32_t node_len) { return offset | ((node_len - 1u - offset) << 16); }
+// the seed a hit gives for a minimizer at read offset p (minimizer_device.hpp header: the hit itself, or flipped for a reverse-canonical one)
+VGK_HD vgk_seed mz_seed(const MzPos q, uint32_t p, bool reverse, uint32_t k) {
+    vgk_seed s;
+    if (!reverse) { s.node = q.node; s.diff = (int32_t)p - (int32_t)(q.offset & 0xffffu); }
+    else { s.node = q.node ^ 1u; s.diff = (int32_t)(p + k - 1) - (int32_t)(q.offset >> 16); }
+    return s;
+}
+// -> count hits at pos[first ..), or (first == MZ_ONE) the key's one position in `one`
+VGK_HD bool mz_find(const MzIndex& x, const MzKmer& m, uint32_t& first, uint32_t& count, MzPos& one) {
     for (uint32_t s = (uint32_t)m.hash & x.mask;; s = (s + 1) & x.mask) {
         const MzSlot e = x.slots[s];
         if (!e.count) return false;
-        if (e.key == m.key) { first = e.first; count = e.count; return true; }
+        if (e.key == m.key) {
+            if (e.count & MZ_INLINE) { first = MZ_ONE; count = 1; one.node = e.first; one.offset = e.count & ~MZ_INLINE; }
+            else { first = e.first; count = e.count; }
+            return true;
+        }
     }
 }
 
@@ -117,14 +136,12 @@ VGK_HD void minimizer_one(const MinimizerParams& P, uint32_t i) {
     uint64_t seen[MZ_MAX_SEEDS];
     mz_minimizers(P.reads + a, L, k, P.index.w, [&](uint32_t p, const MzKmer& m) {
         ++n_min;
-        uint32_t first = 0, count = 0;
-        if (!mz_find(P.index, m, first, count) || count > P.hit_cap) return;
+        uint32_t first = 0, count = 0; MzPos one{0, 0};
+        if (!mz_find(P.index, m, first, count, one) || count > P.hit_cap) return;
         for (uint32_t h = 0; h < count; ++h) {
             if (n_seeds >= MZ_MAX_SEEDS) { truncated = true; break; }      // the cap: this hit and the rest are never looked at (reported in mins[])
-            const MzPos q = P.index.pos[first + h];
-            vgk_seed s;
-            if (!m.reverse) { s.node = q.node; s.diff = (int32_t)p - (int32_t)q.offset; }
-            else { s.node = q.node ^ 1u; s.diff = (int32_t)(p + k - 1) - (int32_t)(g_len(P.graph, (int32_t)q.node) - 1 - q.offset); }
+            const MzPos q = first == MZ_ONE ? one : P.index.pos[first + h];
+            const vgk_seed s = mz_seed(q, p, m.reverse, k);
             const uint64_t key = ((uint64_t)s.node << 32) | (uint32_t)s.diff;
             bool dup = false;
             for (uint32_t j = 0; j < n_seeds && !dup; ++j) dup = seen[j] == key;
