@@ -660,16 +660,10 @@ struct GProf { unsigned long long t0, acc[12]; __device__ void start() { t0 = __
 struct GProf {};
 #define G_TICK(prof, s) do { } while (0)
 #endif
-#if defined(__HIP_DEVICE_COMPILE__)
-#define G_KEEP(X) asm volatile("" :: "v"(X))
-#else
-#define G_KEEP(X) ((void)(X))
-#endif
 struct GSearch {
     GProf* prof;
     uint32_t np, hn, number; bool have_cand; GLean cand; uint32_t cand_idx; int32_t best; GBest best_e;
     uint32_t L, max_mm;
-    uint32_t touched;                   // see g_search_step: the records of the successors just created, asked for ahead of their expansion
 };
 constexpr int32_t G_BADNODE = 2, G_BADOFF = 3;          // winner statuses (beside VGK_OK, VGK_ETOOBIG, G_RETRY): a seed node out of range (checked
                                                         // before the skip rule), a seed offset out of range (checked after it)
@@ -686,7 +680,7 @@ VGK_HD int g_search_begin(const GaplessParams& P, const GCtx& c, const GProb& pb
     const GQuad hf = g_quad(h.rec + ro_f), hb = g_quad(h.rec + ro_b);           // {visits, edges, length, bases} of the seed node on either strand
     const uint32_t slen = hf.z;
     if (read_offset > L || node_offset > slen) return G_BADOFF;
-    s.np = 0; s.hn = 0; s.number = 0; s.have_cand = false; s.cand_idx = 0; s.best = -1; s.L = L; s.max_mm = pb.max_mm; s.touched = 0;
+    s.np = 0; s.hn = 0; s.number = 0; s.have_cand = false; s.cand_idx = 0; s.best = -1; s.L = L; s.max_mm = pb.max_mm;
     s.best_e.score = 0; s.best_e.rr = 0;
     Q.begin_seed();
     // the seed node itself: any number of mismatches (:213-237)
@@ -747,11 +741,6 @@ VGK_HD int g_search_step(const GaplessParams& P, const GCtx& c, ST& Q, GSearch& 
             if (gs_empty(ns)) continue;
             if (s.np >= ST::ENTRIES) return ST::FULL;
             const uint32_t wl = ed.y >> 16;
-            // The successor's own record is what ITS expansion reads first — on a non-branching stretch that is the very next step, and
-            // the step would start with a round trip to memory that nothing overlaps.  Its first line is asked for here, ahead of the
-            // bases: loads return in order, so by the time the bases have been compared it has arrived (no extra wait), and the next
-            // step finds the record in the cache.  The value only keeps the load alive.
-            s.touched ^= h.rec[ed.w + 1];
             // match_forward (:239-266) over the successor's bases from their start / match_backward (:268-296) over the bases of the other
             // strand of x (same length, one strand_shift away) from their end
             const char* t = right ? h.seq + ed.z : h.seq + ((x & 1) ? ed.z - h.strand_shift : ed.z + h.strand_shift) + wl;
@@ -759,7 +748,6 @@ VGK_HD int g_search_step(const GaplessParams& P, const GCtx& c, ST& Q, GSearch& 
             if (right) nx.frec = ed.w; else { nx.brec = ed.w; nx.offset = wl; }
             const uint32_t room = right ? (L - nx.r1 < wl ? L - nx.r1 : wl) : (nx.r0 < wl ? nx.r0 : wl);
             const uint32_t no = g_match_dir(c.seq + (right ? nx.r1 : nx.r0), t, room, nx.internal, limit, !right);
-            G_KEEP(s.touched);
             G_TICK(s.prof, 8);
             if (right) {
                 nx.r1 += no;
