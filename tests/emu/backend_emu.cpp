@@ -7,6 +7,7 @@
 #include <pthread.h>
 #include <ucontext.h>
 #include <memory>
+#include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
@@ -338,6 +339,11 @@ public:
                 for (uint32_t l = 0; l < 64; ++l) {
                     if ((t & 3u) == 0) lane_prefetch(lanes[l], P, t);
                     const uint32_t rh = l ? oh[l - 1] : 0, rf = l ? of[l - 1] : 0, ri = l ? oi[l - 1] : 0;
+                    if (P.tb_mode == TB_REWALK) {
+                        lane_step<K, S8, false>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr);
+                        if (P.want_tb) lane_store_boundary<K>(lanes[l], P, wd, t, l);
+                        continue;
+                    }
                     uint32_t* tb_a = P.want_tb ? P.tb + tb_dword(wd.tb_off, t, l, REC, 0) : nullptr;
                     uint32_t* tb_b = P.want_tb && REC > 4 ? P.tb + tb_dword(wd.tb_off, t, l, REC, 4) : nullptr;
                     lane_step<K, S8>(lanes[l], P, t, rh, rf, ri, tb_a, tb_b);
@@ -362,10 +368,42 @@ public:
                 default: return VGK_EINVAL;
             }
         }
-        if (walk) for (uint32_t i = 0; i < P.n_problems; ++i) walk_one(P, i, P.best[i]);
+        if (walk && P.tb_mode == TB_REWALK) {
+            // the band: every lane of every wavefront again over its band columns; the walks over the band records; then, for the reads
+            // whose walk left its band, the on-demand form
+            for (uint32_t li = 0; li < n; ++li) {
+                const FillLaunch& L = launches[li];
+                for (uint32_t w = L.wave_begin; w < L.wave_begin + L.wave_count; ++w) for (uint32_t l = 0; l < 64; ++l) {
+                    const WaveDesc wd = P.waves[w]; const bool s8 = P.scale == 8;
+                    switch (L.K) {
+                        case 16: if (s8) band_fill_lane<16, true>(P, wd, l); else band_fill_lane<16, false>(P, wd, l); break;
+                        case 19: if (s8) band_fill_lane<19, true>(P, wd, l); else band_fill_lane<19, false>(P, wd, l); break;
+                        case 20: if (s8) band_fill_lane<20, true>(P, wd, l); else band_fill_lane<20, false>(P, wd, l); break;
+                        case 24: if (s8) band_fill_lane<24, true>(P, wd, l); else band_fill_lane<24, false>(P, wd, l); break;
+                        default: return VGK_EINVAL;
+                    }
+                }
+            }
+            for (uint32_t i = 0; i < P.n_problems; ++i) bandwalk_one(P, i, P.best[i]);
+            std::vector<uint32_t> win((TB_CKPT / 2) * 6);          // one lane's window (stride 1)
+            for (uint32_t i = 0; i < P.n_problems; ++i) {
+                if (P.results[i].status == W_MISSED) ++band_misses;
+                const uint32_t K = P.probs[i].geom & 0xffu; const bool s8 = P.scale == 8;
+                switch (K) {
+                    case 16: if (s8) rewalk_one<16, true>(P, i, P.best[i], win.data(), 1); else rewalk_one<16, false>(P, i, P.best[i], win.data(), 1); break;
+                    case 19: if (s8) rewalk_one<19, true>(P, i, P.best[i], win.data(), 1); else rewalk_one<19, false>(P, i, P.best[i], win.data(), 1); break;
+                    case 20: if (s8) rewalk_one<20, true>(P, i, P.best[i], win.data(), 1); else rewalk_one<20, false>(P, i, P.best[i], win.data(), 1); break;
+                    case 24: if (s8) rewalk_one<24, true>(P, i, P.best[i], win.data(), 1); else rewalk_one<24, false>(P, i, P.best[i], win.data(), 1); break;
+                    default: return VGK_EINVAL;
+                }
+            }
+            band_walks += P.n_problems;
+        } else if (walk) for (uint32_t i = 0; i < P.n_problems; ++i) walk_one(P, i, P.best[i]);
         return VGK_OK;
     }
-    double last_ms(int which) const override { return which == 2 ? 1.0 : 0.0; }
+    unsigned long long band_misses = 0, band_walks = 0;
+    ~EmuBackend() override { if (std::getenv("VGAMD_EMU_STATS") && band_walks) std::fprintf(stderr, "[emu] band walks %llu, left their band %llu\n", band_walks, band_misses); }
+    double last_ms(int which) const override { return which == 2 ? 1.0 : which == 8 ? (double)band_misses : which == 9 ? (double)band_walks : 0.0; }
 };
 
 Backend* make_backend(int, std::string&) { return new EmuBackend(); }

@@ -58,7 +58,7 @@ struct TbStage {
     }
 };
 
-template <int K, bool S8>
+template <int K, bool S8, bool REWALK>
 __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const GsswParams P) {
     constexpr uint32_t REC = (K + 3) / 4;   // dwords per (step, lane) traceback record
     __shared__ __attribute__((aligned(16))) uint32_t stage_lds[4][TB_TILE > 1 ? TbStage<K>::DWORDS : 256u];      // (also the fused walk's best keys, below)
@@ -76,13 +76,17 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
         const uint32_t rh = from_lane_above(s.out_h);
         const uint32_t rf = from_lane_above(s.out_f);
         const uint32_t ri = from_lane_above(s.info);
-        if constexpr (TB_TILE > 1) {
+        if constexpr (REWALK) {
+            // the recurrence alone; what the traceback needs to run a window of it again (gssw_device.hpp, TB_REWALK)
+            lane_step<K, S8, false>(s, P, t, rh, rf, ri, nullptr, nullptr);
+            if (tb) lane_store_boundary<K>(s, P, wd, t, lane);
+        } else if constexpr (TB_TILE > 1) {
             lane_step<K, S8>(s, P, t, rh, rf, ri, tb ? stage.slot_a(t, lane) : nullptr, stage.slot_b(t, lane));
             if (tb && ((t % TB_TILE) == TB_TILE - 1u || t + 1u == wd.n_steps)) stage.flush(tb + tb_tile_base(wd.tb_off, t, REC), lane);
         } else
             lane_step<K, S8>(s, P, t, rh, rf, ri, tb ? tb + tb_dword(wd.tb_off, t, lane, REC, 0) : nullptr, tb ? tb + tb_dword(wd.tb_off, t, lane, REC, 4) : nullptr);
     }
-    if (!P.fused) {
+    if (REWALK || !P.fused) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             uint32_t prob; unsigned long long key;
@@ -129,6 +133,35 @@ __global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P, cons
     if (k >= 2u * P.n_pairs) return;
     const uint32_t i = P.order[k];
     if (i != 0xffffffffu) walk_one(P, i, P.best[i]);
+}
+
+// TB_REWALK (gssw_device.hpp), first the band: the fill's wavefronts again — same grid, same lane <-> (pair, lane block) map — each lane over
+// the band columns of its lane block with the code-building lane code; no lane talks to another (the rows above come from HBM).
+template <int K, bool S8>
+__global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_band_kernel(const GsswParams P) {
+    const uint32_t wave = P.wave_begin + blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wave >= P.wave_begin + P.wave_count) return;
+    band_fill_lane<K, S8>(P, P.waves[wave], threadIdx.x & 63u);
+}
+// ... then the walks over the band's records, one lane per read in fill order (the stored-codes walk kernel's shape)
+__global__ __launch_bounds__(256) void gssw_bandwalk_kernel(const GsswParams P) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 2u * P.n_pairs) return;
+    const uint32_t i = P.order[k];
+    if (i != 0xffffffffu) bandwalk_one(P, i, P.best[i]);
+}
+// ... then, for the reads whose walk left its band (status W_MISSED), the on-demand form: one lane per read over the reads of ONE fill launch (the lane code is
+// instantiated per rows-per-lane K), in the order the fill placed them.  A wavefront's windows live in LDS, lane-interleaved.
+template <int K, bool S8>
+__global__ __launch_bounds__(64, 2) void gssw_rewalk_kernel(const GsswParams P) {
+    __shared__ uint32_t win[(TB_CKPT / 2) * ((K + 3) / 4) * 64];
+    const uint32_t pair_begin = P.waves[P.wave_begin].first_pair;
+    const uint32_t wave_end = P.wave_begin + P.wave_count;
+    const uint32_t pair_end = wave_end < P.n_waves ? P.waves[wave_end].first_pair : P.n_pairs;
+    const uint32_t k = 2u * pair_begin + blockIdx.x * 64u + threadIdx.x;
+    if (k >= 2u * pair_end) return;
+    const uint32_t i = P.order[k];
+    if (i != 0xffffffffu) rewalk_one<K, S8>(P, i, P.best[i], win + threadIdx.x, 64u);
 }
 
 // ---- CIGAR ops on their way back: exclusive prefix sums of the per-problem op counts, then a gather ------------------
@@ -874,17 +907,46 @@ public:
         hipSetDevice(dev);
         return hipMemsetAsync(dst, byte, bytes, copy) == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
-    int launch_fill(const GsswParams& p, hipStream_t stream) {
+    template <int K> int launch_fill_k(const GsswParams& p, hipStream_t stream) {
         const dim3 grid((p.wave_count + 3) / 4), block(256);
-        const bool s8 = p.scale == 8;
+        const bool s8 = p.scale == 8, re = p.tb_mode == TB_REWALK;
+        if (re) { if (s8) hipLaunchKernelGGL((gssw_fill_kernel<K, true, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<K, false, true>), grid, block, 0, stream, p); }
+        else    { if (s8) hipLaunchKernelGGL((gssw_fill_kernel<K, true, false>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<K, false, false>), grid, block, 0, stream, p); }
+        return VGK_OK;
+    }
+    int launch_fill(const GsswParams& p, hipStream_t stream) {
         switch (p.K) {
-            case 16: if (s8) hipLaunchKernelGGL((gssw_fill_kernel<16, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<16, false>), grid, block, 0, stream, p); break;
-            case 19: if (s8) hipLaunchKernelGGL((gssw_fill_kernel<19, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<19, false>), grid, block, 0, stream, p); break;
-            case 20: if (s8) hipLaunchKernelGGL((gssw_fill_kernel<20, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<20, false>), grid, block, 0, stream, p); break;
-            case 24: if (s8) hipLaunchKernelGGL((gssw_fill_kernel<24, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<24, false>), grid, block, 0, stream, p); break;
+            case 16: return launch_fill_k<16>(p, stream);
+            case 19: return launch_fill_k<19>(p, stream);
+            case 20: return launch_fill_k<20>(p, stream);
+            case 24: return launch_fill_k<24>(p, stream);
             default: return VGK_EINVAL;
         }
-        return VGK_OK;
+    }
+    // the recomputing tracebacks of one fill launch's reads (p.K / wave_begin / wave_count as for the fill); the grid covers every pair
+    // of the batch (the launch's own count is a device-side fact for batches packed there): blocks beyond its reads leave at once
+    template <int K> void launch_rewalk_k(const GsswParams& p, hipStream_t stream) {
+        const dim3 grid((2 * p.n_pairs + 63) / 64), block(64);
+        if (p.scale == 8) hipLaunchKernelGGL((gssw_rewalk_kernel<K, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_rewalk_kernel<K, false>), grid, block, 0, stream, p);
+    }
+    template <int K> void launch_band_k(const GsswParams& p, hipStream_t stream) {
+        const dim3 grid((p.wave_count + 3) / 4), block(256);
+        if (p.scale == 8) hipLaunchKernelGGL((gssw_band_kernel<K, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_band_kernel<K, false>), grid, block, 0, stream, p);
+    }
+    void launch_walk(const GsswParams& p0, const FillLaunch* launches, uint32_t n, hipStream_t stream) {
+        if (p0.tb_mode != TB_REWALK) { hipLaunchKernelGGL(gssw_walk_kernel, dim3((2 * p0.n_pairs + 255) / 256), dim3(256), 0, stream, p0, walk_in_fill_order ? 1 : 0); return; }
+        GsswParams p = p0;
+        for (uint32_t i = 0; i < n; ++i) {                              // the band records of every fill launch's wavefronts
+            if (!launches[i].wave_count) continue;
+            p.K = launches[i].K; p.wave_begin = launches[i].wave_begin; p.wave_count = launches[i].wave_count;
+            switch (p.K) { case 16: launch_band_k<16>(p, stream); break; case 19: launch_band_k<19>(p, stream); break; case 20: launch_band_k<20>(p, stream); break; case 24: launch_band_k<24>(p, stream); break; default: break; }
+        }
+        hipLaunchKernelGGL(gssw_bandwalk_kernel, dim3((2 * p0.n_pairs + 255) / 256), dim3(256), 0, stream, p0);
+        for (uint32_t i = 0; i < n; ++i) {                              // what left its band
+            if (!launches[i].wave_count) continue;
+            p.K = launches[i].K; p.wave_begin = launches[i].wave_begin; p.wave_count = launches[i].wave_count;
+            switch (p.K) { case 16: launch_rewalk_k<16>(p, stream); break; case 19: launch_rewalk_k<19>(p, stream); break; case 20: launch_rewalk_k<20>(p, stream); break; case 24: launch_rewalk_k<24>(p, stream); break; default: break; }
+        }
     }
     // One fill launch per rows-per-lane instantiation K (lanes-per-pair G is a per-wavefront value), then one traceback launch over all
     // reads.  (Running walk(c) under fill(c+1) on a second stream, and fusing the walk into the fill kernel,
@@ -910,9 +972,9 @@ public:
         }
         hipEventRecord(ev[1], stream);
         hipEventRecord(fill_done[0], stream); fill_done_set[0] = true;
-        timed_walk = walk && !p.fused;
+        timed_walk = walk && (!p.fused || p.tb_mode == TB_REWALK);
         if (timed_walk) {
-            hipLaunchKernelGGL(gssw_walk_kernel, dim3((2 * p.n_pairs + 255) / 256), dim3(256), 0, stream, p, walk_in_fill_order ? 1 : 0);
+            launch_walk(p0, launches, n, stream);
             hipEventRecord(ev[2], stream);
         }
         pending = true;
@@ -938,9 +1000,9 @@ public:
         if (p.wave_count) { const int rc = launch_fill(p, alt); if (rc) return rc; }
         hipEventRecord(evb[1], alt);
         hipEventRecord(fill_done[1], alt); fill_done_set[1] = true;
-        timed_walk_b = walk && !p.fused;
+        timed_walk_b = walk && (!p.fused || p.tb_mode == TB_REWALK);
         if (timed_walk_b) {
-            hipLaunchKernelGGL(gssw_walk_kernel, dim3((2 * p.n_pairs + 255) / 256), dim3(256), 0, alt, p, walk_in_fill_order ? 1 : 0);
+            launch_walk(p0, launches, n, alt);
             hipEventRecord(evb[2], alt);
         }
         pending_b = true;

@@ -1,6 +1,7 @@
 // batch.hpp — a packed gssw batch resident in HBM, shared by the translation units that build one (vgk_api.cpp: per-problem
 // graphs packed on the host; window_api.cpp: windows of a resident graph packed on the device).
 #pragma once
+#include <cstdlib>
 #include <vector>
 #include "backend.hpp"
 #include "ctx.hpp"
@@ -31,6 +32,20 @@ inline int nt_read(char ch) {   // gssw_create_nt_table: case-insensitive ACGT, 
 }
 inline int nt_ref(char ch) {    // after nonATGCNtoN (src/aligner.cpp:39): upper-case ACGT only
     switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
+}
+
+// Which traceback a batch runs (gssw_device.hpp).  The recomputing one (TB_REWALK) lays its band along the diagonal through the end cell, in
+// COLUMN space: it serves a path as long as walking back over a node boundary moves it at most a few columns beyond the previous node's
+// end — chains, SNP bubbles, short insertions.  A predecessor that ends more than TB_JUMP columns before its successor starts (the other side
+// of a long bubble; a sibling subtree of a tail forest) throws the path out of the band and onto the slow on-demand form, so a batch with
+// such an edge keeps the stored codes (TB_CODES).  So do the tiled code layout and the fused walk.  VGAMD_TB_CODES=1 / VGAMD_TB_REWALK=1
+// force either (tests run the random DAGs through the band and its fallback that way).
+constexpr uint32_t TB_JUMP = TB_SLACK / 2;
+inline int32_t default_tb_mode(int fused, bool near_chain) {
+    if (TB_TILE > 1 || fused) return TB_CODES;
+    if (const char* e = std::getenv("VGAMD_TB_CODES")) if (std::atoi(e)) return TB_CODES;
+    if (const char* e = std::getenv("VGAMD_TB_REWALK")) if (std::atoi(e)) return TB_REWALK;
+    return near_chain ? TB_REWALK : TB_CODES;
 }
 
 template <class T>

@@ -114,6 +114,8 @@ struct GsswParams {
     uint32_t go, ge;
     int32_t  bonus;             // full-length bonus (plain contexts; per-read values live in ProbDesc)
     int32_t  want_tb;           // any problem wants traceback -> store codes
+    int32_t  tb_mode;           // TB_CODES: the fill stores a 4-bit code per cell; TB_REWALK: it stores what the traceback needs to compute them again
+                                // where the path runs (see "the traceback that does not tax the fill" below)
     int32_t  fused;             // 1 = each wavefront traces its own reads back at the end of the fill kernel
     uint32_t scale;             // 1 or 8: every DP quantity above (prof4, bias, go, ge, bonus, xoff, scratch) is pre-multiplied.
                                 // With 8, non-zero score differences are >= 8, so min(diff, 1|2|4|8) yields the four traceback
@@ -311,16 +313,11 @@ VGK_HD uint64_t tb_dword(uint64_t tb_off, uint32_t t, uint32_t lane, uint32_t re
 //   VGK_H_MAX3     H = max(diagonal, E, F) as one v_pk_maximum3_f16 on the bit patterns (pk16.hpp) instead of two v_pk_max_u16: ON — exact on
 //                  the device for every triple of halves below 0x7c00 (tools/pkmax3_check.hip: 0 of 1.2e10, denormals included), fill
 //                  20.0 -> 19.15 ms per million reads (profiles/r04)
-//   VGK_FILL_NOTB  timing experiment only (results are wrong): no traceback codes are built or stored — the bound on what a
-//                  traceback that does not tax the fill could gain
 #ifndef VGK_ACC_SHLOR
 #define VGK_ACC_SHLOR 0
 #endif
 #ifndef VGK_H_MAX3
 #define VGK_H_MAX3 1
-#endif
-#ifndef VGK_FILL_NOTB
-#define VGK_FILL_NOTB 0
 #endif
 
 // best-cell key of a row: score*32 + (31 - row_in_lane), so one packed max keeps
@@ -329,7 +326,7 @@ constexpr uint32_t KEY_SHIFT = 5, KEY_LOW = 31;
 
 // One row (compile-time index M) of one lane for one column.  REFN = some half sees
 // an N in the graph (rare): the profile permute cannot express score 0, patch it.
-template <int K, int M, bool REFN, bool S8>
+template <int K, int M, bool REFN, bool S8, bool TB>
 VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, uint32_t go2, uint32_t ge2,
                      bool nA, bool nB, uint32_t& f, uint32_t& d, uint32_t* acc, uint32_t& ck) {
     uint32_t sb = byte_perm(s.PB[M], s.PA[M], sel);
@@ -339,20 +336,20 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
         if (nB) sb = set_hi(sb, row < s.LB ? P.bias + row_bonus(s.bsB, s.beB, row, s.LB) : 0u);
     }
     const uint32_t old = s.H[M];
-#if VGK_FILL_NOTB
-    if constexpr (S8) {
+    if constexpr (!TB) {
+        // The recurrence alone (TB_REWALK fills): no tags, no codes.  Its H / E / F are the tagged build's with the three tag bits
+        // stripped — the tags are below the x8 scale's resolution and every constant that absorbs one is a multiple of 8 away from the
+        // clean one — so a traceback that runs the tagged code again from this fill's boundary values reproduces the codes bit for bit.
         const uint32_t t4 = pk_subs(pk_add_nc(d, sb), bias2);
         const uint32_t e = s.E[M];
-        const uint32_t h = VGK_H_MAX3 ? pk_max3_f16(t4, e, f) : pk_max(pk_max(t4, e), f);
+        const uint32_t h = (S8 && VGK_H_MAX3) ? pk_max3_f16(t4, e, f) : pk_max(pk_max(t4, e), f);
         const uint32_t gg = pk_subs(h, go2);
         const uint32_t en = pk_max(gg, pk_subs(e, ge2)), fn = pk_max(gg, pk_subs(f, ge2));
-        if ((M & 3) == 0) acc[M >> 2] = 0;
-        const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(h, 0x00010001u << (KEY_SHIFT - 3));
+        const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(h, 0x00010001u << (S8 ? KEY_SHIFT - 3 : KEY_SHIFT));
         ck = M == 0 ? key : pk_max(ck, key);
         s.H[M] = h; s.E[M] = en; f = fn; d = old;
         return;
     }
-#endif
     if constexpr (S8) {
         // Scores scaled by 8 leave the three low bits of every value free, and they survive the subtraction of (scaled) constants.
         // Candidates carry a tag there, so the source of a maximum is read off the maximum instead of being recomputed from four
@@ -399,15 +396,15 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
     s.H[M] = h; s.E[M] = en; f = fn; d = old;
 }
 
-template <int K, int M, bool REFN, bool S8>
+template <int K, int M, bool REFN, bool S8, bool TB>
 VGK_HD void lane_rows_from(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, uint32_t go2, uint32_t ge2,
                            bool nA, bool nB, uint32_t& f, uint32_t& d, uint32_t* acc, uint32_t& ck) {
-    lane_row<K, M, REFN, S8>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
-    if constexpr (M + 1 < K) lane_rows_from<K, M + 1, REFN, S8>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+    lane_row<K, M, REFN, S8, TB>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+    if constexpr (M + 1 < K) lane_rows_from<K, M + 1, REFN, S8, TB>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
 }
 
 // The K rows of one lane for one column; returns the K/4 traceback dwords and the column key maximum.
-template <int K, bool REFN, bool S8>
+template <int K, bool REFN, bool S8, bool TB>
 VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t diag0, uint32_t rf,
                       bool nA, bool nB, uint32_t* acc, uint32_t& colkey) {
     uint32_t bias2 = rep2(P.bias), go2 = rep2(P.go), ge2 = rep2(P.ge);
@@ -418,18 +415,17 @@ VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t di
     if (REFN) asm volatile("" : "+v"(sel), "+v"(bias2), "+v"(go2), "+v"(ge2));
 #endif
     uint32_t f = rf, d = diag0, ck = 0;
-    lane_rows_from<K, 0, REFN, S8>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+    lane_rows_from<K, 0, REFN, S8, TB>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
     s.out_h = s.H[K - 1]; s.out_f = f;
     colkey = ck;
 }
 
-// One step of one lane.  rh/rf/rinfo are lane-1's out_h/out_f/info from the
-// previous step (ignored by group leaders, which start a fresh column).
-// tb_a / tb_b = where this (step, lane)'s ceil(K/4)-dword traceback record goes — its first four dwords and the rest (the two parts
-// of the tiled layout; in the step-major form tb_b = tb_a + 4) —, or nullptr.
-template <int K, bool S8>
-VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tb_a, uint32_t* tb_b) {
-    if (s.g == 0) { rh = 0; rf = 0; rinfo = fetch_info(s, P, t); }
+// One column of one lane: rh / rf = H and F of the row above this lane's block in this column, rinfo = the column bytes of the pair.
+// tb_a / tb_b = where the ceil(K/4)-dword traceback record goes — its first four dwords and the rest (the two parts of the tiled
+// layout; in the step-major form tb_b = tb_a + 4) —, or nullptr.  TB = build the codes; RE = the traceback's recomputation of a
+// window (no end-cell tracking, no scratch stores: the fill has done both).
+template <int K, bool S8, bool TB, bool RE>
+VGK_HD void lane_column(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tb_a, uint32_t* tb_b) {
     s.info = rinfo;
     const uint32_t ia = rinfo & 0xffu, ib = (rinfo >> 16) & 0xffu;
     const bool vA = !(ia & CI_INVALID), vB = !(ib & CI_INVALID);
@@ -443,30 +439,42 @@ VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, 
         const uint32_t sel = (rinfo & 0x00030003u) | 0x0c040c00u;
         const bool nA = vA && (ia & CI_BASE_MASK) == 4, nB = vB && (ib & CI_BASE_MASK) == 4;
         uint32_t acc[(K + 3) / 4], colkey;
-        if (nA || nB) lane_rows<K, true, S8>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
-        else          lane_rows<K, false, S8>(s, P, sel, diag0, rf, false, false, acc, colkey);
-        if (tb_a && !VGK_FILL_NOTB) {
-            if (TB_TILE > 1) {                                                 // part A is a 16-byte slot: one store
-                VgkU4 v; v.v[0] = acc[0]; v.v[1] = acc[1]; v.v[2] = acc[2]; v.v[3] = acc[3];
-                *reinterpret_cast<VgkU4*>(tb_a) = v;
+        if (nA || nB) lane_rows<K, true, S8, TB>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
+        else          lane_rows<K, false, S8, TB>(s, P, sel, diag0, rf, false, false, acc, colkey);
+        if constexpr (TB) {
+            if (tb_a) {
+                if (TB_TILE > 1 && !RE) {                                          // part A is a 16-byte slot: one store
+                    VgkU4 v; v.v[0] = acc[0]; v.v[1] = acc[1]; v.v[2] = acc[2]; v.v[3] = acc[3];
+                    *reinterpret_cast<VgkU4*>(tb_a) = v;
 #pragma unroll
-                for (int j = 4; j < (K + 3) / 4; ++j) tb_b[j - 4] = acc[j];
-            } else {
+                    for (int j = 4; j < (K + 3) / 4; ++j) tb_b[j - 4] = acc[j];
+                } else {
 #pragma unroll
-                for (int j = 0; j < (K + 3) / 4; ++j) { if (j < 4) tb_a[j] = acc[j]; else tb_b[j - 4] = acc[j]; }
+                    for (int j = 0; j < (K + 3) / 4; ++j) { if (j < 4) tb_a[j] = acc[j]; else tb_b[j - 4] = acc[j]; }
+                }
             }
         }
-        // local end cell: first column with the best score, smallest row (SSW end_ref/end_read rule)
-        const uint32_t klo = colkey & 0xffffu, khi = colkey >> 16;
-        const bool upA = vA & ((klo >> KEY_SHIFT) > (s.best_lo >> KEY_SHIFT)), upB = vB & ((khi >> KEY_SHIFT) > (s.best_hi >> KEY_SHIFT));   // selects, no branches
-        s.best_lo = upA ? klo : s.best_lo; s.step_lo = upA ? t : s.step_lo;
-        s.best_hi = upB ? khi : s.best_hi; s.step_hi = upB ? t : s.step_hi;
-        if (vA && (ia & CI_STORE_END)) store_to_scratch<0, K>(s, P, s.probA, s.nodeA);
-        if (vB && (ib & CI_STORE_END)) store_to_scratch<1, K>(s, P, s.probB, s.nodeB);
+        if constexpr (!RE) {
+            // local end cell: first column with the best score, smallest row (SSW end_ref/end_read rule)
+            const uint32_t klo = colkey & 0xffffu, khi = colkey >> 16;
+            const bool upA = vA & ((klo >> KEY_SHIFT) > (s.best_lo >> KEY_SHIFT)), upB = vB & ((khi >> KEY_SHIFT) > (s.best_hi >> KEY_SHIFT));   // selects, no branches
+            s.best_lo = upA ? klo : s.best_lo; s.step_lo = upA ? t : s.step_lo;
+            s.best_hi = upB ? khi : s.best_hi; s.step_hi = upB ? t : s.step_hi;
+            if (vA && (ia & CI_STORE_END)) store_to_scratch<0, K>(s, P, s.probA, s.nodeA);
+            if (vB && (ib & CI_STORE_END)) store_to_scratch<1, K>(s, P, s.probB, s.nodeB);
+        }
     } else {
         s.out_h = 0; s.out_f = 0;
     }
     s.prev_rh = rh;
+}
+
+// One step of one lane of the fill.  rh/rf/rinfo are lane-1's out_h/out_f/info from the
+// previous step (ignored by group leaders, which start a fresh column).
+template <int K, bool S8, bool TB = true>
+VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tb_a, uint32_t* tb_b) {
+    if (s.g == 0) { rh = 0; rf = 0; rinfo = fetch_info(s, P, t); }
+    lane_column<K, S8, TB, false>(s, P, t, rh, rf, rinfo, tb_a, tb_b);
 }
 
 // after the last step: publish this lane's best cell (LOCAL mode)
@@ -491,6 +499,7 @@ VGK_HD bool lane_best(const Lane<K>& s, int half, uint32_t& prob, unsigned long 
 #endif
 constexpr uint32_t W_SPEC = VGK_WALK_SPEC;      // diagonal cells fetched together
 struct Walker {
+    static constexpr uint32_t SPEC = W_SPEC;
     const GsswParams& P; const ProbDesc& d; uint32_t half, lane0, K; uint64_t tb_off;
     // bit0 = H not from the diagonal, bit1 = H from F (else E), bit2 = next-column E is an extension, bit3 = next-row F is an extension
     VGK_HD uint32_t code(uint32_t r, uint32_t c) const {
@@ -542,32 +551,24 @@ struct Walker {
     }
 };
 
-VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
-    const ProbDesc d = P.probs[i];      // by value: keeps the descriptor in registers across the walk's global stores
-    vgk_result res;
-    res.score = 0; res.status = VGK_OK; res.end_node = -1; res.end_offset = -1; res.end_read = -1;
-    res.first_offset = 0; res.n_ops = 0; res.ops_begin = d.ops_off;
-    Walker w{P, d, (d.geom >> 16) & 1u, d.lane0, d.geom & 0xffu, P.waves[d.wave].tb_off, 0u, 0xffffffffu, 0u, 0xffffffffu};
+// Where a read's traceback starts: the pinned end (best pinning node's last column, row L - 1) or the best cell the fill published.
+// SAVED(node, row) = H of that node's last column.  Returns false when there is nothing to walk from.
+template <class SAVED>
+VGK_HD bool walk_end_cell(const GsswParams& P, const ProbDesc& d, unsigned long long best_key, SAVED saved, int32_t& cur, uint32_t& c, uint32_t& node, int32_t& r) {
     const NodeRec* nodes = P.nodes + d.node_off;
-    const bool pinned = (d.flags & 15u) == VGK_GSSW_PINNED;
-    const bool xdrop = (d.flags & 15u) == VGK_XDROP_PINNED;   // rows = consumed read bases 0..len, scores carry XOFF
-    const int32_t go = (int32_t)P.go, ge = (int32_t)P.ge;
-    const int32_t S = (int32_t)P.scale;                        // walker arithmetic runs in the kernels' scaled units
-    const int32_t zero = xdrop ? (int32_t)P.xoff : 0;          // representation of score 0
-
-    int32_t cur = 0; uint32_t c = 0, node = 0; int32_t r = 0;
     bool have = false;
-    if (pinned) {
+    cur = 0; c = 0; node = 0; r = 0;
+    if ((d.flags & 15u) == VGK_GSSW_PINNED) {
         r = (int32_t)d.L - 1;
         for (uint32_t n = 0; n < d.n_nodes; ++n) {
             if (!nodes[n].pinning) continue;
-            const int32_t v = (int32_t)(w.saved(nodes[n], (uint32_t)r) & 0xffffu);
+            const int32_t v = (int32_t)(saved(nodes[n], (uint32_t)r) & 0xffffu);
             if (!have || v > cur) { cur = v; node = n; have = true; }
         }
         if (have) c = nodes[node].col_end - 1;
     } else {
         const unsigned long long k = best_key;
-        cur = (int32_t)(k >> 40) * S;
+        cur = (int32_t)(k >> 40) * (int32_t)P.scale;
         if (cur > 0) {
             have = true;
             c = 0xFFFFFu - (uint32_t)((k >> 20) & 0xFFFFFu);
@@ -577,6 +578,29 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
             node = lo;
         }
     }
+    return have;
+}
+
+constexpr uint32_t W_MISS = 0x100u;            // a code a walker cannot serve (BandWalker: the cell lies outside the recomputed band)
+constexpr int32_t  W_MISSED = 100;             // vgk_result::status of a read whose walk met one: the on-demand traceback takes it (never leaves the engine)
+
+// The traceback proper, over whatever serves the codes: W = Walker (the codes the fill stored), BandWalker (recomputed in a band around the
+// end cell's diagonal) or ReWalker (recomputed on demand, window by window).
+template <class W>
+VGK_HD void walk_body(const GsswParams& P, uint32_t i, const ProbDesc& d, W& w, unsigned long long best_key) {
+    constexpr uint32_t W_SPEC = W::SPEC;
+    vgk_result res;
+    res.score = 0; res.status = VGK_OK; res.end_node = -1; res.end_offset = -1; res.end_read = -1;
+    res.first_offset = 0; res.n_ops = 0; res.ops_begin = d.ops_off;
+    const NodeRec* nodes = P.nodes + d.node_off;
+    const bool pinned = (d.flags & 15u) == VGK_GSSW_PINNED;
+    const bool xdrop = (d.flags & 15u) == VGK_XDROP_PINNED;   // rows = consumed read bases 0..len, scores carry XOFF
+    const int32_t go = (int32_t)P.go, ge = (int32_t)P.ge;
+    const int32_t S = (int32_t)P.scale;                        // walker arithmetic runs in the kernels' scaled units
+    const int32_t zero = xdrop ? (int32_t)P.xoff : 0;          // representation of score 0
+
+    int32_t cur = 0; uint32_t c = 0, node = 0; int32_t r = 0;
+    const bool have = walk_end_cell(P, d, best_key, [&](const NodeRec& n, uint32_t row) { return w.saved(n, row); }, cur, c, node, r);
     if (pinned && !have) { res.status = VGK_EINVAL; P.results[i] = res; return; }
     if (cur >= 2047 * S) { res.status = VGK_EOVERFLOW; P.results[i] = res; return; }
     if (!have || cur <= zero) { P.results[i] = res; return; }  // score 0: the caller synthesises soft clips / full insertion
@@ -620,11 +644,12 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
 #if defined(VGK_DEBUG_WALK) && !defined(__HIP_DEVICE_COMPILE__)
             printf("H r=%d c=%u cur=%d nspec=%u fl=%u %u sc=%d %d\n", r, c, cur, nspec, fl[0], fl[1], sc[0], sc[1]);
 #endif
+            if (fl[0] & W_MISS) { status = W_MISSED; break; }
             if (fl[0] & 1u) { st = (fl[0] & 2u) ? ST_F : ST_E; continue; }
             bool stop = false;
 #pragma unroll
             for (uint32_t k = 0; k < W_SPEC; ++k) {
-                if (stop || k >= nspec || (fl[k] & 1u) || (!xdrop && cur == 0)) { stop = true; continue; }
+                if (stop || k >= nspec || (fl[k] & (1u | W_MISS)) || (!xdrop && cur == 0)) { stop = true; continue; }
                 VGK_PUSH(node, VGK_OP_M, 1); first_c = c;
                 cur -= sc[k]; r -= 1;
                 if (r < 0 || (!xdrop && cur == 0)) { stop = true; continue; }
@@ -663,12 +688,16 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
                 if (found < 0) { status = VGK_EINVAL; break; }
                 pnode = (uint32_t)found; pc = nodes[pnode].col_end - 1; node_start = nodes[pnode].col_start;
             }
-            if (!(w.code((uint32_t)r, pc) & 4u)) { st = ST_H; cur += go; } else cur += ge;
+            const uint32_t fe = w.code((uint32_t)r, pc);
+            if (fe & W_MISS) { status = W_MISSED; break; }
+            if (!(fe & 4u)) { st = ST_H; cur += go; } else cur += ge;
             c = pc; node = pnode;
         } else {
             VGK_PUSH(node, VGK_OP_I, 1);
             if (r == 0) { status = VGK_EINVAL; break; }
-            if (!(w.code((uint32_t)r - 1, c) & 8u)) { st = ST_H; cur += go; } else cur += ge;
+            const uint32_t ff = w.code((uint32_t)r - 1, c);
+            if (ff & W_MISS) { status = W_MISSED; break; }
+            if (!(ff & 8u)) { st = ST_H; cur += go; } else cur += ge;
             r -= 1;
         }
     }
@@ -683,6 +712,285 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
         res.first_offset = (int32_t)(first_c - node_start);
     }
     P.results[i] = res;
+}
+
+VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
+    const ProbDesc d = P.probs[i];      // by value: keeps the descriptor in registers across the walk's global stores
+    Walker w{P, d, (d.geom >> 16) & 1u, d.lane0, d.geom & 0xffu, P.waves[d.wave].tb_off, 0u, 0xffffffffu, 0u, 0xffffffffu};
+    walk_body(P, i, d, w, best_key);
+}
+
+// ---------------------------------------------------------------------------
+// The traceback that does not tax the fill (TB_REWALK).
+//
+// Building, merging and storing a 4-bit code per cell is 8-9 of the ~20 VALU instructions the fill spends per row pair, for codes of
+// which the traceback reads one cell in four hundred (a 150-base path through 62 000 cells).  In this mode the fill runs the
+// recurrence alone (lane_row<..., TB = false>) and leaves behind only what is needed to run any piece of it again:
+//   * per (step, lane) the lane's outputs to the lane below — H and F of its last row — 2 dwords ("boundary rows"), and
+//   * per lane and every TB_CKPT-th column its K rows of H and E after that column, 2 K dwords ("checkpoints");
+// about 0.64 of the bytes of the codes.  The traceback (one lane per read) asks for codes cell by cell as before; they come out of
+// a window of one lane block (K rows) x up to TB_CKPT columns that is recomputed on demand by the FILL'S OWN lane code
+// (lane_column<..., TB = true, RE = true>) from the checkpoint before it and the boundary rows above it, and kept in LDS.  The codes
+// are therefore the ones the code-storing fill would have written — same instructions, same inputs: H / E of a checkpoint are the
+// tagged build's values without their tags, which that code strips or overwrites before use — and the path is identical.  A
+// 150-base path crosses ~8 lane blocks and ~2 windows in each: ~5 000 of the 62 000 cells are computed a second time.
+// ---------------------------------------------------------------------------
+enum : int32_t { TB_CODES = 0, TB_REWALK = 1 };
+constexpr uint32_t TB_CKPT = 32;         // columns between two checkpoints = the widest window (even: the window keeps two columns per dword)
+
+// The band: a traceback runs close to the diagonal through its end cell, so the codes it will ask for can be computed BEFORE it starts —
+// for every lane block of a read at once, which the on-demand form (a window when the walk gets there) cannot: lane block g needs the
+// columns the diagonal crosses in its rows, TB_SLACK more on either side, from the checkpoint before them.  All blocks of all reads of a
+// wavefront run that many columns in lock step (no lane waits for another, no input depends on a neighbour: the boundary rows are in HBM),
+// both reads of a pair together as in the fill.  A path that leaves its band (a long gap, a drift of more than TB_SLACK columns) is
+// noticed by the walk and handed to the on-demand form.
+constexpr uint32_t TB_SLACK = 8;
+VGK_HD uint32_t tb_band_cols(uint32_t K) { return K + 2u * TB_SLACK + TB_CKPT - 1u; }      // columns a lane block's band can need, counted from its checkpoint
+struct TbBand { uint32_t cs, hi; bool used; };      // columns [cs, hi] of a lane block are (to be) recomputed; cs is a multiple of TB_CKPT
+VGK_HD TbBand tb_band_of(uint32_t r_e, uint32_t c_e, uint32_t g, uint32_t K) {
+    TbBand b; b.used = g * K <= r_e; b.cs = 0; b.hi = 0;
+    if (!b.used) return b;
+    // the diagonal through the end cell meets row r at column c_e - (r_e - r) (left of column 0: the path has ended or left the diagonal)
+    const uint32_t r_hi = g * K + K - 1u < r_e ? g * K + K - 1u : r_e;
+    const uint32_t back_lo = r_e - g * K + TB_SLACK, back_hi = r_e - r_hi;
+    const uint32_t lo = c_e > back_lo ? c_e - back_lo : 0u;
+    uint32_t hi = c_e > back_hi ? c_e - back_hi + TB_SLACK : TB_SLACK;
+    if (hi > c_e) hi = c_e;                                             // a traceback never moves right of where it started
+    b.cs = lo / TB_CKPT * TB_CKPT;
+    const uint32_t last = b.cs + tb_band_cols(K) - 1u;
+    b.hi = hi < last ? hi : last;
+    return b;
+}
+
+// dwords of a wavefront's traceback arena: enough for either form
+VGK_HD uint64_t tb_wave_dwords(uint32_t n_steps, uint32_t K) {
+    const uint64_t rec = (K + 3u) >> 2;
+    const uint64_t codes = (uint64_t)((n_steps + TB_TILE - 1) / TB_TILE * TB_TILE) * 64u * rec;
+    const uint64_t rewalk = (uint64_t)n_steps * 128u + (uint64_t)((n_steps + TB_CKPT - 1) / TB_CKPT) * 128u * K + 64ull * tb_band_cols(K) * rec;
+    return codes > rewalk ? codes : rewalk;
+}
+VGK_HD uint64_t tb_bnd(uint64_t tb_off, uint32_t t, uint32_t lane) { return tb_off + ((uint64_t)t * 64u + lane) * 2u; }      // {out_h, out_f} of (step, lane)
+VGK_HD uint64_t tb_ckpt(uint64_t tb_off, uint32_t n_steps, uint32_t cb, uint32_t lane, uint32_t K) {                         // H[K] then E[K] after column cb * TB_CKPT + TB_CKPT - 1
+    return tb_off + (uint64_t)n_steps * 128u + ((uint64_t)cb * 64u + lane) * 2u * K;
+}
+VGK_HD uint64_t tb_band(uint64_t tb_off, uint32_t n_steps, uint32_t x, uint32_t lane, uint32_t K) {                          // the record (ceil(K/4) dwords, both reads of the pair) of band column x of a lane
+    return tb_off + (uint64_t)n_steps * 128u + (uint64_t)((n_steps + TB_CKPT - 1) / TB_CKPT) * 128u * K + ((uint64_t)x * 64u + lane) * ((K + 3u) >> 2);
+}
+
+// the fill's stores in this mode, after lane_step<K, S8, false> of step t
+template <int K>
+VGK_HD void lane_store_boundary(const Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint32_t t, uint32_t lane) {
+    uint32_t* b = P.tb + tb_bnd(wd.tb_off, t, lane);
+    b[0] = s.out_h; b[1] = s.out_f;
+    const uint32_t c = t - s.g;                                   // the column this lane has just finished
+    if (t >= s.g && (c & (TB_CKPT - 1u)) == TB_CKPT - 1u && !((s.info & CI_INVALID) && (s.info & (CI_INVALID << 16)))) {
+        uint32_t* k = P.tb + tb_ckpt(wd.tb_off, wd.n_steps, c / TB_CKPT, lane, (uint32_t)K);
+#pragma unroll
+        for (int m = 0; m < K; ++m) { k[m] = s.H[m]; k[K + m] = s.E[m]; }
+    }
+}
+
+// Serves Walker::code() from a recomputed window.  `win` = this lane's slice of the wavefront's LDS buffer (stride 64 dwords):
+// dword (colpair * REC + j) holds the 16 code bits of row quad j for columns 2 colpair (low half) and 2 colpair + 1 (high half).
+template <int K, bool S8>
+struct ReWalker {
+    static constexpr uint32_t SPEC = 1;          // the codes are a few cycles away: nothing to fetch ahead
+    static constexpr uint32_t REC = (K + 3) / 4;
+    Walker base;
+    uint32_t* win; uint32_t win_stride;
+    uint32_t n_steps;
+    uint32_t win_g = 0xffffffffu, win_c0 = 0, win_hi = 0;      // the window: lane block, first column (a multiple of TB_CKPT), last column computed
+    Lane<K> ln;
+
+    VGK_HD int32_t score(uint32_t r, uint32_t c) const { return base.score(r, c); }
+    VGK_HD uint32_t saved(const NodeRec& n, uint32_t r) const { return base.saved(n, r); }
+    VGK_HD int32_t saved_e(const NodeRec& n, uint32_t r) const { return base.saved_e(n, r); }
+
+    VGK_HD uint32_t code(uint32_t r, uint32_t c) {
+        const uint32_t g = r / K, m = r - g * K, j = m >> 2, i = m & 3u;
+        if (g != win_g || c < win_c0 || c > win_hi) refill(g, c);
+        const uint32_t x = c - win_c0;
+        const uint32_t w = (win[((x >> 1) * REC + j) * win_stride] >> (16u * (x & 1u))) & 0xffffu;
+        const uint32_t last = (4 * j + 3 < (uint32_t)K ? 4 * j + 3 : (uint32_t)K - 1) - 4 * j;
+        const uint32_t raw = (w >> (4 * (last - i))) & 15u;
+        if (!S8) return raw;
+        const uint32_t src = (raw >> 1) & 3u;
+        return (src != 2u ? 1u : 0u) | (src == 0u ? 2u : 0u) | ((raw & 1u) ? 0u : 4u) | ((raw & 8u) ? 0u : 8u);
+    }
+
+    // lane block g, columns [c / TB_CKPT * TB_CKPT, c], computed again from the checkpoint before them and the boundary rows above
+    VGK_HD void refill(uint32_t g, uint32_t c) {
+        const GsswParams& P = base.P; const ProbDesc& d = base.d;
+        const uint32_t half = base.half, lane = base.lane0 + g;
+        const uint64_t tb_off = base.tb_off;
+        const uint32_t c0 = c / TB_CKPT * TB_CKPT;
+        Lane<K>& s = ln;
+        // the read in its half of the pair, the other half idle
+        s.g = g; s.Lpad = d.Lpad;
+        s.probA = half ? 0xffffffffu : 0u; s.probB = half ? 0u : 0xffffffffu;      // (set to the read's index below)
+        s.LA = s.LB = 0; s.flagsA = s.flagsB = 0; s.RA = s.RB = 0; s.colA = s.colB = 0; s.ciA = s.ciB = s.ciA_n = s.ciB_n = 0;
+        s.bsA = s.beA = s.bsB = s.beB = 0;
+        if (half) { s.probB = prob_index; s.LB = d.L; s.flagsB = d.flags; s.RB = d.R; s.colB = d.col_off; s.bsB = d.bonus_start; s.beB = d.bonus_end; }
+        else      { s.probA = prob_index; s.LA = d.L; s.flagsA = d.flags; s.RA = d.R; s.colA = d.col_off; s.bsA = d.bonus_start; s.beA = d.bonus_end; }
+        const uint32_t keep = half ? 0xffff0000u : 0x0000ffffu;
+        const uint32_t* ck = c0 ? P.tb + tb_ckpt(tb_off, n_steps, c0 / TB_CKPT - 1u, lane, (uint32_t)K) : nullptr;
+#pragma unroll
+        for (int m = 0; m < K; ++m) {
+            const uint32_t row = g * K + m;
+            uint32_t pw = 0;
+            if (row < d.L) pw = d.prof_off != 0xffffffffu ? P.prof[d.prof_off + row] : P.prof4[P.reads[d.read_off + row]] + 0x01010101u * row_bonus(d.bonus_start, d.bonus_end, row, d.L);
+            s.PA[m] = half ? 0u : pw; s.PB[m] = half ? pw : 0u;
+            s.H[m] = ck ? ck[m] & keep : 0u; s.E[m] = ck ? ck[K + m] & keep : 0u;
+        }
+        s.out_h = 0; s.out_f = 0; s.info = CI_INVALID2;
+        s.best_lo = s.best_hi = 0; s.step_lo = s.step_hi = 0;
+        s.one = 0x00010001u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(s.one));
+#endif
+        // nodes begun up to column c0 - 1; H of the row above at that column
+        uint32_t node = 0xffffffffu;
+        if (c0) {
+            const NodeRec* nodes = P.nodes + d.node_off;
+            uint32_t lo = 0, hi = d.n_nodes;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (nodes[mid].col_start <= c0 - 1u) lo = mid; else hi = mid; }
+            node = lo;
+        }
+        s.nodeA = s.nodeB = node;
+        s.prev_rh = (c0 && g) ? P.tb[tb_bnd(tb_off, c0 - 1u + g - 1u, lane - 1u)] & keep : 0u;
+        uint32_t pend[REC];
+        for (uint32_t col = c0; col <= c; ++col) {
+            const uint32_t t = col + g;
+            uint32_t rh = 0, rf = 0;
+            if (g) { const uint32_t* b = P.tb + tb_bnd(tb_off, t - 1u, lane - 1u); rh = b[0] & keep; rf = b[1] & keep; }
+            const uint32_t ci = P.colinfo[d.col_off + col];
+            const uint32_t rinfo = half ? ((uint32_t)CI_INVALID | (ci << 16)) : (ci | ((uint32_t)CI_INVALID << 16));
+            uint32_t rec[REC];
+            lane_column<K, S8, true, true>(s, P, t, rh, rf, rinfo, rec, rec + 4);
+            const uint32_t x = col - c0;
+#pragma unroll
+            for (uint32_t j = 0; j < REC; ++j) {
+                const uint32_t v = (rec[j] >> (16u * half)) & 0xffffu;
+                if (x & 1u) win[((x >> 1) * REC + j) * win_stride] = pend[j] | (v << 16);
+                else pend[j] = v;
+            }
+        }
+        if (!((c - c0) & 1u)) {                                     // an odd number of columns: the last one alone in its dword
+#pragma unroll
+            for (uint32_t j = 0; j < REC; ++j) win[(((c - c0) >> 1) * REC + j) * win_stride] = pend[j];
+        }
+        win_g = g; win_c0 = c0; win_hi = c;
+    }
+    uint32_t prob_index = 0;
+};
+
+// ---- the band (see TB_SLACK above) ----------------------------------------------------------------------------------------------
+// where a read's traceback will start, if it has one; scratch-resident H of a node's last column read like Walker::saved
+VGK_HD bool tb_band_end(const GsswParams& P, const ProbDesc& d, unsigned long long best_key, uint32_t& r_e, uint32_t& c_e) {
+    if (!(d.flags & VGK_GSSW_TRACEBACK)) return false;
+    int32_t cur, r; uint32_t c, node;
+    const bool have = walk_end_cell(P, d, best_key, [&](const NodeRec& n, uint32_t row) { return P.scratch[d.scratch_off + (uint32_t)n.slot * d.Lpad + row]; }, cur, c, node, r);
+    const int32_t zero = (d.flags & 15u) == VGK_XDROP_PINNED ? (int32_t)P.xoff : 0;
+    if (!have || cur <= zero || cur >= 2047 * (int32_t)P.scale || r < 0) return false;
+    r_e = (uint32_t)r; c_e = c;
+    return true;
+}
+
+// One lane of a fill wavefront again: lane block g of the pair's two reads, each over its own band, with the fill's code-building lane
+// code.  Writes the records of band columns 0 .. tb_band_cols(K) - 1 (a read's own count may be smaller: its half is then idle).
+template <int K, bool S8>
+VGK_HD void band_fill_lane(const GsswParams& P, const WaveDesc& wd, uint32_t lane) {
+    Lane<K> s;
+    lane_init(s, P, wd, lane);                   // the pair, its rows' profiles, the lane block index g — as the fill began
+    const uint32_t g = s.g;
+    uint32_t re[2] = {0, 0}, ce[2] = {0, 0}; TbBand bd[2]; bd[0].used = bd[1].used = false;
+    const uint32_t prob[2] = {s.probA, s.probB};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (prob[h] == 0xffffffffu) continue;
+        const ProbDesc& d = P.probs[prob[h]];
+        if (tb_band_end(P, d, P.best[prob[h]], re[h], ce[h])) bd[h] = tb_band_of(re[h], ce[h], g, (uint32_t)K);
+    }
+    if (!bd[0].used && !bd[1].used) return;
+    // the state before each half's first column: its checkpoint, the nodes begun so far, H of the row above
+    uint32_t prev = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t keep = h ? 0xffff0000u : 0x0000ffffu;
+        uint32_t node = 0xffffffffu;
+        if (bd[h].used && bd[h].cs) {
+            const ProbDesc& d = P.probs[prob[h]];
+            const uint32_t* ck = P.tb + tb_ckpt(wd.tb_off, wd.n_steps, bd[h].cs / TB_CKPT - 1u, lane, (uint32_t)K);
+#pragma unroll
+            for (int m = 0; m < K; ++m) { s.H[m] |= ck[m] & keep; s.E[m] |= ck[K + m] & keep; }
+            const NodeRec* nodes = P.nodes + d.node_off;
+            uint32_t lo = 0, hi = d.n_nodes;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (nodes[mid].col_start <= bd[h].cs - 1u) lo = mid; else hi = mid; }
+            node = lo;
+            if (g) prev |= P.tb[tb_bnd(wd.tb_off, bd[h].cs - 1u + g - 1u, lane - 1u)] & keep;
+        }
+        if (h) s.nodeB = node; else s.nodeA = node;
+    }
+    s.prev_rh = prev;
+    const uint32_t n_cols = tb_band_cols((uint32_t)K);
+    for (uint32_t x = 0; x < n_cols; ++x) {
+        uint32_t rinfo = CI_INVALID2, rh = 0, rf = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t col = bd[h].cs + x;
+            if (!bd[h].used || col > bd[h].hi) continue;
+            const ProbDesc& d = P.probs[prob[h]];
+            const uint32_t ci = P.colinfo[d.col_off + col];
+            rinfo = h ? (rinfo & 0x0000ffffu) | (ci << 16) : (rinfo & 0xffff0000u) | ci;
+            if (g) {
+                const uint32_t keep = h ? 0xffff0000u : 0x0000ffffu;
+                const uint32_t* b = P.tb + tb_bnd(wd.tb_off, col + g - 1u, lane - 1u);
+                rh |= b[0] & keep; rf |= b[1] & keep;
+            }
+        }
+        if (rinfo == CI_INVALID2) break;                            // both bands done (a band is a prefix of the columns)
+        uint32_t* out = P.tb + tb_band(wd.tb_off, wd.n_steps, x, lane, (uint32_t)K);
+        lane_column<K, S8, true, true>(s, P, x, rh, rf, rinfo, out, out + 4);
+    }
+}
+
+// Walker::code() out of the band records
+struct BandWalker {
+    static constexpr uint32_t SPEC = W_SPEC;
+    Walker base;
+    uint32_t n_steps, r_e, c_e;
+    mutable uint32_t bg = 0xffffffffu; mutable TbBand bb{0, 0, false};      // the band of the lane block asked for last
+    VGK_HD int32_t score(uint32_t r, uint32_t c) const { return base.score(r, c); }
+    VGK_HD uint32_t saved(const NodeRec& n, uint32_t r) const { return base.saved(n, r); }
+    VGK_HD int32_t saved_e(const NodeRec& n, uint32_t r) const { return base.saved_e(n, r); }
+    VGK_HD uint32_t code(uint32_t r, uint32_t c) const {
+        const uint32_t K = base.K, g = r / K, m = r - g * K, j = m >> 2, i = m & 3u;
+        if (g != bg) { bg = g; bb = tb_band_of(r_e, c_e, g, K); }
+        if (!bb.used || c < bb.cs || c > bb.hi) return W_MISS;
+        const uint32_t w = base.P.tb[tb_band(base.tb_off, n_steps, c - bb.cs, base.lane0 + g, K) + j];
+        const uint32_t last = (4 * j + 3 < K ? 4 * j + 3 : K - 1) - 4 * j;
+        const uint32_t raw = (w >> (16 * base.half + 4 * (last - i))) & 15u;
+        if (base.P.scale != 8) return raw;
+        const uint32_t src = (raw >> 1) & 3u;
+        return (src != 2u ? 1u : 0u) | (src == 0u ? 2u : 0u) | ((raw & 1u) ? 0u : 4u) | ((raw & 8u) ? 0u : 8u);
+    }
+};
+VGK_HD void bandwalk_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
+    const ProbDesc d = P.probs[i];
+    const WaveDesc wd = P.waves[d.wave];
+    BandWalker w{Walker{P, d, (d.geom >> 16) & 1u, d.lane0, d.geom & 0xffu, wd.tb_off, 0u, 0xffffffffu, 0u, 0xffffffffu}, wd.n_steps, 0u, 0u};
+    if (!tb_band_end(P, d, best_key, w.r_e, w.c_e)) { w.r_e = 0; w.c_e = 0; }      // (no traceback to do: walk_body finds out the same way and never asks for a code)
+    walk_body(P, i, d, w, best_key);
+}
+
+template <int K, bool S8>
+VGK_HD void rewalk_one(const GsswParams& P, uint32_t i, unsigned long long best_key, uint32_t* win, uint32_t win_stride) {
+    if (P.results[i].status != W_MISSED) return;        // the band served this read's walk (nearly all of them)
+    const ProbDesc d = P.probs[i];
+    const WaveDesc wd = P.waves[d.wave];        // the band served this read's walk (nearly all of them)
+    ReWalker<K, S8> w{Walker{P, d, (d.geom >> 16) & 1u, d.lane0, d.geom & 0xffu, wd.tb_off, 0u, 0xffffffffu, 0u, 0xffffffffu}, win, win_stride, wd.n_steps};
+    w.prob_index = i;
+    walk_body(P, i, d, w, best_key);
 }
 
 }  // namespace vgk

@@ -216,7 +216,7 @@ VGK_HD void win_wave_one(const WinParams& P, uint32_t w) {
     wd.n_steps = rmax ? rmax + bk.G - 1 : 0;
     if (wd.n_steps) acc_add(&P.totals->wave_steps, wd.n_steps);
     P.waves[w] = wd;
-    P.wave_tb[w] = P.want_tb ? (unsigned long long)((wd.n_steps + TB_TILE - 1) / TB_TILE * TB_TILE) * 64ull * ((bk.K + 3) / 4) : 0ull;
+    P.wave_tb[w] = P.want_tb ? (unsigned long long)tb_wave_dwords(wd.n_steps, bk.K) : 0ull;
 }
 VGK_HD void win_wave_tb_one(const WinParams& P, uint32_t w) {       // after the prefix sums over wave_tb
     if (w < P.totals->n_waves && w < P.n_waves_cap) P.waves[w].tb_off = P.wave_tb[w];

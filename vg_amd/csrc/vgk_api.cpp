@@ -126,11 +126,11 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     } lease{ctx, ctx->staging_acquire()};
     b->probs = (ProbDesc*)ctx->host_take((uint64_t)std::max<uint32_t>(n, 1u) * sizeof(ProbDesc), b->probs_bytes);
     ProbDesc* probs = b->probs;
-    struct Sizes { uint32_t reads = 0, prof = 0, cols = 0, nodes = 0, preds = 0, pred_at = 0; int status = VGK_OK; bool want_tb = false, malformed = false; };
+    struct Sizes { uint32_t reads = 0, prof = 0, cols = 0, nodes = 0, preds = 0, pred_at = 0; int status = VGK_OK; bool want_tb = false, malformed = false, far = false; };
     Sizes* sizes = (Sizes*)lease.s->get(6, (uint64_t)std::max<uint32_t>(n, 1u) * sizeof(Sizes));
     if (!probs || !sizes) return VGK_ENOMEM;
     std::vector<uint32_t> thread_maxL(MAX_THREADS, 1u);
-    struct Flags { std::vector<uint8_t> store, slow; };
+    struct Flags { std::vector<uint8_t> store, slow; std::vector<uint32_t> col_end; };
     std::vector<Flags> thread_flags(MAX_THREADS);
     // store[v]: the node's last column is saved for a successor / the pinned end; slow[v]: its first column is seeded from scratch
     auto node_flags = [&](const vgk_gssw_problem& p, bool xdrop, uint32_t mode, Flags& f) -> int {
@@ -176,7 +176,12 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         Flags& f = thread_flags[t];
         if ((z.status = node_flags(p, xdrop, mode, f)) != VGK_OK) return;
         uint64_t col = 0; uint32_t slots = 0;
-        for (uint32_t v = 0; v < g.n_nodes; ++v) { col += g.node_len[v]; slots += f.store[v]; }
+        f.col_end.resize(g.n_nodes);
+        for (uint32_t v = 0; v < g.n_nodes; ++v) {
+            // a predecessor that ends more than TB_JUMP columns before this node starts: tracebacks over that edge leave the band (batch.hpp)
+            for (uint32_t k = g.pred_off[v]; k < g.pred_off[v + 1]; ++k) z.far |= col - f.col_end[g.pred_idx[k]] > TB_JUMP;
+            col += g.node_len[v]; slots += f.store[v]; f.col_end[v] = (uint32_t)col;
+        }
         if (col >= (1u << 20)) { z.status = VGK_ETOOBIG; return; }
         d.R = (uint32_t)col; d.n_slots = slots;
         uint32_t pK, pG; geometry(d.L, pK, pG);
@@ -200,7 +205,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     }
     // Offsets into the shared arenas: prefix sums over the problems, in chunks — totals per chunk on the host threads, a serial
     // scan over the chunk totals, then the offsets inside every chunk on the host threads again.
-    struct Totals { uint64_t scratch = 0, ops = 0, reads = 0, prof = 0, cols = 0, nodes = 0, preds = 0, cells = 0, tb_cells = 0, in_bytes = 0; int status = VGK_OK; bool want_tb = false; };
+    struct Totals { uint64_t scratch = 0, ops = 0, reads = 0, prof = 0, cols = 0, nodes = 0, preds = 0, cells = 0, tb_cells = 0, in_bytes = 0; int status = VGK_OK; bool want_tb = false, far = false; };
     const uint32_t n_chunks = chunk_count(n);
     std::vector<Totals> chunk_tot(n_chunks), chunk_at(n_chunks);
     parallel_chunks(n, [&](uint32_t lo, uint32_t hi, uint32_t c) {
@@ -208,7 +213,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         for (uint32_t i = lo; i < hi; ++i) {
             const Sizes& z = sizes[i]; const ProbDesc& d = probs[i];
             if (z.status != VGK_OK) { t.status = z.status; break; }               // the first failing problem of the chunk
-            t.want_tb |= z.want_tb;
+            t.want_tb |= z.want_tb; t.far |= z.far;
             t.scratch += (uint64_t)d.n_slots * d.Lpad; t.ops += d.ops_cap;
             t.nodes += z.nodes; t.reads += z.reads; t.prof += z.prof; t.cols += (z.cols + 3ull) & ~3ull; t.preds += z.preds;   // every column stream starts on a dword
             t.cells += (uint64_t)d.R * d.L;
@@ -223,7 +228,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         if (t.status != VGK_OK) return t.status;
         chunk_at[c] = all;
         all.scratch += t.scratch; all.ops += t.ops; all.nodes += t.nodes; all.reads += t.reads; all.prof += t.prof; all.cols += t.cols; all.preds += t.preds;
-        all.cells += t.cells; all.tb_cells += t.tb_cells; all.in_bytes += t.in_bytes; all.want_tb |= t.want_tb;
+        all.cells += t.cells; all.tb_cells += t.tb_cells; all.in_bytes += t.in_bytes; all.want_tb |= t.want_tb; all.far |= t.far;
     }
     const uint64_t scratch_words = all.scratch, ops_total = all.ops, n_reads = all.reads, n_prof = all.prof, n_cols = all.cols, n_nodes = all.nodes, n_preds = all.preds;
     if (scratch_words >= (1ull << 32) || ops_total >= (1ull << 32) || n_cols >= (1ull << 32) || n_reads >= (1ull << 32) || n_nodes >= (1ull << 32) || n_preds >= (1ull << 32)) return VGK_ETOOBIG;
@@ -410,7 +415,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
                 probs[i].wave = w; probs[i].lane0 = q * bk.G; probs[i].geom = bk.K | (bk.G << 8) | (h << 16);
             }
         wd.n_steps = rmax ? rmax + bk.G - 1 : 0;
-        wd.tb_off = b->want_tb ? (uint64_t)((wd.n_steps + TB_TILE - 1) / TB_TILE * TB_TILE) * 64 * ((bk.K + 3) / 4) : 0;   // size for now
+        wd.tb_off = b->want_tb ? tb_wave_dwords(wd.n_steps, bk.K) : 0;   // size for now
         waves[w] = wd;
     });
     uint64_t tb_dwords = 0;
@@ -439,6 +444,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     P.want_tb = b->want_tb ? 1 : 0;
     P.fused = 0;
     if (const char* e = std::getenv("VGAMD_FUSED_TRACEBACK")) P.fused = std::atoi(e) ? 1 : 0;
+    P.tb_mode = default_tb_mode(P.fused, !all.far);
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = ops_total;
     if ((rc = ctx->be->sync_side())) return fail(rc);     // inputs are resident in HBM when pack returns (the uploads have their own stream)

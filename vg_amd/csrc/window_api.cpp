@@ -6,6 +6,7 @@
 // GSSWAligner::create_gssw_graph converts it (src/aligner.cpp:30-85).  With the graph resident the host's share per read is
 // 32 + read_len bytes of memcpy into page-locked staging; everything else is derived by kernels from the resident tables.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -63,6 +64,12 @@ int vgk_graph_create(vgk_ctx* ctx, const vgk_graph* graph, vgk_dgraph** out) try
         if (cols >= (1ull << 32) - 16) return VGK_ETOOBIG;
     }
     col[n] = (uint32_t)cols;
+    std::vector<uint32_t> far_prefix((size_t)n + 1, 0);
+    for (uint32_t v = 0; v < n; ++v) {
+        bool far = false;
+        for (uint32_t k = g.pred_off[v]; k < g.pred_off[v + 1]; ++k) far |= col[v] - col[g.pred_idx[k] + 1] > TB_JUMP;
+        far_prefix[v + 1] = far_prefix[v] + (far ? 1u : 0u);
+    }
     uint32_t s = 0;
     for (uint32_t v = 0; v < n; ++v) { slot[v] = s; s += store[v]; }
     slot[n] = s;
@@ -75,7 +82,7 @@ int vgk_graph_create(vgk_ctx* ctx, const vgk_graph* graph, vgk_dgraph** out) try
     });
     std::unique_ptr<vgk_dgraph> dg(new (std::nothrow) vgk_dgraph());
     if (!dg) return VGK_ENOMEM;
-    dg->ctx = ctx;
+    dg->ctx = ctx; dg->far_prefix.swap(far_prefix);
     Backend* be = ctx->be.get();
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto put = [&](const void* src, size_t bytes, const void*& dst) -> int {
@@ -142,6 +149,21 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     auto take_temp = [&](uint64_t bytes) -> void* { uint64_t got = 0; void* p = ctx->dev_take(bytes ? bytes : 16, got); if (p) temp.push_back({p, got}); return p; };
     auto take_keep = [&](uint64_t bytes) -> void* { uint64_t got = 0; void* p = ctx->dev_take(bytes ? bytes : 16, got); if (p) { b->dev.push_back({p, got}); b->dev_bytes += bytes; } return p; };
 
+    // does every window keep its tracebacks near a diagonal?  (host-side: the windows are the caller's array; a window's first node has
+    // lost its predecessors, the others must not have a far one)
+    bool near_chain = false;
+    if (!on_device && !dg->far_prefix.empty()) {
+        std::atomic<bool> far{false};
+        const std::vector<uint32_t>& fp = dg->far_prefix; const uint32_t gn = dg->g.n_nodes;
+        parallel_chunks(n, [&](uint32_t lo, uint32_t hi, uint32_t) {
+            for (uint32_t i = lo; i < hi; ++i) {
+                const vgk_window_problem& w = problems[i];
+                if (w.n_nodes < 2 || w.first_node >= gn || w.n_nodes > gn - w.first_node) continue;      // (malformed windows are reported by the packer)
+                if (fp[w.first_node + w.n_nodes] != fp[w.first_node + 1]) { far.store(true, std::memory_order_relaxed); break; }
+            }
+        });
+        near_chain = !far.load();
+    }
     const uint32_t n1 = n + 1;
     const uint32_t waves_cap = n / 2 + WIN_BUCKETS + 1;
     WinParams W{};
@@ -241,7 +263,7 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     P.bias = ctx->bias * S; P.go = ctx->sc.gap_open * S; P.ge = ctx->sc.gap_extend * S; P.bonus = ctx->sc.full_length_bonus * (int32_t)S;
     P.scale = S; P.xoff = XOFF * S;
     P.want_tb = b->want_tb ? 1 : 0;
-    P.fused = 0;
+    P.fused = 0; P.tb_mode = default_tb_mode(0, near_chain);
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = T.tot[WS_OPS]; b->wave_steps = T.wave_steps;
     lap("done");
