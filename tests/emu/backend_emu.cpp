@@ -341,7 +341,7 @@ public:
                     const uint32_t rh = l ? oh[l - 1] : 0, rf = l ? of[l - 1] : 0, ri = l ? oi[l - 1] : 0;
                     if (P.tb_mode == TB_REWALK) {
                         lane_step<K, S8, false>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr);
-                        if (P.want_tb) lane_store_boundary<K>(lanes[l], P, wd, t, l);
+                        if (P.want_tb) { lane_store_boundary<K>(lanes[l], P, wd, t, l); lane_store_checkpoint<K>(lanes[l], P, wd, t, l); }
                         continue;
                     }
                     uint32_t* tb_a = P.want_tb ? P.tb + tb_dword(wd.tb_off, t, l, REC, 0) : nullptr;
@@ -386,8 +386,10 @@ public:
             }
             for (uint32_t i = 0; i < P.n_problems; ++i) bandwalk_one(P, i, P.best[i]);
             std::vector<uint32_t> win((TB_CKPT / 2) * 6);          // one lane's window (stride 1)
-            for (uint32_t i = 0; i < P.n_problems; ++i) {
-                if (P.results[i].status == W_MISSED) ++band_misses;
+            const uint32_t n_missed = *tb_miss_count(P);
+            band_misses += n_missed;
+            for (uint32_t km = 0; km < n_missed; ++km) {
+                const uint32_t i = tb_miss_list(P)[km];
                 const uint32_t K = P.probs[i].geom & 0xffu; const bool s8 = P.scale == 8;
                 switch (K) {
                     case 16: if (s8) rewalk_one<16, true>(P, i, P.best[i], win.data(), 1); else rewalk_one<16, false>(P, i, P.best[i], win.data(), 1); break;

@@ -87,7 +87,7 @@ def chains_and_bubbles(lib):
     problems += [chain_problem(rng, capi.VGK_GSSW_LOCAL, 150, 13, 32, indel=0.15) for _ in range(40)]      # gaps: walks that drift out of their band
     problems += [chain_problem(rng, capi.VGK_GSSW_LOCAL, 150, 13, 32, traceback=False) for _ in range(10)]
     problems += [bubble_chain_problem(rng, m, int(rng.integers(60, 400)), 12, 40) for m in MODES * 15]
-    # the packers' own choice on these: chains -> TB_REWALK, the bubble graphs (a 3-base allele beside a skipped one) mostly TB_CODES
+    # the packers' own choice (stored codes unless asked otherwise)
     ps = problem_set(problems); sc = capi.Scoring.simple()
     with env(VGAMD_TB_REWALK=None, VGAMD_TB_CODES=None):
         ra, oa = capi.Engine(sc, lib=lib).align(ps)

@@ -61,7 +61,7 @@ struct TbStage {
 template <int K, bool S8, bool REWALK>
 __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const GsswParams P) {
     constexpr uint32_t REC = (K + 3) / 4;   // dwords per (step, lane) traceback record
-    __shared__ __attribute__((aligned(16))) uint32_t stage_lds[4][TB_TILE > 1 ? TbStage<K>::DWORDS : 256u];      // (also the fused walk's best keys, below)
+    __shared__ __attribute__((aligned(16))) uint32_t stage_lds[4][REWALK ? 64u * TB_BND_CHUNK * 2u : (TB_TILE > 1 ? TbStage<K>::DWORDS : 256u)];      // (also the fused walk's best keys, below)
     const uint32_t wave = P.wave_begin + blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     if (wave >= P.wave_begin + P.wave_count) return;
@@ -79,7 +79,24 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
         if constexpr (REWALK) {
             // the recurrence alone; what the traceback needs to run a window of it again (gssw_device.hpp, TB_REWALK)
             lane_step<K, S8, false>(s, P, t, rh, rf, ri, nullptr, nullptr);
-            if (tb) lane_store_boundary<K>(s, P, wd, t, lane);
+            if (tb) {
+                // boundary rows: TB_BND_CHUNK steps gathered per lane in LDS (slot index XOR lane: the per-step writes and the flush's reads
+                // both spread over the banks), then each lane's chunk leaves as one 128-byte line of the lane-major layout
+                uint32_t* st = stage_lds[threadIdx.x >> 6] + lane * (TB_BND_CHUNK * 2u);
+                const uint32_t slot = (t ^ lane) & (TB_BND_CHUNK - 1u);
+                *reinterpret_cast<uint2*>(st + slot * 2u) = make_uint2(s.out_h, s.out_f);
+                if ((t & (TB_BND_CHUNK - 1u)) == TB_BND_CHUNK - 1u || t + 1u == wd.n_steps) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    uint4* out = reinterpret_cast<uint4*>(tb + tb_bnd(wd.tb_off, wd.n_steps, t & ~(TB_BND_CHUNK - 1u), lane));
+#pragma unroll
+                    for (uint32_t j = 0; j < TB_BND_CHUNK; j += 2) {
+                        const uint2 a = *reinterpret_cast<const uint2*>(st + ((j ^ lane) & (TB_BND_CHUNK - 1u)) * 2u), b = *reinterpret_cast<const uint2*>(st + (((j + 1u) ^ lane) & (TB_BND_CHUNK - 1u)) * 2u);
+                        out[j >> 1] = make_uint4(a.x, a.y, b.x, b.y);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                }
+                lane_store_checkpoint<K>(s, P, wd, t, lane);
+            }
         } else if constexpr (TB_TILE > 1) {
             lane_step<K, S8>(s, P, t, rh, rf, ri, tb ? stage.slot_a(t, lane) : nullptr, stage.slot_b(t, lane));
             if (tb && ((t % TB_TILE) == TB_TILE - 1u || t + 1u == wd.n_steps)) stage.flush(tb + tb_tile_base(wd.tb_off, t, REC), lane);
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P, cons
 // TB_REWALK (gssw_device.hpp), first the band: the fill's wavefronts again — same grid, same lane <-> (pair, lane block) map — each lane over
 // the band columns of its lane block with the code-building lane code; no lane talks to another (the rows above come from HBM).
 template <int K, bool S8>
-__global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_band_kernel(const GsswParams P) {
+__global__ __launch_bounds__(256, 2) void gssw_band_kernel(const GsswParams P) {
     const uint32_t wave = P.wave_begin + blockIdx.x * 4u + (threadIdx.x >> 6);
     if (wave >= P.wave_begin + P.wave_count) return;
     band_fill_lane<K, S8>(P, P.waves[wave], threadIdx.x & 63u);
@@ -155,13 +172,12 @@ __global__ __launch_bounds__(256) void gssw_bandwalk_kernel(const GsswParams P) 
 template <int K, bool S8>
 __global__ __launch_bounds__(64, 2) void gssw_rewalk_kernel(const GsswParams P) {
     __shared__ uint32_t win[(TB_CKPT / 2) * ((K + 3) / 4) * 64];
-    const uint32_t pair_begin = P.waves[P.wave_begin].first_pair;
-    const uint32_t wave_end = P.wave_begin + P.wave_count;
-    const uint32_t pair_end = wave_end < P.n_waves ? P.waves[wave_end].first_pair : P.n_pairs;
-    const uint32_t k = 2u * pair_begin + blockIdx.x * 64u + threadIdx.x;
-    if (k >= 2u * pair_end) return;
-    const uint32_t i = P.order[k];
-    if (i != 0xffffffffu) rewalk_one<K, S8>(P, i, P.best[i], win + threadIdx.x, 64u);
+    const uint32_t count = *tb_miss_count(P);
+    const uint32_t* list = tb_miss_list(P);
+    for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < count; k += gridDim.x * 64u) {
+        const uint32_t i = list[k];
+        rewalk_one<K, S8>(P, i, P.best[i], win + threadIdx.x, 64u);
+    }
 }
 
 // ---- CIGAR ops on their way back: exclusive prefix sums of the per-problem op counts, then a gather ------------------
@@ -926,7 +942,7 @@ public:
     // the recomputing tracebacks of one fill launch's reads (p.K / wave_begin / wave_count as for the fill); the grid covers every pair
     // of the batch (the launch's own count is a device-side fact for batches packed there): blocks beyond its reads leave at once
     template <int K> void launch_rewalk_k(const GsswParams& p, hipStream_t stream) {
-        const dim3 grid((2 * p.n_pairs + 63) / 64), block(64);
+        const dim3 grid(1024), block(64);                   // (the reads that left their band: a list in HBM whose length only the device knows; each lane takes every 65536th)
         if (p.scale == 8) hipLaunchKernelGGL((gssw_rewalk_kernel<K, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_rewalk_kernel<K, false>), grid, block, 0, stream, p);
     }
     template <int K> void launch_band_k(const GsswParams& p, hipStream_t stream) {

@@ -34,18 +34,22 @@ inline int nt_ref(char ch) {    // after nonATGCNtoN (src/aligner.cpp:39): upper
     switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
 }
 
-// Which traceback a batch runs (gssw_device.hpp).  The recomputing one (TB_REWALK) lays its band along the diagonal through the end cell, in
-// COLUMN space: it serves a path as long as walking back over a node boundary moves it at most a few columns beyond the previous node's
-// end — chains, SNP bubbles, short insertions.  A predecessor that ends more than TB_JUMP columns before its successor starts (the other side
-// of a long bubble; a sibling subtree of a tail forest) throws the path out of the band and onto the slow on-demand form, so a batch with
-// such an edge keeps the stored codes (TB_CODES).  So do the tiled code layout and the fused walk.  VGAMD_TB_CODES=1 / VGAMD_TB_REWALK=1
-// force either (tests run the random DAGs through the band and its fallback that way).
+// Which traceback a batch runs (gssw_device.hpp).  TB_CODES — the fill stores a 4-bit code per cell — is the default.  Measured on the MI355X
+// (profiles/r04), per million 150 bp reads: the recomputing form TB_REWALK takes the fill from 19.3 to 14.8-15.6 ms, but then
+// spends 5.2 ms recomputing the band (1.1 of it finding end cells and loading checkpoints), 4.3 ms walking it — no less than the walk over
+// stored codes, which is bound by the latency of its scattered reads either way — and 1.3 ms on the handful of reads that leave their
+// band (one on-demand walk's own latency): 26.4 ms against 24.3.  It is kept, exact and tested, behind VGAMD_TB_REWALK=1.
+// Its band lies along the diagonal through the end cell in COLUMN space: it serves a path as long as walking back over a node boundary
+// moves it at most a few columns beyond the previous node's end — chains, SNP bubbles, short insertions; a predecessor that ends more than
+// TB_JUMP columns before its successor starts (the far side of a long bubble, a sibling subtree of a tail forest) throws the path onto the slow
+// on-demand form — `near_chain` says the batch has no such edge (the packers work it out; it would gate the mode if it became the default).
 constexpr uint32_t TB_JUMP = TB_SLACK / 2;
 inline int32_t default_tb_mode(int fused, bool near_chain) {
+    (void)near_chain;
     if (TB_TILE > 1 || fused) return TB_CODES;
     if (const char* e = std::getenv("VGAMD_TB_CODES")) if (std::atoi(e)) return TB_CODES;
     if (const char* e = std::getenv("VGAMD_TB_REWALK")) if (std::atoi(e)) return TB_REWALK;
-    return near_chain ? TB_REWALK : TB_CODES;
+    return TB_CODES;
 }
 
 template <class T>

@@ -116,6 +116,7 @@ struct GsswParams {
     int32_t  want_tb;           // any problem wants traceback -> store codes
     int32_t  tb_mode;           // TB_CODES: the fill stores a 4-bit code per cell; TB_REWALK: it stores what the traceback needs to compute them again
                                 // where the path runs (see "the traceback that does not tax the fill" below)
+    int32_t  dbg;               // timing experiments (VGAMD_TB_DBG; results are wrong when set): 1 = the band kernel stops after its first column, 2 = it stores nothing
     int32_t  fused;             // 1 = each wavefront traces its own reads back at the end of the fill kernel
     uint32_t scale;             // 1 or 8: every DP quantity above (prof4, bias, go, ge, bonus, xoff, scratch) is pre-multiplied.
                                 // With 8, non-zero score differences are >= 8, so min(diff, 1|2|4|8) yields the four traceback
@@ -587,7 +588,7 @@ constexpr int32_t  W_MISSED = 100;             // vgk_result::status of a read w
 // The traceback proper, over whatever serves the codes: W = Walker (the codes the fill stored), BandWalker (recomputed in a band around the
 // end cell's diagonal) or ReWalker (recomputed on demand, window by window).
 template <class W>
-VGK_HD void walk_body(const GsswParams& P, uint32_t i, const ProbDesc& d, W& w, unsigned long long best_key) {
+VGK_HD int32_t walk_body(const GsswParams& P, uint32_t i, const ProbDesc& d, W& w, unsigned long long best_key) {
     constexpr uint32_t W_SPEC = W::SPEC;
     vgk_result res;
     res.score = 0; res.status = VGK_OK; res.end_node = -1; res.end_offset = -1; res.end_read = -1;
@@ -601,12 +602,12 @@ VGK_HD void walk_body(const GsswParams& P, uint32_t i, const ProbDesc& d, W& w, 
 
     int32_t cur = 0; uint32_t c = 0, node = 0; int32_t r = 0;
     const bool have = walk_end_cell(P, d, best_key, [&](const NodeRec& n, uint32_t row) { return w.saved(n, row); }, cur, c, node, r);
-    if (pinned && !have) { res.status = VGK_EINVAL; P.results[i] = res; return; }
-    if (cur >= 2047 * S) { res.status = VGK_EOVERFLOW; P.results[i] = res; return; }
-    if (!have || cur <= zero) { P.results[i] = res; return; }  // score 0: the caller synthesises soft clips / full insertion
+    if (pinned && !have) { res.status = VGK_EINVAL; P.results[i] = res; return VGK_EINVAL; }
+    if (cur >= 2047 * S) { res.status = VGK_EOVERFLOW; P.results[i] = res; return VGK_EOVERFLOW; }
+    if (!have || cur <= zero) { P.results[i] = res; return VGK_OK; }  // score 0: the caller synthesises soft clips / full insertion
     res.score = (cur - zero) / S; res.end_node = (int32_t)node; res.end_offset = (int32_t)(c - nodes[node].col_start);
     res.end_read = xdrop ? r - 1 : r;
-    if (!(d.flags & VGK_GSSW_TRACEBACK)) { P.results[i] = res; return; }
+    if (!(d.flags & VGK_GSSW_TRACEBACK)) { P.results[i] = res; return VGK_OK; }
 
     // CIGAR elements are produced back to front into the tail of this read's window.  The run being
     // built lives in registers (rn, ro, rl) and is written once, when a different (node, op) starts.
@@ -712,6 +713,7 @@ VGK_HD void walk_body(const GsswParams& P, uint32_t i, const ProbDesc& d, W& w, 
         res.first_offset = (int32_t)(first_c - node_start);
     }
     P.results[i] = res;
+    return status;
 }
 
 VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
@@ -736,7 +738,7 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
 // 150-base path crosses ~8 lane blocks and ~2 windows in each: ~5 000 of the 62 000 cells are computed a second time.
 // ---------------------------------------------------------------------------
 enum : int32_t { TB_CODES = 0, TB_REWALK = 1 };
-constexpr uint32_t TB_CKPT = 32;         // columns between two checkpoints = the widest window (even: the window keeps two columns per dword)
+constexpr uint32_t TB_CKPT = 16;         // columns between two checkpoints = the widest window (even: the window keeps two columns per dword)
 
 // The band: a traceback runs close to the diagonal through its end cell, so the codes it will ask for can be computed BEFORE it starts —
 // for every lane block of a read at once, which the on-demand form (a window when the walk gets there) cannot: lane block g needs the
@@ -762,26 +764,36 @@ VGK_HD TbBand tb_band_of(uint32_t r_e, uint32_t c_e, uint32_t g, uint32_t K) {
     return b;
 }
 
+constexpr uint32_t TB_BND_CHUNK = 16;    // steps of boundary rows the fill writes at a time (16 x 8 bytes = one line per lane)
+VGK_HD uint32_t tb_steps_padded(uint32_t n_steps) { return (n_steps + TB_BND_CHUNK - 1u) / TB_BND_CHUNK * TB_BND_CHUNK; }
+VGK_HD uint64_t tb_bnd_dwords(uint32_t n_steps) { return 128ull * tb_steps_padded(n_steps); }
+
 // dwords of a wavefront's traceback arena: enough for either form
 VGK_HD uint64_t tb_wave_dwords(uint32_t n_steps, uint32_t K) {
     const uint64_t rec = (K + 3u) >> 2;
     const uint64_t codes = (uint64_t)((n_steps + TB_TILE - 1) / TB_TILE * TB_TILE) * 64u * rec;
-    const uint64_t rewalk = (uint64_t)n_steps * 128u + (uint64_t)((n_steps + TB_CKPT - 1) / TB_CKPT) * 128u * K + 64ull * tb_band_cols(K) * rec;
+    const uint64_t rewalk = tb_bnd_dwords(n_steps) + (uint64_t)((n_steps + TB_CKPT - 1) / TB_CKPT) * 128u * K + 64ull * tb_band_cols(K) * rec;
     return codes > rewalk ? codes : rewalk;
 }
-VGK_HD uint64_t tb_bnd(uint64_t tb_off, uint32_t t, uint32_t lane) { return tb_off + ((uint64_t)t * 64u + lane) * 2u; }      // {out_h, out_f} of (step, lane)
+// {out_h, out_f} of (step, lane): LANE-major — a lane's steps lie behind each other, because whoever computes a window or a band again
+// reads ONE lane's run of consecutive steps (step-major, 64 x 66 scattered 8-byte reads per wavefront made the band kernel 3.5 x slower than
+// its arithmetic: profiles/r04).  The fill gathers TB_BND_CHUNK steps in LDS and writes a lane's chunk as one 128-byte line.
+VGK_HD uint64_t tb_bnd(uint64_t tb_off, uint32_t n_steps, uint32_t t, uint32_t lane) { return tb_off + ((uint64_t)lane * tb_steps_padded(n_steps) + t) * 2u; }
 VGK_HD uint64_t tb_ckpt(uint64_t tb_off, uint32_t n_steps, uint32_t cb, uint32_t lane, uint32_t K) {                         // H[K] then E[K] after column cb * TB_CKPT + TB_CKPT - 1
-    return tb_off + (uint64_t)n_steps * 128u + ((uint64_t)cb * 64u + lane) * 2u * K;
+    return tb_off + tb_bnd_dwords(n_steps) + ((uint64_t)cb * 64u + lane) * 2u * K;
 }
 VGK_HD uint64_t tb_band(uint64_t tb_off, uint32_t n_steps, uint32_t x, uint32_t lane, uint32_t K) {                          // the record (ceil(K/4) dwords, both reads of the pair) of band column x of a lane
-    return tb_off + (uint64_t)n_steps * 128u + (uint64_t)((n_steps + TB_CKPT - 1) / TB_CKPT) * 128u * K + ((uint64_t)x * 64u + lane) * ((K + 3u) >> 2);
+    return tb_off + tb_bnd_dwords(n_steps) + (uint64_t)((n_steps + TB_CKPT - 1) / TB_CKPT) * 128u * K + ((uint64_t)x * 64u + lane) * ((K + 3u) >> 2);
 }
 
 // the fill's stores in this mode, after lane_step<K, S8, false> of step t
 template <int K>
-VGK_HD void lane_store_boundary(const Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint32_t t, uint32_t lane) {
-    uint32_t* b = P.tb + tb_bnd(wd.tb_off, t, lane);
+VGK_HD void lane_store_boundary(const Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint32_t t, uint32_t lane) {      // (the emulator: straight to its place)
+    uint32_t* b = P.tb + tb_bnd(wd.tb_off, wd.n_steps, t, lane);
     b[0] = s.out_h; b[1] = s.out_f;
+}
+template <int K>
+VGK_HD void lane_store_checkpoint(const Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint32_t t, uint32_t lane) {
     const uint32_t c = t - s.g;                                   // the column this lane has just finished
     if (t >= s.g && (c & (TB_CKPT - 1u)) == TB_CKPT - 1u && !((s.info & CI_INVALID) && (s.info & (CI_INVALID << 16)))) {
         uint32_t* k = P.tb + tb_ckpt(wd.tb_off, wd.n_steps, c / TB_CKPT, lane, (uint32_t)K);
@@ -857,12 +869,12 @@ struct ReWalker {
             node = lo;
         }
         s.nodeA = s.nodeB = node;
-        s.prev_rh = (c0 && g) ? P.tb[tb_bnd(tb_off, c0 - 1u + g - 1u, lane - 1u)] & keep : 0u;
+        s.prev_rh = (c0 && g) ? P.tb[tb_bnd(tb_off, n_steps, c0 - 1u + g - 1u, lane - 1u)] & keep : 0u;
         uint32_t pend[REC];
         for (uint32_t col = c0; col <= c; ++col) {
             const uint32_t t = col + g;
             uint32_t rh = 0, rf = 0;
-            if (g) { const uint32_t* b = P.tb + tb_bnd(tb_off, t - 1u, lane - 1u); rh = b[0] & keep; rf = b[1] & keep; }
+            if (g) { const uint32_t* b = P.tb + tb_bnd(tb_off, n_steps, t - 1u, lane - 1u); rh = b[0] & keep; rf = b[1] & keep; }
             const uint32_t ci = P.colinfo[d.col_off + col];
             const uint32_t rinfo = half ? ((uint32_t)CI_INVALID | (ci << 16)) : (ci | ((uint32_t)CI_INVALID << 16));
             uint32_t rec[REC];
@@ -927,30 +939,47 @@ VGK_HD void band_fill_lane(const GsswParams& P, const WaveDesc& wd, uint32_t lan
             uint32_t lo = 0, hi = d.n_nodes;
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (nodes[mid].col_start <= bd[h].cs - 1u) lo = mid; else hi = mid; }
             node = lo;
-            if (g) prev |= P.tb[tb_bnd(wd.tb_off, bd[h].cs - 1u + g - 1u, lane - 1u)] & keep;
+            if (g) prev |= P.tb[tb_bnd(wd.tb_off, wd.n_steps, bd[h].cs - 1u + g - 1u, lane - 1u)] & keep;
         }
         if (h) s.nodeB = node; else s.nodeA = node;
     }
     s.prev_rh = prev;
-    const uint32_t n_cols = tb_band_cols((uint32_t)K);
-    for (uint32_t x = 0; x < n_cols; ++x) {
-        uint32_t rinfo = CI_INVALID2, rh = 0, rf = 0;
+    // the columns: each half's column bytes and the rows above it are runs in memory (column stream; lane - 1's boundary rows), read one
+    // column AHEAD of the arithmetic so that a load's latency lies under a column of DP
+    uint32_t n_col[2]; const uint8_t* ci_at[2]; const uint32_t* up_at[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        n_col[h] = bd[h].used ? bd[h].hi - bd[h].cs + 1u : 0u;
+        ci_at[h] = nullptr; up_at[h] = nullptr;
+        if (n_col[h]) {
+            ci_at[h] = P.colinfo + P.probs[prob[h]].col_off + bd[h].cs;
+            if (g) up_at[h] = P.tb + tb_bnd(wd.tb_off, wd.n_steps, bd[h].cs + g - 1u, lane - 1u);
+        }
+    }
+    uint32_t n_max = n_col[0] > n_col[1] ? n_col[0] : n_col[1];
+    if ((P.dbg & 1) && n_max > 1u) n_max = 1u;
+    struct In { uint32_t rinfo, rh, rf; };
+    auto fetch = [&](uint32_t x) {
+        In in; in.rinfo = CI_INVALID2; in.rh = 0; in.rf = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const uint32_t col = bd[h].cs + x;
-            if (!bd[h].used || col > bd[h].hi) continue;
-            const ProbDesc& d = P.probs[prob[h]];
-            const uint32_t ci = P.colinfo[d.col_off + col];
-            rinfo = h ? (rinfo & 0x0000ffffu) | (ci << 16) : (rinfo & 0xffff0000u) | ci;
-            if (g) {
+            if (x >= n_col[h]) continue;
+            const uint32_t ci = ci_at[h][x];
+            in.rinfo = h ? (in.rinfo & 0x0000ffffu) | (ci << 16) : (in.rinfo & 0xffff0000u) | ci;
+            if (up_at[h]) {
                 const uint32_t keep = h ? 0xffff0000u : 0x0000ffffu;
-                const uint32_t* b = P.tb + tb_bnd(wd.tb_off, col + g - 1u, lane - 1u);
-                rh |= b[0] & keep; rf |= b[1] & keep;
+                in.rh |= up_at[h][2u * x] & keep; in.rf |= up_at[h][2u * x + 1u] & keep;
             }
         }
-        if (rinfo == CI_INVALID2) break;                            // both bands done (a band is a prefix of the columns)
-        uint32_t* out = P.tb + tb_band(wd.tb_off, wd.n_steps, x, lane, (uint32_t)K);
-        lane_column<K, S8, true, true>(s, P, x, rh, rf, rinfo, out, out + 4);
+        return in;
+    };
+    uint32_t* out = P.tb + tb_band(wd.tb_off, wd.n_steps, 0, lane, (uint32_t)K);
+    constexpr uint32_t OUT_STRIDE = 64u * ((K + 3) / 4);
+    In next = fetch(0);
+    for (uint32_t x = 0; x < n_max; ++x, out += OUT_STRIDE) {
+        const In in = next;
+        if (x + 1u < n_max) next = fetch(x + 1u);
+        lane_column<K, S8, true, true>(s, P, x, in.rh, in.rf, in.rinfo, (P.dbg & 2) ? nullptr : out, out + 4);
     }
 }
 
@@ -975,18 +1004,31 @@ struct BandWalker {
         return (src != 2u ? 1u : 0u) | (src == 0u ? 2u : 0u) | ((raw & 1u) ? 0u : 4u) | ((raw & 8u) ? 0u : 8u);
     }
 };
+// The reads whose walk left its band, for the on-demand form: a counter in best[n_problems] (zeroed with the keys before every run) and the
+// read indices behind it (the packers allocate best[] with that room).
+VGK_HD uint32_t* tb_miss_count(const GsswParams& P) { return reinterpret_cast<uint32_t*>(P.best + P.n_problems); }
+VGK_HD uint32_t* tb_miss_list(const GsswParams& P) { return reinterpret_cast<uint32_t*>(P.best + P.n_problems + 1); }
+VGK_HD uint64_t tb_best_entries(uint64_t n) { return n + 2u + (n + 1u) / 2u; }      // 64-bit words of best[]: the keys, the counter, the list
+VGK_HD void tb_miss_add(const GsswParams& P, uint32_t i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t k = atomicAdd(tb_miss_count(P), 1u);
+#else
+    const uint32_t k = (*tb_miss_count(P))++;
+#endif
+    tb_miss_list(P)[k] = i;
+}
 VGK_HD void bandwalk_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
     const ProbDesc d = P.probs[i];
     const WaveDesc wd = P.waves[d.wave];
     BandWalker w{Walker{P, d, (d.geom >> 16) & 1u, d.lane0, d.geom & 0xffu, wd.tb_off, 0u, 0xffffffffu, 0u, 0xffffffffu}, wd.n_steps, 0u, 0u};
     if (!tb_band_end(P, d, best_key, w.r_e, w.c_e)) { w.r_e = 0; w.c_e = 0; }      // (no traceback to do: walk_body finds out the same way and never asks for a code)
-    walk_body(P, i, d, w, best_key);
+    if (walk_body(P, i, d, w, best_key) == W_MISSED) tb_miss_add(P, i);
 }
 
 template <int K, bool S8>
 VGK_HD void rewalk_one(const GsswParams& P, uint32_t i, unsigned long long best_key, uint32_t* win, uint32_t win_stride) {
-    if (P.results[i].status != W_MISSED) return;        // the band served this read's walk (nearly all of them)
     const ProbDesc d = P.probs[i];
+    if ((d.geom & 0xffu) != (uint32_t)K) return;        // another rows-per-lane class's launch takes it
     const WaveDesc wd = P.waves[d.wave];        // the band served this read's walk (nearly all of them)
     ReWalker<K, S8> w{Walker{P, d, (d.geom >> 16) & 1u, d.lane0, d.geom & 0xffu, wd.tb_off, 0u, 0xffffffffu, 0u, 0xffffffffu}, win, win_stride, wd.n_steps};
     w.prob_index = i;

@@ -429,7 +429,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     if ((rc = to_device(b, order, P.order, 2))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)scratch_words + 16, P.scratch))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)tb_dwords + 4, P.tb))) return fail(rc);
-    if ((rc = dev_alloc(b, (size_t)n + 1, P.best))) return fail(rc);
+    if ((rc = dev_alloc(b, (size_t)tb_best_entries(n), P.best))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)n + 1, P.results))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)ops_total + 1, P.ops))) return fail(rc);
     lap("allocs");
@@ -444,7 +444,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     P.want_tb = b->want_tb ? 1 : 0;
     P.fused = 0;
     if (const char* e = std::getenv("VGAMD_FUSED_TRACEBACK")) P.fused = std::atoi(e) ? 1 : 0;
-    P.tb_mode = default_tb_mode(P.fused, !all.far);
+    P.dbg = std::getenv("VGAMD_TB_DBG") ? std::atoi(std::getenv("VGAMD_TB_DBG")) : 0; P.tb_mode = default_tb_mode(P.fused, !all.far);
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = ops_total;
     if ((rc = ctx->be->sync_side())) return fail(rc);     // inputs are resident in HBM when pack returns (the uploads have their own stream)

@@ -237,7 +237,7 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
         nodes = (NodeRec*)take_keep((T.tot[WS_NODES] + 1) * sizeof(NodeRec)); preds = (uint32_t*)take_keep((T.tot[WS_PREDS] + 1) * 4);
         waves = (WaveDesc*)take_keep((uint64_t)waves_cap * sizeof(WaveDesc)); order = (uint32_t*)take_keep(((uint64_t)waves_cap * 2 + 2) * 4);
         rc = dev_alloc(b, (size_t)T.tot[WS_SCRATCH] + 16, P.scratch);
-        if (!rc) rc = dev_alloc(b, (size_t)n + 1, P.best);
+        if (!rc) rc = dev_alloc(b, (size_t)tb_best_entries(n), P.best);
         if (!rc) rc = dev_alloc(b, (size_t)n + 1, P.results);
         if (!rc) rc = dev_alloc(b, (size_t)T.tot[WS_OPS] + 1, P.ops);
         if (!rc && (!colinfo || !rd || !nodes || !preds || !waves || !order)) rc = VGK_ENOMEM;
@@ -263,7 +263,7 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     P.bias = ctx->bias * S; P.go = ctx->sc.gap_open * S; P.ge = ctx->sc.gap_extend * S; P.bonus = ctx->sc.full_length_bonus * (int32_t)S;
     P.scale = S; P.xoff = XOFF * S;
     P.want_tb = b->want_tb ? 1 : 0;
-    P.fused = 0; P.tb_mode = default_tb_mode(0, near_chain);
+    P.fused = 0; P.dbg = std::getenv("VGAMD_TB_DBG") ? std::atoi(std::getenv("VGAMD_TB_DBG")) : 0; P.tb_mode = default_tb_mode(0, near_chain);
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = T.tot[WS_OPS]; b->wave_steps = T.wave_steps;
     lap("done");
