@@ -12,6 +12,8 @@
 #include "tail_stage.hpp"
 #include "gbwt_extender.hpp"
 #include "rescue_fixups.hpp"
+#include "mapq_cap.hpp"
+#include "extension_scoring.hpp"
 
 using namespace vgamd;
 
@@ -670,6 +672,28 @@ int32_t vgh_compute_mapping_quality(vgh_aligner* a, const double* scores, int n,
     return first ? a->a->mapq_calc->compute_first_mapping_quality(s, fast_approximation != 0) : a->a->mapq_calc->compute_max_mapping_quality(s, fast_approximation != 0);
 }
 double vgh_log_base(vgh_aligner* a) { return a->a->scorer->get_log_base(); }
+// MinimizerMapper::score_extension_group: intervals[3 k ..] = {read begin, read end, score} of extension k, in the extender's order
+int vgh_score_extension_group(uint64_t read_length, const int64_t* intervals, int n, int full_length, int gap_open, int gap_extend) {
+    std::vector<ScoredInterval> v((size_t)n);
+    for (int k = 0; k < n; ++k) { v[(size_t)k].begin = (size_t)intervals[3 * k]; v[(size_t)k].end = (size_t)intervals[3 * k + 1]; v[(size_t)k].score = (int32_t)intervals[3 * k + 2]; }
+    return score_extension_group((size_t)read_length, v, full_length != 0, gap_open, gap_extend);
+}
+// MinimizerMapper::faster_cap: minimizers flat, 6 numbers each {hash, offset, is_reverse, agglomeration_start, agglomeration_length, length};
+// explored = indices into them; quality = raw Phred bytes (n_quality 0: none).  *cap_out = the cap (inf without qualities); rc -1 where the
+// reference prints an error and exits.
+int vgh_faster_cap(const uint64_t* minimizers, int n_minimizers, const uint64_t* explored, int n_explored, const char* sequence, const unsigned char* quality, int n_quality, double* cap_out) {
+    try {
+        std::vector<CapMinimizer> ms((size_t)n_minimizers);
+        for (int i = 0; i < n_minimizers; ++i) {
+            CapMinimizer& m = ms[(size_t)i]; const uint64_t* q = minimizers + 6 * (size_t)i;
+            m.hash = q[0]; m.offset = (size_t)q[1]; m.is_reverse = q[2] != 0; m.agglomeration_start = (size_t)q[3]; m.agglomeration_length = (size_t)q[4]; m.length = (int32_t)q[5];
+        }
+        std::vector<size_t> ex(explored, explored + n_explored);
+        for (size_t e : ex) if (e >= ms.size()) throw std::runtime_error("faster_cap: explored minimizer out of range");
+        *cap_out = faster_cap(ms, ex, sequence, std::string((const char*)quality, (size_t)n_quality));
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
 // MinimizerMapper::fix_dozeu_end_deletions over an alignment given flat: positions[m] = {node id, offset, is_reverse} per mapping,
 // edits[k] = {mapping index, from_length, to_length, has sequence}; JSON out = the alignment afterwards
 static int fix_end_deletions_flat(const char* sequence, const int64_t* positions, int n_mappings, const int64_t* edits, int n_edits, bool reference_indexing, char* json_out, size_t json_cap);
