@@ -14,6 +14,8 @@
 #include "rescue_fixups.hpp"
 #include "mapq_cap.hpp"
 #include "extension_scoring.hpp"
+#include "aligner_client.hpp"
+#include <sstream>
 
 using namespace vgamd;
 
@@ -672,6 +674,31 @@ int32_t vgh_compute_mapping_quality(vgh_aligner* a, const double* scores, int n,
     return first ? a->a->mapq_calc->compute_first_mapping_quality(s, fast_approximation != 0) : a->a->mapq_calc->compute_max_mapping_quality(s, fast_approximation != 0);
 }
 double vgh_log_base(vgh_aligner* a) { return a->a->scorer->get_log_base(); }
+// The class shapes of aligner_client.hpp, exercised the way a mapper uses them: an AlignerClient whose scores come from a matrix stream,
+// its regular / quality-adjusted aligner picked by get_aligner; an XdropAligner (or its quality-adjusted twin) given the bonus per call.
+//   what = 0: AlignerClient(matrix text).get_aligner(have qualities)->align_pinned(xdrop = false)
+//   what = 1: XdropAligner(matrix from the client's parse).align_pinned(..., full_length_bonus, max_gap)
+//   what = 2: QualAdjXdropAligner likewise
+int vgh_client_align_pinned(const char* engine_lib, const char* matrix_text, int gap_open, int gap_extend, int full_length_bonus, int adjust_for_quality, int what,
+                            vgh_graph* g, const char* read, const uint8_t* qual, int pin_left, int max_gap, char* json_out, size_t json_cap) {
+    try {
+        auto eng = load_engine(engine_lib ? engine_lib : "");
+        Alignment aln; aln.sequence = read;
+        if (qual) aln.quality.assign(reinterpret_cast<const char*>(qual), aln.sequence.size());
+        std::istringstream in(matrix_text);
+        if (what == 0) {
+            AlignerClient client(0.5, eng, 0);
+            client.adjust_alignments_for_base_quality = adjust_for_quality != 0;
+            client.set_alignment_scores(in, (int8_t)gap_open, (int8_t)gap_extend, (int8_t)full_length_bonus);
+            client.get_aligner(qual != nullptr)->align_pinned(aln, g->g, pin_left != 0);
+        } else {
+            const std::vector<int8_t> m = AlignerClient::parse_matrix(in);
+            if (what == 1) { XdropAligner x(m.data(), (int8_t)gap_open, (int8_t)gap_extend, eng, 0); x.align_pinned(aln, g->g, pin_left != 0, (int8_t)full_length_bonus, (uint16_t)max_gap); }
+            else { QualAdjXdropAligner x(m.data(), (int8_t)gap_open, (int8_t)gap_extend, 0.5, eng, 0); x.align_pinned(aln, g->g, pin_left != 0, (int8_t)full_length_bonus, (uint16_t)max_gap); }
+        }
+        return emit(aln, json_out, json_cap);
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
 // MinimizerMapper::score_extension_group: intervals[3 k ..] = {read begin, read end, score} of extension k, in the extender's order
 int vgh_score_extension_group(uint64_t read_length, const int64_t* intervals, int n, int full_length, int gap_open, int gap_extend) {
     std::vector<ScoredInterval> v((size_t)n);
