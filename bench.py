@@ -416,6 +416,8 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
         return {"seeds": 0, "ext": 0, "tails": 0, "trees": 0, "tree_nodes": 0, "failed": 0, "full_length": 0, "truncated": 0}
 
     lanes = [(eng, index, mindex)]
+    # a streaming caller keeps its read buffers: page-locked once (vgk_host_register), they go up at the link's rate
+    pinned = [bool(eng.host_register(reads)) for reads, _ in wl.batches] if not os.environ.get("VGAMD_CONFIG2_PAGEABLE") else []
 
     def one_step(timing=None, keep=None):
         """one context, one batch after the other"""
@@ -499,6 +501,7 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
                        "timed_region": "per step, %d batches of %d reads from host buffers: vgk_minimizer_seeds (clusters stay in HBM) -> vgk_gapless_extend_seeded (sets come down under the "
                                        "tail stage) -> vgk_tail_stage_aligned%s" % (len(wl.batches), batch, "; two batches in flight: two engine contexts, one host thread each, alternate batches" if pipelined else ""),
                        "one_context": one_context,
+                       "read_buffers": "page-locked by the caller (vgk_host_register)" if pinned and all(pinned) else "pageable",
                        "policies": "every minimizer of a read looked up, hit cap 500 (hard cap), no downsampling / score-based selection (find_seeds' policies: not built); clusters = all seeds of a read",
                        "per_step": {k: v / steps for k, v in tot.items()} if steps == 1 else tot,
                        "ms_per_batch": 1e3 * elapsed / steps / len(wl.batches),
@@ -1297,7 +1300,7 @@ def main():
 # at a size that keeps the whole default run within a few minutes; a record keeps the line's metric, value, roofline, cpu_baseline and
 # parity.  A leg that fails or overruns its time limit leaves {"workload", "error"} — never a missing headline.
 SECONDARY = [
-    ("config2", ["--reads", "2000000", "--steps", "4", "--warmup", "2", "--cpu-sample", "50000"], 200),
+    ("config2", ["--reads", "4000000", "--steps", "4", "--warmup", "2", "--cpu-sample", "50000"], 240),
     ("gapless", ["--steps", "5", "--warmup", "2"], 90),
     ("xband", ["--steps", "3", "--warmup", "1"], 90),
     ("banded", ["--reads", "100000", "--steps", "5", "--warmup", "2"], 90),
@@ -1323,7 +1326,7 @@ def secondary_records():
                 d = json.loads(line[-1])
                 cfg = d.get("config") or {}
                 rec.update({k: d.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "cpu_baseline", "parity", "problems_failed")})
-                rec["config"] = {k: cfg.get(k) for k in ("workload", "timed_region", "ms_per_batch", "kernel_ms_per_batch", "stage_ms_per_batch", "one_context", "policies") if k in cfg}
+                rec["config"] = {k: cfg.get(k) for k in ("workload", "timed_region", "ms_per_batch", "kernel_ms_per_batch", "stage_ms_per_batch", "one_context", "read_buffers", "policies") if k in cfg}
         except subprocess.TimeoutExpired:
             rec["error"] = "time limit of %d s" % limit
         except Exception as e:                                # (a leg must never take the headline down)

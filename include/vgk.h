@@ -160,6 +160,12 @@ int  vgk_create_qual_adj(int device, const vgk_scoring* scoring, const vgk_qual_
 void vgk_destroy(vgk_ctx* ctx);
 int  vgk_device_info(vgk_ctx* ctx, char* name_out, size_t name_cap,
                      int* compute_units, size_t* hbm_bytes);
+/* A caller that streams batches out of buffers it keeps (reads, problem arrays) can page-lock them once: copies from a registered range
+ * run at the link's rate (~50 GB/s on PCIe 5 x16) instead of being staged through the runtime's bounce buffers (~10 GB/s — 150 MB of reads
+ * were 12 of the seeding call's 18 ms).  The range must stay mapped until it is unregistered; registering costs about a millisecond per
+ * 100 MB, so it pays for buffers that are reused.  Purely a transfer-rate matter: every entry point takes unregistered memory as well. */
+int  vgk_host_register(vgk_ctx* ctx, const void* ptr, size_t bytes);
+int  vgk_host_unregister(vgk_ctx* ctx, const void* ptr);
 
 /* gssw path.  pack = validate + encode + H2D (host threads; the copies run on a copy stream of their own, so another
  * thread may pack the next batch while this one runs); run = kernels only (asynchronous on the context's HIP stream,

@@ -82,6 +82,8 @@ int vgk_create_qual_adj(int device, const vgk_scoring* scoring, const vgk_qual_a
 }
 void vgk_destroy(vgk_ctx* ctx) { free(ctx); }
 
+int vgk_host_register(vgk_ctx* ctx, const void* ptr, size_t bytes) { (void)ctx; (void)ptr; (void)bytes; return VGK_OK; }
+int vgk_host_unregister(vgk_ctx* ctx, const void* ptr) { (void)ctx; (void)ptr; return VGK_OK; }
 int vgk_device_info(vgk_ctx* ctx, char* name_out, size_t name_cap, int* cus, size_t* hbm) {
     (void)ctx;
     if (name_out && name_cap) { strncpy(name_out, "cpu-oracle", name_cap - 1); name_out[name_cap - 1] = 0; }

@@ -7,14 +7,17 @@ beside `roofline.traffic`, so a constant that has gone stale behind a changed ke
 import csv, glob, json, os, subprocess, sys, collections, shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r03_pmc")
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
-GROUPS = {   # workload -> (units per launch, kernel-name fragments of its roofline kernels)
+SRC = os.path.join(ROOT, "gpurun_out", "%s_pmc" % ROUND)
+GROUPS = {   # name -> (units per launch, kernel-name fragments of its roofline kernels[, the run the counters come from when it is not `name`])
     "linear": (400000, ["gssw_fill_kernel"]),
     "banded": (100000, ["banded_fill_kernel"]),
     "gapless": (1000000, ["gapless_search_kernel", "gapless_rules_kernel", "gapless_kernel("]),
     "wfa": (500000, ["wfa_kernel", "wfa_wave_kernel"]),
     "xband": (200000, ["xdrop_band_kernel", "xdrop_band_walk_kernel"]),
+    # configs[2], one batch of 1 M reads in one context: the extension kernels of the stage, and its seeding kernels on their own
+    "config2": (1000000, ["gapless_search_kernel", "gapless_rules_kernel", "gapless_kernel("], "config2"),
+    "minimizer": (1000000, ["minimizer_kernel", "minimizer_gather_kernel"], "config2"),
 }
 
 
@@ -38,25 +41,26 @@ def main():
     dst = os.path.join(ROOT, "profiles", ROUND)
     os.makedirs(dst, exist_ok=True)
     only = set(sys.argv[2:])        # e.g. `pmc_constants.py r03 xband`: the other workloads keep their figures and the commit those were measured at
-    for name, (units, frags) in GROUPS.items():
+    for name, spec in GROUPS.items():
+        units, frags = spec[0], spec[1]; run = spec[2] if len(spec) > 2 else name
         if only and name not in only:
             continue
         vals = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            found = glob.glob(os.path.join(SRC, "%s_%s" % (counter, name), "**", "*counter_collection.csv"), recursive=True)
+            found = glob.glob(os.path.join(SRC, "%s_%s" % (counter, run), "**", "*counter_collection.csv"), recursive=True)
             if not found:
                 print("missing", counter, name); break
             vals[counter], dispatches = per_dispatch(found[0], counter, frags)
-            shutil.copy(found[0], os.path.join(dst, "pmc_%s_%s_%s.csv" % (counter.split("_")[0].lower(), name, ROUND)))
+            shutil.copy(found[0], os.path.join(dst, "pmc_%s_%s_%s.csv" % (counter.split("_")[0].lower(), run, ROUND)))
         else:
             table[name] = {"fetch_kib_per_launch": vals["FETCH_SIZE"], "write_kib_per_launch": vals["WRITE_SIZE"], "units_per_launch": units,
                            "kernels": frags, "dispatches_averaged": dispatches, "commit": commit,
-                           "files": ["profiles/%s/pmc_fetch_%s_%s.csv" % (ROUND, name, ROUND), "profiles/%s/pmc_write_%s_%s.csv" % (ROUND, name, ROUND)],
+                           "files": ["profiles/%s/pmc_fetch_%s_%s.csv" % (ROUND, run, ROUND), "profiles/%s/pmc_write_%s_%s.csv" % (ROUND, run, ROUND)],
                            "bytes_per_unit": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / units}
             print(name, table[name]["bytes_per_unit"], "B/unit", dispatches)
-        st = glob.glob(os.path.join(SRC, "stats_%s" % name, "**", "*kernel_stats.csv"), recursive=True)
+        st = glob.glob(os.path.join(SRC, "stats_%s" % run, "**", "*kernel_stats.csv"), recursive=True)
         if st:
-            shutil.copy(st[0], os.path.join(dst, "kernel_stats_%s_%s.csv" % (name, ROUND)))
+            shutil.copy(st[0], os.path.join(dst, "kernel_stats_%s_%s.csv" % (run, ROUND)))
     json.dump(table, open(out_path, "w"), indent=1, sort_keys=True)
     print("->", out_path)
 

@@ -286,6 +286,16 @@ class Engine:
 
     __del__ = close
 
+    def host_register(self, array):
+        """vgk_host_register: page-lock a numpy array this caller keeps (copies out of it then run at the link's rate); False when refused"""
+        a = np.ascontiguousarray(array)
+        self.lib.vgk_host_register.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        return self.lib.vgk_host_register(self.h, a.ctypes.data, a.nbytes) == VGK_OK
+
+    def host_unregister(self, array):
+        self.lib.vgk_host_unregister.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        return self.lib.vgk_host_unregister(self.h, np.ascontiguousarray(array).ctypes.data) == VGK_OK
+
     def device_info(self):
         name = ctypes.create_string_buffer(256); cus = ctypes.c_int(); mem = ctypes.c_size_t()
         self.lib.vgk_device_info(self.h, name, 256, ctypes.byref(cus), ctypes.byref(mem))

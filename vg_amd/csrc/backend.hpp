@@ -35,6 +35,8 @@ public:
     virtual void  release(void* p) = 0;
     virtual void* host_alloc(size_t bytes) = 0;            // page-locked host staging memory (uninitialised; nullptr on failure)
     virtual void  host_release(void* p) = 0;
+    virtual int   host_register(const void* p, size_t bytes) { (void)p; (void)bytes; return VGK_OK; }      // page-lock a caller's range (vgk_host_register)
+    virtual int   host_unregister(const void* p) { (void)p; return VGK_OK; }
     virtual int   upload(void* dst, const void* src, size_t bytes) = 0;     // async on the stream
     virtual int   download(void* dst, const void* src, size_t bytes) = 0;   // synchronous
     // uploads that need not queue behind the kernels of another batch (vgk_gssw_pack while the previous batch runs): a copy

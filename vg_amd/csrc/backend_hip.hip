@@ -841,6 +841,8 @@ public:
         return p;
     }
     void host_release(void* p) override { if (p) { hipSetDevice(dev); hipHostFree(p); } }
+    int host_register(const void* p, size_t bytes) override { hipSetDevice(dev); return hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess ? VGK_OK : VGK_EINVAL; }
+    int host_unregister(const void* p) override { hipSetDevice(dev); return hipHostUnregister(const_cast<void*>(p)) == hipSuccess ? VGK_OK : VGK_EINVAL; }
     int upload(void* dst, const void* src, size_t bytes) override {
         hipSetDevice(dev);
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream) == hipSuccess ? VGK_OK : VGK_ENODEV;

@@ -90,6 +90,16 @@ int vgk_device_info(vgk_ctx* ctx, char* name_out, size_t name_cap, int* cus, siz
     return VGK_OK;
 } catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
+int vgk_host_register(vgk_ctx* ctx, const void* ptr, size_t bytes) try {
+    if (!ctx || !ptr || !bytes) return VGK_EINVAL;
+    return ctx->be->host_register(ptr, bytes);
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
+int vgk_host_unregister(vgk_ctx* ctx, const void* ptr) try {
+    if (!ctx || !ptr) return VGK_EINVAL;
+    ctx->be->sync(); ctx->be->sync_side();                  // no copy out of the range may still be in flight
+    return ctx->be->host_unregister(ptr);
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
+
 void vgk_batch_free(vgk_batch* b) {
     if (!b) return;
     // only THIS batch's work has to be over before its arenas go back to the pool: its kernels (the event behind them) and
