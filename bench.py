@@ -410,7 +410,8 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
                 tot["seeds"] += int(seed_off[-1]); tot["ext"] += len(out["ext"]); tot["tails"] += int(st[0]); tot["trees"] += int(st[1]); tot["tree_nodes"] += int(st[2]); tot["failed"] += int(st[3])
                 tot["full_length"] += int((out["res"]["full_length"] != 0).sum()); tot["truncated"] += int(e.minimizers_truncated.sum())
                 if keep is not None and b == 0:
-                    keep.update(read_score=out["read_score"].copy(), res=out["res"].copy(), ext=out["ext"].copy(), nodes=out["nodes"].copy(), seed_off=seed_off.copy())
+                    keep.update(read_score=out["read_score"].copy(), res=out["res"].copy(), ext=out["ext"].copy(), nodes=out["nodes"].copy(), seed_off=seed_off.copy(),
+                                n_minimizers=int((np.asarray(mins, dtype=np.int64) & 0x7fffffff).sum()) if mins is not None else 19 * (len(off) - 1))
 
     def new_tot():
         return {"seeds": 0, "ext": 0, "tails": 0, "trees": 0, "tree_nodes": 0, "failed": 0, "full_length": 0, "truncated": 0}
@@ -511,7 +512,20 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "kernel": "gapless_search_kernel + gapless_rules_kernel (the stage's longest kernels)", "limiter": "memory latency and divergent issue, not bandwidth (DESIGN.md §11)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                         "traffic": None, "alg_bytes_per_launch": alg0, "avg_launch_ms": gap_ms},
+                         "traffic": PMC_BYTES_PER_UNIT["config2"] * batch if "config2" in PMC_BYTES_PER_UNIT else None,
+                         "traffic_source": traffic_source("config2") if "config2" in PMC_BYTES_PER_UNIT else None,
+                         "alg_bytes_per_launch": alg0, "avg_launch_ms": gap_ms,
+                         "launch_ms_note": "kernel time of the extension call per batch as the engine's own events give it; with two batches in flight it includes what the other context's kernels took of the device"},
+            # the stage's second-longest kernel family on its own: the seeding (minimizer_kernel over four slices of the batch + the gather).
+            # algorithmic bytes: the read once + a 16-byte slot per minimizer looked up + 8 bytes per seed written
+            "roofline_minimizer": (lambda alg_m, ms_m: {"bound": "hbm", "kernel": "minimizer_kernel + minimizer_gather_kernel", "limiter": "64-bit integer issue (two Wang hashes per k-mer position), then the latency of the table lookups",
+                                    "achieved": alg_m / (ms_m * 1e-3) / 1e9 if ms_m else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": alg_m / (ms_m * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_m else None,
+                                    "traffic": PMC_BYTES_PER_UNIT["minimizer"] * batch if "minimizer" in PMC_BYTES_PER_UNIT else None,
+                                    "traffic_source": traffic_source("minimizer") if "minimizer" in PMC_BYTES_PER_UNIT else None,
+                                    "alg_bytes_per_launch": alg_m, "avg_launch_ms": ms_m,
+                                    "launch_ms_note": "device time of the seeding call per batch (its copies of the reads included)"})(
+                float(rl * batch + 16 * first.get("n_minimizers", 19 * batch) + 8 * ns.sum()), kernel_ms["minimizer"] / steps / len(wl.batches)),
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int(tot["failed"])}))
     if dist is not None:
         dist.destroy_process_group()
@@ -1325,7 +1339,7 @@ def secondary_records():
             else:
                 d = json.loads(line[-1])
                 cfg = d.get("config") or {}
-                rec.update({k: d.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "cpu_baseline", "parity", "problems_failed")})
+                rec.update({k: d.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "roofline_minimizer", "cpu_baseline", "parity", "problems_failed") if k in d})
                 rec["config"] = {k: cfg.get(k) for k in ("workload", "timed_region", "ms_per_batch", "kernel_ms_per_batch", "stage_ms_per_batch", "one_context", "read_buffers", "policies") if k in cfg}
         except subprocess.TimeoutExpired:
             rec["error"] = "time limit of %d s" % limit

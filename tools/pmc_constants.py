@@ -22,7 +22,8 @@ GROUPS = {   # name -> (units per launch, kernel-name fragments of its roofline 
 
 
 def per_dispatch(path, counter, frags):
-    """sum over the group's kernels of (total counter value / dispatches of that kernel)"""
+    """the group's counter total per BATCH of the bench: every kernel's total divided by the batches run = the fewest dispatches any kernel of
+    the group has (a kernel launched several times per batch — the seeding kernel's four slices — counts with all of them)"""
     tot = collections.defaultdict(float); disp = collections.defaultdict(set)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
@@ -31,7 +32,8 @@ def per_dispatch(path, counter, frags):
         if not any(f in k for f in frags):
             continue
         tot[k] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
-    return sum(tot[k] / len(disp[k]) for k in tot), {k.split("(")[0]: len(disp[k]) for k in tot}
+    batches = min(len(disp[k]) for k in tot) if tot else 1
+    return sum(tot[k] for k in tot) / batches, {k.split("(")[0]: len(disp[k]) for k in tot}
 
 
 def main():
