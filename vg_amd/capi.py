@@ -584,6 +584,12 @@ class Engine:
     def wfa_last_ms(self):
         return self.lib.vgk_wfa_last_ms(self.h)
 
+    def wfa_last_wave(self):
+        """(ms of the first launch — the hybrid's pair when its kernels ran at once —, ms of the wavefront kernel when it followed the thread
+        kernel, problems handed over / outgrown)"""
+        self.lib.vgk_wfa_last_wave.restype = ctypes.c_double; self.lib.vgk_wfa_last_wave.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        return tuple(self.lib.vgk_wfa_last_wave(self.h, k) for k in range(3))
+
 
 TAIL_DT = np.dtype([("node", "<u4"), ("lo", "<i4"), ("hi", "<i4"), ("offset", "<u4"), ("walk_distance", "<u4")])
 TAIL_RESULT_DT = np.dtype([("status", "<i4"), ("first_node", "<u4"), ("n_nodes", "<u4"), ("n_trees", "<u4"), ("root_trim", "<u4"), ("bases", "<u4")])

@@ -109,6 +109,11 @@ public:
     // p.n problems; last_ms(6) = kernel ms
     virtual int   run_wfa(const WfaParams& p, uint32_t threads) = 0;
     virtual int   run_wfa_wave(const WwParams& p, uint32_t waves) = 0;    // one wavefront per problem (wfa_wave_device.hpp); the time adds to last_ms(6)
+    // the hybrid's two kernels AT ONCE: the thread kernel on the main stream, the wavefront kernel beside it on a second one, polling the
+    // hand-over list while it grows (a.producers_done / p.producers_done: wfa_wave_device.hpp); last_ms(6) = the pair's wall time on the
+    // device.  A backend without a second stream says so and the caller launches them one after the other.
+    virtual bool  wfa_concurrent() const { return false; }
+    virtual int   run_wfa_hybrid(const WfaParams& p, uint32_t threads, const WwParams& a, uint32_t waves) { (void)p; (void)threads; (void)a; (void)waves; return VGK_EUNSUPPORTED; }
     virtual void  reset_wfa_ms() {}
     // pinned gssw fill that keeps H / E / F of every cell (k-best tracebacks): one thread per problem
     virtual int   run_gssw_matrix(const GsswMatrixParams& p) = 0;

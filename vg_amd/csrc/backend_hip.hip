@@ -624,6 +624,11 @@ __global__ void __launch_bounds__(64, 4) wfa_kernel(const WfaParams P, const uin
     __shared__ uint32_t node_end[W_NODES * 64];                    // [trie node][lane]: conflict-free, 8 KB per wavefront
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t < threads) wfa_thread(P, t, node_end + threadIdx.x, 64);
+    if (P.producers_done) {                                        // run beside the wavefront kernel: this wavefront will hand nothing over any more
+        __threadfence();                                           // (its list entries before the count the consumers trust)
+        __builtin_amdgcn_wave_barrier();
+        if (threadIdx.x == 0) atomicAdd(P.producers_done, 1u);
+    }
 }
 
 // ---- wavefront alignment, one wavefront per problem (wfa_wave_device.hpp): trie nodes, possible penalties and the lanes' work lists in
@@ -1264,6 +1269,22 @@ public:
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         float ms = 0.f; hipEventElapsedTime(&ms, bev[0], bev[1]);
         ms_wfa += ms;
+        return VGK_OK;
+    }
+    bool wfa_concurrent() const override { return alt != nullptr; }
+    int run_wfa_hybrid(const WfaParams& p, uint32_t threads, const WwParams& a, uint32_t waves) override {
+        hipSetDevice(dev);
+        ms_wfa = 0.f;
+        if (!p.n || !threads || !waves) return VGK_OK;
+        hipEventRecord(bev[0], stream);
+        hipStreamWaitEvent(alt, bev[0], 0);                        // both start behind whatever the main stream held
+        hipLaunchKernelGGL(wfa_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads);
+        hipLaunchKernelGGL(wfa_wave_kernel, dim3(waves), dim3(64), 0, alt, a);
+        hipEventRecord(bev[2], alt);
+        hipStreamWaitEvent(stream, bev[2], 0);
+        hipEventRecord(bev[1], stream);
+        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
+        hipEventElapsedTime(&ms_wfa, bev[0], bev[1]);
         return VGK_OK;
     }
     void reset_wfa_ms() override { ms_wfa = 0.f; }

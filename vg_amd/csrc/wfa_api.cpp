@@ -83,10 +83,11 @@ int launch_wave_form(vgk_ctx* ctx) {
     return VGK_OK;
 }
 // after_threads: the problems are the thread kernel's hand-over list (its length is on the device only)
-int run_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P, bool after_threads) {
+// per_cu_default: wavefronts per CU of the launch (12: what a CU's LDS and registers hold of this kernel alone; fewer beside the thread kernel)
+int prepare_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P, bool after_threads, uint32_t per_cu_default) {
     Backend* be = ctx->be.get();
     const uint32_t cus = (uint32_t)std::max(1, be->compute_units());
-    uint32_t per_cu = 12;                                                        // 13 KB of LDS and 168 VGPRs per wavefront
+    uint32_t per_cu = per_cu_default;                                            // 13 KB of LDS and 168 VGPRs per wavefront
     if (const char* e = std::getenv("VGAMD_WFA_WAVES_PER_CU")) per_cu = (uint32_t)std::max(1, std::atoi(e));
     // the small size keeps its tables in LDS (256 points cover all but a percent or two of giraffe's links; the median is a dozen); the
     // large size: what a link with a 60-base insertion under the default error model stores, several times over
@@ -112,8 +113,31 @@ int run_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P, bool after_threa
         if (!A.stats || be->zero(A.stats, sizeof(uint32_t) * 8 * ((size_t)P.n + 1))) return VGK_ENOMEM;
     }
     ctx->wfa_wave_last[0] = A; ctx->wfa_wave_waves[0] = z.waves;
+    return VGK_OK;
+}
+int run_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P, bool after_threads) {
+    int rc;
+    if ((rc = prepare_wave_form(ctx, H, P, after_threads, 12))) return rc;
     if ((rc = launch_wave_form(ctx))) return rc;
     ctx->wfa_wave_last_valid = true; ctx->wfa_last_valid = false;
+    return VGK_OK;
+}
+// The hybrid with both kernels AT ONCE (Backend::run_wfa_hybrid): the thread kernel at half its occupancy, the wavefront kernel in the
+// other half of every CU, answering what the threads hand over while they are still at it.  Everything a launch consumes is reset here:
+// the hand-out counters, the list (unwritten entries read 0xffffffff), the count of finished producers.
+int launch_hybrid_at_once(vgk_ctx* ctx) {
+    Backend* be = ctx->be.get();
+    WfaParams& P = ctx->wfa_last; WwParams& A = ctx->wfa_wave_last[0];
+    int rc;
+    if ((rc = be->zero(P.counters, 64)) || (rc = be->zero(P.n_handed_over, 16)) || (rc = be->zero(P.producers_done, 16))) return rc;
+    if ((rc = be->fill(P.handed_over, 0xff, sizeof(uint32_t) * ((size_t)P.n + 8)))) return rc;
+    if ((rc = be->zero(A.n_declined, 16))) return rc;
+    // (the two kernels share counters[0..1] — paths and edits handed out — and use counters[2] / counters[3] as their own hand-out counters)
+    if ((rc = be->run_wfa_hybrid(P, ctx->wfa_last_threads, A, ctx->wfa_wave_waves[0]))) return rc;
+    ctx->wfa_ms = be->last_ms(6); ctx->wfa_wave_ms[0] = ctx->wfa_ms; ctx->wfa_wave_ms[1] = 0;
+    unsigned long long taken_over = 0;
+    if ((rc = be->download(&taken_over, P.n_handed_over, sizeof taken_over))) return rc;
+    ctx->wfa_wave_retried = taken_over;
     return VGK_OK;
 }
 
@@ -299,6 +323,26 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
         char* extra = (char*)ctx->ensure_scratch(61, sizeof(uint32_t) * ((size_t)n + 8) + 16);
         if (!extra) return VGK_ENOMEM;
         P.hand_over_points = hand_over; P.n_handed_over = (unsigned long long*)extra; P.handed_over = (uint32_t*)(extra + 16);
+        if (be->wfa_concurrent() && std::getenv("VGAMD_WFA_AT_ONCE")) {
+            // Both kernels at once: half the CU each (8 wavefronts of threads, 4 of the wavefront kernel).  Built, exact (every -m gpu WFA test
+            // and the bench's 500 000 / 500 000), and NOT the default: the thread kernel fills the register file at 16 wavefronts per CU
+            // (128 VGPRs each), so the wavefront kernel (168) only fits beside it at half that occupancy — and the thread kernel, bound by
+            // memory latency, takes as much longer as it loses wavefronts: 9.46 ms per 500 000 problems either way (profiles/r04).  It pays
+            // only with a wavefront kernel of 128 VGPRs beside 12 wavefronts of threads per CU.
+            uint64_t t_per_cu = 512;
+            if (const char* e = std::getenv("VGAMD_WFA_THREADS_PER_CU")) t_per_cu = (uint64_t)std::max(64, std::atoi(e));
+            const uint32_t t_threads = (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max(1, be->compute_units()) * t_per_cu);
+            P.producers_done = (uint32_t*)ctx->ensure_scratch(65, 64);
+            if (!P.producers_done) return VGK_ENOMEM;
+            ctx->wfa_last = P; ctx->wfa_last_threads = t_threads;
+            if ((rc = prepare_wave_form(ctx, H, P, true, 4))) return rc;
+            WwParams& A = ctx->wfa_wave_last[0];
+            A.base.counters = P.counters; A.producers_done = P.producers_done; A.n_producers = (t_threads + 63u) / 64u;
+            A.hand_out = P.counters + 3;
+            if ((rc = launch_hybrid_at_once(ctx))) return rc;
+            ctx->wfa_last_valid = true; ctx->wfa_wave_last_valid = true; ctx->wfa_at_once = true;
+        } else {
+        ctx->wfa_at_once = false;
         if ((rc = be->zero(P.n_handed_over, 16))) return rc;
         be->reset_wfa_ms();
         if ((rc = be->run_wfa(P, threads))) return rc;
@@ -309,6 +353,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
         ctx->wfa_wave_ms[1] = ctx->wfa_wave_ms[0]; ctx->wfa_wave_ms[0] = ms_threads;
         ctx->wfa_ms = ms_threads + ctx->wfa_wave_ms[1];
         ctx->wfa_last_valid = true;                                                // (vgk_wfa_rerun: both launches again)
+        }
     } else {
         if ((rc = be->run_wfa(P, threads))) return rc;
         ctx->wfa_last = P; ctx->wfa_last_threads = threads; ctx->wfa_last_valid = true; ctx->wfa_wave_last_valid = false;
@@ -354,6 +399,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
 int vgk_wfa_rerun(vgk_ctx* ctx) try {
     if (!ctx) return VGK_EINVAL;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->wfa_wave_last_valid && ctx->wfa_last_valid && ctx->wfa_at_once) return launch_hybrid_at_once(ctx);      // hybrid, both kernels at once
     if (ctx->wfa_wave_last_valid && ctx->wfa_last_valid) {                         // hybrid: the thread kernel, then the wavefront kernel on what it hands over
         Backend* be = ctx->be.get();
         int rc;

@@ -92,6 +92,9 @@ struct WfaParams {
     // hybrid form: the thread kernel gives a problem up at `hand_over_points` stored points (when the caller's own budget lies above that)
     // and lists it for the wavefront kernel (wfa_wave_device.hpp) instead of reporting it
     uint32_t hand_over_points; uint32_t* handed_over; unsigned long long* n_handed_over;
+    // ... and, when the two kernels run AT ONCE (Backend::run_wfa_hybrid): a counter every wavefront of the thread kernel bumps when it has
+    // run dry — the wavefront kernel, polling the list, learns from it that nothing more will come.  Null when the launches follow each other.
+    uint32_t* producers_done;
 };
 
 struct WPos { uint32_t seq, off; uint8_t cur, origin; bool empty; };

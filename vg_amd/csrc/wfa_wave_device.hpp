@@ -59,6 +59,10 @@ struct WwParams {
     WfaParams base;                   // index, problems, sequences, scoring, outputs, counters[2] = next problem to hand out
     const uint32_t* todo; uint32_t n_todo;      // the problems of this launch, in hand-out order
     const unsigned long long* n_todo_dev;        // their number when only the device knows it (the thread kernel's hand-over list); else null
+    // The list is still GROWING (the thread kernel runs beside this one): entries not yet written read 0xffffffff, `producers_done` counts
+    // the thread kernel's wavefronts that have finished, `n_producers` of them in all.  Null: the list is complete when the launch starts.
+    const uint32_t* producers_done; uint32_t n_producers;
+    unsigned long long* hand_out;                // this launch's own "next entry" counter (null: base.counters + 2, which the thread kernel uses when it runs beside)
     uint32_t small_points;            // the small size's own point limit when below WW_SMALL_POINTS (0 = that; a test hook: more problems for the large size)
     // the large size: per resident wavefront ...
     unsigned long long* slots; uint32_t n_slots;   // ... n_slots (a power of two) table slots ...
@@ -861,19 +865,47 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
 // One resident wavefront: problems are handed out one at a time; each starts in the small size (everything in LDS) and, if it outgrows
 // that, is run again at once by the same wavefront in the large size (its slab in HBM).  The two sizes share the wavefront's LDS.
 union WwSharedBoth { WwShared<true> small; WwShared<false> large; };
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ uint32_t ww_peek32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ unsigned long long ww_peek64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ void ww_nap() { __builtin_amdgcn_s_sleep(32); }
+static __device__ __forceinline__ void ww_acquire() { __threadfence(); }
+#else
+static inline uint32_t ww_peek32(const uint32_t* p) { return *p; }
+static inline unsigned long long ww_peek64(const unsigned long long* p) { return *p; }
+static inline void ww_nap() {}
+static inline void ww_acquire() {}
+#endif
 template <class XL> VGK_HD void wfa_wave(const WwParams& P, uint32_t slab, uint32_t lane, WwSharedBoth& sh, XL& xl) {
     bool table_clean = false;
     const uint32_t n_todo = P.n_todo_dev ? (uint32_t)*P.n_todo_dev : P.n_todo;
     for (;;) {
         uint32_t k = 0;
-        if (lane == 0) k = (uint32_t)g_bump(P.base.counters + 2, 1);
+        if (lane == 0) k = (uint32_t)g_bump(P.hand_out ? P.hand_out : P.base.counters + 2, 1);
         k = xl.bcast(k, 0);
-        if (k >= n_todo) break;
+        uint32_t i = 0;
+        if (P.producers_done) {
+            // the k-th entry of a list that is being written: there already, or still to come, or never (every producer has finished and
+            // the list ends before it).  Lane 0 waits, napping between looks; the producers never wait for this kernel.
+            uint32_t verdict = 0;                                            // 1 = take entry i, 2 = the list has ended
+            if (lane == 0) {
+                for (;;) {
+                    if ((unsigned long long)k < ww_peek64(P.n_todo_dev)) { verdict = 1; break; }
+                    if (ww_peek32(P.producers_done) >= P.n_producers) { ww_acquire(); verdict = (unsigned long long)k < ww_peek64(P.n_todo_dev) ? 1u : 2u; break; }
+                    ww_nap();
+                }
+                if (verdict == 1) while ((i = ww_peek32(P.todo + k)) == 0xffffffffu) ww_nap();
+            }
+            verdict = xl.bcast(verdict, 0); i = xl.bcast(i, 0);
+            if (verdict == 2) break;
+        } else {
+            if (k >= n_todo) break;
+            i = P.todo[k];
+        }
         if (!table_clean) {                                                  // (LDS comes up with whatever was there; the large size used it for its own lists)
             for (uint32_t j = lane; j < (uint32_t)WW_SMALL_SLOTS; j += 64) sh.small.slot[j] = 0;
             xl.fence(); table_clean = true;
         }
-        const uint32_t i = P.todo[k];
         if (wfa_wave_problem<XL, true>(P, i, slab, lane, sh.small, xl)) { wfa_wave_problem<XL, false>(P, i, slab, lane, sh.large, xl); table_clean = false; }
     }
 }
