@@ -351,10 +351,94 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
                                               "links": b_out["stats"], "stage_ms": {k: 1e3 * v / args.steps for k, v in b_timing.items()}, "wfa_kernel_ms": b_out["wfa_kernel_ms"]},
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
             "roofline": {"bound": "hbm", "kernel": "wfa_wave_kernel", "limiter": "the mass of easy links (12 wavefronts per CU, one link each) and the critical path of the heaviest one; memory latency, not bandwidth (DESIGN.md §21)",
-                         "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
+                         # algorithmic bytes of the WFA launch: every link's read bases and as many haplotype bases once, a problem descriptor and
+                         # a result per link; against the launch's own device time (vgk_wfa_last_ms as the stage reports it)
+                         **(lambda alg, ms: {"achieved": alg / (ms * 1e-3) / 1e9 if ms else None, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms else None,
+                                             "alg_bytes_per_launch": alg, "avg_launch_ms": ms})(float(2 * wl.read_bases + 72 * wl.n), float(out["wfa_kernel_ms"] or 0.0)),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None},
             "cpu_baseline": cpu, "parity": parity,
             "problems_failed": int(out["stats"]["failed"] + out["stats"]["no_graph"] + out["stats"]["too_big"])}))
     stage.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
+    """A one-GPU slice of BASELINE.json configs[3] (secondary line): read PAIRS of 2 x 150 bp on a variation graph of the chr22-scale
+    construction, both mates through seeding -> gapless extension -> tails (the configs[2] stage), then — giraffe's paired-end shape,
+    MinimizerMapper::attempt_rescue (src/minimizer_mapper.cpp:3264-3440) — the mate without a full-length extension rescued from its
+    partner's position: rescue subgraph, its best extension as dozeu's seed, Aligner::align_xdrop for all such mates at once
+    (align_xdrop_many), fix_dozeu_score, fix_dozeu_end_deletions.  One step = one batch of pairs from host buffers.  The pairs of a
+    stream stay together when it is sharded (shard.shard_range(group = 2)): this is what each rank of an 8-GPU run would do."""
+    import numpy as np
+    from vg_amd import capi, pipeline, shard, workloads
+    n_pairs = (args.reads // 2) if args.reads else 250_000
+    t0 = time.perf_counter()
+    wl = workloads.PairedWorkload(n_pairs, ref_len=int(os.environ.get("VGAMD_PAIRED_REF_LEN", "5000000")), seed=41 + rank)
+    t_gen = time.perf_counter() - t0
+    graph = (wl.node_len, wl.seq)
+    index = eng.haplo_index(graph, wl.threads); mindex = eng.minimizer_index(graph, wl.threads)
+    eng.reuse_outputs = True
+    eng.host_register(wl.reads)
+    aligner = pipeline.HostAlignerHandle(os.environ.get("VGAMD_ENGINE_LIB"), device=eng.device)
+    threads = int(os.environ.get("VGAMD_HOST_THREADS", "0")) or min(shard.usable_cpus(), 48)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        pipeline.paired_stage(eng, index, mindex, wl, aligner, host_threads=threads)
+    barrier()
+    timing = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pipeline.paired_stage(eng, index, mindex, wl, aligner, timing=timing, host_threads=threads)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    cpu = parity = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        ora_lib = os.path.join(ROOT, "oracle", "libvgoracle.so")
+        ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=ora_lib)
+        cores = shard.usable_cpus(); ora.lib.vgo_set_threads(cores)
+        k = min(n_pairs, (args.cpu_sample // 2) if args.cpu_sample else 25_000)
+        sub = wl.subset(k)
+        oidx = ora.haplo_index(graph, wl.threads); omi = ora.minimizer_index(graph, wl.threads)
+        oal = pipeline.HostAlignerHandle(ora_lib)
+        t1 = time.perf_counter()
+        o = pipeline.paired_stage(ora, oidx, omi, sub, oal, oriented_len=np.repeat(wl.node_len, 2), device=False, host_threads=cores)
+        tc = time.perf_counter() - t1
+        same = int((o["pair_score"] == out["pair_score"][:k]).sum())
+        n_resc = len(o["rescued"])
+        same_resc = int((o["rescue"] == out["rescue"][:n_resc]).all(axis=1).sum()) if n_resc and (o["rescued"] == out["rescued"][:n_resc]).all() else 0
+        cpu = {"value": 2 * k / tc, "unit": "reads/s", "cores": cores, "kind": "port", "impl": "the same stage over the oracle (vgo_minimizer.c, vgo_gapless.c, vgo_tail.c, vgo_xdrop.c) and the same host shim bound to it",
+               "sample": "the first %d pairs" % k}
+        parity = {"checked": k, "identical": same, "rescued_mates_checked": n_resc, "rescued_alignments_identical": same_resc,
+                  "what": "per-pair score (mapped mate + the better of the rescued alignment and the stage's own); per rescued mate score, status, first node and offset, mappings, aligned bases"}
+    if rank == 0:
+        resc = out["rescue"]
+        print(json.dumps({
+            "metric": "150 bp paired reads/sec through giraffe's alignment stage with mate rescue (one-GPU slice of configs[3])",
+            "value": 2 * n_pairs * world * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "configs[3] slice: variation graph of the chr22-scale construction over a %d bp reference (%d nodes, two haplotypes), %d pairs of 2 x 150 bp per GPU, fragments N(%.0f, %.0f), "
+                                   "1 %% substitutions, 8 %% of the second mates with an inserted stretch and 3 %% substitutions; k = 29, w = 11 minimizers; rescue window = fragment mean +- 4 sd by column "
+                                   "coordinate (a stand-in for subgraph_in_distance_range: the SnarlDistanceIndex is absent)" % (len(wl.graph.haps[0][0]), len(wl.node_len), n_pairs, wl.mean, wl.sd),
+                       "timed_region": "per step, one batch of pairs from host buffers: vgk_minimizer_seeds -> vgk_gapless_extend_seeded -> vgk_tail_stage for all 2 n reads, then the rescue requests (host, numpy), "
+                                       "then vgh_rescue_stage: subgraphs on host threads, every mate's X-drop passes in Aligner::align_xdrop_many, the fix-ups",
+                       "pairs_rescued": int(len(out["rescued"])), "rescued_with_positive_score": int((resc[:, 0] > 0).sum()), "refused_by_cell_budget": int((resc[:, 1] == 1).sum()),
+                       "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()}, "host_threads": threads,
+                       "parallelism": "pair-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
+            "roofline": {"bound": "hbm", "kernel": "the configs[2] stage's kernels + gssw_fill_kernel (X-drop passes of the rescued mates)", "limiter": "host glue of the rescue half (subgraph construction, requests); DESIGN.md §27.7",
+                         "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
+            "cpu_baseline": cpu, "parity": parity, "problems_failed": int((out["res"]["status"] != 0).sum())}))
+    aligner.close()
     if dist is not None:
         dist.destroy_process_group()
 
@@ -989,7 +1073,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the legs that overlap launches — the two-lane steady state and the warm / double-buffered end-to-end legs — so that a profiler's per-kernel averages are each kernel's own")
     ap.add_argument("--no-secondary", action="store_true", help="default (linear, one GPU) run: do not append the `secondary` records — the other kernel families' own bench lines, each run "
                          "as `bench.py --workload X` in a process of its own after the headline has been measured")
-    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband", "forest", "giraffe", "longread", "config2"], default="linear",
+    ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband", "forest", "giraffe", "longread", "config2", "paired"], default="linear",
                     help="linear = BASELINE.json configs[1] (the headline metric); tails = configs[2] stand-in: "
                          "giraffe-style pinned X-drop tail alignments on a variation graph; banded = configs[4] stand-in: "
                          "banded global alignments between chained anchors; gapless = giraffe's first stage: "
@@ -1039,6 +1123,8 @@ def main():
         return bench_longread(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "config2":
         return bench_config2(args, eng, rank, world, dist, torch, dev_name, cus)
+    if args.workload == "paired":
+        return bench_paired(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "giraffe":
         return bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus)
     if args.workload == "forest":
@@ -1322,6 +1408,7 @@ SECONDARY = [
     ("banded", ["--reads", "100000", "--steps", "5", "--warmup", "2"], 90),
     ("wfa", ["--reads", "500000", "--steps", "5", "--warmup", "2"], 90),
     ("longread", ["--steps", "3", "--warmup", "1"], 120),
+    ("paired", ["--steps", "3", "--warmup", "1"], 150),
 ]
 
 

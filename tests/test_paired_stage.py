@@ -1,0 +1,63 @@
+"""A paired-end slice of configs[3] on one device (vg_amd/pipeline.py: paired_stage; vg_amd/host/rescue_stage.cpp = the rescue half,
+MinimizerMapper::attempt_rescue, src/minimizer_mapper.cpp:3264-3440): both mates through seeding / extension / tails, the mate without a
+full-length extension rescued from its partner's position by the seeded two-pass X-drop + fix-ups.  The engine's stage (emulated kernels
+here, HIP under -m gpu) must give the oracle stage's per-pair scores and rescued alignments, and rescue must actually recover the hard
+mates: a rescued mate lies where the pair was sampled from."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from util import ENGINE_LIB, ORACLE_LIB, ROOT
+from vg_amd import capi, pipeline, workloads
+
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libvgamd_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    subprocess.check_call(["make", "-s", "emu"], cwd=ROOT)
+    return EMU_LIB
+
+
+def run(lib, wl, device):
+    eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=lib)
+    graph = (wl.node_len, wl.seq)
+    index = eng.haplo_index(graph, wl.threads); mindex = eng.minimizer_index(graph, wl.threads)
+    aligner = pipeline.HostAlignerHandle(lib)
+    olen = np.repeat(wl.node_len, 2)
+    out = pipeline.paired_stage(eng, index, mindex, wl, aligner, oriented_len=olen, device=device)
+    aligner.close()
+    return out
+
+
+def check(lib, n_pairs, device):
+    wl = workloads.PairedWorkload(n_pairs, ref_len=300_000, seed=5, hard=0.25)
+    got = run(lib, wl, device)
+    want = run(ORACLE_LIB, wl, False)
+    assert (got["read_score"] == want["read_score"]).all()
+    assert (got["rescued"] == want["rescued"]).all() and (got["requests"] == want["requests"]).all()
+    assert (got["rescue"] == want["rescue"]).all()
+    assert (got["pair_score"] == want["pair_score"]).all()
+    # rescue does its job: most pairs with a hard second mate are rescued, to a positive score, near where the mate came from
+    hard = set(int(i) for i in wl.truth["hard"])
+    rescued_pairs = set(int(r) // 2 for r in got["rescued"])
+    assert len(hard & rescued_pairs) > 0.6 * len(hard)
+    ok = got["rescue"][:, 1] == 0
+    assert ok.mean() > 0.95 and (got["rescue"][ok, 0] > 60).mean() > 0.8
+    # the rescued alignment starts inside its rescue subgraph
+    fn = got["rescue"][ok, 2]; lo = got["requests"][ok, 0]; hi = got["requests"][ok, 1]
+    has = fn >= 0
+    assert ((fn[has] >= lo[has]) & (fn[has] < hi[has])).all()
+    return got
+
+
+def test_paired_stage_on_the_emulated_kernels(emu_lib):
+    got = check(emu_lib, 300, True)
+    assert len(got["rescued"]) > 30
+
+
+@pytest.mark.gpu
+def test_paired_stage_on_hip():
+    check(ENGINE_LIB, 4000, True)

@@ -1,5 +1,11 @@
 #include "aligner.hpp"
 #include <algorithm>
+#include <cstdio>
+#include <chrono>
+#include <cstdlib>
+#include <thread>
+#include <functional>
+#include <atomic>
 #include <set>
 #include <cmath>
 #include <sstream>
@@ -1114,6 +1120,8 @@ void Aligner::xdrop_align_many(std::vector<XdropRequest>& requests) const {
                    std::unordered_map<handle_t, size_t, handle_hash> index_of; std::unique_ptr<ScanJob> scan; std::unique_ptr<ExtensionJob> up, down; };
     const size_t n = requests.size();
     std::vector<State> st(n);
+    auto lap_t0 = std::chrono::steady_clock::now(); const bool lap_on = std::getenv("VGAMD_TIMING") != nullptr;
+    auto lap = [&](const char* what) { if (!lap_on) return; const auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "[align_xdrop_many] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - lap_t0).count()); lap_t0 = t; };
     // one engine call over the problems of a pass; results and ops per problem come back through `take`
     auto run = [&](std::vector<vgk_gssw_problem>& probs, bool band, std::vector<vgk_result>& res, std::vector<vgk_op>& ops, const char* what) {
         res.assign(probs.size(), vgk_result{});
@@ -1127,20 +1135,37 @@ void Aligner::xdrop_align_many(std::vector<XdropRequest>& requests) const {
         for (const vgk_result& r : res) if (r.status != VGK_OK) throw std::runtime_error(std::string("vgamd: ") + what + " failed: " + engine->strerror(r.status));
     };
     auto ops_of = [](const vgk_result& r, const std::vector<vgk_op>& all) { return std::vector<vgk_op>(all.begin() + r.ops_begin, all.begin() + r.ops_begin + r.n_ops); };
+    // The per-request halves around the engine calls are independent of each other: with more than a handful of requests they run on host
+    // threads (a rescue batch is tens of thousands of mates; serially these loops were 0.5 s of a 0.7 s step)
+    auto each = [&](size_t count, const std::function<void(size_t)>& body) {
+        unsigned threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = std::getenv("VGAMD_HOST_THREADS")) threads = (unsigned)std::max(1, std::atoi(e));
+        if (count < 64 || threads < 2) { for (size_t k = 0; k < count; ++k) body(k); return; }
+        threads = (unsigned)std::min<size_t>(threads, (count + 31) / 32);
+        std::atomic<size_t> next{0}; std::exception_ptr err; std::mutex err_mu;
+        auto work = [&]() {
+            try { for (size_t i; (i = next.fetch_add(32)) < count;) for (size_t k = i; k < std::min(count, i + 32); ++k) body(k); }
+            catch (...) { std::lock_guard<std::mutex> lk(err_mu); if (!err) err = std::current_exception(); next.store(count); }
+        };
+        std::vector<std::thread> ts;
+        for (unsigned t = 1; t < threads; ++t) ts.emplace_back(work);
+        work();
+        for (auto& t : ts) t.join();
+        if (err) std::rethrow_exception(err);
+    };
     // ---- first pass: the head position (:629-673) — a scan of the read's last bases, or the extension from the seed towards it
     std::vector<vgk_gssw_problem> scans, ups; std::vector<size_t> scan_of, up_of;
-    for (size_t k = 0; k < n; ++k) {
+    each(n, [&](size_t k) {
         XdropRequest& rq = requests[k]; State& s = st[k];
         Alignment& alignment = *rq.alignment; const HandleGraph& g = *rq.graph;
         if (rq.order.empty()) rq.order = handlealgs::lazier_topological_order(&g);
         alignment.clear_path();
-        if (rq.order.empty() || alignment.sequence.empty()) continue;
+        if (rq.order.empty() || alignment.sequence.empty()) return;
         s.live = true; s.direction = rq.reverse_complemented;
         for (size_t i = 0; i < rq.order.size(); ++i) s.index_of[rq.order[i]] = i;
         if (rq.mems.empty()) {
             s.scan = std::make_unique<ScanJob>();
             xdrop_scan_prepare(alignment, g, rq.order, s.direction, *s.scan);
-            scans.push_back(s.scan->prob); scan_of.push_back(k);
         } else {
             // calculate_seed_position (:75-114)
             const MaximalExactMatch& seed = s.direction ? rq.mems.back() : rq.mems.front();
@@ -1151,12 +1176,19 @@ void Aligner::xdrop_align_many(std::vector<XdropRequest>& requests) const {
             // "upward" extension from the seed; its maximum is the head (:654-672)
             s.up = std::make_unique<ExtensionJob>();
             xdrop_extend_prepare(g, rq.order, sn, sref, alignment.sequence, alignment.quality, squery, s.direction, false, rq.max_gap_length, *s.up);
-            if (s.up->runs) { ups.push_back(s.up->prob); up_of.push_back(k); }
-            else { s.head_node = s.up->ext.end_node; s.head_ref = s.up->ext.end_ref_offset; s.head_query = s.up->ext.end_query; s.have_head = true; }
+            if (!s.up->runs) { s.head_node = s.up->ext.end_node; s.head_ref = s.up->ext.end_ref_offset; s.head_query = s.up->ext.end_query; s.have_head = true; }
         }
+    });
+    for (size_t k = 0; k < n; ++k) {                                     // the passes' problem lists, in request order
+        State& s = st[k];
+        if (!s.live) continue;
+        if (s.scan) { scans.push_back(s.scan->prob); scan_of.push_back(k); }
+        else if (s.up && s.up->runs) { ups.push_back(s.up->prob); up_of.push_back(k); }
     }
+    lap("first pass prepared");
     std::vector<vgk_result> res; std::vector<vgk_op> ops;
     run(scans, false, res, ops, "scan");
+    lap("scan engine call");
     for (size_t q = 0; q < scan_of.size(); ++q) {
         const size_t k = scan_of[q]; State& s = st[k]; const XdropRequest& rq = requests[k]; const vgk_result& r = res[q];
         if (r.score <= 0) continue;      // scan failed: the path stays empty, the caller falls back to gssw (src/aligner.cpp:848-854)
@@ -1168,36 +1200,44 @@ void Aligner::xdrop_align_many(std::vector<XdropRequest>& requests) const {
         else { s.head_ref = rq.graph->get_length(h) - used; s.head_query = scan_len - qused; }
     }
     run(ups, xdrop_band, res, ops, "xdrop engine");
-    for (size_t q = 0; q < up_of.size(); ++q) {
+    lap("seed-side engine call");
+    each(up_of.size(), [&](size_t q) {
         const size_t k = up_of[q]; State& s = st[k]; const XdropRequest& rq = requests[k];
         std::vector<vgk_op> mine = ops_of(res[q], ops);
         const Extension up = xdrop_extend_finish(*rq.graph, rq.order, rq.alignment->sequence, *s.up, res[q], mine);
         s.head_node = up.end_node; s.head_ref = up.end_ref_offset; s.head_query = up.end_query; s.have_head = true;
-    }
+    });
     // ---- second pass: the traced extension from the head the other way (align_downward, :687-722)
     std::vector<vgk_gssw_problem> downs; std::vector<size_t> down_of;
-    for (size_t k = 0; k < n; ++k) {
+    each(n, [&](size_t k) {
         State& s = st[k]; const XdropRequest& rq = requests[k];
-        if (!s.live || !s.have_head) continue;
+        if (!s.live || !s.have_head) return;
         s.down = std::make_unique<ExtensionJob>();
         xdrop_extend_prepare(*rq.graph, rq.order, s.head_node, s.head_ref, rq.alignment->sequence, rq.alignment->quality, s.head_query, !s.direction, true, rq.max_gap_length, *s.down);
-        if (s.down->runs) { downs.push_back(s.down->prob); down_of.push_back(k); }
-    }
+    });
+    for (size_t k = 0; k < n; ++k) if (st[k].down && st[k].down->runs) { downs.push_back(st[k].down->prob); down_of.push_back(k); }
+    lap("second pass prepared");
     run(downs, xdrop_band, res, ops, "xdrop engine");
+    lap("traced engine call");
     std::vector<char> answered(n, 0);
-    for (size_t q = 0; q < down_of.size(); ++q) {
+    each(down_of.size(), [&](size_t q) {
         const size_t k = down_of[q]; State& s = st[k]; const XdropRequest& rq = requests[k];
         std::vector<vgk_op> mine = ops_of(res[q], ops);
         Extension down = xdrop_extend_finish(*rq.graph, rq.order, rq.alignment->sequence, *s.down, res[q], mine);
         xdrop_finish(*rq.alignment, *rq.graph, rq.order, down, s.head_node, s.head_ref, s.head_query, s.direction);
         answered[k] = 1;
-    }
-    for (size_t k = 0; k < n; ++k) {
+    });
+    each(n, [&](size_t k) {
         State& s = st[k]; const XdropRequest& rq = requests[k];
-        if (!s.live || !s.have_head || answered[k]) continue;
+        if (!s.live || !s.have_head || answered[k]) return;
         Extension down = s.down->ext;                                   // nothing ran: nothing of the read or the graph lies that way
         xdrop_finish(*rq.alignment, *rq.graph, rq.order, down, s.head_node, s.head_ref, s.head_query, s.direction);
-    }
+    });
+    lap("finished");
+    // the jobs' arrays were allocated on the threads above; handing them back one request after another on this thread alone was a third of
+    // a rescue batch's time
+    each(n, [&](size_t k) { st[k] = State{}; });
+    lap("released");
 }
 
 void Aligner::align_xdrop_many(std::vector<XdropRequest>& requests) const {

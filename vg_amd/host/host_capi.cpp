@@ -15,6 +15,7 @@
 #include "mapq_cap.hpp"
 #include "extension_scoring.hpp"
 #include "aligner_client.hpp"
+#include "rescue_stage.hpp"
 #include <sstream>
 
 using namespace vgamd;
@@ -187,6 +188,28 @@ int vgh_align_xdrop_many(vgh_aligner* a, vgh_graph** graphs, const char** reads,
         js += "]";
         if (js.size() + 1 > json_cap) { g_last_error = "json buffer too small"; return -2; }
         std::memcpy(json_out, js.c_str(), js.size() + 1);
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// run_rescue_stage (rescue_stage.hpp): requests flat, 6 numbers each {node_lo, node_hi, seed_begin, seed_end, seed_node (-1: none), seed_offset}; reads flat
+// with offsets; out[6 k ..] = {score, status, first_node, first_offset, n_mappings, aligned read bases}
+int vgh_rescue_stage(vgh_aligner* a, uint32_t n_nodes, const uint32_t* node_len, const uint64_t* seq_off, const char* seq, const uint32_t* succ_off, const uint32_t* succ,
+                     int n, const char* reads, const uint64_t* read_off, const int64_t* requests, uint64_t max_dozeu_cells, int host_threads, int64_t* out) {
+    try {
+        RescueGraph G; G.n_nodes = n_nodes; G.node_len = node_len; G.seq_off = seq_off; G.seq = seq; G.succ_off = succ_off; G.succ = succ;
+        std::vector<RescueRequest> rq((size_t)n);
+        for (int k = 0; k < n; ++k) {
+            RescueRequest& r = rq[(size_t)k]; const int64_t* q = requests + 6 * (size_t)k;
+            r.read = reads + read_off[k]; r.read_len = (uint32_t)(read_off[k + 1] - read_off[k]);
+            r.node_lo = (uint32_t)q[0]; r.node_hi = (uint32_t)q[1]; r.seed_begin = q[2]; r.seed_end = q[3]; r.seed_node = q[4]; r.seed_offset = q[5];
+        }
+        std::vector<RescueResult> res;
+        run_rescue_stage(*a->a, G, rq, max_dozeu_cells ? max_dozeu_cells : default_max_dozeu_cells, (unsigned)std::max(host_threads, 0), res);
+        for (int k = 0; k < n; ++k) {
+            const RescueResult& r = res[(size_t)k]; int64_t* o = out + 6 * (size_t)k;
+            o[0] = r.score; o[1] = r.status; o[2] = r.first_node; o[3] = r.first_offset; o[4] = r.n_mappings; o[5] = r.aligned_read_bases;
+        }
         return 0;
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }

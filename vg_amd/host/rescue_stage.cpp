@@ -1,0 +1,82 @@
+// rescue_stage.cpp — see rescue_stage.hpp.
+#include "rescue_stage.hpp"
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <thread>
+#include "rescue_fixups.hpp"
+
+namespace vgamd {
+
+namespace {
+template <class F> void on_threads(size_t n, unsigned threads, F body) {
+    if (!threads) threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(n, 1));
+    std::atomic<size_t> next{0};
+    auto work = [&]() { for (size_t i; (i = next.fetch_add(64)) < n;) for (size_t k = i; k < std::min(n, i + 64); ++k) body(k); };
+    std::vector<std::thread> ts;
+    for (unsigned t = 1; t < threads; ++t) ts.emplace_back(work);
+    work();
+    for (auto& t : ts) t.join();
+}
+}  // namespace
+
+void run_rescue_stage(const Aligner& aligner, const RescueGraph& G, const std::vector<RescueRequest>& requests, uint64_t max_cells,
+                      unsigned host_threads, std::vector<RescueResult>& results) {
+    const size_t n = requests.size();
+    results.assign(n, RescueResult{});
+    auto lap_t0 = std::chrono::steady_clock::now(); const bool lap_on = std::getenv("VGAMD_TIMING") != nullptr;
+    auto lap = [&](const char* what) { if (!lap_on) return; const auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "[rescue_stage] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - lap_t0).count()); lap_t0 = t; };
+    std::deque<HashGraph> graphs(n);
+    std::deque<Alignment> alns(n);
+    std::vector<Aligner::XdropRequest> all(n);
+    std::vector<uint8_t> runs(n, 0);
+    // 1. the subgraphs (nodes [lo, hi) and the edges among them), their order, the guard, dozeu's seed
+    on_threads(n, host_threads, [&](size_t k) {
+        const RescueRequest& rq = requests[k]; RescueResult& out = results[k];
+        if (rq.node_lo >= rq.node_hi || rq.node_hi > G.n_nodes || !rq.read_len) { out.status = 2; return; }
+        uint64_t bases = 0;
+        for (uint32_t v = rq.node_lo; v < rq.node_hi; ++v) bases += G.node_len[v];
+        if (bases * rq.read_len > max_cells) { out.status = 1; return; }                   // (:3372-3381: refused, the pair keeps what it has)
+        HashGraph& g = graphs[k];
+        Aligner::XdropRequest& x = all[k];
+        x.order.reserve(rq.node_hi - rq.node_lo);
+        for (uint32_t v = rq.node_lo; v < rq.node_hi; ++v) x.order.push_back(g.create_handle(std::string(G.seq + G.seq_off[v], G.node_len[v]), (nid_t)v + 1));
+        for (uint32_t v = rq.node_lo; v < rq.node_hi; ++v)
+            for (uint32_t e = G.succ_off[v]; e < G.succ_off[v + 1]; ++e)
+                if (G.succ[e] >= rq.node_lo && G.succ[e] < rq.node_hi) g.create_edge(x.order[v - rq.node_lo], x.order[G.succ[e] - rq.node_lo]);
+        Alignment& aln = alns[k];
+        aln.sequence.assign(rq.read, rq.read_len);
+        x.alignment = &aln; x.graph = &g; x.reverse_complemented = false;
+        x.max_gap_length = (uint16_t)std::min<size_t>(aligner.scorer->longest_detectable_gap(rq.read_len, rq.read_len / 2), 65535);      // (:3383)
+        if (rq.seed_node >= (int64_t)rq.node_lo && rq.seed_node < (int64_t)rq.node_hi && rq.seed_end > rq.seed_begin) {
+            MaximalExactMatch m; m.begin = (size_t)rq.seed_begin; m.end = (size_t)rq.seed_end;
+            m.nodes.push_back({(nid_t)rq.seed_node + 1, (size_t)rq.seed_offset, false});
+            x.mems.push_back(m);
+        }
+        runs[k] = 1;
+    });
+    lap("subgraphs");
+    // 2. every request's X-drop passes side by side
+    std::vector<Aligner::XdropRequest> todo; std::vector<size_t> owner;
+    for (size_t k = 0; k < n; ++k) if (runs[k]) { todo.push_back(std::move(all[k])); owner.push_back(k); }
+    if (!todo.empty()) aligner.align_xdrop_many(todo);
+    lap("align_xdrop_many");
+    // 3. the fix-ups, the answers
+    on_threads(todo.size(), host_threads, [&](size_t a) {
+        const size_t k = owner[a]; Alignment& aln = alns[k]; RescueResult& out = results[k];
+        fix_dozeu_score(aln, aligner, graphs[k], todo[a].order);
+        fix_dozeu_end_deletions(aln);
+        out.score = aln.score; out.n_mappings = (uint32_t)aln.path.mapping.size();
+        if (!aln.path.mapping.empty()) { out.first_node = aln.path.mapping.front().position.node_id - 1; out.first_offset = aln.path.mapping.front().position.offset; }
+        uint32_t to = 0;
+        for (const Mapping& m : aln.path.mapping) for (const Edit& e : m.edit) if (e.from_length) to += (uint32_t)e.to_length;
+        out.aligned_read_bases = to;
+        graphs[k] = HashGraph(); aln = Alignment(); todo[a] = Aligner::XdropRequest();      // released where they were built: on the threads
+    });
+    lap("fix-ups");
+}
+
+}  // namespace vgamd

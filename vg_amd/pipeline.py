@@ -349,3 +349,126 @@ class ChainStage:
 
     def __del__(self):
         self.close()
+
+
+# ---- a paired-end slice: both mates through the stage, the mate without a full-length extension rescued from the other's position ------------
+def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device=True, rescue_stdevs=4.0, timing=None, host_threads=0):
+    """giraffe's paired-end shape on one batch of pairs (PairedWorkload): (1) every read through seeding, gapless extension and the tails
+    (align_stage_device, or align_stage over the oracle when device = False); (2) for a pair with exactly one mate whose extension set is
+    full-length, the other mate is RESCUED: the nodes at the fragment's distance from the mapped mate — here a run of nodes found by
+    column coordinate, a stated stand-in for subgraph_in_distance_range over the absent SnarlDistanceIndex —, the best of its own
+    extensions inside them as dozeu's seed, Aligner::align_xdrop + fix_dozeu_score + fix_dozeu_end_deletions for all such mates at
+    once (vg_amd/host/rescue_stage.cpp = MinimizerMapper::attempt_rescue, src/minimizer_mapper.cpp:3264-3440); (3) a pair's score = the
+    mapped mate's + the better of the rescued alignment and what the stage had for that mate.
+    -> dict(read_score, rescued (indices of rescued reads), rescue (RESCUE_DT-like int64 [k, 6]), pair_score)"""
+    import time
+    t0 = time.perf_counter()
+    n = wl.n
+    if device:
+        class _B:
+            pass
+        b = _B(); b.n = n
+        seed_off, _, _ = eng.minimizer_seeds(mindex, index, wl.reads, wl.read_off, keep_on_device=True)
+        out = align_stage_device(eng, index, b, seeded=int(seed_off[-1]), aligned=False)
+    else:
+        so, sd, _ = eng.minimizer_seeds(mindex, index, wl.reads, wl.read_off)
+        sub = capi.GaplessSet(wl.reads, wl.read_off, sd, so, node_cap=len(sd) * 16, mism_cap=len(sd) * 12)
+        out = align_stage(eng, index, oriented_len, sub)
+    t1 = time.perf_counter()
+    res, ext, nodes = out["res"], out["ext"], out["nodes"]
+    read_score = np.asarray(out["read_score"], dtype=np.int64)
+    L = wl.read_len
+    g = wl.graph
+    full = (res["status"] == 0) & (res["full_length"] != 0)
+    a_full, b_full = full[0::2], full[1::2]
+    pairs = np.nonzero(a_full != b_full)[0]
+    mapped = np.where(a_full[pairs], 2 * pairs, 2 * pairs + 1); lost = mapped ^ 1
+    # where the mapped mate lies: the first node of its first (full-length) extension, on the strand the read reads forward on
+    e0 = res["ext_begin"][mapped].astype(np.int64)
+    first = nodes[ext["path_begin"][e0].astype(np.int64)].astype(np.int64)
+    last = nodes[(ext["path_begin"][e0].astype(np.int64) + ext["path_len"][e0] - 1)].astype(np.int64)
+    fwd = (first & 1) == 0
+    col = g.col
+    # forward-mapped mate starting at column s: its partner lies downstream on the other strand, within [s + mean - k sd - L, s + mean + k sd];
+    # reverse-mapped mate ending at column e (the forward end of its last path node): upstream on the forward strand
+    lo_d = max(0.0, wl.mean - rescue_stdevs * wl.sd - L); hi_d = (wl.mean + rescue_stdevs * wl.sd) * 1.1 + 40
+    s_col = col[first >> 1] + ext["offset"][e0]
+    e_col = col[(first >> 1) + 1] - ext["offset"][e0]                  # reverse strand: the read's first base is the node's last minus the offset
+    c_lo = np.where(fwd, s_col + lo_d, e_col - hi_d); c_hi = np.where(fwd, s_col + hi_d, e_col - lo_d)
+    node_lo = np.clip(np.searchsorted(col, np.maximum(c_lo, 0), side="right") - 1, 0, g.n_nodes - 1)
+    node_hi = np.clip(np.searchsorted(col, np.minimum(c_hi, col[-1] - 1), side="right"), 1, g.n_nodes)
+    # the mate to rescue as it reads along the FORWARD strand of that subgraph: as sequenced when its partner is on the reverse strand
+    rescue_rc = fwd
+    rd = wl.reads.reshape(-1, L)[lost]
+    rd = np.where(rescue_rc[:, None], _COMP[rd[:, ::-1]], rd)
+    # dozeu's seed: the best extension of the lost mate inside the subgraph, on the strand it is rescued on
+    req = np.zeros((len(pairs), 6), dtype=np.int64); req[:, 0] = node_lo; req[:, 1] = node_hi; req[:, 4] = -1
+    olen = np.repeat(g.node_len.astype(np.int64), 2)
+    eb = res["ext_begin"][lost].astype(np.int64); ne = np.where(res["status"][lost] == 0, res["n_ext"][lost].astype(np.int64), 0)
+    tot = int(ne.sum())
+    if tot:
+        # every extension of every lost mate at once: which of them lie inside the mate's subgraph on the strand it is rescued on, the best per mate
+        owner = np.repeat(np.arange(len(pairs)), ne)
+        row = eb[owner] + (np.arange(tot) - np.repeat(np.cumsum(ne) - ne, ne))
+        pb = ext["path_begin"][row].astype(np.int64); pl = ext["path_len"][row].astype(np.int64)
+        keep = pl > 0
+        owner, row, pb, pl = owner[keep], row[keep], pb[keep], pl[keep]
+        if len(row):
+            seg = np.cumsum(pl) - pl
+            idx = np.repeat(pb, pl) + (np.arange(int(pl.sum())) - np.repeat(seg, pl))
+            pv = nodes[idx].astype(np.int64) >> 1
+            pmin = np.minimum.reduceat(pv, seg); pmax = np.maximum.reduceat(pv, seg)
+            first_o = nodes[pb].astype(np.int64); last_o = nodes[pb + pl - 1].astype(np.int64)
+            ok = (((first_o & 1) == 1) == rescue_rc[owner]) & (pmin >= node_lo[owner]) & (pmax < node_hi[owner])
+            owner, row, pb, pl, first_o, last_o = owner[ok], row[ok], pb[ok], pl[ok], first_o[ok], last_o[ok]
+            if len(row):
+                order = np.lexsort((row, -ext["score"][row].astype(np.int64), owner))       # per mate: best score, the earlier extension among equals
+                take = order[np.concatenate([[True], owner[order][1:] != owner[order][:-1]])]
+                k = owner[take]; x = row[take]
+                rb = ext["read_begin"][x].astype(np.int64); re_ = ext["read_end"][x].astype(np.int64); off = ext["offset"][x].astype(np.int64)
+                cs = np.concatenate([[0], np.cumsum(olen[nodes.astype(np.int64)])])
+                path_bases = cs[pb[take] + pl[take]] - cs[pb[take]]
+                lastlen = olen[last_o[take]]
+                # seen from the forward strand (a mate rescued as its reverse complement): the path backwards, the read interval mirrored, the
+                # offset counted from the last node's other end
+                end_in_last = np.where(pl[take] > 1, (re_ - rb) - (path_bases - off - lastlen), off + (re_ - rb))
+                rc = rescue_rc[k]
+                req[k, 2] = np.where(rc, L - re_, rb); req[k, 3] = np.where(rc, L - rb, re_)
+                req[k, 4] = np.where(rc, last_o[take] >> 1, first_o[take] >> 1); req[k, 5] = np.where(rc, lastlen - end_in_last, off)
+    t2 = time.perf_counter()
+    outv = np.zeros((len(pairs), 6), dtype=np.int64)
+    if len(pairs):
+        h = _host_lib()
+        h.vgh_rescue_stage.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
+        flat = np.ascontiguousarray(rd).ravel(); roff = (np.arange(len(pairs) + 1, dtype=np.uint64) * L)
+        node_len = np.ascontiguousarray(g.node_len, dtype=np.uint32); seq_off = np.ascontiguousarray(g.col[:-1], dtype=np.uint64); seq = np.ascontiguousarray(g.seq)
+        rc = h.vgh_rescue_stage(host_aligner.ptr, g.n_nodes, node_len.ctypes.data, seq_off.ctypes.data, seq.ctypes.data, wl.succ_off.ctypes.data, wl.succ.ctypes.data,
+                                len(pairs), flat.ctypes.data, roff.ctypes.data, req.ctypes.data, 0, host_threads, outv.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(h.vgh_last_error().decode())
+    t3 = time.perf_counter()
+    pair_score = read_score[0::2] + read_score[1::2]
+    pair_score[pairs] = read_score[mapped] + np.maximum(outv[:, 0], read_score[lost])
+    if timing is not None:
+        for k, v in (("stage (seeding, extension, tails)", t1 - t0), ("rescue requests (host)", t2 - t1), ("rescue stage (subgraphs, X-drop passes, fix-ups)", t3 - t2)):
+            timing[k] = timing.get(k, 0.0) + v
+    return dict(read_score=read_score, rescued=lost, mapped=mapped, requests=req, rescue=outv, pair_score=pair_score, res=res)
+
+
+class HostAlignerHandle:
+    """a vgamd::Aligner of the host shim bound to an engine library (None: the HIP product library) — what paired_stage's rescue half runs on"""
+
+    def __init__(self, lib=None, device=0, scores=(1, 4, 6, 1, 5)):
+        h = _host_lib()
+        h.vgh_aligner_create.restype = ctypes.c_void_p; h.vgh_aligner_create.argtypes = [ctypes.c_char_p] + [ctypes.c_int] * 6
+        h.vgh_aligner_destroy.argtypes = [ctypes.c_void_p]
+        self.h = h
+        self.ptr = h.vgh_aligner_create(lib.encode() if lib else None, device, *scores)
+        if not self.ptr:
+            raise RuntimeError("vgh_aligner_create: " + (h.vgh_last_error() or b"?").decode())
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.h.vgh_aligner_destroy(self.ptr); self.ptr = None
+
+    __del__ = close

@@ -910,3 +910,63 @@ class Config2Workload:
                 reads[ins] = shifted
             self.batches.append((reads.ravel(), np.arange(n + 1, dtype=np.int64) * read_len))
         self.n = n_reads; self.read_len = read_len
+
+
+class PairedWorkload:
+    """A one-GPU slice of BASELINE.json configs[3]: `n_pairs` read pairs of 2 x 150 bp off the two haplotypes of a VariationGraph (the chr22-scale
+    construction at `ref_len` bases), fragment lengths ~ N(mean, sd), either strand, 1 % substitutions; `hard` of the pairs have a second mate
+    that no gapless extension will cover (an inserted stretch of 3-6 bases and 3 % substitutions) — the mate giraffe rescues from the mapped
+    one's position (MinimizerMapper::attempt_rescue, src/minimizer_mapper.cpp:3264-3440).  Reads lie pair by pair (read 2 i, 2 i + 1): a
+    shard of the stream keeps the two reads of a pair together (vg_amd/shard.py, group = 2)."""
+
+    def __init__(self, n_pairs, ref_len=5_000_000, seed=41, read_len=150, mean=400.0, sd=40.0, hard=0.08, graph=None):
+        g = graph if graph is not None else VariationGraph(ref_len=ref_len)
+        self.graph = g; self.node_len = g.node_len; self.seq = g.seq
+        self.threads = [(2 * np.nonzero(hap_pos >= 0)[0]).astype(np.uint32) for _, hap_pos in g.haps]
+        rng = np.random.default_rng(seed)
+        comp = _comp_table()
+        n = n_pairs
+        frag = np.clip(np.rint(rng.normal(mean, sd, n)), 2 * read_len // 2 + 20, mean + 4 * sd).astype(np.int64)
+        which = rng.integers(0, 2, n); flip = rng.random(n) < 0.5
+        col = np.arange(read_len)[None, :]
+        left = np.empty((n, read_len), dtype=np.uint8); right = np.empty((n, read_len), dtype=np.uint8)
+        start = np.zeros(n, dtype=np.int64)
+        for h in (0, 1):
+            sel = np.nonzero(which == h)[0]
+            hseq = g.haps[h][0]
+            a = rng.integers(0, len(hseq) - int(frag.max()) - 1, len(sel))
+            start[sel] = a
+            left[sel] = hseq[a[:, None] + col]
+            right[sel] = hseq[(a + frag[sel] - read_len)[:, None] + col]
+        right_rc = comp[right[:, ::-1]]; left_rc = comp[left[:, ::-1]]
+        # the fragment as sequenced: mate 1 forward from its left end and mate 2 reverse from its right end, or the other way round
+        m1 = np.where(flip[:, None], right_rc, left); m2 = np.where(flip[:, None], left, right_rc)
+        reads = np.empty((2 * n, read_len), dtype=np.uint8); reads[0::2] = m1; reads[1::2] = m2
+        sub = rng.random(reads.shape) < 0.01
+        reads[sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
+        hard_pairs = np.nonzero(rng.random(n) < hard)[0]
+        for i in hard_pairs:                                               # the second mate: an inserted stretch + more substitutions
+            r = reads[2 * i + 1].copy()
+            k = int(rng.integers(3, 7)); p = int(rng.integers(40, read_len - 40))
+            r = np.concatenate([r[:p], ACGT[rng.integers(0, 4, k)], r[p:]])[:read_len]
+            s = rng.random(read_len) < 0.03
+            r[s] = ACGT[rng.integers(0, 4, int(s.sum()))]
+            reads[2 * i + 1] = r
+        self.reads = reads.ravel(); self.read_off = np.arange(2 * n + 1, dtype=np.int64) * read_len
+        self.n_pairs = n; self.n = 2 * n; self.read_len = read_len; self.mean = mean; self.sd = sd
+        self.truth = dict(hap=which, start=start, frag=frag, flip=flip, hard=hard_pairs)
+        # successors as CSR over node indices (the rescue stage builds its subgraphs from them)
+        dst = np.repeat(np.arange(g.n_nodes), np.diff(g.pred_off.astype(np.int64))); src = g.pred_idx.astype(np.int64)
+        e = np.lexsort((dst, src))
+        self.succ_off = np.concatenate([[0], np.cumsum(np.bincount(src, minlength=g.n_nodes))]).astype(np.uint32)
+        self.succ = dst[e].astype(np.uint32)
+
+    def subset(self, k):
+        """the first k pairs as a workload of their own (same graph, same reads)"""
+        w = object.__new__(PairedWorkload)
+        w.__dict__.update(self.__dict__)
+        w.reads = self.reads[:2 * k * self.read_len]; w.read_off = self.read_off[:2 * k + 1]
+        w.n_pairs = k; w.n = 2 * k
+        w.truth = dict(self.truth, hap=self.truth["hap"][:k], start=self.truth["start"][:k], frag=self.truth["frag"][:k], flip=self.truth["flip"][:k],
+                       hard=self.truth["hard"][self.truth["hard"] < k])
+        return w
