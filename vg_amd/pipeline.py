@@ -2,8 +2,17 @@
 clusters that no full-length extension resolves, the tails of every extension: tail forests (vgk_tail_forest), every tree a window
 of the forest graph (vgk_gssw_pack_windows), left-pinned X-drop -> the extension's total score (src/minimizer_mapper.cpp:5480-5535).
 
-Host-side glue only (numpy, vectorised): which tails exist, where they start, what their bases are.  It is what a maintainer's patch
-of MinimizerMapper::extension_to_alignment's caller would do per batch, and it is what bench.py --workload giraffe times."""
+Which route is which (every route takes an engine handle and runs on whatever library that handle binds):
+
+  product routes — what bench.py times on the HIP library and what a maintainer's patch would call
+    align_stage_device   the stage with the tails on the device too (vgk_tail_stage); configs[2] and the paired slice run this
+    align_stage_native   the stage with the glue behind the extension in the host shim (C++ threads); bench --workload giraffe
+    ChainStage           configs[4]: the chain alignment of a batch of long reads behind one host-shim call
+    paired_stage         configs[3] slice: both mates through align_stage_device, the lost mate through the native rescue stage
+  CHECKER-SIDE ONLY — the stage spelled out in numpy, kept because it is what the OTHER side of every comparison runs (tests/,
+  __graft_entry__.smoke() and bench.py's parity / cpu_baseline legs hand it the oracle's engine handle); nothing timed as the
+  product goes through these, and they are not part of what a maintainer would take over
+    align_stage, tails_of_extensions, tail_sequences, tree_windows, winning_alignments, chain_stage"""
 import ctypes
 import os
 
@@ -17,7 +26,8 @@ for _a, _b in zip(b"ACGTN", b"TGCAN"):
 
 
 def tails_of_extensions(oriented_len, read_off, res, ext, nodes, scoring=(1, 6, 1, 5)):
-    """-> dict of numpy arrays, one entry per TAIL (an extension end that does not reach its read end, of a read whose extension set
+    """[checker-side: the numpy statement of what run_tail_stage / vgk_tail_stage do natively]
+    -> dict of numpy arrays, one entry per TAIL (an extension end that does not reach its read end, of a read whose extension set
     is not full-length): problems (TAIL_DT), ext (index into `ext`), left (bool), read (index), begin / end (the tail's interval of
     the read), gap (longest detectable gap)"""
     n = len(res)
@@ -55,7 +65,7 @@ def tails_of_extensions(oriented_len, read_off, res, ext, nodes, scoring=(1, 6, 
 
 
 def tail_sequences(reads, read_off, t):
-    """the tails' bases, flat: a right tail as it is, a left tail reverse-complemented (:5660) -> (bases, offsets)"""
+    """[checker-side] the tails' bases, flat: a right tail as it is, a left tail reverse-complemented (:5660) -> (bases, offsets)"""
     ln = (t["end"] - t["begin"]).astype(np.int64)
     off = np.concatenate([[0], np.cumsum(ln)])
     left = t["left"]
@@ -74,7 +84,7 @@ def tail_sequences(reads, read_off, t):
 
 
 def tree_windows(res, forest, seq, seq_off, gap):
-    """one left-pinned X-drop window problem per tree -> (WindowSet, tail index of every tree)"""
+    """[checker-side] one left-pinned X-drop window problem per tree -> (WindowSet, tail index of every tree)"""
     flags = capi.VGK_XDROP_PINNED | capi.VGK_GSSW_TRACEBACK
     if (res["n_trees"] <= 1).all():
         has = np.nonzero(res["n_nodes"] > 0)[0]
@@ -100,7 +110,9 @@ def tree_windows(res, forest, seq, seq_off, gap):
 
 
 def align_stage(eng, index, oriented_len, gs, ops_per_problem=32, timing=None):
-    """The whole stage for one batch of clusters (a GaplessSet).  -> dict: the extension outputs, the tails, per tail its best tree's
+    """[checker-side: the route the oracle's handle is driven through in tests, smoke() and bench.py's parity legs; bench.py times it on
+    the HIP library only when VGAMD_GIRAFFE_NUMPY_GLUE asks for the comparison of glue costs]
+    The whole stage for one batch of clusters (a GaplessSet).  -> dict: the extension outputs, the tails, per tail its best tree's
     score, per extension its total score, per read the best total; `forest`, `batch` results for parity checks.  timing: a dict that
     collects seconds per step."""
     import time
@@ -184,7 +196,8 @@ def align_stage_native(eng, index, oriented_len, gs, ops_per_problem=32, scoring
 
 # ---- configs[4]: a long read cut at its anchors (workloads.LongReadWorkload) -------------------------------------------------------
 def chain_stage(eng, index, wl, match=1, timing=None):
-    """Every stretch between anchors through WFAExtender (vgk_wfa_extend: connect / prefix / suffix); the connects it gives up on —
+    """[checker-side since ChainStage exists: tests/test_longread_stage.py holds ChainStage to it]
+    Every stretch between anchors through WFAExtender (vgk_wfa_extend: connect / prefix / suffix); the connects it gives up on —
     score cap, tables — through BandedGlobalAligner between the two anchors (vgk_banded_align), as giraffe's chain alignment does
     (src/minimizer_mapper.cpp:2955-3100).  -> dict: wfa results, the fallback's results, per-read chain score."""
     import time
@@ -242,7 +255,7 @@ def align_stage_device(eng, index, gs, ops_per_problem=32, timing=None, seeded=N
 
 
 def winning_alignments(out):
-    """From align_stage's output (every tree's alignment): per tail what vgk_tail_stage_aligned reports — the best tree's alignment, the
+    """[checker-side] From align_stage's output (every tree's alignment): per tail what vgk_tail_stage_aligned reports — the best tree's alignment, the
     first among equals, nothing for a soft clip; nodes translated to oriented nodes of the index.  -> list of (ext, left, read_begin,
     read_end, score, first_offset, [(node, op, len)])"""
     t = out["tails"]
