@@ -110,3 +110,34 @@ def test_banded_xdrop_on_hip_equals_the_oracle():
     assert run_xdrop_cases_with_band(util.ENGINE_LIB) >= 22
     long_graphs_and_a_reused_context(util.ENGINE_LIB, 300)
     quality_adjusted_band(util.ENGINE_LIB, 1000)
+
+
+# Three fills behind one entry: two rows to a register with 16-bit cells (the default when the call's bounds allow,
+# xdrop_band_pk_lane), int32 arithmetic over 16-bit cells, int32 throughout (GsswMatrixParams::xb_cell16 = 2, 1, 0): the same answers
+def test_emulated_band_with_32_bit_cells(emu_lib, monkeypatch):
+    monkeypatch.setenv("VGAMD_XBAND_CELLS32", "1")
+    band_vs_oracle(emu_lib, 16, max_read=60)
+
+
+def test_emulated_band_with_32_bit_arithmetic_over_16_bit_cells(emu_lib, monkeypatch):
+    monkeypatch.setenv("VGAMD_XBAND_ARITH32", "1")
+    band_vs_oracle(emu_lib, 16, max_read=60)
+
+
+def test_emulated_band_falls_back_to_32_bit_cells_on_large_scores(emu_lib):
+    sc = capi.Scoring.simple(60, 90, 100, 20, 50)          # a step may cost 260: 16-bit cells hold (read + graph) * 260 only for the shortest problems
+    ps = random_xdrop_set(21, 24, None, max_nodes=8, max_node_len=16, max_read=60)
+    same(capi.Engine(sc, lib=emu_lib).xdrop_band_align(ps), capi.Engine(sc, lib=util.ORACLE_LIB).xdrop_band_align(ps))
+
+
+@pytest.mark.gpu
+def test_banded_xdrop_on_hip_with_32_bit_cells(monkeypatch):
+    monkeypatch.setenv("VGAMD_XBAND_ARITH32", "1")
+    band_vs_oracle(util.ENGINE_LIB, 600)
+    monkeypatch.delenv("VGAMD_XBAND_ARITH32")
+    monkeypatch.setenv("VGAMD_XBAND_CELLS32", "1")
+    band_vs_oracle(util.ENGINE_LIB, 600)
+    sc = capi.Scoring.simple(60, 90, 100, 20, 50)
+    ps = random_xdrop_set(21, 400, None, max_nodes=8, max_node_len=16, max_read=100)
+    monkeypatch.delenv("VGAMD_XBAND_CELLS32")
+    same(capi.Engine(sc, lib=util.ENGINE_LIB).xdrop_band_align(ps), capi.Engine(sc, lib=util.ORACLE_LIB).xdrop_band_align(ps))

@@ -686,11 +686,11 @@ __global__ void __launch_bounds__(64) gssw_matrix_kernel(const GsswMatrixParams 
 // of different lengths; a row is active or masked off as a whole, and nothing here reaches outside its row.
 constexpr uint32_t XB_STAGE16 = 1024, XB_STAGE64 = 4096;          // graph bases staged in LDS per problem (xdrop_band_wave_lane)
 struct XlDpp16 {
-    uint8_t* stg; int32_t* cc;
+    uint8_t* stg; int32_t* cc; uint32_t cap = XB_STAGE16;
     __device__ __forceinline__ int32_t* col_cache() const { return cc; }
     __device__ __forceinline__ void lds_sync() const { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
     __device__ __forceinline__ uint8_t* stage() const { return stg; }
-    __device__ __forceinline__ uint32_t stage_cap() const { return XB_STAGE16; }
+    __device__ __forceinline__ uint32_t stage_cap() const { return cap; }
     __device__ __forceinline__ void stage_sync() const { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
     __device__ __forceinline__ uint32_t width() const { return 16u; }
     __device__ __forceinline__ int32_t down(int32_t v) const { return __builtin_amdgcn_update_dpp(BNEG, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false); }
@@ -728,29 +728,53 @@ struct XlDppStaged : XlDpp {
     __device__ __forceinline__ uint32_t stage_cap() const { return XB_STAGE64; }
     __device__ __forceinline__ void stage_sync() const { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 };
+// (CT: the planes' cell type — int32_t, or int16_t when the call's bounds allow, GsswMatrixParams::xb_cell16)
+template <class CT>
 __global__ void __launch_bounds__(64) xdrop_band_kernel(const GsswMatrixParams P) {
     __shared__ uint8_t stg[XB_STAGE64];
     __shared__ int32_t cc[2 * 2 * 64 * 8];                       // two last columns (H | E) of up to 512 rows
     XlDppStaged xl; xl.stg = stg; xl.cc = cc;
-    xdrop_band_wave_lane(P, P.xb_order ? P.xb_order[P.xb_n16 + blockIdx.x] : blockIdx.x, threadIdx.x, xl);
+    xdrop_band_wave_lane_t<CT>(P, P.xb_order ? P.xb_order[P.xb_n16 + blockIdx.x] : blockIdx.x, threadIdx.x, xl);
 }
 // three wavefronts per SIMD (168 VGPRs, five spilled dwords): 26.2 -> 21.0 ms per 200 000 tails against the compiler's own 175 VGPRs = two;
 // four (128 VGPRs, 38 spilled): the same 20.9 ms
 #ifndef VGK_XB_OCC
 #define VGK_XB_OCC 3
 #endif
+template <class CT>
 __global__ void __launch_bounds__(64, VGK_XB_OCC) xdrop_band_kernel16(const GsswMatrixParams P) {
     __shared__ uint8_t stg[4 * XB_STAGE16];
     __shared__ int32_t cc[4 * 2 * 2 * 16 * 8];                   // per problem: two last columns (H | E) of up to 128 rows
     const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 4);
     if (slot >= P.xb_n16) return;
     XlDpp16 xl; xl.stg = stg + (threadIdx.x >> 4) * XB_STAGE16; xl.cc = cc + (threadIdx.x >> 4) * (2 * 2 * 16 * 8);
-    xdrop_band_wave_lane(P, P.xb_order[slot], threadIdx.x & 15u, xl);
+    xdrop_band_wave_lane_t<CT>(P, P.xb_order[slot], threadIdx.x & 15u, xl);
 }
 // the tracebacks of the X-drop band path, one lane per problem, in the fills' launch order (neighbours walk graphs of like size)
+// the packed fill (xdrop_band_pk_lane): two rows to a register, half the registers, a quarter of the LDS (a word per row pair in the column
+// cache, 512 staged bases per problem)
+#ifndef VGK_XBP_OCC
+#define VGK_XBP_OCC 4
+#endif
+constexpr uint32_t XBP_STAGE16 = 512;
+__global__ void __launch_bounds__(64, VGK_XBP_OCC) xdrop_band_pk_kernel16(const GsswMatrixParams P) {
+    __shared__ uint8_t stg[4 * XBP_STAGE16];
+    __shared__ int32_t cc[4 * 2 * 2 * 16 * 4];
+    const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 4);
+    if (slot >= P.xb_n16) return;
+    XlDpp16 xl; xl.stg = stg + (threadIdx.x >> 4) * XBP_STAGE16; xl.cc = cc + (threadIdx.x >> 4) * (2 * 2 * 16 * 4); xl.cap = XBP_STAGE16;
+    xdrop_band_pk_lane(P, P.xb_order[slot], threadIdx.x & 15u, xl);
+}
+__global__ void __launch_bounds__(64) xdrop_band_pk_kernel(const GsswMatrixParams P) {
+    __shared__ uint8_t stg[XB_STAGE64];
+    __shared__ int32_t cc[2 * 2 * 64 * 4];
+    XlDppStaged xl; xl.stg = stg; xl.cc = cc;
+    xdrop_band_pk_lane(P, P.xb_order ? P.xb_order[P.xb_n16 + blockIdx.x] : blockIdx.x, threadIdx.x, xl);
+}
+template <class CT>
 __global__ void __launch_bounds__(64) xdrop_band_walk_kernel(const GsswMatrixParams P) {
     const uint32_t k = blockIdx.x * 64 + threadIdx.x;
-    if (k < P.n) xdrop_band_walk_one(P, P.xb_order ? P.xb_order[k] : k);
+    if (k < P.n) xdrop_band_walk_one_t<CT>(P, P.xb_order ? P.xb_order[k] : k);
 }
 template <int R>
 __global__ void __launch_bounds__(64) gssw_matrix_wave_kernel(const GsswMatrixParams P, const uint32_t rows_lo, const uint32_t rows_hi) {
@@ -1155,11 +1179,21 @@ public:
         ms_xband = 0.f;
         if (!p.n) return VGK_OK;
         hipEventRecord(bev[0], stream);
-        if (p.xb_order) {
-            if (p.xb_n16) hipLaunchKernelGGL(xdrop_band_kernel16, dim3((p.xb_n16 + 3) / 4), dim3(64), 0, stream, p);
-            if (p.xb_n64) hipLaunchKernelGGL(xdrop_band_kernel, dim3(p.xb_n64), dim3(64), 0, stream, p);
-        } else hipLaunchKernelGGL(xdrop_band_kernel, dim3(p.n), dim3(64), 0, stream, p);
-        if (p.xb_results) hipLaunchKernelGGL(xdrop_band_walk_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
+        auto launch = [&](auto cell) {
+            using CT = decltype(cell);
+            if (p.xb_order) {
+                if (p.xb_n16) hipLaunchKernelGGL(xdrop_band_kernel16<CT>, dim3((p.xb_n16 + 3) / 4), dim3(64), 0, stream, p);
+                if (p.xb_n64) hipLaunchKernelGGL(xdrop_band_kernel<CT>, dim3(p.xb_n64), dim3(64), 0, stream, p);
+            } else hipLaunchKernelGGL(xdrop_band_kernel<CT>, dim3(p.n), dim3(64), 0, stream, p);
+            if (p.xb_results) hipLaunchKernelGGL(xdrop_band_walk_kernel<CT>, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
+        };
+        if (p.xb_cell16 == 2) {
+            if (p.xb_order) {
+                if (p.xb_n16) hipLaunchKernelGGL(xdrop_band_pk_kernel16, dim3((p.xb_n16 + 3) / 4), dim3(64), 0, stream, p);
+                if (p.xb_n64) hipLaunchKernelGGL(xdrop_band_pk_kernel, dim3(p.xb_n64), dim3(64), 0, stream, p);
+            } else hipLaunchKernelGGL(xdrop_band_pk_kernel, dim3(p.n), dim3(64), 0, stream, p);
+            if (p.xb_results) hipLaunchKernelGGL(xdrop_band_walk_kernel<int16_t>, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
+        } else if (p.xb_cell16) launch(int16_t{}); else launch(int32_t{});
         hipEventRecord(bev[1], stream);
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         hipEventElapsedTime(&ms_xband, bev[0], bev[1]);

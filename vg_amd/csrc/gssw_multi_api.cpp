@@ -259,7 +259,7 @@ int vgk_gssw_align_multi(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
                   // the predecessor lists go to one arena; pred_begin is an offset into it
                   uint32_t col = 0;
                   for (uint32_t v = 0; v < p.graph.n_nodes; ++v) {
-                      MNode nd; nd.col_start = col; nd.col_end = col + p.graph.node_len[v]; nd.pred_begin = (uint32_t)a_preds; nd.n_pred = p.graph.pred_off[v + 1] - p.graph.pred_off[v];
+                      MNode nd{}; nd.col_start = col; nd.col_end = col + p.graph.node_len[v]; nd.pred_begin = (uint32_t)a_preds; nd.n_pred = p.graph.pred_off[v + 1] - p.graph.pred_off[v];
                       for (uint32_t k = p.graph.pred_off[v]; k < p.graph.pred_off[v + 1]; ++k) preds[a_preds++] = p.graph.pred_idx[k];
                       nodes[a_nodes + v] = nd; col = nd.col_end;
                   }

@@ -45,7 +45,19 @@ template <int N> static __device__ __forceinline__ uint32_t shl_or(uint32_t a, u
 // provided denormals are not flushed (tools/pkmax3_check.hip verifies that on the device).
 static __device__ __forceinline__ uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// a prefix maximum over the rows of packed pairs (xdrop_band_pk_lane): VOP3P's op_sel picks, per result half, which half of each source it reads
+//   pk_max_lo_into_hi(a):  lo = a.lo,               hi = max(a.hi, a.lo)
+//   pk_max_bhi(a, b):      lo = max(a.lo, b.hi),    hi = max(a.hi, b.hi)
+static __device__ __forceinline__ uint32_t pk_max_lo_into_hi(uint32_t a) {
+    uint32_t r; asm("v_pk_max_u16 %0, %1, %1 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a)); return r; }
+static __device__ __forceinline__ uint32_t pk_max_bhi(uint32_t a, uint32_t b) {
+    uint32_t r; asm("v_pk_max_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// the 32 bits that start 16 bits into {hi:lo}: (lo >> 16) | (hi << 16) — the rows of two neighbouring pairs moved down by one
+static __device__ __forceinline__ uint32_t align16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
 #else
+static inline uint32_t pk_max_lo_into_hi(uint32_t a) { const uint32_t lo = a & 0xffffu, hi = a >> 16; return lo | ((hi > lo ? hi : lo) << 16); }
+static inline uint32_t pk_max_bhi(uint32_t a, uint32_t b) { const uint32_t lo = a & 0xffffu, hi = a >> 16, t = b >> 16; return (lo > t ? lo : t) | ((hi > t ? hi : t) << 16); }
+static inline uint32_t align16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }
 template <uint32_t MASK> static inline uint32_t bit_select(uint32_t a, uint32_t b) { return (MASK & a) | (~MASK & b); }
 template <int N> static inline uint32_t shl_or(uint32_t a, uint32_t c) { return (a << N) | c; }
 static inline uint32_t pk_lo(uint32_t x) { return x & 0xffffu; }

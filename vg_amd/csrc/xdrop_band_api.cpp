@@ -8,11 +8,13 @@
 // ops are packed on the device and only results and ops come back (round 2 copied three planes and traced on host threads).  DESIGN.md
 // §15 has the measurements.  VGK_XDROP_PINNED through vgk_gssw_* (every cell kept, 4-bit codes) stays the default and the fast path.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <emmintrin.h>
 #include "ctx.hpp"
 #include "host_parallel.hpp"
 
@@ -20,11 +22,25 @@ using namespace vgk;
 
 namespace {
 
-inline uint8_t code_read(char ch) {
-    switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
-}
-inline uint8_t code_ref(char ch) {      // dozeu sees the raw node sequences; anything but upper-case ACGT scores as N
-    switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
+// base -> code, sixteen bases per step (SSE2: part of every x86-64): a switch or a table lookup per base is most of a nanosecond, and a
+// call of 200 000 tails codes 62 MB of bases — 5 of its 6.4 ms of packing.  FOLD: case-insensitive (reads); dozeu sees the raw node
+// sequences, where anything but upper-case ACGT scores as N.
+template <bool FOLD> inline void code_run(uint8_t* __restrict dst, const char* __restrict src, uint32_t n) {
+    uint32_t k = 0;
+    const __m128i four = _mm_set1_epi8(4), fold = _mm_set1_epi8((char)0xdf);
+    const __m128i cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
+    const __m128i dA = _mm_set1_epi8(4), dC = _mm_set1_epi8(3), dG = _mm_set1_epi8(2), dT = _mm_set1_epi8(1);
+    for (; k + 16 <= n; k += 16) {
+        __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + k));
+        if (FOLD) b = _mm_and_si128(b, fold);
+        __m128i r = four;                                          // 4, minus (4 - code) where a base matches
+        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cA), dA));
+        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cC), dC));
+        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cG), dG));
+        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cT), dT));
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + k), r);
+    }
+    for (; k < n; ++k) { const uint8_t b = FOLD ? (uint8_t)((uint8_t)src[k] & 0xdfu) : (uint8_t)src[k]; dst[k] = (uint8_t)(b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : 4); }
 }
 
 // page-locked staging, kept between calls: the inputs go up and the results come down at the full DMA rate (pageable vectors cost ~7 of 13 host ms per 200 000 tails)
@@ -55,6 +71,16 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
     // per-problem checks; what fails is answered in its own status
     std::vector<int> status(n, VGK_OK); std::vector<uint64_t> cols(n, 0);
     std::vector<uint32_t> n_pred_of(n, 0), len_of(n, 0), nodes_of(n, 0);      // (what the serial placing loops below need, side by side: no second walk through every problem's pointers)
+    // 16-bit cells in the planes (GsswMatrixParams::xb_cell16) when no reachable cell of any problem can leave int16's range on either side:
+    // every step of an alignment costs or earns at most |score| + gap_open + gap_extend, and a cell is L + columns steps from the root at most
+    int32_t step_max = 0, score_abs = 0; bool bytes_ok = true;      // bytes_ok: every score + score_abs (+ the bonus) is a byte — what the packed fill's profile holds
+    { const int8_t* m = qa ? ctx->qmat.data() : ctx->sc.matrix; const size_t nm = qa ? 6400 : 25;
+      for (size_t k = 0; k < nm; ++k) score_abs = std::max<int32_t>(score_abs, m[k] < 0 ? -m[k] : m[k]);
+      int32_t bonus = ctx->sc.full_length_bonus, bonus_min = bonus;
+      if (qa) for (int q = 0; q < 256; ++q) { bonus = std::max<int32_t>(bonus, ctx->qbon[q]); bonus_min = std::min<int32_t>(bonus_min, ctx->qbon[q]); }
+      bytes_ok = bonus_min >= 0 && 2 * score_abs + bonus <= 255 && ctx->sc.gap_extend < 64;
+      step_max = score_abs + (int32_t)ctx->sc.gap_open + (int32_t)ctx->sc.gap_extend + (bonus > 0 ? bonus : -bonus); }
+    std::atomic<uint32_t> beyond16{0};
     parallel_for(n, [&](uint32_t i, unsigned) {
         const vgk_gssw_problem& p = problems[i]; const vgk_graph& g = p.graph;
         int st = VGK_OK;
@@ -70,11 +96,14 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
             }
             if (st == VGK_OK && R * (p.read_len + 1ull) > (1ull << 28)) st = VGK_ETOOBIG;
             cols[i] = R;
+            if (st == VGK_OK && (uint64_t)step_max * (R + p.read_len + 10ull) >= 16000ull) beyond16.fetch_add(1, std::memory_order_relaxed);
             if (st == VGK_OK) { n_pred_of[i] = g.pred_off[g.n_nodes] - g.pred_off[0]; len_of[i] = p.read_len; nodes_of[i] = g.n_nodes; }
         }
         status[i] = st;
     });
     lap("check");
+    const bool cell16 = beyond16.load() == 0 && !std::getenv("VGAMD_XBAND_CELLS32");
+    const size_t cell_bytes = cell16 ? sizeof(int16_t) : sizeof(int32_t);
     size_t used = 0; int rc_all = VGK_OK; uint64_t in_band_total = 0, rect_total = 0; double ms = 0;
     for (uint32_t i = 0; i < n;) {
         uint64_t n_cells = 0, n_read = 0, n_graph = 0, n_nodes = 0, n_preds = 0;
@@ -82,7 +111,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
         for (; j < n; ++j) {
             if (status[j] != VGK_OK) continue;
             const uint64_t c3 = 2ull * cols[j] * ((len_of[j] + 8ull) & ~7ull);               // H and E planes; a column is whole 8-row vectors
-            if (!owner.empty() && (n_cells + c3) * sizeof(int32_t) > budget) break;
+            if (!owner.empty() && (n_cells + c3) * cell_bytes > budget) break;
             n_cells += c3; n_read += len_of[j]; n_graph += cols[j]; n_nodes += nodes_of[j]; n_preds += n_pred_of[j];
             owner.push_back(j);
         }
@@ -112,13 +141,15 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
                 pb.gap_cells = (max_gap + 7) & ~7; pb.xt = ((int32_t)ctx->sc.gap_open - (int32_t)ctx->sc.gap_extend) + (int32_t)ctx->sc.gap_extend * max_gap;
                 uint32_t col = 0; uint64_t a_preds = pred_at[a];
                 for (uint32_t v = 0; v < p.graph.n_nodes; ++v) {
-                    MNode nd; nd.col_start = col; nd.col_end = col + p.graph.node_len[v]; nd.pred_begin = (uint32_t)a_preds; nd.n_pred = p.graph.pred_off[v + 1] - p.graph.pred_off[v];
+                    MNode nd{}; nd.col_start = col; nd.col_end = col + p.graph.node_len[v]; nd.pred_begin = (uint32_t)a_preds; nd.n_pred = p.graph.pred_off[v + 1] - p.graph.pred_off[v];
+                    if (nd.n_pred > 0) nd.p0 = p.graph.pred_idx[p.graph.pred_off[v]];
+                    if (nd.n_pred > 1) nd.p1 = p.graph.pred_idx[p.graph.pred_off[v] + 1];
                     for (uint32_t k = p.graph.pred_off[v]; k < p.graph.pred_off[v + 1]; ++k) preds[a_preds++] = p.graph.pred_idx[k];
                     nodes[pb.node_off + v] = nd; col = nd.col_end;
                 }
-                for (uint32_t r = 0; r < pb.L; ++r) reads[pb.read_off + r] = code_read(p.read[r]);
+                code_run<true>(reads + pb.read_off, p.read, pb.L);
                 if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
-                for (uint32_t c = 0; c < pb.R; ++c) graph[pb.graph_off + c] = code_ref(p.graph.seq[c]);
+                code_run<false>(graph + pb.graph_off, p.graph.seq, pb.R);
             });
             lap("pack");
             GsswMatrixParams P{};
@@ -134,7 +165,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
             P.graph = (const uint8_t*)dev(43, graph, n_graph); P.nodes = (const MNode*)dev(44, nodes, sizeof(MNode) * n_nodes);
             P.preds = (const uint32_t*)dev(45, preds, sizeof(uint32_t) * n_preds);
             P.mat = (const int8_t*)dev(46, qa ? ctx->qmat.data() : ctx->sc.matrix, qa ? 6400 : 25);
-            P.cells = (int32_t*)dev(47, nullptr, sizeof(int32_t) * n_cells);
+            P.cells = (int32_t*)dev(47, nullptr, cell_bytes * n_cells + 64); P.xb_cell16 = cell16 ? (bytes_ok && !std::getenv("VGAMD_XBAND_ARITH32") ? 2 : 1) : 0; P.xb_sb = score_abs;
             P.node_fmax = (int32_t*)ctx->ensure_scratch(48, sizeof(int32_t) * (n_nodes + 1));
             P.stats = (unsigned long long*)ctx->ensure_scratch(49, 64);
             P.xb_front = (uint16_t*)ctx->ensure_scratch(87, sizeof(uint16_t) * (n_graph + 1));
