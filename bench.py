@@ -998,10 +998,18 @@ def bench_xdrop_band(args, eng, rank, world, dist, torch, dev_name, cus):
     n = min(args.reads or 200_000, 200_000)
     ps = workloads.TailWorkload(n, seed=77 + rank).ps
     eng.lib.vgk_xdrop_band_last_ms.restype = ctypes.c_double; eng.lib.vgk_xdrop_band_last_ms.argtypes = [ctypes.c_void_p]
-    eng.xdrop_band_align(ps)                                         # warms the cached buffers
-    eng.xdrop_band_align(ps)                               # warms the context's cached device buffers, as the other workloads' first call does
-    t0 = time.perf_counter(); res, ops, st = eng.xdrop_band_align(ps); t_band = time.perf_counter() - t0
+    for _ in range(max(args.warmup, 2)):                             # warm the context's cached staging and device buffers, as the other workloads' first calls do
+        res, ops, st = eng.xdrop_band_align(ps)
+    keep = (res, np.zeros(len(ops) + 1024, dtype=ops.dtype))         # the caller's own output buffers, kept between calls
+    eng.xdrop_band_align(ps, out=keep)
+    steps = max(args.steps, 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):                                           # a step = one whole call from host buffers
+        res, ops, st = eng.xdrop_band_align(ps, out=keep)
+    t_band = (time.perf_counter() - t0) / steps
     k_ms = eng.lib.vgk_xdrop_band_last_ms(eng.h)
+    eng.lib.vgk_xdrop_band_last_cells.argtypes = [ctypes.c_void_p]
+    cell_form = int(eng.lib.vgk_xdrop_band_last_cells(eng.h)); cell_bytes = 4 if cell_form == 4 else 2
     t0 = time.perf_counter(); eres, eops = eng.align(ps, 48); t_exact = time.perf_counter() - t0
     # band mode against exact mode, alignment by alignment: a tail counts as different when any header field
     # or any CIGAR element differs.  Both op arrays are packed per problem (n_ops elements from ops_begin).
@@ -1035,20 +1043,22 @@ def bench_xdrop_band(args, eng, rank, world, dist, torch, dev_name, cus):
             good[:] = False
         parity = {"checked": k, "identical": int(good.sum())}
         cpu = {"value": k / tc, "unit": "alignments/s", "cores": shard.usable_cpus(), "kind": "port", "impl": "scalar int32 checker with the band (oracle/vgo_xdrop.c)", "sample": "first %d problems" % k}
-    # the kernel keeps H and E (int32) of the cells inside the band, in whole 8-row vectors, and two bytes per column for the band's extent:
-    # that, the inputs and the ops are its algorithmic bytes
+    # the kernel keeps H and E of the cells inside the band (16-bit cells when the call's bounds allow: vgk_xdrop_band_last_cells), in whole
+    # 8-row vectors, and two bytes per column for the band's extent: that, the inputs and the ops are its algorithmic bytes
     L_of = np.diff(ps.read_off).astype(np.int64); cols_of = np.diff(ps.seq_off).astype(np.int64)
-    alg_bytes = float(8 * st[0] + 3 * cols_of.sum() + L_of.sum() + 8 * int(res["n_ops"].sum()))
+    alg_bytes = float(2 * cell_bytes * st[0] + 3 * cols_of.sum() + L_of.sum() + 8 * int(res["n_ops"].sum()))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "xdrop_band_kernel16 (+ xdrop_band_kernel for reads over 127 bases) + xdrop_band_walk_kernel: fill with end cell, then the tracebacks; one timed region",
+    roofline = {"bound": "hbm", "kernel": ("xdrop_band_pk_kernel16 (+ xdrop_band_pk_kernel for reads over 127 bases): two rows to a register, 16-bit cells" if cell_form == 2 else
+                                                "xdrop_band_kernel16 (+ xdrop_band_kernel for reads over 127 bases), %d-byte cells" % cell_bytes) + " + xdrop_band_walk_kernel: fill with end cell, then the tracebacks; one timed region",
+                "cell_bytes": cell_bytes, "limiter": "VALU issue: ~235 instructions per wavefront-column of four tails (DESIGN.md \u00a727.8), not bandwidth",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": PMC_BYTES_PER_UNIT["xband"] * n if "xband" in PMC_BYTES_PER_UNIT else None,
                 "traffic_source": traffic_source("xband") if "xband" in PMC_BYTES_PER_UNIT else None,
                 "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k_ms}
     print(json.dumps({
         "metric": "tail alignments/sec, X-drop with dozeu's band restated (host-inclusive, second call on a warm context: pack + H2D + fill / end cell / traceback kernel + packed ops back)",
-        "value": n / t_band, "unit": "alignments/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * t_band, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+        "value": n / t_band, "unit": "alignments/s", "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 2), "ms_per_step": 1e3 * t_band, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "i32" if cell_form == 4 else "u16", "data": "synthetic",
         "config": {"workload": "round-1 tails stand-in: 2 Mbp variation graph, %d tails of 1-121 bp, left-pinned, one explicit graph per problem; vgk_xdrop_band_align [PARITY-UNPINNED]" % n,
                    "device": dev_name, "compute_units": cus},
         "band": {"cells_in_band": st[0], "cells_of_the_rectangles": st[1], "fraction_kept": st[0] / max(st[1], 1), "fill_kernel_ms": k_ms,
@@ -1404,7 +1414,7 @@ def main():
 SECONDARY = [
     ("config2", ["--reads", "4000000", "--steps", "4", "--warmup", "2", "--cpu-sample", "50000"], 240),
     ("gapless", ["--steps", "5", "--warmup", "2"], 90),
-    ("xband", ["--steps", "3", "--warmup", "1"], 90),
+    ("xband", ["--steps", "5", "--warmup", "2"], 90),
     ("banded", ["--reads", "100000", "--steps", "5", "--warmup", "2"], 90),
     ("wfa", ["--reads", "500000", "--steps", "5", "--warmup", "2"], 90),
     ("longread", ["--steps", "3", "--warmup", "1"], 120),

@@ -296,6 +296,11 @@ double   vgk_tail_stage_last_ms(vgk_ctx* ctx, int which);             /* 0 tails
 int  vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
                           vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written, uint64_t stats[2]);
 double vgk_xdrop_band_last_ms(vgk_ctx* ctx);     /* kernel time (fills + tracebacks) of the last vgk_xdrop_band_align call on this context */
+/* How that call's fill kept its cells: 4 = int32 cells and arithmetic; 2 = 16-bit cells, two rows to a register (taken when
+ * (read + graph + 10) x (largest |score| + gap_open + gap_extend + bonus) < 16 000 for every problem of the call and the scores fit bytes:
+ * no reachable cell can then leave the 16-bit range); 3 = 16-bit cells under int32 arithmetic (VGAMD_XBAND_ARITH32=1; VGAMD_XBAND_CELLS32=1
+ * forces 4).  The answers are the same in every form (tests/test_xdrop_band.py); what differs is the bytes a cell costs: 2 x 4 or 2 x 2. */
+int    vgk_xdrop_band_last_cells(vgk_ctx* ctx);
 
 /* k-best pinned alignments (Aligner::align_pinned_multi -> gssw_graph_trace_back_pinned_multi, src/aligner.cpp:423-435, :455-480).
  * Every problem must be VGK_GSSW_PINNED.  results[i * max_alt_alns + k] is the k-th best alignment of problem i (k <

@@ -141,3 +141,25 @@ def test_banded_xdrop_on_hip_with_32_bit_cells(monkeypatch):
     ps = random_xdrop_set(21, 400, None, max_nodes=8, max_node_len=16, max_read=100)
     monkeypatch.delenv("VGAMD_XBAND_CELLS32")
     same(capi.Engine(sc, lib=util.ENGINE_LIB).xdrop_band_align(ps), capi.Engine(sc, lib=util.ORACLE_LIB).xdrop_band_align(ps))
+
+
+# A call runs as sub-batches, two in flight (pack the next while one runs, hand out the one before): forced small here, with problems the
+# checks decline in between — the answers and their order are the one-batch call's
+def many_sub_batches(lib, n, monkeypatch):
+    ps = random_xdrop_set(31, n, None, max_nodes=10, max_node_len=16, max_read=60, with_n=0.02)
+    whole = capi.Engine(lib=lib).xdrop_band_align(ps)
+    monkeypatch.setenv("VGAMD_MAX_BATCH_BYTES", "30000")
+    same(capi.Engine(lib=lib).xdrop_band_align(ps), whole)
+    monkeypatch.delenv("VGAMD_MAX_BATCH_BYTES")
+    same(whole, capi.Engine(lib=util.ORACLE_LIB).xdrop_band_align(ps))
+
+
+def test_emulated_band_in_many_sub_batches(emu_lib, monkeypatch):
+    many_sub_batches(emu_lib, 48, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_band_in_many_sub_batches_on_hip(monkeypatch):
+    many_sub_batches(util.ENGINE_LIB, 3000, monkeypatch)
+    ps = random_xdrop_set(32, 70000, None, max_nodes=6, max_node_len=12, max_read=40)      # large enough for the call to cut itself in four
+    same(capi.Engine(lib=util.ENGINE_LIB).xdrop_band_align(ps), capi.Engine(lib=util.ORACLE_LIB).xdrop_band_align(ps))

@@ -340,11 +340,15 @@ class Engine:
         self._check(self.lib.vgk_gssw_align(self.h, ps.ptr, ps.n, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written)), "vgk_gssw_align")
         return res, ops[:written.value]
 
-    def xdrop_band_align(self, ps):
-        """vgk_xdrop_band_align over a ProblemSet of VGK_XDROP_PINNED problems -> (results, ops, (cells in band, cells of the rectangles))."""
-        res = np.zeros(ps.n, dtype=RESULT_DT)
-        cap = int(np.diff(ps.read_off).sum() + np.diff(ps.seq_off).sum() + len(ps.node_len) + 4 * ps.n)
-        ops = np.zeros(max(cap, 1), dtype=OP_DT)
+    def xdrop_band_align(self, ps, out=None):
+        """vgk_xdrop_band_align over a ProblemSet of VGK_XDROP_PINNED problems -> (results, ops, (cells in band, cells of the rectangles)).
+        out: (results, ops) arrays of an earlier call on the same set, written again (a caller that keeps its output buffers)."""
+        if out is not None:
+            res, ops = out; cap = len(ops)
+        else:
+            res = np.zeros(ps.n, dtype=RESULT_DT)
+            cap = int(np.diff(ps.read_off).sum() + np.diff(ps.seq_off).sum() + len(ps.node_len) + 4 * ps.n)
+            ops = np.zeros(max(cap, 1), dtype=OP_DT)
         written = ctypes.c_size_t(); stats = (ctypes.c_uint64 * 2)()
         self._check(self.lib.vgk_xdrop_band_align(self.h, ps.ptr, ps.n, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written), ctypes.byref(stats)),
                     "vgk_xdrop_band_align")

@@ -127,6 +127,11 @@ public:
     // X-drop with dozeu's band (vgk_xdrop_band_align): one wavefront per problem, the matrices stay for the host's traceback;
     // last_ms(7) = kernel ms
     virtual int   run_xdrop_band(const GsswMatrixParams& p) = 0;
+    // The same without waiting: the kernels go onto the main stream, bracketed by the timing events of `slot` (0 or 1 — two sub-batches of a
+    // call in flight: the host packs the next one while this one runs).  xdrop_band_ms(slot) is valid once the caller has waited for them
+    // (an event recorded behind the launch, or sync()).  A backend without streams runs it on the spot.
+    virtual int   run_xdrop_band_async(const GsswMatrixParams& p, int slot) { (void)slot; return run_xdrop_band(p); }
+    virtual double xdrop_band_ms(int slot) { (void)slot; return last_ms(7); }
     // tail forests (tail_device.hpp), everything asynchronous on the main stream: one pass of the walks (p.pass; `threads` resident
     // lanes, one TScratch each, take the problems in turn); exclusive prefix sums of n 32-bit values (out[k] = in[0] + ... + in[k-1]);
     // the two per-node stages that turn the forest into the packer's tables; a byte fill; a stopwatch around all of it

@@ -837,12 +837,14 @@ public:
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
     float ms_gapless = 0.f, ms_wfa = 0.f, ms_xband = 0.f;
     float ms_bfill = 0.f, ms_bwalk = 0.f; hipEvent_t bev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t xbev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // run_xdrop_band_async: start / end per slot
     void* scan_tmp = nullptr; size_t scan_tmp_bytes = 0;      // rocPRIM's scratch for scan_u32 (grow-only)
     void* mz_slots = nullptr; size_t mz_slots_bytes = 0;      // per-read seed slots of run_minimizer (grow-only)
     ~HipBackend() override {
         hipSetDevice(dev);
         for (auto& e : ev) if (e) hipEventDestroy(e);
         for (auto& e : bev) if (e) hipEventDestroy(e);
+        for (auto& pair : xbev) for (auto& e : pair) if (e) hipEventDestroy(e);
         if (scan_tmp) hipFree(scan_tmp);
         if (mz_slots) hipFree(mz_slots);
         for (int i = 0; i < 2; ++i) { if (side[i]) hipStreamDestroy(side[i]); if (side_done[i]) hipEventDestroy(side_done[i]); }
@@ -1175,10 +1177,25 @@ public:
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_xdrop_band(const GsswMatrixParams& p) override {
-        hipSetDevice(dev);
         ms_xband = 0.f;
         if (!p.n) return VGK_OK;
-        hipEventRecord(bev[0], stream);
+        const int rc = run_xdrop_band_async(p, 0);
+        if (rc != VGK_OK) return rc;
+        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
+        ms_xband = (float)xdrop_band_ms(0);
+        return VGK_OK;
+    }
+    double xdrop_band_ms(int slot) override {
+        float ms = 0.f;
+        if (!xbev[slot & 1][0] || hipEventElapsedTime(&ms, xbev[slot & 1][0], xbev[slot & 1][1]) != hipSuccess) { (void)hipGetLastError(); return 0.0; }
+        return ms;
+    }
+    int run_xdrop_band_async(const GsswMatrixParams& p, int slot) override {
+        hipSetDevice(dev);
+        if (!p.n) return VGK_OK;
+        hipEvent_t* ev = xbev[slot & 1];
+        for (int k = 0; k < 2; ++k) if (!ev[k] && hipEventCreate(&ev[k]) != hipSuccess) return VGK_ENODEV;
+        hipEventRecord(ev[0], stream);
         auto launch = [&](auto cell) {
             using CT = decltype(cell);
             if (p.xb_order) {
@@ -1194,10 +1211,8 @@ public:
             } else hipLaunchKernelGGL(xdrop_band_pk_kernel, dim3(p.n), dim3(64), 0, stream, p);
             if (p.xb_results) hipLaunchKernelGGL(xdrop_band_walk_kernel<int16_t>, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
         } else if (p.xb_cell16) launch(int16_t{}); else launch(int32_t{});
-        hipEventRecord(bev[1], stream);
-        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
-        hipEventElapsedTime(&ms_xband, bev[0], bev[1]);
-        return VGK_OK;
+        hipEventRecord(ev[1], stream);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int gapless_order(const GOrderParams& p, int stage) override {
         hipSetDevice(dev);

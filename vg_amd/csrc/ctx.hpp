@@ -68,7 +68,7 @@ struct vgk_ctx {
     uint64_t multi_host_walks = 0;       // problems of the last vgk_gssw_align_multi whose alternates a host thread walked
     // device scratch kept between vgk_banded_align calls (grow-only; released with the context)
     struct DevBuf { void* p = nullptr; uint64_t bytes = 0; };
-    DevBuf scratch[100];           // 88..99 gssw_wide_api.cpp; 65 wfa_api.cpp (producers_done); 72..83 gssw_multi_api.cpp (the walk on the device); 0..14 + 31 banded_api.cpp, 15..30 + 59, 60 gapless_api.cpp, 32..39 + 61..63 wfa_api.cpp, 40..47 gssw_multi_api.cpp / xdrop_band_api.cpp (+ 48, 49, 87), 50..54 tail_api.cpp, 55..58 minimizer_api.cpp
+    DevBuf scratch[124];           // 88..99 gssw_wide_api.cpp; 65 wfa_api.cpp (producers_done); 72..83 gssw_multi_api.cpp (the walk on the device); 0..14 + 31 banded_api.cpp, 15..30 + 59, 60 gapless_api.cpp, 32..39 + 61..63 wfa_api.cpp, 40..47 gssw_multi_api.cpp / xdrop_band_api.cpp (+ 48, 49, 87; its second sub-batch in flight: 100..123), 50..54 tail_api.cpp, 55..58 minimizer_api.cpp
     void* ensure_scratch(int slot, uint64_t bytes) {
         DevBuf& b = scratch[slot];
         if (b.p && b.bytes >= bytes) return b.p;
@@ -153,6 +153,7 @@ struct vgk_ctx {
     std::shared_ptr<void> multi_host;       // and of gssw_multi_api.cpp
     std::shared_ptr<void> xband_host;       // and of xdrop_band_api.cpp
     double xband_ms = 0;                    // kernel time of the last vgk_xdrop_band_align call
+    int xband_cells = 4;                    // ... and its cell form (vgk_xdrop_band_last_cells)
     ~vgk_ctx() { if (be) { if (deferred.pending) be->sync_fetch(); if (deferred.ev) be->event_destroy(deferred.ev); for (DevBuf& b : scratch) if (b.p) be->release(b.p); for (Pooled& q : dev_pool) be->release(q.p); for (Pooled& q : host_pool) be->host_release(q.p); } }
 };
 

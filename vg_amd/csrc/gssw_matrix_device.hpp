@@ -31,9 +31,7 @@ struct MProb {
     int32_t  gap_cells, xt;           // X-drop band only: rows of the root column that hold a leading insertion (max_gap_length rounded up to
                                       // dozeu's 8-cell vector), and the x-drop threshold (go - ge) + ge * max_gap_length
 };
-struct alignas(32) MNode { uint32_t col_start, col_end, pred_begin, n_pred;
-               uint32_t p0, p1, pad[2]; };      // p0, p1: the first two predecessors again (X-drop band: the record of the NEXT node is fetched while a node's
-                                                // columns run, and with it what nearly every node of a variation graph needs of `preds`)
+struct MNode { uint32_t col_start, col_end, pred_begin, n_pred; };
 
 struct GsswMatrixParams {
     MProb* probs; uint32_t n;
@@ -526,15 +524,14 @@ VGK_HD void xdrop_band_pk_lane(const GsswMatrixParams& P, uint32_t pi, uint32_t 
                 if (v >= pb.n_nodes) break;
             }
             entered = true;
-            // the node's record was asked for when the node before it began (two dependent round trips to HBM per node — the record, then
-            // its predecessor list — were as long as a dozen columns of arithmetic, and a variation graph's nodes are about that long)
+            // (the node's record was asked for when the node before it began)
             nd = nd_next; if (v + 1 < pb.n_nodes) nd_next = nodes[v + 1];
             c = nd.col_start; front_live = false;
             fmax = (int32_t)XBP_OFF;                           // a source node: the root's best is "nothing consumed", 0
             if (nd.n_pred) {
                 fmax = 0;
                 for (uint32_t q = 0; q < nd.n_pred; ++q) {
-                    const int32_t pr = (int32_t)(q == 0 ? nd.p0 : q == 1 ? nd.p1 : P.preds[nd.pred_begin + q]);
+                    const int32_t pr = (int32_t)P.preds[nd.pred_begin + q];
                     int32_t f;
                     if (pr == tag0) f = cfm0; else if (pr == tag1) f = cfm1;
                     else { if (!fenced) { xl.fence(); fenced = true; } f = node_fmax[pr]; }
@@ -567,7 +564,7 @@ VGK_HD void xdrop_band_pk_lane(const GsswMatrixParams& P, uint32_t pi, uint32_t 
             } else {
                 for (int k = 0; k < 4; ++k) { e[k] = 0; dg[k] = 0; }
                 if (i0 < stride) for (uint32_t q = 0; q < nd.n_pred; ++q) {
-                    const int32_t pr = (int32_t)(q == 0 ? nd.p0 : q == 1 ? nd.p1 : P.preds[nd.pred_begin + q]);
+                    const int32_t pr = (int32_t)P.preds[nd.pred_begin + q];
                     uint32_t ph[4], pe[4], above;
                     if (pr == tag0 || pr == tag1) {
                         const uint32_t* ch = cache + (pr == tag1 ? 2u * cache_w : 0u);

@@ -43,14 +43,28 @@ template <bool FOLD> inline void code_run(uint8_t* __restrict dst, const char* _
     for (; k < n; ++k) { const uint8_t b = FOLD ? (uint8_t)((uint8_t)src[k] & 0xdfu) : (uint8_t)src[k]; dst[k] = (uint8_t)(b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : 4); }
 }
 
-// page-locked staging, kept between calls: the inputs go up and the results come down at the full DMA rate (pageable vectors cost ~7 of 13 host ms per 200 000 tails)
-struct BandHost { PinnedBuf<uint8_t> reads, quals, graph, want; PinnedBuf<MProb> probs; PinnedBuf<MNode> nodes; PinnedBuf<uint32_t> preds, order; PinnedBuf<uint64_t> ops_off;
-                  PinnedBuf<vgk_result> dres; PinnedBuf<vgk_op> dops; };
+// page-locked staging, kept between calls: the inputs go up and the results come down at the full DMA rate (pageable vectors cost ~7 of 13 host
+// ms per 200 000 tails).  Two sets: a call's sub-batches alternate between them (see below).
+struct BandStage { PinnedBuf<uint8_t> reads, quals, graph, want; PinnedBuf<MProb> probs; PinnedBuf<MNode> nodes; PinnedBuf<uint32_t> preds, order; PinnedBuf<uint64_t> ops_off;
+                   PinnedBuf<vgk_result> dres; PinnedBuf<vgk_op> dops; PinnedBuf<unsigned long long> stat; };
+struct BandHost { BandStage set[2]; void* ev[2] = {nullptr, nullptr}; Backend* be = nullptr;
+                  ~BandHost() { if (be) for (void* e : ev) if (e) be->event_destroy(e); } };
+// device scratch slots of the two sets (ctx.hpp lists who owns which slot)
+enum { D_PROBS, D_READS, D_QUALS, D_GRAPH, D_NODES, D_PREDS, D_MAT, D_CELLS, D_FMAX, D_STATS, D_FRONT, D_ORDER, D_RES, D_OPS, D_OPSOFF, D_WANT, D_OFFS, D_SUMS, D_PRES, D_POPS, D_COUNT };
+constexpr int kSlot[2][D_COUNT] = { {40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 87, 80, 72, 73, 74, 75, 76, 77, 78, 79},
+                                    {100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117, 118, 119} };
+static_assert(119 < (int)(sizeof(vgk_ctx::scratch) / sizeof(vgk_ctx::DevBuf)), "scratch slots");
+
+// one sub-batch of a call between its two halves: packed, uploaded and launched — then fetched and handed out
+struct Sub { uint32_t i = 0, j = 0, m = 0; std::vector<uint32_t> owner; GsswMatrixParams P{}; uint64_t ops_total = 0; bool launched = false; };
 
 }  // namespace
 
 extern "C" {
 
+// A call runs as a pipeline of sub-batches, two in flight: while the kernels of one run, the host packs the next and hands out the one
+// before — pack, upload and launch on the main stream; the packed ops and results come back on the fetch stream behind an event.  (One
+// sub-batch at a time, the host's 9 ms of checking, packing and copying per 200 000 tails stood beside 4.5 ms of kernels: 15 ms a call.)
 int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
                          vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written, uint64_t stats[2]) try {
     if (!ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
@@ -63,7 +77,8 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
     const bool qa = ctx->has_qa;
     if (!ctx->xband_host) ctx->xband_host = std::make_shared<BandHost>();
     BandHost& Hs = *static_cast<BandHost*>(ctx->xband_host.get());
-    uint64_t budget = be->memory_bytes() ? be->memory_bytes() / 4 : (1ull << 30);
+    if (!Hs.be) { Hs.be = be; for (void*& e : Hs.ev) e = be->event_create(); }      // (null events: a backend without streams — every wait is then a sync)
+    uint64_t budget = be->memory_bytes() ? be->memory_bytes() / 8 : (1ull << 30);
     if (const char* e = std::getenv("VGAMD_MAX_BATCH_BYTES")) budget = std::strtoull(e, nullptr, 10);
     const bool timing = std::getenv("VGAMD_XBAND_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -82,6 +97,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
       step_max = score_abs + (int32_t)ctx->sc.gap_open + (int32_t)ctx->sc.gap_extend + (bonus > 0 ? bonus : -bonus); }
     std::atomic<uint32_t> beyond16{0};
     parallel_for(n, [&](uint32_t i, unsigned) {
+        if (i + 3 < n) { const vgk_gssw_problem& q = problems[i + 3]; __builtin_prefetch(q.graph.node_len); __builtin_prefetch(q.graph.pred_off); __builtin_prefetch(q.graph.pred_idx); }
         const vgk_gssw_problem& p = problems[i]; const vgk_graph& g = p.graph;
         int st = VGK_OK;
         if (!p.read_len || !p.read || !g.n_nodes || !g.node_len || !g.pred_off || !g.seq || (qa && !p.qual)) st = VGK_EINVAL;
@@ -103,136 +119,164 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
     });
     lap("check");
     const bool cell16 = beyond16.load() == 0 && !std::getenv("VGAMD_XBAND_CELLS32");
+    const int cell_form = !cell16 ? 0 : (bytes_ok && !std::getenv("VGAMD_XBAND_ARITH32") ? 2 : 1);
     const size_t cell_bytes = cell16 ? sizeof(int16_t) : sizeof(int32_t);
+    // sub-batches: what the device budget allows, and for a large call no more than a quarter of it, so that there is something to overlap
+    uint32_t sub_cap = n, n_ok = 0;
+    for (uint32_t i = 0; i < n; ++i) n_ok += status[i] == VGK_OK;      // (counted here: one counter bumped by every thread of the check was 9 of its 10 ms)
+    if (n_ok >= 32768u && !std::getenv("VGAMD_XBAND_ONE_BATCH")) sub_cap = (n_ok + 3u) / 4u;
     size_t used = 0; int rc_all = VGK_OK; uint64_t in_band_total = 0, rect_total = 0; double ms = 0;
-    for (uint32_t i = 0; i < n;) {
+    const bool no_tb = std::getenv("VGAMD_XBAND_SCORES_ONLY") != nullptr;      // (a measuring aid: the fill and the end cell without the walk)
+
+    // ---- first half of a sub-batch: the problems from `from` on that fit, packed, uploaded, launched
+    auto build = [&](uint32_t from, Sub& S, int set) -> int {
+        BandStage& St = Hs.set[set]; const int* slot = kSlot[set];
         uint64_t n_cells = 0, n_read = 0, n_graph = 0, n_nodes = 0, n_preds = 0;
-        uint32_t j = i; std::vector<uint32_t> owner;
+        S.i = from; S.owner.clear(); S.launched = false; S.ops_total = 0;
+        uint32_t j = from;
         for (; j < n; ++j) {
             if (status[j] != VGK_OK) continue;
             const uint64_t c3 = 2ull * cols[j] * ((len_of[j] + 8ull) & ~7ull);               // H and E planes; a column is whole 8-row vectors
-            if (!owner.empty() && (n_cells + c3) * cell_bytes > budget) break;
+            if (!S.owner.empty() && ((n_cells + c3) * cell_bytes > budget || S.owner.size() >= sub_cap)) break;
             n_cells += c3; n_read += len_of[j]; n_graph += cols[j]; n_nodes += nodes_of[j]; n_preds += n_pred_of[j];
-            owner.push_back(j);
+            S.owner.push_back(j);
         }
-        const uint32_t m = (uint32_t)owner.size();
-        vgk_result* dres = Hs.dres.get(be, m + 1); vgk_op* dops = nullptr;       // the sub-batch's results and packed ops as they come back
+        S.j = j;
+        const uint32_t m = S.m = (uint32_t)S.owner.size();
+        if (!m) return VGK_OK;
+        const std::vector<uint32_t>& owner = S.owner;
+        MProb* probs = St.probs.get(be, m + 1);
+        uint8_t* reads = St.reads.get(be, n_read + 1); uint8_t* quals = qa ? St.quals.get(be, n_read + 1) : nullptr; uint8_t* graph = St.graph.get(be, n_graph + 1);
+        MNode* nodes = St.nodes.get(be, n_nodes + 1); uint32_t* preds = St.preds.get(be, n_preds + 1);
+        if (!probs || !reads || (qa && !quals) || !graph || !nodes || !preds) return VGK_ENOMEM;
+        std::vector<uint64_t> pred_at(m + 1, 0);                          // where a problem's predecessor lists start in the shared arena
+        { uint64_t a_cells = 0, a_read = 0, a_graph = 0, a_nodes = 0;
+          for (uint32_t a = 0; a < m; ++a) {                                // the places first (a running sum), the contents on the host threads
+            const uint32_t q = owner[a];
+            MProb pb{}; pb.L = len_of[q]; pb.n_nodes = nodes_of[q]; pb.R = (uint32_t)cols[q];
+            pb.read_off = (uint32_t)a_read; pb.graph_off = (uint32_t)a_graph; pb.node_off = (uint32_t)a_nodes; pb.mat_off = a_cells;
+            probs[a] = pb;
+            pred_at[a + 1] = pred_at[a] + n_pred_of[q];
+            a_cells += 2ull * pb.R * ((pb.L + 8ull) & ~7ull); a_read += pb.L; a_graph += pb.R; a_nodes += pb.n_nodes;
+            rect_total += (uint64_t)pb.R * (pb.L + 1ull);
+          } }
+        parallel_for(m, [&](uint32_t a, unsigned) {
+            // (a problem's arrays are five pointers into the caller's memory, each a miss: the ones of the problem three ahead are asked for now)
+            if (a + 3 < m) { const vgk_gssw_problem& q = problems[owner[a + 3]];
+                             __builtin_prefetch(q.graph.node_len); __builtin_prefetch(q.graph.pred_off); __builtin_prefetch(q.graph.pred_idx); __builtin_prefetch(q.read);
+                             __builtin_prefetch(q.graph.seq); __builtin_prefetch(q.graph.seq + 64); __builtin_prefetch(q.graph.seq + 128); }
+            const vgk_gssw_problem& p = problems[owner[a]]; MProb& pb = probs[a];
+            pb.start_bonus = qa ? ctx->qbon[p.qual[p.read_len - 1]] : ctx->sc.full_length_bonus; pb.status = VGK_OK;
+            const int32_t max_gap = (int32_t)std::max<uint32_t>(p.max_gap_length, 1u);
+            pb.gap_cells = (max_gap + 7) & ~7; pb.xt = ((int32_t)ctx->sc.gap_open - (int32_t)ctx->sc.gap_extend) + (int32_t)ctx->sc.gap_extend * max_gap;
+            uint32_t col = 0; uint64_t a_preds = pred_at[a];
+            for (uint32_t v = 0; v < p.graph.n_nodes; ++v) {
+                MNode nd{}; nd.col_start = col; nd.col_end = col + p.graph.node_len[v]; nd.pred_begin = (uint32_t)a_preds; nd.n_pred = p.graph.pred_off[v + 1] - p.graph.pred_off[v];
+                for (uint32_t k = p.graph.pred_off[v]; k < p.graph.pred_off[v + 1]; ++k) preds[a_preds++] = p.graph.pred_idx[k];
+                nodes[pb.node_off + v] = nd; col = nd.col_end;
+            }
+            code_run<true>(reads + pb.read_off, p.read, pb.L);
+            if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
+            code_run<false>(graph + pb.graph_off, p.graph.seq, pb.R);
+        });
+        lap("pack");
+        GsswMatrixParams& P = S.P; P = GsswMatrixParams{};
+        P.n = m; P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend;
+        auto dev = [&](int what, const void* src, size_t bytes) -> void* {
+            void* d = ctx->ensure_scratch(slot[what], std::max<size_t>(bytes, 16)); if (!d) return nullptr;
+            if (src && bytes && be->upload(d, src, bytes)) return nullptr;
+            return d;
+        };
+        // (set 0's slots are the scratch slots of the k-best pinned path: the two calls never overlap under the context lock)
+        P.probs = (MProb*)dev(D_PROBS, probs, sizeof(MProb) * m);
+        P.reads = (const uint8_t*)dev(D_READS, reads, n_read); P.quals = qa ? (const uint8_t*)dev(D_QUALS, quals, n_read) : nullptr;
+        P.graph = (const uint8_t*)dev(D_GRAPH, graph, n_graph); P.nodes = (const MNode*)dev(D_NODES, nodes, sizeof(MNode) * n_nodes);
+        P.preds = (const uint32_t*)dev(D_PREDS, preds, sizeof(uint32_t) * n_preds);
+        P.mat = (const int8_t*)dev(D_MAT, qa ? ctx->qmat.data() : ctx->sc.matrix, qa ? 6400 : 25);
+        P.cells = (int32_t*)dev(D_CELLS, nullptr, cell_bytes * n_cells + 64); P.xb_cell16 = cell_form; P.xb_sb = score_abs;
+        P.node_fmax = (int32_t*)dev(D_FMAX, nullptr, sizeof(int32_t) * (n_nodes + 1));
+        P.stats = (unsigned long long*)dev(D_STATS, nullptr, 64);
+        P.xb_front = (uint16_t*)dev(D_FRONT, nullptr, sizeof(uint16_t) * (n_graph + 1));
+        // the wavefront that fills a problem also picks its end cell, a second kernel walks the tracebacks: results and ops come back, the
+        // matrices stay where they are
+        uint64_t* ops_off = St.ops_off.get(be, m + 1); uint8_t* want = St.want.get(be, m + 1);
+        if (!ops_off || !want) return VGK_ENOMEM;
+        ops_off[0] = 0;
+        for (uint32_t a = 0; a < m; ++a) { ops_off[a + 1] = ops_off[a] + probs[a].L + probs[a].R + 3ull; want[a] = (problems[owner[a]].flags & VGK_GSSW_TRACEBACK) && !no_tb ? 1 : 0; }
+        if (ops_off[m] >= (1ull << 32)) return VGK_ETOOBIG;
+        S.ops_total = ops_off[m];
+        // launch order: tails of up to 127 bases four to a wavefront (16 lanes each), the longer ones a wavefront each; inside a class
+        // by descending graph size (a counting sort), so that the problems sharing a wavefront take about equally long
+        uint32_t* order = St.order.get(be, m + 1);
+        if (!order) return VGK_ENOMEM;
+        uint32_t n16 = 0;
+        { constexpr uint32_t B = 4096;
+          std::vector<uint32_t> count(2 * B + 1, 0);
+          auto bucket = [&](uint32_t a) { const uint32_t r = probs[a].R < B ? probs[a].R : B - 1; return (probs[a].L <= 127u ? 0u : B) + (B - 1 - r); };
+          for (uint32_t a = 0; a < m; ++a) { ++count[bucket(a) + 1]; if (probs[a].L <= 127u) ++n16; }
+          for (uint32_t b = 0; b < 2 * B; ++b) count[b + 1] += count[b];
+          for (uint32_t a = 0; a < m; ++a) order[count[bucket(a)]++] = a; }
+        P.xb_order = (const uint32_t*)dev(D_ORDER, order, sizeof(uint32_t) * m); P.xb_n16 = n16; P.xb_n64 = m - n16;
+        P.xb_results = (vgk_result*)dev(D_RES, nullptr, sizeof(vgk_result) * m);
+        P.xb_ops = (vgk_op*)dev(D_OPS, nullptr, sizeof(vgk_op) * ops_off[m]);
+        P.xb_ops_off = (const uint64_t*)dev(D_OPSOFF, ops_off, sizeof(uint64_t) * m);
+        P.xb_want_tb = (const uint8_t*)dev(D_WANT, want, m);
+        if (!P.probs || !P.reads || (qa && !P.quals) || !P.graph || !P.nodes || !P.preds || !P.mat || !P.cells || !P.node_fmax || !P.stats ||
+            !P.xb_order || !P.xb_results || !P.xb_ops || !P.xb_ops_off || !P.xb_want_tb || !P.xb_front) return VGK_ENOMEM;
+        int rc;
+        if ((rc = be->zero(P.stats, 64))) return rc;
+        if ((rc = be->run_xdrop_band_async(P, set))) return rc;
+        if ((rc = be->event_record(Hs.ev[set]))) return rc;
+        S.launched = true;
+        lap("launch");
+        return VGK_OK;
+    };
+
+    // ---- second half: wait for the kernels, pack the ops on the device, bring results and ops back, hand them out in the caller's order
+    auto finish = [&](Sub& S, int set) -> int {
+        BandStage& St = Hs.set[set]; const int* slot = kSlot[set];
+        const uint32_t m = S.m; const GsswMatrixParams& P = S.P;
+        vgk_result* dres = St.dres.get(be, m + 1); vgk_op* dops = nullptr;
         if (!dres) return VGK_ENOMEM;
         if (m) {
-            MProb* probs = Hs.probs.get(be, m + 1);
-            uint8_t* reads = Hs.reads.get(be, n_read + 1); uint8_t* quals = qa ? Hs.quals.get(be, n_read + 1) : nullptr; uint8_t* graph = Hs.graph.get(be, n_graph + 1);
-            MNode* nodes = Hs.nodes.get(be, n_nodes + 1); uint32_t* preds = Hs.preds.get(be, n_preds + 1);
-            if (!probs || !reads || (qa && !quals) || !graph || !nodes || !preds) return VGK_ENOMEM;
-            std::vector<uint64_t> pred_at(m + 1, 0);                          // where a problem's predecessor lists start in the shared arena
-            { uint64_t a_cells = 0, a_read = 0, a_graph = 0, a_nodes = 0;
-              for (uint32_t a = 0; a < m; ++a) {                                // the places first (a running sum), the contents on the host threads
-                const uint32_t q = owner[a];
-                MProb pb{}; pb.L = len_of[q]; pb.n_nodes = nodes_of[q]; pb.R = (uint32_t)cols[q];
-                pb.read_off = (uint32_t)a_read; pb.graph_off = (uint32_t)a_graph; pb.node_off = (uint32_t)a_nodes; pb.mat_off = a_cells;
-                probs[a] = pb;
-                pred_at[a + 1] = pred_at[a] + n_pred_of[q];
-                a_cells += 2ull * pb.R * ((pb.L + 8ull) & ~7ull); a_read += pb.L; a_graph += pb.R; a_nodes += pb.n_nodes;
-                rect_total += (uint64_t)pb.R * (pb.L + 1ull);
-              } }
-            parallel_for(m, [&](uint32_t a, unsigned) {
-                const vgk_gssw_problem& p = problems[owner[a]]; MProb& pb = probs[a];
-                pb.start_bonus = qa ? ctx->qbon[p.qual[p.read_len - 1]] : ctx->sc.full_length_bonus; pb.status = VGK_OK;
-                const int32_t max_gap = (int32_t)std::max<uint32_t>(p.max_gap_length, 1u);
-                pb.gap_cells = (max_gap + 7) & ~7; pb.xt = ((int32_t)ctx->sc.gap_open - (int32_t)ctx->sc.gap_extend) + (int32_t)ctx->sc.gap_extend * max_gap;
-                uint32_t col = 0; uint64_t a_preds = pred_at[a];
-                for (uint32_t v = 0; v < p.graph.n_nodes; ++v) {
-                    MNode nd{}; nd.col_start = col; nd.col_end = col + p.graph.node_len[v]; nd.pred_begin = (uint32_t)a_preds; nd.n_pred = p.graph.pred_off[v + 1] - p.graph.pred_off[v];
-                    if (nd.n_pred > 0) nd.p0 = p.graph.pred_idx[p.graph.pred_off[v]];
-                    if (nd.n_pred > 1) nd.p1 = p.graph.pred_idx[p.graph.pred_off[v] + 1];
-                    for (uint32_t k = p.graph.pred_off[v]; k < p.graph.pred_off[v + 1]; ++k) preds[a_preds++] = p.graph.pred_idx[k];
-                    nodes[pb.node_off + v] = nd; col = nd.col_end;
-                }
-                code_run<true>(reads + pb.read_off, p.read, pb.L);
-                if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
-                code_run<false>(graph + pb.graph_off, p.graph.seq, pb.R);
-            });
-            lap("pack");
-            GsswMatrixParams P{};
-            P.n = m; P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend;
-            auto dev = [&](int slot, const void* src, size_t bytes) -> void* {
-                void* d = ctx->ensure_scratch(slot, std::max<size_t>(bytes, 16)); if (!d) return nullptr;
-                if (src && bytes && be->upload(d, src, bytes)) return nullptr;
-                return d;
-            };
-            // (the scratch slots of the k-best pinned path: the two calls never overlap under the context lock)
-            P.probs = (MProb*)dev(40, probs, sizeof(MProb) * m);
-            P.reads = (const uint8_t*)dev(41, reads, n_read); P.quals = qa ? (const uint8_t*)dev(42, quals, n_read) : nullptr;
-            P.graph = (const uint8_t*)dev(43, graph, n_graph); P.nodes = (const MNode*)dev(44, nodes, sizeof(MNode) * n_nodes);
-            P.preds = (const uint32_t*)dev(45, preds, sizeof(uint32_t) * n_preds);
-            P.mat = (const int8_t*)dev(46, qa ? ctx->qmat.data() : ctx->sc.matrix, qa ? 6400 : 25);
-            P.cells = (int32_t*)dev(47, nullptr, cell_bytes * n_cells + 64); P.xb_cell16 = cell16 ? (bytes_ok && !std::getenv("VGAMD_XBAND_ARITH32") ? 2 : 1) : 0; P.xb_sb = score_abs;
-            P.node_fmax = (int32_t*)ctx->ensure_scratch(48, sizeof(int32_t) * (n_nodes + 1));
-            P.stats = (unsigned long long*)ctx->ensure_scratch(49, 64);
-            P.xb_front = (uint16_t*)ctx->ensure_scratch(87, sizeof(uint16_t) * (n_graph + 1));
-            // the wavefront that fills a problem also picks its end cell and walks its traceback (round 3): results and ops come back,
-            // the matrices stay where they are
-            uint64_t* ops_off = Hs.ops_off.get(be, m + 1); uint8_t* want = Hs.want.get(be, m + 1);
-            if (!ops_off || !want) return VGK_ENOMEM;
-            ops_off[0] = 0;
-            const bool no_tb = std::getenv("VGAMD_XBAND_SCORES_ONLY") != nullptr;      // (a measuring aid: the fill and the end cell without the walk)
-            for (uint32_t a = 0; a < m; ++a) { ops_off[a + 1] = ops_off[a] + probs[a].L + probs[a].R + 3ull; want[a] = (problems[owner[a]].flags & VGK_GSSW_TRACEBACK) && !no_tb ? 1 : 0; }
-            if (ops_off[m] >= (1ull << 32)) return VGK_ETOOBIG;
-            // launch order: tails of up to 127 bases four to a wavefront (16 lanes each), the longer ones a wavefront each; inside a class
-            // by descending graph size (a counting sort), so that the problems sharing a wavefront take about equally long
-            uint32_t* order = Hs.order.get(be, m + 1);
-            if (!order) return VGK_ENOMEM;
-            uint32_t n16 = 0;
-            { constexpr uint32_t B = 4096;
-              std::vector<uint32_t> count(2 * B + 1, 0);
-              auto bucket = [&](uint32_t a) { const uint32_t r = probs[a].R < B ? probs[a].R : B - 1; return (probs[a].L <= 127u ? 0u : B) + (B - 1 - r); };
-              for (uint32_t a = 0; a < m; ++a) { ++count[bucket(a) + 1]; if (probs[a].L <= 127u) ++n16; }
-              for (uint32_t b = 0; b < 2 * B; ++b) count[b + 1] += count[b];
-              for (uint32_t a = 0; a < m; ++a) order[count[bucket(a)]++] = a; }
-            P.xb_order = (const uint32_t*)dev(80, order, sizeof(uint32_t) * m); P.xb_n16 = n16; P.xb_n64 = m - n16;
-            if (!P.xb_order) return VGK_ENOMEM;
-            P.xb_results = (vgk_result*)dev(72, nullptr, sizeof(vgk_result) * m);
-            P.xb_ops = (vgk_op*)dev(73, nullptr, sizeof(vgk_op) * ops_off[m]);
-            P.xb_ops_off = (const uint64_t*)dev(74, ops_off, sizeof(uint64_t) * m);
-            P.xb_want_tb = (const uint8_t*)dev(75, want, m);
-            if (!P.probs || !P.reads || (qa && !P.quals) || !P.graph || !P.nodes || !P.preds || !P.mat || !P.cells || !P.node_fmax || !P.stats ||
-                !P.xb_results || !P.xb_ops || !P.xb_ops_off || !P.xb_want_tb || !P.xb_front) return VGK_ENOMEM;
             int rc;
-            if ((rc = be->zero(P.stats, 64))) return rc;
-            lap("h2d");
-            if ((rc = be->run_xdrop_band(P))) return rc;
-            ms += be->last_ms(7);
-            unsigned long long in_band = 0;
-            if ((rc = be->download(&in_band, P.stats, sizeof in_band))) return rc;
-            in_band_total += in_band;
-            lap("kernel");
-            // ops packed behind each other on the device, then results + ops back (a backend without the packing kernels hands the windows over)
+            if (Hs.ev[set]) { if ((rc = be->fetch_after(Hs.ev[set]))) return rc; }
+            else if ((rc = be->sync())) return rc;
+            auto dev = [&](int what, size_t bytes) -> void* { return ctx->ensure_scratch(slot[what], std::max<size_t>(bytes, 16)); };
             const uint32_t blocks = (m + Backend::OPS_SCAN_BLOCK - 1) / Backend::OPS_SCAN_BLOCK;
-            uint32_t* offs = (uint32_t*)dev(76, nullptr, sizeof(uint32_t) * m);
-            uint32_t* sums = (uint32_t*)dev(77, nullptr, sizeof(uint32_t) * (blocks + 8));
+            uint32_t* offs = (uint32_t*)dev(D_OFFS, sizeof(uint32_t) * m);
+            uint32_t* sums = (uint32_t*)dev(D_SUMS, sizeof(uint32_t) * (blocks + 8));
             if (!offs || !sums) return VGK_ENOMEM;
             uint64_t total = 0;
-            rc = be->ops_offsets(P.xb_results, m, offs, sums, &total);
+            rc = be->ops_offsets(P.xb_results, m, offs, sums, &total);                   // (on the fetch stream, behind the event: waits for this sub-batch's kernels only)
             if (rc == VGK_OK) {
-                vgk_result* pres_d = (vgk_result*)dev(78, nullptr, sizeof(vgk_result) * m);
-                vgk_op* pops_d = (vgk_op*)dev(79, nullptr, sizeof(vgk_op) * std::max<uint64_t>(total, 1));
+                vgk_result* pres_d = (vgk_result*)dev(D_PRES, sizeof(vgk_result) * m);
+                vgk_op* pops_d = (vgk_op*)dev(D_POPS, sizeof(vgk_op) * std::max<uint64_t>(total, 1));
                 if (!pres_d || !pops_d) return VGK_ENOMEM;
                 if ((rc = be->ops_gather(P.xb_results, P.xb_ops, m, offs, sums, pres_d, pops_d))) return rc;
+                dops = St.dops.get(be, total + 1);
+                unsigned long long* stat = St.stat.get(be, 8);
+                if (!dops || !stat) return VGK_ENOMEM;
+                if ((rc = be->download_fetch_async(dres, pres_d, sizeof(vgk_result) * m))) return rc;
+                if (total && (rc = be->download_fetch_async(dops, pops_d, sizeof(vgk_op) * total))) return rc;
+                if ((rc = be->download_fetch_async(stat, P.stats, sizeof(unsigned long long)))) return rc;
                 if ((rc = be->sync_fetch())) return rc;
-                dops = Hs.dops.get(be, total + 1);
-                if (!dops) return VGK_ENOMEM;
-                if ((rc = be->download(dres, pres_d, sizeof(vgk_result) * m))) return rc;
-                if (total && (rc = be->download(dops, pops_d, sizeof(vgk_op) * total))) return rc;
+                in_band_total += stat[0];
                 // (ops_gather zeroes n_ops of failed problems and keeps their status)
-            } else if (rc == VGK_EUNSUPPORTED) {
-                dops = Hs.dops.get(be, ops_off[m] + 1);
+            } else if (rc == VGK_EUNSUPPORTED) {                                          // a backend without the packing kernels hands the windows over
+                dops = St.dops.get(be, S.ops_total + 1);
                 if (!dops) return VGK_ENOMEM;
+                unsigned long long in_band = 0;
                 if ((rc = be->download(dres, P.xb_results, sizeof(vgk_result) * m))) return rc;
-                if (ops_off[m] && (rc = be->download(dops, P.xb_ops, sizeof(vgk_op) * ops_off[m]))) return rc;
+                if (S.ops_total && (rc = be->download(dops, P.xb_ops, sizeof(vgk_op) * S.ops_total))) return rc;
+                if ((rc = be->download(&in_band, P.stats, sizeof in_band))) return rc;
+                in_band_total += in_band;
             } else return rc;
-
+            ms += be->xdrop_band_ms(set);
+            lap("fetch");
         }
-        lap("d2h");
         // the caller's order: places first (a running sum), then every problem copies its own ops
+        const uint32_t i = S.i, j = S.j;
         std::vector<uint32_t> from(j - i, 0);
         uint32_t a = 0;
         for (uint32_t q = i; q < j; ++q) {
@@ -251,14 +295,27 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
             if (r.status == VGK_OK && r.n_ops) std::memcpy(ops + r.ops_begin, dops + from[k], sizeof(vgk_op) * r.n_ops);
         });
         lap("results");
-        i = j;
+        return VGK_OK;
+    };
+
+    Sub subs[2]; int set = 0; bool pending = false; int rc = VGK_OK;
+    for (uint32_t i = 0; i < n && rc == VGK_OK;) {
+        Sub& S = subs[set];
+        rc = build(i, S, set);                                    // (its kernels are queued behind the previous sub-batch's)
+        i = S.j;
+        if (pending && rc == VGK_OK) rc = finish(subs[set ^ 1], set ^ 1);
+        pending = rc == VGK_OK;
+        set ^= 1;
     }
-    ctx->xband_ms = ms;
+    if (pending && rc == VGK_OK) rc = finish(subs[set ^ 1], set ^ 1);
+    if (rc != VGK_OK) { be->sync(); be->sync_fetch(); return rc; }      // (nothing of this call stays in flight behind an error)
+    ctx->xband_ms = ms; ctx->xband_cells = !cell16 ? 4 : (cell_form == 2 ? 2 : 3);
     if (ops_written) *ops_written = used;
     if (stats) { stats[0] = in_band_total; stats[1] = rect_total; }
     return rc_all;
 } catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 double vgk_xdrop_band_last_ms(vgk_ctx* ctx) { return ctx ? ctx->xband_ms : 0.0; }
+int vgk_xdrop_band_last_cells(vgk_ctx* ctx) { return ctx ? ctx->xband_cells : 4; }
 
 }  // extern "C"
