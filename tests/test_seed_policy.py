@@ -1,0 +1,233 @@
+"""Which minimizers become seeds (vg_amd/host/seed_policy.cpp): algorithms::sample_minimal held to the reference's six unit tests
+(tests/golden/ref_sample_minimal.json, src/unittest/sample_minimal.cpp:14-176) and to a window-by-window restatement on random inputs;
+MinimizerMapper::find_seeds' filter chain [PARITY-UNPINNED: the reference holds no test for it] held to a direct restatement of
+src/minimizer_mapper.cpp:4109-4440 written out below (checker-side, small cases)."""
+import ctypes
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_sample_minimal.json")
+
+
+def sample_minimal(starts, goodness, element_length, window_size, sequence_length):
+    h = util.host()
+    h.vgh_sample_minimal.argtypes = [ctypes.c_uint64] * 4 + [ctypes.c_void_p] * 3
+    s = np.ascontiguousarray(starts, dtype=np.uint64); g = np.ascontiguousarray(goodness, dtype=np.int64); out = np.zeros(max(len(s), 1), dtype=np.uint8)
+    assert h.vgh_sample_minimal(len(s), element_length, window_size, sequence_length, s.ctypes.data, g.ctypes.data, out.ctypes.data) == 0
+    return set(int(i) for i in np.flatnonzero(out[:len(s)]))
+
+
+def sample_minimal_by_windows(starts, goodness, element_length, window_size, sequence_length):
+    """src/algorithms/sample_minimal.cpp:21-207 one window at a time (the reference jumps between the windows where something changes; in
+    the windows between, the same front element would be sampled again): the queue keeps the window's elements no later one has beaten;
+    per window its front is sampled; an element that leaves together with the front it stood behind — same start — is sampled too."""
+    sampled = set(); queue = []; nxt = 0; n = len(starts)
+    beat = lambda a, b: goodness[a] > goodness[b]
+
+    def admit(w):
+        nonlocal nxt
+        while nxt < n and starts[nxt] + element_length <= w + window_size:
+            while queue and beat(nxt, queue[-1]):
+                queue.pop()
+            queue.append(nxt); nxt += 1
+    if n == 0:
+        return sampled
+    admit(0)
+    if queue:
+        sampled.add(queue[0])
+    last = max(sequence_length - window_size, 0)
+    for w in range(1, last + 1):
+        while queue and starts[queue[0]] < w:
+            queue.pop(0)
+            if queue and starts[queue[0]] < w:
+                sampled.add(queue[0])
+        admit(w)
+        if queue:
+            sampled.add(queue[0])
+    if queue:
+        tie = starts[queue[0]]; queue.pop(0)
+        while queue and starts[queue[0]] == tie:
+            sampled.add(queue.pop(0))
+    return sampled
+
+
+def test_sample_minimal_passes_the_reference_unit_tests():
+    cases = json.load(open(GOLDEN))
+    assert len(cases) == 6
+    for c in cases:
+        for got in (sample_minimal(c["starts"], c["goodness"], c["element_length"], c["window_size"], c["sequence_length"]),
+                    sample_minimal_by_windows(c["starts"], c["goodness"], c["element_length"], c["window_size"], c["sequence_length"])):
+            assert len(got) == c["sampled_count"], c["source"]
+            assert all(i in got for i in c["sampled_contains"]), c["source"]
+
+
+def test_sample_minimal_equals_the_window_by_window_form():
+    rng = np.random.default_rng(5)
+    for _ in range(400):
+        seq_len = int(rng.integers(20, 200)); k = int(rng.integers(3, 15)); window = int(rng.integers(k, 60))
+        n = int(rng.integers(0, 40))
+        starts = np.sort(rng.integers(0, max(seq_len - k + 1, 1), n)).tolist()                      # several elements may share a start, some starts have none
+        goodness = rng.integers(0, int(rng.integers(1, 6)), n).tolist()                              # many ties
+        assert sample_minimal(starts, goodness, k, window, seq_len) == sample_minimal_by_windows(starts, goodness, k, window, seq_len), (starts, goodness, k, window, seq_len)
+
+
+# ---- find_seeds: the restatement ------------------------------------------------------------------------------------------------------
+DEFAULTS = dict(hit_cap=10, hard_hit_cap=500, score_fraction=0.9, max_unique_min=500, num_bp_per_min=1000, exclude_overlapping_min=False,
+                coverage_flank=250, window_count=0, max_window_length=2 ** 62)
+
+
+def scores_of(ms, hard_hit_cap):
+    base = 1.0 + math.log(hard_hit_cap)                                                              # (:3927-3937)
+    return [0.0 if not hits else (base - math.log(hits) if hits <= hard_hit_cap else 1.0) for (_, _, _, hits) in ms]
+
+
+def find_seeds_restated(ms, read_len, P):
+    """ms: (key, forward offset, length, hits) in read order -> the filter each minimizer failed (0: taken)"""
+    n = len(ms); score = scores_of(ms, P["hard_hit_cap"])
+    order = sorted(range(n), key=lambda i: (-score[i], ms[i][0], i))                                 # (:4074-4107; ties by key, then read position — see seed_policy.hpp)
+    use_score = P["hit_cap"] != 0 or P["score_fraction"] != 1.0
+    base_target = 0.0
+    for i in order:
+        base_target += score[i]
+    target = base_target * P["score_fraction"] + 0.000001 if use_score else 0.0
+    selected = 0.0
+    kept = set()
+    if P["window_count"] and n:                                                                      # (:4178-4238)
+        shortest = min(m[2] for m in ms)
+        window = 0 if read_len < P["window_count"] * shortest else read_len // P["window_count"]
+        window = min(window, P["max_window_length"])
+        if window:
+            for length in sorted(set(m[2] for m in ms)):
+                idx = [i for i in range(n) if ms[i][2] == length]
+                # the comparator as a rank: no hits lowest; then score descending, key ascending (equal = tie)
+                keyed = sorted(set((0, 0.0, 0) if not ms[i][3] else (1, score[i], -ms[i][0]) for i in idx))
+                good = [keyed.index((0, 0.0, 0) if not ms[i][3] else (1, score[i], -ms[i][0])) for i in idx]
+                for k in sample_minimal_by_windows([ms[i][1] for i in idx], good, length, window, read_len):
+                    kept.add(idx[k])
+    verdict = [0] * n
+    bits = [False] * (read_len + 1); covered = [False] * read_len
+    taken = 0; worst = 0; by_len = read_len // P["num_bp_per_min"] if P["num_bp_per_min"] else 0
+    at = 0
+    while at < n:
+        end = at + 1
+        while end < n and ms[order[end]][0] == ms[order[at]][0]:
+            end += 1
+        run_hits = sum(ms[order[j]][3] for j in range(at, end)); taking = False
+        for j in range(at, end):
+            i = order[j]; key, off, length, hits = ms[i]
+            failed = 0
+            if kept and i not in kept:
+                failed = 1
+            elif not hits:
+                failed = 2
+            elif run_hits > P["hard_hit_cap"]:
+                failed = 3
+            if not failed and P["exclude_overlapping_min"]:                                          # (:4290-4308)
+                if bits[off] or bits[min(off + length, read_len)]:
+                    failed = 4
+                else:
+                    for p in range(off, min(off + length, read_len + 1)):
+                        bits[p] = True
+            if not failed and P["max_unique_min"]:                                                   # (:4310-4356)
+                lo = 0 if off < P["coverage_flank"] else off - P["coverage_flank"]; hi = min(read_len, off + length + P["coverage_flank"])
+                if taken < max(P["max_unique_min"], by_len):
+                    for p in range(lo, hi):
+                        covered[p] = True
+                    worst = max(worst, hits)
+                elif hits > worst:
+                    failed = 5
+                elif any(covered[lo:hi]):
+                    failed = 5
+                else:
+                    for p in range(lo, hi):
+                        covered[p] = True
+            if not failed and use_score:                                                             # (:4358-4378)
+                if hits <= P["hit_cap"] or (run_hits <= P["hard_hit_cap"] and selected + score[i] <= target) or taking:
+                    selected += score[i]
+                else:
+                    failed = 6; target = selected
+            verdict[i] = failed
+            if not failed:
+                taking = True; taken += 1
+        at = end
+    return verdict, score
+
+
+def select(ms, read_len, P):
+    h = util.host()
+    h.vgh_select_minimizers.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+    a = np.ascontiguousarray([x for m in ms for x in m], dtype=np.uint64) if ms else np.zeros(4, dtype=np.uint64)
+    pol = np.array([P["hit_cap"], P["hard_hit_cap"], P["max_unique_min"], P["num_bp_per_min"], int(P["exclude_overlapping_min"]), P["coverage_flank"], P["window_count"],
+                    P["max_window_length"]], dtype=np.uint64)
+    v = np.zeros(max(len(ms), 1), dtype=np.uint8); sc = np.zeros(max(len(ms), 1), dtype=np.float64)
+    rc = h.vgh_select_minimizers(a.ctypes.data, len(ms), read_len, pol.ctypes.data, P["score_fraction"], v.ctypes.data, sc.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("vgh_select_minimizers")
+    return v[:len(ms)].tolist(), sc[:len(ms)].tolist()
+
+
+def random_minimizers(rng, read_len, k, n_keys):
+    """minimizers of a read in read order: some keys occur several times (runs), hit counts from none to far beyond the hard cap"""
+    n = int(rng.integers(0, 40))
+    offs = np.sort(rng.choice(np.arange(read_len - k + 1), size=min(n, read_len - k + 1), replace=False))
+    hits_of = {key: int(rng.choice([0, 1, 2, 3, 9, 10, 11, 40, 499, 500, 501, 3000])) for key in range(n_keys)}
+    ms = []
+    for o in offs:
+        key = int(rng.integers(0, n_keys))
+        ms.append((key * 7919 + 13, int(o), k, hits_of[key]))
+    return ms
+
+
+def test_minimizer_scores():
+    ms = [(1, 0, 29, 0), (2, 5, 29, 1), (3, 9, 29, 500), (4, 12, 29, 501)]
+    _, sc = select(ms, 150, DEFAULTS)
+    assert sc[0] == 0.0 and sc[1] == 1.0 + math.log(500) and abs(sc[2] - 1.0) < 1e-12 and sc[3] == 1.0
+
+
+def test_selection_equals_the_restatement_with_giraffe_defaults():
+    rng = np.random.default_rng(11)
+    for _ in range(300):
+        ms = random_minimizers(rng, 150, 29, int(rng.integers(1, 30)))
+        got, sc = select(ms, 150, DEFAULTS); want, wsc = find_seeds_restated(ms, 150, DEFAULTS)
+        assert sc == wsc and got == want, ms
+
+
+def test_selection_equals_the_restatement_with_every_filter_on():
+    rng = np.random.default_rng(12)
+    for _ in range(600):
+        read_len = int(rng.integers(60, 400)); k = int(rng.integers(11, 31))
+        P = dict(DEFAULTS, hit_cap=int(rng.choice([0, 1, 3, 10])), hard_hit_cap=int(rng.choice([20, 500])), score_fraction=float(rng.choice([0.5, 0.9, 1.0])),
+                 max_unique_min=int(rng.choice([0, 2, 5, 500])), num_bp_per_min=int(rng.choice([50, 1000])), exclude_overlapping_min=bool(rng.integers(0, 2)),
+                 coverage_flank=int(rng.choice([0, 10, 250])), window_count=int(rng.choice([0, 0, 2, 4])), max_window_length=int(rng.choice([40, 2 ** 62])))
+        ms = random_minimizers(rng, read_len, k, int(rng.integers(1, 25)))
+        if P["window_count"] and ms:
+            w = 0 if read_len < P["window_count"] * k else min(read_len // P["window_count"], P["max_window_length"])
+            if w and k > w:
+                with pytest.raises(RuntimeError):                    # crash_unless(length <= window) (:4203)
+                    select(ms, read_len, P)
+                continue
+        got, _ = select(ms, read_len, P); want, _ = find_seeds_restated(ms, read_len, P)
+        assert got == want, (ms, read_len, P)
+
+
+def test_what_the_filters_mean():
+    # without hits: never a seed; beyond the hard cap (summed over a key's occurrences): never; under the soft cap: always
+    P = dict(DEFAULTS)
+    v, _ = select([(1, 0, 29, 0), (2, 10, 29, 501), (3, 20, 29, 10), (4, 30, 29, 300), (4, 60, 29, 300)], 150, P)
+    assert v[0] == 2 and v[1] == 3 and v[2] == 0 and v[3] == 3 and v[4] == 3           # two occurrences of key 4: 600 hits in the run
+    # between the caps a minimizer is taken only while the selected score is short of the fraction of the total
+    ms = [(k, 5 * k, 29, 11) for k in range(1, 20)]
+    v, _ = select(ms, 150, dict(P, score_fraction=0.5))
+    assert v.count(0) == 9 and v.count(6) == 10                                          # 19 equal scores: floor(0.5 x 19) fit under the target
+    v, _ = select(ms, 150, dict(P, score_fraction=1.0))
+    assert v.count(0) == 19
+    # once a run has one member in, the rest of the run follows (taking_run)
+    ms = [(1, 0, 29, 11), (2, 10, 29, 12), (2, 40, 29, 12), (2, 70, 29, 12)]
+    v, _ = select(ms, 150, dict(P, score_fraction=0.45))
+    assert v == [0, 0, 0, 0] or v[1:] in ([0, 0, 0], [6, 6, 6])

@@ -13,6 +13,7 @@
 #include "gbwt_extender.hpp"
 #include "rescue_fixups.hpp"
 #include "mapq_cap.hpp"
+#include "seed_policy.hpp"
 #include "extension_scoring.hpp"
 #include "aligner_client.hpp"
 #include "rescue_stage.hpp"
@@ -669,6 +670,32 @@ int vgh_chain_stage(vgh_wfa* w, const char* seqs, const uint64_t* seq_off, uint3
         std::copy(out.chain_score.begin(), out.chain_score.end(), chain_score);
         if (stats) { stats[0] = out.n_declined; stats[1] = out.n_between; stats[2] = out.n_no_graph; stats[3] = out.n_too_big; stats[4] = out.n_failed; }
         if (ms) for (int k = 0; k < 5; ++k) ms[k] = out.ms[k];
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// algorithms::sample_minimal with should_beat(a, b) = goodness[a] > goodness[b]: sampled[i] = 1 for every element sampled
+int vgh_sample_minimal(uint64_t count, uint64_t element_length, uint64_t window_size, uint64_t sequence_length, const uint64_t* starts, const int64_t* goodness, uint8_t* sampled) {
+    try {
+        for (uint64_t i = 0; i < count; ++i) sampled[i] = 0;
+        sample_minimal((size_t)count, (size_t)element_length, (size_t)window_size, (size_t)sequence_length,
+                       [&](size_t i) { return (size_t)starts[i]; }, [&](size_t a, size_t b) { return goodness[a] > goodness[b]; }, [&](size_t i) { sampled[i] = 1; });
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+// MinimizerMapper::find_seeds' selection: minimizers in read order, 4 numbers each {key, forward offset, length, hits}; policy = {hit_cap,
+// hard_hit_cap, max_unique_min, num_bp_per_min, exclude_overlapping_min, minimizer_coverage_flank, downsampling_window_count,
+// downsampling_max_window_length}; verdict_out[i] = SeedFilter (0 = its hits become seeds); scores_out (nullable) = find_minimizers' scores
+int vgh_select_minimizers(const uint64_t* minimizers, int n, uint64_t read_length, const uint64_t* policy, double score_fraction, uint8_t* verdict_out, double* scores_out) {
+    try {
+        std::vector<PolicyMinimizer> ms((size_t)n);
+        for (int i = 0; i < n; ++i) { const uint64_t* q = minimizers + 4 * (size_t)i; ms[(size_t)i].key = q[0]; ms[(size_t)i].forward_offset = (size_t)q[1]; ms[(size_t)i].length = (size_t)q[2]; ms[(size_t)i].hits = (size_t)q[3]; }
+        SeedPolicy P; P.hit_cap = (size_t)policy[0]; P.hard_hit_cap = (size_t)policy[1]; P.max_unique_min = (size_t)policy[2]; P.num_bp_per_min = (size_t)policy[3];
+        P.exclude_overlapping_min = policy[4] != 0; P.minimizer_coverage_flank = (size_t)policy[5]; P.minimizer_downsampling_window_count = (size_t)policy[6];
+        P.minimizer_downsampling_max_window_length = (size_t)policy[7]; P.minimizer_score_fraction = score_fraction;
+        score_minimizers(ms, P.hard_hit_cap);
+        const std::vector<uint8_t> v = select_minimizers(ms, (size_t)read_length, P);
+        for (int i = 0; i < n; ++i) { verdict_out[i] = v[(size_t)i]; if (scores_out) scores_out[i] = ms[(size_t)i].score; }
         return 0;
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }

@@ -1,0 +1,52 @@
+// seed_policy.hpp — which of a read's minimizers become seeds: MinimizerMapper::find_seeds' filters (reference
+// src/minimizer_mapper.cpp:4109-4470) with the scores find_minimizers gives them (:3918-3941), the order sort_minimizers_by_score puts them
+// in (:4074-4107) and the window downsampling of algorithms::sample_minimal (src/algorithms/sample_minimal.cpp:21-207).  Host logic beside
+// the seeding stage: the engine's vgk_minimizer_seeds finds every minimizer and its hits; these rules say which hits are
+// looked at.
+//
+// Pinned: sample_minimal, by the reference's six unit tests (src/unittest/sample_minimal.cpp:14-176; tests/golden/ref_sample_minimal.json).
+// [PARITY-UNPINNED] the filter chain — the reference holds no test for find_seeds; tests/test_seed_policy.py holds it to a direct
+// restatement of the cited lines — and one rule that cannot be restated: among runs of EQUAL score the reference shuffles with a generator
+// seeded from the read (sort_shuffling_ties, :4089); here equal scores are ordered by key (Minimizer::operator<,
+// src/minimizer_mapper.hpp:577) and, inside a run of one key, by read position.  The selected set differs from the reference's only where
+// the score-fraction cut falls inside such a tie.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <vector>
+
+namespace vgamd {
+
+// every element minimal in some window of `window_size` bases of a sequence: elements sorted by start, all of one length; should_beat(a, b):
+// a displaces b.  sample(i) at least once for every such element (ties at one start are all sampled; of ties at different starts the
+// earliest, the others when they come to the front).
+void sample_minimal(size_t count, size_t element_length, size_t window_size, size_t sequence_length, const std::function<size_t(size_t)>& get_start,
+                    const std::function<bool(size_t, size_t)>& should_beat, const std::function<void(size_t)>& sample);
+
+struct PolicyMinimizer {                 // what find_seeds reads of MinimizerMapper::Minimizer (src/minimizer_mapper.hpp:540-600)
+    uint64_t key = 0;                    // value.key
+    size_t forward_offset = 0;           // first read base of the k-mer
+    size_t length = 0;                   // k
+    size_t hits = 0;                     // occurrences in the index
+    double score = 0;                    // filled by score_minimizers
+};
+struct SeedPolicy {                      // MinimizerMapper's parameters of the same names (src/minimizer_mapper.hpp:140-260), giraffe's defaults
+    size_t hit_cap = 10, hard_hit_cap = 500;
+    double minimizer_score_fraction = 0.9;
+    size_t max_unique_min = 500, num_bp_per_min = 1000;
+    bool exclude_overlapping_min = false;
+    size_t minimizer_coverage_flank = 250;
+    size_t minimizer_downsampling_window_count = 0, minimizer_downsampling_max_window_length = (size_t)-1;
+};
+enum SeedFilter : uint8_t { SEED_TAKEN = 0, SEED_DOWNSAMPLED = 1, SEED_NO_HITS = 2, SEED_HARD_HIT_CAP = 3, SEED_OVERLAPPING = 4, SEED_MAX_MIN = 5, SEED_HIT_CAP = 6 };
+
+// find_minimizers' score per minimizer (:3927-3937): 1 + ln(hard_hit_cap) - ln(hits), 1 beyond the hard cap, 0 without hits
+void score_minimizers(std::vector<PolicyMinimizer>& minimizers_in_read_order, size_t hard_hit_cap);
+// sort_minimizers_by_score (:4074-4107): runs of one key together, the runs by descending score (ties: header) -> indices in that order
+std::vector<size_t> minimizers_by_score(const std::vector<PolicyMinimizer>& minimizers_in_read_order);
+// find_seeds' selection (:4109-4440): per minimizer (read order) the filter it failed, or SEED_TAKEN — the hits of the taken ones are the seeds.
+// Throws std::runtime_error where the reference crashes (a minimizer longer than the downsampling window).
+std::vector<uint8_t> select_minimizers(const std::vector<PolicyMinimizer>& minimizers_in_read_order, size_t read_length, const SeedPolicy& policy);
+
+}  // namespace vgamd
