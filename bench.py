@@ -187,7 +187,7 @@ def bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus):
                        "timed_region": "K launches of the WFA kernels on the batch resident in HBM (vgk_wfa_rerun)",
                        "kernels": (lambda w: {"first_launch_ms": w[0], "wavefront_kernel_behind_it_ms": w[1], "handed_over": int(w[2]),
                                               "form": "hybrid, the thread kernel and the wavefront kernel at once" if w[1] == 0 and w[2] else "hybrid, one kernel after the other" if w[2] else "one kernel"})(eng.wfa_last_wave()),
-                       "end_to_end_from_host_buffers_alignments_per_s": n / te, "parallelism": "problem-sharded x%d" % world,
+                       "end_to_end_from_host_buffers_alignments_per_s": n / te, "end_to_end_one_batch_alignments_per_s": n / te_one, "parallelism": "problem-sharded x%d" % world,
                        "device": dev_name, "compute_units": cus, "sequence_bases": wl.bases},
             "roofline": {"bound": "hbm", "limiter": "memory latency on each thread's dependent chain and lane divergence, not bandwidth (DESIGN.md §12)", "kernel": {"thread": "wfa_kernel", "wave": "wfa_wave_kernel"}.get(os.environ.get("VGAMD_WFA_KERNEL", ""), "wfa_kernel + wfa_wave_kernel (hybrid: a problem is handed to a wavefront at 16 points)"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["wfa"] * n, "traffic_source": traffic_source("wfa"), "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
@@ -213,8 +213,18 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
             dist.barrier()
         torch.cuda.synchronize()
 
-    eng.banded_align(wl.bs)                                # warms the cached buffers
-    te = time.perf_counter(); res, ops = eng.banded_align(wl.bs); te = time.perf_counter() - te
+    # from host buffers: the call as a caller makes it — a large one runs as four sub-batches, two in flight (banded_align_pipelined)
+    eng.banded_align(wl.bs); eng.banded_align(wl.bs)       # warm the cached staging and device buffers
+    te = time.perf_counter()
+    for _ in range(3):
+        res_p, ops_p = eng.banded_align(wl.bs)
+    te = (time.perf_counter() - te) / 3
+    # ... and once as ONE batch that stays resident in HBM, which the timed region re-launches
+    os.environ["VGAMD_BANDED_ONE_BATCH"] = "1"
+    eng.banded_align(wl.bs)
+    t1 = time.perf_counter(); res, ops = eng.banded_align(wl.bs); te_one = time.perf_counter() - t1
+    del os.environ["VGAMD_BANDED_ONE_BATCH"]
+    assert res_p.tobytes() == res.tobytes() and ops_p.tobytes() == ops.tobytes()
     cells = eng.banded_last(2); alg_bytes = eng.banded_last(3)
     for _ in range(args.warmup):
         eng.banded_rerun()
@@ -256,7 +266,7 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
             "config": {"workload": "configs[4] stand-in: 1 Mbp variation graph, %d anchor-to-anchor windows of 30-500 bp per GPU, "
                                    "BandedGlobalAligner semantics, permissive band, padding floor(sqrt(L))+1, scores 1/4/6/1" % n,
                        "timed_region": "K runs of the fill launches + traceback kernel on the batch resident in HBM (vgk_banded_rerun)",
-                       "end_to_end_from_host_buffers_alignments_per_s": n / te,
+                       "end_to_end_from_host_buffers_alignments_per_s": n / te, "end_to_end_one_batch_alignments_per_s": n / te_one,
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "limiter": "VALU issue: 1.74 G VALU wave-instructions per launch = 2.8 ms on 1024 SIMDs; ~41 VALU per wave-column of <= 64 cells inside the read, plus the per-node work (DESIGN.md §10)", "kernel": "banded_fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["banded"] * n, "traffic_source": traffic_source("banded"), "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": fill,

@@ -206,6 +206,40 @@ def test_emulated_banded_kernels_match_reference_unit_tests_and_oracle():
     assert not _same(problems, ref, got)
 
 
+# A large call runs as four sub-batches, two in flight (banded_align_pipelined): the geometry of a quarter is made while the quarter before
+# runs, its results handed out while the next runs.  VGAMD_BANDED_PIPELINE_MIN lets a small call take that path: the one-batch call's answers.
+def pipelined_equals_one_batch(lib, problems, monkeypatch, qual_adj=None):
+    bs = capi.BandedSet.from_lists(problems)
+    whole = capi.Engine(lib=lib, qual_adj=qual_adj).banded_align(bs)
+    monkeypatch.setenv("VGAMD_BANDED_PIPELINE_MIN", "8")
+    cut = capi.Engine(lib=lib, qual_adj=qual_adj).banded_align(bs)
+    monkeypatch.setenv("VGAMD_MAX_BATCH_BYTES", "200000")                # ... and with quarters that do not fit the device budget in one piece
+    cut_small = capi.Engine(lib=lib, qual_adj=qual_adj).banded_align(bs)
+    monkeypatch.delenv("VGAMD_BANDED_PIPELINE_MIN"); monkeypatch.delenv("VGAMD_MAX_BATCH_BYTES")
+    assert not _same(problems, whole, cut) and not _same(problems, whole, cut_small)
+    assert (whole[0]["ops_begin"] == cut[0]["ops_begin"]).all() and (whole[0]["ops_begin"] == cut_small[0]["ops_begin"]).all()
+    return whole
+
+
+def test_emulated_banded_call_in_four_sub_batches(monkeypatch):
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    problems = random_banded_set(51, 30) + mixed_band_problems(52, 4, 30, 120)
+    problems.insert(7, dict(read="ACGT", nodes=["A" * 70000], preds=[[]], band_padding=1, permissive=True))      # one the checks decline, in between
+    whole = pipelined_equals_one_batch(util.EMU_LIB, problems, monkeypatch)
+    assert not _same(problems, capi.Engine(lib=util.ORACLE_LIB).banded_align(capi.BandedSet.from_lists(problems)), whole)
+
+
+@pytest.mark.gpu
+def test_hip_banded_call_in_four_sub_batches(monkeypatch):
+    problems = random_banded_set(53, 2000) + mixed_band_problems(54, 200, 30, 200)
+    whole = pipelined_equals_one_batch(util.ENGINE_LIB, problems, monkeypatch)
+    assert not _same(problems, capi.Engine(lib=util.ORACLE_LIB).banded_align(capi.BandedSet.from_lists(problems)), whole)
+    big = random_banded_set(55, 36000, max_read=60)                         # past the threshold by itself
+    bs = capi.BandedSet.from_lists(big)
+    assert not _same(big, capi.Engine(lib=util.ORACLE_LIB).banded_align(bs), capi.Engine().banded_align(bs))
+
+
 @pytest.mark.gpu
 def test_hip_banded_matches_reference_unit_tests():
     for c in banded_cases():

@@ -95,6 +95,10 @@ public:
     // banded global alignment: one fill launch per rows-per-lane instantiation (one wavefront per problem), then one
     // traceback launch (one thread per problem) over p.n problems
     virtual int   run_banded(const BandedParams& p, const BandedLaunch* launches, uint32_t n_launches) = 0;
+    // The same without waiting (the primary alignment only), bracketed by the timing events of `slot` (0 or 1): two sub-batches of a call in
+    // flight.  banded_ms(slot, 0 | 1) = fill | traceback time, valid once the caller has waited for the launch.
+    virtual int   run_banded_async(const BandedParams& p, const BandedLaunch* launches, uint32_t n_launches, int slot) { (void)slot; return run_banded(p, launches, n_launches); }
+    virtual double banded_ms(int slot, int which) { (void)slot; return last_ms(which ? 4 : 3); }
     // gapless extension: `threads` resident threads (one scratch slab each) stride over p.n reads; last_ms(5) = kernel ms
     virtual int   run_gapless(const GaplessParams& p, uint32_t threads) = 0;
     // the sets of a gapless batch in problem order (gapless_device.hpp): stage 1 = sizes per read, stage 2 = the gather (the prefix sums

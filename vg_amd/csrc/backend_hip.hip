@@ -838,6 +838,7 @@ public:
     float ms_gapless = 0.f, ms_wfa = 0.f, ms_xband = 0.f;
     float ms_bfill = 0.f, ms_bwalk = 0.f; hipEvent_t bev[3] = {nullptr, nullptr, nullptr};
     hipEvent_t xbev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // run_xdrop_band_async: start / end per slot
+    hipEvent_t bbev[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};      // run_banded_async: start / fills done / walk done per slot
     void* scan_tmp = nullptr; size_t scan_tmp_bytes = 0;      // rocPRIM's scratch for scan_u32 (grow-only)
     void* mz_slots = nullptr; size_t mz_slots_bytes = 0;      // per-read seed slots of run_minimizer (grow-only)
     ~HipBackend() override {
@@ -845,6 +846,7 @@ public:
         for (auto& e : ev) if (e) hipEventDestroy(e);
         for (auto& e : bev) if (e) hipEventDestroy(e);
         for (auto& pair : xbev) for (auto& e : pair) if (e) hipEventDestroy(e);
+        for (auto& trio : bbev) for (auto& e : trio) if (e) hipEventDestroy(e);
         if (scan_tmp) hipFree(scan_tmp);
         if (mz_slots) hipFree(mz_slots);
         for (int i = 0; i < 2; ++i) { if (side[i]) hipStreamDestroy(side[i]); if (side_done[i]) hipEventDestroy(side_done[i]); }
@@ -1089,9 +1091,29 @@ public:
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_banded(const BandedParams& p, const BandedLaunch* launches, uint32_t n) override {
-        hipSetDevice(dev);
         ms_bfill = ms_bwalk = 0.f;
         if (p.n == 0) return VGK_OK;
+        const int rc = banded_launch(p, launches, n, bev);
+        if (rc != VGK_OK) return rc;
+        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
+        hipEventElapsedTime(&ms_bfill, bev[0], bev[1]);
+        hipEventElapsedTime(&ms_bwalk, bev[1], bev[2]);
+        return VGK_OK;
+    }
+    int run_banded_async(const BandedParams& p, const BandedLaunch* launches, uint32_t n, int slot) override {
+        if (p.n == 0) return VGK_OK;
+        hipSetDevice(dev);
+        hipEvent_t* ev = bbev[slot & 1];
+        for (int k = 0; k < 3; ++k) if (!ev[k] && hipEventCreate(&ev[k]) != hipSuccess) return VGK_ENODEV;
+        return banded_launch(p, launches, n, ev);
+    }
+    double banded_ms(int slot, int which) override {
+        hipEvent_t* ev = bbev[slot & 1]; float ms = 0.f;
+        if (!ev[0] || hipEventElapsedTime(&ms, ev[which ? 1 : 0], ev[which ? 2 : 1]) != hipSuccess) { (void)hipGetLastError(); return 0.0; }
+        return ms;
+    }
+    int banded_launch(const BandedParams& p, const BandedLaunch* launches, uint32_t n, hipEvent_t* bev) {
+        hipSetDevice(dev);
         hipEventRecord(bev[0], stream);
         // the rows-per-lane classes are independent: the small ones run on the side streams under the big one
         for (uint32_t i = 0; i < n; ++i) {
@@ -1113,10 +1135,7 @@ public:
         hipEventRecord(bev[1], stream);
         if (!p.scores) hipLaunchKernelGGL(banded_walk_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);      // k-best mode: the host walks the score matrices
         hipEventRecord(bev[2], stream);
-        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
-        hipEventElapsedTime(&ms_bfill, bev[0], bev[1]);
-        hipEventElapsedTime(&ms_bwalk, bev[1], bev[2]);
-        return VGK_OK;
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_gapless(const GaplessParams& p, uint32_t threads) override {
         hipSetDevice(dev);

@@ -20,6 +20,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <emmintrin.h>
 #include "ctx.hpp"
 #include "host_parallel.hpp"
 
@@ -233,14 +234,37 @@ template <class T> int stage(vgk_ctx* ctx, int slot, const T* v, size_t count, c
     return VGK_OK;
 }
 // host arenas kept on the context between calls: uninitialised storage, so a warm call neither zero-fills nor page-faults
+struct PinnedSet {
+    PinnedBuf<BProb> probs; PinnedBuf<BNode> nodes; PinnedBuf<BSeed> seeds; PinnedBuf<uint32_t> pool, order; PinnedBuf<BStart> starts;
+    PinnedBuf<uint8_t> reads, quals, graph; PinnedBuf<BResult> dres; PinnedBuf<vgk_op> dops; PinnedBuf<unsigned long long> count;
+};
 struct HostArenas {
     std::vector<Scratch> scratch; std::vector<Store> store;       // pass 1's per-thread tables: their memory stays mapped between calls
     PinnedBuf<BProb> probs; PinnedBuf<BNode> nodes; PinnedBuf<BSeed> seeds; PinnedBuf<uint32_t> pool, order; PinnedBuf<BStart> starts;
     PinnedBuf<uint8_t> reads, quals, graph; PinnedBuf<BResult> dres; PinnedBuf<vgk_op> dops; PinnedBuf<int32_t> scores;
+    PinnedSet set[2]; void* ev[2] = {nullptr, nullptr}; Backend* be = nullptr;      // the pipelined path: two sub-batches in flight
+    ~HostArenas() { if (be) for (void* e : ev) if (e) be->event_destroy(e); }
 };
 enum { S_PROBS, S_ORDER, S_NODES, S_SEEDS, S_POOL, S_STARTS, S_READS, S_QUALS, S_GRAPH, S_MAT, S_TB, S_LAST, S_OPS, S_DENSE, S_RESULTS, S_COUNT };
 constexpr int S_SCORES = 31;          // k-best mode: the full score matrices (slots 15..30 belong to gapless_api.cpp)
-static_assert(S_COUNT <= 15 && S_SCORES < (int)(sizeof(vgk_ctx::scratch) / sizeof(vgk_ctx::DevBuf)), "scratch slots");
+constexpr int S_SET1 = 124;           // the pipelined path's second sub-batch in flight: slots S_SET1 + S_*
+static_assert(S_COUNT <= 15 && S_SCORES < (int)(sizeof(vgk_ctx::scratch) / sizeof(vgk_ctx::DevBuf)) && S_SET1 + S_COUNT <= (int)(sizeof(vgk_ctx::scratch) / sizeof(vgk_ctx::DevBuf)), "scratch slots");
+
+// base -> code, sixteen at a time (gssw_create_nt_table's rule: case-insensitive ACGT, everything else N)
+inline void nt_code_run(uint8_t* __restrict dst, const char* __restrict src, uint32_t n) {
+    uint32_t k = 0;
+    const __m128i four = _mm_set1_epi8(4), fold = _mm_set1_epi8((char)0xdf);
+    const __m128i cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
+    const __m128i dA = _mm_set1_epi8(4), dC = _mm_set1_epi8(3), dG = _mm_set1_epi8(2), dT = _mm_set1_epi8(1);
+    for (; k + 16 <= n; k += 16) {
+        const __m128i b = _mm_and_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(src + k)), fold);
+        __m128i r = four;
+        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cA), dA)); r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cC), dC));
+        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cG), dG)); r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cT), dT));
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + k), r);
+    }
+    for (; k < n; ++k) dst[k] = nt_code(src[k]);
+}
 
 // ---- k-best alignments: the alternate-traceback stack of the reference (AltTracebackStack, src/banded_global_aligner.cpp:2426-2790)
 // walked on the host over the score matrices the fill kernel left in HBM.  A traceback is the list of its deflections — the first
@@ -556,11 +580,9 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
                 std::copy(T.seeds.begin() + hp.seeds.off, T.seeds.begin() + hp.seeds.off + hp.seeds.len, seeds + pb.seed_base);
                 std::copy(T.pool.begin() + hp.pool.off, T.pool.begin() + hp.pool.off + hp.pool.len, pool + pb.pool_base);
                 for (uint32_t q = 0; q < hp.starts.len; ++q) starts[pb.start_base + q].node = T.starts[hp.starts.off + q];
-                uint8_t* rd = reads + pb.read_off;
-                for (uint32_t q = 0; q < pb.L; ++q) rd[q] = nt_code(p.read[q]);
+                nt_code_run(reads + pb.read_off, p.read, pb.L);
                 if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
-                uint8_t* gr = graph + pb.graph_off;
-                for (uint32_t q = 0; q < pb.graph_len; ++q) gr[q] = nt_code(p.graph.seq[q]);
+                nt_code_run(graph + pb.graph_off, p.graph.seq, pb.graph_len);
             });
             lap("arenas");
             // launches: one per rows-per-lane class; inside a class the problems with the most cells first (counting sort on log2(cells))
@@ -782,8 +804,280 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
     return rc_all;
 }
 
+// ---- a large call of primary alignments as a pipeline of sub-batches, two in flight ---------------------------------------------------
+// banded_align_impl prepares everything, then runs sub-batch after sub-batch with the host waiting for each one's kernels: 14 ms of host work
+// beside 7 ms of kernels per 100 000 problems.  Here the call is cut into quarters; a quarter's geometry (prepare) and arenas are made while
+// the kernels of the quarter before run, its results are handed out while the next one's run; the ops and results come back on the fetch
+// stream behind an event.  Same passes, same tables, same kernels — only the order of the host's work changes.  (The batch does not stay
+// resident for vgk_banded_rerun: a caller that wants that sets VGAMD_BANDED_ONE_BATCH=1.)
+struct BSub { uint32_t i = 0, j = 0, m = 0; std::vector<uint32_t> owner; BandedParams P{}; std::vector<BandedLaunch> launches; uint64_t sizes[9] = {0}; };
+
+static int banded_align_pipelined(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n,
+                                  vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->banded_ms[0] = ctx->banded_ms[1] = 0; ctx->banded_cells = 0; ctx->banded_bytes = 0; ctx->banded_last_valid = false;
+    uint64_t budget = ctx->be->memory_bytes() / 4;
+    if (const char* e = std::getenv("VGAMD_MAX_BATCH_BYTES")) budget = std::strtoull(e, nullptr, 10);
+    if (!budget) budget = 1ull << 30;
+    Backend* be = ctx->be.get();
+    const bool qa = ctx->has_qa;
+    if (!ctx->banded_host) ctx->banded_host = std::make_shared<HostArenas>();
+    HostArenas& H = *static_cast<HostArenas*>(ctx->banded_host.get());
+    if (!H.be) { H.be = be; for (void*& e : H.ev) e = be->event_create(); }
+    const bool timing = std::getenv("VGAMD_BANDED_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "[vgk_banded_align] %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
+    // (the records of 100 000 problems are 18 MB: constructed by the threads that prepare them, not by this one before anything else starts)
+    struct PrepArray { Prep* p; uint32_t made = 0; ~PrepArray() { for (uint32_t k = 0; k < made; ++k) p[k].~Prep(); std::free(p); } } hps_store{(Prep*)std::malloc(sizeof(Prep) * (size_t)std::max<uint32_t>(n, 1))};
+    if (!hps_store.p) return VGK_ENOMEM;
+    Prep* const hps = hps_store.p;
+    if (H.store.empty()) { H.scratch.resize(MAX_THREADS); H.store.resize(MAX_THREADS); }
+    std::vector<Scratch>& scratch = H.scratch; std::vector<Store>& store = H.store;
+    for (Store& T : store) T.clear();
+    const uint32_t quarter = (n + 3u) / 4u;
+    uint32_t prepared = 0;
+    size_t used = 0; int rc_all = VGK_OK;
+    // plain contexts: the table, and behind it its rows as 64-bit words for the kernel's byte permute (banded_device.hpp BMAT_ROWS_AT)
+    int8_t* mat_rows = ctx->banded_mat_rows;
+    std::memset(mat_rows, 0, BMAT_BYTES);
+    if (!qa) { std::memcpy(mat_rows, ctx->sc.matrix, 25); for (int g = 0; g < 5; ++g) std::memcpy(mat_rows + BMAT_ROWS_AT + 8 * g, ctx->sc.matrix + 5 * g, 5); }
+    const int8_t* mat = qa ? ctx->qmat.data() : mat_rows;
+
+    // ---- first half of a sub-batch: geometry of its quarter (if not there yet), placement, arenas, upload, launch
+    auto build = [&](uint32_t from, BSub& S, int set) -> int {
+        PinnedSet& A = H.set[set]; const int base = set ? S_SET1 : 0;
+        const uint32_t limit = std::min<uint32_t>(n, (from / quarter + 1u) * quarter);
+        if (prepared < limit) {
+            const uint32_t lo = prepared;
+            parallel_for(limit - lo, [&](uint32_t k, unsigned t) { Prep* hp = new (&hps[lo + k]) Prep(); hp->thread = t; prepare(ctx, problems[lo + k], *hp, scratch[t], store[t]); });
+            prepared = limit; hps_store.made = limit;
+            lap("prepare");
+        }
+        S.i = from; S.owner.clear(); S.launches.clear();
+        uint64_t n_nodes = 0, n_seeds = 0, n_pool = 0, n_starts = 0, n_read = 0, n_graph = 0, tb_bytes = 0, last_elems = 0, ops_total = 0;
+        uint32_t j = from;
+        // The usual case — the whole quarter fits the device budget — is placed by sums over chunks of problems on the host threads (one
+        // thread walking 25 000 records and their problems was 0.65 ms a quarter); otherwise the running sum below cuts the quarter.
+        struct Sums { uint64_t v[10]; };                          // problems on the device, then the nine arena sizes
+        const uint32_t n_chunks = chunk_count(limit - from);
+        std::vector<Sums> chunk(n_chunks + 1, Sums{});
+        auto sizes_of = [&](uint32_t q, uint64_t (&v)[10]) {
+            const Prep& hp = hps[q]; const vgk_banded_problem& p = problems[q];
+            v[0] = 1; v[1] = p.graph.n_nodes; v[2] = hp.seeds.len; v[3] = hp.pool.len; v[4] = hp.starts.len; v[5] = p.read_len; v[6] = hp.bases; v[7] = hp.tb_bytes; v[8] = hp.last_elems; v[9] = hp.ops_cap;
+        };
+        parallel_chunks(limit - from, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+            Sums t{};
+            for (uint32_t q = from + lo; q < from + hi; ++q) if (hps[q].on_device) { uint64_t v[10]; sizes_of(q, v); for (int x = 0; x < 10; ++x) t.v[x] += v[x]; }
+            chunk[c + 1] = t;
+        });
+        for (uint32_t c = 0; c < n_chunks; ++c) for (int x = 0; x < 10; ++x) chunk[c + 1].v[x] += chunk[c].v[x];
+        const Sums& all = chunk[n_chunks];
+        const bool whole = all.v[7] + all.v[8] * 4 + all.v[9] * 2 * sizeof(vgk_op) <= budget && all.v[1] <= 0xfffffff0ull && all.v[5] <= 0xfffffff0ull && all.v[6] <= 0xfffffff0ull;
+        if (whole) {
+            const uint32_t m_all = (uint32_t)all.v[0];
+            S.owner.resize(m_all);
+            BProb* probs_w = H.set[set].probs.get(be, std::max<uint32_t>(m_all, 1));
+            if (!probs_w) return VGK_ENOMEM;
+            parallel_chunks(limit - from, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+                Sums at = chunk[c];
+                for (uint32_t q = from + lo; q < from + hi; ++q) {
+                    Prep& hp = hps[q];
+                    if (!hp.on_device) continue;
+                    const vgk_banded_problem& p = problems[q];
+                    uint64_t v[10]; sizes_of(q, v);
+                    BProb pb{};
+                    pb.L = p.read_len; pb.n_nodes = p.graph.n_nodes; pb.Hpad = hp.Hpad; pb.graph_len = (uint32_t)hp.bases;
+                    pb.node_base = (uint32_t)at.v[1]; pb.seed_base = (uint32_t)at.v[2]; pb.pool_base = (uint32_t)at.v[3]; pb.start_base = (uint32_t)at.v[4];
+                    pb.n_starts = hp.starts.len; pb.read_off = (uint32_t)at.v[5]; pb.graph_off = (uint32_t)at.v[6];
+                    pb.tb_base = at.v[7]; pb.last_base = at.v[8]; pb.ops_off = at.v[9]; pb.ops_cap = hp.ops_cap;
+                    const uint32_t a = (uint32_t)at.v[0];
+                    hp.arena = a; probs_w[a] = pb; S.owner[a] = q;
+                    for (int x = 0; x < 10; ++x) at.v[x] += v[x];
+                }
+            });
+            n_nodes = all.v[1]; n_seeds = all.v[2]; n_pool = all.v[3]; n_starts = all.v[4]; n_read = all.v[5]; n_graph = all.v[6]; tb_bytes = all.v[7]; last_elems = all.v[8]; ops_total = all.v[9];
+            j = limit;
+        }
+        else for (; j < limit; ++j) {
+            const Prep& hp = hps[j];
+            if (!hp.on_device) continue;
+            const vgk_banded_problem& p = problems[j];
+            if (!S.owner.empty() && ((tb_bytes + hp.tb_bytes) + (last_elems + hp.last_elems) * 4 + (ops_total + hp.ops_cap) * 2 * sizeof(vgk_op) > budget ||
+                                     n_nodes + p.graph.n_nodes > 0xfffffff0ull || n_read + p.read_len > 0xfffffff0ull || n_graph + hp.bases > 0xfffffff0ull)) break;
+            n_nodes += p.graph.n_nodes; n_seeds += hp.seeds.len; n_pool += hp.pool.len; n_starts += hp.starts.len;
+            n_read += p.read_len; n_graph += hp.bases; tb_bytes += hp.tb_bytes; last_elems += hp.last_elems; ops_total += hp.ops_cap;
+            S.owner.push_back(j);
+        }
+        S.j = j;
+        const std::vector<uint32_t>& owner = S.owner;
+        const uint32_t m = S.m = (uint32_t)owner.size();
+        if (!m) return VGK_OK;
+        BProb* probs = A.probs.get(be, m);
+        if (!probs) return VGK_ENOMEM;
+        if (!whole) { uint64_t a_nodes = 0, a_seeds = 0, a_pool = 0, a_starts = 0, a_read = 0, a_graph = 0, a_tb = 0, a_last = 0, a_ops = 0;
+          for (uint32_t a = 0; a < m; ++a) {
+            Prep& hp = hps[owner[a]]; const vgk_banded_problem& p = problems[owner[a]];
+            BProb pb{};
+            pb.L = p.read_len; pb.n_nodes = p.graph.n_nodes; pb.Hpad = hp.Hpad; pb.graph_len = (uint32_t)hp.bases;
+            pb.node_base = (uint32_t)a_nodes; pb.seed_base = (uint32_t)a_seeds; pb.pool_base = (uint32_t)a_pool; pb.start_base = (uint32_t)a_starts;
+            pb.n_starts = hp.starts.len; pb.read_off = (uint32_t)a_read; pb.graph_off = (uint32_t)a_graph;
+            pb.tb_base = a_tb; pb.last_base = a_last; pb.ops_off = a_ops; pb.ops_cap = hp.ops_cap;
+            a_nodes += pb.n_nodes; a_seeds += hp.seeds.len; a_pool += hp.pool.len; a_starts += hp.starts.len;
+            a_read += pb.L; a_graph += hp.bases; a_tb += hp.tb_bytes; a_last += hp.last_elems; a_ops += hp.ops_cap;
+            hp.arena = a; probs[a] = pb;
+          } }
+        BNode* nodes = A.nodes.get(be, n_nodes); BSeed* seeds = A.seeds.get(be, n_seeds); uint32_t* pool = A.pool.get(be, n_pool); BStart* starts = A.starts.get(be, n_starts);
+        uint8_t* reads = A.reads.get(be, n_read); uint8_t* quals = qa ? A.quals.get(be, n_read) : nullptr; uint8_t* graph = A.graph.get(be, n_graph);
+        uint32_t* order = A.order.get(be, m);
+        if (!nodes || !seeds || !pool || !starts || !reads || (qa && !quals) || !graph || !order) return VGK_ENOMEM;
+        parallel_for(m, [&](uint32_t a, unsigned) {
+            const Prep& hp = hps[owner[a]]; const BProb& pb = probs[a]; const vgk_banded_problem& p = problems[owner[a]];
+            const Store& T = store[hp.thread];
+            std::copy(T.nodes.begin() + hp.nodes.off, T.nodes.begin() + hp.nodes.off + hp.nodes.len, nodes + pb.node_base);
+            std::copy(T.seeds.begin() + hp.seeds.off, T.seeds.begin() + hp.seeds.off + hp.seeds.len, seeds + pb.seed_base);
+            std::copy(T.pool.begin() + hp.pool.off, T.pool.begin() + hp.pool.off + hp.pool.len, pool + pb.pool_base);
+            for (uint32_t q = 0; q < hp.starts.len; ++q) starts[pb.start_base + q].node = T.starts[hp.starts.off + q];
+            nt_code_run(reads + pb.read_off, p.read, pb.L);
+            if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
+            nt_code_run(graph + pb.graph_off, p.graph.seq, pb.graph_len);
+        });
+        // launches: one per rows-per-lane class; inside a class the problems with the most cells first (counting sort on log2(cells))
+        { auto key = [&](uint32_t a) { return hps[owner[a]].order_key; };
+          std::vector<uint32_t> count(6 * 64 + 1, 0);
+          for (uint32_t a = 0; a < m; ++a) ++count[key(a) + 1];
+          for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
+          std::vector<uint32_t> at(count.begin(), count.end() - 1);
+          for (uint32_t a = 0; a < m; ++a) order[at[key(a)]++] = a;
+          for (uint32_t r = 0; r < 6; ++r) {
+            const uint32_t lo = count[r * 64], hi = count[(r + 1) * 64];
+            if (lo == hi) continue;
+            uint64_t lds = 0;      // LDS staging area: score table | read codes | qualities | graph codes of the largest problem of the launch
+            for (uint32_t b = lo; b < hi; ++b) { const BProb& pb = probs[order[b]]; lds = std::max<uint64_t>(lds, (qa ? 6400u : 32u) + (uint64_t)pb.L * (qa ? 2 : 1) + pb.graph_len + 96); }
+            S.launches.push_back({1u << r, lo, hi - lo, lds <= 40 * 1024 ? (uint32_t)lds : 0u});
+          } }
+        lap("arenas");
+        S.sizes[0] = n_nodes; S.sizes[1] = n_seeds; S.sizes[2] = n_pool; S.sizes[3] = n_starts; S.sizes[4] = n_read; S.sizes[5] = n_graph; S.sizes[6] = tb_bytes; S.sizes[7] = last_elems; S.sizes[8] = ops_total;
+        return VGK_OK;
+    };
+    // ---- ... upload and launch (after the sub-batch before has been fetched: its downloads would queue behind these uploads — a BNode is 64
+    // bytes, a quarter's tables 30 MB)
+    auto launch = [&](BSub& S, int set) -> int {
+        const uint32_t m = S.m;
+        if (!m) return VGK_OK;
+        PinnedSet& A = H.set[set]; const int base = set ? S_SET1 : 0;
+        const uint64_t n_nodes = S.sizes[0], n_seeds = S.sizes[1], n_pool = S.sizes[2], n_starts = S.sizes[3], n_read = S.sizes[4], n_graph = S.sizes[5], tb_bytes = S.sizes[6], last_elems = S.sizes[7], ops_total = S.sizes[8];
+        const BProb* probs = A.probs.p; const uint32_t* order = A.order.p; const BNode* nodes = A.nodes.p; const BSeed* seeds = A.seeds.p; const uint32_t* pool = A.pool.p; const BStart* starts = A.starts.p;
+        const uint8_t* reads = A.reads.p; const uint8_t* quals = A.quals.p; const uint8_t* graph = A.graph.p;
+        BandedParams& P = S.P; P = BandedParams{};
+        int rc;
+        if ((rc = stage(ctx, base + S_PROBS, (const BProb*)probs, m, P.probs)) || (rc = stage(ctx, base + S_ORDER, (const uint32_t*)order, m, P.order)) ||
+            (rc = stage(ctx, base + S_NODES, (const BNode*)nodes, n_nodes, P.nodes)) || (rc = stage(ctx, base + S_SEEDS, (const BSeed*)seeds, n_seeds, P.seeds)) ||
+            (rc = stage(ctx, base + S_POOL, (const uint32_t*)pool, n_pool, P.pool)) || (rc = stage(ctx, base + S_STARTS, (const BStart*)starts, n_starts, P.starts)) ||
+            (rc = stage(ctx, base + S_READS, (const uint8_t*)reads, n_read, P.reads)) || (qa && (rc = stage(ctx, base + S_QUALS, (const uint8_t*)quals, n_read, P.quals))) ||
+            (rc = stage(ctx, base + S_GRAPH, (const uint8_t*)graph, n_graph, P.graph)) || (rc = stage(ctx, base + S_MAT, mat, qa ? 6400 : BMAT_BYTES, P.mat))) return rc;
+        P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend; P.n = m;
+        P.tb = (uint8_t*)ensure(ctx, base + S_TB, std::max<uint64_t>(tb_bytes, 256));
+        P.last = (int32_t*)ensure(ctx, base + S_LAST, std::max<uint64_t>(last_elems, 64) * sizeof(int32_t));
+        P.ops = (vgk_op*)ensure(ctx, base + S_OPS, std::max<uint64_t>(ops_total, 1) * sizeof(vgk_op));
+        P.dense = (vgk_op*)ensure(ctx, base + S_DENSE, std::max<uint64_t>(ops_total, 1) * sizeof(vgk_op));
+        uint8_t* rblock = (uint8_t*)ensure(ctx, base + S_RESULTS, (size_t)m * sizeof(BResult) + 64);
+        if (!P.tb || !P.last || !P.ops || !P.dense || !rblock) return VGK_ENOMEM;
+        P.dense_count = (unsigned long long*)rblock; P.results = (BResult*)(rblock + 64);
+        if ((rc = be->zero(rblock, 64))) return rc;
+        if ((rc = be->run_banded_async(P, S.launches.data(), (uint32_t)S.launches.size(), set))) return rc;
+        if ((rc = be->event_record(H.ev[set]))) return rc;
+        lap("launch");
+        return VGK_OK;
+    };
+
+    // ---- second half: the packed ops and results back behind the event, then the caller's order (the empty-walk rule and the empty sink
+    // prefixes are host bookkeeping, :2611-2668, :196-203): sizes first, then a running sum, then every problem writes its own slice
+    auto finish = [&](BSub& S, int set) -> int {
+        PinnedSet& A = H.set[set];
+        const uint32_t m = S.m, i = S.i, j = S.j; const BandedParams& P = S.P;
+        BResult* dres = A.dres.get(be, m + 1); const vgk_op* dops = nullptr;
+        if (!dres) return VGK_ENOMEM;
+        if (m) {
+            int rc;
+            if (H.ev[set]) { if ((rc = be->fetch_after(H.ev[set]))) return rc; }
+            else if ((rc = be->sync())) return rc;
+            unsigned long long* dense_n = A.count.get(be, 8);
+            if (!dense_n) return VGK_ENOMEM;
+            if ((rc = be->download_fetch_async(dense_n, P.dense_count, sizeof(unsigned long long)))) return rc;
+            if ((rc = be->download_fetch_async(dres, P.results, (size_t)m * sizeof(BResult)))) return rc;
+            if ((rc = be->sync_fetch())) return rc;
+            vgk_op* hd = A.dops.get(be, dense_n[0] + 1);
+            if (!hd) return VGK_ENOMEM;
+            if (dense_n[0] && (rc = be->download_fetch(hd, P.dense, (size_t)dense_n[0] * sizeof(vgk_op)))) return rc;
+            dops = hd;
+            ctx->banded_ms[0] += be->banded_ms(set, 0); ctx->banded_ms[1] += be->banded_ms(set, 1);
+            lap("fetch");
+        }
+        parallel_for(j - i, [&](uint32_t k, unsigned) {
+            const uint32_t q = i + k; Prep& hp = hps[q]; vgk_result& r = results[q];
+            std::memset(&r, 0, sizeof r);
+            hp.need = 0;
+            if (!hp.on_device) { r.status = hp.status; return; }
+            const BResult& dr = dres[hp.arena]; const vgk_banded_problem& p = problems[q];
+            const int32_t empty_score = -ctx->sc.gap_open - (int32_t)(p.read_len - 1) * ctx->sc.gap_extend;
+            const bool have = dr.status != VGK_ENOBAND;
+            hp.use_empty_walk = hp.have_empty_walk && (!have || empty_score >= dr.score);
+            if (hp.use_empty_walk) { hp.need = hp.empty_walk.len; r.score = empty_score; r.status = VGK_OK; }
+            else if (dr.status != VGK_OK) r.status = dr.status;
+            else { hp.need = dr.n_ops + store[hp.thread].start_prefix[hp.starts.off + dr.start].len; r.score = dr.score; r.status = VGK_OK; }
+        });
+        for (uint32_t q = i; q < j; ++q) {
+            Prep& hp = hps[q]; vgk_result& r = results[q];
+            r.ops_begin = (uint32_t)used;
+            if (hp.on_device) { ctx->banded_cells += hp.cells; ctx->banded_bytes += hp.in_bytes + 2ull * dres[hp.arena].n_ops; }
+            if (r.status != VGK_OK) continue;
+            if (!ops || used + hp.need > ops_cap) { r.status = VGK_EOPS; rc_all = VGK_EOPS; hp.need = 0; continue; }
+            r.n_ops = hp.need; used += hp.need;
+        }
+        parallel_for(j - i, [&](uint32_t k, unsigned) {
+            const uint32_t q = i + k; const Prep& hp = hps[q]; const vgk_result& r = results[q];
+            if (r.status != VGK_OK || !r.n_ops) return;
+            const Store& T = store[hp.thread];
+            vgk_op* out = ops + r.ops_begin;
+            if (hp.use_empty_walk) {
+                for (uint32_t e = hp.empty_walk.len; e-- > 0;) {
+                    vgk_op o{}; o.node = T.prefix[hp.empty_walk.off + e];
+                    if (e + 1 == hp.empty_walk.len) { o.op = VGK_OP_I; o.len = (uint16_t)problems[q].read_len; } else { o.op = VGK_OP_M; o.len = 0; }
+                    *out++ = o;
+                }
+            } else {
+                const BResult& dr = dres[hp.arena];
+                const vgk_op* src = dops + dr.ops_begin;
+                for (uint32_t e = 0; e < dr.n_ops; ++e) { vgk_op o = src[e]; if (o.len == 0) o.op = VGK_OP_M; *out++ = o; }
+                const Span pre = T.start_prefix[hp.starts.off + dr.start];
+                for (uint32_t e = pre.len; e-- > 0;) { vgk_op o{}; o.node = T.prefix[pre.off + e]; o.op = VGK_OP_M; o.len = 0; *out++ = o; }
+            }
+        });
+        lap("results");
+        return VGK_OK;
+    };
+
+    BSub subs[2]; int set = 0; bool pending = false; int rc = VGK_OK;
+    for (uint32_t i = 0; i < n && rc == VGK_OK;) {
+        BSub& S = subs[set];
+        rc = build(i, S, set);                                     // (host only: the kernels of the sub-batch before run meanwhile)
+        i = S.j;
+        if (pending && rc == VGK_OK) rc = finish(subs[set ^ 1], set ^ 1);
+        if (rc == VGK_OK) rc = launch(S, set);
+        pending = rc == VGK_OK;
+        set ^= 1;
+    }
+    if (pending && rc == VGK_OK) rc = finish(subs[set ^ 1], set ^ 1);
+    if (rc != VGK_OK) { be->sync(); be->sync_fetch(); return rc; }
+    if (ops_written) *ops_written = used;
+    return rc_all;
+}
+
 int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n,
                      vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) try {
+    uint32_t pipeline_from = 32768u;                              // (VGAMD_BANDED_PIPELINE_MIN: tests cut small calls in four as well)
+    if (const char* e = std::getenv("VGAMD_BANDED_PIPELINE_MIN")) pipeline_from = (uint32_t)std::max(4, std::atoi(e));
+    if (ctx && problems && results && n >= pipeline_from && !std::getenv("VGAMD_BANDED_ONE_BATCH")) return banded_align_pipelined(ctx, problems, n, results, ops, ops_cap, ops_written);
     return banded_align_impl(ctx, problems, n, 0, results, nullptr, ops, ops_cap, ops_written);
 } catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
