@@ -14,7 +14,7 @@ GROUPS = {   # name -> (units per launch, kernel-name fragments of its roofline 
     "banded": (100000, ["banded_fill_kernel"]),
     "gapless": (1000000, ["gapless_search_kernel", "gapless_rules_kernel", "gapless_kernel("]),
     "wfa": (500000, ["wfa_kernel", "wfa_wave_kernel"]),
-    "xband": (200000, ["xdrop_band_kernel", "xdrop_band_walk_kernel"]),
+    "xband": (200000, ["xdrop_band_pk_kernel", "xdrop_band_kernel", "xdrop_band_walk_kernel"]),
     # configs[2], one batch of 1 M reads in one context: the extension kernels of the stage, and its seeding kernels on their own
     "config2": (1000000, ["gapless_search_kernel", "gapless_rules_kernel", "gapless_kernel("], "config2"),
     "minimizer": (1000000, ["minimizer_kernel", "minimizer_gather_kernel"], "config2"),
