@@ -187,7 +187,7 @@ def bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus):
                        "timed_region": "K launches of the WFA kernels on the batch resident in HBM (vgk_wfa_rerun)",
                        "kernels": (lambda w: {"first_launch_ms": w[0], "wavefront_kernel_behind_it_ms": w[1], "handed_over": int(w[2]),
                                               "form": "hybrid, the thread kernel and the wavefront kernel at once" if w[1] == 0 and w[2] else "hybrid, one kernel after the other" if w[2] else "one kernel"})(eng.wfa_last_wave()),
-                       "end_to_end_from_host_buffers_alignments_per_s": n / te, "end_to_end_one_batch_alignments_per_s": n / te_one, "parallelism": "problem-sharded x%d" % world,
+                       "end_to_end_from_host_buffers_alignments_per_s": n / te, "parallelism": "problem-sharded x%d" % world,
                        "device": dev_name, "compute_units": cus, "sequence_bases": wl.bases},
             "roofline": {"bound": "hbm", "limiter": "memory latency on each thread's dependent chain and lane divergence, not bandwidth (DESIGN.md §12)", "kernel": {"thread": "wfa_kernel", "wave": "wfa_wave_kernel"}.get(os.environ.get("VGAMD_WFA_KERNEL", ""), "wfa_kernel + wfa_wave_kernel (hybrid: a problem is handed to a wavefront at 16 points)"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["wfa"] * n, "traffic_source": traffic_source("wfa"), "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k,
