@@ -234,7 +234,9 @@ extern "C++" int vgk_haplo_from_tables(vgk_ctx* ctx, uint32_t O, const std::vect
     h->dev.n_oriented = O; h->dev.strand_shift = (uint32_t)total;
     h->dev.max_node_len = 0; h->dev.max_visits = 0;          // what the fast kernel's compact entries have to hold (gapless_device.hpp)
     for (uint32_t o = 0; o < O; ++o) { h->dev.max_node_len = std::max(h->dev.max_node_len, len[o]); h->dev.max_visits = std::max(h->dev.max_visits, count[o]); }
-    if ((rc = put(h, rec_off, h->dev.rec_off)) || (rc = put(h, rec, h->dev.rec)) || (rc = put(h, seq, h->dev.seq)) || (rc = ctx->be->sync())) {
+    std::vector<uint64_t> node_tab(O);
+    for (uint32_t o = 0; o < O; ++o) node_tab[o] = (uint64_t)seq_off[o] | ((uint64_t)len[o] << 32);
+    if ((rc = put(h, rec_off, h->dev.rec_off)) || (rc = put(h, rec, h->dev.rec)) || (rc = put(h, seq, h->dev.seq)) || (rc = put(h, node_tab, h->dev.node_tab)) || (rc = ctx->be->sync())) {
         for (void* p : h->held) ctx->be->release(p);
         delete h; return rc;
     }

@@ -36,9 +36,16 @@ struct GIndex {                       // device pointers
     uint32_t        strand_shift;     // offset of a node's reverse-complement bases = offset of its forward bases + strand_shift
     const char*     seq;              // forward strands, then reverse complements (8 bytes of padding at either end)
     uint32_t        max_node_len, max_visits;      // over the whole index: what the compact in-LDS entries of the fast kernel can hold
+    // per oriented node: offset of its bases in `seq` (low word) | its length (high word).  What a walk along a finished path needs of a
+    // node — the set rules' mismatch positions, overlaps and trims; the tail forests; WFA — in ONE load from a table whose neighbours are
+    // the path's next nodes, instead of rec_off[node] and then the record's header (two dependent lines per node: 4.8 of the rules kernel's
+    // 7.5 kB fetched per read went there)
+    const uint64_t* node_tab;
 };
+VGK_HD uint32_t g_seq_off(const GIndex& h, uint32_t o) { return (uint32_t)h.node_tab[o]; }
+VGK_HD uint32_t g_seq_of(const GIndex& h, uint32_t o, uint32_t& len) { const uint64_t t = h.node_tab[o]; len = (uint32_t)(t >> 32); return (uint32_t)t; }
 VGK_HD const uint32_t* g_rec(const GIndex& h, uint32_t o) { return h.rec + h.rec_off[o]; }
-VGK_HD uint32_t g_len(const GIndex& h, int32_t o) { return g_rec(h, (uint32_t)o)[2]; }
+VGK_HD uint32_t g_len(const GIndex& h, int32_t o) { return (uint32_t)(h.node_tab[(uint32_t)o] >> 32); }
 VGK_HD int32_t  ge_to(const uint32_t* rec, uint32_t e) { return (int32_t)rec[4 + 4 * e]; }
 VGK_HD uint32_t ge_base(const uint32_t* rec, uint32_t e) { return rec[5 + 4 * e] & 0xffffu; }
 VGK_HD uint32_t ge_len(const uint32_t* rec, uint32_t e) { return rec[5 + 4 * e] >> 16; }
@@ -585,8 +592,7 @@ VGK_HD void gx_find_mismatches(const GCtx& c, GExt& e, uint32_t* mm, bool& overf
     const GIndex& h = c.P->index;
     uint32_t node_offset = e.offset, read_offset = e.r0;
     for (uint32_t i = 0; i < e.path_len && read_offset < e.r1; ++i) {
-        const uint32_t* rec = g_rec(h, (uint32_t)(e.path[i]));
-        const char* t = h.seq + rec[3]; const uint32_t tl = rec[2];
+        uint32_t tl; const char* t = h.seq + g_seq_of(h, (uint32_t)(e.path[i]), tl);
         uint32_t left = tl - node_offset < e.r1 - read_offset ? tl - node_offset : e.r1 - read_offset;
         while (left) {                                                       // eight bases per compare; the positions come out of the mask of differing bytes
             const uint32_t len = left < 8 ? left : 8;

@@ -144,7 +144,7 @@ VGK_HD void forest_emit_one(const ForestParams& P, uint32_t v) {
     const int32_t par = P.parent[v];
     if (par >= 0) P.pred_idx[P.pred_off[v]] = (uint32_t)par;
     const uint32_t len = P.len[v];
-    const char* sq = P.index.seq + g_rec(P.index, P.node[v])[3] + P.trim[v];
+    const char* sq = P.index.seq + g_seq_off(P.index, P.node[v]) + P.trim[v];
     uint8_t* o = P.info + P.col[v];
     for (uint32_t k = 0; k < len; ++k) o[k] = (uint8_t)t_ref_code(sq[k]);
     o[0] |= (uint8_t)(CI_NODE_START | (P.slow[v] ? CI_SEED_SLOW : 0));

@@ -345,7 +345,7 @@ VGK_HD void w_match_forward(WCtx& c, WPos& p) {
     for (;;) {
         const int32_t gn = c.S->path_node[k];
         const uint32_t start = c.S->path_start[k], gl = g_len(c.P->index, gn);
-        const char* g = c.P->index.seq + g_rec(c.P->index, (uint32_t)gn)[3] + (p.off - start);
+        const char* g = c.P->index.seq + g_seq_off(c.P->index, (uint32_t)gn) + (p.off - start);
         const char* r = c.seq + p.seq;
         uint32_t left = start + gl - p.off; if (c.L - p.seq < left) left = c.L - p.seq;
         uint32_t m = 0;
