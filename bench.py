@@ -470,6 +470,9 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
     t0 = time.perf_counter(); index = eng.haplo_index(graph, wl.threads); t_hindex = time.perf_counter() - t0
     t0 = time.perf_counter(); mindex = eng.minimizer_index(graph, wl.threads); t_mindex = time.perf_counter() - t0
     eng.reuse_outputs = True
+    with_policy = bool(os.environ.get("VGAMD_CONFIG2_POLICY"))              # find_seeds' choice of minimizers on the device (vgk_minimizer_set_policy, giraffe's defaults)
+    if with_policy:
+        mindex.set_policy(10, 500, 0.9)
 
     class Batch:
         def __init__(self, k): self.n = k
@@ -531,6 +534,8 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
         eng_b = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), device=eng.device, lib=eng.lib)          # (the same library, the same device)
         eng_b.reuse_outputs = True
         lanes.append((eng_b, eng_b.haplo_index(graph, wl.threads), eng_b.minimizer_index(graph, wl.threads)))
+        if with_policy:
+            lanes[-1][2].set_policy(10, 500, 0.9)
 
     def one_step_pipelined(timing=None, keep=None):
         tot = new_tot()
@@ -570,6 +575,8 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
         k = min(batch, args.cpu_sample or 200_000)
         reads, off = wl.batches[0]
         oidx = ora.haplo_index(graph, wl.threads); omi = ora.minimizer_index(graph, wl.threads)
+        if with_policy:
+            omi.set_policy(10, 500, 0.9)
         olen = np.repeat(wl.node_len, 2)
         t1 = time.perf_counter()
         so, sd, _ = ora.minimizer_seeds(omi, oidx, reads[:off[k]], off[:k + 1])
@@ -599,7 +606,8 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
                                        "tail stage) -> vgk_tail_stage_aligned%s" % (len(wl.batches), batch, "; two batches in flight: two engine contexts, one host thread each, alternate batches" if pipelined else ""),
                        "one_context": one_context,
                        "read_buffers": "page-locked by the caller (vgk_host_register)" if pinned and all(pinned) else "pageable",
-                       "policies": "every minimizer of a read looked up, hit cap 500 (hard cap), no downsampling / score-based selection (find_seeds' policies: not built); clusters = all seeds of a read",
+                       "policies": ("find_seeds' choice on the device (vgk_minimizer_set_policy: hit cap 10, hard cap 500 over a key's run, score fraction 0.9); clusters = all seeds of the chosen minimizers" if with_policy else
+                                    "every minimizer of a read looked up, hit cap 500 (hard cap) per minimizer, no score-based selection (vgk_minimizer_set_policy exists: VGAMD_CONFIG2_POLICY=1 turns it on here); clusters = all seeds of a read"),
                        "per_step": {k: v / steps for k, v in tot.items()} if steps == 1 else tot,
                        "ms_per_batch": 1e3 * elapsed / steps / len(wl.batches),
                        "stage_ms_per_batch": {k: 1e3 * v / steps / len(wl.batches) for k, v in timing.items()},

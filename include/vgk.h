@@ -466,6 +466,21 @@ int  vgk_minimizer_index_fetch(const vgk_minimizer_index* index, vgk_minimizer_h
 int  vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* index, const vgk_haplo* graph, const char* reads, const uint64_t* read_off, uint32_t n,
                          uint32_t hit_cap, uint32_t* seed_off, uint32_t* minimizers, vgk_seed* seeds, size_t seeds_cap, size_t* written);
 double vgk_minimizer_last_ms(vgk_ctx* ctx);                              /* device time of the last vgk_minimizer_seeds call */
+/* find_seeds' choice of minimizers, applied by vgk_minimizer_seeds on the device (src/minimizer_mapper.cpp:4109-4440 with giraffe's
+ * short-read parameters): a minimizer's score is 1 + ln(hard_hit_cap) - ln(hits) (1 beyond the hard cap, 0 without hits, :3927-3937);
+ * a read's minimizers are taken in order of descending score, runs of one key together [ties: by key, then read position — the
+ * reference shuffles them with a generator seeded from the read, :4089: PARITY-UNPINNED]; a minimizer gives seeds iff it has hits, its
+ * RUN (all occurrences of its key in the read) has at most hard_hit_cap hits, and it has at most hit_cap hits or the scores selected so
+ * far plus its own stay within minimizer_score_fraction of the read's total or an earlier occurrence of its key was taken; the first
+ * minimizer that fails the last test closes it for everything that follows (:4358-4378).  The filters left out are off in those
+ * parameters (window downsampling, exclude-overlapping) or cannot fire below 500 taken minimizers (max-unique-min); the host shim's
+ * select_minimizers (vg_amd/host/seed_policy.cpp) has them all.  A read with more than 64 minimizers is seeded as without a policy and
+ * flagged VGK_MINIMIZERS_POLICY_SKIPPED in minimizers[].  With a policy set the call's `hit_cap` argument is ignored.
+ * policy = NULL: none (every minimizer with at most `hit_cap` hits gives seeds).  VGK_EINVAL: hard_hit_cap 0 or above 65 535, a fraction
+ * outside [0, 1]. */
+typedef struct vgk_seed_policy { uint32_t hit_cap, hard_hit_cap; double minimizer_score_fraction; } vgk_seed_policy;
+#define VGK_MINIMIZERS_POLICY_SKIPPED 0x40000000u
+int  vgk_minimizer_set_policy(vgk_minimizer_index* index, const vgk_seed_policy* policy);
 /* The clusters of the last vgk_minimizer_seeds call on this context, extended as vgk_gapless_extend would extend them — without the
  * reads or the seeds crossing PCIe again: they are still in HBM (reads masked and padded as the extension kernels want them), and the
  * problem descriptors and the hand-out order are made there.  `index` must be the haplotype index that call was given; one

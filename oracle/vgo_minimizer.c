@@ -16,11 +16,12 @@
  */
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include "../include/vgk.h"
 
 typedef struct { uint64_t key, hash; uint32_t node, offset; } Entry;
-struct vgk_minimizer_index { uint32_t k, w, n_nodes; uint32_t* node_len; Entry* e; size_t n; uint64_t n_keys; };
+struct vgk_minimizer_index { uint32_t k, w, n_nodes; uint32_t* node_len; Entry* e; size_t n; uint64_t n_keys; int policy_on; vgk_seed_policy policy; };
 
 static uint64_t wang(uint64_t key) {
     key = (~key) + (key << 21); key ^= key >> 24; key = (key + (key << 3)) + (key << 8); key ^= key >> 14;
@@ -118,14 +119,81 @@ int vgk_minimizer_index_fetch(const vgk_minimizer_index* ix, vgk_minimizer_hit* 
     return VGK_OK;
 }
 
-typedef struct { const vgk_minimizer_index* ix; uint32_t hit_cap; vgk_seed seeds[64]; uint32_t n_seeds, n_min; int truncated; } Query;
+static void key_range(const vgk_minimizer_index* ix, uint64_t key, size_t* first, size_t* end) {      /* the entries with this key */
+    size_t lo = 0, hi = ix->n;
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (ix->e[mid].key < key) lo = mid + 1; else hi = mid; }
+    size_t e = lo; while (e < ix->n && ix->e[e].key == key) ++e;
+    *first = lo; *end = e;
+}
+/* ---- find_seeds' choice of minimizers (include/vgk.h: vgk_seed_policy), restating src/minimizer_mapper.cpp:3927-3937 (scores), :4074-4107 (the
+ * order: runs of one key together, by descending score; ties by key, then read position — the reference's shuffle of ties cannot be restated),
+ * :4395-4440 (the run logic) and the filters any-hits :4270, hard-hit-cap :4277 and hit-cap || score-fraction :4358-4378.  At most 64 minimizers. */
+typedef struct { const vgk_minimizer_index* ix; uint64_t key[64]; uint32_t hits[64]; uint32_t n; } Listing;
+static void list_emit(void* c, uint32_t p, uint64_t key, uint64_t hash, int reverse) {
+    Listing* l = (Listing*)c; (void)p; (void)hash; (void)reverse;
+    if (l->n < 64) { size_t a, b; key_range(l->ix, key, &a, &b); l->key[l->n] = key; l->hits[l->n] = (uint32_t)(b - a); }
+    ++l->n;
+}
+static uint64_t choose(const vgk_seed_policy* P, const uint64_t* key, const uint32_t* hits, uint32_t n) {
+    double score[64]; uint32_t order[64];
+    const double base_score = 1.0 + log((double)P->hard_hit_cap);
+    for (uint32_t i = 0; i < n; ++i) score[i] = !hits[i] ? 0.0 : (hits[i] <= P->hard_hit_cap ? base_score - log((double)hits[i]) : 1.0);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    for (uint32_t i = 1; i < n; ++i) {                                    /* insertion sort: score descending, key ascending, read position */
+        const uint32_t x = order[i]; uint32_t j = i;
+        while (j && (score[order[j - 1]] < score[x] || (score[order[j - 1]] == score[x] && key[order[j - 1]] > key[x]))) { order[j] = order[j - 1]; --j; }
+        order[j] = x;
+    }
+    const int use_score = P->hit_cap != 0 || P->minimizer_score_fraction != 1.0;
+    volatile double base_target = 0.0, target = 0.0, selected = 0.0, t;
+    if (use_score) { for (uint32_t r = 0; r < n; ++r) base_target = base_target + score[order[r]]; t = base_target * P->minimizer_score_fraction; target = t + 0.000001; }
+    uint64_t mask = 0; uint32_t at = 0;
+    while (at < n) {
+        uint32_t end = at + 1; uint64_t run_hits = hits[order[at]];
+        while (end < n && key[order[end]] == key[order[at]]) { run_hits += hits[order[end]]; ++end; }
+        int taking_run = 0;
+        for (uint32_t r = at; r < end; ++r) {
+            const uint32_t i = order[r];
+            int pass = hits[i] > 0 && run_hits <= P->hard_hit_cap;
+            if (pass && use_score) {
+                t = selected + score[i];
+                if (hits[i] <= P->hit_cap || t <= target || taking_run) selected = t;
+                else { pass = 0; target = selected; }
+            }
+            if (pass) { mask |= 1ull << i; taking_run = 1; }
+        }
+        at = end;
+    }
+    return mask;
+}
+int vgk_minimizer_set_policy(vgk_minimizer_index* ix, const vgk_seed_policy* policy) {
+    if (!ix) return VGK_EINVAL;
+    if (!policy) { ix->policy_on = 0; return VGK_OK; }
+    if (!policy->hard_hit_cap || policy->hard_hit_cap > 65535u || !(policy->minimizer_score_fraction >= 0.0 && policy->minimizer_score_fraction <= 1.0)) return VGK_EINVAL;
+    ix->policy = *policy; ix->policy_on = 1;
+    return VGK_OK;
+}
+/* checker-side only: the minimizers of one read as the choice sees them -> their number; key / read offset of the k-mer's first base / hits of
+ * the first `cap` of them (tests/test_seed_policy.py holds the device's choice to the host shim's select_minimizers through this) */
+typedef struct { const vgk_minimizer_index* ix; uint64_t* key; uint32_t* offset; uint32_t* hits; uint32_t n, cap; } Dump;
+static void dump_emit(void* c, uint32_t p, uint64_t key, uint64_t hash, int reverse) {
+    Dump* d = (Dump*)c; (void)hash; (void)reverse;
+    if (d->n < d->cap) { size_t a, b; key_range(d->ix, key, &a, &b); d->key[d->n] = key; d->offset[d->n] = p; d->hits[d->n] = (uint32_t)(b - a); }
+    ++d->n;
+}
+uint32_t vgo_minimizer_list(const vgk_minimizer_index* ix, const char* read, uint32_t len, uint64_t* key, uint32_t* offset, uint32_t* hits, uint32_t cap) {
+    Dump d; d.ix = ix; d.key = key; d.offset = offset; d.hits = hits; d.n = 0; d.cap = cap;
+    minimizers(read, len, ix->k, ix->w, dump_emit, &d);
+    return d.n;
+}
+
+typedef struct { const vgk_minimizer_index* ix; uint32_t hit_cap; vgk_seed seeds[64]; uint32_t n_seeds, n_min; int truncated; uint64_t chosen; } Query;
 static void query_emit(void* c, uint32_t p, uint64_t key, uint64_t hash, int reverse) {
     Query* q = (Query*)c; const vgk_minimizer_index* ix = q->ix; (void)hash;
-    ++q->n_min;
-    size_t lo = 0, hi = ix->n;                                             /* first entry with this key */
-    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (ix->e[mid].key < key) lo = mid + 1; else hi = mid; }
-    size_t end = lo; while (end < ix->n && ix->e[end].key == key) ++end;
+    const uint32_t ordinal = q->n_min++;
+    size_t lo, end; key_range(ix, key, &lo, &end);
     if (end == lo || end - lo > q->hit_cap) return;
+    if (ordinal < 64 && !((q->chosen >> ordinal) & 1ull)) return;
     for (size_t h = lo; h < end; ++h) {
         if (q->n_seeds >= 64) { q->truncated = 1; break; }                /* the cap: this hit and the rest are never looked at */
         vgk_seed s;
@@ -143,9 +211,16 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
     size_t total = 0; int rc = VGK_OK;
     if (seed_off) seed_off[0] = 0;
     for (uint32_t i = 0; i < n; ++i) {
-        Query q; q.ix = ix; q.hit_cap = hit_cap ? hit_cap : 0xffffffffu; q.n_seeds = 0; q.n_min = 0; q.truncated = 0;
+        Query q; q.ix = ix; q.hit_cap = hit_cap ? hit_cap : 0xffffffffu; q.n_seeds = 0; q.n_min = 0; q.truncated = 0; q.chosen = ~0ull;
+        int skipped = 0;
+        if (ix->policy_on) {                                              /* the choice first, over the whole read; then the seeds of the chosen */
+            Listing l; l.ix = ix; l.n = 0;
+            minimizers(reads + read_off[i], (uint32_t)(read_off[i + 1] - read_off[i]), ix->k, ix->w, list_emit, &l);
+            if (l.n > 64) { skipped = 1; q.hit_cap = ix->policy.hard_hit_cap; }
+            else { q.chosen = choose(&ix->policy, l.key, l.hits, l.n); q.hit_cap = 0xffffffffu; }
+        }
         minimizers(reads + read_off[i], (uint32_t)(read_off[i + 1] - read_off[i]), ix->k, ix->w, query_emit, &q);
-        if (mins) mins[i] = q.n_min | (q.truncated ? VGK_MINIMIZERS_TRUNCATED : 0u);
+        if (mins) mins[i] = q.n_min | (q.truncated ? VGK_MINIMIZERS_TRUNCATED : 0u) | (skipped ? VGK_MINIMIZERS_POLICY_SKIPPED : 0u);
         if (total + q.n_seeds <= seeds_cap && seeds) memcpy(seeds + total, q.seeds, sizeof(vgk_seed) * q.n_seeds); else if (q.n_seeds) rc = VGK_EOPS;
         total += q.n_seeds; seed_off[i + 1] = (uint32_t)total;
     }

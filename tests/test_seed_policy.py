@@ -231,3 +231,79 @@ def test_what_the_filters_mean():
     ms = [(1, 0, 29, 11), (2, 10, 29, 12), (2, 40, 29, 12), (2, 70, 29, 12)]
     v, _ = select(ms, 150, dict(P, score_fraction=0.45))
     assert v == [0, 0, 0, 0] or v[1:] in ([0, 0, 0], [6, 6, 6])
+
+
+# ---- the choice on the device (vgk_minimizer_set_policy): oracle = emulated kernel = HIP = the host shim's select_minimizers -----------------
+def policy_seeds(lib, seed, k, w, n_reads, L, hit_cap, hard, frac):
+    """reads of a small repetitive graph (many k-mers with several hits) -> the seeds with the policy on equal the seeds of the minimizers
+    the host shim's select_minimizers takes (brute-force construction of test_minimizer.py), read by read"""
+    import test_minimizer as tm
+    from vg_amd import capi, workloads
+    wl = workloads.GaplessWorkload(4, seed=seed, graph_bp=6000, n_haplotypes=4, snp_every=40, indel_every=300)
+    rng = np.random.default_rng(seed)
+    reads, _ = tm.sample_reads(rng, wl.nodes, wl.threads, n_reads, L)
+    reads += ["", "ACGT" * 3, reads[0] * 6]                                  # no minimizers; too short; more than 64 minimizers
+    index = tm.build_index(wl.nodes, wl.threads, k, w)
+    P = dict(DEFAULTS, hit_cap=hit_cap, hard_hit_cap=hard, score_fraction=frac)
+    expected = []; skipped = []; dropped = 0
+    for r in reads:
+        ms = tm.minimizers(r, k, w)
+        if len(ms) > 64:
+            expected.append(tm.seeds_of(r, index, wl.nodes, k, w, hard)); skipped.append(True); continue
+        skipped.append(False)
+        v, _ = select([(key, p, k, len(index.get(key, []))) for p, key, rev in ms], len(r), P) if ms else ([], [])
+        dropped += sum(1 for x, (p, key, rev) in zip(v, ms) if x and index.get(key))
+        out = []
+        for (p, key, rev), verdict in zip(ms, v):
+            if verdict:
+                continue
+            for node, off in index[key]:
+                if len(out) >= 64:
+                    break
+                s = (node, p - off) if not rev else (node ^ 1, (p + k - 1) - (len(wl.nodes[node >> 1]) - 1 - off))
+                if s not in out:
+                    out.append(s)
+        expected.append(out)
+    flat = np.frombuffer("".join(reads).encode(), dtype=np.uint8); off = np.concatenate([[0], np.cumsum([len(r) for r in reads])])
+    eng = capi.Engine(lib=lib)
+    mi = eng.minimizer_index(wl.nodes, wl.threads, k, w); hi = eng.haplo_index(wl.nodes, wl.threads)
+    mi.set_policy(hit_cap, hard, frac)
+    seed_off, seeds, mins = eng.minimizer_seeds(mi, hi, flat, off, 7)       # (the call's own cap is ignored with a policy set)
+    for i, exp in enumerate(expected):
+        got = [(int(s["node"]), int(s["diff"])) for s in seeds[seed_off[i]:seed_off[i + 1]]]
+        assert got == exp, "read %d: %s vs %s" % (i, got[:6], exp[:6])
+        assert bool(eng.minimizers_policy_skipped[i]) == skipped[i]
+    mi.set_policy(on=False)                                                  # and off again: the plain call
+    seed_off, seeds, mins = eng.minimizer_seeds(mi, hi, flat, off, hard)
+    for i, r in enumerate(reads):
+        assert [(int(s["node"]), int(s["diff"])) for s in seeds[seed_off[i]:seed_off[i + 1]]] == tm.seeds_of(r, index, wl.nodes, k, w, hard)
+    return dropped
+
+
+@pytest.mark.parametrize("lib_name", ["oracle", "emu"])
+def test_the_choice_applied_with_the_seeding(lib_name):
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    lib = util.ORACLE_LIB if lib_name == "oracle" else util.EMU_LIB
+    assert policy_seeds(lib, 3, 8, 4, 60, 100, 1, 6, 0.6) > 20                 # minimizers with hits that the filters drop: the filters did something
+    assert policy_seeds(lib, 4, 9, 5, 40, 150, 2, 500, 0.9) >= 0
+    policy_seeds(lib, 5, 15, 6, 30, 120, 10, 500, 1.0)
+    policy_seeds(lib, 6, 8, 4, 30, 100, 0, 4, 1.0)                             # no hit cap and the whole score: only the hard cap over the run is left
+
+
+def test_policy_arguments():
+    from vg_amd import capi, workloads
+    wl = workloads.GaplessWorkload(4, seed=1, graph_bp=3000, n_haplotypes=2)
+    for lib in (util.ORACLE_LIB, util.EMU_LIB):
+        eng = capi.Engine(lib=lib); mi = eng.minimizer_index(wl.nodes, wl.threads, 11, 4)
+        for bad in ((10, 0, 0.9), (10, 70000, 0.9), (10, 500, 1.5), (10, 500, -0.1)):
+            with pytest.raises(capi.VgkError):
+                mi.set_policy(*bad)
+
+
+@pytest.mark.gpu
+def test_the_choice_applied_with_the_seeding_on_hip():
+    assert policy_seeds(util.ENGINE_LIB, 3, 8, 4, 400, 100, 1, 6, 0.6) > 100
+    policy_seeds(util.ENGINE_LIB, 4, 9, 5, 300, 150, 2, 500, 0.9)
+    policy_seeds(util.ENGINE_LIB, 5, 15, 6, 200, 120, 10, 500, 1.0)
+    policy_seeds(util.ENGINE_LIB, 7, 29, 11, 300, 150, 10, 500, 0.9)

@@ -476,7 +476,8 @@ class Engine:
         self._check(self.lib.vgk_minimizer_seeds(self.h, mindex.h, hindex.h, reads.ctypes.data, off.ctypes.data, n, hit_cap, seed_off.ctypes.data, mins.ctypes.data,
                                                  None if keep_on_device else seeds.ctypes.data, cap, ctypes.byref(written)), "vgk_minimizer_seeds")
         self.minimizers_truncated = (mins[:n] & 0x80000000) != 0
-        return seed_off, seeds[:0 if keep_on_device else written.value], mins[:n] & 0x7fffffff
+        self.minimizers_policy_skipped = (mins[:n] & 0x40000000) != 0          # (VGK_MINIMIZERS_POLICY_SKIPPED: more than 64 minimizers, seeded without the policy)
+        return seed_off, seeds[:0 if keep_on_device else written.value], mins[:n] & 0x3fffffff
 
     def minimizer_last_ms(self):
         self.lib.vgk_minimizer_last_ms.restype = ctypes.c_double; self.lib.vgk_minimizer_last_ms.argtypes = [ctypes.c_void_p]
@@ -654,6 +655,15 @@ class MinimizerIndex:
         eng.lib.vgk_minimizer_index_keys.restype = ctypes.c_uint64; eng.lib.vgk_minimizer_index_keys.argtypes = [ctypes.c_void_p]
         self.keys = int(eng.lib.vgk_minimizer_index_keys(h))
         eng._indexes.add(self)
+
+    def set_policy(self, hit_cap=10, hard_hit_cap=500, score_fraction=0.9, on=True):
+        """vgk_minimizer_set_policy: find_seeds' choice of minimizers (giraffe's short-read defaults) for the following minimizer_seeds calls;
+        on=False: none"""
+        class Policy(ctypes.Structure):
+            _fields_ = [("hit_cap", ctypes.c_uint32), ("hard_hit_cap", ctypes.c_uint32), ("minimizer_score_fraction", ctypes.c_double)]
+        self.eng.lib.vgk_minimizer_set_policy.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        p = Policy(hit_cap, hard_hit_cap, score_fraction)
+        self.eng._check(self.eng.lib.vgk_minimizer_set_policy(self.h, ctypes.byref(p) if on else None), "vgk_minimizer_set_policy")
 
     def fetch(self):
         """vgk_minimizer_index_fetch: every indexed occurrence as (key, oriented node, offset), sorted"""

@@ -450,6 +450,12 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
     __shared__ unsigned long long seen_all[4][MZ_MAX_SEEDS];
     __shared__ unsigned long long cand_all[4][64];                           // a round's candidate seeds, in hit order
     __shared__ uint8_t own_all[4][64];                                       // the minimizer (lane) each of them belongs to
+    // find_seeds' choice (MinimizerParams::policy): the read's minimizers in read order — key, hits, the hits of the key's run, score — and
+    // the order the filters take them in
+    __shared__ unsigned long long pkey_all[4][MZ_POLICY_MAX];
+    __shared__ double psc_all[4][MZ_POLICY_MAX];
+    __shared__ uint32_t phit_all[4][MZ_POLICY_MAX], prun_all[4][MZ_POLICY_MAX];
+    __shared__ uint8_t pord_all[4][MZ_POLICY_MAX];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t i = P.lo + blockIdx.x * 4u + wv;
     if (i >= P.hi) return;
@@ -459,7 +465,48 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
     const char* rd = P.reads + a;
     vgk_seed* dst = slots + (size_t)i * MZ_MAX_SEEDS;
     uint32_t n_min = 0, n_seeds = 0; bool truncated = false;
-    if (L >= k + w - 1) {
+    unsigned long long* pkey = pkey_all[wv]; double* psc = psc_all[wv]; uint32_t* phit = phit_all[wv]; uint32_t* prun = prun_all[wv]; uint8_t* pord = pord_all[wv];
+    unsigned long long chosen = ~0ull; bool skipped = false;
+    // With a policy the rounds run twice: first only to list the read's minimizers and their hit counts (the choice needs all of them
+    // before the first seed is written), then — the choice made, across the lanes, between the two — as without one, the minimizers that were
+    // not chosen giving no seeds.
+    if (L >= k + w - 1) for (int phase = P.policy.on ? 0 : 1; phase < 2; ++phase) {
+        if (phase == 1 && P.policy.on) {
+            const uint32_t np = n_min;
+            if (np > MZ_POLICY_MAX) skipped = true;
+            else {
+                const MzPolicy& Q = P.policy;
+                const unsigned long long my_key = lane < np ? pkey[lane] : 0ull; const uint32_t my_hits = lane < np ? phit[lane] : 0u;
+                uint32_t run = 0;
+                for (uint32_t j = 0; j < np; ++j) run += pkey[j] == my_key ? phit[j] : 0u;
+                const double my_sc = mz_score(Q, my_hits);
+                if (lane < np) { psc[lane] = my_sc; prun[lane] = run; }
+                MZ_WAVE_SYNC();
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < np; ++j) rank += mz_better(psc[j], pkey[j], j, my_sc, my_key, lane) ? 1u : 0u;
+                if (lane < np) pord[rank] = (uint8_t)lane;
+                MZ_WAVE_SYNC();
+                // the filters, in that order: every lane the same few dozen steps (the sums must be made in this order)
+                const bool use_score = Q.hit_cap != 0 || Q.fraction != 1.0;
+                double target = 0.0, selected = 0.0;
+                if (use_score) { double base = 0.0; for (uint32_t r = 0; r < np; ++r) base = mz_add(base, psc[pord[r]]); target = mz_add(mz_mul(base, Q.fraction), 0.000001); }
+                unsigned long long mask = 0ull; bool taking = false; unsigned long long prev = 0ull;
+                for (uint32_t r = 0; r < np; ++r) {
+                    const uint32_t x = pord[r]; const unsigned long long kx = pkey[x]; const uint32_t hx = phit[x]; const double sx = psc[x];
+                    if (r == 0 || kx != prev) taking = false;
+                    prev = kx;
+                    bool pass = hx != 0u && prun[x] <= Q.hard_hit_cap;
+                    if (pass && use_score) {
+                        if (hx <= Q.hit_cap || mz_add(selected, sx) <= target || taking) selected = mz_add(selected, sx);
+                        else { pass = false; target = selected; }
+                    }
+                    if (pass) { mask |= 1ull << x; taking = true; }
+                }
+                chosen = mask;
+            }
+            n_min = 0;
+        }
+        const uint32_t cap_now = P.policy.on && !skipped ? 0xffffffffu : P.hit_cap;      // (the choice held the run's hits against the hard cap)
         const uint32_t n_kmers = L - k + 1, step = 65 - w;
         const uint64_t kmask = (1ull << (2 * k)) - 1ull;                   // k <= 31
         const unsigned long long need = (1ull << k) - 1ull;
@@ -520,8 +567,19 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
             if (report) { MzMin& mm = mins[__popcll(rb & below)]; mm.key = okey; mm.hash_lo = (uint32_t)ohash; mm.pos_rev = (hp << 1) | orev; }
             const uint32_t round_max = __shfl(run, 63, 64);
             if (round_max > last_plus1) last_plus1 = round_max;
+            const uint32_t n_before = n_min;
             n_min += n_round;
             MZ_WAVE_SYNC();
+            if (phase == 0) {                                                // list them; nothing else
+                if (lane < n_round && n_before + lane < MZ_POLICY_MAX) {
+                    const MzMin mm = mins[lane];
+                    MzKmer km; km.key = mm.key; km.hash = mm.hash_lo; km.reverse = (mm.pos_rev & 1u) != 0;
+                    uint32_t f0 = 0, c0 = 0; MzPos o0{0u, 0u};
+                    pkey[n_before + lane] = mm.key; phit[n_before + lane] = mz_find(P.index, km, f0, c0, o0) ? c0 : 0u;
+                }
+                MZ_WAVE_SYNC();
+                continue;
+            }
             // this round's minimizers: one lane each probes the table (a key's single position comes with its slot); then ALL their hits at
             // once — hit c of the round in lane c: an exclusive prefix sum of the counts, the owners spread through LDS, one load for the
             // positions that are not in their slots, every candidate held against the seeds kept so far and the candidates before it
@@ -533,7 +591,8 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
                 const MzMin mm = mins[lane];
                 MzKmer km; km.key = mm.key; km.hash = mm.hash_lo; km.reverse = (mm.pos_rev & 1u) != 0;
                 p = mm.pos_rev >> 1; rv = mm.pos_rev & 1u;
-                if (!mz_find(P.index, km, first, count, one) || count > P.hit_cap) count = 0;
+                if (!mz_find(P.index, km, first, count, one) || count > cap_now) count = 0;
+                if (n_before + lane < 64u && !((chosen >> (n_before + lane)) & 1ull)) count = 0;
             }
             const unsigned long long hb = __ballot(count != 0);
             const uint32_t cc = count > 65u ? 65u : count;                   // (clamped: the sum must not wrap; a round within 64 hits has no clamped count)
@@ -591,7 +650,7 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
             MZ_WAVE_SYNC();
         }
     }
-    if (lane == 0) { P.counts[i] = n_seeds; if (P.mins) P.mins[i] = n_min | (truncated ? VGK_MINIMIZERS_TRUNCATED : 0u); }
+    if (lane == 0) { P.counts[i] = n_seeds; if (P.mins) P.mins[i] = n_min | (truncated ? VGK_MINIMIZERS_TRUNCATED : 0u) | (skipped ? VGK_MINIMIZERS_POLICY_SKIPPED : 0u); }
 }
 __global__ void __launch_bounds__(256) minimizer_gather_kernel(const MinimizerParams P, const vgk_seed* slots) {
     const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;

@@ -1,6 +1,7 @@
 // minimizer_api.cpp — vgk_minimizer_index_create / vgk_minimizer_seeds (minimizer_device.hpp): the minimizer index of the haplotype
 // threads built on host threads and kept in HBM; the reads' minimizers, lookups and seeds on the device.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -20,6 +21,8 @@ struct vgk_minimizer_index {
     std::vector<void*> held;
     uint64_t n_keys = 0, n_pos = 0;
     std::vector<vgk_minimizer_hit> hits;      // what the index holds (vgk_minimizer_index_fetch)
+    MzPolicy policy{};                        // vgk_minimizer_set_policy (on == 0: none); its score table in `policy_tab` (device)
+    void* policy_tab = nullptr;
 };
 
 namespace {
@@ -103,9 +106,30 @@ int vgk_minimizer_index_create(vgk_ctx* ctx, const vgk_haplotypes* d, uint32_t k
 
 void vgk_minimizer_index_destroy(vgk_minimizer_index* ix) {
     if (!ix) return;
-    { std::lock_guard<std::mutex> lk(ix->ctx->mu); ix->ctx->be->sync(); for (void* p : ix->held) ix->ctx->be->release(p); }
+    { std::lock_guard<std::mutex> lk(ix->ctx->mu); ix->ctx->be->sync(); for (void* p : ix->held) ix->ctx->be->release(p); if (ix->policy_tab) ix->ctx->be->release(ix->policy_tab); }
     delete ix;
 }
+int vgk_minimizer_set_policy(vgk_minimizer_index* ix, const vgk_seed_policy* policy) try {
+    if (!ix) return VGK_EINVAL;
+    std::lock_guard<std::mutex> lk(ix->ctx->mu);
+    Backend* be = ix->ctx->be.get();
+    if (!policy) { ix->policy = MzPolicy{}; return VGK_OK; }
+    if (!policy->hard_hit_cap || policy->hard_hit_cap > 65535u || !(policy->minimizer_score_fraction >= 0.0 && policy->minimizer_score_fraction <= 1.0)) return VGK_EINVAL;
+    // find_minimizers' scores by hit count, with the host's logarithm (src/minimizer_mapper.cpp:3927-3937)
+    std::vector<double> tab((size_t)policy->hard_hit_cap + 1, 0.0);
+    const double base = 1.0 + std::log((double)policy->hard_hit_cap);
+    for (uint32_t h = 1; h <= policy->hard_hit_cap; ++h) tab[h] = base - std::log((double)h);
+    int rc = be->sync();
+    if (rc) return rc;
+    if (ix->policy_tab) { be->release(ix->policy_tab); ix->policy_tab = nullptr; ix->policy = MzPolicy{}; }
+    void* d = be->alloc(sizeof(double) * tab.size());
+    if (!d) return VGK_ENOMEM;
+    if ((rc = be->upload(d, tab.data(), sizeof(double) * tab.size())) || (rc = be->sync())) { be->release(d); return rc; }
+    ix->policy_tab = d;
+    ix->policy.on = 1; ix->policy.hit_cap = policy->hit_cap; ix->policy.hard_hit_cap = policy->hard_hit_cap; ix->policy.fraction = policy->minimizer_score_fraction;
+    ix->policy.tab = (const double*)d;
+    return VGK_OK;
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }
 uint64_t vgk_minimizer_index_keys(const vgk_minimizer_index* ix) { return ix ? ix->n_keys : 0; }
 uint64_t vgk_minimizer_index_hits(const vgk_minimizer_index* ix) { return ix ? ix->hits.size() : 0; }
 int vgk_minimizer_index_fetch(const vgk_minimizer_index* ix, vgk_minimizer_hit* hits, size_t cap) try {
@@ -136,6 +160,8 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
     for (size_t i = 0; i < n1; ++i) rel[i] = read_off[i] - read_off[0];
     MinimizerParams P{};
     P.index = ix->dev; P.graph = graph->dev; P.reads = d_reads + 8; P.read_off = d_off; P.n = n; P.hit_cap = hit_cap ? hit_cap : 0xffffffffu;
+    P.policy = ix->policy;
+    if (P.policy.on) P.hit_cap = P.policy.hard_hit_cap;                     // (what a read beyond the selection's 64 minimizers is held to)
     P.counts = d_tab; P.mins = d_tab + n1; P.first = d_tab + 2 * n1;
     int rc = be->upload(d_off, rel.data(), sizeof(uint64_t) * n1);
     if (!rc) rc = be->zero(d_tab, sizeof(uint32_t) * 3 * n1);

@@ -114,8 +114,57 @@ VGK_HD bool mz_find(const MzIndex& x, const MzKmer& m, uint32_t& first, uint32_t
     }
 }
 
+// ---- find_seeds' choice of minimizers (include/vgk.h: vgk_seed_policy; reference src/minimizer_mapper.cpp:4109-4440) ---------------------
+// `tab[h]` = the score of a minimizer with h hits, h = 0 .. hard_hit_cap, computed once on the host (1 + ln(hard) - ln(h): the device's log
+// need not round like the host's); everything here is additions and comparisons of those doubles in one fixed order, with the one
+// product kept apart from its sum (mz_mul / mz_add: no fused multiply-add), so that every backend selects the same minimizers.
+constexpr uint32_t MZ_POLICY_MAX = 64;                                   // minimizers per read the selection takes
+struct MzPolicy { uint32_t on, hit_cap, hard_hit_cap; double fraction; const double* tab; };
+VGK_HD double mz_add(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __dadd_rn(a, b);
+#else
+    volatile double r = a + b; return r;
+#endif
+}
+VGK_HD double mz_mul(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __dmul_rn(a, b);
+#else
+    volatile double r = a * b; return r;
+#endif
+}
+VGK_HD double mz_score(const MzPolicy& Q, uint32_t hits) { return !hits ? 0.0 : (hits <= Q.hard_hit_cap ? Q.tab[hits] : 1.0); }
+VGK_HD bool mz_better(double sa, uint64_t ka, uint32_t ia, double sb, uint64_t kb, uint32_t ib) {      // a before b in the order the filters run in
+    return sa > sb || (sa == sb && (ka < kb || (ka == kb && ia < ib)));
+}
+// n <= MZ_POLICY_MAX minimizers of a read in read order (key, hits) -> bit i set: minimizer i gives seeds.  The serial form (one lane; the
+// emulator, the checker of the wave-parallel form in backend_hip.hip's minimizer_kernel).
+VGK_HD uint64_t mz_policy_select(const MzPolicy& Q, const uint64_t* key, const uint32_t* hits, uint32_t n) {
+    uint32_t order[MZ_POLICY_MAX]; double score[MZ_POLICY_MAX];
+    for (uint32_t i = 0; i < n; ++i) score[i] = mz_score(Q, hits[i]);
+    for (uint32_t i = 0; i < n; ++i) { uint32_t rank = 0; for (uint32_t j = 0; j < n; ++j) rank += mz_better(score[j], key[j], j, score[i], key[i], i) ? 1u : 0u; order[rank] = i; }
+    const bool use_score = Q.hit_cap != 0 || Q.fraction != 1.0;
+    double target = 0.0, selected = 0.0;
+    if (use_score) { double base = 0.0; for (uint32_t r = 0; r < n; ++r) base = mz_add(base, score[order[r]]); target = mz_add(mz_mul(base, Q.fraction), 0.000001); }
+    uint64_t mask = 0; bool taking = false;
+    for (uint32_t r = 0; r < n; ++r) {
+        const uint32_t i = order[r];
+        if (r == 0 || key[order[r - 1]] != key[i]) taking = false;           // a new run of one key
+        uint32_t run = 0; for (uint32_t j = 0; j < n; ++j) if (key[j] == key[i]) run += hits[j];
+        bool pass = hits[i] != 0 && run <= Q.hard_hit_cap;
+        if (pass && use_score) {
+            if (hits[i] <= Q.hit_cap || mz_add(selected, score[i]) <= target || taking) selected = mz_add(selected, score[i]);
+            else { pass = false; target = selected; }
+        }
+        if (pass) { mask |= 1ull << i; taking = true; }
+    }
+    return mask;
+}
+
 struct MinimizerParams {
     MzIndex index; GIndex graph;                                          // graph: node lengths (for the flip of reverse hits)
+    MzPolicy policy;                                                      // on == 0: none
     const char* reads; const uint64_t* read_off; uint32_t n;
     uint32_t hit_cap;                                                      // minimizers with more hits give no seeds (hard_hit_cap, :4180)
     uint32_t* counts;                                                      // pass 1: seeds per read ([n + 1], last 0); minimizers per read in mins[]
@@ -134,10 +183,24 @@ VGK_HD void minimizer_one(const MinimizerParams& P, uint32_t i) {
     vgk_seed* dst = P.pass == 2 ? P.seeds + P.first[i] : nullptr;
     const uint32_t k = P.index.k;
     uint64_t seen[MZ_MAX_SEEDS];
+    // with a policy: the read's minimizers first (key, hits), then the choice, then the seeds of the chosen ones
+    uint64_t chosen = ~0ull; bool skipped = false;
+    if (P.policy.on) {
+        uint64_t pkey[MZ_POLICY_MAX]; uint32_t phits[MZ_POLICY_MAX]; uint32_t np = 0;
+        mz_minimizers(P.reads + a, L, k, P.index.w, [&](uint32_t, const MzKmer& m) {
+            uint32_t first = 0, count = 0; MzPos one{0, 0};
+            const bool found = mz_find(P.index, m, first, count, one);
+            if (np < MZ_POLICY_MAX) { pkey[np] = m.key; phits[np] = found ? count : 0u; }
+            ++np;
+        });
+        if (np > MZ_POLICY_MAX) skipped = true; else chosen = mz_policy_select(P.policy, pkey, phits, np);
+    }
+    const uint32_t cap = P.policy.on && !skipped ? 0xffffffffu : P.hit_cap;      // (the run's hits were held against the hard cap by the choice)
     mz_minimizers(P.reads + a, L, k, P.index.w, [&](uint32_t p, const MzKmer& m) {
-        ++n_min;
+        const uint32_t ordinal = n_min++;
         uint32_t first = 0, count = 0; MzPos one{0, 0};
-        if (!mz_find(P.index, m, first, count, one) || count > P.hit_cap) return;
+        if (!mz_find(P.index, m, first, count, one) || count > cap) return;
+        if (ordinal < 64u && !((chosen >> ordinal) & 1ull)) return;
         for (uint32_t h = 0; h < count; ++h) {
             if (n_seeds >= MZ_MAX_SEEDS) { truncated = true; break; }      // the cap: this hit and the rest are never looked at (reported in mins[])
             const MzPos q = first == MZ_ONE ? one : P.index.pos[first + h];
@@ -151,7 +214,7 @@ VGK_HD void minimizer_one(const MinimizerParams& P, uint32_t i) {
             ++n_seeds;
         }
     });
-    if (P.pass == 1) { P.counts[i] = n_seeds; if (P.mins) P.mins[i] = n_min | (truncated ? VGK_MINIMIZERS_TRUNCATED : 0u); }
+    if (P.pass == 1) { P.counts[i] = n_seeds; if (P.mins) P.mins[i] = n_min | (truncated ? VGK_MINIMIZERS_TRUNCATED : 0u) | (skipped ? VGK_MINIMIZERS_POLICY_SKIPPED : 0u); }
 }
 
 }  // namespace vgk
