@@ -355,7 +355,9 @@ int  vgk_banded_align_multi(vgk_ctx* ctx, const vgk_banded_problem* problems, ui
  * 2 = band cells filled, 3 = algorithmic bytes */
 double vgk_banded_last(vgk_ctx* ctx, int which);
 /* Launch the kernels of the last vgk_banded_align call again on its inputs, which stay resident in HBM (the counterpart of
- * vgk_gssw_run for this path; results stay on the device).  VGK_EINVAL unless that call fitted one sub-batch. */
+ * vgk_gssw_run for this path; results stay on the device).  VGK_EINVAL unless that call fitted one sub-batch — a call of 32 768 problems or
+ * more runs as four sub-batches, two in flight (the next one's geometry and arenas made while one runs), and leaves nothing resident:
+ * VGAMD_BANDED_ONE_BATCH=1 in the environment keeps such a call in one piece. */
 int    vgk_banded_rerun(vgk_ctx* ctx);
 
 /* ---- haplotype-consistent gapless extension (GaplessExtender, src/gbwt_extender.cpp:533-737) ---------
