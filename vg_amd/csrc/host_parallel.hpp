@@ -13,6 +13,8 @@
 #include <unistd.h>
 #include <sched.h>
 #include <cstdio>
+#include <cstdint>
+#include <emmintrin.h>
 
 namespace vgk {
 
@@ -180,6 +182,25 @@ constexpr uint32_t CHUNK = 512;
 inline uint32_t chunk_count(uint32_t n) { return (n + CHUNK - 1) / CHUNK; }
 template <class F> inline void parallel_chunks(uint32_t n, F f) {
     parallel_for(chunk_count(n), [&](uint32_t c, unsigned) { const uint32_t lo = c * CHUNK; f(lo, std::min<uint32_t>(n, lo + CHUNK), c); });
+}
+
+// base -> code (A C G T = 0 1 2 3, everything else 4), sixteen bases per step with SSE2 — part of every x86-64.  A switch or a table lookup per
+// base is most of a nanosecond; the packers code hundreds of megabytes per batch.  FOLD: case-insensitive (gssw_create_nt_table, for reads);
+// graph bases are taken as they are (after nonATGCNtoN, src/aligner.cpp:39: upper-case ACGT only).
+template <bool FOLD> inline void code_bases(uint8_t* __restrict dst, const char* __restrict src, size_t n) {
+    size_t k = 0;
+    const __m128i four = _mm_set1_epi8(4), fold = _mm_set1_epi8((char)0xdf);
+    const __m128i cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
+    const __m128i dA = _mm_set1_epi8(4), dC = _mm_set1_epi8(3), dG = _mm_set1_epi8(2), dT = _mm_set1_epi8(1);
+    for (; k + 16 <= n; k += 16) {
+        __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + k));
+        if (FOLD) b = _mm_and_si128(b, fold);
+        __m128i r = four;                                          // 4, minus (4 - code) where a base matches
+        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cA), dA)); r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cC), dC));
+        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cG), dG)); r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cT), dT));
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + k), r);
+    }
+    for (; k < n; ++k) { const uint8_t b = FOLD ? (uint8_t)((uint8_t)src[k] & 0xdfu) : (uint8_t)src[k]; dst[k] = (uint8_t)(b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : 4); }
 }
 
 // uninitialised array: the threads that fill it also fault its pages in (a std::vector would zero it on one thread first)

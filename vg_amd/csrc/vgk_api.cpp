@@ -273,7 +273,7 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         const uint32_t mode = p.flags & 15u; const bool xdrop = mode == VGK_XDROP_PINNED;
         uint8_t* rd = reads + d.read_off;
         if (xdrop) *rd++ = 5;                                  // row 0 = no read base consumed yet
-        for (uint32_t r = 0; r < p.read_len; ++r) rd[r] = (uint8_t)nt_read(p.read[r]);
+        code_bases<true>(rd, p.read, p.read_len);
         if (ctx->has_qa) {
             const uint32_t S = ctx->scale;
             uint32_t* pf = prof + d.prof_off;
@@ -302,11 +302,11 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
             nr.slot = f.store[v] ? (int32_t)slots++ : -1;
             nr.pinning = (mode == VGK_GSSW_PINNED && p.pinning[v]) ? 1u : 0u;
             nrs[v] = nr;
-            for (uint32_t k = 0; k < g.node_len[v]; ++k, ++seq_pos) {
-                uint8_t ci = (uint8_t)nt_ref(g.seq[seq_pos]);
-                if (k == 0) { ci |= CI_NODE_START; if (f.slow[v]) ci |= CI_SEED_SLOW; }
-                if (k + 1 == g.node_len[v] && f.store[v]) ci |= CI_STORE_END;
-                ci_out[col + k] = ci;
+            if (const uint32_t len = g.node_len[v]) {              // the node's bases, then the marks on its first and last column
+                code_bases<false>(ci_out + col, g.seq + seq_pos, len);
+                ci_out[col] |= (uint8_t)(CI_NODE_START | (f.slow[v] ? CI_SEED_SLOW : 0));
+                if (f.store[v]) ci_out[col + len - 1] |= (uint8_t)CI_STORE_END;
+                seq_pos += len;
             }
             col = nr.col_end;
         }
