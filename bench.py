@@ -530,7 +530,8 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
     # and tail kernels; every batch's results are what the one-context form gives (checked below).  This is the timed form when a step
     # has two batches or more; `config.one_context` keeps the serial rate beside it.
     pipelined = len(wl.batches) >= 2 and not os.environ.get("VGAMD_CONFIG2_ONE_CONTEXT")
-    if pipelined:
+    n_contexts = max(2, min(int(os.environ.get("VGAMD_CONFIG2_CONTEXTS", "2")), len(wl.batches))) if pipelined else 1
+    for _ in range(n_contexts - 1):
         eng_b = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), device=eng.device, lib=eng.lib)          # (the same library, the same device)
         eng_b.reuse_outputs = True
         lanes.append((eng_b, eng_b.haplo_index(graph, wl.threads), eng_b.minimizer_index(graph, wl.threads)))
@@ -539,7 +540,7 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
 
     def one_step_pipelined(timing=None, keep=None):
         tot = new_tot()
-        th = [threading.Thread(target=run_batches, args=(lanes[k], range(k, len(wl.batches), 2), tot, timing, keep)) for k in range(2)]
+        th = [threading.Thread(target=run_batches, args=(lanes[k], range(k, len(wl.batches), n_contexts), tot, timing, keep)) for k in range(n_contexts)]
         for t in th: t.start()
         for t in th: t.join()
         return tot
@@ -603,7 +604,7 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
                                    "variant with p = 0.5; %d reads of 150 bp per GPU from the haplotypes on either strand, 1 %% substitutions, 10 %% of them with one inserted base; "
                                    "k = 29, w = 11 minimizers, hit cap 500; max_mismatches 4; tails left-pinned X-drop against their haplotype trees, scores 1/4/6/1/5" % (len(wl.node_len), n),
                        "timed_region": "per step, %d batches of %d reads from host buffers: vgk_minimizer_seeds (clusters stay in HBM) -> vgk_gapless_extend_seeded (sets come down under the "
-                                       "tail stage) -> vgk_tail_stage_aligned%s" % (len(wl.batches), batch, "; two batches in flight: two engine contexts, one host thread each, alternate batches" if pipelined else ""),
+                                       "tail stage) -> vgk_tail_stage_aligned%s" % (len(wl.batches), batch, "; %d batches in flight: %d engine contexts, one host thread each, batches in turn" % (n_contexts, n_contexts) if pipelined else ""),
                        "one_context": one_context,
                        "read_buffers": "page-locked by the caller (vgk_host_register)" if pinned and all(pinned) else "pageable",
                        "policies": ("find_seeds' choice on the device (vgk_minimizer_set_policy: hit cap 10, hard cap 500 over a key's run, score fraction 0.9); clusters = all seeds of the chosen minimizers" if with_policy else
@@ -1430,7 +1431,7 @@ def main():
 # at a size that keeps the whole default run within a few minutes; a record keeps the line's metric, value, roofline, cpu_baseline and
 # parity.  A leg that fails or overruns its time limit leaves {"workload", "error"} — never a missing headline.
 SECONDARY = [
-    ("config2", ["--reads", "4000000", "--steps", "4", "--warmup", "2", "--cpu-sample", "50000"], 240),
+    ("config2", ["--reads", "8000000", "--steps", "3", "--warmup", "1", "--cpu-sample", "50000"], 300),
     ("gapless", ["--steps", "5", "--warmup", "2"], 90),
     ("xband", ["--steps", "5", "--warmup", "2"], 90),
     ("banded", ["--reads", "100000", "--steps", "5", "--warmup", "2"], 90),
