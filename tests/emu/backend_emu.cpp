@@ -126,6 +126,10 @@ public:
         return VGK_OK;
     }
     int run_xdrop_band(const GsswMatrixParams& P) override {
+        if (std::getenv("VGAMD_EMU_SKIP_XBAND")) {      // (host-side timing of the call on a machine without a GPU: the kernels answer "nothing aligned")
+            if (P.xb_results) for (uint32_t k = 0; k < P.n; ++k) { vgk_result r{}; r.end_node = -1; r.end_offset = -1; r.end_read = -1; r.ops_begin = (uint32_t)P.xb_ops_off[k]; P.xb_results[k] = r; }
+            return VGK_OK;
+        }
         // the launch order's two classes: problems that run in one DPP row of 16 lanes (four to a wavefront on the GPU; here one after the
         // other — the rows do not talk to each other), then the ones that take a whole wavefront
         auto run = [&](uint32_t lanes, uint32_t begin, uint32_t count) {

@@ -250,21 +250,7 @@ constexpr int S_SCORES = 31;          // k-best mode: the full score matrices (s
 constexpr int S_SET1 = 124;           // the pipelined path's second sub-batch in flight: slots S_SET1 + S_*
 static_assert(S_COUNT <= 15 && S_SCORES < (int)(sizeof(vgk_ctx::scratch) / sizeof(vgk_ctx::DevBuf)) && S_SET1 + S_COUNT <= (int)(sizeof(vgk_ctx::scratch) / sizeof(vgk_ctx::DevBuf)), "scratch slots");
 
-// base -> code, sixteen at a time (gssw_create_nt_table's rule: case-insensitive ACGT, everything else N)
-inline void nt_code_run(uint8_t* __restrict dst, const char* __restrict src, uint32_t n) {
-    uint32_t k = 0;
-    const __m128i four = _mm_set1_epi8(4), fold = _mm_set1_epi8((char)0xdf);
-    const __m128i cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
-    const __m128i dA = _mm_set1_epi8(4), dC = _mm_set1_epi8(3), dG = _mm_set1_epi8(2), dT = _mm_set1_epi8(1);
-    for (; k + 16 <= n; k += 16) {
-        const __m128i b = _mm_and_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(src + k)), fold);
-        __m128i r = four;
-        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cA), dA)); r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cC), dC));
-        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cG), dG)); r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cT), dT));
-        _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + k), r);
-    }
-    for (; k < n; ++k) dst[k] = nt_code(src[k]);
-}
+
 
 // ---- k-best alignments: the alternate-traceback stack of the reference (AltTracebackStack, src/banded_global_aligner.cpp:2426-2790)
 // walked on the host over the score matrices the fill kernel left in HBM.  A traceback is the list of its deflections — the first
@@ -580,9 +566,9 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
                 std::copy(T.seeds.begin() + hp.seeds.off, T.seeds.begin() + hp.seeds.off + hp.seeds.len, seeds + pb.seed_base);
                 std::copy(T.pool.begin() + hp.pool.off, T.pool.begin() + hp.pool.off + hp.pool.len, pool + pb.pool_base);
                 for (uint32_t q = 0; q < hp.starts.len; ++q) starts[pb.start_base + q].node = T.starts[hp.starts.off + q];
-                nt_code_run(reads + pb.read_off, p.read, pb.L);
+                code_bases<true>(reads + pb.read_off, p.read, pb.L);
                 if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
-                nt_code_run(graph + pb.graph_off, p.graph.seq, pb.graph_len);
+                code_bases<true>(graph + pb.graph_off, p.graph.seq, pb.graph_len);
             });
             lap("arenas");
             // launches: one per rows-per-lane class; inside a class the problems with the most cells first (counting sort on log2(cells))
@@ -937,9 +923,9 @@ static int banded_align_pipelined(vgk_ctx* ctx, const vgk_banded_problem* proble
             std::copy(T.seeds.begin() + hp.seeds.off, T.seeds.begin() + hp.seeds.off + hp.seeds.len, seeds + pb.seed_base);
             std::copy(T.pool.begin() + hp.pool.off, T.pool.begin() + hp.pool.off + hp.pool.len, pool + pb.pool_base);
             for (uint32_t q = 0; q < hp.starts.len; ++q) starts[pb.start_base + q].node = T.starts[hp.starts.off + q];
-            nt_code_run(reads + pb.read_off, p.read, pb.L);
+            code_bases<true>(reads + pb.read_off, p.read, pb.L);
             if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
-            nt_code_run(graph + pb.graph_off, p.graph.seq, pb.graph_len);
+            code_bases<true>(graph + pb.graph_off, p.graph.seq, pb.graph_len);
         });
         // launches: one per rows-per-lane class; inside a class the problems with the most cells first (counting sort on log2(cells))
         { auto key = [&](uint32_t a) { return hps[owner[a]].order_key; };

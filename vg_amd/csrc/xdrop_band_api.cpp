@@ -22,27 +22,6 @@ using namespace vgk;
 
 namespace {
 
-// base -> code, sixteen bases per step (SSE2: part of every x86-64): a switch or a table lookup per base is most of a nanosecond, and a
-// call of 200 000 tails codes 62 MB of bases — 5 of its 6.4 ms of packing.  FOLD: case-insensitive (reads); dozeu sees the raw node
-// sequences, where anything but upper-case ACGT scores as N.
-template <bool FOLD> inline void code_run(uint8_t* __restrict dst, const char* __restrict src, uint32_t n) {
-    uint32_t k = 0;
-    const __m128i four = _mm_set1_epi8(4), fold = _mm_set1_epi8((char)0xdf);
-    const __m128i cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
-    const __m128i dA = _mm_set1_epi8(4), dC = _mm_set1_epi8(3), dG = _mm_set1_epi8(2), dT = _mm_set1_epi8(1);
-    for (; k + 16 <= n; k += 16) {
-        __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + k));
-        if (FOLD) b = _mm_and_si128(b, fold);
-        __m128i r = four;                                          // 4, minus (4 - code) where a base matches
-        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cA), dA));
-        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cC), dC));
-        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cG), dG));
-        r = _mm_sub_epi8(r, _mm_and_si128(_mm_cmpeq_epi8(b, cT), dT));
-        _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + k), r);
-    }
-    for (; k < n; ++k) { const uint8_t b = FOLD ? (uint8_t)((uint8_t)src[k] & 0xdfu) : (uint8_t)src[k]; dst[k] = (uint8_t)(b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : 4); }
-}
-
 // page-locked staging, kept between calls: the inputs go up and the results come down at the full DMA rate (pageable vectors cost ~7 of 13 host
 // ms per 200 000 tails).  Two sets: a call's sub-batches alternate between them (see below).
 struct BandStage { PinnedBuf<uint8_t> reads, quals, graph, want; PinnedBuf<MProb> probs; PinnedBuf<MNode> nodes; PinnedBuf<uint32_t> preds, order; PinnedBuf<uint64_t> ops_off;
@@ -166,6 +145,9 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
                              __builtin_prefetch(q.graph.node_len); __builtin_prefetch(q.graph.pred_off); __builtin_prefetch(q.graph.pred_idx); __builtin_prefetch(q.read);
                              __builtin_prefetch(q.graph.seq); __builtin_prefetch(q.graph.seq + 64); __builtin_prefetch(q.graph.seq + 128); }
             const vgk_gssw_problem& p = problems[owner[a]]; MProb& pb = probs[a];
+#ifdef VGK_PACK_PROF
+            const unsigned long long c0 = __builtin_ia32_rdtsc();
+#endif
             pb.start_bonus = qa ? ctx->qbon[p.qual[p.read_len - 1]] : ctx->sc.full_length_bonus; pb.status = VGK_OK;
             const int32_t max_gap = (int32_t)std::max<uint32_t>(p.max_gap_length, 1u);
             pb.gap_cells = (max_gap + 7) & ~7; pb.xt = ((int32_t)ctx->sc.gap_open - (int32_t)ctx->sc.gap_extend) + (int32_t)ctx->sc.gap_extend * max_gap;
@@ -175,9 +157,18 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
                 for (uint32_t k = p.graph.pred_off[v]; k < p.graph.pred_off[v + 1]; ++k) preds[a_preds++] = p.graph.pred_idx[k];
                 nodes[pb.node_off + v] = nd; col = nd.col_end;
             }
-            code_run<true>(reads + pb.read_off, p.read, pb.L);
+#ifdef VGK_PACK_PROF
+            const unsigned long long c1 = __builtin_ia32_rdtsc();
+#endif
+            code_bases<true>(reads + pb.read_off, p.read, pb.L);
             if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
-            code_run<false>(graph + pb.graph_off, p.graph.seq, pb.R);
+            code_bases<false>(graph + pb.graph_off, p.graph.seq, pb.R);
+#ifdef VGK_PACK_PROF
+            const unsigned long long c2 = __builtin_ia32_rdtsc();
+            static std::atomic<unsigned long long> tn{0}, tc{0}, cnt{0};
+            tn += c1 - c0; tc += c2 - c1;
+            if ((++cnt % 200000) == 0) std::fprintf(stderr, "[pack prof] per problem: nodes %.0f cycles, coding %.0f cycles\n", (double)tn / cnt, (double)tc / cnt);
+#endif
         });
         lap("pack");
         GsswMatrixParams& P = S.P; P = GsswMatrixParams{};
