@@ -145,9 +145,6 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
                              __builtin_prefetch(q.graph.node_len); __builtin_prefetch(q.graph.pred_off); __builtin_prefetch(q.graph.pred_idx); __builtin_prefetch(q.read);
                              __builtin_prefetch(q.graph.seq); __builtin_prefetch(q.graph.seq + 64); __builtin_prefetch(q.graph.seq + 128); }
             const vgk_gssw_problem& p = problems[owner[a]]; MProb& pb = probs[a];
-#ifdef VGK_PACK_PROF
-            const unsigned long long c0 = __builtin_ia32_rdtsc();
-#endif
             pb.start_bonus = qa ? ctx->qbon[p.qual[p.read_len - 1]] : ctx->sc.full_length_bonus; pb.status = VGK_OK;
             const int32_t max_gap = (int32_t)std::max<uint32_t>(p.max_gap_length, 1u);
             pb.gap_cells = (max_gap + 7) & ~7; pb.xt = ((int32_t)ctx->sc.gap_open - (int32_t)ctx->sc.gap_extend) + (int32_t)ctx->sc.gap_extend * max_gap;
@@ -157,18 +154,9 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
                 for (uint32_t k = p.graph.pred_off[v]; k < p.graph.pred_off[v + 1]; ++k) preds[a_preds++] = p.graph.pred_idx[k];
                 nodes[pb.node_off + v] = nd; col = nd.col_end;
             }
-#ifdef VGK_PACK_PROF
-            const unsigned long long c1 = __builtin_ia32_rdtsc();
-#endif
             code_bases<true>(reads + pb.read_off, p.read, pb.L);
             if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
             code_bases<false>(graph + pb.graph_off, p.graph.seq, pb.R);
-#ifdef VGK_PACK_PROF
-            const unsigned long long c2 = __builtin_ia32_rdtsc();
-            static std::atomic<unsigned long long> tn{0}, tc{0}, cnt{0};
-            tn += c1 - c0; tc += c2 - c1;
-            if ((++cnt % 200000) == 0) std::fprintf(stderr, "[pack prof] per problem: nodes %.0f cycles, coding %.0f cycles\n", (double)tn / cnt, (double)tc / cnt);
-#endif
         });
         lap("pack");
         GsswMatrixParams& P = S.P; P = GsswMatrixParams{};
