@@ -68,7 +68,8 @@ struct alignas(128) Scratch {         // per-thread reusable buffers of pass 1
 
 // Band geometry of one problem (find_banded_paths :2174-2268, path_lengths_to_sinks :2122-2170, shortest_seq_paths :2271-2293)
 // and the tables the kernels need.
-void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch& S, Store& T) {
+// `out` (nullable): where the N node records go instead of T.nodes (the pipelined call writes them where they are uploaded from)
+void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch& S, Store& T, BNode* out = nullptr) {
     const vgk_graph& g = p.graph;
     const uint32_t N = g.n_nodes; const int64_t L = p.read_len;
     if (!N || !L || !p.read || !g.node_len || !g.pred_off || !g.seq || (ctx->has_qa && !p.qual)) { hp.status = VGK_EINVAL; return; }
@@ -141,8 +142,9 @@ void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch&
     uint64_t tb_off = 0, last_off = 0; uint32_t seq_off = 0;
     int64_t prev_filled = -1;              // the node the wave will have in its registers when it reaches v
     const size_t keep_nodes = T.nodes.size(), keep_seeds = T.seeds.size(), keep_pool = T.pool.size();
-    auto fail = [&](int code) { T.nodes.resize(keep_nodes); T.seeds.resize(keep_seeds); T.pool.resize(keep_pool); hp.status = code; };
-    T.nodes.resize(keep_nodes + N);
+    auto fail = [&](int code) { if (!out) T.nodes.resize(keep_nodes); T.seeds.resize(keep_seeds); T.pool.resize(keep_pool); hp.status = code; };
+    if (!out) T.nodes.resize(keep_nodes + N);
+    BNode* const recs = out ? out : T.nodes.data() + keep_nodes;
     for (uint32_t v = 0; v < N; ++v) {
         BNode nd{};
         nd.top = masked[v] ? 0 : (int32_t)top[v]; nd.bot = masked[v] ? -1 : (int32_t)bot[v];
@@ -175,16 +177,16 @@ void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch&
                 nd.chain = sd.path_len == 0 && (int64_t)sd.node == prev_filled && top[v] == top[sd.node] + len[sd.node] && bot[v] == bot[sd.node] + len[sd.node];
             }
             prev_filled = v;
-            if (!nd.chain) for (uint32_t q = 0; q < n_seeds; ++q) T.nodes[keep_nodes + T.seeds[T.seeds.size() - 1 - q].node].keep_last = 1;
+            if (!nd.chain) for (uint32_t q = 0; q < n_seeds; ++q) recs[T.seeds[T.seeds.size() - 1 - q].node].keep_last = 1;
             const uint32_t granule = std::max<uint32_t>(R, 4), H = (uint32_t)(bot[v] - top[v] + 1);
             nd.stride = (H + granule - 1) / granule * granule;
             nd.tb_off = (uint32_t)tb_off;
             tb_off += (uint64_t)len[v] * nd.stride;
             if (tb_off > 0xfffffff0ull) { fail(VGK_ETOOBIG); return; }
         }
-        T.nodes[keep_nodes + v] = nd;
+        recs[v] = nd;
     }
-    hp.nodes = {keep_nodes, N}; hp.seeds = {keep_seeds, (uint32_t)(T.seeds.size() - keep_seeds)}; hp.pool = {keep_pool, (uint32_t)(T.pool.size() - keep_pool)};
+    hp.nodes = {out ? 0 : keep_nodes, N}; hp.seeds = {keep_seeds, (uint32_t)(T.seeds.size() - keep_seeds)}; hp.pool = {keep_pool, (uint32_t)(T.pool.size() - keep_pool)};
     hp.starts.off = T.starts.size();
     // where a traceback may start (:2442-2556): every sink in topological order (PARITY-UNPINNED: the reference iterates an
     // unordered_set of matrix pointers), looking through empty sinks to their predecessors depth-first, last predecessor first
@@ -211,10 +213,10 @@ void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch&
         }
     }
     hp.starts.len = (uint32_t)(T.starts.size() - hp.starts.off);
-    for (uint32_t q = 0; q < hp.starts.len; ++q) T.nodes[keep_nodes + T.starts[hp.starts.off + q]].keep_last = 1;
+    for (uint32_t q = 0; q < hp.starts.len; ++q) recs[T.starts[hp.starts.off + q]].keep_last = 1;
     // last / first columns only where a traceback or a successor will read them
     for (uint32_t v = 0; v < N; ++v) {
-        BNode& nd = T.nodes[keep_nodes + v];
+        BNode& nd = recs[v];
         if (nd.masked || nd.len == 0 || (nd.chain && !nd.keep_last)) continue;
         nd.last_off = (uint32_t)last_off; last_off += 5ull * nd.stride;
     }
@@ -243,6 +245,7 @@ struct HostArenas {
     PinnedBuf<BProb> probs; PinnedBuf<BNode> nodes; PinnedBuf<BSeed> seeds; PinnedBuf<uint32_t> pool, order; PinnedBuf<BStart> starts;
     PinnedBuf<uint8_t> reads, quals, graph; PinnedBuf<BResult> dres; PinnedBuf<vgk_op> dops; PinnedBuf<int32_t> scores;
     PinnedSet set[2]; void* ev[2] = {nullptr, nullptr}; Backend* be = nullptr;      // the pipelined path: two sub-batches in flight
+    PinnedBuf<BNode> qnodes[2];        // ... and the node records of a quarter of the call, written by prepare() where they are uploaded from (quarters alternate)
     ~HostArenas() { if (be) for (void* e : ev) if (e) be->event_destroy(e); }
 };
 enum { S_PROBS, S_ORDER, S_NODES, S_SEEDS, S_POOL, S_STARTS, S_READS, S_QUALS, S_GRAPH, S_MAT, S_TB, S_LAST, S_OPS, S_DENSE, S_RESULTS, S_COUNT };
@@ -822,6 +825,7 @@ static int banded_align_pipelined(vgk_ctx* ctx, const vgk_banded_problem* proble
     for (Store& T : store) T.clear();
     const uint32_t quarter = (n + 3u) / 4u;
     uint32_t prepared = 0;
+    std::vector<uint64_t> qoff[2]; uint32_t qlo[2] = {0, 0};
     size_t used = 0; int rc_all = VGK_OK;
     // plain contexts: the table, and behind it its rows as 64-bit words for the kernel's byte permute (banded_device.hpp BMAT_ROWS_AT)
     int8_t* mat_rows = ctx->banded_mat_rows;
@@ -834,11 +838,20 @@ static int banded_align_pipelined(vgk_ctx* ctx, const vgk_banded_problem* proble
         PinnedSet& A = H.set[set]; const int base = set ? S_SET1 : 0;
         const uint32_t limit = std::min<uint32_t>(n, (from / quarter + 1u) * quarter);
         if (prepared < limit) {
-            const uint32_t lo = prepared;
-            parallel_for(limit - lo, [&](uint32_t k, unsigned t) { Prep* hp = new (&hps[lo + k]) Prep(); hp->thread = t; prepare(ctx, problems[lo + k], *hp, scratch[t], store[t]); });
+            // the node records — 64 bytes a node, the bulk of the tables — are written straight into the quarter's page-locked table, a
+            // problem's at the sum of the node counts before it (a declined problem's slots stay unused); sub-batches upload slices of it
+            const uint32_t lo = prepared, par = (lo / quarter) & 1u;
+            std::vector<uint64_t>& off = qoff[par]; off.assign((size_t)(limit - lo) + 1, 0);
+            for (uint32_t k = 0; k < limit - lo; ++k) off[k + 1] = off[k] + problems[lo + k].graph.n_nodes;
+            BNode* table = H.qnodes[par].get(be, off[limit - lo] + 1);
+            if (!table) return VGK_ENOMEM;
+            qlo[par] = lo;
+            parallel_for(limit - lo, [&](uint32_t k, unsigned t) { Prep* hp = new (&hps[lo + k]) Prep(); hp->thread = t; prepare(ctx, problems[lo + k], *hp, scratch[t], store[t], table + off[k]); });
             prepared = limit; hps_store.made = limit;
             lap("prepare");
         }
+        const uint32_t par = (from / quarter) & 1u; const std::vector<uint64_t>& noff = qoff[par]; const uint32_t nlo = qlo[par];
+        auto node_at = [&](uint32_t q) { return noff[q - nlo] - noff[from - nlo]; };      // a problem's records inside the sub-batch's slice of the table
         S.i = from; S.owner.clear(); S.launches.clear();
         uint64_t n_nodes = 0, n_seeds = 0, n_pool = 0, n_starts = 0, n_read = 0, n_graph = 0, tb_bytes = 0, last_elems = 0, ops_total = 0;
         uint32_t j = from;
@@ -873,7 +886,7 @@ static int banded_align_pipelined(vgk_ctx* ctx, const vgk_banded_problem* proble
                     uint64_t v[10]; sizes_of(q, v);
                     BProb pb{};
                     pb.L = p.read_len; pb.n_nodes = p.graph.n_nodes; pb.Hpad = hp.Hpad; pb.graph_len = (uint32_t)hp.bases;
-                    pb.node_base = (uint32_t)at.v[1]; pb.seed_base = (uint32_t)at.v[2]; pb.pool_base = (uint32_t)at.v[3]; pb.start_base = (uint32_t)at.v[4];
+                    pb.node_base = (uint32_t)node_at(q); pb.seed_base = (uint32_t)at.v[2]; pb.pool_base = (uint32_t)at.v[3]; pb.start_base = (uint32_t)at.v[4];
                     pb.n_starts = hp.starts.len; pb.read_off = (uint32_t)at.v[5]; pb.graph_off = (uint32_t)at.v[6];
                     pb.tb_base = at.v[7]; pb.last_base = at.v[8]; pb.ops_off = at.v[9]; pb.ops_cap = hp.ops_cap;
                     const uint32_t a = (uint32_t)at.v[0];
@@ -881,7 +894,7 @@ static int banded_align_pipelined(vgk_ctx* ctx, const vgk_banded_problem* proble
                     for (int x = 0; x < 10; ++x) at.v[x] += v[x];
                 }
             });
-            n_nodes = all.v[1]; n_seeds = all.v[2]; n_pool = all.v[3]; n_starts = all.v[4]; n_read = all.v[5]; n_graph = all.v[6]; tb_bytes = all.v[7]; last_elems = all.v[8]; ops_total = all.v[9];
+            n_nodes = noff[limit - nlo] - noff[from - nlo]; n_seeds = all.v[2]; n_pool = all.v[3]; n_starts = all.v[4]; n_read = all.v[5]; n_graph = all.v[6]; tb_bytes = all.v[7]; last_elems = all.v[8]; ops_total = all.v[9];
             j = limit;
         }
         else for (; j < limit; ++j) {
@@ -894,6 +907,7 @@ static int banded_align_pipelined(vgk_ctx* ctx, const vgk_banded_problem* proble
             n_read += p.read_len; n_graph += hp.bases; tb_bytes += hp.tb_bytes; last_elems += hp.last_elems; ops_total += hp.ops_cap;
             S.owner.push_back(j);
         }
+        if (!whole) n_nodes = noff[j - nlo] - noff[from - nlo];      // (the slice of the quarter's table, declined problems' slots included)
         S.j = j;
         const std::vector<uint32_t>& owner = S.owner;
         const uint32_t m = S.m = (uint32_t)owner.size();
@@ -905,21 +919,20 @@ static int banded_align_pipelined(vgk_ctx* ctx, const vgk_banded_problem* proble
             Prep& hp = hps[owner[a]]; const vgk_banded_problem& p = problems[owner[a]];
             BProb pb{};
             pb.L = p.read_len; pb.n_nodes = p.graph.n_nodes; pb.Hpad = hp.Hpad; pb.graph_len = (uint32_t)hp.bases;
-            pb.node_base = (uint32_t)a_nodes; pb.seed_base = (uint32_t)a_seeds; pb.pool_base = (uint32_t)a_pool; pb.start_base = (uint32_t)a_starts;
+            pb.node_base = (uint32_t)node_at(owner[a]); pb.seed_base = (uint32_t)a_seeds; pb.pool_base = (uint32_t)a_pool; pb.start_base = (uint32_t)a_starts;
             pb.n_starts = hp.starts.len; pb.read_off = (uint32_t)a_read; pb.graph_off = (uint32_t)a_graph;
             pb.tb_base = a_tb; pb.last_base = a_last; pb.ops_off = a_ops; pb.ops_cap = hp.ops_cap;
             a_nodes += pb.n_nodes; a_seeds += hp.seeds.len; a_pool += hp.pool.len; a_starts += hp.starts.len;
             a_read += pb.L; a_graph += hp.bases; a_tb += hp.tb_bytes; a_last += hp.last_elems; a_ops += hp.ops_cap;
             hp.arena = a; probs[a] = pb;
           } }
-        BNode* nodes = A.nodes.get(be, n_nodes); BSeed* seeds = A.seeds.get(be, n_seeds); uint32_t* pool = A.pool.get(be, n_pool); BStart* starts = A.starts.get(be, n_starts);
+        BSeed* seeds = A.seeds.get(be, n_seeds); uint32_t* pool = A.pool.get(be, n_pool); BStart* starts = A.starts.get(be, n_starts);
         uint8_t* reads = A.reads.get(be, n_read); uint8_t* quals = qa ? A.quals.get(be, n_read) : nullptr; uint8_t* graph = A.graph.get(be, n_graph);
         uint32_t* order = A.order.get(be, m);
-        if (!nodes || !seeds || !pool || !starts || !reads || (qa && !quals) || !graph || !order) return VGK_ENOMEM;
+        if (!seeds || !pool || !starts || !reads || (qa && !quals) || !graph || !order) return VGK_ENOMEM;
         parallel_for(m, [&](uint32_t a, unsigned) {
             const Prep& hp = hps[owner[a]]; const BProb& pb = probs[a]; const vgk_banded_problem& p = problems[owner[a]];
             const Store& T = store[hp.thread];
-            std::copy(T.nodes.begin() + hp.nodes.off, T.nodes.begin() + hp.nodes.off + hp.nodes.len, nodes + pb.node_base);
             std::copy(T.seeds.begin() + hp.seeds.off, T.seeds.begin() + hp.seeds.off + hp.seeds.len, seeds + pb.seed_base);
             std::copy(T.pool.begin() + hp.pool.off, T.pool.begin() + hp.pool.off + hp.pool.len, pool + pb.pool_base);
             for (uint32_t q = 0; q < hp.starts.len; ++q) starts[pb.start_base + q].node = T.starts[hp.starts.off + q];
@@ -952,7 +965,8 @@ static int banded_align_pipelined(vgk_ctx* ctx, const vgk_banded_problem* proble
         if (!m) return VGK_OK;
         PinnedSet& A = H.set[set]; const int base = set ? S_SET1 : 0;
         const uint64_t n_nodes = S.sizes[0], n_seeds = S.sizes[1], n_pool = S.sizes[2], n_starts = S.sizes[3], n_read = S.sizes[4], n_graph = S.sizes[5], tb_bytes = S.sizes[6], last_elems = S.sizes[7], ops_total = S.sizes[8];
-        const BProb* probs = A.probs.p; const uint32_t* order = A.order.p; const BNode* nodes = A.nodes.p; const BSeed* seeds = A.seeds.p; const uint32_t* pool = A.pool.p; const BStart* starts = A.starts.p;
+        const uint32_t par = (S.i / quarter) & 1u;
+        const BProb* probs = A.probs.p; const uint32_t* order = A.order.p; const BNode* nodes = H.qnodes[par].p + qoff[par][S.i - qlo[par]]; const BSeed* seeds = A.seeds.p; const uint32_t* pool = A.pool.p; const BStart* starts = A.starts.p;
         const uint8_t* reads = A.reads.p; const uint8_t* quals = A.quals.p; const uint8_t* graph = A.graph.p;
         BandedParams& P = S.P; P = BandedParams{};
         int rc;
