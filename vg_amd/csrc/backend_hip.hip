@@ -1287,7 +1287,7 @@ public:
                 if (p.xb_n16) hipLaunchKernelGGL(xdrop_band_pk_kernel16, dim3((p.xb_n16 + 3) / 4), dim3(64), 0, stream, p);
                 if (p.xb_n64) hipLaunchKernelGGL(xdrop_band_pk_kernel, dim3(p.xb_n64), dim3(64), 0, stream, p);
             } else hipLaunchKernelGGL(xdrop_band_pk_kernel, dim3(p.n), dim3(64), 0, stream, p);
-            if (p.xb_results) hipLaunchKernelGGL(xdrop_band_walk_kernel<int16_t>, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
+            if (p.xb_results) hipLaunchKernelGGL(xdrop_band_walk_kernel<uint16_t>, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
         } else if (p.xb_cell16) launch(int16_t{}); else launch(int32_t{});
         hipEventRecord(ev[1], stream);
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;

@@ -145,6 +145,15 @@ template <> struct XbPlane<int16_t> {
     }
     VGK_HD void store8(uint64_t at, const int32_t (&v)[8]) const { MVec8h x; for (int k = 0; k < 4; ++k) x.w[k] = xb_pack2(v[2 * k], v[2 * k + 1]); *reinterpret_cast<MVec8h*>(p + at) = x; }
 };
+// the cells as the packed fill (xb_cell16 == 2) keeps them: unsigned, biased by 32 768, anything below 16 768 unreachable — stored as they are
+// (no conversion at the store: eight instructions a column); only the walk reads them through this
+template <> struct XbPlane<uint16_t> {
+    uint16_t* p;
+    static VGK_HD int32_t of(uint16_t x) { return x < 16768u ? -(1 << 28) : (int32_t)x - 32768; }
+    VGK_HD int32_t get(uint64_t at) const { return of(p[at]); }
+    VGK_HD uint16_t raw(uint64_t at) const { return p[at]; }
+    VGK_HD int32_t conv(uint16_t x) const { return of(x); }
+};
 VGK_HD void bump_stat(unsigned long long* p, unsigned long long v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicAdd(p, v);
@@ -452,7 +461,7 @@ VGK_HD void xdrop_band_pk_lane(const GsswMatrixParams& P, uint32_t pi, uint32_t 
     const int32_t L = (int32_t)pb.L, rows = L + 1, go = P.go, ge = P.ge;
     const int32_t stride = (rows + 7) & ~7;
     const uint64_t plane = (uint64_t)pb.R * (uint64_t)stride;
-    int16_t* const Hm = reinterpret_cast<int16_t*>(P.cells) + pb.mat_off; int16_t* const Em = Hm + plane;
+    uint16_t* const Hm = reinterpret_cast<uint16_t*>(P.cells) + pb.mat_off; uint16_t* const Em = Hm + plane;      // biased cells as they are (XbPlane<uint16_t>)
     const uint8_t* rd = P.reads + pb.read_off; const uint8_t* ql = P.quals ? P.quals + pb.read_off : nullptr;
     const uint8_t* gr = P.graph + pb.graph_off;
     const MNode* nodes = P.nodes + pb.node_off;
@@ -501,6 +510,7 @@ VGK_HD void xdrop_band_pk_lane(const GsswMatrixParams& P, uint32_t pi, uint32_t 
     };
     refill(0);
     uint32_t ref_cur = stage[0];
+    uint32_t col_at = (uint32_t)i0;                                 // c * stride + i0 (a problem's planes hold fewer than 2^28 cells each)
     const int32_t band_cells = i0 < stride ? (L < i0 + 7 ? L : i0 + 7) - i0 + 1 : 0;
     {
     uint32_t v = 0, c = 0;
@@ -576,9 +586,9 @@ VGK_HD void xdrop_band_pk_lane(const GsswMatrixParams& P, uint32_t pi, uint32_t 
                         const uint32_t fr = front[pcol], fb = fr & 255u, fe = fr >> 8;
                         if (lane >= fb && lane < fe) {
                             const MVec8h xh = *reinterpret_cast<const MVec8h*>(Hm + pc), xe = *reinterpret_cast<const MVec8h*>(Em + pc);
-                            for (int k = 0; k < 4; ++k) { ph[k] = xh.w[k] ^ 0x80008000u; pe[k] = xe.w[k] ^ 0x80008000u; }
+                            for (int k = 0; k < 4; ++k) { ph[k] = xh.w[k]; pe[k] = xe.w[k]; }
                         } else for (int k = 0; k < 4; ++k) { ph[k] = 0; pe[k] = 0; }
-                        above = (lane >= fb + 1 && lane < fe + 1) ? ((uint32_t)(uint16_t)Hm[pc - 1] ^ 0x8000u) : 0u;
+                        above = (lane >= fb + 1 && lane < fe + 1) ? (uint32_t)Hm[pc - 1] : 0u;
                     }
                     for (int k = 0; k < 4; ++k) {
                         e[k] = pk_max(e[k], pk_max(pk_subs(ph[k], go2), pk_subs(pe[k], ge2)));
@@ -617,10 +627,9 @@ VGK_HD void xdrop_band_pk_lane(const GsswMatrixParams& P, uint32_t pi, uint32_t 
             const uint32_t keep_mask = inside ? 0xffffffffu : 0u;      // (rows beyond L inside the last vector are 0 by themselves)
             for (int k = 0; k < 4; ++k) { Hp[k] = hh[k] & keep_mask; Ep[k] = e[k] & keep_mask; }
             if (inside && i0 < stride) {
-                const uint64_t at = (uint64_t)c * (uint64_t)stride + (uint64_t)i0;
                 MVec8h xh, xe;
-                for (int k = 0; k < 4; ++k) { xh.w[k] = Hp[k] ^ 0x80008000u; xe.w[k] = Ep[k] ^ 0x80008000u; }
-                *reinterpret_cast<MVec8h*>(Hm + at) = xh; *reinterpret_cast<MVec8h*>(Em + at) = xe;
+                for (int k = 0; k < 4; ++k) { xh.w[k] = Hp[k]; xe.w[k] = Ep[k]; }
+                *reinterpret_cast<MVec8h*>(Hm + col_at) = xh; *reinterpret_cast<MVec8h*>(Em + col_at) = xe;      // (col_at: this lane's vector of column c, kept as a running sum)
                 in_band += (unsigned long long)band_cells;
             }
             if (lane == 0) front[c] = (uint16_t)(live ? (sb | (eb << 8)) : 0u);
@@ -628,7 +637,7 @@ VGK_HD void xdrop_band_pk_lane(const GsswMatrixParams& P, uint32_t pi, uint32_t 
             fmax = colmax > fmax ? colmax : fmax;
             front_live = live != 0;
             if (colmax > best) { best = colmax; best_c = (int32_t)c; best_v = (int32_t)v; best_sb = sb; best_eb = eb; }
-            ++c;
+            ++c; col_at += (uint32_t)stride;
             if (c < pb.R) { if (c - stage_base >= stage_cap) refill(c); ref_cur = stage[c - stage_base]; }      // (the columns of a problem are visited in ascending order)
         }
     }
@@ -639,7 +648,7 @@ VGK_HD void xdrop_band_pk_lane(const GsswMatrixParams& P, uint32_t pi, uint32_t 
     const int32_t best_true = best - (int32_t)XBP_OFF;
     int32_t best_i = 0x7fffffff;
     xl.fence();
-    const XbPlane<int16_t> H{Hm};
+    const XbPlane<uint16_t> H{Hm};
     if (best_c >= 0) for (int32_t i = (int32_t)(8u * best_sb + lane); i < rows && i < (int32_t)(8u * best_eb); i += (int32_t)xl.width()) if (H.get((uint64_t)best_c * (uint64_t)stride + i) == best_true && i < best_i) best_i = i;
     best_i = -xl.reduce_max(-best_i);
     if (lane == 0) { pb_out.best = best_true; pb_out.best_c = best_c; pb_out.best_v = best_v; pb_out.best_i = best_i; }
@@ -783,7 +792,7 @@ VGK_HD void xdrop_band_walk_one_t(const GsswMatrixParams& P, uint32_t pi) {
     P.xb_results[pi] = res;
 }
 VGK_HD void xdrop_band_walk_one(const GsswMatrixParams& P, uint32_t pi) {
-    if (P.xb_cell16) xdrop_band_walk_one_t<int16_t>(P, pi); else xdrop_band_walk_one_t<int32_t>(P, pi);
+    if (P.xb_cell16 == 2) xdrop_band_walk_one_t<uint16_t>(P, pi); else if (P.xb_cell16) xdrop_band_walk_one_t<int16_t>(P, pi); else xdrop_band_walk_one_t<int32_t>(P, pi);
 }
 
 }  // namespace vgk
