@@ -408,12 +408,20 @@ public:
                 }
             }
             band_walks += P.n_problems;
+        } else if (walk && P.walk_passes == 2) {                 // the two kernels of the device: diagonal runs alone, then the reads on the miss list
+            for (uint32_t i = 0; i < P.n_problems; ++i) walk_first_one(P, i, P.best[i]);
+            const uint32_t n_missed = *tb_miss_count(P);
+            for (uint32_t km = 0; km < n_missed; ++km) { const uint32_t i = tb_miss_list(P)[km]; walk_one(P, i, P.best[i]); }
+            walk_first_settled += P.n_problems - n_missed; walk_first_missed += n_missed;
         } else if (walk) for (uint32_t i = 0; i < P.n_problems; ++i) walk_one(P, i, P.best[i]);
         return VGK_OK;
     }
-    unsigned long long band_misses = 0, band_walks = 0;
-    ~EmuBackend() override { if (std::getenv("VGAMD_EMU_STATS") && band_walks) std::fprintf(stderr, "[emu] band walks %llu, left their band %llu\n", band_walks, band_misses); }
-    double last_ms(int which) const override { return which == 2 ? 1.0 : which == 8 ? (double)band_misses : which == 9 ? (double)band_walks : 0.0; }
+    unsigned long long band_misses = 0, band_walks = 0, walk_first_settled = 0, walk_first_missed = 0;
+    ~EmuBackend() override {
+        if (std::getenv("VGAMD_EMU_STATS") && band_walks) std::fprintf(stderr, "[emu] band walks %llu, left their band %llu\n", band_walks, band_misses);
+        if (std::getenv("VGAMD_EMU_STATS") && walk_first_settled + walk_first_missed) std::fprintf(stderr, "[emu] two-pass walks: %llu settled by diagonal runs, %llu by their codes\n", walk_first_settled, walk_first_missed);
+    }
+    double last_ms(int which) const override { return which == 2 ? 1.0 : which == 8 ? (double)band_misses : which == 9 ? (double)band_walks : which == 10 ? (double)walk_first_settled : which == 11 ? (double)walk_first_missed : 0.0; }
 };
 
 Backend* make_backend(int, std::string&) { return new EmuBackend(); }

@@ -115,3 +115,18 @@ def every_lane_geometry(lib):
 
 def test_emulated_kernel_matches_oracle_in_every_lane_geometry(emu_lib):
     every_lane_geometry(emu_lib)
+
+
+# The tracebacks of a batch of local alignments run as two kernels (GsswParams::walk_passes): every read by diagonal runs alone — the scores
+# along the diagonal subtracted from H at the run's end must arrive exactly at 0 or at a saved last-column H — then the reads that needed a
+# code.  The same alignments as the oracle's and as the one-kernel walk's.
+def test_two_pass_walk_matches_oracle_and_the_one_pass_walk(emu_lib, monkeypatch):
+    rng = np.random.default_rng(77)
+    problems = [random_problem(rng, mode=capi.VGK_GSSW_LOCAL, max_nodes=12, max_node_len=20, max_read=120, with_n=0.03) for _ in range(1300)]
+    problems += [random_problem(rng, mode=capi.VGK_XDROP_PINNED) for _ in range(100)] + [random_problem(rng, mode=capi.VGK_GSSW_PINNED) for _ in range(100)]
+    for sc in (None, capi.Scoring.simple(1, 1, 1, 1, 5), capi.Scoring.simple(2, 3, 5, 2, 0)):          # (equal mismatch and gap costs: ties at nearly every cell)
+        two = compare(emu_lib, ORACLE_LIB, problems, sc)
+        monkeypatch.setenv("VGAMD_WALK_ONE_PASS", "1")
+        one = compare(emu_lib, ORACLE_LIB, problems, sc)
+        monkeypatch.delenv("VGAMD_WALK_ONE_PASS")
+        assert (two["score"] == one["score"]).all() and (two["n_ops"] == one["n_ops"]).all()

@@ -151,6 +151,21 @@ __global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P, cons
     const uint32_t i = P.order[k];
     if (i != 0xffffffffu) walk_one(P, i, P.best[i]);
 }
+// The tracebacks as two kernels (GsswParams::walk_passes == 2): every read by diagonal runs alone; then the reads that needed a code — one in
+// eight on the headline batch — side by side, so that the wavefronts of the first kernel are never held by a lane that walks cell by cell
+__global__ __launch_bounds__(256) void gssw_walk_first_kernel(const GsswParams P, const int in_fill_order) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!in_fill_order) { if (k < P.n_problems) walk_first_one(P, k, P.best[k]); return; }
+    if (k >= 2u * P.n_pairs) return;
+    const uint32_t i = P.order[k];
+    if (i != 0xffffffffu) walk_first_one(P, i, P.best[i]);
+}
+__global__ __launch_bounds__(256) void gssw_walk_missed_kernel(const GsswParams P) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *tb_miss_count(P)) return;
+    const uint32_t i = tb_miss_list(P)[k];
+    walk_one(P, i, P.best[i]);
+}
 
 // TB_REWALK (gssw_device.hpp), first the band: the fill's wavefronts again — same grid, same lane <-> (pair, lane block) map — each lane over
 // the band columns of its lane block with the code-building lane code; no lane talks to another (the rows above come from HBM).
@@ -1044,7 +1059,13 @@ public:
         if (p.scale == 8) hipLaunchKernelGGL((gssw_band_kernel<K, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_band_kernel<K, false>), grid, block, 0, stream, p);
     }
     void launch_walk(const GsswParams& p0, const FillLaunch* launches, uint32_t n, hipStream_t stream) {
-        if (p0.tb_mode != TB_REWALK) { hipLaunchKernelGGL(gssw_walk_kernel, dim3((2 * p0.n_pairs + 255) / 256), dim3(256), 0, stream, p0, walk_in_fill_order ? 1 : 0); return; }
+        if (p0.tb_mode != TB_REWALK) {
+            if (p0.walk_passes == 2) {
+                hipLaunchKernelGGL(gssw_walk_first_kernel, dim3((2 * p0.n_pairs + 255) / 256), dim3(256), 0, stream, p0, walk_in_fill_order ? 1 : 0);
+                hipLaunchKernelGGL(gssw_walk_missed_kernel, dim3((p0.n_problems + 255) / 256), dim3(256), 0, stream, p0);      // (lanes beyond the list's end leave at once)
+            } else hipLaunchKernelGGL(gssw_walk_kernel, dim3((2 * p0.n_pairs + 255) / 256), dim3(256), 0, stream, p0, walk_in_fill_order ? 1 : 0);
+            return;
+        }
         GsswParams p = p0;
         for (uint32_t i = 0; i < n; ++i) {                              // the band records of every fill launch's wavefronts
             if (!launches[i].wave_count) continue;

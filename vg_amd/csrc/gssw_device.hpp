@@ -114,6 +114,7 @@ struct GsswParams {
     uint32_t go, ge;
     int32_t  bonus;             // full-length bonus (plain contexts; per-read values live in ProbDesc)
     int32_t  want_tb;           // any problem wants traceback -> store codes
+    int32_t  walk_passes;       // 2: the tracebacks run as two kernels — walk_diag_one for every read (whole alignments that are one diagonal run, from the read's and the columns' bytes alone), then walk_one for the reads it left on the miss list; 1: walk_one for all
     int32_t  tb_mode;           // TB_CODES: the fill stores a 4-bit code per cell; TB_REWALK: it stores what the traceback needs to compute them again
                                 // where the path runs (see "the traceback that does not tax the fill" below)
     int32_t  dbg;               // timing experiments (VGAMD_TB_DBG; results are wrong when set): 1 = the band kernel stops after its first column, 2 = it stores nothing
@@ -726,6 +727,90 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
     const ProbDesc d = P.probs[i];      // by value: keeps the descriptor in registers across the walk's global stores
     Walker w{P, d, (d.geom >> 16) & 1u, d.lane0, d.geom & 0xffu, P.waves[d.wave].tb_off, 0u, 0xffffffffu, 0u, 0xffffffffu};
     walk_body(P, i, d, w, best_key);
+}
+
+// ---- the first of two passes over a batch of local alignments (GsswParams::walk_passes == 2; round 4) -----------------------------------
+// The cell-by-cell walk is bound by the rate at which HBM answers scattered requests (§25: ~830 per loop iteration of a wavefront, ~250 per
+// read); most alignments of short reads, though, are ONE diagonal run, and such a traceback need not be walked to be known.  H(r, c) >=
+// H(r - 1, c - 1) + s(r, c) at every cell, and H >= 0: if subtracting the scores along the diagonal from H at the end cell arrives EXACTLY at 0
+// without undercutting it on the way, every one of those inequalities is an equality, the diagonal is an optimal source at every cell of
+// the run, and the traceback — which prefers the diagonal among equals (lane_row's tag order) and stops where H is 0 — is that run.  The
+// scores need only the read's and the columns' bytes: the 160 of each before the end cell are fetched as ten 16-byte words apiece, all asked
+// for at once, and the run is checked out of registers; nothing else is read but the descriptor, the end cell's key and two node records.
+// What this pass does not settle — a gap, a node on the way with other predecessors than the node before it (CI_SEED_SLOW), the window's edge,
+// quality-adjusted profiles, pinned and X-drop problems, reads of more than 160 bases — it leaves alone: W_MISSED, and walk_one does the read.
+constexpr uint32_t WD_STEPS = 160;
+struct alignas(16) WdBlock { uint32_t w[WD_STEPS / 4]; };
+VGK_HD uint32_t wd_byte(const WdBlock& b, uint32_t k) { return (b.w[k >> 2] >> (8u * (k & 3u))) & 0xffu; }      // (k a compile-time constant wherever it matters)
+VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
+    const ProbDesc d = P.probs[i];
+    const uint32_t mode = d.flags & 15u;
+    if (mode != VGK_GSSW_LOCAL || d.prof_off != 0xffffffffu || d.L > WD_STEPS) return W_MISSED;
+    const int32_t S = (int32_t)P.scale;
+    const NodeRec* nodes = P.nodes + d.node_off;
+    int32_t cur = 0; uint32_t c = 0, node = 0; int32_t r = 0;
+    const bool have = walk_end_cell(P, d, best_key, [&](const NodeRec&, uint32_t) { return 0u; }, cur, c, node, r);
+    if (have && cur >= 2047 * S) return W_MISSED;                       // (the overflow answer is walk_body's)
+    vgk_result res;
+    res.score = 0; res.status = VGK_OK; res.end_node = -1; res.end_offset = -1; res.end_read = -1; res.first_offset = 0; res.n_ops = 0; res.ops_begin = d.ops_off;
+    if (!have || cur <= 0) { P.results[i] = res; return VGK_OK; }
+    const uint32_t end_start = nodes[node].col_start;
+    res.score = cur / S; res.end_node = (int32_t)node; res.end_offset = (int32_t)(c - end_start); res.end_read = r;
+    if (!(d.flags & VGK_GSSW_TRACEBACK)) { P.results[i] = res; return VGK_OK; }
+    // the 160 bytes that end with the end cell's row / column (step k of the run is byte 159 - k); a block that would start before its arena
+    // is not asked for — the first read of a batch
+    const uint32_t r_at = d.read_off + (uint32_t)r, c_at = d.col_off + c;
+    if (r_at + 1u < WD_STEPS || c_at + 1u < WD_STEPS) return W_MISSED;
+    WdBlock rb, cb;
+    __builtin_memcpy(&rb, P.reads + (r_at + 1u - WD_STEPS), WD_STEPS);
+    __builtin_memcpy(&cb, P.colinfo + (c_at + 1u - WD_STEPS), WD_STEPS);
+    vgk_op* ops = P.ops + d.ops_off;
+    uint32_t pos = d.ops_cap;
+    bool room_ok = true;
+    auto put = [&](uint32_t nd, uint32_t op, uint32_t len) { if (pos == 0) { room_ok = false; return; } --pos; ops[pos].node = nd; ops[pos].len = (uint16_t)len; ops[pos].op = (uint8_t)op; ops[pos].pad = 0; };
+    if (r < (int32_t)d.L - 1) put(node, VGK_OP_S, d.L - 1 - (uint32_t)r);
+    // the run: v = what H must be at the next cell; (run_node, run_len) = the node being crossed and its cells so far
+    int32_t v = cur; uint32_t run_node = node, run_len = 0, taken = 0;
+    int verdict = 0;                                                  // 1: arrived at 0; -1: not settled here
+    const uint32_t max_steps = (uint32_t)r + 1u < c + 1u ? (uint32_t)r + 1u : c + 1u;      // cells on the diagonal inside the window
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 0; k < WD_STEPS; ++k) {
+        if (verdict) continue;
+        if (k >= max_steps) { verdict = -1; continue; }               // the window's edge before H reached 0: walk_body's business
+        const uint32_t ci = wd_byte(cb, WD_STEPS - 1u - k), q = wd_byte(rb, WD_STEPS - 1u - k), base = ci & CI_BASE_MASK;
+        const uint32_t row = (uint32_t)r - k;
+        int32_t sc = (int32_t)row_bonus(d.bonus_start, d.bonus_end, row, d.L);
+        if (base < 4u) {
+            uint32_t w = P.prof4[0];
+            w = q == 1 ? P.prof4[1] : w; w = q == 2 ? P.prof4[2] : w; w = q == 3 ? P.prof4[3] : w; w = q == 4 ? P.prof4[4] : w;
+            sc += (int32_t)((w >> (8u * base)) & 0xffu) - (int32_t)P.bias;
+        }
+        v -= sc; ++run_len; ++taken;
+        if (v == 0) { verdict = 1; continue; }
+        if (v < 0) { verdict = -1; continue; }
+        if (ci & CI_NODE_START) {                                      // on into the node before this one — if that is its only predecessor
+            if ((ci & CI_SEED_SLOW) || run_node == 0u) { verdict = -1; continue; }
+            put(run_node, VGK_OP_M, run_len);
+            run_node -= 1u; run_len = 0;
+        }
+    }
+    if (verdict != 1 || !room_ok) return W_MISSED;
+    put(run_node, VGK_OP_M, run_len);
+    const int32_t r_left = r - (int32_t)taken;                        // rows above the alignment: a soft clip
+    if (r_left >= 0) put(run_node, VGK_OP_S, (uint32_t)r_left + 1u);
+    if (!room_ok) return W_MISSED;
+    const uint32_t first_c = c - (taken - 1u);
+    res.n_ops = d.ops_cap - pos; res.ops_begin = d.ops_off + pos;
+    res.first_offset = (int32_t)(first_c - nodes[run_node].col_start);
+    P.results[i] = res;
+    return VGK_OK;
+}
+VGK_HD uint32_t* tb_miss_count(const GsswParams& P);
+VGK_HD void tb_miss_add(const GsswParams& P, uint32_t i);
+VGK_HD void walk_first_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
+    if (walk_diag_one(P, i, best_key) == W_MISSED) tb_miss_add(P, i);
 }
 
 // ---------------------------------------------------------------------------

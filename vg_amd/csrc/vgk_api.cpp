@@ -455,6 +455,9 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     P.fused = 0;
     if (const char* e = std::getenv("VGAMD_FUSED_TRACEBACK")) P.fused = std::atoi(e) ? 1 : 0;
     P.dbg = std::getenv("VGAMD_TB_DBG") ? std::atoi(std::getenv("VGAMD_TB_DBG")) : 0; P.tb_mode = default_tb_mode(P.fused, !all.far);
+    { uint32_t local_tb = 0;                                          // local alignments with a traceback: what the diagonal shortcut serves
+      for (uint32_t i = 0; i < n; ++i) local_tb += (problems[i].flags & (15u | VGK_GSSW_TRACEBACK)) == (uint32_t)(VGK_GSSW_LOCAL | VGK_GSSW_TRACEBACK) ? 1u : 0u;
+      P.walk_passes = (!P.fused && n >= 1024 && 2ull * local_tb >= n && !std::getenv("VGAMD_WALK_ONE_PASS")) ? 2 : 1; }
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = ops_total;
     if ((rc = ctx->be->sync_side())) return fail(rc);     // inputs are resident in HBM when pack returns (the uploads have their own stream)

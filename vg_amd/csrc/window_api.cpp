@@ -264,6 +264,10 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     P.scale = S; P.xoff = XOFF * S;
     P.want_tb = b->want_tb ? 1 : 0;
     P.fused = 0; P.dbg = std::getenv("VGAMD_TB_DBG") ? std::atoi(std::getenv("VGAMD_TB_DBG")) : 0; P.tb_mode = default_tb_mode(0, near_chain);
+    P.walk_passes = 1;
+    if (!on_device) { uint32_t local_tb = 0;                          // (windows that were made on the device are tails: X-drop)
+      for (uint32_t i = 0; i < n; ++i) local_tb += (problems[i].flags & (15u | VGK_GSSW_TRACEBACK)) == (uint32_t)(VGK_GSSW_LOCAL | VGK_GSSW_TRACEBACK) ? 1u : 0u;
+      if (n >= 1024 && 2ull * local_tb >= n && !std::getenv("VGAMD_WALK_ONE_PASS")) P.walk_passes = 2; }
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = T.tot[WS_OPS]; b->wave_steps = T.wave_steps;
     lap("done");
