@@ -409,7 +409,7 @@ public:
             }
             band_walks += P.n_problems;
         } else if (walk && P.walk_passes == 2) {                 // the two kernels of the device: diagonal runs alone, then the reads on the miss list
-            for (uint32_t i = 0; i < P.n_problems; ++i) walk_first_one(P, i, P.best[i]);
+            { uint32_t blk[2 * WD_DWORDS]; for (uint32_t i = 0; i < P.n_problems; ++i) walk_first_one(P, i, P.best[i], blk, 1); }
             const uint32_t n_missed = *tb_miss_count(P);
             for (uint32_t km = 0; km < n_missed; ++km) { const uint32_t i = tb_miss_list(P)[km]; walk_one(P, i, P.best[i]); }
             walk_first_settled += P.n_problems - n_missed; walk_first_missed += n_missed;

@@ -153,12 +153,13 @@ __global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P, cons
 }
 // The tracebacks as two kernels (GsswParams::walk_passes == 2): every read by diagonal runs alone; then the reads that needed a code — one in
 // eight on the headline batch — side by side, so that the wavefronts of the first kernel are never held by a lane that walks cell by cell
-__global__ __launch_bounds__(256) void gssw_walk_first_kernel(const GsswParams P, const int in_fill_order) {
+__global__ __launch_bounds__(64) void gssw_walk_first_kernel(const GsswParams P, const int in_fill_order) {
+    __shared__ uint32_t blk[2 * WD_DWORDS * 64];                   // a lane's 160 read bytes and 160 column bytes, dwords interleaved across the lanes
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (!in_fill_order) { if (k < P.n_problems) walk_first_one(P, k, P.best[k]); return; }
+    if (!in_fill_order) { if (k < P.n_problems) walk_first_one(P, k, P.best[k], blk + threadIdx.x, 64); return; }
     if (k >= 2u * P.n_pairs) return;
     const uint32_t i = P.order[k];
-    if (i != 0xffffffffu) walk_first_one(P, i, P.best[i]);
+    if (i != 0xffffffffu) walk_first_one(P, i, P.best[i], blk + threadIdx.x, 64);
 }
 __global__ __launch_bounds__(256) void gssw_walk_missed_kernel(const GsswParams P) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1061,7 +1062,7 @@ public:
     void launch_walk(const GsswParams& p0, const FillLaunch* launches, uint32_t n, hipStream_t stream) {
         if (p0.tb_mode != TB_REWALK) {
             if (p0.walk_passes == 2) {
-                hipLaunchKernelGGL(gssw_walk_first_kernel, dim3((2 * p0.n_pairs + 255) / 256), dim3(256), 0, stream, p0, walk_in_fill_order ? 1 : 0);
+                hipLaunchKernelGGL(gssw_walk_first_kernel, dim3((2 * p0.n_pairs + 63) / 64), dim3(64), 0, stream, p0, walk_in_fill_order ? 1 : 0);
                 hipLaunchKernelGGL(gssw_walk_missed_kernel, dim3((p0.n_problems + 255) / 256), dim3(256), 0, stream, p0);      // (lanes beyond the list's end leave at once)
             } else hipLaunchKernelGGL(gssw_walk_kernel, dim3((2 * p0.n_pairs + 255) / 256), dim3(256), 0, stream, p0, walk_in_fill_order ? 1 : 0);
             return;

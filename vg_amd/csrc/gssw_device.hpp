@@ -739,10 +739,11 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
 // for at once, and the run is checked out of registers; nothing else is read but the descriptor, the end cell's key and two node records.
 // What this pass does not settle — a gap, a node on the way with other predecessors than the node before it (CI_SEED_SLOW), the window's edge,
 // quality-adjusted profiles, pinned and X-drop problems, reads of more than 160 bases — it leaves alone: W_MISSED, and walk_one does the read.
-constexpr uint32_t WD_STEPS = 160;
-struct alignas(16) WdBlock { uint32_t w[WD_STEPS / 4]; };
-VGK_HD uint32_t wd_byte(const WdBlock& b, uint32_t k) { return (b.w[k >> 2] >> (8u * (k & 3u))) & 0xffu; }      // (k a compile-time constant wherever it matters)
-VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
+constexpr uint32_t WD_STEPS = 160, WD_DWORDS = WD_STEPS / 4;
+struct alignas(16) WdQuad { uint32_t x, y, z, w; };
+// blk: 2 x WD_DWORDS dwords of this lane's own, dword j at blk[j * stride] (the kernel: LDS, the lanes' dwords interleaved — held in registers the
+// 160 steps had to be unrolled to index them: 43 000 instructions, more than the instruction cache keeps)
+VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long best_key, uint32_t* blk, uint32_t stride) {
     const ProbDesc d = P.probs[i];
     const uint32_t mode = d.flags & 15u;
     if (mode != VGK_GSSW_LOCAL || d.prof_off != 0xffffffffu || d.L > WD_STEPS) return W_MISSED;
@@ -754,16 +755,20 @@ VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long
     vgk_result res;
     res.score = 0; res.status = VGK_OK; res.end_node = -1; res.end_offset = -1; res.end_read = -1; res.first_offset = 0; res.n_ops = 0; res.ops_begin = d.ops_off;
     if (!have || cur <= 0) { P.results[i] = res; return VGK_OK; }
+    // the 160 bytes that end with the end cell's row / column (step k of the run is byte 159 - k), asked for before anything that has to be
+    // waited for; a block that would start before its arena is not asked for — the first read of a batch
+    const uint32_t r_at = d.read_off + (uint32_t)r, c_at = d.col_off + c;
+    if (r_at + 1u < WD_STEPS || c_at + 1u < WD_STEPS) return W_MISSED;
+    { const uint8_t* rsrc = P.reads + (r_at + 1u - WD_STEPS); const uint8_t* csrc = P.colinfo + (c_at + 1u - WD_STEPS);
+      WdQuad rq[WD_DWORDS / 4], cq[WD_DWORDS / 4];
+      for (uint32_t j = 0; j < WD_DWORDS / 4; ++j) { __builtin_memcpy(&rq[j], rsrc + 16u * j, 16); __builtin_memcpy(&cq[j], csrc + 16u * j, 16); }
+      for (uint32_t j = 0; j < WD_DWORDS / 4; ++j) {
+          blk[(4u * j + 0u) * stride] = rq[j].x; blk[(4u * j + 1u) * stride] = rq[j].y; blk[(4u * j + 2u) * stride] = rq[j].z; blk[(4u * j + 3u) * stride] = rq[j].w;
+          blk[(WD_DWORDS + 4u * j + 0u) * stride] = cq[j].x; blk[(WD_DWORDS + 4u * j + 1u) * stride] = cq[j].y; blk[(WD_DWORDS + 4u * j + 2u) * stride] = cq[j].z; blk[(WD_DWORDS + 4u * j + 3u) * stride] = cq[j].w;
+      } }
     const uint32_t end_start = nodes[node].col_start;
     res.score = cur / S; res.end_node = (int32_t)node; res.end_offset = (int32_t)(c - end_start); res.end_read = r;
     if (!(d.flags & VGK_GSSW_TRACEBACK)) { P.results[i] = res; return VGK_OK; }
-    // the 160 bytes that end with the end cell's row / column (step k of the run is byte 159 - k); a block that would start before its arena
-    // is not asked for — the first read of a batch
-    const uint32_t r_at = d.read_off + (uint32_t)r, c_at = d.col_off + c;
-    if (r_at + 1u < WD_STEPS || c_at + 1u < WD_STEPS) return W_MISSED;
-    WdBlock rb, cb;
-    __builtin_memcpy(&rb, P.reads + (r_at + 1u - WD_STEPS), WD_STEPS);
-    __builtin_memcpy(&cb, P.colinfo + (c_at + 1u - WD_STEPS), WD_STEPS);
     vgk_op* ops = P.ops + d.ops_off;
     uint32_t pos = d.ops_cap;
     bool room_ok = true;
@@ -773,13 +778,12 @@ VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long
     int32_t v = cur; uint32_t run_node = node, run_len = 0, taken = 0;
     int verdict = 0;                                                  // 1: arrived at 0; -1: not settled here
     const uint32_t max_steps = (uint32_t)r + 1u < c + 1u ? (uint32_t)r + 1u : c + 1u;      // cells on the diagonal inside the window
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (uint32_t k = 0; k < WD_STEPS; ++k) {
-        if (verdict) continue;
-        if (k >= max_steps) { verdict = -1; continue; }               // the window's edge before H reached 0: walk_body's business
-        const uint32_t ci = wd_byte(cb, WD_STEPS - 1u - k), q = wd_byte(rb, WD_STEPS - 1u - k), base = ci & CI_BASE_MASK;
+    uint32_t rw = 0, cw = 0;
+    for (uint32_t k = 0; k < WD_STEPS && !verdict; ++k) {
+        if (k >= max_steps) { verdict = -1; break; }                  // the window's edge before H reached 0: walk_body's business
+        const uint32_t at = WD_STEPS - 1u - k;
+        if ((at & 3u) == 3u || k == 0) { rw = blk[(at >> 2) * stride]; cw = blk[(WD_DWORDS + (at >> 2)) * stride]; }
+        const uint32_t ci = (cw >> (8u * (at & 3u))) & 0xffu, q = (rw >> (8u * (at & 3u))) & 0xffu, base = ci & CI_BASE_MASK;
         const uint32_t row = (uint32_t)r - k;
         int32_t sc = (int32_t)row_bonus(d.bonus_start, d.bonus_end, row, d.L);
         if (base < 4u) {
@@ -788,12 +792,11 @@ VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long
             sc += (int32_t)((w >> (8u * base)) & 0xffu) - (int32_t)P.bias;
         }
         v -= sc; ++run_len; ++taken;
-        if (v == 0) { verdict = 1; continue; }
-        if (v < 0) { verdict = -1; continue; }
-        if (ci & CI_NODE_START) {                                      // on into the node before this one — if that is its only predecessor
-            if ((ci & CI_SEED_SLOW) || run_node == 0u) { verdict = -1; continue; }
-            put(run_node, VGK_OP_M, run_len);
-            run_node -= 1u; run_len = 0;
+        if (v == 0) verdict = 1;
+        else if (v < 0) verdict = -1;
+        else if (ci & CI_NODE_START) {                                 // on into the node before this one — if that is its only predecessor
+            if ((ci & CI_SEED_SLOW) || run_node == 0u) verdict = -1;
+            else { put(run_node, VGK_OP_M, run_len); run_node -= 1u; run_len = 0; }
         }
     }
     if (verdict != 1 || !room_ok) return W_MISSED;
@@ -809,8 +812,8 @@ VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long
 }
 VGK_HD uint32_t* tb_miss_count(const GsswParams& P);
 VGK_HD void tb_miss_add(const GsswParams& P, uint32_t i);
-VGK_HD void walk_first_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
-    if (walk_diag_one(P, i, best_key) == W_MISSED) tb_miss_add(P, i);
+VGK_HD void walk_first_one(const GsswParams& P, uint32_t i, unsigned long long best_key, uint32_t* blk, uint32_t stride) {
+    if (walk_diag_one(P, i, best_key, blk, stride) == W_MISSED) tb_miss_add(P, i);
 }
 
 // ---------------------------------------------------------------------------
