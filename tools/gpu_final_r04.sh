@@ -1,6 +1,6 @@
 # round 4 closing run: the whole -m gpu suite, smoke(), and the driver's bench command with its secondary records
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r04_final; mkdir -p $O
-timeout -s KILL 1200 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
+cd $GRAFT_REPO_ROOT; O=$GRAFT_REPO_ROOT/gpurun_out/r04_final; mkdir -p $O
+timeout -s KILL 1200 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1 < /dev/null; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
 timeout -s KILL 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -2 $O/smoke.log | cut -c1-300
 t0=$(date +%s)
 timeout -s KILL 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_run.json 2> $O/bench_default_run.err; echo "bench rc=$? wall $(( $(date +%s) - t0 )) s"
