@@ -1218,7 +1218,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     one_stream = {"ms_per_step": 1e3 * elapsed / args.steps, "fill_ms": sum(fill_ms) / len(fill_ms), "traceback_ms": sum(walk_ms) / len(walk_ms),
-                  "reads_per_s": args.reads * world * args.steps / elapsed}
+                  "reads_per_s": args.reads * world * args.steps / elapsed,
+                  "traceback_kernels": ("one: gssw_walk_kernel (VGAMD_WALK_ONE_PASS)" if os.environ.get("VGAMD_WALK_ONE_PASS") or args.workload == "tails" else
+                                        "two: gssw_walk_first_kernel (alignments that are one diagonal run, settled from the read's and the columns' bytes) + gssw_walk_missed_kernel (the rest, by their codes) — DESIGN.md \u00a727.11")}
     # Steady state of a streaming caller: consecutive batches alternate between the context's two launch lanes (streams), so the
     # traceback of one batch — bound by memory latency — runs under the fill of the next — bound by VALU issue.  Two batches are
     # resident (the same reads packed twice); step i runs batch i mod 2; exactly K steps between the barriers.
