@@ -347,6 +347,7 @@ public:
                 for (uint32_t l = 0; l < 64; ++l) {
                     if ((t & 3u) == 0) lane_prefetch(lanes[l], P, t);
                     const uint32_t rh = l ? oh[l - 1] : 0, rf = l ? of[l - 1] : 0, ri = l ? oi[l - 1] : 0;
+                    if (P.spec_fill == 1) { lane_step<K, S8, false>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr); continue; }      // the speculative batch's first fill: no codes
                     if (P.tb_mode == TB_REWALK) {
                         lane_step<K, S8, false>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr);
                         if (P.want_tb) { lane_store_boundary<K>(lanes[l], P, wd, t, l); lane_store_checkpoint<K>(lanes[l], P, wd, t, l); }
@@ -410,16 +411,29 @@ public:
             band_walks += P.n_problems;
         } else if (walk && P.walk_passes == 2) {                 // the two kernels of the device: diagonal runs alone, then the reads on the miss list
             { uint32_t blk[2 * WD_DWORDS]; for (uint32_t i = 0; i < P.n_problems; ++i) walk_first_one(P, i, P.best[i], blk, 1); }
+            if (P.spec_fill) {                                    // the reads it left: wavefronts of their own, filled again with codes
+                const uint32_t gpw = 64u / P.refill_G, max_waves = (P.n_pairs + gpw - 1u) / gpw;
+                for (uint32_t w2 = 0; w2 < max_waves; ++w2) refill_layout_one(P, w2);
+                GsswParams P2 = P; P2.spec_fill = 2; P2.K = P.refill_K; P2.wave_begin = P.refill_wave0; P2.wave_count = P.refill_count[0];
+                switch (P2.K) {
+                    case 16: if (P2.scale == 8) fill<16, true>(P2); else fill<16, false>(P2); break;
+                    case 19: if (P2.scale == 8) fill<19, true>(P2); else fill<19, false>(P2); break;
+                    case 20: if (P2.scale == 8) fill<20, true>(P2); else fill<20, false>(P2); break;
+                    case 24: if (P2.scale == 8) fill<24, true>(P2); else fill<24, false>(P2); break;
+                    default: return VGK_EINVAL;
+                }
+                spec_refilled += P.refill_count[0];
+            }
             const uint32_t n_missed = *tb_miss_count(P);
             for (uint32_t km = 0; km < n_missed; ++km) { const uint32_t i = tb_miss_list(P)[km]; walk_one(P, i, P.best[i]); }
             walk_first_settled += P.n_problems - n_missed; walk_first_missed += n_missed;
         } else if (walk) for (uint32_t i = 0; i < P.n_problems; ++i) walk_one(P, i, P.best[i]);
         return VGK_OK;
     }
-    unsigned long long band_misses = 0, band_walks = 0, walk_first_settled = 0, walk_first_missed = 0;
+    unsigned long long band_misses = 0, band_walks = 0, walk_first_settled = 0, walk_first_missed = 0, spec_refilled = 0;
     ~EmuBackend() override {
         if (std::getenv("VGAMD_EMU_STATS") && band_walks) std::fprintf(stderr, "[emu] band walks %llu, left their band %llu\n", band_walks, band_misses);
-        if (std::getenv("VGAMD_EMU_STATS") && walk_first_settled + walk_first_missed) std::fprintf(stderr, "[emu] two-pass walks: %llu settled by diagonal runs, %llu by their codes\n", walk_first_settled, walk_first_missed);
+        if (std::getenv("VGAMD_EMU_STATS") && walk_first_settled + walk_first_missed) std::fprintf(stderr, "[emu] two-pass walks: %llu settled by diagonal runs, %llu by their codes (%llu wavefronts filled again)\n", walk_first_settled, walk_first_missed, spec_refilled);
     }
     double last_ms(int which) const override { return which == 2 ? 1.0 : which == 8 ? (double)band_misses : which == 9 ? (double)band_walks : which == 10 ? (double)walk_first_settled : which == 11 ? (double)walk_first_missed : 0.0; }
 };

@@ -130,3 +130,30 @@ def test_two_pass_walk_matches_oracle_and_the_one_pass_walk(emu_lib, monkeypatch
         one = compare(emu_lib, ORACLE_LIB, problems, sc)
         monkeypatch.delenv("VGAMD_WALK_ONE_PASS")
         assert (two["score"] == one["score"]).all() and (two["n_ops"] == one["n_ops"]).all()
+
+
+# The speculative fill (GsswParams::spec_fill): a batch of one geometry fills every read WITHOUT traceback codes, settles the alignments that
+# are one diagonal run from their end cells, lays the rest out as wavefronts of their own, fills those again with codes and walks them.
+def speculative_fill_equals_the_plain_one(lib, n, monkeypatch):
+    from vg_amd import workloads
+    wl = workloads.LinearWorkload(n, seed=43, sub_rate=0.02, indel_rate=0.004)      # uniform reads: one bucket; a third of them with an indel
+    sc = capi.Scoring.simple(1, 4, 6, 1, 5)
+    ro, oo = capi.Engine(sc, lib=ORACLE_LIB).align(wl, 0)
+    eng = capi.Engine(sc, lib=lib)
+    ra, oa = eng.align(wl, 0)                                                        # packed on the host (vgk_gssw_pack)
+    graph = eng.graph(*wl.graph_arrays())
+    with eng.pack_windows(graph, wl.windows(), 0) as b:                              # packed on the device (vgk_gssw_pack_windows)
+        b.run(); b.sync(); rw, ow = b.fetch()
+    monkeypatch.setenv("VGAMD_NO_SPEC_FILL", "1")
+    rp, op = capi.Engine(sc, lib=lib).align(wl, 0)
+    monkeypatch.delenv("VGAMD_NO_SPEC_FILL")
+    for name, (r, o) in (("host-packed", (ra, oa)), ("device-packed", (rw, ow)), ("plain", (rp, op))):
+        for f in ("status", "score", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
+            assert (r[f] == ro[f]).all(), (name, f)
+        for i in range(wl.n):
+            assert capi.cigar_string(r[i], o) == capi.cigar_string(ro[i], oo), (name, i)
+    return int((ro["score"] > 0).sum())
+
+
+def test_speculative_fill_matches_oracle(emu_lib, monkeypatch):
+    assert speculative_fill_equals_the_plain_one(emu_lib, 1200, monkeypatch) > 1100

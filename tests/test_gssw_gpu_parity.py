@@ -108,3 +108,16 @@ def test_hip_quality_adjusted_contexts_match_oracle_and_reference_vectors():
 def test_hip_matches_oracle_in_every_lane_geometry():
     from test_gssw_emu_parity import every_lane_geometry
     every_lane_geometry(ENGINE_LIB)
+
+
+@pytest.mark.gpu
+def test_hip_two_kernel_traceback_and_speculative_fill_match_oracle(monkeypatch):
+    """batches of local alignments: the tracebacks as two kernels (diagonal runs settled from the end cells; the rest by their codes) and, for
+    batches of one geometry, the fill without codes first and the missed reads filled again — equal to the oracle, host- and device-packed"""
+    from test_gssw_emu_parity import speculative_fill_equals_the_plain_one
+    assert speculative_fill_equals_the_plain_one(ENGINE_LIB, 20000, monkeypatch) > 19000
+    rng = np.random.default_rng(78)
+    problems = [random_problem(rng, mode=capi.VGK_GSSW_LOCAL, max_nodes=12, max_node_len=20, max_read=140, with_n=0.03) for _ in range(4000)]
+    problems += [random_problem(rng, mode=capi.VGK_XDROP_PINNED) for _ in range(300)] + [random_problem(rng, mode=capi.VGK_GSSW_PINNED) for _ in range(300)]
+    for sc in (None, capi.Scoring.simple(1, 1, 1, 1, 5), capi.Scoring.simple(2, 3, 5, 2, 0)):
+        compare(ENGINE_LIB, ORACLE_LIB, problems, sc)

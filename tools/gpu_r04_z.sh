@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT; O=$GRAFT_REPO_ROOT/gpurun_out/r04z; mkdir -p $O; export TMPDIR=/tmp
 timeout -s KILL 600 python -m pytest tests/test_gssw_gpu_parity.py tests/test_reference_tap.py tests/test_chain_alignment.py tests/test_giraffe_stage.py tests/test_alignment_batch.py -x -q -m gpu > $O/pytest.log 2>&1 < /dev/null; echo "pytest rc=$?"; tail -2 $O/pytest.log
-for v in two one; do
-  unset VGAMD_WALK_ONE_PASS; [ $v = one ] && export VGAMD_WALK_ONE_PASS=1
+for v in spec two one; do
+  unset VGAMD_WALK_ONE_PASS VGAMD_NO_SPEC_FILL; [ $v = one ] && export VGAMD_WALK_ONE_PASS=1; [ $v = two ] && export VGAMD_NO_SPEC_FILL=1
   timeout -s KILL 200 python bench.py --gpus 1 --steps 10 --warmup 3 --no-secondary > $O/bench_$v.json 2> $O/bench_$v.err < /dev/null; echo "bench rc=$?"
   timeout 30 python3 - <<PY
 import json

@@ -58,13 +58,15 @@ struct TbStage {
     }
 };
 
-template <int K, bool S8, bool REWALK>
+// CODES = false: the recurrence alone and nothing of a traceback (GsswParams::spec_fill's first fill)
+template <int K, bool S8, bool REWALK, bool CODES = true>
 __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const GsswParams P) {
     constexpr uint32_t REC = (K + 3) / 4;   // dwords per (step, lane) traceback record
     __shared__ __attribute__((aligned(16))) uint32_t stage_lds[4][REWALK ? 64u * TB_BND_CHUNK * 2u : (TB_TILE > 1 ? TbStage<K>::DWORDS : 256u)];      // (also the fused walk's best keys, below)
     const uint32_t wave = P.wave_begin + blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     if (wave >= P.wave_begin + P.wave_count) return;
+    if (P.wave_limit && wave - P.wave_begin >= *P.wave_limit) return;
     const WaveDesc wd = P.waves[wave];
     Lane<K> s;
     lane_init(s, P, wd, lane);
@@ -76,7 +78,9 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
         const uint32_t rh = from_lane_above(s.out_h);
         const uint32_t rf = from_lane_above(s.out_f);
         const uint32_t ri = from_lane_above(s.info);
-        if constexpr (REWALK) {
+        if constexpr (!CODES) {
+            lane_step<K, S8, false>(s, P, t, rh, rf, ri, nullptr, nullptr);
+        } else if constexpr (REWALK) {
             // the recurrence alone; what the traceback needs to run a window of it again (gssw_device.hpp, TB_REWALK)
             lane_step<K, S8, false>(s, P, t, rh, rf, ri, nullptr, nullptr);
             if (tb) {
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
         } else
             lane_step<K, S8>(s, P, t, rh, rf, ri, tb ? tb + tb_dword(wd.tb_off, t, lane, REC, 0) : nullptr, tb ? tb + tb_dword(wd.tb_off, t, lane, REC, 4) : nullptr);
     }
-    if (REWALK || !P.fused) {
+    if (REWALK || !CODES || !P.fused) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             uint32_t prob; unsigned long long key;
@@ -160,6 +164,9 @@ __global__ __launch_bounds__(64) void gssw_walk_first_kernel(const GsswParams P,
     if (k >= 2u * P.n_pairs) return;
     const uint32_t i = P.order[k];
     if (i != 0xffffffffu) walk_first_one(P, i, P.best[i], blk + threadIdx.x, 64);
+}
+__global__ __launch_bounds__(64) void gssw_refill_layout_kernel(const GsswParams P) {
+    refill_layout_one(P, blockIdx.x * blockDim.x + threadIdx.x);
 }
 __global__ __launch_bounds__(256) void gssw_walk_missed_kernel(const GsswParams P) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1036,6 +1043,10 @@ public:
     template <int K> int launch_fill_k(const GsswParams& p, hipStream_t stream) {
         const dim3 grid((p.wave_count + 3) / 4), block(256);
         const bool s8 = p.scale == 8, re = p.tb_mode == TB_REWALK;
+        if (p.spec_fill == 1) {                                      // the first fill of a speculative batch: no codes
+            if (s8) hipLaunchKernelGGL((gssw_fill_kernel<K, true, false, false>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<K, false, false, false>), grid, block, 0, stream, p);
+            return VGK_OK;
+        }
         if (re) { if (s8) hipLaunchKernelGGL((gssw_fill_kernel<K, true, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<K, false, true>), grid, block, 0, stream, p); }
         else    { if (s8) hipLaunchKernelGGL((gssw_fill_kernel<K, true, false>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<K, false, false>), grid, block, 0, stream, p); }
         return VGK_OK;
@@ -1063,6 +1074,15 @@ public:
         if (p0.tb_mode != TB_REWALK) {
             if (p0.walk_passes == 2) {
                 hipLaunchKernelGGL(gssw_walk_first_kernel, dim3((2 * p0.n_pairs + 63) / 64), dim3(64), 0, stream, p0, walk_in_fill_order ? 1 : 0);
+                if (p0.spec_fill) {
+                    // the reads the first kernel left: wavefronts of their own, filled again with codes (their number is a device-side fact:
+                    // the grids cover the most there can be, what lies beyond leaves at once)
+                    const uint32_t max_waves = (p0.n_pairs + 64u / p0.refill_G - 1u) / (64u / p0.refill_G);
+                    hipLaunchKernelGGL(gssw_refill_layout_kernel, dim3((max_waves + 63) / 64), dim3(64), 0, stream, p0);
+                    GsswParams p = p0;
+                    p.spec_fill = 2; p.K = p0.refill_K; p.wave_begin = p0.refill_wave0; p.wave_count = max_waves; p.wave_limit = p0.refill_count;
+                    launch_fill(p, stream);
+                }
                 hipLaunchKernelGGL(gssw_walk_missed_kernel, dim3((p0.n_problems + 255) / 256), dim3(256), 0, stream, p0);      // (lanes beyond the list's end leave at once)
             } else hipLaunchKernelGGL(gssw_walk_kernel, dim3((2 * p0.n_pairs + 255) / 256), dim3(256), 0, stream, p0, walk_in_fill_order ? 1 : 0);
             return;

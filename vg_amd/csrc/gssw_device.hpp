@@ -114,6 +114,16 @@ struct GsswParams {
     uint32_t go, ge;
     int32_t  bonus;             // full-length bonus (plain contexts; per-read values live in ProbDesc)
     int32_t  want_tb;           // any problem wants traceback -> store codes
+    // The speculative fill (spec_fill != 0; needs walk_passes == 2, one fill launch, one lanes-per-pair geometry): the fill of ALL reads builds
+    // no traceback codes (two thirds of the time); walk_diag_one settles the alignments that are one diagonal run from the end cells alone;
+    // the reads it leaves — the miss list — are laid out as wavefronts of their own behind the batch's (refill_layout_one), filled again
+    // WITH codes, and walked by them.  refill_wave0 / refill_pair0: where those wavefronts and their pairs start in waves[] / order[];
+    // refill_slot: traceback dwords per such wavefront (sized for the batch's widest window); refill_count[0]: how many there are (device).
+    int32_t  spec_fill;
+    uint32_t refill_wave0, refill_pair0, refill_G, refill_K;
+    unsigned long long refill_slot;
+    uint32_t* refill_count;
+    const uint32_t* wave_limit;  // a fill launch over wavefronts whose number only the device knows: wave_begin + *wave_limit is the end
     int32_t  walk_passes;       // 2: the tracebacks run as two kernels — walk_diag_one for every read (whole alignments that are one diagonal run, from the read's and the columns' bytes alone), then walk_one for the reads it left on the miss list; 1: walk_one for all
     int32_t  tb_mode;           // TB_CODES: the fill stores a 4-bit code per cell; TB_REWALK: it stores what the traceback needs to compute them again
                                 // where the path runs (see "the traceback that does not tax the fill" below)
@@ -1110,6 +1120,32 @@ VGK_HD void tb_miss_add(const GsswParams& P, uint32_t i) {
     const uint32_t k = (*tb_miss_count(P))++;
 #endif
     tb_miss_list(P)[k] = i;
+}
+// one wavefront of the second fill (GsswParams::spec_fill): the reads at [16 w2 .. ) of the miss list, two to a lane group as in the batch's own
+// wavefronts (vgk_api.cpp / gssw_pack_device.hpp build those); the reads' descriptors learn where their codes will lie
+VGK_HD void refill_layout_one(const GsswParams& P, uint32_t w2) {
+    const uint32_t M = *tb_miss_count(P), G = P.refill_G, gpw = 64u / G;
+    const uint32_t n_pairs2 = (M + 1u) / 2u, n_waves2 = (n_pairs2 + gpw - 1u) / gpw;
+    if (w2 == 0) P.refill_count[0] = n_waves2;
+    if (w2 >= n_waves2) return;
+    const uint32_t* list = tb_miss_list(P);
+    ProbDesc* probs = const_cast<ProbDesc*>(P.probs);                 // (the batch's own device array)
+    uint32_t* order = const_cast<uint32_t*>(P.order);
+    WaveDesc* waves = const_cast<WaveDesc*>(P.waves);
+    WaveDesc wd; wd.first_pair = P.refill_pair0 + w2 * gpw; wd.G = G; wd.pair_end = P.refill_pair0 + n_pairs2;
+    uint32_t rmax = 0;
+    for (uint32_t q = 0; q < gpw; ++q) for (uint32_t h = 0; h < 2u; ++h) {
+        const uint32_t k = 2u * (w2 * gpw + q) + h;
+        const uint32_t i = k < M ? list[k] : 0xffffffffu;
+        if (w2 * gpw + q < n_pairs2) order[2u * (size_t)P.refill_pair0 + k] = i;
+        if (i == 0xffffffffu) continue;
+        ProbDesc& d = probs[i];
+        rmax = d.R > rmax ? d.R : rmax;
+        d.wave = P.refill_wave0 + w2; d.lane0 = q * G; d.geom = P.refill_K | (G << 8) | (h << 16);
+    }
+    wd.n_steps = rmax ? rmax + G - 1u : 0u;
+    wd.tb_off = (unsigned long long)w2 * P.refill_slot;
+    waves[P.refill_wave0 + w2] = wd;
 }
 VGK_HD void bandwalk_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
     const ProbDesc d = P.probs[i];

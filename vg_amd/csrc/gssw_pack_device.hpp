@@ -64,6 +64,7 @@ struct WinTotals {               // one per pack, device memory, zeroed before t
     uint32_t max_rows, want_tb;
     uint32_t n_pairs, n_waves, n_buckets, n_launches;
     uint32_t launch_K[4], launch_begin[4], launch_count[4];
+    uint32_t max_steps, first_G;           // the longest wavefront's steps; lanes per pair of wavefront 0 (the speculative fill, window_api.cpp: with ONE bucket that is every wavefront's)
 };
 
 struct WinParams {
@@ -214,7 +215,8 @@ VGK_HD void win_wave_one(const WinParams& P, uint32_t w) {
             d.wave = w; d.lane0 = q * bk.G; d.geom = bk.K | (bk.G << 8) | (h << 16);
         }
     wd.n_steps = rmax ? rmax + bk.G - 1 : 0;
-    if (wd.n_steps) acc_add(&P.totals->wave_steps, wd.n_steps);
+    if (wd.n_steps) { acc_add(&P.totals->wave_steps, wd.n_steps); acc_max(&P.totals->max_steps, wd.n_steps); }
+    if (w == 0) P.totals->first_G = bk.G;
     P.waves[w] = wd;
     P.wave_tb[w] = P.want_tb ? (unsigned long long)tb_wave_dwords(wd.n_steps, bk.K) : 0ull;
 }

@@ -405,8 +405,19 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         buckets.push_back(bk);
         s0 = s1;
     }
-    std::vector<uint32_t> order((size_t)2 * n_pairs);        // pairs
-    std::vector<WaveDesc> waves(n_waves);
+    // The speculative fill (GsswParams::spec_fill): a batch of mostly local alignments with tracebacks, one fill launch, one lanes-per-pair
+    // geometry, on the stored-codes traceback.  Its first fill writes no codes; the traceback arena then only serves the wavefronts of the
+    // reads walk_diag_one leaves — sized for as many of them as there are wavefronts now, each as large as the widest window asks.
+    uint32_t local_tb = 0;
+    for (uint32_t i = 0; i < n; ++i) local_tb += (problems[i].flags & (15u | VGK_GSSW_TRACEBACK)) == (uint32_t)(VGK_GSSW_LOCAL | VGK_GSSW_TRACEBACK) ? 1u : 0u;
+    const bool fused_env = std::getenv("VGAMD_FUSED_TRACEBACK") && std::atoi(std::getenv("VGAMD_FUSED_TRACEBACK"));
+    const bool walk2 = !fused_env && n >= 1024 && 2ull * local_tb >= n && !std::getenv("VGAMD_WALK_ONE_PASS");
+    bool spec = walk2 && b->want_tb && buckets.size() == 1 && launches.size() == 1 && default_tb_mode(fused_env ? 1 : 0, !all.far) == TB_CODES && !std::getenv("VGAMD_NO_SPEC_FILL");
+    uint64_t refill_slot = 0;
+    if (spec) { uint32_t rmax_all = 0; for (uint32_t i = 0; i < n; ++i) rmax_all = std::max(rmax_all, probs[i].R);
+                refill_slot = tb_wave_dwords(rmax_all + buckets[0].G - 1, buckets[0].K); }
+    std::vector<uint32_t> order((size_t)(spec ? 4 : 2) * n_pairs, 0xffffffffu);        // pairs (the speculative fill's second half: the pairs of the wavefronts filled again)
+    std::vector<WaveDesc> waves((size_t)(spec ? 2 : 1) * n_waves);
     parallel_for(n_waves, [&](uint32_t w, unsigned) {
         size_t bi = 0;
         while (bi + 1 < buckets.size() && buckets[bi + 1].wave0 <= w) ++bi;
@@ -429,7 +440,9 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
         waves[w] = wd;
     });
     uint64_t tb_dwords = 0;
-    for (WaveDesc& wd : waves) { const uint64_t size = wd.tb_off; wd.tb_off = tb_dwords; tb_dwords += size; b->wave_steps += wd.n_steps; }
+    for (uint32_t w = 0; w < n_waves; ++w) { WaveDesc& wd = waves[w]; const uint64_t size = wd.tb_off; wd.tb_off = tb_dwords; tb_dwords += size; b->wave_steps += wd.n_steps; }
+    if (spec && (uint64_t)n_waves * refill_slot > tb_dwords + tb_dwords / 2) spec = false;      // windows of very different widths: the worst case would need half as much again
+    if (spec) tb_dwords = (uint64_t)n_waves * refill_slot;
 
     lap("waves");
     // the descriptors (their wave / lane fields are final now), the wavefronts and the order follow; the output arenas are allocated
@@ -442,6 +455,11 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     if ((rc = dev_alloc(b, (size_t)tb_best_entries(n), P.best))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)n + 1, P.results))) return fail(rc);
     if ((rc = dev_alloc(b, (size_t)ops_total + 1, P.ops))) return fail(rc);
+    P.spec_fill = 0; P.wave_limit = nullptr; P.refill_count = nullptr; P.refill_wave0 = P.refill_pair0 = P.refill_G = P.refill_K = 0; P.refill_slot = 0;
+    if (spec) {
+        if ((rc = dev_alloc(b, (size_t)4, P.refill_count))) return fail(rc);
+        P.spec_fill = 1; P.refill_wave0 = n_waves; P.refill_pair0 = n_pairs; P.refill_G = buckets[0].G; P.refill_K = buckets[0].K; P.refill_slot = refill_slot;
+    }
     lap("allocs");
     lk.unlock();
     if ((rc = issue_uploads())) return fail(rc);
@@ -455,9 +473,8 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     P.fused = 0;
     if (const char* e = std::getenv("VGAMD_FUSED_TRACEBACK")) P.fused = std::atoi(e) ? 1 : 0;
     P.dbg = std::getenv("VGAMD_TB_DBG") ? std::atoi(std::getenv("VGAMD_TB_DBG")) : 0; P.tb_mode = default_tb_mode(P.fused, !all.far);
-    { uint32_t local_tb = 0;                                          // local alignments with a traceback: what the diagonal shortcut serves
-      for (uint32_t i = 0; i < n; ++i) local_tb += (problems[i].flags & (15u | VGK_GSSW_TRACEBACK)) == (uint32_t)(VGK_GSSW_LOCAL | VGK_GSSW_TRACEBACK) ? 1u : 0u;
-      P.walk_passes = (!P.fused && n >= 1024 && 2ull * local_tb >= n && !std::getenv("VGAMD_WALK_ONE_PASS")) ? 2 : 1; }
+    P.walk_passes = walk2 && !P.fused ? 2 : 1;                          // (local alignments with a traceback: what walk_diag_one serves)
+    if (P.walk_passes != 2 || P.tb_mode != TB_CODES) P.spec_fill = 0;
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = ops_total;
     if ((rc = ctx->be->sync_side())) return fail(rc);     // inputs are resident in HBM when pack returns (the uploads have their own stream)

@@ -235,7 +235,7 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
         std::lock_guard<std::mutex> lk(ctx->mu);
         colinfo = (uint8_t*)take_keep(T.tot[WS_COLS] + 8); rd = (uint8_t*)take_keep(T.tot[WS_READS] + 8);
         nodes = (NodeRec*)take_keep((T.tot[WS_NODES] + 1) * sizeof(NodeRec)); preds = (uint32_t*)take_keep((T.tot[WS_PREDS] + 1) * 4);
-        waves = (WaveDesc*)take_keep((uint64_t)waves_cap * sizeof(WaveDesc)); order = (uint32_t*)take_keep(((uint64_t)waves_cap * 2 + 2) * 4);
+        waves = (WaveDesc*)take_keep((uint64_t)waves_cap * sizeof(WaveDesc)); order = (uint32_t*)take_keep(((uint64_t)waves_cap * 4 + 4) * 4);      // (order: the batch's pairs, and as many again for the wavefronts a speculative fill fills twice)
         rc = dev_alloc(b, (size_t)T.tot[WS_SCRATCH] + 16, P.scratch);
         if (!rc) rc = dev_alloc(b, (size_t)tb_best_entries(n), P.best);
         if (!rc) rc = dev_alloc(b, (size_t)n + 1, P.results);
@@ -249,11 +249,28 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     if ((rc = be->download_side(&T, W.totals, sizeof T))) return fail(rc);
     lap("stage 2 (order, waves, arenas)");
     if (T.n_waves > waves_cap || T.n_launches > 4) return fail(VGK_EINVAL);
+    // The speculative fill (GsswParams::spec_fill; vgk_api.cpp has the same rule for batches packed on the host): mostly local alignments
+    // with tracebacks, one launch, one lanes-per-pair geometry, stored codes.  The traceback arena then serves only the wavefronts that
+    // are filled a second time: as many as there are wavefronts now at most, each as large as the longest one.
+    uint32_t local_tb = 0;
+    if (!on_device) for (uint32_t i = 0; i < n; ++i) local_tb += (problems[i].flags & (15u | VGK_GSSW_TRACEBACK)) == (uint32_t)(VGK_GSSW_LOCAL | VGK_GSSW_TRACEBACK) ? 1u : 0u;
+    const bool walk2 = !on_device && n >= 1024 && 2ull * local_tb >= n && !std::getenv("VGAMD_WALK_ONE_PASS");
+    bool spec = walk2 && b->want_tb && T.n_launches == 1 && T.n_buckets == 1 && T.first_G && default_tb_mode(0, near_chain) == TB_CODES && 2ull * T.n_waves <= waves_cap &&
+                !std::getenv("VGAMD_NO_SPEC_FILL");
+    uint64_t refill_slot = 0, tb_dwords = T.tb_dwords;
+    if (spec) {
+        refill_slot = tb_wave_dwords(T.max_steps, T.launch_K[0]);
+        if ((uint64_t)T.n_waves * refill_slot > T.tb_dwords + T.tb_dwords / 2) spec = false;      // windows of very different widths
+        else tb_dwords = (uint64_t)T.n_waves * refill_slot;
+    }
+    P.spec_fill = 0; P.wave_limit = nullptr; P.refill_count = nullptr; P.refill_wave0 = P.refill_pair0 = P.refill_G = P.refill_K = 0; P.refill_slot = 0;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        rc = dev_alloc(b, (size_t)T.tb_dwords + 4, P.tb);
+        rc = dev_alloc(b, (size_t)tb_dwords + 4, P.tb);
+        if (!rc && spec) rc = dev_alloc(b, (size_t)4, P.refill_count);
     }
     if (rc) return fail(rc);
+    if (spec) { P.spec_fill = 1; P.refill_wave0 = T.n_waves; P.refill_pair0 = T.n_pairs; P.refill_G = T.first_G; P.refill_K = T.launch_K[0]; P.refill_slot = refill_slot; }
     for (uint32_t k = 0; k < T.n_launches; ++k) b->launches.push_back(FillLaunch{T.launch_K[k], T.launch_begin[k], T.launch_count[k]});
     P.probs = W.probs; P.colinfo = colinfo; P.reads = rd; P.prof = nullptr; P.nodes = nodes; P.preds = preds; P.waves = waves; P.order = order;
     P.wave_begin = 0; P.wave_count = 0; P.K = 0;
@@ -264,10 +281,8 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     P.scale = S; P.xoff = XOFF * S;
     P.want_tb = b->want_tb ? 1 : 0;
     P.fused = 0; P.dbg = std::getenv("VGAMD_TB_DBG") ? std::atoi(std::getenv("VGAMD_TB_DBG")) : 0; P.tb_mode = default_tb_mode(0, near_chain);
-    P.walk_passes = 1;
-    if (!on_device) { uint32_t local_tb = 0;                          // (windows that were made on the device are tails: X-drop)
-      for (uint32_t i = 0; i < n; ++i) local_tb += (problems[i].flags & (15u | VGK_GSSW_TRACEBACK)) == (uint32_t)(VGK_GSSW_LOCAL | VGK_GSSW_TRACEBACK) ? 1u : 0u;
-      if (n >= 1024 && 2ull * local_tb >= n && !std::getenv("VGAMD_WALK_ONE_PASS")) P.walk_passes = 2; }
+    P.walk_passes = walk2 ? 2 : 1;                                    // (windows that were made on the device are tails: X-drop)
+    if (P.walk_passes != 2 || P.tb_mode != TB_CODES) P.spec_fill = 0;
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = T.tot[WS_OPS]; b->wave_steps = T.wave_steps;
     lap("done");
