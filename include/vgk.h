@@ -562,7 +562,9 @@ int    vgk_wfa_set_cost_hints(vgk_ctx* ctx, const uint32_t* extra_bases, uint32_
 void     vgk_batch_free(vgk_batch* batch);
 int      vgk_batch_sync(vgk_batch* batch);
 double   vgk_batch_kernel_ms(vgk_batch* batch, int which /* 0 = fill kernels (sum over launches), 1 = traceback tail after the last
-                                                               fill, 2 = number of fill launches, -1 = fill + traceback */);
+                                                               fill, 2 = number of fill launches, -1 = fill + traceback; 3 = inside the traceback tail, the second fill of a speculative batch — one
+                                                               geometry, mostly local alignments: the first fill builds no traceback codes, the reads whose alignment is not one
+                                                               diagonal run are laid out again and filled with codes — 0 for other batches */);
 uint64_t vgk_batch_cells(vgk_batch* batch);          /* DP cells computed per run            */
 uint64_t vgk_batch_alg_bytes(vgk_batch* batch);      /* algorithmic bytes per run */
 uint64_t vgk_batch_device_bytes(vgk_batch* batch);   /* HBM footprint of the batch            */

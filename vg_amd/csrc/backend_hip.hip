@@ -917,6 +917,7 @@ public:
                                                                                      // runs beside a fill — no faster than one stream (the traceback takes the fill's wave slots); off
     hipDeviceProp_t prop;
     float ms_fill = 0.f, ms_walk = 0.f; bool timed_walk = false, pending = false;
+    hipEvent_t sev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; bool sev_set[2] = {false, false}; float ms_refill[2] = {0.f, 0.f};      // the speculative fill's second fill (layout + fill), per launch lane
     float ms_gapless = 0.f, ms_wfa = 0.f, ms_xband = 0.f;
     float ms_bfill = 0.f, ms_bwalk = 0.f; hipEvent_t bev[3] = {nullptr, nullptr, nullptr};
     hipEvent_t xbev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // run_xdrop_band_async: start / end per slot
@@ -929,6 +930,7 @@ public:
         for (auto& e : bev) if (e) hipEventDestroy(e);
         for (auto& pair : xbev) for (auto& e : pair) if (e) hipEventDestroy(e);
         for (auto& trio : bbev) for (auto& e : trio) if (e) hipEventDestroy(e);
+        for (auto& pair : sev) for (auto& e : pair) if (e) hipEventDestroy(e);
         if (scan_tmp) hipFree(scan_tmp);
         if (mz_slots) hipFree(mz_slots);
         for (int i = 0; i < 2; ++i) { if (side[i]) hipStreamDestroy(side[i]); if (side_done[i]) hipEventDestroy(side_done[i]); }
@@ -1070,7 +1072,8 @@ public:
         const dim3 grid((p.wave_count + 3) / 4), block(256);
         if (p.scale == 8) hipLaunchKernelGGL((gssw_band_kernel<K, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_band_kernel<K, false>), grid, block, 0, stream, p);
     }
-    void launch_walk(const GsswParams& p0, const FillLaunch* launches, uint32_t n, hipStream_t stream) {
+    void launch_walk(const GsswParams& p0, const FillLaunch* launches, uint32_t n, hipStream_t stream, int lane = 0) {
+        sev_set[lane] = false;
         if (p0.tb_mode != TB_REWALK) {
             if (p0.walk_passes == 2) {
                 hipLaunchKernelGGL(gssw_walk_first_kernel, dim3((2 * p0.n_pairs + 63) / 64), dim3(64), 0, stream, p0, walk_in_fill_order ? 1 : 0);
@@ -1078,10 +1081,13 @@ public:
                     // the reads the first kernel left: wavefronts of their own, filled again with codes (their number is a device-side fact:
                     // the grids cover the most there can be, what lies beyond leaves at once)
                     const uint32_t max_waves = (p0.n_pairs + 64u / p0.refill_G - 1u) / (64u / p0.refill_G);
+                    for (int k = 0; k < 2; ++k) if (!sev[lane][k]) hipEventCreate(&sev[lane][k]);
+                    hipEventRecord(sev[lane][0], stream);
                     hipLaunchKernelGGL(gssw_refill_layout_kernel, dim3((max_waves + 63) / 64), dim3(64), 0, stream, p0);
                     GsswParams p = p0;
                     p.spec_fill = 2; p.K = p0.refill_K; p.wave_begin = p0.refill_wave0; p.wave_count = max_waves; p.wave_limit = p0.refill_count;
                     launch_fill(p, stream);
+                    hipEventRecord(sev[lane][1], stream); sev_set[lane] = true;
                 }
                 hipLaunchKernelGGL(gssw_walk_missed_kernel, dim3((p0.n_problems + 255) / 256), dim3(256), 0, stream, p0);      // (lanes beyond the list's end leave at once)
             } else hipLaunchKernelGGL(gssw_walk_kernel, dim3((2 * p0.n_pairs + 255) / 256), dim3(256), 0, stream, p0, walk_in_fill_order ? 1 : 0);
@@ -1154,7 +1160,7 @@ public:
         hipEventRecord(fill_done[1], alt); fill_done_set[1] = true;
         timed_walk_b = walk && (!p.fused || p.tb_mode == TB_REWALK);
         if (timed_walk_b) {
-            launch_walk(p0, launches, n, alt);
+            launch_walk(p0, launches, n, alt, 1);
             hipEventRecord(evb[2], alt);
         }
         pending_b = true;
@@ -1162,6 +1168,14 @@ public:
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     double last_ms_on(int lane, int which) const override {
+        if (which == 12) {                                           // the second fill of a speculative batch (0 when the last run had none)
+            const int l = (lane == 1 && !lane1_on_main) ? 1 : 0;
+            HipBackend* self = const_cast<HipBackend*>(this);
+            if (!sev_set[l]) return 0.0;
+            hipSetDevice(dev); hipStreamSynchronize(l ? alt : stream);
+            float ms = 0.f; if (hipEventElapsedTime(&ms, sev[l][0], sev[l][1]) != hipSuccess) { (void)hipGetLastError(); ms = 0.f; }
+            self->ms_refill[l] = ms; return ms;
+        }
         if (lane != 1 || lane1_on_main || which > 2 || which < 0) return last_ms(which);
         HipBackend* self = const_cast<HipBackend*>(this);
         if (self->pending_b) {

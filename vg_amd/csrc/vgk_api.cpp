@@ -689,6 +689,7 @@ double vgk_batch_kernel_ms(vgk_batch* b, int which) {
     if (!b) return 0.0;
     std::lock_guard<std::mutex> lk(b->ctx->mu);
     if (which == 0 || which == 1 || which == 2) return b->ctx->be->last_ms_on(b->lane, which);
+    if (which == 3) return b->P.spec_fill ? b->ctx->be->last_ms_on(b->lane, 12) : 0.0;
     return b->ctx->be->last_ms_on(b->lane, 0) + b->ctx->be->last_ms_on(b->lane, 1);
 }
 uint64_t vgk_batch_cells(vgk_batch* b) { return b ? b->cells : 0; }
