@@ -435,7 +435,7 @@ public:
         if (std::getenv("VGAMD_EMU_STATS") && band_walks) std::fprintf(stderr, "[emu] band walks %llu, left their band %llu\n", band_walks, band_misses);
         if (std::getenv("VGAMD_EMU_STATS") && walk_first_settled + walk_first_missed) std::fprintf(stderr, "[emu] two-pass walks: %llu settled by diagonal runs, %llu by their codes (%llu wavefronts filled again)\n", walk_first_settled, walk_first_missed, spec_refilled);
     }
-    double last_ms(int which) const override { return which == 2 ? 1.0 : which == 8 ? (double)band_misses : which == 9 ? (double)band_walks : which == 10 ? (double)walk_first_settled : which == 11 ? (double)walk_first_missed : 0.0; }
+    double last_ms(int which) const override { return which == 2 ? 1.0 : which == 8 ? (double)band_misses : which == 9 ? (double)band_walks : which == 10 ? (double)walk_first_settled : which == 11 ? (double)walk_first_missed : which == 12 ? (double)spec_refilled : 0.0; }   // (12: wavefronts the speculative fill laid out again, all runs so far)
 };
 
 Backend* make_backend(int, std::string&) { return new EmuBackend(); }

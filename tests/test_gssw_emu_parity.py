@@ -157,3 +157,36 @@ def speculative_fill_equals_the_plain_one(lib, n, monkeypatch):
 
 def test_speculative_fill_matches_oracle(emu_lib, monkeypatch):
     assert speculative_fill_equals_the_plain_one(emu_lib, 1200, monkeypatch) > 1100
+
+
+# The corners of the speculation: a batch in which NO read misses (the second fill covers nothing), one in which nearly every read does (the
+# refilled wavefronts are as many as the batch's own), the smallest batch that speculates (1 024 reads; one fewer does not), and the same batch
+# run three times (the miss list, the new wavefronts and their count are rebuilt by every run).  Under the emulator vgk_batch_kernel_ms(batch, 3) is the number of
+# wavefronts laid out again so far.
+@pytest.mark.parametrize("n,sub_rate,indel_rate", [(1100, 0.0, 0.0), (1100, 0.05, 0.05), (1024, 0.02, 0.004), (1023, 0.02, 0.004)])
+def test_speculative_fill_corner_batches_and_reruns(emu_lib, n, sub_rate, indel_rate):
+    from vg_amd import workloads
+    wl = workloads.LinearWorkload(n, seed=5, sub_rate=sub_rate, indel_rate=indel_rate)
+    sc = capi.Scoring.simple(1, 4, 6, 1, 5)
+    ro, oo = capi.Engine(sc, lib=ORACLE_LIB).align(wl, 0)
+    eng = capi.Engine(sc, lib=emu_lib)
+    graph = eng.graph(*wl.graph_arrays())
+    with eng.pack_windows(graph, wl.windows(), 0) as b:
+        refilled = []
+        for _ in range(3):
+            b.run(); b.sync(); refilled.append(b.kernel_ms(3))
+        r, o = b.fetch()
+    steps = np.diff([0.0] + refilled)
+    assert (steps == steps[0]).all()                                  # every run lays the same reads out again
+    if indel_rate == 0.0:
+        assert steps[0] <= 2                                           # exact copies: (nearly) every alignment is one diagonal run
+    if n == 1023:
+        assert steps[0] == 0                                           # below the threshold: one fill, with codes
+    elif indel_rate > 0.0:
+        assert steps[0] > 0
+    if indel_rate >= 0.05:
+        assert steps[0] >= n // 16 * 0.9                               # 150 bases at 5 % indels: hardly a read without one
+    for f in ("status", "score", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
+        assert (r[f] == ro[f]).all(), f
+    for i in range(wl.n):
+        assert capi.cigar_string(r[i], o) == capi.cigar_string(ro[i], oo), i
