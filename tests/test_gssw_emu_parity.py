@@ -190,3 +190,45 @@ def test_speculative_fill_corner_batches_and_reruns(emu_lib, n, sub_rate, indel_
         assert (r[f] == ro[f]).all(), f
     for i in range(wl.n):
         assert capi.cigar_string(r[i], o) == capi.cigar_string(ro[i], oo), i
+
+
+# ... and over DAGs with bubbles, several predecessors per node and predecessor lists in both orders (the linear workload above has chains
+# only): reads of 86-94 bases fall into one lanes-per-pair geometry and the graphs are of similar widths, so the batch speculates; the second fill of a LOCAL read stops behind its
+# end cell's column (refill_layout_one), which the other modes in the batch must not.
+def test_speculative_fill_over_random_dags(emu_lib, monkeypatch):
+    from gen import random_dag, random_walk_read
+    rng = np.random.default_rng(4242)
+    problems = []
+    while len(problems) < 1150:
+        nodes, preds = random_dag(rng, int(rng.integers(9, 15)), 22)
+        if not 110 <= sum(len(x) for x in nodes) <= 150:
+            continue
+        read = random_walk_read(rng, nodes, preds, int(rng.integers(86, 95)), sub=0.03, indel=0.004 if rng.random() < 0.7 else 0.03)
+        if not 86 <= len(read) <= 94:
+            continue
+        mode = capi.VGK_GSSW_LOCAL
+        pinning = None
+        if len(problems) % 9 == 8:                                       # a minority of the batch in the other modes
+            mode = capi.VGK_GSSW_PINNED if rng.random() < 0.5 else capi.VGK_XDROP_PINNED
+        p = {"read": read, "nodes": nodes, "preds": preds, "flags": mode | capi.VGK_GSSW_TRACEBACK, "pinning": None}
+        if mode == capi.VGK_GSSW_PINNED:
+            has_succ = [False] * len(nodes)
+            for pr in preds:
+                for q in pr:
+                    has_succ[q] = True
+            p["pinning"] = [0 if h else 1 for h in has_succ]
+        if mode == capi.VGK_XDROP_PINNED:
+            p["max_gap"] = int(rng.integers(0, 60))
+        problems.append(p)
+    ps = problem_set(problems)
+    for sc in (capi.Scoring.simple(1, 4, 6, 1, 5), capi.Scoring.simple(1, 1, 1, 1, 0)):
+        ro, oo = capi.Engine(sc, lib=ORACLE_LIB).align(ps, 0)
+        eng = capi.Engine(sc, lib=emu_lib)
+        with eng.pack(ps, 0) as b:
+            b.run(); b.sync()
+            assert b.kernel_ms(3) > 0, "the batch did not speculate (or no read missed)"
+            r, o = b.fetch()
+        for f in ("status", "score", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
+            assert (r[f] == ro[f]).all(), f
+        for i in range(ps.n):
+            assert capi.cigar_string(r[i], o) == capi.cigar_string(ro[i], oo), i

@@ -138,6 +138,24 @@ struct GsswParams {
 
 VGK_HD uint32_t rep2(uint32_t x) { return (x & 0xffffu) * 0x00010001u; }
 
+// The profile word of a read base — P.prof4[q], q per lane — chosen among five values in registers.  Written as a plain chain of selects over
+// P.prof4[...] it compiles into a choice between the words' ADDRESSES and a vector load per use (from the parameter block, or from a stack copy):
+// in the tracebacks' loops a dependent load per cell.  The empty asm makes the five values results of an instruction, which cannot be folded
+// back into a load.
+struct ProfWords {               // read base A, C, G, T, N: each the four biased scores against the graph's bases
+    uint32_t w0, w1, w2, w3, w4;
+    VGK_HD uint32_t of(uint32_t q) const {
+        uint32_t a = w0, b = w1, c = w2, e = w3, f = w4;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f));
+#endif
+        uint32_t w = a; w = q == 1 ? b : w; w = q == 2 ? c : w; w = q == 3 ? e : w; w = q == 4 ? f : w;
+        return w;
+    }
+    VGK_HD uint32_t of_row(uint32_t q) const { return q == 5 ? 0u : of(q); }      // (the fill's rows: code 5 = row 0 of an X-drop problem, which consumes nothing)
+};
+VGK_HD ProfWords prof_words(const GsswParams& P) { return ProfWords{P.prof4[0], P.prof4[1], P.prof4[2], P.prof4[3], P.prof4[4]}; }
+
 // gssw: start bonus on read base 0; end bonus on base L-1 unless pinned (src/aligner.cpp:401-402).
 // dozeu: one bonus, on consuming the last packed query base (row L-1 of the L = len+1 rows).
 // The host resolves which apply (and their quality-adjusted values) into ProbDesc::bonus_start / bonus_end.
@@ -193,12 +211,13 @@ VGK_HD void lane_init(Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint3
         if (s.probA != 0xffffffffu) s.ciA_n = *(const uint32_t*)(P.colinfo + s.colA);
         if (s.probB != 0xffffffffu) s.ciB_n = *(const uint32_t*)(P.colinfo + s.colB);
     }
+    const ProfWords pw = prof_words(P);
 #pragma unroll
     for (int m = 0; m < K; ++m) {
         const uint32_t row = s.g * K + m;
         uint32_t pa = 0, pb = 0;
-        if (row < s.LA) pa = poA != 0xffffffffu ? P.prof[poA + row] : P.prof4[P.reads[roA + row]] + 0x01010101u * row_bonus(s.bsA, s.beA, row, s.LA);
-        if (row < s.LB) pb = poB != 0xffffffffu ? P.prof[poB + row] : P.prof4[P.reads[roB + row]] + 0x01010101u * row_bonus(s.bsB, s.beB, row, s.LB);
+        if (row < s.LA) pa = poA != 0xffffffffu ? P.prof[poA + row] : pw.of_row(P.reads[roA + row]) + 0x01010101u * row_bonus(s.bsA, s.beA, row, s.LA);
+        if (row < s.LB) pb = poB != 0xffffffffu ? P.prof[poB + row] : pw.of_row(P.reads[roB + row]) + 0x01010101u * row_bonus(s.bsB, s.beB, row, s.LB);
         s.PA[m] = pa; s.PB[m] = pb; s.H[m] = 0; s.E[m] = 0;
     }
     s.out_h = 0; s.out_f = 0; s.info = CI_INVALID2; s.prev_rh = 0;
@@ -537,6 +556,7 @@ struct Walker {
     // aligned-dword caches of the read codes and the column-info bytes: the walk moves one
     // row / one column at a time, so each cached word serves up to four steps
     mutable uint32_t rd_word = 0, rd_base = 0xffffffffu, ci_word = 0, ci_base = 0xffffffffu;
+    const ProfWords pw = prof_words(P);
     VGK_HD uint32_t read_code(uint32_t r) const {
         const uint32_t a = d.read_off + r, b = a & ~3u;
         if (b != rd_base) { rd_base = b; rd_word = *(const uint32_t*)(P.reads + b); }
@@ -558,9 +578,7 @@ struct Walker {
             return (int32_t)((P.prof[d.prof_off + r] >> (8 * base)) & 0xffu) - (int32_t)P.bias;
         const uint32_t q = read_code(r);
         // profile word of read base q (wave-uniform table, per-thread select), byte = reference base
-        uint32_t w = P.prof4[0];
-        w = q == 1 ? P.prof4[1] : w; w = q == 2 ? P.prof4[2] : w; w = q == 3 ? P.prof4[3] : w; w = q == 4 ? P.prof4[4] : w;
-        return (int32_t)((w >> (8 * base)) & 0xffu) - (int32_t)P.bias + bonus;
+        return (int32_t)((pw.of(q) >> (8 * base)) & 0xffu) - (int32_t)P.bias + bonus;
     }
     VGK_HD uint32_t saved(const NodeRec& n, uint32_t r) const { return P.scratch[d.scratch_off + (uint32_t)n.slot * d.Lpad + r]; }
     VGK_HD int32_t saved_e(const NodeRec& n, uint32_t r) const {      // E for the next column, without the x8 build's "opened" tag
@@ -789,6 +807,7 @@ VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long
     int verdict = 0;                                                  // 1: arrived at 0; -1: not settled here
     const uint32_t max_steps = (uint32_t)r + 1u < c + 1u ? (uint32_t)r + 1u : c + 1u;      // cells on the diagonal inside the window
     uint32_t rw = 0, cw = 0;
+    const ProfWords pw = prof_words(P);
     for (uint32_t k = 0; k < WD_STEPS && !verdict; ++k) {
         if (k >= max_steps) { verdict = -1; break; }                  // the window's edge before H reached 0: walk_body's business
         const uint32_t at = WD_STEPS - 1u - k;
@@ -796,11 +815,7 @@ VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long
         const uint32_t ci = (cw >> (8u * (at & 3u))) & 0xffu, q = (rw >> (8u * (at & 3u))) & 0xffu, base = ci & CI_BASE_MASK;
         const uint32_t row = (uint32_t)r - k;
         int32_t sc = (int32_t)row_bonus(d.bonus_start, d.bonus_end, row, d.L);
-        if (base < 4u) {
-            uint32_t w = P.prof4[0];
-            w = q == 1 ? P.prof4[1] : w; w = q == 2 ? P.prof4[2] : w; w = q == 3 ? P.prof4[3] : w; w = q == 4 ? P.prof4[4] : w;
-            sc += (int32_t)((w >> (8u * base)) & 0xffu) - (int32_t)P.bias;
-        }
+        if (base < 4u) sc += (int32_t)((pw.of(q) >> (8u * base)) & 0xffu) - (int32_t)P.bias;
         v -= sc; ++run_len; ++taken;
         if (v == 0) verdict = 1;
         else if (v < 0) verdict = -1;
@@ -1140,7 +1155,15 @@ VGK_HD void refill_layout_one(const GsswParams& P, uint32_t w2) {
         if (w2 * gpw + q < n_pairs2) order[2u * (size_t)P.refill_pair0 + k] = i;
         if (i == 0xffffffffu) continue;
         ProbDesc& d = probs[i];
-        rmax = d.R > rmax ? d.R : rmax;
+        // a traceback never looks right of its end cell, and a LOCAL alignment's end cell is known (the first fill's best key): the second
+        // fill of such a read stops behind that column.  Its own best key is then the maximum over fewer cells — the same cell, first among
+        // equals as before — and atomicMax leaves best[] as it is.
+        uint32_t cols = d.R;
+        if ((d.flags & 15u) == (uint32_t)VGK_GSSW_LOCAL) {
+            const uint32_t c_e = 0xFFFFFu - (uint32_t)((P.best[i] >> 20) & 0xFFFFFu);
+            if (c_e + 1u < cols) cols = c_e + 1u;
+        }
+        rmax = cols > rmax ? cols : rmax;
         d.wave = P.refill_wave0 + w2; d.lane0 = q * G; d.geom = P.refill_K | (G << 8) | (h << 16);
     }
     wd.n_steps = rmax ? rmax + G - 1u : 0u;
