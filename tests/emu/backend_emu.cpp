@@ -410,7 +410,8 @@ public:
             }
             band_walks += P.n_problems;
         } else if (walk && P.walk_passes == 2) {                 // the two kernels of the device: diagonal runs alone, then the reads on the miss list
-            { uint32_t blk[2 * WD_DWORDS]; for (uint32_t i = 0; i < P.n_problems; ++i) walk_first_one(P, i, P.best[i], blk, 1); }
+            { uint32_t blk[2 * WD_DWORDS]; int16_t tab[WD_TAB]; for (uint32_t t = 0; t < WD_TAB; ++t) tab[t] = wd_table_entry(P, t);
+              for (uint32_t i = 0; i < P.n_problems; ++i) walk_first_one(P, i, P.best[i], blk, 1, tab); }
             if (P.spec_fill) {                                    // the reads it left: wavefronts of their own, filled again with codes
                 const uint32_t gpw = 64u / P.refill_G, max_waves = (P.n_pairs + gpw - 1u) / gpw;
                 for (uint32_t w2 = 0; w2 < max_waves; ++w2) refill_layout_one(P, w2);

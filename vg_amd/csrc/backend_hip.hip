@@ -159,11 +159,14 @@ __global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P, cons
 // eight on the headline batch — side by side, so that the wavefronts of the first kernel are never held by a lane that walks cell by cell
 __global__ __launch_bounds__(64) void gssw_walk_first_kernel(const GsswParams P, const int in_fill_order) {
     __shared__ uint32_t blk[2 * WD_DWORDS * 64];                   // a lane's 160 read bytes and 160 column bytes, dwords interleaved across the lanes
+    __shared__ int16_t tab[WD_TAB];
+    if (threadIdx.x < WD_TAB) tab[threadIdx.x] = wd_table_entry(P, threadIdx.x);
+    __syncthreads();
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (!in_fill_order) { if (k < P.n_problems) walk_first_one(P, k, P.best[k], blk + threadIdx.x, 64); return; }
+    if (!in_fill_order) { if (k < P.n_problems) walk_first_one(P, k, P.best[k], blk + threadIdx.x, 64, tab); return; }
     if (k >= 2u * P.n_pairs) return;
     const uint32_t i = P.order[k];
-    if (i != 0xffffffffu) walk_first_one(P, i, P.best[i], blk + threadIdx.x, 64);
+    if (i != 0xffffffffu) walk_first_one(P, i, P.best[i], blk + threadIdx.x, 64, tab);
 }
 __global__ __launch_bounds__(64) void gssw_refill_layout_kernel(const GsswParams P) {
     refill_layout_one(P, blockIdx.x * blockDim.x + threadIdx.x);

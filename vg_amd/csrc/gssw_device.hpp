@@ -771,7 +771,14 @@ constexpr uint32_t WD_STEPS = 160, WD_DWORDS = WD_STEPS / 4;
 struct alignas(16) WdQuad { uint32_t x, y, z, w; };
 // blk: 2 x WD_DWORDS dwords of this lane's own, dword j at blk[j * stride] (the kernel: LDS, the lanes' dwords interleaved — held in registers the
 // 160 steps had to be unrolled to index them: 43 000 instructions, more than the instruction cache keeps)
-VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long best_key, uint32_t* blk, uint32_t stride) {
+// tab: the scores of the run's cells, tab[8 q + (column byte & 7)] for read base q — 0 for the column bytes that are no base (wd_table fills
+// it: LDS in the kernel, so that a cell's score is one byte read instead of a choice among the profile words)
+constexpr uint32_t WD_TAB = 40;
+VGK_HD int16_t wd_table_entry(const GsswParams& P, uint32_t t) {
+    const uint32_t q = t >> 3, b = t & 7u;
+    return b < 4u ? (int16_t)((int32_t)((P.prof4[q] >> (8u * b)) & 0xffu) - (int32_t)P.bias) : (int16_t)0;
+}
+VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long best_key, uint32_t* blk, uint32_t stride, const int16_t* tab) {
     const ProbDesc d = P.probs[i];
     const uint32_t mode = d.flags & 15u;
     if (mode != VGK_GSSW_LOCAL || d.prof_off != 0xffffffffu || d.L > WD_STEPS) return W_MISSED;
@@ -802,28 +809,28 @@ VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long
     bool room_ok = true;
     auto put = [&](uint32_t nd, uint32_t op, uint32_t len) { if (pos == 0) { room_ok = false; return; } --pos; ops[pos].node = nd; ops[pos].len = (uint16_t)len; ops[pos].op = (uint8_t)op; ops[pos].pad = 0; };
     if (r < (int32_t)d.L - 1) put(node, VGK_OP_S, d.L - 1 - (uint32_t)r);
-    // the run: v = what H must be at the next cell; (run_node, run_len) = the node being crossed and its cells so far
-    int32_t v = cur; uint32_t run_node = node, run_len = 0, taken = 0;
+    // the run: v = what H must be at the next cell; run_node = the node being crossed, run_from = the cells taken when it was entered.
+    // A full-length bonus on the read's last base can only belong to the run's first cell (the rows go up from r), one on its first base
+    // only to the cell of row 0 — step r.
+    int32_t v = cur - (r + 1 == (int32_t)d.L ? (int32_t)d.bonus_end : 0);
+    uint32_t run_node = node, run_from = 0, taken = 0;
     int verdict = 0;                                                  // 1: arrived at 0; -1: not settled here
-    const uint32_t max_steps = (uint32_t)r + 1u < c + 1u ? (uint32_t)r + 1u : c + 1u;      // cells on the diagonal inside the window
+    uint32_t n_it = (uint32_t)r + 1u < c + 1u ? (uint32_t)r + 1u : c + 1u;      // cells on the diagonal inside the window ...
+    n_it = n_it < WD_STEPS ? n_it : WD_STEPS;                                      // ... and inside the blocks
     uint32_t rw = 0, cw = 0;
-    const ProfWords pw = prof_words(P);
-    for (uint32_t k = 0; k < WD_STEPS && !verdict; ++k) {
-        if (k >= max_steps) { verdict = -1; break; }                  // the window's edge before H reached 0: walk_body's business
+    for (uint32_t k = 0; k < n_it; ++k) {
         const uint32_t at = WD_STEPS - 1u - k;
         if ((at & 3u) == 3u || k == 0) { rw = blk[(at >> 2) * stride]; cw = blk[(WD_DWORDS + (at >> 2)) * stride]; }
-        const uint32_t ci = (cw >> (8u * (at & 3u))) & 0xffu, q = (rw >> (8u * (at & 3u))) & 0xffu, base = ci & CI_BASE_MASK;
-        const uint32_t row = (uint32_t)r - k;
-        int32_t sc = (int32_t)row_bonus(d.bonus_start, d.bonus_end, row, d.L);
-        if (base < 4u) sc += (int32_t)((pw.of(q) >> (8u * base)) & 0xffu) - (int32_t)P.bias;
-        v -= sc; ++run_len; ++taken;
-        if (v == 0) verdict = 1;
-        else if (v < 0) verdict = -1;
-        else if (ci & CI_NODE_START) {                                 // on into the node before this one — if that is its only predecessor
-            if ((ci & CI_SEED_SLOW) || run_node == 0u) verdict = -1;
-            else { put(run_node, VGK_OP_M, run_len); run_node -= 1u; run_len = 0; }
+        const uint32_t ci = (cw >> (8u * (at & 3u))) & 0xffu, q = (rw >> (8u * (at & 3u))) & 0xffu;
+        v -= (int32_t)tab[8u * q + (ci & CI_BASE_MASK)] + (k == (uint32_t)r ? (int32_t)d.bonus_start : 0);
+        ++taken;
+        if (v <= 0) { verdict = v == 0 ? 1 : -1; break; }
+        if (ci & CI_NODE_START) {                                      // on into the node before this one — if that is its only predecessor
+            if ((ci & CI_SEED_SLOW) || run_node == 0u) { verdict = -1; break; }
+            put(run_node, VGK_OP_M, taken - run_from); run_node -= 1u; run_from = taken;
         }
     }
+    const uint32_t run_len = taken - run_from;                        // (the window's edge or the blocks' before H reached 0: walk_body's business)
     if (verdict != 1 || !room_ok) return W_MISSED;
     put(run_node, VGK_OP_M, run_len);
     const int32_t r_left = r - (int32_t)taken;                        // rows above the alignment: a soft clip
@@ -837,8 +844,8 @@ VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long
 }
 VGK_HD uint32_t* tb_miss_count(const GsswParams& P);
 VGK_HD void tb_miss_add(const GsswParams& P, uint32_t i);
-VGK_HD void walk_first_one(const GsswParams& P, uint32_t i, unsigned long long best_key, uint32_t* blk, uint32_t stride) {
-    if (walk_diag_one(P, i, best_key, blk, stride) == W_MISSED) tb_miss_add(P, i);
+VGK_HD void walk_first_one(const GsswParams& P, uint32_t i, unsigned long long best_key, uint32_t* blk, uint32_t stride, const int16_t* tab) {
+    if (walk_diag_one(P, i, best_key, blk, stride, tab) == W_MISSED) tb_miss_add(P, i);
 }
 
 // ---------------------------------------------------------------------------
