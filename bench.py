@@ -219,6 +219,15 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
     for _ in range(3):
         res_p, ops_p = eng.banded_align(wl.bs)
     te = (time.perf_counter() - te) / 3
+    # ... with the geometry made by prepare() on the host threads (the path of round 3 and of graphs with empty nodes)
+    os.environ["VGAMD_BANDED_HOST_GEOMETRY"] = "1"
+    eng.banded_align(wl.bs)
+    th = time.perf_counter()
+    for _ in range(3):
+        res_h, ops_h = eng.banded_align(wl.bs)
+    th = (time.perf_counter() - th) / 3
+    del os.environ["VGAMD_BANDED_HOST_GEOMETRY"]
+    assert res_p.tobytes() == res_h.tobytes() and ops_p.tobytes() == ops_h.tobytes()
     # ... and once as ONE batch that stays resident in HBM, which the timed region re-launches
     os.environ["VGAMD_BANDED_ONE_BATCH"] = "1"
     eng.banded_align(wl.bs)
@@ -266,7 +275,8 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
             "config": {"workload": "configs[4] stand-in: 1 Mbp variation graph, %d anchor-to-anchor windows of 30-500 bp per GPU, "
                                    "BandedGlobalAligner semantics, permissive band, padding floor(sqrt(L))+1, scores 1/4/6/1" % n,
                        "timed_region": "K runs of the fill launches + traceback kernel on the batch resident in HBM (vgk_banded_rerun)",
-                       "end_to_end_from_host_buffers_alignments_per_s": n / te, "end_to_end_one_batch_alignments_per_s": n / te_one,
+                       "end_to_end_from_host_buffers_alignments_per_s": n / te, "end_to_end_host_geometry_alignments_per_s": n / th, "end_to_end_one_batch_alignments_per_s": n / te_one,
+                       "from_host_buffers": "vgk_banded_align on the caller's arrays: four sub-batches, two in flight; the band geometry and the kernels' tables made on the device from the raw graph arrays (banded_geom_device.hpp; *_host_geometry_*: by prepare() on the host threads, as for graphs with empty nodes) — DESIGN.md §27.13",
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "limiter": "VALU issue: 1.74 G VALU wave-instructions per launch = 2.8 ms on 1024 SIMDs; ~41 VALU per wave-column of <= 64 cells inside the read, plus the per-node work (DESIGN.md §10)", "kernel": "banded_fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_BYTES_PER_UNIT["banded"] * n, "traffic_source": traffic_source("banded"), "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": fill,

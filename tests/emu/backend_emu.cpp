@@ -152,6 +152,7 @@ public:
         matrix_wave_emu<2>(P, 0, 128); matrix_wave_emu<4>(P, 128, 256); matrix_wave_emu<8>(P, 256, 512); matrix_wave_emu<16>(P, 512, 1024);
         return VGK_OK;
     }
+    int run_banded_geometry(const BGeomParams& p) override { for (uint32_t i = 0; i < p.n; ++i) banded_geometry_one(p, i); return VGK_OK; }
     int run_banded_multi(const BandedMultiParams& Q) override { for (uint32_t a = 0; a < Q.P.n; ++a) banded_multi_one(Q, a); return VGK_OK; }
     int run_gssw_multi(const GsswMultiParams& P) override { for (uint32_t i = 0; i < P.M.n; ++i) gssw_multi_one(P, i); return VGK_OK; }
     int gapless_order(const GOrderParams& P, int stage) override { for (uint32_t i = 0; i < P.n; ++i) { if (stage == 1) g_order_sizes_one(P, i); else g_order_gather_one(P, i); } return VGK_OK; }

@@ -230,6 +230,74 @@ def test_emulated_banded_call_in_four_sub_batches(monkeypatch):
     assert not _same(problems, capi.Engine(lib=util.ORACLE_LIB).banded_align(capi.BandedSet.from_lists(problems)), whole)
 
 
+# A large call of graphs WITHOUT empty nodes has its geometry made on the device (banded_align_device_geometry / banded_geom_device.hpp): a lane
+# per problem over the raw graph arrays instead of prepare() on the host threads.  The same kernels over the same tables: every result and every
+# op byte of the host-geometry path (VGAMD_BANDED_HOST_GEOMETRY=1) and of the one-batch call — with problems the checks decline, problems the
+# geometry declines (no band, more cells than allowed), bands of 1 .. 32 rows per lane and quality-adjusted scores among them.
+def no_empty_nodes(problems):
+    return [p for p in problems if all(len(s) for s in p["nodes"])]
+
+
+def device_geometry_equals_host_geometry(lib, problems, monkeypatch, qual_adj=None):
+    assert all(len(s) for p in problems for s in p["nodes"])
+    bs = capi.BandedSet.from_lists(problems)
+    whole = capi.Engine(lib=lib, qual_adj=qual_adj).banded_align(bs)                  # one batch, geometry by prepare()
+    monkeypatch.setenv("VGAMD_BANDED_PIPELINE_MIN", "8")
+    monkeypatch.setenv("VGAMD_BANDED_TIMING", "1")
+    dev = capi.Engine(lib=lib, qual_adj=qual_adj).banded_align(bs)
+    monkeypatch.delenv("VGAMD_BANDED_TIMING")
+    monkeypatch.setenv("VGAMD_BANDED_HOST_GEOMETRY", "1")
+    host = capi.Engine(lib=lib, qual_adj=qual_adj).banded_align(bs)
+    monkeypatch.delenv("VGAMD_BANDED_HOST_GEOMETRY")
+    monkeypatch.setenv("VGAMD_MAX_BATCH_BYTES", "200000")                              # a sub-batch past the device budget: the call goes back to the host path
+    small = capi.Engine(lib=lib, qual_adj=qual_adj).banded_align(bs)
+    monkeypatch.delenv("VGAMD_BANDED_PIPELINE_MIN"); monkeypatch.delenv("VGAMD_MAX_BATCH_BYTES")
+    for other in (dev, host, small):
+        assert not _same(problems, whole, other)
+        assert (whole[0]["ops_begin"] == other[0]["ops_begin"]).all() and (whole[0]["status"] == other[0]["status"]).all()
+    return dev
+
+
+def device_geometry_problems(seed, n, n_mixed, wide_read=700, wide_pad=520, mixed_read=300):
+    problems = no_empty_nodes(random_banded_set(seed, n, p_empty=0.0) + mixed_band_problems(seed + 1, n_mixed, 30, 200, max_read=mixed_read))
+    rng = np.random.default_rng(seed + 2)
+    wide = "".join("ACGT"[i] for i in rng.integers(0, 4, 60))
+    problems.append(dict(read="".join("ACGT"[i] for i in rng.integers(0, 4, wide_read)), nodes=[wide[:20], wide[20:40], wide[40:]], preds=[[], [0], [1]],
+                         band_padding=wide_pad, permissive=True))                         # 32 rows per lane (700 / 520)
+    problems.insert(5, dict(read="ACGT", nodes=["A" * 70000], preds=[[]], band_padding=1, permissive=True))             # declined by the checks
+    problems.insert(9, dict(read="ACGTACGTAC", nodes=["ACGTACGTACGT" * 8], preds=[[]], band_padding=0, permissive=False))  # no band reaches the sink
+    problems.insert(11, dict(read="ACGTACGT" * 30, nodes=["ACGTACGT" * 30, "ACGT"], preds=[[], [0]], band_padding=2000, permissive=True))  # more than 2048 diagonals
+    return problems
+
+
+def test_emulated_banded_geometry_on_the_device_equals_the_host_geometry(monkeypatch, capfd):
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    problems = device_geometry_problems(61, 48, 2, wide_read=90, wide_pad=70, mixed_read=80)      # (the emulator steps every lane: narrower wide ones)
+    dev = device_geometry_equals_host_geometry(util.EMU_LIB, problems, monkeypatch)
+    assert "device geometry" in capfd.readouterr().err                                  # (the path was taken)
+    against_the_oracle(problems, dev)
+
+
+def against_the_oracle(problems, dev):
+    """what the engine aligned or found band-less is the oracle's answer; what it declines (a band of more than 2048 diagonals, a node of more
+    than 65 535 bases) the oracle may well align"""
+    ref = capi.Engine(lib=util.ORACLE_LIB).banded_align(capi.BandedSet.from_lists(problems))
+    declined = {i for i, r in enumerate(dev[0]) if int(r["status"]) not in (0, -8)}
+    assert len(declined) >= 2 and not [b for b in _same(problems, ref, dev) if b[0] not in declined]
+    assert {0, -8}.issubset(set(int(x) for x in dev[0]["status"]))
+
+
+@pytest.mark.gpu
+def test_hip_banded_geometry_on_the_device_equals_the_host_geometry(monkeypatch):
+    problems = device_geometry_problems(63, 3000, 200)
+    dev = device_geometry_equals_host_geometry(util.ENGINE_LIB, problems, monkeypatch)
+    against_the_oracle(problems, dev)
+    big = no_empty_nodes(random_banded_set(65, 40000, max_read=60, p_empty=0.0))         # past the threshold by itself
+    bs = capi.BandedSet.from_lists(big)
+    assert not _same(big, capi.Engine(lib=util.ORACLE_LIB).banded_align(bs), capi.Engine().banded_align(bs))
+
+
 @pytest.mark.gpu
 def test_hip_banded_call_in_four_sub_batches(monkeypatch):
     problems = random_banded_set(53, 2000) + mixed_band_problems(54, 200, 30, 200)

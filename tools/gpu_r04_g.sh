@@ -1,8 +1,12 @@
-# round 4, GPU call G: where the band kernel's time goes (VGAMD_TB_DBG: 1 = one column only, 2 = no stores)
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r04g; mkdir -p $O
-export VGAMD_TB_REWALK=1
-for dbg in 0 1 2; do
-  export VGAMD_TB_DBG=$dbg
-  cd /tmp && export TMPDIR=/tmp && timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof$dbg -o p -- python $GRAFT_REPO_ROOT/bench.py --no-e2e --no-secondary --no-cpu --steps 3 --warmup 1 > $GRAFT_REPO_ROOT/$O/prof$dbg.log 2>&1
-  cd $GRAFT_REPO_ROOT; f=$(find $O/prof$dbg -name '*kernel_stats.csv' | head -1); echo "dbg $dbg"; [ -n "$f" ] && grep -E "band_kernel|bandwalk|fill_kernel" "$f" | cut -d, -f1,4 | cut -c1-120
-done
+# round 4: the banded call with its geometry on the device — parity tests, the bench line, the call's laps
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r04g; mkdir -p $O
+timeout -s KILL 400 python -m pytest tests/test_banded.py -m gpu -q -x > $O/pytest_banded.log 2>&1 < /dev/null; tail -3 $O/pytest_banded.log
+timeout -s KILL 200 python3 bench.py --workload banded --no-cpu --no-secondary --steps 5 --warmup 2 > $O/bench_banded.json 2> $O/bench_banded.err < /dev/null; echo "bench rc=$?"; tail -3 $O/bench_banded.err
+VGAMD_BANDED_TIMING=1 timeout -s KILL 200 python3 bench.py --workload banded --no-cpu --no-secondary --steps 1 --warmup 0 > /dev/null 2> $O/bench_banded_laps.err < /dev/null
+grep "device geometry" $O/bench_banded_laps.err | tail -22
+python3 - <<'PY'
+import json, os
+O = os.environ.get('GRAFT_REPO_ROOT', '.') + '/gpurun_out/r04g'
+d = json.loads(open(O + '/bench_banded.json').read().strip().split('\n')[-1]); c = d['config']
+print('banded resident %.2f M/s; from host buffers: device geometry %.2f M/s, host geometry %.2f M/s, one batch %.2f M/s' % (d['value']/1e6, c['end_to_end_from_host_buffers_alignments_per_s']/1e6, c['end_to_end_host_geometry_alignments_per_s']/1e6, c['end_to_end_one_batch_alignments_per_s']/1e6))
+PY

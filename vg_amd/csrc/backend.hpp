@@ -8,6 +8,7 @@
 #include <string>
 #include "gssw_device.hpp"
 #include "banded_device.hpp"
+#include "banded_geom_device.hpp"
 #include "gapless_device.hpp"
 #include "wfa_device.hpp"
 #include "wfa_wave_device.hpp"
@@ -99,6 +100,9 @@ public:
     // flight.  banded_ms(slot, 0 | 1) = fill | traceback time, valid once the caller has waited for the launch.
     virtual int   run_banded_async(const BandedParams& p, const BandedLaunch* launches, uint32_t n_launches, int slot) { (void)slot; return run_banded(p, launches, n_launches); }
     virtual double banded_ms(int slot, int which) { (void)slot; return last_ms(which ? 4 : 3); }
+    // the band geometry and kernel tables of p.n problems from their raw graph arrays, one lane per problem (banded_geom_device.hpp), on the
+    // SIDE stream — behind upload_side()'s copies, beside whatever the main stream runs; download_side() of p.out waits for it
+    virtual int   run_banded_geometry(const BGeomParams& p) = 0;
     // gapless extension: `threads` resident threads (one scratch slab each) stride over p.n reads; last_ms(5) = kernel ms
     virtual int   run_gapless(const GaplessParams& p, uint32_t threads) = 0;
     // the sets of a gapless batch in problem order (gapless_device.hpp): stage 1 = sizes per read, stage 2 = the gather (the prefix sums

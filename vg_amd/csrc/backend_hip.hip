@@ -155,6 +155,12 @@ __global__ __launch_bounds__(256) void gssw_walk_kernel(const GsswParams P, cons
     const uint32_t i = P.order[k];
     if (i != 0xffffffffu) walk_one(P, i, P.best[i]);
 }
+// the band geometry of a batch of banded problems (banded_geom_device.hpp): a lane per problem
+__global__ __launch_bounds__(64) void banded_geometry_kernel(const BGeomParams P) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.n) banded_geometry_one(P, i);
+}
+
 // The tracebacks as two kernels (GsswParams::walk_passes == 2): every read by diagonal runs alone; then the reads that needed a code — one in
 // eight on the headline batch — side by side, so that the wavefronts of the first kernel are never held by a lane that walks cell by cell
 __global__ __launch_bounds__(64) void gssw_walk_first_kernel(const GsswParams P, const int in_fill_order) {
@@ -1224,6 +1230,12 @@ public:
         hipEvent_t* ev = bbev[slot & 1];
         for (int k = 0; k < 3; ++k) if (!ev[k] && hipEventCreate(&ev[k]) != hipSuccess) return VGK_ENODEV;
         return banded_launch(p, launches, n, ev);
+    }
+    int run_banded_geometry(const BGeomParams& p) override {
+        if (p.n == 0) return VGK_OK;
+        hipSetDevice(dev);
+        hipLaunchKernelGGL(banded_geometry_kernel, dim3((p.n + 63) / 64), dim3(64), 0, copy, p);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     double banded_ms(int slot, int which) override {
         hipEvent_t* ev = bbev[slot & 1]; float ms = 0.f;

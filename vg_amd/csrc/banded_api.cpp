@@ -246,11 +246,17 @@ struct HostArenas {
     PinnedBuf<uint8_t> reads, quals, graph; PinnedBuf<BResult> dres; PinnedBuf<vgk_op> dops; PinnedBuf<int32_t> scores;
     PinnedSet set[2]; void* ev[2] = {nullptr, nullptr}; Backend* be = nullptr;      // the pipelined path: two sub-batches in flight
     PinnedBuf<BNode> qnodes[2];        // ... and the node records of a quarter of the call, written by prepare() where they are uploaded from (quarters alternate)
+    struct GeomSet {                   // the device-geometry path (banded_align_device_geometry): the raw arrays of a sub-batch, and what comes back
+        PinnedBuf<BGeomProb> gprobs; PinnedBuf<uint32_t> node_len, pred_off, pred_idx; PinnedBuf<BGeomOut> gout;
+    } gset[2];
     ~HostArenas() { if (be) for (void* e : ev) if (e) be->event_destroy(e); }
 };
 enum { S_PROBS, S_ORDER, S_NODES, S_SEEDS, S_POOL, S_STARTS, S_READS, S_QUALS, S_GRAPH, S_MAT, S_TB, S_LAST, S_OPS, S_DENSE, S_RESULTS, S_COUNT };
 constexpr int S_SCORES = 31;          // k-best mode: the full score matrices (slots 15..30 belong to gapless_api.cpp)
 constexpr int S_SET1 = 124;           // the pipelined path's second sub-batch in flight: slots S_SET1 + S_*
+enum { G_PROBS, G_NODELEN, G_PREDOFF, G_PREDIDX, G_TMP, G_OUT, G_COUNT };
+constexpr int G_SET0 = 140, G_SET1 = 146;     // the device-geometry path's raw arrays, per sub-batch in flight
+constexpr int BANDED_NOT_HERE = 10000;        // banded_align_device_geometry: this call is for the host-geometry path (never leaves the library)
 static_assert(S_COUNT <= 15 && S_SCORES < (int)(sizeof(vgk_ctx::scratch) / sizeof(vgk_ctx::DevBuf)) && S_SET1 + S_COUNT <= (int)(sizeof(vgk_ctx::scratch) / sizeof(vgk_ctx::DevBuf)), "scratch slots");
 
 
@@ -1073,11 +1079,280 @@ static int banded_align_pipelined(vgk_ctx* ctx, const vgk_banded_problem* proble
     return rc_all;
 }
 
+// ---- A large call of graphs WITHOUT empty nodes: the geometry on the device (banded_geom_device.hpp).  The host gathers each sub-batch's raw
+// arrays — node lengths, predecessor lists, coded reads and bases: 0.8 kB a problem against the 2.1 kB of tables prepare() makes — checks them
+// on the way, and a lane per problem makes the band, the node records, the flattened predecessors and the candidate end nodes where the fill
+// kernels read them; what comes back before the fills are launched is 40 bytes a problem (status, rows per lane, arena sizes), from which the
+// host places the arenas and orders the launches exactly as the host-geometry path does.  Same kernels, same tables, same results.  Four
+// sub-batches, two in flight, as in banded_align_pipelined; the geometry kernel runs on the side stream under the fills of the sub-batch before.
+// Returns BANDED_NOT_HERE — nothing written — when a graph of the call has an empty node or a sub-batch does not fit the device budget.
+struct GPrep { int32_t status; uint32_t N, E, bases, slot, arena; bool on_device; };      // slot: among the sub-batch's gathered problems (tables, BGeomOut); arena: among those the geometry accepted (BProb, BResult)
+
+static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n,
+                                        vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    uint64_t budget = ctx->be->memory_bytes() / 4;
+    if (const char* e = std::getenv("VGAMD_MAX_BATCH_BYTES")) budget = std::strtoull(e, nullptr, 10);
+    if (!budget) budget = 1ull << 30;
+    Backend* be = ctx->be.get();
+    const bool qa = ctx->has_qa;
+    if (!ctx->banded_host) ctx->banded_host = std::make_shared<HostArenas>();
+    HostArenas& H = *static_cast<HostArenas*>(ctx->banded_host.get());
+    if (!H.be) { H.be = be; for (void*& e : H.ev) e = be->event_create(); }
+    const bool timing = std::getenv("VGAMD_BANDED_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "[vgk_banded_align/device geometry] %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
+    std::vector<GPrep> gp(n);
+    std::atomic<int> not_here{0};                                 // a problem whose answer the host path's order of tests decides (below)
+    // empty nodes anywhere: not this path (found before anything is written)
+    { std::atomic<int> empty{0};
+      parallel_chunks(n, [&](uint32_t lo, uint32_t hi, uint32_t) {
+          for (uint32_t q = lo; q < hi && !empty.load(std::memory_order_relaxed); ++q) {
+              const vgk_graph& g = problems[q].graph;
+              if (!g.node_len) continue;
+              for (uint32_t v = 0; v < g.n_nodes; ++v) if (g.node_len[v] == 0) { empty.store(1, std::memory_order_relaxed); break; }
+          }
+      });
+      if (empty.load()) return BANDED_NOT_HERE; }
+    lap("scan");
+    ctx->banded_ms[0] = ctx->banded_ms[1] = 0; ctx->banded_cells = 0; ctx->banded_bytes = 0; ctx->banded_last_valid = false;
+    int8_t* mat_rows = ctx->banded_mat_rows;
+    std::memset(mat_rows, 0, BMAT_BYTES);
+    if (!qa) { std::memcpy(mat_rows, ctx->sc.matrix, 25); for (int g = 0; g < 5; ++g) std::memcpy(mat_rows + BMAT_ROWS_AT + 8 * g, ctx->sc.matrix + 5 * g, 5); }
+    const int8_t* mat = qa ? ctx->qmat.data() : mat_rows;
+    const uint32_t quarter = (n + 3u) / 4u;
+    size_t used = 0; int rc_all = VGK_OK;
+
+    struct Sums { uint64_t v[6]; };                              // problems, nodes, edges, read bases, graph bases, (unused)
+    // ---- first half of a sub-batch: sizes, gather + checks, geometry on the device, placement
+    auto build = [&](uint32_t from, BSub& S, int set) -> int {
+        PinnedSet& A = H.set[set]; HostArenas::GeomSet& G = H.gset[set]; const int gbase = set ? G_SET1 : G_SET0, base = set ? S_SET1 : 0;
+        const uint32_t limit = std::min<uint32_t>(n, (from / quarter + 1u) * quarter), cnt = limit - from;
+        S.i = from; S.j = limit; S.owner.clear(); S.launches.clear(); S.m = 0;
+        const uint32_t n_chunks = chunk_count(cnt);
+        std::vector<Sums> chunk(n_chunks + 1, Sums{});
+        // what can be said before the arrays are walked (prepare()'s first tests, in its order) and the sizes
+        parallel_chunks(cnt, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+            Sums t{};
+            for (uint32_t q = from + lo; q < from + hi; ++q) {
+                const vgk_banded_problem& p = problems[q]; const vgk_graph& g = p.graph; GPrep& z = gp[q];
+                z.status = VGK_OK; z.N = g.n_nodes; z.E = 0; z.bases = 0; z.slot = 0; z.arena = 0; z.on_device = false;
+                const uint32_t N = g.n_nodes;
+                if (!N || !p.read_len || !p.read || !g.node_len || !g.pred_off || !g.seq || (qa && !p.qual)) { z.status = VGK_EINVAL; continue; }
+                if (g.pred_off[N] > g.pred_off[0] && !g.pred_idx) { z.status = VGK_EINVAL; continue; }
+                uint64_t total = 0; int st = VGK_OK;
+                for (uint32_t v = 0; v < N && st == VGK_OK; ++v) {
+                    if (g.pred_off[v + 1] < g.pred_off[v]) { st = VGK_EINVAL; break; }
+                    for (uint32_t e = g.pred_off[v]; e < g.pred_off[v + 1]; ++e) if (g.pred_idx[e] >= v) { st = VGK_EINVAL; break; }
+                    if (st == VGK_OK && g.node_len[v] > 65535u) st = VGK_ETOOBIG;
+                    total += g.node_len[v];
+                }
+                if (st == VGK_OK && p.read_len > 65535u) st = VGK_ETOOBIG;
+                // (a padding of 2^26 diagonals and more, a graph of more than 2^24 bases: prepare() declines them, but after its band pass
+                // — VGK_ETOOBIG or VGK_ENOBAND, whichever test comes first there; the lane's 32-bit diagonals need not see such a problem)
+                if (st == VGK_OK && (p.band_padding >= (1u << 26) || total > (1u << 24))) { not_here.store(1, std::memory_order_relaxed); st = VGK_ETOOBIG; }
+                if (st != VGK_OK) { z.status = st; continue; }
+                z.E = g.pred_off[N] - g.pred_off[0]; z.bases = (uint32_t)total; z.on_device = true;
+                t.v[0] += 1; t.v[1] += N; t.v[2] += z.E; t.v[3] += p.read_len; t.v[4] += total;
+            }
+            chunk[c + 1] = t;
+        });
+        if (not_here.load()) return BANDED_NOT_HERE;
+        for (uint32_t c = 0; c < n_chunks; ++c) for (int x = 0; x < 6; ++x) chunk[c + 1].v[x] += chunk[c].v[x];
+        const Sums all = chunk[n_chunks];
+        const uint32_t m = (uint32_t)all.v[0];
+        if (!m) return VGK_OK;
+        if (all.v[1] + m > 0xfffffff0ull || all.v[2] > 0xfffffff0ull || all.v[3] > 0xfffffff0ull || all.v[4] > 0xfffffff0ull) return BANDED_NOT_HERE;
+        S.owner.resize(m);
+        BGeomProb* gprobs = G.gprobs.get(be, m); uint32_t* node_len = G.node_len.get(be, all.v[1] + 1); uint32_t* pred_off = G.pred_off.get(be, all.v[1] + m + 1);
+        uint32_t* pred_idx = G.pred_idx.get(be, all.v[2] + 1); BGeomOut* gout = G.gout.get(be, m);
+        uint8_t* reads = A.reads.get(be, all.v[3] + 1); uint8_t* quals = qa ? A.quals.get(be, all.v[3] + 1) : nullptr; uint8_t* graph = A.graph.get(be, all.v[4] + 1);
+        BProb* probs = A.probs.get(be, m); uint32_t* order = A.order.get(be, m);
+        if (!gprobs || !node_len || !pred_off || !pred_idx || !gout || !reads || (qa && !quals) || !graph || !probs || !order) return VGK_ENOMEM;
+        parallel_chunks(cnt, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+            Sums at = chunk[c];
+            for (uint32_t q = from + lo; q < from + hi; ++q) {
+                GPrep& z = gp[q];
+                if (!z.on_device) continue;
+                const vgk_banded_problem& p = problems[q]; const vgk_graph& g = p.graph;
+                const uint32_t a = (uint32_t)at.v[0], nb = (uint32_t)at.v[1], eb = (uint32_t)at.v[2];
+                BGeomProb gb{}; gb.node_base = nb; gb.edge_base = eb; gb.n_nodes = z.N; gb.L = p.read_len; gb.band_padding = p.band_padding;
+                gb.permissive = (p.flags & VGK_BANDED_PERMISSIVE) ? 1u : 0u; gb.max_cells = p.max_cells;
+                gprobs[a] = gb;
+                std::memcpy(node_len + nb, g.node_len, (size_t)z.N * 4);
+                const uint32_t e0 = g.pred_off[0]; uint32_t* po = pred_off + nb + a;
+                for (uint32_t v = 0; v <= z.N; ++v) po[v] = g.pred_off[v] - e0;
+                if (z.E) std::memcpy(pred_idx + eb, g.pred_idx + e0, (size_t)z.E * 4);
+                BProb pb{};
+                pb.L = p.read_len; pb.n_nodes = z.N; pb.graph_len = z.bases; pb.node_base = nb; pb.seed_base = eb; pb.pool_base = 0; pb.start_base = nb;
+                pb.read_off = (uint32_t)at.v[3]; pb.graph_off = (uint32_t)at.v[4]; pb.ops_cap = (uint32_t)(p.read_len + (uint64_t)z.bases + 2ull * z.N + 8);
+                probs[a] = pb;                                      // (rows per lane, candidate ends and the arena offsets follow the geometry)
+                code_bases<true>(reads + pb.read_off, p.read, pb.L);
+                if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
+                code_bases<true>(graph + pb.graph_off, p.graph.seq, pb.graph_len);
+                z.slot = a; S.owner[a] = q;
+                at.v[0] += 1; at.v[1] += z.N; at.v[2] += z.E; at.v[3] += p.read_len; at.v[4] += z.bases;
+            }
+        });
+        lap("gather");
+        // the geometry: raw arrays up on the side stream, a lane per problem behind them, the 40 bytes per problem back
+        BGeomParams Q{}; Q.n = m;
+        void* d_gprobs = ensure(ctx, gbase + G_PROBS, (uint64_t)m * sizeof(BGeomProb)); void* d_len = ensure(ctx, gbase + G_NODELEN, (all.v[1] + 1) * 4);
+        void* d_poff = ensure(ctx, gbase + G_PREDOFF, (all.v[1] + m + 1) * 4); void* d_pidx = ensure(ctx, gbase + G_PREDIDX, (all.v[2] + 1) * 4);
+        void* d_tmp = ensure(ctx, gbase + G_TMP, (all.v[1] + 1) * 12); void* d_out = ensure(ctx, gbase + G_OUT, (uint64_t)m * sizeof(BGeomOut));
+        void* d_nodes = ensure(ctx, base + S_NODES, (all.v[1] + 1) * sizeof(BNode)); void* d_seeds = ensure(ctx, base + S_SEEDS, (all.v[2] + 1) * sizeof(BSeed));
+        void* d_starts = ensure(ctx, base + S_STARTS, (all.v[1] + 1) * sizeof(BStart)); void* d_pool = ensure(ctx, base + S_POOL, 16);
+        if (!d_gprobs || !d_len || !d_poff || !d_pidx || !d_tmp || !d_out || !d_nodes || !d_seeds || !d_starts || !d_pool) return VGK_ENOMEM;
+        int rc;
+        if ((rc = be->upload_side(d_gprobs, gprobs, (size_t)m * sizeof(BGeomProb))) || (rc = be->upload_side(d_len, node_len, (size_t)all.v[1] * 4)) ||
+            (rc = be->upload_side(d_poff, pred_off, (size_t)(all.v[1] + m) * 4)) || (all.v[2] && (rc = be->upload_side(d_pidx, pred_idx, (size_t)all.v[2] * 4)))) return rc;
+        Q.probs = (const BGeomProb*)d_gprobs; Q.node_len = (const uint32_t*)d_len; Q.pred_off = (const uint32_t*)d_poff; Q.pred_idx = (const uint32_t*)d_pidx;
+        Q.tmp = (int32_t*)d_tmp; Q.nodes = (BNode*)d_nodes; Q.seeds = (BSeed*)d_seeds; Q.starts = (BStart*)d_starts; Q.out = (BGeomOut*)d_out;
+        if ((rc = be->run_banded_geometry(Q))) return rc;
+        if ((rc = be->download_side(gout, d_out, (size_t)m * sizeof(BGeomOut)))) return rc;
+        lap("geometry");
+        // placement: the problems the geometry accepted keep their slots in the tables; traceback bytes, last columns and op slots are laid out
+        // behind each other in their order (serial: three running sums over 40-byte records)
+        uint64_t tb_bytes = 0, last_elems = 0, ops_total = 0; uint32_t kept = 0;
+        std::vector<uint32_t> keys(m);
+        for (uint32_t a = 0; a < m; ++a) {
+            const BGeomOut& o = gout[a]; GPrep& z = gp[S.owner[a]];
+            if (o.status != VGK_OK) { z.status = o.status; z.on_device = false; continue; }
+            BProb pb = probs[a];                                    // (the kernels count problems, not slots: the accepted ones move up)
+            pb.Hpad = 64u * o.R; pb.n_starts = o.n_starts; pb.tb_base = tb_bytes; pb.last_base = last_elems; pb.ops_off = ops_total;
+            tb_bytes += o.tb_bytes; last_elems += o.last_elems; ops_total += pb.ops_cap;
+            probs[kept] = pb; z.arena = kept;
+            keys[kept] = o.order_key; order[kept] = kept; ++kept;
+        }
+        if (tb_bytes + last_elems * 4 + ops_total * 2 * sizeof(vgk_op) > budget) return BANDED_NOT_HERE;
+        // launches: one per rows-per-lane class; inside a class the problems with the most cells first (counting sort on log2(cells))
+        { std::vector<uint32_t> count(6 * 64 + 1, 0), sorted(kept);
+          for (uint32_t k = 0; k < kept; ++k) ++count[keys[k] + 1];
+          for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
+          std::vector<uint32_t> at(count.begin(), count.end() - 1);
+          for (uint32_t k = 0; k < kept; ++k) sorted[at[keys[k]]++] = order[k];
+          std::copy(sorted.begin(), sorted.end(), order);
+          for (uint32_t r = 0; r < 6; ++r) {
+            const uint32_t lo = count[r * 64], hi = count[(r + 1) * 64];
+            if (lo == hi) continue;
+            uint64_t lds = 0;
+            for (uint32_t b = lo; b < hi; ++b) { const BProb& pb = probs[order[b]]; lds = std::max<uint64_t>(lds, (qa ? 6400u : 32u) + (uint64_t)pb.L * (qa ? 2 : 1) + pb.graph_len + 96); }
+            S.launches.push_back({1u << r, lo, hi - lo, lds <= 40 * 1024 ? (uint32_t)lds : 0u});
+          } }
+        S.m = m;
+        S.sizes[0] = all.v[1]; S.sizes[1] = all.v[2]; S.sizes[2] = 0; S.sizes[3] = all.v[1]; S.sizes[4] = all.v[3]; S.sizes[5] = all.v[4]; S.sizes[6] = tb_bytes; S.sizes[7] = last_elems; S.sizes[8] = ops_total;
+        BandedParams& P = S.P; P = BandedParams{};
+        P.nodes = (const BNode*)d_nodes; P.seeds = (const BSeed*)d_seeds; P.pool = (const uint32_t*)d_pool; P.starts = (const BStart*)d_starts;
+        P.n = kept;
+        lap("placement");
+        return VGK_OK;
+    };
+    // ---- ... the rest up on the main stream, the fills and the tracebacks behind it
+    auto launch = [&](BSub& S, int set) -> int {
+        if (!S.m) return VGK_OK;
+        PinnedSet& A = H.set[set]; const int base = set ? S_SET1 : 0;
+        BandedParams& P = S.P;
+        const uint64_t n_read = S.sizes[4], n_graph = S.sizes[5], tb_bytes = S.sizes[6], last_elems = S.sizes[7], ops_total = S.sizes[8];
+        int rc;
+        if ((rc = stage(ctx, base + S_PROBS, (const BProb*)A.probs.p, std::max<uint32_t>(P.n, 1), P.probs)) || (rc = stage(ctx, base + S_ORDER, (const uint32_t*)A.order.p, std::max<uint32_t>(P.n, 1), P.order)) ||
+            (rc = stage(ctx, base + S_READS, (const uint8_t*)A.reads.p, n_read, P.reads)) || (qa && (rc = stage(ctx, base + S_QUALS, (const uint8_t*)A.quals.p, n_read, P.quals))) ||
+            (rc = stage(ctx, base + S_GRAPH, (const uint8_t*)A.graph.p, n_graph, P.graph)) || (rc = stage(ctx, base + S_MAT, mat, qa ? 6400 : BMAT_BYTES, P.mat))) return rc;
+        P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend;
+        P.tb = (uint8_t*)ensure(ctx, base + S_TB, std::max<uint64_t>(tb_bytes, 256));
+        P.last = (int32_t*)ensure(ctx, base + S_LAST, std::max<uint64_t>(last_elems, 64) * sizeof(int32_t));
+        P.ops = (vgk_op*)ensure(ctx, base + S_OPS, std::max<uint64_t>(ops_total, 1) * sizeof(vgk_op));
+        P.dense = (vgk_op*)ensure(ctx, base + S_DENSE, std::max<uint64_t>(ops_total, 1) * sizeof(vgk_op));
+        uint8_t* rblock = (uint8_t*)ensure(ctx, base + S_RESULTS, (size_t)S.m * sizeof(BResult) + 64);
+        if (!P.tb || !P.last || !P.ops || !P.dense || !rblock) return VGK_ENOMEM;
+        P.dense_count = (unsigned long long*)rblock; P.results = (BResult*)(rblock + 64);
+        if ((rc = be->zero(rblock, 64))) return rc;
+        if (P.n && (rc = be->run_banded_async(P, S.launches.data(), (uint32_t)S.launches.size(), set))) return rc;
+        if ((rc = be->event_record(H.ev[set]))) return rc;
+        lap("launch");
+        return VGK_OK;
+    };
+    // ---- second half: results and packed ops back behind the event, then the caller's order
+    auto finish = [&](BSub& S, int set) -> int {
+        PinnedSet& A = H.set[set]; HostArenas::GeomSet& G = H.gset[set];
+        const uint32_t m = S.m, i = S.i, j = S.j; const BandedParams& P = S.P;
+        BResult* dres = A.dres.get(be, m + 1); const vgk_op* dops = nullptr; const BGeomOut* gout = G.gout.p;
+        if (!dres) return VGK_ENOMEM;
+        if (m && P.n) {
+            int rc;
+            if (H.ev[set]) { if ((rc = be->fetch_after(H.ev[set]))) return rc; }
+            else if ((rc = be->sync())) return rc;
+            unsigned long long* dense_n = A.count.get(be, 8);
+            if (!dense_n) return VGK_ENOMEM;
+            if ((rc = be->download_fetch_async(dense_n, P.dense_count, sizeof(unsigned long long)))) return rc;
+            if ((rc = be->download_fetch_async(dres, P.results, (size_t)m * sizeof(BResult)))) return rc;
+            if ((rc = be->sync_fetch())) return rc;
+            vgk_op* hd = A.dops.get(be, dense_n[0] + 1);
+            if (!hd) return VGK_ENOMEM;
+            if (dense_n[0] && (rc = be->download_fetch(hd, P.dense, (size_t)dense_n[0] * sizeof(vgk_op)))) return rc;
+            dops = hd;
+            ctx->banded_ms[0] += be->banded_ms(set, 0); ctx->banded_ms[1] += be->banded_ms(set, 1);
+            lap("fetch");
+        }
+        std::vector<uint32_t> need(j - i, 0);
+        parallel_for(j - i, [&](uint32_t k, unsigned) {
+            const uint32_t q = i + k; const GPrep& z = gp[q]; vgk_result& r = results[q];
+            std::memset(&r, 0, sizeof r);
+            if (!z.on_device) { r.status = z.status; return; }
+            const BResult& dr = dres[z.arena];
+            if (dr.status != VGK_OK) { r.status = dr.status; return; }
+            need[k] = dr.n_ops; r.score = dr.score; r.status = VGK_OK;
+        });
+        for (uint32_t q = i; q < j; ++q) {
+            const GPrep& z = gp[q]; vgk_result& r = results[q];
+            r.ops_begin = (uint32_t)used;
+            if (z.on_device) {
+                const vgk_banded_problem& p = problems[q];
+                ctx->banded_cells += gout[z.slot].cells;
+                ctx->banded_bytes += p.read_len + (uint64_t)z.bases + 8ull * z.N + 4ull * p.graph.pred_off[z.N] + gout[z.slot].cells + 16 + 2ull * dres[z.arena].n_ops;
+            }
+            if (r.status != VGK_OK) continue;
+            if (!ops || used + need[q - i] > ops_cap) { r.status = VGK_EOPS; rc_all = VGK_EOPS; need[q - i] = 0; continue; }
+            r.n_ops = need[q - i]; used += need[q - i];
+        }
+        parallel_for(j - i, [&](uint32_t k, unsigned) {
+            const uint32_t q = i + k; const vgk_result& r = results[q];
+            if (r.status != VGK_OK || !r.n_ops) return;
+            const BResult& dr = dres[gp[q].arena];
+            const vgk_op* src = dops + dr.ops_begin; vgk_op* out = ops + r.ops_begin;
+            for (uint32_t e = 0; e < dr.n_ops; ++e) { vgk_op o = src[e]; if (o.len == 0) o.op = VGK_OP_M; *out++ = o; }
+        });
+        lap("results");
+        return VGK_OK;
+    };
+
+    BSub subs[2]; int set = 0; bool pending = false; int rc = VGK_OK;
+    for (uint32_t i = 0; i < n && rc == VGK_OK;) {
+        BSub& S = subs[set];
+        rc = build(i, S, set);
+        i = S.j;
+        if (pending && rc == VGK_OK) rc = finish(subs[set ^ 1], set ^ 1);
+        if (rc == VGK_OK) rc = launch(S, set);
+        pending = rc == VGK_OK;
+        set ^= 1;
+    }
+    if (pending && rc == VGK_OK) rc = finish(subs[set ^ 1], set ^ 1);
+    if (rc != VGK_OK) { be->sync_side(); be->sync(); be->sync_fetch(); return rc; }
+    if (ops_written) *ops_written = used;
+    return rc_all;
+}
+
 int vgk_banded_align(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n,
                      vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) try {
     uint32_t pipeline_from = 32768u;                              // (VGAMD_BANDED_PIPELINE_MIN: tests cut small calls in four as well)
     if (const char* e = std::getenv("VGAMD_BANDED_PIPELINE_MIN")) pipeline_from = (uint32_t)std::max(4, std::atoi(e));
-    if (ctx && problems && results && n >= pipeline_from && !std::getenv("VGAMD_BANDED_ONE_BATCH")) return banded_align_pipelined(ctx, problems, n, results, ops, ops_cap, ops_written);
+    if (ctx && problems && results && n >= pipeline_from && !std::getenv("VGAMD_BANDED_ONE_BATCH")) {
+        // graphs without empty nodes: their geometry on the device (VGAMD_BANDED_HOST_GEOMETRY=1: on the host threads, as for every other call)
+        if (!std::getenv("VGAMD_BANDED_HOST_GEOMETRY")) {
+            const int rc = banded_align_device_geometry(ctx, problems, n, results, ops, ops_cap, ops_written);
+            if (rc != BANDED_NOT_HERE) return rc;
+        }
+        return banded_align_pipelined(ctx, problems, n, results, ops, ops_cap, ops_written);
+    }
     return banded_align_impl(ctx, problems, n, 0, results, nullptr, ops, ops_cap, ops_written);
 } catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
