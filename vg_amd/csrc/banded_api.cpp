@@ -1086,7 +1086,7 @@ static int banded_align_pipelined(vgk_ctx* ctx, const vgk_banded_problem* proble
 // host places the arenas and orders the launches exactly as the host-geometry path does.  Same kernels, same tables, same results.  Four
 // sub-batches, two in flight, as in banded_align_pipelined; the geometry kernel runs on the side stream under the fills of the sub-batch before.
 // Returns BANDED_NOT_HERE — nothing written — when a graph of the call has an empty node or a sub-batch does not fit the device budget.
-struct GPrep { int32_t status; uint32_t N, E, bases, slot, arena; bool on_device; };      // slot: among the sub-batch's gathered problems (tables, BGeomOut); arena: among those the geometry accepted (BProb, BResult)
+struct GPrep { int32_t status; uint32_t N, E, bases, slot, arena; uint64_t in_bytes; bool on_device; };      // slot: among the sub-batch's gathered problems (tables, BGeomOut); arena: among those the geometry accepted (BProb, BResult); in_bytes: its share of the call's algorithmic bytes but for cells and ops
 
 static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* problems, uint32_t n,
                                         vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
@@ -1136,7 +1136,7 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
             Sums t{};
             for (uint32_t q = from + lo; q < from + hi; ++q) {
                 const vgk_banded_problem& p = problems[q]; const vgk_graph& g = p.graph; GPrep& z = gp[q];
-                z.status = VGK_OK; z.N = g.n_nodes; z.E = 0; z.bases = 0; z.slot = 0; z.arena = 0; z.on_device = false;
+                z.status = VGK_OK; z.N = g.n_nodes; z.E = 0; z.bases = 0; z.slot = 0; z.arena = 0; z.in_bytes = 0; z.on_device = false;
                 const uint32_t N = g.n_nodes;
                 if (!N || !p.read_len || !p.read || !g.node_len || !g.pred_off || !g.seq || (qa && !p.qual)) { z.status = VGK_EINVAL; continue; }
                 if (g.pred_off[N] > g.pred_off[0] && !g.pred_idx) { z.status = VGK_EINVAL; continue; }
@@ -1153,6 +1153,7 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
                 if (st == VGK_OK && (p.band_padding >= (1u << 26) || total > (1u << 24))) { not_here.store(1, std::memory_order_relaxed); st = VGK_ETOOBIG; }
                 if (st != VGK_OK) { z.status = st; continue; }
                 z.E = g.pred_off[N] - g.pred_off[0]; z.bases = (uint32_t)total; z.on_device = true;
+                z.in_bytes = p.read_len + total + 8ull * N + 4ull * g.pred_off[N] + 16;
                 t.v[0] += 1; t.v[1] += N; t.v[2] += z.E; t.v[3] += p.read_len; t.v[4] += total;
             }
             chunk[c + 1] = t;
@@ -1305,11 +1306,7 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
         for (uint32_t q = i; q < j; ++q) {
             const GPrep& z = gp[q]; vgk_result& r = results[q];
             r.ops_begin = (uint32_t)used;
-            if (z.on_device) {
-                const vgk_banded_problem& p = problems[q];
-                ctx->banded_cells += gout[z.slot].cells;
-                ctx->banded_bytes += p.read_len + (uint64_t)z.bases + 8ull * z.N + 4ull * p.graph.pred_off[z.N] + gout[z.slot].cells + 16 + 2ull * dres[z.arena].n_ops;
-            }
+            if (z.on_device) { ctx->banded_cells += gout[z.slot].cells; ctx->banded_bytes += z.in_bytes + gout[z.slot].cells + 2ull * dres[z.arena].n_ops; }
             if (r.status != VGK_OK) continue;
             if (!ops || used + need[q - i] > ops_cap) { r.status = VGK_EOPS; rc_all = VGK_EOPS; need[q - i] = 0; continue; }
             r.n_ops = need[q - i]; used += need[q - i];

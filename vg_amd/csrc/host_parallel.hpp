@@ -180,8 +180,8 @@ template <class F> inline void parallel_tasks(uint32_t count, F task) {
 // the same over fixed chunks of the index range: f(lo, hi, chunk) — for two-level prefix sums and reductions
 constexpr uint32_t CHUNK = 512;
 inline uint32_t chunk_count(uint32_t n) { return (n + CHUNK - 1) / CHUNK; }
-template <class F> inline void parallel_chunks(uint32_t n, F f) {
-    parallel_for(chunk_count(n), [&](uint32_t c, unsigned) { const uint32_t lo = c * CHUNK; f(lo, std::min<uint32_t>(n, lo + CHUNK), c); });
+template <class F> inline void parallel_chunks(uint32_t n, F f) {      // (coarse tasks: parallel_for would run fewer than 256 of them on the calling thread)
+    parallel_tasks(chunk_count(n), [&](uint32_t c) { const uint32_t lo = c * CHUNK; f(lo, std::min<uint32_t>(n, lo + CHUNK), c); });
 }
 
 // base -> code (A C G T = 0 1 2 3, everything else 4), sixteen bases per step with SSE2 — part of every x86-64 — or thirty-two with AVX2
