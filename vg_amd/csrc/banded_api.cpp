@@ -1204,12 +1204,17 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
         void* d_nodes = ensure(ctx, base + S_NODES, (all.v[1] + 1) * sizeof(BNode)); void* d_seeds = ensure(ctx, base + S_SEEDS, (all.v[2] + 1) * sizeof(BSeed));
         void* d_starts = ensure(ctx, base + S_STARTS, (all.v[1] + 1) * sizeof(BStart)); void* d_pool = ensure(ctx, base + S_POOL, 16);
         if (!d_gprobs || !d_len || !d_poff || !d_pidx || !d_tmp || !d_out || !d_nodes || !d_seeds || !d_starts || !d_pool) return VGK_ENOMEM;
+        // (the coded reads and bases travel on the side stream as well, under the fills of the sub-batch before: the wait for the geometry's
+        // answer below covers them)
+        void* d_reads = ensure(ctx, base + S_READS, all.v[3] + 1); void* d_quals = qa ? ensure(ctx, base + S_QUALS, all.v[3] + 1) : nullptr; void* d_graph = ensure(ctx, base + S_GRAPH, all.v[4] + 1);
+        if (!d_reads || (qa && !d_quals) || !d_graph) return VGK_ENOMEM;
         int rc;
         if ((rc = be->upload_side(d_gprobs, gprobs, (size_t)m * sizeof(BGeomProb))) || (rc = be->upload_side(d_len, node_len, (size_t)all.v[1] * 4)) ||
             (rc = be->upload_side(d_poff, pred_off, (size_t)(all.v[1] + m) * 4)) || (all.v[2] && (rc = be->upload_side(d_pidx, pred_idx, (size_t)all.v[2] * 4)))) return rc;
         Q.probs = (const BGeomProb*)d_gprobs; Q.node_len = (const uint32_t*)d_len; Q.pred_off = (const uint32_t*)d_poff; Q.pred_idx = (const uint32_t*)d_pidx;
         Q.tmp = (int32_t*)d_tmp; Q.nodes = (BNode*)d_nodes; Q.seeds = (BSeed*)d_seeds; Q.starts = (BStart*)d_starts; Q.out = (BGeomOut*)d_out;
         if ((rc = be->run_banded_geometry(Q))) return rc;
+        if ((rc = be->upload_side(d_reads, reads, (size_t)all.v[3])) || (qa && (rc = be->upload_side(d_quals, quals, (size_t)all.v[3]))) || (rc = be->upload_side(d_graph, graph, (size_t)all.v[4]))) return rc;
         if ((rc = be->download_side(gout, d_out, (size_t)m * sizeof(BGeomOut)))) return rc;
         lap("geometry");
         // placement: the problems the geometry accepted keep their slots in the tables; traceback bytes, last columns and op slots are laid out
@@ -1244,6 +1249,7 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
         S.sizes[0] = all.v[1]; S.sizes[1] = all.v[2]; S.sizes[2] = 0; S.sizes[3] = all.v[1]; S.sizes[4] = all.v[3]; S.sizes[5] = all.v[4]; S.sizes[6] = tb_bytes; S.sizes[7] = last_elems; S.sizes[8] = ops_total;
         BandedParams& P = S.P; P = BandedParams{};
         P.nodes = (const BNode*)d_nodes; P.seeds = (const BSeed*)d_seeds; P.pool = (const uint32_t*)d_pool; P.starts = (const BStart*)d_starts;
+        P.reads = (const uint8_t*)d_reads; P.quals = (const uint8_t*)d_quals; P.graph = (const uint8_t*)d_graph;
         P.n = kept;
         lap("placement");
         return VGK_OK;
@@ -1253,11 +1259,10 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
         if (!S.m) return VGK_OK;
         PinnedSet& A = H.set[set]; const int base = set ? S_SET1 : 0;
         BandedParams& P = S.P;
-        const uint64_t n_read = S.sizes[4], n_graph = S.sizes[5], tb_bytes = S.sizes[6], last_elems = S.sizes[7], ops_total = S.sizes[8];
+        const uint64_t tb_bytes = S.sizes[6], last_elems = S.sizes[7], ops_total = S.sizes[8];
         int rc;
         if ((rc = stage(ctx, base + S_PROBS, (const BProb*)A.probs.p, std::max<uint32_t>(P.n, 1), P.probs)) || (rc = stage(ctx, base + S_ORDER, (const uint32_t*)A.order.p, std::max<uint32_t>(P.n, 1), P.order)) ||
-            (rc = stage(ctx, base + S_READS, (const uint8_t*)A.reads.p, n_read, P.reads)) || (qa && (rc = stage(ctx, base + S_QUALS, (const uint8_t*)A.quals.p, n_read, P.quals))) ||
-            (rc = stage(ctx, base + S_GRAPH, (const uint8_t*)A.graph.p, n_graph, P.graph)) || (rc = stage(ctx, base + S_MAT, mat, qa ? 6400 : BMAT_BYTES, P.mat))) return rc;
+            (rc = stage(ctx, base + S_MAT, mat, qa ? 6400 : BMAT_BYTES, P.mat))) return rc;
         P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend;
         P.tb = (uint8_t*)ensure(ctx, base + S_TB, std::max<uint64_t>(tb_bytes, 256));
         P.last = (int32_t*)ensure(ctx, base + S_LAST, std::max<uint64_t>(last_elems, 64) * sizeof(int32_t));
@@ -1327,8 +1332,10 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
         BSub& S = subs[set];
         rc = build(i, S, set);
         i = S.j;
-        if (pending && rc == VGK_OK) rc = finish(subs[set ^ 1], set ^ 1);
+        // (launched BEFORE the results of the sub-batch before are fetched: what this path sends up behind the geometry is a few hundred
+        // kilobytes of descriptors, nothing a download would queue behind — the device never waits for the host's copy-out)
         if (rc == VGK_OK) rc = launch(S, set);
+        if (pending && rc == VGK_OK) rc = finish(subs[set ^ 1], set ^ 1);
         pending = rc == VGK_OK;
         set ^= 1;
     }
