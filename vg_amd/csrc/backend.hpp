@@ -44,6 +44,7 @@ public:
     // stream of their own; sync_side() waits for them only
     virtual int   upload_side(void* dst, const void* src, size_t bytes) { return upload(dst, src, bytes); }
     virtual int   sync_side() { return sync(); }
+    virtual int   main_after_side() { return VGK_OK; }      // what the main stream is given from now on starts after everything the side stream holds so far (no host wait)
     virtual int   zero(void* dst, size_t bytes) = 0;                        // async on the stream
     // A batch's own completion event, and a third stream for the way back.  vgk_gssw_run records the batch's event behind its
     // kernels; vgk_gssw_fetch waits for THAT (polling: no blocking runtime call, no shared poll event), packs the CIGAR ops and

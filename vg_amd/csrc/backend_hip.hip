@@ -1016,6 +1016,13 @@ public:
         hipSetDevice(dev);
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, fetch) == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
+    hipEvent_t side_mark = nullptr;
+    int main_after_side() override {
+        hipSetDevice(dev);
+        if (!side_mark && hipEventCreateWithFlags(&side_mark, hipEventDisableTiming) != hipSuccess) return VGK_ENODEV;
+        if (hipEventRecord(side_mark, copy) != hipSuccess || hipStreamWaitEvent(stream, side_mark, 0) != hipSuccess) return VGK_ENODEV;
+        return VGK_OK;
+    }
     int sync_side() override {
         hipSetDevice(dev);
         return hipStreamSynchronize(copy) == hipSuccess ? VGK_OK : VGK_ENODEV;
@@ -1514,8 +1521,18 @@ Backend* make_backend(int device, std::string& err) {
     b->dev = device;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&b->prop, device) != hipSuccess) {
         err = "cannot select HIP device"; delete b; return nullptr; }
-    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&b->fetch, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->alt, hipStreamNonBlocking) != hipSuccess) { err = "cannot create HIP stream"; delete b; return nullptr; }
+    // The side (copy) and fetch streams carry what the host WAITS for beside a main stream that is busy — small kernels (packers, the banded
+    // geometry), descriptors up, results down: they get the device's highest stream priority, so that their work takes the slots a
+    // saturating fill frees first instead of queueing behind all of its workgroups (VGAMD_STREAM_PRIORITY=0: all streams alike).
+    int prio_least = 0, prio_greatest = 0;
+    const bool use_prio = !(std::getenv("VGAMD_STREAM_PRIORITY") && std::atoi(std::getenv("VGAMD_STREAM_PRIORITY")) == 0) &&
+                          hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_greatest != prio_least;
+    auto make_stream = [&](hipStream_t* st, bool high) {
+        if (high && use_prio && hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_greatest) == hipSuccess) return true;
+        (void)hipGetLastError();
+        return hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
+    };
+    if (!make_stream(&b->stream, false) || !make_stream(&b->copy, true) || !make_stream(&b->fetch, true) || !make_stream(&b->alt, false)) { err = "cannot create HIP stream"; delete b; return nullptr; }
     for (int i = 0; i < 2; ++i)
         if (hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&b->side_done[i], hipEventDisableTiming) != hipSuccess) { err = "cannot create HIP side stream"; delete b; return nullptr; }

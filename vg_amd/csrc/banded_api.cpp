@@ -1204,8 +1204,7 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
         void* d_nodes = ensure(ctx, base + S_NODES, (all.v[1] + 1) * sizeof(BNode)); void* d_seeds = ensure(ctx, base + S_SEEDS, (all.v[2] + 1) * sizeof(BSeed));
         void* d_starts = ensure(ctx, base + S_STARTS, (all.v[1] + 1) * sizeof(BStart)); void* d_pool = ensure(ctx, base + S_POOL, 16);
         if (!d_gprobs || !d_len || !d_poff || !d_pidx || !d_tmp || !d_out || !d_nodes || !d_seeds || !d_starts || !d_pool) return VGK_ENOMEM;
-        // (the coded reads and bases travel on the side stream as well, under the fills of the sub-batch before: the wait for the geometry's
-        // answer below covers them)
+        // (the coded reads and bases travel on the side stream as well, under the fills of the sub-batch before ...
         void* d_reads = ensure(ctx, base + S_READS, all.v[3] + 1); void* d_quals = qa ? ensure(ctx, base + S_QUALS, all.v[3] + 1) : nullptr; void* d_graph = ensure(ctx, base + S_GRAPH, all.v[4] + 1);
         if (!d_reads || (qa && !d_quals) || !d_graph) return VGK_ENOMEM;
         int rc;
@@ -1214,8 +1213,9 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
         Q.probs = (const BGeomProb*)d_gprobs; Q.node_len = (const uint32_t*)d_len; Q.pred_off = (const uint32_t*)d_poff; Q.pred_idx = (const uint32_t*)d_pidx;
         Q.tmp = (int32_t*)d_tmp; Q.nodes = (BNode*)d_nodes; Q.seeds = (BSeed*)d_seeds; Q.starts = (BStart*)d_starts; Q.out = (BGeomOut*)d_out;
         if ((rc = be->run_banded_geometry(Q))) return rc;
-        if ((rc = be->upload_side(d_reads, reads, (size_t)all.v[3])) || (qa && (rc = be->upload_side(d_quals, quals, (size_t)all.v[3]))) || (rc = be->upload_side(d_graph, graph, (size_t)all.v[4]))) return rc;
         if ((rc = be->download_side(gout, d_out, (size_t)m * sizeof(BGeomOut)))) return rc;
+        // (... behind the geometry's answer, so that the host does not wait for them; the fills do: main_after_side in launch)
+        if ((rc = be->upload_side(d_reads, reads, (size_t)all.v[3])) || (qa && (rc = be->upload_side(d_quals, quals, (size_t)all.v[3]))) || (rc = be->upload_side(d_graph, graph, (size_t)all.v[4]))) return rc;
         lap("geometry");
         // placement: the problems the geometry accepted keep their slots in the tables; traceback bytes, last columns and op slots are laid out
         // behind each other in their order (serial: three running sums over 40-byte records)
@@ -1271,7 +1271,7 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
         uint8_t* rblock = (uint8_t*)ensure(ctx, base + S_RESULTS, (size_t)S.m * sizeof(BResult) + 64);
         if (!P.tb || !P.last || !P.ops || !P.dense || !rblock) return VGK_ENOMEM;
         P.dense_count = (unsigned long long*)rblock; P.results = (BResult*)(rblock + 64);
-        if ((rc = be->zero(rblock, 64))) return rc;
+        if ((rc = be->zero(rblock, 64)) || (rc = be->main_after_side())) return rc;
         if (P.n && (rc = be->run_banded_async(P, S.launches.data(), (uint32_t)S.launches.size(), set))) return rc;
         if ((rc = be->event_record(H.ev[set]))) return rc;
         lap("launch");
