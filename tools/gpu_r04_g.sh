@@ -4,6 +4,7 @@ timeout -s KILL 400 python -m pytest tests/test_banded.py -m gpu -q -x > $O/pyte
 timeout -s KILL 200 python3 bench.py --workload banded --no-cpu --no-secondary --steps 5 --warmup 2 > $O/bench_banded.json 2> $O/bench_banded.err < /dev/null; echo "bench rc=$?"; tail -3 $O/bench_banded.err
 VGAMD_BANDED_TIMING=1 timeout -s KILL 200 python3 bench.py --workload banded --no-cpu --no-secondary --steps 1 --warmup 0 > /dev/null 2> $O/bench_banded_laps.err < /dev/null
 grep "device geometry" $O/bench_banded_laps.err | tail -22
+timeout -s KILL 120 python3 tools/banded_subs.py 2> /dev/null < /dev/null | tee $O/banded_subs.txt
 python3 - <<'PY'
 import json, os
 O = os.environ.get('GRAFT_REPO_ROOT', '.') + '/gpurun_out/r04g'

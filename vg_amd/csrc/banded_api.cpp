@@ -1120,7 +1120,9 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
     std::memset(mat_rows, 0, BMAT_BYTES);
     if (!qa) { std::memcpy(mat_rows, ctx->sc.matrix, 25); for (int g = 0; g < 5; ++g) std::memcpy(mat_rows + BMAT_ROWS_AT + 8 * g, ctx->sc.matrix + 5 * g, 5); }
     const int8_t* mat = qa ? ctx->qmat.data() : mat_rows;
-    const uint32_t quarter = (n + 3u) / 4u;
+    uint32_t n_subs = 4;                                          // (VGAMD_BANDED_SUBS: 2 .. 16 sub-batches of a call)
+    if (const char* e = std::getenv("VGAMD_BANDED_SUBS")) n_subs = (uint32_t)std::min(16, std::max(2, std::atoi(e)));
+    const uint32_t quarter = (n + n_subs - 1u) / n_subs;
     size_t used = 0; int rc_all = VGK_OK;
 
     struct Sums { uint64_t v[6]; };                              // problems, nodes, edges, read bases, graph bases, (unused)
@@ -1188,14 +1190,10 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
                 pb.L = p.read_len; pb.n_nodes = z.N; pb.graph_len = z.bases; pb.node_base = nb; pb.seed_base = eb; pb.pool_base = 0; pb.start_base = nb;
                 pb.read_off = (uint32_t)at.v[3]; pb.graph_off = (uint32_t)at.v[4]; pb.ops_cap = (uint32_t)(p.read_len + (uint64_t)z.bases + 2ull * z.N + 8);
                 probs[a] = pb;                                      // (rows per lane, candidate ends and the arena offsets follow the geometry)
-                code_bases<true>(reads + pb.read_off, p.read, pb.L);
-                if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
-                code_bases<true>(graph + pb.graph_off, p.graph.seq, pb.graph_len);
                 z.slot = a; S.owner[a] = q;
                 at.v[0] += 1; at.v[1] += z.N; at.v[2] += z.E; at.v[3] += p.read_len; at.v[4] += z.bases;
             }
         });
-        lap("gather");
         // the geometry: raw arrays up on the side stream, a lane per problem behind them, the 40 bytes per problem back
         BGeomParams Q{}; Q.n = m;
         void* d_gprobs = ensure(ctx, gbase + G_PROBS, (uint64_t)m * sizeof(BGeomProb)); void* d_len = ensure(ctx, gbase + G_NODELEN, (all.v[1] + 1) * 4);
@@ -1213,6 +1211,15 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
         Q.probs = (const BGeomProb*)d_gprobs; Q.node_len = (const uint32_t*)d_len; Q.pred_off = (const uint32_t*)d_poff; Q.pred_idx = (const uint32_t*)d_pidx;
         Q.tmp = (int32_t*)d_tmp; Q.nodes = (BNode*)d_nodes; Q.seeds = (BSeed*)d_seeds; Q.starts = (BStart*)d_starts; Q.out = (BGeomOut*)d_out;
         if ((rc = be->run_banded_geometry(Q))) return rc;
+        lap("gather");
+        // while that runs: the reads and the graphs' bases, coded
+        parallel_for(m, [&](uint32_t a, unsigned) {
+            const BProb& pb = probs[a]; const vgk_banded_problem& p = problems[S.owner[a]];
+            code_bases<true>(reads + pb.read_off, p.read, pb.L);
+            if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
+            code_bases<true>(graph + pb.graph_off, p.graph.seq, pb.graph_len);
+        });
+        lap("bases");
         if ((rc = be->download_side(gout, d_out, (size_t)m * sizeof(BGeomOut)))) return rc;
         // (... behind the geometry's answer, so that the host does not wait for them; the fills do: main_after_side in launch)
         if ((rc = be->upload_side(d_reads, reads, (size_t)all.v[3])) || (qa && (rc = be->upload_side(d_quals, quals, (size_t)all.v[3]))) || (rc = be->upload_side(d_graph, graph, (size_t)all.v[4]))) return rc;
