@@ -237,7 +237,7 @@ template <class T> int stage(vgk_ctx* ctx, int slot, const T* v, size_t count, c
 }
 // host arenas kept on the context between calls: uninitialised storage, so a warm call neither zero-fills nor page-faults
 struct PinnedSet {
-    PinnedBuf<BProb> probs; PinnedBuf<BNode> nodes; PinnedBuf<BSeed> seeds; PinnedBuf<uint32_t> pool, order; PinnedBuf<BStart> starts;
+    PinnedBuf<BProb> probs, probs2; PinnedBuf<BNode> nodes; PinnedBuf<BSeed> seeds; PinnedBuf<uint32_t> pool, order; PinnedBuf<BStart> starts;
     PinnedBuf<uint8_t> reads, quals, graph; PinnedBuf<BResult> dres; PinnedBuf<vgk_op> dops; PinnedBuf<unsigned long long> count;
 };
 struct HostArenas {
@@ -1226,17 +1226,33 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
         lap("geometry");
         // placement: the problems the geometry accepted keep their slots in the tables; traceback bytes, last columns and op slots are laid out
         // behind each other in their order (serial: three running sums over 40-byte records)
-        uint64_t tb_bytes = 0, last_elems = 0, ops_total = 0; uint32_t kept = 0;
-        std::vector<uint32_t> keys(m);
-        for (uint32_t a = 0; a < m; ++a) {
-            const BGeomOut& o = gout[a]; GPrep& z = gp[S.owner[a]];
-            if (o.status != VGK_OK) { z.status = o.status; z.on_device = false; continue; }
-            BProb pb = probs[a];                                    // (the kernels count problems, not slots: the accepted ones move up)
-            pb.Hpad = 64u * o.R; pb.n_starts = o.n_starts; pb.tb_base = tb_bytes; pb.last_base = last_elems; pb.ops_off = ops_total;
-            tb_bytes += o.tb_bytes; last_elems += o.last_elems; ops_total += pb.ops_cap;
-            probs[kept] = pb; z.arena = kept;
-            keys[kept] = o.order_key; order[kept] = kept; ++kept;
-        }
+        // (two passes over chunks of slots on the host threads: the accepted problems' sums, then every chunk places its own)
+        struct Place { uint64_t kept, tb, last, ops; };
+        const uint32_t p_chunks = chunk_count(m);
+        std::vector<Place> pl(p_chunks + 1, Place{0, 0, 0, 0});
+        parallel_chunks(m, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+            Place t{0, 0, 0, 0};
+            for (uint32_t a = lo; a < hi; ++a) { const BGeomOut& o = gout[a]; if (o.status != VGK_OK) continue; t.kept += 1; t.tb += o.tb_bytes; t.last += o.last_elems; t.ops += probs[a].ops_cap; }
+            pl[c + 1] = t;
+        });
+        for (uint32_t c = 0; c < p_chunks; ++c) { pl[c + 1].kept += pl[c].kept; pl[c + 1].tb += pl[c].tb; pl[c + 1].last += pl[c].last; pl[c + 1].ops += pl[c].ops; }
+        const uint64_t tb_bytes = pl[p_chunks].tb, last_elems = pl[p_chunks].last, ops_total = pl[p_chunks].ops; const uint32_t kept = (uint32_t)pl[p_chunks].kept;
+        std::vector<uint32_t> keys(std::max<uint32_t>(kept, 1));
+        BProb* placed = A.probs2.get(be, std::max<uint32_t>(kept, 1));      // (the accepted problems move up: the kernels count problems, not slots)
+        if (!placed) return VGK_ENOMEM;
+        parallel_chunks(m, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+            Place at = pl[c];
+            for (uint32_t a = lo; a < hi; ++a) {
+                const BGeomOut& o = gout[a]; GPrep& z = gp[S.owner[a]];
+                if (o.status != VGK_OK) { z.status = o.status; z.on_device = false; continue; }
+                BProb pb = probs[a];
+                pb.Hpad = 64u * o.R; pb.n_starts = o.n_starts; pb.tb_base = at.tb; pb.last_base = at.last; pb.ops_off = at.ops;
+                const uint32_t k = (uint32_t)at.kept;
+                placed[k] = pb; z.arena = k; keys[k] = o.order_key; order[k] = k;
+                at.kept += 1; at.tb += o.tb_bytes; at.last += o.last_elems; at.ops += pb.ops_cap;
+            }
+        });
+        probs = placed;
         if (tb_bytes + last_elems * 4 + ops_total * 2 * sizeof(vgk_op) > budget) return BANDED_NOT_HERE;
         // launches: one per rows-per-lane class; inside a class the problems with the most cells first (counting sort on log2(cells))
         { std::vector<uint32_t> count(6 * 64 + 1, 0), sorted(kept);
@@ -1268,7 +1284,7 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
         BandedParams& P = S.P;
         const uint64_t tb_bytes = S.sizes[6], last_elems = S.sizes[7], ops_total = S.sizes[8];
         int rc;
-        if ((rc = stage(ctx, base + S_PROBS, (const BProb*)A.probs.p, std::max<uint32_t>(P.n, 1), P.probs)) || (rc = stage(ctx, base + S_ORDER, (const uint32_t*)A.order.p, std::max<uint32_t>(P.n, 1), P.order)) ||
+        if ((rc = stage(ctx, base + S_PROBS, (const BProb*)A.probs2.p, std::max<uint32_t>(P.n, 1), P.probs)) || (rc = stage(ctx, base + S_ORDER, (const uint32_t*)A.order.p, std::max<uint32_t>(P.n, 1), P.order)) ||
             (rc = stage(ctx, base + S_MAT, mat, qa ? 6400 : BMAT_BYTES, P.mat))) return rc;
         P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend;
         P.tb = (uint8_t*)ensure(ctx, base + S_TB, std::max<uint64_t>(tb_bytes, 256));
@@ -1306,30 +1322,48 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
             ctx->banded_ms[0] += be->banded_ms(set, 0); ctx->banded_ms[1] += be->banded_ms(set, 1);
             lap("fetch");
         }
-        std::vector<uint32_t> need(j - i, 0);
-        parallel_for(j - i, [&](uint32_t k, unsigned) {
-            const uint32_t q = i + k; const GPrep& z = gp[q]; vgk_result& r = results[q];
-            std::memset(&r, 0, sizeof r);
-            if (!z.on_device) { r.status = z.status; return; }
-            const BResult& dr = dres[z.arena];
-            if (dr.status != VGK_OK) { r.status = dr.status; return; }
-            need[k] = dr.n_ops; r.score = dr.score; r.status = VGK_OK;
+        // statuses, scores and op counts per problem with the chunks' sums beside them; when everything fits the caller's op buffer (the
+        // usual case) a problem's slice follows from the sums and the copy-out is one parallel pass, otherwise the running sum decides problem
+        // by problem which ones still fit, as the host-geometry path does
+        const uint32_t cnt = j - i, n_chunks = chunk_count(cnt);
+        std::vector<uint32_t> need(cnt, 0);
+        struct Tot { uint64_t ops, cells, bytes; };
+        std::vector<Tot> tot(n_chunks + 1, Tot{0, 0, 0});
+        parallel_chunks(cnt, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+            Tot t{0, 0, 0};
+            for (uint32_t k = lo; k < hi; ++k) {
+                const uint32_t q = i + k; const GPrep& z = gp[q]; vgk_result& r = results[q];
+                std::memset(&r, 0, sizeof r);
+                if (!z.on_device) { r.status = z.status; continue; }
+                const BResult& dr = dres[z.arena];
+                t.cells += gout[z.slot].cells; t.bytes += z.in_bytes + gout[z.slot].cells + 2ull * dr.n_ops;
+                if (dr.status != VGK_OK) { r.status = dr.status; continue; }
+                need[k] = dr.n_ops; r.score = dr.score; r.status = VGK_OK; t.ops += dr.n_ops;
+            }
+            tot[c + 1] = t;
         });
-        for (uint32_t q = i; q < j; ++q) {
-            const GPrep& z = gp[q]; vgk_result& r = results[q];
+        for (uint32_t c = 0; c < n_chunks; ++c) { tot[c + 1].ops += tot[c].ops; tot[c + 1].cells += tot[c].cells; tot[c + 1].bytes += tot[c].bytes; }
+        ctx->banded_cells += tot[n_chunks].cells; ctx->banded_bytes += tot[n_chunks].bytes;
+        const bool all_fit = ops && used + tot[n_chunks].ops <= ops_cap;
+        if (!all_fit) for (uint32_t q = i; q < j; ++q) {
+            vgk_result& r = results[q];
             r.ops_begin = (uint32_t)used;
-            if (z.on_device) { ctx->banded_cells += gout[z.slot].cells; ctx->banded_bytes += z.in_bytes + gout[z.slot].cells + 2ull * dres[z.arena].n_ops; }
             if (r.status != VGK_OK) continue;
             if (!ops || used + need[q - i] > ops_cap) { r.status = VGK_EOPS; rc_all = VGK_EOPS; need[q - i] = 0; continue; }
             r.n_ops = need[q - i]; used += need[q - i];
         }
-        parallel_for(j - i, [&](uint32_t k, unsigned) {
-            const uint32_t q = i + k; const vgk_result& r = results[q];
-            if (r.status != VGK_OK || !r.n_ops) return;
-            const BResult& dr = dres[gp[q].arena];
-            const vgk_op* src = dops + dr.ops_begin; vgk_op* out = ops + r.ops_begin;
-            for (uint32_t e = 0; e < dr.n_ops; ++e) { vgk_op o = src[e]; if (o.len == 0) o.op = VGK_OP_M; *out++ = o; }
+        parallel_chunks(cnt, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+            uint64_t at = used + tot[c].ops;
+            for (uint32_t k = lo; k < hi; ++k) {
+                const uint32_t q = i + k; vgk_result& r = results[q];
+                if (all_fit) { r.ops_begin = (uint32_t)at; if (r.status == VGK_OK) { r.n_ops = need[k]; at += need[k]; } }
+                if (r.status != VGK_OK || !r.n_ops) continue;
+                const BResult& dr = dres[gp[q].arena];
+                const vgk_op* src = dops + dr.ops_begin; vgk_op* out = ops + r.ops_begin;
+                for (uint32_t e = 0; e < dr.n_ops; ++e) { vgk_op o = src[e]; if (o.len == 0) o.op = VGK_OP_M; *out++ = o; }
+            }
         });
+        if (all_fit) used += tot[n_chunks].ops;
         lap("results");
         return VGK_OK;
     };
