@@ -5,6 +5,8 @@ best unbanded global alignment over all source-to-sink walks."""
 import itertools
 
 import os
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -277,6 +279,32 @@ def test_emulated_banded_geometry_on_the_device_equals_the_host_geometry(monkeyp
     dev = device_geometry_equals_host_geometry(util.EMU_LIB, problems, monkeypatch)
     assert "device geometry" in capfd.readouterr().err                                  # (the path was taken)
     against_the_oracle(problems, dev)
+
+
+def test_emulated_banded_device_geometry_with_an_op_buffer_too_small(monkeypatch):
+    """the caller's op buffer runs out half way: VGK_EOPS for the call and for every problem whose ops did not fit — the same problems, the same
+    slices for the others, whichever path made the geometry (the running sum decides problem by problem)"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    problems = no_empty_nodes(random_banded_set(71, 60, p_empty=0.0))
+    bs = capi.BandedSet.from_lists(problems)
+    full = capi.Engine(lib=util.EMU_LIB).banded_align(bs)
+    cap = len(full[1]) // 2
+    outs = []
+    for env in ({}, {"VGAMD_BANDED_PIPELINE_MIN": "8"}, {"VGAMD_BANDED_PIPELINE_MIN": "8", "VGAMD_BANDED_HOST_GEOMETRY": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = capi.Engine(lib=util.EMU_LIB)
+        res = np.zeros(bs.n, dtype=capi.RESULT_DT); ops = np.zeros(cap, dtype=capi.OP_DT); written = ctypes.c_size_t()
+        rc = eng.lib.vgk_banded_align(eng.h, bs.ptr, bs.n, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written))
+        for k in env:
+            monkeypatch.delenv(k)
+        assert rc == -6                                                   # VGK_EOPS
+        outs.append((res, ops[:written.value]))
+    one, dev, host = outs
+    assert (one[0]["status"] == -6).any() and (one[0]["status"] == 0).any()
+    for other in (dev, host):
+        assert one[0].tobytes() == other[0].tobytes() and one[1].tobytes() == other[1].tobytes()
 
 
 def against_the_oracle(problems, dev):
