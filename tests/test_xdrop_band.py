@@ -154,6 +154,31 @@ def many_sub_batches(lib, n, monkeypatch):
     same(whole, capi.Engine(lib=util.ORACLE_LIB).xdrop_band_align(ps))
 
 
+def test_emulated_band_with_an_op_buffer_too_small(emu_lib, monkeypatch):
+    """the caller's op buffer runs out half way: VGK_EOPS for the call and for the problems whose ops did not fit — the same ones, with the
+    same bytes for the others, whether the call ran as one batch or as many"""
+    import ctypes
+    ps = random_xdrop_set(33, 60, None, max_nodes=10, max_node_len=16, max_read=60)
+    full = capi.Engine(lib=emu_lib).xdrop_band_align(ps)
+    cap = len(full[1]) // 2
+    outs = []
+    for env in ({}, {"VGAMD_MAX_BATCH_BYTES": "30000"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = capi.Engine(lib=emu_lib)
+        res = np.zeros(ps.n, dtype=capi.RESULT_DT); ops = np.zeros(cap, dtype=capi.OP_DT); written = ctypes.c_size_t(); stats = (ctypes.c_uint64 * 2)()
+        rc = eng.lib.vgk_xdrop_band_align(eng.h, ps.ptr, ps.n, res.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written), ctypes.byref(stats))
+        for k in env:
+            monkeypatch.delenv(k)
+        assert rc == -6
+        outs.append((res.copy(), ops[:written.value].copy()))
+    one, many = outs
+    assert (one[0]["status"] == -6).any() and (one[0]["status"] == 0).any()
+    assert one[0].tobytes() == many[0].tobytes() and one[1].tobytes() == many[1].tobytes()
+    fits = one[0]["status"] == 0
+    assert (one[0]["score"][fits] == full[0]["score"][fits]).all() and (one[0]["n_ops"][fits] == full[0]["n_ops"][fits]).all()
+
+
 def test_emulated_band_in_many_sub_batches(emu_lib, monkeypatch):
     many_sub_batches(emu_lib, 48, monkeypatch)
 

@@ -24,7 +24,7 @@ namespace {
 
 // page-locked staging, kept between calls: the inputs go up and the results come down at the full DMA rate (pageable vectors cost ~7 of 13 host
 // ms per 200 000 tails).  Two sets: a call's sub-batches alternate between them (see below).
-struct BandStage { PinnedBuf<uint8_t> reads, quals, graph, want; PinnedBuf<MProb> probs; PinnedBuf<MNode> nodes; PinnedBuf<uint32_t> preds, order; PinnedBuf<uint64_t> ops_off;
+struct BandStage { PinnedBuf<uint8_t> reads, quals, graph, want; PinnedBuf<uint16_t> bucket; PinnedBuf<MProb> probs; PinnedBuf<MNode> nodes; PinnedBuf<uint32_t> preds, order; PinnedBuf<uint64_t> ops_off;
                    PinnedBuf<vgk_result> dres; PinnedBuf<vgk_op> dops; PinnedBuf<unsigned long long> stat; };
 struct BandHost { BandStage set[2]; void* ev[2] = {nullptr, nullptr}; Backend* be = nullptr;
                   ~BandHost() { if (be) for (void* e : ev) if (e) be->event_destroy(e); } };
@@ -129,6 +129,9 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
         MNode* nodes = St.nodes.get(be, n_nodes + 1); uint32_t* preds = St.preds.get(be, n_preds + 1);
         if (!probs || !reads || (qa && !quals) || !graph || !nodes || !preds) return VGK_ENOMEM;
         std::vector<uint64_t> pred_at(m + 1, 0);                          // where a problem's predecessor lists start in the shared arena
+        uint64_t* ops_off = St.ops_off.get(be, m + 1); uint8_t* want = St.want.get(be, m + 1); uint16_t* bucket_of = St.bucket.get(be, m + 1);
+        if (!ops_off || !want || !bucket_of) return VGK_ENOMEM;
+        ops_off[0] = 0;
         { uint64_t a_cells = 0, a_read = 0, a_graph = 0, a_nodes = 0;
           for (uint32_t a = 0; a < m; ++a) {                                // the places first (a running sum), the contents on the host threads
             const uint32_t q = owner[a];
@@ -136,6 +139,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
             pb.read_off = (uint32_t)a_read; pb.graph_off = (uint32_t)a_graph; pb.node_off = (uint32_t)a_nodes; pb.mat_off = a_cells;
             probs[a] = pb;
             pred_at[a + 1] = pred_at[a] + n_pred_of[q];
+            ops_off[a + 1] = ops_off[a] + pb.L + pb.R + 3ull;
             a_cells += 2ull * pb.R * ((pb.L + 8ull) & ~7ull); a_read += pb.L; a_graph += pb.R; a_nodes += pb.n_nodes;
             rect_total += (uint64_t)pb.R * (pb.L + 1ull);
           } }
@@ -145,6 +149,8 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
                              __builtin_prefetch(q.graph.node_len); __builtin_prefetch(q.graph.pred_off); __builtin_prefetch(q.graph.pred_idx); __builtin_prefetch(q.read);
                              __builtin_prefetch(q.graph.seq); __builtin_prefetch(q.graph.seq + 64); __builtin_prefetch(q.graph.seq + 128); }
             const vgk_gssw_problem& p = problems[owner[a]]; MProb& pb = probs[a];
+            want[a] = (p.flags & VGK_GSSW_TRACEBACK) && !no_tb ? 1 : 0;
+            { constexpr uint32_t B = 4096; const uint32_t r = pb.R < B ? pb.R : B - 1; bucket_of[a] = (uint16_t)((pb.L <= 127u ? 0u : B) + (B - 1 - r)); }      // (launch order, below)
             pb.start_bonus = qa ? ctx->qbon[p.qual[p.read_len - 1]] : ctx->sc.full_length_bonus; pb.status = VGK_OK;
             const int32_t max_gap = (int32_t)std::max<uint32_t>(p.max_gap_length, 1u);
             pb.gap_cells = (max_gap + 7) & ~7; pb.xt = ((int32_t)ctx->sc.gap_open - (int32_t)ctx->sc.gap_extend) + (int32_t)ctx->sc.gap_extend * max_gap;
@@ -178,10 +184,6 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
         P.xb_front = (uint16_t*)dev(D_FRONT, nullptr, sizeof(uint16_t) * (n_graph + 1));
         // the wavefront that fills a problem also picks its end cell, a second kernel walks the tracebacks: results and ops come back, the
         // matrices stay where they are
-        uint64_t* ops_off = St.ops_off.get(be, m + 1); uint8_t* want = St.want.get(be, m + 1);
-        if (!ops_off || !want) return VGK_ENOMEM;
-        ops_off[0] = 0;
-        for (uint32_t a = 0; a < m; ++a) { ops_off[a + 1] = ops_off[a] + probs[a].L + probs[a].R + 3ull; want[a] = (problems[owner[a]].flags & VGK_GSSW_TRACEBACK) && !no_tb ? 1 : 0; }
         if (ops_off[m] >= (1ull << 32)) return VGK_ETOOBIG;
         S.ops_total = ops_off[m];
         // launch order: tails of up to 127 bases four to a wavefront (16 lanes each), the longer ones a wavefront each; inside a class
@@ -191,8 +193,8 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
         uint32_t n16 = 0;
         { constexpr uint32_t B = 4096;
           std::vector<uint32_t> count(2 * B + 1, 0);
-          auto bucket = [&](uint32_t a) { const uint32_t r = probs[a].R < B ? probs[a].R : B - 1; return (probs[a].L <= 127u ? 0u : B) + (B - 1 - r); };
-          for (uint32_t a = 0; a < m; ++a) { ++count[bucket(a) + 1]; if (probs[a].L <= 127u) ++n16; }
+          auto bucket = [&](uint32_t a) { return (uint32_t)bucket_of[a]; };      // (made by the packing threads: 0 .. B - 1 the short tails by descending graph size, B .. 2 B - 1 the long ones)
+          for (uint32_t a = 0; a < m; ++a) { ++count[bucket(a) + 1]; if (bucket_of[a] < B) ++n16; }
           for (uint32_t b = 0; b < 2 * B; ++b) count[b + 1] += count[b];
           for (uint32_t a = 0; a < m; ++a) order[count[bucket(a)]++] = a; }
         P.xb_order = (const uint32_t*)dev(D_ORDER, order, sizeof(uint32_t) * m); P.xb_n16 = n16; P.xb_n64 = m - n16;
@@ -254,25 +256,56 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
             ms += be->xdrop_band_ms(set);
             lap("fetch");
         }
-        // the caller's order: places first (a running sum), then every problem copies its own ops
-        const uint32_t i = S.i, j = S.j;
-        std::vector<uint32_t> from(j - i, 0);
-        uint32_t a = 0;
-        for (uint32_t q = i; q < j; ++q) {
-            vgk_result& r = results[q];
-            if (status[q] != VGK_OK) { std::memset(&r, 0, sizeof r); r.status = status[q]; r.ops_begin = (uint32_t)used; continue; }
-            const uint32_t mine = a++;
-            r = dres[mine];
-            from[q - i] = r.ops_begin;
-            r.ops_begin = (uint32_t)used;
-            if (r.status != VGK_OK) { r.n_ops = 0; continue; }
-            if (used + r.n_ops > ops_cap || (!ops && r.n_ops)) { r.status = VGK_EOPS; r.n_ops = 0; rc_all = VGK_EOPS; continue; }
-            used += r.n_ops;
-        }
-        parallel_for(j - i, [&](uint32_t k, unsigned) {
-            const vgk_result& r = results[i + k];
-            if (r.status == VGK_OK && r.n_ops) std::memcpy(ops + r.ops_begin, dops + from[k], sizeof(vgk_op) * r.n_ops);
+        // the caller's order.  A problem's place among the sub-batch's results is the number of accepted problems before it, its ops' place
+        // the sum of theirs: both from sums over chunks on the host threads when everything fits the caller's op buffer (the usual case);
+        // otherwise the running sum decides problem by problem which ones still fit
+        const uint32_t i = S.i, j = S.j, cnt = j - i, n_chunks = chunk_count(cnt);
+        struct Tot { uint64_t taken, ops; };
+        std::vector<Tot> tot(n_chunks + 1, Tot{0, 0});
+        parallel_chunks(cnt, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+            uint64_t t = 0;
+            for (uint32_t k = lo; k < hi; ++k) t += status[i + k] == VGK_OK;
+            tot[c + 1].taken = t;
         });
+        for (uint32_t c = 0; c < n_chunks; ++c) tot[c + 1].taken += tot[c].taken;
+        parallel_chunks(cnt, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+            uint64_t t = 0;
+            for (uint64_t a = tot[c].taken; a < tot[c + 1].taken; ++a) if (dres[a].status == VGK_OK) t += dres[a].n_ops;
+            (void)lo; (void)hi;
+            tot[c + 1].ops = t;
+        });
+        for (uint32_t c = 0; c < n_chunks; ++c) tot[c + 1].ops += tot[c].ops;
+        const bool all_fit = (ops || !tot[n_chunks].ops) && used + tot[n_chunks].ops <= ops_cap;
+        std::vector<uint32_t> from(cnt, 0);
+        if (!all_fit) {
+            uint32_t a = 0;
+            for (uint32_t q = i; q < j; ++q) {
+                vgk_result& r = results[q];
+                if (status[q] != VGK_OK) { std::memset(&r, 0, sizeof r); r.status = status[q]; r.ops_begin = (uint32_t)used; continue; }
+                const uint32_t mine = a++;
+                r = dres[mine];
+                from[q - i] = r.ops_begin;
+                r.ops_begin = (uint32_t)used;
+                if (r.status != VGK_OK) { r.n_ops = 0; continue; }
+                if (used + r.n_ops > ops_cap || (!ops && r.n_ops)) { r.status = VGK_EOPS; r.n_ops = 0; rc_all = VGK_EOPS; continue; }
+                used += r.n_ops;
+            }
+        }
+        parallel_chunks(cnt, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+            uint64_t mine = tot[c].taken, at = used + tot[c].ops;
+            for (uint32_t k = lo; k < hi; ++k) {
+                vgk_result& r = results[i + k];
+                if (all_fit) {
+                    if (status[i + k] != VGK_OK) { std::memset(&r, 0, sizeof r); r.status = status[i + k]; r.ops_begin = (uint32_t)at; continue; }
+                    r = dres[mine++];
+                    from[k] = r.ops_begin; r.ops_begin = (uint32_t)at;
+                    if (r.status != VGK_OK) { r.n_ops = 0; continue; }
+                    at += r.n_ops;
+                }
+                if (r.status == VGK_OK && r.n_ops) std::memcpy(ops + r.ops_begin, dops + from[k], sizeof(vgk_op) * r.n_ops);
+            }
+        });
+        if (all_fit) used += tot[n_chunks].ops;
         lap("results");
         return VGK_OK;
     };
