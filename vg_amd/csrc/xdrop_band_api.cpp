@@ -112,57 +112,72 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
         BandStage& St = Hs.set[set]; const int* slot = kSlot[set];
         uint64_t n_cells = 0, n_read = 0, n_graph = 0, n_nodes = 0, n_preds = 0;
         S.i = from; S.owner.clear(); S.launched = false; S.ops_total = 0;
-        uint32_t j = from;
+        // where the sub-batch ends: the running sum of cells and the count decide it (two values per problem)
+        uint32_t j = from, taken = 0;
         for (; j < n; ++j) {
             if (status[j] != VGK_OK) continue;
             const uint64_t c3 = 2ull * cols[j] * ((len_of[j] + 8ull) & ~7ull);               // H and E planes; a column is whole 8-row vectors
-            if (!S.owner.empty() && ((n_cells + c3) * cell_bytes > budget || S.owner.size() >= sub_cap)) break;
-            n_cells += c3; n_read += len_of[j]; n_graph += cols[j]; n_nodes += nodes_of[j]; n_preds += n_pred_of[j];
-            S.owner.push_back(j);
+            if (taken && ((n_cells + c3) * cell_bytes > budget || taken >= sub_cap)) break;
+            n_cells += c3; ++taken;
         }
         S.j = j;
-        const uint32_t m = S.m = (uint32_t)S.owner.size();
+        const uint32_t m = S.m = taken;
         if (!m) return VGK_OK;
-        const std::vector<uint32_t>& owner = S.owner;
+        // the places: sums over chunks of [from, j) on the host threads, then every chunk places and packs its own problems
+        struct Sums { uint64_t ok, cells, read, graph, nodes, preds, ops, rect; };
+        const uint32_t span = j - from, n_chunks = chunk_count(span);
+        std::vector<Sums> pre(n_chunks + 1, Sums{0, 0, 0, 0, 0, 0, 0, 0});
+        auto add = [&](Sums& t, uint32_t q) {
+            const uint64_t L = len_of[q], R = cols[q];
+            t.ok += 1; t.cells += 2ull * R * ((L + 8ull) & ~7ull); t.read += L; t.graph += R; t.nodes += nodes_of[q]; t.preds += n_pred_of[q]; t.ops += L + R + 3ull; t.rect += R * (L + 1ull);
+        };
+        parallel_chunks(span, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+            Sums t{0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t q = from + lo; q < from + hi; ++q) if (status[q] == VGK_OK) add(t, q);
+            pre[c + 1] = t;
+        });
+        for (uint32_t c = 0; c < n_chunks; ++c) { Sums& t = pre[c + 1]; const Sums& u = pre[c];
+            t.ok += u.ok; t.cells += u.cells; t.read += u.read; t.graph += u.graph; t.nodes += u.nodes; t.preds += u.preds; t.ops += u.ops; t.rect += u.rect; }
+        const Sums all = pre[n_chunks];
+        n_read = all.read; n_graph = all.graph; n_nodes = all.nodes; n_preds = all.preds; rect_total += all.rect;
+        S.owner.resize(m);
+        std::vector<uint32_t>& owner = S.owner;
         MProb* probs = St.probs.get(be, m + 1);
         uint8_t* reads = St.reads.get(be, n_read + 1); uint8_t* quals = qa ? St.quals.get(be, n_read + 1) : nullptr; uint8_t* graph = St.graph.get(be, n_graph + 1);
         MNode* nodes = St.nodes.get(be, n_nodes + 1); uint32_t* preds = St.preds.get(be, n_preds + 1);
-        if (!probs || !reads || (qa && !quals) || !graph || !nodes || !preds) return VGK_ENOMEM;
-        std::vector<uint64_t> pred_at(m + 1, 0);                          // where a problem's predecessor lists start in the shared arena
         uint64_t* ops_off = St.ops_off.get(be, m + 1); uint8_t* want = St.want.get(be, m + 1); uint16_t* bucket_of = St.bucket.get(be, m + 1);
-        if (!ops_off || !want || !bucket_of) return VGK_ENOMEM;
-        ops_off[0] = 0;
-        { uint64_t a_cells = 0, a_read = 0, a_graph = 0, a_nodes = 0;
-          for (uint32_t a = 0; a < m; ++a) {                                // the places first (a running sum), the contents on the host threads
-            const uint32_t q = owner[a];
-            MProb pb{}; pb.L = len_of[q]; pb.n_nodes = nodes_of[q]; pb.R = (uint32_t)cols[q];
-            pb.read_off = (uint32_t)a_read; pb.graph_off = (uint32_t)a_graph; pb.node_off = (uint32_t)a_nodes; pb.mat_off = a_cells;
-            probs[a] = pb;
-            pred_at[a + 1] = pred_at[a] + n_pred_of[q];
-            ops_off[a + 1] = ops_off[a] + pb.L + pb.R + 3ull;
-            a_cells += 2ull * pb.R * ((pb.L + 8ull) & ~7ull); a_read += pb.L; a_graph += pb.R; a_nodes += pb.n_nodes;
-            rect_total += (uint64_t)pb.R * (pb.L + 1ull);
-          } }
-        parallel_for(m, [&](uint32_t a, unsigned) {
-            // (a problem's arrays are five pointers into the caller's memory, each a miss: the ones of the problem three ahead are asked for now)
-            if (a + 3 < m) { const vgk_gssw_problem& q = problems[owner[a + 3]];
-                             __builtin_prefetch(q.graph.node_len); __builtin_prefetch(q.graph.pred_off); __builtin_prefetch(q.graph.pred_idx); __builtin_prefetch(q.read);
-                             __builtin_prefetch(q.graph.seq); __builtin_prefetch(q.graph.seq + 64); __builtin_prefetch(q.graph.seq + 128); }
-            const vgk_gssw_problem& p = problems[owner[a]]; MProb& pb = probs[a];
-            want[a] = (p.flags & VGK_GSSW_TRACEBACK) && !no_tb ? 1 : 0;
-            { constexpr uint32_t B = 4096; const uint32_t r = pb.R < B ? pb.R : B - 1; bucket_of[a] = (uint16_t)((pb.L <= 127u ? 0u : B) + (B - 1 - r)); }      // (launch order, below)
-            pb.start_bonus = qa ? ctx->qbon[p.qual[p.read_len - 1]] : ctx->sc.full_length_bonus; pb.status = VGK_OK;
-            const int32_t max_gap = (int32_t)std::max<uint32_t>(p.max_gap_length, 1u);
-            pb.gap_cells = (max_gap + 7) & ~7; pb.xt = ((int32_t)ctx->sc.gap_open - (int32_t)ctx->sc.gap_extend) + (int32_t)ctx->sc.gap_extend * max_gap;
-            uint32_t col = 0; uint64_t a_preds = pred_at[a];
-            for (uint32_t v = 0; v < p.graph.n_nodes; ++v) {
-                MNode nd{}; nd.col_start = col; nd.col_end = col + p.graph.node_len[v]; nd.pred_begin = (uint32_t)a_preds; nd.n_pred = p.graph.pred_off[v + 1] - p.graph.pred_off[v];
-                for (uint32_t k = p.graph.pred_off[v]; k < p.graph.pred_off[v + 1]; ++k) preds[a_preds++] = p.graph.pred_idx[k];
-                nodes[pb.node_off + v] = nd; col = nd.col_end;
+        if (!probs || !reads || (qa && !quals) || !graph || !nodes || !preds || !ops_off || !want || !bucket_of) return VGK_ENOMEM;
+        ops_off[m] = all.ops;
+        parallel_chunks(span, [&](uint32_t lo, uint32_t hi, uint32_t c) {
+            Sums at = pre[c];
+            for (uint32_t q = from + lo; q < from + hi; ++q) {
+                if (status[q] != VGK_OK) continue;
+                // (a problem's arrays are five pointers into the caller's memory, each a miss: the ones of the problem three ahead are asked for now)
+                if (q + 3 < from + hi) { const vgk_gssw_problem& nx = problems[q + 3];
+                                         __builtin_prefetch(nx.graph.node_len); __builtin_prefetch(nx.graph.pred_off); __builtin_prefetch(nx.graph.pred_idx); __builtin_prefetch(nx.read);
+                                         __builtin_prefetch(nx.graph.seq); __builtin_prefetch(nx.graph.seq + 64); __builtin_prefetch(nx.graph.seq + 128); }
+                const uint32_t a = (uint32_t)at.ok;
+                const vgk_gssw_problem& p = problems[q];
+                MProb pb{}; pb.L = len_of[q]; pb.n_nodes = nodes_of[q]; pb.R = (uint32_t)cols[q];
+                pb.read_off = (uint32_t)at.read; pb.graph_off = (uint32_t)at.graph; pb.node_off = (uint32_t)at.nodes; pb.mat_off = at.cells;
+                owner[a] = q; ops_off[a] = at.ops;
+                want[a] = (p.flags & VGK_GSSW_TRACEBACK) && !no_tb ? 1 : 0;
+                { constexpr uint32_t B = 4096; const uint32_t r = pb.R < B ? pb.R : B - 1; bucket_of[a] = (uint16_t)((pb.L <= 127u ? 0u : B) + (B - 1 - r)); }      // (launch order, below)
+                pb.start_bonus = qa ? ctx->qbon[p.qual[p.read_len - 1]] : ctx->sc.full_length_bonus; pb.status = VGK_OK;
+                const int32_t max_gap = (int32_t)std::max<uint32_t>(p.max_gap_length, 1u);
+                pb.gap_cells = (max_gap + 7) & ~7; pb.xt = ((int32_t)ctx->sc.gap_open - (int32_t)ctx->sc.gap_extend) + (int32_t)ctx->sc.gap_extend * max_gap;
+                uint32_t col = 0; uint64_t a_preds = at.preds;
+                for (uint32_t v = 0; v < p.graph.n_nodes; ++v) {
+                    MNode nd{}; nd.col_start = col; nd.col_end = col + p.graph.node_len[v]; nd.pred_begin = (uint32_t)a_preds; nd.n_pred = p.graph.pred_off[v + 1] - p.graph.pred_off[v];
+                    for (uint32_t k = p.graph.pred_off[v]; k < p.graph.pred_off[v + 1]; ++k) preds[a_preds++] = p.graph.pred_idx[k];
+                    nodes[pb.node_off + v] = nd; col = nd.col_end;
+                }
+                probs[a] = pb;
+                code_bases<true>(reads + pb.read_off, p.read, pb.L);
+                if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
+                code_bases<false>(graph + pb.graph_off, p.graph.seq, pb.R);
+                add(at, q);
             }
-            code_bases<true>(reads + pb.read_off, p.read, pb.L);
-            if (qa) std::memcpy(quals + pb.read_off, p.qual, pb.L);
-            code_bases<false>(graph + pb.graph_off, p.graph.seq, pb.R);
         });
         lap("pack");
         GsswMatrixParams& P = S.P; P = GsswMatrixParams{};
