@@ -184,7 +184,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
         P.n = m; P.go = ctx->sc.gap_open; P.ge = ctx->sc.gap_extend;
         auto dev = [&](int what, const void* src, size_t bytes) -> void* {
             void* d = ctx->ensure_scratch(slot[what], std::max<size_t>(bytes, 16)); if (!d) return nullptr;
-            if (src && bytes && be->upload(d, src, bytes)) return nullptr;
+            if (src && bytes && be->upload_side(d, src, bytes)) return nullptr;      // (the side stream: under the kernels of the sub-batch before; the launch below waits for them on the device)
             return d;
         };
         // (set 0's slots are the scratch slots of the k-best pinned path: the two calls never overlap under the context lock)
@@ -220,7 +220,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
         if (!P.probs || !P.reads || (qa && !P.quals) || !P.graph || !P.nodes || !P.preds || !P.mat || !P.cells || !P.node_fmax || !P.stats ||
             !P.xb_order || !P.xb_results || !P.xb_ops || !P.xb_ops_off || !P.xb_want_tb || !P.xb_front) return VGK_ENOMEM;
         int rc;
-        if ((rc = be->zero(P.stats, 64))) return rc;
+        if ((rc = be->zero(P.stats, 64)) || (rc = be->main_after_side())) return rc;
         if ((rc = be->run_xdrop_band_async(P, set))) return rc;
         if ((rc = be->event_record(Hs.ev[set]))) return rc;
         S.launched = true;
@@ -335,7 +335,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
         set ^= 1;
     }
     if (pending && rc == VGK_OK) rc = finish(subs[set ^ 1], set ^ 1);
-    if (rc != VGK_OK) { be->sync(); be->sync_fetch(); return rc; }      // (nothing of this call stays in flight behind an error)
+    if (rc != VGK_OK) { be->sync_side(); be->sync(); be->sync_fetch(); return rc; }      // (nothing of this call stays in flight behind an error)
     ctx->xband_ms = ms; ctx->xband_cells = !cell16 ? 4 : (cell_form == 2 ? 2 : 3);
     if (ops_written) *ops_written = used;
     if (stats) { stats[0] = in_band_total; stats[1] = rect_total; }
