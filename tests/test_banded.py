@@ -275,7 +275,7 @@ def device_geometry_problems(seed, n, n_mixed, wide_read=700, wide_pad=520, mixe
 def test_emulated_banded_geometry_on_the_device_equals_the_host_geometry(monkeypatch, capfd):
     import subprocess
     subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
-    problems = device_geometry_problems(61, 48, 2, wide_read=90, wide_pad=70, mixed_read=80)      # (the emulator steps every lane: narrower wide ones)
+    problems = device_geometry_problems(61, 30, 2, wide_read=90, wide_pad=70, mixed_read=80)      # (the emulator steps every lane: narrower wide ones)
     dev = device_geometry_equals_host_geometry(util.EMU_LIB, problems, monkeypatch)
     assert "device geometry" in capfd.readouterr().err                                  # (the path was taken)
     against_the_oracle(problems, dev)
@@ -286,7 +286,7 @@ def test_emulated_banded_device_geometry_with_an_op_buffer_too_small(monkeypatch
     slices for the others, whichever path made the geometry (the running sum decides problem by problem)"""
     import subprocess
     subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
-    problems = no_empty_nodes(random_banded_set(71, 60, p_empty=0.0))
+    problems = no_empty_nodes(random_banded_set(71, 32, p_empty=0.0))
     bs = capi.BandedSet.from_lists(problems)
     full = capi.Engine(lib=util.EMU_LIB).banded_align(bs)
     cap = len(full[1]) // 2

@@ -64,7 +64,7 @@ def fallbacks_picked_from_flat_connects(lib, n_reads, read_len, seed):
 
 
 def test_fallback_batch_picked_from_flat_connects(emu_lib):
-    fallbacks_picked_from_flat_connects(emu_lib, 8, 5000, 9)
+    fallbacks_picked_from_flat_connects(emu_lib, 5, 5000, 9)
 
 
 @pytest.mark.gpu
