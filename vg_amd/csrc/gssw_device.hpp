@@ -765,7 +765,7 @@ VGK_HD void walk_one(const GsswParams& P, uint32_t i, unsigned long long best_ke
 // the run, and the traceback — which prefers the diagonal among equals (lane_row's tag order) and stops where H is 0 — is that run.  The
 // scores need only the read's and the columns' bytes: the 160 of each before the end cell are fetched as ten 16-byte words apiece, all asked
 // for at once, and the run is checked out of registers; nothing else is read but the descriptor, the end cell's key and two node records.
-// What this pass does not settle — a gap, a node on the way with other predecessors than the node before it (CI_SEED_SLOW), the window's edge,
+// What this pass does not settle — a gap, the window's edge,
 // quality-adjusted profiles, pinned and X-drop problems, reads of more than 160 bases — it leaves alone: W_MISSED, and walk_one does the read.
 constexpr uint32_t WD_STEPS = 160, WD_DWORDS = WD_STEPS / 4;
 struct alignas(16) WdQuad { uint32_t x, y, z, w; };
@@ -818,16 +818,47 @@ VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long
     uint32_t n_it = (uint32_t)r + 1u < c + 1u ? (uint32_t)r + 1u : c + 1u;      // cells on the diagonal inside the window ...
     n_it = n_it < WD_STEPS ? n_it : WD_STEPS;                                      // ... and inside the blocks
     uint32_t rw = 0, cw = 0;
+    bool fresh = true;                                                // the cached words are to be read (again)
+    uint32_t col_base = c;                                            // step k's cell lies in window column col_base - k (re-based where the run jumps to another node's columns)
     for (uint32_t k = 0; k < n_it; ++k) {
         const uint32_t at = WD_STEPS - 1u - k;
-        if ((at & 3u) == 3u || k == 0) { rw = blk[(at >> 2) * stride]; cw = blk[(WD_DWORDS + (at >> 2)) * stride]; }
+        if ((at & 3u) == 3u || fresh) { rw = blk[(at >> 2) * stride]; cw = blk[(WD_DWORDS + (at >> 2)) * stride]; fresh = false; }
         const uint32_t ci = (cw >> (8u * (at & 3u))) & 0xffu, q = (rw >> (8u * (at & 3u))) & 0xffu;
         v -= (int32_t)tab[8u * q + (ci & CI_BASE_MASK)] + (k == (uint32_t)r ? (int32_t)d.bonus_start : 0);
         ++taken;
         if (v <= 0) { verdict = v == 0 ? 1 : -1; break; }
-        if (ci & CI_NODE_START) {                                      // on into the node before this one — if that is its only predecessor
-            if ((ci & CI_SEED_SLOW) || run_node == 0u) { verdict = -1; break; }
-            put(run_node, VGK_OP_M, taken - run_from); run_node -= 1u; run_from = taken;
+        if (ci & CI_NODE_START) {
+            if (!(ci & CI_SEED_SLOW) && run_node != 0u) {              // on into the node before this one: its only predecessor, the columns go on
+                put(run_node, VGK_OP_M, taken - run_from); run_node -= 1u; run_from = taken;
+                continue;
+            }
+            // A node with other predecessors than the node before it.  The traceback takes the first of them, in their order, whose H in the
+            // row above equals what the run needs (walk_body) — H of a node's last column is what the fill keeps for its successors
+            // (P.scratch) — and if the run then arrives at 0 that H was the cell's (the proof above, unchanged: the chosen cell IS a
+            // diagonal predecessor).  The predecessor's columns lie somewhere else in the stream: the column block is fetched again,
+            // ending where the run goes on.
+            const uint32_t row = (uint32_t)r - k;
+            if (row == 0u || k + 1u >= WD_STEPS) { verdict = -1; break; }
+            const NodeRec nr = nodes[run_node];
+            int32_t found = -1;
+            if (nr.n_pred == 1u) found = (int32_t)P.preds[nr.pred_begin];
+            else for (uint32_t kk = 0; kk < nr.n_pred; ++kk) {
+                const uint32_t p = P.preds[nr.pred_begin + kk];
+                const int32_t slot = nodes[p].slot;
+                if (slot >= 0 && (int32_t)(P.scratch[d.scratch_off + (uint32_t)slot * d.Lpad + (row - 1u)] & 0xffffu) == v) { found = (int32_t)p; break; }
+            }
+            if (found < 0) { verdict = -1; break; }
+            const uint32_t pc = nodes[found].col_end - 1u, c_abs = d.col_off + pc, next_at = WD_STEPS - 2u - k;      // the next cell's column, and its byte in the block
+            if (c_abs < next_at) { verdict = -1; break; }                // (a block that would start before the arena)
+            put(run_node, VGK_OP_M, taken - run_from); run_node = (uint32_t)found; run_from = taken;
+            const uint8_t* csrc = P.colinfo + (c_abs - next_at);
+            for (uint32_t j = 0; 4u * j <= next_at; ++j) {               // dwords 0 .. next_at / 4 (the bytes behind next_at are steps already taken; never past c_abs + 3: the arena's padding)
+                uint32_t w; __builtin_memcpy(&w, csrc + 4u * j, 4);
+                blk[(WD_DWORDS + j) * stride] = w;
+            }
+            fresh = true; col_base = pc + k + 1u;
+            const uint32_t more = row < pc + 1u ? row : pc + 1u;         // cells left on the diagonal: rows above, columns of the window from pc down
+            n_it = k + 1u + more < WD_STEPS ? k + 1u + more : WD_STEPS;
         }
     }
     const uint32_t run_len = taken - run_from;                        // (the window's edge or the blocks' before H reached 0: walk_body's business)
@@ -836,7 +867,7 @@ VGK_HD int32_t walk_diag_one(const GsswParams& P, uint32_t i, unsigned long long
     const int32_t r_left = r - (int32_t)taken;                        // rows above the alignment: a soft clip
     if (r_left >= 0) put(run_node, VGK_OP_S, (uint32_t)r_left + 1u);
     if (!room_ok) return W_MISSED;
-    const uint32_t first_c = c - (taken - 1u);
+    const uint32_t first_c = col_base - (taken - 1u);
     res.n_ops = d.ops_cap - pos; res.ops_begin = d.ops_off + pos;
     res.first_offset = (int32_t)(first_c - nodes[run_node].col_start);
     P.results[i] = res;
