@@ -841,7 +841,7 @@ static int banded_align_pipelined(vgk_ctx* ctx, const vgk_banded_problem* proble
 
     // ---- first half of a sub-batch: geometry of its quarter (if not there yet), placement, arenas, upload, launch
     auto build = [&](uint32_t from, BSub& S, int set) -> int {
-        PinnedSet& A = H.set[set]; const int base = set ? S_SET1 : 0;
+        PinnedSet& A = H.set[set];
         const uint32_t limit = std::min<uint32_t>(n, (from / quarter + 1u) * quarter);
         if (prepared < limit) {
             // the node records — 64 bytes a node, the bulk of the tables — are written straight into the quarter's page-locked table, a
@@ -1152,7 +1152,7 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
                 if (st == VGK_OK && p.read_len > 65535u) st = VGK_ETOOBIG;
                 // (a padding of 2^26 diagonals and more, a graph of more than 2^24 bases: prepare() declines them, but after its band pass
                 // — VGK_ETOOBIG or VGK_ENOBAND, whichever test comes first there; the lane's 32-bit diagonals need not see such a problem)
-                if (st == VGK_OK && (p.band_padding >= (1u << 26) || total > (1u << 24))) { not_here.store(1, std::memory_order_relaxed); st = VGK_ETOOBIG; }
+                if (st == VGK_OK && ((uint32_t)p.band_padding >= (1u << 26) || total > (1u << 24)))      // (a negative padding too: the host path's answer) { not_here.store(1, std::memory_order_relaxed); st = VGK_ETOOBIG; }
                 if (st != VGK_OK) { z.status = st; continue; }
                 z.E = g.pred_off[N] - g.pred_off[0]; z.bases = (uint32_t)total; z.on_device = true;
                 z.in_bytes = p.read_len + total + 8ull * N + 4ull * g.pred_off[N] + 16;
