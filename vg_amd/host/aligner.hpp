@@ -40,6 +40,7 @@ struct MatrixAlignmentScorer {
     int8_t score_matrix[25];
     int8_t match, mismatch, gap_open, gap_extension, full_length_bonus;
     MatrixAlignmentScorer(const int8_t* score_matrix_4x4, int8_t go, int8_t ge, int8_t bonus);
+    virtual ~MatrixAlignmentScorer() = default;      // (an aligner owns its scorer through this type: a QualAdjAlignmentScorer's tables must go with it)
     // reference: src/alignment_scorer.cpp:264-271
     size_t longest_detectable_gap(size_t read_length, size_t read_pos) const;
     // re-score an alignment from its edits: matches, substitutions, gaps (a deletion that runs on across a node boundary opens once), the
