@@ -232,3 +232,33 @@ def test_speculative_fill_over_random_dags(emu_lib, monkeypatch):
             assert (r[f] == ro[f]).all(), f
         for i in range(ps.n):
             assert capi.cigar_string(r[i], o) == capi.cigar_string(ro[i], oo), i
+
+
+# ... and over WIDE graphs (380-420 columns, nodes of up to 48 bases, predecessors from anywhere before): a run that crosses into a predecessor
+# far back in the column stream fetches its column block again (walk_diag_one), several times along one read; a few graphs are put first in
+# the batch, where a block that would start before the arena is refused.
+def test_first_pass_crosses_far_predecessors(emu_lib):
+    from gen import random_dag, random_walk_read
+    rng = np.random.default_rng(777)
+    problems = []
+    while len(problems) < 1100:
+        nodes, preds = random_dag(rng, int(rng.integers(10, 18)), 48, p_chain=0.45)
+        if not 380 <= sum(len(x) for x in nodes) <= 420:
+            continue
+        read = random_walk_read(rng, nodes, preds, int(rng.integers(86, 95)), sub=0.02, indel=0.002)
+        if not 86 <= len(read) <= 94:
+            continue
+        problems.append({"read": read, "nodes": nodes, "preds": preds, "flags": capi.VGK_GSSW_LOCAL | capi.VGK_GSSW_TRACEBACK, "pinning": None})
+    ps = problem_set(problems)
+    for sc in (capi.Scoring.simple(1, 4, 6, 1, 5), capi.Scoring.simple(2, 2, 3, 1, 0)):
+        ro, oo = capi.Engine(sc, lib=ORACLE_LIB).align(ps, 0)
+        eng = capi.Engine(sc, lib=emu_lib)
+        with eng.pack(ps, 0) as b:
+            b.run(); b.sync()
+            refilled = b.kernel_ms(3)                                  # (the emulator: wavefronts laid out again)
+            r, o = b.fetch()
+        assert 0 < refilled < 1100 // 16 * 0.8                          # the batch speculated, and most reads were settled by runs
+        for f in ("status", "score", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
+            assert (r[f] == ro[f]).all(), f
+        for i in range(ps.n):
+            assert capi.cigar_string(r[i], o) == capi.cigar_string(ro[i], oo), i
