@@ -307,6 +307,32 @@ def test_emulated_banded_device_geometry_with_an_op_buffer_too_small(monkeypatch
         assert one[0].tobytes() == other[0].tobytes() and one[1].tobytes() == other[1].tobytes()
 
 
+def test_emulated_banded_device_geometry_declines_what_the_checks_decline(monkeypatch):
+    """a forward-pointing predecessor (VGK_EINVAL), a negative / huge band padding, a node past 65 535 bases: the device-geometry path gives the
+    statuses of the one-batch call and of the host-geometry path, and never hands such a problem to the geometry kernel (round-4 advisor: the
+    guard's body had slid into a comment)"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    problems = no_empty_nodes(random_banded_set(81, 24, p_empty=0.0))
+    problems.insert(3, dict(read="ACGTAC", nodes=["ACG", "TAC", "GT"], preds=[[], [2], [0]], band_padding=1, permissive=True))      # pred_idx >= v
+    problems.insert(6, dict(read="ACGTAC", nodes=["ACG", "TAC"], preds=[[], [7]], band_padding=1, permissive=True))                 # pred_idx >= N
+    problems.insert(10, dict(read="ACGT", nodes=["A" * 70000], preds=[[]], band_padding=1, permissive=True))
+    for extra in ([], [dict(read="ACGTACGT", nodes=["ACGT", "ACGT"], preds=[[], [0]], band_padding=-5, permissive=True)],
+                  [dict(read="ACGTACGT", nodes=["ACGT", "ACGT"], preds=[[], [0]], band_padding=1 << 27, permissive=True)]):
+        ps = problems + extra
+        bs = capi.BandedSet.from_lists(ps)
+        whole = capi.Engine(lib=util.EMU_LIB).banded_align(bs)
+        monkeypatch.setenv("VGAMD_BANDED_PIPELINE_MIN", "8")
+        dev = capi.Engine(lib=util.EMU_LIB).banded_align(bs)
+        monkeypatch.setenv("VGAMD_BANDED_HOST_GEOMETRY", "1")
+        host = capi.Engine(lib=util.EMU_LIB).banded_align(bs)
+        monkeypatch.delenv("VGAMD_BANDED_HOST_GEOMETRY"); monkeypatch.delenv("VGAMD_BANDED_PIPELINE_MIN")
+        assert int(whole[0]["status"][3]) == -1 and int(whole[0]["status"][6]) == -1 and int(whole[0]["status"][10]) == -7
+        for other in (dev, host):
+            assert (whole[0]["status"] == other[0]["status"]).all(), (whole[0]["status"], other[0]["status"])
+            assert not _same(ps, whole, other)
+
+
 def against_the_oracle(problems, dev):
     """what the engine aligned or found band-less is the oracle's answer; what it declines (a band of more than 2048 diagonals, a node of more
     than 65 535 bases) the oracle may well align"""

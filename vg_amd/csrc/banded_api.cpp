@@ -1152,7 +1152,10 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
                 if (st == VGK_OK && p.read_len > 65535u) st = VGK_ETOOBIG;
                 // (a padding of 2^26 diagonals and more, a graph of more than 2^24 bases: prepare() declines them, but after its band pass
                 // — VGK_ETOOBIG or VGK_ENOBAND, whichever test comes first there; the lane's 32-bit diagonals need not see such a problem)
-                if (st == VGK_OK && ((uint32_t)p.band_padding >= (1u << 26) || total > (1u << 24)))      // (a negative padding too: the host path's answer) { not_here.store(1, std::memory_order_relaxed); st = VGK_ETOOBIG; }
+                // (a negative padding too: the host path's answer)
+                if (st == VGK_OK && ((uint32_t)p.band_padding >= (1u << 26) || total > (1u << 24))) {
+                    not_here.store(1, std::memory_order_relaxed); st = VGK_ETOOBIG;
+                }
                 if (st != VGK_OK) { z.status = st; continue; }
                 z.E = g.pred_off[N] - g.pred_off[0]; z.bases = (uint32_t)total; z.on_device = true;
                 z.in_bytes = p.read_len + total + 8ull * N + 4ull * g.pred_off[N] + 16;

@@ -5,21 +5,38 @@
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include "rescue_fixups.hpp"
 
 namespace vgamd {
 
 namespace {
+// body(k) for k in [0, n) on up to `threads` host threads.  A body that throws (an engine status inside fix_dozeu_score's re-alignment, bad_alloc
+// building a subgraph) stops the handing-out of work; the first exception is kept and rethrown on the caller after the join — an exception that
+// left a std::thread's function would be std::terminate (Aligner::xdrop_align_many's `each` has the same rule).
 template <class F> void on_threads(size_t n, unsigned threads, F body) {
     if (!threads) threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
     threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(n, 1));
     std::atomic<size_t> next{0};
-    auto work = [&]() { for (size_t i; (i = next.fetch_add(64)) < n;) for (size_t k = i; k < std::min(n, i + 64); ++k) body(k); };
+    std::atomic<bool> failed{false};
+    std::mutex first_mutex; std::exception_ptr first;
+    auto work = [&]() {
+        try {
+            for (size_t i; !failed.load(std::memory_order_relaxed) && (i = next.fetch_add(64)) < n;)
+                for (size_t k = i; k < std::min(n, i + 64); ++k) body(k);
+        } catch (...) {
+            std::lock_guard<std::mutex> hold(first_mutex);
+            if (!first) first = std::current_exception();
+            failed.store(true, std::memory_order_relaxed);
+        }
+    };
     std::vector<std::thread> ts;
     for (unsigned t = 1; t < threads; ++t) ts.emplace_back(work);
     work();
     for (auto& t : ts) t.join();
+    if (first) std::rethrow_exception(first);
 }
 }  // namespace
 
