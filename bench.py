@@ -28,6 +28,38 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 RDEV = "cpu" if os.environ.get("VGAMD_BENCH_ONE_DEVICE") == "1" else "cuda"      # where the max-reduce of the times lives (gloo in the one-device check)
 
+
+def _device_sync(torch):
+    """torch.cuda.synchronize() — a no-op only in the one-device functional check on a box without a GPU (the emulated engine on the CPU:
+    VGAMD_BENCH_ONE_DEVICE=1 with VGAMD_ENGINE_LIB naming tests/emu's library), where there is no device to wait for"""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    elif os.environ.get("VGAMD_BENCH_ONE_DEVICE") != "1":
+        raise SystemExit("bench.py: no GPU visible (the measurement needs one; VGAMD_BENCH_ONE_DEVICE=1 is the functional check)")
+
+
+def _set_device(torch, index):
+    if torch.cuda.is_available():
+        torch.cuda.set_device(index)
+    elif os.environ.get("VGAMD_BENCH_ONE_DEVICE") != "1":
+        raise SystemExit("bench.py: no GPU visible (the measurement needs one; VGAMD_BENCH_ONE_DEVICE=1 is the functional check)")
+
+
+def relaunch_on_ranks(n_gpus):
+    """`python bench.py --gpus N` without a launcher around it (no WORLD_SIZE in the environment): run this very command line again as N ranks,
+    one per GPU, under torch.distributed.run on 127.0.0.1 — what the driver's own `python -m torch.distributed.run --nproc-per-node N bench.py
+    --gpus N ...` does — and hand its exit code back.  Rank 0 of that run prints the JSON line (n_gpus = N)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:                     # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 # HBM bytes per unit of work of the dominant kernel: STORED constants from the PMC passes committed under profiles/r02 (rocprofv3 --pmc
 # FETCH_SIZE and --pmc WRITE_SIZE in separate runs of the same workload; KiB per launch, FETCH_SIZE doubled as MI355X_MICROARCH.md
 # prescribes for gfx950).  bench.py cannot read counters itself, so `roofline.traffic` = this figure x the units of one launch and
@@ -66,10 +98,10 @@ def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
     index = eng.haplo_index(wl.nodes, wl.threads)          # the haplotype index is resident in HBM from here on
 
     def barrier():
-        torch.cuda.synchronize()
+        _device_sync(torch)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _device_sync(torch)
 
     eng.gapless_extend(index, wl.gs)                       # warms the cached buffers
     te = time.perf_counter(); out = eng.gapless_extend(index, wl.gs); te = time.perf_counter() - te
@@ -132,10 +164,10 @@ def bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus):
     index = eng.haplo_index(wl.nodes, wl.threads)
 
     def barrier():
-        torch.cuda.synchronize()
+        _device_sync(torch)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _device_sync(torch)
 
     eng.wfa_extend(index, wl.ws)                           # warms the cached buffers
     te = time.perf_counter(); out = eng.wfa_extend(index, wl.ws); te = time.perf_counter() - te
@@ -208,10 +240,10 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
     wl = workloads.BandedWorkload(n, seed=99 + rank)
 
     def barrier():
-        torch.cuda.synchronize()
+        _device_sync(torch)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _device_sync(torch)
 
     # from host buffers: the call as a caller makes it — a large one runs as four sub-batches, two in flight (banded_align_pipelined)
     eng.banded_align(wl.bs); eng.banded_align(wl.bs)       # warm the cached staging and device buffers
@@ -306,10 +338,10 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
     stage.set_point_budgets(0, 0)
 
     def barrier():
-        torch.cuda.synchronize()
+        _device_sync(torch)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _device_sync(torch)
 
     def timed(steps, timing=None):
         barrier()
@@ -404,10 +436,10 @@ def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
     threads = int(os.environ.get("VGAMD_HOST_THREADS", "0")) or min(shard.usable_cpus(), 48)
 
     def barrier():
-        torch.cuda.synchronize()
+        _device_sync(torch)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _device_sync(torch)
 
     for _ in range(max(1, args.warmup)):
         pipeline.paired_stage(eng, index, mindex, wl, aligner, host_threads=threads)
@@ -488,10 +520,10 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
         def __init__(self, k): self.n = k
 
     def barrier():
-        torch.cuda.synchronize()
+        _device_sync(torch)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _device_sync(torch)
 
     kernel_ms = {"minimizer": 0.0, "gapless": 0.0, "tails derived": 0.0, "tail forest": 0.0, "windows packed": 0.0, "x-drop fill + traceback + totals": 0.0}
     import threading
@@ -662,10 +694,10 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
     index = eng.haplo_index(wl.nodes, wl.threads)
 
     def barrier():
-        torch.cuda.synchronize()
+        _device_sync(torch)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _device_sync(torch)
 
     stage = pipeline.align_stage if os.environ.get("VGAMD_GIRAFFE_NUMPY_GLUE") else pipeline.align_stage_native      # the glue in the host shim (C++) or in numpy
     device_tails = not os.environ.get("VGAMD_GIRAFFE_HOST_TAILS") and stage is pipeline.align_stage_native          # ... or no glue: vgk_tail_stage on the device
@@ -820,10 +852,10 @@ def bench_forest(args, eng, rank, world, dist, torch, dev_name, cus):
     index = eng.haplo_index(wl.nodes, wl.threads)
 
     def barrier():
-        torch.cuda.synchronize()
+        _device_sync(torch)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _device_sync(torch)
 
     def step(keep=False):
         t = [time.perf_counter()]
@@ -941,10 +973,10 @@ def bench_tails(args, eng, rank, world, dist, torch, dev_name, cus):
     n_tails = sum(b.ps.n for b in batches)
 
     def barrier():
-        torch.cuda.synchronize()
+        _device_sync(torch)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _device_sync(torch)
 
     for _ in range(args.warmup):
         for b in batches:
@@ -1118,9 +1150,17 @@ def main():
                          "banded global alignments between chained anchors; gapless = giraffe's first stage: "
                          "haplotype-consistent gapless extension of seeds; wfa = the long-read chaining stage's WFA connects and tails")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:          # no launcher around this process: become one
+        raise SystemExit(relaunch_on_ranks(args.gpus))
 
     from vg_amd import shard
     rank, local_rank, world = shard.env_rank()
+    if world != args.gpus and args.gpus == 1:
+        args.gpus = world                                          # (a launcher without --gpus: its rank count is the answer)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE): the two must agree" % (args.gpus, world))
     import torch   # first, so its bundled HIP runtime is the one the engine library binds to
     dist = None
     # VGAMD_BENCH_ONE_DEVICE=1: a functional check of the N > 1 code path on a box with ONE GPU (every rank on device 0, gloo for
@@ -1131,15 +1171,15 @@ def main():
     if world > 1 and one_device:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(0)
+        _set_device(torch, 0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     elif world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        _set_device(torch, local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
-        torch.cuda.set_device(local_rank)
+        _set_device(torch, local_rank)
 
     import numpy as np
     from vg_amd import capi, workloads
@@ -1204,10 +1244,10 @@ def main():
     t_pack = time.time() - t0
 
     def barrier():
-        torch.cuda.synchronize()
+        _device_sync(torch)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _device_sync(torch)
 
     for _ in range(args.warmup):
         batch.run()
@@ -1382,7 +1422,7 @@ def main():
         # `value` stays the one-stream loop: its per-launch durations are each kernel's own (the roofline below needs that).  The
         # two-lane steady state (config.two_lanes) and the streaming legs from host buffers (end_to_end_*) run fills of consecutive
         # batches side by side, where a launch's wall time is no longer its own.
-        fill_step = sum(fill_ms) / len(fill_ms)          # all fill launches of one step
+        fill_step = (sum(fill_ms) / len(fill_ms)) or 1e-9          # all fill launches of one step (the emulated engine of the functional check reports no kernel time)
         fill_avg = fill_step / n_launch                  # average duration of one fill launch
         # A speculative batch fills twice: every read without traceback codes, then — inside the traceback tail — the reads that need codes
         # again with them.  The algorithmic bytes (SURVEY \u00a78(d): a byte of traceback per cell among them) are the job's, so they are priced
@@ -1399,7 +1439,7 @@ def main():
         elif not tails and wave_steps:
             cyc = 259 * 4 + 94 * 2 + 75 * 4
             valu = {"wave_steps": wave_steps, "issue_cycles_per_step_model": cyc, "simds": 4 * cus, "clock_ghz": 2.4,
-                    "frac_of_issue_peak": wave_steps * cyc / (4 * cus * 2.4e9 * fill_step * 1e-3),
+                    "frac_of_issue_peak": wave_steps * cyc / (4 * max(cus, 1) * 2.4e9 * fill_step * 1e-3),
                     "source": "instruction mix from the ISA listing of gssw_fill_kernel<19,true> (DESIGN.md), issue costs from tools/valu_rate.hip"}
         out = {
             "metric": "tail alignments/sec (pinned X-drop, 1-121 bp)" if tails else "reads/sec aligned (150 bp)",
