@@ -552,6 +552,7 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
                 tot["full_length"] += int((out["res"]["full_length"] != 0).sum()); tot["truncated"] += int(e.minimizers_truncated.sum())
                 if keep is not None and b == 0:
                     keep.update(read_score=out["read_score"].copy(), res=out["res"].copy(), ext=out["ext"].copy(), nodes=out["nodes"].copy(), seed_off=seed_off.copy(),
+                                ext_total=out["ext_total"].copy(), tails=out["tails"].copy(), tail_ops=out["tail_ops"].copy(),
                                 n_minimizers=int((np.asarray(mins, dtype=np.int64) & 0x7fffffff).sum()) if mins is not None else 19 * (len(off) - 1))
 
     def new_tot():
@@ -629,7 +630,25 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
         cpu = {"value": k / tc, "unit": "reads/s", "cores": cores, "kind": "port",
                "impl": "the same stage over the oracle: vgo_minimizer.c, vgo_gapless.c (OpenMP over reads), vgo_tail.c, vgo_xdrop.c (OpenMP over problems)",
                "sample": "the first %d reads of the first batch" % k}
-        parity = {"checked": k, "identical": same, "what": "per-read best total score (extension + both tails' X-drop alignments); tests/test_giraffe_stage.py compares every intermediate product"}
+        # every product of the stage for those reads, not their scores alone: the seeds' counts, every extension of every set (interval, offset,
+        # mismatches, score, both search states, every node of its path), every extension's total, and every TAIL ALIGNMENT the engine chose on the
+        # device (vgk_tail_stage_aligned: score, read interval, first offset, every op with its oriented node) against the best tree's alignment of
+        # the oracle's stage (pipeline.winning_alignment_arrays)
+        tc2 = time.perf_counter()
+        n_ext_k = int(o["res"]["n_ext"].sum())
+        sets_same = pipeline.compare_extension_sets(first["res"], first["ext"], first["nodes"], o["res"], o["ext"], o["nodes"], k)
+        totals_same = int((first["ext_total"][:n_ext_k] == o["ext_total"][:n_ext_k]).sum())
+        tails_verdict = pipeline.compare_tail_alignments(first["tails"], first["tail_ops"], pipeline.winning_alignment_arrays(o), n_ext=n_ext_k)
+        seeds_same = int((np.diff(first["seed_off"][:k + 1].astype(np.int64)) == np.diff(np.asarray(so, dtype=np.int64))).sum())
+        parity = {"checked": k, "identical": min(same, sets_same, seeds_same) if tails_verdict["identical"] == tails_verdict["tails"] and totals_same == n_ext_k else min(same, sets_same, seeds_same, tails_verdict["identical"]),
+                  "reads_with_identical_best_score": same, "reads_with_identical_seed_count": seeds_same, "reads_with_identical_extension_sets": sets_same,
+                  "extensions": n_ext_k, "extensions_with_identical_total": totals_same,
+                  "tail_alignments": tails_verdict["tails"], "tail_alignments_identical": tails_verdict["identical"], "tail_alignment_ops": tails_verdict["ops"],
+                  "first_differing_tail": tails_verdict["first_bad"], "compare_seconds": time.perf_counter() - tc2,
+                  "what": "ALIGNMENTS, not scores: for every one of the checked reads its seed count, every extension of its set (read interval, offset, mismatches, score, both haplotype "
+                          "search states, every path node), every extension's total, and every tail alignment chosen on the device — score, read interval, first offset and every "
+                          "(oriented node, op, length) — against the oracle stage's best tree per tail (src/minimizer_mapper.cpp:5654-5716); `identical` counts a read only when all of that agrees "
+                          "(and is capped by the identical tail alignments when any tail differs)"}
     if rank == 0:
         steps = args.steps
         # the stage's dominant kernel: the gapless search; its algorithmic bytes as in --workload gapless (the read once per seed, outputs)
@@ -1144,6 +1163,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the legs that overlap launches — the two-lane steady state and the warm / double-buffered end-to-end legs — so that a profiler's per-kernel averages are each kernel's own")
     ap.add_argument("--no-secondary", action="store_true", help="default (linear, one GPU) run: do not append the `secondary` records — the other kernel families' own bench lines, each run "
                          "as `bench.py --workload X` in a process of its own after the headline has been measured")
+    ap.add_argument("--sub-rate", type=float, default=None, help="linear workload: substitution rate of the reads (default: the configuration's 1 %%)")
+    ap.add_argument("--indel-rate", type=float, default=None, help="linear workload: indel rate of the reads (default: the configuration's 0.1 %%; 0.05 makes nearly every read miss the "
+                         "speculative fill's diagonal-run shortcut: the leg that shows the context's feedback turning the speculation off)")
     ap.add_argument("--workload", choices=["linear", "tails", "banded", "gapless", "wfa", "xband", "forest", "giraffe", "longread", "config2", "paired"], default="linear",
                     help="linear = BASELINE.json configs[1] (the headline metric); tails = configs[2] stand-in: "
                          "giraffe-style pinned X-drop tail alignments on a variation graph; banded = configs[4] stand-in: "
@@ -1229,7 +1251,12 @@ def main():
         args.reads = n_tails
     else:
         lo, hi = shard.shard_range(args.reads * world, rank, world, group=2)
-        wl = workloads.LinearWorkload(hi - lo, stream_begin=lo)
+        rates = {}
+        if args.sub_rate is not None:
+            rates["sub_rate"] = args.sub_rate
+        if args.indel_rate is not None:
+            rates["indel_rate"] = args.indel_rate
+        wl = workloads.LinearWorkload(hi - lo, stream_begin=lo, **rates)
     OPS_PER = 48
     # configs[1]: the reference graph is resident in HBM once (vgk_graph_create) and every read is a window of it, packed by
     # kernels (vgk_gssw_pack_windows); --host-pack (and the tails workload) hand over one explicit graph per problem instead
@@ -1253,10 +1280,11 @@ def main():
         batch.run()
     batch.sync()
     barrier()
-    fill_ms, walk_ms, refill_ms = [], [], []
+    fill_ms, walk_ms, refill_ms, speculated = [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         batch.run()                        # fill + traceback kernels, async on the engine stream
+        speculated.append(batch.speculated())
         # per-launch kernel durations from HIP events on the launch stream (synchronises this step)
         fill_ms.append(batch.kernel_ms(0)); walk_ms.append(batch.kernel_ms(1)); refill_ms.append(batch.kernel_ms(3))
     n_launch = max(1, int(round(batch.kernel_ms(2))))   # fill launches per step (the batch runs as a chunk pipeline)
@@ -1270,6 +1298,7 @@ def main():
     one_stream = {"ms_per_step": 1e3 * elapsed / args.steps, "fill_ms": sum(fill_ms) / len(fill_ms), "traceback_ms": sum(walk_ms) / len(walk_ms),
                   "reads_per_s": args.reads * world * args.steps / elapsed,
                   "second_fill_ms": sum(refill_ms) / len(refill_ms),
+                  "speculated_steps": int(sum(speculated)), "speculation": eng.speculation_state(), "step_ms_fill_plus_tail": [round(a + b, 3) for a, b in zip(fill_ms, walk_ms)],
                   "speculative_fill": ("on: the first fill builds no traceback codes; fill_ms is that launch; traceback_ms holds everything behind it — gssw_walk_first_kernel, then (second_fill_ms) "
                                        "the layout and the second fill, with codes, of the reads whose alignment is not one diagonal run, then gssw_walk_missed_kernel (DESIGN.md \u00a727.12)"
                                        if sum(refill_ms) > 0 else "off"),
@@ -1451,6 +1480,8 @@ def main():
                                     "per GPU, left-pinned X-drop (dozeu semantics) + traceback, scores 1/4/6/1/5" % args.reads) if tails else
                                    ("configs[1]: linear 1 Mbp graph (32 bp nodes), %d x 150 bp reads per GPU, "
                                     "384-416 bp windows, gssw LOCAL + traceback, scores 1/4/6/1/5" % args.reads),
+                       "read_error_rates": {"substitutions": 0.01 if args.sub_rate is None else args.sub_rate, "indels": 0.001 if args.indel_rate is None else args.indel_rate,
+                                            "note": "the configuration's own unless --sub-rate / --indel-rate were given (then this is NOT the headline configuration)"},
                        "timed_region": timed_region, "one_stream": one_stream, "two_lanes": two_lane,
                        "reads_per_gpu_per_step": args.reads, "parallelism": "read-sharded x%d" % world,
                        "device": dev_name, "compute_units": cus},
@@ -1495,7 +1526,7 @@ def main():
 # at a size that keeps the whole default run within a few minutes; a record keeps the line's metric, value, roofline, cpu_baseline and
 # parity.  A leg that fails or overruns its time limit leaves {"workload", "error"} — never a missing headline.
 SECONDARY = [
-    ("config2", ["--reads", "8000000", "--steps", "3", "--warmup", "1", "--cpu-sample", "50000"], 300),
+    ("config2", ["--reads", "8000000", "--steps", "3", "--warmup", "1", "--cpu-sample", "1000000"], 420),
     ("gapless", ["--steps", "5", "--warmup", "2"], 90),
     ("xband", ["--steps", "5", "--warmup", "2"], 90),
     ("banded", ["--reads", "100000", "--steps", "5", "--warmup", "2"], 90),

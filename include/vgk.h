@@ -570,6 +570,18 @@ uint64_t vgk_batch_alg_bytes(vgk_batch* batch);      /* algorithmic bytes per ru
 uint64_t vgk_batch_device_bytes(vgk_batch* batch);   /* HBM footprint of the batch            */
 int      vgk_batch_lane(vgk_batch* batch);           /* launch lane (stream) of the batch: consecutive batches of a context alternate between
                                                         two, so that one batch's traceback runs under the next one's fill */
+/* ---- the speculative fill and its feedback (no analogue in the reference: the engine's own risk) ------------------------------------------
+ * A batch of mostly local alignments with tracebacks in one lane geometry may be filled WITHOUT traceback codes first: the alignments
+ * that are one diagonal run are settled from the end cells, only the rest are laid out and filled again with codes.  That pays while few
+ * reads miss (configs[1]: one in eight).  Each speculative run reports how many wavefronts it filled twice; the context stops speculating
+ * when that share passes 0.25 (VGAMD_SPEC_MISS_MAX) and probes again after 16 runs (VGAMD_SPEC_PROBE_EVERY), doubling the wait up to 1024
+ * while the probes keep failing.  Results are identical either way (tests/test_gssw_emu_parity.py).
+ * vgk_set_speculation: 0 = by feedback (default), 1 = whenever a batch allows it, 2 = never.  vgk_speculation_state returns 1 while the
+ * context speculates, 0 while it does not; counters (nullable) = runs observed, times turned off, times turned on, runs between probes now.
+ * vgk_batch_speculated: did the batch's last run speculate. */
+int      vgk_set_speculation(vgk_ctx* ctx, int mode);
+int      vgk_speculation_state(vgk_ctx* ctx, uint64_t counters[4], double* last_miss_share);
+int      vgk_batch_speculated(vgk_batch* batch);
 uint64_t vgk_batch_wave_steps(vgk_batch* batch);     /* fill steps summed over the batch's wavefronts (one step = one graph column for
                                                         each of a wavefront's 64 lanes): the unit of the VALU-issue model in DESIGN.md */
 

@@ -449,6 +449,11 @@ uint64_t vgk_batch_alg_bytes(vgk_batch* b) { (void)b; return 0; }
 uint64_t vgk_batch_device_bytes(vgk_batch* b) { (void)b; return 0; }
 uint64_t vgk_batch_wave_steps(vgk_batch* b) { (void)b; return 0; }
 int vgk_batch_lane(vgk_batch* b) { (void)b; return 0; }
+/* the engine's speculative fill has no counterpart here (one scalar fill with its traceback): the checker never speculates */
+int vgk_batch_speculated(vgk_batch* b) { (void)b; return 0; }
+int vgk_set_speculation(vgk_ctx* ctx, int mode) { (void)ctx; return (mode < 0 || mode > 2) ? VGK_EINVAL : VGK_OK; }
+int vgk_speculation_state(vgk_ctx* ctx, uint64_t counters[4], double* last_miss_share) {
+    (void)ctx; if (counters) counters[0] = counters[1] = counters[2] = counters[3] = 0; if (last_miss_share) *last_miss_share = 0.0; return 0; }
 
 /* ---- tail forests (vgo_tail.c) behind the engine's entry points: the walks, then the forest as one graph through the oracle's
  * own vgk_graph_create (node lengths, the bases behind the cuts copied out of the index, one predecessor per non-root node) ---- */

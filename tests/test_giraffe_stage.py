@@ -52,6 +52,21 @@ def run_stage(lib, n, seed, graph_bp, inserted):
     want = pipeline.winning_alignments(b)
     tails, tops = e["tails"], e["tail_ops"]
     assert len(tails) == len(want)
+    # (the flat-array form of the same comparison, the one bench.py runs over a million reads: it must say what the row-by-row one says)
+    arrays = pipeline.winning_alignment_arrays(b)
+    verdict = pipeline.compare_tail_alignments(tails, tops, arrays)
+    assert verdict["tails"] == verdict["identical"] == len(want) and verdict["first_bad"] is None and verdict["ops"] == sum(len(w[6]) for w in want)
+    at = 0
+    for i, wrow in enumerate(want):
+        k = int(arrays["n_ops"][i])
+        row = (int(arrays["ext"][i]), int(arrays["left"][i]), int(arrays["read_begin"][i]), int(arrays["read_end"][i]), int(arrays["score"][i]), int(arrays["first_offset"][i]),
+               [(int(arrays["ops_node"][at + j]), int(arrays["ops_op"][at + j]), int(arrays["ops_len"][at + j])) for j in range(k)])
+        assert row == wrow, (i, row, wrow)
+        at += k
+    if len(tops):                                                       # ... and it notices one op changed
+        spoiled = tops.copy(); spoiled["len"][len(spoiled) // 2] += 1
+        assert pipeline.compare_tail_alignments(tails, spoiled, arrays)["identical"] == len(want) - 1
+    assert pipeline.compare_extension_sets(e["res"], e["ext"], e["nodes"], b["res"], b["ext"], b["nodes"], len(b["res"])) == len(b["res"])
     for i, wrow in enumerate(want):
         tl = tails[i]
         ops = tops[tl["ops_begin"]:tl["ops_begin"] + tl["n_ops"]]

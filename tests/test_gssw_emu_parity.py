@@ -170,6 +170,7 @@ def test_speculative_fill_corner_batches_and_reruns(emu_lib, n, sub_rate, indel_
     sc = capi.Scoring.simple(1, 4, 6, 1, 5)
     ro, oo = capi.Engine(sc, lib=ORACLE_LIB).align(wl, 0)
     eng = capi.Engine(sc, lib=emu_lib)
+    eng.set_speculation(1)                                             # (the mechanics, whatever the feedback would say after the first run)
     graph = eng.graph(*wl.graph_arrays())
     with eng.pack_windows(graph, wl.windows(), 0) as b:
         refilled = []
@@ -192,14 +193,68 @@ def test_speculative_fill_corner_batches_and_reruns(emu_lib, n, sub_rate, indel_
         assert capi.cigar_string(r[i], o) == capi.cigar_string(ro[i], oo), i
 
 
+# Speculation with feedback (vgk_ctx::SpecPolicy): whether a batch that CAN speculate does is decided per run from the miss counts of the
+# context's earlier speculative runs.  A stream of reads full of indels turns it off after the first batch, is probed after VGAMD_SPEC_PROBE_EVERY
+# runs (the wait doubling while the probes fail), and a stream that turns clean turns it on again; every batch equals the oracle whichever way it ran.
+def speculation_follows_the_miss_counts(emu_lib, monkeypatch, n=1100):
+    from vg_amd import workloads
+    monkeypatch.setenv("VGAMD_SPEC_PROBE_EVERY", "2")
+    sc = capi.Scoring.simple(1, 4, 6, 1, 5)
+    noisy = workloads.LinearWorkload(n, seed=5, sub_rate=0.05, indel_rate=0.05)
+    clean = workloads.LinearWorkload(n, seed=6, sub_rate=0.0, indel_rate=0.0)
+    ora = capi.Engine(sc, lib=ORACLE_LIB)
+    want = {id(noisy): ora.align(noisy, 0), id(clean): ora.align(clean, 0)}
+    eng = capi.Engine(sc, lib=emu_lib)
+    graphs = {id(noisy): eng.graph(*noisy.graph_arrays()), id(clean): eng.graph(*clean.graph_arrays())}
+
+    def one(wl):
+        with eng.pack_windows(graphs[id(wl)], wl.windows(), 0) as b:
+            b.run(); b.sync(); spec = b.speculated()
+            r, o = b.fetch()
+        ro, oo = want[id(wl)]
+        for f in ("status", "score", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
+            assert (r[f] == ro[f]).all(), f
+        tot = int(ro["n_ops"].sum())
+        assert (o[:tot].view(np.uint64) == oo[:tot].view(np.uint64)).all()
+        return spec
+
+    assert eng.speculation_state()["on"]
+    ran = [one(noisy) for _ in range(10)]
+    # optimistic start; off after the first count; two plain runs; a probe that fails (wait 4); four plain runs; the next probe (wait 8)
+    assert ran == [True, False, False, True, False, False, False, False, True, False], ran
+    st = eng.speculation_state()
+    assert not st["on"] and st["turned_off"] == 1 and st["observed"] == 3 and st["last_miss"] > 0.5 and st["probe_interval"] == 8
+    ran = [one(clean) for _ in range(10)]
+    assert ran[:7] == [False] * 7 and ran[7:] == [True] * 3, ran          # the probe after the eight-run wait finds hardly a miss: on again
+    st = eng.speculation_state()
+    assert st["on"] and st["turned_on"] == 1 and st["last_miss"] < 0.1
+    # the two overrides
+    eng.set_speculation(2); assert one(clean) is False
+    eng.set_speculation(1); assert one(noisy) is True and one(noisy) is True
+    eng.set_speculation(0)
+    # a resident batch run again and again without a fetch in between: its own last run is the evidence
+    eng2 = capi.Engine(sc, lib=emu_lib)
+    with eng2.pack_windows(eng2.graph(*noisy.graph_arrays()), noisy.windows(), 0) as b:
+        ran = []
+        for _ in range(4):
+            b.run(); b.sync(); ran.append(b.speculated())
+        r, o = b.fetch()
+    assert ran == [True, False, False, True]
+    assert (r["score"] == want[id(noisy)][0]["score"]).all()
+
+
+def test_speculation_follows_the_miss_counts_of_earlier_batches(emu_lib, monkeypatch):
+    speculation_follows_the_miss_counts(emu_lib, monkeypatch)
+
+
 # ... and over DAGs with bubbles, several predecessors per node and predecessor lists in both orders (the linear workload above has chains
 # only): reads of 86-94 bases fall into one lanes-per-pair geometry and the graphs are of similar widths, so the batch speculates; the second fill of a LOCAL read stops behind its
 # end cell's column (refill_layout_one), which the other modes in the batch must not.
-def test_speculative_fill_over_random_dags(emu_lib, monkeypatch):
+def speculative_fill_over_random_dags(lib, n_problems, seed=4242):
     from gen import random_dag, random_walk_read
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(seed)
     problems = []
-    while len(problems) < 1150:
+    while len(problems) < n_problems:
         nodes, preds = random_dag(rng, int(rng.integers(9, 15)), 22)
         if not 110 <= sum(len(x) for x in nodes) <= 150:
             continue
@@ -223,25 +278,30 @@ def test_speculative_fill_over_random_dags(emu_lib, monkeypatch):
     ps = problem_set(problems)
     for sc in (capi.Scoring.simple(1, 4, 6, 1, 5), capi.Scoring.simple(1, 1, 1, 1, 0)):
         ro, oo = capi.Engine(sc, lib=ORACLE_LIB).align(ps, 0)
-        eng = capi.Engine(sc, lib=emu_lib)
+        eng = capi.Engine(sc, lib=lib)
         with eng.pack(ps, 0) as b:
             b.run(); b.sync()
-            assert b.kernel_ms(3) > 0, "the batch did not speculate (or no read missed)"
+            assert b.speculated() and b.kernel_ms(3) > 0, "the batch did not speculate (or no read missed)"
             r, o = b.fetch()
         for f in ("status", "score", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
             assert (r[f] == ro[f]).all(), f
-        for i in range(ps.n):
-            assert capi.cigar_string(r[i], o) == capi.cigar_string(ro[i], oo), i
+        tot = int(ro["n_ops"].sum())
+        bad = np.nonzero(o[:tot].view(np.uint64) != oo[:tot].view(np.uint64))[0]
+        assert len(bad) == 0, (len(bad), np.searchsorted(np.cumsum(ro["n_ops"]), bad[:4], side="right"))
+
+
+def test_speculative_fill_over_random_dags(emu_lib):
+    speculative_fill_over_random_dags(emu_lib, 1150)
 
 
 # ... and over WIDE graphs (380-420 columns, nodes of up to 48 bases, predecessors from anywhere before): a run that crosses into a predecessor
 # far back in the column stream fetches its column block again (walk_diag_one), several times along one read; a few graphs are put first in
 # the batch, where a block that would start before the arena is refused.
-def test_first_pass_crosses_far_predecessors(emu_lib):
+def first_pass_crosses_far_predecessors(lib, n_problems, seed=777):
     from gen import random_dag, random_walk_read
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(seed)
     problems = []
-    while len(problems) < 1100:
+    while len(problems) < n_problems:
         nodes, preds = random_dag(rng, int(rng.integers(10, 18)), 48, p_chain=0.45)
         if not 380 <= sum(len(x) for x in nodes) <= 420:
             continue
@@ -252,13 +312,21 @@ def test_first_pass_crosses_far_predecessors(emu_lib):
     ps = problem_set(problems)
     for sc in (capi.Scoring.simple(1, 4, 6, 1, 5), capi.Scoring.simple(2, 2, 3, 1, 0)):
         ro, oo = capi.Engine(sc, lib=ORACLE_LIB).align(ps, 0)
-        eng = capi.Engine(sc, lib=emu_lib)
+        eng = capi.Engine(sc, lib=lib)
         with eng.pack(ps, 0) as b:
             b.run(); b.sync()
-            refilled = b.kernel_ms(3)                                  # (the emulator: wavefronts laid out again)
+            assert b.speculated()
+            refilled = b.kernel_ms(3)                                  # (the emulator: wavefronts laid out again; HIP: the second fill's ms)
             r, o = b.fetch()
-        assert 0 < refilled < 1100 // 16 * 0.8                          # the batch speculated, and most reads were settled by runs
+        st = eng.speculation_state()
+        assert st["observed"] == 1 and 0 < st["last_miss"] < 0.8        # the batch speculated, and most reads were settled by runs
+        assert refilled > 0
         for f in ("status", "score", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
             assert (r[f] == ro[f]).all(), f
-        for i in range(ps.n):
-            assert capi.cigar_string(r[i], o) == capi.cigar_string(ro[i], oo), i
+        tot = int(ro["n_ops"].sum())
+        bad = np.nonzero(o[:tot].view(np.uint64) != oo[:tot].view(np.uint64))[0]
+        assert len(bad) == 0, (len(bad), np.searchsorted(np.cumsum(ro["n_ops"]), bad[:4], side="right"))
+
+
+def test_first_pass_crosses_far_predecessors(emu_lib):
+    first_pass_crosses_far_predecessors(emu_lib, 1100)

@@ -121,3 +121,27 @@ def test_hip_two_kernel_traceback_and_speculative_fill_match_oracle(monkeypatch)
     problems += [random_problem(rng, mode=capi.VGK_XDROP_PINNED) for _ in range(300)] + [random_problem(rng, mode=capi.VGK_GSSW_PINNED) for _ in range(300)]
     for sc in (None, capi.Scoring.simple(1, 1, 1, 1, 5), capi.Scoring.simple(2, 3, 5, 2, 0)):
         compare(ENGINE_LIB, ORACLE_LIB, problems, sc)
+
+
+# The speculative fill over graphs that are not chains, on the device (emulator-only until now): bubbles, several
+# predecessors per node in both orders, a minority of the batch in the other modes; wide graphs whose diagonal runs cross into predecessors far
+# back in the column stream (walk_diag_one's re-fetched column block); and the LOCAL windows of a resident VARIATION graph with reads of one
+# length — one lane geometry, so the device-packed batch speculates.
+def test_hip_speculative_fill_over_random_dags():
+    from test_gssw_emu_parity import speculative_fill_over_random_dags
+    speculative_fill_over_random_dags(ENGINE_LIB, 6000, seed=4243)
+
+
+def test_hip_first_pass_crosses_far_predecessors():
+    from test_gssw_emu_parity import first_pass_crosses_far_predecessors
+    first_pass_crosses_far_predecessors(ENGINE_LIB, 4000, seed=778)
+
+
+def test_hip_speculative_fill_over_windows_of_a_variation_graph():
+    from test_windows import speculative_windows_of_a_variation_graph
+    speculative_windows_of_a_variation_graph(ENGINE_LIB, n_nodes=6000, n_problems=20000)
+
+
+def test_hip_speculation_follows_the_miss_counts_of_earlier_batches(monkeypatch):
+    from test_gssw_emu_parity import speculation_follows_the_miss_counts
+    speculation_follows_the_miss_counts(ENGINE_LIB, monkeypatch, n=20000)

@@ -100,6 +100,69 @@ def assert_same(ra, oa, rb, ob, what):
         assert (a.view(np.uint64) == b.view(np.uint64)).all(), "%s: ops of problem %d" % (what, i)
 
 
+def uniform_local_windows(rng, nodes, preds, n, read_len, k, sub=0.02, indel=0.003):
+    """n LOCAL + traceback windows of k nodes each, every read read_len bases long: a noisy walk that starts in the window's first two nodes
+    (one lane geometry and windows of similar widths: a batch the packers let speculate)"""
+    succ = [[] for _ in nodes]
+    for v, pr in enumerate(preds):
+        for p in pr:
+            succ[p].append(v)
+    reads, first = [], []
+    while len(reads) < n:
+        a = int(rng.integers(0, len(nodes) - k))
+        v = a + int(rng.integers(0, 2)); off = int(rng.integers(0, len(nodes[v])))
+        out = []
+        while len(out) < read_len:
+            if off >= len(nodes[v]):
+                nx = [w for w in succ[v] if w < a + k]
+                if not nx:
+                    break
+                v = nx[int(rng.integers(0, len(nx)))]; off = 0
+                continue
+            c = nodes[v][off]; off += 1
+            r = rng.random()
+            if r < sub:
+                c = "ACGT"[int(rng.integers(0, 4))]
+            elif r < sub + indel:
+                continue
+            elif r < sub + 2 * indel:
+                out.append("ACGT"[int(rng.integers(0, 4))])
+            out.append(c)
+        if len(out) < read_len:
+            continue                                                   # the walk ran out of window: another start
+        reads.append(np.frombuffer("".join(out[:read_len]).encode(), dtype=np.uint8)); first.append(a)
+    read_off = np.arange(n + 1) * read_len
+    flags = np.full(n, capi.VGK_GSSW_LOCAL | capi.VGK_GSSW_TRACEBACK, dtype=np.uint32)
+    return np.concatenate(reads), read_off, np.array(first), np.full(n, k), flags, np.zeros(n, dtype=np.int64)
+
+
+def speculative_windows_of_a_variation_graph(lib, n_nodes, n_problems, seed=91):
+    """the device-packed windows of a resident DAG with bubbles: the batch speculates (first fill without codes, the misses filled again), and
+    every result and op equals the oracle's on the same induced subgraphs"""
+    rng = np.random.default_rng(seed)
+    nodes, preds = random_dag(rng, n_nodes, 12)
+    arrays = graph_arrays(nodes, preds)
+    w = uniform_local_windows(rng, nodes, preds, n_problems, read_len=90, k=16)
+    for sc in (capi.Scoring.simple(1, 4, 6, 1, 5), capi.Scoring.simple(2, 3, 5, 2, 0)):
+        eng = capi.Engine(sc, lib=lib)
+        g = eng.graph(*arrays)
+        ws = window_set(g.col, *w)
+        with eng.pack_windows(g, ws, 0) as b:
+            b.run(); b.sync()
+            assert b.speculated() and b.kernel_ms(3) > 0, "the window batch did not speculate"
+            rw, ow = b.fetch()
+        st = eng.speculation_state()
+        assert st["observed"] == 1 and 0.0 < st["last_miss"] < 0.9
+        ora = capi.Engine(sc, lib=ORACLE_LIB)
+        ro, oo = ora.align_windows(ora.graph(*arrays), ws, 0)
+        assert_same(rw, ow, ro, oo, "speculative engine windows vs oracle windows")
+        assert (rw["status"] == 0).all() and (rw["score"] > 40).mean() > 0.9
+
+
+def test_emulated_speculative_fill_over_windows_of_a_variation_graph(emu_lib):
+    speculative_windows_of_a_variation_graph(emu_lib, n_nodes=600, n_problems=1100)
+
+
 def run_three_ways(lib, seed, n_nodes, n_problems, scoring=None, ops_per=0):
     rng = np.random.default_rng(seed)
     nodes, preds = random_dag(rng, n_nodes, 12, with_n=0.05)

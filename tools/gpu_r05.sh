@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-5 GPU runs, one parameterised script (no more one-off gpu_r04_*.sh files): `gpurun -- bash tools/gpu_r05.sh <stage>`.
+# Everything is written under gpurun_out/r05/<stage>/; what is cited goes to profiles/r05/ by hand.
+set -u
+stage=${1:-tests}
+out=gpurun_out/r05/$stage
+mkdir -p "$out"
+export TMPDIR=/tmp
+case "$stage" in
+  new_tests)      # the tests added this round, before the whole suite is paid for
+    timeout 900 python -m pytest tests/test_gssw_gpu_parity.py tests/test_windows.py tests/test_banded.py -m gpu -x -q \
+        -k "speculat or far_pred or variation or geometry" > "$out/pytest_new.log" 2>&1; echo "rc=$?" >> "$out/pytest_new.log"; tail -5 "$out/pytest_new.log" ;;
+  tests)          # the whole -m gpu suite + smoke
+    timeout 2400 python -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1; echo "rc=$?" >> "$out/pytest_gpu.log"; tail -5 "$out/pytest_gpu.log"
+    timeout 600 python __graft_entry__.py smoke > "$out/smoke.log" 2>&1; echo "rc=$?" >> "$out/smoke.log"; tail -2 "$out/smoke.log" ;;
+  headline)       # the headline alone, and the speculation's feedback on a stream of reads that all miss (5 % indels)
+    timeout 600 python bench.py --no-secondary > "$out/bench_headline.json" 2> "$out/bench_headline.err"; tail -c 600 "$out/bench_headline.json"
+    for pol in 0 2 1; do
+      VGAMD_SPEC_POLICY=$pol timeout 600 python bench.py --reads 200000 --indel-rate 0.05 --steps 12 --warmup 0 --no-cpu --no-e2e --no-secondary \
+          > "$out/bench_indel5_policy$pol.json" 2> "$out/bench_indel5_policy$pol.err"
+      python - "$out/bench_indel5_policy$pol.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); o = d["config"]["one_stream"]
+print(sys.argv[1], "ms/step", round(d["ms_per_step"], 3), "speculated", o["speculated_steps"], o["speculation"], o["step_ms_fill_plus_tail"])
+PY
+    done ;;
+  config2)        # configs[2] with every tail alignment of a million reads compared
+    timeout 900 python bench.py --workload config2 --reads 8000000 --steps 3 --warmup 1 --cpu-sample 1000000 > "$out/bench_config2.json" 2> "$out/bench_config2.err"
+    python - "$out/bench_config2.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(d["value"], d["parity"], d["cpu_baseline"]["value"])
+PY
+    ;;
+  default)        # what the driver runs: the headline + every secondary record
+    timeout 1700 python bench.py > "$out/bench_default_run.json" 2> "$out/bench_default_run.err"; tail -c 400 "$out/bench_default_run.json" ;;
+  *) echo "unknown stage $stage"; exit 2 ;;
+esac

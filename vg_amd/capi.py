@@ -278,6 +278,18 @@ class Engine:
         self.h = h
         self._indexes = weakref.WeakSet()      # haplotype indexes live in this context: they go first
 
+    def set_speculation(self, mode):
+        """0 = by feedback (default), 1 = whenever a batch allows it, 2 = never (vgk_set_speculation)"""
+        self.lib.vgk_set_speculation.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self._check(self.lib.vgk_set_speculation(self.h, mode), "vgk_set_speculation")
+
+    def speculation_state(self):
+        """-> dict(on, observed, turned_off, turned_on, probe_interval, last_miss): the context's feedback on the speculative fill"""
+        self.lib.vgk_speculation_state.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        c = (ctypes.c_uint64 * 4)(); m = ctypes.c_double()
+        on = self.lib.vgk_speculation_state(self.h, c, ctypes.byref(m))
+        return dict(on=bool(on), observed=int(c[0]), turned_off=int(c[1]), turned_on=int(c[2]), probe_interval=int(c[3]), last_miss=float(m.value))
+
     def close(self):
         if getattr(self, "h", None):
             for index in list(getattr(self, "_indexes", ())):
@@ -880,6 +892,11 @@ class Batch:
 
     def wave_steps(self):
         return self.eng.lib.vgk_batch_wave_steps(self.h)
+
+    def speculated(self):
+        """did the last run fill without traceback codes first (the speculative fill; the context's feedback decides per run)"""
+        self.eng.lib.vgk_batch_speculated.argtypes = [ctypes.c_void_p]
+        return bool(self.eng.lib.vgk_batch_speculated(self.h))
 
     def fetch(self, into=None):
         """-> (results, ops).  `into` = (results, ops) arrays of an earlier fetch of a batch of the same shape, written again

@@ -54,6 +54,7 @@ public:
     virtual void  event_destroy(void* ev) { (void)ev; }
     virtual int   event_record(void* ev) { (void)ev; return VGK_OK; }               // on the main stream
     virtual int   event_wait(void* ev) { (void)ev; return sync(); }                 // host waits, polling
+    virtual bool  event_done(void* ev) { (void)ev; return true; }                   // has everything before ev finished? (never waits; a synchronous backend: always)
     virtual int   fetch_after(void* ev) { (void)ev; return VGK_OK; }                // fetch-stream work queued from now on runs after ev
     virtual int   sync_fetch() { return sync(); }
     virtual int   download_fetch(void* dst, const void* src, size_t bytes) { return download(dst, src, bytes); }   // synchronous, fetch stream

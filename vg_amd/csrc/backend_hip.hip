@@ -988,6 +988,13 @@ public:
         hipSetDevice(dev);
         return hipEventRecord((hipEvent_t)ev, stream) == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
+    bool event_done(void* ev) override {
+        if (!ev) return false;
+        hipSetDevice(dev);
+        const hipError_t e = hipEventQuery((hipEvent_t)ev);
+        if (e != hipSuccess && e != hipErrorNotReady) (void)hipGetLastError();
+        return e == hipSuccess;
+    }
     int event_wait(void* ev) override {
         if (!ev) return sync();
         hipSetDevice(dev);

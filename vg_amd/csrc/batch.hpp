@@ -12,6 +12,7 @@ struct vgk_batch {
     vgk_ctx* ctx = nullptr;
     uint32_t n = 0;
     bool want_tb = false, ran = false;
+    bool ran_spec = false, spec_observed = true;      // the last run speculated | its miss count has been handed to the context's SpecPolicy
     GsswParams P{};
     std::vector<vgk_ctx::Pooled> dev;   // every device allocation of this batch (back to the context's pool when the batch is freed)
     uint64_t cells = 0, tb_cells = 0, in_bytes = 0, dev_bytes = 0, alg_bytes = 0;

@@ -18,8 +18,40 @@ template <class T> struct PinnedBuf {
     ~PinnedBuf() { if (p) be->host_release(p); }
 };
 
+// Runtime feedback for the speculative fill (GsswParams::spec_fill, DESIGN.md: "speculation with feedback").  A batch is packed so that it CAN
+// speculate (one geometry, mostly local alignments with tracebacks); whether a run of it DOES is decided when it is launched, from what the
+// context's earlier speculative runs cost: each leaves the number of wavefronts it had to fill a second time (refill_count, read back with the
+// results), and a run whose share of such wavefronts passes `miss_max` paid the first fill for nothing (break-even on the MI355X: first fill
+// 12.7 ms + m x 19.1 ms against 19.1 ms plain per million reads => m < 0.33, less the layout and the second walk).  Above it the context stops
+// speculating and probes again after `interval` runs, doubling the interval while the probes keep failing (16, 32, ... 1024): a stream of
+// reads full of indels then runs within a few per cent of the plain fill, and a stream that turns clean again is noticed.
+// Guarded by vgk_ctx::mu.
+struct SpecPolicy {
+    int mode = 0;                    // vgk_set_speculation: 0 = by feedback, 1 = whenever the batch allows it, 2 = never
+    double miss_max = 0.25;          // VGAMD_SPEC_MISS_MAX
+    uint32_t probe_every = 16;       // VGAMD_SPEC_PROBE_EVERY: the first interval between probes while speculation is off
+    bool on = true; uint32_t wait = 0, interval = 16;
+    uint64_t observed = 0, turned_off = 0, turned_on = 0; double last_miss = 0.0;
+    bool decide() {
+        if (mode == 1) return true;
+        if (mode == 2) return false;
+        if (on) return true;
+        if (wait) { --wait; return false; }
+        wait = interval;                                                   // a probe: one speculative run; its count decides
+        return true;
+    }
+    void observe(double miss) {
+        ++observed; last_miss = miss;
+        if (miss > miss_max) {
+            if (on) { on = false; ++turned_off; interval = probe_every; wait = interval; }
+            else { interval = interval >= 512 ? 1024 : interval * 2; wait = interval; }      // a probe that failed
+        } else if (!on) { on = true; ++turned_on; interval = probe_every; wait = 0; }
+    }
+};
+
 struct vgk_ctx {
     vgk_scoring sc;
+    SpecPolicy spec;               // speculative fill: on / off by the miss counts of this context's earlier runs
     std::unique_ptr<vgk::Backend> be;
     std::mutex mu;                 // guards the pools and the launch order of a context
     std::mutex stage_mu;           // taken BEFORE mu, for their whole duration, by the calls that make or consume the state one stage leaves for the next in HBM

@@ -69,6 +69,9 @@ static int create_ctx(int device, const vgk_scoring* scoring, const vgk_qual_adj
         for (int r = 0; r < 4; ++r) w |= (uint32_t)(scoring->matrix[5 * r + q] + bias) << (8 * r);
         c->prof4[q] = w;
     }
+    if (const char* e = std::getenv("VGAMD_SPEC_POLICY")) { const int m = std::atoi(e); if (m >= 0 && m <= 2) c->spec.mode = m; }      // vgk_set_speculation
+    if (const char* e = std::getenv("VGAMD_SPEC_MISS_MAX")) { const double m = std::atof(e); if (m > 0.0 && m <= 1.0) c->spec.miss_max = m; }
+    if (const char* e = std::getenv("VGAMD_SPEC_PROBE_EVERY")) { const int m = std::atoi(e); if (m >= 1 && m <= 1024) c->spec.probe_every = c->spec.interval = (uint32_t)m; }
     c->prof4[5] = 0;     // X-drop row 0 ("nothing consumed"): no diagonal move can enter it
     *out = c;
     return VGK_OK;
@@ -483,11 +486,28 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     return VGK_OK;
 } catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
+// the miss count of a speculative run that has finished -> the context's policy (callers hold ctx->mu; the run's kernels are complete)
+static void observe_speculation(vgk_batch* b) {
+    if (!b->ran || !b->ran_spec || b->spec_observed || !b->P.refill_count) return;
+    b->spec_observed = true;
+    uint32_t refilled = 0;
+    if (b->ctx->be->download_fetch(&refilled, b->P.refill_count, sizeof refilled) != VGK_OK) return;
+    b->ctx->spec.observe(b->P.n_waves ? (double)refilled / (double)b->P.n_waves : 0.0);
+}
+
 int vgk_gssw_run(vgk_batch* b) try {
     if (!b) return VGK_EINVAL;
     std::lock_guard<std::mutex> lk(b->ctx->mu);
     if (!b->done) b->done = b->ctx->be->event_create();
-    const int rc = b->ctx->be->run_gssw_on(b->lane, b->P, b->launches.data(), (uint32_t)b->launches.size(), true, b->done);
+    GsswParams P = b->P;
+    if (b->P.spec_fill) {
+        // (a resident batch that is run again without a fetch in between: its own last run tells as much as a fetched one)
+        if (b->ran && b->ran_spec && !b->spec_observed && b->ctx->be->event_done(b->done)) observe_speculation(b);
+        const bool speculate = b->ctx->spec.decide();
+        if (!speculate) { P.spec_fill = 0; P.wave_limit = nullptr; }      // the plain fill with codes over the same arenas (they hold either form)
+        b->ran_spec = speculate; b->spec_observed = !speculate;
+    }
+    const int rc = b->ctx->be->run_gssw_on(b->lane, P, b->launches.data(), (uint32_t)b->launches.size(), true, b->done);
     if (rc == VGK_OK) b->ran = true;
     return rc;
 } catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
@@ -550,6 +570,7 @@ int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_ca
     { int rc = b->done ? b->ctx->be->event_wait(b->done) : b->ctx->be->sync(); if (rc) return rc; }
     int rc = b->ctx->be->fetch_after(b->done);
     if (rc) return rc;
+    if (b->ran_spec && !b->spec_observed) { std::lock_guard<std::mutex> lk(b->ctx->mu); observe_speculation(b); }
     rc = fetch_packed_on_device(b, results, ops, ops_cap, ops_written);       // takes the context lock for its arenas only
     if (rc != VGK_EUNSUPPORTED) return rc;
     std::lock_guard<std::mutex> lk(b->ctx->mu);
@@ -689,7 +710,7 @@ double vgk_batch_kernel_ms(vgk_batch* b, int which) {
     if (!b) return 0.0;
     std::lock_guard<std::mutex> lk(b->ctx->mu);
     if (which == 0 || which == 1 || which == 2) return b->ctx->be->last_ms_on(b->lane, which);
-    if (which == 3) return b->P.spec_fill ? b->ctx->be->last_ms_on(b->lane, 12) : 0.0;
+    if (which == 3) return b->P.spec_fill && b->ran_spec ? b->ctx->be->last_ms_on(b->lane, 12) : 0.0;
     return b->ctx->be->last_ms_on(b->lane, 0) + b->ctx->be->last_ms_on(b->lane, 1);
 }
 uint64_t vgk_batch_cells(vgk_batch* b) { return b ? b->cells : 0; }
@@ -704,5 +725,19 @@ uint64_t vgk_batch_alg_bytes(vgk_batch* b) {
 uint64_t vgk_batch_device_bytes(vgk_batch* b) { return b ? b->dev_bytes : 0; }
 uint64_t vgk_batch_wave_steps(vgk_batch* b) { return b ? b->wave_steps : 0; }
 int      vgk_batch_lane(vgk_batch* b) { return b ? b->lane : 0; }
+int      vgk_batch_speculated(vgk_batch* b) { if (!b) return 0; std::lock_guard<std::mutex> lk(b->ctx->mu); return b->ran && b->ran_spec ? 1 : 0; }
+int      vgk_set_speculation(vgk_ctx* ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 2) return VGK_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->spec.mode = mode;
+    return VGK_OK;
+}
+int      vgk_speculation_state(vgk_ctx* ctx, uint64_t counters[4], double* last_miss) {
+    if (!ctx) return VGK_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (counters) { counters[0] = ctx->spec.observed; counters[1] = ctx->spec.turned_off; counters[2] = ctx->spec.turned_on; counters[3] = ctx->spec.on ? 0 : ctx->spec.interval; }
+    if (last_miss) *last_miss = ctx->spec.last_miss;
+    return ctx->spec.on ? 1 : 0;
+}
 
 }  // extern "C"

@@ -12,7 +12,8 @@ Which route is which (every route takes an engine handle and runs on whatever li
   CHECKER-SIDE ONLY — the stage spelled out in numpy, kept because it is what the OTHER side of every comparison runs (tests/,
   __graft_entry__.smoke() and bench.py's parity / cpu_baseline legs hand it the oracle's engine handle); nothing timed as the
   product goes through these, and they are not part of what a maintainer would take over
-    align_stage, tails_of_extensions, tail_sequences, tree_windows, winning_alignments, chain_stage"""
+    align_stage, tails_of_extensions, tail_sequences, tree_windows, winning_alignments, winning_alignment_arrays, compare_tail_alignments,
+    compare_extension_sets, chain_stage"""
 import ctypes
 import os
 
@@ -283,6 +284,95 @@ def winning_alignments(out):
             row[6] = [(int(fnode[base + int(x["node"])]), int(x["op"]), int(x["len"])) for x in o]
         rows[i] = tuple(row)
     return rows
+
+
+def winning_alignment_arrays(out):
+    """[checker-side] winning_alignments as flat arrays, for comparisons at bench scale (a million reads' tails): -> dict(ext, left, read_begin,
+    read_end, score, first_offset, n_ops — one entry per tail, in align_stage's tail order — and ops_node / ops_op / ops_len, the winners' ops
+    behind each other, nodes translated to oriented nodes of the index)"""
+    t = out["tails"]
+    nt = len(t["problems"])
+    res = dict(ext=t["ext"].astype(np.int64), left=t["left"].astype(np.int64), read_begin=t["begin"].astype(np.int64), read_end=t["end"].astype(np.int64),
+               score=np.zeros(nt, dtype=np.int64), first_offset=np.zeros(nt, dtype=np.int64), n_ops=np.zeros(nt, dtype=np.int64),
+               ops_node=np.zeros(0, dtype=np.int64), ops_op=np.zeros(0, dtype=np.int64), ops_len=np.zeros(0, dtype=np.int64))
+    if "tail_alignments" not in out or nt == 0:
+        return res
+    r, ops, owner, tres = out["tail_alignments"], out["tail_ops"], np.asarray(out["owner"], dtype=np.int64), out["tail_results"]
+    parent, fnode, _ = out["forest"].fetch()
+    first_node = out["windows"].array["first_node"].astype(np.int64)
+    sc = np.where(r["status"] == 0, r["score"], 0).astype(np.int64)
+    order = np.lexsort((np.arange(len(owner)), -sc, owner))              # per tail: the best tree, the first among equals
+    lead = order[np.concatenate([[True], owner[order][1:] != owner[order][:-1]])] if len(order) else order
+    win = lead[sc[lead] > 0]                                             # (a soft clip otherwise: nothing)
+    tail = owner[win]
+    res["score"][tail] = sc[win]
+    n_ops = r["n_ops"][win].astype(np.int64)
+    res["n_ops"][tail] = n_ops
+    # the winners' ops, in tail order
+    by_tail = np.argsort(tail, kind="stable")
+    win, tail, n_ops = win[by_tail], tail[by_tail], n_ops[by_tail]
+    begin = r["ops_begin"][win].astype(np.int64)
+    seg = np.cumsum(n_ops) - n_ops
+    idx = np.repeat(begin, n_ops) + (np.arange(int(n_ops.sum())) - np.repeat(seg, n_ops))
+    o = ops[idx]
+    base = np.repeat(first_node[win], n_ops)
+    res["ops_node"] = fnode[base + o["node"].astype(np.int64)].astype(np.int64); res["ops_op"] = o["op"].astype(np.int64); res["ops_len"] = o["len"].astype(np.int64)
+    has = n_ops > 0
+    v0 = first_node[win][has] + o["node"][seg[has]].astype(np.int64)
+    res["first_offset"][tail[has]] = r["first_offset"][win][has].astype(np.int64) + np.where(parent[v0] < 0, tres["root_trim"][tail[has]].astype(np.int64), 0)
+    return res
+
+
+def compare_tail_alignments(tails, tail_ops, want, n_ext=None):
+    """[checker-side] vgk_tail_stage_aligned's output against winning_alignment_arrays(oracle stage): -> dict(tails, identical, ops, first_bad).
+    n_ext: only the tails of extensions below it (the oracle ran a prefix of the batch's reads)."""
+    if n_ext is not None:
+        tails = tails[tails["ext"] < n_ext]
+    nt = len(want["ext"])
+    if len(tails) != nt:
+        return dict(tails=nt, identical=0, ops=int(want["n_ops"].sum()), first_bad=-1, note="%d tails from the engine, %d from the oracle" % (len(tails), nt))
+    same = np.ones(nt, dtype=bool)
+    for f in ("ext", "left", "read_begin", "read_end", "score", "first_offset", "n_ops"):
+        same &= tails[f].astype(np.int64) == want[f]
+    if same.all() and nt:
+        n_ops = want["n_ops"]
+        seg = np.cumsum(n_ops) - n_ops
+        idx = np.repeat(tails["ops_begin"].astype(np.int64), n_ops) + (np.arange(int(n_ops.sum())) - np.repeat(seg, n_ops))
+        o = tail_ops[idx]
+        bad = (o["node"].astype(np.int64) != want["ops_node"]) | (o["op"].astype(np.int64) != want["ops_op"]) | (o["len"].astype(np.int64) != want["ops_len"])
+        if bad.any():
+            same[np.unique(np.repeat(np.arange(nt), n_ops)[bad])] = False
+    bad = np.nonzero(~same)[0]
+    return dict(tails=nt, identical=int(same.sum()), ops=int(want["n_ops"].sum()), first_bad=int(bad[0]) if len(bad) else None)
+
+
+def compare_extension_sets(a_res, a_ext, a_nodes, b_res, b_ext, b_nodes, k):
+    """[checker-side] the extension sets of the first k reads of two runs (results, extensions with their search states, path nodes): -> reads whose
+    set is identical (every field of every extension, every node of every path)"""
+    same = np.ones(k, dtype=bool)
+    for f in ("status", "n_ext", "full_length"):
+        same &= a_res[f][:k] == b_res[f][:k]
+    if not same.all():
+        return int(same.sum())
+    n_ext = a_res["n_ext"][:k].astype(np.int64)
+    tot = int(n_ext.sum())
+    read_of = np.repeat(np.arange(k), n_ext)
+    ea, eb = a_ext[:tot], b_ext[:tot]
+    bad = np.zeros(tot, dtype=bool)
+    for f in ("path_len", "offset", "read_begin", "read_end", "n_mismatches", "score", "left_full", "right_full"):
+        bad |= ea[f] != eb[f]
+    bad |= (ea["state"] != eb["state"]).any(axis=1)
+    pl = ea["path_len"].astype(np.int64)
+    ok = ~bad
+    # the paths of the extensions that agree so far, node by node (each run's own path_begin)
+    seg = np.cumsum(pl[ok]) - pl[ok]
+    run = np.arange(int(pl[ok].sum())) - np.repeat(seg, pl[ok])
+    na = a_nodes[np.repeat(ea["path_begin"][ok].astype(np.int64), pl[ok]) + run]; nb = b_nodes[np.repeat(eb["path_begin"][ok].astype(np.int64), pl[ok]) + run]
+    diff = na != nb
+    if diff.any():
+        bad[np.nonzero(ok)[0][np.unique(np.repeat(np.arange(int(ok.sum())), pl[ok])[diff])]] = True
+    same[np.unique(read_of[bad])] = False
+    return int(same.sum())
 
 
 # ---- configs[4] with the whole stage in the host shim (vg_amd/host/chain_stage.cpp) -----------------------------------------------------
