@@ -210,6 +210,39 @@ typedef struct vgk_window_problem {
  * out-of-range problem (in index order) decides the return code, as a serial scan would. */
 int  vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* graph, const char* reads, size_t reads_bytes,
                            const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out);
+/* ---- extension windows: the passes of a seeded X-drop alignment inside a window of the resident graph ---------------------------------
+ * Aligner::align_xdrop (DozeuInterface::align, src/dozeu_interface.cpp:608-685) runs two pinned extensions over ONE subgraph: from the
+ * seed (a position inside a node) towards one end of the read to find the "head", then from the head the other way, traced.  Each is
+ * dz_extend over the part of the subgraph that lies in its direction: dozeu is handed the start node's sequence from the offset on
+ * (`seq + ref_offset`, :236-243; a leftward pass: the bases before it, backwards, :178-185), then every node its forefronts reach, in
+ * topological order.  giraffe's mate rescue (MinimizerMapper::attempt_rescue, src/minimizer_mapper.cpp:3264-3440) does this for every
+ * lost mate against the nodes at the fragment's distance from its partner.
+ * With the graph resident such a pass is {read, window, start position, direction}: the engine derives the sub-DAG ON THE DEVICE — the
+ * start node cut at the offset (left out when nothing of it lies that way: its neighbours then start from the root column), the window's
+ * nodes reachable from it in that direction, in extension order (leftward: descending, sequences reversed, successors as predecessors —
+ * no complementing), the read part on that side of query_offset (leftward: reversed) — and runs VGK_XDROP_PINNED over it on the same
+ * kernels as every other batch.  Results are those of vgk_gssw_pack on the sub-DAG a caller would build by hand
+ * (vg_amd/host/aligner.cpp xdrop_extend_prepare), except that end_node and op.node count from the WINDOW's first node (translated at
+ * fetch).  A leftward pass comes back in extension order: its caller flips it as for a right pin (src/aligner.cpp:443-449).  When nothing
+ * lies in the direction (a start at the window's last base, say) the result is score 0, no ops: "did not run".
+ * flags: VGK_XDROP_PINNED (| VGK_GSSW_TRACEBACK).  start_node is an index of the resident graph inside the window; start_offset at most
+ * the node's length; query_offset at most read_len, with a non-empty read part on the extension's side (VGK_EINVAL otherwise, as for a
+ * malformed window).  Graphs from vgk_graph_create only (a forest graph: VGK_EUNSUPPORTED). */
+typedef struct vgk_extension_problem {
+    uint64_t read_off;        /* the whole read in `reads`                                              */
+    uint32_t read_len;
+    uint32_t flags;
+    uint32_t first_node;      /* the window: nodes [first_node, first_node + n_nodes)                    */
+    uint32_t n_nodes;
+    uint32_t max_gap_length;  /* as in vgk_gssw_problem                                                  */
+    uint32_t start_node;      /* the extension starts on this node of the resident graph ...             */
+    uint32_t start_offset;    /* ... rightward: at its base start_offset; leftward: before it            */
+    uint32_t query_offset;    /* rightward: aligns read[query_offset, read_len); leftward: read[0, query_offset) */
+    uint32_t leftward;        /* 0 / 1                                                                   */
+    uint32_t reserved;
+} vgk_extension_problem;
+int  vgk_gssw_pack_extensions(vgk_ctx* ctx, const vgk_dgraph* graph, const char* reads, size_t reads_bytes,
+                              const vgk_extension_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out);
 /* ---- tail forests: the subgraphs giraffe aligns read tails to (MinimizerMapper::get_tail_forest, src/minimizer_mapper.cpp:5745-5860;
  * dfs_gbwt :5909-6013) ---------------------------------------------------------------------------------------------------------------
  * For an extension that does not reach an end of the read, giraffe walks the haplotypes that continue it — a depth-first search over

@@ -45,6 +45,9 @@ struct vgk_batch {
     vgk_result* res; vgk_op* ops; int ran; uint64_t cells;
     /* window batches own the problems built for them */
     vgk_gssw_problem* own_probs; char* own_reads; uint32_t* own_pred_off; uint32_t* own_pred_idx;
+    /* extension batches (vgk_gssw_pack_extensions): sub-DAG node k of problem i is window node ext_node[ext_off[i] + k]; ext_off[i + 1] == ext_off[i]:
+       nothing lay in the extension's direction (the problem built for it is a placeholder whose result is dropped) */
+    uint32_t* own_node_len; char* own_seq; uint32_t* ext_node; uint64_t* ext_off;
 };
 
 int vgk_abi_version(void) { return VGK_ABI_VERSION; }
@@ -184,6 +187,12 @@ int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_ca
         results[i].ops_begin = (uint32_t)w;
         if (w + b->res[i].n_ops > ops_cap) { results[i].status = VGK_EOPS; results[i].n_ops = 0; continue; }
         if (ops) memcpy(ops + w, b->ops + (size_t)i * b->ops_per, sizeof(vgk_op) * b->res[i].n_ops);
+        if (b->ext_off && results[i].status == VGK_OK) {                 /* the sub-DAG's nodes in the window's numbering */
+            const uint64_t e0 = b->ext_off[i], cnt = b->ext_off[i + 1] - e0;
+            if (!cnt) { results[i].score = 0; results[i].n_ops = 0; results[i].end_node = results[i].end_offset = results[i].end_read = -1; results[i].first_offset = 0; continue; }
+            if (results[i].end_node >= 0 && (uint64_t)results[i].end_node < cnt) results[i].end_node = (int32_t)b->ext_node[e0 + (uint64_t)results[i].end_node];
+            if (ops) for (uint32_t k = 0; k < results[i].n_ops; ++k) if (ops[w + k].node < cnt) ops[w + k].node = b->ext_node[e0 + ops[w + k].node];
+        }
         w += b->res[i].n_ops;
     }
     if (ops_written) *ops_written = w;
@@ -359,7 +368,8 @@ int vgk_gssw_align_multi(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
     return rc;
 }
 
-void vgk_batch_free(vgk_batch* b) { if (b) { free(b->res); free(b->ops); free(b->own_probs); free(b->own_reads); free(b->own_pred_off); free(b->own_pred_idx); free(b); } }
+void vgk_batch_free(vgk_batch* b) { if (b) { free(b->res); free(b->ops); free(b->own_probs); free(b->own_reads); free(b->own_pred_off); free(b->own_pred_idx);
+                                        free(b->own_node_len); free(b->own_seq); free(b->ext_node); free(b->ext_off); free(b); } }
 
 /* ---- windows of one graph (vgk_graph_create / vgk_gssw_pack_windows) ---------------------------------------------------
  * The oracle's reading of "a window is the induced subgraph on nodes [first, first + n)": every problem gets its own
@@ -441,6 +451,94 @@ int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* g, const char* reads, 
     if (rc) { free(pr); free(po); free(pi); free(rd); return rc; }
     b->own_probs = pr; b->own_reads = rd; b->own_pred_off = po; b->own_pred_idx = pi;
     *out = b; return VGK_OK;
+}
+/* ---- extension windows (vgk_gssw_pack_extensions): one pass of a seeded X-drop alignment from a position inside a window ------------------
+ * The oracle's construction of the sub-DAG, problem by problem, as DozeuInterface hands dozeu its nodes (src/dozeu_interface.cpp:236-243: the
+ * start node's sequence from the offset on; :178-185: a leftward pass reads the bases before the offset backwards; :261-283: a node is
+ * visited when a forefront of a neighbour on the start's side reaches it) and as the host shim builds it for one subgraph
+ * (vg_amd/host/aligner.cpp, xdrop_extend_prepare): explicit strings, an explicit predecessor CSR, then the ordinary per-problem oracle.
+ * (The engine derives the same sub-DAG on the device from the resident tables: gssw_pack_device.hpp ext_size_one / ext_emit_one.) */
+int vgk_gssw_pack_extensions(vgk_ctx* ctx, const vgk_dgraph* g, const char* reads, size_t reads_bytes,
+                             const vgk_extension_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out) {
+    if (!ctx || !g || !out || (!problems && n) || (!reads && reads_bytes)) return VGK_EINVAL;
+    *out = NULL;
+    if (ctx->has_qa) return VGK_EUNSUPPORTED;
+    int maxs = 0;
+    for (int k = 0; k < 25; ++k) if (ctx->sc.matrix[k] > maxs) maxs = ctx->sc.matrix[k];
+    uint64_t tot_nodes = 0, tot_edges = 0, tot_bases = 0, tot_query = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const vgk_extension_problem* p = &problems[i];
+        if (p->read_len == 0 || p->n_nodes == 0 || (uint64_t)p->first_node + p->n_nodes > g->n_nodes || p->read_off + p->read_len > reads_bytes) return VGK_EINVAL;
+        if ((p->flags & 15u) != VGK_XDROP_PINNED || p->query_offset > p->read_len) return VGK_EINVAL;
+        const uint32_t qlen = p->leftward ? p->query_offset : p->read_len - p->query_offset;
+        if (qlen == 0 || p->start_node < p->first_node || p->start_node >= p->first_node + p->n_nodes || p->start_offset > g->node_len[p->start_node]) return VGK_EINVAL;
+        if (qlen + 1 > 1024) return VGK_ETOOLONG;
+        if ((int64_t)(qlen + 1) * maxs + 2 * (int64_t)ctx->sc.full_length_bonus > 2046) return VGK_EUNSUPPORTED;
+        if ((int64_t)qlen * maxs + ctx->sc.full_length_bonus >= 1023) return VGK_EUNSUPPORTED;
+        tot_nodes += p->n_nodes; tot_edges += g->pred_off[p->first_node + p->n_nodes] - g->pred_off[p->first_node];
+        tot_bases += g->seq_off[p->first_node + p->n_nodes] - g->seq_off[p->first_node] + 1; tot_query += qlen;
+    }
+    vgk_gssw_problem* pr = (vgk_gssw_problem*)calloc(n ? n : 1, sizeof *pr);
+    uint32_t* po = (uint32_t*)malloc(sizeof(uint32_t) * (tot_nodes + 2ull * n + 1)); uint32_t* pi = (uint32_t*)malloc(sizeof(uint32_t) * (tot_edges + 1));
+    uint32_t* nl = (uint32_t*)malloc(sizeof(uint32_t) * (tot_nodes + n + 1)); char* sq = (char*)malloc(tot_bases + n + 1);
+    char* rd = (char*)malloc(tot_query + 1);
+    uint32_t* en = (uint32_t*)malloc(sizeof(uint32_t) * (tot_nodes + 1)); uint64_t* eo = (uint64_t*)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+    int32_t* where = (int32_t*)malloc(sizeof(int32_t) * (g->n_nodes + 1ull));      /* window node -> sub-DAG node, per problem (reset after use) */
+    if (!pr || !po || !pi || !nl || !sq || !rd || !en || !eo || !where) { free(pr); free(po); free(pi); free(nl); free(sq); free(rd); free(en); free(eo); free(where); return VGK_ENOMEM; }
+    for (uint32_t v = 0; v <= g->n_nodes; ++v) where[v] = -2;                     /* -2: not reached; -1: reached but left out (the start, cut to nothing) */
+    uint64_t at_o = 0, at_e = 0, at_n = 0, at_s = 0, at_q = 0, at_x = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const vgk_extension_problem* p = &problems[i];
+        const uint32_t a = p->first_node, b = p->first_node + p->n_nodes, s = p->start_node;
+        const int left = p->leftward != 0;
+        const uint32_t qlen = left ? p->query_offset : p->read_len - p->query_offset;
+        /* the read part on the extension's side, in extension order */
+        for (uint32_t r = 0; r < qlen; ++r) rd[at_q + r] = left ? reads[p->read_off + p->query_offset - 1 - r] : reads[p->read_off + p->query_offset + r];
+        vgk_gssw_problem* q = &pr[i];
+        q->read = rd + at_q; q->read_len = qlen; q->flags = p->flags; q->max_gap_length = p->max_gap_length;
+        q->graph.node_len = nl + at_n; q->graph.seq = sq + at_s; q->graph.pred_off = po + at_o; q->graph.pred_idx = pi + at_e;
+        uint32_t cnt = 0, ne = 0; uint64_t bases = 0;
+        eo[i] = at_x;
+        /* the window's nodes in extension order from the start; the edges that lead back towards it */
+        for (uint32_t step = 0; left ? s >= a + step : s + step < b; ++step) {
+            const uint32_t v = left ? s - step : s + step;
+            uint32_t len = g->node_len[v]; const char* src = g->seq + g->seq_off[v];
+            int reached = v == s;
+            if (v == s) { if (left) len = p->start_offset; else { src += p->start_offset; len -= p->start_offset; } }
+            else {
+                /* neighbours on the start's side: predecessors (rightward) or successors (leftward: found by scanning the later nodes' lists) */
+                if (!left) { for (uint32_t e = g->pred_off[v]; e < g->pred_off[v + 1]; ++e) { const uint32_t u = g->pred_idx[e]; if (u >= s && u < b && where[u] != -2) reached = 1; } }
+                else for (uint32_t u = v + 1; u <= s; ++u) { if (where[u] == -2) continue; for (uint32_t e = g->pred_off[u]; e < g->pred_off[u + 1]; ++e) if (g->pred_idx[e] == v) reached = 1; }
+            }
+            if (!reached) continue;
+            if (v == s && len == 0) { where[v] = -1; continue; }                  /* pinned exactly at the node's end: its neighbours start from the root */
+            where[v] = (int32_t)cnt;
+            po[at_o + cnt] = ne;
+            if (v != s) {
+                if (!left) { for (uint32_t e = g->pred_off[v]; e < g->pred_off[v + 1]; ++e) { const uint32_t u = g->pred_idx[e]; if (u >= s && u < b && where[u] >= 0) pi[at_e + ne++] = (uint32_t)where[u]; } }
+                else for (uint32_t u = v + 1; u <= s; ++u) { if (where[u] < 0) continue; for (uint32_t e = g->pred_off[u]; e < g->pred_off[u + 1]; ++e) if (g->pred_idx[e] == v) pi[at_e + ne++] = (uint32_t)where[u]; }
+            }
+            nl[at_n + cnt] = len;
+            for (uint32_t k = 0; k < len; ++k) sq[at_s + bases + k] = left ? src[len - 1 - k] : src[k];
+            bases += len; en[at_x + cnt] = v - a; ++cnt;
+        }
+        for (uint32_t v = a; v < b; ++v) where[v] = -2;
+        if (cnt == 0) {                                                           /* nothing lies that way: a placeholder the fetch drops */
+            po[at_o] = 0; nl[at_n] = 1; sq[at_s] = 'N'; cnt = 1; bases = 1;
+            po[at_o + 1] = 0; q->graph.n_nodes = 1;
+            at_o += 2; at_n += 1; at_s += 1; at_q += qlen;                        /* (eo[i + 1] == eo[i]) */
+            continue;
+        }
+        po[at_o + cnt] = ne; q->graph.n_nodes = cnt;
+        at_o += cnt + 1; at_e += ne; at_n += cnt; at_s += bases; at_q += qlen; at_x += cnt;
+    }
+    eo[n] = at_x;
+    free(where);
+    vgk_batch* bt = NULL;
+    int rc = vgk_gssw_pack(ctx, pr, n, ops_per_problem, &bt);
+    if (rc) { free(pr); free(po); free(pi); free(nl); free(sq); free(rd); free(en); free(eo); return rc; }
+    bt->own_probs = pr; bt->own_reads = rd; bt->own_pred_off = po; bt->own_pred_idx = pi; bt->own_node_len = nl; bt->own_seq = sq; bt->ext_node = en; bt->ext_off = eo;
+    *out = bt; return VGK_OK;
 }
 int  vgk_batch_sync(vgk_batch* b) { (void)b; return VGK_OK; }
 double vgk_batch_kernel_ms(vgk_batch* b, int which) { (void)b; (void)which; return 0.0; }

@@ -367,6 +367,7 @@ public:
     }
     int run_gssw(const GsswParams& P0, const FillLaunch* launches, uint32_t n, bool walk) override {
         GsswParams P = P0;
+        if (P0.restore_probs) for (uint32_t i = 0; i < P0.n_problems; ++i) refill_restore_one(P0, i);
         for (uint32_t i = 0; i < n; ++i) {
             const FillLaunch& L = launches[i];
             P.K = L.K; P.wave_begin = L.wave_begin; P.wave_count = L.wave_count;

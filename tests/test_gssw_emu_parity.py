@@ -241,6 +241,18 @@ def speculation_follows_the_miss_counts(emu_lib, monkeypatch, n=1100):
         r, o = b.fetch()
     assert ran == [True, False, False, True]
     assert (r["score"] == want[id(noisy)][0]["score"]).all()
+    # ... and a plain run right behind a speculative one of the same resident batch: the speculative run moved its missed reads' descriptors to
+    # their second wavefronts (refill_layout_one); the plain run puts them back first (refill_restore_one) and finds every read's codes
+    eng3 = capi.Engine(sc, lib=emu_lib)
+    with eng3.pack_windows(eng3.graph(*noisy.graph_arrays()), noisy.windows(), 0) as b:
+        b.run(); b.sync(); assert b.speculated()
+        b.run(); b.sync(); assert not b.speculated()
+        r, o = b.fetch()
+    ro, oo = want[id(noisy)]
+    for f in ("status", "score", "end_node", "end_offset", "end_read", "first_offset", "n_ops"):
+        assert (r[f] == ro[f]).all(), f
+    tot = int(ro["n_ops"].sum())
+    assert (o[:tot].view(np.uint64) == oo[:tot].view(np.uint64)).all()
 
 
 def test_speculation_follows_the_miss_counts_of_earlier_batches(emu_lib, monkeypatch):

@@ -34,6 +34,9 @@ OP_DT = np.dtype([("node", "<u4"), ("len", "<u2"), ("op", "u1"), ("pad", "u1")])
 WINDOW_DT = np.dtype([("read_off", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), ("first_node", "<u4"), ("n_nodes", "<u4"),
                       ("max_gap_length", "<u4"), ("reserved", "<u4")])
 assert WINDOW_DT.itemsize == 32
+EXTENSION_DT = np.dtype([("read_off", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), ("first_node", "<u4"), ("n_nodes", "<u4"), ("max_gap_length", "<u4"),
+                         ("start_node", "<u4"), ("start_offset", "<u4"), ("query_offset", "<u4"), ("leftward", "<u4"), ("reserved", "<u4")])
+assert EXTENSION_DT.itemsize == 48
 BANDED_DT = np.dtype([("read", "<u8"), ("qual", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), ("graph", GRAPH_DT),
                       ("band_padding", "<i4"), ("reserved", "<u4"), ("max_cells", "<u8")])
 VGK_BANDED_PERMISSIVE = 1
@@ -332,6 +335,19 @@ class Engine:
         self._check(self.lib.vgk_gssw_pack_windows(self.h, graph.h, ws.reads.ctypes.data, ws.reads.size, ws.array.ctypes.data, ws.n,
                                                    ops_per_problem, ctypes.byref(b)), "vgk_gssw_pack_windows")
         return Batch(self, b, ws, ops_per_problem)
+
+    def pack_extensions(self, graph, es, ops_per_problem=0):
+        """vgk_gssw_pack_extensions: es = ExtensionSet; the sub-DAGs are derived on the device"""
+        b = ctypes.c_void_p()
+        self.lib.vgk_gssw_pack_extensions.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+        self._check(self.lib.vgk_gssw_pack_extensions(self.h, graph.h, es.reads.ctypes.data, es.reads.size, es.array.ctypes.data, es.n,
+                                                      ops_per_problem, ctypes.byref(b)), "vgk_gssw_pack_extensions")
+        return Batch(self, b, es, ops_per_problem)
+
+    def align_extensions(self, graph, es, ops_per_problem=0):
+        with self.pack_extensions(graph, es, ops_per_problem) as b:
+            b.run()
+            return b.fetch()
 
     def align_windows(self, graph, ws, ops_per_problem=0):
         with self.pack_windows(graph, ws, ops_per_problem) as b:
@@ -739,6 +755,27 @@ class WindowSet:
             arr["max_gap_length"] = np.asarray(max_gap, dtype=np.uint32)
         self.array = arr
         self.cols = None if cols is None else np.asarray(cols, dtype=np.int64)      # graph bases per window (sizes the default op array)
+
+    @property
+    def seq_off(self):
+        c = self.cols if self.cols is not None else np.zeros(self.n, dtype=np.int64)
+        return np.concatenate([[0], np.cumsum(c)])
+
+
+class ExtensionSet:
+    """A batch of extension windows (vgk_extension_problem): one pass of a seeded X-drop alignment from a position inside a window."""
+
+    def __init__(self, reads, read_off, first_node, n_nodes, flags, max_gap, start_node, start_offset, query_offset, leftward, cols=None):
+        self.reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        self.read_off = np.asarray(read_off, dtype=np.int64)
+        n = self.n = len(self.read_off) - 1
+        arr = np.zeros(n, dtype=EXTENSION_DT)
+        arr["read_off"] = self.read_off[:-1]; arr["read_len"] = np.diff(self.read_off)
+        for k, v in (("flags", flags), ("first_node", first_node), ("n_nodes", n_nodes), ("max_gap_length", max_gap), ("start_node", start_node),
+                     ("start_offset", start_offset), ("query_offset", query_offset), ("leftward", leftward)):
+            arr[k] = np.asarray(v, dtype=np.uint32)
+        self.array = arr
+        self.cols = None if cols is None else np.asarray(cols, dtype=np.int64)
 
     @property
     def seq_off(self):

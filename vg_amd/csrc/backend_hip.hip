@@ -177,6 +177,10 @@ __global__ __launch_bounds__(64) void gssw_walk_first_kernel(const GsswParams P,
 __global__ __launch_bounds__(64) void gssw_refill_layout_kernel(const GsswParams P) {
     refill_layout_one(P, blockIdx.x * blockDim.x + threadIdx.x);
 }
+__global__ __launch_bounds__(256) void gssw_refill_restore_kernel(const GsswParams P) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.n_problems) refill_restore_one(P, i);
+}
 __global__ __launch_bounds__(256) void gssw_walk_missed_kernel(const GsswParams P) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= *tb_miss_count(P)) return;
@@ -1137,6 +1141,7 @@ public:
         n_launches = n ? (int)n : 1;
         if (p0.n_problems == 0 || n == 0) { ms_fill = ms_walk = 0; pending = false; return VGK_OK; }
         GsswParams p = p0;
+        if (p0.restore_probs) hipLaunchKernelGGL(gssw_refill_restore_kernel, dim3((p0.n_problems + 255) / 256), dim3(256), 0, stream, p0);
         if (fills_take_turns && fill_done_set[1]) hipStreamWaitEvent(stream, fill_done[1], 0);       // (measured: DESIGN.md §5)
         hipEventRecord(ev[0], stream);
         // the (up to three) rows-per-lane instantiations are independent: side streams let a small bucket's
@@ -1176,6 +1181,7 @@ public:
         if (hipMemsetAsync(p0.best, 0, ((size_t)p0.n_problems + 1) * sizeof(unsigned long long), alt) != hipSuccess) return VGK_ENODEV;
         GsswParams p = p0;
         p.K = launches[0].K; p.wave_begin = launches[0].wave_begin; p.wave_count = launches[0].wave_count;
+        if (p0.restore_probs) hipLaunchKernelGGL(gssw_refill_restore_kernel, dim3((p0.n_problems + 255) / 256), dim3(256), 0, alt, p0);
         if (fills_take_turns && fill_done_set[0]) hipStreamWaitEvent(alt, fill_done[0], 0);
         hipEventRecord(evb[0], alt);
         if (p.wave_count) { const int rc = launch_fill(p, alt); if (rc) return rc; }

@@ -12,6 +12,7 @@ struct vgk_batch {
     vgk_ctx* ctx = nullptr;
     uint32_t n = 0;
     bool want_tb = false, ran = false;
+    bool probs_displaced = false;                     // a speculative run has rewritten descriptors of this batch (GsswParams::restore_probs)
     bool ran_spec = false, spec_observed = true;      // the last run speculated | its miss count has been handed to the context's SpecPolicy
     GsswParams P{};
     std::vector<vgk_ctx::Pooled> dev;   // every device allocation of this batch (back to the context's pool when the batch is freed)
@@ -23,6 +24,9 @@ struct vgk_batch {
     void* done = nullptr;               // recorded behind this batch's kernels by vgk_gssw_run (Backend::event_*)
     ~vgk_batch() { if (probs && ctx) ctx->host_give(probs, probs_bytes); if (done && ctx) ctx->be->event_destroy(done); }
     std::vector<FillLaunch> launches;   // one per length bucket
+    // extension windows (vgk_gssw_pack_extensions): problem i's node k is window node ext_nodes[ext_off[i] + k]; ext_count[i] = WIN_EXT_DUMMY: nothing
+    // lay in the extension's direction.  vgk_gssw_fetch hands results and ops back in the window's terms.
+    std::vector<uint32_t> ext_count, ext_off, ext_nodes;
     struct Upload { void* dst; const void* src; size_t bytes; };
     std::vector<Upload> uploads;        // queued by to_device under the context lock, issued by vgk_gssw_pack outside it
 };

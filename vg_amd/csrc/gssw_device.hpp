@@ -120,6 +120,7 @@ struct GsswParams {
     // WITH codes, and walked by them.  refill_wave0 / refill_pair0: where those wavefronts and their pairs start in waves[] / order[];
     // refill_slot: traceback dwords per such wavefront (sized for the batch's widest window); refill_count[0]: how many there are (device).
     int32_t  spec_fill;
+    int32_t  restore_probs;     // this run does not speculate, an earlier run of the same batch did: the displaced reads' descriptors go back first (refill_restore_one)
     uint32_t refill_wave0, refill_pair0, refill_G, refill_K;
     unsigned long long refill_slot;
     uint32_t* refill_count;
@@ -1202,11 +1203,21 @@ VGK_HD void refill_layout_one(const GsswParams& P, uint32_t w2) {
             if (c_e + 1u < cols) cols = c_e + 1u;
         }
         rmax = cols > rmax ? cols : rmax;
+        // (where the batch's own fill put the read: kept in the descriptor's spare word, for a later run of this resident batch WITHOUT the
+        // speculation — vgk_gssw_run's feedback may decide so — which refill_restore_one hands it back to.  Only the first displacement saves.)
+        if (!(d.pad & 0x80000000u)) d.pad = 0x80000000u | (d.wave & 0xffffffu) | ((d.lane0 & 63u) << 24) | (((d.geom >> 16) & 1u) << 30);
         d.wave = P.refill_wave0 + w2; d.lane0 = q * G; d.geom = P.refill_K | (G << 8) | (h << 16);
     }
     wd.n_steps = rmax ? rmax + G - 1u : 0u;
     wd.tb_off = (unsigned long long)w2 * P.refill_slot;
     waves[P.refill_wave0 + w2] = wd;
+}
+// a read an earlier speculative run displaced goes back to the wavefront, lane group and half the batch's own fill gives it
+VGK_HD void refill_restore_one(const GsswParams& P, uint32_t i) {
+    ProbDesc& d = const_cast<ProbDesc*>(P.probs)[i];
+    const uint32_t s = d.pad;
+    if (!(s & 0x80000000u)) return;
+    d.wave = s & 0xffffffu; d.lane0 = (s >> 24) & 63u; d.geom = (d.geom & 0xffffu) | (((s >> 30) & 1u) << 16); d.pad = 0;
 }
 VGK_HD void bandwalk_one(const GsswParams& P, uint32_t i, unsigned long long best_key) {
     const ProbDesc d = P.probs[i];

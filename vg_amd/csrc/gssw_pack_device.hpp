@@ -51,7 +51,32 @@ struct WinGraph {                // the resident graph (device pointers)
     const uint32_t* pred_idx;
     const uint32_t* slot;        // [n_nodes + 1] stored nodes before node v (a node is stored when a successor seeds from scratch)
     uint32_t n_nodes, n_cols;
+    const uint32_t* succ_off;    // [n_nodes + 1] successors as CSR (ascending per node): what a LEFTWARD extension window walks; null for graphs made
+    const uint32_t* succ_idx;    //               on the device (tail forests), which are never extended leftwards
 };
+
+// An EXTENSION window (vgk_rescue_align, rescue_api.cpp): a pinned X-drop extension from a position INSIDE a window of the resident graph — one of
+// the two passes of Aligner::align_xdrop (DozeuInterface::align, src/dozeu_interface.cpp:608-685), as Aligner::xdrop_extend_prepare builds it on
+// the host for one subgraph at a time (vg_amd/host/aligner.cpp): the part of the start node that lies in the direction of the extension, then the
+// window's nodes REACHABLE from it in that direction, in extension order (a leftward pass: descending, every node's bases reversed, successors as
+// predecessors), with the read part on that side of `query_offset` (a leftward pass: reversed).  A start exactly at the node's end is not part
+// of the problem: its neighbours start from the root column.  Nodes the start cannot reach are NOT part of the problem (in dozeu's pinned mode
+// every source would be a root), so the problem's node k is kept[kept_off + k], which stage 1 leaves in `kept` for the caller.
+struct WinExt {
+    uint32_t start_node;         // index in the resident graph; inside the window
+    uint32_t start_offset;       // rightward: the node's bases [start_offset, length) belong to the problem; leftward: its bases [0, start_offset), reversed
+    uint32_t query_offset;       // rightward: read[query_offset, read_len); leftward: read[0, query_offset) reversed
+    uint32_t leftward;
+    uint32_t kept_off;           // first entry of this problem in the per-node temporaries (a prefix sum of the windows' n_nodes)
+    uint32_t pad;
+};
+struct WinKept {                 // per node of an extension window's problem, written by stage 1 (one lane per problem), read by stage 2 (a wavefront per problem)
+    uint32_t node;               // index in the resident graph
+    uint32_t col;                // its first column in the problem
+    uint32_t pred_at;            // predecessors (inside the problem) of the nodes before it
+    uint32_t slot_flags;         // stored nodes before it << 2 | store << 1 | slow
+};
+constexpr uint32_t WIN_EXT_DUMMY = 0x80000000u;       // ext_count[i]: nothing lies in the extension's direction — the problem is one N column that scores nothing; the caller takes "did not run"
 
 struct WinBucket { uint32_t s0, s1, K, G, pair0, pair1, wave0, pad; };
 
@@ -84,6 +109,8 @@ struct WinParams {
     uint32_t* bucket_first;      // [WIN_BUCKETS] first sorted position of the bucket, 0xffffffff = empty
     WinBucket* buckets;          // [WIN_BUCKETS] the non-empty ones, in launch order
     unsigned long long* wave_tb; // [n_waves_cap + 1] traceback dwords per wave, then their exclusive sums
+    // extension windows (null: plain windows): per problem its start; per window node the temporaries; per problem the nodes kept
+    const WinExt* ext; WinKept* kept; uint32_t* ext_count;
     // stage 2 outputs: the arenas of GsswParams
     ProbDesc* probs; uint8_t* colinfo; uint8_t* reads; NodeRec* nodes; uint32_t* preds; WaveDesc* waves; uint32_t* order;
 };
@@ -119,7 +146,106 @@ VGK_HD void win_acc_flush(const WinParams& P, const WinAcc& a) {
 
 // Stage 1, one call per problem: validate, size, choose the lane geometry, fill the fields of ProbDesc that need no offsets.
 // The checks are those of vgk_gssw_pack (vgk_api.cpp); a failing problem reports (index, status) and sizes to nothing.
+// position of graph node v among the nodes kept so far (ascending for a rightward extension, descending for a leftward one), or 0xffffffff
+VGK_HD uint32_t ext_find(const WinKept* kept, uint32_t count, uint32_t v, bool leftward) {
+    uint32_t lo = 0, hi = count;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1, u = kept[mid].node;
+        if (u == v) return mid;
+        if ((u < v) != leftward) lo = mid + 1; else hi = mid;
+    }
+    return 0xffffffffu;
+}
+
+// Stage 1 for an extension window, one call per problem: which nodes the start reaches inside the window, their columns, predecessor counts,
+// stored / slow flags — and from those the sizes, exactly as win_size_one sizes a plain window.
+VGK_HD void ext_size_one(const WinParams& P, uint32_t i, WinAcc& acc) {
+    const vgk_window_problem p = P.problems[i];
+    const WinExt x = P.ext[i];
+    const uint32_t n1 = P.n + 1;
+    ProbDesc d;
+    d.col_off = d.R = d.L = d.read_off = d.node_off = d.n_nodes = d.scratch_off = d.n_slots = d.flags = d.ops_off = d.ops_cap = 0;
+    d.max_gap = d.wave = d.lane0 = d.geom = d.Lpad = d.bonus_start = d.bonus_end = d.pad = 0; d.prof_off = 0xffffffffu;
+    int status = VGK_OK;
+    const bool left = x.leftward != 0;
+    const uint32_t qlen = left ? x.query_offset : (x.query_offset <= p.read_len ? p.read_len - x.query_offset : 0u);
+    const uint32_t rows = qlen + 1u;
+    if (p.read_len == 0 || p.n_nodes == 0 || (unsigned long long)p.first_node + p.n_nodes > P.g.n_nodes ||
+        p.read_off + p.read_len > P.raw_bytes || p.read_off + p.read_len < p.read_off) status = VGK_EINVAL;
+    else if ((p.flags & 15u) != VGK_XDROP_PINNED || x.query_offset > p.read_len || qlen == 0) status = VGK_EINVAL;
+    else if (x.start_node < p.first_node || x.start_node >= p.first_node + p.n_nodes || (left && !P.g.succ_off)) status = VGK_EINVAL;
+    else if (x.start_offset > P.g.col[x.start_node + 1] - P.g.col[x.start_node]) status = VGK_EINVAL;
+    else if (rows > 1024) status = VGK_ETOOLONG;
+    else if ((long long)rows * (P.max_score > 0 ? P.max_score : 0) + 2ll * P.max_bonus > 2046) status = VGK_EUNSUPPORTED;
+    else if ((long long)qlen * (P.max_score > 0 ? P.max_score : 0) + P.max_bonus >= (long long)XOFF) status = VGK_EUNSUPPORTED;
+    uint32_t R = 0, slots = 0, n_preds = 0, count = 0;
+    WinKept* kept = P.kept + x.kept_off;
+    if (status == VGK_OK) {
+        const uint32_t a = p.first_node, b = p.first_node + p.n_nodes, s = x.start_node;
+        const uint32_t start_len = left ? x.start_offset : (P.g.col[s + 1] - P.g.col[s]) - x.start_offset;
+        const bool skip_start = start_len == 0;
+        if (!skip_start) { kept[0].node = s; kept[0].col = 0; kept[0].pred_at = 0; kept[0].slot_flags = 1u; count = 1; R = start_len; }      // (the start: the root column, no predecessors)
+        // the window's other nodes in extension order: reached when a neighbour on the start's side is (the start itself counts, kept or not)
+        for (uint32_t step = 1; left ? s >= a + step : s + step < b; ++step) {
+            const uint32_t v = left ? s - step : s + step;
+            const uint32_t eb = left ? P.g.succ_off[v] : P.g.pred_off[v], ee = left ? P.g.succ_off[v + 1] : P.g.pred_off[v + 1];
+            const uint32_t* nb = left ? P.g.succ_idx : P.g.pred_idx;
+            bool reach = false; uint32_t np = 0, only = 0xffffffffu;
+            for (uint32_t e = eb; e < ee; ++e) {
+                const uint32_t q = nb[e];
+                if (left ? (q > s || q < a) : (q < s || q >= b)) continue;             // beyond the start / outside the window
+                if (q == s) { reach = true; if (!skip_start) { ++np; only = 0; } continue; }
+                const uint32_t at = ext_find(kept, count, q, left);
+                if (at != 0xffffffffu) { reach = true; ++np; only = at; }
+            }
+            if (!reach) continue;
+            const bool chain = np == 1 && only + 1 == count;
+            WinKept k; k.node = v; k.col = R; k.pred_at = n_preds; k.slot_flags = chain ? 0u : 1u;
+            kept[count] = k;
+            if (!chain)                                                                // its predecessors' last columns are saved
+                for (uint32_t e = eb; e < ee; ++e) {
+                    const uint32_t q = nb[e];
+                    if (left ? (q > s || q < a) : (q < s || q >= b)) continue;
+                    const uint32_t at = (q == s) ? (skip_start ? 0xffffffffu : 0u) : ext_find(kept, count, q, left);
+                    if (at != 0xffffffffu) kept[at].slot_flags |= 2u;
+                }
+            n_preds += np; R += P.g.col[v + 1] - P.g.col[v]; ++count;
+        }
+        for (uint32_t k = 0; k < count; ++k) { const uint32_t f = kept[k].slot_flags & 3u; kept[k].slot_flags = (slots << 2) | f; slots += (f >> 1) & 1u; }
+        if (count == 0) { R = 1; }                                                       // the dummy column (WIN_EXT_DUMMY)
+        if (R >= (1u << 20)) status = VGK_ETOOBIG;
+    }
+    uint32_t key = 0xffffffffu;
+    if (status != VGK_OK) {
+        acc_min(&P.totals->first_bad, ((unsigned long long)i << 8) | (unsigned long long)(uint32_t)(-status));
+        for (uint32_t k = 0; k < WIN_COLS; ++k) P.sizes[k * n1 + i] = 0;
+        key = ((WIN_BUCKETS - 1) << 16) | 0xffffu;
+        P.ext_count[i] = 0;
+    } else {
+        uint32_t K, G; lane_geometry(rows, P.forced_k, K, G);
+        const uint32_t nn = count ? count : 1u;
+        d.R = R; d.L = rows; d.n_nodes = nn; d.n_slots = slots; d.flags = p.flags;
+        d.node_off = p.first_node;
+        d.max_gap = ((p.max_gap_length > 1u ? p.max_gap_length : 1u) + 7u) & ~7u;
+        d.geom = K | (G << 8); d.Lpad = G * K;
+        d.bonus_start = 0u; d.bonus_end = (uint32_t)P.bonus * P.scale;
+        const bool tb = (p.flags & VGK_GSSW_TRACEBACK) != 0;
+        d.ops_cap = tb ? (P.ops_per_problem ? P.ops_per_problem : qlen + R + 2u) : 0u;
+        const uint32_t sz[WIN_COLS] = {(R + 3u) & ~3u, nn, n_preds, (rows + 3u) & ~3u, slots * d.Lpad, d.ops_cap};
+        for (uint32_t k = 0; k < WIN_COLS; ++k) { P.sizes[k * n1 + i] = sz[k]; acc.tot[k] += sz[k]; }
+        acc.cells += (unsigned long long)R * rows;
+        if (tb) { acc.tb_cells += (unsigned long long)R * rows; acc.want_tb = 1; }
+        acc.in_bytes += (unsigned long long)qlen + R + 8ull * nn + 4ull * n_preds;
+        acc.max_rows = acc.max_rows > rows ? acc.max_rows : rows;
+        key = ((geometry_index(K) * 65u + G) << 16) | (0xffffu - (R < 0xffffu ? R : 0xffffu));
+        P.ext_count[i] = count ? count : WIN_EXT_DUMMY;
+    }
+    P.probs[i] = d;
+    P.key[i] = key; P.idx[i] = i;
+}
+
 VGK_HD void win_size_one(const WinParams& P, uint32_t i, WinAcc& acc) {
+    if (P.ext) { ext_size_one(P, i, acc); return; }
     const vgk_window_problem p = P.problems[i];
     const uint32_t n1 = P.n + 1;
     ProbDesc d;
@@ -227,7 +353,96 @@ VGK_HD void win_wave_tb_one(const WinParams& P, uint32_t w) {       // after the
 
 // Stage 2, per problem, `lane` of `lanes` cooperating callers (a wavefront on the device): the offsets into the shared arenas,
 // the node records and predecessor lists of the induced subgraph, its column info stream, its read codes.
+// Stage 2 for an extension window: the arenas of its problem from the per-node temporaries stage 1 left (every lane works for itself: nothing
+// written here is read here).
+VGK_HD void ext_emit_one(const WinParams& P, uint32_t i, uint32_t lane, uint32_t lanes) {
+    const uint32_t n1 = P.n + 1;
+    const vgk_window_problem p = P.problems[i];
+    const WinExt x = P.ext[i];
+    ProbDesc& d = P.probs[i];
+    const bool left = x.leftward != 0;
+    const uint32_t col_off = P.offs[WS_COLS * n1 + i], node_off = P.offs[WS_NODES * n1 + i], pred_at = P.offs[WS_PREDS * n1 + i],
+                   read_off = P.offs[WS_READS * n1 + i];
+    const uint32_t cnt = P.ext_count[i];
+    const bool dummy = cnt == WIN_EXT_DUMMY;
+    const uint32_t count = dummy ? 0u : cnt;
+    const WinKept* kept = P.kept + x.kept_off;
+    const uint32_t a = p.first_node, b = p.first_node + p.n_nodes, s = x.start_node;
+    const uint32_t R = d.R, R4 = (R + 3u) & ~3u;
+    const bool start_kept = count && kept[0].node == s;
+    if (dummy) {
+        if (lane == 0) { NodeRec nr; nr.col_start = 0; nr.col_end = 1; nr.pred_begin = pred_at; nr.n_pred = 0; nr.slot = -1; nr.pinning = 0; P.nodes[node_off] = nr; }
+    } else {
+        for (uint32_t k = lane; k < count; k += lanes) {
+            const WinKept kk = kept[k];
+            const uint32_t v = kk.node;
+            NodeRec nr;
+            nr.col_start = kk.col; nr.col_end = (k + 1 < count) ? kept[k + 1].col : R;
+            nr.pred_begin = pred_at + kk.pred_at;
+            uint32_t np = 0;
+            if (v != s) {
+                const uint32_t eb = left ? P.g.succ_off[v] : P.g.pred_off[v], ee = left ? P.g.succ_off[v + 1] : P.g.pred_off[v + 1];
+                const uint32_t* nb = left ? P.g.succ_idx : P.g.pred_idx;
+                for (uint32_t e = eb; e < ee; ++e) {
+                    const uint32_t q = nb[e];
+                    if (left ? (q > s || q < a) : (q < s || q >= b)) continue;
+                    const uint32_t at = (q == s) ? (start_kept ? 0u : 0xffffffffu) : ext_find(kept, k, q, left);
+                    if (at != 0xffffffffu) P.preds[nr.pred_begin + np++] = at;
+                }
+            }
+            nr.n_pred = np;
+            nr.slot = (kk.slot_flags & 2u) ? (int32_t)(kk.slot_flags >> 2) : -1;
+            nr.pinning = 0;
+            P.nodes[node_off + k] = nr;
+        }
+    }
+    // the column stream: every column finds its node (the columns of a problem are a few hundred, its nodes a few dozen)
+    for (uint32_t c = 4u * lane; c < R4; c += 4u * lanes) {
+        uint32_t w = 0;
+        for (uint32_t j = 0; j < 4; ++j) {
+            uint32_t ci = (uint32_t)CI_INVALID;
+            const uint32_t cc = c + j;
+            if (cc < R) {
+                if (dummy) ci = 4u | CI_NODE_START | CI_SEED_SLOW;
+                else {
+                    uint32_t lo = 0, hi = count;                                       // the last node whose first column is <= cc
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (kept[mid].col <= cc) lo = mid; else hi = mid; }
+                    const WinKept kk = kept[lo];
+                    const uint32_t v = kk.node, off = cc - kk.col, end = (lo + 1 < count) ? kept[lo + 1].col : R, len = end - kk.col;
+                    const uint32_t c0 = P.g.col[v];
+                    uint32_t src;
+                    if (!left) src = c0 + (v == s ? x.start_offset : 0u) + off;
+                    else src = c0 + (v == s ? x.start_offset : P.g.col[v + 1] - c0) - 1u - off;
+                    ci = P.g.info[src] & (uint32_t)CI_BASE_MASK;
+                    if (off == 0) ci |= CI_NODE_START | ((kk.slot_flags & 1u) ? (uint32_t)CI_SEED_SLOW : 0u);
+                    if (off + 1 == len && (kk.slot_flags & 2u)) ci |= CI_STORE_END;
+                }
+            }
+            w |= ci << (8 * j);
+        }
+        *(uint32_t*)(P.colinfo + col_off + c) = w;
+    }
+    // read codes: row 0 = "no read base consumed yet", then the read part on the extension's side, in extension order
+    const uint32_t rows4 = (d.L + 3u) & ~3u;
+    for (uint32_t r = 4u * lane; r < rows4; r += 4u * lanes) {
+        uint32_t w = 0;
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t row = r + j;
+            uint32_t code = 0;
+            if (row == 0) code = 5;
+            else if (row < d.L) code = win_nt_read(P.raw_reads[p.read_off + (left ? x.query_offset - row : x.query_offset + row - 1u)]);
+            w |= code << (8 * j);
+        }
+        *(uint32_t*)(P.reads + read_off + r) = w;
+    }
+    if (lane == 0) {
+        d.col_off = col_off; d.node_off = node_off; d.read_off = read_off;
+        d.scratch_off = P.offs[WS_SCRATCH * n1 + i]; d.ops_off = P.offs[WS_OPS * n1 + i];
+    }
+}
+
 VGK_HD void win_emit_one(const WinParams& P, uint32_t i, uint32_t lane, uint32_t lanes) {
+    if (P.ext) { ext_emit_one(P, i, lane, lanes); return; }
     const uint32_t n1 = P.n + 1;
     const vgk_window_problem p = P.problems[i];
     ProbDesc& d = P.probs[i];

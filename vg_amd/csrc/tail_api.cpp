@@ -147,7 +147,8 @@ void vgk_forest_destroy(vgk_forest* f) {
 // call left in HBM (tail_device.hpp "the tails of a batch of extension sets").  The host sees four totals that size allocations and, at
 // the end, one int per extension and one per read.
 int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
-                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out, bool on_device, uint32_t forced_k);
+                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out, bool on_device, uint32_t forced_k,
+                          const vgk::WinExt* extensions);
 }  // extern "C"
 // aligned / tails_cap / ops / ops_cap / written: vgk_tail_stage_aligned's outputs (all null / 0 for vgk_tail_stage)
 static int tail_stage_impl(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score, uint64_t stats[4],
@@ -274,7 +275,7 @@ static int tail_stage_impl(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_pe
             // launches that each leave the device half empty and finish at different times (measured: 4.7 ms; one class, K = 20: 3.8 ms).
             // A million and more (bench.py --workload forest) fill it per class, and the per-problem choice wins again (35.5 vs 37.7 ms).
             const uint32_t forced_k = nw < 400000u ? 20u : 0u;
-            if (!rc) { lk.unlock(); rc = vgk_pack_windows_impl(ctx, forest->graph, d_seq, seq_bytes, d_win, nw, ops_per_problem, &b, true, forced_k); lk.lock(); }
+            if (!rc) { lk.unlock(); rc = vgk_pack_windows_impl(ctx, forest->graph, d_seq, seq_bytes, d_win, nw, ops_per_problem, &b, true, forced_k, nullptr); lk.lock(); }
             be->watch(1); be->sync(); ctx->tail_stage_ms[2] = be->watch_ms();
             wall("windows packed");
             if (!rc) rc = ctx->start_deferred();                                // the extension sets of a VGK_GAPLESS_DEFER call travel under the fills

@@ -504,7 +504,11 @@ int vgk_gssw_run(vgk_batch* b) try {
         // (a resident batch that is run again without a fetch in between: its own last run tells as much as a fetched one)
         if (b->ran && b->ran_spec && !b->spec_observed && b->ctx->be->event_done(b->done)) observe_speculation(b);
         const bool speculate = b->ctx->spec.decide();
-        if (!speculate) { P.spec_fill = 0; P.wave_limit = nullptr; }      // the plain fill with codes over the same arenas (they hold either form)
+        if (!speculate) {                                                  // the plain fill with codes over the same arenas (they hold either form)
+            P.spec_fill = 0; P.wave_limit = nullptr;
+            P.restore_probs = b->probs_displaced ? 1 : 0;                   // (an earlier speculative run moved its missed reads' descriptors to their second wavefronts)
+            b->probs_displaced = false;
+        } else b->probs_displaced = true;
         b->ran_spec = speculate; b->spec_observed = !speculate;
     }
     const int rc = b->ctx->be->run_gssw_on(b->lane, P, b->launches.data(), (uint32_t)b->launches.size(), true, b->done);
@@ -562,7 +566,28 @@ static int fetch_packed_on_device(vgk_batch* b, vgk_result* results, vgk_op* ops
     return VGK_OK;
 }
 
+// an extension batch's results and ops, from the problem's own node numbering to the window's (vgk_gssw_pack_extensions)
+static void translate_extension_results(const vgk_batch* b, vgk_result* results, vgk_op* ops) {
+    parallel_chunks(b->n, [&](uint32_t lo, uint32_t hi, uint32_t) {
+        for (uint32_t i = lo; i < hi; ++i) {
+            vgk_result& r = results[i];
+            if (r.status != VGK_OK) continue;
+            if (b->ext_count[i] == WIN_EXT_DUMMY) { r.score = 0; r.n_ops = 0; r.end_node = r.end_offset = r.end_read = -1; r.first_offset = 0; continue; }
+            const uint32_t* nodes = b->ext_nodes.data() + b->ext_off[i]; const uint32_t cnt = b->ext_count[i];
+            if (r.end_node >= 0 && (uint32_t)r.end_node < cnt) r.end_node = (int32_t)nodes[r.end_node];
+            if (ops) for (uint32_t k = 0; k < r.n_ops; ++k) { vgk_op& o = ops[r.ops_begin + k]; if (o.node < cnt) o.node = nodes[o.node]; }
+        }
+    });
+}
+
+static int gssw_fetch_impl(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written);
 int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) try {
+    const int rc = gssw_fetch_impl(b, results, ops, ops_cap, ops_written);
+    if ((rc == VGK_OK || rc == VGK_EOPS) && b && !b->ext_count.empty()) translate_extension_results(b, results, ops);
+    return rc;
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
+
+static int gssw_fetch_impl(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written) {
     if (!b || !results) return VGK_EINVAL;
     if (!b->ran) { int rc = vgk_gssw_run(b); if (rc) return rc; }
     // wait for THIS batch's kernels (its own event; polling, outside blocking runtime calls and outside the context lock); the
@@ -618,7 +643,7 @@ int vgk_gssw_fetch(vgk_batch* b, vgk_result* results, vgk_op* ops, size_t ops_ca
     b->alg_bytes = b->in_bytes + alg;
     if (ops_written) *ops_written = w;
     return VGK_OK;
-} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
+}
 
 // Rough HBM footprint of one problem (dominated by the 4-bit traceback codes) — used to cut oversize calls into
 // sub-batches that fit the device (288 GB on MI355X holds ~8M of the 150 bp x 400 bp problems at once).

@@ -92,7 +92,13 @@ int vgk_graph_create(vgk_ctx* ctx, const vgk_graph* graph, vgk_dgraph** out) try
         dst = p;
         return bytes ? be->upload(p, src, bytes) : VGK_OK;
     };
-    const void *d_col = nullptr, *d_info = nullptr, *d_po = nullptr, *d_pi = nullptr, *d_slot = nullptr;
+    // successors (ascending per node: the order edges come in when a caller builds the subgraph node by node), for leftward extension windows
+    std::vector<uint32_t> so((size_t)n + 1, 0), si(g.pred_off[n] - g.pred_off[0]);
+    for (uint32_t v = 0; v < n; ++v) for (uint32_t k = g.pred_off[v]; k < g.pred_off[v + 1]; ++k) ++so[g.pred_idx[k] + 1];
+    for (uint32_t v = 0; v < n; ++v) so[v + 1] += so[v];
+    { std::vector<uint32_t> at(so.begin(), so.end() - 1);
+      for (uint32_t v = 0; v < n; ++v) for (uint32_t k = g.pred_off[v]; k < g.pred_off[v + 1]; ++k) si[at[g.pred_idx[k]]++] = v; }
+    const void *d_col = nullptr, *d_info = nullptr, *d_po = nullptr, *d_pi = nullptr, *d_slot = nullptr, *d_so = nullptr, *d_si = nullptr;
     const size_t n_edges = g.pred_off[n] - g.pred_off[0];
     std::vector<uint32_t> po((size_t)n + 1);
     for (uint32_t v = 0; v <= n; ++v) po[v] = g.pred_off[v] - g.pred_off[0];
@@ -101,10 +107,13 @@ int vgk_graph_create(vgk_ctx* ctx, const vgk_graph* graph, vgk_dgraph** out) try
     if (!rc) rc = put(po.data(), po.size() * 4, d_po);
     if (!rc) rc = put(n_edges ? g.pred_idx + g.pred_off[0] : nullptr, n_edges * 4, d_pi);
     if (!rc) rc = put(slot.data(), slot.size() * 4, d_slot);
+    if (!rc) rc = put(so.data(), so.size() * 4, d_so);
+    if (!rc) rc = put(si.empty() ? nullptr : si.data(), si.size() * 4, d_si);
     if (!rc) rc = be->sync();         // the host vectors go away
     if (rc) { for (void* p : dg->dev) be->release(p); return rc; }
     dg->g.col = (const uint32_t*)d_col; dg->g.info = (const uint8_t*)d_info; dg->g.pred_off = (const uint32_t*)d_po;
     dg->g.pred_idx = (const uint32_t*)d_pi; dg->g.slot = (const uint32_t*)d_slot; dg->g.n_nodes = n; dg->g.n_cols = (uint32_t)cols;
+    dg->g.succ_off = (const uint32_t*)d_so; dg->g.succ_idx = (const uint32_t*)d_si;
     *out = dg.release();
     return VGK_OK;
 } catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
@@ -122,9 +131,11 @@ void vgk_graph_destroy(vgk_dgraph* dg) {
 
 // `on_device`: reads and problems are device arrays already (vgk_tail_stage builds them there) and the caller has waited for the
 // kernels that wrote them; nothing is staged.
+// `extensions` (nullable, host array, never with on_device): the problems are EXTENSION windows (gssw_pack_device.hpp WinExt; vgk_gssw_pack_extensions)
 int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
-                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out, bool on_device, uint32_t forced_k) try {
-    if (!ctx || !dg || dg->ctx != ctx || !out || (!problems && n) || (!reads && reads_bytes)) return VGK_EINVAL;
+                          const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out, bool on_device, uint32_t forced_k,
+                          const vgk::WinExt* extensions) try {
+    if (!ctx || !dg || dg->ctx != ctx || !out || (!problems && n) || (!reads && reads_bytes) || (extensions && on_device)) return VGK_EINVAL;
     *out = nullptr;
     if (ctx->has_qa) return VGK_EUNSUPPORTED;
     Lap lap;
@@ -152,7 +163,7 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     // does every window keep its tracebacks near a diagonal?  (host-side: the windows are the caller's array; a window's first node has
     // lost its predecessors, the others must not have a far one)
     bool near_chain = false;
-    if (!on_device && !dg->far_prefix.empty()) {
+    if (!on_device && !extensions && !dg->far_prefix.empty()) {
         std::atomic<bool> far{false};
         const std::vector<uint32_t>& fp = dg->far_prefix; const uint32_t gn = dg->g.n_nodes;
         parallel_chunks(n, [&](uint32_t lo, uint32_t hi, uint32_t) {
@@ -175,6 +186,7 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     void* tmp = nullptr; size_t tmp_bytes = be->win_tmp_bytes(n, waves_cap);
     int rc;
     rc = VGK_OK;
+    uint64_t ext_nodes_total = 0;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         W.problems = on_device ? problems : (const vgk_window_problem*)take_temp((uint64_t)n * sizeof(vgk_window_problem));
@@ -188,6 +200,12 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
         tmp = take_temp(tmp_bytes);
         b->lane = (std::getenv("VGAMD_ONE_STREAM") ? 0 : (int)(ctx->batch_seq++ & 1u));
         W.probs = (ProbDesc*)take_keep((uint64_t)std::max<uint32_t>(n, 1u) * sizeof(ProbDesc));
+        if (extensions) {
+            ext_nodes_total = n ? (uint64_t)extensions[n - 1].kept_off + problems[n - 1].n_nodes : 0;
+            W.ext = (const WinExt*)take_temp((uint64_t)std::max<uint32_t>(n, 1u) * sizeof(WinExt));
+            W.kept = (WinKept*)take_temp((ext_nodes_total + 1) * sizeof(WinKept)); W.ext_count = (uint32_t*)take_temp((uint64_t)std::max<uint32_t>(n, 1u) * 4);
+            if (!W.ext || !W.kept || !W.ext_count) rc = VGK_ENOMEM;
+        }
         if (!W.problems || !W.raw_reads || !W.sizes || !W.offs || !W.key || !W.idx || !W.key_sorted || !W.idx_sorted || !W.totals ||
             !W.bucket_first || !W.buckets || !W.wave_tb || !tmp || !W.probs) rc = VGK_ENOMEM;
     }
@@ -219,6 +237,7 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
         return VGK_OK;
     };
     if (!on_device && (rc = staged_upload(1, (void*)W.problems, problems, (uint64_t)n * sizeof(vgk_window_problem)))) return fail(rc);
+    if (extensions && (rc = staged_upload(3, (void*)W.ext, extensions, (uint64_t)n * sizeof(WinExt)))) return fail(rc);
     lap("problems staged");
     if ((rc = be->win_stage1(W, tmp, tmp_bytes))) return fail(rc);         // needs the problems only: runs while the reads travel
     if (!on_device && (rc = staged_upload(0, (void*)W.raw_reads, reads, reads_bytes))) return fail(rc);
@@ -228,6 +247,25 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     lap("stage 1 (sizes)");
     if (T.first_bad != ~0ull) return fail(-(int)(T.first_bad & 0xffu));
     for (uint32_t k = 0; k < WIN_COLS; ++k) if (T.tot[k] >= (1ull << 32)) return fail(VGK_ETOOBIG);
+    if (extensions && n) {
+        // which window node every node of an extension problem is: results and ops come back in those terms (vgk_gssw_fetch translates)
+        b->ext_count.resize(n); b->ext_off.resize((size_t)n + 1);
+        std::vector<WinKept> kept((size_t)ext_nodes_total + 1);
+        if ((rc = be->download_side(b->ext_count.data(), W.ext_count, (size_t)n * 4))) return fail(rc);
+        if ((rc = be->download_side(kept.data(), W.kept, (size_t)ext_nodes_total * sizeof(WinKept)))) return fail(rc);
+        uint64_t at = 0;
+        for (uint32_t i = 0; i < n; ++i) { b->ext_off[i] = (uint32_t)at; at += (b->ext_count[i] == WIN_EXT_DUMMY) ? 0u : b->ext_count[i]; }
+        b->ext_off[n] = (uint32_t)at;
+        b->ext_nodes.resize((size_t)at);
+        parallel_chunks(n, [&](uint32_t lo, uint32_t hi, uint32_t) {
+            for (uint32_t i = lo; i < hi; ++i) {
+                const uint32_t cnt = b->ext_count[i] == WIN_EXT_DUMMY ? 0u : b->ext_count[i];
+                const WinKept* k = kept.data() + extensions[i].kept_off;
+                for (uint32_t j = 0; j < cnt; ++j) b->ext_nodes[b->ext_off[i] + j] = k[j].node - problems[i].first_node;
+            }
+        });
+        lap("extension nodes");
+    }
     b->want_tb = T.want_tb != 0; b->cells = T.cells; b->tb_cells = T.tb_cells; b->in_bytes = T.in_bytes;
     W.want_tb = b->want_tb ? 1 : 0;
     uint8_t* colinfo; uint8_t* rd; NodeRec* nodes; uint32_t* preds; WaveDesc* waves; uint32_t* order;
@@ -292,7 +330,25 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
 
 int vgk_gssw_pack_windows(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
                           const vgk_window_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out) try {
-    return vgk_pack_windows_impl(ctx, dg, reads, reads_bytes, problems, n, ops_per_problem, out, false, 0);
+    return vgk_pack_windows_impl(ctx, dg, reads, reads_bytes, problems, n, ops_per_problem, out, false, 0, nullptr);
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
+
+int vgk_gssw_pack_extensions(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads, size_t reads_bytes,
+                             const vgk_extension_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out) try {
+    if (!ctx || !dg || dg->ctx != ctx || !out || (!problems && n) || (!reads && reads_bytes)) return VGK_EINVAL;
+    if (!dg->g.succ_off) return VGK_EUNSUPPORTED;                       // (a graph made on the device: tail forests are not extended from inside)
+    // the two halves the packer reads: the window as for vgk_gssw_pack_windows, the start beside it; kept_off = a prefix sum over the windows' nodes
+    std::vector<vgk_window_problem> win(n); std::vector<WinExt> ext(n);
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const vgk_extension_problem& p = problems[i];
+        vgk_window_problem& w = win[i]; WinExt& x = ext[i];
+        w.read_off = p.read_off; w.read_len = p.read_len; w.flags = p.flags; w.first_node = p.first_node; w.n_nodes = p.n_nodes; w.max_gap_length = p.max_gap_length; w.reserved = 0;
+        x.start_node = p.start_node; x.start_offset = p.start_offset; x.query_offset = p.query_offset; x.leftward = p.leftward ? 1u : 0u; x.kept_off = (uint32_t)at; x.pad = 0;
+        at += p.n_nodes;
+        if (at >= (1ull << 32) - 16) return VGK_ETOOBIG;
+    }
+    return vgk_pack_windows_impl(ctx, dg, reads, reads_bytes, win.data(), n, ops_per_problem, out, false, 0, ext.data());
 } catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
 }  // extern "C"
