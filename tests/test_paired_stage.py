@@ -21,15 +21,27 @@ def emu_lib():
     return EMU_LIB
 
 
-def run(lib, wl, device):
+def run(lib, wl, device, resident=False):
     eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=lib)
     graph = (wl.node_len, wl.seq)
     index = eng.haplo_index(graph, wl.threads); mindex = eng.minimizer_index(graph, wl.threads)
     aligner = pipeline.HostAlignerHandle(lib)
     olen = np.repeat(wl.node_len, 2)
-    out = pipeline.paired_stage(eng, index, mindex, wl, aligner, oriented_len=olen, device=device)
+    rg = aligner.rescue_graph(wl) if resident else None
+    out = pipeline.paired_stage(eng, index, mindex, wl, aligner, oriented_len=olen, device=device, resident=rg, want_ops=True)
+    if rg is not None:
+        rg.close()
     aligner.close()
     return out
+
+
+def same_rescues(got, want, what):
+    assert (got["rescued"] == want["rescued"]).all() and (got["requests"] == want["requests"]).all()
+    bad = np.nonzero((got["rescue"] != want["rescue"]).any(axis=1))[0]
+    assert len(bad) == 0, "%s: rescue %s: %s vs %s (request %s)" % (what, bad[:5], got["rescue"][bad[:5]], want["rescue"][bad[:5]], got["requests"][bad[:5]])
+    assert (got["rescue_ops_begin"] == want["rescue_ops_begin"]).all(), what
+    assert (got["rescue_ops"].view(np.uint64) == want["rescue_ops"].view(np.uint64)).all(), what
+    assert (got["pair_score"] == want["pair_score"]).all()
 
 
 def check(lib, n_pairs, device):
@@ -37,9 +49,15 @@ def check(lib, n_pairs, device):
     got = run(lib, wl, device)
     want = run(ORACLE_LIB, wl, False)
     assert (got["read_score"] == want["read_score"]).all()
-    assert (got["rescued"] == want["rescued"]).all() and (got["requests"] == want["requests"]).all()
-    assert (got["rescue"] == want["rescue"]).all()
-    assert (got["pair_score"] == want["pair_score"]).all()
+    same_rescues(got, want, "reference-shaped path on the engine vs on the oracle")
+    # the rescue half on the RESIDENT graph (rescue_resident.cpp: extension windows, flat fix-ups): every rescued alignment, op by op — on the
+    # engine under test and over the oracle's own extension windows
+    res_got = run(lib, wl, device, resident=True)
+    same_rescues(res_got, want, "resident path on the engine vs the reference-shaped path on the oracle")
+    same_rescues(run(ORACLE_LIB, wl, False, resident=True), want, "resident path on the oracle vs the reference-shaped path on the oracle")
+    c = res_got["rescue_counts"]
+    assert c["first_pass"] + c["scans"] > 0 and c["second_pass"] > 0
+    assert len(got["rescue_ops"]) > 3 * len(got["rescued"]) * 0.5
     # rescue does its job: most pairs with a hard second mate are rescued, to a positive score, near where the mate came from
     hard = set(int(i) for i in wl.truth["hard"])
     rescued_pairs = set(int(r) // 2 for r in got["rescued"])

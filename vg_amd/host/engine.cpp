@@ -50,6 +50,9 @@ std::shared_ptr<EngineApi> load_engine(const std::string& path) {
     bind(dl, "vgk_wfa_extend", api->wfa_extend);
     bind(dl, "vgk_xdrop_band_align", api->xdrop_band_align);
     bind(dl, "vgk_gssw_pack_windows", api->gssw_pack_windows);
+    bind(dl, "vgk_gssw_pack_extensions", api->gssw_pack_extensions);
+    bind(dl, "vgk_graph_create", api->graph_create);
+    bind(dl, "vgk_graph_destroy", api->graph_destroy);
     bind(dl, "vgk_tail_forest", api->tail_forest);
     bind(dl, "vgk_forest_fetch", api->forest_fetch);
     bind(dl, "vgk_forest_graph", api->forest_graph);

@@ -33,6 +33,9 @@ struct EngineApi {
     decltype(&vgk_wfa_extend) wfa_extend = nullptr;
     decltype(&vgk_xdrop_band_align) xdrop_band_align = nullptr;
     decltype(&vgk_gssw_pack_windows) gssw_pack_windows = nullptr;
+    decltype(&vgk_gssw_pack_extensions) gssw_pack_extensions = nullptr;
+    decltype(&vgk_graph_create) graph_create = nullptr;
+    decltype(&vgk_graph_destroy) graph_destroy = nullptr;
     decltype(&vgk_tail_forest) tail_forest = nullptr;
     decltype(&vgk_forest_fetch) forest_fetch = nullptr;
     decltype(&vgk_forest_graph) forest_graph = nullptr;

@@ -17,6 +17,7 @@
 #include "extension_scoring.hpp"
 #include "aligner_client.hpp"
 #include "rescue_stage.hpp"
+#include "rescue_resident.hpp"
 #include <sstream>
 
 using namespace vgamd;
@@ -210,6 +211,79 @@ int vgh_rescue_stage(vgh_aligner* a, uint32_t n_nodes, const uint32_t* node_len,
         for (int k = 0; k < n; ++k) {
             const RescueResult& r = res[(size_t)k]; int64_t* o = out + 6 * (size_t)k;
             o[0] = r.score; o[1] = r.status; o[2] = r.first_node; o[3] = r.first_offset; o[4] = r.n_mappings; o[5] = r.aligned_read_bases;
+        }
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// the same with the final alignments as op runs: ops_begin[n + 1], ops up to ops_cap (*ops_written = what there is; -2 when that does not fit)
+int vgh_rescue_stage_ops(vgh_aligner* a, uint32_t n_nodes, const uint32_t* node_len, const uint64_t* seq_off, const char* seq, const uint32_t* succ_off, const uint32_t* succ,
+                         int n, const char* reads, const uint64_t* read_off, const int64_t* requests, uint64_t max_dozeu_cells, int host_threads, int64_t* out,
+                         uint64_t* ops_begin, vgk_op* ops, uint64_t ops_cap, uint64_t* ops_written) {
+    try {
+        RescueGraph G; G.n_nodes = n_nodes; G.node_len = node_len; G.seq_off = seq_off; G.seq = seq; G.succ_off = succ_off; G.succ = succ;
+        std::vector<RescueRequest> rq((size_t)n);
+        for (int k = 0; k < n; ++k) {
+            RescueRequest& r = rq[(size_t)k]; const int64_t* q = requests + 6 * (size_t)k;
+            r.read = reads + read_off[k]; r.read_len = (uint32_t)(read_off[k + 1] - read_off[k]);
+            r.node_lo = (uint32_t)q[0]; r.node_hi = (uint32_t)q[1]; r.seed_begin = q[2]; r.seed_end = q[3]; r.seed_node = q[4]; r.seed_offset = q[5];
+        }
+        std::vector<RescueResult> res; std::vector<vgk_op> o; std::vector<uint64_t> ob;
+        run_rescue_stage(*a->a, G, rq, max_dozeu_cells ? max_dozeu_cells : default_max_dozeu_cells, (unsigned)std::max(host_threads, 0), res, &o, &ob);
+        for (int k = 0; k < n; ++k) {
+            const RescueResult& r = res[(size_t)k]; int64_t* q = out + 6 * (size_t)k;
+            q[0] = r.score; q[1] = r.status; q[2] = r.first_node; q[3] = r.first_offset; q[4] = r.n_mappings; q[5] = r.aligned_read_bases;
+        }
+        if (ops_written) *ops_written = o.size();
+        if (ops_begin) std::copy(ob.begin(), ob.end(), ops_begin);
+        if (o.size() > ops_cap) { g_last_error = "vgh_rescue_stage_ops: op array too small"; return -2; }
+        if (ops) std::copy(o.begin(), o.end(), ops);
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// ---- the same stage on the resident graph (rescue_resident.hpp): the graph goes to the aligner's engine context once, a batch of requests is
+// flat arrays: requests 6 numbers each as above, reads flat with offsets
+struct vgh_rescue_graph { std::unique_ptr<ResidentRescueGraph> g; std::vector<uint32_t> node_len, pred_off, pred_idx; std::vector<char> seq; };
+vgh_rescue_graph* vgh_rescue_graph_create(vgh_aligner* a, uint32_t n_nodes, const uint32_t* node_len, const char* seq, const uint32_t* pred_off, const uint32_t* pred_idx) {
+    try {
+        auto* h = new vgh_rescue_graph();
+        std::unique_ptr<vgh_rescue_graph> hold(h);
+        h->node_len.assign(node_len, node_len + n_nodes); h->pred_off.assign(pred_off, pred_off + n_nodes + 1);
+        h->pred_idx.assign(pred_idx, pred_idx + pred_off[n_nodes]);
+        uint64_t bases = 0; for (uint32_t v = 0; v < n_nodes; ++v) bases += node_len[v];
+        h->seq.assign(seq, seq + bases);
+        h->g = std::make_unique<ResidentRescueGraph>(*a->a, n_nodes, h->node_len.data(), h->seq.data(), h->pred_off.data(), h->pred_idx.empty() ? nullptr : h->pred_idx.data());
+        return hold.release();
+    } catch (std::exception& e) { g_last_error = e.what(); return nullptr; }
+}
+void vgh_rescue_graph_destroy(vgh_rescue_graph* g) { delete g; }
+// laps (nullable): classify, first pass, second pass, alignments + fix-ups, full-DP fallback (ms); counts (nullable): first-pass extensions, scans, second-pass extensions, fallbacks
+int vgh_rescue_stage_resident(vgh_aligner* a, vgh_rescue_graph* g, int n, const char* reads, uint64_t reads_bytes, const uint64_t* read_off, const int64_t* requests,
+                              uint64_t max_dozeu_cells, int host_threads, int64_t* out, uint64_t* ops_begin, vgk_op* ops, uint64_t ops_cap, uint64_t* ops_written,
+                              double* laps, uint64_t* counts) {
+    try {
+        std::vector<RescueRequestFlat> rq((size_t)n);
+        for (int k = 0; k < n; ++k) {
+            RescueRequestFlat& r = rq[(size_t)k]; const int64_t* q = requests + 6 * (size_t)k;
+            r.read_off = read_off[k]; r.read_len = (uint32_t)(read_off[k + 1] - read_off[k]);
+            r.node_lo = (uint32_t)q[0]; r.node_hi = (uint32_t)q[1]; r.seed_begin = q[2]; r.seed_end = q[3]; r.seed_node = q[4]; r.seed_offset = q[5];
+        }
+        std::vector<RescueResult> res; std::vector<vgk_op> o; std::vector<uint64_t> ob; RescueTiming tm;
+        const bool want_ops = ops_begin != nullptr;
+        run_rescue_stage_resident(*a->a, *g->g, reads, (size_t)reads_bytes, rq, max_dozeu_cells ? max_dozeu_cells : default_max_dozeu_cells, (unsigned)std::max(host_threads, 0),
+                                  res, want_ops ? &o : nullptr, want_ops ? &ob : nullptr, &tm);
+        for (int k = 0; k < n; ++k) {
+            const RescueResult& r = res[(size_t)k]; int64_t* q = out + 6 * (size_t)k;
+            q[0] = r.score; q[1] = r.status; q[2] = r.first_node; q[3] = r.first_offset; q[4] = r.n_mappings; q[5] = r.aligned_read_bases;
+        }
+        if (laps) { laps[0] = tm.classify_ms; laps[1] = tm.first_pass_ms; laps[2] = tm.second_pass_ms; laps[3] = tm.finish_ms; laps[4] = tm.fallback_ms; }
+        if (counts) { counts[0] = tm.first_pass; counts[1] = tm.scans; counts[2] = tm.second_pass; counts[3] = tm.fallbacks; }
+        if (ops_written) *ops_written = o.size();
+        if (want_ops) {
+            std::copy(ob.begin(), ob.end(), ops_begin);
+            if (o.size() > ops_cap) { g_last_error = "vgh_rescue_stage_resident: op array too small"; return -2; }
+            if (ops) std::copy(o.begin(), o.end(), ops);
         }
         return 0;
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }

@@ -41,9 +41,10 @@ template <class F> void on_threads(size_t n, unsigned threads, F body) {
 }  // namespace
 
 void run_rescue_stage(const Aligner& aligner, const RescueGraph& G, const std::vector<RescueRequest>& requests, uint64_t max_cells,
-                      unsigned host_threads, std::vector<RescueResult>& results) {
+                      unsigned host_threads, std::vector<RescueResult>& results, std::vector<vgk_op>* out_ops, std::vector<uint64_t>* out_ops_begin) {
     const size_t n = requests.size();
     results.assign(n, RescueResult{});
+    std::vector<std::vector<vgk_op>> op_runs(out_ops && out_ops_begin ? n : 0);
     auto lap_t0 = std::chrono::steady_clock::now(); const bool lap_on = std::getenv("VGAMD_TIMING") != nullptr;
     auto lap = [&](const char* what) { if (!lap_on) return; const auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "[rescue_stage] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - lap_t0).count()); lap_t0 = t; };
     std::deque<HashGraph> graphs(n);
@@ -91,9 +92,24 @@ void run_rescue_stage(const Aligner& aligner, const RescueGraph& G, const std::v
         uint32_t to = 0;
         for (const Mapping& m : aln.path.mapping) for (const Edit& e : m.edit) if (e.from_length) to += (uint32_t)e.to_length;
         out.aligned_read_bases = to;
+        if (!op_runs.empty()) for (const Mapping& m : aln.path.mapping) {
+            int prev = -1;
+            for (const Edit& e : m.edit) {
+                const int op = (edit_is_match(e) || edit_is_sub(e)) ? VGK_OP_M : edit_is_deletion(e) ? VGK_OP_D : VGK_OP_I;
+                if (op == VGK_OP_M && prev == VGK_OP_M) op_runs[k].back().len = (uint16_t)(op_runs[k].back().len + e.to_length);
+                else { vgk_op o{}; o.node = (uint32_t)(m.position.node_id - 1); o.op = (uint8_t)op; o.len = (uint16_t)(op == VGK_OP_D ? e.from_length : e.to_length); op_runs[k].push_back(o); }
+                prev = op;
+            }
+        }
         graphs[k] = HashGraph(); aln = Alignment(); todo[a] = Aligner::XdropRequest();      // released where they were built: on the threads
     });
     lap("fix-ups");
+    if (!op_runs.empty()) {
+        out_ops_begin->assign(n + 1, 0);
+        for (size_t k = 0; k < n; ++k) (*out_ops_begin)[k + 1] = (*out_ops_begin)[k] + op_runs[k].size();
+        out_ops->clear(); out_ops->reserve((size_t)(*out_ops_begin)[n]);
+        for (size_t k = 0; k < n; ++k) out_ops->insert(out_ops->end(), op_runs[k].begin(), op_runs[k].end());
+    }
 }
 
 }  // namespace vgamd

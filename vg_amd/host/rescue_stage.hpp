@@ -29,8 +29,10 @@ struct RescueResult {
 };
 constexpr uint64_t default_max_dozeu_cells = (uint64_t)(1.5 * 1024 * 1024);      // src/minimizer_mapper.hpp:471
 
-// host_threads 0 = as many as the machine grants
+// host_threads 0 = as many as the machine grants.  ops / ops_begin (nullable): the final alignments as (node index, VGK_OP_M / I / D, length) runs,
+// mapping by mapping — a stretch of match and substitution edits is one M run, every deletion and insertion edit a run of its own; request k's
+// are ops[ops_begin[k] .. ops_begin[k + 1]) (what rescue_resident.hpp's path reports in the same form: the two are held against each other)
 void run_rescue_stage(const Aligner& aligner, const RescueGraph& graph, const std::vector<RescueRequest>& requests, uint64_t max_dozeu_cells,
-                      unsigned host_threads, std::vector<RescueResult>& results);
+                      unsigned host_threads, std::vector<RescueResult>& results, std::vector<vgk_op>* ops = nullptr, std::vector<uint64_t>* ops_begin = nullptr);
 
 }  // namespace vgamd

@@ -455,7 +455,7 @@ class ChainStage:
 
 
 # ---- a paired-end slice: both mates through the stage, the mate without a full-length extension rescued from the other's position ------------
-def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device=True, rescue_stdevs=4.0, timing=None, host_threads=0):
+def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device=True, rescue_stdevs=4.0, timing=None, host_threads=0, resident=None, want_ops=False):
     """giraffe's paired-end shape on one batch of pairs (PairedWorkload): (1) every read through seeding, gapless extension and the tails
     (align_stage_device, or align_stage over the oracle when device = False); (2) for a pair with exactly one mate whose extension set is
     full-length, the other mate is RESCUED: the nodes at the fragment's distance from the mapped mate — here a run of nodes found by
@@ -463,6 +463,10 @@ def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device
     extensions inside them as dozeu's seed, Aligner::align_xdrop + fix_dozeu_score + fix_dozeu_end_deletions for all such mates at
     once (vg_amd/host/rescue_stage.cpp = MinimizerMapper::attempt_rescue, src/minimizer_mapper.cpp:3264-3440); (3) a pair's score = the
     mapped mate's + the better of the rescued alignment and what the stage had for that mate.
+    resident: a RescueGraphHandle (host_aligner.rescue_graph(wl)) — the rescue half then runs on the RESIDENT graph (vg_amd/host/rescue_resident.cpp:
+    every X-drop pass an extension window whose sub-DAG the device derives, the fix-ups over flat arrays); without it the reference-shaped path
+    (rescue_stage.cpp: one HashGraph and one Alignment per mate) — the form the checker runs over the oracle.  want_ops: also the rescued
+    alignments as (node, op, length) runs (`rescue_ops`, `rescue_ops_begin`).
     -> dict(read_score, rescued (indices of rescued reads), rescue (RESCUE_DT-like int64 [k, 6]), pair_score)"""
     import time
     t0 = time.perf_counter()
@@ -540,22 +544,43 @@ def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device
                 req[k, 4] = np.where(rc, last_o[take] >> 1, first_o[take] >> 1); req[k, 5] = np.where(rc, lastlen - end_in_last, off)
     t2 = time.perf_counter()
     outv = np.zeros((len(pairs), 6), dtype=np.int64)
+    ops_begin = np.zeros(len(pairs) + 1, dtype=np.uint64); ops = np.zeros(0, dtype=capi.OP_DT)
+    laps = np.zeros(5, dtype=np.float64); counts = np.zeros(4, dtype=np.uint64)
     if len(pairs):
         h = _host_lib()
-        h.vgh_rescue_stage.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
         flat = np.ascontiguousarray(rd).ravel(); roff = (np.arange(len(pairs) + 1, dtype=np.uint64) * L)
-        node_len = np.ascontiguousarray(g.node_len, dtype=np.uint32); seq_off = np.ascontiguousarray(g.col[:-1], dtype=np.uint64); seq = np.ascontiguousarray(g.seq)
-        rc = h.vgh_rescue_stage(host_aligner.ptr, g.n_nodes, node_len.ctypes.data, seq_off.ctypes.data, seq.ctypes.data, wl.succ_off.ctypes.data, wl.succ.ctypes.data,
-                                len(pairs), flat.ctypes.data, roff.ctypes.data, req.ctypes.data, 0, host_threads, outv.ctypes.data)
+        ops_cap = len(pairs) * 64 if (want_ops or resident is None and want_ops) else 0
+        ops = np.zeros(max(ops_cap, 1), dtype=capi.OP_DT); written = ctypes.c_uint64()
+        if resident is not None:
+            h.vgh_rescue_stage_resident.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int,
+                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            rc = h.vgh_rescue_stage_resident(host_aligner.ptr, resident.ptr, len(pairs), flat.ctypes.data, flat.size, roff.ctypes.data, req.ctypes.data, 0, host_threads, outv.ctypes.data,
+                                             ops_begin.ctypes.data if want_ops else None, ops.ctypes.data if want_ops else None, ops_cap, ctypes.byref(written), laps.ctypes.data, counts.ctypes.data)
+        else:
+            node_len = np.ascontiguousarray(g.node_len, dtype=np.uint32); seq_off = np.ascontiguousarray(g.col[:-1], dtype=np.uint64); seq = np.ascontiguousarray(g.seq)
+            args = [host_aligner.ptr, g.n_nodes, node_len.ctypes.data, seq_off.ctypes.data, seq.ctypes.data, wl.succ_off.ctypes.data, wl.succ.ctypes.data,
+                    len(pairs), flat.ctypes.data, roff.ctypes.data, req.ctypes.data, 0, host_threads, outv.ctypes.data]
+            base_types = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
+            if want_ops:
+                h.vgh_rescue_stage_ops.argtypes = base_types + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+                rc = h.vgh_rescue_stage_ops(*args, ops_begin.ctypes.data, ops.ctypes.data, ops_cap, ctypes.byref(written))
+            else:
+                h.vgh_rescue_stage.argtypes = base_types
+                rc = h.vgh_rescue_stage(*args)
         if rc != 0:
             raise RuntimeError(h.vgh_last_error().decode())
+        ops = ops[:int(written.value)] if want_ops else ops[:0]
     t3 = time.perf_counter()
     pair_score = read_score[0::2] + read_score[1::2]
     pair_score[pairs] = read_score[mapped] + np.maximum(outv[:, 0], read_score[lost])
     if timing is not None:
         for k, v in (("stage (seeding, extension, tails)", t1 - t0), ("rescue requests (host)", t2 - t1), ("rescue stage (subgraphs, X-drop passes, fix-ups)", t3 - t2)):
             timing[k] = timing.get(k, 0.0) + v
-    return dict(read_score=read_score, rescued=lost, mapped=mapped, requests=req, rescue=outv, pair_score=pair_score, res=res)
+        if resident is not None:
+            for k, v in zip(("rescue: classify (host)", "rescue: first pass (extension windows + scans)", "rescue: second pass (traced extension windows)", "rescue: alignments + fix-ups (host)", "rescue: full-DP fallback"), laps):
+                timing[k] = timing.get(k, 0.0) + v * 1e-3
+    return dict(read_score=read_score, rescued=lost, mapped=mapped, requests=req, rescue=outv, pair_score=pair_score, res=res, rescue_ops=ops, rescue_ops_begin=ops_begin,
+                rescue_counts=dict(zip(("first_pass", "scans", "second_pass", "fallbacks"), (int(x) for x in counts))))
 
 
 class HostAlignerHandle:
@@ -570,8 +595,40 @@ class HostAlignerHandle:
         if not self.ptr:
             raise RuntimeError("vgh_aligner_create: " + (h.vgh_last_error() or b"?").decode())
 
+    def rescue_graph(self, wl):
+        """the workload's graph resident in this aligner's engine context, for paired_stage(resident = ...)"""
+        return RescueGraphHandle(self, wl)
+
     def close(self):
         if getattr(self, "ptr", None):
             self.h.vgh_aligner_destroy(self.ptr); self.ptr = None
+
+    __del__ = close
+
+
+class RescueGraphHandle:
+    """vgh_rescue_graph: the graph of a paired workload in the host aligner's engine context (vgk_graph_create) — rescue_resident.hpp"""
+
+    def __init__(self, aligner, wl):
+        g = wl.graph
+        h = aligner.h
+        h.vgh_rescue_graph_create.restype = ctypes.c_void_p
+        h.vgh_rescue_graph_create.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        h.vgh_rescue_graph_destroy.argtypes = [ctypes.c_void_p]
+        node_len = np.ascontiguousarray(g.node_len, dtype=np.uint32); seq = np.ascontiguousarray(g.seq)
+        pred_off = np.ascontiguousarray(g.pred_off, dtype=np.uint32); pred_idx = np.ascontiguousarray(g.pred_idx, dtype=np.uint32)
+        # predecessor lists must ascend (the order edges enter a subgraph built node by node, which the reference-shaped path does)
+        po = pred_off.astype(np.int64); inner = np.ones(len(pred_idx), dtype=bool); inner[po[:-1][np.diff(po) > 0]] = False
+        assert (np.diff(pred_idx.astype(np.int64))[inner[1:]] > 0).all() if len(pred_idx) > 1 else True, "predecessor lists must be ascending"
+        self.aligner = aligner
+        self.ptr = h.vgh_rescue_graph_create(aligner.ptr, g.n_nodes, node_len.ctypes.data, seq.ctypes.data, pred_off.ctypes.data, pred_idx.ctypes.data)
+        if not self.ptr:
+            raise RuntimeError("vgh_rescue_graph_create: " + (h.vgh_last_error() or b"?").decode())
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            if getattr(self.aligner, "ptr", None):
+                self.aligner.h.vgh_rescue_graph_destroy(self.ptr)
+            self.ptr = None
 
     __del__ = close
