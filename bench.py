@@ -407,7 +407,9 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
                          # a result per link; against the launch's own device time (vgk_wfa_last_ms as the stage reports it)
                          **(lambda alg, ms: {"achieved": alg / (ms * 1e-3) / 1e9 if ms else None, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms else None,
                                              "alg_bytes_per_launch": alg, "avg_launch_ms": ms})(float(2 * wl.read_bases + 72 * wl.n), float(out["wfa_kernel_ms"] or 0.0)),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None},
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "traffic": PMC_BYTES_PER_UNIT["longread"] * n if "longread" in PMC_BYTES_PER_UNIT else None,
+                         "traffic_source": traffic_source("longread") if "longread" in PMC_BYTES_PER_UNIT else None},
             "cpu_baseline": cpu, "parity": parity,
             "problems_failed": int(out["stats"]["failed"] + out["stats"]["no_graph"] + out["stats"]["too_big"])}))
     stage.close()
@@ -434,6 +436,9 @@ def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
     eng.host_register(wl.reads)
     aligner = pipeline.HostAlignerHandle(os.environ.get("VGAMD_ENGINE_LIB"), device=eng.device)
     threads = int(os.environ.get("VGAMD_HOST_THREADS", "0")) or min(shard.usable_cpus(), 48)
+    # the rescue half runs on the graph RESIDENT in the host aligner's engine context (vg_amd/host/rescue_resident.cpp); VGAMD_PAIRED_PER_GRAPH=1: round 4's
+    # form, one HashGraph per mate on host threads (vg_amd/host/rescue_stage.cpp) — kept as the reference-shaped checker
+    rg = None if os.environ.get("VGAMD_PAIRED_PER_GRAPH") else aligner.rescue_graph(wl)
 
     def barrier():
         _device_sync(torch)
@@ -442,14 +447,18 @@ def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
         _device_sync(torch)
 
     for _ in range(max(1, args.warmup)):
-        pipeline.paired_stage(eng, index, mindex, wl, aligner, host_threads=threads)
+        pipeline.paired_stage(eng, index, mindex, wl, aligner, host_threads=threads, resident=rg)
     barrier()
     timing = {}
+    rescue_kernel_ms = rescue_alg = rescue_cells = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = pipeline.paired_stage(eng, index, mindex, wl, aligner, timing=timing, host_threads=threads)
+        out = pipeline.paired_stage(eng, index, mindex, wl, aligner, timing=timing, host_threads=threads, resident=rg)
+        rescue_kernel_ms += out["rescue_counts"].get("kernel_ms", 0.0); rescue_alg += out["rescue_counts"].get("alg_bytes", 0); rescue_cells += out["rescue_counts"].get("cells", 0)
     barrier()
     elapsed = time.perf_counter() - t0
+    gapless_ms = eng.gapless_last_ms()
+    out = pipeline.paired_stage(eng, index, mindex, wl, aligner, host_threads=threads, resident=rg, want_ops=True)      # (once more, untimed, with the rescued alignments' ops for the parity leg)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -459,20 +468,36 @@ def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
         ora_lib = os.path.join(ROOT, "oracle", "libvgoracle.so")
         ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=ora_lib)
         cores = shard.usable_cpus(); ora.lib.vgo_set_threads(cores)
-        k = min(n_pairs, (args.cpu_sample // 2) if args.cpu_sample else 25_000)
+        k = min(n_pairs, (args.cpu_sample // 2) if args.cpu_sample else 100_000)
         sub = wl.subset(k)
         oidx = ora.haplo_index(graph, wl.threads); omi = ora.minimizer_index(graph, wl.threads)
         oal = pipeline.HostAlignerHandle(ora_lib)
         t1 = time.perf_counter()
-        o = pipeline.paired_stage(ora, oidx, omi, sub, oal, oriented_len=np.repeat(wl.node_len, 2), device=False, host_threads=cores)
+        # the checker: the whole stage over the oracle, its rescue half in the REFERENCE-SHAPED form (one HashGraph and one Alignment per mate, Aligner::align_xdrop_many,
+        # fix_dozeu_score, fix_dozeu_end_deletions: vg_amd/host/rescue_stage.cpp) — not the flat path the engine's side ran
+        o = pipeline.paired_stage(ora, oidx, omi, sub, oal, oriented_len=np.repeat(wl.node_len, 2), device=False, host_threads=cores, want_ops=True)
         tc = time.perf_counter() - t1
         same = int((o["pair_score"] == out["pair_score"][:k]).sum())
         n_resc = len(o["rescued"])
-        same_resc = int((o["rescue"] == out["rescue"][:n_resc]).all(axis=1).sum()) if n_resc and (o["rescued"] == out["rescued"][:n_resc]).all() else 0
-        cpu = {"value": 2 * k / tc, "unit": "reads/s", "cores": cores, "kind": "port", "impl": "the same stage over the oracle (vgo_minimizer.c, vgo_gapless.c, vgo_tail.c, vgo_xdrop.c) and the same host shim bound to it",
+        same_resc = same_ops = 0
+        if n_resc and (o["rescued"] == out["rescued"][:n_resc]).all() and (o["requests"] == out["requests"][:n_resc]).all():
+            row_same = (o["rescue"] == out["rescue"][:n_resc]).all(axis=1)
+            ob, gb = o["rescue_ops_begin"].astype(np.int64), out["rescue_ops_begin"][:n_resc + 1].astype(np.int64)
+            if (ob == gb).all():
+                tot = int(ob[-1])
+                op_bad = o["rescue_ops"][:tot].view(np.uint64) != out["rescue_ops"][:tot].view(np.uint64)
+                owner_bad = np.unique(np.searchsorted(ob, np.nonzero(op_bad)[0], side="right") - 1)
+                row_same[owner_bad] = False
+                same_ops = tot - int(op_bad.sum())
+            else:
+                row_same &= np.diff(ob) == np.diff(gb)
+            same_resc = int(row_same.sum())
+        cpu = {"value": 2 * k / tc, "unit": "reads/s", "cores": cores, "kind": "port", "impl": "the same stage over the oracle (vgo_minimizer.c, vgo_gapless.c, vgo_tail.c, vgo_xdrop.c) and the host shim's reference-shaped rescue path bound to it",
                "sample": "the first %d pairs" % k}
         parity = {"checked": k, "identical": same, "rescued_mates_checked": n_resc, "rescued_alignments_identical": same_resc,
-                  "what": "per-pair score (mapped mate + the better of the rescued alignment and the stage's own); per rescued mate score, status, first node and offset, mappings, aligned bases"}
+                  "rescued_alignment_ops": int(o["rescue_ops_begin"][-1]), "rescued_alignment_ops_identical": same_ops,
+                  "what": "per-pair score (mapped mate + the better of the rescued alignment and the stage's own); per rescued mate the request (node range, dozeu's seed), score, status, first node "
+                          "and offset, mappings, aligned bases AND every (node, op, length) run of the final alignment, against the reference-shaped rescue path over the oracle"}
     if rank == 0:
         resc = out["rescue"]
         print(json.dumps({
@@ -482,14 +507,31 @@ def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
             "config": {"workload": "configs[3] slice: variation graph of the chr22-scale construction over a %d bp reference (%d nodes, two haplotypes), %d pairs of 2 x 150 bp per GPU, fragments N(%.0f, %.0f), "
                                    "1 %% substitutions, 8 %% of the second mates with an inserted stretch and 3 %% substitutions; k = 29, w = 11 minimizers; rescue window = fragment mean +- 4 sd by column "
                                    "coordinate (a stand-in for subgraph_in_distance_range: the SnarlDistanceIndex is absent)" % (len(wl.graph.haps[0][0]), len(wl.node_len), n_pairs, wl.mean, wl.sd),
-                       "timed_region": "per step, one batch of pairs from host buffers: vgk_minimizer_seeds -> vgk_gapless_extend_seeded -> vgk_tail_stage for all 2 n reads, then the rescue requests (host, numpy), "
-                                       "then vgh_rescue_stage: subgraphs on host threads, every mate's X-drop passes in Aligner::align_xdrop_many, the fix-ups",
+                       "timed_region": ("per step, one batch of pairs from host buffers: vgk_minimizer_seeds -> vgk_gapless_extend_seeded -> vgk_tail_stage for all 2 n reads, then the request table "
+                                        "(vgh_rescue_requests: chunked host threads over the extension sets), then vgh_rescue_stage_resident: both X-drop passes of every lost mate as extension windows of the "
+                                        "resident graph (vgk_gssw_pack_extensions: sub-DAGs derived on the device), dozeu's scan and the full-DP fallback as plain windows, the fix-ups over flat arrays") if rg is not None else
+                                       ("per step, one batch of pairs from host buffers: the stage for all 2 n reads, the rescue requests (numpy), then vgh_rescue_stage: one HashGraph per mate on host threads, "
+                                        "Aligner::align_xdrop_many, the fix-ups [VGAMD_PAIRED_PER_GRAPH: round 4's form]"),
+                       "rescue_rounds_per_step": {k2: v for k2, v in out["rescue_counts"].items() if k2 in ("first_pass", "scans", "second_pass", "fallbacks")},
                        "pairs_rescued": int(len(out["rescued"])), "rescued_with_positive_score": int((resc[:, 0] > 0).sum()), "refused_by_cell_budget": int((resc[:, 1] == 1).sum()),
                        "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()}, "host_threads": threads,
                        "parallelism": "pair-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
-            "roofline": {"bound": "hbm", "kernel": "the configs[2] stage's kernels + gssw_fill_kernel (X-drop passes of the rescued mates)", "limiter": "host glue of the rescue half (subgraph construction, requests); DESIGN.md §27.7",
-                         "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
+            # the leg's longest kernel family is the stage's gapless search (as in configs[2]); priced the same way: the reads once per seed + outputs
+            "roofline": (lambda alg, ms: {"bound": "hbm", "kernel": "gapless_search_kernel + gapless_rules_kernel (the stage's longest kernels, as in configs[2])", "limiter": "memory latency and divergent issue, not bandwidth",
+                                          "achieved": alg / (ms * 1e-3) / 1e9 if ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms else None,
+                                          "traffic": PMC_BYTES_PER_UNIT["config2"] * 2 * n_pairs if "config2" in PMC_BYTES_PER_UNIT else None,
+                                          "traffic_source": (traffic_source("config2") + " — the same kernels on the same graph construction, per read") if "config2" in PMC_BYTES_PER_UNIT else None,
+                                          "alg_bytes_per_launch": alg, "avg_launch_ms": ms})(
+                float(wl.read_len * 2 * n_pairs * 5 + 60 * len(out["res"]) * 2), gapless_ms),
+            # ... and the rescue half's own kernels: the X-drop fills and tracebacks of the three rounds (extension windows, scans, fallbacks), SURVEY §8(d)'s bytes per problem
+            "roofline_rescue": {"bound": "valu", "kernel": "gssw_fill_kernel + walk kernels over the rescue rounds' batches", "achieved": rescue_alg / (rescue_kernel_ms * 1e-3) / 1e9 if rescue_kernel_ms else None,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rescue_alg / (rescue_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rescue_kernel_ms else None,
+                                "traffic": PMC_BYTES_PER_UNIT["rescue"] * len(out["rescued"]) if "rescue" in PMC_BYTES_PER_UNIT else None,
+                                "alg_bytes_per_step": rescue_alg / args.steps, "kernel_ms_per_step": rescue_kernel_ms / args.steps,
+                                "gcups": rescue_cells / (rescue_kernel_ms * 1e-3) / 1e9 if rescue_kernel_ms else None},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((out["res"]["status"] != 0).sum())}))
+    if rg is not None:
+        rg.close()
     aligner.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -1532,7 +1574,7 @@ SECONDARY = [
     ("banded", ["--reads", "100000", "--steps", "5", "--warmup", "2"], 90),
     ("wfa", ["--reads", "500000", "--steps", "5", "--warmup", "2"], 90),
     ("longread", ["--steps", "3", "--warmup", "1"], 120),
-    ("paired", ["--steps", "3", "--warmup", "1"], 150),
+    ("paired", ["--steps", "3", "--warmup", "1", "--cpu-sample", "200000"], 240),
 ]
 
 

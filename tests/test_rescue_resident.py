@@ -100,7 +100,7 @@ def both_paths(lib, g, reads, read_off, req, max_cells=0, threads=2):
             assert rg, h.vgh_last_error()
             h.vgh_rescue_stage_resident.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int,
                                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-            counts = np.zeros(4, dtype=np.uint64)
+            counts = np.zeros(6, dtype=np.uint64)
             rc = h.vgh_rescue_stage_resident(aligner.ptr, rg, n, reads.ctypes.data, reads.size, read_off.ctypes.data, req.ctypes.data, max_cells, threads, out.ctypes.data,
                                              ops_begin.ctypes.data, ops.ctypes.data, cap, ctypes.byref(written), None, counts.ctypes.data)
             assert rc == 0, h.vgh_last_error()

@@ -31,6 +31,34 @@ import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(d["value"], d["parity"], d["cpu_baseline"]["value"])
 PY
     ;;
+  rescue_tests)   # extension windows, the rescue stage on the resident graph, the paired stage — on HIP
+    timeout 1200 python -m pytest tests/test_extension_windows.py tests/test_rescue_resident.py tests/test_paired_stage.py -m gpu -x -q > "$out/pytest_rescue.log" 2>&1
+    echo "rc=$?" >> "$out/pytest_rescue.log"; tail -5 "$out/pytest_rescue.log" ;;
+  paired)         # the configs[3] slice: the rescue half on the resident graph, and round 4's per-graph form beside it; host threads 16 and 2
+    for th in 0 2; do
+      VGAMD_HOST_THREADS=$th timeout 900 python bench.py --workload paired --steps 3 --warmup 1 --cpu-sample $([ $th = 0 ] && echo 200000 || echo 2000) \
+          > "$out/bench_paired_threads$th.json" 2> "$out/bench_paired_threads$th.err"
+      python - "$out/bench_paired_threads$th.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(sys.argv[1], round(d["value"]), d["parity"] and {k: v for k, v in d["parity"].items() if k != "what"}, {k: round(v, 2) for k, v in d["config"]["stage_ms"].items()}, d["roofline_rescue"])
+PY
+    done
+    VGAMD_PAIRED_PER_GRAPH=1 timeout 600 python bench.py --workload paired --steps 2 --warmup 1 --no-cpu > "$out/bench_paired_per_graph.json" 2> "$out/bench_paired_per_graph.err"
+    python -c "import json,sys; d=json.loads(open('$out/bench_paired_per_graph.json').read().strip().splitlines()[-1]); print('per-graph form', round(d['value']))" ;;
+  pmc)            # kernel statistics + FETCH_SIZE / WRITE_SIZE passes (separate runs, kernel trace only) of the named workloads -> gpurun_out/r05_pmc (tools/pmc_constants.py r05)
+    P=$GRAFT_REPO_ROOT/gpurun_out/r05_pmc; mkdir -p $P
+    shift
+    for w in "$@"; do
+      case $w in linear) R=400000;; config2) R=1000000; export VGAMD_CONFIG2_ONE_CONTEXT=1;; gapless) R=1000000;; banded) R=100000;; wfa) R=500000;; paired) R=500000;; longread) R=4000;; xband) R=200000;; *) R=0;; esac
+      B="python $GRAFT_REPO_ROOT/bench.py --workload $w --reads $R --no-cpu --no-e2e --no-secondary --steps 2 --warmup 1"
+      ( cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_$w -o s -- $B > $P/stats_$w.log 2>&1 )
+      for c in FETCH_SIZE WRITE_SIZE; do
+        ( cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $P/${c}_$w -o p -- $B > $P/${c}_$w.log 2>&1 )
+      done
+      unset VGAMD_CONFIG2_ONE_CONTEXT
+    done
+    ls $P ;;
   default)        # what the driver runs: the headline + every secondary record
     timeout 1700 python bench.py > "$out/bench_default_run.json" 2> "$out/bench_default_run.err"; tail -c 400 "$out/bench_default_run.json" ;;
   *) echo "unknown stage $stage"; exit 2 ;;

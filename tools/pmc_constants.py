@@ -18,10 +18,15 @@ GROUPS = {   # name -> (units per launch, kernel-name fragments of its roofline 
     # configs[2], one batch of 1 M reads in one context: the extension kernels of the stage, and its seeding kernels on their own
     "config2": (1000000, ["gapless_search_kernel", "gapless_rules_kernel", "gapless_kernel("], "config2"),
     "minimizer": (1000000, ["minimizer_kernel", "minimizer_gather_kernel"], "config2"),
+    # configs[4]: the WFA launches of the chain stage, per read (4 000 reads per launch)
+    "longread": (4000, ["wfa_wave_kernel", "wfa_kernel"], "longread"),
+    # configs[3] slice: the rescue half's kernels (fills and tracebacks of its three rounds) per PAIR of the batch; a step launches them a varying number of
+    # times, so the total is divided by the stage runs of the profiled command (warmup 1 + steps 2 + the untimed run that fetches the ops = 4)
+    "rescue": (250000, ["gssw_fill_kernel", "gssw_walk"], "paired", 4),
 }
 
 
-def per_dispatch(path, counter, frags):
+def per_dispatch(path, counter, frags, runs=None):
     """the group's counter total per BATCH of the bench: every kernel's total divided by the batches run = the fewest dispatches any kernel of
     the group has (a kernel launched several times per batch — the seeding kernel's four slices — counts with all of them)"""
     tot = collections.defaultdict(float); disp = collections.defaultdict(set)
@@ -32,7 +37,7 @@ def per_dispatch(path, counter, frags):
         if not any(f in k for f in frags):
             continue
         tot[k] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
-    batches = min(len(disp[k]) for k in tot) if tot else 1
+    batches = runs if runs else (min(len(disp[k]) for k in tot) if tot else 1)
     return sum(tot[k] for k in tot) / batches, {k.split("(")[0]: len(disp[k]) for k in tot}
 
 
@@ -52,7 +57,7 @@ def main():
             found = glob.glob(os.path.join(SRC, "%s_%s" % (counter, run), "**", "*counter_collection.csv"), recursive=True)
             if not found:
                 print("missing", counter, name); break
-            vals[counter], dispatches = per_dispatch(found[0], counter, frags)
+            vals[counter], dispatches = per_dispatch(found[0], counter, frags, spec[3] if len(spec) > 3 else None)
             shutil.copy(found[0], os.path.join(dst, "pmc_%s_%s_%s.csv" % (counter.split("_")[0].lower(), run, ROUND)))
         else:
             table[name] = {"fetch_kib_per_launch": vals["FETCH_SIZE"], "write_kib_per_launch": vals["WRITE_SIZE"], "units_per_launch": units,

@@ -42,6 +42,9 @@ std::shared_ptr<EngineApi> load_engine(const std::string& path) {
     bind(dl, "vgk_gssw_run", api->gssw_run);
     bind(dl, "vgk_gssw_fetch", api->gssw_fetch);
     bind(dl, "vgk_batch_free", api->batch_free);
+    bind(dl, "vgk_batch_kernel_ms", api->batch_kernel_ms);
+    bind(dl, "vgk_batch_alg_bytes", api->batch_alg_bytes);
+    bind(dl, "vgk_batch_cells", api->batch_cells);
     bind(dl, "vgk_banded_align", api->banded_align);
     bind(dl, "vgk_banded_align_multi", api->banded_align_multi);
     bind(dl, "vgk_haplo_create", api->haplo_create);

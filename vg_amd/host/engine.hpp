@@ -25,6 +25,9 @@ struct EngineApi {
     decltype(&vgk_gssw_run) gssw_run = nullptr;
     decltype(&vgk_gssw_fetch) gssw_fetch = nullptr;
     decltype(&vgk_batch_free) batch_free = nullptr;
+    decltype(&vgk_batch_kernel_ms) batch_kernel_ms = nullptr;
+    decltype(&vgk_batch_alg_bytes) batch_alg_bytes = nullptr;
+    decltype(&vgk_batch_cells) batch_cells = nullptr;
     decltype(&vgk_banded_align) banded_align = nullptr;
     decltype(&vgk_banded_align_multi) banded_align_multi = nullptr;
     decltype(&vgk_haplo_create) haplo_create = nullptr;

@@ -18,6 +18,7 @@
 #include "aligner_client.hpp"
 #include "rescue_stage.hpp"
 #include "rescue_resident.hpp"
+#include "rescue_requests.hpp"
 #include <sstream>
 
 using namespace vgamd;
@@ -258,7 +259,8 @@ vgh_rescue_graph* vgh_rescue_graph_create(vgh_aligner* a, uint32_t n_nodes, cons
     } catch (std::exception& e) { g_last_error = e.what(); return nullptr; }
 }
 void vgh_rescue_graph_destroy(vgh_rescue_graph* g) { delete g; }
-// laps (nullable): classify, first pass, second pass, alignments + fix-ups, full-DP fallback (ms); counts (nullable): first-pass extensions, scans, second-pass extensions, fallbacks
+// laps (nullable, 6): classify, first pass, second pass, alignments + fix-ups, full-DP fallback, kernels of the three rounds (ms); counts (nullable, 6): first-pass extensions,
+// scans, second-pass extensions, fallbacks, algorithmic bytes of the rounds' batches, their DP cells
 int vgh_rescue_stage_resident(vgh_aligner* a, vgh_rescue_graph* g, int n, const char* reads, uint64_t reads_bytes, const uint64_t* read_off, const int64_t* requests,
                               uint64_t max_dozeu_cells, int host_threads, int64_t* out, uint64_t* ops_begin, vgk_op* ops, uint64_t ops_cap, uint64_t* ops_written,
                               double* laps, uint64_t* counts) {
@@ -278,7 +280,8 @@ int vgh_rescue_stage_resident(vgh_aligner* a, vgh_rescue_graph* g, int n, const 
             q[0] = r.score; q[1] = r.status; q[2] = r.first_node; q[3] = r.first_offset; q[4] = r.n_mappings; q[5] = r.aligned_read_bases;
         }
         if (laps) { laps[0] = tm.classify_ms; laps[1] = tm.first_pass_ms; laps[2] = tm.second_pass_ms; laps[3] = tm.finish_ms; laps[4] = tm.fallback_ms; }
-        if (counts) { counts[0] = tm.first_pass; counts[1] = tm.scans; counts[2] = tm.second_pass; counts[3] = tm.fallbacks; }
+        if (counts) { counts[0] = tm.first_pass; counts[1] = tm.scans; counts[2] = tm.second_pass; counts[3] = tm.fallbacks; counts[4] = tm.alg_bytes; counts[5] = tm.cells; }
+        if (laps) laps[5] = tm.kernel_ms;
         if (ops_written) *ops_written = o.size();
         if (want_ops) {
             std::copy(ob.begin(), ob.end(), ops_begin);
@@ -286,6 +289,19 @@ int vgh_rescue_stage_resident(vgh_aligner* a, vgh_rescue_graph* g, int n, const 
             if (ops) std::copy(o.begin(), o.end(), ops);
         }
         return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// the request table of a batch of pairs (rescue_requests.hpp) — returns the number of rescued pairs (-1: error); outputs sized for n_pairs entries
+int64_t vgh_rescue_requests(uint32_t n_pairs, const vgk_gapless_result* results, const vgk_extension* extensions, const uint32_t* nodes, uint32_t n_nodes, const int64_t* col,
+                            const char* reads, uint32_t read_len, double fragment_mean, double fragment_sd, double rescue_stdevs, int host_threads,
+                            uint32_t* mapped, uint32_t* lost, int64_t* requests, char* rescue_reads) {
+    try {
+        RescueRequestTable t;
+        build_rescue_requests(n_pairs, results, extensions, nodes, n_nodes, col, reads, read_len, fragment_mean, fragment_sd, rescue_stdevs, (unsigned)std::max(host_threads, 0), t);
+        std::copy(t.mapped.begin(), t.mapped.end(), mapped); std::copy(t.lost.begin(), t.lost.end(), lost);
+        std::copy(t.requests.begin(), t.requests.end(), requests); std::copy(t.reads.begin(), t.reads.end(), rescue_reads);
+        return (int64_t)t.mapped.size();
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }
 

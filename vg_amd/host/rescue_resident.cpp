@@ -172,6 +172,7 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
         er.assign(ep.size(), vgk_result{}); wr.assign(wp.size(), vgk_result{});
         if (be) { eo.resize(traced ? ep.size() * (size_t)OPS_PER + 1 : 1); check(api.gssw_fetch(be, er.data(), eo.data(), traced ? eo.size() : 0, &written), "vgk_gssw_fetch"); }
         if (bw) { wo.resize(traced ? wp.size() * (size_t)OPS_PER + 1 : 1); check(api.gssw_fetch(bw, wr.data(), wo.data(), traced ? wo.size() : 0, &written), "vgk_gssw_fetch"); }
+        if (timing) for (vgk_batch* b : {be, bw}) if (b) { timing->kernel_ms += api.batch_kernel_ms(b, -1); timing->alg_bytes += api.batch_alg_bytes(b); timing->cells += api.batch_cells(b); }
         for (const vgk_result& r : er) check(r.status, "an extension window");
         for (const vgk_result& r : wr) check(r.status, "a window");
     };

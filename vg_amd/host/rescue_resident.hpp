@@ -37,7 +37,8 @@ struct RescueRequestFlat {
     uint32_t node_lo = 0, node_hi = 0;                      // rescue nodes = [node_lo, node_hi)
     int64_t seed_begin = 0, seed_end = 0, seed_node = -1, seed_offset = 0;      // as RescueRequest
 };
-struct RescueTiming { double classify_ms = 0, first_pass_ms = 0, second_pass_ms = 0, finish_ms = 0, fallback_ms = 0; uint64_t first_pass = 0, scans = 0, second_pass = 0, fallbacks = 0; };
+struct RescueTiming { double classify_ms = 0, first_pass_ms = 0, second_pass_ms = 0, finish_ms = 0, fallback_ms = 0; uint64_t first_pass = 0, scans = 0, second_pass = 0, fallbacks = 0;
+                      double kernel_ms = 0; uint64_t alg_bytes = 0, cells = 0; };      // kernels of the three rounds (HIP events), their algorithmic bytes and DP cells
 
 // results[k] as run_rescue_stage fills them; ops (nullable): the final alignments as (node index, VGK_OP_M / I / D, length) runs, mapping by
 // mapping, ops_begin[k] .. ops_begin[k + 1] those of request k (a match / mismatch stretch is one M run; soft clips are I)

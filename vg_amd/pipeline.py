@@ -486,6 +486,9 @@ def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device
     read_score = np.asarray(out["read_score"], dtype=np.int64)
     L = wl.read_len
     g = wl.graph
+    if resident is not None:
+        # the product route: the request table from the extension sets on chunked host threads (vg_amd/host/rescue_requests.cpp), no numpy in between
+        return _paired_stage_resident(eng, wl, host_aligner, resident, out, read_score, rescue_stdevs, timing, host_threads, want_ops, t0, t1)
     full = (res["status"] == 0) & (res["full_length"] != 0)
     a_full, b_full = full[0::2], full[1::2]
     pairs = np.nonzero(a_full != b_full)[0]
@@ -545,7 +548,7 @@ def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device
     t2 = time.perf_counter()
     outv = np.zeros((len(pairs), 6), dtype=np.int64)
     ops_begin = np.zeros(len(pairs) + 1, dtype=np.uint64); ops = np.zeros(0, dtype=capi.OP_DT)
-    laps = np.zeros(5, dtype=np.float64); counts = np.zeros(4, dtype=np.uint64)
+    laps = np.zeros(6, dtype=np.float64); counts = np.zeros(6, dtype=np.uint64)
     if len(pairs):
         h = _host_lib()
         flat = np.ascontiguousarray(rd).ravel(); roff = (np.arange(len(pairs) + 1, dtype=np.uint64) * L)
@@ -580,7 +583,50 @@ def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device
             for k, v in zip(("rescue: classify (host)", "rescue: first pass (extension windows + scans)", "rescue: second pass (traced extension windows)", "rescue: alignments + fix-ups (host)", "rescue: full-DP fallback"), laps):
                 timing[k] = timing.get(k, 0.0) + v * 1e-3
     return dict(read_score=read_score, rescued=lost, mapped=mapped, requests=req, rescue=outv, pair_score=pair_score, res=res, rescue_ops=ops, rescue_ops_begin=ops_begin,
-                rescue_counts=dict(zip(("first_pass", "scans", "second_pass", "fallbacks"), (int(x) for x in counts))))
+                rescue_counts=dict(zip(("first_pass", "scans", "second_pass", "fallbacks", "alg_bytes", "cells"), (int(x) for x in counts)), kernel_ms=float(laps[5])))
+
+
+def _paired_stage_resident(eng, wl, host_aligner, resident, out, read_score, rescue_stdevs, timing, host_threads, want_ops, t0, t1):
+    import time
+    h = _host_lib()
+    res, ext, nodes = np.ascontiguousarray(out["res"]), np.ascontiguousarray(out["ext"]), np.ascontiguousarray(out["nodes"], dtype=np.uint32)
+    L = wl.read_len; g = wl.graph; n_pairs = wl.n // 2
+    bufs = getattr(resident, "_bufs", None)
+    if bufs is None or bufs[0] < n_pairs:                   # a streaming caller keeps its request / output arrays
+        bufs = resident._bufs = (n_pairs, np.zeros(n_pairs, dtype=np.uint32), np.zeros(n_pairs, dtype=np.uint32), np.zeros((n_pairs, 6), dtype=np.int64),
+                                 np.zeros(n_pairs * L, dtype=np.uint8), np.zeros((n_pairs, 6), dtype=np.int64), np.arange(n_pairs + 1, dtype=np.uint64) * L,
+                                 np.ascontiguousarray(g.col, dtype=np.int64))
+    _, mapped, lost, req, rd, outv, roff, col = bufs
+    h.vgh_rescue_requests.restype = ctypes.c_int64
+    h.vgh_rescue_requests.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                      ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int] + [ctypes.c_void_p] * 4
+    m = h.vgh_rescue_requests(n_pairs, res.ctypes.data, ext.ctypes.data, nodes.ctypes.data, g.n_nodes, col.ctypes.data, wl.reads.ctypes.data, L, float(wl.mean), float(wl.sd),
+                              float(rescue_stdevs), host_threads, mapped.ctypes.data, lost.ctypes.data, req.ctypes.data, rd.ctypes.data)
+    if m < 0:
+        raise RuntimeError(h.vgh_last_error().decode())
+    t2 = time.perf_counter()
+    ops_begin = np.zeros(m + 1, dtype=np.uint64); ops_cap = m * 64 if want_ops else 0
+    ops = np.zeros(max(ops_cap, 1), dtype=capi.OP_DT); written = ctypes.c_uint64()
+    laps = np.zeros(6, dtype=np.float64); counts = np.zeros(6, dtype=np.uint64)
+    if m:
+        h.vgh_rescue_stage_resident.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        rc = h.vgh_rescue_stage_resident(host_aligner.ptr, resident.ptr, m, rd.ctypes.data, m * L, roff.ctypes.data, req.ctypes.data, 0, host_threads, outv.ctypes.data,
+                                         ops_begin.ctypes.data if want_ops else None, ops.ctypes.data if want_ops else None, ops_cap, ctypes.byref(written), laps.ctypes.data, counts.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(h.vgh_last_error().decode())
+    t3 = time.perf_counter()
+    mapped_i = mapped[:m].astype(np.int64); lost_i = lost[:m].astype(np.int64)
+    pair_score = read_score[0::2] + read_score[1::2]
+    pair_score[mapped_i >> 1] = read_score[mapped_i] + np.maximum(outv[:m, 0], read_score[lost_i])
+    if timing is not None:
+        for k, v in (("stage (seeding, extension, tails)", t1 - t0), ("rescue requests (host threads)", t2 - t1), ("rescue stage (resident graph: extension windows, fix-ups)", t3 - t2)):
+            timing[k] = timing.get(k, 0.0) + v
+        for k, v in zip(("rescue: classify (host)", "rescue: first pass (extension windows + scans)", "rescue: second pass (traced extension windows)", "rescue: alignments + fix-ups (host)", "rescue: full-DP fallback"), laps):
+            timing[k] = timing.get(k, 0.0) + v * 1e-3
+    return dict(read_score=read_score, rescued=lost_i, mapped=mapped_i, requests=req[:m].copy(), rescue=outv[:m].copy(), pair_score=pair_score, res=res,
+                rescue_ops=ops[:int(written.value)] if want_ops else ops[:0], rescue_ops_begin=ops_begin,
+                rescue_counts=dict(zip(("first_pass", "scans", "second_pass", "fallbacks", "alg_bytes", "cells"), (int(x) for x in counts)), kernel_ms=float(laps[5])))
 
 
 class HostAlignerHandle:

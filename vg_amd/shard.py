@@ -55,7 +55,8 @@ def host_threads_per_rank(world, cores=None):
 HOST_THREADS_NEEDED = {
     "linear": 1, "tails": 1, "forest": 1, "giraffe": 1, "config2": 1,      # resident: kernels only inside the timed region
     "gapless": 4, "wfa": 4, "xband": 4,                                     # sets handed out / re-ordered on host threads
-    "banded": 8, "longread": 8, "paired": 8,                                # band geometry / local graphs / rescue subgraphs on host threads
+    "paired": 2,                                                            # rescue on the resident graph: the request table and the fix-ups are flat passes (round 5; was 8)
+    "banded": 8, "longread": 8,                                             # band geometry / local graphs on host threads
 }
 
 
