@@ -421,24 +421,39 @@ def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
     """A one-GPU slice of BASELINE.json configs[3] (secondary line): read PAIRS of 2 x 150 bp on a variation graph of the chr22-scale
     construction, both mates through seeding -> gapless extension -> tails (the configs[2] stage), then — giraffe's paired-end shape,
     MinimizerMapper::attempt_rescue (src/minimizer_mapper.cpp:3264-3440) — the mate without a full-length extension rescued from its
-    partner's position: rescue subgraph, its best extension as dozeu's seed, Aligner::align_xdrop for all such mates at once
-    (align_xdrop_many), fix_dozeu_score, fix_dozeu_end_deletions.  One step = one batch of pairs from host buffers.  The pairs of a
-    stream stay together when it is sharded (shard.shard_range(group = 2)): this is what each rank of an 8-GPU run would do."""
+    partner's position: the rescue nodes, its best extension inside them as dozeu's seed, both passes of Aligner::align_xdrop as extension
+    windows of the RESIDENT graph, fix_dozeu_score, fix_dozeu_end_deletions (vg_amd/host/rescue_resident.cpp).  One step = all batches of
+    pairs from host buffers, two batches in flight (two engine contexts over one copy of the indexes, a host thread each) the way configs[2]
+    runs.  The pairs of a stream stay together when it is sharded (shard.shard_range(group = 2)): this is what each rank of an 8-GPU run would do."""
     import numpy as np
+    import threading
     from vg_amd import capi, pipeline, shard, workloads
-    n_pairs = (args.reads // 2) if args.reads else 250_000
+    n_total = (args.reads // 2) if args.reads else 1_000_000                 # pairs per step
+    n_pairs = min(n_total, int(os.environ.get("VGAMD_PAIRED_BATCH", "250000")))   # pairs per batch
+    n_batches = max(1, n_total // n_pairs); n_total = n_batches * n_pairs
     t0 = time.perf_counter()
-    wl = workloads.PairedWorkload(n_pairs, ref_len=int(os.environ.get("VGAMD_PAIRED_REF_LEN", "5000000")), seed=41 + rank)
+    wl_all = workloads.PairedWorkload(n_total, ref_len=int(os.environ.get("VGAMD_PAIRED_REF_LEN", "5000000")), seed=41 + rank)
+    batches = [wl_all.batch(b * n_pairs, (b + 1) * n_pairs) for b in range(n_batches)]
+    wl = batches[0]
     t_gen = time.perf_counter() - t0
     graph = (wl.node_len, wl.seq)
     index = eng.haplo_index(graph, wl.threads); mindex = eng.minimizer_index(graph, wl.threads)
     eng.reuse_outputs = True
-    eng.host_register(wl.reads)
-    aligner = pipeline.HostAlignerHandle(os.environ.get("VGAMD_ENGINE_LIB"), device=eng.device)
+    eng.host_register(wl_all.reads)
     threads = int(os.environ.get("VGAMD_HOST_THREADS", "0")) or min(shard.usable_cpus(), 48)
-    # the rescue half runs on the graph RESIDENT in the host aligner's engine context (vg_amd/host/rescue_resident.cpp); VGAMD_PAIRED_PER_GRAPH=1: round 4's
-    # form, one HashGraph per mate on host threads (vg_amd/host/rescue_stage.cpp) — kept as the reference-shaped checker
-    rg = None if os.environ.get("VGAMD_PAIRED_PER_GRAPH") else aligner.rescue_graph(wl)
+    per_graph = bool(os.environ.get("VGAMD_PAIRED_PER_GRAPH"))
+    n_lanes = 1 if (n_batches < 2 or os.environ.get("VGAMD_PAIRED_ONE_CONTEXT") or per_graph) else 2
+    lane_threads = max(1, threads // n_lanes)
+    # a lane = an engine context for the stage + a host aligner (its own context) with the graph resident in it for the rescue half
+    # (vg_amd/host/rescue_resident.cpp); VGAMD_PAIRED_PER_GRAPH=1: round 4's form, one HashGraph per mate on host threads
+    # (vg_amd/host/rescue_stage.cpp) — kept as the reference-shaped checker
+    lanes = []
+    for k in range(n_lanes):
+        e = eng if k == 0 else capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), device=eng.device, lib=eng.lib)
+        e.reuse_outputs = True
+        al = pipeline.HostAlignerHandle(os.environ.get("VGAMD_ENGINE_LIB"), device=eng.device)
+        lanes.append((e, al, None if per_graph else al.rescue_graph(wl)))
+    aligner, rg = lanes[0][1], lanes[0][2]
 
     def barrier():
         _device_sync(torch)
@@ -446,19 +461,49 @@ def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
             dist.barrier()
         _device_sync(torch)
 
+    lock = threading.Lock()
+    acc = {"kernel_ms": 0.0, "alg": 0.0, "cells": 0.0, "rescued": 0, "gapless_ms": 0.0}
+
+    def run_lane(lane, which, timing, keep):
+        e, al, g_res = lane
+        for b in which:
+            tm = {} if timing is not None else None
+            o = pipeline.paired_stage(e, index, mindex, batches[b], al, timing=tm, host_threads=lane_threads, resident=g_res)
+            with lock:
+                if timing is not None:
+                    for k2, v in tm.items():
+                        timing[k2] = timing.get(k2, 0.0) + v
+                    c = o["rescue_counts"]
+                    acc["kernel_ms"] += c.get("kernel_ms", 0.0); acc["alg"] += c.get("alg_bytes", 0); acc["cells"] += c.get("cells", 0); acc["rescued"] += len(o["rescued"])
+                    acc["gapless_ms"] += e.gapless_last_ms()
+                if keep is not None and b == 0:
+                    keep["out"] = o
+
+    def one_step(timing=None, keep=None):
+        th = [threading.Thread(target=run_lane, args=(lanes[k], range(k, n_batches, n_lanes), timing, keep)) for k in range(1, n_lanes)]
+        for t in th: t.start()
+        run_lane(lanes[0], range(0, n_batches, n_lanes), timing, keep)
+        for t in th: t.join()
+
     for _ in range(max(1, args.warmup)):
-        pipeline.paired_stage(eng, index, mindex, wl, aligner, host_threads=threads, resident=rg)
+        one_step()
     barrier()
-    timing = {}
-    rescue_kernel_ms = rescue_alg = rescue_cells = 0.0
+    timing = {}; kept = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = pipeline.paired_stage(eng, index, mindex, wl, aligner, timing=timing, host_threads=threads, resident=rg)
-        rescue_kernel_ms += out["rescue_counts"].get("kernel_ms", 0.0); rescue_alg += out["rescue_counts"].get("alg_bytes", 0); rescue_cells += out["rescue_counts"].get("cells", 0)
+        one_step(timing, kept)
     barrier()
     elapsed = time.perf_counter() - t0
-    gapless_ms = eng.gapless_last_ms()
-    out = pipeline.paired_stage(eng, index, mindex, wl, aligner, host_threads=threads, resident=rg, want_ops=True)      # (once more, untimed, with the rescued alignments' ops for the parity leg)
+    rescue_kernel_ms, rescue_alg, rescue_cells = acc["kernel_ms"], acc["alg"], acc["cells"]
+    gapless_ms = acc["gapless_ms"] / max(1, args.steps * n_batches)
+    one_context = None
+    if n_lanes > 1:
+        run_lane(lanes[0], range(n_batches), None, None)
+        barrier(); t1 = time.perf_counter()
+        run_lane(lanes[0], range(n_batches), None, None)
+        barrier(); t_one = time.perf_counter() - t1
+        one_context = {"ms_per_batch": 1e3 * t_one / n_batches, "reads_per_s": 2 * n_total / t_one}
+    out = pipeline.paired_stage(eng, index, mindex, wl, aligner, host_threads=threads, resident=rg, want_ops=True)      # (batch 0 once more, untimed, with the rescued alignments' ops for the parity leg)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=RDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -502,37 +547,43 @@ def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
         resc = out["rescue"]
         print(json.dumps({
             "metric": "150 bp paired reads/sec through giraffe's alignment stage with mate rescue (one-GPU slice of configs[3])",
-            "value": 2 * n_pairs * world * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": 2 * n_total * world * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": "configs[3] slice: variation graph of the chr22-scale construction over a %d bp reference (%d nodes, two haplotypes), %d pairs of 2 x 150 bp per GPU, fragments N(%.0f, %.0f), "
                                    "1 %% substitutions, 8 %% of the second mates with an inserted stretch and 3 %% substitutions; k = 29, w = 11 minimizers; rescue window = fragment mean +- 4 sd by column "
-                                   "coordinate (a stand-in for subgraph_in_distance_range: the SnarlDistanceIndex is absent)" % (len(wl.graph.haps[0][0]), len(wl.node_len), n_pairs, wl.mean, wl.sd),
+                                   "coordinate (a stand-in for subgraph_in_distance_range: the SnarlDistanceIndex is absent)" % (len(wl.graph.haps[0][0]), len(wl.node_len), n_total, wl.mean, wl.sd),
+                       "batches": "%d batches of %d pairs per step; %s" % (n_batches, n_pairs, ("two batches in flight: two lanes (engine context + host aligner context + resident rescue graph each, one host thread each, "
+                                                                                                  "%d worker threads per lane) over ONE copy of the haplotype and minimizer indexes" % lane_threads) if n_lanes > 1 else "one after the other in one lane"),
+                       "one_context": one_context, "ms_per_batch": 1e3 * elapsed / args.steps / n_batches,
                        "timed_region": ("per step, one batch of pairs from host buffers: vgk_minimizer_seeds -> vgk_gapless_extend_seeded -> vgk_tail_stage for all 2 n reads, then the request table "
                                         "(vgh_rescue_requests: chunked host threads over the extension sets), then vgh_rescue_stage_resident: both X-drop passes of every lost mate as extension windows of the "
                                         "resident graph (vgk_gssw_pack_extensions: sub-DAGs derived on the device), dozeu's scan and the full-DP fallback as plain windows, the fix-ups over flat arrays") if rg is not None else
                                        ("per step, one batch of pairs from host buffers: the stage for all 2 n reads, the rescue requests (numpy), then vgh_rescue_stage: one HashGraph per mate on host threads, "
                                         "Aligner::align_xdrop_many, the fix-ups [VGAMD_PAIRED_PER_GRAPH: round 4's form]"),
-                       "rescue_rounds_per_step": {k2: v for k2, v in out["rescue_counts"].items() if k2 in ("first_pass", "scans", "second_pass", "fallbacks")},
-                       "pairs_rescued": int(len(out["rescued"])), "rescued_with_positive_score": int((resc[:, 0] > 0).sum()), "refused_by_cell_budget": int((resc[:, 1] == 1).sum()),
-                       "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()}, "host_threads": threads,
+                       "rescue_rounds_in_batch_0": {k2: v for k2, v in out["rescue_counts"].items() if k2 in ("first_pass", "scans", "second_pass", "fallbacks")},
+                       "pairs_rescued_in_batch_0": int(len(out["rescued"])), "rescued_with_positive_score": int((resc[:, 0] > 0).sum()), "refused_by_cell_budget": int((resc[:, 1] == 1).sum()),
+                       "pairs_rescued_per_step": acc["rescued"] / args.steps,
+                       "stage_ms_per_batch": {k: 1e3 * v / args.steps / n_batches for k, v in timing.items()}, "host_threads": threads,
                        "parallelism": "pair-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
             # the leg's longest kernel family is the stage's gapless search (as in configs[2]); priced the same way: the reads once per seed + outputs
             "roofline": (lambda alg, ms: {"bound": "hbm", "kernel": "gapless_search_kernel + gapless_rules_kernel (the stage's longest kernels, as in configs[2])", "limiter": "memory latency and divergent issue, not bandwidth",
                                           "achieved": alg / (ms * 1e-3) / 1e9 if ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms else None,
-                                          "traffic": PMC_BYTES_PER_UNIT["config2"] * 2 * n_pairs if "config2" in PMC_BYTES_PER_UNIT else None,
+                                          "traffic": PMC_BYTES_PER_UNIT["config2"] * 2 * n_pairs if "config2" in PMC_BYTES_PER_UNIT else None,      # (per launch = per batch)
                                           "traffic_source": (traffic_source("config2") + " — the same kernels on the same graph construction, per read") if "config2" in PMC_BYTES_PER_UNIT else None,
                                           "alg_bytes_per_launch": alg, "avg_launch_ms": ms})(
                 float(wl.read_len * 2 * n_pairs * 5 + 60 * len(out["res"]) * 2), gapless_ms),
             # ... and the rescue half's own kernels: the X-drop fills and tracebacks of the three rounds (extension windows, scans, fallbacks), SURVEY §8(d)'s bytes per problem
             "roofline_rescue": {"bound": "valu", "kernel": "gssw_fill_kernel + walk kernels over the rescue rounds' batches", "achieved": rescue_alg / (rescue_kernel_ms * 1e-3) / 1e9 if rescue_kernel_ms else None,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rescue_alg / (rescue_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rescue_kernel_ms else None,
-                                "traffic": PMC_BYTES_PER_UNIT["rescue"] * len(out["rescued"]) if "rescue" in PMC_BYTES_PER_UNIT else None,
-                                "alg_bytes_per_step": rescue_alg / args.steps, "kernel_ms_per_step": rescue_kernel_ms / args.steps,
+                                "traffic": PMC_BYTES_PER_UNIT["rescue"] * n_pairs if "rescue" in PMC_BYTES_PER_UNIT else None,      # (per batch of pairs, like the figures beside it)
+                                "traffic_source": traffic_source("rescue") if "rescue" in PMC_BYTES_PER_UNIT else None,
+                                "alg_bytes_per_batch": rescue_alg / args.steps / n_batches, "kernel_ms_per_batch": rescue_kernel_ms / args.steps / n_batches,
                                 "gcups": rescue_cells / (rescue_kernel_ms * 1e-3) / 1e9 if rescue_kernel_ms else None},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((out["res"]["status"] != 0).sum())}))
-    if rg is not None:
-        rg.close()
-    aligner.close()
+    for e, al, g_res in lanes:
+        if g_res is not None:
+            g_res.close()
+        al.close()
     if dist is not None:
         dist.destroy_process_group()
 
@@ -619,9 +670,12 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
     for _ in range(n_contexts - 1):
         eng_b = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), device=eng.device, lib=eng.lib)          # (the same library, the same device)
         eng_b.reuse_outputs = True
-        lanes.append((eng_b, eng_b.haplo_index(graph, wl.threads), eng_b.minimizer_index(graph, wl.threads)))
-        if with_policy:
-            lanes[-1][2].set_policy(10, 500, 0.9)
+        if os.environ.get("VGAMD_CONFIG2_OWN_INDEXES"):          # (round 4's form: every context uploads its own copy of both indexes)
+            lanes.append((eng_b, eng_b.haplo_index(graph, wl.threads), eng_b.minimizer_index(graph, wl.threads)))
+            if with_policy:
+                lanes[-1][2].set_policy(10, 500, 0.9)
+        else:                                                     # the indexes are read-only tables of the device: one copy serves every context on it (include/vgk.h "sharing an index")
+            lanes.append((eng_b, index, mindex))
 
     def one_step_pipelined(timing=None, keep=None):
         tot = new_tot()
@@ -709,6 +763,7 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
                        "timed_region": "per step, %d batches of %d reads from host buffers: vgk_minimizer_seeds (clusters stay in HBM) -> vgk_gapless_extend_seeded (sets come down under the "
                                        "tail stage) -> vgk_tail_stage_aligned%s" % (len(wl.batches), batch, "; %d batches in flight: %d engine contexts, one host thread each, batches in turn" % (n_contexts, n_contexts) if pipelined else ""),
                        "one_context": one_context,
+                       "indexes": ("one copy of the haplotype and minimizer indexes in HBM, shared by the %d contexts" % n_contexts) if pipelined and not os.environ.get("VGAMD_CONFIG2_OWN_INDEXES") else "one copy per context",
                        "read_buffers": "page-locked by the caller (vgk_host_register)" if pinned and all(pinned) else "pageable",
                        "policies": ("find_seeds' choice on the device (vgk_minimizer_set_policy: hit cap 10, hard cap 500 over a key's run, score fraction 0.9); clusters = all seeds of the chosen minimizers" if with_policy else
                                     "every minimizer of a read looked up, hit cap 500 (hard cap) per minimizer, no score-based selection (vgk_minimizer_set_policy exists: VGAMD_CONFIG2_POLICY=1 turns it on here); clusters = all seeds of a read"),

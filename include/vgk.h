@@ -411,6 +411,11 @@ typedef struct vgk_haplotypes {
     const uint32_t* thread_nodes;    /* oriented nodes along each thread */
 } vgk_haplotypes;
 typedef struct vgk_haplo vgk_haplo;  /* the index, resident in HBM */
+/* Sharing an index: a vgk_haplo and a vgk_minimizer_index are read-only tables in the HBM of the device their context drives (complete
+ * when the create call returns; vgk_minimizer_set_policy aside).  Every context ON THE SAME DEVICE may be handed them — vg calls one
+ * aligner from many threads; here a caller that keeps several batches in flight opens a context per batch (its own streams, scratch and
+ * stage state) over ONE copy of the indexes: 8 ranks x 2 contexts need 8 uploads, not 16.  The creating context must be destroyed last.
+ * (A context of another device: VGK_EINVAL.) */
 int  vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* haplotypes, vgk_haplo** out);
 void vgk_haplo_destroy(vgk_haplo* index);
 /* The same index from the image of a GBWT file (what the reference loads with gbwt_helper's load_gbwt and reaches through

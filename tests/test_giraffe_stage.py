@@ -189,3 +189,35 @@ def test_aligned_tail_stage_reports_the_sizes_it_needs(emu_lib):
     assert call(big_t, small_o) == -6 and (written[0], written[1]) == (len(tails), len(ops))     # ... the ops do not fit
     big_o = np.zeros(len(ops), dtype=capi.OP_DT)
     assert call(big_t, big_o) == 0 and (big_t == tails).all() and (big_o == ops).all()
+
+
+def test_a_second_context_runs_over_the_first_ones_indexes(emu_lib):
+    second_context_over_shared_indexes(emu_lib, 300)
+
+
+@pytest.mark.gpu
+def test_a_second_context_runs_over_the_first_ones_indexes_on_hip():
+    second_context_over_shared_indexes(ENGINE_LIB, 20000)
+
+
+def second_context_over_shared_indexes(emu_lib, n_reads):
+    """the haplotype and minimizer indexes are read-only tables of the device: a second context (its own streams, scratch and stage state) is handed
+    the first one's and gives the first one's results — what configs[2]'s two batches in flight do with ONE copy of the indexes (include/vgk.h
+    "sharing an index")"""
+    wl = workloads.GaplessWorkload(n_reads, seed=21, graph_bp=50000 if n_reads < 1000 else 2_000_000, inserted_reads=0.3)
+    sc = capi.Scoring.simple(1, 4, 6, 1, 5)
+    a = capi.Engine(sc, lib=emu_lib); b = capi.Engine(sc, lib=emu_lib)
+    hi = a.haplo_index(wl.nodes, wl.threads); mi = a.minimizer_index(wl.nodes, wl.threads)
+
+    class B:
+        n = wl.n
+    outs = []
+    for eng in (a, b, a, b):                                               # in turn, as two batches in flight alternate
+        so, _, _ = eng.minimizer_seeds(mi, hi, wl.gs.reads, wl.gs.read_off, keep_on_device=True)
+        o = pipeline.align_stage_device(eng, hi, B, seeded=int(so[-1]), aligned=True)
+        outs.append((so.copy(), o["read_score"].copy(), o["ext_total"].copy(), o["tails"].copy(), o["tail_ops"].copy(), o["stats"]))
+    for o in outs[1:]:
+        assert (o[0] == outs[0][0]).all() and (o[1] == outs[0][1]).all() and (o[2] == outs[0][2]).all() and o[5] == outs[0][5]
+        assert o[3].tobytes() == outs[0][3].tobytes() and o[4].tobytes() == outs[0][4].tobytes()
+    assert outs[0][5][0] > 20
+    b.close(); a.close()

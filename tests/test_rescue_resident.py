@@ -144,6 +144,13 @@ def test_resident_rescue_equals_the_reference_shaped_path_over_the_oracle():
     st = old[0][:, 1]
     assert (st == 2).sum() > 20 and (st == 0).sum() > 2000
     assert (old[0][:, 0] > 20).sum() > 400
+    for threads in (1, 3):                                                   # (one host thread: the chunks one after the other)
+        rng = np.random.default_rng(8)
+        nodes, preds = random_dag(rng, 200, 20)
+        g = Graph(nodes, [sorted(p) for p in preds])
+        reads, read_off, req = random_requests(rng, g, 700)
+        a, b = both_paths(ORACLE_LIB, g, reads, read_off, req, threads=threads)
+        same(b, a, req, "resident vs reference-shaped, %d host threads" % threads)
     old, new, req = corners(ORACLE_LIB, 4, 300, 1200, max_cells=12000)       # a cell budget that refuses the larger windows
     assert (old[0][:, 1] == 1).sum() > 50 and (old[0][:, 1] == 0).sum() > 50
 

@@ -41,7 +41,7 @@ PY
       python - "$out/bench_paired_threads$th.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(sys.argv[1], round(d["value"]), d["parity"] and {k: v for k, v in d["parity"].items() if k != "what"}, {k: round(v, 2) for k, v in d["config"]["stage_ms"].items()}, d["roofline_rescue"])
+print(sys.argv[1], round(d["value"]), d["parity"] and {k: v for k, v in d["parity"].items() if k != "what"}, {k: round(v, 2) for k, v in d["config"]["stage_ms_per_batch"].items()}, d["config"].get("one_context"), d["roofline_rescue"])
 PY
     done
     VGAMD_PAIRED_PER_GRAPH=1 timeout 600 python bench.py --workload paired --steps 2 --warmup 1 --no-cpu > "$out/bench_paired_per_graph.json" 2> "$out/bench_paired_per_graph.err"

@@ -32,6 +32,7 @@ public:
     virtual const char* name() const = 0;
     virtual int compute_units() const = 0;
     virtual size_t memory_bytes() const = 0;
+    virtual int   device_index() const { return 0; }       // which device of the node this backend drives (two contexts on one device may share read-only tables)
     virtual void* alloc(size_t bytes) = 0;                 // device memory (nullptr on failure)
     virtual void  release(void* p) = 0;
     virtual void* host_alloc(size_t bytes) = 0;            // page-locked host staging memory (uninitialised; nullptr on failure)

@@ -1038,6 +1038,7 @@ public:
         hipSetDevice(dev);
         return hipStreamSynchronize(copy) == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
+    int device_index() const override { return dev; }
     int download(void* dst, const void* src, size_t bytes) override {
         hipSetDevice(dev);
         if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return VGK_ENODEV;

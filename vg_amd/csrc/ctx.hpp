@@ -49,6 +49,12 @@ struct SpecPolicy {
     }
 };
 
+struct vgk_ctx;
+// may `user` run over read-only tables (a haplotype index, a minimizer index) that `owner` put into HBM?  Its own, or those of another context
+// on the SAME device of the same library: the tables are device memory of that device, complete when their create call returned, and never
+// written again (vgk_minimizer_set_policy aside, which both then see).  The owner must outlive every user.  (include/vgk.h: "sharing an index")
+static inline bool vgk_tables_usable(const vgk_ctx* owner, const vgk_ctx* user);
+
 struct vgk_ctx {
     vgk_scoring sc;
     SpecPolicy spec;               // speculative fill: on / off by the miss counts of this context's earlier runs
@@ -189,3 +195,6 @@ struct vgk_ctx {
     ~vgk_ctx() { if (be) { if (deferred.pending) be->sync_fetch(); if (deferred.ev) be->event_destroy(deferred.ev); for (DevBuf& b : scratch) if (b.p) be->release(b.p); for (Pooled& q : dev_pool) be->release(q.p); for (Pooled& q : host_pool) be->host_release(q.p); } }
 };
 
+static inline bool vgk_tables_usable(const vgk_ctx* owner, const vgk_ctx* user) {
+    return owner && user && (owner == user || (owner->be && user->be && owner->be->device_index() == user->be->device_index()));
+}

@@ -401,7 +401,7 @@ int vgk_gapless_fetch_deferred(vgk_ctx* ctx) try {
 int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_problem* problems, uint32_t n,
                        vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
                        uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) try {
-    if (!ctx || !index || index->ctx != ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
+    if (!ctx || !index || !vgk_tables_usable(index->ctx, ctx) || (!problems && n) || (!results && n)) return VGK_EINVAL;
     if (written) written[0] = written[1] = written[2] = 0;
     if (!n) return VGK_OK;
     std::lock_guard<std::mutex> stage(ctx->stage_mu);
@@ -501,7 +501,7 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
 int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max_mismatches, double overlap_threshold, uint32_t flags,
                               vgk_gapless_result* results, vgk_extension* extensions, size_t ext_cap,
                               uint32_t* nodes, size_t nodes_cap, uint32_t* mismatches, size_t mism_cap, size_t written[3]) try {
-    if (!ctx || !index || index->ctx != ctx) return VGK_EINVAL;
+    if (!ctx || !index || !vgk_tables_usable(index->ctx, ctx)) return VGK_EINVAL;
     if (written) written[0] = written[1] = written[2] = 0;
     std::lock_guard<std::mutex> stage(ctx->stage_mu);
     std::lock_guard<std::mutex> lock(ctx->mu);

@@ -110,7 +110,7 @@ struct WinParams {
     WinBucket* buckets;          // [WIN_BUCKETS] the non-empty ones, in launch order
     unsigned long long* wave_tb; // [n_waves_cap + 1] traceback dwords per wave, then their exclusive sums
     // extension windows (null: plain windows): per problem its start; per window node the temporaries; per problem the nodes kept
-    const WinExt* ext; WinKept* kept; uint32_t* ext_count;
+    const WinExt* ext; WinKept* kept; uint32_t* ext_count; uint32_t* kept_node;      // kept_node[kept_off + k] = node k of the problem, counted from the window's first node (what the caller downloads)
     // stage 2 outputs: the arenas of GsswParams
     ProbDesc* probs; uint8_t* colinfo; uint8_t* reads; NodeRec* nodes; uint32_t* preds; WaveDesc* waves; uint32_t* order;
 };
@@ -211,7 +211,7 @@ VGK_HD void ext_size_one(const WinParams& P, uint32_t i, WinAcc& acc) {
                 }
             n_preds += np; R += P.g.col[v + 1] - P.g.col[v]; ++count;
         }
-        for (uint32_t k = 0; k < count; ++k) { const uint32_t f = kept[k].slot_flags & 3u; kept[k].slot_flags = (slots << 2) | f; slots += (f >> 1) & 1u; }
+        for (uint32_t k = 0; k < count; ++k) { const uint32_t f = kept[k].slot_flags & 3u; kept[k].slot_flags = (slots << 2) | f; slots += (f >> 1) & 1u; P.kept_node[x.kept_off + k] = kept[k].node - a; }
         if (count == 0) { R = 1; }                                                       // the dummy column (WIN_EXT_DUMMY)
         if (R >= (1u << 20)) status = VGK_ETOOBIG;
     }

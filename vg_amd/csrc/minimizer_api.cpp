@@ -141,7 +141,7 @@ int vgk_minimizer_index_fetch(const vgk_minimizer_index* ix, vgk_minimizer_hit* 
 
 int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_haplo* graph, const char* reads, const uint64_t* read_off, uint32_t n,
                         uint32_t hit_cap, uint32_t* seed_off, uint32_t* minimizers, vgk_seed* seeds, size_t seeds_cap, size_t* written) try {
-    if (!ctx || !ix || !graph || ix->ctx != ctx || graph->ctx != ctx || (n && (!reads || !read_off || !seed_off))) return VGK_EINVAL;
+    if (!ctx || !ix || !graph || !vgk_tables_usable(ix->ctx, ctx) || !vgk_tables_usable(graph->ctx, ctx) || (n && (!reads || !read_off || !seed_off))) return VGK_EINVAL;
     if (written) *written = 0;
     if (!n) { if (seed_off) seed_off[0] = 0; return VGK_OK; }
     for (uint32_t i = 0; i < n; ++i) if (read_off[i + 1] < read_off[i]) return VGK_EINVAL;

@@ -100,7 +100,7 @@ static int tail_forest_core(vgk_ctx* ctx, const vgk_haplo* index, const vgk_tail
 
 int vgk_tail_forest(vgk_ctx* ctx, const vgk_haplo* index, const vgk_tail_problem* problems, uint32_t n,
                     vgk_tail_result* results, vgk_forest** out) try {
-    if (!ctx || !index || !out || (n && (!problems || !results)) || index->ctx != ctx) return VGK_EINVAL;
+    if (!ctx || !index || !out || (n && (!problems || !results)) || !vgk_tables_usable(index->ctx, ctx)) return VGK_EINVAL;
     *out = nullptr;
     Backend* be = ctx->be.get();
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -153,7 +153,7 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
 // aligned / tails_cap / ops / ops_cap / written: vgk_tail_stage_aligned's outputs (all null / 0 for vgk_tail_stage)
 static int tail_stage_impl(vgk_ctx* ctx, const vgk_haplo* index, uint32_t ops_per_problem, int32_t* ext_total, size_t ext_cap, int32_t* read_score, uint64_t stats[4],
                            const bool want_aligned, vgk_tail_alignment* aligned, size_t tails_cap, vgk_op* ops, size_t ops_cap, size_t* written) {
-    if (!ctx || !index || index->ctx != ctx) return VGK_EINVAL;
+    if (!ctx || !index || !vgk_tables_usable(index->ctx, ctx)) return VGK_EINVAL;
     if (written) written[0] = written[1] = 0;
     if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
     Backend* be = ctx->be.get();

@@ -147,7 +147,7 @@ extern "C" {
 
 int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_model* model, const vgk_wfa_problem* problems, uint32_t n,
                    vgk_wfa_result* results, uint32_t* paths, size_t path_cap, uint32_t* edits, size_t edit_cap, size_t written[2]) try {
-    if (!ctx || !index || index->ctx != ctx || (!problems && n) || (!results && n)) return VGK_EINVAL;
+    if (!ctx || !index || !vgk_tables_usable(index->ctx, ctx) || (!problems && n) || (!results && n)) return VGK_EINVAL;
     if (written) written[0] = written[1] = 0;
     if (!n) return VGK_OK;
     const vgk_wfa_error_model& em = model ? *model : kDefaultModel;

@@ -204,7 +204,8 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
             ext_nodes_total = n ? (uint64_t)extensions[n - 1].kept_off + problems[n - 1].n_nodes : 0;
             W.ext = (const WinExt*)take_temp((uint64_t)std::max<uint32_t>(n, 1u) * sizeof(WinExt));
             W.kept = (WinKept*)take_temp((ext_nodes_total + 1) * sizeof(WinKept)); W.ext_count = (uint32_t*)take_temp((uint64_t)std::max<uint32_t>(n, 1u) * 4);
-            if (!W.ext || !W.kept || !W.ext_count) rc = VGK_ENOMEM;
+            W.kept_node = (uint32_t*)take_temp((ext_nodes_total + 1) * 4);
+            if (!W.ext || !W.kept || !W.ext_count || !W.kept_node) rc = VGK_ENOMEM;
         }
         if (!W.problems || !W.raw_reads || !W.sizes || !W.offs || !W.key || !W.idx || !W.key_sorted || !W.idx_sorted || !W.totals ||
             !W.bucket_first || !W.buckets || !W.wave_tb || !tmp || !W.probs) rc = VGK_ENOMEM;
@@ -249,21 +250,15 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     for (uint32_t k = 0; k < WIN_COLS; ++k) if (T.tot[k] >= (1ull << 32)) return fail(VGK_ETOOBIG);
     if (extensions && n) {
         // which window node every node of an extension problem is: results and ops come back in those terms (vgk_gssw_fetch translates)
-        b->ext_count.resize(n); b->ext_off.resize((size_t)n + 1);
-        std::vector<WinKept> kept((size_t)ext_nodes_total + 1);
-        if ((rc = be->download_side(b->ext_count.data(), W.ext_count, (size_t)n * 4))) return fail(rc);
-        if ((rc = be->download_side(kept.data(), W.kept, (size_t)ext_nodes_total * sizeof(WinKept)))) return fail(rc);
-        uint64_t at = 0;
-        for (uint32_t i = 0; i < n; ++i) { b->ext_off[i] = (uint32_t)at; at += (b->ext_count[i] == WIN_EXT_DUMMY) ? 0u : b->ext_count[i]; }
-        b->ext_off[n] = (uint32_t)at;
-        b->ext_nodes.resize((size_t)at);
-        parallel_chunks(n, [&](uint32_t lo, uint32_t hi, uint32_t) {
-            for (uint32_t i = lo; i < hi; ++i) {
-                const uint32_t cnt = b->ext_count[i] == WIN_EXT_DUMMY ? 0u : b->ext_count[i];
-                const WinKept* k = kept.data() + extensions[i].kept_off;
-                for (uint32_t j = 0; j < cnt; ++j) b->ext_nodes[b->ext_off[i] + j] = k[j].node - problems[i].first_node;
-            }
-        });
+        // (page-locked staging: 4 bytes per window node and per problem come down at the link's rate; the batch keeps them in the windows' own layout)
+        uint32_t* st_nodes = (uint32_t*)lease.s->get(4, (ext_nodes_total + 1) * 4); uint32_t* st_count = (uint32_t*)lease.s->get(6, (uint64_t)n * 4);
+        if (!st_nodes || !st_count) return fail(VGK_ENOMEM);
+        if ((rc = be->download_side(st_count, W.ext_count, (size_t)n * 4))) return fail(rc);
+        if ((rc = be->download_side(st_nodes, W.kept_node, (size_t)ext_nodes_total * 4))) return fail(rc);
+        b->ext_count.assign(st_count, st_count + n); b->ext_nodes.assign(st_nodes, st_nodes + ext_nodes_total);
+        b->ext_off.resize((size_t)n + 1);
+        for (uint32_t i = 0; i < n; ++i) b->ext_off[i] = extensions[i].kept_off;
+        b->ext_off[n] = (uint32_t)ext_nodes_total;
         lap("extension nodes");
     }
     b->want_tb = T.want_tb != 0; b->cells = T.cells; b->tb_cells = T.tb_cells; b->in_bytes = T.in_bytes;

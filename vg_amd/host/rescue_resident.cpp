@@ -30,7 +30,7 @@ template <class F> void for_chunks(size_t n, unsigned threads, F body) {
     if (!threads) threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
     const size_t CH = 256;
     threads = (unsigned)std::min<size_t>(threads, std::max<size_t>((n + CH - 1) / CH, 1));
-    if (threads < 2 || n < 2 * CH) { if (n) body((size_t)0, n); return; }
+    if (threads < 2 || n < 2 * CH) { for (size_t i = 0; i < n; i += CH) body(i, std::min(n, i + CH)); return; }      // (always chunk by chunk: callers keep per-chunk buffers)
     std::atomic<size_t> next{0}; std::atomic<bool> failed{false};
     std::mutex first_mutex; std::exception_ptr first;
     auto work = [&]() {
@@ -122,7 +122,6 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
     enum : uint8_t { R_DONE = 0, R_SEEDED = 1, R_SCAN = 2 };
     struct State { uint8_t kind = R_DONE; bool have_head = false, fallback = false, rescore_fallback = false; uint32_t head_node = 0, head_ref = 0, head_query = 0, gap = 1; int32_t slot1 = -1, slot2 = -1, slot3 = -1; };
     std::vector<State> st(n);
-    std::vector<FlatAlignment> alns(n);
     // ---- 0. which requests run at all (:3352-3381), dozeu's seed or the scan (calculate_seed_position / scan_seed_position)
     for_chunks(n, host_threads, [&](size_t lo, size_t hi) {
         for (size_t k = lo; k < hi; ++k) {
@@ -205,11 +204,37 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
     round(ext2, none, true, er, eo, wr, wo);
     if (timing) timing->second_pass += ext2.size();
     lap(&RescueTiming::second_pass_ms);
-    // ---- 3. the alignments (xdrop_extend_finish + xdrop_finish), fix_dozeu_score's verdict
+    // ---- 3. the alignments (xdrop_extend_finish + xdrop_finish), fix_dozeu_score's verdict; what it accepts gets its answer at once
+    // (one FlatAlignment per host thread, the op runs of a chunk of mates behind each other in the chunk's own buffer: no allocation per mate)
+    const bool want_ops = out_ops && out_ops_begin;
+    const size_t CH = 256, n_chunks = (n + CH - 1) / CH;
+    std::vector<std::vector<vgk_op>> chunk_ops(want_ops ? n_chunks : 0);
+    std::vector<uint32_t> op_at(want_ops ? n : 0, 0), op_count(n, 0);                      // where in its chunk's buffer a mate's runs start; how many
+    // fix_dozeu_end_deletions, the answer, the op runs (match / substitution stretches merged into M runs)
+    auto answer = [&](FlatAlignment& a, size_t k, std::vector<vgk_op>* sink) {
+        RescueResult& out = results[k];
+        fix_end_deletions(a);
+        out.score = a.score; out.n_mappings = (uint32_t)a.maps.size();
+        if (!a.maps.empty()) { out.first_node = a.maps.front().node; out.first_offset = a.maps.front().offset; }
+        uint32_t to = 0, runs = 0;
+        for (const FMapping& m : a.maps) {
+            int prev = -1;
+            for (uint32_t j = 0; j < m.n_edits; ++j) {
+                const FEdit& e = a.edits[m.first_edit + j];
+                if (e.kind == E_MATCH || e.kind == E_SUB) to += e.len;
+                const int op = e.kind <= E_SUB ? VGK_OP_M : e.kind == E_DEL ? VGK_OP_D : VGK_OP_I;
+                if (op == VGK_OP_M && prev == VGK_OP_M) { if (sink) sink->back().len = (uint16_t)(sink->back().len + e.len); }
+                else { ++runs; if (sink) { vgk_op o{}; o.node = m.node; o.op = (uint8_t)op; o.len = (uint16_t)e.len; sink->push_back(o); } }
+                prev = op;
+            }
+        }
+        out.aligned_read_bases = to; op_count[k] = runs;
+    };
     for_chunks(n, host_threads, [&](size_t lo, size_t hi) {
-        std::vector<vgk_op> ops;
+        std::vector<vgk_op> ops; FlatAlignment a;
+        std::vector<vgk_op>* sink = want_ops ? &chunk_ops[lo / CH] : nullptr;
         for (size_t k = lo; k < hi; ++k) {
-            State& s = st[k]; const RescueRequestFlat& rq = requests[k]; FlatAlignment& a = alns[k];
+            State& s = st[k]; const RescueRequestFlat& rq = requests[k];
             if (s.kind == R_DONE || !s.have_head) continue;
             const char* read = reads + rq.read_off;
             a.clear();
@@ -263,7 +288,8 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
             }
             // MinimizerMapper::fix_dozeu_score (:3502-3517)
             const int32_t rescored = score_contiguous(a, sc);
-            if (rescored > 0) a.score = rescored; else s.fallback = true;                              // not worth keeping: the full DP instead (:3510-3515)
+            if (rescored > 0) { a.score = rescored; if (sink) op_at[k] = (uint32_t)sink->size(); answer(a, k, sink); }
+            else s.fallback = true;                                                                    // not worth keeping: the full DP instead (:3510-3515)
         }
     });
     lap(&RescueTiming::finish_ms);
@@ -278,9 +304,11 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
     std::vector<vgk_extension_problem> no_ext;
     if (!full.empty()) round(no_ext, full, true, er, eo, wr, wo);
     if (timing) timing->fallbacks += full.size();
+    std::vector<std::vector<vgk_op>> full_ops(want_ops ? full.size() : 0);                 // (the few mates that took the full DP keep their runs apart)
     for_chunks(full.size(), host_threads, [&](size_t lo, size_t hi) {
+        FlatAlignment a;
         for (size_t q = lo; q < hi; ++q) {
-            const size_t k = full_of[q]; State& s = st[k]; const RescueRequestFlat& rq = requests[k]; FlatAlignment& a = alns[k]; const vgk_result& r = wr[q];
+            const size_t k = full_of[q]; State& s = st[k]; const RescueRequestFlat& rq = requests[k]; const vgk_result& r = wr[q];
             const char* read = reads + rq.read_off;
             // gssw_mapping_to_alignment (src/aligner.cpp:120-241) over the op list: matches and single-base substitutions by character (the node's
             // bases as gssw saw them: nonATGCNtoN), every insertion / soft clip an edit of its own
@@ -313,49 +341,21 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
                 const int32_t rescored = score_contiguous(a, sc);
                 if (rescored > 0) a.score = rescored;                                        // (else: cleared and aligned again — the same alignment, gssw's score)
             }
+            answer(a, k, want_ops ? &full_ops[q] : nullptr);
         }
     });
     lap(&RescueTiming::fallback_ms);
-    // ---- 5. fix_dozeu_end_deletions, the answers
-    std::vector<uint64_t> n_ops(n + 1, 0);
-    for_chunks(n, host_threads, [&](size_t lo, size_t hi) {
-        for (size_t k = lo; k < hi; ++k) {
-            const State& s = st[k]; FlatAlignment& a = alns[k]; RescueResult& out = results[k];
-            if (s.kind == R_DONE) continue;
-            fix_end_deletions(a);
-            out.score = a.score; out.n_mappings = (uint32_t)a.maps.size();
-            if (!a.maps.empty()) { out.first_node = a.maps.front().node; out.first_offset = a.maps.front().offset; }
-            uint32_t to = 0; uint64_t runs = 0;
-            for (const FMapping& m : a.maps) {
-                int prev = -1;
-                for (uint32_t j = 0; j < m.n_edits; ++j) {
-                    const FEdit& e = a.edits[m.first_edit + j];
-                    if (e.kind == E_MATCH || e.kind == E_SUB) to += e.len;
-                    const int op = e.kind <= E_SUB ? VGK_OP_M : e.kind == E_DEL ? VGK_OP_D : VGK_OP_I;
-                    if (op != prev || op != VGK_OP_M) ++runs;
-                    prev = op;
-                }
-            }
-            out.aligned_read_bases = to; n_ops[k + 1] = runs;
-        }
-    });
-    if (out_ops && out_ops_begin) {
-        for (size_t k = 0; k < n; ++k) n_ops[k + 1] += n_ops[k];
-        out_ops->assign((size_t)n_ops[n], vgk_op{}); *out_ops_begin = n_ops;
+    // ---- 5. the op runs, request by request
+    if (want_ops) {
+        std::vector<uint64_t>& begin = *out_ops_begin;
+        begin.assign(n + 1, 0);
+        for (size_t k = 0; k < n; ++k) begin[k + 1] = begin[k] + op_count[k];
+        out_ops->resize((size_t)begin[n]);
         for_chunks(n, host_threads, [&](size_t lo, size_t hi) {
             for (size_t k = lo; k < hi; ++k) {
-                const FlatAlignment& a = alns[k]; if (st[k].kind == R_DONE) continue;
-                vgk_op* o = out_ops->data() + n_ops[k];
-                for (const FMapping& m : a.maps) {
-                    int prev = -1;
-                    for (uint32_t j = 0; j < m.n_edits; ++j) {
-                        const FEdit& e = a.edits[m.first_edit + j];
-                        const int op = e.kind <= E_SUB ? VGK_OP_M : e.kind == E_DEL ? VGK_OP_D : VGK_OP_I;
-                        if (op == VGK_OP_M && prev == VGK_OP_M) { (o - 1)->len = (uint16_t)((o - 1)->len + e.len); }
-                        else { o->node = m.node; o->op = (uint8_t)op; o->len = (uint16_t)e.len; o->pad = 0; ++o; }
-                        prev = op;
-                    }
-                }
+                if (!op_count[k]) continue;
+                const vgk_op* src = st[k].fallback ? full_ops[(size_t)st[k].slot3].data() : chunk_ops[k / CH].data() + op_at[k];
+                std::copy(src, src + op_count[k], out_ops->data() + begin[k]);
             }
         });
     }

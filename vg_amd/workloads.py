@@ -961,6 +961,17 @@ class PairedWorkload:
         self.succ_off = np.concatenate([[0], np.cumsum(np.bincount(src, minlength=g.n_nodes))]).astype(np.uint32)
         self.succ = dst[e].astype(np.uint32)
 
+    def batch(self, a, b):
+        """pairs [a, b) as a workload of their own (same graph; the reads are a view)"""
+        w = object.__new__(PairedWorkload)
+        w.__dict__.update(self.__dict__)
+        L = self.read_len
+        w.reads = self.reads[2 * a * L:2 * b * L]; w.read_off = self.read_off[:2 * (b - a) + 1]
+        w.n_pairs = b - a; w.n = 2 * (b - a)
+        t = self.truth; hard = t["hard"][(t["hard"] >= a) & (t["hard"] < b)] - a
+        w.truth = dict(t, hap=t["hap"][a:b], start=t["start"][a:b], frag=t["frag"][a:b], flip=t["flip"][a:b], hard=hard)
+        return w
+
     def subset(self, k):
         """the first k pairs as a workload of their own (same graph, same reads)"""
         w = object.__new__(PairedWorkload)
