@@ -184,8 +184,73 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) try
 // The records as the kernels read them, from the tables either builder makes (this file's, from threads; gbwt_file.cpp's, straight from
 // a GBWT's own records): per oriented node its visits (count), per visit the edge it leaves through (body, from body_off), its edges in
 // successor order (edge_to from edge_off; -1 = the path ends here, first) and per edge the rank of its first visit in the successor's record.
+// Unary runs merged (gapless_device.hpp GMerge): runs of consecutive nodes v, v + 1, ... where every visit of 2 v leaves through the one edge to
+// 2 (v + 1) and every visit of 2 (v + 1) arrives that way (rank offset 0, equal visit counts), the same on the other strand, at most 255 bases
+// together.  The merged node takes the visits of its first node and the edges and visit bodies of its last (in either orientation); its bases
+// are the run's, which already lie behind each other.  -> VGK_OK with h->merged set, or with nothing set when no two nodes merge.
+static int merge_unary_runs(vgk_ctx* ctx, vgk_haplo* h, uint32_t O, const std::vector<uint32_t>& len, const std::vector<char>& seq, uint32_t total, const HaploTables& T) {
+    const uint32_t N = O / 2;
+    if (N < 2 || std::getenv("VGAMD_HAPLO_NO_MERGE")) return VGK_OK;
+    auto unary = [&](uint32_t o, uint32_t p) {
+        return T.count[o] > 0 && T.edge_off[o + 1] - T.edge_off[o] == 1 && T.edge_to[T.edge_off[o]] == (int32_t)p && T.edge_base[T.edge_off[o]] == 0 && T.count[p] == T.count[o];
+    };
+    constexpr uint32_t MAX_RUN_BASES = 255;                 // the fast kernel's entries hold 8-bit offsets (gapless_device.hpp GStoreLds)
+    std::vector<uint32_t> run_first; std::vector<uint32_t> run_of(N);
+    uint32_t bases = 0;
+    for (uint32_t v = 0; v < N; ++v) {
+        const bool joins = v > 0 && unary(2 * (v - 1), 2 * v) && unary(2 * v + 1, 2 * (v - 1) + 1) && bases + len[2 * v] <= MAX_RUN_BASES;
+        if (!joins) { run_first.push_back(v); bases = 0; }
+        bases += len[2 * v];
+        run_of[v] = (uint32_t)run_first.size() - 1;
+    }
+    const uint32_t M = (uint32_t)run_first.size();
+    if (M == N) return VGK_OK;
+    run_first.push_back(N);
+    std::vector<uint32_t> ocol((size_t)N + 1, 0);
+    for (uint32_t v = 0; v < N; ++v) ocol[v + 1] = ocol[v] + len[2 * v];
+    std::vector<uint32_t> mlen(M);
+    for (uint32_t m = 0; m < M; ++m) mlen[m] = ocol[run_first[m + 1]] - ocol[run_first[m]];
+    HaploTables U;
+    U.count.assign(2 * M, 0); U.body_off.assign(2 * (size_t)M + 1, 0); U.edge_off.assign(2 * (size_t)M + 1, 0);
+    for (uint32_t mo = 0; mo < 2 * M; ++mo) {
+        const uint32_t m = mo >> 1, v0 = run_first[m], v1 = run_first[m + 1];
+        const uint32_t first = (mo & 1u) ? 2 * (v1 - 1) + 1 : 2 * v0, last = (mo & 1u) ? 2 * v0 + 1 : 2 * (v1 - 1);
+        U.count[mo] = T.count[first];
+        if (T.count[last] != T.count[first]) return VGK_OK;                              // (cannot happen; the original index is complete either way)
+        U.body.insert(U.body.end(), T.body.begin() + T.body_off[last], T.body.begin() + T.body_off[last + 1]);
+        U.body_off[mo + 1] = (uint32_t)U.body.size();
+        for (uint32_t e = T.edge_off[last]; e < T.edge_off[last + 1]; ++e) {
+            const int32_t to = T.edge_to[e];
+            int32_t mt = -1;
+            if (to >= 0) {
+                const uint32_t tv = (uint32_t)to >> 1, tm = run_of[tv];
+                if (((uint32_t)to & 1u) ? tv + 1 != run_first[tm + 1] : tv != run_first[tm]) return VGK_OK;      // a successor inside a run: not a unary run after all
+                mt = (int32_t)(2 * tm + ((uint32_t)to & 1u));
+            }
+            U.edge_to.push_back(mt); U.edge_base.push_back(T.edge_base[e]);
+        }
+        U.edge_off[mo + 1] = (uint32_t)U.edge_to.size();
+    }
+    U.edge_base.push_back(0);
+    std::vector<uint32_t> mlen2, mseq_off; std::vector<char> mseq; uint64_t mtotal = 0;
+    int rc = vgk_haplo_strands(M, mlen.data(), seq.data() + 8, mlen2, mseq_off, mseq, mtotal);      // (the forward strands of the runs ARE the forward strands of the nodes, in a row)
+    if (rc || mtotal != total) return rc;
+    vgk_haplo* mh = nullptr;
+    if ((rc = vgk_haplo_from_tables(ctx, 2 * M, mlen2, mseq_off, mseq, total, U, &mh, false))) return rc;
+    std::vector<uint64_t> seed_map(O);
+    for (uint32_t o = 0; o < O; ++o) {
+        const uint32_t v = o >> 1, m = run_of[v], v0 = run_first[m], v1 = run_first[m + 1];
+        const uint32_t off = (o & 1u) ? ocol[v1] - ocol[v + 1] : ocol[v] - ocol[v0];
+        seed_map[o] = (uint64_t)(2 * m + (o & 1u)) | ((uint64_t)off << 32);
+    }
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if ((rc = put(h, seed_map, h->merge.seed_map)) || (rc = put(h, run_first, h->merge.run_first)) || (rc = put(h, ocol, h->merge.ocol)) || (rc = ctx->be->sync())) { vgk_haplo_destroy(mh); return rc; }
+    h->merge.on = 1; h->merge.n_orig_oriented = O; h->merged = mh;
+    return VGK_OK;
+}
+
 extern "C++" int vgk_haplo_from_tables(vgk_ctx* ctx, uint32_t O, const std::vector<uint32_t>& len, const std::vector<uint32_t>& seq_off, const std::vector<char>& seq, uint32_t total,
-                          const HaploTables& T, vgk_haplo** out) {
+                          const HaploTables& T, vgk_haplo** out, bool merge_runs) {
     const std::vector<uint32_t>& count = T.count; const std::vector<uint32_t>& body_off = T.body_off; const std::vector<uint32_t>& body = T.body;
     const std::vector<uint32_t>& edge_off = T.edge_off; const std::vector<int32_t>& edge_to = T.edge_to; const std::vector<uint32_t>& edge_base = T.edge_base;
     // one padded record per oriented node (layout in gapless_device.hpp): sizes first, so that every edge can name its successor's
@@ -229,7 +294,7 @@ extern "C++" int vgk_haplo_from_tables(vgk_ctx* ctx, uint32_t O, const std::vect
     rec_off[O] = (uint32_t)rec.size();
     vgk_haplo* h = new vgk_haplo();
     h->ctx = ctx; h->n_oriented = O; h->len = len;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::unique_lock<std::mutex> lock(ctx->mu);
     int rc;
     h->dev.n_oriented = O; h->dev.strand_shift = (uint32_t)total;
     h->dev.max_node_len = 0; h->dev.max_visits = 0;          // what the fast kernel's compact entries have to hold (gapless_device.hpp)
@@ -240,12 +305,15 @@ extern "C++" int vgk_haplo_from_tables(vgk_ctx* ctx, uint32_t O, const std::vect
         for (void* p : h->held) ctx->be->release(p);
         delete h; return rc;
     }
+    lock.unlock();
+    if (merge_runs && (rc = merge_unary_runs(ctx, h, O, len, seq, total, T))) { vgk_haplo_destroy(h); return rc; }
     *out = h;
     return VGK_OK;
 }
 
 void vgk_haplo_destroy(vgk_haplo* h) {
     if (!h) return;
+    if (h->merged) vgk_haplo_destroy(h->merged);
     { std::lock_guard<std::mutex> lock(h->ctx->mu); for (void* p : h->held) h->ctx->be->release(p); }
     delete h;
 }
@@ -464,7 +532,7 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
         return d;
     };
     GaplessParams P{};
-    P.index = index->dev; P.n = n;
+    P.index = index->merged ? index->merged->dev : index->dev; P.merge = index->merge; P.n = n;
     P.probs = (const GProb*)dev(probs.data(), sizeof(GProb) * n);
     P.reads = (const char*)dev(nullptr, n_read + 16);                  // 8 bytes of padding at either end
     if (P.reads && n_read && be->upload(const_cast<char*>(P.reads) + 8, reads_in_a_row ? read0 : reads + 8, n_read)) return VGK_ENODEV;
@@ -529,7 +597,7 @@ int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max
     if (!rc) rc = be->sort_pairs_u32(d_sort, d_sort + 2 * (size_t)n, d_sort + n, d_sort + 3 * (size_t)n, n, bits);
     if (rc) return rc;
     GaplessParams P{};
-    P.index = index->dev; P.n = n;
+    P.index = index->merged ? index->merged->dev : index->dev; P.merge = index->merge; P.n = n;
     P.probs = d_probs; P.reads = ctx->seeded.reads; P.seeds = ctx->seeded.seeds; P.order = d_sort + 3 * (size_t)n;
     lap("descriptors and order on the device");
     return gapless_run_and_fetch(ctx, P, n, n_seed, next_slot, H, lap, results, extensions, ext_cap, nodes, nodes_cap, mismatches, mism_cap, written, (flags & VGK_GAPLESS_DEFER) != 0);

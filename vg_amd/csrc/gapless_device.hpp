@@ -56,6 +56,20 @@ VGK_HD bool g_rle(const uint32_t* rec) { return (rec[1] >> 31) != 0; }         /
 VGK_HD const uint32_t* g_visits(const uint32_t* rec) { return rec + 4 + 4 * g_ne(rec); }
 struct GProb { uint32_t read_off, read_len, seed_off, n_seeds, max_mm, flags; double overlap; };
 
+// Unary runs merged at index build (gapless_api.cpp merge_unary_runs): the search and the set rules run on an index whose nodes are maximal
+// runs of CONSECUTIVE nodes v, v + 1, ... in which every visit of a node leaves through the one edge to the next and every visit of the next
+// arrives that way — so a search state's ranges map through unchanged — of at most 255 bases together (the fast kernel's 8-bit offsets).  A
+// read of 150 bases over nodes of at most 32 then crosses one or two records per direction instead of five to ten dependent hops; what the
+// reference does per problem for WFA (WFANode: unary paths up to 1 024 bp, src/gbwt_extender.cpp:1431-1487) is done once per index.  Seeds
+// come in and extension sets go out in ORIGINAL nodes: seed_map translates a seed on its way in, the emit stage expands a merged path into the
+// original nodes its aligned interval touches.  on == 0: the index is the original one, nothing is translated.
+struct GMerge {
+    uint32_t on, n_orig_oriented;
+    const uint64_t* seed_map;        // per ORIGINAL oriented node: merged oriented node (low word) | offset of its first base in that node (high word)
+    const uint32_t* run_first;       // per merged node m: first original node of its run (run_first[m + 1] - 1 = the last)
+    const uint32_t* ocol;            // per original node v: bases of the nodes before it (ocol[n_nodes] = all)
+};
+
 struct GState { int32_t fn, flo, fhi, bn, blo, bhi; };      // forward / backward strand: node, visit range [lo, hi]
 VGK_HD bool gs_empty(const GState& s) { return s.flo > s.fhi; }
 VGK_HD uint32_t gs_size(const GState& s) { return s.flo > s.fhi ? 0u : (uint32_t)(s.fhi - s.flo + 1); }
@@ -267,7 +281,8 @@ struct GRes {                          // the G_SEEDS winners of a read as one a
 };
 
 struct GaplessParams {
-    GIndex index;
+    GIndex index;                     // what the search walks: the merged index when merge.on
+    GMerge merge;
     const GProb* probs; uint32_t n;
     const uint32_t* order;            // the order the threads take the problems in: sorted by the node of the first seed, so that the reads of a
                                       // wavefront (and of the wavefronts around it) walk the same few records and bases of the index
@@ -295,6 +310,24 @@ VGK_HD unsigned long long g_bump(unsigned long long* counter, unsigned long long
 }
 
 struct GCtx { const GaplessParams* P; const char* seq; uint32_t L; };
+
+// seed `idx` of the batch as the search sees it.  status: VGK_OK, G_BADNODE (node outside the index) — with merged runs the node and the
+// diagonal are those on the merged node, `seed_end` the offset in that node where the ORIGINAL seed node ends (the initial match with any
+// number of mismatches covers the seed node only, :213-237) and `orig_len` that node's length (the offset check is against it)
+struct GSeedIn { int32_t node; int64_t diff; uint32_t seed_begin, seed_end, orig_len; };
+VGK_HD bool g_seed_in(const GaplessParams& P, uint32_t idx, GSeedIn& out) {
+    const vgk_seed sd = P.seeds[idx];
+    if (!P.merge.on) {
+        if (sd.node >= P.index.n_oriented) return false;
+        out.node = (int32_t)sd.node; out.diff = sd.diff; out.seed_begin = 0; out.orig_len = g_len(P.index, (int32_t)sd.node); out.seed_end = out.orig_len;
+        return true;
+    }
+    if (sd.node >= P.merge.n_orig_oriented) return false;
+    const uint64_t mp = P.merge.seed_map[sd.node];
+    const uint32_t v = sd.node >> 1, olen = P.merge.ocol[v + 1] - P.merge.ocol[v], off = (uint32_t)(mp >> 32);
+    out.node = (int32_t)(uint32_t)mp; out.diff = (int64_t)sd.diff - (int64_t)off; out.seed_begin = off; out.seed_end = off + olen; out.orig_len = olen;
+    return true;
+}
 
 // Eight bases per compare, like the reference's memcpy'd uint64 words (:219-224).  Both buffers carry 8 bytes of padding at
 // either end, so a word that straddles the end of the data stays inside the allocation.
@@ -677,15 +710,18 @@ constexpr int32_t G_BADNODE = 2, G_BADOFF = 3;          // winner statuses (besi
 template <class ST>
 VGK_HD int g_search_begin(const GaplessParams& P, const GCtx& c, const GProb& pb, uint32_t si, ST& Q, GSearch& s) {
     const GIndex& h = P.index;
-    const vgk_seed sd = P.seeds[pb.seed_off + si];
-    const int32_t snode = (int32_t)sd.node; const int64_t diff = sd.diff;
-    if ((uint32_t)snode >= h.n_oriented) return G_BADNODE;
+    GSeedIn sin;
+    if (!g_seed_in(P, pb.seed_off + si, sin)) return G_BADNODE;
     const uint32_t L = pb.read_len;
-    const uint32_t read_offset = diff < 0 ? 0u : (uint32_t)diff, node_offset = diff < 0 ? (uint32_t)(-diff) : 0u;
+    // (the seed's own offsets are those on the ORIGINAL node: read_offset - node_offset = the caller's diff; the merged node adds seed_begin)
+    const int64_t diff0 = sin.diff + (int64_t)sin.seed_begin;
+    const uint32_t read_offset = diff0 < 0 ? 0u : (uint32_t)diff0, node_offset0 = diff0 < 0 ? (uint32_t)(-diff0) : 0u;
+    if (read_offset > L || node_offset0 > sin.orig_len) return G_BADOFF;
+    const int32_t snode = sin.node;
+    const uint32_t node_offset = node_offset0 + sin.seed_begin;
     const uint32_t ro_f = h.rec_off[(uint32_t)snode], ro_b = h.rec_off[(uint32_t)snode ^ 1u];
     const GQuad hf = g_quad(h.rec + ro_f), hb = g_quad(h.rec + ro_b);           // {visits, edges, length, bases} of the seed node on either strand
     const uint32_t slen = hf.z;
-    if (read_offset > L || node_offset > slen) return G_BADOFF;
     s.np = 0; s.hn = 0; s.number = 0; s.have_cand = false; s.cand_idx = 0; s.best = -1; s.L = L; s.max_mm = pb.max_mm;
     s.best_e.score = 0; s.best_e.rr = 0;
     Q.begin_seed();
@@ -695,11 +731,22 @@ VGK_HD int g_search_begin(const GaplessParams& P, const GCtx& c, const GProb& pb
     m.left_full = m.right_full = m.left_max = m.right_max = 0; m.pad[0] = m.pad[1] = m.pad[2] = 0; m.frec = ro_f; m.brec = ro_b;
     m.state.fn = snode; m.state.flo = 0; m.state.fhi = (int32_t)hf.x - 1; m.state.bn = snode ^ 1; m.state.blo = 0; m.state.bhi = (int32_t)hb.x - 1;      // gs_find
     const char* t = h.seq + hf.w;
-    const uint32_t left = L - m.r1 < slen - node_offset ? L - m.r1 : slen - node_offset;
+    const uint32_t left = L - m.r1 < sin.seed_end - node_offset ? L - m.r1 : sin.seed_end - node_offset;
     m.r1 += g_match_fwd(c.seq + m.r1, t + node_offset, left, m.internal, 0xffffffffu);
     m.old = m.internal;
     if (m.r0 == 0) m.left_full = m.left_max = 1;
     if (m.r1 >= L) m.right_full = m.right_max = 1;
+    else if (sin.seed_end < slen) {
+        // merged runs: the seed node ends inside the merged node — what follows in it are the run's next nodes, which match_forward (:239-266) would
+        // take one by one under the mismatch limit: here in one piece, and where it stops the entry is right-maximal exactly as the node-by-node
+        // form leaves it (a next node that matches nothing is dropped and the state kept as right-maximal, :617-619, :633-637)
+        const uint32_t lim_a = pb.max_mm + 1, lim_b = pb.max_mm / 2 + m.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
+        const uint32_t rest = slen - sin.seed_end, room = L - m.r1 < rest ? L - m.r1 : rest;
+        const uint32_t no = g_match_fwd(c.seq + m.r1, t + sin.seed_end, room, m.internal, limit);
+        m.r1 += no;
+        if (m.r1 >= L) { m.right_full = m.right_max = 1; m.old = m.internal; }
+        else if (no < rest) { m.right_max = 1; m.old = m.internal; }
+    }
     g_set_score(c, m); m.number = s.number++;
     Q.link_set(s.np, m);
     s.cand = g_lean(m); s.cand_idx = s.np; s.have_cand = true; ++s.np;
@@ -728,6 +775,28 @@ VGK_HD int g_search_step(const GaplessParams& P, const GCtx& c, ST& Q, GSearch& 
     // same instructions — which record, which state, which way the bases are compared are data — because in a wavefront there are
     // always lanes going either way, and two code paths would each be paid by all of them.
     const bool right = !cur.right_max;
+    if (!right && !cur.left_max && cur.offset > 0) {
+        // merged runs: the path's first node has bases before the alignment (the seed node lies inside a run): the run's earlier nodes, which
+        // match_backward (:268-296) would take one by one — in one piece, the same limit, the same flags where it stops
+        const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
+        const uint32_t first = (uint32_t)cur.state.bn ^ 1u;
+        const char* t = h.seq + g_seq_off(h, first) + cur.offset;                        // one past the last base before the alignment
+        const uint32_t room = cur.r0 < cur.offset ? cur.r0 : cur.offset;
+        GEntry nx = cur; nx.parent = (int32_t)ci; nx.node = -1;
+        const uint32_t no = g_match_dir(c.seq + nx.r0, t, room, nx.internal, limit, true);
+        if (no == 0) cur.left_max = 1;                                                   // (a node that matches nothing is dropped: the entry is left-maximal as it stands)
+        else {
+            if (s.np >= ST::ENTRIES) return ST::FULL;
+            nx.r0 -= no; nx.offset -= no;
+            if (nx.r0 == 0) nx.left_full = nx.left_max = 1;
+            else if (nx.offset > 0) nx.left_max = 1;
+            g_set_score(c, nx); nx.number = s.number++;
+            Q.link_set(s.np, nx);
+            if (!g_offer(Q, s.hn, s.have_cand, s.cand, s.cand_idx, nx, s.np)) return ST::FULL;
+            ++s.np;
+            return VGK_OK;
+        }
+    }
     if (right || !cur.left_max) {
         uint32_t num_ext = 0; bool found = false;
         const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
@@ -807,6 +876,31 @@ VGK_HD int g_search_end(const ST& Q, const GSearch& s, GExt& r) {
     return VGK_OK;
 }
 
+// merged runs: the ORIGINAL oriented nodes an extension's aligned interval touches, in path order -> their number; out (nullable): written there;
+// first_offset (nullable): in: the offset in the first merged node, out: the offset in the first original node
+VGK_HD uint32_t gx_expand(const GaplessParams& P, const GExt& e, uint32_t* out, uint32_t* first_offset) {
+    const GMerge& M = P.merge;
+    uint32_t n = 0, left = e.r1 - e.r0, a = e.offset;
+    for (uint32_t i = 0; i < e.path_len && left; ++i) {
+        const uint32_t mo = (uint32_t)e.path[i], m = mo >> 1, rev = mo & 1u;
+        const uint32_t v0 = M.run_first[m], v1 = M.run_first[m + 1];                        // original nodes [v0, v1)
+        const uint32_t mlen = M.ocol[v1] - M.ocol[v0];
+        const uint32_t b = a + left < mlen ? a + left : mlen;                                // the interval [a, b) of the merged node
+        // original node k of the run in path direction starts at s_k: forward v0 + k at ocol[v0 + k] - ocol[v0]; reverse v1 - 1 - k at ocol[v1] - ocol[v1 - k]
+        for (uint32_t k = 0; k < v1 - v0; ++k) {
+            const uint32_t v = rev ? v1 - 1u - k : v0 + k;
+            const uint32_t s0 = rev ? M.ocol[v1] - M.ocol[v + 1] : M.ocol[v] - M.ocol[v0], s1 = s0 + (M.ocol[v + 1] - M.ocol[v]);
+            if (s1 <= a) continue;
+            if (s0 >= b) break;
+            if (n == 0 && first_offset) *first_offset = a - s0;
+            if (out) out[n] = 2u * v + rev;
+            ++n;
+        }
+        left -= b - a; a = 0;
+    }
+    return n;
+}
+
 // The rules over a read's winners (the second half of GaplessExtender::extend): RES(i) = the i-th USED winner, n_res of them, in seed
 // order; best_alignment as the seed loop left it.  `order` = n_res bytes of scratch for the permutation the rules sort.
 template <class RESV>
@@ -847,9 +941,9 @@ VGK_HD void gapless_set_rules(const GaplessParams& P, uint32_t pi, const GProb& 
         if (trimmed) n_out = gx_remove_duplicates(RES, order, n_out);
     }
     if (overflow) { out.status = VGK_ETOOBIG; return; }
-    // hand the set out
+    // hand the set out (merged runs: in the ORIGINAL nodes the aligned interval touches — gx_expand)
     uint32_t nn = 0, nm = 0;
-    for (uint32_t i = 0; i < n_out; ++i) { nn += RES[order[i]].path_len; nm += RES[order[i]].n_mism; }
+    for (uint32_t i = 0; i < n_out; ++i) { nn += P.merge.on ? gx_expand(P, RES[order[i]], nullptr, nullptr) : RES[order[i]].path_len; nm += RES[order[i]].n_mism; }
     const unsigned long long e0 = g_bump(P.counters + 0, n_out), n0 = g_bump(P.counters + 1, nn), m0 = g_bump(P.counters + 2, nm);
     if (e0 + n_out > P.caps[0] || n0 + nn > P.caps[1] || m0 + nm > P.caps[2]) { out.status = VGK_EOPS; return; }
     out.ext_begin = (uint32_t)e0; out.n_ext = n_out;
@@ -862,13 +956,20 @@ VGK_HD void gapless_set_rules(const GaplessParams& P, uint32_t pi, const GProb& 
         x.pad[0] = x.pad[1] = 0;
         x.state[0] = (uint32_t)e.state.fn; x.state[1] = (uint32_t)e.state.flo; x.state[2] = (uint32_t)e.state.fhi;
         x.state[3] = (uint32_t)e.state.bn; x.state[4] = (uint32_t)e.state.blo; x.state[5] = (uint32_t)e.state.bhi;
-        P.ext[e0 + i] = x;
+        uint32_t plen = e.path_len;
+        if (P.merge.on) {
+            uint32_t first_off = e.offset;
+            plen = gx_expand(P, e, P.nodes + n0 + na, &first_off);
+            x.path_len = plen; x.offset = first_off;
+            if (plen) { x.state[0] = P.nodes[n0 + na + plen - 1]; x.state[3] = P.nodes[n0 + na] ^ 1u; }      // the states' nodes: the last / the first original node (their ranges run through a run unchanged)
+        } else
         for (uint32_t k = 0; k < e.path_len; ++k) P.nodes[n0 + na + k] = (uint32_t)e.path[k];
+        P.ext[e0 + i] = x;
         if (e.n_mism) {
             if (order[i] == mm_owner) for (uint32_t k = 0; k < e.n_mism; ++k) P.mism[m0 + ma + k] = mm[k];
             else { GExt& me = RES[order[i]]; bool ov = false; gx_find_mismatches(c, me, P.mism + m0 + ma, ov); }      // written straight to the output
         }
-        na += e.path_len; ma += e.n_mism;
+        na += plen; ma += e.n_mism;
     }
 }
 
@@ -888,9 +989,9 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, ST& Q, GScra
     uint32_t n_res = 0, best_alignment = 0xffffffffu;
     int status = VGK_OK;
     for (uint32_t si = 0; si < pb.n_seeds && status == VGK_OK; ++si) {
-        const vgk_seed sd = P.seeds[pb.seed_off + si];
-        if (sd.node >= h.n_oriented) { status = VGK_EINVAL; break; }
-        if (best_alignment < n_res && RES[best_alignment].internal == 0 && gx_contains(h, RES[best_alignment], (int32_t)sd.node, sd.diff)) continue;
+        GSeedIn sd;
+        if (!g_seed_in(P, pb.seed_off + si, sd)) { status = VGK_EINVAL; break; }
+        if (best_alignment < n_res && RES[best_alignment].internal == 0 && gx_contains(h, RES[best_alignment], sd.node, sd.diff)) continue;
         GSearch s; s.prof = nullptr;
         const int b = g_search_begin(P, c, pb, si, Q, s);
         if (b != VGK_OK) { status = VGK_EINVAL; break; }
@@ -949,11 +1050,11 @@ VGK_HD void gapless_search_lane(const GaplessParams& P, ST& Q, GScratch& S, W& w
                     else if (ST::FULL == G_RETRY && (pb.read_len > 255u || h.max_node_len > 255u || h.max_visits > 254u)) status = G_RETRY;
                     continue;
                 }
-                const vgk_seed sd = P.seeds[pb.seed_off + si];
-                if (sd.node >= h.n_oriented) { status = VGK_EINVAL; continue; }
+                GSeedIn sd;
+                if (!g_seed_in(P, pb.seed_off + si, sd)) { status = VGK_EINVAL; continue; }
                 if (best_alignment != NONE) {
                     const GExt& ba = P.winners[pb.seed_off + best_alignment];
-                    if (ba.internal == 0 && gx_contains_diag(ba, S.diag, (int32_t)sd.node, sd.diff)) { ++si; continue; }
+                    if (ba.internal == 0 && gx_contains_diag(ba, S.diag, sd.node, sd.diff)) { ++si; continue; }
                 }
                 if (g_search_begin(P, c, pb, si, Q, s) != VGK_OK) { status = VGK_EINVAL; continue; }
                 ++si; searching = true;

@@ -34,7 +34,15 @@ void build_rescue_requests(uint32_t n_pairs, const vgk_gapless_result* res, cons
     // a reverse-mapped mate ending at column e: upstream on the forward strand
     const double lo_d = std::max(0.0, mean - stdevs * sd - (double)L), hi_d = (mean + stdevs * sd) * 1.1 + 40.0;
     const int64_t* col_end = col + n_nodes + 1;
-    auto upper = [&](double x) { return (int64_t)(std::upper_bound(col, col_end, x, [](double v, int64_t c) { return v < (double)c; }) - col); };      // numpy searchsorted(side = "right")
+    // numpy searchsorted(col, x, side = "right") = the first node whose first column lies beyond x — looked for from `near` outwards: the rescue window
+    // lies a fragment's length from the mapped mate, a few dozen nodes, and a binary search over the whole table is seventeen cache misses
+    auto upper = [&](double x, int64_t near) {
+        int64_t lo = near, hi = near, step = 16;
+        while (lo > 0 && !((double)col[lo] <= x)) { lo = std::max<int64_t>(0, lo - step); step *= 2; }                 // col[lo] <= x (or lo = 0)
+        step = 16;
+        while (hi < (int64_t)n_nodes + 1 && !(x < (double)col[hi])) { hi = std::min<int64_t>((int64_t)n_nodes + 1, hi + step); step *= 2; }   // x < col[hi] (or hi = past the end)
+        return (int64_t)(std::upper_bound(col + lo, std::min(col + hi + 1, col_end), x, [](double v, int64_t c) { return v < (double)c; }) - col);
+    };
     auto olen = [&](uint32_t oriented) { return col[(oriented >> 1) + 1] - col[oriented >> 1]; };
     chunks(n_pairs, host_threads, [&](size_t plo, size_t phi) {
         for (size_t p = plo; p < phi; ++p) {
@@ -47,8 +55,8 @@ void build_rescue_requests(uint32_t n_pairs, const vgk_gapless_result* res, cons
             const bool fwd = (first & 1u) == 0;
             const double s_col = (double)(col[first >> 1] + (int64_t)e0.offset), e_col = (double)(col[(first >> 1) + 1] - (int64_t)e0.offset);
             const double c_lo = fwd ? s_col + lo_d : e_col - hi_d, c_hi = fwd ? s_col + hi_d : e_col - lo_d;
-            const int64_t node_lo = std::min<int64_t>(std::max<int64_t>(upper(std::max(c_lo, 0.0)) - 1, 0), (int64_t)n_nodes - 1);
-            const int64_t node_hi = std::min<int64_t>(std::max<int64_t>(upper(std::min(c_hi, (double)(col[n_nodes] - 1))), 1), (int64_t)n_nodes);
+            const int64_t node_lo = std::min<int64_t>(std::max<int64_t>(upper(std::max(c_lo, 0.0), first >> 1) - 1, 0), (int64_t)n_nodes - 1);
+            const int64_t node_hi = std::min<int64_t>(std::max<int64_t>(upper(std::min(c_hi, (double)(col[n_nodes] - 1)), first >> 1), 1), (int64_t)n_nodes);
             int64_t* rq = out.requests.data() + 6 * k;
             rq[0] = node_lo; rq[1] = node_hi; rq[2] = 0; rq[3] = 0; rq[4] = -1; rq[5] = 0;
             // the mate as it reads along the FORWARD strand of that subgraph: reverse-complemented when its partner maps forward
