@@ -474,6 +474,17 @@ int  vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_
 int    vgk_gapless_fetch_deferred(vgk_ctx* ctx);   /* wait for and finish the copies of a VGK_GAPLESS_DEFER call (no-op when none is pending) */
 int    vgk_gapless_rerun(vgk_ctx* ctx);      /* launch the kernel of the last vgk_gapless_extend call again on its resident inputs */
 double vgk_gapless_last_ms(vgk_ctx* ctx);    /* kernel time of the last vgk_gapless_extend call on this context */
+/* The search walks an index in which UNARY RUNS are merged at build time: consecutive nodes v, v + 1, ... where every haplotype that visits
+ * one goes on to the next and every visit of the next arrives that way (so a search state's ranges map through unchanged), at most 255 bases
+ * together — what the reference does per problem for WFA (WFANode: unary paths up to 1 024 bp, src/gbwt_extender.cpp:1431-1487), done once
+ * per index: a 150-base read over 32-base nodes crosses one or two records per direction instead of five to ten dependent hops.  Seeds come
+ * in and sets go out in the ORIGINAL nodes.  A search extends every partial extension until nothing is left and keeps the best finished one,
+ * the first among equals: the one thing that depends on the order of the steps, and so on their granularity.  A search whose best score two
+ * finished extensions share is therefore run again on the original index — the results are those of the node-by-node search, tie for tie.
+ * vgk_haplo_search_nodes: nodes of the index the search walks (= the graph's when nothing merged; VGAMD_HAPLO_NO_MERGE=1 builds without);
+ * vgk_gapless_last_redone: seeds of the last call whose search ran twice. */
+uint64_t vgk_haplo_search_nodes(const vgk_haplo* index);
+uint64_t vgk_gapless_last_redone(vgk_ctx* ctx);
 uint64_t vgk_gapless_last_retried(vgk_ctx* ctx);   /* reads of that call whose search outgrew the fast (in-LDS) kernel and ran in the slab kernel */
 
 /* ---- minimizer seeding (MinimizerMapper::find_minimizers / find_seeds over gbwtgraph::MinimizerIndex, src/minimizer_mapper.cpp:3918-3965,

@@ -264,6 +264,7 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* haplotypes, vgk_haplo**
 void vgk_haplo_destroy(vgk_haplo* index) { vgo_haplo_destroy(index); }
 double vgk_gapless_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }
 uint64_t vgk_gapless_last_retried(vgk_ctx* ctx) { (void)ctx; return 0; }
+uint64_t vgk_gapless_last_redone(vgk_ctx* ctx) { (void)ctx; return 0; }      /* (the oracle walks the graph's own nodes, one by one) */
 int vgk_gapless_rerun(vgk_ctx* ctx) { (void)ctx; return VGK_EINVAL; }     /* nothing is resident on the CPU */
 int vgk_banded_rerun(vgk_ctx* ctx) { (void)ctx; return VGK_EINVAL; }
 int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_problem* problems, uint32_t n,

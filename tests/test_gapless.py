@@ -401,3 +401,40 @@ def test_reads_gathered_or_uploaded_in_a_row_give_the_same_sets(monkeypatch):
         ea = a[1][ra["ext_begin"][i]:ra["ext_begin"][i] + ra["n_ext"][i]]; ec = c[1][rc["ext_begin"][i]:rc["ext_begin"][i] + rc["n_ext"][i]]
         for f in ("offset", "read_begin", "read_end", "score", "path_len", "n_mismatches", "state"):
             assert (ea[f] == ec[f]).all(), (i, f)
+
+
+# Unary runs merged at index build (gapless_device.hpp GMerge): on a chopped variation graph most nodes sit in runs, the search walks a fraction of
+# the records, and every set still equals the oracle's node-by-node search — with the seeds that branched run again on the original index.
+def merged_runs_equal_the_node_by_node_search(lib, n_reads, graph_bp, monkeypatch):
+    from vg_amd import workloads
+    wl = workloads.GaplessWorkload(n_reads, seed=17, graph_bp=graph_bp, inserted_reads=0.2)
+    ora = capi.Engine(lib=util.ORACLE_LIB)
+    want = ora.gapless_extend(ora.haplo_index(wl.nodes, wl.threads), wl.gs)
+    outs = []
+    for merge in (True, False):
+        if not merge:
+            monkeypatch.setenv("VGAMD_HAPLO_NO_MERGE", "1")
+        eng = capi.Engine(lib=lib)
+        hi = eng.haplo_index(wl.nodes, wl.threads)
+        got = eng.gapless_extend(hi, wl.gs)
+        outs.append((hi.search_nodes(), eng.gapless_last_redone(), got))
+        if not merge:
+            monkeypatch.delenv("VGAMD_HAPLO_NO_MERGE")
+    (m_nodes, m_redone, with_runs), (p_nodes, p_redone, plain) = outs
+    assert p_nodes == len(wl.nodes) and p_redone == 0
+    assert m_nodes < 0.7 * p_nodes, (m_nodes, p_nodes)                      # (a SNP every 100 bases here: runs of two or three nodes; configs[2]'s graph: seven or eight)
+    assert 0 < m_redone < 0.3 * len(wl.gs.seeds)                            # ties at the top: the reads with an inserted base (a fifth here), whose extensions run on misaligned past it
+    for got in (with_runs, plain):
+        for a, b in zip(got, want):
+            assert len(a) == len(b) and a.tobytes() == b.tobytes()
+    return m_nodes, p_nodes, m_redone
+
+
+def test_emulated_merged_runs_equal_the_node_by_node_search(monkeypatch):
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    merged_runs_equal_the_node_by_node_search(util.EMU_LIB, 3000, 120_000, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_hip_merged_runs_equal_the_node_by_node_search(monkeypatch):
+    merged_runs_equal_the_node_by_node_search(util.ENGINE_LIB, 200_000, 2_000_000, monkeypatch)

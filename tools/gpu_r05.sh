@@ -59,6 +59,23 @@ PY
       unset VGAMD_CONFIG2_ONE_CONTEXT
     done
     ls $P ;;
+  merged_runs)    # the gapless search on the merged-run index against the node-by-node index: the gapless leg, configs[2], and the new gpu tests
+    timeout 900 python -m pytest tests/test_gapless.py tests/test_giraffe_stage.py tests/test_tail_forest.py tests/test_minimizer.py tests/test_wfa.py -m gpu -x -q > "$out/pytest_merged.log" 2>&1
+    echo "rc=$?" >> "$out/pytest_merged.log"; tail -3 "$out/pytest_merged.log"
+    for m in merged plain; do
+      if [ $m = plain ]; then export VGAMD_HAPLO_NO_MERGE=1; else unset VGAMD_HAPLO_NO_MERGE; fi
+      timeout 600 python bench.py --workload gapless --steps 5 --warmup 2 > "$out/bench_gapless_$m.json" 2> "$out/bench_gapless_$m.err"
+      timeout 900 python bench.py --workload config2 --reads 8000000 --steps 3 --warmup 1 --cpu-sample 1000000 > "$out/bench_config2_$m.json" 2> "$out/bench_config2_$m.err"
+      python - "$out" $m <<'PY'
+import json, sys
+o, m = sys.argv[1], sys.argv[2]
+g = json.loads(open("%s/bench_gapless_%s.json" % (o, m)).read().strip().splitlines()[-1])
+c = json.loads(open("%s/bench_config2_%s.json" % (o, m)).read().strip().splitlines()[-1])
+print(m, "gapless", round(g["value"]), g["parity"], "launch ms", g["roofline"].get("avg_launch_ms"), "| config2", round(c["value"]), {k: v for k, v in c["parity"].items() if k != "what"},
+      "kernel ms/batch", {k: round(v, 2) for k, v in c["config"]["kernel_ms_per_batch"].items()}, "one context", c["config"]["one_context"])
+PY
+    done
+    unset VGAMD_HAPLO_NO_MERGE ;;
   default)        # what the driver runs: the headline + every secondary record
     timeout 1700 python bench.py > "$out/bench_default_run.json" 2> "$out/bench_default_run.err"; tail -c 400 "$out/bench_default_run.json" ;;
   *) echo "unknown stage $stage"; exit 2 ;;

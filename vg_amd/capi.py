@@ -573,6 +573,11 @@ class Engine:
     def gapless_last_ms(self):
         return self.lib.vgk_gapless_last_ms(self.h)
 
+    def gapless_last_redone(self):
+        """seeds of the last extension call whose search branched on the merged-run index and ran again on the original one"""
+        self.lib.vgk_gapless_last_redone.restype = ctypes.c_uint64; self.lib.vgk_gapless_last_redone.argtypes = [ctypes.c_void_p]
+        return int(self.lib.vgk_gapless_last_redone(self.h))
+
     def gapless_last_retried(self):
         self.lib.vgk_gapless_last_retried.restype = ctypes.c_uint64
         self.lib.vgk_gapless_last_retried.argtypes = [ctypes.c_void_p]
@@ -880,6 +885,11 @@ class HaploIndex:
         eng._check(eng.lib.vgk_haplo_create(eng.h, ctypes.byref(d), ctypes.byref(h)), "vgk_haplo_create")
         self.h = h
         eng._indexes.add(self)
+
+    def search_nodes(self):
+        """nodes of the index the gapless search walks (unary runs merged at build; = the graph's nodes when nothing merged)"""
+        self.eng.lib.vgk_haplo_search_nodes.restype = ctypes.c_uint64; self.eng.lib.vgk_haplo_search_nodes.argtypes = [ctypes.c_void_p]
+        return int(self.eng.lib.vgk_haplo_search_nodes(self.h))
 
     def close(self):
         if getattr(self, "h", None):

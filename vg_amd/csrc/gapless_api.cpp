@@ -361,9 +361,9 @@ static int gapless_run_and_fetch(vgk_ctx* ctx, GaplessParams& P, uint32_t n, uin
     if ((rc = be->run_gapless(P, threads))) return cleanup(rc);
     lap("uploads + kernels");
     ctx->gapless_last = P; ctx->gapless_last_threads = threads; ctx->gapless_last_valid = true;
-    unsigned long long counters[4] = {0, 0, 0, 0};
+    unsigned long long counters[6] = {0, 0, 0, 0, 0, 0};
     if ((rc = be->download(counters, P.counters, sizeof counters))) return cleanup(rc);
-    ctx->gapless_ms = be->last_ms(5); ctx->gapless_retried = counters[3];
+    ctx->gapless_ms = be->last_ms(5); ctx->gapless_retried = counters[3]; ctx->gapless_redone = counters[5];
 #if defined(VGAMD_GAPLESS_PROF)
     { unsigned long long sec[20] = {0}; be->download(sec, P.counters + 8, sizeof(unsigned long long) * 12);
       std::fprintf(stderr, "gapless sections (wave cycles):"); for (int i = 0; i < 12; ++i) std::fprintf(stderr, " [%d]=%llu", i, sec[i]); std::fprintf(stderr, "\n"); }
@@ -532,7 +532,7 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
         return d;
     };
     GaplessParams P{};
-    P.index = index->merged ? index->merged->dev : index->dev; P.merge = index->merge; P.n = n;
+    P.index = index->merged ? index->merged->dev : index->dev; P.orig = index->dev; P.merge = index->merge; P.n = n;
     P.probs = (const GProb*)dev(probs.data(), sizeof(GProb) * n);
     P.reads = (const char*)dev(nullptr, n_read + 16);                  // 8 bytes of padding at either end
     if (P.reads && n_read && be->upload(const_cast<char*>(P.reads) + 8, reads_in_a_row ? read0 : reads + 8, n_read)) return VGK_ENODEV;
@@ -597,7 +597,7 @@ int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max
     if (!rc) rc = be->sort_pairs_u32(d_sort, d_sort + 2 * (size_t)n, d_sort + n, d_sort + 3 * (size_t)n, n, bits);
     if (rc) return rc;
     GaplessParams P{};
-    P.index = index->merged ? index->merged->dev : index->dev; P.merge = index->merge; P.n = n;
+    P.index = index->merged ? index->merged->dev : index->dev; P.orig = index->dev; P.merge = index->merge; P.n = n;
     P.probs = d_probs; P.reads = ctx->seeded.reads; P.seeds = ctx->seeded.seeds; P.order = d_sort + 3 * (size_t)n;
     lap("descriptors and order on the device");
     return gapless_run_and_fetch(ctx, P, n, n_seed, next_slot, H, lap, results, extensions, ext_cap, nodes, nodes_cap, mismatches, mism_cap, written, (flags & VGK_GAPLESS_DEFER) != 0);
@@ -617,5 +617,7 @@ int vgk_gapless_rerun(vgk_ctx* ctx) try {
 
 double vgk_gapless_last_ms(vgk_ctx* ctx) { return ctx ? ctx->gapless_ms : 0.0; }
 uint64_t vgk_gapless_last_retried(vgk_ctx* ctx) { return ctx ? ctx->gapless_retried : 0; }
+uint64_t vgk_gapless_last_redone(vgk_ctx* ctx) { return ctx ? ctx->gapless_redone : 0; }
+uint64_t vgk_haplo_search_nodes(const vgk_haplo* index) { return index ? (index->merged ? index->merged->n_oriented / 2 : index->n_oriented / 2) : 0; }
 
 }  // extern "C"

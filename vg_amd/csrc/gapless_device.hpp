@@ -281,8 +281,9 @@ struct GRes {                          // the G_SEEDS winners of a read as one a
 };
 
 struct GaplessParams {
-    GIndex index;                     // what the search walks: the merged index when merge.on
-    GMerge merge;
+    GIndex index;                     // what the search walks first and the set rules see: the merged index when merge.on
+    GIndex orig;                      // merge.on: the original index — a search whose best score two finished extensions share is run again on it
+    GMerge merge;                     //   (which of them finishes first depends on the steps' granularity; everything else about a search does not)
     const GProb* probs; uint32_t n;
     const uint32_t* order;            // the order the threads take the problems in: sorted by the node of the first seed, so that the reads of a
                                       // wavefront (and of the wavefronts around it) walk the same few records and bases of the index
@@ -297,7 +298,7 @@ struct GaplessParams {
     vgk_extension* ext; uint32_t* nodes; uint32_t* mism;
     uint8_t* retry;                   // [n]: 1 = the flat search handed the read to the slab kernel (kept apart from results[].status, which that kernel
                                       // rewrites while the rules kernel runs beside it)
-    unsigned long long* counters;     // [0] extensions, [1] nodes, [2] mismatches handed out, [3] reads the fast kernel passed on to the slab kernel, [4] reads handed to lanes (flat form)
+    unsigned long long* counters;     // [0] extensions, [1] nodes, [2] mismatches handed out, [3] reads the fast kernel passed on to the slab kernel, [4] reads handed to lanes (flat form), [5] searches run again on the original index (merged runs)
     unsigned long long caps[3];
 };
 
@@ -315,11 +316,12 @@ struct GCtx { const GaplessParams* P; const char* seq; uint32_t L; };
 // diagonal are those on the merged node, `seed_end` the offset in that node where the ORIGINAL seed node ends (the initial match with any
 // number of mismatches covers the seed node only, :213-237) and `orig_len` that node's length (the offset check is against it)
 struct GSeedIn { int32_t node; int64_t diff; uint32_t seed_begin, seed_end, orig_len; };
-VGK_HD bool g_seed_in(const GaplessParams& P, uint32_t idx, GSeedIn& out) {
+VGK_HD bool g_seed_in(const GaplessParams& P, uint32_t idx, GSeedIn& out, bool merged = true) {
     const vgk_seed sd = P.seeds[idx];
-    if (!P.merge.on) {
-        if (sd.node >= P.index.n_oriented) return false;
-        out.node = (int32_t)sd.node; out.diff = sd.diff; out.seed_begin = 0; out.orig_len = g_len(P.index, (int32_t)sd.node); out.seed_end = out.orig_len;
+    if (!P.merge.on || !merged) {
+        const GIndex& h = P.merge.on ? P.orig : P.index;
+        if (sd.node >= h.n_oriented) return false;
+        out.node = (int32_t)sd.node; out.diff = sd.diff; out.seed_begin = 0; out.orig_len = g_len(h, (int32_t)sd.node); out.seed_end = out.orig_len;
         return true;
     }
     if (sd.node >= P.merge.n_orig_oriented) return false;
@@ -703,15 +705,18 @@ struct GSearch {
     GProf* prof;
     uint32_t np, hn, number; bool have_cand; GLean cand; uint32_t cand_idx; int32_t best; GBest best_e;
     uint32_t L, max_mm;
+    bool merged, tie;                // the search runs on the merged index | the best score so far was reached by two finished extensions
 };
+constexpr int32_t G_REDO = 4;        // g_search_end: a merged search whose best score is a tie — the caller begins the same seed again with merged = false
 constexpr int32_t G_BADNODE = 2, G_BADOFF = 3;          // winner statuses (beside VGK_OK, VGK_ETOOBIG, G_RETRY): a seed node out of range (checked
                                                         // before the skip rule), a seed offset out of range (checked after it)
 // winner record of a seed = GExt with pad[0] = 1 when there is an extension, pad[1] = status
 template <class ST>
-VGK_HD int g_search_begin(const GaplessParams& P, const GCtx& c, const GProb& pb, uint32_t si, ST& Q, GSearch& s) {
-    const GIndex& h = P.index;
+VGK_HD int g_search_begin(const GaplessParams& P, const GCtx& c, const GProb& pb, uint32_t si, ST& Q, GSearch& s, bool merged = true) {
+    s.merged = merged && P.merge.on; s.tie = false;
+    const GIndex& h = (P.merge.on && !s.merged) ? P.orig : P.index;
     GSeedIn sin;
-    if (!g_seed_in(P, pb.seed_off + si, sin)) return G_BADNODE;
+    if (!g_seed_in(P, pb.seed_off + si, sin, s.merged)) return G_BADNODE;
     const uint32_t L = pb.read_len;
     // (the seed's own offsets are those on the ORIGINAL node: read_offset - node_offset = the caller's diff; the merged node adds seed_begin)
     const int64_t diff0 = sin.diff + (int64_t)sin.seed_begin;
@@ -759,7 +764,7 @@ VGK_HD int g_search_begin(const GaplessParams& P, const GCtx& c, const GProb& pb
 VGK_HD bool g_search_live(const GSearch& s) { return s.hn || s.have_cand; }
 template <class ST>
 VGK_HD int g_search_step(const GaplessParams& P, const GCtx& c, ST& Q, GSearch& s) {
-    const GIndex& h = P.index;
+    const GIndex& h = (P.merge.on && !s.merged) ? P.orig : P.index;
     const uint32_t L = s.L, max_mm = s.max_mm;
     uint32_t ci; GEntry cur;
     if (s.have_cand && (s.hn == 0 || g_key(s.cand, s.cand_idx) > Q.heap_get(0))) { ci = s.cand_idx; cur = g_fat(s.cand); s.have_cand = false; }
@@ -775,7 +780,7 @@ VGK_HD int g_search_step(const GaplessParams& P, const GCtx& c, ST& Q, GSearch& 
     // same instructions — which record, which state, which way the bases are compared are data — because in a wavefront there are
     // always lanes going either way, and two code paths would each be paid by all of them.
     const bool right = !cur.right_max;
-    if (!right && !cur.left_max && cur.offset > 0) {
+    if (s.merged && !right && !cur.left_max && cur.offset > 0) {
         // merged runs: the path's first node has bases before the alignment (the seed node lies inside a run): the run's earlier nodes, which
         // match_backward (:268-296) would take one by one — in one piece, the same limit, the same flags where it stops
         const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
@@ -848,7 +853,7 @@ VGK_HD int g_search_step(const GaplessParams& P, const GCtx& c, ST& Q, GSearch& 
                 if (s.np >= ST::ENTRIES) return ST::FULL;
                 GEntry nx = cur; nx.parent = (int32_t)ci; nx.node = -1; nx.right_max = 1; nx.old = nx.internal; nx.number = s.number++;
                 Q.link_set(s.np, nx);
-                if (!g_offer(Q, s.hn, s.have_cand, s.cand, s.cand_idx, nx, s.np)) return ST::FULL;
+                    if (!g_offer(Q, s.hn, s.have_cand, s.cand, s.cand_idx, nx, s.np)) return ST::FULL;
                 ++s.np;
             }
             G_TICK(s.prof, 3);
@@ -858,14 +863,18 @@ VGK_HD int g_search_step(const GaplessParams& P, const GCtx& c, ST& Q, GSearch& 
         if (found) return VGK_OK;
         cur.left_max = 1;
     }
-    if (s.best < 0 || s.best_e.score < cur.score) { s.best = (int32_t)ci; s.best_e = g_best(cur); }
+    // (every partial extension is extended until nothing is left: the winner is the best finished one, the first among equals — the one thing
+    // that depends on the ORDER of the steps, and so on their granularity: a tie at the top sends a merged search back to the original index)
+    if (s.best < 0 || s.best_e.score < cur.score) { s.best = (int32_t)ci; s.best_e = g_best(cur); s.tie = false; }
+    else if (s.best_e.score == cur.score) s.tie = true;
     G_TICK(s.prof, 5);
     return VGK_OK;
 }
 // the winner of a finished search into `r` (pad[0] = 1 when there is one); VGK_ETOOBIG when its path does not fit
 template <class ST>
-VGK_HD int g_search_end(const ST& Q, const GSearch& s, GExt& r) {
+VGK_HD int g_search_end(const GaplessParams& P, const ST& Q, const GSearch& s, GExt& r) {
     r.pad[0] = 0; r.pad[1] = 0; r.path_len = 0; r.n_mism = 0;
+    if (s.merged && s.tie) return G_REDO;
     const GBest& b = s.best_e;
     if (!(s.best >= 0 && (b.rr >> 16) > (b.rr & 0xffffu))) return VGK_OK;
     const int plen = g_path(Q, s.best, r.path);
@@ -873,6 +882,19 @@ VGK_HD int g_search_end(const ST& Q, const GSearch& s, GExt& r) {
     r.path_len = (uint32_t)plen; r.offset = b.oi & 0xffffu; r.r0 = b.rr & 0xffffu; r.r1 = b.rr >> 16; r.internal = b.oi >> 16; r.score = b.score;
     r.state.fn = b.fn; r.state.bn = b.bn; g_unrange(b.fr, r.state.flo, r.state.fhi); g_unrange(b.br, r.state.blo, r.state.bhi);
     r.left_full = (uint8_t)(b.full & 1u); r.right_full = (uint8_t)((b.full >> 1) & 1u); r.n_mism = 0; r.pad[0] = 1;
+    if (P.merge.on && !s.merged) {
+        // a winner found on the original index, into the merged index's terms (the rules see one kind of path): consecutive nodes of a run
+        // collapse into their merged node, the offset counts from that node's start, the states' nodes are the merged ones (the ranges are the same)
+        const uint64_t first = P.merge.seed_map[(uint32_t)r.path[0]];
+        r.offset += (uint32_t)(first >> 32);
+        uint32_t n = 0;
+        for (uint32_t k = 0; k < r.path_len; ++k) {
+            const int32_t mo = (int32_t)(uint32_t)P.merge.seed_map[(uint32_t)r.path[k]];
+            if (n == 0 || r.path[n - 1] != mo || (uint32_t)(P.merge.seed_map[(uint32_t)r.path[k]] >> 32) == 0u) r.path[n++] = mo;      // (a run entered again from its start — a cycle — is a node of its own)
+        }
+        r.path_len = n;
+        r.state.fn = (int32_t)(uint32_t)P.merge.seed_map[(uint32_t)r.state.fn]; r.state.bn = (int32_t)(uint32_t)P.merge.seed_map[(uint32_t)r.state.bn];
+    }
     return VGK_OK;
 }
 
@@ -993,12 +1015,17 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, ST& Q, GScra
         if (!g_seed_in(P, pb.seed_off + si, sd)) { status = VGK_EINVAL; break; }
         if (best_alignment < n_res && RES[best_alignment].internal == 0 && gx_contains(h, RES[best_alignment], sd.node, sd.diff)) continue;
         GSearch s; s.prof = nullptr;
-        const int b = g_search_begin(P, c, pb, si, Q, s);
-        if (b != VGK_OK) { status = VGK_EINVAL; break; }
-        while (status == VGK_OK && g_search_live(s)) status = g_search_step(P, c, Q, s);
-        if (status != VGK_OK) break;
         GExt& r = RES[n_res];
-        if ((status = g_search_end(Q, s, r)) != VGK_OK) break;
+        for (bool merged = true;; merged = false) {
+            const int b = g_search_begin(P, c, pb, si, Q, s, merged);
+            if (b != VGK_OK) { status = VGK_EINVAL; break; }
+            while (status == VGK_OK && g_search_live(s)) status = g_search_step(P, c, Q, s);
+            if (status != VGK_OK) break;
+            status = g_search_end(P, Q, s, r);
+            if (status != G_REDO) break;
+            status = VGK_OK; g_bump(P.counters + 5, 1);                      // the search branched on the merged index: once more on the original one
+        }
+        if (status != VGK_OK) break;
         if (r.pad[0]) {
             if (gx_full(r) && (best_alignment >= n_res || r.internal < RES[best_alignment].internal)) best_alignment = n_res;
             ++n_res;
@@ -1027,7 +1054,7 @@ VGK_HD void gapless_search_lane(const GaplessParams& P, ST& Q, GScratch& S, W& w
     GProb pb; pb.n_seeds = 0; pb.read_len = 0; pb.seed_off = 0; pb.read_off = 0; pb.max_mm = 0; pb.flags = 0; pb.overlap = 0;
     GCtx c; c.P = &P; c.seq = P.reads; c.L = 0;
     GSearch s; s.hn = 0; s.have_cand = false; s.prof = wave.prof();
-    bool searching = false, done = false;
+    bool searching = false, done = false, redo = false;
     for (;;) {
         const bool idle = !searching && !done;
         const int v = wave.vote(idle, searching);
@@ -1056,7 +1083,8 @@ VGK_HD void gapless_search_lane(const GaplessParams& P, ST& Q, GScratch& S, W& w
                     const GExt& ba = P.winners[pb.seed_off + best_alignment];
                     if (ba.internal == 0 && gx_contains_diag(ba, S.diag, sd.node, sd.diff)) { ++si; continue; }
                 }
-                if (g_search_begin(P, c, pb, si, Q, s) != VGK_OK) { status = VGK_EINVAL; continue; }
+                if (g_search_begin(P, c, pb, si, Q, s, !redo) != VGK_OK) { status = VGK_EINVAL; continue; }
+                redo = false;
                 ++si; searching = true;
                 break;
             }
@@ -1068,8 +1096,9 @@ VGK_HD void gapless_search_lane(const GaplessParams& P, ST& Q, GScratch& S, W& w
             else if (!g_search_live(s)) {
                 searching = false;
                 GExt& r = P.winners[pb.seed_off + n_res];
-                status = g_search_end(Q, s, r);
-                if (status == VGK_OK && r.pad[0]) {
+                status = g_search_end(P, Q, s, r);
+                if (status == G_REDO) { status = VGK_OK; --si; redo = true; g_bump(P.counters + 5, 1); }          // the same seed again, on the original index
+                else if (status == VGK_OK && r.pad[0]) {
                     if (gx_full(r) && (best_alignment == NONE || r.internal < P.winners[pb.seed_off + best_alignment].internal)) {
                         best_alignment = n_res;
                         if (r.internal == 0) gx_diagonals(h, r, S.diag);
