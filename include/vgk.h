@@ -183,6 +183,10 @@ int  vgk_gssw_fetch(vgk_batch* batch, vgk_result* results /* [n] */,
 int  vgk_gssw_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
                     vgk_result* results, vgk_op* ops, size_t ops_cap,
                     size_t* ops_written);
+/* The wide route's share of the last vgk_gssw_align call on this context (problems beyond the packed kernels' range: reads of more than 1024
+ * rows, scores beyond 11 bits — four wavefronts per problem, int32 cells, strips through HBM): 0 = fill kernels ms, 1 = traceback kernel ms,
+ * 2 = DP cells, 3 = cells whose traceback codes were stored, 4 = launches. */
+double vgk_gssw_wide_last(vgk_ctx* ctx, int which);
 /* ---- one graph resident in HBM, problems as windows of it (device-side packing) --------------------------------------
  * `vg map` aligns every read against a subgraph cut out of ONE graph around its seed cluster (the id range around the MEMs,
  * src/mapper.cpp:2445-2518) and converts that subgraph node by node on the CPU (create_gssw_graph, src/aligner.cpp:30-85).

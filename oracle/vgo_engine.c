@@ -548,6 +548,7 @@ uint64_t vgk_batch_alg_bytes(vgk_batch* b) { (void)b; return 0; }
 uint64_t vgk_batch_device_bytes(vgk_batch* b) { (void)b; return 0; }
 uint64_t vgk_batch_wave_steps(vgk_batch* b) { (void)b; return 0; }
 int vgk_batch_lane(vgk_batch* b) { (void)b; return 0; }
+double vgk_gssw_wide_last(vgk_ctx* ctx, int which) { (void)ctx; (void)which; return 0.0; }      /* (one scalar route for every read length here) */
 /* the engine's speculative fill has no counterpart here (one scalar fill with its traceback): the checker never speculates */
 int vgk_batch_speculated(vgk_batch* b) { (void)b; return 0; }
 int vgk_set_speculation(vgk_ctx* ctx, int mode) { (void)ctx; return (mode < 0 || mode > 2) ? VGK_EINVAL : VGK_OK; }

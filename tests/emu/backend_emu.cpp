@@ -262,16 +262,16 @@ public:
             for (uint32_t t = 0; t < threads; ++t) {
                 Wave w{(P.n + threads - 1) / threads};
                 GStoreLds Q{lds.data(), 1u, P.scratch[t], 0u};
-                gapless_search_lane(P, Q, P.scratch[t], w);
+                gapless_search_lane<true>(P, Q, P.scratch[t], w);
             }
-            for (uint32_t t = 0; t < threads; ++t) for (uint32_t k = t; k < P.n; k += threads) gapless_rules_one(P, P.order[k], P.scratch[t].order);
+            for (uint32_t t = 0; t < threads; ++t) for (uint32_t k = t; k < P.n; k += threads) gapless_rules_one<true>(P, P.order[k], P.scratch[t].order);
             for (uint32_t t = 0; t < threads; ++t) for (uint32_t k = t; k < P.n; k += threads) {
                 const uint32_t i = P.order[k];
-                if (P.retry ? P.retry[i] != 0 : P.results[i].status == G_RETRY) { GStoreSlab Q{P.scratch[t]}; gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]); }
+                if (P.retry ? P.retry[i] != 0 : P.results[i].status == G_RETRY) { GStoreSlab Q{P.scratch[t]}; gapless_extend_one<true>(P, i, Q, P.scratch[t], P.cold[t]); }
             }
             return VGK_OK;
         }
-        for (uint32_t t = 0; t < threads; ++t) for (uint32_t k = t; k < P.n; k += threads) { GStoreSlab Q{P.scratch[t]}; gapless_extend_one(P, P.order[k], Q, P.scratch[t], P.cold[t]); }
+        for (uint32_t t = 0; t < threads; ++t) for (uint32_t k = t; k < P.n; k += threads) { GStoreSlab Q{P.scratch[t]}; gapless_extend_one<true>(P, P.order[k], Q, P.scratch[t], P.cold[t]); }
         return VGK_OK;
     }
     int run_banded(const BandedParams& P, const BandedLaunch* launches, uint32_t n) override {

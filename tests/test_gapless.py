@@ -411,6 +411,7 @@ def merged_runs_equal_the_node_by_node_search(lib, n_reads, graph_bp, monkeypatc
     ora = capi.Engine(lib=util.ORACLE_LIB)
     want = ora.gapless_extend(ora.haplo_index(wl.nodes, wl.threads), wl.gs)
     outs = []
+    monkeypatch.setenv("VGAMD_HAPLO_MERGE", "1")                             # (whatever the run lengths: this graph's are short)
     for merge in (True, False):
         if not merge:
             monkeypatch.setenv("VGAMD_HAPLO_NO_MERGE", "1")

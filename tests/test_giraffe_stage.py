@@ -221,3 +221,40 @@ def second_context_over_shared_indexes(emu_lib, n_reads):
         assert o[3].tobytes() == outs[0][3].tobytes() and o[4].tobytes() == outs[0][4].tobytes()
     assert outs[0][5][0] > 20
     b.close(); a.close()
+
+
+# configs[2]'s graph at a small size (a variant site every ~900 bases, nodes of at most 32: the haplotype index merges its unary runs by itself):
+# the whole stage from bare reads on the merged-run index — seeds in, sets, tails and tail alignments out in the graph's own nodes — against the
+# oracle's node-by-node stage.
+def config2_stage_on_merged_runs(lib, n_reads, ref_len):
+    g = workloads.VariationGraph(ref_len=ref_len)
+    wl = workloads.Config2Workload(n_reads, batch=n_reads, seed=3, graph=g)
+    graph = (wl.node_len, wl.seq)
+    reads, off = wl.batches[0]
+    eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=lib); ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=ORACLE_LIB)
+    hi = eng.haplo_index(graph, wl.threads); mi = eng.minimizer_index(graph, wl.threads)
+    assert hi.search_nodes() < 0.4 * len(wl.node_len), (hi.search_nodes(), len(wl.node_len))      # the runs were merged
+
+    class B:
+        n = n_reads
+    so, _, _ = eng.minimizer_seeds(mi, hi, reads, off, keep_on_device=True)
+    got = pipeline.align_stage_device(eng, hi, B, seeded=int(so[-1]), aligned=True)
+    ohi = ora.haplo_index(graph, wl.threads); omi = ora.minimizer_index(graph, wl.threads)
+    oso, osd, _ = ora.minimizer_seeds(omi, ohi, reads, off)
+    assert (so == oso).all()
+    sub = capi.GaplessSet(reads, off, osd, oso, node_cap=len(osd) * 16, mism_cap=len(osd) * 12)
+    want = pipeline.align_stage(ora, ohi, np.repeat(wl.node_len, 2), sub)
+    assert pipeline.compare_extension_sets(got["res"], got["ext"], got["nodes"], want["res"], want["ext"], want["nodes"], n_reads) == n_reads
+    assert (got["read_score"] == want["read_score"]).all() and (got["ext_total"] == want["ext_total"][:len(got["ext_total"])]).all()
+    verdict = pipeline.compare_tail_alignments(got["tails"], got["tail_ops"], pipeline.winning_alignment_arrays(want))
+    assert verdict["tails"] == verdict["identical"] > n_reads // 20, verdict
+    return eng.gapless_last_redone()
+
+
+def test_config2_stage_on_merged_runs_emulated(emu_lib):
+    config2_stage_on_merged_runs(emu_lib, 2500, 150_000)
+
+
+@pytest.mark.gpu
+def test_config2_stage_on_merged_runs_on_hip():
+    config2_stage_on_merged_runs(ENGINE_LIB, 200_000, 3_000_000)

@@ -76,6 +76,15 @@ print(m, "gapless", round(g["value"]), g["parity"], "launch ms", g["roofline"].g
 PY
     done
     unset VGAMD_HAPLO_NO_MERGE ;;
+  misc)           # the wide route's first number; configs[2] with one copy of the indexes per context (round 4's form) beside the shared copy
+    timeout 600 python bench.py --workload wide --steps 3 --warmup 1 > "$out/bench_wide.json" 2> "$out/bench_wide.err"
+    python -c "import json; d=json.loads(open('$out/bench_wide.json').read().strip().splitlines()[-1]); print('wide', round(d['value']), d['parity'], d['config']['kernel_ms_per_step'], d['config']['gcups_fill'], d['roofline']['frac'], d['cpu_baseline'] and d['cpu_baseline']['value'])"
+    for own in 0 1; do
+      if [ $own = 1 ]; then export VGAMD_CONFIG2_OWN_INDEXES=1; else unset VGAMD_CONFIG2_OWN_INDEXES; fi
+      timeout 900 python bench.py --workload config2 --reads 8000000 --steps 3 --warmup 1 --no-cpu > "$out/bench_config2_own$own.json" 2> "$out/bench_config2_own$own.err"
+      python -c "import json; d=json.loads(open('$out/bench_config2_own$own.json').read().strip().splitlines()[-1]); print('config2 own=$own', round(d['value']), d['config']['ms_per_batch'], d['config']['one_context'])"
+    done
+    unset VGAMD_CONFIG2_OWN_INDEXES ;;
   default)        # what the driver runs: the headline + every secondary record
     timeout 1700 python bench.py > "$out/bench_default_run.json" 2> "$out/bench_default_run.err"; tail -c 400 "$out/bench_default_run.json" ;;
   *) echo "unknown stage $stage"; exit 2 ;;

@@ -393,14 +393,14 @@ __global__ void __launch_bounds__(64) banded_walk_kernel(const BandedParams P) {
 // thread's slab; gapless_rules_kernel applies the set rules to the winners, one read per lane; a search whose queue outgrows the LDS
 // slots marks its read G_RETRY and the slab kernel below (nested loops, the whole search in the thread's 11 KB HBM slab, round 1's
 // kernel) runs exactly those reads again.
-__global__ void __launch_bounds__(64, 4) gapless_kernel(const GaplessParams P, const uint32_t threads, const int retry_only) {
+template <bool MG> __global__ void __launch_bounds__(64, 4) gapless_kernel(const GaplessParams P, const uint32_t threads, const int retry_only) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t >= threads) return;
     GStoreSlab Q{P.scratch[t]};
     for (uint32_t k = t; k < P.n; k += threads) {
         const uint32_t i = P.order[k];
         if (retry_only && !(P.retry ? P.retry[i] != 0 : P.results[i].status == G_RETRY)) continue;
-        gapless_extend_one(P, i, Q, P.scratch[t], P.cold[t]);
+        gapless_extend_one<MG>(P, i, Q, P.scratch[t], P.cold[t]);
     }
 }
 // The flat form (gapless_device.hpp, "the flat form"): lanes take reads from a counter and never wait for another lane's search; the
@@ -418,7 +418,7 @@ struct GWaveDev {
         return k < (unsigned long long)P.n ? (uint32_t)k : 0xffffffffu;
     }
 };
-__global__ void __launch_bounds__(64, 4) gapless_search_kernel(const GaplessParams P, const uint32_t threads) {
+template <bool MG> __global__ void __launch_bounds__(64, 4) gapless_search_kernel(const GaplessParams P, const uint32_t threads) {
     __shared__ uint32_t lds[64 * G_FAST_DW];
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t >= threads) return;
@@ -426,18 +426,18 @@ __global__ void __launch_bounds__(64, 4) gapless_search_kernel(const GaplessPara
 #if defined(VGAMD_GAPLESS_PROF)
     GProf prof; prof.start();
     GWaveDev wave{&prof, P.flat_min_idle};
-    gapless_search_lane(P, Q, P.scratch[t], wave);
+    gapless_search_lane<MG>(P, Q, P.scratch[t], wave);
     if ((threadIdx.x & 63) == 0) for (int i = 0; i < 12; ++i) atomicAdd(P.counters + 8 + i, prof.acc[i]);
 #else
     GWaveDev wave{nullptr, P.flat_min_idle};
-    gapless_search_lane(P, Q, P.scratch[t], wave);
+    gapless_search_lane<MG>(P, Q, P.scratch[t], wave);
 #endif
 }
-__global__ void __launch_bounds__(64, 6) gapless_rules_kernel(const GaplessParams P) {
+template <bool MG> __global__ void __launch_bounds__(64, 6) gapless_rules_kernel(const GaplessParams P) {
     __shared__ uint8_t order[64 * G_SEEDS];           // the permutation the rules sort, per lane
     const uint32_t k = blockIdx.x * 64 + threadIdx.x;
     if (k >= P.n) return;
-    gapless_rules_one(P, P.order[k], order + threadIdx.x * G_SEEDS);
+    gapless_rules_one<MG>(P, P.order[k], order + threadIdx.x * G_SEEDS);
 }
 
 __global__ void __launch_bounds__(256) gapless_order_kernel(const GOrderParams P, const int stage) {
@@ -1288,23 +1288,24 @@ public:
         hipEventRecord(bev[2], stream);
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
+    template <bool MG> void launch_gapless(const GaplessParams& p, uint32_t threads) {
+        if (std::getenv("VGAMD_GAPLESS_SLAB_ONLY")) { hipLaunchKernelGGL(gapless_kernel<MG>, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads, 0); return; }
+        hipLaunchKernelGGL(gapless_search_kernel<MG>, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads);
+        // the rules over the searched reads and the slab kernel over the few G_RETRY reads touch different reads (the rules skip
+        // G_RETRY, the slab kernel everything else; both take output space from the same atomic counters): side by side
+        hipEventRecord(side_done[0], stream);
+        hipStreamWaitEvent(side[0], side_done[0], 0);
+        hipLaunchKernelGGL(gapless_kernel<MG>, dim3((threads + 63) / 64), dim3(64), 0, side[0], p, threads, 1);
+        hipEventRecord(side_done[1], side[0]);
+        hipLaunchKernelGGL(gapless_rules_kernel<MG>, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
+        hipStreamWaitEvent(stream, side_done[1], 0);
+    }
     int run_gapless(const GaplessParams& p, uint32_t threads) override {
         hipSetDevice(dev);
         ms_gapless = 0.f;
         if (!p.n || !threads) return VGK_OK;
         hipEventRecord(bev[0], stream);
-        if (std::getenv("VGAMD_GAPLESS_SLAB_ONLY")) hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads, 0);
-        else {
-            hipLaunchKernelGGL(gapless_search_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, p, threads);
-            // the rules over the searched reads and the slab kernel over the few G_RETRY reads touch different reads (the rules skip
-            // G_RETRY, the slab kernel everything else; both take output space from the same atomic counters): side by side
-            hipEventRecord(side_done[0], stream);
-            hipStreamWaitEvent(side[0], side_done[0], 0);
-            hipLaunchKernelGGL(gapless_kernel, dim3((threads + 63) / 64), dim3(64), 0, side[0], p, threads, 1);
-            hipEventRecord(side_done[1], side[0]);
-            hipLaunchKernelGGL(gapless_rules_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
-            hipStreamWaitEvent(stream, side_done[1], 0);
-        }
+        if (p.merge.on) launch_gapless<true>(p, threads); else launch_gapless<false>(p, threads);      // (the kernels without the merged-run code keep the plain search's registers)
         hipEventRecord(bev[1], stream);
         if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VGK_ENODEV;
         hipEventElapsedTime(&ms_gapless, bev[0], bev[1]);
@@ -1341,9 +1342,13 @@ public:
         hipSetDevice(dev);
         if (!p0.n) return VGK_OK;
         WideParams p = p0;
+        for (int k = 0; k < 3; ++k) if (!wev[k]) hipEventCreate(&wev[k]);
+        hipEventRecord(wev[0], stream);
         if (n8) { p.order_begin = 0; p.order_count = n8; hipLaunchKernelGGL(gssw_wide_kernel<8>, dim3(n8), dim3(256), 0, stream, p); }
         if (n16) { p.order_begin = n8; p.order_count = n16; hipLaunchKernelGGL(gssw_wide_kernel<16>, dim3(n16), dim3(256), 0, stream, p); }
+        hipEventRecord(wev[1], stream);
         hipLaunchKernelGGL(gssw_wide_walk_kernel, dim3((p.n + 63) / 64), dim3(64), 0, stream, p);
+        hipEventRecord(wev[2], stream); wide_pending = true;
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_xdrop_band(const GsswMatrixParams& p) override {
@@ -1507,7 +1512,13 @@ public:
         return VGK_OK;
     }
     void reset_wfa_ms() override { ms_wfa = 0.f; }
+    hipEvent_t wev[3] = {nullptr, nullptr, nullptr}; bool wide_pending = false; float ms_wide_fill = 0.f, ms_wide_walk = 0.f;
     double last_ms(int which) const override {
+        if (which == 13 || which == 14) {                                // the wide route's last launch: fill | traceback
+            HipBackend* self = const_cast<HipBackend*>(this);
+            if (self->wide_pending) { hipSetDevice(dev); hipEventSynchronize(wev[2]); hipEventElapsedTime(&self->ms_wide_fill, wev[0], wev[1]); hipEventElapsedTime(&self->ms_wide_walk, wev[1], wev[2]); self->wide_pending = false; }
+            return which == 13 ? ms_wide_fill : ms_wide_walk;
+        }
         if (which == 6) return ms_wfa;
         if (which == 7) return ms_xband;
         if (which == 5) return ms_gapless;

@@ -72,6 +72,7 @@ struct vgk_ctx {
     // last vgk_banded_align call: kernel times (ms), band cells, algorithmic bytes
     double banded_ms[2] = {0, 0}; uint64_t banded_cells = 0, banded_bytes = 0;
     double gapless_ms = 0;         // kernel time of the last vgk_gapless_extend call
+    double wide_ms[2] = {0, 0}; uint64_t wide_cells = 0, wide_tb_cells = 0, wide_launches = 0;     // the wide route's share of the last vgk_gssw_align call: fill | traceback kernels (ms), DP cells, cells with codes, launches
     uint64_t gapless_redone = 0;   // seeds of that call whose search branched on the merged-run index and ran again on the original one
     uint64_t gapless_retried = 0;  // reads of that call whose search outgrew the fast kernel's LDS store and ran in the slab kernel
     double wfa_ms = 0;             // and of the last vgk_wfa_extend call

@@ -205,6 +205,11 @@ static int merge_unary_runs(vgk_ctx* ctx, vgk_haplo* h, uint32_t O, const std::v
     }
     const uint32_t M = (uint32_t)run_first.size();
     if (M == N) return VGK_OK;
+    // Measured on the MI355X (profiles/r05/NOTES.md): where runs average fewer than two and a half nodes (a SNP every 100 bases, eight haplotypes: the
+    // gapless bench's graph, 0.57 merged nodes per node) a seed's translation, the in-node continuations and the expansion of the paths cost more
+    // than the hops they save (13.2 ms against 9.5 per million reads); at chr22-scale variant density (a site every ~900 bases: 0.17) the search
+    // kernel drops from 7.9 to 6.7 ms per million reads.  VGAMD_HAPLO_MERGE=1 merges whatever can be merged.
+    if ((double)M > 0.4 * (double)N && !std::getenv("VGAMD_HAPLO_MERGE")) return VGK_OK;
     run_first.push_back(N);
     std::vector<uint32_t> ocol((size_t)N + 1, 0);
     for (uint32_t v = 0; v < N; ++v) ocol[v + 1] = ocol[v] + len[2 * v];

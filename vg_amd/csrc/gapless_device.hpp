@@ -316,10 +316,11 @@ struct GCtx { const GaplessParams* P; const char* seq; uint32_t L; };
 // diagonal are those on the merged node, `seed_end` the offset in that node where the ORIGINAL seed node ends (the initial match with any
 // number of mismatches covers the seed node only, :213-237) and `orig_len` that node's length (the offset check is against it)
 struct GSeedIn { int32_t node; int64_t diff; uint32_t seed_begin, seed_end, orig_len; };
-VGK_HD bool g_seed_in(const GaplessParams& P, uint32_t idx, GSeedIn& out, bool merged = true) {
+// (MG: the kernel is built with the merged-run code at all — a build without it keeps the registers of the plain search)
+template <bool MG> VGK_HD bool g_seed_in(const GaplessParams& P, uint32_t idx, GSeedIn& out, bool merged = true) {
     const vgk_seed sd = P.seeds[idx];
-    if (!P.merge.on || !merged) {
-        const GIndex& h = P.merge.on ? P.orig : P.index;
+    if (!(MG && P.merge.on) || !merged) {
+        const GIndex& h = (MG && P.merge.on) ? P.orig : P.index;
         if (sd.node >= h.n_oriented) return false;
         out.node = (int32_t)sd.node; out.diff = sd.diff; out.seed_begin = 0; out.orig_len = g_len(h, (int32_t)sd.node); out.seed_end = out.orig_len;
         return true;
@@ -711,12 +712,12 @@ constexpr int32_t G_REDO = 4;        // g_search_end: a merged search whose best
 constexpr int32_t G_BADNODE = 2, G_BADOFF = 3;          // winner statuses (beside VGK_OK, VGK_ETOOBIG, G_RETRY): a seed node out of range (checked
                                                         // before the skip rule), a seed offset out of range (checked after it)
 // winner record of a seed = GExt with pad[0] = 1 when there is an extension, pad[1] = status
-template <class ST>
+template <bool MG, class ST>
 VGK_HD int g_search_begin(const GaplessParams& P, const GCtx& c, const GProb& pb, uint32_t si, ST& Q, GSearch& s, bool merged = true) {
-    s.merged = merged && P.merge.on; s.tie = false;
-    const GIndex& h = (P.merge.on && !s.merged) ? P.orig : P.index;
+    s.merged = MG && merged && P.merge.on; s.tie = false;
+    const GIndex& h = (MG && P.merge.on && !s.merged) ? P.orig : P.index;
     GSeedIn sin;
-    if (!g_seed_in(P, pb.seed_off + si, sin, s.merged)) return G_BADNODE;
+    if (!g_seed_in<MG>(P, pb.seed_off + si, sin, s.merged)) return G_BADNODE;
     const uint32_t L = pb.read_len;
     // (the seed's own offsets are those on the ORIGINAL node: read_offset - node_offset = the caller's diff; the merged node adds seed_begin)
     const int64_t diff0 = sin.diff + (int64_t)sin.seed_begin;
@@ -741,7 +742,7 @@ VGK_HD int g_search_begin(const GaplessParams& P, const GCtx& c, const GProb& pb
     m.old = m.internal;
     if (m.r0 == 0) m.left_full = m.left_max = 1;
     if (m.r1 >= L) m.right_full = m.right_max = 1;
-    else if (sin.seed_end < slen) {
+    else if (MG && sin.seed_end < slen) {
         // merged runs: the seed node ends inside the merged node — what follows in it are the run's next nodes, which match_forward (:239-266) would
         // take one by one under the mismatch limit: here in one piece, and where it stops the entry is right-maximal exactly as the node-by-node
         // form leaves it (a next node that matches nothing is dropped and the state kept as right-maximal, :617-619, :633-637)
@@ -762,9 +763,9 @@ VGK_HD int g_search_begin(const GaplessParams& P, const GCtx& c, const GProb& pb
 // it beats the queue's top — always, on a non-branching stretch — it is the next one popped and the round trip through the store
 // is skipped; otherwise it joins the queue first.
 VGK_HD bool g_search_live(const GSearch& s) { return s.hn || s.have_cand; }
-template <class ST>
+template <bool MG, class ST>
 VGK_HD int g_search_step(const GaplessParams& P, const GCtx& c, ST& Q, GSearch& s) {
-    const GIndex& h = (P.merge.on && !s.merged) ? P.orig : P.index;
+    const GIndex& h = (MG && P.merge.on && !s.merged) ? P.orig : P.index;
     const uint32_t L = s.L, max_mm = s.max_mm;
     uint32_t ci; GEntry cur;
     if (s.have_cand && (s.hn == 0 || g_key(s.cand, s.cand_idx) > Q.heap_get(0))) { ci = s.cand_idx; cur = g_fat(s.cand); s.have_cand = false; }
@@ -780,7 +781,7 @@ VGK_HD int g_search_step(const GaplessParams& P, const GCtx& c, ST& Q, GSearch& 
     // same instructions — which record, which state, which way the bases are compared are data — because in a wavefront there are
     // always lanes going either way, and two code paths would each be paid by all of them.
     const bool right = !cur.right_max;
-    if (s.merged && !right && !cur.left_max && cur.offset > 0) {
+    if (MG && s.merged && !right && !cur.left_max && cur.offset > 0) {
         // merged runs: the path's first node has bases before the alignment (the seed node lies inside a run): the run's earlier nodes, which
         // match_backward (:268-296) would take one by one — in one piece, the same limit, the same flags where it stops
         const uint32_t lim_a = max_mm + 1, lim_b = max_mm / 2 + cur.old + 1, limit = lim_a > lim_b ? lim_a : lim_b;
@@ -871,10 +872,10 @@ VGK_HD int g_search_step(const GaplessParams& P, const GCtx& c, ST& Q, GSearch& 
     return VGK_OK;
 }
 // the winner of a finished search into `r` (pad[0] = 1 when there is one); VGK_ETOOBIG when its path does not fit
-template <class ST>
+template <bool MG, class ST>
 VGK_HD int g_search_end(const GaplessParams& P, const ST& Q, const GSearch& s, GExt& r) {
     r.pad[0] = 0; r.pad[1] = 0; r.path_len = 0; r.n_mism = 0;
-    if (s.merged && s.tie) return G_REDO;
+    if (MG && s.merged && s.tie) return G_REDO;
     const GBest& b = s.best_e;
     if (!(s.best >= 0 && (b.rr >> 16) > (b.rr & 0xffffu))) return VGK_OK;
     const int plen = g_path(Q, s.best, r.path);
@@ -882,7 +883,7 @@ VGK_HD int g_search_end(const GaplessParams& P, const ST& Q, const GSearch& s, G
     r.path_len = (uint32_t)plen; r.offset = b.oi & 0xffffu; r.r0 = b.rr & 0xffffu; r.r1 = b.rr >> 16; r.internal = b.oi >> 16; r.score = b.score;
     r.state.fn = b.fn; r.state.bn = b.bn; g_unrange(b.fr, r.state.flo, r.state.fhi); g_unrange(b.br, r.state.blo, r.state.bhi);
     r.left_full = (uint8_t)(b.full & 1u); r.right_full = (uint8_t)((b.full >> 1) & 1u); r.n_mism = 0; r.pad[0] = 1;
-    if (P.merge.on && !s.merged) {
+    if (MG && P.merge.on && !s.merged) {
         // a winner found on the original index, into the merged index's terms (the rules see one kind of path): consecutive nodes of a run
         // collapse into their merged node, the offset counts from that node's start, the states' nodes are the merged ones (the ranges are the same)
         const uint64_t first = P.merge.seed_map[(uint32_t)r.path[0]];
@@ -925,7 +926,7 @@ VGK_HD uint32_t gx_expand(const GaplessParams& P, const GExt& e, uint32_t* out, 
 
 // The rules over a read's winners (the second half of GaplessExtender::extend): RES(i) = the i-th USED winner, n_res of them, in seed
 // order; best_alignment as the seed loop left it.  `order` = n_res bytes of scratch for the permutation the rules sort.
-template <class RESV>
+template <bool MG, class RESV>
 VGK_HD void gapless_set_rules(const GaplessParams& P, uint32_t pi, const GProb& pb, const GCtx& c, const RESV& RES, uint32_t n_res, uint32_t best_alignment, uint8_t* order) {
     const GIndex& h = P.index;
     vgk_gapless_result& out = P.results[pi];
@@ -965,7 +966,7 @@ VGK_HD void gapless_set_rules(const GaplessParams& P, uint32_t pi, const GProb& 
     if (overflow) { out.status = VGK_ETOOBIG; return; }
     // hand the set out (merged runs: in the ORIGINAL nodes the aligned interval touches — gx_expand)
     uint32_t nn = 0, nm = 0;
-    for (uint32_t i = 0; i < n_out; ++i) { nn += P.merge.on ? gx_expand(P, RES[order[i]], nullptr, nullptr) : RES[order[i]].path_len; nm += RES[order[i]].n_mism; }
+    for (uint32_t i = 0; i < n_out; ++i) { nn += (MG && P.merge.on) ? gx_expand(P, RES[order[i]], nullptr, nullptr) : RES[order[i]].path_len; nm += RES[order[i]].n_mism; }
     const unsigned long long e0 = g_bump(P.counters + 0, n_out), n0 = g_bump(P.counters + 1, nn), m0 = g_bump(P.counters + 2, nm);
     if (e0 + n_out > P.caps[0] || n0 + nn > P.caps[1] || m0 + nm > P.caps[2]) { out.status = VGK_EOPS; return; }
     out.ext_begin = (uint32_t)e0; out.n_ext = n_out;
@@ -979,7 +980,7 @@ VGK_HD void gapless_set_rules(const GaplessParams& P, uint32_t pi, const GProb& 
         x.state[0] = (uint32_t)e.state.fn; x.state[1] = (uint32_t)e.state.flo; x.state[2] = (uint32_t)e.state.fhi;
         x.state[3] = (uint32_t)e.state.bn; x.state[4] = (uint32_t)e.state.blo; x.state[5] = (uint32_t)e.state.bhi;
         uint32_t plen = e.path_len;
-        if (P.merge.on) {
+        if (MG && P.merge.on) {
             uint32_t first_off = e.offset;
             plen = gx_expand(P, e, P.nodes + n0 + na, &first_off);
             x.path_len = plen; x.offset = first_off;
@@ -997,7 +998,7 @@ VGK_HD void gapless_set_rules(const GaplessParams& P, uint32_t pi, const GProb& 
 
 // one read, the nested form: every seed's search in turn (skipping seeds the best exact full-length extension so far contains), then
 // the rules.  ST = where a seed's search lives (GStoreSlab / GStoreLds); the winners and the permutation sit in the thread's slab.
-template <class ST>
+template <bool MG, class ST>
 VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, ST& Q, GScratch& S, GCold& C) {
     const GRes RES{S.res, C.res};
     const GProb pb = P.probs[pi];
@@ -1012,16 +1013,16 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, ST& Q, GScra
     int status = VGK_OK;
     for (uint32_t si = 0; si < pb.n_seeds && status == VGK_OK; ++si) {
         GSeedIn sd;
-        if (!g_seed_in(P, pb.seed_off + si, sd)) { status = VGK_EINVAL; break; }
+        if (!g_seed_in<MG>(P, pb.seed_off + si, sd)) { status = VGK_EINVAL; break; }
         if (best_alignment < n_res && RES[best_alignment].internal == 0 && gx_contains(h, RES[best_alignment], sd.node, sd.diff)) continue;
         GSearch s; s.prof = nullptr;
         GExt& r = RES[n_res];
         for (bool merged = true;; merged = false) {
-            const int b = g_search_begin(P, c, pb, si, Q, s, merged);
+            const int b = g_search_begin<MG>(P, c, pb, si, Q, s, merged);
             if (b != VGK_OK) { status = VGK_EINVAL; break; }
-            while (status == VGK_OK && g_search_live(s)) status = g_search_step(P, c, Q, s);
+            while (status == VGK_OK && g_search_live(s)) status = g_search_step<MG>(P, c, Q, s);
             if (status != VGK_OK) break;
-            status = g_search_end(P, Q, s, r);
+            status = g_search_end<MG>(P, Q, s, r);
             if (status != G_REDO) break;
             status = VGK_OK; g_bump(P.counters + 5, 1);                      // the search branched on the merged index: once more on the original one
         }
@@ -1032,7 +1033,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, ST& Q, GScra
         }
     }
     if (status != VGK_OK) { out.status = status; if (status == G_RETRY) g_bump(P.counters + 3, 1); return; }
-    gapless_set_rules(P, pi, pb, c, RES, n_res, best_alignment, S.order);
+    gapless_set_rules<MG>(P, pi, pb, c, RES, n_res, best_alignment, S.order);
 }
 
 // ---- the flat form ----------------------------------------------------------------------------------------------------------------------
@@ -1046,7 +1047,7 @@ VGK_HD void gapless_extend_one(const GaplessParams& P, uint32_t pi, ST& Q, GScra
 constexpr uint32_t G_FLAT_MIN_IDLE = 12;
 struct GWinArr { GExt* base; VGK_HD GExt& operator[](uint32_t i) const { return base[i]; } };
 // W: next_read(P) -> position in P.order or 0xffffffff; vote(idle, searching) -> 0 = every lane is done, 1 = idle lanes act now, 2 = only step
-template <class ST, class W>
+template <bool MG, class ST, class W>
 VGK_HD void gapless_search_lane(const GaplessParams& P, ST& Q, GScratch& S, W& wave) {
     const GIndex& h = P.index;
     constexpr uint32_t NONE = 0xffffffffu;
@@ -1078,12 +1079,12 @@ VGK_HD void gapless_search_lane(const GaplessParams& P, ST& Q, GScratch& S, W& w
                     continue;
                 }
                 GSeedIn sd;
-                if (!g_seed_in(P, pb.seed_off + si, sd)) { status = VGK_EINVAL; continue; }
+                if (!g_seed_in<MG>(P, pb.seed_off + si, sd)) { status = VGK_EINVAL; continue; }
                 if (best_alignment != NONE) {
                     const GExt& ba = P.winners[pb.seed_off + best_alignment];
                     if (ba.internal == 0 && gx_contains_diag(ba, S.diag, sd.node, sd.diff)) { ++si; continue; }
                 }
-                if (g_search_begin(P, c, pb, si, Q, s, !redo) != VGK_OK) { status = VGK_EINVAL; continue; }
+                if (g_search_begin<MG>(P, c, pb, si, Q, s, !redo) != VGK_OK) { status = VGK_EINVAL; continue; }
                 redo = false;
                 ++si; searching = true;
                 break;
@@ -1091,12 +1092,12 @@ VGK_HD void gapless_search_lane(const GaplessParams& P, ST& Q, GScratch& S, W& w
         }
         G_TICK(s.prof, 1);
         if (searching) {
-            status = g_search_step(P, c, Q, s);
+            status = g_search_step<MG>(P, c, Q, s);
             if (status != VGK_OK) searching = false;
             else if (!g_search_live(s)) {
                 searching = false;
                 GExt& r = P.winners[pb.seed_off + n_res];
-                status = g_search_end(P, Q, s, r);
+                status = g_search_end<MG>(P, Q, s, r);
                 if (status == G_REDO) { status = VGK_OK; --si; redo = true; g_bump(P.counters + 5, 1); }          // the same seed again, on the original index
                 else if (status == VGK_OK && r.pad[0]) {
                     if (gx_full(r) && (best_alignment == NONE || r.internal < P.winners[pb.seed_off + best_alignment].internal)) {
@@ -1111,7 +1112,7 @@ VGK_HD void gapless_search_lane(const GaplessParams& P, ST& Q, GScratch& S, W& w
     }
 }
 // the rules of one read over the winners its searches left
-VGK_HD void gapless_rules_one(const GaplessParams& P, uint32_t pi, uint8_t* order) {
+template <bool MG> VGK_HD void gapless_rules_one(const GaplessParams& P, uint32_t pi, uint8_t* order) {
     if (P.retry && P.retry[pi]) return;                                        // the slab kernel's read (it may be at work on it right now): hands off
     const GProb pb = P.probs[pi];
     vgk_gapless_result& out = P.results[pi];
@@ -1120,7 +1121,7 @@ VGK_HD void gapless_rules_one(const GaplessParams& P, uint32_t pi, uint8_t* orde
     if (out.status != VGK_OK || !pb.read_len || !pb.n_seeds) return;           // an error, or nothing to do
     GCtx c; c.P = &P; c.seq = P.reads + pb.read_off; c.L = pb.read_len;
     const GWinArr RES{P.winners + pb.seed_off};
-    gapless_set_rules(P, pi, pb, c, RES, n_res, best_alignment, order);
+    gapless_set_rules<MG>(P, pi, pb, c, RES, n_res, best_alignment, order);
 }
 
 // ---- the sets in problem order ------------------------------------------------------------------------------------------------------

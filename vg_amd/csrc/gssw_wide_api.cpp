@@ -119,6 +119,7 @@ int vgk::wide_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, const uint32
                     vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_at) {
     if (!m) return VGK_OK;
     Backend* be = ctx->be.get();
+    ctx->wide_ms[0] = ctx->wide_ms[1] = 0; ctx->wide_cells = ctx->wide_tb_cells = 0; ctx->wide_launches = 0;
     uint64_t budget = be->memory_bytes() ? be->memory_bytes() / 4 : (2ull << 30);
     if (const char* e = std::getenv("VGAMD_MAX_BATCH_BYTES")) budget = std::strtoull(e, nullptr, 10);
     std::lock_guard<std::mutex> lock(ctx->mu);
@@ -174,6 +175,8 @@ int vgk::wide_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, const uint32
             int rc = be->zero(P.best, 8ull * (n + 1));
             if (!rc) rc = be->run_gssw_wide(P, n8, n - n8);
             if (rc) return rc;
+            { uint64_t cells = 0, tb = 0; for (uint32_t k = 0; k < n; ++k) { const WideProb& d = A.probs[k]; cells += (uint64_t)d.L * d.R; if (d.flags & VGK_GSSW_TRACEBACK) tb += (uint64_t)d.L * d.R; }
+              ctx->wide_cells += cells; ctx->wide_tb_cells += tb; ctx->wide_launches += 1; }
             std::vector<vgk_result> res(n); std::vector<vgk_op> all(A.ops + 1);
             if ((rc = be->download(res.data(), P.results, sizeof(vgk_result) * n))) return rc;
             if (A.ops && (rc = be->download(all.data(), P.ops, sizeof(vgk_op) * A.ops))) return rc;
@@ -187,8 +190,14 @@ int vgk::wide_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, const uint32
                 r.ops_begin = (uint32_t)*ops_at; *ops_at += r.n_ops;
                 results[idx[owner[k]]] = r;
             }
+            ctx->wide_ms[0] += be->last_ms(13); ctx->wide_ms[1] += be->last_ms(14);
         }
         begin = end;
     }
     return VGK_OK;
+}
+
+extern "C" double vgk_gssw_wide_last(vgk_ctx* ctx, int which) {
+    if (!ctx) return 0.0;
+    switch (which) { case 0: return ctx->wide_ms[0]; case 1: return ctx->wide_ms[1]; case 2: return (double)ctx->wide_cells; case 3: return (double)ctx->wide_tb_cells; case 4: return (double)ctx->wide_launches; default: return 0.0; }
 }

@@ -54,7 +54,7 @@ def host_threads_per_rank(world, cores=None):
 # their work on host threads (band geometry, hand-out and re-ordering of sets, local graphs between anchors).
 HOST_THREADS_NEEDED = {
     "linear": 1, "tails": 1, "forest": 1, "giraffe": 1, "config2": 1,      # resident: kernels only inside the timed region
-    "gapless": 4, "wfa": 4, "xband": 4,                                     # sets handed out / re-ordered on host threads
+    "gapless": 4, "wfa": 4, "xband": 4, "wide": 4,                          # sets handed out / re-ordered / packed on host threads
     "paired": 2,                                                            # rescue on the resident graph: the request table and the fix-ups are flat passes (round 5; was 8)
     "banded": 8, "longread": 8,                                             # band geometry / local graphs on host threads
 }
