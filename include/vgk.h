@@ -485,7 +485,8 @@ double vgk_gapless_last_ms(vgk_ctx* ctx);    /* kernel time of the last vgk_gapl
  * in and sets go out in the ORIGINAL nodes.  A search extends every partial extension until nothing is left and keeps the best finished one,
  * the first among equals: the one thing that depends on the order of the steps, and so on their granularity.  A search whose best score two
  * finished extensions share is therefore run again on the original index — the results are those of the node-by-node search, tie for tie.
- * vgk_haplo_search_nodes: nodes of the index the search walks (= the graph's when nothing merged; VGAMD_HAPLO_NO_MERGE=1 builds without);
+ * Measured: it does not pay yet (the search kernel is bound by the bytes it moves, not by its hops: DESIGN.md §28.3), so an index is built with
+ * merged runs only under VGAMD_HAPLO_MERGE=1.  vgk_haplo_search_nodes: nodes of the index the search walks (= the graph's when nothing merged);
  * vgk_gapless_last_redone: seeds of the last call whose search ran twice. */
 uint64_t vgk_haplo_search_nodes(const vgk_haplo* index);
 uint64_t vgk_gapless_last_redone(vgk_ctx* ctx);

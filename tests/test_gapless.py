@@ -411,16 +411,15 @@ def merged_runs_equal_the_node_by_node_search(lib, n_reads, graph_bp, monkeypatc
     ora = capi.Engine(lib=util.ORACLE_LIB)
     want = ora.gapless_extend(ora.haplo_index(wl.nodes, wl.threads), wl.gs)
     outs = []
-    monkeypatch.setenv("VGAMD_HAPLO_MERGE", "1")                             # (whatever the run lengths: this graph's are short)
     for merge in (True, False):
-        if not merge:
-            monkeypatch.setenv("VGAMD_HAPLO_NO_MERGE", "1")
+        if merge:
+            monkeypatch.setenv("VGAMD_HAPLO_MERGE", "1")                     # (off by default: DESIGN.md §28.3)
+        else:
+            monkeypatch.delenv("VGAMD_HAPLO_MERGE")
         eng = capi.Engine(lib=lib)
         hi = eng.haplo_index(wl.nodes, wl.threads)
         got = eng.gapless_extend(hi, wl.gs)
         outs.append((hi.search_nodes(), eng.gapless_last_redone(), got))
-        if not merge:
-            monkeypatch.delenv("VGAMD_HAPLO_NO_MERGE")
     (m_nodes, m_redone, with_runs), (p_nodes, p_redone, plain) = outs
     assert p_nodes == len(wl.nodes) and p_redone == 0
     assert m_nodes < 0.7 * p_nodes, (m_nodes, p_nodes)                      # (a SNP every 100 bases here: runs of two or three nodes; configs[2]'s graph: seven or eight)

@@ -223,10 +223,11 @@ def second_context_over_shared_indexes(emu_lib, n_reads):
     b.close(); a.close()
 
 
-# configs[2]'s graph at a small size (a variant site every ~900 bases, nodes of at most 32: the haplotype index merges its unary runs by itself):
+# configs[2]'s graph at a small size (a variant site every ~900 bases, nodes of at most 32), its haplotype index built with unary runs merged (VGAMD_HAPLO_MERGE):
 # the whole stage from bare reads on the merged-run index — seeds in, sets, tails and tail alignments out in the graph's own nodes — against the
 # oracle's node-by-node stage.
-def config2_stage_on_merged_runs(lib, n_reads, ref_len):
+def config2_stage_on_merged_runs(lib, n_reads, ref_len, monkeypatch):
+    monkeypatch.setenv("VGAMD_HAPLO_MERGE", "1")
     g = workloads.VariationGraph(ref_len=ref_len)
     wl = workloads.Config2Workload(n_reads, batch=n_reads, seed=3, graph=g)
     graph = (wl.node_len, wl.seq)
@@ -251,10 +252,10 @@ def config2_stage_on_merged_runs(lib, n_reads, ref_len):
     return eng.gapless_last_redone()
 
 
-def test_config2_stage_on_merged_runs_emulated(emu_lib):
-    config2_stage_on_merged_runs(emu_lib, 2500, 150_000)
+def test_config2_stage_on_merged_runs_emulated(emu_lib, monkeypatch):
+    config2_stage_on_merged_runs(emu_lib, 2500, 150_000, monkeypatch)
 
 
 @pytest.mark.gpu
-def test_config2_stage_on_merged_runs_on_hip():
-    config2_stage_on_merged_runs(ENGINE_LIB, 200_000, 3_000_000)
+def test_config2_stage_on_merged_runs_on_hip(monkeypatch):
+    config2_stage_on_merged_runs(ENGINE_LIB, 200_000, 3_000_000, monkeypatch)

@@ -85,6 +85,22 @@ PY
       python -c "import json; d=json.loads(open('$out/bench_config2_own$own.json').read().strip().splitlines()[-1]); print('config2 own=$own', round(d['value']), d['config']['ms_per_batch'], d['config']['one_context'])"
     done
     unset VGAMD_CONFIG2_OWN_INDEXES ;;
+  ab_r04)         # configs[2] on round 4's library (build/variants/libvgamd_r04.so: git worktree of 6434d4a, `make lib`) beside this round's, same bench, same session
+    for rep in 1 2; do
+      VGAMD_ENGINE_LIB=$GRAFT_REPO_ROOT/build/variants/libvgamd_r04.so VGAMD_CONFIG2_OWN_INDEXES=1 timeout 600 python bench.py --workload config2 --reads 8000000 --steps 3 --warmup 1 --no-cpu > "$out/config2_r04lib_$rep.json" 2> "$out/config2_r04lib_$rep.err"
+      VGAMD_CONFIG2_OWN_INDEXES=1 timeout 600 python bench.py --workload config2 --reads 8000000 --steps 3 --warmup 1 --no-cpu > "$out/config2_r05lib_own_$rep.json" 2> "$out/config2_r05lib_own_$rep.err"
+      timeout 600 python bench.py --workload config2 --reads 8000000 --steps 3 --warmup 1 --no-cpu > "$out/config2_r05lib_shared_$rep.json" 2> "$out/config2_r05lib_shared_$rep.err"
+    done
+    python - "$out" <<'PY'
+import json, sys, glob
+for f in sorted(glob.glob(sys.argv[1] + "/config2_*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1]); c = d["config"]
+        print(f.split("/")[-1], round(d["value"] / 1e6, 1), "M reads/s", round(c["ms_per_batch"], 2), "ms/batch", {k: round(v, 2) for k, v in c["kernel_ms_per_batch"].items()}, "one context", round(c["one_context"]["ms_per_batch"], 2))
+    except Exception as e:
+        print(f, "failed", e)
+PY
+    ;;
   default)        # what the driver runs: the headline + every secondary record
     timeout 1700 python bench.py > "$out/bench_default_run.json" 2> "$out/bench_default_run.err"; tail -c 400 "$out/bench_default_run.json" ;;
   *) echo "unknown stage $stage"; exit 2 ;;

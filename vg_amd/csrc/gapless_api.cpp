@@ -190,7 +190,10 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) try
 // are the run's, which already lie behind each other.  -> VGK_OK with h->merged set, or with nothing set when no two nodes merge.
 static int merge_unary_runs(vgk_ctx* ctx, vgk_haplo* h, uint32_t O, const std::vector<uint32_t>& len, const std::vector<char>& seq, uint32_t total, const HaploTables& T) {
     const uint32_t N = O / 2;
-    if (N < 2 || std::getenv("VGAMD_HAPLO_NO_MERGE")) return VGK_OK;
+    // Built, exact (tie for tie), measured on the MI355X (profiles/r05/NOTES.md) — and OFF unless VGAMD_HAPLO_MERGE=1: the search kernel's
+    // time is the bytes it moves, not its hops (6.48 against 6.62 ms per million reads at chr22-scale variant density, 13.2 against 9.5 ms where runs
+    // are two or three nodes), and the merged build's extra live values are scratch traffic of their own.
+    if (N < 2 || !std::getenv("VGAMD_HAPLO_MERGE") || std::getenv("VGAMD_HAPLO_NO_MERGE")) return VGK_OK;
     auto unary = [&](uint32_t o, uint32_t p) {
         return T.count[o] > 0 && T.edge_off[o + 1] - T.edge_off[o] == 1 && T.edge_to[T.edge_off[o]] == (int32_t)p && T.edge_base[T.edge_off[o]] == 0 && T.count[p] == T.count[o];
     };
@@ -205,11 +208,7 @@ static int merge_unary_runs(vgk_ctx* ctx, vgk_haplo* h, uint32_t O, const std::v
     }
     const uint32_t M = (uint32_t)run_first.size();
     if (M == N) return VGK_OK;
-    // Measured on the MI355X (profiles/r05/NOTES.md): where runs average fewer than two and a half nodes (a SNP every 100 bases, eight haplotypes: the
-    // gapless bench's graph, 0.57 merged nodes per node) a seed's translation, the in-node continuations and the expansion of the paths cost more
-    // than the hops they save (13.2 ms against 9.5 per million reads); at chr22-scale variant density (a site every ~900 bases: 0.17) the search
-    // kernel drops from 7.9 to 6.7 ms per million reads.  VGAMD_HAPLO_MERGE=1 merges whatever can be merged.
-    if ((double)M > 0.4 * (double)N && !std::getenv("VGAMD_HAPLO_MERGE")) return VGK_OK;
+
     run_first.push_back(N);
     std::vector<uint32_t> ocol((size_t)N + 1, 0);
     for (uint32_t v = 0; v < N; ++v) ocol[v + 1] = ocol[v] + len[2 * v];
