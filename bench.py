@@ -675,7 +675,8 @@ def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
             "roofline_rescue": {"bound": "valu", "kernel": "gssw_fill_kernel + walk kernels over the rescue rounds' batches", "achieved": rescue_alg / (rescue_kernel_ms * 1e-3) / 1e9 if rescue_kernel_ms else None,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rescue_alg / (rescue_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rescue_kernel_ms else None,
                                 "traffic": PMC_BYTES_PER_UNIT["rescue"] * n_pairs if "rescue" in PMC_BYTES_PER_UNIT else None,      # (per batch of pairs, like the figures beside it)
-                                "traffic_source": traffic_source("rescue") if "rescue" in PMC_BYTES_PER_UNIT else None,
+                                "traffic_source": (traffic_source("rescue") + " — the counters name kernels, not callers: this is every gssw fill and walk of a step, the stage's tail windows "
+                                                   "(rows-per-lane 16 / 20 / 24) as well as the rescue rounds (19), so an upper bound for the rescue half") if "rescue" in PMC_BYTES_PER_UNIT else None,
                                 "alg_bytes_per_batch": rescue_alg / args.steps / n_batches, "kernel_ms_per_batch": rescue_kernel_ms / args.steps / n_batches,
                                 "gcups": rescue_cells / (rescue_kernel_ms * 1e-3) / 1e9 if rescue_kernel_ms else None},
             "cpu_baseline": cpu, "parity": parity, "problems_failed": int((out["res"]["status"] != 0).sum())}))
@@ -742,13 +743,15 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
                         kernel_ms[k] += v
                 tot["seeds"] += int(seed_off[-1]); tot["ext"] += len(out["ext"]); tot["tails"] += int(st[0]); tot["trees"] += int(st[1]); tot["tree_nodes"] += int(st[2]); tot["failed"] += int(st[3])
                 tot["full_length"] += int((out["res"]["full_length"] != 0).sum()); tot["truncated"] += int(e.minimizers_truncated.sum())
+                if mins is not None:      # reads with more than 64 minimizers, seeded without find_seeds' policy (VGK_MINIMIZERS_POLICY_SKIPPED): a caller routes those through the shim's select_minimizers
+                    tot["policy_skipped"] += int(((np.asarray(mins, dtype=np.int64) & 0x40000000) != 0).sum())
                 if keep is not None and b == 0:
                     keep.update(read_score=out["read_score"].copy(), res=out["res"].copy(), ext=out["ext"].copy(), nodes=out["nodes"].copy(), seed_off=seed_off.copy(),
                                 ext_total=out["ext_total"].copy(), tails=out["tails"].copy(), tail_ops=out["tail_ops"].copy(),
                                 n_minimizers=int((np.asarray(mins, dtype=np.int64) & 0x7fffffff).sum()) if mins is not None else 19 * (len(off) - 1))
 
     def new_tot():
-        return {"seeds": 0, "ext": 0, "tails": 0, "trees": 0, "tree_nodes": 0, "failed": 0, "full_length": 0, "truncated": 0}
+        return {"seeds": 0, "ext": 0, "tails": 0, "trees": 0, "tree_nodes": 0, "failed": 0, "full_length": 0, "truncated": 0, "policy_skipped": 0}
 
     lanes = [(eng, index, mindex)]
     # a streaming caller keeps its read buffers: page-locked once (vgk_host_register), they go up at the link's rate

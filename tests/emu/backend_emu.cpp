@@ -35,6 +35,8 @@ struct XlEmu {
         if (mode == 0) { if (lane + 1 < lanes) out = sh->buf[lane + 1]; }
         else if (mode == 1) { if (lane > 0) out = sh->buf[lane - 1]; }
         else if (mode == 3) { for (uint32_t l = 0; l < lanes; ++l) out = bmax(out, sh->buf[l]); }
+        else if (mode == 4) out = sh->buf[0];
+        else if (mode == 5) out = sh->buf[lanes - 1];
         else for (uint32_t l = 0; l < lane; ++l) out = bmax(out, sh->buf[l]);
         pthread_barrier_wait(&sh->bar);
         return out;
@@ -58,6 +60,8 @@ struct XlEmu {
         return m;
     }
     int32_t reduce_max(int32_t v) { return exchange(v, 3); }
+    int32_t first_lane(int32_t v) { return exchange(v, 4); }
+    int32_t last_lane(int32_t v) { return exchange(v, 5); }
     unsigned long long reduce_add(unsigned long long v) {
         sh->wide[lane] = v;
         pthread_barrier_wait(&sh->bar);
@@ -76,6 +80,11 @@ template <int R, bool QA> static void banded_fill_emu(const BandedParams& P, uin
             BSrc src; src.rd = P.reads + pb.read_off; src.q = QA ? P.quals + pb.read_off : nullptr; src.graph = P.graph + pb.graph_off; src.mat = P.mat;
             src.rows = reinterpret_cast<const uint64_t*>(P.mat + BMAT_ROWS_AT);
             constexpr bool FAST = !QA && R <= 4;                            // the kernel's choice for problems staged in LDS; both paths give the same cells
+            if constexpr (R >= 16) {                                        // wide bands: blocks of 8 rows per lane, the other blocks' rows in the lane's store
+                std::vector<int32_t> store((size_t)(R / 8) * 3 * 8, BNEG);
+                if (std::getenv("VGAMD_EMU_BANDED_TALL_LANES")) banded_fill_lane<R, QA, false>(P, pb, src, lane, xl);      // (the form it replaces: the two must agree)
+                else banded_fill_lane_blocks<R / 8, QA>(P, pb, src, lane, xl, store.data(), 1u);
+            } else
             if (FAST && (i & 1) == 0) banded_fill_lane<R, QA, FAST>(P, pb, src, lane, xl);
             else banded_fill_lane<R, QA, false>(P, pb, src, lane, xl);
             xl.fence();

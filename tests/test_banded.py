@@ -333,6 +333,43 @@ def test_emulated_banded_device_geometry_declines_what_the_checks_decline(monkey
             assert not _same(ps, whole, other)
 
 
+# Bands of more than 512 diagonals (16 / 32 band rows per lane) run as blocks of 64 lanes x 8 rows, a lane's rows of the other blocks in LDS
+# (banded_fill_lane_blocks): the cells, codes and last columns of the tall-lane form it replaces (399-512 VGPRs, up to 1.6 KB of scratch per lane).
+def wide_band_problems(seed, n, max_read=700):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        p = gen.random_banded_problem(rng, max_nodes=8, max_node_len=40, max_read=max_read, p_empty=0.1)
+        p["band_padding"] = int(rng.integers(260, 1000)); p["permissive"] = bool(rng.random() < 0.8)
+        out.append(p)
+    return out
+
+
+def test_emulated_wide_bands_in_blocks_equal_tall_lanes_and_the_oracle(monkeypatch):
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    problems = wide_band_problems(91, 10, max_read=260)                          # (the emulator steps every lane of every column)
+    bs = capi.BandedSet.from_lists(problems)
+    blocks = capi.Engine(lib=util.EMU_LIB).banded_align(bs)
+    monkeypatch.setenv("VGAMD_EMU_BANDED_TALL_LANES", "1")
+    tall = capi.Engine(lib=util.EMU_LIB).banded_align(bs)
+    monkeypatch.delenv("VGAMD_EMU_BANDED_TALL_LANES")
+    ref = capi.Engine(lib=util.ORACLE_LIB).banded_align(bs)
+    assert not _same(problems, tall, blocks) and not _same(problems, ref, blocks)
+    assert (blocks[0]["status"] == 0).sum() >= 5
+
+
+@pytest.mark.gpu
+def test_hip_wide_bands_in_blocks_match_the_oracle():
+    problems = wide_band_problems(93, 400)
+    qual = None
+    bs = capi.BandedSet.from_lists(problems)
+    got = capi.Engine().banded_align(bs)
+    ref = capi.Engine(lib=util.ORACLE_LIB).banded_align(bs)
+    assert not _same(problems, ref, got)
+    assert (got[0]["status"] == 0).sum() > 200
+
+
 def against_the_oracle(problems, dev):
     """what the engine aligned or found band-less is the oracle's answer; what it declines (a band of more than 2048 diagonals, a node of more
     than 65 535 bases) the oracle may well align"""

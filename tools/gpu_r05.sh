@@ -101,6 +101,24 @@ for f in sorted(glob.glob(sys.argv[1] + "/config2_*.json")):
         print(f, "failed", e)
 PY
     ;;
+  banded_blocks)  # bands of more than 512 diagonals as blocks of 8 rows per lane: the banded gpu tests, and the fill's time beside round 4's tall-lane kernels
+    timeout 900 python -m pytest tests/test_banded.py -m gpu -x -q > "$out/pytest_banded.log" 2>&1; echo "rc=$?" >> "$out/pytest_banded.log"; tail -3 "$out/pytest_banded.log"
+    for lib in vg_amd/libvgamd.so build/variants/libvgamd_r04.so; do
+      PYTHONPATH=$GRAFT_REPO_ROOT:$GRAFT_REPO_ROOT/tests timeout 600 python - $lib <<'PY' | tee -a "$out/wide_band_fill_ms.txt"
+import ctypes, sys, time, numpy as np
+import util
+from vg_amd import capi
+from test_banded import wide_band_problems
+problems = wide_band_problems(95, 2000)
+bs = capi.BandedSet.from_lists(problems)
+eng = capi.Engine(lib=sys.argv[1])
+eng.lib.vgk_banded_last.restype = ctypes.c_double; eng.lib.vgk_banded_last.argtypes = [ctypes.c_void_p, ctypes.c_int]
+eng.banded_align(bs)
+t = time.perf_counter(); res, ops = eng.banded_align(bs); t = time.perf_counter() - t
+cells = eng.lib.vgk_banded_last(eng.h, 2); fill = eng.lib.vgk_banded_last(eng.h, 0)
+print(sys.argv[1], "2000 wide-band problems: fill %.2f ms, %.0f GCUPS, call %.1f ms, aligned %d" % (fill, cells / (fill * 1e-3) / 1e9 if fill else 0, 1e3 * t, int((res["status"] == 0).sum())))
+PY
+    done ;;
   default)        # what the driver runs: the headline + every secondary record
     timeout 1700 python bench.py > "$out/bench_default_run.json" 2> "$out/bench_default_run.err"; tail -c 400 "$out/bench_default_run.json" ;;
   *) echo "unknown stage $stage"; exit 2 ;;

@@ -324,6 +324,8 @@ struct XlDpp {
         return old;
     }
     __device__ __forceinline__ uint32_t width() const { return 64u; }
+    __device__ __forceinline__ int32_t first_lane(int32_t v) const { return __builtin_amdgcn_readlane(v, 0); }
+    __device__ __forceinline__ int32_t last_lane(int32_t v) const { return __builtin_amdgcn_readlane(v, 63); }
     __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
     __device__ __forceinline__ bool any(int32_t flag) const { return __ballot(flag != 0) != 0ull; }
     __device__ __forceinline__ unsigned long long ballot(bool flag) const { return __ballot(flag); }
@@ -367,6 +369,44 @@ __global__ void __launch_bounds__(64) banded_fill_kernel(const BandedParams P, c
     }
     XlDpp xl;
     banded_fill_lane<R, QA, FAST>(P, pb, src, threadIdx.x, xl);
+}
+
+// Wide bands (more than 512 diagonals): B blocks of 64 lanes x 8 rows per column, a lane's rows of the other blocks in LDS (banded_fill_lane_blocks)
+// — instead of 16 / 32 rows per lane in registers, which needed 399-512 VGPRs and up to 1.6 KB of scratch per lane.
+template <int B, bool QA, bool LDS>
+__global__ void __launch_bounds__(64) banded_fill_blocks_kernel(const BandedParams P, const uint32_t begin) {
+    extern __shared__ uint8_t smem[];
+    __shared__ int32_t bstate[B * 3 * 8 * 64];          // element e of lane l at bstate[e * 64 + l]: no bank conflicts
+    const BProb pb = P.probs[P.order[begin + blockIdx.x]];
+    BSrc src;
+    if (LDS) {       // stage what every column reads — score table, read, qualities, graph bases — into LDS once (as banded_fill_kernel)
+        constexpr uint32_t MAT = QA ? 6400u : 32u;
+        int8_t* smat = reinterpret_cast<int8_t*>(smem);
+        uint8_t* srd = smem + MAT; uint8_t* sq = srd + pb.L; uint8_t* sg = QA ? sq + pb.L : sq;
+        for (uint32_t i = threadIdx.x; i < (QA ? 6400u : 25u); i += 64) smat[i] = P.mat[i];
+        for (uint32_t i = threadIdx.x; i < pb.L; i += 64) { srd[i] = P.reads[pb.read_off + i]; if (QA) sq[i] = P.quals[pb.read_off + i]; }
+        for (uint32_t i = threadIdx.x; i < pb.graph_len; i += 64) sg[i] = P.graph[pb.graph_off + i];
+        __syncthreads();
+        src.rd = srd; src.q = sq; src.graph = sg; src.mat = smat;
+    } else {
+        src.rd = P.reads + pb.read_off; src.q = QA ? P.quals + pb.read_off : nullptr; src.graph = P.graph + pb.graph_off; src.mat = P.mat;
+    }
+    src.rows = nullptr;
+    XlDpp xl;
+    banded_fill_lane_blocks<B, QA>(P, pb, src, threadIdx.x, xl, bstate + threadIdx.x, 64u);
+}
+template <int B>
+static void launch_banded_fill_blocks(const BandedParams& p, const BandedLaunch& L, hipStream_t stream) {
+    const dim3 grid(L.count), block(64);
+    const bool qa = p.quals != nullptr;
+    const uint32_t dyn = (L.lds_bytes && L.lds_bytes + (uint32_t)sizeof(int32_t) * B * 3 * 8 * 64 <= 64u * 1024u) ? L.lds_bytes : 0u;      // (the blocks' state and the staged inputs share a workgroup's 64 KB)
+    if (dyn) {
+        if (qa) hipLaunchKernelGGL((banded_fill_blocks_kernel<B, true, true>), grid, block, dyn, stream, p, L.begin);
+        else    hipLaunchKernelGGL((banded_fill_blocks_kernel<B, false, true>), grid, block, dyn, stream, p, L.begin);
+    } else {
+        if (qa) hipLaunchKernelGGL((banded_fill_blocks_kernel<B, true, false>), grid, block, 0, stream, p, L.begin);
+        else    hipLaunchKernelGGL((banded_fill_blocks_kernel<B, false, false>), grid, block, 0, stream, p, L.begin);
+    }
 }
 
 template <int R>
@@ -1277,8 +1317,8 @@ public:
                 case 2:  launch_banded_fill<2>(p, L, st); break;
                 case 4:  launch_banded_fill<4>(p, L, st); break;
                 case 8:  launch_banded_fill<8>(p, L, st); break;
-                case 16: launch_banded_fill<16>(p, L, st); break;
-                case 32: launch_banded_fill<32>(p, L, st); break;
+                case 16: launch_banded_fill_blocks<2>(p, L, st); break;      // bands of more than 512 diagonals: blocks of 8 rows per lane (banded_fill_lane_blocks)
+                case 32: launch_banded_fill_blocks<4>(p, L, st); break;
                 default: return VGK_EINVAL;
             }
             if (st != stream) { hipEventRecord(side_done[i - 1], st); hipStreamWaitEvent(stream, side_done[i - 1], 0); }

@@ -355,6 +355,170 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
     }
 }
 
+// ---- fill, wide bands: the band as B BLOCKS of 64 lanes x 8 rows, one after the other per column ------------------------------------------------
+// A band of more than 512 diagonals used to run as 16 or 32 rows per lane: 399-512 VGPRs and up to 1.6 KB of scratch per lane (the row arrays of
+// banded_fill_lane live in registers only up to 8 rows).  Here a lane keeps 8 rows of ONE block in registers and the M / Ic / Ir of its rows in
+// the other blocks in `st` (LDS on the device, lane-interleaved: st[e * st_stride]); per column the blocks run top to bottom: block b's last lane
+// takes "the next row of the previous column" from block b + 1's first row, which that block has not overwritten yet (kept wave-uniform in
+// `first`), and block b's first lane takes the row above — the running maximum of the row-gap scan and the gap-opening sources — from what
+// block b - 1 has just computed for this column (wave-uniform carries).  Same cells, same codes, same last columns as banded_fill_lane<16 | 32>.
+// XL additionally supplies first_lane(v) / last_lane(v): the value of the first / last lane, to every lane.
+template <int B, bool QA, class XL>
+VGK_HD void banded_fill_lane_blocks(const BandedParams& P, const BProb& pb, const BSrc& src, uint32_t lane, XL& xl, int32_t* st, uint32_t st_stride) {
+    constexpr int R = 8;
+    const int32_t go = P.go, ge = P.ge, L = (int32_t)pb.L;
+    const uint32_t W = xl.width();
+    const BNode* nodes = P.nodes + pb.node_base;
+    int32_t* last = P.last + pb.last_base;
+    uint8_t* tb = P.tb + pb.tb_base;
+    auto S = [&](int b, int m, int i) -> int32_t& { return st[(uint32_t)((b * 3 + m) * R + i) * st_stride]; };
+    for (int b = 0; b < B; ++b) for (int m = 0; m < 3; ++m) for (int i = 0; i < R; ++i) S(b, m, i) = BNEG;
+    // block b's first row (M, Ic, Ir) of the column computed last: wave-uniform values, chosen by selects (the block loops are NOT unrolled — four
+    // copies of a column's code are 300 VGPRs — and a register array indexed by a loop counter would live in scratch)
+    int32_t first[B][3];
+    for (int b = 0; b < B; ++b) first[b][0] = first[b][1] = first[b][2] = BNEG;
+    auto first_get = [&](int b, int m) { int32_t v = BNEG; for (int q = 0; q < B; ++q) v = q == b ? first[q][m] : v; return v; };
+    auto first_set = [&](int b, int m, int32_t v) { for (int q = 0; q < B; ++q) first[q][m] = q == b ? v : first[q][m]; };
+    const bool last_l = lane + 1 == W, first_l = lane == 0;
+    for (uint32_t v = 0; v < pb.n_nodes; ++v) {
+        const BNode nd = nodes[v];
+        if (nd.masked || nd.len == 0) continue;
+        const int32_t H = nd.bot - nd.top + 1;
+        const uint8_t* seq = src.graph + nd.seq_off;
+        uint8_t* tbn = tb + nd.tb_off;
+        // the row gaps of block b's column and its traceback bytes (finish_column of banded_fill_lane, every column in its EDGE form); carries in
+        // and out: the scan's running maximum over the rows above, and M / Ic of the row right above a gap opening away
+        auto finish = [&](int b, int32_t j, const int32_t (&nM)[R], const int32_t (&nIc)[R], const int32_t (&ir0)[R], const uint32_t (&code_mc)[R],
+                          int32_t& carry_excl, int32_t& carry_upM, int32_t& carry_upIc) {
+            const int32_t k0 = (int32_t)((uint32_t)b * W + lane) * R, jge = j * ge;
+            int32_t run = BNEG, pre[R], kge[R];
+            for (int i = 0; i < R; ++i) {
+                kge[i] = (k0 + i + nd.top) * ge;
+                pre[i] = run;
+                const int32_t y = bmax(bmax(nM[i], nIc[i]) - go, ir0[i] - ge) + kge[i] + jge;
+                run = i == 0 ? y : bmax(run, y);
+            }
+            const int32_t excl = bmax(xl.scan_excl(run), carry_excl);
+            int32_t upM = xl.down(nM[R - 1]), upIc = xl.down(nIc[R - 1]);
+            upM = first_l ? carry_upM : upM - go; upIc = first_l ? carry_upIc : upIc - go;
+            uint8_t codes[R]; int32_t nIr[R];
+            for (int i = 0; i < R; ++i) {
+                const int32_t k = k0 + i, r = k + nd.top + j;
+                const bool valid = k < H && r >= 0 && r < L;
+                const int32_t from_above = (i == 0 ? excl : bmax(excl, pre[i])) + ge - kge[i] - jge;
+                int32_t ir = bmax(ir0[i], from_above);
+                const uint32_t cr = ir == upM ? BM : ir == upIc ? BIC : BIR;
+                if (!valid) ir = BNEG;
+                upM = nM[i] - go; upIc = nIc[i] - go;
+                nIr[i] = ir;
+                codes[i] = (uint8_t)(code_mc[i] | (cr << 2));
+            }
+            for (int i = 0; i < R; ++i) { S(b, 0, i) = nM[i]; S(b, 1, i) = nIc[i]; S(b, 2, i) = nIr[i]; }
+            if (k0 < (int32_t)nd.stride) store_codes<R>(tbn + (size_t)j * nd.stride + (uint32_t)k0, codes);
+            if (P.scores) {
+                int32_t* sc = P.scores + 3 * (pb.tb_base + nd.tb_off + (size_t)j * nd.stride);
+                for (int i = 0; i < R; ++i) if (k0 + i < (int32_t)nd.stride) { sc[k0 + i] = nM[i]; sc[nd.stride + k0 + i] = nIc[i]; sc[2 * nd.stride + k0 + i] = nIr[i]; }
+            }
+            carry_excl = xl.last_lane(bmax(excl, run));
+            carry_upM = xl.last_lane(nM[R - 1]) - go; carry_upIc = xl.last_lane(nIc[R - 1]) - go;
+            first_set(b, 0, xl.first_lane(nM[0])); first_set(b, 1, xl.first_lane(nIc[0])); first_set(b, 2, xl.first_lane(nIr[0]));
+        };
+        // a column whose left neighbour is the stored state (columns 1.. of a node; column 0 of a chained node)
+        auto column = [&](int32_t j) {
+            const uint32_t g = seq[j];
+            const int32_t lead_m = -go - (nd.cum + j - 1) * ge;
+            const int32_t lead_ir = nd.top + j < 0 ? -2 * go - (nd.cum + j) * ge : BNEG;
+            int32_t carry_excl = BNEG, carry_upM = BNEG, carry_upIc = BNEG;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                const int32_t k0 = (int32_t)((uint32_t)b * W + lane) * R;
+                int32_t M[R], Ic[R], Ir[R];
+                for (int i = 0; i < R; ++i) { M[i] = S(b, 0, i); Ic[i] = S(b, 1, i); Ir[i] = S(b, 2, i); }
+                // row k + 1 of the previous column for the lane's last row: the next lane's first row, or the next block's
+                int32_t nxM = xl.up(M[0]), nxIc = xl.up(Ic[0]), nxIr = xl.up(Ir[0]);
+                if (last_l) { nxM = first_get(b + 1, 0); nxIc = first_get(b + 1, 1); nxIr = first_get(b + 1, 2); }      // (past the last block: BNEG)
+                int32_t nM[R], nIc[R], ir0[R]; uint32_t code_mc[R];
+                for (int i = 0; i < R; ++i) {
+                    const int32_t k = k0 + i, r = k + nd.top + j;
+                    const bool valid = k < H && r >= 0 && r < L;
+                    const int32_t oM = (i + 1 < R ? M[i + 1 < R ? i + 1 : 0] : nxM) - go, oIc = (i + 1 < R ? Ic[i + 1 < R ? i + 1 : 0] : nxIc) - ge,
+                                  oIr = (i + 1 < R ? Ir[i + 1 < R ? i + 1 : 0] : nxIr) - go;
+                    const int32_t rc = r < 0 ? 0 : r >= L ? L - 1 : r;
+                    const int32_t ms = bsub<QA>(src, g, rc);
+                    const int32_t b3 = bmax(bmax(M[i], Ic[i]), Ir[i]);
+                    const uint32_t cm = b3 == M[i] ? BM : b3 == Ic[i] ? BIC : BIR;
+                    const int32_t icv = bmax(bmax(oM, oIr), oIc);
+                    const uint32_t cc = icv == oM ? BM : icv == oIc ? BIC : BIR;
+                    const bool top_row = r == 0;
+                    nM[i] = valid ? (top_row ? ms + lead_m : ms + b3) : BNEG;
+                    nIc[i] = valid ? icv : BNEG;
+                    ir0[i] = valid && top_row ? lead_ir : BNEG;
+                    code_mc[i] = cm | (cc << 4);
+                }
+                finish(b, j, nM, nIc, ir0, code_mc, carry_excl, carry_upM, carry_upIc);
+            }
+        };
+        int32_t j0 = 0;
+        if (!nd.chain) {
+            // ---- column 0: gather from the predecessors' last columns and the implied lead gaps (as banded_fill_lane)
+            const uint32_t g = seq[0];
+            const int32_t hi0 = nd.bot >= L ? L - 1 : nd.bot;
+            int32_t carry_excl = BNEG, carry_upM = BNEG, carry_upIc = BNEG;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b) {
+                const int32_t k0 = (int32_t)((uint32_t)b * W + lane) * R;
+                int32_t nM[R], nIc[R], ir0[R]; uint32_t code_mc[R];
+                for (int i = 0; i < R; ++i) {
+                    const int32_t k = k0 + i, r = k + nd.top;
+                    const bool valid = k < H && r >= 0 && r < L;
+                    int32_t m = BNEG, ic = BNEG, ir = BNEG;
+                    if (valid) {
+                        const int32_t ms = bsub<QA>(src, g, r);
+                        for (uint32_t si = 0; si < nd.n_seeds; ++si) {
+                            const BNode sd = nodes[P.seeds[pb.seed_base + nd.seed_off + si].node];
+                            const int32_t snt = sd.top + sd.len, snb = sd.bot + sd.len;
+                            const int32_t lo = snt < 0 ? 0 : snt, hi = snb >= L ? L - 1 : snb;
+                            if (r < lo || r > hi) continue;
+                            const int32_t ext = sd.cum + sd.len;
+                            const int32_t* sl = last + sd.last_off;
+                            if (r == lo && snt <= 0) {
+                                m = bmax(m, ms - go - (ext - 1) * ge);
+                                if (snt < 0) ir = bmax(ir, -2 * go - ext * ge);
+                            } else {
+                                const int32_t ks = r - snt;
+                                m = bmax(m, ms + bmax(bmax(sl[ks], sl[2 * sd.stride + ks]), sl[sd.stride + ks]));
+                            }
+                            if (r <= snb - 1) {
+                                const int32_t ks = r - snt + 1;
+                                ic = bmax(ic, bmax(bmax(sl[ks] - go, sl[2 * sd.stride + ks] - go), sl[sd.stride + ks] - ge));
+                            }
+                        }
+                        if (nd.as_source) {
+                            if (r == 0) { m = QA ? bmax(m, ms) : ms; ir = bmax(ir, -2 * go); ic = bmax(ic, -2 * go); }
+                            else { m = bmax(m, ms - go - (r - 1) * ge); ic = bmax(ic, -2 * go - r * ge); }
+                            if (r == hi0) ic = BNEG;
+                        }
+                    }
+                    nM[i] = m; nIc[i] = ic; ir0[i] = ir; code_mc[i] = 0;
+                }
+                finish(b, 0, nM, nIc, ir0, code_mc, carry_excl, carry_upM, carry_upIc);
+                int32_t* nf = last + nd.last_off + 3 * nd.stride;          // the traceback re-examines the predecessors from this column: keep its M and Ic
+                for (int i = 0; i < R; ++i) if (k0 + i < (int32_t)nd.stride) { nf[k0 + i] = S(b, 0, i); nf[nd.stride + k0 + i] = S(b, 1, i); }
+            }
+            j0 = 1;
+        }
+        for (int32_t j = j0; j < nd.len; ++j) column(j);
+        if (nd.keep_last) {
+            int32_t* nl = last + nd.last_off;
+            for (int b = 0; b < B; ++b) for (int i = 0; i < R; ++i) {
+                const uint32_t k = ((uint32_t)b * W + lane) * R + (uint32_t)i;
+                if (k < nd.stride) { nl[k] = S(b, 0, i); nl[nd.stride + k] = S(b, 1, i); nl[2 * nd.stride + k] = S(b, 2, i); }
+            }
+        }
+        xl.fence();        // successors read these through memory
+    }
+}
+
 // ---- traceback: one thread per problem (BAMatrix::traceback :756-1126, traceback_over_edge :1129-1780, BABuilder :44-205)
 struct BWalker {
     vgk_op* end; vgk_op* cur; vgk_op* floor;      // finished runs are written back to front

@@ -23,6 +23,9 @@ struct RescueRequest {
     // the best gapless extension inside the subgraph (dozeu's seed), or seed_node < 0 for none: read interval, first node of its path (index), offset there
     int64_t seed_begin = 0, seed_end = 0, seed_node = -1, seed_offset = 0;
 };
+// [PARITY deviation, stated: the reference hands longest_detectable_gap (a size_t) to align_xdrop's uint16_t parameter (src/minimizer_mapper.cpp:3383-3385),
+// where a value above 65 535 wraps modulo 65 536; both rescue paths here clamp it to 65 535 instead — the saner reading, and the same for every
+// scoring and read length a 16-bit score range admits (150-base reads: 81).]
 struct RescueResult {
     int32_t score = 0; int32_t status = 0;                  // status: 0 aligned (score may be 0), 1 refused by the cell budget, 2 empty subgraph
     int64_t first_node = -1, first_offset = 0; uint32_t n_mappings = 0, aligned_read_bases = 0;

@@ -496,7 +496,6 @@ def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device
     # where the mapped mate lies: the first node of its first (full-length) extension, on the strand the read reads forward on
     e0 = res["ext_begin"][mapped].astype(np.int64)
     first = nodes[ext["path_begin"][e0].astype(np.int64)].astype(np.int64)
-    last = nodes[(ext["path_begin"][e0].astype(np.int64) + ext["path_len"][e0] - 1)].astype(np.int64)
     fwd = (first & 1) == 0
     col = g.col
     # forward-mapped mate starting at column s: its partner lies downstream on the other strand, within [s + mean - k sd - L, s + mean + k sd];
