@@ -119,6 +119,24 @@ cells = eng.lib.vgk_banded_last(eng.h, 2); fill = eng.lib.vgk_banded_last(eng.h,
 print(sys.argv[1], "2000 wide-band problems: fill %.2f ms, %.0f GCUPS, call %.1f ms, aligned %d" % (fill, cells / (fill * 1e-3) / 1e9 if fill else 0, 1e3 * t, int((res["status"] == 0).sum())))
 PY
     done ;;
+  gapless_pmc)    # where the gapless search's bytes come from: L2 hits / misses, vector-memory and scratch instruction counts of its kernels (counter passes, kernel trace only)
+    P=$GRAFT_REPO_ROOT/gpurun_out/r05_pmc; mkdir -p $P
+    ( cd /tmp && timeout 120 rocprofv3 -L 2>/dev/null | grep -ioE "\b(TCC_HIT_sum|TCC_MISS_sum|TCC_REQ_sum|TCC_EA0_RDREQ_sum|TCC_EA0_WRREQ_sum|TCP_TCC_READ_REQ_sum|TCP_TCC_WRITE_REQ_sum|SQ_INSTS_VMEM_RD|SQ_INSTS_VMEM_WR|SQ_INSTS_FLAT|SQ_INSTS_LDS|SQ_INSTS_SALU|SQ_INSTS_VALU|SQ_WAVE_CYCLES|SQ_WAIT_ANY|SQ_WAIT_INST_ANY|SQ_ACTIVE_INST_ANY|SQ_INSTS_SMEM|SQ_INST_LEVEL_VMEM|SQ_INSTS_VMEM|SQ_INSTS_SCRATCH[A-Z_]*|SPI_[A-Z_]*SCRATCH[A-Z_]*)\b" | sort -u > $P/counters_available.txt ); cat $P/counters_available.txt | tr '\n' ' '; echo
+    B="python $GRAFT_REPO_ROOT/bench.py --workload gapless --reads 1000000 --no-cpu --no-e2e --no-secondary --steps 2 --warmup 1"
+    for set in "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+      tag=$(echo $set | tr ' ' '+')
+      ( cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $P/gapless_$tag -o p -- $B > $P/gapless_$tag.log 2>&1 )
+      python - $P/gapless_$tag <<'PY'
+import csv, glob, sys, collections
+f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
+if not f: print("no counters in", sys.argv[1]); sys.exit(0)
+tot = collections.defaultdict(float); n = collections.defaultdict(set)
+for r in csv.DictReader(open(f[0])):
+    k = (r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"]); tot[k] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
+for k in sorted(tot):
+    if "gapless" in k[0]: print(k[0], k[1], "%.4g per dispatch over %d dispatches" % (tot[k] / len(n[k]), len(n[k])))
+PY
+    done ;;
   default)        # what the driver runs: the headline + every secondary record
     timeout 1700 python bench.py > "$out/bench_default_run.json" 2> "$out/bench_default_run.err"; tail -c 400 "$out/bench_default_run.json" ;;
   *) echo "unknown stage $stage"; exit 2 ;;
