@@ -655,7 +655,7 @@ def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
                                                                                                   "%d worker threads per lane) over ONE copy of the haplotype and minimizer indexes" % lane_threads) if n_lanes > 1 else "one after the other in one lane"),
                        "one_context": one_context, "ms_per_batch": 1e3 * elapsed / args.steps / n_batches,
                        "timed_region": ("per step, one batch of pairs from host buffers: vgk_minimizer_seeds -> vgk_gapless_extend_seeded -> vgk_tail_stage for all 2 n reads, then the request table "
-                                        "(vgh_rescue_requests: chunked host threads over the extension sets), then vgh_rescue_stage_resident: both X-drop passes of every lost mate as extension windows of the "
+                                        "(vgk_rescue_requests: one lane per pair over the sets where the extension kernels left them; the host adds the lost mates' bytes), then vgh_rescue_stage_resident: both X-drop passes of every lost mate as extension windows of the "
                                         "resident graph (vgk_gssw_pack_extensions: sub-DAGs derived on the device), dozeu's scan and the full-DP fallback as plain windows, the fix-ups over flat arrays") if rg is not None else
                                        ("per step, one batch of pairs from host buffers: the stage for all 2 n reads, the rescue requests (numpy), then vgh_rescue_stage: one HashGraph per mate on host threads, "
                                         "Aligner::align_xdrop_many, the fix-ups [VGAMD_PAIRED_PER_GRAPH: round 4's form]"),

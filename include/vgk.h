@@ -247,6 +247,28 @@ typedef struct vgk_extension_problem {
 } vgk_extension_problem;
 int  vgk_gssw_pack_extensions(vgk_ctx* ctx, const vgk_dgraph* graph, const char* reads, size_t reads_bytes,
                               const vgk_extension_problem* problems, uint32_t n, uint32_t ops_per_problem, vgk_batch** out);
+/* Which pairs of the batch the last vgk_gapless_extend / vgk_gapless_extend_seeded call on this context extended (reads 2 i and 2 i + 1 are
+ * a pair) are rescue candidates, and what the rescue of each is given: a pair with a full-length extension set for exactly one mate
+ * (MinimizerMapper::map_paired, src/minimizer_mapper.cpp:1793-1901, rescues the end without alignments from the other), the rescue nodes
+ * [node_lo, node_hi) of the resident graph at the fragment's distance from the mapped mate (attempt_rescue, :3264-3300, takes them from
+ * subgraph_in_distance_range over the SnarlDistanceIndex — an absent dependency: here the nodes whose columns lie within
+ * [mean - k sd - read length, (mean + k sd) 1.1 + 40] of the mapped mate's start, downstream of a forward-mapped mate and upstream of a
+ * reverse-mapped one, on a graph whose node order is topological; a stated stand-in), and dozeu's seed: the best gapless extension of the
+ * lost mate inside those nodes on the strand it is rescued on, the earlier among equals (:3322-3348), as the mate reads along the forward
+ * strand of the subgraph.  The sets never leave HBM for this: one lane per pair reads them where the extension kernels left them; only the
+ * table comes down, in pair order.  `graph`: the resident graph whose node v is the index's node v (any context of the same device).
+ * *written = the entries needed (VGK_EOPS when cap is too small). */
+typedef struct vgk_rescue_request {
+    uint32_t mapped, lost;           /* reads of the batch */
+    uint32_t node_lo, node_hi;       /* the rescue nodes */
+    int32_t  seed_begin, seed_end;   /* the seed's read interval (0, 0 without a seed) ... */
+    int32_t  seed_node;              /* ... the node it starts on (-1: none) ... */
+    int32_t  seed_offset;            /* ... and the offset there */
+    uint32_t reverse;                /* 1: the lost mate is rescued as its reverse complement (its partner maps forward) */
+    uint32_t reserved;
+} vgk_rescue_request;
+int  vgk_rescue_requests(vgk_ctx* ctx, const vgk_dgraph* graph, double fragment_mean, double fragment_sd, double rescue_stdevs,
+                         vgk_rescue_request* requests, size_t cap, size_t* written);
 /* ---- tail forests: the subgraphs giraffe aligns read tails to (MinimizerMapper::get_tail_forest, src/minimizer_mapper.cpp:5745-5860;
  * dfs_gbwt :5909-6013) ---------------------------------------------------------------------------------------------------------------
  * For an extension that does not reach an end of the read, giraffe walks the haplotypes that continue it — a depth-first search over

@@ -555,6 +555,11 @@ int vgk_set_speculation(vgk_ctx* ctx, int mode) { (void)ctx; return (mode < 0 ||
 int vgk_speculation_state(vgk_ctx* ctx, uint64_t counters[4], double* last_miss_share) {
     (void)ctx; if (counters) counters[0] = counters[1] = counters[2] = counters[3] = 0; if (last_miss_share) *last_miss_share = 0.0; return 0; }
 
+/* the oracle keeps no sets between calls (every entry point takes and returns host arrays): the table over host arrays that the engine's
+ * vgk_rescue_requests is checked against is vg_amd/host/rescue_requests.cpp */
+int vgk_rescue_requests(vgk_ctx* ctx, const vgk_dgraph* graph, double fragment_mean, double fragment_sd, double rescue_stdevs, vgk_rescue_request* requests, size_t cap, size_t* written) {
+    (void)ctx; (void)graph; (void)fragment_mean; (void)fragment_sd; (void)rescue_stdevs; (void)requests; (void)cap; if (written) *written = 0; return VGK_EUNSUPPORTED; }
+
 /* ---- tail forests (vgo_tail.c) behind the engine's entry points: the walks, then the forest as one graph through the oracle's
  * own vgk_graph_create (node lengths, the bases behind the cuts copied out of the index, one predecessor per non-root node) ---- */
 int vgo_tail_forest(const vgk_haplo* h, const vgk_tail_problem* pb, vgk_tail_result* out, int32_t** parent, uint32_t** node, uint32_t** len, size_t* n, size_t* cap);

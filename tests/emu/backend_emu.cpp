@@ -179,6 +179,10 @@ public:
         if (P.pass == 1) { for (uint32_t i = P.lo; i < P.hi; ++i) minimizer_one(P, i); } else for (uint32_t i = 0; i < P.n; ++i) minimizer_one(P, i);
         return VGK_OK;
     }
+    int run_rescue_requests(const RqParams& P, int what) override {
+        if (what == RQ_FLAG) { for (uint32_t p = 0; p <= P.n_pairs; ++p) rq_flag_one(P, p); } else { for (uint32_t p = 0; p < P.n_pairs; ++p) rq_emit_one(P, p); }
+        return VGK_OK;
+    }
     int run_tail_stage(const TStageParams& P, int what) override { const uint32_t items = tstage_items(P, what); for (uint32_t i = 0; i < items; ++i) tstage_one(P, what, i); return VGK_OK; }
     int run_tail(const TailParams& P, uint32_t threads) override {
         for (uint32_t t = 0; t < threads; ++t) for (uint32_t i = t; i < P.n; i += threads) tail_walk_one(P, i, P.scratch[t]);

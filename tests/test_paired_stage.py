@@ -21,14 +21,16 @@ def emu_lib():
     return EMU_LIB
 
 
-def run(lib, wl, device, resident=False):
+def run(lib, wl, device, resident=False, request_table=None):
     eng = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=lib)
     graph = (wl.node_len, wl.seq)
     index = eng.haplo_index(graph, wl.threads); mindex = eng.minimizer_index(graph, wl.threads)
     aligner = pipeline.HostAlignerHandle(lib)
     olen = np.repeat(wl.node_len, 2)
     rg = aligner.rescue_graph(wl) if resident else None
-    out = pipeline.paired_stage(eng, index, mindex, wl, aligner, oriented_len=olen, device=device, resident=rg, want_ops=True)
+    timing = {}
+    out = pipeline.paired_stage(eng, index, mindex, wl, aligner, oriented_len=olen, device=device, resident=rg, want_ops=True, request_table=request_table, timing=timing)
+    out["timing_keys"] = set(timing)
     if rg is not None:
         rg.close()
     aligner.close()
@@ -54,6 +56,13 @@ def check(lib, n_pairs, device):
     # engine under test and over the oracle's own extension windows
     res_got = run(lib, wl, device, resident=True)
     same_rescues(res_got, want, "resident path on the engine vs the reference-shaped path on the oracle")
+    # (that run took its request table from vgk_rescue_requests — one lane per pair over the sets in HBM; the same with the table made by host
+    # threads over the fetched sets, vg_amd/host/rescue_requests.cpp)
+    if device:
+        assert "rescue requests (device table + the mates' reads)" in res_got["timing_keys"]
+        host_table = run(lib, wl, device, resident=True, request_table="host")
+        assert "rescue requests (host threads)" in host_table["timing_keys"]
+        same_rescues(host_table, want, "resident path, request table on host threads, vs the reference-shaped path on the oracle")
     same_rescues(run(ORACLE_LIB, wl, False, resident=True), want, "resident path on the oracle vs the reference-shaped path on the oracle")
     c = res_got["rescue_counts"]
     assert c["first_pass"] + c["scans"] > 0 and c["second_pass"] > 0

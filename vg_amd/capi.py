@@ -37,6 +37,9 @@ assert WINDOW_DT.itemsize == 32
 EXTENSION_DT = np.dtype([("read_off", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), ("first_node", "<u4"), ("n_nodes", "<u4"), ("max_gap_length", "<u4"),
                          ("start_node", "<u4"), ("start_offset", "<u4"), ("query_offset", "<u4"), ("leftward", "<u4"), ("reserved", "<u4")])
 assert EXTENSION_DT.itemsize == 48
+RESCUE_REQUEST_DT = np.dtype([("mapped", "<u4"), ("lost", "<u4"), ("node_lo", "<u4"), ("node_hi", "<u4"), ("seed_begin", "<i4"), ("seed_end", "<i4"),
+                              ("seed_node", "<i4"), ("seed_offset", "<i4"), ("reverse", "<u4"), ("reserved", "<u4")])
+assert RESCUE_REQUEST_DT.itemsize == 40
 BANDED_DT = np.dtype([("read", "<u8"), ("qual", "<u8"), ("read_len", "<u4"), ("flags", "<u4"), ("graph", GRAPH_DT),
                       ("band_padding", "<i4"), ("reserved", "<u4"), ("max_cells", "<u8")])
 VGK_BANDED_PERMISSIVE = 1
@@ -343,6 +346,22 @@ class Engine:
         self._check(self.lib.vgk_gssw_pack_extensions(self.h, graph.h, es.reads.ctypes.data, es.reads.size, es.array.ctypes.data, es.n,
                                                       ops_per_problem, ctypes.byref(b)), "vgk_gssw_pack_extensions")
         return Batch(self, b, es, ops_per_problem)
+
+    def rescue_requests(self, graph, mean, sd, stdevs=4.0, out=None):
+        """vgk_rescue_requests over the sets the last gapless_extend(_seeded) call on this context left in HBM; graph: a DeviceGraph or a vgk_dgraph
+        pointer (int) of the same device; out: a RESCUE_REQUEST_DT array to fill (grown when too small) -> the filled part"""
+        gh = graph if isinstance(graph, int) else graph.h
+        self.lib.vgk_rescue_requests.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        if out is None:
+            out = np.zeros(4096, dtype=RESCUE_REQUEST_DT)
+        w = ctypes.c_size_t()
+        rc = self.lib.vgk_rescue_requests(self.h, gh, float(mean), float(sd), float(stdevs), out.ctypes.data, len(out), ctypes.byref(w))
+        if rc == VGK_EOPS:
+            out = np.zeros(int(w.value) + int(w.value) // 8 + 64, dtype=RESCUE_REQUEST_DT)
+            rc = self.lib.vgk_rescue_requests(self.h, gh, float(mean), float(sd), float(stdevs), out.ctypes.data, len(out), ctypes.byref(w))
+        self._check(rc, "vgk_rescue_requests")
+        self._rescue_requests_buf = out
+        return out[:int(w.value)]
 
     def align_extensions(self, graph, es, ops_per_problem=0):
         with self.pack_extensions(graph, es, ops_per_problem) as b:

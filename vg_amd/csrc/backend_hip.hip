@@ -745,6 +745,11 @@ __global__ void __launch_bounds__(256) tail_stage_kernel(const TStageParams P, c
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < items) tstage_one(P, what, i);
 }
+__global__ void __launch_bounds__(256) rescue_requests_kernel(const RqParams P, const int what) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (what == RQ_FLAG) { if (p <= P.n_pairs) rq_flag_one(P, p); }
+    else if (p < P.n_pairs) rq_emit_one(P, p);
+}
 __global__ void __launch_bounds__(256) forest_flags_kernel(const ForestParams P) {
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     if (v < P.n_nodes) forest_flags_one(P, v);
@@ -1476,6 +1481,11 @@ public:
         const uint32_t items = tstage_items(p, what);
         if (!items) return VGK_OK;
         hipLaunchKernelGGL(tail_stage_kernel, dim3((items + 255) / 256), dim3(256), 0, stream, p, what, items);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int run_rescue_requests(const RqParams& p, int what) override {
+        hipSetDevice(dev);
+        hipLaunchKernelGGL(rescue_requests_kernel, dim3((p.n_pairs + 256) / 256), dim3(256), 0, stream, p, what);
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_tail(const TailParams& p, uint32_t threads) override {

@@ -8,6 +8,7 @@
 #include <deque>
 #include <memory>
 #include <string>
+#include <thread>
 #include "aligner.hpp"
 #include "tail_stage.hpp"
 #include "gbwt_extender.hpp"
@@ -302,6 +303,38 @@ int64_t vgh_rescue_requests(uint32_t n_pairs, const vgk_gapless_result* results,
         std::copy(t.mapped.begin(), t.mapped.end(), mapped); std::copy(t.lost.begin(), t.lost.end(), lost);
         std::copy(t.requests.begin(), t.requests.end(), requests); std::copy(t.reads.begin(), t.reads.end(), rescue_reads);
         return (int64_t)t.mapped.size();
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
+// the resident graph as the engine knows it (a vgk_dgraph of the aligner's context: vgk_rescue_requests takes it from any context of the same device)
+const void* vgh_rescue_graph_dgraph(vgh_rescue_graph* g) { return g && g->g ? (const void*)g->g->dg : nullptr; }
+// The table vgk_rescue_requests made on the device, in the form vgh_rescue_stage_resident takes (mapped, lost, 6 numbers per request as above) with the
+// lost mates' reads as they read along the forward strand of their subgraphs (read_len each; reverse-complemented where the request says so): the
+// one part of the table that needs the reads' own bytes, which are the host's (the engine keeps them masked).  Chunked host threads; a read is
+// three cache lines and a table lookup per base.
+int vgh_rescue_reads(uint32_t m, const vgk_rescue_request* table, const char* reads, uint32_t read_len, int host_threads,
+                     uint32_t* mapped, uint32_t* lost, int64_t* requests, char* rescue_reads) {
+    try {
+        static const std::array<char, 256> comp = [] { std::array<char, 256> t{}; for (int c = 0; c < 256; ++c) t[(size_t)c] = (char)c; t['A'] = 'T'; t['C'] = 'G'; t['G'] = 'C'; t['T'] = 'A'; return t; }();
+        unsigned threads = host_threads > 0 ? (unsigned)host_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+        threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(m / 2048, 1));
+        auto body = [&](size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi; ++k) {
+                if (k + 4 < hi) { const char* nx = reads + (size_t)table[k + 4].lost * read_len; __builtin_prefetch(nx); __builtin_prefetch(nx + 64); __builtin_prefetch(nx + 128); }
+                const vgk_rescue_request& r = table[k];
+                mapped[k] = r.mapped; lost[k] = r.lost;
+                int64_t* q = requests + 6 * k;
+                q[0] = r.node_lo; q[1] = r.node_hi; q[2] = r.seed_begin; q[3] = r.seed_end; q[4] = r.seed_node; q[5] = r.seed_offset;
+                const char* src = reads + (size_t)r.lost * read_len; char* dst = rescue_reads + k * (size_t)read_len;
+                if (r.reverse) for (uint32_t t = 0; t < read_len; ++t) dst[t] = comp[(unsigned char)src[read_len - 1 - t]]; else std::copy(src, src + read_len, dst);
+            }
+        };
+        if (threads < 2) { body(0, m); return 0; }
+        std::vector<std::thread> ts; const size_t per = ((size_t)m + threads - 1) / threads;
+        for (unsigned t = 1; t < threads; ++t) ts.emplace_back([&, t]() { const size_t lo = std::min<size_t>(m, t * per), hi = std::min<size_t>(m, lo + per); if (lo < hi) body(lo, hi); });
+        body(0, std::min<size_t>(m, per));
+        for (auto& t : ts) t.join();
+        return 0;
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }
 

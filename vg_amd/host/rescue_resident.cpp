@@ -5,7 +5,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <exception>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -43,6 +45,17 @@ template <class F> void for_chunks(size_t n, unsigned threads, F body) {
     for (auto& t : ts) t.join();
     if (first) std::rethrow_exception(first);
 }
+
+// Room for a round's op lists: ops_per_problem entries per problem is what the engine may write, a tenth of that is what it does write (the lists come
+// packed behind each other) — so the room is never filled in (a std::vector would write 20 MB of zeros per batch, touching every page), only claimed.
+struct OpBuffer {
+    std::unique_ptr<vgk_op[]> p; size_t cap = 0;
+    void need(size_t n) { if (n > cap) { p.reset(new vgk_op[n]); cap = n; } }
+    vgk_op* data() const { return p.get(); }
+};
+
+// the stretch of `len` bases of a node against the read: pushes the match runs and single-base substitutions (eight bases per comparison while they agree)
+inline uint64_t load8(const char* q) { uint64_t w; std::memcpy(&w, q, 8); return w; }
 
 // an alignment as the fix-ups see it: mappings of edits (what Alignment / Path / Mapping / Edit hold, without the strings)
 enum : uint8_t { E_MATCH = 0, E_SUB = 1, E_DEL = 2, E_INS = 3 };
@@ -160,7 +173,7 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
     const uint32_t OPS_PER = max_nodes + 96;
     auto check = [&](int rc, const char* what) { if (rc != VGK_OK) throw std::runtime_error(std::string("vgamd: rescue stage: ") + what + " failed: " + api.strerror(rc)); };
     auto round = [&](const std::vector<vgk_extension_problem>& ep, const std::vector<vgk_window_problem>& wp, bool traced,
-                     std::vector<vgk_result>& er, std::vector<vgk_op>& eo, std::vector<vgk_result>& wr, std::vector<vgk_op>& wo) {
+                     std::vector<vgk_result>& er, OpBuffer& eo, std::vector<vgk_result>& wr, OpBuffer& wo) {
         vgk_batch* be = nullptr; vgk_batch* bw = nullptr;
         struct Free { const EngineApi& api; vgk_batch*& b; ~Free() { if (b) api.batch_free(b); } } fe{api, be}, fw{api, bw};
         if (!ep.empty()) check(api.gssw_pack_extensions(ctx, G.dg, reads, reads_bytes, ep.data(), (uint32_t)ep.size(), traced ? OPS_PER : 0, &be), "vgk_gssw_pack_extensions");
@@ -169,13 +182,13 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
         if (bw) check(api.gssw_run(bw), "vgk_gssw_run");
         size_t written = 0;
         er.assign(ep.size(), vgk_result{}); wr.assign(wp.size(), vgk_result{});
-        if (be) { eo.resize(traced ? ep.size() * (size_t)OPS_PER + 1 : 1); check(api.gssw_fetch(be, er.data(), eo.data(), traced ? eo.size() : 0, &written), "vgk_gssw_fetch"); }
-        if (bw) { wo.resize(traced ? wp.size() * (size_t)OPS_PER + 1 : 1); check(api.gssw_fetch(bw, wr.data(), wo.data(), traced ? wo.size() : 0, &written), "vgk_gssw_fetch"); }
+        if (be) { eo.need(traced ? ep.size() * (size_t)OPS_PER + 1 : 1); check(api.gssw_fetch(be, er.data(), eo.data(), traced ? eo.cap : 0, &written), "vgk_gssw_fetch"); }
+        if (bw) { wo.need(traced ? wp.size() * (size_t)OPS_PER + 1 : 1); check(api.gssw_fetch(bw, wr.data(), wo.data(), traced ? wo.cap : 0, &written), "vgk_gssw_fetch"); }
         if (timing) for (vgk_batch* b : {be, bw}) if (b) { timing->kernel_ms += api.batch_kernel_ms(b, -1); timing->alg_bytes += api.batch_alg_bytes(b); timing->cells += api.batch_cells(b); }
         for (const vgk_result& r : er) check(r.status, "an extension window");
         for (const vgk_result& r : wr) check(r.status, "a window");
     };
-    std::vector<vgk_result> er, wr; std::vector<vgk_op> eo, wo;
+    std::vector<vgk_result> er, wr; OpBuffer eo, wo;
     round(ext1, scan, false, er, eo, wr, wo);
     if (timing) { timing->first_pass += ext1.size(); timing->scans += scan.size(); }
     // the heads (xdrop_extend_finish's end position; the scan's end cell: src/dozeu_interface.cpp:188-208)
@@ -207,6 +220,7 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
     // ---- 3. the alignments (xdrop_extend_finish + xdrop_finish), fix_dozeu_score's verdict; what it accepts gets its answer at once
     // (one FlatAlignment per host thread, the op runs of a chunk of mates behind each other in the chunk's own buffer: no allocation per mate)
     const bool want_ops = out_ops && out_ops_begin;
+    const char* const seq_end = G.seq + G.seq_off[G.n_nodes]; const char* const reads_end = reads + reads_bytes;
     const size_t CH = 256, n_chunks = (n + CH - 1) / CH;
     std::vector<std::vector<vgk_op>> chunk_ops(want_ops ? n_chunks : 0);
     std::vector<uint32_t> op_at(want_ops ? n : 0, 0), op_count(n, 0);                      // where in its chunk's buffer a mate's runs start; how many
@@ -235,6 +249,13 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
         std::vector<vgk_op>* sink = want_ops ? &chunk_ops[lo / CH] : nullptr;
         for (size_t k = lo; k < hi; ++k) {
             State& s = st[k]; const RescueRequestFlat& rq = requests[k];
+            if (k + 2 < hi && st[k + 2].slot2 >= 0) {                                       // what the mate after next will read: its op list, its window's bases, its read
+                const RescueRequestFlat& nx = requests[k + 2]; const vgk_result& nr = er[(size_t)st[k + 2].slot2];
+                __builtin_prefetch(eo.data() + nr.ops_begin);
+                const char* b = G.seq + G.seq_off[std::min<uint32_t>(st[k + 2].head_node, G.n_nodes - 1)] + st[k + 2].head_ref;      // (the pass runs leftwards from the head)
+                for (int line = -3; line <= 1; ++line) __builtin_prefetch(b + 64 * line);
+                __builtin_prefetch(reads + nx.read_off); __builtin_prefetch(reads + nx.read_off + 64); __builtin_prefetch(reads + nx.read_off + 128);
+            }
             if (s.kind == R_DONE || !s.have_head) continue;
             const char* read = reads + rq.read_off;
             a.clear();
@@ -243,7 +264,7 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
                 const vgk_result& r = er[(size_t)s.slot2];
                 down_score = r.score;
                 // the pass ran on reversed strings: flip it back (unreverse_graph_mapping, src/aligner.cpp:255-300, on the op list)
-                ops.assign(eo.begin() + r.ops_begin, eo.begin() + r.ops_begin + r.n_ops);
+                ops.assign(eo.data() + r.ops_begin, eo.data() + r.ops_begin + r.n_ops);
                 std::reverse(ops.begin(), ops.end());
                 const uint32_t first = ops[0].node; uint32_t aligned = 0, groups = 1;
                 for (size_t i = 0; i < ops.size(); ++i) {
@@ -264,9 +285,17 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
                         const uint32_t len = ops[q].len;
                         if (ops[q].op == VGK_OP_M) {
                             uint32_t run = 0;
-                            for (uint32_t t = 0; t < len; ++t) {
-                                if (node_seq[fp + t] == read[to_pos + t]) ++run;
+                            const char* x = node_seq + fp; const char* y = read + to_pos;
+                            for (uint32_t t = 0; t < len;) {
+                                if (t + 8 <= len && x + t + 8 <= seq_end && y + t + 8 <= reads_end) {
+                                    const uint64_t d = load8(x + t) ^ load8(y + t);
+                                    if (!d) { run += 8; t += 8; continue; }
+                                    const uint32_t same = (uint32_t)(__builtin_ctzll(d) >> 3);
+                                    run += same; t += same;
+                                }
+                                if (x[t] == y[t]) ++run;
                                 else { if (run) { a.push(E_MATCH, run); run = 0; } a.push(E_SUB, 1); }
+                                ++t;
                             }
                             if (run) a.push(E_MATCH, run);
                             fp += len; to_pos += len;

@@ -455,7 +455,8 @@ class ChainStage:
 
 
 # ---- a paired-end slice: both mates through the stage, the mate without a full-length extension rescued from the other's position ------------
-def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device=True, rescue_stdevs=4.0, timing=None, host_threads=0, resident=None, want_ops=False):
+def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device=True, rescue_stdevs=4.0, timing=None, host_threads=0, resident=None, want_ops=False,
+                 request_table=None):
     """giraffe's paired-end shape on one batch of pairs (PairedWorkload): (1) every read through seeding, gapless extension and the tails
     (align_stage_device, or align_stage over the oracle when device = False); (2) for a pair with exactly one mate whose extension set is
     full-length, the other mate is RESCUED: the nodes at the fragment's distance from the mapped mate — here a run of nodes found by
@@ -466,7 +467,9 @@ def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device
     resident: a RescueGraphHandle (host_aligner.rescue_graph(wl)) — the rescue half then runs on the RESIDENT graph (vg_amd/host/rescue_resident.cpp:
     every X-drop pass an extension window whose sub-DAG the device derives, the fix-ups over flat arrays); without it the reference-shaped path
     (rescue_stage.cpp: one HashGraph and one Alignment per mate) — the form the checker runs over the oracle.  want_ops: also the rescued
-    alignments as (node, op, length) runs (`rescue_ops`, `rescue_ops_begin`).
+    alignments as (node, op, length) runs (`rescue_ops`, `rescue_ops_begin`).  request_table (resident route): "device" — vgk_rescue_requests over
+    the sets the stage left in HBM (the default when device = True) — or "host": vg_amd/host/rescue_requests.cpp over the fetched sets, the
+    statement the tests hold the device's table against.
     -> dict(read_score, rescued (indices of rescued reads), rescue (RESCUE_DT-like int64 [k, 6]), pair_score)"""
     import time
     t0 = time.perf_counter()
@@ -488,7 +491,8 @@ def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device
     g = wl.graph
     if resident is not None:
         # the product route: the request table from the extension sets on chunked host threads (vg_amd/host/rescue_requests.cpp), no numpy in between
-        return _paired_stage_resident(eng, wl, host_aligner, resident, out, read_score, rescue_stdevs, timing, host_threads, want_ops, t0, t1)
+        return _paired_stage_resident(eng, wl, host_aligner, resident, out, read_score, rescue_stdevs, timing, host_threads, want_ops, t0, t1,
+                                      table_on_device=device if request_table is None else request_table == "device")
     full = (res["status"] == 0) & (res["full_length"] != 0)
     a_full, b_full = full[0::2], full[1::2]
     pairs = np.nonzero(a_full != b_full)[0]
@@ -585,7 +589,7 @@ def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device
                 rescue_counts=dict(zip(("first_pass", "scans", "second_pass", "fallbacks", "alg_bytes", "cells"), (int(x) for x in counts)), kernel_ms=float(laps[5])))
 
 
-def _paired_stage_resident(eng, wl, host_aligner, resident, out, read_score, rescue_stdevs, timing, host_threads, want_ops, t0, t1):
+def _paired_stage_resident(eng, wl, host_aligner, resident, out, read_score, rescue_stdevs, timing, host_threads, want_ops, t0, t1, table_on_device=False):
     import time
     h = _host_lib()
     res, ext, nodes = np.ascontiguousarray(out["res"]), np.ascontiguousarray(out["ext"]), np.ascontiguousarray(out["nodes"], dtype=np.uint32)
@@ -596,6 +600,15 @@ def _paired_stage_resident(eng, wl, host_aligner, resident, out, read_score, res
                                  np.zeros(n_pairs * L, dtype=np.uint8), np.zeros((n_pairs, 6), dtype=np.int64), np.arange(n_pairs + 1, dtype=np.uint64) * L,
                                  np.ascontiguousarray(g.col, dtype=np.int64))
     _, mapped, lost, req, rd, outv, roff, col = bufs
+    if table_on_device:
+        # the table from the sets where the extension kernels left them (one lane per pair); the host adds the lost mates' own bytes
+        tab = eng.rescue_requests(resident.dgraph, wl.mean, wl.sd, rescue_stdevs, out=getattr(resident, "_table", None))
+        resident._table = eng._rescue_requests_buf
+        m = len(tab)
+        h.vgh_rescue_reads.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int] + [ctypes.c_void_p] * 4
+        if m and h.vgh_rescue_reads(m, tab.ctypes.data, wl.reads.ctypes.data, L, host_threads, mapped.ctypes.data, lost.ctypes.data, req.ctypes.data, rd.ctypes.data) != 0:
+            raise RuntimeError(h.vgh_last_error().decode())
+        return _paired_rescue_half(eng, wl, host_aligner, resident, read_score, timing, host_threads, want_ops, t0, t1, res, m, "rescue requests (device table + the mates' reads)")
     h.vgh_rescue_requests.restype = ctypes.c_int64
     h.vgh_rescue_requests.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int] + [ctypes.c_void_p] * 4
@@ -603,6 +616,15 @@ def _paired_stage_resident(eng, wl, host_aligner, resident, out, read_score, res
                               float(rescue_stdevs), host_threads, mapped.ctypes.data, lost.ctypes.data, req.ctypes.data, rd.ctypes.data)
     if m < 0:
         raise RuntimeError(h.vgh_last_error().decode())
+    return _paired_rescue_half(eng, wl, host_aligner, resident, read_score, timing, host_threads, want_ops, t0, t1, res, m, "rescue requests (host threads)")
+
+
+def _paired_rescue_half(eng, wl, host_aligner, resident, read_score, timing, host_threads, want_ops, t0, t1, res, m, table_label):
+    """the m requests in the resident graph's buffers through vgh_rescue_stage_resident, and the pairs' scores"""
+    import time
+    h = _host_lib()
+    L = wl.read_len
+    _, mapped, lost, req, rd, outv, roff, col = resident._bufs
     t2 = time.perf_counter()
     ops_begin = np.zeros(m + 1, dtype=np.uint64); ops_cap = m * 64 if want_ops else 0
     ops = np.zeros(max(ops_cap, 1), dtype=capi.OP_DT); written = ctypes.c_uint64()
@@ -619,7 +641,7 @@ def _paired_stage_resident(eng, wl, host_aligner, resident, out, read_score, res
     pair_score = read_score[0::2] + read_score[1::2]
     pair_score[mapped_i >> 1] = read_score[mapped_i] + np.maximum(outv[:m, 0], read_score[lost_i])
     if timing is not None:
-        for k, v in (("stage (seeding, extension, tails)", t1 - t0), ("rescue requests (host threads)", t2 - t1), ("rescue stage (resident graph: extension windows, fix-ups)", t3 - t2)):
+        for k, v in (("stage (seeding, extension, tails)", t1 - t0), (table_label, t2 - t1), ("rescue stage (resident graph: extension windows, fix-ups)", t3 - t2)):
             timing[k] = timing.get(k, 0.0) + v
         for k, v in zip(("rescue: classify (host)", "rescue: first pass (extension windows + scans)", "rescue: second pass (traced extension windows)", "rescue: alignments + fix-ups (host)", "rescue: full-DP fallback"), laps):
             timing[k] = timing.get(k, 0.0) + v * 1e-3
@@ -669,6 +691,8 @@ class RescueGraphHandle:
         self.ptr = h.vgh_rescue_graph_create(aligner.ptr, g.n_nodes, node_len.ctypes.data, seq.ctypes.data, pred_off.ctypes.data, pred_idx.ctypes.data)
         if not self.ptr:
             raise RuntimeError("vgh_rescue_graph_create: " + (h.vgh_last_error() or b"?").decode())
+        h.vgh_rescue_graph_dgraph.restype = ctypes.c_void_p; h.vgh_rescue_graph_dgraph.argtypes = [ctypes.c_void_p]
+        self.dgraph = int(h.vgh_rescue_graph_dgraph(self.ptr) or 0)          # the vgk_dgraph: what Engine.rescue_requests takes
 
     def close(self):
         if getattr(self, "ptr", None):
