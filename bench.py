@@ -427,14 +427,25 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
     The headline and the parity line run WITHOUT a WFA point budget (the reference's WFAExtender has none); the budgeted rate is reported
     beside it, never instead."""
     import numpy as np
+    import threading
     from vg_amd import pipeline, shard, workloads
-    n = args.reads if args.reads else 4000
+    # a step = n reads in batches of `per`; two batches in flight (a lane = a ChainStage of its own: engine context, haplotype graph, WFA extender,
+    # host threads), because a launch of the WFA kernel ends with ONE heavy link's dependent chain — the second lane's links run in the wavefronts
+    # the first lane's launch has already given back, and its host work (local graphs, problem records) runs beside the other's kernels
+    n = args.reads if args.reads else 8000
+    per = min(n, int(os.environ.get("VGAMD_LONGREAD_BATCH", "4000")))
+    n_batches = max(1, n // per); n = n_batches * per
+    n_lanes = 1 if (n_batches < 2 or os.environ.get("VGAMD_LONGREAD_ONE_LANE")) else 2
     t0 = time.perf_counter()
-    wl = workloads.LongReadWorkload(n, seed=515 + rank)
+    wls = [workloads.LongReadWorkload(per, seed=515 + rank + 1000 * b) for b in range(n_batches)]
+    wl = wls[0]
     t_gen = time.perf_counter() - t0
     threads = max(1, shard.usable_cpus() // max(world, 1))
-    stage = pipeline.ChainStage(wl, device=int(os.environ.get("LOCAL_RANK", "0")))
-    stage.set_point_budgets(0, 0)
+    lane_threads = max(1, threads // n_lanes)
+    stages = [pipeline.ChainStage(w, device=int(os.environ.get("LOCAL_RANK", "0"))) for w in wls]
+    for st in stages:
+        st.set_point_budgets(0, 0)
+    lock = threading.Lock()
 
     def barrier():
         _device_sync(torch)
@@ -442,11 +453,29 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
             dist.barrier()
         _device_sync(torch)
 
+    def run_lane(which, timing, outs):
+        for b in which:
+            tm = {} if timing is not None else None
+            o = stages[b].run(threads=lane_threads, timing=tm)
+            with lock:
+                outs[b] = o
+                if timing is not None:
+                    for k, v in tm.items():
+                        timing[k] = timing.get(k, 0.0) + v
+
+    def one_step(timing=None):
+        outs = [None] * n_batches
+        th = [threading.Thread(target=run_lane, args=(range(k, n_batches, n_lanes), timing, outs)) for k in range(1, n_lanes)]
+        for t in th: t.start()
+        run_lane(range(0, n_batches, n_lanes), timing, outs)
+        for t in th: t.join()
+        return outs
+
     def timed(steps, timing=None):
         barrier()
         t = time.perf_counter()
         for _ in range(steps):
-            o = stage.run(threads=threads, timing=timing)
+            o = one_step(timing)
         barrier()
         e = time.perf_counter() - t
         if dist is not None:
@@ -456,34 +485,50 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
         return e, o
 
     for _ in range(max(1, args.warmup)):
-        out = stage.run(threads=threads)
+        outs = one_step()
     timing = {}
-    elapsed, out = timed(args.steps, timing)
+    elapsed, outs = timed(args.steps, timing)
+    out = outs[0]
+    one_lane = None
+    if n_lanes > 1:                                  # the same batches one after the other in one lane, for the record
+        t1 = time.perf_counter()
+        run_lane(range(n_batches), None, [None] * n_batches)
+        one_lane = {"ms_per_batch": 1e3 * (time.perf_counter() - t1) / n_batches}
+        one_lane["reads_per_s"] = per / (one_lane["ms_per_batch"] * 1e-3)
     # the same with round 2's point budgets (connects give up at 128 stored wavefront points and go to the DP route at once, tails at 512)
     budget = int(os.environ.get("VGAMD_WFA_POINT_BUDGET", "128")); tail_budget = int(os.environ.get("VGAMD_WFA_TAIL_BUDGET", "512"))
-    stage.set_point_budgets(budget, tail_budget)
-    stage.run(threads=threads)
+    for st in stages:
+        st.set_point_budgets(budget, tail_budget)
+    one_step()
     b_timing = {}
-    b_elapsed, b_out = timed(args.steps, b_timing)
-    stage.set_point_budgets(0, 0)
+    b_elapsed, b_outs = timed(args.steps, b_timing)
+    b_out = b_outs[0]
+    for st in stages:
+        st.set_point_budgets(0, 0)
+    stats_sum = lambda os_: {k: int(sum(o["stats"][k] for o in os_)) for k in os_[0]["stats"]}
+    n_links = sum(w.n for w in wls); read_bases = sum(w.read_bases for w in wls)
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        ora = pipeline.ChainStage(wl, lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
-        cores = shard.usable_cpus()
         import ctypes
+        cores = shard.usable_cpus()
         ctypes.CDLL(os.path.join(ROOT, "oracle", "libvgoracle.so")).vgo_set_threads(cores)
-        t1 = time.perf_counter(); o = ora.run(threads=cores); tc = time.perf_counter() - t1
-        ora.close()
-        same = int((o["chain_score"] == out["chain_score"]).sum()); diff = o["chain_score"] != out["chain_score"]
-        b_same = int((o["chain_score"] == b_out["chain_score"]).sum())
+        same = b_same = differing = higher = 0; tc = 0.0
+        for b in range(n_batches):                    # every batch of the step against the same stage over the oracle
+            ora = pipeline.ChainStage(wls[b], lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
+            t1 = time.perf_counter(); o = ora.run(threads=cores); tc += time.perf_counter() - t1
+            ora.close()
+            diff = o["chain_score"] != outs[b]["chain_score"]
+            same += int((~diff).sum()); differing += int(diff.sum()); higher += int((outs[b]["chain_score"][diff] > o["chain_score"][diff]).sum())
+            b_same += int((o["chain_score"] == b_outs[b]["chain_score"]).sum())
         cpu = {"value": n / tc, "unit": "reads/s", "cores": cores, "kind": "port", "impl": "the same stage (vgh_chain_stage) bound to the oracle: vgo_wfa.c, vgo_banded.c, vgo_xdrop.c (OpenMP over problems)",
                "sample": "all %d reads" % n}
-        parity = {"checked": n, "identical": same, "wfa_point_budget": "none", "differing_reads": int(diff.sum()),
-                  "differing_reads_where_the_engine_scores_higher": int((out["chain_score"][diff] > o["chain_score"][diff]).sum()),
+        parity = {"checked": n, "identical": same, "wfa_point_budget": "none", "differing_reads": differing,
+                  "differing_reads_where_the_engine_scores_higher": higher,
                   "identical_with_point_budgets": b_same,
-                  "what": "per-read chain score (anchors + every link).  No point budget: a link leaves the WFA route only when the engine's tables decline it (VGK_ETOOBIG), "
+                  "what": "per-read chain score (anchors + every link), every batch of the step.  No point budget: a link leaves the WFA route only when the engine's tables decline it (VGK_ETOOBIG), "
                           "which the oracle's WFA (no tables) never does; such a link takes align_sequence_between, which is not bound to haplotypes and can only score "
                           "as high or higher"}
+    wfa_ms = float(np.mean([o["wfa_kernel_ms"] or 0.0 for o in outs]))
     if rank == 0:
         print(json.dumps({
             "metric": "15 kbp reads/sec through the chain alignment stage (WFA between anchors; align_sequence_between — local graph extraction + banded global / pinned X-drop — for what WFA declines)",
@@ -492,26 +537,30 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
             "config": {"workload": "configs[4]: 1 Mbp variation graph, 8 random haplotype threads, %d reads of 15 000 bp per GPU on either strand, error-free 29-mer anchors every "
                                    "120-400 bp, 0.5 %% errors between them (half substitutions, half 1-bp indels), 1 %% of the connects with a 25-60 bp insertion; "
                                    "WFAExtender connect / prefix / suffix with the default error model and NO point budget; align_sequence_between_consistently for what it declines" % n,
-                       "timed_region": "per step, from host buffers, one vgh_chain_stage call: vgk_wfa_extend over every link; for the declined links extract_connecting_graph / "
+                       "batches": "%d batches of %d reads per step; %s" % (n_batches, per, ("two batches in flight: two lanes (a ChainStage each: engine context, haplotype graph, WFA extender; %d host threads per lane)" % lane_threads)
+                                                                          if n_lanes > 1 else "one after the other in one lane"),
+                       "one_lane": one_lane, "ms_per_batch": 1e3 * elapsed / args.steps / n_batches,
+                       "timed_region": "per batch, from host buffers, one vgh_chain_stage call: vgk_wfa_extend over every link; for the declined links extract_connecting_graph / "
                                        "extract_extending_graph on the haplotype graph, strand split, dagify_from, tip trimming (host threads); one flush of banded-global / pinned X-drop problems; "
                                        "translation back to the base graph; per-read totals",
-                       "problems": wl.n, "problems_per_read": wl.n / n, "read_bases": wl.read_bases, "bases_per_s": wl.read_bases * world * args.steps / elapsed,
-                       "links": out["stats"], "host_threads": threads,
-                       "stage_ms": {k: 1e3 * v / args.steps for k, v in timing.items()}, "wfa_kernel_ms": out["wfa_kernel_ms"], "wfa_launches": out["wfa_launches"],
+                       "problems": n_links, "problems_per_read": n_links / n, "read_bases": read_bases, "bases_per_s": read_bases * world * args.steps / elapsed,
+                       "links": stats_sum(outs), "host_threads": threads,
+                       "stage_ms_per_batch": {k: 1e3 * v / args.steps / n_batches for k, v in timing.items()}, "wfa_kernel_ms": wfa_ms, "wfa_launches_of_batch_0": out["wfa_launches"],
                        "with_point_budgets": {"connect": budget, "tail": tail_budget, "reads_per_s": n * world * args.steps / b_elapsed, "ms_per_step": 1e3 * b_elapsed / args.steps,
-                                              "links": b_out["stats"], "stage_ms": {k: 1e3 * v / args.steps for k, v in b_timing.items()}, "wfa_kernel_ms": b_out["wfa_kernel_ms"]},
+                                              "links": stats_sum(b_outs), "stage_ms_per_batch": {k: 1e3 * v / args.steps / n_batches for k, v in b_timing.items()}, "wfa_kernel_ms": b_out["wfa_kernel_ms"]},
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
             "roofline": {"bound": "hbm", "kernel": "wfa_wave_kernel", "limiter": "the mass of easy links (12 wavefronts per CU, one link each) and the critical path of the heaviest one; memory latency, not bandwidth (DESIGN.md §21)",
-                         # algorithmic bytes of the WFA launch: every link's read bases and as many haplotype bases once, a problem descriptor and
-                         # a result per link; against the launch's own device time (vgk_wfa_last_ms as the stage reports it)
+                         # algorithmic bytes of a batch's WFA launch: every link's read bases and as many haplotype bases once, a problem descriptor and
+                         # a result per link; against the launch's own device time (vgk_wfa_last_ms as the stage reports it, mean over the step's batches)
                          **(lambda alg, ms: {"achieved": alg / (ms * 1e-3) / 1e9 if ms else None, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms else None,
-                                             "alg_bytes_per_launch": alg, "avg_launch_ms": ms})(float(2 * wl.read_bases + 72 * wl.n), float(out["wfa_kernel_ms"] or 0.0)),
+                                             "alg_bytes_per_launch": alg, "avg_launch_ms": ms})(float(2 * read_bases + 72 * n_links) / n_batches, wfa_ms),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "traffic": PMC_BYTES_PER_UNIT["longread"] * n if "longread" in PMC_BYTES_PER_UNIT else None,
+                         "traffic": PMC_BYTES_PER_UNIT["longread"] * per if "longread" in PMC_BYTES_PER_UNIT else None,
                          "traffic_source": traffic_source("longread") if "longread" in PMC_BYTES_PER_UNIT else None},
             "cpu_baseline": cpu, "parity": parity,
-            "problems_failed": int(out["stats"]["failed"] + out["stats"]["no_graph"] + out["stats"]["too_big"])}))
-    stage.close()
+            "problems_failed": int(sum(o["stats"]["failed"] + o["stats"]["no_graph"] + o["stats"]["too_big"] for o in outs))}))
+    for st in stages:
+        st.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -511,6 +511,12 @@ double vgk_gapless_last_ms(vgk_ctx* ctx);    /* kernel time of the last vgk_gapl
  * merged runs only under VGAMD_HAPLO_MERGE=1.  vgk_haplo_search_nodes: nodes of the index the search walks (= the graph's when nothing merged);
  * vgk_gapless_last_redone: seeds of the last call whose search ran twice. */
 uint64_t vgk_haplo_search_nodes(const vgk_haplo* index);
+/* The merged-run form of the index is built with it always (VGAMD_HAPLO_NO_MERGE=1: not at all): the WFA wavefront kernel walks it — a trie node
+ * there is a non-branching path, and walking one is a single lane's chain of record fetches, so hops are its time; positions are taken onto
+ * the runs at a problem's start, paths come back in the original nodes, and the trie is the node-by-node walk's (a run is cut where WFANode's
+ * walk would end a node inside it: at the target, at 1 024 bases) — results identical, tie for tie.  vgk_haplo_run_nodes: nodes of that form
+ * (= the graph's when no run could be merged). */
+uint64_t vgk_haplo_run_nodes(const vgk_haplo* index);
 uint64_t vgk_gapless_last_redone(vgk_ctx* ctx);
 uint64_t vgk_gapless_last_retried(vgk_ctx* ctx);   /* reads of that call whose search outgrew the fast (in-LDS) kernel and ran in the slab kernel */
 

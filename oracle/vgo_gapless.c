@@ -36,6 +36,7 @@ static char comp(char c) {
                  case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a'; default: return c; }
 }
 
+uint64_t vgk_haplo_run_nodes(const vgk_haplo* index) { return index ? index->n_nodes : 0; }
 uint64_t vgk_haplo_search_nodes(const vgk_haplo* index) { return index ? index->n_nodes : 0; }      /* (the engine's search may walk merged runs; the oracle's walks the nodes) */
 void vgo_haplo_destroy(vgk_haplo* h) {
     if (!h) return;

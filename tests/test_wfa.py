@@ -494,3 +494,114 @@ def test_emulated_cost_hints_change_the_order_only():
 @pytest.mark.gpu
 def test_hip_cost_hints_change_the_order_only():
     cost_hints_change_the_order_only(None)
+
+
+# ---- the wavefront kernel over MERGED RUNS (wfa_wave_device.hpp: pieces of runs, cut where the node-by-node walk ends a trie node) ----
+def long_run_case(rng, n_problems, n_haplotypes=3):
+    """Chains of long non-branching stretches (2-14 nodes of 1-32 bases, node ids in path order: what the index merges into runs) between
+    SNP bubbles and the odd deletion; sequences of up to 1 400 bases cut from a thread, few errors: trie nodes that run past WFANode's
+    1 024 bases inside a run, targets in the middle of runs, prefixes (the other strand: runs walked backwards)."""
+    bases = "ACGT"
+    nodes = []; segments = []
+    for _ in range(int(rng.integers(6, 16))):
+        run = []
+        for _ in range(int(rng.integers(2, 15))):
+            nodes.append("".join(bases[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 33))))); run.append(len(nodes) - 1)
+        kind = rng.random()
+        if kind < 0.6:                                         # a SNP bubble behind the stretch
+            a, b = bases[int(rng.integers(0, 4))], bases[int(rng.integers(0, 4))]
+            nodes.append(a); nodes.append(b if b != a else bases[(bases.index(a) + 1) % 4])
+            segments.append((run, [len(nodes) - 2, len(nodes) - 1]))
+        elif kind < 0.8:                                       # a node some threads skip
+            nodes.append("".join(bases[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 9)))))
+            segments.append((run, [len(nodes) - 1, None]))
+        else:
+            segments.append((run, [None]))                     # the next stretch follows at once (a run ends at the 255-base cap or goes on)
+    threads = []
+    for _ in range(n_haplotypes):
+        t = []
+        for run, alleles in segments:
+            t += [2 * v for v in run]
+            a = alleles[int(rng.integers(0, len(alleles)))]
+            if a is not None:
+                t.append(2 * a)
+        threads.append(t)
+
+    def comp(s):
+        return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    problems = []
+    for _ in range(n_problems):
+        t = threads[int(rng.integers(0, len(threads)))]
+        if rng.random() < 0.5:
+            t = [o ^ 1 for o in reversed(t)]
+        seq = "".join(nodes[o // 2] if not o & 1 else comp(nodes[o // 2]) for o in t)
+        starts = np.cumsum([0] + [len(nodes[o // 2]) for o in t])
+
+        def pos(g):
+            k = int(np.searchsorted(starts, g, side="right") - 1)
+            return (int(t[k]), int(g - starts[k]))
+        f = int(rng.integers(0, max(1, len(seq) // 3)))
+        n = int(rng.integers(0, min(1400, len(seq) - f - 2) + 1))
+        rate = float(rng.choice([0.0, 0.004, 0.01]))
+        read = []
+        for c in seq[f + 1:f + 1 + n]:
+            r = rng.random()
+            if r < rate:
+                read.append(bases[int(rng.integers(0, 4))])
+            elif r < 1.3 * rate:
+                continue
+            elif r < 1.6 * rate:
+                read.append(c); read.append(bases[int(rng.integers(0, 4))])
+            else:
+                read.append(c)
+        mode = ["connect", "suffix", "prefix"][int(rng.integers(0, 3))]
+        p = dict(seq="".join(read), mode=mode)
+        if mode != "prefix":
+            p["from"] = pos(f)
+        if mode != "suffix":
+            p["to"] = pos(f + n + 1)
+        problems.append(p)
+    return nodes, threads, problems
+
+
+def merged_runs_give_the_node_by_node_answers(lib, seeds, monkeypatch, n_problems=40):
+    ora = capi.Engine(lib=util.ORACLE_LIB)
+    monkeypatch.setenv("VGAMD_WFA_KERNEL", "wave")
+    fields = ("status", "ok", "score", "node_offset", "seq_offset", "length", "path_len", "n_edits")
+    answered = long_nodes = 0
+    for s in seeds:
+        rng = np.random.default_rng(s)
+        nodes, threads, problems = long_run_case(rng, n_problems, n_haplotypes=1 if s % 3 == 0 else 3)      # (one thread: nothing branches, every long trie node meets the 1 024-base rule)
+        eng = capi.Engine(lib=lib)
+        index = eng.haplo_index(nodes, threads)
+        assert index.run_nodes() < len(nodes) * 0.6, "the case is meant to have runs to merge"
+        a = ora.wfa_extend(ora.haplo_index(nodes, threads), problems)
+        b = eng.wfa_extend(index, problems)
+        monkeypatch.setenv("VGAMD_WFA_NO_MERGE", "1")
+        c = eng.wfa_extend(index, problems)                  # the same kernel hopping node by node
+        monkeypatch.delenv("VGAMD_WFA_NO_MERGE")
+        # the trie is the same node for node: what one walk declines for its tables (points, trie nodes) the other declines as well; only the
+        # path pool differs (a run is one entry)
+        for i in range(len(problems)):
+            rb, pb, eb = unpack(*b, i); rc, pc, ec = unpack(*c, i)
+            if rb["status"] == -7 or rc["status"] == -7:
+                assert rc["status"] == -7, (s, i, "declined on the runs only", rb, rc)
+                continue
+            ra, pa, ea = unpack(*a, i)
+            assert all(ra[f] == rb[f] == rc[f] for f in fields) and pa == pb == pc and ea == eb == ec, (s, i, problems[i], ra, rb, rc, pa, pb, pc)
+            answered += int(ra["ok"]); long_nodes += int(ra["ok"] and len(problems[i]["seq"]) > 1100)
+        eng.close()
+    return answered, long_nodes
+
+
+def test_wave_form_over_merged_runs_on_the_emulator(monkeypatch):
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    answered, long_nodes = merged_runs_give_the_node_by_node_answers(util.EMU_LIB, range(900, 912), monkeypatch)
+    assert answered > 250 and long_nodes > 10
+
+
+@pytest.mark.gpu
+def test_wave_form_over_merged_runs_on_hip(monkeypatch):
+    answered, long_nodes = merged_runs_give_the_node_by_node_answers(util.ENGINE_LIB, range(900, 940), monkeypatch, n_problems=60)
+    assert answered > 1200 and long_nodes > 50

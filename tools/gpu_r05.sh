@@ -119,6 +119,35 @@ cells = eng.lib.vgk_banded_last(eng.h, 2); fill = eng.lib.vgk_banded_last(eng.h,
 print(sys.argv[1], "2000 wide-band problems: fill %.2f ms, %.0f GCUPS, call %.1f ms, aligned %d" % (fill, cells / (fill * 1e-3) / 1e9 if fill else 0, 1e3 * t, int((res["status"] == 0).sum())))
 PY
     done ;;
+  longread)       # configs[4] as reads: two batches in flight (two ChainStages) against one lane; 2 host threads as well
+    for tag in two_lanes one_lane two_lanes_2threads; do
+      case $tag in one_lane) export VGAMD_LONGREAD_ONE_LANE=1;; *) unset VGAMD_LONGREAD_ONE_LANE;; esac
+      case $tag in two_lanes_2threads) T=2;; *) T=0;; esac
+      if [ $T = 0 ]; then timeout 600 python bench.py --workload longread --steps 3 --warmup 1 > "$out/bench_longread_$tag.json" 2> "$out/bench_longread_$tag.err"
+      else timeout 600 taskset -c 0-$((T-1)) python bench.py --workload longread --steps 3 --warmup 1 --no-cpu > "$out/bench_longread_$tag.json" 2> "$out/bench_longread_$tag.err"; fi
+      python - "$out/bench_longread_$tag.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c = d["config"]
+print(sys.argv[1], round(d["value"]), "ms/batch", round(c["ms_per_batch"], 1), c["batches"], c["one_lane"], {k: round(v, 1) for k, v in c["stage_ms_per_batch"].items()}, "wfa ms", round(c["wfa_kernel_ms"], 1), d["parity"] and {k: v for k, v in d["parity"].items() if k != "what"}, "budgets:", round(c["with_point_budgets"]["reads_per_s"]))
+PY
+    done; unset VGAMD_LONGREAD_ONE_LANE ;;
+  wfa_runs)       # the WFA wavefront kernel on the merged-run index against the node-by-node walk: gpu tests, the WFA leg, the long-read stage
+    timeout 900 python -m pytest tests/test_wfa.py tests/test_longread_stage.py tests/test_chain_alignment.py -m gpu -x -q > "$out/pytest_wfa.log" 2>&1; echo "rc=$?" >> "$out/pytest_wfa.log"; tail -3 "$out/pytest_wfa.log"
+    for m in runs nodes; do
+      case $m in nodes) export VGAMD_WFA_NO_MERGE=1;; *) unset VGAMD_WFA_NO_MERGE;; esac
+      timeout 600 python bench.py --workload wfa --steps 5 --warmup 2 $([ $m = nodes ] && echo --no-cpu) > "$out/bench_wfa_$m.json" 2> "$out/bench_wfa_$m.err"
+      python - "$out/bench_wfa_$m.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(sys.argv[1], round(d["value"]), "ms/step", round(d["ms_per_step"], 2), d.get("parity") and {k: v for k, v in d["parity"].items() if k != "what"}, {k: v for k, v in d["config"].items() if "ms" in k})
+PY
+      timeout 600 python bench.py --workload longread --steps 3 --warmup 1 $([ $m = nodes ] && echo --no-cpu) > "$out/bench_longread_$m.json" 2> "$out/bench_longread_$m.err"
+      python - "$out/bench_longread_$m.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c = d["config"]
+print(sys.argv[1], round(d["value"]), "ms/batch", round(c["ms_per_batch"], 1), c["one_lane"], {k: round(v, 1) for k, v in c["stage_ms_per_batch"].items()}, "wfa ms", round(c["wfa_kernel_ms"], 1), d["parity"] and {k: v for k, v in d["parity"].items() if k != "what"}, "budgets:", round(c["with_point_budgets"]["reads_per_s"]))
+PY
+    done; unset VGAMD_WFA_NO_MERGE ;;
   gapless_pmc)    # where the gapless search's bytes come from: L2 hits / misses, vector-memory and scratch instruction counts of its kernels (counter passes, kernel trace only)
     P=$GRAFT_REPO_ROOT/gpurun_out/r05_pmc; mkdir -p $P
     ( cd /tmp && timeout 120 rocprofv3 -L 2>/dev/null | grep -ioE "\b(TCC_HIT_sum|TCC_MISS_sum|TCC_REQ_sum|TCC_EA0_RDREQ_sum|TCC_EA0_WRREQ_sum|TCP_TCC_READ_REQ_sum|TCP_TCC_WRITE_REQ_sum|SQ_INSTS_VMEM_RD|SQ_INSTS_VMEM_WR|SQ_INSTS_FLAT|SQ_INSTS_LDS|SQ_INSTS_SALU|SQ_INSTS_VALU|SQ_WAVE_CYCLES|SQ_WAIT_ANY|SQ_WAIT_INST_ANY|SQ_ACTIVE_INST_ANY|SQ_INSTS_SMEM|SQ_INST_LEVEL_VMEM|SQ_INSTS_VMEM|SQ_INSTS_SCRATCH[A-Z_]*|SPI_[A-Z_]*SCRATCH[A-Z_]*)\b" | sort -u > $P/counters_available.txt ); cat $P/counters_available.txt | tr '\n' ' '; echo

@@ -905,6 +905,11 @@ class HaploIndex:
         self.h = h
         eng._indexes.add(self)
 
+    def run_nodes(self):
+        """nodes of the index's merged-run form, which the WFA wavefront kernel walks (= the graph's nodes when nothing merged)"""
+        self.eng.lib.vgk_haplo_run_nodes.restype = ctypes.c_uint64; self.eng.lib.vgk_haplo_run_nodes.argtypes = [ctypes.c_void_p]
+        return int(self.eng.lib.vgk_haplo_run_nodes(self.h))
+
     def search_nodes(self):
         """nodes of the index the gapless search walks (unary runs merged at build; = the graph's nodes when nothing merged)"""
         self.eng.lib.vgk_haplo_search_nodes.restype = ctypes.c_uint64; self.eng.lib.vgk_haplo_search_nodes.argtypes = [ctypes.c_void_p]

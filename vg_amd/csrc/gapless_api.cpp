@@ -190,10 +190,12 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) try
 // are the run's, which already lie behind each other.  -> VGK_OK with h->merged set, or with nothing set when no two nodes merge.
 static int merge_unary_runs(vgk_ctx* ctx, vgk_haplo* h, uint32_t O, const std::vector<uint32_t>& len, const std::vector<char>& seq, uint32_t total, const HaploTables& T) {
     const uint32_t N = O / 2;
-    // Built, exact (tie for tie), measured on the MI355X (profiles/r05/NOTES.md) — and OFF unless VGAMD_HAPLO_MERGE=1: the search kernel's
+    // For the gapless search: built, exact (tie for tie), measured on the MI355X (profiles/r05/NOTES.md) — and OFF unless VGAMD_HAPLO_MERGE=1: the search kernel's
     // time is the bytes it moves, not its hops (6.48 against 6.62 ms per million reads at chr22-scale variant density, 13.2 against 9.5 ms where runs
     // are two or three nodes), and the merged build's extra live values are scratch traffic of their own.
-    if (N < 2 || !std::getenv("VGAMD_HAPLO_MERGE") || std::getenv("VGAMD_HAPLO_NO_MERGE")) return VGK_OK;
+    // The WFA wavefront kernel walks the merged index always (its trie walk is one lane's chain of record fetches: hops are its time).
+    if (N < 2 || std::getenv("VGAMD_HAPLO_NO_MERGE")) return VGK_OK;
+    h->search_merged = std::getenv("VGAMD_HAPLO_MERGE") != nullptr;
     auto unary = [&](uint32_t o, uint32_t p) {
         return T.count[o] > 0 && T.edge_off[o + 1] - T.edge_off[o] == 1 && T.edge_to[T.edge_off[o]] == (int32_t)p && T.edge_base[T.edge_off[o]] == 0 && T.count[p] == T.count[o];
     };
@@ -536,7 +538,8 @@ int vgk_gapless_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_gapless_p
         return d;
     };
     GaplessParams P{};
-    P.index = index->merged ? index->merged->dev : index->dev; P.orig = index->dev; P.merge = index->merge; P.n = n;
+    { const bool runs = index->merged && index->search_merged;
+      P.index = runs ? index->merged->dev : index->dev; P.orig = index->dev; P.merge = runs ? index->merge : GMerge{}; P.n = n; }
     P.probs = (const GProb*)dev(probs.data(), sizeof(GProb) * n);
     P.reads = (const char*)dev(nullptr, n_read + 16);                  // 8 bytes of padding at either end
     if (P.reads && n_read && be->upload(const_cast<char*>(P.reads) + 8, reads_in_a_row ? read0 : reads + 8, n_read)) return VGK_ENODEV;
@@ -601,7 +604,8 @@ int vgk_gapless_extend_seeded(vgk_ctx* ctx, const vgk_haplo* index, uint32_t max
     if (!rc) rc = be->sort_pairs_u32(d_sort, d_sort + 2 * (size_t)n, d_sort + n, d_sort + 3 * (size_t)n, n, bits);
     if (rc) return rc;
     GaplessParams P{};
-    P.index = index->merged ? index->merged->dev : index->dev; P.orig = index->dev; P.merge = index->merge; P.n = n;
+    { const bool runs = index->merged && index->search_merged;
+      P.index = runs ? index->merged->dev : index->dev; P.orig = index->dev; P.merge = runs ? index->merge : GMerge{}; P.n = n; }
     P.probs = d_probs; P.reads = ctx->seeded.reads; P.seeds = ctx->seeded.seeds; P.order = d_sort + 3 * (size_t)n;
     lap("descriptors and order on the device");
     return gapless_run_and_fetch(ctx, P, n, n_seed, next_slot, H, lap, results, extensions, ext_cap, nodes, nodes_cap, mismatches, mism_cap, written, (flags & VGK_GAPLESS_DEFER) != 0);
@@ -622,6 +626,7 @@ int vgk_gapless_rerun(vgk_ctx* ctx) try {
 double vgk_gapless_last_ms(vgk_ctx* ctx) { return ctx ? ctx->gapless_ms : 0.0; }
 uint64_t vgk_gapless_last_retried(vgk_ctx* ctx) { return ctx ? ctx->gapless_retried : 0; }
 uint64_t vgk_gapless_last_redone(vgk_ctx* ctx) { return ctx ? ctx->gapless_redone : 0; }
-uint64_t vgk_haplo_search_nodes(const vgk_haplo* index) { return index ? (index->merged ? index->merged->n_oriented / 2 : index->n_oriented / 2) : 0; }
+uint64_t vgk_haplo_run_nodes(const vgk_haplo* index) { return index ? (index->merged ? index->merged->n_oriented / 2 : index->n_oriented / 2) : 0; }
+uint64_t vgk_haplo_search_nodes(const vgk_haplo* index) { return index ? (index->merged && index->search_merged ? index->merged->n_oriented / 2 : index->n_oriented / 2) : 0; }
 
 }  // extern "C"

@@ -10,10 +10,11 @@ struct vgk_haplo {
     std::vector<void*> held;
     uint32_t n_oriented = 0;
     std::vector<uint32_t> len;          // host copy, for validation
-    // the index the gapless search walks when unary runs could be merged (gapless_device.hpp GMerge; owned: destroyed with this one), and the
-    // tables that take seeds onto it and extension sets back
+    // the same index with its unary runs merged (gapless_device.hpp GMerge; owned: destroyed with this one), and the tables that take positions
+    // onto it and paths back: what the WFA wavefront kernel walks (wfa_wave_device.hpp), and the gapless search when asked to
     vgk_haplo* merged = nullptr;
     vgk::GMerge merge{};
+    bool search_merged = false;         // the gapless search walks `merged` (VGAMD_HAPLO_MERGE=1: measured, it does not pay there); the WFA wavefront kernel always does
 };
 
 // What either index builder hands to vgk_haplo_from_tables (gapless_api.cpp): see there.

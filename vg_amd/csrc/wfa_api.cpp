@@ -18,7 +18,8 @@ using namespace vgk;
 namespace {
 
 struct WfaHost { PinnedBuf<char> seqs; PinnedBuf<WProb> probs; PinnedBuf<vgk_wfa_result> dres; PinnedBuf<uint32_t> dpaths, dedits; uint64_t zeroed_bytes = 0; void* zeroed_ptr = nullptr;
-                 void* slab_ptr = nullptr; uint64_t slab_bytes = 0, slab_shape = 0; };
+                 void* slab_ptr = nullptr; uint64_t slab_bytes = 0, slab_shape = 0;
+                 GIndex walk_index{}; GMerge walk_merge{}; };      // the index the wavefront kernel walks in the current call: the caller's, or its merged-run form
 
 const vgk_wfa_error_model kDefaultModel = { { 0.03, 1, 6 }, { 0.05, 1, 10 }, { 0.1, 1, 20 }, { 0.1, 10, 200 } };   // gbwt_extender.hpp:386-395
 
@@ -75,6 +76,10 @@ int launch_wave_form(vgk_ctx* ctx) {
             for (uint32_t i : idx) items += st[8 * i + 3] >> 8;
             std::fprintf(stderr, "[wfa wave] %zu problems: %llu chunks, %llu points, %llu steps, %llu filtered items in all; heaviest (points, steps, chunks, trie nodes, items; us in extend, next, between, after):", idx.size(), chunks, points, steps, items);
             for (size_t k = 0; k < idx.size() && k < 8; ++k) std::fprintf(stderr, " (%u,%u,%u,%u,%u; %u,%u,%u,%u)", st[8 * idx[k]], st[8 * idx[k] + 1], st[8 * idx[k] + 2], st[8 * idx[k] + 3] & 255u, st[8 * idx[k] + 3] >> 8, st[8 * idx[k] + 4], st[8 * idx[k] + 5], st[8 * idx[k] + 6], st[8 * idx[k] + 7]);
+            { unsigned long long us[4] = {0, 0, 0, 0}, nodes = 0;
+              for (uint32_t i : idx) { for (int k = 0; k < 4; ++k) us[k] += st[8 * i + 4 + k]; nodes += st[8 * i + 3] & 255u; }
+              std::fprintf(stderr, " | all problems together: %llu us in extend, %llu in next, %llu at the start and between the two, %llu after the loop (backtrace, output); %llu trie nodes; the launch: %.2f ms x %u wavefronts = %.0f us of wavefront time",
+                           us[0], us[1], us[2], us[3], nodes, be->last_ms(6), ctx->wfa_wave_waves[0], 1e3 * be->last_ms(6) * ctx->wfa_wave_waves[0]); }
             for (size_t q : {idx.size() / 100, idx.size() / 10, idx.size() / 2}) if (q < idx.size()) std::fprintf(stderr, " | rank %zu: (%u,%u,%u,%u,%u)", q, st[8 * idx[q]], st[8 * idx[q] + 1], st[8 * idx[q] + 2], st[8 * idx[q] + 3] & 255u, st[8 * idx[q] + 3] >> 8);
             std::fprintf(stderr, "\n");
         }
@@ -96,6 +101,7 @@ int prepare_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P, bool after_t
     WaveSlabs z{after_threads ? cus * per_cu : std::min<uint32_t>(P.n, cus * per_cu), 32768u, 16384u, 2048u, std::getenv("VGAMD_WFA_NO_FILTER") ? 0u : 512u};
     WwParams A{};
     A.base = P;
+    A.index = H.walk_index; A.merge = H.walk_merge;
     // a caller's point budget below the tables' own sizes ends a problem as before (vgk_wfa_set_point_budgets); 0 = none
     A.base.max_points = ctx->wfa_point_budget ? ctx->wfa_point_budget : 0xffffffffu;
     A.base.max_points_tail = ctx->wfa_point_budget_tail ? ctx->wfa_point_budget_tail : 0xffffffffu;
@@ -167,6 +173,9 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
 
     if (!ctx->wfa_host) ctx->wfa_host = std::make_shared<WfaHost>();
     WfaHost& H = *static_cast<WfaHost*>(ctx->wfa_host.get());
+    // the wavefront kernel walks the index with its unary runs merged when there is one (VGAMD_WFA_NO_MERGE=1: the original, for comparisons)
+    { const bool runs = index->merged && index->merge.on && !std::getenv("VGAMD_WFA_NO_MERGE");
+      H.walk_index = runs ? index->merged->dev : index->dev; H.walk_merge = runs ? index->merge : GMerge{}; }
     WProb* probs = H.probs.get(be, n);
     if (!probs) return VGK_ENOMEM;
     uint64_t n_seq = 0;

@@ -32,6 +32,15 @@
 // VGK_ETOOBIG.  A path-pool entry carries what comparing bases needs (where the node's bases lie, how many), and the walk along a
 // non-branching path takes a successor's length, bases and record from the edge it follows (the index stores them there): one
 // dependent load per hop instead of three.
+//
+// Merged runs.  A trie node is a non-branching path, and walking one is the wavefront's serial part: one lane follows records hop by hop while
+// 63 wait, three or four dependent loads per 32-base node.  When the index has its UNARY RUNS merged (gapless_api.cpp merge_unary_runs: consecutive
+// nodes that every haplotype crosses together, one record and one base span per run) the walk hops run by run: WwParams::index is then the merged
+// index, a problem's from / to positions are taken onto it at its start, and the path goes back out in the original nodes.  The trie — node for
+// node, base for base — stays the original's: WFANode's walk ends a node after the ORIGINAL graph node that holds the target or brings the node
+// to 1 024 bases (:1470-1487), so a run that such a node lies in is CUT there (ww_append_piece looks at the run's original lengths, no record
+// fetched) and the rest of the run is the only child's first piece.  Offsets, stored points, node numbers and with them every tie are those of the
+// node-by-node walk; the oracle (which knows no runs) is the check.
 #pragma once
 #include "wfa_device.hpp"
 
@@ -50,13 +59,14 @@ struct WwNode {                       // WNode of wfa_device.hpp + where the rec
     uint32_t len, target_offset;
     uint16_t path_head, path_tail;
     uint8_t  parent, first_child, n_children, dead_end;
-    uint8_t  complete, pad[3];
+    uint8_t  complete, cut, pad[2];   // cut: the walk ended INSIDE a merged run (after the original node that ends this trie node); the rest of the run is its only child's
     uint32_t ancestors;
 };
 struct WwPath { int32_t node; uint32_t seq_off; uint16_t start, len, next, pad; };     // a graph node on a trie node's path: its bases at index.seq + seq_off
 
 struct WwParams {
     WfaParams base;                   // index, problems, sequences, scoring, outputs, counters[2] = next problem to hand out
+    GIndex index; GMerge merge;       // the index this kernel walks: base.index, or its merged-run form (merge.on) with the tables between the two
     const uint32_t* todo; uint32_t n_todo;      // the problems of this launch, in hand-out order
     const unsigned long long* n_todo_dev;        // their number when only the device knows it (the thread kernel's hand-over list); else null
     // The list is still GROWING (the thread kernel runs beside this one): entries not yet written read 0xffffffff, `producers_done` counts
@@ -103,7 +113,8 @@ template <class XL, bool SMALL> struct WwCtx {
     uint32_t mask, max_points, path_cap;
     uint32_t* masks; uint32_t mask_width;                                       // the item filter's node masks (large size; null = off)
     const char* seq; uint32_t L;
-    int32_t to_node; uint32_t to_off; bool no_to;
+    int32_t to_node; uint32_t to_off; bool no_to;      // the target in the index walked: (merged) node, offset there ...
+    uint32_t to_inner, to_orig_len;   // ... and where in that node the ORIGINAL target node starts, and its length (merged runs; 0, the node's length otherwise)
     uint32_t grow_cap;                // bases a trie node is walked at its creation unless it ends earlier
     int32_t min_distance;
     // this lane's findings, merged after every phase
@@ -158,6 +169,37 @@ template <class XL, bool SMALL> VGK_HD bool ww_lookup(WwCtx<XL, SMALL>& c, uint3
     }
     node = best;
     return found;
+}
+// The same lookup with its first two slots read ahead (WwProbe): next() reads the first slots of all five source cells of an item TOGETHER — ten
+// loads in flight, then five walks that mostly end within what is already there (a cell that is found takes two probes: the point and the free slot
+// behind it) — instead of five chains of dependent loads from the HBM slab one after the other.  Scalars, not arrays: arrays of probe states went
+// to scratch memory when this was tried with loops (profiles/r03).
+struct WwProbe { uint32_t i; unsigned long long a, b; bool on; };
+template <class XL, bool SMALL> VGK_HD bool ww_at_dead_end(WwCtx<XL, SMALL>& c, const WPos& p);
+template <class XL, bool SMALL> VGK_HD WwProbe ww_probe(WwCtx<XL, SMALL>& c, bool on, int kind, const WSrc& src, int32_t diag) {
+    WwProbe p; p.on = on && !(diag < src.lo || diag > src.hi); p.i = 0; p.a = 0; p.b = 0;
+    if (p.on) { p.i = ww_hash(c, w_key(0, kind, src.score, diag)); p.a = c.xl->load64(c.tbl(p.i)); p.b = c.xl->load64(c.tbl((p.i + 1) & c.mask)); }
+    return p;
+}
+template <class XL, bool SMALL> VGK_HD WPos ww_find_probed(WwCtx<XL, SMALL>& c, const WwProbe& pr, int kind, const WSrc& src, uint32_t ancestors, uint32_t origin, int32_t diag, bool ext_seq, bool ext_graph) {
+    if (!pr.on) return w_none();
+    const uint32_t cell = (w_key(0, kind, src.score, diag) - 1u) >> 5;
+    bool found = false; uint32_t best = 0, seq = 0, off = 0, probes = 0;
+    for (uint32_t i = pr.i;; i = (i + 1) & c.mask) {
+        if (probes > c.mask) { c.overflow = true; c.why = 8; break; }
+        const unsigned long long s = probes == 0 ? pr.a : probes == 1 ? pr.b : c.xl->load64(c.tbl(i));
+        ++probes;
+        if (!s) break;
+        const uint32_t key = (uint32_t)(s >> 32) - 1u, holder = key & 31u;
+        if ((key >> 5) == cell && ((ancestors >> holder) & 1u) && (!found || holder > best)) {
+            found = true; best = holder; seq = (uint32_t)(s >> 16) & 0xffffu; off = (uint32_t)s & 0xffffu;
+        }
+    }
+    if (!found) return w_none();
+    WPos p = { seq, off, (uint8_t)best, (uint8_t)origin, false };
+    if (ext_seq && p.seq >= c.L) return w_none();
+    if (ext_graph && ww_at_dead_end(c, p)) return w_none();
+    return p;
 }
 template <class XL, bool SMALL> VGK_HD void ww_store(WwCtx<XL, SMALL>& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t seq, uint32_t off) {
     if constexpr (!SMALL) {
@@ -230,7 +272,7 @@ template <class XL, bool SMALL> VGK_HD bool ww_wants_expansion(WwCtx<XL, SMALL>&
 
 template <class XL, bool SMALL> VGK_HD void ww_match_forward(WwCtx<XL, SMALL>& c, WPos& p) {
     if (p.seq >= c.L || ww_past_end(c, p.cur, p.off)) return;
-    const GIndex& h = c.P->base.index;
+    const GIndex& h = c.P->index;
     // the entry that holds offset p.off: a trie node's entries are made in one go when the node is walked (ww_node_create), so they lie
     // next to each other in the pool with ascending starts — a binary search instead of a walk from the head (for the large size every
     // step of that walk is a dependent load from the HBM slab, and a position 250 bases into a node sits eight entries down)
@@ -246,10 +288,15 @@ template <class XL, bool SMALL> VGK_HD void ww_match_forward(WwCtx<XL, SMALL>& c
         const char* r = c.seq + p.seq;
         uint32_t left = (uint32_t)e.start + e.len - p.off; if (c.L - p.seq < left) left = c.L - p.seq;
         uint32_t m = 0;
-        while (m < left) {
-            const uint64_t x = g_load8(g + m) ^ g_load8(r + m);
-            if (x) { m += (uint32_t)(__builtin_ctzll(x) >> 3); break; }
-            m += 8;
+        while (m < left) {                                                     // 32 bases per round: the eight loads are in flight together (an item's match is ONE lane's chain: nothing else hides their latency)
+            const uint64_t x0 = g_load8(g + m) ^ g_load8(r + m);
+            const uint64_t x1 = m + 8 < left ? g_load8(g + m + 8) ^ g_load8(r + m + 8) : 0ull, x2 = m + 16 < left ? g_load8(g + m + 16) ^ g_load8(r + m + 16) : 0ull,
+                           x3 = m + 24 < left ? g_load8(g + m + 24) ^ g_load8(r + m + 24) : 0ull;
+            if (x0) { m += (uint32_t)(__builtin_ctzll(x0) >> 3); break; }
+            if (x1) { m += 8u + (uint32_t)(__builtin_ctzll(x1) >> 3); break; }
+            if (x2) { m += 16u + (uint32_t)(__builtin_ctzll(x2) >> 3); break; }
+            if (x3) { m += 24u + (uint32_t)(__builtin_ctzll(x3) >> 3); break; }
+            m += 32;
         }
         const bool differs = m < left;
         if (!differs) m = left;
@@ -261,36 +308,65 @@ template <class XL, bool SMALL> VGK_HD void ww_match_forward(WwCtx<XL, SMALL>& c
 
 // ---- changes to the trie: one lane, everyone else waiting at a fence ----
 // the graph node a walk steps to: its search state and, from the edge followed, its length, bases and record
-struct WwStep { WState state; uint32_t len, seq_off, rec; };
-template <class XL, bool SMALL> VGK_HD bool ww_append_node(WwCtx<XL, SMALL>& c, WwNode& n, const WwStep& next) {
+// (with merged runs `len` bases of the run from its base `inner` on — a PIECE: the whole run, or what a cut left of it)
+struct WwStep { WState state; uint32_t len, seq_off, rec, inner; };
+// the original nodes of a run, in the order its strand reads them: node index and length of the one that starts `inner` bases into the run, then on
+struct WwOriginals {
+    const GMerge* M; uint32_t v, v_end; bool reverse; uint32_t at;          // at: bases of the run before original v
+    VGK_HD uint32_t length() const { return M->ocol[v + 1] - M->ocol[v]; }
+    VGK_HD uint32_t oriented() const { return 2u * v + (reverse ? 1u : 0u); }
+    VGK_HD bool done() const { return v == v_end; }
+    VGK_HD void step() { at += length(); v = reverse ? v - 1u : v + 1u; }
+};
+VGK_HD WwOriginals ww_originals(const GMerge& M, uint32_t merged_oriented, uint32_t inner) {
+    const uint32_t m = merged_oriented >> 1, v0 = M.run_first[m], v1 = M.run_first[m + 1];
+    WwOriginals it; it.M = &M; it.reverse = (merged_oriented & 1u) != 0; it.at = 0;
+    it.v = it.reverse ? v1 - 1u : v0; it.v_end = it.reverse ? v0 - 1u : v1;
+    while (!it.done() && it.at < inner) it.step();
+    return it;
+}
+// Appends a piece to a trie node the way WFANode's walk appends its original nodes one by one (:1470-1487): the node ends after the original that
+// holds the target, or that brings it to W_TARGET_LENGTH bases — inside a run, the piece is cut there (n.cut).  -> whether the node is complete.
+template <class XL, bool SMALL> VGK_HD bool ww_append_piece(WwCtx<XL, SMALL>& c, WwNode& n, const WwStep& next) {
     n.st_node = next.state.node; n.st_lo = next.state.lo; n.st_hi = next.state.hi; n.st_rec = next.rec;
     if (c.sh->n_path >= c.path_cap) { c.overflow = true; c.why = 3; return true; }
+    uint32_t take = next.len; bool complete = false, at_target = false;
+    const bool holds_target = !c.no_to && c.to_node == next.state.node && c.to_inner >= next.inner;
+    if (holds_target) { take = c.to_inner + c.to_orig_len - next.inner; complete = true; at_target = true; }
+    if (n.len + take >= W_TARGET_LENGTH && c.P->merge.on) {
+        // the first original whose end brings the node to the target length (it may lie before the target's)
+        WwOriginals it = ww_originals(c.P->merge, (uint32_t)next.state.node, next.inner);
+        uint32_t got = 0;
+        while (!it.done() && got < take) { got += it.length(); it.step(); if (n.len + got >= W_TARGET_LENGTH) break; }
+        if (got < take) { take = got; complete = true; at_target = false; }
+    }
     const uint16_t at = (uint16_t)c.sh->n_path++;
-    WwPath e; e.node = next.state.node; e.seq_off = next.seq_off; e.start = (uint16_t)n.len; e.len = (uint16_t)next.len; e.next = W_NIL; e.pad = 0;
+    WwPath e; e.node = next.state.node; e.seq_off = next.seq_off; e.start = (uint16_t)n.len; e.len = (uint16_t)take; e.next = W_NIL; e.pad = 0;
     c.pth(at) = e;
     if (n.path_head == W_NIL) n.path_head = at; else c.pth(n.path_tail).next = at;
     n.path_tail = at;
-    n.len += next.len;
+    n.len += take;
+    n.cut = take < next.len ? 1 : 0;
     if (n.len > 0xfff0u) { c.overflow = true; c.why = 5; return true; }
-    if (!c.no_to && c.to_node == next.state.node) { n.target_offset = n.len - (next.len - c.to_off); return true; }
-    return false;
+    if (at_target) n.target_offset = n.len - (c.to_orig_len - c.to_off);
+    return complete;
 }
 // w_follow over a record that is already at hand; the step's length / bases / record come from the edge (gapless_device.hpp: record layout)
 template <class XL, bool SMALL> VGK_HD uint32_t ww_follow(WwCtx<XL, SMALL>& c, uint32_t rec_off, const WState& s, uint32_t want, WwStep& out, uint32_t stop_at) {
-    const uint32_t* rec = c.P->base.index.rec + rec_off;
+    const uint32_t* rec = c.P->index.rec + rec_off;
     uint32_t edge = 0;
     const uint32_t k = w_follow_rec(rec, s, want, out.state, stop_at, &edge);
-    if (k > want) { out.len = ge_len(rec, edge); out.seq_off = ge_seq(rec, edge); out.rec = ge_rec(rec, edge); }
+    if (k > want) { out.len = ge_len(rec, edge); out.seq_off = ge_seq(rec, edge); out.rec = ge_rec(rec, edge); out.inner = 0; }
     return k;
 }
 // WFANode's constructor (:1463-1487), walked as far as this problem can look
 template <class XL, bool SMALL> VGK_HD void ww_node_create(WwCtx<XL, SMALL>& c, uint32_t id, const WwStep& first, uint32_t parent, uint32_t reach) {
     WwNode n;
     n.len = 0; n.target_offset = W_NO_OFFSET; n.path_head = n.path_tail = W_NIL;
-    n.parent = (uint8_t)parent; n.first_child = 0; n.n_children = 0; n.dead_end = 0; n.pad[0] = n.pad[1] = n.pad[2] = 0;
+    n.parent = (uint8_t)parent; n.first_child = 0; n.n_children = 0; n.dead_end = 0; n.cut = 0; n.pad[0] = n.pad[1] = 0;
     n.ancestors = (id ? c.sh->nodes[parent].ancestors : 0u) | (1u << id);
     c.sh->leaves |= 1u << id;
-    n.complete = ww_append_node(c, n, first) ? 1 : 0;
+    n.complete = ww_append_piece(c, n, first) ? 1 : 0;
     for (uint32_t hops = 0; !n.complete && !c.overflow; ++hops) {
         if (hops > c.path_cap) { c.overflow = true; c.why = 9; break; }
         if (n.len >= W_TARGET_LENGTH) { n.complete = 1; break; }
@@ -299,7 +375,7 @@ template <class XL, bool SMALL> VGK_HD void ww_node_create(WwCtx<XL, SMALL>& c, 
         const uint32_t successors = ww_follow(c, n.st_rec, cur, 0, next, 2);
         if (successors == 0) { n.dead_end = 1; n.complete = 1; }
         else if (successors > 1) n.complete = 1;
-        else if (ww_append_node(c, n, next)) n.complete = 1;
+        else if (ww_append_piece(c, n, next)) n.complete = 1;
     }
     c.sh->nodes[id] = n;
 }
@@ -309,6 +385,18 @@ template <class XL, bool SMALL> VGK_HD bool ww_expand(WwCtx<XL, SMALL>& c, uint3
     const WState st = { c.sh->nodes[node].st_node, c.sh->nodes[node].st_lo, c.sh->nodes[node].st_hi };
     const uint32_t rec = c.sh->nodes[node].st_rec;
     WwStep next; next.state.node = 0; next.state.lo = 0; next.state.hi = -1;
+    if (c.sh->nodes[node].cut) {
+        // the walk ended inside a run: the original's next graph node is the run's next original, reached by every haplotype of the state — one
+        // child, whose first piece is the rest of the run (the same search state, the same record)
+        if (c.sh->n_nodes + 1 > (uint32_t)W_NODES) { c.overflow = true; c.why = 2; return false; }
+        const WwPath last = c.pth(c.sh->nodes[node].path_tail);
+        uint32_t run_len = 0; const uint32_t run_seq = g_seq_of(c.P->index, (uint32_t)st.node, run_len);
+        next.state = st; next.rec = rec; next.inner = (last.seq_off - run_seq) + last.len; next.seq_off = last.seq_off + last.len; next.len = run_len - next.inner;
+        c.sh->nodes[node].first_child = (uint8_t)c.sh->n_nodes; c.sh->nodes[node].n_children = 1;
+        c.sh->leaves &= ~(1u << node);
+        ww_node_create(c, c.sh->n_nodes, next, node, c.grow_cap); ++c.sh->n_nodes;
+        return true;
+    }
     const uint32_t k = ww_follow(c, rec, st, 0, next, 0xffffffffu);
     if (!k) { c.sh->nodes[node].dead_end = 1; return false; }
     if (c.sh->n_nodes + k > (uint32_t)W_NODES) { c.overflow = true; c.why = 2; return false; }
@@ -545,22 +633,26 @@ template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t
             // that does not is not probed — the probe would walk its hash chain to the first free slot and find nothing
             uint32_t has = 31u;
             if constexpr (!SMALL) { if (filtered) { has = 0u; for (uint32_t k = 0; k < 5u; ++k) if (c.sh->src_mask[diag - diag0][k] & anc) has |= 1u << k; } }
+            // (the first two slots of every source cell's probe sequence, read together: ww_probe)
+            const WwProbe p_io = ww_probe(c, (has & 2u) != 0, WK_MATCH, src_open, diag - 1), p_ie = ww_probe(c, (has & 4u) != 0, WK_INS, src_extend, diag - 1),
+                          p_do = ww_probe(c, (has & 8u) != 0, WK_MATCH, src_open, diag + 1), p_de = ww_probe(c, (has & 16u) != 0, WK_DEL, src_extend, diag + 1),
+                          p_s = ww_probe(c, (has & 1u) != 0, WK_MATCH, src_mismatch, diag);
             WPos ins;
-            { const WPos open = (has & 2u) ? ww_find_in(c, WK_MATCH, src_open, anc, leaf, diag - 1, true, false) : w_none(), ext = (has & 4u) ? ww_find_in(c, WK_INS, src_extend, anc, leaf, diag - 1, true, false) : w_none();
+            { const WPos open = ww_find_probed(c, p_io, WK_MATCH, src_open, anc, leaf, diag - 1, true, false), ext = ww_find_probed(c, p_ie, WK_INS, src_extend, anc, leaf, diag - 1, true, false);
               ins = w_less(open, ext) ? ext : open; }
             if (!ins.empty) {
                 ins.seq++;
                 if (w_distance(ins, diag) >= c.min_distance) { ww_update(c, WK_INS, score, diag, ins); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
             }
             WPos del;
-            { const WPos open = (has & 8u) ? ww_find_in(c, WK_MATCH, src_open, anc, leaf, diag + 1, false, true) : w_none(), ext = (has & 16u) ? ww_find_in(c, WK_DEL, src_extend, anc, leaf, diag + 1, false, true) : w_none();
+            { const WPos open = ww_find_probed(c, p_do, WK_MATCH, src_open, anc, leaf, diag + 1, false, true), ext = ww_find_probed(c, p_de, WK_DEL, src_extend, anc, leaf, diag + 1, false, true);
               del = w_less(open, ext) ? ext : open; }
             if (!del.empty) {
                 ww_successor_offset(c, del);
                 if (w_distance(del, diag) >= c.min_distance) { ww_update(c, WK_DEL, score, diag, del); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
                 if (ww_wants_expansion(c, del)) want = del.cur;
             }
-            WPos subst = (has & 1u) ? ww_find_in(c, WK_MATCH, src_mismatch, anc, leaf, diag, true, true) : w_none();
+            WPos subst = ww_find_probed(c, p_s, WK_MATCH, src_mismatch, anc, leaf, diag, true, true);
             if (!subst.empty) { subst.seq++; ww_successor_offset(c, subst); if (want == (uint32_t)W_NODES && ww_wants_expansion(c, subst)) want = subst.cur; }
             if (w_less(subst, ins)) subst = ins;
             if (w_less(subst, del)) subst = del;
@@ -653,6 +745,7 @@ template <class XL, bool SMALL> VGK_HD void ww_append_edit(WwCtx<XL, SMALL>& c, 
 // -> true: the problem outgrew the small size's tables and the large size is to take it over (never from the large size itself)
 template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, uint32_t i, uint32_t slab, uint32_t lane, WwShared<SMALL>& sh, XL& xl) {
     const WfaParams& B = P.base;
+    const uint32_t t_begin = P.stats ? xl.clock_us() : 0u;
     const WProb pb = B.probs[i];
     vgk_wfa_result out; out.status = pb.status; out.ok = 0; out.score = 0; out.node_offset = 0; out.seq_offset = 0; out.length = 0;
     out.path_begin = 0; out.path_len = 0; out.edit_begin = 0; out.n_edits = 0;
@@ -675,6 +768,16 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
     }
     c.seq = B.seqs + pb.seq_off; c.L = pb.seq_len;
     c.no_to = pb.to_node == VGK_WFA_NO_NODE; c.to_node = (int32_t)pb.to_node; c.to_off = pb.to_off;
+    // the two positions in the index this kernel walks: with merged runs, the run each lies in and where in it the original node starts
+    uint32_t from_walked = pb.from_node, from_inner = 0;
+    c.to_inner = 0; c.to_orig_len = 0;
+    if (P.merge.on) { const uint64_t t = P.merge.seed_map[pb.from_node]; from_walked = (uint32_t)t; from_inner = (uint32_t)(t >> 32); }
+    if (!c.no_to) {
+        if (pb.to_node < B.index.n_oriented) {
+            c.to_orig_len = g_len(B.index, (int32_t)pb.to_node);
+            if (P.merge.on) { const uint64_t t = P.merge.seed_map[pb.to_node]; c.to_node = (int32_t)(uint32_t)t; c.to_inner = (uint32_t)(t >> 32); }
+        } else c.to_node = -2;                                                 // (no such node: nothing the walk meets is the target)
+    }
     { const uint32_t budget = c.no_to ? B.max_points_tail : B.max_points; c.max_points = budget < own_points ? budget : own_points; }
     // no position gets further into a trie node than the sequence plus the deletions the score cap pays for (+ where the root starts)
     c.grow_cap = c.L + (uint32_t)(pb.score_bound / B.gap_extend) + 2u;
@@ -686,9 +789,10 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
     ww_clear_masks(c, 0);
     if (lane == 0) {
         sh.n_nodes = 0; sh.n_path = 0; sh.n_points = 0; sh.leaves = 0;
-        const uint32_t root_rec = B.index.rec_off[pb.from_node];
-        const uint32_t* rec = B.index.rec + root_rec;
-        WwStep root; root.state.node = (int32_t)pb.from_node; root.state.lo = 0; root.state.hi = (int32_t)rec[0] - 1; root.len = rec[2]; root.seq_off = rec[3]; root.rec = root_rec;
+        const uint32_t root_rec = P.index.rec_off[from_walked];
+        const uint32_t* rec = P.index.rec + root_rec;
+        // (the root's first piece starts with the original `from` node: the trie's offsets count from there, as the node-by-node walk's do)
+        WwStep root; root.state.node = (int32_t)from_walked; root.state.lo = 0; root.state.hi = (int32_t)rec[0] - 1; root.len = rec[2] - from_inner; root.seq_off = rec[3] + from_inner; root.rec = root_rec; root.inner = from_inner;
         ww_node_create(c, 0, root, 0, c.grow_cap + pb.from_off + 1); sh.n_nodes = 1;
         if (!c.overflow) ww_store(c, 0, WK_MATCH, 0, 0, 0, pb.from_off + 1);
         ww_mark(c, 0, false);
@@ -699,6 +803,7 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
     bool failed = ww_any_overflow(c);
     const bool timed = P.stats != nullptr;
     uint32_t t_mark = timed ? xl.clock_us() : 0u;
+    if (timed) c.us_score += t_mark - t_begin;                                 // (the problem's start — its record, the root's walk, the first point — counts with the bookkeeping)
     auto lap = [&](uint32_t& into) { if (timed) { const uint32_t t = xl.clock_us(); into += t - t_mark; t_mark = t; } };
     while (!failed) {
         ww_extend(c, score, best_score, best_diag, best_seq, best_off, best_node);
@@ -794,35 +899,51 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
             for (uint32_t x = c.cand_node;; x = sh.nodes[x].parent) { chain[n_chain++] = (uint8_t)x; if (x == 0) break; }
             uint32_t ref_len = 0;
             for (uint32_t e = 0; e < n_edits; ++e) if ((runs[e] & 3u) != (uint32_t)VGK_WFA_INSERTION) ref_len += runs[e] >> 2;
-            const uint32_t first_len = c.pth(sh.nodes[0].path_head).len;
+            const uint32_t first_len = g_len(B.index, (int32_t)pb.from_node);
             const bool drop_first = out.node_offset >= first_len;
             if (drop_first) out.node_offset = 0;
             const uint32_t used = out.node_offset + ref_len;
-            uint32_t kept = 0, at = 0, last_start = 0, last_len = 0;
-            for (uint32_t k = n_chain; k-- > 0;) {
-                const WwNode& n = sh.nodes[chain[k]];
-                for (uint32_t j = n.path_head; j != W_NIL; j = c.pth(j).next) {
-                    const uint32_t gl = c.pth(j).len;
-                    if (k == n_chain - 1 && j == n.path_head && drop_first) continue;
-                    if (kept == 0 || at < used) { ++kept; last_start = at; last_len = gl; }
-                    at += gl;
+            // the ORIGINAL graph nodes along the chain, root first (a path entry is one of them, or a piece of a merged run: its originals in a row);
+            // visit(oriented node, length) -> false: enough
+            auto originals = [&](auto&& visit) {
+                bool first = true;
+                for (uint32_t k = n_chain; k-- > 0;) {
+                    const WwNode& n = sh.nodes[chain[k]];
+                    for (uint32_t j = n.path_head; j != W_NIL; j = c.pth(j).next) {
+                        const WwPath e = c.pth(j);
+                        if (P.merge.on) {
+                            uint32_t run_len = 0; const uint32_t inner = e.seq_off - g_seq_of(P.index, (uint32_t)e.node, run_len);
+                            WwOriginals it = ww_originals(P.merge, (uint32_t)e.node, inner);
+                            for (uint32_t got = 0; got < e.len && !it.done(); it.step()) {
+                                const uint32_t gl = it.length(); got += gl;
+                                const bool skip = first && drop_first; first = false;
+                                if (!skip && !visit(it.oriented(), gl)) return;
+                            }
+                        } else {
+                            const bool skip = first && drop_first; first = false;
+                            if (!skip && !visit((uint32_t)e.node, (uint32_t)e.len)) return;
+                        }
+                    }
                 }
-            }
+            };
+            uint32_t kept = 0, at = 0, last_start = 0, last_len = 0;
+            originals([&](uint32_t, uint32_t gl) {
+                if (kept != 0 && at >= used) return false;                      // (everything from here on starts behind the alignment's last base)
+                ++kept; last_start = at; last_len = gl; at += gl;
+                return true;
+            });
             if (kept == 1 && used == out.node_offset) kept = 0;
             const unsigned long long p0 = g_bump(B.counters + 0, kept), e0 = g_bump(B.counters + 1, n_edits);
             if (p0 + kept > B.caps[0] || e0 + n_edits > B.caps[1]) { out.status = VGK_EOPS; out.ok = 0; }
             else {
                 const bool flip = pb.mode == VGK_WFA_PREFIX;
                 uint32_t w = 0;
-                for (uint32_t k = n_chain; k-- > 0 && w < kept;) {
-                    const WwNode& n = sh.nodes[chain[k]];
-                    for (uint32_t j = n.path_head; j != W_NIL && w < kept; j = c.pth(j).next) {
-                        if (k == n_chain - 1 && j == n.path_head && drop_first) continue;
-                        const uint32_t o = (uint32_t)c.pth(j).node;
-                        B.paths[p0 + (flip ? kept - 1 - w : w)] = flip ? (o ^ 1u) : o;
-                        ++w;
-                    }
-                }
+                originals([&](uint32_t o, uint32_t) {
+                    if (w >= kept) return false;
+                    B.paths[p0 + (flip ? kept - 1 - w : w)] = flip ? (o ^ 1u) : o;
+                    ++w;
+                    return true;
+                });
                 for (uint32_t e = 0; e < n_edits; ++e) B.edits[e0 + e] = runs[flip ? e : n_edits - 1 - e];
                 out.path_begin = (uint32_t)p0; out.path_len = kept; out.edit_begin = (uint32_t)e0; out.n_edits = n_edits;
                 if (pb.mode != VGK_WFA_CONNECT && n_edits && out.length == c.L) {
