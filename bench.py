@@ -432,10 +432,12 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
     # a step = n reads in batches of `per`; two batches in flight (a lane = a ChainStage of its own: engine context, haplotype graph, WFA extender,
     # host threads), because a launch of the WFA kernel ends with ONE heavy link's dependent chain — the second lane's links run in the wavefronts
     # the first lane's launch has already given back, and its host work (local graphs, problem records) runs beside the other's kernels
-    n = args.reads if args.reads else 8000
-    per = min(n, int(os.environ.get("VGAMD_LONGREAD_BATCH", "4000")))
+    want_lanes = 1 if os.environ.get("VGAMD_LONGREAD_ONE_LANE") else max(1, int(os.environ.get("VGAMD_LONGREAD_LANES", "2")))
+    per = int(os.environ.get("VGAMD_LONGREAD_BATCH", "4000"))
+    n = args.reads if args.reads else per * max(2, want_lanes)
+    per = min(n, per)
     n_batches = max(1, n // per); n = n_batches * per
-    n_lanes = 1 if (n_batches < 2 or os.environ.get("VGAMD_LONGREAD_ONE_LANE")) else 2
+    n_lanes = min(want_lanes, n_batches)
     t0 = time.perf_counter()
     wls = [workloads.LongReadWorkload(per, seed=515 + rank + 1000 * b) for b in range(n_batches)]
     wl = wls[0]
@@ -537,7 +539,7 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
             "config": {"workload": "configs[4]: 1 Mbp variation graph, 8 random haplotype threads, %d reads of 15 000 bp per GPU on either strand, error-free 29-mer anchors every "
                                    "120-400 bp, 0.5 %% errors between them (half substitutions, half 1-bp indels), 1 %% of the connects with a 25-60 bp insertion; "
                                    "WFAExtender connect / prefix / suffix with the default error model and NO point budget; align_sequence_between_consistently for what it declines" % n,
-                       "batches": "%d batches of %d reads per step; %s" % (n_batches, per, ("two batches in flight: two lanes (a ChainStage each: engine context, haplotype graph, WFA extender; %d host threads per lane)" % lane_threads)
+                       "batches": "%d batches of %d reads per step; %s" % (n_batches, per, ("%d batches in flight: %d lanes (a ChainStage each: engine context, haplotype graph, WFA extender; %d host threads per lane)" % (n_lanes, n_lanes, lane_threads))
                                                                           if n_lanes > 1 else "one after the other in one lane"),
                        "one_lane": one_lane, "ms_per_batch": 1e3 * elapsed / args.steps / n_batches,
                        "timed_region": "per batch, from host buffers, one vgh_chain_stage call: vgk_wfa_extend over every link; for the declined links extract_connecting_graph / "
