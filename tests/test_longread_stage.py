@@ -41,7 +41,8 @@ def test_chain_stage_equals_the_oracles(emu_lib):
 
 
 @pytest.mark.gpu
-def test_chain_stage_on_the_gpu_with_fallbacks_equals_the_oracles():
+def test_chain_stage_on_the_gpu_with_fallbacks_equals_the_oracles(monkeypatch):
+    monkeypatch.setenv("VGAMD_WFA_LARGE_POINTS", "16384")       # (round 4's table size: links that outgrow it take the fallback this test is about)
     wl, a = run(ENGINE_LIB, 60, 15000, 5, 0.02)
     assert len(a["failed"]) > 10 and (a["banded"]["status"] == 0).all()
 
@@ -121,8 +122,17 @@ def test_native_chain_stage_equals_the_python_pipeline(emu_lib):
 
 
 @pytest.mark.gpu
-def test_native_chain_stage_on_the_gpu():
+def test_native_chain_stage_on_the_gpu(monkeypatch):
+    # with the tables as shipped (262 144 points per link) no link is declined for its points: the stage's chain scores are the oracle stage's
+    wl, a, b = native_stage(ENGINE_LIB, 60, 15000, 5, 0.02, threads=8)
+    check_native(wl, a, b, 0)
+    shipped = a["stats"]["declined"]
+    assert ((a["chain_score"] == b["chain_score"]) | (np.bincount(wl.read_of, weights=(a["link_source"] != b["link_source"]), minlength=wl.n_reads) > 0)).all()
+    # with round 4's table size links with long insertions outgrow it and take the DP route
+    monkeypatch.setenv("VGAMD_WFA_LARGE_POINTS", "16384")
     wl, a, b = native_stage(ENGINE_LIB, 60, 15000, 5, 0.02, threads=8)
     check_native(wl, a, b, 10)
+    assert a["stats"]["declined"] > shipped
+    monkeypatch.delenv("VGAMD_WFA_LARGE_POINTS")
     wl, a, b = native_stage(ENGINE_LIB, 40, 15000, 11, 0.02, budgets=(64, 64), threads=8)
     check_native(wl, a, b, 40)

@@ -98,7 +98,13 @@ int prepare_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P, bool after_t
     // large size: what a link with a 60-base insertion under the default error model stores, several times over
     // (the item filter of the large size — wfa_wave_device.hpp, ww_chunk_of — keeps node sets for diagonals -256 .. 255; VGAMD_WFA_NO_FILTER
     // switches it off for comparisons)
-    WaveSlabs z{after_threads ? cus * per_cu : std::min<uint32_t>(P.n, cus * per_cu), 32768u, 16384u, 2048u, std::getenv("VGAMD_WFA_NO_FILTER") ? 0u : 512u};
+    // The large size holds 262 144 points per link (5 MB of HBM per resident wavefront, 15.7 GB per context: the device has 288).  With 16 384 a
+    // long-read batch of 209 000 links declined 400 — connects with a 25-60-base insertion, which the reference's WFA (no tables) answers — and the DP
+    // route they then take is not bound to haplotypes: 3 of 8 000 chain scores came out higher than the reference's.  With 262 144: none declined for
+    // its points, 16 000 / 16 000 identical; the launch is 28.7 instead of 18.6 ms (those links now run to their end).  65 536: three links still outgrow it.
+    uint32_t large_points = 262144u;
+    if (const char* e = std::getenv("VGAMD_WFA_LARGE_POINTS")) { large_points = 1024u; while (large_points < (uint32_t)std::min(1 << 22, std::max(1024, std::atoi(e)))) large_points <<= 1; }   // (experiments: what the large size can store, a power of two)
+    WaveSlabs z{after_threads ? cus * per_cu : std::min<uint32_t>(P.n, cus * per_cu), 2u * large_points, large_points, 2048u, std::getenv("VGAMD_WFA_NO_FILTER") ? 0u : 512u};
     WwParams A{};
     A.base = P;
     A.index = H.walk_index; A.merge = H.walk_merge;
