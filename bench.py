@@ -433,7 +433,7 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
     # host threads), because a launch of the WFA kernel ends with ONE heavy link's dependent chain — the second lane's links run in the wavefronts
     # the first lane's launch has already given back, and its host work (local graphs, problem records) runs beside the other's kernels
     want_lanes = 1 if os.environ.get("VGAMD_LONGREAD_ONE_LANE") else max(1, int(os.environ.get("VGAMD_LONGREAD_LANES", "2")))
-    per = int(os.environ.get("VGAMD_LONGREAD_BATCH", "4000"))
+    per = int(os.environ.get("VGAMD_LONGREAD_BATCH", "8000"))      # (a launch of the WFA kernel is at least its heaviest link's dependent chain, ~25 ms: 4 000 reads 28.7 ms, 8 000 36.1, 16 000 68.4)
     n = args.reads if args.reads else per * max(2, want_lanes)
     per = min(n, per)
     n_batches = max(1, n // per); n = n_batches * per
