@@ -444,7 +444,7 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
     t_gen = time.perf_counter() - t0
     threads = max(1, shard.usable_cpus() // max(world, 1))
     lane_threads = max(1, threads // n_lanes)
-    stages = [pipeline.ChainStage(w, device=int(os.environ.get("LOCAL_RANK", "0"))) for w in wls]
+    stages = [pipeline.ChainStage(w, device=eng.device) for w in wls]
     for st in stages:
         st.set_point_budgets(0, 0)
     lock = threading.Lock()
