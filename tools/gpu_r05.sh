@@ -131,6 +131,19 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c = d["config
 print(sys.argv[1], round(d["value"]), "ms/batch", round(c["ms_per_batch"], 1), c["batches"], c["one_lane"], {k: round(v, 1) for k, v in c["stage_ms_per_batch"].items()}, "wfa ms", round(c["wfa_kernel_ms"], 1), d["parity"] and {k: v for k, v in d["parity"].items() if k != "what"}, "budgets:", round(c["with_point_budgets"]["reads_per_s"]))
 PY
     done; unset VGAMD_LONGREAD_ONE_LANE ;;
+  longread_sweep) # the long-read stage against one knob at a time: SWEEP="lanes 3 4" | "waves 6 8" (resident wavefronts per CU of a WFA launch) |
+                  # "points 65536 262144" (what the WFA kernel's large size stores per link) | "batch 8000 16000" (reads per batch)
+    set -- ${SWEEP:-batch 8000 16000}; knob=$1; shift
+    for v in "$@"; do
+      case $knob in lanes) export VGAMD_LONGREAD_LANES=$v;; waves) export VGAMD_WFA_WAVES_PER_CU=$v;; points) export VGAMD_WFA_LARGE_POINTS=$v;; batch) export VGAMD_LONGREAD_BATCH=$v;; *) echo "unknown knob $knob"; exit 2;; esac
+      timeout -s KILL 600 python bench.py --workload longread --steps 3 --warmup 1 ${SWEEP_ARGS:-} > "$out/${knob}_$v.json" 2> "$out/${knob}_$v.err"
+      python - "$out/${knob}_$v.json" $knob $v <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c = d["config"]
+print(sys.argv[2], sys.argv[3], round(d["value"]), "ms/batch", round(c["ms_per_batch"], 1), c["one_lane"], {k: round(v, 1) for k, v in c["stage_ms_per_batch"].items()}, "wfa ms", round(c["wfa_kernel_ms"], 1), c["links"],
+      d["parity"] and {k: v for k, v in d["parity"].items() if k != "what"})
+PY
+    done; unset VGAMD_LONGREAD_LANES VGAMD_WFA_WAVES_PER_CU VGAMD_WFA_LARGE_POINTS VGAMD_LONGREAD_BATCH ;;
   wfa_runs)       # the WFA wavefront kernel on the merged-run index against the node-by-node walk: gpu tests, the WFA leg, the long-read stage
     timeout 900 python -m pytest tests/test_wfa.py tests/test_longread_stage.py tests/test_chain_alignment.py -m gpu -x -q > "$out/pytest_wfa.log" 2>&1; echo "rc=$?" >> "$out/pytest_wfa.log"; tail -3 "$out/pytest_wfa.log"
     for m in runs nodes; do
