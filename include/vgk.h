@@ -349,8 +349,8 @@ double   vgk_tail_stage_last_ms(vgk_ctx* ctx, int which);             /* 0 tails
  * a node whose incoming fronts are all empty is skipped.  Everything else — root column, seeds, bonus, end cell, traceback
  * preferences — is as in VGK_XDROP_PINNED.  Problems must be VGK_XDROP_PINNED (| VGK_GSSW_TRACEBACK); reads up to 511 bases.
  * stats (nullable): [0] cells inside the bands, [1] cells of the full read x graph rectangles.
- * The device fills the columns (one 8-row vector per lane; tails of up to 127 bases four to a wavefront, 16 lanes each, longer reads a
- * wavefront each; only a column's front is kept in HBM) and picks the end cell; a second kernel, one lane per problem, walks the
+ * The device fills the columns (one 8-row vector per lane; tails of up to 127 bases four to a wavefront, 16 lanes each — with VGAMD_XBAND_EIGHTS=1
+ * those of up to 63 bases eight to a wavefront, 8 lanes each: measured slower, off by default —, longer reads a wavefront each; only a column's front is kept in HBM) and picks the end cell; a second kernel, one lane per problem, walks the
  * tracebacks; ops are packed on the device and only results and ops come back.  VGAMD_XBAND_TIMING=1 prints the call's host laps. */
 int  vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n,
                           vgk_result* results, vgk_op* ops, size_t ops_cap, size_t* ops_written, uint64_t stats[2]);
@@ -360,6 +360,9 @@ double vgk_xdrop_band_last_ms(vgk_ctx* ctx);     /* kernel time (fills + traceba
  * no reachable cell can then leave the 16-bit range); 3 = 16-bit cells under int32 arithmetic (VGAMD_XBAND_ARITH32=1; VGAMD_XBAND_CELLS32=1
  * forces 4).  The answers are the same in every form (tests/test_xdrop_band.py); what differs is the bytes a cell costs: 2 x 4 or 2 x 2. */
 int    vgk_xdrop_band_last_cells(vgk_ctx* ctx);
+/* ... and how its problems shared wavefronts (summed over the call's sub-batches): which = 0: tails of at most 63 bases, EIGHT to a wavefront
+ * (8 lanes of 8 rows each; the packed fill only); 1: tails of at most 127 bases, four to a wavefront; 2: the rest, a wavefront each. */
+uint64_t vgk_xdrop_band_last_class(vgk_ctx* ctx, int which);
 
 /* k-best pinned alignments (Aligner::align_pinned_multi -> gssw_graph_trace_back_pinned_multi, src/aligner.cpp:423-435, :455-480).
  * Every problem must be VGK_GSSW_PINNED.  results[i * max_alt_alns + k] is the k-th best alignment of problem i (k <

@@ -162,6 +162,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
 
 double vgk_xdrop_band_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }
 int vgk_xdrop_band_last_cells(vgk_ctx* ctx) { (void)ctx; return 4; }      /* the checker's cells are int32 */
+uint64_t vgk_xdrop_band_last_class(vgk_ctx* ctx, int which) { (void)ctx; (void)which; return 0; }      /* (no wavefronts to share here) */
 
 /* threads of the OpenMP loops below (bench.py sets the CPUs the container may really use; the default is every hardware thread) */
 #include <omp.h>

@@ -152,7 +152,7 @@ public:
             for (auto& t : ts) t.join();
             pthread_barrier_destroy(&sh.bar);
         };
-        if (P.xb_order) { run(16, 0, P.xb_n16); run(64, P.xb_n16, P.xb_n64); } else run(64, 0, P.n);
+        if (P.xb_order) { run(8, 0, P.xb_n8); run(16, P.xb_n8, P.xb_n16); run(64, P.xb_n8 + P.xb_n16, P.xb_n64); } else run(64, 0, P.n);
         if (P.xb_results) for (uint32_t k = 0; k < P.n; ++k) xdrop_band_walk_one(P, P.xb_order ? P.xb_order[k] : k);      // the walk kernel: one lane per problem
         return VGK_OK;
     }

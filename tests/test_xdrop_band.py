@@ -188,3 +188,41 @@ def test_band_in_many_sub_batches_on_hip(monkeypatch):
     many_sub_batches(util.ENGINE_LIB, 3000, monkeypatch)
     ps = random_xdrop_set(32, 70000, None, max_nodes=6, max_node_len=12, max_read=40)      # large enough for the call to cut itself in four
     same(capi.Engine(lib=util.ENGINE_LIB).xdrop_band_align(ps), capi.Engine(lib=util.ORACLE_LIB).xdrop_band_align(ps))
+
+
+# ---- tails of at most 63 bases EIGHT to a wavefront (8 lanes of 8 rows: XlDpp8 in backend_hip.hip; the lane code is the 16-lane class's) ----
+def eight_lane_class(lib, n, monkeypatch):
+    """reads of every length around the class boundaries (63 | 64 rows: one lane more or fewer; 127 | 128), the same answers from the oracle, and
+    from the engine without the class (the default)"""
+    rng = np.random.default_rng(77)
+    lengths = [1, 2, 7, 8, 9, 15, 16, 17, 31, 32, 33, 47, 48, 49, 55, 56, 57, 61, 62, 63, 64, 65, 71, 72, 96, 126, 127, 128, 129, 160]
+    probs = []
+    for k in range(n):
+        L = lengths[k % len(lengths)]
+        p = random_problem(rng, mode=capi.VGK_XDROP_PINNED, max_nodes=14, max_node_len=20, max_read=L, with_n=0.03)
+        while len(p["read"]) != L:                                   # (the generator draws a length up to max_read)
+            p = random_problem(rng, mode=capi.VGK_XDROP_PINNED, max_nodes=14, max_node_len=20, max_read=L, with_n=0.03)
+        if k % 3 == 0:
+            p["max_gap"] = int(rng.integers(0, 5))
+        probs.append(p)
+    ps = problem_set(probs)
+    monkeypatch.setenv("VGAMD_XBAND_EIGHTS", "1")                      # (measured slower than four to a wavefront: not the default)
+    eng = capi.Engine(lib=lib); ora = capi.Engine(lib=util.ORACLE_LIB)
+    got = eng.xdrop_band_align(ps)
+    c8, c16, c64 = eng.xdrop_band_last_classes()
+    short = sum(1 for p in probs if len(p["read"]) <= 63); mid = sum(1 for p in probs if 63 < len(p["read"]) <= 127)
+    assert (c8, c16, c64) == (short, mid, n - short - mid) and c8 > n // 3
+    same(got, ora.xdrop_band_align(ps))
+    monkeypatch.delenv("VGAMD_XBAND_EIGHTS")
+    plain = capi.Engine(lib=lib)
+    same(got, plain.xdrop_band_align(ps))
+    assert plain.xdrop_band_last_classes() == (0, short + mid, n - short - mid)
+
+
+def test_emulated_band_with_eight_tails_to_a_wavefront(emu_lib, monkeypatch):
+    eight_lane_class(emu_lib, 120, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_band_with_eight_tails_to_a_wavefront_on_hip(monkeypatch):
+    eight_lane_class(util.ENGINE_LIB, 6000, monkeypatch)

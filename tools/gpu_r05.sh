@@ -144,6 +144,19 @@ print(sys.argv[2], sys.argv[3], round(d["value"]), "ms/batch", round(c["ms_per_b
       d["parity"] and {k: v for k, v in d["parity"].items() if k != "what"})
 PY
     done; unset VGAMD_LONGREAD_LANES VGAMD_WFA_WAVES_PER_CU VGAMD_WFA_LARGE_POINTS VGAMD_LONGREAD_BATCH ;;
+  xband_eights)   # the X-drop band's 8-lane class (tails of at most 63 bases eight to a wavefront) against four to a wavefront: gpu tests, the xband leg
+    timeout 900 python -m pytest tests/test_xdrop_band.py tests/test_rescue_fixups.py tests/test_golden_gssw_oracle.py -m gpu -x -q > "$out/pytest_xband.log" 2>&1; echo "rc=$?" >> "$out/pytest_xband.log"; tail -3 "$out/pytest_xband.log"
+    for m in eights fours; do
+      case $m in eights) export VGAMD_XBAND_EIGHTS=1;; *) unset VGAMD_XBAND_EIGHTS;; esac
+      for rep in 1 2; do
+      timeout 600 python bench.py --workload xband --steps 5 --warmup 2 $([ $m = fours ] && echo --no-cpu) > "$out/bench_xband_${m}_$rep.json" 2> "$out/bench_xband_${m}_$rep.err"
+      python - "$out/bench_xband_${m}_$rep.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c = d["config"]
+print(sys.argv[1], round(d["value"]), "ms/step", round(d["ms_per_step"], 2), {k: v for k, v in c.items() if "ms" in k or "kernel" in k}, d["roofline"].get("frac"), d.get("parity") and {k: v for k, v in d["parity"].items() if k != "what"})
+PY
+      done
+    done; unset VGAMD_XBAND_EIGHTS ;;
   wfa_runs)       # the WFA wavefront kernel on the merged-run index against the node-by-node walk: gpu tests, the WFA leg, the long-read stage
     timeout 900 python -m pytest tests/test_wfa.py tests/test_longread_stage.py tests/test_chain_alignment.py -m gpu -x -q > "$out/pytest_wfa.log" 2>&1; echo "rc=$?" >> "$out/pytest_wfa.log"; tail -3 "$out/pytest_wfa.log"
     for m in runs nodes; do

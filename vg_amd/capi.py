@@ -401,6 +401,11 @@ class Engine:
                     "vgk_xdrop_band_align")
         return res, ops[:written.value], (int(stats[0]), int(stats[1]))
 
+    def xdrop_band_last_classes(self):
+        """problems of the last xdrop_band_align call by the lanes they ran on: (8, 16, 64)"""
+        self.lib.vgk_xdrop_band_last_class.restype = ctypes.c_uint64; self.lib.vgk_xdrop_band_last_class.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        return tuple(int(self.lib.vgk_xdrop_band_last_class(self.h, k)) for k in range(3))
+
     def align_multi(self, ps, max_alt_alns):
         """vgk_gssw_align_multi over a ProblemSet of pinned problems -> (results [n, max_alt_alns], n_alignments [n], ops)."""
         res = np.zeros((ps.n, max_alt_alns), dtype=RESULT_DT); cnt = np.zeros(ps.n, dtype=np.uint32)

@@ -874,7 +874,7 @@ __global__ void __launch_bounds__(64) xdrop_band_kernel(const GsswMatrixParams P
     __shared__ uint8_t stg[XB_STAGE64];
     __shared__ int32_t cc[2 * 2 * 64 * 8];                       // two last columns (H | E) of up to 512 rows
     XlDppStaged xl; xl.stg = stg; xl.cc = cc;
-    xdrop_band_wave_lane_t<CT>(P, P.xb_order ? P.xb_order[P.xb_n16 + blockIdx.x] : blockIdx.x, threadIdx.x, xl);
+    xdrop_band_wave_lane_t<CT>(P, P.xb_order ? P.xb_order[P.xb_n8 + P.xb_n16 + blockIdx.x] : blockIdx.x, threadIdx.x, xl);
 }
 // three wavefronts per SIMD (168 VGPRs, five spilled dwords): 26.2 -> 21.0 ms per 200 000 tails against the compiler's own 175 VGPRs = two;
 // four (128 VGPRs, 38 spilled): the same 20.9 ms
@@ -888,7 +888,7 @@ __global__ void __launch_bounds__(64, VGK_XB_OCC) xdrop_band_kernel16(const Gssw
     const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 4);
     if (slot >= P.xb_n16) return;
     XlDpp16 xl; xl.stg = stg + (threadIdx.x >> 4) * XB_STAGE16; xl.cc = cc + (threadIdx.x >> 4) * (2 * 2 * 16 * 8);
-    xdrop_band_wave_lane_t<CT>(P, P.xb_order[slot], threadIdx.x & 15u, xl);
+    xdrop_band_wave_lane_t<CT>(P, P.xb_order[P.xb_n8 + slot], threadIdx.x & 15u, xl);
 }
 // the tracebacks of the X-drop band path, one lane per problem, in the fills' launch order (neighbours walk graphs of like size)
 // the packed fill (xdrop_band_pk_lane): two rows to a register, half the registers, a quarter of the LDS (a word per row pair in the column
@@ -903,13 +903,60 @@ __global__ void __launch_bounds__(64, VGK_XBP_OCC) xdrop_band_pk_kernel16(const 
     const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 4);
     if (slot >= P.xb_n16) return;
     XlDpp16 xl; xl.stg = stg + (threadIdx.x >> 4) * XBP_STAGE16; xl.cc = cc + (threadIdx.x >> 4) * (2 * 2 * 16 * 4); xl.cap = XBP_STAGE16;
-    xdrop_band_pk_lane(P, P.xb_order[slot], threadIdx.x & 15u, xl);
+    xdrop_band_pk_lane(P, P.xb_order[P.xb_n8 + slot], threadIdx.x & 15u, xl);
+}
+// The same over HALF a DPP row: eight problems share a wavefront, 8 lanes (64 rows) each — tails of at most 63 bases, which left half of a
+// 16-lane row idle.  The DPP shifts stay row-wide; what would cross from lane 7 into lane 8 is masked: bank_mask for the shift by 4 (banks are
+// four lanes), a select per lane for the shifts by 1 and 2; the maximum over the group is two quad permutes and a half-row mirror.
+struct XlDpp8 {
+    uint8_t* stg; int32_t* cc; uint32_t cap;
+    __device__ __forceinline__ int32_t* col_cache() const { return cc; }
+    __device__ __forceinline__ void lds_sync() const { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+    __device__ __forceinline__ uint8_t* stage() const { return stg; }
+    __device__ __forceinline__ uint32_t stage_cap() const { return cap; }
+    __device__ __forceinline__ void stage_sync() const { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+    __device__ __forceinline__ uint32_t width() const { return 8u; }
+    __device__ __forceinline__ int32_t down(int32_t v) const {
+        const int32_t r = __builtin_amdgcn_update_dpp(BNEG, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+        return (threadIdx.x & 7u) ? r : BNEG;
+    }
+    __device__ __forceinline__ int32_t scan_excl(int32_t v) const {       // exclusive max-scan over the group's 8 lanes
+        const uint32_t l = threadIdx.x & 7u;
+        int32_t t = __builtin_amdgcn_update_dpp(BNEG, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false); t = l >= 1u ? t : BNEG; v = t > v ? t : v;
+        t = __builtin_amdgcn_update_dpp(BNEG, v, 0x112 /* row_shr:2 */, 0xf, 0xf, false); t = l >= 2u ? t : BNEG; v = t > v ? t : v;
+        t = __builtin_amdgcn_update_dpp(BNEG, v, 0x114 /* row_shr:4 */, 0xf, 0xa /* lanes 4-7 and 12-15 */, false); v = t > v ? t : v;
+        return down(v);
+    }
+    __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+    __device__ __forceinline__ unsigned long long ballot(bool flag) const { return (__ballot(flag) >> (threadIdx.x & 56u)) & 0xffull; }
+    __device__ __forceinline__ bool any(int32_t flag) const { return ballot(flag != 0) != 0ull; }
+    __device__ __forceinline__ int32_t reduce_max(int32_t v) const {
+        int32_t o;
+        o = __builtin_amdgcn_update_dpp(v, v, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false); v = o > v ? o : v;
+        o = __builtin_amdgcn_update_dpp(v, v, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false); v = o > v ? o : v;
+        o = __builtin_amdgcn_update_dpp(v, v, 0x141 /* row_half_mirror */, 0xf, 0xf, false); v = o > v ? o : v;
+        return v;
+    }
+    __device__ __forceinline__ unsigned long long reduce_add(unsigned long long v) const {
+#pragma unroll
+        for (int d = 4; d > 0; d >>= 1) v += __shfl_xor(v, d, 8);
+        return v;
+    }
+};
+constexpr uint32_t XBP_STAGE8 = 256;
+__global__ void __launch_bounds__(64, VGK_XBP_OCC) xdrop_band_pk_kernel8(const GsswMatrixParams P) {
+    __shared__ uint8_t stg[8 * XBP_STAGE8];
+    __shared__ int32_t cc[8 * 2 * 2 * 8 * 4];
+    const uint32_t slot = blockIdx.x * 8u + (threadIdx.x >> 3);
+    if (slot >= P.xb_n8) return;
+    XlDpp8 xl; xl.stg = stg + (threadIdx.x >> 3) * XBP_STAGE8; xl.cc = cc + (threadIdx.x >> 3) * (2 * 2 * 8 * 4); xl.cap = XBP_STAGE8;
+    xdrop_band_pk_lane(P, P.xb_order[slot], threadIdx.x & 7u, xl);
 }
 __global__ void __launch_bounds__(64) xdrop_band_pk_kernel(const GsswMatrixParams P) {
     __shared__ uint8_t stg[XB_STAGE64];
     __shared__ int32_t cc[2 * 2 * 64 * 4];
     XlDppStaged xl; xl.stg = stg; xl.cc = cc;
-    xdrop_band_pk_lane(P, P.xb_order ? P.xb_order[P.xb_n16 + blockIdx.x] : blockIdx.x, threadIdx.x, xl);
+    xdrop_band_pk_lane(P, P.xb_order ? P.xb_order[P.xb_n8 + P.xb_n16 + blockIdx.x] : blockIdx.x, threadIdx.x, xl);
 }
 template <class CT>
 __global__ void __launch_bounds__(64) xdrop_band_walk_kernel(const GsswMatrixParams P) {
@@ -1426,6 +1473,7 @@ public:
         };
         if (p.xb_cell16 == 2) {
             if (p.xb_order) {
+                if (p.xb_n8) hipLaunchKernelGGL(xdrop_band_pk_kernel8, dim3((p.xb_n8 + 7) / 8), dim3(64), 0, stream, p);
                 if (p.xb_n16) hipLaunchKernelGGL(xdrop_band_pk_kernel16, dim3((p.xb_n16 + 3) / 4), dim3(64), 0, stream, p);
                 if (p.xb_n64) hipLaunchKernelGGL(xdrop_band_pk_kernel, dim3(p.xb_n64), dim3(64), 0, stream, p);
             } else hipLaunchKernelGGL(xdrop_band_pk_kernel, dim3(p.n), dim3(64), 0, stream, p);

@@ -194,6 +194,7 @@ struct vgk_ctx {
     std::shared_ptr<void> xband_host;       // and of xdrop_band_api.cpp
     double xband_ms = 0;                    // kernel time of the last vgk_xdrop_band_align call
     int xband_cells = 4;                    // ... and its cell form (vgk_xdrop_band_last_cells)
+    uint64_t xband_class[3] = {0, 0, 0};    // ... and its problems by the lanes they ran on: 8 | 16 | 64 (vgk_xdrop_band_last_class)
     ~vgk_ctx() { if (be) { if (deferred.pending) be->sync_fetch(); if (deferred.ev) be->event_destroy(deferred.ev); for (DevBuf& b : scratch) if (b.p) be->release(b.p); for (Pooled& q : dev_pool) be->release(q.p); for (Pooled& q : host_pool) be->host_release(q.p); } }
 };
 

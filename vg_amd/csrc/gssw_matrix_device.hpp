@@ -51,7 +51,8 @@ struct GsswMatrixParams {
     // of them share a wavefront, 16 lanes each (giraffe's tails are 1-121 bases: a whole wavefront per tail left 48-60 lanes idle);
     // order[n16 .. n16 + n64) = the longer ones, a wavefront each.  Inside a class by descending graph size, so that the four of a
     // wavefront run about equally long.  Null: every problem a wavefront of its own, in the order given.
-    const uint32_t* xb_order; uint32_t xb_n16, xb_n64;
+    // (packed fill only: order[0 .. n8) = tails of at most 63 bases, EIGHT to a wavefront, 8 lanes each — then the 16-lane class, then the rest)
+    const uint32_t* xb_order; uint32_t xb_n16, xb_n64, xb_n8;
     uint16_t* xb_front;               // per column (a problem's at its graph_off): first vector of the front | one past the last << 8 — only those vectors are stored
     // X-drop band only: 1 = the planes hold 16-bit cells (`cells` is then an int16_t array of the same element count).  The arithmetic is
     // the same; a stored cell is its value saturated to int16, and whatever comes back at or below XB16_DEAD is unreachable.  The caller

@@ -54,6 +54,7 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
     std::lock_guard<std::mutex> lock(ctx->mu);
     Backend* be = ctx->be.get();
     const bool qa = ctx->has_qa;
+    ctx->xband_class[0] = ctx->xband_class[1] = ctx->xband_class[2] = 0;
     if (!ctx->xband_host) ctx->xband_host = std::make_shared<BandHost>();
     BandHost& Hs = *static_cast<BandHost*>(ctx->xband_host.get());
     if (!Hs.be) { Hs.be = be; for (void*& e : Hs.ev) e = be->event_create(); }      // (null events: a backend without streams — every wait is then a sync)
@@ -205,14 +206,22 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
         // by descending graph size (a counting sort), so that the problems sharing a wavefront take about equally long
         uint32_t* order = St.order.get(be, m + 1);
         if (!order) return VGK_ENOMEM;
-        uint32_t n16 = 0;
+        // (the packed fill has a third class in front: tails of at most 63 bases — 64 rows, 8 lanes of 8 — eight to a wavefront: a 40-base
+        // tail uses 6 of its 16 lanes.  Built, exact (tests/test_xdrop_band.py, 6 000 problems around the class boundaries on the MI355X), and OFF
+        // unless VGAMD_XBAND_EIGHTS=1: the fills + walks of 200 000 bench tails take 5.19-5.31 ms with it against 4.82-4.98 ms without
+        // (profiles/r05/NOTES.md) — what differs between the groups of a wavefront (node boundaries, predecessor fronts, the root column) runs
+        // group after group, twice as many of them, and the kernel's time is its stores and their latency, not its lanes)
+        uint32_t n16 = 0, n8 = 0;
         { constexpr uint32_t B = 4096;
-          std::vector<uint32_t> count(2 * B + 1, 0);
-          auto bucket = [&](uint32_t a) { return (uint32_t)bucket_of[a]; };      // (made by the packing threads: 0 .. B - 1 the short tails by descending graph size, B .. 2 B - 1 the long ones)
-          for (uint32_t a = 0; a < m; ++a) { ++count[bucket(a) + 1]; if (bucket_of[a] < B) ++n16; }
-          for (uint32_t b = 0; b < 2 * B; ++b) count[b + 1] += count[b];
+          const bool eights = cell_form == 2 && std::getenv("VGAMD_XBAND_EIGHTS") != nullptr;
+          std::vector<uint32_t> count(3 * B + 1, 0);
+          // (bucket_of, made by the packing threads: 0 .. B - 1 the short tails by descending graph size, B .. 2 B - 1 the long ones)
+          auto bucket = [&](uint32_t a) { const uint32_t b = bucket_of[a]; return b >= B ? b + B : (eights && probs[a].L <= 63u ? b : b + B); };
+          for (uint32_t a = 0; a < m; ++a) { const uint32_t b = bucket(a); ++count[b + 1]; if (b < B) ++n8; else if (b < 2 * B) ++n16; }
+          for (uint32_t b = 0; b < 3 * B; ++b) count[b + 1] += count[b];
           for (uint32_t a = 0; a < m; ++a) order[count[bucket(a)]++] = a; }
-        P.xb_order = (const uint32_t*)dev(D_ORDER, order, sizeof(uint32_t) * m); P.xb_n16 = n16; P.xb_n64 = m - n16;
+        P.xb_order = (const uint32_t*)dev(D_ORDER, order, sizeof(uint32_t) * m); P.xb_n8 = n8; P.xb_n16 = n16; P.xb_n64 = m - n16 - n8;
+        ctx->xband_class[0] += n8; ctx->xband_class[1] += n16; ctx->xband_class[2] += m - n16 - n8;
         P.xb_results = (vgk_result*)dev(D_RES, nullptr, sizeof(vgk_result) * m);
         P.xb_ops = (vgk_op*)dev(D_OPS, nullptr, sizeof(vgk_op) * ops_off[m]);
         P.xb_ops_off = (const uint64_t*)dev(D_OPSOFF, ops_off, sizeof(uint64_t) * m);
@@ -344,5 +353,6 @@ int vgk_xdrop_band_align(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_
 
 double vgk_xdrop_band_last_ms(vgk_ctx* ctx) { return ctx ? ctx->xband_ms : 0.0; }
 int vgk_xdrop_band_last_cells(vgk_ctx* ctx) { return ctx ? ctx->xband_cells : 4; }
+uint64_t vgk_xdrop_band_last_class(vgk_ctx* ctx, int which) { return ctx && which >= 0 && which < 3 ? ctx->xband_class[which] : 0; }
 
 }  // extern "C"
