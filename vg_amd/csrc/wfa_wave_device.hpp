@@ -62,7 +62,7 @@ struct WwNode {                       // WNode of wfa_device.hpp + where the rec
     uint8_t  complete, cut, pad[2];   // cut: the walk ended INSIDE a merged run (after the original node that ends this trie node); the rest of the run is its only child's
     uint32_t ancestors;
 };
-struct WwPath { int32_t node; uint32_t seq_off; uint16_t start, len, next, pad; };     // a graph node on a trie node's path: its bases at index.seq + seq_off
+struct WwPath { int32_t node; uint32_t seq_off; uint16_t start, len, next, inner; };   // a graph node on a trie node's path (or a piece of a merged run: from base `inner` of the run on): its bases at index.seq + seq_off
 
 struct WwParams {
     WfaParams base;                   // index, problems, sequences, scoring, outputs, counters[2] = next problem to hand out
@@ -273,17 +273,15 @@ template <class XL, bool SMALL> VGK_HD bool ww_wants_expansion(WwCtx<XL, SMALL>&
 template <class XL, bool SMALL> VGK_HD void ww_match_forward(WwCtx<XL, SMALL>& c, WPos& p) {
     if (p.seq >= c.L || ww_past_end(c, p.cur, p.off)) return;
     const GIndex& h = c.P->index;
-    // the entry that holds offset p.off: a trie node's entries are made in one go when the node is walked (ww_node_create), so they lie
-    // next to each other in the pool with ascending starts — a binary search instead of a walk from the head (for the large size every
-    // step of that walk is a dependent load from the HBM slab, and a position 250 bases into a node sits eight entries down)
+    // the entry that holds offset p.off: along the node's chain from its head (the entries of sibling nodes interleave in the pool — their walks run
+    // on as many lanes at once —, so no search by index; over merged runs a node has two or three entries, a position is one or two hops down)
     uint32_t k = c.sh->nodes[p.cur].path_head;
     uint32_t hops = 0;
-    { uint32_t hi = c.sh->nodes[p.cur].path_tail;
-      while (k < hi) { const uint32_t mid = (k + hi + 1) >> 1; if (c.pth(mid).start <= p.off) k = mid; else hi = mid - 1; } }
     for (;;) {
         if (hops++ > 2 * c.path_cap || k >= c.path_cap) { c.overflow = true; c.why = 9; return; }       // a broken chain: never walk it for ever
         const WwPath e = c.pth(k);                                             // one entry: where the node's bases lie and how many
-        if (p.off < e.start || p.off >= (uint32_t)e.start + e.len) { c.overflow = true; c.why = 9; return; }      // (not the entry of this offset: cannot happen)
+        if (p.off >= (uint32_t)e.start + e.len) { k = e.next; continue; }      // (the entries before the offset's: a node over merged runs has two or three in all)
+        if (p.off < e.start) { c.overflow = true; c.why = 9; return; }        // (not the entry of this offset: cannot happen)
         const char* g = h.seq + e.seq_off + (p.off - e.start);
         const char* r = c.seq + p.seq;
         uint32_t left = (uint32_t)e.start + e.len - p.off; if (c.L - p.seq < left) left = c.L - p.seq;
@@ -329,7 +327,6 @@ VGK_HD WwOriginals ww_originals(const GMerge& M, uint32_t merged_oriented, uint3
 // holds the target, or that brings it to W_TARGET_LENGTH bases — inside a run, the piece is cut there (n.cut).  -> whether the node is complete.
 template <class XL, bool SMALL> VGK_HD bool ww_append_piece(WwCtx<XL, SMALL>& c, WwNode& n, const WwStep& next) {
     n.st_node = next.state.node; n.st_lo = next.state.lo; n.st_hi = next.state.hi; n.st_rec = next.rec;
-    if (c.sh->n_path >= c.path_cap) { c.overflow = true; c.why = 3; return true; }
     uint32_t take = next.len; bool complete = false, at_target = false;
     const bool holds_target = !c.no_to && c.to_node == next.state.node && c.to_inner >= next.inner;
     if (holds_target) { take = c.to_inner + c.to_orig_len - next.inner; complete = true; at_target = true; }
@@ -340,8 +337,10 @@ template <class XL, bool SMALL> VGK_HD bool ww_append_piece(WwCtx<XL, SMALL>& c,
         while (!it.done() && got < take) { got += it.length(); it.step(); if (n.len + got >= W_TARGET_LENGTH) break; }
         if (got < take) { take = got; complete = true; at_target = false; }
     }
-    const uint16_t at = (uint16_t)c.sh->n_path++;
-    WwPath e; e.node = next.state.node; e.seq_off = next.seq_off; e.start = (uint16_t)n.len; e.len = (uint16_t)take; e.next = W_NIL; e.pad = 0;
+    const uint32_t slot_at = c.xl->add32(&c.sh->n_path, 1u);                   // (the children of an expansion are walked by as many lanes at once: ww_expand_wave)
+    if (slot_at >= c.path_cap) { c.overflow = true; c.why = 3; return true; }
+    const uint16_t at = (uint16_t)slot_at;
+    WwPath e; e.node = next.state.node; e.seq_off = next.seq_off; e.start = (uint16_t)n.len; e.len = (uint16_t)take; e.next = W_NIL; e.inner = (uint16_t)next.inner;
     c.pth(at) = e;
     if (n.path_head == W_NIL) n.path_head = at; else c.pth(n.path_tail).next = at;
     n.path_tail = at;
@@ -365,7 +364,7 @@ template <class XL, bool SMALL> VGK_HD void ww_node_create(WwCtx<XL, SMALL>& c, 
     n.len = 0; n.target_offset = W_NO_OFFSET; n.path_head = n.path_tail = W_NIL;
     n.parent = (uint8_t)parent; n.first_child = 0; n.n_children = 0; n.dead_end = 0; n.cut = 0; n.pad[0] = n.pad[1] = 0;
     n.ancestors = (id ? c.sh->nodes[parent].ancestors : 0u) | (1u << id);
-    c.sh->leaves |= 1u << id;
+    c.xl->or32(&c.sh->leaves, 1u << id);
     n.complete = ww_append_piece(c, n, first) ? 1 : 0;
     for (uint32_t hops = 0; !n.complete && !c.overflow; ++hops) {
         if (hops > c.path_cap) { c.overflow = true; c.why = 9; break; }
@@ -391,7 +390,8 @@ template <class XL, bool SMALL> VGK_HD bool ww_expand(WwCtx<XL, SMALL>& c, uint3
         if (c.sh->n_nodes + 1 > (uint32_t)W_NODES) { c.overflow = true; c.why = 2; return false; }
         const WwPath last = c.pth(c.sh->nodes[node].path_tail);
         uint32_t run_len = 0; const uint32_t run_seq = g_seq_of(c.P->index, (uint32_t)st.node, run_len);
-        next.state = st; next.rec = rec; next.inner = (last.seq_off - run_seq) + last.len; next.seq_off = last.seq_off + last.len; next.len = run_len - next.inner;
+        (void)run_seq;
+        next.state = st; next.rec = rec; next.inner = (uint32_t)last.inner + last.len; next.seq_off = last.seq_off + last.len; next.len = run_len - next.inner;
         c.sh->nodes[node].first_child = (uint8_t)c.sh->n_nodes; c.sh->nodes[node].n_children = 1;
         c.sh->leaves &= ~(1u << node);
         ww_node_create(c, c.sh->n_nodes, next, node, c.grow_cap); ++c.sh->n_nodes;
@@ -408,6 +408,31 @@ template <class XL, bool SMALL> VGK_HD bool ww_expand(WwCtx<XL, SMALL>& c, uint3
         if (c.overflow) return true;
     }
     return true;
+}
+
+// The same by the whole wavefront — EVERY lane calls, with the same node: the children are walked by as many lanes at once (a walk is a chain of
+// dependent record loads; two children one after the other was half of extend()'s time in a link with a bubble every hundred bases).  Every lane
+// reads the node's record (the same words: one fetch) and takes extension number `lane` of it; the numbers the children get are those of the
+// loop — first_child + their position among the edges.  -> on lane `who` only: whether this call made the children.
+template <class XL, bool SMALL> VGK_HD bool ww_expand_wave(WwCtx<XL, SMALL>& c, uint32_t node, uint32_t who) {
+    const WwNode par = c.sh->nodes[node];
+    if (par.n_children || par.dead_end) return false;
+    if (par.cut) return c.lane == who ? ww_expand(c, node) : false;             // (one child, the rest of the run: nothing to share)
+    const WState st = { par.st_node, par.st_lo, par.st_hi };
+    WwStep next; next.state.node = 0; next.state.lo = 0; next.state.hi = -1;
+    const uint32_t k = ww_follow(c, par.st_rec, st, c.lane, next, 0xffffffffu);
+    const uint32_t base = c.sh->n_nodes;
+    c.xl->fence_lds();                                                         // (everyone has read the node and the count before they change)
+    if (!k) { if (c.lane == who) c.sh->nodes[node].dead_end = 1; return false; }
+    if (base + k > (uint32_t)W_NODES) { c.overflow = true; c.why = 2; return false; }
+    if (c.lane == who) {
+        c.sh->nodes[node].first_child = (uint8_t)base; c.sh->nodes[node].n_children = (uint8_t)k;
+        c.sh->leaves &= ~(1u << node);
+        c.sh->n_nodes = base + k;
+    }
+    c.xl->fence_lds();
+    if (c.lane < k) ww_node_create(c, base + c.lane, next, node, c.grow_cap);
+    return c.lane == who;
 }
 
 // the lanes agree on whether anyone has failed; the reason of the lowest such lane is everyone's
@@ -580,8 +605,7 @@ template <class XL, bool SMALL> VGK_HD void ww_extend(WwCtx<XL, SMALL>& c, int32
             if (first == none) break;                                          // everyone is done
             const uint32_t who = (uint32_t)(first & 0xffu);
             const uint32_t node = c.xl->bcast(it.blocked_on, who);
-            bool made = false;
-            if (c.lane == who) made = ww_expand(c, node);
+            const bool made = ww_expand_wave(c, node, who);
             c.xl->fence();
             if (ww_any_overflow(c)) return;                                    // (a trie that ran out of nodes is half made: nobody may look at it)
             if (it.st == WX_BLOCKED && it.blocked_on == node) { it.st = WX_AFTER; it.creator = made; }
@@ -673,7 +697,7 @@ template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t
             const uint32_t who = (uint32_t)__builtin_ctzll(asking);
             const uint32_t node = c.xl->bcast(want, who);
             const int32_t at = (int32_t)c.xl->bcast((uint32_t)diag, who);
-            if (c.lane == who && ww_expand(c, node)) c.sh->expanded_at[node] = at;
+            if (ww_expand_wave(c, node, who)) c.sh->expanded_at[node] = at;
             c.xl->fence();
             if (ww_any_overflow(c)) return;
         }
@@ -912,8 +936,7 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
                     for (uint32_t j = n.path_head; j != W_NIL; j = c.pth(j).next) {
                         const WwPath e = c.pth(j);
                         if (P.merge.on) {
-                            uint32_t run_len = 0; const uint32_t inner = e.seq_off - g_seq_of(P.index, (uint32_t)e.node, run_len);
-                            WwOriginals it = ww_originals(P.merge, (uint32_t)e.node, inner);
+                            WwOriginals it = ww_originals(P.merge, (uint32_t)e.node, (uint32_t)e.inner);
                             for (uint32_t got = 0; got < e.len && !it.done(); it.step()) {
                                 const uint32_t gl = it.length(); got += gl;
                                 const bool skip = first && drop_first; first = false;
