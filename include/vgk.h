@@ -555,14 +555,17 @@ int  vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* index, const v
 double vgk_minimizer_last_ms(vgk_ctx* ctx);                              /* device time of the last vgk_minimizer_seeds call */
 /* find_seeds' choice of minimizers, applied by vgk_minimizer_seeds on the device (src/minimizer_mapper.cpp:4109-4440 with giraffe's
  * short-read parameters): a minimizer's score is 1 + ln(hard_hit_cap) - ln(hits) (1 beyond the hard cap, 0 without hits, :3927-3937);
- * a read's minimizers are taken in order of descending score, runs of one key together [ties: by key, then read position — the
- * reference shuffles them with a generator seeded from the read, :4089: PARITY-UNPINNED]; a minimizer gives seeds iff it has hits, its
+ * a read's minimizers are taken in order of descending score, runs of one key together, equal scores by key, and the runs that share the
+ * BEST score shuffled as the reference shuffles them (sort_shuffling_ties, src/utility.hpp:771-799: Knuth's shuffle over std::minstd_rand
+ * seeded from the read's sequence, src/utility.cpp:911-927 — the single-end rule, :620-627; the paired path's one generator over both mates,
+ * :1529-1541, is not restated); a minimizer gives seeds iff it has hits, its
  * RUN (all occurrences of its key in the read) has at most hard_hit_cap hits, and it has at most hit_cap hits or the scores selected so
  * far plus its own stay within minimizer_score_fraction of the read's total or an earlier occurrence of its key was taken; the first
  * minimizer that fails the last test closes it for everything that follows (:4358-4378).  The filters left out are off in those
  * parameters (window downsampling, exclude-overlapping) or cannot fire below 500 taken minimizers (max-unique-min); the host shim's
- * select_minimizers (vg_amd/host/seed_policy.cpp) has them all.  A read with more than 64 minimizers is seeded as without a policy and
- * flagged VGK_MINIMIZERS_POLICY_SKIPPED in minimizers[].  With a policy set the call's `hit_cap` argument is ignored.
+ * select_minimizers (vg_amd/host/seed_policy.cpp) has them all.  A read with more than 64 minimizers — or one with a base other than A, C,
+ * G, T whose shuffle could change the choice: the engine keeps reads masked and cannot seed the generator from its bytes — is seeded as
+ * without a policy and flagged VGK_MINIMIZERS_POLICY_SKIPPED in minimizers[].  With a policy set the call's `hit_cap` argument is ignored.
  * policy = NULL: none (every minimizer with at most `hit_cap` hits gives seeds).  VGK_EINVAL: hard_hit_cap 0 or above 65 535, a fraction
  * outside [0, 1]. */
 typedef struct vgk_seed_policy { uint32_t hit_cap, hard_hit_cap; double minimizer_score_fraction; } vgk_seed_policy;

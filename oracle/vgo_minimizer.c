@@ -126,7 +126,8 @@ static void key_range(const vgk_minimizer_index* ix, uint64_t key, size_t* first
     *first = lo; *end = e;
 }
 /* ---- find_seeds' choice of minimizers (include/vgk.h: vgk_seed_policy), restating src/minimizer_mapper.cpp:3927-3937 (scores), :4074-4107 (the
- * order: runs of one key together, by descending score; ties by key, then read position — the reference's shuffle of ties cannot be restated),
+ * order: runs of one key together, by descending score, equal scores by key — and the runs tied with the BEST score shuffled as
+ * sort_shuffling_ties does it, src/utility.hpp:720-727, :771-799, with the generator LazyRNG seeds from the read, src/utility.cpp:911-927),
  * :4395-4440 (the run logic) and the filters any-hits :4270, hard-hit-cap :4277 and hit-cap || score-fraction :4358-4378.  At most 64 minimizers. */
 typedef struct { const vgk_minimizer_index* ix; uint64_t key[64]; uint32_t hits[64]; uint32_t n; } Listing;
 static void list_emit(void* c, uint32_t p, uint64_t key, uint64_t hash, int reverse) {
@@ -134,8 +135,14 @@ static void list_emit(void* c, uint32_t p, uint64_t key, uint64_t hash, int reve
     if (l->n < 64) { size_t a, b; key_range(l->ix, key, &a, &b); l->key[l->n] = key; l->hits[l->n] = (uint32_t)(b - a); }
     ++l->n;
 }
-static uint64_t choose(const vgk_seed_policy* P, const uint64_t* key, const uint32_t* hits, uint32_t n) {
+/* the generator: std::minstd_rand (Lehmer, multiplier 48271 modulo 2^31 - 1; a seed that is 0 modulo that starts it at 1) */
+static uint32_t lehmer_start(uint32_t seed) { const uint32_t x = seed % 2147483647u; return x ? x : 1u; }
+static uint32_t lehmer_next(uint32_t* x) { *x = (uint32_t)(((uint64_t)*x * 48271ull) % 2147483647ull); return *x; }
+/* seq / L: the read as the caller gave it.  *unsure: the read holds a base other than A, C, G, T and the order inside its top tie can change the choice —
+ * the engine, which keeps reads masked, does not choose for such a read (VGK_MINIMIZERS_POLICY_SKIPPED), and neither does this checker */
+static uint64_t choose(const vgk_seed_policy* P, const uint64_t* key, const uint32_t* hits, uint32_t n, const char* seq, uint32_t L, int* unsure) {
     double score[64]; uint32_t order[64];
+    *unsure = 0;
     const double base_score = 1.0 + log((double)P->hard_hit_cap);
     for (uint32_t i = 0; i < n; ++i) score[i] = !hits[i] ? 0.0 : (hits[i] <= P->hard_hit_cap ? base_score - log((double)hits[i]) : 1.0);
     for (uint32_t i = 0; i < n; ++i) order[i] = i;
@@ -145,6 +152,21 @@ static uint64_t choose(const vgk_seed_policy* P, const uint64_t* key, const uint
         order[j] = x;
     }
     const int use_score = P->hit_cap != 0 || P->minimizer_score_fraction != 1.0;
+    {   /* the ties at the top: the run boundaries of the leading stretch of equal score, a Knuth shuffle of those runs, the runs laid out again */
+        uint32_t first[65], n_runs = 0, r = 0;
+        while (r < n && score[order[r]] == score[order[0]]) { first[n_runs++] = r; const uint64_t k = key[order[r]]; while (r < n && key[order[r]] == k) ++r; }
+        first[n_runs] = r;
+        if (n_runs >= 2) {
+            uint32_t seed = 0; int other = 0;
+            for (uint32_t i = 0; i < L; ++i) { const char c = seq[i]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T') other = 1; seed = seed * 13u + (uint32_t)(unsigned char)c; }
+            if (other && use_score && hits[order[0]] > P->hit_cap) { *unsure = 1; return 0; }
+            uint32_t which[64], x = lehmer_start(seed), laid[64], at = 0;
+            for (uint32_t i = 0; i < n_runs; ++i) which[i] = i;
+            for (uint32_t i = 1; i < n_runs; ++i) { const uint32_t j = lehmer_next(&x) % (i + 1u), t2 = which[j]; which[j] = which[i]; which[i] = t2; }
+            for (uint32_t i = 0; i < n_runs; ++i) for (uint32_t e = first[which[i]]; e < first[which[i] + 1]; ++e) laid[at++] = order[e];
+            for (uint32_t e = 0; e < at; ++e) order[e] = laid[e];
+        }
+    }
     volatile double base_target = 0.0, target = 0.0, selected = 0.0, t;
     if (use_score) { for (uint32_t r = 0; r < n; ++r) base_target = base_target + score[order[r]]; t = base_target * P->minimizer_score_fraction; target = t + 0.000001; }
     uint64_t mask = 0; uint32_t at = 0;
@@ -217,7 +239,11 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
             Listing l; l.ix = ix; l.n = 0;
             minimizers(reads + read_off[i], (uint32_t)(read_off[i + 1] - read_off[i]), ix->k, ix->w, list_emit, &l);
             if (l.n > 64) { skipped = 1; q.hit_cap = ix->policy.hard_hit_cap; }
-            else { q.chosen = choose(&ix->policy, l.key, l.hits, l.n); q.hit_cap = 0xffffffffu; }
+            else {
+                int unsure = 0;
+                q.chosen = choose(&ix->policy, l.key, l.hits, l.n, reads + read_off[i], (uint32_t)(read_off[i + 1] - read_off[i]), &unsure); q.hit_cap = 0xffffffffu;
+                if (unsure) { skipped = 1; q.chosen = ~0ull; q.hit_cap = ix->policy.hard_hit_cap; }
+            }
         }
         minimizers(reads + read_off[i], (uint32_t)(read_off[i + 1] - read_off[i]), ix->k, ix->w, query_emit, &q);
         if (mins) mins[i] = q.n_min | (q.truncated ? VGK_MINIMIZERS_TRUNCATED : 0u) | (skipped ? VGK_MINIMIZERS_POLICY_SKIPPED : 0u);

@@ -87,10 +87,36 @@ def scores_of(ms, hard_hit_cap):
     return [0.0 if not hits else (base - math.log(hits) if hits <= hard_hit_cap else 1.0) for (_, _, _, hits) in ms]
 
 
-def find_seeds_restated(ms, read_len, P):
+def shuffle_top_ties(order, ms, score, sequence):
+    """sort_shuffling_ties over the runs of one key (src/utility.hpp:771-799, :720-727; src/utility.cpp:911-927): the runs whose score equals the best one's,
+    Knuth-shuffled with std::minstd_rand (x <- 48271 x mod 2^31 - 1) seeded by seed * 13 + byte over the read's bytes"""
+    if not order:
+        return order
+    runs = []; at = 0
+    while at < len(order) and score[order[at]] == score[order[0]]:
+        end = at + 1
+        while end < len(order) and ms[order[end]][0] == ms[order[at]][0]:
+            end += 1
+        runs.append(order[at:end]); at = end
+    if len(runs) < 2:
+        return order
+    seed = 0
+    for byte in sequence.encode():
+        seed = (seed * 13 + byte) & 0xffffffff
+    x = seed % 2147483647 or 1
+    for i in range(1, len(runs)):
+        x = x * 48271 % 2147483647
+        j = x % (i + 1)
+        runs[j], runs[i] = runs[i], runs[j]
+    return [i for run in runs for i in run] + order[at:]
+
+
+def find_seeds_restated(ms, read_len, P, sequence=None):
     """ms: (key, forward offset, length, hits) in read order -> the filter each minimizer failed (0: taken)"""
     n = len(ms); score = scores_of(ms, P["hard_hit_cap"])
-    order = sorted(range(n), key=lambda i: (-score[i], ms[i][0], i))                                 # (:4074-4107; ties by key, then read position — see seed_policy.hpp)
+    order = sorted(range(n), key=lambda i: (-score[i], ms[i][0], i))                                 # (:4074-4107; equal scores by key; inside a run the order cannot matter)
+    if sequence is not None:
+        order = shuffle_top_ties(order, ms, score, sequence)
     use_score = P["hit_cap"] != 0 or P["score_fraction"] != 1.0
     base_target = 0.0
     for i in order:
@@ -159,14 +185,20 @@ def find_seeds_restated(ms, read_len, P):
     return verdict, score
 
 
-def select(ms, read_len, P):
+def select(ms, read_len, P, sequence=None):
+    """the host shim's select_minimizers; sequence: the read (its bytes seed the shuffle of the runs tied at the top)"""
     h = util.host()
     h.vgh_select_minimizers.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+    h.vgh_select_minimizers_of_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     a = np.ascontiguousarray([x for m in ms for x in m], dtype=np.uint64) if ms else np.zeros(4, dtype=np.uint64)
     pol = np.array([P["hit_cap"], P["hard_hit_cap"], P["max_unique_min"], P["num_bp_per_min"], int(P["exclude_overlapping_min"]), P["coverage_flank"], P["window_count"],
                     P["max_window_length"]], dtype=np.uint64)
     v = np.zeros(max(len(ms), 1), dtype=np.uint8); sc = np.zeros(max(len(ms), 1), dtype=np.float64)
-    rc = h.vgh_select_minimizers(a.ctypes.data, len(ms), read_len, pol.ctypes.data, P["score_fraction"], v.ctypes.data, sc.ctypes.data)
+    if sequence is None:
+        rc = h.vgh_select_minimizers(a.ctypes.data, len(ms), read_len, pol.ctypes.data, P["score_fraction"], v.ctypes.data, sc.ctypes.data)
+    else:
+        assert len(sequence) == read_len
+        rc = h.vgh_select_minimizers_of_read(a.ctypes.data, len(ms), sequence.encode(), read_len, pol.ctypes.data, P["score_fraction"], v.ctypes.data, sc.ctypes.data, None)
     if rc != 0:
         raise RuntimeError("vgh_select_minimizers")
     return v[:len(ms)].tolist(), sc[:len(ms)].tolist()
@@ -216,6 +248,33 @@ def test_selection_equals_the_restatement_with_every_filter_on():
         assert got == want, (ms, read_len, P)
 
 
+def test_top_ties_are_shuffled_as_the_reference_shuffles_them():
+    """the runs that share the best score, shuffled by the read's own generator (sort_shuffling_ties): the host shim (std::minstd_rand itself) against
+    the restatement above (the Lehmer formula written out) — order and choice; and the shuffle changes the choice where the cut falls inside the tie"""
+    rng = np.random.default_rng(13)
+    h = util.host()
+    changed = shuffled = 0
+    for _ in range(400):
+        read_len = int(rng.integers(60, 300)); k = int(rng.integers(11, 31))
+        seq = "".join("ACGTN"[int(x)] for x in rng.choice(5, read_len, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+        P = dict(DEFAULTS, hit_cap=int(rng.choice([0, 0, 1, 10])), hard_hit_cap=int(rng.choice([20, 500])), score_fraction=float(rng.choice([0.3, 0.6, 0.9])))
+        ms = random_minimizers(rng, read_len, k, int(rng.integers(2, 25)))
+        got, _ = select(ms, read_len, P, seq); want, score = find_seeds_restated(ms, read_len, P, seq)
+        assert got == want, (ms, seq, P)
+        # the order itself
+        n = len(ms)
+        if n:
+            a = np.ascontiguousarray([x for m in ms for x in m], dtype=np.uint64)
+            pol = np.array([P["hit_cap"], P["hard_hit_cap"], P["max_unique_min"], P["num_bp_per_min"], 0, P["coverage_flank"], 0, P["max_window_length"]], dtype=np.uint64)
+            v = np.zeros(n, dtype=np.uint8); order = np.zeros(n, dtype=np.uint64)
+            assert h.vgh_select_minimizers_of_read(a.ctypes.data, n, seq.encode(), read_len, pol.ctypes.data, P["score_fraction"], v.ctypes.data, None, order.ctypes.data) == 0
+            plain = sorted(range(n), key=lambda i: (-score[i], ms[i][0], i))
+            assert order.tolist() == shuffle_top_ties(plain, ms, score, seq)
+            shuffled += order.tolist() != plain
+        changed += got != select(ms, read_len, P)[0]
+    assert shuffled > 40 and changed >= 5, (shuffled, changed)
+
+
 def test_what_the_filters_mean():
     # without hits: never a seed; beyond the hard cap (summed over a key's occurrences): never; under the soft cap: always
     P = dict(DEFAULTS)
@@ -243,6 +302,9 @@ def policy_seeds(lib, seed, k, w, n_reads, L, hit_cap, hard, frac):
     rng = np.random.default_rng(seed)
     reads, _ = tm.sample_reads(rng, wl.nodes, wl.threads, n_reads, L)
     reads += ["", "ACGT" * 3, reads[0] * 6]                                  # no minimizers; too short; more than 64 minimizers
+    for i in range(0, len(reads) - 3, 7):                                    # every seventh read with a base that is none of A, C, G, T
+        if len(reads[i]) > 20:
+            at = int(rng.integers(0, len(reads[i]))); reads[i] = reads[i][:at] + "N" + reads[i][at + 1:]
     index = tm.build_index(wl.nodes, wl.threads, k, w)
     P = dict(DEFAULTS, hit_cap=hit_cap, hard_hit_cap=hard, score_fraction=frac)
     expected = []; skipped = []; dropped = 0
@@ -250,8 +312,15 @@ def policy_seeds(lib, seed, k, w, n_reads, L, hit_cap, hard, frac):
         ms = tm.minimizers(r, k, w)
         if len(ms) > 64:
             expected.append(tm.seeds_of(r, index, wl.nodes, k, w, hard)); skipped.append(True); continue
+        listed = [(key, p, k, len(index.get(key, []))) for p, key, rev in ms]
+        # a read with a masked base whose top tie can change the choice is not chosen for by the engine (it cannot seed the reference's generator)
+        if ms and any(c not in "ACGT" for c in r):
+            sc = scores_of(listed, hard); top = max(sc); tied = set(m[0] for m, x in zip(listed, sc) if x == top)
+            top_hits = max(m[3] for m, x in zip(listed, sc) if x == top)
+            if len(tied) >= 2 and (hit_cap != 0 or frac != 1.0) and top_hits > hit_cap:
+                expected.append(tm.seeds_of(r, index, wl.nodes, k, w, hard)); skipped.append(True); continue
         skipped.append(False)
-        v, _ = select([(key, p, k, len(index.get(key, []))) for p, key, rev in ms], len(r), P) if ms else ([], [])
+        v, _ = select(listed, len(r), P, r) if ms else ([], [])
         dropped += sum(1 for x, (p, key, rev) in zip(v, ms) if x and index.get(key))
         out = []
         for (p, key, rev), verdict in zip(ms, v):
@@ -289,6 +358,7 @@ def test_the_choice_applied_with_the_seeding(lib_name):
     assert policy_seeds(lib, 4, 9, 5, 40, 150, 2, 500, 0.9) >= 0
     policy_seeds(lib, 5, 15, 6, 30, 120, 10, 500, 1.0)
     policy_seeds(lib, 6, 8, 4, 30, 100, 0, 4, 1.0)                             # no hit cap and the whole score: only the hard cap over the run is left
+    assert policy_seeds(lib, 8, 8, 4, 80, 100, 0, 6, 0.6) > 20                 # no hit cap, a score fraction: the cut falls inside the top tie — the shuffle decides
 
 
 def test_policy_arguments():
@@ -307,3 +377,4 @@ def test_the_choice_applied_with_the_seeding_on_hip():
     policy_seeds(util.ENGINE_LIB, 4, 9, 5, 300, 150, 2, 500, 0.9)
     policy_seeds(util.ENGINE_LIB, 5, 15, 6, 200, 120, 10, 500, 1.0)
     policy_seeds(util.ENGINE_LIB, 7, 29, 11, 300, 150, 10, 500, 0.9)
+    assert policy_seeds(util.ENGINE_LIB, 8, 8, 4, 600, 100, 0, 6, 0.6) > 100   # the cut inside the top tie: the shuffle decides

@@ -532,6 +532,7 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
     __shared__ double psc_all[4][MZ_POLICY_MAX];
     __shared__ uint32_t phit_all[4][MZ_POLICY_MAX], prun_all[4][MZ_POLICY_MAX];
     __shared__ uint8_t pord_all[4][MZ_POLICY_MAX];
+    __shared__ uint8_t ptie_all[4][3 * (MZ_POLICY_MAX + 1)];                  // the top tie's runs, their permutation and the new order (mz_shuffle_top_ties)
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t i = P.lo + blockIdx.x * 4u + wv;
     if (i >= P.hi) return;
@@ -562,6 +563,19 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
                 for (uint32_t j = 0; j < np; ++j) rank += mz_better(psc[j], pkey[j], j, my_sc, my_key, lane) ? 1u : 0u;
                 if (lane < np) pord[rank] = (uint8_t)lane;
                 MZ_WAVE_SYNC();
+                // the runs tied at the top, shuffled as the reference shuffles them (minimizer_device.hpp): one lane, a few dozen steps at most, rarely
+                { uint32_t tie_state = 0;                                    // 1: the read has a masked base and its top tie matters — not chosen for
+                  if (lane == 0) {
+                      uint32_t elements = 0; const uint32_t runs = mz_top_ties(pord, pkey, psc, np, &elements);
+                      if (runs >= 2u) {
+                          bool masked = false; const uint32_t seed = mz_shuffle_seed(rd, L, masked);
+                          if (masked && mz_tie_matters(Q, runs, phit[pord[0]])) tie_state = 1u;
+                          else { uint8_t* t = ptie_all[wv]; mz_shuffle_top_ties(pord, pkey, elements, runs, seed, t, t + (MZ_POLICY_MAX + 1), t + 2 * (MZ_POLICY_MAX + 1)); }
+                      }
+                  }
+                  tie_state = __shfl(tie_state, 0, 64);
+                  MZ_WAVE_SYNC();
+                  if (tie_state) skipped = true; }
                 // the filters, in that order: every lane the same few dozen steps (the sums must be made in this order)
                 const bool use_score = Q.hit_cap != 0 || Q.fraction != 1.0;
                 double target = 0.0, selected = 0.0;
@@ -578,7 +592,7 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
                     }
                     if (pass) { mask |= 1ull << x; taking = true; }
                 }
-                chosen = mask;
+                chosen = skipped ? ~0ull : mask;                             // (a read that is not chosen for is seeded as without a policy)
             }
             n_min = 0;
         }

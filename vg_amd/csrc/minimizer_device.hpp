@@ -138,12 +138,61 @@ VGK_HD double mz_score(const MzPolicy& Q, uint32_t hits) { return !hits ? 0.0 : 
 VGK_HD bool mz_better(double sa, uint64_t ka, uint32_t ia, double sb, uint64_t kb, uint32_t ib) {      // a before b in the order the filters run in
     return sa > sb || (sa == sb && (ka < kb || (ka == kb && ia < ib)));
 }
+// ---- the ties at the top (sort_minimizers_by_score, :4074-4107 -> sort_shuffling_ties, src/utility.hpp:771-799) ----
+// The runs are stable-sorted by descending score — which leaves them in the order above — and then the runs whose score EQUALS THE BEST ONE'S are
+// shuffled: Knuth's shuffle as deterministic_shuffle writes it (:720-727: for i = 1 .. width - 1: swap(x[rng() % (i + 1)], x[i])) over a
+// std::minstd_rand (x <- 48271 x mod (2^31 - 1); first state = seed mod (2^31 - 1), or 1 when that is 0) that LazyRNG seeds from the read's
+// sequence: seed = seed * 13 + byte over its bytes, in 32 bits (src/utility.cpp:911-927; single-end: the read's own sequence, a fresh generator per
+// read, src/minimizer_mapper.cpp:620-627).  Ties further down keep the order above.  [The PAIRED path seeds ONE generator from both mates' sequences
+// and carries its state from the first mate's sort to the second's (:1529-1541): not restated — a pair's reads are shuffled as single reads here.]
+// The engine keeps reads masked (anything but ACGT became 'X'): a read with such a base whose shuffle could change the choice is not chosen for
+// here but flagged VGK_MINIMIZERS_POLICY_SKIPPED, like a read with more than 64 minimizers — the host shim (seed_policy.cpp) has its real bytes.
+VGK_HD uint32_t mz_shuffle_seed(const char* seq, uint32_t L, bool& masked) {
+    uint32_t s = 0; masked = false;
+    for (uint32_t i = 0; i < L; ++i) { const char c = seq[i]; masked = masked || !(c == 'A' || c == 'C' || c == 'G' || c == 'T'); s = s * 13u + (uint32_t)(uint8_t)c; }
+    return s;
+}
+// the leading runs of `order` whose score equals the first one's -> their number; *elements = the minimizers in them
+template <class IDX, class KEY> VGK_HD uint32_t mz_top_ties(const IDX* order, const KEY* key, const double* score, uint32_t n, uint32_t* elements) {
+    uint32_t runs = 0, r = 0;
+    if (n) { const double s0 = score[order[0]];
+             while (r < n && score[order[r]] == s0) { ++runs; const KEY k = key[order[r]]; while (r < n && key[order[r]] == k) ++r; } }
+    *elements = r;
+    return runs;
+}
+// shuffles those runs in place; start / perm / tmp: room for MZ_POLICY_MAX + 1 entries each (LDS in the kernel, the stack elsewhere)
+template <class IDX, class KEY> VGK_HD void mz_shuffle_top_ties(IDX* order, const KEY* key, uint32_t elements, uint32_t runs, uint32_t seed, uint8_t* start, uint8_t* perm, IDX* tmp) {
+    uint32_t r = 0, q = 0;
+    while (r < elements) { start[q] = (uint8_t)r; perm[q] = (uint8_t)q; ++q; const KEY k = key[order[r]]; while (r < elements && key[order[r]] == k) ++r; }
+    start[q] = (uint8_t)elements;
+    uint32_t x = seed % 2147483647u; if (!x) x = 1u;
+    for (uint32_t i = 1; i < runs; ++i) {
+        x = (uint32_t)(((uint64_t)x * 48271ull) % 2147483647ull);
+        const uint32_t j = x % (i + 1u);
+        const uint8_t t = perm[j]; perm[j] = perm[i]; perm[i] = t;
+    }
+    uint32_t at = 0;
+    for (uint32_t i = 0; i < runs; ++i) for (uint32_t e = start[perm[i]]; e < start[perm[i] + 1u]; ++e) tmp[at++] = order[e];
+    for (uint32_t e = 0; e < elements; ++e) order[e] = tmp[e];
+}
+// whether the order inside the top tie can change the choice: only when its runs are held against the score fraction (more hits than hit_cap)
+VGK_HD bool mz_tie_matters(const MzPolicy& Q, uint32_t runs, uint32_t top_hits) { return runs >= 2u && (Q.hit_cap != 0 || Q.fraction != 1.0) && top_hits > Q.hit_cap; }
+
 // n <= MZ_POLICY_MAX minimizers of a read in read order (key, hits) -> bit i set: minimizer i gives seeds.  The serial form (one lane; the
-// emulator, the checker of the wave-parallel form in backend_hip.hip's minimizer_kernel).
-VGK_HD uint64_t mz_policy_select(const MzPolicy& Q, const uint64_t* key, const uint32_t* hits, uint32_t n) {
+// emulator, the checker of the wave-parallel form in backend_hip.hip's minimizer_kernel).  seq / L: the read as the engine holds it (masked);
+// *unsure: the read has a masked base and its top tie matters — not chosen for (the result is to be ignored).
+VGK_HD uint64_t mz_policy_select(const MzPolicy& Q, const uint64_t* key, const uint32_t* hits, uint32_t n, const char* seq, uint32_t L, bool* unsure) {
     uint32_t order[MZ_POLICY_MAX]; double score[MZ_POLICY_MAX];
     for (uint32_t i = 0; i < n; ++i) score[i] = mz_score(Q, hits[i]);
     for (uint32_t i = 0; i < n; ++i) { uint32_t rank = 0; for (uint32_t j = 0; j < n; ++j) rank += mz_better(score[j], key[j], j, score[i], key[i], i) ? 1u : 0u; order[rank] = i; }
+    *unsure = false;
+    { uint32_t elements = 0; const uint32_t runs = mz_top_ties(order, key, score, n, &elements);
+      if (runs >= 2u) {
+          bool masked = false; const uint32_t seed = mz_shuffle_seed(seq, L, masked);
+          if (masked && mz_tie_matters(Q, runs, hits[order[0]])) { *unsure = true; return 0; }
+          uint8_t start[MZ_POLICY_MAX + 1], perm[MZ_POLICY_MAX + 1]; uint32_t tmp[MZ_POLICY_MAX + 1];
+          mz_shuffle_top_ties(order, key, elements, runs, seed, start, perm, tmp);
+      } }
     const bool use_score = Q.hit_cap != 0 || Q.fraction != 1.0;
     double target = 0.0, selected = 0.0;
     if (use_score) { double base = 0.0; for (uint32_t r = 0; r < n; ++r) base = mz_add(base, score[order[r]]); target = mz_add(mz_mul(base, Q.fraction), 0.000001); }
@@ -193,7 +242,8 @@ VGK_HD void minimizer_one(const MinimizerParams& P, uint32_t i) {
             if (np < MZ_POLICY_MAX) { pkey[np] = m.key; phits[np] = found ? count : 0u; }
             ++np;
         });
-        if (np > MZ_POLICY_MAX) skipped = true; else chosen = mz_policy_select(P.policy, pkey, phits, np);
+        if (np > MZ_POLICY_MAX) skipped = true;
+        else { bool unsure = false; chosen = mz_policy_select(P.policy, pkey, phits, np, P.reads + a, L, &unsure); if (unsure) { skipped = true; chosen = ~0ull; } }
     }
     const uint32_t cap = P.policy.on && !skipped ? 0xffffffffu : P.hit_cap;      // (the run's hits were held against the hard cap by the choice)
     mz_minimizers(P.reads + a, L, k, P.index.w, [&](uint32_t p, const MzKmer& m) {

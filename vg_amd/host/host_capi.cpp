@@ -809,7 +809,20 @@ int vgh_sample_minimal(uint64_t count, uint64_t element_length, uint64_t window_
 // MinimizerMapper::find_seeds' selection: minimizers in read order, 4 numbers each {key, forward offset, length, hits}; policy = {hit_cap,
 // hard_hit_cap, max_unique_min, num_bp_per_min, exclude_overlapping_min, minimizer_coverage_flank, downsampling_window_count,
 // downsampling_max_window_length}; verdict_out[i] = SeedFilter (0 = its hits become seeds); scores_out (nullable) = find_minimizers' scores
+static int select_minimizers_impl(const uint64_t* minimizers, int n, uint64_t read_length, const uint64_t* policy, double score_fraction, uint8_t* verdict_out, double* scores_out,
+                                  const std::string* sequence, uint64_t* order_out);
 int vgh_select_minimizers(const uint64_t* minimizers, int n, uint64_t read_length, const uint64_t* policy, double score_fraction, uint8_t* verdict_out, double* scores_out) {
+    return select_minimizers_impl(minimizers, n, read_length, policy, score_fraction, verdict_out, scores_out, nullptr, nullptr);
+}
+// the same with the read's sequence: the runs tied at the best score are shuffled as the reference shuffles them (sort_shuffling_ties); order_out (nullable, n):
+// the minimizers' indices in the order the filters took them
+int vgh_select_minimizers_of_read(const uint64_t* minimizers, int n, const char* sequence, uint64_t read_length, const uint64_t* policy, double score_fraction,
+                                  uint8_t* verdict_out, double* scores_out, uint64_t* order_out) {
+    const std::string seq(sequence, (size_t)read_length);
+    return select_minimizers_impl(minimizers, n, read_length, policy, score_fraction, verdict_out, scores_out, &seq, order_out);
+}
+static int select_minimizers_impl(const uint64_t* minimizers, int n, uint64_t read_length, const uint64_t* policy, double score_fraction, uint8_t* verdict_out, double* scores_out,
+                                  const std::string* sequence, uint64_t* order_out) {
     try {
         std::vector<PolicyMinimizer> ms((size_t)n);
         for (int i = 0; i < n; ++i) { const uint64_t* q = minimizers + 4 * (size_t)i; ms[(size_t)i].key = q[0]; ms[(size_t)i].forward_offset = (size_t)q[1]; ms[(size_t)i].length = (size_t)q[2]; ms[(size_t)i].hits = (size_t)q[3]; }
@@ -817,8 +830,9 @@ int vgh_select_minimizers(const uint64_t* minimizers, int n, uint64_t read_lengt
         P.exclude_overlapping_min = policy[4] != 0; P.minimizer_coverage_flank = (size_t)policy[5]; P.minimizer_downsampling_window_count = (size_t)policy[6];
         P.minimizer_downsampling_max_window_length = (size_t)policy[7]; P.minimizer_score_fraction = score_fraction;
         score_minimizers(ms, P.hard_hit_cap);
-        const std::vector<uint8_t> v = select_minimizers(ms, (size_t)read_length, P);
+        const std::vector<uint8_t> v = select_minimizers(ms, (size_t)read_length, P, sequence);
         for (int i = 0; i < n; ++i) { verdict_out[i] = v[(size_t)i]; if (scores_out) scores_out[i] = ms[(size_t)i].score; }
+        if (order_out) { const std::vector<size_t> order = minimizers_by_score(ms, sequence); for (int i = 0; i < n; ++i) order_out[i] = order[(size_t)i]; }
         return 0;
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }

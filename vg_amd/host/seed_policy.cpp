@@ -5,6 +5,8 @@
 #include <deque>
 #include <map>
 #include <stdexcept>
+#include <random>
+#include <string>
 #include <unordered_set>
 
 namespace vgamd {
@@ -55,7 +57,7 @@ void score_minimizers(std::vector<PolicyMinimizer>& ms, size_t hard_hit_cap) {
     for (PolicyMinimizer& m : ms) m.score = !m.hits ? 0.0 : (m.hits <= hard_hit_cap ? base - std::log((double)m.hits) : 1.0);
 }
 
-std::vector<size_t> minimizers_by_score(const std::vector<PolicyMinimizer>& ms) {
+std::vector<size_t> minimizers_by_score(const std::vector<PolicyMinimizer>& ms, const std::string* sequence) {
     std::vector<size_t> order(ms.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = i;
     // a key's occurrences have one hit count and so one score: sorting by (score descending, key, read position) keeps every run together
@@ -63,13 +65,30 @@ std::vector<size_t> minimizers_by_score(const std::vector<PolicyMinimizer>& ms) 
         if (ms[a].score != ms[b].score) return ms[a].score > ms[b].score;
         return ms[a].key < ms[b].key;
     });
+    if (!sequence || order.empty()) return order;
+    // sort_shuffling_ties over the runs (src/utility.hpp:771-799): the runs that share the best score are shuffled — deterministic_shuffle
+    // (:720-727) with the generator LazyRNG makes from the read's sequence (src/utility.cpp:911-927), which is std::minstd_rand itself
+    std::vector<std::pair<size_t, size_t>> runs;                        // [first, end) in `order`, the leading stretch of equal score only
+    for (size_t at = 0; at < order.size() && ms[order[at]].score == ms[order[0]].score;) {
+        size_t end = at + 1;
+        while (end < order.size() && ms[order[end]].key == ms[order[at]].key) ++end;
+        runs.emplace_back(at, end); at = end;
+    }
+    if (runs.size() < 2) return order;
+    uint32_t seed = 0;
+    for (unsigned char byte : *sequence) seed = seed * 13u + byte;
+    std::minstd_rand generator(seed);
+    for (size_t i = 1; i < runs.size(); ++i) std::swap(runs[generator() % (i + 1)], runs[i]);
+    std::vector<size_t> laid; laid.reserve(order.size());
+    for (const auto& run : runs) laid.insert(laid.end(), order.begin() + (std::ptrdiff_t)run.first, order.begin() + (std::ptrdiff_t)run.second);
+    std::copy(laid.begin(), laid.end(), order.begin());
     return order;
 }
 
-std::vector<uint8_t> select_minimizers(const std::vector<PolicyMinimizer>& ms, size_t read_length, const SeedPolicy& P) {
+std::vector<uint8_t> select_minimizers(const std::vector<PolicyMinimizer>& ms, size_t read_length, const SeedPolicy& P, const std::string* sequence) {
     const size_t n = ms.size();
     std::vector<uint8_t> verdict(n, SEED_TAKEN);
-    const std::vector<size_t> order = minimizers_by_score(ms);
+    const std::vector<size_t> order = minimizers_by_score(ms, sequence);
     const bool score_filter = P.hit_cap != 0 || P.minimizer_score_fraction != 1.0;
     double base_target = 0.0, target = 0.0, selected = 0.0;
     if (score_filter) { for (size_t i : order) base_target += ms[i].score; target = base_target * P.minimizer_score_fraction + 0.000001; }      // (summed in score order, as the reference does: :4120-4125)

@@ -6,14 +6,17 @@
 //
 // Pinned: sample_minimal, by the reference's six unit tests (src/unittest/sample_minimal.cpp:14-176; tests/golden/ref_sample_minimal.json).
 // [PARITY-UNPINNED] the filter chain — the reference holds no test for find_seeds; tests/test_seed_policy.py holds it to a direct
-// restatement of the cited lines — and one rule that cannot be restated: among runs of EQUAL score the reference shuffles with a generator
-// seeded from the read (sort_shuffling_ties, :4089); here equal scores are ordered by key (Minimizer::operator<,
-// src/minimizer_mapper.hpp:577) and, inside a run of one key, by read position.  The selected set differs from the reference's only where
-// the score-fraction cut falls inside such a tie.
+// restatement of the cited lines.  Equal scores are ordered by key (Minimizer::operator<, src/minimizer_mapper.hpp:577); the runs that share
+// the BEST score are shuffled as sort_shuffling_ties shuffles them (src/utility.hpp:771-799, :720-727: Knuth's shuffle over std::minstd_rand,
+// which LazyRNG seeds from the read's sequence, src/utility.cpp:911-927) when the read's sequence is given — the single-end rule
+// (src/minimizer_mapper.cpp:620-627); the paired path seeds one generator from both mates and carries it from the first mate's sort to the
+// second's (:1529-1541): a caller that maps pairs passes the sequence of mate 1 + mate 2 for mate 1 and orders mate 2 itself.  Inside a run
+// of one key the order (std::sort's, unspecified) cannot matter: its minimizers share hits and score, and pass or fail together.
 #pragma once
 #include <cstddef>
 #include <cstdint>
 #include <functional>
+#include <string>
 #include <vector>
 
 namespace vgamd {
@@ -44,9 +47,11 @@ enum SeedFilter : uint8_t { SEED_TAKEN = 0, SEED_DOWNSAMPLED = 1, SEED_NO_HITS =
 // find_minimizers' score per minimizer (:3927-3937): 1 + ln(hard_hit_cap) - ln(hits), 1 beyond the hard cap, 0 without hits
 void score_minimizers(std::vector<PolicyMinimizer>& minimizers_in_read_order, size_t hard_hit_cap);
 // sort_minimizers_by_score (:4074-4107): runs of one key together, the runs by descending score (ties: header) -> indices in that order
-std::vector<size_t> minimizers_by_score(const std::vector<PolicyMinimizer>& minimizers_in_read_order);
+std::vector<size_t> minimizers_by_score(const std::vector<PolicyMinimizer>& minimizers_in_read_order, const std::string* sequence = nullptr);
 // find_seeds' selection (:4109-4440): per minimizer (read order) the filter it failed, or SEED_TAKEN — the hits of the taken ones are the seeds.
 // Throws std::runtime_error where the reference crashes (a minimizer longer than the downsampling window).
-std::vector<uint8_t> select_minimizers(const std::vector<PolicyMinimizer>& minimizers_in_read_order, size_t read_length, const SeedPolicy& policy);
+// sequence (nullable): the read — seeds the shuffle of the runs tied at the top; without it they stay in key order
+std::vector<uint8_t> select_minimizers(const std::vector<PolicyMinimizer>& minimizers_in_read_order, size_t read_length, const SeedPolicy& policy,
+                                       const std::string* sequence = nullptr);
 
 }  // namespace vgamd
