@@ -53,7 +53,7 @@ PY
       case $w in linear) R=400000;; config2) R=1000000; export VGAMD_CONFIG2_ONE_CONTEXT=1;; gapless) R=1000000;; banded) R=100000;; wfa) R=500000;; paired) R=500000;; longread) R=4000;; xband) R=200000;; *) R=0;; esac
       B="python $GRAFT_REPO_ROOT/bench.py --workload $w --reads $R --no-cpu --no-e2e --no-secondary --steps 2 --warmup 1"
       ( cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_$w -o s -- $B > $P/stats_$w.log 2>&1 )
-      for c in FETCH_SIZE WRITE_SIZE; do
+      for c in ${PMC_COUNTERS-FETCH_SIZE WRITE_SIZE}; do      # (PMC_COUNTERS="": the kernel statistics only)
         ( cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $P/${c}_$w -o p -- $B > $P/${c}_$w.log 2>&1 )
       done
       unset VGAMD_CONFIG2_ONE_CONTEXT
