@@ -108,6 +108,8 @@ struct WCtx {
     const char* seq; uint32_t L;
     int32_t to_node; uint32_t to_off; bool no_to;
     uint32_t n_nodes, n_path, n_points, max_points;
+    uint32_t slot_mask;               // the part of the slab's table this problem uses: four slots per point it may store (a problem the hybrid form gives up at 16 points
+                                      // keeps to 64 slots = four cache lines of its 16 KB table: a probe then hits a line the problem has touched before)
     uint32_t leaves;                  // trie nodes without children (WFANode::is_leaf: a dead end has none either)
     int32_t cand_score, cand_diag; uint32_t cand_seq, cand_off, cand_node;
     int32_t max_distance, min_distance;
@@ -133,7 +135,7 @@ VGK_HD uint32_t w_hash(uint32_t key) { return (((key - 1u) >> 5) * 2654435761u) 
 VGK_HD bool w_lookup(WCtx& c, uint32_t ancestors, int kind, int32_t score, int32_t diag, uint32_t& node, uint32_t& seq, uint32_t& off) {
     const uint32_t cell = (w_key(0, kind, score, diag) - 1u) >> 5;
     bool found = false; uint32_t best = 0;
-    for (uint32_t i = w_hash(w_key(0, kind, score, diag));; i = (i + 1) & (W_SLOTS - 1)) {
+    for (uint32_t i = w_hash(w_key(0, kind, score, diag)) & c.slot_mask;; i = (i + 1) & c.slot_mask) {
         const uint64_t s = c.S->slot[i];
         if (!s) break;
         const uint32_t key = (uint32_t)(s >> 32) - 1u, holder = key & 31u;
@@ -147,7 +149,7 @@ VGK_HD bool w_lookup(WCtx& c, uint32_t ancestors, int kind, int32_t score, int32
 VGK_HD void w_store(WCtx& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t seq, uint32_t off) {                     // WFANode::update (:1517-1530)
     const uint32_t key = w_key(node, kind, score, diag);
     const uint64_t v = ((uint64_t)key << 32) | ((uint64_t)(seq & 0xffffu) << 16) | (off & 0xffffu);
-    for (uint32_t i = w_hash(key);; i = (i + 1) & (W_SLOTS - 1)) {
+    for (uint32_t i = w_hash(key) & c.slot_mask;; i = (i + 1) & c.slot_mask) {
         const uint64_t s = c.S->slot[i];
         if (!s) {
             if (c.n_points >= c.max_points) { c.overflow = true; c.why = 1; return; }
@@ -517,6 +519,7 @@ VGK_HD void wfa_extend_one(const WfaParams& P, uint32_t i, WScratch& S, uint32_t
     c.max_points = c.no_to ? P.max_points_tail : P.max_points;
     const bool hands_over = P.handed_over && P.hand_over_points < c.max_points;
     if (hands_over) c.max_points = P.hand_over_points;
+    { uint32_t slots = 64; while (slots < (uint32_t)W_SLOTS && slots < 4u * c.max_points) slots <<= 1; c.slot_mask = slots - 1u; }
     c.cand_score = 0x7fffffff; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0;
     c.max_distance = 0; c.min_distance = 0;
     const int32_t top_score = pb.score_bound + P.gap_open + P.gap_extend + P.mismatch;               // the host keeps this below W_SCORES
