@@ -275,6 +275,58 @@ def test_top_ties_are_shuffled_as_the_reference_shuffles_them():
     assert shuffled > 40 and changed >= 5, (shuffled, changed)
 
 
+def test_a_pair_shares_one_generator():
+    """the paired path (src/minimizer_mapper.cpp:1529-1541): one generator seeded from mate 1 + mate 2, drawn from by the first mate's sort and then, where it
+    left off, by the second's — the host shim's ReadRng against the restatement with the generator's state carried by hand"""
+    rng = np.random.default_rng(14)
+    h = util.host()
+    h.vgh_select_minimizers_of_pair.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64,
+                                                ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    differs_from_single = carried = 0
+    for _ in range(300):
+        P = dict(DEFAULTS, hit_cap=int(rng.choice([0, 1, 10])), hard_hit_cap=int(rng.choice([20, 500])), score_fraction=float(rng.choice([0.3, 0.6, 0.9])))
+        pol = np.array([P["hit_cap"], P["hard_hit_cap"], P["max_unique_min"], P["num_bp_per_min"], 0, P["coverage_flank"], 0, P["max_window_length"]], dtype=np.uint64)
+        mates = []
+        for _m in range(2):
+            L = int(rng.integers(60, 200)); k = int(rng.integers(11, 31))
+            mates.append(("".join("ACGT"[int(x)] for x in rng.integers(0, 4, L)), random_minimizers(rng, L, k, int(rng.integers(2, 20)))))
+        (s1, m1), (s2, m2) = mates
+        if not m1 or not m2:
+            continue
+        a1 = np.ascontiguousarray([x for m in m1 for x in m], dtype=np.uint64); a2 = np.ascontiguousarray([x for m in m2 for x in m], dtype=np.uint64)
+        v1 = np.zeros(len(m1), np.uint8); v2 = np.zeros(len(m2), np.uint8); o1 = np.zeros(len(m1), np.uint64); o2 = np.zeros(len(m2), np.uint64)
+        assert h.vgh_select_minimizers_of_pair(a1.ctypes.data, len(m1), s1.encode(), len(s1), a2.ctypes.data, len(m2), s2.encode(), len(s2), pol.ctypes.data, P["score_fraction"],
+                                               v1.ctypes.data, v2.ctypes.data, o1.ctypes.data, o2.ctypes.data) == 0
+        # the restatement: one Lehmer state over both sorts
+        seed = 0
+        for byte in (s1 + s2).encode():
+            seed = (seed * 13 + byte) & 0xffffffff
+        state = [seed % 2147483647 or 1]
+
+        def draw():
+            state[0] = state[0] * 48271 % 2147483647
+            return state[0]
+        want = []
+        for ms in (m1, m2):
+            score = scores_of(ms, P["hard_hit_cap"]); order = sorted(range(len(ms)), key=lambda i: (-score[i], ms[i][0], i))
+            runs = []; at = 0
+            while at < len(order) and score[order[at]] == score[order[0]]:
+                end = at + 1
+                while end < len(order) and ms[order[end]][0] == ms[order[at]][0]:
+                    end += 1
+                runs.append(order[at:end]); at = end
+            if len(runs) >= 2:
+                for i in range(1, len(runs)):
+                    j = draw() % (i + 1); runs[j], runs[i] = runs[i], runs[j]
+            want.append([i for r in runs for i in r] + order[at:])
+        assert o1.tolist() == want[0] and o2.tolist() == want[1], (m1, m2, s1, s2)
+        # mate 2 ordered on its own (a fresh generator from its own sequence) is another order, as a rule, when mate 1 drew from the shared one
+        sc2 = scores_of(m2, P["hard_hit_cap"]); alone = shuffle_top_ties(sorted(range(len(m2)), key=lambda i: (-sc2[i], m2[i][0], i)), m2, sc2, s2)
+        differs_from_single += alone != want[1]
+        carried += state[0] != (seed % 2147483647 or 1)
+    assert carried > 50 and differs_from_single > 10
+
+
 def test_what_the_filters_mean():
     # without hits: never a seed; beyond the hard cap (summed over a key's occurrences): never; under the soft cap: always
     P = dict(DEFAULTS)

@@ -821,6 +821,28 @@ int vgh_select_minimizers_of_read(const uint64_t* minimizers, int n, const char*
     const std::string seq(sequence, (size_t)read_length);
     return select_minimizers_impl(minimizers, n, read_length, policy, score_fraction, verdict_out, scores_out, &seq, order_out);
 }
+// the paired path (src/minimizer_mapper.cpp:1529-1541): ONE generator seeded from mate 1 + mate 2 orders mate 1's minimizers, then mate 2's.
+// minimizers1 / minimizers2 as above; order1_out / order2_out (n1 / n2): the orders the filters took them in; verdict1_out / verdict2_out: SeedFilter per minimizer
+int vgh_select_minimizers_of_pair(const uint64_t* minimizers1, int n1, const char* sequence1, uint64_t length1, const uint64_t* minimizers2, int n2, const char* sequence2, uint64_t length2,
+                                  const uint64_t* policy, double score_fraction, uint8_t* verdict1_out, uint8_t* verdict2_out, uint64_t* order1_out, uint64_t* order2_out) {
+    try {
+        SeedPolicy P; P.hit_cap = (size_t)policy[0]; P.hard_hit_cap = (size_t)policy[1]; P.max_unique_min = (size_t)policy[2]; P.num_bp_per_min = (size_t)policy[3];
+        P.exclude_overlapping_min = policy[4] != 0; P.minimizer_coverage_flank = (size_t)policy[5]; P.minimizer_downsampling_window_count = (size_t)policy[6];
+        P.minimizer_downsampling_max_window_length = (size_t)policy[7]; P.minimizer_score_fraction = score_fraction;
+        ReadRng rng(std::string(sequence1, (size_t)length1) + std::string(sequence2, (size_t)length2));
+        for (int mate = 0; mate < 2; ++mate) {
+            const uint64_t* in = mate ? minimizers2 : minimizers1; const int n = mate ? n2 : n1;
+            std::vector<PolicyMinimizer> ms((size_t)n);
+            for (int i = 0; i < n; ++i) { const uint64_t* q = in + 4 * (size_t)i; ms[(size_t)i].key = q[0]; ms[(size_t)i].forward_offset = (size_t)q[1]; ms[(size_t)i].length = (size_t)q[2]; ms[(size_t)i].hits = (size_t)q[3]; }
+            score_minimizers(ms, P.hard_hit_cap);
+            // (the order is drawn once per mate — sort_minimizers_by_score is called once per mate — and the filters run over that order)
+            const std::vector<size_t> order = minimizers_by_score(ms, rng);
+            const std::vector<uint8_t> v = select_minimizers_in_order(ms, (size_t)(mate ? length2 : length1), P, order);
+            for (int i = 0; i < n; ++i) { (mate ? verdict2_out : verdict1_out)[i] = v[(size_t)i]; if (mate ? order2_out : order1_out) (mate ? order2_out : order1_out)[i] = order[(size_t)i]; }
+        }
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
 static int select_minimizers_impl(const uint64_t* minimizers, int n, uint64_t read_length, const uint64_t* policy, double score_fraction, uint8_t* verdict_out, double* scores_out,
                                   const std::string* sequence, uint64_t* order_out) {
     try {

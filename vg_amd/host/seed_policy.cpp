@@ -57,7 +57,39 @@ void score_minimizers(std::vector<PolicyMinimizer>& ms, size_t hard_hit_cap) {
     for (PolicyMinimizer& m : ms) m.score = !m.hits ? 0.0 : (m.hits <= hard_hit_cap ? base - std::log((double)m.hits) : 1.0);
 }
 
+uint32_t ReadRng::operator()() {
+    if (!started_) {                                                     // (std::minstd_rand's seeding: the seed modulo 2^31 - 1, 1 when that is 0)
+        uint32_t seed = 0;
+        for (unsigned char byte : seed_) seed = seed * 13u + byte;
+        state_ = seed % 2147483647u; if (!state_) state_ = 1u;
+        started_ = true;
+    }
+    state_ = (uint32_t)(((uint64_t)state_ * 48271ull) % 2147483647ull);
+    return state_;
+}
+
+static std::vector<size_t> by_score_drawing_from(const std::vector<PolicyMinimizer>& ms, const std::function<uint32_t()>* draw);
+
+std::vector<size_t> minimizers_by_score(const std::vector<PolicyMinimizer>& ms, ReadRng& rng) {
+    const std::function<uint32_t()> draw = [&]() { return rng(); };
+    return by_score_drawing_from(ms, &draw);
+}
+std::vector<uint8_t> select_minimizers_in_order(const std::vector<PolicyMinimizer>& ms, size_t read_length, const SeedPolicy& P, const std::vector<size_t>& order);
+std::vector<uint8_t> select_minimizers(const std::vector<PolicyMinimizer>& ms, size_t read_length, const SeedPolicy& P, ReadRng& rng) {
+    return select_minimizers_in_order(ms, read_length, P, minimizers_by_score(ms, rng));
+}
+
 std::vector<size_t> minimizers_by_score(const std::vector<PolicyMinimizer>& ms, const std::string* sequence) {
+    if (!sequence) return by_score_drawing_from(ms, nullptr);
+    // (the single-end path: the generator std::minstd_rand itself, seeded as LazyRNG seeds it — the statement ReadRng's written-out form is tested against)
+    uint32_t seed = 0;
+    for (unsigned char byte : *sequence) seed = seed * 13u + byte;
+    std::minstd_rand generator(seed);
+    const std::function<uint32_t()> draw = [&]() { return (uint32_t)generator(); };
+    return by_score_drawing_from(ms, &draw);
+}
+
+static std::vector<size_t> by_score_drawing_from(const std::vector<PolicyMinimizer>& ms, const std::function<uint32_t()>* draw) {
     std::vector<size_t> order(ms.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = i;
     // a key's occurrences have one hit count and so one score: sorting by (score descending, key, read position) keeps every run together
@@ -65,7 +97,7 @@ std::vector<size_t> minimizers_by_score(const std::vector<PolicyMinimizer>& ms, 
         if (ms[a].score != ms[b].score) return ms[a].score > ms[b].score;
         return ms[a].key < ms[b].key;
     });
-    if (!sequence || order.empty()) return order;
+    if (!draw || order.empty()) return order;
     // sort_shuffling_ties over the runs (src/utility.hpp:771-799): the runs that share the best score are shuffled — deterministic_shuffle
     // (:720-727) with the generator LazyRNG makes from the read's sequence (src/utility.cpp:911-927), which is std::minstd_rand itself
     std::vector<std::pair<size_t, size_t>> runs;                        // [first, end) in `order`, the leading stretch of equal score only
@@ -75,10 +107,7 @@ std::vector<size_t> minimizers_by_score(const std::vector<PolicyMinimizer>& ms, 
         runs.emplace_back(at, end); at = end;
     }
     if (runs.size() < 2) return order;
-    uint32_t seed = 0;
-    for (unsigned char byte : *sequence) seed = seed * 13u + byte;
-    std::minstd_rand generator(seed);
-    for (size_t i = 1; i < runs.size(); ++i) std::swap(runs[generator() % (i + 1)], runs[i]);
+    for (size_t i = 1; i < runs.size(); ++i) std::swap(runs[(*draw)() % (i + 1)], runs[i]);
     std::vector<size_t> laid; laid.reserve(order.size());
     for (const auto& run : runs) laid.insert(laid.end(), order.begin() + (std::ptrdiff_t)run.first, order.begin() + (std::ptrdiff_t)run.second);
     std::copy(laid.begin(), laid.end(), order.begin());
@@ -86,9 +115,11 @@ std::vector<size_t> minimizers_by_score(const std::vector<PolicyMinimizer>& ms, 
 }
 
 std::vector<uint8_t> select_minimizers(const std::vector<PolicyMinimizer>& ms, size_t read_length, const SeedPolicy& P, const std::string* sequence) {
+    return select_minimizers_in_order(ms, read_length, P, minimizers_by_score(ms, sequence));
+}
+std::vector<uint8_t> select_minimizers_in_order(const std::vector<PolicyMinimizer>& ms, size_t read_length, const SeedPolicy& P, const std::vector<size_t>& order) {
     const size_t n = ms.size();
     std::vector<uint8_t> verdict(n, SEED_TAKEN);
-    const std::vector<size_t> order = minimizers_by_score(ms, sequence);
     const bool score_filter = P.hit_cap != 0 || P.minimizer_score_fraction != 1.0;
     double base_target = 0.0, target = 0.0, selected = 0.0;
     if (score_filter) { for (size_t i : order) base_target += ms[i].score; target = base_target * P.minimizer_score_fraction + 0.000001; }      // (summed in score order, as the reference does: :4120-4125)

@@ -10,7 +10,7 @@
 // the BEST score are shuffled as sort_shuffling_ties shuffles them (src/utility.hpp:771-799, :720-727: Knuth's shuffle over std::minstd_rand,
 // which LazyRNG seeds from the read's sequence, src/utility.cpp:911-927) when the read's sequence is given — the single-end rule
 // (src/minimizer_mapper.cpp:620-627); the paired path seeds one generator from both mates and carries it from the first mate's sort to the
-// second's (:1529-1541): a caller that maps pairs passes the sequence of mate 1 + mate 2 for mate 1 and orders mate 2 itself.  Inside a run
+// second's (:1529-1541): a caller that maps pairs keeps a ReadRng over mate 1 + mate 2 and hands it to both calls.  Inside a run
 // of one key the order (std::sort's, unspecified) cannot matter: its minimizers share hits and score, and pass or fail together.
 #pragma once
 #include <cstddef>
@@ -46,12 +46,27 @@ enum SeedFilter : uint8_t { SEED_TAKEN = 0, SEED_DOWNSAMPLED = 1, SEED_NO_HITS =
 
 // find_minimizers' score per minimizer (:3927-3937): 1 + ln(hard_hit_cap) - ln(hits), 1 beyond the hard cap, 0 without hits
 void score_minimizers(std::vector<PolicyMinimizer>& minimizers_in_read_order, size_t hard_hit_cap);
+// LazyRNG (src/utility.hpp:693-713, src/utility.cpp:907-927): std::minstd_rand, seeded at its first use from a string — the read's sequence in the
+// single-end path (:620), both mates' sequences in a row in the paired path (:1529), where ONE generator serves the first mate's sort and then the second's.
+class ReadRng {
+public:
+    explicit ReadRng(std::string seed_sequence) : seed_(std::move(seed_sequence)) {}
+    uint32_t operator()();               // the next number; the generator is made at the first call
+    bool started() const { return started_; }
+private:
+    std::string seed_; bool started_ = false; uint32_t state_ = 1;
+};
 // sort_minimizers_by_score (:4074-4107): runs of one key together, the runs by descending score (ties: header) -> indices in that order
 std::vector<size_t> minimizers_by_score(const std::vector<PolicyMinimizer>& minimizers_in_read_order, const std::string* sequence = nullptr);
+// the same drawing from a generator the caller keeps (the paired path: ReadRng rng(mate1 + mate2); the first mate's call, then the second's)
+std::vector<size_t> minimizers_by_score(const std::vector<PolicyMinimizer>& minimizers_in_read_order, ReadRng& rng);
 // find_seeds' selection (:4109-4440): per minimizer (read order) the filter it failed, or SEED_TAKEN — the hits of the taken ones are the seeds.
 // Throws std::runtime_error where the reference crashes (a minimizer longer than the downsampling window).
 // sequence (nullable): the read — seeds the shuffle of the runs tied at the top; without it they stay in key order
 std::vector<uint8_t> select_minimizers(const std::vector<PolicyMinimizer>& minimizers_in_read_order, size_t read_length, const SeedPolicy& policy,
                                        const std::string* sequence = nullptr);
+std::vector<uint8_t> select_minimizers(const std::vector<PolicyMinimizer>& minimizers_in_read_order, size_t read_length, const SeedPolicy& policy, ReadRng& rng);
+// the filters over an order made before (minimizers_by_score)
+std::vector<uint8_t> select_minimizers_in_order(const std::vector<PolicyMinimizer>& minimizers_in_read_order, size_t read_length, const SeedPolicy& policy, const std::vector<size_t>& order);
 
 }  // namespace vgamd
