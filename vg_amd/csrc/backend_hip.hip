@@ -563,19 +563,29 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
                 for (uint32_t j = 0; j < np; ++j) rank += mz_better(psc[j], pkey[j], j, my_sc, my_key, lane) ? 1u : 0u;
                 if (lane < np) pord[rank] = (uint8_t)lane;
                 MZ_WAVE_SYNC();
-                // the runs tied at the top, shuffled as the reference shuffles them (minimizer_device.hpp): one lane, a few dozen steps at most, rarely
-                { uint32_t tie_state = 0;                                    // 1: the read has a masked base and its top tie matters — not chosen for
-                  if (lane == 0) {
-                      uint32_t elements = 0; const uint32_t runs = mz_top_ties(pord, pkey, psc, np, &elements);
-                      if (runs >= 2u) {
-                          bool masked = false; const uint32_t seed = mz_shuffle_seed(rd, L, masked);
-                          if (masked && mz_tie_matters(Q, runs, phit[pord[0]])) tie_state = 1u;
-                          else { uint8_t* t = ptie_all[wv]; mz_shuffle_top_ties(pord, pkey, elements, runs, seed, t, t + (MZ_POLICY_MAX + 1), t + 2 * (MZ_POLICY_MAX + 1)); }
+                // the runs tied at the top, shuffled as the reference shuffles them (minimizer_device.hpp) — when their order can change the choice at
+                // all: tied runs with at most hit_cap hits are all taken whatever their order (nearly every read: its unique minimizers tie at the
+                // top), so the generator is only made for a read whose BEST minimizers are repetitive.  The seed is folded across the lanes
+                // (seed = sum of byte_i x 13^(L - 1 - i) in 32 bits: a lane's bytes times their powers, summed over the wavefront).
+                { // (the tie itself across the lanes: lane r looks at the r-th minimizer of the order — tied with the first one? the first of its run?)
+                  const uint32_t xr = lane < np ? pord[lane] : 0u, x0 = np ? pord[0] : 0u;
+                  const bool tied = lane < np && psc[xr] == psc[x0];
+                  const bool opens = tied && (lane == 0 || pkey[pord[lane - 1]] != pkey[xr]);
+                  const uint32_t t_elems = (uint32_t)__popcll(__ballot(tied)), t_runs = (uint32_t)__popcll(__ballot(opens)), t_hits = np ? phit[x0] : 0u;
+                  if (mz_tie_matters(Q, t_runs, t_hits)) {
+                      uint32_t part = 0; bool other = false;
+                      for (uint32_t b = lane; b < L; b += 64u) {
+                          const char c = rd[b]; other = other || !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+                          uint32_t pw = 1u, base = 13u;
+                          for (uint32_t e = L - 1u - b; e; e >>= 1) { if (e & 1u) pw *= base; base *= base; }
+                          part += (uint32_t)(uint8_t)c * pw;
                       }
+#pragma unroll
+                      for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+                      if (__ballot(other) != 0ull) skipped = true;          // a masked base: the reference's seed cannot be made here — not chosen for
+                      else if (lane == 0) { uint8_t* t = ptie_all[wv]; mz_shuffle_top_ties(pord, pkey, t_elems, t_runs, part, t, t + (MZ_POLICY_MAX + 1), t + 2 * (MZ_POLICY_MAX + 1)); }
                   }
-                  tie_state = __shfl(tie_state, 0, 64);
-                  MZ_WAVE_SYNC();
-                  if (tie_state) skipped = true; }
+                  MZ_WAVE_SYNC(); }
                 // the filters, in that order: every lane the same few dozen steps (the sums must be made in this order)
                 const bool use_score = Q.hit_cap != 0 || Q.fraction != 1.0;
                 double target = 0.0, selected = 0.0;

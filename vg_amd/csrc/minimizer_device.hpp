@@ -187,9 +187,9 @@ VGK_HD uint64_t mz_policy_select(const MzPolicy& Q, const uint64_t* key, const u
     for (uint32_t i = 0; i < n; ++i) { uint32_t rank = 0; for (uint32_t j = 0; j < n; ++j) rank += mz_better(score[j], key[j], j, score[i], key[i], i) ? 1u : 0u; order[rank] = i; }
     *unsure = false;
     { uint32_t elements = 0; const uint32_t runs = mz_top_ties(order, key, score, n, &elements);
-      if (runs >= 2u) {
+      if (mz_tie_matters(Q, runs, n ? hits[order[0]] : 0u)) {                  // (tied runs of at most hit_cap hits are all taken whatever their order: no generator is made for them)
           bool masked = false; const uint32_t seed = mz_shuffle_seed(seq, L, masked);
-          if (masked && mz_tie_matters(Q, runs, hits[order[0]])) { *unsure = true; return 0; }
+          if (masked) { *unsure = true; return 0; }
           uint8_t start[MZ_POLICY_MAX + 1], perm[MZ_POLICY_MAX + 1]; uint32_t tmp[MZ_POLICY_MAX + 1];
           mz_shuffle_top_ties(order, key, elements, runs, seed, start, perm, tmp);
       } }
