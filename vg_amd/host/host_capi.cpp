@@ -7,6 +7,7 @@
 #include <cstring>
 #include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include "aligner.hpp"
@@ -331,9 +332,12 @@ int vgh_rescue_reads(uint32_t m, const vgk_rescue_request* table, const char* re
         };
         if (threads < 2) { body(0, m); return 0; }
         std::vector<std::thread> ts; const size_t per = ((size_t)m + threads - 1) / threads;
-        for (unsigned t = 1; t < threads; ++t) ts.emplace_back([&, t]() { const size_t lo = std::min<size_t>(m, t * per), hi = std::min<size_t>(m, lo + per); if (lo < hi) body(lo, hi); });
-        body(0, std::min<size_t>(m, per));
+        std::mutex first_mutex; std::exception_ptr first;                // (as everywhere in the shim: a worker's exception comes back on the caller)
+        auto guarded = [&](size_t lo, size_t hi) { try { if (lo < hi) body(lo, hi); } catch (...) { std::lock_guard<std::mutex> hold(first_mutex); if (!first) first = std::current_exception(); } };
+        for (unsigned t = 1; t < threads; ++t) ts.emplace_back([&, t]() { const size_t lo = std::min<size_t>(m, t * per); guarded(lo, std::min<size_t>(m, lo + per)); });
+        guarded(0, std::min<size_t>(m, per));
         for (auto& t : ts) t.join();
+        if (first) std::rethrow_exception(first);
         return 0;
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }

@@ -2,6 +2,8 @@
 #include "rescue_requests.hpp"
 #include <algorithm>
 #include <cmath>
+#include <exception>
+#include <mutex>
 #include <thread>
 
 namespace vgamd {
@@ -15,9 +17,12 @@ template <class F> void chunks(size_t n, unsigned threads, F body) {
     if (threads < 2) { body((size_t)0, n); return; }
     std::vector<std::thread> ts;
     const size_t per = (n + threads - 1) / threads;
-    for (unsigned t = 1; t < threads; ++t) ts.emplace_back([&, t]() { const size_t lo = std::min(n, t * per), hi = std::min(n, lo + per); if (lo < hi) body(lo, hi); });
-    body((size_t)0, std::min(n, per));
+    std::mutex first_mutex; std::exception_ptr first;                    // (a worker's exception is rethrown on the caller after the join, never left to std::terminate)
+    auto guarded = [&](size_t lo, size_t hi) { try { if (lo < hi) body(lo, hi); } catch (...) { std::lock_guard<std::mutex> hold(first_mutex); if (!first) first = std::current_exception(); } };
+    for (unsigned t = 1; t < threads; ++t) ts.emplace_back([&, t]() { const size_t lo = std::min(n, t * per); guarded(lo, std::min(n, lo + per)); });
+    guarded((size_t)0, std::min(n, per));
     for (auto& t : ts) t.join();
+    if (first) std::rethrow_exception(first);
 }
 }  // namespace
 
