@@ -26,6 +26,36 @@ def run_leg(emu_lib, args, env_extra):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
+def test_default_run_ends_with_a_short_headline_line(emu_lib, tmp_path):
+    """the driver keeps a bounded tail of stdout and parses the LAST line.  The default run's last line is the headline
+    alone (< 4 KB, the only line that starts with "{"); every secondary record is an earlier `[secondary]` line and a record of
+    bench_secondary.json."""
+    side = str(tmp_path / "side.json")
+    legs = [["gapless", ["--reads", "300", "--steps", "1", "--warmup", "0"], 600], ["wfa", ["--reads", "300", "--steps", "1", "--warmup", "0"], 600]]
+    env = dict(os.environ, VGAMD_BENCH_ONE_DEVICE="1", VGAMD_ENGINE_LIB=emu_lib, VGAMD_BENCH_SECONDARY_LEGS=json.dumps(legs), VGAMD_BENCH_SIDE_FILE=side)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "400", "--steps", "2", "--warmup", "1", "--cpu-sample", "400"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    assert [l for l in lines if l.startswith("{")] == [lines[-1]]
+    assert len(lines[-1]) < 4096
+    d = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert k in d, k
+    assert "secondary" not in d and d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
+    assert {"workload", "timed_region", "reads_per_gpu_per_step", "parallelism", "device"} <= set(d["config"])
+    assert d["parity"]["checked"] == d["parity"]["identical"] > 0
+    sec = [json.loads(l[len("[secondary] "):]) for l in lines if l.startswith("[secondary] ")]
+    assert [r["workload"] for r in sec] == ["gapless", "wfa"] and all("error" not in r and r["value"] > 0 for r in sec), sec
+    assert any(l.startswith("[detail] ") for l in lines)
+    saved = json.load(open(side))
+    assert saved["secondary"] == sec and "one_stream" in saved["headline_detail"]
+
+
 def test_paired_leg_on_the_emulated_kernels(emu_lib):
     d = run_leg(emu_lib, ["--workload", "paired", "--reads", "1200", "--steps", "1", "--warmup", "1", "--cpu-sample", "1200"],
                 {"VGAMD_PAIRED_REF_LEN": "300000", "VGAMD_PAIRED_BATCH": "300"})
