@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-6 GPU runs, one parameterised script: `gpurun -- bash tools/gpu_r06.sh <stage> [args]`.
+# Everything is written under gpurun_out/r06/<stage>/; what is cited goes to profiles/r06/ by hand.
+set -u
+stage=${1:-tests}
+out=gpurun_out/r06/$stage
+mkdir -p "$out"
+export TMPDIR=/tmp
+last_json() { python -c "import json,sys; d=json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith('{')][-1]); $2" "$1"; }
+case "$stage" in
+  tests)          # the whole -m gpu suite + smoke
+    timeout 2700 python -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1; echo "rc=$?" >> "$out/pytest_gpu.log"; tail -5 "$out/pytest_gpu.log"
+    timeout 600 python __graft_entry__.py smoke > "$out/smoke.log" 2>&1; echo "rc=$?" >> "$out/smoke.log"; tail -2 "$out/smoke.log" ;;
+  some_tests)     # named test files / -k expression: SOME="tests/test_x.py -k foo"
+    timeout 1500 python -m pytest ${SOME:-tests} -m gpu -x -q > "$out/pytest_some.log" 2>&1; echo "rc=$?" >> "$out/pytest_some.log"; tail -8 "$out/pytest_some.log" ;;
+  default)        # what the driver runs: the headline line + every secondary record
+    /usr/bin/time -v timeout 1700 python bench.py > "$out/bench_default_run.out" 2> "$out/bench_default_run.err"
+    cp bench_secondary.json "$out/" 2>/dev/null
+    python - "$out/bench_default_run.out" <<'PY'
+import json, sys
+lines = open(sys.argv[1]).read().strip().splitlines()
+print("last line bytes", len(lines[-1]), "json lines", sum(l.startswith("{") for l in lines))
+d = json.loads(lines[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["cpu_baseline"]["value"], d["parity"])
+for l in lines:
+    if l.startswith("[secondary] "):
+        r = json.loads(l[12:]); print(r["workload"], r.get("value"), r.get("error"), r.get("parity") and {k: v for k, v in r["parity"].items() if k != "what"}, r["wall_s"])
+PY
+    grep -E "Elapsed|Maximum resident" "$out/bench_default_run.err" ;;
+  leg)            # one secondary leg: LEG="longread --steps 3 --warmup 1"
+    set -- ${LEG:-longread --steps 3 --warmup 1}; w=$1; shift
+    timeout 1200 python bench.py --workload $w "$@" > "$out/bench_$w${TAG:-}.json" 2> "$out/bench_$w${TAG:-}.err"; tail -3 "$out/bench_$w${TAG:-}.err"
+    last_json "$out/bench_$w${TAG:-}.json" "print(round(d['value']), d['ms_per_step'], d.get('parity') and {k: v for k, v in d['parity'].items() if k != 'what'}, d['roofline'].get('frac'), d['config'].get('stage_ms_per_batch'))" ;;
+  *) echo "unknown stage $stage"; exit 2 ;;
+esac
