@@ -22,6 +22,9 @@
  *                             (src/gbwt_extender.cpp:533-737)
  *   vgk_wfa_extend  replaces  WFAExtender::connect / prefix / suffix
  *                             (src/gbwt_extender.cpp:2052-2263)
+ *   vgk_chain_stitch
+ *                   replaces  the Path composition of MinimizerMapper::find_chain_alignment
+ *                             (src/minimizer_mapper_from_chains.cpp:2606-3295: append_path of every piece's Path, simplify)
  *
  * Everything is plain pointers and sizes.  All "graphs" handed over are DAGs
  * whose nodes are ALREADY in the topological order the reference would use
@@ -48,7 +51,7 @@
 extern "C" {
 #endif
 
-#define VGK_ABI_VERSION 5
+#define VGK_ABI_VERSION 6
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -645,6 +648,53 @@ int    vgk_wfa_get_form(vgk_ctx* ctx);          /* the form in force (a stage th
  * than that holds a 40-base insertion and will fill the wavefront tables whatever its length.  A hint changes the order only, never a
  * result; it is used once. */
 int    vgk_wfa_set_cost_hints(vgk_ctx* ctx, const uint32_t* extra_bases, uint32_t n);
+
+/* ---- one Path per read out of a chain's pieces ------------------------------------------------------------------------------------------
+ * vgk_chain_stitch replaces the composition inside MinimizerMapper::find_chain_alignment (reference
+ * src/minimizer_mapper_from_chains.cpp): every piece of a read's chain — left tail, anchor, link, anchor, ..., right tail — becomes a
+ * Path (WFAAlignment::to_path, src/gbwt_extender.cpp:954-1070; align_sequence_between's Alignment::path as it is), the Paths are appended
+ * in read order (append_path :2606 / :2662 / :2892 / :3035 / :3103 / :3147 / :3262; src/path.cpp:284-287) and the whole is simplified
+ * (`simplify(composed_path, false)` :3295; src/path.cpp:1314-1497 with Mapping simplify :1509-1563 and concat_mappings :1499-1507):
+ * edits of one kind merged, insertions pushed onto the previous mapping, mappings that continue each other on one node joined, leading and
+ * trailing deletions removed.  For a whole batch of reads at once, on the device: the WFA results of the context's last vgk_wfa_extend
+ * call never leave HBM as paths and edit runs — only the composed alignments come back.
+ * A piece is one of
+ *   LINK       result `link` of the LAST vgk_wfa_extend call on this context (with the same index), which must be ok; unused fields 0;
+ *   ALIGNMENT  a WFAAlignment the caller states: node path nodes[path_begin .. +path_len) (oriented nodes), node_offset in its first node,
+ *              edit runs edits[edit_begin .. +n_edits) as length << 2 | VGK_WFA_*  (an anchor = one match run, to_wfa_alignment :4083-4104;
+ *              path_len = 0 with one insertion run = WFAAlignment::make_unlocalized_insertion: a mapping without a position);
+ *   PATH       a Path the caller states: mappings[path_begin .. +path_len), each with its position and its own edit runs (what
+ *              align_sequence_between_consistently answered for a link that WFA declined).
+ * A zero-length run is not an edit (to_path refuses it; a Path's empty edits are skipped as simplify skips them).
+ * Results, dense and in read order: per read {status, mapping_begin, n_mappings, edit_begin, n_edits, from_length, to_length} — status
+ * VGK_EINVAL when a LINK piece names a problem that is not ok or a piece walks off its node path (the reference throws), VGK_EOPS when
+ * out_mappings / out_edits are too small (*written = what is needed) —; per mapping {node (oriented; VGK_WFA_NO_NODE: no position),
+ * offset, edit_begin, n_edits}; per edit length << 2 | VGK_WFA_* (a mismatch run of several bases is ONE edit when its source — a PATH piece
+ * of BandedGlobalAligner's — or simplify's merging made it one).  Mapping ranks are their indices + 1; substituted / inserted bases are the
+ * read's own at the edit's read offset, so they are not repeated here. */
+enum { VGK_PIECE_LINK = 0, VGK_PIECE_ALIGNMENT = 1, VGK_PIECE_PATH = 2 };
+typedef struct vgk_chain_piece {
+    uint32_t kind;
+    uint32_t link;                    /* LINK */
+    uint32_t node_offset;             /* ALIGNMENT */
+    uint32_t path_begin, path_len;    /* ALIGNMENT: in `nodes`; PATH: in `mappings` */
+    uint32_t edit_begin, n_edits;     /* ALIGNMENT: in `edits` */
+    uint32_t reserved;
+} vgk_chain_piece;
+typedef struct vgk_chain_mapping { uint32_t node, offset, edit_begin, n_edits; } vgk_chain_mapping;
+typedef struct vgk_chain_result {
+    int32_t  status;
+    uint32_t mapping_begin, n_mappings;
+    uint32_t edit_begin, n_edits;
+    uint32_t from_length, to_length;  /* path_from_length / path_to_length of the result */
+    uint32_t reserved;
+} vgk_chain_result;
+int  vgk_chain_stitch(vgk_ctx* ctx, const vgk_haplo* index,
+                      const vgk_chain_piece* pieces, const uint64_t* piece_off /* n_reads + 1: read r = pieces[piece_off[r], piece_off[r + 1]) */, uint32_t n_reads,
+                      const uint32_t* nodes, size_t n_nodes, const vgk_chain_mapping* mappings, size_t n_mappings, const uint32_t* edits, size_t n_edits,
+                      vgk_chain_result* results, vgk_chain_mapping* out_mappings, size_t mapping_cap, uint32_t* out_edits, size_t edit_cap,
+                      size_t written[2] /* mappings, edits */);
+double vgk_chain_stitch_last_ms(vgk_ctx* ctx);   /* device time of the last call's kernels */
 
 /* batch introspection (used by bench.py for the roofline line) */
 void     vgk_batch_free(vgk_batch* batch);

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
     for s in declared_symbols():
         assert hasattr(h, s), "%s does not export %s" % (lib, s)
     h.vgk_abi_version.restype = ctypes.c_int
-    assert h.vgk_abi_version() == 5
+    assert h.vgk_abi_version() == 6
 
 
 def test_engine_refuses_to_run_without_a_gpu_instead_of_falling_back():

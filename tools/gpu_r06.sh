@@ -14,7 +14,7 @@ case "$stage" in
   some_tests)     # named test files / -k expression: SOME="tests/test_x.py -k foo"
     timeout 1500 python -m pytest ${SOME:-tests} -m gpu -x -q > "$out/pytest_some.log" 2>&1; echo "rc=$?" >> "$out/pytest_some.log"; tail -8 "$out/pytest_some.log" ;;
   default)        # what the driver runs: the headline line + every secondary record
-    /usr/bin/time -v timeout 1700 python bench.py > "$out/bench_default_run.out" 2> "$out/bench_default_run.err"
+    t0=$(date +%s); timeout 1700 python bench.py > "$out/bench_default_run.out" 2> "$out/bench_default_run.err"; echo "wall $(( $(date +%s) - t0 )) s"
     cp bench_secondary.json "$out/" 2>/dev/null
     python - "$out/bench_default_run.out" <<'PY'
 import json, sys
@@ -25,7 +25,7 @@ for l in lines:
     if l.startswith("[secondary] "):
         r = json.loads(l[12:]); print(r["workload"], r.get("value"), r.get("error"), r.get("parity") and {k: v for k, v in r["parity"].items() if k != "what"}, r["wall_s"])
 PY
-    grep -E "Elapsed|Maximum resident" "$out/bench_default_run.err" ;;
+    ;;
   leg)            # one secondary leg: LEG="longread --steps 3 --warmup 1"
     set -- ${LEG:-longread --steps 3 --warmup 1}; w=$1; shift
     timeout 1200 python bench.py --workload $w "$@" > "$out/bench_$w${TAG:-}.json" 2> "$out/bench_$w${TAG:-}.err"; tail -3 "$out/bench_$w${TAG:-}.err"

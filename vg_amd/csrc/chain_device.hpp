@@ -1,0 +1,242 @@
+// chain_device.hpp — one Path per read out of the pieces of its chain (vgk_chain_stitch): one lane per read walks the read's pieces in read
+// order, turns each into mappings as WFAAlignment::to_path does (reference src/gbwt_extender.cpp:954-1070) — or takes a stated Path's mappings
+// as they are —, and feeds them, one mapping at a time, through the rules of `simplify(path, false)` (src/path.cpp:1314-1497; Mapping simplify
+// :1509-1563; concat_mappings :1499-1507), which only ever look at the mapping they are given and at the LAST mapping kept so far.
+//
+// MI355X-first: the reference composes a protobuf Path per read on the mapping thread (append_path + simplify copy every Mapping two or three
+// times); here the WFA results of a whole batch stay in HBM as flat node paths and edit runs, a lane per read writes flat mappings and edit
+// runs into the read's own stretch of a work array — the LAST mapping's edits are always the tail of that stretch, so "append to the last
+// mapping", "join with the last mapping" and "merge its runs again" are all in place —, and a gather packs the reads behind each other, so
+// that only the composed alignments cross PCIe.  HBM-bound byte work: ~12 B read and ~12 B written per mapping.
+//
+// Three stages around two prefix sums (Backend::scan_u32):  CS_BOUND  per read, how many mappings / edit runs its pieces can make at most;
+// CS_STITCH  the composition into the stretch those bounds reserve, exact sizes out;  CS_GATHER  dense copy in read order.
+#pragma once
+#include <cstdint>
+#include "../../include/vgk.h"
+#include "gapless_device.hpp"
+
+namespace vgk {
+
+struct CsParams {
+    GIndex index;                                               // node lengths (g_len)
+    const vgk_chain_piece* pieces; const uint64_t* piece_off; uint32_t n_reads;
+    const uint32_t* nodes; const vgk_chain_mapping* mappings; const uint32_t* edits;       // the caller's arrays, in HBM
+    uint64_t n_nodes, n_mappings, n_edits;
+    // what the last vgk_wfa_extend call left in HBM (results in problem order; paths and edit runs in completion order)
+    const vgk_wfa_result* link_res; const uint32_t* link_paths; const uint32_t* link_edits; uint32_t n_links; uint64_t link_path_cap, link_edit_cap;
+    uint32_t* bound;                                            // [2 (n_reads + 1)] CS_BOUND: mappings | edit runs per read at most (entry n_reads of either half = 0)
+    const uint32_t* slot;                                       // [2 (n_reads + 1)] their exclusive prefix sums, half by half
+    vgk_chain_mapping* work_m; uint32_t* work_e;                // the stretches
+    vgk_chain_result* res;                                      // [n_reads] CS_STITCH: status, sizes; mapping_begin / edit_begin inside the work arrays
+    uint32_t* count;                                            // [2 (n_reads + 1)] exact sizes
+    const uint32_t* out_slot;                                   // [2 (n_reads + 1)] their exclusive prefix sums
+    vgk_chain_mapping* out_m; uint32_t* out_e; vgk_chain_result* out_res;     // CS_GATHER: dense, in read order
+    uint64_t out_m_cap, out_e_cap;
+};
+enum { CS_BOUND = 0, CS_STITCH = 1, CS_GATHER = 2 };
+
+VGK_HD uint32_t cs_kind(uint32_t run) { return run & 3u; }
+VGK_HD uint32_t cs_len(uint32_t run) { return run >> 2; }
+VGK_HD bool cs_link_ok(const CsParams& P, const vgk_chain_piece& pc) {
+    if (pc.link >= P.n_links) return false;
+    const vgk_wfa_result& r = P.link_res[pc.link];
+    return r.status == VGK_OK && r.ok != 0 && (uint64_t)r.path_begin + r.path_len <= P.link_path_cap && (uint64_t)r.edit_begin + r.n_edits <= P.link_edit_cap;
+}
+
+// ---- CS_BOUND --------------------------------------------------------------------------------------------------------------------------
+// A WFAAlignment of p nodes and e runs makes at most max(p, 1) mappings and e + p edits (a run is cut at most once per node boundary);
+// a stated Path makes what it holds.  Nothing in simplify makes more of either.
+VGK_HD void cs_bound_one(const CsParams& P, uint32_t r) {
+    uint64_t m = 0, e = 0;
+    if (r < P.n_reads) {
+        for (uint64_t k = P.piece_off[r]; k < P.piece_off[r + 1]; ++k) {
+            const vgk_chain_piece pc = P.pieces[k];
+            if (pc.kind == (uint32_t)VGK_PIECE_LINK) {
+                if (!cs_link_ok(P, pc)) continue;
+                const vgk_wfa_result& w = P.link_res[pc.link];
+                m += w.path_len ? w.path_len : 1u; e += (uint64_t)w.n_edits + w.path_len;
+            } else if (pc.kind == (uint32_t)VGK_PIECE_ALIGNMENT) {
+                m += pc.path_len ? pc.path_len : 1u; e += (uint64_t)pc.n_edits + pc.path_len;
+            } else if (pc.kind == (uint32_t)VGK_PIECE_PATH) {
+                if ((uint64_t)pc.path_begin + pc.path_len > P.n_mappings) continue;
+                m += pc.path_len;
+                for (uint32_t q = 0; q < pc.path_len; ++q) e += P.mappings[pc.path_begin + q].n_edits;
+            }
+        }
+    }
+    P.bound[r] = m < 0xffffffffull ? (uint32_t)m : 0xffffffffu;
+    P.bound[(size_t)P.n_reads + 1 + r] = e < 0xffffffffull ? (uint32_t)e : 0xffffffffu;
+}
+
+// ---- CS_STITCH -------------------------------------------------------------------------------------------------------------------------
+// The composed path so far: mappings M[0 .. nm), the edits of M[k] at E[M[k].edit_begin .. + n_edits) (offsets inside the read's stretch),
+// the last mapping's edits ending at `tail`.  `cur` is the mapping being made: its edits are E[cur.edit_begin .. tail_cur).
+struct CsState {
+    vgk_chain_mapping* M; uint32_t* E; uint32_t nm, tail, cap_m, cap_e;
+    vgk_chain_mapping cur; uint32_t cur_end;        // cur's edits: E[cur.edit_begin, cur_end)
+    int32_t status;
+};
+VGK_HD uint32_t cs_from_length(const uint32_t* E, uint32_t b, uint32_t n) { uint32_t f = 0; for (uint32_t k = 0; k < n; ++k) if (cs_kind(E[b + k]) != (uint32_t)VGK_WFA_INSERTION) f += cs_len(E[b + k]); return f; }
+VGK_HD uint32_t cs_to_length(const uint32_t* E, uint32_t b, uint32_t n) { uint32_t t = 0; for (uint32_t k = 0; k < n; ++k) if (cs_kind(E[b + k]) != (uint32_t)VGK_WFA_DELETION) t += cs_len(E[b + k]); return t; }
+// Mapping simplify (:1509-1563, trim_internal_deletions = false) over E[b, b + n): runs of one kind become one; -> the new n
+VGK_HD uint32_t cs_merge_runs(uint32_t* E, uint32_t b, uint32_t n) {
+    if (!n) return 0;
+    uint32_t w = b;
+    for (uint32_t k = b + 1; k < b + n; ++k) {
+        if (cs_len(E[k]) == 0) continue;                                       // edit_is_empty(f): skipped (:1545)
+        if (cs_kind(E[k]) == cs_kind(E[w])) E[w] += cs_len(E[k]) << 2;        // edits_are_compatible -> merge_edits_in_place
+        else E[++w] = E[k];
+    }
+    return w - b + 1;
+}
+VGK_HD void cs_open(CsState& S, uint32_t node, uint32_t offset) { S.cur.node = node; S.cur.offset = offset; S.cur.edit_begin = S.tail; S.cur.n_edits = 0; S.cur_end = S.tail; }
+// one edit of the mapping in the making; Mapping simplify's merging happens here (a run of the kind of the mapping's last run extends it)
+VGK_HD void cs_edit(CsState& S, uint32_t kind, uint32_t len) {
+    if (!len) return;
+    if (S.cur_end > S.cur.edit_begin && cs_kind(S.E[S.cur_end - 1]) == kind) { S.E[S.cur_end - 1] += len << 2; return; }
+    if (S.cur_end >= S.cap_e) { S.status = VGK_EOPS; return; }
+    S.E[S.cur_end++] = len << 2 | kind;
+}
+// the mapping in the making is complete: simplify's loop body for it (:1324-1406)
+VGK_HD void cs_close(CsState& S) {
+    uint32_t mb = S.cur.edit_begin, me = S.cur_end;
+    if (me == mb) return;                                                      // no edits: redundant (:1334)
+    if (!S.nm) {
+        if (S.nm >= S.cap_m) { S.status = VGK_EOPS; return; }
+        S.cur.n_edits = me - mb; S.M[S.nm++] = S.cur; S.tail = me; return;
+    }
+    vgk_chain_mapping& l = S.M[S.nm - 1];
+    // insertions at the start of this mapping belong to the previous one: appended there as they are (:1345-1352)
+    uint32_t moved = 0;
+    while (mb + moved < me && cs_kind(S.E[mb + moved]) == (uint32_t)VGK_WFA_INSERTION) ++moved;
+    l.n_edits += moved; mb += moved;
+    uint32_t node = S.cur.node, offset = S.cur.offset;
+    const uint32_t l_from = cs_from_length(S.E, l.edit_begin, l.n_edits);
+    if (l.node == VGK_WFA_NO_NODE && node != VGK_WFA_NO_NODE) { l.node = node; l.offset = offset; }                  // (:1361-1369)
+    else if (node == VGK_WFA_NO_NODE && l.node != VGK_WFA_NO_NODE) { node = l.node; offset = l_from; }              // (:1371-1380: the offset is from_length(*l), as written there)
+    const bool joins = (l.node == VGK_WFA_NO_NODE && node == VGK_WFA_NO_NODE) || (l.node != VGK_WFA_NO_NODE && node != VGK_WFA_NO_NODE && l.node == node && l.offset + l_from == offset);
+    if (joins) {                                                               // concat_mappings: all edits, merged again (:1382-1394)
+        l.n_edits += me - mb;
+        l.n_edits = cs_merge_runs(S.E, l.edit_begin, l.n_edits);
+        S.tail = l.edit_begin + l.n_edits;
+    } else if (me > mb) {                                                      // from_length(m) || to_length(m) (:1396)
+        if (S.nm >= S.cap_m) { S.status = VGK_EOPS; return; }
+        vgk_chain_mapping m; m.node = node; m.offset = offset; m.edit_begin = mb; m.n_edits = me - mb;
+        S.M[S.nm++] = m; S.tail = me;
+    } else S.tail = mb;
+}
+// WFAAlignment::to_path over (node path, node_offset, edit runs): a mapping per node the edits reach
+VGK_HD void cs_alignment(const CsParams& P, CsState& S, const uint32_t* path, uint32_t path_len, uint32_t node_offset, const uint32_t* runs, uint32_t n_runs) {
+    if (!path_len) {
+        if (n_runs == 1 && cs_kind(runs[0]) == (uint32_t)VGK_WFA_INSERTION) {   // unlocalized_insertion(): a mapping without a position (:964-970)
+            cs_open(S, VGK_WFA_NO_NODE, 0); cs_edit(S, VGK_WFA_INSERTION, cs_len(runs[0])); cs_close(S);
+        } else if (n_runs) S.status = VGK_EINVAL;
+        return;                                                                // path empty: an empty Path (:972-974)
+    }
+    if (path[0] >= P.index.n_oriented) { S.status = VGK_EINVAL; return; }
+    uint32_t step = 0, node_at = node_offset, node_end = g_len(P.index, (int32_t)path[0]);
+    if (node_offset >= node_end || !n_runs) { S.status = VGK_EINVAL; return; } // "offset to or past end of first node", "has no edits"
+    cs_open(S, path[0], node_offset);
+    for (uint32_t k = 0; k < n_runs && S.status == VGK_OK; ++k) {
+        const uint32_t kind = cs_kind(runs[k]);
+        uint32_t left = cs_len(runs[k]);
+        if (!left) { S.status = VGK_EINVAL; return; }                          // "has empty edit"
+        const bool uses_graph = kind != (uint32_t)VGK_WFA_INSERTION;
+        while (left && S.status == VGK_OK) {
+            uint32_t take = left;
+            if (uses_graph) {
+                if (step == path_len || node_at == node_end) { S.status = VGK_EINVAL; return; }     // "tried to go past end of path / node"
+                if (node_end - node_at < take) take = node_end - node_at;
+            }
+            cs_edit(S, kind, take);
+            left -= take;
+            if (uses_graph) {
+                node_at += take;
+                if (node_at == node_end) {
+                    node_at = 0; ++step;
+                    if (step != path_len) {
+                        if (path[step] >= P.index.n_oriented) { S.status = VGK_EINVAL; return; }
+                        node_end = g_len(P.index, (int32_t)path[step]);
+                        if (!node_end) { S.status = VGK_EINVAL; return; }      // "has empty node"
+                        cs_close(S); cs_open(S, path[step], 0);
+                    } else node_end = 0;
+                }
+            }
+        }
+    }
+    if (S.status == VGK_OK) cs_close(S);
+}
+
+VGK_HD void cs_stitch_one(const CsParams& P, uint32_t r) {
+    const uint32_t R = P.n_reads + 1;
+    CsState S;
+    S.M = P.work_m + P.slot[r]; S.E = P.work_e + P.slot[R + r]; S.cap_m = P.bound[r]; S.cap_e = P.bound[R + r];
+    S.nm = 0; S.tail = 0; S.status = VGK_OK; S.cur_end = 0; S.cur.node = VGK_WFA_NO_NODE; S.cur.offset = 0; S.cur.edit_begin = 0; S.cur.n_edits = 0;
+    for (uint64_t k = P.piece_off[r]; k < P.piece_off[r + 1] && S.status == VGK_OK; ++k) {
+        const vgk_chain_piece pc = P.pieces[k];
+        if (pc.kind == (uint32_t)VGK_PIECE_LINK) {
+            if (!cs_link_ok(P, pc)) { S.status = VGK_EINVAL; break; }          // "WFAAlignment is not OK and cannot become a path"
+            const vgk_wfa_result w = P.link_res[pc.link];
+            cs_alignment(P, S, P.link_paths + w.path_begin, w.path_len, w.node_offset, P.link_edits + w.edit_begin, w.n_edits);
+        } else if (pc.kind == (uint32_t)VGK_PIECE_ALIGNMENT) {
+            if ((uint64_t)pc.path_begin + pc.path_len > P.n_nodes || (uint64_t)pc.edit_begin + pc.n_edits > P.n_edits) { S.status = VGK_EINVAL; break; }
+            cs_alignment(P, S, P.nodes + pc.path_begin, pc.path_len, pc.node_offset, P.edits + pc.edit_begin, pc.n_edits);
+        } else if (pc.kind == (uint32_t)VGK_PIECE_PATH) {
+            if ((uint64_t)pc.path_begin + pc.path_len > P.n_mappings) { S.status = VGK_EINVAL; break; }
+            for (uint32_t q = 0; q < pc.path_len && S.status == VGK_OK; ++q) {
+                const vgk_chain_mapping m = P.mappings[pc.path_begin + q];
+                if ((uint64_t)m.edit_begin + m.n_edits > P.n_edits || (m.node != VGK_WFA_NO_NODE && m.node >= P.index.n_oriented)) { S.status = VGK_EINVAL; break; }
+                cs_open(S, m.node, m.offset);
+                for (uint32_t x = 0; x < m.n_edits; ++x) cs_edit(S, cs_kind(P.edits[m.edit_begin + x]), cs_len(P.edits[m.edit_begin + x]));
+                cs_close(S);
+            }
+        } else S.status = VGK_EINVAL;
+    }
+    vgk_chain_result out; out.status = S.status; out.mapping_begin = P.slot[r]; out.edit_begin = P.slot[R + r];
+    out.n_mappings = out.n_edits = out.from_length = out.to_length = 0; out.reserved = 0;
+    if (S.status == VGK_OK) {
+        // leading and trailing deletions go (:1422-1475), the mappings close up, the edits close up behind each other
+        uint32_t total_to = 0;
+        for (uint32_t k = 0; k < S.nm; ++k) total_to += cs_to_length(S.E, S.M[k].edit_begin, S.M[k].n_edits);
+        uint32_t seen = 0, wm = 0, we = 0, from = 0;
+        for (uint32_t k = 0; k < S.nm; ++k) {
+            vgk_chain_mapping m = S.M[k];
+            const uint32_t curr = cs_to_length(S.E, m.edit_begin, m.n_edits);
+            if ((!seen && !curr) || seen == total_to) continue;
+            if (seen) {
+                if (seen + curr == total_to)                                   // the last mapping with read bases: deletions at its end go
+                    while (m.n_edits && cs_kind(S.E[m.edit_begin + m.n_edits - 1]) == (uint32_t)VGK_WFA_DELETION) --m.n_edits;
+            } else {                                                           // the first one: deletions at its start go, its offset moves on
+                while (m.n_edits && cs_kind(S.E[m.edit_begin]) == (uint32_t)VGK_WFA_DELETION) { m.offset += cs_len(S.E[m.edit_begin]); ++m.edit_begin; --m.n_edits; }
+            }
+            seen += cs_to_length(S.E, m.edit_begin, m.n_edits);
+            from += cs_from_length(S.E, m.edit_begin, m.n_edits);
+            for (uint32_t x = 0; x < m.n_edits; ++x) S.E[we + x] = S.E[m.edit_begin + x];       // (we <= m.edit_begin: a move towards the front)
+            m.edit_begin = we; we += m.n_edits;
+            S.M[wm++] = m;
+        }
+        out.n_mappings = wm; out.n_edits = we; out.from_length = from; out.to_length = seen;
+    }
+    P.res[r] = out;
+    P.count[r] = out.n_mappings; P.count[R + r] = out.n_edits;
+}
+
+// ---- CS_GATHER: lane `lane` of `lanes` copies its share of read r's mappings and edit runs into the dense arrays -----------------------------
+VGK_HD void cs_gather_one(const CsParams& P, uint32_t r, uint32_t lane, uint32_t lanes) {
+    const uint32_t R = P.n_reads + 1;
+    const vgk_chain_result w = P.res[r];
+    const uint32_t mb = P.out_slot[r], eb = P.out_slot[R + r];
+    const bool fits = (uint64_t)mb + w.n_mappings <= P.out_m_cap && (uint64_t)eb + w.n_edits <= P.out_e_cap;
+    if (fits) {
+        for (uint32_t k = lane; k < w.n_mappings; k += lanes) { vgk_chain_mapping m = P.work_m[w.mapping_begin + k]; m.edit_begin += eb; P.out_m[mb + k] = m; }
+        for (uint32_t k = lane; k < w.n_edits; k += lanes) P.out_e[eb + k] = P.work_e[w.edit_begin + k];
+    }
+    if (lane == 0) {
+        vgk_chain_result o = w; o.mapping_begin = mb; o.edit_begin = eb;
+        if (!fits && o.status == VGK_OK) o.status = VGK_EOPS;
+        P.out_res[r] = o;
+    }
+}
+
+}  // namespace vgk
