@@ -448,6 +448,9 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
     for st in stages:
         st.set_point_budgets(0, 0)
     lock = threading.Lock()
+    # every step composes ONE alignment per read (find_chain_alignment's composed_path, simplified: vgk_chain_stitch) and brings it to the host;
+    # VGAMD_LONGREAD_SCORES_ONLY=1: round 5's form (chain scores only), for comparisons
+    compose = not os.environ.get("VGAMD_LONGREAD_SCORES_ONLY")
 
     def barrier():
         _device_sync(torch)
@@ -455,10 +458,15 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
             dist.barrier()
         _device_sync(torch)
 
+    def keep(o):                                      # (the alignments are views of the stage's own arrays: copied before the stage runs again)
+        if compose:
+            o["alignments"] = tuple(np.array(x) for x in o["alignments"]); o["broken"] = np.array(o["broken"])
+        return o
+
     def run_lane(which, timing, outs):
         for b in which:
             tm = {} if timing is not None else None
-            o = stages[b].run(threads=lane_threads, timing=tm)
+            o = stages[b].run(threads=lane_threads, timing=tm, compose=compose)
             with lock:
                 outs[b] = o
                 if timing is not None:
@@ -490,6 +498,7 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
         outs = one_step()
     timing = {}
     elapsed, outs = timed(args.steps, timing)
+    outs = [keep(o) for o in outs]
     out = outs[0]
     one_lane = None
     if n_lanes > 1:                                  # the same batches one after the other in one lane, for the record
@@ -515,19 +524,44 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
         cores = shard.usable_cpus()
         ctypes.CDLL(os.path.join(ROOT, "oracle", "libvgoracle.so")).vgo_set_threads(cores)
         same = b_same = differing = higher = 0; tc = 0.0
+        aln_same = aln_other_route = n_mappings = n_edit_runs = broken = 0
+
+        def same_alignments(x, y):
+            """per read: is the composed alignment of x the one of y — status, every mapping (node, offset), every edit run"""
+            (rx, mx, ex), (ry, my, ey) = x["alignments"], y["alignments"]
+            hdr = np.ones(len(rx), dtype=bool)
+            for f in ("status", "n_mappings", "n_edits", "from_length", "to_length"):
+                hdr &= rx[f] == ry[f]
+            if hdr.all() and mx.tobytes() == my.tobytes() and ex.tobytes() == ey.tobytes():      # same sizes -> same offsets: the dense arrays compare as wholes
+                return hdr
+            for r in np.nonzero(hdr)[0]:
+                a = mx[int(rx["mapping_begin"][r]):int(rx["mapping_begin"][r]) + int(rx["n_mappings"][r])].copy(); a["edit_begin"] -= rx["edit_begin"][r]
+                c = my[int(ry["mapping_begin"][r]):int(ry["mapping_begin"][r]) + int(ry["n_mappings"][r])].copy(); c["edit_begin"] -= ry["edit_begin"][r]
+                hdr[r] = a.tobytes() == c.tobytes() and ex[int(rx["edit_begin"][r]):int(rx["edit_begin"][r]) + int(rx["n_edits"][r])].tobytes() == ey[int(ry["edit_begin"][r]):int(ry["edit_begin"][r]) + int(ry["n_edits"][r])].tobytes()
+            return hdr
         for b in range(n_batches):                    # every batch of the step against the same stage over the oracle
             ora = pipeline.ChainStage(wls[b], lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
-            t1 = time.perf_counter(); o = ora.run(threads=cores); tc += time.perf_counter() - t1
-            ora.close()
+            t1 = time.perf_counter(); o = ora.run(threads=cores, compose=compose); tc += time.perf_counter() - t1
             diff = o["chain_score"] != outs[b]["chain_score"]
-            same += int((~diff).sum()); differing += int(diff.sum()); higher += int((outs[b]["chain_score"][diff] > o["chain_score"][diff]).sum())
+            if compose:
+                ok = same_alignments(outs[b], o)
+                # a link that took another route in the engine (its tables declined it: DP over the local graph, not bound to haplotypes) may be aligned differently
+                route = np.bincount(wls[b].read_of, weights=(o["link_source"] != outs[b]["link_source"]), minlength=per) > 0
+                aln_same += int((ok & ~diff).sum()); aln_other_route += int((~ok & route).sum())
+                diff = diff | (~ok & ~route)
+                n_mappings += len(outs[b]["alignments"][1]); n_edit_runs += len(outs[b]["alignments"][2]); broken += int(outs[b]["broken"].sum())
+            ora.close()
+            same += int((~diff).sum()) if not compose else int((ok & ~diff).sum()); differing += int(diff.sum()); higher += int((outs[b]["chain_score"][diff] > o["chain_score"][diff]).sum())
             b_same += int((o["chain_score"] == b_outs[b]["chain_score"]).sum())
         cpu = {"value": n / tc, "unit": "reads/s", "cores": cores, "kind": "port", "impl": "the same stage (vgh_chain_stage) bound to the oracle: vgo_wfa.c, vgo_banded.c, vgo_xdrop.c (OpenMP over problems)",
                "sample": "all %d reads" % n}
         parity = {"checked": n, "identical": same, "wfa_point_budget": "none", "differing_reads": differing,
                   "differing_reads_where_the_engine_scores_higher": higher,
                   "identical_with_point_budgets": b_same,
-                  "what": "per-read chain score (anchors + every link), every batch of the step.  No point budget: a link leaves the WFA route only when the engine's tables decline it (VGK_ETOOBIG), "
+                  "composed_alignments": {"identical": aln_same, "reads_with_a_link_on_another_route_and_another_alignment": aln_other_route, "mappings": n_mappings, "edit_runs": n_edit_runs, "broken_chains": broken} if compose else None,
+                  "what": ("per read: the chain score (anchors + every link) AND the composed alignment — every mapping (node, offset) and every edit run of find_chain_alignment's "
+                           "simplified Path, stitched on the device inside the timed region — against the same stage bound to the oracle, every batch of the step.  " if compose else "") +
+                          "per-read chain score (anchors + every link), every batch of the step.  No point budget: a link leaves the WFA route only when the engine's tables decline it (VGK_ETOOBIG), "
                           "which the oracle's WFA (no tables) never does; such a link takes align_sequence_between, which is not bound to haplotypes and can only score "
                           "as high or higher"}
     wfa_ms = float(np.mean([o["wfa_kernel_ms"] or 0.0 for o in outs]))
@@ -544,7 +578,8 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
                        "one_lane": one_lane, "ms_per_batch": 1e3 * elapsed / args.steps / n_batches,
                        "timed_region": "per batch, from host buffers, one vgh_chain_stage call: vgk_wfa_extend over every link; for the declined links extract_connecting_graph / "
                                        "extract_extending_graph on the haplotype graph, strand split, dagify_from, tip trimming (host threads); one flush of banded-global / pinned X-drop problems; "
-                                       "translation back to the base graph; per-read totals",
+                                       "translation back to the base graph; per-read totals" + ("; the pieces of every read (anchors, WFA results in HBM, the DP route's Paths) composed into one alignment "
+                                       "per read on the device (vgk_chain_stitch: to_path, append_path, simplify) and brought to the host" if compose else " (scores only: VGAMD_LONGREAD_SCORES_ONLY)"),
                        "problems": n_links, "problems_per_read": n_links / n, "read_bases": read_bases, "bases_per_s": read_bases * world * args.steps / elapsed,
                        "links": stats_sum(outs), "host_threads": threads,
                        "stage_ms_per_batch": {k: 1e3 * v / args.steps / n_batches for k, v in timing.items()}, "wfa_kernel_ms": wfa_ms, "wfa_launches_of_batch_0": out["wfa_launches"],

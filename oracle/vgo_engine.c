@@ -33,7 +33,9 @@ int vgo_wfa_one(const vgk_scoring* sc, const vgk_haplo* h, const vgk_wfa_error_m
 int vgo_gssw_pinned_multi(const vgk_scoring* sc, const vgk_qual_adj* qa, const vgk_gssw_problem* p, uint32_t max_alt_alns,
                           vgk_result** results_out, uint32_t* n_out, vgk_op** ops_out, uint32_t* n_ops_out);
 
-struct vgk_ctx { vgk_scoring sc; int has_qa; vgk_qual_adj qa; int8_t qmat[256 * 25]; int8_t qbon[256]; };
+struct vgk_ctx { vgk_scoring sc; int has_qa; vgk_qual_adj qa; int8_t qmat[256 * 25]; int8_t qbon[256];
+                 /* what the last vgk_wfa_extend call answered, in problem order: vgk_chain_stitch's LINK pieces name these */
+                 vgk_wfa_result* wfa_res; uint32_t* wfa_paths; uint32_t* wfa_edits; uint32_t wfa_n; const vgk_haplo* wfa_index; };
 
 static int vgo_dispatch(const vgk_ctx* c, const vgk_gssw_problem* p, vgk_result* res, vgk_op* ops, uint32_t ops_cap) {
     const vgk_qual_adj* qa = c->has_qa ? &c->qa : NULL;
@@ -83,7 +85,7 @@ int vgk_create_qual_adj(int device, const vgk_scoring* scoring, const vgk_qual_a
     (*out)->has_qa = 1; (*out)->qa.matrix = (*out)->qmat; (*out)->qa.bonuses = (*out)->qbon;
     return VGK_OK;
 }
-void vgk_destroy(vgk_ctx* ctx) { free(ctx); }
+void vgk_destroy(vgk_ctx* ctx) { if (ctx) { free(ctx->wfa_res); free(ctx->wfa_paths); free(ctx->wfa_edits); } free(ctx); }
 
 int vgk_host_register(vgk_ctx* ctx, const void* ptr, size_t bytes) { (void)ctx; (void)ptr; (void)bytes; return VGK_OK; }
 int vgk_host_unregister(vgk_ctx* ctx, const void* ptr) { (void)ctx; (void)ptr; return VGK_OK; }
@@ -326,6 +328,23 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     for (uint32_t i = 0; i < n; ++i) vgo_wfa_one(&ctx->sc, index, model, &problems[i], &results[i], &tp[i], &te[i]);
     size_t np = 0, ne = 0; int rc = VGK_OK;
     const int scores_only = !paths && !edits && !path_cap && !edit_cap;           /* (include/vgk.h: results without paths and edit runs) */
+    {   /* the call's alignments stay with the context (the engine keeps them in HBM) for vgk_chain_stitch */
+        size_t tp_all = 0, te_all = 0;
+        for (uint32_t i = 0; i < n; ++i) if (results[i].status == VGK_OK && results[i].ok) { tp_all += results[i].path_len; te_all += results[i].n_edits; }
+        free(ctx->wfa_res); free(ctx->wfa_paths); free(ctx->wfa_edits);
+        ctx->wfa_res = (vgk_wfa_result*)malloc(sizeof(vgk_wfa_result) * ((size_t)n + 1)); ctx->wfa_paths = (uint32_t*)malloc(sizeof(uint32_t) * (tp_all + 1));
+        ctx->wfa_edits = (uint32_t*)malloc(sizeof(uint32_t) * (te_all + 1)); ctx->wfa_n = n; ctx->wfa_index = index;
+        size_t kp = 0, ke = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            vgk_wfa_result r = results[i];
+            if (r.status != VGK_OK || !r.ok) { r.ok = 0; r.path_len = r.n_edits = 0; }
+            r.path_begin = (uint32_t)kp; r.edit_begin = (uint32_t)ke;
+            for (uint32_t k = 0; k < r.path_len; ++k) ctx->wfa_paths[kp + k] = (uint32_t)tp[i][k];
+            if (r.n_edits) memcpy(ctx->wfa_edits + ke, te[i], sizeof(uint32_t) * r.n_edits);
+            kp += r.path_len; ke += r.n_edits;
+            ctx->wfa_res[i] = r;
+        }
+    }
     for (uint32_t i = 0; i < n; ++i) {
         vgk_wfa_result* r = &results[i];
         if (scores_only) { if (r->status != VGK_OK) r->ok = 0; r->path_begin = r->path_len = r->edit_begin = r->n_edits = 0; free(tp[i]); free(te[i]); continue; }
@@ -339,6 +358,40 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     }
     free(tp); free(te);
     if (written) { written[0] = np; written[1] = ne; }
+    return rc;
+}
+
+/* vgk_chain_stitch: read by read through vgo_chain.c */
+int vgo_chain_stitch_one(const vgk_haplo* index, const vgk_chain_piece* pieces, uint64_t n_pieces, const uint32_t* nodes, size_t n_nodes,
+                         const vgk_chain_mapping* mappings, size_t n_mappings, const uint32_t* edits, size_t n_edits,
+                         const vgk_wfa_result* link_res, const uint32_t* link_paths, const uint32_t* link_edits, uint32_t n_links,
+                         vgk_chain_result* res, vgk_chain_mapping** out_m, uint32_t** out_e);
+double vgk_chain_stitch_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }
+int vgk_chain_stitch(vgk_ctx* ctx, const vgk_haplo* index, const vgk_chain_piece* pieces, const uint64_t* piece_off, uint32_t n_reads,
+                     const uint32_t* nodes, size_t n_nodes, const vgk_chain_mapping* mappings, size_t n_mappings, const uint32_t* edits, size_t n_edits,
+                     vgk_chain_result* results, vgk_chain_mapping* out_mappings, size_t mapping_cap, uint32_t* out_edits, size_t edit_cap, size_t written[2]) {
+    if (!ctx || !index || !piece_off || (!results && n_reads) || (!pieces && n_reads && piece_off[n_reads]) || (!nodes && n_nodes) || (!mappings && n_mappings) || (!edits && n_edits)
+        || (!out_mappings && mapping_cap) || (!out_edits && edit_cap)) return VGK_EINVAL;
+    for (uint32_t r = 0; r < n_reads; ++r) if (piece_off[r + 1] < piece_off[r]) return VGK_EINVAL;
+    vgk_chain_mapping** tm = (vgk_chain_mapping**)calloc((size_t)n_reads + 1, sizeof *tm); uint32_t** te = (uint32_t**)calloc((size_t)n_reads + 1, sizeof *te);
+    const uint32_t n_links = ctx->wfa_index == index ? ctx->wfa_n : 0;
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (uint32_t r = 0; r < n_reads; ++r)
+        vgo_chain_stitch_one(index, pieces + piece_off[r], piece_off[r + 1] - piece_off[r], nodes, n_nodes, mappings, n_mappings, edits, n_edits,
+                             ctx->wfa_res, ctx->wfa_paths, ctx->wfa_edits, n_links, &results[r], &tm[r], &te[r]);
+    size_t nm = 0, ne = 0; int rc = VGK_OK;
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        vgk_chain_result* o = &results[r];
+        o->mapping_begin = (uint32_t)nm; o->edit_begin = (uint32_t)ne;
+        if (nm + o->n_mappings <= mapping_cap && ne + o->n_edits <= edit_cap) {
+            for (uint32_t k = 0; k < o->n_mappings; ++k) { out_mappings[nm + k] = tm[r][k]; out_mappings[nm + k].edit_begin += (uint32_t)ne; }
+            if (o->n_edits) memcpy(out_edits + ne, te[r], sizeof(uint32_t) * o->n_edits);
+        } else { if (o->status == VGK_OK) o->status = VGK_EOPS; rc = VGK_EOPS; }
+        nm += o->n_mappings; ne += o->n_edits;
+        free(tm[r]); free(te[r]);
+    }
+    free(tm); free(te);
+    if (written) { written[0] = nm; written[1] = ne; }
     return rc;
 }
 

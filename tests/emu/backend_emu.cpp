@@ -179,6 +179,11 @@ public:
         if (P.pass == 1) { for (uint32_t i = P.lo; i < P.hi; ++i) minimizer_one(P, i); } else for (uint32_t i = 0; i < P.n; ++i) minimizer_one(P, i);
         return VGK_OK;
     }
+    int run_chain_stitch(const CsParams& P, int what) override {
+        if (what == CS_GATHER) { for (uint32_t r = 0; r < P.n_reads; ++r) for (uint32_t l = 0; l < 64; ++l) cs_gather_one(P, r, l, 64); }
+        else for (uint32_t r = 0; r <= P.n_reads; ++r) cs_one(P, what, r);
+        return VGK_OK;
+    }
     int run_rescue_requests(const RqParams& P, int what) override {
         if (what == RQ_FLAG) { for (uint32_t p = 0; p <= P.n_pairs; ++p) rq_flag_one(P, p); } else { for (uint32_t p = 0; p < P.n_pairs; ++p) rq_emit_one(P, p); }
         return VGK_OK;

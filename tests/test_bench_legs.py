@@ -75,5 +75,7 @@ def test_longread_leg_on_the_emulated_kernels(emu_lib):
     assert d["unit"] == "reads/s" and {"bound", "achieved", "peak", "frac", "traffic"} <= set(d["roofline"])
     p = d["parity"]
     assert p["checked"] == 12 and p["identical"] == 12 and p["differing_reads"] == 0
+    assert p["composed_alignments"]["identical"] == 12 and p["composed_alignments"]["mappings"] > 12 * 300 and p["composed_alignments"]["broken_chains"] == 0 and "every edit run" in p["what"]
+    assert "one alignment per read: pieces + vgk_chain_stitch" in d["config"]["stage_ms_per_batch"]
     c = d["config"]
     assert "2 lanes" in c["batches"] and c["one_lane"]["ms_per_batch"] > 0 and c["links"]["failed"] == 0 and d["problems_failed"] == 0

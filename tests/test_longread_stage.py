@@ -74,7 +74,7 @@ def test_fallback_batch_picked_from_flat_connects_on_the_gpu():
 
 
 # ---- the stage in the host shim (vg_amd/host/chain_stage.cpp): one call, the local graphs extracted inside it -------------------------
-def native_stage(lib, n_reads, read_len, seed, sv, budgets=None, threads=3):
+def native_stage(lib, n_reads, read_len, seed, sv, budgets=None, threads=3, compose=False):
     """ChainStage (C++: WFA, then align_sequence_between_consistently for what WFA declines) on `lib` and on the oracle -> both outputs"""
     wl = workloads.LongReadWorkload(n_reads, seed=seed, graph_bp=150_000, read_len=read_len, sv_fraction=sv)
     outs = []
@@ -82,7 +82,10 @@ def native_stage(lib, n_reads, read_len, seed, sv, budgets=None, threads=3):
         cs = pipeline.ChainStage(wl, lib=which)
         if budgets and which != ORACLE_LIB:
             cs.set_point_budgets(*budgets)
-        outs.append(cs.run(threads=threads))
+        o = cs.run(threads=threads, compose=compose)
+        if compose:                                   # (views of the stage's arrays: copied before it goes)
+            o["alignments"] = tuple(np.array(x) for x in o["alignments"]); o["broken"] = np.array(o["broken"])
+        outs.append(o)
         cs.close()
     return wl, outs[0], outs[1]
 
@@ -119,6 +122,126 @@ def test_native_chain_stage_equals_the_python_pipeline(emu_lib):
     old = pipeline.chain_stage(eng, eng.haplo_index(wl.nodes, wl.threads), wl)
     assert len(old["failed"]) == a["stats"]["declined"] > 0
     assert (old["chain_score"] == a["chain_score"]).all()
+
+
+# ---- one alignment per read (find_chain_alignment's composed_path, simplified: vgk_chain_stitch inside the stage) ---------------------------------
+def read_sequences(wl):
+    """every read spelled out: its links' sequences and, between them, its anchors' bases read off their node paths"""
+    comp = str.maketrans("ACGT", "TGCA")
+
+    def oriented_seq(o):
+        s = wl.nodes[o >> 1]
+        return s[::-1].translate(comp) if o & 1 else s
+    mode = wl.ws.array["mode"]; reads = []
+    link = 0
+    for r in range(wl.n_reads):
+        parts = []; a = int(wl.anchor_off[r]); a_end = int(wl.anchor_off[r + 1])
+
+        def anchor(a):
+            path = wl.anchor_nodes[int(wl.anchor_path_off[a]):int(wl.anchor_path_off[a + 1])]
+            s = "".join(oriented_seq(int(o)) for o in path)
+            return s[int(wl.anchor_node_offset[a]):int(wl.anchor_node_offset[a]) + int(wl.anchor_length[a])]
+        first = link
+        while link < wl.n and wl.read_of[link] == r:
+            link += 1
+        if mode[first] != capi.WFA_PREFIX:
+            parts.append(anchor(a)); a += 1
+        for i in range(first, link):
+            parts.append(wl.ws.seqs[wl.ws.seq_off[i]:wl.ws.seq_off[i + 1]].tobytes().decode())
+            if mode[i] != capi.WFA_SUFFIX:
+                parts.append(anchor(a)); a += 1
+        assert a == a_end
+        reads.append("".join(parts))
+    return reads
+
+
+def check_alignment_against_graph(wl, read, res, maps, edits, r):
+    """the composed alignment of read r walks real graph bases: every match run matches, every mismatch base differs, the read is covered end to
+    end, a mapping stays inside its node, and consecutive mappings either continue on one node or follow an edge some thread crosses"""
+    comp = str.maketrans("ACGT", "TGCA")
+    crossed = wl.__dict__.setdefault("_crossed", None)
+    if crossed is None:
+        crossed = set()
+        for t in wl.threads:
+            for x, y in zip(t[:-1], t[1:]):
+                crossed.add((int(x), int(y))); crossed.add((int(y) ^ 1, int(x) ^ 1))
+        wl._crossed = crossed
+    at = 0; prev = None
+    assert res["status"][r] == 0 and res["to_length"][r] == len(read)
+    for k in range(int(res["mapping_begin"][r]), int(res["mapping_begin"][r]) + int(res["n_mappings"][r])):
+        m = maps[k]; node = int(m["node"])
+        runs = [(int(e) & 3, int(e) >> 2) for e in edits[int(m["edit_begin"]):int(m["edit_begin"]) + int(m["n_edits"])]]
+        assert runs and all(l > 0 for _, l in runs) and all(a[0] != b[0] for a, b in zip(runs[:-1], runs[1:])), (r, k, runs)     # no empty mapping, no empty run, runs of one kind merged
+        if node == capi.WFA_NO_NODE:
+            assert all(kind == capi.WFA_INSERTION for kind, _ in runs)
+            at += sum(l for _, l in runs); continue
+        s = wl.nodes[node >> 1]
+        s = s[::-1].translate(comp) if node & 1 else s
+        g = int(m["offset"])
+        if prev is not None:
+            assert (prev[0] == node and prev[1] < g + 1) or (prev[0], node) in crossed or prev[1] != prev[2] or g != 0, (r, k, prev, node, g)
+        for kind, l in runs:
+            if kind == capi.WFA_MATCH:
+                assert s[g:g + l] == read[at:at + l], (r, k, kind, l)
+                g += l; at += l
+            elif kind == capi.WFA_MISMATCH:
+                assert len(s) >= g + l and all(x != y for x, y in zip(s[g:g + l], read[at:at + l])), (r, k, kind, l)
+                g += l; at += l
+            elif kind == capi.WFA_INSERTION:
+                at += l
+            else:
+                g += l
+        assert g <= len(s)
+        prev = (node, g, len(s))
+    assert at == len(read)
+
+
+def same_alignments(a, b, reads):
+    ra, ma, ea = a["alignments"]; rb, mb, eb = b["alignments"]
+    same = 0
+    for r in reads:
+        x = (ma[int(ra["mapping_begin"][r]):int(ra["mapping_begin"][r]) + int(ra["n_mappings"][r])], ea[int(ra["edit_begin"][r]):int(ra["edit_begin"][r]) + int(ra["n_edits"][r])])
+        y = (mb[int(rb["mapping_begin"][r]):int(rb["mapping_begin"][r]) + int(rb["n_mappings"][r])], eb[int(rb["edit_begin"][r]):int(rb["edit_begin"][r]) + int(rb["n_edits"][r])])
+        fx = x[0].copy(); fx["edit_begin"] -= ra["edit_begin"][r]; fy = y[0].copy(); fy["edit_begin"] -= rb["edit_begin"][r]
+        same += int(ra["status"][r] == rb["status"][r] and fx.tobytes() == fy.tobytes() and x[1].tobytes() == y[1].tobytes()
+                    and ra["from_length"][r] == rb["from_length"][r] and ra["to_length"][r] == rb["to_length"][r])
+    return same
+
+
+def check_composed(wl, a, b):
+    reads = read_sequences(wl)
+    ra, ma, ea = a["alignments"]
+    for r in range(wl.n_reads):
+        check_alignment_against_graph(wl, reads[r], ra, ma, ea, r)
+    # reads whose links all took the same route in both engines (the DP route is not bound to haplotypes): the same alignment, op for op
+    route = np.bincount(wl.read_of, weights=(a["link_source"] != b["link_source"]), minlength=wl.n_reads) == 0
+    idx = np.nonzero(route)[0]
+    assert same_alignments(a, b, idx) == len(idx) > 0
+    assert not a["broken"].any() and not b["broken"].any()
+    return len(idx)
+
+
+def test_native_chain_stage_composes_the_oracles_alignments(emu_lib):
+    wl, a, b = native_stage(emu_lib, 6, 2500, 4, 0.0, compose=True)
+    assert check_composed(wl, a, b) == 6
+    assert (a["chain_score"] == b["chain_score"]).all()
+
+
+def test_native_chain_stage_composes_alignments_with_declined_links(emu_lib):
+    """links WFA declines are answered by align_sequence_between: their Paths (BandedGlobalAligner's mappings, translated back) join the WFA pieces"""
+    wl, a, b = native_stage(emu_lib, 4, 2500, 6, 0.2, budgets=(48, 48), compose=True)
+    assert a["stats"]["between"] >= 4
+    check_composed(wl, a, b)
+    # the engine's stage and the oracle's took different routes for those links; the same stage on the emulated engine WITHOUT budgets is the oracle's route
+    wl, c, d = native_stage(emu_lib, 4, 2500, 6, 0.2, compose=True)
+    assert check_composed(wl, c, d) >= 3
+
+
+@pytest.mark.gpu
+def test_native_chain_stage_composes_alignments_on_the_gpu():
+    wl, a, b = native_stage(ENGINE_LIB, 120, 15000, 5, 0.02, threads=8, compose=True)
+    assert check_composed(wl, a, b) >= 110
+    assert (a["chain_score"] >= b["chain_score"]).all()
 
 
 @pytest.mark.gpu

@@ -64,7 +64,13 @@ WFA_CONNECT, WFA_SUFFIX, WFA_PREFIX = 0, 1, 2
 WFA_MATCH, WFA_MISMATCH, WFA_INSERTION, WFA_DELETION = 0, 1, 2, 3
 WFA_NO_NODE = 0xffffffff
 WFA_DEFAULT_MODEL = ((0.03, 1, 6), (0.05, 1, 10), (0.1, 1, 20), (0.1, 10, 200))      # gbwt_extender.hpp:386-395
+# vgk_chain_stitch (include/vgk.h): pieces of a read's chain in, one composed alignment per read out
+CHAIN_PIECE_DT = np.dtype([("kind", "<u4"), ("link", "<u4"), ("node_offset", "<u4"), ("path_begin", "<u4"), ("path_len", "<u4"), ("edit_begin", "<u4"), ("n_edits", "<u4"), ("reserved", "<u4")])
+CHAIN_MAPPING_DT = np.dtype([("node", "<u4"), ("offset", "<u4"), ("edit_begin", "<u4"), ("n_edits", "<u4")])
+CHAIN_RESULT_DT = np.dtype([("status", "<i4"), ("mapping_begin", "<u4"), ("n_mappings", "<u4"), ("edit_begin", "<u4"), ("n_edits", "<u4"), ("from_length", "<u4"), ("to_length", "<u4"), ("reserved", "<u4")])
+PIECE_LINK, PIECE_ALIGNMENT, PIECE_PATH = 0, 1, 2
 assert WFA_DT.itemsize == 32 and WFA_RESULT_DT.itemsize == 40 and WFA_EVENT_DT.itemsize == 16
+assert CHAIN_PIECE_DT.itemsize == 32 and CHAIN_MAPPING_DT.itemsize == 16 and CHAIN_RESULT_DT.itemsize == 32
 assert GAPLESS_DT.itemsize == 40 and EXT_DT.itemsize == 60 and GAPLESS_RESULT_DT.itemsize == 16
 assert BANDED_DT.itemsize == 80
 assert GRAPH_DT.itemsize == 40 and PROBLEM_DT.itemsize == 80 and RESULT_DT.itemsize == 32 and OP_DT.itemsize == 8
@@ -136,6 +142,8 @@ def load_library(path=None):
     lib.vgk_banded_rerun.argtypes = [vp]
     lib.vgk_gapless_rerun.argtypes = [vp]
     lib.vgk_wfa_extend.argtypes = [vp, vp, vp, vp, u32, vp, vp, sz, vp, sz, ctypes.POINTER(sz * 2)]
+    lib.vgk_chain_stitch.argtypes = [vp, vp, vp, vp, u32, vp, sz, vp, sz, vp, sz, vp, vp, sz, vp, sz, ctypes.POINTER(sz * 2)]
+    lib.vgk_chain_stitch_last_ms.restype = ctypes.c_double; lib.vgk_chain_stitch_last_ms.argtypes = [vp]
     lib.vgk_wfa_rerun.argtypes = [vp]
     lib.vgk_wfa_last_ms.restype = ctypes.c_double
     lib.vgk_wfa_last_ms.argtypes = [vp]
@@ -624,6 +632,32 @@ class Engine:
                                             res.ctypes.data, paths.ctypes.data, ws.path_cap, edits.ctypes.data, ws.edit_cap,
                                             ctypes.byref(written)), "vgk_wfa_extend")
         return res, paths[:written[0]], edits[:written[1]]
+
+    def chain_stitch(self, index, pieces, piece_off, nodes=None, mappings=None, edits=None, mapping_cap=None, edit_cap=None):
+        """vgk_chain_stitch: pieces (CHAIN_PIECE_DT; LINK pieces name results of the last wfa_extend on this engine with `index`), piece_off (n_reads + 1),
+        the arrays ALIGNMENT / PATH pieces point into -> (results CHAIN_RESULT_DT, mappings CHAIN_MAPPING_DT, edits uint32: length << 2 | WFA_*).
+        Without caps the call is made twice when the first guess is too small."""
+        pieces = np.ascontiguousarray(pieces, dtype=CHAIN_PIECE_DT); piece_off = np.ascontiguousarray(piece_off, dtype=np.uint64)
+        nodes = np.ascontiguousarray(nodes if nodes is not None else [], dtype=np.uint32)
+        mappings = np.ascontiguousarray(mappings if mappings is not None else [], dtype=CHAIN_MAPPING_DT)
+        edits = np.ascontiguousarray(edits if edits is not None else [], dtype=np.uint32)
+        n = len(piece_off) - 1
+        res = np.zeros(n, dtype=CHAIN_RESULT_DT)
+        retry = mapping_cap is None and edit_cap is None
+        mcap = mapping_cap if mapping_cap is not None else 4 * len(pieces) + len(nodes) + len(mappings) + 16
+        ecap = edit_cap if edit_cap is not None else 4 * len(pieces) + len(nodes) + len(edits) + 16
+        while True:
+            om = np.zeros(mcap, dtype=CHAIN_MAPPING_DT); oe = np.zeros(ecap, dtype=np.uint32)
+            written = (ctypes.c_size_t * 2)()
+            rc = self.lib.vgk_chain_stitch(self.h, index.h, pieces.ctypes.data if len(pieces) else None, piece_off.ctypes.data, n, nodes.ctypes.data if len(nodes) else None, len(nodes),
+                                           mappings.ctypes.data if len(mappings) else None, len(mappings), edits.ctypes.data if len(edits) else None, len(edits),
+                                           res.ctypes.data, om.ctypes.data, mcap, oe.ctypes.data, ecap, ctypes.byref(written))
+            if rc == VGK_EOPS and retry:
+                mcap, ecap, retry = int(written[0]) + 1, int(written[1]) + 1, False
+                continue
+            if rc != VGK_EOPS:
+                self._check(rc, "vgk_chain_stitch")
+            return res, om[:min(written[0], mcap)], oe[:min(written[1], ecap)]
 
     def wfa_set_cost_hints(self, extra_bases):
         """vgk_wfa_set_cost_hints: per problem of the NEXT wfa_extend, bases to add to its length when the hand-out order is made (order only)"""

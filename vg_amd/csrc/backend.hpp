@@ -20,6 +20,7 @@
 #include "minimizer_device.hpp"
 #include "gssw_wide_device.hpp"
 #include "rescue_requests_device.hpp"
+#include "chain_device.hpp"
 
 namespace vgk {
 
@@ -152,6 +153,7 @@ public:
     virtual int   run_tail(const TailParams& p, uint32_t threads) = 0;
     virtual int   run_tail_stage(const TStageParams& p, int what) = 0;     // one of the per-item stages of vgk_tail_stage (tail_device.hpp: TS_*)
     virtual int   run_rescue_requests(const RqParams& p, int what) = 0;    // one of the per-pair stages of vgk_rescue_requests (rescue_requests_device.hpp: RQ_*)
+    virtual int   run_chain_stitch(const CsParams& p, int what) = 0;       // one of the stages of vgk_chain_stitch (chain_device.hpp: CS_*), asynchronous on the main stream
     virtual int   scan_u32(const uint32_t* in, uint32_t* out, uint32_t n) = 0;
     virtual int   forest_flags(const ForestParams& p) = 0;
     virtual int   forest_emit(const ForestParams& p) = 0;

@@ -774,6 +774,14 @@ __global__ void __launch_bounds__(256) rescue_requests_kernel(const RqParams P, 
     if (what == RQ_FLAG) { if (p <= P.n_pairs) rq_flag_one(P, p); }
     else if (p < P.n_pairs) rq_emit_one(P, p);
 }
+// ---- one Path per read (chain_device.hpp): a lane per read for the bounds and the composition, a wavefront per read for the dense copy
+__global__ void __launch_bounds__(64) chain_stitch_kernel(const CsParams P, const int what) {
+    cs_one(P, what, blockIdx.x * 64 + threadIdx.x);
+}
+__global__ void __launch_bounds__(256) chain_gather_kernel(const CsParams P) {
+    const uint32_t r = blockIdx.x * 4 + threadIdx.x / 64;
+    if (r < P.n_reads) cs_gather_one(P, r, threadIdx.x & 63u, 64);
+}
 __global__ void __launch_bounds__(256) forest_flags_kernel(const ForestParams P) {
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     if (v < P.n_nodes) forest_flags_one(P, v);
@@ -1553,6 +1561,12 @@ public:
         const uint32_t items = tstage_items(p, what);
         if (!items) return VGK_OK;
         hipLaunchKernelGGL(tail_stage_kernel, dim3((items + 255) / 256), dim3(256), 0, stream, p, what, items);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int run_chain_stitch(const CsParams& p, int what) override {
+        hipSetDevice(dev);
+        if (what == CS_GATHER) hipLaunchKernelGGL(chain_gather_kernel, dim3((p.n_reads + 3) / 4), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(chain_stitch_kernel, dim3((p.n_reads + 64) / 64), dim3(64), 0, stream, p, what);
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_rescue_requests(const RqParams& p, int what) override {

@@ -187,7 +187,7 @@ VGK_HD void cs_stitch_one(const CsParams& P, uint32_t r) {
             for (uint32_t q = 0; q < pc.path_len && S.status == VGK_OK; ++q) {
                 const vgk_chain_mapping m = P.mappings[pc.path_begin + q];
                 if ((uint64_t)m.edit_begin + m.n_edits > P.n_edits || (m.node != VGK_WFA_NO_NODE && m.node >= P.index.n_oriented)) { S.status = VGK_EINVAL; break; }
-                cs_open(S, m.node, m.offset);
+                cs_open(S, m.node, m.node == VGK_WFA_NO_NODE ? 0u : m.offset);          // (a mapping without a position has no offset)
                 for (uint32_t x = 0; x < m.n_edits; ++x) cs_edit(S, cs_kind(P.edits[m.edit_begin + x]), cs_len(P.edits[m.edit_begin + x]));
                 cs_close(S);
             }
@@ -237,6 +237,12 @@ VGK_HD void cs_gather_one(const CsParams& P, uint32_t r, uint32_t lane, uint32_t
         if (!fits && o.status == VGK_OK) o.status = VGK_EOPS;
         P.out_res[r] = o;
     }
+}
+
+// what one lane does in stage `what`: item r of n_reads + 1 (the bounds' and sizes' last entries are 0: the prefix sums' totals land there)
+VGK_HD void cs_one(const CsParams& P, int what, uint32_t r) {
+    if (what == CS_BOUND) { if (r <= P.n_reads) cs_bound_one(P, r); }
+    else if (what == CS_STITCH) { if (r < P.n_reads) cs_stitch_one(P, r); else if (r == P.n_reads) { P.count[r] = 0; P.count[(size_t)P.n_reads + 1 + r] = 0; } }
 }
 
 }  // namespace vgk

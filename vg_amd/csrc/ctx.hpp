@@ -104,11 +104,16 @@ struct vgk_ctx {
     vgk::WwParams wfa_wave_last[2] = {}; uint32_t wfa_wave_waves[2] = {0, 0}; bool wfa_wave_last_valid = false;    // the wavefront form: small-table launch, large-table launch
     double wfa_wave_ms[2] = {0, 0}; uint64_t wfa_wave_retried = 0;
     bool wfa_at_once = false;            // the last hybrid call ran its two kernels at once (vgk_wfa_rerun does the same)
+    // what the last vgk_wfa_extend call left in HBM — results in problem order, node paths and edit runs in completion order — for vgk_chain_stitch's LINK pieces
+    struct WfaOut { bool valid = false; uint32_t n = 0; const vgk_wfa_result* res = nullptr; const uint32_t* paths = nullptr; const uint32_t* edits = nullptr;
+                    uint64_t path_cap = 0, edit_cap = 0; const void* index = nullptr; } wfa_out;
+    double chain_stitch_ms = 0;          // device time of the last vgk_chain_stitch call
+    std::shared_ptr<void> chain_host;    // host staging arenas of chain_api.cpp
     std::vector<uint32_t> wfa_cost_hints;   // vgk_wfa_set_cost_hints: per problem of the NEXT vgk_wfa_extend, bases to add to its length when the hand-out order is made
     uint64_t multi_host_walks = 0;       // problems of the last vgk_gssw_align_multi whose alternates a host thread walked
     // device scratch kept between vgk_banded_align calls (grow-only; released with the context)
     struct DevBuf { void* p = nullptr; uint64_t bytes = 0; };
-    DevBuf scratch[160];           // 88..99 gssw_wide_api.cpp; 65 wfa_api.cpp (producers_done); 72..83 gssw_multi_api.cpp (the walk on the device); 0..14 + 31 banded_api.cpp (+ 124..138: its second sub-batch in flight), 15..30 + 59, 60 gapless_api.cpp, 32..39 + 61..63 wfa_api.cpp, 40..47 gssw_multi_api.cpp / xdrop_band_api.cpp (+ 48, 49, 87; its second sub-batch in flight: 100..123), 50..54 tail_api.cpp, 55..58 minimizer_api.cpp
+    DevBuf scratch[160];           // 140..149 chain_api.cpp; 88..99 gssw_wide_api.cpp; 65 wfa_api.cpp (producers_done); 72..83 gssw_multi_api.cpp (the walk on the device); 0..14 + 31 banded_api.cpp (+ 124..138: its second sub-batch in flight), 15..30 + 59, 60 gapless_api.cpp, 32..39 + 61..63 wfa_api.cpp, 40..47 gssw_multi_api.cpp / xdrop_band_api.cpp (+ 48, 49, 87; its second sub-batch in flight: 100..123), 50..54 tail_api.cpp, 55..58 minimizer_api.cpp
     void* ensure_scratch(int slot, uint64_t bytes) {
         DevBuf& b = scratch[slot];
         if (b.p && b.bytes >= bytes) return b.p;

@@ -168,6 +168,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     const int32_t match = ctx->sc.matrix[0], mism = -ctx->sc.matrix[1], go = ctx->sc.gap_open, ge = ctx->sc.gap_extend;
     if (match < 0 || mism <= 0 || go < ge || ge <= 0) return VGK_EUNSUPPORTED;                    // (:1256-1259)
     std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->wfa_out.valid = false;
     ctx->wfa_last_valid = false; ctx->wfa_wave_last_valid = false;            // (set again only by a call that got through: vgk_wfa_rerun must never relaunch over released buffers)
     // vgk_wfa_set_cost_hints: taken by THIS call whatever becomes of it (a call that fails below must not leave them to a later one)
     std::vector<uint32_t> hint_store; hint_store.swap(ctx->wfa_cost_hints);
@@ -374,6 +375,8 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
         ctx->wfa_last = P; ctx->wfa_last_threads = threads; ctx->wfa_last_valid = true; ctx->wfa_wave_last_valid = false;
         ctx->wfa_ms = be->last_ms(6);
     }
+    ctx->wfa_out.valid = true; ctx->wfa_out.n = n; ctx->wfa_out.res = P.results; ctx->wfa_out.paths = P.paths; ctx->wfa_out.edits = P.edits;
+    ctx->wfa_out.path_cap = cap_p; ctx->wfa_out.edit_cap = cap_e; ctx->wfa_out.index = index;
     unsigned long long counters[2] = {0, 0};
     vgk_wfa_result* dres = H.dres.get(be, n);
     if (!dres) return VGK_ENOMEM;

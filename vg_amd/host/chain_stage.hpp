@@ -28,14 +28,31 @@ struct ChainStageInput {
     unsigned threads = 0;
     int wfa_form = VGK_WFA_FORM_WAVE;                                   // vgk_wfa_set_form for the stage's WFA call
     bool dp_for_tails = true;                                           // a declined prefix / suffix goes to pinned X-drop (:2713, :3261); false: it scores 0
+    // The anchors themselves, read by read in read order (nullable: scores only).  With them the stage composes ONE alignment per read as
+    // find_chain_alignment does (:2606-3295): left tail, anchor, link, anchor, ..., right tail, each piece's Path appended, the whole simplified
+    // (vgk_chain_stitch, on the device: the WFA paths and edit runs never come down).  A read's links are PREFIX?, CONNECT*, SUFFIX? in read order and
+    // an anchor follows every PREFIX / CONNECT link (and leads the read when it has no PREFIX): anchors of read r = [anchor_off[r], anchor_off[r + 1]).
+    // Anchor a is an exact match of anchor_length[a] bases from anchor_node_offset[a] in the first of the oriented nodes
+    // anchor_nodes[anchor_path_off[a] .. anchor_path_off[a + 1]) (to_wfa_alignment :4083-4104 makes it of one node; several are allowed).
+    const uint64_t* anchor_off = nullptr; const uint32_t* anchor_length = nullptr; const uint32_t* anchor_node_offset = nullptr;
+    const uint64_t* anchor_path_off = nullptr; const uint32_t* anchor_nodes = nullptr;
 };
 struct ChainStageOutput {
-    enum Source : uint8_t { WFA = 0, BETWEEN = 1 /* align_sequence_between */, NONE = 2 /* nothing aligned: scores 0 */ };
+    enum Source : uint8_t { WFA = 0, BETWEEN = 1 /* align_sequence_between */, NONE = 2 /* nothing aligned: scores 0 */,
+                            UNLOCALIZED = 3 /* a connect WFA declined between anchors at graph distance 0: an insertion without a position, score_gap (:2996-3008) */ };
     std::vector<int32_t> link_score; std::vector<uint8_t> link_source;
     std::vector<int32_t> wfa_status;                                    // per link: vgk_wfa_result.status (declined links: VGK_ETOOBIG ...), ok folded in as VGK_ENOBAND when !ok
     std::vector<int64_t> chain_score;                                   // per read
     uint64_t n_declined = 0, n_between = 0, n_no_graph = 0, n_too_big = 0, n_failed = 0;
-    double ms[5] = {0, 0, 0, 0, 0};                                     // wfa call | requests made | local graphs (host threads) | banded + X-drop flush | translation + totals
+    double ms[6] = {0, 0, 0, 0, 0, 0};                                  // wfa call | requests made | local graphs (host threads) | banded + X-drop flush | translation + totals | pieces + vgk_chain_stitch
+    // with anchors: the composed alignments, dense and in read order (include/vgk.h: vgk_chain_result / vgk_chain_mapping / edit runs length << 2 | VGK_WFA_*)
+    std::vector<vgk_chain_result> read_result; std::vector<vgk_chain_mapping> mappings; std::vector<uint32_t> edits;      // mappings / edits: the first n_mappings / n_edits entries count (the vectors keep their room between batches)
+    size_t n_mappings = 0, n_edits = 0;
+    // A read whose chain broke at a link nothing could align (the reference leaves the loop there, :3057 / :3093, and treats the rest of the read as
+    // its right tail): here the rest of the read — that link, every later anchor and link — becomes one insertion without a position (what the
+    // reference makes of a tail beyond max_tail_dp_length, :3217), and the read is flagged
+    std::vector<uint8_t> read_broken; uint64_t n_broken = 0;
+    double stitch_kernel_ms = 0;
 };
 
 // graph: the HandleGraph the index was built over (HaplotypeGraph: node ids in index order).  -> a VGK_* code

@@ -464,7 +464,7 @@ int vgh_gapless_tail_forest(vgh_extender* x, const char* read, const int64_t* se
 }
 
 // ---- WFAExtender (src/gbwt_extender.hpp:346-461) -------------------------------------------------------------------------
-struct vgh_wfa { std::unique_ptr<HaplotypeGraph> graph; WFAExtender::ErrorModel model; std::unique_ptr<WFAExtender> ext; };
+struct vgh_wfa { std::unique_ptr<HaplotypeGraph> graph; WFAExtender::ErrorModel model; std::unique_ptr<WFAExtender> ext; std::shared_ptr<void> chain_out; };
 // model: 4 x (per_base, min, max) for mismatches, gaps, gap_length, distance; nullptr = the default model
 vgh_wfa* vgh_wfa_create(vgh_aligner* a, vgh_graph* g, const int64_t* thread_nodes, const int32_t* thread_off, int n_threads, const double* model) {
     try {
@@ -776,18 +776,27 @@ int vgh_connector_run(vgh_connector* c, int threads, double* ms, char* json_out,
 // ---- the chain stage (chain_stage.hpp): every link of a batch of reads through WFA, the declined ones through align_sequence_between ----
 #include "chain_stage.hpp"
 extern "C" {
-// w: the WFA handle (haplotype graph + index + aligner) of vgh_wfa_create.  stats: declined, between, no graph, too big, failed; ms[5].
+// w: the WFA handle (haplotype graph + index + aligner) of vgh_wfa_create.  stats: declined, between, no graph, too big, failed, broken reads; ms[6].
+// anchors (anchor_off ... anchor_nodes, all or none; chain_stage.hpp): with them one alignment per read is composed (vgk_chain_stitch) and stays with
+// the handle until the next call: sizes = {mappings, edits}; vgh_chain_stage_view hands out the arrays (no copy).
 int vgh_chain_stage(vgh_wfa* w, const char* seqs, const uint64_t* seq_off, uint32_t n_links, const uint32_t* mode, const uint32_t* from_node, const uint32_t* from_offset,
                     const uint32_t* to_node, const uint32_t* to_offset, const uint32_t* read_of, uint32_t n_reads, const uint32_t* graph_distance,
                     const uint32_t* read_begin, const uint32_t* read_length, const int64_t* anchor_score, int threads, int dp_for_tails,
-                    int32_t* link_score, uint8_t* link_source, int32_t* wfa_status, int64_t* chain_score, uint64_t stats[5], double ms[5]) {
+                    int32_t* link_score, uint8_t* link_source, int32_t* wfa_status, int64_t* chain_score, uint64_t stats[6], double ms[6],
+                    const uint64_t* anchor_off, const uint32_t* anchor_length, const uint32_t* anchor_node_offset, const uint64_t* anchor_path_off, const uint32_t* anchor_nodes,
+                    uint64_t sizes[2]) {
     try {
         ChainStageInput in{};
         in.seqs = seqs; in.seq_off = seq_off; in.n_links = n_links; in.mode = mode; in.from_node = from_node; in.from_offset = from_offset;
         in.to_node = to_node; in.to_offset = to_offset; in.read_of = read_of; in.n_reads = n_reads; in.graph_distance = graph_distance;
         in.read_begin = read_begin; in.read_length = read_length; in.anchor_score = anchor_score; in.threads = (unsigned)std::max(threads, 0);
         in.dp_for_tails = dp_for_tails != 0;
-        ChainStageOutput out;
+        if (anchor_off) {
+            if (!anchor_length || !anchor_node_offset || !anchor_path_off || !anchor_nodes) { g_last_error = "vgh_chain_stage: anchors need all five arrays"; return -1; }
+            in.anchor_off = anchor_off; in.anchor_length = anchor_length; in.anchor_node_offset = anchor_node_offset; in.anchor_path_off = anchor_path_off; in.anchor_nodes = anchor_nodes;
+        }
+        if (!w->chain_out) w->chain_out = std::make_shared<ChainStageOutput>();       // (its arrays keep their room from batch to batch)
+        ChainStageOutput& out = *static_cast<ChainStageOutput*>(w->chain_out.get());
         const Aligner& aligner = *w->ext->aligner;
         const int rc = run_chain_stage(aligner.engine_api(), aligner.engine_context(), w->ext->engine_index(), *w->graph, aligner, nullptr, in, out);
         if (rc) { g_last_error = aligner.engine_api().strerror(rc); return rc; }
@@ -795,10 +804,22 @@ int vgh_chain_stage(vgh_wfa* w, const char* seqs, const uint64_t* seq_off, uint3
         std::copy(out.link_source.begin(), out.link_source.end(), link_source);
         if (wfa_status) std::copy(out.wfa_status.begin(), out.wfa_status.end(), wfa_status);
         std::copy(out.chain_score.begin(), out.chain_score.end(), chain_score);
-        if (stats) { stats[0] = out.n_declined; stats[1] = out.n_between; stats[2] = out.n_no_graph; stats[3] = out.n_too_big; stats[4] = out.n_failed; }
-        if (ms) for (int k = 0; k < 5; ++k) ms[k] = out.ms[k];
+        if (stats) { stats[0] = out.n_declined; stats[1] = out.n_between; stats[2] = out.n_no_graph; stats[3] = out.n_too_big; stats[4] = out.n_failed; stats[5] = out.n_broken; }
+        if (ms) for (int k = 0; k < 6; ++k) ms[k] = out.ms[k];
+        if (sizes) { sizes[0] = anchor_off ? out.n_mappings : 0; sizes[1] = anchor_off ? out.n_edits : 0; }
         return 0;
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+// the composed alignments of the last vgh_chain_stage call with anchors: per read vgk_chain_result, the mappings, the edit runs, per read 1 = chain broken; valid until the next call
+int vgh_chain_stage_view(vgh_wfa* w, const void** read_result, const void** mappings, const void** edits, const uint8_t** read_broken, double* stitch_kernel_ms) {
+    if (!w || !w->chain_out) { g_last_error = "vgh_chain_stage_view: no chain stage has run on this handle"; return -1; }
+    ChainStageOutput& out = *static_cast<ChainStageOutput*>(w->chain_out.get());
+    if (read_result) *read_result = out.read_result.data();
+    if (mappings) *mappings = out.mappings.data();
+    if (edits) *edits = out.edits.data();
+    if (read_broken) *read_broken = out.read_broken.data();
+    if (stitch_kernel_ms) *stitch_kernel_ms = out.stitch_kernel_ms;
+    return 0;
 }
 
 // algorithms::sample_minimal with should_beat(a, b) = goodness[a] > goodness[b]: sampled[i] = 1 for every element sampled

@@ -398,7 +398,8 @@ class ChainStage:
         h.vgh_wfa_last_kernel_ms.restype = ctypes.c_double; h.vgh_wfa_last_kernel_ms.argtypes = [ctypes.c_void_p]
         h.vgh_wfa_last_wave.restype = ctypes.c_double; h.vgh_wfa_last_wave.argtypes = [ctypes.c_void_p, ctypes.c_int]
         h.vgh_chain_stage.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_uint32] + [ctypes.c_void_p] * 4 + \
-                                     [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6
+                                     [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_void_p] * 6
+        h.vgh_chain_stage_view.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_void_p)] * 4 + [ctypes.POINTER(ctypes.c_double)]
         self.h = h
         self.aligner = h.vgh_aligner_create(lib.encode() if lib else None, device, *scores)
         if not self.aligner:
@@ -424,25 +425,45 @@ class ChainStage:
         self.graph_distance = np.ascontiguousarray(wl.span, dtype=np.uint32)
         self.read_begin = np.ascontiguousarray(wl.link_begin, dtype=np.uint32); self.read_length = np.ascontiguousarray(wl.link_read_length, dtype=np.uint32)
         self.anchor_score = np.ascontiguousarray(wl.anchor_bases, dtype=np.int64)
+        self.anchors = [np.ascontiguousarray(getattr(wl, k)) for k in ("anchor_off", "anchor_length", "anchor_node_offset", "anchor_path_off", "anchor_nodes")] if hasattr(wl, "anchor_off") else None
 
     def set_point_budgets(self, connect, tail):
         self.h.vgh_wfa_set_point_budgets(self.wfa, connect, tail)
 
-    def run(self, threads=0, dp_for_tails=True, timing=None):
+    def run(self, threads=0, dp_for_tails=True, timing=None, compose=False):
+        """compose: also ONE alignment per read (find_chain_alignment's composed_path, simplified) — `alignments` = (results CHAIN_RESULT_DT, mappings
+        CHAIN_MAPPING_DT, edits uint32) as views of the stage's own arrays, valid until the next run — and `broken` (per read)"""
         link_score = np.zeros(self.n, dtype=np.int32); source = np.zeros(self.n, dtype=np.uint8); status = np.zeros(self.n, dtype=np.int32)
-        chain = np.zeros(self.n_reads, dtype=np.int64); stats = np.zeros(5, dtype=np.uint64); ms = np.zeros(5, dtype=np.float64)
+        chain = np.zeros(self.n_reads, dtype=np.int64); stats = np.zeros(6, dtype=np.uint64); ms = np.zeros(6, dtype=np.float64); sizes = np.zeros(2, dtype=np.uint64)
+        if compose and self.anchors is None:
+            raise ValueError("ChainStage.run(compose=True): the workload states no anchors")
+        anchors = [a.ctypes.data for a in self.anchors] if compose else [None] * 5
         rc = self.h.vgh_chain_stage(self.wfa, self.seqs.ctypes.data, self.seq_off.ctypes.data, self.n, *[f.ctypes.data for f in self.fields], self.read_of.ctypes.data,
                                     self.n_reads, self.graph_distance.ctypes.data, self.read_begin.ctypes.data, self.read_length.ctypes.data, self.anchor_score.ctypes.data,
-                                    threads, int(dp_for_tails), link_score.ctypes.data, source.ctypes.data, status.ctypes.data, chain.ctypes.data, stats.ctypes.data, ms.ctypes.data)
+                                    threads, int(dp_for_tails), link_score.ctypes.data, source.ctypes.data, status.ctypes.data, chain.ctypes.data, stats.ctypes.data, ms.ctypes.data,
+                                    *anchors, sizes.ctypes.data)
         if rc:
             raise RuntimeError("vgh_chain_stage: " + (self.h.vgh_last_error() or b"?").decode())
         if timing is not None:
             for k, v in zip(("wfa_extend (all links)", "requests for the declined links", "local graphs: extract + split + dagify + trim (host threads)",
-                             "banded + X-drop flush", "translation + totals"), ms):
+                             "banded + X-drop flush", "translation + totals", "one alignment per read: pieces + vgk_chain_stitch"), ms):
                 timing[k] = timing.get(k, 0.0) + v * 1e-3
-        return dict(link_score=link_score, link_source=source, wfa_status=status, chain_score=chain,
-                    stats=dict(zip(("declined", "between", "no_graph", "too_big", "failed"), (int(x) for x in stats))), wfa_kernel_ms=self.h.vgh_wfa_last_kernel_ms(self.wfa),
-                    wfa_launches=dict(small_tables_ms=self.h.vgh_wfa_last_wave(self.wfa, 0), large_tables_ms=self.h.vgh_wfa_last_wave(self.wfa, 1), problems_in_the_large_launch=int(self.h.vgh_wfa_last_wave(self.wfa, 2))))
+        out = dict(link_score=link_score, link_source=source, wfa_status=status, chain_score=chain,
+                   stats=dict(zip(("declined", "between", "no_graph", "too_big", "failed", "broken_reads"), (int(x) for x in stats))), wfa_kernel_ms=self.h.vgh_wfa_last_kernel_ms(self.wfa),
+                   wfa_launches=dict(small_tables_ms=self.h.vgh_wfa_last_wave(self.wfa, 0), large_tables_ms=self.h.vgh_wfa_last_wave(self.wfa, 1), problems_in_the_large_launch=int(self.h.vgh_wfa_last_wave(self.wfa, 2))))
+        if compose:
+            from . import capi
+            ptr = [ctypes.c_void_p() for _ in range(4)]; kms = ctypes.c_double()
+            if self.h.vgh_chain_stage_view(self.wfa, *[ctypes.byref(p) for p in ptr], ctypes.byref(kms)):
+                raise RuntimeError("vgh_chain_stage_view: " + (self.h.vgh_last_error() or b"?").decode())
+
+            def view(p, count, dt):
+                if not count:
+                    return np.zeros(0, dtype=dt)
+                return np.frombuffer((ctypes.c_char * (count * np.dtype(dt).itemsize)).from_address(p.value), dtype=dt)
+            out["alignments"] = (view(ptr[0], self.n_reads, capi.CHAIN_RESULT_DT), view(ptr[1], int(sizes[0]), capi.CHAIN_MAPPING_DT), view(ptr[2], int(sizes[1]), np.uint32))
+            out["broken"] = view(ptr[3], self.n_reads, np.uint8); out["stitch_kernel_ms"] = kms.value
+        return out
 
     def close(self):
         if getattr(self, "wfa", None):

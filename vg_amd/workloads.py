@@ -767,6 +767,7 @@ class LongReadWorkload:
         hap_start = [np.concatenate([[0], np.cumsum(lens[t])]) for t in threads]
         pieces, mode, fn, fo, tn, to, read_of, span, truth = [], [], [], [], [], [], [], [], []
         link_begin, read_total = [], []                                       # where a link starts in its read; its read's length (for longest_detectable_gap_in_range)
+        a_off, a_len, a_noff, a_poff, a_nodes = [0], [], [], [0], []          # the anchors, read by read in read order: exact matches along their node paths (chain_stage.hpp)
         self.anchor_bases = np.zeros(n_reads, dtype=np.int64)
         for r in range(n_reads):
             h = int(rng.integers(0, n_haplotypes)); rev = bool(rng.random() < 0.5)
@@ -782,6 +783,15 @@ class LongReadWorkload:
             if rev:
                 segs = segs[::-1]
             self.anchor_bases[r] = anchor_len * len(anchors)
+            for c0, c1 in (anchors[::-1] if rev else anchors):
+                k0 = int(np.searchsorted(st, c0, side="right") - 1); k1 = int(np.searchsorted(st, c1 - 1, side="right") - 1)
+                walk = [int(t[k]) for k in range(k0, k1 + 1)]
+                if rev:
+                    a_nodes += [2 * v + 1 for v in walk[::-1]]; a_noff.append(int(st[k1 + 1]) - c1)     # first base on the read's strand = base c1 - 1: its offset from the END of its node
+                else:
+                    a_nodes += [2 * v for v in walk]; a_noff.append(c0 - int(st[k0]))
+                a_len.append(c1 - c0); a_poff.append(len(a_nodes))
+            a_off.append(len(a_len))
             pos_in_read = 0; first_link = len(pieces)
 
             def pos(g):
@@ -829,6 +839,8 @@ class LongReadWorkload:
         self.link_begin = np.array(link_begin, dtype=np.int64); self.link_read_length = np.array(read_total, dtype=np.int64)
         self.read_bases = int(seq_off[-1]) + int(self.anchor_bases.sum())
         self.hap_start = hap_start; self.thread_nodes = threads
+        self.anchor_off = np.array(a_off, dtype=np.uint64); self.anchor_length = np.array(a_len, dtype=np.uint32); self.anchor_node_offset = np.array(a_noff, dtype=np.uint32)
+        self.anchor_path_off = np.array(a_poff, dtype=np.uint64); self.anchor_nodes = np.array(a_nodes, dtype=np.uint32)
 
     def prepare_connects(self):
         """every connect's graph between its anchors (between()) laid out once in one flat BandedSet: `connects`, `connect_row[i]` = problem
