@@ -583,6 +583,7 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
                        "problems": n_links, "problems_per_read": n_links / n, "read_bases": read_bases, "bases_per_s": read_bases * world * args.steps / elapsed,
                        "links": stats_sum(outs), "host_threads": threads,
                        "stage_ms_per_batch": {k: 1e3 * v / args.steps / n_batches for k, v in timing.items()}, "wfa_kernel_ms": wfa_ms, "wfa_launches_of_batch_0": out["wfa_launches"],
+                       "stitch_device_ms": float(np.mean([o.get("stitch_kernel_ms", 0.0) for o in outs])) if compose else None,
                        "with_point_budgets": {"connect": budget, "tail": tail_budget, "reads_per_s": n * world * args.steps / b_elapsed, "ms_per_step": 1e3 * b_elapsed / args.steps,
                                               "links": stats_sum(b_outs), "stage_ms_per_batch": {k: 1e3 * v / args.steps / n_batches for k, v in b_timing.items()}, "wfa_kernel_ms": b_out["wfa_kernel_ms"]},
                        "parallelism": "read-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},

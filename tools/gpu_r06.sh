@@ -29,6 +29,6 @@ PY
   leg)            # one secondary leg: LEG="longread --steps 3 --warmup 1"
     set -- ${LEG:-longread --steps 3 --warmup 1}; w=$1; shift
     timeout 1200 python bench.py --workload $w "$@" > "$out/bench_$w${TAG:-}.json" 2> "$out/bench_$w${TAG:-}.err"; tail -3 "$out/bench_$w${TAG:-}.err"
-    last_json "$out/bench_$w${TAG:-}.json" "print(round(d['value']), d['ms_per_step'], d.get('parity') and {k: v for k, v in d['parity'].items() if k != 'what'}, d['roofline'].get('frac'), d['config'].get('stage_ms_per_batch'))" ;;
+    last_json "$out/bench_$w${TAG:-}.json" "print(round(d['value']), d['ms_per_step'], d.get('parity') and {k: v for k, v in d['parity'].items() if k != 'what'}, d['roofline'].get('frac'), d['config'].get('stage_ms_per_batch'), d['config'].get('stitch_device_ms'))" ;;
   *) echo "unknown stage $stage"; exit 2 ;;
 esac

@@ -214,6 +214,7 @@ VGK_HD void cs_stitch_one(const CsParams& P, uint32_t r) {
             from += cs_from_length(S.E, m.edit_begin, m.n_edits);
             for (uint32_t x = 0; x < m.n_edits; ++x) S.E[we + x] = S.E[m.edit_begin + x];       // (we <= m.edit_begin: a move towards the front)
             m.edit_begin = we; we += m.n_edits;
+            if (m.node == VGK_WFA_NO_NODE) m.offset = 0;                          // an empty position is cleared (:1484-1487)
             S.M[wm++] = m;
         }
         out.n_mappings = wm; out.n_edits = we; out.from_length = from; out.to_length = seen;

@@ -6,6 +6,11 @@
 
 namespace vgamd {
 
+void ChainStageOutput::release(const EngineApi& api, vgk_ctx* ctx) {
+    if (api.host_unregister) { if (pinned_m) api.host_unregister(ctx, pinned_m); if (pinned_e) api.host_unregister(ctx, pinned_e); }
+    pinned_m = pinned_e = nullptr;
+}
+
 int run_chain_stage(const EngineApi& api, vgk_ctx* ctx, const vgk_haplo* index, const HaplotypeGraph& graph, const Aligner& aligner,
                     const vgk_wfa_error_model* model, const ChainStageInput& in, ChainStageOutput& out) {
     using clock = std::chrono::steady_clock;
@@ -178,10 +183,16 @@ int run_chain_stage(const EngineApi& api, vgk_ctx* ctx, const vgk_haplo* index, 
     if (out.mappings.size() < 1024) out.mappings.resize(std::max<size_t>(1024, (bases + in.anchor_off[in.n_reads] * 32) / 12));       // (a first guess; afterwards the last batch's size and a quarter)
     if (out.edits.size() < 1024) out.edits.resize(std::max<size_t>(1024, (bases + in.anchor_off[in.n_reads] * 32) / 10));
     for (int attempt = 0; attempt < 2; ++attempt) {
+        if (api.host_register && (out.pinned_m != out.mappings.data() || out.pinned_e != out.edits.data())) {
+            out.release(api, ctx);
+            if (api.host_register(ctx, out.mappings.data(), out.mappings.size() * sizeof(vgk_chain_mapping)) == VGK_OK) out.pinned_m = out.mappings.data();
+            if (api.host_register(ctx, out.edits.data(), out.edits.size() * sizeof(uint32_t)) == VGK_OK) out.pinned_e = out.edits.data();
+        }
         rc = api.chain_stitch(ctx, index, pieces.data(), piece_off.data(), in.n_reads, in.anchor_nodes, (size_t)in.anchor_path_off[in.anchor_off[in.n_reads]],
                               p_maps.data(), p_maps.size(), p_edits.data(), p_edits.size(), out.read_result.data(), out.mappings.data(), out.mappings.size(),
                               out.edits.data(), out.edits.size(), stitched);
         if (rc != VGK_EOPS) break;
+        out.release(api, ctx);
         out.mappings.resize(stitched[0] + stitched[0] / 4 + 1024); out.edits.resize(stitched[1] + stitched[1] / 4 + 1024);
     }
     if (rc != VGK_OK) return rc;

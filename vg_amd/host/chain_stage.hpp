@@ -53,6 +53,10 @@ struct ChainStageOutput {
     // reference makes of a tail beyond max_tail_dp_length, :3217), and the read is flagged
     std::vector<uint8_t> read_broken; uint64_t n_broken = 0;
     double stitch_kernel_ms = 0;
+    // mappings / edits are page-locked through the engine while they keep their size (full-rate DMA on the way back: 110 MB per batch of 8 000
+    // reads); release() before the engine context goes
+    const void* pinned_m = nullptr; const void* pinned_e = nullptr;
+    void release(const EngineApi& api, vgk_ctx* ctx);
 };
 
 // graph: the HandleGraph the index was built over (HaplotypeGraph: node ids in index order).  -> a VGK_* code

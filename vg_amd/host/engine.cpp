@@ -68,6 +68,8 @@ std::shared_ptr<EngineApi> load_engine(const std::string& path) {
     bind(dl, "vgk_wfa_get_form", api->wfa_get_form);
     bind(dl, "vgk_wfa_set_cost_hints", api->wfa_set_cost_hints);
     bind(dl, "vgk_chain_stitch", api->chain_stitch);
+    bind(dl, "vgk_host_register", api->host_register);
+    bind(dl, "vgk_host_unregister", api->host_unregister);
     bind(dl, "vgk_chain_stitch_last_ms", api->chain_stitch_last_ms);
     if (api->abi_version() != VGK_ABI_VERSION) throw std::runtime_error("vgamd engine: ABI version mismatch in " + p);
     return api;

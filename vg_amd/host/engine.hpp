@@ -51,6 +51,8 @@ struct EngineApi {
     decltype(&vgk_wfa_get_form) wfa_get_form = nullptr;
     decltype(&vgk_wfa_set_cost_hints) wfa_set_cost_hints = nullptr;
     decltype(&vgk_chain_stitch) chain_stitch = nullptr;
+    decltype(&vgk_host_register) host_register = nullptr;
+    decltype(&vgk_host_unregister) host_unregister = nullptr;
     decltype(&vgk_chain_stitch_last_ms) chain_stitch_last_ms = nullptr;
     ~EngineApi();
 };

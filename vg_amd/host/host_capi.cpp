@@ -481,7 +481,7 @@ vgh_wfa* vgh_wfa_create(vgh_aligner* a, vgh_graph* g, const int64_t* thread_node
         return h;
     } catch (std::exception& e) { g_last_error = e.what(); return nullptr; }
 }
-void vgh_wfa_destroy(vgh_wfa* w) { delete w; }
+void vgh_wfa_destroy(vgh_wfa* w);       // (below: the chain stage's page-locked arrays go first)
 // kind: 0 connect, 1 suffix, 2 prefix; from / to: [node id, is_reverse, offset]
 int vgh_wfa_align(vgh_wfa* w, int kind, const char* seq, const int64_t* from, const int64_t* to, char* json_out, size_t json_cap) {
     try {
@@ -809,6 +809,10 @@ int vgh_chain_stage(vgh_wfa* w, const char* seqs, const uint64_t* seq_off, uint3
         if (sizes) { sizes[0] = anchor_off ? out.n_mappings : 0; sizes[1] = anchor_off ? out.n_edits : 0; }
         return 0;
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+void vgh_wfa_destroy(vgh_wfa* w) {
+    if (w && w->chain_out && w->ext) { const Aligner& aligner = *w->ext->aligner; static_cast<ChainStageOutput*>(w->chain_out.get())->release(aligner.engine_api(), aligner.engine_context()); }
+    delete w;
 }
 // the composed alignments of the last vgh_chain_stage call with anchors: per read vgk_chain_result, the mappings, the edit runs, per read 1 = chain broken; valid until the next call
 int vgh_chain_stage_view(vgh_wfa* w, const void** read_result, const void** mappings, const void** edits, const uint8_t** read_broken, double* stitch_kernel_ms) {
