@@ -64,6 +64,15 @@ def relaunch_on_ranks(n_gpus):
 # FETCH_SIZE and --pmc WRITE_SIZE in separate runs of the same workload; KiB per launch, FETCH_SIZE doubled as MI355X_MICROARCH.md
 # prescribes for gfx950).  bench.py cannot read counters itself, so `roofline.traffic` = this figure x the units of one launch and
 # `traffic_source` says so; re-measure with tools/collect_r02.sh.
+def _hbm_in_use(torch, index=0):
+    """bytes of the device's HBM in use right now, by anyone (hipMemGetInfo through torch); None where there is no device"""
+    try:
+        free, total = torch.cuda.mem_get_info(index)
+        return int(total - free)
+    except Exception:
+        return None
+
+
 def _pmc_constants():
     """profiles/pmc_constants.json (tools/collect_r03.sh + tools/pmc_constants.py): per workload the counter bytes per unit and the commit
     they were measured at; round 2's figures stand in for a workload the file does not hold."""
@@ -439,12 +448,23 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
     n_batches = max(1, n // per); n = n_batches * per
     n_lanes = min(want_lanes, n_batches)
     t0 = time.perf_counter()
-    wls = [workloads.LongReadWorkload(per, seed=515 + rank + 1000 * b) for b in range(n_batches)]
+    # the graph BASELINE.json names for this configuration: the chr22-scale SNP + indel graph of configs[2] / configs[3] (VariationGraph: 50.8 Mbp,
+    # ~1.74 M nodes, two haplotypes); VGAMD_LONGREAD_REF_LEN=0: rounds 2-5's 1 Mbp graph with 8 random threads
+    ref_len = int(os.environ.get("VGAMD_LONGREAD_REF_LEN", "50818468"))
+    if ref_len:
+        big = workloads.VariationGraph(ref_len=ref_len)
+        t_graph = time.perf_counter() - t0
+        wls = [workloads.LongReadWorkload.in_parallel(per, big, seed=515 + rank + 1000 * b, workers=max(1, shard.usable_cpus() // max(world, 1))) for b in range(n_batches)]
+    else:
+        t_graph = 0.0
+        wls = [workloads.LongReadWorkload(per, seed=515 + rank + 1000 * b) for b in range(n_batches)]
     wl = wls[0]
     t_gen = time.perf_counter() - t0
     threads = max(1, shard.usable_cpus() // max(world, 1))
     lane_threads = max(1, threads // n_lanes)
+    t0 = time.perf_counter()
     stages = [pipeline.ChainStage(w, device=eng.device) for w in wls]
+    t_stages = time.perf_counter() - t0
     for st in stages:
         st.set_point_budgets(0, 0)
     lock = threading.Lock()
@@ -570,9 +590,12 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
             "metric": "15 kbp reads/sec through the chain alignment stage (WFA between anchors; align_sequence_between — local graph extraction + banded global / pinned X-drop — for what WFA declines)",
             "value": n * world * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
-            "config": {"workload": "configs[4]: 1 Mbp variation graph, 8 random haplotype threads, %d reads of 15 000 bp per GPU on either strand, error-free 29-mer anchors every "
-                                   "120-400 bp, 0.5 %% errors between them (half substitutions, half 1-bp indels), 1 %% of the connects with a 25-60 bp insertion; "
-                                   "WFAExtender connect / prefix / suffix with the default error model and NO point budget; align_sequence_between_consistently for what it declines" % n,
+            "config": {"workload": ("configs[4]: %s, %%d reads of 15 000 bp per GPU on either strand, error-free 29-mer anchors every "
+                                    "120-400 bp, 0.5 %%%% errors between them (half substitutions, half 1-bp indels), 1 %%%% of the connects with a 25-60 bp insertion; "
+                                    "WFAExtender connect / prefix / suffix with the default error model and NO point budget; align_sequence_between_consistently for what it declines"
+                                    % (("the chr22-scale SNP + indel graph (%d bp, %d nodes, two haplotypes)" % (ref_len, big.n_nodes)) if ref_len else "1 Mbp variation graph, 8 random haplotype threads")) % n,
+                       "hbm_bytes": {"with the lanes' indexes, WFA tables and the step's arenas": _hbm_in_use(torch, eng.device)},
+                       "setup_seconds": {"graph": t_graph, "graph + reads generated": t_gen, "stages (host graph, haplotype graph, index in HBM; one per lane)": t_stages},
                        "batches": "%d batches of %d reads per step; %s" % (n_batches, per, ("%d batches in flight: %d lanes (a ChainStage each: engine context, haplotype graph, WFA extender; %d host threads per lane)" % (n_lanes, n_lanes, lane_threads))
                                                                           if n_lanes > 1 else "one after the other in one lane"),
                        "one_lane": one_lane, "ms_per_batch": 1e3 * elapsed / args.steps / n_batches,
@@ -618,12 +641,14 @@ def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
     n_pairs = min(n_total, int(os.environ.get("VGAMD_PAIRED_BATCH", "250000")))   # pairs per batch
     n_batches = max(1, n_total // n_pairs); n_total = n_batches * n_pairs
     t0 = time.perf_counter()
-    wl_all = workloads.PairedWorkload(n_total, ref_len=int(os.environ.get("VGAMD_PAIRED_REF_LEN", "5000000")), seed=41 + rank)
+    wl_all = workloads.PairedWorkload(n_total, ref_len=int(os.environ.get("VGAMD_PAIRED_REF_LEN", "50818468")), seed=41 + rank)
     batches = [wl_all.batch(b * n_pairs, (b + 1) * n_pairs) for b in range(n_batches)]
     wl = batches[0]
     t_gen = time.perf_counter() - t0
     graph = (wl.node_len, wl.seq)
-    index = eng.haplo_index(graph, wl.threads); mindex = eng.minimizer_index(graph, wl.threads)
+    hbm0 = _hbm_in_use(torch, eng.device)
+    t1 = time.perf_counter(); index = eng.haplo_index(graph, wl.threads); t_hindex = time.perf_counter() - t1
+    t1 = time.perf_counter(); mindex = eng.minimizer_index(graph, wl.threads); t_mindex = time.perf_counter() - t1
     eng.reuse_outputs = True
     eng.host_register(wl_all.reads)
     threads = int(os.environ.get("VGAMD_HOST_THREADS", "0")) or min(shard.usable_cpus(), 48)
@@ -750,6 +775,8 @@ def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
                        "pairs_rescued_in_batch_0": int(len(out["rescued"])), "rescued_with_positive_score": int((resc[:, 0] > 0).sum()), "refused_by_cell_budget": int((resc[:, 1] == 1).sum()),
                        "pairs_rescued_per_step": acc["rescued"] / args.steps,
                        "stage_ms_per_batch": {k: 1e3 * v / args.steps / n_batches for k, v in timing.items()}, "host_threads": threads,
+                       "index_seconds": {"graph + pairs generated": t_gen, "haplotype index": t_hindex, "minimizer index": t_mindex},
+                       "hbm_bytes": {"before the indexes": hbm0, "with indexes, lanes and the step's arenas": _hbm_in_use(torch, eng.device)},
                        "parallelism": "pair-sharded x%d" % world, "device": dev_name, "compute_units": cus, "generation_seconds": t_gen},
             # the leg's longest kernel family is the stage's gapless search (as in configs[2]); priced the same way: the reads once per seed + outputs
             "roofline": (lambda alg, ms: {"bound": "hbm", "kernel": "gapless_search_kernel + gapless_rules_kernel (the stage's longest kernels, as in configs[2])", "limiter": "memory latency and divergent issue, not bandwidth",
@@ -1834,14 +1861,14 @@ def main():
 # parity.  A leg that fails or overruns its time limit leaves {"workload", "error"} — never a missing headline.
 SECONDARY = [
     ("config2", ["--reads", "8000000", "--steps", "3", "--warmup", "1", "--cpu-sample", "1000000"], 420),
-    ("paired", ["--steps", "5", "--warmup", "2", "--cpu-sample", "200000"], 240),
+    ("paired", ["--steps", "5", "--warmup", "2", "--cpu-sample", "200000"], 360),
     ("gapless", ["--steps", "5", "--warmup", "2"], 90),
     ("xband", ["--steps", "5", "--warmup", "2"], 90),
     ("banded", ["--reads", "100000", "--steps", "5", "--warmup", "2"], 90),
     ("wfa", ["--reads", "500000", "--steps", "5", "--warmup", "2"], 90),
     ("wide", ["--steps", "3", "--warmup", "1"], 150),
     # (last: its two contexts hold 31 GB of WFA tables; the leg that followed it in one run of round 5 — paired — measured a third slower than in every run of its own)
-    ("longread", ["--steps", "3", "--warmup", "1"], 150),
+    ("longread", ["--steps", "3", "--warmup", "1"], 420),
 ]
 
 
@@ -1863,7 +1890,7 @@ def secondary_records():
                 d = json.loads(line[-1])
                 cfg = d.get("config") or {}
                 rec.update({k: d.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "roofline_minimizer", "cpu_baseline", "parity", "problems_failed") if k in d})
-                rec["config"] = {k: cfg.get(k) for k in ("workload", "timed_region", "ms_per_batch", "kernel_ms_per_batch", "stage_ms_per_batch", "one_context", "read_buffers", "policies") if k in cfg}
+                rec["config"] = {k: cfg.get(k) for k in ("workload", "timed_region", "ms_per_batch", "kernel_ms_per_batch", "stage_ms_per_batch", "one_context", "read_buffers", "policies", "index_seconds", "setup_seconds", "hbm_bytes", "stitch_device_ms", "links") if k in cfg}
         except subprocess.TimeoutExpired:
             rec["error"] = "time limit of %d s" % limit
         except Exception as e:                                # (a leg must never take the headline down)

@@ -71,7 +71,7 @@ def test_paired_leg_on_the_emulated_kernels(emu_lib):
 
 
 def test_longread_leg_on_the_emulated_kernels(emu_lib):
-    d = run_leg(emu_lib, ["--workload", "longread", "--reads", "12", "--steps", "1", "--warmup", "1"], {"VGAMD_LONGREAD_BATCH": "6"})
+    d = run_leg(emu_lib, ["--workload", "longread", "--reads", "12", "--steps", "1", "--warmup", "1"], {"VGAMD_LONGREAD_BATCH": "6", "VGAMD_LONGREAD_REF_LEN": "400000"})
     assert d["unit"] == "reads/s" and {"bound", "achieved", "peak", "frac", "traffic"} <= set(d["roofline"])
     p = d["parity"]
     assert p["checked"] == 12 and p["identical"] == 12 and p["differing_reads"] == 0

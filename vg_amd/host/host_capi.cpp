@@ -38,6 +38,15 @@ void vgh_graph_destroy(vgh_graph* g) { delete g; }
 int vgh_graph_add_node(vgh_graph* g, int64_t id, const char* seq) {
     try { g->g.create_handle(seq, id); return 0; } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }
+// the same in bulk (graphs of millions of nodes): node k has id ids[k] and the bases seq[seq_off[k], seq_off[k + 1]); edge k joins from[k] -> to[k], forward strands
+int vgh_graph_add_nodes(vgh_graph* g, uint64_t n, const int64_t* ids, const char* seq, const uint64_t* seq_off) {
+    try { for (uint64_t k = 0; k < n; ++k) g->g.create_handle(std::string(seq + seq_off[k], seq + seq_off[k + 1]), ids[k]); return 0; }
+    catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+int vgh_graph_add_edges(vgh_graph* g, uint64_t n, const int64_t* from, const int64_t* to) {
+    try { for (uint64_t k = 0; k < n; ++k) g->g.create_edge(g->g.get_handle(from[k]), g->g.get_handle(to[k])); return 0; }
+    catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
 int vgh_graph_add_edge(vgh_graph* g, int64_t from, int64_t to) {
     try { g->g.create_edge(g->g.get_handle(from), g->g.get_handle(to)); return 0; }
     catch (std::exception& e) { g_last_error = e.what(); return -1; }

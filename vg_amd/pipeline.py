@@ -405,11 +405,22 @@ class ChainStage:
         if not self.aligner:
             raise RuntimeError("vgh_aligner_create: " + (h.vgh_last_error() or b"?").decode())
         g = h.vgh_graph_create()                                        # node v of the workload is node id v + 1: oriented node 2 v + strand in the index
-        for v, s in enumerate(wl.nodes):
-            h.vgh_graph_add_node(g, v + 1, s.encode())
-        for v, preds in enumerate(wl.preds):
-            for p in preds:
-                h.vgh_graph_add_edge(g, p + 1, v + 1)
+        big = getattr(wl, "graph", None)
+        if big is not None:                                               # a VariationGraph's arrays, in two calls
+            h.vgh_graph_add_nodes.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            h.vgh_graph_add_edges.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+            ids = np.arange(1, big.n_nodes + 1, dtype=np.int64); so = np.ascontiguousarray(big.col, dtype=np.uint64); sq = np.ascontiguousarray(big.seq)
+            if h.vgh_graph_add_nodes(g, big.n_nodes, ids.ctypes.data, sq.ctypes.data, so.ctypes.data):
+                raise RuntimeError("vgh_graph_add_nodes: " + (h.vgh_last_error() or b"?").decode())
+            to = np.repeat(ids, np.diff(big.pred_off.astype(np.int64))); fr = big.pred_idx.astype(np.int64) + 1
+            if h.vgh_graph_add_edges(g, len(to), np.ascontiguousarray(fr).ctypes.data, np.ascontiguousarray(to).ctypes.data):
+                raise RuntimeError("vgh_graph_add_edges: " + (h.vgh_last_error() or b"?").decode())
+        else:
+            for v, s in enumerate(wl.nodes):
+                h.vgh_graph_add_node(g, v + 1, s.encode())
+            for v, preds in enumerate(wl.preds):
+                for p in preds:
+                    h.vgh_graph_add_edge(g, p + 1, v + 1)
         flat = np.concatenate([np.asarray(t, dtype=np.int64) for t in wl.threads])
         tn = ((flat >> 1) + 1) * 2 + (flat & 1)                           # handles: (id << 1) | strand
         toff = np.concatenate([[0], np.cumsum([len(t) for t in wl.threads])]).astype(np.int32)

@@ -450,7 +450,13 @@ class WfaWorkload:
                     w = comp[w[::-1]]; lo, hi = hi, lo
                 # errors: substitutions and 1-bp indels
                 e = rng.random(len(w)) < error_rate
-                if e.any():
+                if e.any() and graph is not None:                      # (the same error model, drawn array-wise: a chr22-scale run makes 240 Mbp of reads)
+                    idx = np.nonzero(e)[0]; x = rng.random(len(idx)); nb = ACGT[rng.integers(0, 4, len(idx))]
+                    w = w.copy(); w[idx[x < 0.5]] = nb[x < 0.5]
+                    keep_base = np.ones(len(w), dtype=bool); keep_base[idx[(x >= 0.5) & (x < 0.75)]] = False
+                    at = idx[x >= 0.75] + 1
+                    w = np.insert(w, at, nb[x >= 0.75])[np.insert(keep_base, at, True)]
+                elif e.any():
                     out = []
                     for c, bad in zip(w, e):
                         if not bad:
@@ -744,27 +750,43 @@ class LongReadWorkload:
     (src/minimizer_mapper.cpp:2955-3100, :3925).  Problems are laid out read by read; `read_of[i]` names problem i's read."""
 
     def __init__(self, n_reads, seed=515, graph_bp=1_000_000, n_haplotypes=8, read_len=15_000, anchor_len=29, min_gap=120, max_gap=400,
-                 error_rate=0.005, sv_fraction=0.01, snp_every=100, indel_every=1000):
+                 error_rate=0.005, sv_fraction=0.01, snp_every=100, indel_every=1000, graph=None):
+        """graph: a VariationGraph (the chr22-scale construction of configs[2] / configs[3]: SNPs, insertions AND deletions, two haplotypes that carry
+        each variant with p = 0.5) — the reads then follow its haplotypes; without one, a graph of `graph_bp` bases with `n_haplotypes` random threads
+        is made here (the tests' small graphs, round 2-5's 1 Mbp leg)."""
         rng = np.random.default_rng(seed)
-        seqs, preds, kind = build_variation_graph(rng, graph_bp, snp_every, indel_every)
-        lens = np.array([len(s) for s in seqs], dtype=np.int64)
-        succ = [[] for _ in seqs]
-        for v, pr in enumerate(preds):
-            for p in pr:
-                succ[p].append(v)
-        self.nodes = [s.tobytes().decode() for s in seqs]
-        self.preds = preds; self.lens = lens
-        threads = []
-        for _ in range(n_haplotypes):
-            t = [0]; v = 0
-            while succ[v]:
-                v = succ[v][int(rng.integers(0, len(succ[v])))]
-                t.append(v)
-            threads.append(np.array(t, dtype=np.int64))
-        self.threads = [list((2 * t).astype(int)) for t in threads]
+        if graph is not None:
+            lens = graph.node_len.astype(np.int64)
+            col = graph.col
+            seqs = None
+            self.graph = graph                                            # (ChainStage hands its arrays over in bulk)
+            self.__dict__["_nodes"] = None; self.__dict__["_preds"] = None
+            threads = [np.nonzero(hap_pos >= 0)[0].astype(np.int64) for _, hap_pos in graph.haps]
+            n_haplotypes = len(threads)
+            self.lens = lens
+            self.threads = [(2 * t).astype(np.int64) for t in threads]
+            hap_seq = [hseq for hseq, _ in graph.haps]
+            hap_start = [np.concatenate([hap_pos[t], [len(hseq)]]).astype(np.int64) for (hseq, hap_pos), t in zip(graph.haps, threads)]
+        else:
+            seqs, preds, kind = build_variation_graph(rng, graph_bp, snp_every, indel_every)
+            lens = np.array([len(s) for s in seqs], dtype=np.int64)
+            succ = [[] for _ in seqs]
+            for v, pr in enumerate(preds):
+                for p in pr:
+                    succ[p].append(v)
+            self.nodes = [s.tobytes().decode() for s in seqs]
+            self.preds = preds; self.lens = lens
+            threads = []
+            for _ in range(n_haplotypes):
+                t = [0]; v = 0
+                while succ[v]:
+                    v = succ[v][int(rng.integers(0, len(succ[v])))]
+                    t.append(v)
+                threads.append(np.array(t, dtype=np.int64))
+            self.threads = [list((2 * t).astype(int)) for t in threads]
+            hap_seq = [np.concatenate([seqs[v] for v in t]) for t in threads]
+            hap_start = [np.concatenate([[0], np.cumsum(lens[t])]) for t in threads]
         comp = _comp_table()
-        hap_seq = [np.concatenate([seqs[v] for v in t]) for t in threads]
-        hap_start = [np.concatenate([[0], np.cumsum(lens[t])]) for t in threads]
         pieces, mode, fn, fo, tn, to, read_of, span, truth = [], [], [], [], [], [], [], [], []
         link_begin, read_total = [], []                                       # where a link starts in its read; its read's length (for longest_detectable_gap_in_range)
         a_off, a_len, a_noff, a_poff, a_nodes = [0], [], [], [0], []          # the anchors, read by read in read order: exact matches along their node paths (chain_stage.hpp)
@@ -803,7 +825,13 @@ class LongReadWorkload:
                 if rev:
                     w = comp[w[::-1]]
                 e = rng.random(len(w)) < error_rate
-                if e.any():
+                if e.any() and graph is not None:                      # (the same error model, drawn array-wise: a chr22-scale run makes 240 Mbp of reads)
+                    idx = np.nonzero(e)[0]; x = rng.random(len(idx)); nb = ACGT[rng.integers(0, 4, len(idx))]
+                    w = w.copy(); w[idx[x < 0.5]] = nb[x < 0.5]
+                    keep_base = np.ones(len(w), dtype=bool); keep_base[idx[(x >= 0.5) & (x < 0.75)]] = False
+                    at = idx[x >= 0.75] + 1
+                    w = np.insert(w, at, nb[x >= 0.75])[np.insert(keep_base, at, True)]
+                elif e.any():
                     out = []
                     for c, bad in zip(w, e):
                         if not bad:
@@ -841,6 +869,53 @@ class LongReadWorkload:
         self.hap_start = hap_start; self.thread_nodes = threads
         self.anchor_off = np.array(a_off, dtype=np.uint64); self.anchor_length = np.array(a_len, dtype=np.uint32); self.anchor_node_offset = np.array(a_noff, dtype=np.uint32)
         self.anchor_path_off = np.array(a_poff, dtype=np.uint64); self.anchor_nodes = np.array(a_nodes, dtype=np.uint32)
+
+    @classmethod
+    def in_parallel(cls, n_reads, graph, seed=515, workers=8, chunk=500, **kw):
+        """the same workload generated in chunks of `chunk` reads on `workers` forked processes (read r's chunk draws from seed * 4096 + chunk index:
+        the result depends on `chunk`, not on `workers`) and laid behind each other — a chr22-scale leg makes 16 000 reads of 15 kbp, a minute of
+        Python on one core"""
+        import multiprocessing as mp
+        jobs = [(min(chunk, n_reads - lo), seed * 4096 + k) for k, lo in enumerate(range(0, n_reads, chunk))]
+        global _LR_GRAPH, _LR_KW
+        _LR_GRAPH, _LR_KW = graph, kw
+        if workers > 1 and len(jobs) > 1:
+            with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+                parts = pool.map(_lr_chunk, jobs)
+        else:
+            parts = [_lr_chunk(j) for j in jobs]
+        _LR_GRAPH = None
+        w = object.__new__(cls)
+        from . import capi
+        first = cls(1, seed=seed, graph=graph, **kw)                   # (the graph-wide members: haplotype tables, threads)
+        w.__dict__.update({k: v for k, v in first.__dict__.items() if k in ("graph", "lens", "threads", "hap_start", "thread_nodes")})
+        links = np.concatenate([[0], np.cumsum([p["n"] for p in parts])]); reads = np.concatenate([[0], np.cumsum([p["n_reads"] for p in parts])])
+        seq_off = np.concatenate([[0]] + [p["seq_off"][1:] + off for p, off in zip(parts, np.concatenate([[0], np.cumsum([p["seq_off"][-1] for p in parts])]))]).astype(np.int64)
+        buf = np.concatenate([p["seqs"][:p["seq_off"][-1]] for p in parts])
+        cat = lambda k: np.concatenate([p[k] for p in parts])
+        n = int(links[-1])
+        w.ws = capi.WfaSet(buf, seq_off, cat("mode"), cat("from_node"), cat("from_offset"), cat("to_node"), cat("to_offset"), path_cap=n * 24 + int(seq_off[-1]) // 4, edit_cap=n * 12)
+        w.n = n; w.n_reads = int(reads[-1])
+        w.read_of = np.concatenate([p["read_of"] + r0 for p, r0 in zip(parts, reads)]); w.span = cat("span"); w.truth = [t for p in parts for t in p["truth"]]
+        w.link_begin = cat("link_begin"); w.link_read_length = cat("link_read_length"); w.anchor_bases = cat("anchor_bases")
+        w.read_bases = int(seq_off[-1]) + int(w.anchor_bases.sum())
+        a0 = np.concatenate([[0], np.cumsum([len(p["anchor_length"]) for p in parts])]); n0 = np.concatenate([[0], np.cumsum([len(p["anchor_nodes"]) for p in parts])])
+        w.anchor_off = np.concatenate([[0]] + [p["anchor_off"][1:] + np.uint64(o) for p, o in zip(parts, a0)]).astype(np.uint64)
+        w.anchor_path_off = np.concatenate([[0]] + [p["anchor_path_off"][1:] + np.uint64(o) for p, o in zip(parts, n0)]).astype(np.uint64)
+        w.anchor_length = cat("anchor_length"); w.anchor_node_offset = cat("anchor_node_offset"); w.anchor_nodes = cat("anchor_nodes")
+        return w
+
+    def __getattr__(self, name):
+        # a chr22-scale graph: the node strings and predecessor lists (1.7 M Python objects each) are made only when something asks for them
+        if name == "nodes" and self.__dict__.get("graph") is not None:
+            g = self.graph; buf = g.seq.tobytes(); col = g.col
+            self.__dict__["nodes"] = [buf[int(col[v]):int(col[v + 1])].decode() for v in range(g.n_nodes)]
+            return self.__dict__["nodes"]
+        if name == "preds" and self.__dict__.get("graph") is not None:
+            g = self.graph; po = g.pred_off.astype(np.int64); pi = g.pred_idx
+            self.__dict__["preds"] = [[int(p) for p in pi[po[v]:po[v + 1]]] for v in range(g.n_nodes)]
+            return self.__dict__["preds"]
+        raise AttributeError(name)
 
     def prepare_connects(self):
         """every connect's graph between its anchors (between()) laid out once in one flat BandedSet: `connects`, `connect_row[i]` = problem
@@ -881,6 +956,20 @@ class LongReadWorkload:
             seq = _comp_table()[seq[::-1]]
         cache[i] = dict(read=seq.tobytes().decode(), nodes=nodes, preds=preds, band_padding=int(np.sqrt(max(len(seq), 1))) + 1 + 64, permissive=True)
         return cache[i]
+
+
+_LR_GRAPH = None; _LR_KW = {}
+
+
+def _lr_chunk(job):
+    """one chunk of LongReadWorkload.in_parallel (a forked worker: the graph is the parent's, copy-on-write) -> plain arrays"""
+    n, seed = job
+    w = LongReadWorkload(n, seed=seed, graph=_LR_GRAPH, **_LR_KW)
+    a = w.ws.array
+    return dict(n=w.n, n_reads=w.n_reads, seqs=w.ws.seqs, seq_off=np.asarray(w.ws.seq_off), mode=a["mode"].copy(), from_node=a["from_node"].copy(), from_offset=a["from_offset"].copy(),
+                to_node=a["to_node"].copy(), to_offset=a["to_offset"].copy(), read_of=np.asarray(w.read_of), span=np.asarray(w.span), truth=w.truth, link_begin=w.link_begin,
+                link_read_length=w.link_read_length, anchor_bases=w.anchor_bases, anchor_off=w.anchor_off, anchor_length=w.anchor_length, anchor_node_offset=w.anchor_node_offset,
+                anchor_path_off=w.anchor_path_off, anchor_nodes=w.anchor_nodes)
 
 
 class Config2Workload:
