@@ -63,7 +63,7 @@ def relaunch_on_ranks(n_gpus):
 # HBM bytes per unit of work of the dominant kernel: STORED constants from the PMC passes committed under profiles/r02 (rocprofv3 --pmc
 # FETCH_SIZE and --pmc WRITE_SIZE in separate runs of the same workload; KiB per launch, FETCH_SIZE doubled as MI355X_MICROARCH.md
 # prescribes for gfx950).  bench.py cannot read counters itself, so `roofline.traffic` = this figure x the units of one launch and
-# `traffic_source` says so; re-measure with tools/collect_r02.sh.
+# `traffic_source` says so; re-measure with `tools/gpu_r06.sh pmc <workload>` + tools/pmc_constants.py.
 def _hbm_in_use(torch, index=0):
     """bytes of the device's HBM in use right now, by anyone (hipMemGetInfo through torch); None where there is no device"""
     try:
@@ -74,7 +74,7 @@ def _hbm_in_use(torch, index=0):
 
 
 def _pmc_constants():
-    """profiles/pmc_constants.json (tools/collect_r03.sh + tools/pmc_constants.py): per workload the counter bytes per unit and the commit
+    """profiles/pmc_constants.json (`tools/gpu_r06.sh pmc` + tools/pmc_constants.py): per workload the counter bytes per unit and the commit
     they were measured at; round 2's figures stand in for a workload the file does not hold."""
     r02 = {"linear": (2 * 704590 + 13574060) * 1024 / 400000, "banded": (2 * 406349 + 2245028) * 1024 / 100000,
            "gapless": (2 * 11460323 + 2860944) * 1024 / 1000000, "wfa": (2 * 4094544 + 1914811) * 1024 / 500000}

@@ -30,5 +30,20 @@ PY
     set -- ${LEG:-longread --steps 3 --warmup 1}; w=$1; shift
     timeout 1200 python bench.py --workload $w "$@" > "$out/bench_$w${TAG:-}.json" 2> "$out/bench_$w${TAG:-}.err"; tail -3 "$out/bench_$w${TAG:-}.err"
     last_json "$out/bench_$w${TAG:-}.json" "print(round(d['value']), d['ms_per_step'], d.get('parity') and {k: v for k, v in d['parity'].items() if k != 'what'}, d['roofline'].get('frac'), d['config'].get('stage_ms_per_batch'), d['config'].get('stitch_device_ms'))" ;;
+  pmc)            # kernel statistics + FETCH_SIZE / WRITE_SIZE passes (separate runs, kernel trace only) of the named workloads -> gpurun_out/r06_pmc (tools/pmc_constants.py r06)
+    P=$GRAFT_REPO_ROOT/gpurun_out/r06_pmc; mkdir -p $P
+    shift
+    for w in "$@"; do
+      case $w in linear) R=400000;; config2) R=1000000; export VGAMD_CONFIG2_ONE_CONTEXT=1;; gapless) R=1000000;; banded) R=100000;; wfa) R=500000;; paired) R=500000;; longread) R=4000; export VGAMD_LONGREAD_BATCH=4000 VGAMD_LONGREAD_ONE_LANE=1;; xband) R=200000;; *) R=0;; esac
+      B="python $GRAFT_REPO_ROOT/bench.py --workload $w --reads $R --no-cpu --no-e2e --no-secondary --steps 2 --warmup 1"
+      ( cd /tmp && timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_$w -o s -- $B > $P/stats_$w.log 2>&1 )
+      for c in ${PMC_COUNTERS-FETCH_SIZE WRITE_SIZE}; do      # (PMC_COUNTERS="": the kernel statistics only)
+        ( cd /tmp && timeout -s KILL 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $P/${c}_$w -o p -- $B > $P/${c}_$w.log 2>&1 )
+      done
+      unset VGAMD_CONFIG2_ONE_CONTEXT VGAMD_LONGREAD_BATCH VGAMD_LONGREAD_ONE_LANE
+    done
+    ls $P ;;
+  registers)      # VGPRs, spills, scratch and LDS of every kernel of the built library
+    python tools/kernel_registers.py vg_amd/libvgamd.so > "$out/kernel_registers.txt" 2>&1; head -50 "$out/kernel_registers.txt" ;;
   *) echo "unknown stage $stage"; exit 2 ;;
 esac

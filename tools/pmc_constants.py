@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/r03_pmc/ (tools/collect_r03.sh) -> profiles/pmc_constants.json + the CSV summaries under profiles/rNN/.
+"""gpurun_out/r03_pmc/ (`tools/gpu_r06.sh pmc ...`; rounds 3-5: the collect_r0N.sh / gpu_r05.sh scripts of their time, in git history) -> profiles/pmc_constants.json + the CSV summaries under profiles/rNN/.
 
 For every workload: FETCH_SIZE and WRITE_SIZE (KiB) of its roofline kernels, averaged per dispatch of the bench's launches and summed over
 the kernels of the group, with the units one launch processes and THE COMMIT the library was built from — bench.py quotes that commit
