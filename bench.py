@@ -135,7 +135,7 @@ def bench_gapless(args, eng, rank, world, dist, torch, dev_name, cus):
         ora.lib.vgo_set_threads(shard.usable_cpus())
         oidx = ora.haplo_index(wl.nodes, wl.threads)
         tc = time.perf_counter(); o = ora.gapless_extend(oidx, wl.gs); tc = time.perf_counter() - tc
-        cpu = {"value": n / tc, "unit": "reads/s", "cores": shard.usable_cpus(), "kind": "port",
+        cpu = {"value": n / tc, "unit": "reads/s", "cores": shard.usable_cpus(), "kind": "port", "impl": "scalar checker (oracle/vgo_gapless.c: un-tuned restatement, built -march=x86-64-v2); not a tuned CPU baseline",
                "sample": "the same %d reads, oracle/vgo_gapless.c (scalar best-first extension over the uncompressed haplotype index), OpenMP over reads" % n}
         same = all(len(a) == len(b) and bool((a == b).all()) for a, b in zip(o, out))
         parity = {"checked": n, "identical": n if same else int((o[0] == res).sum())}
@@ -201,7 +201,7 @@ def bench_wfa(args, eng, rank, world, dist, torch, dev_name, cus):
         ora.lib.vgo_set_threads(shard.usable_cpus())
         oidx = ora.haplo_index(wl.nodes, wl.threads)
         tc = time.perf_counter(); o = ora.wfa_extend(oidx, wl.ws); tc = time.perf_counter() - tc
-        cpu = {"value": n / tc, "unit": "alignments/s", "cores": shard.usable_cpus(), "kind": "port",
+        cpu = {"value": n / tc, "unit": "alignments/s", "cores": shard.usable_cpus(), "kind": "port", "impl": "scalar int32 checker (oracle/vgo_wfa.c: un-tuned restatement); not a tuned CPU baseline",
                "sample": "the same %d problems, oracle/vgo_wfa.c (scalar WFA over the haplotype trie, hash-table wavefronts), OpenMP over problems" % n}
         good = res["status"] == 0
         fields = ("ok", "score", "node_offset", "seq_offset", "length", "path_len", "n_edits")
@@ -295,7 +295,7 @@ def bench_banded(args, eng, rank, world, dist, torch, dev_name, cus):
         ora = capi.Engine(capi.Scoring.simple(1, 4, 6, 1, 5), lib=os.path.join(ROOT, "oracle", "libvgoracle.so"))
         ora.lib.vgo_set_threads(shard.usable_cpus())
         tc = time.perf_counter(); ores, oops = ora.banded_align(wl.bs); tc = time.perf_counter() - tc
-        cpu = {"value": n / tc, "unit": "alignments/s", "cores": shard.usable_cpus(), "kind": "port",
+        cpu = {"value": n / tc, "unit": "alignments/s", "cores": shard.usable_cpus(), "kind": "port", "impl": "scalar int32 checker (oracle/vgo_banded.c: un-tuned restatement; the reference picks int8 / int16 cells where they fit); not a tuned CPU baseline",
                "sample": "the same %d problems, oracle/vgo_banded.c scalar int32 three-matrix DP + traceback, OpenMP over problems" % n}
         hdr = (res["score"] == ores["score"]) & (res["status"] == ores["status"]) & (res["n_ops"] == ores["n_ops"])
         same = int(hdr.sum())
@@ -402,7 +402,7 @@ def bench_wide(args, eng, rank, world, dist, torch, dev_name, cus):
             if all(a[f] == b[f] for f in ("status", "score", "end_node", "end_offset", "end_read", "first_offset", "n_ops")) and \
                (ops[a["ops_begin"]:a["ops_begin"] + a["n_ops"]].view(np.uint64) == oops[b["ops_begin"]:b["ops_begin"] + b["n_ops"]].view(np.uint64)).all():
                 same += 1
-        cpu = {"value": k / tc, "unit": "alignments/s", "cores": cores, "kind": "port", "impl": "oracle/vgo_gssw.c, vgo_xdrop.c: scalar int32 DP + traceback, OpenMP over problems", "sample": "the first %d problems" % k}
+        cpu = {"value": k / tc, "unit": "alignments/s", "cores": cores, "kind": "port", "impl": "scalar int32 checker (oracle/vgo_gssw.c, vgo_xdrop.c: DP + traceback, OpenMP over problems); not a tuned CPU baseline", "sample": "the first %d problems" % k}
         parity = {"checked": k, "identical": same, "what": "score, end cell, first offset and every op"}
     if rank == 0:
         read_b = float(np.diff(ps.read_off).sum()); graph_b = float(np.diff(ps.seq_off).sum())
@@ -573,7 +573,7 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
             ora.close()
             same += int((~diff).sum()) if not compose else int((ok & ~diff).sum()); differing += int(diff.sum()); higher += int((outs[b]["chain_score"][diff] > o["chain_score"][diff]).sum())
             b_same += int((o["chain_score"] == b_outs[b]["chain_score"]).sum())
-        cpu = {"value": n / tc, "unit": "reads/s", "cores": cores, "kind": "port", "impl": "the same stage (vgh_chain_stage) bound to the oracle: vgo_wfa.c, vgo_banded.c, vgo_xdrop.c (OpenMP over problems)",
+        cpu = {"value": n / tc, "unit": "reads/s", "cores": cores, "kind": "port", "impl": "scalar int32 checkers: the same stage (vgh_chain_stage) bound to the oracle — vgo_wfa.c, vgo_banded.c, vgo_xdrop.c, vgo_chain.c (OpenMP over problems / reads); not a tuned CPU baseline",
                "sample": "all %d reads" % n}
         parity = {"checked": n, "identical": same, "wfa_point_budget": "none", "differing_reads": differing,
                   "differing_reads_where_the_engine_scores_higher": higher,
@@ -748,7 +748,7 @@ def bench_paired(args, eng, rank, world, dist, torch, dev_name, cus):
             else:
                 row_same &= np.diff(ob) == np.diff(gb)
             same_resc = int(row_same.sum())
-        cpu = {"value": 2 * k / tc, "unit": "reads/s", "cores": cores, "kind": "port", "impl": "the same stage over the oracle (vgo_minimizer.c, vgo_gapless.c, vgo_tail.c, vgo_xdrop.c) and the host shim's reference-shaped rescue path bound to it",
+        cpu = {"value": 2 * k / tc, "unit": "reads/s", "cores": cores, "kind": "port", "impl": "scalar checkers: the same stage over the oracle (vgo_minimizer.c, vgo_gapless.c, vgo_tail.c, vgo_xdrop.c) and the host shim's reference-shaped rescue path bound to it",
                "sample": "the first %d pairs" % k}
         parity = {"checked": k, "identical": same, "rescued_mates_checked": n_resc, "rescued_alignments_identical": same_resc,
                   "rescued_alignment_ops": int(o["rescue_ops_begin"][-1]), "rescued_alignment_ops_identical": same_ops,
@@ -940,7 +940,7 @@ def bench_config2(args, eng, rank, world, dist, torch, dev_name, cus):
         o = pipeline.align_stage(ora, oidx, olen, sub); tc = time.perf_counter() - t1
         same = int((o["read_score"] == first["read_score"][:k]).sum())
         cpu = {"value": k / tc, "unit": "reads/s", "cores": cores, "kind": "port",
-               "impl": "the same stage over the oracle: vgo_minimizer.c, vgo_gapless.c (OpenMP over reads), vgo_tail.c, vgo_xdrop.c (OpenMP over problems)",
+               "impl": "scalar checkers, not a tuned CPU baseline: the same stage over the oracle: vgo_minimizer.c, vgo_gapless.c (OpenMP over reads), vgo_tail.c, vgo_xdrop.c (OpenMP over problems)",
                "sample": "the first %d reads of the first batch" % k}
         # every product of the stage for those reads, not their scores alone: the seeds' counts, every extension of every set (interval, offset,
         # mismatches, score, both search states, every node of its path), every extension's total, and every TAIL ALIGNMENT the engine chose on the
@@ -1128,7 +1128,7 @@ def bench_giraffe(args, eng, rank, world, dist, torch, dev_name, cus):
         o = pipeline.align_stage(ora, oidx, olen, sub); tc = time.perf_counter() - t1
         same = int((o["read_score"] == out["read_score"][:k]).sum())
         cpu = {"value": k / tc, "unit": "reads/s", "cores": cores, "kind": "port",
-               "impl": "the same pipeline over the oracle: vgo_gapless.c (OpenMP over reads), vgo_tail.c (one thread), vgo_xdrop.c (OpenMP over problems)",
+               "impl": "scalar checkers, not a tuned CPU baseline: the same pipeline over the oracle: vgo_gapless.c (OpenMP over reads), vgo_tail.c (one thread), vgo_xdrop.c (OpenMP over problems)",
                "sample": "the first %d reads of the batch" % k}
         parity = {"checked": k, "identical": same, "what": "per-read best total score (extension + both tails); tests/test_giraffe_stage.py compares every intermediate product"}
         if with_alignments and not from_reads:
@@ -1245,7 +1245,7 @@ def bench_forest(args, eng, rank, world, dist, torch, dev_name, cus):
         tot = int(orr["n_ops"].sum())
         ops_same = bool((ops[:tot].view(np.uint64) == oops[:tot].view(np.uint64)).all()) if same.all() else False
         cpu = {"value": k / (t_walk + t_align), "unit": "tails/s", "cores": cores, "kind": "port",
-               "impl": "oracle/vgo_tail.c (dfs_gbwt restated, one thread) + oracle/vgo_xdrop.c (scalar int32 checker, OpenMP over problems)",
+               "impl": "scalar checkers, not a tuned CPU baseline: oracle/vgo_tail.c (dfs_gbwt restated, one thread) + oracle/vgo_xdrop.c (scalar int32 checker, OpenMP over problems)",
                "sample": "the first %d tails: forests %.2f s on one core, alignments %.2f s on %d" % (k, t_walk, t_align, cores)}
         parity = {"checked": k, "identical": int(same.sum()) if (forest_same and ops_same) else int(same.sum()) - 1, "forests_identical": forest_same, "ops_identical": ops_same}
     if rank == 0:
