@@ -30,6 +30,14 @@ PY
     set -- ${LEG:-longread --steps 3 --warmup 1}; w=$1; shift
     timeout 1200 python bench.py --workload $w "$@" > "$out/bench_$w${TAG:-}.json" 2> "$out/bench_$w${TAG:-}.err"; tail -3 "$out/bench_$w${TAG:-}.err"
     last_json "$out/bench_$w${TAG:-}.json" "print(round(d['value']), d['ms_per_step'], d.get('parity') and {k: v for k, v in d['parity'].items() if k != 'what'}, d['roofline'].get('frac'), d['config'].get('stage_ms_per_batch'), d['config'].get('stitch_device_ms'))" ;;
+  two_cpus)       # legs pinned to TWO host CPUs (what a rank of an 8-rank run on a 16-CPU box gets) beside the whole box: TWO="longread banded"
+    for w in ${TWO:-longread banded}; do
+      for cpus in all 2; do
+        if [ $cpus = 2 ]; then pre="taskset -c 0-1"; export VGAMD_HOST_THREADS=2; else pre=""; unset VGAMD_HOST_THREADS; fi
+        timeout 900 $pre python bench.py --workload $w --steps 3 --warmup 1 --no-cpu > "$out/bench_${w}_cpus_$cpus.json" 2> "$out/bench_${w}_cpus_$cpus.err"
+        last_json "$out/bench_${w}_cpus_$cpus.json" "print('$w', '$cpus', round(d['value']), d['ms_per_step'], d['config'].get('stage_ms_per_batch'), d['config'].get('host_ms'), d['config'].get('one_lane'))"
+      done
+    done; unset VGAMD_HOST_THREADS ;;
   pmc)            # kernel statistics + FETCH_SIZE / WRITE_SIZE passes (separate runs, kernel trace only) of the named workloads -> gpurun_out/r06_pmc (tools/pmc_constants.py r06)
     P=$GRAFT_REPO_ROOT/gpurun_out/r06_pmc; mkdir -p $P
     shift
