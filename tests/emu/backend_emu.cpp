@@ -179,6 +179,10 @@ public:
         if (P.pass == 1) { for (uint32_t i = P.lo; i < P.hi; ++i) minimizer_one(P, i); } else for (uint32_t i = 0; i < P.n; ++i) minimizer_one(P, i);
         return VGK_OK;
     }
+    int run_wfa_mask(const WProb* probs, const uint32_t* src_off, const char* raw, char* seqs, uint32_t n) override {
+        for (uint32_t i = 0; i < n; ++i) for (uint32_t l = 0; l < 64; ++l) wfa_mask_one(probs, src_off, raw, seqs, i, l, 64);
+        return VGK_OK;
+    }
     int run_chain_stitch(const CsParams& P, int what) override {
         if (what == CS_GATHER) { for (uint32_t r = 0; r < P.n_reads; ++r) for (uint32_t l = 0; l < 64; ++l) cs_gather_one(P, r, l, 64); }
         else for (uint32_t r = 0; r <= P.n_reads; ++r) cs_one(P, what, r);

@@ -487,6 +487,37 @@ def cost_hints_change_the_order_only(lib):
     assert (plain[0]["status"] == want[0]["status"]).all() and (plain[0]["score"] == want[0]["score"]).all()
 
 
+def sequences_masked_on_the_device_or_the_host(lib, monkeypatch):
+    """the caller's sequences in one stretch of memory go up as they are and a kernel masks / flips / lays them out (wfa_mask_one); sequences
+    scattered over the heap — or VGAMD_WFA_HOST_MASK=1 — are gathered and masked by the host threads: the same answers, N's and PREFIX problems included"""
+    eng = capi.Engine(lib=lib) if lib else capi.Engine()
+    rng = np.random.default_rng(909)
+    nodes, threads, problems = random_wfa_case(rng, 400)
+    assert any(p["mode"] == "prefix" for p in problems) and any("N" in p["seq"] for p in problems)
+    idx = eng.haplo_index(nodes, threads)
+    device = eng.wfa_extend(idx, problems)
+    monkeypatch.setenv("VGAMD_WFA_HOST_MASK", "1")
+    host = eng.wfa_extend(idx, problems)
+    monkeypatch.delenv("VGAMD_WFA_HOST_MASK")
+    assert all(len(x) == len(y) and (x == y).all() for x, y in zip(device, host))
+    # scattered: every sequence a buffer of its own, megabytes apart
+    ws = capi.WfaSet.from_lists(problems)
+    keep = [np.frombuffer((p["seq"] or "A").encode(), dtype=np.uint8).copy() for p in problems] + [np.zeros(1 << 22, dtype=np.uint8)]
+    far = np.zeros(1 << 23, dtype=np.uint8); far[:len(keep[0])] = keep[0]; keep[0] = far
+    ws.array["seq"] = [k.ctypes.data for k in keep[:len(problems)]]
+    scattered = eng.wfa_extend(idx, ws)
+    assert all(len(x) == len(y) and (x == y).all() for x, y in zip(device, scattered))
+
+
+def test_sequences_masked_on_the_emulated_device_or_the_host(monkeypatch):
+    sequences_masked_on_the_device_or_the_host(util.EMU_LIB, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_sequences_masked_on_the_device_or_the_host(monkeypatch):
+    sequences_masked_on_the_device_or_the_host(None, monkeypatch)
+
+
 def test_emulated_cost_hints_change_the_order_only():
     cost_hints_change_the_order_only(util.EMU_LIB)
 

@@ -121,6 +121,7 @@ public:
     // wavefront alignment: likewise, `threads` resident threads (one WScratch each, zeroed by the caller once) stride over
     // p.n problems; last_ms(6) = kernel ms
     virtual int   run_wfa(const WfaParams& p, uint32_t threads) = 0;
+    virtual int   run_wfa_mask(const WProb* probs, const uint32_t* src_off, const char* raw, char* seqs, uint32_t n) = 0;     // wfa_mask_one for problems [0, n): asynchronous on the main stream
     virtual int   run_wfa_wave(const WwParams& p, uint32_t waves) = 0;    // one wavefront per problem (wfa_wave_device.hpp); the time adds to last_ms(6)
     // the hybrid's two kernels AT ONCE: the thread kernel on the main stream, the wavefront kernel beside it on a second one, polling the
     // hand-over list while it grows (a.producers_done / p.producers_done: wfa_wave_device.hpp); last_ms(6) = the pair's wall time on the

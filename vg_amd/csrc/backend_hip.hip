@@ -791,6 +791,11 @@ __global__ void __launch_bounds__(256) forest_emit_kernel(const ForestParams P) 
     if (v < P.n_nodes) forest_emit_one(P, v);
 }
 
+// ---- the WFA problems' sequences masked / flipped / laid out on the device: a wavefront per problem, four to a block
+__global__ void __launch_bounds__(256) wfa_mask_kernel(const WProb* probs, const uint32_t* src_off, const char* raw, char* seqs, const uint32_t n) {
+    const uint32_t i = blockIdx.x * 4 + threadIdx.x / 64;
+    if (i < n) wfa_mask_one(probs, src_off, raw, seqs, i, threadIdx.x & 63u, 64);
+}
 // ---- wavefront alignment (wfa_device.hpp): the same launch shape
 __global__ void __launch_bounds__(64, 4) wfa_kernel(const WfaParams P, const uint32_t threads) {
     __shared__ uint32_t node_end[W_NODES * 64];                    // [trie node][lane]: conflict-free, 8 KB per wavefront
@@ -1561,6 +1566,11 @@ public:
         const uint32_t items = tstage_items(p, what);
         if (!items) return VGK_OK;
         hipLaunchKernelGGL(tail_stage_kernel, dim3((items + 255) / 256), dim3(256), 0, stream, p, what, items);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int run_wfa_mask(const WProb* probs, const uint32_t* src_off, const char* raw, char* seqs, uint32_t n) override {
+        hipSetDevice(dev);
+        if (n) hipLaunchKernelGGL(wfa_mask_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, probs, src_off, raw, seqs, n);
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_chain_stitch(const CsParams& p, int what) override {

@@ -5,6 +5,7 @@
 // score cap and distance band per sequence length (:1631-1634, :2077; gbwt_extender.hpp:371-373), upload, launch one
 // thread per problem over zero-initialised per-thread slabs, download, and hand paths / edits back in problem order.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,7 +18,7 @@ using namespace vgk;
 
 namespace {
 
-struct WfaHost { PinnedBuf<char> seqs; PinnedBuf<WProb> probs; PinnedBuf<vgk_wfa_result> dres; PinnedBuf<uint32_t> dpaths, dedits; uint64_t zeroed_bytes = 0; void* zeroed_ptr = nullptr;
+struct WfaHost { PinnedBuf<char> seqs; PinnedBuf<uint32_t> src_off; PinnedBuf<WProb> probs; PinnedBuf<vgk_wfa_result> dres; PinnedBuf<uint32_t> dpaths, dedits; uint64_t zeroed_bytes = 0; void* zeroed_ptr = nullptr;
                  void* slab_ptr = nullptr; uint64_t slab_bytes = 0, slab_shape = 0;
                  GIndex walk_index{}; GMerge walk_merge{}; };      // the index the wavefront kernel walks in the current call: the caller's, or its merged-run form
 
@@ -168,6 +169,11 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     const int32_t match = ctx->sc.matrix[0], mism = -ctx->sc.matrix[1], go = ctx->sc.gap_open, ge = ctx->sc.gap_extend;
     if (match < 0 || mism <= 0 || go < ge || ge <= 0) return VGK_EUNSUPPORTED;                    // (:1256-1259)
     std::lock_guard<std::mutex> lock(ctx->mu);
+    // VGAMD_WFA_TIMES=1: where the call's host time goes (stderr, one line per call)
+    const bool times = std::getenv("VGAMD_WFA_TIMES") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto t_begin = now(); auto t_mark = t_begin; double t_phase[6] = {0, 0, 0, 0, 0, 0};
+    auto lap = [&](int k) { const auto t = now(); t_phase[k] += std::chrono::duration<double, std::milli>(t - t_mark).count(); t_mark = t; };
     ctx->wfa_out.valid = false;
     ctx->wfa_last_valid = false; ctx->wfa_wave_last_valid = false;            // (set again only by a call that got through: vgk_wfa_rerun must never relaunch over released buffers)
     // vgk_wfa_set_cost_hints: taken by THIS call whatever becomes of it (a call that fails below must not leave them to a later one)
@@ -190,6 +196,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     const uint32_t slices = std::min<uint32_t>(64u, (n + 8191u) / 8192u);
     auto lo_of = [&](uint32_t c) { return (uint32_t)((uint64_t)n * c / slices); };
     std::vector<uint64_t> slice_seq((size_t)slices + 1, 0); std::vector<int> slice_bad(slices, 0);
+    std::vector<uintptr_t> slice_lo(slices, ~(uintptr_t)0), slice_hi(slices, 0);    // the stretch of memory the slice's sequences lie in
     parallel_tasks(slices, [&](uint32_t c) {
     uint64_t n_seq = 0;                                                              // (of this slice)
     for (uint32_t i = lo_of(c); i < lo_of(c + 1); ++i) {
@@ -218,6 +225,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
         }
         if (w.status != VGK_OK) w.seq_len = 0;
         n_seq += w.seq_len;
+        if (w.seq_len) { slice_lo[c] = std::min(slice_lo[c], (uintptr_t)p.seq); slice_hi[c] = std::max(slice_hi[c], (uintptr_t)p.seq + w.seq_len); }
     }
     slice_seq[c + 1] = n_seq;
     });
@@ -225,16 +233,29 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     n_seq = slice_seq[slices];
     if (n_seq > 0xfffffff0ull) return VGK_ETOOBIG;
     parallel_tasks(slices, [&](uint32_t c) { const uint32_t add = (uint32_t)slice_seq[c]; if (add) for (uint32_t i = lo_of(c); i < lo_of(c + 1); ++i) probs[i].seq_off += add; });
-    char* seqs = H.seqs.get(be, n_seq + 16);
-    if (!seqs) return VGK_ENOMEM;
-    std::memset(seqs, 0, 8); std::memset(seqs + 8 + n_seq, 0, 8);
-    parallel_for(n, [&](uint32_t i, unsigned) {
-        const vgk_wfa_problem& p = problems[i]; const WProb& w = probs[i];
-        char* r = seqs + w.seq_off;
-        if (w.mode == (uint32_t)VGK_WFA_PREFIX) for (uint32_t k = 0; k < w.seq_len; ++k) r[k] = complement(p.seq[w.seq_len - 1 - k]);
-        else for (uint32_t k = 0; k < w.seq_len; ++k) { const char c = p.seq[k]; r[k] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'X'; }
-    });
+    // The sequences as the kernels read them: ReadMasker's bytes (:160-170), PREFIX problems reverse-complemented, behind each other with 8 bytes
+    // of padding at either end.  When the caller's sequences lie in ONE stretch of memory (a read's pieces cut out of the read, a batch's reads
+    // in one arena: the rule, not the exception) that stretch goes up as it is — straight from the caller's pages when they are page-locked
+    // (vgk_host_register) — and a kernel masks, flips and lays out (wfa_mask_one): 108 MB per 8 000 long reads that no host thread touches.
+    // Otherwise (pointers all over the heap) the host threads gather and mask as before.
+    uintptr_t span_lo = ~(uintptr_t)0, span_hi = 0;
+    for (uint32_t c = 0; c < slices; ++c) { span_lo = std::min(span_lo, slice_lo[c]); span_hi = std::max(span_hi, slice_hi[c]); }
+    const bool one_stretch = n_seq && span_hi > span_lo && (uint64_t)(span_hi - span_lo) <= std::max<uint64_t>(2 * n_seq, n_seq + (1u << 20)) && (uint64_t)(span_hi - span_lo) < 0xfffffff0ull
+                             && !std::getenv("VGAMD_WFA_HOST_MASK");
+    char* seqs = nullptr;
+    if (!one_stretch) {
+        seqs = H.seqs.get(be, n_seq + 16);
+        if (!seqs) return VGK_ENOMEM;
+        std::memset(seqs, 0, 8); std::memset(seqs + 8 + n_seq, 0, 8);
+        parallel_for(n, [&](uint32_t i, unsigned) {
+            const vgk_wfa_problem& p = problems[i]; const WProb& w = probs[i];
+            char* r = seqs + w.seq_off;
+            if (w.mode == (uint32_t)VGK_WFA_PREFIX) for (uint32_t k = 0; k < w.seq_len; ++k) r[k] = complement(p.seq[w.seq_len - 1 - k]);
+            else for (uint32_t k = 0; k < w.seq_len; ++k) { const char c = p.seq[k]; r[k] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'X'; }
+        });
+    }
 
+    lap(0);                                                                      // descriptors + masked sequences (host threads)
     int next_slot = 33;
     auto dev = [&](const void* src, size_t bytes) -> void* {
         void* d = ctx->ensure_scratch(next_slot++, std::max<size_t>(bytes, 16)); if (!d) return nullptr;
@@ -242,7 +263,21 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
         return d;
     };
     P.probs = (const WProb*)dev(probs, sizeof(WProb) * n);
-    P.seqs = (const char*)dev(seqs, n_seq + 16);
+    if (!one_stretch) P.seqs = (const char*)dev(seqs, n_seq + 16);
+    else {
+        uint32_t* src_off = H.src_off.get(be, n);
+        if (!src_off) return VGK_ENOMEM;
+        parallel_for(n, [&](uint32_t i, unsigned) { src_off[i] = probs[i].seq_len ? (uint32_t)((uintptr_t)problems[i].seq - span_lo) : 0u; });
+        char* d_seqs = (char*)ctx->ensure_scratch(next_slot++, n_seq + 16);
+        const char* d_raw = (const char*)ctx->ensure_scratch(66, (uint64_t)(span_hi - span_lo) + 16);
+        const uint32_t* d_src = (const uint32_t*)ctx->ensure_scratch(67, sizeof(uint32_t) * (uint64_t)n);
+        if (!d_seqs || !d_raw || !d_src || !P.probs) return VGK_ENOMEM;
+        if (be->upload((void*)d_raw, (const void*)span_lo, (size_t)(span_hi - span_lo)) || be->upload((void*)d_src, src_off, sizeof(uint32_t) * (size_t)n)) return VGK_ENODEV;
+        if (be->zero(d_seqs, 8) || be->zero(d_seqs + 8 + n_seq, 8)) return VGK_ENODEV;
+        if (int rcm = be->run_wfa_mask(P.probs, d_src, d_raw, d_seqs, n)) return rcm;
+        if (be->sync()) return VGK_ENODEV;                                       // (the caller's pages were the copy's source: it is over before the call returns them)
+        P.seqs = d_seqs;
+    }
     // Hand-out order.  Threads take problems one at a time from a counter, so the order decides two things: problems that sit next to
     // each other in the graph run at the same time and find each other's records and bases in the L2 (mode 1), and long problems —
     // the expensive ones: the cost grows with the errors a sequence can hold — start first instead of leaving a tail of a few late
@@ -299,6 +334,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     P.order = (const uint32_t*)dev(order.data(), sizeof(uint32_t) * n);
     if (P.order && be->sync()) return VGK_ENODEV;                                // (order goes out of scope)
     }
+    lap(1);                                                                      // uploads + the hand-out order
     // dense outputs; the kernel checks them
     const uint64_t cap_p = std::max<uint64_t>(path_cap, (uint64_t)n * 8 + n_seq / 4 + 1024) + 1, cap_e = std::max<uint64_t>(edit_cap, (uint64_t)n * 4 + 1024) + 1;
     P.caps[0] = cap_p; P.caps[1] = cap_e;
@@ -375,6 +411,7 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
         ctx->wfa_last = P; ctx->wfa_last_threads = threads; ctx->wfa_last_valid = true; ctx->wfa_wave_last_valid = false;
         ctx->wfa_ms = be->last_ms(6);
     }
+    lap(2);                                                                      // launches, and the host's wait for them
     ctx->wfa_out.valid = true; ctx->wfa_out.n = n; ctx->wfa_out.res = P.results; ctx->wfa_out.paths = P.paths; ctx->wfa_out.edits = P.edits;
     ctx->wfa_out.path_cap = cap_p; ctx->wfa_out.edit_cap = cap_e; ctx->wfa_out.index = index;
     unsigned long long counters[2] = {0, 0};
@@ -389,8 +426,12 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     if (!dpaths || !dedits) return VGK_ENOMEM;
     if (np && (rc = be->download(dpaths, P.paths, sizeof(uint32_t) * np))) return rc;
     if (ne && (rc = be->download(dedits, P.edits, sizeof(uint32_t) * ne))) return rc;
+    lap(3);                                                                      // results (and paths / edit runs) down
     if (scores_only) {
         parallel_for(n, [&](uint32_t i, unsigned) { vgk_wfa_result r = dres[i]; if (r.status != VGK_OK) r.ok = 0; r.path_begin = r.path_len = r.edit_begin = r.n_edits = 0; results[i] = r; });
+        lap(4);
+        if (times) std::fprintf(stderr, "[wfa times] %u problems, %llu bases: descriptors + masking %.2f ms | uploads + order %.2f | launch + wait %.2f (kernels %.2f) | download %.2f | results %.2f\n",
+                                n, (unsigned long long)n_seq, t_phase[0], t_phase[1], t_phase[2], ctx->wfa_ms, t_phase[3], t_phase[4]);
         return VGK_OK;
     }
     // the device packs alignments in completion order; hand them back in problem order

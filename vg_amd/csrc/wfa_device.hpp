@@ -40,6 +40,14 @@ constexpr uint32_t W_TARGET_LENGTH = 1024;   // WFANode::TARGET_LENGTH
 constexpr uint32_t W_NO_OFFSET = 0xffffffffu;
 enum { WK_MATCH = 0, WK_INS = 1, WK_DEL = 2 };
 
+// The sequence of problem i as the kernels read it, made on the device from the caller's bytes (wfa_api.cpp: the caller's sequences in one
+// stretch of memory, uploaded as it is): ReadMasker's bytes (reference src/gbwt_extender.cpp:160-170: anything but ACGT never matches), a PREFIX
+// problem's reverse complement (:2248-2255).  Lane `lane` of `lanes` takes every lanes-th base.
+VGK_HD char wfa_mask_base(char c) { return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'X'; }
+VGK_HD char wfa_complement_base(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'X'; }
+struct WProb;
+VGK_HD void wfa_mask_one(const WProb* probs, const uint32_t* src_off, const char* raw, char* seqs, uint32_t i, uint32_t lane, uint32_t lanes);
+
 struct WProb {                        // packed by the host
     uint32_t seq_off, seq_len;
     uint32_t mode;
@@ -47,6 +55,12 @@ struct WProb {                        // packed by the host
     int32_t  score_bound, distance_band;
     int32_t  status;                  // problems the host refused keep their status
 };
+VGK_HD void wfa_mask_one(const WProb* probs, const uint32_t* src_off, const char* raw, char* seqs, uint32_t i, uint32_t lane, uint32_t lanes) {
+    const WProb w = probs[i];
+    const char* src = raw + src_off[i]; char* dst = seqs + w.seq_off;
+    if (w.mode == 2u /* VGK_WFA_PREFIX */) for (uint32_t k = lane; k < w.seq_len; k += lanes) dst[k] = wfa_complement_base(src[w.seq_len - 1 - k]);
+    else for (uint32_t k = lane; k < w.seq_len; k += lanes) dst[k] = wfa_mask_base(src[k]);
+}
 
 struct WNode {
     int32_t  st_node, st_lo, st_hi;   // search state at the end of the (materialised) path

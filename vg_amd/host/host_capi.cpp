@@ -823,6 +823,16 @@ void vgh_wfa_destroy(vgh_wfa* w) {
     if (w && w->chain_out && w->ext) { const Aligner& aligner = *w->ext->aligner; static_cast<ChainStageOutput*>(w->chain_out.get())->release(aligner.engine_api(), aligner.engine_context()); }
     delete w;
 }
+// page-lock / release a caller's buffer through the WFA handle's engine context (a batch's sequence arena: it then goes up by DMA straight from the caller's pages)
+int vgh_wfa_host_register(vgh_wfa* w, const void* ptr, uint64_t bytes, int on) {
+    try {
+        const Aligner& aligner = *w->ext->aligner; const EngineApi& api = aligner.engine_api();
+        if (!api.host_register || !api.host_unregister) return 0;
+        const int rc = on ? api.host_register(aligner.engine_context(), ptr, (size_t)bytes) : api.host_unregister(aligner.engine_context(), ptr);
+        if (rc) { g_last_error = api.strerror(rc); return rc; }
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
 // the composed alignments of the last vgh_chain_stage call with anchors: per read vgk_chain_result, the mappings, the edit runs, per read 1 = chain broken; valid until the next call
 int vgh_chain_stage_view(vgh_wfa* w, const void** read_result, const void** mappings, const void** edits, const uint8_t** read_broken, double* stitch_kernel_ms) {
     if (!w || !w->chain_out) { g_last_error = "vgh_chain_stage_view: no chain stage has run on this handle"; return -1; }

@@ -436,6 +436,8 @@ class ChainStage:
         self.graph_distance = np.ascontiguousarray(wl.span, dtype=np.uint32)
         self.read_begin = np.ascontiguousarray(wl.link_begin, dtype=np.uint32); self.read_length = np.ascontiguousarray(wl.link_read_length, dtype=np.uint32)
         self.anchor_score = np.ascontiguousarray(wl.anchor_bases, dtype=np.int64)
+        h.vgh_wfa_host_register.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]
+        self.registered = h.vgh_wfa_host_register(self.wfa, self.seqs.ctypes.data, self.seqs.nbytes, 1) == 0 and self.seqs.nbytes > 0      # (the links' sequences go up by DMA from here)
         self.anchors = [np.ascontiguousarray(getattr(wl, k)) for k in ("anchor_off", "anchor_length", "anchor_node_offset", "anchor_path_off", "anchor_nodes")] if hasattr(wl, "anchor_off") else None
 
     def set_point_budgets(self, connect, tail):
@@ -478,6 +480,8 @@ class ChainStage:
 
     def close(self):
         if getattr(self, "wfa", None):
+            if getattr(self, "registered", False):
+                self.h.vgh_wfa_host_register(self.wfa, self.seqs.ctypes.data, self.seqs.nbytes, 0); self.registered = False
             self.h.vgh_wfa_destroy(self.wfa); self.wfa = None
         if getattr(self, "aligner", None):
             self.h.vgh_aligner_destroy(self.aligner); self.aligner = None
