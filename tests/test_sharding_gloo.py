@@ -74,13 +74,16 @@ def test_host_thread_budget_is_checked_per_rank(monkeypatch):
     assert shard.check_host_thread_budget("linear", 8, cores=16) == 2
     assert shard.check_host_thread_budget("config2", 8, cores=8) == 1
     assert shard.check_host_thread_budget("banded", 2, cores=16) == 8
+    # every leg fits 8 ranks on the 16 CPUs the driver's container grants (banded and longread needed 8 each)
+    for leg in shard.HOST_THREADS_NEEDED:
+        assert shard.HOST_THREADS_NEEDED[leg] <= 4 and (leg in ("gapless", "wfa", "xband", "wide") or shard.check_host_thread_budget(leg, 8, cores=16) == 2), leg
     with pytest.raises(shard.HostThreadBudgetError) as e:
-        shard.check_host_thread_budget("banded", 8, cores=16)
-    assert "8 host threads per rank" in str(e.value) and "leave 2" in str(e.value)
+        shard.check_host_thread_budget("gapless", 8, cores=16)
+    assert "4 host threads per rank" in str(e.value) and "leave 2" in str(e.value)
     with pytest.raises(shard.HostThreadBudgetError):
-        shard.check_host_thread_budget("longread", 4, cores=16)
+        shard.check_host_thread_budget("longread", 16, cores=16)
     monkeypatch.setenv("VGAMD_ALLOW_HOST_STARVED", "1")
-    assert shard.check_host_thread_budget("banded", 8, cores=16) == 2
+    assert shard.check_host_thread_budget("gapless", 8, cores=16) == 2
 
 
 def test_bench_gpus_flag_launches_that_many_ranks():

@@ -56,7 +56,10 @@ HOST_THREADS_NEEDED = {
     "linear": 1, "tails": 1, "forest": 1, "giraffe": 1, "config2": 1,      # resident: kernels only inside the timed region
     "gapless": 4, "wfa": 4, "xband": 4, "wide": 4,                          # sets handed out / re-ordered / packed on host threads
     "paired": 2,                                                            # rescue on the resident graph: the request table and the fix-ups are flat passes (round 5; was 8)
-    "banded": 8, "longread": 8,                                             # band geometry / local graphs on host threads
+    # round 6, measured on the MI355X box pinned to two CPUs (`taskset -c 0-1`, tools/gpu_r06.sh two_cpus; profiles/r06/two_cpus/): the banded leg's timed
+    # region is the resident batch's kernels (27.16 M alignments/s against 27.49 M on 16 CPUs); the long-read stage no longer masks its 108 MB of
+    # link sequences on host threads (vgk_wfa_extend: a kernel does) and composes its alignments on the device: 160.0 k reads/s against 159.2 k (were 121.5 k / 156.8 k)
+    "banded": 2, "longread": 2,
 }
 
 
