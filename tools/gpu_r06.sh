@@ -30,6 +30,14 @@ PY
     set -- ${LEG:-longread --steps 3 --warmup 1}; w=$1; shift
     timeout 1200 python bench.py --workload $w "$@" > "$out/bench_$w${TAG:-}.json" 2> "$out/bench_$w${TAG:-}.err"; tail -3 "$out/bench_$w${TAG:-}.err"
     last_json "$out/bench_$w${TAG:-}.json" "print(round(d['value']), d['ms_per_step'], d.get('parity') and {k: v for k, v in d['parity'].items() if k != 'what'}, d['roofline'].get('frac'), d['config'].get('stage_ms_per_batch'), d['config'].get('stitch_device_ms'))" ;;
+  ab)             # the headline on another build of the library beside the shipped one, twice each: AB=build/variants/libvgamd_NAME.so [ARGS="--workload linear"]
+    for rep in 1 2; do
+      for lib in shipped ${AB:?}; do
+        if [ $lib = shipped ]; then unset VGAMD_ENGINE_LIB; tag=shipped; else export VGAMD_ENGINE_LIB=$GRAFT_REPO_ROOT/$lib; tag=$(basename $lib .so); fi
+        timeout 600 python bench.py ${ARGS:-} --no-secondary --no-cpu --no-e2e > "$out/${tag}_$rep.json" 2> "$out/${tag}_$rep.err"
+        last_json "$out/${tag}_$rep.json" "print('$tag', $rep, round(d['value']), round(d['ms_per_step'], 3), d['roofline'].get('avg_launch_ms'), d['roofline'].get('second_fill_ms'), d['roofline'].get('traceback_tail_ms'), d.get('parity'))"
+      done
+    done; unset VGAMD_ENGINE_LIB ;;
   two_cpus)       # legs pinned to TWO host CPUs (what a rank of an 8-rank run on a 16-CPU box gets) beside the whole box: TWO="longread banded"
     for w in ${TWO:-longread banded}; do
       for cpus in all 2; do

@@ -69,6 +69,10 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
     if (P.wave_limit && wave - P.wave_begin >= *P.wave_limit) return;
     const WaveDesc wd = P.waves[wave];
     Lane<K> s;
+#if VGK_PB_LDS
+    __shared__ uint32_t pb_lds[4][64 * K];      // read B's profile words, [row][lane] per wavefront (gssw_device.hpp: VGK_PB_LDS)
+    s.PBL = (typename Lane<K>::lds_u32*)(pb_lds[threadIdx.x >> 6] + lane);
+#endif
     lane_init(s, P, wd, lane);
     asm volatile("" : "+v"(s.one));   // keep min(x,1) a packed min instead of cmp+cndmask
     uint32_t* tb = P.want_tb ? P.tb : nullptr;

@@ -171,12 +171,27 @@ VGK_HD unsigned long long key64(uint32_t score, uint32_t col, uint32_t row) {
 // ---------------------------------------------------------------------------
 // per-lane state of the fill
 // ---------------------------------------------------------------------------
+// VGK_PB_LDS (device builds of the fill kernels; tools/build_variant.sh): read B's profile words live in LDS, [row][lane] of the wavefront's own
+// 64 K dwords (conflict-free: a row is one 256-byte line), instead of K registers per lane — the rows' only loop-invariant registers the
+// allocator may give up without a spill.  Without it the K = 19 / 20 kernels keep 15 profile words in scratch and load them back every step.
+#ifndef VGK_PB_LDS
+#define VGK_PB_LDS 0
+#endif
 template <int K>
 struct Lane {
     uint32_t H[K];      // H of the last processed column          {B:A}
     uint32_t E[K];      // E for the next column                   {B:A}
     uint32_t PA[K];     // query profile of read A: 4 biased bytes (ref A,C,G,T) per row
+#if VGK_PB_LDS && defined(__HIPCC__)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* PBL;       // this lane's column of the wavefront's LDS block: row m at PBL[64 m] (a 32-bit LDS address: ds_read_b32 with the row as the instruction's offset)
+    VGK_HD uint32_t pb(int m) const { return *(const volatile lds_u32*)(PBL + 64 * m); }      // (volatile: read where it is used — hoisted out of the step loop the K words would be registers again, and spilled)
+    VGK_HD void set_pb(int m, uint32_t v) { PBL[64 * m] = v; }
+#else
     uint32_t PB[K];
+    VGK_HD uint32_t pb(int m) const { return PB[m]; }
+    VGK_HD void set_pb(int m, uint32_t v) { PB[m] = v; }
+#endif
     uint32_t out_h, out_f, info;    // handed to lane+1 at the next step
     uint32_t prev_rh;               // H of the row above this lane's block, previous column
     uint32_t best_lo, best_hi, step_lo, step_hi;
@@ -219,7 +234,7 @@ VGK_HD void lane_init(Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint3
         uint32_t pa = 0, pb = 0;
         if (row < s.LA) pa = poA != 0xffffffffu ? P.prof[poA + row] : pw.of_row(P.reads[roA + row]) + 0x01010101u * row_bonus(s.bsA, s.beA, row, s.LA);
         if (row < s.LB) pb = poB != 0xffffffffu ? P.prof[poB + row] : pw.of_row(P.reads[roB + row]) + 0x01010101u * row_bonus(s.bsB, s.beB, row, s.LB);
-        s.PA[m] = pa; s.PB[m] = pb; s.H[m] = 0; s.E[m] = 0;
+        s.PA[m] = pa; s.set_pb(m, pb); s.H[m] = 0; s.E[m] = 0;
     }
     s.out_h = 0; s.out_f = 0; s.info = CI_INVALID2; s.prev_rh = 0;
     s.best_lo = s.best_hi = 0; s.step_lo = s.step_hi = 0;
@@ -361,7 +376,7 @@ constexpr uint32_t KEY_SHIFT = 5, KEY_LOW = 31;
 template <int K, int M, bool REFN, bool S8, bool TB>
 VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, uint32_t go2, uint32_t ge2,
                      bool nA, bool nB, uint32_t& f, uint32_t& d, uint32_t* acc, uint32_t& ck) {
-    uint32_t sb = byte_perm(s.PB[M], s.PA[M], sel);
+    uint32_t sb = byte_perm(s.pb(M), s.PA[M], sel);
     if (REFN) {
         const uint32_t row = s.g * K + M;
         if (nA) sb = set_lo(sb, row < s.LA ? P.bias + row_bonus(s.bsA, s.beA, row, s.LA) : 0u);
@@ -993,6 +1008,9 @@ struct ReWalker {
         const GsswParams& P = base.P; const ProbDesc& d = base.d;
         const uint32_t half = base.half, lane = base.lane0 + g;
         const uint64_t tb_off = base.tb_off;
+#if VGK_PB_LDS && defined(__HIPCC__)
+        ln.PBL = (typename Lane<K>::lds_u32*)(uintptr_t)0;      // (unsupported with VGK_PB_LDS: the rewalk kernels are not built for it)
+#endif
         const uint32_t c0 = c / TB_CKPT * TB_CKPT;
         Lane<K>& s = ln;
         // the read in its half of the pair, the other half idle
@@ -1009,7 +1027,7 @@ struct ReWalker {
             const uint32_t row = g * K + m;
             uint32_t pw = 0;
             if (row < d.L) pw = d.prof_off != 0xffffffffu ? P.prof[d.prof_off + row] : P.prof4[P.reads[d.read_off + row]] + 0x01010101u * row_bonus(d.bonus_start, d.bonus_end, row, d.L);
-            s.PA[m] = half ? 0u : pw; s.PB[m] = half ? pw : 0u;
+            s.PA[m] = half ? 0u : pw; s.set_pb(m, half ? pw : 0u);
             s.H[m] = ck ? ck[m] & keep : 0u; s.E[m] = ck ? ck[K + m] & keep : 0u;
         }
         s.out_h = 0; s.out_f = 0; s.info = CI_INVALID2;
@@ -1071,6 +1089,9 @@ VGK_HD bool tb_band_end(const GsswParams& P, const ProbDesc& d, unsigned long lo
 template <int K, bool S8>
 VGK_HD void band_fill_lane(const GsswParams& P, const WaveDesc& wd, uint32_t lane) {
     Lane<K> s;
+#if VGK_PB_LDS && defined(__HIPCC__)
+    s.PBL = (typename Lane<K>::lds_u32*)(uintptr_t)0;      // (unsupported with VGK_PB_LDS)
+#endif
     lane_init(s, P, wd, lane);                   // the pair, its rows' profiles, the lane block index g — as the fill began
     const uint32_t g = s.g;
     uint32_t re[2] = {0, 0}, ce[2] = {0, 0}; TbBand bd[2]; bd[0].used = bd[1].used = false;
