@@ -441,7 +441,9 @@ def bench_longread(args, eng, rank, world, dist, torch, dev_name, cus):
     # a step = n reads in batches of `per`; two batches in flight (a lane = a ChainStage of its own: engine context, haplotype graph, WFA extender,
     # host threads), because a launch of the WFA kernel ends with ONE heavy link's dependent chain — the second lane's links run in the wavefronts
     # the first lane's launch has already given back, and its host work (local graphs, problem records) runs beside the other's kernels
-    want_lanes = 1 if os.environ.get("VGAMD_LONGREAD_ONE_LANE") else max(1, int(os.environ.get("VGAMD_LONGREAD_LANES", "2")))
+    # (round 6: four lanes — the stage's host work per batch, descriptors, pieces and copies, is as long as its kernels: 190 k reads/s with four batches of
+    # 8 000 in flight against 167 k with two, profiles/r06/sweeps.txt)
+    want_lanes = 1 if os.environ.get("VGAMD_LONGREAD_ONE_LANE") else max(1, int(os.environ.get("VGAMD_LONGREAD_LANES", "4")))
     per = int(os.environ.get("VGAMD_LONGREAD_BATCH", "8000"))      # (a launch of the WFA kernel is at least its heaviest link's dependent chain, ~25 ms: 4 000 reads 28.7 ms, 8 000 36.1, 16 000 68.4)
     n = args.reads if args.reads else per * max(2, want_lanes)
     per = min(n, per)

@@ -38,6 +38,13 @@ PY
         last_json "$out/${tag}_$rep.json" "print('$tag', $rep, round(d['value']), round(d['ms_per_step'], 3), d['roofline'].get('avg_launch_ms'), d['roofline'].get('second_fill_ms'), d['roofline'].get('traceback_tail_ms'), d.get('parity'))"
       done
     done; unset VGAMD_ENGINE_LIB ;;
+  sweep)          # one leg against one environment knob: SWEEP="VGAMD_LONGREAD_LANES 2 3 4" LEGARGS="longread --steps 3 --warmup 1 --no-cpu"
+    set -- ${SWEEP:?}; knob=$1; shift
+    for v in "$@"; do
+      export $knob=$v
+      timeout 900 python bench.py --workload ${LEGARGS:?} > "$out/${knob}_$v.json" 2> "$out/${knob}_$v.err"
+      last_json "$out/${knob}_$v.json" "print('$knob', '$v', round(d['value']), round(d['ms_per_step'], 2), d['config'].get('ms_per_batch'), d['config'].get('kernel_ms_per_batch'), d['config'].get('one_lane') or d['config'].get('one_context'))"
+    done; unset $knob ;;
   two_cpus)       # legs pinned to TWO host CPUs (what a rank of an 8-rank run on a 16-CPU box gets) beside the whole box: TWO="longread banded"
     for w in ${TWO:-longread banded}; do
       for cpus in all 2; do
