@@ -13,6 +13,7 @@ struct vgk_batch {
     uint32_t n = 0;
     bool want_tb = false, ran = false;
     bool probs_displaced = false;                     // a speculative run has rewritten descriptors of this batch (GsswParams::restore_probs)
+    bool spec_probe = false;                           // the last run was a probe of the context's SpecPolicy (ctx.hpp)
     bool ran_spec = false, spec_observed = true;      // the last run speculated | its miss count has been handed to the context's SpecPolicy
     GsswParams P{};
     std::vector<vgk_ctx::Pooled> dev;   // every device allocation of this batch (back to the context's pool when the batch is freed)

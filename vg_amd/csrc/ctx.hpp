@@ -32,20 +32,25 @@ struct SpecPolicy {
     uint32_t probe_every = 16;       // VGAMD_SPEC_PROBE_EVERY: the first interval between probes while speculation is off
     bool on = true; uint32_t wait = 0, interval = 16;
     uint64_t observed = 0, turned_off = 0, turned_on = 0; double last_miss = 0.0;
-    bool decide() {
+    // *probe: this run is a probe (one speculative run while speculation is off); its observation alone may lengthen the interval
+    bool decide(bool* probe = nullptr) {
+        if (probe) *probe = false;
         if (mode == 1) return true;
         if (mode == 2) return false;
         if (on) return true;
         if (wait) { --wait; return false; }
         wait = interval;                                                   // a probe: one speculative run; its count decides
+        if (probe) *probe = true;
         return true;
     }
-    void observe(double miss) {
+    // was_probe: the observed run was launched as a probe.  A run launched while speculation was still ON and observed after it went off (two
+    // batches in flight) is no probe: its high count neither turns anything off again nor doubles the interval.
+    void observe(double miss, bool was_probe = false) {
         ++observed; last_miss = miss;
         if (miss > miss_max) {
             if (on) { on = false; ++turned_off; interval = probe_every; wait = interval; }
-            else { interval = interval >= 512 ? 1024 : interval * 2; wait = interval; }      // a probe that failed
-        } else if (!on) { on = true; ++turned_on; interval = probe_every; wait = 0; }
+            else if (was_probe) { interval = interval >= 512 ? 1024 : interval * 2; wait = interval; }      // a probe that failed
+        } else if (!on && (was_probe || mode == 0)) { on = true; ++turned_on; interval = probe_every; wait = 0; }
     }
 };
 

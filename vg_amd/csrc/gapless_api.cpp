@@ -181,6 +181,8 @@ int vgk_haplo_create(vgk_ctx* ctx, const vgk_haplotypes* d, vgk_haplo** out) try
     return vgk_haplo_from_tables(ctx, O, len, seq_off, seq, (uint32_t)total, T, out);
 } catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }      // (no exception leaves the C ABI)
 
+struct vgk_haplo::PendingMerge { uint32_t O = 0, total = 0; std::vector<uint32_t> len; std::vector<char> seq; HaploTables T; };
+
 // The records as the kernels read them, from the tables either builder makes (this file's, from threads; gbwt_file.cpp's, straight from
 // a GBWT's own records): per oriented node its visits (count), per visit the edge it leaves through (body, from body_off), its edges in
 // successor order (edge_to from edge_off; -1 = the path ends here, first) and per edge the rank of its first visit in the successor's record.
@@ -195,7 +197,6 @@ static int merge_unary_runs(vgk_ctx* ctx, vgk_haplo* h, uint32_t O, const std::v
     // are two or three nodes), and the merged build's extra live values are scratch traffic of their own.
     // The WFA wavefront kernel walks the merged index always (its trie walk is one lane's chain of record fetches: hops are its time).
     if (N < 2 || std::getenv("VGAMD_HAPLO_NO_MERGE")) return VGK_OK;
-    h->search_merged = std::getenv("VGAMD_HAPLO_MERGE") != nullptr;
     auto unary = [&](uint32_t o, uint32_t p) {
         return T.count[o] > 0 && T.edge_off[o + 1] - T.edge_off[o] == 1 && T.edge_to[T.edge_off[o]] == (int32_t)p && T.edge_base[T.edge_off[o]] == 0 && T.count[p] == T.count[o];
     };
@@ -252,6 +253,7 @@ static int merge_unary_runs(vgk_ctx* ctx, vgk_haplo* h, uint32_t O, const std::v
     std::lock_guard<std::mutex> lock(ctx->mu);
     if ((rc = put(h, seed_map, h->merge.seed_map)) || (rc = put(h, run_first, h->merge.run_first)) || (rc = put(h, ocol, h->merge.ocol)) || (rc = ctx->be->sync())) { vgk_haplo_destroy(mh); return rc; }
     h->merge.on = 1; h->merge.n_orig_oriented = O; h->merged = mh;
+    h->search_merged = std::getenv("VGAMD_HAPLO_MERGE") != nullptr;              // (only with a merged form to search)
     return VGK_OK;
 }
 
@@ -312,9 +314,22 @@ extern "C++" int vgk_haplo_from_tables(vgk_ctx* ctx, uint32_t O, const std::vect
         delete h; return rc;
     }
     lock.unlock();
-    if (merge_runs && (rc = merge_unary_runs(ctx, h, O, len, seq, total, T))) { vgk_haplo_destroy(h); return rc; }
+    if (merge_runs && !std::getenv("VGAMD_HAPLO_NO_MERGE")) {
+        if (std::getenv("VGAMD_HAPLO_MERGE")) { if ((rc = merge_unary_runs(ctx, h, O, len, seq, total, T))) { vgk_haplo_destroy(h); return rc; } }      // the gapless search walks it: now
+        else { auto pm = std::make_shared<vgk_haplo::PendingMerge>(); pm->O = O; pm->len = len; pm->seq = seq; pm->total = total; pm->T = T; h->pending_merge = pm; }   // the first vgk_wfa_extend builds it
+    }
     *out = h;
     return VGK_OK;
+}
+
+extern "C++" int vgk_haplo_ensure_merged(vgk_haplo* h) {
+    if (!h) return VGK_EINVAL;
+    std::lock_guard<std::mutex> once(h->merge_mu);
+    if (!h->pending_merge) return VGK_OK;
+    std::shared_ptr<vgk_haplo::PendingMerge> pm = h->pending_merge;
+    const int rc = merge_unary_runs(h->ctx, h, pm->O, pm->len, pm->seq, pm->total, pm->T);
+    h->pending_merge.reset();                                                   // (built, or not buildable: either way the tables go)
+    return rc;
 }
 
 void vgk_haplo_destroy(vgk_haplo* h) {
@@ -626,7 +641,11 @@ int vgk_gapless_rerun(vgk_ctx* ctx) try {
 double vgk_gapless_last_ms(vgk_ctx* ctx) { return ctx ? ctx->gapless_ms : 0.0; }
 uint64_t vgk_gapless_last_retried(vgk_ctx* ctx) { return ctx ? ctx->gapless_retried : 0; }
 uint64_t vgk_gapless_last_redone(vgk_ctx* ctx) { return ctx ? ctx->gapless_redone : 0; }
-uint64_t vgk_haplo_run_nodes(const vgk_haplo* index) { return index ? (index->merged ? index->merged->n_oriented / 2 : index->n_oriented / 2) : 0; }
+uint64_t vgk_haplo_run_nodes(const vgk_haplo* index) {      // (asks about the merged form: builds it when it is still pending)
+    if (!index) return 0;
+    if (index->pending_merge) vgk_haplo_ensure_merged(const_cast<vgk_haplo*>(index));
+    return index->merged ? index->merged->n_oriented / 2 : index->n_oriented / 2;
+}
 uint64_t vgk_haplo_search_nodes(const vgk_haplo* index) { return index ? (index->merged && index->search_merged ? index->merged->n_oriented / 2 : index->n_oriented / 2) : 0; }
 
 }  // extern "C"

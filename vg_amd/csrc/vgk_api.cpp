@@ -492,7 +492,7 @@ static void observe_speculation(vgk_batch* b) {
     b->spec_observed = true;
     uint32_t refilled = 0;
     if (b->ctx->be->download_fetch(&refilled, b->P.refill_count, sizeof refilled) != VGK_OK) return;
-    b->ctx->spec.observe(b->P.n_waves ? (double)refilled / (double)b->P.n_waves : 0.0);
+    b->ctx->spec.observe(b->P.n_waves ? (double)refilled / (double)b->P.n_waves : 0.0, b->spec_probe);
 }
 
 int vgk_gssw_run(vgk_batch* b) try {
@@ -503,7 +503,9 @@ int vgk_gssw_run(vgk_batch* b) try {
     if (b->P.spec_fill) {
         // (a resident batch that is run again without a fetch in between: its own last run tells as much as a fetched one)
         if (b->ran && b->ran_spec && !b->spec_observed && b->ctx->be->event_done(b->done)) observe_speculation(b);
-        const bool speculate = b->ctx->spec.decide();
+        bool probe = false;
+        const bool speculate = b->ctx->spec.decide(&probe);
+        b->spec_probe = probe;
         if (!speculate) {                                                  // the plain fill with codes over the same arenas (they hold either form)
             P.spec_fill = 0; P.wave_limit = nullptr;
             P.restore_probs = b->probs_displaced ? 1 : 0;                   // (an earlier speculative run moved its missed reads' descriptors to their second wavefronts)
@@ -595,7 +597,7 @@ static int gssw_fetch_impl(vgk_batch* b, vgk_result* results, vgk_op* ops, size_
     { int rc = b->done ? b->ctx->be->event_wait(b->done) : b->ctx->be->sync(); if (rc) return rc; }
     int rc = b->ctx->be->fetch_after(b->done);
     if (rc) return rc;
-    if (b->ran_spec && !b->spec_observed) { std::lock_guard<std::mutex> lk(b->ctx->mu); observe_speculation(b); }
+    { std::lock_guard<std::mutex> lk(b->ctx->mu); if (b->ran_spec && !b->spec_observed) observe_speculation(b); }      // (the two flags are vgk_gssw_run's, written under the lock)
     rc = fetch_packed_on_device(b, results, ops, ops_cap, ops_written);       // takes the context lock for its arenas only
     if (rc != VGK_EUNSUPPORTED) return rc;
     std::lock_guard<std::mutex> lk(b->ctx->mu);

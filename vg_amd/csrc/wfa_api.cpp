@@ -168,6 +168,8 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
         if (e->per_base < 0 || e->min < 0 || e->max < e->min) return VGK_EINVAL;
     const int32_t match = ctx->sc.matrix[0], mism = -ctx->sc.matrix[1], go = ctx->sc.gap_open, ge = ctx->sc.gap_extend;
     if (match < 0 || mism <= 0 || go < ge || ge <= 0) return VGK_EUNSUPPORTED;                    // (:1256-1259)
+    // the index with its unary runs merged is what the wavefront kernel walks: built here, once, by the first call that wants it (haplo.hpp)
+    if (index->pending_merge && !std::getenv("VGAMD_WFA_NO_MERGE")) { if (int rcm = vgk_haplo_ensure_merged(const_cast<vgk_haplo*>(index))) return rcm; }
     std::lock_guard<std::mutex> lock(ctx->mu);
     // VGAMD_WFA_TIMES=1: where the call's host time goes (stderr, one line per call)
     const bool times = std::getenv("VGAMD_WFA_TIMES") != nullptr;

@@ -182,11 +182,11 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
         if (bw) check(api.gssw_run(bw), "vgk_gssw_run");
         size_t written = 0;
         er.assign(ep.size(), vgk_result{}); wr.assign(wp.size(), vgk_result{});
-        if (be) { eo.need(traced ? ep.size() * (size_t)OPS_PER + 1 : 1); check(api.gssw_fetch(be, er.data(), eo.data(), traced ? eo.cap : 0, &written), "vgk_gssw_fetch"); }
-        if (bw) { wo.need(traced ? wp.size() * (size_t)OPS_PER + 1 : 1); check(api.gssw_fetch(bw, wr.data(), wo.data(), traced ? wo.cap : 0, &written), "vgk_gssw_fetch"); }
+        if (be) { eo.need(traced ? ep.size() * (size_t)OPS_PER + 1 : 1); const int rcf = api.gssw_fetch(be, er.data(), eo.data(), traced ? eo.cap : 0, &written); if (rcf != VGK_EOPS) check(rcf, "vgk_gssw_fetch"); }      // (VGK_EOPS: single problems' tracebacks outgrew their budgets — their statuses say which)
+        if (bw) { wo.need(traced ? wp.size() * (size_t)OPS_PER + 1 : 1); const int rcf = api.gssw_fetch(bw, wr.data(), wo.data(), traced ? wo.cap : 0, &written); if (rcf != VGK_EOPS) check(rcf, "vgk_gssw_fetch"); }
         if (timing) for (vgk_batch* b : {be, bw}) if (b) { timing->kernel_ms += api.batch_kernel_ms(b, -1); timing->alg_bytes += api.batch_alg_bytes(b); timing->cells += api.batch_cells(b); }
-        for (const vgk_result& r : er) check(r.status, "an extension window");
-        for (const vgk_result& r : wr) check(r.status, "a window");
+        // (a single problem the engine declined — VGK_EOPS: more op runs than a traceback's budget, VGK_ETOOBIG ... — is its request's affair, not the
+        // batch's: MinimizerMapper::attempt_rescue fails per pair and leaves the other pairs what they have.  The callers below look at r.status.)
     };
     std::vector<vgk_result> er, wr; OpBuffer eo, wo;
     round(ext1, scan, false, er, eo, wr, wo);
@@ -194,13 +194,14 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
     // the heads (xdrop_extend_finish's end position; the scan's end cell: src/dozeu_interface.cpp:188-208)
     for (size_t q = 0; q < ext1.size(); ++q) {
         const vgk_result& r = er[q]; State& s = st[ext1_of[q]]; const RescueRequestFlat& rq = requests[ext1_of[q]];
+        if (r.status != VGK_OK) { s.have_head = false; s.fallback = true; s.rescore_fallback = true; continue; }      // the engine declined this extension: the full DP for this mate
         if (r.score <= 0) continue;                                                         // the seed's own position stays the head
         const uint32_t en = rq.node_lo + (uint32_t)r.end_node, used = (uint32_t)r.end_offset + 1;
         s.head_ref = (en == (uint32_t)rq.seed_node ? (uint32_t)rq.seed_offset : 0u) + used; s.head_node = en; s.head_query = (uint32_t)rq.seed_begin + (uint32_t)r.end_read + 1;
     }
     for (size_t q = 0; q < scan.size(); ++q) {
         const vgk_result& r = wr[q]; State& s = st[scan_of[q]]; const RescueRequestFlat& rq = requests[scan_of[q]];
-        if (r.score <= 0) { s.fallback = true; s.rescore_fallback = true; continue; }      // dozeu's seeding heuristic failed: gssw instead (src/aligner.cpp:848-854), then fix_dozeu_score sees that alignment
+        if (r.status != VGK_OK || r.score <= 0) { s.fallback = true; s.rescore_fallback = true; continue; }      // dozeu's seeding heuristic failed (or the engine declined the scan): gssw instead (src/aligner.cpp:848-854), then fix_dozeu_score sees that alignment
         const uint32_t scan_len = std::min<uint32_t>(rq.read_len, 15);
         s.have_head = true; s.head_node = rq.node_lo + (uint32_t)r.end_node; s.head_ref = (uint32_t)r.end_offset + 1; s.head_query = (rq.read_len - scan_len) + (uint32_t)r.end_read + 1;
     }
@@ -257,6 +258,7 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
                 __builtin_prefetch(reads + nx.read_off); __builtin_prefetch(reads + nx.read_off + 64); __builtin_prefetch(reads + nx.read_off + 128);
             }
             if (s.kind == R_DONE || !s.have_head) continue;
+            if (s.slot2 >= 0 && er[(size_t)s.slot2].status != VGK_OK) { s.fallback = true; s.rescore_fallback = true; continue; }      // the traced pass was declined: the full DP for this mate
             const char* read = reads + rq.read_off;
             a.clear();
             int32_t down_score = 0;
@@ -338,6 +340,7 @@ void run_rescue_stage_resident(const Aligner& aligner, const ResidentRescueGraph
         FlatAlignment a;
         for (size_t q = lo; q < hi; ++q) {
             const size_t k = full_of[q]; State& s = st[k]; const RescueRequestFlat& rq = requests[k]; const vgk_result& r = wr[q];
+            if (r.status != VGK_OK) { RescueResult& out = results[k]; out = RescueResult{}; out.status = 3; out.score = 0; out.first_node = r.status; op_count[k] = 0; continue; }   // this mate stays unrescued (status 3; first_node: the VGK_E* code)
             const char* read = reads + rq.read_off;
             // gssw_mapping_to_alignment (src/aligner.cpp:120-241) over the op list: matches and single-base substitutions by character (the node's
             // bases as gssw saw them: nonATGCNtoN), every insertion / soft clip an edit of its own

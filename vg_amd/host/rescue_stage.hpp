@@ -27,7 +27,7 @@ struct RescueRequest {
 // where a value above 65 535 wraps modulo 65 536; both rescue paths here clamp it to 65 535 instead — the saner reading, and the same for every
 // scoring and read length a 16-bit score range admits (150-base reads: 81).]
 struct RescueResult {
-    int32_t score = 0; int32_t status = 0;                  // status: 0 aligned (score may be 0), 1 refused by the cell budget, 2 empty subgraph
+    int32_t score = 0; int32_t status = 0;                  // status: 0 aligned (score may be 0), 1 refused by the cell budget, 2 empty subgraph, 3 the engine declined every route for this mate (first_node = the VGK_E* code; rescue_resident.cpp)
     int64_t first_node = -1, first_offset = 0; uint32_t n_mappings = 0, aligned_read_bases = 0;
 };
 constexpr uint64_t default_max_dozeu_cells = (uint64_t)(1.5 * 1024 * 1024);      // src/minimizer_mapper.hpp:471

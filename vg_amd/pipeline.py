@@ -591,24 +591,24 @@ def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device
     if len(pairs):
         h = _host_lib()
         flat = np.ascontiguousarray(rd).ravel(); roff = (np.arange(len(pairs) + 1, dtype=np.uint64) * L)
-        ops_cap = len(pairs) * 64 if (want_ops or resident is None and want_ops) else 0
-        ops = np.zeros(max(ops_cap, 1), dtype=capi.OP_DT); written = ctypes.c_uint64()
-        if resident is not None:
-            h.vgh_rescue_stage_resident.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int,
-                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-            rc = h.vgh_rescue_stage_resident(host_aligner.ptr, resident.ptr, len(pairs), flat.ctypes.data, flat.size, roff.ctypes.data, req.ctypes.data, 0, host_threads, outv.ctypes.data,
-                                             ops_begin.ctypes.data if want_ops else None, ops.ctypes.data if want_ops else None, ops_cap, ctypes.byref(written), laps.ctypes.data, counts.ctypes.data)
-        else:
-            node_len = np.ascontiguousarray(g.node_len, dtype=np.uint32); seq_off = np.ascontiguousarray(g.col[:-1], dtype=np.uint64); seq = np.ascontiguousarray(g.seq)
-            args = [host_aligner.ptr, g.n_nodes, node_len.ctypes.data, seq_off.ctypes.data, seq.ctypes.data, wl.succ_off.ctypes.data, wl.succ.ctypes.data,
-                    len(pairs), flat.ctypes.data, roff.ctypes.data, req.ctypes.data, 0, host_threads, outv.ctypes.data]
-            base_types = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
+        # (the resident route returned above: this is the per-graph form — one HashGraph per mate on host threads)
+        node_len = np.ascontiguousarray(g.node_len, dtype=np.uint32); seq_off = np.ascontiguousarray(g.col[:-1], dtype=np.uint64); seq = np.ascontiguousarray(g.seq)
+        args = [host_aligner.ptr, g.n_nodes, node_len.ctypes.data, seq_off.ctypes.data, seq.ctypes.data, wl.succ_off.ctypes.data, wl.succ.ctypes.data,
+                len(pairs), flat.ctypes.data, roff.ctypes.data, req.ctypes.data, 0, host_threads, outv.ctypes.data]
+        base_types = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
+        ops_cap = len(pairs) * 64 if want_ops else 0
+        written = ctypes.c_uint64()
+        for attempt in range(2):                       # -2: the op runs need more room than the first guess; `written` says how much (as Engine.rescue_requests retries on VGK_EOPS)
+            ops = np.zeros(max(ops_cap, 1), dtype=capi.OP_DT)
             if want_ops:
                 h.vgh_rescue_stage_ops.argtypes = base_types + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
                 rc = h.vgh_rescue_stage_ops(*args, ops_begin.ctypes.data, ops.ctypes.data, ops_cap, ctypes.byref(written))
             else:
                 h.vgh_rescue_stage.argtypes = base_types
                 rc = h.vgh_rescue_stage(*args)
+            if rc != -2 or not want_ops or int(written.value) <= ops_cap:
+                break
+            ops_cap = int(written.value)
         if rc != 0:
             raise RuntimeError(h.vgh_last_error().decode())
         ops = ops[:int(written.value)] if want_ops else ops[:0]
@@ -618,9 +618,6 @@ def paired_stage(eng, index, mindex, wl, host_aligner, oriented_len=None, device
     if timing is not None:
         for k, v in (("stage (seeding, extension, tails)", t1 - t0), ("rescue requests (host)", t2 - t1), ("rescue stage (subgraphs, X-drop passes, fix-ups)", t3 - t2)):
             timing[k] = timing.get(k, 0.0) + v
-        if resident is not None:
-            for k, v in zip(("rescue: classify (host)", "rescue: first pass (extension windows + scans)", "rescue: second pass (traced extension windows)", "rescue: alignments + fix-ups (host)", "rescue: full-DP fallback"), laps):
-                timing[k] = timing.get(k, 0.0) + v * 1e-3
     return dict(read_score=read_score, rescued=lost, mapped=mapped, requests=req, rescue=outv, pair_score=pair_score, res=res, rescue_ops=ops, rescue_ops_begin=ops_begin,
                 rescue_counts=dict(zip(("first_pass", "scans", "second_pass", "fallbacks", "alg_bytes", "cells"), (int(x) for x in counts)), kernel_ms=float(laps[5])))
 
