@@ -450,13 +450,7 @@ class WfaWorkload:
                     w = comp[w[::-1]]; lo, hi = hi, lo
                 # errors: substitutions and 1-bp indels
                 e = rng.random(len(w)) < error_rate
-                if e.any() and graph is not None:                      # (the same error model, drawn array-wise: a chr22-scale run makes 240 Mbp of reads)
-                    idx = np.nonzero(e)[0]; x = rng.random(len(idx)); nb = ACGT[rng.integers(0, 4, len(idx))]
-                    w = w.copy(); w[idx[x < 0.5]] = nb[x < 0.5]
-                    keep_base = np.ones(len(w), dtype=bool); keep_base[idx[(x >= 0.5) & (x < 0.75)]] = False
-                    at = idx[x >= 0.75] + 1
-                    w = np.insert(w, at, nb[x >= 0.75])[np.insert(keep_base, at, True)]
-                elif e.any():
+                if e.any():
                     out = []
                     for c, bad in zip(w, e):
                         if not bad:
