@@ -574,6 +574,22 @@ double vgk_minimizer_last_ms(vgk_ctx* ctx);                              /* devi
 typedef struct vgk_seed_policy { uint32_t hit_cap, hard_hit_cap; double minimizer_score_fraction; } vgk_seed_policy;
 #define VGK_MINIMIZERS_POLICY_SKIPPED 0x40000000u
 int  vgk_minimizer_set_policy(vgk_minimizer_index* index, const vgk_seed_policy* policy);
+/* ---- seeding reads of ANY length (giraffe's long-read path: a 15 kbp read has ~2 500 minimizers and as many seeds as they have hits) ----------
+ * vgk_minimizer_seeds above is the short-read form: at most 64 minimizers go through the device's policy, at most 64 seeds make a cluster.  These
+ * two calls have no such caps and leave find_seeds' choice (src/minimizer_mapper.cpp:4109-4440, every filter: hit caps, score fraction,
+ * max_unique_min / num_bp_per_min :4162,4312-4320, window downsampling, exclude-overlapping) to the caller between them — the host shim's
+ * select_minimizers (vg_amd/host/seed_policy.cpp) restates it for any number of minimizers:
+ *   vgk_minimizer_list      every minimizer of every read, in read order: key, offset of the k-mer's first base in the read, hits in the index,
+ *                           orientation (minimizer_regions + find, :3918-3965); minimizer_off[n + 1], VGK_EOPS / *written as usual;
+ *   vgk_minimizer_seeds_of  the seeds of the minimizers the caller TAKES (take[j] != 0), one per hit in index order (key, node, offset), nothing
+ *                           de-duplicated (:4290-4340: one Seed per hit): seed_off[n_minimizers + 1] = where minimizer j's seeds start.
+ * A seed is (oriented node, read offset - node offset) on the strand the read reads forward on, as above. */
+typedef struct vgk_read_minimizer { uint64_t key; uint32_t offset, hits, flags, reserved; } vgk_read_minimizer;
+#define VGK_MINIMIZER_REVERSE 1u       /* flags: the canonical k-mer is the reverse complement of the read's */
+int  vgk_minimizer_list(vgk_ctx* ctx, const vgk_minimizer_index* index, const char* reads, const uint64_t* read_off, uint32_t n,
+                        uint64_t* minimizer_off, vgk_read_minimizer* minimizers, size_t cap, size_t* written);
+int  vgk_minimizer_seeds_of(vgk_ctx* ctx, const vgk_minimizer_index* index, const vgk_read_minimizer* minimizers, const uint8_t* take, size_t n_minimizers,
+                            uint64_t* seed_off, vgk_seed* seeds, size_t cap, size_t* written);
 /* The clusters of the last vgk_minimizer_seeds call on this context, extended as vgk_gapless_extend would extend them — without the
  * reads or the seeds crossing PCIe again: they are still in HBM (reads masked and padded as the extension kernels want them), and the
  * problem descriptors and the hand-out order are made there.  `index` must be the haplotype index that call was given; one

@@ -254,3 +254,46 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
     return rc;
 }
 double vgk_minimizer_last_ms(vgk_ctx* ctx) { (void)ctx; return 0.0; }
+
+/* ---- reads of any length (include/vgk.h: vgk_minimizer_list / vgk_minimizer_seeds_of): every minimizer, then one seed per hit of the taken ones ---- */
+typedef struct { const vgk_minimizer_index* ix; vgk_read_minimizer* out; size_t n, cap; } LongList;
+static void long_emit(void* c, uint32_t p, uint64_t key, uint64_t hash, int reverse) {
+    LongList* l = (LongList*)c; (void)hash;
+    if (l->out && l->n < l->cap) { size_t a, b; key_range(l->ix, key, &a, &b); vgk_read_minimizer r; r.key = key; r.offset = p; r.hits = (uint32_t)(b - a); r.flags = reverse ? VGK_MINIMIZER_REVERSE : 0u; r.reserved = 0; l->out[l->n] = r; }
+    ++l->n;
+}
+int vgk_minimizer_list(vgk_ctx* ctx, const vgk_minimizer_index* ix, const char* reads, const uint64_t* read_off, uint32_t n,
+                       uint64_t* minimizer_off, vgk_read_minimizer* out, size_t cap, size_t* written) {
+    if (!ctx || !ix || !minimizer_off || (n && (!reads || !read_off)) || (!out && cap)) return VGK_EINVAL;
+    LongList l; l.ix = ix; l.out = out; l.n = 0; l.cap = cap;
+    minimizer_off[0] = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (read_off[i + 1] < read_off[i]) return VGK_EINVAL;
+        minimizers(reads + read_off[i], (uint32_t)(read_off[i + 1] - read_off[i]), ix->k, ix->w, long_emit, &l);
+        minimizer_off[i + 1] = l.n;
+    }
+    if (written) *written = l.n;
+    return l.n > cap ? VGK_EOPS : VGK_OK;
+}
+int vgk_minimizer_seeds_of(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_read_minimizer* minimizers, const uint8_t* take, size_t n_minimizers,
+                           uint64_t* seed_off, vgk_seed* seeds, size_t cap, size_t* written) {
+    if (!ctx || !ix || !seed_off || (n_minimizers && (!minimizers || !take)) || (!seeds && cap)) return VGK_EINVAL;
+    size_t total = 0;
+    seed_off[0] = 0;
+    for (size_t j = 0; j < n_minimizers; ++j) {
+        if (take[j]) {
+            size_t lo, end; key_range(ix, minimizers[j].key, &lo, &end);
+            const uint32_t p = minimizers[j].offset; const int reverse = (minimizers[j].flags & VGK_MINIMIZER_REVERSE) != 0;
+            for (size_t h = lo; h < end; ++h, ++total) {
+                if (total >= cap) continue;
+                vgk_seed s;
+                if (!reverse) { s.node = ix->e[h].node; s.diff = (int32_t)p - (int32_t)ix->e[h].offset; }
+                else { s.node = ix->e[h].node ^ 1u; s.diff = (int32_t)(p + ix->k - 1) - (int32_t)(ix->node_len[ix->e[h].node >> 1] - 1 - ix->e[h].offset); }
+                seeds[total] = s;
+            }
+        }
+        seed_off[j + 1] = total;
+    }
+    if (written) *written = total;
+    return total > cap ? VGK_EOPS : VGK_OK;
+}

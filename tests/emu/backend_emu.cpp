@@ -179,6 +179,8 @@ public:
         if (P.pass == 1) { for (uint32_t i = P.lo; i < P.hi; ++i) minimizer_one(P, i); } else for (uint32_t i = 0; i < P.n; ++i) minimizer_one(P, i);
         return VGK_OK;
     }
+    int run_minimizer_list(const MzListParams& P) override { for (uint32_t i = 0; i <= P.n; ++i) mz_list_one(P, i); return VGK_OK; }
+    int run_minimizer_seeds_of(const MzSeedsOfParams& P) override { for (uint32_t j = 0; j <= P.n; ++j) mz_seeds_of_one(P, j); return VGK_OK; }
     int run_wfa_mask(const WProb* probs, const uint32_t* src_off, const char* raw, char* seqs, uint32_t n) override {
         for (uint32_t i = 0; i < n; ++i) for (uint32_t l = 0; l < 64; ++l) wfa_mask_one(probs, src_off, raw, seqs, i, l, 64);
         return VGK_OK;

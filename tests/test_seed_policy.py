@@ -430,3 +430,63 @@ def test_the_choice_applied_with_the_seeding_on_hip():
     policy_seeds(util.ENGINE_LIB, 5, 15, 6, 200, 120, 10, 500, 1.0)
     policy_seeds(util.ENGINE_LIB, 7, 29, 11, 300, 150, 10, 500, 0.9)
     assert policy_seeds(util.ENGINE_LIB, 8, 8, 4, 600, 100, 0, 6, 0.6) > 100   # the cut inside the top tie: the shuffle decides
+
+
+# ---- reads of any length: vgk_minimizer_list -> the shim's choice -> vgk_minimizer_seeds_of (vg_amd/pipeline.py seed_long_reads) -----------------------
+def long_read_seeds(lib, seed, k, w, n_reads, L, policy):
+    """long reads off a small repetitive graph: the listed minimizers are the brute-force construction's (test_minimizer.py), the minimizers taken
+    are the ones find_seeds_restated (this file's statement of src/minimizer_mapper.cpp:4109-4440, every filter) takes, the seeds are one per hit of
+    those in index order — no cap of 64 anywhere"""
+    import test_minimizer as tm
+    from vg_amd import capi, pipeline, workloads
+    wl = workloads.GaplessWorkload(4, seed=seed, graph_bp=30000, n_haplotypes=4, snp_every=60, indel_every=400)
+    rng = np.random.default_rng(seed)
+    reads, _ = tm.sample_reads(rng, wl.nodes, wl.threads, n_reads, L)
+    reads = [r for r in reads if r] + ["", "ACGT" * 3]
+    if len(reads[0]) > 50:
+        reads[0] = reads[0][:40] + "N" + reads[0][41:]
+    index = tm.build_index(wl.nodes, wl.threads, k, w)
+    P = dict(DEFAULTS, **policy)
+    flat = np.frombuffer("".join(reads).encode(), dtype=np.uint8); off = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    eng = capi.Engine(lib=lib)
+    mi = eng.minimizer_index(wl.nodes, wl.threads, k, w)
+    out = pipeline.seed_long_reads(eng, mi, flat, off, k, policy=P, threads=3)
+    moff, recs, take, soff, seeds = out["minimizer_off"], out["minimizers"], out["take"], out["seed_off"], out["seeds"]
+    many = dropped = 0
+    for i, r in enumerate(reads):
+        ms = tm.minimizers(r, k, w)
+        got = recs[int(moff[i]):int(moff[i + 1])]
+        assert [(int(x["offset"]), int(x["key"]), bool(x["flags"] & 1), int(x["hits"])) for x in got] == [(p, key, bool(rev), len(index.get(key, []))) for p, key, rev in ms], i
+        many += len(ms) > 64
+        listed = [(key, p, k, len(index.get(key, []))) for p, key, rev in ms]
+        want, _ = find_seeds_restated(listed, len(r), P, r) if ms else ([], [])
+        assert [int(t) for t in take[int(moff[i]):int(moff[i + 1])]] == [1 if v == 0 else 0 for v in want], i
+        dropped += sum(1 for v, m in zip(want, listed) if v and m[3])
+        for j, ((p, key, rev), v) in enumerate(zip(ms, want)):
+            s = seeds[int(soff[int(moff[i]) + j]):int(soff[int(moff[i]) + j + 1])]
+            exp = [] if v else [((node, p - o) if not rev else (node ^ 1, (p + k - 1) - (len(wl.nodes[node >> 1]) - 1 - o))) for node, o in index.get(key, [])]
+            assert [(int(x["node"]), int(x["diff"])) for x in s] == exp, (i, j)
+        assert int(out["seeds_per_read"][i]) == int(soff[int(moff[i + 1])] - soff[int(moff[i])])
+    return many, dropped
+
+
+@pytest.mark.parametrize("lib_name", ["oracle", "emu"])
+def test_long_reads_are_seeded_without_caps(lib_name):
+    """VERDICT r05 missing #5: a read with more than 64 minimizers goes through find_seeds' whole choice — max_unique_min / num_bp_per_min included —
+    and gets every seed of the minimizers taken"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu", "host"], cwd=util.ROOT)
+    lib = util.ORACLE_LIB if lib_name == "oracle" else util.EMU_LIB
+    many, dropped = long_read_seeds(lib, 21, 9, 5, 12, 2500, dict(hit_cap=2, hard_hit_cap=40, score_fraction=0.8, max_unique_min=30, num_bp_per_min=50))
+    assert many >= 10 and dropped > 50                              # (the unique-minimizer budget of a 2 500-base read is max(30, 2500 / 50) = 50: it bites)
+    many, dropped = long_read_seeds(lib, 22, 11, 7, 6, 6000, dict(hit_cap=10, hard_hit_cap=500, score_fraction=0.9, max_unique_min=500, num_bp_per_min=1000))
+    assert many >= 5
+    long_read_seeds(lib, 23, 9, 5, 8, 1500, dict(hit_cap=1, hard_hit_cap=8, score_fraction=0.5, max_unique_min=10, num_bp_per_min=100, exclude_overlapping_min=True,
+                                                 window_count=8, max_window_length=64))
+
+
+@pytest.mark.gpu
+def test_long_reads_are_seeded_without_caps_on_hip():
+    many, dropped = long_read_seeds(util.ENGINE_LIB, 31, 11, 7, 60, 15000, dict(hit_cap=10, hard_hit_cap=500, score_fraction=0.9, max_unique_min=500, num_bp_per_min=1000))
+    assert many >= 55
+    long_read_seeds(util.ENGINE_LIB, 32, 9, 5, 40, 4000, dict(hit_cap=2, hard_hit_cap=40, score_fraction=0.8, max_unique_min=30, num_bp_per_min=50))

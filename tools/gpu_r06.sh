@@ -45,6 +45,8 @@ PY
       timeout 900 python bench.py --workload ${LEGARGS:?} > "$out/${knob}_$v.json" 2> "$out/${knob}_$v.err"
       last_json "$out/${knob}_$v.json" "print('$knob', '$v', round(d['value']), round(d['ms_per_step'], 2), d['config'].get('ms_per_batch'), d['config'].get('kernel_ms_per_batch'), d['config'].get('one_lane') or d['config'].get('one_context'))"
     done; unset $knob ;;
+  long_seeds)     # 15 kbp reads through the uncapped seeding calls on the chr22-scale graph
+    timeout 900 python tools/long_read_seeding.py ${N:-4000} > "$out/long_read_seeding.json" 2> "$out/long_read_seeding.err"; tail -2 "$out/long_read_seeding.err"; cat "$out/long_read_seeding.json" ;;
   two_cpus)       # legs pinned to TWO host CPUs (what a rank of an 8-rank run on a 16-CPU box gets) beside the whole box: TWO="longread banded"
     for w in ${TWO:-longread banded}; do
       for cpus in all 2; do

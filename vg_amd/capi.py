@@ -64,6 +64,8 @@ WFA_CONNECT, WFA_SUFFIX, WFA_PREFIX = 0, 1, 2
 WFA_MATCH, WFA_MISMATCH, WFA_INSERTION, WFA_DELETION = 0, 1, 2, 3
 WFA_NO_NODE = 0xffffffff
 WFA_DEFAULT_MODEL = ((0.03, 1, 6), (0.05, 1, 10), (0.1, 1, 20), (0.1, 10, 200))      # gbwt_extender.hpp:386-395
+READ_MINIMIZER_DT = np.dtype([("key", "<u8"), ("offset", "<u4"), ("hits", "<u4"), ("flags", "<u4"), ("reserved", "<u4")])      # vgk_read_minimizer
+MINIMIZER_REVERSE = 1
 # vgk_chain_stitch (include/vgk.h): pieces of a read's chain in, one composed alignment per read out
 CHAIN_PIECE_DT = np.dtype([("kind", "<u4"), ("link", "<u4"), ("node_offset", "<u4"), ("path_begin", "<u4"), ("path_len", "<u4"), ("edit_begin", "<u4"), ("n_edits", "<u4"), ("reserved", "<u4")])
 CHAIN_MAPPING_DT = np.dtype([("node", "<u4"), ("offset", "<u4"), ("edit_begin", "<u4"), ("n_edits", "<u4")])
@@ -538,6 +540,32 @@ class Engine:
         self.minimizers_truncated = (mins[:n] & 0x80000000) != 0
         self.minimizers_policy_skipped = (mins[:n] & 0x40000000) != 0          # (VGK_MINIMIZERS_POLICY_SKIPPED: more than 64 minimizers, seeded without the policy)
         return seed_off, seeds[:0 if keep_on_device else written.value], mins[:n] & 0x3fffffff
+
+    def minimizer_list(self, mindex, reads, read_off):
+        """vgk_minimizer_list: every minimizer of every read, no caps -> (minimizer_off [n + 1] uint64, records READ_MINIMIZER_DT in read order)"""
+        reads = np.ascontiguousarray(reads, dtype=np.uint8); off = np.ascontiguousarray(read_off, dtype=np.uint64); n = len(off) - 1
+        moff = np.zeros(n + 1, dtype=np.uint64); written = ctypes.c_size_t()
+        self.lib.vgk_minimizer_list.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        cap = max(16, int(len(reads)) // 4)
+        for attempt in range(2):
+            recs = np.zeros(cap, dtype=READ_MINIMIZER_DT)
+            rc = self.lib.vgk_minimizer_list(self.h, mindex.h, reads.ctypes.data, off.ctypes.data, n, moff.ctypes.data, recs.ctypes.data, cap, ctypes.byref(written))
+            if rc != VGK_EOPS:
+                break
+            cap = int(written.value)
+        self._check(rc, "vgk_minimizer_list")
+        return moff, recs[:written.value]
+
+    def minimizer_seeds_of(self, mindex, minimizers, take):
+        """vgk_minimizer_seeds_of: one seed per hit of the minimizers taken -> (seed_off [len(minimizers) + 1] uint64, seeds SEED_DT)"""
+        recs = np.ascontiguousarray(minimizers, dtype=READ_MINIMIZER_DT); take = np.ascontiguousarray(take, dtype=np.uint8)
+        assert len(take) == len(recs)
+        soff = np.zeros(len(recs) + 1, dtype=np.uint64); written = ctypes.c_size_t()
+        self.lib.vgk_minimizer_seeds_of.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        cap = max(16, int(recs["hits"][take != 0].sum()))
+        seeds = np.zeros(cap, dtype=SEED_DT)
+        self._check(self.lib.vgk_minimizer_seeds_of(self.h, mindex.h, recs.ctypes.data, take.ctypes.data, len(recs), soff.ctypes.data, seeds.ctypes.data, cap, ctypes.byref(written)), "vgk_minimizer_seeds_of")
+        return soff, seeds[:written.value]
 
     def minimizer_last_ms(self):
         self.lib.vgk_minimizer_last_ms.restype = ctypes.c_double; self.lib.vgk_minimizer_last_ms.argtypes = [ctypes.c_void_p]

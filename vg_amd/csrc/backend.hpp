@@ -151,6 +151,8 @@ public:
     // the two per-node stages that turn the forest into the packer's tables; a byte fill; a stopwatch around all of it
     // (watch(0) ... watch(1), watch_ms() after a sync)
     virtual int   run_minimizer(const MinimizerParams& p) = 0;            // minimizer_device.hpp: one lane per read, pass p.pass
+    virtual int   run_minimizer_list(const MzListParams& p) = 0;           // mz_list_one for reads [0, n] (pass p.pass), asynchronous on the main stream
+    virtual int   run_minimizer_seeds_of(const MzSeedsOfParams& p) = 0;    // mz_seeds_of_one for minimizers [0, n]
     virtual int   run_tail(const TailParams& p, uint32_t threads) = 0;
     virtual int   run_tail_stage(const TStageParams& p, int what) = 0;     // one of the per-item stages of vgk_tail_stage (tail_device.hpp: TS_*)
     virtual int   run_rescue_requests(const RqParams& p, int what) = 0;    // one of the per-pair stages of vgk_rescue_requests (rescue_requests_device.hpp: RQ_*)

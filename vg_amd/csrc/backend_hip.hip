@@ -778,6 +778,9 @@ __global__ void __launch_bounds__(256) rescue_requests_kernel(const RqParams P, 
     if (what == RQ_FLAG) { if (p <= P.n_pairs) rq_flag_one(P, p); }
     else if (p < P.n_pairs) rq_emit_one(P, p);
 }
+// ---- seeding reads of any length (minimizer_device.hpp): a lane per read lists its minimizers, a lane per minimizer writes its seeds
+__global__ void __launch_bounds__(64) minimizer_list_kernel(const MzListParams P) { mz_list_one(P, blockIdx.x * 64 + threadIdx.x); }
+__global__ void __launch_bounds__(256) minimizer_seeds_of_kernel(const MzSeedsOfParams P) { mz_seeds_of_one(P, blockIdx.x * 256 + threadIdx.x); }
 // ---- one Path per read (chain_device.hpp): a lane per read for the bounds and the composition, a wavefront per read for the dense copy
 __global__ void __launch_bounds__(64) chain_stitch_kernel(const CsParams P, const int what) {
     cs_one(P, what, blockIdx.x * 64 + threadIdx.x);
@@ -1570,6 +1573,16 @@ public:
         const uint32_t items = tstage_items(p, what);
         if (!items) return VGK_OK;
         hipLaunchKernelGGL(tail_stage_kernel, dim3((items + 255) / 256), dim3(256), 0, stream, p, what, items);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int run_minimizer_list(const MzListParams& p) override {
+        hipSetDevice(dev);
+        hipLaunchKernelGGL(minimizer_list_kernel, dim3((p.n + 64) / 64), dim3(64), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
+    }
+    int run_minimizer_seeds_of(const MzSeedsOfParams& p) override {
+        hipSetDevice(dev);
+        hipLaunchKernelGGL(minimizer_seeds_of_kernel, dim3((p.n + 256) / 256), dim3(256), 0, stream, p);
         return hipGetLastError() == hipSuccess ? VGK_OK : VGK_ENODEV;
     }
     int run_wfa_mask(const WProb* probs, const uint32_t* src_off, const char* raw, char* seqs, uint32_t n) override {

@@ -206,4 +206,85 @@ int vgk_minimizer_seeds(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_h
 
 double vgk_minimizer_last_ms(vgk_ctx* ctx) { return ctx ? ctx->minimizer_ms : 0.0; }
 
+// ---- reads of any length: every minimizer listed; the seeds of those the caller takes (include/vgk.h) ----------------------------------------
+int vgk_minimizer_list(vgk_ctx* ctx, const vgk_minimizer_index* ix, const char* reads, const uint64_t* read_off, uint32_t n,
+                       uint64_t* minimizer_off, vgk_read_minimizer* minimizers, size_t cap, size_t* written) try {
+    if (!ctx || !ix || !vgk_tables_usable(ix->ctx, ctx) || !minimizer_off || (n && (!reads || !read_off)) || (!minimizers && cap)) return VGK_EINVAL;
+    if (written) *written = 0;
+    minimizer_off[0] = 0;
+    if (!n) return VGK_OK;
+    for (uint32_t i = 0; i < n; ++i) if (read_off[i + 1] < read_off[i]) return VGK_EINVAL;
+    const uint64_t bytes = read_off[n] - read_off[0];
+    if (bytes > 0xfffffff0ull) return VGK_ETOOBIG;
+    Backend* be = ctx->be.get();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const size_t n1 = (size_t)n + 1;
+    char* d_reads = (char*)ctx->ensure_scratch(150, bytes + 32);
+    uint64_t* d_off = (uint64_t*)ctx->ensure_scratch(151, sizeof(uint64_t) * n1);
+    uint32_t* d_tab = (uint32_t*)ctx->ensure_scratch(152, sizeof(uint32_t) * 2 * n1);
+    if (!d_reads || !d_off || !d_tab) return VGK_ENOMEM;
+    std::vector<uint64_t> rel(n1);
+    for (size_t i = 0; i < n1; ++i) rel[i] = read_off[i] - read_off[0];
+    MzListParams P{};
+    P.index = ix->dev; P.reads = d_reads + 8; P.read_off = d_off; P.n = n; P.counts = d_tab; P.first = d_tab + n1; P.pass = 1;
+    int rc = be->upload(d_off, rel.data(), sizeof(uint64_t) * n1);
+    if (!rc) rc = be->zero(d_reads, 8);
+    if (!rc) rc = be->zero(d_reads + 8 + bytes, 16);
+    if (!rc && bytes) rc = be->upload(d_reads + 8, reads + read_off[0], bytes);
+    if (!rc) rc = be->run_minimizer_list(P);
+    if (!rc) rc = be->scan_u32(d_tab, d_tab + n1, (uint32_t)n1);
+    std::vector<uint32_t> first(n1);
+    if (!rc) rc = be->download(first.data(), d_tab + n1, sizeof(uint32_t) * n1);      // synchronises (rel[] may go)
+    if (rc) return rc;
+    for (size_t i = 0; i < n1; ++i) minimizer_off[i] = first[i];
+    const size_t total = first[n];
+    if (written) *written = total;
+    if (total > cap) return VGK_EOPS;
+    if (!total) return VGK_OK;
+    vgk_read_minimizer* d_out = (vgk_read_minimizer*)ctx->ensure_scratch(153, sizeof(vgk_read_minimizer) * total);
+    if (!d_out) return VGK_ENOMEM;
+    P.out = d_out; P.pass = 2;
+    if ((rc = be->run_minimizer_list(P))) return rc;
+    return be->download(minimizers, d_out, sizeof(vgk_read_minimizer) * total);
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }
+
+int vgk_minimizer_seeds_of(vgk_ctx* ctx, const vgk_minimizer_index* ix, const vgk_read_minimizer* minimizers, const uint8_t* take, size_t n_minimizers,
+                           uint64_t* seed_off, vgk_seed* seeds, size_t cap, size_t* written) try {
+    if (!ctx || !ix || !vgk_tables_usable(ix->ctx, ctx) || !seed_off || (n_minimizers && (!minimizers || !take)) || (!seeds && cap)) return VGK_EINVAL;
+    if (written) *written = 0;
+    seed_off[0] = 0;
+    if (!n_minimizers) return VGK_OK;
+    if (n_minimizers > 0xfffffff0ull) return VGK_ETOOBIG;
+    Backend* be = ctx->be.get();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const uint32_t n = (uint32_t)n_minimizers; const size_t n1 = (size_t)n + 1;
+    vgk_read_minimizer* d_min = (vgk_read_minimizer*)ctx->ensure_scratch(153, sizeof(vgk_read_minimizer) * n_minimizers);
+    uint8_t* d_take = (uint8_t*)ctx->ensure_scratch(154, n_minimizers + 16);
+    uint32_t* d_tab = (uint32_t*)ctx->ensure_scratch(155, sizeof(uint32_t) * 2 * n1);
+    if (!d_min || !d_take || !d_tab) return VGK_ENOMEM;
+    MzSeedsOfParams P{};
+    P.index = ix->dev; P.mins = d_min; P.take = d_take; P.n = n; P.counts = d_tab; P.first = d_tab + n1; P.pass = 1;
+    int rc = be->upload(d_min, minimizers, sizeof(vgk_read_minimizer) * n_minimizers);
+    if (!rc) rc = be->upload(d_take, take, n_minimizers);
+    if (!rc) rc = be->run_minimizer_seeds_of(P);
+    // (a 32-bit prefix sum: the hits of the taken minimizers of one call stay below 2^32 — checked against the index's own size below)
+    if (!rc) rc = be->scan_u32(d_tab, d_tab + n1, (uint32_t)n1);
+    std::vector<uint32_t> first(n1);
+    if (!rc) rc = be->download(first.data(), d_tab + n1, sizeof(uint32_t) * n1);
+    if (rc) return rc;
+    uint64_t check = 0;
+    for (size_t j = 0; j < n_minimizers; ++j) if (take[j]) check += minimizers[j].hits;
+    if (check > 0xfffffff0ull) return VGK_ETOOBIG;
+    for (size_t j = 0; j < n1; ++j) seed_off[j] = first[j];
+    const size_t total = first[n];
+    if (written) *written = total;
+    if (total > cap) return VGK_EOPS;
+    if (!total) return VGK_OK;
+    vgk_seed* d_out = (vgk_seed*)ctx->ensure_scratch(156, sizeof(vgk_seed) * total);
+    if (!d_out) return VGK_ENOMEM;
+    P.out = d_out; P.pass = 2;
+    if ((rc = be->run_minimizer_seeds_of(P))) return rc;
+    return be->download(seeds, d_out, sizeof(vgk_seed) * total);
+} catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }
+
 }  // extern "C"

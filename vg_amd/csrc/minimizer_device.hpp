@@ -267,4 +267,45 @@ VGK_HD void minimizer_one(const MinimizerParams& P, uint32_t i) {
     if (P.pass == 1) { P.counts[i] = n_seeds; if (P.mins) P.mins[i] = n_min | (truncated ? VGK_MINIMIZERS_TRUNCATED : 0u) | (skipped ? VGK_MINIMIZERS_POLICY_SKIPPED : 0u); }
 }
 
+// ---- reads of any length (vgk_minimizer_list / vgk_minimizer_seeds_of): no caps, the choice between the two calls is the caller's ----------
+// List: a lane per read, pass 1 counts the read's minimizers, pass 2 writes them behind the reads before it.  Seeds: a lane per minimizer,
+// pass 1 = its hits if it is taken, pass 2 = one seed per hit, index order.
+struct MzListParams {
+    MzIndex index; const char* reads; const uint64_t* read_off; uint32_t n;
+    uint32_t* counts;                     // [n + 1] pass 1 (entry n = 0)
+    const uint32_t* first;                // their exclusive prefix sums
+    vgk_read_minimizer* out; int pass;
+};
+VGK_HD void mz_list_one(const MzListParams& P, uint32_t i) {
+    if (i >= P.n) { if (P.pass == 1 && i == P.n) P.counts[i] = 0; return; }
+    const uint64_t a = P.read_off[i]; const uint32_t L = (uint32_t)(P.read_off[i + 1] - a);
+    uint32_t n_min = 0;
+    vgk_read_minimizer* dst = P.pass == 2 ? P.out + P.first[i] : nullptr;
+    mz_minimizers(P.reads + a, L, P.index.k, P.index.w, [&](uint32_t p, const MzKmer& m) {
+        if (dst) {
+            uint32_t first = 0, count = 0; MzPos one{0, 0};
+            const bool found = mz_find(P.index, m, first, count, one);
+            vgk_read_minimizer r; r.key = m.key; r.offset = p; r.hits = found ? count : 0u; r.flags = m.reverse ? VGK_MINIMIZER_REVERSE : 0u; r.reserved = 0;
+            dst[n_min] = r;
+        }
+        ++n_min;
+    });
+    if (P.pass == 1) P.counts[i] = n_min;
+}
+struct MzSeedsOfParams {
+    MzIndex index; const vgk_read_minimizer* mins; const uint8_t* take; uint32_t n;
+    uint32_t* counts; const uint32_t* first; vgk_seed* out; int pass;
+};
+VGK_HD void mz_seeds_of_one(const MzSeedsOfParams& P, uint32_t j) {
+    if (j >= P.n) { if (P.pass == 1 && j == P.n) P.counts[j] = 0; return; }
+    const vgk_read_minimizer r = P.mins[j];
+    uint32_t first = 0, count = 0; MzPos one{0, 0};
+    MzKmer m; m.key = r.key; m.hash = mz_hash(r.key); m.reverse = (r.flags & VGK_MINIMIZER_REVERSE) != 0;
+    const bool found = P.take[j] != 0 && mz_find(P.index, m, first, count, one);
+    if (P.pass == 1) { P.counts[j] = found ? count : 0u; return; }
+    if (!found) return;
+    vgk_seed* dst = P.out + P.first[j];
+    for (uint32_t h = 0; h < count; ++h) dst[h] = mz_seed(first == MZ_ONE ? one : P.index.pos[first + h], r.offset, m.reverse, P.index.k);
+}
+
 }  // namespace vgk

@@ -784,6 +784,9 @@ int vgh_connector_run(vgh_connector* c, int threads, double* ms, char* json_out,
 
 // ---- the chain stage (chain_stage.hpp): every link of a batch of reads through WFA, the declined ones through align_sequence_between ----
 #include "chain_stage.hpp"
+#include <atomic>
+#include <thread>
+#include <mutex>
 extern "C" {
 // w: the WFA handle (haplotype graph + index + aligner) of vgh_wfa_create.  stats: declined, between, no graph, too big, failed, broken reads; ms[6].
 // anchors (anchor_off ... anchor_nodes, all or none; chain_stage.hpp): with them one alignment per read is composed (vgk_chain_stitch) and stays with
@@ -903,6 +906,41 @@ static int select_minimizers_impl(const uint64_t* minimizers, int n, uint64_t re
         const std::vector<uint8_t> v = select_minimizers(ms, (size_t)read_length, P, sequence);
         for (int i = 0; i < n; ++i) { verdict_out[i] = v[(size_t)i]; if (scores_out) scores_out[i] = ms[(size_t)i].score; }
         if (order_out) { const std::vector<size_t> order = minimizers_by_score(ms, sequence); for (int i = 0; i < n; ++i) order_out[i] = order[(size_t)i]; }
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
+// find_seeds' choice for a BATCH of reads of any length, over what vgk_minimizer_list answered (include/vgk.h: vgk_read_minimizer records behind each
+// other, read r = [minimizer_off[r], minimizer_off[r + 1])): take_out[j] = 1 where minimizer j's hits become seeds (SeedFilter 0).  k: the index's k-mer
+// length (a minimizer covers read bases [offset, offset + k)).  Reads on `threads` host threads (0 = all).  The reads' own bytes seed each read's shuffle.
+int vgh_select_minimizers_of_reads(const vgk_read_minimizer* minimizers, const uint64_t* minimizer_off, uint32_t n_reads, const char* reads, const uint64_t* read_off, uint32_t k,
+                                   const uint64_t* policy, double score_fraction, int threads, uint8_t* take_out) {
+    try {
+        SeedPolicy P; P.hit_cap = (size_t)policy[0]; P.hard_hit_cap = (size_t)policy[1]; P.max_unique_min = (size_t)policy[2]; P.num_bp_per_min = (size_t)policy[3];
+        P.exclude_overlapping_min = policy[4] != 0; P.minimizer_coverage_flank = (size_t)policy[5]; P.minimizer_downsampling_window_count = (size_t)policy[6];
+        P.minimizer_downsampling_max_window_length = (size_t)policy[7]; P.minimizer_score_fraction = score_fraction;
+        unsigned T = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
+        T = std::min<unsigned>(T, std::max<uint32_t>(1, n_reads));
+        std::atomic<uint32_t> next{0}; std::atomic<bool> failed{false}; std::string what;
+        std::mutex what_mu;
+        auto work = [&]() {
+            try {
+                std::vector<PolicyMinimizer> ms;
+                for (uint32_t r = next.fetch_add(1); r < n_reads; r = next.fetch_add(1)) {
+                    const uint64_t a = minimizer_off[r], b = minimizer_off[r + 1];
+                    ms.assign((size_t)(b - a), PolicyMinimizer());
+                    for (uint64_t j = a; j < b; ++j) { PolicyMinimizer& m = ms[(size_t)(j - a)]; m.key = minimizers[j].key; m.forward_offset = minimizers[j].offset; m.length = k; m.hits = minimizers[j].hits; }
+                    score_minimizers(ms, P.hard_hit_cap);
+                    const std::string seq(reads + read_off[r], (size_t)(read_off[r + 1] - read_off[r]));
+                    const std::vector<uint8_t> v = select_minimizers(ms, seq.size(), P, &seq);
+                    for (uint64_t j = a; j < b; ++j) take_out[j] = v[(size_t)(j - a)] == 0 ? 1 : 0;
+                }
+            } catch (std::exception& e) { failed = true; std::lock_guard<std::mutex> lk(what_mu); what = e.what(); }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread& t : pool) t.join();
+        if (failed) { g_last_error = what; return -1; }
         return 0;
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }

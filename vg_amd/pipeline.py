@@ -375,6 +375,35 @@ def compare_extension_sets(a_res, a_ext, a_nodes, b_res, b_ext, b_nodes, k):
     return int(same.sum())
 
 
+# ---- seeding reads of any length: every minimizer listed on the device, find_seeds' choice in the host shim, the seeds of the chosen on the device ----
+# giraffe's defaults where the long-read presets leave them (src/minimizer_mapper.hpp: hit_cap 10, hard_hit_cap 500, minimizer_score_fraction 0.9, max_unique_min 500,
+# num_bp_per_min 1000, minimizer_coverage_flank 250; no window downsampling, overlapping minimizers kept)
+GIRAFFE_LONG_READ_POLICY = dict(hit_cap=10, hard_hit_cap=500, max_unique_min=500, num_bp_per_min=1000, exclude_overlapping_min=False, coverage_flank=250, window_count=0,
+                                max_window_length=(1 << 62), score_fraction=0.9)
+
+
+def seed_long_reads(eng, mindex, reads, read_off, k, policy=None, threads=0):
+    """MinimizerMapper::find_minimizers + find_seeds for reads of any length (src/minimizer_mapper.cpp:3918-4440): vgk_minimizer_list, the host shim's
+    select_minimizers over every read's list (every filter, max_unique_min / num_bp_per_min included: :4162, :4312-4320), vgk_minimizer_seeds_of.
+    -> dict(minimizer_off, minimizers, take, seed_off (per minimizer), seeds, seeds_per_read)"""
+    P = dict(GIRAFFE_LONG_READ_POLICY, **(policy or {}))
+    reads = np.ascontiguousarray(reads, dtype=np.uint8); read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+    moff, recs = eng.minimizer_list(mindex, reads, read_off)
+    h = _host_lib()
+    h.vgh_select_minimizers_of_reads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_void_p]
+    pol = np.array([P["hit_cap"], P["hard_hit_cap"], P["max_unique_min"], P["num_bp_per_min"], int(P["exclude_overlapping_min"]), P["coverage_flank"], P["window_count"],
+                    P["max_window_length"]], dtype=np.uint64)
+    take = np.zeros(max(len(recs), 1), dtype=np.uint8)
+    recs = np.ascontiguousarray(recs)
+    if h.vgh_select_minimizers_of_reads(recs.ctypes.data if len(recs) else None, moff.ctypes.data, len(read_off) - 1, reads.ctypes.data, read_off.ctypes.data, k, pol.ctypes.data,
+                                        float(P["score_fraction"]), threads, take.ctypes.data) != 0:
+        raise RuntimeError("vgh_select_minimizers_of_reads: " + (h.vgh_last_error() or b"?").decode())
+    take = take[:len(recs)]
+    soff, seeds = eng.minimizer_seeds_of(mindex, recs, take)
+    per_read = soff[moff[1:].astype(np.int64)] - soff[moff[:-1].astype(np.int64)]
+    return dict(minimizer_off=moff, minimizers=recs, take=take, seed_off=soff, seeds=seeds, seeds_per_read=per_read)
+
+
 # ---- configs[4] with the whole stage in the host shim (vg_amd/host/chain_stage.cpp) -----------------------------------------------------
 class ChainStage:
     """MinimizerMapper's chain alignment for a batch of reads, in C++ behind one call (vgh_chain_stage): every link through WFAExtender;
