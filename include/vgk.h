@@ -571,7 +571,11 @@ double vgk_minimizer_last_ms(vgk_ctx* ctx);                              /* devi
  * without a policy and flagged VGK_MINIMIZERS_POLICY_SKIPPED in minimizers[].  With a policy set the call's `hit_cap` argument is ignored.
  * policy = NULL: none (every minimizer with at most `hit_cap` hits gives seeds).  VGK_EINVAL: hard_hit_cap 0 or above 65 535, a fraction
  * outside [0, 1]. */
-typedef struct vgk_seed_policy { uint32_t hit_cap, hard_hit_cap; double minimizer_score_fraction; } vgk_seed_policy;
+/* paired != 0: reads 2 i and 2 i + 1 are the mates of a pair.  The reference's paired path draws both mates' shuffles from ONE generator seeded
+ * from mate 1's + mate 2's sequence (src/minimizer_mapper.cpp:1529-1541), which the per-read kernels do not restate: a read whose top tie can change
+ * the choice is then not chosen for but flagged VGK_MINIMIZERS_POLICY_SKIPPED, and the caller takes its PAIR through its own choice (the host shim:
+ * vgh_select_minimizers_of_pair).  Reads whose tie cannot matter — nearly all — are chosen for as before: their choice does not depend on any draw. */
+typedef struct vgk_seed_policy { uint32_t hit_cap, hard_hit_cap; double minimizer_score_fraction; uint32_t paired, reserved; } vgk_seed_policy;
 #define VGK_MINIMIZERS_POLICY_SKIPPED 0x40000000u
 int  vgk_minimizer_set_policy(vgk_minimizer_index* index, const vgk_seed_policy* policy);
 /* ---- seeding reads of ANY length (giraffe's long-read path: a 15 kbp read has ~2 500 minimizers and as many seeds as they have hits) ----------

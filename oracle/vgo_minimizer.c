@@ -159,7 +159,7 @@ static uint64_t choose(const vgk_seed_policy* P, const uint64_t* key, const uint
         if (n_runs >= 2) {
             uint32_t seed = 0; int other = 0;
             for (uint32_t i = 0; i < L; ++i) { const char c = seq[i]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T') other = 1; seed = seed * 13u + (uint32_t)(unsigned char)c; }
-            if (other && use_score && hits[order[0]] > P->hit_cap) { *unsure = 1; return 0; }
+            if ((other || P->paired) && use_score && hits[order[0]] > P->hit_cap) { *unsure = 1; return 0; }      /* (paired: the pair's one generator is the caller's, include/vgk.h) */
             uint32_t which[64], x = lehmer_start(seed), laid[64], at = 0;
             for (uint32_t i = 0; i < n_runs; ++i) which[i] = i;
             for (uint32_t i = 1; i < n_runs; ++i) { const uint32_t j = lehmer_next(&x) % (i + 1u), t2 = which[j]; which[j] = which[i]; which[i] = t2; }

@@ -490,3 +490,38 @@ def test_long_reads_are_seeded_without_caps_on_hip():
     many, dropped = long_read_seeds(util.ENGINE_LIB, 31, 11, 7, 60, 15000, dict(hit_cap=10, hard_hit_cap=500, score_fraction=0.9, max_unique_min=500, num_bp_per_min=1000))
     assert many >= 55
     long_read_seeds(util.ENGINE_LIB, 32, 9, 5, 40, 4000, dict(hit_cap=2, hard_hit_cap=40, score_fraction=0.8, max_unique_min=30, num_bp_per_min=50))
+
+
+@pytest.mark.parametrize("lib_name", ["oracle", "emu"])
+def test_paired_policy_flags_the_reads_whose_tie_matters(lib_name):
+    """the reference's paired path shuffles both mates' top ties from ONE generator (src/minimizer_mapper.cpp:1529-1541), which the per-read
+    kernels do not restate.  With vgk_seed_policy::paired a read whose top tie can change the choice is flagged POLICY_SKIPPED (the caller's pair choice takes
+    it: vgh_select_minimizers_of_pair); every other read is chosen for exactly as in single-end mode."""
+    import subprocess
+    import test_minimizer as tm
+    from vg_amd import capi, workloads
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    lib = util.ORACLE_LIB if lib_name == "oracle" else util.EMU_LIB
+    k, w, hit_cap, hard, frac = 4, 3, 1, 6, 0.6           # (4-mers on 1.5 kbp: a fifth of the reads has no unique minimizer — their best ones tie with several hits each)
+    wl = workloads.GaplessWorkload(4, seed=8, graph_bp=1500, n_haplotypes=4, snp_every=40, indel_every=300)
+    reads, _ = tm.sample_reads(np.random.default_rng(8), wl.nodes, wl.threads, 120, 60)
+    index = tm.build_index(wl.nodes, wl.threads, k, w)
+    flat = np.frombuffer("".join(reads).encode(), dtype=np.uint8); off = np.concatenate([[0], np.cumsum([len(r) for r in reads])])
+    eng = capi.Engine(lib=lib)
+    mi = eng.minimizer_index(wl.nodes, wl.threads, k, w); hi = eng.haplo_index(wl.nodes, wl.threads)
+    mi.set_policy(hit_cap, hard, frac)
+    s_off, s_seeds, _ = eng.minimizer_seeds(mi, hi, flat, off, 7); single = [s_seeds[s_off[i]:s_off[i + 1]].copy() for i in range(len(reads))]
+    already = eng.minimizers_policy_skipped.copy()           # (reads with more than 64 minimizers: flagged in either mode)
+    assert already.sum() < 5
+    mi.set_policy(hit_cap, hard, frac, paired=True)
+    p_off, p_seeds, _ = eng.minimizer_seeds(mi, hi, flat, off, 7); flagged = eng.minimizers_policy_skipped.copy()
+    matters = []
+    for r in reads:
+        ms = tm.minimizers(r, k, w); listed = [(key, p, k, len(index.get(key, []))) for p, key, rev in ms]
+        sc = scores_of(listed, hard) if listed else []
+        top = max(sc) if sc else 0; tied = set(m[0] for m, x in zip(listed, sc) if x == top); top_hits = max([m[3] for m, x in zip(listed, sc) if x == top] or [0])
+        matters.append(len(tied) >= 2 and top_hits > hit_cap)
+    assert [bool(f) for f in flagged] == [bool(m or a) for m, a in zip(matters, already)] and 3 < sum(matters) < len(reads) - 3
+    for i in range(len(reads)):
+        if not matters[i] and not already[i]:
+            assert p_seeds[p_off[i]:p_off[i + 1]].tobytes() == single[i].tobytes(), i

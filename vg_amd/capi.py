@@ -775,13 +775,13 @@ class MinimizerIndex:
         self.keys = int(eng.lib.vgk_minimizer_index_keys(h))
         eng._indexes.add(self)
 
-    def set_policy(self, hit_cap=10, hard_hit_cap=500, score_fraction=0.9, on=True):
+    def set_policy(self, hit_cap=10, hard_hit_cap=500, score_fraction=0.9, on=True, paired=False):
         """vgk_minimizer_set_policy: find_seeds' choice of minimizers (giraffe's short-read defaults) for the following minimizer_seeds calls;
         on=False: none"""
         class Policy(ctypes.Structure):
-            _fields_ = [("hit_cap", ctypes.c_uint32), ("hard_hit_cap", ctypes.c_uint32), ("minimizer_score_fraction", ctypes.c_double)]
+            _fields_ = [("hit_cap", ctypes.c_uint32), ("hard_hit_cap", ctypes.c_uint32), ("minimizer_score_fraction", ctypes.c_double), ("paired", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
         self.eng.lib.vgk_minimizer_set_policy.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        p = Policy(hit_cap, hard_hit_cap, score_fraction)
+        p = Policy(hit_cap, hard_hit_cap, score_fraction, 1 if paired else 0, 0)
         self.eng._check(self.eng.lib.vgk_minimizer_set_policy(self.h, ctypes.byref(p) if on else None), "vgk_minimizer_set_policy")
 
     def fetch(self):

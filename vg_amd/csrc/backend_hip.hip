@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(256) minimizer_kernel(const MinimizerParams P,
                       }
 #pragma unroll
                       for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
-                      if (__ballot(other) != 0ull) skipped = true;          // a masked base: the reference's seed cannot be made here — not chosen for
+                      if (__ballot(other) != 0ull || Q.paired) skipped = true;          // a masked base — or a mate of a pair, whose generator is the pair's (include/vgk.h): the reference's seed cannot be made here — not chosen for
                       else if (lane == 0) { uint8_t* t = ptie_all[wv]; mz_shuffle_top_ties(pord, pkey, t_elems, t_runs, part, t, t + (MZ_POLICY_MAX + 1), t + 2 * (MZ_POLICY_MAX + 1)); }
                   }
                   MZ_WAVE_SYNC(); }

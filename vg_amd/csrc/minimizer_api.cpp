@@ -126,7 +126,7 @@ int vgk_minimizer_set_policy(vgk_minimizer_index* ix, const vgk_seed_policy* pol
     if (!d) return VGK_ENOMEM;
     if ((rc = be->upload(d, tab.data(), sizeof(double) * tab.size())) || (rc = be->sync())) { be->release(d); return rc; }
     ix->policy_tab = d;
-    ix->policy.on = 1; ix->policy.hit_cap = policy->hit_cap; ix->policy.hard_hit_cap = policy->hard_hit_cap; ix->policy.fraction = policy->minimizer_score_fraction;
+    ix->policy.on = 1; ix->policy.hit_cap = policy->hit_cap; ix->policy.hard_hit_cap = policy->hard_hit_cap; ix->policy.fraction = policy->minimizer_score_fraction; ix->policy.paired = policy->paired;
     ix->policy.tab = (const double*)d;
     return VGK_OK;
 } catch (const std::bad_alloc&) { return VGK_ENOMEM; } catch (...) { return VGK_EINVAL; }

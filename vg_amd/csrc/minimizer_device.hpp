@@ -119,7 +119,7 @@ VGK_HD bool mz_find(const MzIndex& x, const MzKmer& m, uint32_t& first, uint32_t
 // need not round like the host's); everything here is additions and comparisons of those doubles in one fixed order, with the one
 // product kept apart from its sum (mz_mul / mz_add: no fused multiply-add), so that every backend selects the same minimizers.
 constexpr uint32_t MZ_POLICY_MAX = 64;                                   // minimizers per read the selection takes
-struct MzPolicy { uint32_t on, hit_cap, hard_hit_cap; double fraction; const double* tab; };
+struct MzPolicy { uint32_t on, hit_cap, hard_hit_cap; double fraction; const double* tab; uint32_t paired; };      // paired: include/vgk.h vgk_seed_policy
 VGK_HD double mz_add(double a, double b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __dadd_rn(a, b);
@@ -189,7 +189,7 @@ VGK_HD uint64_t mz_policy_select(const MzPolicy& Q, const uint64_t* key, const u
     { uint32_t elements = 0; const uint32_t runs = mz_top_ties(order, key, score, n, &elements);
       if (mz_tie_matters(Q, runs, n ? hits[order[0]] : 0u)) {                  // (tied runs of at most hit_cap hits are all taken whatever their order: no generator is made for them)
           bool masked = false; const uint32_t seed = mz_shuffle_seed(seq, L, masked);
-          if (masked) { *unsure = true; return 0; }
+          if (masked || Q.paired) { *unsure = true; return 0; }                  // (a pair's one generator over both mates is the caller's: include/vgk.h)
           uint8_t start[MZ_POLICY_MAX + 1], perm[MZ_POLICY_MAX + 1]; uint32_t tmp[MZ_POLICY_MAX + 1];
           mz_shuffle_top_ties(order, key, elements, runs, seed, start, perm, tmp);
       } }
