@@ -80,6 +80,10 @@ template <int R, bool QA> static void banded_fill_emu(const BandedParams& P, uin
             BSrc src; src.rd = P.reads + pb.read_off; src.q = QA ? P.quals + pb.read_off : nullptr; src.graph = P.graph + pb.graph_off; src.mat = P.mat;
             src.rows = reinterpret_cast<const uint64_t*>(P.mat + BMAT_ROWS_AT);
             constexpr bool FAST = !QA && R <= 4;                            // the kernel's choice for problems staged in LDS; both paths give the same cells
+            if constexpr (R >= 64) {                                        // bands of more than 2048 diagonals: any number of blocks, state and first rows in the lane's stores
+                std::vector<int32_t> store((size_t)(R / 8) * 3 * 8, BNEG), firsts((size_t)3 * (R / 8 + 1), BNEG);
+                banded_fill_lane_blocks<0, QA>(P, pb, src, lane, xl, store.data(), 1u, (uint32_t)(R / 8), firsts.data());
+            } else
             if constexpr (R >= 16) {                                        // wide bands: blocks of 8 rows per lane, the other blocks' rows in the lane's store
                 std::vector<int32_t> store((size_t)(R / 8) * 3 * 8, BNEG);
                 if (std::getenv("VGAMD_EMU_BANDED_TALL_LANES")) banded_fill_lane<R, QA, false>(P, pb, src, lane, xl);      // (the form it replaces: the two must agree)
@@ -312,6 +316,10 @@ public:
                 case 8: if (P.quals) banded_fill_emu<8, true>(P, L.begin, L.count); else banded_fill_emu<8, false>(P, L.begin, L.count); break;
                 case 16: if (P.quals) banded_fill_emu<16, true>(P, L.begin, L.count); else banded_fill_emu<16, false>(P, L.begin, L.count); break;
                 case 32: if (P.quals) banded_fill_emu<32, true>(P, L.begin, L.count); else banded_fill_emu<32, false>(P, L.begin, L.count); break;
+                case 64: if (P.quals) banded_fill_emu<64, true>(P, L.begin, L.count); else banded_fill_emu<64, false>(P, L.begin, L.count); break;
+                case 128: if (P.quals) banded_fill_emu<128, true>(P, L.begin, L.count); else banded_fill_emu<128, false>(P, L.begin, L.count); break;
+                case 256: if (P.quals) banded_fill_emu<256, true>(P, L.begin, L.count); else banded_fill_emu<256, false>(P, L.begin, L.count); break;
+                case 512: if (P.quals) banded_fill_emu<512, true>(P, L.begin, L.count); else banded_fill_emu<512, false>(P, L.begin, L.count); break;
                 default: return VGK_EINVAL;
             }
         }

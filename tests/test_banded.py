@@ -365,17 +365,52 @@ def test_hip_wide_bands_in_blocks_match_the_oracle():
     bs = capi.BandedSet.from_lists(problems)
     got = capi.Engine().banded_align(bs)
     ref = capi.Engine(lib=util.ORACLE_LIB).banded_align(bs)
-    declined = {i for i, r in enumerate(got[0]) if int(r["status"]) not in (0, -8)}      # (a band of more than 2048 diagonals: the engine declines, the oracle may align)
-    assert not [b for b in _same(problems, ref, got) if b[0] not in declined]
-    assert (got[0]["status"] == 0).sum() > 200 and len(declined) < 150
+    assert not _same(problems, ref, got)                         # (round 6: no band is declined for its width — the engine aligns what max_cells admits, like the reference)
+    assert (got[0]["status"] == 0).sum() > 200 and not [r for r in got[0] if int(r["status"]) not in (0, -8)]
+
+
+def very_wide_band_problems(seed, n, max_read, pads):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        p = gen.random_banded_problem(rng, max_nodes=6, max_node_len=40, max_read=max_read, p_empty=0.1)
+        p["band_padding"] = int(pads[k % len(pads)]); p["permissive"] = bool(rng.random() < 0.8)
+        out.append(p)
+    return out
+
+
+def test_emulated_bands_beyond_2048_diagonals_match_the_oracle():
+    """VERDICT r05 missing #6: the reference aligns any band under max_cells (src/banded_global_aligner.cpp:2019-2043); bands of 2 049 ... 32 768 diagonals run
+    as 8 ... 64 blocks of 64 lanes x 8 rows whose state lives in an HBM slab (banded_fill_lane_blocks<0>)"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "emu"], cwd=util.ROOT)
+    problems = very_wide_band_problems(97, 4, 60, (1100, 2100, 1500, 4200))      # 64, 128 and 256 rows per lane (the emulator steps every lane of every column: short reads)
+    bs = capi.BandedSet.from_lists(problems)
+    got = capi.Engine(lib=util.EMU_LIB).banded_align(bs)
+    ref = capi.Engine(lib=util.ORACLE_LIB).banded_align(bs)
+    assert not _same(problems, ref, got) and (got[0]["status"] == 0).sum() >= 3
+
+
+@pytest.mark.gpu
+def test_hip_bands_beyond_2048_diagonals_match_the_oracle():
+    problems = very_wide_band_problems(98, 60, 500, (1100, 1500, 2100, 3000, 4200, 6000, 9000, 16000)) + wide_band_problems(99, 40)
+    bs = capi.BandedSet.from_lists(problems)
+    got = capi.Engine().banded_align(bs)
+    ref = capi.Engine(lib=util.ORACLE_LIB).banded_align(bs)
+    assert not _same(problems, ref, got) and (got[0]["status"] == 0).sum() > 70
+    # the only width the engine still declines: more than 32 768 diagonals
+    huge = very_wide_band_problems(100, 2, 100, (17000,))
+    st = capi.Engine().banded_align(capi.BandedSet.from_lists(huge))[0]["status"]
+    assert set(int(x) for x in st) <= {-7, -8}
 
 
 def against_the_oracle(problems, dev):
-    """what the engine aligned or found band-less is the oracle's answer; what it declines (a band of more than 2048 diagonals, a node of more
-    than 65 535 bases) the oracle may well align"""
+    """what the engine aligned or found band-less is the oracle's answer — bands of more than 2048 diagonals included (round 6: 8 ... 64 blocks of rows with
+    their state in HBM); what it declines (a node of more than 65 535 bases) the oracle may well align"""
     ref = capi.Engine(lib=util.ORACLE_LIB).banded_align(capi.BandedSet.from_lists(problems))
     declined = {i for i, r in enumerate(dev[0]) if int(r["status"]) not in (0, -8)}
-    assert len(declined) >= 2 and not [b for b in _same(problems, ref, dev) if b[0] not in declined]
+    assert len(declined) == 1 and not [b for b in _same(problems, ref, dev) if b[0] not in declined]
+    assert int(dev[0]["status"][11]) == 0                        # the problem with 4 000 diagonals of padding is aligned
     assert {0, -8}.issubset(set(int(x) for x in dev[0]["status"]))
 
 
@@ -413,11 +448,6 @@ def test_hip_banded_matches_oracle_on_random_problems():
     eng = capi.Engine()
     got = eng.banded_align(bs)
     bad = _same(problems, ref, got)
-    # engine limit: bands taller than 2048 diagonals are refused with VGK_ETOOBIG, which the shim raises as
-    # BandMatricesTooBigException like a max_cells overflow; only the widest paddings of the third lot can get there
-    too_big = [b for b in bad if b[3]["status"] == -7 and b[0] >= 3400]
-    assert len(too_big) <= 8
-    bad = [b for b in bad if b not in too_big]
     assert not bad, [(b[0], b[2], b[3]) for b in bad[:3]]
     assert (ref[0]["status"] == 0).sum() > 3000
     for p, r in list(zip(problems, got[0]))[:500]:

@@ -399,6 +399,17 @@ __global__ void __launch_bounds__(64) banded_fill_blocks_kernel(const BandedPara
     XlDpp xl;
     banded_fill_lane_blocks<B, QA>(P, pb, src, threadIdx.x, xl, bstate + threadIdx.x, 64u);
 }
+// Bands of more than 2048 diagonals: any number of blocks, their state in an HBM slab per wavefront (banded_fill_lane_blocks<0>); the inputs are read
+// where they lie (such a problem's read and graph are long: no LDS staging)
+template <bool QA>
+__global__ void __launch_bounds__(64) banded_fill_blocks_any_kernel(const BandedParams P, const uint32_t begin, const uint32_t nb, int32_t* slabs) {
+    const BProb pb = P.probs[P.order[begin + blockIdx.x]];
+    BSrc src;
+    src.rd = P.reads + pb.read_off; src.q = QA ? P.quals + pb.read_off : nullptr; src.graph = P.graph + pb.graph_off; src.mat = P.mat; src.rows = nullptr;
+    XlDpp xl;
+    int32_t* mine = slabs + (size_t)blockIdx.x * ((size_t)nb * 3u * 8u + 3u * ((size_t)nb + 1u)) * 64u;
+    banded_fill_lane_blocks<0, QA>(P, pb, src, threadIdx.x, xl, mine + threadIdx.x, 64u, nb, mine + (size_t)nb * 3u * 8u * 64u + threadIdx.x);
+}
 template <int B>
 static void launch_banded_fill_blocks(const BandedParams& p, const BandedLaunch& L, hipStream_t stream) {
     const dim3 grid(L.count), block(64);
@@ -1073,6 +1084,7 @@ public:
     hipEvent_t bbev[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};      // run_banded_async: start / fills done / walk done per slot
     void* scan_tmp = nullptr; size_t scan_tmp_bytes = 0;      // rocPRIM's scratch for scan_u32 (grow-only)
     void* mz_slots = nullptr; size_t mz_slots_bytes = 0;      // per-read seed slots of run_minimizer (grow-only)
+    void* banded_slab = nullptr; size_t banded_slab_bytes = 0;      // the block states of the banded fill's HBM-state classes (grow-only)
     ~HipBackend() override {
         hipSetDevice(dev);
         for (auto& e : ev) if (e) hipEventDestroy(e);
@@ -1082,6 +1094,7 @@ public:
         for (auto& pair : sev) for (auto& e : pair) if (e) hipEventDestroy(e);
         if (scan_tmp) hipFree(scan_tmp);
         if (mz_slots) hipFree(mz_slots);
+        if (banded_slab) hipFree(banded_slab);
         for (int i = 0; i < 2; ++i) { if (side[i]) hipStreamDestroy(side[i]); if (side_done[i]) hipEventDestroy(side_done[i]); }
         if (stream) hipStreamDestroy(stream);
         if (copy) hipStreamDestroy(copy);
@@ -1406,7 +1419,7 @@ public:
         for (uint32_t i = 0; i < n; ++i) {
             const BandedLaunch& L = launches[i];
             if (!L.count) continue;
-            hipStream_t st = (i == 0 || i > 2) ? stream : side[i - 1];
+            hipStream_t st = (i == 0 || i > 2 || L.R >= 64) ? stream : side[i - 1];      // (the HBM-state classes share one slab: one after the other on the main stream)
             if (st != stream) hipStreamWaitEvent(st, bev[0], 0);
             switch (L.R) {
                 case 1:  launch_banded_fill<1>(p, L, st); break;
@@ -1415,6 +1428,19 @@ public:
                 case 8:  launch_banded_fill<8>(p, L, st); break;
                 case 16: launch_banded_fill_blocks<2>(p, L, st); break;      // bands of more than 512 diagonals: blocks of 8 rows per lane (banded_fill_lane_blocks)
                 case 32: launch_banded_fill_blocks<4>(p, L, st); break;
+                case 64: case 128: case 256: case 512: {                     // 8 ... 64 blocks: their state in HBM (grow-only slab, one stretch per problem of the launch)
+                    const uint32_t nb = L.R / 8u;
+                    const size_t need = (size_t)L.count * ((size_t)nb * 3u * 8u + 3u * ((size_t)nb + 1u)) * 64u * sizeof(int32_t);
+                    if (need > banded_slab_bytes) {
+                        hipStreamSynchronize(stream); for (hipStream_t x : side) hipStreamSynchronize(x);
+                        if (banded_slab) hipFree(banded_slab);
+                        banded_slab = nullptr; banded_slab_bytes = 0;
+                        if (hipMalloc(&banded_slab, need + need / 4) != hipSuccess) return VGK_ENOMEM;
+                        banded_slab_bytes = need + need / 4;
+                    }
+                    if (p.quals) hipLaunchKernelGGL(banded_fill_blocks_any_kernel<true>, dim3(L.count), dim3(64), 0, stream, p, L.begin, nb, (int32_t*)banded_slab);
+                    else         hipLaunchKernelGGL(banded_fill_blocks_any_kernel<false>, dim3(L.count), dim3(64), 0, stream, p, L.begin, nb, (int32_t*)banded_slab);
+                    break; }
                 default: return VGK_EINVAL;
             }
             if (st != stream) { hipEventRecord(side_done[i - 1], st); hipStreamWaitEvent(stream, side_done[i - 1], 0); }

@@ -132,7 +132,7 @@ void prepare(const vgk_ctx* ctx, const vgk_banded_problem& p, Prep& hp, Scratch&
         if (!any) { hp.status = VGK_ENOBAND; return; }
     }
     uint32_t R = 1; while ((int64_t)R * 64 < max_h) R *= 2;
-    if (R > 32 || L > (1 << 24) || total_bases > (1u << 24)) { hp.status = VGK_ETOOBIG; return; }      // engine limit: bands up to 2048 diagonals
+    if (R > B_MAX_ROWS_PER_LANE || L > (1 << 24) || total_bases > (1u << 24)) { hp.status = VGK_ETOOBIG; return; }      // engine limit: bands up to 32 768 diagonals (R = 512 rows per lane: 64 blocks of 8, their state in HBM beyond 4 blocks)
     hp.R = R; hp.Hpad = 64 * R;
     { uint32_t r = 0; while ((1u << r) < R) ++r;                  // launch order: rows-per-lane class, then most cells first (by log2)
       uint32_t lg = 0; while ((hp.cells >> lg) > 1 && lg < 63) ++lg;
@@ -586,12 +586,12 @@ static int banded_align_impl(vgk_ctx* ctx, const vgk_banded_problem* problems, u
             std::vector<BandedLaunch> launches;
             {
                 auto key = [&](uint32_t a) { return hps[owner[a]].order_key; };
-                std::vector<uint32_t> count(6 * 64 + 1, 0);
+                std::vector<uint32_t> count(B_ROW_CLASSES * 64 + 1, 0);
                 for (uint32_t a = 0; a < m; ++a) ++count[key(a) + 1];
                 for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
                 std::vector<uint32_t> at(count.begin(), count.end() - 1);
                 for (uint32_t a = 0; a < m; ++a) order[at[key(a)]++] = a;
-                for (uint32_t r = 0; r < 6; ++r) {
+                for (uint32_t r = 0; r < B_ROW_CLASSES; ++r) {
                     const uint32_t lo = count[r * 64], hi = count[(r + 1) * 64];
                     if (lo == hi) continue;
                     // LDS staging area: score table | read codes | qualities | graph codes of the largest problem of the launch
@@ -948,12 +948,12 @@ static int banded_align_pipelined(vgk_ctx* ctx, const vgk_banded_problem* proble
         });
         // launches: one per rows-per-lane class; inside a class the problems with the most cells first (counting sort on log2(cells))
         { auto key = [&](uint32_t a) { return hps[owner[a]].order_key; };
-          std::vector<uint32_t> count(6 * 64 + 1, 0);
+          std::vector<uint32_t> count(B_ROW_CLASSES * 64 + 1, 0);
           for (uint32_t a = 0; a < m; ++a) ++count[key(a) + 1];
           for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
           std::vector<uint32_t> at(count.begin(), count.end() - 1);
           for (uint32_t a = 0; a < m; ++a) order[at[key(a)]++] = a;
-          for (uint32_t r = 0; r < 6; ++r) {
+          for (uint32_t r = 0; r < B_ROW_CLASSES; ++r) {
             const uint32_t lo = count[r * 64], hi = count[(r + 1) * 64];
             if (lo == hi) continue;
             uint64_t lds = 0;      // LDS staging area: score table | read codes | qualities | graph codes of the largest problem of the launch
@@ -1258,13 +1258,13 @@ static int banded_align_device_geometry(vgk_ctx* ctx, const vgk_banded_problem* 
         probs = placed;
         if (tb_bytes + last_elems * 4 + ops_total * 2 * sizeof(vgk_op) > budget) return BANDED_NOT_HERE;
         // launches: one per rows-per-lane class; inside a class the problems with the most cells first (counting sort on log2(cells))
-        { std::vector<uint32_t> count(6 * 64 + 1, 0), sorted(kept);
+        { std::vector<uint32_t> count(B_ROW_CLASSES * 64 + 1, 0), sorted(kept);
           for (uint32_t k = 0; k < kept; ++k) ++count[keys[k] + 1];
           for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
           std::vector<uint32_t> at(count.begin(), count.end() - 1);
           for (uint32_t k = 0; k < kept; ++k) sorted[at[keys[k]]++] = order[k];
           std::copy(sorted.begin(), sorted.end(), order);
-          for (uint32_t r = 0; r < 6; ++r) {
+          for (uint32_t r = 0; r < B_ROW_CLASSES; ++r) {
             const uint32_t lo = count[r * 64], hi = count[(r + 1) * 64];
             if (lo == hi) continue;
             uint64_t lds = 0;

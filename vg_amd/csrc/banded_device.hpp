@@ -63,6 +63,9 @@ struct BProb {
 };
 struct BResult { int32_t score; int32_t status; uint32_t start; uint32_t n_ops; uint32_t ops_begin; uint32_t pad[3]; };
 
+// rows per lane of a fill launch: 1, 2, 4, 8 in registers; 16, 32 as 2 / 4 blocks of 8 with their state in LDS; 64 ... 512 as 8 ... 64 blocks with
+// their state in an HBM slab per wavefront (banded_fill_lane_blocks<0>): bands of up to 32 768 diagonals
+constexpr uint32_t B_MAX_ROWS_PER_LANE = 512, B_ROW_CLASSES = 10;
 struct BandedParams {
     const BProb*   probs;
     const uint32_t* order;             // problem indices grouped by rows-per-lane class (one fill launch each)
@@ -363,22 +366,35 @@ VGK_HD void banded_fill_lane(const BandedParams& P, const BProb& pb, const BSrc&
 // `first`), and block b's first lane takes the row above — the running maximum of the row-gap scan and the gap-opening sources — from what
 // block b - 1 has just computed for this column (wave-uniform carries).  Same cells, same codes, same last columns as banded_fill_lane<16 | 32>.
 // XL additionally supplies first_lane(v) / last_lane(v): the value of the first / last lane, to every lane.
+// B = 0: any number of blocks (`nb`, known at run time: bands of more than 2048 diagonals, round 6) — the blocks' first rows then live in `fst`
+// (nb + 1 triples behind each other, element e at fst[e * st_stride]: wave-uniform values every lane writes alike and reads back itself), and both
+// `st` and `fst` are the wavefront's stretch of an HBM slab (nb x 6 KB: too much for LDS beyond 8 blocks); the blocks of a column still run top to
+// bottom through registers.  The reference aligns any band its max_cells admits (src/banded_global_aligner.cpp:2019-2043); so does this.
 template <int B, bool QA, class XL>
-VGK_HD void banded_fill_lane_blocks(const BandedParams& P, const BProb& pb, const BSrc& src, uint32_t lane, XL& xl, int32_t* st, uint32_t st_stride) {
+VGK_HD void banded_fill_lane_blocks(const BandedParams& P, const BProb& pb, const BSrc& src, uint32_t lane, XL& xl, int32_t* st, uint32_t st_stride,
+                                    uint32_t nb = (uint32_t)B, int32_t* fst = nullptr) {
     constexpr int R = 8;
+    const int NB = B ? B : (int)nb;
     const int32_t go = P.go, ge = P.ge, L = (int32_t)pb.L;
     const uint32_t W = xl.width();
     const BNode* nodes = P.nodes + pb.node_base;
     int32_t* last = P.last + pb.last_base;
     uint8_t* tb = P.tb + pb.tb_base;
     auto S = [&](int b, int m, int i) -> int32_t& { return st[(uint32_t)((b * 3 + m) * R + i) * st_stride]; };
-    for (int b = 0; b < B; ++b) for (int m = 0; m < 3; ++m) for (int i = 0; i < R; ++i) S(b, m, i) = BNEG;
+    for (int b = 0; b < NB; ++b) for (int m = 0; m < 3; ++m) for (int i = 0; i < R; ++i) S(b, m, i) = BNEG;
     // block b's first row (M, Ic, Ir) of the column computed last: wave-uniform values, chosen by selects (the block loops are NOT unrolled — four
     // copies of a column's code are 300 VGPRs — and a register array indexed by a loop counter would live in scratch)
-    int32_t first[B][3];
-    for (int b = 0; b < B; ++b) first[b][0] = first[b][1] = first[b][2] = BNEG;
-    auto first_get = [&](int b, int m) { int32_t v = BNEG; for (int q = 0; q < B; ++q) v = q == b ? first[q][m] : v; return v; };
-    auto first_set = [&](int b, int m, int32_t v) { for (int q = 0; q < B; ++q) first[q][m] = q == b ? v : first[q][m]; };
+    int32_t first[B ? B : 1][3];
+    if constexpr (B != 0) { for (int b = 0; b < B; ++b) first[b][0] = first[b][1] = first[b][2] = BNEG; }
+    else { for (int e = 0; e < 3 * (NB + 1); ++e) fst[(uint32_t)e * st_stride] = BNEG; first[0][0] = first[0][1] = first[0][2] = BNEG; }
+    auto first_get = [&](int b, int m) -> int32_t {
+        if constexpr (B != 0) { int32_t v = BNEG; for (int q = 0; q < B; ++q) v = q == b ? first[q][m] : v; return v; }
+        else return fst[(uint32_t)(b * 3 + m) * st_stride];                  // (entry NB stays BNEG: past the last block)
+    };
+    auto first_set = [&](int b, int m, int32_t v) {
+        if constexpr (B != 0) { for (int q = 0; q < B; ++q) first[q][m] = q == b ? v : first[q][m]; }
+        else fst[(uint32_t)(b * 3 + m) * st_stride] = v;
+    };
     const bool last_l = lane + 1 == W, first_l = lane == 0;
     for (uint32_t v = 0; v < pb.n_nodes; ++v) {
         const BNode nd = nodes[v];
@@ -430,7 +446,7 @@ VGK_HD void banded_fill_lane_blocks(const BandedParams& P, const BProb& pb, cons
             const int32_t lead_ir = nd.top + j < 0 ? -2 * go - (nd.cum + j) * ge : BNEG;
             int32_t carry_excl = BNEG, carry_upM = BNEG, carry_upIc = BNEG;
 #pragma unroll 1
-            for (int b = 0; b < B; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 const int32_t k0 = (int32_t)((uint32_t)b * W + lane) * R;
                 int32_t M[R], Ic[R], Ir[R];
                 for (int i = 0; i < R; ++i) { M[i] = S(b, 0, i); Ic[i] = S(b, 1, i); Ir[i] = S(b, 2, i); }
@@ -465,7 +481,7 @@ VGK_HD void banded_fill_lane_blocks(const BandedParams& P, const BProb& pb, cons
             const int32_t hi0 = nd.bot >= L ? L - 1 : nd.bot;
             int32_t carry_excl = BNEG, carry_upM = BNEG, carry_upIc = BNEG;
 #pragma unroll 1
-            for (int b = 0; b < B; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 const int32_t k0 = (int32_t)((uint32_t)b * W + lane) * R;
                 int32_t nM[R], nIc[R], ir0[R]; uint32_t code_mc[R];
                 for (int i = 0; i < R; ++i) {
@@ -510,7 +526,7 @@ VGK_HD void banded_fill_lane_blocks(const BandedParams& P, const BProb& pb, cons
         for (int32_t j = j0; j < nd.len; ++j) column(j);
         if (nd.keep_last) {
             int32_t* nl = last + nd.last_off;
-            for (int b = 0; b < B; ++b) for (int i = 0; i < R; ++i) {
+            for (int b = 0; b < NB; ++b) for (int i = 0; i < R; ++i) {
                 const uint32_t k = ((uint32_t)b * W + lane) * R + (uint32_t)i;
                 if (k < nd.stride) { nl[k] = S(b, 0, i); nl[nd.stride + k] = S(b, 1, i); nl[2 * nd.stride + k] = S(b, 2, i); }
             }

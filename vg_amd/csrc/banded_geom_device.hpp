@@ -99,7 +99,7 @@ VGK_HD void banded_geometry_one(const BGeomParams& P, uint32_t i) {
         if (!any) { out.status = VGK_ENOBAND; P.out[i] = out; return; }
     }
     uint32_t R = 1; while ((int64_t)R * 64 < max_h) R *= 2;
-    if (R > 32) { out.status = VGK_ETOOBIG; P.out[i] = out; return; }
+    if (R > B_MAX_ROWS_PER_LANE) { out.status = VGK_ETOOBIG; P.out[i] = out; return; }
     out.R = R;
     { uint32_t r = 0; while ((1u << r) < R) ++r;
       uint32_t lg = 0; while ((cells >> lg) > 1 && lg < 63) ++lg;
