@@ -118,7 +118,7 @@ struct vgk_ctx {
     uint64_t multi_host_walks = 0;       // problems of the last vgk_gssw_align_multi whose alternates a host thread walked
     // device scratch kept between vgk_banded_align calls (grow-only; released with the context)
     struct DevBuf { void* p = nullptr; uint64_t bytes = 0; };
-    DevBuf scratch[160];           // 140..149 chain_api.cpp; 150..156 minimizer_api.cpp (reads of any length); 66, 67 wfa_api.cpp (the sequences as the caller holds them, their offsets); 88..99 gssw_wide_api.cpp; 65 wfa_api.cpp (producers_done); 72..83 gssw_multi_api.cpp (the walk on the device); 0..14 + 31 banded_api.cpp (+ 124..138: its second sub-batch in flight), 15..30 + 59, 60 gapless_api.cpp, 32..39 + 61..63 wfa_api.cpp, 40..47 gssw_multi_api.cpp / xdrop_band_api.cpp (+ 48, 49, 87; its second sub-batch in flight: 100..123), 50..54 tail_api.cpp, 55..58 minimizer_api.cpp
+    DevBuf scratch[160];           // 140..149 chain_api.cpp; 150..157 minimizer_api.cpp (reads of any length); 66, 67 wfa_api.cpp (the sequences as the caller holds them, their offsets); 88..99 gssw_wide_api.cpp; 65 wfa_api.cpp (producers_done); 72..83 gssw_multi_api.cpp (the walk on the device); 0..14 + 31 banded_api.cpp (+ 124..138: its second sub-batch in flight), 15..30 + 59, 60 gapless_api.cpp, 32..39 + 61..63 wfa_api.cpp, 40..47 gssw_multi_api.cpp / xdrop_band_api.cpp (+ 48, 49, 87; its second sub-batch in flight: 100..123), 50..54 tail_api.cpp, 55..58 minimizer_api.cpp
     void* ensure_scratch(int slot, uint64_t bytes) {
         DevBuf& b = scratch[slot];
         if (b.p && b.bytes >= bytes) return b.p;

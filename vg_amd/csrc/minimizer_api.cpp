@@ -218,26 +218,40 @@ int vgk_minimizer_list(vgk_ctx* ctx, const vgk_minimizer_index* ix, const char* 
     if (bytes > 0xfffffff0ull) return VGK_ETOOBIG;
     Backend* be = ctx->be.get();
     std::lock_guard<std::mutex> lk(ctx->mu);
-    const size_t n1 = (size_t)n + 1;
+    // a read is cut into stretches of MZ_LIST_WINDOWS windows, a lane each (a 15 kbp read alone would keep one lane busy for 15 000 steps)
+    std::vector<MzListItem> items; std::vector<uint64_t> item_first((size_t)n + 1, 0);
+    const uint32_t k = ix->dev.k, w = ix->dev.w;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t L = read_off[i + 1] - read_off[i];
+        if (L > 0xfffffff0ull) return VGK_ETOOBIG;
+        const uint32_t windows = L >= (uint64_t)k + w - 1 ? (uint32_t)(L - k - w + 2) : 0u;
+        for (uint32_t s = 0; s < windows; s += MZ_LIST_WINDOWS) items.push_back(MzListItem{i, s});
+        item_first[i + 1] = items.size();
+    }
+    if (items.size() > 0xfffffff0ull) return VGK_ETOOBIG;
+    const uint32_t n_items = (uint32_t)items.size();
+    const size_t n1 = (size_t)n + 1, m1 = (size_t)n_items + 1;
     char* d_reads = (char*)ctx->ensure_scratch(150, bytes + 32);
     uint64_t* d_off = (uint64_t*)ctx->ensure_scratch(151, sizeof(uint64_t) * n1);
-    uint32_t* d_tab = (uint32_t*)ctx->ensure_scratch(152, sizeof(uint32_t) * 2 * n1);
-    if (!d_reads || !d_off || !d_tab) return VGK_ENOMEM;
+    uint32_t* d_tab = (uint32_t*)ctx->ensure_scratch(152, sizeof(uint32_t) * 2 * m1);
+    MzListItem* d_items = (MzListItem*)ctx->ensure_scratch(157, sizeof(MzListItem) * std::max<size_t>(n_items, 1));
+    if (!d_reads || !d_off || !d_tab || !d_items) return VGK_ENOMEM;
     std::vector<uint64_t> rel(n1);
     for (size_t i = 0; i < n1; ++i) rel[i] = read_off[i] - read_off[0];
     MzListParams P{};
-    P.index = ix->dev; P.reads = d_reads + 8; P.read_off = d_off; P.n = n; P.counts = d_tab; P.first = d_tab + n1; P.pass = 1;
+    P.index = ix->dev; P.reads = d_reads + 8; P.read_off = d_off; P.n = n_items; P.items = d_items; P.counts = d_tab; P.first = d_tab + m1; P.pass = 1;
     int rc = be->upload(d_off, rel.data(), sizeof(uint64_t) * n1);
+    if (!rc && n_items) rc = be->upload(d_items, items.data(), sizeof(MzListItem) * n_items);
     if (!rc) rc = be->zero(d_reads, 8);
     if (!rc) rc = be->zero(d_reads + 8 + bytes, 16);
     if (!rc && bytes) rc = be->upload(d_reads + 8, reads + read_off[0], bytes);
     if (!rc) rc = be->run_minimizer_list(P);
-    if (!rc) rc = be->scan_u32(d_tab, d_tab + n1, (uint32_t)n1);
-    std::vector<uint32_t> first(n1);
-    if (!rc) rc = be->download(first.data(), d_tab + n1, sizeof(uint32_t) * n1);      // synchronises (rel[] may go)
+    if (!rc) rc = be->scan_u32(d_tab, d_tab + m1, (uint32_t)m1);
+    std::vector<uint32_t> first(m1);
+    if (!rc) rc = be->download(first.data(), d_tab + m1, sizeof(uint32_t) * m1);      // synchronises (rel[], items may go)
     if (rc) return rc;
-    for (size_t i = 0; i < n1; ++i) minimizer_off[i] = first[i];
-    const size_t total = first[n];
+    for (size_t i = 0; i < n1; ++i) minimizer_off[i] = first[item_first[i]];
+    const size_t total = first[n_items];
     if (written) *written = total;
     if (total > cap) return VGK_EOPS;
     if (!total) return VGK_OK;

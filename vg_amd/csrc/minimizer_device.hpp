@@ -83,6 +83,38 @@ VGK_HD void mz_minimizers(const char* seq, uint32_t L, uint32_t k, uint32_t w, O
     }
 }
 
+// The same for the windows [wa, wb) of the sequence only (window s = k-mers [s, s + w)): what mz_minimizers reports while it is at those windows —
+// a minimizer that window wa - 1 already had is not reported again.  The best of a window is its leftmost smallest candidate whichever window the
+// scan started at, so a long read cut into stretches of windows, one lane each, lists exactly the minimizers of the whole read, stretch by stretch.
+template <class OUT>
+VGK_HD void mz_minimizers_range(const char* seq, uint32_t L, uint32_t k, uint32_t w, uint32_t wa, uint32_t wb, OUT out) {
+    if (L < k + w - 1 || k == 0 || k > MZ_MAX_K || w == 0 || w > MZ_MAX_W) return;
+    constexpr uint64_t NONE = ~0ull;
+    const uint32_t n_windows = L - k - w + 2;
+    if (wb > n_windows) wb = n_windows;
+    if (wa >= wb) return;
+    uint64_t ring_hash[MZ_MAX_W], ring_key[MZ_MAX_W]; uint8_t ring_rev[MZ_MAX_W];
+    const uint32_t j0 = wa ? wa - 1 : 0;                                  // first k-mer looked at: window wa - 1's first
+    MzRoll roll; roll.init(k);
+    for (uint32_t i = 0; i + 1 < k; ++i) roll.push(seq[j0 + i]);
+    int64_t best = -1, reported = -1;
+    for (uint32_t j = j0; j < wb + w - 1; ++j) {
+        roll.push(seq[j + k - 1]);
+        const uint32_t slot = j % w;
+        if (roll.full()) { const MzKmer m = mz_canonical(roll); ring_hash[slot] = m.hash; ring_key[slot] = m.key; ring_rev[slot] = m.reverse ? 1 : 0; }
+        else { ring_hash[slot] = NONE; ring_key[slot] = 0; ring_rev[slot] = 0; }
+        if (j + 1 < j0 + w) continue;                                     // the first window is not complete yet
+        const uint32_t sidx = j + 1 - w;                                  // the window that ends at k-mer j
+        if (best >= 0 && best < (int64_t)sidx) best = -1;                 // the minimum slid out
+        if (best < 0) { for (uint32_t i = sidx; i <= j; ++i) { const uint64_t h = ring_hash[i % w]; if (h != NONE && (best < 0 || h < ring_hash[best % w])) best = i; } }
+        else if (ring_hash[slot] != NONE && ring_hash[slot] < ring_hash[best % w]) best = j;
+        if (best >= 0 && best != reported) {
+            if (sidx >= wa) { MzKmer m; m.hash = ring_hash[best % w]; m.key = ring_key[best % w]; m.reverse = ring_rev[best % w] != 0; out((uint32_t)best, m); }
+            reported = best;
+        }
+    }
+}
+
 // ---- the index on the device: open addressing, linear probing --------------------------------------------------------------------
 // A key with ONE position — nearly every key of a genome-scale index — holds it in its slot (count = MZ_INLINE | offset word, first =
 // node): a lookup is then one 16-byte request instead of two dependent ones.  A position's offset word carries the offset in its low
@@ -270,18 +302,22 @@ VGK_HD void minimizer_one(const MinimizerParams& P, uint32_t i) {
 // ---- reads of any length (vgk_minimizer_list / vgk_minimizer_seeds_of): no caps, the choice between the two calls is the caller's ----------
 // List: a lane per read, pass 1 counts the read's minimizers, pass 2 writes them behind the reads before it.  Seeds: a lane per minimizer,
 // pass 1 = its hits if it is taken, pass 2 = one seed per hit, index order.
+constexpr uint32_t MZ_LIST_WINDOWS = 192;     // windows per work item: a 15 kbp read is 78 items
+struct MzListItem { uint32_t read, window; };      // windows [window, window + MZ_LIST_WINDOWS) of read `read`
 struct MzListParams {
-    MzIndex index; const char* reads; const uint64_t* read_off; uint32_t n;
+    MzIndex index; const char* reads; const uint64_t* read_off; uint32_t n;      // n: ITEMS (a read is cut into stretches of windows, a lane each)
+    const MzListItem* items;
     uint32_t* counts;                     // [n + 1] pass 1 (entry n = 0)
     const uint32_t* first;                // their exclusive prefix sums
     vgk_read_minimizer* out; int pass;
 };
 VGK_HD void mz_list_one(const MzListParams& P, uint32_t i) {
     if (i >= P.n) { if (P.pass == 1 && i == P.n) P.counts[i] = 0; return; }
-    const uint64_t a = P.read_off[i]; const uint32_t L = (uint32_t)(P.read_off[i + 1] - a);
+    const MzListItem it = P.items[i];
+    const uint64_t a = P.read_off[it.read]; const uint32_t L = (uint32_t)(P.read_off[it.read + 1] - a);
     uint32_t n_min = 0;
     vgk_read_minimizer* dst = P.pass == 2 ? P.out + P.first[i] : nullptr;
-    mz_minimizers(P.reads + a, L, P.index.k, P.index.w, [&](uint32_t p, const MzKmer& m) {
+    mz_minimizers_range(P.reads + a, L, P.index.k, P.index.w, it.window, it.window + MZ_LIST_WINDOWS, [&](uint32_t p, const MzKmer& m) {
         if (dst) {
             uint32_t first = 0, count = 0; MzPos one{0, 0};
             const bool found = mz_find(P.index, m, first, count, one);
