@@ -525,3 +525,25 @@ def test_paired_policy_flags_the_reads_whose_tie_matters(lib_name):
     for i in range(len(reads)):
         if not matters[i] and not already[i]:
             assert p_seeds[p_off[i]:p_off[i + 1]].tobytes() == single[i].tobytes(), i
+
+
+def test_score_cluster_is_the_sum_over_the_distinct_minimizers_present():
+    """src/minimizer_mapper.cpp:4738-4781 restated: score = sum of find_minimizers' scores over the distinct sources of the cluster's seeds (in read order), coverage =
+    covered read bases / read length"""
+    h = util.host()
+    h.vgh_score_cluster.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(12)
+    for _ in range(200):
+        L = int(rng.integers(40, 400)); k = int(rng.integers(5, 31)); n = int(rng.integers(1, 40))
+        ms = [(int(rng.integers(0, 1 << 40)), int(rng.integers(0, L - k + 1)), k, int(rng.integers(0, 700))) for _ in range(n)]
+        ms.sort(key=lambda m: m[1])
+        sources = [int(x) for x in rng.integers(0, n, int(rng.integers(0, 30)))]
+        a = np.ascontiguousarray([x for m in ms for x in m], dtype=np.uint64); src = np.ascontiguousarray(sources if sources else [0], dtype=np.uint64)
+        out = np.zeros(2, dtype=np.float64); present = np.zeros(n, dtype=np.uint8)
+        assert h.vgh_score_cluster(a.ctypes.data, n, 500, src.ctypes.data, len(sources), L, out.ctypes.data, present.ctypes.data) == 0
+        sc = scores_of(ms, 500)
+        score = 0.0; covered = np.zeros(L, dtype=bool)
+        for j in range(n):
+            if j in sources:
+                score += sc[j]; covered[ms[j][1]:ms[j][1] + k] = True
+        assert out[0] == score and out[1] == covered.sum() / L and list(present) == [1 if j in sources else 0 for j in range(n)]

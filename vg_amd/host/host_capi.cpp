@@ -909,6 +909,19 @@ static int select_minimizers_impl(const uint64_t* minimizers, int n, uint64_t re
         return 0;
     } catch (std::exception& e) { g_last_error = e.what(); return -1; }
 }
+// MinimizerMapper::score_cluster: minimizers as for vgh_select_minimizers (4 numbers each; scores from find_minimizers' rule with policy[1] = hard_hit_cap);
+// seed_sources[n_seeds]: the minimizer each seed of the cluster came from -> out[0] = score, out[1] = coverage; present_out (nullable, n): 1 per minimizer present
+int vgh_score_cluster(const uint64_t* minimizers, int n, uint64_t hard_hit_cap, const uint64_t* seed_sources, int n_seeds, uint64_t seq_length, double out[2], uint8_t* present_out) {
+    try {
+        std::vector<PolicyMinimizer> ms((size_t)n);
+        for (int i = 0; i < n; ++i) { const uint64_t* q = minimizers + 4 * (size_t)i; ms[(size_t)i].key = q[0]; ms[(size_t)i].forward_offset = (size_t)q[1]; ms[(size_t)i].length = (size_t)q[2]; ms[(size_t)i].hits = (size_t)q[3]; }
+        score_minimizers(ms, (size_t)hard_hit_cap);
+        const ClusterScore c = score_cluster(std::vector<size_t>(seed_sources, seed_sources + n_seeds), ms, (size_t)seq_length);
+        out[0] = c.score; out[1] = c.coverage;
+        if (present_out) for (int i = 0; i < n; ++i) present_out[i] = c.present[(size_t)i];
+        return 0;
+    } catch (std::exception& e) { g_last_error = e.what(); return -1; }
+}
 // find_seeds' choice for a BATCH of reads of any length, over what vgk_minimizer_list answered (include/vgk.h: vgk_read_minimizer records behind each
 // other, read r = [minimizer_off[r], minimizer_off[r + 1])): take_out[j] = 1 where minimizer j's hits become seeds (SeedFilter 0).  k: the index's k-mer
 // length (a minimizer covers read bases [offset, offset + k)).  Reads on `threads` host threads (0 = all).  The reads' own bytes seed each read's shuffle.

@@ -192,4 +192,18 @@ std::vector<uint8_t> select_minimizers_in_order(const std::vector<PolicyMinimize
     return verdict;
 }
 
+ClusterScore score_cluster(const std::vector<size_t>& seed_sources, const std::vector<PolicyMinimizer>& minimizers, size_t seq_length) {
+    ClusterScore c; c.present.assign(minimizers.size(), 0);
+    for (size_t source : seed_sources) c.present.at(source) = 1;                                  // (:4746-4748)
+    std::vector<uint8_t> covered(seq_length, 0);
+    for (size_t j = 0; j < minimizers.size(); ++j) {                                              // (:4755-4768) in read order: the sum's order is the reference's
+        if (!c.present[j]) continue;
+        c.score += minimizers[j].score;
+        for (size_t b = minimizers[j].forward_offset; b < minimizers[j].forward_offset + minimizers[j].length && b < seq_length; ++b) covered[b] = 1;
+    }
+    size_t ones = 0; for (uint8_t b : covered) ones += b;
+    c.coverage = seq_length ? (double)ones / (double)seq_length : 0.0;                             // (:4770)
+    return c;
+}
+
 }  // namespace vgamd

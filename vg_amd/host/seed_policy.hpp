@@ -69,4 +69,11 @@ std::vector<uint8_t> select_minimizers(const std::vector<PolicyMinimizer>& minim
 // the filters over an order made before (minimizers_by_score)
 std::vector<uint8_t> select_minimizers_in_order(const std::vector<PolicyMinimizer>& minimizers_in_read_order, size_t read_length, const SeedPolicy& policy, const std::vector<size_t>& order);
 
+// MinimizerMapper::score_cluster (src/minimizer_mapper.cpp:4738-4781): a cluster's score is the sum of the scores of the DISTINCT minimizers its seeds come
+// from (`present`), its coverage the fraction of the read's bases that those minimizers' k-mers cover.  seed_sources[i] = the minimizer (index into
+// minimizers_in_read_order) seed i of the cluster came from (Seed::source).  [PARITY-UNPINNED: the reference holds no test for it; tests/test_seed_policy.py
+// holds it to the cited lines restated.  Who makes the clusters — SnarlDistanceIndexClusterer — is outside the snapshot.]
+struct ClusterScore { double score = 0.0, coverage = 0.0; std::vector<uint8_t> present; };
+ClusterScore score_cluster(const std::vector<size_t>& seed_sources, const std::vector<PolicyMinimizer>& minimizers_in_read_order, size_t seq_length);
+
 }  // namespace vgamd
