@@ -71,10 +71,17 @@ VGK_HD void cs_bound_one(const CsParams& P, uint32_t r) {
 
 // ---- CS_STITCH -------------------------------------------------------------------------------------------------------------------------
 // The composed path so far: mappings M[0 .. nm), the edits of M[k] at E[M[k].edit_begin .. + n_edits) (offsets inside the read's stretch),
-// the last mapping's edits ending at `tail`.  `cur` is the mapping being made: its edits are E[cur.edit_begin .. tail_cur).
+// behind each other without gaps, the last mapping's edits ending at `tail`.
+// A lane's time is its chain of dependent memory operations (a load that follows a store to the same stretch waits ~1 us at 125 wavefronts per
+// launch), so what the rules look at lives in registers: the LAST mapping kept (l_*: node, offset, its runs' place, its from_length, its last run —
+// M[nm - 1] itself is written when the next mapping is pushed, and at the end) and the mapping in the making (c_*: its last run is written only when
+// the next run begins or the mapping closes).  Per run one store; per mapping the inputs' loads, a store or two, no load of anything written here.
 struct CsState {
     vgk_chain_mapping* M; uint32_t* E; uint32_t nm, tail, cap_m, cap_e;
-    vgk_chain_mapping cur; uint32_t cur_end;        // cur's edits: E[cur.edit_begin, cur_end)
+    uint32_t l_node, l_offset, l_begin, l_n, l_from, l_last;
+    bool l_mixed;                 // an insertion was appended behind an insertion: two runs of one kind side by side until something joins (:1349: appended, not merged)
+    uint32_t c_node, c_offset, c_begin, c_end, c_last, c_first, c_from;
+    uint32_t total_to, total_from;
     int32_t status;
 };
 VGK_HD uint32_t cs_from_length(const uint32_t* E, uint32_t b, uint32_t n) { uint32_t f = 0; for (uint32_t k = 0; k < n; ++k) if (cs_kind(E[b + k]) != (uint32_t)VGK_WFA_INSERTION) f += cs_len(E[b + k]); return f; }
@@ -90,40 +97,55 @@ VGK_HD uint32_t cs_merge_runs(uint32_t* E, uint32_t b, uint32_t n) {
     }
     return w - b + 1;
 }
-VGK_HD void cs_open(CsState& S, uint32_t node, uint32_t offset) { S.cur.node = node; S.cur.offset = offset; S.cur.edit_begin = S.tail; S.cur.n_edits = 0; S.cur_end = S.tail; }
+VGK_HD void cs_open(CsState& S, uint32_t node, uint32_t offset) { S.c_node = node; S.c_offset = offset; S.c_begin = S.c_end = S.tail; S.c_from = 0; S.c_last = S.c_first = 0; }
 // one edit of the mapping in the making; Mapping simplify's merging happens here (a run of the kind of the mapping's last run extends it)
 VGK_HD void cs_edit(CsState& S, uint32_t kind, uint32_t len) {
     if (!len) return;
-    if (S.cur_end > S.cur.edit_begin && cs_kind(S.E[S.cur_end - 1]) == kind) { S.E[S.cur_end - 1] += len << 2; return; }
-    if (S.cur_end >= S.cap_e) { S.status = VGK_EOPS; return; }
-    S.E[S.cur_end++] = len << 2 | kind;
+    if (kind != (uint32_t)VGK_WFA_DELETION) S.total_to += len;
+    if (kind != (uint32_t)VGK_WFA_INSERTION) { S.total_from += len; S.c_from += len; }
+    if (S.c_end > S.c_begin && cs_kind(S.c_last) == kind) { S.c_last += len << 2; return; }
+    if (S.c_end > S.c_begin) { S.E[S.c_end - 1] = S.c_last; if (S.c_end - S.c_begin == 1) S.c_first = S.c_last; }
+    if (S.c_end >= S.cap_e) { S.status = VGK_EOPS; return; }
+    S.c_last = len << 2 | kind; ++S.c_end;
 }
+VGK_HD void cs_flush_last(CsState& S) { vgk_chain_mapping m; m.node = S.l_node; m.offset = S.l_offset; m.edit_begin = S.l_begin; m.n_edits = S.l_n; S.M[S.nm - 1] = m; }
 // the mapping in the making is complete: simplify's loop body for it (:1324-1406)
 VGK_HD void cs_close(CsState& S) {
-    uint32_t mb = S.cur.edit_begin, me = S.cur_end;
+    uint32_t mb = S.c_begin; const uint32_t me = S.c_end;
     if (me == mb) return;                                                      // no edits: redundant (:1334)
+    S.E[me - 1] = S.c_last; if (me - mb == 1) S.c_first = S.c_last;
     if (!S.nm) {
         if (S.nm >= S.cap_m) { S.status = VGK_EOPS; return; }
-        S.cur.n_edits = me - mb; S.M[S.nm++] = S.cur; S.tail = me; return;
+        S.l_node = S.c_node; S.l_offset = S.c_offset; S.l_begin = mb; S.l_n = me - mb; S.l_from = S.c_from; S.l_last = S.c_last; S.l_mixed = false;
+        S.nm = 1; S.tail = me; return;
     }
-    vgk_chain_mapping& l = S.M[S.nm - 1];
-    // insertions at the start of this mapping belong to the previous one: appended there as they are (:1345-1352)
-    uint32_t moved = 0;
-    while (mb + moved < me && cs_kind(S.E[mb + moved]) == (uint32_t)VGK_WFA_INSERTION) ++moved;
-    l.n_edits += moved; mb += moved;
-    uint32_t node = S.cur.node, offset = S.cur.offset;
-    const uint32_t l_from = cs_from_length(S.E, l.edit_begin, l.n_edits);
-    if (l.node == VGK_WFA_NO_NODE && node != VGK_WFA_NO_NODE) { l.node = node; l.offset = offset; }                  // (:1361-1369)
-    else if (node == VGK_WFA_NO_NODE && l.node != VGK_WFA_NO_NODE) { node = l.node; offset = l_from; }              // (:1371-1380: the offset is from_length(*l), as written there)
-    const bool joins = (l.node == VGK_WFA_NO_NODE && node == VGK_WFA_NO_NODE) || (l.node != VGK_WFA_NO_NODE && node != VGK_WFA_NO_NODE && l.node == node && l.offset + l_from == offset);
+    // an insertion at the start of this mapping belongs to the previous one: appended there as it is (:1345-1352; the mapping's runs are merged: at most one)
+    const bool moved = cs_kind(S.c_first) == (uint32_t)VGK_WFA_INSERTION;
+    if (moved) { if (cs_kind(S.l_last) == (uint32_t)VGK_WFA_INSERTION) S.l_mixed = true; ++S.l_n; S.l_last = S.c_first; ++mb; }
+    uint32_t node = S.c_node, offset = S.c_offset;
+    if (S.l_node == VGK_WFA_NO_NODE && node != VGK_WFA_NO_NODE) { S.l_node = node; S.l_offset = offset; }              // (:1361-1369)
+    else if (node == VGK_WFA_NO_NODE && S.l_node != VGK_WFA_NO_NODE) { node = S.l_node; offset = S.l_from; }           // (:1371-1380: the offset is from_length(*l), as written there)
+    const bool joins = (S.l_node == VGK_WFA_NO_NODE && node == VGK_WFA_NO_NODE) || (S.l_node != VGK_WFA_NO_NODE && node != VGK_WFA_NO_NODE && S.l_node == node && S.l_offset + S.l_from == offset);
+    const uint32_t rem = me - mb;
     if (joins) {                                                               // concat_mappings: all edits, merged again (:1382-1394)
-        l.n_edits += me - mb;
-        l.n_edits = cs_merge_runs(S.E, l.edit_begin, l.n_edits);
-        S.tail = l.edit_begin + l.n_edits;
-    } else if (me > mb) {                                                      // from_length(m) || to_length(m) (:1396)
+        if (S.l_mixed) {                                                       // runs of one kind side by side somewhere in l: the general merge, over memory
+            S.l_n = cs_merge_runs(S.E, S.l_begin, S.l_n + rem); S.l_last = S.E[S.l_begin + S.l_n - 1]; S.l_mixed = false;
+        } else if (rem) {                                                      // l and m are merged inside: only the run where they meet can merge
+            const uint32_t first_rem = !moved ? S.c_first : rem == 1 ? S.c_last : S.E[mb];
+            if (cs_kind(first_rem) == cs_kind(S.l_last)) {
+                const uint32_t merged = S.l_last + (cs_len(first_rem) << 2);
+                S.E[S.l_begin + S.l_n - 1] = merged;
+                for (uint32_t x = mb + 1; x < me; ++x) S.E[x - 1] = S.E[x];
+                S.l_n += rem - 1; S.l_last = rem == 1 ? merged : S.c_last;
+            } else { S.l_n += rem; S.l_last = S.c_last; }
+        }
+        S.l_from += S.c_from;
+        S.tail = S.l_begin + S.l_n;
+    } else if (rem) {                                                          // from_length(m) || to_length(m) (:1396)
         if (S.nm >= S.cap_m) { S.status = VGK_EOPS; return; }
-        vgk_chain_mapping m; m.node = node; m.offset = offset; m.edit_begin = mb; m.n_edits = me - mb;
-        S.M[S.nm++] = m; S.tail = me;
+        cs_flush_last(S);
+        S.l_node = node; S.l_offset = offset; S.l_begin = mb; S.l_n = rem; S.l_from = S.c_from; S.l_last = S.c_last; S.l_mixed = false;
+        ++S.nm; S.tail = me;
     } else S.tail = mb;
 }
 // WFAAlignment::to_path over (node path, node_offset, edit runs): a mapping per node the edits reach
@@ -172,7 +194,9 @@ VGK_HD void cs_stitch_one(const CsParams& P, uint32_t r) {
     const uint32_t R = P.n_reads + 1;
     CsState S;
     S.M = P.work_m + P.slot[r]; S.E = P.work_e + P.slot[R + r]; S.cap_m = P.bound[r]; S.cap_e = P.bound[R + r];
-    S.nm = 0; S.tail = 0; S.status = VGK_OK; S.cur_end = 0; S.cur.node = VGK_WFA_NO_NODE; S.cur.offset = 0; S.cur.edit_begin = 0; S.cur.n_edits = 0;
+    S.nm = 0; S.tail = 0; S.status = VGK_OK; S.total_to = S.total_from = 0;
+    S.l_node = VGK_WFA_NO_NODE; S.l_offset = S.l_begin = S.l_n = S.l_from = S.l_last = 0; S.l_mixed = false;
+    cs_open(S, VGK_WFA_NO_NODE, 0);
     for (uint64_t k = P.piece_off[r]; k < P.piece_off[r + 1] && S.status == VGK_OK; ++k) {
         const vgk_chain_piece pc = P.pieces[k];
         if (pc.kind == (uint32_t)VGK_PIECE_LINK) {
@@ -195,29 +219,30 @@ VGK_HD void cs_stitch_one(const CsParams& P, uint32_t r) {
     }
     vgk_chain_result out; out.status = S.status; out.mapping_begin = P.slot[r]; out.edit_begin = P.slot[R + r];
     out.n_mappings = out.n_edits = out.from_length = out.to_length = 0; out.reserved = 0;
-    if (S.status == VGK_OK) {
-        // leading and trailing deletions go (:1422-1475), the mappings close up, the edits close up behind each other
-        uint32_t total_to = 0;
-        for (uint32_t k = 0; k < S.nm; ++k) total_to += cs_to_length(S.E, S.M[k].edit_begin, S.M[k].n_edits);
-        uint32_t seen = 0, wm = 0, we = 0, from = 0;
-        for (uint32_t k = 0; k < S.nm; ++k) {
-            vgk_chain_mapping m = S.M[k];
-            const uint32_t curr = cs_to_length(S.E, m.edit_begin, m.n_edits);
-            if ((!seen && !curr) || seen == total_to) continue;
-            if (seen) {
-                if (seen + curr == total_to)                                   // the last mapping with read bases: deletions at its end go
-                    while (m.n_edits && cs_kind(S.E[m.edit_begin + m.n_edits - 1]) == (uint32_t)VGK_WFA_DELETION) --m.n_edits;
-            } else {                                                           // the first one: deletions at its start go, its offset moves on
-                while (m.n_edits && cs_kind(S.E[m.edit_begin]) == (uint32_t)VGK_WFA_DELETION) { m.offset += cs_len(S.E[m.edit_begin]); ++m.edit_begin; --m.n_edits; }
-            }
-            seen += cs_to_length(S.E, m.edit_begin, m.n_edits);
-            from += cs_from_length(S.E, m.edit_begin, m.n_edits);
-            for (uint32_t x = 0; x < m.n_edits; ++x) S.E[we + x] = S.E[m.edit_begin + x];       // (we <= m.edit_begin: a move towards the front)
-            m.edit_begin = we; we += m.n_edits;
-            if (m.node == VGK_WFA_NO_NODE) m.offset = 0;                          // an empty position is cleared (:1484-1487)
-            S.M[wm++] = m;
+    if (S.status == VGK_OK && S.nm && S.total_to) {
+        cs_flush_last(S);
+        // Deletions before the first and after the last read base go (:1422-1475): the mappings without a read base at either end, the deletion at the
+        // start of the first mapping that has one (its offset moves on), the deletion at the end of the last one — when that is another mapping (a path
+        // whose one mapping holds every read base keeps its trailing deletion: the first-mapping branch at :1453-1470 does not look at the end).  Only
+        // the ends are looked at; what lies between is where it is: the result names the stretch of mappings and of runs that is left.
+        uint32_t f = 0, g = S.nm - 1, from = S.total_from;
+        while (f < S.nm) { const vgk_chain_mapping m = S.M[f]; if (cs_to_length(S.E, m.edit_begin, m.n_edits)) break; from -= cs_from_length(S.E, m.edit_begin, m.n_edits); ++f; }
+        while (g > f) { const vgk_chain_mapping m = S.M[g]; if (cs_to_length(S.E, m.edit_begin, m.n_edits)) break; from -= cs_from_length(S.E, m.edit_begin, m.n_edits); --g; }
+        vgk_chain_mapping mf = S.M[f];
+        if (mf.n_edits && cs_kind(S.E[mf.edit_begin]) == (uint32_t)VGK_WFA_DELETION) {      // (runs are merged: one run at most)
+            const uint32_t d = cs_len(S.E[mf.edit_begin]); mf.offset += d; ++mf.edit_begin; --mf.n_edits; from -= d;
         }
-        out.n_mappings = wm; out.n_edits = we; out.from_length = from; out.to_length = seen;
+        if (mf.node == VGK_WFA_NO_NODE) mf.offset = 0;                         // an empty position is cleared (:1484-1487)
+        S.M[f] = mf;
+        uint32_t end_e;
+        if (g > f) {
+            vgk_chain_mapping mg = S.M[g];
+            if (mg.n_edits && cs_kind(S.E[mg.edit_begin + mg.n_edits - 1]) == (uint32_t)VGK_WFA_DELETION) { from -= cs_len(S.E[mg.edit_begin + mg.n_edits - 1]); --mg.n_edits; S.M[g] = mg; }
+            end_e = mg.edit_begin + mg.n_edits;
+        } else end_e = mf.edit_begin + mf.n_edits;
+        out.mapping_begin = P.slot[r] + f; out.n_mappings = g - f + 1;
+        out.edit_begin = P.slot[R + r] + mf.edit_begin; out.n_edits = end_e - mf.edit_begin;
+        out.from_length = from; out.to_length = S.total_to;
     }
     P.res[r] = out;
     P.count[r] = out.n_mappings; P.count[R + r] = out.n_edits;
@@ -230,7 +255,8 @@ VGK_HD void cs_gather_one(const CsParams& P, uint32_t r, uint32_t lane, uint32_t
     const uint32_t mb = P.out_slot[r], eb = P.out_slot[R + r];
     const bool fits = (uint64_t)mb + w.n_mappings <= P.out_m_cap && (uint64_t)eb + w.n_edits <= P.out_e_cap;
     if (fits) {
-        for (uint32_t k = lane; k < w.n_mappings; k += lanes) { vgk_chain_mapping m = P.work_m[w.mapping_begin + k]; m.edit_begin += eb; P.out_m[mb + k] = m; }
+        const uint32_t rebase = eb - (w.edit_begin - P.slot[R + r]);          // a mapping's runs are named by their place in the read's stretch; the result's first run sits at w.edit_begin
+        for (uint32_t k = lane; k < w.n_mappings; k += lanes) { vgk_chain_mapping m = P.work_m[w.mapping_begin + k]; m.edit_begin += rebase; P.out_m[mb + k] = m; }
         for (uint32_t k = lane; k < w.n_edits; k += lanes) P.out_e[eb + k] = P.work_e[w.edit_begin + k];
     }
     if (lane == 0) {
