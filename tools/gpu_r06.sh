@@ -68,6 +68,10 @@ PY
       unset VGAMD_CONFIG2_ONE_CONTEXT VGAMD_LONGREAD_BATCH VGAMD_LONGREAD_ONE_LANE
     done
     ls $P ;;
+  stats_default)  # rocprofv3 kernel statistics of the headline at the bench's own size (1 M reads per launch, the default steps / warmup; no secondary legs, no CPU leg, one stream)
+    P=$GRAFT_REPO_ROOT/gpurun_out/r06_pmc; mkdir -p $P
+    ( cd /tmp && timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_default -o s -- python $GRAFT_REPO_ROOT/bench.py --no-secondary --no-cpu --no-e2e > $P/stats_default.log 2>&1 )
+    grep -E "^\{" $P/stats_default.log | tail -1 | cut -c1-300; head -6 $P/stats_default/s_kernel_stats.csv | cut -c1-160 ;;
   registers)      # VGPRs, spills, scratch and LDS of every kernel of the built library
     python tools/kernel_registers.py vg_amd/libvgamd.so > "$out/kernel_registers.txt" 2>&1; head -50 "$out/kernel_registers.txt" ;;
   *) echo "unknown stage $stage"; exit 2 ;;
