@@ -268,7 +268,7 @@ def device_geometry_problems(seed, n, n_mixed, wide_read=700, wide_pad=520, mixe
                          band_padding=wide_pad, permissive=True))                         # 32 rows per lane (700 / 520)
     problems.insert(5, dict(read="ACGT", nodes=["A" * 70000], preds=[[]], band_padding=1, permissive=True))             # declined by the checks
     problems.insert(9, dict(read="ACGTACGTAC", nodes=["ACGTACGTACGT" * 8], preds=[[]], band_padding=0, permissive=False))  # no band reaches the sink
-    problems.insert(11, dict(read="ACGTACGT" * 30, nodes=["ACGTACGT" * 30, "ACGT"], preds=[[], [0]], band_padding=2000, permissive=True))  # more than 2048 diagonals
+    problems.insert(11, dict(read="ACGTACGT" * 3, nodes=["ACGTACGT" * 3, "ACGT"], preds=[[], [0]], band_padding=2000, permissive=True))  # more than 2048 diagonals (aligned since round 6; few columns: the emulator steps every lane of each)
     return problems
 
 

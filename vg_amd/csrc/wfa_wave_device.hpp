@@ -949,24 +949,34 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
                     }
                 }
             };
+            // One walk, not two: the originals it passes are kept where the penalties' table was (done with after the loop; W_SCORES words of this wavefront's
+            // LDS) and copied out once their place in `paths` is known — through the merged-run tables every original is two dependent loads, and this
+            // serial epilogue was 35 % of the kernel's wavefront time on the chr22-scale graph (profiles/r06/NOTES.md §4).  A path of more nodes than the
+            // table holds is walked a second time, as before.
             uint32_t kept = 0, at = 0, last_start = 0, last_len = 0;
-            originals([&](uint32_t, uint32_t gl) {
+            uint32_t* const walked = sh.ps_range;
+            originals([&](uint32_t o, uint32_t gl) {
                 if (kept != 0 && at >= used) return false;                      // (everything from here on starts behind the alignment's last base)
+                if (kept < (uint32_t)W_SCORES) walked[kept] = o;
                 ++kept; last_start = at; last_len = gl; at += gl;
                 return true;
             });
+            const bool walked_all = kept <= (uint32_t)W_SCORES;
             if (kept == 1 && used == out.node_offset) kept = 0;
             const unsigned long long p0 = g_bump(B.counters + 0, kept), e0 = g_bump(B.counters + 1, n_edits);
             if (p0 + kept > B.caps[0] || e0 + n_edits > B.caps[1]) { out.status = VGK_EOPS; out.ok = 0; }
             else {
                 const bool flip = pb.mode == VGK_WFA_PREFIX;
-                uint32_t w = 0;
-                originals([&](uint32_t o, uint32_t) {
-                    if (w >= kept) return false;
-                    B.paths[p0 + (flip ? kept - 1 - w : w)] = flip ? (o ^ 1u) : o;
-                    ++w;
-                    return true;
-                });
+                if (walked_all) { for (uint32_t w = 0; w < kept; ++w) { const uint32_t o = walked[w]; B.paths[p0 + (flip ? kept - 1 - w : w)] = flip ? (o ^ 1u) : o; } }
+                else {
+                    uint32_t w = 0;
+                    originals([&](uint32_t o, uint32_t) {
+                        if (w >= kept) return false;
+                        B.paths[p0 + (flip ? kept - 1 - w : w)] = flip ? (o ^ 1u) : o;
+                        ++w;
+                        return true;
+                    });
+                }
                 for (uint32_t e = 0; e < n_edits; ++e) B.edits[e0 + e] = runs[flip ? e : n_edits - 1 - e];
                 out.path_begin = (uint32_t)p0; out.path_len = kept; out.edit_begin = (uint32_t)e0; out.n_edits = n_edits;
                 if (pb.mode != VGK_WFA_CONNECT && n_edits && out.length == c.L) {
