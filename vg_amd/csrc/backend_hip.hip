@@ -473,7 +473,10 @@ struct GWaveDev {
         return k < (unsigned long long)P.n ? (uint32_t)k : 0xffffffffu;
     }
 };
-template <bool MG> __global__ void __launch_bounds__(64, 4) gapless_search_kernel(const GaplessParams P, const uint32_t threads) {
+#ifndef VGK_GAPLESS_OCC
+#define VGK_GAPLESS_OCC 4          // wavefronts per SIMD the search kernel is built for (tools/build_variant.sh: 5 and 6 measured in round 6, profiles/r06/NOTES.md §5)
+#endif
+template <bool MG> __global__ void __launch_bounds__(64, VGK_GAPLESS_OCC) gapless_search_kernel(const GaplessParams P, const uint32_t threads) {
     __shared__ uint32_t lds[64 * G_FAST_DW];
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t >= threads) return;
