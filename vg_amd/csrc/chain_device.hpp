@@ -157,12 +157,21 @@ VGK_HD void cs_alignment(const CsParams& P, CsState& S, const uint32_t* path, ui
         return;                                                                // path empty: an empty Path (:972-974)
     }
     if (path[0] >= P.index.n_oriented) { S.status = VGK_EINVAL; return; }
+    // The walk's inputs are read AHEAD of their use — the node after the current one and its length, the node after that, the run after the current
+    // one — so that a mapping costs no load it has to wait a whole memory latency for: the loads of step s + 1 and s + 2 are in flight while step s
+    // is written.  (A node index beyond the index is refused when the walk reaches it, as before: its "length" is then never loaded.)
+    const uint32_t NO = P.index.n_oriented;
     uint32_t step = 0, node_at = node_offset, node_end = g_len(P.index, (int32_t)path[0]);
+    uint32_t n1 = path_len > 1 ? path[1] : 0u, n2 = path_len > 2 ? path[2] : 0u;
+    uint32_t l1 = path_len > 1 && n1 < NO ? g_len(P.index, (int32_t)n1) : 0u;
     if (node_offset >= node_end || !n_runs) { S.status = VGK_EINVAL; return; } // "offset to or past end of first node", "has no edits"
     cs_open(S, path[0], node_offset);
+    uint32_t run_next = runs[0];
     for (uint32_t k = 0; k < n_runs && S.status == VGK_OK; ++k) {
-        const uint32_t kind = cs_kind(runs[k]);
-        uint32_t left = cs_len(runs[k]);
+        const uint32_t run = run_next;
+        if (k + 1 < n_runs) run_next = runs[k + 1];
+        const uint32_t kind = cs_kind(run);
+        uint32_t left = cs_len(run);
         if (!left) { S.status = VGK_EINVAL; return; }                          // "has empty edit"
         const bool uses_graph = kind != (uint32_t)VGK_WFA_INSERTION;
         while (left && S.status == VGK_OK) {
@@ -178,10 +187,14 @@ VGK_HD void cs_alignment(const CsParams& P, CsState& S, const uint32_t* path, ui
                 if (node_at == node_end) {
                     node_at = 0; ++step;
                     if (step != path_len) {
-                        if (path[step] >= P.index.n_oriented) { S.status = VGK_EINVAL; return; }
-                        node_end = g_len(P.index, (int32_t)path[step]);
+                        const uint32_t node = n1;
+                        if (node >= NO) { S.status = VGK_EINVAL; return; }
+                        node_end = l1;
                         if (!node_end) { S.status = VGK_EINVAL; return; }      // "has empty node"
-                        cs_close(S); cs_open(S, path[step], 0);
+                        n1 = n2;                                                // (loaded a step ago)
+                        l1 = step + 1 < path_len && n1 < NO ? g_len(P.index, (int32_t)n1) : 0u;
+                        n2 = step + 2 < path_len ? path[step + 2] : 0u;
+                        cs_close(S); cs_open(S, node, 0);
                     } else node_end = 0;
                 }
             }
@@ -197,11 +210,16 @@ VGK_HD void cs_stitch_one(const CsParams& P, uint32_t r) {
     S.nm = 0; S.tail = 0; S.status = VGK_OK; S.total_to = S.total_from = 0;
     S.l_node = VGK_WFA_NO_NODE; S.l_offset = S.l_begin = S.l_n = S.l_from = S.l_last = 0; S.l_mixed = false;
     cs_open(S, VGK_WFA_NO_NODE, 0);
-    for (uint64_t k = P.piece_off[r]; k < P.piece_off[r + 1] && S.status == VGK_OK; ++k) {
-        const vgk_chain_piece pc = P.pieces[k];
+    // (the next piece and, for a LINK, the result it names are read while the current piece is walked)
+    const uint64_t k_end = P.piece_off[r + 1];
+    vgk_chain_piece pc_next{}; vgk_wfa_result w_next{};
+    auto fetch = [&](uint64_t k) { pc_next = P.pieces[k]; if (pc_next.kind == (uint32_t)VGK_PIECE_LINK && pc_next.link < P.n_links) w_next = P.link_res[pc_next.link]; };
+    if (P.piece_off[r] < k_end) fetch(P.piece_off[r]);
+    for (uint64_t k = P.piece_off[r]; k < k_end && S.status == VGK_OK; ++k) {
+        const vgk_chain_piece pc = pc_next; const vgk_wfa_result w = w_next;
+        if (k + 1 < k_end) fetch(k + 1);
         if (pc.kind == (uint32_t)VGK_PIECE_LINK) {
-            if (!cs_link_ok(P, pc)) { S.status = VGK_EINVAL; break; }          // "WFAAlignment is not OK and cannot become a path"
-            const vgk_wfa_result w = P.link_res[pc.link];
+            if (pc.link >= P.n_links || w.status != VGK_OK || !w.ok || (uint64_t)w.path_begin + w.path_len > P.link_path_cap || (uint64_t)w.edit_begin + w.n_edits > P.link_edit_cap) { S.status = VGK_EINVAL; break; }          // "WFAAlignment is not OK and cannot become a path" (cs_link_ok over the result already read)
             cs_alignment(P, S, P.link_paths + w.path_begin, w.path_len, w.node_offset, P.link_edits + w.edit_begin, w.n_edits);
         } else if (pc.kind == (uint32_t)VGK_PIECE_ALIGNMENT) {
             if ((uint64_t)pc.path_begin + pc.path_len > P.n_nodes || (uint64_t)pc.edit_begin + pc.n_edits > P.n_edits) { S.status = VGK_EINVAL; break; }
