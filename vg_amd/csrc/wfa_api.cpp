@@ -242,8 +242,20 @@ int vgk_wfa_extend(vgk_ctx* ctx, const vgk_haplo* index, const vgk_wfa_error_mod
     // Otherwise (pointers all over the heap) the host threads gather and mask as before.
     uintptr_t span_lo = ~(uintptr_t)0, span_hi = 0;
     for (uint32_t c = 0; c < slices; ++c) { span_lo = std::min(span_lo, slice_lo[c]); span_hi = std::max(span_hi, slice_hi[c]); }
-    const bool one_stretch = n_seq && span_hi > span_lo && (uint64_t)(span_hi - span_lo) <= std::max<uint64_t>(2 * n_seq, n_seq + (1u << 20)) && (uint64_t)(span_hi - span_lo) < 0xfffffff0ull
-                             && !std::getenv("VGAMD_WFA_HOST_MASK");
+    bool one_stretch = n_seq && span_hi > span_lo && (uint64_t)(span_hi - span_lo) <= std::max<uint64_t>(2 * n_seq, n_seq + (1u << 20)) && (uint64_t)(span_hi - span_lo) < 0xfffffff0ull
+                       && !std::getenv("VGAMD_WFA_HOST_MASK");
+    // ... and every byte of the stretch must be the caller's to read: the sequences in address order as they are in problem order, with less than a page
+    // between one's end and the next one's start — every page such a gap touches then also holds a byte of a sequence, so it is mapped (a read's links
+    // with its anchors' 29 bases between them; a batch's arena).  Anything else takes the host path.
+    if (one_stretch) {
+        uintptr_t prev_end = 0;
+        for (uint32_t i = 0; i < n && one_stretch; ++i) {
+            if (!probs[i].seq_len) continue;
+            const uintptr_t a = (uintptr_t)problems[i].seq;
+            if (prev_end && (a < prev_end || a - prev_end >= 4096)) one_stretch = false;
+            prev_end = a + probs[i].seq_len;
+        }
+    }
     char* seqs = nullptr;
     if (!one_stretch) {
         seqs = H.seqs.get(be, n_seq + 16);
