@@ -66,22 +66,25 @@ int launch_wave_form(vgk_ctx* ctx) {
     if ((rc = be->download(&taken_over, A.n_todo_dev ? A.n_todo_dev : A.n_declined, sizeof taken_over))) return rc;
     ctx->wfa_wave_retried = taken_over;                                           // hybrid: what the thread kernel handed over; else: what outgrew the small tables
     if (A.stats) {
-        std::vector<uint32_t> st(8 * (size_t)A.base.n);
+        constexpr size_t SW = WW_STAT_WORDS;
+        std::vector<uint32_t> st(SW * (size_t)A.base.n);
         if (!be->download(st.data(), A.stats, sizeof(uint32_t) * st.size())) {
             std::vector<uint32_t> idx;
-            for (uint32_t i = 0; i < A.base.n; ++i) if (st[8 * i + 2]) idx.push_back(i);
-            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return st[8 * a + 2] > st[8 * b + 2]; });
+            for (uint32_t i = 0; i < A.base.n; ++i) if (st[SW * i + 2]) idx.push_back(i);
+            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return st[SW * a + 2] > st[SW * b + 2]; });
             unsigned long long chunks = 0, points = 0, steps = 0;
-            for (uint32_t i : idx) { chunks += st[8 * i + 2]; points += st[8 * i]; steps += st[8 * i + 1]; }
+            for (uint32_t i : idx) { chunks += st[SW * i + 2]; points += st[SW * i]; steps += st[SW * i + 1]; }
             unsigned long long items = 0;
-            for (uint32_t i : idx) items += st[8 * i + 3] >> 8;
+            for (uint32_t i : idx) items += st[SW * i + 3] >> 8;
             std::fprintf(stderr, "[wfa wave] %zu problems: %llu chunks, %llu points, %llu steps, %llu filtered items in all; heaviest (points, steps, chunks, trie nodes, items; us in extend, next, between, after):", idx.size(), chunks, points, steps, items);
-            for (size_t k = 0; k < idx.size() && k < 8; ++k) std::fprintf(stderr, " (%u,%u,%u,%u,%u; %u,%u,%u,%u)", st[8 * idx[k]], st[8 * idx[k] + 1], st[8 * idx[k] + 2], st[8 * idx[k] + 3] & 255u, st[8 * idx[k] + 3] >> 8, st[8 * idx[k] + 4], st[8 * idx[k] + 5], st[8 * idx[k] + 6], st[8 * idx[k] + 7]);
+            for (size_t k = 0; k < idx.size() && k < 8; ++k) std::fprintf(stderr, " (%u,%u,%u,%u,%u; %u,%u,%u,%u)", st[SW * idx[k]], st[SW * idx[k] + 1], st[SW * idx[k] + 2], st[SW * idx[k] + 3] & 255u, st[SW * idx[k] + 3] >> 8, st[SW * idx[k] + 4], st[SW * idx[k] + 5], st[SW * idx[k] + 6], st[SW * idx[k] + 7]);
             { unsigned long long us[4] = {0, 0, 0, 0}, nodes = 0;
-              for (uint32_t i : idx) { for (int k = 0; k < 4; ++k) us[k] += st[8 * i + 4 + k]; nodes += st[8 * i + 3] & 255u; }
+              unsigned long long after[4] = {0, 0, 0, 0};
+              for (uint32_t i : idx) { for (int k = 0; k < 4; ++k) { us[k] += st[SW * i + 4 + k]; after[k] += st[SW * i + 8 + k]; } nodes += st[SW * i + 3] & 255u; }
+              std::fprintf(stderr, " | after the loop: %llu us backtrace, %llu the path's originals, %llu room + output; before the loop %llu us", after[0], after[1], after[2], after[3]);
               std::fprintf(stderr, " | all problems together: %llu us in extend, %llu in next, %llu at the start and between the two, %llu after the loop (backtrace, output); %llu trie nodes; the launch: %.2f ms x %u wavefronts = %.0f us of wavefront time",
                            us[0], us[1], us[2], us[3], nodes, be->last_ms(6), ctx->wfa_wave_waves[0], 1e3 * be->last_ms(6) * ctx->wfa_wave_waves[0]); }
-            for (size_t q : {idx.size() / 100, idx.size() / 10, idx.size() / 2}) if (q < idx.size()) std::fprintf(stderr, " | rank %zu: (%u,%u,%u,%u,%u)", q, st[8 * idx[q]], st[8 * idx[q] + 1], st[8 * idx[q] + 2], st[8 * idx[q] + 3] & 255u, st[8 * idx[q] + 3] >> 8);
+            for (size_t q : {idx.size() / 100, idx.size() / 10, idx.size() / 2}) if (q < idx.size()) std::fprintf(stderr, " | rank %zu: (%u,%u,%u,%u,%u)", q, st[SW * idx[q]], st[SW * idx[q] + 1], st[SW * idx[q] + 2], st[SW * idx[q] + 3] & 255u, st[SW * idx[q] + 3] >> 8);
             std::fprintf(stderr, "\n");
         }
     }
@@ -122,8 +125,8 @@ int prepare_wave_form(vgk_ctx* ctx, WfaHost& H, const WfaParams& P, bool after_t
     A.n_declined = (unsigned long long*)extra;
     A.stats = nullptr;
     if (std::getenv("VGAMD_WFA_STATS")) {                                        // per-problem statistics, printed by the call (a debugging aid)
-        A.stats = (uint32_t*)ctx->ensure_scratch(64, sizeof(uint32_t) * 8 * ((size_t)P.n + 1));
-        if (!A.stats || be->zero(A.stats, sizeof(uint32_t) * 8 * ((size_t)P.n + 1))) return VGK_ENOMEM;
+        A.stats = (uint32_t*)ctx->ensure_scratch(64, sizeof(uint32_t) * WW_STAT_WORDS * ((size_t)P.n + 1));
+        if (!A.stats || be->zero(A.stats, sizeof(uint32_t) * WW_STAT_WORDS * ((size_t)P.n + 1))) return VGK_ENOMEM;
     }
     ctx->wfa_wave_last[0] = A; ctx->wfa_wave_waves[0] = z.waves;
     return VGK_OK;

@@ -64,6 +64,7 @@ struct WwNode {                       // WNode of wfa_device.hpp + where the rec
 };
 struct WwPath { int32_t node; uint32_t seq_off; uint16_t start, len, next, inner; };   // a graph node on a trie node's path (or a piece of a merged run: from base `inner` of the run on): its bases at index.seq + seq_off
 
+constexpr uint32_t WW_STAT_WORDS = 12;      // per problem, when WwParams::stats is set (a debugging aid: wfa_api.cpp prints them)
 struct WwParams {
     WfaParams base;                   // index, problems, sequences, scoring, outputs, counters[2] = next problem to hand out
     GIndex index; GMerge merge;       // the index this kernel walks: base.index, or its merged-run form (merge.on) with the tables between the two
@@ -153,7 +154,18 @@ template <class XL, bool SMALL> VGK_HD WSrc ww_src(const WwCtx<XL, SMALL>& c, in
 }
 
 // ---- the wavefront table: w_key / the node-free hash of wfa_device.hpp over this launch's slot count ----
-template <class XL, bool SMALL> VGK_HD uint32_t ww_hash(const WwCtx<XL, SMALL>& c, uint32_t key) { return ((((key - 1u) >> 5) * 2654435761u) >> 8) & c.mask; }
+// The small size (LDS, up to half full) scatters cells; the large size (an HBM slab of 4 MB per wavefront, a few percent full) keeps eight neighbouring
+// diagonals of one (kind, penalty) in ONE 128-byte line — 16 slots, a diagonal's home at every second one, so that the free slot that ends its lookup lies in
+// the line too: the lanes of a chunk are neighbouring diagonals, and with scattered cells every probe, every new point and every slot wiped at the end was a
+// line of its own fetched and written back for 8 bytes (the kernel's HBM traffic was 52 x its algorithmic bytes, profiles/r06/NOTES.md §4).
+template <class XL, bool SMALL> VGK_HD uint32_t ww_hash(const WwCtx<XL, SMALL>& c, uint32_t key) {
+    const uint32_t cell = (key - 1u) >> 5;                                      // kind | penalty << 2 | (diagonal + 512) << 12
+    if constexpr (SMALL) return ((cell * 2654435761u) >> 8) & c.mask;
+    else {
+        const uint32_t group = (cell & 0xfffu) | ((cell >> 15) << 12);
+        return (((((group * 2654435761u) >> 8) << 4) | (((cell >> 12) & 7u) << 1))) & c.mask;
+    }
+}
 template <class XL, bool SMALL> VGK_HD bool ww_lookup(WwCtx<XL, SMALL>& c, uint32_t ancestors, int kind, int32_t score, int32_t diag, uint32_t& node, uint32_t& seq, uint32_t& off) {
     const uint32_t cell = (w_key(0, kind, score, diag) - 1u) >> 5;
     bool found = false; uint32_t best = 0;
@@ -213,16 +225,13 @@ template <class XL, bool SMALL> VGK_HD void ww_store(WwCtx<XL, SMALL>& c, uint32
     uint32_t probes = 0;
     for (uint32_t i = ww_hash(c, key);; i = (i + 1) & c.mask) {
         if (probes++ > c.mask) { c.overflow = true; c.why = 8; return; }
-        unsigned long long s = c.xl->load64(c.tbl(i));
-        if (!s) {
-            if (c.sh->n_points >= c.max_points + 64u) { c.overflow = true; c.why = 1; return; }     // (someone's table has run over already: do not pile on)
-            s = c.xl->cas64(c.tbl(i), 0ull, v);
-            if (!s) {                                                          // the slot is ours: a new point
-                const uint32_t at = c.xl->add32(&c.sh->n_points, 1u);
-                if (at >= c.max_points) { c.overflow = true; c.why = 1; return; }     // (the table is wiped whole after an overflow)
-                c.log_put(at, i);
-                return;
-            }
+        if (c.sh->n_points >= c.max_points + 64u) { c.overflow = true; c.why = 1; return; }         // (someone's table has run over already: do not pile on)
+        const unsigned long long s = c.xl->cas64(c.tbl(i), 0ull, v);          // (no load first: a new point is one trip to its slot, not two)
+        if (!s) {                                                              // the slot is ours: a new point
+            const uint32_t at = c.xl->add32(&c.sh->n_points, 1u);
+            if (at >= c.max_points) { c.overflow = true; c.why = 1; return; }         // (the table is wiped whole after an overflow)
+            c.log_put(at, i);
+            return;
         }
         if ((uint32_t)(s >> 32) == key) { c.xl->store64(c.tbl(i), v); return; }
     }
@@ -828,6 +837,8 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
     const bool timed = P.stats != nullptr;
     uint32_t t_mark = timed ? xl.clock_us() : 0u;
     if (timed) c.us_score += t_mark - t_begin;                                 // (the problem's start — its record, the root's walk, the first point — counts with the bookkeeping)
+    const uint32_t t_first = t_mark - t_begin;
+    uint32_t t_after[3] = {0, 0, 0};
     auto lap = [&](uint32_t& into) { if (timed) { const uint32_t t = xl.clock_us(); into += t - t_mark; t_mark = t; } };
     while (!failed) {
         ww_extend(c, score, best_score, best_diag, best_seq, best_off, best_node);
@@ -850,9 +861,10 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
     // the rest is one chain of dependent lookups: lane 0
     const uint32_t n_points = sh.n_points < c.max_points ? sh.n_points : c.max_points;
     uint32_t* runs = c.run_buf();
+    uint32_t n_edits = 0, n_chain = 0, used = 0; bool ok = false, drop_first = false;      // lane 0's until they are handed round
     if (lane == 0 && !failed) {
         c.cand_score = best_score; c.cand_diag = best_diag; c.cand_seq = best_seq; c.cand_off = best_off; c.cand_node = best_node;
-        bool ok = true;
+        ok = true;
         uint32_t unaligned_tail = c.L - c.cand_seq;
         if (c.cand_score > pb.score_bound) {
             unaligned_tail = 0;
@@ -874,7 +886,7 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
                 }
             } else ok = false;
         }
-        uint32_t n_edits = 0; bool lost = false;
+        bool lost = false;
         if (ok) {
             out.ok = 1; out.node_offset = pb.from_off + 1;
             out.length = c.cand_seq + unaligned_tail;
@@ -916,68 +928,126 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
             }
             ok = !c.overflow && !lost;
         }
+        if (timed) t_after[0] = xl.clock_us() - t_loop_end;
         if (lost) { out.status = VGK_ENOBAND; out.ok = 0; out.score = 0; out.node_offset = 0; out.length = 0; }
         if (ok) {
-            uint8_t chain[W_NODES];
-            uint32_t n_chain = 0;
-            for (uint32_t x = c.cand_node;; x = sh.nodes[x].parent) { chain[n_chain++] = (uint8_t)x; if (x == 0) break; }
+            // the chain of trie nodes, leaf first, where the lanes can read it (expanded_at is next()'s: done with)
+            for (uint32_t x = c.cand_node;; x = sh.nodes[x].parent) { sh.expanded_at[n_chain++] = (int32_t)x; if (x == 0) break; }
             uint32_t ref_len = 0;
             for (uint32_t e = 0; e < n_edits; ++e) if ((runs[e] & 3u) != (uint32_t)VGK_WFA_INSERTION) ref_len += runs[e] >> 2;
             const uint32_t first_len = g_len(B.index, (int32_t)pb.from_node);
-            const bool drop_first = out.node_offset >= first_len;
+            drop_first = out.node_offset >= first_len;
             if (drop_first) out.node_offset = 0;
-            const uint32_t used = out.node_offset + ref_len;
-            // the ORIGINAL graph nodes along the chain, root first (a path entry is one of them, or a piece of a merged run: its originals in a row);
-            // visit(oriented node, length) -> false: enough
-            auto originals = [&](auto&& visit) {
-                bool first = true;
-                for (uint32_t k = n_chain; k-- > 0;) {
-                    const WwNode& n = sh.nodes[chain[k]];
-                    for (uint32_t j = n.path_head; j != W_NIL; j = c.pth(j).next) {
-                        const WwPath e = c.pth(j);
-                        if (P.merge.on) {
-                            WwOriginals it = ww_originals(P.merge, (uint32_t)e.node, (uint32_t)e.inner);
-                            for (uint32_t got = 0; got < e.len && !it.done(); it.step()) {
-                                const uint32_t gl = it.length(); got += gl;
-                                const bool skip = first && drop_first; first = false;
-                                if (!skip && !visit(it.oriented(), gl)) return;
-                            }
-                        } else {
+            used = out.node_offset + ref_len;
+        } else if (c.overflow) failed = true;                                  // (the backtrace's edit runs: reported like any table that ran out)
+    }
+    // The path's ORIGINAL graph nodes and the output: the whole wavefront.  On lane 0 alone this was one chain of dependent loads through the merged-run
+    // tables — two per original — and 12 % of the kernel's wavefront time on the chr22-scale graph (profiles/r06/NOTES.md §4); now a path entry (a piece of a
+    // merged run) is two trips: its run's bounds, then every lane its own original's stretch of `ocol`.
+    if (xl.bcast(lane == 0 && ok ? 1u : 0u, 0) != 0u) {
+        n_edits = xl.bcast(n_edits, 0); n_chain = xl.bcast(n_chain, 0); used = xl.bcast(used, 0); drop_first = xl.bcast(drop_first ? 1u : 0u, 0) != 0u;
+        const uint32_t node_offset = xl.bcast(out.node_offset, 0);
+        xl.fence();                                                            // (the chain, the edit runs: lane 0's, read by everyone)
+        // the ORIGINAL graph nodes along the chain, root first (a path entry is one of them, or a piece of a merged run: its originals in a row), one after
+        // the other on the calling lane; visit(oriented node, length) -> false: enough
+        auto originals = [&](auto&& visit) {
+            bool first = true;
+            for (uint32_t k = n_chain; k-- > 0;) {
+                const WwNode& n = sh.nodes[(uint32_t)sh.expanded_at[k]];
+                for (uint32_t j = n.path_head; j != W_NIL; j = c.pth(j).next) {
+                    const WwPath e = c.pth(j);
+                    if (P.merge.on) {
+                        WwOriginals it = ww_originals(P.merge, (uint32_t)e.node, (uint32_t)e.inner);
+                        for (uint32_t got = 0; got < e.len && !it.done(); it.step()) {
+                            const uint32_t gl = it.length(); got += gl;
                             const bool skip = first && drop_first; first = false;
-                            if (!skip && !visit((uint32_t)e.node, (uint32_t)e.len)) return;
+                            if (!skip && !visit(it.oriented(), gl)) return;
                         }
+                    } else {
+                        const bool skip = first && drop_first; first = false;
+                        if (!skip && !visit((uint32_t)e.node, (uint32_t)e.len)) return;
                     }
                 }
-            };
-            // One walk, not two: the originals it passes are kept where the penalties' table was (done with after the loop; W_SCORES words of this wavefront's
-            // LDS) and copied out once their place in `paths` is known — through the merged-run tables every original is two dependent loads, and this
-            // serial epilogue was 35 % of the kernel's wavefront time on the chr22-scale graph (profiles/r06/NOTES.md §4).  A path of more nodes than the
-            // table holds is walked a second time, as before.
-            uint32_t kept = 0, at = 0, last_start = 0, last_len = 0;
-            uint32_t* const walked = sh.ps_range;
-            originals([&](uint32_t o, uint32_t gl) {
-                if (kept != 0 && at >= used) return false;                      // (everything from here on starts behind the alignment's last base)
+            }
+        };
+        // The originals it passes are kept where the penalties' table was (done with after the loop; W_SCORES words of this wavefront's LDS) and copied out
+        // once their place in `paths` is known.  A path of more nodes than the table holds is walked a second time, by lane 0.
+        uint32_t kept = 0, at = 0, last_start = 0, last_len = 0;              // (the same on every lane)
+        uint32_t* const walked = sh.ps_range;
+        if (P.merge.on) {
+            bool skip_pending = drop_first, stop = false;
+            for (uint32_t k = n_chain; k-- > 0 && !stop;) {
+                const WwNode& n = sh.nodes[(uint32_t)sh.expanded_at[k]];
+                for (uint32_t j = n.path_head; j != W_NIL && !stop; j = c.pth(j).next) {
+                    const WwPath e = c.pth(j);
+                    const uint32_t m = (uint32_t)e.node >> 1; const bool rev = ((uint32_t)e.node & 1u) != 0;
+                    const uint32_t v0 = P.merge.run_first[m], v1 = P.merge.run_first[m + 1], nq = v1 - v0;
+                    const uint32_t edge = P.merge.ocol[rev ? v1 : v0];         // the run's first base on this strand's side
+                    bool have_s0 = false, entry_done = false; uint32_t s0 = 0;
+                    for (uint32_t base = 0; base < nq && !entry_done && !stop; base += 64u) {
+                        const uint32_t q = base + lane; const bool valid = q < nq;
+                        const uint32_t v = valid ? (rev ? v1 - 1u - q : v0 + q) : v0;
+                        const uint32_t a = P.merge.ocol[v], b = P.merge.ocol[v + 1];
+                        const uint32_t start = rev ? edge - b : a - edge, gl = b - a;      // bases of the run before this original, on this strand
+                        const bool from = valid && start >= (uint32_t)e.inner;
+                        if (!have_s0) {
+                            const unsigned long long fm = xl.ballot(from);
+                            if (fm) { have_s0 = true; s0 = xl.bcast(start, (uint32_t)__builtin_ctzll(fm)); }
+                        }
+                        const bool in = from && have_s0 && start - s0 < (uint32_t)e.len;
+                        if (xl.ballot(from && !in) != 0ull) entry_done = true;   // (an original that starts behind the piece: the piece is through)
+                        unsigned long long in_mask = xl.ballot(in);
+                        if (skip_pending && in_mask) { in_mask &= in_mask - 1ull; skip_pending = false; }
+                        if (!in_mask) continue;
+                        const bool mine = ((in_mask >> lane) & 1ull) != 0ull;
+                        const uint32_t rank = (uint32_t)__builtin_popcountll(in_mask & ((1ull << lane) - 1ull));
+                        const uint32_t first_start = xl.bcast(start, (uint32_t)__builtin_ctzll(in_mask));
+                        const uint32_t pos = at + (start - first_start);
+                        const bool keep = mine && (kept + rank == 0u || pos < used);
+                        const unsigned long long keep_mask = xl.ballot(keep);
+                        if (keep && kept + rank < (uint32_t)W_SCORES) walked[kept + rank] = 2u * v + (rev ? 1u : 0u);
+                        if (keep_mask) {
+                            const uint32_t last = 63u - (uint32_t)__builtin_clzll(keep_mask);
+                            last_start = xl.bcast(pos, last); last_len = xl.bcast(gl, last);
+                            at = last_start + last_len; kept += (uint32_t)__builtin_popcountll(keep_mask);
+                        }
+                        if (keep_mask != in_mask) stop = true;                 // (everything from here on starts behind the alignment's last base)
+                    }
+                }
+            }
+        } else {
+            if (lane == 0) originals([&](uint32_t o, uint32_t gl) {
+                if (kept != 0 && at >= used) return false;
                 if (kept < (uint32_t)W_SCORES) walked[kept] = o;
                 ++kept; last_start = at; last_len = gl; at += gl;
                 return true;
             });
-            const bool walked_all = kept <= (uint32_t)W_SCORES;
-            if (kept == 1 && used == out.node_offset) kept = 0;
-            const unsigned long long p0 = g_bump(B.counters + 0, kept), e0 = g_bump(B.counters + 1, n_edits);
-            if (p0 + kept > B.caps[0] || e0 + n_edits > B.caps[1]) { out.status = VGK_EOPS; out.ok = 0; }
-            else {
-                const bool flip = pb.mode == VGK_WFA_PREFIX;
-                if (walked_all) { for (uint32_t w = 0; w < kept; ++w) { const uint32_t o = walked[w]; B.paths[p0 + (flip ? kept - 1 - w : w)] = flip ? (o ^ 1u) : o; } }
-                else {
-                    uint32_t w = 0;
-                    originals([&](uint32_t o, uint32_t) {
-                        if (w >= kept) return false;
-                        B.paths[p0 + (flip ? kept - 1 - w : w)] = flip ? (o ^ 1u) : o;
-                        ++w;
-                        return true;
-                    });
-                }
-                for (uint32_t e = 0; e < n_edits; ++e) B.edits[e0 + e] = runs[flip ? e : n_edits - 1 - e];
+            kept = xl.bcast(kept, 0); last_start = xl.bcast(last_start, 0); last_len = xl.bcast(last_len, 0);
+        }
+        xl.fence_lds();                                                        // (walked[]: written by the lanes, copied out by others)
+        const bool walked_all = kept <= (uint32_t)W_SCORES;
+        if (timed && lane == 0) t_after[1] = xl.clock_us() - t_loop_end - t_after[0];
+        if (kept == 1 && used == node_offset) kept = 0;
+        // room in the dense outputs: lane 0 asks for the path's, lane 1 for the edits' (one trip for both)
+        unsigned long long got = 0;
+        if (lane < 2u) got = g_bump(B.counters + lane, lane == 0 ? kept : n_edits);
+        const unsigned long long p0 = (unsigned long long)xl.bcast((uint32_t)got, 0) | ((unsigned long long)xl.bcast((uint32_t)(got >> 32), 0) << 32),
+                                 e0 = (unsigned long long)xl.bcast((uint32_t)got, 1) | ((unsigned long long)xl.bcast((uint32_t)(got >> 32), 1) << 32);
+        if (p0 + kept > B.caps[0] || e0 + n_edits > B.caps[1]) { if (lane == 0) { out.status = VGK_EOPS; out.ok = 0; } }
+        else {
+            const bool flip = pb.mode == VGK_WFA_PREFIX;
+            if (walked_all) { for (uint32_t w = lane; w < kept; w += 64u) { const uint32_t o = walked[w]; B.paths[p0 + (flip ? kept - 1 - w : w)] = flip ? (o ^ 1u) : o; } }
+            else if (lane == 0) {
+                uint32_t w = 0;
+                originals([&](uint32_t o, uint32_t) {
+                    if (w >= kept) return false;
+                    B.paths[p0 + (flip ? kept - 1 - w : w)] = flip ? (o ^ 1u) : o;
+                    ++w;
+                    return true;
+                });
+            }
+            for (uint32_t e = lane; e < n_edits; e += 64u) B.edits[e0 + e] = runs[flip ? e : n_edits - 1 - e];
+            if (lane == 0) {
                 out.path_begin = (uint32_t)p0; out.path_len = kept; out.edit_begin = (uint32_t)e0; out.n_edits = n_edits;
                 if (pb.mode != VGK_WFA_CONNECT && n_edits && out.length == c.L) {
                     const uint32_t last = runs[0] & 3u;
@@ -988,7 +1058,8 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
                     if (kept) out.node_offset = last_len - (used - last_start);
                 }
             }
-        } else if (c.overflow) failed = true;                                  // (the backtrace's edit runs: reported like any table that ran out)
+        }
+        if (timed && lane == 0) t_after[2] = xl.clock_us() - t_loop_end - t_after[0] - t_after[1];
     }
     failed = xl.ballot(failed) != 0ull;
     // tables of the small size were not enough: the large size takes the problem over — unless it was the caller's own point budget that
@@ -1002,9 +1073,10 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
         }
         if (!retry) B.results[i] = out;
         if (P.stats && !retry) {
-            uint32_t* st = P.stats + 8 * (size_t)i;
+            uint32_t* st = P.stats + WW_STAT_WORDS * (size_t)i;
             st[0] = sh.n_points; st[1] = c.n_steps; st[2] = c.n_chunks; st[3] = sh.n_nodes | (c.n_items << 8);      // (items: those the filter let through; 0 when every item is looked at)
             st[4] = c.us_extend; st[5] = c.us_next; st[6] = c.us_score; st[7] = xl.clock_us() - t_loop_end;
+            st[8] = t_after[0]; st[9] = t_after[1]; st[10] = t_after[2]; st[11] = t_first;                           // after the loop: backtrace, the path's originals, room + output; before the loop
         }
     }
     retry = xl.bcast(retry ? 1u : 0u, 0) != 0u;
