@@ -76,8 +76,8 @@ int launch_wave_form(vgk_ctx* ctx) {
             for (uint32_t i : idx) { chunks += st[SW * i + 2]; points += st[SW * i]; steps += st[SW * i + 1]; }
             unsigned long long items = 0;
             for (uint32_t i : idx) items += st[SW * i + 3] >> 8;
-            std::fprintf(stderr, "[wfa wave] %zu problems: %llu chunks, %llu points, %llu steps, %llu filtered items in all; heaviest (points, steps, chunks, trie nodes, items; us in extend, next, between, after):", idx.size(), chunks, points, steps, items);
-            for (size_t k = 0; k < idx.size() && k < 8; ++k) std::fprintf(stderr, " (%u,%u,%u,%u,%u; %u,%u,%u,%u)", st[SW * idx[k]], st[SW * idx[k] + 1], st[SW * idx[k] + 2], st[SW * idx[k] + 3] & 255u, st[SW * idx[k] + 3] >> 8, st[SW * idx[k] + 4], st[SW * idx[k] + 5], st[SW * idx[k] + 6], st[SW * idx[k] + 7]);
+            std::fprintf(stderr, "[wfa wave] %zu problems: %llu chunks, %llu points, %llu steps, %llu filtered items in all; heaviest (points, steps, chunks, trie nodes, items; us in extend, next, between, after; after the loop: backtrace, originals, room + output; before the loop):", idx.size(), chunks, points, steps, items);
+            for (size_t k = 0; k < idx.size() && k < 8; ++k) std::fprintf(stderr, " (%u,%u,%u,%u,%u; %u,%u,%u,%u; %u,%u,%u,%u)", st[SW * idx[k]], st[SW * idx[k] + 1], st[SW * idx[k] + 2], st[SW * idx[k] + 3] & 255u, st[SW * idx[k] + 3] >> 8, st[SW * idx[k] + 4], st[SW * idx[k] + 5], st[SW * idx[k] + 6], st[SW * idx[k] + 7], st[SW * idx[k] + 8], st[SW * idx[k] + 9], st[SW * idx[k] + 10], st[SW * idx[k] + 11]);
             { unsigned long long us[4] = {0, 0, 0, 0}, nodes = 0;
               unsigned long long after[4] = {0, 0, 0, 0};
               for (uint32_t i : idx) { for (int k = 0; k < 4; ++k) { us[k] += st[SW * i + 4 + k]; after[k] += st[SW * i + 8 + k]; } nodes += st[SW * i + 3] & 255u; }

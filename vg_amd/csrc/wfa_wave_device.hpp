@@ -86,12 +86,18 @@ struct WwParams {
                                       // and microseconds (xl.clock_us) in extend(), next(), the penalty bookkeeping between them, everything after the loop
 };
 
+#ifndef VGK_WW_FINE_STATS
+#define VGK_WW_FINE_STATS 0
+#endif
+constexpr int WW_LARGE_PATH_LDS = 64;
 constexpr int WW_MASK_ROWS = 32;      // penalties whose node masks are kept at a time (a ring): more than any source wavefront lies back
 
 template <bool SMALL> struct WwTables {                                       // the large size: its tables are a slab in HBM; in LDS only ...
     uint32_t sv[64];                  // ... a chunk in the making: per diagonal looked at, the leaves that have something to do there
     uint32_t src_mask[64][5];         // ... next(): per diagonal looked at, the node sets of its five source cells (an item probes only the cells that can answer)
     uint32_t filter_off;              // ... and whether some diagonal has left the masks' width (then every item is looked at again, as in the small size)
+    WwPath   path_first[WW_LARGE_PATH_LDS];   // ... and the first entries of the path pool (a link that outgrew the small tables did so by its points: its trie is a node or
+                                      //     two, and every item of every chunk reads its entry — from the slab that was a trip to HBM each)
 };
 template <> struct WwTables<true> {   // the small size keeps its tables in LDS
     unsigned long long slot[WW_SMALL_SLOTS]; uint16_t log[WW_SMALL_POINTS]; WwPath path[WW_SMALL_PATH]; uint32_t runs[W_EDITS];
@@ -123,12 +129,17 @@ template <class XL, bool SMALL> struct WwCtx {
     int32_t max_distance;
     uint32_t n_chunks, n_steps, n_items;      // (statistics)
     uint32_t us_extend, us_next, us_score;
+#if VGK_WW_FINE_STATS
+    uint32_t us_fine[4], t_fine;      // (an experiment's build: where next() spends its time — filter + chunk, lookups, stores, expansions + merge)
+#endif
     bool overflow; int why;           // why: 1 points, 2 trie nodes, 3 path pool, 4 edits, 5 node length, 6 walked end reached, 7 work list,
                                       // 8 table without a free slot, 9 broken path chain, 10 a loop ran past its bound (8-10: cannot happen; never hang)
     VGK_HD unsigned long long* tbl(uint32_t i) { if constexpr (SMALL) return sh->slot + i; else return slot + i; }
     VGK_HD void log_put(uint32_t at, uint32_t i) { if constexpr (SMALL) sh->log[at] = (uint16_t)i; else log[at] = i; }
     VGK_HD uint32_t log_at(uint32_t k) const { if constexpr (SMALL) return sh->log[k]; else return log[k]; }
-    VGK_HD WwPath& pth(uint32_t k) { if constexpr (SMALL) return sh->path[k]; else return path[k]; }
+    VGK_HD WwPath pth(uint32_t k) const { if constexpr (SMALL) return sh->path[k]; else { if (k < (uint32_t)WW_LARGE_PATH_LDS) return sh->path_first[k]; return path[k]; } }
+    VGK_HD void pth_put(uint32_t k, const WwPath& e) { if constexpr (SMALL) sh->path[k] = e; else { if (k < (uint32_t)WW_LARGE_PATH_LDS) sh->path_first[k] = e; else path[k] = e; } }
+    VGK_HD void pth_link(uint32_t k, uint16_t next) { if constexpr (SMALL) sh->path[k].next = next; else { if (k < (uint32_t)WW_LARGE_PATH_LDS) sh->path_first[k].next = next; else path[k].next = next; } }
     VGK_HD uint32_t* run_buf() { if constexpr (SMALL) return sh->runs; else return runs; }
     // the word that names the trie nodes holding a point of (kind, score, diag); null when the diagonal lies outside the masks
     VGK_HD uint32_t* mask_word(int kind, int32_t score, int32_t diag) const {
@@ -213,28 +224,45 @@ template <class XL, bool SMALL> VGK_HD WPos ww_find_probed(WwCtx<XL, SMALL>& c, 
     if (ext_graph && ww_at_dead_end(c, p)) return w_none();
     return p;
 }
-template <class XL, bool SMALL> VGK_HD void ww_store(WwCtx<XL, SMALL>& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t seq, uint32_t off) {
+// A point is stored in two halves — the trip to its home slot (a CAS against "free"), then what that found — so that next() can have an item's three
+// stores (insertion, deletion, match) on their way together instead of three trips one after the other.
+struct WwPut { uint32_t i, key; unsigned long long v, old; bool on; };
+template <class XL, bool SMALL> VGK_HD WwPut ww_put_begin(WwCtx<XL, SMALL>& c, bool on, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t seq, uint32_t off) {
+    WwPut p; p.on = on; p.i = 0; p.key = 0; p.v = 0; p.old = 0;
+    if (!on) return p;
     if constexpr (!SMALL) {
         if (c.masks) {
             uint32_t* w = c.mask_word(kind, score, diag);
             if (w) c.xl->or32(w, 1u << node); else c.sh->filter_off = 1u;       // (read by everyone after the phase's fence)
         }
     }
-    const uint32_t key = w_key(node, kind, score, diag);
-    const unsigned long long v = ((unsigned long long)key << 32) | ((unsigned long long)(seq & 0xffffu) << 16) | (off & 0xffffu);
-    uint32_t probes = 0;
-    for (uint32_t i = ww_hash(c, key);; i = (i + 1) & c.mask) {
-        if (probes++ > c.mask) { c.overflow = true; c.why = 8; return; }
-        if (c.sh->n_points >= c.max_points + 64u) { c.overflow = true; c.why = 1; return; }         // (someone's table has run over already: do not pile on)
-        const unsigned long long s = c.xl->cas64(c.tbl(i), 0ull, v);          // (no load first: a new point is one trip to its slot, not two)
+    p.key = w_key(node, kind, score, diag);
+    p.v = ((unsigned long long)p.key << 32) | ((unsigned long long)(seq & 0xffffu) << 16) | (off & 0xffffu);
+    p.i = ww_hash(c, p.key);
+    if (c.sh->n_points >= c.max_points + 64u) { c.overflow = true; c.why = 1; p.on = false; return p; }     // (someone's table has run over already: do not pile on)
+    p.old = c.xl->cas64(c.tbl(p.i), 0ull, p.v);                               // (no load first: a new point is one trip to its slot, not two)
+    return p;
+}
+template <class XL, bool SMALL> VGK_HD void ww_put_end(WwCtx<XL, SMALL>& c, const WwPut& p) {
+    if (!p.on) return;
+    uint32_t i = p.i, probes = 0;
+    for (unsigned long long s = p.old;;) {
         if (!s) {                                                              // the slot is ours: a new point
             const uint32_t at = c.xl->add32(&c.sh->n_points, 1u);
             if (at >= c.max_points) { c.overflow = true; c.why = 1; return; }         // (the table is wiped whole after an overflow)
             c.log_put(at, i);
             return;
         }
-        if ((uint32_t)(s >> 32) == key) { c.xl->store64(c.tbl(i), v); return; }
+        if ((uint32_t)(s >> 32) == p.key) { c.xl->store64(c.tbl(i), p.v); return; }
+        i = (i + 1) & c.mask;
+        if (probes++ > c.mask) { c.overflow = true; c.why = 8; return; }
+        if (c.sh->n_points >= c.max_points + 64u) { c.overflow = true; c.why = 1; return; }
+        s = c.xl->cas64(c.tbl(i), 0ull, p.v);
     }
+}
+template <class XL, bool SMALL> VGK_HD void ww_store(WwCtx<XL, SMALL>& c, uint32_t node, int kind, int32_t score, int32_t diag, uint32_t seq, uint32_t off) {
+    const WwPut p = ww_put_begin(c, true, node, kind, score, diag, seq, off);
+    ww_put_end(c, p);
 }
 
 // ---- trie nodes (all of these read only; the trie changes in ww_node_create / ww_expand, one lane at a time) ----
@@ -350,8 +378,8 @@ template <class XL, bool SMALL> VGK_HD bool ww_append_piece(WwCtx<XL, SMALL>& c,
     if (slot_at >= c.path_cap) { c.overflow = true; c.why = 3; return true; }
     const uint16_t at = (uint16_t)slot_at;
     WwPath e; e.node = next.state.node; e.seq_off = next.seq_off; e.start = (uint16_t)n.len; e.len = (uint16_t)take; e.next = W_NIL; e.inner = (uint16_t)next.inner;
-    c.pth(at) = e;
-    if (n.path_head == W_NIL) n.path_head = at; else c.pth(n.path_tail).next = at;
+    c.pth_put(at, e);
+    if (n.path_head == W_NIL) n.path_head = at; else c.pth_link(n.path_tail, at);
     n.path_tail = at;
     n.len += take;
     n.cut = take < next.len ? 1 : 0;
@@ -596,7 +624,7 @@ template <class XL, bool SMALL> VGK_HD void ww_extend(WwCtx<XL, SMALL>& c, int32
         WwItem it; it.st = WX_DONE; it.qh = it.qt = 0; it.sp = 0; it.key_leaf = 0; it.blocked_on = 0; it.creator = false; it.pos = w_none();
         int32_t diag = diag0;
         bool have = false; uint32_t top = 0;
-        if (ww_filtering(c)) {
+        if (n_leaves > 1u && ww_filtering(c)) {                                 // (a trie of one leaf has an item on every diagonal: nothing to pack, and the sets' loads and the packing cost a chunk more than its lookups)
             if constexpr (!SMALL) n_diag = ww_chunk_of(c, diag0, ps.max_d, ww_mask_at(c, WK_MATCH, here, diag0 + (int32_t)c.lane), diag, top, have);
         } else {
             const uint32_t fit = 64u / n_leaves, left = (uint32_t)(ps.max_d - diag0 + 1);
@@ -642,8 +670,14 @@ template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t
         uint32_t n_diag;
         ++c.n_chunks;
         uint32_t want = W_NODES;                                               // the node this item asks to have expanded
+#if VGK_WW_FINE_STATS
+        c.t_fine = c.xl->clock_us();
+#define WW_FINE(k) { const uint32_t t_ = c.xl->clock_us(); c.us_fine[k] += t_ - c.t_fine; c.t_fine = t_; }
+#else
+#define WW_FINE(k)
+#endif
         int32_t diag = diag0; uint32_t leaf = 0; bool have_cand = false, have = false, filtered = false;
-        if (ww_filtering(c)) {
+        if (n_leaves > 1u && ww_filtering(c)) {                                 // (a trie of one leaf has an item on every diagonal: nothing to pack, and the sets' loads and the packing cost a chunk more than its lookups)
             if constexpr (!SMALL) {
                 const int32_t d = diag0 + (int32_t)c.lane;
                 uint32_t mk[5] = {0u, 0u, 0u, 0u, 0u};
@@ -660,6 +694,7 @@ template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t
             n_diag = fit < left ? fit : left;
             if (c.lane < n_diag * n_leaves) { have = true; diag = diag0 + (int32_t)(c.lane / n_leaves); leaf = ww_nth_bit(leaves, c.lane % n_leaves); }
         }
+        WW_FINE(0)
         if (have) {
             const uint32_t anc = c.sh->nodes[leaf].ancestors;
             // which of the five source cells hold a point on this leaf's way to the root (all, when every item is looked at): a cell
@@ -673,16 +708,17 @@ template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t
             WPos ins;
             { const WPos open = ww_find_probed(c, p_io, WK_MATCH, src_open, anc, leaf, diag - 1, true, false), ext = ww_find_probed(c, p_ie, WK_INS, src_extend, anc, leaf, diag - 1, true, false);
               ins = w_less(open, ext) ? ext : open; }
+            bool put_ins = false, put_del = false, put_match = false;          // (the three stores go out together at the end: ww_put_begin)
             if (!ins.empty) {
                 ins.seq++;
-                if (w_distance(ins, diag) >= c.min_distance) { ww_update(c, WK_INS, score, diag, ins); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
+                if (w_distance(ins, diag) >= c.min_distance) { put_ins = true; if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
             }
             WPos del;
             { const WPos open = ww_find_probed(c, p_do, WK_MATCH, src_open, anc, leaf, diag + 1, false, true), ext = ww_find_probed(c, p_de, WK_DEL, src_extend, anc, leaf, diag + 1, false, true);
               del = w_less(open, ext) ? ext : open; }
             if (!del.empty) {
                 ww_successor_offset(c, del);
-                if (w_distance(del, diag) >= c.min_distance) { ww_update(c, WK_DEL, score, diag, del); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
+                if (w_distance(del, diag) >= c.min_distance) { put_del = true; if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
                 if (ww_wants_expansion(c, del)) want = del.cur;
             }
             WPos subst = ww_find_probed(c, p_s, WK_MATCH, src_mismatch, anc, leaf, diag, true, true);
@@ -697,8 +733,13 @@ template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t
                     ww_candidate(c, score + (gap_length ? ww_gap_penalty(c, gap_length) : 0), diag, subst.seq, subst.off, subst.cur, leaf);
                     have_cand = c.cand_score != before;
                 }
-                if (w_distance(subst, diag) >= c.min_distance) { ww_update(c, WK_MATCH, score, diag, subst); if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
+                if (w_distance(subst, diag) >= c.min_distance) { put_match = true; if (diag < alo) alo = diag; if (diag > ahi) ahi = diag; }
             }
+            WW_FINE(1)
+            const WwPut s_ins = ww_put_begin(c, put_ins, ins.cur, WK_INS, score, diag, ins.seq, ins.off), s_del = ww_put_begin(c, put_del, del.cur, WK_DEL, score, diag, del.seq, del.off),
+                        s_match = ww_put_begin(c, put_match, subst.cur, WK_MATCH, score, diag, subst.seq, subst.off);
+            ww_put_end(c, s_ins); ww_put_end(c, s_del); ww_put_end(c, s_match);
+            WW_FINE(2)
         }
         if (ww_any_overflow(c)) return;
         // the expansions this chunk asked for, in key order (= lane order); a node is expanded for the first item that asks
@@ -716,6 +757,7 @@ template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t
         diag0 += (int32_t)n_diag;
         // (a lane holds at most one candidate per chunk, and chunks come in key order: merge chunk by chunk)
         ww_merge_candidates(c, best_score, best_diag, best_seq, best_off, best_node, lo);
+        WW_FINE(3)
     }
     const int32_t rlo = -c.xl->reduce_max(-alo), rhi = c.xl->reduce_max(ahi);
     if (c.lane == 0 && (c.sh->ps_flags[score] & 1)) c.sh->ps_range[score] = ((uint32_t)rlo & 0xffffu) | ((uint32_t)rhi << 16);
@@ -815,6 +857,9 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
     // no position gets further into a trie node than the sequence plus the deletions the score cap pays for (+ where the root starts)
     c.grow_cap = c.L + (uint32_t)(pb.score_bound / B.gap_extend) + 2u;
     c.cand_score = 0x7fffffff; c.cand_diag = 0; c.cand_seq = 0; c.cand_off = 0; c.cand_node = 0; c.cand_leaf = 0;
+#if VGK_WW_FINE_STATS
+    c.us_fine[0] = c.us_fine[1] = c.us_fine[2] = c.us_fine[3] = 0; c.t_fine = 0;
+#endif
     c.max_distance = 0; c.min_distance = 0; c.overflow = false; c.why = 0; c.n_chunks = 0; c.n_steps = 0; c.n_items = 0; c.us_extend = c.us_next = c.us_score = 0;
     const int32_t top_score = pb.score_bound + B.gap_open + B.gap_extend + B.mismatch;
     for (int32_t s = (int32_t)lane; s <= top_score && s < W_SCORES; s += 64) sh.ps_flags[s] = 0;
@@ -1076,7 +1121,11 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
             uint32_t* st = P.stats + WW_STAT_WORDS * (size_t)i;
             st[0] = sh.n_points; st[1] = c.n_steps; st[2] = c.n_chunks; st[3] = sh.n_nodes | (c.n_items << 8);      // (items: those the filter let through; 0 when every item is looked at)
             st[4] = c.us_extend; st[5] = c.us_next; st[6] = c.us_score; st[7] = xl.clock_us() - t_loop_end;
-            st[8] = t_after[0]; st[9] = t_after[1]; st[10] = t_after[2]; st[11] = t_first;                           // after the loop: backtrace, the path's originals, room + output; before the loop
+#if VGK_WW_FINE_STATS
+            st[8] = c.us_fine[0]; st[9] = c.us_fine[1]; st[10] = c.us_fine[2]; st[11] = c.us_fine[3];
+#else
+            st[8] = t_after[0]; st[9] = t_after[1]; st[10] = t_after[2]; st[11] = t_first;
+#endif                           // after the loop: backtrace, the path's originals, room + output; before the loop
         }
     }
     retry = xl.bcast(retry ? 1u : 0u, 0) != 0u;
