@@ -90,12 +90,15 @@ struct WwParams {
 #define VGK_WW_FINE_STATS 0
 #endif
 constexpr int WW_LARGE_PATH_LDS = 64;
+constexpr int32_t WW_NO_MASKS = 0x7fffffff;
 constexpr int WW_MASK_ROWS = 32;      // penalties whose node masks are kept at a time (a ring): more than any source wavefront lies back
 
 template <bool SMALL> struct WwTables {                                       // the large size: its tables are a slab in HBM; in LDS only ...
     uint32_t sv[64];                  // ... a chunk in the making: per diagonal looked at, the leaves that have something to do there
     uint32_t src_mask[64][5];         // ... next(): per diagonal looked at, the node sets of its five source cells (an item probes only the cells that can answer)
     uint32_t filter_off;              // ... and whether some diagonal has left the masks' width (then every item is looked at again, as in the small size)
+    int32_t  masks_from;              // ... and the first penalty whose sets are kept: the one after the trie's first expansion (WW_NO_MASKS until then — a trie of one node
+                                      //     is never filtered, and most links that outgrow the small tables keep theirs to the end: their sets were 40 % of the kernel's writes)
     WwPath   path_first[WW_LARGE_PATH_LDS];   // ... and the first entries of the path pool (a link that outgrew the small tables did so by its points: its trie is a node or
                                       //     two, and every item of every chunk reads its entry — from the slab that was a trip to HBM each)
 };
@@ -231,7 +234,7 @@ template <class XL, bool SMALL> VGK_HD WwPut ww_put_begin(WwCtx<XL, SMALL>& c, b
     WwPut p; p.on = on; p.i = 0; p.key = 0; p.v = 0; p.old = 0;
     if (!on) return p;
     if constexpr (!SMALL) {
-        if (c.masks) {
+        if (c.masks && score >= c.sh->masks_from) {
             uint32_t* w = c.mask_word(kind, score, diag);
             if (w) c.xl->or32(w, 1u << node); else c.sh->filter_off = 1u;       // (read by everyone after the phase's fence)
         }
@@ -519,17 +522,26 @@ template <class XL, bool SMALL> VGK_HD uint32_t ww_mask_at(WwCtx<XL, SMALL>& c, 
         return w ? c.xl->load32(w) : 0xffffffffu;
     }
 }
-// is the filter on for the coming chunk?  (the same answer on every lane: filter_off changes only between fences)
-template <class XL, bool SMALL> VGK_HD bool ww_filtering(WwCtx<XL, SMALL>& c) {
+// is the filter on for the coming chunk?  `need` = the oldest penalty whose sets the chunk reads (the same answer on every lane: filter_off and masks_from
+// change only between fences)
+template <class XL, bool SMALL> VGK_HD bool ww_filtering(WwCtx<XL, SMALL>& c, int32_t need) {
     if constexpr (SMALL) return false;
-    else { if (!c.masks) return false; c.xl->fence_lds(); return c.sh->filter_off == 0u; }
+    else { if (!c.masks) return false; c.xl->fence_lds(); return c.sh->filter_off == 0u && need >= c.sh->masks_from; }
 }
 template <class XL, bool SMALL> VGK_HD void ww_clear_masks(WwCtx<XL, SMALL>& c, int32_t score) {       // a penalty's sets, before its first point is stored
     if constexpr (!SMALL) {
-        if (!c.masks) return;
+        if (!c.masks || score < c.sh->masks_from) return;
         uint32_t* row = c.masks + (size_t)((uint32_t)score % (uint32_t)WW_MASK_ROWS) * 3u * c.mask_width;
         for (uint32_t j = c.lane; j < 3u * c.mask_width; j += 64u) row[j] = 0u;
         c.xl->fence();
+    }
+}
+// the trie has grown beyond its root during the phase of penalty `score`: the sets are kept from the next penalty on (this one's points are partly stored already)
+template <class XL, bool SMALL> VGK_HD void ww_masks_begin(WwCtx<XL, SMALL>& c, int32_t score) {
+    if constexpr (!SMALL) {
+        if (!c.masks) return;
+        if (c.sh->masks_from == WW_NO_MASKS && c.sh->n_nodes > 1u) c.sh->masks_from = score + 1;      // (every lane the same value)
+        c.xl->fence_lds();
     }
 }
 
@@ -624,7 +636,7 @@ template <class XL, bool SMALL> VGK_HD void ww_extend(WwCtx<XL, SMALL>& c, int32
         WwItem it; it.st = WX_DONE; it.qh = it.qt = 0; it.sp = 0; it.key_leaf = 0; it.blocked_on = 0; it.creator = false; it.pos = w_none();
         int32_t diag = diag0;
         bool have = false; uint32_t top = 0;
-        if (n_leaves > 1u && ww_filtering(c)) {                                 // (a trie of one leaf has an item on every diagonal: nothing to pack, and the sets' loads and the packing cost a chunk more than its lookups)
+        if (n_leaves > 1u && ww_filtering(c, score)) {                          // (a trie of one leaf has an item on every diagonal: nothing to pack, and the sets' loads and the packing cost a chunk more than its lookups)
             if constexpr (!SMALL) n_diag = ww_chunk_of(c, diag0, ps.max_d, ww_mask_at(c, WK_MATCH, here, diag0 + (int32_t)c.lane), diag, top, have);
         } else {
             const uint32_t fit = 64u / n_leaves, left = (uint32_t)(ps.max_d - diag0 + 1);
@@ -644,6 +656,7 @@ template <class XL, bool SMALL> VGK_HD void ww_extend(WwCtx<XL, SMALL>& c, int32
             const uint32_t node = c.xl->bcast(it.blocked_on, who);
             const bool made = ww_expand_wave(c, node, who);
             c.xl->fence();
+            ww_masks_begin(c, score);
             if (ww_any_overflow(c)) return;                                    // (a trie that ran out of nodes is half made: nobody may look at it)
             if (it.st == WX_BLOCKED && it.blocked_on == node) { it.st = WX_AFTER; it.creator = made; }
         }
@@ -677,7 +690,7 @@ template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t
 #define WW_FINE(k)
 #endif
         int32_t diag = diag0; uint32_t leaf = 0; bool have_cand = false, have = false, filtered = false;
-        if (n_leaves > 1u && ww_filtering(c)) {                                 // (a trie of one leaf has an item on every diagonal: nothing to pack, and the sets' loads and the packing cost a chunk more than its lookups)
+        if (n_leaves > 1u && ww_filtering(c, score - (B.mismatch > B.gap_open + B.gap_extend ? B.mismatch : B.gap_open + B.gap_extend))) {      // (one leaf: an item on every diagonal, nothing to pack)
             if constexpr (!SMALL) {
                 const int32_t d = diag0 + (int32_t)c.lane;
                 uint32_t mk[5] = {0u, 0u, 0u, 0u, 0u};
@@ -749,6 +762,7 @@ template <class XL, bool SMALL> VGK_HD void ww_next(WwCtx<XL, SMALL>& c, int32_t
             const int32_t at = (int32_t)c.xl->bcast((uint32_t)diag, who);
             if (ww_expand_wave(c, node, who)) c.sh->expanded_at[node] = at;
             c.xl->fence();
+            ww_masks_begin(c, score);
             if (ww_any_overflow(c)) return;
         }
         // A candidate of an item whose leaf was expanded by an item of an EARLIER diagonal of this chunk: sequentially that diagonal's
@@ -839,7 +853,7 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
         // the item filter needs every source wavefront of a step inside the ring of penalties it keeps
         const bool ring_holds = B.mismatch < WW_MASK_ROWS && B.gap_open + B.gap_extend < WW_MASK_ROWS && B.gap_extend > 0;
         c.masks = P.node_masks && ring_holds ? P.node_masks + (size_t)slab * WW_MASK_ROWS * 3u * P.mask_width : nullptr; c.mask_width = P.mask_width;
-        if (lane == 0) sh.filter_off = 0u;
+        if (lane == 0) { sh.filter_off = 0u; sh.masks_from = WW_NO_MASKS; }
     }
     c.seq = B.seqs + pb.seq_off; c.L = pb.seq_len;
     c.no_to = pb.to_node == VGK_WFA_NO_NODE; c.to_node = (int32_t)pb.to_node; c.to_off = pb.to_off;
@@ -864,7 +878,6 @@ template <class XL, bool SMALL> VGK_HD bool wfa_wave_problem(const WwParams& P, 
     const int32_t top_score = pb.score_bound + B.gap_open + B.gap_extend + B.mismatch;
     for (int32_t s = (int32_t)lane; s <= top_score && s < W_SCORES; s += 64) sh.ps_flags[s] = 0;
     if (lane < (uint32_t)W_NODES) sh.expanded_at[lane] = 0;
-    ww_clear_masks(c, 0);
     if (lane == 0) {
         sh.n_nodes = 0; sh.n_path = 0; sh.n_points = 0; sh.leaves = 0;
         const uint32_t root_rec = P.index.rec_off[from_walked];
