@@ -380,7 +380,7 @@ public:
                 for (uint32_t l = 0; l < 64; ++l) {
                     if ((t & 3u) == 0) lane_prefetch(lanes[l], P, t);
                     const uint32_t rh = l ? oh[l - 1] : 0, rf = l ? of[l - 1] : 0, ri = l ? oi[l - 1] : 0;
-                    if (P.spec_fill == 1) { lane_step<K, S8, false>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr); continue; }      // the speculative batch's first fill: no codes
+                    if (P.spec_fill == 1) { if (S8 && P.key3) lane_step<K, S8, false, true>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr); else lane_step<K, S8, false>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr); continue; }      // the speculative batch's first fill: no codes
                     if (P.tb_mode == TB_REWALK) {
                         lane_step<K, S8, false>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr);
                         if (P.want_tb) { lane_store_boundary<K>(lanes[l], P, wd, t, l); lane_store_checkpoint<K>(lanes[l], P, wd, t, l); }

@@ -134,10 +134,10 @@ def test_two_pass_walk_matches_oracle_and_the_one_pass_walk(emu_lib, monkeypatch
 
 # The speculative fill (GsswParams::spec_fill): a batch of one geometry fills every read WITHOUT traceback codes, settles the alignments that
 # are one diagonal run from their end cells, lays the rest out as wavefronts of their own, fills those again with codes and walks them.
-def speculative_fill_equals_the_plain_one(lib, n, monkeypatch):
+def speculative_fill_equals_the_plain_one(lib, n, monkeypatch, match=1):
     from vg_amd import workloads
     wl = workloads.LinearWorkload(n, seed=43, sub_rate=0.02, indel_rate=0.004)      # uniform reads: one bucket; a third of them with an indel
-    sc = capi.Scoring.simple(1, 4, 6, 1, 5)
+    sc = capi.Scoring.simple(match, 4, 6, 1, 5)
     ro, oo = capi.Engine(sc, lib=ORACLE_LIB).align(wl, 0)
     eng = capi.Engine(sc, lib=lib)
     ra, oa = eng.align(wl, 0)                                                        # packed on the host (vgk_gssw_pack)
@@ -157,6 +157,14 @@ def speculative_fill_equals_the_plain_one(lib, n, monkeypatch):
 
 def test_speculative_fill_matches_oracle(emu_lib, monkeypatch):
     assert speculative_fill_equals_the_plain_one(emu_lib, 1200, monkeypatch) > 1100
+
+
+# The first fill's column key maximum (gssw_device.hpp, K3; GsswParams::key3): one v_pk_maximum3_f16 per two rows while every key of the batch stays below
+# 0x7c00, i.e. scores up to 990.  A match worth 6 takes 150-base reads to 910 (keys up to 0x71c0: the top of the range, three-input maximum taken); a match
+# worth 7 to 1 060: the packers must leave it off, and the batch still speculates.
+@pytest.mark.parametrize("match", [6, 7])
+def test_speculative_fill_with_scores_at_the_key_maximums_limit(emu_lib, monkeypatch, match):
+    assert speculative_fill_equals_the_plain_one(emu_lib, 1100, monkeypatch, match=match) > 1000
 
 
 # The corners of the speculation: a batch in which NO read misses (the second fill covers nothing), one in which nearly every read does (the

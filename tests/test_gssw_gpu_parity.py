@@ -111,6 +111,14 @@ def test_hip_matches_oracle_in_every_lane_geometry():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("match", [6, 7])
+def test_hip_speculative_fill_with_scores_at_the_key_maximums_limit(monkeypatch, match):
+    # (v_pk_maximum3_f16 on keys up to 0x71c0 with a match worth 6; with 7 the keys would pass 0x7c00 and the packers leave the three-input maximum off)
+    from test_gssw_emu_parity import speculative_fill_equals_the_plain_one
+    assert speculative_fill_equals_the_plain_one(ENGINE_LIB, 8000, monkeypatch, match=match) > 7500
+
+
+@pytest.mark.gpu
 def test_hip_two_kernel_traceback_and_speculative_fill_match_oracle(monkeypatch):
     """batches of local alignments: the tracebacks as two kernels (diagonal runs settled from the end cells; the rest by their codes) and, for
     batches of one geometry, the fill without codes first and the missed reads filled again — equal to the oracle, host- and device-packed"""

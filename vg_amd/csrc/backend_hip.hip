@@ -59,7 +59,7 @@ struct TbStage {
 };
 
 // CODES = false: the recurrence alone and nothing of a traceback (GsswParams::spec_fill's first fill)
-template <int K, bool S8, bool REWALK, bool CODES = true>
+template <int K, bool S8, bool REWALK, bool CODES = true, bool KEY3 = false>
 __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const GsswParams P) {
     constexpr uint32_t REC = (K + 3) / 4;   // dwords per (step, lane) traceback record
     __shared__ __attribute__((aligned(16))) uint32_t stage_lds[4][REWALK ? 64u * TB_BND_CHUNK * 2u : (TB_TILE > 1 ? TbStage<K>::DWORDS : 256u)];      // (also the fused walk's best keys, below)
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
         const uint32_t rf = from_lane_above(s.out_f);
         const uint32_t ri = from_lane_above(s.info);
         if constexpr (!CODES) {
-            lane_step<K, S8, false>(s, P, t, rh, rf, ri, nullptr, nullptr);
+            lane_step<K, S8, false, KEY3>(s, P, t, rh, rf, ri, nullptr, nullptr);
         } else if constexpr (REWALK) {
             // the recurrence alone; what the traceback needs to run a window of it again (gssw_device.hpp, TB_REWALK)
             lane_step<K, S8, false>(s, P, t, rh, rf, ri, nullptr, nullptr);
@@ -1226,7 +1226,8 @@ public:
         const dim3 grid((p.wave_count + 3) / 4), block(256);
         const bool s8 = p.scale == 8, re = p.tb_mode == TB_REWALK;
         if (p.spec_fill == 1) {                                      // the first fill of a speculative batch: no codes
-            if (s8) hipLaunchKernelGGL((gssw_fill_kernel<K, true, false, false>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<K, false, false, false>), grid, block, 0, stream, p);
+            if (s8 && p.key3) hipLaunchKernelGGL((gssw_fill_kernel<K, true, false, false, true>), grid, block, 0, stream, p);
+            else if (s8) hipLaunchKernelGGL((gssw_fill_kernel<K, true, false, false>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<K, false, false, false>), grid, block, 0, stream, p);
             return VGK_OK;
         }
         if (re) { if (s8) hipLaunchKernelGGL((gssw_fill_kernel<K, true, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<K, false, true>), grid, block, 0, stream, p); }

@@ -120,6 +120,7 @@ struct GsswParams {
     // WITH codes, and walked by them.  refill_wave0 / refill_pair0: where those wavefronts and their pairs start in waves[] / order[];
     // refill_slot: traceback dwords per such wavefront (sized for the batch's widest window); refill_count[0]: how many there are (device).
     int32_t  spec_fill;
+    uint32_t key3;              // the speculative first fill may take the column key maximum with v_pk_maximum3_f16 (gssw_key3_ok: every key of the batch below 0x7c00)
     int32_t  restore_probs;     // this run does not speculate, an earlier run of the same batch did: the displaced reads' descriptors go back first (refill_restore_one)
     uint32_t refill_wave0, refill_pair0, refill_G, refill_K;
     unsigned long long refill_slot;
@@ -366,14 +367,22 @@ VGK_HD uint64_t tb_dword(uint64_t tb_off, uint32_t t, uint32_t lane, uint32_t re
 #ifndef VGK_H_MAX3
 #define VGK_H_MAX3 1
 #endif
+//   K3 (a template flag, not a build switch; GsswParams::key3): the speculative first fill's column key maximum over row PAIRS — one v_pk_maximum3_f16 per two
+//                  rows instead of two v_pk_max_u16 — when every key of the batch stays below 0x7c00 (scores up to 990, no X-drop offset; the packers decide):
+//                  hot block 243 -> 228 instructions, first fill 12.80 -> 12.39 ms per million reads (profiles/r06/ab_key3)
 
+// Whether every end-cell key of a batch stays below 0x7c00, where v_pk_maximum3_f16 on the bit patterns is the unsigned maximum (pk16.hpp): the x8 scale, plain
+// scoring, no problem in the X-drop mode (its scores carry an offset of 1023), and the longest read's best possible score at most 990 (990 * 32 + 31 < 0x7c00).
+VGK_HD bool gssw_key3_ok(uint32_t scale, bool quality_adjusted, bool any_xdrop, uint32_t longest_read, uint32_t max_score, uint32_t max_bonus) {
+    return scale == 8u && !quality_adjusted && !any_xdrop && (uint64_t)longest_read * max_score + 2ull * max_bonus <= 990ull;
+}
 // best-cell key of a row: score*32 + (31 - row_in_lane), so one packed max keeps
 // the best score and, on ties, the smallest row (scores stay below 2047).
 constexpr uint32_t KEY_SHIFT = 5, KEY_LOW = 31;
 
 // One row (compile-time index M) of one lane for one column.  REFN = some half sees
 // an N in the graph (rare): the profile permute cannot express score 0, patch it.
-template <int K, int M, bool REFN, bool S8, bool TB>
+template <int K, int M, bool REFN, bool S8, bool TB, bool K3>
 VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, uint32_t go2, uint32_t ge2,
                      bool nA, bool nB, uint32_t& f, uint32_t& d, uint32_t* acc, uint32_t& ck) {
     uint32_t sb = byte_perm(s.pb(M), s.PA[M], sel);
@@ -393,7 +402,11 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
         const uint32_t gg = pk_subs(h, go2);
         const uint32_t en = pk_max(gg, pk_subs(e, ge2)), fn = pk_max(gg, pk_subs(f, ge2));
         const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(h, 0x00010001u << (S8 ? KEY_SHIFT - 3 : KEY_SHIFT));
-        ck = M == 0 ? key : pk_max(ck, key);
+        if constexpr (S8 && K3) {
+            // (acc[] is free in this build and carries the even row's key to the odd one)
+            if constexpr ((M & 1) == 0) { if constexpr (M + 1 < K) acc[0] = key; else ck = M == 0 ? key : pk_max(ck, key); }
+            else ck = M == 1 ? pk_max(acc[0], key) : pk_max3_f16(ck, acc[0], key);
+        } else ck = M == 0 ? key : pk_max(ck, key);
         s.H[M] = h; s.E[M] = en; f = fn; d = old;
         return;
     }
@@ -443,15 +456,15 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
     s.H[M] = h; s.E[M] = en; f = fn; d = old;
 }
 
-template <int K, int M, bool REFN, bool S8, bool TB>
+template <int K, int M, bool REFN, bool S8, bool TB, bool K3>
 VGK_HD void lane_rows_from(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, uint32_t go2, uint32_t ge2,
                            bool nA, bool nB, uint32_t& f, uint32_t& d, uint32_t* acc, uint32_t& ck) {
-    lane_row<K, M, REFN, S8, TB>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
-    if constexpr (M + 1 < K) lane_rows_from<K, M + 1, REFN, S8, TB>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+    lane_row<K, M, REFN, S8, TB, K3>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+    if constexpr (M + 1 < K) lane_rows_from<K, M + 1, REFN, S8, TB, K3>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
 }
 
 // The K rows of one lane for one column; returns the K/4 traceback dwords and the column key maximum.
-template <int K, bool REFN, bool S8, bool TB>
+template <int K, bool REFN, bool S8, bool TB, bool K3>
 VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t diag0, uint32_t rf,
                       bool nA, bool nB, uint32_t* acc, uint32_t& colkey) {
     uint32_t bias2 = rep2(P.bias), go2 = rep2(P.go), ge2 = rep2(P.ge);
@@ -462,7 +475,7 @@ VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t di
     if (REFN) asm volatile("" : "+v"(sel), "+v"(bias2), "+v"(go2), "+v"(ge2));
 #endif
     uint32_t f = rf, d = diag0, ck = 0;
-    lane_rows_from<K, 0, REFN, S8, TB>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+    lane_rows_from<K, 0, REFN, S8, TB, K3>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
     s.out_h = s.H[K - 1]; s.out_f = f;
     colkey = ck;
 }
@@ -471,7 +484,7 @@ VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t di
 // tb_a / tb_b = where the ceil(K/4)-dword traceback record goes — its first four dwords and the rest (the two parts of the tiled
 // layout; in the step-major form tb_b = tb_a + 4) —, or nullptr.  TB = build the codes; RE = the traceback's recomputation of a
 // window (no end-cell tracking, no scratch stores: the fill has done both).
-template <int K, bool S8, bool TB, bool RE>
+template <int K, bool S8, bool TB, bool RE, bool K3 = false>
 VGK_HD void lane_column(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tb_a, uint32_t* tb_b) {
     s.info = rinfo;
     const uint32_t ia = rinfo & 0xffu, ib = (rinfo >> 16) & 0xffu;
@@ -486,8 +499,8 @@ VGK_HD void lane_column(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh
         const uint32_t sel = (rinfo & 0x00030003u) | 0x0c040c00u;
         const bool nA = vA && (ia & CI_BASE_MASK) == 4, nB = vB && (ib & CI_BASE_MASK) == 4;
         uint32_t acc[(K + 3) / 4], colkey;
-        if (nA || nB) lane_rows<K, true, S8, TB>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
-        else          lane_rows<K, false, S8, TB>(s, P, sel, diag0, rf, false, false, acc, colkey);
+        if (nA || nB) lane_rows<K, true, S8, TB, K3>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
+        else          lane_rows<K, false, S8, TB, K3>(s, P, sel, diag0, rf, false, false, acc, colkey);
         if constexpr (TB) {
             if (tb_a) {
                 if (TB_TILE > 1 && !RE) {                                          // part A is a 16-byte slot: one store
@@ -518,10 +531,10 @@ VGK_HD void lane_column(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh
 
 // One step of one lane of the fill.  rh/rf/rinfo are lane-1's out_h/out_f/info from the
 // previous step (ignored by group leaders, which start a fresh column).
-template <int K, bool S8, bool TB = true>
+template <int K, bool S8, bool TB = true, bool K3 = false>
 VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tb_a, uint32_t* tb_b) {
     if (s.g == 0) { rh = 0; rf = 0; rinfo = fetch_info(s, P, t); }
-    lane_column<K, S8, TB, false>(s, P, t, rh, rf, rinfo, tb_a, tb_b);
+    lane_column<K, S8, TB, false, K3>(s, P, t, rh, rf, rinfo, tb_a, tb_b);
 }
 
 // after the last step: publish this lane's best cell (LOCAL mode)

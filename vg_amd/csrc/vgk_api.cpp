@@ -478,6 +478,12 @@ int vgk_gssw_pack(vgk_ctx* ctx, const vgk_gssw_problem* problems, uint32_t n, ui
     P.dbg = std::getenv("VGAMD_TB_DBG") ? std::atoi(std::getenv("VGAMD_TB_DBG")) : 0; P.tb_mode = default_tb_mode(P.fused, !all.far);
     P.walk_passes = walk2 && !P.fused ? 2 : 1;                          // (local alignments with a traceback: what walk_diag_one serves)
     if (P.walk_passes != 2 || P.tb_mode != TB_CODES) P.spec_fill = 0;
+    P.key3 = 0;
+    if (P.spec_fill) {                                                  // the first fill's column key maximum by v_pk_maximum3_f16 (gssw_device.hpp, K3)
+        uint32_t longest = 0; bool xdrop = false;
+        for (uint32_t i = 0; i < n; ++i) { longest = std::max(longest, probs[i].L); xdrop = xdrop || (problems[i].flags & 15u) == (uint32_t)VGK_XDROP_PINNED; }
+        P.key3 = gssw_key3_ok(S, ctx->has_qa, xdrop, longest, (uint32_t)std::max(0, ctx->max_score), (uint32_t)std::max(0, ctx->max_bonus)) && !std::getenv("VGAMD_NO_KEY3") ? 1u : 0u;
+    }
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = ops_total;
     if ((rc = ctx->be->sync_side())) return fail(rc);     // inputs are resident in HBM when pack returns (the uploads have their own stream)

@@ -316,6 +316,12 @@ int vgk_pack_windows_impl(vgk_ctx* ctx, const vgk_dgraph* dg, const char* reads,
     P.fused = 0; P.dbg = std::getenv("VGAMD_TB_DBG") ? std::atoi(std::getenv("VGAMD_TB_DBG")) : 0; P.tb_mode = default_tb_mode(0, near_chain);
     P.walk_passes = walk2 ? 2 : 1;                                    // (windows that were made on the device are tails: X-drop)
     if (P.walk_passes != 2 || P.tb_mode != TB_CODES) P.spec_fill = 0;
+    P.key3 = 0;
+    if (P.spec_fill) {                                                  // (speculation only with the problems at hand on the host: walk2)
+        uint32_t longest = 0; bool xdrop = false;
+        for (uint32_t i = 0; i < n; ++i) { longest = std::max(longest, problems[i].read_len); xdrop = xdrop || (problems[i].flags & 15u) == (uint32_t)VGK_XDROP_PINNED; }
+        P.key3 = gssw_key3_ok(S, ctx->has_qa, xdrop, longest, (uint32_t)std::max(0, ctx->max_score), (uint32_t)std::max(0, ctx->max_bonus)) && !std::getenv("VGAMD_NO_KEY3") ? 1u : 0u;
+    }
     std::memcpy(P.matrix, ctx->sc.matrix, 25);
     b->ops_total = T.tot[WS_OPS]; b->wave_steps = T.wave_steps;
     lap("done");
