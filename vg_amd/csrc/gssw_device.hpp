@@ -382,21 +382,30 @@ constexpr uint32_t KEY_SHIFT = 5, KEY_LOW = 31;
 
 // One row (compile-time index M) of one lane for one column.  REFN = some half sees
 // an N in the graph (rare): the profile permute cannot express score 0, patch it.
-template <int K, int M, bool REFN, bool S8, bool TB, bool K3>
-VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, uint32_t go2, uint32_t ge2,
-                     bool nA, bool nB, uint32_t& f, uint32_t& d, uint32_t* acc, uint32_t& ck) {
+// max(0, diagonal + s) of row M, d = H of the row above in the previous column (the sum stays far below 2^16 per half).  With the tagged
+// candidates of the x8 traceback build the constant absorbs the diagonal's tag.
+template <int K, int M, bool REFN, bool S8, bool TB>
+VGK_HD uint32_t row_diag(const Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, bool nA, bool nB, uint32_t d) {
     uint32_t sb = byte_perm(s.pb(M), s.PA[M], sel);
     if (REFN) {
         const uint32_t row = s.g * K + M;
         if (nA) sb = set_lo(sb, row < s.LA ? P.bias + row_bonus(s.bsA, s.beA, row, s.LA) : 0u);
         if (nB) sb = set_hi(sb, row < s.LB ? P.bias + row_bonus(s.bsB, s.beB, row, s.LB) : 0u);
     }
-    const uint32_t old = s.H[M];
+    return pk_subs(pk_add_nc(d, sb), (TB && S8) ? bias2 - 0x00040004u : bias2);
+}
+// `d` comes in as THIS row's diagonal candidate (row_diag) and leaves as the next row's, made from this row's old H before the new one is
+// written: the old value's last use then precedes the new value's definition, H[M] is updated in its register, and the step loop carries no
+// copy per row (the rotation "new H[M] lives where old H[M - 1] did" cost K - 1 v_mov_b32 per step: 18 of ~290 VALU instructions).
+template <int K, int M, bool REFN, bool S8, bool TB, bool K3>
+VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, uint32_t go2, uint32_t ge2,
+                     bool nA, bool nB, uint32_t& f, uint32_t& d, uint32_t* acc, uint32_t& ck) {
+    const uint32_t t4 = d;
+    if constexpr (M + 1 < K) d = row_diag<K, M + 1, REFN, S8, TB>(s, P, sel, bias2, nA, nB, s.H[M]);
     if constexpr (!TB) {
         // The recurrence alone (TB_REWALK fills): no tags, no codes.  Its H / E / F are the tagged build's with the three tag bits
         // stripped — the tags are below the x8 scale's resolution and every constant that absorbs one is a multiple of 8 away from the
         // clean one — so a traceback that runs the tagged code again from this fill's boundary values reproduces the codes bit for bit.
-        const uint32_t t4 = pk_subs(pk_add_nc(d, sb), bias2);
         const uint32_t e = s.E[M];
         const uint32_t h = (S8 && VGK_H_MAX3) ? pk_max3_f16(t4, e, f) : pk_max(pk_max(t4, e), f);
         const uint32_t gg = pk_subs(h, go2);
@@ -407,7 +416,7 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
             if constexpr ((M & 1) == 0) { if constexpr (M + 1 < K) acc[0] = key; else ck = M == 0 ? key : pk_max(ck, key); }
             else ck = M == 1 ? pk_max(acc[0], key) : pk_max3_f16(ck, acc[0], key);
         } else ck = M == 0 ? key : pk_max(ck, key);
-        s.H[M] = h; s.E[M] = en; f = fn; d = old;
+        s.H[M] = h; s.E[M] = en; f = fn;
         return;
     }
     if constexpr (S8) {
@@ -417,7 +426,6 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
         // candidates 1 (opened from H) > 0 (extended) — ties go to the open.  The constants absorb the tags (t - (bias - 4) etc.);
         // E and F inputs are normalised by an OR before they are extended; H is stored clean (it feeds the diagonal sum, the
         // end-cell key and the next gap open).  A saturated 0 has no tag: cells worth 0 are never walked.
-        const uint32_t t4 = pk_subs(pk_add_nc(d, sb), bias2 - 0x00040004u);
         const uint32_t ei = s.E[M] | 0x00030003u;
         const uint32_t h = VGK_H_MAX3 ? pk_max3_f16(t4, ei, f) : pk_max(pk_max(t4, ei), f);
         const uint32_t hc = h & 0xfff8fff8u;
@@ -430,10 +438,9 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
         acc[M >> 2] = (M & 3) == 0 ? code : (VGK_ACC_SHLOR ? shl_or<4>(acc[M >> 2], code) : pk_mul_add_imm<16>(acc[M >> 2], code));
         const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(hc, 0x00010001u << (KEY_SHIFT - 3));
         ck = M == 0 ? key : pk_max(ck, key);
-        s.H[M] = hc; s.E[M] = en; f = fn; d = old;
+        s.H[M] = hc; s.E[M] = en; f = fn;
         return;
     }
-    const uint32_t t4 = pk_subs(pk_add_nc(d, sb), bias2);  // max(0, diag + s); the sum stays far below 2^16 per half
     const uint32_t e = s.E[M];
     const uint32_t h = pk_max(pk_max(t4, e), f);
     const uint32_t gg = pk_subs(h, go2);                   // max(0, H - go)
@@ -453,7 +460,7 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
     acc[M >> 2] = (M & 3) == 0 ? code : pk_mul_add_imm<16>(acc[M >> 2], code);
     const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(h, 0x00010001u << KEY_SHIFT);
     ck = M == 0 ? key : pk_max(ck, key);
-    s.H[M] = h; s.E[M] = en; f = fn; d = old;
+    s.H[M] = h; s.E[M] = en; f = fn;
 }
 
 template <int K, int M, bool REFN, bool S8, bool TB, bool K3>
@@ -474,7 +481,7 @@ VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t di
     // (that hoisting cost 32 live VGPRs and spilled the hot loop).
     if (REFN) asm volatile("" : "+v"(sel), "+v"(bias2), "+v"(go2), "+v"(ge2));
 #endif
-    uint32_t f = rf, d = diag0, ck = 0;
+    uint32_t f = rf, d = row_diag<K, 0, REFN, S8, TB>(s, P, sel, bias2, nA, nB, diag0), ck = 0;
     lane_rows_from<K, 0, REFN, S8, TB, K3>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
     s.out_h = s.H[K - 1]; s.out_f = f;
     colkey = ck;
