@@ -59,7 +59,8 @@ struct TbStage {
 };
 
 // CODES = false: the recurrence alone and nothing of a traceback (GsswParams::spec_fill's first fill)
-template <int K, bool S8, bool REWALK, bool CODES = true, bool KEY3 = false>
+// NOKEY: the second fill of a speculative batch (spec_fill == 2) — codes only; the end cells are the first fill's, nothing is tracked or published
+template <int K, bool S8, bool REWALK, bool CODES = true, bool KEY3 = false, bool NOKEY = false>
 __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const GsswParams P) {
     constexpr uint32_t REC = (K + 3) / 4;   // dwords per (step, lane) traceback record
     __shared__ __attribute__((aligned(16))) uint32_t stage_lds[4][REWALK ? 64u * TB_BND_CHUNK * 2u : (TB_TILE > 1 ? TbStage<K>::DWORDS : 256u)];      // (also the fused walk's best keys, below)
@@ -106,11 +107,12 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
                 lane_store_checkpoint<K>(s, P, wd, t, lane);
             }
         } else if constexpr (TB_TILE > 1) {
-            lane_step<K, S8>(s, P, t, rh, rf, ri, tb ? stage.slot_a(t, lane) : nullptr, stage.slot_b(t, lane));
+            lane_step<K, S8, true, false, NOKEY>(s, P, t, rh, rf, ri, tb ? stage.slot_a(t, lane) : nullptr, stage.slot_b(t, lane));
             if (tb && ((t % TB_TILE) == TB_TILE - 1u || t + 1u == wd.n_steps)) stage.flush(tb + tb_tile_base(wd.tb_off, t, REC), lane);
         } else
-            lane_step<K, S8>(s, P, t, rh, rf, ri, tb ? tb + tb_dword(wd.tb_off, t, lane, REC, 0) : nullptr, tb ? tb + tb_dword(wd.tb_off, t, lane, REC, 4) : nullptr);
+            lane_step<K, S8, true, false, NOKEY>(s, P, t, rh, rf, ri, tb ? tb + tb_dword(wd.tb_off, t, lane, REC, 0) : nullptr, tb ? tb + tb_dword(wd.tb_off, t, lane, REC, 4) : nullptr);
     }
+    if constexpr (NOKEY) return;
     if (REWALK || !CODES || !P.fused) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -1230,6 +1232,7 @@ public:
             else if (s8) hipLaunchKernelGGL((gssw_fill_kernel<K, true, false, false>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<K, false, false, false>), grid, block, 0, stream, p);
             return VGK_OK;
         }
+        if (p.spec_fill == 2 && s8 && !re && !p.fused) { hipLaunchKernelGGL((gssw_fill_kernel<K, true, false, true, false, true>), grid, block, 0, stream, p); return VGK_OK; }      // (codes only: the end cells are the first fill's)
         if (re) { if (s8) hipLaunchKernelGGL((gssw_fill_kernel<K, true, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<K, false, true>), grid, block, 0, stream, p); }
         else    { if (s8) hipLaunchKernelGGL((gssw_fill_kernel<K, true, false>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gssw_fill_kernel<K, false, false>), grid, block, 0, stream, p); }
         return VGK_OK;

@@ -397,7 +397,7 @@ VGK_HD uint32_t row_diag(const Lane<K>& s, const GsswParams& P, uint32_t sel, ui
 // `d` comes in as THIS row's diagonal candidate (row_diag) and leaves as the next row's, made from this row's old H before the new one is
 // written: the old value's last use then precedes the new value's definition, H[M] is updated in its register, and the step loop carries no
 // copy per row (the rotation "new H[M] lives where old H[M - 1] did" cost K - 1 v_mov_b32 per step: 18 of ~290 VALU instructions).
-template <int K, int M, bool REFN, bool S8, bool TB, bool K3>
+template <int K, int M, bool REFN, bool S8, bool TB, bool K3, bool NK>
 VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, uint32_t go2, uint32_t ge2,
                      bool nA, bool nB, uint32_t& f, uint32_t& d, uint32_t* acc, uint32_t& ck) {
     const uint32_t t4 = d;
@@ -436,8 +436,10 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
         uint32_t code = bit_select<0x00010001u>(en, h) & 0x00070007u;
         code = shl_or<3>(fn & 0x00010001u, code);
         acc[M >> 2] = (M & 3) == 0 ? code : (VGK_ACC_SHLOR ? shl_or<4>(acc[M >> 2], code) : pk_mul_add_imm<16>(acc[M >> 2], code));
-        const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(hc, 0x00010001u << (KEY_SHIFT - 3));
-        ck = M == 0 ? key : pk_max(ck, key);
+        if constexpr (!NK) {                                                       // (NK: the second fill of a speculative batch — the end cells are the first fill's)
+            const uint32_t key = pk_mad_add_imm<(int)KEY_LOW - M>(hc, 0x00010001u << (KEY_SHIFT - 3));
+            ck = M == 0 ? key : pk_max(ck, key);
+        }
         s.H[M] = hc; s.E[M] = en; f = fn;
         return;
     }
@@ -463,15 +465,15 @@ VGK_HD void lane_row(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bia
     s.H[M] = h; s.E[M] = en; f = fn;
 }
 
-template <int K, int M, bool REFN, bool S8, bool TB, bool K3>
+template <int K, int M, bool REFN, bool S8, bool TB, bool K3, bool NK>
 VGK_HD void lane_rows_from(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t bias2, uint32_t go2, uint32_t ge2,
                            bool nA, bool nB, uint32_t& f, uint32_t& d, uint32_t* acc, uint32_t& ck) {
-    lane_row<K, M, REFN, S8, TB, K3>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
-    if constexpr (M + 1 < K) lane_rows_from<K, M + 1, REFN, S8, TB, K3>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+    lane_row<K, M, REFN, S8, TB, K3, NK>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+    if constexpr (M + 1 < K) lane_rows_from<K, M + 1, REFN, S8, TB, K3, NK>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
 }
 
 // The K rows of one lane for one column; returns the K/4 traceback dwords and the column key maximum.
-template <int K, bool REFN, bool S8, bool TB, bool K3>
+template <int K, bool REFN, bool S8, bool TB, bool K3, bool NK>
 VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t diag0, uint32_t rf,
                       bool nA, bool nB, uint32_t* acc, uint32_t& colkey) {
     uint32_t bias2 = rep2(P.bias), go2 = rep2(P.go), ge2 = rep2(P.ge);
@@ -482,7 +484,7 @@ VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t di
     if (REFN) asm volatile("" : "+v"(sel), "+v"(bias2), "+v"(go2), "+v"(ge2));
 #endif
     uint32_t f = rf, d = row_diag<K, 0, REFN, S8, TB>(s, P, sel, bias2, nA, nB, diag0), ck = 0;
-    lane_rows_from<K, 0, REFN, S8, TB, K3>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
+    lane_rows_from<K, 0, REFN, S8, TB, K3, NK>(s, P, sel, bias2, go2, ge2, nA, nB, f, d, acc, ck);
     s.out_h = s.H[K - 1]; s.out_f = f;
     colkey = ck;
 }
@@ -491,7 +493,7 @@ VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t di
 // tb_a / tb_b = where the ceil(K/4)-dword traceback record goes — its first four dwords and the rest (the two parts of the tiled
 // layout; in the step-major form tb_b = tb_a + 4) —, or nullptr.  TB = build the codes; RE = the traceback's recomputation of a
 // window (no end-cell tracking, no scratch stores: the fill has done both).
-template <int K, bool S8, bool TB, bool RE, bool K3 = false>
+template <int K, bool S8, bool TB, bool RE, bool K3 = false, bool NK = false>
 VGK_HD void lane_column(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tb_a, uint32_t* tb_b) {
     s.info = rinfo;
     const uint32_t ia = rinfo & 0xffu, ib = (rinfo >> 16) & 0xffu;
@@ -506,8 +508,8 @@ VGK_HD void lane_column(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh
         const uint32_t sel = (rinfo & 0x00030003u) | 0x0c040c00u;
         const bool nA = vA && (ia & CI_BASE_MASK) == 4, nB = vB && (ib & CI_BASE_MASK) == 4;
         uint32_t acc[(K + 3) / 4], colkey;
-        if (nA || nB) lane_rows<K, true, S8, TB, K3>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
-        else          lane_rows<K, false, S8, TB, K3>(s, P, sel, diag0, rf, false, false, acc, colkey);
+        if (nA || nB) lane_rows<K, true, S8, TB, K3, NK>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
+        else          lane_rows<K, false, S8, TB, K3, NK>(s, P, sel, diag0, rf, false, false, acc, colkey);
         if constexpr (TB) {
             if (tb_a) {
                 if (TB_TILE > 1 && !RE) {                                          // part A is a 16-byte slot: one store
@@ -522,11 +524,13 @@ VGK_HD void lane_column(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh
             }
         }
         if constexpr (!RE) {
+            if constexpr (!NK) {
             // local end cell: first column with the best score, smallest row (SSW end_ref/end_read rule)
             const uint32_t klo = colkey & 0xffffu, khi = colkey >> 16;
             const bool upA = vA & ((klo >> KEY_SHIFT) > (s.best_lo >> KEY_SHIFT)), upB = vB & ((khi >> KEY_SHIFT) > (s.best_hi >> KEY_SHIFT));   // selects, no branches
             s.best_lo = upA ? klo : s.best_lo; s.step_lo = upA ? t : s.step_lo;
             s.best_hi = upB ? khi : s.best_hi; s.step_hi = upB ? t : s.step_hi;
+            }
             if (vA && (ia & CI_STORE_END)) store_to_scratch<0, K>(s, P, s.probA, s.nodeA);
             if (vB && (ib & CI_STORE_END)) store_to_scratch<1, K>(s, P, s.probB, s.nodeB);
         }
@@ -538,10 +542,10 @@ VGK_HD void lane_column(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh
 
 // One step of one lane of the fill.  rh/rf/rinfo are lane-1's out_h/out_f/info from the
 // previous step (ignored by group leaders, which start a fresh column).
-template <int K, bool S8, bool TB = true, bool K3 = false>
+template <int K, bool S8, bool TB = true, bool K3 = false, bool NK = false>
 VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tb_a, uint32_t* tb_b) {
     if (s.g == 0) { rh = 0; rf = 0; rinfo = fetch_info(s, P, t); }
-    lane_column<K, S8, TB, false, K3>(s, P, t, rh, rf, rinfo, tb_a, tb_b);
+    lane_column<K, S8, TB, false, K3, NK>(s, P, t, rh, rf, rinfo, tb_a, tb_b);
 }
 
 // after the last step: publish this lane's best cell (LOCAL mode)
