@@ -207,6 +207,15 @@ struct Lane {
     uint32_t one;                   // 0x00010001 kept opaque to the optimiser (see lane_rows)
 };
 
+// The word is made good for its four steps when it is loaded — columns from R on read CI_INVALID (the stream goes on with another read's bytes) —, so that
+// a step takes its byte of both reads with ONE v_perm_b32 instead of two shifts, two compares against R and two selects (7 of ~270 VALU instructions per step).
+VGK_HD uint32_t ci_word(uint32_t w, uint32_t t, uint32_t R) {
+    const uint32_t none = CI_INVALID * 0x01010101u;
+    if (t + 4u <= R) return w;
+    if (t >= R) return none;
+    const uint32_t keep = (1u << (8u * (R - t))) - 1u;                          // (R - t = 1 .. 3 columns left)
+    return (w & keep) | (none & ~keep);
+}
 template <int K>
 VGK_HD void lane_init(Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint32_t lane_id) {
     const uint32_t q = lane_id / wd.G;
@@ -217,7 +226,7 @@ VGK_HD void lane_init(Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint3
     s.probA = live ? P.order[2 * pair] : 0xffffffffu;
     s.probB = live ? P.order[2 * pair + 1] : 0xffffffffu;
     s.LA = s.LB = 0; s.flagsA = s.flagsB = 0; s.RA = s.RB = 0; s.colA = s.colB = 0;
-    s.ciA = s.ciB = s.ciA_n = s.ciB_n = 0;
+    s.ciA = s.ciB = s.ciA_n = s.ciB_n = CI_INVALID * 0x01010101u;
     uint32_t roA = 0, roB = 0, poA = 0xffffffffu, poB = 0xffffffffu;
     s.bsA = s.beA = s.bsB = s.beB = 0;
     if (s.probA != 0xffffffffu) { const ProbDesc& d = P.probs[s.probA]; s.LA = d.L; s.flagsA = d.flags; roA = d.read_off; s.RA = d.R; s.colA = d.col_off;
@@ -225,8 +234,8 @@ VGK_HD void lane_init(Lane<K>& s, const GsswParams& P, const WaveDesc& wd, uint3
     if (s.probB != 0xffffffffu) { const ProbDesc& d = P.probs[s.probB]; s.LB = d.L; s.flagsB = d.flags; roB = d.read_off; s.RB = d.R; s.colB = d.col_off;
                                    s.bsB = d.bonus_start; s.beB = d.bonus_end; poB = d.prof_off; }
     if (s.g == 0) {   // streams are padded with 8 readable bytes, so these loads never run off the arena
-        if (s.probA != 0xffffffffu) s.ciA_n = *(const uint32_t*)(P.colinfo + s.colA);
-        if (s.probB != 0xffffffffu) s.ciB_n = *(const uint32_t*)(P.colinfo + s.colB);
+        if (s.probA != 0xffffffffu) s.ciA_n = ci_word(*(const uint32_t*)(P.colinfo + s.colA), 0, s.RA);
+        if (s.probB != 0xffffffffu) s.ciB_n = ci_word(*(const uint32_t*)(P.colinfo + s.colB), 0, s.RB);
     }
     const ProfWords pw = prof_words(P);
 #pragma unroll
@@ -250,18 +259,15 @@ template <int K>
 VGK_HD void lane_prefetch(Lane<K>& s, const GsswParams& P, uint32_t t) {
     if (s.g != 0) return;
     s.ciA = s.ciA_n; s.ciB = s.ciB_n;
-    if (t + 4 < s.RA) s.ciA_n = *(const uint32_t*)(P.colinfo + s.colA + t + 4);
-    if (t + 4 < s.RB) s.ciB_n = *(const uint32_t*)(P.colinfo + s.colB + t + 4);
+    s.ciA_n = t + 4 < s.RA ? ci_word(*(const uint32_t*)(P.colinfo + s.colA + t + 4), t + 4, s.RA) : CI_INVALID * 0x01010101u;
+    s.ciB_n = t + 4 < s.RB ? ci_word(*(const uint32_t*)(P.colinfo + s.colB + t + 4), t + 4, s.RB) : CI_INVALID * 0x01010101u;
 }
 
-// fresh column info for the group leader at step t: {infoB<<16 | infoA}
+// fresh column info for the group leader at step t: {infoB<<16 | infoA} — byte t & 3 of either word
 template <int K>
 VGK_HD uint32_t fetch_info(const Lane<K>& s, const GsswParams& P, uint32_t t) {
     (void)P;
-    const uint32_t sh = 8 * (t & 3u);
-    const uint32_t ia = t < s.RA ? (s.ciA >> sh) & 0xffu : (uint32_t)CI_INVALID;
-    const uint32_t ib = t < s.RB ? (s.ciB >> sh) & 0xffu : (uint32_t)CI_INVALID;
-    return ia | (ib << 16);
+    return byte_perm(s.ciB, s.ciA, 0x0c040c00u + (t & 3u) * 0x00010001u);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -506,9 +512,9 @@ VGK_HD void lane_column(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh
         if (vB && (ib & CI_SEED_SLOW)) seed_from_scratch<1, K>(s, P, s.probB, s.nodeB, diag0);
         // selector: byte0 <- PA[baseA], byte2 <- PB[baseB] (bytes 4..7 of the permute), bytes 1,3 <- 0
         const uint32_t sel = (rinfo & 0x00030003u) | 0x0c040c00u;
-        const bool nA = vA && (ia & CI_BASE_MASK) == 4, nB = vB && (ib & CI_BASE_MASK) == 4;
         uint32_t acc[(K + 3) / 4], colkey;
-        if (nA || nB) lane_rows<K, true, S8, TB, K3, NK>(s, P, sel, diag0, rf, nA, nB, acc, colkey);
+        // (an N is base code 4, the only code with bit 2 set; a column that is not there reads CI_INVALID, whose base bits are 0)
+        if (rinfo & 0x00040004u) { const bool nA = (ia & CI_BASE_MASK) == 4, nB = (ib & CI_BASE_MASK) == 4; lane_rows<K, true, S8, TB, K3, NK>(s, P, sel, diag0, rf, nA, nB, acc, colkey); }
         else          lane_rows<K, false, S8, TB, K3, NK>(s, P, sel, diag0, rf, false, false, acc, colkey);
         if constexpr (TB) {
             if (tb_a) {
