@@ -375,12 +375,19 @@ public:
         for (uint32_t w = P.wave_begin; w < P.wave_begin + P.wave_count; ++w) {
             const WaveDesc wd = P.waves[w];
             for (uint32_t l = 0; l < 64; ++l) lane_init(lanes[l], P, wd, l);
+            uint32_t steady_from = 0, steady_to = 0;                       // (the first fill's steady middle, as in the kernel)
+            { uint32_t shortest = 0xffffffffu; for (uint32_t l = 0; l < 64; ++l) shortest = std::min(shortest, std::min(lanes[l].RA, lanes[l].RB)); steady_steps(wd.G, shortest, wd.n_steps, steady_from, steady_to); }
             for (uint32_t t = 0; t < wd.n_steps; ++t) {
                 for (uint32_t l = 0; l < 64; ++l) { oh[l] = lanes[l].out_h; of[l] = lanes[l].out_f; oi[l] = lanes[l].info; }
                 for (uint32_t l = 0; l < 64; ++l) {
                     if ((t & 3u) == 0) lane_prefetch(lanes[l], P, t);
                     const uint32_t rh = l ? oh[l - 1] : 0, rf = l ? of[l - 1] : 0, ri = l ? oi[l - 1] : 0;
-                    if (P.spec_fill == 1) { if (S8 && P.key3) lane_step<K, S8, false, true>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr); else lane_step<K, S8, false>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr); continue; }      // the speculative batch's first fill: no codes
+                    if (P.spec_fill == 1) {                                    // the speculative batch's first fill: no codes
+                        const bool av = t >= steady_from && t < steady_to;
+                        if (S8 && P.key3) { if (av) lane_step<K, S8, false, true, false, true>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr); else lane_step<K, S8, false, true>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr); }
+                        else { if (av) lane_step<K, S8, false, false, false, true>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr); else lane_step<K, S8, false>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr); }
+                        continue;
+                    }
                     if (P.tb_mode == TB_REWALK) {
                         lane_step<K, S8, false>(lanes[l], P, t, rh, rf, ri, nullptr, nullptr);
                         if (P.want_tb) { lane_store_boundary<K>(lanes[l], P, wd, t, l); lane_store_checkpoint<K>(lanes[l], P, wd, t, l); }

@@ -78,13 +78,41 @@ __global__ __launch_bounds__(256, (K <= 16 ? 4 : 3)) void gssw_fill_kernel(const
     asm volatile("" : "+v"(s.one));   // keep min(x,1) a packed min instead of cmp+cndmask
     uint32_t* tb = P.want_tb ? P.tb : nullptr;
     TbStage<K> stage{stage_lds[threadIdx.x >> 6]};
-    for (uint32_t t = 0; t < wd.n_steps; ++t) {
+    // the first fill of a speculative batch runs its steady middle — every lane with a column of both reads — through a copy of the step that tests nothing for
+    // being there (gssw_device.hpp, AV)
+    uint32_t steady_from = 0, steady_to = 0;
+    if constexpr (!CODES) {
+        uint32_t shortest = s.RA < s.RB ? s.RA : s.RB;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)shortest, d, 64); shortest = o < shortest ? o : shortest; }
+        steady_steps(wd.G, shortest, wd.n_steps, steady_from, steady_to);
+        steady_from = (uint32_t)__builtin_amdgcn_readfirstlane((int)steady_from); steady_to = (uint32_t)__builtin_amdgcn_readfirstlane((int)steady_to);
+    }
+    if constexpr (!CODES) {
+        // three loops, not a branch in one: the step's two copies share no block, and each loop keeps the registers of one
+        uint32_t t = 0;
+        for (; t < steady_from; ++t) {
+            if ((t & 3u) == 0) lane_prefetch(s, P, t);
+            const uint32_t rh = from_lane_above(s.out_h), rf = from_lane_above(s.out_f), ri = from_lane_above(s.info);
+            lane_step<K, S8, false, KEY3>(s, P, t, rh, rf, ri, nullptr, nullptr);
+        }
+        for (; t < steady_to; ++t) {
+            if ((t & 3u) == 0) lane_prefetch(s, P, t);
+            const uint32_t rh = from_lane_above(s.out_h), rf = from_lane_above(s.out_f), ri = from_lane_above(s.info);
+            lane_step<K, S8, false, KEY3, false, true>(s, P, t, rh, rf, ri, nullptr, nullptr);
+        }
+        for (; t < wd.n_steps; ++t) {
+            if ((t & 3u) == 0) lane_prefetch(s, P, t);
+            const uint32_t rh = from_lane_above(s.out_h), rf = from_lane_above(s.out_f), ri = from_lane_above(s.info);
+            lane_step<K, S8, false, KEY3>(s, P, t, rh, rf, ri, nullptr, nullptr);
+        }
+    }
+    for (uint32_t t = 0; CODES && t < wd.n_steps; ++t) {
         if ((t & 3u) == 0) lane_prefetch(s, P, t);
         const uint32_t rh = from_lane_above(s.out_h);
         const uint32_t rf = from_lane_above(s.out_f);
         const uint32_t ri = from_lane_above(s.info);
         if constexpr (!CODES) {
-            lane_step<K, S8, false, KEY3>(s, P, t, rh, rf, ri, nullptr, nullptr);
         } else if constexpr (REWALK) {
             // the recurrence alone; what the traceback needs to run a window of it again (gssw_device.hpp, TB_REWALK)
             lane_step<K, S8, false>(s, P, t, rh, rf, ri, nullptr, nullptr);

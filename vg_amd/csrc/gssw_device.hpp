@@ -499,12 +499,14 @@ VGK_HD void lane_rows(Lane<K>& s, const GsswParams& P, uint32_t sel, uint32_t di
 // tb_a / tb_b = where the ceil(K/4)-dword traceback record goes — its first four dwords and the rest (the two parts of the tiled
 // layout; in the step-major form tb_b = tb_a + 4) —, or nullptr.  TB = build the codes; RE = the traceback's recomputation of a
 // window (no end-cell tracking, no scratch stores: the fill has done both).
-template <int K, bool S8, bool TB, bool RE, bool K3 = false, bool NK = false>
+// AV: every lane of the wavefront has a column of both its reads at this step (the steady middle of a fill: steps G - 1 .. the shortest window's
+// end) — nothing is tested for being there.
+template <int K, bool S8, bool TB, bool RE, bool K3 = false, bool NK = false, bool AV = false>
 VGK_HD void lane_column(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tb_a, uint32_t* tb_b) {
     s.info = rinfo;
     const uint32_t ia = rinfo & 0xffu, ib = (rinfo >> 16) & 0xffu;
-    const bool vA = !(ia & CI_INVALID), vB = !(ib & CI_INVALID);
-    if (vA || vB) {
+    const bool vA = AV || !(ia & CI_INVALID), vB = AV || !(ib & CI_INVALID);
+    if (AV || vA || vB) {
         uint32_t diag0 = s.prev_rh;
         if (vA && (ia & CI_NODE_START)) s.nodeA += 1;
         if (vB && (ib & CI_NODE_START)) s.nodeB += 1;
@@ -546,12 +548,17 @@ VGK_HD void lane_column(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh
     s.prev_rh = rh;
 }
 
+// The steps of a wavefront at which EVERY lane has a column of both its reads: [G - 1, the shortest window's columns) — empty when a lane has no pair
+// or a pair has one read (R = 0).  `shortest` = the minimum of RA and RB over the wavefront's lanes.
+VGK_HD void steady_steps(uint32_t G, uint32_t shortest, uint32_t n_steps, uint32_t& from, uint32_t& to) {
+    from = G - 1u < n_steps ? G - 1u : n_steps; to = shortest < n_steps ? shortest : n_steps; if (to < from) to = from;
+}
 // One step of one lane of the fill.  rh/rf/rinfo are lane-1's out_h/out_f/info from the
 // previous step (ignored by group leaders, which start a fresh column).
-template <int K, bool S8, bool TB = true, bool K3 = false, bool NK = false>
+template <int K, bool S8, bool TB = true, bool K3 = false, bool NK = false, bool AV = false>
 VGK_HD void lane_step(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh, uint32_t rf, uint32_t rinfo, uint32_t* tb_a, uint32_t* tb_b) {
     if (s.g == 0) { rh = 0; rf = 0; rinfo = fetch_info(s, P, t); }
-    lane_column<K, S8, TB, false, K3, NK>(s, P, t, rh, rf, rinfo, tb_a, tb_b);
+    lane_column<K, S8, TB, false, K3, NK, AV>(s, P, t, rh, rf, rinfo, tb_a, tb_b);
 }
 
 // after the last step: publish this lane's best cell (LOCAL mode)
