@@ -510,8 +510,10 @@ VGK_HD void lane_column(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh
         uint32_t diag0 = s.prev_rh;
         if (vA && (ia & CI_NODE_START)) s.nodeA += 1;
         if (vB && (ib & CI_NODE_START)) s.nodeB += 1;
-        if (vA && (ia & CI_SEED_SLOW)) seed_from_scratch<0, K>(s, P, s.probA, s.nodeA, diag0);
-        if (vB && (ib & CI_SEED_SLOW)) seed_from_scratch<1, K>(s, P, s.probB, s.nodeB, diag0);
+        if (rinfo & (CI_SEED_SLOW * 0x00010001u)) {                                // (one test for the pair: a column that is not there carries no flag)
+            if (vA && (ia & CI_SEED_SLOW)) seed_from_scratch<0, K>(s, P, s.probA, s.nodeA, diag0);
+            if (vB && (ib & CI_SEED_SLOW)) seed_from_scratch<1, K>(s, P, s.probB, s.nodeB, diag0);
+        }
         // selector: byte0 <- PA[baseA], byte2 <- PB[baseB] (bytes 4..7 of the permute), bytes 1,3 <- 0
         const uint32_t sel = (rinfo & 0x00030003u) | 0x0c040c00u;
         uint32_t acc[(K + 3) / 4], colkey;
@@ -539,8 +541,10 @@ VGK_HD void lane_column(Lane<K>& s, const GsswParams& P, uint32_t t, uint32_t rh
             s.best_lo = upA ? klo : s.best_lo; s.step_lo = upA ? t : s.step_lo;
             s.best_hi = upB ? khi : s.best_hi; s.step_hi = upB ? t : s.step_hi;
             }
-            if (vA && (ia & CI_STORE_END)) store_to_scratch<0, K>(s, P, s.probA, s.nodeA);
-            if (vB && (ib & CI_STORE_END)) store_to_scratch<1, K>(s, P, s.probB, s.nodeB);
+            if (rinfo & (CI_STORE_END * 0x00010001u)) {
+                if (vA && (ia & CI_STORE_END)) store_to_scratch<0, K>(s, P, s.probA, s.nodeA);
+                if (vB && (ib & CI_STORE_END)) store_to_scratch<1, K>(s, P, s.probB, s.nodeB);
+            }
         }
     } else {
         s.out_h = 0; s.out_f = 0;
