@@ -165,6 +165,41 @@ def _host_lib():
     return _HOST
 
 
+def gaf_lines(seqs, seq_off, results, mappings, runs, node_seq, node_off, names=None, node_ids=None, mapq=None, score=None, threads=4):
+    """GAF records of a batch of composed alignments (vgh_gaf_lines, vg_amd/host/gaf_output.cpp: what alignment_to_gaf + the emitter write in vg).
+    seqs / seq_off: the reads' bases behind each other; results / mappings / runs: vgk_chain_stitch's output (ChainStage.run(compose=True)["alignments"]);
+    node_seq / node_off: the graph's forward strands; names: a list of bytes or None; node_ids: int64 names of the nodes (None: index + 1).
+    -> the lines (bytes, one per read, without the newline)"""
+    import numpy as np
+    h = _host_lib()
+    h.vgh_gaf_lines.restype = ctypes.c_int64
+    h.vgh_gaf_lines.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
+    n = len(results)
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8); seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+    results = np.ascontiguousarray(results); mappings = np.ascontiguousarray(mappings); runs = np.ascontiguousarray(runs, dtype=np.uint32)
+    node_seq = np.ascontiguousarray(node_seq, dtype=np.uint8); node_off = np.ascontiguousarray(node_off, dtype=np.uint64)
+    name_arr = (ctypes.c_char_p * n)(*names) if names is not None else None
+    ids = np.ascontiguousarray(node_ids, dtype=np.int64) if node_ids is not None else None
+    mq = np.ascontiguousarray(mapq, dtype=np.int32) if mapq is not None else None
+    sc = np.ascontiguousarray(score, dtype=np.int32) if score is not None else None
+    line_off = np.zeros(n + 1, dtype=np.uint64)
+    bad = ctypes.c_uint32(0)
+    ptr = lambda a: a.ctypes.data if a is not None else None
+    def call(buf):
+        return h.vgh_gaf_lines(n, name_arr, ptr(seqs), ptr(seq_off), ptr(results), ptr(mappings), ptr(runs), ptr(node_seq), ptr(node_off), len(node_off) - 1,
+                               ptr(ids), ptr(mq), ptr(sc), ptr(buf), 0 if buf is None else len(buf), ptr(line_off), int(threads), ctypes.byref(bad))
+    need = call(None)
+    if need < 0:
+        raise ValueError("gaf_lines: the alignment of read %d does not fit the graph or its own length" % bad.value)
+    out = np.empty(need, dtype=np.uint8)
+    if call(out) != need:
+        raise RuntimeError("gaf_lines: size changed between the two calls")
+    text = out.tobytes()
+    return [text[int(line_off[r]):int(line_off[r + 1]) - 1] for r in range(n)]
+
+
 def align_stage_native(eng, index, oriented_len, gs, ops_per_problem=32, scoring=(1, 6, 1, 5), timing=None, seeded=None):
     """align_stage with everything behind the gapless extension done by the host shim's run_tail_stage (C++ threads instead of numpy)
     -> dict(res, ext, nodes, ext_total, read_score, stats = (tails, trees, tree nodes, failed), stage_ms)"""
