@@ -1167,10 +1167,15 @@ static inline void ww_acquire() {}
 template <class XL> VGK_HD void wfa_wave(const WwParams& P, uint32_t slab, uint32_t lane, WwSharedBoth& sh, XL& xl) {
     bool table_clean = false;
     const uint32_t n_todo = P.n_todo_dev ? (uint32_t)*P.n_todo_dev : P.n_todo;
+    // (a list that is complete when the launch begins: the NEXT hand-out is asked for when a problem starts — the counter's trip runs beside the problem's
+    //  first loads — and looked at when it ends; a list that is still being written is asked for entry by entry, as before)
+    const bool ahead = !P.producers_done;
+    uint32_t k_ahead = 0;
+    if (ahead) { if (lane == 0) k_ahead = (uint32_t)g_bump(P.hand_out ? P.hand_out : P.base.counters + 2, 1); k_ahead = xl.bcast(k_ahead, 0); }
     for (;;) {
         uint32_t k = 0;
-        if (lane == 0) k = (uint32_t)g_bump(P.hand_out ? P.hand_out : P.base.counters + 2, 1);
-        k = xl.bcast(k, 0);
+        if (ahead) k = k_ahead;
+        else { if (lane == 0) k = (uint32_t)g_bump(P.hand_out ? P.hand_out : P.base.counters + 2, 1); k = xl.bcast(k, 0); }
         uint32_t i = 0;
         if (P.producers_done) {
             // the k-th entry of a list that is being written: there already, or still to come, or never (every producer has finished and
@@ -1189,12 +1194,14 @@ template <class XL> VGK_HD void wfa_wave(const WwParams& P, uint32_t slab, uint3
         } else {
             if (k >= n_todo) break;
             i = P.todo[k];
+            if (lane == 0) k_ahead = (uint32_t)g_bump(P.hand_out ? P.hand_out : P.base.counters + 2, 1);      // (read after the problem, below)
         }
         if (!table_clean) {                                                  // (LDS comes up with whatever was there; the large size used it for its own lists)
             for (uint32_t j = lane; j < (uint32_t)WW_SMALL_SLOTS; j += 64) sh.small.slot[j] = 0;
             xl.fence(); table_clean = true;
         }
         if (wfa_wave_problem<XL, true>(P, i, slab, lane, sh.small, xl)) { wfa_wave_problem<XL, false>(P, i, slab, lane, sh.large, xl); table_clean = false; }
+        if (ahead) k_ahead = xl.bcast(k_ahead, 0);
     }
 }
 
